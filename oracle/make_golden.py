@@ -1,0 +1,366 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference, agi-brain/xuance v1.4.4) on CPU through oracle/ref_shim.py.
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+The reference does not exist on the GPU box, so the resulting fixtures are committed.
+Every fixture stores the exact inputs next to the reference's outputs so any engine can replay them.
+
+Versions used to generate the committed fixtures: torch 2.10.0+rocm7.0 (CPU path), numpy 2.2.6,
+python 3.10.12, 8 threads.
+"""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+from xuance.common.memory_tools import DummyOnPolicyBuffer, DummyOffPolicyBuffer, DummyOffPolicyBuffer_Atari  # noqa: E402
+from xuance.common.statistic_tools import RunningMeanStd  # noqa: E402
+from xuance.common.callback import BaseCallback  # noqa: E402
+from xuance.common import AgentGrouping  # noqa: E402
+from xuance.torch.learners import PPO_Learner, DQN_Learner, QMIX_Learner  # noqa: E402
+from xuance.torch.rl_models.representations import Basic_MLP, Basic_Identical, Basic_CNN  # noqa: E402
+from xuance.torch.rl_models.heads.actor_head import CategoricalActorHead, GaussianActorHead  # noqa: E402
+from xuance.torch.rl_models.heads.critic_head import ValueHead  # noqa: E402
+from xuance.torch.rl_models.heads.q_mix_head import QMIX_Mixer  # noqa: E402
+from xuance.torch.rl_models.architectures.single_agent.actor_critic import SharedActorCritic  # noqa: E402
+from xuance.torch.rl_models.architectures.single_agent.deep_q_network import DeepQNetwork  # noqa: E402
+from xuance.torch.rl_models.architectures.multi_agent.value_factorization import MixingQNetwork  # noqa: E402
+
+sp = ref_shim.spaces()
+
+
+class Capture(BaseCallback):
+    """Records every tensor kwarg handed to on_update_end (ppo_learner.py:90-94 etc.)."""
+
+    def __init__(self):
+        super().__init__()
+        self.records = []
+
+    def on_update_end(self, iterations, **kwargs):
+        rec = {}
+        for k, v in kwargs.items():
+            if isinstance(v, torch.Tensor):
+                rec[k] = v.detach().cpu().numpy().copy()
+        self.records.append(rec)
+        return {}
+
+
+def sd_np(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def flat(prefix, d):
+    return {f"{prefix}/{k}": np.asarray(v) for k, v in d.items()}
+
+
+def base_config(**kw):
+    c = dict(distributed_training=False, episode_length=60, learning_rate=4e-4, gamma=0.98, use_grad_clip=True,
+             grad_clip_norm=0.5, device="cpu", model_dir="/tmp/xrl_golden_models", running_steps=120000,
+             parallels=4)
+    c.update(kw)
+    return Namespace(**c)
+
+
+# ------------------------------------------------------------------------------ on-policy buffer
+def golden_onpolicy_buffer():
+    rng = np.random.default_rng(7)
+    n_envs, T, D = 6, 24, 4
+    out = {}
+    for tag, use_gae in (("gae", True), ("nogae", False)):
+        buf = DummyOnPolicyBuffer(sp.Box(-1, 1, (D,)), sp.Discrete(2), {"old_logp": ()}, n_envs, T,
+                                  use_gae=use_gae, use_advnorm=True, gamma=0.98, gae_lam=0.95)
+        obs = rng.standard_normal((T, n_envs, D)).astype(np.float32)
+        act = rng.integers(0, 2, (T, n_envs)).astype(np.float32)
+        rew = rng.standard_normal((T, n_envs)).astype(np.float32)
+        val = rng.standard_normal((T, n_envs)).astype(np.float32)
+        logp = (-rng.random((T, n_envs))).astype(np.float32)
+        term = rng.random((T, n_envs)) < 0.08
+        trunc = (rng.random((T, n_envs)) < 0.06) & ~term
+        boot = rng.standard_normal((T, n_envs)).astype(np.float32)   # V(next_obs) the agent would pass
+        for t in range(T):
+            buf.store(obs[t], act[t], rew[t], val[t], term[t], {"old_logp": logp[t]})
+            if buf.full:   # ppo_agent.py:129-135
+                for i in range(n_envs):
+                    buf.finish_path(0.0 if term[t, i] else boot[t, i], i)
+            for i in range(n_envs):  # ppo_agent.py:146-157
+                if term[t, i] or trunc[t, i]:
+                    buf.finish_path(0.0 if term[t, i] else boot[t, i], i)
+        idx = rng.permutation(n_envs * T)[:48]
+        s = buf.sample(idx)
+        out.update(flat(tag, dict(obs=obs, act=act, rew=rew, val=val, logp=logp, term=term, trunc=trunc, boot=boot,
+                                  returns=buf.returns, advantages=buf.advantages, idx=idx,
+                                  s_obs=s["obs"], s_actions=s["actions"], s_returns=s["returns"],
+                                  s_values=s["values"], s_old_logp=s["aux_batch"]["old_logp"],
+                                  s_advantages=s["advantages"])))
+    out["meta"] = np.array([n_envs, T, D, 0.98, 0.95])
+    np.savez_compressed(os.path.join(OUT, "onpolicy_buffer.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ off-policy buffer
+def golden_offpolicy_buffer():
+    rng = np.random.default_rng(11)
+    out = {}
+    for tag, cls, shape, dtype in (("f32", DummyOffPolicyBuffer, (5,), np.float32),
+                                   ("u8", DummyOffPolicyBuffer_Atari, (12, 12, 4), np.uint8)):
+        n_envs, n_size, bs, steps = 4, 10, 16, 13   # wraps around the ring
+        buf = cls(sp.Box(0, 255, shape), sp.Discrete(4), None, n_envs, n_envs * n_size, bs)
+        if dtype == np.uint8:
+            obs = rng.integers(0, 256, (steps, n_envs) + shape).astype(np.uint8)
+            nxt = rng.integers(0, 256, (steps, n_envs) + shape).astype(np.uint8)
+        else:
+            obs = rng.standard_normal((steps, n_envs) + shape).astype(np.float32)
+            nxt = rng.standard_normal((steps, n_envs) + shape).astype(np.float32)
+        act = rng.integers(0, 4, (steps, n_envs))
+        rew = rng.standard_normal((steps, n_envs)).astype(np.float32)
+        term = rng.random((steps, n_envs)) < 0.1
+        for t in range(steps):
+            buf.store(obs[t], act[t], rew[t], term[t], nxt[t])
+        np.random.seed(123)
+        env = np.random.choice(n_envs, bs)
+        step = np.random.choice(buf.size, bs)
+        np.random.seed(123)
+        s = buf.sample()
+        out.update(flat(tag, dict(obs=obs, nxt=nxt, act=act, rew=rew, term=term, env=env, step=step,
+                                  s_obs=s["obs"], s_actions=s["actions"], s_obs_next=s["obs_next"],
+                                  s_rewards=s["rewards"], s_terminals=s["terminals"],
+                                  meta=np.array([n_envs, n_size, bs, steps, buf.ptr, buf.size]))))
+    np.savez_compressed(os.path.join(OUT, "offpolicy_buffer.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ running mean/std
+def golden_rms():
+    rng = np.random.default_rng(3)
+    n, D, steps = 16, 4, 12
+    rms = RunningMeanStd((D,))
+    xs = (rng.standard_normal((steps, n, D)) * np.array([1, 3, 0.1, 10]) + np.array([0, 1, -2, 5])).astype(np.float32)
+    means, vars_, counts, normed = [], [], [], []
+    for t in range(steps):
+        rms.update(xs[t])                                              # ppo_agent.py:114
+        means.append(rms.mean.copy()); vars_.append(rms.var.copy()); counts.append(rms.count)
+        normed.append(np.clip((xs[t] - rms.mean) / (rms.std + 1e-8), -5, 5))   # agent.py:262-283
+    # return-normaliser: sequential single-sample updates (ppo_agent.py:144-149)
+    ret = RunningMeanStd(())
+    rs = rng.standard_normal(20).astype(np.float32) * 30
+    rmean, rvar, rcount, rproc = [], [], [], []
+    rew = rng.standard_normal((20, 3)).astype(np.float32) * 4
+    for i in range(20):
+        ret.update(rs[i:i + 1])
+        rmean.append(ret.mean.copy()); rvar.append(ret.var.copy()); rcount.append(ret.count)
+        std = np.clip(ret.std, 0.1, 100)
+        rproc.append(np.clip(rew[i] / std, -5, 5))
+    np.savez_compressed(os.path.join(OUT, "rms.npz"), xs=xs, means=np.array(means), vars=np.array(vars_),
+                        counts=np.array(counts), normed=np.array(normed), rs=rs, rmean=np.array(rmean),
+                        rvar=np.array(rvar), rcount=np.array(rcount), rew=rew, rproc=np.array(rproc))
+
+
+# ------------------------------------------------------------------------------ PPO
+def run_learner_updates(learner, model, cb, batches, call):
+    out = {}
+    out.update(flat("init", sd_np(model)))
+    for u, b in enumerate(batches):
+        info = call(b)
+        out.update(flat(f"u{u}/batch", {k: v for k, v in b.items()}))
+        out.update(flat(f"u{u}/info", {k: np.float64(v) for k, v in info.items() if np.isscalar(v) or
+                                       isinstance(v, (float, int, torch.Tensor))}))
+        out.update(flat(f"u{u}/cb", cb.records[-1]))
+        out.update(flat(f"u{u}/grad", {n: p.grad.detach().numpy().copy()
+                                       for n, p in model.named_parameters() if p.grad is not None}))
+        out.update(flat(f"u{u}/param", sd_np(model)))
+    opt = learner.optimizer
+    names = [n for n, _ in model.named_parameters()]
+    for n, p in model.named_parameters():
+        st = opt.state.get(p, None)
+        if st:
+            out[f"adam/exp_avg/{n}"] = st["exp_avg"].numpy().copy()
+            out[f"adam/exp_avg_sq/{n}"] = st["exp_avg_sq"].numpy().copy()
+    out["param_names"] = np.array(names)
+    return out
+
+
+def golden_ppo(dist):
+    torch.manual_seed(1)
+    rng = np.random.default_rng(5)
+    act_fn = nn.LeakyReLU if dist == "categorical" else nn.ReLU
+    init = torch.nn.init.orthogonal_
+    if dist == "categorical":
+        D, A, bs = 4, 2, 96
+        rep = Basic_MLP((D,), [128], None, init, act_fn, "cpu")
+        actor = CategoricalActorHead(128, [128], A, None, init, act_fn, "cpu")
+        critic = ValueHead(128, [128], None, init, act_fn, "cpu")
+        cfg = base_config(horizon_size=256, n_epochs=8, n_minibatch=8, vf_coef=0.25, ent_coef=0.01, clip_range=0.2,
+                          end_factor_lr_decay=0.5)
+    else:
+        D, A, bs = 17, 6, 80
+        rep = Basic_Identical((D,), "cpu")
+        actor = GaussianActorHead(D, [64, 64], A, None, init, act_fn, nn.Tanh, "cpu")
+        critic = ValueHead(D, [64, 64], None, init, act_fn, "cpu")
+        cfg = base_config(horizon_size=256, n_epochs=16, n_minibatch=8, vf_coef=0.25, ent_coef=0.001, clip_range=0.2,
+                          gamma=0.99)
+    model = SharedActorCritic(rep, actor, critic)
+    # give biases / log_std non-trivial values so their gradients paths are exercised with non-zero state
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.1))
+    cb = Capture()
+    learner = PPO_Learner(cfg, model, cb)
+    batches = []
+    for u in range(3):
+        obs = np.clip(rng.standard_normal((bs, D)), -5, 5).astype(np.float32)
+        with torch.no_grad():
+            mo = model(torch.from_numpy(obs))
+            if dist == "categorical":
+                actions = rng.integers(0, A, bs).astype(np.float32)
+            else:
+                actions = rng.standard_normal((bs, A)).astype(np.float32)
+            old_logp = mo.distributions.log_prob(torch.from_numpy(actions)).numpy()
+        old_logp = (old_logp + rng.standard_normal(bs) * 0.3).astype(np.float32)   # make ratios leave the clip range
+        adv = rng.standard_normal(bs).astype(np.float32)
+        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).astype(np.float32)
+        ret = rng.standard_normal(bs).astype(np.float32)
+        batches.append(dict(obs=obs, actions=actions, returns=ret, advantages=adv, old_logp=old_logp,
+                            values=rng.standard_normal(bs).astype(np.float32)))
+
+    def call(b):
+        return learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
+                              advantages=b["advantages"], aux_batch={"old_logp": b["old_logp"]},
+                              batch_size=len(b["obs"]))
+    out = run_learner_updates(learner, model, cb, batches, call)
+    out["cfg"] = np.array([cfg.learning_rate, cfg.vf_coef, cfg.ent_coef, cfg.clip_range, cfg.grad_clip_norm,
+                           getattr(cfg, "end_factor_lr_decay", 1.0), learner.total_iters])
+    np.savez_compressed(os.path.join(OUT, f"ppo_{dist}.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ DQN
+def golden_dqn(kind):
+    torch.manual_seed(2)
+    rng = np.random.default_rng(9)
+    init = torch.nn.init.orthogonal_
+    if kind == "mlp":
+        D, A, bs = 6, 4, 32
+        rep = Basic_MLP((D,), [64], None, init, nn.ReLU, "cpu")
+        hidden = [64]
+    else:
+        A, bs = 4, 4
+        rep = Basic_CNN((84, 84, 4), [8, 4, 3], [4, 2, 1], [32, 64, 64], None, init, nn.ReLU, "cpu")
+        hidden = [512]
+    model = DeepQNetwork(rep, hidden, sp.Discrete(A), None, init, nn.ReLU, "cpu")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.1))
+        # de-synchronise target from eval so the target path is really exercised
+        for n, p in model.named_parameters():
+            if n.startswith("target_"):
+                p.add_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.05))
+    cfg = base_config(learning_rate=1e-3, gamma=0.99, sync_frequency=2, start_training=0, training_frequency=1,
+                      use_grad_clip=(kind == "mlp"), grad_clip_norm=0.5)
+    cb = Capture()
+    learner = DQN_Learner(cfg, model, cb)
+    batches = []
+    for u in range(3):
+        if kind == "mlp":
+            obs = rng.standard_normal((bs, D)).astype(np.float32)
+            nxt = rng.standard_normal((bs, D)).astype(np.float32)
+        else:
+            obs = rng.integers(0, 256, (bs, 84, 84, 4)).astype(np.uint8)
+            nxt = rng.integers(0, 256, (bs, 84, 84, 4)).astype(np.uint8)
+        batches.append(dict(obs=obs, obs_next=nxt, actions=rng.integers(0, A, bs).astype(np.float32),
+                            rewards=rng.standard_normal(bs).astype(np.float32),
+                            terminals=(rng.random(bs) < 0.2).astype(np.float32)))
+
+    def call(b):
+        return learner.update(batch_size=bs, **b)
+    out = run_learner_updates(learner, model, cb, batches, call)
+    out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm,
+                           float(cfg.use_grad_clip), learner.total_iters])
+    np.savez_compressed(os.path.join(OUT, f"dqn_{kind}.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ QMIX (feed-forward)
+def golden_qmix(double_q):
+    from xuance.torch.rl_models.critics.base_critics import DiscreteActionValueCritic
+    from xuance.torch.rl_models.representations.agent_feature import AgentFeatureEncoder
+    torch.manual_seed(3)
+    rng = np.random.default_rng(13)
+    N, O, S, A, B = 3, 30, 48, 9, 16
+    agent_keys = [f"agent_{i}" for i in range(N)]
+    grouping = AgentGrouping.shared(agent_keys)            # agents_marl.py:210-215
+    group = grouping.group_keys[0]
+    init = torch.nn.init.orthogonal_
+    obs_rep = Basic_MLP((O,), [64], None, init, nn.ReLU, "cpu")
+    from xuance.torch.rl_models.modules.identity_encoder import build_identity_encoder, IdentityFeatureFusion
+    ident = build_identity_encoder(num_identities=N, mode="none", embedding_dim=None, device="cpu")   # agents_marl.py:313-318
+    fusion = IdentityFeatureFusion(observation_feature_dim=64, identity_feature_dim=ident.output_dim, mode="concat")
+    rep = AgentFeatureEncoder(representation=obs_rep, identity_encoder=ident, fusion=fusion)
+    critic = DiscreteActionValueCritic(representation=rep, action_space=sp.Discrete(A), critic_hidden_size=[64],
+                                       normalizer=None, initializer=init, activation=nn.ReLU, device="cpu")
+    mixer = QMIX_Mixer(S, 32, 32, N, "cpu")
+    model = MixingQNetwork(grouping, nn.ModuleDict({group: critic}), mixer, use_rnn=False, device="cpu")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("target_"):
+                p.add_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.05))
+    cfg = base_config(learning_rate=7e-4, gamma=0.99, sync_frequency=2, start_training=0, training_frequency=1,
+                      use_parameter_sharing=True, double_q=double_q, use_actions_mask=True, use_rnn=False,
+                      n_epochs=8, grad_clip_norm=10.0)
+    cb = Capture()
+    learner = QMIX_Learner(cfg, grouping, model, cb)
+    batches, samples = [], []
+    for u in range(3):
+        avail = (rng.random((B, N, A)) < 0.7)
+        avail[..., 0] = True
+        avail_n = (rng.random((B, N, A)) < 0.7)
+        avail_n[..., 0] = True
+        acts = np.zeros((B, N), np.float32)
+        for b in range(B):
+            for i in range(N):
+                acts[b, i] = rng.choice(np.flatnonzero(avail[b, i]))
+        term = rng.random((B, N)) < 0.5
+        term[: B // 4] = True
+        b = dict(obs=rng.standard_normal((B, N, O)).astype(np.float32),
+                 obs_next=rng.standard_normal((B, N, O)).astype(np.float32), actions=acts,
+                 rewards=rng.standard_normal((B, N)).astype(np.float32), terminals=term,
+                 agent_mask=(rng.random((B, N)) < 0.85), avail_actions=avail, avail_actions_next=avail_n,
+                 state=rng.standard_normal((B, S)).astype(np.float32),
+                 state_next=rng.standard_normal((B, S)).astype(np.float32))
+        batches.append(b)
+        sample = {k: {a: b[k][:, i] for i, a in enumerate(agent_keys)}
+                  for k in ("obs", "obs_next", "actions", "rewards", "terminals", "agent_mask", "avail_actions",
+                            "avail_actions_next")}
+        sample.update(state=b["state"], state_next=b["state_next"], batch_size=B)
+        samples.append(sample)
+    it = iter(samples)
+    out = run_learner_updates(learner, model, cb, batches, lambda b: learner.update(next(it)))
+    out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm, float(double_q),
+                           learner.total_iters])
+    out["group"] = np.array(group)
+    np.savez_compressed(os.path.join(OUT, f"qmix_ff_{'double' if double_q else 'single'}.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    golden_onpolicy_buffer()
+    golden_offpolicy_buffer()
+    golden_rms()
+    golden_ppo("categorical")
+    golden_ppo("gaussian")
+    golden_dqn("mlp")
+    golden_dqn("cnn")
+    golden_qmix(True)
+    golden_qmix(False)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,715 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (NumPy) of the reference hot path.
+
+This file is the *checker* for the HIP path in ``xuance_amd/``; it is never the
+thing shipped or measured.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` may import it.
+
+It restates, in plain NumPy with hand-derived backward passes (no autograd, no
+import of the reference), the arithmetic of agi-brain/xuance v1.4.4's torch
+backend for:
+
+  * rollout buffer            xuance/common/memory_tools.py:182-287 (on-policy),
+                              :331-387 (off-policy), :601-630 (Atari uint8)
+  * running mean/std          xuance/common/statistic_tools.py:65-185,
+                              xuance/torch/agents/base/agent.py:262-294
+  * PPO-clip learner          xuance/torch/learners/policy_gradient/ppo_learner.py:35-95
+  * DQN learner               xuance/torch/learners/qlearning_family/dqn_learner.py:28-75
+  * QMIX learner (FF)         xuance/torch/learners/multi_agent_rl/qmix_learner.py:24-112,
+                              iql_learner.py:37-83, q_mix_head.py:66-95
+  * networks                  rl_models/modules/layers.py:16-33 (mlp_block),
+                              heads/actor_head.py:14-72, heads/critic_head.py:9-30,
+                              heads/q_head.py:11-39, modules/distributions.py:128-192
+  * optimiser                 torch.optim.Adam(eps=1e-5) + clip_grad_norm_ + LinearLR
+                              (PyTorch >=2.0,<3.0 -- third-party, restated from its
+                              documented algorithm; call sites ppo_learner.py:18-22,61-67)
+
+Pinning: every function here is checked against fixtures produced by running
+the *unmodified reference* in the build container (oracle/make_golden.py ->
+tests/golden/*.npz; tests/test_oracle_vs_golden.py).  The reference's own
+tests hold no numeric assertion for this path, so those
+generated fixtures are the only pin.
+
+All arithmetic is float32 unless ``dtype=np.float64`` is requested (used by
+tests to bound rounding error).
+"""
+import math
+import numpy as np
+
+EPS = 1e-8  # xuance/common/common_tools.py EPS (used by agent.py:262-294)
+
+
+# --------------------------------------------------------------------------------------
+# Rollout buffer (on-policy)                                   memory_tools.py:182-287
+# --------------------------------------------------------------------------------------
+def gae_finish_path(rewards, values, dones, val, gamma, lam, use_gae=True):
+    """One ``finish_path`` slice (memory_tools.py:242-265).
+
+    Dtype quirk that parity has to reproduce (NumPy >= 2 promotion rules, the NumPy in this image):
+    ``vs = np.append(values, [val])`` is float64 when ``val`` is a Python float -- which is what the
+    agent passes for a *terminated* episode (``finish_path(0.0, i)``, ppo_agent.py:133,154) -- and
+    float32 when ``val`` is a NumPy float32 (``vals[i]``: truncation / buffer-full bootstrap).  In the
+    float64 case the recurrence is carried in float64 (with float32-rounded coefficients
+    ``(1-d)*gamma`` and ``(1-d)*gamma*lam``) and only the stored advantages/returns are rounded to
+    float32; in the float32 case everything is float32.  The expressions below are written with the
+    same operand order as the reference so that NumPy applies the same promotions.
+    (Under NumPy < 2, which the reference pins, scalar arithmetic with Python floats is float64
+    everywhere; the difference to either branch here is <= 1 ulp of float32 per step.)
+
+    rewards/values/dones: 1-D float32 arrays of the path.  Returns (returns, advantages) float32.
+    """
+    gamma, lam = float(gamma), float(lam)      # Python floats in the reference (config values): "weak" scalars
+    rewards = np.asarray(rewards, np.float32)
+    dones = np.asarray(dones, np.float32)
+    vs = np.append(np.asarray(values, np.float32), [val], axis=0)        # :247
+    L = len(rewards)
+    if use_gae:
+        adv = np.zeros_like(rewards)
+        last = 0
+        for t in reversed(range(L)):
+            delta = rewards[t] + (1 - dones[t]) * gamma * vs[t + 1] - vs[t]          # :255
+            adv[t] = last = delta + (1 - dones[t]) * gamma * lam * last             # :256
+        ret = adv + vs[:-1]                                                        # :257
+    else:
+        # discount_cumsum == scipy.signal.lfilter([1],[1,-gamma], x[::-1])[::-1]  (common_tools.py:160-174)
+        r = np.append(rewards, [val], axis=0)                                      # :259
+        out = np.zeros(len(r), np.float64)
+        acc = 0.0
+        for t in reversed(range(len(r))):
+            acc = float(r[t]) + gamma * acc
+            out[t] = acc
+        ret = out[:-1]                                                             # :260
+        adv = r[:-1] + gamma * vs[1:] - vs[:-1]                                    # :261
+    return np.asarray(ret).astype(np.float32), np.asarray(adv).astype(np.float32)
+
+
+class OnPolicyBufferOracle:
+    """Env-major restatement of DummyOnPolicyBuffer (memory_tools.py:182-287)."""
+
+    def __init__(self, obs_shape, act_shape, n_envs, horizon_size, use_gae=True, use_advnorm=True,
+                 gamma=0.99, gae_lam=0.95, obs_dtype=np.float32):
+        self.obs_shape, self.act_shape = tuple(obs_shape), tuple(act_shape)
+        self.n_envs, self.n_size = n_envs, horizon_size
+        self.buffer_size = n_envs * horizon_size
+        self.use_gae, self.use_advnorm = use_gae, use_advnorm
+        self.gamma, self.gae_lam = gamma, gae_lam
+        self.obs_dtype = obs_dtype
+        self.start_ids = np.zeros(n_envs, np.int64)
+        self.clear()
+
+    @property
+    def full(self):
+        return self.size >= self.n_size
+
+    def clear(self):                                                    # :221-230
+        n, T = self.n_envs, self.n_size
+        self.ptr, self.size = 0, 0
+        self.observations = np.zeros((n, T) + self.obs_shape, self.obs_dtype)
+        self.actions = np.zeros((n, T) + self.act_shape, np.float32)
+        self.rewards = np.zeros((n, T), np.float32)
+        self.returns = np.zeros((n, T), np.float32)
+        self.values = np.zeros((n, T), np.float32)
+        self.terminals = np.zeros((n, T), np.float32)
+        self.advantages = np.zeros((n, T), np.float32)
+        self.old_logp = np.zeros((n, T), np.float32)
+
+    def store(self, obs, acts, rews, value, terminals, aux_info=None):  # :232-240
+        p = self.ptr
+        self.observations[:, p] = obs
+        self.actions[:, p] = acts
+        self.rewards[:, p] = rews
+        self.values[:, p] = value
+        self.terminals[:, p] = terminals
+        if aux_info is not None:
+            self.old_logp[:, p] = aux_info["old_logp"]
+        self.ptr = (self.ptr + 1) % self.n_size
+        self.size = min(self.size + 1, self.n_size)
+
+    def finish_path(self, val, i):                                      # :242-265
+        end = self.n_size if self.full else self.ptr
+        sl = np.arange(self.start_ids[i], end)
+        ret, adv = gae_finish_path(self.rewards[i, sl], self.values[i, sl], self.terminals[i, sl],
+                                   val, self.gamma, self.gae_lam, self.use_gae)
+        self.returns[i, sl] = ret
+        self.advantages[i, sl] = adv
+        self.start_ids[i] = self.ptr
+
+    def sample(self, indexes):                                          # :267-287
+        assert self.full, "Not enough transitions for on-policy buffer to random sample"
+        env, step = np.divmod(np.asarray(indexes), self.n_size)
+        adv = self.advantages[env, step]
+        if self.use_advnorm:
+            adv = (adv - np.mean(adv)) / (np.std(adv) + 1e-8)            # population std (ddof=0)
+        return {
+            "obs": self.observations[env, step], "actions": self.actions[env, step],
+            "returns": self.returns[env, step], "values": self.values[env, step],
+            "aux_batch": {"old_logp": self.old_logp[env, step]}, "batch_size": len(indexes),
+            "advantages": adv.astype(np.float32),
+        }
+
+
+class OffPolicyBufferOracle:
+    """Restatement of DummyOffPolicyBuffer(_Atari) (memory_tools.py:331-387, 601-630)."""
+
+    def __init__(self, obs_shape, act_shape, n_envs, buffer_size, batch_size, obs_dtype=np.float32):
+        assert buffer_size % n_envs == 0, "buffer_size must be divisible by the number of envs (parallels)"
+        self.n_envs, self.n_size = n_envs, buffer_size // n_envs
+        self.buffer_size, self.batch_size = buffer_size, batch_size
+        n, S = self.n_envs, self.n_size
+        self.ptr, self.size = 0, 0
+        self.observations = np.zeros((n, S) + tuple(obs_shape), obs_dtype)
+        self.next_observations = np.zeros((n, S) + tuple(obs_shape), obs_dtype)
+        self.actions = np.zeros((n, S) + tuple(act_shape), np.float32)
+        self.rewards = np.zeros((n, S), np.float32)
+        self.terminals = np.zeros((n, S), np.float32)
+
+    def store(self, obs, acts, rews, terminals, next_obs):              # :365-372
+        p = self.ptr
+        self.observations[:, p] = obs
+        self.actions[:, p] = acts
+        self.rewards[:, p] = rews
+        self.terminals[:, p] = terminals
+        self.next_observations[:, p] = next_obs
+        self.ptr = (self.ptr + 1) % self.n_size
+        self.size = min(self.size + 1, self.n_size)
+
+    def sample_at(self, env, step):
+        """The gather of ``sample`` (:379-386) with the random (env, step) choices made explicit."""
+        return {"obs": self.observations[env, step], "actions": self.actions[env, step],
+                "obs_next": self.next_observations[env, step], "rewards": self.rewards[env, step],
+                "terminals": self.terminals[env, step], "batch_size": len(env)}
+
+    def sample(self, batch_size=None, rng=np.random):                   # :374-387
+        bs = self.batch_size if batch_size is None else batch_size
+        env = rng.choice(self.n_envs, bs)
+        step = rng.choice(self.size, bs)
+        return self.sample_at(env, step)
+
+
+# --------------------------------------------------------------------------------------
+# Running mean / std and obs / reward processing   statistic_tools.py:65-185, agent.py:262-294
+# --------------------------------------------------------------------------------------
+class RunningMeanStdOracle:
+    def __init__(self, shape, epsilon=1e-4):
+        self.mean = np.zeros(shape, np.float32)
+        self.var = np.ones(shape, np.float32)
+        self.count = epsilon
+
+    @property
+    def std(self):
+        return np.sqrt(self.var)
+
+    def update(self, x):                                                # :117-147
+        x = np.asarray(x)
+        self.update_from_moments(np.mean(x, axis=0), np.square(np.std(x, axis=0)), x.shape[0])
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):  # :149-185
+        delta = batch_mean - self.mean
+        tot = self.count + batch_count
+        new_mean = self.mean + delta * batch_count / tot
+        m_a = self.var * self.count
+        m_b = batch_var * batch_count
+        M2 = m_a + m_b + np.square(delta) * self.count * batch_count / tot
+        self.mean, self.var, self.count = new_mean, M2 / tot, tot
+
+
+def process_observation(obs, rms, obsnorm_range=5.0):                  # agent.py:262-283
+    return np.clip((obs - rms.mean) / (rms.std + EPS), -obsnorm_range, obsnorm_range)
+
+
+def process_reward(rew, ret_rms, rewnorm_range=5.0):                   # agent.py:285-294
+    std = np.clip(ret_rms.std, 0.1, 100)
+    return np.clip(rew / std, -rewnorm_range, rewnorm_range)
+
+
+# --------------------------------------------------------------------------------------
+# Dense layers with explicit backward                          layers.py:16-33 (mlp_block)
+# --------------------------------------------------------------------------------------
+def act_fwd(z, kind):
+    if kind is None or kind == "none":
+        return z
+    if kind == "leaky_relu":
+        return np.where(z > 0, z, z * z.dtype.type(0.01))
+    if kind == "relu":
+        return np.maximum(z, 0)
+    if kind == "tanh":
+        return np.tanh(z)
+    if kind == "sigmoid":
+        return 1 / (1 + np.exp(-z))
+    raise ValueError(kind)
+
+
+def act_bwd_from_out(y, kind):
+    """d act / d z expressed with the activation OUTPUT y (what torch's backward kernels use)."""
+    if kind is None or kind == "none":
+        return np.ones_like(y)
+    if kind == "leaky_relu":
+        return np.where(y > 0, y.dtype.type(1), y.dtype.type(0.01))
+    if kind == "relu":
+        return (y > 0).astype(y.dtype)
+    if kind == "tanh":
+        return 1 - y * y
+    if kind == "sigmoid":
+        return y * (1 - y)
+    raise ValueError(kind)
+
+
+class MLP:
+    """A stack of Linear(+activation) layers held as (W [out,in], b [out], act) -- nn.Sequential of mlp_blocks."""
+
+    def __init__(self, layers):
+        self.layers = layers          # list of dict(W=..., b=..., act=...)
+
+    def forward(self, x):
+        self.cache = [x]
+        for L in self.layers:
+            x = act_fwd(x @ L["W"].T + L["b"], L["act"])
+            self.cache.append(x)
+        return x
+
+    def backward(self, dy, need_dx=True):
+        grads = []
+        for li in reversed(range(len(self.layers))):
+            L = self.layers[li]
+            y, xin = self.cache[li + 1], self.cache[li]
+            dz = dy * act_bwd_from_out(y, L["act"])
+            grads.append((dz.T @ xin, dz.sum(0)))
+            dy = dz @ L["W"] if (li > 0 or need_dx) else None
+        grads.reverse()
+        return dy, grads
+
+
+def log_softmax(z):
+    m = z.max(-1, keepdims=True)
+    s = z - m
+    return s - np.log(np.exp(s).sum(-1, keepdims=True))
+
+
+# --------------------------------------------------------------------------------------
+# Optimiser: clip_grad_norm_ + Adam(eps=1e-5) + LinearLR   (PyTorch, restated)
+# --------------------------------------------------------------------------------------
+class AdamOracle:
+    """torch.optim.Adam (betas .9/.999, no amsgrad) over a dict name->array; LinearLR(start=1, end=ef, total)."""
+
+    def __init__(self, params, lr, eps=1e-5, weight_decay=0.0, end_factor=1.0, total_iters=1):
+        self.params = params
+        self.base_lr, self.eps, self.wd = lr, eps, weight_decay
+        self.end_factor, self.total_iters = end_factor, max(int(total_iters), 1)
+        self.t = 0            # optimiser steps taken
+        self.sched_steps = 0  # scheduler steps taken
+        self.m = {k: np.zeros_like(v) for k, v in params.items()}
+        self.v = {k: np.zeros_like(v) for k, v in params.items()}
+
+    @property
+    def lr(self):
+        k = min(self.sched_steps, self.total_iters)
+        return self.base_lr * (1.0 + (self.end_factor - 1.0) * k / self.total_iters)
+
+    @staticmethod
+    def clip_grad_norm_(grads, max_norm):
+        tot = math.sqrt(sum(float(np.sum(np.square(g.astype(np.float64)))) for g in grads.values()))
+        coef = min(max_norm / (tot + 1e-6), 1.0)
+        for k in grads:
+            grads[k] = (grads[k] * grads[k].dtype.type(coef))
+        return tot
+
+    def step(self, grads):
+        self.t += 1
+        b1, b2 = 0.9, 0.999
+        lr = self.lr
+        bc1 = 1 - b1 ** self.t
+        bc2 = 1 - b2 ** self.t
+        step_size = lr / bc1
+        bc2_sqrt = math.sqrt(bc2)
+        for k, p in self.params.items():
+            g = grads.get(k)
+            if g is None:
+                continue           # parameters without grad (frozen targets) are skipped by torch
+            T = p.dtype.type
+            if self.wd != 0:
+                g = g + T(self.wd) * p
+            self.m[k] = self.m[k] + (g - self.m[k]) * T(1 - b1)
+            self.v[k] = self.v[k] * T(b2) + T(1 - b2) * g * g
+            denom = np.sqrt(self.v[k]) / T(bc2_sqrt) + T(self.eps)
+            p -= T(step_size) * (self.m[k] / denom)
+        self.sched_steps += 1      # scheduler.step() after optimizer.step()
+
+
+# --------------------------------------------------------------------------------------
+# PPO-clip                                                        ppo_learner.py:35-95
+# --------------------------------------------------------------------------------------
+def build_actor_critic_layers(sd, prefix_rep="representation.model", actor_key="actor.logits",
+                              critic_key="critic.values", act="leaky_relu", activation_action=None):
+    """Group a reference-style state_dict into (rep, actor, critic) layer lists."""
+    def collect(prefix, last_act):
+        idx = sorted({int(k[len(prefix) + 1:].split(".")[0]) for k in sd if k.startswith(prefix + ".")})
+        layers = [dict(W=sd[f"{prefix}.{i}.weight"], b=sd[f"{prefix}.{i}.bias"], act=act, name=f"{prefix}.{i}")
+                  for i in idx]
+        if layers and last_act != "keep":
+            layers[-1]["act"] = last_act
+        return layers
+    rep = collect(prefix_rep, "keep")
+    actor = collect(actor_key, activation_action)
+    critic = collect(critic_key, None)
+    return rep, actor, critic
+
+
+def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", activation_action=None):
+    """Forward + loss + backward of PPO_Learner.update (ppo_learner.py:46-62).
+
+    sd: dict name->np.ndarray in the reference's state_dict naming.
+    batch: obs, actions, returns, advantages, old_logp.
+    Returns (info dict of intermediates, grads dict name->array).
+    """
+    actor_key = "actor.logits" if dist == "categorical" else "actor.mu"
+    rep_l, actor_l, critic_l = build_actor_critic_layers(sd, actor_key=actor_key, act=act,
+                                                         activation_action=activation_action)
+    dt = batch["obs"].dtype if batch["obs"].dtype in (np.float32, np.float64) else np.float32
+    dt = np.dtype(dt).type
+    rep, actor, critic = MLP(rep_l), MLP(actor_l), MLP(critic_l)
+    obs = batch["obs"].astype(dt)
+    h = rep.forward(obs) if rep_l else obs
+    out_a = actor.forward(h)
+    v = critic.forward(h)[:, 0]
+    B = obs.shape[0]
+    adv, ret, old_logp = batch["advantages"].astype(dt), batch["returns"].astype(dt), batch["old_logp"].astype(dt)
+    clip = dt(cfg["clip_range"])
+
+    if dist == "categorical":
+        a = batch["actions"].astype(np.int64)
+        lsm = log_softmax(out_a)
+        p = np.exp(lsm)
+        logp = lsm[np.arange(B), a]                                     # Categorical.log_prob
+        ent = -(p * lsm).sum(-1)                                        # Categorical.entropy
+    else:
+        log_std = sd["actor.log_std"].astype(dt)
+        std = np.exp(log_std)
+        x = batch["actions"].astype(dt)
+        var = std * std
+        # Normal.log_prob: -((x-mu)^2)/(2 var) - log(std) - log(sqrt(2 pi))   (distributions.py:179-180)
+        lp = -((x - out_a) ** 2) / (2 * var) - log_std - dt(math.log(math.sqrt(2 * math.pi)))
+        logp = lp.sum(-1)
+        ent = np.broadcast_to((dt(0.5 + 0.5 * math.log(2 * math.pi)) + log_std).sum(-1), (B,)).astype(dt)
+
+    ratio = np.exp(logp - old_logp)                                     # :52
+    s1 = np.clip(ratio, 1 - clip, 1 + clip) * adv                       # :53
+    s2 = adv * ratio                                                    # :54
+    a_loss = -np.minimum(s1, s2).mean()                                 # :55
+    c_loss = ((v - ret) ** 2).mean()                                    # :57
+    e_loss = ent.mean()                                                 # :59
+    loss = a_loss - dt(cfg["ent_coef"]) * e_loss + dt(cfg["vf_coef"]) * c_loss   # :60
+
+    # ---- backward ----
+    invB = dt(1.0 / B)
+    # d(-mean(min(s1,s2)))/d ratio: torch.minimum routes the gradient to s1 when s1 < s2, to s2 when
+    # s2 < s1 and splits it 0.5/0.5 on ties; clamp passes gradient only strictly inside... (clamp
+    # backward mask is  lo <= x <= hi).
+    inside = ((ratio >= 1 - clip) & (ratio <= 1 + clip)).astype(dt)
+    w1 = np.where(s1 < s2, dt(1), np.where(s1 == s2, dt(0.5), dt(0)))
+    w2 = dt(1) - w1
+    dratio = -(w1 * inside * adv + w2 * adv) * invB
+    dlogp = dratio * ratio
+    dv = dt(cfg["vf_coef"]) * 2 * (v - ret) * invB
+    grads = {}
+    if dist == "categorical":
+        onehot = np.zeros_like(out_a)
+        onehot[np.arange(B), a] = 1
+        dlogits = dlogp[:, None] * (onehot - p)
+        # d entropy / d logits_j = -p_j (lsm_j + H)
+        dent = -p * (lsm + ent[:, None])
+        dlogits = dlogits + (-dt(cfg["ent_coef"]) * invB) * dent
+        dout_a = dlogits
+    else:
+        dmu = dlogp[:, None] * (x - out_a) / var
+        dlog_std = (dlogp[:, None] * (((x - out_a) ** 2) / var - 1)).sum(0)
+        dlog_std = dlog_std + (-dt(cfg["ent_coef"])) * np.ones_like(log_std)   # d mean(ent)/d log_std = 1
+        grads["actor.log_std"] = dlog_std.astype(dt)
+        dout_a = dmu
+    dh_a, g_actor = actor.backward(dout_a, need_dx=bool(rep_l))
+    dh_c, g_critic = critic.backward(dv[:, None], need_dx=bool(rep_l))
+    for L, (gw, gb) in zip(actor_l, g_actor):
+        grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    for L, (gw, gb) in zip(critic_l, g_critic):
+        grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    if rep_l:
+        _, g_rep = rep.backward(dh_a + dh_c, need_dx=False)
+        for L, (gw, gb) in zip(rep_l, g_rep):
+            grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+
+    cr = ((ratio < 1 - clip).sum() + (ratio > 1 + clip).sum()) / ratio.shape[0]   # :70
+    info = dict(logits_or_mu=out_a, v_pred=v, log_prob=logp, ratio=ratio, surrogate1=s1, surrogate2=s2,
+                a_loss=a_loss, c_loss=c_loss, e_loss=e_loss, loss=loss, clip_ratio=cr,
+                predict_value=v.mean(), entropy=ent)
+    return info, grads
+
+
+def ppo_update(sd, opt, batch, cfg, **kw):
+    """One full PPO_Learner.update: fwd/bwd, clip_grad_norm_, Adam, LinearLR (ppo_learner.py:35-95)."""
+    info, grads = ppo_forward_backward(sd, batch, cfg, **kw)
+    raw = {k: g.copy() for k, g in grads.items()}
+    if cfg.get("use_grad_clip", True):
+        info["grad_norm"] = AdamOracle.clip_grad_norm_(grads, cfg["grad_clip_norm"])
+    opt.step(grads)
+    info["learning_rate"] = opt.lr
+    return info, raw
+
+
+# --------------------------------------------------------------------------------------
+# DQN                                                              dqn_learner.py:28-75
+# --------------------------------------------------------------------------------------
+def collect_seq(sd, prefix, act, last_act=None):
+    idx = sorted({int(k[len(prefix) + 1:].split(".")[0]) for k in sd if k.startswith(prefix + ".")})
+    layers = [dict(W=sd[f"{prefix}.{i}.weight"], b=sd[f"{prefix}.{i}.bias"], act=act, name=f"{prefix}.{i}")
+              for i in idx]
+    if layers:
+        layers[-1]["act"] = last_act
+    return layers
+
+
+def dqn_forward_backward(sd, batch, cfg, act="relu"):
+    """DQN_Learner.update forward/loss/backward for an MLP-representation DeepQNetwork.
+
+    State-dict names follow deep_q_network.py:19-60: representation.model.*, eval_Q_head.q_value.*,
+    target_representation.model.*, target_Q_head.q_value.*.
+    """
+    dt = np.float32 if cfg.get("dtype", "f32") == "f32" else np.float64
+    rep_l = collect_seq(sd, "representation.model", act, last_act=act)
+    q_l = collect_seq(sd, "eval_Q_head.q_value", act)
+    trep_l = collect_seq(sd, "target_representation.model", act, last_act=act)
+    tq_l = collect_seq(sd, "target_Q_head.q_value", act)
+    rep, q, trep, tq = MLP(rep_l), MLP(q_l), MLP(trep_l), MLP(tq_l)
+    obs, nxt = batch["obs"].astype(dt), batch["obs_next"].astype(dt)
+    B = obs.shape[0]
+    h = rep.forward(obs) if rep_l else obs
+    evalQ = q.forward(h)                                                # :39
+    targetQ_all = tq.forward(trep.forward(nxt) if trep_l else nxt)      # :40
+    a = batch["actions"].astype(np.int64)
+    predictQ = evalQ[np.arange(B), a]                                   # :42
+    tmax = targetQ_all.max(-1)                                          # :43
+    g = dt(cfg["gamma"])
+    targetQ = batch["rewards"].astype(dt) + g * (1 - batch["terminals"].astype(dt)) * tmax   # :44
+    loss = ((predictQ - targetQ) ** 2).mean()                           # :46
+    dpred = 2 * (predictQ - targetQ) / dt(B)
+    dQ = np.zeros_like(evalQ)
+    dQ[np.arange(B), a] = dpred
+    dh, g_q = q.backward(dQ, need_dx=bool(rep_l))
+    grads = {}
+    for L, (gw, gb) in zip(q_l, g_q):
+        grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    if rep_l:
+        _, g_rep = rep.backward(dh, need_dx=False)
+        for L, (gw, gb) in zip(rep_l, g_rep):
+            grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    info = dict(evalQ=evalQ, predictQ=predictQ, targetQ=targetQ, loss=loss, dQ=dQ)
+    return info, grads
+
+
+def dqn_copy_target(sd):                                                # deep_q_network.py:95-99
+    for k in list(sd):
+        if k.startswith("representation."):
+            sd["target_" + k][...] = sd[k]
+        elif k.startswith("eval_Q_head."):
+            sd["target_Q_head." + k[len("eval_Q_head."):]][...] = sd[k]
+
+
+def egreedy_select(greedy, random_actions, uniforms, eps):             # off_policy.py:138-141
+    return np.where(uniforms < eps, random_actions, greedy)
+
+
+def egreedy_schedule(start, end, decay_steps, n_envs, n_vector_steps):  # off_policy.py:119-127, dqn_agent.py:28-30
+    delta = (start - end) / (decay_steps / n_envs)
+    e, cur, out = start, 0, []
+    for _ in range(n_vector_steps):
+        out.append(e)
+        cur += n_envs
+        if e > end:
+            e = start - cur * delta
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# QMIX (feed-forward)      qmix_learner.py:24-112, iql_learner.py:37-83, q_mix_head.py:66-95
+# --------------------------------------------------------------------------------------
+def elu(x):
+    return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+
+
+def qmix_mixer_forward(sd, prefix, agent_qs, states):
+    """QMIX_Mixer.forward (q_mix_head.py:66-95). agent_qs [R,N], states [R,S]. Returns q_tot [R] + cache."""
+    dt = agent_qs.dtype.type
+    W = lambda n: sd[f"{prefix}.{n}"]
+    N = agent_qs.shape[1]
+    a1 = np.maximum(states @ W("hyper_w_1.0.weight").T + W("hyper_w_1.0.bias"), 0)
+    w1_raw = a1 @ W("hyper_w_1.2.weight").T + W("hyper_w_1.2.bias")
+    H = w1_raw.shape[1] // N
+    w1 = np.abs(w1_raw).reshape(-1, N, H)
+    b1 = states @ W("hyper_b_1.weight").T + W("hyper_b_1.bias")
+    pre = np.einsum("rn,rnh->rh", agent_qs, w1) + b1
+    hidden = elu(pre)
+    a2 = np.maximum(states @ W("hyper_w_2.0.weight").T + W("hyper_w_2.0.bias"), 0)
+    w2_raw = a2 @ W("hyper_w_2.2.weight").T + W("hyper_w_2.2.bias")
+    w2 = np.abs(w2_raw)
+    a3 = np.maximum(states @ W("hyper_b_2.0.weight").T + W("hyper_b_2.0.bias"), 0)
+    b2 = (a3 @ W("hyper_b_2.2.weight").T + W("hyper_b_2.2.bias"))[:, 0]
+    q_tot = (hidden * w2).sum(-1) + b2
+    cache = dict(states=states, agent_qs=agent_qs, a1=a1, w1_raw=w1_raw, w1=w1, pre=pre, hidden=hidden,
+                 a2=a2, w2_raw=w2_raw, w2=w2, a3=a3, N=N, H=H)
+    return q_tot.astype(dt), cache
+
+
+def qmix_mixer_backward(sd, prefix, cache, dq_tot):
+    """Backward of the mixer: returns (d agent_qs [R,N], grads dict)."""
+    W = lambda n: sd[f"{prefix}.{n}"]
+    c = cache
+    s = c["states"]
+    g = {}
+    dhidden = dq_tot[:, None] * c["w2"]
+    dw2 = dq_tot[:, None] * c["hidden"]
+    db2 = dq_tot
+    dpre = dhidden * np.where(c["pre"] > 0, 1, np.exp(np.minimum(c["pre"], 0)))
+    dq = np.einsum("rh,rnh->rn", dpre, c["w1"])
+    dw1 = np.einsum("rn,rh->rnh", c["agent_qs"], dpre).reshape(len(s), -1)
+    db1 = dpre
+    # hyper_b_1 (single Linear)
+    g[f"{prefix}.hyper_b_1.weight"] = db1.T @ s
+    g[f"{prefix}.hyper_b_1.bias"] = db1.sum(0)
+    # hyper_w_1: Linear-ReLU-Linear then abs
+    dw1_raw = dw1 * np.sign(c["w1_raw"])
+    g[f"{prefix}.hyper_w_1.2.weight"] = dw1_raw.T @ c["a1"]
+    g[f"{prefix}.hyper_w_1.2.bias"] = dw1_raw.sum(0)
+    da1 = (dw1_raw @ W("hyper_w_1.2.weight")) * (c["a1"] > 0)
+    g[f"{prefix}.hyper_w_1.0.weight"] = da1.T @ s
+    g[f"{prefix}.hyper_w_1.0.bias"] = da1.sum(0)
+    # hyper_w_2
+    dw2_raw = dw2 * np.sign(c["w2_raw"])
+    g[f"{prefix}.hyper_w_2.2.weight"] = dw2_raw.T @ c["a2"]
+    g[f"{prefix}.hyper_w_2.2.bias"] = dw2_raw.sum(0)
+    da2 = (dw2_raw @ W("hyper_w_2.2.weight")) * (c["a2"] > 0)
+    g[f"{prefix}.hyper_w_2.0.weight"] = da2.T @ s
+    g[f"{prefix}.hyper_w_2.0.bias"] = da2.sum(0)
+    # hyper_b_2
+    db2c = db2[:, None]
+    g[f"{prefix}.hyper_b_2.2.weight"] = db2c.T @ c["a3"]
+    g[f"{prefix}.hyper_b_2.2.bias"] = db2c.sum(0)
+    da3 = (db2c @ W("hyper_b_2.2.weight")) * (c["a3"] > 0)
+    g[f"{prefix}.hyper_b_2.0.weight"] = da3.T @ s
+    g[f"{prefix}.hyper_b_2.0.bias"] = da3.sum(0)
+    return dq, g
+
+
+def qmix_forward_backward(sd, batch, cfg, act="relu", group="shared"):
+    """QMIX_Learner.update (feed-forward branch) with parameter sharing (one group).
+
+    sd names follow value_factorization.py:17-52:
+      individual_q_networks.<group>.representation.obs_representation.model.<i>.{weight,bias}
+      individual_q_networks.<group>.critic_head.q_value.<i>.{weight,bias}
+      target_individual_q_networks.<group>....   eval_Qtot.* / target_Qtot.*
+    batch (already stacked like build_training_data, marl_learner.py:319-408):
+      obs [B,N,O], obs_next [B,N,O], actions [B,N] (float), rewards [B,N], terminals [B,N] (bool/float),
+      agent_mask [B,N], avail_actions [B,N,A], avail_actions_next [B,N,A], state [B,S], state_next [B,S]
+    """
+    dt = np.float32
+    pe = f"individual_q_networks.{group}"
+    pt = f"target_individual_q_networks.{group}"
+    rep_l = collect_seq(sd, f"{pe}.representation.obs_representation.model", act, last_act=act)
+    q_l = collect_seq(sd, f"{pe}.critic_head.q_value", act)
+    trep_l = collect_seq(sd, f"{pt}.representation.obs_representation.model", act, last_act=act)
+    tq_l = collect_seq(sd, f"{pt}.critic_head.q_value", act)
+    B, N, O = batch["obs"].shape
+    obs = batch["obs"].reshape(B * N, O).astype(dt)
+    nxt = batch["obs_next"].reshape(B * N, O).astype(dt)
+    rep, q = MLP(rep_l), MLP(q_l)
+    q_eval = q.forward(rep.forward(obs))                                 # iql_learner.py:41-47
+    A = q_eval.shape[-1]
+    q_next = MLP(tq_l).forward(MLP(trep_l).forward(nxt)).copy()         # :63-66
+    use_mask = cfg.get("use_actions_mask", True)
+    if cfg.get("double_q", True):                                       # :68-71
+        qn_eval = MLP(q_l).forward(MLP(rep_l).forward(nxt)).copy()
+        if use_mask:
+            qn_eval[batch["avail_actions_next"].reshape(B * N, A) == 0] = -1e10   # value_factorization.py:87-90
+        a_next = qn_eval.argmax(-1)
+    if use_mask:
+        q_next[batch["avail_actions_next"].reshape(B * N, A) == 0] = -1e10      # iql_learner.py:75-81
+    rewards_tot = batch["rewards"].astype(dt).mean(1)                   # qmix_learner.py:34
+    terminals_tot = batch["terminals"].astype(bool).all(1).astype(dt)   # :35
+    mask = batch["agent_mask"].astype(dt)                               # valid_mask, :45
+    a_taken = batch["actions"].reshape(B * N).astype(np.int64)
+    rows = np.arange(B * N)
+    q_eval_taken = q_eval[rows, a_taken].reshape(B, N)                  # :48-50
+    if cfg.get("double_q", True):
+        q_next_taken = q_next[rows, a_next].reshape(B, N)               # :52-55
+    else:
+        q_next_taken = q_next.max(-1).reshape(B, N)                     # :57-58
+    q_eval_m = q_eval_taken * mask                                      # :60
+    q_next_m = q_next_taken * mask                                      # :61
+    q_tot_eval, cache = qmix_mixer_forward(sd, "eval_Qtot", q_eval_m, batch["state"].astype(dt))
+    q_tot_next, _ = qmix_mixer_forward(sd, "target_Qtot", q_next_m, batch["state_next"].astype(dt))
+    target = rewards_tot + (1 - terminals_tot) * dt(cfg["gamma"]) * q_tot_next     # :78
+    loss = ((q_tot_eval - target) ** 2).mean()                          # :86
+    dq_tot = (2 * (q_tot_eval - target) / dt(B)).astype(dt)
+    dq_m, grads = qmix_mixer_backward(sd, "eval_Qtot", cache, dq_tot)
+    dq_taken = (dq_m * mask).reshape(B * N)
+    dQ = np.zeros_like(q_eval)
+    dQ[rows, a_taken] = dq_taken
+    dh, g_q = q.backward(dQ, need_dx=True)
+    for L, (gw, gb) in zip(q_l, g_q):
+        grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    _, g_rep = rep.backward(dh, need_dx=False)
+    for L, (gw, gb) in zip(rep_l, g_rep):
+        grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    info = dict(q_eval=q_eval.reshape(B, N, A), q_next=q_next.reshape(B, N, A), q_tot_eval=q_tot_eval,
+                q_tot_next=q_tot_next, q_tot_target=target, loss=loss, predictQ=q_tot_eval.mean(),
+                rewards_tot=rewards_tot, terminals_tot=terminals_tot)
+    if cfg.get("double_q", True):
+        info["actions_next"] = a_next.reshape(B, N)
+    return info, grads
+
+
+def qmix_copy_target(sd):                                               # value_factorization.py:169-174
+    for k in list(sd):
+        if k.startswith("individual_q_networks."):
+            sd["target_" + k][...] = sd[k]
+        elif k.startswith("eval_Qtot."):
+            sd["target_Qtot." + k[len("eval_Qtot."):]][...] = sd[k]
+
+
+# --------------------------------------------------------------------------------------
+# Sampling helpers (inverse-CDF with supplied uniforms; parity is defined on fixed uniforms)
+# --------------------------------------------------------------------------------------
+def categorical_sample_icdf(logits, u):
+    """Smallest k with cumsum(softmax(logits))[k] > u  (float32 cumulative sum, left to right)."""
+    p = np.exp(log_softmax(logits.astype(np.float32))).astype(np.float32)
+    c = np.cumsum(p, axis=-1, dtype=np.float32)
+    k = (c <= u[:, None]).sum(-1)
+    return np.minimum(k, logits.shape[-1] - 1)
+
+
+# --------------------------------------------------------------------------------------
+# CartPole-v1 physics (public equations, Barto-Sutton-Anderson 1983 / Gymnasium classic_control;
+# NOT part of the reference tree -- SURVEY.md section 7).  float64 state, float32 observations.
+# --------------------------------------------------------------------------------------
+class CartPoleOracle:
+    gravity, masscart, masspole, length, force_mag, tau = 9.8, 1.0, 0.1, 0.5, 10.0, 0.02
+    theta_thr, x_thr, max_steps = 12 * 2 * math.pi / 360, 2.4, 500
+
+    def __init__(self, state):
+        self.state = np.array(state, np.float64)      # [n,4]
+        self.steps = np.zeros(len(self.state), np.int64)
+
+    def step(self, action):
+        x, xd, th, thd = self.state.T
+        force = np.where(np.asarray(action) == 1, self.force_mag, -self.force_mag)
+        ct, st = np.cos(th), np.sin(th)
+        total_mass = self.masspole + self.masscart
+        pml = self.masspole * self.length
+        temp = (force + pml * thd * thd * st) / total_mass
+        thacc = (self.gravity * st - ct * temp) / (self.length * (4.0 / 3.0 - self.masspole * ct * ct / total_mass))
+        xacc = temp - pml * thacc * ct / total_mass
+        x = x + self.tau * xd
+        xd = xd + self.tau * xacc
+        th = th + self.tau * thd
+        thd = thd + self.tau * thacc
+        self.state = np.stack([x, xd, th, thd], 1)
+        self.steps += 1
+        term = (x < -self.x_thr) | (x > self.x_thr) | (th < -self.theta_thr) | (th > self.theta_thr)
+        trunc = self.steps >= self.max_steps
+        return self.state.astype(np.float32), np.ones(len(x), np.float32), term, trunc

@@ -1,0 +1,155 @@
+"""CPU: pins oracle/xrl_oracle.py against fixtures generated from the unmodified reference
+(oracle/make_golden.py -> tests/golden/*.npz).  The oracle is the checker used by the -m gpu tests."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, sub, assert_close
+
+
+def test_gae_and_sample_bit_exact(oracle):
+    g = load_golden("onpolicy_buffer")
+    n_envs, T, D, gamma, lam = g["meta"]
+    n_envs, T, D = int(n_envs), int(T), int(D)
+    for tag, use_gae in (("gae", True), ("nogae", False)):
+        d = sub(g, tag)
+        buf = oracle.OnPolicyBufferOracle((D,), (), n_envs, T, use_gae=use_gae, gamma=gamma, gae_lam=lam)
+        for t in range(T):
+            buf.store(d["obs"][t], d["act"][t], d["rew"][t], d["val"][t], d["term"][t], {"old_logp": d["logp"][t]})
+            if buf.full:
+                for i in range(n_envs):
+                    buf.finish_path(0.0 if d["term"][t, i] else d["boot"][t, i], i)
+            for i in range(n_envs):
+                if d["term"][t, i] or d["trunc"][t, i]:
+                    buf.finish_path(0.0 if d["term"][t, i] else d["boot"][t, i], i)
+        if use_gae:   # float32 recurrence restated op-for-op: bit exact
+            assert np.array_equal(buf.advantages, d["advantages"])
+            assert np.array_equal(buf.returns, d["returns"])
+        else:
+            assert_close(buf.returns, d["returns"], 1e-6, "returns")
+            assert_close(buf.advantages, d["advantages"], 1e-6, "adv")
+        s = buf.sample(d["idx"])
+        for k, gk in (("obs", "s_obs"), ("actions", "s_actions"), ("returns", "s_returns"), ("values", "s_values")):
+            assert_close(s[k], d[gk], 1e-6, k)
+        assert_close(s["aux_batch"]["old_logp"], d["s_old_logp"], 0, "old_logp")
+        assert_close(s["advantages"], d["s_advantages"], 1e-6, "adv-norm")
+
+
+def test_offpolicy_buffer(oracle):
+    g = load_golden("offpolicy_buffer")
+    for tag, dtype in (("f32", np.float32), ("u8", np.uint8)):
+        d = sub(g, tag)
+        n_envs, n_size, bs, steps, ptr, size = [int(x) for x in d["meta"]]
+        buf = oracle.OffPolicyBufferOracle(d["obs"].shape[2:], (), n_envs, n_envs * n_size, bs, obs_dtype=dtype)
+        for t in range(steps):
+            buf.store(d["obs"][t], d["act"][t], d["rew"][t], d["term"][t], d["nxt"][t])
+        assert (buf.ptr, buf.size) == (ptr, size)
+        s = buf.sample_at(d["env"], d["step"])
+        assert np.array_equal(s["obs"], d["s_obs"]) and np.array_equal(s["obs_next"], d["s_obs_next"])
+        assert np.array_equal(s["actions"], d["s_actions"]) and np.array_equal(s["rewards"], d["s_rewards"])
+        assert np.array_equal(s["terminals"], d["s_terminals"])
+        # same NumPy global-RNG draw order as the reference (memory_tools.py:376-377)
+        np.random.seed(123)
+        s2 = buf.sample()
+        assert np.array_equal(s2["obs"], d["s_obs"])
+
+
+def test_running_mean_std(oracle):
+    g = load_golden("rms")
+    rms = oracle.RunningMeanStdOracle((g["xs"].shape[-1],))
+    for t in range(len(g["xs"])):
+        rms.update(g["xs"][t])
+        assert_close(rms.mean, g["means"][t], 1e-6, "mean")
+        assert_close(rms.var, g["vars"][t], 1e-6, "var")
+        assert abs(rms.count - g["counts"][t]) < 1e-9
+        assert_close(oracle.process_observation(g["xs"][t], rms), g["normed"][t], 1e-6, "normed")
+    ret = oracle.RunningMeanStdOracle(())
+    for i in range(len(g["rs"])):
+        ret.update(g["rs"][i:i + 1])
+        assert_close(ret.mean, g["rmean"][i], 1e-6)
+        assert_close(ret.var, g["rvar"][i], 1e-6)
+        assert_close(oracle.process_reward(g["rew"][i], ret), g["rproc"][i], 1e-6)
+
+
+def _replay(g, n_updates, fb, opt_kwargs, oracle, on_update=None, tol=1e-5, gtol=2e-5):
+    sd = {k: v.copy() for k, v in sub(g, "init").items()}
+    names = [str(n) for n in g["param_names"]]
+    opt = oracle.AdamOracle({k: sd[k] for k in names}, **opt_kwargs)
+    for u in range(n_updates):
+        batch = sub(g, f"u{u}/batch")
+        info, grads = fb(sd, batch)
+        yield u, info, grads, sd, opt
+        assert_close(info["loss"], sub(g, f"u{u}/cb").get("loss", info["loss"]), tol, "loss")
+        ref_grads = sub(g, f"u{u}/grad")
+        clip = opt_kwargs_clip.get("clip")
+        if clip is not None:
+            oracle.AdamOracle.clip_grad_norm_(grads, clip)
+        for k, rg in ref_grads.items():
+            assert_close(grads[k], rg, gtol, f"grad {k}")
+        opt.step(grads)
+        if on_update is not None:
+            on_update(u, sd)
+        for k, rp in sub(g, f"u{u}/param").items():
+            assert_close(sd[k], rp, tol, f"param {k} after update {u}")
+
+
+opt_kwargs_clip = {}
+
+
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+def test_ppo_update(oracle, dist):
+    g = load_golden(f"ppo_{dist}")
+    lr, vf, ent, clip, gclip, ef, total = g["cfg"]
+    cfg = dict(vf_coef=vf, ent_coef=ent, clip_range=clip)
+    act = "leaky_relu" if dist == "categorical" else "relu"
+    aa = None if dist == "categorical" else "tanh"
+    opt_kwargs_clip["clip"] = gclip
+    fb = lambda sd, b: oracle.ppo_forward_backward(sd, b, cfg, dist=dist, act=act, activation_action=aa)
+    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
+        cb = sub(g, f"u{u}/cb")
+        lp_scale = max(1.0, float(np.abs(cb["log_prob"]).max()))   # fp32 floor of a sum of that magnitude
+        for k in ("v_pred", "a_loss", "c_loss", "e_loss"):
+            assert_close(info[k], cb[k], 1e-5, k)
+        for k in ("log_prob", "ratio", "surrogate1", "surrogate2"):
+            assert_close(info[k], cb[k], 1e-6, k, scale=lp_scale)
+        ref_info = sub(g, f"u{u}/info")
+        assert_close(info["clip_ratio"], ref_info["clip_ratio"], 1e-6, "clip_ratio")
+        assert_close(info["predict_value"], ref_info["predict_value"], 1e-5)
+    # Adam moments and the scheduled learning rate at the end
+    for k in [str(n) for n in g["param_names"]]:
+        assert_close(opt.m[k], g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
+        assert_close(opt.v[k], g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
+    assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")
+
+
+def test_dqn_mlp_update(oracle):
+    g = load_golden("dqn_mlp")
+    lr, gamma, sync, gclip, use_clip, total = g["cfg"]
+    opt_kwargs_clip["clip"] = gclip if use_clip else None
+    fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma))
+
+    def on_update(u, sd):
+        if (u + 1) % int(sync) == 0:
+            oracle.dqn_copy_target(sd)
+    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, total_iters=int(total)), oracle, on_update):
+        cb = sub(g, f"u{u}/cb")
+        for k in ("evalQ", "predictQ", "targetQ"):
+            assert_close(info[k], cb[k], 1e-5, k)
+
+
+@pytest.mark.parametrize("double_q", [True, False])
+def test_qmix_ff_update(oracle, double_q):
+    g = load_golden(f"qmix_ff_{'double' if double_q else 'single'}")
+    lr, gamma, sync, gclip, dq, total = g["cfg"]
+    opt_kwargs_clip["clip"] = gclip
+    cfg = dict(gamma=gamma, double_q=bool(dq), use_actions_mask=True)
+    fb = lambda sd, b: oracle.qmix_forward_backward(sd, b, cfg, group=str(g["group"]))
+
+    def on_update(u, sd):
+        if (u + 1) % int(sync) == 0:
+            oracle.qmix_copy_target(sd)
+    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, total_iters=int(total)), oracle, on_update):
+        cb = sub(g, f"u{u}/cb")
+        for k in ("q_tot_eval", "q_tot_next", "q_tot_target"):
+            assert_close(info[k], cb[k], 1e-5, k)
+        ref_info = sub(g, f"u{u}/info")
+        assert_close(info["loss"], ref_info["loss_Q"], 1e-5, "loss_Q")
