@@ -1,0 +1,166 @@
+/*
+ * xrl_hip.h -- C ABI of libxrl_hip.so, the MI355X (gfx950) engine for XuanCe's RL update loop.
+ *
+ * The reference (agi-brain/xuance v1.4.4, /root/reference) is 100% Python and has no FFI; its plugin
+ * seam for this path is the Python registries (xuance/torch/learners/__init__.py:41-99, Agent._build_memory
+ * xuance/torch/agents/core/on_policy.py:65-104, Agent._build_learner xuance/torch/agents/base/agent.py:340).
+ * The host-side classes in xuance_amd/ mirror those Python interfaces and bind the entry points below with
+ * ctypes (INTEGRATION.md shows the binding a XuanCe maintainer would add).  Each entry point names the
+ * reference code whose arithmetic it replaces.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch-ROCm allocations, passed as
+ *     tensor.data_ptr()); the library never allocates or frees caller memory and keeps no hidden state
+ *     besides the handles created by xrl_graph_* ;
+ *   - all work is enqueued on the hipStream_t given (xrl_stream_t == hipStream_t); no hidden synchronisation,
+ *     so every entry point is legal inside hipStreamBeginCapture (hipGraph capture);
+ *   - return 0 on success, a negative XRL_E* code otherwise (never throws); xrl_last_error() gives the text;
+ *   - all floating-point data is IEEE fp32 unless the name says otherwise; "f32 actions" follow the
+ *     reference's buffers, which store action indices as float32 (memory_tools.py:12-41).
+ *   - rollout data is a structure of arrays, TIME-MAJOR:  field[t][env][row]  (the reference is env-major
+ *     [env][t][row], memory_tools.py:12-41, which makes the per-step write strided).
+ */
+#ifndef XRL_HIP_H
+#define XRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* xrl_stream_t; /* hipStream_t */
+
+enum { XRL_OK = 0, XRL_EINVAL = -1, XRL_EHIP = -2, XRL_EUNSUPPORTED = -3 };
+enum { XRL_ACT_NONE = 0, XRL_ACT_RELU = 1, XRL_ACT_LEAKY_RELU = 2, XRL_ACT_TANH = 3, XRL_ACT_SIGMOID = 4 };
+
+const char* xrl_version(void);
+const char* xrl_last_error(void);
+/* multiProcessorCount, warpSize and gcnArchName of the current device */
+int xrl_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------ rollout buffer (structure of arrays) */
+
+/* One field of a per-step write / per-batch gather.  row_bytes must be a multiple of 4. */
+typedef struct {
+    void* dst;        /* store: field base [T][n_envs][row_bytes]   gather: dense output [bs][row_bytes] */
+    const void* src;  /* store: dense step data [n_envs][row_bytes]  gather: field base                  */
+    int32_t row_bytes;
+    int32_t flags;    /* gather only: bit0 = normalise this (scalar f32) field with stats (adv-norm)     */
+} xrl_field_t;
+
+/* store_element x6 (memory_tools.py:44-61,232-240; off-policy :365-372): field[t] <- src for every field.
+ * Time-major layout makes each field one contiguous copy of n_envs*row_bytes bytes. fields: HOST array. */
+int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n_envs, int t, xrl_stream_t stream);
+
+/* DummyOnPolicyBuffer.finish_path for every env and every closed path segment at once
+ * (memory_tools.py:242-265, call sites ppo_agent.py:129-135,146-157).
+ *   rew,val,term : [T][n_envs] f32     bootv : [T][n_envs] bootstrap value of a segment ending at (t,env)
+ *   seg          : [T][n_envs] u8, bit0 = a path ends after step t (finish_path was called with ptr==t+1),
+ *                  bit1 = that call passed a Python float (float64 carry, see oracle/xrl_oracle.py
+ *                  gae_finish_path); steps after the last closed segment of an env are left untouched.
+ *   adv,ret      : [T][n_envs] outputs.  gamma/lam as double = the Python floats of the config.
+ * Bit-exact with the reference for use_gae=1. */
+int xrl_gae_scan(const float* rew, const float* val, const float* term, const float* bootv,
+                 const uint8_t* seg, float* adv, float* ret, int n_envs, int T,
+                 double gamma, double lam, int use_gae, xrl_stream_t stream);
+
+/* mean / population std (ddof=0) of adv[idx] for n_batches consecutive minibatches of size bs
+ * (memory_tools.py:281-282).  idx: int64 flat ENV-MAJOR indices (env*T + t, memory_tools.py:270).
+ * stats out: [n_batches][2] f32 (mean, std).  Accumulates in float64. */
+int xrl_adv_stats(const float* adv_field, const int64_t* idx, int bs, int n_batches, int n_envs, int T,
+                  float* stats, xrl_stream_t stream);
+
+/* DummyOnPolicyBuffer.sample / DummyOffPolicyBuffer.sample gather (memory_tools.py:64-84,267-287,374-387):
+ * dst[b] = field[t_b][env_b] for every field; idx as above (env-major flat index, env*T + t).
+ * Fields flagged bit0 are written as (x - stats[0]) / (stats[1] + 1e-8).  fields: HOST array. */
+int xrl_soa_gather(const xrl_field_t* fields, int n_fields, const int64_t* idx, int bs, int n_envs, int T,
+                   const float* stats, xrl_stream_t stream);
+
+/* ------------------------------------------------------------------ dense layers on fp32 MFMA */
+
+/* One GEMM of a grouped launch (all groups of a launch share the kernel, blockIdx.z selects the group). */
+typedef struct {
+    const float* A;    /* see each entry point */
+    const float* B;
+    float* C;
+    const float* bias; /* fwd: [N] or NULL.  bwd_weight: unused */
+    float* dbias;      /* bwd_weight: [n_split][...] slab address of the bias gradient or NULL */
+    const float* aux;  /* bwd_data: activation OUTPUT of the layer that produced this layer's input, or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldaux;
+    int32_t act;       /* fwd: activation applied to C.  bwd_data: activation whose derivative (from aux) scales C */
+    int32_t pad;
+} xrl_gemm_t;
+
+/* nn.Linear (+activation) forward, mlp_block (rl_models/modules/layers.py:16-33):
+ *   C[M,N] = act(A[M,K] . B[N,K]^T + bias[N])          A = input rows, B = weight [out,in] */
+int xrl_linear_fwd(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream);
+/* backward w.r.t. the layer input (autograd of the same block):
+ *   C[M,N] = (A[M,K] . B[K,N]) * act'(aux[M,N])        A = dY, B = weight [out=K,in=N] */
+int xrl_linear_bwd_data(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream);
+/* backward w.r.t. weight and bias, split over the batch into n_split deterministic partial slabs:
+ *   C_s[N,K] = sum_{m in chunk s} A[m,N]^T X[m,K],  dbias_s[N] = sum_m A[m,N]     A = dY, B = X = layer input
+ *   slab s of C is at C + s*slab_stride (floats); same for dbias. */
+int xrl_linear_bwd_weight(const xrl_gemm_t* groups, int n_groups, int n_split, int64_t slab_stride,
+                          xrl_stream_t stream);
+
+/* ------------------------------------------------------------------ PPO-clip loss (ppo_learner.py:46-60,70) */
+
+typedef struct {
+    const float* out;      /* [M][ld_out] actor head output: logits (categorical) or mu after activation_action */
+    const float* value;    /* [M][ld_v] critic output (column 0) */
+    const float* actions;  /* categorical: [M] f32 action index; gaussian: [M][A] f32 */
+    const float* adv;      /* [M] advantages (already normalised unless stats != NULL) */
+    const float* stats;    /* NULL or [2] (mean, std): adv <- (adv-mean)/(std+1e-8) on the fly */
+    const float* returns;  /* [M] */
+    const float* old_logp; /* [M] */
+    const float* log_std;  /* gaussian: [A] parameter; categorical: NULL */
+    float* d_out;          /* [M][ld_out] d loss / d (pre-activation head output) */
+    float* d_value;        /* [M][ld_v]  d loss / d value (column 0) */
+    float* d_log_std;      /* gaussian: [n_blocks][slab_stride...] see n_split; NULL for categorical */
+    float* diag;           /* NULL or [4][M]: log_prob, ratio, surrogate1, surrogate2 (callback tensors) */
+    double* partials;      /* [n_split][8]: sum min(s1,s2), sum (v-ret)^2, sum entropy, sum v, n_clipped, 0,0,0 */
+    int32_t M, A, ld_out, ld_v;
+    int32_t out_act;       /* activation already applied to `out` (gaussian activation_action), XRL_ACT_* */
+    int32_t n_split;       /* number of blocks == number of gradient slabs */
+    int64_t slab_stride;   /* floats between consecutive slabs of d_log_std */
+    float clip_range, vf_coef, ent_coef, pad;
+} xrl_ppo_loss_t;
+
+int xrl_ppo_loss_categorical(const xrl_ppo_loss_t* p, xrl_stream_t stream);
+int xrl_ppo_loss_gaussian(const xrl_ppo_loss_t* p, xrl_stream_t stream);
+/* out[j] = sum_s partials[s][j]  (float64 in, float64 out), j < width */
+int xrl_sum_partials(const double* partials, int n_rows, int width, double* out, xrl_stream_t stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * clip_grad_norm_ + torch.optim.Adam(eps=1e-5) + LinearLR.step (ppo_learner.py:18-22,61-67;
+ * dqn_learner.py:18-22,47-53; marl_learner.py:64-75 with qmix_learner.py:88-96). */
+typedef struct {
+    int32_t step;          /* optimiser steps taken */
+    int32_t sched_steps;   /* LinearLR steps taken */
+    int32_t total_iters;   /* LinearLR total_iters */
+    int32_t ticket;        /* internal: block-completion counter of xrl_adam_step, must start at 0 */
+    double base_lr, end_factor, beta1, beta2, eps, weight_decay;
+    double last_lr;        /* lr after the last scheduler step (what the reference logs) */
+    double last_grad_norm; /* total norm before clipping */
+} xrl_adam_state_t;        /* lives in DEVICE memory so a captured graph can advance it */
+
+/* grad[p] = sum_s slabs[s][p]; sumsq_part[b] = sum over block b of grad^2 (float64). n_part blocks. */
+int xrl_grad_reduce(const float* slabs, int n_split, int64_t slab_stride, int64_t P, float* grad,
+                    double* sumsq_part, int n_part, xrl_stream_t stream);
+/* total_norm = sqrt(sum sumsq_part); grad *= min(1, max_norm/(total_norm+1e-6)) when max_norm > 0;
+ * Adam update of params/m/v; advances *state (step, sched_steps, last_lr, last_grad_norm). */
+int xrl_adam_step(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
+                  const double* sumsq_part, int n_part, double max_norm, xrl_stream_t stream);
+
+/* ------------------------------------------------------------------ hipGraph capture of op sequences */
+int xrl_graph_begin(xrl_stream_t stream);
+int xrl_graph_end(xrl_stream_t stream, void** graph_exec_out);
+int xrl_graph_launch(void* graph_exec, xrl_stream_t stream);
+int xrl_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRL_HIP_H */

@@ -90,18 +90,21 @@ def golden_onpolicy_buffer():
         term = rng.random((T, n_envs)) < 0.08
         trunc = (rng.random((T, n_envs)) < 0.06) & ~term
         boot = rng.standard_normal((T, n_envs)).astype(np.float32)   # V(next_obs) the agent would pass
+        idx = rng.permutation(n_envs * T)[:48]
         for t in range(T):
             buf.store(obs[t], act[t], rew[t], val[t], term[t], {"old_logp": logp[t]})
-            if buf.full:   # ppo_agent.py:129-135
+            if buf.full:   # ppo_agent.py:129-142: finish every env, train (sample), then clear()
                 for i in range(n_envs):
                     buf.finish_path(0.0 if term[t, i] else boot[t, i], i)
-            for i in range(n_envs):  # ppo_agent.py:146-157
+                returns, advantages = buf.returns.copy(), buf.advantages.copy()
+                s = buf.sample(idx)
+                buf.clear()
+            for i in range(n_envs):  # ppo_agent.py:146-157 (after a clear() these act on an empty slice)
                 if term[t, i] or trunc[t, i]:
                     buf.finish_path(0.0 if term[t, i] else boot[t, i], i)
-        idx = rng.permutation(n_envs * T)[:48]
-        s = buf.sample(idx)
+        assert buf.ptr == 0 and buf.size == 0 and not buf.returns.any()
         out.update(flat(tag, dict(obs=obs, act=act, rew=rew, val=val, logp=logp, term=term, trunc=trunc, boot=boot,
-                                  returns=buf.returns, advantages=buf.advantages, idx=idx,
+                                  returns=returns, advantages=advantages, idx=idx,
                                   s_obs=s["obs"], s_actions=s["actions"], s_returns=s["returns"],
                                   s_values=s["values"], s_old_logp=s["aux_batch"]["old_logp"],
                                   s_advantages=s["advantages"])))

@@ -1,0 +1,332 @@
+"""GPU parity of every C-ABI primitive against the oracle (oracle/xrl_oracle.py) and the reference fixtures."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, sub, assert_close
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from xuance_amd import ops
+    info = ops.device_info()
+    assert info["wave_size"] == 64
+    return ops
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def seg_from_events(term, trunc, boot):
+    """(bootv, seg) arrays equivalent to the reference's finish_path call pattern (ppo_agent.py:129-157)."""
+    T, n = term.shape
+    seg = np.zeros((T, n), np.uint8)
+    bootv = np.zeros((T, n), np.float32)
+    ended = term | trunc
+    seg[ended] = 1
+    seg[term] |= 2                       # finish_path(0.0, i): Python float -> float64 carry
+    bootv[trunc & ~term] = boot[trunc & ~term]
+    seg[T - 1] = 1 | np.where(term[T - 1], 2, 0)
+    bootv[T - 1] = np.where(term[T - 1], 0.0, boot[T - 1])
+    return bootv, seg
+
+
+def run_gae(ops, rew, val, term, bootv, seg, gamma, lam, use_gae=True):
+    adv = torch.zeros(rew.shape, device="cuda")
+    ret = torch.zeros(rew.shape, device="cuda")
+    ops.gae_scan(dev(rew), dev(val), dev(term, torch.float32), dev(bootv), dev(seg), adv, ret, gamma, lam, use_gae)
+    torch.cuda.synchronize()
+    return adv.cpu().numpy(), ret.cpu().numpy()
+
+
+def test_gae_golden_bit_exact(ops):
+    g = load_golden("onpolicy_buffer")
+    d = sub(g, "gae")
+    gamma, lam = float(g["meta"][3]), float(g["meta"][4])
+    bootv, seg = seg_from_events(d["term"], d["trunc"], d["boot"])
+    adv, ret = run_gae(ops, d["rew"], d["val"], d["term"].astype(np.float32), bootv, seg, gamma, lam)
+    assert np.array_equal(adv.T, d["advantages"])      # fixture is env-major [env][t]
+    assert np.array_equal(ret.T, d["returns"])
+    dn = sub(g, "nogae")
+    bootv, seg = seg_from_events(dn["term"], dn["trunc"], dn["boot"])
+    adv, ret = run_gae(ops, dn["rew"], dn["val"], dn["term"].astype(np.float32), bootv, seg, gamma, lam, use_gae=False)
+    assert_close(adv.T, dn["advantages"], 1e-6)
+    assert_close(ret.T, dn["returns"], 1e-6)
+
+
+@pytest.mark.parametrize("n_envs,T", [(1, 1), (3, 7), (64, 256), (257, 33), (1000, 64)])
+def test_gae_vs_oracle_bit_exact(ops, oracle, n_envs, T):
+    rng = np.random.default_rng(n_envs * 1000 + T)
+    rew = rng.standard_normal((T, n_envs)).astype(np.float32)
+    val = rng.standard_normal((T, n_envs)).astype(np.float32)
+    term = rng.random((T, n_envs)) < 0.05
+    trunc = (rng.random((T, n_envs)) < 0.03) & ~term
+    boot = rng.standard_normal((T, n_envs)).astype(np.float32)
+    bootv, seg = seg_from_events(term, trunc, boot)
+    if n_envs > 2:          # leave one env without a closing call at the end: its tail must stay untouched
+        seg[T - 1, 1] = 0
+    adv, ret = run_gae(ops, rew, val, term.astype(np.float32), bootv, seg, 0.98, 0.95)
+    exp_adv = np.zeros((T, n_envs), np.float32)
+    exp_ret = np.zeros((T, n_envs), np.float32)
+    for e in range(n_envs):
+        start = 0
+        for t in range(T):
+            if seg[t, e] & 1:
+                v = 0.0 if (seg[t, e] & 2) else np.float32(bootv[t, e])
+                r_, a_ = oracle.gae_finish_path(rew[start:t + 1, e], val[start:t + 1, e],
+                                                term[start:t + 1, e].astype(np.float32), v, 0.98, 0.95)
+                exp_ret[start:t + 1, e], exp_adv[start:t + 1, e] = r_, a_
+                start = t + 1
+    assert np.array_equal(adv, exp_adv)
+    assert np.array_equal(ret, exp_ret)
+
+
+def test_store_gather_advstats(ops, oracle):
+    rng = np.random.default_rng(0)
+    n_envs, T, D = 37, 19, 5
+    ob = oracle.OnPolicyBufferOracle((D,), (), n_envs, T)
+    f_obs = torch.zeros(T, n_envs, D, device="cuda")
+    f_adv = torch.zeros(T, n_envs, device="cuda")
+    f_u8 = torch.zeros(T, n_envs, 16, dtype=torch.uint8, device="cuda")
+    u8_ref = np.zeros((n_envs, T, 16), np.uint8)
+    for t in range(T):
+        obs = rng.standard_normal((n_envs, D)).astype(np.float32)
+        adv = rng.standard_normal(n_envs).astype(np.float32)
+        u8 = rng.integers(0, 256, (n_envs, 16)).astype(np.uint8)
+        ob.observations[:, t], ob.advantages[:, t], u8_ref[:, t] = obs, adv, u8
+        ops.soa_store_step([(f_obs, dev(obs), D * 4), (f_adv, dev(adv), 4), (f_u8, dev(u8), 16)], n_envs, t)
+    ob.size = T
+    bs, nb = 50, 3
+    idx = rng.permutation(n_envs * T)[: bs * nb]
+    didx = dev(idx.astype(np.int64))
+    stats = torch.zeros(nb, 2, device="cuda")
+    ops.adv_stats(f_adv, didx, bs, nb, n_envs, T, stats)
+    for b in range(nb):
+        sl = idx[b * bs:(b + 1) * bs]
+        s = ob.sample(sl)
+        o_obs = torch.zeros(bs, D, device="cuda")
+        o_adv = torch.zeros(bs, device="cuda")
+        o_u8 = torch.zeros(bs, 16, dtype=torch.uint8, device="cuda")
+        ops.soa_gather([(o_obs, f_obs, D * 4), (o_adv, f_adv, 4), (o_u8, f_u8, 16)], didx[b * bs:(b + 1) * bs],
+                       n_envs, T, stats=stats[b], flags=[0, 1, 0])
+        torch.cuda.synchronize()
+        assert np.array_equal(o_obs.cpu().numpy(), s["obs"])
+        env, step = np.divmod(sl, T)
+        assert np.array_equal(o_u8.cpu().numpy(), u8_ref[env, step])
+        assert_close(o_adv.cpu().numpy(), s["advantages"], 1e-6, "adv-norm")
+        raw = ob.advantages[env, step]
+        assert_close(stats[b].cpu().numpy(), [raw.mean(), raw.std()], 1e-6, "stats")
+
+
+SHAPES = [(1, 1, 1), (5, 3, 2), (100, 2, 17), (64, 64, 32), (130, 70, 33), (256, 128, 128), (513, 9, 30),
+          (1000, 256, 4), (77, 257, 65)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("act", [None, "leaky_relu", "tanh"])
+def test_linear_fwd(ops, M, N, K, act, oracle):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dA, dW, db = dev(A), dev(W), dev(b)
+    Cm = torch.full((M, N), 7.0, device="cuda")
+    ops.linear_fwd([ops.gemm_desc(dA.data_ptr(), dW.data_ptr(), Cm.data_ptr(), M, N, K, K, K, N, bias=db.data_ptr(),
+                                  act=act)])
+    torch.cuda.synchronize()
+    ref = oracle.act_fwd(A.astype(np.float64) @ W.astype(np.float64).T + b, act)
+    assert_close(Cm.cpu().numpy(), ref, 1e-6, "fwd", scale=max(1.0, float(np.max(np.abs(A) @ np.abs(W).T))))
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_bwd_data(ops, M, N, K, oracle):
+    """C[M,N] = (dY[M,K] . W[K,N]) * act'(aux)."""
+    rng = np.random.default_rng(M * 3 + N + K)
+    dY = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    aux = np.tanh(rng.standard_normal((M, N))).astype(np.float32)
+    ddY, dW, daux = dev(dY), dev(W), dev(aux)
+    Cm = torch.full((M, N), 7.0, device="cuda")
+    ops.linear_bwd_data([ops.gemm_desc(ddY.data_ptr(), dW.data_ptr(), Cm.data_ptr(), M, N, K, K, N, N,
+                                       aux=daux.data_ptr(), ldaux=N, act="tanh")])
+    torch.cuda.synchronize()
+    ref = (dY.astype(np.float64) @ W.astype(np.float64)) * (1 - aux.astype(np.float64) ** 2)
+    assert_close(Cm.cpu().numpy(), ref, 1e-6, "bwd_data", scale=max(1.0, float(np.max(np.abs(dY) @ np.abs(W)))))
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("n_split", [1, 4])
+def test_linear_bwd_weight(ops, M, N, K, n_split):
+    """dW[N,K] = dY[M,N]^T X[M,K], db[N] = sum_m dY, as n_split deterministic slabs."""
+    rng = np.random.default_rng(M * 5 + N + K)
+    dY = rng.standard_normal((M, N)).astype(np.float32)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    ddY, dX = dev(dY), dev(X)
+    P = N * K + N
+    slabs = torch.full((n_split, P), 7.0, device="cuda")
+    ops.linear_bwd_weight([ops.gemm_desc(ddY.data_ptr(), dX.data_ptr(), slabs.data_ptr(), M, N, K, N, K, K,
+                                         dbias=slabs.data_ptr() + 4 * N * K)], n_split, P)
+    torch.cuda.synchronize()
+    got = slabs.cpu().numpy().astype(np.float64).sum(0)
+    refW = dY.astype(np.float64).T @ X.astype(np.float64)
+    refb = dY.astype(np.float64).sum(0)
+    sc = max(1.0, float(np.max(np.abs(dY).T @ np.abs(X))))
+    assert_close(got[: N * K].reshape(N, K), refW, 1e-6, "dW", scale=sc)
+    assert_close(got[N * K:], refb, 1e-6, "db", scale=sc)
+
+
+def test_linear_grouped(ops, oracle):
+    rng = np.random.default_rng(1)
+    M = 200
+    shapes = [(7, 33), (64, 128), (1, 128)]
+    descs, keep, refs = [], [], []
+    for (N, K) in shapes:
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = rng.standard_normal((N, K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        dA, dW, db = dev(A), dev(W), dev(b)
+        Cm = torch.zeros(M, N, device="cuda")
+        keep += [dA, dW, db, Cm]
+        descs.append(ops.gemm_desc(dA.data_ptr(), dW.data_ptr(), Cm.data_ptr(), M, N, K, K, K, N, bias=db.data_ptr(),
+                                   act="relu"))
+        refs.append((Cm, np.maximum(A.astype(np.float64) @ W.T.astype(np.float64) + b, 0), np.abs(A) @ np.abs(W).T))
+    ops.linear_fwd(descs)
+    torch.cuda.synchronize()
+    for Cm, ref, sc in refs:
+        assert_close(Cm.cpu().numpy(), ref, 1e-6, "grouped", scale=max(1.0, float(sc.max())))
+
+
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+@pytest.mark.parametrize("M,n_split", [(96, 1), (1000, 7), (8192, 32)])
+def test_ppo_loss(ops, oracle, dist, M, n_split):
+    rng = np.random.default_rng(M)
+    A = 3 if dist == "categorical" else 6
+    out = rng.standard_normal((M, A)).astype(np.float32)
+    if dist == "gaussian":
+        out = np.tanh(out).astype(np.float32)
+    v = rng.standard_normal(M).astype(np.float32)
+    adv_raw = rng.standard_normal(M).astype(np.float32) * 2 + 0.3
+    ret = rng.standard_normal(M).astype(np.float32)
+    log_std = (rng.standard_normal(A) * 0.2 - 1).astype(np.float32)
+    cfg = dict(clip_range=0.2, vf_coef=0.25, ent_coef=0.01)
+    if dist == "categorical":
+        act = rng.integers(0, A, M).astype(np.float32)
+        lsm = oracle.log_softmax(out)
+        base = lsm[np.arange(M), act.astype(int)]
+    else:
+        act = (out + np.exp(log_std) * rng.standard_normal((M, A))).astype(np.float32)
+        base = (-((act - out) ** 2) / (2 * np.exp(log_std) ** 2) - log_std - 0.9189385).sum(-1)
+    old_logp = (base + rng.standard_normal(M) * 0.3).astype(np.float32)
+    stats = np.array([adv_raw.mean(), adv_raw.std()], np.float32)
+    adv = ((adv_raw - stats[0]) / (stats[1] + 1e-8)).astype(np.float32)
+
+    # oracle: a network whose "last layer" is the identity on `out`; we check the head-level gradients only
+    lo, hi = np.float32(1 - 0.2), np.float32(1 + 0.2)
+    if dist == "categorical":
+        p = np.exp(lsm); logp = base.astype(np.float32); ent = -(p * lsm).sum(-1)
+    else:
+        logp = base.astype(np.float32); ent = np.full(M, (0.5 + 0.9189385 + log_std).sum(), np.float32)
+    ratio = np.exp(logp - old_logp)
+    s1 = np.clip(ratio, lo, hi) * adv; s2 = adv * ratio
+    inside = ((ratio >= lo) & (ratio <= hi)).astype(np.float32)
+    w1 = np.where(s1 < s2, 1.0, np.where(s1 == s2, 0.5, 0.0)).astype(np.float32)
+    dlogp = -(w1 * inside * adv + (1 - w1) * adv) / M * ratio
+    if dist == "categorical":
+        onehot = np.zeros_like(out); onehot[np.arange(M), act.astype(int)] = 1
+        d_out = dlogp[:, None] * (onehot - p) + (-0.01 / M) * (-p * (lsm + ent[:, None]))
+    else:
+        var = np.exp(log_std) ** 2
+        d_out = dlogp[:, None] * (act - out) / var * (1 - out ** 2)
+        d_ls = (dlogp[:, None] * ((act - out) ** 2 / var - 1)).sum(0) - 0.01
+    d_v = 0.25 * 2 * (v - ret) / M
+
+    t = {k: dev(x) for k, x in dict(out=out, v=v, act=act, adv=adv_raw, stats=stats, ret=ret, old=old_logp,
+                                    ls=log_std).items()}
+    g_out = torch.zeros(M, A, device="cuda"); g_v = torch.zeros(M, device="cuda")
+    diag = torch.zeros(4, M, device="cuda")
+    partials = torch.zeros(n_split, 8, dtype=torch.float64, device="cuda")
+    g_ls = torch.zeros(n_split, A, device="cuda")
+    ops.ppo_loss(dist, out=t["out"].data_ptr(), value=t["v"].data_ptr(), actions=t["act"].data_ptr(),
+                 adv=t["adv"].data_ptr(), stats=t["stats"].data_ptr(), returns=t["ret"].data_ptr(),
+                 old_logp=t["old"].data_ptr(), log_std=t["ls"].data_ptr() if dist == "gaussian" else None,
+                 d_out=g_out.data_ptr(), d_value=g_v.data_ptr(),
+                 d_log_std=g_ls.data_ptr() if dist == "gaussian" else None, diag=diag.data_ptr(),
+                 partials=partials.data_ptr(), M=M, A=A, ld_out=A, ld_v=1, out_act=3 if dist == "gaussian" else 0,
+                 n_split=n_split, slab_stride=A, **cfg)
+    sums = torch.zeros(8, dtype=torch.float64, device="cuda")
+    ops.sum_partials(partials, n_split, 8, sums)
+    torch.cuda.synchronize()
+    lp_scale = max(1.0, float(np.abs(logp).max()))
+    dg = diag.cpu().numpy()
+    assert_close(dg[0], logp, 1e-6, "logp", scale=lp_scale)
+    assert_close(dg[1], ratio, 2e-6, "ratio", scale=lp_scale)
+    assert_close(dg[2], s1, 2e-6, "s1", scale=lp_scale * 4)
+    assert_close(dg[3], s2, 2e-6, "s2", scale=lp_scale * 4)
+    sm = sums.cpu().numpy()
+    assert_close(-sm[0] / M, -np.minimum(s1, s2).astype(np.float64).mean(), 1e-5, "a_loss")
+    assert_close(sm[1] / M, ((v - ret).astype(np.float64) ** 2).mean(), 1e-5, "c_loss")
+    assert_close(sm[2] / M, ent.astype(np.float64).mean(), 1e-5, "e_loss")
+    assert_close(sm[3] / M, v.astype(np.float64).mean(), 1e-5, "v mean")
+    assert sm[4] == ((ratio < lo).sum() + (ratio > hi).sum())
+    gscale = float(np.abs(d_out).max())
+    assert_close(g_out.cpu().numpy() / gscale, d_out / gscale, 2e-5, "d_out")
+    assert_close(g_v.cpu().numpy() * M, d_v * M, 1e-5, "d_v")
+    if dist == "gaussian":
+        assert_close(g_ls.cpu().numpy().astype(np.float64).sum(0), d_ls, 1e-5, "d_log_std",
+                     scale=max(1.0, float(np.abs(d_ls).max())))
+
+
+@pytest.mark.parametrize("P", [1, 1000, 34051])
+def test_adam_clip(ops, oracle, P):
+    rng = np.random.default_rng(P)
+    S = 5
+    params = rng.standard_normal(P).astype(np.float32)
+    sd = {"w": params.copy()}
+    opt = oracle.AdamOracle(sd, lr=4e-4, eps=1e-5, end_factor=0.5, total_iters=10)
+    d_p = dev(params); d_m = torch.zeros(P, device="cuda"); d_v = torch.zeros(P, device="cuda")
+    d_g = torch.zeros(P, device="cuda")
+    st = ops.adam_state_tensor(4e-4, 10, end_factor=0.5)
+    part = torch.zeros(64, dtype=torch.float64, device="cuda")
+    for it in range(4):
+        slabs = (rng.standard_normal((S, P)) * (0.01 if it % 2 else 1.0)).astype(np.float32)
+        g = {"w": slabs.astype(np.float64).sum(0).astype(np.float32)}
+        norm = opt.clip_grad_norm_(g, 0.5)
+        opt.step(g)
+        ops.grad_reduce(dev(slabs), S, P, P, d_g, part)
+        ops.adam_step(d_p, d_g, d_m, d_v, P, st, part, 0.5)
+        torch.cuda.synchronize()
+        s = ops.read_adam_state(st)
+        assert s.step == it + 1 and s.sched_steps == it + 1 and s.ticket == 0
+        assert_close(s.last_grad_norm, norm, 1e-6, "norm", scale=norm)
+        assert_close(s.last_lr, opt.lr, 1e-12, "lr")
+        assert_close(d_g.cpu().numpy(), g["w"], 1e-6, "clipped grad")
+        assert_close(d_p.cpu().numpy(), sd["w"], 1e-6, "params")
+        assert_close(d_m.cpu().numpy(), opt.m["w"], 1e-6, "m")
+        assert_close(d_v.cpu().numpy(), opt.v["w"], 1e-6, "v")
+
+
+def test_graph_replay(ops):
+    P = 1000
+    a = torch.ones(P, device="cuda"); g = torch.full((P,), 0.1, device="cuda")
+    m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+    slabs = torch.full((2, P), 0.05, device="cuda")
+    part = torch.zeros(8, dtype=torch.float64, device="cuda")
+    st = ops.adam_state_tensor(1e-3, 100)
+    torch.cuda.synchronize()
+    gr = ops.Graph()
+    with gr:
+        ops.grad_reduce(slabs, 2, P, P, g, part)
+        ops.adam_step(a, g, m, v, P, st, part, 0.0)
+    for _ in range(5):
+        gr.launch()
+    torch.cuda.synchronize()
+    s = ops.read_adam_state(st)
+    assert s.step == 5
+    assert abs(float(a[0]) - (1 - 5e-3)) < 1e-4

@@ -15,19 +15,21 @@ def test_gae_and_sample_bit_exact(oracle):
         buf = oracle.OnPolicyBufferOracle((D,), (), n_envs, T, use_gae=use_gae, gamma=gamma, gae_lam=lam)
         for t in range(T):
             buf.store(d["obs"][t], d["act"][t], d["rew"][t], d["val"][t], d["term"][t], {"old_logp": d["logp"][t]})
-            if buf.full:
+            if buf.full:      # ppo_agent.py:129-142: finish every env, sample/train, clear()
                 for i in range(n_envs):
                     buf.finish_path(0.0 if d["term"][t, i] else d["boot"][t, i], i)
-            for i in range(n_envs):
+                returns, advantages = buf.returns.copy(), buf.advantages.copy()
+                s = buf.sample(d["idx"])
+                buf.clear()
+            for i in range(n_envs):   # ppo_agent.py:146-157 (empty slice right after a clear())
                 if d["term"][t, i] or d["trunc"][t, i]:
                     buf.finish_path(0.0 if d["term"][t, i] else d["boot"][t, i], i)
-        if use_gae:   # float32 recurrence restated op-for-op: bit exact
-            assert np.array_equal(buf.advantages, d["advantages"])
-            assert np.array_equal(buf.returns, d["returns"])
+        if use_gae:   # float32 / float64-carry recurrence restated op-for-op: bit exact
+            assert np.array_equal(advantages, d["advantages"])
+            assert np.array_equal(returns, d["returns"])
         else:
-            assert_close(buf.returns, d["returns"], 1e-6, "returns")
-            assert_close(buf.advantages, d["advantages"], 1e-6, "adv")
-        s = buf.sample(d["idx"])
+            assert_close(returns, d["returns"], 1e-6, "returns")
+            assert_close(advantages, d["advantages"], 1e-6, "adv")
         for k, gk in (("obs", "s_obs"), ("actions", "s_actions"), ("returns", "s_returns"), ("values", "s_values")):
             assert_close(s[k], d[gk], 1e-6, k)
         assert_close(s["aux_batch"]["old_logp"], d["s_old_logp"], 0, "old_logp")

@@ -1,0 +1,105 @@
+"""ctypes binding of libxrl_hip.so (include/xrl_hip.h).  The product path has NO CPU fallback: if the shared
+library is missing or a call fails, an exception is raised."""
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+c_void_p, c_int, c_int32, c_int64, c_float, c_double = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
+
+
+class XrlError(RuntimeError):
+    pass
+
+
+class Field(C.Structure):
+    _fields_ = [("dst", c_void_p), ("src", c_void_p), ("row_bytes", c_int32), ("flags", c_int32)]
+
+
+class Gemm(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("dbias", c_void_p),
+                ("aux", c_void_p), ("M", c_int32), ("N", c_int32), ("K", c_int32), ("lda", c_int32), ("ldb", c_int32),
+                ("ldc", c_int32), ("ldaux", c_int32), ("act", c_int32), ("pad", c_int32)]
+
+
+class PpoLoss(C.Structure):
+    _fields_ = [("out", c_void_p), ("value", c_void_p), ("actions", c_void_p), ("adv", c_void_p), ("stats", c_void_p),
+                ("returns", c_void_p), ("old_logp", c_void_p), ("log_std", c_void_p), ("d_out", c_void_p),
+                ("d_value", c_void_p), ("d_log_std", c_void_p), ("diag", c_void_p), ("partials", c_void_p),
+                ("M", c_int32), ("A", c_int32), ("ld_out", c_int32), ("ld_v", c_int32), ("out_act", c_int32),
+                ("n_split", c_int32), ("slab_stride", c_int64), ("clip_range", c_float), ("vf_coef", c_float),
+                ("ent_coef", c_float), ("pad", c_float)]
+
+
+class AdamState(C.Structure):
+    _fields_ = [("step", c_int32), ("sched_steps", c_int32), ("total_iters", c_int32), ("ticket", c_int32),
+                ("base_lr", c_double), ("end_factor", c_double), ("beta1", c_double), ("beta2", c_double),
+                ("eps", c_double), ("weight_decay", c_double), ("last_lr", c_double), ("last_grad_norm", c_double)]
+
+
+_SIGS = {
+    "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],
+    "xrl_soa_store_step": [C.POINTER(Field), c_int, c_int, c_int, c_void_p],
+    "xrl_gae_scan": [c_void_p] * 7 + [c_int, c_int, c_double, c_double, c_int, c_void_p],
+    "xrl_adv_stats": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "xrl_soa_gather": [C.POINTER(Field), c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "xrl_linear_fwd": [C.POINTER(Gemm), c_int, c_void_p],
+    "xrl_linear_bwd_data": [C.POINTER(Gemm), c_int, c_void_p],
+    "xrl_linear_bwd_weight": [C.POINTER(Gemm), c_int, c_int, c_int64, c_void_p],
+    "xrl_ppo_loss_categorical": [C.POINTER(PpoLoss), c_void_p],
+    "xrl_ppo_loss_gaussian": [C.POINTER(PpoLoss), c_void_p],
+    "xrl_sum_partials": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "xrl_grad_reduce": [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p],
+    "xrl_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double, c_void_p],
+    "xrl_graph_begin": [c_void_p],
+    "xrl_graph_end": [c_void_p, C.POINTER(c_void_p)],
+    "xrl_graph_launch": [c_void_p, c_void_p],
+    "xrl_graph_destroy": [c_void_p],
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every entry point include/xrl_hip.h declares (checked by the CPU test-suite)."""
+    return ["xrl_version", "xrl_last_error"] + list(_SIGS)
+
+
+def load():
+    """dlopen the in-tree library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XrlError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). xuance_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.xrl_version.restype = C.c_char_p
+    lib.xrl_last_error.restype = C.c_char_p
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, name=""):
+    if rc != 0:
+        raise XrlError(f"{name} failed (rc={rc}): {load().xrl_last_error().decode()}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

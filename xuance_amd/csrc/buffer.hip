@@ -1,0 +1,263 @@
+// Rollout / replay buffer kernels: time-major structure-of-arrays store, gather, GAE scan, adv statistics.
+// Reference arithmetic: xuance/common/memory_tools.py (store_element :44-61, finish_path :242-265,
+// sample :267-287 / :374-387).  All HBM-bound; layouts are chosen so every access is coalesced.
+#include "common.h"
+#include <stdarg.h>
+
+namespace xrl {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int MAX_FIELDS = 8;
+struct FieldPack {
+    void* dst[MAX_FIELDS];
+    const void* src[MAX_FIELDS];
+    int row_bytes[MAX_FIELDS];
+    int flags[MAX_FIELDS];
+    int n;
+};
+
+// ------------------------------------------------------------------------------------------ store
+// field[t] <- src : one contiguous copy of n_envs*row_bytes per field (blockIdx.y = field).
+template <typename V>
+__global__ void __launch_bounds__(256) store_step_kernel(FieldPack f, int n_envs, int t) {
+    const int fi = blockIdx.y;
+    const size_t step_bytes = (size_t)n_envs * f.row_bytes[fi];
+    const size_t n = step_bytes / sizeof(V);
+    const V* __restrict__ s = reinterpret_cast<const V*>(f.src[fi]);
+    V* __restrict__ d = reinterpret_cast<V*>(reinterpret_cast<char*>(f.dst[fi]) + (size_t)t * step_bytes);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------------ gather
+// dst[b] = field[t_b][env_b], (env_b, t_b) = divmod(idx[b], T).  Unit V = 16 B or 4 B.
+template <typename V>
+__global__ void __launch_bounds__(256) gather_kernel(FieldPack f, const int64_t* __restrict__ idx, int bs,
+                                                     int n_envs, int T, const float* __restrict__ stats) {
+    const int fi = blockIdx.y;
+    const int rw = f.row_bytes[fi] / (int)sizeof(V);  // units per row
+    const size_t total = (size_t)bs * rw;
+    const V* __restrict__ s = reinterpret_cast<const V*>(f.src[fi]);
+    V* __restrict__ d = reinterpret_cast<V*>(f.dst[fi]);
+    const bool norm = (f.flags[fi] & 1) && stats != nullptr;
+    float mean = 0.f, denom = 1.f;
+    if (norm) {
+        mean = stats[0];
+        denom = stats[1] + 1e-8f;  // np.std(adv) + 1e-8   (memory_tools.py:282)
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / rw), w = (int)(i - (size_t)b * rw);
+        const int64_t fl = idx[b];
+        const int env = (int)(fl / T), t = (int)(fl - (int64_t)env * T);
+        V v = s[((size_t)t * n_envs + env) * rw + w];
+        if constexpr (sizeof(V) == 4) {
+            if (norm) {
+                float x = __builtin_bit_cast(float, v);
+                x = __fdiv_rn(__fsub_rn(x, mean), denom);
+                v = __builtin_bit_cast(V, x);
+            }
+        }
+        d[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ adv stats
+// One block per minibatch: two-pass mean / population std in float64 over adv[idx[...]].
+__global__ void __launch_bounds__(1024) adv_stats_kernel(const float* __restrict__ adv, const int64_t* __restrict__ idx,
+                                                         int bs, int n_envs, int T, float* __restrict__ stats) {
+    __shared__ double scratch[16];
+    const int64_t* my = idx + (size_t)blockIdx.x * bs;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < bs; i += blockDim.x) {
+        const int64_t fl = my[i];
+        const int env = (int)(fl / T), t = (int)(fl - (int64_t)env * T);
+        s += (double)adv[(size_t)t * n_envs + env];
+    }
+    const double mean = block_sum(s, scratch) / bs;
+    double q = 0.0;
+    for (int i = threadIdx.x; i < bs; i += blockDim.x) {
+        const int64_t fl = my[i];
+        const int env = (int)(fl / T), t = (int)(fl - (int64_t)env * T);
+        const double dlt = (double)adv[(size_t)t * n_envs + env] - mean;
+        q += dlt * dlt;
+    }
+    const double var = block_sum(q, scratch) / bs;
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x + 0] = (float)mean;
+        stats[2 * blockIdx.x + 1] = (float)sqrt(var);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GAE scan
+// One lane per env, backwards in time; loads of a chunk of CH steps are issued before the recurrence so
+// CH*5 independent coalesced loads are in flight per lane.  Arithmetic is written with explicit
+// round-to-nearest intrinsics (no FMA contraction) in the operand order of memory_tools.py:255-257 so the
+// result is bit-identical to NumPy's float32 (seg bit1 = 0) or float64-carry (bit1 = 1) evaluation.
+template <int CH>
+__global__ void __launch_bounds__(64) gae_scan_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                      const float* __restrict__ term, const float* __restrict__ bootv,
+                                                      const uint8_t* __restrict__ seg, float* __restrict__ adv,
+                                                      float* __restrict__ ret, int n_envs, int T, float gamma_f,
+                                                      float lam_f, double gamma_d, int use_gae) {
+#pragma clang fp contract(off)   // bit-exactness: every multiply and add rounds separately, like NumPy
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_envs) return;
+    bool active = false, m64 = false, first = true;
+    float last_f = 0.f, vnext_f = 0.f;
+    double last_d = 0.0, vnext_d = 0.0, disc_d = 0.0;  // disc_d: discounted reward sum for use_gae == 0
+    for (int t1 = T; t1 > 0; t1 -= CH) {
+        const int t0 = t1 - CH;  // chunk covers t0 .. t1-1 (t0 may be negative)
+        float r[CH], v[CH], d[CH], bv[CH];
+        uint8_t sg[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int t = t0 + j;
+            if (t >= 0) {
+                const size_t o = (size_t)t * n_envs + e;
+                r[j] = rew[o]; v[j] = val[o]; d[j] = term[o]; bv[j] = bootv[o]; sg[j] = seg[o];
+            } else { r[j] = v[j] = d[j] = bv[j] = 0.f; sg[j] = 0; }
+        }
+#pragma unroll
+        for (int j = CH - 1; j >= 0; --j) {
+            const int t = t0 + j;
+            if (t < 0) continue;
+            if (sg[j] & 1) {  // a finish_path(val, env) call closed a path after step t
+                active = true; first = true;
+                m64 = (sg[j] & 2) != 0;
+                last_f = 0.f; last_d = 0.0;
+                vnext_f = bv[j]; vnext_d = (double)bv[j];
+                disc_d = (double)bv[j];
+            }
+            if (!active) continue;
+            const size_t o = (size_t)t * n_envs + e;
+            const float nd = __fsub_rn(1.0f, d[j]);
+            const float c1 = __fmul_rn(nd, gamma_f);                 // (1 - d) * gamma      (float32)
+            if (use_gae) {
+                const float c2 = __fmul_rn(c1, lam_f);               // (1 - d) * gamma * lam (float32)
+                if (!m64) {
+                    const float delta = __fsub_rn(__fadd_rn(r[j], __fmul_rn(c1, vnext_f)), v[j]);
+                    last_f = __fadd_rn(delta, __fmul_rn(c2, last_f));
+                    adv[o] = last_f;
+                    ret[o] = __fadd_rn(last_f, v[j]);
+                } else {
+                    const double vd = (double)v[j];
+                    const double delta = __dsub_rn(__dadd_rn((double)r[j], __dmul_rn((double)c1, vnext_d)), vd);
+                    // first step of a path: `last` is the Python int 0 -> c2 * 0 stays float32
+                    const double carry = first ? (double)__fmul_rn(c2, 0.0f) : __dmul_rn((double)c2, last_d);
+                    last_d = __dadd_rn(delta, carry);
+                    const float a = (float)last_d;
+                    adv[o] = a;
+                    ret[o] = (float)__dadd_rn((double)a, vd);
+                }
+            } else {
+                // returns = discount_cumsum(rewards + [val])[:-1] (float64 filter); adv = r + gamma*v' - v
+                disc_d = (double)r[j] + gamma_d * disc_d;
+                ret[o] = (float)disc_d;
+                if (!m64) adv[o] = __fsub_rn(__fadd_rn(r[j], __fmul_rn(gamma_f, vnext_f)), v[j]);
+                else adv[o] = (float)__dsub_rn(__dadd_rn((double)r[j], __dmul_rn(gamma_d, vnext_d)), (double)v[j]);
+            }
+            first = false;
+            vnext_f = v[j]; vnext_d = (double)v[j];
+        }
+    }
+}
+
+static int pack_fields(const xrl_field_t* fields, int n_fields, FieldPack& fp, bool& vec16) {
+    if (fields == nullptr || n_fields < 1 || n_fields > MAX_FIELDS) return XRL_EINVAL;
+    fp.n = n_fields;
+    vec16 = true;
+    for (int i = 0; i < n_fields; ++i) {
+        if (!fields[i].dst || !fields[i].src || fields[i].row_bytes <= 0 || (fields[i].row_bytes & 3)) return XRL_EINVAL;
+        fp.dst[i] = fields[i].dst; fp.src[i] = fields[i].src;
+        fp.row_bytes[i] = fields[i].row_bytes; fp.flags[i] = fields[i].flags;
+        if ((fields[i].row_bytes & 15) || ((uintptr_t)fields[i].dst & 15) || ((uintptr_t)fields[i].src & 15)) vec16 = false;
+    }
+    return XRL_OK;
+}
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" const char* xrl_version(void) { return "xrl_hip 0.1.0 (gfx950)"; }
+extern "C" const char* xrl_last_error(void) { return xrl::g_err; }
+
+extern "C" int xrl_device_info(int* cu_count, int* wave_size, char* arch, int arch_len) {
+    int dev = 0;
+    XRL_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    XRL_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (wave_size) *wave_size = prop.warpSize;
+    if (arch && arch_len > 0) { strncpy(arch, prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return XRL_OK;
+}
+
+extern "C" int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n_envs, int t, xrl_stream_t stream) {
+    FieldPack fp; bool vec16;
+    XRL_CHECK_ARG(pack_fields(fields, n_fields, fp, vec16) == XRL_OK);
+    XRL_CHECK_ARG(n_envs > 0 && t >= 0);
+    size_t max_bytes = 0;
+    for (int i = 0; i < n_fields; ++i) {
+        const size_t sb = (size_t)n_envs * fp.row_bytes[i];
+        max_bytes = sb > max_bytes ? sb : max_bytes;
+        if ((sb & 15) || (((size_t)t * sb) & 15)) vec16 = false;
+    }
+    const size_t unit = vec16 ? 16 : 4;
+    size_t nb = (max_bytes / unit + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    dim3 grid((unsigned)nb, n_fields);
+    if (vec16) hipLaunchKernelGGL(store_step_kernel<uint4>, grid, 256, 0, as_stream(stream), fp, n_envs, t);
+    else hipLaunchKernelGGL(store_step_kernel<uint32_t>, grid, 256, 0, as_stream(stream), fp, n_envs, t);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_soa_gather(const xrl_field_t* fields, int n_fields, const int64_t* idx, int bs, int n_envs, int T,
+                              const float* stats, xrl_stream_t stream) {
+    FieldPack fp; bool vec16;
+    XRL_CHECK_ARG(pack_fields(fields, n_fields, fp, vec16) == XRL_OK);
+    XRL_CHECK_ARG(idx != nullptr && bs > 0 && n_envs > 0 && T > 0);
+    for (int i = 0; i < n_fields; ++i)
+        if ((fp.flags[i] & 1)) { XRL_CHECK_ARG(fp.row_bytes[i] == 4); vec16 = false; }
+    size_t max_units = 0;
+    for (int i = 0; i < n_fields; ++i) {
+        const size_t u = (size_t)bs * fp.row_bytes[i] / (vec16 ? 16 : 4);
+        max_units = u > max_units ? u : max_units;
+    }
+    size_t nb = (max_units + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    dim3 grid((unsigned)nb, n_fields);
+    if (vec16) hipLaunchKernelGGL(gather_kernel<uint4>, grid, 256, 0, as_stream(stream), fp, idx, bs, n_envs, T, stats);
+    else hipLaunchKernelGGL(gather_kernel<uint32_t>, grid, 256, 0, as_stream(stream), fp, idx, bs, n_envs, T, stats);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_adv_stats(const float* adv_field, const int64_t* idx, int bs, int n_batches, int n_envs, int T,
+                             float* stats, xrl_stream_t stream) {
+    XRL_CHECK_ARG(adv_field && idx && stats && bs > 0 && n_batches > 0 && n_envs > 0 && T > 0);
+    hipLaunchKernelGGL(adv_stats_kernel, dim3(n_batches), dim3(1024), 0, as_stream(stream), adv_field, idx, bs, n_envs,
+                       T, stats);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_gae_scan(const float* rew, const float* val, const float* term, const float* bootv,
+                            const uint8_t* seg, float* adv, float* ret, int n_envs, int T, double gamma, double lam,
+                            int use_gae, xrl_stream_t stream) {
+    XRL_CHECK_ARG(rew && val && term && bootv && seg && adv && ret && n_envs > 0 && T > 0);
+    const int nb = (n_envs + 63) / 64;
+    hipLaunchKernelGGL(gae_scan_kernel<8>, dim3(nb), dim3(64), 0, as_stream(stream), rew, val, term, bootv, seg, adv,
+                       ret, n_envs, T, (float)gamma, (float)lam, gamma, use_gae);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

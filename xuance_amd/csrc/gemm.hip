@@ -1,0 +1,246 @@
+// Dense layers on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+// Replaces nn.Linear forward / autograd backward of mlp_block (xuance/torch/rl_models/modules/layers.py:16-33)
+// for the actor / critic / Q / hyper-network MLPs of the three learners.
+//
+// Tiling (64-wide wavefronts): one 256-thread workgroup = 4 waves in a 2x2 arrangement computes a 64x64 tile
+// of C; each wave owns one 32x32 MFMA accumulator (16 VGPRs).  K is consumed in slabs of 32 staged through LDS.
+// Three operand layouts are needed and they only differ in how the LDS slab is read:
+//   NT  fwd         C[M,N]  = A[M,K]  . B[N,K]^T   both operands k-contiguous  -> ds_read_b128 of 4 k's per lane
+//   NN  bwd_data    C[M,N]  = A[M,K]  . B[K,N]     B is k-major                -> ds_read_b32 rows
+//   TN  bwd_weight  C[N',K'] = A[M,N']^T . X[M,K']  both k(=m)-major            -> ds_read_b32 rows, split over M
+// The MFMA consumes, per instruction, k = {h} for lane-half h = lane>>5; since the GEMM sums over k any fixed
+// permutation of k shared by A and B is legal, so the b128 path feeds lane-half h with k = 8q+4h+s (s = 0..3).
+#include "common.h"
+
+namespace xrl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDK = BK + 4;   // k-contiguous slab row stride (floats): 144 B, conflict-free for ds_read_b128
+constexpr int LDR = 64 + 0;   // k-major slab row stride (floats)
+constexpr int MAX_GROUPS = 4;
+
+struct GemmBatch {
+    xrl_gemm_t g[MAX_GROUPS];
+    int n_groups;
+    int n_split;
+    int64_t slab_stride;
+};
+
+enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
+
+// ---- global -> register staging -------------------------------------------------------------------
+// k-contiguous operand: tile rows r0..r0+63 (bounded by R), k range k0..k0+31 (bounded by K); row-major, ld.
+// thread t loads 2 float4: rows (t>>3) and (t>>3)+32, k offset (t&7)*4.
+__device__ __forceinline__ void load_kcontig(const float* __restrict__ P, int ld, int R, int K, int r0, int k0,
+                                             float4 (&reg)[2]) {
+    const int t = threadIdx.x;
+    const int kk = k0 + (t & 7) * 4;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = r0 + (t >> 3) + 32 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            const float* p = P + (size_t)r * ld + kk;
+            if (vec && kk + 3 < K) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (kk + 0 < K) v.x = p[0];
+                if (kk + 1 < K) v.y = p[1];
+                if (kk + 2 < K) v.z = p[2];
+                if (kk + 3 < K) v.w = p[3];
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+// k-major operand: tile k rows k0..k0+31 (bounded by Kr), columns c0..c0+63 (bounded by C); row-major, ld.
+// `ones_col`: column index that reads as 1.0 for valid rows (bias-gradient trick of the TN mode), or -1.
+// thread t loads 2 float4: k rows (t>>4) and (t>>4)+16, column offset (t&15)*4.
+__device__ __forceinline__ void load_kmajor(const float* __restrict__ P, int ld, int Kr, int C, int k0, int c0,
+                                            int ones_col, float4 (&reg)[2]) {
+    const int t = threadIdx.x;
+    const int cc = c0 + (t & 15) * 4;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = k0 + (t >> 4) + 16 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < Kr) {
+            const float* p = P + (size_t)k * ld + cc;
+            if (vec && cc + 3 < C) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (cc + 0 < C) v.x = p[0];
+                if (cc + 1 < C) v.y = p[1];
+                if (cc + 2 < C) v.z = p[2];
+                if (cc + 3 < C) v.w = p[3];
+            }
+            if (ones_col >= 0) {
+                if (cc + 0 == ones_col) v.x = 1.f;
+                if (cc + 1 == ones_col) v.y = 1.f;
+                if (cc + 2 == ones_col) v.z = 1.f;
+                if (cc + 3 == ones_col) v.w = 1.f;
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+__device__ __forceinline__ void stage_kcontig(float* S, const float4 (&reg)[2]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<float4*>(&S[((t >> 3) + 32 * i) * LDK + (t & 7) * 4]) = reg[i];
+}
+__device__ __forceinline__ void stage_kmajor(float* S, const float4 (&reg)[2]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<float4*>(&S[((t >> 4) + 16 * i) * LDR + (t & 15) * 4]) = reg[i];
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
+    __shared__ __attribute__((aligned(16))) float sA[64 * LDK > 32 * LDR ? 64 * LDK : 32 * LDR];
+    __shared__ __attribute__((aligned(16))) float sB[64 * LDK > 32 * LDR ? 64 * LDK : 32 * LDR];
+
+    const xrl_gemm_t& g = p.g[blockIdx.z];
+    // logical problem: C[Mo, No] = sum_k opA[Mo,k] opB[k,No], k < Kred
+    int Mo, No, Kred;
+    if (MODE == MODE_TN) { Mo = g.N; No = g.K + (g.dbias ? 1 : 0); Kred = g.M; }
+    else { Mo = g.M; No = g.N; Kred = g.K; }
+    const int tiles_n = (No + BN - 1) / BN;
+    const int tiles_m = (Mo + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_m * tiles_n) return;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // reduction range (split over the batch for the weight gradient)
+    int kbeg = 0, kend = Kred;
+    if (MODE == MODE_TN) {
+        const int chunk = (Kred + p.n_split - 1) / p.n_split;
+        kbeg = blockIdx.y * chunk;
+        kend = min(Kred, kbeg + chunk);
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    // a wave whose 32x32 sub-tile is entirely out of range skips the matrix work (wave-uniform)
+    const bool wave_live = (m0 + wm * 32 < Mo) && (n0 + wn * 32 < No);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    float4 ra[2], rb[2];
+    auto load_tiles = [&](int k0) {
+        if (MODE == MODE_NT) {
+            load_kcontig(g.A, g.lda, g.M, g.K, m0, k0, ra);
+            load_kcontig(g.B, g.ldb, g.N, g.K, n0, k0, rb);
+        } else if (MODE == MODE_NN) {
+            load_kcontig(g.A, g.lda, g.M, g.K, m0, k0, ra);
+            load_kmajor(g.B, g.ldb, g.K, g.N, k0, n0, -1, rb);
+        } else {
+            load_kmajor(g.A, g.lda, kend, g.N, k0, m0, -1, ra);                       // dY[m, n']
+            load_kmajor(g.B, g.ldb, kend, g.K, k0, n0, g.dbias ? g.K : -1, rb);      // X[m, k'] (+ ones column)
+        }
+    };
+
+    if (kbeg < kend) load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        if (MODE == MODE_TN) stage_kmajor(sA, ra); else stage_kcontig(sA, ra);
+        if (MODE == MODE_NT) stage_kcontig(sB, rb); else stage_kmajor(sB, rb);
+        __syncthreads();
+        if (k0 + BK < kend) load_tiles(k0 + BK);   // next slab in flight while the matrix cores work
+        if (wave_live) {
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                float a4[4], b4[4];
+                if (MODE == MODE_TN) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) a4[s] = sA[(q * 8 + 4 * lh + s) * LDR + wm * 32 + li];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(&sA[(wm * 32 + li) * LDK + q * 8 + 4 * lh]);
+                    a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w;
+                }
+                if (MODE == MODE_NT) {
+                    const float4 v = *reinterpret_cast<const float4*>(&sB[(wn * 32 + li) * LDK + q * 8 + 4 * lh]);
+                    b4[0] = v.x; b4[1] = v.y; b4[2] = v.z; b4[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b4[s] = sB[(q * 8 + 4 * lh + s) * LDR + wn * 32 + li];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!wave_live) return;
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int col = n0 + wn * 32 + li;
+    if (col >= No) return;
+    float bias = 0.f;
+    if (MODE == MODE_NT && g.bias) bias = g.bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= Mo) continue;
+        float v = acc[r];
+        if (MODE == MODE_NT) {
+            v = act_apply(v + bias, g.act);
+            g.C[(size_t)row * g.ldc + col] = v;
+        } else if (MODE == MODE_NN) {
+            if (g.aux) v *= act_grad_from_out(g.aux[(size_t)row * g.ldaux + col], g.act);
+            g.C[(size_t)row * g.ldc + col] = v;
+        } else {
+            const size_t so = (size_t)blockIdx.y * p.slab_stride;
+            if (col < g.K) g.C[so + (size_t)row * g.ldc + col] = v;
+            else g.dbias[so + row] = v;          // the ones column: sum_m dY[m, row]
+        }
+    }
+}
+
+static int launch(int mode, const xrl_gemm_t* groups, int n_groups, int n_split, int64_t slab_stride,
+                  xrl_stream_t stream) {
+    XRL_CHECK_ARG(groups != nullptr && n_groups >= 1 && n_groups <= MAX_GROUPS);
+    XRL_CHECK_ARG(n_split >= 1 && n_split <= 65535);
+    GemmBatch b;
+    b.n_groups = n_groups; b.n_split = n_split; b.slab_stride = slab_stride;
+    int max_tiles = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const xrl_gemm_t& g = groups[i];
+        XRL_CHECK_ARG(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0);
+        XRL_CHECK_ARG(g.lda > 0 && g.ldb > 0 && g.ldc > 0);
+        b.g[i] = g;
+        int Mo, No;
+        if (mode == MODE_TN) { Mo = g.N; No = g.K + (g.dbias ? 1 : 0); } else { Mo = g.M; No = g.N; }
+        const int tiles = ((Mo + BM - 1) / BM) * ((No + BN - 1) / BN);
+        max_tiles = tiles > max_tiles ? tiles : max_tiles;
+    }
+    dim3 grid(max_tiles, mode == MODE_TN ? n_split : 1, n_groups);
+    if (mode == MODE_NT) hipLaunchKernelGGL(gemm_f32_kernel<MODE_NT>, grid, 256, 0, as_stream(stream), b);
+    else if (mode == MODE_NN) hipLaunchKernelGGL(gemm_f32_kernel<MODE_NN>, grid, 256, 0, as_stream(stream), b);
+    else hipLaunchKernelGGL(gemm_f32_kernel<MODE_TN>, grid, 256, 0, as_stream(stream), b);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+}  // namespace xrl
+
+extern "C" int xrl_linear_fwd(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream) {
+    return xrl::launch(xrl::MODE_NT, groups, n_groups, 1, 0, stream);
+}
+extern "C" int xrl_linear_bwd_data(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream) {
+    return xrl::launch(xrl::MODE_NN, groups, n_groups, 1, 0, stream);
+}
+extern "C" int xrl_linear_bwd_weight(const xrl_gemm_t* groups, int n_groups, int n_split, int64_t slab_stride,
+                                     xrl_stream_t stream) {
+    return xrl::launch(xrl::MODE_TN, groups, n_groups, n_split, slab_stride, stream);
+}

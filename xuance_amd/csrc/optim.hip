@@ -1,0 +1,102 @@
+// Optimiser kernels: deterministic reduction of the per-chunk gradient slabs, global-norm clipping, Adam and the
+// LinearLR schedule.  Replaces  clip_grad_norm_ + torch.optim.Adam(eps=1e-5).step() + LinearLR.step()
+// (xuance/torch/learners/policy_gradient/ppo_learner.py:18-22,61-67; dqn_learner.py:18-22,47-53;
+//  base/marl_learner.py:64-75 with multi_agent_rl/qmix_learner.py:88-96).
+// The optimiser state (step counters, learning rate) lives in device memory so a captured hipGraph advances it.
+#include "common.h"
+
+namespace xrl {
+
+constexpr int RED_THREADS = 256;
+
+// grad[p] = sum_s slabs[s][p]   (fixed order s = 0..S-1 -> deterministic);  block partial of sum grad^2 (fp64)
+__global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* __restrict__ slabs, int n_split,
+                                                                  int64_t slab_stride, int64_t P,
+                                                                  float* __restrict__ grad,
+                                                                  double* __restrict__ sumsq_part) {
+    __shared__ double scratch[16];
+    double sq = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = 0.f;
+        for (int s = 0; s < n_split; ++s) g += slabs[(size_t)s * slab_stride + i];
+        grad[i] = g;
+        sq += (double)g * (double)g;
+    }
+    const double t = block_sum(sq, scratch);
+    if (threadIdx.x == 0) sumsq_part[blockIdx.x] = t;
+}
+
+// torch._single_tensor_adam, evaluated per element with the scalar prefactors in float64 like the Python side:
+//   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= lr/(1-b1^t) * m/denom
+__global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restrict__ params, float* __restrict__ grad,
+                                                                float* __restrict__ m, float* __restrict__ v, int64_t P,
+                                                                xrl_adam_state_t* __restrict__ st,
+                                                                const double* __restrict__ sumsq_part, int n_part,
+                                                                double max_norm) {
+    __shared__ double scratch[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) s += sumsq_part[i];
+    const double total_norm = sqrt(block_sum(s, scratch));
+    float coef = 1.f;
+    if (max_norm > 0.0) {
+        const double c = max_norm / (total_norm + 1e-6);       // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
+        coef = (float)(c < 1.0 ? c : 1.0);
+    }
+    const int step = st->step + 1;
+    const int k = st->sched_steps < st->total_iters ? st->sched_steps : st->total_iters;
+    const double lr = st->base_lr * (1.0 + (st->end_factor - 1.0) * (double)k / (double)st->total_iters);
+    const double b1 = st->beta1, b2 = st->beta2;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2), eps = (float)st->eps;
+    const float w1 = (float)(1.0 - b1), fb2 = (float)b2, w2 = (float)(1.0 - b2), wd = (float)st->weight_decay;
+
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = grad[i] * coef;
+        grad[i] = g;                                             // p.grad holds the clipped gradient afterwards
+        if (wd != 0.f) g += wd * params[i];
+        const float mi = m[i] + (g - m[i]) * w1;
+        const float vi = v[i] * fb2 + w2 * g * g;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        params[i] -= step_size * (mi / denom);
+    }
+    // The last block to finish advances the device-resident state (every block has consumed the old state by
+    // the time it takes its ticket; the next launch observes the new state across the kernel boundary).
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ticket = atomicAdd(&st->ticket, 1);
+        if (ticket == (int)gridDim.x - 1) {
+            st->ticket = 0;
+            st->last_grad_norm = total_norm;
+            st->step = step;
+            const int ns = st->sched_steps + 1;                  // scheduler.step() after optimizer.step()
+            st->sched_steps = ns;
+            const int k2 = ns < st->total_iters ? ns : st->total_iters;
+            st->last_lr = st->base_lr * (1.0 + (st->end_factor - 1.0) * (double)k2 / (double)st->total_iters);
+        }
+    }
+}
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_grad_reduce(const float* slabs, int n_split, int64_t slab_stride, int64_t P, float* grad,
+                               double* sumsq_part, int n_part, xrl_stream_t stream) {
+    XRL_CHECK_ARG(slabs && grad && sumsq_part && n_split >= 1 && P > 0 && n_part >= 1 && n_part <= 1024);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_part), dim3(RED_THREADS), 0, as_stream(stream), slabs, n_split,
+                       slab_stride, P, grad, sumsq_part);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_adam_step(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
+                             const double* sumsq_part, int n_part, double max_norm, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params && grad && m && v && state && sumsq_part && P > 0 && n_part >= 1 && n_part <= 1024);
+    int nb = (int)((P + RED_THREADS - 1) / RED_THREADS);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(adam_step_kernel, dim3(nb), dim3(RED_THREADS), 0, as_stream(stream), params, grad, m, v, P,
+                       state, sumsq_part, n_part, max_norm);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

@@ -1,0 +1,165 @@
+// PPO-clip loss head: log-prob / entropy / ratio / clipped surrogate / value MSE and their gradients with
+// respect to the actor-head output and the value, one thread per sample (HBM-bound, ~50 B per sample).
+// Reference arithmetic: xuance/torch/learners/policy_gradient/ppo_learner.py:46-60,70 with
+// CategoricalDistribution / DiagGaussianDistribution (rl_models/modules/distributions.py:128-192) and the
+// autograd rules of torch.clamp (gradient where lo <= x <= hi) and torch.minimum (0.5/0.5 on ties).
+#include "common.h"
+
+namespace xrl {
+
+constexpr int LOSS_THREADS = 256;
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+struct Surrogate {
+    float ratio, s1, s2, dlogp;
+    int clipped;
+};
+
+__device__ __forceinline__ Surrogate surrogate(float logp, float old_logp, float adv, float lo, float hi, float invM) {
+    Surrogate r;
+    r.ratio = expf(logp - old_logp);                        // :52
+    const float rc = fminf(fmaxf(r.ratio, lo), hi);
+    r.s1 = rc * adv;                                        // :53
+    r.s2 = adv * r.ratio;                                   // :54
+    const float inside = (r.ratio >= lo && r.ratio <= hi) ? 1.f : 0.f;
+    const float w1 = r.s1 < r.s2 ? 1.f : (r.s1 == r.s2 ? 0.5f : 0.f);
+    const float dratio = -(w1 * inside * adv + (1.f - w1) * adv) * invM;   // d(-mean(min(s1,s2)))/d ratio
+    r.dlogp = dratio * r.ratio;
+    r.clipped = (r.ratio < lo) || (r.ratio > hi);           // :70
+    return r;
+}
+
+template <bool GAUSSIAN>
+__global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p) {
+    __shared__ double scratch[16];
+    const int chunk = (p.M + p.n_split - 1) / p.n_split;
+    const int mbeg = blockIdx.x * chunk, mend = min(p.M, mbeg + chunk);
+    const float invM = 1.f / (float)p.M;
+    const float lo = (float)(1.0 - (double)p.clip_range), hi = (float)(1.0 + (double)p.clip_range);
+    float mean = 0.f, denom = 1.f;
+    if (p.stats) { mean = p.stats[0]; denom = p.stats[1] + 1e-8f; }
+    const int A = p.A;
+
+    double acc_s = 0.0, acc_c = 0.0, acc_e = 0.0, acc_v = 0.0, acc_n = 0.0;
+    // gaussian: per-thread partial of d log_std (A <= 32)
+    float dls[32];
+    if (GAUSSIAN) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) dls[j] = 0.f;
+    }
+
+    for (int m = mbeg + threadIdx.x; m < mend; m += blockDim.x) {
+        const float* o = p.out + (size_t)m * p.ld_out;
+        float adv = p.adv[m];
+        if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, mean), denom);
+        const float ret = p.returns[m], v = p.value[(size_t)m * p.ld_v], oldlp = p.old_logp[m];
+        float logp, ent;
+        if (!GAUSSIAN) {
+            const int a = (int)p.actions[m];
+            float mx = o[0];
+            for (int j = 1; j < A; ++j) mx = fmaxf(mx, o[j]);
+            float se = 0.f;
+            for (int j = 0; j < A; ++j) se += expf(o[j] - mx);
+            const float lse = mx + logf(se);
+            logp = o[a] - lse;
+            ent = 0.f;
+            for (int j = 0; j < A; ++j) { const float l = o[j] - lse; ent -= expf(l) * l; }
+            const Surrogate s = surrogate(logp, oldlp, adv, lo, hi, invM);
+            float* dq = p.d_out + (size_t)m * p.ld_out;
+            const float ce = p.ent_coef * invM;
+            for (int j = 0; j < A; ++j) {
+                const float l = o[j] - lse, pj = expf(l);
+                // d logp/d z_j = 1[j==a] - p_j ;  d H/d z_j = -p_j (l_j + H) ; loss has  -ent_coef * mean(H)
+                dq[j] = s.dlogp * ((j == a ? 1.f : 0.f) - pj) + ce * pj * (l + ent);
+            }
+            acc_s += (double)fminf(s.s1, s.s2); acc_n += s.clipped;
+            if (p.diag) { p.diag[m] = logp; p.diag[p.M + m] = s.ratio; p.diag[2 * (size_t)p.M + m] = s.s1; p.diag[3 * (size_t)p.M + m] = s.s2; }
+        } else {
+            const float* x = p.actions + (size_t)m * A;
+            logp = 0.f; ent = 0.f;
+            for (int j = 0; j < A; ++j) {
+                const float ls = p.log_std[j], sd = expf(ls), var = sd * sd, df = x[j] - o[j];
+                logp += -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;     // Normal.log_prob, summed (:179-180)
+                ent += 0.5f + LOG_SQRT_2PI + logf(sd);                           // Normal.entropy, summed (:182-183)
+            }
+            const Surrogate s = surrogate(logp, oldlp, adv, lo, hi, invM);
+            float* dq = p.d_out + (size_t)m * p.ld_out;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (j < A) {
+                    const float ls = p.log_std[j], sd = expf(ls), var = sd * sd, df = x[j] - o[j];
+                    dq[j] = s.dlogp * df / var * act_grad_from_out(o[j], p.out_act);   // through activation_action
+                    dls[j] += s.dlogp * (df * df / var - 1.f);
+                }
+            }
+            acc_s += (double)fminf(s.s1, s.s2); acc_n += s.clipped;
+            if (p.diag) { p.diag[m] = logp; p.diag[p.M + m] = s.ratio; p.diag[2 * (size_t)p.M + m] = s.s1; p.diag[3 * (size_t)p.M + m] = s.s2; }
+        }
+        const float dv = v - ret;
+        p.d_value[(size_t)m * p.ld_v] = p.vf_coef * 2.f * dv * invM;           // d(vf * mean((v-ret)^2))/dv
+        acc_c += (double)dv * dv; acc_e += ent; acc_v += v;
+    }
+
+    const double t0 = block_sum(acc_s, scratch), t1 = block_sum(acc_c, scratch), t2 = block_sum(acc_e, scratch),
+                 t3 = block_sum(acc_v, scratch), t4 = block_sum(acc_n, scratch);
+    if (threadIdx.x == 0) {
+        double* q = p.partials + (size_t)blockIdx.x * 8;
+        q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = t4; q[5] = 0; q[6] = 0; q[7] = 0;
+    }
+    if (GAUSSIAN && p.d_log_std) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (j < A) {
+                double t = block_sum((double)dls[j], scratch);
+                // d(-ent_coef * mean_m sum_j(log_std_j + c))/d log_std_j = -ent_coef, added once (slab 0)
+                if (blockIdx.x == 0) t -= (double)p.ent_coef;
+                if (threadIdx.x == 0) p.d_log_std[(size_t)blockIdx.x * p.slab_stride + j] = (float)t;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) sum_partials_kernel(const double* __restrict__ partials, int n_rows, int width,
+                                                          double* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j >= width) return;
+    double s = 0.0;
+    for (int r = 0; r < n_rows; ++r) s += partials[(size_t)r * width + j];
+    out[j] = s;
+}
+
+static int check(const xrl_ppo_loss_t* p, bool gaussian) {
+    XRL_CHECK_ARG(p != nullptr);
+    XRL_CHECK_ARG(p->out && p->value && p->actions && p->adv && p->returns && p->old_logp && p->d_out && p->d_value && p->partials);
+    XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->A <= (gaussian ? 32 : 4096) && p->ld_out >= p->A && p->ld_v >= 1);
+    XRL_CHECK_ARG(p->n_split >= 1);
+    if (gaussian) XRL_CHECK_ARG(p->log_std != nullptr);
+    return XRL_OK;
+}
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_ppo_loss_categorical(const xrl_ppo_loss_t* p, xrl_stream_t stream) {
+    int rc = check(p, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ppo_loss_kernel<false>, dim3(p->n_split), dim3(LOSS_THREADS), 0, as_stream(stream), *p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_ppo_loss_gaussian(const xrl_ppo_loss_t* p, xrl_stream_t stream) {
+    int rc = check(p, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ppo_loss_kernel<true>, dim3(p->n_split), dim3(LOSS_THREADS), 0, as_stream(stream), *p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_sum_partials(const double* partials, int n_rows, int width, double* out, xrl_stream_t stream) {
+    XRL_CHECK_ARG(partials && out && n_rows > 0 && width > 0 && width <= 64);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), partials, n_rows, width, out);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

@@ -1,0 +1,162 @@
+"""Thin, allocation-free Python wrappers over the C ABI (include/xrl_hip.h).
+
+Every function takes torch CUDA tensors (device memory owned by PyTorch-ROCm), passes raw device pointers and the
+current HIP stream to libxrl_hip.so, and returns nothing: outputs are written into caller-provided tensors, so all
+of them may be recorded into a hipGraph (xuance_amd.graph.Graph).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT, Field, Gemm, PpoLoss, AdamState, call, ptr, stream_ptr
+
+
+def _chk(t, dtype=torch.float32):
+    assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, (t.device, t.is_contiguous(), t.dtype)
+    return t
+
+
+def device_info():
+    cu, ws, arch = C.c_int(), C.c_int(), C.create_string_buffer(64)
+    call("xrl_device_info", C.byref(cu), C.byref(ws), arch, 64)
+    return dict(cu_count=cu.value, wave_size=ws.value, arch=arch.value.decode())
+
+
+# ------------------------------------------------------------------------------------------ buffer
+def _fields(pairs, flags=None):
+    arr = (Field * len(pairs))()
+    for i, (dst, src, row_bytes) in enumerate(pairs):
+        arr[i].dst, arr[i].src, arr[i].row_bytes = ptr(dst), ptr(src), int(row_bytes)
+        arr[i].flags = 0 if flags is None else int(flags[i])
+    return arr
+
+
+def soa_store_step(pairs, n_envs, t):
+    """pairs: [(field_tensor [T,n_envs,...], step_tensor [n_envs,...], row_bytes)]"""
+    arr = _fields(pairs)
+    call("xrl_soa_store_step", arr, len(pairs), int(n_envs), int(t), stream_ptr())
+
+
+def soa_gather(pairs, idx, n_envs, T, stats=None, flags=None):
+    """pairs: [(dst [bs,...], field [T,n_envs,...], row_bytes)]; idx int64 env-major flat indices."""
+    _chk(idx, torch.int64)
+    arr = _fields(pairs, flags)
+    call("xrl_soa_gather", arr, len(pairs), ptr(idx), idx.numel(), int(n_envs), int(T), ptr(stats), stream_ptr())
+
+
+def adv_stats(adv_field, idx, bs, n_batches, n_envs, T, stats):
+    call("xrl_adv_stats", ptr(_chk(adv_field)), ptr(_chk(idx, torch.int64)), int(bs), int(n_batches), int(n_envs),
+         int(T), ptr(_chk(stats)), stream_ptr())
+
+
+def gae_scan(rew, val, term, bootv, seg, adv, ret, gamma, lam, use_gae=True):
+    T, n_envs = rew.shape
+    for t in (rew, val, term, bootv, adv, ret):
+        _chk(t)
+    _chk(seg, torch.uint8)
+    call("xrl_gae_scan", ptr(rew), ptr(val), ptr(term), ptr(bootv), ptr(seg), ptr(adv), ptr(ret), n_envs, T,
+         float(gamma), float(lam), int(bool(use_gae)), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------ dense layers
+def gemm_desc(A, B, Cm, M, N, K, lda, ldb, ldc, bias=None, dbias=None, aux=None, ldaux=0, act=None):
+    g = Gemm()
+    g.A, g.B, g.C = A, B, Cm
+    g.bias, g.dbias, g.aux = bias, dbias, aux
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldaux = M, N, K, lda, ldb, ldc, ldaux
+    g.act = ACT[act] if not isinstance(act, int) else act
+    return g
+
+
+def _garr(groups):
+    arr = (Gemm * len(groups))()
+    for i, g in enumerate(groups):
+        arr[i] = g
+    return arr
+
+
+def linear_fwd(groups):
+    call("xrl_linear_fwd", _garr(groups), len(groups), stream_ptr())
+
+
+def linear_bwd_data(groups):
+    call("xrl_linear_bwd_data", _garr(groups), len(groups), stream_ptr())
+
+
+def linear_bwd_weight(groups, n_split, slab_stride):
+    call("xrl_linear_bwd_weight", _garr(groups), len(groups), int(n_split), int(slab_stride), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------ PPO loss
+def ppo_loss(dist, **kw):
+    p = PpoLoss()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    call("xrl_ppo_loss_categorical" if dist == "categorical" else "xrl_ppo_loss_gaussian", C.byref(p), stream_ptr())
+
+
+def sum_partials(partials, n_rows, width, out):
+    call("xrl_sum_partials", ptr(partials), int(n_rows), int(width), ptr(out), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def adam_state_tensor(lr, total_iters, end_factor=1.0, eps=1e-5, weight_decay=0.0, device="cuda"):
+    """Device-resident xrl_adam_state_t, returned as a uint8 tensor (use read_adam_state to inspect)."""
+    st = AdamState(0, 0, max(int(total_iters), 1), 0, float(lr), float(end_factor), 0.9, 0.999, float(eps),
+                   float(weight_decay), float(lr), 0.0)
+    raw = bytes(st)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def read_adam_state(t):
+    return AdamState.from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+
+
+def write_adam_state(t, st):
+    t.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
+
+
+def grad_reduce(slabs, n_split, slab_stride, P, grad, sumsq_part):
+    call("xrl_grad_reduce", ptr(slabs), int(n_split), int(slab_stride), int(P), ptr(grad), ptr(sumsq_part),
+         sumsq_part.numel(), stream_ptr())
+
+
+def adam_step(params, grad, m, v, P, state, sumsq_part, max_norm):
+    call("xrl_adam_step", ptr(params), ptr(grad), ptr(m), ptr(v), int(P), ptr(state), ptr(sumsq_part),
+         sumsq_part.numel(), float(max_norm if max_norm else 0.0), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------ graphs
+class Graph:
+    """hipGraph capture / replay of a sequence of xrl ops issued on the current torch stream."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+        self.stream = None
+
+    def __enter__(self):
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        call("xrl_graph_begin", self.stream.cuda_stream)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        try:
+            if et is None:
+                call("xrl_graph_end", self.stream.cuda_stream, C.byref(self.handle))
+        finally:
+            self._ctx.__exit__(et, ev, tb)
+        return False
+
+    def launch(self):
+        call("xrl_graph_launch", self.handle, stream_ptr())
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().xrl_graph_destroy(self.handle)
+        except Exception:
+            pass
