@@ -1,0 +1,137 @@
+"""GPU parity of the host-side PPO path (HipOnPolicyBuffer + ActorCriticNet + PPO_Learner) against fixtures
+generated from the unmodified reference (tests/golden/ppo_*.npz, onpolicy_buffer.npz)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, sub, assert_close
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class Capture:
+    def __init__(self):
+        self.records = []
+
+    def on_update_start(self, iterations, **kw):
+        return {}
+
+    def on_update_end(self, iterations, **kw):
+        self.records.append({k: (v.detach().cpu().numpy().copy() if isinstance(v, torch.Tensor) else v)
+                             for k, v in kw.items() if k not in ("policy", "info")})
+        return {}
+
+
+def make_learner(dist, g):
+    from xuance_amd.nets import ActorCriticNet
+    from xuance_amd.learners import PPO_Learner
+    lr, vf, ent, clip, gclip, ef, total = g["cfg"]
+    if dist == "categorical":
+        net = ActorCriticNet(4, 2, "categorical", (128,), (128,), (128,), "leaky_relu")
+        cfg = Namespace(horizon_size=256, n_epochs=8, n_minibatch=8, parallels=4, running_steps=120000, gamma=0.98)
+    else:
+        net = ActorCriticNet(17, 6, "gaussian", (), (64, 64), (64, 64), "relu", activation_action="tanh")
+        cfg = Namespace(horizon_size=256, n_epochs=16, n_minibatch=8, parallels=4, running_steps=120000, gamma=0.99)
+    cfg.__dict__.update(learning_rate=float(lr), vf_coef=float(vf), ent_coef=float(ent), clip_range=float(clip),
+                        use_grad_clip=True, grad_clip_norm=float(gclip), end_factor_lr_decay=float(ef),
+                        distributed_training=False, device="cuda", model_dir="/tmp/xrl_models")
+    cb = Capture()
+    learner = PPO_Learner(cfg, net, cb)
+    assert learner.total_iters == int(total)
+    return net, learner, cb
+
+
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+def test_ppo_learner_vs_reference_fixture(dist):
+    g = load_golden(f"ppo_{dist}")
+    net, learner, cb = make_learner(dist, g)
+    assert list(net.ref_order) == [str(n) for n in g["param_names"]]      # same state_dict order as the reference
+    net.load_state_dict(sub(g, "init"))
+    for u in range(3):
+        b = sub(g, f"u{u}/batch")
+        info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
+                              advantages=b["advantages"], aux_batch={"old_logp": b["old_logp"]},
+                              batch_size=len(b["obs"]))
+        ref_info, ref_cb = sub(g, f"u{u}/info"), sub(g, f"u{u}/cb")
+        for k in ("actor_loss", "critic_loss", "entropy", "predict_value", "clip_ratio"):
+            assert_close(info[k], ref_info[k], 1e-5, k)
+        assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "lr")
+        rec = cb.records[-1]
+        lp_scale = max(1.0, float(np.abs(ref_cb["log_prob"]).max()))
+        assert_close(rec["v_pred"], ref_cb["v_pred"], 1e-5, "v_pred")
+        for k in ("log_prob", "ratio", "surrogate1", "surrogate2"):
+            assert_close(rec[k], ref_cb[k], 1e-6, k, scale=lp_scale)
+        assert_close(rec["loss"], ref_cb["loss"], 1e-5, "loss")
+        # p.grad after the step = clipped gradients
+        for k, rg in sub(g, f"u{u}/grad").items():
+            got = net.params.view(k, learner.optimizer.grad).cpu().numpy()
+            assert_close(got, rg, 2e-5, f"grad {k}")
+        sd = net.state_dict()
+        for k, rp in sub(g, f"u{u}/param").items():
+            assert_close(sd[k].cpu().numpy(), rp, 1e-5, f"param {k} after update {u}")
+    osd = learner.optimizer.state_dict()
+    for i, k in enumerate(net.ref_order):
+        assert_close(osd["state"][i]["exp_avg"].cpu().numpy(), g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
+        assert_close(osd["state"][i]["exp_avg_sq"].cpu().numpy(), g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
+    assert learner.iterations == 3 and learner.scheduler.last_epoch == 3
+
+
+@pytest.mark.parametrize("tag", ["gae", "nogae"])
+def test_onpolicy_buffer_vs_reference_fixture(tag):
+    from xuance_amd.memory import HipOnPolicyBuffer
+    from xuance_amd.spaces import Box, Discrete
+    g = load_golden("onpolicy_buffer")
+    n_envs, T, D, gamma, lam = g["meta"]
+    n_envs, T, D = int(n_envs), int(T), int(D)
+    d = sub(g, tag)
+    buf = HipOnPolicyBuffer(Box(-1, 1, (D,)), Discrete(2), {"old_logp": ()}, n_envs, T, use_gae=(tag == "gae"),
+                            use_advnorm=True, gamma=float(gamma), gae_lam=float(lam))
+    for t in range(T):
+        buf.store(d["obs"][t], d["act"][t], d["rew"][t], d["val"][t], d["term"][t], {"old_logp": d["logp"][t]})
+        if buf.full:                                           # ppo_agent.py:129-142
+            for i in range(n_envs):
+                buf.finish_path(0.0 if d["term"][t, i] else d["boot"][t, i], i)
+            returns, advantages = buf.returns.cpu().numpy(), buf.advantages.cpu().numpy()
+            s = buf.sample(d["idx"])
+            s = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in s.items()}
+            s["aux_batch"] = {k: v.cpu().numpy() for k, v in s["aux_batch"].items()}
+            buf.clear()
+        for i in range(n_envs):                                # ppo_agent.py:146-157
+            if d["term"][t, i] or d["trunc"][t, i]:
+                buf.finish_path(0.0 if d["term"][t, i] else d["boot"][t, i], i)
+    if tag == "gae":
+        assert np.array_equal(advantages, d["advantages"]) and np.array_equal(returns, d["returns"])   # bit exact
+    else:
+        assert_close(advantages, d["advantages"], 1e-6)
+        assert_close(returns, d["returns"], 1e-6)
+    assert np.array_equal(s["obs"], d["s_obs"]) and np.array_equal(s["actions"], d["s_actions"])
+    assert_close(s["returns"], d["s_returns"], 1e-6)
+    assert np.array_equal(s["values"], d["s_values"])
+    assert np.array_equal(s["aux_batch"]["old_logp"], d["s_old_logp"])
+    assert_close(s["advantages"], d["s_advantages"], 1e-6, "adv-norm")
+    assert s["batch_size"] == len(d["idx"])
+    assert buf.ptr == 0 and buf.size == 0 and float(buf.field("returns").abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", "float32"), ("u8", "uint8")])
+def test_offpolicy_buffer_vs_reference_fixture(tag, dtype):
+    from xuance_amd.memory import HipOffPolicyBuffer, HipOffPolicyBuffer_Atari
+    from xuance_amd.spaces import Box, Discrete
+    g = load_golden("offpolicy_buffer")
+    d = sub(g, tag)
+    n_envs, n_size, bs, steps, ptr, size = [int(x) for x in d["meta"]]
+    cls = HipOffPolicyBuffer_Atari if tag == "u8" else HipOffPolicyBuffer
+    buf = cls(Box(0, 255, d["obs"].shape[2:]), Discrete(4), None, n_envs, n_envs * n_size, bs)
+    for t in range(steps):
+        buf.store(d["obs"][t], d["act"][t], d["rew"][t], d["term"][t], d["nxt"][t])
+    assert (buf.ptr, buf.size) == (ptr, size)
+    np.random.seed(123)                                         # same global-RNG draws as memory_tools.py:376-377
+    s = buf.sample()
+    assert np.array_equal(s["obs"].cpu().numpy(), d["s_obs"])
+    assert np.array_equal(s["obs_next"].cpu().numpy(), d["s_obs_next"])
+    assert np.array_equal(s["actions"].cpu().numpy(), d["s_actions"].astype(np.float32))
+    assert np.array_equal(s["rewards"].cpu().numpy(), d["s_rewards"])
+    assert np.array_equal(s["terminals"].cpu().numpy(), d["s_terminals"].astype(np.float32))
+    assert str(s["obs"].dtype).endswith(dtype)

@@ -1,0 +1,149 @@
+"""Learner base: config plumbing, optimiser / scheduler facades and checkpoint format of the reference
+(xuance/torch/learners/base/drl_learner.py:12-214)."""
+import os
+from collections import OrderedDict
+
+import torch
+
+from .. import ops
+
+
+class _NullCallback:
+    def on_update_start(self, iterations, **kwargs):
+        return {}
+
+    def on_update_end(self, iterations, **kwargs):
+        return {}
+
+
+class AdamHandle:
+    """Presents the fused device optimiser (xrl_adam_step) with torch.optim.Adam's state_dict() layout so the
+    reference's checkpoint code (drl_learner.py:64-93) and ``optimizer.state_dict()['param_groups'][0]['lr']``
+    (ppo_learner.py:69) keep working."""
+
+    def __init__(self, params, ref_order, lr, eps=1e-5, weight_decay=0.0, total_iters=1, end_factor=1.0):
+        self.params, self.ref_order = params, list(ref_order)
+        self.grad = params.like()
+        self.m = params.like()
+        self.v = params.like()
+        self.state = ops.adam_state_tensor(lr, total_iters, end_factor, eps, weight_decay, device=params.device)
+        self.defaults = dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=weight_decay, amsgrad=False)
+
+    def read(self):
+        return ops.read_adam_state(self.state)
+
+    @property
+    def lr(self):
+        return self.read().last_lr
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def state_dict(self):
+        s = self.read()
+        state = {}
+        for i, n in enumerate(self.ref_order):
+            state[i] = {"step": torch.tensor(float(s.step)), "exp_avg": self.params.view(n, self.m).clone(),
+                        "exp_avg_sq": self.params.view(n, self.v).clone()}
+        group = dict(self.defaults, lr=s.last_lr, initial_lr=s.base_lr, params=list(range(len(self.ref_order))))
+        return {"state": state if s.step > 0 else {}, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        s = self.read()
+        for i, n in enumerate(self.ref_order):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.params.view(n, self.m).copy_(st["exp_avg"])
+            self.params.view(n, self.v).copy_(st["exp_avg_sq"])
+            s.step = int(float(st["step"]))
+        g = sd["param_groups"][0]
+        s.base_lr = float(g.get("initial_lr", g["lr"]))
+        s.last_lr = float(g["lr"])
+        ops.write_adam_state(self.state, s)
+
+
+class LinearLRHandle:
+    """torch.optim.lr_scheduler.LinearLR(start_factor=1.0, end_factor, total_iters) facade (ppo_learner.py:19-22)."""
+
+    def __init__(self, opt: AdamHandle):
+        self.opt = opt
+
+    @property
+    def last_epoch(self):
+        return self.opt.read().sched_steps
+
+    def get_last_lr(self):
+        return [self.opt.read().last_lr]
+
+    def state_dict(self):
+        s = self.opt.read()
+        return dict(start_factor=1.0, end_factor=s.end_factor, total_iters=s.total_iters, last_epoch=s.sched_steps,
+                    _last_lr=[s.last_lr])
+
+    def step(self):   # stepping happens inside xrl_adam_step; kept for _safe_scheduler_step-style resume loops
+        s = self.opt.read()
+        s.sched_steps += 1
+        k = min(s.sched_steps, s.total_iters)
+        s.last_lr = s.base_lr * (1.0 + (s.end_factor - 1.0) * k / s.total_iters)
+        ops.write_adam_state(self.opt.state, s)
+
+
+class Learner:
+    def __init__(self, config, model, callback=None):
+        self.config = config
+        self.distributed_training = getattr(config, "distributed_training", False)
+        self.episode_length = getattr(config, "episode_length", None)
+        self.learning_rate = getattr(config, "learning_rate", None)
+        self.end_factor_lr_decay = getattr(config, "end_factor_lr_decay", 1.0)
+        self.gamma = getattr(config, "gamma", 0.99)
+        self.use_rnn = getattr(config, "use_rnn", False)
+        self.use_actions_mask = getattr(config, "use_actions_mask", False)
+        self.model = model
+        self.optimizer = None
+        self.scheduler = None
+        self.callback = callback if callback is not None else _NullCallback()
+        if self.distributed_training:
+            self.world_size = int(os.environ["WORLD_SIZE"])
+            self.rank = int(os.environ["RANK"])
+        else:
+            self.world_size, self.rank = 1, 0
+        self.use_grad_clip = getattr(config, "use_grad_clip", False)
+        self.grad_clip_norm = getattr(config, "grad_clip_norm", 0.5)
+        self.device = getattr(config, "device", "cuda")
+        self.model_dir = getattr(config, "model_dir", "models")
+        self.snapshot_path = os.path.join(os.getcwd(), self.model_dir, "DDP_Snapshot")
+        self.total_iters = self.estimate_total_iterations()
+        self.iterations = 0
+
+    def estimate_total_iterations(self):                        # drl_learner.py:56-62
+        start_training = getattr(self.config, "start_training", 0)
+        training_frequency = getattr(self.config, "training_frequency", 1)
+        return (self.config.running_steps - start_training) // (training_frequency * self.config.parallels)
+
+    def _key(self, k):                                          # "/rank_{r}" suffix (ppo_learner.py:72-80)
+        return f"{k}/rank_{self.rank}" if self.distributed_training else k
+
+    # -- checkpoint format of drl_learner.py:64-157 ------------------------------------------------------
+    def save_model(self, model_path):
+        os.makedirs(os.path.dirname(model_path) or ".", exist_ok=True)
+        torch.save({"policy": OrderedDict((k, v.cpu()) for k, v in self.model.state_dict().items()),
+                    "optimizer": self.optimizer.state_dict(),
+                    "rng_state": torch.get_rng_state(),
+                    "cuda_rng_state": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None},
+                   model_path)
+
+    def load_model(self, path, model=None):
+        if os.path.isdir(path):
+            files = sorted(f for f in os.listdir(path) if f.endswith(".pth"))
+            if not files:
+                raise RuntimeError(f"No model file found in {path}")
+            path = os.path.join(path, files[-1])
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ckpt["policy"] if "policy" in ckpt else ckpt)
+        if "optimizer" in ckpt and self.optimizer is not None:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+        return path
+
+    def update(self, *args, **kwargs):
+        raise NotImplementedError

@@ -1,0 +1,111 @@
+"""PPO-clip learner on the HIP engine.  Same constructor, ``update(**samples)`` contract, info keys and callback
+hooks as xuance/torch/learners/policy_gradient/ppo_learner.py:12-95; the arithmetic runs in
+xuance_amd/csrc/{gemm,ppo_loss,optim}.hip through the C ABI (include/xrl_hip.h)."""
+import numpy as np
+import torch
+
+from .. import ops
+from .base import Learner, AdamHandle, LinearLRHandle
+
+
+def pick_n_split(M):
+    """Number of deterministic gradient slabs (= batch chunks of the weight-gradient GEMMs)."""
+    return int(min(32, max(1, (M + 255) // 256)))
+
+
+class PPO_Learner(Learner):
+    def __init__(self, config, model, callback=None):
+        super().__init__(config, model, callback)
+        self.vf_coef, self.ent_coef, self.clip_range = config.vf_coef, config.ent_coef, config.clip_range
+        P = model.params
+        self.optimizer = AdamHandle(P, model.ref_order, self.learning_rate, eps=1e-5, total_iters=self.total_iters,
+                                    end_factor=self.end_factor_lr_decay)
+        self.scheduler = LinearLRHandle(self.optimizer)
+        dev = P.device
+        self._cap = 0
+        self.sumsq = torch.zeros(64, dtype=torch.float64, device=dev)
+        self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.keep_diag = True     # keep the per-sample callback tensors (log_prob, ratio, surrogates)
+
+    def estimate_total_iterations(self):                        # ppo_learner.py:28-33
+        buffer_size = self.config.horizon_size * self.config.parallels
+        update_times = self.config.running_steps // buffer_size
+        return update_times * self.config.n_epochs * self.config.n_minibatch
+
+    def _ensure(self, M):
+        if M <= self._cap:
+            return
+        dev, P = self.model.params.device, self.model.params.P
+        self._cap = M
+        self.n_split_cap = 32
+        self.slabs = torch.zeros(self.n_split_cap, P, device=dev)
+        self.partials = torch.zeros(self.n_split_cap, 8, dtype=torch.float64, device=dev)
+        self.diag = torch.zeros(4, M, device=dev)
+        self.model.plan.ensure(M)
+
+    def _as_dev(self, x, dtype=torch.float32):
+        return torch.as_tensor(x, device=self.model.params.device).to(dtype).contiguous()
+
+    # ------------------------------------------------------------------ one minibatch, tensors already on device
+    def _step(self, obs, ldx, act, ret, adv, old_logp, M, stats=None):
+        """Enqueue forward, loss, backward, clip and Adam for one minibatch (no host sync; graph-capturable)."""
+        model, opt = self.model, self.optimizer
+        S = pick_n_split(M)
+        heads = model.forward(obs, M, ldx)
+        A = model.action_dim
+        d_heads = model.d_heads
+        kw = dict(out=heads.data_ptr(), value=heads.data_ptr() + 4 * A, actions=act.data_ptr(), adv=adv.data_ptr(),
+                  stats=None if stats is None else stats.data_ptr(), returns=ret.data_ptr(),
+                  old_logp=old_logp.data_ptr(), d_out=d_heads.data_ptr(), d_value=d_heads.data_ptr() + 4 * A,
+                  diag=self.diag.data_ptr() if self.keep_diag else None, partials=self.partials.data_ptr(),
+                  M=M, A=A, ld_out=model.head_ld, ld_v=model.head_ld, n_split=S, slab_stride=model.params.P,
+                  clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
+        if model.dist == "gaussian":
+            kw.update(log_std=model.params.ptr("actor.log_std"),
+                      d_log_std=self.slabs.data_ptr() + 4 * model.params.offsets["actor.log_std"],
+                      out_act=ops.ACT[model.activation_action])
+        ops.ppo_loss(model.dist, **kw)
+        model.backward(obs, M, self.slabs, S, ldx)
+        ops.grad_reduce(self.slabs, S, model.params.P, model.params.P, opt.grad, self.sumsq)
+        if self.distributed_training and self.world_size > 1:
+            from ..dist import allreduce_mean_
+            allreduce_mean_(opt.grad)                               # one flat RCCL all-reduce per optimiser step
+            ops.grad_reduce(opt.grad, 1, model.params.P, model.params.P, opt.grad, self.sumsq)
+        ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq,
+                      self.grad_clip_norm if self.use_grad_clip else 0.0)
+        return S
+
+    def _info(self, M, S):
+        ops.sum_partials(self.partials, S, 8, self.sums)
+        s = self.sums.cpu().numpy()                                 # the one host sync of an update
+        st = self.optimizer.read()
+        return {self._key("actor_loss"): float(-s[0] / M), self._key("critic_loss"): float(s[1] / M),
+                self._key("entropy"): float(s[2] / M), self._key("learning_rate"): st.last_lr,
+                self._key("predict_value"): float(s[3] / M), self._key("clip_ratio"): float(s[4] / M)}
+
+    # ------------------------------------------------------------------ reference API (ppo_learner.py:35-95)
+    def update(self, **samples):
+        self.iterations += 1
+        obs = self._as_dev(samples["obs"])
+        act = self._as_dev(samples["actions"])
+        ret = self._as_dev(samples["returns"])
+        adv = self._as_dev(samples["advantages"])
+        old_logp = self._as_dev(samples["aux_batch"]["old_logp"])
+        M = obs.shape[0]
+        obs = obs.reshape(M, -1)
+        self._ensure(M)
+        info = self.callback.on_update_start(self.iterations, policy=self.model, obs=obs, act=act, returns=ret,
+                                             advantages=adv, old_logp=old_logp) or {}
+        S = self._step(obs, obs.shape[1], act, ret, adv, old_logp, M)
+        info.update(self._info(M, S))
+        heads = self.model.plan.acts[len(self.model.plan.widths) - 1]
+        A = self.model.action_dim
+        d = self.diag.view(-1)                                      # the loss kernel packs [4][M] for the current M
+        cb = dict(policy=self.model, info=info, v_pred=heads[:M, A], log_prob=d[0:M], ratio=d[M:2 * M],
+                  surrogate1=d[2 * M:3 * M], surrogate2=d[3 * M:4 * M],
+                  a_loss=info[self._key("actor_loss")], c_loss=info[self._key("critic_loss")],
+                  e_loss=info[self._key("entropy")])
+        cb["loss"] = cb["a_loss"] - self.ent_coef * cb["e_loss"] + self.vf_coef * cb["c_loss"]
+        cb["a_dist"] = heads[:M, :A]
+        info.update(self.callback.on_update_end(self.iterations, **cb) or {})
+        return info

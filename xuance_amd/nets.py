@@ -1,0 +1,318 @@
+"""Network containers: parameters live in ONE flat fp32 device buffer (so gradient slabs, Adam moments and the
+RCCL all-reduce are single contiguous ranges) and the forward/backward passes are *plans* of grouped MFMA GEMM
+launches (xuance_amd/csrc/gemm.hip).
+
+The classes mirror the reference modules they replace and export ``state_dict()`` with the reference's names, so
+checkpoints are interchangeable:
+  ActorCriticNet  <-> SharedActorCritic(Basic_MLP | Basic_Identical, CategoricalActorHead | GaussianActorHead,
+                      ValueHead)   (rl_models/architectures/single_agent/actor_critic.py:40-72,
+                      heads/actor_head.py:14-72, heads/critic_head.py:9-30, representations/mlp.py:10-60)
+  SequentialNet   <-> a plain nn.Sequential of mlp_blocks (rl_models/modules/layers.py:16-33), used for the DQN
+                      Q-head, the per-agent QMIX Q-network and the mixer hyper-networks.
+"""
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+
+def _align4(n):
+    return (n + 3) // 4 * 4
+
+
+class FlatParams:
+    """Named fp32 tensors carved out of one flat buffer; every tensor starts on a 16-byte boundary."""
+
+    def __init__(self, specs, device):
+        self.names, self.shapes, self.offsets = [], {}, {}
+        off = 0
+        for name, shape in specs:
+            self.names.append(name)
+            self.shapes[name] = tuple(shape)
+            self.offsets[name] = off
+            n = 1
+            for s in shape:
+                n *= s
+            off = _align4(off + n)
+        self.P = off
+        self.device = device
+        self.flat = torch.zeros(self.P, dtype=torch.float32, device=device)
+
+    def view(self, name, flat=None):
+        flat = self.flat if flat is None else flat
+        n = 1
+        for s in self.shapes[name]:
+            n *= s
+        o = self.offsets[name]
+        return flat[o:o + n].view(self.shapes[name])
+
+    def ptr(self, name, flat=None):
+        flat = self.flat if flat is None else flat
+        return flat.data_ptr() + 4 * self.offsets[name]
+
+    def like(self):
+        return torch.zeros_like(self.flat)
+
+    def named_views(self, order, flat=None):
+        return OrderedDict((n, self.view(n, flat)) for n in order)
+
+
+@dataclass
+class Layer:
+    name: str            # reference parameter prefix ("actor.logits.0"); stacked layers carry several names
+    K: int
+    N: int
+    act: Optional[str]
+    in_level: int
+    in_off: int
+    out_level: int
+    out_off: int
+    w_name: str = ""     # key of the (possibly stacked) weight in FlatParams
+    b_name: str = ""
+
+
+class Plan:
+    """A feed-forward DAG of Linear(+act) layers executed level by level with grouped launches."""
+
+    def __init__(self, params: FlatParams, widths: List[int], stages: List[List[Layer]]):
+        self.params, self.widths, self.stages = params, widths, stages
+        self.cap = 0
+        self.acts, self.dacts = {}, {}
+
+    def ensure(self, M):
+        if M <= self.cap:
+            return
+        dev = self.params.device
+        self.cap = M
+        for lvl in range(1, len(self.widths)):
+            self.acts[lvl] = torch.zeros(M, self.widths[lvl], device=dev)
+            self.dacts[lvl] = torch.zeros(M, self.widths[lvl], device=dev)
+
+    # -- pointer helpers -------------------------------------------------------------------------
+    def _buf(self, store, lvl, off, x, ldx):
+        if lvl == 0:
+            return x.data_ptr() + 4 * off, ldx
+        return store[lvl].data_ptr() + 4 * off, self.widths[lvl]
+
+    def forward(self, x, ldx, M, flat=None):
+        """x: device tensor holding the input rows with row stride ldx (floats)."""
+        self.ensure(M)
+        P = self.params
+        for stage in self.stages:
+            groups = []
+            for L in stage:
+                a, lda = self._buf(self.acts, L.in_level, L.in_off, x, ldx)
+                c, ldc = self._buf(self.acts, L.out_level, L.out_off, x, ldx)
+                groups.append(ops.gemm_desc(a, P.ptr(L.w_name, flat), c, M, L.N, L.K, lda, L.K, ldc,
+                                            bias=P.ptr(L.b_name, flat), act=L.act))
+            ops.linear_fwd(groups)
+        return self.acts[len(self.widths) - 1]
+
+    def backward(self, x, ldx, M, slabs, n_split, flat=None):
+        """dacts[last] must hold d loss / d (pre-activation) of the last level. Writes weight/bias gradient
+        partials into slabs[s][layout of params]."""
+        P = self.params
+        stride = slabs.shape[1]
+        for si in reversed(range(len(self.stages))):
+            stage = self.stages[si]
+            wg, dg = [], []
+            for L in stage:
+                dy, lddy = self._buf(self.dacts, L.out_level, L.out_off, x, ldx)
+                a, lda = self._buf(self.acts, L.in_level, L.in_off, x, ldx)
+                wg.append(ops.gemm_desc(dy, a, slabs.data_ptr() + 4 * P.offsets[L.w_name], M, L.N, L.K, lddy, lda, L.K,
+                                        dbias=slabs.data_ptr() + 4 * P.offsets[L.b_name]))
+                if L.in_level > 0:
+                    dx, lddx = self._buf(self.dacts, L.in_level, L.in_off, x, ldx)
+                    aux, ldaux = self._buf(self.acts, L.in_level, L.in_off, x, ldx)
+                    prev_act = self._act_of(L.in_level, L.in_off)
+                    dg.append(ops.gemm_desc(dy, P.ptr(L.w_name, flat), dx, M, L.K, L.N, lddy, L.K, lddx,
+                                            aux=aux, ldaux=ldaux, act=prev_act))
+            ops.linear_bwd_weight(wg, n_split, stride)
+            if dg:
+                ops.linear_bwd_data(dg)
+
+    def _act_of(self, lvl, off):
+        for stage in self.stages:
+            for L in stage:
+                if L.out_level == lvl and L.out_off <= off < L.out_off + L.N:
+                    return L.act
+        raise KeyError((lvl, off))
+
+
+def _orthogonal(shape, gen_seeded=True):
+    w = torch.empty(shape)
+    torch.nn.init.orthogonal_(w)      # same initializer call the reference makes (agent.py:133, layers.py:23-26)
+    return w
+
+
+class ActorCriticNet:
+    """SharedActorCritic re-laid-out for the device: first actor/critic hidden layers are stacked into one GEMM."""
+
+    def __init__(self, obs_dim, action_dim, dist="categorical", representation_hidden=(128,), actor_hidden=(128,),
+                 critic_hidden=(128,), activation="leaky_relu", activation_action=None, device="cuda", init=True):
+        assert dist in ("categorical", "gaussian")
+        self.obs_dim, self.action_dim, self.dist = obs_dim, action_dim, dist
+        self.activation, self.activation_action = activation, activation_action
+        rep, ah, ch = list(representation_hidden or []), list(actor_hidden), list(critic_hidden)
+        assert len(ah) == len(ch) and len(ah) >= 1, "actor/critic hidden stacks must have equal depth >= 1"
+        akey = "actor.logits" if dist == "categorical" else "actor.mu"
+        self.ref_order = []           # reference state_dict order: representation, actor, critic
+        specs = []
+        feat = obs_dim
+        rep_layers = []
+        for i, h in enumerate(rep):
+            rep_layers.append((f"representation.model.{2 * i}", feat, h))
+            feat = h
+        a_layers, c_layers = [], []
+        fa = fc = feat
+        for i, (ha, hc) in enumerate(zip(ah, ch)):
+            a_layers.append((f"{akey}.{2 * i}", fa, ha))
+            c_layers.append((f"critic.values.{2 * i}", fc, hc))
+            fa, fc = ha, hc
+        a_out = (f"{akey}.{2 * len(ah)}", fa, action_dim)
+        c_out = (f"critic.values.{2 * len(ch)}", fc, 1)
+        for n, k, o in rep_layers:
+            self.ref_order += [n + ".weight", n + ".bias"]
+        if dist == "gaussian":
+            pass
+        for n, k, o in a_layers + [a_out]:
+            self.ref_order += [n + ".weight", n + ".bias"]
+        if dist == "gaussian":
+            # nn.Module registers parameters before sub-modules' parameters: actor.log_std precedes actor.mu.*
+            idx = self.ref_order.index(f"{akey}.0.weight")
+            self.ref_order.insert(idx, "actor.log_std")
+        for n, k, o in c_layers + [c_out]:
+            self.ref_order += [n + ".weight", n + ".bias"]
+
+        # physical layout: per level, [W_actor; W_critic] adjacent and [b_actor; b_critic] adjacent
+        for n, k, o in rep_layers:
+            specs += [(n + ".weight", (o, k)), (n + ".bias", (o,))]
+        self._stack0 = None
+        widths = [obs_dim] + [h for h in rep]
+        stages = []
+        lvl = 0
+        for i, (n, k, o) in enumerate(rep_layers):
+            stages.append([Layer(n, k, o, activation, lvl, 0, lvl + 1, 0, n + ".weight", n + ".bias")])
+            lvl += 1
+        # level of stacked first hidden layers (shared input): weights must be physically adjacent, same K
+        (na, ka, oa), (nc, kc, oc) = a_layers[0], c_layers[0]
+        specs += [(na + ".weight", (oa, ka)), (nc + ".weight", (oc, kc)), (na + ".bias", (oa,)), (nc + ".bias", (oc,))]
+        assert (oa * ka) % 4 == 0 and oa % 4 == 0, "stacked actor/critic layer needs 16-byte aligned halves"
+        widths.append(oa + oc)
+        stages.append([Layer(na + "+" + nc, ka, oa + oc, activation, lvl, 0, lvl + 1, 0, na + ".weight", na + ".bias")])
+        lvl += 1
+        prev_a, prev_c = oa, oc
+        for (na, ka, oa), (nc, kc, oc) in zip(a_layers[1:], c_layers[1:]):
+            specs += [(na + ".weight", (oa, ka)), (na + ".bias", (oa,)), (nc + ".weight", (oc, kc)), (nc + ".bias", (oc,))]
+            widths.append(oa + oc)
+            stages.append([Layer(na, ka, oa, activation, lvl, 0, lvl + 1, 0, na + ".weight", na + ".bias"),
+                           Layer(nc, kc, oc, activation, lvl, prev_a, lvl + 1, oa, nc + ".weight", nc + ".bias")])
+            lvl += 1
+            prev_a, prev_c = oa, oc
+        (na, ka, oa), (nc, kc, oc) = a_out, c_out
+        specs += [(na + ".weight", (oa, ka)), (na + ".bias", (oa,)), (nc + ".weight", (oc, kc)), (nc + ".bias", (oc,))]
+        widths.append(action_dim + 1)
+        stages.append([Layer(na, ka, oa, activation_action if dist == "gaussian" else None, lvl, 0, lvl + 1, 0,
+                             na + ".weight", na + ".bias"),
+                       Layer(nc, kc, 1, None, lvl, prev_a, lvl + 1, action_dim, nc + ".weight", nc + ".bias")])
+        if dist == "gaussian":
+            specs.append(("actor.log_std", (action_dim,)))
+        self.params = FlatParams(specs, device)
+        self.plan = Plan(self.params, widths, stages)
+        self.head_ld = action_dim + 1
+        if init:
+            self.reset_parameters()
+
+    # -- parameters --------------------------------------------------------------------------------
+    def reset_parameters(self):
+        """orthogonal_(gain=1) weights, zero biases, log_std = -1, drawn in the reference's construction order
+        (representation, actor, critic) from torch's global CPU generator."""
+        sd = OrderedDict()
+        for name in self.ref_order:
+            shape = self.params.shapes[name]
+            if name == "actor.log_std":
+                continue
+            if name.endswith(".weight"):
+                sd[name] = _orthogonal(shape)
+            else:
+                sd[name] = torch.zeros(shape)
+        if self.dist == "gaussian":
+            sd["actor.log_std"] = -torch.ones(self.action_dim)
+        self.load_state_dict(sd)
+
+    def state_dict(self):
+        return OrderedDict((n, self.params.view(n).detach().clone()) for n in self.ref_order)
+
+    def load_state_dict(self, sd):
+        for n in self.ref_order:
+            self.params.view(n).copy_(torch.as_tensor(sd[n], dtype=torch.float32))
+
+    def parameters(self):
+        return [self.params.view(n) for n in self.ref_order]
+
+    # -- compute -------------------------------------------------------------------------------------
+    def forward(self, x, M, ldx=None):
+        """Returns the head buffer [cap, action_dim+1]: columns [0,A) actor output, column A the value."""
+        return self.plan.forward(x, self.obs_dim if ldx is None else ldx, M)
+
+    @property
+    def d_heads(self):
+        return self.plan.dacts[len(self.plan.widths) - 1]
+
+    def backward(self, x, M, slabs, n_split, ldx=None):
+        self.plan.backward(x, self.obs_dim if ldx is None else ldx, M, slabs, n_split)
+
+
+class SequentialNet:
+    """nn.Sequential of mlp_blocks with reference-style parameter names ``<prefix>.<2i>.{weight,bias}``.
+
+    ``segments``: list of (prefix, [hidden...], last_act) chained one after another, e.g. the DQN network is
+    [("representation.model", [64], act), ("eval_Q_head.q_value", [64, n_actions], None)]."""
+
+    def __init__(self, in_dim, segments, activation="relu", device="cuda", init=True, params=None):
+        self.in_dim, self.activation = in_dim, activation
+        specs, stages, widths = [], [], [in_dim]
+        self.ref_order = []
+        feat, lvl = in_dim, 0
+        for prefix, sizes, last_act in segments:
+            for i, h in enumerate(sizes):
+                n = f"{prefix}.{2 * i}"
+                act = activation if (i < len(sizes) - 1 or last_act == "same") else last_act
+                specs += [(n + ".weight", (h, feat)), (n + ".bias", (h,))]
+                self.ref_order += [n + ".weight", n + ".bias"]
+                stages.append([Layer(n, feat, h, act, lvl, 0, lvl + 1, 0, n + ".weight", n + ".bias")])
+                widths.append(h)
+                feat, lvl = h, lvl + 1
+        self.out_dim = feat
+        self.params = FlatParams(specs, device) if params is None else params
+        self.plan = Plan(self.params, widths, stages)
+        if init and params is None:
+            self.reset_parameters()
+
+    def reset_parameters(self):
+        for name in self.ref_order:
+            v = self.params.view(name)
+            if name.endswith(".weight"):
+                v.copy_(_orthogonal(v.shape))
+            else:
+                v.zero_()
+
+    def state_dict(self, flat=None):
+        return OrderedDict((n, self.params.view(n, flat).detach().clone()) for n in self.ref_order)
+
+    def load_state_dict(self, sd, flat=None):
+        for n in self.ref_order:
+            self.params.view(n, flat).copy_(torch.as_tensor(sd[n], dtype=torch.float32))
+
+    def forward(self, x, M, ldx=None, flat=None):
+        return self.plan.forward(x, self.in_dim if ldx is None else ldx, M, flat)
+
+    @property
+    def d_out(self):
+        return self.plan.dacts[len(self.plan.widths) - 1]
+
+    def backward(self, x, M, slabs, n_split, ldx=None, flat=None):
+        self.plan.backward(x, self.in_dim if ldx is None else ldx, M, slabs, n_split, flat)
