@@ -154,6 +154,101 @@ int xrl_grad_reduce(const float* slabs, int n_split, int64_t slab_stride, int64_
 int xrl_adam_step(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
                   const double* sumsq_part, int n_part, double max_norm, xrl_stream_t stream);
 
+
+/* ------------------------------------------------------------------ rollout-side ops (one small launch per step)
+ * RunningMeanStd.update + _process_observation (statistic_tools.py:117-185, agent.py:262-283) */
+typedef struct {
+    const float* x;       // [n][D] raw observations
+    float* mean;          // [D] running mean (float32 like the reference's np.float32 arrays)
+    float* var;           // [D]
+    double* count;        // [1] python float in the reference
+    float* out0;          // normalised copy 0 (e.g. the policy input rows), may be NULL
+    float* out1;          // normalised copy 1 (e.g. the rollout-buffer slot of this step), may be NULL
+    int n, D, ld_x, ld0, ld1;
+    int update;           // 1: RunningMeanStd.update(x) first (ppo_agent.py:114)
+    int normalize;        // 1: clip((x-mean)/(std+1e-8), +-range) (agent.py:262-283); 0: plain copy
+    float range;
+} xrl_rms_t;
+int xrl_obs_normalize(const xrl_rms_t* p, xrl_stream_t stream);
+
+/* OnPolicyAgent.get_actions (core/on_policy.py:128-169): sample an action from the policy head output, its
+ * log-prob and the value; inverse-CDF / Box-Muller on Philox4x32-10 randomness, or on supplied noise. */
+typedef struct {
+    const float* heads;     // [2n or n][ld] policy head buffer: cols [0,A) actor output, col A value
+    const float* log_std;   // gaussian: [A]
+    const float* noise;     // optional supplied randomness (parity tests): categorical [n] uniforms, gaussian [n][A] normals
+    float* act_out;         // rollout-buffer slot actions[t]: [n] (categorical, f32 index) or [n][A]; NULL = only bootv_prev
+    float* val_out;         // values[t] [n]
+    float* logp_out;        // old_logp[t] [n]
+    int32_t* env_action;    // discrete action for the device env [n] (categorical) or NULL
+    float* env_action_f;    // continuous action for the device env [n][A] or NULL
+    float* bootv_prev;      // NULL or bootv[t-1] [n]: value of the previous step's (normalised) next_obs = rows [n,2n)
+    int n, A, ld, gaussian;
+    uint64_t seed;
+    uint32_t step;          // global vector-step counter (RNG counter)
+    const uint32_t* step_dev; // if non-NULL the counter is read from device memory (graph replay) and `step` is added
+} xrl_sample_t;
+int xrl_policy_sample(const xrl_sample_t* p, xrl_stream_t stream);
+
+/* Device-resident CartPole-v1 vector env with the DummyVecEnv auto-reset contract
+ * (environment/vector_envs/dummy_vec_env.py:65-76: terminal obs returned, reset obs becomes buf_obs). */
+typedef struct {
+    double* state;            // [n][4] x, x_dot, theta, theta_dot (float64 like Gymnasium)
+    int32_t* steps;           // [n] elapsed steps of the running episode
+    int32_t* episodes;        // [n] finished-episode counter (also the reset RNG counter)
+    const int32_t* action;    // [n] 0/1
+    float* obs;               // [n][4] observation the agent sees next (after auto-reset)      == buf_obs
+    float* next_obs;          // [n][4] observation returned by step() before any reset (terminal obs on episode end)
+    float* reward;            // [n]
+    float* terminated;        // [n] 0/1
+    float* truncated;         // [n] 0/1
+    float* ep_score;          // [n] running episode score (XuanCeEnvWrapper.episode_score, utils/wrapper.py)
+    double* stats;            // [4] totals: finished episodes, sum of scores, sum of lengths, (unused)
+    int n, max_steps;
+    uint64_t seed;
+} xrl_cartpole_t;
+int xrl_cartpole_step(const xrl_cartpole_t* p, int reset, xrl_stream_t stream);
+
+/* Per-step bookkeeping of PPO_Agent.train (ppo_agent.py:128,144-157): reward normalisation + store,
+ * path-end flags, return tracker and ret_rms updates in env order, normalised next_obs for bootstrapping. */
+typedef struct {
+    const float* reward;      // [n] raw env reward
+    const float* terminated;  // [n]
+    const float* truncated;   // [n]
+    const float* next_obs;    // [n][D] raw pre-reset next observation
+    const float* obs_mean;    // [D] observation running stats AFTER this step's update
+    const float* obs_var;     // [D]
+    float* next_obs_norm;     // [n][ld_next] normalised next_obs -> policy input rows [n,2n) of the next forward
+    float* rew_out;           // rewards[t]   (normalised reward, agent.py:285-294)
+    float* term_out;          // terminals[t]
+    uint8_t* seg_out;         // seg[t]: path-end flags for xrl_gae_scan
+    float* ret_track;         // [n] discounted return tracker (ppo_agent.py:144)
+    float* ret_mean;          // [1] RunningMeanStd of returns
+    float* ret_var;           // [1]
+    double* ret_count;        // [1]
+    int n, D, ld_next;
+    int use_obsnorm, use_rewnorm, last_step;   // last_step: buffer becomes full -> every env closes its path
+    float obs_range, rew_range, gamma;
+} xrl_poststep_t;
+int xrl_rollout_poststep(const xrl_poststep_t* p, xrl_stream_t stream);
+
+/* OffPolicyAgent.exploration (core/off_policy.py:129-148): greedy argmax + per-env epsilon coin. */
+typedef struct {
+    const float* q;          // [n][ld] Q-values
+    const float* uniforms;   // optional [n] supplied uniforms
+    const int32_t* randoms;  // optional [n] supplied random actions
+    const float* eps_dev;    // epsilon in device memory
+    int32_t* action;         // [n]
+    float* action_f;         // [n] float copy for the replay buffer (actions are stored as float32)
+    int n, A, ld;
+    uint64_t seed;
+    uint32_t step;
+    const uint32_t* step_dev;
+} xrl_egreedy_t;
+int xrl_egreedy(const xrl_egreedy_t* p, xrl_stream_t stream);
+/* *counter += inc on the stream (advances RNG step counters between replays of a captured rollout). */
+int xrl_counter_add(uint32_t* counter, uint32_t inc, xrl_stream_t stream);
+
 /* ------------------------------------------------------------------ hipGraph capture of op sequences */
 int xrl_graph_begin(xrl_stream_t stream);
 int xrl_graph_end(xrl_stream_t stream, void** graph_exec_out);

@@ -353,6 +353,16 @@ def build_actor_critic_layers(sd, prefix_rep="representation.model", actor_key="
     return rep, actor, critic
 
 
+def actor_critic_forward(sd, obs, dist="categorical", act="leaky_relu", activation_action=None):
+    """SharedActorCritic.forward (actor_critic.py:51-59): returns (actor head output, values)."""
+    actor_key = "actor.logits" if dist == "categorical" else "actor.mu"
+    rep_l, actor_l, critic_l = build_actor_critic_layers(sd, actor_key=actor_key, act=act,
+                                                         activation_action=activation_action)
+    obs = np.asarray(obs, np.float32)
+    h = MLP(rep_l).forward(obs) if rep_l else obs
+    return MLP(actor_l).forward(h), MLP(critic_l).forward(h)[:, 0]
+
+
 def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", activation_action=None):
     """Forward + loss + backward of PPO_Learner.update (ppo_learner.py:46-62).
 

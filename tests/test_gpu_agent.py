@@ -1,0 +1,155 @@
+"""GPU: end-to-end parity of the device rollout + update loop (PPO_Agent on DeviceCartPoleVecEnv) against the
+oracle replaying the SAME trajectory: the device's sampled actions, reset observations and minibatch indices are
+the fixed inputs (RNG streams cannot be matched), everything else -- physics, running
+statistics, normalisation, values, log-probs, reward processing, path flags, GAE, advantages normalisation and all
+minibatch updates -- is recomputed by the oracle and compared."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def make_config(n_envs, T, **kw):
+    c = dict(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128],
+             critic_hidden_size=[128], activation="leaky_relu", seed=1, parallels=n_envs, running_steps=10 ** 6,
+             horizon_size=T, n_epochs=2, n_minibatch=2, learning_rate=4e-4, vf_coef=0.25, ent_coef=0.01,
+             clip_range=0.2, gamma=0.98, use_gae=True, gae_lambda=0.95, use_advnorm=True, use_grad_clip=True,
+             grad_clip_norm=0.5, use_obsnorm=True, use_rewnorm=True, obsnorm_range=5, rewnorm_range=5,
+             distributed_training=False, device="cuda", model_dir="/tmp/xrl_models", use_hip_graph=False)
+    c.update(kw)
+    return Namespace(**c)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def test_rollout_and_update_vs_oracle(oracle):
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    n, T = 24, 40
+    torch.manual_seed(0)
+    env = DeviceCartPoleVecEnv(n, seed=3)
+    env.max_episode_steps = 25                     # force truncations inside the rollout
+    agent = PPO_Agent(make_config(n, T), env)
+    sd0 = {k: npy(v) for k, v in agent.model.state_dict().items()}
+    env.reset()
+    agent._started = True
+    st = oracle.CartPoleOracle(npy(env.state))
+    st.max_steps = 25
+    obs_rms, ret_rms = oracle.RunningMeanStdOracle((4,)), oracle.RunningMeanStdOracle(())
+    returns = np.zeros(n, np.float32)
+    buf = oracle.OnPolicyBufferOracle((4,), (), n, T, gamma=0.98, gae_lam=0.95)
+    raw_obs = npy(env.buf_obs)
+    f = agent.memory.soa.fields
+    for t in range(T):
+        agent._enqueue_step(t)
+        torch.cuda.synchronize()
+        # ---- oracle mirror of ppo_agent.py:113-177 -------------------------------------------------------
+        obs_rms.update(raw_obs)
+        obs_n = oracle.process_observation(raw_obs, obs_rms).astype(np.float32)
+        assert_close(npy(f["observations"][t]), obs_n, 1e-5, f"normalised obs t={t}")
+        logits, value = oracle.actor_critic_forward(sd0, obs_n)
+        acts = npy(f["actions"][t])                                   # fixed input: the device's sampled actions
+        logp = oracle.log_softmax(logits)[np.arange(n), acts.astype(int)]
+        assert_close(npy(f["values"][t]), value, 1e-5, "values")
+        assert_close(npy(f["aux_old_logp"][t]), logp, 1e-5, "old_logp")
+        next_obs, rew, term, trunc = st.step(acts.astype(int))
+        assert_close(npy(env.next_obs), next_obs, 1e-6, "physics")
+        assert np.array_equal(npy(env.terminated) > 0, term) and np.array_equal(npy(env.truncated) > 0, trunc)
+        rew_n = oracle.process_reward(rew, ret_rms).astype(np.float32)
+        assert_close(npy(f["rewards"][t]), rew_n, 1e-5, "normalised reward")
+        buf.store(obs_n, acts, rew_n, value, term, {"old_logp": logp})
+        vals_next, _ = None, None
+        boot = oracle.actor_critic_forward(sd0, oracle.process_observation(next_obs, obs_rms).astype(np.float32))[1]
+        if buf.full:                                                  # ppo_agent.py:129-135
+            for i in range(n):
+                buf.finish_path(0.0 if term[i] else boot[i], i)
+            adv_full, ret_full = buf.advantages.copy(), buf.returns.copy()
+        returns = (0.98 * returns + rew).astype(np.float32)
+        done = term | trunc
+        reset_obs = npy(env.buf_obs)
+        for i in range(n):
+            if done[i]:
+                ret_rms.update(returns[i:i + 1])
+                returns[i] = 0.0
+                if not buf.full:
+                    buf.finish_path(0.0 if term[i] else boot[i], i)
+                st.state[i] = npy(env.state)[i]                       # fixed input: the device's reset state
+                st.steps[i] = 0
+        raw_obs = np.where(done[:, None], reset_obs, next_obs)
+        assert_close(npy(agent.returns), returns, 1e-5, "return tracker")
+        assert_close(npy(agent.ret_var)[0], ret_rms.var, 1e-5, "ret_rms.var")
+        assert_close(npy(agent.obs_mean), obs_rms.mean, 1e-5, "obs_rms.mean")
+        assert_close(npy(agent.obs_var), obs_rms.var, 1e-5, "obs_rms.var")
+    assert int((npy(f["seg"]) & 1).sum()) > n                         # episodes really ended inside the rollout
+    assert int(npy(env.truncated).sum()) >= 0
+    # ---- close the rollout: bootstrap forward + GAE --------------------------------------------------------
+    heads = agent.model.forward(agent.X, 2 * n)
+    from xuance_amd import ops
+    ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None, bootv_prev=f["bootv"][T - 1], n=n, A=2,
+                      ld=3, gaussian=0, seed=1, step=0, step_dev=None)
+    ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
+                 0.98, 0.95, True)
+    torch.cuda.synchronize()
+    assert_close(npy(f["advantages"]).T, adv_full, 2e-5, "advantages", scale=float(np.abs(adv_full).max()))
+    assert_close(npy(f["returns"]).T, ret_full, 2e-5, "returns", scale=float(np.abs(ret_full).max()))
+    # ---- update phase ------------------------------------------------------------------------------------------
+    agent.memory.ptr, agent.memory.size = 0, T
+    info = agent.update()
+    idx = npy(agent.idx)
+    sd = {k: v.copy() for k, v in sd0.items()}
+    opt = oracle.AdamOracle(sd, lr=4e-4, eps=1e-5, total_iters=agent.learner.total_iters)
+    cfg = dict(vf_coef=0.25, ent_coef=0.01, clip_range=0.2, use_grad_clip=True, grad_clip_norm=0.5)
+    # the oracle buffer holds the oracle's own GAE; use it (not the device's) so the whole chain is independent
+    for k in range(idx.shape[0]):
+        s = buf.sample(idx[k])
+        b = dict(obs=s["obs"], actions=s["actions"], returns=s["returns"], advantages=s["advantages"],
+                 old_logp=s["aux_batch"]["old_logp"])
+        oinfo, _ = oracle.ppo_update(sd, opt, b, cfg)
+    for key in ("actor_loss", "critic_loss", "entropy", "predict_value"):
+        ref = {"actor_loss": oinfo["a_loss"], "critic_loss": oinfo["c_loss"], "entropy": oinfo["e_loss"],
+               "predict_value": oinfo["predict_value"]}[key]
+        assert_close(info[key], ref, 5e-5, key)
+    got = agent.model.state_dict()
+    for k_, v in sd.items():
+        assert_close(npy(got[k_]), v, 5e-5, f"param {k_} after {idx.shape[0]} updates")
+
+
+def test_graph_replay_equals_eager():
+    """The captured rollout/update graphs must reproduce the eager launch sequence bit for bit."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        env = DeviceCartPoleVecEnv(64, seed=5)
+        agent = PPO_Agent(make_config(64, 32, use_hip_graph=use_graph, n_epochs=2, n_minibatch=4), env)
+        idx = np.stack([np.random.default_rng(e).permutation(64 * 32) for e in range(2)]).reshape(8, -1)
+        agent.set_indices(idx)
+        infos = [agent.train(32) for _ in range(3)]
+        torch.cuda.synchronize()
+        outs.append((npy(agent.model.params.flat), npy(agent.memory.soa.fields["advantages"]), infos[-1]))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2]["actor_loss"] == outs[1][2]["actor_loss"]
+
+
+def test_cartpole_learns():
+    """Sanity (not parity): a few hundred thousand env steps of the fused loop must raise the episode score."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(1)
+    env = DeviceCartPoleVecEnv(64, seed=1)
+    agent = PPO_Agent(make_config(64, 256, use_hip_graph=True, n_epochs=8, n_minibatch=8, running_steps=64 * 256 * 30), env)
+    agent.train(256 * 3)
+    e0, s0, _ = env.episode_stats()
+    env.stats.zero_()
+    agent.train(256 * 27)
+    e1, s1, _ = env.episode_stats()
+    assert s0 < 60 and s1 > 100, (s0, s1)

@@ -39,7 +39,48 @@ class AdamState(C.Structure):
                 ("eps", c_double), ("weight_decay", c_double), ("last_lr", c_double), ("last_grad_norm", c_double)]
 
 
+class Rms(C.Structure):
+    _fields_ = [("x", c_void_p), ("mean", c_void_p), ("var", c_void_p), ("count", c_void_p), ("out0", c_void_p),
+                ("out1", c_void_p), ("n", c_int), ("D", c_int), ("ld_x", c_int), ("ld0", c_int), ("ld1", c_int),
+                ("update", c_int), ("normalize", c_int), ("range", c_float)]
+
+
+class Sample(C.Structure):
+    _fields_ = [("heads", c_void_p), ("log_std", c_void_p), ("noise", c_void_p), ("act_out", c_void_p),
+                ("val_out", c_void_p), ("logp_out", c_void_p), ("env_action", c_void_p), ("env_action_f", c_void_p),
+                ("bootv_prev", c_void_p), ("n", c_int), ("A", c_int), ("ld", c_int), ("gaussian", c_int),
+                ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
+
+
+class CartPole(C.Structure):
+    _fields_ = [("state", c_void_p), ("steps", c_void_p), ("episodes", c_void_p), ("action", c_void_p),
+                ("obs", c_void_p), ("next_obs", c_void_p), ("reward", c_void_p), ("terminated", c_void_p),
+                ("truncated", c_void_p), ("ep_score", c_void_p), ("stats", c_void_p), ("n", c_int),
+                ("max_steps", c_int), ("seed", C.c_uint64)]
+
+
+class PostStep(C.Structure):
+    _fields_ = [("reward", c_void_p), ("terminated", c_void_p), ("truncated", c_void_p), ("next_obs", c_void_p),
+                ("obs_mean", c_void_p), ("obs_var", c_void_p), ("next_obs_norm", c_void_p), ("rew_out", c_void_p),
+                ("term_out", c_void_p), ("seg_out", c_void_p), ("ret_track", c_void_p), ("ret_mean", c_void_p),
+                ("ret_var", c_void_p), ("ret_count", c_void_p), ("n", c_int), ("D", c_int), ("ld_next", c_int),
+                ("use_obsnorm", c_int), ("use_rewnorm", c_int), ("last_step", c_int), ("obs_range", c_float),
+                ("rew_range", c_float), ("gamma", c_float)]
+
+
+class EGreedy(C.Structure):
+    _fields_ = [("q", c_void_p), ("uniforms", c_void_p), ("randoms", c_void_p), ("eps_dev", c_void_p),
+                ("action", c_void_p), ("action_f", c_void_p), ("n", c_int), ("A", c_int), ("ld", c_int),
+                ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
+
+
 _SIGS = {
+    "xrl_obs_normalize": [C.POINTER(Rms), c_void_p],
+    "xrl_policy_sample": [C.POINTER(Sample), c_void_p],
+    "xrl_cartpole_step": [C.POINTER(CartPole), c_int, c_void_p],
+    "xrl_rollout_poststep": [C.POINTER(PostStep), c_void_p],
+    "xrl_egreedy": [C.POINTER(EGreedy), c_void_p],
+    "xrl_counter_add": [c_void_p, C.c_uint32, c_void_p],
     "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],
     "xrl_soa_store_step": [C.POINTER(Field), c_int, c_int, c_int, c_void_p],
     "xrl_gae_scan": [c_void_p] * 7 + [c_int, c_int, c_double, c_double, c_int, c_void_p],

@@ -1,0 +1,199 @@
+"""PPO-clip agent: rollout + update loop on the HIP engine.
+
+Mirrors xuance/torch/agents/policy_gradient/ppo_agent.py:12-181 with core/on_policy.py:23-300 (constructor
+signature ``(config, envs, callback)``, ``train(train_steps)``, ``_build_model/_build_memory/_build_learner``,
+``get_actions``, obs/reward normalisation, per-env path closing), restructured for the device:
+
+  * one vector step = 6 small launches (normalise+store, 3 grouped GEMMs, sample+store, env, bookkeeping);
+    the policy batch carries 2n rows -- the n current observations and the n (normalised) next observations of
+    the previous step -- so the bootstrap value V(next_obs) the reference obtains with extra forward passes
+    (ppo_agent.py:130,156) comes out of the same launch;
+  * a whole rollout (T steps) and a whole update phase (n_epochs x n_minibatch minibatches) are each captured
+    into one hipGraph and replayed;
+  * with more than one rank the envs are sharded and gradients are all-reduced (xuance_amd/dist.py).
+"""
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..learners.ppo_learner import PPO_Learner
+from ..memory import HipOnPolicyBuffer
+from ..nets import ActorCriticNet
+from ..spaces import is_discrete, space2shape
+
+
+def _get(cfg, name, default=None):
+    return getattr(cfg, name, default)
+
+
+class PPO_Agent:
+    def __init__(self, config: Namespace, envs, callback=None):
+        self.config, self.envs, self.callback = config, envs, callback
+        self.device = _get(config, "device", "cuda")
+        self.n_envs = envs.num_envs
+        self.observation_space, self.action_space = envs.observation_space, envs.action_space
+        self.gamma = config.gamma
+        self.gae_lam = _get(config, "gae_lambda", 0.95)
+        self.horizon_size, self.n_epochs, self.n_minibatch = config.horizon_size, config.n_epochs, config.n_minibatch
+        self.use_obsnorm, self.use_rewnorm = _get(config, "use_obsnorm", False), _get(config, "use_rewnorm", False)
+        self.obsnorm_range, self.rewnorm_range = _get(config, "obsnorm_range", 5.0), _get(config, "rewnorm_range", 5.0)
+        self.seed = int(_get(config, "seed", 1))
+        self.current_step = 0
+        self.use_graph = _get(config, "use_hip_graph", True)
+        dev, n = self.device, self.n_envs
+        self.obs_dim = int(np.prod(space2shape(self.observation_space)))
+        self.model = self._build_model()
+        self.memory = self._build_memory(self.auxiliary_info_shape)
+        self.learner = self._build_learner(self.config, self.model, self.callback)
+        # running statistics (statistic_tools.py:65-110: mean 0, var 1, count 1e-4)
+        D = self.obs_dim
+        self.obs_mean = torch.zeros(D, device=dev)
+        self.obs_var = torch.ones(D, device=dev)
+        self.obs_count = torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
+        self.ret_mean = torch.zeros(1, device=dev)
+        self.ret_var = torch.ones(1, device=dev)
+        self.ret_count = torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
+        self.returns = torch.zeros(n, device=dev)               # discounted return tracker (ppo_agent.py:144)
+        self.X = torch.zeros(2 * n, D, device=dev)              # policy input: [obs_t ; next_obs_{t-1}] (normalised)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)   # RNG counter base, advanced per rollout
+        self.model.plan.ensure(2 * n)
+        self.buffer_size = n * self.horizon_size
+        self.batch_size = self.buffer_size // self.n_minibatch
+        self.idx = torch.zeros(self.n_epochs * self.n_minibatch, self.batch_size, dtype=torch.int64, device=dev)
+        self._rollout_graph = None
+        self._update_graph = None
+        self._started = False
+
+    # -- builders (same hooks as the reference) -----------------------------------------------------------
+    @property
+    def auxiliary_info_shape(self):
+        return {"old_logp": ()}
+
+    def _build_model(self):
+        c = self.config
+        discrete = is_discrete(self.action_space)
+        rep = list(_get(c, "representation_hidden_size", []) or []) if _get(c, "representation", "Basic_MLP") != "Basic_Identical" else []
+        return ActorCriticNet(self.obs_dim, self.action_space.n if discrete else int(self.action_space.shape[0]),
+                              "categorical" if discrete else "gaussian", rep, list(c.actor_hidden_size),
+                              list(c.critic_hidden_size), _get(c, "activation", "leaky_relu"),
+                              None if discrete else _get(c, "activation_action", "tanh"), device=self.device)
+
+    def _build_memory(self, auxiliary_info_shape=None):
+        c = self.config
+        return HipOnPolicyBuffer(self.observation_space, self.action_space, auxiliary_info_shape, self.n_envs,
+                                 self.horizon_size, _get(c, "use_gae", True), _get(c, "use_advnorm", True), self.gamma,
+                                 self.gae_lam, device=self.device)
+
+    def _build_learner(self, *args):
+        return PPO_Learner(*args)
+
+    # -- one vector step on the device ------------------------------------------------------------------------
+    def _enqueue_step(self, t):
+        env, mem, n, D, A = self.envs, self.memory, self.n_envs, self.obs_dim, self.model.action_dim
+        f = mem.soa.fields
+        gaussian = self.model.dist == "gaussian"
+        # obs_rms.update(obs); obs = _process_observation(obs); memory.observations[t] = obs   (ppo_agent.py:114-115,128)
+        ops.obs_normalize(x=env.buf_obs, mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=self.X,
+                          out1=f["observations"][t], n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(self.use_obsnorm),
+                          normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
+        heads = self.model.forward(self.X, 2 * n)
+        # actions / log-probs / values of rows [0,n) -> buffer slot t; value of rows [n,2n) -> bootv[t-1]
+        ops.policy_sample(heads=heads, log_std=self.model.params.ptr("actor.log_std") if gaussian else None,
+                          act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
+                          env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
+                          bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A, ld=A + 1, gaussian=int(gaussian),
+                          seed=self.seed, step=t, step_dev=self.step_counter)
+        env.step_device()
+        ops.rollout_poststep(reward=env.reward, terminated=env.terminated, truncated=env.truncated, next_obs=env.next_obs,
+                             obs_mean=self.obs_mean, obs_var=self.obs_var, next_obs_norm=self.X[n:], rew_out=f["rewards"][t],
+                             term_out=f["terminals"][t], seg_out=f["seg"][t], ret_track=self.returns,
+                             ret_mean=self.ret_mean, ret_var=self.ret_var, ret_count=self.ret_count, n=n, D=D, ld_next=D,
+                             use_obsnorm=int(self.use_obsnorm), use_rewnorm=int(self.use_rewnorm),
+                             last_step=int(t == self.horizon_size - 1), obs_range=float(self.obsnorm_range),
+                             rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
+
+    def _enqueue_rollout(self):
+        T, n, A = self.horizon_size, self.n_envs, self.model.action_dim
+        for t in range(T):
+            self._enqueue_step(t)
+        # buffer full: vals = get_terminated_values(next_obs) for every env (ppo_agent.py:129-135)
+        heads = self.model.forward(self.X, 2 * n)
+        ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
+                          bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
+                          gaussian=0, seed=self.seed, step=0, step_dev=None)
+        ops.counter_add(self.step_counter, T)
+        f = self.memory.soa.fields
+        ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
+                     self.gamma, self.gae_lam, self.memory.use_gae)
+
+    def _enqueue_update(self):
+        """train_epochs (core/on_policy.py:182-205): n_epochs x n_minibatch minibatches taken from self.idx."""
+        mem, lr = self.memory, self.learner
+        nb, bs = self.idx.shape
+        f = mem.soa
+        lr.prepare_buffer_update(mem, bs)
+        if mem.use_advnorm:
+            ops.adv_stats(f.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs, self.horizon_size, lr.stats)
+        for k in range(nb):
+            lr.enqueue_minibatch_from_buffer(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None)
+
+    def _new_indices(self):
+        """np.random.shuffle of arange(buffer_size) per epoch (on_policy.py:194-204), generated on the device."""
+        N = self.buffer_size
+        perm = torch.rand(self.n_epochs, N, device=self.device).argsort(dim=1)
+        self.idx.copy_(perm[:, : self.n_minibatch * self.batch_size].reshape(self.idx.shape))
+
+    # -- public API -----------------------------------------------------------------------------------------------
+    def set_indices(self, idx):
+        """Parity hook: use the caller's minibatch indices (e.g. the ones NumPy produced for the reference)."""
+        self.idx.copy_(torch.as_tensor(np.asarray(idx)).reshape(self.idx.shape))
+        self._fixed_idx = True
+
+    def rollout(self):
+        if not self._started:
+            self.envs.reset()
+            self._started = True
+        if self.use_graph:
+            if self._rollout_graph is None:
+                torch.cuda.synchronize()
+                g = ops.Graph()
+                with g:
+                    self._enqueue_rollout()
+                self._rollout_graph = g
+            self._rollout_graph.launch()
+        else:
+            self._enqueue_rollout()
+        self.current_step += self.n_envs * self.horizon_size
+
+    def update(self):
+        if not getattr(self, "_fixed_idx", False):
+            self._new_indices()
+        if self.use_graph:
+            if self._update_graph is None:
+                self.learner.prepare_buffer_update(self.memory, self.batch_size)
+                torch.cuda.synchronize()
+                g = ops.Graph()
+                with g:
+                    self._enqueue_update()
+                self._update_graph = g
+            self._update_graph.launch()
+        else:
+            self._enqueue_update()
+        self.learner.iterations += self.idx.shape[0]
+        return self.learner.last_info(self.batch_size)
+
+    def train(self, train_steps):
+        """Runs ``train_steps`` vector steps (rounded up to whole rollouts of horizon_size steps)."""
+        info = {}
+        n_rollouts = (train_steps + self.horizon_size - 1) // self.horizon_size
+        for _ in range(n_rollouts):
+            self.rollout()
+            info = self.update()
+        eps, score, length = self.envs.episode_stats() if hasattr(self.envs, "episode_stats") else (0, 0.0, 0.0)
+        info.update({"episodes": eps, "mean_episode_score": score, "mean_episode_length": length})
+        return info
+
+    def finish(self):
+        self.envs.close()

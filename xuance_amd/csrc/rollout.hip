@@ -1,0 +1,378 @@
+// Rollout-side kernels: running observation statistics + normalisation, action sampling from the policy head,
+// device-resident CartPole-v1 physics, and the per-step bookkeeping of the on-policy agent loop.
+// Reference arithmetic: xuance/common/statistic_tools.py:117-185 (RunningMeanStd), xuance/torch/agents/base/agent.py:262-294
+// (_process_observation/_process_reward), core/on_policy.py:128-169 (get_actions), policy_gradient/ppo_agent.py:111-181
+// (train loop), core/off_policy.py:129-148 (epsilon-greedy).  CartPole equations: Barto, Sutton & Anderson (1983) as
+// published with Gymnasium's classic_control/cartpole.py (not part of the reference tree).
+// All of these are latency-bound at the reference's sizes (n_envs <= a few thousand): each is ONE small launch per
+// step with coalesced [env]-major accesses, meant to be replayed from a hipGraph.
+#include "common.h"
+
+namespace xrl {
+
+// ------------------------------------------------------------------------------------------------ Philox4x32-10
+// Counter-based RNG (Salmon et al., SC'11).  key = (seed_lo, seed_hi), counter = (env, step, stream, 0).
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ void philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t (&out)[4]) {
+    uint32_t c[4] = {c0, c1, c2, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) philox_round(c, k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }          // [0,1)
+__device__ __forceinline__ double u01d(uint32_t a, uint32_t b) {
+    return (double)((((uint64_t)a << 21) ^ (uint64_t)b) & ((1ull << 53) - 1)) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------------------------------------ running mean/std
+
+constexpr int RMS_THREADS = 1024;
+constexpr int RMS_MAXD = 64;
+
+__global__ void __launch_bounds__(RMS_THREADS) rms_normalize_kernel(xrl_rms_t p) {
+#pragma clang fp contract(off)
+    __shared__ double part[RMS_THREADS];
+    __shared__ double bmean[RMS_MAXD], bvar[RMS_MAXD];
+    __shared__ float s_mean[RMS_MAXD], s_std[RMS_MAXD];
+    const int D = p.D, n = p.n, tid = threadIdx.x;
+    if (p.update) {
+        // batch moments over the env axis (np.mean / np.std, axis=0) accumulated in float64
+        const int R = RMS_THREADS / D;                 // row-lanes per dimension
+        const int d = tid % D, r0 = tid / D;
+        const bool live = r0 < R;
+        double s = 0.0;
+        if (live) for (int r = r0; r < n; r += R) s += (double)p.x[(size_t)r * p.ld_x + d];
+        part[tid] = live ? s : 0.0;
+        __syncthreads();
+        if (tid < D) {
+            double t = 0.0;
+            for (int r = 0; r < R; ++r) t += part[r * D + tid];
+            bmean[tid] = (double)(float)(t / n);       // np.mean returns float32
+        }
+        __syncthreads();
+        double q = 0.0;
+        if (live) {
+            const double m = bmean[d];
+            for (int r = r0; r < n; r += R) { const double df = (double)p.x[(size_t)r * p.ld_x + d] - m; q += df * df; }
+        }
+        part[tid] = live ? q : 0.0;
+        __syncthreads();
+        if (tid < D) {
+            double t = 0.0;
+            for (int r = 0; r < R; ++r) t += part[r * D + tid];
+            const float bstd = (float)sqrt(t / n);     // np.std -> float32
+            bvar[tid] = (double)(bstd * bstd);         // batch_var = np.square(batch_std)
+        }
+        __syncthreads();
+        if (tid < D) {
+            // update_from_moments (statistic_tools.py:173-185), float32 arrays with Python-float count
+            const double cnt = *p.count, tot = cnt + (double)n;
+            const float mean = p.mean[tid], var = p.var[tid];
+            const float bm = (float)bmean[tid], bv = (float)bvar[tid];
+            const float delta = bm - mean;
+            const float new_mean = mean + delta * (float)n / (float)tot;
+            const float m_a = var * (float)cnt;
+            const float m_b = bv * (float)n;
+            const float M2 = m_a + m_b + (delta * delta) * (float)cnt * (float)n / (float)tot;
+            const float new_var = M2 / (float)tot;
+            p.mean[tid] = new_mean; p.var[tid] = new_var;
+            s_mean[tid] = new_mean; s_std[tid] = sqrtf(new_var);
+        }
+        __syncthreads();
+        if (tid == 0) *p.count = *p.count + (double)n;
+    } else {
+        if (tid < D) { s_mean[tid] = p.mean[tid]; s_std[tid] = sqrtf(p.var[tid]); }
+        __syncthreads();
+    }
+    const int total = n * D;
+    for (int i = tid; i < total; i += RMS_THREADS) {
+        const int r = i / D, d = i - r * D;
+        float v = p.x[(size_t)r * p.ld_x + d];
+        if (p.normalize) {
+            v = (v - s_mean[d]) / (s_std[d] + 1e-8f);
+            v = fminf(fmaxf(v, -p.range), p.range);
+        }
+        if (p.out0) p.out0[(size_t)r * p.ld0 + d] = v;
+        if (p.out1) p.out1[(size_t)r * p.ld1 + d] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ policy sampling
+
+__global__ void __launch_bounds__(256) policy_sample_kernel(xrl_sample_t p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.n) return;
+    const float* h = p.heads + (size_t)e * p.ld;
+    const int A = p.A;
+    if (p.bootv_prev) p.bootv_prev[e] = p.heads[(size_t)(p.n + e) * p.ld + A];
+    if (!p.act_out) return;                                // bootstrap-only launch (end of a rollout)
+    const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
+    float logp;
+    if (!p.gaussian) {
+        float u;
+        if (p.noise) u = p.noise[e];
+        else { uint32_t r[4]; philox4x32(p.seed, (uint32_t)e, step, 0x41435431u, r); u = u01(r[0]); }
+        float mx = h[0];
+        for (int j = 1; j < A; ++j) mx = fmaxf(mx, h[j]);
+        float se = 0.f;
+        for (int j = 0; j < A; ++j) se += expf(h[j] - mx);
+        const float lse = mx + logf(se);
+        // inverse CDF over softmax probabilities accumulated left to right in float32
+        int a = A - 1;
+        float c = 0.f;
+        for (int j = 0; j < A; ++j) {
+            c += expf(h[j] - lse);
+            if (c > u) { a = j; break; }
+        }
+        logp = h[a] - lse;                               // Categorical.log_prob (distributions.py:147-148)
+        p.act_out[e] = (float)a;
+        if (p.env_action) p.env_action[e] = a;
+    } else {
+        logp = 0.f;
+        for (int j = 0; j < A; ++j) {
+            float z;
+            if (p.noise) z = p.noise[(size_t)e * A + j];
+            else {
+                uint32_t r[4];
+                philox4x32(p.seed, (uint32_t)e, step, 0x47415500u + (uint32_t)j, r);
+                const float u1 = fmaxf(u01(r[0]), 5.96e-8f), u2 = u01(r[1]);
+                z = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+            }
+            const float ls = p.log_std[j], sd = expf(ls);
+            const float x = h[j] + sd * z;                // Normal(mu, std).sample()
+            const float df = x - h[j];
+            logp += -(df * df) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+            p.act_out[(size_t)e * A + j] = x;
+            if (p.env_action_f) p.env_action_f[(size_t)e * A + j] = x;
+        }
+    }
+    p.val_out[e] = h[A];
+    p.logp_out[e] = logp;
+}
+
+// ------------------------------------------------------------------------------------------------ CartPole-v1
+
+__device__ __forceinline__ void cartpole_reset(double* s, uint64_t seed, int e, uint32_t episode) {
+    uint32_t r[4], q[4];
+    philox4x32(seed, (uint32_t)e, episode, 0x52455345u, r);
+    philox4x32(seed, (uint32_t)e, episode, 0x52455346u, q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = -0.05 + 0.1 * u01d(r[j], q[j]);   // uniform(-0.05, 0.05)
+}
+
+__global__ void __launch_bounds__(256) cartpole_step_kernel(xrl_cartpole_t p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.n) return;
+    const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
+    const double total_mass = masspole + masscart, polemass_length = masspole * length;
+    const double theta_thr = 12.0 * 2.0 * 3.14159265358979323846 / 360.0, x_thr = 2.4;
+    double* s = p.state + (size_t)e * 4;
+    double x = s[0], xd = s[1], th = s[2], thd = s[3];
+    const double force = p.action[e] == 1 ? force_mag : -force_mag;
+    const double ct = cos(th), st = sin(th);
+    const double temp = (force + polemass_length * thd * thd * st) / total_mass;
+    const double thacc = (gravity * st - ct * temp) / (length * (4.0 / 3.0 - masspole * ct * ct / total_mass));
+    const double xacc = temp - polemass_length * thacc * ct / total_mass;
+    x = x + tau * xd; xd = xd + tau * xacc; th = th + tau * thd; thd = thd + tau * thacc;   // explicit Euler
+    const int steps = p.steps[e] + 1;
+    const bool term = (x < -x_thr) || (x > x_thr) || (th < -theta_thr) || (th > theta_thr);
+    const bool trunc = steps >= p.max_steps;
+    float* no = p.next_obs + (size_t)e * 4;
+    no[0] = (float)x; no[1] = (float)xd; no[2] = (float)th; no[3] = (float)thd;
+    p.reward[e] = 1.0f;
+    p.terminated[e] = term ? 1.f : 0.f;
+    p.truncated[e] = trunc ? 1.f : 0.f;
+    const float score = p.ep_score[e] + 1.0f;
+    float* o = p.obs + (size_t)e * 4;
+    if (term || trunc) {
+        const int ep = p.episodes[e] + 1;
+        p.episodes[e] = ep;
+        cartpole_reset(s, p.seed, e, (uint32_t)ep);
+        p.steps[e] = 0;
+        p.ep_score[e] = 0.f;
+        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];   // info["reset_obs"]
+        atomicAdd(&p.stats[0], 1.0); atomicAdd(&p.stats[1], (double)score); atomicAdd(&p.stats[2], (double)steps);
+    } else {
+        s[0] = x; s[1] = xd; s[2] = th; s[3] = thd;
+        p.steps[e] = steps;
+        p.ep_score[e] = score;
+        o[0] = no[0]; o[1] = no[1]; o[2] = no[2]; o[3] = no[3];
+    }
+}
+
+__global__ void __launch_bounds__(256) cartpole_reset_kernel(xrl_cartpole_t p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.n) return;
+    double* s = p.state + (size_t)e * 4;
+    cartpole_reset(s, p.seed, e, 0u);
+    p.steps[e] = 0; p.episodes[e] = 0; p.ep_score[e] = 0.f;
+    float* o = p.obs + (size_t)e * 4;
+    o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+}
+
+// ------------------------------------------------------------------------------------------------ post-step bookkeeping
+
+constexpr int POST_THREADS = 1024;
+
+__global__ void __launch_bounds__(POST_THREADS) poststep_kernel(xrl_poststep_t p) {
+#pragma clang fp contract(off)
+    __shared__ unsigned long long ended_mask[64];     // up to 4096 envs per pass
+    const int tid = threadIdx.x, n = p.n;
+    // reward normalisation uses the return statistics BEFORE this step's episode-end updates (ppo_agent.py:128)
+    float rstd = sqrtf(*p.ret_var);
+    rstd = fminf(fmaxf(rstd, 0.1f), 100.f);
+    for (int e = tid; e < n; e += POST_THREADS) {
+        const float r = p.reward[e];
+        float rn = r;
+        if (p.use_rewnorm) rn = fminf(fmaxf(r / rstd, -p.rew_range), p.rew_range);
+        p.rew_out[e] = rn;
+        const bool term = p.terminated[e] != 0.f, trunc = p.truncated[e] != 0.f;
+        p.term_out[e] = term ? 1.f : 0.f;
+        uint8_t sg = 0;
+        if (term || trunc || p.last_step) sg = 1 | (term ? 2 : 0);   // finish_path(0.0, i) is the float64-carry form
+        p.seg_out[e] = sg;
+        p.ret_track[e] = p.gamma * p.ret_track[e] + r;              // self.returns = gamma * self.returns + rewards
+    }
+    // normalised next observation with the current observation statistics (get_terminated_values, on_policy.py:109)
+    const int total = n * p.D;
+    for (int i = tid; i < total; i += POST_THREADS) {
+        const int e = i / p.D, d = i - e * p.D;
+        float v = p.next_obs[(size_t)e * p.D + d];
+        if (p.use_obsnorm) {
+            v = (v - p.obs_mean[d]) / (sqrtf(p.obs_var[d]) + 1e-8f);
+            v = fminf(fmaxf(v, -p.obs_range), p.obs_range);
+        }
+        p.next_obs_norm[(size_t)e * p.ld_next + d] = v;
+    }
+    __syncthreads();
+    // ret_rms.update(self.returns[i:i+1]) for every finished env IN ENV ORDER (ppo_agent.py:146-149): sequential
+    // single-sample merges, then self.returns[i] = 0.
+    for (int base = 0; base < n; base += 4096) {
+        const int cnt = min(4096, n - base);
+        for (int w = tid >> 6; w * 64 < cnt; w += POST_THREADS / 64) {
+            const int e = base + w * 64 + (tid & 63);
+            const bool ended = (e < n) && (p.terminated[e] != 0.f || p.truncated[e] != 0.f);
+            const unsigned long long m = __ballot(ended);
+            if ((tid & 63) == 0) ended_mask[w] = m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float mean = *p.ret_mean, var = *p.ret_var;
+            double count = *p.ret_count;
+            for (int w = 0; w * 64 < cnt; ++w) {
+                unsigned long long m = ended_mask[w];
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int e = base + w * 64 + b;
+                    const float bm = p.ret_track[e];                 // batch_mean of one sample; batch_var = 0, count 1
+                    const double tot = count + 1.0;
+                    const float delta = bm - mean;
+                    const float new_mean = mean + delta * 1.0f / (float)tot;
+                    const float m_a = var * (float)count;
+                    const float m_b = 0.f * 1.0f;
+                    const float M2 = m_a + m_b + (delta * delta) * (float)count * 1.0f / (float)tot;
+                    mean = new_mean; var = M2 / (float)tot; count = tot;
+                    p.ret_track[e] = 0.f;
+                }
+            }
+            *p.ret_mean = mean; *p.ret_var = var; *p.ret_count = count;
+        }
+        __syncthreads();
+    }
+}
+
+// epsilon-greedy selection (off_policy.py:138-141): where(rand < eps, randint, greedy)
+
+__global__ void __launch_bounds__(256) egreedy_kernel(xrl_egreedy_t p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.n) return;
+    const float* q = p.q + (size_t)e * p.ld;
+    int best = 0;
+    float bv = q[0];
+    for (int j = 1; j < p.A; ++j) if (q[j] > bv) { bv = q[j]; best = j; }     // argmax: first maximal index
+    const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
+    uint32_t r[4];
+    philox4x32(p.seed, (uint32_t)e, step, 0x45475200u, r);
+    const float u = p.uniforms ? p.uniforms[e] : u01(r[0]);
+    const int ra = p.randoms ? p.randoms[e] : (int)(r[1] % (uint32_t)p.A);
+    const int a = (u < *p.eps_dev) ? ra : best;
+    p.action[e] = a;
+    if (p.action_f) p.action_f[e] = (float)a;
+}
+
+__global__ void counter_add_kernel(uint32_t* c, uint32_t inc) { *c += inc; }
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_obs_normalize(const xrl_rms_t* params, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_rms_t& p = *params;
+    XRL_CHECK_ARG(p.x && p.mean && p.var && p.count && p.n > 0 && p.D > 0 && p.D <= RMS_MAXD);
+    hipLaunchKernelGGL(rms_normalize_kernel, dim3(1), dim3(RMS_THREADS), 0, as_stream(stream), p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_policy_sample(const xrl_sample_t* params, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_sample_t& p = *params;
+    XRL_CHECK_ARG(p.heads && p.n > 0 && p.A > 0 && p.ld > p.A);
+    XRL_CHECK_ARG((p.act_out && p.val_out && p.logp_out) || (!p.act_out && p.bootv_prev));
+    XRL_CHECK_ARG(!p.gaussian || p.log_std);
+    hipLaunchKernelGGL(policy_sample_kernel, dim3((p.n + 255) / 256), dim3(256), 0, as_stream(stream), p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_cartpole_step(const xrl_cartpole_t* params, int reset, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_cartpole_t& p = *params;
+    XRL_CHECK_ARG(p.state && p.steps && p.episodes && p.obs && p.ep_score && p.n > 0);
+    if (reset) {
+        hipLaunchKernelGGL(cartpole_reset_kernel, dim3((p.n + 255) / 256), dim3(256), 0, as_stream(stream), p);
+    } else {
+        XRL_CHECK_ARG(p.action && p.next_obs && p.reward && p.terminated && p.truncated && p.stats);
+        hipLaunchKernelGGL(cartpole_step_kernel, dim3((p.n + 255) / 256), dim3(256), 0, as_stream(stream), p);
+    }
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_rollout_poststep(const xrl_poststep_t* params, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_poststep_t& p = *params;
+    XRL_CHECK_ARG(p.reward && p.terminated && p.truncated && p.next_obs && p.next_obs_norm && p.rew_out && p.term_out &&
+                  p.seg_out && p.ret_track && p.ret_mean && p.ret_var && p.ret_count && p.n > 0 && p.D > 0);
+    XRL_CHECK_ARG(!p.use_obsnorm || (p.obs_mean && p.obs_var));
+    hipLaunchKernelGGL(poststep_kernel, dim3(1), dim3(POST_THREADS), 0, as_stream(stream), p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_egreedy(const xrl_egreedy_t* params, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_egreedy_t& p = *params;
+    XRL_CHECK_ARG(p.q && p.eps_dev && p.action && p.n > 0 && p.A > 0 && p.ld >= p.A);
+    hipLaunchKernelGGL(egreedy_kernel, dim3((p.n + 255) / 256), dim3(256), 0, as_stream(stream), p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_counter_add(uint32_t* counter, uint32_t inc, xrl_stream_t stream) {
+    XRL_CHECK_ARG(counter != nullptr);
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, as_stream(stream), counter, inc);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

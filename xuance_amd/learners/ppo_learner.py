@@ -83,6 +83,38 @@ class PPO_Learner(Learner):
                 self._key("entropy"): float(s[2] / M), self._key("learning_rate"): st.last_lr,
                 self._key("predict_value"): float(s[3] / M), self._key("clip_ratio"): float(s[4] / M)}
 
+    # ------------------------------------------------------------------ fused path: minibatches straight from HBM
+    def prepare_buffer_update(self, memory, bs):
+        """Allocate the minibatch staging tensors once (nothing may be allocated while a hipGraph is captured)."""
+        if getattr(self, "_stage_bs", 0) == bs:
+            return
+        dev = self.model.params.device
+        self._ensure(bs)
+        f = memory.soa
+        self._stage = {"observations": torch.zeros((bs,) + tuple(memory.obs_shape), device=dev),
+                       "actions": torch.zeros((bs,) + tuple(memory.act_shape), device=dev),
+                       "returns": torch.zeros(bs, device=dev), "advantages": torch.zeros(bs, device=dev),
+                       "aux_old_logp": torch.zeros(bs, device=dev)}
+        self.stats = torch.zeros(4096, 2, device=dev)
+        self._stage_bs = bs
+        self._last_S = pick_n_split(bs)
+
+    def enqueue_minibatch_from_buffer(self, memory, idx, stats=None):
+        """memory.sample(idx) + update(**samples) without materialising Python objects: one gather launch
+        (advantages normalised on the fly, memory_tools.py:281-282) followed by the update launches."""
+        st, f = self._stage, memory.soa
+        names = list(st)
+        flags = [1 if (n == "advantages" and stats is not None) else 0 for n in names]
+        ops.soa_gather([(st[n], f.fields[n], f.row_bytes[n]) for n in names], idx, memory.n_envs, memory.n_size,
+                       stats=stats, flags=flags)
+        M = idx.numel()
+        obs = st["observations"].view(M, -1)
+        self._last_S = self._step(obs, obs.shape[1], st["actions"], st["returns"], st["advantages"], st["aux_old_logp"], M)
+
+    def last_info(self, M):
+        """Info dict of the most recent minibatch (what train_epochs returns, on_policy.py:205)."""
+        return self._info(M, self._last_S)
+
     # ------------------------------------------------------------------ reference API (ppo_learner.py:35-95)
     def update(self, **samples):
         self.iterations += 1

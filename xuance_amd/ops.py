@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT, Field, Gemm, PpoLoss, AdamState, call, ptr, stream_ptr
+from ._lib import ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, call, ptr, stream_ptr
 
 
 def _chk(t, dtype=torch.float32):
@@ -125,6 +125,40 @@ def grad_reduce(slabs, n_split, slab_stride, P, grad, sumsq_part):
 def adam_step(params, grad, m, v, P, state, sumsq_part, max_norm):
     call("xrl_adam_step", ptr(params), ptr(grad), ptr(m), ptr(v), int(P), ptr(state), ptr(sumsq_part),
          sumsq_part.numel(), float(max_norm if max_norm else 0.0), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------ rollout side
+def _struct(cls, kw):
+    p = cls()
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(p, k, v)
+    return p
+
+
+def obs_normalize(**kw):
+    call("xrl_obs_normalize", C.byref(_struct(Rms, kw)), stream_ptr())
+
+
+def policy_sample(**kw):
+    call("xrl_policy_sample", C.byref(_struct(Sample, kw)), stream_ptr())
+
+
+def cartpole_step(reset=False, **kw):
+    call("xrl_cartpole_step", C.byref(_struct(CartPole, kw)), int(bool(reset)), stream_ptr())
+
+
+def rollout_poststep(**kw):
+    call("xrl_rollout_poststep", C.byref(_struct(PostStep, kw)), stream_ptr())
+
+
+def egreedy(**kw):
+    call("xrl_egreedy", C.byref(_struct(EGreedy, kw)), stream_ptr())
+
+
+def counter_add(counter, inc):
+    call("xrl_counter_add", ptr(counter), int(inc), stream_ptr())
 
 
 # ------------------------------------------------------------------------------------------ graphs
