@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: env-steps/sec of PPO-Clip rollout+update on CartPole-v1 (BASELINE.json configs[1]:
+256 parallel envs per GPU, horizon 256, 8 epochs x 8 minibatches of 8192, net 4->128->{128->2,128->1}).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch = one rollout of horizon_size vector steps on n_envs envs
+(policy inference, device CartPole physics, SoA store, obs/reward normalisation, GAE) followed by the full update
+phase (n_epochs x n_minibatch minibatch updates: gather, fp32-MFMA forward/backward, PPO loss, clip, Adam).
+Nothing is skipped inside the timed region.  Weak scaling: every rank owns n_envs envs and its own buffer,
+gradients are averaged with one flat RCCL all-reduce per optimiser step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_config(n_envs, horizon, world, rank):
+    return Namespace(agent="PPO", env_id="CartPole-v1", representation="Basic_MLP", representation_hidden_size=[128],
+                     actor_hidden_size=[128], critic_hidden_size=[128], activation="leaky_relu", seed=1 + rank,
+                     parallels=n_envs, running_steps=10 ** 9, horizon_size=horizon, n_epochs=8, n_minibatch=8,
+                     learning_rate=4e-4, vf_coef=0.25, ent_coef=0.01, clip_range=0.2, gamma=0.98, use_gae=True,
+                     gae_lambda=0.95, use_advnorm=True, use_grad_clip=True, grad_clip_norm=0.5, use_obsnorm=True,
+                     use_rewnorm=True, obsnorm_range=5, rewnorm_range=5, distributed_training=world > 1, device="cuda",
+                     model_dir="/tmp/xrl_bench_models", use_hip_graph=True)
+
+
+def dominant_kernel_roofline(agent, iters=200):
+    """Roofline of the kernel that dominates the timed region (see profiles/): the fp32-MFMA GEMM of the
+    128x128 hidden layers on an 8192-sample minibatch.  Timed live with HIP events on the launch stream over
+    `iters` back-to-back launches of exactly the minibatch forward launch the update phase issues."""
+    from xuance_amd import ops
+    net, lr = agent.model, agent.learner
+    M = agent.batch_size
+    lr.prepare_buffer_update(agent.memory, M)
+    x = lr._stage["observations"].view(M, -1)
+    stage = net.plan.stages[1]                         # stacked [actor.0 ; critic.0]: [M,128] x [256,128]^T
+    L = stage[0]
+    P = net.params
+    a = net.plan.acts[L.in_level].data_ptr()
+    c = net.plan.acts[L.out_level].data_ptr()
+    desc = [ops.gemm_desc(a, P.ptr(L.w_name), c, M, L.N, L.K, net.plan.widths[L.in_level], L.K,
+                          net.plan.widths[L.out_level], bias=P.ptr(L.b_name), act=L.act)]
+    for _ in range(10):
+        ops.linear_fwd(desc)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.linear_fwd(desc)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    flops = 2.0 * M * L.N * L.K                       # algorithmic flops of one launch
+    achieved = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "gemm_f32_kernel<NT> (linear_fwd %dx%dx%d)" % (M, L.N, L.K),
+            "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(sec * 1e6, 3), "algorithmic_flops_per_launch": flops}
+
+
+def cpu_baseline(n_envs, horizon, budget_s=20.0):
+    """The oracle's CPU port of the same loop (oracle/cpu_agent.py), timed on this host."""
+    from oracle import cpu_agent
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    r = cpu_agent.run_ppo_cartpole(n_envs=n_envs, horizon=horizon, n_rollouts=6, time_budget_s=budget_s)
+    return {"value": round(r["env_steps"] / r["seconds"], 1), "unit": "env-steps/s", "cores": int(threads),
+            "kind": "port",
+            "sample": "%d rollout(s) of %d envs x %d steps incl. 64 minibatch updates each, oracle/cpu_agent.py "
+                      "(NumPy, %d BLAS threads, %.1f s)" % (r["rollouts"], n_envs, horizon, threads, r["seconds"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-envs", type=int, default=256, help="envs PER GPU")
+    ap.add_argument("--horizon", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        from xuance_amd.dist import init_distributed_mode
+        init_distributed_mode("nccl")
+    import torch.distributed as dist
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+
+    torch.manual_seed(1)                               # same initial parameters on every rank (DDP broadcasts rank 0's)
+    cfg = make_config(args.n_envs, args.horizon, world, rank)
+    env = DeviceCartPoleVecEnv(args.n_envs, seed=1 + rank)
+    agent = PPO_Agent(cfg, env)
+    if world > 1:
+        from xuance_amd.dist import broadcast_
+        broadcast_(agent.model.params.flat, 0)
+
+    def step():
+        agent.rollout()
+        return agent.update()
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    info = {}
+    for _ in range(args.steps):
+        info = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    env_steps = world * args.n_envs * args.horizon * args.steps
+    out = {"metric": "env-steps/sec (rollout+update), PPO-Clip CartPole-v1", "value": round(env_steps / elapsed, 1),
+           "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "PPO-Clip CartPole-v1, %d envs/GPU x horizon %d, 8 epochs x 8 minibatches of %d, "
+                                  "net 4-128-{128-2,128-1} (BASELINE.json configs[1])"
+                                  % (args.n_envs, args.horizon, args.n_envs * args.horizon // 8),
+                      "env": "device-resident CartPole-v1 (xrl_cartpole_step)", "parallelism": "dp%d" % world,
+                      "env_steps_per_step": world * args.n_envs * args.horizon,
+                      "last_info": {k: round(float(v), 6) for k, v in info.items()}}}
+    if rank == 0:
+        if not args.no_roofline:
+            out["roofline"] = dominant_kernel_roofline(agent)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.n_envs, args.horizon)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

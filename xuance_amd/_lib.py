@@ -113,6 +113,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm must load ITS libamdhip64 first: libxrl_hip.so then binds to the same HIP runtime instance
+    # (device memory, streams and kernels have to live in one runtime).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise XrlError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). xuance_amd has no CPU fallback.")

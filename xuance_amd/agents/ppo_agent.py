@@ -167,10 +167,39 @@ class PPO_Agent:
             self._enqueue_rollout()
         self.current_step += self.n_envs * self.horizon_size
 
+    def _update_distributed(self):
+        """N > 1 ranks: the per-minibatch launch sequence is captured in two graphs split at the gradient
+        all-reduce (RCCL runs on its own stream, outside the capture)."""
+        mem, lr = self.memory, self.learner
+        nb, bs = self.idx.shape
+        lr.prepare_buffer_update(mem, bs)
+        if getattr(self, "_mb_graphs", None) is None:
+            torch.cuda.synchronize()
+            self._mb_graphs = []
+            for k in range(nb):
+                g = ops.Graph()
+                with g:
+                    if k == 0 and mem.use_advnorm:
+                        ops.adv_stats(mem.soa.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs,
+                                      self.horizon_size, lr.stats)
+                    lr.enqueue_minibatch_from_buffer(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None,
+                                                     finish=False)
+                self._mb_graphs.append(g)
+            g = ops.Graph()
+            with g:
+                lr.finish_step()
+            self._finish_graph = g
+        for k in range(nb):
+            self._mb_graphs[k].launch()
+            lr.allreduce_grad()
+            self._finish_graph.launch()
+
     def update(self):
         if not getattr(self, "_fixed_idx", False):
             self._new_indices()
-        if self.use_graph:
+        if self.learner.distributed_training and self.learner.world_size > 1:
+            self._update_distributed()
+        elif self.use_graph:
             if self._update_graph is None:
                 self.learner.prepare_buffer_update(self.memory, self.batch_size)
                 torch.cuda.synchronize()

@@ -47,8 +47,10 @@ class PPO_Learner(Learner):
         return torch.as_tensor(x, device=self.model.params.device).to(dtype).contiguous()
 
     # ------------------------------------------------------------------ one minibatch, tensors already on device
-    def _step(self, obs, ldx, act, ret, adv, old_logp, M, stats=None):
-        """Enqueue forward, loss, backward, clip and Adam for one minibatch (no host sync; graph-capturable)."""
+    def _step(self, obs, ldx, act, ret, adv, old_logp, M, stats=None, finish=True):
+        """Enqueue forward, loss, backward, clip and Adam for one minibatch (no host sync; graph-capturable).
+        With finish=False the launches stop after the local gradient reduction (multi-GPU: the caller all-reduces
+        the flat gradient, then calls finish_step)."""
         model, opt = self.model, self.optimizer
         S = pick_n_split(M)
         heads = model.forward(obs, M, ldx)
@@ -67,13 +69,24 @@ class PPO_Learner(Learner):
         ops.ppo_loss(model.dist, **kw)
         model.backward(obs, M, self.slabs, S, ldx)
         ops.grad_reduce(self.slabs, S, model.params.P, model.params.P, opt.grad, self.sumsq)
-        if self.distributed_training and self.world_size > 1:
-            from ..dist import allreduce_mean_
-            allreduce_mean_(opt.grad)                               # one flat RCCL all-reduce per optimiser step
-            ops.grad_reduce(opt.grad, 1, model.params.P, model.params.P, opt.grad, self.sumsq)
+        if finish:
+            if self.distributed_training and self.world_size > 1:
+                self.allreduce_grad()
+            self.finish_step()
+        return S
+
+    def allreduce_grad(self):
+        """DDP-equivalent gradient averaging as ONE flat RCCL all-reduce, then the norm of the averaged gradient."""
+        from ..dist import allreduce_mean_
+        opt, P = self.optimizer, self.model.params.P
+        allreduce_mean_(opt.grad)
+        ops.grad_reduce(opt.grad, 1, P, P, opt.grad, self.sumsq)
+
+    def finish_step(self):
+        """clip_grad_norm_ + Adam.step + LinearLR.step (ppo_learner.py:63-67)."""
+        model, opt = self.model, self.optimizer
         ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq,
                       self.grad_clip_norm if self.use_grad_clip else 0.0)
-        return S
 
     def _info(self, M, S):
         ops.sum_partials(self.partials, S, 8, self.sums)
@@ -99,7 +112,7 @@ class PPO_Learner(Learner):
         self._stage_bs = bs
         self._last_S = pick_n_split(bs)
 
-    def enqueue_minibatch_from_buffer(self, memory, idx, stats=None):
+    def enqueue_minibatch_from_buffer(self, memory, idx, stats=None, finish=True):
         """memory.sample(idx) + update(**samples) without materialising Python objects: one gather launch
         (advantages normalised on the fly, memory_tools.py:281-282) followed by the update launches."""
         st, f = self._stage, memory.soa
@@ -109,7 +122,8 @@ class PPO_Learner(Learner):
                        stats=stats, flags=flags)
         M = idx.numel()
         obs = st["observations"].view(M, -1)
-        self._last_S = self._step(obs, obs.shape[1], st["actions"], st["returns"], st["advantages"], st["aux_old_logp"], M)
+        self._last_S = self._step(obs, obs.shape[1], st["actions"], st["returns"], st["advantages"], st["aux_old_logp"], M,
+                                  finish=finish)
 
     def last_info(self, M):
         """Info dict of the most recent minibatch (what train_epochs returns, on_policy.py:205)."""
