@@ -1,0 +1,168 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header declares, ctypes
+structs match the C layout, the parameter layout / state_dict order of the nets, buffer path bookkeeping, the
+plain-C GAE restatement, and the multi-rank plumbing over gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, sub
+
+
+def test_library_exports_every_declared_symbol():
+    from xuance_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "xrl_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(xrl_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 20
+    lib = _lib.load()                         # dlopen works without a GPU; no compute call is made here
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/xrl_hip.h but not exported"
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    assert b"gfx950" in lib.xrl_version()
+
+
+def test_ctypes_structs_match_c_layout():
+    from xuance_amd import _lib
+    pairs = {"xrl_field_t": _lib.Field, "xrl_gemm_t": _lib.Gemm, "xrl_ppo_loss_t": _lib.PpoLoss,
+             "xrl_adam_state_t": _lib.AdamState, "xrl_rms_t": _lib.Rms, "xrl_sample_t": _lib.Sample,
+             "xrl_cartpole_t": _lib.CartPole, "xrl_poststep_t": _lib.PostStep, "xrl_egreedy_t": _lib.EGreedy}
+    for extra in ("xrl_dqn_td_t", "xrl_qmix_t"):
+        cls = getattr(_lib, {"xrl_dqn_td_t": "DqnTd", "xrl_qmix_t": "Qmix"}[extra], None)
+        if cls is not None:
+            pairs[extra] = cls
+    src = '#include "xrl_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){\n'
+    for cname in pairs:
+        src += f'printf("{cname} %zu\\n", sizeof({cname}));\n'
+    src += 'printf("adam.base_lr %zu\\n", offsetof(xrl_adam_state_t, base_lr));\n'
+    src += 'printf("loss.M %zu\\n", offsetof(xrl_ppo_loss_t, M));\nreturn 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "sz.c"), os.path.join(d, "sz")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = dict(line.split() for line in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), cname
+    assert int(out["adam.base_lr"]) == _lib.AdamState.base_lr.offset
+    assert int(out["loss.M"]) == _lib.PpoLoss.M.offset
+
+
+@pytest.mark.parametrize("dist,args", [("categorical", (4, 2, "categorical", (128,), (128,), (128,), "leaky_relu")),
+                                       ("gaussian", (17, 6, "gaussian", (), (64, 64), (64, 64), "relu", "tanh"))])
+def test_net_layout_and_state_dict_order(dist, args):
+    from xuance_amd.nets import ActorCriticNet
+    g = load_golden(f"ppo_{dist}")
+    net = ActorCriticNet(*args, device="cpu")
+    assert list(net.ref_order) == [str(n) for n in g["param_names"]]       # the reference's state_dict order
+    init = sub(g, "init")
+    net.load_state_dict(init)
+    sd = net.state_dict()
+    for k, v in init.items():
+        assert sd[k].shape == v.shape and np.array_equal(sd[k].numpy(), v)
+    P = net.params
+    for name in P.names:
+        assert P.offsets[name] % 4 == 0                                     # 16-byte aligned tensors
+    a0 = "actor.logits.0" if dist == "categorical" else "actor.mu.0"
+    wa, wc = P.offsets[a0 + ".weight"], P.offsets["critic.values.0.weight"]
+    n_a = int(np.prod(P.shapes[a0 + ".weight"]))
+    assert wc == wa + n_a                                                   # stacked [Wa;Wc] is contiguous
+    assert P.offsets["critic.values.0.bias"] == P.offsets[a0 + ".bias"] + P.shapes[a0 + ".bias"][0]
+    n_params = sum(int(np.prod(v.shape)) for v in init.values())
+    assert n_params == (34051 if dist == "categorical" else n_params) and P.P >= n_params
+
+
+def test_orthogonal_init_follows_reference_order():
+    from xuance_amd.nets import ActorCriticNet
+    torch.manual_seed(7)
+    net = ActorCriticNet(4, 2, "categorical", (128,), (128,), (128,), "leaky_relu", device="cpu")
+    torch.manual_seed(7)
+    ws = [torch.nn.init.orthogonal_(torch.empty(s)) for s in [(128, 4), (128, 128), (2, 128), (128, 128), (1, 128)]]
+    sd = net.state_dict()
+    for k, w in zip([k for k in net.ref_order if k.endswith("weight")], ws):
+        assert torch.equal(sd[k], w), k
+    assert all(float(sd[k].abs().sum()) == 0 for k in net.ref_order if k.endswith("bias"))
+
+
+def test_buffer_path_bookkeeping_on_host():
+    """finish_path only records (bootv, seg); check the records against the call pattern incl. the corner cases."""
+    from xuance_amd.memory import HipOnPolicyBuffer
+    from xuance_amd.spaces import Box, Discrete
+    buf = HipOnPolicyBuffer(Box(-1, 1, (3,)), Discrete(2), {"old_logp": ()}, 4, 6, device="cpu")
+    buf.ptr, buf.size = 3, 3
+    buf.finish_path(0.0, 0)                       # Python float -> float64-carry flag
+    buf.finish_path(np.float32(1.5), 1)           # float32 bootstrap
+    buf.finish_path(torch.tensor(2.5), 2)
+    assert buf._seg_h[2].tolist() == [3, 1, 1, 0] and buf._bootv_h[2].tolist() == [0.0, 1.5, 2.5, 0.0]
+    assert buf.start_ids.tolist() == [3, 3, 3, 0]
+    buf.finish_path(9.0, 0)                       # empty slice [3,3): no-op
+    assert buf._seg_h.sum() == 5
+    buf.ptr, buf.size = 0, 6                      # buffer full, ptr wrapped
+    for i in range(4):
+        buf.finish_path(np.float32(0.25), i)
+    assert buf._seg_h[5].tolist() == [1, 1, 1, 1] and buf.start_ids.tolist() == [0, 0, 0, 0]
+    buf.finish_path(0.0, 3)                       # second call over the whole row: ONE path [0,6) (reference quirk)
+    assert buf._seg_h[:, 3].tolist() == [0, 0, 0, 0, 0, 3]
+    buf.finish_path(0.0, 0)
+    assert buf._seg_h[:, 0].tolist() == [0, 0, 0, 0, 0, 3]     # earlier boundary at t=2 dropped, like the reference
+    with pytest.raises(AssertionError):
+        HipOnPolicyBuffer(Box(-1, 1, (3,)), Discrete(2), None, 4, 6, device="cpu").sample(np.arange(4))
+
+
+def test_c_restatement_matches_numpy_oracle(oracle):
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libgae_ref.so"))
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.gae_finish_path_ref.argtypes = [fp, fp, fp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                        ctypes.c_double, fp, fp]
+    rng = np.random.default_rng(0)
+    for L in (1, 2, 17, 256):
+        for pyfloat in (0, 1):
+            r, v = rng.standard_normal(L).astype(np.float32), rng.standard_normal(L).astype(np.float32)
+            d = (rng.random(L) < 0.1).astype(np.float32)
+            val = 0.0 if pyfloat else np.float32(rng.standard_normal())
+            ret, adv = np.zeros(L, np.float32), np.zeros(L, np.float32)
+            lib.gae_finish_path_ref(r.ctypes.data_as(fp), v.ctypes.data_as(fp), d.ctypes.data_as(fp), L, float(val),
+                                    pyfloat, 0.98, 0.95, ret.ctypes.data_as(fp), adv.ctypes.data_as(fp))
+            eret, eadv = oracle.gae_finish_path(r, v, d, val, 0.98, 0.95)
+            assert np.array_equal(adv, eadv) and np.array_equal(ret, eret)
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from xuance_amd import dist as xd
+    import torch.distributed as dist
+    r, w, _ = xd.init_distributed_mode("gloo")
+    g = torch.full((1000,), float(r + 1))
+    xd.allreduce_mean_(g)                                        # DDP-style gradient mean as one flat message
+    p = torch.arange(10, dtype=torch.float32) * (r + 1)
+    xd.broadcast_(p, 0)                                           # rank 0's parameters everywhere
+    lo, hi = xd.shard_range(512)
+    t = torch.tensor([0.5 + r], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # bench.py's max-over-ranks timing
+    q.put((r, w, float(g[0]), p.tolist(), (lo, hi), float(t)))
+    xd.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_rank_plumbing_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r, w, gmean, params, shard, tmax in res:
+        assert w == 2 and gmean == 1.5 and params == list(map(float, range(10))) and tmax == 1.5
+    assert res[0][4] == (0, 256) and res[1][4] == (256, 512)
