@@ -249,6 +249,58 @@ int xrl_egreedy(const xrl_egreedy_t* p, xrl_stream_t stream);
 /* *counter += inc on the stream (advances RNG step counters between replays of a captured rollout). */
 int xrl_counter_add(uint32_t* counter, uint32_t inc, xrl_stream_t stream);
 
+/* ------------------------------------------------------------------ TD targets: DQN and QMIX */
+
+/* DQN_Learner.update loss head (qlearning_family/dqn_learner.py:39-46): predictQ = gather(evalQ, a);
+ * y = r + gamma (1-d) max_a' targetQ  (or targetQ[argmax_a' q_next_eval] when q_next_eval != NULL, the DDQN rule of
+ * ddqn_learner.py:39-47); loss = mean((predictQ - y)^2); d_q = dLoss/d evalQ. */
+typedef struct {
+    const float* q_eval;       /* [M][ld] Q(s,.) of the eval network */
+    const float* q_next;       /* [M][ld] Q_target(s',.) */
+    const float* q_next_eval;  /* NULL (DQN) or [M][ld] Q_eval(s',.) (double-Q action selection) */
+    const float* actions;      /* [M] f32 action indices (the replay buffer stores actions as float32) */
+    const float* rewards;      /* [M] */
+    const float* terminals;    /* [M] f32 0/1 */
+    float* d_q;                /* [M][ld] */
+    float* diag;               /* NULL or [2][M]: predictQ, targetQ (callback tensors dqn_learner.py:72-74) */
+    double* partials;          /* [n_split][8]: sum (predictQ-y)^2, sum predictQ, 0... */
+    int32_t M, A, ld, n_split;
+    float gamma, pad;
+} xrl_dqn_td_t;
+int xrl_dqn_td(const xrl_dqn_td_t* p, xrl_stream_t stream);
+
+/* QMIX_Learner.update between the per-agent Q-networks and the hyper-networks
+ * (multi_agent_rl/qmix_learner.py:34-86, iql_learner.py:63-81, heads/q_mix_head.py:66-95): gather taken Q, masked
+ * (double-)Q target action, agent masks, monotonic mixing (abs / bmm / ELU) for the eval and target mixers, TD target,
+ * MSE loss and the backward pass down to d Q_eval and d(hyper-network outputs).  One wavefront per batch row. */
+typedef struct {
+    const float* q_eval;       /* [B*N][ldq] Q_eval(obs), row b*N+n */
+    const float* q_next_eval;  /* NULL or [B*N][ldq] Q_eval(next_obs): double-Q argmax (config.double_q) */
+    const float* q_next;       /* [B*N][ldq] Q_target(next_obs) */
+    const float* actions;      /* [B][N] f32 */
+    const float* avail_next;   /* NULL or [B][N][A] f32 0/1 (use_actions_mask) */
+    const float* agent_mask;   /* [B][N] f32 0/1 */
+    const float* rewards;      /* [B][N] */
+    const float* terminals;    /* [B][N] f32 0/1 */
+    const float* e_b1;         /* [B][ld_e1] eval hyper_b_1(state) */
+    const float* e_raw;        /* [B][ld_e2] eval raw hyper outputs: w1_raw[N*H] | w2_raw[H] | b2[1] */
+    const float* t_b1;         /* target mixer, same layout, on state_next */
+    const float* t_raw;
+    float* d_q;                /* [B*N][ldq] dLoss/dQ_eval */
+    float* d_e_b1;             /* [B][ld_e1] */
+    float* d_e_raw;            /* [B][ld_e2] */
+    float* diag;               /* NULL or [3][B]: q_tot_eval, q_tot_next, q_tot_target (qmix_learner.py:108-110) */
+    double* partials;          /* [B][8]: (q_tot_eval-y)^2, q_tot_eval, 0... */
+    int32_t B, N, A, H, ldq, ld_e1, ld_e2, ld_t1, ld_t2, double_q;
+    float gamma, pad;
+} xrl_qmix_t;
+int xrl_qmix_mix_td(const xrl_qmix_t* p, xrl_stream_t stream);
+
+/* Hard target update inside a captured graph: if (state->step % sync_frequency == 0) target <- params
+ * (dqn_learner.py:56-57, qmix_learner.py:105-106; copy_target deep_q_network.py:95-99). */
+int xrl_sync_target(const float* params, float* target, int64_t P, const xrl_adam_state_t* state,
+                    int sync_frequency, xrl_stream_t stream);
+
 /* ------------------------------------------------------------------ hipGraph capture of op sequences */
 int xrl_graph_begin(xrl_stream_t stream);
 int xrl_graph_end(xrl_stream_t stream, void** graph_exec_out);

@@ -1,0 +1,97 @@
+"""GPU parity of DQN_Learner and QMIX_Learner (feed-forward) against fixtures generated from the unmodified
+reference (tests/golden/dqn_mlp.npz, qmix_ff_{double,single}.npz): Q-values, TD targets, mixer outputs, clipped
+gradients, parameters after every update (incl. hard target syncs) and the Adam moments."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, sub, assert_close
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class Capture:
+    def __init__(self):
+        self.records = []
+
+    def on_update_start(self, iterations, **kw):
+        return {}
+
+    def on_update_end(self, iterations, **kw):
+        self.records.append({k: v.detach().cpu().numpy().copy() for k, v in kw.items() if isinstance(v, torch.Tensor)})
+        return {}
+
+
+def base_cfg(**kw):
+    c = dict(distributed_training=False, device="cuda", model_dir="/tmp/xrl_models", running_steps=120000, parallels=4,
+             start_training=0, training_frequency=1)
+    c.update(kw)
+    return Namespace(**c)
+
+
+def check_updates(g, net, learner, cb, call, cb_keys, loss_key, n_updates=3, gtol=2e-5):
+    for u in range(n_updates):
+        info = call(sub(g, f"u{u}/batch"))
+        ref_info, ref_cb = sub(g, f"u{u}/info"), sub(g, f"u{u}/cb")
+        assert_close(info[loss_key], ref_info[loss_key], 1e-5, loss_key)
+        assert_close(info["predictQ"], ref_info["predictQ"], 1e-5, "predictQ")
+        assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "lr")
+        for k in cb_keys:
+            assert_close(cb.records[-1][k], ref_cb[k], 1e-5, k)
+        for k, rg in sub(g, f"u{u}/grad").items():
+            got = net.params.view(k, learner.optimizer.grad).cpu().numpy()
+            assert_close(got, rg, gtol, f"grad {k} (update {u})")
+        sd = net.state_dict()
+        for k, rp in sub(g, f"u{u}/param").items():
+            assert_close(sd[k].cpu().numpy(), rp, 1e-5, f"param {k} after update {u}")
+    osd = learner.optimizer.state_dict()
+    for i, k in enumerate(net.trainable_order):
+        assert_close(osd["state"][i]["exp_avg"].cpu().numpy(), g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
+        assert_close(osd["state"][i]["exp_avg_sq"].cpu().numpy(), g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
+
+
+def test_dqn_learner_vs_reference_fixture():
+    from xuance_amd.nets import DeepQNet
+    from xuance_amd.learners import DQN_Learner
+    g = load_golden("dqn_mlp")
+    lr, gamma, sync, gclip, use_clip, total = g["cfg"]
+    net = DeepQNet(6, 4, (64,), (64,), "relu")
+    assert list(net.ref_order) == list(sub(g, "init").keys())          # same state_dict order as the reference
+    net.load_state_dict(sub(g, "init"))
+    cb = Capture()
+    learner = DQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
+                                   use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip)), net, cb)
+    assert learner.total_iters == int(total)
+    check_updates(g, net, learner, cb, lambda b: learner.update(batch_size=len(b["obs"]), **b),
+                  ("evalQ", "predictQ", "targetQ"), "Qloss")
+
+
+@pytest.mark.parametrize("double_q", [True, False])
+def test_qmix_learner_vs_reference_fixture(double_q):
+    from xuance_amd.nets import MixingQNet
+    from xuance_amd.learners import QMIX_Learner
+    g = load_golden(f"qmix_ff_{'double' if double_q else 'single'}")
+    lr, gamma, sync, gclip, dq, total = g["cfg"]
+    N, O, S, A = 3, 30, 48, 9
+    keys = [f"agent_{i}" for i in range(N)]
+    net = MixingQNet(N, O, A, S, (64,), (64,), 32, 32, "relu", group=str(g["group"]))
+    assert list(net.ref_order) == list(sub(g, "init").keys())
+    net.load_state_dict(sub(g, "init"))
+    cb = Capture()
+    learner = QMIX_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
+                                    use_grad_clip=True, grad_clip_norm=float(gclip), double_q=bool(dq),
+                                    use_actions_mask=True, use_parameter_sharing=True, n_epochs=8), keys, net, cb)
+    assert learner.total_iters == int(total)
+
+    def call(b):
+        # hand the learner the reference buffer's nested format: field -> agent -> [B, ...]
+        sample = {k: {a: b[k][:, i] for i, a in enumerate(keys)}
+                  for k in ("obs", "obs_next", "actions", "rewards", "terminals", "agent_mask", "avail_actions",
+                            "avail_actions_next")}
+        sample.update(state=b["state"], state_next=b["state_next"], batch_size=len(b["state"]))
+        info = learner.update(sample)
+        info["loss_Q"] = info["loss_Q"]
+        return info
+    check_updates(g, net, learner, cb, call, ("q_tot_eval", "q_tot_next", "q_tot_target"), "loss_Q")

@@ -74,7 +74,27 @@ class EGreedy(C.Structure):
                 ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
 
 
+class DqnTd(C.Structure):
+    _fields_ = [("q_eval", c_void_p), ("q_next", c_void_p), ("q_next_eval", c_void_p), ("actions", c_void_p),
+                ("rewards", c_void_p), ("terminals", c_void_p), ("d_q", c_void_p), ("diag", c_void_p),
+                ("partials", c_void_p), ("M", c_int32), ("A", c_int32), ("ld", c_int32), ("n_split", c_int32),
+                ("gamma", c_float), ("pad", c_float)]
+
+
+class Qmix(C.Structure):
+    _fields_ = [("q_eval", c_void_p), ("q_next_eval", c_void_p), ("q_next", c_void_p), ("actions", c_void_p),
+                ("avail_next", c_void_p), ("agent_mask", c_void_p), ("rewards", c_void_p), ("terminals", c_void_p),
+                ("e_b1", c_void_p), ("e_raw", c_void_p), ("t_b1", c_void_p), ("t_raw", c_void_p), ("d_q", c_void_p),
+                ("d_e_b1", c_void_p), ("d_e_raw", c_void_p), ("diag", c_void_p), ("partials", c_void_p),
+                ("B", c_int32), ("N", c_int32), ("A", c_int32), ("H", c_int32), ("ldq", c_int32), ("ld_e1", c_int32),
+                ("ld_e2", c_int32), ("ld_t1", c_int32), ("ld_t2", c_int32), ("double_q", c_int32),
+                ("gamma", c_float), ("pad", c_float)]
+
+
 _SIGS = {
+    "xrl_dqn_td": [C.POINTER(DqnTd), c_void_p],
+    "xrl_qmix_mix_td": [C.POINTER(Qmix), c_void_p],
+    "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],
     "xrl_obs_normalize": [C.POINTER(Rms), c_void_p],
     "xrl_policy_sample": [C.POINTER(Sample), c_void_p],
     "xrl_cartpole_step": [C.POINTER(CartPole), c_int, c_void_p],

@@ -19,7 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int LDK = BK + 4;   // k-contiguous slab row stride (floats): 144 B, conflict-free for ds_read_b128
 constexpr int LDR = 64 + 0;   // k-major slab row stride (floats)
-constexpr int MAX_GROUPS = 4;
+constexpr int MAX_GROUPS = 8;
 
 struct GemmBatch {
     xrl_gemm_t g[MAX_GROUPS];

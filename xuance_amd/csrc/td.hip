@@ -1,0 +1,177 @@
+// TD-target / value-factorisation kernels for the off-policy learners.
+//   dqn_td_kernel   : xuance/torch/learners/qlearning_family/dqn_learner.py:39-46 (+ DDQN rule ddqn_learner.py:39-47)
+//   qmix_kernel     : multi_agent_rl/qmix_learner.py:34-86, iql_learner.py:63-81, rl_models/heads/q_mix_head.py:66-95
+//   sync_target     : dqn_learner.py:56-57 / qmix_learner.py:105-106 (hard target copy), graph-capturable
+// All HBM/latency bound: per row a few hundred bytes; the dense work (Q-networks, hyper-networks) runs in gemm.hip.
+#include "common.h"
+
+namespace xrl {
+
+__global__ void __launch_bounds__(256) dqn_td_kernel(xrl_dqn_td_t p) {
+    __shared__ double scratch[16];
+    const int chunk = (p.M + p.n_split - 1) / p.n_split;
+    const int mbeg = blockIdx.x * chunk, mend = min(p.M, mbeg + chunk);
+    const float invM = 1.f / (float)p.M;
+    double acc_l = 0.0, acc_q = 0.0;
+    for (int m = mbeg + threadIdx.x; m < mend; m += blockDim.x) {
+        const float* qe = p.q_eval + (size_t)m * p.ld;
+        const float* qn = p.q_next + (size_t)m * p.ld;
+        const int a = (int)p.actions[m];
+        const float pred = qe[a];                                        // :42
+        float tq;
+        if (p.q_next_eval) {                                             // double-Q: argmax of the eval net
+            const float* qs = p.q_next_eval + (size_t)m * p.ld;
+            int best = 0; float bv = qs[0];
+            for (int j = 1; j < p.A; ++j) if (qs[j] > bv) { bv = qs[j]; best = j; }
+            tq = qn[best];
+        } else {
+            tq = qn[0];
+            for (int j = 1; j < p.A; ++j) tq = fmaxf(tq, qn[j]);         // :43
+        }
+        const float y = p.rewards[m] + p.gamma * (1.f - p.terminals[m]) * tq;    // :44
+        const float td = pred - y;
+        float* dq = p.d_q + (size_t)m * p.ld;
+        for (int j = 0; j < p.A; ++j) dq[j] = (j == a) ? 2.f * td * invM : 0.f;   // MSELoss backward through gather
+        if (p.diag) { p.diag[m] = pred; p.diag[p.M + m] = y; }
+        acc_l += (double)td * td; acc_q += pred;
+    }
+    const double t0 = block_sum(acc_l, scratch), t1 = block_sum(acc_q, scratch);
+    if (threadIdx.x == 0) {
+        double* q = p.partials + (size_t)blockIdx.x * 8;
+        q[0] = t0; q[1] = t1;
+        for (int j = 2; j < 8; ++j) q[j] = 0.0;
+    }
+}
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+
+// One wavefront per batch row b.  Lane n < N owns agent n, lane h < H owns mixer hidden unit h.
+__global__ void __launch_bounds__(64) qmix_kernel(xrl_qmix_t p) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int N = p.N, A = p.A, H = p.H;
+    float qe = 0.f, qn = 0.f, mask = 0.f;
+    int a_taken = 0;
+    if (lane < N) {
+        const size_t row = (size_t)b * N + lane;
+        mask = p.agent_mask[row];
+        a_taken = (int)p.actions[row];
+        qe = p.q_eval[row * p.ldq + a_taken] * mask;                                  // qmix_learner.py:48-50,60
+        const float* qt = p.q_next + row * p.ldq;
+        const float* av = p.avail_next ? p.avail_next + row * A : nullptr;
+        if (p.double_q) {                                                             // :52-55, iql_learner.py:68-71
+            const float* qs = p.q_next_eval + row * p.ldq;
+            int best = 0; float bv = (av && av[0] == 0.f) ? -1e10f : qs[0];
+            for (int j = 1; j < A; ++j) {
+                const float v = (av && av[j] == 0.f) ? -1e10f : qs[j];                // value_factorization.py:87-90
+                if (v > bv) { bv = v; best = j; }
+            }
+            qn = (av && av[best] == 0.f) ? -1e10f : qt[best];                         // iql_learner.py:75-81
+        } else {                                                                      // :57-58
+            qn = (av && av[0] == 0.f) ? -1e10f : qt[0];
+            for (int j = 1; j < A; ++j) qn = fmaxf(qn, (av && av[j] == 0.f) ? -1e10f : qt[j]);
+        }
+        qn *= mask;                                                                   // :61
+    }
+    // mixing networks (q_mix_head.py:78-95)
+    const float* e_raw = p.e_raw + (size_t)b * p.ld_e2;
+    const float* t_raw = p.t_raw + (size_t)b * p.ld_t2;
+    float pre_e = 0.f, pre_t = 0.f, w2e = 0.f, w2t = 0.f;
+    if (lane < H) { pre_e = p.e_b1[(size_t)b * p.ld_e1 + lane]; pre_t = p.t_b1[(size_t)b * p.ld_t1 + lane]; }
+    for (int n = 0; n < N; ++n) {
+        const float qen = __shfl(qe, n, 64), qnn = __shfl(qn, n, 64);
+        if (lane < H) {
+            pre_e += qen * fabsf(e_raw[n * H + lane]);                                // bmm(agent_qs, |w1|) + b1
+            pre_t += qnn * fabsf(t_raw[n * H + lane]);
+        }
+    }
+    float hid_e = 0.f, hid_t = 0.f;
+    if (lane < H) {
+        hid_e = elu_f(pre_e); hid_t = elu_f(pre_t);
+        w2e = fabsf(e_raw[N * H + lane]); w2t = fabsf(t_raw[N * H + lane]);
+    }
+    const float q_tot_e = wave_sum(hid_e * w2e) + e_raw[N * H + H];                   // bmm(hidden, |w2|) + b2
+    const float q_tot_n = wave_sum(hid_t * w2t) + t_raw[N * H + H];
+    // rewards_tot = mean over agents, terminals_tot = all agents terminated (qmix_learner.py:34-35)
+    float r = 0.f, dn = 1.f;
+    if (lane < N) { r = p.rewards[(size_t)b * N + lane]; dn = p.terminals[(size_t)b * N + lane] != 0.f ? 1.f : 0.f; }
+    const float r_tot = wave_sum(r) / (float)N;
+    float all_d = dn;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) all_d = fminf(all_d, __shfl_xor(all_d, off, 64));
+    const float y = r_tot + (1.f - all_d) * p.gamma * q_tot_n;                        // :78
+    const float td = q_tot_e - y;
+    const float dq_tot = 2.f * td / (float)p.B;                                       // d mean(td^2) / d q_tot_eval
+    // backward through the eval mixer
+    float* d_raw = p.d_e_raw + (size_t)b * p.ld_e2;
+    float d_pre = 0.f;
+    if (lane < H) {
+        const float w2_raw = e_raw[N * H + lane];
+        const float sgn2 = (w2_raw > 0.f) - (w2_raw < 0.f);
+        d_raw[N * H + lane] = dq_tot * hid_e * sgn2;                                  // through abs()
+        d_pre = dq_tot * w2e * (pre_e > 0.f ? 1.f : expf(pre_e));                     // ELU'
+        p.d_e_b1[(size_t)b * p.ld_e1 + lane] = d_pre;
+    }
+    if (lane == 0) d_raw[N * H + H] = dq_tot;
+    for (int n = 0; n < N; ++n) {
+        const float qen = __shfl(qe, n, 64);
+        float contrib = 0.f;
+        if (lane < H) {
+            const float w1_raw = e_raw[n * H + lane];
+            const float sgn1 = (w1_raw > 0.f) - (w1_raw < 0.f);
+            d_raw[n * H + lane] = qen * d_pre * sgn1;
+            contrib = d_pre * fabsf(w1_raw);
+        }
+        const float dqe = wave_sum(contrib);                                          // d loss / d (masked q_eval_n)
+        if (lane == n) {
+            float* dq = p.d_q + ((size_t)b * N + n) * p.ldq;
+            for (int j = 0; j < A; ++j) dq[j] = (j == a_taken) ? dqe * mask : 0.f;
+        }
+    }
+    if (lane == 0) {
+        double* q = p.partials + (size_t)b * 8;
+        q[0] = (double)td * td; q[1] = q_tot_e;
+        for (int j = 2; j < 8; ++j) q[j] = 0.0;
+        if (p.diag) { p.diag[b] = q_tot_e; p.diag[p.B + b] = q_tot_n; p.diag[2 * (size_t)p.B + b] = y; }
+    }
+}
+
+__global__ void __launch_bounds__(256) sync_target_kernel(const float* __restrict__ params, float* __restrict__ target,
+                                                          int64_t P, const xrl_adam_state_t* st, int freq) {
+    if (st->step % freq != 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x)
+        target[i] = params[i];
+}
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_dqn_td(const xrl_dqn_td_t* p, xrl_stream_t stream) {
+    XRL_CHECK_ARG(p && p->q_eval && p->q_next && p->actions && p->rewards && p->terminals && p->d_q && p->partials);
+    XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->ld >= p->A && p->n_split >= 1);
+    hipLaunchKernelGGL(dqn_td_kernel, dim3(p->n_split), dim3(256), 0, as_stream(stream), *p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_qmix_mix_td(const xrl_qmix_t* p, xrl_stream_t stream) {
+    XRL_CHECK_ARG(p && p->q_eval && p->q_next && p->actions && p->agent_mask && p->rewards && p->terminals);
+    XRL_CHECK_ARG(p->e_b1 && p->e_raw && p->t_b1 && p->t_raw && p->d_q && p->d_e_b1 && p->d_e_raw && p->partials);
+    XRL_CHECK_ARG(p->B > 0 && p->N > 0 && p->N <= 64 && p->H > 0 && p->H <= 64 && p->A > 0 && p->ldq >= p->A);
+    XRL_CHECK_ARG(!p->double_q || p->q_next_eval);
+    XRL_CHECK_ARG(p->ld_e2 >= p->N * p->H + p->H + 1 && p->ld_t2 >= p->N * p->H + p->H + 1);
+    hipLaunchKernelGGL(qmix_kernel, dim3(p->B), dim3(64), 0, as_stream(stream), *p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_sync_target(const float* params, float* target, int64_t P, const xrl_adam_state_t* state,
+                               int sync_frequency, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params && target && state && P > 0 && sync_frequency > 0);
+    int nb = (int)((P + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(sync_target_kernel, dim3(nb), dim3(256), 0, as_stream(stream), params, target, P, state,
+                       sync_frequency);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

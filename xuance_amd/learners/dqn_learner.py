@@ -1,0 +1,83 @@
+"""DQN learner on the HIP engine: same constructor / ``update(**samples)`` contract / info keys / callback hooks as
+xuance/torch/learners/qlearning_family/dqn_learner.py:12-75 (MSE TD loss, max-target, hard target sync).  With
+``double_q=True`` the target action comes from the eval network (the DDQN rule, ddqn_learner.py:39-47)."""
+import torch
+
+from .. import ops
+from .base import Learner, AdamHandle, LinearLRHandle
+from .ppo_learner import pick_n_split
+
+
+class DQN_Learner(Learner):
+    def __init__(self, config, model, callback=None):
+        super().__init__(config, model, callback)
+        self.sync_frequency = config.sync_frequency
+        self.double_q = bool(getattr(config, "double_q", False))
+        self.n_actions = model.n_actions
+        P = model.params
+        self.optimizer = AdamHandle(P, model.trainable_order, self.learning_rate, eps=1e-5,
+                                    total_iters=self.total_iters, end_factor=self.end_factor_lr_decay)
+        self.scheduler = LinearLRHandle(self.optimizer)
+        dev = P.device
+        self._cap = 0
+        self.sumsq = torch.zeros(64, dtype=torch.float64, device=dev)
+        self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+
+    def _ensure(self, M):
+        if M <= self._cap:
+            return
+        dev, P = self.model.params.device, self.model.params.P
+        self._cap = M
+        self.slabs = torch.zeros(32, P, device=dev)
+        self.partials = torch.zeros(32, 8, dtype=torch.float64, device=dev)
+        self.diag = torch.zeros(2 * M, device=dev)
+        self.X = torch.zeros(2 * M, self.model.obs_dim, device=dev)
+        self.model.plan.ensure(2 * M)
+        self.model.target_plan.ensure(M)
+
+    def _as_dev(self, x, dtype=torch.float32):
+        return torch.as_tensor(x, device=self.model.params.device).to(dtype).contiguous()
+
+    def _step(self, M, act, rew, ter):
+        """self.X rows [0,M) = obs, rows [M,2M) = obs_next (already on the device)."""
+        model, opt, A = self.model, self.optimizer, self.n_actions
+        S = pick_n_split(M)
+        q_all = model.forward(self.X, 2 * M if self.double_q else M)                 # evalQ (:39) [+ Q_eval(s')]
+        q_next = model.target(self.X[M:], M)                                         # targetQ (:40)
+        d_q = model.plan.dacts[len(model.plan.widths) - 1]
+        ops.dqn_td(q_eval=q_all, q_next=q_next, q_next_eval=q_all[M:] if self.double_q else None, actions=act,
+                   rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A, ld=A,
+                   n_split=S, gamma=float(self.gamma))
+        model.plan.backward(self.X, model.obs_dim, M, self.slabs, S)
+        ops.grad_reduce(self.slabs, S, model.params.P, model.params.P, opt.grad, self.sumsq)
+        if self.distributed_training and self.world_size > 1:
+            from ..dist import allreduce_mean_
+            allreduce_mean_(opt.grad)
+            ops.grad_reduce(opt.grad, 1, model.params.P, model.params.P, opt.grad, self.sumsq)
+        ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq,
+                      self.grad_clip_norm if self.use_grad_clip else 0.0)
+        ops.sync_target(model.params.flat, model.target_flat, model.params.P, opt.state, self.sync_frequency)   # :56-57
+        return S
+
+    def update(self, **samples):
+        self.iterations += 1
+        obs = self._as_dev(samples["obs"])
+        M = obs.shape[0]
+        self._ensure(M)
+        self.X[:M].copy_(obs.reshape(M, -1))
+        self.X[M:2 * M].copy_(self._as_dev(samples["obs_next"]).reshape(M, -1))
+        act, rew, ter = self._as_dev(samples["actions"]), self._as_dev(samples["rewards"]), self._as_dev(samples["terminals"])
+        info = self.callback.on_update_start(self.iterations, policy=self.model, obs=self.X[:M], act=act,
+                                             next_obs=self.X[M:2 * M], rew=rew, termination=ter) or {}
+        S = self._step(M, act, rew, ter)
+        ops.sum_partials(self.partials, S, 8, self.sums)
+        s = self.sums.cpu().numpy()
+        st = self.optimizer.read()
+        info.update({self._key("Qloss"): float(s[0] / M), self._key("predictQ"): float(s[1] / M),
+                     self._key("learning_rate"): st.last_lr})
+        A = self.n_actions
+        evalQ = self.model.plan.acts[len(self.model.plan.widths) - 1][:M, :A]
+        info.update(self.callback.on_update_end(self.iterations, policy=self.model, info=info, evalQ=evalQ,
+                                                predictQ=self.diag[:M], targetQ=self.diag[M:2 * M],
+                                                loss=info[self._key("Qloss")]) or {})
+        return info

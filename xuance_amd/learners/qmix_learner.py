@@ -1,0 +1,128 @@
+"""QMIX learner (feed-forward agents, parameter sharing) on the HIP engine.
+
+Same constructor ``(config, agent_grouping_or_keys, model, callback)``, ``update(sample)`` contract, info keys
+(``learning_rate, loss_Q, predictQ``) and callback hooks as
+xuance/torch/learners/multi_agent_rl/qmix_learner.py:13-112 (with iql_learner.py:37-83 and
+base/marl_learner.py:319-408).  ``sample`` may be the reference buffer's nested dict (field -> agent -> array
+[B, ...]) or the stacked form produced by HipMARLOffPolicyBuffer (field -> tensor [B, N, ...]).
+The GRU/episode variant (use_rnn) is SURVEY.md section 8f "next" and raises NotImplementedError.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from .base import Learner, AdamHandle, LinearLRHandle
+from .ppo_learner import pick_n_split
+
+
+class QMIX_Learner(Learner):
+    def __init__(self, config, agent_grouping, model, callback=None):
+        super().__init__(config, model, callback)
+        if getattr(config, "use_rnn", False):
+            raise NotImplementedError("QMIX with recurrent agents is not part of round 1 (SURVEY.md section 8f)")
+        self.agent_keys = list(getattr(agent_grouping, "agent_keys", agent_grouping))
+        self.n_agents = len(self.agent_keys)
+        assert self.n_agents == model.n_agents
+        self.use_parameter_sharing = getattr(config, "use_parameter_sharing", True)
+        self.sync_frequency = config.sync_frequency
+        self.double_q = bool(getattr(config, "double_q", True))
+        P = model.params
+        self.optimizer = AdamHandle(P, model.trainable_order, self.learning_rate, eps=1e-5,
+                                    weight_decay=getattr(config, "weight_decay", 0.0), total_iters=self.total_iters,
+                                    end_factor=self.end_factor_lr_decay)
+        self.scheduler = LinearLRHandle(self.optimizer)
+        dev = P.device
+        self._cap = 0
+        self.sumsq = torch.zeros(64, dtype=torch.float64, device=dev)
+        self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+
+    def estimate_total_iterations(self):                        # marl_learner.py:36-47 (feed-forward branch)
+        c = self.config
+        start_training = getattr(c, "start_training", 0)
+        training_frequency = getattr(c, "training_frequency", 1)
+        return (c.running_steps - start_training) // (training_frequency * c.parallels) * getattr(c, "n_epochs", 1)
+
+    def _ensure(self, B):
+        if B <= self._cap:
+            return
+        m, dev = self.model, self.model.params.device
+        self._cap = B
+        N, R = m.n_agents, B * m.n_agents
+        self.slabs = torch.zeros(32, m.params.P, device=dev)
+        self.partials = torch.zeros(B, 8, dtype=torch.float64, device=dev)
+        self.diag = torch.zeros(3 * B, device=dev)
+        self.X = torch.zeros(2 * R, m.obs_dim, device=dev)       # rows [0,R) obs, rows [R,2R) obs_next
+        self.states = torch.zeros(2 * B, m.state_dim, device=dev)
+        self.buf = {k: torch.zeros(B, N, device=dev) for k in ("actions", "rewards", "terminals", "agent_mask")}
+        self.buf["avail_next"] = torch.ones(B, N, m.n_actions, device=dev)
+        m.agent_plan.ensure(2 * R)
+        m.agent_target_plan.ensure(R)
+        m.mixer_plan.ensure(B)
+        m.mixer_target_plan.ensure(B)
+
+    def _stack(self, x, dtype=torch.float32):
+        """field -> agent -> [B, ...]  (reference buffers)  or an already stacked [B, N, ...] tensor/array."""
+        dev = self.model.params.device
+        if isinstance(x, dict):
+            return torch.stack([torch.as_tensor(np.asarray(x[k]) if not isinstance(x[k], torch.Tensor) else x[k],
+                                                device=dev).to(dtype) for k in self.agent_keys], dim=1)
+        return torch.as_tensor(x, device=dev).to(dtype)
+
+    def build_training_data(self, sample):                      # marl_learner.py:319-408
+        B = int(sample["batch_size"])
+        self._ensure(B)
+        m = self.model
+        R = B * m.n_agents
+        self.X[:R].copy_(self._stack(sample["obs"]).reshape(R, -1))
+        self.X[R:2 * R].copy_(self._stack(sample["obs_next"]).reshape(R, -1))
+        for k in ("actions", "rewards", "terminals", "agent_mask"):
+            self.buf[k][:B].copy_(self._stack(sample[k]).reshape(B, m.n_agents))
+        if self.use_actions_mask:
+            self.buf["avail_next"][:B].copy_(self._stack(sample["avail_actions_next"]).reshape(B, m.n_agents, -1))
+        dev = m.params.device
+        self.states[:B].copy_(torch.as_tensor(sample["state"], device=dev).reshape(B, -1))
+        self.states[B:2 * B].copy_(torch.as_tensor(sample["state_next"], device=dev).reshape(B, -1))
+        return B
+
+    def _step(self, B):
+        m, opt = self.model, self.optimizer
+        N, A, H = m.n_agents, m.n_actions, m.H
+        R = B * N
+        S = pick_n_split(R)
+        q_all = m.agent_plan.forward(self.X, m.obs_dim, 2 * R if self.double_q else R)            # iql_learner.py:41-47,68-71
+        q_next = m.agent_target_plan.forward(self.X[R:], m.obs_dim, R, flat=m.target_flat)        # :63-66
+        e_raw = m.mixer_plan.forward(self.states, m.state_dim, B)                                 # eval hyper-nets (state)
+        t_raw = m.mixer_target_plan.forward(self.states[B:], m.state_dim, B, flat=m.target_flat)  # target (state_next)
+        e_l1, t_l1 = m.mixer_plan.acts[1], m.mixer_target_plan.acts[1]
+        d_l1, d_raw = m.mixer_plan.dacts[1], m.mixer_plan.dacts[2]
+        ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]
+        ops.qmix_mix_td(q_eval=q_all, q_next_eval=q_all[R:] if self.double_q else None, q_next=q_next,
+                        actions=self.buf["actions"], avail_next=self.buf["avail_next"] if self.use_actions_mask else None,
+                        agent_mask=self.buf["agent_mask"], rewards=self.buf["rewards"], terminals=self.buf["terminals"],
+                        e_b1=e_l1.data_ptr() + 4 * 3 * m.HH, e_raw=e_raw, t_b1=t_l1.data_ptr() + 4 * 3 * m.HH, t_raw=t_raw,
+                        d_q=m.agent_plan.dacts[len(m.agent_plan.widths) - 1], d_e_b1=d_l1.data_ptr() + 4 * 3 * m.HH,
+                        d_e_raw=d_raw, diag=self.diag, partials=self.partials, B=B, N=N, A=A, H=H, ldq=A, ld_e1=ld1,
+                        ld_e2=ld2, ld_t1=ld1, ld_t2=ld2, double_q=int(self.double_q), gamma=float(self.gamma))
+        m.mixer_plan.backward(self.states, m.state_dim, B, self.slabs, S)
+        m.agent_plan.backward(self.X, m.obs_dim, R, self.slabs, S)
+        ops.grad_reduce(self.slabs, S, m.params.P, m.params.P, opt.grad, self.sumsq)
+        if self.distributed_training and self.world_size > 1:
+            from ..dist import allreduce_mean_
+            allreduce_mean_(opt.grad)
+            ops.grad_reduce(opt.grad, 1, m.params.P, m.params.P, opt.grad, self.sumsq)
+        ops.adam_step(m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state, self.sumsq,
+                      self.grad_clip_norm if self.use_grad_clip else 0.0)                         # qmix_learner.py:88-96
+        ops.sync_target(m.params.flat, m.target_flat, m.params.P, opt.state, self.sync_frequency)  # :105-106
+
+    def update(self, sample):
+        self.iterations += 1
+        B = self.build_training_data(sample)
+        info = self.callback.on_update_start(self.iterations, model=self.model) or {}
+        self._step(B)
+        ops.sum_partials(self.partials, B, 8, self.sums)
+        s = self.sums.cpu().numpy()
+        st = self.optimizer.read()
+        info.update({"learning_rate": st.last_lr, "loss_Q": float(s[0] / B), "predictQ": float(s[1] / B)})
+        info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, q_tot_eval=self.diag[:B],
+                                                q_tot_next=self.diag[B:2 * B], q_tot_target=self.diag[2 * B:3 * B]) or {})
+        return info

@@ -316,3 +316,160 @@ class SequentialNet:
 
     def backward(self, x, M, slabs, n_split, ldx=None, flat=None):
         self.plan.backward(x, self.in_dim if ldx is None else ldx, M, slabs, n_split, flat)
+
+
+def _seq_layers(prefix, in_dim, sizes, activation, last_act, lvl0, specs, order, stages, widths):
+    """Append a chain of mlp_blocks named ``<prefix>.<2i>`` to (specs, order, stages, widths)."""
+    feat, lvl = in_dim, lvl0
+    for i, h in enumerate(sizes):
+        n = f"{prefix}.{2 * i}"
+        act = activation if (i < len(sizes) - 1 or last_act == "same") else last_act
+        specs += [(n + ".weight", (h, feat)), (n + ".bias", (h,))]
+        order += [n + ".weight", n + ".bias"]
+        stages.append([Layer(n, feat, h, act, lvl, 0, lvl + 1, 0, n + ".weight", n + ".bias")])
+        widths.append(h)
+        feat, lvl = h, lvl + 1
+    return feat, lvl
+
+
+class DeepQNet:
+    """DeepQNetwork with an MLP / identity representation (rl_models/architectures/single_agent/deep_q_network.py:19-99):
+    eval and target networks share one parameter layout; the target lives in a second flat buffer."""
+
+    def __init__(self, obs_dim, n_actions, representation_hidden=(), q_hidden=(64,), activation="relu", device="cuda",
+                 init=True):
+        self.obs_dim, self.n_actions, self.activation = obs_dim, n_actions, activation
+        specs, order, stages, widths = [], [], [], [obs_dim]
+        feat, lvl = _seq_layers("representation.model", obs_dim, list(representation_hidden or []), activation, "same",
+                                0, specs, order, stages, widths)
+        _seq_layers("eval_Q_head.q_value", feat, list(q_hidden) + [n_actions], activation, None, lvl, specs, order,
+                    stages, widths)
+        self.eval_order = order
+        self.params = FlatParams(specs, device)
+        self.target_flat = self.params.like()
+        self.plan = Plan(self.params, widths, stages)            # eval network (forward + backward)
+        self.target_plan = Plan(self.params, widths, stages)     # target network (forward only, on target_flat)
+        rep = [k for k in order if k.startswith("representation.")]
+        head = [k for k in order if k.startswith("eval_Q_head.")]
+        # reference state_dict order: representation, target_representation, eval_Q_head, target_Q_head
+        self.ref_order = rep + ["target_" + k for k in rep] + head + ["target_Q_head." + k[len("eval_Q_head."):] for k in head]
+        self.trainable_order = rep + head
+        if init:
+            for name in order:
+                v = self.params.view(name)
+                v.copy_(_orthogonal(v.shape)) if name.endswith(".weight") else v.zero_()
+            self.copy_target()
+
+    def _target_key(self, k):
+        if k.startswith("target_representation."):
+            return k[len("target_"):]
+        if k.startswith("target_Q_head."):
+            return "eval_Q_head." + k[len("target_Q_head."):]
+        return None
+
+    def state_dict(self):
+        out = OrderedDict()
+        for k in self.ref_order:
+            tk = self._target_key(k)
+            out[k] = (self.params.view(tk, self.target_flat) if tk else self.params.view(k)).detach().clone()
+        return out
+
+    def load_state_dict(self, sd):
+        for k in self.ref_order:
+            tk = self._target_key(k)
+            dst = self.params.view(tk, self.target_flat) if tk else self.params.view(k)
+            dst.copy_(torch.as_tensor(sd[k], dtype=torch.float32))
+
+    def copy_target(self):                                        # deep_q_network.py:95-99
+        self.target_flat.copy_(self.params.flat)
+
+    def forward(self, x, M, ldx=None):
+        return self.plan.forward(x, self.obs_dim if ldx is None else ldx, M)
+
+    def target(self, x, M, ldx=None):
+        return self.target_plan.forward(x, self.obs_dim if ldx is None else ldx, M, flat=self.target_flat)
+
+
+class MixingQNet:
+    """MixingQNetwork(ModuleDict{group: DiscreteActionValueCritic(AgentFeatureEncoder(Basic_MLP))}, QMIX_Mixer)
+    with parameter sharing (one group) and identity encoding 'none'
+    (architectures/multi_agent/value_factorization.py:17-174, critics/base_critics.py:91-132, heads/q_mix_head.py:28-95).
+    Agent network and mixer share ONE flat parameter buffer (one optimiser step); the targets are a second buffer."""
+
+    def __init__(self, n_agents, obs_dim, n_actions, state_dim, representation_hidden=(64,), q_hidden=(64,),
+                 mixer_hidden=32, hyper_hidden=32, activation="relu", group="shared", device="cuda", init=True):
+        self.n_agents, self.obs_dim, self.n_actions, self.state_dim = n_agents, obs_dim, n_actions, state_dim
+        self.H, self.HH, self.group = mixer_hidden, hyper_hidden, group
+        N, H, HH, S = n_agents, mixer_hidden, hyper_hidden, state_dim
+        specs, a_order, a_stages, a_widths = [], [], [], [obs_dim]
+        pe = f"individual_q_networks.{group}"
+        feat, lvl = _seq_layers(f"{pe}.representation.obs_representation.model", obs_dim, list(representation_hidden),
+                                activation, "same", 0, specs, a_order, a_stages, a_widths)
+        _seq_layers(f"{pe}.critic_head.q_value", feat, list(q_hidden) + [n_actions], activation, None, lvl, specs,
+                    a_order, a_stages, a_widths)
+        # mixer hyper-networks: the three ReLU first layers are stacked into one GEMM ([hyper_w_1.0; hyper_w_2.0;
+        # hyper_b_2.0]), hyper_b_1 is a second group of the same launch; second layers are three groups.
+        m = "eval_Qtot"
+        firsts = [f"{m}.hyper_w_1.0", f"{m}.hyper_w_2.0", f"{m}.hyper_b_2.0"]
+        specs += [(n + ".weight", (HH, S)) for n in firsts] + [(n + ".bias", (HH,)) for n in firsts]
+        specs += [(f"{m}.hyper_b_1.weight", (H, S)), (f"{m}.hyper_b_1.bias", (H,)),
+                  (f"{m}.hyper_w_1.2.weight", (N * H, HH)), (f"{m}.hyper_w_1.2.bias", (N * H,)),
+                  (f"{m}.hyper_w_2.2.weight", (H, HH)), (f"{m}.hyper_w_2.2.bias", (H,)),
+                  (f"{m}.hyper_b_2.2.weight", (1, HH)), (f"{m}.hyper_b_2.2.bias", (1,))]
+        assert (HH * S) % 4 == 0 and HH % 4 == 0
+        self.raw_width = N * H + H + 1
+        m_widths = [S, 3 * HH + H, (self.raw_width + 3) // 4 * 4]
+        m_stages = [[Layer("+".join(firsts), S, 3 * HH, "relu", 0, 0, 1, 0, firsts[0] + ".weight", firsts[0] + ".bias"),
+                     Layer(f"{m}.hyper_b_1", S, H, None, 0, 0, 1, 3 * HH, f"{m}.hyper_b_1.weight", f"{m}.hyper_b_1.bias")],
+                    [Layer(f"{m}.hyper_w_1.2", HH, N * H, None, 1, 0, 2, 0, f"{m}.hyper_w_1.2.weight", f"{m}.hyper_w_1.2.bias"),
+                     Layer(f"{m}.hyper_w_2.2", HH, H, None, 1, HH, 2, N * H, f"{m}.hyper_w_2.2.weight", f"{m}.hyper_w_2.2.bias"),
+                     Layer(f"{m}.hyper_b_2.2", HH, 1, None, 1, 2 * HH, 2, N * H + H, f"{m}.hyper_b_2.2.weight", f"{m}.hyper_b_2.2.bias")]]
+        mixer_order = []
+        for n in (f"{m}.hyper_w_1.0", f"{m}.hyper_w_1.2", f"{m}.hyper_w_2.0", f"{m}.hyper_w_2.2", f"{m}.hyper_b_1",
+                  f"{m}.hyper_b_2.0", f"{m}.hyper_b_2.2"):
+            mixer_order += [n + ".weight", n + ".bias"]
+        self.params = FlatParams(specs, device)
+        self.target_flat = self.params.like()
+        self.agent_plan = Plan(self.params, a_widths, a_stages)
+        self.agent_target_plan = Plan(self.params, a_widths, a_stages)
+        self.mixer_plan = Plan(self.params, m_widths, m_stages)
+        self.mixer_target_plan = Plan(self.params, m_widths, m_stages)
+        self.trainable_order = a_order + mixer_order
+        # reference order: individual_q_networks, target_individual_q_networks, eval_Qtot, target_Qtot
+        self.ref_order = a_order + ["target_" + k for k in a_order] + mixer_order + \
+            ["target_Qtot." + k[len("eval_Qtot."):] for k in mixer_order]
+        if init:
+            for name in self.trainable_order:
+                v = self.params.view(name)
+                if name.endswith(".weight") and name.startswith("individual_q_networks"):
+                    v.copy_(_orthogonal(v.shape))
+                elif name.startswith("eval_Qtot"):       # nn.Linear default init (q_mix_head.py builds plain nn.Linear)
+                    fan_in = self.params.shapes[name[:-5] + ".weight" if name.endswith(".bias") else name][1]
+                    bound = 1.0 / fan_in ** 0.5
+                    v.copy_((torch.rand(v.shape) * 2 - 1) * bound)
+                else:
+                    v.zero_()
+            self.copy_target()
+
+    def _target_key(self, k):
+        if k.startswith("target_individual_q_networks."):
+            return k[len("target_"):]
+        if k.startswith("target_Qtot."):
+            return "eval_Qtot." + k[len("target_Qtot."):]
+        return None
+
+    def state_dict(self):
+        out = OrderedDict()
+        for k in self.ref_order:
+            tk = self._target_key(k)
+            out[k] = (self.params.view(tk, self.target_flat) if tk else self.params.view(k)).detach().clone()
+        return out
+
+    def load_state_dict(self, sd):
+        for k in self.ref_order:
+            tk = self._target_key(k)
+            dst = self.params.view(tk, self.target_flat) if tk else self.params.view(k)
+            dst.copy_(torch.as_tensor(sd[k], dtype=torch.float32))
+
+    def copy_target(self):                                        # value_factorization.py:169-174
+        self.target_flat.copy_(self.params.flat)

@@ -9,7 +9,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, call, ptr, stream_ptr
+from ._lib import (ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, call, ptr,
+                   stream_ptr)
 
 
 def _chk(t, dtype=torch.float32):
@@ -155,6 +156,18 @@ def rollout_poststep(**kw):
 
 def egreedy(**kw):
     call("xrl_egreedy", C.byref(_struct(EGreedy, kw)), stream_ptr())
+
+
+def dqn_td(**kw):
+    call("xrl_dqn_td", C.byref(_struct(DqnTd, kw)), stream_ptr())
+
+
+def qmix_mix_td(**kw):
+    call("xrl_qmix_mix_td", C.byref(_struct(Qmix, kw)), stream_ptr())
+
+
+def sync_target(params, target, P, state, sync_frequency):
+    call("xrl_sync_target", ptr(params), ptr(target), int(P), ptr(state), int(sync_frequency), stream_ptr())
 
 
 def counter_add(counter, inc):
