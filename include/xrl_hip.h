@@ -38,6 +38,8 @@ const char* xrl_version(void);
 const char* xrl_last_error(void);
 /* multiProcessorCount, warpSize and gcnArchName of the current device */
 int xrl_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+/* one-time per-process device setup (kernel attributes); call once after the device is selected, outside capture */
+int xrl_init(void);
 
 /* ------------------------------------------------------------------ rollout buffer (structure of arrays) */
 
@@ -248,6 +250,55 @@ typedef struct {
 int xrl_egreedy(const xrl_egreedy_t* p, xrl_stream_t stream);
 /* *counter += inc on the stream (advances RNG step counters between replays of a captured rollout). */
 int xrl_counter_add(uint32_t* counter, uint32_t inc, xrl_stream_t stream);
+
+/* ------------------------------------------------------------------ fused rollout step (ONE launch per vector step)
+ * The whole body of the on-policy agent's step loop (ppo_agent.py:113-177) for a device-resident CartPole:
+ * deferred ret_rms merges, obs_rms.update + normalisation + store, the complete actor-critic MLP forward on
+ * LDS-resident 32-row tiles (fp32 MFMA), action sampling / log-prob / value + store, physics with auto-reset,
+ * reward normalisation + store, path-end flags, return tracker, normalised next_obs for bootstrapping.
+ * Workgroup i < n/32 owns envs [32i, 32i+32) ("act" tile); workgroups i >= n/32 evaluate V(next_obs of the previous
+ * step) for the same envs ("boot" tile -> bootv[t-1]).  All cross-workgroup inputs are read from *_in buffers written
+ * by the previous launch and all outputs go to *_out buffers (the host ping-pongs them), so no in-launch
+ * synchronisation between workgroups is needed; statistics that couple all envs are recomputed redundantly per
+ * workgroup from the (tiny) *_in arrays.  Produces the same numbers as the unfused sequence
+ * xrl_obs_normalize -> xrl_linear_fwd x L -> xrl_policy_sample -> xrl_cartpole_step -> xrl_rollout_poststep. */
+#define XRL_FUSED_MAX_LAYERS 8
+#define XRL_FUSED_MAX_LEVELS 6
+typedef struct {
+    int32_t w_off, b_off;          /* float offsets of weight [N][K] and bias [N] in the flat parameter buffer */
+    int32_t K, N, act;
+    int32_t in_level, in_off, out_level, out_off;
+    int32_t pad;
+} xrl_fused_layer_t;
+
+typedef struct {
+    const float* params;                               /* flat parameter buffer */
+    xrl_fused_layer_t layers[XRL_FUSED_MAX_LAYERS];
+    int32_t n_layers, n_levels;
+    int32_t level_width[XRL_FUSED_MAX_LEVELS];        /* level 0 = observation */
+    /* cross-workgroup state, ping-ponged by the host */
+    const float* obs_raw_in;   float* obs_raw_out;     /* [n][D] raw observation the agent acts on */
+    const float* xnext_in;     float* xnext_out;       /* [n][D] normalised next_obs (pre-reset) */
+    const float* obs_stats_in; float* obs_stats_out;   /* [2*D] mean | var (float32) */
+    const double* obs_count_in; double* obs_count_out; /* [1] */
+    const float* ret_stats_in; float* ret_stats_out;   /* [2] mean, var */
+    const double* ret_count_in; double* ret_count_out; /* [1] */
+    const uint8_t* ended_in;   uint8_t* ended_out;     /* [n] episode ended at the previous / this step */
+    const float* ret_final_in; float* ret_final_out;   /* [n] discounted return of an episode that just ended */
+    float* ret_track;                                  /* [n] return tracker (owner workgroup only) */
+    /* rollout-buffer slots of this step */
+    float* obs_slot; float* act_slot; float* val_slot; float* logp_slot; float* rew_slot; float* term_slot;
+    uint8_t* seg_slot; float* bootv_prev;              /* bootv_prev: bootv[t-1] or NULL (no boot tiles) */
+    const float* log_std;                              /* gaussian head: [A] */
+    /* CartPole state */
+    double* cp_state; int32_t* cp_steps; int32_t* cp_episodes; float* cp_score; double* cp_stats;
+    int32_t n, D, A, gaussian, max_steps;
+    int32_t use_obsnorm, use_rewnorm, last_step, boot_only;
+    float obs_range, rew_range, gamma;
+    uint64_t seed, env_seed;
+    uint32_t step; const uint32_t* step_dev;
+} xrl_rollout_step_t;
+int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
 
 /* ------------------------------------------------------------------ TD targets: DQN and QMIX */
 

@@ -153,3 +153,36 @@ def test_cartpole_learns():
     agent.train(256 * 27)
     e1, s1, _ = env.episode_stats()
     assert s0 < 60 and s1 > 100, (s0, s1)
+
+
+def test_fused_rollout_step_equals_unfused_sequence():
+    """xrl_rollout_step_cartpole (one launch per step) must reproduce the seven-launch sequence it replaces."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    res = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        env = DeviceCartPoleVecEnv(100, seed=3)          # not a multiple of the 32-row tile
+        env.max_episode_steps = 30
+        agent = PPO_Agent(make_config(100, 48, use_fused_rollout=fused), env)
+        assert agent.use_fused_rollout == fused
+        agent.rollout()
+        agent.rollout()                                   # second rollout: state carried across the boundary
+        torch.cuda.synchronize()
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        if fused:
+            i = agent.horizon_size & 1
+            stats = dict(obs_mean=npy(agent.pp["obs_stats"][i][:4]), obs_var=npy(agent.pp["obs_stats"][i][4:]),
+                         ret_track=npy(agent.returns), eps=env.episode_stats())
+        else:
+            stats = dict(obs_mean=npy(agent.obs_mean), obs_var=npy(agent.obs_var), ret_track=npy(agent.returns),
+                         eps=env.episode_stats())
+        res.append((f, stats))
+    (fa, sa), (fb, sb) = res
+    assert np.array_equal(fa["actions"], fb["actions"]) and np.array_equal(fa["seg"], fb["seg"])
+    assert np.array_equal(fa["terminals"], fb["terminals"])
+    for k in ("observations", "values", "aux_old_logp", "rewards", "bootv", "advantages", "returns"):
+        assert_close(fb[k], fa[k], 2e-6, k, scale=max(1.0, float(np.abs(fa[k]).max())))
+    for k in ("obs_mean", "obs_var", "ret_track"):
+        assert_close(sb[k], sa[k], 1e-6, k)
+    assert sa["eps"][0] == sb["eps"][0] and sa["eps"][0] > 100

@@ -91,7 +91,33 @@ class Qmix(C.Structure):
                 ("gamma", c_float), ("pad", c_float)]
 
 
+class FusedLayer(C.Structure):
+    _fields_ = [("w_off", c_int32), ("b_off", c_int32), ("K", c_int32), ("N", c_int32), ("act", c_int32),
+                ("in_level", c_int32), ("in_off", c_int32), ("out_level", c_int32), ("out_off", c_int32), ("pad", c_int32)]
+
+
+class RolloutStep(C.Structure):
+    _fields_ = [("params", c_void_p), ("layers", FusedLayer * 8), ("n_layers", c_int32), ("n_levels", c_int32),
+                ("level_width", c_int32 * 6),
+                ("obs_raw_in", c_void_p), ("obs_raw_out", c_void_p), ("xnext_in", c_void_p), ("xnext_out", c_void_p),
+                ("obs_stats_in", c_void_p), ("obs_stats_out", c_void_p), ("obs_count_in", c_void_p),
+                ("obs_count_out", c_void_p), ("ret_stats_in", c_void_p), ("ret_stats_out", c_void_p),
+                ("ret_count_in", c_void_p), ("ret_count_out", c_void_p), ("ended_in", c_void_p), ("ended_out", c_void_p),
+                ("ret_final_in", c_void_p), ("ret_final_out", c_void_p), ("ret_track", c_void_p),
+                ("obs_slot", c_void_p), ("act_slot", c_void_p), ("val_slot", c_void_p), ("logp_slot", c_void_p),
+                ("rew_slot", c_void_p), ("term_slot", c_void_p), ("seg_slot", c_void_p), ("bootv_prev", c_void_p),
+                ("log_std", c_void_p),
+                ("cp_state", c_void_p), ("cp_steps", c_void_p), ("cp_episodes", c_void_p), ("cp_score", c_void_p),
+                ("cp_stats", c_void_p),
+                ("n", c_int32), ("D", c_int32), ("A", c_int32), ("gaussian", c_int32), ("max_steps", c_int32),
+                ("use_obsnorm", c_int32), ("use_rewnorm", c_int32), ("last_step", c_int32), ("boot_only", c_int32),
+                ("obs_range", c_float), ("rew_range", c_float), ("gamma", c_float),
+                ("seed", C.c_uint64), ("env_seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
+
+
 _SIGS = {
+    "xrl_init": [],
+    "xrl_rollout_step_cartpole": [C.POINTER(RolloutStep), c_void_p],
     "xrl_dqn_td": [C.POINTER(DqnTd), c_void_p],
     "xrl_qmix_mix_td": [C.POINTER(Qmix), c_void_p],
     "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],

@@ -65,6 +65,21 @@ class PPO_Agent:
         self._rollout_graph = None
         self._update_graph = None
         self._started = False
+        # fused rollout (one launch per vector step) for the device CartPole with a categorical policy
+        from ..envs.cartpole import DeviceCartPoleVecEnv
+        self.use_fused_rollout = bool(_get(config, "use_fused_rollout", True)) and isinstance(envs, DeviceCartPoleVecEnv) \
+            and self.model.dist == "categorical" and self.horizon_size % 2 == 0
+        if self.use_fused_rollout:
+            # ping-pong copies of everything one workgroup reads from another workgroup's previous step
+            self.pp = {"obs_raw": torch.zeros(2, n, D, device=dev), "xnext": torch.zeros(2, n, D, device=dev),
+                       "obs_stats": torch.stack([torch.cat([self.obs_mean, self.obs_var])] * 2).contiguous(),
+                       "obs_count": torch.full((2, 1), 1e-4, dtype=torch.float64, device=dev),
+                       "ret_stats": torch.tensor([[0.0, 1.0], [0.0, 1.0]], device=dev),
+                       "ret_count": torch.full((2, 1), 1e-4, dtype=torch.float64, device=dev),
+                       "ended": torch.zeros(2, n, dtype=torch.uint8, device=dev),
+                       "ret_final": torch.zeros(2, n, device=dev)}
+        if torch.cuda.is_available():
+            ops.init_device()
 
     # -- builders (same hooks as the reference) -----------------------------------------------------------
     @property
@@ -114,7 +129,37 @@ class PPO_Agent:
                              last_step=int(t == self.horizon_size - 1), obs_range=float(self.obsnorm_range),
                              rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
 
+    def _enqueue_rollout_fused(self):
+        """T launches of xrl_rollout_step_cartpole + one bootstrap-only launch + GAE (same numbers as _enqueue_rollout)."""
+        T, n, D, A = self.horizon_size, self.n_envs, self.obs_dim, self.model.action_dim
+        env, f, pp = self.envs, self.memory.soa.fields, self.pp
+        common = dict(params=self.model.params.flat, ret_track=self.returns, cp_state=env.state, cp_steps=env.steps,
+                      cp_episodes=env.episodes, cp_score=env.ep_score, cp_stats=env.stats, n=n, D=D, A=A, gaussian=0,
+                      max_steps=int(env.max_episode_steps), use_obsnorm=int(self.use_obsnorm),
+                      use_rewnorm=int(self.use_rewnorm), obs_range=float(self.obsnorm_range),
+                      rew_range=float(self.rewnorm_range), gamma=float(self.gamma), seed=self.seed, env_seed=env.seed,
+                      step_dev=self.step_counter)
+        for t in range(T):
+            i, o = t & 1, (t + 1) & 1
+            ops.rollout_step_cartpole(
+                self.model.plan, obs_raw_in=pp["obs_raw"][i], obs_raw_out=pp["obs_raw"][o], xnext_in=pp["xnext"][i],
+                xnext_out=pp["xnext"][o], obs_stats_in=pp["obs_stats"][i], obs_stats_out=pp["obs_stats"][o],
+                obs_count_in=pp["obs_count"][i], obs_count_out=pp["obs_count"][o], ret_stats_in=pp["ret_stats"][i],
+                ret_stats_out=pp["ret_stats"][o], ret_count_in=pp["ret_count"][i], ret_count_out=pp["ret_count"][o],
+                ended_in=pp["ended"][i], ended_out=pp["ended"][o], ret_final_in=pp["ret_final"][i],
+                ret_final_out=pp["ret_final"][o], obs_slot=f["observations"][t], act_slot=f["actions"][t],
+                val_slot=f["values"][t], logp_slot=f["aux_old_logp"][t], rew_slot=f["rewards"][t],
+                term_slot=f["terminals"][t], seg_slot=f["seg"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None,
+                last_step=int(t == T - 1), boot_only=0, step=t, **common)
+        ops.rollout_step_cartpole(self.model.plan, xnext_in=pp["xnext"][T & 1], bootv_prev=f["bootv"][T - 1], boot_only=1,
+                                  last_step=0, step=0, **common)
+        ops.counter_add(self.step_counter, T)
+        ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
+                     self.gamma, self.gae_lam, self.memory.use_gae)
+
     def _enqueue_rollout(self):
+        if self.use_fused_rollout:
+            return self._enqueue_rollout_fused()
         T, n, A = self.horizon_size, self.n_envs, self.model.action_dim
         for t in range(T):
             self._enqueue_step(t)
@@ -154,6 +199,8 @@ class PPO_Agent:
     def rollout(self):
         if not self._started:
             self.envs.reset()
+            if self.use_fused_rollout:
+                self.pp["obs_raw"][0].copy_(self.envs.buf_obs)
             self._started = True
         if self.use_graph:
             if self._rollout_graph is None:

@@ -7,31 +7,10 @@
 // All of these are latency-bound at the reference's sizes (n_envs <= a few thousand): each is ONE small launch per
 // step with coalesced [env]-major accesses, meant to be replayed from a hipGraph.
 #include "common.h"
+#include "rng.h"
+#include "cartpole.h"
 
 namespace xrl {
-
-// ------------------------------------------------------------------------------------------------ Philox4x32-10
-// Counter-based RNG (Salmon et al., SC'11).  key = (seed_lo, seed_hi), counter = (env, step, stream, 0).
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-}
-__device__ __forceinline__ void philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t (&out)[4]) {
-    uint32_t c[4] = {c0, c1, c2, 0u};
-    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-    for (int i = 0; i < 10; ++i) philox_round(c, k);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = c[i];
-}
-__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }          // [0,1)
-__device__ __forceinline__ double u01d(uint32_t a, uint32_t b) {
-    return (double)((((uint64_t)a << 21) ^ (uint64_t)b) & ((1ull << 53) - 1)) * (1.0 / 9007199254740992.0);
-}
 
 // ------------------------------------------------------------------------------------------------ running mean/std
 
@@ -120,7 +99,7 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(xrl_sample_t p) {
     if (!p.gaussian) {
         float u;
         if (p.noise) u = p.noise[e];
-        else { uint32_t r[4]; philox4x32(p.seed, (uint32_t)e, step, 0x41435431u, r); u = u01(r[0]); }
+        else { uint32_t r[4]; philox4x32(p.seed, (uint32_t)e, step, STREAM_ACTION, r); u = u01(r[0]); }
         float mx = h[0];
         for (int j = 1; j < A; ++j) mx = fmaxf(mx, h[j]);
         float se = 0.f;
@@ -143,7 +122,7 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(xrl_sample_t p) {
             if (p.noise) z = p.noise[(size_t)e * A + j];
             else {
                 uint32_t r[4];
-                philox4x32(p.seed, (uint32_t)e, step, 0x47415500u + (uint32_t)j, r);
+                philox4x32(p.seed, (uint32_t)e, step, STREAM_GAUSS + (uint32_t)j, r);
                 const float u1 = fmaxf(u01(r[0]), 5.96e-8f), u2 = u01(r[1]);
                 z = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
             }
@@ -161,30 +140,14 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(xrl_sample_t p) {
 
 // ------------------------------------------------------------------------------------------------ CartPole-v1
 
-__device__ __forceinline__ void cartpole_reset(double* s, uint64_t seed, int e, uint32_t episode) {
-    uint32_t r[4], q[4];
-    philox4x32(seed, (uint32_t)e, episode, 0x52455345u, r);
-    philox4x32(seed, (uint32_t)e, episode, 0x52455346u, q);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = -0.05 + 0.1 * u01d(r[j], q[j]);   // uniform(-0.05, 0.05)
-}
-
 __global__ void __launch_bounds__(256) cartpole_step_kernel(xrl_cartpole_t p) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.n) return;
-    const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
-    const double total_mass = masspole + masscart, polemass_length = masspole * length;
-    const double theta_thr = 12.0 * 2.0 * 3.14159265358979323846 / 360.0, x_thr = 2.4;
     double* s = p.state + (size_t)e * 4;
-    double x = s[0], xd = s[1], th = s[2], thd = s[3];
-    const double force = p.action[e] == 1 ? force_mag : -force_mag;
-    const double ct = cos(th), st = sin(th);
-    const double temp = (force + polemass_length * thd * thd * st) / total_mass;
-    const double thacc = (gravity * st - ct * temp) / (length * (4.0 / 3.0 - masspole * ct * ct / total_mass));
-    const double xacc = temp - polemass_length * thacc * ct / total_mass;
-    x = x + tau * xd; xd = xd + tau * xacc; th = th + tau * thd; thd = thd + tau * thacc;   // explicit Euler
+    double x, xd, th, thd;
+    bool term;
+    cartpole_advance(s, p.action[e], x, xd, th, thd, term);
     const int steps = p.steps[e] + 1;
-    const bool term = (x < -x_thr) || (x > x_thr) || (th < -theta_thr) || (th > theta_thr);
     const bool trunc = steps >= p.max_steps;
     float* no = p.next_obs + (size_t)e * 4;
     no[0] = (float)x; no[1] = (float)xd; no[2] = (float)th; no[3] = (float)thd;
@@ -302,7 +265,7 @@ __global__ void __launch_bounds__(256) egreedy_kernel(xrl_egreedy_t p) {
     for (int j = 1; j < p.A; ++j) if (q[j] > bv) { bv = q[j]; best = j; }     // argmax: first maximal index
     const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
     uint32_t r[4];
-    philox4x32(p.seed, (uint32_t)e, step, 0x45475200u, r);
+    philox4x32(p.seed, (uint32_t)e, step, STREAM_EGREEDY, r);
     const float u = p.uniforms ? p.uniforms[e] : u01(r[0]);
     const int ra = p.randoms ? p.randoms[e] : (int)(r[1] % (uint32_t)p.A);
     const int a = (u < *p.eps_dev) ? ra : best;

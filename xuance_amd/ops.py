@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, call, ptr,
+from ._lib import (ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, call, ptr,
                    stream_ptr)
 
 
@@ -158,6 +158,38 @@ def egreedy(**kw):
     call("xrl_egreedy", C.byref(_struct(EGreedy, kw)), stream_ptr())
 
 
+_inited = False
+
+
+def init_device():
+    """xrl_init once per process (kernel attributes); must happen outside hipGraph capture."""
+    global _inited
+    if not _inited:
+        call("xrl_init")
+        _inited = True
+
+
+def fused_layers_from_plan(plan, p):
+    """Fill p.layers / level widths of an xrl_rollout_step_t from a nets.Plan (stage order = execution order)."""
+    li = 0
+    for stage in plan.stages:
+        for L in stage:
+            f = p.layers[li]
+            f.w_off, f.b_off = plan.params.offsets[L.w_name], plan.params.offsets[L.b_name]
+            f.K, f.N, f.act = L.K, L.N, ACT[L.act]
+            f.in_level, f.in_off, f.out_level, f.out_off = L.in_level, L.in_off, L.out_level, L.out_off
+            li += 1
+    p.n_layers, p.n_levels = li, len(plan.widths)
+    for i, w in enumerate(plan.widths):
+        p.level_width[i] = w
+
+
+def rollout_step_cartpole(plan, **kw):
+    p = _struct(RolloutStep, kw)
+    fused_layers_from_plan(plan, p)
+    call("xrl_rollout_step_cartpole", C.byref(p), stream_ptr())
+
+
 def dqn_td(**kw):
     call("xrl_dqn_td", C.byref(_struct(DqnTd, kw)), stream_ptr())
 
@@ -183,6 +215,7 @@ class Graph:
         self.stream = None
 
     def __enter__(self):
+        init_device()
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         self._ctx = torch.cuda.stream(self.stream)
