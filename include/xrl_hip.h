@@ -273,8 +273,10 @@ typedef struct {
 
 typedef struct {
     const float* params;                               /* flat parameter buffer */
+    const float* cache_image;                          /* packed LDS parameter-cache image (xrl_pack_rollout_cache) */
     xrl_fused_layer_t layers[XRL_FUSED_MAX_LAYERS];
     int32_t n_layers, n_levels;
+    int32_t n_head_layers, pad0;                       /* trailing layers that write the last (head) level */
     int32_t level_width[XRL_FUSED_MAX_LEVELS];        /* level 0 = observation */
     /* cross-workgroup state, ping-ponged by the host */
     const float* obs_raw_in;   float* obs_raw_out;     /* [n][D] raw observation the agent acts on */
@@ -297,8 +299,13 @@ typedef struct {
     float obs_range, rew_range, gamma;
     uint64_t seed, env_seed;
     uint32_t step; const uint32_t* step_dev;
+    long long* dbg;                                    /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
 } xrl_rollout_step_t;
 int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
+/* Re-pack the small parameters (first layer, biases, merged heads) into the image the step kernel copies to LDS with
+ * one round trip; call once per rollout after the parameters changed.  Only params/layers/levels of *p are read. */
+int xrl_pack_rollout_cache(const xrl_rollout_step_t* p, float* image, int64_t image_floats, xrl_stream_t stream);
+int64_t xrl_rollout_cache_floats(const xrl_rollout_step_t* p);
 
 /* ------------------------------------------------------------------ TD targets: DQN and QMIX */
 
@@ -351,6 +358,9 @@ int xrl_qmix_mix_td(const xrl_qmix_t* p, xrl_stream_t stream);
  * (dqn_learner.py:56-57, qmix_learner.py:105-106; copy_target deep_q_network.py:95-99). */
 int xrl_sync_target(const float* params, float* target, int64_t P, const xrl_adam_state_t* state,
                     int sync_frequency, xrl_stream_t stream);
+
+/* diagnostics: `iters` dependent v_mfma_f32_32x32x2_f32 per wave; out[0] shader cycles, out[1] wall-clock ticks */
+int xrl_debug_mfma_chain(int iters, int blocks, long long* out, float* sink, xrl_stream_t stream);
 
 /* ------------------------------------------------------------------ hipGraph capture of op sequences */
 int xrl_graph_begin(xrl_stream_t stream);

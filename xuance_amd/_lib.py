@@ -97,8 +97,8 @@ class FusedLayer(C.Structure):
 
 
 class RolloutStep(C.Structure):
-    _fields_ = [("params", c_void_p), ("layers", FusedLayer * 8), ("n_layers", c_int32), ("n_levels", c_int32),
-                ("level_width", c_int32 * 6),
+    _fields_ = [("params", c_void_p), ("cache_image", c_void_p), ("layers", FusedLayer * 8), ("n_layers", c_int32), ("n_levels", c_int32),
+                ("n_head_layers", c_int32), ("pad0", c_int32), ("level_width", c_int32 * 6),
                 ("obs_raw_in", c_void_p), ("obs_raw_out", c_void_p), ("xnext_in", c_void_p), ("xnext_out", c_void_p),
                 ("obs_stats_in", c_void_p), ("obs_stats_out", c_void_p), ("obs_count_in", c_void_p),
                 ("obs_count_out", c_void_p), ("ret_stats_in", c_void_p), ("ret_stats_out", c_void_p),
@@ -112,12 +112,15 @@ class RolloutStep(C.Structure):
                 ("n", c_int32), ("D", c_int32), ("A", c_int32), ("gaussian", c_int32), ("max_steps", c_int32),
                 ("use_obsnorm", c_int32), ("use_rewnorm", c_int32), ("last_step", c_int32), ("boot_only", c_int32),
                 ("obs_range", c_float), ("rew_range", c_float), ("gamma", c_float),
-                ("seed", C.c_uint64), ("env_seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
+                ("seed", C.c_uint64), ("env_seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p),
+                ("dbg", c_void_p)]
 
 
 _SIGS = {
     "xrl_init": [],
+    "xrl_debug_mfma_chain": [c_int, c_int, c_void_p, c_void_p, c_void_p],
     "xrl_rollout_step_cartpole": [C.POINTER(RolloutStep), c_void_p],
+    "xrl_pack_rollout_cache": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p],
     "xrl_dqn_td": [C.POINTER(DqnTd), c_void_p],
     "xrl_qmix_mix_td": [C.POINTER(Qmix), c_void_p],
     "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],
@@ -151,7 +154,7 @@ _lib = None
 
 def exported_symbols():
     """Names every entry point include/xrl_hip.h declares (checked by the CPU test-suite)."""
-    return ["xrl_version", "xrl_last_error"] + list(_SIGS)
+    return ["xrl_version", "xrl_last_error", "xrl_rollout_cache_floats"] + list(_SIGS)
 
 
 def load():
@@ -168,6 +171,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.xrl_version.restype = C.c_char_p
     lib.xrl_last_error.restype = C.c_char_p
+    lib.xrl_rollout_cache_floats.restype = c_int64
+    lib.xrl_rollout_cache_floats.argtypes = [C.POINTER(RolloutStep)]
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args

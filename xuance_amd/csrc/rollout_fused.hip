@@ -2,16 +2,22 @@
 // device-resident CartPole.  See include/xrl_hip.h (xrl_rollout_step_t) for the dataflow contract.
 //
 // Why: at the reference's sizes (256..1024 envs, 34k-parameter net) a vector step is ~17 MFLOP and ~20 KB of
-// traffic -- far below one launch's worth of roofline work -- so the seven-launch unfused sequence spends its time
-// on kernel boundaries (measured ~4.5 us each, profiles/r01_a_*).  Here a workgroup keeps a 32-row tile of every
-// activation level in LDS, streams the (L2-resident) weights straight into MFMA B-fragments and finishes sampling,
-// physics and bookkeeping for its 32 envs before exiting.
+// traffic -- far below one launch's worth of roofline work -- so the step is bound by *dependent latencies*: kernel
+// boundaries (1.6 us each) and global-memory round trips (~1 us each right after a boundary; measured with the
+// shader-clock stamps behind p.dbg).  The design therefore minimises round trips, not bytes or flops:
+//   * one launch; a workgroup keeps a 32-row tile of every activation level in LDS for the whole MLP;
+//   * every global load the kernel will ever need is ISSUED in the first few hundred cycles: biases and the small
+//     layers' weights are copied into an LDS parameter cache, the first big layer's B-fragments go straight into
+//     registers (16 x 16 B per lane), raw observations / flags for the statistics are loaded at the same time, so all of
+//     them share one round trip that ends at the first barrier;
+//   * statistics that couple all envs are recomputed per workgroup from the (tiny) previous-step arrays instead of
+//     being synchronised across workgroups.
 //
-// MFMA mapping (64-wide wavefronts): v_mfma_f32_32x32x2_f32, the tile's 32 rows are the M dimension, each wave owns
-// 32-column output tiles.  A-fragments are ds_read_b128 from the LDS activations (row stride = roundup8(width)+4
-// floats: conflict-free), B-fragments are 16-byte global loads of 4 consecutive k of one weight row per lane; as in
-// gemm.hip lane-half h consumes k = 8q+4h+s so both operands use the same k permutation.  Layers with fewer than 4
-// column tiles (the heads) split K over the 4 waves and reduce through LDS in a fixed order.
+// MFMA mapping (64-wide wavefronts): v_mfma_f32_32x32x2_f32, the tile's 32 rows are M, each of the 8 waves owns 32-column
+// output tiles.  A-fragments are ds_read_b128 from the LDS activations (row stride roundup8(width)+4 floats:
+// conflict-free), B-fragments are 4 consecutive k of one weight row per lane (ds_read_b128 from the parameter cache or a
+// 16-byte global load); as in gemm.hip lane-half h consumes k = 8q+4h+s so both operands share one k permutation.
+// Layers with fewer than 8 column tiles split K over waves and reduce the partial tiles through LDS in wave order.
 #include "common.h"
 #include "rng.h"
 #include "cartpole.h"
@@ -20,52 +26,86 @@ namespace xrl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int FT = 32;             // rows per tile
-constexpr int FUSED_THREADS = 256; // 4 waves
+constexpr int FT = 32;               // rows per tile
+constexpr int FUSED_THREADS = 512;   // 8 waves
+constexpr int NW = FUSED_THREADS / 64;
+constexpr int PD = 16;               // prefetched B chunks (of 8 k) held in registers for the first big layer
+constexpr int SMALL_W = 4608;        // a layer whose padded weights fit in this many floats lives in the LDS cache
 
 __host__ __device__ inline int level_ld(int width) { return ((width + 7) / 8) * 8 + 4; }
+__host__ __device__ inline bool layer_small(int N, int K) { return N * level_ld(K) <= SMALL_W; }
 
-// out[32][N] (+out_off) = act(in[32][K] (+in_off) . W[N][K]^T + b)      in/out: LDS tiles, W/b: global
-__device__ __forceinline__ void fused_layer(const float* __restrict__ W, const float* __restrict__ bias, int K, int N,
-                                            int act, const float* in, int ld_in, float* out, int ld_out, float* red) {
+#define MFMA4(a, b, acc)                                                         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).x, (b).x, acc, 0, 0, 0);      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).y, (b).y, acc, 0, 0, 0);      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).z, (b).z, acc, 0, 0, 0);      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).w, (b).w, acc, 0, 0, 0);
+
+// out[32][N] = act(in[32][K] . W[N][K]^T + bias)   in/out: LDS tiles.  Wl != null: weights in the LDS cache with row
+// stride ldw (zero padded); else Wg in global memory, and pf[] holds this wave's first PD chunks when `use_pf`.
+__device__ __forceinline__ void fused_layer(const float* __restrict__ Wg, const float* Wl, int ldw, const float* bias_l,
+                                            int K, int N, int act, const float* in, int ld_in, float* out, int ld_out,
+                                            float* red, const float4 (&pf)[PD], bool use_pf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int n_tiles = (N + 31) / 32;
-    const int kq = (K + 7) / 8;    // chunks of 8 k
-    const bool vecW = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
-    const bool split_k = n_tiles < 4;
-    for (int tile = split_k ? 0 : wave; tile < n_tiles; tile += split_k ? 1 : 4) {
+    const int kq = (K + 7) / 8;
+    const bool fast_g = ((K & 7) == 0) && ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0);
+    const int wpt = n_tiles >= NW ? 1 : NW / n_tiles;               // waves per tile (split-K factor)
+    const int tiles_per_pass = NW / wpt;
+    for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_pass) {
+        const int tile = t0 + wave / wpt, ks = wave % wpt;
+        const bool live = tile < n_tiles && (wave / wpt) < tiles_per_pass;
         const int n0 = tile * 32;
-        const int wr = n0 + li;                                   // weight row of this lane's B fragment
-        const float* wrow = W + (size_t)wr * K;
+        const int wr = min(n0 + li, N - 1);   // rows >= N only feed output columns that are never stored: clamp
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const int q0 = split_k ? wave : 0, qs = split_k ? 4 : 1;
+        if (live) {
+            const float* arow = in + li * ld_in + 4 * lh;
+            if (Wl) {
+                const float* wrow = Wl + wr * ldw + 4 * lh;
 #pragma unroll 4
-        for (int q = q0; q < kq; q += qs) {
-            const int kk = q * 8 + 4 * lh;
-            const float4 a = *reinterpret_cast<const float4*>(&in[li * ld_in + kk]);
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (wr < N) {
-                if (vecW && kk + 3 < K) b = *reinterpret_cast<const float4*>(wrow + kk);
-                else {
-                    if (kk + 0 < K) b.x = wrow[kk + 0];
-                    if (kk + 1 < K) b.y = wrow[kk + 1];
-                    if (kk + 2 < K) b.z = wrow[kk + 2];
-                    if (kk + 3 < K) b.w = wrow[kk + 3];
+                for (int q = ks; q < kq; q += wpt) {
+                    const float4 b = *reinterpret_cast<const float4*>(wrow + q * 8);
+                    const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
+                    MFMA4(a, b, acc)
+                }
+            } else if (fast_g) {
+                const float* wrow = Wg + (size_t)wr * K + 4 * lh;
+                int qstart = 0;
+                if (use_pf && t0 == 0 && wpt == 1) {                // chunks 0..PD-1 are already in registers
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) {
+                        if (q < kq) { const float4 a = *reinterpret_cast<const float4*>(arow + q * 8); MFMA4(a, pf[q], acc) }
+                    }
+                    qstart = PD;
+                }
+#pragma unroll 8
+                for (int q = qstart + ks; q < kq; q += wpt) {
+                    const float4 b = *reinterpret_cast<const float4*>(wrow + q * 8);
+                    const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
+                    MFMA4(a, b, acc)
+                }
+            } else {
+                const float* wrow = Wg + (size_t)wr * K;
+                for (int q = ks; q < kq; q += wpt) {
+                    const int kk = q * 8 + 4 * lh;
+                    const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
+                    float4 b;
+                    b.x = kk + 0 < K ? wrow[kk + 0] : 0.f;
+                    b.y = kk + 1 < K ? wrow[kk + 1] : 0.f;
+                    b.z = kk + 2 < K ? wrow[kk + 2] : 0.f;
+                    b.w = kk + 3 < K ? wrow[kk + 3] : 0.f;
+                    MFMA4(a, b, acc)
                 }
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
         // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        if (!split_k) {
+        if (wpt == 1) {
             const int col = n0 + li;
-            if (col < N) {
-                const float bv = bias[col];
+            if (live && col < N) {
+                const float bv = bias_l[col];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -73,21 +113,19 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ W, const f
                 }
             }
         } else {
-            // partial tiles of the 4 waves -> red[wave][row][33], summed in wave order (deterministic)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 red[(wave * 32 + row) * 33 + li] = acc[r];
             }
             __syncthreads();
-            for (int i = threadIdx.x; i < 32 * 32; i += FUSED_THREADS) {
-                const int row = i >> 5, c = i & 31, col = n0 + c;
-                if (col < N) {
-                    float v = red[(0 * 32 + row) * 33 + c];
-                    v += red[(1 * 32 + row) * 33 + c];
-                    v += red[(2 * 32 + row) * 33 + c];
-                    v += red[(3 * 32 + row) * 33 + c];
-                    out[row * ld_out + col] = act_apply(v + bias[col], act);
+                for (int i = threadIdx.x; i < tiles_per_pass * 32 * 32; i += FUSED_THREADS) {
+                const int tl = i >> 10, row = (i >> 5) & 31, c = i & 31;
+                const int col = (t0 + tl) * 32 + c;
+                if (t0 + tl < n_tiles && col < N) {
+                    float v = 0.f;
+                    for (int w = 0; w < wpt; ++w) v += red[((tl * wpt + w) * 32 + row) * 33 + c];   // fixed order
+                    out[row * ld_out + col] = act_apply(v + bias_l[col], act);
                 }
             }
             __syncthreads();
@@ -96,88 +134,155 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ W, const f
     __syncthreads();
 }
 
+// Layer roles (host order = execution order): layers[0] is the first layer (K = D = 4, evaluated on the VALU while the
+// observation is normalised -- bitwise the same k-ordered fma chain the MFMA would produce), the last n_head layers all
+// write the head level and are merged into ONE block-structured layer in the LDS cache, everything between runs on MFMA.
 __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xrl_rollout_step_t p) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ double part[FUSED_THREADS];
-    __shared__ double bmean[64], bvar[64];
-    __shared__ float s_mean[64], s_std[64];
+    __shared__ double part[2 * NW * 4];
+    __shared__ float s_mean[4], s_std[4];
     __shared__ float s_ret[2];
-    __shared__ unsigned long long s_mask[64];
 
-    const int tid = threadIdx.x, n = p.n, D = p.D, A = p.A;
+    constexpr int D = 4;
+    const int tid = threadIdx.x, n = p.n, A = p.A;
+    long long* dbg = p.dbg;
+    int dbi = 0;
+#define STAMP() do { if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) dbg[dbi++] = clock64(); } while (0)
+    STAMP();
     const int n_act_tiles = (n + FT - 1) / FT;
     const bool boot = p.boot_only || ((int)blockIdx.x >= n_act_tiles);
     const int tile = p.boot_only ? blockIdx.x : (boot ? blockIdx.x - n_act_tiles : blockIdx.x);
     const int e0 = tile * FT;
+    const int lane = tid & 63, wave = tid >> 6, li_ = lane & 31, lh_ = lane >> 5;
+    const int nL = p.n_layers, nH = p.n_head_layers, nLv = p.n_levels;
+    const int first_mid = 1, end_mid = nL - nH;                      // MFMA layers [first_mid, end_mid)
 
-    // LDS carve: level buffers, then the split-K reduction scratch (offsets kept in LDS: they are indexed at run time)
-    __shared__ int lvl_off[XRL_FUSED_MAX_LEVELS], lvl_ld[XRL_FUSED_MAX_LEVELS];
+    // ---- LDS carve (uniform arithmetic): activation levels 1.., split-K scratch, parameter cache
+    int lvl_off[XRL_FUSED_MAX_LEVELS], lvl_ld[XRL_FUSED_MAX_LEVELS];  // small, fully unrolled uses only
     int off = 0;
-    for (int l = 0; l < p.n_levels; ++l) {
-        const int ld = level_ld(p.level_width[l]);
-        if (tid == 0) { lvl_ld[l] = ld; lvl_off[l] = off; }
-        off += FT * ld;
+#pragma unroll
+    for (int l = 0; l < XRL_FUSED_MAX_LEVELS; ++l) {
+        lvl_ld[l] = l < nLv ? level_ld(p.level_width[l]) : 0;
+        lvl_off[l] = off;
+        if (l >= 1 && l < nLv) off += FT * lvl_ld[l];
     }
-    float* red = lds + off;
-    for (int i = tid; i < off; i += FUSED_THREADS) lds[i] = 0.f;      // padding columns must read as zero
+    const int acts_end = off;
+    float* red = lds + off;             off += NW * 32 * 33;
+    const xrl_fused_layer_t& L0 = p.layers[0];
+    off = (off + 3) / 4 * 4;
+    const int c_w0 = off;               off += L0.N * 4;              // first layer weights [N0][4]
+    const int c_b0 = off;               off += (L0.N + 3) / 4 * 4;
+    int c_bm[XRL_FUSED_MAX_LAYERS], c_wm[XRL_FUSED_MAX_LAYERS];
+#pragma unroll
+    for (int l = 0; l < XRL_FUSED_MAX_LAYERS; ++l) {
+        c_bm[l] = off; c_wm[l] = -1;
+        if (l >= first_mid && l < end_mid) {
+            off += (p.layers[l].N + 3) / 4 * 4;
+            if (layer_small(p.layers[l].N, p.layers[l].K)) { c_wm[l] = off; off += p.layers[l].N * level_ld(p.layers[l].K); }
+        }
+    }
+    const int KH = p.level_width[nLv - 2], NH = p.level_width[nLv - 1], ldH = level_ld(KH);
+    const int c_wh = off;               off += NH * ldH;              // merged head weights [NH][ldH]
+    const int c_bh = off;               off += (NH + 3) / 4 * 4;
+
+    // ---- issue EVERY global load now.  (1) B-fragments of the first big MFMA layer straight into registers
+    float4 pf[PD];
+    int pf_layer = -1;
+#pragma unroll
+    for (int l = 1; l < XRL_FUSED_MAX_LAYERS; ++l) {
+        if (pf_layer < 0 && l >= first_mid && l < end_mid && c_wm[l] < 0) {
+            const xrl_fused_layer_t& L = p.layers[l];
+            const float* Wg = p.params + L.w_off;
+            if ((L.N + 31) / 32 >= NW && (L.K & 7) == 0 && ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0)) {
+                pf_layer = l;
+                const int kq = L.K / 8;
+                const float* wrow = Wg + (size_t)min(wave * 32 + li_, L.N - 1) * L.K + 4 * lh_;
+#pragma unroll
+                for (int q = 0; q < PD; ++q) pf[q] = q < kq ? *reinterpret_cast<const float4*>(wrow + q * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    // (2) this thread's row of the tile (16 threads share a row) and, for act tiles, its share of ALL raw observations
+    const int r = tid >> 4, sub = tid & 15, e_row = e0 + r;
+    float4 xrow = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e_row < n) xrow = *reinterpret_cast<const float4*>((boot ? p.xnext_in : p.obs_raw_in) + (size_t)e_row * D);
+    double s1 = 0.0, s2 = 0.0;                                      // sums for dimension d = tid & 3
+    unsigned long long ended_mask[16];
+    if (!boot) {
+        if (p.use_obsnorm) {
+            float sv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int i = tid + j * FUSED_THREADS; sv[j] = i < n * D ? p.obs_raw_in[i] : 0.f; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const double v = (double)sv[j]; s1 += v; s2 += v * v; }
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const int e = j * 64 + lane; ended_mask[j] = __ballot(e < n && p.ended_in[e] != 0); }
+        }
+    }
+    // (3) the LDS parameter cache is a flat copy of the image xrl_pack_rollout_cache built once per rollout (same layout:
+    //     first-layer W | b | middle biases (+ small middle weights, zero padded) | merged head W | head b): every
+    //     thread issues its <= 4 independent 16-byte loads back to back, so the whole cache costs ONE round trip.
+    const int pc_base = c_w0, pc_floats = off - c_w0;
+    float4 img[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i4 = (tid + j * FUSED_THREADS) * 4;
+        img[j] = i4 < pc_floats ? *reinterpret_cast<const float4*>(p.cache_image + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i4 = (tid + 4 * FUSED_THREADS) * 4; i4 < pc_floats; i4 += FUSED_THREADS * 4)      // larger nets: plain tail
+        *reinterpret_cast<float4*>(&lds[pc_base + i4]) = *reinterpret_cast<const float4*>(p.cache_image + i4);
+    // (4) zero the activation tiles (padding columns must read as zero) while the loads are in flight
+    for (int i = tid; i < acts_end; i += FUSED_THREADS) lds[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i4 = (tid + j * FUSED_THREADS) * 4;
+        if (i4 < pc_floats) *reinterpret_cast<float4*>(&lds[pc_base + i4]) = img[j];
+    }
 
     if (!boot) {
         // ---- deferred ret_rms.update() of the episodes that ended at the previous step, in env order (ppo_agent.py:146-149)
-        if (tid < 64) {
+        if (wave == 0) {
             float mean = p.ret_stats_in[0], var = p.ret_stats_in[1];
             double count = *p.ret_count_in;
-            for (int base = 0; base < n; base += 64) {
-                const int e = base + tid;
-                const unsigned long long m = __ballot(e < n && p.ended_in[e] != 0);
-                unsigned long long mm = m;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                unsigned long long mm = ended_mask[j];
                 while (mm) {                                            // wave-uniform loop over finished envs
-                    const int bpos = __ffsll((long long)mm) - 1;
-                    mm &= mm - 1;
-                    const float bm = p.ret_final_in[base + bpos];
-                    const double tot = count + 1.0;
-                    const float delta = bm - mean;
+                    const int bpos = __ffsll((long long)mm) - 1; mm &= mm - 1;
+                    const float bm = p.ret_final_in[j * 64 + bpos];
+                    const double tot = count + 1.0; const float delta = bm - mean;
                     const float new_mean = mean + delta * 1.0f / (float)tot;
-                    const float m_a = var * (float)count;
-                    const float M2 = m_a + 0.f + (delta * delta) * (float)count * 1.0f / (float)tot;
+                    const float M2 = var * (float)count + 0.f + (delta * delta) * (float)count * 1.0f / (float)tot;
                     mean = new_mean; var = M2 / (float)tot; count = tot;
                 }
             }
-            if (tid == 0) {
+            if (lane == 0) {
                 s_ret[0] = mean; s_ret[1] = var;
                 if (blockIdx.x == 0) { p.ret_stats_out[0] = mean; p.ret_stats_out[1] = var; *p.ret_count_out = count; }
             }
         }
-        // ---- obs_rms.update(obs) over ALL envs (recomputed per workgroup), then normalise this tile's rows
+        // ---- obs_rms.update(obs) over ALL envs, recomputed per workgroup: one pass, sum / sum of squares in float64
         if (p.use_obsnorm) {
-            const int R = FUSED_THREADS / D;
-            const int d = tid % D, r0 = tid / D;
-            const bool live = r0 < R;
-            double s = 0.0;
-            if (live) for (int r = r0; r < n; r += R) s += (double)p.obs_raw_in[(size_t)r * D + d];
-            part[tid] = live ? s : 0.0;
-            __syncthreads();
-            if (tid < D) {
-                double t = 0.0;
-                for (int r = 0; r < R; ++r) t += part[r * D + tid];
-                bmean[tid] = (double)(float)(t / n);
-            }
-            __syncthreads();
-            double q = 0.0;
-            if (live) {
-                const double m = bmean[d];
-                for (int r = r0; r < n; r += R) { const double df = (double)p.obs_raw_in[(size_t)r * D + d] - m; q += df * df; }
-            }
-            part[tid] = live ? q : 0.0;
-            __syncthreads();
-            if (tid < D) {
-                double t = 0.0;
-                for (int r = 0; r < R; ++r) t += part[r * D + tid];
-                const float bstd = (float)sqrt(t / n);
-                const float bv = bstd * bstd, bm = (float)bmean[tid];
+            for (int o = 32; o >= D; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (lane < D) { part[wave * 4 + lane] = s1; part[NW * 4 + wave * 4 + lane] = s2; }
+        }
+    }
+    __syncthreads();
+    if (!boot) {
+        if (tid < D) {
+            if (p.use_obsnorm) {
+                double a = 0.0, b = 0.0;
+                for (int w = 0; w < NW; ++w) { a += part[w * 4 + tid]; b += part[NW * 4 + w * 4 + tid]; }
+                const double m = a / n;
+                const float bm = (float)m;                              // np.mean -> float32
+                const float bstd = (float)sqrt(fmax(b / n - m * m, 0.0));          // np.std -> float32
+                const float bv = bstd * bstd;                           // batch_var = np.square(batch_std)
                 const double cnt = *p.obs_count_in, tot = cnt + (double)n;
                 const float mean = p.obs_stats_in[tid], var = p.obs_stats_in[D + tid];
-                const float delta = bm - mean;
+                const float delta = bm - mean;                          // update_from_moments (statistic_tools.py:173-185)
                 const float new_mean = mean + delta * (float)n / (float)tot;
                 const float m_a = var * (float)cnt, m_b = bv * (float)n;
                 const float M2 = m_a + m_b + (delta * delta) * (float)cnt * (float)n / (float)tot;
@@ -187,37 +292,50 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
                     p.obs_stats_out[tid] = new_mean; p.obs_stats_out[D + tid] = new_var;
                     if (tid == 0) *p.obs_count_out = tot;
                 }
-            }
-        } else if (tid < D) { s_mean[tid] = 0.f; s_std[tid] = 1.f; }
-        __syncthreads();
-        for (int i = tid; i < FT * D; i += FUSED_THREADS) {
-            const int r = i / D, d = i - r * D, e = e0 + r;
-            float v = 0.f;
-            if (e < n) {
-                v = p.obs_raw_in[(size_t)e * D + d];
-                if (p.use_obsnorm) { v = (v - s_mean[d]) / (s_std[d] + 1e-8f); v = fminf(fmaxf(v, -p.obs_range), p.obs_range); }
-                p.obs_slot[(size_t)e * D + d] = v;                      // memory.observations[t] (ppo_agent.py:128)
-            }
-            lds[lvl_off[0] + r * lvl_ld[0] + d] = v;
+            } else { s_mean[tid] = 0.f; s_std[tid] = 1.f; }
         }
-    } else {
         __syncthreads();
-        for (int i = tid; i < FT * D; i += FUSED_THREADS) {
-            const int r = i / D, d = i - r * D, e = e0 + r;
-            lds[lvl_off[0] + r * lvl_ld[0] + d] = (e < n) ? p.xnext_in[(size_t)e * D + d] : 0.f;
+        if (p.use_obsnorm) {
+            xrow.x = fminf(fmaxf((xrow.x - s_mean[0]) / (s_std[0] + 1e-8f), -p.obs_range), p.obs_range);
+            xrow.y = fminf(fmaxf((xrow.y - s_mean[1]) / (s_std[1] + 1e-8f), -p.obs_range), p.obs_range);
+            xrow.z = fminf(fmaxf((xrow.z - s_mean[2]) / (s_std[2] + 1e-8f), -p.obs_range), p.obs_range);
+            xrow.w = fminf(fmaxf((xrow.w - s_mean[3]) / (s_std[3] + 1e-8f), -p.obs_range), p.obs_range);
+        }
+        if (sub == 0 && e_row < n) *reinterpret_cast<float4*>(p.obs_slot + (size_t)e_row * D) = xrow;   // memory.observations[t]
+    }
+    STAMP();
+    // ---- first layer on the VALU: out = act(fma(x3,w3, fma(x2,w2, fma(x1,w1, x0*w0))) + b), 16 threads per row
+    {
+        float* o1 = lds + lvl_off[L0.out_level] + L0.out_off + r * lvl_ld[L0.out_level];
+        for (int c = sub; c < L0.N; c += 16) {
+            const float4 w = *reinterpret_cast<const float4*>(&lds[c_w0 + c * 4]);
+            float acc = __fmaf_rn(xrow.x, w.x, 0.f);
+            acc = __fmaf_rn(xrow.y, w.y, acc);
+            acc = __fmaf_rn(xrow.z, w.z, acc);
+            acc = __fmaf_rn(xrow.w, w.w, acc);
+            o1[c] = act_apply(acc + lds[c_b0 + c], L0.act);
         }
     }
     __syncthreads();
-
-    // ---- the whole actor-critic MLP on the LDS-resident tile
-    for (int li = 0; li < p.n_layers; ++li) {
-        const xrl_fused_layer_t& L = p.layers[li];
-        fused_layer(p.params + L.w_off, p.params + L.b_off, L.K, L.N, L.act,
-                    lds + lvl_off[L.in_level] + L.in_off, lvl_ld[L.in_level],
-                    lds + lvl_off[L.out_level] + L.out_off, lvl_ld[L.out_level], red);
+    STAMP();
+    // ---- middle layers on the matrix cores
+#pragma unroll
+    for (int l = 1; l < XRL_FUSED_MAX_LAYERS; ++l) {
+        if (l >= first_mid && l < end_mid) {
+            const xrl_fused_layer_t& L = p.layers[l];
+            fused_layer(p.params + L.w_off, c_wm[l] >= 0 ? lds + c_wm[l] : nullptr, level_ld(L.K), lds + c_bm[l], L.K, L.N, L.act,
+                        lds + lvl_off[L.in_level] + L.in_off, lvl_ld[L.in_level],
+                        lds + lvl_off[L.out_level] + L.out_off, lvl_ld[L.out_level], red, pf, l == pf_layer);
+            STAMP();
+        }
     }
-    const float* heads = lds + lvl_off[p.n_levels - 1];
-    const int ldh = lvl_ld[p.n_levels - 1];
+    // ---- all heads as one block-structured layer from the LDS cache (per-head activation is the identity for the
+    //      categorical actor and the critic)
+    fused_layer(nullptr, lds + c_wh, ldH, lds + c_bh, KH, NH, XRL_ACT_NONE, lds + lvl_off[nLv - 2], lvl_ld[nLv - 2],
+                lds + lvl_off[nLv - 1], lvl_ld[nLv - 1], red, pf, false);
+    STAMP();
+    const float* heads = lds + lvl_off[nLv - 1];
+    const int ldh = lvl_ld[nLv - 1];
 
     if (tid >= FT) return;
     const int e = e0 + tid;
@@ -225,6 +343,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     const float* h = heads + tid * ldh;
     if (boot) {                                                         // V(next_obs_{t-1}) -> bootv[t-1]
         if (p.bootv_prev) p.bootv_prev[e] = h[A];
+        if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) { dbg[dbi++] = clock64(); dbg[15] = dbi; }
         return;
     }
     // ---- get_actions (core/on_policy.py:128-169): sample, log-prob, value; store (ppo_agent.py:128)
@@ -232,9 +351,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     int a = 0;
     float logp;
     {
-        uint32_t r[4];
-        philox4x32(p.seed, (uint32_t)e, step, STREAM_ACTION, r);
-        const float u = u01(r[0]);
+        uint32_t rr[4];
+        philox4x32(p.seed, (uint32_t)e, step, STREAM_ACTION, rr);
+        const float u = u01(rr[0]);
         float mx = h[0];
         for (int j = 1; j < A; ++j) mx = fmaxf(mx, h[j]);
         float se = 0.f;
@@ -281,13 +400,87 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     const float tr = p.gamma * p.ret_track[e] + reward;
     if (term || trunc) { p.ret_final_out[e] = tr; p.ended_out[e] = 1; p.ret_track[e] = 0.f; }
     else { p.ended_out[e] = 0; p.ret_track[e] = tr; }
+    float4 ro = make_float4(robs[0], robs[1], robs[2], robs[3]), xn;
+    *reinterpret_cast<float4*>(p.obs_raw_out + (size_t)e * 4) = ro;    // buf_obs for the next step (reset_obs on episode end)
+    float nv[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        p.obs_raw_out[(size_t)e * 4 + d] = robs[d];                    // buf_obs for the next step (reset_obs on episode end)
         float v = nobs[d];
         if (p.use_obsnorm) { v = (v - s_mean[d]) / (s_std[d] + 1e-8f); v = fminf(fmaxf(v, -p.obs_range), p.obs_range); }
-        p.xnext_out[(size_t)e * 4 + d] = v;                            // get_terminated_values input (on_policy.py:109)
+        nv[d] = v;
     }
+    xn = make_float4(nv[0], nv[1], nv[2], nv[3]);
+    *reinterpret_cast<float4*>(p.xnext_out + (size_t)e * 4) = xn;      // get_terminated_values input (on_policy.py:109)
+    if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) { dbg[dbi++] = clock64(); dbg[15] = dbi; }
+}
+
+// Builds the parameter-cache image (same carve as the kernel above, offsets relative to the image start).
+__global__ void __launch_bounds__(256) pack_rollout_cache_kernel(xrl_rollout_step_t p, float* __restrict__ image) {
+    const int nL = p.n_layers, nH = p.n_head_layers, nLv = p.n_levels, end_mid = nL - nH;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    const xrl_fused_layer_t& L0 = p.layers[0];
+    int off = 0;
+    const int c_w0 = off; off += L0.N * 4;
+    const int c_b0 = off; off += (L0.N + 3) / 4 * 4;
+    for (int i = tid; i < L0.N * 4; i += nt) image[c_w0 + i] = p.params[L0.w_off + i];
+    for (int i = tid; i < (L0.N + 3) / 4 * 4; i += nt) image[c_b0 + i] = i < L0.N ? p.params[L0.b_off + i] : 0.f;
+    for (int l = 1; l < end_mid; ++l) {
+        const xrl_fused_layer_t& L = p.layers[l];
+        const int nb = (L.N + 3) / 4 * 4;
+        for (int i = tid; i < nb; i += nt) image[off + i] = i < L.N ? p.params[L.b_off + i] : 0.f;
+        off += nb;
+        if (layer_small(L.N, L.K)) {
+            const int ldw = level_ld(L.K);
+            for (int i = tid; i < L.N * ldw; i += nt) { const int r = i / ldw, k = i - r * ldw; image[off + i] = k < L.K ? p.params[L.w_off + (size_t)r * L.K + k] : 0.f; }
+            off += L.N * ldw;
+        }
+    }
+    const int KH = p.level_width[nLv - 2], NH = p.level_width[nLv - 1], ldH = level_ld(KH);
+    const int c_wh = off; off += NH * ldH;
+    const int c_bh = off;
+    for (int i = tid; i < NH * ldH; i += nt) {                          // merged heads: W_h[out_off+j][in_off+k] = W_l[j][k]
+        const int row = i / ldH, k = i - row * ldH;
+        float v = 0.f;
+        for (int l = end_mid; l < nL; ++l) {
+            const xrl_fused_layer_t& L = p.layers[l];
+            if (row >= L.out_off && row < L.out_off + L.N && k >= L.in_off && k < L.in_off + L.K)
+                v = p.params[L.w_off + (size_t)(row - L.out_off) * L.K + (k - L.in_off)];
+        }
+        image[c_wh + i] = v;
+    }
+    for (int i = tid; i < (NH + 3) / 4 * 4; i += nt) {
+        float v = 0.f;
+        for (int l = end_mid; l < nL; ++l) {
+            const xrl_fused_layer_t& L = p.layers[l];
+            if (i >= L.out_off && i < L.out_off + L.N) v = p.params[L.b_off + i - L.out_off];
+        }
+        image[c_bh + i] = v;
+    }
+}
+
+static size_t fused_cache_floats(const xrl_rollout_step_t& p) {
+    size_t floats = (size_t)p.layers[0].N * 4 + (p.layers[0].N + 3) / 4 * 4;
+    for (int l = 1; l < p.n_layers - p.n_head_layers; ++l) {
+        floats += (p.layers[l].N + 3) / 4 * 4;
+        if (layer_small(p.layers[l].N, p.layers[l].K)) floats += (size_t)p.layers[l].N * level_ld(p.layers[l].K);
+    }
+    const int NH = p.level_width[p.n_levels - 1], KH = p.level_width[p.n_levels - 2];
+    floats += (size_t)NH * level_ld(KH) + (NH + 3) / 4 * 4;
+    return floats;
+}
+
+static size_t fused_lds_bytes(const xrl_rollout_step_t& p) {
+    size_t floats = 0;
+    for (int l = 1; l < p.n_levels; ++l) floats += (size_t)FT * level_ld(p.level_width[l]);
+    floats += NW * 32 * 33;                                           // split-K reduction scratch
+    floats += (size_t)p.layers[0].N * 4 + (p.layers[0].N + 3) / 4 * 4;
+    for (int l = 1; l < p.n_layers - p.n_head_layers; ++l) {
+        floats += (p.layers[l].N + 3) / 4 * 4;
+        if (layer_small(p.layers[l].N, p.layers[l].K)) floats += (size_t)p.layers[l].N * level_ld(p.layers[l].K);
+    }
+    const int NH = p.level_width[p.n_levels - 1], KH = p.level_width[p.n_levels - 2];
+    floats += (size_t)NH * level_ld(KH) + (NH + 3) / 4 * 4;
+    return floats * sizeof(float);
 }
 
 }  // namespace xrl
@@ -297,7 +490,7 @@ using namespace xrl;
 extern "C" int xrl_init(void) {
     // kernels that carve more than 64 KB of dynamic LDS need the attribute; set it outside any graph capture
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_step_cartpole_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     return XRL_OK;
 }
 
@@ -307,7 +500,9 @@ extern "C" int xrl_rollout_step_cartpole(const xrl_rollout_step_t* pp, xrl_strea
     XRL_CHECK_ARG(p.params && p.n > 0 && p.D == 4 && p.A >= 2 && !p.gaussian);
     XRL_CHECK_ARG(p.n_layers >= 1 && p.n_layers <= XRL_FUSED_MAX_LAYERS && p.n_levels >= 2 && p.n_levels <= XRL_FUSED_MAX_LEVELS);
     XRL_CHECK_ARG(p.level_width[0] == p.D && p.level_width[p.n_levels - 1] >= p.A + 1);
-    XRL_CHECK_ARG(p.xnext_in != nullptr);
+    XRL_CHECK_ARG(p.n_head_layers >= 1 && p.n_head_layers < p.n_layers && p.layers[0].K == 4 && p.layers[0].in_level == 0);
+    XRL_CHECK_ARG(p.n <= 1024);
+    XRL_CHECK_ARG(p.xnext_in != nullptr && p.cache_image != nullptr && (reinterpret_cast<uintptr_t>(p.cache_image) & 15) == 0);
     if (!p.boot_only) {
         XRL_CHECK_ARG(p.obs_raw_in && p.obs_raw_out && p.xnext_out && p.obs_stats_in && p.obs_stats_out && p.obs_count_in &&
                       p.obs_count_out && p.ret_stats_in && p.ret_stats_out && p.ret_count_in && p.ret_count_out &&
@@ -317,14 +512,25 @@ extern "C" int xrl_rollout_step_cartpole(const xrl_rollout_step_t* pp, xrl_strea
     } else {
         XRL_CHECK_ARG(p.bootv_prev != nullptr);
     }
-    size_t floats = 0;
-    for (int l = 0; l < p.n_levels; ++l) floats += (size_t)FT * level_ld(p.level_width[l]);
-    floats += 4 * 32 * 33;                                            // split-K reduction scratch
-    const size_t lds_bytes = floats * sizeof(float);
-    XRL_CHECK_ARG(lds_bytes <= 150 * 1024);
+    const size_t lds_bytes = fused_lds_bytes(p);
+    XRL_CHECK_ARG(lds_bytes <= 144 * 1024);
     const int n_tiles = (p.n + FT - 1) / FT;
     const int grid = p.boot_only ? n_tiles : (p.bootv_prev ? 2 * n_tiles : n_tiles);
     hipLaunchKernelGGL(rollout_step_cartpole_kernel, dim3(grid), dim3(FUSED_THREADS), lds_bytes, as_stream(stream), p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
+}
+
+extern "C" int xrl_pack_rollout_cache(const xrl_rollout_step_t* pp, float* image, int64_t image_floats, xrl_stream_t stream) {
+    XRL_CHECK_ARG(pp && image && pp->params);
+    const xrl_rollout_step_t& p = *pp;
+    XRL_CHECK_ARG(p.n_layers >= 2 && p.n_layers <= XRL_FUSED_MAX_LAYERS && p.n_head_layers >= 1 && p.n_head_layers < p.n_layers);
+    XRL_CHECK_ARG((int64_t)fused_cache_floats(p) <= image_floats);
+    hipLaunchKernelGGL(pack_rollout_cache_kernel, dim3(8), dim3(256), 0, as_stream(stream), p, image);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int64_t xrl_rollout_cache_floats(const xrl_rollout_step_t* pp) {
+    return pp ? (int64_t)fused_cache_floats(*pp) : -1;
 }

@@ -180,8 +180,22 @@ def fused_layers_from_plan(plan, p):
             f.in_level, f.in_off, f.out_level, f.out_off = L.in_level, L.in_off, L.out_level, L.out_off
             li += 1
     p.n_layers, p.n_levels = li, len(plan.widths)
+    p.n_head_layers = len(plan.stages[-1])
     for i, w in enumerate(plan.widths):
         p.level_width[i] = w
+
+
+def rollout_cache_floats(plan):
+    p = RolloutStep()
+    fused_layers_from_plan(plan, p)
+    return int(_lib.load().xrl_rollout_cache_floats(C.byref(p)))
+
+
+def pack_rollout_cache(plan, params_flat, image):
+    p = RolloutStep()
+    p.params = params_flat.data_ptr()
+    fused_layers_from_plan(plan, p)
+    call("xrl_pack_rollout_cache", C.byref(p), ptr(image), image.numel(), stream_ptr())
 
 
 def rollout_step_cartpole(plan, **kw):
