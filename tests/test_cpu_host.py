@@ -18,7 +18,7 @@ from conftest import ROOT, load_golden, sub
 def test_library_exports_every_declared_symbol():
     from xuance_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "xrl_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(xrl_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(xrl_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 20
     lib = _lib.load()                         # dlopen works without a GPU; no compute call is made here
     for sym in declared:
