@@ -307,6 +307,35 @@ int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
 int xrl_pack_rollout_cache(const xrl_rollout_step_t* p, float* image, int64_t image_floats, xrl_stream_t stream);
 int64_t xrl_rollout_cache_floats(const xrl_rollout_step_t* p);
 
+/* ------------------------------------------------------------------ fused PPO minibatch (ONE launch: gather -> MLP forward
+ * -> PPO-clip loss -> MLP backward incl. weight gradients) for an actor-critic MLP with a categorical head.
+ * A workgroup owns a 32-row tile of the minibatch and keeps every activation and gradient level in LDS; the weight
+ * gradients of the middle layers are accumulated in MFMA registers and written once as this workgroup's slab.
+ * Replaces, per minibatch, memory.sample (memory_tools.py:267-287) + PPO_Learner.update's forward/loss/backward
+ * (ppo_learner.py:46-62); xrl_grad_reduce + xrl_adam_step finish the step.  Same numbers as the layered path
+ * xrl_soa_gather -> xrl_linear_fwd x L -> xrl_ppo_loss_categorical -> xrl_linear_bwd_* (fp32 rounding order differs). */
+typedef struct {
+    const float* params;        /* flat parameters */
+    const float* params_t;      /* same layout, middle-layer weights stored transposed ([K][N]) -- xrl_transpose_mid */
+    const float* cache_image;   /* xrl_pack_rollout_cache image (first layer, biases, merged heads) */
+    xrl_fused_layer_t layers[XRL_FUSED_MAX_LAYERS];
+    int32_t n_layers, n_levels, n_head_layers, pad0;
+    int32_t level_width[XRL_FUSED_MAX_LEVELS];
+    /* rollout buffer fields [T][n_envs][...] and the minibatch's env-major flat indices (memory_tools.py:270) */
+    const float* f_obs; const float* f_act; const float* f_ret; const float* f_adv; const float* f_logp;
+    const int64_t* idx;
+    const float* stats;         /* NULL or (mean, std) of this minibatch's advantages: normalised on the fly */
+    float* slabs;               /* [n_tiles][slab_stride] per-workgroup gradient partials, layout of params */
+    double* partials;           /* [n_tiles][8] like xrl_ppo_loss_t.partials */
+    float* diag;                /* NULL or [4][M] */
+    int64_t slab_stride;
+    int32_t M, n_envs, T, D, A, pad1;
+    float clip_range, vf_coef, ent_coef, pad2;
+} xrl_ppo_fused_t;
+int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* p, xrl_stream_t stream);
+/* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */
+int xrl_transpose_mid(const xrl_ppo_fused_t* p, float* params_t, xrl_stream_t stream);
+
 /* ------------------------------------------------------------------ TD targets: DQN and QMIX */
 
 /* DQN_Learner.update loss head (qlearning_family/dqn_learner.py:39-46): predictQ = gather(evalQ, a);

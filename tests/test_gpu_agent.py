@@ -186,3 +186,37 @@ def test_fused_rollout_step_equals_unfused_sequence():
     for k in ("obs_mean", "obs_var", "ret_track"):
         assert_close(sb[k], sa[k], 1e-6, k)
     assert sa["eps"][0] == sb["eps"][0] and sa["eps"][0] > 100
+
+
+@pytest.mark.parametrize("n,T,nmb", [(24, 40, 2), (64, 64, 4), (50, 30, 3)])
+def test_fused_minibatch_kernel_equals_layered_path(n, T, nmb):
+    """xrl_ppo_fused_minibatch (one launch) vs gather + grouped GEMMs + loss + backward GEMMs: same gradient and losses."""
+    from xuance_amd import ops
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(0)
+    env = DeviceCartPoleVecEnv(n, seed=2)
+    agent = PPO_Agent(make_config(n, T, n_epochs=1, n_minibatch=nmb), env)
+    agent.rollout()
+    agent._new_indices()
+    mem, lr = agent.memory, agent.learner
+    assert lr.fused_eligible(mem)
+    bs = agent.batch_size
+    lr.prepare_buffer_update(mem, bs)
+    lr.prepare_fused(mem, bs)
+    lr.refresh_fused_params()
+    ops.adv_stats(mem.soa.fields["advantages"], agent.idx.view(-1), bs, agent.idx.shape[0], n, T, lr.stats)
+    k = agent.idx.shape[0] - 1
+    lr.enqueue_minibatch_from_buffer(mem, agent.idx[k], lr.stats[k], finish=False)
+    torch.cuda.synchronize()
+    g_ref = npy(lr.optimizer.grad); info_ref = lr.last_info(bs); diag_ref = npy(lr.diag.view(-1)[:4 * bs])
+    lr.optimizer.grad.zero_()
+    lr.enqueue_minibatch_fused(mem, agent.idx[k], lr.stats[k], finish=False)
+    torch.cuda.synchronize()
+    g_fused = npy(lr.optimizer.grad); info_fused = lr.last_info(bs); diag_fused = npy(lr.diag.view(-1)[:4 * bs])
+    scale = float(np.abs(g_ref).max())
+    assert scale > 0
+    assert_close(g_fused / scale, g_ref / scale, 2e-5, "gradient")
+    for key in ("actor_loss", "critic_loss", "entropy", "predict_value", "clip_ratio"):
+        assert_close(info_fused[key], info_ref[key], 1e-5, key)
+    assert_close(diag_fused, diag_ref, 1e-5, "log_prob/ratio/surrogates")

@@ -116,7 +116,20 @@ class RolloutStep(C.Structure):
                 ("dbg", c_void_p)]
 
 
+class PpoFused(C.Structure):
+    _fields_ = [("params", c_void_p), ("params_t", c_void_p), ("cache_image", c_void_p), ("layers", FusedLayer * 8),
+                ("n_layers", c_int32), ("n_levels", c_int32), ("n_head_layers", c_int32), ("pad0", c_int32),
+                ("level_width", c_int32 * 6),
+                ("f_obs", c_void_p), ("f_act", c_void_p), ("f_ret", c_void_p), ("f_adv", c_void_p), ("f_logp", c_void_p),
+                ("idx", c_void_p), ("stats", c_void_p), ("slabs", c_void_p), ("partials", c_void_p), ("diag", c_void_p),
+                ("slab_stride", c_int64), ("M", c_int32), ("n_envs", c_int32), ("T", c_int32), ("D", c_int32),
+                ("A", c_int32), ("pad1", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
+                ("pad2", c_float)]
+
+
 _SIGS = {
+    "xrl_ppo_fused_minibatch": [C.POINTER(PpoFused), c_void_p],
+    "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_init": [],
     "xrl_debug_mfma_chain": [c_int, c_int, c_void_p, c_void_p, c_void_p],
     "xrl_rollout_step_cartpole": [C.POINTER(RolloutStep), c_void_p],

@@ -180,11 +180,17 @@ class PPO_Agent:
         mem, lr = self.memory, self.learner
         nb, bs = self.idx.shape
         f = mem.soa
-        lr.prepare_buffer_update(mem, bs)
+        fused = lr.fused_eligible(mem)
+        if fused:
+            lr.prepare_fused(mem, bs)
+            lr.refresh_fused_params()
+        else:
+            lr.prepare_buffer_update(mem, bs)
         if mem.use_advnorm:
             ops.adv_stats(f.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs, self.horizon_size, lr.stats)
+        step = lr.enqueue_minibatch_fused if fused else lr.enqueue_minibatch_from_buffer
         for k in range(nb):
-            lr.enqueue_minibatch_from_buffer(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None)
+            step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None)
 
     def _new_indices(self):
         """np.random.shuffle of arange(buffer_size) per epoch (on_policy.py:194-204), generated on the device."""
@@ -221,7 +227,12 @@ class PPO_Agent:
         all-reduce (RCCL runs on its own stream, outside the capture)."""
         mem, lr = self.memory, self.learner
         nb, bs = self.idx.shape
-        lr.prepare_buffer_update(mem, bs)
+        fused = lr.fused_eligible(mem)
+        if fused:
+            lr.prepare_fused(mem, bs)
+        else:
+            lr.prepare_buffer_update(mem, bs)
+        step = lr.enqueue_minibatch_fused if fused else lr.enqueue_minibatch_from_buffer
         if getattr(self, "_mb_graphs", None) is None:
             torch.cuda.synchronize()
             self._mb_graphs = []
@@ -231,12 +242,15 @@ class PPO_Agent:
                     if k == 0 and mem.use_advnorm:
                         ops.adv_stats(mem.soa.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs,
                                       self.horizon_size, lr.stats)
-                    lr.enqueue_minibatch_from_buffer(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None,
-                                                     finish=False)
+                    if k == 0 and fused:
+                        lr.refresh_fused_params()
+                    step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None, finish=False)
                 self._mb_graphs.append(g)
             g = ops.Graph()
             with g:
                 lr.finish_step()
+                if fused:
+                    lr.refresh_fused_params()
             self._finish_graph = g
         for k in range(nb):
             self._mb_graphs[k].launch()
@@ -250,7 +264,10 @@ class PPO_Agent:
             self._update_distributed()
         elif self.use_graph:
             if self._update_graph is None:
-                self.learner.prepare_buffer_update(self.memory, self.batch_size)
+                if self.learner.fused_eligible(self.memory):
+                    self.learner.prepare_fused(self.memory, self.batch_size)
+                else:
+                    self.learner.prepare_buffer_update(self.memory, self.batch_size)
                 torch.cuda.synchronize()
                 g = ops.Graph()
                 with g:

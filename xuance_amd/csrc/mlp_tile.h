@@ -1,0 +1,125 @@
+// LDS-resident 32-row MLP tile on the fp32 matrix cores (shared by rollout_fused.hip and ppo_fused.hip).
+// See rollout_fused.hip for the mapping notes.
+#pragma once
+#include "common.h"
+
+namespace xrl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FT = 32;               // rows per tile
+constexpr int FUSED_THREADS = 512;   // 8 waves
+constexpr int NW = FUSED_THREADS / 64;
+constexpr int PD = 16;               // prefetched B chunks (of 8 k) held in registers for the first big layer
+constexpr int SMALL_W = 4608;        // a layer whose padded weights fit in this many floats lives in the LDS cache
+
+__host__ __device__ inline int level_ld(int width) { return ((width + 7) / 8) * 8 + 4; }
+__host__ __device__ inline bool layer_small(int N, int K) { return N * level_ld(K) <= SMALL_W; }
+
+#define MFMA4(a, b, acc)                                                         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).x, (b).x, acc, 0, 0, 0);      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).y, (b).y, acc, 0, 0, 0);      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).z, (b).z, acc, 0, 0, 0);      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).w, (b).w, acc, 0, 0, 0);
+
+// out[32][N] = act(in[32][K] . W[N][K]^T + bias)   in/out: LDS tiles.  Wl != null: weights in the LDS cache with row
+// stride ldw (zero padded); else Wg in global memory, and pf[] holds this wave's first PD chunks when `use_pf`.
+__device__ __forceinline__ void fused_layer(const float* __restrict__ Wg, const float* Wl, int ldw, const float* bias_l,
+                                            int K, int N, int act, const float* in, int ld_in, float* out, int ld_out,
+                                            float* red, const float4 (&pf)[PD], bool use_pf,
+                                            const float* aux = nullptr, int ld_aux = 0) {
+    // aux == null : out = act(acc + bias)                      (forward)
+    // aux != null : out = acc * act'(aux[row][col])            (backward w.r.t. the layer input; `act` is the
+    //               activation that produced aux, bias_l is unused)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n_tiles = (N + 31) / 32;
+    const int kq = (K + 7) / 8;
+    const bool fast_g = ((K & 7) == 0) && ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0);
+    const int wpt = n_tiles >= NW ? 1 : NW / n_tiles;               // waves per tile (split-K factor)
+    const int tiles_per_pass = NW / wpt;
+    for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_pass) {
+        const int tile = t0 + wave / wpt, ks = wave % wpt;
+        const bool live = tile < n_tiles && (wave / wpt) < tiles_per_pass;
+        const int n0 = tile * 32;
+        const int wr = min(n0 + li, N - 1);   // rows >= N only feed output columns that are never stored: clamp
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (live) {
+            const float* arow = in + li * ld_in + 4 * lh;
+            if (Wl) {
+                const float* wrow = Wl + wr * ldw + 4 * lh;
+#pragma unroll 4
+                for (int q = ks; q < kq; q += wpt) {
+                    const float4 b = *reinterpret_cast<const float4*>(wrow + q * 8);
+                    const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
+                    MFMA4(a, b, acc)
+                }
+            } else if (fast_g) {
+                const float* wrow = Wg + (size_t)wr * K + 4 * lh;
+                int qstart = 0;
+                if (use_pf && t0 == 0 && wpt == 1) {                // chunks 0..PD-1 are already in registers
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) {
+                        if (q < kq) { const float4 a = *reinterpret_cast<const float4*>(arow + q * 8); MFMA4(a, pf[q], acc) }
+                    }
+                    qstart = PD;
+                }
+#pragma unroll 8
+                for (int q = qstart + ks; q < kq; q += wpt) {
+                    const float4 b = *reinterpret_cast<const float4*>(wrow + q * 8);
+                    const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
+                    MFMA4(a, b, acc)
+                }
+            } else {
+                const float* wrow = Wg + (size_t)wr * K;
+                for (int q = ks; q < kq; q += wpt) {
+                    const int kk = q * 8 + 4 * lh;
+                    const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
+                    float4 b;
+                    b.x = kk + 0 < K ? wrow[kk + 0] : 0.f;
+                    b.y = kk + 1 < K ? wrow[kk + 1] : 0.f;
+                    b.z = kk + 2 < K ? wrow[kk + 2] : 0.f;
+                    b.w = kk + 3 < K ? wrow[kk + 3] : 0.f;
+                    MFMA4(a, b, acc)
+                }
+            }
+        }
+        // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (wpt == 1) {
+            const int col = n0 + li;
+            if (live && col < N) {
+                const float bv = aux ? 0.f : bias_l[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    out[row * ld_out + col] = aux ? acc[r] * act_grad_from_out(aux[row * ld_aux + col], act)
+                                                  : act_apply(acc[r] + bv, act);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                red[(wave * 32 + row) * 33 + li] = acc[r];
+            }
+            __syncthreads();
+                for (int i = threadIdx.x; i < tiles_per_pass * 32 * 32; i += FUSED_THREADS) {
+                const int tl = i >> 10, row = (i >> 5) & 31, c = i & 31;
+                const int col = (t0 + tl) * 32 + c;
+                if (t0 + tl < n_tiles && col < N) {
+                    float v = 0.f;
+                    for (int w = 0; w < wpt; ++w) v += red[((tl * wpt + w) * 32 + row) * 33 + c];   // fixed order
+                    out[row * ld_out + col] = aux ? v * act_grad_from_out(aux[row * ld_aux + col], act)
+                                                  : act_apply(v + bias_l[col], act);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+}
+
+
+}  // namespace xrl

@@ -9,18 +9,47 @@ namespace xrl {
 
 constexpr int RED_THREADS = 256;
 
-// grad[p] = sum_s slabs[s][p]   (fixed order s = 0..S-1 -> deterministic);  block partial of sum grad^2 (fp64)
+// grad[p] = sum_s slabs[s][p]   (fixed order s = 0..S-1 -> deterministic);  block partial of sum grad^2 (fp64).
+// Each thread owns 4 consecutive parameters (one 16-byte load per slab) and keeps up to 8 slab loads in flight.
 __global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* __restrict__ slabs, int n_split,
                                                                   int64_t slab_stride, int64_t P,
                                                                   float* __restrict__ grad,
                                                                   double* __restrict__ sumsq_part) {
     __shared__ double scratch[16];
     double sq = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-        float g = 0.f;
-        for (int s = 0; s < n_split; ++s) g += slabs[(size_t)s * slab_stride + i];
-        grad[i] = g;
-        sq += (double)g * (double)g;
+    const bool vec = ((slab_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
+    if (vec) {
+        const int64_t P4 = P / 4;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P4; i += (int64_t)gridDim.x * blockDim.x) {
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4* src = reinterpret_cast<const float4*>(slabs) + i;
+            const int64_t st4 = slab_stride / 4;
+            int s = 0;
+            for (; s + 8 <= n_split; s += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(s + j) * st4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { g.x += v[j].x; g.y += v[j].y; g.z += v[j].z; g.w += v[j].w; }
+            }
+            for (; s < n_split; ++s) { const float4 v = src[(int64_t)s * st4]; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+            reinterpret_cast<float4*>(grad)[i] = g;
+            sq += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
+        }
+        for (int64_t i = P4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+            float g = 0.f;
+            for (int s = 0; s < n_split; ++s) g += slabs[(size_t)s * slab_stride + i];
+            grad[i] = g;
+            sq += (double)g * (double)g;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+            float g = 0.f;
+            for (int s = 0; s < n_split; ++s) g += slabs[(size_t)s * slab_stride + i];
+            grad[i] = g;
+            sq += (double)g * (double)g;
+        }
     }
     const double t = block_sum(sq, scratch);
     if (threadIdx.x == 0) sumsq_part[blockIdx.x] = t;

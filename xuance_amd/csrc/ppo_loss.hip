@@ -4,30 +4,11 @@
 // CategoricalDistribution / DiagGaussianDistribution (rl_models/modules/distributions.py:128-192) and the
 // autograd rules of torch.clamp (gradient where lo <= x <= hi) and torch.minimum (0.5/0.5 on ties).
 #include "common.h"
+#include "ppo_math.h"
 
 namespace xrl {
 
 constexpr int LOSS_THREADS = 256;
-constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
-
-struct Surrogate {
-    float ratio, s1, s2, dlogp;
-    int clipped;
-};
-
-__device__ __forceinline__ Surrogate surrogate(float logp, float old_logp, float adv, float lo, float hi, float invM) {
-    Surrogate r;
-    r.ratio = expf(logp - old_logp);                        // :52
-    const float rc = fminf(fmaxf(r.ratio, lo), hi);
-    r.s1 = rc * adv;                                        // :53
-    r.s2 = adv * r.ratio;                                   // :54
-    const float inside = (r.ratio >= lo && r.ratio <= hi) ? 1.f : 0.f;
-    const float w1 = r.s1 < r.s2 ? 1.f : (r.s1 == r.s2 ? 0.5f : 0.f);
-    const float dratio = -(w1 * inside * adv + (1.f - w1) * adv) * invM;   // d(-mean(min(s1,s2)))/d ratio
-    r.dlogp = dratio * r.ratio;
-    r.clipped = (r.ratio < lo) || (r.ratio > hi);           // :70
-    return r;
-}
 
 template <bool GAUSSIAN>
 __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p) {

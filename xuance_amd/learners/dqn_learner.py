@@ -20,7 +20,7 @@ class DQN_Learner(Learner):
         self.scheduler = LinearLRHandle(self.optimizer)
         dev = P.device
         self._cap = 0
-        self.sumsq = torch.zeros(64, dtype=torch.float64, device=dev)
+        self.sumsq = torch.zeros(128, dtype=torch.float64, device=dev)
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
 
     def _ensure(self, M):

@@ -23,7 +23,7 @@ class PPO_Learner(Learner):
         self.scheduler = LinearLRHandle(self.optimizer)
         dev = P.device
         self._cap = 0
-        self.sumsq = torch.zeros(64, dtype=torch.float64, device=dev)
+        self.sumsq = torch.zeros(128, dtype=torch.float64, device=dev)
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
         self.keep_diag = True     # keep the per-sample callback tensors (log_prob, ratio, surrogates)
 
@@ -88,8 +88,8 @@ class PPO_Learner(Learner):
         ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq,
                       self.grad_clip_norm if self.use_grad_clip else 0.0)
 
-    def _info(self, M, S):
-        ops.sum_partials(self.partials, S, 8, self.sums)
+    def _info(self, M, S, partials=None):
+        ops.sum_partials(self.partials if partials is None else partials, S, 8, self.sums)
         s = self.sums.cpu().numpy()                                 # the one host sync of an update
         st = self.optimizer.read()
         return {self._key("actor_loss"): float(-s[0] / M), self._key("critic_loss"): float(s[1] / M),
@@ -112,6 +112,61 @@ class PPO_Learner(Learner):
         self._stage_bs = bs
         self._last_S = pick_n_split(bs)
 
+    # ------------------------------------------------------------------ fused minibatch kernel (xrl_ppo_fused_minibatch)
+    def fused_eligible(self, memory):
+        """One-launch gather+forward+loss+backward: categorical head, 4-d observations, middle layers in 32-multiples,
+        activations + gradients of a 32-row tile must fit in LDS."""
+        m, plan = self.model, self.model.plan
+        if not getattr(self.config, "use_fused_update", True) or m.dist != "categorical" or m.obs_dim != 4:
+            return False
+        if len(plan.stages) < 2 or len(plan.stages[0]) != 1 or len(plan.widths) > 6:
+            return False
+        n_layers = sum(len(s) for s in plan.stages)
+        mids = [L for s in plan.stages[1:-1] for L in s]
+        if n_layers > 8 or any(L.N % 32 or L.K % 32 for L in mids):
+            return False
+        ld = lambda w: (w + 7) // 8 * 8 + 4
+        floats = sum(2 * 32 * ld(w) for w in plan.widths[1:]) + 8 * 32 * 33 + ops.rollout_cache_floats(plan) + 64
+        return floats * 4 <= 150 * 1024 and tuple(memory.act_shape) == ()
+
+    def prepare_fused(self, memory, bs):
+        if getattr(self, "_fused_bs", 0) == bs:
+            return
+        dev, P = self.model.params.device, self.model.params.P
+        self._ensure(bs)
+        self.n_tiles = (bs + 31) // 32
+        self.fslabs = torch.zeros(self.n_tiles, P, device=dev)
+        self.fpartials = torch.zeros(self.n_tiles, 8, dtype=torch.float64, device=dev)
+        self.params_t = torch.zeros(P, device=dev)
+        self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
+        self.stats = torch.zeros(4096, 2, device=dev)
+        self.sumsq = torch.zeros(256, dtype=torch.float64, device=dev)
+        self._fused_bs = bs
+        self._params_dirty = True
+
+    def refresh_fused_params(self):
+        """Derived parameter layouts the fused kernel reads (transposed middle weights, packed small parameters)."""
+        ops.transpose_mid(self.model.plan, self.model.params.flat, self.params_t)
+        ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)
+
+    def enqueue_minibatch_fused(self, memory, idx, stats=None, finish=True):
+        """One launch for gather + forward + loss + backward, then reduce + Adam, then refresh the derived layouts."""
+        m, opt, f = self.model, self.optimizer, memory.soa.fields
+        M = idx.numel()
+        ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=self.params_t, cache_image=self.cache_image,
+                                f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
+                                f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs,
+                                partials=self.fpartials, diag=self.diag if self.keep_diag else None,
+                                slab_stride=m.params.P, M=M, n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim,
+                                clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
+        ops.grad_reduce(self.fslabs, self.n_tiles, m.params.P, m.params.P, opt.grad, self.sumsq)
+        self._last_S, self._last_partials = self.n_tiles, self.fpartials
+        if finish:
+            if self.distributed_training and self.world_size > 1:
+                self.allreduce_grad()
+            self.finish_step()
+            self.refresh_fused_params()
+
     def enqueue_minibatch_from_buffer(self, memory, idx, stats=None, finish=True):
         """memory.sample(idx) + update(**samples) without materialising Python objects: one gather launch
         (advantages normalised on the fly, memory_tools.py:281-282) followed by the update launches."""
@@ -124,10 +179,11 @@ class PPO_Learner(Learner):
         obs = st["observations"].view(M, -1)
         self._last_S = self._step(obs, obs.shape[1], st["actions"], st["returns"], st["advantages"], st["aux_old_logp"], M,
                                   finish=finish)
+        self._last_partials = self.partials
 
     def last_info(self, M):
         """Info dict of the most recent minibatch (what train_epochs returns, on_policy.py:205)."""
-        return self._info(M, self._last_S)
+        return self._info(M, self._last_S, getattr(self, "_last_partials", None))
 
     # ------------------------------------------------------------------ reference API (ppo_learner.py:35-95)
     def update(self, **samples):

@@ -33,7 +33,7 @@ class QMIX_Learner(Learner):
         self.scheduler = LinearLRHandle(self.optimizer)
         dev = P.device
         self._cap = 0
-        self.sumsq = torch.zeros(64, dtype=torch.float64, device=dev)
+        self.sumsq = torch.zeros(128, dtype=torch.float64, device=dev)
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
 
     def estimate_total_iterations(self):                        # marl_learner.py:36-47 (feed-forward branch)

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, call, ptr,
+from ._lib import (ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, call, ptr,
                    stream_ptr)
 
 
@@ -183,6 +183,19 @@ def fused_layers_from_plan(plan, p):
     p.n_head_layers = len(plan.stages[-1])
     for i, w in enumerate(plan.widths):
         p.level_width[i] = w
+
+
+def ppo_fused_minibatch(plan, **kw):
+    p = _struct(PpoFused, kw)
+    fused_layers_from_plan(plan, p)
+    call("xrl_ppo_fused_minibatch", C.byref(p), stream_ptr())
+
+
+def transpose_mid(plan, params_flat, params_t):
+    p = PpoFused()
+    p.params = params_flat.data_ptr()
+    fused_layers_from_plan(plan, p)
+    call("xrl_transpose_mid", C.byref(p), ptr(params_t), stream_ptr())
 
 
 def rollout_cache_floats(plan):
