@@ -155,6 +155,12 @@ int xrl_grad_reduce(const float* slabs, int n_split, int64_t slab_stride, int64_
  * Adam update of params/m/v; advances *state (step, sched_steps, last_lr, last_grad_norm). */
 int xrl_adam_step(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
                   const double* sumsq_part, int n_part, double max_norm, xrl_stream_t stream);
+/* Same, and every updated parameter i is also written to dst_a[map_a[i]] / dst_b[map_b[i]] (map < 0: skip): keeps the
+ * derived layouts of the fused kernels (transposed middle weights, packed LDS-cache image) current without extra
+ * launches.  Maps are int32 [P] device arrays built once by the host. */
+int xrl_adam_step_mirrored(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
+                           const double* sumsq_part, int n_part, double max_norm, const int32_t* map_a, float* dst_a,
+                           const int32_t* map_b, float* dst_b, xrl_stream_t stream);
 
 
 /* ------------------------------------------------------------------ rollout-side ops (one small launch per step)
@@ -331,6 +337,7 @@ typedef struct {
     int64_t slab_stride;
     int32_t M, n_envs, T, D, A, pad1;
     float clip_range, vf_coef, ent_coef, pad2;
+    long long* dbg;             /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
 } xrl_ppo_fused_t;
 int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* p, xrl_stream_t stream);
 /* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */

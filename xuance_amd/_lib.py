@@ -124,7 +124,7 @@ class PpoFused(C.Structure):
                 ("idx", c_void_p), ("stats", c_void_p), ("slabs", c_void_p), ("partials", c_void_p), ("diag", c_void_p),
                 ("slab_stride", c_int64), ("M", c_int32), ("n_envs", c_int32), ("T", c_int32), ("D", c_int32),
                 ("A", c_int32), ("pad1", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
-                ("pad2", c_float)]
+                ("pad2", c_float), ("dbg", c_void_p)]
 
 
 _SIGS = {
@@ -156,6 +156,8 @@ _SIGS = {
     "xrl_sum_partials": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrl_grad_reduce": [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "xrl_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double, c_void_p],
+    "xrl_adam_step_mirrored": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "xrl_graph_begin": [c_void_p],
     "xrl_graph_end": [c_void_p, C.POINTER(c_void_p)],
     "xrl_graph_launch": [c_void_p, c_void_p],

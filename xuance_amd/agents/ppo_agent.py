@@ -249,8 +249,6 @@ class PPO_Agent:
             g = ops.Graph()
             with g:
                 lr.finish_step()
-                if fused:
-                    lr.refresh_fused_params()
             self._finish_graph = g
         for k in range(nb):
             self._mb_graphs[k].launch()

@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
                                                                 float* __restrict__ m, float* __restrict__ v, int64_t P,
                                                                 xrl_adam_state_t* __restrict__ st,
                                                                 const double* __restrict__ sumsq_part, int n_part,
-                                                                double max_norm) {
+                                                                double max_norm, const int32_t* __restrict__ map_a,
+                                                                float* __restrict__ dst_a, const int32_t* __restrict__ map_b,
+                                                                float* __restrict__ dst_b) {
     __shared__ double scratch[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < n_part; i += blockDim.x) s += sumsq_part[i];
@@ -87,7 +89,11 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
         const float vi = v[i] * fb2 + w2 * g * g;
         m[i] = mi; v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        params[i] -= step_size * (mi / denom);
+        const float pn = params[i] - step_size * (mi / denom);
+        params[i] = pn;
+        // derived layouts kept in sync in the same launch (transposed middle weights, packed LDS-cache image)
+        if (map_a) { const int j = map_a[i]; if (j >= 0) dst_a[j] = pn; }
+        if (map_b) { const int j = map_b[i]; if (j >= 0) dst_b[j] = pn; }
     }
     // The last block to finish advances the device-resident state (every block has consumed the old state by
     // the time it takes its ticket; the next launch observes the new state across the kernel boundary).
@@ -125,7 +131,21 @@ extern "C" int xrl_adam_step(float* params, float* grad, float* m, float* v, int
     int nb = (int)((P + RED_THREADS - 1) / RED_THREADS);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(adam_step_kernel, dim3(nb), dim3(RED_THREADS), 0, as_stream(stream), params, grad, m, v, P,
-                       state, sumsq_part, n_part, max_norm);
+                       state, sumsq_part, n_part, max_norm, (const int32_t*)nullptr, (float*)nullptr,
+                       (const int32_t*)nullptr, (float*)nullptr);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_adam_step_mirrored(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
+                                      const double* sumsq_part, int n_part, double max_norm, const int32_t* map_a,
+                                      float* dst_a, const int32_t* map_b, float* dst_b, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params && grad && m && v && state && sumsq_part && P > 0 && n_part >= 1 && n_part <= 1024);
+    XRL_CHECK_ARG((!map_a || dst_a) && (!map_b || dst_b));
+    int nb = (int)((P + RED_THREADS - 1) / RED_THREADS);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(adam_step_kernel, dim3(nb), dim3(RED_THREADS), 0, as_stream(stream), params, grad, m, v, P,
+                       state, sumsq_part, n_part, max_norm, map_a, dst_a, map_b, dst_b);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

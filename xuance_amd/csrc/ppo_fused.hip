@@ -69,6 +69,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
     const int m0 = blockIdx.x * FT;
     const int nL = p.n_layers, nH = p.n_head_layers, nLv = p.n_levels, end_mid = nL - nH;
     float* slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
+    long long* dbg = p.dbg;
+    int dbi = 0;
+#define PSTAMP() do { if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) { dbg[dbi++] = clock64(); dbg[15] = dbi; } } while (0)
+    PSTAMP();
 
     // ---- LDS carve: activation levels 1.., gradient levels 1.., split-K scratch, parameter cache (same image as the rollout)
     int lvl_off[XRL_FUSED_MAX_LEVELS], g_off[XRL_FUSED_MAX_LEVELS], lvl_ld[XRL_FUSED_MAX_LEVELS];
@@ -153,6 +157,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
         s_row[r][0] = g_act; s_row[r][1] = g_ret; s_row[r][2] = adv; s_row[r][3] = g_lp;
     }
     __syncthreads();
+    PSTAMP();
 
     // ================================================================== forward
     {   // first layer on the VALU (K = 4): same k-ordered fma chain as the MFMA path
@@ -179,6 +184,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
     fused_layer(nullptr, lds + c_wh, ldH, lds + c_bh, KH, NH, XRL_ACT_NONE, lds + lvl_off[nLv - 2], lvl_ld[nLv - 2],
                 lds + lvl_off[nLv - 1], lvl_ld[nLv - 1], red, pf, false);
 
+    PSTAMP();
     // ================================================================== loss (one thread per row)
     const int ldh = lvl_ld[nLv - 1];
     float* heads = lds + lvl_off[nLv - 1];
@@ -223,23 +229,30 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
         }
     }
     __syncthreads();
+    PSTAMP();
 
     // ================================================================== backward
     // ---- heads: dW_h[j][k] = sum_rows dZh[row][j] * H[row][k] (only the blocks that belong to a head), db_h, and
-    //      dH = dZh . W_h, times act'(H) of the layer that produced H
+    //      dH = dZh . W_h, times act'(H) of the layer that produced H (all layers writing one level share an activation)
     {
         const float* hprev = lds + lvl_off[nLv - 2];
         const int ldp = lvl_ld[nLv - 2];
         float* dprev = lds + g_off[nLv - 2];
+        int pact = L0.act;
+#pragma unroll
+        for (int l = 1; l < XRL_FUSED_MAX_LAYERS; ++l)
+            if (l < end_mid && p.layers[l].out_level == nLv - 2) pact = p.layers[l].act;
 #pragma unroll
         for (int l = 1; l < XRL_FUSED_MAX_LAYERS; ++l) {
             if (l >= end_mid && l < nL) {
                 const xrl_fused_layer_t& L = p.layers[l];
-                for (int i = tid; i < L.N * L.K; i += FUSED_THREADS) {
-                    const int j = i / L.K, k = i - j * L.K;
-                    float acc = 0.f;
-                    for (int rr = 0; rr < FT; ++rr) acc += dheads[rr * ldh + L.out_off + j] * hprev[rr * ldp + L.in_off + k];
-                    slab[L.w_off + i] = acc;
+                for (int j = 0; j < L.N; ++j) {
+                    for (int k = tid; k < L.K; k += FUSED_THREADS) {
+                        float acc = 0.f;
+#pragma unroll 8
+                        for (int rr = 0; rr < FT; ++rr) acc += dheads[rr * ldh + L.out_off + j] * hprev[rr * ldp + L.in_off + k];
+                        slab[L.w_off + j * L.K + k] = acc;
+                    }
                 }
                 if (tid < L.N) {
                     float acc = 0.f;
@@ -248,19 +261,25 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
                 }
             }
         }
-        // producer activation of the previous level (the last middle layer, or the first layer when there is none)
-        for (int i = tid; i < FT * KH; i += FUSED_THREADS) {
-            const int rr = i / KH, k = i - rr * KH;
-            float acc = 0.f;
-            for (int j = 0; j < NH; ++j) acc += dheads[rr * ldh + j] * lds[c_wh + j * ldH + k];
-            int pact = L0.act;
+        // thread -> (row group, column): column k = tid mod KH' with KH' = 512 / rows-in-flight, no divisions
+        const int cols_per_pass = KH < FUSED_THREADS ? KH : FUSED_THREADS;
+        const int rows_per_pass = FUSED_THREADS / cols_per_pass;       // KH = 256 -> 2 rows at a time
+        const int rsub = tid / cols_per_pass, k0c = tid - rsub * cols_per_pass;
+        for (int k = k0c; k < KH; k += cols_per_pass) {
+            float w[8];
 #pragma unroll
-            for (int l = 1; l < XRL_FUSED_MAX_LAYERS; ++l)
-                if (l < end_mid && p.layers[l].out_level == nLv - 2 && k >= p.layers[l].out_off && k < p.layers[l].out_off + p.layers[l].N) pact = p.layers[l].act;
-            dprev[rr * ldp + k] = acc * act_grad_from_out(hprev[rr * ldp + k], pact);
+            for (int j = 0; j < 8; ++j) w[j] = j < NH ? lds[c_wh + j * ldH + k] : 0.f;
+            for (int rr = rsub; rr < FT; rr += rows_per_pass) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < NH) acc += dheads[rr * ldh + j] * w[j];
+                for (int j = 8; j < NH; ++j) acc += dheads[rr * ldh + j] * lds[c_wh + j * ldH + k];
+                dprev[rr * ldp + k] = acc * act_grad_from_out(hprev[rr * ldp + k], pact);
+            }
         }
     }
     __syncthreads();
+    PSTAMP();
     // ---- middle layers, last to first: dW (MFMA, register accumulators -> slab), db (column sums), dH (MFMA on W^T)
 #pragma unroll
     for (int l = XRL_FUSED_MAX_LAYERS - 1; l >= 1; --l) {
@@ -271,8 +290,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
             const float* hin = lds + lvl_off[L.in_level] + L.in_off;
             const int ldi = lvl_ld[L.in_level];
             tile_weight_grad(dz, ldz, hin, ldi, L.N, L.K, slab + L.w_off);
+            PSTAMP();
             for (int j = tid; j < L.N; j += FUSED_THREADS) {
                 float acc = 0.f;
+#pragma unroll 8
                 for (int rr = 0; rr < FT; ++rr) acc += dz[rr * ldz + j];
                 slab[L.b_off + j] = acc;
             }
@@ -280,12 +301,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
             int pact = L0.act;
 #pragma unroll
             for (int l2 = 1; l2 < XRL_FUSED_MAX_LAYERS; ++l2)
-                if (l2 < l && p.layers[l2].out_level == L.in_level && L.in_off >= p.layers[l2].out_off &&
-                    L.in_off < p.layers[l2].out_off + p.layers[l2].N) pact = p.layers[l2].act;
+                if (l2 < l && p.layers[l2].out_level == L.in_level) pact = p.layers[l2].act;
             fused_layer(p.params_t + L.w_off, nullptr, 0, nullptr, L.N, L.K, pact, dz, ldz,
                         lds + g_off[L.in_level] + L.in_off, ldi, red, pf, false, hin, ldi);
         }
     }
+    PSTAMP();
     // ---- first layer: dW0[c][k] = sum_rows dZ1[row][c] * x[row][k], db0 (VALU; x rows are re-read from LDS scratch)
     {
         float* xs = red;                                                // [32][4] scratch
@@ -305,6 +326,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
             slab[L0.b_off + c] = acc;
         }
     }
+    PSTAMP();
 }
 
 // params_t[w_off + k*N + n] = params[w_off + n*K + k] for every middle layer

@@ -83,10 +83,15 @@ class PPO_Learner(Learner):
         ops.grad_reduce(opt.grad, 1, P, P, opt.grad, self.sumsq)
 
     def finish_step(self):
-        """clip_grad_norm_ + Adam.step + LinearLR.step (ppo_learner.py:63-67)."""
+        """clip_grad_norm_ + Adam.step + LinearLR.step (ppo_learner.py:63-67).  When the fused kernels are in use the
+        same launch also refreshes their derived parameter layouts."""
         model, opt = self.model, self.optimizer
-        ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq,
-                      self.grad_clip_norm if self.use_grad_clip else 0.0)
+        clip = self.grad_clip_norm if self.use_grad_clip else 0.0
+        if getattr(self, "_mirror", False):
+            ops.adam_step_mirrored(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq, clip,
+                                   self.map_t, self.params_t, self.map_img, self.cache_image)
+        else:
+            ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq, clip)
 
     def _info(self, M, S, partials=None):
         ops.sum_partials(self.partials if partials is None else partials, S, 8, self.sums)
@@ -142,7 +147,8 @@ class PPO_Learner(Learner):
         self.stats = torch.zeros(4096, 2, device=dev)
         self.sumsq = torch.zeros(256, dtype=torch.float64, device=dev)
         self._fused_bs = bs
-        self._params_dirty = True
+        self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
+        self._mirror = True
 
     def refresh_fused_params(self):
         """Derived parameter layouts the fused kernel reads (transposed middle weights, packed small parameters)."""
@@ -165,7 +171,6 @@ class PPO_Learner(Learner):
             if self.distributed_training and self.world_size > 1:
                 self.allreduce_grad()
             self.finish_step()
-            self.refresh_fused_params()
 
     def enqueue_minibatch_from_buffer(self, memory, idx, stats=None, finish=True):
         """memory.sample(idx) + update(**samples) without materialising Python objects: one gather launch

@@ -128,6 +128,31 @@ def adam_step(params, grad, m, v, P, state, sumsq_part, max_norm):
          sumsq_part.numel(), float(max_norm if max_norm else 0.0), stream_ptr())
 
 
+def adam_step_mirrored(params, grad, m, v, P, state, sumsq_part, max_norm, map_a, dst_a, map_b, dst_b):
+    call("xrl_adam_step_mirrored", ptr(params), ptr(grad), ptr(m), ptr(v), int(P), ptr(state), ptr(sumsq_part),
+         sumsq_part.numel(), float(max_norm if max_norm else 0.0), ptr(map_a), ptr(dst_a), ptr(map_b), ptr(dst_b),
+         stream_ptr())
+
+
+def derived_layout_maps(plan, P, device):
+    """int32 maps param index -> index in (a) the transposed-middle-weights buffer, (b) the packed cache image,
+    computed by running the two layout kernels on an index ramp (so they can never disagree with the kernels)."""
+    ramp = torch.arange(P, dtype=torch.float32, device=device) + 1.0          # exact in fp32 for P < 2^24
+    pt = torch.zeros(P, device=device)
+    img = torch.zeros(rollout_cache_floats(plan) + 16, device=device)
+    transpose_mid(plan, ramp, pt)
+    pack_rollout_cache(plan, ramp, img)
+    torch.cuda.synchronize()
+
+    def invert(dst):
+        m = torch.full((P,), -1, dtype=torch.int32, device=device)
+        j = torch.nonzero(dst > 0).flatten()
+        src = (dst[j] - 1.0).to(torch.int64)
+        m[src] = j.to(torch.int32)
+        return m
+    return invert(pt), invert(img)
+
+
 # ------------------------------------------------------------------------------------------ rollout side
 def _struct(cls, kw):
     p = cls()
