@@ -38,38 +38,56 @@ def make_config(n_envs, horizon, world, rank):
                      model_dir="/tmp/xrl_bench_models", use_hip_graph=True)
 
 
-def dominant_kernel_roofline(agent, iters=200):
-    """Roofline of the kernel that dominates the timed region (see profiles/): the fp32-MFMA GEMM of the
-    128x128 hidden layers on an 8192-sample minibatch.  Timed live with HIP events on the launch stream over
-    `iters` back-to-back launches of exactly the minibatch forward launch the update phase issues."""
-    from xuance_amd import ops
-    net, lr = agent.model, agent.learner
-    M = agent.batch_size
-    lr.prepare_buffer_update(agent.memory, M)
-    x = lr._stage["observations"].view(M, -1)
-    stage = net.plan.stages[1]                         # stacked [actor.0 ; critic.0]: [M,128] x [256,128]^T
-    L = stage[0]
-    P = net.params
-    a = net.plan.acts[L.in_level].data_ptr()
-    c = net.plan.acts[L.out_level].data_ptr()
-    desc = [ops.gemm_desc(a, P.ptr(L.w_name), c, M, L.N, L.K, net.plan.widths[L.in_level], L.K,
-                          net.plan.widths[L.out_level], bias=P.ptr(L.b_name), act=L.act)]
-    for _ in range(10):
-        ops.linear_fwd(desc)
+def _event_time_us(fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        ops.linear_fwd(desc)
+    for _ in range(reps):
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    flops = 2.0 * M * L.N * L.K                       # algorithmic flops of one launch
-    achieved = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "gemm_f32_kernel<NT> (linear_fwd %dx%dx%d)" % (M, L.N, L.K),
-            "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-            "avg_launch_us": round(sec * 1e6, 3), "algorithmic_flops_per_launch": flops}
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def kernel_rooflines(agent):
+    """Rooflines of the two kernels that make up the timed region (profiles/*.csv), timed live with HIP events on the
+    launch stream: (1) xrl::rollout_step_cartpole_kernel -- 53% of kernel time, one launch per vector step -- measured as
+    the captured rollout graph (T+1 launches of that kernel plus one GAE scan and one counter bump) divided by T+1;
+    (2) xrl::ppo_fused_kernel -- one launch per minibatch -- measured over back-to-back launches on the last minibatch.
+    `achieved` = ALGORITHMIC fp32 flops of the policy network (67 328 flop forward per row, 201 984
+    flop forward+backward per sample) divided by the launch time; both kernels are latency-bound at this workload."""
+    from xuance_amd import ops
+    lr, mem, m = agent.learner, agent.memory, agent.model
+    T, n, bs = agent.horizon_size, agent.n_envs, agent.batch_size
+    fwd_flops_row = sum(2.0 * L.N * L.K for st in m.plan.stages for L in st)
+    # (1) rollout step kernel
+    agent._rollout_graph.launch()
+    us_step = _event_time_us(agent._rollout_graph.launch, 5) / (T + 1)
+    rows = 2 * n                                          # act tiles + bootstrap tiles
+    fl_step = fwd_flops_row * rows
+    r1 = {"bound": "mfma", "kernel": "xrl::rollout_step_cartpole_kernel", "achieved": round(fl_step / us_step / 1e6, 4),
+          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_step / us_step / 1e6 / PEAK_FP32_MFMA_TFLOPS, 5),
+          "traffic": None, "avg_launch_us": round(us_step, 3), "algorithmic_flops_per_launch": fl_step,
+          "note": "latency-bound: %d rows x %.0f flop per launch; see DESIGN.md section 3" % (rows, fwd_flops_row)}
+    # (2) fused minibatch kernel
+    f = mem.soa.fields
+    k = agent.idx.shape[0] - 1
+
+    def mb():
+        ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=lr.params_t, cache_image=lr.cache_image,
+                                f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
+                                f_logp=f["aux_old_logp"], idx=agent.idx[k], stats=lr.stats[k], slabs=lr.fslabs,
+                                partials=lr.fpartials, diag=None, slab_stride=m.params.P, M=bs, n_envs=n, T=T, D=4,
+                                A=m.action_dim, clip_range=lr.clip_range, vf_coef=lr.vf_coef, ent_coef=lr.ent_coef)
+    r2 = None
+    if lr.fused_eligible(mem):
+        mb()
+        us_mb = _event_time_us(mb, 50)
+        fl_mb = 3.0 * fwd_flops_row * bs
+        r2 = {"bound": "mfma", "kernel": "xrl::ppo_fused_kernel", "achieved": round(fl_mb / us_mb / 1e6, 3),
+              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
+              "traffic": None, "avg_launch_us": round(us_mb, 3), "algorithmic_flops_per_launch": fl_mb}
+    return r1, r2
 
 
 def cpu_baseline(n_envs, horizon, budget_s=20.0):
@@ -157,7 +175,9 @@ def main():
                       "last_info": {k: round(float(v), 6) for k, v in info.items()}}}
     if rank == 0:
         if not args.no_roofline:
-            out["roofline"] = dominant_kernel_roofline(agent)
+            out["roofline"], second = kernel_rooflines(agent)
+            if second is not None:
+                out["roofline_update_kernel"] = second
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.n_envs, args.horizon)
         print(json.dumps(out), flush=True)
