@@ -254,6 +254,23 @@ typedef struct {
     const uint32_t* step_dev;
 } xrl_egreedy_t;
 int xrl_egreedy(const xrl_egreedy_t* p, xrl_stream_t stream);
+/* OffPolicyMARLAgents action selection (core/off_policy_marl.py:212-255,289-308; value_factorization.py:87-92):
+ * greedy = argmax_a Q with unavailable actions at -1e10; exploration = ONE coin for the whole vector step, and when it
+ * lands every agent of every env takes a uniformly random AVAILABLE action (Categorical(avail_mask).sample()). */
+typedef struct {
+    const float* q;          /* [R][ld] per-agent Q-values, R = n_envs * n_agents */
+    const float* avail;      /* NULL or [R][A] f32 0/1 */
+    const float* eps_dev;    /* [1] epsilon in device memory */
+    const float* coin;       /* NULL or [1] supplied uniform for the step coin (parity tests) */
+    const float* uniforms;   /* NULL or [R] supplied uniforms for the random actions */
+    int32_t* action;         /* [R] */
+    float* action_f;         /* NULL or [R] float32 copy (the replay buffer stores actions as float32) */
+    int32_t R, A, ld, pad;
+    uint64_t seed;
+    uint32_t step; const uint32_t* step_dev;
+} xrl_marl_act_t;
+int xrl_marl_select_actions(const xrl_marl_act_t* p, xrl_stream_t stream);
+
 /* *counter += inc on the stream (advances RNG step counters between replays of a captured rollout). */
 int xrl_counter_add(uint32_t* counter, uint32_t inc, xrl_stream_t stream);
 

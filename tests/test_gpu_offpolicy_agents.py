@@ -1,0 +1,138 @@
+"""GPU: off-policy agent loops at the shapes of BASELINE configs C3/C5 (DQN, QMIX), the MARL replay buffer against a
+NumPy mirror of memory_tools_marl.py:634-767, and the action-selection kernels on supplied randomness."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_egreedy_and_marl_select_on_supplied_randomness(oracle):
+    from xuance_amd import ops
+    rng = np.random.default_rng(0)
+    n, A = 300, 5
+    q = rng.standard_normal((n, A)).astype(np.float32)
+    u = rng.random(n).astype(np.float32)
+    ra = rng.integers(0, A, n).astype(np.int32)
+    eps = torch.tensor([0.3], device="cuda")
+    act = torch.zeros(n, dtype=torch.int32, device="cuda")
+    act_f = torch.zeros(n, device="cuda")
+    ops.egreedy(q=torch.as_tensor(q).cuda(), uniforms=torch.as_tensor(u).cuda(), randoms=torch.as_tensor(ra).cuda(),
+                eps_dev=eps, action=act, action_f=act_f, n=n, A=A, ld=A, seed=1, step=0, step_dev=None)
+    exp = oracle.egreedy_select(q.argmax(1), ra, u, np.float32(0.3))         # off_policy.py:138-141
+    assert np.array_equal(act.cpu().numpy(), exp) and np.array_equal(act_f.cpu().numpy(), exp.astype(np.float32))
+    # MARL: masked greedy when the coin does not land, uniformly random AVAILABLE action when it does
+    R = 240
+    qm = rng.standard_normal((R, 9)).astype(np.float32)
+    av = (rng.random((R, 9)) < 0.6).astype(np.float32); av[:, 0] = 1
+    um = rng.random(R).astype(np.float32)
+    out = torch.zeros(R, dtype=torch.int32, device="cuda")
+    for coin, explore in ((0.9, False), (0.1, True)):
+        ops.marl_select_actions(q=torch.as_tensor(qm).cuda(), avail=torch.as_tensor(av).cuda(), eps_dev=eps,
+                                coin=torch.tensor([coin], device="cuda"), uniforms=torch.as_tensor(um).cuda(), action=out,
+                                action_f=None, R=R, A=9, ld=9, seed=1, step=0, step_dev=None)
+        got = out.cpu().numpy()
+        if not explore:
+            assert np.array_equal(got, np.where(av > 0, qm, -1e10).argmax(1))   # value_factorization.py:87-92
+        else:
+            for r in range(R):
+                idxs = np.flatnonzero(av[r])
+                assert got[r] == idxs[min(int(np.float32(um[r]) * np.float32(len(idxs))), len(idxs) - 1)]
+
+
+def test_marl_buffer_matches_numpy_mirror():
+    from xuance_amd.memory_marl import HipMARLOffPolicyBuffer
+    from xuance_amd.spaces import Box, Discrete
+    rng = np.random.default_rng(1)
+    keys = ["agent_0", "agent_1", "agent_2"]
+    n_envs, n_size, O, S, A, steps, bs = 4, 6, 5, 7, 4, 9, 10
+    buf = HipMARLOffPolicyBuffer(keys, Box(-1, 1, (S,)), {k: Box(-1, 1, (O,)) for k in keys}, {k: Discrete(A) for k in keys},
+                                 n_envs, n_envs * n_size, bs, use_actions_mask=True,
+                                 avail_actions_shape={k: (A,) for k in keys})
+    ref = {}
+
+    def ref_store(t, data):                                    # memory_tools_marl.py:731-740 (env-major arrays)
+        p = t % n_size
+        for k, v in data.items():
+            if k in ("state", "state_next"):
+                ref.setdefault(k, np.zeros((n_envs, n_size) + v.shape[1:], np.float32))[:, p] = v
+            else:
+                for a in keys:
+                    ref.setdefault((k, a), np.zeros((n_envs, n_size) + v[a].shape[1:], np.float32))[:, p] = v[a]
+    for t in range(steps):
+        data = {"obs": {a: rng.standard_normal((n_envs, O)).astype(np.float32) for a in keys},
+                "obs_next": {a: rng.standard_normal((n_envs, O)).astype(np.float32) for a in keys},
+                "actions": {a: rng.integers(0, A, n_envs).astype(np.float32) for a in keys},
+                "rewards": {a: rng.standard_normal(n_envs).astype(np.float32) for a in keys},
+                "terminals": {a: rng.random(n_envs) < 0.2 for a in keys},
+                "agent_mask": {a: rng.random(n_envs) < 0.9 for a in keys},
+                "avail_actions": {a: rng.random((n_envs, A)) < 0.7 for a in keys},
+                "avail_actions_next": {a: rng.random((n_envs, A)) < 0.7 for a in keys},
+                "state": rng.standard_normal((n_envs, S)).astype(np.float32),
+                "state_next": rng.standard_normal((n_envs, S)).astype(np.float32)}
+        buf.store(**data)
+        ref_store(t, data)
+    assert (buf.ptr, buf.size) == (steps % n_size, n_size)
+    np.random.seed(5)
+    env = np.random.choice(n_envs, bs); step = np.random.choice(n_size, bs)
+    np.random.seed(5)
+    s = buf.sample()
+    for k in ("obs", "obs_next", "actions", "rewards", "terminals", "agent_mask", "avail_actions", "avail_actions_next"):
+        for a in keys:
+            assert np.array_equal(s[k][a].cpu().numpy(), ref[(k, a)][env, step].astype(np.float32)), (k, a)
+    assert np.array_equal(s["state"].cpu().numpy(), ref["state"][env, step])
+    assert s["batch_size"] == bs
+
+
+def test_dqn_agent_learns_cartpole():
+    """C3-style loop (store -> sample -> TD update with target sync, epsilon decay) on the device CartPole."""
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[128], q_hidden_size=[128], activation="relu",
+                    seed=1, parallels=16, running_steps=200000, buffer_size=16 * 2000, batch_size=256, learning_rate=1e-3,
+                    gamma=0.99, start_greedy=0.5, end_greedy=0.01, decay_step_greedy=20000, sync_frequency=50,
+                    training_frequency=16, start_training=1000, use_grad_clip=False, grad_clip_norm=0.5,
+                    use_obsnorm=False, use_rewnorm=False, distributed_training=False, device="cuda", model_dir="/tmp/x")
+    env = DeviceCartPoleVecEnv(16, seed=1)
+    agent = DQN_Agent(cfg, env)
+    agent.train(300)
+    e0, s0, _ = env.episode_stats()
+    env.stats.zero_()
+    info = agent.train(2500)
+    e1, s1, _ = env.episode_stats()
+    assert np.isfinite(info["Qloss"]) and agent.learner.iterations > 1000
+    assert abs(agent.e_greedy - 0.01) < 0.02                  # reaches end_greedy after decay_step/n_envs vector steps
+    assert s1 > 2 * s0 and s1 > 50, (s0, s1)
+
+
+def test_qmix_agents_on_smac_3m_shape():
+    """C5 shapes: 3 agents, obs 30, state 48, 9 masked actions, 64 envs, batch 32, n_epochs 8 (configs/qmix/sc2/3m.yaml)."""
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = Namespace(representation_hidden_size=[64], q_hidden_size=[64], hidden_dim_mixing_net=32, hidden_dim_hyper_net=32,
+                    activation="relu", seed=1, parallels=64, running_steps=10 ** 6, buffer_size=64 * 64, batch_size=32,
+                    learning_rate=7e-4, gamma=0.99, double_q=True, start_greedy=1.0, end_greedy=0.05,
+                    decay_step_greedy=50000, sync_frequency=200, training_frequency=1, start_training=640, n_epochs=8,
+                    use_grad_clip=False, grad_clip_norm=10.0, use_actions_mask=True, use_parameter_sharing=True,
+                    use_rnn=False, distributed_training=False, device="cuda", model_dir="/tmp/x")
+    env = SyntheticSMACVecEnv(64, seed=3)
+    agent = QMIX_Agents(cfg, env)
+    assert agent.model.params.P >= 17258                      # trainable parameters of the FF 3m model
+    p0 = agent.model.params.flat.clone()
+    info = agent.train(40)
+    assert agent.learner.iterations == 8 * 30                 # updates start at current_step >= 640 (vector step 10)
+    assert np.isfinite(info["loss_Q"]) and np.isfinite(info["predictQ"])
+    assert float((agent.model.params.flat - p0).abs().max()) > 0
+    # every stored action was available when it was taken
+    f = agent.memory.soa.fields
+    acts = f["actions"][:40].long().view(40, 64, 3)
+    av = f["avail_actions"][:40].view(40, 64, 3, 9)
+    assert bool(av.gather(-1, acts.unsqueeze(-1)).all())

@@ -127,7 +127,14 @@ class PpoFused(C.Structure):
                 ("pad2", c_float), ("dbg", c_void_p)]
 
 
+class MarlAct(C.Structure):
+    _fields_ = [("q", c_void_p), ("avail", c_void_p), ("eps_dev", c_void_p), ("coin", c_void_p), ("uniforms", c_void_p),
+                ("action", c_void_p), ("action_f", c_void_p), ("R", c_int32), ("A", c_int32), ("ld", c_int32),
+                ("pad", c_int32), ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
+
+
 _SIGS = {
+    "xrl_marl_select_actions": [C.POINTER(MarlAct), c_void_p],
     "xrl_ppo_fused_minibatch": [C.POINTER(PpoFused), c_void_p],
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_init": [],

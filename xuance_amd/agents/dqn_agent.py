@@ -1,0 +1,112 @@
+"""DQN agent loop on the HIP engine (xuance/torch/agents/qlearning_family/dqn_agent.py:10-52 with
+core/off_policy.py:23-270): greedy action from the eval network, per-env epsilon coin (off_policy.py:138-141), the
+reference's epsilon schedule quirk (delta computed with decay_step_greedy / n_envs while current_step grows by n_envs
+per vector step, :119-127), replay store, and one learner update per vector step after ``start_training``."""
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..learners.dqn_learner import DQN_Learner
+from ..memory import HipOffPolicyBuffer, HipOffPolicyBuffer_Atari
+from ..nets import DeepQNet
+from ..spaces import space2shape
+
+
+def _get(cfg, name, default=None):
+    return getattr(cfg, name, default)
+
+
+class DQN_Agent:
+    def __init__(self, config: Namespace, envs, callback=None):
+        self.config, self.envs, self.callback = config, envs, callback
+        self.device = _get(config, "device", "cuda")
+        self.n_envs = envs.num_envs
+        self.observation_space, self.action_space = envs.observation_space, envs.action_space
+        self.gamma = config.gamma
+        self.use_obsnorm, self.use_rewnorm = _get(config, "use_obsnorm", False), _get(config, "use_rewnorm", False)
+        self.obsnorm_range, self.rewnorm_range = _get(config, "obsnorm_range", 5.0), _get(config, "rewnorm_range", 5.0)
+        self.start_training, self.training_frequency = config.start_training, config.training_frequency
+        self.n_epochs = _get(config, "n_epochs", 1)
+        self.seed = int(_get(config, "seed", 1))
+        # dqn_agent.py:28-30
+        self.start_greedy, self.end_greedy = config.start_greedy, config.end_greedy
+        self.e_greedy = config.start_greedy
+        self.delta_egreedy = (self.start_greedy - self.end_greedy) / (config.decay_step_greedy / self.n_envs)
+        self.current_step = 0
+        dev, n = self.device, self.n_envs
+        self.obs_shape = space2shape(self.observation_space)
+        self.obs_dim = int(np.prod(self.obs_shape))
+        self.atari = _get(config, "env_name", "") == "Atari"
+        self.model = self._build_model()
+        self.memory = self._build_memory()
+        self.learner = self._build_learner(self.config, self.model, self.callback)
+        D = self.obs_dim
+        self.obs_mean = torch.zeros(D, device=dev)
+        self.obs_var = torch.ones(D, device=dev)
+        self.obs_count = torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
+        self.X = torch.zeros(n, D, device=dev)                 # processed observation
+        self.Xn = torch.zeros(n, D, device=dev)                # processed next observation
+        self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.act_f = torch.zeros(n, device=dev)
+        self.model.plan.ensure(max(n, 2 * config.batch_size))
+        self._started = False
+
+    def _build_model(self):
+        c = self.config
+        rep = list(_get(c, "representation_hidden_size", []) or []) if _get(c, "representation", "Basic_MLP") == "Basic_MLP" else []
+        return DeepQNet(self.obs_dim, self.action_space.n, rep, list(c.q_hidden_size), _get(c, "activation", "relu"),
+                        device=self.device)
+
+    def _build_memory(self):
+        c = self.config
+        Buffer = HipOffPolicyBuffer_Atari if self.atari else HipOffPolicyBuffer
+        return Buffer(self.observation_space, self.action_space, None, self.n_envs, c.buffer_size, c.batch_size,
+                      device=self.device)
+
+    def _build_learner(self, *args):
+        return DQN_Learner(*args)
+
+    def _update_explore_factor(self):                          # off_policy.py:119-127
+        if self.e_greedy is not None:
+            if self.e_greedy > self.end_greedy:
+                self.e_greedy = self.start_greedy - self.current_step * self.delta_egreedy
+        self.eps_dev.fill_(float(self.e_greedy))
+
+    def _normalize(self, raw, out, update):
+        n, D = self.n_envs, self.obs_dim
+        ops.obs_normalize(x=raw.reshape(n, D), mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=out,
+                          out1=None, n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(update and self.use_obsnorm),
+                          normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
+
+    def train(self, train_steps):
+        env, n, A = self.envs, self.n_envs, self.action_space.n
+        if not self._started:
+            env.reset()
+            self._started = True
+        info = {}
+        for _ in range(train_steps):
+            self._normalize(env.buf_obs.float(), self.X, update=True)        # obs_rms.update(obs); obs = process(obs)
+            q = self.model.forward(self.X, n)
+            ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=A, seed=self.seed,
+                        step=0, step_dev=self.step_counter)
+            env.step_device()
+            ops.counter_add(self.step_counter, 1)
+            self._normalize(env.next_obs.float(), self.Xn, update=False)
+            self.memory.store(self.X.view((n,) + tuple(self.obs_shape)), self.act_f, env.reward, env.terminated,
+                              self.Xn.view((n,) + tuple(self.obs_shape)))
+            if self.current_step > self.start_training and self.current_step % self.training_frequency == 0:
+                for _e in range(self.n_epochs):
+                    info = self.learner.update(**self.memory.sample())
+            self.current_step += n
+            self._update_explore_factor()
+        if hasattr(env, "episode_stats"):
+            eps, score, length = env.episode_stats()
+            info.update({"episodes": eps, "mean_episode_score": score, "mean_episode_length": length})
+        info["epsilon"] = self.e_greedy
+        return info
+
+    def finish(self):
+        self.envs.close()

@@ -1,0 +1,101 @@
+"""QMIX agents loop on the HIP engine, feed-forward agents with parameter sharing
+(xuance/torch/agents/multi_agent_rl/qmix_agents.py:12-93 with core/off_policy_marl.py:90-424 and
+base/agents_marl.py:339-376): per vector step the [n_envs, n_agents, obs] batch goes through the shared Q-network,
+actions are the masked greedy ones unless the step's single exploration coin lands (off_policy_marl.py:236-243),
+transitions are stored and, once ``current_step >= start_training`` and on the training frequency, ``n_epochs``
+updates are made (off_policy_marl.py:376-377)."""
+from argparse import Namespace
+
+import torch
+
+from .. import ops
+from ..learners.qmix_learner import QMIX_Learner
+from ..memory_marl import HipMARLOffPolicyBuffer
+from ..nets import MixingQNet
+
+
+def _get(cfg, name, default=None):
+    return getattr(cfg, name, default)
+
+
+class QMIX_Agents:
+    def __init__(self, config: Namespace, envs, callback=None):
+        self.config, self.envs, self.callback = config, envs, callback
+        self.device = _get(config, "device", "cuda")
+        self.n_envs = envs.num_envs
+        self.agent_keys = list(envs.agent_keys)
+        self.n_agents = len(self.agent_keys)
+        self.use_actions_mask = _get(config, "use_actions_mask", True)
+        self.start_training, self.training_frequency = config.start_training, config.training_frequency
+        self.n_epochs = _get(config, "n_epochs", 1)
+        self.seed = int(_get(config, "seed", 1))
+        self.start_greedy, self.end_greedy = config.start_greedy, config.end_greedy
+        self.e_greedy = config.start_greedy
+        self.delta_egreedy = (self.start_greedy - self.end_greedy) / config.decay_step_greedy
+        self.current_step = 0
+        k0 = self.agent_keys[0]
+        self.obs_dim = envs.observation_space[k0].shape[0]
+        self.n_actions = envs.action_space[k0].n
+        self.state_dim = envs.state_space.shape[0]
+        self.model = self._build_model()
+        self.memory = self._build_memory()
+        self.learner = self._build_learner(self.config, self.agent_keys, self.model, self.callback)
+        dev, R = self.device, self.n_envs * self.n_agents
+        self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.act_f = torch.zeros(self.n_envs, self.n_agents, device=dev)
+        self.model.agent_plan.ensure(max(R, 2 * config.batch_size * self.n_agents))
+        self._started = False
+
+    def _build_model(self):
+        c = self.config
+        return MixingQNet(self.n_agents, self.obs_dim, self.n_actions, self.state_dim,
+                          list(_get(c, "representation_hidden_size", [64])), list(_get(c, "q_hidden_size", [64])),
+                          _get(c, "hidden_dim_mixing_net", 32), _get(c, "hidden_dim_hyper_net", 32),
+                          _get(c, "activation", "relu"), device=self.device)
+
+    def _build_memory(self):
+        c, env = self.config, self.envs
+        return HipMARLOffPolicyBuffer(self.agent_keys, env.state_space, env.observation_space, env.action_space,
+                                      self.n_envs, c.buffer_size, c.batch_size, device=self.device,
+                                      use_actions_mask=self.use_actions_mask,
+                                      avail_actions_shape={k: (self.n_actions,) for k in self.agent_keys})
+
+    def _build_learner(self, *args):
+        return QMIX_Learner(*args)
+
+    def _update_explore_factor(self):                          # off_policy_marl.py:197-204
+        if self.e_greedy > self.end_greedy:
+            self.e_greedy = self.start_greedy - self.delta_egreedy * self.current_step
+        else:
+            self.e_greedy = self.end_greedy
+        self.eps_dev.fill_(float(self.e_greedy))
+
+    def train(self, train_steps):
+        env, n, N, A = self.envs, self.n_envs, self.n_agents, self.n_actions
+        R = n * N
+        if not self._started:
+            env.reset()
+            self._started = True
+        info = {}
+        for _ in range(train_steps):
+            obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
+            q = self.model.agent_plan.forward(obs.view(R, -1), self.obs_dim, R)      # shared network on [n*N, obs]
+            ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
+                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,
+                                    step_dev=self.step_counter)
+            env.step_device()
+            ops.counter_add(self.step_counter, 1)
+            self.memory.store(obs=obs, actions=self.act_f, obs_next=env.next_obs, rewards=env.rewards,
+                              terminals=env.terminals, agent_mask=env.agent_mask, state=state, state_next=env.next_state,
+                              avail_actions=avail, avail_actions_next=env.next_avail)
+            if self.current_step >= self.start_training and self.current_step % self.training_frequency == 0:
+                for _e in range(self.n_epochs):
+                    info = self.learner.update(self.memory.sample())
+            self.current_step += n
+            self._update_explore_factor()
+        info["epsilon"] = self.e_greedy
+        return info
+
+    def finish(self):
+        self.envs.close()

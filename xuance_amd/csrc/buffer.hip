@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-constexpr int MAX_FIELDS = 8;
+constexpr int MAX_FIELDS = 16;
 struct FieldPack {
     void* dst[MAX_FIELDS];
     const void* src[MAX_FIELDS];

@@ -273,6 +273,39 @@ __global__ void __launch_bounds__(256) egreedy_kernel(xrl_egreedy_t p) {
     if (p.action_f) p.action_f[e] = (float)a;
 }
 
+__global__ void __launch_bounds__(256) marl_select_kernel(xrl_marl_act_t p) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.R) return;
+    const float* q = p.q + (size_t)r * p.ld;
+    const float* av = p.avail ? p.avail + (size_t)r * p.A : nullptr;
+    int best = 0, n_avail = 0;
+    float bv = (av && av[0] == 0.f) ? -1e10f : q[0];
+    for (int j = 0; j < p.A; ++j) {
+        const bool ok = !av || av[j] != 0.f;
+        n_avail += ok;
+        const float v = ok ? q[j] : -1e10f;
+        if (j > 0 && v > bv) { bv = v; best = j; }
+    }
+    const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
+    uint32_t c[4];
+    philox4x32(p.seed, 0xFFFFFFFFu, step, STREAM_EGREEDY, c);             // the step coin: same counter for every row
+    const float coin = p.coin ? *p.coin : u01(c[0]);
+    int a = best;
+    if (coin < *p.eps_dev) {
+        uint32_t rr[4];
+        philox4x32(p.seed, (uint32_t)r, step, STREAM_EGREEDY + 1u, rr);
+        const float u = p.uniforms ? p.uniforms[r] : u01(rr[0]);
+        int kth = min((int)(u * (float)max(n_avail, 1)), max(n_avail, 1) - 1), seen = 0;
+        a = 0;
+        for (int j = 0; j < p.A; ++j) {
+            const bool ok = !av || av[j] != 0.f;
+            if (ok) { if (seen == kth) { a = j; break; } ++seen; }
+        }
+    }
+    p.action[r] = a;
+    if (p.action_f) p.action_f[r] = (float)a;
+}
+
 __global__ void counter_add_kernel(uint32_t* c, uint32_t inc) { *c += inc; }
 
 }  // namespace xrl
@@ -329,6 +362,15 @@ extern "C" int xrl_egreedy(const xrl_egreedy_t* params, xrl_stream_t stream) {
     const xrl_egreedy_t& p = *params;
     XRL_CHECK_ARG(p.q && p.eps_dev && p.action && p.n > 0 && p.A > 0 && p.ld >= p.A);
     hipLaunchKernelGGL(egreedy_kernel, dim3((p.n + 255) / 256), dim3(256), 0, as_stream(stream), p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_marl_select_actions(const xrl_marl_act_t* params, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_marl_act_t& p = *params;
+    XRL_CHECK_ARG(p.q && p.eps_dev && p.action && p.R > 0 && p.A > 0 && p.ld >= p.A);
+    hipLaunchKernelGGL(marl_select_kernel, dim3((p.R + 255) / 256), dim3(256), 0, as_stream(stream), p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -1,0 +1,149 @@
+"""Shape-faithful synthetic vector environments that live on the device (no simulator is installed in this image:
+SURVEY.md section 8d).  They emit exactly the tensors the agents of BASELINE configs C3-C5 consume -- Atari-shaped uint8
+frame stacks, MuJoCo-shaped float vectors with continuous actions, SMAC-3m-shaped multi-agent observations / global
+state / action masks -- with cheap deterministic dynamics so that rollouts, buffers and learners are exercised at the
+real shapes.  They are input providers, not part of the measured hot path."""
+import numpy as np
+import torch
+
+from ..spaces import Box, Discrete
+
+
+class _Base:
+    def __init__(self, num_envs, seed, device, max_episode_steps):
+        self.num_envs, self.device, self.max_episode_steps = int(num_envs), device, int(max_episode_steps)
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(int(seed))
+        self.steps = torch.zeros(self.num_envs, dtype=torch.int32, device=device)
+        self.terminated = torch.zeros(self.num_envs, device=device)
+        self.truncated = torch.zeros(self.num_envs, device=device)
+        self.reward = torch.zeros(self.num_envs, device=device)
+
+    def _end_of_step(self, p_term):
+        self.steps += 1
+        self.terminated = (torch.rand(self.num_envs, device=self.device, generator=self.gen) < p_term).float()
+        self.truncated = ((self.steps >= self.max_episode_steps) & (self.terminated == 0)).float()
+        done = (self.terminated + self.truncated) > 0
+        self.steps[done] = 0
+        return done
+
+    def close(self):
+        pass
+
+
+class SyntheticAtariVecEnv(_Base):
+    """84x84x4 uint8 frame stacks, Discrete(4) (Breakout-shaped, configs/dqn/atari.yaml:7-8)."""
+
+    def __init__(self, num_envs, seed=1, device="cuda", n_actions=4, max_episode_steps=1000):
+        super().__init__(num_envs, seed, device, max_episode_steps)
+        self.observation_space = Box(0, 255, (84, 84, 4), np.uint8)
+        self.action_space = Discrete(n_actions)
+        self.buf_obs = torch.zeros(self.num_envs, 84, 84, 4, dtype=torch.uint8, device=device)
+        self.next_obs = torch.zeros_like(self.buf_obs)
+        self.action = torch.zeros(self.num_envs, dtype=torch.int32, device=device)
+
+    def _frames(self):
+        return torch.randint(0, 256, self.buf_obs.shape, dtype=torch.uint8, device=self.device, generator=self.gen)
+
+    def reset(self):
+        self.buf_obs.copy_(self._frames())
+        return self.buf_obs, [{} for _ in range(self.num_envs)]
+
+    def step_device(self):
+        self.next_obs.copy_(self._frames())
+        self.reward = (self.action == (self.steps % self.action_space.n)).float()
+        done = self._end_of_step(0.002)
+        self.buf_obs.copy_(self.next_obs)
+        if bool(done.any()):
+            self.buf_obs[done] = self._frames()[done]
+
+
+class SyntheticMujocoVecEnv(_Base):
+    """obs (17,) float32, Box(6) actions (HalfCheetah-shaped, configs/ppo/mujoco.yaml); linear-tanh dynamics."""
+
+    def __init__(self, num_envs, seed=1, device="cuda", obs_dim=17, act_dim=6, max_episode_steps=1000):
+        super().__init__(num_envs, seed, device, max_episode_steps)
+        self.observation_space = Box(-np.inf, np.inf, (obs_dim,), np.float32)
+        self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
+        g = torch.Generator().manual_seed(int(seed) + 1000)
+        self.A = (torch.randn(obs_dim, obs_dim, generator=g) * 0.3).to(device)
+        self.B = (torch.randn(act_dim, obs_dim, generator=g) * 0.5).to(device)
+        self.state = torch.zeros(self.num_envs, obs_dim, device=device)
+        self.buf_obs = torch.zeros(self.num_envs, obs_dim, device=device)
+        self.next_obs = torch.zeros_like(self.buf_obs)
+        self.action = torch.zeros(self.num_envs, act_dim, device=device)
+        self.ep_score = torch.zeros(self.num_envs, device=device)
+        self.stats = torch.zeros(4, dtype=torch.float64, device=device)
+
+    def reset(self):
+        self.state = torch.randn(self.state.shape, device=self.device, generator=self.gen) * 0.1
+        self.buf_obs.copy_(self.state)
+        return self.buf_obs, [{} for _ in range(self.num_envs)]
+
+    def step_device(self):
+        a = self.action.clamp(-1, 1)
+        self.state = torch.tanh(self.state @ self.A + a @ self.B) + 0.01 * torch.randn(self.state.shape, device=self.device,
+                                                                                      generator=self.gen)
+        self.reward = self.state[:, 0] - 0.1 * (a * a).sum(1)
+        self.next_obs.copy_(self.state)
+        self.ep_score += self.reward
+        done = self._end_of_step(0.0)
+        if bool(done.any()):
+            self.stats[0] += done.sum()
+            self.stats[1] += self.ep_score[done].sum().double()
+            self.ep_score[done] = 0
+            self.state[done] = torch.randn(self.state.shape, device=self.device, generator=self.gen)[done] * 0.1
+        self.buf_obs.copy_(self.state)
+
+    def episode_stats(self):
+        s = self.stats.cpu().numpy()
+        return int(s[0]), float(s[1] / max(s[0], 1.0)), float(self.max_episode_steps)
+
+
+class SyntheticSMACVecEnv(_Base):
+    """SMAC map 3m shape: 3 agents, obs (30,), state (48,), 9 actions with availability masks, 60-step episodes
+    (docs/source/documents/benchmark/smac/smac.rst:15,19; obs/state/action dims are SMAC-upstream values)."""
+
+    def __init__(self, num_envs, seed=1, device="cuda", n_agents=3, obs_dim=30, state_dim=48, n_actions=9,
+                 max_episode_steps=60):
+        super().__init__(num_envs, seed, device, max_episode_steps)
+        self.n_agents, self.obs_dim, self.state_dim, self.n_actions = n_agents, obs_dim, state_dim, n_actions
+        self.agent_keys = [f"agent_{i}" for i in range(n_agents)]
+        self.observation_space = {k: Box(-np.inf, np.inf, (obs_dim,), np.float32) for k in self.agent_keys}
+        self.action_space = {k: Discrete(n_actions) for k in self.agent_keys}
+        self.state_space = Box(-np.inf, np.inf, (state_dim,), np.float32)
+        n, N = self.num_envs, n_agents
+        self.buf_obs = torch.zeros(n, N, obs_dim, device=device)
+        self.buf_state = torch.zeros(n, state_dim, device=device)
+        self.buf_avail = torch.ones(n, N, n_actions, device=device)
+        self.agent_mask = torch.ones(n, N, device=device)
+        self.action = torch.zeros(n, N, dtype=torch.int32, device=device)
+        self.next_obs, self.next_state, self.next_avail = (torch.zeros_like(self.buf_obs), torch.zeros_like(self.buf_state),
+                                                           torch.ones_like(self.buf_avail))
+        self.rewards = torch.zeros(n, N, device=device)
+        self.terminals = torch.zeros(n, N, device=device)
+
+    def _draw(self):
+        n, N = self.num_envs, self.n_agents
+        obs = torch.randn(n, N, self.obs_dim, device=self.device, generator=self.gen)
+        state = torch.randn(n, self.state_dim, device=self.device, generator=self.gen)
+        avail = (torch.rand(n, N, self.n_actions, device=self.device, generator=self.gen) < 0.7).float()
+        avail[..., 0] = 1.0                                   # no-op is always available (SMAC convention)
+        return obs, state, avail
+
+    def reset(self):
+        o, s, a = self._draw()
+        self.buf_obs.copy_(o); self.buf_state.copy_(s); self.buf_avail.copy_(a)
+        return self.buf_obs, [{} for _ in range(self.num_envs)]
+
+    def step_device(self):
+        o, s, a = self._draw()
+        self.next_obs.copy_(o); self.next_state.copy_(s); self.next_avail.copy_(a)
+        r = (self.action.float().mean(1) / self.n_actions + 0.1 * self.buf_state[:, 0])
+        self.rewards.copy_(r[:, None].expand(-1, self.n_agents))          # shared team reward
+        done = self._end_of_step(0.01)
+        self.terminals.copy_(self.terminated[:, None].expand(-1, self.n_agents))
+        o2, s2, a2 = self._draw()
+        d3 = done[:, None, None]
+        self.buf_obs.copy_(torch.where(d3, o2, o)); self.buf_state.copy_(torch.where(done[:, None], s2, s))
+        self.buf_avail.copy_(torch.where(d3, a2, a))

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, call, ptr,
+from ._lib import (ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -252,6 +252,10 @@ def qmix_mix_td(**kw):
 
 def sync_target(params, target, P, state, sync_frequency):
     call("xrl_sync_target", ptr(params), ptr(target), int(P), ptr(state), int(sync_frequency), stream_ptr())
+
+
+def marl_select_actions(**kw):
+    call("xrl_marl_select_actions", C.byref(_struct(MarlAct, kw)), stream_ptr())
 
 
 def counter_add(counter, inc):
