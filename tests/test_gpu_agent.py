@@ -220,3 +220,50 @@ def test_fused_minibatch_kernel_equals_layered_path(n, T, nmb):
     for key in ("actor_loss", "critic_loss", "entropy", "predict_value", "clip_ratio"):
         assert_close(info_fused[key], info_ref[key], 1e-5, key)
     assert_close(diag_fused, diag_ref, 1e-5, "log_prob/ratio/surrogates")
+
+
+def test_ppo_gaussian_agent_on_mujoco_shape(oracle):
+    """C4 shapes (obs 17, Box(6), Gaussian actor 17-256-256-6 tanh, critic 17-256-256-1, Basic_Identical): the layered
+    rollout + update path end to end, checked against the oracle on the device's own rollout data."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import SyntheticMujocoVecEnv
+    torch.manual_seed(0)
+    n, T = 32, 16
+    cfg = make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
+                      critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1,
+                      n_minibatch=2, ent_coef=0.0, gamma=0.99, use_hip_graph=False)
+    env = SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=10)
+    agent = PPO_Agent(cfg, env)
+    assert agent.model.dist == "gaussian" and not agent.use_fused_rollout
+    assert sum(int(np.prod(v.shape)) for v in agent.model.state_dict().values()) == 142605    # SURVEY 8a parameter count
+    sd = {k: npy(v) for k, v in agent.model.state_dict().items()}
+    agent.rollout()
+    torch.cuda.synchronize()
+    f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+    # acting: values and log-probs of the stored (observation, action) pairs under the initial parameters
+    mu, v = oracle.actor_critic_forward(sd, f["observations"].reshape(-1, 17), "gaussian", "leaky_relu", "tanh")
+    assert_close(f["values"].reshape(-1), v, 1e-5, "values")
+    ls = sd["actor.log_std"]
+    x = f["actions"].reshape(-1, 6)
+    lp = (-((x - mu) ** 2) / (2 * np.exp(ls) ** 2) - ls - 0.5 * np.log(2 * np.pi)).sum(-1)
+    assert_close(f["aux_old_logp"].reshape(-1), lp, 1e-5, "old_logp", scale=float(np.abs(lp).max()))
+    assert (f["seg"][9] & 1).all() and (f["seg"][T - 1] & 1).all()       # truncation at 10 steps and at buffer end
+    # update: oracle on the same minibatches
+    idx = np.stack([np.random.default_rng(3).permutation(n * T)]).reshape(2, -1)
+    agent.set_indices(idx)
+    info = agent.update()
+    buf = oracle.OnPolicyBufferOracle((17,), (6,), n, T)
+    buf.size = T
+    buf.observations, buf.actions = f["observations"].transpose(1, 0, 2), f["actions"].transpose(1, 0, 2)
+    buf.returns, buf.values, buf.advantages, buf.old_logp = f["returns"].T, f["values"].T, f["advantages"].T, f["aux_old_logp"].T
+    opt = oracle.AdamOracle(sd, lr=4e-4, eps=1e-5, total_iters=agent.learner.total_iters)
+    c = dict(vf_coef=0.25, ent_coef=0.0, clip_range=0.2, use_grad_clip=True, grad_clip_norm=0.5)
+    for k in range(2):
+        s = buf.sample(idx[k])
+        oi, _ = oracle.ppo_update(sd, opt, dict(obs=s["obs"], actions=s["actions"], returns=s["returns"],
+                                                advantages=s["advantages"], old_logp=s["aux_batch"]["old_logp"]), c,
+                                  dist="gaussian", act="leaky_relu", activation_action="tanh")
+    got = agent.model.state_dict()
+    for k_, val in sd.items():
+        assert_close(npy(got[k_]), val, 2e-5, f"param {k_}")
+    assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss")

@@ -210,7 +210,7 @@ class PPO_Agent:
             if self.use_fused_rollout:
                 self.pp["obs_raw"][0].copy_(self.envs.buf_obs)
             self._started = True
-        if self.use_graph:
+        if self.use_graph and getattr(self.envs, "graph_safe", True):
             if self._rollout_graph is None:
                 torch.cuda.synchronize()
                 g = ops.Graph()

@@ -10,6 +10,8 @@ from ..spaces import Box, Discrete
 
 
 class _Base:
+    graph_safe = False      # torch RNG ops inside step_device(): do not capture these envs into a hipGraph
+
     def __init__(self, num_envs, seed, device, max_episode_steps):
         self.num_envs, self.device, self.max_episode_steps = int(num_envs), device, int(max_episode_steps)
         self.gen = torch.Generator(device=device)
