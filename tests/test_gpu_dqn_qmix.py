@@ -95,3 +95,20 @@ def test_qmix_learner_vs_reference_fixture(double_q):
         info["loss_Q"] = info["loss_Q"]
         return info
     check_updates(g, net, learner, cb, call, ("q_tot_eval", "q_tot_next", "q_tot_target"), "loss_Q")
+
+
+def test_dqn_cnn_learner_vs_reference_fixture():
+    """BASELINE config C3 shapes: 84x84x4 uint8 frames, CNN 32/64/64 (k 8/4/3, s 4/2/1) + global max-pool + 64-512-4 head."""
+    from xuance_amd.nets import DeepQCNN
+    from xuance_amd.learners import DQN_Learner
+    g = load_golden("dqn_cnn")
+    lr, gamma, sync, gclip, use_clip, total = g["cfg"]
+    net = DeepQCNN((84, 84, 4), 4)
+    assert list(net.ref_order) == list(sub(g, "init").keys())
+    assert sum(int(np.prod(net.params.shapes[k])) for k in net.trainable_order) == 113316      # SURVEY 8a
+    net.load_state_dict(sub(g, "init"))
+    cb = Capture()
+    learner = DQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
+                                   use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip)), net, cb)
+    check_updates(g, net, learner, cb, lambda b: learner.update(batch_size=len(b["obs"]), **b),
+                  ("evalQ", "predictQ", "targetQ"), "Qloss", gtol=5e-5)

@@ -89,7 +89,7 @@ class DQN_Agent:
         info = {}
         for _ in range(train_steps):
             self._normalize(env.buf_obs.float(), self.X, update=True)        # obs_rms.update(obs); obs = process(obs)
-            q = self.model.forward(self.X, n)
+            q = self.model.forward(self.X[:n], n)
             ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=A, seed=self.seed,
                         step=0, step_dev=self.step_counter)
             env.step_device()

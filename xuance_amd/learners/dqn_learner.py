@@ -31,7 +31,8 @@ class DQN_Learner(Learner):
         self.slabs = torch.zeros(32, P, device=dev)
         self.partials = torch.zeros(32, 8, dtype=torch.float64, device=dev)
         self.diag = torch.zeros(2 * M, device=dev)
-        self.X = torch.zeros(2 * M, self.model.obs_dim, device=dev)
+        xdt = torch.uint8 if getattr(self.model, "obs_shape", None) is not None and len(self.model.obs_shape) == 3 else torch.float32
+        self.X = torch.zeros(2 * M, self.model.obs_dim, dtype=xdt, device=dev)
         self.model.plan.ensure(2 * M)
         self.model.target_plan.ensure(M)
 
@@ -42,13 +43,13 @@ class DQN_Learner(Learner):
         """self.X rows [0,M) = obs, rows [M,2M) = obs_next (already on the device)."""
         model, opt, A = self.model, self.optimizer, self.n_actions
         S = pick_n_split(M)
-        q_all = model.forward(self.X, 2 * M if self.double_q else M)                 # evalQ (:39) [+ Q_eval(s')]
-        q_next = model.target(self.X[M:], M)                                         # targetQ (:40)
-        d_q = model.plan.dacts[len(model.plan.widths) - 1]
+        q_all = model.forward(self.X[:2 * M] if self.double_q else self.X[:M], M)    # evalQ (:39) [+ Q_eval(s')]
+        q_next = model.target(self.X[M:2 * M], M)                                    # targetQ (:40)
+        d_q = model.d_out
         ops.dqn_td(q_eval=q_all, q_next=q_next, q_next_eval=q_all[M:] if self.double_q else None, actions=act,
                    rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A, ld=A,
                    n_split=S, gamma=float(self.gamma))
-        model.plan.backward(self.X, model.obs_dim, M, self.slabs, S)
+        model.backward(self.X, M, self.slabs, S)
         ops.grad_reduce(self.slabs, S, model.params.P, model.params.P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_
@@ -61,11 +62,10 @@ class DQN_Learner(Learner):
 
     def update(self, **samples):
         self.iterations += 1
-        obs = self._as_dev(samples["obs"])
-        M = obs.shape[0]
+        M = len(samples["obs"])
         self._ensure(M)
-        self.X[:M].copy_(obs.reshape(M, -1))
-        self.X[M:2 * M].copy_(self._as_dev(samples["obs_next"]).reshape(M, -1))
+        self.X[:M].copy_(torch.as_tensor(samples["obs"], device=self.X.device).reshape(M, -1))
+        self.X[M:2 * M].copy_(torch.as_tensor(samples["obs_next"], device=self.X.device).reshape(M, -1))
         act, rew, ter = self._as_dev(samples["actions"]), self._as_dev(samples["rewards"]), self._as_dev(samples["terminals"])
         info = self.callback.on_update_start(self.iterations, policy=self.model, obs=self.X[:M], act=act,
                                              next_obs=self.X[M:2 * M], rew=rew, termination=ter) or {}

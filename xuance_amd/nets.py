@@ -111,9 +111,9 @@ class Plan:
             ops.linear_fwd(groups)
         return self.acts[len(self.widths) - 1]
 
-    def backward(self, x, ldx, M, slabs, n_split, flat=None):
+    def backward(self, x, ldx, M, slabs, n_split, flat=None, dx0=None):
         """dacts[last] must hold d loss / d (pre-activation) of the last level. Writes weight/bias gradient
-        partials into slabs[s][layout of params]."""
+        partials into slabs[s][layout of params].  dx0: optional [M, widths[0]] tensor receiving d loss / d input."""
         P = self.params
         stride = slabs.shape[1]
         for si in reversed(range(len(self.stages))):
@@ -130,6 +130,9 @@ class Plan:
                     prev_act = self._act_of(L.in_level, L.in_off)
                     dg.append(ops.gemm_desc(dy, P.ptr(L.w_name, flat), dx, M, L.K, L.N, lddy, L.K, lddx,
                                             aux=aux, ldaux=ldaux, act=prev_act))
+                elif dx0 is not None:
+                    dg.append(ops.gemm_desc(dy, P.ptr(L.w_name, flat), dx0.data_ptr() + 4 * L.in_off, M, L.K, L.N, lddy,
+                                            L.K, self.widths[0]))
             ops.linear_bwd_weight(wg, n_split, stride)
             if dg:
                 ops.linear_bwd_data(dg)
@@ -384,10 +387,18 @@ class DeepQNet:
         self.target_flat.copy_(self.params.flat)
 
     def forward(self, x, M, ldx=None):
-        return self.plan.forward(x, self.obs_dim if ldx is None else ldx, M)
+        """x holds x.shape[0] >= M rows; all rows are evaluated, backward() differentiates the first M."""
+        return self.plan.forward(x, self.obs_dim if ldx is None else ldx, x.shape[0])
 
     def target(self, x, M, ldx=None):
         return self.target_plan.forward(x, self.obs_dim if ldx is None else ldx, M, flat=self.target_flat)
+
+    @property
+    def d_out(self):
+        return self.plan.dacts[len(self.plan.widths) - 1]
+
+    def backward(self, x, M, slabs, n_split):
+        self.plan.backward(x, self.obs_dim, M, slabs, n_split)
 
 
 class MixingQNet:
@@ -473,3 +484,93 @@ class MixingQNet:
 
     def copy_target(self):                                        # value_factorization.py:169-174
         self.target_flat.copy_(self.params.flat)
+
+
+class DeepQCNN:
+    """DeepQNetwork with the Basic_CNN representation of configs/dqn/atari.yaml (rl_models/representations/cnn.py:11-50:
+    x/255, NHWC->NCHW, Conv2d(k, s, pad=(k-s)//2)+ReLU x3, AdaptiveMaxPool2d(1,1), Flatten) and a QValueHead MLP.
+
+    Hybrid in round 1 ("conv stays on MIOpen/torch initially"): the convolution stack runs
+    on PyTorch-ROCm's MIOpen convolutions over views of OUR flat parameter buffer, everything after the 64-d feature
+    (Q head GEMMs, TD target, gradient slabs, clip, Adam, target sync) runs on the HIP engine.  Conv gradients are
+    written into slab 0 of the shared gradient layout so the optimiser treats all parameters uniformly."""
+
+    def __init__(self, obs_shape=(84, 84, 4), n_actions=4, kernels=(8, 4, 3), strides=(4, 2, 1), filters=(32, 64, 64),
+                 q_hidden=(512,), activation="relu", device="cuda", init=True):
+        assert activation == "relu"
+        self.obs_shape, self.n_actions, self.obs_dim = tuple(obs_shape), n_actions, int(obs_shape[0] * obs_shape[1] * obs_shape[2])
+        self.kernels, self.strides, self.filters = tuple(kernels), tuple(strides), tuple(filters)
+        specs, order, stages, widths = [], [], [], [filters[-1]]
+        C = obs_shape[2]
+        self.conv_names = []
+        for i, (k, f) in enumerate(zip(kernels, filters)):
+            n = f"representation.model.{2 * i}"
+            specs += [(n + ".weight", (f, C, k, k)), (n + ".bias", (f,))]
+            order += [n + ".weight", n + ".bias"]
+            self.conv_names.append(n)
+            C = f
+        _seq_layers("eval_Q_head.q_value", filters[-1], list(q_hidden) + [n_actions], activation, None, 0, specs, order,
+                    stages, widths)
+        self.params = FlatParams(specs, device)
+        self.target_flat = self.params.like()
+        self.plan = Plan(self.params, widths, stages)
+        self.target_plan = Plan(self.params, widths, stages)
+        rep = [k for k in order if k.startswith("representation.")]
+        head = [k for k in order if k.startswith("eval_Q_head.")]
+        self.ref_order = rep + ["target_" + k for k in rep] + head + ["target_Q_head." + k[len("eval_Q_head."):] for k in head]
+        self.trainable_order = rep + head
+        self._feat = None
+        if init:
+            for name in order:
+                v = self.params.view(name)
+                v.copy_(_orthogonal(v.shape)) if name.endswith(".weight") else v.zero_()
+            self.copy_target()
+
+    _target_key = DeepQNet._target_key
+    state_dict = DeepQNet.state_dict
+    load_state_dict = DeepQNet.load_state_dict
+    copy_target = DeepQNet.copy_target
+
+    def _features(self, x_u8, flat, grad):
+        import torch.nn.functional as F
+        x = (x_u8.reshape((-1,) + self.obs_shape) / 255.0).to(torch.float32).permute(0, 3, 1, 2)     # cnn.py:45-48
+        leaves = []
+        with torch.set_grad_enabled(grad):
+            for n, k, s in zip(self.conv_names, self.kernels, self.strides):
+                w, b = self.params.view(n + ".weight", flat), self.params.view(n + ".bias", flat)
+                if grad:
+                    w, b = w.detach().requires_grad_(True), b.detach().requires_grad_(True)
+                    leaves += [w, b]
+                x = F.relu(F.conv2d(x, w, b, stride=s, padding=(k - s) // 2))                       # layers.py:46
+            x = torch.amax(x, dim=(2, 3))                                                          # AdaptiveMaxPool2d((1,1))
+        return x, leaves
+
+    def forward(self, x_u8, M, ldx=None):
+        """Rows [0, M) are differentiated through (eval Q of obs); returns Q [rows, n_actions]."""
+        rows = x_u8.shape[0]
+        feat, self._leaves = self._features(x_u8[:M], None, True)
+        self._feat = feat
+        if rows > M:                                       # double-Q: eval net on next_obs, no gradient
+            feat = torch.cat([feat.detach(), self._features(x_u8[M:], None, False)[0]], 0)
+        self._feat_in = feat.detach().contiguous()
+        return self.plan.forward(self._feat_in, self.filters[-1], rows)
+
+    def target(self, x_u8, M, ldx=None):
+        feat, _ = self._features(x_u8, self.target_flat, False)
+        self._tfeat = feat.contiguous()
+        return self.target_plan.forward(self._tfeat, self.filters[-1], M, flat=self.target_flat)
+
+    @property
+    def d_out(self):
+        return self.plan.dacts[len(self.plan.widths) - 1]
+
+    def backward(self, x_u8, M, slabs, n_split):
+        dfeat = torch.zeros(M, self.filters[-1], device=self.params.device)
+        self.plan.backward(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=dfeat)
+        grads = torch.autograd.grad(self._feat, self._leaves, grad_outputs=dfeat)
+        P = self.params
+        for name, g in zip([n + s for n in self.conv_names for s in (".weight", ".bias")], grads):
+            o = P.offsets[name]
+            slabs[0, o:o + g.numel()].copy_(g.reshape(-1))
+            if n_split > 1:
+                slabs[1:n_split, o:o + g.numel()].zero_()
