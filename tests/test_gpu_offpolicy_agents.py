@@ -136,3 +136,28 @@ def test_qmix_agents_on_smac_3m_shape():
     acts = f["actions"][:40].long().view(40, 64, 3)
     av = f["avail_actions"][:40].view(40, 64, 3, 9)
     assert bool(av.gather(-1, acts.unsqueeze(-1)).all())
+
+
+def test_dqn_agent_on_atari_shape():
+    """C3 shapes: 64 envs of 84x84x4 uint8 frames, SoA uint8 replay in HBM (2 x 28 224 B per transition), batch 32."""
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = Namespace(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                    q_hidden_size=[512], activation="relu", seed=1, parallels=64, running_steps=10 ** 6,
+                    buffer_size=64 * 32, batch_size=32, learning_rate=1e-4, gamma=0.99, start_greedy=0.5, end_greedy=0.05,
+                    decay_step_greedy=10 ** 6, sync_frequency=500, training_frequency=64, start_training=64 * 8,
+                    use_grad_clip=False, grad_clip_norm=0.5, use_obsnorm=False, use_rewnorm=False,
+                    distributed_training=False, device="cuda", model_dir="/tmp/x")
+    env = SyntheticAtariVecEnv(64, seed=2)
+    agent = DQN_Agent(cfg, env)
+    assert agent.memory.soa.fields["observations"].dtype == torch.uint8
+    assert agent.memory.soa.row_bytes["observations"] == 28224
+    p0 = agent.model.params.flat.clone()
+    info = agent.train(14)
+    assert agent.learner.iterations == 5 and np.isfinite(info["Qloss"])
+    assert float((agent.model.params.flat - p0).abs().max()) > 0
+    # the frames written to the ring are the frames the env produced (last stored step)
+    t = (agent.memory.ptr - 1) % agent.memory.n_size
+    assert torch.equal(agent.memory.soa.fields["next_observations"][t], env.next_obs)

@@ -46,16 +46,22 @@ class DQN_Agent:
         self.obs_mean = torch.zeros(D, device=dev)
         self.obs_var = torch.ones(D, device=dev)
         self.obs_count = torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
-        self.X = torch.zeros(n, D, device=dev)                 # processed observation
-        self.Xn = torch.zeros(n, D, device=dev)                # processed next observation
+        xdt = torch.uint8 if self.atari else torch.float32
+        self.X = torch.zeros(n, D, dtype=xdt, device=dev)      # processed observation
+        self.Xn = torch.zeros(n, D, dtype=xdt, device=dev)     # processed next observation
         self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.act_f = torch.zeros(n, device=dev)
         self.model.plan.ensure(max(n, 2 * config.batch_size))
+        assert not (self.atari and self.use_obsnorm), "Atari frames are stored as uint8 (configs/dqn/atari.yaml:42-43)"
         self._started = False
 
     def _build_model(self):
         c = self.config
+        if _get(c, "representation", "Basic_MLP") == "Basic_CNN":
+            from ..nets import DeepQCNN
+            return DeepQCNN(tuple(self.obs_shape), self.action_space.n, tuple(c.kernels), tuple(c.strides), tuple(c.filters),
+                            tuple(c.q_hidden_size), _get(c, "activation", "relu"), device=self.device)
         rep = list(_get(c, "representation_hidden_size", []) or []) if _get(c, "representation", "Basic_MLP") == "Basic_MLP" else []
         return DeepQNet(self.obs_dim, self.action_space.n, rep, list(c.q_hidden_size), _get(c, "activation", "relu"),
                         device=self.device)
@@ -77,6 +83,9 @@ class DQN_Agent:
 
     def _normalize(self, raw, out, update):
         n, D = self.n_envs, self.obs_dim
+        if self.atari:
+            out.copy_(raw.reshape(n, D))
+            return
         ops.obs_normalize(x=raw.reshape(n, D), mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=out,
                           out1=None, n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(update and self.use_obsnorm),
                           normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
@@ -88,13 +97,13 @@ class DQN_Agent:
             self._started = True
         info = {}
         for _ in range(train_steps):
-            self._normalize(env.buf_obs.float(), self.X, update=True)        # obs_rms.update(obs); obs = process(obs)
+            self._normalize(env.buf_obs if self.atari else env.buf_obs.float(), self.X, update=True)   # obs_rms.update; process
             q = self.model.forward(self.X[:n], n)
             ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=A, seed=self.seed,
                         step=0, step_dev=self.step_counter)
             env.step_device()
             ops.counter_add(self.step_counter, 1)
-            self._normalize(env.next_obs.float(), self.Xn, update=False)
+            self._normalize(env.next_obs if self.atari else env.next_obs.float(), self.Xn, update=False)
             self.memory.store(self.X.view((n,) + tuple(self.obs_shape)), self.act_f, env.reward, env.terminated,
                               self.Xn.view((n,) + tuple(self.obs_shape)))
             if self.current_step > self.start_training and self.current_step % self.training_frequency == 0:
