@@ -169,6 +169,111 @@ __global__ void __launch_bounds__(64) gae_scan_kernel(const float* __restrict__ 
     }
 }
 
+// ---- "relay" formulation used for every launch (the lane-per-env kernel above is kept for reference / tiny T) -------------
+// A workgroup owns 64 envs and NWV waves; wave w owns CH consecutive timesteps of a super-chunk of CH*NWV steps.
+//   phase 1 (all waves in parallel): every wave loads its CH steps (5 coalesced loads per step) and precomputes, for
+//           both carry precisions, everything that does not depend on the carried advantage: c2 = (1-d)*gamma*lam and
+//           delta = r + (1-d)*gamma*v_next - v  (v_next is the next step's value, the bootstrap value at a path end, or the
+//           first value of the following chunk) -- ONE global round trip per super-chunk instead of one per 8 steps;
+//   phase 2 (relay, latest wave first): the wave whose turn it is reads the carried state from LDS, runs the two-op
+//           recurrence last = delta + c2*last over its CH steps, stores advantages/returns, hands the state on.
+// The arithmetic per step is unchanged (same operations, same order, no contraction), so results stay bit-identical to NumPy.
+template <int CH, int NWV>
+__global__ void __launch_bounds__(64 * NWV) gae_relay_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                             const float* __restrict__ term, const float* __restrict__ bootv,
+                                                             const uint8_t* __restrict__ seg, float* __restrict__ adv,
+                                                             float* __restrict__ ret, int n_envs, int T, float gamma_f,
+                                                             float lam_f, double gamma_d, int use_gae) {
+#pragma clang fp contract(off)
+    __shared__ float c_lastf[64];
+    __shared__ double c_lastd[64], c_disc[64];
+    __shared__ int c_flags[64];                     // bit0 active, bit1 float64 carry
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const bool valid = e < n_envs;
+    if (w == 0) { c_lastf[lane] = 0.f; c_lastd[lane] = 0.0; c_disc[lane] = 0.0; c_flags[lane] = 0; }
+    __syncthreads();
+    for (int hi = T; hi > 0; hi -= CH * NWV) {
+        const int t0 = hi - CH * (NWV - w);         // this wave covers [t0, t0 + CH); steps < 0 do not exist
+        float v[CH], c2[CH], df[CH], bvk[CH], vnk[CH];
+        double dd[CH];
+        uint8_t sg[CH];
+        {
+            float r[CH], d[CH], bv[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int t = t0 + j;
+                if (valid && t >= 0) {
+                    const size_t o = (size_t)t * n_envs + e;
+                    r[j] = rew[o]; v[j] = val[o]; d[j] = term[o]; bv[j] = bootv[o]; sg[j] = seg[o];
+                } else { r[j] = v[j] = d[j] = bv[j] = 0.f; sg[j] = 0; }
+            }
+            const int tn = t0 + CH;
+            const float vext = (valid && tn >= 0 && tn < T) ? val[(size_t)tn * n_envs + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float vn = (sg[j] & 1) ? bv[j] : (j + 1 < CH ? v[j + 1] : vext);
+                const float nd = __fsub_rn(1.0f, d[j]);
+                const float c1 = use_gae ? __fmul_rn(nd, gamma_f) : gamma_f;                   // (1 - d) * gamma
+                c2[j] = __fmul_rn(c1, lam_f);                                                  // (1 - d) * gamma * lam
+                df[j] = __fsub_rn(__fadd_rn(r[j], __fmul_rn(c1, vn)), v[j]);                   // memory_tools.py:255 / :261
+                dd[j] = use_gae ? __dsub_rn(__dadd_rn((double)r[j], __dmul_rn((double)c1, (double)vn)), (double)v[j])
+                                : __dsub_rn(__dadd_rn((double)r[j], __dmul_rn(gamma_d, (double)vn)), (double)v[j]);
+                if (!use_gae) c2[j] = r[j];          // non-GAE: the relay needs the raw reward for the discounted sum
+                bvk[j] = bv[j]; vnk[j] = vn;
+            }
+        }
+        // phase 2: relay.  Nothing touches global memory here (results stay in registers), so the barriers are cheap.
+        unsigned wmask = 0, m64mask = 0;            // per-step: result valid / float64 path
+        for (int turn = NWV - 1; turn >= 0; --turn) {
+            if (w == turn && valid && t0 + CH > 0) {
+                int fl = c_flags[lane];
+                bool active = fl & 1, m64 = (fl & 2) != 0;
+                float last_f = c_lastf[lane];
+                double last_d = c_lastd[lane], disc = c_disc[lane];
+#pragma unroll
+                for (int j = CH - 1; j >= 0; --j) {
+                    if (t0 + j < 0) continue;
+                    if (sg[j] & 1) {                  // finish_path(val, env) closed a path after step t
+                        active = true; m64 = (sg[j] & 2) != 0; last_f = 0.f; last_d = 0.0;
+                        disc = (double)bvk[j];
+                    }
+                    if (!active) continue;
+                    wmask |= 1u << j;
+                    if (m64) m64mask |= 1u << j;
+                    if (use_gae) {
+                        if (!m64) {
+                            last_f = __fadd_rn(df[j], __fmul_rn(c2[j], last_f));               // :256
+                            df[j] = last_f;
+                        } else {
+                            last_d = __dadd_rn(dd[j], __dmul_rn((double)c2[j], last_d));
+                            df[j] = (float)last_d;
+                        }
+                    } else {
+                        disc = (double)c2[j] + gamma_d * disc;                                 // discount_cumsum, float64
+                        dd[j] = disc;                                                          // -> returns
+                        if (m64) df[j] = (float)__dsub_rn(__dadd_rn((double)c2[j], __dmul_rn(gamma_d, (double)vnk[j])), (double)v[j]);
+                    }
+                }
+                c_flags[lane] = (active ? 1 : 0) | (m64 ? 2 : 0);
+                c_lastf[lane] = last_f; c_lastd[lane] = last_d; c_disc[lane] = disc;
+            }
+            __syncthreads();
+        }
+        // phase 3: all waves store their results together (one store drain per super-chunk)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (wmask & (1u << j)) {
+                const size_t o = (size_t)(t0 + j) * n_envs + e;
+                const float a = df[j];
+                adv[o] = a;
+                if (use_gae) ret[o] = (m64mask & (1u << j)) ? (float)__dadd_rn((double)a, (double)v[j]) : __fadd_rn(a, v[j]);   // :257
+                else ret[o] = (float)dd[j];
+            }
+        }
+    }
+}
+
 static int pack_fields(const xrl_field_t* fields, int n_fields, FieldPack& fp, bool& vec16) {
     if (fields == nullptr || n_fields < 1 || n_fields > MAX_FIELDS) return XRL_EINVAL;
     fp.n = n_fields;
@@ -256,8 +361,14 @@ extern "C" int xrl_gae_scan(const float* rew, const float* val, const float* ter
                             int use_gae, xrl_stream_t stream) {
     XRL_CHECK_ARG(rew && val && term && bootv && seg && adv && ret && n_envs > 0 && T > 0);
     const int nb = (n_envs + 63) / 64;
-    hipLaunchKernelGGL(gae_scan_kernel<8>, dim3(nb), dim3(64), 0, as_stream(stream), rew, val, term, bootv, seg, adv,
-                       ret, n_envs, T, (float)gamma, (float)lam, gamma, use_gae);
+    // few envs -> few workgroups: split the time axis over 8 waves per workgroup (relay); many envs: the lane-per-env
+    // scan already fills the chip and streams at a higher rate (tools/scale_sweep.py)
+    if (T >= 32 && n_envs <= 16384)
+        hipLaunchKernelGGL((gae_relay_kernel<16, 8>), dim3(nb), dim3(512), 0, as_stream(stream), rew, val, term, bootv, seg,
+                           adv, ret, n_envs, T, (float)gamma, (float)lam, gamma, use_gae);
+    else
+        hipLaunchKernelGGL(gae_scan_kernel<8>, dim3(nb), dim3(64), 0, as_stream(stream), rew, val, term, bootv, seg, adv,
+                           ret, n_envs, T, (float)gamma, (float)lam, gamma, use_gae);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
