@@ -297,6 +297,7 @@ typedef struct {
 typedef struct {
     const float* params;                               /* flat parameter buffer */
     const float* cache_image;                          /* packed LDS parameter-cache image (xrl_pack_rollout_cache) */
+    const float* frag_image;                           /* NULL or the prefetched layer's weights in MFMA-fragment order */
     xrl_fused_layer_t layers[XRL_FUSED_MAX_LAYERS];
     int32_t n_layers, n_levels;
     int32_t n_head_layers, pad0;                       /* trailing layers that write the last (head) level */
@@ -328,6 +329,9 @@ int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
 /* Re-pack the small parameters (first layer, biases, merged heads) into the image the step kernel copies to LDS with
  * one round trip; call once per rollout after the parameters changed.  Only params/layers/levels of *p are read. */
 int xrl_pack_rollout_cache(const xrl_rollout_step_t* p, float* image, int64_t image_floats, xrl_stream_t stream);
+/* Same, plus `frag` (N*K floats of the first big middle layer): its weights re-ordered so that wave w / k-chunk q / lane l
+ * reads 16 contiguous bytes at ((w*K/8 + q)*64 + l)*16 -- every prefetch instruction of the step kernel is one 1 KB line run. */
+int xrl_pack_rollout_cache2(const xrl_rollout_step_t* p, float* image, int64_t image_floats, float* frag, xrl_stream_t stream);
 int64_t xrl_rollout_cache_floats(const xrl_rollout_step_t* p);
 
 /* ------------------------------------------------------------------ fused PPO minibatch (ONE launch: gather -> MLP forward

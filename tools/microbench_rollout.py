@@ -29,7 +29,7 @@ def timed(fn, reps=200, rounds=5):
 
 T, D, A = agent.horizon_size, agent.obs_dim, agent.model.action_dim
 env, f, pp = agent.envs, agent.memory.soa.fields, agent.pp
-common = dict(params=agent.model.params.flat, cache_image=agent.cache_image, ret_track=agent.returns, cp_state=env.state, cp_steps=env.steps,
+common = dict(params=agent.model.params.flat, cache_image=agent.cache_image, frag_image=agent.frag_image, ret_track=agent.returns, cp_state=env.state, cp_steps=env.steps,
               cp_episodes=env.episodes, cp_score=env.ep_score, cp_stats=env.stats, n=n, D=D, A=A, gaussian=0,
               max_steps=500, use_obsnorm=1, use_rewnorm=1, obs_range=5.0, rew_range=5.0, gamma=0.98, seed=1, env_seed=1,
               step_dev=agent.step_counter)

@@ -97,7 +97,7 @@ class FusedLayer(C.Structure):
 
 
 class RolloutStep(C.Structure):
-    _fields_ = [("params", c_void_p), ("cache_image", c_void_p), ("layers", FusedLayer * 8), ("n_layers", c_int32), ("n_levels", c_int32),
+    _fields_ = [("params", c_void_p), ("cache_image", c_void_p), ("frag_image", c_void_p), ("layers", FusedLayer * 8), ("n_layers", c_int32), ("n_levels", c_int32),
                 ("n_head_layers", c_int32), ("pad0", c_int32), ("level_width", c_int32 * 6),
                 ("obs_raw_in", c_void_p), ("obs_raw_out", c_void_p), ("xnext_in", c_void_p), ("xnext_out", c_void_p),
                 ("obs_stats_in", c_void_p), ("obs_stats_out", c_void_p), ("obs_count_in", c_void_p),
@@ -141,6 +141,7 @@ _SIGS = {
     "xrl_debug_mfma_chain": [c_int, c_int, c_void_p, c_void_p, c_void_p],
     "xrl_rollout_step_cartpole": [C.POINTER(RolloutStep), c_void_p],
     "xrl_pack_rollout_cache": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p],
+    "xrl_pack_rollout_cache2": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p, c_void_p],
     "xrl_dqn_td": [C.POINTER(DqnTd), c_void_p],
     "xrl_qmix_mix_td": [C.POINTER(Qmix), c_void_p],
     "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],

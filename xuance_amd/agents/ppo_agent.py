@@ -79,6 +79,7 @@ class PPO_Agent:
                        "ended": torch.zeros(2, n, dtype=torch.uint8, device=dev),
                        "ret_final": torch.zeros(2, n, device=dev)}
             self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
+            self.frag_image = torch.zeros(self.model.params.P, device=dev)
         if torch.cuda.is_available():
             ops.init_device()
 
@@ -134,8 +135,9 @@ class PPO_Agent:
         """T launches of xrl_rollout_step_cartpole + one bootstrap-only launch + GAE (same numbers as _enqueue_rollout)."""
         T, n, D, A = self.horizon_size, self.n_envs, self.obs_dim, self.model.action_dim
         env, f, pp = self.envs, self.memory.soa.fields, self.pp
-        ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)   # parameters changed since last rollout
-        common = dict(params=self.model.params.flat, cache_image=self.cache_image, ret_track=self.returns, cp_state=env.state, cp_steps=env.steps,
+        ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image, self.frag_image)   # params changed
+        common = dict(params=self.model.params.flat, cache_image=self.cache_image, frag_image=self.frag_image,
+                      ret_track=self.returns, cp_state=env.state, cp_steps=env.steps,
                       cp_episodes=env.episodes, cp_score=env.ep_score, cp_stats=env.stats, n=n, D=D, A=A, gaussian=0,
                       max_steps=int(env.max_episode_steps), use_obsnorm=int(self.use_obsnorm),
                       use_rewnorm=int(self.use_rewnorm), obs_range=float(self.obsnorm_range),

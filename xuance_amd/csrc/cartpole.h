@@ -21,7 +21,8 @@ __device__ __forceinline__ void cartpole_advance(const double* s, int a, double&
     const double theta_thr = 12.0 * 2.0 * 3.14159265358979323846 / 360.0, x_thr = 2.4;
     x = s[0]; xd = s[1]; th = s[2]; thd = s[3];
     const double force = a == 1 ? force_mag : -force_mag;
-    const double ct = cos(th), st = sin(th);
+    double st, ct;
+    sincos(th, &st, &ct);
     const double temp = (force + polemass_length * thd * thd * st) / total_mass;
     const double thacc = (gravity * st - ct * temp) / (length * (4.0 / 3.0 - masspole * ct * ct / total_mass));
     const double xacc = temp - polemass_length * thacc * ct / total_mass;

@@ -22,6 +22,37 @@ __host__ __device__ inline bool layer_small(int N, int K) { return N * level_ld(
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).z, (b).z, acc, 0, 0, 0);      \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).w, (b).w, acc, 0, 0, 0);
 
+// Narrow layer (N <= 8, e.g. the merged policy/value heads) on the VALU: thread (row = tid>>4, sub = tid&15) accumulates a
+// 1/16 slice of K for every output column, the 16 partials are combined with xor-shuffles.  One barrier instead of the
+// three of the split-K MFMA path; the summation order differs from the MFMA chain by fp32 rounding only.
+__device__ __forceinline__ void narrow_layer_valu(const float* Wl, int ldw, const float* bias_l, int K, int N, int act,
+                                                  const float* in, int ld_in, float* out, int ld_out) {
+    const int r = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    const int k4 = (K + 3) / 4;                                         // float4 chunks; padding columns are zero on both sides
+    for (int q = sub; q < k4; q += 16) {
+        const float4 a = *reinterpret_cast<const float4*>(in + r * ld_in + q * 4);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c < N) {
+                const float4 w = *reinterpret_cast<const float4*>(Wl + c * ldw + q * 4);
+                acc[c] += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c < N) {
+            float v = acc[c];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+            if (sub == 0) out[r * ld_out + c] = act_apply(v + bias_l[c], act);
+        }
+    }
+    __syncthreads();
+}
+
 // out[32][N] = act(in[32][K] . W[N][K]^T + bias)   in/out: LDS tiles.  Wl != null: weights in the LDS cache with row
 // stride ldw (zero padded); else Wg in global memory, and pf[] holds this wave's first PD chunks when `use_pf`.
 __device__ __forceinline__ void fused_layer(const float* __restrict__ Wg, const float* Wl, int ldw, const float* bias_l,
@@ -60,9 +91,12 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ Wg, const 
                 const float* wrow = Wg + (size_t)wr * K + 4 * lh;
                 int qstart = 0;
                 if (use_pf && t0 == 0 && wpt == 1) {                // chunks 0..PD-1 are already in registers
+                    float4 af[PD];                                  // all A fragments first: one LDS latency, then pure MFMA
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) af[q] = q < kq ? *reinterpret_cast<const float4*>(arow + q * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int q = 0; q < PD; ++q) {
-                        if (q < kq) { const float4 a = *reinterpret_cast<const float4*>(arow + q * 8); MFMA4(a, pf[q], acc) }
+                        if (q < kq) { MFMA4(af[q], pf[q], acc) }
                     }
                     qstart = PD;
                 }

@@ -181,8 +181,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
                         lds + lvl_off[L.out_level] + L.out_off, lvl_ld[L.out_level], red, pf, l == pf_layer);
         }
     }
-    fused_layer(nullptr, lds + c_wh, ldH, lds + c_bh, KH, NH, XRL_ACT_NONE, lds + lvl_off[nLv - 2], lvl_ld[nLv - 2],
-                lds + lvl_off[nLv - 1], lvl_ld[nLv - 1], red, pf, false);
+    if (NH <= 8)
+        narrow_layer_valu(lds + c_wh, ldH, lds + c_bh, KH, NH, XRL_ACT_NONE, lds + lvl_off[nLv - 2], lvl_ld[nLv - 2],
+                          lds + lvl_off[nLv - 1], lvl_ld[nLv - 1]);
+    else
+        fused_layer(nullptr, lds + c_wh, ldH, lds + c_bh, KH, NH, XRL_ACT_NONE, lds + lvl_off[nLv - 2], lvl_ld[nLv - 2],
+                    lds + lvl_off[nLv - 1], lvl_ld[nLv - 1], red, pf, false);
 
     PSTAMP();
     // ================================================================== loss (one thread per row)

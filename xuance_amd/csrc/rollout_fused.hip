@@ -88,9 +88,16 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
             if ((L.N + 31) / 32 >= NW && (L.K & 7) == 0 && ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0)) {
                 pf_layer = l;
                 const int kq = L.K / 8;
-                const float* wrow = Wg + (size_t)min(wave * 32 + li_, L.N - 1) * L.K + 4 * lh_;
+                if (p.frag_image) {
+                    // fragment-ordered copy (xrl_pack_rollout_cache): wave w, chunk q, lane l -> one contiguous 1 KB per load
+                    const float4* fr = reinterpret_cast<const float4*>(p.frag_image) + (size_t)wave * kq * 64 + lane;
 #pragma unroll
-                for (int q = 0; q < PD; ++q) pf[q] = q < kq ? *reinterpret_cast<const float4*>(wrow + q * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int q = 0; q < PD; ++q) pf[q] = q < kq ? fr[q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    const float* wrow = Wg + (size_t)min(wave * 32 + li_, L.N - 1) * L.K + 4 * lh_;
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) pf[q] = q < kq ? *reinterpret_cast<const float4*>(wrow + q * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
     }
@@ -98,8 +105,21 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     const int r = tid >> 4, sub = tid & 15, e_row = e0 + r;
     float4 xrow = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e_row < n) xrow = *reinterpret_cast<const float4*>((boot ? p.xnext_in : p.obs_raw_in) + (size_t)e_row * D);
+    // (2b) the tail (sampling + physics) runs on lanes 0..31: fetch their env state now instead of after the MLP
+    double cps[4] = {0.0, 0.0, 0.0, 0.0};
+    int cp_steps0 = 0, cp_ep0 = 0;
+    float cp_score0 = 0.f, rtrack0 = 0.f;
+    if (!boot && tid < FT && e0 + tid < n) {
+        const int et = e0 + tid;
+        cps[0] = p.cp_state[(size_t)et * 4 + 0]; cps[1] = p.cp_state[(size_t)et * 4 + 1];
+        cps[2] = p.cp_state[(size_t)et * 4 + 2]; cps[3] = p.cp_state[(size_t)et * 4 + 3];
+        cp_steps0 = p.cp_steps[et]; cp_ep0 = p.cp_episodes[et]; cp_score0 = p.cp_score[et]; rtrack0 = p.ret_track[et];
+    }
     double s1 = 0.0, s2 = 0.0;                                      // sums for dimension d = tid & 3
     unsigned long long ended_mask[16];
+    float rfin[16];
+    float ret_m0 = 0.f, ret_v0 = 1.f, st_mean = 0.f, st_var = 1.f;
+    double ret_c0 = 0.0, st_cnt = 0.0;
     if (!boot) {
         if (p.use_obsnorm) {
             float sv[8];
@@ -110,8 +130,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
         }
         if (wave == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { const int e = j * 64 + lane; ended_mask[j] = __ballot(e < n && p.ended_in[e] != 0); }
+            for (int j = 0; j < 16; ++j) {
+                const int e = j * 64 + lane;
+                const bool in = e < n;
+                rfin[j] = in ? p.ret_final_in[e] : 0.f;               // loaded up front: no memory access inside the merge loop
+                ended_mask[j] = __ballot(in && p.ended_in[e] != 0);
+            }
+            ret_m0 = p.ret_stats_in[0]; ret_v0 = p.ret_stats_in[1]; ret_c0 = *p.ret_count_in;
         }
+        if (tid < D && p.use_obsnorm) { st_mean = p.obs_stats_in[tid]; st_var = p.obs_stats_in[D + tid]; st_cnt = *p.obs_count_in; }
     }
     // (3) the LDS parameter cache is a flat copy of the image xrl_pack_rollout_cache built once per rollout (same layout:
     //     first-layer W | b | middle biases (+ small middle weights, zero padded) | merged head W | head b): every
@@ -136,14 +163,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     if (!boot) {
         // ---- deferred ret_rms.update() of the episodes that ended at the previous step, in env order (ppo_agent.py:146-149)
         if (wave == 0) {
-            float mean = p.ret_stats_in[0], var = p.ret_stats_in[1];
-            double count = *p.ret_count_in;
+            float mean = ret_m0, var = ret_v0;
+            double count = ret_c0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 unsigned long long mm = ended_mask[j];
                 while (mm) {                                            // wave-uniform loop over finished envs
                     const int bpos = __ffsll((long long)mm) - 1; mm &= mm - 1;
-                    const float bm = p.ret_final_in[j * 64 + bpos];
+                    const float bm = __shfl(rfin[j], bpos, 64);
                     const double tot = count + 1.0; const float delta = bm - mean;
                     const float new_mean = mean + delta * 1.0f / (float)tot;
                     const float M2 = var * (float)count + 0.f + (delta * delta) * (float)count * 1.0f / (float)tot;
@@ -161,7 +188,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
             if (lane < D) { part[wave * 4 + lane] = s1; part[NW * 4 + wave * 4 + lane] = s2; }
         }
     }
+    STAMP();
     __syncthreads();
+    STAMP();
     if (!boot) {
         if (tid < D) {
             if (p.use_obsnorm) {
@@ -171,8 +200,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
                 const float bm = (float)m;                              // np.mean -> float32
                 const float bstd = (float)sqrt(fmax(b / n - m * m, 0.0));          // np.std -> float32
                 const float bv = bstd * bstd;                           // batch_var = np.square(batch_std)
-                const double cnt = *p.obs_count_in, tot = cnt + (double)n;
-                const float mean = p.obs_stats_in[tid], var = p.obs_stats_in[D + tid];
+                const double cnt = st_cnt, tot = cnt + (double)n;
+                const float mean = st_mean, var = st_var;
                 const float delta = bm - mean;                          // update_from_moments (statistic_tools.py:173-185)
                 const float new_mean = mean + delta * (float)n / (float)tot;
                 const float m_a = var * (float)cnt, m_b = bv * (float)n;
@@ -222,8 +251,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     }
     // ---- all heads as one block-structured layer from the LDS cache (per-head activation is the identity for the
     //      categorical actor and the critic)
-    fused_layer(nullptr, lds + c_wh, ldH, lds + c_bh, KH, NH, XRL_ACT_NONE, lds + lvl_off[nLv - 2], lvl_ld[nLv - 2],
-                lds + lvl_off[nLv - 1], lvl_ld[nLv - 1], red, pf, false);
+    if (NH <= 8)
+        narrow_layer_valu(lds + c_wh, ldH, lds + c_bh, KH, NH, XRL_ACT_NONE, lds + lvl_off[nLv - 2], lvl_ld[nLv - 2],
+                          lds + lvl_off[nLv - 1], lvl_ld[nLv - 1]);
+    else
+        fused_layer(nullptr, lds + c_wh, ldH, lds + c_bh, KH, NH, XRL_ACT_NONE, lds + lvl_off[nLv - 2], lvl_ld[nLv - 2],
+                    lds + lvl_off[nLv - 1], lvl_ld[nLv - 1], red, pf, false);
     STAMP();
     const float* heads = lds + lvl_off[nLv - 1];
     const int ldh = lvl_ld[nLv - 1];
@@ -262,14 +295,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     double* s = p.cp_state + (size_t)e * 4;
     double x, xd, th, thd;
     bool term;
-    cartpole_advance(s, a, x, xd, th, thd, term);
-    const int steps = p.cp_steps[e] + 1;
+    cartpole_advance(cps, a, x, xd, th, thd, term);
+    const int steps = cp_steps0 + 1;
     const bool trunc = steps >= p.max_steps;
     const float nobs[4] = {(float)x, (float)xd, (float)th, (float)thd};
-    const float score = p.cp_score[e] + 1.0f;
+    const float score = cp_score0 + 1.0f;
     float robs[4] = {nobs[0], nobs[1], nobs[2], nobs[3]};
     if (term || trunc) {
-        const int ep = p.cp_episodes[e] + 1;
+        const int ep = cp_ep0 + 1;
         p.cp_episodes[e] = ep;
         cartpole_reset(s, p.env_seed, e, (uint32_t)ep);
         p.cp_steps[e] = 0; p.cp_score[e] = 0.f;
@@ -288,7 +321,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     p.rew_slot[e] = rn;
     p.term_slot[e] = term ? 1.f : 0.f;
     p.seg_slot[e] = (term || trunc || p.last_step) ? (uint8_t)(1 | (term ? 2 : 0)) : (uint8_t)0;
-    const float tr = p.gamma * p.ret_track[e] + reward;
+    const float tr = p.gamma * rtrack0 + reward;
     if (term || trunc) { p.ret_final_out[e] = tr; p.ended_out[e] = 1; p.ret_track[e] = 0.f; }
     else { p.ended_out[e] = 0; p.ret_track[e] = tr; }
     float4 ro = make_float4(robs[0], robs[1], robs[2], robs[3]), xn;
@@ -306,9 +339,25 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
 }
 
 // Builds the parameter-cache image (same carve as the kernel above, offsets relative to the image start).
-__global__ void __launch_bounds__(256) pack_rollout_cache_kernel(xrl_rollout_step_t p, float* __restrict__ image) {
+__global__ void __launch_bounds__(256) pack_rollout_cache_kernel(xrl_rollout_step_t p, float* __restrict__ image,
+                                                                 float* __restrict__ frag) {
     const int nL = p.n_layers, nH = p.n_head_layers, nLv = p.n_levels, end_mid = nL - nH;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (frag) {
+        // first middle layer that qualifies for register prefetch (same test as the step kernel)
+        for (int l = 1; l < end_mid; ++l) {
+            const xrl_fused_layer_t& L = p.layers[l];
+            if (!layer_small(L.N, L.K) && (L.N + 31) / 32 >= NW && (L.K & 7) == 0) {
+                const int kq = L.K / 8, total = ((L.N + 31) / 32) * kq * 64 * 4;
+                for (int i = tid; i < total; i += nt) {
+                    const int sidx = i & 3, ln = (i >> 2) & 63, q = (i >> 8) % kq, t = (i >> 8) / kq;
+                    const int row = min(t * 32 + (ln & 31), L.N - 1), k = q * 8 + 4 * (ln >> 5) + sidx;
+                    frag[i] = p.params[L.w_off + (size_t)row * L.K + k];
+                }
+                break;
+            }
+        }
+    }
     const xrl_fused_layer_t& L0 = p.layers[0];
     int off = 0;
     const int c_w0 = off; off += L0.N * 4;
@@ -379,6 +428,8 @@ static size_t fused_lds_bytes(const xrl_rollout_step_t& p) {
 using namespace xrl;
 
 extern "C" int xrl_init_ppo_fused(void);
+extern "C" int xrl_pack_rollout_cache2(const xrl_rollout_step_t* pp, float* image, int64_t image_floats, float* frag,
+                                       xrl_stream_t stream);
 
 extern "C" int xrl_init(void) {
     if (int rc = xrl_init_ppo_fused()) return rc;
@@ -416,11 +467,16 @@ extern "C" int xrl_rollout_step_cartpole(const xrl_rollout_step_t* pp, xrl_strea
 }
 
 extern "C" int xrl_pack_rollout_cache(const xrl_rollout_step_t* pp, float* image, int64_t image_floats, xrl_stream_t stream) {
+    return xrl_pack_rollout_cache2(pp, image, image_floats, nullptr, stream);
+}
+
+extern "C" int xrl_pack_rollout_cache2(const xrl_rollout_step_t* pp, float* image, int64_t image_floats, float* frag,
+                                       xrl_stream_t stream) {
     XRL_CHECK_ARG(pp && image && pp->params);
     const xrl_rollout_step_t& p = *pp;
     XRL_CHECK_ARG(p.n_layers >= 2 && p.n_layers <= XRL_FUSED_MAX_LAYERS && p.n_head_layers >= 1 && p.n_head_layers < p.n_layers);
     XRL_CHECK_ARG((int64_t)fused_cache_floats(p) <= image_floats);
-    hipLaunchKernelGGL(pack_rollout_cache_kernel, dim3(8), dim3(256), 0, as_stream(stream), p, image);
+    hipLaunchKernelGGL(pack_rollout_cache_kernel, dim3(32), dim3(256), 0, as_stream(stream), p, image, frag);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -229,11 +229,11 @@ def rollout_cache_floats(plan):
     return int(_lib.load().xrl_rollout_cache_floats(C.byref(p)))
 
 
-def pack_rollout_cache(plan, params_flat, image):
+def pack_rollout_cache(plan, params_flat, image, frag=None):
     p = RolloutStep()
     p.params = params_flat.data_ptr()
     fused_layers_from_plan(plan, p)
-    call("xrl_pack_rollout_cache", C.byref(p), ptr(image), image.numel(), stream_ptr())
+    call("xrl_pack_rollout_cache2", C.byref(p), ptr(image), image.numel(), ptr(frag), stream_ptr())
 
 
 def rollout_step_cartpole(plan, **kw):
