@@ -38,6 +38,17 @@ def make_config(n_envs, horizon, world, rank):
                      model_dir="/tmp/xrl_bench_models", use_hip_graph=True)
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, FETCH_SIZE doubled
+    per MI355X_MICROARCH.md); None if the summary is not there.  PMC counters cannot be read from inside the process."""
+    path = os.path.join(ROOT, "profiles", "r01_c_ppo_c2_pmc_hbm.json")
+    try:
+        with open(path) as f:
+            return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def _event_time_us(fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -67,7 +78,8 @@ def kernel_rooflines(agent):
     fl_step = fwd_flops_row * rows
     r1 = {"bound": "mfma", "kernel": "xrl::rollout_step_cartpole_kernel", "achieved": round(fl_step / us_step / 1e6, 4),
           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_step / us_step / 1e6 / PEAK_FP32_MFMA_TFLOPS, 5),
-          "traffic": None, "avg_launch_us": round(us_step, 3), "algorithmic_flops_per_launch": fl_step,
+          "traffic": _pmc_traffic("xrl::rollout_step_cartpole_kernel"), "avg_launch_us": round(us_step, 3),
+          "algorithmic_flops_per_launch": fl_step,
           "note": "latency-bound: %d rows x %.0f flop per launch; see DESIGN.md section 3" % (rows, fwd_flops_row)}
     # (2) fused minibatch kernel
     f = mem.soa.fields
@@ -86,7 +98,8 @@ def kernel_rooflines(agent):
         fl_mb = 3.0 * fwd_flops_row * bs
         r2 = {"bound": "mfma", "kernel": "xrl::ppo_fused_kernel", "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
-              "traffic": None, "avg_launch_us": round(us_mb, 3), "algorithmic_flops_per_launch": fl_mb}
+              "traffic": _pmc_traffic("xrl::ppo_fused_kernel"), "avg_launch_us": round(us_mb, 3),
+              "algorithmic_flops_per_launch": fl_mb}
     return r1, r2
 
 
