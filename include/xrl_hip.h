@@ -320,7 +320,8 @@ typedef struct {
     double* cp_state; int32_t* cp_steps; int32_t* cp_episodes; float* cp_score; double* cp_stats;
     int32_t n, D, A, gaussian, max_steps;
     int32_t use_obsnorm, use_rewnorm, last_step, boot_only;
-    float obs_range, rew_range, gamma;
+    int32_t role_split, split_col;                      /* actor / critic branches of the stacked layer in separate workgroups */
+    float obs_range, rew_range, gamma, pad1;
     uint64_t seed, env_seed;
     uint32_t step; const uint32_t* step_dev;
     long long* dbg;                                    /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */

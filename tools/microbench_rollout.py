@@ -29,7 +29,7 @@ def timed(fn, reps=200, rounds=5):
 
 T, D, A = agent.horizon_size, agent.obs_dim, agent.model.action_dim
 env, f, pp = agent.envs, agent.memory.soa.fields, agent.pp
-common = dict(params=agent.model.params.flat, cache_image=agent.cache_image, frag_image=agent.frag_image, ret_track=agent.returns, cp_state=env.state, cp_steps=env.steps,
+common = dict(params=agent.model.params.flat, cache_image=agent.cache_image, frag_image=agent.frag_image, role_split=int(os.environ.get('SPLIT','1')), split_col=128, ret_track=agent.returns, cp_state=env.state, cp_steps=env.steps,
               cp_episodes=env.episodes, cp_score=env.ep_score, cp_stats=env.stats, n=n, D=D, A=A, gaussian=0,
               max_steps=500, use_obsnorm=1, use_rewnorm=1, obs_range=5.0, rew_range=5.0, gamma=0.98, seed=1, env_seed=1,
               step_dev=agent.step_counter)
@@ -64,7 +64,7 @@ print("fused boot-only (MLP only)   : %.2f us" % timed(boot_only))
 X = agent.X
 print("unfused 3-layer forward M=2n : %.2f us" % timed(lambda: agent.model.forward(X, 2 * n)))
 
-dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(48, dtype=torch.int64, device="cuda")
 def full_dbg(t=5):
     i, o = t & 1, (t + 1) & 1
     ops.rollout_step_cartpole(agent.model.plan, obs_raw_in=pp["obs_raw"][i], obs_raw_out=pp["obs_raw"][o],
@@ -83,3 +83,6 @@ for name, fn in (("boot-only", lambda: ops.rollout_step_cartpole(agent.model.pla
         fn(); torch.cuda.synchronize()
     d = dbg.tolist(); k = d[15]
     print(name, "phase cycles:", [d[i + 1] - d[i] for i in range(k - 1)], "total", d[k - 1] - d[0])
+    pr = [x for x in d[16:] if x]
+    if pr:
+        print("   in-layer probe deltas (enter, mfma done, epilogue done, barrier done ...):", [pr[i + 1] - pr[i] for i in range(len(pr) - 1)])

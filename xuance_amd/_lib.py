@@ -111,7 +111,8 @@ class RolloutStep(C.Structure):
                 ("cp_stats", c_void_p),
                 ("n", c_int32), ("D", c_int32), ("A", c_int32), ("gaussian", c_int32), ("max_steps", c_int32),
                 ("use_obsnorm", c_int32), ("use_rewnorm", c_int32), ("last_step", c_int32), ("boot_only", c_int32),
-                ("obs_range", c_float), ("rew_range", c_float), ("gamma", c_float),
+                ("role_split", c_int32), ("split_col", c_int32),
+                ("obs_range", c_float), ("rew_range", c_float), ("gamma", c_float), ("pad1", c_float),
                 ("seed", C.c_uint64), ("env_seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p),
                 ("dbg", c_void_p)]
 

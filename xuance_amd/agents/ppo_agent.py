@@ -136,8 +136,13 @@ class PPO_Agent:
         T, n, D, A = self.horizon_size, self.n_envs, self.obs_dim, self.model.action_dim
         env, f, pp = self.envs, self.memory.soa.fields, self.pp
         ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image, self.frag_image)   # params changed
+        plan = self.model.plan
+        mids = [L for st in plan.stages[1:-1] for L in st]
+        heads = plan.stages[-1]
+        split_ok = bool(_get(self.config, "use_role_split", True)) and len(mids) == 1 and len(heads) == 2 and \
+            mids[0].N == plan.widths[mids[0].out_level] and heads[1].in_off % 32 == 0 and heads[1].in_off > 0
         common = dict(params=self.model.params.flat, cache_image=self.cache_image, frag_image=self.frag_image,
-                      ret_track=self.returns, cp_state=env.state, cp_steps=env.steps,
+                      role_split=int(split_ok), split_col=int(heads[1].in_off) if split_ok else 0, ret_track=self.returns, cp_state=env.state, cp_steps=env.steps,
                       cp_episodes=env.episodes, cp_score=env.ep_score, cp_stats=env.stats, n=n, D=D, A=A, gaussian=0,
                       max_steps=int(env.max_episode_steps), use_obsnorm=int(self.use_obsnorm),
                       use_rewnorm=int(self.use_rewnorm), obs_range=float(self.obsnorm_range),

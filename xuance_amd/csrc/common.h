@@ -54,6 +54,35 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
     return t;
 }
 
+// Compile-time activation variants.  IMPORTANT (measured, tools/microbench_rollout.py with -DXRL_TILE_PROBE): a run-time
+// `switch (act)` inside a per-element loop is if-converted by hipcc -- tanhf AND expf are evaluated for every element and
+// the result selected -- which cost ~775 cycles per element (12 k cycles per 16-value MFMA epilogue).  Hot loops therefore
+// dispatch ONCE on the activation (XRL_ACT_DISPATCH) and run a loop specialised for it.
+template <int ACT>
+__device__ __forceinline__ float act_apply_c(float z) {
+    if (ACT == XRL_ACT_RELU) return z > 0.f ? z : 0.f;
+    if (ACT == XRL_ACT_LEAKY_RELU) return z > 0.f ? z : z * 0.01f;
+    if (ACT == XRL_ACT_TANH) return tanhf(z);
+    if (ACT == XRL_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+    return z;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_c(float y) {
+    if (ACT == XRL_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (ACT == XRL_ACT_LEAKY_RELU) return y > 0.f ? 1.f : 0.01f;
+    if (ACT == XRL_ACT_TANH) return 1.f - y * y;
+    if (ACT == XRL_ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+#define XRL_ACT_DISPATCH(act_value, ...)                                                            \
+    switch (act_value) {                                                                            \
+        case XRL_ACT_RELU: { constexpr int ACT = XRL_ACT_RELU; __VA_ARGS__ } break;                 \
+        case XRL_ACT_LEAKY_RELU: { constexpr int ACT = XRL_ACT_LEAKY_RELU; __VA_ARGS__ } break;     \
+        case XRL_ACT_TANH: { constexpr int ACT = XRL_ACT_TANH; __VA_ARGS__ } break;                 \
+        case XRL_ACT_SIGMOID: { constexpr int ACT = XRL_ACT_SIGMOID; __VA_ARGS__ } break;           \
+        default: { constexpr int ACT = XRL_ACT_NONE; __VA_ARGS__ } break;                           \
+    }
+
 __device__ __forceinline__ float act_apply(float z, int act) {
     switch (act) {
         case XRL_ACT_RELU: return z > 0.f ? z : 0.f;

@@ -188,21 +188,34 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     if (col >= No) return;
     float bias = 0.f;
     if (MODE == MODE_NT && g.bias) bias = g.bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= Mo) continue;
-        float v = acc[r];
-        if (MODE == MODE_NT) {
-            v = act_apply(v + bias, g.act);
-            g.C[(size_t)row * g.ldc + col] = v;
-        } else if (MODE == MODE_NN) {
-            if (g.aux) v *= act_grad_from_out(g.aux[(size_t)row * g.ldaux + col], g.act);
-            g.C[(size_t)row * g.ldc + col] = v;
+    if (MODE == MODE_NT) {
+        XRL_ACT_DISPATCH(g.act,
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < Mo) g.C[(size_t)row * g.ldc + col] = act_apply_c<ACT>(acc[r] + bias);
+            })
+    } else if (MODE == MODE_NN) {
+        if (g.aux) {
+            XRL_ACT_DISPATCH(g.act,
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < Mo) g.C[(size_t)row * g.ldc + col] = acc[r] * act_grad_c<ACT>(g.aux[(size_t)row * g.ldaux + col]);
+                })
         } else {
-            const size_t so = (size_t)blockIdx.y * p.slab_stride;
-            if (col < g.K) g.C[so + (size_t)row * g.ldc + col] = v;
-            else g.dbias[so + row] = v;          // the ones column: sum_m dY[m, row]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < Mo) g.C[(size_t)row * g.ldc + col] = acc[r];
+            }
+        }
+    } else {
+        const size_t so = (size_t)blockIdx.y * p.slab_stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= Mo) continue;
+            if (col < g.K) g.C[so + (size_t)row * g.ldc + col] = acc[r];
+            else g.dbias[so + row] = acc[r];          // the ones column: sum_m dY[m, row]
         }
     }
 }

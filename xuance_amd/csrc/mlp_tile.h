@@ -16,6 +16,11 @@ constexpr int SMALL_W = 4608;        // a layer whose padded weights fit in this
 __host__ __device__ inline int level_ld(int width) { return ((width + 7) / 8) * 8 + 4; }
 __host__ __device__ inline bool layer_small(int N, int K) { return N * level_ld(K) <= SMALL_W; }
 
+#ifdef XRL_TILE_PROBE
+static __device__ long long* g_probe = nullptr;
+static __device__ int g_probe_i = 0;
+#endif
+
 #define MFMA4(a, b, acc)                                                         \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).x, (b).x, acc, 0, 0, 0);      \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a).y, (b).y, acc, 0, 0, 0);      \
@@ -47,10 +52,16 @@ __device__ __forceinline__ void narrow_layer_valu(const float* Wl, int ldw, cons
         if (c < N) {
             float v = acc[c];
             v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-            if (sub == 0) out[r * ld_out + c] = act_apply(v + bias_l[c], act);
+            if (sub == 0) { XRL_ACT_DISPATCH(act, out[r * ld_out + c] = act_apply_c<ACT>(v + bias_l[c]);) }
         }
     }
+#ifdef XRL_TILE_PROBE
+    if (g_probe && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) g_probe[g_probe_i++] = clock64();
+#endif
     __syncthreads();
+#ifdef XRL_TILE_PROBE
+    if (g_probe && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) g_probe[g_probe_i++] = clock64();
+#endif
 }
 
 // out[32][N] = act(in[32][K] . W[N][K]^T + bias)   in/out: LDS tiles.  Wl != null: weights in the LDS cache with row
@@ -58,18 +69,24 @@ __device__ __forceinline__ void narrow_layer_valu(const float* Wl, int ldw, cons
 __device__ __forceinline__ void fused_layer(const float* __restrict__ Wg, const float* Wl, int ldw, const float* bias_l,
                                             int K, int N, int act, const float* in, int ld_in, float* out, int ld_out,
                                             float* red, const float4 (&pf)[PD], bool use_pf,
-                                            const float* aux = nullptr, int ld_aux = 0) {
+                                            const float* aux = nullptr, int ld_aux = 0, int tile_begin = 0, int tile_end = -1) {
+    // tile_begin/tile_end restrict the output column tiles [tile_begin, tile_end) (a workgroup that owns only one branch
+    // of a stacked actor|critic layer); with a restriction the waves map 1:1 onto the tiles (no split-K).
     // aux == null : out = act(acc + bias)                      (forward)
     // aux != null : out = acc * act'(aux[row][col])            (backward w.r.t. the layer input; `act` is the
     //               activation that produced aux, bias_l is unused)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int n_tiles = (N + 31) / 32;
+#ifdef XRL_TILE_PROBE
+    if (g_probe && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) g_probe[g_probe_i++] = clock64();
+#endif
+    const bool restricted = tile_end >= 0;
+    const int n_tiles = restricted ? tile_end : (N + 31) / 32;
     const int kq = (K + 7) / 8;
     const bool fast_g = ((K & 7) == 0) && ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0);
-    const int wpt = n_tiles >= NW ? 1 : NW / n_tiles;               // waves per tile (split-K factor)
+    const int wpt = (restricted || n_tiles >= NW) ? 1 : NW / n_tiles;   // waves per tile (split-K factor)
     const int tiles_per_pass = NW / wpt;
-    for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_pass) {
+    for (int t0 = restricted ? tile_begin : 0; t0 < n_tiles; t0 += tiles_per_pass) {
         const int tile = t0 + wave / wpt, ks = wave % wpt;
         const bool live = tile < n_tiles && (wave / wpt) < tiles_per_pass;
         const int n0 = tile * 32;
@@ -90,7 +107,7 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ Wg, const 
             } else if (fast_g) {
                 const float* wrow = Wg + (size_t)wr * K + 4 * lh;
                 int qstart = 0;
-                if (use_pf && t0 == 0 && wpt == 1) {                // chunks 0..PD-1 are already in registers
+                if (use_pf && t0 == (restricted ? tile_begin : 0) && wpt == 1) {   // chunks 0..PD-1 are already in registers
                     float4 af[PD];                                  // all A fragments first: one LDS latency, then pure MFMA
 #pragma unroll
                     for (int q = 0; q < PD; ++q) af[q] = q < kq ? *reinterpret_cast<const float4*>(arow + q * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -120,16 +137,26 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ Wg, const 
                 }
             }
         }
+#ifdef XRL_TILE_PROBE
+        { float t_ = acc[15]; asm volatile("" ::"v"(t_)); if (g_probe && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) g_probe[g_probe_i++] = clock64(); }
+#endif
         // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         if (wpt == 1) {
             const int col = n0 + li;
             if (live && col < N) {
-                const float bv = aux ? 0.f : bias_l[col];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    out[row * ld_out + col] = aux ? acc[r] * act_grad_from_out(aux[row * ld_aux + col], act)
-                                                  : act_apply(acc[r] + bv, act);
+                if (aux) {
+                    XRL_ACT_DISPATCH(act,
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            out[row * ld_out + col] = acc[r] * act_grad_c<ACT>(aux[row * ld_aux + col]);
+                        })
+                } else {
+                    const float bv = bias_l[col];
+                    XRL_ACT_DISPATCH(act,
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            out[row * ld_out + col] = act_apply_c<ACT>(acc[r] + bv);
+                        })
                 }
             }
         } else {
@@ -139,16 +166,17 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ Wg, const 
                 red[(wave * 32 + row) * 33 + li] = acc[r];
             }
             __syncthreads();
+                XRL_ACT_DISPATCH(act,
                 for (int i = threadIdx.x; i < tiles_per_pass * 32 * 32; i += FUSED_THREADS) {
-                const int tl = i >> 10, row = (i >> 5) & 31, c = i & 31;
-                const int col = (t0 + tl) * 32 + c;
-                if (t0 + tl < n_tiles && col < N) {
-                    float v = 0.f;
-                    for (int w = 0; w < wpt; ++w) v += red[((tl * wpt + w) * 32 + row) * 33 + c];   // fixed order
-                    out[row * ld_out + col] = aux ? v * act_grad_from_out(aux[row * ld_aux + col], act)
-                                                  : act_apply(v + bias_l[col], act);
-                }
-            }
+                    const int tl = i >> 10, row = (i >> 5) & 31, c = i & 31;
+                    const int col = (t0 + tl) * 32 + c;
+                    if (t0 + tl < n_tiles && col < N) {
+                        float v = 0.f;
+                        for (int w = 0; w < wpt; ++w) v += red[((tl * wpt + w) * 32 + row) * 33 + c];   // fixed order
+                        out[row * ld_out + col] = aux ? v * act_grad_c<ACT>(aux[row * ld_aux + col])
+                                                      : act_apply_c<ACT>(v + bias_l[col]);
+                    }
+                })
             __syncthreads();
         }
     }

@@ -20,22 +20,39 @@ __global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* _
     const bool vec = ((slab_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
     if (vec) {
+        // 256 threads = 64 parameter quads x 4 slab groups: thread (pq, sg) sums slabs sg, sg+4, sg+8, ... of its quad
+        // (8 independent 16-byte loads in flight), the 4 group sums are combined through LDS in group order.  The slab
+        // order inside a group is fixed, so the result is deterministic (it differs from a purely sequential s = 0..S-1
+        // sum only by fp32 re-association).
+        __shared__ float4 gsum[4][64];
         const int64_t P4 = P / 4;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t st4 = slab_stride / 4;
+        const int pq = threadIdx.x & 63, sg = threadIdx.x >> 6;
+        for (int64_t base = (int64_t)blockIdx.x * 64; base < P4; base += (int64_t)gridDim.x * 64) {
+            const int64_t i = base + pq;
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4* src = reinterpret_cast<const float4*>(slabs) + i;
-            const int64_t st4 = slab_stride / 4;
-            int s = 0;
-            for (; s + 8 <= n_split; s += 8) {
-                float4 v[8];
+            if (i < P4) {
+                const float4* src = reinterpret_cast<const float4*>(slabs) + i;
+                int s = sg;
+                for (; s + 28 < n_split; s += 32) {
+                    float4 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(s + j) * st4];
+                    for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(s + 4 * j) * st4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { g.x += v[j].x; g.y += v[j].y; g.z += v[j].z; g.w += v[j].w; }
+                    for (int j = 0; j < 8; ++j) { g.x += v[j].x; g.y += v[j].y; g.z += v[j].z; g.w += v[j].w; }
+                }
+                for (; s < n_split; s += 4) { const float4 v = src[(int64_t)s * st4]; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
             }
-            for (; s < n_split; ++s) { const float4 v = src[(int64_t)s * st4]; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
-            reinterpret_cast<float4*>(grad)[i] = g;
-            sq += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
+            gsum[sg][pq] = g;
+            __syncthreads();
+            if (sg == 0 && i < P4) {
+                float4 t = gsum[0][pq];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) { const float4 u = gsum[k][pq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+                reinterpret_cast<float4*>(grad)[i] = t;
+                sq += (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
+            }
+            __syncthreads();
         }
         for (int64_t i = P4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
             float g = 0.f;

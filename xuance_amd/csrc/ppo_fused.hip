@@ -162,14 +162,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
     // ================================================================== forward
     {   // first layer on the VALU (K = 4): same k-ordered fma chain as the MFMA path
         float* o1 = lds + lvl_off[L0.out_level] + L0.out_off + r * lvl_ld[L0.out_level];
-        for (int c = sub; c < L0.N; c += 16) {
-            const float4 w = *reinterpret_cast<const float4*>(&lds[c_w0 + c * 4]);
-            float acc = __fmaf_rn(xrow.x, w.x, 0.f);
-            acc = __fmaf_rn(xrow.y, w.y, acc);
-            acc = __fmaf_rn(xrow.z, w.z, acc);
-            acc = __fmaf_rn(xrow.w, w.w, acc);
-            o1[c] = act_apply(acc + lds[c_b0 + c], L0.act);
-        }
+        XRL_ACT_DISPATCH(L0.act,
+            for (int c = sub; c < L0.N; c += 16) {
+                const float4 w = *reinterpret_cast<const float4*>(&lds[c_w0 + c * 4]);
+                float acc = __fmaf_rn(xrow.x, w.x, 0.f);
+                acc = __fmaf_rn(xrow.y, w.y, acc);
+                acc = __fmaf_rn(xrow.z, w.z, acc);
+                acc = __fmaf_rn(xrow.w, w.w, acc);
+                o1[c] = act_apply_c<ACT>(acc + lds[c_b0 + c]);
+            })
     }
     __syncthreads();
 #pragma unroll
@@ -269,18 +270,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
         const int cols_per_pass = KH < FUSED_THREADS ? KH : FUSED_THREADS;
         const int rows_per_pass = FUSED_THREADS / cols_per_pass;       // KH = 256 -> 2 rows at a time
         const int rsub = tid / cols_per_pass, k0c = tid - rsub * cols_per_pass;
-        for (int k = k0c; k < KH; k += cols_per_pass) {
-            float w[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = j < NH ? lds[c_wh + j * ldH + k] : 0.f;
-            for (int rr = rsub; rr < FT; rr += rows_per_pass) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < NH) acc += dheads[rr * ldh + j] * w[j];
-                for (int j = 8; j < NH; ++j) acc += dheads[rr * ldh + j] * lds[c_wh + j * ldH + k];
-                dprev[rr * ldp + k] = acc * act_grad_from_out(hprev[rr * ldp + k], pact);
-            }
-        }
+        XRL_ACT_DISPATCH(pact,
+            for (int k = k0c; k < KH; k += cols_per_pass) {
+                float w[8];
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) w[j] = j < NH ? lds[c_wh + j * ldH + k] : 0.f;
+                for (int rr = rsub; rr < FT; rr += rows_per_pass) {
+                    float acc = 0.f;
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j) if (j < NH) acc += dheads[rr * ldh + j] * w[j];
+                    for (int j = 8; j < NH; ++j) acc += dheads[rr * ldh + j] * lds[c_wh + j * ldH + k];
+                    dprev[rr * ldp + k] = acc * act_grad_c<ACT>(hprev[rr * ldp + k]);
+                }
+            })
     }
     __syncthreads();
     PSTAMP();

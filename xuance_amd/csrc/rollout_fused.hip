@@ -41,9 +41,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     int dbi = 0;
 #define STAMP() do { if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) dbg[dbi++] = clock64(); } while (0)
     STAMP();
+    // workgroup role: with role_split the actor and critic branches of an act tile run in different workgroups
+    //   role 0: act tile, actor branch (+ sampling, physics, bookkeeping)      role 1: act tile, critic branch -> val_slot
+    //   role 2: bootstrap tile (critic branch only when role_split) -> bootv[t-1]
     const int n_act_tiles = (n + FT - 1) / FT;
-    const bool boot = p.boot_only || ((int)blockIdx.x >= n_act_tiles);
-    const int tile = p.boot_only ? blockIdx.x : (boot ? blockIdx.x - n_act_tiles : blockIdx.x);
+    const int group = blockIdx.x / n_act_tiles, tile = blockIdx.x - group * n_act_tiles;
+    const int role = p.boot_only ? 2 : (p.role_split ? group : (group == 0 ? 0 : 2));
+    const bool boot = role == 2;
+    const bool do_actor = !p.role_split ? !boot : role == 0;          // computes the actor columns / logits
+    const bool do_critic = !p.role_split || role != 0;                // computes the critic columns / value
     const int e0 = tile * FT;
     const int lane = tid & 63, wave = tid >> 6, li_ = lane & 31, lh_ = lane >> 5;
     const int nL = p.n_layers, nH = p.n_head_layers, nLv = p.n_levels;
@@ -89,12 +95,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
                 pf_layer = l;
                 const int kq = L.K / 8;
                 if (p.frag_image) {
-                    // fragment-ordered copy (xrl_pack_rollout_cache): wave w, chunk q, lane l -> one contiguous 1 KB per load
-                    const float4* fr = reinterpret_cast<const float4*>(p.frag_image) + (size_t)wave * kq * 64 + lane;
+                    // fragment-ordered copy (xrl_pack_rollout_cache): tile, chunk q, lane l -> one contiguous 1 KB per load
+                    const int my_tile = (p.role_split && !do_actor ? p.split_col / 32 : 0) + wave;
+                    const float4* fr = reinterpret_cast<const float4*>(p.frag_image) +
+                                       (size_t)min(my_tile, (L.N + 31) / 32 - 1) * kq * 64 + lane;
 #pragma unroll
                     for (int q = 0; q < PD; ++q) pf[q] = q < kq ? fr[q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
-                    const float* wrow = Wg + (size_t)min(wave * 32 + li_, L.N - 1) * L.K + 4 * lh_;
+                    const int my_tile = (p.role_split && !do_actor ? p.split_col / 32 : 0) + wave;
+                    const float* wrow = Wg + (size_t)min(my_tile * 32 + li_, L.N - 1) * L.K + 4 * lh_;
 #pragma unroll
                     for (int q = 0; q < PD; ++q) pf[q] = q < kq ? *reinterpret_cast<const float4*>(wrow + q * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -221,31 +230,37 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
             xrow.z = fminf(fmaxf((xrow.z - s_mean[2]) / (s_std[2] + 1e-8f), -p.obs_range), p.obs_range);
             xrow.w = fminf(fmaxf((xrow.w - s_mean[3]) / (s_std[3] + 1e-8f), -p.obs_range), p.obs_range);
         }
-        if (sub == 0 && e_row < n) *reinterpret_cast<float4*>(p.obs_slot + (size_t)e_row * D) = xrow;   // memory.observations[t]
+        if (sub == 0 && e_row < n && role == 0) *reinterpret_cast<float4*>(p.obs_slot + (size_t)e_row * D) = xrow;   // memory.observations[t]
     }
     STAMP();
     // ---- first layer on the VALU: out = act(fma(x3,w3, fma(x2,w2, fma(x1,w1, x0*w0))) + b), 16 threads per row
     {
         float* o1 = lds + lvl_off[L0.out_level] + L0.out_off + r * lvl_ld[L0.out_level];
-        for (int c = sub; c < L0.N; c += 16) {
-            const float4 w = *reinterpret_cast<const float4*>(&lds[c_w0 + c * 4]);
-            float acc = __fmaf_rn(xrow.x, w.x, 0.f);
-            acc = __fmaf_rn(xrow.y, w.y, acc);
-            acc = __fmaf_rn(xrow.z, w.z, acc);
-            acc = __fmaf_rn(xrow.w, w.w, acc);
-            o1[c] = act_apply(acc + lds[c_b0 + c], L0.act);
-        }
+        XRL_ACT_DISPATCH(L0.act,
+            for (int c = sub; c < L0.N; c += 16) {
+                const float4 w = *reinterpret_cast<const float4*>(&lds[c_w0 + c * 4]);
+                float acc = __fmaf_rn(xrow.x, w.x, 0.f);
+                acc = __fmaf_rn(xrow.y, w.y, acc);
+                acc = __fmaf_rn(xrow.z, w.z, acc);
+                acc = __fmaf_rn(xrow.w, w.w, acc);
+                o1[c] = act_apply_c<ACT>(acc + lds[c_b0 + c]);
+            })
     }
     __syncthreads();
     STAMP();
     // ---- middle layers on the matrix cores
+#ifdef XRL_TILE_PROBE
+    if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) { g_probe = dbg + 16; g_probe_i = 0; }
+#endif
 #pragma unroll
     for (int l = 1; l < XRL_FUSED_MAX_LAYERS; ++l) {
         if (l >= first_mid && l < end_mid) {
             const xrl_fused_layer_t& L = p.layers[l];
+            const int tb = p.role_split ? (do_actor ? 0 : p.split_col / 32) : 0;
+            const int te = p.role_split ? (do_actor ? p.split_col / 32 : (L.N + 31) / 32) : -1;
             fused_layer(p.params + L.w_off, c_wm[l] >= 0 ? lds + c_wm[l] : nullptr, level_ld(L.K), lds + c_bm[l], L.K, L.N, L.act,
                         lds + lvl_off[L.in_level] + L.in_off, lvl_ld[L.in_level],
-                        lds + lvl_off[L.out_level] + L.out_off, lvl_ld[L.out_level], red, pf, l == pf_layer);
+                        lds + lvl_off[L.out_level] + L.out_off, lvl_ld[L.out_level], red, pf, l == pf_layer, nullptr, 0, tb, te);
             STAMP();
         }
     }
@@ -270,6 +285,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
         if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) { dbg[dbi++] = clock64(); dbg[15] = dbi; }
         return;
     }
+    if (role == 1) { p.val_slot[e] = h[A]; return; }                   // critic workgroup of an act tile
     // ---- get_actions (core/on_policy.py:128-169): sample, log-prob, value; store (ppo_agent.py:128)
     const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
     int a = 0;
@@ -289,7 +305,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
         logp = h[a] - lse;
     }
     p.act_slot[e] = (float)a;
-    p.val_slot[e] = h[A];
+    if (!p.role_split) p.val_slot[e] = h[A];
     p.logp_slot[e] = logp;
     // ---- envs.step(acts): physics + DummyVecEnv auto-reset
     double* s = p.cp_state + (size_t)e * 4;
@@ -460,7 +476,9 @@ extern "C" int xrl_rollout_step_cartpole(const xrl_rollout_step_t* pp, xrl_strea
     const size_t lds_bytes = fused_lds_bytes(p);
     XRL_CHECK_ARG(lds_bytes <= 144 * 1024);
     const int n_tiles = (p.n + FT - 1) / FT;
-    const int grid = p.boot_only ? n_tiles : (p.bootv_prev ? 2 * n_tiles : n_tiles);
+    if (p.role_split) XRL_CHECK_ARG(p.split_col > 0 && p.split_col % 32 == 0 && p.n_layers - p.n_head_layers == 2);
+    const int act_groups = p.role_split ? 2 : 1;
+    const int grid = p.boot_only ? n_tiles : (p.bootv_prev ? (act_groups + 1) * n_tiles : act_groups * n_tiles);
     hipLaunchKernelGGL(rollout_step_cartpole_kernel, dim3(grid), dim3(FUSED_THREADS), lds_bytes, as_stream(stream), p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
