@@ -327,6 +327,9 @@ typedef struct {
     long long* dbg;                                    /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
 } xrl_rollout_step_t;
 int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
+/* The fused kernels have shape-specialised twins (compile-time extents, bit-identical results) that are selected
+ * automatically when the network is the 4-128-{128-2,128-1} class; 0 forces the any-shape kernels (parity tests). */
+int xrl_set_fast_kernels(int enable);
 /* Re-pack the small parameters (first layer, biases, merged heads) into the image the step kernel copies to LDS with
  * one round trip; call once per rollout after the parameters changed.  Only params/layers/levels of *p are read. */
 int xrl_pack_rollout_cache(const xrl_rollout_step_t* p, float* image, int64_t image_floats, xrl_stream_t stream);
@@ -419,6 +422,10 @@ int xrl_sync_target(const float* params, float* target, int64_t P, const xrl_ada
 
 /* diagnostics: `iters` dependent v_mfma_f32_32x32x2_f32 per wave; out[0] shader cycles, out[1] wall-clock ticks */
 int xrl_debug_mfma_chain(int iters, int blocks, long long* out, float* sink, xrl_stream_t stream);
+/* diagnostics: 16 KB of straight-line VALU code executed `passes` times; out[pass] = shader cycles (pass 0 = cold I-cache) */
+int xrl_debug_icache(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream);
+/* diagnostics: 16 taken branches, each over 2 KB of padding; out[pass] = shader cycles (pass 0 = cold I-cache) */
+int xrl_debug_ijump(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream);
 
 /* ------------------------------------------------------------------ hipGraph capture of op sequences */
 int xrl_graph_begin(xrl_stream_t stream);

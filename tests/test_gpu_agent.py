@@ -188,6 +188,37 @@ def test_fused_rollout_step_equals_unfused_sequence():
     assert sa["eps"][0] == sb["eps"][0] and sa["eps"][0] > 100
 
 
+@pytest.mark.parametrize("act,n", [("leaky_relu", 100), ("tanh", 64), ("relu", 37)])
+def test_specialised_rollout_kernel_is_bit_identical_to_any_shape_kernel(act, n):
+    """rollout_step_fast_kernel (compile-time 4-128-{128-2,128-1}) vs rollout_step_cartpole_kernel: same bits everywhere."""
+    from xuance_amd import ops
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    res = []
+    try:
+        for fast in (False, True):
+            ops.set_fast_kernels(fast)
+            torch.manual_seed(0)
+            env = DeviceCartPoleVecEnv(n, seed=3)
+            env.max_episode_steps = 30
+            agent = PPO_Agent(make_config(n, 48, activation=act), env)
+            assert agent.use_fused_rollout
+            agent.rollout()
+            agent.rollout()
+            torch.cuda.synchronize()
+            i = agent.horizon_size & 1
+            f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+            f.update(obs_stats=npy(agent.pp["obs_stats"][i]), ret_stats=npy(agent.pp["ret_stats"][i]),
+                     ret_track=npy(agent.returns), cp_state=npy(env.state), eps=np.asarray(env.episode_stats()))
+            res.append(f)
+    finally:
+        ops.set_fast_kernels(True)
+    a, b = res
+    assert a["eps"][0] > 50
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("n,T,nmb", [(24, 40, 2), (64, 64, 4), (50, 30, 3)])
 def test_fused_minibatch_kernel_equals_layered_path(n, T, nmb):
     """xrl_ppo_fused_minibatch (one launch) vs gather + grouped GEMMs + loss + backward GEMMs: same gradient and losses."""

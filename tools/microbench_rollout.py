@@ -64,7 +64,7 @@ print("fused boot-only (MLP only)   : %.2f us" % timed(boot_only))
 X = agent.X
 print("unfused 3-layer forward M=2n : %.2f us" % timed(lambda: agent.model.forward(X, 2 * n)))
 
-dbg = torch.zeros(48, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
 def full_dbg(t=5):
     i, o = t & 1, (t + 1) & 1
     ops.rollout_step_cartpole(agent.model.plan, obs_raw_in=pp["obs_raw"][i], obs_raw_out=pp["obs_raw"][o],
@@ -77,12 +77,16 @@ def full_dbg(t=5):
         bootv_prev=None, last_step=0, boot_only=0, step=t, dbg=dbg, **common)
 
 
-for name, fn in (("boot-only", lambda: ops.rollout_step_cartpole(agent.model.plan, xnext_in=pp["xnext"][0], bootv_prev=f["bootv"][T - 1], boot_only=1, last_step=0, step=0, dbg=dbg, **common)),
-                 ("act tile ", full_dbg)):
+nt = (n + 31) // 32
+for name, fn, blk in (("boot-only", lambda: ops.rollout_step_cartpole(agent.model.plan, xnext_in=pp["xnext"][0], bootv_prev=f["bootv"][T - 1], boot_only=1, last_step=0, step=0, dbg=dbg, **common), 0),
+                      ("role0 act-actor ", full_dbg, 0), ("role1 act-critic", full_dbg, nt)):
     for _ in range(3):
+        dbg.zero_(); dbg[63] = blk
         fn(); torch.cuda.synchronize()
     d = dbg.tolist(); k = d[15]
     print(name, "phase cycles:", [d[i + 1] - d[i] for i in range(k - 1)], "total", d[k - 1] - d[0])
-    pr = [x for x in d[16:] if x]
+    if d[16] and d[17] and d[32] == 0:
+        print("   per-wave section (start, end) relative to kernel start:", [(d[16 + 2 * w] - d[0], d[17 + 2 * w] - d[0]) for w in range(8)])
+    pr = [] if d[32] == 0 else [x for x in d[16:63] if x]
     if pr:
         print("   in-layer probe deltas (enter, mfma done, epilogue done, barrier done ...):", [pr[i + 1] - pr[i] for i in range(len(pr) - 1)])

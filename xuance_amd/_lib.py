@@ -140,6 +140,8 @@ _SIGS = {
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_init": [],
     "xrl_debug_mfma_chain": [c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "xrl_debug_icache": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "xrl_debug_ijump": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "xrl_rollout_step_cartpole": [C.POINTER(RolloutStep), c_void_p],
     "xrl_pack_rollout_cache": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p],
     "xrl_pack_rollout_cache2": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p, c_void_p],
@@ -152,6 +154,7 @@ _SIGS = {
     "xrl_rollout_poststep": [C.POINTER(PostStep), c_void_p],
     "xrl_egreedy": [C.POINTER(EGreedy), c_void_p],
     "xrl_counter_add": [c_void_p, C.c_uint32, c_void_p],
+    "xrl_set_fast_kernels": [C.c_int],
     "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],
     "xrl_soa_store_step": [C.POINTER(Field), c_int, c_int, c_int, c_void_p],
     "xrl_gae_scan": [c_void_p] * 7 + [c_int, c_int, c_double, c_double, c_int, c_void_p],

@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     const int tid = threadIdx.x, n = p.n, A = p.A;
     long long* dbg = p.dbg;
     int dbi = 0;
-#define STAMP() do { if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) dbg[dbi++] = clock64(); } while (0)
+    const bool dbg_me = dbg && tid == 0 && (int)blockIdx.x == (int)dbg[63];   // dbg[63] selects the stamped workgroup
+#define STAMP() do { if (dbg_me) dbg[dbi++] = clock64(); } while (0)
     STAMP();
     // workgroup role: with role_split the actor and critic branches of an act tile run in different workgroups
     //   role 0: act tile, actor branch (+ sampling, physics, bookkeeping)      role 1: act tile, critic branch -> val_slot
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     STAMP();
     // ---- middle layers on the matrix cores
 #ifdef XRL_TILE_PROBE
-    if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) { g_probe = dbg + 16; g_probe_i = 0; }
+    if (dbg_me) { g_probe = dbg + 16; g_probe_i = 0; }
 #endif
 #pragma unroll
     for (int l = 1; l < XRL_FUSED_MAX_LAYERS; ++l) {
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     const float* h = heads + tid * ldh;
     if (boot) {                                                         // V(next_obs_{t-1}) -> bootv[t-1]
         if (p.bootv_prev) p.bootv_prev[e] = h[A];
-        if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) { dbg[dbi++] = clock64(); dbg[15] = dbi; }
+        if (dbg_me) { dbg[dbi++] = clock64(); dbg[15] = dbi; }
         return;
     }
     if (role == 1) { p.val_slot[e] = h[A]; return; }                   // critic workgroup of an act tile
@@ -304,6 +305,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
         for (int j = 0; j < A; ++j) { c += expf(h[j] - lse); if (c > u) { a = j; break; } }
         logp = h[a] - lse;
     }
+    STAMP();
     p.act_slot[e] = (float)a;
     if (!p.role_split) p.val_slot[e] = h[A];
     p.logp_slot[e] = logp;
@@ -328,6 +330,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
         s[0] = x; s[1] = xd; s[2] = th; s[3] = thd;
         p.cp_steps[e] = steps; p.cp_score[e] = score;
     }
+    STAMP();
     // ---- bookkeeping (ppo_agent.py:128,144-157)
     const float reward = 1.0f;
     float rstd = sqrtf(s_ret[1]);
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_cartpole_kernel(xr
     }
     xn = make_float4(nv[0], nv[1], nv[2], nv[3]);
     *reinterpret_cast<float4*>(p.xnext_out + (size_t)e * 4) = xn;      // get_terminated_values input (on_policy.py:109)
-    if (dbg && tid == 0 && blockIdx.x == gridDim.x - 1) { dbg[dbi++] = clock64(); dbg[15] = dbi; }
+    if (dbg_me) { dbg[dbi++] = clock64(); dbg[15] = dbi; }
 }
 
 // Builds the parameter-cache image (same carve as the kernel above, offsets relative to the image start).
@@ -443,6 +446,10 @@ static size_t fused_lds_bytes(const xrl_rollout_step_t& p) {
 
 using namespace xrl;
 
+namespace xrl {
+bool rollout_fast_eligible(const xrl_rollout_step_t& p);
+int launch_rollout_fast(const xrl_rollout_step_t& p, int grid, hipStream_t stream);
+}
 extern "C" int xrl_init_ppo_fused(void);
 extern "C" int xrl_pack_rollout_cache2(const xrl_rollout_step_t* pp, float* image, int64_t image_floats, float* frag,
                                        xrl_stream_t stream);
@@ -479,6 +486,7 @@ extern "C" int xrl_rollout_step_cartpole(const xrl_rollout_step_t* pp, xrl_strea
     if (p.role_split) XRL_CHECK_ARG(p.split_col > 0 && p.split_col % 32 == 0 && p.n_layers - p.n_head_layers == 2);
     const int act_groups = p.role_split ? 2 : 1;
     const int grid = p.boot_only ? n_tiles : (p.bootv_prev ? (act_groups + 1) * n_tiles : act_groups * n_tiles);
+    if (rollout_fast_eligible(p)) return launch_rollout_fast(p, grid, as_stream(stream));   // shape-specialised twin
     hipLaunchKernelGGL(rollout_step_cartpole_kernel, dim3(grid), dim3(FUSED_THREADS), lds_bytes, as_stream(stream), p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;

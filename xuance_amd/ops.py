@@ -262,6 +262,11 @@ def counter_add(counter, inc):
     call("xrl_counter_add", ptr(counter), int(inc), stream_ptr())
 
 
+def set_fast_kernels(enable):
+    """Select (default) or bypass the shape-specialised twins of the fused kernels; results are bit-identical."""
+    call("xrl_set_fast_kernels", int(bool(enable)))
+
+
 # ------------------------------------------------------------------------------------------ graphs
 class Graph:
     """hipGraph capture / replay of a sequence of xrl ops issued on the current torch stream."""
