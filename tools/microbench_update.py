@@ -22,6 +22,6 @@ for _ in range(3):
                             vf_coef=0.25, ent_coef=0.01, dbg=dbg)
     torch.cuda.synchronize()
 d = dbg.tolist(); k = d[15]
-names = ["setup", "forward", "loss", "heads-bwd", "dW(mid)", "dH+db(mid)", "first-bwd"]
+names = ["loads+L0", "mid fwd", "heads+loss", "small grads", "dW(mid)", "dH(mid)", "g1", "first-bwd"] if k == 9 else ["setup", "forward", "loss", "heads-bwd", "dW(mid)", "dH+db(mid)", "first-bwd"]
 print("phase cycles:", {names[i] if i < len(names) else i: d[i + 1] - d[i] for i in range(k - 1)}, "total", d[k - 1] - d[0],
       "= %.1f us at 2.4 GHz" % ((d[k - 1] - d[0]) / 2400.0))

@@ -449,7 +449,9 @@ int launch_rollout_fast(const xrl_rollout_step_t& p, int grid, hipStream_t strea
 
 }  // namespace xrl
 
+namespace xrl { extern bool g_fast_enabled_ppo; }
 extern "C" int xrl_set_fast_kernels(int enable) {
     xrl::g_fast_enabled = enable != 0;
+    xrl::g_fast_enabled_ppo = enable != 0;
     return XRL_OK;
 }
