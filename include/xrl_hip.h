@@ -161,6 +161,16 @@ int xrl_adam_step(float* params, float* grad, float* m, float* v, int64_t P, xrl
 int xrl_adam_step_mirrored(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
                            const double* sumsq_part, int n_part, double max_norm, const int32_t* map_a, float* dst_a,
                            const int32_t* map_b, float* dst_b, xrl_stream_t stream);
+/* General form: up to XRL_MAX_MIRRORS (map, dst) pairs (the fused kernels' fragment-ordered weight copies need two more). */
+#define XRL_MAX_MIRRORS 4
+typedef struct {
+    const int32_t* map[XRL_MAX_MIRRORS];
+    float* dst[XRL_MAX_MIRRORS];
+    int32_t n, pad;
+} xrl_mirrors_t;
+int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
+                          const double* sumsq_part, int n_part, double max_norm, const xrl_mirrors_t* mirrors,
+                          xrl_stream_t stream);
 
 
 /* ------------------------------------------------------------------ rollout-side ops (one small launch per step)
@@ -363,8 +373,22 @@ typedef struct {
     int32_t M, n_envs, T, D, A, pad1;
     float clip_range, vf_coef, ent_coef, pad2;
     long long* dbg;             /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
+    const float* frag_image;    /* NULL, or xrl_pack_mid_frags copy of the first middle layer in MFMA B-fragment order */
+    const float* f_packed;      /* NULL, or xrl_pack_transitions records [T*n_envs][8] = obs[4] | act | ret | adv | old_logp:
+                                 * one 32-byte random access per sampled row instead of five (D == 4 only) */
 } xrl_ppo_fused_t;
 int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* p, xrl_stream_t stream);
+/* packed[i][0..7] = obs[i][0..3], act[i], ret[i], adv[i], logp[i] for i < count (the rollout buffer's [t][env] order):
+ * the record form the fused minibatch kernel gathers from; run once per update phase after the advantages exist. */
+int xrl_pack_transitions(const float* f_obs, const float* f_act, const float* f_ret, const float* f_adv,
+                         const float* f_logp, float* packed, int64_t count, xrl_stream_t stream);
+/* frag <- the first middle layer W[N][K] (N % 32 == 0, K % 32 == 0) in the order the matrix-core kernels consume it, so
+ * that every prefetch instruction of a wave reads one contiguous 1 KB run:
+ *   forward section  [N/32][K/8][64 lanes][4]: W[32 t + (l & 31)][8 q + 4 (l >> 5) + s] in slot (q + t) mod K/8 of tile t
+ *   backward section [K/32][N/8][64 lanes][4]: W[8 q + 4 (l >> 5) + s][32 t + (l & 31)] in slot (q + 2t) mod N/8 (offset N*K)
+ * (the slot rotation spreads the simultaneous fetches of a workgroup's waves over all L2 channels)
+ * Only params/layers of *p are read; frag_floats >= 2*N*K. */
+int xrl_pack_mid_frags(const xrl_ppo_fused_t* p, float* frag, int64_t frag_floats, xrl_stream_t stream);
 /* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */
 int xrl_transpose_mid(const xrl_ppo_fused_t* p, float* params_t, xrl_stream_t stream);
 

@@ -290,6 +290,26 @@ def test_specialised_minibatch_kernel_is_bit_identical_to_any_shape_kernel(act, 
         assert np.array_equal(a[key], b[key]), key
 
 
+def test_adam_mirrors_keep_every_derived_layout_current():
+    """After full update phases the transposed / packed / fragment-ordered copies equal a fresh re-pack of the parameters."""
+    from xuance_amd import ops
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(0)
+    agent = PPO_Agent(make_config(64, 32, n_epochs=2, n_minibatch=2), DeviceCartPoleVecEnv(64, seed=5))
+    for _ in range(2):
+        agent.rollout()
+        agent.update()
+    lr, plan, flat = agent.learner, agent.model.plan, agent.model.params.flat
+    assert lr.frag is not None and len(lr._mirrors) == 4
+    pt, img, fr = torch.zeros_like(lr.params_t), torch.zeros_like(lr.cache_image), torch.zeros_like(lr.frag)
+    ops.transpose_mid(plan, flat, pt); ops.pack_rollout_cache(plan, flat, img); ops.pack_mid_frags(plan, flat, fr)
+    torch.cuda.synchronize()
+    mid = [L for st in plan.stages[1:-1] for L in st]
+    lo = agent.model.params.offsets[mid[0].w_name]; hi = lo + mid[0].N * mid[0].K
+    assert torch.equal(lr.params_t[lo:hi], pt[lo:hi]) and torch.equal(lr.cache_image, img) and torch.equal(lr.frag, fr)
+
+
 def test_ppo_gaussian_agent_on_mujoco_shape(oracle):
     """C4 shapes (obs 17, Box(6), Gaussian actor 17-256-256-6 tanh, critic 17-256-256-1, Basic_Identical): the layered
     rollout + update path end to end, checked against the oracle on the device's own rollout data."""

@@ -19,9 +19,44 @@ for _ in range(3):
                             f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                             f_logp=f["aux_old_logp"], idx=idx, stats=lr.stats[3], slabs=lr.fslabs, partials=lr.fpartials,
                             diag=None, slab_stride=m.params.P, M=idx.numel(), n_envs=n, T=256, D=4, A=2, clip_range=0.2,
-                            vf_coef=0.25, ent_coef=0.01, dbg=dbg)
+                            vf_coef=0.25, ent_coef=0.01, dbg=dbg, frag_image=lr.frag, f_packed=lr.packed)
     torch.cuda.synchronize()
-d = dbg.tolist(); k = d[15]
-names = ["loads+L0", "mid fwd", "heads+loss", "small grads", "dW(mid)", "dH(mid)", "g1", "first-bwd"] if k == 9 else ["setup", "forward", "loss", "heads-bwd", "dW(mid)", "dH+db(mid)", "first-bwd"]
-print("phase cycles:", {names[i] if i < len(names) else i: d[i + 1] - d[i] for i in range(k - 1)}, "total", d[k - 1] - d[0],
-      "= %.1f us at 2.4 GHz" % ((d[k - 1] - d[0]) / 2400.0))
+d = dbg.tolist()
+names = ["start", "h1 ready", "h2 ready", "heads+loss done", "small grads done", "dW done", "dH partials", "g1 ready", "end", "rows gathered"]
+print("stamps (cycles from kernel start; needs a -DXRL_TILE_PROBE build):", dict(zip(names, d[:10])))
+
+def mb(dbg_=None):
+    ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=lr.params_t, cache_image=lr.cache_image,
+                            f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
+                            f_logp=f["aux_old_logp"], idx=idx, stats=lr.stats[3], slabs=lr.fslabs, partials=lr.fpartials,
+                            diag=None, slab_stride=m.params.P, M=idx.numel(), n_envs=n, T=256, D=4, A=2, clip_range=0.2,
+                            vf_coef=0.25, ent_coef=0.01, frag_image=lr.frag, f_packed=lr.packed)
+def timed(fn, reps=50):
+    g = ops.Graph()
+    with g:
+        for _ in range(reps):
+            fn()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.launch(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+
+opt = lr.optimizer
+print("fused minibatch kernel (specialised) : %.2f us per launch" % timed(mb))
+ops.set_fast_kernels(False)
+print("fused minibatch kernel (any-shape)   : %.2f us per launch" % timed(mb))
+ops.set_fast_kernels(True)
+print("grad_reduce (256 slabs)              : %.2f us" % timed(lambda: ops.grad_reduce(lr.fslabs, lr.n_tiles, m.params.P, m.params.P, opt.grad, lr.sumsq)))
+print("adam + 4 mirrors                     : %.2f us" % timed(lr.finish_step))
+
+for Msub in (256, 1024, 2048, 4096, 8192):
+    def mbs():
+        ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=lr.params_t, cache_image=lr.cache_image,
+                                f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
+                                f_logp=f["aux_old_logp"], idx=idx[:Msub], stats=lr.stats[3], slabs=lr.fslabs, partials=lr.fpartials,
+                                diag=None, slab_stride=m.params.P, M=Msub, n_envs=n, T=256, D=4, A=2, clip_range=0.2,
+                                vf_coef=0.25, ent_coef=0.01, frag_image=lr.frag, f_packed=lr.packed)
+    print("   specialised kernel with M = %5d rows (%3d workgroups): %.2f us" % (Msub, Msub // 32, timed(mbs)))

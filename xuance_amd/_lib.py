@@ -125,7 +125,11 @@ class PpoFused(C.Structure):
                 ("idx", c_void_p), ("stats", c_void_p), ("slabs", c_void_p), ("partials", c_void_p), ("diag", c_void_p),
                 ("slab_stride", c_int64), ("M", c_int32), ("n_envs", c_int32), ("T", c_int32), ("D", c_int32),
                 ("A", c_int32), ("pad1", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
-                ("pad2", c_float), ("dbg", c_void_p)]
+                ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_packed", c_void_p)]
+
+
+class Mirrors(C.Structure):
+    _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("pad", c_int32)]
 
 
 class MarlAct(C.Structure):
@@ -138,6 +142,8 @@ _SIGS = {
     "xrl_marl_select_actions": [C.POINTER(MarlAct), c_void_p],
     "xrl_ppo_fused_minibatch": [C.POINTER(PpoFused), c_void_p],
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
+    "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
+    "xrl_pack_transitions": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrl_init": [],
     "xrl_debug_mfma_chain": [c_int, c_int, c_void_p, c_void_p, c_void_p],
     "xrl_debug_icache": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
@@ -170,6 +176,8 @@ _SIGS = {
     "xrl_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double, c_void_p],
     "xrl_adam_step_mirrored": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "xrl_adam_step_mirrors": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double,
+                              C.POINTER(Mirrors), c_void_p],
     "xrl_graph_begin": [c_void_p],
     "xrl_graph_end": [c_void_p, C.POINTER(c_void_p)],
     "xrl_graph_launch": [c_void_p, c_void_p],

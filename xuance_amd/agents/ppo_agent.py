@@ -190,7 +190,7 @@ class PPO_Agent:
         fused = lr.fused_eligible(mem)
         if fused:
             lr.prepare_fused(mem, bs)
-            lr.refresh_fused_params()
+            lr.refresh_fused_params(mem)
         else:
             lr.prepare_buffer_update(mem, bs)
         if mem.use_advnorm:
@@ -250,7 +250,7 @@ class PPO_Agent:
                         ops.adv_stats(mem.soa.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs,
                                       self.horizon_size, lr.stats)
                     if k == 0 and fused:
-                        lr.refresh_fused_params()
+                        lr.refresh_fused_params(mem)
                     step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None, finish=False)
                 self._mb_graphs.append(g)
             g = ops.Graph()

@@ -21,6 +21,11 @@ static __device__ long long* g_probe = nullptr;
 static __device__ int g_probe_i = 0;
 #endif
 
+// Slot of k-chunk q inside tile t of a fragment-ordered weight copy.  The waves of a workgroup fetch chunk q of their
+// tiles at the same moment; consecutive tiles are a multiple of 4 KB apart, which is the period of the 16 x 256-byte L2
+// channel interleave, so without the rotation every wave (of every CU) would hammer the same 4 channels.
+__host__ __device__ inline int frag_slot(int q, int t, int n_chunks, int step) { return (q + t * step) % n_chunks; }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_waitcnt vmcnt(0) + s_barrier on gfx9, i.e.
 // it also waits for every global load still in flight -- including the weight prefetch stream the fused kernels issue at
 // their start precisely so that it overlaps the phases in between (measured: the first barrier of the rollout step

@@ -78,9 +78,7 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
                                                                 float* __restrict__ m, float* __restrict__ v, int64_t P,
                                                                 xrl_adam_state_t* __restrict__ st,
                                                                 const double* __restrict__ sumsq_part, int n_part,
-                                                                double max_norm, const int32_t* __restrict__ map_a,
-                                                                float* __restrict__ dst_a, const int32_t* __restrict__ map_b,
-                                                                float* __restrict__ dst_b) {
+                                                                double max_norm, xrl_mirrors_t mir) {
     __shared__ double scratch[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < n_part; i += blockDim.x) s += sumsq_part[i];
@@ -109,8 +107,9 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
         const float pn = params[i] - step_size * (mi / denom);
         params[i] = pn;
         // derived layouts kept in sync in the same launch (transposed middle weights, packed LDS-cache image)
-        if (map_a) { const int j = map_a[i]; if (j >= 0) dst_a[j] = pn; }
-        if (map_b) { const int j = map_b[i]; if (j >= 0) dst_b[j] = pn; }
+#pragma unroll
+        for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
+            if (q < mir.n) { const int j = mir.map[q][i]; if (j >= 0) mir.dst[q][j] = pn; }
     }
     // The last block to finish advances the device-resident state (every block has consumed the old state by
     // the time it takes its ticket; the next launch observes the new state across the kernel boundary).
@@ -148,8 +147,7 @@ extern "C" int xrl_adam_step(float* params, float* grad, float* m, float* v, int
     int nb = (int)((P + RED_THREADS - 1) / RED_THREADS);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(adam_step_kernel, dim3(nb), dim3(RED_THREADS), 0, as_stream(stream), params, grad, m, v, P,
-                       state, sumsq_part, n_part, max_norm, (const int32_t*)nullptr, (float*)nullptr,
-                       (const int32_t*)nullptr, (float*)nullptr);
+                       state, sumsq_part, n_part, max_norm, xrl_mirrors_t{});
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
@@ -159,10 +157,24 @@ extern "C" int xrl_adam_step_mirrored(float* params, float* grad, float* m, floa
                                       float* dst_a, const int32_t* map_b, float* dst_b, xrl_stream_t stream) {
     XRL_CHECK_ARG(params && grad && m && v && state && sumsq_part && P > 0 && n_part >= 1 && n_part <= 1024);
     XRL_CHECK_ARG((!map_a || dst_a) && (!map_b || dst_b));
+    xrl_mirrors_t mir{};
+    if (map_a) { mir.map[mir.n] = map_a; mir.dst[mir.n] = dst_a; ++mir.n; }
+    if (map_b) { mir.map[mir.n] = map_b; mir.dst[mir.n] = dst_b; ++mir.n; }
+    return xrl_adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, n_part, max_norm, &mir, stream);
+}
+
+extern "C" int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
+                                     const double* sumsq_part, int n_part, double max_norm, const xrl_mirrors_t* mirrors,
+                                     xrl_stream_t stream) {
+    XRL_CHECK_ARG(params && grad && m && v && state && sumsq_part && P > 0 && n_part >= 1 && n_part <= 1024);
+    xrl_mirrors_t mir{};
+    if (mirrors) mir = *mirrors;
+    XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);
+    for (int q = 0; q < mir.n; ++q) XRL_CHECK_ARG(mir.map[q] && mir.dst[q]);
     int nb = (int)((P + RED_THREADS - 1) / RED_THREADS);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(adam_step_kernel, dim3(nb), dim3(RED_THREADS), 0, as_stream(stream), params, grad, m, v, P,
-                       state, sumsq_part, n_part, max_norm, map_a, dst_a, map_b, dst_b);
+                       state, sumsq_part, n_part, max_norm, mir);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -19,7 +19,8 @@ constexpr int PLD1 = PH + 4;                 // row stride of 128-wide levels
 constexpr int PLD2 = 2 * PH + 4;             // row stride of the stacked actor|critic level
 // packed image layout (pack_rollout_cache_kernel) for 4-128-256-{2|1}
 constexpr int PI_W0 = 0, PI_B0 = 4 * PH, PI_BM = PI_B0 + PH, PI_WH = PI_BM + 2 * PH, PI_LDH = 2 * PH + 4, PI_BH = PI_WH + 3 * PI_LDH;
-constexpr int PF_LDS_FLOATS = FT * (2 * PLD1 + 2 * PLD2) + NW * 32 * 33 + FT * 4 + FT * 4;
+constexpr int PI_FLOATS = PI_BH + 4;          // 1680: first layer | biases | merged heads
+constexpr int PF_LDS_FLOATS = FT * (2 * PLD1 + 2 * PLD2) + NW * 32 * 33 + 3 * FT * 4 + PI_FLOATS;
 constexpr int PF_LDS_BYTES = PF_LDS_FLOATS * 4 + FT * 5 * 8;
 
 template <int CTRL>
@@ -42,7 +43,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     float* red = g1 + FT * PLD1;                       // [8][32][33] split-K partial tiles
     float* xs = red + NW * 32 * 33;                    // [32][4] gathered observations
     float* dzh = xs + FT * 4;                          // [32][4] dLoss/d(logits, value)
-    double* rowstat = reinterpret_cast<double*>(dzh + FT * 4);   // [5][32] per-row loss terms
+    float* rsc = dzh + FT * 4;                         // [32][4] gathered act | ret | adv | old_logp
+    float* pimg = rsc + FT * 4;                        // [PI_FLOATS] copy of the packed small-parameter image
+    double* rowstat = reinterpret_cast<double*>(pimg + PI_FLOATS);   // [5][32] per-row loss terms
 
     kernarg_prefetch<sizeof(xrl_ppo_fused_t)>();
     constexpr int D = 4, A = 2;
@@ -55,55 +58,79 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     float* slab = p.slabs + (size_t)blockIdx.x * p.slab_stride;
     const float* img = p.cache_image;
     const xrl_fused_layer_t &L0 = p.layers[0], &L1 = p.layers[1], &La = p.layers[2], &Lc = p.layers[3];
+#ifdef XRL_TILE_PROBE                                   // phase stamps cost 20 VGPRs: diagnostic builds only
     long long* dbg = p.dbg;
     const bool dbg_me = dbg && tid == 0 && blockIdx.x == gridDim.x - 1;
     long long tst[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) tst[i] = 0;
 #define QSTAMP(k) do { if (dbg_me) tst[k] = clock64(); } while (0)
+#else
+#define QSTAMP(k) do { } while (0)
+#endif
     QSTAMP(0);
 
-    // ================= loads: gather chain first (index -> sample), then parameters, then the forward weight stream
-    size_t src = 0;
-    if (row_ok) {                                                       // (env, t) = divmod(idx, T); field[t][env]
-        const int64_t fl = p.idx[m_row];
-        const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);
-        src = (size_t)t * p.n_envs + env;
+    // ================= loads.  A CU streams weights from L2 at only ~10 B/clk (64 outstanding 64-byte misses per L1 and
+    // ~350 cycles of L2 latency), so the two 128 KB streams take as long as all the matrix-core work of the tile and must
+    // flow from the first cycle; the gather (a dependent chain index -> record) would queue behind them in every wave, so
+    // ONE wave (7) does it for all 32 rows before starting its own share of the streams and hands the rows over in LDS.
+    float4 pf[PD], pt[PD];                              // B fragments: forward tile `wave` | backward tile wave / 2, half wave & 1
+    if (wave == 7) {
+        const int m = m0 + (lane & 31);
+        int64_t fl = 0;
+        if (m < M && lane < FT) fl = p.idx[m];
+        const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);   // (env, t) = divmod(idx, T); field[t][env]
+        const size_t src = (size_t)t * p.n_envs + env;
+        float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && lane < FT) {
+            if (p.f_packed) {                                           // one 32-byte record per row
+                const float4* rec = reinterpret_cast<const float4*>(p.f_packed) + src * 2;
+                xr = rec[0]; sc = rec[1];
+            } else {
+                xr = *reinterpret_cast<const float4*>(p.f_obs + src * D);
+                sc = make_float4(p.f_act[src], p.f_ret[src], p.f_adv[src], p.f_logp[src]);
+            }
+        }
+        if (lane < FT) { *reinterpret_cast<float4*>(xs + lane * 4) = xr; *reinterpret_cast<float4*>(rsc + lane * 4) = sc; }
     }
-    float4 xrow = make_float4(0.f, 0.f, 0.f, 0.f);
-    float g_act = 0.f, g_ret = 0.f, g_adv = 0.f, g_lp = 0.f;
-    if (row_ok) {
-        xrow = *reinterpret_cast<const float4*>(p.f_obs + src * D);
-        g_act = p.f_act[src]; g_ret = p.f_ret[src]; g_adv = p.f_adv[src]; g_lp = p.f_logp[src];
-    }
-    float st_mean = 0.f, st_den = 1.f;
-    if (p.stats) { st_mean = p.stats[0]; st_den = p.stats[1]; }
-    float4 w0r[8], b0r[2];                              // first layer: thread (r, sub) -> columns [8 sub, 8 sub + 8)
+    // forward stream now; the backward stream in two halves later (PT_LOAD): a CU keeps only ~64 wave-loads in flight and
+    // a wave that cannot issue cannot compute either, so no phase may queue more than that
+    const float4* ft = nullptr;
+    const float* trow = nullptr;
+    if (p.frag_image) {
+        const float4* fr = reinterpret_cast<const float4*>(p.frag_image) + (size_t)wave * (PH / 8) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w0r[j] = *reinterpret_cast<const float4*>(img + PI_W0 + (sub * 8 + j) * 4);
-    b0r[0] = *reinterpret_cast<const float4*>(img + PI_B0 + sub * 8);
-    b0r[1] = *reinterpret_cast<const float4*>(img + PI_B0 + sub * 8 + 4);
-    // heads: k-chunks q = sub + 16 i; i = 0,1 lie in the actor half (rows 0,1 of the merged head), i = 2,3 in the critic half
-    float4 wa[2][2], wc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        wa[0][i] = *reinterpret_cast<const float4*>(img + PI_WH + 0 * PI_LDH + 4 * (sub + 16 * i));
-        wa[1][i] = *reinterpret_cast<const float4*>(img + PI_WH + 1 * PI_LDH + 4 * (sub + 16 * i));
-        wc[i] = *reinterpret_cast<const float4*>(img + PI_WH + 2 * PI_LDH + 4 * (sub + 16 * (i + 2)));
-    }
-    const float bh0 = img[PI_BH + 0], bh1 = img[PI_BH + 1], bh2 = img[PI_BH + 2];
-    const float bm = img[PI_BM + wave * 32 + li];       // branch-layer bias of this lane's output column
-    float4 pf[PD];                                      // forward B fragments: output tile `wave`, all 16 k-chunks
-    {
+        for (int q = 0; q < PD; ++q) pf[q] = fr[frag_slot(q, wave, PH / 8, 1) * 64];
+        ft = reinterpret_cast<const float4*>(p.frag_image + 2 * PH * PH) + (size_t)(wave >> 1) * (2 * PH / 8) * 64 + lane;
+    } else {
         const float* wrow = p.params + L1.w_off + (size_t)(wave * 32 + li) * PH + 4 * lh;
 #pragma unroll
         for (int q = 0; q < PD; ++q) pf[q] = *reinterpret_cast<const float4*>(wrow + q * 8);
+        trow = p.params_t + L1.w_off + (size_t)((wave >> 1) * 32 + li) * (2 * PH) + 4 * lh;
     }
-    asm volatile("" ::: "memory");
+#define PT_LOAD(i0, i1)                                                                                               \
+    do {                                                                                                              \
+        if (ft) { _Pragma("unroll") for (int i = i0; i < i1; ++i) pt[i] = ft[frag_slot((wave & 1) + 2 * i, wave >> 1, 2 * PH / 8, 2) * 64]; } \
+        else { _Pragma("unroll") for (int i = i0; i < i1; ++i) pt[i] = *reinterpret_cast<const float4*>(trow + ((wave & 1) + 2 * i) * 8); }      \
+    } while (0)
+    float st_mean = 0.f, st_std = 1.f;
+    if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
+    // the small parameters (first layer, biases, heads: 6.7 KB) go through LDS: both streams are live in registers, so
+    // there is no room to park them there until they are needed
+    if (tid < PI_FLOATS / 4) *reinterpret_cast<float4*>(pimg + tid * 4) = *reinterpret_cast<const float4*>(img + tid * 4);
+    lds_barrier();                                                                                   // #0 gathered rows
+    QSTAMP(9);
+    const float4 xrow = *reinterpret_cast<const float4*>(xs + r * 4);
+    const float4 rowsc = *reinterpret_cast<const float4*>(rsc + r * 4);
+    const float g_act = rowsc.x, g_ret = rowsc.y, g_adv = rowsc.z, g_lp = rowsc.w;
 
     // ================= forward: first layer on the VALU (k-ordered fma chain == the MFMA result)
-    if (sub == 0) *reinterpret_cast<float4*>(xs + r * 4) = xrow;
     {
+        float4 w0r[8], b0r[2];                          // thread (r, sub) -> columns [8 sub, 8 sub + 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w0r[j] = *reinterpret_cast<const float4*>(pimg + PI_W0 + (sub * 8 + j) * 4);
+        b0r[0] = *reinterpret_cast<const float4*>(pimg + PI_B0 + sub * 8);
+        b0r[1] = *reinterpret_cast<const float4*>(pimg + PI_B0 + sub * 8 + 4);
         const float b0v[8] = {b0r[0].x, b0r[0].y, b0r[0].z, b0r[0].w, b0r[1].x, b0r[1].y, b0r[1].z, b0r[1].w};
         float o[8];
 #pragma unroll
@@ -121,36 +148,45 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     lds_barrier();                                                                                   // #1 h1
     QSTAMP(1);
     // ---- branch layer 128 -> 256 on the matrix cores: wave w owns output columns [32 w, 32 w + 32)
+    PT_LOAD(0, 4);
     {
         const float* arow = h1 + li * PLD1 + 4 * lh;
-        float4 af[PD];
-#pragma unroll
-        for (int q = 0; q < PD; ++q) af[q] = *reinterpret_cast<const float4*>(arow + q * 8);
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int q = 0; q < PD; ++q) { MFMA4(af[q], pf[q], acc) }
+        for (int hq = 0; hq < 2; ++hq) {                // A fragments in two batches of 8 (register budget: both streams live)
+            float4 af[PD / 2];
+#pragma unroll
+            for (int q = 0; q < PD / 2; ++q) af[q] = *reinterpret_cast<const float4*>(arow + (hq * 8 + q) * 8);
+#pragma unroll
+            for (int q = 0; q < PD / 2; ++q) { MFMA4(af[q], pf[hq * 8 + q], acc) }
+            if (hq == 0) PT_LOAD(4, 8);
+        }
         const int col = wave * 32 + li;
+        const float bm = pimg[PI_BM + col];             // branch-layer bias of this lane's output column
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
             h2[row * PLD2 + col] = act_apply_c<ACT>(acc[rr] + bm);
         }
     }
-    // backward-data stream: W1^T[k][n] (params_t), output tile k-tile = wave / 2, chunks q = (wave & 1) + 2 i of n
-    {
-        const float* wrow = p.params_t + L1.w_off + (size_t)((wave >> 1) * 32 + li) * (2 * PH) + 4 * lh;
-#pragma unroll
-        for (int i = 0; i < PD; ++i) pf[i] = *reinterpret_cast<const float4*>(wrow + ((wave & 1) + 2 * i) * 8);
-    }
     lds_barrier();                                                                                   // #2 h2
     QSTAMP(2);
 
+    PT_LOAD(8, 12);
     // ================= heads forward (VALU, 16 threads per row), loss, heads backward -- all in registers
-    float4 a[4];
+    // k-chunks q = sub + 16 i; i = 0,1 lie in the actor half (rows 0,1 of the merged head), i = 2,3 in the critic half
+    float4 a[4], wa[2][2], wc[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(h2 + r * PLD2 + 4 * (sub + 16 * i));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        wa[0][i] = *reinterpret_cast<const float4*>(pimg + PI_WH + 0 * PI_LDH + 4 * (sub + 16 * i));
+        wa[1][i] = *reinterpret_cast<const float4*>(pimg + PI_WH + 1 * PI_LDH + 4 * (sub + 16 * i));
+        wc[i] = *reinterpret_cast<const float4*>(pimg + PI_WH + 2 * PI_LDH + 4 * (sub + 16 * (i + 2)));
+    }
+    const float bh0 = pimg[PI_BH + 0], bh1 = pimg[PI_BH + 1], bh2 = pimg[PI_BH + 2];
     float hv0, hv1, hv2;
     {
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
@@ -169,7 +205,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
         double t_s = 0.0, t_c = 0.0, t_e = 0.0, t_v = 0.0, t_n = 0.0;
         if (row_ok) {
             float adv = g_adv;
-            if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, st_mean), st_den + 1e-8f);           // memory_tools.py:281-282
+            asm volatile("" : "+v"(st_std));     // keeps hipcc from consuming the statistics (and waiting) at the top
+            if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, st_mean), st_std + 1e-8f);           // memory_tools.py:281-282
             const float invM = 1.f / (float)M;
             const float lo = (float)(1.0 - (double)p.clip_range), hi = (float)(1.0 + (double)p.clip_range);
             const int act = (int)g_act;
@@ -221,12 +258,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
         c.w = (dz2 * wc[i].w) * act_grad_c<ACT>(a[i + 2].w);
         *reinterpret_cast<float4*>(g2 + r * PLD2 + 4 * (sub + 16 * (i + 2))) = c;
     }
+    PT_LOAD(12, 16);
     lds_barrier();                                                                                   // #3 g2, dzh, rowstat
     QSTAMP(3);
 
     // ================= backward
-    // ---- loss terms of the tile: same reduction tree as the any-shape kernel (rows on lanes 0..31 of wave 0)
-    if (wave == 0) {
+    // ---- loss terms of the tile: same reduction tree as the any-shape kernel (rows on lanes 0..31 of one wave)
+    if (wave == 7) {
         double acc_s = 0.0, acc_c = 0.0, acc_e = 0.0, acc_v = 0.0, acc_n = 0.0;
         if (lane < FT) { acc_s = rowstat[lane]; acc_c = rowstat[FT + lane]; acc_e = rowstat[2 * FT + lane]; acc_v = rowstat[3 * FT + lane]; acc_n = rowstat[4 * FT + lane]; }
         acc_s = wave_sum(acc_s); acc_c = wave_sum(acc_c); acc_e = wave_sum(acc_e); acc_v = wave_sum(acc_v); acc_n = wave_sum(acc_n);
@@ -235,26 +273,27 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
             q[0] = acc_s; q[1] = acc_c; q[2] = acc_e; q[3] = acc_v; q[4] = acc_n; q[5] = 0; q[6] = 0; q[7] = 0;
         }
     }
-    // ---- head weight / bias gradients and the branch-layer bias gradient (VALU reductions over the 32 rows)
-    if (tid < 3 * PH) {
+    // ---- head weight / bias gradients (waves 0-5) and the branch-layer bias gradient (waves 6-7): VALU reductions over
+    //      the 32 rows, all LDS reads of a thread issued back to back
+    if (wave < 6) {
         const int j = tid >> 7, k = tid & (PH - 1);
         const float* hp = h2 + (j == 2 ? PH : 0) + k;
         float acc = 0.f;
 #pragma unroll
         for (int rr = 0; rr < FT; ++rr) acc += dzh[rr * 4 + j] * hp[rr * PLD2];
         slab[(j == 2 ? Lc.w_off : La.w_off + j * PH) + k] = acc;
-    } else if (tid < 3 * PH + 3) {
-        const int j = tid - 3 * PH;
-        float acc = 0.f;
+    } else {
+        const int t = tid - 6 * 64;                                      // 0..127
+        float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < FT; ++rr) acc += dzh[rr * 4 + j];
-        slab[j == 2 ? Lc.b_off : La.b_off + j] = acc;
-    }
-    if (tid < 2 * PH) {
-        float acc = 0.f;
+        for (int rr = 0; rr < FT; ++rr) { acc0 += g2[rr * PLD2 + t]; acc1 += g2[rr * PLD2 + PH + t]; }
+        slab[L1.b_off + t] = acc0; slab[L1.b_off + PH + t] = acc1;
+        if (t < 3) {
+            float acc = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < FT; ++rr) acc += g2[rr * PLD2 + tid];
-        slab[L1.b_off + tid] = acc;
+            for (int rr = 0; rr < FT; ++rr) acc += dzh[rr * 4 + t];
+            slab[t == 2 ? Lc.b_off : La.b_off + t] = acc;
+        }
     }
     QSTAMP(4);
     // ---- dW1[n][k] = sum_rows g2[row][n] * h1[row][k]: wave w owns rows n in [32 w, 32 w + 32), 4 column tiles
@@ -295,7 +334,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < PD; ++i) { MFMA4(af[i], pf[i], acc) }
+        for (int i = 0; i < PD; ++i) { MFMA4(af[i], pt[i], acc) }
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
@@ -330,11 +369,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
         }
     }
     QSTAMP(8);
-    if (dbg_me) { int c_ = 0;
+#ifdef XRL_TILE_PROBE
+    if (dbg_me) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) if (tst[i]) dbg[c_++] = tst[i];
-        dbg[15] = c_; }
+        for (int i = 0; i < 10; ++i) dbg[i] = tst[i] - tst[0];
+        dbg[15] = 10;
+    }
+#endif
 #undef QSTAMP
+#undef PT_LOAD
 }
 
 extern bool g_fast_enabled_ppo;

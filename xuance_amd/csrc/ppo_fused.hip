@@ -346,6 +346,35 @@ __global__ void __launch_bounds__(256) transpose_mid_kernel(xrl_ppo_fused_t p, f
     }
 }
 
+// fragment-ordered copies of the first middle layer (see include/xrl_hip.h)
+__global__ void __launch_bounds__(256) pack_mid_frags_kernel(xrl_ppo_fused_t p, float* __restrict__ frag) {
+    const xrl_fused_layer_t& L = p.layers[1];
+    const int N = L.N, K = L.K, kq = K / 8, nq = N / 8;
+    const float* W = p.params + L.w_off;
+    const int total = N * K;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int s = i & 3, l = (i >> 2) & 63;
+        {   // forward section: chunk q of tile t lives in slot frag_slot(q, t, kq, 1)
+            const int q = (i >> 8) % kq, t = (i >> 8) / kq;
+            frag[((size_t)(t * kq + frag_slot(q, t, kq, 1)) * 64 + l) * 4 + s] = W[(size_t)(t * 32 + (l & 31)) * K + q * 8 + 4 * (l >> 5) + s];
+        }
+        {   // backward section: slot frag_slot(q, t, nq, 2) (two waves share a tile, taking even / odd chunks)
+            const int q = (i >> 8) % nq, t = (i >> 8) / nq;
+            frag[total + ((size_t)(t * nq + frag_slot(q, t, nq, 2)) * 64 + l) * 4 + s] = W[(size_t)(q * 8 + 4 * (l >> 5) + s) * K + t * 32 + (l & 31)];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) pack_transitions_kernel(const float4* __restrict__ obs, const float* __restrict__ act,
+                                                               const float* __restrict__ ret, const float* __restrict__ adv,
+                                                               const float* __restrict__ logp, float4* __restrict__ out,
+                                                               int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        out[2 * i] = obs[i];
+        out[2 * i + 1] = make_float4(act[i], ret[i], adv[i], logp[i]);
+    }
+}
+
 static size_t ppo_fused_lds_bytes(const xrl_ppo_fused_t& p) {
     size_t floats = 0;
     for (int l = 1; l < p.n_levels; ++l) floats += 2 * (size_t)FT * level_ld(p.level_width[l]);
@@ -391,6 +420,27 @@ extern "C" int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* pp, xrl_stream_t s
     XRL_CHECK_ARG(lds_bytes <= 156 * 1024);
     const int n_tiles = (p.M + FT - 1) / FT;
     hipLaunchKernelGGL(ppo_fused_kernel, dim3(n_tiles), dim3(FUSED_THREADS), lds_bytes, as_stream(stream), p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_pack_transitions(const float* f_obs, const float* f_act, const float* f_ret, const float* f_adv,
+                                    const float* f_logp, float* packed, int64_t count, xrl_stream_t stream) {
+    XRL_CHECK_ARG(f_obs && f_act && f_ret && f_adv && f_logp && packed && count > 0);
+    XRL_CHECK_ARG(((reinterpret_cast<uintptr_t>(f_obs) | reinterpret_cast<uintptr_t>(packed)) & 15) == 0);
+    int nb = (int)((count + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(pack_transitions_kernel, dim3(nb), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(f_obs), f_act, f_ret, f_adv, f_logp, reinterpret_cast<float4*>(packed), count);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_pack_mid_frags(const xrl_ppo_fused_t* pp, float* frag, int64_t frag_floats, xrl_stream_t stream) {
+    XRL_CHECK_ARG(pp && frag && pp->params && pp->n_layers - pp->n_head_layers >= 2);
+    const xrl_fused_layer_t& L = pp->layers[1];
+    XRL_CHECK_ARG(L.N % 32 == 0 && L.K % 32 == 0 && frag_floats >= 2 * (int64_t)L.N * L.K);
+    hipLaunchKernelGGL(pack_mid_frags_kernel, dim3(64), dim3(256), 0, as_stream(stream), *pp, frag);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -88,8 +88,8 @@ class PPO_Learner(Learner):
         model, opt = self.model, self.optimizer
         clip = self.grad_clip_norm if self.use_grad_clip else 0.0
         if getattr(self, "_mirror", False):
-            ops.adam_step_mirrored(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq, clip,
-                                   self.map_t, self.params_t, self.map_img, self.cache_image)
+            ops.adam_step_mirrors(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq, clip,
+                                  self._mirrors)
         else:
             ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq, clip)
 
@@ -148,12 +148,27 @@ class PPO_Learner(Learner):
         self.sumsq = torch.zeros(256, dtype=torch.float64, device=dev)
         self._fused_bs = bs
         self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
+        self._mirrors = [(self.map_t, self.params_t), (self.map_img, self.cache_image)]
+        nf = ops.mid_frag_floats(self.model.plan)
+        self.frag = torch.zeros(nf, device=dev) if nf else None       # MFMA-fragment-ordered copy of the middle layer
+        if nf:
+            mf, mb = ops.frag_layout_maps(self.model.plan, P, dev)
+            self._mirrors += [(mf, self.frag), (mb, self.frag)]
+        self.packed = torch.zeros(memory.n_size * memory.n_envs * 8, device=dev)   # transition records the kernel gathers
         self._mirror = True
 
-    def refresh_fused_params(self):
-        """Derived parameter layouts the fused kernel reads (transposed middle weights, packed small parameters)."""
+    def refresh_fused_params(self, memory=None):
+        """Derived parameter layouts the fused kernel reads (transposed middle weights, packed small parameters); with
+        `memory`, also the packed transition records of the finished rollout (once per update phase)."""
+        if memory is not None:
+            f = memory.soa.fields
+            ops.pack_transitions(f["observations"], f["actions"], f["returns"], f["advantages"], f["aux_old_logp"],
+                                 self.packed, memory.n_size * memory.n_envs)
+            self._packed_valid = True
         ops.transpose_mid(self.model.plan, self.model.params.flat, self.params_t)
         ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)
+        if self.frag is not None:
+            ops.pack_mid_frags(self.model.plan, self.model.params.flat, self.frag)
 
     def enqueue_minibatch_fused(self, memory, idx, stats=None, finish=True):
         """One launch for gather + forward + loss + backward, then reduce + Adam, then refresh the derived layouts."""
@@ -161,7 +176,8 @@ class PPO_Learner(Learner):
         M = idx.numel()
         ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=self.params_t, cache_image=self.cache_image,
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
-                                f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs,
+                                f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs, frag_image=self.frag,
+                                f_packed=self.packed if getattr(self, "_packed_valid", False) else None,
                                 partials=self.fpartials, diag=self.diag if self.keep_diag else None,
                                 slab_stride=m.params.P, M=M, n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim,
                                 clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)

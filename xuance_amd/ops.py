@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Mirrors, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -132,6 +132,53 @@ def adam_step_mirrored(params, grad, m, v, P, state, sumsq_part, max_norm, map_a
     call("xrl_adam_step_mirrored", ptr(params), ptr(grad), ptr(m), ptr(v), int(P), ptr(state), ptr(sumsq_part),
          sumsq_part.numel(), float(max_norm if max_norm else 0.0), ptr(map_a), ptr(dst_a), ptr(map_b), ptr(dst_b),
          stream_ptr())
+
+
+def adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, max_norm, mirrors):
+    """`mirrors`: up to 4 (int32 map [P], destination tensor) pairs refreshed in the Adam launch."""
+    mir = Mirrors()
+    mir.n = len(mirrors)
+    for q, (mp, dst) in enumerate(mirrors):
+        mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
+    call("xrl_adam_step_mirrors", ptr(params), ptr(grad), ptr(m), ptr(v), int(P), ptr(state), ptr(sumsq_part),
+         sumsq_part.numel(), float(max_norm if max_norm else 0.0), C.byref(mir), stream_ptr())
+
+
+def pack_mid_frags(plan, params_flat, frag):
+    p = PpoFused()
+    p.params = params_flat.data_ptr()
+    fused_layers_from_plan(plan, p)
+    call("xrl_pack_mid_frags", C.byref(p), ptr(frag), frag.numel(), stream_ptr())
+
+
+def pack_transitions(f_obs, f_act, f_ret, f_adv, f_logp, packed, count):
+    call("xrl_pack_transitions", ptr(f_obs), ptr(f_act), ptr(f_ret), ptr(f_adv), ptr(f_logp), ptr(packed), int(count),
+         stream_ptr())
+
+
+def mid_frag_floats(plan):
+    """2*N*K of the first middle layer when it has a fragment-ordered form (multiples of 32), else 0."""
+    mids = [L for st in plan.stages[1:-1] for L in st]
+    if len(mids) < 1 or mids[0].N % 32 or mids[0].K % 32:
+        return 0
+    return 2 * mids[0].N * mids[0].K
+
+
+def frag_layout_maps(plan, P, device):
+    """int32 maps param index -> index in the forward / backward section of the fragment-ordered copy (ramp inversion)."""
+    nf = mid_frag_floats(plan)
+    ramp = torch.arange(P, dtype=torch.float32, device=device) + 1.0
+    fr = torch.zeros(nf, device=device)
+    pack_mid_frags(plan, ramp, fr)
+    torch.cuda.synchronize()
+    maps = []
+    for lo, hi in ((0, nf // 2), (nf // 2, nf)):
+        m = torch.full((P,), -1, dtype=torch.int32, device=device)
+        sec = fr[lo:hi]
+        j = torch.nonzero(sec > 0).flatten()
+        m[(sec[j] - 1.0).to(torch.int64)] = (j + lo).to(torch.int32)
+        maps.append(m)
+    return maps
 
 
 def derived_layout_maps(plan, P, device):
