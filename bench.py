@@ -41,12 +41,16 @@ def make_config(n_envs, horizon, world, rank):
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, FETCH_SIZE doubled
     per MI355X_MICROARCH.md); None if the summary is not there.  PMC counters cannot be read from inside the process."""
-    path = os.path.join(ROOT, "profiles", "r01_c_ppo_c2_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r01_d_ppo_c2_pmc_hbm.json")
     try:
         with open(path) as f:
-            return int(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+            ks = json.load(f)["kernels"]
+        for name, v in ks.items():                       # template instantiations carry their arguments in the name
+            if name.startswith(kernel):
+                return int(v["hbm_bytes_per_launch"])
     except Exception:
-        return None
+        pass
+    return None
 
 
 def _event_time_us(fn, reps):
@@ -62,9 +66,9 @@ def _event_time_us(fn, reps):
 
 def kernel_rooflines(agent):
     """Rooflines of the two kernels that make up the timed region (profiles/*.csv), timed live with HIP events on the
-    launch stream: (1) xrl::rollout_step_cartpole_kernel -- 53% of kernel time, one launch per vector step -- measured as
+    launch stream: (1) xrl::rollout_step_fast_kernel -- 42% of kernel time, one launch per vector step -- measured as
     the captured rollout graph (T+1 launches of that kernel plus one GAE scan and one counter bump) divided by T+1;
-    (2) xrl::ppo_fused_kernel -- one launch per minibatch -- measured over back-to-back launches on the last minibatch.
+    (2) xrl::ppo_fast_kernel -- 35%, one launch per minibatch -- measured over back-to-back launches on the last minibatch.
     `achieved` = ALGORITHMIC fp32 flops of the policy network (67 328 flop forward per row, 201 984
     flop forward+backward per sample) divided by the launch time; both kernels are latency-bound at this workload."""
     from xuance_amd import ops
@@ -76,9 +80,9 @@ def kernel_rooflines(agent):
     us_step = _event_time_us(agent._rollout_graph.launch, 5) / (T + 1)
     rows = 2 * n                                          # act tiles + bootstrap tiles
     fl_step = fwd_flops_row * rows
-    r1 = {"bound": "mfma", "kernel": "xrl::rollout_step_cartpole_kernel", "achieved": round(fl_step / us_step / 1e6, 4),
+    r1 = {"bound": "mfma", "kernel": "xrl::rollout_step_fast_kernel", "achieved": round(fl_step / us_step / 1e6, 4),
           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_step / us_step / 1e6 / PEAK_FP32_MFMA_TFLOPS, 5),
-          "traffic": _pmc_traffic("xrl::rollout_step_cartpole_kernel"), "avg_launch_us": round(us_step, 3),
+          "traffic": _pmc_traffic("xrl::rollout_step_fast_kernel"), "avg_launch_us": round(us_step, 3),
           "algorithmic_flops_per_launch": fl_step,
           "note": "latency-bound: %d rows x %.0f flop per launch; see DESIGN.md section 3" % (rows, fwd_flops_row)}
     # (2) fused minibatch kernel
@@ -90,15 +94,16 @@ def kernel_rooflines(agent):
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=agent.idx[k], stats=lr.stats[k], slabs=lr.fslabs,
                                 partials=lr.fpartials, diag=None, slab_stride=m.params.P, M=bs, n_envs=n, T=T, D=4,
+                                frag_image=lr.frag, f_packed=lr.packed,
                                 A=m.action_dim, clip_range=lr.clip_range, vf_coef=lr.vf_coef, ent_coef=lr.ent_coef)
     r2 = None
     if lr.fused_eligible(mem):
         mb()
         us_mb = _event_time_us(mb, 50)
         fl_mb = 3.0 * fwd_flops_row * bs
-        r2 = {"bound": "mfma", "kernel": "xrl::ppo_fused_kernel", "achieved": round(fl_mb / us_mb / 1e6, 3),
+        r2 = {"bound": "mfma", "kernel": "xrl::ppo_fast_kernel", "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
-              "traffic": _pmc_traffic("xrl::ppo_fused_kernel"), "avg_launch_us": round(us_mb, 3),
+              "traffic": _pmc_traffic("xrl::ppo_fast_kernel"), "avg_launch_us": round(us_mb, 3),
               "algorithmic_flops_per_launch": fl_mb}
     return r1, r2
 

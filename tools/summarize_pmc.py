@@ -1,0 +1,37 @@
+"""Summarise the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (csv) of tools/collect_profiles.sh into one json:
+per kernel, launches and bytes per launch.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
+(a wide coalesced stream is tallied at 64 B per 128-B request); WRITE_SIZE is reported raw (uncalibrated)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+out_dir, tag = sys.argv[1], sys.argv[2]
+
+
+def load(sub, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for path in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter:
+                    continue
+                k = row["Kernel_Name"]
+                acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
+    return acc
+
+
+fetch, write = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
+kernels = {}
+for k in sorted(set(fetch) | set(write)):
+    short = k.split("(")[0].replace("void ", "")
+    fr = fetch[k][0] / max(fetch[k][1], 1)
+    wr = write[k][0] / max(write[k][1], 1)
+    kernels[short] = {"launches": max(fetch[k][1], write[k][1]), "FETCH_SIZE_KB_per_launch_raw": round(fr, 1),
+                      "WRITE_SIZE_KB_per_launch_raw": round(wr, 1), "hbm_bytes_per_launch": int((2 * fr + wr) * 1024)}
+doc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 3 "
+                  "--warmup 1 --no-cpu-baseline --no-roofline",
+       "unit_note": "raw counter values are KB; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a wide "
+                    "coalesced stream); WRITE_SIZE uncalibrated; Infinity-Cache hits are counted",
+       "kernels": kernels}
+with open(os.path.join(out_dir, f"{tag}_ppo_c2_pmc_hbm.json"), "w") as f:
+    json.dump(doc, f, indent=1)
+print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in kernels.items() if "xrl::" in k}, indent=1))
