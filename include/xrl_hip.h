@@ -281,6 +281,12 @@ typedef struct {
 } xrl_marl_act_t;
 int xrl_marl_select_actions(const xrl_marl_act_t* p, xrl_stream_t stream);
 
+/* out[e][j] (j < take) = first `take` entries of the e-th of n_perm independent pseudo-random permutations of [0, N):
+ * the minibatch indices of one update phase (np.random.shuffle per epoch, core/on_policy.py:194-204).  A keyed bijection
+ * evaluated per element (no sort), keyed by (seed, counter + *counter_dev, e).  take == N gives full permutations. */
+int xrl_random_permutation(int64_t* out, int n_perm, int64_t N, int64_t take, uint64_t seed, uint32_t counter,
+                           const uint32_t* counter_dev, xrl_stream_t stream);
+
 /* *counter += inc on the stream (advances RNG step counters between replays of a captured rollout). */
 int xrl_counter_add(uint32_t* counter, uint32_t inc, xrl_stream_t stream);
 

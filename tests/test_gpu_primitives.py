@@ -330,3 +330,27 @@ def test_graph_replay(ops):
     s = ops.read_adam_state(st)
     assert s.step == 5
     assert abs(float(a[0]) - (1 - 5e-3)) < 1e-4
+
+
+@pytest.mark.parametrize("N,take,n_perm", [(65536, 65536, 8), (1000, 1000, 3), (4097, 4000, 2), (2, 2, 4)])
+def test_random_permutation_rows_are_permutations(N, take, n_perm):
+    """xrl_random_permutation: every row holds `take` distinct values of range(N); rows and update phases differ."""
+    from xuance_amd import ops
+    out = torch.full((n_perm, take), -1, dtype=torch.int64, device="cuda")
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.random_permutation(out, n_perm, N, take, seed=7, counter=0, counter_dev=ctr)
+    a = out.cpu().numpy()
+    for e in range(n_perm):
+        assert a[e].min() >= 0 and a[e].max() < N and len(np.unique(a[e])) == take
+    if N > 100:
+        assert not np.array_equal(a[0], a[1])
+        if take == N:                                     # no fixed-point / identity bias worth noticing
+            assert (a[0] == np.arange(N)).mean() < 0.01
+            assert abs(np.corrcoef(a[0], np.arange(N))[0, 1]) < 0.05
+        ops.counter_add(ctr, 1)
+        out2 = torch.empty_like(out)
+        ops.random_permutation(out2, n_perm, N, take, seed=7, counter=0, counter_dev=ctr)
+        assert not np.array_equal(out2.cpu().numpy()[0], a[0])
+        out3 = torch.empty_like(out)
+        ops.random_permutation(out3, n_perm, N, take, seed=7, counter=1, counter_dev=None)
+        assert np.array_equal(out3.cpu().numpy(), out2.cpu().numpy())

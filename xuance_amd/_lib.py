@@ -161,6 +161,7 @@ _SIGS = {
     "xrl_egreedy": [C.POINTER(EGreedy), c_void_p],
     "xrl_counter_add": [c_void_p, C.c_uint32, c_void_p],
     "xrl_set_fast_kernels": [C.c_int],
+    "xrl_random_permutation": [c_void_p, c_int, c_int64, c_int64, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
     "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],
     "xrl_soa_store_step": [C.POINTER(Field), c_int, c_int, c_int, c_void_p],
     "xrl_gae_scan": [c_void_p] * 7 + [c_int, c_int, c_double, c_double, c_int, c_void_p],

@@ -58,6 +58,7 @@ class PPO_Agent:
         self.returns = torch.zeros(n, device=dev)               # discounted return tracker (ppo_agent.py:144)
         self.X = torch.zeros(2 * n, D, device=dev)              # policy input: [obs_t ; next_obs_{t-1}] (normalised)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)   # RNG counter base, advanced per rollout
+        self.perm_counter = torch.zeros(1, dtype=torch.int32, device=dev)   # one tick per update phase (index generation)
         self.model.plan.ensure(2 * n)
         self.buffer_size = n * self.horizon_size
         self.batch_size = self.buffer_size // self.n_minibatch
@@ -193,6 +194,8 @@ class PPO_Agent:
             lr.refresh_fused_params(mem)
         else:
             lr.prepare_buffer_update(mem, bs)
+        if not getattr(self, "_fixed_idx", False):
+            self._new_indices()
         if mem.use_advnorm:
             ops.adv_stats(f.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs, self.horizon_size, lr.stats)
         step = lr.enqueue_minibatch_fused if fused else lr.enqueue_minibatch_from_buffer
@@ -201,14 +204,19 @@ class PPO_Agent:
 
     def _new_indices(self):
         """np.random.shuffle of arange(buffer_size) per epoch (on_policy.py:194-204), generated on the device."""
-        N = self.buffer_size
-        perm = torch.rand(self.n_epochs, N, device=self.device).argsort(dim=1)
-        self.idx.copy_(perm[:, : self.n_minibatch * self.batch_size].reshape(self.idx.shape))
+        # one launch, part of the captured update graph: a keyed bijection per epoch (xrl_random_permutation), keyed by a
+        # device counter that ticks once per update phase
+        ops.random_permutation(self.idx, self.n_epochs, self.buffer_size, self.n_minibatch * self.batch_size, self.seed,
+                               0, self.perm_counter)
+        ops.counter_add(self.perm_counter, 1)
 
     # -- public API -----------------------------------------------------------------------------------------------
     def set_indices(self, idx):
         """Parity hook: use the caller's minibatch indices (e.g. the ones NumPy produced for the reference)."""
         self.idx.copy_(torch.as_tensor(np.asarray(idx)).reshape(self.idx.shape))
+        if not getattr(self, "_fixed_idx", False):
+            self._update_graph = None                     # a captured graph would regenerate the indices
+            self._mb_graphs = None
         self._fixed_idx = True
 
     def rollout(self):
@@ -246,6 +254,8 @@ class PPO_Agent:
             for k in range(nb):
                 g = ops.Graph()
                 with g:
+                    if k == 0 and not getattr(self, "_fixed_idx", False):
+                        self._new_indices()
                     if k == 0 and mem.use_advnorm:
                         ops.adv_stats(mem.soa.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs,
                                       self.horizon_size, lr.stats)
@@ -263,8 +273,6 @@ class PPO_Agent:
             self._finish_graph.launch()
 
     def update(self):
-        if not getattr(self, "_fixed_idx", False):
-            self._new_indices()
         if self.learner.distributed_training and self.learner.world_size > 1:
             self._update_distributed()
         elif self.use_graph:

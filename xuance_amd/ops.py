@@ -309,6 +309,12 @@ def counter_add(counter, inc):
     call("xrl_counter_add", ptr(counter), int(inc), stream_ptr())
 
 
+def random_permutation(out, n_perm, N, take, seed, counter=0, counter_dev=None):
+    """out [n_perm][take] int64 <- first `take` entries of n_perm pseudo-random permutations of range(N)."""
+    call("xrl_random_permutation", ptr(out), int(n_perm), int(N), int(take), int(seed), int(counter), ptr(counter_dev),
+         stream_ptr())
+
+
 def set_fast_kernels(enable):
     """Select (default) or bypass the shape-specialised twins of the fused kernels; results are bit-identical."""
     call("xrl_set_fast_kernels", int(bool(enable)))
