@@ -343,6 +343,23 @@ typedef struct {
     long long* dbg;                                    /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
 } xrl_rollout_step_t;
 int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
+/* Persistent form: all T vector steps of a rollout plus the final bootstrap pass in ONE launch (the workgroups stay
+ * resident, parameters / simulator state / running statistics stay on chip, steps are separated by a counter barrier in
+ * the L2 of one XCD).  Same results as T calls of xrl_rollout_step_cartpole(step t: slots of row t, *_in/*_out swapped
+ * every step, bootv_prev = bootv[t-1]) followed by one boot_only call.  Requirements: the 4-128-{128-2,128-1} network
+ * class with role_split and frag_image, 3*ceil(n/32) <= CUs of one XCD (n <= 320 on MI355X).
+ * step0 describes step 0: *_slot = row 0 of the [T][n] fields, *_in = ping-pong buffer 0, *_out = buffer 1
+ * (step0.bootv_prev, last_step, boot_only are ignored; step0.step is the RNG step of row 0).  After the call the
+ * statistics / flags of the last step are in buffer T & 1, exactly as after the per-step calls. */
+typedef struct {
+    xrl_rollout_step_t step0;
+    float* bootv;               /* [T][n] bootstrap values */
+    uint32_t* barrier;          /* [1] scratch counter (zeroed by the call, on the stream) */
+    int32_t* status;            /* [4] zero-initialised by the caller: [0] != 0 -> a barrier timed out, results invalid;
+                                 * [1] XCC id of workgroup 0, [2] bit mask of the XCC ids the workgroups ran on */
+    int32_t T, pad;
+} xrl_rollout_persist_t;
+int xrl_rollout_cartpole_persistent(const xrl_rollout_persist_t* p, xrl_stream_t stream);
 /* The fused kernels have shape-specialised twins (compile-time extents, bit-identical results) that are selected
  * automatically when the network is the 4-128-{128-2,128-1} class; 0 forces the any-shape kernels (parity tests). */
 int xrl_set_fast_kernels(int enable);
@@ -455,6 +472,9 @@ int xrl_debug_mfma_chain(int iters, int blocks, long long* out, float* sink, xrl
 /* diagnostics: 16 KB of straight-line VALU code executed `passes` times; out[pass] = shader cycles (pass 0 = cold I-cache) */
 int xrl_debug_icache(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream);
 /* diagnostics: 16 taken branches, each over 2 KB of padding; out[pass] = shader cycles (pass 0 = cold I-cache) */
+/* diagnostics: counter barrier + device-scope data exchange between n_wg workgroups pinned to one XCD (blockIdx % 8 == 0):
+ * out[0] cycles per iteration (two barriers + exchange), out[1] wrong values seen, out[2] timeouts, out[3..] XCC id per workgroup */
+int xrl_debug_xcd_barrier(int iters, int n_wg, unsigned* counter, float* slots, long long* out, xrl_stream_t stream);
 int xrl_debug_ijump(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream);
 
 /* ------------------------------------------------------------------ hipGraph capture of op sequences */

@@ -219,6 +219,40 @@ def test_specialised_rollout_kernel_is_bit_identical_to_any_shape_kernel(act, n)
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("act,n", [("leaky_relu", 100), ("tanh", 256), ("relu", 37)])
+def test_persistent_rollout_is_bit_identical_to_per_step_launches(act, n):
+    """rollout_persistent_kernel (ONE launch per rollout, counter barrier between steps) vs T + 1 launches of
+    rollout_step_fast_kernel: every buffer field, statistic and simulator state must carry the same bits."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    res = []
+    for persistent in (False, True):
+        torch.manual_seed(0)
+        env = DeviceCartPoleVecEnv(n, seed=3)
+        env.max_episode_steps = 30
+        agent = PPO_Agent(make_config(n, 48, activation=act, use_persistent_rollout=persistent), env)
+        assert agent.use_fused_rollout
+        agent.rollout()
+        agent.rollout()
+        torch.cuda.synchronize()
+        if persistent:
+            st = agent.persist_status.tolist()
+            assert st[0] == 0 and bin(st[2]).count("1") == 1, st      # no time-out, all workgroups on one XCD
+        else:
+            assert getattr(agent, "persist_status", None) is None
+        i = agent.horizon_size & 1
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        f.update(obs_stats=npy(agent.pp["obs_stats"][i]), ret_stats=npy(agent.pp["ret_stats"][i]),
+                 obs_count=npy(agent.pp["obs_count"][i]), ret_count=npy(agent.pp["ret_count"][i]),
+                 obs_raw=npy(agent.pp["obs_raw"][i]), ret_track=npy(agent.returns), cp_state=npy(env.state),
+                 cp_steps=npy(env.steps), cp_episodes=npy(env.episodes), eps=np.asarray(env.episode_stats()))
+        res.append(f)
+    a, b = res
+    assert a["eps"][0] > 50
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("n,T,nmb", [(24, 40, 2), (64, 64, 4), (50, 30, 3)])
 def test_fused_minibatch_kernel_equals_layered_path(n, T, nmb):
     """xrl_ppo_fused_minibatch (one launch) vs gather + grouped GEMMs + loss + backward GEMMs: same gradient and losses."""

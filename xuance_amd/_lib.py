@@ -117,6 +117,11 @@ class RolloutStep(C.Structure):
                 ("dbg", c_void_p)]
 
 
+class RolloutPersist(C.Structure):
+    _fields_ = [("step0", RolloutStep), ("bootv", c_void_p), ("barrier", c_void_p), ("status", c_void_p),
+                ("T", c_int32), ("pad", c_int32)]
+
+
 class PpoFused(C.Structure):
     _fields_ = [("params", c_void_p), ("params_t", c_void_p), ("cache_image", c_void_p), ("layers", FusedLayer * 8),
                 ("n_layers", c_int32), ("n_levels", c_int32), ("n_head_layers", c_int32), ("pad0", c_int32),
@@ -148,6 +153,7 @@ _SIGS = {
     "xrl_debug_mfma_chain": [c_int, c_int, c_void_p, c_void_p, c_void_p],
     "xrl_debug_icache": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "xrl_debug_ijump": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "xrl_debug_xcd_barrier": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "xrl_rollout_step_cartpole": [C.POINTER(RolloutStep), c_void_p],
     "xrl_pack_rollout_cache": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p],
     "xrl_pack_rollout_cache2": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p, c_void_p],
@@ -161,6 +167,7 @@ _SIGS = {
     "xrl_egreedy": [C.POINTER(EGreedy), c_void_p],
     "xrl_counter_add": [c_void_p, C.c_uint32, c_void_p],
     "xrl_set_fast_kernels": [C.c_int],
+    "xrl_rollout_cartpole_persistent": [C.POINTER(RolloutPersist), c_void_p],
     "xrl_random_permutation": [c_void_p, c_int, c_int64, c_int64, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
     "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],
     "xrl_soa_store_step": [C.POINTER(Field), c_int, c_int, c_int, c_void_p],

@@ -77,7 +77,7 @@ class PPO_Agent:
                        "obs_count": torch.full((2, 1), 1e-4, dtype=torch.float64, device=dev),
                        "ret_stats": torch.tensor([[0.0, 1.0], [0.0, 1.0]], device=dev),
                        "ret_count": torch.full((2, 1), 1e-4, dtype=torch.float64, device=dev),
-                       "ended": torch.zeros(2, n, dtype=torch.uint8, device=dev),
+                       "ended": torch.zeros(2, (n + 3) // 4 * 4, dtype=torch.uint8, device=dev),   # rows word-aligned
                        "ret_final": torch.zeros(2, n, device=dev)}
             self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
             self.frag_image = torch.zeros(self.model.params.P, device=dev)
@@ -149,23 +149,47 @@ class PPO_Agent:
                       use_rewnorm=int(self.use_rewnorm), obs_range=float(self.obsnorm_range),
                       rew_range=float(self.rewnorm_range), gamma=float(self.gamma), seed=self.seed, env_seed=env.seed,
                       step_dev=self.step_counter)
-        for t in range(T):
-            i, o = t & 1, (t + 1) & 1
-            ops.rollout_step_cartpole(
-                self.model.plan, obs_raw_in=pp["obs_raw"][i], obs_raw_out=pp["obs_raw"][o], xnext_in=pp["xnext"][i],
-                xnext_out=pp["xnext"][o], obs_stats_in=pp["obs_stats"][i], obs_stats_out=pp["obs_stats"][o],
-                obs_count_in=pp["obs_count"][i], obs_count_out=pp["obs_count"][o], ret_stats_in=pp["ret_stats"][i],
-                ret_stats_out=pp["ret_stats"][o], ret_count_in=pp["ret_count"][i], ret_count_out=pp["ret_count"][o],
-                ended_in=pp["ended"][i], ended_out=pp["ended"][o], ret_final_in=pp["ret_final"][i],
-                ret_final_out=pp["ret_final"][o], obs_slot=f["observations"][t], act_slot=f["actions"][t],
-                val_slot=f["values"][t], logp_slot=f["aux_old_logp"][t], rew_slot=f["rewards"][t],
-                term_slot=f["terminals"][t], seg_slot=f["seg"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None,
-                last_step=int(t == T - 1), boot_only=0, step=t, **common)
-        ops.rollout_step_cartpole(self.model.plan, xnext_in=pp["xnext"][T & 1], bootv_prev=f["bootv"][T - 1], boot_only=1,
-                                  last_step=0, step=0, **common)
+        step0 = dict(obs_raw_in=pp["obs_raw"][0], obs_raw_out=pp["obs_raw"][1], xnext_in=pp["xnext"][0],
+                     xnext_out=pp["xnext"][1], obs_stats_in=pp["obs_stats"][0], obs_stats_out=pp["obs_stats"][1],
+                     obs_count_in=pp["obs_count"][0], obs_count_out=pp["obs_count"][1], ret_stats_in=pp["ret_stats"][0],
+                     ret_stats_out=pp["ret_stats"][1], ret_count_in=pp["ret_count"][0], ret_count_out=pp["ret_count"][1],
+                     ended_in=pp["ended"][0], ended_out=pp["ended"][1], ret_final_in=pp["ret_final"][0],
+                     ret_final_out=pp["ret_final"][1], obs_slot=f["observations"][0], act_slot=f["actions"][0],
+                     val_slot=f["values"][0], logp_slot=f["aux_old_logp"][0], rew_slot=f["rewards"][0],
+                     term_slot=f["terminals"][0], seg_slot=f["seg"][0], last_step=0, boot_only=0, step=0)
+        if self._persistent_ok(split_ok):
+            # ONE launch for the whole rollout: resident workgroups, counter barrier between steps (rollout_persist.hip)
+            ops.rollout_cartpole_persistent(plan, T, f["bootv"], self.persist_barrier, self.persist_status, **step0, **common)
+        else:
+            for t in range(T):
+                i, o = t & 1, (t + 1) & 1
+                ops.rollout_step_cartpole(
+                    self.model.plan, obs_raw_in=pp["obs_raw"][i], obs_raw_out=pp["obs_raw"][o], xnext_in=pp["xnext"][i],
+                    xnext_out=pp["xnext"][o], obs_stats_in=pp["obs_stats"][i], obs_stats_out=pp["obs_stats"][o],
+                    obs_count_in=pp["obs_count"][i], obs_count_out=pp["obs_count"][o], ret_stats_in=pp["ret_stats"][i],
+                    ret_stats_out=pp["ret_stats"][o], ret_count_in=pp["ret_count"][i], ret_count_out=pp["ret_count"][o],
+                    ended_in=pp["ended"][i], ended_out=pp["ended"][o], ret_final_in=pp["ret_final"][i],
+                    ret_final_out=pp["ret_final"][o], obs_slot=f["observations"][t], act_slot=f["actions"][t],
+                    val_slot=f["values"][t], logp_slot=f["aux_old_logp"][t], rew_slot=f["rewards"][t],
+                    term_slot=f["terminals"][t], seg_slot=f["seg"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None,
+                    last_step=int(t == T - 1), boot_only=0, step=t, **common)
+            ops.rollout_step_cartpole(self.model.plan, xnext_in=pp["xnext"][T & 1], bootv_prev=f["bootv"][T - 1], boot_only=1,
+                                      last_step=0, step=0, **common)
         ops.counter_add(self.step_counter, T)
         ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
                      self.gamma, self.gae_lam, self.memory.use_gae)
+
+    def _persistent_ok(self, split_ok):
+        """Whole-rollout launch: the 4-128-{128-2,128-1} class, all workgroups resident on one XCD (n_envs <= 320)."""
+        if not bool(_get(self.config, "use_persistent_rollout", True)) or not split_ok:
+            return False
+        plan = self.model.plan
+        if list(plan.widths) != [4, 128, 256, 3] or 3 * ((self.n_envs + 31) // 32) > 32 or not ops.fast_kernels_enabled():
+            return False
+        if getattr(self, "persist_status", None) is None:
+            self.persist_barrier = torch.zeros(16, dtype=torch.int32, device=self.device)
+            self.persist_status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        return True
 
     def _enqueue_rollout(self):
         if self.use_fused_rollout:

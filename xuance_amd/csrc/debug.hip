@@ -71,3 +71,94 @@ extern "C" int xrl_debug_ijump(int passes, int blocks, int threads, long long* o
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
+
+// Intra-XCD grid barrier probe: workgroups are dealt round-robin to the 8 XCDs, so of a grid of 8*n_wg only those with
+// blockIdx % 8 == 0 stay (the rest exit): the survivors share ONE L2.  Each iteration every survivor publishes a value,
+// crosses a counter barrier (L2 atomics) and reads every other survivor's value with device-scope loads.
+// out[0] = cycles per iteration (workgroup 0), out[1] = number of wrong values seen, out[2] = timeouts, out[3..] = XCC ids.
+namespace xrl {
+template <int VARIANT>
+__device__ __forceinline__ void probe_barrier(unsigned* counter, unsigned want, int* s_to) {
+    if (VARIANT == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) { if (++spins > 2000000) { *s_to = 1; break; } }
+    } else if (VARIANT == 1) {         // L2-local atomics (workgroup-scope encoding: no fabric round trip), relaxed polling
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int spins = 0;
+        while (__hip_atomic_fetch_add(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 2000000) { *s_to = 1; break; }
+        }
+    } else if (VARIANT == 3) {         // formally correct form: release fence, relaxed add + relaxed polling, acquire fence
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 2000000) { *s_to = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    } else {                           // agent-scope relaxed add, relaxed agent-scope load polling with back-off
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 2000000) { *s_to = 1; break; }
+        }
+    }
+}
+
+template <int VARIANT>
+__global__ void __launch_bounds__(256) xcd_barrier_probe_kernel(int iters, int n_wg, unsigned* counter, float* slots,
+                                                                long long* out) {
+    if (blockIdx.x % 8 != 0) return;
+    const int wg = blockIdx.x / 8;
+    __shared__ int s_bad, s_to;
+    if (threadIdx.x == 0) { s_bad = 0; s_to = 0; }
+    __syncthreads();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) out[3 + wg] = xcc & 0xf;
+    const long long c0 = clock64();
+    for (int it = 1; it <= iters; ++it) {
+        if (threadIdx.x < 64) slots[wg * 64 + threadIdx.x] = (float)(it * 1000 + wg);
+        if (VARIANT == 3) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // by the storing wave itself
+        __builtin_amdgcn_s_waitcnt(0);                       // stores acknowledged by L2
+        __syncthreads();
+        if (threadIdx.x == 0) probe_barrier<VARIANT>(counter, (unsigned)(n_wg * it), &s_to);
+        __syncthreads();
+        if (s_to) break;
+        // read everybody's slot with device-scope loads (bypass this CU's L1)
+        if (VARIANT == 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // every wave: invalidate this CU's view
+        for (int i = threadIdx.x; i < n_wg * 64; i += blockDim.x) {
+            const float v = VARIANT == 3 ? slots[i] : __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != (float)(it * 1000 + i / 64)) atomicAdd(&s_bad, 1);
+        }
+        __syncthreads();
+        // second barrier so nobody overwrites a slot that is still being read
+        if (threadIdx.x == 0) probe_barrier<VARIANT>(counter + 32, (unsigned)(n_wg * it), &s_to);
+        __syncthreads();
+        if (s_to) break;
+    }
+    const long long c1 = clock64();
+    if (threadIdx.x == 0) {
+        if (wg == 0) out[0] = (c1 - c0) / (iters > 0 ? iters : 1);
+        atomicAdd((unsigned long long*)&out[1], (unsigned long long)s_bad);
+        atomicAdd((unsigned long long*)&out[2], (unsigned long long)s_to);
+    }
+}
+}  // namespace xrl
+
+extern "C" int xrl_debug_xcd_barrier(int iters, int n_wg, unsigned* counter, float* slots, long long* out, xrl_stream_t stream) {
+    XRL_CHECK_ARG(n_wg >= 1 && n_wg <= 32 && counter && slots && out);
+    const int variant = iters >> 24;
+    iters &= 0xffffff;
+    if (variant == 1) hipLaunchKernelGGL(xrl::xcd_barrier_probe_kernel<1>, dim3(8 * n_wg), dim3(256), 0, xrl::as_stream(stream), iters, n_wg, counter, slots, out);
+    else if (variant == 3) hipLaunchKernelGGL(xrl::xcd_barrier_probe_kernel<3>, dim3(8 * n_wg), dim3(256), 0, xrl::as_stream(stream), iters, n_wg, counter, slots, out);
+    else if (variant == 2) hipLaunchKernelGGL(xrl::xcd_barrier_probe_kernel<2>, dim3(8 * n_wg), dim3(256), 0, xrl::as_stream(stream), iters, n_wg, counter, slots, out);
+    else hipLaunchKernelGGL(xrl::xcd_barrier_probe_kernel<0>, dim3(8 * n_wg), dim3(256), 0, xrl::as_stream(stream), iters, n_wg, counter,
+                       slots, out);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

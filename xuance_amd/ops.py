@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (Mirrors, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Mirrors, RolloutPersist, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -289,6 +289,18 @@ def rollout_step_cartpole(plan, **kw):
     call("xrl_rollout_step_cartpole", C.byref(p), stream_ptr())
 
 
+def rollout_cartpole_persistent(plan, T, bootv, barrier, status, **kw):
+    """All T steps + the bootstrap pass in one launch; kw as for rollout_step_cartpole (describing step 0)."""
+    q = RolloutPersist()
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(q.step0, k, v)
+    fused_layers_from_plan(plan, q.step0)
+    q.bootv, q.barrier, q.status, q.T = bootv.data_ptr(), barrier.data_ptr(), status.data_ptr(), int(T)
+    call("xrl_rollout_cartpole_persistent", C.byref(q), stream_ptr())
+
+
 def dqn_td(**kw):
     call("xrl_dqn_td", C.byref(_struct(DqnTd, kw)), stream_ptr())
 
@@ -315,9 +327,18 @@ def random_permutation(out, n_perm, N, take, seed, counter=0, counter_dev=None):
          stream_ptr())
 
 
+_fast_enabled = True
+
+
 def set_fast_kernels(enable):
     """Select (default) or bypass the shape-specialised twins of the fused kernels; results are bit-identical."""
+    global _fast_enabled
+    _fast_enabled = bool(enable)
     call("xrl_set_fast_kernels", int(bool(enable)))
+
+
+def fast_kernels_enabled():
+    return _fast_enabled
 
 
 # ------------------------------------------------------------------------------------------ graphs
