@@ -41,7 +41,7 @@ def make_config(n_envs, horizon, world, rank):
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, FETCH_SIZE doubled
     per MI355X_MICROARCH.md); None if the summary is not there.  PMC counters cannot be read from inside the process."""
-    path = os.path.join(ROOT, "profiles", "r01_d_ppo_c2_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r01_e_ppo_c2_pmc_hbm.json")
     try:
         with open(path) as f:
             ks = json.load(f)["kernels"]
@@ -66,25 +66,29 @@ def _event_time_us(fn, reps):
 
 def kernel_rooflines(agent):
     """Rooflines of the two kernels that make up the timed region (profiles/*.csv), timed live with HIP events on the
-    launch stream: (1) xrl::rollout_step_fast_kernel -- 42% of kernel time, one launch per vector step -- measured as
-    the captured rollout graph (T+1 launches of that kernel plus one GAE scan and one counter bump) divided by T+1;
-    (2) xrl::ppo_fast_kernel -- 35%, one launch per minibatch -- measured over back-to-back launches on the last minibatch.
+    launch stream: (1) xrl::rollout_persistent_kernel -- ONE launch per rollout: T vector steps + the bootstrap pass (or,
+    when the persistent form is not eligible, xrl::rollout_step_fast_kernel, T + 1 launches) -- and
+    (2) xrl::ppo_fast_kernel -- one launch per minibatch -- measured over back-to-back launches on the last minibatch.
     `achieved` = ALGORITHMIC fp32 flops of the policy network (67 328 flop forward per row, 201 984
     flop forward+backward per sample) divided by the launch time; both kernels are latency-bound at this workload."""
     from xuance_amd import ops
     lr, mem, m = agent.learner, agent.memory, agent.model
     T, n, bs = agent.horizon_size, agent.n_envs, agent.batch_size
     fwd_flops_row = sum(2.0 * L.N * L.K for st in m.plan.stages for L in st)
-    # (1) rollout step kernel
-    agent._rollout_graph.launch()
-    us_step = _event_time_us(agent._rollout_graph.launch, 5) / (T + 1)
-    rows = 2 * n                                          # act tiles + bootstrap tiles
-    fl_step = fwd_flops_row * rows
-    r1 = {"bound": "mfma", "kernel": "xrl::rollout_step_fast_kernel", "achieved": round(fl_step / us_step / 1e6, 4),
-          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_step / us_step / 1e6 / PEAK_FP32_MFMA_TFLOPS, 5),
-          "traffic": _pmc_traffic("xrl::rollout_step_fast_kernel"), "avg_launch_us": round(us_step, 3),
-          "algorithmic_flops_per_launch": fl_step,
-          "note": "latency-bound: %d rows x %.0f flop per launch; see DESIGN.md section 3" % (rows, fwd_flops_row)}
+    # (1) rollout kernel(s), without the GAE scan / counter bump / parameter re-pack of the rollout graph
+    persistent = getattr(agent, "persist_status", None) is not None
+    kernel_only = lambda: agent._enqueue_rollout_fused(kernel_only=True)
+    kernel_only()
+    launches = 1 if persistent else T + 1
+    us_launch = _event_time_us(kernel_only, 5) / launches
+    rows = 2 * n * (T + 1 if persistent else 1)           # act tiles + bootstrap tiles, per launch
+    fl_launch = fwd_flops_row * rows
+    name = "xrl::rollout_persistent_kernel" if persistent else "xrl::rollout_step_fast_kernel"
+    r1 = {"bound": "mfma", "kernel": name, "achieved": round(fl_launch / us_launch / 1e6, 4),
+          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_launch / us_launch / 1e6 / PEAK_FP32_MFMA_TFLOPS, 5),
+          "traffic": _pmc_traffic(name), "avg_launch_us": round(us_launch, 3), "algorithmic_flops_per_launch": fl_launch,
+          "note": "latency-bound: %d rows x %.0f flop per launch (%s); see DESIGN.md section 3"
+                  % (rows, fwd_flops_row, "%d vector steps of 2 x %d rows" % (T + 1, n) if persistent else "one vector step")}
     # (2) fused minibatch kernel
     f = mem.soa.fields
     k = agent.idx.shape[0] - 1

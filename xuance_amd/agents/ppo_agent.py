@@ -132,11 +132,13 @@ class PPO_Agent:
                              last_step=int(t == self.horizon_size - 1), obs_range=float(self.obsnorm_range),
                              rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
 
-    def _enqueue_rollout_fused(self):
-        """T launches of xrl_rollout_step_cartpole + one bootstrap-only launch + GAE (same numbers as _enqueue_rollout)."""
+    def _enqueue_rollout_fused(self, kernel_only=False):
+        """ONE persistent launch (or T launches of xrl_rollout_step_cartpole + one bootstrap-only launch) + GAE: same
+        numbers as _enqueue_rollout.  kernel_only: just the rollout kernel(s) (bench.py times them in isolation)."""
         T, n, D, A = self.horizon_size, self.n_envs, self.obs_dim, self.model.action_dim
         env, f, pp = self.envs, self.memory.soa.fields, self.pp
-        ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image, self.frag_image)   # params changed
+        if not kernel_only:
+            ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image, self.frag_image)   # params changed
         plan = self.model.plan
         mids = [L for st in plan.stages[1:-1] for L in st]
         heads = plan.stages[-1]
@@ -175,6 +177,8 @@ class PPO_Agent:
                     last_step=int(t == T - 1), boot_only=0, step=t, **common)
             ops.rollout_step_cartpole(self.model.plan, xnext_in=pp["xnext"][T & 1], bootv_prev=f["bootv"][T - 1], boot_only=1,
                                       last_step=0, step=0, **common)
+        if kernel_only:
+            return
         ops.counter_add(self.step_counter, T)
         ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
                      self.gamma, self.gae_lam, self.memory.use_gae)
