@@ -98,7 +98,7 @@ def kernel_rooflines(agent):
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=agent.idx[k], stats=lr.stats[k], slabs=lr.fslabs,
                                 partials=lr.fpartials, diag=None, slab_stride=m.params.P, M=bs, n_envs=n, T=T, D=4,
-                                frag_image=lr.frag, f_packed=lr.packed,
+                                frag_image=lr.frag, f_packed=lr.packed, f_rows=lr.rows[k * bs * 8:(k + 1) * bs * 8],
                                 A=m.action_dim, clip_range=lr.clip_range, vf_coef=lr.vf_coef, ent_coef=lr.ent_coef)
     r2 = None
     if lr.fused_eligible(mem):

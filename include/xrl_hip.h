@@ -397,6 +397,8 @@ typedef struct {
     float clip_range, vf_coef, ent_coef, pad2;
     long long* dbg;             /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
     const float* frag_image;    /* NULL, or xrl_pack_mid_frags copy of the first middle layer in MFMA B-fragment order */
+    const float* f_rows;        /* NULL, or this minibatch's records already gathered, [M][8] (xrl_gather_rows): the kernel's
+                                 * first load then needs neither the index nor a dependent second hop */
     const float* f_packed;      /* NULL, or xrl_pack_transitions records [T*n_envs][8] = obs[4] | act | ret | adv | old_logp:
                                  * one 32-byte random access per sampled row instead of five (D == 4 only) */
 } xrl_ppo_fused_t;
@@ -405,6 +407,9 @@ int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* p, xrl_stream_t stream);
  * the record form the fused minibatch kernel gathers from; run once per update phase after the advantages exist. */
 int xrl_pack_transitions(const float* f_obs, const float* f_act, const float* f_ret, const float* f_adv,
                          const float* f_logp, float* packed, int64_t count, xrl_stream_t stream);
+/* out[i][0..7] = packed[(idx[i] % T) * n_envs + idx[i] / T][0..7] for i < count: every minibatch of an update phase gathered
+ * in one launch (idx = all n_epochs x n_minibatch x batch indices, env-major flat indices as in memory_tools.py:270). */
+int xrl_gather_rows(const float* packed, const int64_t* idx, float* out, int64_t count, int n_envs, int T, xrl_stream_t stream);
 /* frag <- the first middle layer W[N][K] (N % 32 == 0, K % 32 == 0) in the order the matrix-core kernels consume it, so
  * that every prefetch instruction of a wave reads one contiguous 1 KB run:
  *   forward section  [N/32][K/8][64 lanes][4]: W[32 t + (l & 31)][8 q + 4 (l >> 5) + s] in slot (q + t) mod K/8 of tile t

@@ -30,7 +30,10 @@ def mb(dbg_=None):
                             f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                             f_logp=f["aux_old_logp"], idx=idx, stats=lr.stats[3], slabs=lr.fslabs, partials=lr.fpartials,
                             diag=None, slab_stride=m.params.P, M=idx.numel(), n_envs=n, T=256, D=4, A=2, clip_range=0.2,
-                            vf_coef=0.25, ent_coef=0.01, frag_image=lr.frag, f_packed=lr.packed)
+                            vf_coef=0.25, ent_coef=0.01, frag_image=lr.frag, f_packed=lr.packed,
+                            f_rows=lr.rows[3 * 8192 * 8:4 * 8192 * 8] if os.environ.get("ROWS", "1") == "1" else None)
+
+
 def timed(fn, reps=50):
     g = ops.Graph()
     with g:

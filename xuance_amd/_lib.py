@@ -130,7 +130,7 @@ class PpoFused(C.Structure):
                 ("idx", c_void_p), ("stats", c_void_p), ("slabs", c_void_p), ("partials", c_void_p), ("diag", c_void_p),
                 ("slab_stride", c_int64), ("M", c_int32), ("n_envs", c_int32), ("T", c_int32), ("D", c_int32),
                 ("A", c_int32), ("pad1", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
-                ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_packed", c_void_p)]
+                ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p)]
 
 
 class Mirrors(C.Structure):
@@ -148,6 +148,7 @@ _SIGS = {
     "xrl_ppo_fused_minibatch": [C.POINTER(PpoFused), c_void_p],
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
+    "xrl_gather_rows": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "xrl_pack_transitions": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrl_init": [],
     "xrl_debug_mfma_chain": [c_int, c_int, c_void_p, c_void_p, c_void_p],

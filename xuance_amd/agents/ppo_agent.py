@@ -219,11 +219,12 @@ class PPO_Agent:
         fused = lr.fused_eligible(mem)
         if fused:
             lr.prepare_fused(mem, bs)
-            lr.refresh_fused_params(mem)
         else:
             lr.prepare_buffer_update(mem, bs)
         if not getattr(self, "_fixed_idx", False):
             self._new_indices()
+        if fused:
+            lr.refresh_fused_params(mem, self.idx)
         if mem.use_advnorm:
             ops.adv_stats(f.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs, self.horizon_size, lr.stats)
         step = lr.enqueue_minibatch_fused if fused else lr.enqueue_minibatch_from_buffer
@@ -273,6 +274,7 @@ class PPO_Agent:
         fused = lr.fused_eligible(mem)
         if fused:
             lr.prepare_fused(mem, bs)
+            lr.prepare_rows(self.idx.numel())
         else:
             lr.prepare_buffer_update(mem, bs)
         step = lr.enqueue_minibatch_fused if fused else lr.enqueue_minibatch_from_buffer
@@ -288,7 +290,7 @@ class PPO_Agent:
                         ops.adv_stats(mem.soa.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs,
                                       self.horizon_size, lr.stats)
                     if k == 0 and fused:
-                        lr.refresh_fused_params(mem)
+                        lr.refresh_fused_params(mem, self.idx)
                     step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None, finish=False)
                 self._mb_graphs.append(g)
             g = ops.Graph()
@@ -307,6 +309,7 @@ class PPO_Agent:
             if self._update_graph is None:
                 if self.learner.fused_eligible(self.memory):
                     self.learner.prepare_fused(self.memory, self.batch_size)
+                    self.learner.prepare_rows(self.idx.numel())
                 else:
                     self.learner.prepare_buffer_update(self.memory, self.batch_size)
                 torch.cuda.synchronize()

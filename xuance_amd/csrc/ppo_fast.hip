@@ -74,15 +74,19 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     // ~350 cycles of L2 latency), so the two 128 KB streams take as long as all the matrix-core work of the tile and must
     // flow from the first cycle; the gather (a dependent chain index -> record) would queue behind them in every wave, so
     // ONE wave (7) does it for all 32 rows before starting its own share of the streams and hands the rows over in LDS.
-    float4 pf[PD], pt[PD];                              // B fragments: forward tile `wave` | backward tile wave / 2, half wave & 1
+    float4 pf[PD];                                      // B fragments of W1: output tile `wave` (rows 32 w .. 32 w + 31), all 16 k-chunks
     if (wave == 7) {
         const int m = m0 + (lane & 31);
-        int64_t fl = 0;
-        if (m < M && lane < FT) fl = p.idx[m];
-        const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);   // (env, t) = divmod(idx, T); field[t][env]
-        const size_t src = (size_t)t * p.n_envs + env;
         float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && lane < FT) {
+        if (p.f_rows) {                                                 // records gathered for the whole update phase
+            if (m < M && lane < FT) {
+                const float4* rec = reinterpret_cast<const float4*>(p.f_rows) + (size_t)m * 2;
+                xr = rec[0]; sc = rec[1];
+            }
+        } else if (m < M && lane < FT) {
+            const int64_t fl = p.idx[m];
+            const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);   // (env, t) = divmod(idx, T); field[t][env]
+            const size_t src = (size_t)t * p.n_envs + env;
             if (p.f_packed) {                                           // one 32-byte record per row
                 const float4* rec = reinterpret_cast<const float4*>(p.f_packed) + src * 2;
                 xr = rec[0]; sc = rec[1];
@@ -93,31 +97,26 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
         }
         if (lane < FT) { *reinterpret_cast<float4*>(xs + lane * 4) = xr; *reinterpret_cast<float4*>(rsc + lane * 4) = sc; }
     }
-    // forward stream now; the backward stream in two halves later (PT_LOAD): a CU keeps only ~64 wave-loads in flight and
-    // a wave that cannot issue cannot compute either, so no phase may queue more than that
-    const float4* ft = nullptr;
-    const float* trow = nullptr;
+    // small loads first: the parameter image (first layer, biases, heads: 6.7 KB, handed over through LDS) and the
+    // advantage statistics must not queue behind the stream in this wave's in-order vmcnt
+    float st_mean = 0.f, st_std = 1.f;
+    if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
+    float4 imgv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < PI_FLOATS / 4) imgv = *reinterpret_cast<const float4*>(img + tid * 4);
+    // ONE weight stream per workgroup: backward-data needs W1 transposed, and the per-CU stream rate (~10 B/clk) makes a
+    // second 128 KB stream as expensive as all the matrix-core work of the tile; the forward fragments stay in registers
+    // and are transposed through LDS instead (128 B/clk) when the backward pass needs them.
     if (p.frag_image) {
         const float4* fr = reinterpret_cast<const float4*>(p.frag_image) + (size_t)wave * (PH / 8) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < PD; ++q) pf[q] = fr[frag_slot(q, wave, PH / 8, 1) * 64];
-        ft = reinterpret_cast<const float4*>(p.frag_image + 2 * PH * PH) + (size_t)(wave >> 1) * (2 * PH / 8) * 64 + lane;
     } else {
         const float* wrow = p.params + L1.w_off + (size_t)(wave * 32 + li) * PH + 4 * lh;
 #pragma unroll
         for (int q = 0; q < PD; ++q) pf[q] = *reinterpret_cast<const float4*>(wrow + q * 8);
-        trow = p.params_t + L1.w_off + (size_t)((wave >> 1) * 32 + li) * (2 * PH) + 4 * lh;
     }
-#define PT_LOAD(i0, i1)                                                                                               \
-    do {                                                                                                              \
-        if (ft) { _Pragma("unroll") for (int i = i0; i < i1; ++i) pt[i] = ft[frag_slot((wave & 1) + 2 * i, wave >> 1, 2 * PH / 8, 2) * 64]; } \
-        else { _Pragma("unroll") for (int i = i0; i < i1; ++i) pt[i] = *reinterpret_cast<const float4*>(trow + ((wave & 1) + 2 * i) * 8); }      \
-    } while (0)
-    float st_mean = 0.f, st_std = 1.f;
-    if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
-    // the small parameters (first layer, biases, heads: 6.7 KB) go through LDS: both streams are live in registers, so
-    // there is no room to park them there until they are needed
-    if (tid < PI_FLOATS / 4) *reinterpret_cast<float4*>(pimg + tid * 4) = *reinterpret_cast<const float4*>(img + tid * 4);
+    // (vmcnt retires in order: the image was LOADED before the stream so that it can be stored without waiting for it)
+    if (tid < PI_FLOATS / 4) *reinterpret_cast<float4*>(pimg + tid * 4) = imgv;
     lds_barrier();                                                                                   // #0 gathered rows
     QSTAMP(9);
     const float4 xrow = *reinterpret_cast<const float4*>(xs + r * 4);
@@ -148,7 +147,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     lds_barrier();                                                                                   // #1 h1
     QSTAMP(1);
     // ---- branch layer 128 -> 256 on the matrix cores: wave w owns output columns [32 w, 32 w + 32)
-    PT_LOAD(0, 4);
     {
         const float* arow = h1 + li * PLD1 + 4 * lh;
         f32x16 acc;
@@ -161,7 +159,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
             for (int q = 0; q < PD / 2; ++q) af[q] = *reinterpret_cast<const float4*>(arow + (hq * 8 + q) * 8);
 #pragma unroll
             for (int q = 0; q < PD / 2; ++q) { MFMA4(af[q], pf[hq * 8 + q], acc) }
-            if (hq == 0) PT_LOAD(4, 8);
         }
         const int col = wave * 32 + li;
         const float bm = pimg[PI_BM + col];             // branch-layer bias of this lane's output column
@@ -174,7 +171,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     lds_barrier();                                                                                   // #2 h2
     QSTAMP(2);
 
-    PT_LOAD(8, 12);
     // ================= heads forward (VALU, 16 threads per row), loss, heads backward -- all in registers
     // k-chunks q = sub + 16 i; i = 0,1 lie in the actor half (rows 0,1 of the merged head), i = 2,3 in the critic half
     float4 a[4], wa[2][2], wc[2];
@@ -258,7 +254,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
         c.w = (dz2 * wc[i].w) * act_grad_c<ACT>(a[i + 2].w);
         *reinterpret_cast<float4*>(g2 + r * PLD2 + 4 * (sub + 16 * (i + 2))) = c;
     }
-    PT_LOAD(12, 16);
     lds_barrier();                                                                                   // #3 g2, dzh, rowstat
     QSTAMP(3);
 
@@ -324,17 +319,52 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
             }
     }
     QSTAMP(5);
-    // ---- dH1 = g2 . W1 on the transposed stream: tile = wave / 2, k-half = wave & 1, partial tiles meet in `red`
+    // ---- dH1 = g2 . W1: output tile kt = wave / 2 (columns 32 kt ..), n-half = wave & 1 (chunks q = half, half + 2, ..),
+    //      partial tiles meet in `red`.  The B operand W1^T comes from the forward fragments, transposed through LDS in four
+    //      stages of 64 rows of W1 (stage j = W1[64 j .. 64 j + 63][0 .. 127] stored as T[k][n], 4-float groups
+    //      XOR-swizzled by k so that the scalar writes and the float4 reads both spread over the banks); waves 2j, 2j+1 own
+    //      those rows.  Two stage buffers: the (dead) h2 region and the not-yet-used partial-tile region.
     {
+        const int kt = wave >> 1, half = wave & 1;
         const float* arow = g2 + li * PLD2 + 4 * lh;
-        float4 af[PD];
-#pragma unroll
-        for (int i = 0; i < PD; ++i) af[i] = *reinterpret_cast<const float4*>(arow + ((wave & 1) + 2 * i) * 8);
+        const int k_out = kt * 32 + li;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < PD; ++i) { MFMA4(af[i], pt[i], acc) }
+        for (int jp = 0; jp < 2; ++jp) {                                // stages 2 jp (buffer h2) and 2 jp + 1 (buffer red)
+            lds_barrier();                                              // buffers free (first: h2 no longer read)
+            if ((wave >> 2) == jp) {                                    // waves 4 jp .. 4 jp + 3 own rows 128 jp .. 128 jp + 127
+                float* T = ((wave >> 1) & 1) ? red : h2;
+                const int nl = 32 * (wave & 1) + li;                    // row of this lane inside its stage
+#pragma unroll
+                for (int qq = 0; qq < PD; ++qq) {
+                    const float v4[4] = {pf[qq].x, pf[qq].y, pf[qq].z, pf[qq].w};
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int k = 8 * qq + 4 * lh + s4;
+                        T[k * 64 + ((((nl >> 2) ^ (k & 15)) << 2) | (nl & 3))] = v4[s4];
+                    }
+                }
+            }
+            lds_barrier();                                              // stages visible
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float* T = jj ? red : h2;
+                const int j = 2 * jp + jj;
+                float4 af[4], bt[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = 8 * j + half + 2 * i;                 // n-chunk (of 8) consumed by this wave, ascending
+                    af[i] = *reinterpret_cast<const float4*>(arow + q * 8);
+                    const int g = 2 * (half + 2 * i) + lh;              // 4-float group of n inside the stage
+                    bt[i] = *reinterpret_cast<const float4*>(T + k_out * 64 + ((g ^ (k_out & 15)) << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { MFMA4(af[i], bt[i], acc) }
+            }
+        }
+        lds_barrier();                                                  // stage buffer `red` consumed: partial tiles may land
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
@@ -377,7 +407,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     }
 #endif
 #undef QSTAMP
-#undef PT_LOAD
 }
 
 extern bool g_fast_enabled_ppo;

@@ -375,6 +375,16 @@ __global__ void __launch_bounds__(256) pack_transitions_kernel(const float4* __r
     }
 }
 
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float4* __restrict__ packed, const int64_t* __restrict__ idx,
+                                                          float4* __restrict__ out, int64_t count, int n_envs, int T) {
+    // two threads per record (one float4 each)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t fl = idx[i >> 1];
+        const int env = (int)(fl / T), t = (int)(fl - (int64_t)env * T);
+        out[i] = packed[2 * ((size_t)t * n_envs + env) + (i & 1)];
+    }
+}
+
 static size_t ppo_fused_lds_bytes(const xrl_ppo_fused_t& p) {
     size_t floats = 0;
     for (int l = 1; l < p.n_levels; ++l) floats += 2 * (size_t)FT * level_ld(p.level_width[l]);
@@ -432,6 +442,18 @@ extern "C" int xrl_pack_transitions(const float* f_obs, const float* f_act, cons
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(pack_transitions_kernel, dim3(nb), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(f_obs), f_act, f_ret, f_adv, f_logp, reinterpret_cast<float4*>(packed), count);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_gather_rows(const float* packed, const int64_t* idx, float* out, int64_t count, int n_envs, int T,
+                               xrl_stream_t stream) {
+    XRL_CHECK_ARG(packed && idx && out && count > 0 && n_envs > 0 && T > 0);
+    XRL_CHECK_ARG(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    int nb = (int)((2 * count + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(packed), idx,
+                       reinterpret_cast<float4*>(out), count, n_envs, T);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -157,7 +157,12 @@ class PPO_Learner(Learner):
         self.packed = torch.zeros(memory.n_size * memory.n_envs * 8, device=dev)   # transition records the kernel gathers
         self._mirror = True
 
-    def refresh_fused_params(self, memory=None):
+    def prepare_rows(self, count):
+        """Allocate the gathered-record staging of an update phase (outside graph capture)."""
+        if getattr(self, "rows", None) is None or self.rows.numel() != count * 8:
+            self.rows = torch.zeros(count * 8, device=self.model.params.device)
+
+    def refresh_fused_params(self, memory=None, idx_all=None):
         """Derived parameter layouts the fused kernel reads (transposed middle weights, packed small parameters); with
         `memory`, also the packed transition records of the finished rollout (once per update phase)."""
         if memory is not None:
@@ -165,6 +170,13 @@ class PPO_Learner(Learner):
             ops.pack_transitions(f["observations"], f["actions"], f["returns"], f["advantages"], f["aux_old_logp"],
                                  self.packed, memory.n_size * memory.n_envs)
             self._packed_valid = True
+            self._rows_idx = None
+            if idx_all is not None:
+                # every minibatch of the phase gathered now: the minibatch kernel's first load is then a contiguous read
+                # that needs neither the index nor a second dependent hop
+                self.prepare_rows(idx_all.numel())
+                ops.gather_rows(self.packed, idx_all, self.rows, idx_all.numel(), memory.n_envs, memory.n_size)
+                self._rows_idx = idx_all
         ops.transpose_mid(self.model.plan, self.model.params.flat, self.params_t)
         ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)
         if self.frag is not None:
@@ -174,10 +186,16 @@ class PPO_Learner(Learner):
         """One launch for gather + forward + loss + backward, then reduce + Adam, then refresh the derived layouts."""
         m, opt, f = self.model, self.optimizer, memory.soa.fields
         M = idx.numel()
+        rows = None
+        base = getattr(self, "_rows_idx", None)
+        if base is not None:                               # `idx` is a row of the index matrix the records were gathered for
+            off = (idx.data_ptr() - base.data_ptr()) // 8
+            if 0 <= off and off + M <= base.numel() and idx.is_contiguous():
+                rows = self.rows[off * 8:(off + M) * 8]
         ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=self.params_t, cache_image=self.cache_image,
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs, frag_image=self.frag,
-                                f_packed=self.packed if getattr(self, "_packed_valid", False) else None,
+                                f_packed=self.packed if getattr(self, "_packed_valid", False) else None, f_rows=rows,
                                 partials=self.fpartials, diag=self.diag if self.keep_diag else None,
                                 slab_stride=m.params.P, M=M, n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim,
                                 clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)

@@ -156,6 +156,10 @@ def pack_transitions(f_obs, f_act, f_ret, f_adv, f_logp, packed, count):
          stream_ptr())
 
 
+def gather_rows(packed, idx, out, count, n_envs, T):
+    call("xrl_gather_rows", ptr(packed), ptr(idx), ptr(out), int(count), int(n_envs), int(T), stream_ptr())
+
+
 def mid_frag_floats(plan):
     """2*N*K of the first middle layer when it has a fragment-ordered form (multiples of 32), else 0."""
     mids = [L for st in plan.stages[1:-1] for L in st]
