@@ -106,14 +106,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     // ONE weight stream per workgroup: backward-data needs W1 transposed, and the per-CU stream rate (~10 B/clk) makes a
     // second 128 KB stream as expensive as all the matrix-core work of the tile; the forward fragments stay in registers
     // and are transposed through LDS instead (128 B/clk) when the backward pass needs them.
-    if (p.frag_image) {
-        const float4* fr = reinterpret_cast<const float4*>(p.frag_image) + (size_t)wave * (PH / 8) * 64 + lane;
+    {
+        // one load instruction per chunk whatever the source layout (two code paths assigning pf[] make hipcc split every
+        // 16-byte load into four 4-byte ones: 4x the instructions and 4x the L1 traffic)
+        const bool fo = p.frag_image != nullptr;
+        const float* base = fo ? p.frag_image + ((size_t)wave * (PH / 8) * 64 + lane) * 4
+                               : p.params + L1.w_off + (size_t)(wave * 32 + li) * PH + 4 * lh;
 #pragma unroll
-        for (int q = 0; q < PD; ++q) pf[q] = fr[frag_slot(q, wave, PH / 8, 1) * 64];
-    } else {
-        const float* wrow = p.params + L1.w_off + (size_t)(wave * 32 + li) * PH + 4 * lh;
-#pragma unroll
-        for (int q = 0; q < PD; ++q) pf[q] = *reinterpret_cast<const float4*>(wrow + q * 8);
+        for (int q = 0; q < PD; ++q)
+            pf[q] = *reinterpret_cast<const float4*>(base + (fo ? frag_slot(q, wave, PH / 8, 1) * 256 : q * 8));
     }
     // (vmcnt retires in order: the image was LOADED before the stream so that it can be stored without waiting for it)
     if (tid < PI_FLOATS / 4) *reinterpret_cast<float4*>(pimg + tid * 4) = imgv;
