@@ -328,6 +328,33 @@ def test_specialised_minibatch_kernel_is_bit_identical_to_any_shape_kernel(act, 
         assert np.array_equal(a[key], c[key]), key + " (pre-gathered rows)"
 
 
+def test_fused_reduce_adam_is_bit_identical_to_the_two_launches():
+    """xrl_reduce_adam (slab reduction + clip + Adam + mirrors behind a counter barrier) vs xrl_grad_reduce followed by
+    xrl_adam_step_mirrors: parameters, moments, clipped gradient and schedule state after whole update phases."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    res = []
+    for fused_opt in (False, True):
+        torch.manual_seed(0)
+        agent = PPO_Agent(make_config(64, 32, n_epochs=2, n_minibatch=2, use_fused_optimizer=fused_opt),
+                          DeviceCartPoleVecEnv(64, seed=5))
+        for _ in range(2):
+            agent.rollout()
+            info = agent.update()
+        torch.cuda.synchronize()
+        lr, opt = agent.learner, agent.learner.optimizer
+        st = opt.read()
+        if fused_opt:
+            assert lr.opt_sync.tolist()[:3] == [0, 0, 0]          # barrier reset itself, no time-out
+        res.append(dict(p=npy(agent.model.params.flat), m=npy(opt.m), v=npy(opt.v), g=npy(opt.grad), frag=npy(lr.frag),
+                        img=npy(lr.cache_image), sched=np.array([st.step, st.sched_steps, st.last_lr, st.last_grad_norm]),
+                        info=np.array([info[k] for k in sorted(info)])))
+    a, b = res
+    assert a["sched"][0] == 8
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_adam_mirrors_keep_every_derived_layout_current():
     """After full update phases the transposed / packed / fragment-ordered copies equal a fresh re-pack of the parameters."""
     from xuance_amd import ops

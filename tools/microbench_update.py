@@ -63,3 +63,6 @@ for Msub in (256, 1024, 2048, 4096, 8192):
                                 diag=None, slab_stride=m.params.P, M=Msub, n_envs=n, T=256, D=4, A=2, clip_range=0.2,
                                 vf_coef=0.25, ent_coef=0.01, frag_image=lr.frag, f_packed=lr.packed)
     print("   specialised kernel with M = %5d rows (%3d workgroups): %.2f us" % (Msub, Msub // 32, timed(mbs)))
+
+clip = lr.grad_clip_norm if lr.use_grad_clip else 0.0
+print("reduce + adam fused (1 launch)       : %.2f us" % timed(lambda: ops.reduce_adam(lr.fslabs, lr.n_tiles, m.params.P, m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state, lr.sumsq, clip, lr._mirrors, lr.opt_sync)))

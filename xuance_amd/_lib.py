@@ -187,6 +187,8 @@ _SIGS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "xrl_adam_step_mirrors": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double,
                               C.POINTER(Mirrors), c_void_p],
+    "xrl_reduce_adam": [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                        c_double, C.POINTER(Mirrors), c_void_p, c_void_p],
     "xrl_graph_begin": [c_void_p],
     "xrl_graph_end": [c_void_p, C.POINTER(c_void_p)],
     "xrl_graph_launch": [c_void_p, c_void_p],

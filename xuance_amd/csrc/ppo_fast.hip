@@ -321,10 +321,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     }
     QSTAMP(5);
     // ---- dH1 = g2 . W1: output tile kt = wave / 2 (columns 32 kt ..), n-half = wave & 1 (chunks q = half, half + 2, ..),
-    //      partial tiles meet in `red`.  The B operand W1^T comes from the forward fragments, transposed through LDS in four
-    //      stages of 64 rows of W1 (stage j = W1[64 j .. 64 j + 63][0 .. 127] stored as T[k][n], 4-float groups
-    //      XOR-swizzled by k so that the scalar writes and the float4 reads both spread over the banks); waves 2j, 2j+1 own
-    //      those rows.  Two stage buffers: the (dead) h2 region and the not-yet-used partial-tile region.
+    //      partial tiles meet in `red`.  The B operand (W1 with the reduction index n on the MFMA's k axis) comes from the
+    //      forward fragments through LDS in four stages of 64 rows of W1: stage j = T[n - 64 j][k], written as the float4s
+    //      the fragments already are (4-float groups XOR-swizzled by the row so that rows do not collide) and read back as
+    //      the four scalars of an MFMA4 (lanes = consecutive k: conflict-free).  Waves 2j, 2j+1 own the rows of stage j.
+    //      Two stage buffers: the (dead) h2 region and the not-yet-used partial-tile region.
     {
         const int kt = wave >> 1, half = wave & 1;
         const float* arow = g2 + li * PLD2 + 4 * lh;
@@ -339,14 +340,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
                 float* T = ((wave >> 1) & 1) ? red : h2;
                 const int nl = 32 * (wave & 1) + li;                    // row of this lane inside its stage
 #pragma unroll
-                for (int qq = 0; qq < PD; ++qq) {
-                    const float v4[4] = {pf[qq].x, pf[qq].y, pf[qq].z, pf[qq].w};
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const int k = 8 * qq + 4 * lh + s4;
-                        T[k * 64 + ((((nl >> 2) ^ (k & 15)) << 2) | (nl & 3))] = v4[s4];
-                    }
-                }
+                for (int qq = 0; qq < PD; ++qq)                         // W1[n][8 qq + 4 lh .. + 3] -> group 2 qq + lh of row nl
+                    *reinterpret_cast<float4*>(T + nl * 128 + ((((2 * qq + lh) ^ (nl & 31))) << 2)) = pf[qq];
             }
             lds_barrier();                                              // stages visible
 #pragma unroll
@@ -358,8 +353,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
                 for (int i = 0; i < 4; ++i) {
                     const int q = 8 * j + half + 2 * i;                 // n-chunk (of 8) consumed by this wave, ascending
                     af[i] = *reinterpret_cast<const float4*>(arow + q * 8);
-                    const int g = 2 * (half + 2 * i) + lh;              // 4-float group of n inside the stage
-                    bt[i] = *reinterpret_cast<const float4*>(T + k_out * 64 + ((g ^ (k_out & 15)) << 2));
+                    const int n0 = 8 * (half + 2 * i) + 4 * lh;         // rows n0 .. n0 + 3 of the stage
+                    float bs[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int nr = n0 + s4;
+                        bs[s4] = T[nr * 128 + ((((k_out >> 2) ^ (nr & 31)) << 2) | (k_out & 3))];
+                    }
+                    bt[i] = make_float4(bs[0], bs[1], bs[2], bs[3]);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { MFMA4(af[i], bt[i], acc) }

@@ -146,6 +146,7 @@ class PPO_Learner(Learner):
         self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
         self.stats = torch.zeros(4096, 2, device=dev)
         self.sumsq = torch.zeros(256, dtype=torch.float64, device=dev)
+        self.opt_sync = torch.zeros(4, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
         self._fused_bs = bs
         self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
         self._mirrors = [(self.map_t, self.params_t), (self.map_img, self.cache_image)]
@@ -199,10 +200,17 @@ class PPO_Learner(Learner):
                                 partials=self.fpartials, diag=self.diag if self.keep_diag else None,
                                 slab_stride=m.params.P, M=M, n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim,
                                 clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
-        ops.grad_reduce(self.fslabs, self.n_tiles, m.params.P, m.params.P, opt.grad, self.sumsq)
         self._last_S, self._last_partials = self.n_tiles, self.fpartials
+        dist = self.distributed_training and self.world_size > 1
+        if finish and not dist and m.params.P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
+            # slab reduction + clip + Adam + derived layouts in ONE launch (xrl_reduce_adam)
+            clip = self.grad_clip_norm if self.use_grad_clip else 0.0
+            ops.reduce_adam(self.fslabs, self.n_tiles, m.params.P, m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state,
+                            self.sumsq, clip, self._mirrors, self.opt_sync)
+            return
+        ops.grad_reduce(self.fslabs, self.n_tiles, m.params.P, m.params.P, opt.grad, self.sumsq)
         if finish:
-            if self.distributed_training and self.world_size > 1:
+            if dist:
                 self.allreduce_grad()
             self.finish_step()
 
