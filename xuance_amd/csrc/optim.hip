@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
 // parameters [256 b, 256 b + 256) in both phases, keeps the reduced gradient on chip, publishes its sum of squares with a
 // device-scope store and meets the other blocks at a counter barrier (relaxed atomics; all blocks are resident: one
 // 256-thread block per 256 parameters).  Saves a kernel boundary, the argument fetch + first round trip of the second
-// launch and the re-read of the gradient.  sync[0] arrivals, sync[1] departures (self-resetting), sync[2] time-out flag.
+// launch and the re-read of the gradient.  sync[1] departures (self-resetting), sync[2] time-out flag, sync[4 + b] arrival flag of block b.
 constexpr int RA_GROUPS = 1;                      // 256-thread groups per block (measured: 4 groups = 4x fewer barrier participants but the 35 MB slab read then rides on 34 CUs: 22.8 vs 15.8 us)
 constexpr int RA_THREADS = RED_THREADS * RA_GROUPS;
 
@@ -206,16 +206,26 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     const int64_t i = (int64_t)vb * RED_THREADS + tg;
     float p0 = 0.f, m0 = 0.f, v0 = 0.f;
     if (i < P) { p0 = params[i]; m0 = m[i]; v0 = v[i]; }
+    // ---- barrier without read-modify-write atomics: every block publishes its partial sum, then (after the store has been
+    //      acknowledged) its flag = the optimiser step this launch performs -- a value no earlier launch has written -- and
+    //      polls all flags with one coalesced device-scope load per round.  sync[4 + b] is block b's flag.
     if (tg == 0 && vb < n_vb) __hip_atomic_store(&sumsq_part[vb], tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         s_fail = 0;
-        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync[4 + blockIdx.x], (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    {
         int spins = 0;
-        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        for (;;) {
+            int ok = 1;
+            for (int j = threadIdx.x; j < (int)gridDim.x; j += blockDim.x)
+                ok &= __hip_atomic_load(&sync[4 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)step;
+            if (__syncthreads_and(ok)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > 4000000) { s_fail = 1; __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > 2000000) { if (threadIdx.x == 0) { s_fail = 1; __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } break; }
         }
     }
     __syncthreads();
@@ -246,8 +256,7 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned left = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == gridDim.x - 1) {                            // last block out: reset the barrier, advance the state
-            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == gridDim.x - 1) {                            // last block out: reset the counter, advance the state
             __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             st->last_grad_norm = total_norm;
             st->step = step;

@@ -146,7 +146,7 @@ class PPO_Learner(Learner):
         self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
         self.stats = torch.zeros(4096, 2, device=dev)
         self.sumsq = torch.zeros(256, dtype=torch.float64, device=dev)
-        self.opt_sync = torch.zeros(4, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
+        self.opt_sync = torch.zeros(4 + (P + 255) // 256 + 8, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
         self._fused_bs = bs
         self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
         self._mirrors = [(self.map_t, self.params_t), (self.map_img, self.cache_image)]
