@@ -361,7 +361,7 @@ int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
 typedef struct {
     xrl_rollout_step_t step0;
     float* bootv;               /* [T][n] bootstrap values */
-    uint32_t* barrier;          /* [1] scratch counter (zeroed by the call, on the stream) */
+    uint32_t* barrier;          /* [64] scratch flags (zeroed by the call, on the stream) */
     int32_t* status;            /* [4] zero-initialised by the caller: [0] != 0 -> a barrier timed out, results invalid;
                                  * [1] XCC id of workgroup 0, [2] bit mask of the XCC ids the workgroups ran on */
     int32_t T, pad;

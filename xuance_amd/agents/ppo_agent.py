@@ -191,7 +191,7 @@ class PPO_Agent:
         if list(plan.widths) != [4, 128, 256, 3] or 3 * ((self.n_envs + 31) // 32) > 32 or not ops.fast_kernels_enabled():
             return False
         if getattr(self, "persist_status", None) is None:
-            self.persist_barrier = torch.zeros(16, dtype=torch.int32, device=self.device)
+            self.persist_barrier = torch.zeros(64, dtype=torch.int32, device=self.device)
             self.persist_status = torch.zeros(4, dtype=torch.int32, device=self.device)
         return True
 

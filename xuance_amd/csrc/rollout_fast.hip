@@ -227,9 +227,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_fast_kernel(xrl_ro
                 double a = 0.0, b = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) { a += part[w * 4 + lane]; b += part[NW * 4 + w * 4 + lane]; }
-                const double m = a / n;
+                // n a power of two: scaling by 1/n is the exact same number as the division (and ~400 cycles shorter)
+                const bool pow2 = (n & (n - 1)) == 0;
+                const double inv_n = 1.0 / (double)n;
+                const double m = pow2 ? a * inv_n : a / n;
                 const float bmean = (float)m;                 // np.mean -> float32
-                const float bstd = (float)sqrt(fmax(b / n - m * m, 0.0));
+                const float bstd = (float)sqrt(fmax((pow2 ? b * inv_n : b / n) - m * m, 0.0));
                 const float bv = bstd * bstd;                 // batch_var = np.square(batch_std)
                 const double cnt = st_cnt, tot = cnt + (double)n;
                 const float delta = bmean - st_mean;          // update_from_moments (statistic_tools.py:173-185)
