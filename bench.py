@@ -41,7 +41,7 @@ def make_config(n_envs, horizon, world, rank):
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, FETCH_SIZE doubled
     per MI355X_MICROARCH.md); None if the summary is not there.  PMC counters cannot be read from inside the process."""
-    path = os.path.join(ROOT, "profiles", "r01_e_ppo_c2_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_ppo_c2_pmc_hbm.json")
     try:
         with open(path) as f:
             ks = json.load(f)["kernels"]
@@ -89,11 +89,13 @@ def kernel_rooflines(agent):
           "traffic": _pmc_traffic(name), "avg_launch_us": round(us_launch, 3), "algorithmic_flops_per_launch": fl_launch,
           "note": "latency-bound: %d rows x %.0f flop per launch (%s); see DESIGN.md section 3"
                   % (rows, fwd_flops_row, "%d vector steps of 2 x %d rows" % (T + 1, n) if persistent else "one vector step")}
-    # (2) fused minibatch kernel
+    # (2) fused minibatch kernel, timed INSIDE the real minibatch sequence: (graph of nb x [minibatch kernel, optimiser
+    #     launch]) minus (graph of nb x [optimiser launch]), per minibatch.  Timed alone, back to back, the kernel
+    #     re-reads parameters that are still in L2 and comes out ~10 % faster than what rocprofv3 sees in the loop.
     f = mem.soa.fields
-    k = agent.idx.shape[0] - 1
+    nb = agent.idx.shape[0]
 
-    def mb():
+    def mb(k):
         ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=lr.params_t, cache_image=lr.cache_image,
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=agent.idx[k], stats=lr.stats[k], slabs=lr.fslabs,
@@ -101,9 +103,22 @@ def kernel_rooflines(agent):
                                 frag_image=lr.frag, f_packed=lr.packed, f_rows=lr.rows[k * bs * 8:(k + 1) * bs * 8],
                                 A=m.action_dim, clip_range=lr.clip_range, vf_coef=lr.vf_coef, ent_coef=lr.ent_coef)
     r2 = None
-    if lr.fused_eligible(mem):
-        mb()
-        us_mb = _event_time_us(mb, 50)
+    if lr.fused_eligible(mem) and getattr(lr, "rows", None) is not None and getattr(lr, "opt_sync", None) is not None:
+        clip = lr.grad_clip_norm if lr.use_grad_clip else 0.0
+        opt = lr.optimizer
+        def ra():
+            ops.reduce_adam(lr.fslabs, lr.n_tiles, m.params.P, m.params.flat, opt.grad, opt.m, opt.v, m.params.P,
+                            opt.state, lr.sumsq, clip, lr._mirrors, lr.opt_sync)
+        g_both, g_opt = ops.Graph(), ops.Graph()           # the real minibatch sequence, and the optimiser launches alone
+        torch.cuda.synchronize()
+        with g_both:
+            for k in range(nb):
+                mb(k); ra()
+        with g_opt:
+            for k in range(nb):
+                ra()
+        g_both.launch(); g_opt.launch()
+        us_mb = (_event_time_us(g_both.launch, 3) - _event_time_us(g_opt.launch, 3)) / nb
         fl_mb = 3.0 * fwd_flops_row * bs
         r2 = {"bound": "mfma", "kernel": "xrl::ppo_fast_kernel", "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -195,7 +210,30 @@ def main():
                       "env": "device-resident CartPole-v1 (xrl_cartpole_step)", "parallelism": "dp%d" % world,
                       "env_steps_per_step": world * args.n_envs * args.horizon,
                       "last_info": {k: round(float(v), 6) for k, v in info.items()}}}
+    # the update-phase rate separately (transitions consumed per second by GAE + sampling + the
+    # minibatch updates), so that the simulator's share is separable.  Timed after the contract region, same graphs.
+    phases = None
+    if world == 1 and not args.no_roofline:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            agent.rollout()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(5):
+            agent.update()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        n_tr = args.n_envs * args.horizon
+        phases = {"rollout_ms": round((t2 - t1) / 5 * 1e3, 4), "update_ms": round((t3 - t2) / 5 * 1e3, 4),
+                  "rollout_env_steps_per_s": round(n_tr * 5 / (t2 - t1), 1),
+                  "update_transitions_per_s": round(n_tr * 5 / (t3 - t2), 1),
+                  "update_sample_passes_per_s": round(n_tr * 8 * 5 / (t3 - t2), 1),
+                  "note": "rollout = %d vector steps incl. GAE; update = 8 epochs x 8 minibatches over the same %d transitions"
+                          % (args.horizon, n_tr)}
     if rank == 0:
+        if phases is not None:
+            out["phases"] = phases
         if not args.no_roofline:
             out["roofline"], second = kernel_rooflines(agent)
             if second is not None:
