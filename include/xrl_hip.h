@@ -294,6 +294,12 @@ int xrl_marl_select_actions(const xrl_marl_act_t* p, xrl_stream_t stream);
 int xrl_random_permutation(int64_t* out, int n_perm, int64_t N, int64_t take, uint64_t seed, uint32_t counter,
                            const uint32_t* counter_dev, xrl_stream_t stream);
 
+/* out[b] = env_b * n_size + step_b with env_b ~ U{0..n_envs-1}, step_b ~ U{0..*size_dev-1}: uniform replay sampling with
+ * replacement (memory_tools.py:376-377, memory_tools_marl.py:753-754) on the device; *size_dev is the number of valid
+ * ring rows, read at run time so a captured graph follows the filling buffer.  Keyed by (seed, counter + *counter_dev). */
+int xrl_sample_replay_indices(int64_t* out, int bs, int n_envs, int n_size, const int32_t* size_dev, uint64_t seed,
+                              uint32_t counter, const uint32_t* counter_dev, xrl_stream_t stream);
+
 /* *counter += inc on the stream (advances RNG step counters between replays of a captured rollout). */
 int xrl_counter_add(uint32_t* counter, uint32_t inc, xrl_stream_t stream);
 

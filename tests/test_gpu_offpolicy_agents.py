@@ -161,3 +161,46 @@ def test_dqn_agent_on_atari_shape():
     # the frames written to the ring are the frames the env produced (last stored step)
     t = (agent.memory.ptr - 1) % agent.memory.n_size
     assert torch.equal(agent.memory.soa.fields["next_observations"][t], env.next_obs)
+
+
+def test_qmix_graph_update_phase_equals_eager_updates_on_the_same_indices():
+    """QMIX_Learner.update_from_buffer (device sampling + gather + update, n_epochs per hipGraph launch) vs
+    update(memory.sample(indexes)) with the indices the sampling kernel draws: identical parameters and losses."""
+    from xuance_amd import ops
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    cfg = dict(representation_hidden_size=[64], q_hidden_size=[64], hidden_dim_mixing_net=32, hidden_dim_hyper_net=32,
+               activation="relu", seed=1, parallels=16, running_steps=10 ** 6, buffer_size=16 * 40, batch_size=32,
+               learning_rate=7e-4, gamma=0.99, double_q=True, start_greedy=1.0, end_greedy=0.05, decay_step_greedy=50000,
+               sync_frequency=5, training_frequency=1, start_training=10 ** 9, n_epochs=4, use_grad_clip=True,
+               grad_clip_norm=10.0, use_actions_mask=True, use_parameter_sharing=True, use_rnn=False,
+               distributed_training=False, device="cuda", model_dir="/tmp/x")
+    res = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        agent = QMIX_Agents(Namespace(**cfg), SyntheticSMACVecEnv(16, seed=3))
+        agent.train(25)                                       # fills 25 ring rows, no updates (start_training is far away)
+        lr, mem = agent.learner, agent.memory
+        assert mem.size == 25 and int(mem.size_dev.item()) == 25
+        infos = []
+        if graph:
+            for _ in range(3):                                # first call eager + capture, then two graph launches
+                infos.append(lr.update_from_buffer(mem, 4, seed=7))
+            assert lr._buf_graph is not None
+        else:
+            idx = torch.zeros(32, dtype=torch.int64, device="cuda")
+            ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for _ in range(3):
+                for e in range(4):
+                    ops.sample_replay_indices(idx, mem.n_envs, mem.n_size, mem.size_dev, 7, 0, ctr)
+                    ops.counter_add(ctr, 1)
+                    assert int(idx.max()) < 16 * mem.n_size and int((idx % mem.n_size).max()) < 25
+                    info = lr.update(mem.sample(indexes=idx.clone()))
+                infos.append(info)
+        torch.cuda.synchronize()
+        assert lr.iterations == 12
+        res.append((agent.model.params.flat.cpu().numpy().copy(), agent.model.target_flat.cpu().numpy().copy(),
+                    np.array([[i["loss_Q"], i["predictQ"]] for i in infos])))
+    (pa, ta, ia), (pb, tb, ib) = res
+    assert np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(ia, ib)

@@ -169,6 +169,7 @@ _SIGS = {
     "xrl_counter_add": [c_void_p, C.c_uint32, c_void_p],
     "xrl_set_fast_kernels": [C.c_int],
     "xrl_rollout_cartpole_persistent": [C.POINTER(RolloutPersist), c_void_p],
+    "xrl_sample_replay_indices": [c_void_p, c_int, c_int, c_int, c_void_p, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
     "xrl_random_permutation": [c_void_p, c_int, c_int64, c_int64, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
     "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],
     "xrl_soa_store_step": [C.POINTER(Field), c_int, c_int, c_int, c_void_p],

@@ -293,14 +293,9 @@ class PPO_Agent:
                         lr.refresh_fused_params(mem, self.idx)
                     step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None, finish=False)
                 self._mb_graphs.append(g)
-            g = ops.Graph()
-            with g:
-                lr.finish_step()
-            self._finish_graph = g
         for k in range(nb):
-            self._mb_graphs[k].launch()
-            lr.allreduce_grad()
-            self._finish_graph.launch()
+            self._mb_graphs[k].launch()                     # gather + forward + loss + backward + slab reduction
+            lr.allreduce_and_finish()                       # RCCL mean of the flat gradient, then norm/clip/Adam in one launch
 
     def update(self):
         if self.learner.distributed_training and self.learner.world_size > 1:

@@ -28,6 +28,7 @@ class QMIX_Agents:
         self.use_actions_mask = _get(config, "use_actions_mask", True)
         self.start_training, self.training_frequency = config.start_training, config.training_frequency
         self.n_epochs = _get(config, "n_epochs", 1)
+        self.use_graph_updates = bool(_get(config, "use_hip_graph", True))   # whole update phases as one hipGraph launch
         self.seed = int(_get(config, "seed", 1))
         self.start_greedy, self.end_greedy = config.start_greedy, config.end_greedy
         self.e_greedy = config.start_greedy
@@ -90,8 +91,11 @@ class QMIX_Agents:
                               terminals=env.terminals, agent_mask=env.agent_mask, state=state, state_next=env.next_state,
                               avail_actions=avail, avail_actions_next=env.next_avail)
             if self.current_step >= self.start_training and self.current_step % self.training_frequency == 0:
-                for _e in range(self.n_epochs):
-                    info = self.learner.update(self.memory.sample())
+                if self.use_graph_updates:
+                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed)
+                else:
+                    for _e in range(self.n_epochs):
+                        info = self.learner.update(self.memory.sample())
             self.current_step += n
             self._update_explore_factor()
         info["epsilon"] = self.e_greedy

@@ -31,6 +31,9 @@ void set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(xrl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// compute units of the current device (cached: hipGetDeviceProperties is far too slow for a per-launch query); 0 on error
+int device_cu_count();
+
 constexpr int WAVE = 64;  // CDNA4 wavefront
 
 // ---- wavefront / block reductions (64-lane shuffles, no LDS for the wave part) ----

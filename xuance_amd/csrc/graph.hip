@@ -3,6 +3,20 @@
 // and replays them with one hipGraphLaunch.  Every xrl_* entry point is capture-safe (no allocation, no sync).
 #include "common.h"
 
+namespace xrl {
+int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cached[dev] = v;
+    }
+    return cached[dev];
+}
+}  // namespace xrl
+
 using namespace xrl;
 
 extern "C" int xrl_graph_begin(xrl_stream_t stream) {

@@ -280,11 +280,7 @@ extern "C" int xrl_reduce_adam(const float* slabs, int n_split, int64_t slab_str
     const int n_vb = (int)((P / 4 + 63) / 64);
     XRL_CHECK_ARG(n_vb <= n_part && n_part <= 1024);
     const int nb = (n_vb + RA_GROUPS - 1) / RA_GROUPS;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    XRL_CHECK_HIP(hipGetDevice(&dev));
-    XRL_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    XRL_CHECK_ARG(nb <= 2 * prop.multiProcessorCount);          // every block resident (the barrier spins)
+    XRL_CHECK_ARG(nb <= 2 * device_cu_count());                 // every block resident (the barrier spins)
     xrl_mirrors_t mir{};
     if (mirrors) mir = *mirrors;
     XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);

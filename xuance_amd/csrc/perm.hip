@@ -42,7 +42,34 @@ __global__ void __launch_bounds__(256) random_permutation_kernel(int64_t* __rest
     }
 }
 
+// Uniform replay sampling with replacement (DummyOffPolicyBuffer.sample, memory_tools.py:376-377; MARL_OffPolicyBuffer
+// .sample, memory_tools_marl.py:753-754): env = choice(n_envs), step = choice(size), flat index env * n_size + step.
+// `size` is read from device memory so that a captured graph follows the filling ring.
+__global__ void __launch_bounds__(256) sample_replay_kernel(int64_t* __restrict__ out, int bs, int n_envs, int n_size,
+                                                            const int32_t* __restrict__ size_dev, uint64_t seed, uint32_t counter,
+                                                            const uint32_t* __restrict__ counter_dev) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= bs) return;
+    const uint32_t ctr = counter + (counter_dev ? *counter_dev : 0u);
+    int size = *size_dev;
+    size = size < 1 ? 1 : (size > n_size ? n_size : size);
+    uint32_t r[4];
+    philox4x32(seed, (uint32_t)b, ctr, 0x53414D50u, r);
+    const int env = (int)(((uint64_t)r[0] * (uint64_t)n_envs) >> 32);        // floor(u * n), u = r / 2^32
+    const int step = (int)(((uint64_t)r[1] * (uint64_t)size) >> 32);
+    out[b] = (int64_t)env * n_size + step;
+}
+
 }  // namespace xrl
+
+extern "C" int xrl_sample_replay_indices(int64_t* out, int bs, int n_envs, int n_size, const int32_t* size_dev, uint64_t seed,
+                                         uint32_t counter, const uint32_t* counter_dev, xrl_stream_t stream) {
+    XRL_CHECK_ARG(out && size_dev && bs > 0 && n_envs > 0 && n_size > 0);
+    hipLaunchKernelGGL(xrl::sample_replay_kernel, dim3((bs + 255) / 256), dim3(256), 0, xrl::as_stream(stream), out, bs, n_envs,
+                       n_size, size_dev, seed, counter, counter_dev);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
 
 extern "C" int xrl_random_permutation(int64_t* out, int n_perm, int64_t N, int64_t take, uint64_t seed, uint32_t counter,
                                       const uint32_t* counter_dev, xrl_stream_t stream) {

@@ -460,11 +460,7 @@ extern "C" int xrl_rollout_cartpole_persistent(const xrl_rollout_persist_t* qq, 
     if (!rollout_fast_eligible(p)) { set_error("xrl_rollout_cartpole_persistent: network is not the 4-128-{128-2,128-1} class"); return XRL_EINVAL; }
     const int n_tiles = (p.n + FT - 1) / FT;
     const int n_wg = 3 * n_tiles;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    XRL_CHECK_HIP(hipGetDevice(&dev));
-    XRL_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    XRL_CHECK_ARG(n_wg <= prop.multiProcessorCount / 8);            // all resident workgroups on ONE XCD, one per CU
+    XRL_CHECK_ARG(n_wg <= device_cu_count() / 8);                   // all resident workgroups on ONE XCD, one per CU
     XRL_CHECK_HIP(hipMemsetAsync(q.barrier, 0, 64 * sizeof(uint32_t), as_stream(stream)));
     XRL_ACT_DISPATCH(p.layers[0].act,
         if (p.n <= 256) hipLaunchKernelGGL((rollout_persistent_kernel<ACT, 4>), dim3(8 * n_wg), dim3(FUSED_THREADS), 0, as_stream(stream), q);

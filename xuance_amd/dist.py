@@ -37,8 +37,11 @@ def allreduce_mean_(flat):
     """In-place mean over ranks of one flat tensor (what DDP does to gradients, as ONE message)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return flat
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(dist.get_world_size())
+    if dist.get_backend() == "nccl":                       # RCCL averages inside the collective: no extra launch
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:                                                  # gloo (CPU tests) has no AVG
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
     return flat
 
 

@@ -82,6 +82,22 @@ class PPO_Learner(Learner):
         allreduce_mean_(opt.grad)
         ops.grad_reduce(opt.grad, 1, P, P, opt.grad, self.sumsq)
 
+    def allreduce_and_finish(self):
+        """Multi-GPU optimiser step: ONE flat RCCL all-reduce (mean) of the gradient, then norm + clip + Adam + derived
+        layouts in ONE launch (xrl_reduce_adam over the averaged gradient as a single slab) when the fused kernels are
+        in use; the generic two-launch sequence otherwise.  Same numbers either way."""
+        from ..dist import allreduce_mean_
+        model, opt, P = self.model, self.optimizer, self.model.params.P
+        allreduce_mean_(opt.grad)
+        if getattr(self, "_mirror", False) and P % 4 == 0 and getattr(self, "opt_sync", None) is not None and \
+                getattr(self.config, "use_fused_optimizer", True):
+            clip = self.grad_clip_norm if self.use_grad_clip else 0.0
+            ops.reduce_adam(opt.grad, 1, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip,
+                            self._mirrors, self.opt_sync)
+        else:
+            ops.grad_reduce(opt.grad, 1, P, P, opt.grad, self.sumsq)
+            self.finish_step()
+
     def finish_step(self):
         """clip_grad_norm_ + Adam.step + LinearLR.step (ppo_learner.py:63-67).  When the fused kernels are in use the
         same launch also refreshes their derived parameter layouts."""

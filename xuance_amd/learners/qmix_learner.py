@@ -114,6 +114,56 @@ class QMIX_Learner(Learner):
                       self.grad_clip_norm if self.use_grad_clip else 0.0)                         # qmix_learner.py:88-96
         ops.sync_target(m.params.flat, m.target_flat, m.params.P, opt.state, self.sync_frequency)  # :105-106
 
+    # ------------------------------------------------------------------ whole update phases straight from the HBM replay buffer
+    def update_from_buffer(self, memory, n_epochs=1, seed=1):
+        """`n_epochs` updates (sample -> gather -> forward / mixer TD / backward -> Adam -> target sync) as ONE captured
+        hipGraph launch: indices are drawn on the device (xrl_sample_replay_indices, following the filling ring through
+        memory.size_dev), the gather writes straight into the staging tensors the networks read, and the loss terms of
+        every update are read back with a single host sync at the end.  Same arithmetic as update(memory.sample())."""
+        B, m, dev = memory.batch_size, self.model, self.model.params.device
+        key = (id(memory), n_epochs, B)
+        if getattr(self, "_buf_graph_key", None) != key:
+            self._ensure(B)
+            R, N = B * m.n_agents, m.n_agents
+            self._idx = torch.zeros(B, dtype=torch.int64, device=dev)
+            self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._epoch_sums = torch.zeros(n_epochs, 8, dtype=torch.float64, device=dev)
+            dst = {"obs": self.X[:R].view(B, -1), "obs_next": self.X[R:2 * R].view(B, -1), "actions": self.buf["actions"][:B],
+                   "rewards": self.buf["rewards"][:B], "terminals": self.buf["terminals"][:B],
+                   "agent_mask": self.buf["agent_mask"][:B], "state": self.states[:B], "state_next": self.states[B:2 * B]}
+            if self.use_actions_mask:
+                dst["avail_actions_next"] = self.buf["avail_next"][:B].view(B, -1)
+
+            def enqueue():
+                for e in range(n_epochs):
+                    ops.sample_replay_indices(self._idx, memory.n_envs, memory.n_size, memory.size_dev, seed, 0, self._sample_counter)
+                    ops.counter_add(self._sample_counter, 1)
+                    memory.gather_into(self._idx, dst)
+                    self._step(B)
+                    ops.sum_partials(self.partials, B, 8, self._epoch_sums[e])
+            self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
+            enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
+            if not (self.distributed_training and self.world_size > 1):
+                torch.cuda.synchronize()                    # ... and is then captured for the following calls (the gradient
+                g = ops.Graph()                             #     all-reduce of the multi-GPU path cannot be captured)
+                with g:
+                    enqueue()
+                self._buf_graph = g
+        elif self._buf_graph is not None:
+            self._buf_graph.launch()
+        else:
+            self._buf_enqueue()
+        sums = self._epoch_sums.cpu().numpy()               # the one host sync of the phase
+        st = self.optimizer.read()
+        info = {}
+        for e in range(n_epochs):
+            self.iterations += 1
+            info = self.callback.on_update_start(self.iterations, model=self.model) or {}
+            info.update({"learning_rate": st.last_lr, "loss_Q": float(sums[e, 0] / B), "predictQ": float(sums[e, 1] / B)})
+            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, q_tot_eval=self.diag[:B],
+                                                    q_tot_next=self.diag[B:2 * B], q_tot_target=self.diag[2 * B:3 * B]) or {})
+        return info
+
     def update(self, sample):
         self.iterations += 1
         B = self.build_training_data(sample)

@@ -46,6 +46,7 @@ class HipMARLOffPolicyBuffer:
         self.soa = _SoA(self.n_size, n_envs, specs, device)
         self.stager = _Stager(n_envs, specs, device)
         self.ptr, self.size = 0, 0
+        self.size_dev = torch.zeros(1, dtype=torch.int32, device=device)   # `size` for sampling kernels inside captured graphs
 
     @property
     def full(self):
@@ -53,6 +54,7 @@ class HipMARLOffPolicyBuffer:
 
     def clear(self):
         self.ptr, self.size = 0, 0
+        self.size_dev.zero_()
         self.soa.zero()
 
     def _stack(self, v):
@@ -70,7 +72,14 @@ class HipMARLOffPolicyBuffer:
         f = self.soa
         ops.soa_store_step([(f.fields[k], step[k], f.row_bytes[k]) for k in step], self.n_envs, self.ptr)
         self.ptr = (self.ptr + 1) % self.n_size
-        self.size = min(self.size + 1, self.n_size)
+        if self.size < self.n_size:
+            self.size += 1
+            self.size_dev.fill_(self.size)
+
+    def gather_into(self, idx, dst):
+        """dst: field name -> device tensor [bs, row] (e.g. a learner's staging views); one launch, no host work."""
+        f = self.soa
+        ops.soa_gather([(dst[k], f.fields[k], f.row_bytes[k]) for k in dst], idx, self.n_envs, self.n_size)
 
     def sample_indices(self, batch_size=None):                # memory_tools_marl.py:753-754
         bs = self.batch_size if batch_size is None else batch_size

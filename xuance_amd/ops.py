@@ -345,6 +345,11 @@ def random_permutation(out, n_perm, N, take, seed, counter=0, counter_dev=None):
 _fast_enabled = True
 
 
+def sample_replay_indices(out, n_envs, n_size, size_dev, seed, counter=0, counter_dev=None):
+    call("xrl_sample_replay_indices", ptr(out), out.numel(), int(n_envs), int(n_size), ptr(size_dev), int(seed), int(counter),
+         ptr(counter_dev), stream_ptr())
+
+
 def set_fast_kernels(enable):
     """Select (default) or bypass the shape-specialised twins of the fused kernels; results are bit-identical."""
     global _fast_enabled
