@@ -159,10 +159,18 @@ class PPO_Agent:
                      ret_final_out=pp["ret_final"][1], obs_slot=f["observations"][0], act_slot=f["actions"][0],
                      val_slot=f["values"][0], logp_slot=f["aux_old_logp"][0], rew_slot=f["rewards"][0],
                      term_slot=f["terminals"][0], seg_slot=f["seg"][0], last_step=0, boot_only=0, step=0)
-        if self._persistent_ok(split_ok):
-            # ONE launch for the whole rollout: resident workgroups, counter barrier between steps (rollout_persist.hip)
-            ops.rollout_cartpole_persistent(plan, T, f["bootv"], self.persist_barrier, self.persist_status, **step0, **common)
-        else:
+        persistent = self._persistent_ok(split_ok)
+        if persistent:
+            # ONE launch for the whole rollout: resident workgroups, flag barrier between steps (rollout_persist.hip).  The
+            # library refuses (before launching anything) when the workgroups cannot all be resident on one XCD, e.g. on a
+            # partitioned device: fall back to one launch per step.
+            try:
+                ops.rollout_cartpole_persistent(plan, T, f["bootv"], self.persist_barrier, self.persist_status, **step0, **common)
+            except ops.XrlError:
+                persistent = False
+                self.persist_status = None
+                self.config.use_persistent_rollout = False
+        if not persistent:
             for t in range(T):
                 i, o = t & 1, (t + 1) & 1
                 ops.rollout_step_cartpole(

@@ -29,6 +29,9 @@ def init_distributed_mode(backend=None):
     return rank, world, local_rank
 
 
+_avg_ok = True
+
+
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
@@ -37,11 +40,15 @@ def allreduce_mean_(flat):
     """In-place mean over ranks of one flat tensor (what DDP does to gradients, as ONE message)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return flat
-    if dist.get_backend() == "nccl":                       # RCCL averages inside the collective: no extra launch
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-    else:                                                  # gloo (CPU tests) has no AVG
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(dist.get_world_size())
+    global _avg_ok
+    if _avg_ok and dist.get_backend() == "nccl":           # RCCL averages inside the collective: no extra launch
+        try:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            return flat
+        except (RuntimeError, ValueError):                 # a build without ncclAvg: fall back for good
+            _avg_ok = False
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)            # gloo (CPU tests) has no AVG
+    flat.div_(dist.get_world_size())
     return flat
 
 

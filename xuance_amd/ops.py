@@ -9,6 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from ._lib import XrlError  # noqa: F401  (re-exported)
 from ._lib import (Mirrors, RolloutPersist, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
