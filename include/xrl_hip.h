@@ -107,6 +107,21 @@ int xrl_linear_bwd_data(const xrl_gemm_t* groups, int n_groups, xrl_stream_t str
 int xrl_linear_bwd_weight(const xrl_gemm_t* groups, int n_groups, int n_split, int64_t slab_stride,
                           xrl_stream_t stream);
 
+/* ------------------------------------------------------------------ convolution stack of the Atari Q-network
+ * (rl_models/representations/cnn.py:11-50, modules/layers.py:36-65) as im2col + the GEMMs above, NHWC end to end:
+ *   y[B*OH*OW][F] = relu(col . W^T + b) with col = im2col(x), column order (c, kh, kw) == the reference weight
+ *   layout [F][C][kh][kw]; OH = (H + 2p - k)/s + 1.  x: uint8 (scaled by /255.0 like cnn.py:45) or float32 NHWC. */
+int xrl_im2col_nhwc(const void* x, int x_is_u8, float* col, int B, int H, int W, int C, int k, int s, int p,
+                    xrl_stream_t stream);
+/* dx[B][H][W][C] = col2im(dcol) (gather form, fixed summation order) * [xact > 0] (xact NULL: no mask) */
+int xrl_col2im_nhwc(const float* dcol, const float* xact, float* dx, int B, int H, int W, int C, int k, int s, int p,
+                    xrl_stream_t stream);
+/* AdaptiveMaxPool2d((1,1)) over the P positions of y[B][P][F] -> feat[B][ld_feat], argmax[B][F] (NULL: not kept);
+ * backward: dy[b][q][f] = dfeat[b][f] if q == argmax[b][f] and y[b][q][f] > 0 (the ReLU in front of the pool) else 0 */
+int xrl_maxpool_hw_fwd(const float* y, float* feat, int32_t* argmax, int B, int P, int F, int ld_feat, xrl_stream_t stream);
+int xrl_maxpool_hw_bwd(const float* dfeat, const int32_t* argmax, const float* y, float* dy, int B, int P, int F, int ld_dfeat,
+                       xrl_stream_t stream);
+
 /* ------------------------------------------------------------------ PPO-clip loss (ppo_learner.py:46-60,70) */
 
 typedef struct {

@@ -14,6 +14,7 @@ from collections import OrderedDict
 from dataclasses import dataclass
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from . import ops
@@ -486,14 +487,94 @@ class MixingQNet:
         self.target_flat.copy_(self.params.flat)
 
 
+class ConvStack:
+    """Conv2d(k, s, pad=(k-s)//2) + ReLU layers followed by AdaptiveMaxPool2d((1,1)) (Basic_CNN, cnn.py:11-50) on the
+    HIP engine: im2col (column order c, kh, kw == the reference weight layout) + the fp32-MFMA GEMMs, NHWC end to end.
+    `Workspace` objects hold the per-pass buffers: one with saved columns for the differentiated pass, scratch ones for
+    the no-gradient passes (target network, double-Q, acting)."""
+
+    class Workspace:
+        def __init__(self, stack, rows, keep):
+            dev = stack.params.device
+            self.rows, self.keep = rows, keep
+            self.col, self.y, self.dy, self.dcol = [], [], [], []
+            for (H, W, C, k, s, p, OH, OW, F) in stack.geo:
+                M, K = rows * OH * OW, C * k * k
+                self.col.append(torch.empty(M, K, device=dev))
+                self.y.append(torch.empty(M, F, device=dev))
+                if keep:
+                    self.dy.append(torch.empty(M, F, device=dev))
+                    self.dcol.append(torch.empty(M, K, device=dev))
+            self.feat = torch.empty(rows, stack.geo[-1][8], device=dev)
+            self.arg = torch.zeros(rows, stack.geo[-1][8], dtype=torch.int32, device=dev) if keep else None
+
+    def __init__(self, params, conv_names, obs_shape, kernels, strides, filters):
+        self.params, self.names = params, list(conv_names)
+        H, W, C = obs_shape
+        self.geo = []
+        for k, s, F in zip(kernels, strides, filters):
+            p = (k - s) // 2                                  # layers.py:46
+            OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            self.geo.append((H, W, C, k, s, p, OH, OW, F))
+            H, W, C = OH, OW, F
+        self.n_feat = filters[-1]
+        self._ws = {}
+
+    def workspace(self, tag, rows, keep):
+        ws = self._ws.get(tag)
+        if ws is None or ws.rows < rows:
+            ws = self._ws[tag] = ConvStack.Workspace(self, rows, keep)
+        return ws
+
+    def forward(self, x, rows, ws, flat=None):
+        """x: [rows, H*W*C] uint8 (or float32) NHWC frames -> ws.feat[:rows] (n_feat features per frame)."""
+        P = self.params
+        for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            M, K = rows * OH * OW, C * k * k
+            ops.im2col_nhwc(x, ws.col[i], rows, H, W, C, k, s, p)
+            n = self.names[i]
+            ops.linear_fwd([ops.gemm_desc(ws.col[i].data_ptr(), P.ptr(n + ".weight", flat), ws.y[i].data_ptr(), M, F, K, K, K, F,
+                                          bias=P.ptr(n + ".bias", flat), act="relu")])
+            x = ws.y[i]
+        H, W, C, k, s, p, OH, OW, F = self.geo[-1]
+        ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, rows, OH * OW, F, F)
+        return ws.feat
+
+    N_SPLIT = 32                                              # row chunks of a conv layer's weight gradient (parallelism)
+
+    def backward(self, dfeat, rows, ws, slabs, n_split, flat=None):
+        """dfeat [rows, n_feat] -> weight / bias gradients of every conv layer, summed into slabs[0] (the conv parameters
+        are the first `p_conv` floats of the layout; their regions in slabs[1:] stay zero).  The GEMM rows of a conv
+        layer are B*OH*OW (14 112 for the first Atari layer at batch 32), so the weight-gradient GEMM is split over
+        N_SPLIT row chunks into a private slab set and reduced in a fixed order."""
+        P = self.params
+        p_conv = max(P.offsets[n + sfx] + int(np.prod(P.shapes[n + sfx])) for n in self.names for sfx in (".weight", ".bias"))
+        if getattr(self, "_cslabs", None) is None:
+            self._cslabs = torch.zeros(self.N_SPLIT, (p_conv + 3) // 4 * 4, device=P.device)
+            self._csq = torch.zeros(256, dtype=torch.float64, device=P.device)
+        cs, stride = self._cslabs, self._cslabs.shape[1]
+        H, W, C, k, s, p, OH, OW, F = self.geo[-1]
+        ops.maxpool_hw_bwd(dfeat, ws.arg, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
+        for i in reversed(range(len(self.geo))):
+            H, W, C, k, s, p, OH, OW, F = self.geo[i]
+            M, K = rows * OH * OW, C * k * k
+            n = self.names[i]
+            ops.linear_bwd_weight([ops.gemm_desc(ws.dy[i].data_ptr(), ws.col[i].data_ptr(),
+                                                 cs.data_ptr() + 4 * P.offsets[n + ".weight"], M, F, K, F, K, K,
+                                                 dbias=cs.data_ptr() + 4 * P.offsets[n + ".bias"])], self.N_SPLIT, stride)
+            if i > 0:
+                ops.linear_bwd_data([ops.gemm_desc(ws.dy[i].data_ptr(), P.ptr(n + ".weight", flat), ws.dcol[i].data_ptr(),
+                                                   M, K, F, F, K, K)])
+                ops.col2im_nhwc(ws.dcol[i], ws.y[i - 1], ws.dy[i - 1], rows, H, W, C, k, s, p)   # times relu'(y_{i-1})
+        ops.grad_reduce(cs, self.N_SPLIT, stride, p_conv, slabs[0], self._csq)
+
+
 class DeepQCNN:
     """DeepQNetwork with the Basic_CNN representation of configs/dqn/atari.yaml (rl_models/representations/cnn.py:11-50:
     x/255, NHWC->NCHW, Conv2d(k, s, pad=(k-s)//2)+ReLU x3, AdaptiveMaxPool2d(1,1), Flatten) and a QValueHead MLP.
 
-    Hybrid in round 1 ("conv stays on MIOpen/torch initially"): the convolution stack runs
-    on PyTorch-ROCm's MIOpen convolutions over views of OUR flat parameter buffer, everything after the 64-d feature
-    (Q head GEMMs, TD target, gradient slabs, clip, Adam, target sync) runs on the HIP engine.  Conv gradients are
-    written into slab 0 of the shared gradient layout so the optimiser treats all parameters uniformly."""
+    Fully on the HIP engine: the convolution stack is ConvStack (im2col + fp32-MFMA GEMMs + max-pool kernels over OUR flat
+    parameter buffer, csrc/conv.hip), the Q head, TD target, gradient slabs, clip, Adam and target sync as everywhere."""
 
     def __init__(self, obs_shape=(84, 84, 4), n_actions=4, kernels=(8, 4, 3), strides=(4, 2, 1), filters=(32, 64, 64),
                  q_hidden=(512,), activation="relu", device="cuda", init=True):
@@ -519,7 +600,7 @@ class DeepQCNN:
         head = [k for k in order if k.startswith("eval_Q_head.")]
         self.ref_order = rep + ["target_" + k for k in rep] + head + ["target_Q_head." + k[len("eval_Q_head."):] for k in head]
         self.trainable_order = rep + head
-        self._feat = None
+        self.conv = ConvStack(self.params, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters)
         if init:
             for name in order:
                 v = self.params.view(name)
@@ -531,33 +612,25 @@ class DeepQCNN:
     load_state_dict = DeepQNet.load_state_dict
     copy_target = DeepQNet.copy_target
 
-    def _features(self, x_u8, flat, grad):
-        import torch.nn.functional as F
-        x = (x_u8.reshape((-1,) + self.obs_shape) / 255.0).to(torch.float32).permute(0, 3, 1, 2)     # cnn.py:45-48
-        leaves = []
-        with torch.set_grad_enabled(grad):
-            for n, k, s in zip(self.conv_names, self.kernels, self.strides):
-                w, b = self.params.view(n + ".weight", flat), self.params.view(n + ".bias", flat)
-                if grad:
-                    w, b = w.detach().requires_grad_(True), b.detach().requires_grad_(True)
-                    leaves += [w, b]
-                x = F.relu(F.conv2d(x, w, b, stride=s, padding=(k - s) // 2))                       # layers.py:46
-            x = torch.amax(x, dim=(2, 3))                                                          # AdaptiveMaxPool2d((1,1))
-        return x, leaves
-
     def forward(self, x_u8, M, ldx=None):
         """Rows [0, M) are differentiated through (eval Q of obs); returns Q [rows, n_actions]."""
         rows = x_u8.shape[0]
-        feat, self._leaves = self._features(x_u8[:M], None, True)
-        self._feat = feat
-        if rows > M:                                       # double-Q: eval net on next_obs, no gradient
-            feat = torch.cat([feat.detach(), self._features(x_u8[M:], None, False)[0]], 0)
-        self._feat_in = feat.detach().contiguous()
+        ws = self.conv.workspace("grad", M, True)
+        self._ws = ws
+        feat = self.conv.forward(x_u8[:M].reshape(M, -1), M, ws)
+        if rows > M:                                       # double-Q / acting rows: eval net, no gradient
+            ws2 = self.conv.workspace("nograd", rows - M, False)
+            f2 = self.conv.forward(x_u8[M:].reshape(rows - M, -1), rows - M, ws2)
+            if getattr(self, "_cat", None) is None or self._cat.shape[0] < rows:
+                self._cat = torch.empty(rows, self.filters[-1], device=self.params.device)
+            self._cat[:M].copy_(feat[:M]); self._cat[M:rows].copy_(f2[:rows - M])
+            feat = self._cat
+        self._feat_in = feat
         return self.plan.forward(self._feat_in, self.filters[-1], rows)
 
     def target(self, x_u8, M, ldx=None):
-        feat, _ = self._features(x_u8, self.target_flat, False)
-        self._tfeat = feat.contiguous()
+        ws = self.conv.workspace("target", M, False)
+        self._tfeat = self.conv.forward(x_u8.reshape(M, -1), M, ws, flat=self.target_flat)
         return self.target_plan.forward(self._tfeat, self.filters[-1], M, flat=self.target_flat)
 
     @property
@@ -565,12 +638,7 @@ class DeepQCNN:
         return self.plan.dacts[len(self.plan.widths) - 1]
 
     def backward(self, x_u8, M, slabs, n_split):
-        dfeat = torch.zeros(M, self.filters[-1], device=self.params.device)
-        self.plan.backward(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=dfeat)
-        grads = torch.autograd.grad(self._feat, self._leaves, grad_outputs=dfeat)
-        P = self.params
-        for name, g in zip([n + s for n in self.conv_names for s in (".weight", ".bias")], grads):
-            o = P.offsets[name]
-            slabs[0, o:o + g.numel()].copy_(g.reshape(-1))
-            if n_split > 1:
-                slabs[1:n_split, o:o + g.numel()].zero_()
+        if getattr(self, "_dfeat", None) is None or self._dfeat.shape[0] < M:
+            self._dfeat = torch.zeros(M, self.filters[-1], device=self.params.device)
+        self.plan.backward(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat)
+        self.conv.backward(self._dfeat, M, self._ws, slabs, n_split)

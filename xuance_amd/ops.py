@@ -90,6 +90,23 @@ def linear_bwd_weight(groups, n_split, slab_stride):
     call("xrl_linear_bwd_weight", _garr(groups), len(groups), int(n_split), int(slab_stride), stream_ptr())
 
 
+# ------------------------------------------------------------------------------------------ convolution helpers
+def im2col_nhwc(x, col, B, H, W, C, k, s, p):
+    call("xrl_im2col_nhwc", ptr(x), int(x.dtype == torch.uint8), ptr(col), B, H, W, C, k, s, p, stream_ptr())
+
+
+def col2im_nhwc(dcol, xact, dx, B, H, W, C, k, s, p):
+    call("xrl_col2im_nhwc", ptr(dcol), ptr(xact), ptr(dx), B, H, W, C, k, s, p, stream_ptr())
+
+
+def maxpool_hw_fwd(y, feat, argmax, B, P, F, ld_feat):
+    call("xrl_maxpool_hw_fwd", ptr(y), ptr(feat), ptr(argmax), B, P, F, ld_feat, stream_ptr())
+
+
+def maxpool_hw_bwd(dfeat, argmax, y, dy, B, P, F, ld_dfeat):
+    call("xrl_maxpool_hw_bwd", ptr(dfeat), ptr(argmax), ptr(y), ptr(dy), B, P, F, ld_dfeat, stream_ptr())
+
+
 # ------------------------------------------------------------------------------------------ PPO loss
 def ppo_loss(dist, **kw):
     p = PpoLoss()
