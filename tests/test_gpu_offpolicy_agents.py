@@ -204,3 +204,50 @@ def test_qmix_graph_update_phase_equals_eager_updates_on_the_same_indices():
                     np.array([[i["loss_Q"], i["predictQ"]] for i in infos])))
     (pa, ta, ia), (pb, tb, ib) = res
     assert np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(ia, ib)
+
+
+@pytest.mark.parametrize("atari", [False, True])
+def test_dqn_graph_update_phase_equals_eager_updates_on_the_same_indices(atari):
+    """DQN_Learner.update_from_buffer (device sampling + gather + update per hipGraph launch) vs update(**memory.sample(
+    indexes)) with the indices the sampling kernel draws: identical parameters, target parameters and losses."""
+    from xuance_amd import ops
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv, SyntheticAtariVecEnv
+    n = 8
+    cfg = dict(representation="Basic_MLP", representation_hidden_size=[64], q_hidden_size=[64], activation="relu", seed=1,
+               parallels=n, running_steps=10 ** 6, buffer_size=n * 40, batch_size=16, learning_rate=1e-3, gamma=0.99,
+               start_greedy=0.5, end_greedy=0.05, decay_step_greedy=10 ** 5, sync_frequency=3, training_frequency=1,
+               start_training=10 ** 9, n_epochs=2, use_grad_clip=True, grad_clip_norm=0.5, use_obsnorm=False,
+               use_rewnorm=False, distributed_training=False, device="cuda", model_dir="/tmp/x")
+    if atari:
+        cfg.update(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                   q_hidden_size=[512])
+    res = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        env = SyntheticAtariVecEnv(n, seed=2) if atari else DeviceCartPoleVecEnv(n, seed=1)
+        agent = DQN_Agent(Namespace(**cfg), env)
+        agent.train(20)                                       # fills 20 ring rows, no updates
+        lr, mem = agent.learner, agent.memory
+        assert mem.size == 20 and int(mem.size_dev.item()) == 20
+        infos = []
+        if graph:
+            for _ in range(3):
+                infos.append(lr.update_from_buffer(mem, 2, seed=5))
+            assert lr._buf_graph is not None
+        else:
+            idx = torch.zeros(16, dtype=torch.int64, device="cuda")
+            ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for _ in range(3):
+                for e in range(2):
+                    ops.sample_replay_indices(idx, mem.n_envs, mem.n_size, mem.size_dev, 5, 0, ctr)
+                    ops.counter_add(ctr, 1)
+                    info = lr.update(**mem.sample(indexes=idx.clone()))
+                infos.append(info)
+        torch.cuda.synchronize()
+        assert lr.iterations == 6
+        res.append((agent.model.params.flat.cpu().numpy().copy(), agent.model.target_flat.cpu().numpy().copy(),
+                    np.array([[i["Qloss"], i["predictQ"]] for i in infos])))
+    (pa, ta, ia), (pb, tb, ib) = res
+    assert np.abs(pa).max() > 0 and np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(ia, ib)

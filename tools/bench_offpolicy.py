@@ -41,7 +41,13 @@ def dqn_c3(steps):
                     distributed_training=False, device="cuda", model_dir="/tmp/x")
     agent = DQN_Agent(cfg, SyntheticAtariVecEnv(n, seed=2))
     dt = timed_train(agent, 16, steps)
-    return {"config": "C3 DQN, 64 envs x 84x84x4 uint8 frames, CNN 32/64/64 + 512, batch 32, one update per vector step",
+    lr, mem = agent.learner, agent.memory
+    lr.update_from_buffer(mem, 1, seed=1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(30):
+        lr._buf_graph.launch()
+    torch.cuda.synchronize(); graph_us = (time.perf_counter() - t0) / 30 * 1e6
+    return {"update_graph_us": round(graph_us, 1), "config": "C3 DQN, 64 envs x 84x84x4 uint8 frames, CNN 32/64/64 + 512, batch 32, one update per vector step",
             "env_steps_per_s": round(n * steps / dt, 1), "vector_step_us": round(dt / steps * 1e6, 1),
             "update_us": round(update_us(agent), 1), "replay_bytes_per_transition": 2 * 28224 + 12}
 

@@ -29,6 +29,7 @@ class DQN_Agent:
         self.obsnorm_range, self.rewnorm_range = _get(config, "obsnorm_range", 5.0), _get(config, "rewnorm_range", 5.0)
         self.start_training, self.training_frequency = config.start_training, config.training_frequency
         self.n_epochs = _get(config, "n_epochs", 1)
+        self.use_graph_updates = bool(_get(config, "use_hip_graph", True))   # whole update phases as one hipGraph launch
         self.seed = int(_get(config, "seed", 1))
         # dqn_agent.py:28-30
         self.start_greedy, self.end_greedy = config.start_greedy, config.end_greedy
@@ -107,8 +108,11 @@ class DQN_Agent:
             self.memory.store(self.X.view((n,) + tuple(self.obs_shape)), self.act_f, env.reward, env.terminated,
                               self.Xn.view((n,) + tuple(self.obs_shape)))
             if self.current_step > self.start_training and self.current_step % self.training_frequency == 0:
-                for _e in range(self.n_epochs):
-                    info = self.learner.update(**self.memory.sample())
+                if self.use_graph_updates:
+                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed)
+                else:
+                    for _e in range(self.n_epochs):
+                        info = self.learner.update(**self.memory.sample())
             self.current_step += n
             self._update_explore_factor()
         if hasattr(env, "episode_stats"):

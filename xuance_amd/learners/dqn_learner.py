@@ -60,6 +60,58 @@ class DQN_Learner(Learner):
         ops.sync_target(model.params.flat, model.target_flat, model.params.P, opt.state, self.sync_frequency)   # :56-57
         return S
 
+    # ------------------------------------------------------------------ whole update phases straight from the HBM replay buffer
+    def update_from_buffer(self, memory, n_epochs=1, seed=1):
+        """`n_epochs` updates (sample -> gather -> forward / TD / backward -> Adam -> target sync) as ONE captured hipGraph
+        launch: indices are drawn on the device (xrl_sample_replay_indices follows the filling ring through
+        memory.size_dev), the gather writes the uint8 / float32 rows straight into the staging tensor the network reads.
+        Same arithmetic as update(**memory.sample()); one host sync per phase."""
+        M, dev = memory.batch_size, self.model.params.device
+        key = (id(memory), n_epochs, M)
+        if getattr(self, "_buf_graph_key", None) != key:
+            self._ensure(M)
+            self._idx = torch.zeros(M, dtype=torch.int64, device=dev)
+            self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._epoch_sums = torch.zeros(n_epochs, 8, dtype=torch.float64, device=dev)
+            self._act, self._rew, self._ter = (torch.zeros(M, device=dev) for _ in range(3))
+            dst = {"observations": self.X[:M], "next_observations": self.X[M:2 * M], "actions": self._act,
+                   "rewards": self._rew, "terminals": self._ter}
+            self._buf_S = pick_n_split(M)
+
+            def enqueue():
+                for e in range(n_epochs):
+                    ops.sample_replay_indices(self._idx, memory.n_envs, memory.n_size, memory.size_dev, seed, 0, self._sample_counter)
+                    ops.counter_add(self._sample_counter, 1)
+                    memory.gather_into(self._idx, dst)
+                    S = self._step(M, self._act, self._rew, self._ter)
+                    ops.sum_partials(self.partials, S, 8, self._epoch_sums[e])
+            self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
+            enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
+            if not (self.distributed_training and self.world_size > 1):
+                torch.cuda.synchronize()                    # ... and is then captured for the following calls
+                g = ops.Graph()
+                with g:
+                    enqueue()
+                self._buf_graph = g
+        elif self._buf_graph is not None:
+            self._buf_graph.launch()
+        else:
+            self._buf_enqueue()
+        sums = self._epoch_sums.cpu().numpy()               # the one host sync of the phase
+        st = self.optimizer.read()
+        info, A = {}, self.n_actions
+        for e in range(n_epochs):
+            self.iterations += 1
+            info = self.callback.on_update_start(self.iterations, policy=self.model, obs=self.X[:M], act=self._act,
+                                                 next_obs=self.X[M:2 * M], rew=self._rew, termination=self._ter) or {}
+            info.update({self._key("Qloss"): float(sums[e, 0] / M), self._key("predictQ"): float(sums[e, 1] / M),
+                         self._key("learning_rate"): st.last_lr})
+            evalQ = self.model.plan.acts[len(self.model.plan.widths) - 1][:M, :A]
+            info.update(self.callback.on_update_end(self.iterations, policy=self.model, info=info, evalQ=evalQ,
+                                                    predictQ=self.diag[:M], targetQ=self.diag[M:2 * M],
+                                                    loss=info[self._key("Qloss")]) or {})
+        return info
+
     def update(self, **samples):
         self.iterations += 1
         M = len(samples["obs"])

@@ -240,6 +240,7 @@ class HipOffPolicyBuffer:
         self.soa = _SoA(self.n_size, n_envs, specs, device)
         self.stager = _Stager(n_envs, specs, device)
         self.ptr, self.size = 0, 0
+        self.size_dev = torch.zeros(1, dtype=torch.int32, device=device)
 
     @property
     def full(self):
@@ -247,6 +248,7 @@ class HipOffPolicyBuffer:
 
     def clear(self):
         self.ptr, self.size = 0, 0
+        self.size_dev.zero_()
         self.soa.zero()
 
     def store(self, obs, acts, rews, terminals, next_obs):     # memory_tools.py:365-372
@@ -255,7 +257,14 @@ class HipOffPolicyBuffer:
         f = self.soa
         ops.soa_store_step([(f.fields[k], step[k], f.row_bytes[k]) for k in step], self.n_envs, self.ptr)
         self.ptr = (self.ptr + 1) % self.n_size
-        self.size = min(self.size + 1, self.n_size)
+        if self.size < self.n_size:
+            self.size += 1
+            self.size_dev.fill_(self.size)                   # `size` for sampling kernels inside captured graphs
+
+    def gather_into(self, idx, dst):
+        """dst: field name -> device tensor [bs, row] (a learner's staging views); one launch, no host work."""
+        f = self.soa
+        ops.soa_gather([(dst[k], f.fields[k], f.row_bytes[k]) for k in dst], idx, self.n_envs, self.n_size)
 
     def sample_indices(self, batch_size=None):
         """The two NumPy global-RNG draws of memory_tools.py:376-377, as flat env-major indices."""
