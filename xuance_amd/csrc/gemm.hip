@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     __shared__ __attribute__((aligned(16))) float sA[64 * LDK > 32 * LDR ? 64 * LDK : 32 * LDR];
     __shared__ __attribute__((aligned(16))) float sB[64 * LDK > 32 * LDR ? 64 * LDK : 32 * LDR];
 
+    kernarg_prefetch<sizeof(GemmBatch)>();
     const xrl_gemm_t& g = p.g[blockIdx.z];
     // logical problem: C[Mo, No] = sum_k opA[Mo,k] opB[k,No], k < Kred
     int Mo, No, Kred;
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         if (MODE == MODE_TN) stage_kmajor(sA, ra); else stage_kcontig(sA, ra);
         if (MODE == MODE_NT) stage_kcontig(sB, rb); else stage_kmajor(sB, rb);
-        __syncthreads();
+        lds_barrier();                             // LDS-only: __syncthreads() would also drain the prefetch below
         if (k0 + BK < kend) load_tiles(k0 + BK);   // next slab in flight while the matrix cores work
         if (wave_live) {
 #pragma unroll
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
                 for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], acc, 0, 0, 0);
             }
         }
-        __syncthreads();
+        lds_barrier();                             // slab consumed; the next one is still on its way
     }
 
     if (!wave_live) return;
