@@ -188,8 +188,8 @@ def test_fused_rollout_step_equals_unfused_sequence():
     assert sa["eps"][0] == sb["eps"][0] and sa["eps"][0] > 100
 
 
-@pytest.mark.parametrize("act,n", [("leaky_relu", 100), ("tanh", 64), ("relu", 37)])
-def test_specialised_rollout_kernel_is_bit_identical_to_any_shape_kernel(act, n):
+@pytest.mark.parametrize("act,n,norm", [("leaky_relu", 100, True), ("tanh", 64, True), ("relu", 37, True), ("sigmoid", 32, False)])
+def test_specialised_rollout_kernel_is_bit_identical_to_any_shape_kernel(act, n, norm):
     """rollout_step_fast_kernel (compile-time 4-128-{128-2,128-1}) vs rollout_step_cartpole_kernel: same bits everywhere."""
     from xuance_amd import ops
     from xuance_amd.agents import PPO_Agent
@@ -201,7 +201,8 @@ def test_specialised_rollout_kernel_is_bit_identical_to_any_shape_kernel(act, n)
             torch.manual_seed(0)
             env = DeviceCartPoleVecEnv(n, seed=3)
             env.max_episode_steps = 30
-            agent = PPO_Agent(make_config(n, 48, activation=act), env)
+            agent = PPO_Agent(make_config(n, 48, activation=act, use_obsnorm=norm, use_rewnorm=norm,
+                                          use_persistent_rollout=False), env)
             assert agent.use_fused_rollout
             agent.rollout()
             agent.rollout()
@@ -219,8 +220,8 @@ def test_specialised_rollout_kernel_is_bit_identical_to_any_shape_kernel(act, n)
         assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("act,n", [("leaky_relu", 100), ("tanh", 256), ("relu", 37)])
-def test_persistent_rollout_is_bit_identical_to_per_step_launches(act, n):
+@pytest.mark.parametrize("act,n,norm", [("leaky_relu", 100, True), ("tanh", 256, True), ("relu", 37, True), ("relu", 64, False)])
+def test_persistent_rollout_is_bit_identical_to_per_step_launches(act, n, norm):
     """rollout_persistent_kernel (ONE launch per rollout, counter barrier between steps) vs T + 1 launches of
     rollout_step_fast_kernel: every buffer field, statistic and simulator state must carry the same bits."""
     from xuance_amd.agents import PPO_Agent
@@ -230,7 +231,8 @@ def test_persistent_rollout_is_bit_identical_to_per_step_launches(act, n):
         torch.manual_seed(0)
         env = DeviceCartPoleVecEnv(n, seed=3)
         env.max_episode_steps = 30
-        agent = PPO_Agent(make_config(n, 48, activation=act, use_persistent_rollout=persistent), env)
+        agent = PPO_Agent(make_config(n, 48, activation=act, use_persistent_rollout=persistent, use_obsnorm=norm,
+                                      use_rewnorm=norm), env)
         assert agent.use_fused_rollout
         agent.rollout()
         agent.rollout()
