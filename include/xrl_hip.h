@@ -249,6 +249,26 @@ typedef struct {
 } xrl_cartpole_t;
 int xrl_cartpole_step(const xrl_cartpole_t* p, int reset, xrl_stream_t stream);
 
+/* Synthetic MuJoCo-shaped vector env on the device (an input provider for the continuous-control shapes of BASELINE
+ * config C4 -- no simulator is installed; NOT a reference component): state' = tanh(state.A + clip(a).B) + 0.01 N(0,1),
+ * reward = state'[0] - 0.1 |a|^2, truncation after max_steps, same auto-reset contract as xrl_cartpole_step. */
+typedef struct {
+    float* state;             /* [n][D] */
+    int32_t* steps;           /* [n] */
+    const float* action;      /* [n][A] */
+    const float* Amat;        /* [D][D] */
+    const float* Bmat;        /* [A][D] */
+    float* obs;               /* [n][D] observation the agent sees next (after auto-reset) */
+    float* next_obs;          /* [n][D] pre-reset next observation */
+    float* reward; float* terminated; float* truncated;   /* [n] */
+    float* ep_score;          /* [n] */
+    double* stats;            /* [4] finished episodes, sum of scores, sum of lengths, - */
+    int32_t n, D, A, max_steps;
+    uint64_t seed;
+    uint32_t step; const uint32_t* step_dev;
+} xrl_synth_ctl_t;
+int xrl_synth_control_step(const xrl_synth_ctl_t* p, int reset, xrl_stream_t stream);
+
 /* Per-step bookkeeping of PPO_Agent.train (ppo_agent.py:128,144-157): reward normalisation + store,
  * path-end flags, return tracker and ret_rms updates in env order, normalised next_obs for bootstrapping. */
 typedef struct {

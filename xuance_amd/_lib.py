@@ -117,6 +117,13 @@ class RolloutStep(C.Structure):
                 ("dbg", c_void_p)]
 
 
+class SynthCtl(C.Structure):
+    _fields_ = [("state", c_void_p), ("steps", c_void_p), ("action", c_void_p), ("Amat", c_void_p), ("Bmat", c_void_p),
+                ("obs", c_void_p), ("next_obs", c_void_p), ("reward", c_void_p), ("terminated", c_void_p),
+                ("truncated", c_void_p), ("ep_score", c_void_p), ("stats", c_void_p), ("n", c_int32), ("D", c_int32),
+                ("A", c_int32), ("max_steps", c_int32), ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
+
+
 class RolloutPersist(C.Structure):
     _fields_ = [("step0", RolloutStep), ("bootv", c_void_p), ("barrier", c_void_p), ("status", c_void_p),
                 ("T", c_int32), ("pad", c_int32)]
@@ -168,6 +175,7 @@ _SIGS = {
     "xrl_egreedy": [C.POINTER(EGreedy), c_void_p],
     "xrl_counter_add": [c_void_p, C.c_uint32, c_void_p],
     "xrl_set_fast_kernels": [C.c_int],
+    "xrl_synth_control_step": [C.POINTER(SynthCtl), c_int, c_void_p],
     "xrl_im2col_nhwc": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_col2im_nhwc": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_maxpool_hw_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

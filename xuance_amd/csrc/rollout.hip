@@ -182,6 +182,54 @@ __global__ void __launch_bounds__(256) cartpole_reset_kernel(xrl_cartpole_t p) {
     o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
 }
 
+// ------------------------------------------------------------------------------------------------ synthetic control env
+// MuJoCo-shaped input provider (no simulator in this image): state' = tanh(state . A + clip(a) . B)
+// + 0.01 N(0,1), reward = state'[0] - 0.1 |a|^2, truncation after max_steps, reset to 0.1 N(0,1); same auto-reset
+// contract as the CartPole kernel.  One thread per env; the noise is Philox keyed by (seed, env, step).
+__device__ __forceinline__ float synth_normal(uint64_t seed, uint32_t e, uint32_t step, uint32_t j) {
+    uint32_t r[4];
+    philox4x32(seed, e, step, 0x53594E00u + j, r);
+    const float u1 = fmaxf(u01(r[0]), 1e-7f), u2 = u01(r[1]);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+__global__ void __launch_bounds__(128) synth_control_kernel(xrl_synth_ctl_t p, int reset) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.n) return;
+    const int D = p.D, Ad = p.A;
+    const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
+    float* st = p.state + (size_t)e * D;
+    if (reset) {
+        for (int j = 0; j < D; ++j) { const float v = 0.1f * synth_normal(p.seed, (uint32_t)e, 0xffffff00u, (uint32_t)j); st[j] = v; p.obs[(size_t)e * D + j] = v; }
+        p.steps[e] = 0; p.ep_score[e] = 0.f;
+        return;
+    }
+    float a[16], x[32], y[32];
+    float pen = 0.f;
+    for (int i = 0; i < Ad; ++i) { a[i] = fminf(fmaxf(p.action[(size_t)e * Ad + i], -1.f), 1.f); pen += a[i] * a[i]; }
+    for (int j = 0; j < D; ++j) x[j] = st[j];
+    for (int j = 0; j < D; ++j) {
+        float acc = 0.f;
+        for (int k = 0; k < D; ++k) acc += x[k] * p.Amat[k * D + j];
+        for (int i = 0; i < Ad; ++i) acc += a[i] * p.Bmat[i * D + j];
+        y[j] = tanhf(acc) + 0.01f * synth_normal(p.seed, (uint32_t)e, step, (uint32_t)j);
+    }
+    const float rew = y[0] - 0.1f * pen;
+    const int steps = p.steps[e] + 1;
+    const bool trunc = steps >= p.max_steps;
+    for (int j = 0; j < D; ++j) p.next_obs[(size_t)e * D + j] = y[j];
+    p.reward[e] = rew; p.terminated[e] = 0.f; p.truncated[e] = trunc ? 1.f : 0.f;
+    const float score = p.ep_score[e] + rew;
+    if (trunc) {
+        atomicAdd(&p.stats[0], 1.0); atomicAdd(&p.stats[1], (double)score); atomicAdd(&p.stats[2], (double)steps);
+        for (int j = 0; j < D; ++j) { const float v = 0.1f * synth_normal(p.seed, (uint32_t)e, step, 64u + (uint32_t)j); st[j] = v; p.obs[(size_t)e * D + j] = v; }
+        p.steps[e] = 0; p.ep_score[e] = 0.f;
+    } else {
+        for (int j = 0; j < D; ++j) { st[j] = y[j]; p.obs[(size_t)e * D + j] = y[j]; }
+        p.steps[e] = steps; p.ep_score[e] = score;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ post-step bookkeeping
 
 constexpr int POST_THREADS = 1024;
@@ -342,6 +390,16 @@ extern "C" int xrl_cartpole_step(const xrl_cartpole_t* params, int reset, xrl_st
         XRL_CHECK_ARG(p.action && p.next_obs && p.reward && p.terminated && p.truncated && p.stats);
         hipLaunchKernelGGL(cartpole_step_kernel, dim3((p.n + 255) / 256), dim3(256), 0, as_stream(stream), p);
     }
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_synth_control_step(const xrl_synth_ctl_t* params, int reset, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_synth_ctl_t& p = *params;
+    XRL_CHECK_ARG(p.state && p.obs && p.steps && p.ep_score && p.n > 0 && p.D > 0 && p.D <= 32 && p.A > 0 && p.A <= 16);
+    if (!reset) XRL_CHECK_ARG(p.action && p.next_obs && p.reward && p.terminated && p.truncated && p.stats && p.Amat && p.Bmat);
+    hipLaunchKernelGGL(synth_control_kernel, dim3((p.n + 127) / 128), dim3(128), 0, as_stream(stream), p, reset);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

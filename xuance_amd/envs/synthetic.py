@@ -61,45 +61,47 @@ class SyntheticAtariVecEnv(_Base):
 
 
 class SyntheticMujocoVecEnv(_Base):
-    """obs (17,) float32, Box(6) actions (HalfCheetah-shaped, configs/ppo/mujoco.yaml); linear-tanh dynamics."""
+    """obs (17,) float32, Box(6) actions (HalfCheetah-shaped, configs/ppo/mujoco.yaml); linear-tanh dynamics evaluated by
+    one kernel per vector step (xrl_synth_control_step), so that the whole rollout of the continuous-control path can be
+    captured into a hipGraph like the CartPole one."""
+    graph_safe = True
 
     def __init__(self, num_envs, seed=1, device="cuda", obs_dim=17, act_dim=6, max_episode_steps=1000):
         super().__init__(num_envs, seed, device, max_episode_steps)
+        from .. import ops
+        self._ops = ops
+        self.seed = int(seed)
+        self.obs_dim, self.act_dim = obs_dim, act_dim
         self.observation_space = Box(-np.inf, np.inf, (obs_dim,), np.float32)
         self.action_space = Box(-1.0, 1.0, (act_dim,), np.float32)
         g = torch.Generator().manual_seed(int(seed) + 1000)
-        self.A = (torch.randn(obs_dim, obs_dim, generator=g) * 0.3).to(device)
-        self.B = (torch.randn(act_dim, obs_dim, generator=g) * 0.5).to(device)
+        self.A = (torch.randn(obs_dim, obs_dim, generator=g) * 0.3).to(device).contiguous()
+        self.B = (torch.randn(act_dim, obs_dim, generator=g) * 0.5).to(device).contiguous()
         self.state = torch.zeros(self.num_envs, obs_dim, device=device)
         self.buf_obs = torch.zeros(self.num_envs, obs_dim, device=device)
         self.next_obs = torch.zeros_like(self.buf_obs)
         self.action = torch.zeros(self.num_envs, act_dim, device=device)
         self.ep_score = torch.zeros(self.num_envs, device=device)
         self.stats = torch.zeros(4, dtype=torch.float64, device=device)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def _args(self):
+        return dict(state=self.state, steps=self.steps, action=self.action, Amat=self.A, Bmat=self.B, obs=self.buf_obs,
+                    next_obs=self.next_obs, reward=self.reward, terminated=self.terminated, truncated=self.truncated,
+                    ep_score=self.ep_score, stats=self.stats, n=self.num_envs, D=self.obs_dim, A=self.act_dim,
+                    max_steps=self.max_episode_steps, seed=self.seed, step=0, step_dev=self.step_counter)
 
     def reset(self):
-        self.state = torch.randn(self.state.shape, device=self.device, generator=self.gen) * 0.1
-        self.buf_obs.copy_(self.state)
+        self._ops.synth_control_step(reset=True, **self._args())
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
     def step_device(self):
-        a = self.action.clamp(-1, 1)
-        self.state = torch.tanh(self.state @ self.A + a @ self.B) + 0.01 * torch.randn(self.state.shape, device=self.device,
-                                                                                      generator=self.gen)
-        self.reward = self.state[:, 0] - 0.1 * (a * a).sum(1)
-        self.next_obs.copy_(self.state)
-        self.ep_score += self.reward
-        done = self._end_of_step(0.0)
-        if bool(done.any()):
-            self.stats[0] += done.sum()
-            self.stats[1] += self.ep_score[done].sum().double()
-            self.ep_score[done] = 0
-            self.state[done] = torch.randn(self.state.shape, device=self.device, generator=self.gen)[done] * 0.1
-        self.buf_obs.copy_(self.state)
+        self._ops.synth_control_step(**self._args())
+        self._ops.counter_add(self.step_counter, 1)
 
     def episode_stats(self):
         s = self.stats.cpu().numpy()
-        return int(s[0]), float(s[1] / max(s[0], 1.0)), float(self.max_episode_steps)
+        return int(s[0]), float(s[1] / max(s[0], 1.0)), float(s[2] / max(s[0], 1.0))
 
 
 class SyntheticSMACVecEnv(_Base):

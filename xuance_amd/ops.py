@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Mirrors, RolloutPersist, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -253,6 +253,10 @@ def policy_sample(**kw):
 
 def cartpole_step(reset=False, **kw):
     call("xrl_cartpole_step", C.byref(_struct(CartPole, kw)), int(bool(reset)), stream_ptr())
+
+
+def synth_control_step(reset=False, **kw):
+    call("xrl_synth_control_step", C.byref(_struct(SynthCtl, kw)), int(bool(reset)), stream_ptr())
 
 
 def rollout_poststep(**kw):
