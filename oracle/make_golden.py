@@ -30,7 +30,7 @@ from xuance.common.memory_tools import DummyOnPolicyBuffer, DummyOffPolicyBuffer
 from xuance.common.statistic_tools import RunningMeanStd  # noqa: E402
 from xuance.common.callback import BaseCallback  # noqa: E402
 from xuance.common import AgentGrouping  # noqa: E402
-from xuance.torch.learners import PPO_Learner, DQN_Learner, QMIX_Learner  # noqa: E402
+from xuance.torch.learners import PPO_Learner, DQN_Learner, DDQN_Learner, QMIX_Learner  # noqa: E402
 from xuance.torch.rl_models.representations import Basic_MLP, Basic_Identical, Basic_CNN  # noqa: E402
 from xuance.torch.rl_models.heads.actor_head import CategoricalActorHead, GaussianActorHead  # noqa: E402
 from xuance.torch.rl_models.heads.critic_head import ValueHead  # noqa: E402
@@ -248,7 +248,9 @@ def golden_ppo(dist):
 
 
 # ------------------------------------------------------------------------------ DQN
-def golden_dqn(kind):
+def golden_dqn(kind, learner_cls=None, name=None):
+    """learner_cls: DQN_Learner (default) or DDQN_Learner (ddqn_learner.py:39-47, the double-Q target)."""
+    learner_cls = learner_cls or DQN_Learner
     torch.manual_seed(2)
     rng = np.random.default_rng(9)
     init = torch.nn.init.orthogonal_
@@ -272,7 +274,7 @@ def golden_dqn(kind):
     cfg = base_config(learning_rate=1e-3, gamma=0.99, sync_frequency=2, start_training=0, training_frequency=1,
                       use_grad_clip=(kind == "mlp"), grad_clip_norm=0.5)
     cb = Capture()
-    learner = DQN_Learner(cfg, model, cb)
+    learner = learner_cls(cfg, model, cb)
     batches = []
     for u in range(3):
         if kind == "mlp":
@@ -290,7 +292,7 @@ def golden_dqn(kind):
     out = run_learner_updates(learner, model, cb, batches, call)
     out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm,
                            float(cfg.use_grad_clip), learner.total_iters])
-    np.savez_compressed(os.path.join(OUT, f"dqn_{kind}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"{name or 'dqn'}_{kind}.npz"), **out)
 
 
 # ------------------------------------------------------------------------------ QMIX (feed-forward)
@@ -363,6 +365,7 @@ if __name__ == "__main__":
     golden_ppo("gaussian")
     golden_dqn("mlp")
     golden_dqn("cnn")
+    golden_dqn("mlp", DDQN_Learner, "ddqn")
     golden_qmix(True)
     golden_qmix(False)
     for f in sorted(os.listdir(OUT)):

@@ -494,7 +494,13 @@ def dqn_forward_backward(sd, batch, cfg, act="relu"):
     targetQ_all = tq.forward(trep.forward(nxt) if trep_l else nxt)      # :40
     a = batch["actions"].astype(np.int64)
     predictQ = evalQ[np.arange(B), a]                                   # :42
-    tmax = targetQ_all.max(-1)                                          # :43
+    if cfg.get("double_q", False):                                      # DDQN_Learner (ddqn_learner.py:39-47): the target
+        h2 = rep.forward(nxt) if rep_l else nxt                         # action is the eval network's argmax on next_obs
+        tmax = targetQ_all[np.arange(B), q.forward(h2).argmax(-1)]
+        h = rep.forward(obs) if rep_l else obs                          # (restore the activations backward() uses)
+        evalQ = q.forward(h)
+    else:
+        tmax = targetQ_all.max(-1)                                      # :43
     g = dt(cfg["gamma"])
     targetQ = batch["rewards"].astype(dt) + g * (1 - batch["terminals"].astype(dt)) * tmax   # :44
     loss = ((predictQ - targetQ) ** 2).mean()                           # :46

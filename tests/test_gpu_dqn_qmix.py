@@ -52,10 +52,13 @@ def check_updates(g, net, learner, cb, call, cb_keys, loss_key, n_updates=3, gto
         assert_close(osd["state"][i]["exp_avg_sq"].cpu().numpy(), g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
 
 
-def test_dqn_learner_vs_reference_fixture():
+@pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp"])
+def test_dqn_learner_vs_reference_fixture(name):
+    """DQN_Learner vs the reference's DQN_Learner fixture; DDQN_Learner vs the reference's DDQN_Learner fixture."""
     from xuance_amd.nets import DeepQNet
-    from xuance_amd.learners import DQN_Learner
-    g = load_golden("dqn_mlp")
+    from xuance_amd.learners import DQN_Learner, DDQN_Learner
+    DQN_Learner = DDQN_Learner if name.startswith("ddqn") else DQN_Learner
+    g = load_golden(name)
     lr, gamma, sync, gclip, use_clip, total = g["cfg"]
     net = DeepQNet(6, 4, (64,), (64,), "relu")
     assert list(net.ref_order) == list(sub(g, "init").keys())          # same state_dict order as the reference

@@ -123,11 +123,13 @@ def test_ppo_update(oracle, dist):
     assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")
 
 
-def test_dqn_mlp_update(oracle):
-    g = load_golden("dqn_mlp")
+@pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp"])
+def test_dqn_mlp_update(oracle, name):
+    """dqn_mlp: DQN_Learner (dqn_learner.py:28-75); ddqn_mlp: DDQN_Learner (ddqn_learner.py:28-75), same network."""
+    g = load_golden(name)
     lr, gamma, sync, gclip, use_clip, total = g["cfg"]
     opt_kwargs_clip["clip"] = gclip if use_clip else None
-    fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma))
+    fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma, double_q=name.startswith("ddqn")))
 
     def on_update(u, sd):
         if (u + 1) % int(sync) == 0:

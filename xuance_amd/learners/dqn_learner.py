@@ -133,3 +133,13 @@ class DQN_Learner(Learner):
                                                 predictQ=self.diag[:M], targetQ=self.diag[M:2 * M],
                                                 loss=info[self._key("Qloss")]) or {})
         return info
+
+
+class DDQN_Learner(DQN_Learner):
+    """Double DQN (xuance/torch/learners/qlearning_family/ddqn_learner.py:13-75): identical to DQN_Learner except that the
+    target action is argmax_a Q_eval(s', a) (`targetA = self.model(next_batch).actions`, :40-44); xrl_dqn_td implements
+    both rules, the eval network simply runs on 2M rows (obs | next_obs) in the same launches."""
+
+    def __init__(self, config, model, callback=None):
+        super().__init__(config, model, callback)
+        self.double_q = True
