@@ -142,7 +142,9 @@ typedef struct {
     int32_t out_act;       /* activation already applied to `out` (gaussian activation_action), XRL_ACT_* */
     int32_t n_split;       /* number of blocks == number of gradient slabs */
     int64_t slab_stride;   /* floats between consecutive slabs of d_log_std */
-    float clip_range, vf_coef, ent_coef, pad;
+    float clip_range, vf_coef, ent_coef;
+    int32_t mode;          /* 0: PPO-clip surrogate; 1: A2C actor term -(adv * log_prob).mean() (a2c_learner.py:47), no ratio:
+                            * old_logp is not read, partials[0] = sum adv*log_prob, n_clipped = 0 */
 } xrl_ppo_loss_t;
 
 int xrl_ppo_loss_categorical(const xrl_ppo_loss_t* p, xrl_stream_t stream);

@@ -30,7 +30,7 @@ from xuance.common.memory_tools import DummyOnPolicyBuffer, DummyOffPolicyBuffer
 from xuance.common.statistic_tools import RunningMeanStd  # noqa: E402
 from xuance.common.callback import BaseCallback  # noqa: E402
 from xuance.common import AgentGrouping  # noqa: E402
-from xuance.torch.learners import PPO_Learner, DQN_Learner, DDQN_Learner, QMIX_Learner  # noqa: E402
+from xuance.torch.learners import PPO_Learner, A2C_Learner, DQN_Learner, DDQN_Learner, QMIX_Learner  # noqa: E402
 from xuance.torch.rl_models.representations import Basic_MLP, Basic_Identical, Basic_CNN  # noqa: E402
 from xuance.torch.rl_models.heads.actor_head import CategoricalActorHead, GaussianActorHead  # noqa: E402
 from xuance.torch.rl_models.heads.critic_head import ValueHead  # noqa: E402
@@ -193,7 +193,7 @@ def run_learner_updates(learner, model, cb, batches, call):
     return out
 
 
-def golden_ppo(dist):
+def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo"):
     torch.manual_seed(1)
     rng = np.random.default_rng(5)
     act_fn = nn.LeakyReLU if dist == "categorical" else nn.ReLU
@@ -219,7 +219,10 @@ def golden_ppo(dist):
             if n.endswith("bias"):
                 p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.1))
     cb = Capture()
-    learner = PPO_Learner(cfg, model, cb)
+    if name == "a2c":
+        cfg.running_steps = 40          # the LinearLR horizon of a2c_learner.py:21; short so the decay is visible
+        cfg.end_factor_lr_decay = 0.5
+    learner = learner_cls(cfg, model, cb)
     batches = []
     for u in range(3):
         obs = np.clip(rng.standard_normal((bs, D)), -5, 5).astype(np.float32)
@@ -243,8 +246,9 @@ def golden_ppo(dist):
                               batch_size=len(b["obs"]))
     out = run_learner_updates(learner, model, cb, batches, call)
     out["cfg"] = np.array([cfg.learning_rate, cfg.vf_coef, cfg.ent_coef, cfg.clip_range, cfg.grad_clip_norm,
-                           getattr(cfg, "end_factor_lr_decay", 1.0), learner.total_iters])
-    np.savez_compressed(os.path.join(OUT, f"ppo_{dist}.npz"), **out)
+                           getattr(cfg, "end_factor_lr_decay", 1.0),
+                           cfg.running_steps if name == "a2c" else learner.total_iters])
+    np.savez_compressed(os.path.join(OUT, f"{name}_{dist}.npz"), **out)
 
 
 # ------------------------------------------------------------------------------ DQN
@@ -363,6 +367,8 @@ if __name__ == "__main__":
     golden_rms()
     golden_ppo("categorical")
     golden_ppo("gaussian")
+    golden_ppo("categorical", A2C_Learner, "a2c")
+    golden_ppo("gaussian", A2C_Learner, "a2c")
     golden_dqn("mlp")
     golden_dqn("cnn")
     golden_dqn("mlp", DDQN_Learner, "ddqn")

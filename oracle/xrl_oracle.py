@@ -363,8 +363,9 @@ def actor_critic_forward(sd, obs, dist="categorical", act="leaky_relu", activati
     return MLP(actor_l).forward(h), MLP(critic_l).forward(h)[:, 0]
 
 
-def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", activation_action=None):
-    """Forward + loss + backward of PPO_Learner.update (ppo_learner.py:46-62).
+def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", activation_action=None, loss_kind="ppo"):
+    """Forward + loss + backward of PPO_Learner.update (ppo_learner.py:46-62); with loss_kind="a2c" of
+    A2C_Learner.update (a2c_learner.py:41-53): a_loss = -(adv * log_prob).mean(), no ratio / old_logp.
 
     sd: dict name->np.ndarray in the reference's state_dict naming.
     batch: obs, actions, returns, advantages, old_logp.
@@ -381,8 +382,10 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
     out_a = actor.forward(h)
     v = critic.forward(h)[:, 0]
     B = obs.shape[0]
-    adv, ret, old_logp = batch["advantages"].astype(dt), batch["returns"].astype(dt), batch["old_logp"].astype(dt)
-    clip = dt(cfg["clip_range"])
+    adv, ret = batch["advantages"].astype(dt), batch["returns"].astype(dt)
+    a2c = loss_kind == "a2c"
+    old_logp = np.zeros(B, dt) if a2c else batch["old_logp"].astype(dt)
+    clip = dt(cfg.get("clip_range", 0.0))
 
     if dist == "categorical":
         a = batch["actions"].astype(np.int64)
@@ -404,6 +407,8 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
     s1 = np.clip(ratio, 1 - clip, 1 + clip) * adv                       # :53
     s2 = adv * ratio                                                    # :54
     a_loss = -np.minimum(s1, s2).mean()                                 # :55
+    if a2c:
+        a_loss = -(adv * logp).mean()                                   # a2c_learner.py:47
     c_loss = ((v - ret) ** 2).mean()                                    # :57
     e_loss = ent.mean()                                                 # :59
     loss = a_loss - dt(cfg["ent_coef"]) * e_loss + dt(cfg["vf_coef"]) * c_loss   # :60
@@ -418,6 +423,8 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
     w2 = dt(1) - w1
     dratio = -(w1 * inside * adv + w2 * adv) * invB
     dlogp = dratio * ratio
+    if a2c:
+        dlogp = -adv * invB
     dv = dt(cfg["vf_coef"]) * 2 * (v - ret) * invB
     grads = {}
     if dist == "categorical":

@@ -422,3 +422,43 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle):
     for k_, val in sd.items():
         assert_close(npy(got[k_]), val, 2e-5, f"param {k_}")
     assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_a2c_agent_vs_oracle(oracle, use_graph):
+    """A2C_Agent (a2c_agent.py:18-79 + a2c_learner.py:34-90) on the device CartPole: ActorCritic model with one trunk
+    per head, the rollout kernels shared with PPO, one whole-buffer update per rollout; the oracle replays the update
+    on the device's own rollout data."""
+    from xuance_amd.agents import A2C_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(0)
+    n, T = 16, 16
+    cfg = make_config(n, T, n_epochs=1, n_minibatch=1, running_steps=4000, end_factor_lr_decay=0.5, use_hip_graph=use_graph)
+    agent = A2C_Agent(cfg, DeviceCartPoleVecEnv(n, seed=5))
+    assert list(agent.model.plan.widths) == [4, 256, 256, 3] and agent.learner.loss_mode == 1
+    sd = {k: npy(v) for k, v in agent.model.state_dict().items()}
+    opt = oracle.AdamOracle(sd, lr=4e-4, eps=1e-5, end_factor=0.5, total_iters=4000)
+    c = dict(vf_coef=0.25, ent_coef=0.01, use_grad_clip=True, grad_clip_norm=0.5)
+    for it in range(3 if use_graph else 2):                       # the third pass replays the captured graphs
+        agent.rollout()
+        torch.cuda.synchronize()
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        logits, v = oracle.actor_critic_forward(sd, f["observations"].reshape(-1, 4))
+        assert_close(f["values"].reshape(-1), v, 1e-5, "values")
+        idx = np.random.default_rng(it).permutation(n * T).reshape(1, -1)
+        agent.set_indices(idx)
+        info = agent.update()
+        buf = oracle.OnPolicyBufferOracle((4,), (), n, T)
+        buf.size = T
+        buf.observations, buf.actions = f["observations"].transpose(1, 0, 2), f["actions"].T
+        buf.returns, buf.values, buf.advantages, buf.old_logp = f["returns"].T, f["values"].T, f["advantages"].T, f["aux_old_logp"].T
+        s = buf.sample(idx[0])
+        oi, _ = oracle.ppo_update(sd, opt, dict(obs=s["obs"], actions=s["actions"], returns=s["returns"],
+                                                advantages=s["advantages"]), c, loss_kind="a2c")
+        got = agent.model.state_dict()
+        for k_, val in sd.items():
+            assert_close(npy(got[k_]), val, 2e-5, f"param {k_} after update {it}")
+        assert_close(info["actor-loss"], oi["a_loss"], 1e-5, "actor-loss")
+        assert_close(info["critic-loss"], oi["c_loss"], 1e-5, "critic-loss")
+        assert_close(info["learning_rate"], oi["learning_rate"], 1e-9, "lr")
+    assert "clip_ratio" not in info

@@ -24,9 +24,9 @@ class Capture:
         return {}
 
 
-def make_learner(dist, g):
+def make_learner(dist, g, cls_name="PPO_Learner"):
     from xuance_amd.nets import ActorCriticNet
-    from xuance_amd.learners import PPO_Learner
+    from xuance_amd.learners import REGISTRY_Learners
     lr, vf, ent, clip, gclip, ef, total = g["cfg"]
     if dist == "categorical":
         net = ActorCriticNet(4, 2, "categorical", (128,), (128,), (128,), "leaky_relu")
@@ -38,9 +38,43 @@ def make_learner(dist, g):
                         use_grad_clip=True, grad_clip_norm=float(gclip), end_factor_lr_decay=float(ef),
                         distributed_training=False, device="cuda", model_dir="/tmp/xrl_models")
     cb = Capture()
-    learner = PPO_Learner(cfg, net, cb)
+    if cls_name == "A2C_Learner":
+        cfg.running_steps = int(total)                             # the fixture's LinearLR horizon (a2c_learner.py:21)
+    learner = REGISTRY_Learners[cls_name](cfg, net, cb)
     assert learner.total_iters == int(total)
     return net, learner, cb
+
+
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+def test_a2c_learner_vs_reference_fixture(dist):
+    """A2C_Learner (first on-policy sibling of SURVEY 8f): xrl_ppo_loss_* in mode 1 + the same backward / clip / Adam
+    launches, against the unmodified reference's a2c_learner.py run (tests/golden/a2c_*.npz)."""
+    g = load_golden(f"a2c_{dist}")
+    net, learner, cb = make_learner(dist, g, "A2C_Learner")
+    net.load_state_dict(sub(g, "init"))
+    for u in range(3):
+        b = sub(g, f"u{u}/batch")
+        info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
+                              advantages=b["advantages"], batch_size=len(b["obs"]))
+        ref_info, ref_cb = sub(g, f"u{u}/info"), sub(g, f"u{u}/cb")
+        assert set(info) == set(ref_info)                          # the reference's key spelling ("actor-loss", ...)
+        for k in ("actor-loss", "critic-loss", "entropy", "predict_value"):
+            assert_close(info[k], ref_info[k], 1e-5, k)
+        assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "lr")
+        rec = cb.records[-1]
+        lp_scale = max(1.0, float(np.abs(ref_cb["log_prob"]).max()))
+        assert_close(rec["v_pred"], ref_cb["v_pred"], 1e-5, "v_pred")
+        assert_close(rec["log_prob"], ref_cb["log_prob"], 1e-6, "log_prob", scale=lp_scale)
+        assert_close(rec["loss"], ref_cb["loss"], 1e-5, "loss")
+        for k, rg in sub(g, f"u{u}/grad").items():
+            assert_close(net.params.view(k, learner.optimizer.grad).cpu().numpy(), rg, 2e-5, f"grad {k}")
+        sd = net.state_dict()
+        for k, rp in sub(g, f"u{u}/param").items():
+            assert_close(sd[k].cpu().numpy(), rp, 1e-5, f"param {k} after update {u}")
+    osd = learner.optimizer.state_dict()
+    for i, k in enumerate(net.ref_order):
+        assert_close(osd["state"][i]["exp_avg"].cpu().numpy(), g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
+        assert_close(osd["state"][i]["exp_avg_sq"].cpu().numpy(), g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
 
 
 @pytest.mark.parametrize("dist", ["categorical", "gaussian"])

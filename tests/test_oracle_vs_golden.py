@@ -123,6 +123,31 @@ def test_ppo_update(oracle, dist):
     assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")
 
 
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+def test_a2c_update(oracle, dist):
+    """A2C_Learner.update (a2c_learner.py:34-90) replayed by the oracle against the reference's own run."""
+    g = load_golden(f"a2c_{dist}")
+    lr, vf, ent, clip, gclip, ef, total = g["cfg"]
+    cfg = dict(vf_coef=vf, ent_coef=ent)
+    act = "leaky_relu" if dist == "categorical" else "relu"
+    aa = None if dist == "categorical" else "tanh"
+    opt_kwargs_clip["clip"] = gclip
+    fb = lambda sd, b: oracle.ppo_forward_backward(sd, b, cfg, dist=dist, act=act, activation_action=aa, loss_kind="a2c")
+    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
+        cb, ref_info = sub(g, f"u{u}/cb"), sub(g, f"u{u}/info")
+        lp_scale = max(1.0, float(np.abs(cb["log_prob"]).max()))
+        for k in ("v_pred", "a_loss", "c_loss", "e_loss"):
+            assert_close(info[k], cb[k], 1e-5, k)
+        assert_close(info["log_prob"], cb["log_prob"], 1e-6, "log_prob", scale=lp_scale)
+        assert_close(info["a_loss"], ref_info["actor-loss"], 1e-5)
+        assert_close(info["predict_value"], ref_info["predict_value"], 1e-5)
+    for k in [str(n) for n in g["param_names"]]:
+        assert_close(opt.m[k], g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
+        assert_close(opt.v[k], g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
+    assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")
+    assert opt.lr < lr                                            # the short LinearLR horizon of the fixture is visible
+
+
 @pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp"])
 def test_dqn_mlp_update(oracle, name):
     """dqn_mlp: DQN_Learner (dqn_learner.py:28-75); ddqn_mlp: DDQN_Learner (ddqn_learner.py:28-75), same network."""

@@ -30,7 +30,7 @@ class PpoLoss(C.Structure):
                 ("d_value", c_void_p), ("d_log_std", c_void_p), ("diag", c_void_p), ("partials", c_void_p),
                 ("M", c_int32), ("A", c_int32), ("ld_out", c_int32), ("ld_v", c_int32), ("out_act", c_int32),
                 ("n_split", c_int32), ("slab_stride", c_int64), ("clip_range", c_float), ("vf_coef", c_float),
-                ("ent_coef", c_float), ("pad", c_float)]
+                ("ent_coef", c_float), ("mode", c_int32)]
 
 
 class AdamState(C.Structure):

@@ -339,3 +339,23 @@ class PPO_Agent:
 
     def finish(self):
         self.envs.close()
+
+
+class A2C_Agent(PPO_Agent):
+    """Advantage actor-critic agent (xuance/torch/agents/policy_gradient/a2c_agent.py:18-79): the on-policy loop of
+    PPO_Agent with A2C_Learner, no auxiliary buffer fields the learner reads, and the reference's ActorCritic model
+    (actor and critic each own a copy of the representation, :41-77) -- here one trunk per head, i.e. the
+    representation's layers prepended to each head's hidden layers."""
+
+    def _build_model(self):
+        c = self.config
+        discrete = is_discrete(self.action_space)
+        rep = list(_get(c, "representation_hidden_size", []) or []) if _get(c, "representation", "Basic_MLP") != "Basic_Identical" else []
+        return ActorCriticNet(self.obs_dim, self.action_space.n if discrete else int(self.action_space.shape[0]),
+                              "categorical" if discrete else "gaussian", [], rep + list(c.actor_hidden_size),
+                              rep + list(c.critic_hidden_size), _get(c, "activation", "leaky_relu"),
+                              None if discrete else _get(c, "activation_action", "tanh"), device=self.device)
+
+    def _build_learner(self, *args):
+        from ..learners.ppo_learner import A2C_Learner
+        return A2C_Learner(*args)

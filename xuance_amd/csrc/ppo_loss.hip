@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
         const float* o = p.out + (size_t)m * p.ld_out;
         float adv = p.adv[m];
         if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, mean), denom);
-        const float ret = p.returns[m], v = p.value[(size_t)m * p.ld_v], oldlp = p.old_logp[m];
+        const float ret = p.returns[m], v = p.value[(size_t)m * p.ld_v], oldlp = p.mode == 1 ? 0.f : p.old_logp[m];
         float logp, ent;
         if (!GAUSSIAN) {
             const int a = (int)p.actions[m];
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
             logp = o[a] - lse;
             ent = 0.f;
             for (int j = 0; j < A; ++j) { const float l = o[j] - lse; ent -= expf(l) * l; }
-            const Surrogate s = surrogate(logp, oldlp, adv, lo, hi, invM);
+            const Surrogate s = p.mode == 1 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM);
             float* dq = p.d_out + (size_t)m * p.ld_out;
             const float ce = p.ent_coef * invM;
             for (int j = 0; j < A; ++j) {
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
                 logp += -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;     // Normal.log_prob, summed (:179-180)
                 ent += 0.5f + LOG_SQRT_2PI + logf(sd);                           // Normal.entropy, summed (:182-183)
             }
-            const Surrogate s = surrogate(logp, oldlp, adv, lo, hi, invM);
+            const Surrogate s = p.mode == 1 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM);
             float* dq = p.d_out + (size_t)m * p.ld_out;
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(64) sum_partials_kernel(const double* __restri
 
 static int check(const xrl_ppo_loss_t* p, bool gaussian) {
     XRL_CHECK_ARG(p != nullptr);
-    XRL_CHECK_ARG(p->out && p->value && p->actions && p->adv && p->returns && p->old_logp && p->d_out && p->d_value && p->partials);
+    XRL_CHECK_ARG(p->out && p->value && p->actions && p->adv && p->returns && (p->old_logp || p->mode == 1) && p->d_out && p->d_value && p->partials);
+    XRL_CHECK_ARG(p->mode == 0 || p->mode == 1);
     XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->A <= (gaussian ? 32 : 4096) && p->ld_out >= p->A && p->ld_v >= 1);
     XRL_CHECK_ARG(p->n_split >= 1);
     if (gaussian) XRL_CHECK_ARG(p->log_std != nullptr);

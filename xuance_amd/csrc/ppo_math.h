@@ -27,5 +27,15 @@ __device__ __forceinline__ Surrogate surrogate(float logp, float old_logp, float
     return r;
 }
 
+// A2C actor term (a2c_learner.py:47): a_loss = -(adv * log_prob).mean().  Reported through the same fields: s1 = s2 =
+// adv * log_prob (so that -sum(min(s1, s2))/M is the loss), d a_loss / d log_prob = -adv / M, nothing is ever clipped.
+__device__ __forceinline__ Surrogate surrogate_a2c(float logp, float adv, float invM) {
+    Surrogate r;
+    r.ratio = 1.f;
+    r.s1 = r.s2 = adv * logp;
+    r.dlogp = -adv * invM;
+    r.clipped = 0;
+    return r;
+}
 
 }  // namespace xrl

@@ -26,6 +26,7 @@ class PPO_Learner(Learner):
         self.sumsq = torch.zeros(128, dtype=torch.float64, device=dev)
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
         self.keep_diag = True     # keep the per-sample callback tensors (log_prob, ratio, surrogates)
+        self.loss_mode = 0        # xrl_ppo_loss_t.mode: 0 PPO-clip, 1 A2C (see A2C_Learner)
 
     def estimate_total_iterations(self):                        # ppo_learner.py:28-33
         buffer_size = self.config.horizon_size * self.config.parallels
@@ -61,7 +62,7 @@ class PPO_Learner(Learner):
                   old_logp=old_logp.data_ptr(), d_out=d_heads.data_ptr(), d_value=d_heads.data_ptr() + 4 * A,
                   diag=self.diag.data_ptr() if self.keep_diag else None, partials=self.partials.data_ptr(),
                   M=M, A=A, ld_out=model.head_ld, ld_v=model.head_ld, n_split=S, slab_stride=model.params.P,
-                  clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
+                  clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef, mode=self.loss_mode)
         if model.dist == "gaussian":
             kw.update(log_std=model.params.ptr("actor.log_std"),
                       d_log_std=self.slabs.data_ptr() + 4 * model.params.offsets["actor.log_std"],
@@ -272,5 +273,49 @@ class PPO_Learner(Learner):
                   e_loss=info[self._key("entropy")])
         cb["loss"] = cb["a_loss"] - self.ent_coef * cb["e_loss"] + self.vf_coef * cb["c_loss"]
         cb["a_dist"] = heads[:M, :A]
+        info.update(self.callback.on_update_end(self.iterations, **cb) or {})
+        return info
+
+
+class A2C_Learner(PPO_Learner):
+    """Advantage actor-critic (xuance/torch/learners/policy_gradient/a2c_learner.py:11-90): the PPO machinery with the
+    actor term -(adv * log_prob).mean() instead of the clipped surrogate (xrl_ppo_loss_t.mode = 1), no old log-prob, the
+    reference's info keys (`actor-loss`, `critic-loss`, ...) and its LinearLR horizon (total_iters = running_steps, :19-21).
+    Always the layered path (the fused minibatch kernel implements the PPO-clip loss only)."""
+
+    def __init__(self, config, model, callback=None):
+        if not hasattr(config, "clip_range"):
+            config.clip_range = 0.0
+        super().__init__(config, model, callback)
+        self.loss_mode = 1
+
+    def estimate_total_iterations(self):                        # a2c_learner.py:19-21: total_iters=self.config.running_steps
+        return int(self.config.running_steps)
+
+    def fused_eligible(self, memory):
+        return False
+
+    def _info(self, M, S, partials=None):
+        i = super()._info(M, S, partials)
+        k = self._key
+        return {k("actor-loss"): i[k("actor_loss")], k("critic-loss"): i[k("critic_loss")], k("entropy"): i[k("entropy")],
+                k("learning_rate"): i[k("learning_rate")], k("predict_value"): i[k("predict_value")]}
+
+    def update(self, **samples):                                  # a2c_learner.py:34-90
+        self.iterations += 1
+        obs = self._as_dev(samples["obs"])
+        act, ret, adv = self._as_dev(samples["actions"]), self._as_dev(samples["returns"]), self._as_dev(samples["advantages"])
+        M = obs.shape[0]
+        obs = obs.reshape(M, -1)
+        self._ensure(M)
+        info = self.callback.on_update_start(self.iterations, model=self.model, obs=obs, act=act, returns=ret,
+                                             advantages=adv) or {}
+        S = self._step(obs, obs.shape[1], act, ret, adv, adv, M)     # (old_logp is not read in mode 1)
+        info.update(self._info(M, S))
+        heads = self.model.plan.acts[len(self.model.plan.widths) - 1]
+        A = self.model.action_dim
+        cb = dict(model=self.model, info=info, v_pred=heads[:M, A], log_prob=self.diag.view(-1)[0:M],
+                  a_loss=info[self._key("actor-loss")], c_loss=info[self._key("critic-loss")], e_loss=info[self._key("entropy")])
+        cb["loss"] = cb["a_loss"] - self.ent_coef * cb["e_loss"] + self.vf_coef * cb["c_loss"]
         info.update(self.callback.on_update_end(self.iterations, **cb) or {})
         return info
