@@ -360,6 +360,105 @@ def golden_qmix(double_q):
     np.savez_compressed(os.path.join(OUT, f"qmix_ff_{'double' if double_q else 'single'}.npz"), **out)
 
 
+def golden_qmix_rnn(double_q=True, fixed=False):
+    """QMIX_Learner.update with recurrent agents (3m.yaml defaults: Basic_RNN fc 64 + GRU 64, q_hidden 64) on episode
+    samples in the layout MARL_OffPolicyBuffer_RNN.sample returns (memory_tools_marl.py:970-996).
+
+    fixed=False: the UNMODIFIED reference, use_actions_mask off.  Two properties of the unmodified recurrent branch:
+      (1) with use_actions_mask on it cannot run at all: iql_learner.py:78 slices the AGENT axis
+          (`avail_actions.group(group)[:, 1:]` on a [B, N, T+1, A] tensor) and line 81 raises IndexError
+          (mask [B, N-1, T+1, A] vs values [B, N, T, A]);
+      (2) iql_learner.py:58 re-slices q_eval (`v[:, :, :-1]`) INSIDE `with torch.no_grad()` (:49), so q_eval reaches the
+          loss detached: the agent networks (fc, GRU, Q head) receive no gradient, only the mixer trains.
+    fixed=True runs a subclass that restates _forward_transitions with exactly those two lines changed (time-axis
+    slice `[:, :, 1:]`; q_eval sliced outside no_grad) -- the algorithm the surrounding code implies.  The fixture
+    name says so (`..._fixed`); it pins the full back-propagation-through-time path."""
+    from xuance.torch.rl_models.critics.base_critics import DiscreteActionValueCritic
+    from xuance.torch.rl_models.representations.agent_feature import AgentFeatureEncoder
+    from xuance.torch.rl_models.representations import Basic_RNN
+    from xuance.torch.rl_models.modules.identity_encoder import build_identity_encoder, IdentityFeatureFusion
+    torch.manual_seed(4)
+    rng = np.random.default_rng(17)
+    N, O, S, A, B, T = 3, 30, 48, 9, 8, 12
+    agent_keys = [f"agent_{i}" for i in range(N)]
+    grouping = AgentGrouping.shared(agent_keys)
+    group = grouping.group_keys[0]
+    init = torch.nn.init.orthogonal_
+    obs_rep = Basic_RNN((O,), None, None, init, nn.ReLU, "cpu", fc_hidden_sizes=[64], recurrent_hidden_size=64,
+                        N_recurrent_layers=1, dropout=0, rnn="GRU")
+    ident = build_identity_encoder(num_identities=N, mode="none", embedding_dim=None, device="cpu")
+    fusion = IdentityFeatureFusion(observation_feature_dim=64, identity_feature_dim=ident.output_dim, mode="concat")
+    rep = AgentFeatureEncoder(representation=obs_rep, identity_encoder=ident, fusion=fusion)
+    critic = DiscreteActionValueCritic(representation=rep, action_space=sp.Discrete(A), critic_hidden_size=[64],
+                                       normalizer=None, initializer=init, activation=nn.ReLU, device="cpu")
+    mixer = QMIX_Mixer(S, 32, 32, N, "cpu")
+    model = MixingQNetwork(grouping, nn.ModuleDict({group: critic}), mixer, use_rnn=True, device="cpu")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("target_"):
+                p.add_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.05))
+            elif "bias" in n and "rnn" in n:            # GRU biases are initialised to 0: make their paths non-trivial
+                p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.1))
+    cfg = base_config(learning_rate=7e-4, gamma=0.99, sync_frequency=2, start_training=0, training_frequency=1,
+                      use_parameter_sharing=True, double_q=double_q, use_actions_mask=fixed, use_rnn=True,
+                      n_epochs=8, grad_clip_norm=10.0, episode_length=T, parallels=4, running_steps=4800)
+    cb = Capture()
+    cls = QMIX_Learner
+    if fixed:
+        class QMIX_Learner_Fixed(QMIX_Learner):
+            def _forward_transitions(self, batch):                # iql_learner.py:37-83, recurrent branch, two lines changed
+                rnn_states = self.model.init_rnn_states(batch.batch_size)
+                out = self.model(observations=batch.observations, agent_indices=batch.agent_indices,
+                                 avail_actions=batch.avail_actions, rnn_states=rnn_states)
+                q_eval = out.values
+                q_eval.grouped_tensor = {k: v[:, :, :-1] for k, v in q_eval.grouped_tensor.items()}     # outside no_grad
+                with torch.no_grad():
+                    actions_next = out.actions
+                    q_next = self.model.Qtarget(observations=batch.observations, agent_indices=batch.agent_indices,
+                                                rnn_states=rnn_states).values
+                    q_next.grouped_tensor = {k: v[:, :, 1:] for k, v in q_next.grouped_tensor.items()}
+                    actions_next.grouped_tensor = {k: v[:, :, 1:] for k, v in actions_next.grouped_tensor.items()}
+                for g_ in self.group_keys:
+                    q_next.group(g_)[batch.avail_actions.group(g_)[:, :, 1:] == 0] = -1e10                # time axis
+                return q_eval, q_next, actions_next
+        cls = QMIX_Learner_Fixed
+    learner = cls(cfg, grouping, model, cb)
+    batches, samples = [], []
+    for u in range(3):
+        avail = (rng.random((B, N, T + 1, A)) < 0.7)
+        avail[..., 0] = True
+        acts = np.zeros((B, N, T), np.float32)
+        for b in range(B):
+            for i in range(N):
+                for t in range(T):
+                    acts[b, i, t] = rng.choice(np.flatnonzero(avail[b, i, t]))
+        lengths = rng.integers(3, T + 1, B)
+        lengths[0] = T
+        filled = np.arange(T)[None, :] < lengths[:, None]
+        term = np.zeros((B, N, T), bool)
+        for b in range(B):
+            if b % 2 == 0:
+                term[b, :, lengths[b] - 1] = True               # episode ended by termination (all agents)
+            else:
+                term[b, 0, lengths[b] - 1] = True               # only one agent: terminals_tot stays 0 (truncation)
+        b = dict(obs=rng.standard_normal((B, N, T + 1, O)).astype(np.float32), actions=acts,
+                 rewards=rng.standard_normal((B, N, T)).astype(np.float32), terminals=term,
+                 agent_mask=(rng.random((B, N, T)) < 0.85), avail_actions=avail,
+                 state=rng.standard_normal((B, T + 1, S)).astype(np.float32), filled=filled)
+        batches.append(b)
+        sample = {k: {a: b[k][:, i] for i, a in enumerate(agent_keys)}
+                  for k in ("obs", "actions", "rewards", "terminals", "agent_mask", "avail_actions")}
+        sample.update(state=b["state"], filled=b["filled"], batch_size=B, sequence_length=T)
+        samples.append(sample)
+    it = iter(samples)
+    out = run_learner_updates(learner, model, cb, batches, lambda b: learner.update(next(it)))
+    out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm, float(double_q),
+                           learner.total_iters])
+    out["group"] = np.array(group)
+    np.savez_compressed(os.path.join(OUT, f"qmix_rnn_{'double' if double_q else 'single'}{'_fixed' if fixed else ''}.npz"),
+                        **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_onpolicy_buffer()
@@ -374,5 +473,8 @@ if __name__ == "__main__":
     golden_dqn("mlp", DDQN_Learner, "ddqn")
     golden_qmix(True)
     golden_qmix(False)
+    golden_qmix_rnn(True)
+    golden_qmix_rnn(False)
+    golden_qmix_rnn(True, fixed=True)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

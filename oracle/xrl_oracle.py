@@ -687,6 +687,145 @@ def qmix_forward_backward(sd, batch, cfg, act="relu", group="shared"):
     return info, grads
 
 
+# --------------------------------------------------------------------------------------
+# GRU (torch.nn.GRU, one layer, batch_first; third-party arithmetic: PyTorch ATen gru cell --
+#   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr); z = sigmoid(W_iz x + b_iz + W_hz h + b_hz);
+#   n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h' = (h - n) * z + n
+# -- used by Basic_RNN, representations/rnn.py:52-77, built by layers.py:79-98)
+# --------------------------------------------------------------------------------------
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def gru_forward(x, h0, w_ih, w_hh, b_ih, b_hh):
+    """x [R,T,I], h0 [R,H] -> hs [R,T,H] + cache for gru_backward."""
+    R, T, _ = x.shape
+    H = w_hh.shape[1]
+    dt = x.dtype.type
+    gi = x @ w_ih.T + b_ih                                               # [R,T,3H]
+    hs = np.zeros((R, T, H), x.dtype)
+    gates = np.zeros((R, T, 4 * H), x.dtype)                             # r, z, n, (W_hn h + b_hn)
+    h = h0.astype(x.dtype)
+    for t in range(T):
+        gh = h @ w_hh.T + b_hh
+        r = _sigmoid(gi[:, t, :H] + gh[:, :H]).astype(x.dtype)
+        z = _sigmoid(gi[:, t, H:2 * H] + gh[:, H:2 * H]).astype(x.dtype)
+        n = np.tanh(gi[:, t, 2 * H:] + r * gh[:, 2 * H:]).astype(x.dtype)
+        gates[:, t] = np.concatenate([r, z, n, gh[:, 2 * H:]], -1)
+        h = ((h - n) * z + n).astype(x.dtype)
+        hs[:, t] = h
+    return hs, dict(x=x, h0=h0.astype(x.dtype), hs=hs, gates=gates, w_ih=w_ih, w_hh=w_hh)
+
+
+def gru_backward(cache, dhs):
+    """dhs [R,T,H] = d loss / d hs.  Returns (dx [R,T,I], dict of parameter gradients w_ih, w_hh, b_ih, b_hh)."""
+    x, hs, gates, w_ih, w_hh = cache["x"], cache["hs"], cache["gates"], cache["w_ih"], cache["w_hh"]
+    R, T, _ = x.shape
+    H = w_hh.shape[1]
+    dgi = np.zeros((R, T, 3 * H), x.dtype)
+    dgh = np.zeros((R, T, 3 * H), x.dtype)
+    carry = np.zeros((R, H), x.dtype)
+    for t in reversed(range(T)):
+        r, z, n, hn = (gates[:, t, i * H:(i + 1) * H] for i in range(4))
+        hp = hs[:, t - 1] if t > 0 else cache["h0"]
+        dh = dhs[:, t] + carry
+        dn_pre = dh * (1 - z) * (1 - n * n)
+        dz_pre = dh * (hp - n) * z * (1 - z)
+        dr_pre = dn_pre * hn * r * (1 - r)
+        dgi[:, t] = np.concatenate([dr_pre, dz_pre, dn_pre], -1)
+        dgh[:, t] = np.concatenate([dr_pre, dz_pre, dn_pre * r], -1)
+        carry = (dh * z + dgh[:, t] @ w_hh).astype(x.dtype)
+    hprev = np.concatenate([cache["h0"][:, None], hs[:, :-1]], 1)
+    g = dict(w_ih=dgi.reshape(-1, 3 * H).T @ x.reshape(R * T, -1), b_ih=dgi.reshape(-1, 3 * H).sum(0),
+             w_hh=dgh.reshape(-1, 3 * H).T @ hprev.reshape(R * T, H), b_hh=dgh.reshape(-1, 3 * H).sum(0))
+    return dgi @ w_ih, g
+
+
+def qmix_rnn_agent_forward(sd, prefix, obs, act="relu"):
+    """DiscreteActionValueCritic(AgentFeatureEncoder(Basic_RNN)) over whole sequences from zero hidden state
+    (base_critics.py:125-132, rnn.py:52-77, iql_learner.py:39-47).  obs [R,T1,O] -> Q [R,T1,A] + caches."""
+    rp = f"{prefix}.representation.obs_representation"
+    fc_l = collect_seq(sd, f"{rp}.mlp", act, last_act=act)
+    q_l = collect_seq(sd, f"{prefix}.critic_head.q_value", act)
+    R, T1, O = obs.shape
+    fc, q = MLP(fc_l), MLP(q_l)
+    f = fc.forward(obs.reshape(R * T1, O)).reshape(R, T1, -1) if fc_l else obs
+    hs, gc = gru_forward(f, np.zeros((R, sd[f"{rp}.rnn.weight_hh_l0"].shape[1]), obs.dtype), sd[f"{rp}.rnn.weight_ih_l0"],
+                         sd[f"{rp}.rnn.weight_hh_l0"], sd[f"{rp}.rnn.bias_ih_l0"], sd[f"{rp}.rnn.bias_hh_l0"])
+    Q = q.forward(hs.reshape(R * T1, -1)).reshape(R, T1, -1)
+    return Q, dict(fc=fc, fc_l=fc_l, q=q, q_l=q_l, gru=gc, rp=rp, hs=hs)
+
+
+def qmix_rnn_forward_backward(sd, batch, cfg, act="relu", group="shared"):
+    """QMIX_Learner.update, recurrent branch (qmix_learner.py:24-112 with iql_learner.py:37-83, use_rnn), one group.
+
+    batch (stacked MARL_OffPolicyBuffer_RNN.sample, memory_tools_marl.py:970-996): obs [B,N,T+1,O], actions [B,N,T],
+    rewards [B,N,T], terminals [B,N,T], agent_mask [B,N,T], avail_actions [B,N,T+1,A] (when use_actions_mask),
+    state [B,T+1,S], filled [B,T].
+    cfg["agent_grad"] (default False = the unmodified reference): iql_learner.py:58 re-slices q_eval inside
+    torch.no_grad(), so the agent networks get NO gradient (only the mixer trains); True = gradient flows through the
+    Q head, the GRU (BPTT) and the fc layer.  The action mask of step t+1 is applied on the TIME axis (the reference's
+    iql_learner.py:78 slices the agent axis and raises IndexError).  Both deviations are pinned by the `_fixed`
+    fixture, see oracle/make_golden.py golden_qmix_rnn."""
+    dt = np.float32
+    pe, pt = f"individual_q_networks.{group}", f"target_individual_q_networks.{group}"
+    B, N, T1, O = batch["obs"].shape
+    T = T1 - 1
+    obs = batch["obs"].reshape(B * N, T1, O).astype(dt)
+    Q, c = qmix_rnn_agent_forward(sd, pe, obs, act)                      # iql_learner.py:41-47
+    A = Q.shape[-1]
+    Qt, _ = qmix_rnn_agent_forward(sd, pt, obs, act)                     # :53-57
+    use_mask = cfg.get("use_actions_mask", True)
+    avail = batch["avail_actions"].reshape(B * N, T1, A) if use_mask else None
+    qd = Q.copy()
+    if use_mask:
+        qd[avail == 0] = -1e10                                           # value_factorization.py:87-90
+    a_next = qd.argmax(-1)[:, 1:]                                        # iql_learner.py:51,60
+    q_eval, q_next = Q[:, :-1], Qt[:, 1:].copy()                         # :58-59
+    if use_mask:
+        q_next[avail[:, 1:] == 0] = -1e10                                # :76-81 (time axis)
+    rewards_tot = batch["rewards"].astype(dt).mean(1)                    # qmix_learner.py:34  [B,T]
+    terminals_tot = batch["terminals"].astype(bool).all(1).astype(dt)    # :35
+    filled = batch["filled"].astype(dt)                                  # [B,T]
+    mask = (batch["agent_mask"].astype(dt) * filled[:, None, :]).reshape(B * N, T)   # outputs.py:138-143
+    a_taken = batch["actions"].reshape(B * N, T).astype(np.int64)
+    q_eval_taken = np.take_along_axis(q_eval, a_taken[..., None], -1)[..., 0]        # :48-50
+    if cfg.get("double_q", True):
+        q_next_taken = np.take_along_axis(q_next, a_next[..., None], -1)[..., 0]     # :52-55
+    else:
+        q_next_taken = q_next.max(-1)                                    # :57-58
+    qe = (q_eval_taken * mask).reshape(B, N, T).transpose(0, 2, 1).reshape(B * T, N)  # :60,64-66 + Q_tot reshape
+    qn = (q_next_taken * mask).reshape(B, N, T).transpose(0, 2, 1).reshape(B * T, N)
+    S = batch["state"].shape[-1]
+    q_tot_eval, cache = qmix_mixer_forward(sd, "eval_Qtot", qe, batch["state"][:, :-1].reshape(B * T, S).astype(dt))   # :69
+    q_tot_next, _ = qmix_mixer_forward(sd, "target_Qtot", qn, batch["state"][:, 1:].reshape(B * T, S).astype(dt))      # :70
+    target = rewards_tot.reshape(-1) + (1 - terminals_tot.reshape(-1)) * dt(cfg["gamma"]) * q_tot_next                 # :78
+    fl = filled.reshape(-1)
+    td = (q_tot_eval - target) * fl                                      # :83
+    loss = (td ** 2).sum() / fl.sum()                                    # :84
+    dq_tot = (2 * td * fl / fl.sum()).astype(dt)
+    dq_m, grads = qmix_mixer_backward(sd, "eval_Qtot", cache, dq_tot)
+    info = dict(q_eval=Q, q_target=Qt, q_tot_eval=q_tot_eval, q_tot_next=q_tot_next, q_tot_target=target, loss=loss,
+                predictQ=q_tot_eval.mean(), hs=c["hs"], actions_next=a_next)
+    if not cfg.get("agent_grad", False):
+        return info, grads
+    dq_taken = dq_m.reshape(B, T, N).transpose(0, 2, 1).reshape(B * N, T) * mask
+    dQ = np.zeros((B * N, T1, A), dt)
+    np.put_along_axis(dQ[:, :-1], a_taken[..., None], dq_taken[..., None], -1)
+    dhs, g_q = c["q"].backward(dQ.reshape(B * N * T1, A), need_dx=True)
+    for L, (gw, gb) in zip(c["q_l"], g_q):
+        grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    df, gg = gru_backward(c["gru"], dhs.reshape(B * N, T1, -1))
+    rp = c["rp"]
+    grads[f"{rp}.rnn.weight_ih_l0"], grads[f"{rp}.rnn.weight_hh_l0"] = gg["w_ih"], gg["w_hh"]
+    grads[f"{rp}.rnn.bias_ih_l0"], grads[f"{rp}.rnn.bias_hh_l0"] = gg["b_ih"], gg["b_hh"]
+    if c["fc_l"]:
+        _, g_fc = c["fc"].backward(df.reshape(B * N * T1, -1), need_dx=False)
+        for L, (gw, gb) in zip(c["fc_l"], g_fc):
+            grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    return info, grads
+
+
 def qmix_copy_target(sd):                                               # value_factorization.py:169-174
     for k in list(sd):
         if k.startswith("individual_q_networks."):

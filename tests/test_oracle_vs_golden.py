@@ -182,3 +182,30 @@ def test_qmix_ff_update(oracle, double_q):
             assert_close(info[k], cb[k], 1e-5, k)
         ref_info = sub(g, f"u{u}/info")
         assert_close(info["loss"], ref_info["loss_Q"], 1e-5, "loss_Q")
+
+
+@pytest.mark.parametrize("name", ["qmix_rnn_double", "qmix_rnn_single", "qmix_rnn_double_fixed"])
+def test_qmix_rnn_update(oracle, name):
+    """Recurrent QMIX: Basic_RNN fc+GRU agents over whole episodes, masked TD loss (qmix_learner.py:81-84).
+    The unmodified reference gives the agent networks no gradient here (q_eval is re-sliced under no_grad,
+    iql_learner.py:49,58) and cannot run with action masks (:78-81 raise); `*_fixed` was generated with those two lines
+    restated (oracle/make_golden.py) and pins back-propagation through time + the masked argmax.
+    (the ReLU/GRU arithmetic itself is PyTorch's in all three fixtures)"""
+    g = load_golden(name)
+    lr, gamma, sync, gclip, dq, total = g["cfg"]
+    opt_kwargs_clip["clip"] = gclip
+    fixed = name.endswith("fixed")
+    cfg = dict(gamma=gamma, double_q=bool(dq), use_actions_mask=fixed, agent_grad=fixed)
+    fb = lambda sd, b: oracle.qmix_rnn_forward_backward(sd, b, cfg, group=str(g["group"]))
+
+    def on_update(u, sd):
+        if (u + 1) % int(sync) == 0:
+            oracle.qmix_copy_target(sd)
+    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, total_iters=int(total)), oracle, on_update):
+        cb = sub(g, f"u{u}/cb")
+        for k in ("q_tot_eval", "q_tot_next", "q_tot_target"):
+            assert_close(info[k], cb[k], 1e-5, k)
+        ref_info = sub(g, f"u{u}/info")
+        assert_close(info["loss"], ref_info["loss_Q"], 1e-5, "loss_Q")
+        assert_close(info["predictQ"], ref_info["predictQ"], 1e-5, "predictQ")
+        assert any(k.startswith("individual_q_networks") for k in grads) == fixed
