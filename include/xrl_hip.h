@@ -514,8 +514,43 @@ typedef struct {
     double* partials;          /* [B][8]: (q_tot_eval-y)^2, q_tot_eval, 0... */
     int32_t B, N, A, H, ldq, ld_e1, ld_e2, ld_t1, ld_t2, double_q;
     float gamma, pad;
+    const float* filled;       /* NULL (feed-forward: MSE over B rows, qmix_learner.py:86) or [B] f32 0/1 step mask of the
+                                * recurrent branch (:60-61 valid_mask = agent_mask * filled, :82-84 loss =
+                                * sum((td * filled)^2) / sum(filled)); partials[b][2] = filled[b].  In that mode the B rows
+                                * are the (t, episode) pairs of a time-major batch and the "next" arrays are the same
+                                * arrays one time slot further (caller passes offset pointers). */
 } xrl_qmix_t;
 int xrl_qmix_mix_td(const xrl_qmix_t* p, xrl_stream_t stream);
+
+/* One-layer GRU over whole sequences, time-major (Basic_RNN, rl_models/representations/rnn.py:52-77; nn.GRU built by
+ * rl_models/modules/layers.py:79-98; the recurrent agents of qmix/sc2/3m.yaml).  gi = x W_ih^T + b_ih for all steps is
+ * the caller's GEMM (xrl_linear_fwd); this launch runs the serial part, one wavefront per sequence. H must be 64. */
+typedef struct {
+    const float* gi;      /* [T1][R][ld_gi]: input-side gate pre-activations r | z | n (3H values per row) */
+    const float* w_hh;    /* [3H][H]  weight_hh_l0 */
+    const float* b_hh;    /* [3H]     bias_hh_l0 */
+    const float* h0;      /* NULL (zeros: init_rnn_states, rnn.py:79-84) or [R][H] */
+    const float* reset;   /* NULL or [R] f32: != 0 -> start this row from zeros (init_rnn_states_item, rnn.py:86-92) */
+    float* hs;            /* [T1+1][R][H]: slot 0 = initial state, slot t+1 = h_t */
+    float* gates;         /* NULL or [T1][R][4H]: r | z | n | W_hn h + b_hn, kept for xrl_gru_backward */
+    float* h_last;        /* NULL or [R][H]: h_{T1-1} (may alias h0: the state carried between acting steps) */
+    int32_t R, T1, H, ld_gi;
+} xrl_gru_fwd_t;
+int xrl_gru_forward(const xrl_gru_fwd_t* p, xrl_stream_t stream);
+
+/* Back-propagation through time of xrl_gru_forward.  d_gi feeds the backward pass of the layers below (and dW_ih, db_ih);
+ * dW_hh = d_gh^T [hs slots 0..T1-1], db_hh = column sums of d_gh are the caller's GEMM (xrl_linear_bwd_weight). */
+typedef struct {
+    const float* d_hs;    /* [T1][R][ld_dhs] d loss / d h_t */
+    const float* hs;      /* [T1+1][R][H] from the forward pass */
+    const float* gates;   /* [T1][R][4H] from the forward pass */
+    const float* w_hh;    /* [3H][H] */
+    float* d_gi;          /* [T1][R][ld_dgi] */
+    float* d_gh;          /* [T1][R][3H] */
+    float* d_h0;          /* NULL or [R][H] */
+    int32_t R, T1, H, ld_dhs, ld_dgi, pad;
+} xrl_gru_bwd_t;
+int xrl_gru_backward(const xrl_gru_bwd_t* p, xrl_stream_t stream);
 
 /* Hard target update inside a captured graph: if (state->step % sync_frequency == 0) target <- params
  * (dqn_learner.py:56-57, qmix_learner.py:105-106; copy_target deep_q_network.py:95-99). */

@@ -88,7 +88,19 @@ class Qmix(C.Structure):
                 ("d_e_b1", c_void_p), ("d_e_raw", c_void_p), ("diag", c_void_p), ("partials", c_void_p),
                 ("B", c_int32), ("N", c_int32), ("A", c_int32), ("H", c_int32), ("ldq", c_int32), ("ld_e1", c_int32),
                 ("ld_e2", c_int32), ("ld_t1", c_int32), ("ld_t2", c_int32), ("double_q", c_int32),
-                ("gamma", c_float), ("pad", c_float)]
+                ("gamma", c_float), ("pad", c_float), ("filled", c_void_p)]
+
+
+class GruFwd(C.Structure):
+    _fields_ = [("gi", c_void_p), ("w_hh", c_void_p), ("b_hh", c_void_p), ("h0", c_void_p), ("reset", c_void_p),
+                ("hs", c_void_p), ("gates", c_void_p), ("h_last", c_void_p),
+                ("R", c_int32), ("T1", c_int32), ("H", c_int32), ("ld_gi", c_int32)]
+
+
+class GruBwd(C.Structure):
+    _fields_ = [("d_hs", c_void_p), ("hs", c_void_p), ("gates", c_void_p), ("w_hh", c_void_p), ("d_gi", c_void_p),
+                ("d_gh", c_void_p), ("d_h0", c_void_p),
+                ("R", c_int32), ("T1", c_int32), ("H", c_int32), ("ld_dhs", c_int32), ("ld_dgi", c_int32), ("pad", c_int32)]
 
 
 class FusedLayer(C.Structure):
@@ -167,6 +179,8 @@ _SIGS = {
     "xrl_pack_rollout_cache2": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p, c_void_p],
     "xrl_dqn_td": [C.POINTER(DqnTd), c_void_p],
     "xrl_qmix_mix_td": [C.POINTER(Qmix), c_void_p],
+    "xrl_gru_forward": [C.POINTER(GruFwd), c_void_p],
+    "xrl_gru_backward": [C.POINTER(GruBwd), c_void_p],
     "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],
     "xrl_obs_normalize": [C.POINTER(Rms), c_void_p],
     "xrl_policy_sample": [C.POINTER(Sample), c_void_p],

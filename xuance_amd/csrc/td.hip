@@ -51,9 +51,17 @@ __global__ void __launch_bounds__(64) qmix_kernel(xrl_qmix_t p) {
     const int N = p.N, A = p.A, H = p.H;
     float qe = 0.f, qn = 0.f, mask = 0.f;
     int a_taken = 0;
+    // recurrent branch: step mask and its sum (every wave adds the B values in the same order)
+    float fl = 1.f, inv_norm = 0.f;
+    if (p.filled) {
+        float s = 0.f;
+        for (int i = lane; i < p.B; i += 64) s += p.filled[i];
+        inv_norm = 1.f / wave_sum(s);
+        fl = p.filled[b];
+    }
     if (lane < N) {
         const size_t row = (size_t)b * N + lane;
-        mask = p.agent_mask[row];
+        mask = p.agent_mask[row] * fl;                                                // outputs.py:138-143
         a_taken = (int)p.actions[row];
         qe = p.q_eval[row * p.ldq + a_taken] * mask;                                  // qmix_learner.py:48-50,60
         const float* qt = p.q_next + row * p.ldq;
@@ -99,8 +107,9 @@ __global__ void __launch_bounds__(64) qmix_kernel(xrl_qmix_t p) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) all_d = fminf(all_d, __shfl_xor(all_d, off, 64));
     const float y = r_tot + (1.f - all_d) * p.gamma * q_tot_n;                        // :78
-    const float td = q_tot_e - y;
-    const float dq_tot = 2.f * td / (float)p.B;                                       // d mean(td^2) / d q_tot_eval
+    const float td = (q_tot_e - y) * fl;                                              // :83
+    // d mean(td^2) / d q_tot_eval (:86), or d (sum(td^2) / sum(filled)) (:84)
+    const float dq_tot = p.filled ? 2.f * td * fl * inv_norm : 2.f * td / (float)p.B;
     // backward through the eval mixer
     float* d_raw = p.d_e_raw + (size_t)b * p.ld_e2;
     float d_pre = 0.f;
@@ -129,8 +138,8 @@ __global__ void __launch_bounds__(64) qmix_kernel(xrl_qmix_t p) {
     }
     if (lane == 0) {
         double* q = p.partials + (size_t)b * 8;
-        q[0] = (double)td * td; q[1] = q_tot_e;
-        for (int j = 2; j < 8; ++j) q[j] = 0.0;
+        q[0] = (double)td * td; q[1] = q_tot_e; q[2] = p.filled ? (double)fl : 0.0;
+        for (int j = 3; j < 8; ++j) q[j] = 0.0;
         if (p.diag) { p.diag[b] = q_tot_e; p.diag[p.B + b] = q_tot_n; p.diag[2 * (size_t)p.B + b] = y; }
     }
 }

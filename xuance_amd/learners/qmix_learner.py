@@ -5,7 +5,18 @@ Same constructor ``(config, agent_grouping_or_keys, model, callback)``, ``update
 xuance/torch/learners/multi_agent_rl/qmix_learner.py:13-112 (with iql_learner.py:37-83 and
 base/marl_learner.py:319-408).  ``sample`` may be the reference buffer's nested dict (field -> agent -> array
 [B, ...]) or the stacked form produced by HipMARLOffPolicyBuffer (field -> tensor [B, N, ...]).
-The GRU/episode variant (use_rnn) is SURVEY.md section 8f "next" and raises NotImplementedError.
+
+Recurrent agents (use_rnn, the default of configs/qmix/sc2/3m.yaml): ``sample`` is what
+MARL_OffPolicyBuffer_RNN.sample returns (memory_tools_marl.py:970-996: obs [B, T+1, ...] per agent, actions / rewards /
+terminals / agent_mask [B, T], avail_actions [B, T+1, A], state [B, T+1, S], filled [B, T]).  On the device the batch is
+TIME-MAJOR (row t*B*N + b*N + n): every layer outside the recurrence is one GEMM over all (T+1)*B*N rows, "next step"
+tensors are the same tensors one slot further, and the mixer / TD kernel treats the T*B (step, episode) pairs as its
+batch.  Two properties of the reference's recurrent branch (both pinned by fixtures, oracle/make_golden.py):
+  * iql_learner.py:58 re-slices q_eval inside torch.no_grad(): the agent networks get no gradient, only the mixer
+    trains.  ``config.rnn_backprop_agents`` (default False) keeps that behaviour; True back-propagates through the Q
+    head, the GRU (xrl_gru_backward) and the fc layer.
+  * iql_learner.py:78-81 raises IndexError when use_actions_mask is on (agent axis sliced instead of time); here the
+    mask of step t+1 is applied to step t's target, as the feed-forward branch does.
 """
 import numpy as np
 import torch
@@ -18,8 +29,9 @@ from .ppo_learner import pick_n_split
 class QMIX_Learner(Learner):
     def __init__(self, config, agent_grouping, model, callback=None):
         super().__init__(config, model, callback)
-        if getattr(config, "use_rnn", False):
-            raise NotImplementedError("QMIX with recurrent agents is not part of round 1 (SURVEY.md section 8f)")
+        self.use_rnn = bool(getattr(config, "use_rnn", False))
+        assert self.use_rnn == bool(getattr(model, "use_rnn", False)), "config.use_rnn and the model disagree"
+        self.rnn_backprop_agents = bool(getattr(config, "rnn_backprop_agents", False))
         self.agent_keys = list(getattr(agent_grouping, "agent_keys", agent_grouping))
         self.n_agents = len(self.agent_keys)
         assert self.n_agents == model.n_agents
@@ -40,6 +52,8 @@ class QMIX_Learner(Learner):
         c = self.config
         start_training = getattr(c, "start_training", 0)
         training_frequency = getattr(c, "training_frequency", 1)
+        if getattr(c, "use_rnn", False):                           # marl_learner.py:42-43
+            return (c.running_steps - start_training) // (self.episode_length * c.parallels) * getattr(c, "n_epochs", 1)
         return (c.running_steps - start_training) // (training_frequency * c.parallels) * getattr(c, "n_epochs", 1)
 
     def _ensure(self, B):
@@ -114,6 +128,84 @@ class QMIX_Learner(Learner):
                       self.grad_clip_norm if self.use_grad_clip else 0.0)                         # qmix_learner.py:88-96
         ops.sync_target(m.params.flat, m.target_flat, m.params.P, opt.state, self.sync_frequency)  # :105-106
 
+    # ------------------------------------------------------------------ recurrent branch
+    def _ensure_rnn(self, B, T):
+        if getattr(self, "_cap_rnn", None) == (B, T):
+            return
+        m, dev = self.model, self.model.params.device
+        self._cap_rnn = (B, T)
+        N, T1, R = m.n_agents, T + 1, B * m.n_agents
+        self.slabs = torch.zeros(32, m.params.P, device=dev)
+        self.partials = torch.zeros(T * B, 8, dtype=torch.float64, device=dev)
+        self.diag = torch.zeros(3 * T * B, device=dev)
+        self.Xs = torch.zeros(T1 * R, m.obs_dim, device=dev)                  # [t][b][n][obs]
+        self.states_s = torch.zeros(T1 * B, m.state_dim, device=dev)          # [t][b][state]
+        self.seq = {k: torch.zeros(T, B, N, device=dev) for k in ("actions", "rewards", "terminals", "agent_mask")}
+        self.seq["avail"] = torch.ones(T1, B, N, m.n_actions, device=dev)
+        self.seq["filled"] = torch.zeros(T, B, device=dev)
+        m.seq_workspace(0, R, T1)
+        m.seq_workspace(1, R, T1)
+        m.mixer_plan.ensure(T1 * B)
+        m.mixer_target_plan.ensure(T1 * B)
+
+    def build_training_data_rnn(self, sample):                  # marl_learner.py:319-408, recurrent branch
+        B, T = int(sample["batch_size"]), int(sample["sequence_length"])
+        self._ensure_rnn(B, T)
+        m, dev = self.model, self.model.params.device
+        N, T1 = m.n_agents, T + 1
+        self.Xs.view(T1, B, N, -1).copy_(self._stack(sample["obs"]).reshape(B, N, T1, -1).permute(2, 0, 1, 3))
+        for k in ("actions", "rewards", "terminals", "agent_mask"):
+            self.seq[k].copy_(self._stack(sample[k]).reshape(B, N, T).permute(2, 0, 1))
+        if self.use_actions_mask:
+            self.seq["avail"].copy_(self._stack(sample["avail_actions"]).reshape(B, N, T1, -1).permute(2, 0, 1, 3))
+        self.states_s.view(T1, B, -1).copy_(torch.as_tensor(sample["state"], device=dev).to(torch.float32)
+                                            .reshape(B, T1, -1).permute(1, 0, 2))
+        self.seq["filled"].copy_(torch.as_tensor(sample["filled"], device=dev).to(torch.float32).reshape(B, T).t())
+        return B, T
+
+    def _step_rnn(self, B, T):
+        m, opt = self.model, self.optimizer
+        N, A, H, T1 = m.n_agents, m.n_actions, m.H, T + 1
+        R, BT = B * N, T * B
+        S = pick_n_split(T1 * R)
+        q_all = m.agent_forward_seq(self.Xs, R, T1, which=0)                                   # iql_learner.py:39-47
+        q_tgt = m.agent_forward_seq(self.Xs, R, T1, which=1)                                   # :53-57
+        e_raw = m.mixer_plan.forward(self.states_s, m.state_dim, T1 * B)                       # eval mixer: slots 0..T-1 used
+        t_raw = m.mixer_target_plan.forward(self.states_s, m.state_dim, T1 * B, flat=m.target_flat)   # target: slots 1..T
+        e_l1, t_l1 = m.mixer_plan.acts[1], m.mixer_target_plan.acts[1]
+        d_l1, d_raw = m.mixer_plan.dacts[1], m.mixer_plan.dacts[2]
+        ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]
+        post = m.post_plans[0]
+        d_q = post.dacts[len(post.widths) - 1]
+        d_q[T * R:T1 * R].zero_()                                                              # Q of the last slot is not in the loss (:58)
+        ops.qmix_mix_td(q_eval=q_all, q_next_eval=q_all[R:] if self.double_q else None, q_next=q_tgt[R:],
+                        actions=self.seq["actions"], avail_next=self.seq["avail"][1:] if self.use_actions_mask else None,
+                        agent_mask=self.seq["agent_mask"], rewards=self.seq["rewards"], terminals=self.seq["terminals"],
+                        e_b1=e_l1.data_ptr() + 4 * 3 * m.HH, e_raw=e_raw, t_b1=t_l1[B:].data_ptr() + 4 * 3 * m.HH, t_raw=t_raw[B:],
+                        d_q=d_q, d_e_b1=d_l1.data_ptr() + 4 * 3 * m.HH, d_e_raw=d_raw, diag=self.diag, partials=self.partials,
+                        B=BT, N=N, A=A, H=H, ldq=A, ld_e1=ld1, ld_e2=ld2, ld_t1=ld1, ld_t2=ld2, double_q=int(self.double_q),
+                        gamma=float(self.gamma), filled=self.seq["filled"])
+        m.mixer_plan.backward(self.states_s, m.state_dim, BT, self.slabs, S)
+        if self.rnn_backprop_agents:
+            m.agent_backward_seq(self.Xs, R, T1, self.slabs, S)
+        ops.grad_reduce(self.slabs, S, m.params.P, m.params.P, opt.grad, self.sumsq)
+        if self.distributed_training and self.world_size > 1:
+            from ..dist import allreduce_mean_
+            allreduce_mean_(opt.grad)
+            ops.grad_reduce(opt.grad, 1, m.params.P, m.params.P, opt.grad, self.sumsq)
+        ops.adam_step(m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state, self.sumsq,
+                      self.grad_clip_norm if self.use_grad_clip else 0.0)
+        ops.sync_target(m.params.flat, m.target_flat, m.params.P, opt.state, self.sync_frequency)
+
+    def _info_rnn(self, B, T, sums):
+        """loss = sum((td * filled)^2) / sum(filled) (qmix_learner.py:82-84); predictQ = mean over all B*T (:101)."""
+        return {"learning_rate": self.optimizer.read().last_lr, "loss_Q": float(sums[0] / sums[2]),
+                "predictQ": float(sums[1] / (B * T))}
+
+    def _cb_rnn(self, B, T):
+        d = self.diag.view(3, T, B).transpose(1, 2).reshape(3, B * T)          # the reference's (episode, step) order
+        return dict(q_tot_eval=d[0], q_tot_next=d[1], q_tot_target=d[2])
+
     # ------------------------------------------------------------------ whole update phases straight from the HBM replay buffer
     def update_from_buffer(self, memory, n_epochs=1, seed=1):
         """`n_epochs` updates (sample -> gather -> forward / mixer TD / backward -> Adam -> target sync) as ONE captured
@@ -166,6 +258,14 @@ class QMIX_Learner(Learner):
 
     def update(self, sample):
         self.iterations += 1
+        if self.use_rnn:
+            B, T = self.build_training_data_rnn(sample)
+            info = self.callback.on_update_start(self.iterations, model=self.model) or {}
+            self._step_rnn(B, T)
+            ops.sum_partials(self.partials, T * B, 8, self.sums)
+            info.update(self._info_rnn(B, T, self.sums.cpu().numpy()))
+            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **self._cb_rnn(B, T)) or {})
+            return info
         B = self.build_training_data(sample)
         info = self.callback.on_update_start(self.iterations, model=self.model) or {}
         self._step(B)

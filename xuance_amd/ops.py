@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -344,6 +344,14 @@ def dqn_td(**kw):
 
 def qmix_mix_td(**kw):
     call("xrl_qmix_mix_td", C.byref(_struct(Qmix, kw)), stream_ptr())
+
+
+def gru_forward(**kw):
+    call("xrl_gru_forward", C.byref(_struct(GruFwd, kw)), stream_ptr())
+
+
+def gru_backward(**kw):
+    call("xrl_gru_backward", C.byref(_struct(GruBwd, kw)), stream_ptr())
 
 
 def sync_target(params, target, P, state, sync_frequency):
