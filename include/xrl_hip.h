@@ -552,6 +552,30 @@ typedef struct {
 } xrl_gru_bwd_t;
 int xrl_gru_backward(const xrl_gru_bwd_t* p, xrl_stream_t stream);
 
+/* ------------------------------------------------------------------ episode replay buffer (recurrent multi-agent path)
+ * MARL_OffPolicyBuffer_RNN (xuance/common/memory_tools_marl.py:770-996).  Every field is [episode][slots][row_bytes]
+ * (slots = T for per-step fields, T+1 for obs / state / avail_actions); `a`, `b`, `c` per entry point: */
+typedef struct {
+    void* a;
+    const void* b;
+    const void* c;
+    int32_t row_bytes;     /* bytes of one time slot (all agents of a step), multiple of 4 */
+    int32_t slots;
+    int32_t flags;         /* xrl_episode_finish: bit0 = zero the staging row after the copy (the `filled` field) */
+    int32_t pad;
+} xrl_episode_field_t;
+/* store (:904-921): a = staging [n_envs][slots][row], b = step data [n_envs][row]: staging[env][steps[env]] <- b[env]
+ * (`filled` is a field whose step data is ones). */
+int xrl_episode_store_step(const xrl_episode_field_t* fields, int n_fields, const int32_t* steps, int n_envs,
+                           xrl_stream_t stream);
+/* finish_path + store_episodes (:923-968) for every env with done[env] != 0, in env order: c (NULL or [n_envs][row]) is
+ * written at slot end_step[env] of the staging row b, the whole row is copied to ring row a[(ptr + rank) % buffer_size],
+ * then ptr_size = {ptr, size} advance (device-resident: captured graphs and sampling kernels read them). */
+int xrl_episode_finish(const xrl_episode_field_t* fields, int n_fields, const float* done, const int32_t* end_step,
+                       int32_t* ptr_size, int n_envs, int buffer_size, xrl_stream_t stream);
+/* sample (:970-996): a = time-major batch [slots][B][row], b = ring: a[t][i] <- b[idx[i]][t]. */
+int xrl_episode_gather(const xrl_episode_field_t* fields, int n_fields, const int64_t* idx, int B, xrl_stream_t stream);
+
 /* Hard target update inside a captured graph: if (state->step % sync_frequency == 0) target <- params
  * (dqn_learner.py:56-57, qmix_learner.py:105-106; copy_target deep_q_network.py:95-99). */
 int xrl_sync_target(const float* params, float* target, int64_t P, const xrl_adam_state_t* state,

@@ -459,6 +459,70 @@ def golden_qmix_rnn(double_q=True, fixed=False):
                         **out)
 
 
+def golden_marl_rnn_buffer():
+    """MARL_OffPolicyBuffer_RNN (memory_tools_marl.py:770-996): store / finish_path / clear_episodes / sample on a small
+    scripted scenario -- ragged episode lengths, several envs finishing in the same step, the ring wrapping, and short
+    episodes that follow longer ones in the same staging row (store_episodes copies the stale tail, :935-949)."""
+    from xuance.common.memory_tools_marl import MARL_OffPolicyBuffer_RNN
+    rng = np.random.default_rng(23)
+    n_envs, N, O, A, S, T, cap, bs = 3, 2, 3, 4, 5, 5, 6, 6
+    keys = [f"agent_{i}" for i in range(N)]
+    buf = MARL_OffPolicyBuffer_RNN(agent_keys=keys, state_space=sp.Box(-np.inf, np.inf, (S,), np.float32),
+                                   obs_space={k: sp.Box(-np.inf, np.inf, (O,), np.float32) for k in keys},
+                                   act_space={k: sp.Discrete(A) for k in keys}, n_envs=n_envs, buffer_size=cap,
+                                   batch_size=bs, max_episode_steps=T, use_actions_mask=True,
+                                   avail_actions_shape={k: (A,) for k in keys})
+    lengths = [[5, 2, 4, 1], [3, 5, 2, 2], [1, 1, 5, 3]]           # per env: successive episode lengths
+    ep, es = [0] * n_envs, np.zeros(n_envs, np.int64)
+    out, n_steps = {}, 12
+    for t in range(n_steps):
+        if t == 8:
+            buf.clear_episodes()                                    # what run_episodes does when it is entered again (:459)
+            es[:] = 0
+            for e in range(n_envs):
+                ep[e] += 1
+        d = dict(obs=rng.standard_normal((n_envs, N, O)).astype(np.float32),
+                 actions=rng.integers(0, A, (n_envs, N)).astype(np.float32),
+                 rewards=rng.standard_normal((n_envs, N)).astype(np.float32),
+                 terminals=rng.random((n_envs, N)) < 0.3, agent_mask=rng.random((n_envs, N)) < 0.8,
+                 avail_actions=rng.random((n_envs, N, A)) < 0.7, state=rng.standard_normal((n_envs, S)).astype(np.float32),
+                 term_obs=rng.standard_normal((n_envs, N, O)).astype(np.float32),
+                 term_state=rng.standard_normal((n_envs, S)).astype(np.float32),
+                 term_avail=rng.random((n_envs, N, A)) < 0.7)
+        step = {k: {a: d[k][:, i] for i, a in enumerate(keys)} for k in ("obs", "actions", "rewards", "terminals",
+                                                                           "agent_mask", "avail_actions")}
+        step.update(state=d["state"], episode_steps=es.copy())
+        buf.store(**step)
+        done = np.zeros(n_envs, bool)
+        for e in range(n_envs):
+            if es[e] + 1 >= lengths[e][ep[e] % 4]:
+                done[e] = True
+                buf.finish_path(e, obs={a: d["term_obs"][e, i] for i, a in enumerate(keys)}, state=d["term_state"][e],
+                                avail_actions={a: d["term_avail"][e, i] for i, a in enumerate(keys)},
+                                episode_step=int(es[e] + 1))
+        d["episode_steps"], d["done"] = es.copy(), done
+        out.update(flat(f"t{t}", d))
+        for e in range(n_envs):
+            if done[e]:
+                es[e], ep[e] = 0, ep[e] + 1
+            else:
+                es[e] += 1
+        out[f"t{t}/ptr_size"] = np.array([buf.ptr, buf.size])
+    for k, v in buf.data.items():
+        out[f"data/{k}"] = np.stack([v[a] for a in keys], 2) if isinstance(v, dict) else v   # [cap, slots, N, ...]
+    np.random.seed(7)
+    smp = buf.sample()
+    np.random.seed(7)
+    out["sample/idx"] = np.random.choice(buf.size, bs)
+    for k, v in smp.items():
+        if isinstance(v, dict):
+            out[f"sample/{k}"] = np.stack([v[a] for a in keys], 1)                              # [B, N, slots, ...]
+        elif isinstance(v, np.ndarray):
+            out[f"sample/{k}"] = v
+    out["meta"] = np.array([n_envs, N, O, A, S, T, cap, bs, n_steps])
+    np.savez_compressed(os.path.join(OUT, "marl_rnn_buffer.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_onpolicy_buffer()
@@ -476,5 +540,6 @@ if __name__ == "__main__":
     golden_qmix_rnn(True)
     golden_qmix_rnn(False)
     golden_qmix_rnn(True, fixed=True)
+    golden_marl_rnn_buffer()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

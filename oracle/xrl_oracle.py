@@ -687,6 +687,43 @@ def qmix_forward_backward(sd, batch, cfg, act="relu", group="shared"):
     return info, grads
 
 
+class EpisodeBufferOracle:
+    """MARL_OffPolicyBuffer_RNN (memory_tools_marl.py:770-996) with the agents stacked on one axis:
+    obs [rows, T+1, N, O], actions/rewards/terminals/agent_mask [rows, T, N], avail_actions [rows, T+1, N, A],
+    state [rows, T+1, S], filled [rows, T]; `data` = ring of buffer_size episodes, `episode_data` = one row per env."""
+
+    def __init__(self, n_envs, buffer_size, T, N, O, A, S):
+        self.n_envs, self.buffer_size, self.T = n_envs, buffer_size, T
+        shapes = dict(obs=(T + 1, N, O), actions=(T, N), rewards=(T, N), terminals=(T, N), agent_mask=(T, N),
+                      filled=(T,), state=(T + 1, S), avail_actions=(T + 1, N, A))
+        self.shapes = shapes
+        self.data = {k: np.zeros((buffer_size,) + v, np.float32) for k, v in shapes.items()}          # clear(), :822-857
+        self.ptr = self.size = 0
+        self.clear_episodes()
+
+    def clear_episodes(self):                                  # :859-902
+        self.episode_data = {k: np.zeros((self.n_envs,) + v, np.float32) for k, v in self.shapes.items()}
+
+    def store(self, episode_steps, **step):                    # :904-921
+        e = np.arange(self.n_envs)
+        self.episode_data["filled"][e, episode_steps] = 1
+        for k, v in step.items():
+            self.episode_data[k][e, episode_steps] = v
+
+    def finish_path(self, i_env, episode_step, obs, state, avail_actions):      # :951-968 then store_episodes :923-949
+        self.episode_data["state"][i_env, episode_step] = state
+        self.episode_data["obs"][i_env, episode_step] = obs
+        self.episode_data["avail_actions"][i_env, episode_step] = avail_actions
+        for k in self.data:
+            self.data[k][self.ptr] = self.episode_data[k][i_env]               # the whole row, stale tail included
+        self.ptr = (self.ptr + 1) % self.buffer_size
+        self.size = min(self.size + 1, self.buffer_size)
+        self.episode_data["filled"][i_env] = 0
+
+    def sample(self, idx):                                     # :970-996 (idx = np.random.choice(size, batch_size))
+        return {k: v[idx] for k, v in self.data.items()}
+
+
 # --------------------------------------------------------------------------------------
 # GRU (torch.nn.GRU, one layer, batch_first; third-party arithmetic: PyTorch ATen gru cell --
 #   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr); z = sigmoid(W_iz x + b_iz + W_hz h + b_hz);

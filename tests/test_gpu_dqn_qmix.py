@@ -191,3 +191,46 @@ def test_qmix_rnn_learner_vs_reference_fixture(name):
         sample.update(state=b["state"], filled=b["filled"], batch_size=len(b["state"]), sequence_length=T)
         return learner.update(sample)
     check_updates(g, net, learner, cb, call, ("q_tot_eval", "q_tot_next", "q_tot_target"), "loss_Q")
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_marl_rnn_buffer_vs_reference_fixture(batched):
+    """HipMARLOffPolicyBufferRNN against MARL_OffPolicyBuffer_RNN's own run (tests/golden/marl_rnn_buffer.npz): staging
+    rows, ring contents after ragged / simultaneous / wrapping episode ends, ptr/size and a sampled batch -- bit exact.
+    batched: finish_paths (all finished envs of a step in two launches) vs the reference's per-env finish_path call."""
+    from xuance_amd.memory_marl import HipMARLOffPolicyBufferRNN
+    from xuance_amd.spaces import Box, Discrete
+    g = load_golden("marl_rnn_buffer")
+    n_envs, N, O, A, S, T, cap, bs, n_steps = (int(x) for x in g["meta"])
+    keys = [f"agent_{i}" for i in range(N)]
+    buf = HipMARLOffPolicyBufferRNN(keys, Box(-np.inf, np.inf, (S,)), {k: Box(-np.inf, np.inf, (O,)) for k in keys},
+                                    {k: Discrete(A) for k in keys}, n_envs, cap, bs, T, use_actions_mask=True,
+                                    avail_actions_shape={k: (A,) for k in keys})
+    for t in range(n_steps):
+        d = sub(g, f"t{t}")
+        if t == 8:
+            buf.clear_episodes()
+        step = {k: {a: d[k][:, i] for i, a in enumerate(keys)} for k in ("obs", "actions", "rewards", "terminals",
+                                                                           "agent_mask", "avail_actions")}
+        buf.store(state=d["state"], episode_steps=d["episode_steps"], **step)
+        if batched:
+            buf.finish_paths(torch.from_numpy(d["done"].astype(np.float32)).cuda(),
+                             torch.from_numpy((d["episode_steps"] + 1).astype(np.int32)).cuda(),
+                             obs=torch.from_numpy(d["term_obs"]).cuda(), state=torch.from_numpy(d["term_state"]).cuda(),
+                             avail_actions=torch.from_numpy(d["term_avail"].astype(np.float32)).cuda())
+        else:
+            for e in np.flatnonzero(d["done"]):
+                buf.finish_path(int(e), obs={a: d["term_obs"][e, i] for i, a in enumerate(keys)}, state=d["term_state"][e],
+                                avail_actions={a: d["term_avail"][e, i] for i, a in enumerate(keys)},
+                                episode_step=int(d["episode_steps"][e]) + 1)
+        assert [buf.ptr, buf.size] == d["ptr_size"].tolist(), t
+    for k, v in sub(g, "data").items():
+        got = buf.data[k].cpu().numpy().reshape(v.shape)
+        assert np.array_equal(got, v.astype(np.float32)), k
+    smp = buf.sample(indexes=g["sample/idx"])
+    assert smp["batch_size"] == bs and smp["sequence_length"] == T
+    for k in buf.data_keys:
+        ref = g[f"sample/{k}"].astype(np.float32)
+        got = smp[k]
+        got = torch.stack([got[a] for a in keys], 1) if isinstance(got, dict) else got
+        assert np.array_equal(got.cpu().numpy().reshape(ref.shape), ref), k

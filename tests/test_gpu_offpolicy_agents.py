@@ -251,3 +251,98 @@ def test_dqn_graph_update_phase_equals_eager_updates_on_the_same_indices(atari):
                     np.array([[i["Qloss"], i["predictQ"]] for i in infos])))
     (pa, ta, ia), (pb, tb, ib) = res
     assert np.abs(pa).max() > 0 and np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(ia, ib)
+
+
+def _rnn_cfg(**kw):
+    c = dict(q_hidden_size=[64], fc_hidden_sizes=[64], recurrent_hidden_size=64, hidden_dim_mixing_net=32,
+             hidden_dim_hyper_net=32, activation="relu", seed=1, parallels=8, running_steps=10 ** 6, buffer_size=64,
+             batch_size=8, learning_rate=7e-4, gamma=0.99, double_q=True, start_greedy=1.0, end_greedy=0.05,
+             decay_step_greedy=50000, sync_frequency=3, training_frequency=1, start_training=0, n_epochs=2,
+             use_grad_clip=True, grad_clip_norm=10.0, use_actions_mask=True, use_parameter_sharing=True, use_rnn=True,
+             rnn_backprop_agents=True, episode_length=12, distributed_training=False, device="cuda", model_dir="/tmp/x",
+             use_hip_graph=True)
+    c.update(kw)
+    return Namespace(**c)
+
+
+def test_qmix_rnn_agents_episode_loop_vs_oracle(oracle):
+    """Recurrent QMIX agents end to end on the device: run_episodes (GRU state carried and reset per env,
+    staging rows -> episode ring), then update phases from the ring (device sampling + time-major gather + BPTT update
+    as one hipGraph).  Checked: the carried GRU state against the oracle's GRU over the staged observations of the
+    running episodes; every stored action was available; the update phases against the oracle replaying the same
+    sampled episodes (the device's indices are the fixed input)."""
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    torch.manual_seed(0)
+    n, N, T = 8, 3, 12
+    env = SyntheticSMACVecEnv(n, seed=3, max_episode_steps=T)
+    agent = QMIX_Agents(_rnn_cfg(), env)
+    mem, lr, net = agent.memory, agent.learner, agent.model
+    sd = {k: v.cpu().numpy().copy() for k, v in net.state_dict().items()}
+    agent.run_episodes(n)
+    torch.cuda.synchronize()
+    size = mem.size
+    assert size >= n and agent.current_step > 0
+    # (1) carried state: for every env the GRU over the staged observations of its running episode, from zeros
+    steps = env.steps.cpu().numpy()
+    obs_stage = mem.episode_data["obs"].cpu().numpy().reshape(n, T + 1, N, -1)
+    h = agent.rnn_h.cpu().numpy().reshape(n, N, -1)
+    for e in range(n):
+        if steps[e] == 0:
+            continue
+        _, c = oracle.qmix_rnn_agent_forward(sd, "individual_q_networks.shared", obs_stage[e, :steps[e]].transpose(1, 0, 2))
+        assert_close(h[e], c["hs"][:, -1], 1e-5, f"carried GRU state of env {e}")
+    # (2) ring contents: filled prefix, available actions
+    data = {k: v.cpu().numpy() for k, v in mem.data.items()}
+    for ep in range(size):
+        L = int(data["filled"][ep].sum())
+        assert L >= 1 and data["filled"][ep, :L, 0].all()
+        acts = data["actions"][ep, :L].astype(int)                                   # [L, N]
+        av = data["avail_actions"][ep, :L].reshape(L, N, -1)
+        assert np.take_along_axis(av, acts[..., None], -1).all()
+    # (3) update phases (eager+capture, then graph replays) vs the oracle on the same episodes
+    opt = oracle.AdamOracle({k: sd[k] for k in net.ref_order}, lr=7e-4, eps=1e-5, total_iters=lr.total_iters)
+    cfg = dict(gamma=0.99, double_q=True, use_actions_mask=True, agent_grad=True)
+    seen = []
+    lr.callback.on_update_end = lambda it, **kw: seen.append(it) or {}
+    for phase in range(3):
+        info = lr.update_from_buffer(mem, 2, seed=5)
+        # replay: the indices of the phase's epochs come from the sampling kernel with counter = 2*phase + e
+        from xuance_amd import ops
+        idx = torch.zeros(8, dtype=torch.int64, device="cuda")
+        for e in range(2):
+            ops.sample_replay_indices(idx, 1, mem.buffer_size, mem.size_dev, 5, 2 * phase + e, None)
+            ii = idx.cpu().numpy()
+            b = dict(obs=data["obs"][ii].reshape(8, T + 1, N, -1).transpose(0, 2, 1, 3),
+                     actions=data["actions"][ii].transpose(0, 2, 1), rewards=data["rewards"][ii].transpose(0, 2, 1),
+                     terminals=data["terminals"][ii].transpose(0, 2, 1), agent_mask=data["agent_mask"][ii].transpose(0, 2, 1),
+                     avail_actions=data["avail_actions"][ii].reshape(8, T + 1, N, -1).transpose(0, 2, 1, 3),
+                     state=data["state"][ii], filled=data["filled"][ii][..., 0])
+            oi, grads = oracle.qmix_rnn_forward_backward(sd, b, cfg)
+            oracle.AdamOracle.clip_grad_norm_(grads, 10.0)
+            opt.step(grads)
+            if (2 * phase + e + 1) % 3 == 0:
+                oracle.qmix_copy_target(sd)
+        assert_close(info["loss_Q"], oi["loss"], 1e-5, "loss_Q")
+        got = net.state_dict()
+        for k, v in sd.items():
+            assert_close(got[k].cpu().numpy(), v, 2e-5, f"{k} after phase {phase}")
+    assert lr._buf_graph is not None and lr.iterations == 6 and seen == [1, 2, 3, 4, 5, 6]
+
+
+def test_qmix_rnn_agents_train_at_3m_shape():
+    """configs/qmix/sc2/3m.yaml shapes and defaults (64 envs here, 60-step episodes, batch 32 episodes, n_epochs 8,
+    reference behaviour: agents' gradient detached): the whole train() loop."""
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    torch.manual_seed(0)
+    env = SyntheticSMACVecEnv(64, seed=3)
+    agent = QMIX_Agents(_rnn_cfg(parallels=64, buffer_size=5000, batch_size=32, n_epochs=8, sync_frequency=200,
+                                 start_training=1000, use_grad_clip=False, rnn_backprop_agents=False, episode_length=60), env)
+    a0 = agent.model.params.view(agent.model.w_hh).clone()
+    m0 = agent.model.params.view("eval_Qtot.hyper_b_1.weight").clone()
+    info = agent.train(120)
+    assert agent.current_step >= 120 * 64 and agent.learner.iterations > 0 and agent.learner.iterations % 8 == 0
+    assert np.isfinite(info["loss_Q"]) and np.isfinite(info["predictQ"])
+    assert torch.equal(agent.model.params.view(agent.model.w_hh), a0)              # iql_learner.py:49,58: agents detached
+    assert not torch.equal(agent.model.params.view("eval_Qtot.hyper_b_1.weight"), m0)

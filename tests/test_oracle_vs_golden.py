@@ -209,3 +209,39 @@ def test_qmix_rnn_update(oracle, name):
         assert_close(info["loss"], ref_info["loss_Q"], 1e-5, "loss_Q")
         assert_close(info["predictQ"], ref_info["predictQ"], 1e-5, "predictQ")
         assert any(k.startswith("individual_q_networks") for k in grads) == fixed
+
+
+def replay_marl_rnn_buffer(g, buf, store, finish, clear_episodes):
+    """Drive a buffer through the scripted scenario of tests/golden/marl_rnn_buffer.npz (oracle/make_golden.py)."""
+    n_envs, N, O, A, S, T, cap, bs, n_steps = (int(x) for x in g["meta"])
+    for t in range(n_steps):
+        d = sub(g, f"t{t}")
+        if t == 8:
+            clear_episodes()
+        store(d)
+        finish(d)
+        yield t, d
+
+
+def test_marl_rnn_buffer(oracle):
+    g = load_golden("marl_rnn_buffer")
+    n_envs, N, O, A, S, T, cap, bs, n_steps = (int(x) for x in g["meta"])
+    buf = oracle.EpisodeBufferOracle(n_envs, cap, T, N, O, A, S)
+
+    def store(d):
+        buf.store(d["episode_steps"], **{k: d[k] for k in ("obs", "actions", "rewards", "terminals", "agent_mask",
+                                                          "avail_actions", "state")})
+
+    def finish(d):
+        for e in np.flatnonzero(d["done"]):
+            buf.finish_path(e, int(d["episode_steps"][e]) + 1, d["term_obs"][e], d["term_state"][e], d["term_avail"][e])
+    for t, d in replay_marl_rnn_buffer(g, buf, store, finish, buf.clear_episodes):
+        assert [buf.ptr, buf.size] == d["ptr_size"].tolist()
+    for k, v in sub(g, "data").items():
+        assert np.array_equal(buf.data[k], v.astype(np.float32)), k
+    smp = buf.sample(g["sample/idx"])
+    for k in buf.data:
+        ref = g[f"sample/{k}"].astype(np.float32)
+        if ref.ndim >= 3 and k not in ("state",):
+            ref = np.moveaxis(ref, 1, 2)                       # fixture [B, N, slots, ...] -> [B, slots, N, ...]
+        assert np.array_equal(smp[k], ref), k

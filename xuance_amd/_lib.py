@@ -91,6 +91,11 @@ class Qmix(C.Structure):
                 ("gamma", c_float), ("pad", c_float), ("filled", c_void_p)]
 
 
+class EpisodeField(C.Structure):
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("c", c_void_p), ("row_bytes", c_int32), ("slots", c_int32),
+                ("flags", c_int32), ("pad", c_int32)]
+
+
 class GruFwd(C.Structure):
     _fields_ = [("gi", c_void_p), ("w_hh", c_void_p), ("b_hh", c_void_p), ("h0", c_void_p), ("reset", c_void_p),
                 ("hs", c_void_p), ("gates", c_void_p), ("h_last", c_void_p),
@@ -179,6 +184,9 @@ _SIGS = {
     "xrl_pack_rollout_cache2": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p, c_void_p],
     "xrl_dqn_td": [C.POINTER(DqnTd), c_void_p],
     "xrl_qmix_mix_td": [C.POINTER(Qmix), c_void_p],
+    "xrl_episode_store_step": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
+    "xrl_episode_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "xrl_episode_gather": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_gru_forward": [C.POINTER(GruFwd), c_void_p],
     "xrl_gru_backward": [C.POINTER(GruBwd), c_void_p],
     "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],

@@ -3,14 +3,21 @@
 base/agents_marl.py:339-376): per vector step the [n_envs, n_agents, obs] batch goes through the shared Q-network,
 actions are the masked greedy ones unless the step's single exploration coin lands (off_policy_marl.py:236-243),
 transitions are stored and, once ``current_step >= start_training`` and on the training frequency, ``n_epochs``
-updates are made (off_policy_marl.py:376-377)."""
+updates are made (off_policy_marl.py:376-377).
+
+Recurrent agents (``use_rnn``, the default of configs/qmix/sc2/3m.yaml): training alternates ``run_episodes(n_envs)`` and
+``n_epochs`` updates (off_policy_marl.py:335-349); the GRU state of every (env, agent) row lives on the device, is
+carried by xrl_gru_forward between steps and zeroed for the rows of a finished env (:504-505); steps go into the
+staging rows of HipMARLOffPolicyBufferRNN and finished episodes into its ring without the host knowing which envs
+finished -- the one host read per vector step is the (episodes, env-steps) count that run_episodes' loop condition and
+the exploration schedule need (:494,532-534)."""
 from argparse import Namespace
 
 import torch
 
 from .. import ops
 from ..learners.qmix_learner import QMIX_Learner
-from ..memory_marl import HipMARLOffPolicyBuffer
+from ..memory_marl import HipMARLOffPolicyBuffer, HipMARLOffPolicyBufferRNN
 from ..nets import MixingQNet
 
 
@@ -26,6 +33,7 @@ class QMIX_Agents:
         self.agent_keys = list(envs.agent_keys)
         self.n_agents = len(self.agent_keys)
         self.use_actions_mask = _get(config, "use_actions_mask", True)
+        self.use_rnn = bool(_get(config, "use_rnn", False))
         self.start_training, self.training_frequency = config.start_training, config.training_frequency
         self.n_epochs = _get(config, "n_epochs", 1)
         self.use_graph_updates = bool(_get(config, "use_hip_graph", True))   # whole update phases as one hipGraph launch
@@ -45,7 +53,13 @@ class QMIX_Agents:
         self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.act_f = torch.zeros(self.n_envs, self.n_agents, device=dev)
-        self.model.agent_plan.ensure(max(R, 2 * config.batch_size * self.n_agents))
+        if self.use_rnn:
+            self.rnn_h = torch.zeros(R, self.model.RH, device=dev)           # init_rnn_states (value_factorization.py:151-159)
+            self.reset_rows = torch.zeros(R, device=dev)
+            self._counts = torch.zeros(2, device=dev)
+            self._counts_h = torch.zeros(2).pin_memory() if torch.cuda.is_available() else torch.zeros(2)
+        else:
+            self.model.agent_plan.ensure(max(R, 2 * config.batch_size * self.n_agents))
         self._started = False
 
     def _build_model(self):
@@ -53,10 +67,16 @@ class QMIX_Agents:
         return MixingQNet(self.n_agents, self.obs_dim, self.n_actions, self.state_dim,
                           list(_get(c, "representation_hidden_size", [64])), list(_get(c, "q_hidden_size", [64])),
                           _get(c, "hidden_dim_mixing_net", 32), _get(c, "hidden_dim_hyper_net", 32),
-                          _get(c, "activation", "relu"), device=self.device)
+                          _get(c, "activation", "relu"), device=self.device, use_rnn=self.use_rnn,
+                          fc_hidden=list(_get(c, "fc_hidden_sizes", [64])), recurrent_hidden=_get(c, "recurrent_hidden_size", 64))
 
     def _build_memory(self):
         c, env = self.config, self.envs
+        if self.use_rnn:                                       # off_policy_marl.py:106
+            return HipMARLOffPolicyBufferRNN(self.agent_keys, env.state_space, env.observation_space, env.action_space,
+                                             self.n_envs, c.buffer_size, c.batch_size, env.max_episode_steps,
+                                             device=self.device, use_actions_mask=self.use_actions_mask,
+                                             avail_actions_shape={k: (self.n_actions,) for k in self.agent_keys})
         return HipMARLOffPolicyBuffer(self.agent_keys, env.state_space, env.observation_space, env.action_space,
                                       self.n_envs, c.buffer_size, c.batch_size, device=self.device,
                                       use_actions_mask=self.use_actions_mask,
@@ -72,7 +92,51 @@ class QMIX_Agents:
             self.e_greedy = self.end_greedy
         self.eps_dev.fill_(float(self.e_greedy))
 
+    def run_episodes(self, n_episodes):                        # off_policy_marl.py:426-546 (training mode)
+        env, n, N, A, mem = self.envs, self.n_envs, self.n_agents, self.n_actions, self.memory
+        R = n * N
+        env.reset()
+        mem.clear_episodes()
+        self.rnn_h.zero_()
+        self.reset_rows.zero_()
+        episodes = 0
+        while episodes < n_episodes:
+            obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
+            steps = env.steps.clone()
+            q = self.model.agent_forward_seq(obs.view(R, -1), R, 1, which=2, h0=self.rnn_h, reset=self.reset_rows,
+                                             h_last=self.rnn_h)
+            ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
+                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,
+                                    step_dev=self.step_counter)
+            env.step_device()
+            ops.counter_add(self.step_counter, 1)
+            mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
+                      avail_actions=avail, state=state, episode_steps=steps)
+            mem.finish_paths(env.done, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail)
+            self.reset_rows.view(n, N).copy_(env.done[:, None].expand(n, N))
+            self._counts[0] = env.done.sum()
+            self._counts[1] = (env.done * env.end_step).sum()
+            self._counts_h.copy_(self._counts)                 # the step's only host read
+            episodes += int(self._counts_h[0])
+            self.current_step += int(self._counts_h[1])        # current_step += info[i]["episode_step"] (:532)
+            self._update_explore_factor()
+
+    def _train_rnn(self, train_steps):                         # off_policy_marl.py:335-349
+        info, start = {}, self.current_step
+        while self.current_step - start < train_steps * self.n_envs:
+            self.run_episodes(self.n_envs)
+            if self.current_step >= self.start_training:
+                if self.use_graph_updates:
+                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed)
+                else:
+                    for _e in range(self.n_epochs):
+                        info = self.learner.update(self.memory.sample())
+        info["epsilon"] = self.e_greedy
+        return info
+
     def train(self, train_steps):
+        if self.use_rnn:
+            return self._train_rnn(train_steps)
         env, n, N, A = self.envs, self.n_envs, self.n_agents, self.n_actions
         R = n * N
         if not self._started:

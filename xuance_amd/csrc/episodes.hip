@@ -1,0 +1,130 @@
+// Episode replay buffer of the recurrent multi-agent path: MARL_OffPolicyBuffer_RNN
+// (xuance/common/memory_tools_marl.py:770-996) on the device.  Per-env staging rows ("episode_data") collect a running
+// episode; a finished episode is copied as a whole row into the ring ("data"); sampling gathers whole episodes.
+// Layout: every field is [episode][slot][row] with the agents of a step contiguous inside `row` (parameter sharing: the
+// agents are homogeneous), so a step write is one contiguous row per field and an episode is one contiguous block; the
+// gather writes the learner's TIME-MAJOR batch ([slot][episode][row]) directly.  All HBM-bound, 4- or 16-byte units.
+#include "common.h"
+
+namespace xrl {
+
+constexpr int EP_MAX_FIELDS = 12;
+struct EpPack {
+    void* a[EP_MAX_FIELDS];
+    const void* b[EP_MAX_FIELDS];
+    const void* c[EP_MAX_FIELDS];
+    int row_bytes[EP_MAX_FIELDS];
+    int slots[EP_MAX_FIELDS];
+    int flags[EP_MAX_FIELDS];
+    int n;
+};
+
+// staging[env][steps[env]] <- src[env]   (store, :904-921).  grid (n_envs, n_fields)
+__global__ void __launch_bounds__(64) episode_store_kernel(EpPack f, const int32_t* __restrict__ steps) {
+    const int env = blockIdx.x, fi = blockIdx.y;
+    const int rw = f.row_bytes[fi] >> 2;
+    const int st = steps[env];
+    if (st < 0 || st >= f.slots[fi]) return;
+    uint32_t* d = reinterpret_cast<uint32_t*>(f.a[fi]) + ((size_t)env * f.slots[fi] + st) * rw;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(f.b[fi]) + (size_t)env * rw;
+    for (int i = threadIdx.x; i < rw; i += 64) d[i] = s[i];
+}
+
+// finish_path + store_episodes (:923-968) for every finished env, in env order.  grid (n_envs, n_fields), 256 threads
+__global__ void __launch_bounds__(256) episode_finish_kernel(EpPack f, const float* __restrict__ done,
+                                                             const int32_t* __restrict__ end_step,
+                                                             const int32_t* __restrict__ ptr_size, int n_envs,
+                                                             int buffer_size) {
+    const int env = blockIdx.x, fi = blockIdx.y;
+    if (done[env] == 0.f) return;
+    int rank = 0;
+    for (int j = 0; j < env; ++j) rank += done[j] != 0.f;                // this env's position among the finished ones
+    const int dst_ep = (ptr_size[0] + rank) % buffer_size;               // self.ptr advances once per stored episode
+    const int rw = f.row_bytes[fi] >> 2, slots = f.slots[fi];
+    uint32_t* stage = reinterpret_cast<uint32_t*>(const_cast<void*>(f.b[fi])) + (size_t)env * slots * rw;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(f.a[fi]) + (size_t)dst_ep * slots * rw;
+    const int es = end_step[env];
+    const uint32_t* term = f.c[fi] ? reinterpret_cast<const uint32_t*>(f.c[fi]) + (size_t)env * rw : nullptr;
+    const int n = slots * rw;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        uint32_t v = stage[i];
+        if (term && i / rw == es) {                                      // terminal obs / state / avail_actions (:931-937)
+            v = term[i - es * rw];
+            stage[i] = v;                                                // the reference writes it into episode_data first
+        }
+        ring[i] = v;
+        if (f.flags[fi] & 1) stage[i] = 0u;                              // `filled` of this env is cleared (:921)
+    }
+}
+
+__global__ void episode_advance_kernel(const float* __restrict__ done, int32_t* __restrict__ ptr_size, int n_envs,
+                                       int buffer_size) {
+    int c = 0;
+    for (int j = 0; j < n_envs; ++j) c += done[j] != 0.f;
+    ptr_size[0] = (ptr_size[0] + c) % buffer_size;
+    const int s = ptr_size[1] + c;
+    ptr_size[1] = s < buffer_size ? s : buffer_size;
+}
+
+// dst[slot][b][row] = ring[idx[b]][slot][row]   (sample, :970-996, transposed to time-major).  grid (B, n_fields)
+__global__ void __launch_bounds__(256) episode_gather_kernel(EpPack f, const int64_t* __restrict__ idx, int B) {
+    const int b = blockIdx.x, fi = blockIdx.y;
+    const int rw = f.row_bytes[fi] >> 2, slots = f.slots[fi];
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(f.b[fi]) + (size_t)idx[b] * slots * rw;
+    uint32_t* d = reinterpret_cast<uint32_t*>(f.a[fi]);
+    const int n = slots * rw;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / rw, w = i - t * rw;
+        d[((size_t)t * B + b) * rw + w] = s[i];
+    }
+}
+
+static int pack(const xrl_episode_field_t* fields, int n, EpPack& p) {
+    if (!fields || n <= 0 || n > EP_MAX_FIELDS) return XRL_EINVAL;
+    p.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (!fields[i].a || !fields[i].b || fields[i].row_bytes <= 0 || (fields[i].row_bytes & 3) || fields[i].slots <= 0)
+            return XRL_EINVAL;
+        p.a[i] = fields[i].a; p.b[i] = fields[i].b; p.c[i] = fields[i].c;
+        p.row_bytes[i] = fields[i].row_bytes; p.slots[i] = fields[i].slots; p.flags[i] = fields[i].flags;
+    }
+    return XRL_OK;
+}
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_episode_store_step(const xrl_episode_field_t* fields, int n_fields, const int32_t* steps, int n_envs,
+                                      xrl_stream_t stream) {
+    EpPack p;
+    XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
+    XRL_CHECK_ARG(steps && n_envs > 0);
+    hipLaunchKernelGGL(episode_store_kernel, dim3(n_envs, n_fields), dim3(64), 0, as_stream(stream), p, steps);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_episode_finish(const xrl_episode_field_t* fields, int n_fields, const float* done,
+                                  const int32_t* end_step, int32_t* ptr_size, int n_envs, int buffer_size,
+                                  xrl_stream_t stream) {
+    EpPack p;
+    XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
+    XRL_CHECK_ARG(done && end_step && ptr_size && n_envs > 0 && buffer_size > 0);
+    hipLaunchKernelGGL(episode_finish_kernel, dim3(n_envs, n_fields), dim3(256), 0, as_stream(stream), p, done, end_step,
+                       ptr_size, n_envs, buffer_size);
+    hipLaunchKernelGGL(episode_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), done, ptr_size, n_envs,
+                       buffer_size);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_episode_gather(const xrl_episode_field_t* fields, int n_fields, const int64_t* idx, int B,
+                                  xrl_stream_t stream) {
+    EpPack p;
+    XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
+    XRL_CHECK_ARG(idx && B > 0);
+    hipLaunchKernelGGL(episode_gather_kernel, dim3(B, n_fields), dim3(256), 0, as_stream(stream), p, idx, B);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

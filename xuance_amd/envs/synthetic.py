@@ -26,6 +26,8 @@ class _Base:
         self.terminated = (torch.rand(self.num_envs, device=self.device, generator=self.gen) < p_term).float()
         self.truncated = ((self.steps >= self.max_episode_steps) & (self.terminated == 0)).float()
         done = (self.terminated + self.truncated) > 0
+        self.done = done.float()                    # episode ended in this step ...
+        self.end_step = self.steps.clone()          # ... after this many steps (info["episode_step"])
         self.steps[done] = 0
         return done
 
@@ -138,6 +140,7 @@ class SyntheticSMACVecEnv(_Base):
     def reset(self):
         o, s, a = self._draw()
         self.buf_obs.copy_(o); self.buf_state.copy_(s); self.buf_avail.copy_(a)
+        self.steps.zero_()
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
     def step_device(self):

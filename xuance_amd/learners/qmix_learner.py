@@ -212,6 +212,8 @@ class QMIX_Learner(Learner):
         hipGraph launch: indices are drawn on the device (xrl_sample_replay_indices, following the filling ring through
         memory.size_dev), the gather writes straight into the staging tensors the networks read, and the loss terms of
         every update are read back with a single host sync at the end.  Same arithmetic as update(memory.sample())."""
+        if self.use_rnn:
+            return self._update_from_episodes(memory, n_epochs, seed)
         B, m, dev = memory.batch_size, self.model, self.model.params.device
         key = (id(memory), n_epochs, B)
         if getattr(self, "_buf_graph_key", None) != key:
@@ -254,6 +256,52 @@ class QMIX_Learner(Learner):
             info.update({"learning_rate": st.last_lr, "loss_Q": float(sums[e, 0] / B), "predictQ": float(sums[e, 1] / B)})
             info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, q_tot_eval=self.diag[:B],
                                                     q_tot_next=self.diag[B:2 * B], q_tot_target=self.diag[2 * B:3 * B]) or {})
+        return info
+
+    def _update_from_episodes(self, memory, n_epochs, seed):
+        """Recurrent twin of update_from_buffer: episodes are drawn on the device (uniform over memory.size_dev, as
+        np.random.choice(size, batch_size) does, memory_tools_marl.py:981), gathered time-major straight into the staging
+        tensors (xrl_episode_gather) and the whole n_epochs phase replays as one hipGraph."""
+        B, T, m, dev = memory.batch_size, memory.max_eps_len, self.model, self.model.params.device
+        key = (id(memory), n_epochs, B, T)
+        if getattr(self, "_buf_graph_key", None) != key:
+            self._ensure_rnn(B, T)
+            T1, N = T + 1, m.n_agents
+            self._idx = torch.zeros(B, dtype=torch.int64, device=dev)
+            self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._epoch_sums = torch.zeros(n_epochs, 8, dtype=torch.float64, device=dev)
+            dst = {"obs": self.Xs.view(T1, B, -1), "actions": self.seq["actions"], "rewards": self.seq["rewards"],
+                   "terminals": self.seq["terminals"], "agent_mask": self.seq["agent_mask"],
+                   "state": self.states_s.view(T1, B, -1), "filled": self.seq["filled"].view(T, B, 1)}
+            if self.use_actions_mask:
+                dst["avail_actions"] = self.seq["avail"].view(T1, B, -1)
+
+            def enqueue():
+                for e in range(n_epochs):
+                    ops.sample_replay_indices(self._idx, 1, memory.buffer_size, memory.size_dev, seed, 0, self._sample_counter)
+                    ops.counter_add(self._sample_counter, 1)
+                    memory.gather_into(self._idx, dst)
+                    self._step_rnn(B, T)
+                    ops.sum_partials(self.partials, T * B, 8, self._epoch_sums[e])
+            self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
+            enqueue()
+            if not (self.distributed_training and self.world_size > 1) and getattr(self.config, "use_hip_graph", True):
+                torch.cuda.synchronize()
+                g = ops.Graph()
+                with g:
+                    enqueue()
+                self._buf_graph = g
+        elif self._buf_graph is not None:
+            self._buf_graph.launch()
+        else:
+            self._buf_enqueue()
+        sums = self._epoch_sums.cpu().numpy()
+        info = {}
+        for e in range(n_epochs):
+            self.iterations += 1
+            info = self.callback.on_update_start(self.iterations, model=self.model) or {}
+            info.update(self._info_rnn(B, T, sums[e]))
+            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **self._cb_rnn(B, T)) or {})
         return info
 
     def update(self, sample):

@@ -7,7 +7,7 @@ stacked device tensors), so both QMIX_Learner implementations consume it.
 Layout: the reference keeps one NumPy array per agent and field, [n_envs][n_size][dim]; under parameter sharing all
 agents are homogeneous, so here each field is ONE time-major device array [n_size][n_envs][n_agents*dim]: the per-step
 write is one contiguous copy per field and a sampled transition is one contiguous row per field.
-The recurrent/episode variant (MARL_OffPolicyBuffer_RNN, :770-996) is SURVEY section 8f "next".
+HipMARLOffPolicyBufferRNN below is the recurrent / episode variant (MARL_OffPolicyBuffer_RNN, :770-996).
 """
 import numpy as np
 import torch
@@ -108,3 +108,146 @@ class HipMARLOffPolicyBuffer:
 
     def finish_path(self, *args, **kwargs):                   # memory_tools_marl.py:766-767
         return
+
+
+class HipMARLOffPolicyBufferRNN:
+    """MARL_OffPolicyBuffer_RNN (memory_tools_marl.py:770-996) in HBM: per-env staging rows (`episode_data`) collect the
+    running episodes, a finished episode is copied as one row into the ring (`data`), `sample` draws whole episodes.
+
+    Every field is [episode][slot][all agents of the step]: obs [T+1][N*obs], actions / rewards / terminals /
+    agent_mask [T][N], avail_actions [T+1][N*A], state [T+1][S], filled [T][1] (all float32; the reference keeps bools
+    for three of them and converts to float in build_training_data, marl_learner.py:354-385).  `store`,
+    `finish_path(s)`, `clear_episodes` and `sample` keep the reference's meaning, including that store_episodes copies
+    the WHOLE staging row -- slots past the end of a short episode still hold what an earlier, longer episode of the same
+    run_episodes() call left there (:935-949; masked by `filled`).  ptr and size live on the device (`ptr_size`), so
+    a step never needs the host to know which envs finished."""
+
+    def __init__(self, agent_keys, state_space=None, obs_space=None, act_space=None, n_envs=1, buffer_size=1,
+                 batch_size=1, max_episode_steps=1, device="cuda", **kwargs):
+        self.agent_keys = list(agent_keys)
+        self.n_agents = N = len(self.agent_keys)
+        self.n_envs, self.buffer_size, self.batch_size = n_envs, buffer_size, batch_size
+        self.max_eps_len = T = int(max_episode_steps)
+        self.device = device
+        self.store_global_state = state_space is not None
+        self.use_actions_mask = kwargs.get("use_actions_mask", False)
+        k0 = self.agent_keys[0]
+        self.obs_dim = int(np.prod(space2shape(obs_space[k0])))
+        self.state_dim = int(np.prod(space2shape(state_space))) if self.store_global_state else 0
+        # field -> (floats per slot, slots)
+        self.layout = {"obs": (N * self.obs_dim, T + 1), "actions": (N, T), "rewards": (N, T), "terminals": (N, T),
+                       "agent_mask": (N, T), "filled": (1, T)}
+        if self.store_global_state:
+            self.layout["state"] = (self.state_dim, T + 1)
+        if self.use_actions_mask:
+            shp = kwargs["avail_actions_shape"]
+            self.n_actions = int(np.prod(shp[k0] if isinstance(shp, dict) else shp))
+            self.layout["avail_actions"] = (N * self.n_actions, T + 1)
+        self.data_keys = list(self.layout)
+        mk = lambda rows: {k: torch.zeros(rows, sl, w, device=device) for k, (w, sl) in self.layout.items()}
+        self.data, self.episode_data = mk(buffer_size), mk(n_envs)
+        self.ptr_size = torch.zeros(2, dtype=torch.int32, device=device)       # ptr, size
+        self.size_dev = self.ptr_size[1:2]
+        self._ones = torch.ones(n_envs, 1, device=device)
+        self.stager = _Stager(n_envs, {k: ((w,), torch.float32) for k, (w, _) in self.layout.items() if k != "filled"}, device)
+        self._steps = torch.zeros(n_envs, dtype=torch.int32, device=device)
+
+    # -- host views of the device counters (one sync each; only the reference-style host API uses them) ---------------
+    @property
+    def ptr(self):
+        return int(self.ptr_size[0].item())
+
+    @property
+    def size(self):
+        return int(self.ptr_size[1].item())
+
+    @property
+    def full(self):
+        return self.size >= self.buffer_size
+
+    def clear(self):                                           # :822-857
+        for v in self.data.values():
+            v.zero_()
+        self.ptr_size.zero_()
+
+    def clear_episodes(self):                                  # :859-902
+        for v in self.episode_data.values():
+            v.zero_()
+
+    def _stack(self, v, width):
+        if isinstance(v, dict):
+            parts = [torch.as_tensor(np.asarray(v[k]) if not isinstance(v[k], torch.Tensor) else v[k]).to(torch.float32)
+                     .reshape(self.n_envs, -1) for k in self.agent_keys]
+            return torch.cat(parts, dim=1)
+        t = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+        return t.to(torch.float32).reshape(self.n_envs, width)
+
+    def _dev_steps(self, steps):
+        if isinstance(steps, torch.Tensor) and steps.is_cuda:
+            return steps.to(torch.int32).contiguous()
+        self._steps.copy_(torch.as_tensor(np.asarray(steps), dtype=torch.int32))
+        return self._steps
+
+    def store(self, **step_data):                              # :904-921
+        steps = self._dev_steps(step_data["episode_steps"])
+        items = {k: self._stack(v, self.layout[k][0]) for k, v in step_data.items() if k in self.layout and k != "filled"}
+        dev = self.stager.put(items)
+        fields = [(self.episode_data[k], dev[k], None, 4 * self.layout[k][0], self.layout[k][1], 0) for k in dev]
+        fields.append((self.episode_data["filled"], self._ones, None, 4, self.max_eps_len, 0))
+        ops.episode_store_step(fields, steps, self.n_envs)
+
+    def finish_paths(self, done, end_step, obs=None, state=None, avail_actions=None):
+        """finish_path (:951-968) for every env with done != 0, in env order, in two launches.  done [n_envs] f32,
+        end_step [n_envs] int32 (info['episode_step']), terminal obs / state / avail_actions as in `store`."""
+        term = {"obs": obs, "state": state if self.store_global_state else None,
+                "avail_actions": avail_actions if self.use_actions_mask else None}
+        term = {k: self._stack(v, self.layout[k][0]).contiguous() for k, v in term.items() if v is not None}
+        self._term_keep = term                                  # keep the temporaries alive until the launch ran
+        fields = [(self.data[k], self.episode_data[k], term.get(k), 4 * w, sl, 1 if k == "filled" else 0)
+                  for k, (w, sl) in self.layout.items()]
+        ops.episode_finish(fields, done.to(torch.float32).contiguous(), self._dev_steps(end_step), self.ptr_size,
+                           self.n_envs, self.buffer_size)
+
+    def finish_path(self, i_env, **terminal_data):            # :951-968, one env (the reference's call)
+        done = torch.zeros(self.n_envs, device=self.device)
+        done[i_env] = 1.0
+        end = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
+        end[i_env] = int(terminal_data["episode_step"])
+
+        def full(v, k):                                        # the reference passes one env's data: place it in row i_env
+            if v is None:
+                return None
+            row = torch.cat([torch.as_tensor(np.asarray(v[a])).to(torch.float32).reshape(-1) for a in self.agent_keys]) \
+                if isinstance(v, dict) else torch.as_tensor(np.asarray(v)).to(torch.float32).reshape(-1)
+            out = torch.zeros(self.n_envs, self.layout[k][0], device=self.device)
+            out[i_env] = row.to(self.device)
+            return out
+        self.finish_paths(done, end, obs=full(terminal_data.get("obs"), "obs"), state=full(terminal_data.get("state"), "state"),
+                          avail_actions=full(terminal_data.get("avail_actions"), "avail_actions"))
+
+    def gather_into(self, idx, dst):
+        """dst: field -> time-major device tensor [slots][B][row] (a learner's staging tensors); one launch."""
+        ops.episode_gather([(dst[k], self.data[k], None, 4 * self.layout[k][0], self.layout[k][1], 0) for k in dst],
+                           idx, idx.numel())
+
+    def sample(self, batch_size=None, indexes=None):           # :970-996
+        size = self.size
+        assert size > 0, "You need to first store experience data into the buffer!"
+        bs = self.batch_size if batch_size is None else batch_size
+        idx = np.random.choice(size, bs) if indexes is None else np.asarray(indexes)
+        idx = torch.as_tensor(idx).to(device=self.device, dtype=torch.int64).contiguous()
+        N, out = self.n_agents, {}
+        tm = {k: torch.empty(sl, bs, w, device=self.device) for k, (w, sl) in self.layout.items()}
+        self.gather_into(idx, tm)
+        for k, v in tm.items():
+            v = v.transpose(0, 1)                               # [B][slots][row] views, the reference's axis order
+            if k == "filled":
+                out[k] = v[..., 0]
+            elif k == "state":
+                out[k] = v
+            else:
+                vv = v.reshape(bs, v.shape[1], N, -1)
+                out[k] = {a: (vv[:, :, i, 0] if k in ("actions", "rewards", "terminals", "agent_mask") else vv[:, :, i])
+                          for i, a in enumerate(self.agent_keys)}
+        out["batch_size"], out["sequence_length"] = bs, self.max_eps_len
+        return out

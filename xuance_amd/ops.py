@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -344,6 +344,28 @@ def dqn_td(**kw):
 
 def qmix_mix_td(**kw):
     call("xrl_qmix_mix_td", C.byref(_struct(Qmix, kw)), stream_ptr())
+
+
+def _ep_fields(items):
+    """items: [(a, b, c or None, row_bytes, slots, flags)] of device tensors."""
+    arr = (EpisodeField * len(items))()
+    for i, (a, b, c, rb, slots, flags) in enumerate(items):
+        arr[i].a, arr[i].b, arr[i].c = a.data_ptr(), b.data_ptr(), (c.data_ptr() if c is not None else None)
+        arr[i].row_bytes, arr[i].slots, arr[i].flags = int(rb), int(slots), int(flags)
+    return arr
+
+
+def episode_store_step(items, steps, n_envs):
+    call("xrl_episode_store_step", _ep_fields(items), len(items), ptr(_chk(steps, torch.int32)), int(n_envs), stream_ptr())
+
+
+def episode_finish(items, done, end_step, ptr_size, n_envs, buffer_size):
+    call("xrl_episode_finish", _ep_fields(items), len(items), ptr(_chk(done)), ptr(_chk(end_step, torch.int32)),
+         ptr(_chk(ptr_size, torch.int32)), int(n_envs), int(buffer_size), stream_ptr())
+
+
+def episode_gather(items, idx, B):
+    call("xrl_episode_gather", _ep_fields(items), len(items), ptr(_chk(idx, torch.int64)), int(B), stream_ptr())
 
 
 def gru_forward(**kw):
