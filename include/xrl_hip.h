@@ -535,6 +535,9 @@ typedef struct {
     float* gates;         /* NULL or [T1][R][4H]: r | z | n | W_hn h + b_hn, kept for xrl_gru_backward */
     float* h_last;        /* NULL or [R][H]: h_{T1-1} (may alias h0: the state carried between acting steps) */
     int32_t R, T1, H, ld_gi;
+    /* optional second problem of the same launch (same R, T1, zero initial state, no gates kept): the target network's
+     * sequences of a QMIX update -- the recurrence is latency-bound, two problems cost the time of one.  gi2 NULL = none */
+    const float* gi2; const float* w_hh2; const float* b_hh2; float* hs2;
 } xrl_gru_fwd_t;
 int xrl_gru_forward(const xrl_gru_fwd_t* p, xrl_stream_t stream);
 

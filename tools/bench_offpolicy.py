@@ -78,8 +78,44 @@ def qmix_c5(steps):
             "update_us": round(update_us(agent), 1)}
 
 
+def qmix_c5_rnn(steps, backprop):
+    """configs/qmix/sc2/3m.yaml defaults: Basic_RNN (fc 64 + GRU 64), 60-step episodes, batch 32 EPISODES (1 920 steps,
+    5 856 agent rows), 8 updates after every n_envs episodes.  backprop: False = the reference's detached agents."""
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    n = 64
+    cfg = Namespace(q_hidden_size=[64], fc_hidden_sizes=[64], recurrent_hidden_size=64, hidden_dim_mixing_net=32,
+                    hidden_dim_hyper_net=32, activation="relu", seed=1, parallels=n, running_steps=10 ** 7, buffer_size=5000,
+                    batch_size=32, learning_rate=7e-4, gamma=0.99, double_q=True, start_greedy=1.0, end_greedy=0.05,
+                    decay_step_greedy=50000, sync_frequency=200, training_frequency=1, start_training=1000, n_epochs=8,
+                    use_grad_clip=False, grad_clip_norm=10.0, use_actions_mask=True, use_parameter_sharing=True,
+                    use_rnn=True, rnn_backprop_agents=backprop, episode_length=60, distributed_training=False, device="cuda",
+                    model_dir="/tmp/x")
+    agent = QMIX_Agents(cfg, SyntheticSMACVecEnv(n, seed=3))
+    agent.train(60)
+    torch.cuda.synchronize()
+    s0 = agent.current_step; t0 = time.perf_counter()
+    agent.train(steps)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    env_steps = agent.current_step - s0
+    lr, mem = agent.learner, agent.memory
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        lr._buf_graph.launch()
+    torch.cuda.synchronize(); graph_us = (time.perf_counter() - t0) / 20 * 1e6
+    return {"config": "C5 QMIX recurrent (3m.yaml: fc 64 + GRU 64, 60-step episodes), 64 envs/GPU x 3 agents, batch 32 episodes, "
+                      "8 updates per 64 episodes, agents " + ("trained (BPTT)" if backprop else "detached (reference behaviour)"),
+            "env_steps_per_s": round(env_steps / dt, 1), "update_graph_us_8_updates": round(graph_us, 1),
+            "update_us": round(graph_us / 8, 1), "transitions_per_update": 32 * 60}
+
+
 if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     torch.manual_seed(0); np.random.seed(0)
-    for fn in (dqn_c3, qmix_c5):
-        print(json.dumps(fn(steps)), flush=True)
+    which = sys.argv[2] if len(sys.argv) > 2 else "all"
+    if which in ("all", "ff"):
+        for fn in (dqn_c3, qmix_c5):
+            print(json.dumps(fn(steps)), flush=True)
+    if which in ("all", "rnn"):
+        for bp in (False, True):
+            print(json.dumps(qmix_c5_rnn(steps, bp)), flush=True)

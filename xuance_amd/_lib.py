@@ -99,7 +99,8 @@ class EpisodeField(C.Structure):
 class GruFwd(C.Structure):
     _fields_ = [("gi", c_void_p), ("w_hh", c_void_p), ("b_hh", c_void_p), ("h0", c_void_p), ("reset", c_void_p),
                 ("hs", c_void_p), ("gates", c_void_p), ("h_last", c_void_p),
-                ("R", c_int32), ("T1", c_int32), ("H", c_int32), ("ld_gi", c_int32)]
+                ("R", c_int32), ("T1", c_int32), ("H", c_int32), ("ld_gi", c_int32),
+                ("gi2", c_void_p), ("w_hh2", c_void_p), ("b_hh2", c_void_p), ("hs2", c_void_p)]
 
 
 class GruBwd(C.Structure):

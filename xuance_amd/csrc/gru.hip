@@ -23,13 +23,21 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 
 __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
     __shared__ __attribute__((aligned(16))) float hl[GH];
-    const int row = blockIdx.x, j = threadIdx.x;
+    const int j = threadIdx.x;
     const int R = p.R;
+    // second problem of the launch (same shapes, other weights / inputs: the target network of a QMIX update)
+    const bool second = (int)blockIdx.x >= R;
+    const int row = second ? blockIdx.x - R : blockIdx.x;
+    const float* w_hh = second ? p.w_hh2 : p.w_hh;
+    const float* b_hh = second ? p.b_hh2 : p.b_hh;
+    const float* gi_base = second ? p.gi2 : p.gi;
+    float* hs = second ? p.hs2 : p.hs;
+    float* gates = second ? nullptr : p.gates;
     float wr[GH], wz[GH], wn[GH];
     {
-        const float4* a = reinterpret_cast<const float4*>(p.w_hh + (size_t)j * GH);
-        const float4* b = reinterpret_cast<const float4*>(p.w_hh + (size_t)(GH + j) * GH);
-        const float4* c = reinterpret_cast<const float4*>(p.w_hh + (size_t)(2 * GH + j) * GH);
+        const float4* a = reinterpret_cast<const float4*>(w_hh + (size_t)j * GH);
+        const float4* b = reinterpret_cast<const float4*>(w_hh + (size_t)(GH + j) * GH);
+        const float4* c = reinterpret_cast<const float4*>(w_hh + (size_t)(2 * GH + j) * GH);
 #pragma unroll
         for (int q = 0; q < GH / 4; ++q) {
             const float4 x = a[q], y = b[q], z = c[q];
@@ -38,11 +46,11 @@ __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
             wn[4 * q] = z.x; wn[4 * q + 1] = z.y; wn[4 * q + 2] = z.z; wn[4 * q + 3] = z.w;
         }
     }
-    const float br = p.b_hh[j], bz = p.b_hh[GH + j], bn = p.b_hh[2 * GH + j];
-    float h = p.h0 ? p.h0[(size_t)row * GH + j] : 0.f;
-    if (p.reset && p.reset[row] != 0.f) h = 0.f;                            // init_rnn_states_item (rnn.py:86-92)
-    p.hs[(size_t)row * GH + j] = h;                                         // slot 0
-    const float* gi = p.gi + (size_t)row * p.ld_gi;
+    const float br = b_hh[j], bz = b_hh[GH + j], bn = b_hh[2 * GH + j];
+    float h = (p.h0 && !second) ? p.h0[(size_t)row * GH + j] : 0.f;
+    if (p.reset && !second && p.reset[row] != 0.f) h = 0.f;                 // init_rnn_states_item (rnn.py:86-92)
+    hs[(size_t)row * GH + j] = h;                                           // slot 0
+    const float* gi = gi_base + (size_t)row * p.ld_gi;
     float g_r = gi[j], g_z = gi[GH + j], g_n = gi[2 * GH + j];
     for (int t = 0; t < p.T1; ++t) {
         // next step's input-side gates do not depend on h: issue their loads before the dot products
@@ -52,7 +60,7 @@ __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
             nx_r = g2[j]; nx_z = g2[GH + j]; nx_n = g2[2 * GH + j];
         }
         hl[j] = h;
-        __syncthreads();                                                    // one wave per workgroup: LDS visibility only
+        lds_barrier();                      // LDS only: __syncthreads() would also drain the global stores / prefetch loads
         float ar = br, az = bz, an = bn;
 #pragma unroll
         for (int q = 0; q < GH / 4; ++q) {
@@ -64,20 +72,20 @@ __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
             an = fmaf(wn[4 * q], hv.x, an); an = fmaf(wn[4 * q + 1], hv.y, an);
             an = fmaf(wn[4 * q + 2], hv.z, an); an = fmaf(wn[4 * q + 3], hv.w, an);
         }
-        __syncthreads();                                                    // hl is rewritten next step
+        lds_barrier();                                                      // hl is rewritten next step
         const float r = sigmoid_f(g_r + ar);
         const float z = sigmoid_f(g_z + az);
         const float n = tanhf(g_n + r * an);
         h = (h - n) * z + n;
         const size_t o = (size_t)t * R + row;
-        p.hs[((size_t)(t + 1) * R + row) * GH + j] = h;
-        if (p.gates) {
-            float* g = p.gates + o * 4 * GH;
+        hs[((size_t)(t + 1) * R + row) * GH + j] = h;
+        if (gates) {
+            float* g = gates + o * 4 * GH;
             g[j] = r; g[GH + j] = z; g[2 * GH + j] = n; g[3 * GH + j] = an;
         }
         g_r = nx_r; g_z = nx_z; g_n = nx_n;
     }
-    if (p.h_last) p.h_last[(size_t)row * GH + j] = h;
+    if (p.h_last && !second) p.h_last[(size_t)row * GH + j] = h;
 }
 
 // BPTT.  Lane k owns hidden unit k: column k of W_hh (192 values) in registers.
@@ -89,12 +97,20 @@ __global__ void __launch_bounds__(64) gru_backward_kernel(xrl_gru_bwd_t p) {
 #pragma unroll
     for (int jj = 0; jj < 3 * GH; ++jj) wc[jj] = p.w_hh[(size_t)jj * GH + k];
     float carry = 0.f;
+    // operands of step t are loaded one step ahead (they do not depend on the carry)
+    size_t o = (size_t)(p.T1 - 1) * R + row;
+    const float* g = p.gates + o * 4 * GH;
+    float r = g[k], z = g[GH + k], n = g[2 * GH + k], hn = g[3 * GH + k];
+    float hp = p.hs[o * GH + k], dhs = p.d_hs[o * p.ld_dhs + k];            // hs slot t = h_{t-1}
     for (int t = p.T1 - 1; t >= 0; --t) {
-        const size_t o = (size_t)t * R + row;
-        const float* g = p.gates + o * 4 * GH;
-        const float r = g[k], z = g[GH + k], n = g[2 * GH + k], hn = g[3 * GH + k];
-        const float hp = p.hs[o * GH + k];                                  // slot t = h_{t-1}
-        const float dh = p.d_hs[o * p.ld_dhs + k] + carry;
+        float r2 = 0.f, z2 = 0.f, n2 = 0.f, hn2 = 0.f, hp2 = 0.f, dhs2 = 0.f;
+        if (t > 0) {
+            const size_t o2 = o - R;
+            const float* g2 = p.gates + o2 * 4 * GH;
+            r2 = g2[k]; z2 = g2[GH + k]; n2 = g2[2 * GH + k]; hn2 = g2[3 * GH + k];
+            hp2 = p.hs[o2 * GH + k]; dhs2 = p.d_hs[o2 * p.ld_dhs + k];
+        }
+        const float dh = dhs + carry;
         const float dn_pre = dh * (1.f - z) * (1.f - n * n);
         const float dz_pre = dh * (hp - n) * z * (1.f - z);
         const float dr_pre = dn_pre * hn * r * (1.f - r);
@@ -104,7 +120,7 @@ __global__ void __launch_bounds__(64) gru_backward_kernel(xrl_gru_bwd_t p) {
         float* dgh = p.d_gh + o * 3 * GH;
         dgh[k] = dr_pre; dgh[GH + k] = dz_pre; dgh[2 * GH + k] = dhn;
         gl[k] = dr_pre; gl[GH + k] = dz_pre; gl[2 * GH + k] = dhn;
-        __syncthreads();
+        lds_barrier();
         float acc = dh * z;
 #pragma unroll
         for (int q = 0; q < 3 * GH / 4; ++q) {
@@ -112,8 +128,10 @@ __global__ void __launch_bounds__(64) gru_backward_kernel(xrl_gru_bwd_t p) {
             acc = fmaf(gv.x, wc[4 * q], acc); acc = fmaf(gv.y, wc[4 * q + 1], acc);
             acc = fmaf(gv.z, wc[4 * q + 2], acc); acc = fmaf(gv.w, wc[4 * q + 3], acc);
         }
-        __syncthreads();
+        lds_barrier();
         carry = acc;
+        r = r2; z = z2; n = n2; hn = hn2; hp = hp2; dhs = dhs2;
+        o -= R;
     }
     if (p.d_h0) p.d_h0[(size_t)row * GH + k] = carry;
 }
@@ -126,7 +144,9 @@ extern "C" int xrl_gru_forward(const xrl_gru_fwd_t* p, xrl_stream_t stream) {
     XRL_CHECK_ARG(p && p->gi && p->w_hh && p->b_hh && p->hs);
     XRL_CHECK_ARG(p->H == GH);                       // one lane per hidden unit (3m.yaml: recurrent_hidden_size 64)
     XRL_CHECK_ARG(p->R > 0 && p->T1 > 0 && p->ld_gi >= 3 * GH);
-    hipLaunchKernelGGL(gru_forward_kernel, dim3(p->R), dim3(64), 0, as_stream(stream), *p);
+    const bool dual = p->gi2 != nullptr;
+    XRL_CHECK_ARG(!dual || (p->w_hh2 && p->b_hh2 && p->hs2));
+    hipLaunchKernelGGL(gru_forward_kernel, dim3(dual ? 2 * p->R : p->R), dim3(64), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

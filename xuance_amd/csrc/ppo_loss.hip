@@ -117,6 +117,24 @@ __global__ void __launch_bounds__(64) sum_partials_kernel(const double* __restri
     out[j] = s;
 }
 
+// Many rows (the recurrent QMIX update has T*B = 1920): 128 row chunks x 8 columns, fixed-order tree over the chunks.
+__global__ void __launch_bounds__(1024) sum_partials_wide_kernel(const double* __restrict__ partials, int n_rows, int width,
+                                                                 double* __restrict__ out) {
+    __shared__ double sh[1024];
+    const int j = threadIdx.x & 7, c = threadIdx.x >> 3;                     // width <= 8 here
+    const int per = (n_rows + 127) / 128;
+    double s = 0.0;
+    if (j < width)
+        for (int r = c * per; r < min(n_rows, (c + 1) * per); ++r) s += partials[(size_t)r * width + j];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int half = 64; half >= 1; half >>= 1) {
+        if (c < half) sh[threadIdx.x] += sh[threadIdx.x + half * 8];
+        __syncthreads();
+    }
+    if (c == 0 && j < width) out[j] = sh[j];
+}
+
 static int check(const xrl_ppo_loss_t* p, bool gaussian) {
     XRL_CHECK_ARG(p != nullptr);
     XRL_CHECK_ARG(p->out && p->value && p->actions && p->adv && p->returns && (p->old_logp || p->mode == 1) && p->d_out && p->d_value && p->partials);
@@ -149,7 +167,10 @@ extern "C" int xrl_ppo_loss_gaussian(const xrl_ppo_loss_t* p, xrl_stream_t strea
 
 extern "C" int xrl_sum_partials(const double* partials, int n_rows, int width, double* out, xrl_stream_t stream) {
     XRL_CHECK_ARG(partials && out && n_rows > 0 && width > 0 && width <= 64);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), partials, n_rows, width, out);
+    if (n_rows > 256 && width <= 8)
+        hipLaunchKernelGGL(sum_partials_wide_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, n_rows, width, out);
+    else
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), partials, n_rows, width, out);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

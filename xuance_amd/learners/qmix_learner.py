@@ -103,10 +103,13 @@ class QMIX_Learner(Learner):
         N, A, H = m.n_agents, m.n_actions, m.H
         R = B * N
         S = pick_n_split(R)
-        q_all = m.agent_plan.forward(self.X, m.obs_dim, 2 * R if self.double_q else R)            # iql_learner.py:41-47,68-71
-        q_next = m.agent_target_plan.forward(self.X[R:], m.obs_dim, R, flat=m.target_flat)        # :63-66
-        e_raw = m.mixer_plan.forward(self.states, m.state_dim, B)                                 # eval hyper-nets (state)
-        t_raw = m.mixer_target_plan.forward(self.states[B:], m.state_dim, B, flat=m.target_flat)  # target (state_next)
+        from ..nets import Plan
+        # eval network on obs (+ next_obs for the double-Q argmax) and target network on next_obs (iql_learner.py:41-47,
+        # 63-71); eval hyper-networks on state, target ones on state_next: each pair is one grouped launch per layer
+        q_all, q_next = Plan.forward_many([(m.agent_plan, self.X, m.obs_dim, 2 * R if self.double_q else R, None),
+                                           (m.agent_target_plan, self.X[R:], m.obs_dim, R, m.target_flat)])
+        e_raw, t_raw = Plan.forward_many([(m.mixer_plan, self.states, m.state_dim, B, None),
+                                          (m.mixer_target_plan, self.states[B:], m.state_dim, B, m.target_flat)])
         e_l1, t_l1 = m.mixer_plan.acts[1], m.mixer_target_plan.acts[1]
         d_l1, d_raw = m.mixer_plan.dacts[1], m.mixer_plan.dacts[2]
         ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]
@@ -168,10 +171,11 @@ class QMIX_Learner(Learner):
         N, A, H, T1 = m.n_agents, m.n_actions, m.H, T + 1
         R, BT = B * N, T * B
         S = pick_n_split(T1 * R)
-        q_all = m.agent_forward_seq(self.Xs, R, T1, which=0)                                   # iql_learner.py:39-47
-        q_tgt = m.agent_forward_seq(self.Xs, R, T1, which=1)                                   # :53-57
-        e_raw = m.mixer_plan.forward(self.states_s, m.state_dim, T1 * B)                       # eval mixer: slots 0..T-1 used
-        t_raw = m.mixer_target_plan.forward(self.states_s, m.state_dim, T1 * B, flat=m.target_flat)   # target: slots 1..T
+        from ..nets import Plan
+        q_all, q_tgt = m.agent_forward_seq_pair(self.Xs, R, T1)                                # iql_learner.py:39-47, 53-57
+        # hyper-networks of the eval mixer (slots 0..T-1 are used) and of the target mixer (slots 1..T): grouped launches
+        e_raw, t_raw = Plan.forward_many([(m.mixer_plan, self.states_s, m.state_dim, T1 * B, None),
+                                          (m.mixer_target_plan, self.states_s, m.state_dim, T1 * B, m.target_flat)])
         e_l1, t_l1 = m.mixer_plan.acts[1], m.mixer_target_plan.acts[1]
         d_l1, d_raw = m.mixer_plan.dacts[1], m.mixer_plan.dacts[2]
         ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]

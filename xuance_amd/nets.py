@@ -112,6 +112,26 @@ class Plan:
             ops.linear_fwd(groups)
         return self.acts[len(self.widths) - 1]
 
+    @staticmethod
+    def forward_many(items):
+        """Several plans of the same depth as ONE grouped launch per stage (e.g. an eval network and its target twin):
+        items = [(plan, x, ldx, M, flat)].  Returns each plan's output level."""
+        depth = len(items[0][0].stages)
+        assert all(len(it[0].stages) == depth for it in items)
+        for plan, x, ldx, M, flat in items:
+            plan.ensure(M)
+        for si in range(depth):
+            groups = []
+            for plan, x, ldx, M, flat in items:
+                P = plan.params
+                for L in plan.stages[si]:
+                    a, lda = plan._buf(plan.acts, L.in_level, L.in_off, x, ldx)
+                    c, ldc = plan._buf(plan.acts, L.out_level, L.out_off, x, ldx)
+                    groups.append(ops.gemm_desc(a, P.ptr(L.w_name, flat), c, M, L.N, L.K, lda, L.K, ldc,
+                                                bias=P.ptr(L.b_name, flat), act=L.act))
+            ops.linear_fwd(groups)
+        return [it[0].acts[len(it[0].widths) - 1] for it in items]
+
     def backward(self, x, ldx, M, slabs, n_split, flat=None, dx0=None):
         """dacts[last] must hold d loss / d (pre-activation) of the last level. Writes weight/bias gradient
         partials into slabs[s][layout of params].  dx0: optional [M, widths[0]] tensor receiving d loss / d input."""
@@ -513,6 +533,17 @@ class MixingQNet:
         ops.gru_forward(gi=gi, w_hh=P.ptr(self.w_hh, flat), b_hh=P.ptr(self.b_hh, flat), h0=h0, reset=reset, hs=ws["hs"],
                         gates=ws["gates"] if which == 0 else None, h_last=h_last, R=R, T1=T1, H=H, ld_gi=3 * H)
         return self.post_plans[which].forward(ws["hs"][R:], H, T1 * R, flat=flat)
+
+    def agent_forward_seq_pair(self, X, R, T1):
+        """Eval and target networks over the same sequences (iql_learner.py:41-57): the layers below and above the GRU as
+        grouped launches (eval + target in one), the two recurrences as one dual launch.  Returns (Q_eval, Q_target)."""
+        P, H, M, tf = self.params, self.RH, T1 * R, self.target_flat
+        ws0, ws1 = self.seq_workspace(0, R, T1), self.seq_workspace(1, R, T1)
+        gi0, gi1 = Plan.forward_many([(self.pre_plans[0], X, self.obs_dim, M, None), (self.pre_plans[1], X, self.obs_dim, M, tf)])
+        ops.gru_forward(gi=gi0, w_hh=P.ptr(self.w_hh), b_hh=P.ptr(self.b_hh), h0=None, reset=None, hs=ws0["hs"],
+                        gates=ws0["gates"], h_last=None, R=R, T1=T1, H=H, ld_gi=3 * H, gi2=gi1, w_hh2=P.ptr(self.w_hh, tf),
+                        b_hh2=P.ptr(self.b_hh, tf), hs2=ws1["hs"])
+        return Plan.forward_many([(self.post_plans[0], ws0["hs"][R:], H, M, None), (self.post_plans[1], ws1["hs"][R:], H, M, tf)])
 
     def agent_backward_seq(self, X, R, T1, slabs, n_split):
         """post_plans[0].dacts[last] holds dLoss/dQ [T1*R, A]: Q head, BPTT, W_hh/b_hh, then the layers below the GRU."""
