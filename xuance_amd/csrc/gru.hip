@@ -10,21 +10,39 @@
 // steps) that chain is latency-bound, not throughput-bound, so the recurrence runs ONE WAVEFRONT PER SEQUENCE with no
 // workgroup barrier and no cross-wave traffic at all: lane j owns hidden unit j and keeps its three rows of W_hh (forward)
 // or its column of W_hh (backward) in 192 registers for the whole sequence; the previous hidden state (forward) or the
-// gate gradients (backward) are broadcast to the wave through 256 / 768 bytes of LDS.  A step costs 192 FMAs per lane +
-// 16 (48) broadcast ds_read_b128; a 32-row MFMA tile would need 6 output tiles x 32 chained v_mfma_f32_32x32x2 per step
-// on one CU and leave all but 3 CUs idle.
+// gate gradients (backward) are broadcast to the wave through 256 / 768 bytes of LDS.  A step costs 96 v_pk_fma_f32 per
+// lane + 16 (48) broadcast ds_read_b128; a 32-row MFMA tile would need 6 output tiles x 32 chained v_mfma_f32_32x32x2 per
+// step on one CU and leave all but 3 CUs idle.  Per-step operands that do not depend on the recurrence (gi; saved gates
+// and d_hs in the backward pass) are loaded two steps ahead into a statically indexed 3-slot register ring, so no step
+// waits on a global round trip.
 #include "common.h"
 
 namespace xrl {
 
 constexpr int GH = 64;    // hidden width == wavefront width
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+typedef float v2f __attribute__((ext_vector_type(2)));
+// two fp32 FMAs per lane and issue slot (v_pk_fma_f32): the dot products run as two half-sums (k < 32 | k >= 32)
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the branchy libm expf / tanhf / IEEE division: the gate non-linearities sit
+// on the serial chain of every step.  Absolute error ~1e-7, far inside the 1e-5 parity tolerance.
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_f(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// One wave per workgroup and LDS operations of a wave execute in order: a ds_write followed by ds_reads of the same wave
+// needs no s_barrier.  This only stops the compiler from moving LDS accesses across the point.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
+    // h of the previous step, stored as pairs (h[u], h[u+32]) so that one ds_read_b128 yields two packed operands
     __shared__ __attribute__((aligned(16))) float hl[GH];
     const int j = threadIdx.x;
-    const int R = p.R;
+    const int R = p.R, T1 = p.T1;
     // second problem of the launch (same shapes, other weights / inputs: the target network of a QMIX update)
     const bool second = (int)blockIdx.x >= R;
     const int row = second ? blockIdx.x - R : blockIdx.x;
@@ -33,106 +51,130 @@ __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
     const float* gi_base = second ? p.gi2 : p.gi;
     float* hs = second ? p.hs2 : p.hs;
     float* gates = second ? nullptr : p.gates;
-    float wr[GH], wz[GH], wn[GH];
+    v2f wr[GH / 2], wz[GH / 2], wn[GH / 2];          // (W[j][k], W[j][k+32]) of the three gate rows of unit j
     {
         const float4* a = reinterpret_cast<const float4*>(w_hh + (size_t)j * GH);
         const float4* b = reinterpret_cast<const float4*>(w_hh + (size_t)(GH + j) * GH);
         const float4* c = reinterpret_cast<const float4*>(w_hh + (size_t)(2 * GH + j) * GH);
 #pragma unroll
-        for (int q = 0; q < GH / 4; ++q) {
-            const float4 x = a[q], y = b[q], z = c[q];
-            wr[4 * q] = x.x; wr[4 * q + 1] = x.y; wr[4 * q + 2] = x.z; wr[4 * q + 3] = x.w;
-            wz[4 * q] = y.x; wz[4 * q + 1] = y.y; wz[4 * q + 2] = y.z; wz[4 * q + 3] = y.w;
-            wn[4 * q] = z.x; wn[4 * q + 1] = z.y; wn[4 * q + 2] = z.z; wn[4 * q + 3] = z.w;
+        for (int q = 0; q < GH / 8; ++q) {
+            const float4 xl = a[q], xh = a[q + 8], yl = b[q], yh = b[q + 8], zl = c[q], zh = c[q + 8];
+            wr[4 * q] = {xl.x, xh.x}; wr[4 * q + 1] = {xl.y, xh.y}; wr[4 * q + 2] = {xl.z, xh.z}; wr[4 * q + 3] = {xl.w, xh.w};
+            wz[4 * q] = {yl.x, yh.x}; wz[4 * q + 1] = {yl.y, yh.y}; wz[4 * q + 2] = {yl.z, yh.z}; wz[4 * q + 3] = {yl.w, yh.w};
+            wn[4 * q] = {zl.x, zh.x}; wn[4 * q + 1] = {zl.y, zh.y}; wn[4 * q + 2] = {zl.z, zh.z}; wn[4 * q + 3] = {zl.w, zh.w};
         }
     }
     const float br = b_hh[j], bz = b_hh[GH + j], bn = b_hh[2 * GH + j];
     float h = (p.h0 && !second) ? p.h0[(size_t)row * GH + j] : 0.f;
     if (p.reset && !second && p.reset[row] != 0.f) h = 0.f;                 // init_rnn_states_item (rnn.py:86-92)
     hs[(size_t)row * GH + j] = h;                                           // slot 0
-    const float* gi = gi_base + (size_t)row * p.ld_gi;
-    float g_r = gi[j], g_z = gi[GH + j], g_n = gi[2 * GH + j];
-    for (int t = 0; t < p.T1; ++t) {
-        // next step's input-side gates do not depend on h: issue their loads before the dot products
-        float nx_r = 0.f, nx_z = 0.f, nx_n = 0.f;
-        if (t + 1 < p.T1) {
-            const float* g2 = gi + (size_t)(t + 1) * R * p.ld_gi;
-            nx_r = g2[j]; nx_z = g2[GH + j]; nx_n = g2[2 * GH + j];
-        }
-        hl[j] = h;
-        lds_barrier();                      // LDS only: __syncthreads() would also drain the global stores / prefetch loads
-        float ar = br, az = bz, an = bn;
+    const int pos = ((j & 31) << 1) | (j >> 5);
+    const float* gi = gi_base + (size_t)row * p.ld_gi + j;
+    const size_t gstep = (size_t)R * p.ld_gi;
+    // input-side gates of step t are loaded two steps ahead into a 3-slot register ring (they do not depend on h)
+    float gq[3][3];
 #pragma unroll
-        for (int q = 0; q < GH / 4; ++q) {
-            const float4 hv = reinterpret_cast<const float4*>(hl)[q];       // same address in every lane: broadcast
-            ar = fmaf(wr[4 * q], hv.x, ar); ar = fmaf(wr[4 * q + 1], hv.y, ar);
-            ar = fmaf(wr[4 * q + 2], hv.z, ar); ar = fmaf(wr[4 * q + 3], hv.w, ar);
-            az = fmaf(wz[4 * q], hv.x, az); az = fmaf(wz[4 * q + 1], hv.y, az);
-            az = fmaf(wz[4 * q + 2], hv.z, az); az = fmaf(wz[4 * q + 3], hv.w, az);
-            an = fmaf(wn[4 * q], hv.x, an); an = fmaf(wn[4 * q + 1], hv.y, an);
-            an = fmaf(wn[4 * q + 2], hv.z, an); an = fmaf(wn[4 * q + 3], hv.w, an);
-        }
-        lds_barrier();                                                      // hl is rewritten next step
-        const float r = sigmoid_f(g_r + ar);
-        const float z = sigmoid_f(g_z + az);
-        const float n = tanhf(g_n + r * an);
-        h = (h - n) * z + n;
-        const size_t o = (size_t)t * R + row;
-        hs[((size_t)(t + 1) * R + row) * GH + j] = h;
-        if (gates) {
-            float* g = gates + o * 4 * GH;
-            g[j] = r; g[GH + j] = z; g[2 * GH + j] = n; g[3 * GH + j] = an;
-        }
-        g_r = nx_r; g_z = nx_z; g_n = nx_n;
+    for (int s = 0; s < 2; ++s) {
+        const float* g2 = gi + (size_t)min(s, T1 - 1) * gstep;
+        gq[s][0] = g2[0]; gq[s][1] = g2[GH]; gq[s][2] = g2[2 * GH];
     }
+    int t = 0;
+#define GRU_FWD_STEP(CUR, NXT)                                                                                  \
+    {                                                                                                           \
+        {                                                                                                       \
+            const float* g2 = gi + (size_t)min(t + 2, T1 - 1) * gstep;                                          \
+            gq[NXT][0] = g2[0]; gq[NXT][1] = g2[GH]; gq[NXT][2] = g2[2 * GH];                                   \
+        }                                                                                                       \
+        hl[pos] = h;                                                                                            \
+        wave_lds_fence();                                                                                       \
+        v2f ar = {br, 0.f}, az = {bz, 0.f}, an = {bn, 0.f};                                                     \
+        _Pragma("unroll") for (int q = 0; q < GH / 4; ++q) {                                                    \
+            const float4 hv = reinterpret_cast<const float4*>(hl)[q];    /* same address in all lanes: broadcast */ \
+            const v2f h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};                                                     \
+            ar = pk_fma(wr[2 * q], h0, ar); ar = pk_fma(wr[2 * q + 1], h1, ar);                                 \
+            az = pk_fma(wz[2 * q], h0, az); az = pk_fma(wz[2 * q + 1], h1, az);                                 \
+            an = pk_fma(wn[2 * q], h0, an); an = pk_fma(wn[2 * q + 1], h1, an);                                 \
+        }                                                                                                       \
+        wave_lds_fence();                                                                                       \
+        const float hn = an.x + an.y;                                                                           \
+        const float r = sigmoid_f(gq[CUR][0] + (ar.x + ar.y));                                                  \
+        const float z = sigmoid_f(gq[CUR][1] + (az.x + az.y));                                                  \
+        const float n = tanh_f(gq[CUR][2] + r * hn);                                                            \
+        h = (h - n) * z + n;                                                                                    \
+        hs[((size_t)(t + 1) * R + row) * GH + j] = h;                                                           \
+        if (gates) {                                                                                            \
+            float* g = gates + ((size_t)t * R + row) * 4 * GH;                                                  \
+            g[j] = r; g[GH + j] = z; g[2 * GH + j] = n; g[3 * GH + j] = hn;                                     \
+        }                                                                                                       \
+        if (++t >= T1) break;                                                                                   \
+    }
+    for (;;) {
+        GRU_FWD_STEP(0, 2)
+        GRU_FWD_STEP(1, 0)
+        GRU_FWD_STEP(2, 1)
+    }
+#undef GRU_FWD_STEP
     if (p.h_last && !second) p.h_last[(size_t)row * GH + j] = h;
 }
 
-// BPTT.  Lane k owns hidden unit k: column k of W_hh (192 values) in registers.
+// BPTT.  Lane k owns hidden unit k: column k of W_hh (192 values) in registers, as pairs (W[e][k], W[e+96][k]).
 __global__ void __launch_bounds__(64) gru_backward_kernel(xrl_gru_bwd_t p) {
-    __shared__ __attribute__((aligned(16))) float gl[3 * GH];
+    __shared__ __attribute__((aligned(16))) float gl[3 * GH];      // gate gradients of the step, pairs (g[e], g[e+96])
     const int row = blockIdx.x, k = threadIdx.x;
-    const int R = p.R;
-    float wc[3 * GH];
+    const int R = p.R, T1 = p.T1;
+    v2f wc[3 * GH / 2];
 #pragma unroll
-    for (int jj = 0; jj < 3 * GH; ++jj) wc[jj] = p.w_hh[(size_t)jj * GH + k];
+    for (int e = 0; e < 3 * GH / 2; ++e) wc[e] = {p.w_hh[(size_t)e * GH + k], p.w_hh[(size_t)(e + 96) * GH + k]};
+    // entries k, 64+k, 128+k of the 192-vector: entry e lives at 2e (e < 96) or 2(e-96)+1
+    const int p0 = 2 * k, p1 = (k < 32) ? 2 * (64 + k) : 2 * (k - 32) + 1, p2 = 2 * (32 + k) + 1;
     float carry = 0.f;
-    // operands of step t are loaded one step ahead (they do not depend on the carry)
-    size_t o = (size_t)(p.T1 - 1) * R + row;
-    const float* g = p.gates + o * 4 * GH;
-    float r = g[k], z = g[GH + k], n = g[2 * GH + k], hn = g[3 * GH + k];
-    float hp = p.hs[o * GH + k], dhs = p.d_hs[o * p.ld_dhs + k];            // hs slot t = h_{t-1}
-    for (int t = p.T1 - 1; t >= 0; --t) {
-        float r2 = 0.f, z2 = 0.f, n2 = 0.f, hn2 = 0.f, hp2 = 0.f, dhs2 = 0.f;
-        if (t > 0) {
-            const size_t o2 = o - R;
-            const float* g2 = p.gates + o2 * 4 * GH;
-            r2 = g2[k]; z2 = g2[GH + k]; n2 = g2[2 * GH + k]; hn2 = g2[3 * GH + k];
-            hp2 = p.hs[o2 * GH + k]; dhs2 = p.d_hs[o2 * p.ld_dhs + k];
-        }
-        const float dh = dhs + carry;
-        const float dn_pre = dh * (1.f - z) * (1.f - n * n);
-        const float dz_pre = dh * (hp - n) * z * (1.f - z);
-        const float dr_pre = dn_pre * hn * r * (1.f - r);
-        const float dhn = dn_pre * r;
-        float* dgi = p.d_gi + o * p.ld_dgi;
-        dgi[k] = dr_pre; dgi[GH + k] = dz_pre; dgi[2 * GH + k] = dn_pre;
-        float* dgh = p.d_gh + o * 3 * GH;
-        dgh[k] = dr_pre; dgh[GH + k] = dz_pre; dgh[2 * GH + k] = dhn;
-        gl[k] = dr_pre; gl[GH + k] = dz_pre; gl[2 * GH + k] = dhn;
-        lds_barrier();
-        float acc = dh * z;
-#pragma unroll
-        for (int q = 0; q < 3 * GH / 4; ++q) {
-            const float4 gv = reinterpret_cast<const float4*>(gl)[q];
-            acc = fmaf(gv.x, wc[4 * q], acc); acc = fmaf(gv.y, wc[4 * q + 1], acc);
-            acc = fmaf(gv.z, wc[4 * q + 2], acc); acc = fmaf(gv.w, wc[4 * q + 3], acc);
-        }
-        lds_barrier();
-        carry = acc;
-        r = r2; z = z2; n = n2; hn = hn2; hp = hp2; dhs = dhs2;
-        o -= R;
+    // operands of step t: r z n hn | h_{t-1} | d_hs, loaded two steps ahead (they do not depend on the carry)
+    float op[3][6];
+    const float* gbase = p.gates + (size_t)row * 4 * GH + k;
+    const float* hbase = p.hs + (size_t)row * GH + k;                        // slot t = h_{t-1}
+    const float* dbase = p.d_hs + (size_t)row * p.ld_dhs + k;
+#define GRU_BWD_LOAD(S, TT)                                                                                     \
+    {                                                                                                           \
+        const size_t tt = (size_t)max((TT), 0);                                                                 \
+        const float* g = gbase + tt * R * 4 * GH;                                                               \
+        op[S][0] = g[0]; op[S][1] = g[GH]; op[S][2] = g[2 * GH]; op[S][3] = g[3 * GH];                          \
+        op[S][4] = hbase[tt * R * GH]; op[S][5] = dbase[tt * R * p.ld_dhs];                                     \
     }
+    int t = T1 - 1;
+    GRU_BWD_LOAD(0, t)
+    GRU_BWD_LOAD(1, t - 1)
+#define GRU_BWD_STEP(CUR, NXT)                                                                                  \
+    {                                                                                                           \
+        GRU_BWD_LOAD(NXT, t - 2)                                                                                \
+        const float r = op[CUR][0], z = op[CUR][1], n = op[CUR][2], hn = op[CUR][3], hp = op[CUR][4];           \
+        const float dh = op[CUR][5] + carry;                                                                    \
+        const float dn_pre = dh * (1.f - z) * (1.f - n * n);                                                    \
+        const float dz_pre = dh * (hp - n) * z * (1.f - z);                                                     \
+        const float dr_pre = dn_pre * hn * r * (1.f - r);                                                       \
+        const float dhn = dn_pre * r;                                                                           \
+        const size_t o = (size_t)t * R + row;                                                                   \
+        float* dgi = p.d_gi + o * p.ld_dgi;                                                                     \
+        dgi[k] = dr_pre; dgi[GH + k] = dz_pre; dgi[2 * GH + k] = dn_pre;                                        \
+        float* dgh = p.d_gh + o * 3 * GH;                                                                       \
+        dgh[k] = dr_pre; dgh[GH + k] = dz_pre; dgh[2 * GH + k] = dhn;                                           \
+        gl[p0] = dr_pre; gl[p1] = dz_pre; gl[p2] = dhn;                                                         \
+        wave_lds_fence();                                                                                       \
+        v2f acc = {dh * z, 0.f};                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 3 * GH / 4; ++q) {                                                \
+            const float4 gv = reinterpret_cast<const float4*>(gl)[q];                                           \
+            acc = pk_fma(v2f{gv.x, gv.y}, wc[2 * q], acc); acc = pk_fma(v2f{gv.z, gv.w}, wc[2 * q + 1], acc);   \
+        }                                                                                                       \
+        wave_lds_fence();                                                                                       \
+        carry = acc.x + acc.y;                                                                                  \
+        if (--t < 0) break;                                                                                     \
+    }
+    for (;;) {
+        GRU_BWD_STEP(0, 2)
+        GRU_BWD_STEP(1, 0)
+        GRU_BWD_STEP(2, 1)
+    }
+#undef GRU_BWD_STEP
+#undef GRU_BWD_LOAD
     if (p.d_h0) p.d_h0[(size_t)row * GH + k] = carry;
 }
 

@@ -120,8 +120,13 @@ class QMIX_Learner(Learner):
                         d_q=m.agent_plan.dacts[len(m.agent_plan.widths) - 1], d_e_b1=d_l1.data_ptr() + 4 * 3 * m.HH,
                         d_e_raw=d_raw, diag=self.diag, partials=self.partials, B=B, N=N, A=A, H=H, ldq=A, ld_e1=ld1,
                         ld_e2=ld2, ld_t1=ld1, ld_t2=ld2, double_q=int(self.double_q), gamma=float(self.gamma))
-        m.mixer_plan.backward(self.states, m.state_dim, B, self.slabs, S)
-        m.agent_plan.backward(self.X, m.obs_dim, R, self.slabs, S)
+        # data-gradient chains first, then the weight gradients of every layer of a plan as one grouped launch
+        wg = []
+        m.mixer_plan.backward(self.states, m.state_dim, B, self.slabs, S, defer_wgrad=wg)
+        ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
+        wg = []
+        m.agent_plan.backward(self.X, m.obs_dim, R, self.slabs, S, defer_wgrad=wg)
+        ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
         ops.grad_reduce(self.slabs, S, m.params.P, m.params.P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_
@@ -189,7 +194,9 @@ class QMIX_Learner(Learner):
                         d_q=d_q, d_e_b1=d_l1.data_ptr() + 4 * 3 * m.HH, d_e_raw=d_raw, diag=self.diag, partials=self.partials,
                         B=BT, N=N, A=A, H=H, ldq=A, ld_e1=ld1, ld_e2=ld2, ld_t1=ld1, ld_t2=ld2, double_q=int(self.double_q),
                         gamma=float(self.gamma), filled=self.seq["filled"])
-        m.mixer_plan.backward(self.states_s, m.state_dim, BT, self.slabs, S)
+        wg = []
+        m.mixer_plan.backward(self.states_s, m.state_dim, BT, self.slabs, S, defer_wgrad=wg)
+        ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
         if self.rnn_backprop_agents:
             m.agent_backward_seq(self.Xs, R, T1, self.slabs, S)
         ops.grad_reduce(self.slabs, S, m.params.P, m.params.P, opt.grad, self.sumsq)
