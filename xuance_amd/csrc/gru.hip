@@ -34,14 +34,17 @@ __device__ __forceinline__ float tanh_f(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
-// One wave per workgroup and LDS operations of a wave execute in order: a ds_write followed by ds_reads of the same wave
-// needs no s_barrier.  This only stops the compiler from moving LDS accesses across the point.
+// Two waves per sequence split every dot product of a step in halves (forward: k < 32 | k >= 32; backward: the first /
+// second 96 of the 192 gate gradients): 96 instead of 192 weight registers per lane leave room to have a whole step's
+// broadcast LDS reads in flight at once (with all 192 weights in one wave only ~2 ds_read_b128 fit, and their latency was
+// exposed 24 times per step).  Everything else of a step is computed redundantly by both waves, so the only cross-wave
+// traffic is the partial sums: one LDS exchange + one s_barrier per step (double-buffered by step parity).
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-__global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
-    // h of the previous step, stored as pairs (h[u], h[u+32]) so that one ds_read_b128 yields two packed operands
-    __shared__ __attribute__((aligned(16))) float hl[GH];
-    const int j = threadIdx.x;
+__global__ void __launch_bounds__(128) gru_forward_kernel(xrl_gru_fwd_t p) {
+    __shared__ __attribute__((aligned(16))) float hl[2][GH / 2];    // per wave: its k-half of h as pairs (h[k], h[k+16])
+    __shared__ float xch[2][2][3][GH];                              // [step parity][wave][gate][unit] partial sums
+    const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int R = p.R, T1 = p.T1;
     // second problem of the launch (same shapes, other weights / inputs: the target network of a QMIX update)
     const bool second = (int)blockIdx.x >= R;
@@ -50,15 +53,15 @@ __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
     const float* b_hh = second ? p.b_hh2 : p.b_hh;
     const float* gi_base = second ? p.gi2 : p.gi;
     float* hs = second ? p.hs2 : p.hs;
-    float* gates = second ? nullptr : p.gates;
-    v2f wr[GH / 2], wz[GH / 2], wn[GH / 2];          // (W[j][k], W[j][k+32]) of the three gate rows of unit j
+    float* gates = (second || w) ? nullptr : p.gates;               // wave 0 does the global stores
+    v2f wr[GH / 4], wz[GH / 4], wn[GH / 4];          // (W[j][k], W[j][k+16]), k in this wave's half, of unit j's three rows
     {
-        const float4* a = reinterpret_cast<const float4*>(w_hh + (size_t)j * GH);
-        const float4* b = reinterpret_cast<const float4*>(w_hh + (size_t)(GH + j) * GH);
-        const float4* c = reinterpret_cast<const float4*>(w_hh + (size_t)(2 * GH + j) * GH);
+        const float4* a = reinterpret_cast<const float4*>(w_hh + (size_t)j * GH + 32 * w);
+        const float4* b = reinterpret_cast<const float4*>(w_hh + (size_t)(GH + j) * GH + 32 * w);
+        const float4* c = reinterpret_cast<const float4*>(w_hh + (size_t)(2 * GH + j) * GH + 32 * w);
 #pragma unroll
-        for (int q = 0; q < GH / 8; ++q) {
-            const float4 xl = a[q], xh = a[q + 8], yl = b[q], yh = b[q + 8], zl = c[q], zh = c[q + 8];
+        for (int q = 0; q < 4; ++q) {
+            const float4 xl = a[q], xh = a[q + 4], yl = b[q], yh = b[q + 4], zl = c[q], zh = c[q + 4];
             wr[4 * q] = {xl.x, xh.x}; wr[4 * q + 1] = {xl.y, xh.y}; wr[4 * q + 2] = {xl.z, xh.z}; wr[4 * q + 3] = {xl.w, xh.w};
             wz[4 * q] = {yl.x, yh.x}; wz[4 * q + 1] = {yl.y, yh.y}; wz[4 * q + 2] = {yl.z, yh.z}; wz[4 * q + 3] = {yl.w, yh.w};
             wn[4 * q] = {zl.x, zh.x}; wn[4 * q + 1] = {zl.y, zh.y}; wn[4 * q + 2] = {zl.z, zh.z}; wn[4 * q + 3] = {zl.w, zh.w};
@@ -67,8 +70,9 @@ __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
     const float br = b_hh[j], bz = b_hh[GH + j], bn = b_hh[2 * GH + j];
     float h = (p.h0 && !second) ? p.h0[(size_t)row * GH + j] : 0.f;
     if (p.reset && !second && p.reset[row] != 0.f) h = 0.f;                 // init_rnn_states_item (rnn.py:86-92)
-    hs[(size_t)row * GH + j] = h;                                           // slot 0
-    const int pos = ((j & 31) << 1) | (j >> 5);
+    if (w == 0) hs[(size_t)row * GH + j] = h;                               // slot 0
+    const bool mine = (j >> 5) == w;                                        // this lane's unit lies in this wave's k-half
+    const int pos = ((j & 15) << 1) | ((j >> 4) & 1);                       // k-in-half kk: pair (kk, kk+16) -> 2*(kk&15) + (kk>>4)
     const float* gi = gi_base + (size_t)row * p.ld_gi + j;
     const size_t gstep = (size_t)R * p.ld_gi;
     // input-side gates of step t are loaded two steps ahead into a 3-slot register ring (they do not depend on h)
@@ -85,23 +89,29 @@ __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
             const float* g2 = gi + (size_t)min(t + 2, T1 - 1) * gstep;                                          \
             gq[NXT][0] = g2[0]; gq[NXT][1] = g2[GH]; gq[NXT][2] = g2[2 * GH];                                   \
         }                                                                                                       \
-        hl[pos] = h;                                                                                            \
+        if (mine) hl[w][pos] = h;                                                                               \
         wave_lds_fence();                                                                                       \
-        v2f ar = {br, 0.f}, az = {bz, 0.f}, an = {bn, 0.f};                                                     \
-        _Pragma("unroll") for (int q = 0; q < GH / 4; ++q) {                                                    \
-            const float4 hv = reinterpret_cast<const float4*>(hl)[q];    /* same address in all lanes: broadcast */ \
+        v2f ar = {0.f, 0.f}, az = {0.f, 0.f}, an = {0.f, 0.f};                                                  \
+        float4 hq[GH / 8];               /* all broadcast reads of the step in flight before the first FMA */   \
+        _Pragma("unroll") for (int q = 0; q < GH / 8; ++q) hq[q] = reinterpret_cast<const float4*>(hl[w])[q];   \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int q = 0; q < GH / 8; ++q) {                                                    \
+            const float4 hv = hq[q];                                                                            \
             const v2f h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};                                                     \
             ar = pk_fma(wr[2 * q], h0, ar); ar = pk_fma(wr[2 * q + 1], h1, ar);                                 \
             az = pk_fma(wz[2 * q], h0, az); az = pk_fma(wz[2 * q + 1], h1, az);                                 \
             an = pk_fma(wn[2 * q], h0, an); an = pk_fma(wn[2 * q + 1], h1, an);                                 \
         }                                                                                                       \
-        wave_lds_fence();                                                                                       \
-        const float hn = an.x + an.y;                                                                           \
-        const float r = sigmoid_f(gq[CUR][0] + (ar.x + ar.y));                                                  \
-        const float z = sigmoid_f(gq[CUR][1] + (az.x + az.y));                                                  \
+        float(*x)[3][GH] = xch[t & 1];                                                                          \
+        x[w][0][j] = ar.x + ar.y; x[w][1][j] = az.x + az.y; x[w][2][j] = an.x + an.y;                           \
+        lds_barrier();                                                                                          \
+        const float sr = br + (x[0][0][j] + x[1][0][j]), sz = bz + (x[0][1][j] + x[1][1][j]);                   \
+        const float hn = bn + (x[0][2][j] + x[1][2][j]);                                                        \
+        const float r = sigmoid_f(gq[CUR][0] + sr);                                                             \
+        const float z = sigmoid_f(gq[CUR][1] + sz);                                                             \
         const float n = tanh_f(gq[CUR][2] + r * hn);                                                            \
         h = (h - n) * z + n;                                                                                    \
-        hs[((size_t)(t + 1) * R + row) * GH + j] = h;                                                           \
+        if (w == 0) hs[((size_t)(t + 1) * R + row) * GH + j] = h;                                               \
         if (gates) {                                                                                            \
             float* g = gates + ((size_t)t * R + row) * 4 * GH;                                                  \
             g[j] = r; g[GH + j] = z; g[2 * GH + j] = n; g[3 * GH + j] = hn;                                     \
@@ -114,19 +124,25 @@ __global__ void __launch_bounds__(64) gru_forward_kernel(xrl_gru_fwd_t p) {
         GRU_FWD_STEP(2, 1)
     }
 #undef GRU_FWD_STEP
-    if (p.h_last && !second) p.h_last[(size_t)row * GH + j] = h;
+    if (p.h_last && !second && w == 0) p.h_last[(size_t)row * GH + j] = h;
 }
 
-// BPTT.  Lane k owns hidden unit k: column k of W_hh (192 values) in registers, as pairs (W[e][k], W[e+96][k]).
-__global__ void __launch_bounds__(64) gru_backward_kernel(xrl_gru_bwd_t p) {
-    __shared__ __attribute__((aligned(16))) float gl[3 * GH];      // gate gradients of the step, pairs (g[e], g[e+96])
-    const int row = blockIdx.x, k = threadIdx.x;
+// BPTT.  Lane k owns hidden unit k: its wave's half of column k of W_hh (96 of 192 values), as pairs (W[e][k], W[e+48][k]).
+__global__ void __launch_bounds__(128) gru_backward_kernel(xrl_gru_bwd_t p) {
+    __shared__ __attribute__((aligned(16))) float gl[2][3 * GH / 2];   // per wave: its 96 gate gradients, pairs (g[e], g[e+48])
+    __shared__ float xch[2][2][GH];                                    // [step parity][wave][unit] partial sums
+    const int row = blockIdx.x, k = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int R = p.R, T1 = p.T1;
-    v2f wc[3 * GH / 2];
+    v2f wc[3 * GH / 4];
 #pragma unroll
-    for (int e = 0; e < 3 * GH / 2; ++e) wc[e] = {p.w_hh[(size_t)e * GH + k], p.w_hh[(size_t)(e + 96) * GH + k]};
-    // entries k, 64+k, 128+k of the 192-vector: entry e lives at 2e (e < 96) or 2(e-96)+1
-    const int p0 = 2 * k, p1 = (k < 32) ? 2 * (64 + k) : 2 * (k - 32) + 1, p2 = 2 * (32 + k) + 1;
+    for (int e = 0; e < 3 * GH / 4; ++e)
+        wc[e] = {p.w_hh[(size_t)(96 * w + e) * GH + k], p.w_hh[(size_t)(96 * w + e + 48) * GH + k]};
+    // the 192-vector is dr_pre[0..63] | dz_pre[0..63] | dhn[0..63]; wave 0 needs entries 0..95, wave 1 entries 96..191.
+    // local entry le (0..95) lives at 2*le (le < 48) or 2*(le-48)+1.
+    auto lpos = [](int le) { return le < 48 ? 2 * le : 2 * (le - 48) + 1; };
+    const int pa = lpos(w == 0 ? k : 32 + k);                         // wave 0: dr_pre[k] -> le k;  wave 1: dhn[k] -> le 32+k
+    const bool has_b = (w == 0) ? (k < 32) : (k >= 32);               // dz_pre[k]: wave 0 takes k < 32 (le 64+k), wave 1 k >= 32 (le k-32)
+    const int pb = lpos(w == 0 ? 64 + (k & 31) : (k & 31));
     float carry = 0.f;
     // operands of step t: r z n hn | h_{t-1} | d_hs, loaded two steps ahead (they do not depend on the carry)
     float op[3][6];
@@ -152,20 +168,28 @@ __global__ void __launch_bounds__(64) gru_backward_kernel(xrl_gru_bwd_t p) {
         const float dz_pre = dh * (hp - n) * z * (1.f - z);                                                     \
         const float dr_pre = dn_pre * hn * r * (1.f - r);                                                       \
         const float dhn = dn_pre * r;                                                                           \
-        const size_t o = (size_t)t * R + row;                                                                   \
-        float* dgi = p.d_gi + o * p.ld_dgi;                                                                     \
-        dgi[k] = dr_pre; dgi[GH + k] = dz_pre; dgi[2 * GH + k] = dn_pre;                                        \
-        float* dgh = p.d_gh + o * 3 * GH;                                                                       \
-        dgh[k] = dr_pre; dgh[GH + k] = dz_pre; dgh[2 * GH + k] = dhn;                                           \
-        gl[p0] = dr_pre; gl[p1] = dz_pre; gl[p2] = dhn;                                                         \
+        if (w == 0) {                                                                                           \
+            const size_t o = (size_t)t * R + row;                                                               \
+            float* dgi = p.d_gi + o * p.ld_dgi;                                                                 \
+            dgi[k] = dr_pre; dgi[GH + k] = dz_pre; dgi[2 * GH + k] = dn_pre;                                    \
+            float* dgh = p.d_gh + o * 3 * GH;                                                                   \
+            dgh[k] = dr_pre; dgh[GH + k] = dz_pre; dgh[2 * GH + k] = dhn;                                       \
+        }                                                                                                       \
+        gl[w][pa] = (w == 0) ? dr_pre : dhn;                                                                    \
+        if (has_b) gl[w][pb] = dz_pre;                                                                          \
         wave_lds_fence();                                                                                       \
-        v2f acc = {dh * z, 0.f};                                                                                \
-        _Pragma("unroll") for (int q = 0; q < 3 * GH / 4; ++q) {                                                \
-            const float4 gv = reinterpret_cast<const float4*>(gl)[q];                                           \
+        v2f acc = {0.f, 0.f};                                                                                   \
+        float4 gq4[3 * GH / 8];          /* all 24 broadcast reads in flight before the first FMA */            \
+        _Pragma("unroll") for (int q = 0; q < 3 * GH / 8; ++q) gq4[q] = reinterpret_cast<const float4*>(gl[w])[q]; \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 3 * GH / 8; ++q) {                                                \
+            const float4 gv = gq4[q];                                                                           \
             acc = pk_fma(v2f{gv.x, gv.y}, wc[2 * q], acc); acc = pk_fma(v2f{gv.z, gv.w}, wc[2 * q + 1], acc);   \
         }                                                                                                       \
-        wave_lds_fence();                                                                                       \
-        carry = acc.x + acc.y;                                                                                  \
+        float(*x)[GH] = xch[t & 1];                                                                             \
+        x[w][k] = acc.x + acc.y;                                                                                \
+        lds_barrier();                                                                                          \
+        carry = dh * z + (x[0][k] + x[1][k]);                                                                   \
         if (--t < 0) break;                                                                                     \
     }
     for (;;) {
@@ -175,7 +199,7 @@ __global__ void __launch_bounds__(64) gru_backward_kernel(xrl_gru_bwd_t p) {
     }
 #undef GRU_BWD_STEP
 #undef GRU_BWD_LOAD
-    if (p.d_h0) p.d_h0[(size_t)row * GH + k] = carry;
+    if (p.d_h0 && w == 0) p.d_h0[(size_t)row * GH + k] = carry;
 }
 
 }  // namespace xrl
@@ -188,7 +212,7 @@ extern "C" int xrl_gru_forward(const xrl_gru_fwd_t* p, xrl_stream_t stream) {
     XRL_CHECK_ARG(p->R > 0 && p->T1 > 0 && p->ld_gi >= 3 * GH);
     const bool dual = p->gi2 != nullptr;
     XRL_CHECK_ARG(!dual || (p->w_hh2 && p->b_hh2 && p->hs2));
-    hipLaunchKernelGGL(gru_forward_kernel, dim3(dual ? 2 * p->R : p->R), dim3(64), 0, as_stream(stream), *p);
+    hipLaunchKernelGGL(gru_forward_kernel, dim3(dual ? 2 * p->R : p->R), dim3(128), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
@@ -197,7 +221,7 @@ extern "C" int xrl_gru_backward(const xrl_gru_bwd_t* p, xrl_stream_t stream) {
     XRL_CHECK_ARG(p && p->d_hs && p->hs && p->gates && p->w_hh && p->d_gi && p->d_gh);
     XRL_CHECK_ARG(p->H == GH);
     XRL_CHECK_ARG(p->R > 0 && p->T1 > 0 && p->ld_dhs >= GH && p->ld_dgi >= 3 * GH);
-    hipLaunchKernelGGL(gru_backward_kernel, dim3(p->R), dim3(64), 0, as_stream(stream), *p);
+    hipLaunchKernelGGL(gru_backward_kernel, dim3(p->R), dim3(128), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

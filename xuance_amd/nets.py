@@ -568,180 +568,6 @@ class MixingQNet:
             ops.linear_bwd_weight(wg, n_split, slabs.shape[1])
 
     def _target_key(self, k):
-        if k.startswith("target_representation."):
-            return k[len("target_"):]
-        if k.startswith("target_Q_head."):
-            return "eval_Q_head." + k[len("target_Q_head."):]
-        return None
-
-    def state_dict(self):
-        out = OrderedDict()
-        for k in self.ref_order:
-            tk = self._target_key(k)
-            out[k] = (self.params.view(tk, self.target_flat) if tk else self.params.view(k)).detach().clone()
-        return out
-
-    def load_state_dict(self, sd):
-        for k in self.ref_order:
-            tk = self._target_key(k)
-            dst = self.params.view(tk, self.target_flat) if tk else self.params.view(k)
-            dst.copy_(torch.as_tensor(sd[k], dtype=torch.float32))
-
-    def copy_target(self):                                        # deep_q_network.py:95-99
-        self.target_flat.copy_(self.params.flat)
-
-    def forward(self, x, M, ldx=None):
-        """x holds x.shape[0] >= M rows; all rows are evaluated, backward() differentiates the first M."""
-        return self.plan.forward(x, self.obs_dim if ldx is None else ldx, x.shape[0])
-
-    def target(self, x, M, ldx=None):
-        return self.target_plan.forward(x, self.obs_dim if ldx is None else ldx, M, flat=self.target_flat)
-
-    @property
-    def d_out(self):
-        return self.plan.dacts[len(self.plan.widths) - 1]
-
-    def backward(self, x, M, slabs, n_split):
-        self.plan.backward(x, self.obs_dim, M, slabs, n_split)
-
-
-class MixingQNet:
-    """MixingQNetwork(ModuleDict{group: DiscreteActionValueCritic(AgentFeatureEncoder(Basic_MLP))}, QMIX_Mixer)
-    with parameter sharing (one group) and identity encoding 'none'
-    (architectures/multi_agent/value_factorization.py:17-174, critics/base_critics.py:91-132, heads/q_mix_head.py:28-95).
-    Agent network and mixer share ONE flat parameter buffer (one optimiser step); the targets are a second buffer."""
-
-    def __init__(self, n_agents, obs_dim, n_actions, state_dim, representation_hidden=(64,), q_hidden=(64,),
-                 mixer_hidden=32, hyper_hidden=32, activation="relu", group="shared", device="cuda", init=True,
-                 use_rnn=False, fc_hidden=(64,), recurrent_hidden=64):
-        self.n_agents, self.obs_dim, self.n_actions, self.state_dim = n_agents, obs_dim, n_actions, state_dim
-        self.H, self.HH, self.group = mixer_hidden, hyper_hidden, group
-        self.use_rnn, self.RH = bool(use_rnn), int(recurrent_hidden)
-        N, H, HH, S = n_agents, mixer_hidden, hyper_hidden, state_dim
-        specs, a_order, a_stages, a_widths = [], [], [], [obs_dim]
-        pe = f"individual_q_networks.{group}"
-        if not use_rnn:
-            feat, lvl = _seq_layers(f"{pe}.representation.obs_representation.model", obs_dim, list(representation_hidden),
-                                    activation, "same", 0, specs, a_order, a_stages, a_widths)
-            _seq_layers(f"{pe}.critic_head.q_value", feat, list(q_hidden) + [n_actions], activation, None, lvl, specs,
-                        a_order, a_stages, a_widths)
-        else:
-            # Basic_RNN (rnn.py:38-77): mlp blocks, then nn.GRU; the input-side GRU product is the last layer of the
-            # "pre" plan (no activation), the recurrence is xrl_gru_forward, the Q head is the "post" plan.
-            assert recurrent_hidden == 64, "xrl_gru_forward keeps one hidden unit per lane: recurrent_hidden_size must be 64"
-            rp, G = f"{pe}.representation.obs_representation", 3 * recurrent_hidden
-            feat, lvl = _seq_layers(f"{rp}.mlp", obs_dim, list(fc_hidden), activation, "same", 0, specs, a_order,
-                                    a_stages, a_widths)
-            self.w_ih, self.w_hh, self.b_ih, self.b_hh = (f"{rp}.rnn.weight_ih_l0", f"{rp}.rnn.weight_hh_l0",
-                                                          f"{rp}.rnn.bias_ih_l0", f"{rp}.rnn.bias_hh_l0")
-            specs += [(self.w_ih, (G, feat)), (self.w_hh, (G, recurrent_hidden)), (self.b_ih, (G,)), (self.b_hh, (G,))]
-            a_order += [self.w_ih, self.w_hh, self.b_ih, self.b_hh]               # nn.GRU parameter order
-            a_stages.append([Layer(f"{rp}.rnn.ih", feat, G, None, lvl, 0, lvl + 1, 0, self.w_ih, self.b_ih)])
-            a_widths.append(G)
-            q_stages, q_widths = [], [recurrent_hidden]
-            _seq_layers(f"{pe}.critic_head.q_value", recurrent_hidden, list(q_hidden) + [n_actions], activation, None, 0,
-                        specs, a_order, q_stages, q_widths)
-        # mixer hyper-networks: the three ReLU first layers are stacked into one GEMM ([hyper_w_1.0; hyper_w_2.0;
-        # hyper_b_2.0]), hyper_b_1 is a second group of the same launch; second layers are three groups.
-        m = "eval_Qtot"
-        firsts = [f"{m}.hyper_w_1.0", f"{m}.hyper_w_2.0", f"{m}.hyper_b_2.0"]
-        specs += [(n + ".weight", (HH, S)) for n in firsts] + [(n + ".bias", (HH,)) for n in firsts]
-        specs += [(f"{m}.hyper_b_1.weight", (H, S)), (f"{m}.hyper_b_1.bias", (H,)),
-                  (f"{m}.hyper_w_1.2.weight", (N * H, HH)), (f"{m}.hyper_w_1.2.bias", (N * H,)),
-                  (f"{m}.hyper_w_2.2.weight", (H, HH)), (f"{m}.hyper_w_2.2.bias", (H,)),
-                  (f"{m}.hyper_b_2.2.weight", (1, HH)), (f"{m}.hyper_b_2.2.bias", (1,))]
-        assert (HH * S) % 4 == 0 and HH % 4 == 0
-        self.raw_width = N * H + H + 1
-        m_widths = [S, 3 * HH + H, (self.raw_width + 3) // 4 * 4]
-        m_stages = [[Layer("+".join(firsts), S, 3 * HH, "relu", 0, 0, 1, 0, firsts[0] + ".weight", firsts[0] + ".bias"),
-                     Layer(f"{m}.hyper_b_1", S, H, None, 0, 0, 1, 3 * HH, f"{m}.hyper_b_1.weight", f"{m}.hyper_b_1.bias")],
-                    [Layer(f"{m}.hyper_w_1.2", HH, N * H, None, 1, 0, 2, 0, f"{m}.hyper_w_1.2.weight", f"{m}.hyper_w_1.2.bias"),
-                     Layer(f"{m}.hyper_w_2.2", HH, H, None, 1, HH, 2, N * H, f"{m}.hyper_w_2.2.weight", f"{m}.hyper_w_2.2.bias"),
-                     Layer(f"{m}.hyper_b_2.2", HH, 1, None, 1, 2 * HH, 2, N * H + H, f"{m}.hyper_b_2.2.weight", f"{m}.hyper_b_2.2.bias")]]
-        mixer_order = []
-        for n in (f"{m}.hyper_w_1.0", f"{m}.hyper_w_1.2", f"{m}.hyper_w_2.0", f"{m}.hyper_w_2.2", f"{m}.hyper_b_1",
-                  f"{m}.hyper_b_2.0", f"{m}.hyper_b_2.2"):
-            mixer_order += [n + ".weight", n + ".bias"]
-        self.params = FlatParams(specs, device)
-        self.target_flat = self.params.like()
-        if not use_rnn:
-            self.agent_plan = Plan(self.params, a_widths, a_stages)
-            self.agent_target_plan = Plan(self.params, a_widths, a_stages)
-        else:
-            # [update eval, update target, acting]: separate activation buffers (captured graphs keep their pointers)
-            self.pre_plans = [Plan(self.params, a_widths, a_stages) for _ in range(3)]
-            self.post_plans = [Plan(self.params, q_widths, q_stages) for _ in range(3)]
-            self._seq_ws = {}
-        self.mixer_plan = Plan(self.params, m_widths, m_stages)
-        self.mixer_target_plan = Plan(self.params, m_widths, m_stages)
-        self.trainable_order = a_order + mixer_order
-        # reference order: individual_q_networks, target_individual_q_networks, eval_Qtot, target_Qtot
-        self.ref_order = a_order + ["target_" + k for k in a_order] + mixer_order + \
-            ["target_Qtot." + k[len("eval_Qtot."):] for k in mixer_order]
-        if init:
-            for name in self.trainable_order:
-                v = self.params.view(name)
-                if (name.endswith(".weight") or "rnn.weight_" in name) and name.startswith("individual_q_networks"):
-                    v.copy_(_orthogonal(v.shape))               # gru_block: orthogonal on 2-D weights, 0 on biases (layers.py:91-97)
-                elif name.startswith("eval_Qtot"):       # nn.Linear default init (q_mix_head.py builds plain nn.Linear)
-                    fan_in = self.params.shapes[name[:-5] + ".weight" if name.endswith(".bias") else name][1]
-                    bound = 1.0 / fan_in ** 0.5
-                    v.copy_((torch.rand(v.shape) * 2 - 1) * bound)
-                else:
-                    v.zero_()
-            self.copy_target()
-
-    # ---------------------------------------------------------------- recurrent agents (time-major sequences)
-    def seq_workspace(self, which, R, T1):
-        key = (which, R, T1)
-        ws = self._seq_ws.get(key)
-        if ws is None:
-            dev, H = self.params.device, self.RH
-            ws = {"hs": torch.zeros((T1 + 1) * R, H, device=dev), "gates": torch.zeros(T1 * R, 4 * H, device=dev)}
-            if which == 0:
-                ws["d_hs"] = torch.zeros(T1 * R, H, device=dev)
-                ws["d_gh"] = torch.zeros(T1 * R, 3 * H, device=dev)
-            self._seq_ws[key] = ws
-            self.pre_plans[which].ensure(T1 * R)
-            self.post_plans[which].ensure(T1 * R)
-        return ws
-
-    def agent_forward_seq(self, X, R, T1, which=0, h0=None, reset=None, h_last=None):
-        """Q values of R sequences over T1 steps.  X [T1*R, obs_dim] time-major (row t*R + r) -> [T1*R, n_actions].
-        which: 0 = eval network (keeps what BPTT needs), 1 = target network, 2 = eval network for acting."""
-        flat = self.target_flat if which == 1 else None
-        P, H = self.params, self.RH
-        ws = self.seq_workspace(which, R, T1)
-        gi = self.pre_plans[which].forward(X, self.obs_dim, T1 * R, flat=flat)
-        ops.gru_forward(gi=gi, w_hh=P.ptr(self.w_hh, flat), b_hh=P.ptr(self.b_hh, flat), h0=h0, reset=reset, hs=ws["hs"],
-                        gates=ws["gates"] if which == 0 else None, h_last=h_last, R=R, T1=T1, H=H, ld_gi=3 * H)
-        return self.post_plans[which].forward(ws["hs"][R:], H, T1 * R, flat=flat)
-
-    def agent_forward_seq_pair(self, X, R, T1):
-        """Eval and target networks over the same sequences (iql_learner.py:41-57): the layers below and above the GRU as
-        grouped launches (eval + target in one), the two recurrences as one dual launch.  Returns (Q_eval, Q_target)."""
-        P, H, M, tf = self.params, self.RH, T1 * R, self.target_flat
-        ws0, ws1 = self.seq_workspace(0, R, T1), self.seq_workspace(1, R, T1)
-        gi0, gi1 = Plan.forward_many([(self.pre_plans[0], X, self.obs_dim, M, None), (self.pre_plans[1], X, self.obs_dim, M, tf)])
-        ops.gru_forward(gi=gi0, w_hh=P.ptr(self.w_hh), b_hh=P.ptr(self.b_hh), h0=None, reset=None, hs=ws0["hs"],
-                        gates=ws0["gates"], h_last=None, R=R, T1=T1, H=H, ld_gi=3 * H, gi2=gi1, w_hh2=P.ptr(self.w_hh, tf),
-                        b_hh2=P.ptr(self.b_hh, tf), hs2=ws1["hs"])
-        return Plan.forward_many([(self.post_plans[0], ws0["hs"][R:], H, M, None), (self.post_plans[1], ws1["hs"][R:], H, M, tf)])
-
-    def agent_backward_seq(self, X, R, T1, slabs, n_split):
-        """post_plans[0].dacts[last] holds dLoss/dQ [T1*R, A]: Q head, BPTT, W_hh/b_hh, then the layers below the GRU."""
-        P, H, M = self.params, self.RH, T1 * R
-        ws, pre, post = self.seq_workspace(0, R, T1), self.pre_plans[0], self.post_plans[0]
-        post.backward(ws["hs"][R:], H, M, slabs, n_split, dx0=ws["d_hs"])
-        d_gi = pre.dacts[len(pre.widths) - 1]
-        ops.gru_backward(d_hs=ws["d_hs"], hs=ws["hs"], gates=ws["gates"], w_hh=P.ptr(self.w_hh), d_gi=d_gi, d_gh=ws["d_gh"],
-                         d_h0=None, R=R, T1=T1, H=H, ld_dhs=H, ld_dgi=3 * H)
-        ops.linear_bwd_weight([ops.gemm_desc(ws["d_gh"].data_ptr(), ws["hs"].data_ptr(),
-                                             slabs.data_ptr() + 4 * P.offsets[self.w_hh], M, 3 * H, H, 3 * H, H, H,
-                                             dbias=slabs.data_ptr() + 4 * P.offsets[self.b_hh])], n_split, slabs.shape[1])
-        pre.backward(X, self.obs_dim, M, slabs, n_split)
-
-    def _target_key(self, k):
         if k.startswith("target_individual_q_networks."):
             return k[len("target_"):]
         if k.startswith("target_Qtot."):
