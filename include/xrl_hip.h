@@ -513,7 +513,11 @@ typedef struct {
     float* diag;               /* NULL or [3][B]: q_tot_eval, q_tot_next, q_tot_target (qmix_learner.py:108-110) */
     double* partials;          /* [B][8]: (q_tot_eval-y)^2, q_tot_eval, 0... */
     int32_t B, N, A, H, ldq, ld_e1, ld_e2, ld_t1, ld_t2, double_q;
-    float gamma, pad;
+    float gamma;
+    int32_t mixer;             /* 0: QMIX_Mixer (q_mix_head.py:28-95).  1: VDN_Mixer, the sum over agents (vdn_learner.py:13-106;
+                                * e_, t_, d_e_ pointers unused).  2: IndependentMixer / IQL_Learner (iql_learner.py:85-142):
+                                * per-agent TD (td * mask), loss sum(td^2)/sum(mask); partials[b] = {sum_n td^2, sum_n taken Q,
+                                * sum_n mask}, diag [2][B*N] = taken Q, target (feed-forward only) */
     const float* filled;       /* NULL (feed-forward: MSE over B rows, qmix_learner.py:86) or [B] f32 0/1 step mask of the
                                 * recurrent branch (:60-61 valid_mask = agent_mask * filled, :82-84 loss =
                                 * sum((td * filled)^2) / sum(filled)); partials[b][2] = filled[b].  In that mode the B rows

@@ -183,6 +183,8 @@ def run_learner_updates(learner, model, cb, batches, call):
                                        for n, p in model.named_parameters() if p.grad is not None}))
         out.update(flat(f"u{u}/param", sd_np(model)))
     opt = learner.optimizer
+    if isinstance(opt, dict):                                    # IQL: one optimiser per group (iql_learner.py:24-36)
+        opt = next(iter(opt.values()))
     names = [n for n, _ in model.named_parameters()]
     for n, p in model.named_parameters():
         st = opt.state.get(p, None)
@@ -300,7 +302,9 @@ def golden_dqn(kind, learner_cls=None, name=None):
 
 
 # ------------------------------------------------------------------------------ QMIX (feed-forward)
-def golden_qmix(double_q):
+def golden_qmix(double_q, algo="qmix"):
+    """algo: qmix (QMIX_Learner + QMIX_Mixer), vdn (VDN_Learner + VDN_Mixer, vdn_learner.py:13-106), iql (IQL_Learner +
+    IndependentMixer, iql_learner.py:13-142): same feed-forward agents, same batches."""
     from xuance.torch.rl_models.critics.base_critics import DiscreteActionValueCritic
     from xuance.torch.rl_models.representations.agent_feature import AgentFeatureEncoder
     torch.manual_seed(3)
@@ -317,7 +321,9 @@ def golden_qmix(double_q):
     rep = AgentFeatureEncoder(representation=obs_rep, identity_encoder=ident, fusion=fusion)
     critic = DiscreteActionValueCritic(representation=rep, action_space=sp.Discrete(A), critic_hidden_size=[64],
                                        normalizer=None, initializer=init, activation=nn.ReLU, device="cpu")
-    mixer = QMIX_Mixer(S, 32, 32, N, "cpu")
+    from xuance.torch.rl_models.heads import VDN_Mixer, IndependentMixer
+    from xuance.torch.learners import VDN_Learner, IQL_Learner
+    mixer = {"qmix": lambda: QMIX_Mixer(S, 32, 32, N, "cpu"), "vdn": VDN_Mixer, "iql": IndependentMixer}[algo]()
     model = MixingQNetwork(grouping, nn.ModuleDict({group: critic}), mixer, use_rnn=False, device="cpu")
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -327,7 +333,7 @@ def golden_qmix(double_q):
                       use_parameter_sharing=True, double_q=double_q, use_actions_mask=True, use_rnn=False,
                       n_epochs=8, grad_clip_norm=10.0)
     cb = Capture()
-    learner = QMIX_Learner(cfg, grouping, model, cb)
+    learner = {"qmix": QMIX_Learner, "vdn": VDN_Learner, "iql": IQL_Learner}[algo](cfg, grouping, model, cb)
     batches, samples = [], []
     for u in range(3):
         avail = (rng.random((B, N, A)) < 0.7)
@@ -357,7 +363,7 @@ def golden_qmix(double_q):
     out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm, float(double_q),
                            learner.total_iters])
     out["group"] = np.array(group)
-    np.savez_compressed(os.path.join(OUT, f"qmix_ff_{'double' if double_q else 'single'}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"{algo}_ff_{'double' if double_q else 'single'}.npz"), **out)
 
 
 def golden_qmix_rnn(double_q=True, fixed=False):
@@ -537,6 +543,9 @@ if __name__ == "__main__":
     golden_dqn("mlp", DDQN_Learner, "ddqn")
     golden_qmix(True)
     golden_qmix(False)
+    golden_qmix(True, "vdn")
+    golden_qmix(True, "iql")
+    golden_qmix(False, "iql")
     golden_qmix_rnn(True)
     golden_qmix_rnn(False)
     golden_qmix_rnn(True, fixed=True)

@@ -662,15 +662,32 @@ def qmix_forward_backward(sd, batch, cfg, act="relu", group="shared"):
         q_next_taken = q_next[rows, a_next].reshape(B, N)               # :52-55
     else:
         q_next_taken = q_next.max(-1).reshape(B, N)                     # :57-58
-    q_eval_m = q_eval_taken * mask                                      # :60
-    q_next_m = q_next_taken * mask                                      # :61
-    q_tot_eval, cache = qmix_mixer_forward(sd, "eval_Qtot", q_eval_m, batch["state"].astype(dt))
-    q_tot_next, _ = qmix_mixer_forward(sd, "target_Qtot", q_next_m, batch["state_next"].astype(dt))
-    target = rewards_tot + (1 - terminals_tot) * dt(cfg["gamma"]) * q_tot_next     # :78
-    loss = ((q_tot_eval - target) ** 2).mean()                          # :86
-    dq_tot = (2 * (q_tot_eval - target) / dt(B)).astype(dt)
-    dq_m, grads = qmix_mixer_backward(sd, "eval_Qtot", cache, dq_tot)
-    dq_taken = (dq_m * mask).reshape(B * N)
+    mixer = cfg.get("mixer", "qmix")
+    if mixer == "iql":                                                  # iql_learner.py:98-117: per-agent TD, no mixing
+        r_a, d_a = batch["rewards"].astype(dt), batch["terminals"].astype(dt)
+        target = r_a + (1 - d_a) * dt(cfg["gamma"]) * q_next_taken                  # :113
+        td = (q_eval_taken - target) * mask                                        # :116
+        loss = (td ** 2).sum() / mask.sum()                                         # :117
+        dq_taken = (2 * td * mask / mask.sum()).astype(dt).reshape(B * N)
+        grads = {}
+        q_tot_eval, q_tot_next, pred = q_eval_taken.reshape(-1), q_next_taken.reshape(-1), q_eval_taken.mean()
+    else:
+        q_eval_m = q_eval_taken * mask                                  # :60
+        q_next_m = q_next_taken * mask                                  # :61
+        if mixer == "vdn":                                              # VDN_Mixer: sum over agents (vdn_learner.py:74-75)
+            q_tot_eval, q_tot_next = q_eval_m.sum(1), q_next_m.sum(1)
+        else:
+            q_tot_eval, cache = qmix_mixer_forward(sd, "eval_Qtot", q_eval_m, batch["state"].astype(dt))
+            q_tot_next, _ = qmix_mixer_forward(sd, "target_Qtot", q_next_m, batch["state_next"].astype(dt))
+        target = rewards_tot + (1 - terminals_tot) * dt(cfg["gamma"]) * q_tot_next     # :78
+        loss = ((q_tot_eval - target) ** 2).mean()                      # :86
+        dq_tot = (2 * (q_tot_eval - target) / dt(B)).astype(dt)
+        if mixer == "vdn":
+            dq_m, grads = np.repeat(dq_tot[:, None], N, 1), {}
+        else:
+            dq_m, grads = qmix_mixer_backward(sd, "eval_Qtot", cache, dq_tot)
+        dq_taken = (dq_m * mask).reshape(B * N)
+        pred = q_tot_eval.mean()
     dQ = np.zeros_like(q_eval)
     dQ[rows, a_taken] = dq_taken
     dh, g_q = q.backward(dQ, need_dx=True)
@@ -680,7 +697,7 @@ def qmix_forward_backward(sd, batch, cfg, act="relu", group="shared"):
     for L, (gw, gb) in zip(rep_l, g_rep):
         grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
     info = dict(q_eval=q_eval.reshape(B, N, A), q_next=q_next.reshape(B, N, A), q_tot_eval=q_tot_eval,
-                q_tot_next=q_tot_next, q_tot_target=target, loss=loss, predictQ=q_tot_eval.mean(),
+                q_tot_next=q_tot_next, q_tot_target=target, loss=loss, predictQ=pred,
                 rewards_tot=rewards_tot, terminals_tot=terminals_tot)
     if cfg.get("double_q", True):
         info["actions_next"] = a_next.reshape(B, N)

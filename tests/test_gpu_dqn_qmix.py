@@ -234,3 +234,41 @@ def test_marl_rnn_buffer_vs_reference_fixture(batched):
         got = smp[k]
         got = torch.stack([got[a] for a in keys], 1) if isinstance(got, dict) else got
         assert np.array_equal(got.cpu().numpy().reshape(ref.shape), ref), k
+
+
+@pytest.mark.parametrize("name", ["vdn_ff_double", "iql_ff_double", "iql_ff_single"])
+def test_vdn_iql_learners_vs_reference_fixture(name):
+    """VDN_Learner / IQL_Learner (sibling learners of SURVEY 8f.2: "QMIX minus mixer") against the reference's own
+    vdn_learner.py / iql_learner.py runs: `xrl_qmix_mix_td` with mixer = 1 (sum) / 2 (per-agent masked TD)."""
+    from xuance_amd.nets import MixingQNet
+    from xuance_amd.learners import REGISTRY_Learners
+    g = load_golden(name)
+    algo = name[:3]
+    lr, gamma, sync, gclip, dq, total = g["cfg"]
+    N, O, S, A = 3, 30, 48, 9
+    keys = [f"agent_{i}" for i in range(N)]
+    net = MixingQNet(N, O, A, S, (64,), (64,), 32, 32, "relu", group=str(g["group"]), mixer={"vdn": "VDN", "iql": "Independent"}[algo])
+    assert list(net.ref_order) == list(sub(g, "init").keys())
+    net.load_state_dict(sub(g, "init"))
+    cb = Capture()
+    learner = REGISTRY_Learners[algo.upper() + "_Learner"](
+        base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync), use_grad_clip=True,
+                 grad_clip_norm=float(gclip), double_q=bool(dq), use_actions_mask=True, use_parameter_sharing=True,
+                 n_epochs=8), keys, net, cb)
+    assert learner.total_iters == int(total)
+
+    def call(b):
+        sample = {k: {a: b[k][:, i] for i, a in enumerate(keys)}
+                  for k in ("obs", "obs_next", "actions", "rewards", "terminals", "agent_mask", "avail_actions",
+                            "avail_actions_next")}
+        sample.update(state=b["state"], state_next=b["state_next"], batch_size=len(b["state"]))
+        info = learner.update(sample)
+        ref_keys = set(sub(g, "u0/info"))
+        assert set(info) == ref_keys, (set(info), ref_keys)            # IQL: "<group>/loss_Q", ...
+        return {k.split("/")[-1]: v for k, v in info.items()}
+    g2 = dict(g)
+    for u in range(3):                                                 # give check_updates the un-prefixed info keys
+        for k in list(g2):
+            if k.startswith(f"u{u}/info/") and k.count("/") == 3:
+                g2[f"u{u}/info/" + k.split("/")[-1]] = g2[k]
+    check_updates(g2, net, learner, cb, call, ("q_tot_eval", "q_tot_next", "q_tot_target") if algo == "vdn" else (), "loss_Q")

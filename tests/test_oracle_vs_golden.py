@@ -184,6 +184,30 @@ def test_qmix_ff_update(oracle, double_q):
         assert_close(info["loss"], ref_info["loss_Q"], 1e-5, "loss_Q")
 
 
+@pytest.mark.parametrize("name", ["vdn_ff_double", "iql_ff_double", "iql_ff_single"])
+def test_vdn_iql_update(oracle, name):
+    """VDN_Learner (vdn_learner.py:13-106: sum mixer) and IQL_Learner (iql_learner.py:85-142: per-agent masked TD) on the
+    feed-forward agents and batches of the QMIX fixtures."""
+    g = load_golden(name)
+    lr, gamma, sync, gclip, dq, total = g["cfg"]
+    opt_kwargs_clip["clip"] = gclip
+    algo = name[:3]
+    cfg = dict(gamma=gamma, double_q=bool(dq), use_actions_mask=True, mixer=algo)
+    fb = lambda sd, b: oracle.qmix_forward_backward(sd, b, cfg, group=str(g["group"]))
+
+    def on_update(u, sd):
+        if (u + 1) % int(sync) == 0:
+            oracle.qmix_copy_target(sd)
+    pre = "shared/" if algo == "iql" else ""
+    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, total_iters=int(total)), oracle, on_update):
+        ref_info = sub(g, f"u{u}/info")
+        assert_close(info["loss"], ref_info[pre + "loss_Q"], 1e-5, "loss_Q")
+        assert_close(info["predictQ"], ref_info[pre + "predictQ"], 1e-5, "predictQ")
+        if algo == "vdn":
+            for k in ("q_tot_eval", "q_tot_next", "q_tot_target"):
+                assert_close(info[k], sub(g, f"u{u}/cb")[k], 1e-5, k)
+
+
 @pytest.mark.parametrize("name", ["qmix_rnn_double", "qmix_rnn_single", "qmix_rnn_double_fixed"])
 def test_qmix_rnn_update(oracle, name):
     """Recurrent QMIX: Basic_RNN fc+GRU agents over whole episodes, masked TD loss (qmix_learner.py:81-84).

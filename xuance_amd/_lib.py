@@ -88,7 +88,7 @@ class Qmix(C.Structure):
                 ("d_e_b1", c_void_p), ("d_e_raw", c_void_p), ("diag", c_void_p), ("partials", c_void_p),
                 ("B", c_int32), ("N", c_int32), ("A", c_int32), ("H", c_int32), ("ldq", c_int32), ("ld_e1", c_int32),
                 ("ld_e2", c_int32), ("ld_t1", c_int32), ("ld_t2", c_int32), ("double_q", c_int32),
-                ("gamma", c_float), ("pad", c_float), ("filled", c_void_p)]
+                ("gamma", c_float), ("mixer", c_int32), ("filled", c_void_p)]
 
 
 class EpisodeField(C.Structure):

@@ -16,7 +16,7 @@ from argparse import Namespace
 import torch
 
 from .. import ops
-from ..learners.qmix_learner import QMIX_Learner
+from ..learners.qmix_learner import QMIX_Learner, VDN_Learner, IQL_Learner
 from ..memory_marl import HipMARLOffPolicyBuffer, HipMARLOffPolicyBufferRNN
 from ..nets import MixingQNet
 
@@ -26,6 +26,8 @@ def _get(cfg, name, default=None):
 
 
 class QMIX_Agents:
+    mixer_name, learner_cls = "QMIX", QMIX_Learner
+
     def __init__(self, config: Namespace, envs, callback=None):
         self.config, self.envs, self.callback = config, envs, callback
         self.device = _get(config, "device", "cuda")
@@ -68,7 +70,8 @@ class QMIX_Agents:
                           list(_get(c, "representation_hidden_size", [64])), list(_get(c, "q_hidden_size", [64])),
                           _get(c, "hidden_dim_mixing_net", 32), _get(c, "hidden_dim_hyper_net", 32),
                           _get(c, "activation", "relu"), device=self.device, use_rnn=self.use_rnn,
-                          fc_hidden=list(_get(c, "fc_hidden_sizes", [64])), recurrent_hidden=_get(c, "recurrent_hidden_size", 64))
+                          fc_hidden=list(_get(c, "fc_hidden_sizes", [64])), recurrent_hidden=_get(c, "recurrent_hidden_size", 64),
+                          mixer=self.mixer_name)
 
     def _build_memory(self):
         c, env = self.config, self.envs
@@ -83,7 +86,7 @@ class QMIX_Agents:
                                       avail_actions_shape={k: (self.n_actions,) for k in self.agent_keys})
 
     def _build_learner(self, *args):
-        return QMIX_Learner(*args)
+        return self.learner_cls(*args)
 
     def _update_explore_factor(self):                          # off_policy_marl.py:197-204
         if self.e_greedy > self.end_greedy:
@@ -167,3 +170,13 @@ class QMIX_Agents:
 
     def finish(self):
         self.envs.close()
+
+
+class VDN_Agents(QMIX_Agents):
+    """xuance/torch/agents/multi_agent_rl/vdn_agents.py: the QMIX loop with VDN_Mixer (sum) and VDN_Learner."""
+    mixer_name, learner_cls = "VDN", VDN_Learner
+
+
+class IQL_Agents(QMIX_Agents):
+    """xuance/torch/agents/multi_agent_rl/iql_agents.py: independent Q-learners (IndependentMixer, IQL_Learner)."""
+    mixer_name, learner_cls = "Independent", IQL_Learner

@@ -78,7 +78,52 @@ __global__ void __launch_bounds__(64) qmix_kernel(xrl_qmix_t p) {
             qn = (av && av[0] == 0.f) ? -1e10f : qt[0];
             for (int j = 1; j < A; ++j) qn = fmaxf(qn, (av && av[j] == 0.f) ? -1e10f : qt[j]);
         }
-        qn *= mask;                                                                   // :61
+        if (p.mixer == 2) {
+            // IQL_Learner (iql_learner.py:98-117): per-agent TD on the UNMASKED taken values, mask applied to the error
+            const float msum = [&] { float s = 0.f; for (int i = 0; i < p.B * N; ++i) s += p.agent_mask[i]; return s; }();
+            const float y = p.rewards[row] + (1.f - (p.terminals[row] != 0.f ? 1.f : 0.f)) * p.gamma * qn;      // :113
+            const float qraw = p.q_eval[row * p.ldq + a_taken];
+            const float td = (qraw - y) * mask;                                                                  // :116
+            float* dq = p.d_q + row * p.ldq;
+            for (int j = 0; j < A; ++j) dq[j] = (j == a_taken) ? 2.f * td * mask / msum : 0.f;                   // :117
+            qe = td; qn = qraw;
+            if (p.diag) { p.diag[row] = qraw; p.diag[(size_t)p.B * N + row] = y; }
+        } else {
+            qn *= mask;                                                               // :61
+        }
+    }
+    if (p.mixer == 2) {
+        const float l = wave_sum(lane < N ? qe * qe : 0.f), q = wave_sum(lane < N ? qn : 0.f), m = wave_sum(mask);
+        if (lane == 0) {
+            double* o = p.partials + (size_t)b * 8;
+            o[0] = l; o[1] = q; o[2] = m;                       // loss = sum o[0] / sum o[2]; predictQ = sum o[1] / (B N)
+            for (int j = 3; j < 8; ++j) o[j] = 0.0;
+        }
+        return;
+    }
+    if (p.mixer == 1) {
+        // VDN_Learner (vdn_learner.py:13-106): the mixer is the sum over agents (VDN_Mixer), no state, no parameters
+        const float q_tot_e = wave_sum(qe), q_tot_n = wave_sum(qn);
+        float r = 0.f, dn = 1.f;
+        if (lane < N) { r = p.rewards[(size_t)b * N + lane]; dn = p.terminals[(size_t)b * N + lane] != 0.f ? 1.f : 0.f; }
+        const float r_tot = wave_sum(r) / (float)N;
+        float all_d = dn;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) all_d = fminf(all_d, __shfl_xor(all_d, off, 64));
+        const float y = r_tot + (1.f - all_d) * p.gamma * q_tot_n;
+        const float td = (q_tot_e - y) * fl;
+        const float dq_tot = p.filled ? 2.f * td * fl * inv_norm : 2.f * td / (float)p.B;
+        if (lane < N) {
+            float* dq = p.d_q + ((size_t)b * N + lane) * p.ldq;
+            for (int j = 0; j < A; ++j) dq[j] = (j == a_taken) ? dq_tot * mask : 0.f;
+        }
+        if (lane == 0) {
+            double* q = p.partials + (size_t)b * 8;
+            q[0] = (double)td * td; q[1] = q_tot_e; q[2] = p.filled ? (double)fl : 0.0;
+            for (int j = 3; j < 8; ++j) q[j] = 0.0;
+            if (p.diag) { p.diag[b] = q_tot_e; p.diag[p.B + b] = q_tot_n; p.diag[2 * (size_t)p.B + b] = y; }
+        }
+        return;
     }
     // mixing networks (q_mix_head.py:78-95)
     const float* e_raw = p.e_raw + (size_t)b * p.ld_e2;
@@ -165,10 +210,14 @@ extern "C" int xrl_dqn_td(const xrl_dqn_td_t* p, xrl_stream_t stream) {
 
 extern "C" int xrl_qmix_mix_td(const xrl_qmix_t* p, xrl_stream_t stream) {
     XRL_CHECK_ARG(p && p->q_eval && p->q_next && p->actions && p->agent_mask && p->rewards && p->terminals);
-    XRL_CHECK_ARG(p->e_b1 && p->e_raw && p->t_b1 && p->t_raw && p->d_q && p->d_e_b1 && p->d_e_raw && p->partials);
-    XRL_CHECK_ARG(p->B > 0 && p->N > 0 && p->N <= 64 && p->H > 0 && p->H <= 64 && p->A > 0 && p->ldq >= p->A);
+    XRL_CHECK_ARG(p->d_q && p->partials && p->mixer >= 0 && p->mixer <= 2);
+    XRL_CHECK_ARG(p->B > 0 && p->N > 0 && p->N <= 64 && p->A > 0 && p->ldq >= p->A);
     XRL_CHECK_ARG(!p->double_q || p->q_next_eval);
-    XRL_CHECK_ARG(p->ld_e2 >= p->N * p->H + p->H + 1 && p->ld_t2 >= p->N * p->H + p->H + 1);
+    if (p->mixer == 0) {
+        XRL_CHECK_ARG(p->e_b1 && p->e_raw && p->t_b1 && p->t_raw && p->d_e_b1 && p->d_e_raw && p->H > 0 && p->H <= 64);
+        XRL_CHECK_ARG(p->ld_e2 >= p->N * p->H + p->H + 1 && p->ld_t2 >= p->N * p->H + p->H + 1);
+    }
+    XRL_CHECK_ARG(p->mixer != 2 || !p->filled);
     hipLaunchKernelGGL(qmix_kernel, dim3(p->B), dim3(64), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;

@@ -27,8 +27,16 @@ from .ppo_learner import pick_n_split
 
 
 class QMIX_Learner(Learner):
+    mixer_mode = 0          # xrl_qmix_t.mixer: 0 QMIX, 1 VDN (sum), 2 independent (IQL)
+
     def __init__(self, config, agent_grouping, model, callback=None):
         super().__init__(config, model, callback)
+        assert {"QMIX": 0, "VDN": 1, "Independent": 2}[getattr(model, "mixer", "QMIX")] == self.mixer_mode, \
+            "the model's mixer does not match the learner"
+        if self.mixer_mode and getattr(config, "use_rnn", False):
+            # the reference's recurrent branch detaches q_eval (iql_learner.py:49,58): without a trainable mixer nothing
+            # requires grad there and its loss.backward() raises
+            raise NotImplementedError("VDN / IQL with recurrent agents: the reference's own update raises in this configuration")
         self.use_rnn = bool(getattr(config, "use_rnn", False))
         assert self.use_rnn == bool(getattr(model, "use_rnn", False)), "config.use_rnn and the model disagree"
         self.rnn_backprop_agents = bool(getattr(config, "rnn_backprop_agents", False))
@@ -64,15 +72,16 @@ class QMIX_Learner(Learner):
         N, R = m.n_agents, B * m.n_agents
         self.slabs = torch.zeros(32, m.params.P, device=dev)
         self.partials = torch.zeros(B, 8, dtype=torch.float64, device=dev)
-        self.diag = torch.zeros(3 * B, device=dev)
+        self.diag = torch.zeros(3 * B * N, device=dev)
         self.X = torch.zeros(2 * R, m.obs_dim, device=dev)       # rows [0,R) obs, rows [R,2R) obs_next
         self.states = torch.zeros(2 * B, m.state_dim, device=dev)
         self.buf = {k: torch.zeros(B, N, device=dev) for k in ("actions", "rewards", "terminals", "agent_mask")}
         self.buf["avail_next"] = torch.ones(B, N, m.n_actions, device=dev)
         m.agent_plan.ensure(2 * R)
         m.agent_target_plan.ensure(R)
-        m.mixer_plan.ensure(B)
-        m.mixer_target_plan.ensure(B)
+        if self.mixer_mode == 0:
+            m.mixer_plan.ensure(B)
+            m.mixer_target_plan.ensure(B)
 
     def _stack(self, x, dtype=torch.float32):
         """field -> agent -> [B, ...]  (reference buffers)  or an already stacked [B, N, ...] tensor/array."""
@@ -94,8 +103,9 @@ class QMIX_Learner(Learner):
         if self.use_actions_mask:
             self.buf["avail_next"][:B].copy_(self._stack(sample["avail_actions_next"]).reshape(B, m.n_agents, -1))
         dev = m.params.device
-        self.states[:B].copy_(torch.as_tensor(sample["state"], device=dev).reshape(B, -1))
-        self.states[B:2 * B].copy_(torch.as_tensor(sample["state_next"], device=dev).reshape(B, -1))
+        if self.mixer_mode == 0:                               # only the QMIX mixer reads the global state
+            self.states[:B].copy_(torch.as_tensor(sample["state"], device=dev).reshape(B, -1))
+            self.states[B:2 * B].copy_(torch.as_tensor(sample["state_next"], device=dev).reshape(B, -1))
         return B
 
     def _step(self, B):
@@ -108,22 +118,27 @@ class QMIX_Learner(Learner):
         # 63-71); eval hyper-networks on state, target ones on state_next: each pair is one grouped launch per layer
         q_all, q_next = Plan.forward_many([(m.agent_plan, self.X, m.obs_dim, 2 * R if self.double_q else R, None),
                                            (m.agent_target_plan, self.X[R:], m.obs_dim, R, m.target_flat)])
-        e_raw, t_raw = Plan.forward_many([(m.mixer_plan, self.states, m.state_dim, B, None),
-                                          (m.mixer_target_plan, self.states[B:], m.state_dim, B, m.target_flat)])
-        e_l1, t_l1 = m.mixer_plan.acts[1], m.mixer_target_plan.acts[1]
-        d_l1, d_raw = m.mixer_plan.dacts[1], m.mixer_plan.dacts[2]
-        ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]
-        ops.qmix_mix_td(q_eval=q_all, q_next_eval=q_all[R:] if self.double_q else None, q_next=q_next,
-                        actions=self.buf["actions"], avail_next=self.buf["avail_next"] if self.use_actions_mask else None,
-                        agent_mask=self.buf["agent_mask"], rewards=self.buf["rewards"], terminals=self.buf["terminals"],
-                        e_b1=e_l1.data_ptr() + 4 * 3 * m.HH, e_raw=e_raw, t_b1=t_l1.data_ptr() + 4 * 3 * m.HH, t_raw=t_raw,
-                        d_q=m.agent_plan.dacts[len(m.agent_plan.widths) - 1], d_e_b1=d_l1.data_ptr() + 4 * 3 * m.HH,
-                        d_e_raw=d_raw, diag=self.diag, partials=self.partials, B=B, N=N, A=A, H=H, ldq=A, ld_e1=ld1,
-                        ld_e2=ld2, ld_t1=ld1, ld_t2=ld2, double_q=int(self.double_q), gamma=float(self.gamma))
-        # data-gradient chains first, then the weight gradients of every layer of a plan as one grouped launch
-        wg = []
-        m.mixer_plan.backward(self.states, m.state_dim, B, self.slabs, S, defer_wgrad=wg)
-        ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
+        d_q = m.agent_plan.dacts[len(m.agent_plan.widths) - 1]
+        common = dict(q_eval=q_all, q_next_eval=q_all[R:] if self.double_q else None, q_next=q_next,
+                      actions=self.buf["actions"], avail_next=self.buf["avail_next"] if self.use_actions_mask else None,
+                      agent_mask=self.buf["agent_mask"], rewards=self.buf["rewards"], terminals=self.buf["terminals"],
+                      d_q=d_q, diag=self.diag, partials=self.partials, B=B, N=N, A=A, ldq=A, double_q=int(self.double_q),
+                      gamma=float(self.gamma), mixer=self.mixer_mode)
+        if self.mixer_mode == 0:
+            e_raw, t_raw = Plan.forward_many([(m.mixer_plan, self.states, m.state_dim, B, None),
+                                              (m.mixer_target_plan, self.states[B:], m.state_dim, B, m.target_flat)])
+            e_l1, t_l1 = m.mixer_plan.acts[1], m.mixer_target_plan.acts[1]
+            d_l1, d_raw = m.mixer_plan.dacts[1], m.mixer_plan.dacts[2]
+            ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]
+            ops.qmix_mix_td(e_b1=e_l1.data_ptr() + 4 * 3 * m.HH, e_raw=e_raw, t_b1=t_l1.data_ptr() + 4 * 3 * m.HH, t_raw=t_raw,
+                            d_e_b1=d_l1.data_ptr() + 4 * 3 * m.HH, d_e_raw=d_raw, H=H, ld_e1=ld1, ld_e2=ld2, ld_t1=ld1,
+                            ld_t2=ld2, **common)
+            # data-gradient chains first, then the weight gradients of every layer of a plan as one grouped launch
+            wg = []
+            m.mixer_plan.backward(self.states, m.state_dim, B, self.slabs, S, defer_wgrad=wg)
+            ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
+        else:
+            ops.qmix_mix_td(**common)                       # VDN: sum mixer; IQL: per-agent TD (no hyper-networks)
         wg = []
         m.agent_plan.backward(self.X, m.obs_dim, R, self.slabs, S, defer_wgrad=wg)
         ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
@@ -264,10 +279,15 @@ class QMIX_Learner(Learner):
         for e in range(n_epochs):
             self.iterations += 1
             info = self.callback.on_update_start(self.iterations, model=self.model) or {}
-            info.update({"learning_rate": st.last_lr, "loss_Q": float(sums[e, 0] / B), "predictQ": float(sums[e, 1] / B)})
-            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, q_tot_eval=self.diag[:B],
-                                                    q_tot_next=self.diag[B:2 * B], q_tot_target=self.diag[2 * B:3 * B]) or {})
+            info.update(self._info_ff(B, sums[e], st.last_lr))
+            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **self._cb_ff(B)) or {})
         return info
+
+    def _info_ff(self, B, sums, lr):                            # qmix_learner.py:98-102
+        return {"learning_rate": lr, "loss_Q": float(sums[0] / B), "predictQ": float(sums[1] / B)}
+
+    def _cb_ff(self, B):                                        # :108-110
+        return dict(q_tot_eval=self.diag[:B], q_tot_next=self.diag[B:2 * B], q_tot_target=self.diag[2 * B:3 * B])
 
     def _update_from_episodes(self, memory, n_epochs, seed):
         """Recurrent twin of update_from_buffer: episodes are drawn on the device (uniform over memory.size_dev, as
@@ -329,9 +349,29 @@ class QMIX_Learner(Learner):
         info = self.callback.on_update_start(self.iterations, model=self.model) or {}
         self._step(B)
         ops.sum_partials(self.partials, B, 8, self.sums)
-        s = self.sums.cpu().numpy()
-        st = self.optimizer.read()
-        info.update({"learning_rate": st.last_lr, "loss_Q": float(s[0] / B), "predictQ": float(s[1] / B)})
-        info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, q_tot_eval=self.diag[:B],
-                                                q_tot_next=self.diag[B:2 * B], q_tot_target=self.diag[2 * B:3 * B]) or {})
+        info.update(self._info_ff(B, self.sums.cpu().numpy(), self.optimizer.read().last_lr))
+        info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **self._cb_ff(B)) or {})
         return info
+
+
+class VDN_Learner(QMIX_Learner):
+    """Value decomposition networks (xuance/torch/learners/multi_agent_rl/vdn_learner.py:13-106): QMIX_Learner with
+    VDN_Mixer, the parameter-free sum over the (masked) agent values -- `xrl_qmix_t.mixer = 1`, no hyper-network launches.
+    The model is MixingQNet(mixer="VDN") (vdn_agents.py:71-79)."""
+    mixer_mode = 1
+
+
+class IQL_Learner(QMIX_Learner):
+    """Independent Q-learning (iql_learner.py:13-142): per-agent TD error on the unmixed values, loss
+    sum((td * mask)^2) / sum(mask), info keys prefixed with the group name -- `xrl_qmix_t.mixer = 2`.  With parameter
+    sharing there is one group, hence one optimiser (iql_learner.py:24-36 builds one per group).
+    The model is MixingQNet(mixer="Independent") (iql_agents.py:71-79)."""
+    mixer_mode = 2
+
+    def _info_ff(self, B, sums, lr):                            # iql_learner.py:129-135
+        g = self.model.group
+        return {f"{g}/learning_rate": lr, f"{g}/loss_Q": float(sums[0] / sums[2]),
+                f"{g}/predictQ": float(sums[1] / (B * self.n_agents))}
+
+    def _cb_ff(self, B):                                        # :140 passes no tensors
+        return {}

@@ -436,7 +436,7 @@ class MixingQNet:
 
     def __init__(self, n_agents, obs_dim, n_actions, state_dim, representation_hidden=(64,), q_hidden=(64,),
                  mixer_hidden=32, hyper_hidden=32, activation="relu", group="shared", device="cuda", init=True,
-                 use_rnn=False, fc_hidden=(64,), recurrent_hidden=64):
+                 use_rnn=False, fc_hidden=(64,), recurrent_hidden=64, mixer="QMIX"):
         self.n_agents, self.obs_dim, self.n_actions, self.state_dim = n_agents, obs_dim, n_actions, state_dim
         self.H, self.HH, self.group = mixer_hidden, hyper_hidden, group
         self.use_rnn, self.RH = bool(use_rnn), int(recurrent_hidden)
@@ -464,27 +464,31 @@ class MixingQNet:
             q_stages, q_widths = [], [recurrent_hidden]
             _seq_layers(f"{pe}.critic_head.q_value", recurrent_hidden, list(q_hidden) + [n_actions], activation, None, 0,
                         specs, a_order, q_stages, q_widths)
-        # mixer hyper-networks: the three ReLU first layers are stacked into one GEMM ([hyper_w_1.0; hyper_w_2.0;
-        # hyper_b_2.0]), hyper_b_1 is a second group of the same launch; second layers are three groups.
-        m = "eval_Qtot"
-        firsts = [f"{m}.hyper_w_1.0", f"{m}.hyper_w_2.0", f"{m}.hyper_b_2.0"]
-        specs += [(n + ".weight", (HH, S)) for n in firsts] + [(n + ".bias", (HH,)) for n in firsts]
-        specs += [(f"{m}.hyper_b_1.weight", (H, S)), (f"{m}.hyper_b_1.bias", (H,)),
-                  (f"{m}.hyper_w_1.2.weight", (N * H, HH)), (f"{m}.hyper_w_1.2.bias", (N * H,)),
-                  (f"{m}.hyper_w_2.2.weight", (H, HH)), (f"{m}.hyper_w_2.2.bias", (H,)),
-                  (f"{m}.hyper_b_2.2.weight", (1, HH)), (f"{m}.hyper_b_2.2.bias", (1,))]
-        assert (HH * S) % 4 == 0 and HH % 4 == 0
-        self.raw_width = N * H + H + 1
-        m_widths = [S, 3 * HH + H, (self.raw_width + 3) // 4 * 4]
-        m_stages = [[Layer("+".join(firsts), S, 3 * HH, "relu", 0, 0, 1, 0, firsts[0] + ".weight", firsts[0] + ".bias"),
-                     Layer(f"{m}.hyper_b_1", S, H, None, 0, 0, 1, 3 * HH, f"{m}.hyper_b_1.weight", f"{m}.hyper_b_1.bias")],
-                    [Layer(f"{m}.hyper_w_1.2", HH, N * H, None, 1, 0, 2, 0, f"{m}.hyper_w_1.2.weight", f"{m}.hyper_w_1.2.bias"),
-                     Layer(f"{m}.hyper_w_2.2", HH, H, None, 1, HH, 2, N * H, f"{m}.hyper_w_2.2.weight", f"{m}.hyper_w_2.2.bias"),
-                     Layer(f"{m}.hyper_b_2.2", HH, 1, None, 1, 2 * HH, 2, N * H + H, f"{m}.hyper_b_2.2.weight", f"{m}.hyper_b_2.2.bias")]]
-        mixer_order = []
-        for n in (f"{m}.hyper_w_1.0", f"{m}.hyper_w_1.2", f"{m}.hyper_w_2.0", f"{m}.hyper_w_2.2", f"{m}.hyper_b_1",
-                  f"{m}.hyper_b_2.0", f"{m}.hyper_b_2.2"):
-            mixer_order += [n + ".weight", n + ".bias"]
+        # mixer: "QMIX" (QMIX_Mixer, q_mix_head.py:28-95), "VDN" (VDN_Mixer: sum over agents) or "Independent"
+        # (IndependentMixer, IQL): the last two have no parameters (vdn_agents.py:71-72, iql_agents.py:71)
+        self.mixer = mixer
+        mixer_order, m_widths, m_stages = [], None, None
+        if mixer == "QMIX":
+            # mixer hyper-networks: the three ReLU first layers are stacked into one GEMM ([hyper_w_1.0; hyper_w_2.0;
+            # hyper_b_2.0]), hyper_b_1 is a second group of the same launch; second layers are three groups.
+            m = "eval_Qtot"
+            firsts = [f"{m}.hyper_w_1.0", f"{m}.hyper_w_2.0", f"{m}.hyper_b_2.0"]
+            specs += [(n + ".weight", (HH, S)) for n in firsts] + [(n + ".bias", (HH,)) for n in firsts]
+            specs += [(f"{m}.hyper_b_1.weight", (H, S)), (f"{m}.hyper_b_1.bias", (H,)),
+                      (f"{m}.hyper_w_1.2.weight", (N * H, HH)), (f"{m}.hyper_w_1.2.bias", (N * H,)),
+                      (f"{m}.hyper_w_2.2.weight", (H, HH)), (f"{m}.hyper_w_2.2.bias", (H,)),
+                      (f"{m}.hyper_b_2.2.weight", (1, HH)), (f"{m}.hyper_b_2.2.bias", (1,))]
+            assert (HH * S) % 4 == 0 and HH % 4 == 0
+            self.raw_width = N * H + H + 1
+            m_widths = [S, 3 * HH + H, (self.raw_width + 3) // 4 * 4]
+            m_stages = [[Layer("+".join(firsts), S, 3 * HH, "relu", 0, 0, 1, 0, firsts[0] + ".weight", firsts[0] + ".bias"),
+                         Layer(f"{m}.hyper_b_1", S, H, None, 0, 0, 1, 3 * HH, f"{m}.hyper_b_1.weight", f"{m}.hyper_b_1.bias")],
+                        [Layer(f"{m}.hyper_w_1.2", HH, N * H, None, 1, 0, 2, 0, f"{m}.hyper_w_1.2.weight", f"{m}.hyper_w_1.2.bias"),
+                         Layer(f"{m}.hyper_w_2.2", HH, H, None, 1, HH, 2, N * H, f"{m}.hyper_w_2.2.weight", f"{m}.hyper_w_2.2.bias"),
+                         Layer(f"{m}.hyper_b_2.2", HH, 1, None, 1, 2 * HH, 2, N * H + H, f"{m}.hyper_b_2.2.weight", f"{m}.hyper_b_2.2.bias")]]
+            for n in (f"{m}.hyper_w_1.0", f"{m}.hyper_w_1.2", f"{m}.hyper_w_2.0", f"{m}.hyper_w_2.2", f"{m}.hyper_b_1",
+                      f"{m}.hyper_b_2.0", f"{m}.hyper_b_2.2"):
+                mixer_order += [n + ".weight", n + ".bias"]
         self.params = FlatParams(specs, device)
         self.target_flat = self.params.like()
         if not use_rnn:
@@ -495,8 +499,9 @@ class MixingQNet:
             self.pre_plans = [Plan(self.params, a_widths, a_stages) for _ in range(3)]
             self.post_plans = [Plan(self.params, q_widths, q_stages) for _ in range(3)]
             self._seq_ws = {}
-        self.mixer_plan = Plan(self.params, m_widths, m_stages)
-        self.mixer_target_plan = Plan(self.params, m_widths, m_stages)
+        if mixer == "QMIX":
+            self.mixer_plan = Plan(self.params, m_widths, m_stages)
+            self.mixer_target_plan = Plan(self.params, m_widths, m_stages)
         self.trainable_order = a_order + mixer_order
         # reference order: individual_q_networks, target_individual_q_networks, eval_Qtot, target_Qtot
         self.ref_order = a_order + ["target_" + k for k in a_order] + mixer_order + \
