@@ -486,7 +486,9 @@ typedef struct {
     float* diag;               /* NULL or [2][M]: predictQ, targetQ (callback tensors dqn_learner.py:72-74) */
     double* partials;          /* [n_split][8]: sum (predictQ-y)^2, sum predictQ, 0... */
     int32_t M, A, ld, n_split;
-    float gamma, pad;
+    float gamma;
+    int32_t dueling;           /* != 0: head rows are [advantages (A) | value] and Q = V + (A_j - mean A)
+                                * (DuelingQValueHead, rl_models/heads/q_head.py:42-80; dueldqn_learner.py:28-75); ld >= A + 1 */
 } xrl_dqn_td_t;
 int xrl_dqn_td(const xrl_dqn_td_t* p, xrl_stream_t stream);
 

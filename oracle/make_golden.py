@@ -254,9 +254,11 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo"):
 
 
 # ------------------------------------------------------------------------------ DQN
-def golden_dqn(kind, learner_cls=None, name=None):
-    """learner_cls: DQN_Learner (default) or DDQN_Learner (ddqn_learner.py:39-47, the double-Q target)."""
+def golden_dqn(kind, learner_cls=None, name=None, model_cls=None):
+    """learner_cls: DQN_Learner (default), DDQN_Learner (ddqn_learner.py:39-47, the double-Q target) or DuelDQN_Learner
+    with model_cls=DuelingDeepQNetwork (dueldqn_learner.py:28-75, q_head.py:42-80)."""
     learner_cls = learner_cls or DQN_Learner
+    model_cls = model_cls or DeepQNetwork
     torch.manual_seed(2)
     rng = np.random.default_rng(9)
     init = torch.nn.init.orthogonal_
@@ -268,7 +270,7 @@ def golden_dqn(kind, learner_cls=None, name=None):
         A, bs = 4, 4
         rep = Basic_CNN((84, 84, 4), [8, 4, 3], [4, 2, 1], [32, 64, 64], None, init, nn.ReLU, "cpu")
         hidden = [512]
-    model = DeepQNetwork(rep, hidden, sp.Discrete(A), None, init, nn.ReLU, "cpu")
+    model = model_cls(rep, hidden, sp.Discrete(A), None, init, nn.ReLU, "cpu")
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.endswith("bias"):
@@ -541,6 +543,9 @@ if __name__ == "__main__":
     golden_dqn("mlp")
     golden_dqn("cnn")
     golden_dqn("mlp", DDQN_Learner, "ddqn")
+    from xuance.torch.learners import DuelDQN_Learner
+    from xuance.torch.rl_models.architectures.single_agent.deep_q_network import DuelingDeepQNetwork
+    golden_dqn("mlp", DuelDQN_Learner, "dueldqn", DuelingDeepQNetwork)
     golden_qmix(True)
     golden_qmix(False)
     golden_qmix(True, "vdn")

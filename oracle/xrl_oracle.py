@@ -526,6 +526,44 @@ def dqn_forward_backward(sd, batch, cfg, act="relu"):
     return info, grads
 
 
+def dueldqn_forward_backward(sd, batch, cfg, act="relu"):
+    """DuelDQN_Learner.update (dueldqn_learner.py:28-75) on DuelingDeepQNetwork: DuelingQValueHead (q_head.py:42-80) with
+    v_model / a_model streams, Q = V + (A - mean(A)); the update rule is DQN's."""
+    dt = np.float32
+    rep_l = collect_seq(sd, "representation.model", act, last_act=act)
+    trep_l = collect_seq(sd, "target_representation.model", act, last_act=act)
+    nets = {k: MLP(collect_seq(sd, k, act)) for k in ("eval_Q_head.v_model", "eval_Q_head.a_model", "target_Q_head.v_model",
+                                                      "target_Q_head.a_model")}
+    rep, trep = MLP(rep_l), MLP(trep_l)
+    obs, nxt = batch["obs"].astype(dt), batch["obs_next"].astype(dt)
+    B = obs.shape[0]
+    h = rep.forward(obs) if rep_l else obs
+    V, Adv = nets["eval_Q_head.v_model"].forward(h), nets["eval_Q_head.a_model"].forward(h)
+    evalQ = V + (Adv - Adv.mean(-1, keepdims=True))                    # q_head.py:75-77
+    ht = trep.forward(nxt) if trep_l else nxt
+    Vt, At = nets["target_Q_head.v_model"].forward(ht), nets["target_Q_head.a_model"].forward(ht)
+    tmax = (Vt + (At - At.mean(-1, keepdims=True))).max(-1)             # dueldqn_learner.py:43
+    a = batch["actions"].astype(np.int64)
+    predictQ = evalQ[np.arange(B), a]                                   # :42
+    targetQ = batch["rewards"].astype(dt) + dt(cfg["gamma"]) * (1 - batch["terminals"].astype(dt)) * tmax   # :44
+    loss = ((predictQ - targetQ) ** 2).mean()                           # :46
+    dQ = np.zeros_like(evalQ)
+    dQ[np.arange(B), a] = 2 * (predictQ - targetQ) / dt(B)
+    dV = dQ.sum(-1, keepdims=True)
+    dA = dQ - dQ.sum(-1, keepdims=True) / dt(Adv.shape[1])
+    dh_v, g_v = nets["eval_Q_head.v_model"].backward(dV, need_dx=bool(rep_l))
+    dh_a, g_a = nets["eval_Q_head.a_model"].backward(dA, need_dx=bool(rep_l))
+    grads = {}
+    for key, gl in (("eval_Q_head.v_model", g_v), ("eval_Q_head.a_model", g_a)):
+        for L, (gw, gb) in zip(nets[key].layers, gl):
+            grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    if rep_l:
+        _, g_rep = rep.backward(dh_v + dh_a, need_dx=False)
+        for L, (gw, gb) in zip(rep_l, g_rep):
+            grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    return dict(evalQ=evalQ, predictQ=predictQ, targetQ=targetQ, loss=loss, dQ=dQ), grads
+
+
 def dqn_copy_target(sd):                                                # deep_q_network.py:95-99
     for k in list(sd):
         if k.startswith("representation."):

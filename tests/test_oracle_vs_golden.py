@@ -148,13 +148,17 @@ def test_a2c_update(oracle, dist):
     assert opt.lr < lr                                            # the short LinearLR horizon of the fixture is visible
 
 
-@pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp"])
+@pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp"])
 def test_dqn_mlp_update(oracle, name):
-    """dqn_mlp: DQN_Learner (dqn_learner.py:28-75); ddqn_mlp: DDQN_Learner (ddqn_learner.py:28-75), same network."""
+    """dqn_mlp: DQN_Learner (dqn_learner.py:28-75); ddqn_mlp: DDQN_Learner (ddqn_learner.py:28-75), same network;
+    dueldqn_mlp: DuelDQN_Learner on DuelingDeepQNetwork (dueldqn_learner.py:28-75, q_head.py:42-80)."""
     g = load_golden(name)
     lr, gamma, sync, gclip, use_clip, total = g["cfg"]
     opt_kwargs_clip["clip"] = gclip if use_clip else None
-    fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma, double_q=name.startswith("ddqn")))
+    if name.startswith("duel"):
+        fb = lambda sd, b: oracle.dueldqn_forward_backward(sd, b, dict(gamma=gamma))
+    else:
+        fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma, double_q=name.startswith("ddqn")))
 
     def on_update(u, sd):
         if (u + 1) % int(sync) == 0:

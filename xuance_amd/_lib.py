@@ -78,7 +78,7 @@ class DqnTd(C.Structure):
     _fields_ = [("q_eval", c_void_p), ("q_next", c_void_p), ("q_next_eval", c_void_p), ("actions", c_void_p),
                 ("rewards", c_void_p), ("terminals", c_void_p), ("d_q", c_void_p), ("diag", c_void_p),
                 ("partials", c_void_p), ("M", c_int32), ("A", c_int32), ("ld", c_int32), ("n_split", c_int32),
-                ("gamma", c_float), ("pad", c_float)]
+                ("gamma", c_float), ("dueling", c_int32)]
 
 
 class Qmix(C.Structure):

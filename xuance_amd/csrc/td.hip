@@ -13,25 +13,37 @@ __global__ void __launch_bounds__(256) dqn_td_kernel(xrl_dqn_td_t p) {
     const int mbeg = blockIdx.x * chunk, mend = min(p.M, mbeg + chunk);
     const float invM = 1.f / (float)p.M;
     double acc_l = 0.0, acc_q = 0.0;
+    const int A = p.A;
+    const bool duel = p.dueling != 0;
+    // Q(s, j) of a head row.  Plain head: r[j].  Dueling head (DuelingQValueHead.forward, q_head.py:75-77): the row is
+    // [advantages (A) | value], Q = V + (A_j - mean(A)).
+    auto row_mean = [&](const float* r) { float s = 0.f; for (int j = 0; j < A; ++j) s += r[j]; return s / (float)A; };
     for (int m = mbeg + threadIdx.x; m < mend; m += blockDim.x) {
         const float* qe = p.q_eval + (size_t)m * p.ld;
         const float* qn = p.q_next + (size_t)m * p.ld;
         const int a = (int)p.actions[m];
-        const float pred = qe[a];                                        // :42
+        const float me = duel ? row_mean(qe) : 0.f, mn = duel ? row_mean(qn) : 0.f;
+        const float pred = duel ? qe[A] + (qe[a] - me) : qe[a];          // :42
         float tq;
         if (p.q_next_eval) {                                             // double-Q: argmax of the eval net
-            const float* qs = p.q_next_eval + (size_t)m * p.ld;
+            const float* qs = p.q_next_eval + (size_t)m * p.ld;          // (argmax over advantages == argmax over Q)
             int best = 0; float bv = qs[0];
-            for (int j = 1; j < p.A; ++j) if (qs[j] > bv) { bv = qs[j]; best = j; }
-            tq = qn[best];
+            for (int j = 1; j < A; ++j) if (qs[j] > bv) { bv = qs[j]; best = j; }
+            tq = duel ? qn[A] + (qn[best] - mn) : qn[best];
         } else {
-            tq = qn[0];
-            for (int j = 1; j < p.A; ++j) tq = fmaxf(tq, qn[j]);         // :43
+            tq = duel ? qn[A] + (qn[0] - mn) : qn[0];
+            for (int j = 1; j < A; ++j) tq = fmaxf(tq, duel ? qn[A] + (qn[j] - mn) : qn[j]);   // :43
         }
         const float y = p.rewards[m] + p.gamma * (1.f - p.terminals[m]) * tq;    // :44
         const float td = pred - y;
         float* dq = p.d_q + (size_t)m * p.ld;
-        for (int j = 0; j < p.A; ++j) dq[j] = (j == a) ? 2.f * td * invM : 0.f;   // MSELoss backward through gather
+        const float g = 2.f * td * invM;                                 // MSELoss backward through gather
+        if (duel) {      // dA_j = g [j == a] + (-g) / A (backward of `- mean`), dV = g
+            for (int j = 0; j < A; ++j) dq[j] = ((j == a) ? g : 0.f) + (-g) / (float)A;
+            dq[A] = g;
+        } else {
+            for (int j = 0; j < A; ++j) dq[j] = (j == a) ? g : 0.f;
+        }
         if (p.diag) { p.diag[m] = pred; p.diag[p.M + m] = y; }
         acc_l += (double)td * td; acc_q += pred;
     }
@@ -202,7 +214,7 @@ using namespace xrl;
 
 extern "C" int xrl_dqn_td(const xrl_dqn_td_t* p, xrl_stream_t stream) {
     XRL_CHECK_ARG(p && p->q_eval && p->q_next && p->actions && p->rewards && p->terminals && p->d_q && p->partials);
-    XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->ld >= p->A && p->n_split >= 1);
+    XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->ld >= p->A + (p->dueling ? 1 : 0) && p->n_split >= 1);
     hipLaunchKernelGGL(dqn_td_kernel, dim3(p->n_split), dim3(256), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;

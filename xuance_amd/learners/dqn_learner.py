@@ -47,8 +47,8 @@ class DQN_Learner(Learner):
         q_next = model.target(self.X[M:2 * M], M)                                    # targetQ (:40)
         d_q = model.d_out
         ops.dqn_td(q_eval=q_all, q_next=q_next, q_next_eval=q_all[M:] if self.double_q else None, actions=act,
-                   rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A, ld=A,
-                   n_split=S, gamma=float(self.gamma))
+                   rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A,
+                   ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)))
         model.backward(self.X, M, self.slabs, S)
         ops.grad_reduce(self.slabs, S, model.params.P, model.params.P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
@@ -106,11 +106,19 @@ class DQN_Learner(Learner):
                                                  next_obs=self.X[M:2 * M], rew=self._rew, termination=self._ter) or {}
             info.update({self._key("Qloss"): float(sums[e, 0] / M), self._key("predictQ"): float(sums[e, 1] / M),
                          self._key("learning_rate"): st.last_lr})
-            evalQ = self.model.plan.acts[len(self.model.plan.widths) - 1][:M, :A]
+            evalQ = self._eval_q(M, A)
             info.update(self.callback.on_update_end(self.iterations, policy=self.model, info=info, evalQ=evalQ,
                                                     predictQ=self.diag[:M], targetQ=self.diag[M:2 * M],
                                                     loss=info[self._key("Qloss")]) or {})
         return info
+
+    def _eval_q(self, M, A):
+        """evalQ of the callback (dqn_learner.py:72): the head output, combined for a dueling head (q_head.py:77)."""
+        out = self.model.plan.acts[len(self.model.plan.widths) - 1]
+        if getattr(self.model, "dueling", False):
+            adv, val = out[:M, :A], out[:M, A:A + 1]
+            return val + (adv - adv.mean(dim=-1, keepdim=True))
+        return out[:M, :A]
 
     def update(self, **samples):
         self.iterations += 1
@@ -128,11 +136,21 @@ class DQN_Learner(Learner):
         info.update({self._key("Qloss"): float(s[0] / M), self._key("predictQ"): float(s[1] / M),
                      self._key("learning_rate"): st.last_lr})
         A = self.n_actions
-        evalQ = self.model.plan.acts[len(self.model.plan.widths) - 1][:M, :A]
+        evalQ = self._eval_q(M, A)
         info.update(self.callback.on_update_end(self.iterations, policy=self.model, info=info, evalQ=evalQ,
                                                 predictQ=self.diag[:M], targetQ=self.diag[M:2 * M],
                                                 loss=info[self._key("Qloss")]) or {})
         return info
+
+
+class DuelDQN_Learner(DQN_Learner):
+    """Dueling DQN (xuance/torch/learners/qlearning_family/dueldqn_learner.py:13-82): DQN_Learner's update on a network
+    with DuelingQValueHead (Q = V + A - mean A, rl_models/heads/q_head.py:42-80).  The head's two streams are two groups of
+    the same GEMM launches; the combination and its backward live inside xrl_dqn_td (`dueling = 1`)."""
+
+    def __init__(self, config, model, callback=None):
+        assert getattr(model, "dueling", False), "DuelDQN_Learner needs a model built with dueling=True"
+        super().__init__(config, model, callback)
 
 
 class DDQN_Learner(DQN_Learner):

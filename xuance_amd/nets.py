@@ -80,6 +80,13 @@ class Plan:
 
     def __init__(self, params: FlatParams, widths: List[int], stages: List[List[Layer]]):
         self.params, self.widths, self.stages = params, widths, stages
+        # the data-gradient GEMMs WRITE d(input): two layers of a stage must not read overlapping columns of a hidden
+        # level (stack such layers into one, like the first layers of the dueling streams or of the mixer's hyper-networks)
+        for stage in stages:
+            spans = [(L.in_level, L.in_off, L.in_off + L.K) for L in stage if L.in_level > 0]
+            for i, a in enumerate(spans):
+                for b in spans[i + 1:]:
+                    assert a[0] != b[0] or a[2] <= b[1] or b[2] <= a[1], "layers of one stage share hidden input columns"
         self.cap = 0
         self.acts, self.dacts = {}, {}
 
@@ -367,13 +374,44 @@ class DeepQNet:
     eval and target networks share one parameter layout; the target lives in a second flat buffer."""
 
     def __init__(self, obs_dim, n_actions, representation_hidden=(), q_hidden=(64,), activation="relu", device="cuda",
-                 init=True):
-        self.obs_dim, self.n_actions, self.activation = obs_dim, n_actions, activation
+                 init=True, dueling=False):
+        self.obs_dim, self.n_actions, self.activation, self.dueling = obs_dim, n_actions, activation, bool(dueling)
         specs, order, stages, widths = [], [], [], [obs_dim]
         feat, lvl = _seq_layers("representation.model", obs_dim, list(representation_hidden or []), activation, "same",
                                 0, specs, order, stages, widths)
-        _seq_layers("eval_Q_head.q_value", feat, list(q_hidden) + [n_actions], activation, None, lvl, specs, order,
-                    stages, widths)
+        if not dueling:
+            _seq_layers("eval_Q_head.q_value", feat, list(q_hidden) + [n_actions], activation, None, lvl, specs, order,
+                        stages, widths)
+        else:
+            # DuelingQValueHead (q_head.py:42-80): v_model feat -> h/2 ... -> 1 and a_model feat -> h/2 ... -> A side by
+            # side (two groups per launch); the output level is [advantages (A) | value], combined inside xrl_dqn_td
+            v_specs, a_specs, v_order, a_order = [], [], [], []
+            assert len(list(q_hidden)) >= 1, "dueling head: at least one hidden layer (the two streams' first layers are stacked)"
+            vin, ain, k_in = 0, 0, feat
+            for i, h in enumerate(list(q_hidden)):
+                hh = h // 2
+                nv, na = f"eval_Q_head.v_model.{2 * i}", f"eval_Q_head.a_model.{2 * i}"
+                v_order += [nv + ".weight", nv + ".bias"]; a_order += [na + ".weight", na + ".bias"]
+                if i == 0:
+                    # both streams read the same features: ONE stacked layer [v; a] (one data-gradient GEMM into the shared
+                    # input); the flat layout keeps the two weights, then the two biases, adjacent
+                    assert (hh * k_in) % 4 == 0 and hh % 4 == 0
+                    specs += [(nv + ".weight", (hh, k_in)), (na + ".weight", (hh, k_in)), (nv + ".bias", (hh,)), (na + ".bias", (hh,))]
+                    stages.append([Layer(nv + "+" + na, k_in, 2 * hh, activation, lvl, 0, lvl + 1, 0, nv + ".weight", nv + ".bias")])
+                else:
+                    specs += [(nv + ".weight", (hh, k_in)), (nv + ".bias", (hh,)), (na + ".weight", (hh, k_in)), (na + ".bias", (hh,))]
+                    stages.append([Layer(nv, k_in, hh, activation, lvl, vin, lvl + 1, 0, nv + ".weight", nv + ".bias"),
+                                   Layer(na, k_in, hh, activation, lvl, ain, lvl + 1, hh, na + ".weight", na + ".bias")])
+                widths.append(2 * hh)
+                lvl, k_in, vin, ain = lvl + 1, hh, 0, hh
+            i = len(list(q_hidden))
+            nv, na = f"eval_Q_head.v_model.{2 * i}", f"eval_Q_head.a_model.{2 * i}"
+            specs += [(nv + ".weight", (1, k_in)), (nv + ".bias", (1,)), (na + ".weight", (n_actions, k_in)), (na + ".bias", (n_actions,))]
+            v_order += [nv + ".weight", nv + ".bias"]; a_order += [na + ".weight", na + ".bias"]
+            stages.append([Layer(na, k_in, n_actions, None, lvl, ain, lvl + 1, 0, na + ".weight", na + ".bias"),
+                           Layer(nv, k_in, 1, None, lvl, vin, lvl + 1, n_actions, nv + ".weight", nv + ".bias")])
+            widths.append(n_actions + 1)
+            order += v_order + a_order                          # state_dict order of the reference head: v_model, a_model
         self.eval_order = order
         self.params = FlatParams(specs, device)
         self.target_flat = self.params.like()
