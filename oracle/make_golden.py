@@ -531,6 +531,54 @@ def golden_marl_rnn_buffer():
     np.savez_compressed(os.path.join(OUT, "marl_rnn_buffer.npz"), **out)
 
 
+def golden_checkpoint():
+    """Checkpoint compatibility: a `.pth` written by the reference's Learner.save_model
+    (drl_learner.py:64-93) after two PPO updates, and the parameters the REFERENCE reaches when a fresh learner loads that
+    file (load_model, :95-157) and makes a third update.  tests/golden/ppo_ckpt_ref.pth + ppo_ckpt.npz."""
+    import copy
+    torch.manual_seed(6)
+    rng = np.random.default_rng(31)
+    init = torch.nn.init.orthogonal_
+    D, A, bs = 4, 2, 64
+
+    def build():
+        rep = Basic_MLP((D,), [128], None, init, nn.LeakyReLU, "cpu")
+        actor = CategoricalActorHead(128, [128], A, None, init, nn.LeakyReLU, "cpu")
+        critic = ValueHead(128, [128], None, init, nn.LeakyReLU, "cpu")
+        m = SharedActorCritic(rep, actor, critic)
+        cfg = base_config(horizon_size=256, n_epochs=8, n_minibatch=8, vf_coef=0.25, ent_coef=0.01, clip_range=0.2)
+        return m, PPO_Learner(cfg, m, Capture())
+    model, learner = build()
+    batches = []
+    for u in range(3):
+        obs = np.clip(rng.standard_normal((bs, D)), -5, 5).astype(np.float32)
+        actions = rng.integers(0, A, bs).astype(np.float32)
+        with torch.no_grad():
+            old_logp = model(torch.from_numpy(obs)).distributions.log_prob(torch.from_numpy(actions)).numpy()
+        adv = rng.standard_normal(bs).astype(np.float32)
+        batches.append(dict(obs=obs, actions=actions, returns=rng.standard_normal(bs).astype(np.float32), advantages=adv,
+                            old_logp=(old_logp + rng.standard_normal(bs) * 0.2).astype(np.float32),
+                            values=rng.standard_normal(bs).astype(np.float32)))
+
+    def call(l, b):
+        return l.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
+                        advantages=b["advantages"], aux_batch={"old_logp": b["old_logp"]}, batch_size=bs)
+    out = flat("init", sd_np(model))
+    call(learner, batches[0]); call(learner, batches[1])
+    path = os.path.join(OUT, "ppo_ckpt_ref.pth")
+    learner.save_model(path)
+    out.update(flat("saved", sd_np(model)))
+    model2, learner2 = build()                                      # fresh process: new model, new optimiser
+    learner2.load_model(path)
+    info = call(learner2, batches[2])
+    out.update(flat("resumed", sd_np(model2)))
+    for u, b in enumerate(batches):
+        out.update(flat(f"u{u}/batch", b))
+    out["resumed_info/learning_rate"] = np.float64(info["learning_rate"])
+    out["resumed_info/actor_loss"] = np.float64(info["actor_loss"])
+    np.savez_compressed(os.path.join(OUT, "ppo_ckpt.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_onpolicy_buffer()
@@ -555,5 +603,6 @@ if __name__ == "__main__":
     golden_qmix_rnn(False)
     golden_qmix_rnn(True, fixed=True)
     golden_marl_rnn_buffer()
+    golden_checkpoint()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -166,3 +166,47 @@ def test_multi_rank_plumbing_gloo_world2():
     for r, w, gmean, params, shard, tmax in res:
         assert w == 2 and gmean == 1.5 and params == list(map(float, range(10))) and tmax == 1.5
     assert res[0][4] == (0, 256) and res[1][4] == (256, 512)
+
+
+def test_checkpoint_layout_is_the_references(tmp_path):
+    """(1) a `.pth` written by the REFERENCE's Learner.save_model (tests/golden/ppo_ckpt_ref.pth, produced by
+    oracle/make_golden.py golden_checkpoint) loads into this engine's learner -- parameters, Adam moments, step, lr;
+    (2) a file written by this engine has the reference's layout: torch.optim.Adam over parameters of the same shapes
+    accepts its optimiser state and steps with it.  Host-side only (no kernels are launched)."""
+    import os
+    from argparse import Namespace
+    import numpy as np
+    import torch
+    from conftest import load_golden, sub, GOLDEN
+    from xuance_amd.nets import ActorCriticNet
+    from xuance_amd.learners import PPO_Learner
+    g = load_golden("ppo_ckpt")
+    cfg = Namespace(horizon_size=256, n_epochs=8, n_minibatch=8, parallels=4, running_steps=120000, gamma=0.98,
+                    learning_rate=4e-4, vf_coef=0.25, ent_coef=0.01, clip_range=0.2, use_grad_clip=True, grad_clip_norm=0.5,
+                    distributed_training=False, device="cpu", model_dir=str(tmp_path))
+    net = ActorCriticNet(4, 2, "categorical", (128,), (128,), (128,), "leaky_relu", device="cpu")
+    learner = PPO_Learner(cfg, net)
+    ref_path = os.path.join(GOLDEN, "ppo_ckpt_ref.pth")
+    learner.load_model(ref_path)
+    ref = torch.load(ref_path, weights_only=True)
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.numpy(), sub(g, "saved")[k]), k
+    st = learner.optimizer.read()
+    assert st.step == 2 and abs(st.last_lr - 4e-4) < 1e-12
+    osd = learner.optimizer.state_dict()
+    for i in range(len(net.ref_order)):
+        assert torch.equal(osd["state"][i]["exp_avg"], ref["optimizer"]["state"][i]["exp_avg"])
+        assert torch.equal(osd["state"][i]["exp_avg_sq"], ref["optimizer"]["state"][i]["exp_avg_sq"])
+    # (2) our file -> the stock optimiser
+    mine = str(tmp_path / "mine.pth")
+    learner.save_model(mine)
+    ck = torch.load(mine, weights_only=True)
+    assert list(ck.keys()) == list(ref.keys()) and list(ck["policy"].keys()) == list(ref["policy"].keys())
+    assert set(ck["optimizer"]["param_groups"][0]) == set(ref["optimizer"]["param_groups"][0])
+    params = [torch.nn.Parameter(v.clone()) for v in ck["policy"].values()]
+    opt = torch.optim.Adam(params, 1e-3, eps=1e-5)
+    opt.load_state_dict(ck["optimizer"])
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    assert float(opt.state[params[0]]["step"]) == 3.0 and opt.param_groups[0]["lr"] == 4e-4

@@ -169,3 +169,27 @@ def test_offpolicy_buffer_vs_reference_fixture(tag, dtype):
     assert np.array_equal(s["rewards"].cpu().numpy(), d["s_rewards"])
     assert np.array_equal(s["terminals"].cpu().numpy(), d["s_terminals"].astype(np.float32))
     assert str(s["obs"].dtype).endswith(dtype)
+
+
+def test_resume_from_a_reference_checkpoint():
+    """A fresh learner loads the `.pth` the REFERENCE wrote after two updates and makes the third one: parameters equal
+    the ones the reference reaches when IT resumes from that file (tests/golden/ppo_ckpt.npz, oracle/make_golden.py)."""
+    import os
+    from conftest import GOLDEN
+    from xuance_amd.nets import ActorCriticNet
+    from xuance_amd.learners import PPO_Learner
+    g = load_golden("ppo_ckpt")
+    cfg = Namespace(horizon_size=256, n_epochs=8, n_minibatch=8, parallels=4, running_steps=120000, gamma=0.98,
+                    learning_rate=4e-4, vf_coef=0.25, ent_coef=0.01, clip_range=0.2, use_grad_clip=True, grad_clip_norm=0.5,
+                    distributed_training=False, device="cuda", model_dir="/tmp/xrl_models")
+    net = ActorCriticNet(4, 2, "categorical", (128,), (128,), (128,), "leaky_relu")
+    learner = PPO_Learner(cfg, net)
+    learner.load_model(os.path.join(GOLDEN, "ppo_ckpt_ref.pth"))
+    b = sub(g, "u2/batch")
+    info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
+                          advantages=b["advantages"], aux_batch={"old_logp": b["old_logp"]}, batch_size=len(b["obs"]))
+    assert_close(info["actor_loss"], g["resumed_info/actor_loss"], 1e-5, "actor_loss")
+    assert_close(info["learning_rate"], g["resumed_info/learning_rate"], 1e-9, "lr")
+    for k, rp in sub(g, "resumed").items():
+        assert_close(net.state_dict()[k].cpu().numpy(), rp, 1e-5, f"param {k} after the resumed update")
+    assert learner.optimizer.read().step == 3

@@ -337,6 +337,44 @@ class PPO_Agent:
         info.update({"episodes": eps, "mean_episode_score": score, "mean_episode_length": length})
         return info
 
+    # -- checkpoints (agent.py:199-230: learner .pth + obs_rms.npy with {'count','mean','var'}) ---------------------------
+    def _obs_stats_tensors(self):
+        """(mean, var, count) tensors holding the CURRENT observation statistics: the fused rollout keeps them in the
+        ping-pong slot 0 between rollouts (horizon_size is even), the layered path in obs_mean / obs_var / obs_count."""
+        if self.use_fused_rollout:
+            D = self.obs_dim
+            return self.pp["obs_stats"][0][:D], self.pp["obs_stats"][0][D:], self.pp["obs_count"][0]
+        return self.obs_mean, self.obs_var, self.obs_count
+
+    def save_model(self, model_name, model_path=None):
+        import os
+        model_path = _get(self.config, "model_dir", "models") if model_path is None else model_path
+        os.makedirs(model_path, exist_ok=True)
+        self.learner.save_model(os.path.join(model_path, model_name))
+        if self.use_obsnorm:
+            mean, var, count = self._obs_stats_tensors()
+            np.save(os.path.join(model_path, "obs_rms.npy"),
+                    {"count": float(count.item()), "mean": mean.cpu().numpy().astype(np.float32).reshape(space2shape(self.observation_space)),
+                     "var": var.cpu().numpy().astype(np.float32).reshape(space2shape(self.observation_space))})
+
+    def load_model(self, path, model=None):
+        import os
+        loaded = self.learner.load_model(os.path.join(path, model) if model is not None else path)
+        if self.use_obsnorm:
+            f = os.path.join(os.path.dirname(loaded), "obs_rms.npy")
+            if not os.path.exists(f):
+                raise RuntimeError(f"Failed to load observation status file 'obs_rms.npy' from {f}!")
+            st = np.load(f, allow_pickle=True).item()
+            mean, var, count = self._obs_stats_tensors()
+            mean.copy_(torch.as_tensor(np.asarray(st["mean"], np.float32).reshape(-1)))
+            var.copy_(torch.as_tensor(np.asarray(st["var"], np.float32).reshape(-1)))
+            count.fill_(float(st["count"]))
+            if self.use_fused_rollout:                         # both ping-pong slots start from the same statistics
+                self.pp["obs_stats"][1].copy_(self.pp["obs_stats"][0]); self.pp["obs_count"][1].copy_(self.pp["obs_count"][0])
+        self._rollout_graph = None                             # parameters' derived layouts are rebuilt on the next rollout/update
+        self._update_graph = None
+        return loaded
+
     def finish(self):
         self.envs.close()
 

@@ -27,7 +27,9 @@ class AdamHandle:
         self.m = params.like()
         self.v = params.like()
         self.state = ops.adam_state_tensor(lr, total_iters, end_factor, eps, weight_decay, device=params.device)
-        self.defaults = dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=weight_decay, amsgrad=False)
+        # every key torch.optim.Adam keeps in a param group: a file written here loads into the reference's optimiser
+        self.defaults = dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                             foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
 
     def read(self):
         return ops.read_adam_state(self.state)
@@ -127,10 +129,12 @@ class Learner:
     # -- checkpoint format of drl_learner.py:64-157 ------------------------------------------------------
     def save_model(self, model_path):
         os.makedirs(os.path.dirname(model_path) or ".", exist_ok=True)
+        osd = self.optimizer.state_dict()
+        osd["state"] = {i: {k: v.cpu() for k, v in st.items()} for i, st in osd["state"].items()}
         torch.save({"policy": OrderedDict((k, v.cpu()) for k, v in self.model.state_dict().items()),
-                    "optimizer": self.optimizer.state_dict(),
+                    "optimizer": osd,
                     "rng_state": torch.get_rng_state(),
-                    "cuda_rng_state": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None},
+                    "cuda_rng_state": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else []},
                    model_path)
 
     def load_model(self, path, model=None):
@@ -139,10 +143,16 @@ class Learner:
             if not files:
                 raise RuntimeError(f"No model file found in {path}")
             path = os.path.join(path, files[-1])
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)          # drl_learner.py:119-121
         self.model.load_state_dict(ckpt["policy"] if "policy" in ckpt else ckpt)
         if "optimizer" in ckpt and self.optimizer is not None:
             self.optimizer.load_state_dict(ckpt["optimizer"])
+            self.learning_rate = self.optimizer.lr                              # :133-135
+        if ckpt.get("rng_state") is not None:                                   # :137-140
+            torch.set_rng_state(ckpt["rng_state"].cpu().to(torch.uint8))
+        if ckpt.get("cuda_rng_state") and torch.cuda.is_available():           # :142-153
+            for i, st in enumerate(ckpt["cuda_rng_state"][:torch.cuda.device_count()]):
+                torch.cuda.set_rng_state(st.cpu().to(torch.uint8), device=i)
         return path
 
     def update(self, *args, **kwargs):
