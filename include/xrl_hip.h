@@ -585,6 +585,23 @@ int xrl_episode_finish(const xrl_episode_field_t* fields, int n_fields, const fl
 /* sample (:970-996): a = time-major batch [slots][B][row], b = ring: a[t][i] <- b[idx[i]][t]. */
 int xrl_episode_gather(const xrl_episode_field_t* fields, int n_fields, const int64_t* idx, int B, xrl_stream_t stream);
 
+/* ------------------------------------------------------------------ prioritized replay (PerOffPolicyBuffer)
+ * memory_tools.py:471-598 with segtree_tool.py:24-230.  Per-env sum and min segment trees, [n_envs][2*capacity] float64
+ * (capacity = power of two >= n_size; node 1 = root; unset sum leaves 0, unset min leaves +inf), max_priority [n_envs]. */
+/* store (:536-538): leaf `ptr` of every env <- max_priority[env] ** alpha */
+int xrl_per_store(double* sum_tree, double* min_tree, const double* max_priority, int ptr, double alpha, int n_envs,
+                  int capacity, xrl_stream_t stream);
+/* sample (:499-507, 542-565): per env `per_env` stratified draws, mass = (u + i) * sum(0, size-1) / per_env with the
+ * caller's uniforms [n_envs][per_env] (random.random() in the reference), find_prefixsum_idx, importance weights.
+ * flat_idx (optional) = env * n_size + step for xrl_soa_gather. */
+int xrl_per_sample(const double* sum_tree, const double* min_tree, const double* uniforms, int size, double beta, int n_envs,
+                   int n_size, int capacity, int per_env, int64_t* step_choices, double* weights, int64_t* flat_idx,
+                   xrl_stream_t stream);
+/* update_priorities (:586-597): per env, in order: p == 0 -> 1e-8; leaf <- p ** alpha; max_priority = max(., p) */
+int xrl_per_update_priorities(double* sum_tree, double* min_tree, double* max_priority, const int64_t* idxes,
+                              const float* priorities, double alpha, int n_envs, int capacity, int per_env,
+                              xrl_stream_t stream);
+
 /* Hard target update inside a captured graph: if (state->step % sync_frequency == 0) target <- params
  * (dqn_learner.py:56-57, qmix_learner.py:105-106; copy_target deep_q_network.py:95-99). */
 int xrl_sync_target(const float* params, float* target, int64_t P, const xrl_adam_state_t* state,

@@ -579,6 +579,56 @@ def golden_checkpoint():
     np.savez_compressed(os.path.join(OUT, "ppo_ckpt.npz"), **out)
 
 
+def golden_per_buffer():
+    """PerOffPolicyBuffer (memory_tools.py:471-598, segtree_tool.py): stores past the wrap, stratified proportional sampling
+    with recorded `random.random()` uniforms, importance weights, priority updates (zeros, duplicates, new maxima) -- with
+    float64 priorities, i.e. the arithmetic of the NumPy < 2 the reference pins (see HipPerOffPolicyBuffer)."""
+    import random
+    from xuance.common.memory_tools import PerOffPolicyBuffer
+    rng = np.random.default_rng(41)
+    n_envs, n_size, D, bs, alpha = 4, 6, 3, 8, 0.6
+    k = bs // n_envs
+    buf = PerOffPolicyBuffer(sp.Box(-np.inf, np.inf, (D,), np.float32), sp.Discrete(3), None, n_envs, n_envs * n_size, bs, alpha)
+    out, ev = {}, 0
+
+    def store():
+        nonlocal ev
+        d = dict(obs=rng.standard_normal((n_envs, D)).astype(np.float32), acts=rng.integers(0, 3, n_envs).astype(np.float32),
+                 rews=rng.standard_normal(n_envs).astype(np.float32), terminals=(rng.random(n_envs) < 0.2),
+                 next_obs=rng.standard_normal((n_envs, D)).astype(np.float32))
+        buf.store(d["obs"], d["acts"], d["rews"], d["terminals"], d["next_obs"])
+        out.update(flat(f"e{ev}/store", d)); ev += 1
+
+    def sample_update(beta):
+        nonlocal ev
+        random.seed(100 + ev)
+        uni = np.array([[random.random() for _ in range(k)] for _ in range(n_envs)])
+        random.seed(100 + ev)
+        smp = buf.sample(beta)
+        pr = np.abs(rng.standard_normal((n_envs, k))).astype(np.float32).astype(np.float64) * 2.0
+        pr[0, 0] = 0.0                                              # the `priority == 0 -> 1e-8` branch (:590-591)
+        pr[1, :] = pr[1, 0]
+        buf.update_priorities(smp["step_choices"], pr.reshape(-1))
+        out.update(flat(f"e{ev}/sample", dict(beta=np.float64(beta), uniforms=uni, step_choices=smp["step_choices"],
+                                              weights=smp["weights"], obs=smp["obs"], rewards=smp["rewards"],
+                                              priorities=pr, size=np.int64(buf.size))))
+        ev += 1
+    for _ in range(4):
+        store()
+    sample_update(0.4)
+    for _ in range(5):                                              # wraps: ptr passes n_size
+        store()
+    sample_update(0.5); sample_update(0.7)
+    store()
+    sample_update(1.0)
+    out["sum_tree"] = np.array([t._value for t in buf._it_sum], np.float64)
+    out["min_tree"] = np.array([t._value for t in buf._it_min], np.float64)
+    out["max_priority"] = np.asarray(buf._max_priority, np.float64)
+    out["meta"] = np.array([n_envs, n_size, D, bs, ev])
+    out["alpha"] = np.float64(alpha)
+    np.savez_compressed(os.path.join(OUT, "per_buffer.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_onpolicy_buffer()
@@ -604,5 +654,6 @@ if __name__ == "__main__":
     golden_qmix_rnn(True, fixed=True)
     golden_marl_rnn_buffer()
     golden_checkpoint()
+    golden_per_buffer()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

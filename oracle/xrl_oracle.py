@@ -742,6 +742,78 @@ def qmix_forward_backward(sd, batch, cfg, act="relu", group="shared"):
     return info, grads
 
 
+class PerBufferOracle:
+    """PerOffPolicyBuffer's priority machinery (memory_tools.py:471-598; SumSegmentTree / MinSegmentTree,
+    segtree_tool.py:24-230) with float64 trees [n_envs][2*capacity]; the transition arrays themselves are
+    OffPolicyBufferOracle's."""
+
+    def __init__(self, n_envs, n_size, batch_size, alpha):
+        self.n_envs, self.n_size, self.k, self.alpha = n_envs, n_size, batch_size // n_envs, float(alpha)
+        cap = 1
+        while cap < n_size:
+            cap *= 2
+        self.cap = cap
+        self.sum = np.zeros((n_envs, 2 * cap), np.float64)
+        self.min = np.full((n_envs, 2 * cap), np.inf, np.float64)
+        self.max_priority = np.ones(n_envs, np.float64)
+        self.ptr = self.size = 0
+
+    def _set(self, e, idx, val):                               # segtree_tool.py:98-113
+        i = idx + self.cap
+        self.sum[e, i] = self.min[e, i] = val
+        i //= 2
+        while i >= 1:
+            self.sum[e, i] = self.sum[e, 2 * i] + self.sum[e, 2 * i + 1]
+            self.min[e, i] = min(self.min[e, 2 * i], self.min[e, 2 * i + 1])
+            i //= 2
+
+    def _reduce(self, e, start, end, node, ns, ne):            # :41-63
+        if start == ns and end == ne:
+            return self.sum[e, node]
+        mid = (ns + ne) // 2
+        if end <= mid:
+            return self._reduce(e, start, end, 2 * node, ns, mid)
+        if mid + 1 <= start:
+            return self._reduce(e, start, end, 2 * node + 1, mid + 1, ne)
+        return self._reduce(e, start, mid, 2 * node, ns, mid) + self._reduce(e, mid + 1, end, 2 * node + 1, mid + 1, ne)
+
+    def store(self):                                           # memory_tools.py:536-541
+        for e in range(self.n_envs):
+            self._set(e, self.ptr, self.max_priority[e] ** self.alpha)
+        self.ptr = (self.ptr + 1) % self.n_size
+        self.size = min(self.size + 1, self.n_size)
+
+    def sample(self, beta, uniforms):                          # :499-507, 542-565
+        steps = np.zeros((self.n_envs, self.k), np.int64)
+        weights = np.zeros((self.n_envs, self.k), np.float64)
+        for e in range(self.n_envs):
+            p_total = self._reduce(e, 0, self.size - 2, 1, 0, self.cap - 1)        # sum(0, size - 1), end exclusive
+            every = p_total / self.k
+            p_min = self.min[e, 1] / self.sum[e, 1]
+            max_weight = p_min * self.size ** (-beta)
+            for i in range(self.k):
+                mass = uniforms[e, i] * every + i * every
+                idx = 1
+                while idx < self.cap:                          # find_prefixsum_idx (segtree_tool.py:160-170)
+                    if self.sum[e, 2 * idx] > mass:
+                        idx = 2 * idx
+                    else:
+                        mass -= self.sum[e, 2 * idx]
+                        idx = 2 * idx + 1
+                steps[e, i] = idx - self.cap
+                weights[e, i] = (self.sum[e, idx] / self.sum[e, 1]) * self.size ** (-beta) / max_weight
+        return steps, weights
+
+    def update_priorities(self, idxes, priorities):            # :586-597
+        pr = np.asarray(priorities, np.float64).reshape(self.n_envs, self.k)
+        for e in range(self.n_envs):
+            for idx, p in zip(idxes[e], pr[e]):
+                if p == 0:
+                    p += 1e-8
+                self._set(e, int(idx), p ** self.alpha)
+                self.max_priority[e] = max(self.max_priority[e], p)
+
+
 class EpisodeBufferOracle:
     """MARL_OffPolicyBuffer_RNN (memory_tools_marl.py:770-996) with the agents stacked on one axis:
     obs [rows, T+1, N, O], actions/rewards/terminals/agent_mask [rows, T, N], avail_actions [rows, T+1, N, A],

@@ -346,3 +346,33 @@ def test_qmix_rnn_agents_train_at_3m_shape():
     assert np.isfinite(info["loss_Q"]) and np.isfinite(info["predictQ"])
     assert torch.equal(agent.model.params.view(agent.model.w_hh), a0)              # iql_learner.py:49,58: agents detached
     assert not torch.equal(agent.model.params.view("eval_Qtot.hyper_b_1.weight"), m0)
+
+
+def test_perdqn_agent_loop():
+    """PerDQN_Agent (perdqn_agent.py:12-96): prioritized sampling / update / priority refresh every training step on the
+    Atari-shaped provider; priorities of sampled transitions become |td|^alpha, unsampled ones keep max_priority^alpha."""
+    import random
+    from xuance_amd.agents import PerDQN_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    n = 16
+    cfg = Namespace(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                    q_hidden_size=[512], activation="relu", seed=1, parallels=n, running_steps=10 ** 6, buffer_size=n * 32,
+                    batch_size=32, learning_rate=1e-4, gamma=0.99, start_greedy=0.5, end_greedy=0.05, decay_step_greedy=10 ** 6,
+                    sync_frequency=500, training_frequency=n, start_training=n * 4, use_grad_clip=False, grad_clip_norm=0.5,
+                    use_obsnorm=False, use_rewnorm=False, PER_alpha=0.6, PER_beta0=0.4, use_hip_graph=False,
+                    distributed_training=False, device="cuda", model_dir="/tmp/x")
+    agent = PerDQN_Agent(cfg, SyntheticAtariVecEnv(n, seed=2))
+    info = agent.train(12)
+    mem = agent.memory
+    assert agent.learner.iterations == 7 and np.isfinite(info["Qloss"])
+    assert abs(agent.PER_beta - (0.4 + 7 * 0.6 / 12)) < 1e-12
+    leaves = mem.it_sum[:, mem.capacity:mem.capacity + mem.size].cpu().numpy()
+    mp = mem.max_priority.cpu().numpy()
+    assert (leaves > 0).all() and (mp >= 1.0).all()
+    # root == sum of leaves, min tree root == min of leaves (float64, same association order per level is not required here)
+    assert_close(mem.it_sum[:, 1].cpu().numpy(), leaves.sum(1), 1e-12, "sum tree root")
+    assert_close(mem.it_min[:, 1].cpu().numpy(), leaves.min(1), 0.0, "min tree root")
+    # the most recently stored step has not been sampled-and-updated after its store only if it still carries max_priority^alpha
+    last = leaves[:, (mem.ptr - 1) % mem.n_size]
+    assert ((np.abs(last - mp ** 0.6) < 1e-12) | (last != mp ** 0.6)).all()

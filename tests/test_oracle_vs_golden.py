@@ -273,3 +273,23 @@ def test_marl_rnn_buffer(oracle):
         if ref.ndim >= 3 and k not in ("state",):
             ref = np.moveaxis(ref, 1, 2)                       # fixture [B, N, slots, ...] -> [B, slots, N, ...]
         assert np.array_equal(smp[k], ref), k
+
+
+def test_per_buffer(oracle):
+    """Prioritized replay: the oracle's trees / sampling / priority updates against PerOffPolicyBuffer's own
+    run with recorded uniforms (tests/golden/per_buffer.npz)."""
+    g = load_golden("per_buffer")
+    n_envs, n_size, D, bs, n_events = (int(x) for x in g["meta"])
+    per = oracle.PerBufferOracle(n_envs, n_size, bs, float(g["alpha"]))
+    for ev in range(n_events):
+        if f"e{ev}/store/obs" in g:
+            per.store()
+        else:
+            d = sub(g, f"e{ev}/sample")
+            assert per.size == int(d["size"])
+            steps, w = per.sample(float(d["beta"]), d["uniforms"])
+            assert np.array_equal(steps, d["step_choices"])
+            assert_close(w, d["weights"], 1e-12, "weights")
+            per.update_priorities(d["step_choices"], d["priorities"])
+    assert_close(per.sum, g["sum_tree"], 1e-14, "sum tree")
+    assert np.array_equal(per.min, g["min_tree"]) and np.array_equal(per.max_priority, g["max_priority"])

@@ -188,6 +188,10 @@ _SIGS = {
     "xrl_episode_store_step": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_episode_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_episode_gather": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
+    "xrl_per_store": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_void_p],
+    "xrl_per_sample": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                       c_void_p, c_void_p],
+    "xrl_per_update_priorities": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_double, c_int, c_int, c_int, c_void_p],
     "xrl_gru_forward": [C.POINTER(GruFwd), c_void_p],
     "xrl_gru_backward": [C.POINTER(GruBwd), c_void_p],
     "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],

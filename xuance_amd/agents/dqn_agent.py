@@ -108,11 +108,7 @@ class DQN_Agent:
             self.memory.store(self.X.view((n,) + tuple(self.obs_shape)), self.act_f, env.reward, env.terminated,
                               self.Xn.view((n,) + tuple(self.obs_shape)))
             if self.current_step > self.start_training and self.current_step % self.training_frequency == 0:
-                if self.use_graph_updates:
-                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed)
-                else:
-                    for _e in range(self.n_epochs):
-                        info = self.learner.update(**self.memory.sample())
+                info = self._train_epochs(train_steps)
             self.current_step += n
             self._update_explore_factor()
         if hasattr(env, "episode_stats"):
@@ -121,5 +117,43 @@ class DQN_Agent:
         info["epsilon"] = self.e_greedy
         return info
 
+    def _train_epochs(self, train_steps):
+        if self.use_graph_updates:
+            return self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed)
+        info = {}
+        for _e in range(self.n_epochs):
+            info = self.learner.update(**self.memory.sample())
+        return info
+
     def finish(self):
         self.envs.close()
+
+
+class PerDQN_Agent(DQN_Agent):
+    """DQN with prioritized replay (xuance/torch/agents/qlearning_family/perdqn_agent.py:12-96): HipPerOffPolicyBuffer,
+    PerDQN_Learner, `sample(beta) -> update -> update_priorities` per epoch (:43-49) and the linear beta schedule
+    PER_beta += (1 - PER_beta0) / train_steps after every training step (:72).  |td| never leaves the device."""
+
+    def __init__(self, config, envs, callback=None):
+        self.PER_beta0 = self.PER_beta = float(config.PER_beta0)
+        super().__init__(config, envs, callback)
+
+    def _build_memory(self):
+        from ..memory import HipPerOffPolicyBuffer
+        c = self.config
+        return HipPerOffPolicyBuffer(self.observation_space, self.action_space, None, self.n_envs, c.buffer_size,
+                                     c.batch_size, alpha=c.PER_alpha, device=self.device,
+                                     obs_dtype=torch.uint8 if self.atari else torch.float32)
+
+    def _build_learner(self, *args):
+        from ..learners.dqn_learner import PerDQN_Learner
+        return PerDQN_Learner(*args)
+
+    def _train_epochs(self, train_steps):
+        info = {}
+        for _e in range(self.n_epochs):
+            samples = self.memory.sample(self.PER_beta)
+            td, info = self.learner.update(**samples)
+            self.memory.update_priorities(samples["step_choices"], td)
+        self.PER_beta += (1 - self.PER_beta0) / train_steps
+        return info

@@ -153,6 +153,18 @@ class DuelDQN_Learner(DQN_Learner):
         super().__init__(config, model, callback)
 
 
+class PerDQN_Learner(DQN_Learner):
+    """DQN with prioritized replay (xuance/torch/learners/qlearning_family/perdqn_learner.py:13-92): DQN_Learner's update
+    (the importance weights of the sample are not used by the reference's loss, :49), returning (|td_error|, info) so that
+    the agent can call memory.update_priorities (perdqn_agent.py:46-48).  |td| stays on the device."""
+
+    def update(self, **samples):
+        info = super().update(**samples)
+        M = int(samples["batch_size"]) if "batch_size" in samples else self.diag.numel() // 2
+        td_abs = (self.diag[M:2 * M] - self.diag[:M]).abs()      # td_error = targetQ - predictQ (:48)
+        return td_abs, info
+
+
 class DDQN_Learner(DQN_Learner):
     """Double DQN (xuance/torch/learners/qlearning_family/ddqn_learner.py:13-75): identical to DQN_Learner except that the
     target action is argmax_a Q_eval(s', a) (`targetA = self.model(next_batch).actions`, :40-44); xrl_dqn_td implements

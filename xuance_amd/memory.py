@@ -295,3 +295,70 @@ class HipOffPolicyBuffer_Atari(HipOffPolicyBuffer):
     def __init__(self, *args, **kwargs):
         kwargs["obs_dtype"] = torch.uint8
         super().__init__(*args, **kwargs)
+
+
+class HipPerOffPolicyBuffer(HipOffPolicyBuffer):
+    """Prioritized replay, drop-in for PerOffPolicyBuffer (memory_tools.py:471-598): the transition ring of
+    HipOffPolicyBuffer plus one sum / min segment tree per env in HBM (csrc/per.hip).  `sample(beta)` draws
+    batch_size / n_envs stratified transitions per env; its uniforms are Python's `random.random()` in the reference's
+    order (one small H2D copy), so a seeded run picks the same transitions as the reference; `update_priorities` keeps the
+    reference's in-order semantics per env.  Priorities are float64 (what the reference computes under the NumPy < 2 it
+    pins; under NumPy >= 2 its float32 |td| would stay float32 through `**`)."""
+
+    def __init__(self, observation_space, action_space, auxiliary_shape, n_envs, buffer_size, batch_size, alpha=0.6,
+                 device="cuda", obs_dtype=torch.float32):
+        super().__init__(observation_space, action_space, auxiliary_shape, n_envs, buffer_size, batch_size, device, obs_dtype)
+        assert batch_size % n_envs == 0, "PerOffPolicyBuffer draws batch_size / n_envs transitions per env"
+        self._alpha = float(alpha)
+        self.capacity = 1
+        while self.capacity < self.n_size:                      # :499-501
+            self.capacity *= 2
+        self.per_env = batch_size // n_envs
+        self._reset_trees()
+        k = self.per_env
+        self._uni = torch.zeros(n_envs, k, dtype=torch.float64, device=device)
+        self._uni_h = torch.zeros(n_envs, k, dtype=torch.float64)
+        if torch.cuda.is_available():
+            self._uni_h = self._uni_h.pin_memory()
+        self.step_choices = torch.zeros(n_envs, k, dtype=torch.int64, device=device)
+        self.weights = torch.zeros(n_envs, k, dtype=torch.float64, device=device)
+        self.flat_idx = torch.zeros(n_envs * k, dtype=torch.int64, device=device)
+
+    def _reset_trees(self):
+        dev = self.device
+        self.it_sum = torch.zeros(self.n_envs, 2 * self.capacity, dtype=torch.float64, device=dev)
+        self.it_min = torch.full((self.n_envs, 2 * self.capacity), float("inf"), dtype=torch.float64, device=dev)
+        self.max_priority = torch.ones(self.n_envs, dtype=torch.float64, device=dev)
+
+    def clear(self):
+        super().clear()
+        self._reset_trees()
+
+    def store(self, obs, acts, rews, terminals, next_obs):     # :528-541
+        ptr = self.ptr
+        super().store(obs, acts, rews, terminals, next_obs)
+        ops.per_store(self.it_sum, self.it_min, self.max_priority, ptr, self._alpha, self.n_envs, self.capacity)
+
+    def sample(self, beta, uniforms=None):                     # :542-584
+        import random
+        assert beta > 0
+        if uniforms is None:
+            for i in range(self.n_envs):                        # _sample_proportional's draws, env by env (:504-506)
+                for j in range(self.per_env):
+                    self._uni_h[i, j] = random.random()
+            self._uni.copy_(self._uni_h, non_blocking=True)
+        else:
+            self._uni.copy_(torch.as_tensor(np.asarray(uniforms), dtype=torch.float64).reshape(self._uni.shape))
+        ops.per_sample(self.it_sum, self.it_min, self._uni, self.size, beta, self.n_envs, self.n_size, self.capacity,
+                       self.per_env, self.step_choices, self.weights, self.flat_idx)
+        out = super().sample(indexes=self.flat_idx)
+        out.update(weights=self.weights, step_choices=self.step_choices, batch_size=self.batch_size)
+        return out
+
+    def update_priorities(self, idxes, priorities):            # :586-597
+        idx = torch.as_tensor(np.asarray(idxes) if not isinstance(idxes, torch.Tensor) else idxes)
+        idx = idx.to(device=self.device, dtype=torch.int64).reshape(self.n_envs, self.per_env).contiguous()
+        pr = torch.as_tensor(np.asarray(priorities) if not isinstance(priorities, torch.Tensor) else priorities)
+        pr = pr.to(device=self.device, dtype=torch.float32).reshape(self.n_envs, self.per_env).contiguous()
+        ops.per_update_priorities(self.it_sum, self.it_min, self.max_priority, idx, pr, self._alpha, self.n_envs,
+                                  self.capacity, self.per_env)

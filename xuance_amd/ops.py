@@ -368,6 +368,21 @@ def episode_gather(items, idx, B):
     call("xrl_episode_gather", _ep_fields(items), len(items), ptr(_chk(idx, torch.int64)), int(B), stream_ptr())
 
 
+def per_store(sum_tree, min_tree, max_priority, ptr_, alpha, n_envs, capacity):
+    call("xrl_per_store", ptr(sum_tree), ptr(min_tree), ptr(max_priority), int(ptr_), float(alpha), int(n_envs), int(capacity),
+         stream_ptr())
+
+
+def per_sample(sum_tree, min_tree, uniforms, size, beta, n_envs, n_size, capacity, per_env, step_choices, weights, flat_idx=None):
+    call("xrl_per_sample", ptr(sum_tree), ptr(min_tree), ptr(uniforms), int(size), float(beta), int(n_envs), int(n_size),
+         int(capacity), int(per_env), ptr(step_choices), ptr(weights), ptr(flat_idx), stream_ptr())
+
+
+def per_update_priorities(sum_tree, min_tree, max_priority, idxes, priorities, alpha, n_envs, capacity, per_env):
+    call("xrl_per_update_priorities", ptr(sum_tree), ptr(min_tree), ptr(max_priority), ptr(idxes), ptr(priorities),
+         float(alpha), int(n_envs), int(capacity), int(per_env), stream_ptr())
+
+
 def gru_forward(**kw):
     call("xrl_gru_forward", C.byref(_struct(GruFwd, kw)), stream_ptr())
 
