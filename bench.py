@@ -41,9 +41,10 @@ def make_config(n_envs, horizon, world, rank):
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, FETCH_SIZE doubled
     per MI355X_MICROARCH.md); None if the summary is not there.  PMC counters cannot be read from inside the process."""
-    path = os.path.join(ROOT, "profiles", "r01_f_ppo_c2_pmc_hbm.json")
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ppo_c2_pmc_hbm.json")))      # latest committed pass
     try:
-        with open(path) as f:
+        with open(paths[-1]) as f:
             ks = json.load(f)["kernels"]
         for name, v in ks.items():                       # template instantiations carry their arguments in the name
             if name.startswith(kernel):
