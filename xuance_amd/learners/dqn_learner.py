@@ -43,8 +43,7 @@ class DQN_Learner(Learner):
         """self.X rows [0,M) = obs, rows [M,2M) = obs_next (already on the device)."""
         model, opt, A = self.model, self.optimizer, self.n_actions
         S = pick_n_split(M)
-        q_all = model.forward(self.X[:2 * M] if self.double_q else self.X[:M], M)    # evalQ (:39) [+ Q_eval(s')]
-        q_next = model.target(self.X[M:2 * M], M)                                    # targetQ (:40)
+        q_all, q_next = model.forward_pair(self.X, M, self.double_q)   # evalQ (:39) [+ Q_eval(s')], targetQ (:40): grouped
         d_q = model.d_out
         ops.dqn_td(q_eval=q_all, q_next=q_next, q_next_eval=q_all[M:] if self.double_q else None, actions=act,
                    rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A,

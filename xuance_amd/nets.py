@@ -458,6 +458,11 @@ class DeepQNet:
     def target(self, x, M, ldx=None):
         return self.target_plan.forward(x, self.obs_dim if ldx is None else ldx, M, flat=self.target_flat)
 
+    def forward_pair(self, X, M, double_q):
+        """Eval network on X[:M] (+ X[M:2M] under double-Q) and target network on X[M:2M] as grouped launches."""
+        return Plan.forward_many([(self.plan, X, self.obs_dim, 2 * M if double_q else M, None),
+                                  (self.target_plan, X[M:], self.obs_dim, M, self.target_flat)])
+
     @property
     def d_out(self):
         return self.plan.dacts[len(self.plan.widths) - 1]
@@ -687,6 +692,30 @@ class ConvStack:
         ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, rows, OH * OW, F, F)
         return ws.feat
 
+    def forward_dual(self, x, M, Re, ws, flat_t):
+        """Eval network on frames [0, Re) and target network (parameters `flat_t`) on frames [M, 2M) of x [2M, H*W*C] in
+        ONE pass: one im2col per layer over all frames (the first layer's columns of the next_obs frames are shared by the
+        target and, under double-Q, the eval network) and one grouped GEMM launch per layer (eval rows | target rows).
+        ws rows: frames [0, Re) eval, [Re, Re+M) target; returns ws.feat.  Re = M (DQN) or 2M (double-Q)."""
+        P = self.params
+        tot = Re + M
+        for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            K, ohw = C * k * k, OH * OW
+            n = self.names[i]
+            if i == 0:
+                ops.im2col_nhwc(x, ws.col[0], 2 * M, H, W, C, k, s, p)
+                a_e, a_t = ws.col[0].data_ptr(), ws.col[0].data_ptr() + 4 * M * ohw * K
+            else:
+                ops.im2col_nhwc(ws.y[i - 1], ws.col[i], tot, H, W, C, k, s, p)
+                a_e, a_t = ws.col[i].data_ptr(), ws.col[i].data_ptr() + 4 * Re * ohw * K
+            y_e, y_t = ws.y[i].data_ptr(), ws.y[i].data_ptr() + 4 * Re * ohw * F
+            ops.linear_fwd([ops.gemm_desc(a_e, P.ptr(n + ".weight"), y_e, Re * ohw, F, K, K, K, F, bias=P.ptr(n + ".bias"), act="relu"),
+                            ops.gemm_desc(a_t, P.ptr(n + ".weight", flat_t), y_t, M * ohw, F, K, K, K, F,
+                                          bias=P.ptr(n + ".bias", flat_t), act="relu")])
+        H, W, C, k, s, p, OH, OW, F = self.geo[-1]
+        ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, tot, OH * OW, F, F)
+        return ws.feat
+
     N_SPLIT = 32                                              # row chunks of a conv layer's weight gradient (parallelism)
 
     def backward(self, dfeat, rows, ws, slabs, n_split, flat=None):
@@ -779,6 +808,18 @@ class DeepQCNN:
         ws = self.conv.workspace("target", M, False)
         self._tfeat = self.conv.forward(x_u8.reshape(M, -1), M, ws, flat=self.target_flat)
         return self.target_plan.forward(self._tfeat, self.filters[-1], M, flat=self.target_flat)
+
+    def forward_pair(self, X, M, double_q):
+        """One update's three network passes (dqn_learner.py:39-40, ddqn_learner.py:40): eval Q of obs = X[:M] (kept for
+        backward), target Q of next_obs = X[M:2M] and, under double-Q, eval Q of next_obs -- as one im2col + one grouped
+        GEMM launch per layer.  Returns (Q_eval [Re, A], Q_target [M, A])."""
+        Re, F = (2 * M if double_q else M), self.filters[-1]
+        ws = self.conv.workspace("dual", 3 * M, True)
+        self._ws = ws
+        feat = self.conv.forward_dual(X[:2 * M].reshape(2 * M, -1), M, Re, ws, self.target_flat)
+        self._feat_in = feat
+        q_e, q_t = Plan.forward_many([(self.plan, feat, F, Re, None), (self.target_plan, feat[Re:], F, M, self.target_flat)])
+        return q_e, q_t
 
     @property
     def d_out(self):
