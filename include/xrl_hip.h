@@ -97,6 +97,10 @@ typedef struct {
 
 /* nn.Linear (+activation) forward, mlp_block (rl_models/modules/layers.py:16-33):
  *   C[M,N] = act(A[M,K] . B[N,K]^T + bias[N])          A = input rows, B = weight [out,in] */
+/*   Split-K (optional, per group): `aux` = caller-owned workspace of ldaux * M * N floats, ldaux = number of K ranges
+ *   (2..64).  Each range is reduced by its own workgroups into its workspace slab and an epilogue launch adds the slabs
+ *   in order and applies bias + activation: for layers with few output tiles and a long reduction (the 3 200 x 64 x 512
+ *   convolution GEMMs of the Atari Q-network would otherwise occupy 50 of 256 CUs). */
 int xrl_linear_fwd(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream);
 /* backward w.r.t. the layer input (autograd of the same block):
  *   C[M,N] = (A[M,K] . B[K,N]) * act'(aux[M,N])        A = dY, B = weight [out=K,in=N] */

@@ -10,23 +10,53 @@
 
 namespace xrl {
 
+// One workgroup per group of output positions (b, oh, ow): the position is decomposed once per row (scalar), each thread
+// then handles the column entries j = (c, kh, kw) of that row with 32-bit arithmetic and coalesced stores.  (The first
+// version decomposed a flat 64-bit element index per thread -- five 64-bit divisions per element -- and ran at 0.75 TB/s.)
 template <typename T>
 __global__ void __launch_bounds__(256) im2col_nhwc_kernel(const T* __restrict__ x, float* __restrict__ col, int B, int H, int W,
                                                           int C, int k, int s, int p, int OH, int OW, int scale255) {
-    const int K = C * k * k;
-    const int64_t total = (int64_t)B * OH * OW * K;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i % K);
-        const int64_t row = i / K;
-        const int ow = (int)(row % OW), oh = (int)((row / OW) % OH), b = (int)(row / ((int64_t)OW * OH));
-        const int kw = j % k, kh = (j / k) % k, c = j / (k * k);
+    const int K = C * k * k, kk = k * k;
+    const int rows = B * OH * OW;
+    constexpr int RPB = 4;                                               // rows per workgroup
+    if (sizeof(T) == 1 && C == 4 && kk == 64) {
+        // Atari first layer (uint8, 4 stacked frames, 8x8 kernel): one wave per output position, lane = (kh, kw) loads
+        // the 4 channels of its pixel with ONE 32-bit load (each patch row is 32 contiguous bytes) and writes them to the
+        // four channel planes of the column row: every store instruction of the wave covers 256 contiguous bytes.
+        const int row = blockIdx.x * RPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (row >= rows) return;
+        const int ow = row % OW, t = row / OW, oh = t % OH, b = t / OH;
+        const int kh = lane >> 3, kw = lane & 7;
         const int ih = oh * s - p + kh, iw = ow * s - p + kw;
-        float v = 0.f;
-        if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
-            v = (float)x[(((int64_t)b * H + ih) * W + iw) * C + c];
-            if (scale255) v = v / 255.0f;                                // observations / 255.0 (cnn.py:45)
+        uint32_t px = 0;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+            px = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(x) + (((size_t)b * H + ih) * W + iw) * 4);
+        float* out = col + (size_t)row * K + lane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = (float)((px >> (8 * c)) & 0xffu);
+            if (scale255) v = v / 255.0f;
+            out[c * 64] = v;
         }
-        col[i] = v;
+        return;
+    }
+    for (int r = 0; r < RPB; ++r) {
+        const int row = blockIdx.x * RPB + r;
+        if (row >= rows) return;
+        const int ow = row % OW, t = row / OW, oh = t % OH, b = t / OH;
+        const int ih0 = oh * s - p, iw0 = ow * s - p;
+        const T* xb = x + (size_t)b * H * W * C;
+        float* out = col + (size_t)row * K;
+        for (int j = threadIdx.x; j < K; j += 256) {
+            const int c = j / kk, rem = j - c * kk, kh = rem / k, kw = rem - kh * k;
+            const int ih = ih0 + kh, iw = iw0 + kw;
+            float v = 0.f;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+                v = (float)xb[((size_t)ih * W + iw) * C + c];
+                if (scale255) v = v / 255.0f;                            // observations / 255.0 (cnn.py:45)
+            }
+            out[j] = v;
+        }
     }
 }
 
@@ -121,12 +151,13 @@ extern "C" int xrl_im2col_nhwc(const void* x, int x_is_u8, float* col, int B, in
     XRL_CHECK_ARG(x && col && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && s > 0 && p >= 0);
     const int OH = (H + 2 * p - k) / s + 1, OW = (W + 2 * p - k) / s + 1;
     XRL_CHECK_ARG(OH > 0 && OW > 0);
-    const int64_t total = (int64_t)B * OH * OW * C * k * k;
+    XRL_CHECK_ARG((int64_t)B * OH * OW < ((int64_t)1 << 31));
+    const unsigned grid = (unsigned)(((int64_t)B * OH * OW + 3) / 4);                 // 4 output positions per workgroup
     if (x_is_u8)
-        hipLaunchKernelGGL(im2col_nhwc_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+        hipLaunchKernelGGL(im2col_nhwc_kernel<uint8_t>, dim3(grid), dim3(256), 0, as_stream(stream),
                            reinterpret_cast<const uint8_t*>(x), col, B, H, W, C, k, s, p, OH, OW, 1);
     else
-        hipLaunchKernelGGL(im2col_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+        hipLaunchKernelGGL(im2col_nhwc_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
                            reinterpret_cast<const float*>(x), col, B, H, W, C, k, s, p, OH, OW, 0);
     XRL_CHECK_LAUNCH();
     return XRL_OK;

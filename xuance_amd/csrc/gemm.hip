@@ -120,12 +120,23 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // reduction range (split over the batch for the weight gradient)
+    // reduction range (split over the batch for the weight gradient; split-K of a forward layer, see xrl_linear_fwd)
     int kbeg = 0, kend = Kred;
     if (MODE == MODE_TN) {
         const int chunk = (Kred + p.n_split - 1) / p.n_split;
         kbeg = blockIdx.y * chunk;
         kend = min(Kred, kbeg + chunk);
+    }
+    const bool splitk = MODE == MODE_NT && g.aux != nullptr && g.ldaux > 1;
+    if (MODE == MODE_NT) {
+        if (splitk) {
+            if ((int)blockIdx.y >= g.ldaux) return;
+            const int chunk = ((Kred + g.ldaux - 1) / g.ldaux + BK - 1) / BK * BK;
+            kbeg = blockIdx.y * chunk;
+            kend = min(Kred, kbeg + chunk);
+        } else if (blockIdx.y > 0) {
+            return;
+        }
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -187,6 +198,15 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int col = n0 + wn * 32 + li;
     if (col >= No) return;
+    if (splitk) {                                  // raw partial sums of this K range; bias / activation in the epilogue
+        float* ws = const_cast<float*>(g.aux) + (size_t)blockIdx.y * Mo * No;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < Mo) ws[(size_t)row * No + col] = acc[r];
+        }
+        return;
+    }
     float bias = 0.f;
     if (MODE == MODE_NT && g.bias) bias = g.bias[col];
     if (MODE == MODE_NT) {
@@ -221,6 +241,22 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     }
 }
 
+// C[m, n] = act(sum_s ws[s][m][n] + bias[n]) of the split-K groups of a forward launch (fixed summation order)
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(GemmBatch p) {
+    const xrl_gemm_t& g = p.g[blockIdx.y];
+    if (!(g.aux && g.ldaux > 1)) return;
+    const int64_t total = (int64_t)g.M * g.N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / g.N), n = (int)(i - (int64_t)m * g.N);
+        float s = g.aux[i];
+        for (int q = 1; q < g.ldaux; ++q) s += g.aux[(size_t)q * total + i];
+        const float z = s + (g.bias ? g.bias[n] : 0.f);
+        float y = z;
+        XRL_ACT_DISPATCH(g.act, y = act_apply_c<ACT>(z);)
+        g.C[(size_t)m * g.ldc + n] = y;
+    }
+}
+
 // ---- skinny layers -------------------------------------------------------------------------------------------------
 // A layer with a handful of outputs and a long reduction (the 512 -> n_actions output layer of the Atari Q head on a
 // batch of 32..96 rows) is ONE 64x64 tile for the kernel above: a single workgroup walking K = 512 in 16 dependent
@@ -235,12 +271,28 @@ __global__ void __launch_bounds__(64) skinny_fwd_kernel(GemmBatch p) {
     float acc[SKINNY_N];
 #pragma unroll
     for (int n = 0; n < SKINNY_N; ++n) acc[n] = 0.f;
-    const float* a = g.A + (size_t)m * g.lda;
-    for (int k = lane; k < g.K; k += 64) {
+    const float* __restrict__ a = g.A + (size_t)m * g.lda;
+    const float* __restrict__ B = g.B;
+    const int N = g.N;
+    int k = lane;
+    for (; k + 64 * 3 < g.K; k += 64 * 4) {              // 4 k-steps: every load issued before the first FMA
+        float av[4], bv[4][SKINNY_N];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = a[k + 64 * u];
+#pragma unroll
+            for (int n = 0; n < SKINNY_N; ++n) bv[u][n] = n < N ? B[(size_t)n * g.ldb + k + 64 * u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int n = 0; n < SKINNY_N; ++n) acc[n] = fmaf(av[u], bv[u][n], acc[n]);
+    }
+    for (; k < g.K; k += 64) {
         const float av = a[k];
 #pragma unroll
         for (int n = 0; n < SKINNY_N; ++n)
-            if (n < g.N) acc[n] = fmaf(av, g.B[(size_t)n * g.ldb + k], acc[n]);
+            if (n < N) acc[n] = fmaf(av, B[(size_t)n * g.ldb + k], acc[n]);
     }
 #pragma unroll
     for (int n = 0; n < SKINNY_N; ++n) {
@@ -271,6 +323,47 @@ __global__ void __launch_bounds__(256) skinny_bwd_data_kernel(GemmBatch p) {
     }
 }
 
+// Data gradient of a few-row layer with a LONG reduction (dX[32, 64] = dY[32, 512] . W[512, 64] of the Atari head: one
+// 64x64 tile walking K = 512, measured 26 us): one wave per (row, 64 output columns), the row's dY values broadcast, W
+// rows read coalesced.
+__global__ void __launch_bounds__(256) rowwise_bwd_data_kernel(GemmBatch p) {
+    __shared__ float part[4][64];
+    const xrl_gemm_t& g = p.g[blockIdx.z];
+    const int m = blockIdx.x, lane = threadIdx.x & 63, kq = threadIdx.x >> 6;     // 4 waves split the reduction
+    const int c = blockIdx.y * 64 + lane;
+    const bool live = m < g.M && c < g.N;
+    const float* __restrict__ a = g.A + (size_t)(live ? m : 0) * g.lda;
+    const float* __restrict__ bcol = g.B + (live ? c : 0);
+    float s = 0.f;
+    constexpr int U = 8;                                   // loads of U steps are issued before the first FMA
+    int k = kq;
+    for (; k + 4 * (U - 1) < g.K; k += 4 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { av[u] = a[k + 4 * u]; bv[u] = bcol[(size_t)(k + 4 * u) * g.ldb]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) s = fmaf(av[u], bv[u], s);
+    }
+    for (; k < g.K; k += 4) s = fmaf(a[k], bcol[(size_t)k * g.ldb], s);
+    part[kq][lane] = s;
+    __syncthreads();
+    if (kq == 0 && live) {
+        float r = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (g.aux) {
+            const float y = g.aux[(size_t)m * g.ldaux + c];
+            XRL_ACT_DISPATCH(g.act, r *= act_grad_c<ACT>(y);)
+        }
+        g.C[(size_t)m * g.ldc + c] = r;
+    }
+}
+
+static bool all_rowwise_nn(int mode, const xrl_gemm_t* groups, int n_groups) {
+    if (mode != MODE_NN) return false;
+    for (int i = 0; i < n_groups; ++i)
+        if (!(groups[i].M <= 128 && groups[i].K >= 512)) return false;
+    return true;
+}
+
 static bool all_skinny(int mode, const xrl_gemm_t* groups, int n_groups) {
     for (int i = 0; i < n_groups; ++i) {
         const xrl_gemm_t& g = groups[i];
@@ -287,6 +380,20 @@ static int launch(int mode, const xrl_gemm_t* groups, int n_groups, int n_split,
                   xrl_stream_t stream) {
     XRL_CHECK_ARG(groups != nullptr && n_groups >= 1 && n_groups <= MAX_GROUPS);
     XRL_CHECK_ARG(n_split >= 1 && n_split <= 65535);
+    if (all_rowwise_nn(mode, groups, n_groups)) {
+        GemmBatch b;
+        b.n_groups = n_groups; b.n_split = 1; b.slab_stride = 0;
+        int maxM = 0, maxN = 0;
+        for (int i = 0; i < n_groups; ++i) {
+            XRL_CHECK_ARG(groups[i].A && groups[i].B && groups[i].C && groups[i].M > 0 && groups[i].N > 0 && groups[i].K > 0);
+            b.g[i] = groups[i];
+            maxM = groups[i].M > maxM ? groups[i].M : maxM;
+            maxN = groups[i].N > maxN ? groups[i].N : maxN;
+        }
+        hipLaunchKernelGGL(rowwise_bwd_data_kernel, dim3(maxM, (maxN + 63) / 64, n_groups), dim3(256), 0, as_stream(stream), b);
+        XRL_CHECK_LAUNCH();
+        return XRL_OK;
+    }
     if (all_skinny(mode, groups, n_groups)) {
         GemmBatch b;
         b.n_groups = n_groups; b.n_split = 1; b.slab_stride = 0;
@@ -319,7 +426,25 @@ static int launch(int mode, const xrl_gemm_t* groups, int n_groups, int n_split,
         const int tiles = ((Mo + BM - 1) / BM) * ((No + BN - 1) / BN);
         max_tiles = tiles > max_tiles ? tiles : max_tiles;
     }
-    dim3 grid(max_tiles, mode == MODE_TN ? n_split : 1, n_groups);
+    int ksplit = 1;                                // forward split-K: groups that carry a workspace in `aux`
+    int64_t max_el = 0;
+    if (mode == MODE_NT)
+        for (int i = 0; i < n_groups; ++i)
+            if (groups[i].aux && groups[i].ldaux > 1) {
+                XRL_CHECK_ARG(groups[i].ldaux <= 64);
+                ksplit = groups[i].ldaux > ksplit ? groups[i].ldaux : ksplit;
+                const int64_t el = (int64_t)groups[i].M * groups[i].N;
+                max_el = el > max_el ? el : max_el;
+            }
+    dim3 grid(max_tiles, mode == MODE_TN ? n_split : ksplit, n_groups);
+    if (mode == MODE_NT && ksplit > 1) {
+        hipLaunchKernelGGL(gemm_f32_kernel<MODE_NT>, grid, 256, 0, as_stream(stream), b);
+        unsigned nb = (unsigned)((max_el + 255) / 256);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(nb, n_groups), dim3(256), 0, as_stream(stream), b);
+        XRL_CHECK_LAUNCH();
+        return XRL_OK;
+    }
     if (mode == MODE_NT) hipLaunchKernelGGL(gemm_f32_kernel<MODE_NT>, grid, 256, 0, as_stream(stream), b);
     else if (mode == MODE_NN) hipLaunchKernelGGL(gemm_f32_kernel<MODE_NN>, grid, 256, 0, as_stream(stream), b);
     else hipLaunchKernelGGL(gemm_f32_kernel<MODE_TN>, grid, 256, 0, as_stream(stream), b);

@@ -657,6 +657,10 @@ class ConvStack:
                 if keep:
                     self.dy.append(torch.empty(M, F, device=dev))
                     self.dcol.append(torch.empty(M, K, device=dev))
+            # split-K workspaces of the forward GEMMs (layers whose row-tile count alone cannot fill the chip)
+            self.ksplit = [stack.ksplit_for(rows * OH * OW, F, C * k * k) for (H, W, C, k, s, p, OH, OW, F) in stack.geo]
+            self.skw = [torch.empty(2 * ks * rows * OH * OW * F, device=dev) if ks > 1 else None
+                        for ks, (H, W, C, k, s, p, OH, OW, F) in zip(self.ksplit, stack.geo)]
             self.feat = torch.empty(rows, stack.geo[-1][8], device=dev)
             self.arg = torch.zeros(rows, stack.geo[-1][8], dtype=torch.int32, device=dev) if keep else None
 
@@ -672,6 +676,15 @@ class ConvStack:
         self.n_feat = filters[-1]
         self._ws = {}
 
+    @staticmethod
+    def ksplit_for(M, N, K):
+        """K ranges of a conv layer's forward GEMM: ~1.5 workgroups per CU, at least 128 reduction steps each."""
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        ks = 1
+        while tiles * ks < 384 and K // (ks * 2) >= 128 and ks < 8:
+            ks *= 2
+        return ks
+
     def workspace(self, tag, rows, keep):
         ws = self._ws.get(tag)
         if ws is None or ws.rows < rows:
@@ -685,8 +698,11 @@ class ConvStack:
             M, K = rows * OH * OW, C * k * k
             ops.im2col_nhwc(x, ws.col[i], rows, H, W, C, k, s, p)
             n = self.names[i]
+            ks = self.ksplit_for(M, F, K)
+            ks = ks if (ks > 1 and ws.skw[i] is not None and ws.skw[i].numel() >= ks * M * F) else 1
             ops.linear_fwd([ops.gemm_desc(ws.col[i].data_ptr(), P.ptr(n + ".weight", flat), ws.y[i].data_ptr(), M, F, K, K, K, F,
-                                          bias=P.ptr(n + ".bias", flat), act="relu")])
+                                          bias=P.ptr(n + ".bias", flat), act="relu",
+                                          aux=ws.skw[i].data_ptr() if ks > 1 else None, ldaux=ks if ks > 1 else 0)])
             x = ws.y[i]
         H, W, C, k, s, p, OH, OW, F = self.geo[-1]
         ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, rows, OH * OW, F, F)
@@ -709,9 +725,14 @@ class ConvStack:
                 ops.im2col_nhwc(ws.y[i - 1], ws.col[i], tot, H, W, C, k, s, p)
                 a_e, a_t = ws.col[i].data_ptr(), ws.col[i].data_ptr() + 4 * Re * ohw * K
             y_e, y_t = ws.y[i].data_ptr(), ws.y[i].data_ptr() + 4 * Re * ohw * F
-            ops.linear_fwd([ops.gemm_desc(a_e, P.ptr(n + ".weight"), y_e, Re * ohw, F, K, K, K, F, bias=P.ptr(n + ".bias"), act="relu"),
+            ks = self.ksplit_for(tot * ohw, F, K)                 # both groups together fill the chip
+            ks = ks if (ks > 1 and ws.skw[i] is not None and ws.skw[i].numel() >= ks * tot * ohw * F) else 1
+            w_e = ws.skw[i].data_ptr() if ks > 1 else None
+            w_t = ws.skw[i].data_ptr() + 4 * ks * Re * ohw * F if ks > 1 else None
+            ops.linear_fwd([ops.gemm_desc(a_e, P.ptr(n + ".weight"), y_e, Re * ohw, F, K, K, K, F, bias=P.ptr(n + ".bias"), act="relu",
+                                          aux=w_e, ldaux=ks if ks > 1 else 0),
                             ops.gemm_desc(a_t, P.ptr(n + ".weight", flat_t), y_t, M * ohw, F, K, K, K, F,
-                                          bias=P.ptr(n + ".bias", flat_t), act="relu")])
+                                          bias=P.ptr(n + ".bias", flat_t), act="relu", aux=w_t, ldaux=ks if ks > 1 else 0)])
         H, W, C, k, s, p, OH, OW, F = self.geo[-1]
         ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, tot, OH * OW, F, F)
         return ws.feat
