@@ -171,6 +171,14 @@ class Plan:
             if dg:
                 ops.linear_bwd_data(dg)
 
+    def backward_grouped(self, x, ldx, M, slabs, n_split, flat=None, dx0=None):
+        """backward() with the data-gradient chain first and ALL weight gradients of the plan as one grouped launch
+        (chunks of 8 groups): same kernels per layer, fewer launches."""
+        wg = []
+        self.backward(x, ldx, M, slabs, n_split, flat=flat, dx0=dx0, defer_wgrad=wg)
+        for i in range(0, len(wg), 8):
+            ops.linear_bwd_weight(wg[i:i + 8], n_split, slabs.shape[1])
+
     def _act_of(self, lvl, off):
         for stage in self.stages:
             for L in stage:
@@ -300,7 +308,7 @@ class ActorCriticNet:
         return self.plan.dacts[len(self.plan.widths) - 1]
 
     def backward(self, x, M, slabs, n_split, ldx=None):
-        self.plan.backward(x, self.obs_dim if ldx is None else ldx, M, slabs, n_split)
+        self.plan.backward_grouped(x, self.obs_dim if ldx is None else ldx, M, slabs, n_split)
 
 
 class SequentialNet:
@@ -352,7 +360,7 @@ class SequentialNet:
         return self.plan.dacts[len(self.plan.widths) - 1]
 
     def backward(self, x, M, slabs, n_split, ldx=None, flat=None):
-        self.plan.backward(x, self.in_dim if ldx is None else ldx, M, slabs, n_split, flat)
+        self.plan.backward_grouped(x, self.in_dim if ldx is None else ldx, M, slabs, n_split, flat)
 
 
 def _seq_layers(prefix, in_dim, sizes, activation, last_act, lvl0, specs, order, stages, widths):
@@ -468,7 +476,7 @@ class DeepQNet:
         return self.plan.dacts[len(self.plan.widths) - 1]
 
     def backward(self, x, M, slabs, n_split):
-        self.plan.backward(x, self.obs_dim, M, slabs, n_split)
+        self.plan.backward_grouped(x, self.obs_dim, M, slabs, n_split)
 
 
 class MixingQNet:
@@ -849,5 +857,5 @@ class DeepQCNN:
     def backward(self, x_u8, M, slabs, n_split):
         if getattr(self, "_dfeat", None) is None or self._dfeat.shape[0] < M:
             self._dfeat = torch.zeros(M, self.filters[-1], device=self.params.device)
-        self.plan.backward(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat)
+        self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat)
         self.conv.backward(self._dfeat, M, self._ws, slabs, n_split)
