@@ -187,7 +187,11 @@ int xrl_adam_step_mirrored(float* params, float* grad, float* m, float* v, int64
 typedef struct {
     const int32_t* map[XRL_MAX_MIRRORS];
     float* dst[XRL_MAX_MIRRORS];
-    int32_t n, pad;
+    int32_t n;
+    int32_t target_every;   /* > 0 with `target`: hard target-network update inside the optimiser launch -- when the step this
+                             * launch performs is a multiple of target_every, target[i] <- new parameter
+                             * (copy_target(), dqn_learner.py:56-57, qmix_learner.py:105-106; same as xrl_sync_target) */
+    float* target;          /* NULL or [P] */
 } xrl_mirrors_t;
 int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
                           const double* sumsq_part, int n_part, double max_norm, const xrl_mirrors_t* mirrors,

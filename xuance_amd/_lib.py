@@ -159,7 +159,7 @@ class PpoFused(C.Structure):
 
 
 class Mirrors(C.Structure):
-    _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("pad", c_int32)]
+    _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("target_every", c_int32), ("target", c_void_p)]
 
 
 class MarlAct(C.Structure):

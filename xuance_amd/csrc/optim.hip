@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
 #pragma unroll
         for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
             if (q < mir.n) { const int j = mir.map[q][i]; if (j >= 0) mir.dst[q][j] = pn; }
+        if (mir.target && mir.target_every > 0 && step % mir.target_every == 0) mir.target[i] = pn;
     }
     // The last block to finish advances the device-resident state (every block has consumed the old state by
     // the time it takes its ticket; the next launch observes the new state across the kernel boundary).
@@ -252,6 +253,7 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
 #pragma unroll
         for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
             if (q < mir.n) { const int j = mir.map[q][i]; if (j >= 0) mir.dst[q][j] = pn; }
+        if (mir.target && mir.target_every > 0 && step % mir.target_every == 0) mir.target[i] = pn;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -20,7 +20,8 @@ class DQN_Learner(Learner):
         self.scheduler = LinearLRHandle(self.optimizer)
         dev = P.device
         self._cap = 0
-        self.sumsq = torch.zeros(128, dtype=torch.float64, device=dev)
+        self.sumsq = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self.opt_sync = torch.zeros(4 + (P.P + 255) // 256 + 8, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
 
     def _ensure(self, M):
@@ -49,14 +50,20 @@ class DQN_Learner(Learner):
                    rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A,
                    ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)))
         model.backward(self.X, M, self.slabs, S)
-        ops.grad_reduce(self.slabs, S, model.params.P, model.params.P, opt.grad, self.sumsq)
+        P, clip = model.params.P, (self.grad_clip_norm if self.use_grad_clip else 0.0)
+        if not (self.distributed_training and self.world_size > 1) and P % 4 == 0 and (P + 255) // 256 <= 512 and \
+                getattr(self.config, "use_fused_optimizer", True):
+            # slab reduction + norm + clip + Adam + LinearLR + periodic hard target update (:50-57) in ONE launch
+            ops.reduce_adam(self.slabs, S, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
+                            self.opt_sync, target=model.target_flat, target_every=self.sync_frequency)
+            return S
+        ops.grad_reduce(self.slabs, S, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_
             allreduce_mean_(opt.grad)
-            ops.grad_reduce(opt.grad, 1, model.params.P, model.params.P, opt.grad, self.sumsq)
-        ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state, self.sumsq,
-                      self.grad_clip_norm if self.use_grad_clip else 0.0)
-        ops.sync_target(model.params.flat, model.target_flat, model.params.P, opt.state, self.sync_frequency)   # :56-57
+            ops.grad_reduce(opt.grad, 1, P, P, opt.grad, self.sumsq)
+        ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip)
+        ops.sync_target(model.params.flat, model.target_flat, P, opt.state, self.sync_frequency)   # :56-57
         return S
 
     # ------------------------------------------------------------------ whole update phases straight from the HBM replay buffer

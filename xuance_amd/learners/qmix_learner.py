@@ -53,8 +53,9 @@ class QMIX_Learner(Learner):
         self.scheduler = LinearLRHandle(self.optimizer)
         dev = P.device
         self._cap = 0
-        self.sumsq = torch.zeros(128, dtype=torch.float64, device=dev)
+        self.sumsq = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.opt_sync = torch.zeros(4 + (P.P + 255) // 256 + 8, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
 
     def estimate_total_iterations(self):                        # marl_learner.py:36-47 (feed-forward branch)
         c = self.config
@@ -142,14 +143,25 @@ class QMIX_Learner(Learner):
         wg = []
         m.agent_plan.backward(self.X, m.obs_dim, R, self.slabs, S, defer_wgrad=wg)
         ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
-        ops.grad_reduce(self.slabs, S, m.params.P, m.params.P, opt.grad, self.sumsq)
+        self._finish_step(S)
+
+    def _finish_step(self, S):
+        """Slab reduction, gradient norm, clip, Adam, LinearLR and the periodic hard target update (qmix_learner.py:88-106):
+        ONE launch (xrl_reduce_adam with the target as a periodic mirror) on a single GPU; with several ranks the flat
+        gradient is all-reduced between the reduction and the optimiser launch."""
+        m, opt, P = self.model, self.optimizer, self.model.params.P
+        clip = self.grad_clip_norm if self.use_grad_clip else 0.0
+        if not (self.distributed_training and self.world_size > 1) and P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
+            ops.reduce_adam(self.slabs, S, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
+                            self.opt_sync, target=m.target_flat, target_every=self.sync_frequency)
+            return
+        ops.grad_reduce(self.slabs, S, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_
             allreduce_mean_(opt.grad)
-            ops.grad_reduce(opt.grad, 1, m.params.P, m.params.P, opt.grad, self.sumsq)
-        ops.adam_step(m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state, self.sumsq,
-                      self.grad_clip_norm if self.use_grad_clip else 0.0)                         # qmix_learner.py:88-96
-        ops.sync_target(m.params.flat, m.target_flat, m.params.P, opt.state, self.sync_frequency)  # :105-106
+            ops.grad_reduce(opt.grad, 1, P, P, opt.grad, self.sumsq)
+        ops.adam_step(m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip)
+        ops.sync_target(m.params.flat, m.target_flat, P, opt.state, self.sync_frequency)
 
     # ------------------------------------------------------------------ recurrent branch
     def _ensure_rnn(self, B, T):
@@ -168,6 +180,7 @@ class QMIX_Learner(Learner):
         self.seq["filled"] = torch.zeros(T, B, device=dev)
         m.seq_workspace(0, R, T1)
         m.seq_workspace(1, R, T1)
+        m.post_plans[0].dacts[len(m.post_plans[0].widths) - 1].zero_()
         m.mixer_plan.ensure(T1 * B)
         m.mixer_target_plan.ensure(T1 * B)
 
@@ -201,7 +214,7 @@ class QMIX_Learner(Learner):
         ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]
         post = m.post_plans[0]
         d_q = post.dacts[len(post.widths) - 1]
-        d_q[T * R:T1 * R].zero_()                                                              # Q of the last slot is not in the loss (:58)
+        # (rows of the last slot of d_q stay zero: Q of slot T is not in the loss (:58) and nothing ever writes them)
         ops.qmix_mix_td(q_eval=q_all, q_next_eval=q_all[R:] if self.double_q else None, q_next=q_tgt[R:],
                         actions=self.seq["actions"], avail_next=self.seq["avail"][1:] if self.use_actions_mask else None,
                         agent_mask=self.seq["agent_mask"], rewards=self.seq["rewards"], terminals=self.seq["terminals"],
@@ -214,14 +227,7 @@ class QMIX_Learner(Learner):
         ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
         if self.rnn_backprop_agents:
             m.agent_backward_seq(self.Xs, R, T1, self.slabs, S)
-        ops.grad_reduce(self.slabs, S, m.params.P, m.params.P, opt.grad, self.sumsq)
-        if self.distributed_training and self.world_size > 1:
-            from ..dist import allreduce_mean_
-            allreduce_mean_(opt.grad)
-            ops.grad_reduce(opt.grad, 1, m.params.P, m.params.P, opt.grad, self.sumsq)
-        ops.adam_step(m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state, self.sumsq,
-                      self.grad_clip_norm if self.use_grad_clip else 0.0)
-        ops.sync_target(m.params.flat, m.target_flat, m.params.P, opt.state, self.sync_frequency)
+        self._finish_step(S)
 
     def _info_rnn(self, B, T, sums):
         """loss = sum((td * filled)^2) / sum(filled) (qmix_learner.py:82-84); predictQ = mean over all B*T (:101)."""

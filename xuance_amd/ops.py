@@ -162,12 +162,16 @@ def adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, max_norm, mirror
          sumsq_part.numel(), float(max_norm if max_norm else 0.0), C.byref(mir), stream_ptr())
 
 
-def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, max_norm, mirrors, sync):
-    """grad_reduce + clip + Adam + mirrors in one launch (blocks meet at a counter barrier); same numbers."""
+def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, max_norm, mirrors, sync, target=None,
+                target_every=0):
+    """grad_reduce + clip + Adam + mirrors (+ the periodic hard target update) in one launch (blocks meet at a counter
+    barrier); same numbers."""
     mir = Mirrors()
     mir.n = len(mirrors)
     for q, (mp, dst) in enumerate(mirrors):
         mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
+    if target is not None and target_every > 0:
+        mir.target, mir.target_every = target.data_ptr(), int(target_every)
     call("xrl_reduce_adam", ptr(slabs), int(n_split), int(slab_stride), ptr(params), ptr(grad), ptr(m), ptr(v), int(P),
          ptr(state), ptr(sumsq_part), sumsq_part.numel(), float(max_norm if max_norm else 0.0), C.byref(mir), ptr(sync),
          stream_ptr())
