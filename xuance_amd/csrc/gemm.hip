@@ -149,50 +149,63 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    float4 ra[2], rb[2];
-    auto load_tiles = [&](int k0) {
+    // Operand slabs travel global -> registers -> LDS.  The register stage is a 3-slot ring indexed statically: the loads
+    // of slab s+2 are issued while slab s is multiplied, so a slab has two full iterations (~1 us of MFMA work) to arrive.
+    // With a single slab in flight every iteration waited out most of a global round trip (measured ~2 us per 32-wide
+    // slab on the [3200..5856] x [64..256] x [256..576] layers of the CNN / recurrent / MuJoCo-shaped networks).
+    float4 ra[3][2], rb[3][2];
+    auto load_tiles = [&](int k0, float4 (&qa)[2], float4 (&qb)[2]) {
         if (MODE == MODE_NT) {
-            load_kcontig(g.A, g.lda, g.M, g.K, m0, k0, ra);
-            load_kcontig(g.B, g.ldb, g.N, g.K, n0, k0, rb);
+            load_kcontig(g.A, g.lda, g.M, g.K, m0, k0, qa);
+            load_kcontig(g.B, g.ldb, g.N, g.K, n0, k0, qb);
         } else if (MODE == MODE_NN) {
-            load_kcontig(g.A, g.lda, g.M, g.K, m0, k0, ra);
-            load_kmajor(g.B, g.ldb, g.K, g.N, k0, n0, -1, rb);
+            load_kcontig(g.A, g.lda, g.M, g.K, m0, k0, qa);
+            load_kmajor(g.B, g.ldb, g.K, g.N, k0, n0, -1, qb);
         } else {
-            load_kmajor(g.A, g.lda, kend, g.N, k0, m0, -1, ra);                       // dY[m, n']
-            load_kmajor(g.B, g.ldb, kend, g.K, k0, n0, g.dbias ? g.K : -1, rb);      // X[m, k'] (+ ones column)
+            load_kmajor(g.A, g.lda, kend, g.N, k0, m0, -1, qa);                       // dY[m, n']
+            load_kmajor(g.B, g.ldb, kend, g.K, k0, n0, g.dbias ? g.K : -1, qb);      // X[m, k'] (+ ones column)
         }
     };
 
-    if (kbeg < kend) load_tiles(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        if (MODE == MODE_TN) stage_kmajor(sA, ra); else stage_kcontig(sA, ra);
-        if (MODE == MODE_NT) stage_kcontig(sB, rb); else stage_kmajor(sB, rb);
-        lds_barrier();                             // LDS-only: __syncthreads() would also drain the prefetch below
-        if (k0 + BK < kend) load_tiles(k0 + BK);   // next slab in flight while the matrix cores work
-        if (wave_live) {
-#pragma unroll
-            for (int q = 0; q < BK / 8; ++q) {
-                float a4[4], b4[4];
-                if (MODE == MODE_TN) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) a4[s] = sA[(q * 8 + 4 * lh + s) * LDR + wm * 32 + li];
-                } else {
-                    const float4 v = *reinterpret_cast<const float4*>(&sA[(wm * 32 + li) * LDK + q * 8 + 4 * lh]);
-                    a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w;
-                }
-                if (MODE == MODE_NT) {
-                    const float4 v = *reinterpret_cast<const float4*>(&sB[(wn * 32 + li) * LDK + q * 8 + 4 * lh]);
-                    b4[0] = v.x; b4[1] = v.y; b4[2] = v.z; b4[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) b4[s] = sB[(q * 8 + 4 * lh + s) * LDR + wn * 32 + li];
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], acc, 0, 0, 0);
-            }
-        }
-        lds_barrier();                             // slab consumed; the next one is still on its way
+    if (kbeg < kend) load_tiles(kbeg, ra[0], rb[0]);
+    if (kbeg + BK < kend) load_tiles(kbeg + BK, ra[1], rb[1]);
+    int k0 = kbeg;
+#define GEMM_SLAB_STEP(CUR, NXT)                                                                                         \
+    {                                                                                                                    \
+        if (MODE == MODE_TN) stage_kmajor(sA, ra[CUR]); else stage_kcontig(sA, ra[CUR]);                                 \
+        if (MODE == MODE_NT) stage_kcontig(sB, rb[CUR]); else stage_kmajor(sB, rb[CUR]);                                 \
+        lds_barrier();                             /* LDS-only: __syncthreads() would also drain the prefetches */       \
+        if (k0 + 2 * BK < kend) load_tiles(k0 + 2 * BK, ra[NXT], rb[NXT]);                                               \
+        if (wave_live) {                                                                                                 \
+            _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                                         \
+                float a4[4], b4[4];                                                                                      \
+                if (MODE == MODE_TN) {                                                                                   \
+                    _Pragma("unroll") for (int s = 0; s < 4; ++s) a4[s] = sA[(q * 8 + 4 * lh + s) * LDR + wm * 32 + li]; \
+                } else {                                                                                                 \
+                    const float4 v = *reinterpret_cast<const float4*>(&sA[(wm * 32 + li) * LDK + q * 8 + 4 * lh]);       \
+                    a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w;                                                  \
+                }                                                                                                        \
+                if (MODE == MODE_NT) {                                                                                   \
+                    const float4 v = *reinterpret_cast<const float4*>(&sB[(wn * 32 + li) * LDK + q * 8 + 4 * lh]);       \
+                    b4[0] = v.x; b4[1] = v.y; b4[2] = v.z; b4[3] = v.w;                                                  \
+                } else {                                                                                                 \
+                    _Pragma("unroll") for (int s = 0; s < 4; ++s) b4[s] = sB[(q * 8 + 4 * lh + s) * LDR + wn * 32 + li]; \
+                }                                                                                                        \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                            \
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], acc, 0, 0, 0);                              \
+            }                                                                                                            \
+        }                                                                                                                \
+        lds_barrier();                             /* slab consumed; the next two are still on their way */              \
+        k0 += BK;                                                                                                        \
+        if (k0 >= kend) break;                                                                                           \
     }
+    if (kbeg < kend)
+        for (;;) {
+            GEMM_SLAB_STEP(0, 2)
+            GEMM_SLAB_STEP(1, 0)
+            GEMM_SLAB_STEP(2, 1)
+        }
+#undef GEMM_SLAB_STEP
 
     if (!wave_live) return;
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
