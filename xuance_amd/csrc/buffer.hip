@@ -112,18 +112,27 @@ __global__ void __launch_bounds__(64) gae_scan_kernel(const float* __restrict__ 
     bool active = false, m64 = false, first = true;
     float last_f = 0.f, vnext_f = 0.f;
     double last_d = 0.0, vnext_d = 0.0, disc_d = 0.0;  // disc_d: discounted reward sum for use_gae == 0
-    for (int t1 = T; t1 > 0; t1 -= CH) {
-        const int t0 = t1 - CH;  // chunk covers t0 .. t1-1 (t0 may be negative)
-        float r[CH], v[CH], d[CH], bv[CH];
-        uint8_t sg[CH];
+    // the chunk after the current one is loaded while the current one is scanned (two chunks of 5*CH loads in flight)
+    float nr[CH], nv[CH], nd_[CH], nbv[CH];
+    uint8_t nsg[CH];
+    auto load_chunk = [&](int t0) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int t = t0 + j;
             if (t >= 0) {
                 const size_t o = (size_t)t * n_envs + e;
-                r[j] = rew[o]; v[j] = val[o]; d[j] = term[o]; bv[j] = bootv[o]; sg[j] = seg[o];
-            } else { r[j] = v[j] = d[j] = bv[j] = 0.f; sg[j] = 0; }
+                nr[j] = rew[o]; nv[j] = val[o]; nd_[j] = term[o]; nbv[j] = bootv[o]; nsg[j] = seg[o];
+            } else { nr[j] = nv[j] = nd_[j] = nbv[j] = 0.f; nsg[j] = 0; }
         }
+    };
+    load_chunk(T - CH);
+    for (int t1 = T; t1 > 0; t1 -= CH) {
+        const int t0 = t1 - CH;  // chunk covers t0 .. t1-1 (t0 may be negative)
+        float r[CH], v[CH], d[CH], bv[CH];
+        uint8_t sg[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { r[j] = nr[j]; v[j] = nv[j]; d[j] = nd_[j]; bv[j] = nbv[j]; sg[j] = nsg[j]; }
+        if (t0 > 0) load_chunk(t0 - CH);
 #pragma unroll
         for (int j = CH - 1; j >= 0; --j) {
             const int t = t0 + j;
