@@ -148,7 +148,9 @@ typedef struct {
     int64_t slab_stride;   /* floats between consecutive slabs of d_log_std */
     float clip_range, vf_coef, ent_coef;
     int32_t mode;          /* 0: PPO-clip surrogate; 1: A2C actor term -(adv * log_prob).mean() (a2c_learner.py:47), no ratio:
-                            * old_logp is not read, partials[0] = sum adv*log_prob, n_clipped = 0 */
+                            * old_logp is not read, partials[0] = sum adv*log_prob, n_clipped = 0;
+                            * 2: PG actor term -(returns * log_prob).mean(), no critic (pg_learner.py:40-45): adv, value,
+                            * d_value, old_logp are not touched */
 } xrl_ppo_loss_t;
 
 int xrl_ppo_loss_categorical(const xrl_ppo_loss_t* p, xrl_stream_t stream);

@@ -629,6 +629,45 @@ def golden_per_buffer():
     np.savez_compressed(os.path.join(OUT, "per_buffer.npz"), **out)
 
 
+def golden_pg(dist):
+    """PG_Learner.update (pg_learner.py:30-71) on VanillaPolicyGradient(CategoricalActor | GaussianActor) (reinforce.py:6-31,
+    pg_agent.py:36-61): a_loss = -(returns * log_prob).mean(), entropy bonus, no critic."""
+    from xuance.torch.learners import PG_Learner
+    from xuance.torch.rl_models.actors.categorical_actors import CategoricalActor
+    from xuance.torch.rl_models.actors.gaussian_actors import GaussianActor
+    from xuance.torch.rl_models.architectures.single_agent.reinforce import VanillaPolicyGradient
+    torch.manual_seed(8)
+    rng = np.random.default_rng(51)
+    init = torch.nn.init.orthogonal_
+    if dist == "categorical":
+        D, A, bs = 4, 2, 96
+        rep = Basic_MLP((D,), [128], None, init, nn.LeakyReLU, "cpu")
+        actor = CategoricalActor(representation=rep, action_space=sp.Discrete(A), actor_hidden_size=[128], normalizer=None,
+                                 initializer=init, activation=nn.LeakyReLU, device="cpu")
+    else:
+        D, A, bs = 17, 6, 80
+        rep = Basic_Identical((D,), "cpu")
+        actor = GaussianActor(representation=rep, action_space=sp.Box(-1, 1, (A,), np.float32), actor_hidden_size=[64, 64],
+                              normalizer=None, initializer=init, activation=nn.ReLU, activation_action=nn.Tanh, device="cpu")
+    model = VanillaPolicyGradient(actor=actor)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.1))
+    cfg = base_config(horizon_size=256, n_epochs=1, n_minibatch=1, ent_coef=0.01, end_factor_lr_decay=0.5)
+    cb = Capture()
+    learner = PG_Learner(cfg, model, cb)
+    batches = []
+    for u in range(3):
+        obs = np.clip(rng.standard_normal((bs, D)), -5, 5).astype(np.float32)
+        actions = rng.integers(0, A, bs).astype(np.float32) if dist == "categorical" else rng.standard_normal((bs, A)).astype(np.float32)
+        batches.append(dict(obs=obs, actions=actions, returns=rng.standard_normal(bs).astype(np.float32)))
+    out = run_learner_updates(learner, model, cb, batches,
+                              lambda b: learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], batch_size=bs))
+    out["cfg"] = np.array([cfg.learning_rate, cfg.ent_coef, cfg.grad_clip_norm, cfg.end_factor_lr_decay, learner.total_iters])
+    np.savez_compressed(os.path.join(OUT, f"pg_{dist}.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_onpolicy_buffer()
@@ -655,5 +694,7 @@ if __name__ == "__main__":
     golden_marl_rnn_buffer()
     golden_checkpoint()
     golden_per_buffer()
+    golden_pg("categorical")
+    golden_pg("gaussian")
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

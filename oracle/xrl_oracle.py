@@ -459,6 +459,52 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
     return info, grads
 
 
+def pg_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", activation_action=None):
+    """PG_Learner.update (pg_learner.py:30-71) on VanillaPolicyGradient(actor): loss = -(returns * log_prob).mean()
+    - ent_coef * entropy.mean().  sd names: actor.representation.model.*, actor.actor_head.{logits|mu}.*, actor.actor_head.log_std."""
+    dt = np.float32
+    key = "actor.actor_head.logits" if dist == "categorical" else "actor.actor_head.mu"
+    rep_l = collect_seq(sd, "actor.representation.model", act, last_act=act)
+    act_l = collect_seq(sd, key, act, last_act=activation_action)
+    rep, actor = MLP(rep_l), MLP(act_l)
+    obs = batch["obs"].astype(dt)
+    B = obs.shape[0]
+    h = rep.forward(obs) if rep_l else obs
+    out = actor.forward(h)
+    ret = batch["returns"].astype(dt)
+    invB = dt(1.0 / B)
+    grads = {}
+    if dist == "categorical":
+        a = batch["actions"].astype(np.int64)
+        lsm = log_softmax(out)
+        p = np.exp(lsm)
+        logp = lsm[np.arange(B), a]
+        ent = -(p * lsm).sum(-1)
+        onehot = np.zeros_like(out); onehot[np.arange(B), a] = 1
+        dout = (-ret * invB)[:, None] * (onehot - p) + (-dt(cfg["ent_coef"]) * invB) * (-p * (lsm + ent[:, None]))
+    else:
+        log_std = sd["actor.actor_head.log_std"].astype(dt)
+        var = np.exp(log_std) ** 2
+        x = batch["actions"].astype(dt)
+        logp = (-((x - out) ** 2) / (2 * var) - log_std - dt(math.log(math.sqrt(2 * math.pi)))).sum(-1)
+        ent = np.broadcast_to((dt(0.5 + 0.5 * math.log(2 * math.pi)) + log_std).sum(-1), (B,)).astype(dt)
+        dlogp = -ret * invB
+        dout = dlogp[:, None] * (x - out) / var
+        grads["actor.actor_head.log_std"] = ((dlogp[:, None] * (((x - out) ** 2) / var - 1)).sum(0)
+                                             - dt(cfg["ent_coef"]) * np.ones_like(log_std)).astype(dt)
+    a_loss = -(ret * logp).mean()
+    e_loss = ent.mean()
+    loss = a_loss - dt(cfg["ent_coef"]) * e_loss
+    dh, g_a = actor.backward(dout, need_dx=bool(rep_l))
+    for L, (gw, gb) in zip(act_l, g_a):
+        grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    if rep_l:
+        _, g_rep = rep.backward(dh, need_dx=False)
+        for L, (gw, gb) in zip(rep_l, g_rep):
+            grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
+    return dict(log_prob=logp, a_loss=a_loss, e_loss=e_loss, loss=loss, out=out), grads
+
+
 def ppo_update(sd, opt, batch, cfg, **kw):
     """One full PPO_Learner.update: fwd/bwd, clip_grad_norm_, Adam, LinearLR (ppo_learner.py:35-95)."""
     info, grads = ppo_forward_backward(sd, batch, cfg, **kw)

@@ -193,3 +193,40 @@ def test_resume_from_a_reference_checkpoint():
     for k, rp in sub(g, "resumed").items():
         assert_close(net.state_dict()[k].cpu().numpy(), rp, 1e-5, f"param {k} after the resumed update")
     assert learner.optimizer.read().step == 3
+
+
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+def test_pg_learner_vs_reference_fixture(dist):
+    """PG_Learner on the actor-only model (VanillaPolicyGradient): `xrl_ppo_loss_*` in mode 2 (weight = returns, no critic
+    columns) against the reference's pg_learner.py run (tests/golden/pg_*.npz)."""
+    from xuance_amd.nets import ActorNet
+    from xuance_amd.learners import PG_Learner
+    g = load_golden(f"pg_{dist}")
+    lr, ent, gclip, ef, total = g["cfg"]
+    if dist == "categorical":
+        net = ActorNet(4, 2, "categorical", (128,), (128,), "leaky_relu")
+    else:
+        net = ActorNet(17, 6, "gaussian", (), (64, 64), "relu", activation_action="tanh")
+    assert list(net.ref_order) == [str(n) for n in g["param_names"]]
+    net.load_state_dict(sub(g, "init"))
+    cfg = Namespace(horizon_size=256, n_epochs=1, n_minibatch=1, parallels=4, running_steps=120000, gamma=0.98,
+                    learning_rate=float(lr), ent_coef=float(ent), use_grad_clip=True, grad_clip_norm=float(gclip),
+                    end_factor_lr_decay=float(ef), distributed_training=False, device="cuda", model_dir="/tmp/xrl_models")
+    cb = Capture()
+    learner = PG_Learner(cfg, net, cb)
+    assert learner.total_iters == int(total)
+    for u in range(3):
+        b = sub(g, f"u{u}/batch")
+        info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], batch_size=len(b["obs"]))
+        ref_info, ref_cb = sub(g, f"u{u}/info"), sub(g, f"u{u}/cb")
+        assert set(info) == set(ref_info)
+        assert_close(info["actor-loss"], ref_info["actor-loss"], 1e-5, "actor-loss")
+        assert_close(info["entropy"], ref_info["entropy"], 1e-5, "entropy")
+        assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "lr")
+        rec = cb.records[-1]
+        assert_close(rec["log_prob"], ref_cb["log_prob"], 1e-6, "log_prob", scale=max(1.0, float(np.abs(ref_cb["log_prob"]).max())))
+        for k, rg in sub(g, f"u{u}/grad").items():
+            assert_close(net.params.view(k, learner.optimizer.grad).cpu().numpy(), rg, 2e-5, f"grad {k}")
+        sd = net.state_dict()
+        for k, rp in sub(g, f"u{u}/param").items():
+            assert_close(sd[k].cpu().numpy(), rp, 1e-5, f"param {k} after update {u}")

@@ -293,3 +293,20 @@ def test_per_buffer(oracle):
             per.update_priorities(d["step_choices"], d["priorities"])
     assert_close(per.sum, g["sum_tree"], 1e-14, "sum tree")
     assert np.array_equal(per.min, g["min_tree"]) and np.array_equal(per.max_priority, g["max_priority"])
+
+
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+def test_pg_update(oracle, dist):
+    """PG_Learner.update (pg_learner.py:30-71) on VanillaPolicyGradient replayed by the oracle."""
+    g = load_golden(f"pg_{dist}")
+    lr, ent, gclip, ef, total = g["cfg"]
+    act = "leaky_relu" if dist == "categorical" else "relu"
+    aa = None if dist == "categorical" else "tanh"
+    opt_kwargs_clip["clip"] = gclip
+    fb = lambda sd, b: oracle.pg_forward_backward(sd, b, dict(ent_coef=ent), dist=dist, act=act, activation_action=aa)
+    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
+        cb = sub(g, f"u{u}/cb")
+        assert_close(info["log_prob"], cb["log_prob"], 1e-6, "log_prob", scale=max(1.0, float(np.abs(cb["log_prob"]).max())))
+        for k in ("a_loss", "e_loss"):
+            assert_close(info[k], cb[k], 1e-5, k)
+    assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")

@@ -31,9 +31,10 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
 
     for (int m = mbeg + threadIdx.x; m < mend; m += blockDim.x) {
         const float* o = p.out + (size_t)m * p.ld_out;
-        float adv = p.adv[m];
-        if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, mean), denom);
-        const float ret = p.returns[m], v = p.value[(size_t)m * p.ld_v], oldlp = p.mode == 1 ? 0.f : p.old_logp[m];
+        const bool pg = p.mode == 2;                     // PG_Learner: weight = returns, no critic (pg_learner.py:40-45)
+        float adv = pg ? p.returns[m] : p.adv[m];
+        if (p.stats && !pg) adv = __fdiv_rn(__fsub_rn(adv, mean), denom);
+        const float ret = p.returns[m], v = pg ? 0.f : p.value[(size_t)m * p.ld_v], oldlp = p.mode == 0 ? p.old_logp[m] : 0.f;
         float logp, ent;
         if (!GAUSSIAN) {
             const int a = (int)p.actions[m];
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
             logp = o[a] - lse;
             ent = 0.f;
             for (int j = 0; j < A; ++j) { const float l = o[j] - lse; ent -= expf(l) * l; }
-            const Surrogate s = p.mode == 1 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM);
+            const Surrogate s = p.mode != 0 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM);
             float* dq = p.d_out + (size_t)m * p.ld_out;
             const float ce = p.ent_coef * invM;
             for (int j = 0; j < A; ++j) {
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
                 logp += -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;     // Normal.log_prob, summed (:179-180)
                 ent += 0.5f + LOG_SQRT_2PI + logf(sd);                           // Normal.entropy, summed (:182-183)
             }
-            const Surrogate s = p.mode == 1 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM);
+            const Surrogate s = p.mode != 0 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM);
             float* dq = p.d_out + (size_t)m * p.ld_out;
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
@@ -76,9 +77,12 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
             acc_s += (double)fminf(s.s1, s.s2); acc_n += s.clipped;
             if (p.diag) { p.diag[m] = logp; p.diag[p.M + m] = s.ratio; p.diag[2 * (size_t)p.M + m] = s.s1; p.diag[3 * (size_t)p.M + m] = s.s2; }
         }
-        const float dv = v - ret;
-        p.d_value[(size_t)m * p.ld_v] = p.vf_coef * 2.f * dv * invM;           // d(vf * mean((v-ret)^2))/dv
-        acc_c += (double)dv * dv; acc_e += ent; acc_v += v;
+        acc_e += ent;
+        if (!pg) {
+            const float dv = v - ret;
+            p.d_value[(size_t)m * p.ld_v] = p.vf_coef * 2.f * dv * invM;       // d(vf * mean((v-ret)^2))/dv
+            acc_c += (double)dv * dv; acc_v += v;
+        }
     }
 
     const double t0 = block_sum(acc_s, scratch), t1 = block_sum(acc_c, scratch), t2 = block_sum(acc_e, scratch),
@@ -137,8 +141,9 @@ __global__ void __launch_bounds__(1024) sum_partials_wide_kernel(const double* _
 
 static int check(const xrl_ppo_loss_t* p, bool gaussian) {
     XRL_CHECK_ARG(p != nullptr);
-    XRL_CHECK_ARG(p->out && p->value && p->actions && p->adv && p->returns && (p->old_logp || p->mode == 1) && p->d_out && p->d_value && p->partials);
-    XRL_CHECK_ARG(p->mode == 0 || p->mode == 1);
+    XRL_CHECK_ARG(p->mode >= 0 && p->mode <= 2);
+    XRL_CHECK_ARG(p->out && p->actions && p->returns && p->d_out && p->partials && (p->old_logp || p->mode != 0));
+    XRL_CHECK_ARG(p->mode == 2 || (p->value && p->adv && p->d_value));
     XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->A <= (gaussian ? 32 : 4096) && p->ld_out >= p->A && p->ld_v >= 1);
     XRL_CHECK_ARG(p->n_split >= 1);
     if (gaussian) XRL_CHECK_ARG(p->log_std != nullptr);

@@ -57,15 +57,18 @@ class PPO_Learner(Learner):
         heads = model.forward(obs, M, ldx)
         A = model.action_dim
         d_heads = model.d_heads
-        kw = dict(out=heads.data_ptr(), value=heads.data_ptr() + 4 * A, actions=act.data_ptr(), adv=adv.data_ptr(),
-                  stats=None if stats is None else stats.data_ptr(), returns=ret.data_ptr(),
-                  old_logp=old_logp.data_ptr(), d_out=d_heads.data_ptr(), d_value=d_heads.data_ptr() + 4 * A,
+        critic = model.head_ld > A                                  # ActorNet (PG) has no value column
+        kw = dict(out=heads.data_ptr(), value=heads.data_ptr() + 4 * A if critic else None, actions=act.data_ptr(),
+                  adv=None if adv is None else adv.data_ptr(), stats=None if stats is None else stats.data_ptr(),
+                  returns=ret.data_ptr(), old_logp=None if old_logp is None else old_logp.data_ptr(),
+                  d_out=d_heads.data_ptr(), d_value=d_heads.data_ptr() + 4 * A if critic else None,
                   diag=self.diag.data_ptr() if self.keep_diag else None, partials=self.partials.data_ptr(),
                   M=M, A=A, ld_out=model.head_ld, ld_v=model.head_ld, n_split=S, slab_stride=model.params.P,
                   clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef, mode=self.loss_mode)
         if model.dist == "gaussian":
-            kw.update(log_std=model.params.ptr("actor.log_std"),
-                      d_log_std=self.slabs.data_ptr() + 4 * model.params.offsets["actor.log_std"],
+            ls = getattr(model, "log_std_name", "actor.log_std")
+            kw.update(log_std=model.params.ptr(ls),
+                      d_log_std=self.slabs.data_ptr() + 4 * model.params.offsets[ls],
                       out_act=ops.ACT[model.activation_action])
         ops.ppo_loss(model.dist, **kw)
         model.backward(obs, M, self.slabs, S, ldx)
@@ -318,4 +321,39 @@ class A2C_Learner(PPO_Learner):
                   a_loss=info[self._key("actor-loss")], c_loss=info[self._key("critic-loss")], e_loss=info[self._key("entropy")])
         cb["loss"] = cb["a_loss"] - self.ent_coef * cb["e_loss"] + self.vf_coef * cb["c_loss"]
         info.update(self.callback.on_update_end(self.iterations, **cb) or {})
+        return info
+
+
+class PG_Learner(PPO_Learner):
+    """Vanilla policy gradient (xuance/torch/learners/policy_gradient/pg_learner.py:10-77): a_loss = -(returns * log_prob).mean()
+    with the entropy bonus, on an actor-only model (nets.ActorNet = VanillaPolicyGradient) -- `xrl_ppo_loss_t.mode = 2`, no
+    critic columns, the reference's info keys (`actor-loss`, `entropy`, `learning_rate`)."""
+
+    def __init__(self, config, model, callback=None):
+        for k, v in (("clip_range", 0.0), ("vf_coef", 0.0)):
+            if not hasattr(config, k):
+                setattr(config, k, v)
+        super().__init__(config, model, callback)
+        self.loss_mode = 2
+
+    def fused_eligible(self, memory):
+        return False
+
+    def _info(self, M, S, partials=None):
+        i = super()._info(M, S, partials)
+        k = self._key
+        return {k("actor-loss"): i[k("actor_loss")], k("entropy"): i[k("entropy")], k("learning_rate"): i[k("learning_rate")]}
+
+    def update(self, **samples):                                  # pg_learner.py:30-71
+        self.iterations += 1
+        obs, act, ret = self._as_dev(samples["obs"]), self._as_dev(samples["actions"]), self._as_dev(samples["returns"])
+        M = obs.shape[0]
+        obs = obs.reshape(M, -1)
+        self._ensure(M)
+        info = self.callback.on_update_start(self.iterations, model=self.model, obs=obs, act=act, returns=ret) or {}
+        S = self._step(obs, obs.shape[1], act, ret, None, None, M)
+        info.update(self._info(M, S))
+        a_loss, e_loss = info[self._key("actor-loss")], info[self._key("entropy")]
+        info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, log_prob=self.diag.view(-1)[0:M],
+                                                a_loss=a_loss, e_loss=e_loss, loss=a_loss - self.ent_coef * e_loss) or {})
         return info

@@ -311,6 +311,47 @@ class ActorCriticNet:
         self.plan.backward_grouped(x, self.obs_dim if ldx is None else ldx, M, slabs, n_split)
 
 
+class ActorNet:
+    """VanillaPolicyGradient(CategoricalActor | GaussianActor) (rl_models/architectures/single_agent/reinforce.py:6-31,
+    actors/categorical_actors.py, gaussian_actors.py): representation + actor head, no critic.  Same compute surface as
+    ActorCriticNet (forward -> head buffer [cap, action_dim], d_heads, backward), reference parameter names
+    ``actor.representation.model.<i>``, ``actor.actor_head.{logits|mu}.<i>``, ``actor.actor_head.log_std``."""
+
+    def __init__(self, obs_dim, action_dim, dist="categorical", representation_hidden=(128,), actor_hidden=(128,),
+                 activation="leaky_relu", activation_action=None, device="cuda", init=True):
+        assert dist in ("categorical", "gaussian")
+        self.obs_dim, self.action_dim, self.dist = obs_dim, action_dim, dist
+        self.activation, self.activation_action = activation, activation_action
+        specs, order, stages, widths = [], [], [], [obs_dim]
+        feat, lvl = _seq_layers("actor.representation.model", obs_dim, list(representation_hidden or []), activation, "same",
+                                0, specs, order, stages, widths)
+        key = "actor.actor_head.logits" if dist == "categorical" else "actor.actor_head.mu"
+        _seq_layers(key, feat, list(actor_hidden) + [action_dim], activation, activation_action if dist == "gaussian" else None,
+                    lvl, specs, order, stages, widths)
+        self.log_std_name = "actor.actor_head.log_std"
+        if dist == "gaussian":
+            specs.append((self.log_std_name, (action_dim,)))
+            order.insert(order.index(key + ".0.weight"), self.log_std_name)      # nn.Module: own parameters before sub-modules
+        self.ref_order = order
+        self.params = FlatParams(specs, device)
+        self.plan = Plan(self.params, widths, stages)
+        self.head_ld = action_dim
+        if init:
+            for name in order:
+                v = self.params.view(name)
+                if name == self.log_std_name:
+                    v.fill_(-1.0)
+                else:
+                    v.copy_(_orthogonal(v.shape)) if name.endswith(".weight") else v.zero_()
+
+    state_dict = ActorCriticNet.state_dict
+    load_state_dict = ActorCriticNet.load_state_dict
+    parameters = ActorCriticNet.parameters
+    forward = ActorCriticNet.forward
+    d_heads = ActorCriticNet.d_heads
+    backward = ActorCriticNet.backward
+
+
 class SequentialNet:
     """nn.Sequential of mlp_blocks with reference-style parameter names ``<prefix>.<2i>.{weight,bias}``.
 
