@@ -210,3 +210,37 @@ def test_checkpoint_layout_is_the_references(tmp_path):
         p.grad = torch.zeros_like(p)
     opt.step()
     assert float(opt.state[params[0]]["step"]) == 3.0 and opt.param_groups[0]["lr"] == 4e-4
+
+
+def test_shm_subproc_vec_env_matches_in_process_stepping():
+    """ShmSubprocVecEnv: 6 host CartPole envs in 2 worker processes, step data through the shared block --
+    observation / reward / flags / reset_obs / episode statistics identical to stepping the same seeded envs in this
+    process with the reference worker's auto-reset rule (subproc_vec_env.py:9-14), through many episode ends."""
+    import numpy as np
+    from xuance_amd.envs import ShmSubprocVecEnv, NumpyCartPoleEnv
+    n, steps = 6, 400
+    venv = ShmSubprocVecEnv([NumpyCartPoleEnv] * n, env_seed=11, in_series=3, device="cpu")
+    try:
+        assert venv.num_envs == n and venv.max_episode_steps == 500 and venv.n_remotes == 2
+        local = [NumpyCartPoleEnv(env_seed=11 + i) for i in range(n)]
+        obs, infos = venv.reset()
+        ref = np.stack([e.reset()[0] for e in local])
+        assert np.array_equal(obs, ref) and len(infos) == n
+        rng = np.random.default_rng(0)
+        ends = 0
+        for t in range(steps):
+            acts = rng.integers(0, 2, n)
+            o, r, term, trunc, infos = venv.step(acts)
+            for i, e in enumerate(local):
+                eo, er, et, etr, einfo = e.step(acts[i])
+                assert np.array_equal(o[i], eo) and r[i] == er and term[i] == et and trunc[i] == etr
+                assert infos[i]["episode_step"] == einfo["episode_step"] and infos[i]["episode_score"] == einfo["episode_score"]
+                if et or etr:
+                    ends += 1
+                    assert np.array_equal(infos[i]["reset_obs"], e.reset()[0])
+                else:
+                    assert "reset_obs" not in infos[i]
+        assert ends > 10
+    finally:
+        venv.close()
+    assert all(not p.is_alive() for p in venv.ps)

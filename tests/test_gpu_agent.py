@@ -494,3 +494,35 @@ def test_agent_checkpoint_files(tmp_path, fused):
     obs0 = npy(b.memory.soa.fields["observations"][0])
     raw = npy(b.envs.buf_obs) if False else None
     assert np.isfinite(obs0).all() and np.abs(obs0).max() <= 5.0
+
+
+def test_shm_subproc_vec_env_to_device():
+    """ShmSubprocVecEnv.step_to_device: a vector step of host envs (worker processes) reaches HBM through ONE async copy
+    of the page-locked shared block, and from there the on-policy buffer; device tensors == the host arrays."""
+    from xuance_amd.envs import ShmSubprocVecEnv, NumpyCartPoleEnv
+    from xuance_amd.memory import HipOnPolicyBuffer
+    from xuance_amd.spaces import Discrete
+    n, T = 8, 12
+    venv = ShmSubprocVecEnv([NumpyCartPoleEnv] * n, env_seed=3, in_series=2, device="cuda")
+    try:
+        assert venv._pinned, "hipHostRegister of the shared block failed"
+        buf = HipOnPolicyBuffer(venv.observation_space, Discrete(2), {"old_logp": ()}, n, T)
+        obs, _ = venv.reset()
+        rng = np.random.default_rng(1)
+        host = []
+        for t in range(T):
+            acts = rng.integers(0, 2, n).astype(np.float32)
+            d = venv.step_to_device(torch.from_numpy(acts).cuda())
+            torch.cuda.synchronize()
+            h = {k: venv.v[k].copy() for k in ("obs", "rewards", "terminated", "truncated")}
+            for k in h:
+                assert np.array_equal(d[k].cpu().numpy(), h[k]), k
+            buf.store(d["obs"], torch.from_numpy(acts).cuda(), d["rewards"], torch.zeros(n, device="cuda"),
+                      d["terminated"].float(), {"old_logp": torch.zeros(n, device="cuda")})
+            host.append(h)
+        f = buf.soa.fields
+        for t in range(T):
+            assert np.array_equal(npy(f["observations"][t]), host[t]["obs"])
+            assert np.array_equal(npy(f["rewards"][t]), host[t]["rewards"])
+    finally:
+        venv.close()
