@@ -571,6 +571,34 @@ typedef struct {
 } xrl_gru_bwd_t;
 int xrl_gru_backward(const xrl_gru_bwd_t* p, xrl_stream_t stream);
 
+/* One-layer LSTM, the `rnn: "LSTM"` option of Basic_RNN (rnn.py:45-47,59-66; layers.py:101-125): same conventions as the
+ * GRU entry points above, gate order i | f | g | o (torch.nn.LSTM), 4H values per row of gi / gates / d_gates. */
+typedef struct {
+    const float* gi;      /* [T1][R][ld_gi] */
+    const float* w_hh;    /* [4H][H] */
+    const float* b_hh;    /* [4H] */
+    const float* h0;      /* NULL (zeros) or [R][H] */
+    const float* c0;      /* NULL (zeros) or [R][H] */
+    const float* reset;   /* NULL or [R]: != 0 -> this row starts from zero hidden AND cell state */
+    float* hs;            /* [T1+1][R][H] */
+    float* cs;            /* NULL or [T1+1][R][H] cell states (slot 0 = initial), kept for xrl_lstm_backward */
+    float* gates;         /* NULL or [T1][R][4H] activated gates i | f | g | o */
+    float* h_last;        /* NULL or [R][H] (may alias h0) */
+    float* c_last;        /* NULL or [R][H] (may alias c0) */
+    int32_t R, T1, H, ld_gi;
+    const float* gi2; const float* w_hh2; const float* b_hh2; float* hs2;   /* optional second problem (target network) */
+} xrl_lstm_fwd_t;
+int xrl_lstm_forward(const xrl_lstm_fwd_t* p, xrl_stream_t stream);
+typedef struct {
+    const float* d_hs;    /* [T1][R][ld_dhs] */
+    const float* cs;      /* [T1+1][R][H] */
+    const float* gates;   /* [T1][R][4H] */
+    const float* w_hh;    /* [4H][H] */
+    float* d_gates;       /* [T1][R][ld_dg]: gradient of the gate pre-activations (input AND hidden side) */
+    int32_t R, T1, H, ld_dhs, ld_dg, pad;
+} xrl_lstm_bwd_t;
+int xrl_lstm_backward(const xrl_lstm_bwd_t* p, xrl_stream_t stream);
+
 /* ------------------------------------------------------------------ episode replay buffer (recurrent multi-agent path)
  * MARL_OffPolicyBuffer_RNN (xuance/common/memory_tools_marl.py:770-996).  Every field is [episode][slots][row_bytes]
  * (slots = T for per-step fields, T+1 for obs / state / avail_actions); `a`, `b`, `c` per entry point: */

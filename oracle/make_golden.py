@@ -368,7 +368,7 @@ def golden_qmix(double_q, algo="qmix"):
     np.savez_compressed(os.path.join(OUT, f"{algo}_ff_{'double' if double_q else 'single'}.npz"), **out)
 
 
-def golden_qmix_rnn(double_q=True, fixed=False):
+def golden_qmix_rnn(double_q=True, fixed=False, rnn="GRU"):
     """QMIX_Learner.update with recurrent agents (3m.yaml defaults: Basic_RNN fc 64 + GRU 64, q_hidden 64) on episode
     samples in the layout MARL_OffPolicyBuffer_RNN.sample returns (memory_tools_marl.py:970-996).
 
@@ -393,7 +393,7 @@ def golden_qmix_rnn(double_q=True, fixed=False):
     group = grouping.group_keys[0]
     init = torch.nn.init.orthogonal_
     obs_rep = Basic_RNN((O,), None, None, init, nn.ReLU, "cpu", fc_hidden_sizes=[64], recurrent_hidden_size=64,
-                        N_recurrent_layers=1, dropout=0, rnn="GRU")
+                        N_recurrent_layers=1, dropout=0, rnn=rnn)
     ident = build_identity_encoder(num_identities=N, mode="none", embedding_dim=None, device="cpu")
     fusion = IdentityFeatureFusion(observation_feature_dim=64, identity_feature_dim=ident.output_dim, mode="concat")
     rep = AgentFeatureEncoder(representation=obs_rep, identity_encoder=ident, fusion=fusion)
@@ -463,7 +463,7 @@ def golden_qmix_rnn(double_q=True, fixed=False):
     out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm, float(double_q),
                            learner.total_iters])
     out["group"] = np.array(group)
-    np.savez_compressed(os.path.join(OUT, f"qmix_rnn_{'double' if double_q else 'single'}{'_fixed' if fixed else ''}.npz"),
+    np.savez_compressed(os.path.join(OUT, f"qmix_{'rnn' if rnn == 'GRU' else rnn.lower()}_{'double' if double_q else 'single'}{'_fixed' if fixed else ''}.npz"),
                         **out)
 
 
@@ -691,6 +691,7 @@ if __name__ == "__main__":
     golden_qmix_rnn(True)
     golden_qmix_rnn(False)
     golden_qmix_rnn(True, fixed=True)
+    golden_qmix_rnn(True, fixed=True, rnn="LSTM")
     golden_marl_rnn_buffer()
     golden_checkpoint()
     golden_per_buffer()

@@ -951,6 +951,45 @@ def gru_backward(cache, dhs):
     return dgi @ w_ih, g
 
 
+def lstm_forward(x, h0, c0, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.LSTM (one layer, batch_first; gate order i | f | g | o): x [R,T,I] -> hs [R,T,H] + cache."""
+    R, T, _ = x.shape
+    H = w_hh.shape[1]
+    gi = x @ w_ih.T + b_ih
+    hs, cs, gates = np.zeros((R, T, H), x.dtype), np.zeros((R, T + 1, H), x.dtype), np.zeros((R, T, 4 * H), x.dtype)
+    h, c = h0.astype(x.dtype), c0.astype(x.dtype)
+    cs[:, 0] = c
+    for t in range(T):
+        pre = gi[:, t] + (h @ w_hh.T + b_hh)
+        i, f, o = _sigmoid(pre[:, :H]), _sigmoid(pre[:, H:2 * H]), _sigmoid(pre[:, 3 * H:])
+        g = np.tanh(pre[:, 2 * H:3 * H])
+        c = (f * c + i * g).astype(x.dtype)
+        h = (o * np.tanh(c)).astype(x.dtype)
+        gates[:, t] = np.concatenate([i, f, g, o], -1)
+        hs[:, t], cs[:, t + 1] = h, c
+    return hs, dict(x=x, h0=h0.astype(x.dtype), hs=hs, cs=cs, gates=gates, w_ih=w_ih, w_hh=w_hh, lstm=True)
+
+
+def lstm_backward(cache, dhs):
+    x, hs, cs, gates, w_ih, w_hh = cache["x"], cache["hs"], cache["cs"], cache["gates"], cache["w_ih"], cache["w_hh"]
+    R, T, _ = x.shape
+    H = w_hh.shape[1]
+    dgt = np.zeros((R, T, 4 * H), x.dtype)
+    dh_c, dc_c = np.zeros((R, H), x.dtype), np.zeros((R, H), x.dtype)
+    for t in reversed(range(T)):
+        i, f, g, o = (gates[:, t, q * H:(q + 1) * H] for q in range(4))
+        tc = np.tanh(cs[:, t + 1])
+        dh = dhs[:, t] + dh_c
+        dc = dh * o * (1 - tc * tc) + dc_c
+        dgt[:, t] = np.concatenate([dc * g * i * (1 - i), dc * cs[:, t] * f * (1 - f), dc * i * (1 - g * g), dh * tc * o * (1 - o)], -1)
+        dh_c = (dgt[:, t] @ w_hh).astype(x.dtype)
+        dc_c = (dc * f).astype(x.dtype)
+    hprev = np.concatenate([cache["h0"][:, None], hs[:, :-1]], 1)
+    flat = dgt.reshape(-1, 4 * H)
+    g = dict(w_ih=flat.T @ x.reshape(R * T, -1), b_ih=flat.sum(0), w_hh=flat.T @ hprev.reshape(R * T, H), b_hh=flat.sum(0))
+    return dgt @ w_ih, g
+
+
 def qmix_rnn_agent_forward(sd, prefix, obs, act="relu"):
     """DiscreteActionValueCritic(AgentFeatureEncoder(Basic_RNN)) over whole sequences from zero hidden state
     (base_critics.py:125-132, rnn.py:52-77, iql_learner.py:39-47).  obs [R,T1,O] -> Q [R,T1,A] + caches."""
@@ -960,8 +999,12 @@ def qmix_rnn_agent_forward(sd, prefix, obs, act="relu"):
     R, T1, O = obs.shape
     fc, q = MLP(fc_l), MLP(q_l)
     f = fc.forward(obs.reshape(R * T1, O)).reshape(R, T1, -1) if fc_l else obs
-    hs, gc = gru_forward(f, np.zeros((R, sd[f"{rp}.rnn.weight_hh_l0"].shape[1]), obs.dtype), sd[f"{rp}.rnn.weight_ih_l0"],
-                         sd[f"{rp}.rnn.weight_hh_l0"], sd[f"{rp}.rnn.bias_ih_l0"], sd[f"{rp}.rnn.bias_hh_l0"])
+    w_hh = sd[f"{rp}.rnn.weight_hh_l0"]
+    z0 = np.zeros((R, w_hh.shape[1]), obs.dtype)
+    if w_hh.shape[0] == 4 * w_hh.shape[1]:                              # rnn: "LSTM" (rnn.py:45-47)
+        hs, gc = lstm_forward(f, z0, z0, sd[f"{rp}.rnn.weight_ih_l0"], w_hh, sd[f"{rp}.rnn.bias_ih_l0"], sd[f"{rp}.rnn.bias_hh_l0"])
+    else:
+        hs, gc = gru_forward(f, z0, sd[f"{rp}.rnn.weight_ih_l0"], w_hh, sd[f"{rp}.rnn.bias_ih_l0"], sd[f"{rp}.rnn.bias_hh_l0"])
     Q = q.forward(hs.reshape(R * T1, -1)).reshape(R, T1, -1)
     return Q, dict(fc=fc, fc_l=fc_l, q=q, q_l=q_l, gru=gc, rp=rp, hs=hs)
 
@@ -1025,7 +1068,7 @@ def qmix_rnn_forward_backward(sd, batch, cfg, act="relu", group="shared"):
     dhs, g_q = c["q"].backward(dQ.reshape(B * N * T1, A), need_dx=True)
     for L, (gw, gb) in zip(c["q_l"], g_q):
         grads[L["name"] + ".weight"], grads[L["name"] + ".bias"] = gw, gb
-    df, gg = gru_backward(c["gru"], dhs.reshape(B * N, T1, -1))
+    df, gg = (lstm_backward if c["gru"].get("lstm") else gru_backward)(c["gru"], dhs.reshape(B * N, T1, -1))
     rp = c["rp"]
     grads[f"{rp}.rnn.weight_ih_l0"], grads[f"{rp}.rnn.weight_hh_l0"] = gg["w_ih"], gg["w_hh"]
     grads[f"{rp}.rnn.bias_ih_l0"], grads[f"{rp}.rnn.bias_hh_l0"] = gg["b_ih"], gg["b_hh"]

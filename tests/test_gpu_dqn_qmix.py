@@ -163,7 +163,7 @@ def test_gru_kernels_vs_oracle(oracle, R, T1):
                  scale=float(np.abs(g_ref["w_hh"]).max()))
 
 
-@pytest.mark.parametrize("name", ["qmix_rnn_double", "qmix_rnn_single", "qmix_rnn_double_fixed"])
+@pytest.mark.parametrize("name", ["qmix_rnn_double", "qmix_rnn_single", "qmix_rnn_double_fixed", "qmix_lstm_double_fixed"])
 def test_qmix_rnn_learner_vs_reference_fixture(name):
     """Recurrent QMIX against the reference's GRU branch: unmodified (agents receive no gradient, no action
     masks) and the `_fixed` fixture (BPTT + time-axis masks, see oracle/make_golden.py golden_qmix_rnn)."""
@@ -174,10 +174,11 @@ def test_qmix_rnn_learner_vs_reference_fixture(name):
     lr, gamma, sync, gclip, dq, total = g["cfg"]
     N, O, S, A, T = 3, 30, 48, 9, 12
     keys = [f"agent_{i}" for i in range(N)]
+    lstm = "lstm" in name                                        # `rnn: "LSTM"` option of Basic_RNN (xrl_lstm_forward / _backward)
     net = MixingQNet(N, O, A, S, (), (64,), 32, 32, "relu", group=str(g["group"]), use_rnn=True, fc_hidden=(64,),
-                     recurrent_hidden=64)
+                     recurrent_hidden=64, rnn="LSTM" if lstm else "GRU")
     assert list(net.ref_order) == list(sub(g, "init").keys())
-    assert sum(int(np.prod(net.params.shapes[k])) for k in net.trainable_order) == 42218
+    assert lstm or sum(int(np.prod(net.params.shapes[k])) for k in net.trainable_order) == 42218
     net.load_state_dict(sub(g, "init"))
     cb = Capture()
     learner = QMIX_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
@@ -324,3 +325,37 @@ def test_perdqn_learner_returns_td_errors():
     ref = sub(g, "u0/cb")
     assert_close(td.cpu().numpy(), np.abs(ref["targetQ"] - ref["predictQ"]), 1e-5, "|td|")
     assert_close(info["Qloss"], sub(g, "u0/info")["Qloss"], 1e-5, "Qloss")
+
+
+@pytest.mark.parametrize("R,T1", [(96, 61), (7, 4), (192, 1)])
+def test_lstm_kernels_vs_oracle(oracle, R, T1):
+    """xrl_lstm_forward / xrl_lstm_backward against the oracle's LSTM (whole sequences at the 3m sizes, a ragged small case,
+    the single-step acting shape with carried hidden + cell state and per-row resets)."""
+    from xuance_amd import ops
+    rng = np.random.default_rng(R * 7 + T1)
+    H = 64
+    gi = rng.standard_normal((R, T1, 4 * H)).astype(np.float32)
+    w_hh = (rng.standard_normal((4 * H, H)) * 0.2).astype(np.float32)
+    b_hh = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+    h0, c0 = rng.standard_normal((R, H)).astype(np.float32), rng.standard_normal((R, H)).astype(np.float32)
+    reset = (rng.random(R) < 0.3).astype(np.float32)
+    dhs = rng.standard_normal((R, T1, H)).astype(np.float32)
+    keep = (1 - reset)[:, None]
+    hs_ref, cache = oracle.lstm_forward(gi, h0 * keep, c0 * keep, np.eye(4 * H, dtype=np.float32), w_hh,
+                                        np.zeros(4 * H, np.float32), b_hh)
+    dgi_ref, g_ref = oracle.lstm_backward(cache, dhs)
+    tm = lambda x: torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).cuda()
+    d_w = torch.from_numpy(w_hh).cuda()
+    hs, cs = torch.zeros(T1 + 1, R, H, device="cuda"), torch.zeros(T1 + 1, R, H, device="cuda")
+    gates = torch.zeros(T1, R, 4 * H, device="cuda")
+    sh, sc = torch.from_numpy(h0).cuda(), torch.from_numpy(c0).cuda()
+    ops.lstm_forward(gi=tm(gi), w_hh=d_w, b_hh=torch.from_numpy(b_hh).cuda(), h0=sh, c0=sc, reset=torch.from_numpy(reset).cuda(),
+                     hs=hs, cs=cs, gates=gates, h_last=sh, c_last=sc, R=R, T1=T1, H=H, ld_gi=4 * H)
+    d_gates = torch.zeros(T1, R, 4 * H, device="cuda")
+    ops.lstm_backward(d_hs=tm(dhs), cs=cs, gates=gates, w_hh=d_w, d_gates=d_gates, R=R, T1=T1, H=H, ld_dhs=H, ld_dg=4 * H)
+    torch.cuda.synchronize()
+    assert_close(hs[1:].cpu().numpy().transpose(1, 0, 2), hs_ref, 1e-5, "hs")
+    assert_close(cs.cpu().numpy().transpose(1, 0, 2), cache["cs"], 1e-5, "cs", scale=float(np.abs(cache["cs"]).max()))
+    assert_close(sh.cpu().numpy(), hs_ref[:, -1], 1e-5, "carried h")
+    assert_close(sc.cpu().numpy(), cache["cs"][:, -1], 1e-5, "carried c", scale=float(np.abs(cache["cs"]).max()))
+    assert_close(d_gates.cpu().numpy().transpose(1, 0, 2), dgi_ref, 1e-5, "d_gates", scale=float(np.abs(dgi_ref).max()))

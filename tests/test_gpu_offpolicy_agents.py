@@ -376,3 +376,32 @@ def test_perdqn_agent_loop():
     # the most recently stored step has not been sampled-and-updated after its store only if it still carries max_priority^alpha
     last = leaves[:, (mem.ptr - 1) % mem.n_size]
     assert ((np.abs(last - mp ** 0.6) < 1e-12) | (last != mp ** 0.6)).all()
+
+
+def test_qmix_lstm_agents_episode_loop(oracle):
+    """`rnn: "LSTM"`: hidden AND cell state of every (env, agent) row are carried between acting steps and zeroed with the
+    env's episode; checked against the oracle's LSTM over the staged observations of the running episodes."""
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    torch.manual_seed(0)
+    n, N, T = 8, 3, 12
+    env = SyntheticSMACVecEnv(n, seed=5, max_episode_steps=T)
+    agent = QMIX_Agents(_rnn_cfg(rnn="LSTM"), env)
+    assert agent.model.lstm and agent.model.G == 256
+    sd = {k: v.cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+    agent.run_episodes(n)
+    torch.cuda.synchronize()
+    steps = env.steps.cpu().numpy()
+    obs_stage = agent.memory.episode_data["obs"].cpu().numpy().reshape(n, T + 1, N, -1)
+    h, c = agent.rnn_h.cpu().numpy().reshape(n, N, -1), agent.rnn_c.cpu().numpy().reshape(n, N, -1)
+    checked = 0
+    for e in range(n):
+        if steps[e] == 0:
+            continue
+        _, cc = oracle.qmix_rnn_agent_forward(sd, "individual_q_networks.shared", obs_stage[e, :steps[e]].transpose(1, 0, 2))
+        assert_close(h[e], cc["hs"][:, -1], 1e-5, f"carried h of env {e}")
+        assert_close(c[e], cc["gru"]["cs"][:, -1], 1e-5, f"carried c of env {e}")
+        checked += 1
+    assert checked > 0
+    info = agent.learner.update_from_buffer(agent.memory, 2, seed=5)
+    assert np.isfinite(info["loss_Q"])

@@ -212,7 +212,7 @@ def test_vdn_iql_update(oracle, name):
                 assert_close(info[k], sub(g, f"u{u}/cb")[k], 1e-5, k)
 
 
-@pytest.mark.parametrize("name", ["qmix_rnn_double", "qmix_rnn_single", "qmix_rnn_double_fixed"])
+@pytest.mark.parametrize("name", ["qmix_rnn_double", "qmix_rnn_single", "qmix_rnn_double_fixed", "qmix_lstm_double_fixed"])
 def test_qmix_rnn_update(oracle, name):
     """Recurrent QMIX: Basic_RNN fc+GRU agents over whole episodes, masked TD loss (qmix_learner.py:81-84).
     The unmodified reference gives the agent networks no gradient here (q_eval is re-sliced under no_grad,

@@ -109,6 +109,18 @@ class GruBwd(C.Structure):
                 ("R", c_int32), ("T1", c_int32), ("H", c_int32), ("ld_dhs", c_int32), ("ld_dgi", c_int32), ("pad", c_int32)]
 
 
+class LstmFwd(C.Structure):
+    _fields_ = [("gi", c_void_p), ("w_hh", c_void_p), ("b_hh", c_void_p), ("h0", c_void_p), ("c0", c_void_p), ("reset", c_void_p),
+                ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("h_last", c_void_p), ("c_last", c_void_p),
+                ("R", c_int32), ("T1", c_int32), ("H", c_int32), ("ld_gi", c_int32),
+                ("gi2", c_void_p), ("w_hh2", c_void_p), ("b_hh2", c_void_p), ("hs2", c_void_p)]
+
+
+class LstmBwd(C.Structure):
+    _fields_ = [("d_hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("w_hh", c_void_p), ("d_gates", c_void_p),
+                ("R", c_int32), ("T1", c_int32), ("H", c_int32), ("ld_dhs", c_int32), ("ld_dg", c_int32), ("pad", c_int32)]
+
+
 class FusedLayer(C.Structure):
     _fields_ = [("w_off", c_int32), ("b_off", c_int32), ("K", c_int32), ("N", c_int32), ("act", c_int32),
                 ("in_level", c_int32), ("in_off", c_int32), ("out_level", c_int32), ("out_off", c_int32), ("pad", c_int32)]
@@ -192,6 +204,8 @@ _SIGS = {
     "xrl_per_sample": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                        c_void_p, c_void_p],
     "xrl_per_update_priorities": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_double, c_int, c_int, c_int, c_void_p],
+    "xrl_lstm_forward": [C.POINTER(LstmFwd), c_void_p],
+    "xrl_lstm_backward": [C.POINTER(LstmBwd), c_void_p],
     "xrl_gru_forward": [C.POINTER(GruFwd), c_void_p],
     "xrl_gru_backward": [C.POINTER(GruBwd), c_void_p],
     "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],

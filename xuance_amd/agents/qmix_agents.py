@@ -57,6 +57,7 @@ class QMIX_Agents:
         self.act_f = torch.zeros(self.n_envs, self.n_agents, device=dev)
         if self.use_rnn:
             self.rnn_h = torch.zeros(R, self.model.RH, device=dev)           # init_rnn_states (value_factorization.py:151-159)
+            self.rnn_c = torch.zeros(R, self.model.RH, device=dev) if self.model.lstm else None   # LSTM cell states (rnn.py:79-84)
             self.reset_rows = torch.zeros(R, device=dev)
             self._counts = torch.zeros(2, device=dev)
             self._counts_h = torch.zeros(2).pin_memory() if torch.cuda.is_available() else torch.zeros(2)
@@ -71,7 +72,7 @@ class QMIX_Agents:
                           _get(c, "hidden_dim_mixing_net", 32), _get(c, "hidden_dim_hyper_net", 32),
                           _get(c, "activation", "relu"), device=self.device, use_rnn=self.use_rnn,
                           fc_hidden=list(_get(c, "fc_hidden_sizes", [64])), recurrent_hidden=_get(c, "recurrent_hidden_size", 64),
-                          mixer=self.mixer_name)
+                          mixer=self.mixer_name, rnn=_get(c, "rnn", "GRU"))
 
     def _build_memory(self):
         c, env = self.config, self.envs
@@ -101,13 +102,15 @@ class QMIX_Agents:
         env.reset()
         mem.clear_episodes()
         self.rnn_h.zero_()
+        if self.rnn_c is not None:
+            self.rnn_c.zero_()
         self.reset_rows.zero_()
         episodes = 0
         while episodes < n_episodes:
             obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
             steps = env.steps.clone()
             q = self.model.agent_forward_seq(obs.view(R, -1), R, 1, which=2, h0=self.rnn_h, reset=self.reset_rows,
-                                             h_last=self.rnn_h)
+                                             h_last=self.rnn_h, c0=self.rnn_c, c_last=self.rnn_c)
             ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
                                     action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,
                                     step_dev=self.step_counter)

@@ -528,10 +528,13 @@ class MixingQNet:
 
     def __init__(self, n_agents, obs_dim, n_actions, state_dim, representation_hidden=(64,), q_hidden=(64,),
                  mixer_hidden=32, hyper_hidden=32, activation="relu", group="shared", device="cuda", init=True,
-                 use_rnn=False, fc_hidden=(64,), recurrent_hidden=64, mixer="QMIX"):
+                 use_rnn=False, fc_hidden=(64,), recurrent_hidden=64, mixer="QMIX", rnn="GRU"):
         self.n_agents, self.obs_dim, self.n_actions, self.state_dim = n_agents, obs_dim, n_actions, state_dim
         self.H, self.HH, self.group = mixer_hidden, hyper_hidden, group
         self.use_rnn, self.RH = bool(use_rnn), int(recurrent_hidden)
+        assert rnn in ("GRU", "LSTM")
+        self.lstm = bool(use_rnn) and rnn == "LSTM"
+        self.G = (4 if self.lstm else 3) * int(recurrent_hidden)       # gate rows of weight_ih_l0 / weight_hh_l0
         N, H, HH, S = n_agents, mixer_hidden, hyper_hidden, state_dim
         specs, a_order, a_stages, a_widths = [], [], [], [obs_dim]
         pe = f"individual_q_networks.{group}"
@@ -544,7 +547,7 @@ class MixingQNet:
             # Basic_RNN (rnn.py:38-77): mlp blocks, then nn.GRU; the input-side GRU product is the last layer of the
             # "pre" plan (no activation), the recurrence is xrl_gru_forward, the Q head is the "post" plan.
             assert recurrent_hidden == 64, "xrl_gru_forward keeps one hidden unit per lane: recurrent_hidden_size must be 64"
-            rp, G = f"{pe}.representation.obs_representation", 3 * recurrent_hidden
+            rp, G = f"{pe}.representation.obs_representation", self.G
             feat, lvl = _seq_layers(f"{rp}.mlp", obs_dim, list(fc_hidden), activation, "same", 0, specs, a_order,
                                     a_stages, a_widths)
             self.w_ih, self.w_hh, self.b_ih, self.b_hh = (f"{rp}.rnn.weight_ih_l0", f"{rp}.rnn.weight_hh_l0",
@@ -618,48 +621,68 @@ class MixingQNet:
         if ws is None:
             dev, H = self.params.device, self.RH
             ws = {"hs": torch.zeros((T1 + 1) * R, H, device=dev), "gates": torch.zeros(T1 * R, 4 * H, device=dev)}
+            if self.lstm:
+                ws["cs"] = torch.zeros((T1 + 1) * R, H, device=dev)
             if which == 0:
                 ws["d_hs"] = torch.zeros(T1 * R, H, device=dev)
-                ws["d_gh"] = torch.zeros(T1 * R, 3 * H, device=dev)
+                if not self.lstm:
+                    ws["d_gh"] = torch.zeros(T1 * R, 3 * H, device=dev)
             self._seq_ws[key] = ws
             self.pre_plans[which].ensure(T1 * R)
             self.post_plans[which].ensure(T1 * R)
         return ws
 
-    def agent_forward_seq(self, X, R, T1, which=0, h0=None, reset=None, h_last=None):
+    def _recurrence(self, gi, ws, R, T1, flat, keep, h0=None, c0=None, reset=None, h_last=None, c_last=None, second=None):
+        """The serial part between the plan below and the plan above: xrl_gru_forward or xrl_lstm_forward (`rnn: "LSTM"`).
+        second = (gi2, ws2, flat2): the target network's sequences in the same launch."""
+        P, H, G = self.params, self.RH, self.G
+        kw = dict(gi=gi, w_hh=P.ptr(self.w_hh, flat), b_hh=P.ptr(self.b_hh, flat), h0=h0, reset=reset, hs=ws["hs"],
+                  gates=ws["gates"] if keep else None, h_last=h_last, R=R, T1=T1, H=H, ld_gi=G)
+        if second is not None:
+            gi2, ws2, flat2 = second
+            kw.update(gi2=gi2, w_hh2=P.ptr(self.w_hh, flat2), b_hh2=P.ptr(self.b_hh, flat2), hs2=ws2["hs"])
+        if self.lstm:
+            ops.lstm_forward(c0=c0, cs=ws["cs"] if keep else None, c_last=c_last, **kw)
+        else:
+            ops.gru_forward(**kw)
+
+    def agent_forward_seq(self, X, R, T1, which=0, h0=None, reset=None, h_last=None, c0=None, c_last=None):
         """Q values of R sequences over T1 steps.  X [T1*R, obs_dim] time-major (row t*R + r) -> [T1*R, n_actions].
         which: 0 = eval network (keeps what BPTT needs), 1 = target network, 2 = eval network for acting."""
         flat = self.target_flat if which == 1 else None
-        P, H = self.params, self.RH
         ws = self.seq_workspace(which, R, T1)
         gi = self.pre_plans[which].forward(X, self.obs_dim, T1 * R, flat=flat)
-        ops.gru_forward(gi=gi, w_hh=P.ptr(self.w_hh, flat), b_hh=P.ptr(self.b_hh, flat), h0=h0, reset=reset, hs=ws["hs"],
-                        gates=ws["gates"] if which == 0 else None, h_last=h_last, R=R, T1=T1, H=H, ld_gi=3 * H)
-        return self.post_plans[which].forward(ws["hs"][R:], H, T1 * R, flat=flat)
+        self._recurrence(gi, ws, R, T1, flat, which == 0, h0=h0, c0=c0, reset=reset, h_last=h_last, c_last=c_last)
+        return self.post_plans[which].forward(ws["hs"][R:], self.RH, T1 * R, flat=flat)
 
     def agent_forward_seq_pair(self, X, R, T1):
-        """Eval and target networks over the same sequences (iql_learner.py:41-57): the layers below and above the GRU as
-        grouped launches (eval + target in one), the two recurrences as one dual launch.  Returns (Q_eval, Q_target)."""
-        P, H, M, tf = self.params, self.RH, T1 * R, self.target_flat
+        """Eval and target networks over the same sequences (iql_learner.py:41-57): the layers below and above the
+        recurrence as grouped launches (eval + target in one), the two recurrences as one dual launch.
+        Returns (Q_eval, Q_target)."""
+        H, M, tf = self.RH, T1 * R, self.target_flat
         ws0, ws1 = self.seq_workspace(0, R, T1), self.seq_workspace(1, R, T1)
         gi0, gi1 = Plan.forward_many([(self.pre_plans[0], X, self.obs_dim, M, None), (self.pre_plans[1], X, self.obs_dim, M, tf)])
-        ops.gru_forward(gi=gi0, w_hh=P.ptr(self.w_hh), b_hh=P.ptr(self.b_hh), h0=None, reset=None, hs=ws0["hs"],
-                        gates=ws0["gates"], h_last=None, R=R, T1=T1, H=H, ld_gi=3 * H, gi2=gi1, w_hh2=P.ptr(self.w_hh, tf),
-                        b_hh2=P.ptr(self.b_hh, tf), hs2=ws1["hs"])
+        self._recurrence(gi0, ws0, R, T1, None, True, second=(gi1, ws1, tf))
         return Plan.forward_many([(self.post_plans[0], ws0["hs"][R:], H, M, None), (self.post_plans[1], ws1["hs"][R:], H, M, tf)])
 
     def agent_backward_seq(self, X, R, T1, slabs, n_split, defer_wgrad=None):
-        """post_plans[0].dacts[last] holds dLoss/dQ [T1*R, A]: data-gradient chain Q head -> BPTT -> layers below the GRU,
-        then every weight gradient of the agent network (Q head, W_hh, W_ih, fc) as ONE grouped launch."""
-        P, H, M = self.params, self.RH, T1 * R
+        """post_plans[0].dacts[last] holds dLoss/dQ [T1*R, A]: data-gradient chain Q head -> BPTT -> layers below the
+        recurrence, then every weight gradient of the agent network (Q head, W_hh, W_ih, fc) as ONE grouped launch."""
+        P, H, G, M = self.params, self.RH, self.G, T1 * R
         ws, pre, post = self.seq_workspace(0, R, T1), self.pre_plans[0], self.post_plans[0]
         wg = [] if defer_wgrad is None else defer_wgrad
         post.backward(ws["hs"][R:], H, M, slabs, n_split, dx0=ws["d_hs"], defer_wgrad=wg)
         d_gi = pre.dacts[len(pre.widths) - 1]
-        ops.gru_backward(d_hs=ws["d_hs"], hs=ws["hs"], gates=ws["gates"], w_hh=P.ptr(self.w_hh), d_gi=d_gi, d_gh=ws["d_gh"],
-                         d_h0=None, R=R, T1=T1, H=H, ld_dhs=H, ld_dgi=3 * H)
-        wg.append(ops.gemm_desc(ws["d_gh"].data_ptr(), ws["hs"].data_ptr(), slabs.data_ptr() + 4 * P.offsets[self.w_hh],
-                                M, 3 * H, H, 3 * H, H, H, dbias=slabs.data_ptr() + 4 * P.offsets[self.b_hh]))
+        if self.lstm:      # one gate-gradient buffer serves the input and the hidden side (csrc/lstm.hip)
+            ops.lstm_backward(d_hs=ws["d_hs"], cs=ws["cs"], gates=ws["gates"], w_hh=P.ptr(self.w_hh), d_gates=d_gi, R=R, T1=T1,
+                              H=H, ld_dhs=H, ld_dg=G)
+            d_gh = d_gi
+        else:
+            ops.gru_backward(d_hs=ws["d_hs"], hs=ws["hs"], gates=ws["gates"], w_hh=P.ptr(self.w_hh), d_gi=d_gi, d_gh=ws["d_gh"],
+                             d_h0=None, R=R, T1=T1, H=H, ld_dhs=H, ld_dgi=G)
+            d_gh = ws["d_gh"]
+        wg.append(ops.gemm_desc(d_gh.data_ptr(), ws["hs"].data_ptr(), slabs.data_ptr() + 4 * P.offsets[self.w_hh],
+                                M, G, H, G, H, H, dbias=slabs.data_ptr() + 4 * P.offsets[self.b_hh]))
         pre.backward(X, self.obs_dim, M, slabs, n_split, defer_wgrad=wg)
         if defer_wgrad is None:
             ops.linear_bwd_weight(wg, n_split, slabs.shape[1])

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -385,6 +385,14 @@ def per_sample(sum_tree, min_tree, uniforms, size, beta, n_envs, n_size, capacit
 def per_update_priorities(sum_tree, min_tree, max_priority, idxes, priorities, alpha, n_envs, capacity, per_env):
     call("xrl_per_update_priorities", ptr(sum_tree), ptr(min_tree), ptr(max_priority), ptr(idxes), ptr(priorities),
          float(alpha), int(n_envs), int(capacity), int(per_env), stream_ptr())
+
+
+def lstm_forward(**kw):
+    call("xrl_lstm_forward", C.byref(_struct(LstmFwd, kw)), stream_ptr())
+
+
+def lstm_backward(**kw):
+    call("xrl_lstm_backward", C.byref(_struct(LstmBwd, kw)), stream_ptr())
 
 
 def gru_forward(**kw):
