@@ -385,13 +385,16 @@ def test_qmix_lstm_agents_episode_loop(oracle):
     from xuance_amd.envs import SyntheticSMACVecEnv
     torch.manual_seed(0)
     n, N, T = 8, 3, 12
-    env = SyntheticSMACVecEnv(n, seed=5, max_episode_steps=T)
-    agent = QMIX_Agents(_rnn_cfg(rnn="LSTM"), env)
-    assert agent.model.lstm and agent.model.G == 256
-    sd = {k: v.cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
-    agent.run_episodes(n)
-    torch.cuda.synchronize()
-    steps = env.steps.cpu().numpy()
+    for seed in range(3, 20):          # a provider seed for which some episode ends early, so that envs are mid-episode at the end
+        env = SyntheticSMACVecEnv(n, seed=seed, max_episode_steps=T)
+        agent = QMIX_Agents(_rnn_cfg(rnn="LSTM"), env)
+        assert agent.model.lstm and agent.model.G == 256
+        sd = {k: v.cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
+        agent.run_episodes(n)
+        torch.cuda.synchronize()
+        steps = env.steps.cpu().numpy()
+        if (steps > 0).any():
+            break
     obs_stage = agent.memory.episode_data["obs"].cpu().numpy().reshape(n, T + 1, N, -1)
     h, c = agent.rnn_h.cpu().numpy().reshape(n, N, -1), agent.rnn_c.cpu().numpy().reshape(n, N, -1)
     checked = 0
