@@ -526,3 +526,44 @@ def test_shm_subproc_vec_env_to_device():
             assert np.array_equal(npy(f["rewards"][t]), host[t]["rewards"])
     finally:
         venv.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ragged_minibatches_vs_oracle(oracle, use_graph):
+    """buffer_size not divisible by n_minibatch (5 envs x 10 steps, 4 minibatches -> 12, 12, 12, 12, 2 per epoch): the
+    reference's train_epochs ends every epoch with a short minibatch (on_policy.py:198-203); the oracle replays the same
+    permutations."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(0)
+    n, T = 5, 10
+    cfg = make_config(n, T, n_epochs=2, n_minibatch=4, use_hip_graph=use_graph, use_fused_rollout=False)
+    agent = PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=2))
+    assert agent.batch_size == 12 and agent.rem == 2
+    sd = {k: npy(v) for k, v in agent.model.state_dict().items()}
+    opt = oracle.AdamOracle(sd, lr=4e-4, eps=1e-5, total_iters=agent.learner.total_iters)
+    c = dict(vf_coef=0.25, ent_coef=0.01, clip_range=0.2, use_grad_clip=True, grad_clip_norm=0.5)
+    for it in range(3 if use_graph else 1):
+        agent.rollout()
+        torch.cuda.synchronize()
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        perms = np.stack([np.random.default_rng(10 * it + e).permutation(n * T) for e in range(2)])
+        agent.set_indices(perms)
+        info = agent.update()
+        buf = oracle.OnPolicyBufferOracle((4,), (), n, T)
+        buf.size = T
+        buf.observations, buf.actions = f["observations"].transpose(1, 0, 2), f["actions"].T
+        buf.returns, buf.values, buf.advantages, buf.old_logp = f["returns"].T, f["values"].T, f["advantages"].T, f["aux_old_logp"].T
+        n_updates = 0
+        for e in range(2):
+            for start in range(0, n * T, 12):
+                s = buf.sample(perms[e, start:start + 12])
+                oi, _ = oracle.ppo_update(sd, opt, dict(obs=s["obs"], actions=s["actions"], returns=s["returns"],
+                                                        advantages=s["advantages"], old_logp=s["aux_batch"]["old_logp"]), c)
+                n_updates += 1
+        assert n_updates == 10 and len(s["obs"]) == 2
+        got = agent.model.state_dict()
+        for k_, val in sd.items():
+            assert_close(npy(got[k_]), val, 2e-5, f"param {k_} (pass {it})")
+        assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss of the short minibatch")
+    assert agent.learner.iterations == 10 * (3 if use_graph else 1)

@@ -63,6 +63,10 @@ class PPO_Agent:
         self.buffer_size = n * self.horizon_size
         self.batch_size = self.buffer_size // self.n_minibatch
         self.idx = torch.zeros(self.n_epochs * self.n_minibatch, self.batch_size, dtype=torch.int64, device=dev)
+        # buffer_size not divisible by n_minibatch: the reference's loop `range(0, buffer_size, batch_size)` ends every epoch
+        # with one SHORT minibatch of the remaining transitions (on_policy.py:198-203)
+        self.rem = self.buffer_size - self.n_minibatch * self.batch_size
+        self.idx_full = torch.zeros(self.n_epochs, self.buffer_size, dtype=torch.int64, device=dev) if self.rem else None
         self._rollout_graph = None
         self._update_graph = None
         self._started = False
@@ -222,6 +226,8 @@ class PPO_Agent:
     def _enqueue_update(self):
         """train_epochs (core/on_policy.py:182-205): n_epochs x n_minibatch minibatches taken from self.idx."""
         mem, lr = self.memory, self.learner
+        if self.rem:
+            return self._enqueue_update_ragged()
         nb, bs = self.idx.shape
         f = mem.soa
         fused = lr.fused_eligible(mem)
@@ -239,6 +245,24 @@ class PPO_Agent:
         for k in range(nb):
             step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None)
 
+    def _enqueue_update_ragged(self):
+        """buffer_size % n_minibatch != 0: per epoch n_minibatch full minibatches and one short one (layered path)."""
+        mem, lr, bs = self.memory, self.learner, self.batch_size
+        lr.prepare_buffer_update(mem, bs)
+        if not getattr(self, "_fixed_idx", False):
+            ops.random_permutation(self.idx_full, self.n_epochs, self.buffer_size, self.buffer_size, self.seed, 0, self.perm_counter)
+            ops.counter_add(self.perm_counter, 1)
+        adv, k = mem.soa.fields["advantages"], 0
+        for e in range(self.n_epochs):
+            for start in range(0, self.buffer_size, bs):
+                idx = self.idx_full[e, start:start + bs]
+                st = None
+                if mem.use_advnorm:
+                    st = lr.stats[k]
+                    ops.adv_stats(adv, idx, idx.numel(), 1, self.n_envs, self.horizon_size, st)
+                lr.enqueue_minibatch_from_buffer(mem, idx, st)
+                k += 1
+
     def _new_indices(self):
         """np.random.shuffle of arange(buffer_size) per epoch (on_policy.py:194-204), generated on the device."""
         # one launch, part of the captured update graph: a keyed bijection per epoch (xrl_random_permutation), keyed by a
@@ -249,8 +273,12 @@ class PPO_Agent:
 
     # -- public API -----------------------------------------------------------------------------------------------
     def set_indices(self, idx):
-        """Parity hook: use the caller's minibatch indices (e.g. the ones NumPy produced for the reference)."""
-        self.idx.copy_(torch.as_tensor(np.asarray(idx)).reshape(self.idx.shape))
+        """Parity hook: use the caller's minibatch indices (e.g. the ones NumPy produced for the reference); with a
+        remainder ([n_epochs, buffer_size]: every epoch's whole permutation)."""
+        if self.rem:
+            self.idx_full.copy_(torch.as_tensor(np.asarray(idx)).reshape(self.idx_full.shape))
+        else:
+            self.idx.copy_(torch.as_tensor(np.asarray(idx)).reshape(self.idx.shape))
         if not getattr(self, "_fixed_idx", False):
             self._update_graph = None                     # a captured graph would regenerate the indices
             self._mb_graphs = None
@@ -277,6 +305,7 @@ class PPO_Agent:
     def _update_distributed(self):
         """N > 1 ranks: the per-minibatch launch sequence is captured in two graphs split at the gradient
         all-reduce (RCCL runs on its own stream, outside the capture)."""
+        assert not self.rem, "multi-GPU updates need buffer_size divisible by n_minibatch"
         mem, lr = self.memory, self.learner
         nb, bs = self.idx.shape
         fused = lr.fused_eligible(mem)
@@ -310,7 +339,9 @@ class PPO_Agent:
             self._update_distributed()
         elif self.use_graph:
             if self._update_graph is None:
-                if self.learner.fused_eligible(self.memory):
+                if self.rem:
+                    self.learner.prepare_buffer_update(self.memory, self.batch_size)
+                elif self.learner.fused_eligible(self.memory):
                     self.learner.prepare_fused(self.memory, self.batch_size)
                     self.learner.prepare_rows(self.idx.numel())
                 else:
@@ -323,8 +354,8 @@ class PPO_Agent:
             self._update_graph.launch()
         else:
             self._enqueue_update()
-        self.learner.iterations += self.idx.shape[0]
-        return self.learner.last_info(self.batch_size)
+        self.learner.iterations += self.idx.shape[0] + (self.n_epochs if self.rem else 0)
+        return self.learner.last_info(self.rem if self.rem else self.batch_size)
 
     def train(self, train_steps):
         """Runs ``train_steps`` vector steps (rounded up to whole rollouts of horizon_size steps)."""

@@ -242,8 +242,8 @@ class PPO_Learner(Learner):
         flags = [1 if (n == "advantages" and stats is not None) else 0 for n in names]
         ops.soa_gather([(st[n], f.fields[n], f.row_bytes[n]) for n in names], idx, memory.n_envs, memory.n_size,
                        stats=stats, flags=flags)
-        M = idx.numel()
-        obs = st["observations"].view(M, -1)
+        M = idx.numel()                                     # (a short final minibatch uses the first M staging rows)
+        obs = st["observations"][:M].view(M, -1)
         self._last_S = self._step(obs, obs.shape[1], st["actions"], st["returns"], st["advantages"], st["aux_old_logp"], M,
                                   finish=finish)
         self._last_partials = self.partials
