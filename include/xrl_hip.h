@@ -281,6 +281,24 @@ typedef struct {
 } xrl_synth_ctl_t;
 int xrl_synth_control_step(const xrl_synth_ctl_t* p, int reset, xrl_stream_t stream);
 
+/* SMAC-3m-shaped multi-agent input provider (no simulator in the image; docs/source/documents/benchmark/smac/smac.rst:15,19
+ * for the agent count / episode limit): per step fresh observations [n][N*O], global state [n][S] and availability masks
+ * [n][N*A] (action 0 always available), team reward, episode end with probability p_term or at max_steps, auto-reset
+ * (next_* = what the step returned, buf_* = what the agents act on next).  Input provider, not part of the measured path. */
+typedef struct {
+    float* buf_obs; float* buf_state; float* buf_avail;      /* acted on next (post-reset) */
+    float* next_obs; float* next_state; float* next_avail;   /* returned by this step (pre-reset) */
+    const int32_t* action;                                   /* [n][N] */
+    float* rewards; float* terminals;                        /* [n][N] */
+    float* terminated; float* truncated; float* done;        /* [n] */
+    int32_t* steps; int32_t* end_step;                       /* [n] running / final step count of the episode */
+    int32_t n, N, O, S, A, max_steps;
+    float p_term, pad;
+    uint64_t seed;
+    uint32_t step; const uint32_t* step_dev;
+} xrl_synth_marl_t;
+int xrl_synth_marl_step(const xrl_synth_marl_t* p, int reset, xrl_stream_t stream);
+
 /* Per-step bookkeeping of PPO_Agent.train (ppo_agent.py:128,144-157): reward normalisation + store,
  * path-end flags, return tracker and ret_rms updates in env order, normalised next_obs for bootstrapping. */
 typedef struct {

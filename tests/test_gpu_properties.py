@@ -176,3 +176,44 @@ def test_update_phase_is_deterministic_at_c2_size():
         torch.cuda.synchronize()
         out.append((a.model.params.flat.clone(), a.memory.soa.fields["advantages"].clone()))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_synthetic_marl_provider_semantics():
+    """The SMAC-shaped provider (one launch per vector step): auto-reset, availability of action 0, episode limits,
+    determinism per seed, reward formula."""
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    n, T = 96, 12
+    runs = []
+    for rep in range(2):
+        env = SyntheticSMACVecEnv(n, seed=5, max_episode_steps=T, p_term=0.05)
+        env.reset()
+        assert float(env.buf_avail[:, :, 0].min()) == 1.0 and int(env.steps.abs().sum()) == 0
+        g = torch.Generator(device="cpu").manual_seed(0)
+        trace, steps_host = [], np.zeros(n, np.int64)
+        for t in range(40):
+            state0 = env.buf_state.clone()
+            env.action.copy_(torch.randint(0, env.n_actions, (n, env.n_agents), generator=g, dtype=torch.int32))
+            env.step_device()
+            torch.cuda.synchronize()
+            steps_host += 1
+            term, trunc, done = env.terminated.cpu().numpy(), env.truncated.cpu().numpy(), env.done.cpu().numpy()
+            assert np.array_equal(done, np.maximum(term, trunc)) and not np.any((term > 0) & (trunc > 0))
+            assert np.array_equal(trunc > 0, (term == 0) & (steps_host >= T))
+            assert np.array_equal(env.end_step.cpu().numpy(), steps_host)
+            steps_host[done > 0] = 0
+            assert np.array_equal(env.steps.cpu().numpy(), steps_host)
+            cont = torch.from_numpy(done == 0).cuda()
+            assert torch.equal(env.buf_obs[cont], env.next_obs[cont]) and torch.equal(env.buf_state[cont], env.next_state[cont])
+            if (~cont).any():
+                assert not torch.equal(env.buf_obs[~cont], env.next_obs[~cont])
+            assert float(env.buf_avail[:, :, 0].min()) == 1.0 and float(env.next_avail[:, :, 0].min()) == 1.0
+            rew = env.action.float().mean(1) / env.n_actions + 0.1 * state0[:, 0]
+            assert torch.allclose(env.rewards, rew[:, None].expand(-1, env.n_agents), atol=1e-6)
+            assert torch.equal(env.terminals, env.terminated[:, None].expand(-1, env.n_agents))
+            trace.append(torch.cat([env.next_obs.flatten(), env.next_state.flatten(), env.next_avail.flatten(), env.done]).cpu())
+        runs.append(torch.stack(trace))
+    assert torch.equal(runs[0], runs[1])
+    x = runs[0][:, :n * 3 * 30]
+    assert abs(float(x.mean())) < 0.02 and abs(float(x.std()) - 1.0) < 0.02
+    avail = runs[0][:, n * 3 * 30 + n * 48: n * 3 * 30 + n * 48 + n * 27].reshape(-1, 9)[:, 1:]
+    assert abs(float(avail.mean()) - 0.7) < 0.02

@@ -239,6 +239,56 @@ __global__ void __launch_bounds__(256) synth_control_kernel(xrl_synth_ctl_t p, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------ synthetic multi-agent env
+// SMAC-3m-shaped input provider (no simulator in this image): N agents, per-agent observations, a global state and
+// action-availability masks drawn from Philox streams keyed by (seed, env, step); team reward from the chosen actions and
+// the state; episodes end with probability p_term per step or at max_steps; auto-reset like the reference's vector envs
+// (the returned next_* are the terminal ones, buf_* already hold the first step of the next episode).  One wavefront per env.
+__device__ __forceinline__ float synth_uniform(uint64_t seed, uint32_t e, uint32_t step, uint32_t j) {
+    uint32_t r[4];
+    philox4x32(seed, e, step, 0x554E4900u + j, r);
+    return u01(r[0]);
+}
+
+__global__ void __launch_bounds__(256) synth_marl_kernel(xrl_synth_marl_t p, int reset) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= p.n) return;
+    const int N = p.N, NO = p.N * p.O, NA = p.N * p.A, S = p.S;
+    const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
+    // stream ids: 2 * step (+1 for the post-reset draw); element spaces: obs [0, NO), state [4096, ..), avail [8192, ..)
+    auto draw = [&](uint32_t st, float* obs, float* state, float* avail) {
+        for (int j = lane; j < NO; j += 64) obs[(size_t)e * NO + j] = synth_normal(p.seed, (uint32_t)e, st, (uint32_t)j);
+        for (int j = lane; j < S; j += 64) state[(size_t)e * S + j] = synth_normal(p.seed, (uint32_t)e, st, 4096u + (uint32_t)j);
+        for (int j = lane; j < NA; j += 64)
+            avail[(size_t)e * NA + j] = (j % p.A == 0 || synth_uniform(p.seed, (uint32_t)e, st, 8192u + (uint32_t)j) < 0.7f) ? 1.f : 0.f;
+    };
+    if (reset) {
+        draw(0xfffffff0u, p.buf_obs, p.buf_state, p.buf_avail);
+        if (lane == 0) { p.steps[e] = 0; p.done[e] = 0.f; p.end_step[e] = 0; }
+        return;
+    }
+    float asum = 0.f;
+    for (int a = 0; a < N; ++a) asum += (float)p.action[(size_t)e * N + a];
+    const float rew = asum / (float)N / (float)p.A + 0.1f * p.buf_state[(size_t)e * S];
+    const int steps = p.steps[e] + 1;
+    const bool term = synth_uniform(p.seed, (uint32_t)e, 2u * step, 16384u) < p.p_term;
+    const bool trunc = !term && steps >= p.max_steps;
+    const bool done = term || trunc;
+    draw(2u * step, p.next_obs, p.next_state, p.next_avail);
+    if (done) {
+        draw(2u * step + 1u, p.buf_obs, p.buf_state, p.buf_avail);
+    } else {
+        for (int j = lane; j < NO; j += 64) p.buf_obs[(size_t)e * NO + j] = p.next_obs[(size_t)e * NO + j];
+        for (int j = lane; j < S; j += 64) p.buf_state[(size_t)e * S + j] = p.next_state[(size_t)e * S + j];
+        for (int j = lane; j < NA; j += 64) p.buf_avail[(size_t)e * NA + j] = p.next_avail[(size_t)e * NA + j];
+    }
+    if (lane < N) { p.rewards[(size_t)e * N + lane] = rew; p.terminals[(size_t)e * N + lane] = term ? 1.f : 0.f; }
+    if (lane == 0) {
+        p.terminated[e] = term ? 1.f : 0.f; p.truncated[e] = trunc ? 1.f : 0.f; p.done[e] = done ? 1.f : 0.f;
+        p.end_step[e] = steps; p.steps[e] = done ? 0 : steps;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ post-step bookkeeping
 
 constexpr int POST_THREADS = 1024;
@@ -409,6 +459,17 @@ extern "C" int xrl_synth_control_step(const xrl_synth_ctl_t* params, int reset, 
     XRL_CHECK_ARG(p.state && p.obs && p.steps && p.ep_score && p.n > 0 && p.D > 0 && p.D <= 32 && p.A > 0 && p.A <= 16);
     if (!reset) XRL_CHECK_ARG(p.action && p.next_obs && p.reward && p.terminated && p.truncated && p.stats && p.Amat && p.Bmat);
     hipLaunchKernelGGL(synth_control_kernel, dim3((p.n + 3) / 4), dim3(256), 0, as_stream(stream), p, reset);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_synth_marl_step(const xrl_synth_marl_t* params, int reset, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_synth_marl_t& p = *params;
+    XRL_CHECK_ARG(p.buf_obs && p.buf_state && p.buf_avail && p.steps && p.done && p.end_step && p.n > 0);
+    XRL_CHECK_ARG(p.N > 0 && p.N <= 64 && p.O > 0 && p.A > 0 && p.S > 0 && p.N * p.O < 4096 && p.S < 4096 && p.N * p.A < 4096);
+    if (!reset) XRL_CHECK_ARG(p.action && p.next_obs && p.next_state && p.next_avail && p.rewards && p.terminals && p.terminated && p.truncated);
+    hipLaunchKernelGGL(synth_marl_kernel, dim3((p.n + 3) / 4), dim3(256), 0, as_stream(stream), p, reset);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

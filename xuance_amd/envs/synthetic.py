@@ -108,12 +108,15 @@ class SyntheticMujocoVecEnv(_Base):
 
 class SyntheticSMACVecEnv(_Base):
     """SMAC map 3m shape: 3 agents, obs (30,), state (48,), 9 actions with availability masks, 60-step episodes
-    (docs/source/documents/benchmark/smac/smac.rst:15,19; obs/state/action dims are SMAC-upstream values)."""
+    (docs/source/documents/benchmark/smac/smac.rst:15,19; obs/state/action dims are SMAC-upstream values).
+    One native launch per vector step (xrl_synth_marl_step; Philox streams keyed by seed / env / step)."""
+    graph_safe = True
 
     def __init__(self, num_envs, seed=1, device="cuda", n_agents=3, obs_dim=30, state_dim=48, n_actions=9,
-                 max_episode_steps=60):
+                 max_episode_steps=60, p_term=0.01):
         super().__init__(num_envs, seed, device, max_episode_steps)
         self.n_agents, self.obs_dim, self.state_dim, self.n_actions = n_agents, obs_dim, state_dim, n_actions
+        self.seed, self.p_term = int(seed), float(p_term)
         self.agent_keys = [f"agent_{i}" for i in range(n_agents)]
         self.observation_space = {k: Box(-np.inf, np.inf, (obs_dim,), np.float32) for k in self.agent_keys}
         self.action_space = {k: Discrete(n_actions) for k in self.agent_keys}
@@ -128,29 +131,24 @@ class SyntheticSMACVecEnv(_Base):
                                                            torch.ones_like(self.buf_avail))
         self.rewards = torch.zeros(n, N, device=device)
         self.terminals = torch.zeros(n, N, device=device)
+        self.done = torch.zeros(n, device=device)
+        self.end_step = torch.zeros(n, dtype=torch.int32, device=device)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
 
-    def _draw(self):
-        n, N = self.num_envs, self.n_agents
-        obs = torch.randn(n, N, self.obs_dim, device=self.device, generator=self.gen)
-        state = torch.randn(n, self.state_dim, device=self.device, generator=self.gen)
-        avail = (torch.rand(n, N, self.n_actions, device=self.device, generator=self.gen) < 0.7).float()
-        avail[..., 0] = 1.0                                   # no-op is always available (SMAC convention)
-        return obs, state, avail
+    def _kw(self):
+        return dict(buf_obs=self.buf_obs, buf_state=self.buf_state, buf_avail=self.buf_avail, next_obs=self.next_obs,
+                    next_state=self.next_state, next_avail=self.next_avail, action=self.action, rewards=self.rewards,
+                    terminals=self.terminals, terminated=self.terminated, truncated=self.truncated, done=self.done,
+                    steps=self.steps, end_step=self.end_step, n=self.num_envs, N=self.n_agents, O=self.obs_dim,
+                    S=self.state_dim, A=self.n_actions, max_steps=self.max_episode_steps, p_term=self.p_term, seed=self.seed,
+                    step=0, step_dev=self.step_counter)
 
     def reset(self):
-        o, s, a = self._draw()
-        self.buf_obs.copy_(o); self.buf_state.copy_(s); self.buf_avail.copy_(a)
-        self.steps.zero_()
+        from .. import ops
+        ops.synth_marl_step(reset=True, **self._kw())
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
     def step_device(self):
-        o, s, a = self._draw()
-        self.next_obs.copy_(o); self.next_state.copy_(s); self.next_avail.copy_(a)
-        r = (self.action.float().mean(1) / self.n_actions + 0.1 * self.buf_state[:, 0])
-        self.rewards.copy_(r[:, None].expand(-1, self.n_agents))          # shared team reward
-        done = self._end_of_step(0.01)
-        self.terminals.copy_(self.terminated[:, None].expand(-1, self.n_agents))
-        o2, s2, a2 = self._draw()
-        d3 = done[:, None, None]
-        self.buf_obs.copy_(torch.where(d3, o2, o)); self.buf_state.copy_(torch.where(done[:, None], s2, s))
-        self.buf_avail.copy_(torch.where(d3, a2, a))
+        from .. import ops
+        ops.synth_marl_step(**self._kw())
+        ops.counter_add(self.step_counter, 1)
