@@ -66,3 +66,100 @@ def test_two_ranks_share_gradients_and_stay_in_sync():
     assert not np.array_equal(pa, p0a)
     assert any(k.endswith("/rank_0") for k in ia) and any(k.endswith("/rank_1") for k in ib)   # ppo_learner.py:72-80
     assert ia["actor_loss/rank_0"] != ib["actor_loss/rank_1"]                                  # different env shards
+
+
+# ---------------------------------------------------------------------------------------------- off-policy learners, 2 ranks
+def _build_offpolicy(kind, distributed):
+    """(net, learner, call(batch) -> info, fixture) for a learner built from a reference fixture's initial parameters."""
+    from conftest import load_golden, sub
+    from test_gpu_dqn_qmix import base_cfg
+    from xuance_amd.learners import DQN_Learner, QMIX_Learner
+    from xuance_amd.nets import DeepQNet, MixingQNet
+    g = load_golden(kind)
+    lr, gamma, sync, gclip = (float(g["cfg"][i]) for i in range(4))
+    keys = [f"agent_{i}" for i in range(3)]
+    if kind == "dqn_mlp":
+        net = DeepQNet(6, 4, (64,), (64,), "relu")
+        net.load_state_dict(sub(g, "init"))
+        learner = DQN_Learner(base_cfg(learning_rate=lr, gamma=gamma, sync_frequency=int(sync), use_grad_clip=bool(g["cfg"][4]),
+                                       grad_clip_norm=gclip, distributed_training=distributed), net, None)
+        return net, learner, (lambda b: learner.update(batch_size=len(b["obs"]), **b)), g
+    rnn = "rnn" in kind
+    if rnn:
+        net = MixingQNet(3, 30, 9, 48, (), (64,), 32, 32, "relu", group=str(g["group"]), use_rnn=True, fc_hidden=(64,),
+                         recurrent_hidden=64)
+    else:
+        net = MixingQNet(3, 30, 9, 48, (64,), (64,), 32, 32, "relu", group=str(g["group"]))
+    net.load_state_dict(sub(g, "init"))
+    extra = dict(use_rnn=True, episode_length=12, running_steps=4800, rnn_backprop_agents=True) if rnn else {}
+    learner = QMIX_Learner(base_cfg(learning_rate=lr, gamma=gamma, sync_frequency=int(sync), use_grad_clip=True,
+                                    grad_clip_norm=gclip, double_q=bool(g["cfg"][4]), use_actions_mask=True,
+                                    use_parameter_sharing=True, n_epochs=8, distributed_training=distributed, **extra),
+                           keys, net, None)
+
+    def call(b):
+        per_agent = ("obs", "actions", "rewards", "terminals", "agent_mask", "avail_actions") + \
+                    (() if rnn else ("obs_next", "avail_actions_next"))
+        sample = {k: {a: b[k][:, i] for i, a in enumerate(keys)} for k in per_agent}
+        sample.update(state=b["state"], batch_size=len(b["state"]))
+        if rnn:
+            sample.update(filled=b["filled"], sequence_length=12)
+        else:
+            sample.update(state_next=b["state_next"])
+        return learner.update(sample)
+    return net, learner, call, g
+
+
+def _offpolicy_worker(rank, world, port, q, kind):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    from conftest import sub
+    from xuance_amd import dist as xd
+    torch.cuda.set_device(0)
+    xd.init_distributed_mode("gloo")
+    net, learner, call, g = _build_offpolicy(kind, True)
+    assert learner.world_size == 2
+    xd.broadcast_(net.params.flat, 0)            # (the fixtures start with target != eval on purpose: leave the target alone)
+    infos = [call(sub(g, f"u{(rank + u) % 2}/batch")) for u in range(2)]       # ranks see different batches every update
+    torch.cuda.synchronize()
+    q.put((rank, net.params.flat.cpu().numpy(), float(learner.optimizer.read().step), sorted(infos[-1].keys())))
+    xd.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["dqn_mlp", "qmix_ff_double", "qmix_rnn_double_fixed"])
+def test_offpolicy_learners_two_ranks(kind):
+    """DQN / QMIX with distributed_training: each rank updates on its own batch, the flat gradient is averaged between the
+    slab reduction and the optimiser launch (the reference wraps these models in DDP: deep_q_network.py:55-59,
+    value_factorization.py:44-48).  Ranks must stay bit-identical; for the feed-forward losses (a mean over the batch) the
+    result must equal ONE process updating on the concatenation of the two batches."""
+    import torch.multiprocessing as mp
+    from conftest import sub
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 300
+    procs = [ctx.Process(target=_offpolicy_worker, args=(r, 2, port, q, kind)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, pa, stepa, ka), (_, pb, stepb, kb) = res
+    assert stepa == stepb == 2 and np.array_equal(pa, pb)
+    net, learner, call, g = _build_offpolicy(kind, False)
+    p0 = net.params.flat.cpu().numpy().copy()
+    assert not np.array_equal(pa, p0)
+    if "rnn" in kind:
+        return                       # masked loss normalised by each rank's own sum(filled): not a mean over the concatenation
+    for u in range(2):
+        b0, b1 = sub(g, f"u{u % 2}/batch"), sub(g, f"u{(u + 1) % 2}/batch")
+        call({k: np.concatenate([b0[k], b1[k]]) for k in b0})
+    single = net.params.flat.cpu().numpy()
+    trainable = np.abs(single - p0) > 0
+    assert trainable.any()
+    np.testing.assert_allclose(pa[trainable], single[trainable], rtol=0, atol=3e-6)
