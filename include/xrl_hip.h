@@ -281,6 +281,22 @@ typedef struct {
 } xrl_synth_ctl_t;
 int xrl_synth_control_step(const xrl_synth_ctl_t* p, int reset, xrl_stream_t stream);
 
+/* Atari-shaped input provider (no emulator in the image; configs/dqn/atari.yaml:7-8 for the 84x84 x 4-frame uint8 shape):
+ * per step a fresh frame stack per env (next_obs), reward, episode end with probability p_term or at max_steps,
+ * auto-reset.  cur_obs (what the agent acts on next) must be a different buffer from the one it acted on in this step:
+ * the env alternates two, so (obs, next_obs) go to the replay ring without a copy.  Input provider, not measured path. */
+typedef struct {
+    uint8_t* cur_obs; uint8_t* next_obs;                     /* [n][row_bytes] */
+    const int32_t* action;                                   /* [n] */
+    float* reward; float* terminated; float* truncated; float* done;   /* [n] */
+    int32_t* steps; int32_t* end_step;                       /* [n] */
+    int32_t n, row_bytes, A, max_steps;
+    float p_term, pad;
+    uint64_t seed;
+    uint32_t step; const uint32_t* step_dev;
+} xrl_synth_frames_t;
+int xrl_synth_frames_step(const xrl_synth_frames_t* p, int reset, xrl_stream_t stream);
+
 /* SMAC-3m-shaped multi-agent input provider (no simulator in the image; docs/source/documents/benchmark/smac/smac.rst:15,19
  * for the agent count / episode limit): per step fresh observations [n][N*O], global state [n][S] and availability masks
  * [n][N*A] (action 0 always available), team reward, episode end with probability p_term or at max_steps, auto-reset

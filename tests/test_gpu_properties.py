@@ -217,3 +217,39 @@ def test_synthetic_marl_provider_semantics():
     assert abs(float(x.mean())) < 0.02 and abs(float(x.std()) - 1.0) < 0.02
     avail = runs[0][:, n * 3 * 30 + n * 48: n * 3 * 30 + n * 48 + n * 27].reshape(-1, 9)[:, 1:]
     assert abs(float(avail.mean()) - 0.7) < 0.02
+
+
+def test_synthetic_frame_provider_semantics():
+    """The Atari-shaped provider: alternating observation buffers (the acted-on frames survive the step), auto-reset,
+    reward rule, episode limits, determinism per seed, uniform bytes."""
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    n, T = 48, 9
+    runs = []
+    for rep in range(2):
+        env = SyntheticAtariVecEnv(n, seed=4, max_episode_steps=T, p_term=0.05)
+        env.reset()
+        g = torch.Generator(device="cpu").manual_seed(0)
+        steps_host, sums = np.zeros(n, np.int64), []
+        for t in range(30):
+            acted_on = env.buf_obs
+            snapshot = acted_on.clone()
+            env.action.copy_(torch.randint(0, 4, (n,), generator=g, dtype=torch.int32))
+            env.step_device()
+            torch.cuda.synchronize()
+            assert env.buf_obs.data_ptr() != acted_on.data_ptr() and torch.equal(acted_on, snapshot)
+            assert np.array_equal(env.reward.cpu().numpy(), (env.action.cpu().numpy() == steps_host % 4).astype(np.float32))
+            steps_host += 1
+            term, trunc, done = env.terminated.cpu().numpy(), env.truncated.cpu().numpy(), env.done.cpu().numpy()
+            assert np.array_equal(done, np.maximum(term, trunc)) and np.array_equal(trunc > 0, (term == 0) & (steps_host >= T))
+            assert np.array_equal(env.end_step.cpu().numpy(), steps_host)
+            steps_host[done > 0] = 0
+            assert np.array_equal(env.steps.cpu().numpy(), steps_host)
+            cont = torch.from_numpy(done == 0).cuda()
+            assert torch.equal(env.buf_obs[cont], env.next_obs[cont])
+            if (~cont).any():
+                assert not torch.equal(env.buf_obs[~cont], env.next_obs[~cont])
+            sums.append(torch.cat([env.next_obs.flatten()[::97].float(), env.done]).cpu())
+        runs.append(torch.stack(sums))
+        x = env.next_obs.float()
+        assert abs(float(x.mean()) - 127.5) < 0.5 and abs(float(x.std()) - 73.9) < 0.5
+    assert torch.equal(runs[0], runs[1])

@@ -154,6 +154,13 @@ class SynthCtl(C.Structure):
                 ("A", c_int32), ("max_steps", c_int32), ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
 
 
+class SynthFrames(C.Structure):
+    _fields_ = [("cur_obs", c_void_p), ("next_obs", c_void_p), ("action", c_void_p), ("reward", c_void_p),
+                ("terminated", c_void_p), ("truncated", c_void_p), ("done", c_void_p), ("steps", c_void_p),
+                ("end_step", c_void_p), ("n", c_int32), ("row_bytes", c_int32), ("A", c_int32), ("max_steps", c_int32),
+                ("p_term", c_float), ("pad", c_float), ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
+
+
 class SynthMarl(C.Structure):
     _fields_ = [("buf_obs", c_void_p), ("buf_state", c_void_p), ("buf_avail", c_void_p), ("next_obs", c_void_p),
                 ("next_state", c_void_p), ("next_avail", c_void_p), ("action", c_void_p), ("rewards", c_void_p),
@@ -216,6 +223,7 @@ _SIGS = {
     "xrl_lstm_forward": [C.POINTER(LstmFwd), c_void_p],
     "xrl_lstm_backward": [C.POINTER(LstmBwd), c_void_p],
     "xrl_synth_marl_step": [C.POINTER(SynthMarl), c_int, c_void_p],
+    "xrl_synth_frames_step": [C.POINTER(SynthFrames), c_int, c_void_p],
     "xrl_gru_forward": [C.POINTER(GruFwd), c_void_p],
     "xrl_gru_backward": [C.POINTER(GruBwd), c_void_p],
     "xrl_sync_target": [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p],

@@ -51,6 +51,7 @@ class DQN_Agent:
         self.X = torch.zeros(n, D, dtype=xdt, device=dev)      # processed observation
         self.Xn = torch.zeros(n, D, dtype=xdt, device=dev)     # processed next observation
         self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
+        self._eps_on_device = self.e_greedy
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.act_f = torch.zeros(n, device=dev)
         self.model.plan.ensure(max(n, 2 * config.batch_size))
@@ -80,7 +81,9 @@ class DQN_Agent:
         if self.e_greedy is not None:
             if self.e_greedy > self.end_greedy:
                 self.e_greedy = self.start_greedy - self.current_step * self.delta_egreedy
-        self.eps_dev.fill_(float(self.e_greedy))
+        if self.e_greedy != self._eps_on_device:
+            self.eps_dev.fill_(float(self.e_greedy))
+            self._eps_on_device = self.e_greedy
 
     def _normalize(self, raw, out, update):
         n, D = self.n_envs, self.obs_dim
@@ -97,20 +100,31 @@ class DQN_Agent:
             env.reset()
             self._started = True
         info = {}
+        zero_copy = self.atari and getattr(env, "double_buffered", False)     # uint8 frames go to the ring as they are
+        shp = (n,) + tuple(self.obs_shape)
         for _ in range(train_steps):
-            self._normalize(env.buf_obs if self.atari else env.buf_obs.float(), self.X, update=True)   # obs_rms.update; process
-            q = self.model.forward(self.X[:n], n)
+            if zero_copy:
+                X = env.buf_obs.view(n, -1)                   # stays intact over step_device(): the env alternates buffers
+            else:
+                self._normalize(env.buf_obs if self.atari else env.buf_obs.float(), self.X, update=True)   # obs_rms.update; process
+                X = self.X
+            q = self.model.forward(X[:n], n)
             ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=A, seed=self.seed,
                         step=0, step_dev=self.step_counter)
             env.step_device()
             ops.counter_add(self.step_counter, 1)
-            self._normalize(env.next_obs if self.atari else env.next_obs.float(), self.Xn, update=False)
-            self.memory.store(self.X.view((n,) + tuple(self.obs_shape)), self.act_f, env.reward, env.terminated,
-                              self.Xn.view((n,) + tuple(self.obs_shape)))
+            if zero_copy:
+                Xn = env.next_obs.view(n, -1)
+            else:
+                self._normalize(env.next_obs if self.atari else env.next_obs.float(), self.Xn, update=False)
+                Xn = self.Xn
+            self.memory.store(X.view(shp), self.act_f, env.reward, env.terminated, Xn.view(shp))
             if self.current_step > self.start_training and self.current_step % self.training_frequency == 0:
-                info = self._train_epochs(train_steps)
+                info = self._train_epochs(train_steps) or info
             self.current_step += n
             self._update_explore_factor()
+        if self.use_graph_updates and hasattr(self.learner, "flush_info"):
+            info = dict(self.learner.flush_info() or info)      # the one host read of this call (phases ran unsynchronised)
         if hasattr(env, "episode_stats"):
             eps, score, length = env.episode_stats()
             info.update({"episodes": eps, "mean_episode_score": score, "mean_episode_length": length})
@@ -119,7 +133,7 @@ class DQN_Agent:
 
     def _train_epochs(self, train_steps):
         if self.use_graph_updates:
-            return self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed)
+            return self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed, sync=False)
         info = {}
         for _e in range(self.n_epochs):
             info = self.learner.update(**self.memory.sample())

@@ -94,7 +94,9 @@ class QMIX_Agents:
             self.e_greedy = self.start_greedy - self.delta_egreedy * self.current_step
         else:
             self.e_greedy = self.end_greedy
-        self.eps_dev.fill_(float(self.e_greedy))
+        if self.e_greedy != getattr(self, "_eps_on_device", None):
+            self.eps_dev.fill_(float(self.e_greedy))
+            self._eps_on_device = self.e_greedy
 
     def run_episodes(self, n_episodes):                        # off_policy_marl.py:426-546 (training mode)
         env, n, N, A, mem = self.envs, self.n_envs, self.n_agents, self.n_actions, self.memory
@@ -133,10 +135,11 @@ class QMIX_Agents:
             self.run_episodes(self.n_envs)
             if self.current_step >= self.start_training:
                 if self.use_graph_updates:
-                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed)
+                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed, sync=False) or info
                 else:
                     for _e in range(self.n_epochs):
                         info = self.learner.update(self.memory.sample())
+        info = dict(self.learner.flush_info() or info)          # update phases ran unsynchronised: read the last one's info
         info["epsilon"] = self.e_greedy
         return info
 
@@ -162,12 +165,13 @@ class QMIX_Agents:
                               avail_actions=avail, avail_actions_next=env.next_avail)
             if self.current_step >= self.start_training and self.current_step % self.training_frequency == 0:
                 if self.use_graph_updates:
-                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed)
+                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed, sync=False) or info
                 else:
                     for _e in range(self.n_epochs):
                         info = self.learner.update(self.memory.sample())
             self.current_step += n
             self._update_explore_factor()
+        info = dict(self.learner.flush_info() or info)          # update phases ran unsynchronised: read the last one's info
         info["epsilon"] = self.e_greedy
         return info
 

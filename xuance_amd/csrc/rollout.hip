@@ -289,6 +289,50 @@ __global__ void __launch_bounds__(256) synth_marl_kernel(xrl_synth_marl_t p, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------ synthetic frame env
+// Atari-shaped input provider (no emulator in this image): uint8 frame stacks drawn from Philox streams keyed by
+// (seed, env, step), 16 bytes per draw; reward 1 when the action equals (step count mod A); episodes end with probability
+// p_term per step or at max_steps; auto-reset (next_obs = the frame the step returned, cur_obs = what the agent acts on
+// next).  cur_obs is a DIFFERENT buffer from the one the agent just acted on (the env alternates two), so the agent can
+// store (obs, next_obs) without copying either.  One workgroup per env.
+__global__ void __launch_bounds__(256) synth_frames_kernel(xrl_synth_frames_t p, int reset) {
+    const int e = blockIdx.x, tid = threadIdx.x, W = p.row_bytes / 16;
+    uint4* cur = reinterpret_cast<uint4*>(p.cur_obs + (size_t)e * p.row_bytes);
+    if (reset) {
+        for (int w = tid; w < W; w += 256) {
+            uint32_t r[4];
+            philox4x32(p.seed, (uint32_t)e, 0xfffffff0u, (uint32_t)w, r);
+            cur[w] = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        if (tid == 0) { p.steps[e] = 0; p.done[e] = 0.f; p.end_step[e] = 0; }
+        return;
+    }
+    const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
+    const int before = p.steps[e], steps = before + 1;
+    uint32_t c[4];
+    philox4x32(p.seed, (uint32_t)e, 2u * step, 0x80000000u, c);
+    const bool term = u01(c[0]) < p.p_term, trunc = !term && steps >= p.max_steps, done = term || trunc;
+    uint4* nxt = reinterpret_cast<uint4*>(p.next_obs + (size_t)e * p.row_bytes);
+    for (int w = tid; w < W; w += 256) {
+        uint32_t r[4];
+        philox4x32(p.seed, (uint32_t)e, 2u * step, (uint32_t)w, r);
+        const uint4 v = make_uint4(r[0], r[1], r[2], r[3]);
+        nxt[w] = v;
+        if (done) {
+            philox4x32(p.seed, (uint32_t)e, 2u * step + 1u, (uint32_t)w, r);
+            cur[w] = make_uint4(r[0], r[1], r[2], r[3]);
+        } else {
+            cur[w] = v;
+        }
+    }
+    __syncthreads();                                     // every thread has read steps[e]
+    if (tid == 0) {
+        p.reward[e] = (p.action[e] == before % p.A) ? 1.f : 0.f;
+        p.terminated[e] = term ? 1.f : 0.f; p.truncated[e] = trunc ? 1.f : 0.f; p.done[e] = done ? 1.f : 0.f;
+        p.end_step[e] = steps; p.steps[e] = done ? 0 : steps;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ post-step bookkeeping
 
 constexpr int POST_THREADS = 1024;
@@ -459,6 +503,16 @@ extern "C" int xrl_synth_control_step(const xrl_synth_ctl_t* params, int reset, 
     XRL_CHECK_ARG(p.state && p.obs && p.steps && p.ep_score && p.n > 0 && p.D > 0 && p.D <= 32 && p.A > 0 && p.A <= 16);
     if (!reset) XRL_CHECK_ARG(p.action && p.next_obs && p.reward && p.terminated && p.truncated && p.stats && p.Amat && p.Bmat);
     hipLaunchKernelGGL(synth_control_kernel, dim3((p.n + 3) / 4), dim3(256), 0, as_stream(stream), p, reset);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_synth_frames_step(const xrl_synth_frames_t* params, int reset, xrl_stream_t stream) {
+    XRL_CHECK_ARG(params != nullptr);
+    const xrl_synth_frames_t& p = *params;
+    XRL_CHECK_ARG(p.cur_obs && p.steps && p.done && p.end_step && p.n > 0 && p.row_bytes > 0 && p.row_bytes % 16 == 0);
+    if (!reset) XRL_CHECK_ARG(p.next_obs && p.action && p.reward && p.terminated && p.truncated && p.A > 0 && p.cur_obs != p.next_obs);
+    hipLaunchKernelGGL(synth_frames_kernel, dim3(p.n), dim3(256), 0, as_stream(stream), p, reset);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

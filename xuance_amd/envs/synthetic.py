@@ -36,30 +36,44 @@ class _Base:
 
 
 class SyntheticAtariVecEnv(_Base):
-    """84x84x4 uint8 frame stacks, Discrete(4) (Breakout-shaped, configs/dqn/atari.yaml:7-8)."""
+    """84x84x4 uint8 frame stacks, Discrete(4) (Breakout-shaped, configs/dqn/atari.yaml:7-8).  One native launch per
+    vector step (xrl_synth_frames_step).  `double_buffered`: step_device() leaves the tensor that was `buf_obs` before the
+    call untouched and rebinds `buf_obs` to the other of two buffers, so an agent can hand (obs, next_obs) to the replay
+    ring without copying the 28 KB frames."""
+    graph_safe = False          # buf_obs alternates between two tensors: addresses change from step to step
+    double_buffered = True
 
-    def __init__(self, num_envs, seed=1, device="cuda", n_actions=4, max_episode_steps=1000):
+    def __init__(self, num_envs, seed=1, device="cuda", n_actions=4, max_episode_steps=1000, p_term=0.002):
         super().__init__(num_envs, seed, device, max_episode_steps)
+        self.seed, self.p_term = int(seed), float(p_term)
         self.observation_space = Box(0, 255, (84, 84, 4), np.uint8)
         self.action_space = Discrete(n_actions)
-        self.buf_obs = torch.zeros(self.num_envs, 84, 84, 4, dtype=torch.uint8, device=device)
+        self._bufs = [torch.zeros(self.num_envs, 84, 84, 4, dtype=torch.uint8, device=device) for _ in range(2)]
+        self._cur = 0
+        self.buf_obs = self._bufs[0]
         self.next_obs = torch.zeros_like(self.buf_obs)
         self.action = torch.zeros(self.num_envs, dtype=torch.int32, device=device)
+        self.done = torch.zeros(self.num_envs, device=device)
+        self.end_step = torch.zeros(self.num_envs, dtype=torch.int32, device=device)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
 
-    def _frames(self):
-        return torch.randint(0, 256, self.buf_obs.shape, dtype=torch.uint8, device=self.device, generator=self.gen)
+    def _kw(self, cur):
+        return dict(cur_obs=cur, next_obs=self.next_obs, action=self.action, reward=self.reward, terminated=self.terminated,
+                    truncated=self.truncated, done=self.done, steps=self.steps, end_step=self.end_step, n=self.num_envs,
+                    row_bytes=84 * 84 * 4, A=self.action_space.n, max_steps=self.max_episode_steps, p_term=self.p_term,
+                    seed=self.seed, step=0, step_dev=self.step_counter)
 
     def reset(self):
-        self.buf_obs.copy_(self._frames())
+        from .. import ops
+        ops.synth_frames_step(reset=True, **self._kw(self.buf_obs))
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
     def step_device(self):
-        self.next_obs.copy_(self._frames())
-        self.reward = (self.action == (self.steps % self.action_space.n)).float()
-        done = self._end_of_step(0.002)
-        self.buf_obs.copy_(self.next_obs)
-        if bool(done.any()):
-            self.buf_obs[done] = self._frames()[done]
+        from .. import ops
+        self._cur ^= 1
+        ops.synth_frames_step(**self._kw(self._bufs[self._cur]))
+        self.buf_obs = self._bufs[self._cur]
+        ops.counter_add(self.step_counter, 1)
 
 
 class SyntheticMujocoVecEnv(_Base):

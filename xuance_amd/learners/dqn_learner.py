@@ -4,7 +4,7 @@ xuance/torch/learners/qlearning_family/dqn_learner.py:12-75 (MSE TD loss, max-ta
 import torch
 
 from .. import ops
-from .base import Learner, AdamHandle, LinearLRHandle
+from .base import _NullCallback, Learner, AdamHandle, LinearLRHandle
 from .ppo_learner import pick_n_split
 
 
@@ -67,11 +67,13 @@ class DQN_Learner(Learner):
         return S
 
     # ------------------------------------------------------------------ whole update phases straight from the HBM replay buffer
-    def update_from_buffer(self, memory, n_epochs=1, seed=1):
+    def update_from_buffer(self, memory, n_epochs=1, seed=1, sync=True):
         """`n_epochs` updates (sample -> gather -> forward / TD / backward -> Adam -> target sync) as ONE captured hipGraph
         launch: indices are drawn on the device (xrl_sample_replay_indices follows the filling ring through
         memory.size_dev), the gather writes the uint8 / float32 rows straight into the staging tensor the network reads.
-        Same arithmetic as update(**memory.sample()); one host sync per phase."""
+        Same arithmetic as update(**memory.sample()); one host sync per phase -- or none: with `sync=False` (and no user
+        callback to serve) the call returns None right after the launch, so the host goes on enqueueing the next vector
+        step while the update runs; `flush_info()` later returns the info of the last phase launched."""
         M, dev = memory.batch_size, self.model.params.device
         key = (id(memory), n_epochs, M)
         if getattr(self, "_buf_graph_key", None) != key:
@@ -103,11 +105,24 @@ class DQN_Learner(Learner):
             self._buf_graph.launch()
         else:
             self._buf_enqueue()
+        self._pending_phase = (n_epochs, M)
+        if not sync and isinstance(self.callback, _NullCallback):
+            self.iterations += n_epochs
+            return None
+        return self._phase_info(count=True)
+
+    def flush_info(self):
+        """Info of the last update phase launched with sync=False ({} if there was none)."""
+        return self._phase_info(count=False) if getattr(self, "_pending_phase", None) else {}
+
+    def _phase_info(self, count):
+        n_epochs, M = self._pending_phase
+        self._pending_phase = None
         sums = self._epoch_sums.cpu().numpy()               # the one host sync of the phase
         st = self.optimizer.read()
         info, A = {}, self.n_actions
         for e in range(n_epochs):
-            self.iterations += 1
+            self.iterations += int(count)
             info = self.callback.on_update_start(self.iterations, policy=self.model, obs=self.X[:M], act=self._act,
                                                  next_obs=self.X[M:2 * M], rew=self._rew, termination=self._ter) or {}
             info.update({self._key("Qloss"): float(sums[e, 0] / M), self._key("predictQ"): float(sums[e, 1] / M),

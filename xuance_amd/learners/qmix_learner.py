@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from .base import Learner, AdamHandle, LinearLRHandle
+from .base import _NullCallback, Learner, AdamHandle, LinearLRHandle
 from .ppo_learner import pick_n_split
 
 
@@ -239,13 +239,15 @@ class QMIX_Learner(Learner):
         return dict(q_tot_eval=d[0], q_tot_next=d[1], q_tot_target=d[2])
 
     # ------------------------------------------------------------------ whole update phases straight from the HBM replay buffer
-    def update_from_buffer(self, memory, n_epochs=1, seed=1):
+    def update_from_buffer(self, memory, n_epochs=1, seed=1, sync=True):
         """`n_epochs` updates (sample -> gather -> forward / mixer TD / backward -> Adam -> target sync) as ONE captured
         hipGraph launch: indices are drawn on the device (xrl_sample_replay_indices, following the filling ring through
         memory.size_dev), the gather writes straight into the staging tensors the networks read, and the loss terms of
-        every update are read back with a single host sync at the end.  Same arithmetic as update(memory.sample())."""
+        every update are read back with a single host sync at the end.  Same arithmetic as update(memory.sample()).
+        With `sync=False` (and no user callback to serve) the call returns None right after the launch; `flush_info()`
+        later returns the info of the last phase launched."""
         if self.use_rnn:
-            return self._update_from_episodes(memory, n_epochs, seed)
+            return self._update_from_episodes(memory, n_epochs, seed, sync)
         B, m, dev = memory.batch_size, self.model, self.model.params.device
         key = (id(memory), n_epochs, B)
         if getattr(self, "_buf_graph_key", None) != key:
@@ -279,14 +281,35 @@ class QMIX_Learner(Learner):
             self._buf_graph.launch()
         else:
             self._buf_enqueue()
+        return self._finish_phase(("ff", n_epochs, B, None), sync)
+
+    def _finish_phase(self, phase, sync):
+        self._pending_phase = phase
+        if not sync and isinstance(self.callback, _NullCallback):
+            self.iterations += phase[1]
+            return None
+        return self._phase_info(count=True)
+
+    def flush_info(self):
+        """Info of the last update phase launched with sync=False ({} if there was none)."""
+        return self._phase_info(count=False) if getattr(self, "_pending_phase", None) else {}
+
+    def _phase_info(self, count):
+        kind, n_epochs, B, T = self._pending_phase
+        self._pending_phase = None
         sums = self._epoch_sums.cpu().numpy()               # the one host sync of the phase
-        st = self.optimizer.read()
+        st = self.optimizer.read() if kind == "ff" else None
         info = {}
         for e in range(n_epochs):
-            self.iterations += 1
+            self.iterations += int(count)
             info = self.callback.on_update_start(self.iterations, model=self.model) or {}
-            info.update(self._info_ff(B, sums[e], st.last_lr))
-            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **self._cb_ff(B)) or {})
+            if kind == "ff":
+                info.update(self._info_ff(B, sums[e], st.last_lr))
+                cb = self._cb_ff(B)
+            else:
+                info.update(self._info_rnn(B, T, sums[e]))
+                cb = self._cb_rnn(B, T)
+            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **cb) or {})
         return info
 
     def _info_ff(self, B, sums, lr):                            # qmix_learner.py:98-102
@@ -295,7 +318,7 @@ class QMIX_Learner(Learner):
     def _cb_ff(self, B):                                        # :108-110
         return dict(q_tot_eval=self.diag[:B], q_tot_next=self.diag[B:2 * B], q_tot_target=self.diag[2 * B:3 * B])
 
-    def _update_from_episodes(self, memory, n_epochs, seed):
+    def _update_from_episodes(self, memory, n_epochs, seed, sync=True):
         """Recurrent twin of update_from_buffer: episodes are drawn on the device (uniform over memory.size_dev, as
         np.random.choice(size, batch_size) does, memory_tools_marl.py:981), gathered time-major straight into the staging
         tensors (xrl_episode_gather) and the whole n_epochs phase replays as one hipGraph."""
@@ -332,14 +355,7 @@ class QMIX_Learner(Learner):
             self._buf_graph.launch()
         else:
             self._buf_enqueue()
-        sums = self._epoch_sums.cpu().numpy()
-        info = {}
-        for e in range(n_epochs):
-            self.iterations += 1
-            info = self.callback.on_update_start(self.iterations, model=self.model) or {}
-            info.update(self._info_rnn(B, T, sums[e]))
-            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **self._cb_rnn(B, T)) or {})
-        return info
+        return self._finish_phase(("rnn", n_epochs, B, T), sync)
 
     def update(self, sample):
         self.iterations += 1

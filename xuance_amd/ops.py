@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (SynthMarl, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -261,6 +261,10 @@ def cartpole_step(reset=False, **kw):
 
 def synth_control_step(reset=False, **kw):
     call("xrl_synth_control_step", C.byref(_struct(SynthCtl, kw)), int(bool(reset)), stream_ptr())
+
+
+def synth_frames_step(reset=False, **kw):
+    call("xrl_synth_frames_step", C.byref(_struct(SynthFrames, kw)), int(bool(reset)), stream_ptr())
 
 
 def synth_marl_step(reset=False, **kw):
