@@ -157,6 +157,10 @@ int xrl_ppo_loss_categorical(const xrl_ppo_loss_t* p, xrl_stream_t stream);
 int xrl_ppo_loss_gaussian(const xrl_ppo_loss_t* p, xrl_stream_t stream);
 /* out[j] = sum_s partials[s][j]  (float64 in, float64 out), j < width */
 int xrl_sum_partials(const double* partials, int n_rows, int width, double* out, xrl_stream_t stream);
+/* n_batches independent sums in one launch: batch b reads partials + b*in_stride, writes out + b*out_stride (elements);
+ * the loss terms of all updates of an update phase (n_epochs, e.g. off_policy_marl.py:341-343) leave with one launch. */
+int xrl_sum_partials_batched(const double* partials, int n_rows, int width, double* out, int n_batches, long in_stride,
+                             long out_stride, xrl_stream_t stream);
 
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_ + torch.optim.Adam(eps=1e-5) + LinearLR.step (ppo_learner.py:18-22,61-67;

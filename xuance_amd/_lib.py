@@ -253,6 +253,7 @@ _SIGS = {
     "xrl_ppo_loss_categorical": [C.POINTER(PpoLoss), c_void_p],
     "xrl_ppo_loss_gaussian": [C.POINTER(PpoLoss), c_void_p],
     "xrl_sum_partials": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "xrl_sum_partials_batched": [c_void_p, c_int, c_int, c_void_p, c_int, C.c_long, C.c_long, c_void_p],
     "xrl_grad_reduce": [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "xrl_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double, c_void_p],
     "xrl_adam_step_mirrored": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double,

@@ -105,9 +105,11 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
 }
 
 __global__ void __launch_bounds__(64) sum_partials_kernel(const double* __restrict__ partials, int n_rows, int width,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, long in_stride, long out_stride) {
     const int j = threadIdx.x;
     if (j >= width) return;
+    partials += (size_t)blockIdx.x * in_stride;       // one independent sum per block (xrl_sum_partials_batched)
+    out += (size_t)blockIdx.x * out_stride;
     double s = 0.0;
     int r = 0;
     for (; r + 8 <= n_rows; r += 8) {                 // loads issued 8 at a time; the summation order stays row by row
@@ -123,8 +125,10 @@ __global__ void __launch_bounds__(64) sum_partials_kernel(const double* __restri
 
 // Many rows (the recurrent QMIX update has T*B = 1920): 128 row chunks x 8 columns, fixed-order tree over the chunks.
 __global__ void __launch_bounds__(1024) sum_partials_wide_kernel(const double* __restrict__ partials, int n_rows, int width,
-                                                                 double* __restrict__ out) {
+                                                                 double* __restrict__ out, long in_stride, long out_stride) {
     __shared__ double sh[1024];
+    partials += (size_t)blockIdx.x * in_stride;
+    out += (size_t)blockIdx.x * out_stride;
     const int j = threadIdx.x & 7, c = threadIdx.x >> 3;                     // width <= 8 here
     const int per = (n_rows + 127) / 128;
     double s = 0.0;
@@ -170,12 +174,20 @@ extern "C" int xrl_ppo_loss_gaussian(const xrl_ppo_loss_t* p, xrl_stream_t strea
     return XRL_OK;
 }
 
-extern "C" int xrl_sum_partials(const double* partials, int n_rows, int width, double* out, xrl_stream_t stream) {
-    XRL_CHECK_ARG(partials && out && n_rows > 0 && width > 0 && width <= 64);
+extern "C" int xrl_sum_partials_batched(const double* partials, int n_rows, int width, double* out, int n_batches,
+                                        long in_stride, long out_stride, xrl_stream_t stream) {
+    XRL_CHECK_ARG(partials && out && n_rows > 0 && width > 0 && width <= 64 && n_batches > 0);
+    XRL_CHECK_ARG(n_batches == 1 || (in_stride >= (long)n_rows * width && out_stride >= width));
     if (n_rows > 256 && width <= 8)
-        hipLaunchKernelGGL(sum_partials_wide_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, n_rows, width, out);
+        hipLaunchKernelGGL(sum_partials_wide_kernel, dim3(n_batches), dim3(1024), 0, as_stream(stream), partials, n_rows, width,
+                           out, in_stride, out_stride);
     else
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), partials, n_rows, width, out);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(n_batches), dim3(64), 0, as_stream(stream), partials, n_rows, width, out,
+                           in_stride, out_stride);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
+}
+
+extern "C" int xrl_sum_partials(const double* partials, int n_rows, int width, double* out, xrl_stream_t stream) {
+    return xrl_sum_partials_batched(partials, n_rows, width, out, 1, 0, 0, stream);
 }

@@ -86,13 +86,17 @@ class DQN_Learner(Learner):
                    "rewards": self._rew, "terminals": self._ter}
             self._buf_S = pick_n_split(M)
 
+            self._phase_partials = torch.zeros(n_epochs, 32, 8, dtype=torch.float64, device=dev)
+
             def enqueue():
+                # per update: draw, gather, step; the draw counter and the loss sums are settled once per phase
                 for e in range(n_epochs):
-                    ops.sample_replay_indices(self._idx, memory.n_envs, memory.n_size, memory.size_dev, seed, 0, self._sample_counter)
-                    ops.counter_add(self._sample_counter, 1)
+                    ops.sample_replay_indices(self._idx, memory.n_envs, memory.n_size, memory.size_dev, seed, e, self._sample_counter)
                     memory.gather_into(self._idx, dst)
+                    self.partials = self._phase_partials[e]
                     S = self._step(M, self._act, self._rew, self._ter)
-                    ops.sum_partials(self.partials, S, 8, self._epoch_sums[e])
+                ops.counter_add(self._sample_counter, n_epochs)
+                ops.sum_partials_batched(self._phase_partials, S, 8, self._epoch_sums, n_epochs, 32 * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
             if not (self.distributed_training and self.world_size > 1):

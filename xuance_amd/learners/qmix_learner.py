@@ -262,13 +262,17 @@ class QMIX_Learner(Learner):
             if self.use_actions_mask:
                 dst["avail_actions_next"] = self.buf["avail_next"][:B].view(B, -1)
 
+            self._phase_partials = torch.zeros(n_epochs, B, 8, dtype=torch.float64, device=dev)
+
             def enqueue():
+                # per update: draw, gather, step; the draw counter and the loss sums are settled once per phase
                 for e in range(n_epochs):
-                    ops.sample_replay_indices(self._idx, memory.n_envs, memory.n_size, memory.size_dev, seed, 0, self._sample_counter)
-                    ops.counter_add(self._sample_counter, 1)
+                    ops.sample_replay_indices(self._idx, memory.n_envs, memory.n_size, memory.size_dev, seed, e, self._sample_counter)
                     memory.gather_into(self._idx, dst)
+                    self.partials = self._phase_partials[e]
                     self._step(B)
-                    ops.sum_partials(self.partials, B, 8, self._epoch_sums[e])
+                ops.counter_add(self._sample_counter, n_epochs)
+                ops.sum_partials_batched(self._phase_partials, B, 8, self._epoch_sums, n_epochs, B * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
             if not (self.distributed_training and self.world_size > 1):
@@ -336,13 +340,16 @@ class QMIX_Learner(Learner):
             if self.use_actions_mask:
                 dst["avail_actions"] = self.seq["avail"].view(T1, B, -1)
 
+            self._phase_partials = torch.zeros(n_epochs, T * B, 8, dtype=torch.float64, device=dev)
+
             def enqueue():
                 for e in range(n_epochs):
-                    ops.sample_replay_indices(self._idx, 1, memory.buffer_size, memory.size_dev, seed, 0, self._sample_counter)
-                    ops.counter_add(self._sample_counter, 1)
+                    ops.sample_replay_indices(self._idx, 1, memory.buffer_size, memory.size_dev, seed, e, self._sample_counter)
                     memory.gather_into(self._idx, dst)
+                    self.partials = self._phase_partials[e]
                     self._step_rnn(B, T)
-                    ops.sum_partials(self.partials, T * B, 8, self._epoch_sums[e])
+                ops.counter_add(self._sample_counter, n_epochs)
+                ops.sum_partials_batched(self._phase_partials, T * B, 8, self._epoch_sums, n_epochs, T * B * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()
             if not (self.distributed_training and self.world_size > 1) and getattr(self.config, "use_hip_graph", True):

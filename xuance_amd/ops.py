@@ -119,6 +119,11 @@ def sum_partials(partials, n_rows, width, out):
     call("xrl_sum_partials", ptr(partials), int(n_rows), int(width), ptr(out), stream_ptr())
 
 
+def sum_partials_batched(partials, n_rows, width, out, n_batches, in_stride, out_stride):
+    call("xrl_sum_partials_batched", ptr(partials), int(n_rows), int(width), ptr(out), int(n_batches), int(in_stride),
+         int(out_stride), stream_ptr())
+
+
 # ------------------------------------------------------------------------------------------ optimiser
 def adam_state_tensor(lr, total_iters, end_factor=1.0, eps=1e-5, weight_decay=0.0, device="cuda"):
     """Device-resident xrl_adam_state_t, returned as a uint8 tensor (use read_adam_state to inspect)."""
