@@ -116,33 +116,35 @@ class QMIX_Learner(Learner):
         S = pick_n_split(R)
         from ..nets import Plan
         # eval network on obs (+ next_obs for the double-Q argmax) and target network on next_obs (iql_learner.py:41-47,
-        # 63-71); eval hyper-networks on state, target ones on state_next: each pair is one grouped launch per layer
-        q_all, q_next = Plan.forward_many([(m.agent_plan, self.X, m.obs_dim, 2 * R if self.double_q else R, None),
-                                           (m.agent_target_plan, self.X[R:], m.obs_dim, R, m.target_flat)])
+        # 63-71); eval hyper-networks on state, target ones on state_next.  The four plans are independent until the
+        # mixer needs them all, so layer i of each goes into ONE grouped launch (3 launches for the whole forward)
+        items = [(m.agent_plan, self.X, m.obs_dim, 2 * R if self.double_q else R, None),
+                 (m.agent_target_plan, self.X[R:], m.obs_dim, R, m.target_flat)]
+        if self.mixer_mode == 0:
+            items += [(m.mixer_plan, self.states, m.state_dim, B, None),
+                      (m.mixer_target_plan, self.states[B:], m.state_dim, B, m.target_flat)]
+        outs = Plan.forward_many(items)
+        q_all, q_next = outs[0], outs[1]
         d_q = m.agent_plan.dacts[len(m.agent_plan.widths) - 1]
         common = dict(q_eval=q_all, q_next_eval=q_all[R:] if self.double_q else None, q_next=q_next,
                       actions=self.buf["actions"], avail_next=self.buf["avail_next"] if self.use_actions_mask else None,
                       agent_mask=self.buf["agent_mask"], rewards=self.buf["rewards"], terminals=self.buf["terminals"],
                       d_q=d_q, diag=self.diag, partials=self.partials, B=B, N=N, A=A, ldq=A, double_q=int(self.double_q),
                       gamma=float(self.gamma), mixer=self.mixer_mode)
+        back = [(m.agent_plan, self.X, m.obs_dim, R)]
         if self.mixer_mode == 0:
-            e_raw, t_raw = Plan.forward_many([(m.mixer_plan, self.states, m.state_dim, B, None),
-                                              (m.mixer_target_plan, self.states[B:], m.state_dim, B, m.target_flat)])
+            e_raw, t_raw = outs[2], outs[3]
             e_l1, t_l1 = m.mixer_plan.acts[1], m.mixer_target_plan.acts[1]
             d_l1, d_raw = m.mixer_plan.dacts[1], m.mixer_plan.dacts[2]
             ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]
             ops.qmix_mix_td(e_b1=e_l1.data_ptr() + 4 * 3 * m.HH, e_raw=e_raw, t_b1=t_l1.data_ptr() + 4 * 3 * m.HH, t_raw=t_raw,
                             d_e_b1=d_l1.data_ptr() + 4 * 3 * m.HH, d_e_raw=d_raw, H=H, ld_e1=ld1, ld_e2=ld2, ld_t1=ld1,
                             ld_t2=ld2, **common)
-            # data-gradient chains first, then the weight gradients of every layer of a plan as one grouped launch
-            wg = []
-            m.mixer_plan.backward(self.states, m.state_dim, B, self.slabs, S, defer_wgrad=wg)
-            ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
+            back.append((m.mixer_plan, self.states, m.state_dim, B))
         else:
             ops.qmix_mix_td(**common)                       # VDN: sum mixer; IQL: per-agent TD (no hyper-networks)
-        wg = []
-        m.agent_plan.backward(self.X, m.obs_dim, R, self.slabs, S, defer_wgrad=wg)
-        ops.linear_bwd_weight(wg, S, self.slabs.shape[1])
+        # data-gradient chains of both plans side by side, then every weight gradient of the update as one grouped launch
+        Plan.backward_many(back, self.slabs, S)
         self._finish_step(S)
 
     def _finish_step(self, S):

@@ -121,17 +121,17 @@ class Plan:
 
     @staticmethod
     def forward_many(items):
-        """Several plans of the same depth as ONE grouped launch per stage (e.g. an eval network and its target twin):
-        items = [(plan, x, ldx, M, flat)].  Returns each plan's output level."""
-        depth = len(items[0][0].stages)
-        assert all(len(it[0].stages) == depth for it in items)
+        """Several independent plans as ONE grouped launch per stage (an eval network and its target twin; the agent
+        networks and the mixer's hyper-networks): items = [(plan, x, ldx, M, flat)]; stage i of every plan that has one
+        goes into launch i.  Returns each plan's output level."""
+        depth = max(len(it[0].stages) for it in items)
         for plan, x, ldx, M, flat in items:
             plan.ensure(M)
         for si in range(depth):
             groups = []
             for plan, x, ldx, M, flat in items:
                 P = plan.params
-                for L in plan.stages[si]:
+                for L in (plan.stages[si] if si < len(plan.stages) else ()):
                     a, lda = plan._buf(plan.acts, L.in_level, L.in_off, x, ldx)
                     c, ldc = plan._buf(plan.acts, L.out_level, L.out_off, x, ldx)
                     groups.append(ops.gemm_desc(a, P.ptr(L.w_name, flat), c, M, L.N, L.K, lda, L.K, ldc,
@@ -170,6 +170,34 @@ class Plan:
                 ops.linear_bwd_weight(wg, n_split, stride)
             if dg:
                 ops.linear_bwd_data(dg)
+
+    @staticmethod
+    def backward_many(items, slabs, n_split):
+        """The backward passes of several independent plans together: items = [(plan, x, ldx, M)], every plan's dacts[last]
+        filled.  Step k launches the data-gradient GEMMs of each plan's k-th stage from the end as one group; all weight
+        gradients follow as one grouped launch (chunks of 8 groups)."""
+        wg, depth = [], max(len(it[0].stages) for it in items)
+        for k in range(depth):
+            dg = []
+            for plan, x, ldx, M in items:
+                si = len(plan.stages) - 1 - k
+                if si < 0:
+                    continue
+                P = plan.params
+                for L in plan.stages[si]:
+                    dy, lddy = plan._buf(plan.dacts, L.out_level, L.out_off, x, ldx)
+                    a, lda = plan._buf(plan.acts, L.in_level, L.in_off, x, ldx)
+                    wg.append(ops.gemm_desc(dy, a, slabs.data_ptr() + 4 * P.offsets[L.w_name], M, L.N, L.K, lddy, lda, L.K,
+                                            dbias=slabs.data_ptr() + 4 * P.offsets[L.b_name]))
+                    if L.in_level > 0:
+                        dx, lddx = plan._buf(plan.dacts, L.in_level, L.in_off, x, ldx)
+                        aux, ldaux = plan._buf(plan.acts, L.in_level, L.in_off, x, ldx)
+                        dg.append(ops.gemm_desc(dy, P.ptr(L.w_name, None), dx, M, L.K, L.N, lddy, L.K, lddx,
+                                                aux=aux, ldaux=ldaux, act=plan._act_of(L.in_level, L.in_off)))
+            for i in range(0, len(dg), 8):
+                ops.linear_bwd_data(dg[i:i + 8])
+        for i in range(0, len(wg), 8):
+            ops.linear_bwd_weight(wg[i:i + 8], n_split, slabs.shape[1])
 
     def backward_grouped(self, x, ldx, M, slabs, n_split, flat=None, dx0=None):
         """backward() with the data-gradient chain first and ALL weight gradients of the plan as one grouped launch
