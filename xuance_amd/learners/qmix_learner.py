@@ -207,10 +207,11 @@ class QMIX_Learner(Learner):
         R, BT = B * N, T * B
         S = pick_n_split(T1 * R)
         from ..nets import Plan
-        q_all, q_tgt = m.agent_forward_seq_pair(self.Xs, R, T1)                                # iql_learner.py:39-47, 53-57
-        # hyper-networks of the eval mixer (slots 0..T-1 are used) and of the target mixer (slots 1..T): grouped launches
-        e_raw, t_raw = Plan.forward_many([(m.mixer_plan, self.states_s, m.state_dim, T1 * B, None),
-                                          (m.mixer_target_plan, self.states_s, m.state_dim, T1 * B, m.target_flat)])
+        # agent networks over the sequences (iql_learner.py:39-47, 53-57); the hyper-networks of the eval mixer (slots
+        # 0..T-1 are used) and of the target mixer (slots 1..T) ride in the launches of the layers above the recurrence
+        q_all, q_tgt, e_raw, t_raw = m.agent_forward_seq_pair(
+            self.Xs, R, T1, ride_along=[(m.mixer_plan, self.states_s, m.state_dim, T1 * B, None),
+                                        (m.mixer_target_plan, self.states_s, m.state_dim, T1 * B, m.target_flat)])
         e_l1, t_l1 = m.mixer_plan.acts[1], m.mixer_target_plan.acts[1]
         d_l1, d_raw = m.mixer_plan.dacts[1], m.mixer_plan.dacts[2]
         ld1, ld2 = m.mixer_plan.widths[1], m.mixer_plan.widths[2]

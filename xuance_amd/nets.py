@@ -683,15 +683,17 @@ class MixingQNet:
         self._recurrence(gi, ws, R, T1, flat, which == 0, h0=h0, c0=c0, reset=reset, h_last=h_last, c_last=c_last)
         return self.post_plans[which].forward(ws["hs"][R:], self.RH, T1 * R, flat=flat)
 
-    def agent_forward_seq_pair(self, X, R, T1):
+    def agent_forward_seq_pair(self, X, R, T1, ride_along=()):
         """Eval and target networks over the same sequences (iql_learner.py:41-57): the layers below and above the
         recurrence as grouped launches (eval + target in one), the two recurrences as one dual launch.
-        Returns (Q_eval, Q_target)."""
+        ride_along: forward_many items of independent plans (the mixer's hyper-networks) that share the launches of the
+        layers above the recurrence.  Returns [Q_eval, Q_target, outputs of the ride-along plans...]."""
         H, M, tf = self.RH, T1 * R, self.target_flat
         ws0, ws1 = self.seq_workspace(0, R, T1), self.seq_workspace(1, R, T1)
         gi0, gi1 = Plan.forward_many([(self.pre_plans[0], X, self.obs_dim, M, None), (self.pre_plans[1], X, self.obs_dim, M, tf)])
         self._recurrence(gi0, ws0, R, T1, None, True, second=(gi1, ws1, tf))
-        return Plan.forward_many([(self.post_plans[0], ws0["hs"][R:], H, M, None), (self.post_plans[1], ws1["hs"][R:], H, M, tf)])
+        return Plan.forward_many([(self.post_plans[0], ws0["hs"][R:], H, M, None), (self.post_plans[1], ws1["hs"][R:], H, M, tf)]
+                                 + list(ride_along))
 
     def agent_backward_seq(self, X, R, T1, slabs, n_split, defer_wgrad=None):
         """post_plans[0].dacts[last] holds dLoss/dQ [T1*R, A]: data-gradient chain Q head -> BPTT -> layers below the
