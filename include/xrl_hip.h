@@ -316,6 +316,9 @@ typedef struct {
     float p_term, pad;
     uint64_t seed;
     uint32_t step; const uint32_t* step_dev;
+    const float* prev_state;   /* optional: the state the agents acted on, when buf_* are the other of two alternating buffers */
+    int32_t* prev_steps;       /* optional [n]: step index of this transition inside its episode */
+    int64_t* totals;           /* optional [2]: running totals of finished episodes and of the env steps in them */
 } xrl_synth_marl_t;
 int xrl_synth_marl_step(const xrl_synth_marl_t* p, int reset, xrl_stream_t stream);
 

@@ -189,14 +189,19 @@ def test_synthetic_marl_provider_semantics():
         env.reset()
         assert float(env.buf_avail[:, :, 0].min()) == 1.0 and int(env.steps.abs().sum()) == 0
         g = torch.Generator(device="cpu").manual_seed(0)
-        trace, steps_host = [], np.zeros(n, np.int64)
+        trace, steps_host, totals = [], np.zeros(n, np.int64), np.zeros(2, np.int64)
         for t in range(40):
-            state0 = env.buf_state.clone()
+            state0 = env.buf_state
+            acted = (env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone(), env.buf_obs, env.buf_avail)
             env.action.copy_(torch.randint(0, env.n_actions, (n, env.n_agents), generator=g, dtype=torch.int32))
             env.step_device()
             torch.cuda.synchronize()
+            assert np.array_equal(env.prev_steps.cpu().numpy(), steps_host)
+            assert env.buf_state.data_ptr() != state0.data_ptr()          # alternating buffers: the acted-on set is intact
             steps_host += 1
             term, trunc, done = env.terminated.cpu().numpy(), env.truncated.cpu().numpy(), env.done.cpu().numpy()
+            totals += np.array([int((done > 0).sum()), int(steps_host[done > 0].sum())])
+            assert np.array_equal(env.episode_totals.cpu().numpy(), totals)
             assert np.array_equal(done, np.maximum(term, trunc)) and not np.any((term > 0) & (trunc > 0))
             assert np.array_equal(trunc > 0, (term == 0) & (steps_host >= T))
             assert np.array_equal(env.end_step.cpu().numpy(), steps_host)
@@ -207,6 +212,7 @@ def test_synthetic_marl_provider_semantics():
             if (~cont).any():
                 assert not torch.equal(env.buf_obs[~cont], env.next_obs[~cont])
             assert float(env.buf_avail[:, :, 0].min()) == 1.0 and float(env.next_avail[:, :, 0].min()) == 1.0
+            assert torch.equal(acted[0], acted[3]) and torch.equal(acted[1], state0) and torch.equal(acted[2], acted[4])
             rew = env.action.float().mean(1) / env.n_actions + 0.1 * state0[:, 0]
             assert torch.allclose(env.rewards, rew[:, None].expand(-1, env.n_agents), atol=1e-6)
             assert torch.equal(env.terminals, env.terminated[:, None].expand(-1, env.n_agents))

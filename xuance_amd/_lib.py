@@ -167,7 +167,7 @@ class SynthMarl(C.Structure):
                 ("terminals", c_void_p), ("terminated", c_void_p), ("truncated", c_void_p), ("done", c_void_p),
                 ("steps", c_void_p), ("end_step", c_void_p), ("n", c_int32), ("N", c_int32), ("O", c_int32), ("S", c_int32),
                 ("A", c_int32), ("max_steps", c_int32), ("p_term", c_float), ("pad", c_float), ("seed", C.c_uint64),
-                ("step", C.c_uint32), ("step_dev", c_void_p)]
+                ("step", C.c_uint32), ("step_dev", c_void_p), ("prev_state", c_void_p), ("prev_steps", c_void_p), ("totals", c_void_p)]
 
 
 class RolloutPersist(C.Structure):

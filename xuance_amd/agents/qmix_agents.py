@@ -61,6 +61,9 @@ class QMIX_Agents:
             self.reset_rows = torch.zeros(R, device=dev)
             self._counts = torch.zeros(2, device=dev)
             self._counts_h = torch.zeros(2).pin_memory() if torch.cuda.is_available() else torch.zeros(2)
+            self._totals_h = torch.zeros(2, dtype=torch.int64)
+            if torch.cuda.is_available():
+                self._totals_h = self._totals_h.pin_memory()
         else:
             self.model.agent_plan.ensure(max(R, 2 * config.batch_size * self.n_agents))
         self._started = False
@@ -108,9 +111,18 @@ class QMIX_Agents:
             self.rnn_c.zero_()
         self.reset_rows.zero_()
         episodes = 0
+        # an env that alternates its observation buffers and keeps running episode totals saves the copies and the
+        # reductions of a step (envs/synthetic.py); any other env goes through clones and two small sums
+        two_buf, totals = getattr(env, "double_buffered", False), getattr(env, "episode_totals", None)
+        if totals is not None:
+            self._totals_h.copy_(totals)
+            seen = self._totals_h.clone()
         while episodes < n_episodes:
-            obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
-            steps = env.steps.clone()
+            if two_buf:
+                obs, state, avail = env.buf_obs, env.buf_state, env.buf_avail
+            else:
+                obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
+                steps = env.steps.clone()
             q = self.model.agent_forward_seq(obs.view(R, -1), R, 1, which=2, h0=self.rnn_h, reset=self.reset_rows,
                                              h_last=self.rnn_h, c0=self.rnn_c, c_last=self.rnn_c)
             ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
@@ -119,14 +131,20 @@ class QMIX_Agents:
             env.step_device()
             ops.counter_add(self.step_counter, 1)
             mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
-                      avail_actions=avail, state=state, episode_steps=steps)
+                      avail_actions=avail, state=state, episode_steps=env.prev_steps if two_buf else steps)
             mem.finish_paths(env.done, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail)
             self.reset_rows.view(n, N).copy_(env.done[:, None].expand(n, N))
-            self._counts[0] = env.done.sum()
-            self._counts[1] = (env.done * env.end_step).sum()
-            self._counts_h.copy_(self._counts)                 # the step's only host read
-            episodes += int(self._counts_h[0])
-            self.current_step += int(self._counts_h[1])        # current_step += info[i]["episode_step"] (:532)
+            if totals is not None:
+                self._totals_h.copy_(totals)                   # the step's only host read
+                episodes += int(self._totals_h[0] - seen[0])
+                self.current_step += int(self._totals_h[1] - seen[1])      # current_step += info[i]["episode_step"] (:532)
+                seen.copy_(self._totals_h)
+            else:
+                self._counts[0] = env.done.sum()
+                self._counts[1] = (env.done * env.end_step).sum()
+                self._counts_h.copy_(self._counts)             # the step's only host read
+                episodes += int(self._counts_h[0])
+                self.current_step += int(self._counts_h[1])
             self._update_explore_factor()
 
     def _train_rnn(self, train_steps):                         # off_policy_marl.py:335-349
@@ -152,8 +170,12 @@ class QMIX_Agents:
             env.reset()
             self._started = True
         info = {}
+        two_buf = getattr(env, "double_buffered", False)       # the acted-on tensors survive step_device(): no copies
         for _ in range(train_steps):
-            obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
+            if two_buf:
+                obs, state, avail = env.buf_obs, env.buf_state, env.buf_avail
+            else:
+                obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
             q = self.model.agent_plan.forward(obs.view(R, -1), self.obs_dim, R)      # shared network on [n*N, obs]
             ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
                                     action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,

@@ -269,7 +269,8 @@ __global__ void __launch_bounds__(256) synth_marl_kernel(xrl_synth_marl_t p, int
     }
     float asum = 0.f;
     for (int a = 0; a < N; ++a) asum += (float)p.action[(size_t)e * N + a];
-    const float rew = asum / (float)N / (float)p.A + 0.1f * p.buf_state[(size_t)e * S];
+    const float* acted_state = p.prev_state ? p.prev_state : p.buf_state;     // two-buffer mode: buf_* are the OTHER buffers
+    const float rew = asum / (float)N / (float)p.A + 0.1f * acted_state[(size_t)e * S];
     const int steps = p.steps[e] + 1;
     const bool term = synth_uniform(p.seed, (uint32_t)e, 2u * step, 16384u) < p.p_term;
     const bool trunc = !term && steps >= p.max_steps;
@@ -286,6 +287,11 @@ __global__ void __launch_bounds__(256) synth_marl_kernel(xrl_synth_marl_t p, int
     if (lane == 0) {
         p.terminated[e] = term ? 1.f : 0.f; p.truncated[e] = trunc ? 1.f : 0.f; p.done[e] = done ? 1.f : 0.f;
         p.end_step[e] = steps; p.steps[e] = done ? 0 : steps;
+        if (p.prev_steps) p.prev_steps[e] = steps - 1;
+        if (done && p.totals) {                          // running totals: episodes finished, env steps in them (integer adds)
+            atomicAdd(reinterpret_cast<unsigned long long*>(p.totals), 1ull);
+            atomicAdd(reinterpret_cast<unsigned long long*>(p.totals) + 1, (unsigned long long)steps);
+        }
     }
 }
 

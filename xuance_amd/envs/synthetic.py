@@ -123,8 +123,12 @@ class SyntheticMujocoVecEnv(_Base):
 class SyntheticSMACVecEnv(_Base):
     """SMAC map 3m shape: 3 agents, obs (30,), state (48,), 9 actions with availability masks, 60-step episodes
     (docs/source/documents/benchmark/smac/smac.rst:15,19; obs/state/action dims are SMAC-upstream values).
-    One native launch per vector step (xrl_synth_marl_step; Philox streams keyed by seed / env / step)."""
-    graph_safe = True
+    One native launch per vector step (xrl_synth_marl_step; Philox streams keyed by seed / env / step).
+    `double_buffered`: step_device() leaves the tensors that were buf_obs / buf_state / buf_avail before the call intact
+    and rebinds those names to the other of two buffer sets; `prev_steps` = step index of the transition inside its
+    episode; `episode_totals` = running totals [episodes finished, env steps in them] (int64, on the device)."""
+    graph_safe = False          # buf_* alternate between two tensors: addresses change from step to step
+    double_buffered = True
 
     def __init__(self, num_envs, seed=1, device="cuda", n_agents=3, obs_dim=30, state_dim=48, n_actions=9,
                  max_episode_steps=60, p_term=0.01):
@@ -136,9 +140,10 @@ class SyntheticSMACVecEnv(_Base):
         self.action_space = {k: Discrete(n_actions) for k in self.agent_keys}
         self.state_space = Box(-np.inf, np.inf, (state_dim,), np.float32)
         n, N = self.num_envs, n_agents
-        self.buf_obs = torch.zeros(n, N, obs_dim, device=device)
-        self.buf_state = torch.zeros(n, state_dim, device=device)
-        self.buf_avail = torch.ones(n, N, n_actions, device=device)
+        self._sets = [(torch.zeros(n, N, obs_dim, device=device), torch.zeros(n, state_dim, device=device),
+                       torch.ones(n, N, n_actions, device=device)) for _ in range(2)]
+        self._cur = 0
+        self.buf_obs, self.buf_state, self.buf_avail = self._sets[0]
         self.agent_mask = torch.ones(n, N, device=device)
         self.action = torch.zeros(n, N, dtype=torch.int32, device=device)
         self.next_obs, self.next_state, self.next_avail = (torch.zeros_like(self.buf_obs), torch.zeros_like(self.buf_state),
@@ -147,22 +152,29 @@ class SyntheticSMACVecEnv(_Base):
         self.terminals = torch.zeros(n, N, device=device)
         self.done = torch.zeros(n, device=device)
         self.end_step = torch.zeros(n, dtype=torch.int32, device=device)
+        self.prev_steps = torch.zeros(n, dtype=torch.int32, device=device)
+        self.episode_totals = torch.zeros(2, dtype=torch.int64, device=device)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
 
-    def _kw(self):
-        return dict(buf_obs=self.buf_obs, buf_state=self.buf_state, buf_avail=self.buf_avail, next_obs=self.next_obs,
+    def _kw(self, new, prev_state=None):
+        return dict(buf_obs=new[0], buf_state=new[1], buf_avail=new[2], next_obs=self.next_obs,
                     next_state=self.next_state, next_avail=self.next_avail, action=self.action, rewards=self.rewards,
                     terminals=self.terminals, terminated=self.terminated, truncated=self.truncated, done=self.done,
                     steps=self.steps, end_step=self.end_step, n=self.num_envs, N=self.n_agents, O=self.obs_dim,
                     S=self.state_dim, A=self.n_actions, max_steps=self.max_episode_steps, p_term=self.p_term, seed=self.seed,
-                    step=0, step_dev=self.step_counter)
+                    step=0, step_dev=self.step_counter, prev_state=prev_state, prev_steps=self.prev_steps,
+                    totals=self.episode_totals)
 
     def reset(self):
         from .. import ops
-        ops.synth_marl_step(reset=True, **self._kw())
+        ops.synth_marl_step(reset=True, **self._kw(self._sets[self._cur]))
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
     def step_device(self):
         from .. import ops
-        ops.synth_marl_step(**self._kw())
+        acted_state = self.buf_state
+        self._cur ^= 1
+        new = self._sets[self._cur]
+        ops.synth_marl_step(**self._kw(new, prev_state=acted_state))
+        self.buf_obs, self.buf_state, self.buf_avail = new
         ops.counter_add(self.step_counter, 1)
