@@ -839,7 +839,7 @@ class ConvStack:
         ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, tot, OH * OW, F, F)
         return ws.feat
 
-    N_SPLIT = 32                                              # row chunks of a conv layer's weight gradient (parallelism)
+    N_SPLIT = 64                                              # row chunks of a conv layer's weight gradient (parallelism)
 
     def backward(self, dfeat, rows, ws, slabs, n_split, flat=None):
         """dfeat [rows, n_feat] -> weight / bias gradients of every conv layer, summed into slabs[0] (the conv parameters
@@ -854,17 +854,20 @@ class ConvStack:
         cs, stride = self._cslabs, self._cslabs.shape[1]
         H, W, C, k, s, p, OH, OW, F = self.geo[-1]
         ops.maxpool_hw_bwd(dfeat, ws.arg, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
+        wg = []
         for i in reversed(range(len(self.geo))):
             H, W, C, k, s, p, OH, OW, F = self.geo[i]
             M, K = rows * OH * OW, C * k * k
             n = self.names[i]
-            ops.linear_bwd_weight([ops.gemm_desc(ws.dy[i].data_ptr(), ws.col[i].data_ptr(),
-                                                 cs.data_ptr() + 4 * P.offsets[n + ".weight"], M, F, K, F, K, K,
-                                                 dbias=cs.data_ptr() + 4 * P.offsets[n + ".bias"])], self.N_SPLIT, stride)
+            wg.append(ops.gemm_desc(ws.dy[i].data_ptr(), ws.col[i].data_ptr(), cs.data_ptr() + 4 * P.offsets[n + ".weight"],
+                                    M, F, K, F, K, K, dbias=cs.data_ptr() + 4 * P.offsets[n + ".bias"]))
             if i > 0:
                 ops.linear_bwd_data([ops.gemm_desc(ws.dy[i].data_ptr(), P.ptr(n + ".weight", flat), ws.dcol[i].data_ptr(),
                                                    M, K, F, F, K, K)])
                 ops.col2im_nhwc(ws.dcol[i], ws.y[i - 1], ws.dy[i - 1], rows, H, W, C, k, s, p)   # times relu'(y_{i-1})
+        # the weight gradients need nothing but dy / col of their layer: all layers in ONE grouped launch after the
+        # data-gradient chain (the three launches took 13 + 13 + 33 us one after the other, each on a part of the chip)
+        ops.linear_bwd_weight(wg, self.N_SPLIT, stride)
         ops.grad_reduce(cs, self.N_SPLIT, stride, p_conv, slabs[0], self._csq)
 
 
