@@ -531,6 +531,48 @@ def golden_marl_rnn_buffer():
     np.savez_compressed(os.path.join(OUT, "marl_rnn_buffer.npz"), **out)
 
 
+def golden_marl_ff_buffer():
+    """MARL_OffPolicyBuffer (memory_tools_marl.py:634-767): store over a wrapping ring (bool fields included), then
+    sample() with the two NumPy global-RNG draws (:755-756).  tests/golden/marl_ff_buffer.npz."""
+    from xuance.common.memory_tools_marl import MARL_OffPolicyBuffer
+    rng = np.random.default_rng(29)
+    n_envs, n_size, N, O, A, S, bs, n_steps = 4, 6, 3, 5, 4, 7, 10, 9
+    keys = [f"agent_{i}" for i in range(N)]
+    buf = MARL_OffPolicyBuffer(agent_keys=keys, state_space=sp.Box(-np.inf, np.inf, (S,), np.float32),
+                               obs_space={k: sp.Box(-np.inf, np.inf, (O,), np.float32) for k in keys},
+                               act_space={k: sp.Discrete(A) for k in keys}, n_envs=n_envs, buffer_size=n_envs * n_size,
+                               batch_size=bs, use_actions_mask=True, avail_actions_shape={k: (A,) for k in keys})
+    out = {}
+    per_agent = ("obs", "obs_next", "actions", "rewards", "terminals", "agent_mask", "avail_actions", "avail_actions_next")
+    for t in range(n_steps):
+        d = dict(obs=rng.standard_normal((n_envs, N, O)).astype(np.float32),
+                 obs_next=rng.standard_normal((n_envs, N, O)).astype(np.float32),
+                 actions=rng.integers(0, A, (n_envs, N)).astype(np.float32),
+                 rewards=rng.standard_normal((n_envs, N)).astype(np.float32),
+                 terminals=rng.random((n_envs, N)) < 0.2, agent_mask=rng.random((n_envs, N)) < 0.9,
+                 avail_actions=rng.random((n_envs, N, A)) < 0.7, avail_actions_next=rng.random((n_envs, N, A)) < 0.7,
+                 state=rng.standard_normal((n_envs, S)).astype(np.float32),
+                 state_next=rng.standard_normal((n_envs, S)).astype(np.float32))
+        step = {k: {a: d[k][:, i] for i, a in enumerate(keys)} for k in per_agent}
+        step.update(state=d["state"], state_next=d["state_next"])
+        buf.store(**step)
+        out.update(flat(f"t{t}", d))
+        out[f"t{t}/ptr_size"] = np.array([buf.ptr, buf.size])
+    for k, v in buf.data.items():
+        out[f"data/{k}"] = np.stack([v[a] for a in keys], 2) if isinstance(v, dict) else v      # [n_envs, n_size, N, ...]
+    np.random.seed(11)
+    smp = buf.sample()
+    np.random.seed(11)
+    out["sample/env"], out["sample/step"] = np.random.choice(n_envs, bs), np.random.choice(buf.size, bs)
+    for k, v in smp.items():
+        if isinstance(v, dict):
+            out[f"sample/{k}"] = np.stack([v[a] for a in keys], 1)                                # [B, N, ...]
+        elif isinstance(v, np.ndarray):
+            out[f"sample/{k}"] = v
+    out["meta"] = np.array([n_envs, n_size, N, O, A, S, bs, n_steps])
+    np.savez_compressed(os.path.join(OUT, "marl_ff_buffer.npz"), **out)
+
+
 def golden_checkpoint():
     """Checkpoint compatibility: a `.pth` written by the reference's Learner.save_model
     (drl_learner.py:64-93) after two PPO updates, and the parameters the REFERENCE reaches when a fresh learner loads that
@@ -693,6 +735,7 @@ if __name__ == "__main__":
     golden_qmix_rnn(True, fixed=True)
     golden_qmix_rnn(True, fixed=True, rnn="LSTM")
     golden_marl_rnn_buffer()
+    golden_marl_ff_buffer()
     golden_checkpoint()
     golden_per_buffer()
     golden_pg("categorical")

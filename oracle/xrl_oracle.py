@@ -860,6 +860,28 @@ class PerBufferOracle:
                 self.max_priority[e] = max(self.max_priority[e], p)
 
 
+class MarlBufferOracle:
+    """MARL_OffPolicyBuffer (memory_tools_marl.py:634-767) with the agents stacked on one axis: per-agent fields
+    [n_envs, n_size, N, ...], state / state_next [n_envs, n_size, S]; bool fields keep their dtype (:717-719, :727-728)."""
+    BOOL = ("terminals", "agent_mask", "avail_actions", "avail_actions_next")
+
+    def __init__(self, n_envs, n_size, N, O, A, S):
+        self.n_envs, self.n_size = n_envs, n_size
+        shapes = dict(obs=(N, O), obs_next=(N, O), actions=(N,), rewards=(N,), terminals=(N,), agent_mask=(N,),
+                      state=(S,), state_next=(S,), avail_actions=(N, A), avail_actions_next=(N, A))
+        self.data = {k: np.zeros((n_envs, n_size) + v, np.bool_ if k in self.BOOL else np.float32) for k, v in shapes.items()}
+        self.ptr = self.size = 0
+
+    def store(self, **step):                                   # :731-740
+        for k, v in step.items():
+            self.data[k][:, self.ptr] = v
+        self.ptr = (self.ptr + 1) % self.n_size
+        self.size = min(self.size + 1, self.n_size)
+
+    def sample(self, env_choices, step_choices):               # :742-764 (the two np.random.choice draws, :755-756)
+        return {k: v[env_choices, step_choices] for k, v in self.data.items()}
+
+
 class EpisodeBufferOracle:
     """MARL_OffPolicyBuffer_RNN (memory_tools_marl.py:770-996) with the agents stacked on one axis:
     obs [rows, T+1, N, O], actions/rewards/terminals/agent_mask [rows, T, N], avail_actions [rows, T+1, N, A],

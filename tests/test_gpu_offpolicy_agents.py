@@ -88,6 +88,43 @@ def test_marl_buffer_matches_numpy_mirror():
     assert s["batch_size"] == bs
 
 
+def test_marl_buffer_vs_reference_fixture():
+    """HipMARLOffPolicyBuffer against the unmodified MARL_OffPolicyBuffer (tests/golden/marl_ff_buffer.npz): ring contents
+    after a wrapping sequence of stores (reference nested agent dicts in, bool fields as 0/1) and sample() on the same
+    NumPy global-RNG draws."""
+    from conftest import load_golden, sub
+    from xuance_amd.memory_marl import HipMARLOffPolicyBuffer
+    from xuance_amd.spaces import Box, Discrete
+    g = load_golden("marl_ff_buffer")
+    n_envs, n_size, N, O, A, S, bs, n_steps = (int(x) for x in g["meta"])
+    keys = [f"agent_{i}" for i in range(N)]
+    buf = HipMARLOffPolicyBuffer(keys, Box(-1, 1, (S,)), {k: Box(-1, 1, (O,)) for k in keys}, {k: Discrete(A) for k in keys},
+                                 n_envs, n_envs * n_size, bs, use_actions_mask=True,
+                                 avail_actions_shape={k: (A,) for k in keys})
+    per_agent = ("obs", "obs_next", "actions", "rewards", "terminals", "agent_mask", "avail_actions", "avail_actions_next")
+    for t in range(n_steps):
+        d = sub(g, f"t{t}")
+        step = {k: {a: d[k][:, i] for i, a in enumerate(keys)} for k in per_agent}
+        buf.store(state=d["state"], state_next=d["state_next"], **step)
+        assert [buf.ptr, buf.size] == d["ptr_size"].tolist()
+    np.random.seed(11)
+    s = buf.sample()
+    for k in per_agent:
+        ref = g[f"sample/{k}"].astype(np.float32)
+        for i, a in enumerate(keys):
+            assert np.array_equal(s[k][a].cpu().numpy(), ref[:, i]), (k, a)
+    for k in ("state", "state_next"):
+        assert np.array_equal(s[k].cpu().numpy(), g[f"sample/{k}"]), k
+    assert s["batch_size"] == bs
+    # the whole ring, through gathers of every (env, step) cell
+    idx = torch.arange(n_envs * n_size, device="cuda")
+    full = buf.sample(indexes=idx)                             # flat index = env * n_size + step (memory_marl.py)
+    for k in per_agent:
+        ref = g[f"data/{k}"].astype(np.float32).reshape((n_envs * n_size,) + g[f"data/{k}"].shape[2:])
+        for i, a in enumerate(keys):
+            assert np.array_equal(full[k][a].cpu().numpy(), ref[:, i]), (k, a)
+
+
 def test_dqn_agent_learns_cartpole():
     """C3-style loop (store -> sample -> TD update with target sync, epsilon decay) on the device CartPole."""
     from xuance_amd.agents import DQN_Agent

@@ -275,6 +275,22 @@ def test_marl_rnn_buffer(oracle):
         assert np.array_equal(smp[k], ref), k
 
 
+def test_marl_ff_buffer(oracle):
+    """MARL_OffPolicyBuffer: ring contents after a wrapping sequence of stores and a sample, from the unmodified reference."""
+    g = load_golden("marl_ff_buffer")
+    n_envs, n_size, N, O, A, S, bs, n_steps = (int(x) for x in g["meta"])
+    buf = oracle.MarlBufferOracle(n_envs, n_size, N, O, A, S)
+    for t in range(n_steps):
+        d = sub(g, f"t{t}")
+        buf.store(**{k: d[k] for k in buf.data})
+        assert [buf.ptr, buf.size] == d["ptr_size"].tolist()
+    for k, v in sub(g, "data").items():
+        assert buf.data[k].dtype == v.dtype and np.array_equal(buf.data[k], v), k
+    smp = buf.sample(g["sample/env"], g["sample/step"])
+    for k in buf.data:
+        assert np.array_equal(smp[k], g[f"sample/{k}"]), k
+
+
 def test_per_buffer(oracle):
     """Prioritized replay: the oracle's trees / sampling / priority updates against PerOffPolicyBuffer's own
     run with recorded uniforms (tests/golden/per_buffer.npz)."""
