@@ -445,3 +445,42 @@ def test_qmix_lstm_agents_episode_loop(oracle):
     assert checked > 0
     info = agent.learner.update_from_buffer(agent.memory, 2, seed=5)
     assert np.isfinite(info["loss_Q"])
+
+
+@pytest.mark.parametrize("name", ["DDQN", "Duel_DQN"])
+def test_sibling_dqn_agents_from_the_registry(name):
+    """REGISTRY_Agents["DDQN"] / ["Duel_DQN"] (reference keys, agents/__init__.py:84-86): the DQN loop with the sibling
+    learner / the dueling network; greedy actions of the dueling head = argmax of V + A - mean(A)."""
+    from xuance_amd.agents import REGISTRY_Agents
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    from xuance_amd.learners import DDQN_Learner, DuelDQN_Learner
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[64], q_hidden_size=[64], activation="relu", seed=1,
+                    parallels=16, running_steps=200000, buffer_size=16 * 500, batch_size=64, learning_rate=1e-3, gamma=0.99,
+                    start_greedy=0.0, end_greedy=0.0, decay_step_greedy=20000, sync_frequency=50, training_frequency=16,
+                    start_training=200, use_grad_clip=False, grad_clip_norm=0.5, use_obsnorm=False, use_rewnorm=False,
+                    distributed_training=False, device="cuda", model_dir="/tmp/x")
+    env = DeviceCartPoleVecEnv(16, seed=1)
+    agent = REGISTRY_Agents[name](cfg, env)
+    assert isinstance(agent.learner, DDQN_Learner if name == "DDQN" else DuelDQN_Learner)
+    assert agent.model.dueling == (name == "Duel_DQN")
+    p0 = agent.model.params.flat.clone()
+    info = agent.train(60)
+    assert agent.learner.iterations > 0 and np.isfinite(info["Qloss"])
+    assert float((agent.model.params.flat - p0).abs().max()) > 0
+    # epsilon = 0: the stored action of the last step is the greedy one for the observation it was taken on
+    n, A = 16, 2
+    t = (agent.memory.ptr - 1) % agent.memory.n_size
+    obs = agent.memory.soa.fields["observations"][t].clone()
+    act = agent.memory.soa.fields["actions"][t].cpu().numpy()
+    sd = {k: v.cpu().numpy() for k, v in agent.model.state_dict().items()}
+    out = agent.model.forward(obs.view(n, -1), n)[:n].cpu().numpy()
+    if name == "Duel_DQN":
+        q = out[:, A:A + 1] + out[:, :A] - out[:, :A].mean(1, keepdims=True)          # q_head.py:77
+    else:
+        q = out[:, :A]
+    # the last update ran AFTER the last act pass: compare only where the greedy choice is not a near-tie
+    gap = np.abs(q[:, 0] - q[:, 1])
+    ok = gap > 1e-2
+    assert ok.any() and np.array_equal(act[ok], q.argmax(1)[ok].astype(np.float32))

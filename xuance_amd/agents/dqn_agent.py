@@ -109,7 +109,7 @@ class DQN_Agent:
                 self._normalize(env.buf_obs if self.atari else env.buf_obs.float(), self.X, update=True)   # obs_rms.update; process
                 X = self.X
             q = self.model.forward(X[:n], n)
-            ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=A, seed=self.seed,
+            ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=q.stride(0), seed=self.seed,
                         step=0, step_dev=self.step_counter)
             env.step_device()
             ops.counter_add(self.step_counter, 1)
@@ -141,6 +141,30 @@ class DQN_Agent:
 
     def finish(self):
         self.envs.close()
+
+
+class DDQN_Agent(DQN_Agent):
+    """Double DQN (xuance/torch/agents/qlearning_family/ddqn_agent.py:10-33): DQN_Agent whose learner takes the target
+    action from the eval network (DDQN_Learner; `learner: "DDQN_Learner"` in configs/ddqn/*.yaml)."""
+
+    def _build_learner(self, *args):
+        from ..learners.dqn_learner import DDQN_Learner
+        return DDQN_Learner(*args)
+
+
+class DuelDQN_Agent(DQN_Agent):
+    """Dueling DQN (xuance/torch/agents/qlearning_family/dueldqn_agent.py:12-48): DuelingDeepQNetwork (value + advantage
+    streams on the shared representation, deep_q_network.py:102-171) with DuelDQN_Learner."""
+
+    def _build_model(self):
+        c = self.config
+        assert _get(c, "representation", "Basic_MLP") == "Basic_MLP", "the dueling head is built for MLP representations"
+        return DeepQNet(self.obs_dim, self.action_space.n, list(_get(c, "representation_hidden_size", []) or []),
+                        list(c.q_hidden_size), _get(c, "activation", "relu"), device=self.device, dueling=True)
+
+    def _build_learner(self, *args):
+        from ..learners.dqn_learner import DuelDQN_Learner
+        return DuelDQN_Learner(*args)
 
 
 class PerDQN_Agent(DQN_Agent):
