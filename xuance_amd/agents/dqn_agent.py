@@ -52,7 +52,7 @@ class DQN_Agent:
         self.Xn = torch.zeros(n, D, dtype=xdt, device=dev)     # processed next observation
         self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
         self._eps_on_device = self.e_greedy
-        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._host_step = 0
         self.act_f = torch.zeros(n, device=dev)
         self.model.plan.ensure(max(n, 2 * config.batch_size))
         assert not (self.atari and self.use_obsnorm), "Atari frames are stored as uint8 (configs/dqn/atari.yaml:42-43)"
@@ -110,9 +110,9 @@ class DQN_Agent:
                 X = self.X
             q = self.model.forward(X[:n], n)
             ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=q.stride(0), seed=self.seed,
-                        step=0, step_dev=self.step_counter)
+                        step=self._host_step, step_dev=None)       # eager loop: the host knows the step index
             env.step_device()
-            ops.counter_add(self.step_counter, 1)
+            self._host_step += 1
             if zero_copy:
                 Xn = env.next_obs.view(n, -1)
             else:

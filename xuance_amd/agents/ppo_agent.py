@@ -127,7 +127,10 @@ class PPO_Agent:
                           env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
                           bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A, ld=A + 1, gaussian=int(gaussian),
                           seed=self.seed, step=t, step_dev=self.step_counter)
-        env.step_device()
+        if hasattr(env, "advance"):
+            env.step_device(offset=t)                           # static step index: the env's counter ticks once per rollout
+        else:
+            env.step_device()
         ops.rollout_poststep(reward=env.reward, terminated=env.terminated, truncated=env.truncated, next_obs=env.next_obs,
                              obs_mean=self.obs_mean, obs_var=self.obs_var, next_obs_norm=self.X[n:], rew_out=f["rewards"][t],
                              term_out=f["terminals"][t], seg_out=f["seg"][t], ret_track=self.returns,
@@ -213,6 +216,8 @@ class PPO_Agent:
         T, n, A = self.horizon_size, self.n_envs, self.model.action_dim
         for t in range(T):
             self._enqueue_step(t)
+        if hasattr(self.envs, "advance"):
+            self.envs.advance(T)
         # buffer full: vals = get_terminated_values(next_obs) for every env (ppo_agent.py:129-135)
         heads = self.model.forward(self.X, 2 * n)
         ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,

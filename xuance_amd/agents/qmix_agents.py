@@ -53,7 +53,7 @@ class QMIX_Agents:
         self.learner = self._build_learner(self.config, self.agent_keys, self.model, self.callback)
         dev, R = self.device, self.n_envs * self.n_agents
         self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
-        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._host_step = 0
         self.act_f = torch.zeros(self.n_envs, self.n_agents, device=dev)
         if self.use_rnn:
             self.rnn_h = torch.zeros(R, self.model.RH, device=dev)           # init_rnn_states (value_factorization.py:151-159)
@@ -126,10 +126,10 @@ class QMIX_Agents:
             q = self.model.agent_forward_seq(obs.view(R, -1), R, 1, which=2, h0=self.rnn_h, reset=self.reset_rows,
                                              h_last=self.rnn_h, c0=self.rnn_c, c_last=self.rnn_c)
             ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
-                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,
-                                    step_dev=self.step_counter)
+                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=self._host_step,
+                                    step_dev=None)            # eager loop: the host knows the step index
             env.step_device()
-            ops.counter_add(self.step_counter, 1)
+            self._host_step += 1
             mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
                       avail_actions=avail, state=state, episode_steps=env.prev_steps if two_buf else steps)
             mem.finish_paths(env.done, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail)
@@ -178,10 +178,10 @@ class QMIX_Agents:
                 obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
             q = self.model.agent_plan.forward(obs.view(R, -1), self.obs_dim, R)      # shared network on [n*N, obs]
             ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
-                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,
-                                    step_dev=self.step_counter)
+                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=self._host_step,
+                                    step_dev=None)            # eager loop: the host knows the step index
             env.step_device()
-            ops.counter_add(self.step_counter, 1)
+            self._host_step += 1
             self.memory.store(obs=obs, actions=self.act_f, obs_next=env.next_obs, rewards=env.rewards,
                               terminals=env.terminals, agent_mask=env.agent_mask, state=state, state_next=env.next_state,
                               avail_actions=avail, avail_actions_next=env.next_avail)

@@ -55,13 +55,13 @@ class SyntheticAtariVecEnv(_Base):
         self.action = torch.zeros(self.num_envs, dtype=torch.int32, device=device)
         self.done = torch.zeros(self.num_envs, device=device)
         self.end_step = torch.zeros(self.num_envs, dtype=torch.int32, device=device)
-        self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self._host_step = 0
 
     def _kw(self, cur):
         return dict(cur_obs=cur, next_obs=self.next_obs, action=self.action, reward=self.reward, terminated=self.terminated,
                     truncated=self.truncated, done=self.done, steps=self.steps, end_step=self.end_step, n=self.num_envs,
                     row_bytes=84 * 84 * 4, A=self.action_space.n, max_steps=self.max_episode_steps, p_term=self.p_term,
-                    seed=self.seed, step=0, step_dev=self.step_counter)
+                    seed=self.seed, step=self._host_step, step_dev=None)     # eager loops: the host knows the step index
 
     def reset(self):
         from .. import ops
@@ -73,7 +73,7 @@ class SyntheticAtariVecEnv(_Base):
         self._cur ^= 1
         ops.synth_frames_step(**self._kw(self._bufs[self._cur]))
         self.buf_obs = self._bufs[self._cur]
-        ops.counter_add(self.step_counter, 1)
+        self._host_step += 1
 
 
 class SyntheticMujocoVecEnv(_Base):
@@ -101,19 +101,28 @@ class SyntheticMujocoVecEnv(_Base):
         self.stats = torch.zeros(4, dtype=torch.float64, device=device)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
 
-    def _args(self):
+    def _args(self, offset=0):
         return dict(state=self.state, steps=self.steps, action=self.action, Amat=self.A, Bmat=self.B, obs=self.buf_obs,
                     next_obs=self.next_obs, reward=self.reward, terminated=self.terminated, truncated=self.truncated,
                     ep_score=self.ep_score, stats=self.stats, n=self.num_envs, D=self.obs_dim, A=self.act_dim,
-                    max_steps=self.max_episode_steps, seed=self.seed, step=0, step_dev=self.step_counter)
+                    max_steps=self.max_episode_steps, seed=self.seed, step=int(offset), step_dev=self.step_counter)
 
     def reset(self):
         self._ops.synth_control_step(reset=True, **self._args())
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
-    def step_device(self):
-        self._ops.synth_control_step(**self._args())
-        self._ops.counter_add(self.step_counter, 1)
+    def step_device(self, offset=None):
+        """offset=None: one step, the device counter advances by one.  offset=t (inside a captured rollout whose steps are
+        enqueued with static indices): step index = counter + t and the counter is left alone -- call advance(T) once
+        after the T steps (one launch per rollout instead of one per step)."""
+        if offset is None:
+            self._ops.synth_control_step(**self._args())
+            self._ops.counter_add(self.step_counter, 1)
+        else:
+            self._ops.synth_control_step(**self._args(offset))
+
+    def advance(self, k):
+        self._ops.counter_add(self.step_counter, int(k))
 
     def episode_stats(self):
         s = self.stats.cpu().numpy()
@@ -154,7 +163,7 @@ class SyntheticSMACVecEnv(_Base):
         self.end_step = torch.zeros(n, dtype=torch.int32, device=device)
         self.prev_steps = torch.zeros(n, dtype=torch.int32, device=device)
         self.episode_totals = torch.zeros(2, dtype=torch.int64, device=device)
-        self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self._host_step = 0
 
     def _kw(self, new, prev_state=None):
         return dict(buf_obs=new[0], buf_state=new[1], buf_avail=new[2], next_obs=self.next_obs,
@@ -162,7 +171,7 @@ class SyntheticSMACVecEnv(_Base):
                     terminals=self.terminals, terminated=self.terminated, truncated=self.truncated, done=self.done,
                     steps=self.steps, end_step=self.end_step, n=self.num_envs, N=self.n_agents, O=self.obs_dim,
                     S=self.state_dim, A=self.n_actions, max_steps=self.max_episode_steps, p_term=self.p_term, seed=self.seed,
-                    step=0, step_dev=self.step_counter, prev_state=prev_state, prev_steps=self.prev_steps,
+                    step=self._host_step, step_dev=None, prev_state=prev_state, prev_steps=self.prev_steps,
                     totals=self.episode_totals)
 
     def reset(self):
@@ -177,4 +186,4 @@ class SyntheticSMACVecEnv(_Base):
         new = self._sets[self._cur]
         ops.synth_marl_step(**self._kw(new, prev_state=acted_state))
         self.buf_obs, self.buf_state, self.buf_avail = new
-        ops.counter_add(self.step_counter, 1)
+        self._host_step += 1
