@@ -78,6 +78,11 @@ int xrl_adv_stats(const float* adv_field, const int64_t* idx, int bs, int n_batc
  * Fields flagged bit0 are written as (x - stats[0]) / (stats[1] + 1e-8).  fields: HOST array. */
 int xrl_soa_gather(const xrl_field_t* fields, int n_fields, const int64_t* idx, int bs, int n_envs, int T,
                    const float* stats, xrl_stream_t stream);
+/* xrl_sample_replay_indices + xrl_soa_gather in ONE launch (bs <= 256): the rows are drawn inside the gather with the
+ * same Philox stream, so both forms pick the same transitions; idx_out (optional, [bs]) receives the drawn flat indices. */
+int xrl_soa_gather_sampled(const xrl_field_t* fields, int n_fields, int64_t* idx_out, int bs, int n_envs, int n_size,
+                           const int32_t* size_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_dev,
+                           xrl_stream_t stream);
 
 /* ------------------------------------------------------------------ dense layers on fp32 MFMA */
 

@@ -247,6 +247,8 @@ _SIGS = {
     "xrl_gae_scan": [c_void_p] * 7 + [c_int, c_int, c_double, c_double, c_int, c_void_p],
     "xrl_adv_stats": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "xrl_soa_gather": [C.POINTER(Field), c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "xrl_soa_gather_sampled": [C.POINTER(Field), c_int, c_void_p, c_int, c_int, c_int, c_void_p, C.c_uint64, C.c_uint32, c_void_p,
+                               c_void_p],
     "xrl_linear_fwd": [C.POINTER(Gemm), c_int, c_void_p],
     "xrl_linear_bwd_data": [C.POINTER(Gemm), c_int, c_void_p],
     "xrl_linear_bwd_weight": [C.POINTER(Gemm), c_int, c_int, c_int64, c_void_p],

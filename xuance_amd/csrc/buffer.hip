@@ -2,6 +2,7 @@
 // Reference arithmetic: xuance/common/memory_tools.py (store_element :44-61, finish_path :242-265,
 // sample :267-287 / :374-387).  All HBM-bound; layouts are chosen so every access is coalesced.
 #include "common.h"
+#include "rng.h"
 #include <stdarg.h>
 
 namespace xrl {
@@ -37,10 +38,36 @@ __global__ void __launch_bounds__(256) store_step_kernel(FieldPack f, int n_envs
 }
 
 // ------------------------------------------------------------------------------------------ gather
+// Draw of xrl_sample_replay_indices for batch row b (same Philox stream: the fused draw + gather picks the same rows).
+struct ReplayDraw {
+    const int32_t* size_dev; uint64_t seed; uint32_t counter; const uint32_t* counter_dev; int64_t* idx_out;
+};
+__device__ __forceinline__ int64_t replay_draw(const ReplayDraw& s, int b, int n_envs, int n_size) {
+    const uint32_t ctr = s.counter + (s.counter_dev ? *s.counter_dev : 0u);
+    int size = *s.size_dev;
+    size = size < 1 ? 1 : (size > n_size ? n_size : size);
+    uint32_t r[4];
+    philox4x32(s.seed, (uint32_t)b, ctr, 0x53414D50u, r);
+    const int env = (int)(((uint64_t)r[0] * (uint64_t)n_envs) >> 32);
+    const int step = (int)(((uint64_t)r[1] * (uint64_t)size) >> 32);
+    return (int64_t)env * n_size + step;
+}
+
 // dst[b] = field[t_b][env_b], (env_b, t_b) = divmod(idx[b], T).  Unit V = 16 B or 4 B.
-template <typename V>
+// SAMPLED: the indices are not read but drawn here (bs <= 256: every workgroup draws all of them into LDS; workgroup
+// (0, 0) also writes them to draw.idx_out) -- one launch instead of xrl_sample_replay_indices + xrl_soa_gather.
+template <typename V, bool SAMPLED>
 __global__ void __launch_bounds__(256) gather_kernel(FieldPack f, const int64_t* __restrict__ idx, int bs,
-                                                     int n_envs, int T, const float* __restrict__ stats) {
+                                                     int n_envs, int T, const float* __restrict__ stats, ReplayDraw draw) {
+    __shared__ int64_t sidx[SAMPLED ? 256 : 1];
+    if (SAMPLED) {
+        if ((int)threadIdx.x < bs) {
+            const int64_t v = replay_draw(draw, threadIdx.x, n_envs, T);
+            sidx[threadIdx.x] = v;
+            if (blockIdx.x == 0 && blockIdx.y == 0 && draw.idx_out) draw.idx_out[threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
     const int fi = blockIdx.y;
     const int rw = f.row_bytes[fi] / (int)sizeof(V);  // units per row
     const size_t total = (size_t)bs * rw;
@@ -54,7 +81,7 @@ __global__ void __launch_bounds__(256) gather_kernel(FieldPack f, const int64_t*
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / rw), w = (int)(i - (size_t)b * rw);
-        const int64_t fl = idx[b];
+        const int64_t fl = SAMPLED ? sidx[b] : idx[b];
         const int env = (int)(fl / T), t = (int)(fl - (int64_t)env * T);
         V v = s[((size_t)t * n_envs + env) * rw + w];
         if constexpr (sizeof(V) == 4) {
@@ -350,8 +377,30 @@ extern "C" int xrl_soa_gather(const xrl_field_t* fields, int n_fields, const int
     size_t nb = (max_units + 255) / 256;
     if (nb > 4096) nb = 4096;
     dim3 grid((unsigned)nb, n_fields);
-    if (vec16) hipLaunchKernelGGL(gather_kernel<uint4>, grid, 256, 0, as_stream(stream), fp, idx, bs, n_envs, T, stats);
-    else hipLaunchKernelGGL(gather_kernel<uint32_t>, grid, 256, 0, as_stream(stream), fp, idx, bs, n_envs, T, stats);
+    if (vec16) hipLaunchKernelGGL((gather_kernel<uint4, false>), grid, 256, 0, as_stream(stream), fp, idx, bs, n_envs, T, stats, ReplayDraw{});
+    else hipLaunchKernelGGL((gather_kernel<uint32_t, false>), grid, 256, 0, as_stream(stream), fp, idx, bs, n_envs, T, stats, ReplayDraw{});
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_soa_gather_sampled(const xrl_field_t* fields, int n_fields, int64_t* idx_out, int bs, int n_envs, int n_size,
+                                      const int32_t* size_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_dev,
+                                      xrl_stream_t stream) {
+    FieldPack fp; bool vec16;
+    XRL_CHECK_ARG(pack_fields(fields, n_fields, fp, vec16) == XRL_OK);
+    XRL_CHECK_ARG(size_dev != nullptr && bs > 0 && bs <= 256 && n_envs > 0 && n_size > 0);
+    for (int i = 0; i < n_fields; ++i) XRL_CHECK_ARG(!(fp.flags[i] & 1));
+    size_t max_units = 0;
+    for (int i = 0; i < n_fields; ++i) {
+        const size_t u = (size_t)bs * fp.row_bytes[i] / (vec16 ? 16 : 4);
+        max_units = u > max_units ? u : max_units;
+    }
+    size_t nb = (max_units + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    dim3 grid((unsigned)nb, n_fields);
+    const ReplayDraw d{size_dev, seed, counter, counter_dev, idx_out};
+    if (vec16) hipLaunchKernelGGL((gather_kernel<uint4, true>), grid, 256, 0, as_stream(stream), fp, nullptr, bs, n_envs, n_size, nullptr, d);
+    else hipLaunchKernelGGL((gather_kernel<uint32_t, true>), grid, 256, 0, as_stream(stream), fp, nullptr, bs, n_envs, n_size, nullptr, d);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

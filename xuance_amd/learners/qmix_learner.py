@@ -270,8 +270,7 @@ class QMIX_Learner(Learner):
             def enqueue():
                 # per update: draw, gather, step; the draw counter and the loss sums are settled once per phase
                 for e in range(n_epochs):
-                    ops.sample_replay_indices(self._idx, memory.n_envs, memory.n_size, memory.size_dev, seed, e, self._sample_counter)
-                    memory.gather_into(self._idx, dst)
+                    memory.draw_into(self._idx, dst, seed, e, self._sample_counter)     # draw + gather: one launch
                     self.partials = self._phase_partials[e]
                     self._step(B)
                 ops.counter_add(self._sample_counter, n_epochs)

@@ -266,6 +266,16 @@ class HipOffPolicyBuffer:
         f = self.soa
         ops.soa_gather([(dst[k], f.fields[k], f.row_bytes[k]) for k in dst], idx, self.n_envs, self.n_size)
 
+    def draw_into(self, idx_out, dst, seed, counter, counter_dev):
+        """Uniform draw (xrl_sample_replay_indices' stream, following the filling ring through size_dev) + gather_into as
+        ONE launch; idx_out receives the rows that were picked.  Batches above 256 rows take the two launches."""
+        f = self.soa
+        if idx_out.numel() > 256:
+            ops.sample_replay_indices(idx_out, self.n_envs, self.n_size, self.size_dev, seed, counter, counter_dev)
+            return self.gather_into(idx_out, dst)
+        ops.soa_gather_sampled([(dst[k], f.fields[k], f.row_bytes[k]) for k in dst], idx_out, self.n_envs, self.n_size,
+                               self.size_dev, seed, counter, counter_dev)
+
     def sample_indices(self, batch_size=None):
         """The two NumPy global-RNG draws of memory_tools.py:376-377, as flat env-major indices."""
         bs = self.batch_size if batch_size is None else batch_size

@@ -47,6 +47,14 @@ def soa_gather(pairs, idx, n_envs, T, stats=None, flags=None):
     call("xrl_soa_gather", arr, len(pairs), ptr(idx), idx.numel(), int(n_envs), int(T), ptr(stats), stream_ptr())
 
 
+def soa_gather_sampled(pairs, idx_out, n_envs, n_size, size_dev, seed, counter=0, counter_dev=None):
+    """sample_replay_indices + soa_gather in one launch (bs = idx_out.numel() <= 256); idx_out receives the drawn rows."""
+    _chk(idx_out, torch.int64)
+    arr = _fields(pairs, None)
+    call("xrl_soa_gather_sampled", arr, len(pairs), ptr(idx_out), idx_out.numel(), int(n_envs), int(n_size), ptr(size_dev),
+         int(seed), int(counter), ptr(counter_dev), stream_ptr())
+
+
 def adv_stats(adv_field, idx, bs, n_batches, n_envs, T, stats):
     call("xrl_adv_stats", ptr(_chk(adv_field)), ptr(_chk(idx, torch.int64)), int(bs), int(n_batches), int(n_envs),
          int(T), ptr(_chk(stats)), stream_ptr())
