@@ -354,3 +354,32 @@ def test_random_permutation_rows_are_permutations(N, take, n_perm):
         out3 = torch.empty_like(out)
         ops.random_permutation(out3, n_perm, N, take, seed=7, counter=1, counter_dev=None)
         assert np.array_equal(out3.cpu().numpy(), out2.cpu().numpy())
+
+
+def test_c_abi_rejects_bad_arguments_without_launching():
+    """Error behaviour of the boundary (include/xrl_hip.h:17): a negative XRL_E* code and a message from xrl_last_error(),
+    never an exception across the ABI, and nothing enqueued -- the destination stays untouched."""
+    import ctypes as C
+    from xuance_amd import _lib, ops
+    lib = _lib.load()
+    out = torch.full((8,), 7.0, device="cuda")
+    part = torch.ones(4, 8, dtype=torch.float64, device="cuda")
+    sums = torch.full((8,), 7.0, dtype=torch.float64, device="cuda")
+    rc = lib.xrl_sum_partials(None, 4, 8, sums.data_ptr(), None)                   # null input
+    assert rc == -1 and len(lib.xrl_last_error()) > 0
+    rc = lib.xrl_sum_partials(part.data_ptr(), 4, 65, sums.data_ptr(), None)      # unsupported width
+    assert rc < 0 and len(lib.xrl_last_error()) > 0
+    rc = lib.xrl_sample_replay_indices(None, 8, 4, 4, None, 1, 0, None, None)
+    assert rc < 0
+    torch.cuda.synchronize()
+    assert float(sums.min()) == 7.0 and float(out.min()) == 7.0
+    # the Python wrappers turn the code into XrlError with the library's message
+    with pytest.raises(ops.XrlError) as e:
+        ops.sum_partials(part, 0, 8, sums)
+    assert "xrl_sum_partials" in str(e.value)
+    with pytest.raises(ops.XrlError):
+        ops.sample_replay_indices(torch.zeros(4, dtype=torch.int64, device="cuda"), 0, 4,
+                                  torch.ones(1, dtype=torch.int32, device="cuda"), 1)          # n_envs = 0
+    # a valid call still works afterwards
+    ops.sum_partials(part, 4, 8, sums)
+    assert torch.equal(sums, torch.full((8,), 4.0, dtype=torch.float64, device="cuda"))
