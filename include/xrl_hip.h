@@ -60,7 +60,9 @@ int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n_envs, int 
  *   rew,val,term : [T][n_envs] f32     bootv : [T][n_envs] bootstrap value of a segment ending at (t,env)
  *   seg          : [T][n_envs] u8, bit0 = a path ends after step t (finish_path was called with ptr==t+1),
  *                  bit1 = that call passed a Python float (float64 carry, see oracle/xrl_oracle.py
- *                  gae_finish_path); steps after the last closed segment of an env are left untouched.
+ *                  gae_finish_path), bit2 = the bootstrap value of that call is 0 whatever bootv holds (set by the
+ *                  device rollouts for terminated envs: finish_path(0.0, i), ppo_agent.py:132); steps after the last
+ *                  closed segment of an env are left untouched.
  *   adv,ret      : [T][n_envs] outputs.  gamma/lam as double = the Python floats of the config.
  * Bit-exact with the reference for use_gae=1. */
 int xrl_gae_scan(const float* rew, const float* val, const float* term, const float* bootv,

@@ -567,3 +567,63 @@ def test_ragged_minibatches_vs_oracle(oracle, use_graph):
             assert_close(npy(got[k_]), val, 2e-5, f"param {k_} (pass {it})")
         assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss of the short minibatch")
     assert agent.learner.iterations == 10 * (3 if use_graph else 1)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pg_agent_rollout_and_update(use_graph):
+    """PG_Agent (pg_agent.py:12-79): actor-only model, stored values 0, paths closed with the processed reward of the cut
+    step, non-GAE returns; the whole-buffer update through the agent equals PG_Learner.update (pinned by
+    tests/golden/pg_*.npz) on the same sampled batch."""
+    from xuance_amd.agents import REGISTRY_Agents
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    from xuance_amd.learners import PG_Learner
+    from xuance_amd.nets import ActorNet
+    torch.manual_seed(0)
+    n, T, gamma = 16, 24, 0.98
+    cfg = make_config(n, T, n_epochs=1, n_minibatch=1, running_steps=4000, use_hip_graph=use_graph, use_gae=False,
+                      use_advnorm=False, activation="relu", representation_hidden_size=[128], actor_hidden_size=[128])
+    env = DeviceCartPoleVecEnv(n, seed=5)
+    env.max_episode_steps = 9                                     # truncations inside the horizon: paths cut with a bootstrap
+    agent = REGISTRY_Agents["PG"](cfg, env)
+    assert isinstance(agent.model, ActorNet) and isinstance(agent.learner, PG_Learner) and not agent.use_fused_rollout
+    for it in range(3 if use_graph else 2):
+        agent.rollout()
+        torch.cuda.synchronize()
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        assert not f["values"].any() and np.array_equal(f["bootv"], f["rewards"])
+        # returns: discounted sums inside a path; a path ends where seg is set, bootstrapped with the processed reward of that
+        # step unless the env terminated there (on_policy.py:246-252, 263-268; memory_tools.py:259-263)
+        ret = np.zeros((T, n), np.float64)
+        for e in range(n):
+            nxt = 0.0
+            for t in reversed(range(T)):
+                if f["seg"][t, e] & 1:
+                    assert bool(f["seg"][t, e] & 4) == bool(f["terminals"][t, e])       # terminated: finish_path(0.0, i)
+                    nxt = 0.0 if f["terminals"][t, e] else float(f["bootv"][t, e])
+                ret[t, e] = f["rewards"][t, e] + gamma * nxt
+                nxt = ret[t, e]
+        assert (f["seg"][T - 1] & 1).all() and (f["seg"][:T - 1] & 1).any()
+        assert_close(f["returns"], ret.astype(np.float32), 2e-6, "returns")
+        # advantages of the non-GAE branch: rewards[:-1] + gamma * vs[1:] - vs[:-1] with vs = 0 inside a path and `val` at
+        # its end (memory_tools.py:261) -- PG_Learner does not read them
+        end = (f["seg"] & 1) > 0
+        val = np.where(f["terminals"] > 0, 0.0, f["bootv"])
+        assert_close(f["advantages"], (f["rewards"] + np.where(end, gamma * val, 0.0)).astype(np.float32), 2e-6, "advantages")
+        # the agent's update against a stand-alone PG_Learner on the same batch, from the same parameters
+        twin = ActorNet(4, 2, "categorical", (128,), (128,), "relu")
+        twin.load_state_dict(agent.model.state_dict())
+        tl = PG_Learner(cfg, twin, None)
+        tl.optimizer.load_state_dict(agent.learner.optimizer.state_dict())
+        tl.iterations = agent.learner.iterations
+        idx = np.random.default_rng(it).permutation(n * T).reshape(1, -1)
+        agent.set_indices(idx)
+        info = agent.update()
+        env_i, t_i = np.divmod(idx[0], T)
+        ti = tl.update(obs=f["observations"][t_i, env_i], actions=f["actions"][t_i, env_i], returns=f["returns"][t_i, env_i],
+                       batch_size=n * T)
+        assert set(info) == set(ti) == {"actor-loss", "entropy", "learning_rate"}
+        for k in ti:
+            assert_close(info[k], ti[k], 1e-6, k)
+        got, ref = agent.model.state_dict(), twin.state_dict()
+        for k in ref:
+            assert_close(npy(got[k]), npy(ref[k]), 1e-6, f"param {k} after update {it}")

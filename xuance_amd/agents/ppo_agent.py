@@ -433,3 +433,68 @@ class A2C_Agent(PPO_Agent):
     def _build_learner(self, *args):
         from ..learners.ppo_learner import A2C_Learner
         return A2C_Learner(*args)
+
+
+class PG_Agent(PPO_Agent):
+    """Vanilla policy-gradient agent (xuance/torch/agents/policy_gradient/pg_agent.py:12-79 on core/on_policy.py:225-300):
+    the on-policy loop with the actor-only VanillaPolicyGradient model (nets.ActorNet) and PG_Learner.  What differs from
+    PPO_Agent's loop, as in the reference: the stored value of every step is 0 (on_policy.py:160 `values = 0 if values is
+    None`), and the "value" that closes a truncated or buffer-cut path is the PROCESSED REWARD of that step
+    (pg_agent.py:66-79 get_terminated_values returns `_process_reward(rewards)`); configs/pg/*.yaml set use_gae: False,
+    so returns are discounted reward sums and advantages = returns."""
+
+    def __init__(self, config, envs, callback=None):
+        config.use_fused_rollout = False                        # the fused rollout kernels evaluate an actor-critic
+        super().__init__(config, envs, callback)
+
+    def _build_model(self):
+        from ..nets import ActorNet
+        c = self.config
+        discrete = is_discrete(self.action_space)
+        rep = list(_get(c, "representation_hidden_size", []) or []) if _get(c, "representation", "Basic_MLP") != "Basic_Identical" else []
+        return ActorNet(self.obs_dim, self.action_space.n if discrete else int(self.action_space.shape[0]),
+                        "categorical" if discrete else "gaussian", rep, list(c.actor_hidden_size),
+                        _get(c, "activation", "leaky_relu"), None if discrete else _get(c, "activation_action", "tanh"),
+                        device=self.device)
+
+    def _build_learner(self, *args):
+        from ..learners.ppo_learner import PG_Learner
+        return PG_Learner(*args)
+
+    def _enqueue_step(self, t):
+        env, mem, n, D, A = self.envs, self.memory, self.n_envs, self.obs_dim, self.model.action_dim
+        f = mem.soa.fields
+        gaussian = self.model.dist == "gaussian"
+        ops.obs_normalize(x=env.buf_obs, mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=self.X,
+                          out1=f["observations"][t], n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(self.use_obsnorm),
+                          normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
+        heads = self.model.forward(self.X, n)
+        ops.policy_sample(heads=heads, log_std=self.model.params.ptr(self.model.log_std_name) if gaussian else None,
+                          act_out=f["actions"][t], val_out=None, logp_out=f["aux_old_logp"][t],
+                          env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
+                          bootv_prev=None, n=n, A=A, ld=self.model.head_ld, gaussian=int(gaussian),
+                          seed=self.seed, step=t, step_dev=self.step_counter)
+        if hasattr(env, "advance"):
+            env.step_device(offset=t)
+        else:
+            env.step_device()
+        ops.rollout_poststep(reward=env.reward, terminated=env.terminated, truncated=env.truncated, next_obs=env.next_obs,
+                             obs_mean=self.obs_mean, obs_var=self.obs_var, next_obs_norm=self.X[n:], rew_out=f["rewards"][t],
+                             term_out=f["terminals"][t], seg_out=f["seg"][t], ret_track=self.returns,
+                             ret_mean=self.ret_mean, ret_var=self.ret_var, ret_count=self.ret_count, n=n, D=D, ld_next=D,
+                             use_obsnorm=int(self.use_obsnorm), use_rewnorm=int(self.use_rewnorm),
+                             last_step=int(t == self.horizon_size - 1), obs_range=float(self.obsnorm_range),
+                             rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
+        # get_terminated_values = the processed reward (pg_agent.py:66-79); terminated envs close with 0 (seg bit 2)
+        f["bootv"][t].copy_(f["rewards"][t])
+
+    def _enqueue_rollout(self):
+        T = self.horizon_size
+        for t in range(T):
+            self._enqueue_step(t)
+        if hasattr(self.envs, "advance"):
+            self.envs.advance(T)
+        ops.counter_add(self.step_counter, T)
+        f = self.memory.soa.fields
+        ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
+                     self.gamma, self.gae_lam, self.memory.use_gae)

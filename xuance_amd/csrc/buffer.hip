@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(64) gae_scan_kernel(const float* __restrict__ 
         float r[CH], v[CH], d[CH], bv[CH];
         uint8_t sg[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { r[j] = nr[j]; v[j] = nv[j]; d[j] = nd_[j]; bv[j] = nbv[j]; sg[j] = nsg[j]; }
+        for (int j = 0; j < CH; ++j) { r[j] = nr[j]; v[j] = nv[j]; d[j] = nd_[j]; bv[j] = (nsg[j] & 4) ? 0.f : nbv[j]; sg[j] = nsg[j]; }
         if (t0 > 0) load_chunk(t0 - CH);
 #pragma unroll
         for (int j = CH - 1; j >= 0; --j) {
@@ -242,6 +242,7 @@ __global__ void __launch_bounds__(64 * NWV) gae_relay_kernel(const float* __rest
                 if (valid && t >= 0) {
                     const size_t o = (size_t)t * n_envs + e;
                     r[j] = rew[o]; v[j] = val[o]; d[j] = term[o]; bv[j] = bootv[o]; sg[j] = seg[o];
+                    if (sg[j] & 4) bv[j] = 0.f;               // device rollouts: the env terminated, finish_path(0.0, i)
                 } else { r[j] = v[j] = d[j] = bv[j] = 0.f; sg[j] = 0; }
             }
             const int tn = t0 + CH;

@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(xrl_sample_t p) {
             if (p.env_action_f) p.env_action_f[(size_t)e * A + j] = x;
         }
     }
-    p.val_out[e] = h[A];
+    if (p.val_out) p.val_out[e] = h[A];                  // actor-only policies (VanillaPolicyGradient) have no value column
     p.logp_out[e] = logp;
 }
 
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(POST_THREADS) poststep_kernel(xrl_poststep_t p
         const bool term = p.terminated[e] != 0.f, trunc = p.truncated[e] != 0.f;
         p.term_out[e] = term ? 1.f : 0.f;
         uint8_t sg = 0;
-        if (term || trunc || p.last_step) sg = 1 | (term ? 2 : 0);   // finish_path(0.0, i) is the float64-carry form
+        if (term || trunc || p.last_step) sg = 1 | (term ? 6 : 0);   // finish_path(0.0, i): float64-carry form (2), bootstrap value 0 (4)
         p.seg_out[e] = sg;
         p.ret_track[e] = p.gamma * p.ret_track[e] + r;              // self.returns = gamma * self.returns + rewards
     }
@@ -481,8 +481,9 @@ extern "C" int xrl_obs_normalize(const xrl_rms_t* params, xrl_stream_t stream) {
 extern "C" int xrl_policy_sample(const xrl_sample_t* params, xrl_stream_t stream) {
     XRL_CHECK_ARG(params != nullptr);
     const xrl_sample_t& p = *params;
-    XRL_CHECK_ARG(p.heads && p.n > 0 && p.A > 0 && p.ld > p.A);
-    XRL_CHECK_ARG((p.act_out && p.val_out && p.logp_out) || (!p.act_out && p.bootv_prev));
+    XRL_CHECK_ARG(p.heads && p.n > 0 && p.A > 0 && p.ld >= p.A);
+    XRL_CHECK_ARG(p.ld > p.A || (!p.val_out && !p.bootv_prev));     /* a value column only when someone reads it */
+    XRL_CHECK_ARG((p.act_out && p.logp_out) || (!p.act_out && p.bootv_prev));
     XRL_CHECK_ARG(!p.gaussian || p.log_std);
     hipLaunchKernelGGL(policy_sample_kernel, dim3((p.n + 255) / 256), dim3(256), 0, as_stream(stream), p);
     XRL_CHECK_LAUNCH();

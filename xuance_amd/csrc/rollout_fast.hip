@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_step_fast_kernel(xrl_ro
     // ---- bookkeeping (ppo_agent.py:128,144-157)
     const float reward = 1.0f;                               // (rew_slot: critic workgroup of this tile)
     p.term_slot[e] = term ? 1.f : 0.f;
-    p.seg_slot[e] = (term || trunc || p.last_step) ? (uint8_t)(1 | (term ? 2 : 0)) : (uint8_t)0;
+    p.seg_slot[e] = (term || trunc || p.last_step) ? (uint8_t)(1 | (term ? 6 : 0)) : (uint8_t)0;
     const float tr = p.gamma * rtrack0 + reward;
     if (term || trunc) { p.ret_final_out[e] = tr; p.ended_out[e] = 1; p.ret_track[e] = 0.f; }
     else { p.ended_out[e] = 0; p.ret_track[e] = tr; }

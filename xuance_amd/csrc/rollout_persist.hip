@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
                     // ---- bookkeeping
                     const float reward = 1.0f;
                     p.term_slot[(size_t)t * n + e] = term ? 1.f : 0.f;
-                    p.seg_slot[(size_t)t * n + e] = (term || trunc || last_step) ? (uint8_t)(1 | (term ? 2 : 0)) : (uint8_t)0;
+                    p.seg_slot[(size_t)t * n + e] = (term || trunc || last_step) ? (uint8_t)(1 | (term ? 6 : 0)) : (uint8_t)0;
                     const float tr = p.gamma * rtrack + reward;
                     if (term || trunc) { ret_final_out[e] = tr; ended_out[e] = 1; rtrack = 0.f; }
                     else { ended_out[e] = 0; rtrack = tr; }
