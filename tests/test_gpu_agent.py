@@ -29,14 +29,17 @@ def npy(t):
     return t.detach().cpu().numpy().copy()
 
 
-def test_rollout_and_update_vs_oracle(oracle):
+@pytest.mark.parametrize("use_gae", [True, False])
+def test_rollout_and_update_vs_oracle(oracle, use_gae):
+    """use_gae=False: discounted-sum returns (memory_tools.py:258-261), where a terminated env must close its path with 0
+    although bootv holds V(next_obs) -- bit 2 of `seg`."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv
     n, T = 24, 40
     torch.manual_seed(0)
     env = DeviceCartPoleVecEnv(n, seed=3)
     env.max_episode_steps = 25                     # force truncations inside the rollout
-    agent = PPO_Agent(make_config(n, T), env)
+    agent = PPO_Agent(make_config(n, T, use_gae=use_gae), env)
     sd0 = {k: npy(v) for k, v in agent.model.state_dict().items()}
     env.reset()
     agent._started = True
@@ -44,7 +47,7 @@ def test_rollout_and_update_vs_oracle(oracle):
     st.max_steps = 25
     obs_rms, ret_rms = oracle.RunningMeanStdOracle((4,)), oracle.RunningMeanStdOracle(())
     returns = np.zeros(n, np.float32)
-    buf = oracle.OnPolicyBufferOracle((4,), (), n, T, gamma=0.98, gae_lam=0.95)
+    buf = oracle.OnPolicyBufferOracle((4,), (), n, T, gamma=0.98, gae_lam=0.95, use_gae=use_gae)
     raw_obs = npy(env.buf_obs)
     f = agent.memory.soa.fields
     for t in range(T):
@@ -95,8 +98,9 @@ def test_rollout_and_update_vs_oracle(oracle):
     ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None, bootv_prev=f["bootv"][T - 1], n=n, A=2,
                       ld=3, gaussian=0, seed=1, step=0, step_dev=None)
     ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
-                 0.98, 0.95, True)
+                 0.98, 0.95, use_gae)
     torch.cuda.synchronize()
+    assert int(((npy(f["seg"]) & 4) > 0).sum()) == int((npy(f["terminals"]) > 0).sum()) > 0
     assert_close(npy(f["advantages"]).T, adv_full, 2e-5, "advantages", scale=float(np.abs(adv_full).max()))
     assert_close(npy(f["returns"]).T, ret_full, 2e-5, "returns", scale=float(np.abs(ret_full).max()))
     # ---- update phase ------------------------------------------------------------------------------------------
