@@ -162,10 +162,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    local_rank %= torch.cuda.device_count()            # (ranks share a device only in the 2-rank gloo test on a 1-GPU box)
+    os.environ["LOCAL_RANK"] = str(local_rank)
     torch.cuda.set_device(local_rank)
     if world > 1:
         from xuance_amd.dist import init_distributed_mode
-        init_distributed_mode("nccl")
+        init_distributed_mode(os.environ.get("XRL_DIST_BACKEND", "nccl"))     # "nccl" = RCCL over xGMI
     import torch.distributed as dist
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv

@@ -163,3 +163,25 @@ def test_offpolicy_learners_two_ranks(kind):
     trainable = np.abs(single - p0) > 0
     assert trainable.any()
     np.testing.assert_allclose(pa[trainable], single[trainable], rtol=0, atol=3e-6)
+
+
+def test_bench_contract_with_two_ranks():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank,
+    127.0.0.1 rendezvous), here with two ranks sharing the test box's one GPU over gloo: rank 0 prints ONE JSON line with
+    the whole-job value, max-over-ranks timing, n_gpus = 2, weak scaling."""
+    import json
+    import subprocess
+    env = dict(os.environ, XRL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--n-envs", "64", "--horizon", "64"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "env-steps/s"
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["env_steps_per_step"] == 2 * 64 * 64
+    assert abs(d["value"] - d["config"]["env_steps_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert any(k.endswith("/rank_0") for k in d["config"]["last_info"])
