@@ -43,3 +43,12 @@ def assert_close(a, b, tol=1e-5, what="", scale=1.0):
     err = np.abs(a - b) / np.maximum(float(scale), np.abs(b))
     assert np.all(np.isfinite(a)), f"{what}: non-finite values"
     assert err.max(initial=0.0) <= tol, f"{what}: max err {err.max():.3e} > {tol}"
+
+
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests: a fixed, pid-derived port could
+    still be held by the previous test's process group)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

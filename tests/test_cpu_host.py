@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, load_golden, sub
+from conftest import ROOT, load_golden, sub, free_port
 
 
 def test_library_exports_every_declared_symbol():
@@ -155,7 +155,7 @@ def test_multi_rank_plumbing_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 400
+    port = free_port()
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

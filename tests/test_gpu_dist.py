@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from conftest import ROOT  # noqa: E402
+from conftest import ROOT, free_port  # noqa: E402
 
 
 def _worker(rank, world, port, q):
@@ -51,7 +51,7 @@ def test_two_ranks_share_gradients_and_stay_in_sync():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 300
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -141,7 +141,7 @@ def test_offpolicy_learners_two_ranks(kind):
     from conftest import sub
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + os.getpid() % 300
+    port = free_port()
     procs = [ctx.Process(target=_offpolicy_worker, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
@@ -172,7 +172,7 @@ def test_bench_contract_with_two_ranks():
     import json
     import subprocess
     env = dict(os.environ, XRL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29700 + os.getpid() % 200
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--n-envs", "64", "--horizon", "64"]
