@@ -244,3 +244,28 @@ def test_shm_subproc_vec_env_matches_in_process_stepping():
     finally:
         venv.close()
     assert all(not p.is_alive() for p in venv.ps)
+
+
+def test_qmix_update_launch_grouping(monkeypatch):
+    """Host logic of the QMIX update (no GPU: the launch wrappers are replaced by recorders): the agent networks and the
+    mixer's hyper-networks share grouped launches -- 3 forward, 2 data-gradient, 1 weight-gradient launch per update --
+    and no launch exceeds the library's 8 groups (csrc/gemm.hip MAX_GROUPS)."""
+    import torch
+    from xuance_amd import nets, ops
+    calls = []
+    monkeypatch.setattr(ops, "gemm_desc", lambda *a, **k: (a, k))
+    monkeypatch.setattr(ops, "linear_fwd", lambda g: calls.append(("fwd", len(g))))
+    monkeypatch.setattr(ops, "linear_bwd_data", lambda g: calls.append(("dg", len(g))))
+    monkeypatch.setattr(ops, "linear_bwd_weight", lambda g, s, stride: calls.append(("wg", len(g))))
+    m = nets.MixingQNet(3, 30, 9, 48, (64,), (64,), 32, 32, "relu", device="cpu")
+    B, R = 32, 96
+    X, S = torch.zeros(2 * R, 30), torch.zeros(2 * B, 48)
+    outs = nets.Plan.forward_many([(m.agent_plan, X, 30, 2 * R, None), (m.agent_target_plan, X[R:], 30, R, m.target_flat),
+                                   (m.mixer_plan, S, 48, B, None), (m.mixer_target_plan, S[B:], 48, B, m.target_flat)])
+    assert [tuple(o.shape) for o in outs[:2]] == [(2 * R, 9), (2 * R, 9)] or outs[0].shape[1] == 9
+    nets.Plan.backward_many([(m.agent_plan, X, 30, R), (m.mixer_plan, S, 48, B)], torch.zeros(4, m.params.P), 1)
+    assert calls == [("fwd", 6), ("fwd", 8), ("fwd", 2), ("dg", 4), ("dg", 1), ("wg", 8)]
+    assert max(n for _, n in calls) <= 8
+    # 8 weight-gradient descriptors cover the 3 agent layers + 7 hyper-network layers (the three ReLU first layers of the
+    # hyper-networks are one stacked GEMM)
+    assert len(m.trainable_order) == 2 * (3 + 7)
