@@ -268,6 +268,26 @@ __global__ void __launch_bounds__(64 * NWV) gae_relay_kernel(const float* __rest
                 bool active = fl & 1, m64 = (fl & 2) != 0;
                 float last_f = c_lastf[lane];
                 double last_d = c_lastd[lane], disc = c_disc[lane];
+                if (use_gae) {
+                    // branch-free: both carry precisions advance at every step (each is reset at a path end, and a path
+                    // has one precision for its whole length, so the chain that is read never sees the other's steps);
+                    // the per-step work is two dependent fp32 and two dependent fp64 operations instead of a divergent
+                    // if / else nest (measured: ~450 cycles per step before)
+#pragma unroll
+                    for (int j = CH - 1; j >= 0; --j) {
+                        const bool end = (sg[j] & 1) != 0;
+                        active = active || end;
+                        m64 = end ? ((sg[j] & 2) != 0) : m64;
+                        last_f = end ? 0.f : last_f;
+                        last_d = end ? 0.0 : last_d;
+                        last_f = __fadd_rn(df[j], __fmul_rn(c2[j], last_f));                   // :256
+                        last_d = __dadd_rn(dd[j], __dmul_rn((double)c2[j], last_d));
+                        const bool live = active && (t0 + j >= 0);
+                        df[j] = m64 ? (float)last_d : last_f;
+                        wmask |= live ? (1u << j) : 0u;
+                        m64mask |= (live && m64) ? (1u << j) : 0u;
+                    }
+                } else
 #pragma unroll
                 for (int j = CH - 1; j >= 0; --j) {
                     if (t0 + j < 0) continue;
