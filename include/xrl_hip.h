@@ -693,16 +693,6 @@ int xrl_per_update_priorities(double* sum_tree, double* min_tree, double* max_pr
 int xrl_sync_target(const float* params, float* target, int64_t P, const xrl_adam_state_t* state,
                     int sync_frequency, xrl_stream_t stream);
 
-/* diagnostics: `iters` dependent v_mfma_f32_32x32x2_f32 per wave; out[0] shader cycles, out[1] wall-clock ticks */
-int xrl_debug_mfma_chain(int iters, int blocks, long long* out, float* sink, xrl_stream_t stream);
-/* diagnostics: 16 KB of straight-line VALU code executed `passes` times; out[pass] = shader cycles (pass 0 = cold I-cache) */
-int xrl_debug_icache(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream);
-/* diagnostics: 16 taken branches, each over 2 KB of padding; out[pass] = shader cycles (pass 0 = cold I-cache) */
-/* diagnostics: counter barrier + device-scope data exchange between n_wg workgroups pinned to one XCD (blockIdx % 8 == 0):
- * out[0] cycles per iteration (two barriers + exchange), out[1] wrong values seen, out[2] timeouts, out[3..] XCC id per workgroup */
-int xrl_debug_xcd_barrier(int iters, int n_wg, unsigned* counter, float* slots, long long* out, xrl_stream_t stream);
-int xrl_debug_ijump(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream);
-
 /* ------------------------------------------------------------------ hipGraph capture of op sequences */
 int xrl_graph_begin(xrl_stream_t stream);
 int xrl_graph_end(xrl_stream_t stream, void** graph_exec_out);

@@ -195,23 +195,35 @@ def run_learner_updates(learner, model, cb, batches, call):
     return out
 
 
-def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo"):
+def q16(a):
+    """BASELINE-size fixtures: inputs rounded to float16-representable float32 values (13 zero mantissa bits: the
+    .npz compresses to about half).  Parity does not care what the input values are."""
+    return np.asarray(a).astype(np.float16).astype(np.float32)
+
+
+def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo", size=None):
+    """size=None: the small round-1 fixtures.  size="c1" / "c2": the CartPole net at the minibatch sizes of BASELINE
+    configs C1 (128) and C2 (8 192); size="c4": the HalfCheetah-shape Gaussian net of configs/ppo/mujoco.yaml
+    (Basic_Identical, 17-256-256-6 / 17-256-256-1, leaky_relu, tanh action activation) at its per-GPU minibatch 4 096."""
     torch.manual_seed(1)
-    rng = np.random.default_rng(5)
-    act_fn = nn.LeakyReLU if dist == "categorical" else nn.ReLU
+    rng = np.random.default_rng(5 if size is None else {"c1": 105, "c2": 205, "c4": 405}[size])
+    act_fn = nn.LeakyReLU if (dist == "categorical" or size == "c4") else nn.ReLU
     init = torch.nn.init.orthogonal_
+    n_updates = 3 if size is None else 2
+    quant = (lambda a: a) if size is None else q16
     if dist == "categorical":
-        D, A, bs = 4, 2, 96
+        D, A, bs = 4, 2, {None: 96, "c1": 128, "c2": 8192}[size]
         rep = Basic_MLP((D,), [128], None, init, act_fn, "cpu")
         actor = CategoricalActorHead(128, [128], A, None, init, act_fn, "cpu")
         critic = ValueHead(128, [128], None, init, act_fn, "cpu")
         cfg = base_config(horizon_size=256, n_epochs=8, n_minibatch=8, vf_coef=0.25, ent_coef=0.01, clip_range=0.2,
                           end_factor_lr_decay=0.5)
     else:
-        D, A, bs = 17, 6, 80
+        D, A, bs = 17, 6, {None: 80, "c4": 4096}[size]
+        hid = [64, 64] if size is None else [256, 256]
         rep = Basic_Identical((D,), "cpu")
-        actor = GaussianActorHead(D, [64, 64], A, None, init, act_fn, nn.Tanh, "cpu")
-        critic = ValueHead(D, [64, 64], None, init, act_fn, "cpu")
+        actor = GaussianActorHead(D, hid, A, None, init, act_fn, nn.Tanh, "cpu")
+        critic = ValueHead(D, hid, None, init, act_fn, "cpu")
         cfg = base_config(horizon_size=256, n_epochs=16, n_minibatch=8, vf_coef=0.25, ent_coef=0.001, clip_range=0.2,
                           gamma=0.99)
     model = SharedActorCritic(rep, actor, critic)
@@ -226,21 +238,21 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo"):
         cfg.end_factor_lr_decay = 0.5
     learner = learner_cls(cfg, model, cb)
     batches = []
-    for u in range(3):
-        obs = np.clip(rng.standard_normal((bs, D)), -5, 5).astype(np.float32)
+    for u in range(n_updates):
+        obs = quant(np.clip(rng.standard_normal((bs, D)), -5, 5).astype(np.float32))
         with torch.no_grad():
             mo = model(torch.from_numpy(obs))
             if dist == "categorical":
                 actions = rng.integers(0, A, bs).astype(np.float32)
             else:
-                actions = rng.standard_normal((bs, A)).astype(np.float32)
+                actions = quant(rng.standard_normal((bs, A)).astype(np.float32))
             old_logp = mo.distributions.log_prob(torch.from_numpy(actions)).numpy()
-        old_logp = (old_logp + rng.standard_normal(bs) * 0.3).astype(np.float32)   # make ratios leave the clip range
+        old_logp = quant((old_logp + rng.standard_normal(bs) * 0.3).astype(np.float32))   # make ratios leave the clip range
         adv = rng.standard_normal(bs).astype(np.float32)
-        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).astype(np.float32)
-        ret = rng.standard_normal(bs).astype(np.float32)
+        adv = quant(((adv - adv.mean()) / (adv.std() + 1e-8)).astype(np.float32))
+        ret = quant(rng.standard_normal(bs).astype(np.float32))
         batches.append(dict(obs=obs, actions=actions, returns=ret, advantages=adv, old_logp=old_logp,
-                            values=rng.standard_normal(bs).astype(np.float32)))
+                            values=quant(rng.standard_normal(bs).astype(np.float32))))
 
     def call(b):
         return learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
@@ -250,24 +262,29 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo"):
     out["cfg"] = np.array([cfg.learning_rate, cfg.vf_coef, cfg.ent_coef, cfg.clip_range, cfg.grad_clip_norm,
                            getattr(cfg, "end_factor_lr_decay", 1.0),
                            cfg.running_steps if name == "a2c" else learner.total_iters])
-    np.savez_compressed(os.path.join(OUT, f"{name}_{dist}.npz"), **out)
+    if size is not None:
+        out["n_updates"] = np.int64(n_updates)
+    np.savez_compressed(os.path.join(OUT, f"{name}_{dist}{'_' + size if size else ''}.npz"), **out)
 
 
 # ------------------------------------------------------------------------------ DQN
-def golden_dqn(kind, learner_cls=None, name=None, model_cls=None):
+def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None):
     """learner_cls: DQN_Learner (default), DDQN_Learner (ddqn_learner.py:39-47, the double-Q target) or DuelDQN_Learner
-    with model_cls=DuelingDeepQNetwork (dueldqn_learner.py:28-75, q_head.py:42-80)."""
+    with model_cls=DuelingDeepQNetwork (dueldqn_learner.py:28-75, q_head.py:42-80).
+    size="c3" (kind "cnn"): the batch of configs/dqn/atari.yaml:27 (32 frames of 84x84x4), two updates, lr 1e-4, no clip;
+    frames take 16 grey levels so the file compresses."""
     learner_cls = learner_cls or DQN_Learner
     model_cls = model_cls or DeepQNetwork
     torch.manual_seed(2)
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(9 if size is None else 309)
+    n_updates = 3 if size is None else 2
     init = torch.nn.init.orthogonal_
     if kind == "mlp":
         D, A, bs = 6, 4, 32
         rep = Basic_MLP((D,), [64], None, init, nn.ReLU, "cpu")
         hidden = [64]
     else:
-        A, bs = 4, 4
+        A, bs = 4, (4 if size is None else 32)
         rep = Basic_CNN((84, 84, 4), [8, 4, 3], [4, 2, 1], [32, 64, 64], None, init, nn.ReLU, "cpu")
         hidden = [512]
     model = model_cls(rep, hidden, sp.Discrete(A), None, init, nn.ReLU, "cpu")
@@ -279,15 +296,18 @@ def golden_dqn(kind, learner_cls=None, name=None, model_cls=None):
         for n, p in model.named_parameters():
             if n.startswith("target_"):
                 p.add_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.05))
-    cfg = base_config(learning_rate=1e-3, gamma=0.99, sync_frequency=2, start_training=0, training_frequency=1,
-                      use_grad_clip=(kind == "mlp"), grad_clip_norm=0.5)
+    cfg = base_config(learning_rate=1e-3 if size is None else 1e-4, gamma=0.99, sync_frequency=2, start_training=0,
+                      training_frequency=1, use_grad_clip=(kind == "mlp"), grad_clip_norm=0.5)
     cb = Capture()
     learner = learner_cls(cfg, model, cb)
     batches = []
-    for u in range(3):
+    for u in range(n_updates):
         if kind == "mlp":
             obs = rng.standard_normal((bs, D)).astype(np.float32)
             nxt = rng.standard_normal((bs, D)).astype(np.float32)
+        elif size is not None:
+            obs = (rng.integers(0, 16, (bs, 84, 84, 4)) * 17).astype(np.uint8)
+            nxt = (rng.integers(0, 16, (bs, 84, 84, 4)) * 17).astype(np.uint8)
         else:
             obs = rng.integers(0, 256, (bs, 84, 84, 4)).astype(np.uint8)
             nxt = rng.integers(0, 256, (bs, 84, 84, 4)).astype(np.uint8)
@@ -300,18 +320,21 @@ def golden_dqn(kind, learner_cls=None, name=None, model_cls=None):
     out = run_learner_updates(learner, model, cb, batches, call)
     out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm,
                            float(cfg.use_grad_clip), learner.total_iters])
-    np.savez_compressed(os.path.join(OUT, f"{name or 'dqn'}_{kind}.npz"), **out)
+    if size is not None:
+        out["n_updates"] = np.int64(n_updates)
+    np.savez_compressed(os.path.join(OUT, f"{name or 'dqn'}_{kind}{'_' + size if size else ''}.npz"), **out)
 
 
 # ------------------------------------------------------------------------------ QMIX (feed-forward)
-def golden_qmix(double_q, algo="qmix"):
+def golden_qmix(double_q, algo="qmix", size=None):
     """algo: qmix (QMIX_Learner + QMIX_Mixer), vdn (VDN_Learner + VDN_Mixer, vdn_learner.py:13-106), iql (IQL_Learner +
-    IndependentMixer, iql_learner.py:13-142): same feed-forward agents, same batches."""
+    IndependentMixer, iql_learner.py:13-142): same feed-forward agents, same batches.
+    size="c5": batch 32 (configs/qmix/sc2/3m.yaml:32)."""
     from xuance.torch.rl_models.critics.base_critics import DiscreteActionValueCritic
     from xuance.torch.rl_models.representations.agent_feature import AgentFeatureEncoder
     torch.manual_seed(3)
-    rng = np.random.default_rng(13)
-    N, O, S, A, B = 3, 30, 48, 9, 16
+    rng = np.random.default_rng(13 if size is None else 513)
+    N, O, S, A, B = 3, 30, 48, 9, (16 if size is None else 32)
     agent_keys = [f"agent_{i}" for i in range(N)]
     grouping = AgentGrouping.shared(agent_keys)            # agents_marl.py:210-215
     group = grouping.group_keys[0]
@@ -365,10 +388,10 @@ def golden_qmix(double_q, algo="qmix"):
     out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm, float(double_q),
                            learner.total_iters])
     out["group"] = np.array(group)
-    np.savez_compressed(os.path.join(OUT, f"{algo}_ff_{'double' if double_q else 'single'}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"{algo}_ff_{'double' if double_q else 'single'}{'_' + size if size else ''}.npz"), **out)
 
 
-def golden_qmix_rnn(double_q=True, fixed=False, rnn="GRU"):
+def golden_qmix_rnn(double_q=True, fixed=False, rnn="GRU", size=None):
     """QMIX_Learner.update with recurrent agents (3m.yaml defaults: Basic_RNN fc 64 + GRU 64, q_hidden 64) on episode
     samples in the layout MARL_OffPolicyBuffer_RNN.sample returns (memory_tools_marl.py:970-996).
 
@@ -386,8 +409,10 @@ def golden_qmix_rnn(double_q=True, fixed=False, rnn="GRU"):
     from xuance.torch.rl_models.representations import Basic_RNN
     from xuance.torch.rl_models.modules.identity_encoder import build_identity_encoder, IdentityFeatureFusion
     torch.manual_seed(4)
-    rng = np.random.default_rng(17)
-    N, O, S, A, B, T = 3, 30, 48, 9, 8, 12
+    rng = np.random.default_rng(17 if size is None else 517)
+    N, O, S, A, B, T = (3, 30, 48, 9, 8, 12) if size is None else (3, 30, 48, 9, 32, 60)   # c5: 3m.yaml:32, smac.rst:19
+    n_updates = 3 if size is None else 2
+    quant = (lambda a: a) if size is None else q16
     agent_keys = [f"agent_{i}" for i in range(N)]
     grouping = AgentGrouping.shared(agent_keys)
     group = grouping.group_keys[0]
@@ -432,7 +457,7 @@ def golden_qmix_rnn(double_q=True, fixed=False, rnn="GRU"):
         cls = QMIX_Learner_Fixed
     learner = cls(cfg, grouping, model, cb)
     batches, samples = [], []
-    for u in range(3):
+    for u in range(n_updates):
         avail = (rng.random((B, N, T + 1, A)) < 0.7)
         avail[..., 0] = True
         acts = np.zeros((B, N, T), np.float32)
@@ -449,10 +474,10 @@ def golden_qmix_rnn(double_q=True, fixed=False, rnn="GRU"):
                 term[b, :, lengths[b] - 1] = True               # episode ended by termination (all agents)
             else:
                 term[b, 0, lengths[b] - 1] = True               # only one agent: terminals_tot stays 0 (truncation)
-        b = dict(obs=rng.standard_normal((B, N, T + 1, O)).astype(np.float32), actions=acts,
-                 rewards=rng.standard_normal((B, N, T)).astype(np.float32), terminals=term,
+        b = dict(obs=quant(rng.standard_normal((B, N, T + 1, O)).astype(np.float32)), actions=acts,
+                 rewards=quant(rng.standard_normal((B, N, T)).astype(np.float32)), terminals=term,
                  agent_mask=(rng.random((B, N, T)) < 0.85), avail_actions=avail,
-                 state=rng.standard_normal((B, T + 1, S)).astype(np.float32), filled=filled)
+                 state=quant(rng.standard_normal((B, T + 1, S)).astype(np.float32)), filled=filled)
         batches.append(b)
         sample = {k: {a: b[k][:, i] for i, a in enumerate(agent_keys)}
                   for k in ("obs", "actions", "rewards", "terminals", "agent_mask", "avail_actions")}
@@ -463,7 +488,9 @@ def golden_qmix_rnn(double_q=True, fixed=False, rnn="GRU"):
     out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm, float(double_q),
                            learner.total_iters])
     out["group"] = np.array(group)
-    np.savez_compressed(os.path.join(OUT, f"qmix_{'rnn' if rnn == 'GRU' else rnn.lower()}_{'double' if double_q else 'single'}{'_fixed' if fixed else ''}.npz"),
+    if size is not None:
+        out["n_updates"] = np.int64(n_updates)
+    np.savez_compressed(os.path.join(OUT, f"qmix_{'rnn' if rnn == 'GRU' else rnn.lower()}_{'double' if double_q else 'single'}{'_fixed' if fixed else ''}{'_' + size if size else ''}.npz"),
                         **out)
 
 
@@ -573,13 +600,16 @@ def golden_marl_ff_buffer():
     np.savez_compressed(os.path.join(OUT, "marl_ff_buffer.npz"), **out)
 
 
-def golden_checkpoint():
+def golden_checkpoint(decay=False):
     """Checkpoint compatibility: a `.pth` written by the reference's Learner.save_model
     (drl_learner.py:64-93) after two PPO updates, and the parameters the REFERENCE reaches when a fresh learner loads that
-    file (load_model, :95-157) and makes a third update.  tests/golden/ppo_ckpt_ref.pth + ppo_ckpt.npz."""
+    file (load_model, :95-157) and makes a third update.  tests/golden/ppo_ckpt_ref.pth + ppo_ckpt.npz.
+    decay=True: end_factor_lr_decay 0.5 over a short LinearLR horizon (128 iterations), so the schedule is visible: the
+    reference resumes from the DECAYED param-group lr with a fresh scheduler (its chained LinearLR form then continues as
+    lr_saved * (1 + (ef - 1) * j / total), j = steps since the resume).  ppo_ckpt_decay_ref.pth + ppo_ckpt_decay.npz."""
     import copy
     torch.manual_seed(6)
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(31 if not decay else 131)
     init = torch.nn.init.orthogonal_
     D, A, bs = 4, 2, 64
 
@@ -589,6 +619,8 @@ def golden_checkpoint():
         critic = ValueHead(128, [128], None, init, nn.LeakyReLU, "cpu")
         m = SharedActorCritic(rep, actor, critic)
         cfg = base_config(horizon_size=256, n_epochs=8, n_minibatch=8, vf_coef=0.25, ent_coef=0.01, clip_range=0.2)
+        if decay:
+            cfg.running_steps, cfg.end_factor_lr_decay = 2048, 0.5
         return m, PPO_Learner(cfg, m, Capture())
     model, learner = build()
     batches = []
@@ -606,8 +638,9 @@ def golden_checkpoint():
         return l.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
                         advantages=b["advantages"], aux_batch={"old_logp": b["old_logp"]}, batch_size=bs)
     out = flat("init", sd_np(model))
-    call(learner, batches[0]); call(learner, batches[1])
-    path = os.path.join(OUT, "ppo_ckpt_ref.pth")
+    call(learner, batches[0]); info1 = call(learner, batches[1])
+    tag = "ppo_ckpt_decay" if decay else "ppo_ckpt"
+    path = os.path.join(OUT, tag + "_ref.pth")
     learner.save_model(path)
     out.update(flat("saved", sd_np(model)))
     model2, learner2 = build()                                      # fresh process: new model, new optimiser
@@ -618,7 +651,13 @@ def golden_checkpoint():
         out.update(flat(f"u{u}/batch", b))
     out["resumed_info/learning_rate"] = np.float64(info["learning_rate"])
     out["resumed_info/actor_loss"] = np.float64(info["actor_loss"])
-    np.savez_compressed(os.path.join(OUT, "ppo_ckpt.npz"), **out)
+    if decay:
+        out["saved_info/learning_rate"] = np.float64(info1["learning_rate"])
+        out["total_iters"] = np.int64(learner.total_iters)
+        info4 = call(learner2, batches[0])                            # a second update after the resume
+        out["resumed2_info/learning_rate"] = np.float64(info4["learning_rate"])
+        out.update(flat("resumed2", sd_np(model2)))
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
 
 
 def golden_per_buffer():
@@ -710,8 +749,28 @@ def golden_pg(dist):
     np.savez_compressed(os.path.join(OUT, f"pg_{dist}.npz"), **out)
 
 
+def golden_baseline_sizes():
+    """Fixtures at the batch sizes of the BASELINE configs (C1 128, C2 8 192, C3 32 frames, C4 4 096 on 17-256-256,
+    C5 32 transitions / 32 episodes x 60 steps): the split-K epilogues, multi-slab reductions and multi-tile paths of
+    the HIP kernels only engage at these sizes."""
+    golden_ppo("categorical", size="c1")
+    golden_ppo("categorical", size="c2")
+    golden_ppo("gaussian", size="c4")
+    golden_dqn("cnn", size="c3")
+    golden_qmix(True, size="c5")
+    golden_qmix_rnn(True, size="c5")
+    golden_qmix_rnn(True, fixed=True, size="c5")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "sized":
+        golden_baseline_sizes()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in globals():               # one generator by name, e.g. `golden_checkpoint decay=True`
+        kw = {k: eval(v) for k, v in (a.split("=") for a in sys.argv[2:])}
+        globals()[sys.argv[1]](**kw)
+        sys.exit(0)
     golden_onpolicy_buffer()
     golden_offpolicy_buffer()
     golden_rms()
@@ -737,8 +796,10 @@ if __name__ == "__main__":
     golden_marl_rnn_buffer()
     golden_marl_ff_buffer()
     golden_checkpoint()
+    golden_checkpoint(decay=True)
     golden_per_buffer()
     golden_pg("categorical")
     golden_pg("gaussian")
+    golden_baseline_sizes()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1120,6 +1120,63 @@ def categorical_sample_icdf(logits, u):
     return np.minimum(k, logits.shape[-1] - 1)
 
 
+def gaussian_sample_reparam(mu, log_std, z):
+    """Normal(mu, exp(log_std)).sample() with supplied standard normals z and its summed log-prob
+    (DiagGaussianDistribution.stochastic_sample / log_prob, distributions.py:172-180): x = mu + std * z."""
+    mu, z = mu.astype(np.float32), z.astype(np.float32)
+    ls = log_std.astype(np.float32)
+    std = np.exp(ls)
+    x = (mu + std * z).astype(np.float32)
+    lp = (-((x - mu) ** 2) / (2 * std * std) - ls - np.float32(math.log(math.sqrt(2 * math.pi)))).sum(-1)
+    return x, lp.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Philox4x32-10 (Salmon et al., SC'11) as the device uses it (csrc/rng.h): key = 64-bit seed, counter (c0, c1, c2, 0).
+# OUR engine's random streams, not the reference's (torch / NumPy generators cannot be matched): restated so that a
+# whole device rollout -- reset states and sampled actions included -- can be replayed on the CPU.
+# --------------------------------------------------------------------------------------
+STREAM_ACTION, STREAM_GAUSS, STREAM_RESET_A, STREAM_RESET_B = 0x41435431, 0x47415500, 0x52455345, 0x52455346
+
+
+def philox4x32(seed, c0, c1, c2, c3=0):
+    """Vectorised over the counter words (uint32 arrays or scalars; the device always uses c3 = 0); returns four uint32
+    arrays.  Pinned by the three known-answer vectors of Random123's kat_vectors (tests/test_cpu_host.py)."""
+    c0, c1, c2, c3 = np.broadcast_arrays(np.asarray(c0, np.uint64), np.asarray(c1, np.uint64), np.asarray(c2, np.uint64),
+                                         np.asarray(c3, np.uint64))
+    c = [c0 & 0xFFFFFFFF, c1 & 0xFFFFFFFF, c2 & 0xFFFFFFFF, c3 & 0xFFFFFFFF]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return [x.astype(np.uint32) for x in c]
+
+
+def u01(x):
+    """rng.h u01: top 24 bits -> [0, 1) float32."""
+    return ((np.asarray(x, np.uint32) >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
+
+def u01d(a, b):
+    a, b = np.asarray(a, np.uint64), np.asarray(b, np.uint64)
+    return (((a << np.uint64(21)) ^ b) & np.uint64((1 << 53) - 1)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def cartpole_reset_state(seed, envs, episodes):
+    """cartpole.h cartpole_reset: uniform(-0.05, 0.05) float64 state of env `e` at the start of its `episode`-th episode."""
+    r = philox4x32(seed, envs, episodes, STREAM_RESET_A)
+    q = philox4x32(seed, envs, episodes, STREAM_RESET_B)
+    return np.stack([-0.05 + 0.1 * u01d(r[j], q[j]) for j in range(4)], -1)
+
+
+def action_uniforms(seed, n_envs, step):
+    """The uniform the device draws for env e at global vector step `step` (xrl_policy_sample / the fused rollout kernels)."""
+    return u01(philox4x32(seed, np.arange(n_envs), step, STREAM_ACTION)[0])
+
+
 # --------------------------------------------------------------------------------------
 # CartPole-v1 physics (public equations, Barto-Sutton-Anderson 1983 / Gymnasium classic_control;
 # NOT part of the reference tree -- SURVEY.md section 7).  float64 state, float32 observations.

@@ -269,3 +269,21 @@ def test_qmix_update_launch_grouping(monkeypatch):
     # 8 weight-gradient descriptors cover the 3 agent layers + 7 hyper-network layers (the three ReLU first layers of the
     # hyper-networks are one stacked GEMM)
     assert len(m.trainable_order) == 2 * (3 + 7)
+
+
+def test_oracle_philox_known_answer_vectors():
+    """oracle.philox4x32 (the restatement of csrc/rng.h that lets the oracle replay the device's reset states and action
+    draws) against the three Philox4x32-10 known-answer vectors published with Random123 (kat_vectors: counter, key -> out)."""
+    from oracle import xrl_oracle as o
+    kat = [((0, 0, 0, 0), 0, (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, 0xffffffffffffffff, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0x299f31d0 << 32) | 0xa4093822,
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kat:
+        assert tuple(int(x) for x in o.philox4x32(key, *ctr)) == out
+    # vectorised over env indices, 24-bit uniforms in [0, 1), float64 reset states in [-0.05, 0.05)
+    u = o.action_uniforms(5, 1000, 17)
+    assert u.dtype == np.float32 and 0 <= u.min() and u.max() < 1 and abs(float(u.mean()) - 0.5) < 0.05
+    s = o.cartpole_reset_state(3, np.arange(64), np.arange(64) % 5)
+    assert s.shape == (64, 4) and s.dtype == np.float64 and np.abs(s).max() < 0.05
+    assert not np.array_equal(s[0], o.cartpole_reset_state(3, np.arange(1), 1)[0])

@@ -101,8 +101,8 @@ def test_rollout_and_update_vs_oracle(oracle, use_gae):
                  0.98, 0.95, use_gae)
     torch.cuda.synchronize()
     assert int(((npy(f["seg"]) & 4) > 0).sum()) == int((npy(f["terminals"]) > 0).sum()) > 0
-    assert_close(npy(f["advantages"]).T, adv_full, 2e-5, "advantages", scale=float(np.abs(adv_full).max()))
-    assert_close(npy(f["returns"]).T, ret_full, 2e-5, "returns", scale=float(np.abs(ret_full).max()))
+    assert_close(npy(f["advantages"]).T, adv_full, 1e-5, "advantages", scale=float(np.abs(adv_full).max()))
+    assert_close(npy(f["returns"]).T, ret_full, 1e-5, "returns", scale=float(np.abs(ret_full).max()))
     # ---- update phase ------------------------------------------------------------------------------------------
     agent.memory.ptr, agent.memory.size = 0, T
     info = agent.update()
@@ -119,10 +119,10 @@ def test_rollout_and_update_vs_oracle(oracle, use_gae):
     for key in ("actor_loss", "critic_loss", "entropy", "predict_value"):
         ref = {"actor_loss": oinfo["a_loss"], "critic_loss": oinfo["c_loss"], "entropy": oinfo["e_loss"],
                "predict_value": oinfo["predict_value"]}[key]
-        assert_close(info[key], ref, 5e-5, key)
+        assert_close(info[key], ref, 1e-5, key)
     got = agent.model.state_dict()
     for k_, v in sd.items():
-        assert_close(npy(got[k_]), v, 5e-5, f"param {k_} after {idx.shape[0]} updates")
+        assert_close(npy(got[k_]), v, 1e-5, f"param {k_} after {idx.shape[0]} updates")
 
 
 def test_graph_replay_equals_eager():
@@ -287,7 +287,7 @@ def test_fused_minibatch_kernel_equals_layered_path(n, T, nmb):
     g_fused = npy(lr.optimizer.grad); info_fused = lr.last_info(bs); diag_fused = npy(lr.diag.view(-1)[:4 * bs])
     scale = float(np.abs(g_ref).max())
     assert scale > 0
-    assert_close(g_fused / scale, g_ref / scale, 2e-5, "gradient")
+    assert_close(g_fused / scale, g_ref / scale, 1e-5, "gradient")
     for key in ("actor_loss", "critic_loss", "entropy", "predict_value", "clip_ratio"):
         assert_close(info_fused[key], info_ref[key], 1e-5, key)
     assert_close(diag_fused, diag_ref, 1e-5, "log_prob/ratio/surrogates")
@@ -424,7 +424,7 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle):
                                   dist="gaussian", act="leaky_relu", activation_action="tanh")
     got = agent.model.state_dict()
     for k_, val in sd.items():
-        assert_close(npy(got[k_]), val, 2e-5, f"param {k_}")
+        assert_close(npy(got[k_]), val, 1e-5, f"param {k_}")
     assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss")
 
 
@@ -461,7 +461,7 @@ def test_a2c_agent_vs_oracle(oracle, use_graph):
                                                 advantages=s["advantages"]), c, loss_kind="a2c")
         got = agent.model.state_dict()
         for k_, val in sd.items():
-            assert_close(npy(got[k_]), val, 2e-5, f"param {k_} after update {it}")
+            assert_close(npy(got[k_]), val, 1e-5, f"param {k_} after update {it}")
         assert_close(info["actor-loss"], oi["a_loss"], 1e-5, "actor-loss")
         assert_close(info["critic-loss"], oi["c_loss"], 1e-5, "critic-loss")
         assert_close(info["learning_rate"], oi["learning_rate"], 1e-9, "lr")
@@ -568,7 +568,7 @@ def test_ragged_minibatches_vs_oracle(oracle, use_graph):
         assert n_updates == 10 and len(s["obs"]) == 2
         got = agent.model.state_dict()
         for k_, val in sd.items():
-            assert_close(npy(got[k_]), val, 2e-5, f"param {k_} (pass {it})")
+            assert_close(npy(got[k_]), val, 1e-5, f"param {k_} (pass {it})")
         assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss of the short minibatch")
     assert agent.learner.iterations == 10 * (3 if use_graph else 1)
 
@@ -631,3 +631,59 @@ def test_pg_agent_rollout_and_update(use_graph):
         got, ref = agent.model.state_dict(), twin.state_dict()
         for k in ref:
             assert_close(npy(got[k]), npy(ref[k]), 1e-6, f"param {k} after update {it}")
+
+
+def test_unusable_whole_rollout_launch_falls_back_and_redoes_the_rollout():
+    """The whole-rollout launch reports workgroups on more than one XCD (status[2]) or a barrier time-out (status[0]); the
+    kernel leaves at its first step boundary.  Fault injected by a memset of the XCC mask captured in front of the launch:
+    the agent must notice on its FIRST rollout (read synchronously), restore simulator / statistics / counters, fall
+    back to per-step launches for good and redo the rollout -- ending bit-identical to an agent that never used it."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    res = []
+    for inject in (False, True):
+        torch.manual_seed(0)
+        env = DeviceCartPoleVecEnv(64, seed=3)
+        env.max_episode_steps = 30
+        agent = PPO_Agent(make_config(64, 48, use_hip_graph=True, use_persistent_rollout=inject), env)
+        if inject:
+            orig = agent._persistent_ok
+
+            def faulty(split_ok):
+                ok = orig(split_ok)
+                if ok:
+                    agent.persist_status[2:3].fill_(1 << 15)          # "another XCD was seen"
+                return ok
+            agent._persistent_ok = faulty
+            with pytest.warns(UserWarning, match="whole-rollout launch unusable"):
+                agent.rollout()
+            assert agent.persist_status is None and agent.config.use_persistent_rollout is False
+        else:
+            agent.rollout()
+        agent.rollout()
+        info = agent.update()                                         # no status to complain about
+        torch.cuda.synchronize()
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        f.update(cp_state=npy(env.state), cp_episodes=npy(env.episodes), ret_track=npy(agent.returns),
+                 obs_stats=npy(agent.pp["obs_stats"][0]), params=npy(agent.model.params.flat), step=npy(agent.step_counter))
+        res.append(f)
+        assert agent.current_step == 2 * 64 * 48 and np.isfinite(info["actor_loss"])
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
+def test_whole_rollout_time_out_after_the_first_rollout_raises_at_the_update_readback():
+    """Later rollouts are not read synchronously; their status words ride in the learner's read-back block and a raised
+    flag makes PPO_Agent.update() fail loudly instead of training on a partly stale buffer."""
+    from xuance_amd import ops
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(0)
+    agent = PPO_Agent(make_config(64, 32, use_hip_graph=True), DeviceCartPoleVecEnv(64, seed=3))
+    agent.rollout()
+    assert agent.persist_status is not None and agent._persist_status_ok(agent.persist_status.tolist())
+    agent.update()
+    agent.rollout()
+    agent.persist_status[0:1].fill_(1)                                # what a barrier time-out leaves behind
+    with pytest.raises(ops.XrlError, match="xrl_rollout_cartpole_persistent"):
+        agent.update()

@@ -1,0 +1,162 @@
+"""GPU: the HEADLINE configuration (BASELINE.json configs[1]: PPO-Clip CartPole-v1, 256 envs x horizon 256, 8 epochs x 8
+minibatches of 8 192, graphs on, the whole-rollout launch + the fused minibatch kernel + the fused optimiser launch --
+exactly what bench.py times) replayed by the oracle.
+
+Fixed inputs are only what no two RNG implementations can share: the device's sampled actions and its minibatch
+indices.  Even those are checked: the oracle's Philox restatement reproduces the reset states exactly and the sampled
+actions through its own inverse-CDF draw on its own logits (up to knife-edge ties |cdf - u| < 1e-6).  Everything else --
+physics, running statistics, normalised observations / rewards, values, log-probs, bootstrap values, path flags, GAE,
+advantage normalisation and all 64 minibatch updates -- is recomputed by the oracle and compared at 1e-5; GAE on the
+device's own stored rewards / values is compared bit for bit."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def c2_config(n, T, **kw):
+    c = dict(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128],
+             critic_hidden_size=[128], activation="leaky_relu", seed=1, parallels=n, running_steps=10 ** 7,
+             horizon_size=T, n_epochs=8, n_minibatch=8, learning_rate=4e-4, vf_coef=0.25, ent_coef=0.01,
+             clip_range=0.2, gamma=0.98, use_gae=True, gae_lambda=0.95, use_advnorm=True, use_grad_clip=True,
+             grad_clip_norm=0.5, use_obsnorm=True, use_rewnorm=True, obsnorm_range=5, rewnorm_range=5,
+             distributed_training=False, device="cuda", model_dir="/tmp/xrl_models", use_hip_graph=True)
+    c.update(kw)
+    return Namespace(**c)
+
+
+def replay_rollout(oracle, sd, f, n, T, env_seed, agent_seed, step0, carry, max_steps=500, gamma=0.98, lam=0.95):
+    """The oracle's mirror of ppo_agent.py:113-177 over one stored device rollout `f` (time-major field arrays).
+    carry: dict(st, episodes, raw_obs, obs_rms, ret_rms, returns) carried from rollout to rollout.
+    Returns the oracle's buffer (own GAE) and the number of knife-edge action draws."""
+    st, episodes, obs_rms, ret_rms = carry["st"], carry["episodes"], carry["obs_rms"], carry["ret_rms"]
+    raw_obs, returns = carry["raw_obs"], carry["returns"]
+    buf = oracle.OnPolicyBufferOracle((4,), (), n, T, gamma=gamma, gae_lam=lam)
+    knife = 0
+    for t in range(T):
+        obs_rms.update(raw_obs)
+        obs_n = oracle.process_observation(raw_obs, obs_rms).astype(np.float32)
+        assert_close(f["observations"][t], obs_n, 1e-5, f"normalised obs t={t}")
+        logits, value = oracle.actor_critic_forward(sd, obs_n)
+        acts = f["actions"][t]                                         # fixed input: the device's sampled actions
+        # ... which the oracle's own draw reproduces: same Philox uniform, inverse CDF over its own softmax
+        u = oracle.action_uniforms(agent_seed, n, step0 + t)
+        mine = oracle.categorical_sample_icdf(logits, u)
+        diff = np.flatnonzero(mine != acts.astype(int))
+        if diff.size:
+            p0 = np.exp(oracle.log_softmax(logits.astype(np.float32)))[diff, 0]
+            assert np.all(np.abs(p0 - u[diff]) < 1e-6), f"sampled actions differ away from a tie at t={t}"
+            knife += diff.size
+        logp = oracle.log_softmax(logits)[np.arange(n), acts.astype(int)]
+        assert_close(f["values"][t], value, 1e-5, f"values t={t}")
+        assert_close(f["aux_old_logp"][t], logp, 1e-5, f"old_logp t={t}")
+        next_obs, rew, term, trunc = st.step(acts.astype(int))
+        rew_n = oracle.process_reward(rew, ret_rms).astype(np.float32)
+        assert_close(f["rewards"][t], rew_n, 1e-5, f"normalised reward t={t}")
+        assert np.array_equal(f["terminals"][t] > 0, term), f"terminals t={t}"
+        buf.store(obs_n, acts, rew_n, value, term, {"old_logp": logp})
+        boot = oracle.actor_critic_forward(sd, oracle.process_observation(next_obs, obs_rms).astype(np.float32))[1]
+        done = term | trunc
+        ends = done | (t == T - 1)
+        assert np.array_equal((f["seg"][t] & 1) > 0, ends), f"path ends t={t}"
+        assert_close(f["bootv"][t][ends], boot[ends], 1e-5, f"bootstrap values t={t}")
+        if buf.full:                                                   # ppo_agent.py:129-135
+            for i in range(n):
+                buf.finish_path(0.0 if term[i] else boot[i], i)
+        returns = (gamma * returns + rew).astype(np.float32)
+        for i in np.flatnonzero(done):
+            ret_rms.update(returns[i:i + 1])
+            returns[i] = 0.0
+            if not buf.full:
+                buf.finish_path(0.0 if term[i] else boot[i], i)
+        if done.any():                                                 # reset states: the oracle's own Philox draw
+            idx = np.flatnonzero(done)
+            episodes[idx] += 1
+            st.state[idx] = oracle.cartpole_reset_state(env_seed, idx, episodes[idx])
+            st.steps[idx] = 0
+        raw_obs = np.where(done[:, None], st.state.astype(np.float32), next_obs)
+    carry.update(raw_obs=raw_obs, returns=returns)
+    return buf, knife
+
+
+def gae_bit_exact(oracle, f, n, T, gamma=0.98, lam=0.95):
+    """memory_tools.py:242-265 on the device's OWN stored rewards / values / flags: bit for bit."""
+    for e in range(n):
+        start = 0
+        for t in np.flatnonzero(f["seg"][:, e] & 1):
+            v = 0.0 if (f["seg"][t, e] & 2) else np.float32(f["bootv"][t, e])
+            r_, a_ = oracle.gae_finish_path(f["rewards"][start:t + 1, e], f["values"][start:t + 1, e],
+                                            f["terminals"][start:t + 1, e], v, gamma, lam)
+            assert np.array_equal(a_, f["advantages"][start:t + 1, e]), f"GAE mismatch env {e} path ending {t}"
+            assert np.array_equal(r_, f["returns"][start:t + 1, e]), f"returns mismatch env {e} path ending {t}"
+            start = t + 1
+
+
+@pytest.mark.parametrize("n,T", [(256, 256), (16, 256)])
+def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
+    """(256, 256): BASELINE configs[1], what bench.py measures.  (16, 256): the north-star's "16 parallel envs" size."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(0)
+    env = DeviceCartPoleVecEnv(n, seed=3)
+    agent = PPO_Agent(c2_config(n, T), env)
+    assert agent.use_fused_rollout and agent.learner.fused_eligible(agent.memory)
+    sd = {k: npy(v) for k, v in agent.model.state_dict().items()}
+    carry = dict(st=oracle.CartPoleOracle(oracle.cartpole_reset_state(env.seed, np.arange(n), 0)),
+                 episodes=np.zeros(n, np.int64), obs_rms=oracle.RunningMeanStdOracle((4,)),
+                 ret_rms=oracle.RunningMeanStdOracle(()), returns=np.zeros(n, np.float32))
+    carry["raw_obs"] = carry["st"].state.astype(np.float32)
+    opt = oracle.AdamOracle(sd, lr=4e-4, eps=1e-5, total_iters=agent.learner.total_iters)
+    cfg = dict(vf_coef=0.25, ent_coef=0.01, clip_range=0.2, use_grad_clip=True, grad_clip_norm=0.5)
+    knife_total = 0
+    for it in range(2):                                               # second pass: replayed graphs, carried statistics
+        agent.rollout()
+        torch.cuda.synchronize()
+        # the path bench.py times: ONE persistent launch for the whole rollout, resident on one XCD, no time-out
+        assert agent._rollout_graph is not None and agent.persist_status is not None
+        stt = agent.persist_status.tolist()
+        assert stt[0] == 0 and bin(stt[2]).count("1") == 1, stt
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        buf, knife = replay_rollout(oracle, sd, f, n, T, env.seed, agent.seed, it * T, carry)
+        knife_total += knife
+        assert_close(npy(env.state), carry["st"].state, 1e-6, "simulator state after the rollout")
+        assert np.array_equal(npy(env.episodes), carry["episodes"]), "episode counters"
+        i = T & 1
+        assert_close(npy(agent.pp["obs_stats"][i][:4]), carry["obs_rms"].mean, 1e-5, "obs_rms.mean")
+        assert_close(npy(agent.pp["obs_stats"][i][4:]), carry["obs_rms"].var, 1e-5, "obs_rms.var")
+        assert_close(npy(agent.pp["ret_stats"][i])[1], carry["ret_rms"].var, 1e-5, "ret_rms.var")
+        assert_close(npy(agent.returns), carry["returns"], 1e-5, "return tracker")
+        gae_bit_exact(oracle, f, n, T)
+        scale = float(np.abs(buf.advantages).max())
+        assert_close(f["advantages"].T, buf.advantages, 1e-5, "advantages (oracle chain)", scale=scale)
+        assert_close(f["returns"].T, buf.returns, 1e-5, "returns (oracle chain)", scale=float(np.abs(buf.returns).max()))
+        # ---- update phase: 64 launches of the fused minibatch kernel + fused optimiser, one graph ----------------
+        info = agent.update()
+        torch.cuda.synchronize()
+        assert agent._update_graph is not None and agent.learner._mirror
+        idx = npy(agent.idx)                                           # fixed input: the device's minibatch indices
+        assert idx.shape == (64, n * T // 8)
+        for e in range(8):                                             # every epoch is a permutation of the buffer
+            assert np.array_equal(np.sort(idx[8 * e:8 * e + 8].reshape(-1)), np.arange(n * T))
+        for k in range(idx.shape[0]):
+            s = buf.sample(idx[k])
+            oinfo, _ = oracle.ppo_update(sd, opt, dict(obs=s["obs"], actions=s["actions"], returns=s["returns"],
+                                                        advantages=s["advantages"], old_logp=s["aux_batch"]["old_logp"]), cfg)
+        for key, ok in (("actor_loss", "a_loss"), ("critic_loss", "c_loss"), ("entropy", "e_loss"),
+                        ("predict_value", "predict_value"), ("clip_ratio", "clip_ratio")):
+            assert_close(info[key], oinfo[ok], 1e-5, f"{key} (pass {it})")
+        got = agent.model.state_dict()
+        for k_, v in sd.items():
+            assert_close(npy(got[k_]), v, 1e-5, f"param {k_} after {64 * (it + 1)} updates")
+        st_ = agent.learner.optimizer.read()
+        assert st_.step == 64 * (it + 1)
+    assert knife_total <= 2, knife_total                               # ties of a float32 cdf with a 24-bit uniform are rare

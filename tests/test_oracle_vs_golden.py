@@ -72,7 +72,7 @@ def test_running_mean_std(oracle):
         assert_close(oracle.process_reward(g["rew"][i], ret), g["rproc"][i], 1e-6)
 
 
-def _replay(g, n_updates, fb, opt_kwargs, oracle, on_update=None, tol=1e-5, gtol=2e-5):
+def _replay(g, n_updates, fb, opt_kwargs, oracle, on_update=None, tol=1e-5, gtol=1e-5):
     sd = {k: v.copy() for k, v in sub(g, "init").items()}
     names = [str(n) for n in g["param_names"]]
     opt = oracle.AdamOracle({k: sd[k] for k in names}, **opt_kwargs)
@@ -97,16 +97,19 @@ def _replay(g, n_updates, fb, opt_kwargs, oracle, on_update=None, tol=1e-5, gtol
 opt_kwargs_clip = {}
 
 
-@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
-def test_ppo_update(oracle, dist):
-    g = load_golden(f"ppo_{dist}")
+@pytest.mark.parametrize("dist,size", [("categorical", None), ("gaussian", None), ("categorical", "c1"),
+                                       ("categorical", "c2"), ("gaussian", "c4")])
+def test_ppo_update(oracle, dist, size):
+    """size: the minibatch of BASELINE C1 (128) / C2 (8 192) on the CartPole net, C4 (4 096) on 17-256-256 (leaky_relu)."""
+    g = load_golden(f"ppo_{dist}" + (f"_{size}" if size else ""))
     lr, vf, ent, clip, gclip, ef, total = g["cfg"]
     cfg = dict(vf_coef=vf, ent_coef=ent, clip_range=clip)
-    act = "leaky_relu" if dist == "categorical" else "relu"
+    act = "leaky_relu" if (dist == "categorical" or size == "c4") else "relu"
     aa = None if dist == "categorical" else "tanh"
     opt_kwargs_clip["clip"] = gclip
+    nu = int(g.get("n_updates", 3))
     fb = lambda sd, b: oracle.ppo_forward_backward(sd, b, cfg, dist=dist, act=act, activation_action=aa)
-    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
+    for u, info, grads, sd, opt in _replay(g, nu, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
         cb = sub(g, f"u{u}/cb")
         lp_scale = max(1.0, float(np.abs(cb["log_prob"]).max()))   # fp32 floor of a sum of that magnitude
         for k in ("v_pred", "a_loss", "c_loss", "e_loss"):
@@ -120,7 +123,7 @@ def test_ppo_update(oracle, dist):
     for k in [str(n) for n in g["param_names"]]:
         assert_close(opt.m[k], g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
         assert_close(opt.v[k], g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
-    assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")
+    assert_close(opt.lr, sub(g, f"u{nu - 1}/info")["learning_rate"], 1e-9, "lr")
 
 
 @pytest.mark.parametrize("dist", ["categorical", "gaussian"])
@@ -169,9 +172,10 @@ def test_dqn_mlp_update(oracle, name):
             assert_close(info[k], cb[k], 1e-5, k)
 
 
-@pytest.mark.parametrize("double_q", [True, False])
-def test_qmix_ff_update(oracle, double_q):
-    g = load_golden(f"qmix_ff_{'double' if double_q else 'single'}")
+@pytest.mark.parametrize("double_q,size", [(True, None), (False, None), (True, "c5")])
+def test_qmix_ff_update(oracle, double_q, size):
+    """size "c5": batch 32 (3m.yaml:32)."""
+    g = load_golden(f"qmix_ff_{'double' if double_q else 'single'}" + (f"_{size}" if size else ""))
     lr, gamma, sync, gclip, dq, total = g["cfg"]
     opt_kwargs_clip["clip"] = gclip
     cfg = dict(gamma=gamma, double_q=bool(dq), use_actions_mask=True)
@@ -212,7 +216,8 @@ def test_vdn_iql_update(oracle, name):
                 assert_close(info[k], sub(g, f"u{u}/cb")[k], 1e-5, k)
 
 
-@pytest.mark.parametrize("name", ["qmix_rnn_double", "qmix_rnn_single", "qmix_rnn_double_fixed", "qmix_lstm_double_fixed"])
+@pytest.mark.parametrize("name", ["qmix_rnn_double", "qmix_rnn_single", "qmix_rnn_double_fixed", "qmix_lstm_double_fixed",
+                                  "qmix_rnn_double_c5", "qmix_rnn_double_fixed_c5"])
 def test_qmix_rnn_update(oracle, name):
     """Recurrent QMIX: Basic_RNN fc+GRU agents over whole episodes, masked TD loss (qmix_learner.py:81-84).
     The unmodified reference gives the agent networks no gradient here (q_eval is re-sliced under no_grad,
@@ -222,14 +227,14 @@ def test_qmix_rnn_update(oracle, name):
     g = load_golden(name)
     lr, gamma, sync, gclip, dq, total = g["cfg"]
     opt_kwargs_clip["clip"] = gclip
-    fixed = name.endswith("fixed")
+    fixed = "fixed" in name                 # `_c5`: 32 episodes of 60 steps (3m.yaml:32), two updates
     cfg = dict(gamma=gamma, double_q=bool(dq), use_actions_mask=fixed, agent_grad=fixed)
     fb = lambda sd, b: oracle.qmix_rnn_forward_backward(sd, b, cfg, group=str(g["group"]))
 
     def on_update(u, sd):
         if (u + 1) % int(sync) == 0:
             oracle.qmix_copy_target(sd)
-    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, total_iters=int(total)), oracle, on_update):
+    for u, info, grads, sd, opt in _replay(g, int(g.get("n_updates", 3)), fb, dict(lr=lr, total_iters=int(total)), oracle, on_update):
         cb = sub(g, f"u{u}/cb")
         for k in ("q_tot_eval", "q_tot_next", "q_tot_target"):
             assert_close(info[k], cb[k], 1e-5, k)

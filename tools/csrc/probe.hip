@@ -1,5 +1,13 @@
-// Diagnostics (not on the product path): shader-clock / MFMA-issue probes used by tools/microbench_*.py.
+// Diagnostics (NOT part of libxrl_hip.so): shader-clock / MFMA-issue / I-cache / XCD-barrier probes, built by
+// tools/probe_lib.py into tools/lib/libxrl_probe.so and used by tools/microbench_{clock,icache,xcd_barrier}.py.
 #include "common.h"
+#include <cstdarg>
+#include <cstdio>
+
+namespace xrl {   // the two helpers common.h expects from the product library
+void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
+int device_cu_count() { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }
+}  // namespace xrl
 
 namespace xrl {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -18,7 +26,7 @@ __global__ void __launch_bounds__(64) mfma_chain_kernel(int iters, long long* ou
 }
 }  // namespace xrl
 
-extern "C" int xrl_debug_mfma_chain(int iters, int blocks, long long* out, float* sink, xrl_stream_t stream) {
+extern "C" int xrl_probe_mfma_chain(int iters, int blocks, long long* out, float* sink, xrl_stream_t stream) {
     hipLaunchKernelGGL(xrl::mfma_chain_kernel, dim3(blocks), dim3(64), 0, xrl::as_stream(stream), iters, out, sink);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
@@ -43,7 +51,7 @@ __global__ void __launch_bounds__(512) icache_probe_kernel(int passes, long long
 }
 }  // namespace xrl
 
-extern "C" int xrl_debug_icache(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream) {
+extern "C" int xrl_probe_icache(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream) {
     hipLaunchKernelGGL(xrl::icache_probe_kernel, dim3(blocks), dim3(threads), 0, xrl::as_stream(stream), passes, out, sink, 1.0001f, 0.5f);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
@@ -66,7 +74,7 @@ __global__ void __launch_bounds__(512) ijump_probe_kernel(int passes, long long*
 }
 }  // namespace xrl
 
-extern "C" int xrl_debug_ijump(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream) {
+extern "C" int xrl_probe_ijump(int passes, int blocks, int threads, long long* out, float* sink, xrl_stream_t stream) {
     hipLaunchKernelGGL(xrl::ijump_probe_kernel, dim3(blocks), dim3(threads), 0, xrl::as_stream(stream), passes, out, sink, 1.0001f);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
@@ -150,7 +158,7 @@ __global__ void __launch_bounds__(256) xcd_barrier_probe_kernel(int iters, int n
 }
 }  // namespace xrl
 
-extern "C" int xrl_debug_xcd_barrier(int iters, int n_wg, unsigned* counter, float* slots, long long* out, xrl_stream_t stream) {
+extern "C" int xrl_probe_xcd_barrier(int iters, int n_wg, unsigned* counter, float* slots, long long* out, xrl_stream_t stream) {
     XRL_CHECK_ARG(n_wg >= 1 && n_wg <= 32 && counter && slots && out);
     const int variant = iters >> 24;
     iters &= 0xffffff;

@@ -2,14 +2,15 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from xuance_amd import _lib
-from xuance_amd._lib import call, stream_ptr
+from xuance_amd._lib import stream_ptr
+from probe_lib import call
 out = torch.zeros(2, dtype=torch.int64, device="cuda"); sink = torch.zeros(64 * 1024, device="cuda")
 for blocks in (1, 16, 256, 1024):
     for iters in (1000, 20000):
-        call("xrl_debug_mfma_chain", iters, blocks, out.data_ptr(), sink.data_ptr(), stream_ptr())
+        call("xrl_probe_mfma_chain", iters, blocks, out.data_ptr(), sink.data_ptr(), stream_ptr())
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); call("xrl_debug_mfma_chain", iters, blocks, out.data_ptr(), sink.data_ptr(), stream_ptr()); e1.record()
+        e0.record(); call("xrl_probe_mfma_chain", iters, blocks, out.data_ptr(), sink.data_ptr(), stream_ptr()); e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3
         c, w = out.tolist()

@@ -204,10 +204,6 @@ _SIGS = {
     "xrl_gather_rows": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "xrl_pack_transitions": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrl_init": [],
-    "xrl_debug_mfma_chain": [c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "xrl_debug_icache": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "xrl_debug_ijump": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "xrl_debug_xcd_barrier": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "xrl_rollout_step_cartpole": [C.POINTER(RolloutStep), c_void_p],
     "xrl_pack_rollout_cache": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p],
     "xrl_pack_rollout_cache2": [C.POINTER(RolloutStep), c_void_p, c_int64, c_void_p, c_void_p],

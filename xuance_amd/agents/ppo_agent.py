@@ -207,7 +207,10 @@ class PPO_Agent:
             return False
         if getattr(self, "persist_status", None) is None:
             self.persist_barrier = torch.zeros(64, dtype=torch.int32, device=self.device)
-            self.persist_status = torch.zeros(4, dtype=torch.int32, device=self.device)
+            # the status words ride in the learner's read-back block: the host sees them at the one sync of every update
+            self.persist_status = self.learner.status_words
+            self.persist_status.zero_()
+            self._persist_validated = False
         return True
 
     def _enqueue_rollout(self):
@@ -289,12 +292,18 @@ class PPO_Agent:
             self._mb_graphs = None
         self._fixed_idx = True
 
-    def rollout(self):
-        if not self._started:
-            self.envs.reset()
-            if self.use_fused_rollout:
-                self.pp["obs_raw"][0].copy_(self.envs.buf_obs)
-            self._started = True
+    # -- whole-rollout launch: its failure flags (csrc/rollout_persist.hip) are part of the contract -----------------------
+    @staticmethod
+    def _persist_status_ok(st):
+        return st[0] == 0 and bin(st[2] & 0xffff).count("1") == 1
+
+    def _rollout_state_tensors(self):
+        """Everything a rollout launch mutates besides the buffer slots it overwrites (simulator, statistics, counters)."""
+        env, t = self.envs, [self.returns, self.step_counter]
+        t += [getattr(env, k) for k in ("state", "steps", "episodes", "ep_score", "stats", "buf_obs")]
+        return t + list(self.pp.values())
+
+    def _launch_rollout(self):
         if self.use_graph and getattr(self.envs, "graph_safe", True):
             if self._rollout_graph is None:
                 torch.cuda.synchronize()
@@ -305,6 +314,36 @@ class PPO_Agent:
             self._rollout_graph.launch()
         else:
             self._enqueue_rollout()
+
+    def rollout(self):
+        if not self._started:
+            self.envs.reset()
+            if self.use_fused_rollout:
+                self.pp["obs_raw"][0].copy_(self.envs.buf_obs)
+            self._started = True
+        first = self.use_fused_rollout and not getattr(self, "_persist_checked", False)
+        saved = [x.clone() for x in self._rollout_state_tensors()] if first else None
+        self._launch_rollout()
+        if first:
+            # First rollout of this agent: if it went through the whole-rollout launch, read its status synchronously.
+            # A device where the surviving workgroups do not share one L2 (partitioned modes, another dispatch order)
+            # or a barrier time-out shows here -- then the state is restored, the agent falls back to per-step launches
+            # for good and redoes the rollout.  Later rollouts are checked at the read-back of every update phase.
+            self._persist_checked = True
+            if getattr(self, "persist_status", None) is not None:
+                torch.cuda.synchronize()
+                st = self.persist_status.tolist()
+                if not self._persist_status_ok(st):
+                    import warnings
+                    warnings.warn(f"xuance_amd: whole-rollout launch unusable on this device (status {st}); "
+                                  "falling back to one launch per vector step")
+                    for x, s0 in zip(self._rollout_state_tensors(), saved):
+                        x.copy_(s0)
+                    self.config.use_persistent_rollout = False
+                    self.persist_status.zero_()
+                    self.persist_status = None
+                    self._rollout_graph = None
+                    self._launch_rollout()
         self.current_step += self.n_envs * self.horizon_size
 
     def _update_distributed(self):
@@ -360,7 +399,13 @@ class PPO_Agent:
         else:
             self._enqueue_update()
         self.learner.iterations += self.idx.shape[0] + (self.n_epochs if self.rem else 0)
-        return self.learner.last_info(self.rem if self.rem else self.batch_size)
+        info = self.learner.last_info(self.rem if self.rem else self.batch_size)
+        if getattr(self, "persist_status", None) is not None and not self._persist_status_ok(self.learner.last_status):
+            # read at the one host sync of the update phase: the rollout this update consumed was cut short
+            raise ops.XrlError(f"xrl_rollout_cartpole_persistent: status {self.learner.last_status} (barrier time-out or "
+                               "workgroups on more than one XCD): the last rollout is incomplete; restart with "
+                               "use_persistent_rollout: False")
+        return info
 
     def train(self, train_steps):
         """Runs ``train_steps`` vector steps (rounded up to whole rollouts of horizon_size steps)."""

@@ -14,8 +14,11 @@
 //     (a counter with atomic adds costs ~2.2 k cycles for 24 workgroups, tools/microbench_xcd_barrier.py).  Workgroups are dealt round-robin to the 8
 //     XCDs, so the grid is 8x oversubscribed and only blockIdx % 8 == 0 stays: the survivors share ONE L2, which makes
 //     plain stores (write-through to L2, completed by s_waitcnt vmcnt(0)) + device-scope loads a coherent exchange
-//     without any L2 write-back / invalidate.  Each survivor checks its XCC id; a mismatch or a barrier time-out raises
-//     *status and every workgroup leaves (the host then falls back to per-step launches).
+//     without any L2 write-back / invalidate.  Each survivor publishes its XCC id (status[2] = mask of ids seen); at the first
+//     step boundary every workgroup reads the mask: more than one id (status[0] = 2) or, at any boundary, a barrier
+//     time-out (status[0] = 1) makes every workgroup leave.  The host reads status at its next synchronisation
+//     (PPO_Agent: validated synchronously on the first rollout -> falls back to per-step launches and redoes it;
+//     afterwards at the read-back of every update phase -> raises).
 #include "common.h"
 #include "rng.h"
 #include "cartpole.h"
@@ -424,6 +427,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
                             break;
                         }
                     }
+                }
+                // first boundary: every workgroup has published its XCC id by now (its atomicOr precedes its first flag
+                // store).  More than one XCD in the mask = the hand-off through ONE L2 with plain stores does not hold
+                // (partitioned device, different dispatch order): raise status[0] = 2 and leave -- the host reads it.
+                if (t == 0 && lane == 0) {
+                    const int seen = __hip_atomic_load(q.status + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__popc(seen) != 1) { __hip_atomic_store(q.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
                 }
             }
             __syncthreads();

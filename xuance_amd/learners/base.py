@@ -27,6 +27,7 @@ class AdamHandle:
         self.m = params.like()
         self.v = params.like()
         self.state = ops.adam_state_tensor(lr, total_iters, end_factor, eps, weight_decay, device=params.device)
+        self.initial_lr = float(lr)       # what torch's scheduler records as param_group['initial_lr']
         # every key torch.optim.Adam keeps in a param group: a file written here loads into the reference's optimiser
         self.defaults = dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                              foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
@@ -47,10 +48,16 @@ class AdamHandle:
         for i, n in enumerate(self.ref_order):
             state[i] = {"step": torch.tensor(float(s.step)), "exp_avg": self.params.view(n, self.m).clone(),
                         "exp_avg_sq": self.params.view(n, self.v).clone()}
-        group = dict(self.defaults, lr=s.last_lr, initial_lr=s.base_lr, params=list(range(len(self.ref_order))))
+        group = dict(self.defaults, lr=s.last_lr, initial_lr=self.initial_lr, params=list(range(len(self.ref_order))))
         return {"state": state if s.step > 0 else {}, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """torch.optim.Adam.load_state_dict as the reference's resume sees it (drl_learner.py:124-135): the moments and
+        step counts come back, and so does the DECAYED param_group lr -- while the scheduler object of the new process
+        is fresh.  torch's chained LinearLR then continues as lr_saved * (1 + (end_factor - 1) * j / total_iters), j =
+        scheduler steps since the resume (the chained factors telescope; fixture tests/golden/ppo_ckpt_decay.npz).  The
+        device computes lr = base_lr * (1 + (end_factor - 1) * min(sched_steps, total) / total), so exactly that is
+        base_lr := the restored lr, sched_steps := 0; `initial_lr` is only reported back in state_dict()."""
         s = self.read()
         for i, n in enumerate(self.ref_order):
             st = sd["state"].get(i)
@@ -60,9 +67,12 @@ class AdamHandle:
             self.params.view(n, self.v).copy_(st["exp_avg_sq"])
             s.step = int(float(st["step"]))
         g = sd["param_groups"][0]
-        s.base_lr = float(g.get("initial_lr", g["lr"]))
+        self.initial_lr = float(g.get("initial_lr", g["lr"]))
+        s.base_lr = float(g["lr"])
         s.last_lr = float(g["lr"])
+        s.sched_steps = 0
         ops.write_adam_state(self.state, s)
+        self.generation = getattr(self, "generation", 0) + 1        # users with launch-epoch barriers re-arm them
 
 
 class LinearLRHandle:
@@ -83,9 +93,16 @@ class LinearLRHandle:
         return dict(start_factor=1.0, end_factor=s.end_factor, total_iters=s.total_iters, last_epoch=s.sched_steps,
                     _last_lr=[s.last_lr])
 
-    def step(self):   # stepping happens inside xrl_adam_step; kept for _safe_scheduler_step-style resume loops
+    def step(self, epoch=None):
+        """Stepping happens inside the Adam launches; this is the host-side hook of _safe_scheduler_step
+        (drl_learner.py:189-210).  step(epoch): torch's closed form, lr = scheduler.base_lrs * factor(epoch), where
+        base_lrs is the learning rate the scheduler was CONSTRUCTED with (the config value), not the restored one."""
         s = self.opt.read()
-        s.sched_steps += 1
+        if epoch is None:
+            s.sched_steps += 1
+        else:
+            s.sched_steps = int(epoch)
+            s.base_lr = float(self.opt.defaults["lr"])
         k = min(s.sched_steps, s.total_iters)
         s.last_lr = s.base_lr * (1.0 + (s.end_factor - 1.0) * k / s.total_iters)
         ops.write_adam_state(self.opt.state, s)
@@ -153,7 +170,20 @@ class Learner:
         if ckpt.get("cuda_rng_state") and torch.cuda.is_available():           # :142-153
             for i, st in enumerate(ckpt["cuda_rng_state"][:torch.cuda.device_count()]):
                 torch.cuda.set_rng_state(st.cpu().to(torch.uint8), device=i)
+        self._safe_scheduler_step()
+        if getattr(self, "opt_sync", None) is not None:                         # barrier flags of xrl_reduce_adam hold step
+            self.opt_sync.zero_()                                               # values: a rewound step must not match them
         return path
+
+    def _safe_scheduler_step(self):
+        """drl_learner.py:189-210: only when the config carries `rt_epoch` (resumed benchmark runs) the scheduler jumps to
+        the iteration that epoch corresponds to."""
+        if self.scheduler is None or not hasattr(self.config, "rt_epoch"):
+            return
+        train_steps = self.config.running_steps // self.config.parallels
+        eval_interval = self.config.eval_interval // self.config.parallels
+        num_epoch = int(train_steps / eval_interval)
+        self.scheduler.step(int(self.total_iters * self.config.rt_epoch / num_epoch))
 
     def update(self, *args, **kwargs):
         raise NotImplementedError

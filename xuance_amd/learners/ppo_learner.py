@@ -24,7 +24,12 @@ class PPO_Learner(Learner):
         dev = P.device
         self._cap = 0
         self.sumsq = torch.zeros(128, dtype=torch.float64, device=dev)
-        self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        # everything the host reads back per update phase in ONE copy: 8 loss sums + 4 status words (the whole-rollout
+        # launch's time-out / XCC flags, PPO_Agent.persist_status) + 4 words of the fused optimiser's barrier scratch
+        self._readback = torch.zeros(12, dtype=torch.float64, device=dev)
+        self.sums = self._readback[:8]
+        self.status_words = self._readback[8:10].view(torch.int32)
+        self.last_status = [0, 0, 0, 0]
         self.keep_diag = True     # keep the per-sample callback tensors (log_prob, ratio, surrogates)
         self.loss_mode = 0        # xrl_ppo_loss_t.mode: 0 PPO-clip, 1 A2C (see A2C_Learner)
 
@@ -115,7 +120,14 @@ class PPO_Learner(Learner):
 
     def _info(self, M, S, partials=None):
         ops.sum_partials(self.partials if partials is None else partials, S, 8, self.sums)
-        s = self.sums.cpu().numpy()                                 # the one host sync of an update
+        if getattr(self, "opt_sync", None) is not None:             # xrl_reduce_adam: sync[2] != 0 = barrier time-out
+            self._readback[10:12].view(torch.int32).copy_(self.opt_sync[:4])
+        rb = self._readback.cpu().numpy()                           # the one host sync of an update
+        s = rb[:8]
+        self.last_status = rb[8:10].view(np.int32).tolist()
+        if rb[10:12].view(np.int32)[2] != 0:
+            raise ops.XrlError("xrl_reduce_adam: inter-block barrier timed out -- the optimiser step of this update phase "
+                               "is invalid (set use_fused_optimizer: False to use the two-launch sequence)")
         st = self.optimizer.read()
         return {self._key("actor_loss"): float(-s[0] / M), self._key("critic_loss"): float(s[1] / M),
                 self._key("entropy"): float(s[2] / M), self._key("learning_rate"): st.last_lr,
