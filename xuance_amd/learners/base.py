@@ -109,8 +109,14 @@ class LinearLRHandle:
 
 
 class Learner:
-    def __init__(self, config, model, callback=None):
+    def __init__(self, config, model, callback=None, adopt_hints=None):
+        """`model`: a xuance_amd.nets container, or the policy object the REFERENCE built (an nn.Module such as
+        SharedActorCritic / DeepQNetwork / MixingQNetwork -- what Agent._build_learner hands to
+        REGISTRY_Learners[config.learner], agent.py:340-341): it is adopted (xuance_amd/adapters.py), i.e. rebuilt over the
+        flat device buffers with the module's parameters re-pointed at them, so module and engine share storage."""
+        from ..adapters import adopt
         self.config = config
+        model = adopt(model, config, **(adopt_hints or {}))
         self.distributed_training = getattr(config, "distributed_training", False)
         self.episode_length = getattr(config, "episode_length", None)
         self.learning_rate = getattr(config, "learning_rate", None)
@@ -119,6 +125,7 @@ class Learner:
         self.use_rnn = getattr(config, "use_rnn", False)
         self.use_actions_mask = getattr(config, "use_actions_mask", False)
         self.model = model
+        self.policy = getattr(model, "module", model)           # what callbacks receive: the caller's own object
         self.optimizer = None
         self.scheduler = None
         self.callback = callback if callback is not None else _NullCallback()

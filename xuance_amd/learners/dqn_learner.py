@@ -11,6 +11,7 @@ from .ppo_learner import pick_n_split
 class DQN_Learner(Learner):
     def __init__(self, config, model, callback=None):
         super().__init__(config, model, callback)
+        model = self.model                                          # (a reference nn.Module was adopted by the base class)
         self.sync_frequency = config.sync_frequency
         self.double_q = bool(getattr(config, "double_q", False))
         self.n_actions = model.n_actions
@@ -126,12 +127,12 @@ class DQN_Learner(Learner):
         info, A = {}, self.n_actions
         for e in range(n_epochs):
             self.iterations += int(count)
-            info = self.callback.on_update_start(self.iterations, policy=self.model, obs=self.X[:M], act=self._act,
+            info = self.callback.on_update_start(self.iterations, policy=self.policy, obs=self.X[:M], act=self._act,
                                                  next_obs=self.X[M:2 * M], rew=self._rew, termination=self._ter) or {}
             info.update({self._key("Qloss"): float(sums[e, 0] / M), self._key("predictQ"): float(sums[e, 1] / M),
                          self._key("learning_rate"): st.last_lr})
             evalQ = self._eval_q(M, A)
-            info.update(self.callback.on_update_end(self.iterations, policy=self.model, info=info, evalQ=evalQ,
+            info.update(self.callback.on_update_end(self.iterations, policy=self.policy, info=info, evalQ=evalQ,
                                                     predictQ=self.diag[:M], targetQ=self.diag[M:2 * M],
                                                     loss=info[self._key("Qloss")]) or {})
         return info
@@ -151,7 +152,7 @@ class DQN_Learner(Learner):
         self.X[:M].copy_(torch.as_tensor(samples["obs"], device=self.X.device).reshape(M, -1))
         self.X[M:2 * M].copy_(torch.as_tensor(samples["obs_next"], device=self.X.device).reshape(M, -1))
         act, rew, ter = self._as_dev(samples["actions"]), self._as_dev(samples["rewards"]), self._as_dev(samples["terminals"])
-        info = self.callback.on_update_start(self.iterations, policy=self.model, obs=self.X[:M], act=act,
+        info = self.callback.on_update_start(self.iterations, policy=self.policy, obs=self.X[:M], act=act,
                                              next_obs=self.X[M:2 * M], rew=rew, termination=ter) or {}
         S = self._step(M, act, rew, ter)
         ops.sum_partials(self.partials, S, 8, self.sums)
@@ -161,7 +162,7 @@ class DQN_Learner(Learner):
                      self._key("learning_rate"): st.last_lr})
         A = self.n_actions
         evalQ = self._eval_q(M, A)
-        info.update(self.callback.on_update_end(self.iterations, policy=self.model, info=info, evalQ=evalQ,
+        info.update(self.callback.on_update_end(self.iterations, policy=self.policy, info=info, evalQ=evalQ,
                                                 predictQ=self.diag[:M], targetQ=self.diag[M:2 * M],
                                                 loss=info[self._key("Qloss")]) or {})
         return info
@@ -173,8 +174,8 @@ class DuelDQN_Learner(DQN_Learner):
     the same GEMM launches; the combination and its backward live inside xrl_dqn_td (`dueling = 1`)."""
 
     def __init__(self, config, model, callback=None):
-        assert getattr(model, "dueling", False), "DuelDQN_Learner needs a model built with dueling=True"
         super().__init__(config, model, callback)
+        assert getattr(self.model, "dueling", False), "DuelDQN_Learner needs a network with DuelingQValueHead (dueling=True)"
 
 
 class PerDQN_Learner(DQN_Learner):

@@ -16,6 +16,7 @@ def pick_n_split(M):
 class PPO_Learner(Learner):
     def __init__(self, config, model, callback=None):
         super().__init__(config, model, callback)
+        model = self.model                                          # (a reference nn.Module was adopted by the base class)
         self.vf_coef, self.ent_coef, self.clip_range = config.vf_coef, config.ent_coef, config.clip_range
         P = model.params
         self.optimizer = AdamHandle(P, model.ref_order, self.learning_rate, eps=1e-5, total_iters=self.total_iters,
@@ -275,14 +276,14 @@ class PPO_Learner(Learner):
         M = obs.shape[0]
         obs = obs.reshape(M, -1)
         self._ensure(M)
-        info = self.callback.on_update_start(self.iterations, policy=self.model, obs=obs, act=act, returns=ret,
+        info = self.callback.on_update_start(self.iterations, policy=self.policy, obs=obs, act=act, returns=ret,
                                              advantages=adv, old_logp=old_logp) or {}
         S = self._step(obs, obs.shape[1], act, ret, adv, old_logp, M)
         info.update(self._info(M, S))
         heads = self.model.plan.acts[len(self.model.plan.widths) - 1]
         A = self.model.action_dim
         d = self.diag.view(-1)                                      # the loss kernel packs [4][M] for the current M
-        cb = dict(policy=self.model, info=info, v_pred=heads[:M, A], log_prob=d[0:M], ratio=d[M:2 * M],
+        cb = dict(policy=self.policy, info=info, v_pred=heads[:M, A], log_prob=d[0:M], ratio=d[M:2 * M],
                   surrogate1=d[2 * M:3 * M], surrogate2=d[3 * M:4 * M],
                   a_loss=info[self._key("actor_loss")], c_loss=info[self._key("critic_loss")],
                   e_loss=info[self._key("entropy")])
@@ -323,13 +324,13 @@ class A2C_Learner(PPO_Learner):
         M = obs.shape[0]
         obs = obs.reshape(M, -1)
         self._ensure(M)
-        info = self.callback.on_update_start(self.iterations, model=self.model, obs=obs, act=act, returns=ret,
+        info = self.callback.on_update_start(self.iterations, model=self.policy, obs=obs, act=act, returns=ret,
                                              advantages=adv) or {}
         S = self._step(obs, obs.shape[1], act, ret, adv, adv, M)     # (old_logp is not read in mode 1)
         info.update(self._info(M, S))
         heads = self.model.plan.acts[len(self.model.plan.widths) - 1]
         A = self.model.action_dim
-        cb = dict(model=self.model, info=info, v_pred=heads[:M, A], log_prob=self.diag.view(-1)[0:M],
+        cb = dict(model=self.policy, info=info, v_pred=heads[:M, A], log_prob=self.diag.view(-1)[0:M],
                   a_loss=info[self._key("actor-loss")], c_loss=info[self._key("critic-loss")], e_loss=info[self._key("entropy")])
         cb["loss"] = cb["a_loss"] - self.ent_coef * cb["e_loss"] + self.vf_coef * cb["c_loss"]
         info.update(self.callback.on_update_end(self.iterations, **cb) or {})
@@ -362,10 +363,10 @@ class PG_Learner(PPO_Learner):
         M = obs.shape[0]
         obs = obs.reshape(M, -1)
         self._ensure(M)
-        info = self.callback.on_update_start(self.iterations, model=self.model, obs=obs, act=act, returns=ret) or {}
+        info = self.callback.on_update_start(self.iterations, model=self.policy, obs=obs, act=act, returns=ret) or {}
         S = self._step(obs, obs.shape[1], act, ret, None, None, M)
         info.update(self._info(M, S))
         a_loss, e_loss = info[self._key("actor-loss")], info[self._key("entropy")]
-        info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, log_prob=self.diag.view(-1)[0:M],
+        info.update(self.callback.on_update_end(self.iterations, model=self.policy, info=info, log_prob=self.diag.view(-1)[0:M],
                                                 a_loss=a_loss, e_loss=e_loss, loss=a_loss - self.ent_coef * e_loss) or {})
         return info

@@ -30,7 +30,10 @@ class QMIX_Learner(Learner):
     mixer_mode = 0          # xrl_qmix_t.mixer: 0 QMIX, 1 VDN (sum), 2 independent (IQL)
 
     def __init__(self, config, agent_grouping, model, callback=None):
-        super().__init__(config, model, callback)
+        keys = list(getattr(agent_grouping, "agent_keys", agent_grouping))
+        super().__init__(config, model, callback,
+                         adopt_hints=dict(n_agents=len(keys), mixer=("QMIX", "VDN", "Independent")[self.mixer_mode]))
+        model = self.model                                          # (a reference nn.Module was adopted by the base class)
         assert {"QMIX": 0, "VDN": 1, "Independent": 2}[getattr(model, "mixer", "QMIX")] == self.mixer_mode, \
             "the model's mixer does not match the learner"
         if self.mixer_mode and getattr(config, "use_rnn", False):
@@ -308,14 +311,14 @@ class QMIX_Learner(Learner):
         info = {}
         for e in range(n_epochs):
             self.iterations += int(count)
-            info = self.callback.on_update_start(self.iterations, model=self.model) or {}
+            info = self.callback.on_update_start(self.iterations, model=self.policy) or {}
             if kind == "ff":
                 info.update(self._info_ff(B, sums[e], st.last_lr))
                 cb = self._cb_ff(B)
             else:
                 info.update(self._info_rnn(B, T, sums[e]))
                 cb = self._cb_rnn(B, T)
-            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **cb) or {})
+            info.update(self.callback.on_update_end(self.iterations, model=self.policy, info=info, **cb) or {})
         return info
 
     def _info_ff(self, B, sums, lr):                            # qmix_learner.py:98-102
@@ -370,18 +373,18 @@ class QMIX_Learner(Learner):
         self.iterations += 1
         if self.use_rnn:
             B, T = self.build_training_data_rnn(sample)
-            info = self.callback.on_update_start(self.iterations, model=self.model) or {}
+            info = self.callback.on_update_start(self.iterations, model=self.policy) or {}
             self._step_rnn(B, T)
             ops.sum_partials(self.partials, T * B, 8, self.sums)
             info.update(self._info_rnn(B, T, self.sums.cpu().numpy()))
-            info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **self._cb_rnn(B, T)) or {})
+            info.update(self.callback.on_update_end(self.iterations, model=self.policy, info=info, **self._cb_rnn(B, T)) or {})
             return info
         B = self.build_training_data(sample)
-        info = self.callback.on_update_start(self.iterations, model=self.model) or {}
+        info = self.callback.on_update_start(self.iterations, model=self.policy) or {}
         self._step(B)
         ops.sum_partials(self.partials, B, 8, self.sums)
         info.update(self._info_ff(B, self.sums.cpu().numpy(), self.optimizer.read().last_lr))
-        info.update(self.callback.on_update_end(self.iterations, model=self.model, info=info, **self._cb_ff(B)) or {})
+        info.update(self.callback.on_update_end(self.iterations, model=self.policy, info=info, **self._cb_ff(B)) or {})
         return info
 
 
