@@ -453,7 +453,7 @@ typedef struct {
 int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
 /* Persistent form: all T vector steps of a rollout plus the final bootstrap pass in ONE launch (the workgroups stay
  * resident, parameters / simulator state / running statistics stay on chip, steps are separated by a counter barrier in
- * the L2 of one XCD).  Same results as T calls of xrl_rollout_step_cartpole(step t: slots of row t, *_in/*_out swapped
+ * the L2 of one XCD).  Same results as T calls of xrl_rollout_step_cartpole(step t: slots of row t, the _in / _out buffers swapped
  * every step, bootv_prev = bootv[t-1]) followed by one boot_only call.  Requirements: the 4-128-{128-2,128-1} network
  * class with role_split and frag_image, 3*ceil(n/32) <= CUs of one XCD (n <= 320 on MI355X).
  * step0 describes step 0: *_slot = row 0 of the [T][n] fields, *_in = ping-pong buffer 0, *_out = buffer 1
@@ -462,10 +462,12 @@ int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
 typedef struct {
     xrl_rollout_step_t step0;
     float* bootv;               /* [T][n] bootstrap values */
-    uint32_t* barrier;          /* [64] scratch flags (zeroed by the call, on the stream) */
+    uint32_t* barrier;          /* [128] scratch flags (zeroed by the call, on the stream) */
     int32_t* status;            /* [4] zero-initialised by the caller: [0] != 0 -> a barrier timed out, results invalid;
-                                 * [1] XCC id of workgroup 0, [2] bit mask of the XCC ids the workgroups ran on */
-    int32_t T, pad;
+                                 * [1] XCC id of workgroup 0, [2] bit mask of every XCC id the workgroups ever ran on,
+                                 * [3] launches whose workgroups did not share one L2 (exchange through device-scope stores) */
+    int32_t T;
+    int32_t flags;              /* bit 0: always exchange through device-scope stores (diagnostics / tests) */
 } xrl_rollout_persist_t;
 int xrl_rollout_cartpole_persistent(const xrl_rollout_persist_t* p, xrl_stream_t stream);
 /* The fused kernels have shape-specialised twins (compile-time extents, bit-identical results) that are selected

@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A hung GPU test (a rank waiting for a peer that died, a spinning kernel) must not eat the GPU box's time budget:
+    every test gets a wall-clock limit when pytest-timeout is installed."""
+    if config.pluginmanager.hasplugin("timeout"):
+        for it in items:
+            if it.get_closest_marker("timeout") is None:
+                it.add_marker(pytest.mark.timeout(420 if "headline" in it.nodeid else 240))
+
+
 def load_golden(name):
     """Load tests/golden/<name>.npz (fixtures produced by oracle/make_golden.py from the reference)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)

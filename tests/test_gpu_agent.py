@@ -227,23 +227,26 @@ def test_specialised_rollout_kernel_is_bit_identical_to_any_shape_kernel(act, n,
 @pytest.mark.parametrize("act,n,norm", [("leaky_relu", 100, True), ("tanh", 256, True), ("relu", 37, True), ("relu", 64, False)])
 def test_persistent_rollout_is_bit_identical_to_per_step_launches(act, n, norm):
     """rollout_persistent_kernel (ONE launch per rollout, counter barrier between steps) vs T + 1 launches of
-    rollout_step_fast_kernel: every buffer field, statistic and simulator state must carry the same bits."""
+    rollout_step_fast_kernel: every buffer field, statistic and simulator state must carry the same bits -- with the
+    exchange through plain stores in one L2 (what the launch geometry aims for; status[3] counts launches that did not get
+    that placement) and with the exchange forced through device-scope stores (the mode for any other placement)."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv
     res = []
-    for persistent in (False, True):
+    for persistent in (False, True, "coherent"):
         torch.manual_seed(0)
         env = DeviceCartPoleVecEnv(n, seed=3)
         env.max_episode_steps = 30
-        agent = PPO_Agent(make_config(n, 48, activation=act, use_persistent_rollout=persistent, use_obsnorm=norm,
-                                      use_rewnorm=norm), env)
+        agent = PPO_Agent(make_config(n, 48, activation=act, use_persistent_rollout=bool(persistent), use_obsnorm=norm,
+                                      use_rewnorm=norm, persistent_coherent_exchange=(persistent == "coherent")), env)
         assert agent.use_fused_rollout
         agent.rollout()
         agent.rollout()
         torch.cuda.synchronize()
         if persistent:
             st = agent.persist_status.tolist()
-            assert st[0] == 0 and bin(st[2]).count("1") == 1, st      # no time-out, all workgroups on one XCD
+            assert st[0] == 0, st                                      # no time-out
+            assert st[3] == (2 if persistent == "coherent" else st[3]) and (st[3] == 0) == (bin(st[2]).count("1") == 1 and persistent is True), st
         else:
             assert getattr(agent, "persist_status", None) is None
         i = agent.horizon_size & 1
@@ -253,10 +256,11 @@ def test_persistent_rollout_is_bit_identical_to_per_step_launches(act, n, norm):
                  obs_raw=npy(agent.pp["obs_raw"][i]), ret_track=npy(agent.returns), cp_state=npy(env.state),
                  cp_steps=npy(env.steps), cp_episodes=npy(env.episodes), eps=np.asarray(env.episode_stats()))
         res.append(f)
-    a, b = res
+    a, b, c = res
     assert a["eps"][0] > 50
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], c[k]), k + " (device-scope exchange)"
 
 
 @pytest.mark.parametrize("n,T,nmb", [(24, 40, 2), (64, 64, 4), (50, 30, 3)])
@@ -634,10 +638,10 @@ def test_pg_agent_rollout_and_update(use_graph):
 
 
 def test_unusable_whole_rollout_launch_falls_back_and_redoes_the_rollout():
-    """The whole-rollout launch reports workgroups on more than one XCD (status[2]) or a barrier time-out (status[0]); the
-    kernel leaves at its first step boundary.  Fault injected by a memset of the XCC mask captured in front of the launch:
-    the agent must notice on its FIRST rollout (read synchronously), restore simulator / statistics / counters, fall
-    back to per-step launches for good and redo the rollout -- ending bit-identical to an agent that never used it."""
+    """The whole-rollout launch reports a barrier time-out in status[0] (results invalid).  Fault injected by a memset of
+    that word captured in front of the launch: the agent must notice on its FIRST rollout (read synchronously), restore
+    simulator / statistics / counters, fall back to per-step launches for good and redo the rollout -- ending
+    bit-identical to an agent that never used the whole-rollout launch."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv
     res = []
@@ -652,7 +656,7 @@ def test_unusable_whole_rollout_launch_falls_back_and_redoes_the_rollout():
             def faulty(split_ok):
                 ok = orig(split_ok)
                 if ok:
-                    agent.persist_status[2:3].fill_(1 << 15)          # "another XCD was seen"
+                    agent.persist_status[0:1].fill_(1)                # "a barrier timed out"
                 return ok
             agent._persistent_ok = faulty
             with pytest.warns(UserWarning, match="whole-rollout launch unusable"):
@@ -687,3 +691,48 @@ def test_whole_rollout_time_out_after_the_first_rollout_raises_at_the_update_rea
     agent.persist_status[0:1].fill_(1)                                # what a barrier time-out leaves behind
     with pytest.raises(ops.XrlError, match="xrl_rollout_cartpole_persistent"):
         agent.update()
+
+
+def test_runner_surface_of_the_ppo_agent(tmp_path):
+    """What xuance/engine/run_drl.py:101-203 calls on an agent: train -> save_model("final_train_model.pth") into
+    model_dir_save (a seed_* run folder), a fresh agent's load_model(model_dir_load) finds it (drl_learner.py:95-157),
+    test(test_episodes, test_envs=host vec env, close_envs) returns one score per finished episode, meta_data /
+    distributed_training / current_step exist; get_actions has the reference's signature and output fields."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv, DummyVecEnv, NumpyCartPoleEnv
+    n, T = 32, 32
+    cfg = make_config(n, T, use_hip_graph=True, n_epochs=4, n_minibatch=4, model_dir=str(tmp_path / "models"), agent="PPO",
+                      env_name="Classic Control", env_id="CartPole-v1")
+    torch.manual_seed(0)
+    a = PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=3))
+    assert a.distributed_training is False and a.model_dir_load == cfg.model_dir and a.meta_data["algo"] == "PPO"
+    a.train(8 * T)
+    a.save_model(model_name="final_train_model.pth")
+    run_dirs = [d for d in (tmp_path / "models").iterdir()]
+    assert len(run_dirs) == 1 and run_dirs[0].name.startswith("seed_1_") and (run_dirs[0] / "obs_rms.npy").exists()
+    b = PPO_Agent(make_config(n, T, use_hip_graph=True, n_epochs=4, n_minibatch=4, model_dir=str(tmp_path / "models")),
+                  DeviceCartPoleVecEnv(n, seed=3))
+    loaded = b.load_model(b.model_dir_load)
+    assert loaded == str(run_dirs[0])
+    for k, v in a.model.state_dict().items():
+        assert torch.equal(v, b.model.state_dict()[k]), k
+    for x, y in zip(a._obs_stats_tensors(), b._obs_stats_tensors()):
+        assert torch.equal(x.float(), y.float())
+    test_envs = DummyVecEnv([NumpyCartPoleEnv] * 4, env_seed=11)
+    scores = b.test(test_episodes=6, test_envs=test_envs, close_envs=True)
+    assert len(scores) >= 6 and all(8 <= s <= 500 for s in scores) and test_envs.closed
+    assert b.logged[-1][1]["Test-Episode-Rewards/Mean-Score"] == float(np.mean(scores))
+    # get_actions (on_policy.py:128-169): processed observations in, NumPy actions / values (/ log-probs) out
+    obs = np.random.default_rng(0).standard_normal((5, 4)).astype(np.float32)
+    out = b.get_actions(obs, deterministic=True, return_dists=True, return_logpi=True)
+    sd = {k: npy(v) for k, v in b.model.state_dict().items()}
+    from oracle import xrl_oracle as o
+    logits, value = o.actor_critic_forward(sd, obs)
+    assert np.array_equal(out.env_actions, logits.argmax(-1)) and out.env_actions.dtype == np.int64
+    assert_close(out.values, value, 1e-5, "values")
+    assert_close(out.distributions["logits"], logits, 1e-5, "logits")
+    assert_close(out.log_probs, o.log_softmax(logits)[np.arange(5), out.env_actions], 1e-5, "log-probs")
+    out = b.get_actions(obs, return_logpi=True)                       # stochastic draw
+    assert set(out.env_actions.tolist()) <= {0, 1}
+    assert_close(out.log_probs, o.log_softmax(logits)[np.arange(5), out.env_actions], 1e-5, "log-probs of the draw")
+    b.finish()

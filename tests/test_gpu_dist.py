@@ -47,6 +47,25 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _collect(q, procs, n=2, limit=200):
+    """n results from the rank processes; a rank that died makes the test fail at once (its peer would otherwise wait for
+    it in a collective until the queue's time-out -- minutes of GPU-box time)."""
+    import queue
+    import time
+    out, t0 = [], time.monotonic()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.monotonic() - t0 > limit:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError(f"rank process failed (exit codes {[p.exitcode for p in procs]})")
+    return sorted(out, key=lambda t: t[0])
+
+
 def test_two_ranks_share_gradients_and_stay_in_sync():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -55,7 +74,7 @@ def test_two_ranks_share_gradients_and_stay_in_sync():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = _collect(q, procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -145,7 +164,7 @@ def test_offpolicy_learners_two_ranks(kind):
     procs = [ctx.Process(target=_offpolicy_worker, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = _collect(q, procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

@@ -121,10 +121,10 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
     for it in range(2):                                               # second pass: replayed graphs, carried statistics
         agent.rollout()
         torch.cuda.synchronize()
-        # the path bench.py times: ONE persistent launch for the whole rollout, resident on one XCD, no time-out
+        # the path bench.py times: ONE persistent launch for the whole rollout, no time-out, exchange inside one L2
         assert agent._rollout_graph is not None and agent.persist_status is not None
         stt = agent.persist_status.tolist()
-        assert stt[0] == 0 and bin(stt[2]).count("1") == 1, stt
+        assert stt[0] == 0 and stt[3] == 0, stt
         f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
         buf, knife = replay_rollout(oracle, sd, f, n, T, env.seed, agent.seed, it * T, carry)
         knife_total += knife

@@ -484,3 +484,54 @@ def test_sibling_dqn_agents_from_the_registry(name):
     gap = np.abs(q[:, 0] - q[:, 1])
     ok = gap > 1e-2
     assert ok.any() and np.array_equal(act[ok], q.argmax(1)[ok].astype(np.float32))
+
+
+def test_runner_surface_of_the_dqn_and_qmix_agents(tmp_path):
+    """save_model / load_model / test / get_actions / meta_data on the off-policy agents (run_drl.py:101-203;
+    core/off_policy.py:150-171, 272-350; core/off_policy_marl.py:596-640), with host evaluation envs."""
+    from argparse import Namespace
+    from xuance_amd.agents import DQN_Agent, QMIX_Agents
+    from xuance_amd.envs import DeviceCartPoleVecEnv, DummyVecEnv, NumpyCartPoleEnv, DummyVecMultiAgentEnv, HostSMACLikeEnv, \
+        SyntheticSMACVecEnv
+    from oracle import xrl_oracle as o
+    base = dict(seed=1, gamma=0.99, learning_rate=1e-3, start_greedy=0.5, end_greedy=0.05, decay_step_greedy=10000,
+                sync_frequency=50, training_frequency=1, running_steps=100000, use_grad_clip=False, grad_clip_norm=0.5,
+                distributed_training=False, device="cuda", use_obsnorm=True, use_rewnorm=False, obsnorm_range=5, rewnorm_range=5)
+    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[64], q_hidden_size=[64], activation="relu",
+                    parallels=16, buffer_size=16 * 64, batch_size=32, start_training=64, model_dir=str(tmp_path / "dqn"),
+                    agent="DQN", **base)
+    a = DQN_Agent(cfg, DeviceCartPoleVecEnv(16, seed=2))
+    a.train(40)
+    a.save_model("final_train_model.pth")
+    b = DQN_Agent(Namespace(**vars(cfg)), DeviceCartPoleVecEnv(16, seed=2))
+    b.load_model(b.model_dir_load)
+    for k, v in a.model.state_dict().items():
+        assert torch.equal(v, b.model.state_dict()[k]), k
+    assert torch.equal(a.obs_mean, b.obs_mean) and b.meta_data["algo"] == "DQN"
+    scores = b.test(test_episodes=5, test_envs=DummyVecEnv([NumpyCartPoleEnv] * 3, env_seed=4))
+    assert len(scores) >= 5 and all(s >= 8 for s in scores)
+    obs = np.random.default_rng(1).standard_normal((7, 4)).astype(np.float32)
+    sd = {k: v.cpu().numpy() for k, v in b.model.state_dict().items()}
+    q = obs
+    for name in ("representation.model.0", "eval_Q_head.q_value.0"):
+        q = np.maximum(q @ sd[name + ".weight"].T + sd[name + ".bias"], 0)
+    q = q @ sd["eval_Q_head.q_value.2.weight"].T + sd["eval_Q_head.q_value.2.bias"]
+    assert np.array_equal(b.get_actions(obs, test_mode=True).env_actions, q.argmax(-1))
+    # ---- QMIX (recurrent, the 3m default) on a host multi-agent env
+    mcfg = Namespace(use_rnn=True, rnn="GRU", fc_hidden_sizes=[64], recurrent_hidden_size=64, q_hidden_size=[64], activation="relu",
+                     hidden_dim_mixing_net=32, hidden_dim_hyper_net=32, parallels=8, buffer_size=64, batch_size=8,
+                     start_training=0, n_epochs=2, double_q=True, use_actions_mask=True, use_parameter_sharing=True,
+                     model_dir=str(tmp_path / "qmix"), agent="QMIX", **{**base, "use_obsnorm": False, "use_grad_clip": True,
+                                                                        "grad_clip_norm": 10.0})
+    env = SyntheticSMACVecEnv(8, seed=3, max_episode_steps=12, p_term=0.05)
+    m = QMIX_Agents(mcfg, env)
+    m.train(12)
+    m.save_model("final_train_model.pth")
+    m2 = QMIX_Agents(Namespace(**vars(mcfg)), SyntheticSMACVecEnv(8, seed=3, max_episode_steps=12, p_term=0.05))
+    m2.load_model(m2.model_dir_load)
+    for k, v in m.model.state_dict().items():
+        assert torch.equal(v, m2.model.state_dict()[k]), k
+    tenv = DummyVecMultiAgentEnv([HostSMACLikeEnv] * 4, env_seed=9)
+    scores = m2.test(test_episodes=5, test_envs=tenv, close_envs=True)       # (an unavailable action would assert in the env)
+    assert len(scores) >= 5 and all(0.0 <= s <= 60.0 for s in scores) and tenv.closed
+    assert "Test-Results/Episode-Rewards" in m2.logged[-1][1]

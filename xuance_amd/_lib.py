@@ -172,7 +172,7 @@ class SynthMarl(C.Structure):
 
 class RolloutPersist(C.Structure):
     _fields_ = [("step0", RolloutStep), ("bootv", c_void_p), ("barrier", c_void_p), ("status", c_void_p),
-                ("T", c_int32), ("pad", c_int32)]
+                ("T", c_int32), ("flags", c_int32)]
 
 
 class PpoFused(C.Structure):

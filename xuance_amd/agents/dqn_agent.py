@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .base import AgentSurface, ActionOutput
 from ..learners.dqn_learner import DQN_Learner
 from ..memory import HipOffPolicyBuffer, HipOffPolicyBuffer_Atari
 from ..nets import DeepQNet
@@ -18,10 +19,11 @@ def _get(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
-class DQN_Agent:
+class DQN_Agent(AgentSurface):
     def __init__(self, config: Namespace, envs, callback=None):
         self.config, self.envs, self.callback = config, envs, callback
         self.device = _get(config, "device", "cuda")
+        self._init_surface()
         self.n_envs = envs.num_envs
         self.observation_space, self.action_space = envs.observation_space, envs.action_space
         self.gamma = config.gamma
@@ -57,6 +59,7 @@ class DQN_Agent:
         self.model.plan.ensure(max(n, 2 * config.batch_size))
         assert not (self.atari and self.use_obsnorm), "Atari frames are stored as uint8 (configs/dqn/atari.yaml:42-43)"
         self._started = False
+        self._act_calls = 0
 
     def _build_model(self):
         c = self.config
@@ -139,8 +142,34 @@ class DQN_Agent:
             info = self.learner.update(**self.memory.sample())
         return info
 
-    def finish(self):
-        self.envs.close()
+    # -- acting outside the training loop (core/off_policy.py:150-171, 272-350) ---------------------------------------------
+    @torch.no_grad()
+    def get_actions(self, observations, test_mode=False):
+        """OffPolicyAgent.get_actions: PROCESSED observations [m, *obs_shape] -> ActionOutput(env_actions [m] int64):
+        greedy actions of the eval network; unless test_mode, the per-env epsilon coin on top (exploration, :129-148)."""
+        dev = self.model.params.device
+        X = torch.as_tensor(np.asarray(observations) if not isinstance(observations, torch.Tensor) else observations, device=dev)
+        X = X.reshape(-1, self.obs_dim).to(torch.uint8 if self.atari else torch.float32).contiguous()
+        m, A = X.shape[0], self.action_space.n
+        q = self.model.forward(X, m)
+        act = torch.zeros(m, dtype=torch.int32, device=dev)
+        eps = self.eps_dev if not test_mode else torch.zeros(1, device=dev)
+        ops.egreedy(q=q, eps_dev=eps, action=act, action_f=None, n=m, A=A, ld=q.stride(0), seed=self.seed,
+                    step=(1 << 20) + self._act_calls, step_dev=None)
+        self._act_calls = (self._act_calls + 1) & 0xfffff
+        return ActionOutput(env_actions=act.cpu().numpy().astype(np.int64), values=None, distributions=None, log_probs=None)
+
+    def _test_actions(self, obs, deterministic=True):
+        # off_policy.py:319-321: obs_rms.update(obs); obs = _process_observation(obs); get_actions(obs, test_mode=True)
+        dev, m = self.model.params.device, len(obs)
+        raw = torch.as_tensor(np.asarray(obs), device=dev).reshape(m, self.obs_dim)
+        if self.atari or not self.use_obsnorm:
+            return self.get_actions(raw, test_mode=True).env_actions
+        X = torch.empty(m, self.obs_dim, device=dev)
+        ops.obs_normalize(x=raw.float().contiguous(), mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=X, out1=None,
+                          n=m, D=self.obs_dim, ld_x=self.obs_dim, ld0=self.obs_dim, ld1=self.obs_dim, update=1, normalize=1,
+                          range=float(self.obsnorm_range))
+        return self.get_actions(X, test_mode=True).env_actions
 
 
 class DDQN_Agent(DQN_Agent):

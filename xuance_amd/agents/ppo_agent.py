@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .base import AgentSurface, ActionOutput
 from ..learners.ppo_learner import PPO_Learner
 from ..memory import HipOnPolicyBuffer
 from ..nets import ActorCriticNet
@@ -28,10 +29,11 @@ def _get(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
-class PPO_Agent:
+class PPO_Agent(AgentSurface):
     def __init__(self, config: Namespace, envs, callback=None):
         self.config, self.envs, self.callback = config, envs, callback
         self.device = _get(config, "device", "cuda")
+        self._init_surface()
         self.n_envs = envs.num_envs
         self.observation_space, self.action_space = envs.observation_space, envs.action_space
         self.gamma = config.gamma
@@ -70,6 +72,7 @@ class PPO_Agent:
         self._rollout_graph = None
         self._update_graph = None
         self._started = False
+        self._act_calls = 1 << 20                                   # Philox step offset of get_actions() draws (outside the rollout's range)
         # fused rollout (one launch per vector step) for the device CartPole with a categorical policy
         from ..envs.cartpole import DeviceCartPoleVecEnv
         self.use_fused_rollout = bool(_get(config, "use_fused_rollout", True)) and isinstance(envs, DeviceCartPoleVecEnv) \
@@ -172,7 +175,9 @@ class PPO_Agent:
             # library refuses (before launching anything) when the workgroups cannot all be resident on one XCD, e.g. on a
             # partitioned device: fall back to one launch per step.
             try:
-                ops.rollout_cartpole_persistent(plan, T, f["bootv"], self.persist_barrier, self.persist_status, **step0, **common)
+                ops.rollout_cartpole_persistent(plan, T, f["bootv"], self.persist_barrier, self.persist_status,
+                                                flags=int(bool(_get(self.config, "persistent_coherent_exchange", False))),
+                                                **step0, **common)
             except ops.XrlError:
                 persistent = False
                 self.persist_status = None
@@ -206,7 +211,7 @@ class PPO_Agent:
         if list(plan.widths) != [4, 128, 256, 3] or 3 * ((self.n_envs + 31) // 32) > 32 or not ops.fast_kernels_enabled():
             return False
         if getattr(self, "persist_status", None) is None:
-            self.persist_barrier = torch.zeros(64, dtype=torch.int32, device=self.device)
+            self.persist_barrier = torch.zeros(128, dtype=torch.int32, device=self.device)
             # the status words ride in the learner's read-back block: the host sees them at the one sync of every update
             self.persist_status = self.learner.status_words
             self.persist_status.zero_()
@@ -295,7 +300,9 @@ class PPO_Agent:
     # -- whole-rollout launch: its failure flags (csrc/rollout_persist.hip) are part of the contract -----------------------
     @staticmethod
     def _persist_status_ok(st):
-        return st[0] == 0 and bin(st[2] & 0xffff).count("1") == 1
+        """status[0] != 0: a barrier timed out (results invalid).  Workgroups on more than one XCD are NOT a failure: the
+        kernel notices in every launch and exchanges through device-scope stores then (status[3] counts those launches)."""
+        return st[0] == 0
 
     def _rollout_state_tensors(self):
         """Everything a rollout launch mutates besides the buffer slots it overwrites (simulator, statistics, counters)."""
@@ -418,7 +425,7 @@ class PPO_Agent:
         info.update({"episodes": eps, "mean_episode_score": score, "mean_episode_length": length})
         return info
 
-    # -- checkpoints (agent.py:199-230: learner .pth + obs_rms.npy with {'count','mean','var'}) ---------------------------
+    # -- checkpoints: AgentSurface.save_model / load_model (agent.py:199-233) over these two hooks --------------------------
     def _obs_stats_tensors(self):
         """(mean, var, count) tensors holding the CURRENT observation statistics: the fused rollout keeps them in the
         ping-pong slot 0 between rollouts (horizon_size is even), the layered path in obs_mean / obs_var / obs_count."""
@@ -427,37 +434,66 @@ class PPO_Agent:
             return self.pp["obs_stats"][0][:D], self.pp["obs_stats"][0][D:], self.pp["obs_count"][0]
         return self.obs_mean, self.obs_var, self.obs_count
 
-    def save_model(self, model_name, model_path=None):
-        import os
-        model_path = _get(self.config, "model_dir", "models") if model_path is None else model_path
-        os.makedirs(model_path, exist_ok=True)
-        self.learner.save_model(os.path.join(model_path, model_name))
-        if self.use_obsnorm:
-            mean, var, count = self._obs_stats_tensors()
-            np.save(os.path.join(model_path, "obs_rms.npy"),
-                    {"count": float(count.item()), "mean": mean.cpu().numpy().astype(np.float32).reshape(space2shape(self.observation_space)),
-                     "var": var.cpu().numpy().astype(np.float32).reshape(space2shape(self.observation_space))})
-
-    def load_model(self, path, model=None):
-        import os
-        loaded = self.learner.load_model(os.path.join(path, model) if model is not None else path)
-        if self.use_obsnorm:
-            f = os.path.join(os.path.dirname(loaded), "obs_rms.npy")
-            if not os.path.exists(f):
-                raise RuntimeError(f"Failed to load observation status file 'obs_rms.npy' from {f}!")
-            st = np.load(f, allow_pickle=True).item()
-            mean, var, count = self._obs_stats_tensors()
-            mean.copy_(torch.as_tensor(np.asarray(st["mean"], np.float32).reshape(-1)))
-            var.copy_(torch.as_tensor(np.asarray(st["var"], np.float32).reshape(-1)))
-            count.fill_(float(st["count"]))
-            if self.use_fused_rollout:                         # both ping-pong slots start from the same statistics
-                self.pp["obs_stats"][1].copy_(self.pp["obs_stats"][0]); self.pp["obs_count"][1].copy_(self.pp["obs_count"][0])
-        self._rollout_graph = None                             # parameters' derived layouts are rebuilt on the next rollout/update
+    def _after_load(self):
+        if self.use_fused_rollout and self.use_obsnorm:            # both ping-pong slots start from the same statistics
+            self.pp["obs_stats"][1].copy_(self.pp["obs_stats"][0]); self.pp["obs_count"][1].copy_(self.pp["obs_count"][0])
+        self._rollout_graph = None                                 # parameters' derived layouts are rebuilt on the next rollout/update
         self._update_graph = None
-        return loaded
+        self._mb_graphs = None
 
-    def finish(self):
-        self.envs.close()
+    # -- acting outside the training loop (core/on_policy.py:128-169, 303-400) ----------------------------------------------
+    @torch.no_grad()
+    def get_actions(self, observations, deterministic=False, return_dists=False, return_logpi=False):
+        """OnPolicyAgent.get_actions: PROCESSED observations [m, obs_dim] (NumPy or device tensor) -> ActionOutput with
+        NumPy env_actions / values (/ log_probs).  One forward through the same GEMM plan as the training loop; sampling by
+        xrl_policy_sample (its Philox stream continues from the agent's step counter), the deterministic choice
+        (CategoricalDistribution.deterministic_sample = argmax of the probabilities, Gaussian: the mean,
+        distributions.py:150-153, 185-188) from the head outputs.  distributions: the head outputs as a dict when asked."""
+        X = torch.as_tensor(np.asarray(observations) if not isinstance(observations, torch.Tensor) else observations,
+                            device=self.model.params.device).to(torch.float32).reshape(-1, self.obs_dim).contiguous()
+        m, A, gaussian = X.shape[0], self.model.action_dim, self.model.dist == "gaussian"
+        critic = self.model.head_ld > A
+        heads = self.model.forward(X, m)
+        ls = None
+        if gaussian:
+            ls = self.model.params.ptr(getattr(self.model, "log_std_name", "actor.log_std"))
+        if deterministic:
+            out = heads[:m, :A]
+            acts = out.clone() if gaussian else out.argmax(-1).to(torch.float32)
+            logp = None
+            if return_logpi:
+                logp = torch.log_softmax(out, -1).gather(1, acts.long()[:, None])[:, 0] if not gaussian else None
+        else:
+            acts = torch.zeros((m, A) if gaussian else (m,), device=X.device)
+            logp = torch.zeros(m, device=X.device)
+            ops.policy_sample(heads=heads, log_std=ls, act_out=acts, val_out=None, logp_out=logp, env_action=None,
+                              env_action_f=None, bootv_prev=None, n=m, A=A, ld=self.model.head_ld, gaussian=int(gaussian),
+                              seed=self.seed, step=self._act_calls, step_dev=self.step_counter)
+            self._act_calls = (self._act_calls + 1) & 0x7fffffff
+        values = heads[:m, A].cpu().numpy() if critic else 0
+        env_actions = acts.cpu().numpy() if gaussian else acts.cpu().numpy().astype(np.int64)
+        dists = None
+        if return_dists:
+            dists = {"mu": heads[:m, :A].cpu().numpy(), "log_std": self.model.state_dict()[getattr(self.model, "log_std_name", "actor.log_std")].cpu().numpy()} \
+                if gaussian else {"logits": heads[:m, :A].cpu().numpy()}
+        return ActionOutput(env_actions=env_actions, values=values, distributions=dists,
+                            log_probs=logp.cpu().numpy() if (return_logpi and logp is not None) else None)
+
+    def _process_observation(self, observations, update=False):
+        """obs_rms.update (optional) + clip((obs - mean) / (std + 1e-8)) (agent.py:262-283) on the CURRENT statistics, for
+        observations that come from outside the device loop (evaluation envs).  Returns a device tensor [m, obs_dim]."""
+        X = torch.as_tensor(np.asarray(observations), device=self.model.params.device).to(torch.float32).reshape(-1, self.obs_dim).contiguous()
+        if not self.use_obsnorm:
+            return X
+        mean, var, count = self._obs_stats_tensors()
+        out = torch.empty_like(X)
+        ops.obs_normalize(x=X, mean=mean, var=var, count=count, out0=out, out1=None, n=X.shape[0], D=self.obs_dim, ld_x=self.obs_dim,
+                          ld0=self.obs_dim, ld1=self.obs_dim, update=int(update), normalize=1, range=float(self.obsnorm_range))
+        return out
+
+    def _test_actions(self, obs, deterministic):
+        # on_policy.py:355-357: the reference updates obs_rms with the evaluation observations too
+        return self.get_actions(self._process_observation(obs, update=True), deterministic=deterministic).env_actions
 
 
 class A2C_Agent(PPO_Agent):

@@ -13,9 +13,11 @@ finished -- the one host read per vector step is the (episodes, env-steps) count
 the exploration schedule need (:494,532-534)."""
 from argparse import Namespace
 
+import numpy as np
 import torch
 
 from .. import ops
+from .base import AgentSurface
 from ..learners.qmix_learner import QMIX_Learner, VDN_Learner, IQL_Learner
 from ..memory_marl import HipMARLOffPolicyBuffer, HipMARLOffPolicyBufferRNN
 from ..nets import MixingQNet
@@ -25,12 +27,13 @@ def _get(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
-class QMIX_Agents:
+class QMIX_Agents(AgentSurface):
     mixer_name, learner_cls = "QMIX", QMIX_Learner
 
     def __init__(self, config: Namespace, envs, callback=None):
         self.config, self.envs, self.callback = config, envs, callback
         self.device = _get(config, "device", "cuda")
+        self._init_surface()
         self.n_envs = envs.num_envs
         self.agent_keys = list(envs.agent_keys)
         self.n_agents = len(self.agent_keys)
@@ -197,8 +200,70 @@ class QMIX_Agents:
         info["epsilon"] = self.e_greedy
         return info
 
-    def finish(self):
-        self.envs.close()
+    # -- evaluation on HOST multi-agent vector envs (core/off_policy_marl.py:596-640 = run_episodes(test_mode=True), :426-560)
+    @torch.no_grad()
+    def greedy_actions(self, obs, avail=None, rnn=None):
+        """obs [m, N, obs_dim] (NumPy / tensor), avail [m, N, A] or None -> int64 actions [m, N]: the masked argmax of the
+        shared agent network (value_factorization.py:87-92), exploration off.  rnn: dict(h, c, reset) of device tensors
+        [m*N, H] for recurrent agents (carried and reset row-wise by the recurrence kernel)."""
+        dev, N, A = self.device, self.n_agents, self.n_actions
+        X = torch.as_tensor(np.asarray(obs) if not isinstance(obs, torch.Tensor) else obs, device=dev).to(torch.float32)
+        m = X.shape[0]
+        R = m * N
+        X = X.reshape(R, -1).contiguous()
+        av = None
+        if avail is not None and self.use_actions_mask:
+            av = torch.as_tensor(np.asarray(avail) if not isinstance(avail, torch.Tensor) else avail, device=dev).to(torch.float32).reshape(R, A).contiguous()
+        if self.use_rnn:
+            q = self.model.agent_forward_seq(X, R, 1, which=2, h0=rnn["h"], reset=rnn["reset"], h_last=rnn["h"], c0=rnn.get("c"),
+                                             c_last=rnn.get("c"))
+        else:
+            q = self.model.agent_plan.forward(X, self.obs_dim, R)
+        act = torch.zeros(R, dtype=torch.int32, device=dev)
+        ops.marl_select_actions(q=q, avail=av, eps_dev=torch.zeros(1, device=dev), action=act, action_f=None, R=R, A=A, ld=A,
+                                seed=self.seed, step=0, step_dev=None)
+        return act.view(m, N).cpu().numpy().astype(np.int64)
+
+    def test(self, test_episodes, test_envs=None, close_envs=True):
+        """Episode scores (mean over agents) of `test_episodes` greedy episodes on `test_envs`: a vector env with the
+        reference's multi-agent contract (dummy_vec_maenv.py:33-83: reset() -> (obs_list, infos); buf_avail_actions /
+        buf_state; step(actions_list) -> (obs_list, rewards, terminated dicts, truncated, infos with reset_obs /
+        reset_avail_actions / episode_score per agent))."""
+        if test_envs is None:
+            raise ValueError("`test_envs` must be provided for evaluation (the training envs live on the device).")
+        keys, m = self.agent_keys, test_envs.num_envs
+        obs_list, _ = test_envs.reset()
+        avail = test_envs.buf_avail_actions if self.use_actions_mask else None
+        rnn = None
+        if self.use_rnn:
+            z = lambda: torch.zeros(m * self.n_agents, self.model.RH, device=self.device)
+            rnn = {"h": z(), "reset": torch.zeros(m * self.n_agents, device=self.device)}
+            if self.model.lstm:
+                rnn["c"] = z()
+        scores, episodes = [], 0
+        stack = lambda lst: np.stack([[np.asarray(d[k]) for k in keys] for d in lst])
+        while episodes < test_episodes:
+            acts = self.greedy_actions(stack(obs_list), stack(avail) if avail is not None else None, rnn)
+            actions_list = [{k: int(acts[i, j]) for j, k in enumerate(keys)} for i in range(m)]
+            next_obs, rewards, terminated, truncated, info = test_envs.step(actions_list)
+            obs_list = list(next_obs)
+            avail = list(test_envs.buf_avail_actions) if self.use_actions_mask else None
+            ended = np.zeros(m, np.float32)
+            for i in range(m):
+                if all(terminated[i].values()) or truncated[i]:
+                    episodes += 1
+                    obs_list[i] = info[i]["reset_obs"]
+                    if avail is not None:
+                        avail[i] = info[i]["reset_avail_actions"]
+                    ended[i] = 1.0                                         # init_rnn_states_item (:504-505)
+                    scores.append(float(np.mean([info[i]["episode_score"][k] for k in keys])))
+            if rnn is not None:
+                rnn["reset"].view(m, self.n_agents).copy_(torch.from_numpy(ended).to(self.device)[:, None].expand(m, self.n_agents))
+        self.log_infos({"Test-Results/Episode-Rewards": float(np.mean(scores)),
+                        "Test-Results/Episode-Rewards-Std": float(np.std(scores))}, self.current_step)
+        if close_envs:
+            test_envs.close()
+        return scores
 
 
 class VDN_Agents(QMIX_Agents):

@@ -14,11 +14,12 @@
 //     (a counter with atomic adds costs ~2.2 k cycles for 24 workgroups, tools/microbench_xcd_barrier.py).  Workgroups are dealt round-robin to the 8
 //     XCDs, so the grid is 8x oversubscribed and only blockIdx % 8 == 0 stays: the survivors share ONE L2, which makes
 //     plain stores (write-through to L2, completed by s_waitcnt vmcnt(0)) + device-scope loads a coherent exchange
-//     without any L2 write-back / invalidate.  Each survivor publishes its XCC id (status[2] = mask of ids seen); at the first
-//     step boundary every workgroup reads the mask: more than one id (status[0] = 2) or, at any boundary, a barrier
-//     time-out (status[0] = 1) makes every workgroup leave.  The host reads status at its next synchronisation
-//     (PPO_Agent: validated synchronously on the first rollout -> falls back to per-step launches and redoes it;
-//     afterwards at the read-back of every update phase -> raises).
+//     without any L2 write-back / invalidate.  That placement is CHECKED in every launch: each survivor publishes its XCC id
+//     behind a start-up barrier; if the ids differ (partitioned device, a second process on the GPU, another dispatch order)
+//     the launch switches its exchange stores to device-scope atomic stores -- correct on any placement, slower per step
+//     (status[3] counts such launches, status[2] is the mask of every XCC ever seen).  A barrier time-out (status[0] = 1)
+//     makes every workgroup leave; the host reads status at its next synchronisation (PPO_Agent: synchronously after the
+//     first rollout -> falls back to per-step launches and redoes it; afterwards at the read-back of every update -> raises).
 #include "common.h"
 #include "rng.h"
 #include "cartpole.h"
@@ -27,6 +28,7 @@
 namespace xrl {
 
 constexpr int QH = 128, QLD = QH + 4;
+constexpr int PB_FLAGS = 64, PB_MASK = 96;        // start-up barrier flags / XCC mask of the launch inside the barrier scratch
 constexpr int QI_W0 = 0, QI_B0 = 4 * QH, QI_BM = QI_B0 + QH, QI_WH = QI_BM + 2 * QH, QI_LDH = 2 * QH + 4, QI_BH = QI_WH + 3 * QI_LDH;
 
 template <int CTRL>
@@ -54,6 +56,10 @@ __device__ __forceinline__ int ld_dev_u8(const uint8_t* p) {
     return (int)((w >> (8 * (a & 3))) & 0xffu);
 }
 __device__ __forceinline__ float4 ld_dev4(const float* p) { return make_float4(ld_dev(p), ld_dev(p + 1), ld_dev(p + 2), ld_dev(p + 3)); }
+// device-scope stores: for the exchange between workgroups that do NOT share an L2 (see `multi` below)
+__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev_u8(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev4(float* p, float a, float b, float c, float d) { st_dev(p, a); st_dev(p + 1, b); st_dev(p + 2, c); st_dev(p + 3, d); }
 
 template <int ACT, int NJ>
 __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_rollout_persist_t q) {
@@ -70,7 +76,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
     __shared__ float s_u[FT];
     __shared__ float s_ret[2];
     __shared__ float s_norm[8];
-    __shared__ int s_abort;
+    __shared__ int s_abort, s_multi;
 
     const xrl_rollout_step_t& p = q.step0;
     constexpr int D = 4, A = 2;
@@ -93,11 +99,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
     const int eh = e0 + li;
 
     if (tid == 0) {
-        s_abort = 0;
+        s_abort = 0; s_multi = 0;
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         if (wg == 0) __hip_atomic_store(q.status + 1, (int)(xcc & 0xf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicOr(q.status + 2, 1 << (xcc & 0xf));
+        atomicOr(q.status + 2, 1 << (xcc & 0xf));                                 // every XCC ever seen (diagnostics, sticky)
+        const unsigned seen = atomicOr(q.barrier + PB_MASK, 1u << (xcc & 0xf));   // the XCCs of THIS launch (scratch is zeroed per call)
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");                // performed before the flag below is published
+        __hip_atomic_store(q.barrier + PB_FLAGS + wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // ================= one-time loads: parameters into registers, simulator state into registers / LDS =================
@@ -146,7 +155,32 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
     double ret_cnt = 0.0;
     if (role == 1 && wave == 6) { ret_mean = p.ret_stats_in[0]; ret_var = p.ret_stats_in[1]; ret_cnt = *p.ret_count_in; }
     const uint32_t step_base = p.step + (p.step_dev ? *p.step_dev : 0u);
+    // ================= placement check: do the workgroups of this launch share ONE L2? =================
+    // Every workgroup has published its XCC id; once all flags are up the mask is complete.  One bit: the hand-off through
+    // plain stores + device-scope loads holds (the case the launch geometry aims for).  More bits (a partitioned device,
+    // another process sharing the GPU, a different dispatch order): the exchange stores become device-scope atomic stores,
+    // which reach the coherence point of the whole device -- slower per step, same results.  status[3] counts such launches.
+    if (wave == 0) {
+        int spins = 0;
+        for (;;) {
+            const unsigned f = lane < n_wg ? __hip_atomic_load(q.barrier + PB_FLAGS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+            if (__ballot(f == 0u) == 0ull) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023) == 0 && (spins > 4000000 || __hip_atomic_load(q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (lane == 0) { __hip_atomic_store(q.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
+                break;
+            }
+        }
+        if (lane == 0) {
+            const unsigned mask = __hip_atomic_load(q.barrier + PB_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int m = (__popc(mask) != 1 || (q.flags & 1)) ? 1 : 0;
+            s_multi = m;
+            if (m && wg == 0) atomicAdd(q.status + 3, 1);
+        }
+    }
     __syncthreads();
+    const bool multi = s_multi != 0;
+    if (s_abort) return;                                          // time-out before anything was touched
 
     for (int t = 0; t <= T; ++t) {
         const bool odd = (t & 1) != 0;
@@ -392,9 +426,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
                     p.term_slot[(size_t)t * n + e] = term ? 1.f : 0.f;
                     p.seg_slot[(size_t)t * n + e] = (term || trunc || last_step) ? (uint8_t)(1 | (term ? 6 : 0)) : (uint8_t)0;
                     const float tr = p.gamma * rtrack + reward;
-                    if (term || trunc) { ret_final_out[e] = tr; ended_out[e] = 1; rtrack = 0.f; }
-                    else { ended_out[e] = 0; rtrack = tr; }
-                    *reinterpret_cast<float4*>(obs_raw_out + (size_t)e * 4) = make_float4(robs[0], robs[1], robs[2], robs[3]);
+                    const bool fin = term || trunc;
+                    if (multi) {
+                        if (fin) st_dev(ret_final_out + e, tr);
+                        st_dev_u8(ended_out + e, fin ? 1 : 0);
+                        st_dev4(obs_raw_out + (size_t)e * 4, robs[0], robs[1], robs[2], robs[3]);
+                    } else {
+                        if (fin) ret_final_out[e] = tr;
+                        ended_out[e] = fin ? 1 : 0;
+                        *reinterpret_cast<float4*>(obs_raw_out + (size_t)e * 4) = make_float4(robs[0], robs[1], robs[2], robs[3]);
+                    }
+                    rtrack = fin ? 0.f : tr;
                     float nv[4];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -402,7 +444,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
                         if (p.use_obsnorm) { v = (v - s_norm[d]) / (s_norm[4 + d] + 1e-8f); v = fminf(fmaxf(v, -p.obs_range), p.obs_range); }
                         nv[d] = v;
                     }
-                    *reinterpret_cast<float4*>(xnext_out + (size_t)e * 4) = make_float4(nv[0], nv[1], nv[2], nv[3]);
+                    if (multi) st_dev4(xnext_out + (size_t)e * 4, nv[0], nv[1], nv[2], nv[3]);
+                    else *reinterpret_cast<float4*>(xnext_out + (size_t)e * 4) = make_float4(nv[0], nv[1], nv[2], nv[3]);
                 }
             }
         }
@@ -427,13 +470,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
                             break;
                         }
                     }
-                }
-                // first boundary: every workgroup has published its XCC id by now (its atomicOr precedes its first flag
-                // store).  More than one XCD in the mask = the hand-off through ONE L2 with plain stores does not hold
-                // (partitioned device, different dispatch order): raise status[0] = 2 and leave -- the host reads it.
-                if (t == 0 && lane == 0) {
-                    const int seen = __hip_atomic_load(q.status + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__popc(seen) != 1) { __hip_atomic_store(q.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
                 }
             }
             __syncthreads();
@@ -471,7 +507,7 @@ extern "C" int xrl_rollout_cartpole_persistent(const xrl_rollout_persist_t* qq, 
     const int n_tiles = (p.n + FT - 1) / FT;
     const int n_wg = 3 * n_tiles;
     XRL_CHECK_ARG(n_wg <= device_cu_count() / 8);                   // all resident workgroups on ONE XCD, one per CU
-    XRL_CHECK_HIP(hipMemsetAsync(q.barrier, 0, 64 * sizeof(uint32_t), as_stream(stream)));
+    XRL_CHECK_HIP(hipMemsetAsync(q.barrier, 0, 128 * sizeof(uint32_t), as_stream(stream)));
     XRL_ACT_DISPATCH(p.layers[0].act,
         if (p.n <= 256) hipLaunchKernelGGL((rollout_persistent_kernel<ACT, 4>), dim3(8 * n_wg), dim3(FUSED_THREADS), 0, as_stream(stream), q);
         else hipLaunchKernelGGL((rollout_persistent_kernel<ACT, 16>), dim3(8 * n_wg), dim3(FUSED_THREADS), 0, as_stream(stream), q);)

@@ -88,19 +88,10 @@ class ShmSubprocVecEnv:
         self.lay, nbytes = _layout(n, self.obs_shape, self.obs_dtype, self.act_dim)
         self.block = torch.zeros(nbytes, dtype=torch.uint8).share_memory_()
         self.v = _views(self.block, self.lay, n, self.obs_shape, self.obs_dtype, self.act_dim)
-        self.device = device
-        self._pinned = False
-        if torch.cuda.is_available() and str(device).startswith("cuda"):
-            # page-lock the shared block in place: H2D copies from it are true asynchronous DMAs
-            err = torch.cuda.cudart().cudaHostRegister(self.block.data_ptr(), nbytes, 0)
-            self._pinned = int(err) == 0
-            self.dev_block = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-            d = lambda name, dt, shape: self.dev_block[self.lay[name][0]:self.lay[name][0] + self.lay[name][1]].view(dt).view(shape)
-            tdt = torch.uint8 if self.obs_dtype == np.uint8 else torch.float32
-            self.dev = dict(obs=d("obs", tdt, (n,) + self.obs_shape), reset_obs=d("reset_obs", tdt, (n,) + self.obs_shape),
-                            rewards=d("rewards", torch.float32, (n,)), terminated=d("terminated", torch.uint8, (n,)),
-                            truncated=d("truncated", torch.uint8, (n,)), episode_step=d("episode_step", torch.int32, (n,)),
-                            episode_score=d("episode_score", torch.float32, (n,)))
+        # the worker processes are fork()ed BEFORE this object makes its first HIP call (hipHostRegister, the device
+        # mirror): a child forked from a process whose HIP runtime is already live inherits runtime state it must never
+        # use.  (If the caller initialised HIP earlier, create the vector env first -- or the workers simply never touch it:
+        # they only see NumPy views of the shared block.)
         ctx = mp.get_context("fork")
         self.n_remotes = n // in_series
         bounds = np.array_split(np.arange(n), self.n_remotes)
@@ -114,6 +105,20 @@ class ShmSubprocVecEnv:
             self.ps.append(p)
         for wr in work:
             wr.close()
+        self.device = device
+        self._pinned = False
+        self._dma_done = None                                       # event of the last step_to_device copy
+        if torch.cuda.is_available() and str(device).startswith("cuda"):
+            # page-lock the shared block in place: H2D copies from it are true asynchronous DMAs
+            err = torch.cuda.cudart().cudaHostRegister(self.block.data_ptr(), nbytes, 0)
+            self._pinned = int(err) == 0
+            self.dev_block = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            d = lambda name, dt, shape: self.dev_block[self.lay[name][0]:self.lay[name][0] + self.lay[name][1]].view(dt).view(shape)
+            tdt = torch.uint8 if self.obs_dtype == np.uint8 else torch.float32
+            self.dev = dict(obs=d("obs", tdt, (n,) + self.obs_shape), reset_obs=d("reset_obs", tdt, (n,) + self.obs_shape),
+                            rewards=d("rewards", torch.float32, (n,)), terminated=d("terminated", torch.uint8, (n,)),
+                            truncated=d("truncated", torch.uint8, (n,)), episode_step=d("episode_step", torch.int32, (n,)),
+                            episode_score=d("episode_score", torch.float32, (n,)))
         self.buf_obs = np.zeros((n,) + self.obs_shape, self.obs_dtype)
 
     # -- reference surface ---------------------------------------------------------------------------------------------
@@ -131,6 +136,9 @@ class ShmSubprocVecEnv:
 
     def step_async(self, actions):
         self._assert_not_closed()
+        if self._dma_done is not None:                              # the previous step_to_device copy still reads the block
+            self._dma_done.synchronize()
+            self._dma_done = None
         self.v["actions"][...] = np.asarray(actions, np.float32).reshape(self.num_envs, self.act_dim)
         for r in self.remotes:
             r.send_bytes(b"s")
@@ -169,6 +177,9 @@ class ShmSubprocVecEnv:
         self.step_async(actions)
         self._wait()
         self.dev_block.copy_(self.block, non_blocking=self._pinned)
+        if self._pinned:
+            self._dma_done = torch.cuda.Event()
+            self._dma_done.record()
         return self.dev
 
     def close(self):

@@ -142,6 +142,22 @@ class Learner:
         self.total_iters = self.estimate_total_iterations()
         self.iterations = 0
 
+    def sync_replicas_from_rank0(self):
+        """What the reference's DistributedDataParallel wrap does at construction (deep_q_network.py:55-59,
+        value_factorization.py:44-48): every rank starts from rank 0's parameters (and target copies).  Ranks are seeded
+        differently on purpose -- distinct env shards, distinct action draws -- so without this they would average
+        gradients across diverged replicas.  Called at the end of every learner constructor; the derived parameter
+        layouts of the fused kernels are (re)built from params.flat at the start of every update phase anyway."""
+        if not (self.distributed_training and self.world_size > 1):
+            return
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return
+        from ..dist import broadcast_
+        broadcast_(self.model.params.flat, 0)
+        if getattr(self.model, "target_flat", None) is not None:
+            broadcast_(self.model.target_flat, 0)
+
     def estimate_total_iterations(self):                        # drl_learner.py:56-62
         start_training = getattr(self.config, "start_training", 0)
         training_frequency = getattr(self.config, "training_frequency", 1)
@@ -162,11 +178,22 @@ class Learner:
                    model_path)
 
     def load_model(self, path, model=None):
-        if os.path.isdir(path):
-            files = sorted(f for f in os.listdir(path) if f.endswith(".pth"))
+        """drl_learner.py:95-157: `path`/`model` names a file, or `path` is a directory holding `seed_*` run folders (the
+        last one in sorted order is taken, `final_train_model.pth` preferred inside it) -- or, as a convenience, `.pth`
+        files directly.  Returns the DIRECTORY the file was loaded from (the agent looks for obs_rms.npy there)."""
+        target = os.path.join(path, model) if model is not None else path
+        if os.path.isfile(target):
+            path = target
+        else:
+            if not os.path.isdir(path):
+                raise RuntimeError(f"The path '{path}' is not a valid directory or file!")
+            runs = sorted(f for f in os.listdir(path) if "seed_" in f and os.path.isdir(os.path.join(path, f)))
+            folder = os.path.join(path, runs[-1]) if runs else path
+            files = sorted(f for f in os.listdir(folder) if f.endswith(".pth"))
             if not files:
-                raise RuntimeError(f"No model file found in {path}")
-            path = os.path.join(path, files[-1])
+                raise (FileNotFoundError(f"No .pth file found in {folder}") if runs else
+                       RuntimeError(f"No model files with 'seed_' found in '{path}'!"))
+            path = os.path.join(folder, "final_train_model.pth" if "final_train_model.pth" in files else files[-1])
         ckpt = torch.load(path, map_location="cpu", weights_only=True)          # drl_learner.py:119-121
         self.model.load_state_dict(ckpt["policy"] if "policy" in ckpt else ckpt)
         if "optimizer" in ckpt and self.optimizer is not None:
@@ -180,7 +207,7 @@ class Learner:
         self._safe_scheduler_step()
         if getattr(self, "opt_sync", None) is not None:                         # barrier flags of xrl_reduce_adam hold step
             self.opt_sync.zero_()                                               # values: a rewound step must not match them
-        return path
+        return os.path.dirname(path)
 
     def _safe_scheduler_step(self):
         """drl_learner.py:189-210: only when the config carries `rt_epoch` (resumed benchmark runs) the scheduler jumps to

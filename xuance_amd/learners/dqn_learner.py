@@ -24,6 +24,7 @@ class DQN_Learner(Learner):
         self.sumsq = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.opt_sync = torch.zeros(4 + (P.P + 255) // 256 + 8, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.sync_replicas_from_rank0()
 
     def _ensure(self, M):
         if M <= self._cap:

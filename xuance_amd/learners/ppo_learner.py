@@ -33,6 +33,7 @@ class PPO_Learner(Learner):
         self.last_status = [0, 0, 0, 0]
         self.keep_diag = True     # keep the per-sample callback tensors (log_prob, ratio, surrogates)
         self.loss_mode = 0        # xrl_ppo_loss_t.mode: 0 PPO-clip, 1 A2C (see A2C_Learner)
+        self.sync_replicas_from_rank0()
 
     def estimate_total_iterations(self):                        # ppo_learner.py:28-33
         buffer_size = self.config.horizon_size * self.config.parallels

@@ -59,6 +59,7 @@ class QMIX_Learner(Learner):
         self.sumsq = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
         self.opt_sync = torch.zeros(4 + (P.P + 255) // 256 + 8, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
+        self.sync_replicas_from_rank0()
 
     def estimate_total_iterations(self):                        # marl_learner.py:36-47 (feed-forward branch)
         c = self.config

@@ -353,10 +353,15 @@ class HipPerOffPolicyBuffer(HipOffPolicyBuffer):
         import random
         assert beta > 0
         if uniforms is None:
+            if getattr(self, "_uni_copied", None) is not None:  # the previous asynchronous copy still reads the pinned block
+                self._uni_copied.synchronize()
             for i in range(self.n_envs):                        # _sample_proportional's draws, env by env (:504-506)
                 for j in range(self.per_env):
                     self._uni_h[i, j] = random.random()
             self._uni.copy_(self._uni_h, non_blocking=True)
+            if self._uni_h.is_pinned():
+                self._uni_copied = torch.cuda.Event()
+                self._uni_copied.record()
         else:
             self._uni.copy_(torch.as_tensor(np.asarray(uniforms), dtype=torch.float64).reshape(self._uni.shape))
         ops.per_sample(self.it_sum, self.it_min, self._uni, self.size, beta, self.n_envs, self.n_size, self.capacity,

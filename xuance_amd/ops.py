@@ -351,9 +351,11 @@ def rollout_step_cartpole(plan, **kw):
     call("xrl_rollout_step_cartpole", C.byref(p), stream_ptr())
 
 
-def rollout_cartpole_persistent(plan, T, bootv, barrier, status, **kw):
+def rollout_cartpole_persistent(plan, T, bootv, barrier, status, flags=0, **kw):
     """All T steps + the bootstrap pass in one launch; kw as for rollout_step_cartpole (describing step 0)."""
     q = RolloutPersist()
+    q.flags = int(flags)
+    assert barrier.numel() >= 128
     for k, v in kw.items():
         if isinstance(v, torch.Tensor):
             v = v.data_ptr()
