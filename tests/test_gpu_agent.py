@@ -144,6 +144,33 @@ def test_graph_replay_equals_eager():
     assert outs[0][2]["actor_loss"] == outs[1][2]["actor_loss"]
 
 
+def test_replayed_rollout_graphs_are_deterministic():
+    """Regression: the rollout graph (parameter re-pack -> scratch zeroing -> whole-rollout launch -> GAE) replayed after
+    update phases must give the same bits in every repetition.  With a hipMemsetAsync node between the re-pack kernel and
+    the whole-rollout launch, replays started the launch before the re-pack had finished (stale critic parameters in a
+    workgroup now and then: 16 of 29 repetitions differed); the scratch is zeroed by a kernel now."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    ref = None
+    for rep in range(8):
+        torch.manual_seed(0)
+        agent = PPO_Agent(make_config(64, 32, use_hip_graph=True, n_epochs=2, n_minibatch=4), DeviceCartPoleVecEnv(64, seed=3))
+        snaps = []
+        for it in range(3):
+            agent.rollout()
+            torch.cuda.synchronize()
+            snaps.append({k: npy(v) for k, v in agent.memory.soa.fields.items()})
+            agent.update()
+        snaps.append({"params": npy(agent.model.params.flat)})
+        assert agent.persist_status is not None
+        if ref is None:
+            ref = snaps
+            continue
+        for i, (a, b) in enumerate(zip(ref, snaps)):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), f"repetition {rep}, snapshot {i}, field {k}"
+
+
 def test_cartpole_learns():
     """Sanity (not parity): a few hundred thousand env steps of the fused loop must raise the episode score."""
     from xuance_amd.agents import PPO_Agent
@@ -482,7 +509,7 @@ def test_agent_checkpoint_files(tmp_path, fused):
     cfg = make_config(n, T, use_fused_rollout=fused, use_hip_graph=False, model_dir=str(tmp_path))
     a = PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=3))
     a.train(2 * T)
-    a.save_model("final_train_model.pth")
+    a.save_model("final_train_model.pth", model_path=str(tmp_path))        # (default: a seed_* run folder under model_dir)
     st = np.load(tmp_path / "obs_rms.npy", allow_pickle=True).item()
     assert set(st) == {"count", "mean", "var"} and st["mean"].shape == (4,) and st["mean"].dtype == np.float32
     assert st["count"] > 2 * T * n - 1

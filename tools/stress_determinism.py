@@ -10,7 +10,8 @@ from xuance_amd.envs import DeviceCartPoleVecEnv
 
 n, T, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 kw = dict(use_persistent_rollout=os.environ.get("PERSIST", "1") == "1", use_hip_graph=os.environ.get("GRAPH", "1") == "1",
-          use_fused_optimizer=os.environ.get("FUSEDOPT", "1") == "1")
+          use_fused_optimizer=os.environ.get("FUSEDOPT", "1") == "1",
+          persistent_coherent_exchange=os.environ.get("COHERENT", "0") == "1")
 if len(sys.argv) > 4:
     kw.update(n_epochs=int(sys.argv[4]), n_minibatch=int(sys.argv[5]))
 ref, bad = None, 0

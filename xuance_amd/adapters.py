@@ -48,7 +48,9 @@ def _last_activation_of(seq, default):
     kids = list(seq.children())
     if kids and type(kids[-1]).__name__ in _ACT:
         return _ACT[type(kids[-1]).__name__]
-    return None if kids else default
+    if not any(type(k).__name__ == "Linear" for k in kids):          # not a real layer stack (e.g. a bare parameter tree)
+        return default
+    return None
 
 
 def _chain(sd, prefix):

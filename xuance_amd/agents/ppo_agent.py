@@ -567,7 +567,8 @@ class PG_Agent(PPO_Agent):
                              last_step=int(t == self.horizon_size - 1), obs_range=float(self.obsnorm_range),
                              rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
         # get_terminated_values = the processed reward (pg_agent.py:66-79); terminated envs close with 0 (seg bit 2)
-        f["bootv"][t].copy_(f["rewards"][t])
+        torch.mul(f["rewards"][t], 1.0, out=f["bootv"][t])      # (an elementwise KERNEL: a D2D copy would become a memcpy node
+        #                                                            when this step is captured, see csrc/rollout_persist.hip)
 
     def _enqueue_rollout(self):
         T = self.horizon_size

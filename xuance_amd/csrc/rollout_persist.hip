@@ -485,6 +485,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) rollout_persistent_kernel(xrl_r
     }
 }
 
+__global__ void zero_words_kernel(uint32_t* p) { p[threadIdx.x] = 0u; }
+
 bool rollout_fast_eligible(const xrl_rollout_step_t& p);
 
 }  // namespace xrl
@@ -507,7 +509,11 @@ extern "C" int xrl_rollout_cartpole_persistent(const xrl_rollout_persist_t* qq, 
     const int n_tiles = (p.n + FT - 1) / FT;
     const int n_wg = 3 * n_tiles;
     XRL_CHECK_ARG(n_wg <= device_cu_count() / 8);                   // all resident workgroups on ONE XCD, one per CU
-    XRL_CHECK_HIP(hipMemsetAsync(q.barrier, 0, 128 * sizeof(uint32_t), as_stream(stream)));
+    // The barrier scratch is zeroed by a KERNEL, not by hipMemsetAsync: inside a captured hipGraph a memset node does not
+    // hold back the kernel node behind it until the kernel node in front of it (xrl_pack_rollout_cache) has finished --
+    // measured on ROCm 7.2 / MI355X with tools/stress_determinism.py: with the memset node 16 of 29 replays of the rollout
+    // graph read partly stale parameter images, with a zeroing kernel 0 of 29 (eager launches were never affected).
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(128), 0, as_stream(stream), q.barrier);
     XRL_ACT_DISPATCH(p.layers[0].act,
         if (p.n <= 256) hipLaunchKernelGGL((rollout_persistent_kernel<ACT, 4>), dim3(8 * n_wg), dim3(FUSED_THREADS), 0, as_stream(stream), q);
         else hipLaunchKernelGGL((rollout_persistent_kernel<ACT, 16>), dim3(8 * n_wg), dim3(FUSED_THREADS), 0, as_stream(stream), q);)
