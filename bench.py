@@ -38,9 +38,13 @@ def make_config(n_envs, horizon, world, rank):
                      model_dir="/tmp/xrl_bench_models", use_hip_graph=True)
 
 
+_PMC_SOURCE = [None]
+
+
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, FETCH_SIZE doubled
-    per MI355X_MICROARCH.md); None if the summary is not there.  PMC counters cannot be read from inside the process."""
+    per MI355X_MICROARCH.md); None if the summary is not there.  PMC counters cannot be read from inside the process:
+    this number is COPIED from the builder-run pass named in `traffic_source`, not measured in this run."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ppo_c2_pmc_hbm.json")))      # latest committed pass
     try:
@@ -48,10 +52,27 @@ def _pmc_traffic(kernel):
             ks = json.load(f)["kernels"]
         for name, v in ks.items():                       # template instantiations carry their arguments in the name
             if name.startswith(kernel):
+                _PMC_SOURCE[0] = "profiles/" + os.path.basename(paths[-1]) + " (committed rocprofv3 --pmc pass of this command, not measured in this run)"
                 return int(v["hbm_bytes_per_launch"])
     except Exception:
         pass
     return None
+
+
+def reference_cpu_baseline(key, sub=None):
+    """The CPU baseline of record: the UNMODIFIED reference timed by oracle/time_reference_cpu.py through its own
+    agent.train() (profiles/ref_cpu_baseline.json, cores stated).  The reference tree does not exist on the GPU box, so it
+    cannot be re-timed here; the file says where it was measured."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "ref_cpu_baseline.json")) as f:
+            r = json.load(f)
+        e = r[key][sub] if sub is not None else r[key]
+        return {"value": e["env_steps_per_s"], "unit": "env-steps/s", "cores": r["cores"], "kind": "reference",
+                "sample": e["what"] + "; median of %d timed calls after one warm-up call; unmodified reference on device 'cpu', "
+                          "torch %s, %d threads; measured on: %s (profiles/ref_cpu_baseline.json, oracle/time_reference_cpu.py)"
+                          % (len(e["runs"]), r["torch"], r["threads"], r["host"])}
+    except Exception as ex:                                  # noqa: BLE001
+        return {"value": None, "kind": "reference", "error": repr(ex)}
 
 
 def _event_time_us(fn, reps):
@@ -87,7 +108,8 @@ def kernel_rooflines(agent):
     name = "xrl::rollout_persistent_kernel" if persistent else "xrl::rollout_step_fast_kernel"
     r1 = {"bound": "mfma", "kernel": name, "achieved": round(fl_launch / us_launch / 1e6, 4),
           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_launch / us_launch / 1e6 / PEAK_FP32_MFMA_TFLOPS, 5),
-          "traffic": _pmc_traffic(name), "avg_launch_us": round(us_launch, 3), "algorithmic_flops_per_launch": fl_launch,
+          "traffic": _pmc_traffic(name), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_launch, 3),
+          "algorithmic_flops_per_launch": fl_launch,
           "note": "latency-bound: %d rows x %.0f flop per launch (%s); see DESIGN.md section 3"
                   % (rows, fwd_flops_row, "%d vector steps of 2 x %d rows" % (T + 1, n) if persistent else "one vector step")}
     # (2) fused minibatch kernel, timed INSIDE the real minibatch sequence: (graph of nb x [minibatch kernel, optimiser
@@ -124,7 +146,7 @@ def kernel_rooflines(agent):
         n_mb = nb                                          # agent.idx holds n_epochs x n_minibatch index rows
         r2 = {"bound": "mfma", "kernel": "xrl::ppo_fast_kernel", "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
-              "traffic": _pmc_traffic("xrl::ppo_fast_kernel"), "avg_launch_us": round(us_mb, 3),
+              "traffic": _pmc_traffic("xrl::ppo_fast_kernel"), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_mb, 3),
               "algorithmic_flops_per_launch": fl_mb, "launches_per_step": n_mb, "us_per_step": round(us_mb * n_mb, 1),
               "note": "%d rows x %.0f flop (forward + backward) per launch; see DESIGN.md section 3" % (bs, 3.0 * fwd_flops_row)}
     r1.update(launches_per_step=launches, us_per_step=round(us_launch * launches, 1))
@@ -155,6 +177,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the PPO-16-envs / QMIX-3m / eager-PyTorch lines")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -251,7 +274,27 @@ def main():
                 if second is not None:
                     out["roofline_update_kernel"] = second
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.n_envs, args.horizon)
+            # cpu_baseline: the reference's own CPU torch path (kind "reference", timed where the reference exists);
+            # cpu_port: the oracle's NumPy port of the same loop, timed live on THIS host's cores
+            out["cpu_baseline"] = reference_cpu_baseline("ppo_cartpole", str(args.n_envs))
+            out["cpu_port"] = cpu_baseline(args.n_envs, args.horizon)
+        if world == 1 and not args.no_secondary:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            sec = {}
+            try:
+                import eager_torch_ppo
+                out["gpu_eager_baseline"] = eager_torch_ppo.measure(args.n_envs, args.horizon, steps=2, warmup=1)
+            except Exception as ex:                          # noqa: BLE001
+                out["gpu_eager_baseline"] = {"error": repr(ex)}
+            try:
+                import bench_secondary as bs
+                sec["ppo_cartpole_16_envs"] = bs.ppo_small(make_config, kernel_rooflines, 16, args.horizon,
+                                                           ref=reference_cpu_baseline("ppo_cartpole", "16"))
+                sec["qmix_3m_ff"] = bs.qmix_3m(False, ref=reference_cpu_baseline("qmix_3m_ff"))
+                sec["qmix_3m_gru"] = bs.qmix_3m(True, ref=reference_cpu_baseline("qmix_3m_gru"))
+            except Exception as ex:                          # noqa: BLE001
+                sec["error"] = repr(ex)
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

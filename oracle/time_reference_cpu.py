@@ -1,6 +1,15 @@
-"""TEST INFRASTRUCTURE / DOCUMENTATION ONLY -- times the UNMODIFIED reference's learner updates on this container's CPU
-(through oracle/ref_shim.py) at the BASELINE shapes, as context for the device numbers in DESIGN.md.  Not used by any
-test or by bench.py (the reference does not exist on the GPU box).   PYTHONDONTWRITEBYTECODE=1 python oracle/time_reference_cpu.py
+"""TEST INFRASTRUCTURE / MEASUREMENT ONLY -- the CPU baseline of record: the UNMODIFIED reference
+(through oracle/ref_shim.py), device "cpu", torch threads = all cores of this container, timed
+
+  * as whole agents: REGISTRY_Agents["PPO"] / ["QMIX"] constructed from the reference's own yaml configs and run through
+    their own ``train()`` (rollout + buffer + learner updates) on host vector envs with the reference's contracts
+    (xuance_amd.envs.DummyVecEnv over NumpyCartPoleEnv; DummyVecMultiAgentEnv over the SMAC-3m-shaped HostSMACLikeEnv --
+    gymnasium / SMAC are not installed) -> env-steps/s, the metric of BASELINE.json;
+  * per learner update at the BASELINE batch shapes.
+
+The reference tree does not exist on the GPU box, so bench.py cannot run this there: the result is committed as
+profiles/ref_cpu_baseline.json (cores stated) and bench.py reports it as `cpu_baseline` (kind "reference").
+    PYTHONDONTWRITEBYTECODE=1 python oracle/time_reference_cpu.py [out.json]
 """
 import os, sys, time, json
 sys.dont_write_bytecode = True
@@ -94,10 +103,117 @@ def ppo(bs):
     return timed(lambda: learner.update(**b), 20)
 
 
+class _NullWriter:
+    def __init__(self, *a, **k): pass
+    def add_scalar(self, *a, **k): pass
+    def add_scalars(self, *a, **k): pass
+
+
+def _agent_config(yaml_rel, **over):
+    import yaml
+    from argparse import Namespace
+    root = "/root/reference/xuance/configs"
+    c = yaml.safe_load(open(os.path.join(root, "basic.yaml")))
+    c.update(yaml.safe_load(open(os.path.join(root, yaml_rel))))
+    c.update(device="cpu", log_dir="/tmp/xrl_ref_logs", model_dir="/tmp/xrl_ref_models", logger="tensorboard", render=False,
+             render_mode="rgb_array", fps=50, test_mode=False, dl_toolbox="torch", running_steps=10 ** 8)
+    c.update(over)
+    return Namespace(**c)
+
+
+def _median_rate(agent, steps_per_call, calls, count):
+    agent.train(steps_per_call)                                   # warm-up (first rollout / first updates)
+    rates = []
+    for _ in range(calls):
+        s0, t0 = count(), time.perf_counter()
+        agent.train(steps_per_call)
+        rates.append((count() - s0) / (time.perf_counter() - t0))
+    return float(np.median(rates)), [round(r, 1) for r in rates]
+
+
+def ppo_agent_loop(n_envs, calls=3):
+    """The reference's PPO_Agent.train (ppo_agent.py:111-181) with configs/ppo/classic_control/CartPole-v1.yaml; one call =
+    one rollout of 256 vector steps + 64 minibatch updates."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import xuance.torch.agents.base.agent as agent_mod
+    from xuance.torch.agents import REGISTRY_Agents
+    from xuance_amd.envs import DummyVecEnv, NumpyCartPoleEnv
+    agent_mod.SummaryWriter = _NullWriter
+    import tqdm as _tq
+    import xuance.torch.agents.policy_gradient.ppo_agent as pa
+    pa.tqdm = lambda x, *a, **k: x                                # no progress bars in the timed region
+    cfg = _agent_config("ppo/classic_control/CartPole-v1.yaml", parallels=n_envs)
+    envs = DummyVecEnv([NumpyCartPoleEnv] * n_envs, env_seed=1)
+    envs.observation_space, envs.action_space = sp.Box(-np.inf, np.inf, (4,), np.float32), sp.Discrete(2)
+    envs.reset()
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs)
+        rate, all_rates = _median_rate(agent, cfg.horizon_size, calls, lambda: agent.current_step)
+    finally:
+        os.chdir(cwd)
+    return {"env_steps_per_s": round(rate, 1), "runs": all_rates, "n_envs": n_envs,
+            "what": "reference PPO_Agent.train(256): 256 vector steps + 8 x 8 minibatch updates of %d" % (n_envs * 32)}
+
+
+def qmix_agent_loop(n_envs, rnn, calls=3):
+    """The reference's QMIX_Agents.train (off_policy_marl.py:310-424) with configs/qmix/sc2/3m.yaml.  Recurrent agents (the
+    yaml default) with use_actions_mask as in the yaml crash in the reference's own update (iql_learner.py:78-81, see
+    oracle/make_golden.py), so the recurrent run switches the mask off; the feed-forward run keeps it."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import xuance.torch.agents.base.agents_marl as am
+    from xuance.torch.agents import REGISTRY_Agents
+    from xuance_amd.envs import DummyVecMultiAgentEnv, HostSMACLikeEnv
+    am.SummaryWriter = _NullWriter
+    import xuance.torch.agents.core.off_policy_marl as opm
+    class _Quiet:                                                  # tqdm stand-in: iterable and context manager, silent
+        last_print_n = n = 0
+        def __init__(self, it=None, *a, **k): self.it = it
+        def __iter__(self): return iter(self.it)
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def update(self, *a, **k): pass
+    opm.tqdm = _Quiet
+    over = dict(parallels=n_envs, use_rnn=rnn, start_training=0 if rnn else 4 * n_envs,
+                buffer_size=(5000 // n_envs) * n_envs)             # must divide by n_envs (memory_tools_marl.py:31)
+    if rnn:
+        over.update(use_actions_mask=False)
+    else:
+        over.update(representation="Basic_MLP")
+    cfg = _agent_config("qmix/sc2/3m.yaml", **over)
+    class _Env(HostSMACLikeEnv):
+        strict_actions = not rnn                                   # (with the masks off the reference picks unavailable actions)
+    envs = DummyVecMultiAgentEnv([_Env] * n_envs, env_seed=1)
+    envs.observation_space = {k: sp.Box(-np.inf, np.inf, (30,), np.float32) for k in envs.agents}
+    class _Disc(sp.Discrete):                                      # gymnasium's Discrete.sample (masks-off exploration, :242)
+        def sample(self):
+            return int(np.random.randint(self.n))
+    envs.action_space = {k: _Disc(9) for k in envs.agents}
+    envs.state_space = sp.Box(-np.inf, np.inf, (48,), np.float32)
+    envs.groups_info = None
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs)
+        rate, all_rates = _median_rate(agent, 60 if rnn else 16, calls, lambda: agent.current_step)
+    finally:
+        os.chdir(cwd)
+    return {"env_steps_per_s": round(rate, 1), "runs": all_rates, "n_envs": n_envs,
+            "what": "reference QMIX_Agents.train on the SMAC-3m-shaped host env, %s, batch 32, 8 updates per %s"
+                    % ("Basic_RNN/GRU, use_actions_mask off" if rnn else "Basic_MLP, action masks on",
+                       "%d episodes" % n_envs if rnn else "vector step")}
+
+
 if __name__ == "__main__":
-    out = {"threads": os.cpu_count(),
+    import platform
+    out = {"threads": os.cpu_count(), "cores": os.cpu_count(), "host": "build container (no GPU), %s" % platform.processor(),
+           "torch": torch.__version__, "numpy": np.__version__,
+           "ppo_cartpole": {str(n): ppo_agent_loop(n) for n in (4, 16, 256)},
+           "qmix_3m_ff": qmix_agent_loop(64, False), "qmix_3m_gru": qmix_agent_loop(64, True),
            "ppo_update_bs8192_ms": round(ppo(8192), 3),
            "qmix_ff_update_b32_ms": round(qmix(False), 3),
            "qmix_rnn_update_b32x60_ms": round(qmix(True), 3),
            "dqn_cnn_update_b32_ms": round(dqn_cnn(), 3)}
     print(json.dumps(out))
+    if len(sys.argv) > 1:
+        with open(sys.argv[1], "w") as f:
+            json.dump(out, f, indent=1)

@@ -1,0 +1,109 @@
+"""MEASUREMENT INFRASTRUCTURE -- the secondary lines of bench.py: the other two workloads the north-star's target sentence
+names besides BASELINE configs[1] -- PPO-Clip CartPole-v1 with 16 parallel envs, and QMIX on the SMAC-3m shape (64 envs per
+GPU = configs[4] / 8, feed-forward agents and the yaml-default recurrent agents) -- each with its own roofline object.
+Every function returns a dict; bench.py attaches them under "secondary".  Timed regions are bracketed by
+torch.cuda.synchronize(); kernel / graph times come from HIP events on the launch stream."""
+import time
+from argparse import Namespace
+
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def _events_us(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def ppo_small(make_config, kernel_rooflines, n_envs=16, horizon=256, steps=20, warmup=3, ref=None):
+    """PPO-Clip CartPole-v1 with 16 parallel envs (the north-star's smallest size): same engine, same graphs."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    torch.manual_seed(1)
+    agent = PPO_Agent(make_config(n_envs, horizon, 1, 0), DeviceCartPoleVecEnv(n_envs, seed=1))
+    for _ in range(warmup):
+        agent.rollout(); agent.update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.rollout()
+        info = agent.update()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "PPO-Clip CartPole-v1, %d envs x horizon %d, 8 epochs x 8 minibatches of %d" % (n_envs, horizon, n_envs * horizon // 8),
+           "value": round(n_envs * horizon * steps / dt, 1), "unit": "env-steps/s", "ms_per_step": round(dt / steps * 1e3, 4),
+           "steps": steps, "warmup": warmup}
+    r1, r2 = kernel_rooflines(agent)
+    out["roofline"] = r2 if r2 is not None else r1
+    out["roofline_rollout_kernel"] = r1
+    if ref:
+        out["cpu_baseline"] = ref
+    return out
+
+
+def _qmix_cfg(n, rnn):
+    c = dict(q_hidden_size=[64], hidden_dim_mixing_net=32, hidden_dim_hyper_net=32, activation="relu", seed=1, parallels=n,
+             running_steps=10 ** 7, batch_size=32, learning_rate=7e-4, gamma=0.99, double_q=True, start_greedy=1.0,
+             end_greedy=0.05, decay_step_greedy=50000, sync_frequency=200, training_frequency=1, n_epochs=8,
+             use_grad_clip=False, grad_clip_norm=10.0, use_actions_mask=True, use_parameter_sharing=True, use_rnn=rnn,
+             distributed_training=False, device="cuda", model_dir="/tmp/xrl_bench_models")
+    if rnn:   # configs/qmix/sc2/3m.yaml defaults; rnn_backprop_agents False = the reference's behaviour (agents detached)
+        c.update(fc_hidden_sizes=[64], recurrent_hidden_size=64, buffer_size=5000, start_training=1000, rnn_backprop_agents=False,
+                 episode_length=60)
+    else:
+        c.update(representation_hidden_size=[64], buffer_size=n * 78, start_training=640)
+    return Namespace(**c)
+
+
+# algorithmic fp32 flops per update: per-agent Q network forward, mixer hyper-networks forward
+_FF_AGENT_FWD = 2.0 * (30 * 64 + 64 * 64 + 64 * 9)                        # 13 184 flop per agent row
+_RNN_AGENT_FWD = 2.0 * (30 * 64 + 64 * 192 + 64 * 192 + 64 * 64 + 64 * 9)  # fc + W_ih + W_hh + Q head per agent row and step
+_MIXER_FWD = 20800.0                                                      # per mixer row (eval); eval fwd+bwd + target fwd = 4x
+
+
+def qmix_3m(rnn, n=64, steps=None, ref=None):
+    """QMIX on the SMAC-3m shape, 64 envs (one GPU's share of BASELINE configs[4]): env-steps/s of the whole agent loop
+    (synthetic provider on the device, acting, replay store, 8 updates per vector step / per 64 episodes) and the update
+    phase as one captured graph.  Roofline of the update: algorithmic flops of one update / its time (launch-bound)."""
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    torch.manual_seed(0)
+    agent = QMIX_Agents(_qmix_cfg(n, rnn), SyntheticSMACVecEnv(n, seed=3))
+    steps = steps or (180 if rnn else 200)
+    agent.train(60 if rnn else 20)
+    torch.cuda.synchronize()
+    s0, t0 = agent.current_step, time.perf_counter()
+    agent.train(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env_steps = agent.current_step - s0
+    lr = agent.learner
+    graph_us = _events_us(lr._buf_graph.launch, 20)
+    upd_us = graph_us / 8
+    B, N, T = 32, 3, 60
+    if rnn:
+        flops = (T + 1) * B * N * _RNN_AGENT_FWD * 2 + T * B * _MIXER_FWD * 4     # eval + target agents (detached), mixer f+b + target
+        what = "recurrent agents (3m.yaml: fc 64 + GRU 64, 60-step episodes, batch 32 episodes = 1 920 mixer rows, agents detached as in the reference)"
+    else:
+        flops = B * N * _FF_AGENT_FWD * 5 + B * _MIXER_FWD * 4                    # eval f+b (3x), eval(next), target; mixer as above
+        what = "feed-forward agents (Basic_MLP 64 + Q 64-9, batch 32 transitions)"
+    tf = flops / upd_us / 1e6
+    out = {"workload": "QMIX SMAC-3m shape, %d envs x 3 agents, obs 30 / state 48 / 9 masked actions, %s, 8 updates per %s"
+                       % (n, what, "%d episodes" % n if rnn else "vector step"),
+           "value": round(env_steps / dt, 1), "unit": "env-steps/s", "update_us": round(upd_us, 2),
+           "env_steps_timed": int(env_steps), "seconds": round(dt, 3),
+           "roofline": {"bound": "mfma", "kernel": "update graph (xrl::gemm_f32_kernel launches + " + ("xrl::gru_*_kernel + " if rnn else "")
+                                                    + "xrl::qmix_prefetch_kernel + xrl::reduce_adam_kernel)",
+                        "achieved": round(tf, 4), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 5),
+                        "traffic": None, "avg_launch_us": round(upd_us, 2), "algorithmic_flops_per_launch": flops,
+                        "note": "one 'launch' = one whole update (a graph of ~9 kernels); launch-latency-bound at batch 32, see DESIGN.md section 3"}}
+    if ref:
+        out["cpu_baseline"] = ref
+    return out

@@ -113,6 +113,7 @@ class HostSMACLikeEnv:
     reward favours ONE action per step (the index the state's first component points to) when it is available, so a policy
     is scoreable; dynamics are a seeded random walk."""
     n_agents, obs_dim, state_dim, n_actions, max_episode_steps = 3, 30, 48, 9, 60
+    strict_actions = True            # an unavailable action is an error (False: it merely earns nothing)
 
     def __init__(self, env_seed=None):
         self.agents = [f"agent_{i}" for i in range(self.n_agents)]
@@ -136,20 +137,23 @@ class HostSMACLikeEnv:
     def reset(self):
         self.steps, self.score = 0, {k: 0.0 for k in self.agents}
         obs = self._emit()
-        return obs, {"state": self.state, "avail_actions": self.avail}
+        return obs, {"state": self.state, "avail_actions": self.avail, "agent_mask": {k: True for k in self.agents},
+                     "episode_step": 0, "episode_score": dict(self.score)}
 
     def step(self, actions):
         target = int(abs(self.state[0]) * 3) % self.n_actions
         rew = {}
         for k in self.agents:
-            assert self.avail[k][int(actions[k])] > 0, "unavailable action chosen"
-            rew[k] = 1.0 if int(actions[k]) == target else 0.0
+            ok = self.avail[k][int(actions[k])] > 0
+            assert ok or not self.strict_actions, "unavailable action chosen"
+            rew[k] = 1.0 if (ok and int(actions[k]) == target) else 0.0
             self.score[k] += rew[k]
         self.steps += 1
         term = bool(self.rng.random() < 0.02)
         trunc = (not term) and self.steps >= self.max_episode_steps
         obs = self._emit()
-        info = {"state": self.state, "avail_actions": self.avail, "episode_step": self.steps, "episode_score": dict(self.score)}
+        info = {"state": self.state, "avail_actions": self.avail, "agent_mask": {k: True for k in self.agents},   # wrapper.py:160-178
+                "episode_step": self.steps, "episode_score": dict(self.score)}
         return obs, rew, {k: term for k in self.agents}, trunc, info
 
     def close(self):
