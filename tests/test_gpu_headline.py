@@ -156,8 +156,11 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
             oinfo, _ = oracle.ppo_update(sd, opt, dict(obs=s["obs"], actions=s["actions"], returns=s["returns"],
                                                         advantages=s["advantages"], old_logp=s["aux_batch"]["old_logp"]), cfg)
         for key, ok in (("actor_loss", "a_loss"), ("critic_loss", "c_loss"), ("entropy", "e_loss"),
-                        ("predict_value", "predict_value"), ("clip_ratio", "clip_ratio")):
+                        ("predict_value", "predict_value")):
             assert_close(info[key], oinfo[ok], 1e-5, f"{key} (pass {it})")
+        # clip_ratio is a COUNT of samples with ratio outside [1 - eps, 1 + eps], divided by the minibatch size: a ratio
+        # within float32 rounding of the boundary may fall on either side (<= 2 such samples of 8 192)
+        assert abs(info["clip_ratio"] - float(oinfo["clip_ratio"])) * idx.shape[1] <= 2.0 + 1e-6, "clip_ratio"
         got = agent.model.state_dict()
         for k_, v in sd.items():
             assert_close(npy(got[k_]), v, 1e-5, f"param {k_} after {64 * (it + 1)} updates")
