@@ -122,7 +122,8 @@ def kernel_rooflines(agent):
         ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=lr.params_t, cache_image=lr.cache_image,
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=agent.idx[k], stats=lr.stats[k], slabs=lr.fslabs,
-                                partials=lr.fpartials, diag=None, slab_stride=m.params.P, M=bs, n_envs=n, T=T, D=4,
+                                partials=lr.fpartials, diag=None, slab_stride=lr.slab_stride,
+                                l0_fold_off=lr.fold[0] if lr.fold else 0, M=bs, n_envs=n, T=T, D=4,
                                 frag_image=lr.frag, f_packed=lr.packed, f_rows=lr.rows[k * bs * 8:(k + 1) * bs * 8],
                                 A=m.action_dim, clip_range=lr.clip_range, vf_coef=lr.vf_coef, ent_coef=lr.ent_coef)
     r2 = None
@@ -130,8 +131,8 @@ def kernel_rooflines(agent):
         clip = lr.grad_clip_norm if lr.use_grad_clip else 0.0
         opt = lr.optimizer
         def ra():
-            ops.reduce_adam(lr.fslabs, lr.n_tiles, m.params.P, m.params.flat, opt.grad, opt.m, opt.v, m.params.P,
-                            opt.state, lr.sumsq, clip, lr._mirrors, lr.opt_sync)
+            ops.reduce_adam(lr.fslabs, lr.n_tiles, lr.slab_stride, m.params.flat, opt.grad, opt.m, opt.v, m.params.P,
+                            opt.state, lr.sumsq, clip, lr._mirrors, lr.opt_sync, fold=lr.fold)
         g_both, g_opt = ops.Graph(), ops.Graph()           # the real minibatch sequence, and the optimiser launches alone
         torch.cuda.synchronize()
         with g_both:
@@ -144,9 +145,10 @@ def kernel_rooflines(agent):
         us_mb = (_event_time_us(g_both.launch, 3) - _event_time_us(g_opt.launch, 3)) / nb
         fl_mb = 3.0 * fwd_flops_row * bs
         n_mb = nb                                          # agent.idx holds n_epochs x n_minibatch index rows
-        r2 = {"bound": "mfma", "kernel": "xrl::ppo_fast_kernel", "achieved": round(fl_mb / us_mb / 1e6, 3),
+        kname = "xrl::ppo_split_kernel" if lr.fold else "xrl::ppo_fast_kernel"
+        r2 = {"bound": "mfma", "kernel": kname, "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
-              "traffic": _pmc_traffic("xrl::ppo_fast_kernel"), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_mb, 3),
+              "traffic": _pmc_traffic(kname), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_mb, 3),
               "algorithmic_flops_per_launch": fl_mb, "launches_per_step": n_mb, "us_per_step": round(us_mb * n_mb, 1),
               "note": "%d rows x %.0f flop (forward + backward) per launch; see DESIGN.md section 3" % (bs, 3.0 * fwd_flops_row)}
     r1.update(launches_per_step=launches, us_per_step=round(us_launch * launches, 1))
@@ -178,6 +180,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the PPO-16-envs / QMIX-3m / eager-PyTorch lines")
+    ap.add_argument("--no-role-split", action="store_true", help="one workgroup per minibatch tile (ppo_fast_kernel) instead of two")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -197,6 +200,7 @@ def main():
 
     torch.manual_seed(1)                               # same initial parameters on every rank (DDP broadcasts rank 0's)
     cfg = make_config(args.n_envs, args.horizon, world, rank)
+    cfg.use_role_split_update = False if args.no_role_split else "auto"
     env = DeviceCartPoleVecEnv(args.n_envs, seed=1 + rank)
     agent = PPO_Agent(cfg, env)
     if world > 1:

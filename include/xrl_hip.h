@@ -183,6 +183,10 @@ typedef struct {
 } xrl_adam_state_t;        /* lives in DEVICE memory so a captured graph can advance it */
 
 /* grad[p] = sum_s slabs[s][p]; sumsq_part[b] = sum over block b of grad^2 (float64). n_part blocks. */
+/* xrl_grad_reduce with a fold region: slab columns [fold_off, fold_off + fold_len) (fold_off >= P) are added onto columns
+ * [0, fold_len) after the main columns, in the same fixed slab order (see xrl_mirrors_t.fold_off). */
+int xrl_grad_reduce_fold(const float* slabs, int n_split, int64_t slab_stride, int64_t P, float* grad, double* sumsq_part,
+                         int n_part, int64_t fold_off, int fold_len, xrl_stream_t stream);
 int xrl_grad_reduce(const float* slabs, int n_split, int64_t slab_stride, int64_t P, float* grad,
                     double* sumsq_part, int n_part, xrl_stream_t stream);
 /* total_norm = sqrt(sum sumsq_part); grad *= min(1, max_norm/(total_norm+1e-6)) when max_norm > 0;
@@ -205,6 +209,9 @@ typedef struct {
                              * launch performs is a multiple of target_every, target[i] <- new parameter
                              * (copy_target(), dqn_learner.py:56-57, qmix_learner.py:105-106; same as xrl_sync_target) */
     float* target;          /* NULL or [P] */
+    int64_t fold_off;       /* xrl_reduce_adam only: slab columns [fold_off, fold_off + fold_len) are a second partial of */
+    int32_t fold_len;       /* columns [0, fold_len) (ppo_split_kernel's critic-role first-layer gradient); 0 = none */
+    int32_t pad;
 } xrl_mirrors_t;
 int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
                           const double* sumsq_part, int n_part, double max_norm, const xrl_mirrors_t* mirrors,
@@ -503,7 +510,10 @@ typedef struct {
     double* partials;           /* [n_tiles][8] like xrl_ppo_loss_t.partials */
     float* diag;                /* NULL or [4][M] */
     int64_t slab_stride;
-    int32_t M, n_envs, T, D, A, pad1;
+    int32_t M, n_envs, T, D, A;
+    int32_t l0_fold_off;        /* 0, or the slab column (>= P, multiple of 4) of a 640-float fold region: selects the role-split
+                                 * kernel (ppo_split.hip: TWO workgroups per tile, partials [2 n_tiles][8]; the critic role's
+                                 * first-layer gradient goes to the fold region -- reduce with xrl_mirrors_t.fold_off / _len) */
     float clip_range, vf_coef, ent_coef, pad2;
     long long* dbg;             /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
     const float* frag_image;    /* NULL, or xrl_pack_mid_frags copy of the first middle layer in MFMA B-fragment order */

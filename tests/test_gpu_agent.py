@@ -326,13 +326,14 @@ def test_fused_minibatch_kernel_equals_layered_path(n, T, nmb):
 
 @pytest.mark.parametrize("act,n,T,nmb", [("leaky_relu", 64, 64, 4), ("tanh", 50, 30, 3), ("relu", 24, 40, 2)])
 def test_specialised_minibatch_kernel_is_bit_identical_to_any_shape_kernel(act, n, T, nmb):
-    """ppo_fast_kernel (compile-time 4-128-{128-2,128-1}) vs ppo_fused_kernel: same gradient slabs, loss terms, diagnostics."""
+    """ppo_fast_kernel (compile-time 4-128-{128-2,128-1}, one workgroup per tile) vs ppo_fused_kernel: same gradient slabs,
+    loss terms, diagnostics.  (use_role_split_update=False: the role-split kernel has its own test below.)"""
     from xuance_amd import ops
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv
     torch.manual_seed(0)
     env = DeviceCartPoleVecEnv(n, seed=2)
-    agent = PPO_Agent(make_config(n, T, n_epochs=1, n_minibatch=nmb, activation=act), env)
+    agent = PPO_Agent(make_config(n, T, n_epochs=1, n_minibatch=nmb, activation=act, use_role_split_update=False), env)
     agent.rollout()
     agent._new_indices()
     mem, lr = agent.memory, agent.learner
@@ -363,6 +364,45 @@ def test_specialised_minibatch_kernel_is_bit_identical_to_any_shape_kernel(act, 
     for key in a:
         assert np.array_equal(a[key], b[key]), key
         assert np.array_equal(a[key], c[key]), key + " (pre-gathered rows)"
+
+
+@pytest.mark.parametrize("act,n,T,nmb", [("leaky_relu", 64, 64, 4), ("tanh", 50, 30, 3), ("relu", 256, 256, 8)])
+def test_role_split_minibatch_kernel_vs_single_workgroup_kernel(act, n, T, nmb):
+    """ppo_split_kernel (two workgroups per tile: actor branch / critic branch, two per CU) vs ppo_fast_kernel on the same
+    minibatch: the per-sample diagnostics (log-prob, ratio, surrogates) and every branch / head gradient carry the SAME
+    bits (same MFMA chains and reduction trees per element); the first-layer gradient -- whose two branch parts are now
+    added by the slab reduction instead of in LDS -- and the loss sums agree to fp32 / fp64 re-association."""
+    from xuance_amd import ops
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    res = []
+    for split in (False, True):
+        torch.manual_seed(0)
+        agent = PPO_Agent(make_config(n, T, n_epochs=1, n_minibatch=nmb, activation=act, use_role_split_update=split),
+                          DeviceCartPoleVecEnv(n, seed=2))
+        agent.rollout()
+        agent._new_indices()
+        mem, lr = agent.memory, agent.learner
+        bs = agent.batch_size
+        lr.prepare_buffer_update(mem, bs)
+        lr.prepare_fused(mem, bs)
+        assert lr.split == split
+        lr.refresh_fused_params(mem, agent.idx)
+        ops.adv_stats(mem.soa.fields["advantages"], agent.idx.view(-1), bs, agent.idx.shape[0], n, T, lr.stats)
+        k = agent.idx.shape[0] - 1
+        lr.enqueue_minibatch_fused(mem, agent.idx[k], lr.stats[k], finish=False)
+        torch.cuda.synchronize()
+        res.append(dict(grad=npy(lr.optimizer.grad), info=lr.last_info(bs), diag=npy(lr.diag.view(-1)[:4 * bs]),
+                        off=dict(lr.model.params.offsets)))
+    a, b = res
+    assert np.array_equal(a["diag"], b["diag"])
+    first = slice(0, 640)                                             # representation.model.0.{weight,bias}
+    assert np.array_equal(a["grad"][640:], b["grad"][640:]), "branch / head gradients"
+    scale = float(np.abs(a["grad"][first]).max())
+    assert scale > 0 and np.abs(b["grad"][first]).max() > 0
+    assert_close(b["grad"][first] / scale, a["grad"][first] / scale, 1e-6, "first-layer gradient")
+    for key in a["info"]:
+        assert_close(b["info"][key], a["info"][key], 1e-12 if key != "learning_rate" else 0, key)
 
 
 def test_fused_reduce_adam_is_bit_identical_to_the_two_launches():

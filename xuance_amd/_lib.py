@@ -182,12 +182,13 @@ class PpoFused(C.Structure):
                 ("f_obs", c_void_p), ("f_act", c_void_p), ("f_ret", c_void_p), ("f_adv", c_void_p), ("f_logp", c_void_p),
                 ("idx", c_void_p), ("stats", c_void_p), ("slabs", c_void_p), ("partials", c_void_p), ("diag", c_void_p),
                 ("slab_stride", c_int64), ("M", c_int32), ("n_envs", c_int32), ("T", c_int32), ("D", c_int32),
-                ("A", c_int32), ("pad1", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
+                ("A", c_int32), ("l0_fold_off", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
                 ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p)]
 
 
 class Mirrors(C.Structure):
-    _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("target_every", c_int32), ("target", c_void_p)]
+    _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("target_every", c_int32), ("target", c_void_p),
+                ("fold_off", c_int64), ("fold_len", c_int32), ("pad", c_int32)]
 
 
 class MarlAct(C.Structure):
@@ -253,6 +254,7 @@ _SIGS = {
     "xrl_sum_partials": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrl_sum_partials_batched": [c_void_p, c_int, c_int, c_void_p, c_int, C.c_long, C.c_long, c_void_p],
     "xrl_grad_reduce": [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p],
+    "xrl_grad_reduce_fold": [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p],
     "xrl_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double, c_void_p],
     "xrl_adam_step_mirrored": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_double,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -17,6 +17,11 @@ ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=off"]
 
 
+def extra_flags():
+    """XRL_BUILD_DEFINES="-DXRL_TILE_PROBE": diagnostic builds (phase stamps in the fused kernels; use with --force)."""
+    return os.environ.get("XRL_BUILD_DEFINES", "").split()
+
+
 def hipcc():
     h = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     return h if os.path.exists(h) else "hipcc"
@@ -55,7 +60,7 @@ def build(force=False, verbose=True):
     todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
 
     def compile_one(src):
-        cmd = [hipcc(), *FLAGS, "-c", src, "-o", _obj(src)]
+        cmd = [hipcc(), *FLAGS, *extra_flags(), "-c", src, "-o", _obj(src)]
         if verbose:
             print("[xuance_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

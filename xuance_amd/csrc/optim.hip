@@ -11,10 +11,13 @@ constexpr int RED_THREADS = 256;
 
 // grad[p] = sum_s slabs[s][p]   (fixed order s = 0..S-1 -> deterministic);  block partial of sum grad^2 (fp64).
 // Each thread owns 4 consecutive parameters (one 16-byte load per slab) and keeps up to 8 slab loads in flight.
+// fold: slab columns [fold_off, fold_off + fold_len) hold a second partial of columns [0, fold_len) (the critic role's
+// first-layer gradient of ppo_split_kernel); they are added after the main columns, slab group by slab group, in the same
+// fixed order.  fold_len == 0: no fold.
 __global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* __restrict__ slabs, int n_split,
                                                                   int64_t slab_stride, int64_t P,
                                                                   float* __restrict__ grad,
-                                                                  double* __restrict__ sumsq_part) {
+                                                                  double* __restrict__ sumsq_part, int64_t fold_off, int fold_len) {
     __shared__ double scratch[16];
     double sq = 0.0;
     const bool vec = ((slab_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0) &&
@@ -42,6 +45,17 @@ __global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* _
                     for (int j = 0; j < 8; ++j) { g.x += v[j].x; g.y += v[j].y; g.z += v[j].z; g.w += v[j].w; }
                 }
                 for (; s < n_split; s += 4) { const float4 v = src[(int64_t)s * st4]; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+                if (i * 4 < fold_len) {
+                    const float4* src2 = src + fold_off / 4;
+                    for (s = sg; s + 28 < n_split; s += 32) {
+                        float4 v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = src2[(int64_t)(s + 4 * j) * st4];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { g.x += v[j].x; g.y += v[j].y; g.z += v[j].z; g.w += v[j].w; }
+                    }
+                    for (; s < n_split; s += 4) { const float4 v = src2[(int64_t)s * st4]; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+                }
             }
             gsum[sg][pq] = g;
             __syncthreads();
@@ -181,6 +195,17 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
                 for (int j = 0; j < 8; ++j) { g.x += w[j].x; g.y += w[j].y; g.z += w[j].z; g.w += w[j].w; }
             }
             for (; s < n_split; s += 4) { const float4 w = src[(int64_t)s * st4]; g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w; }
+            if (qi * 4 < mir.fold_len) {                            // (same statements as grad_reduce_kernel's fold)
+                const float4* src2 = src + mir.fold_off / 4;
+                for (s = sg; s + 28 < n_split; s += 32) {
+                    float4 w[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = src2[(int64_t)(s + 4 * j) * st4];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { g.x += w[j].x; g.y += w[j].y; g.z += w[j].z; g.w += w[j].w; }
+                }
+                for (; s < n_split; s += 4) { const float4 w = src2[(int64_t)s * st4]; g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w; }
+            }
         }
         gsum[grp][sg][pq] = g;
         __syncthreads();
@@ -287,6 +312,8 @@ extern "C" int xrl_reduce_adam(const float* slabs, int n_split, int64_t slab_str
     if (mirrors) mir = *mirrors;
     XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);
     for (int q = 0; q < mir.n; ++q) XRL_CHECK_ARG(mir.map[q] && mir.dst[q]);
+    XRL_CHECK_ARG(mir.fold_len >= 0 && (mir.fold_len & 3) == 0 && (mir.fold_off & 3) == 0 &&
+                  (mir.fold_len == 0 || (mir.fold_off >= P && mir.fold_off + mir.fold_len <= slab_stride && mir.fold_len <= P)));
     hipLaunchKernelGGL(reduce_adam_kernel, dim3(nb), dim3(RA_THREADS), 0, as_stream(stream), slabs, n_split, slab_stride, params,
                        grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync);
     XRL_CHECK_LAUNCH();
@@ -297,7 +324,19 @@ extern "C" int xrl_grad_reduce(const float* slabs, int n_split, int64_t slab_str
                                double* sumsq_part, int n_part, xrl_stream_t stream) {
     XRL_CHECK_ARG(slabs && grad && sumsq_part && n_split >= 1 && P > 0 && n_part >= 1 && n_part <= 1024);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_part), dim3(RED_THREADS), 0, as_stream(stream), slabs, n_split,
-                       slab_stride, P, grad, sumsq_part);
+                       slab_stride, P, grad, sumsq_part, (int64_t)0, 0);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_grad_reduce_fold(const float* slabs, int n_split, int64_t slab_stride, int64_t P, float* grad,
+                                    double* sumsq_part, int n_part, int64_t fold_off, int fold_len, xrl_stream_t stream) {
+    XRL_CHECK_ARG(slabs && grad && sumsq_part && n_split >= 1 && P > 0 && n_part >= 1 && n_part <= 1024);
+    XRL_CHECK_ARG((slab_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0);
+    XRL_CHECK_ARG(fold_len >= 0 && (fold_len & 3) == 0 && (fold_off & 3) == 0 &&
+                  (fold_len == 0 || (fold_off >= P && fold_off + fold_len <= slab_stride && fold_len <= P)));
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(n_part), dim3(RED_THREADS), 0, as_stream(stream), slabs, n_split,
+                       slab_stride, P, grad, sumsq_part, fold_off, fold_len);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

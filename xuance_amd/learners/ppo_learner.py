@@ -168,14 +168,35 @@ class PPO_Learner(Learner):
         floats = sum(2 * 32 * ld(w) for w in plan.widths[1:]) + 8 * 32 * 33 + ops.rollout_cache_floats(plan) + 64
         return floats * 4 <= 150 * 1024 and tuple(memory.act_shape) == ()
 
+    L0_FOLD = 640        # first-layer weights (128 x 4) + bias of the 4-128-{128-2,128-1} network
+
+    def split_eligible(self, n_tiles):
+        """Role-split minibatch kernel (csrc/ppo_split.hip: two workgroups per 32-row tile, one per branch): the
+        4-128-{128-2,128-1} class with the first layer at the front of the flat layout.  config.use_role_split_update:
+        "auto" (default) = for minibatches of at most 32 tiles, where the split puts a small minibatch on twice as many CUs
+        (measured: 16 tiles 29.8 vs 34.1 us per minibatch; 256 tiles 51.1 vs 47.0 us -- see the kernel's header);
+        True / False force it on / off."""
+        m, plan = self.model, self.model.plan
+        want = getattr(self.config, "use_role_split_update", "auto")
+        want = (n_tiles <= 32) if want == "auto" else bool(want)
+        return want and list(plan.widths) == [4, 128, 256, 3] and \
+            m.dist == "categorical" and m.params.offsets.get("representation.model.0.weight", -1) == 0 and \
+            m.params.offsets.get("representation.model.0.bias", -1) == 512 and ops.fast_kernels_enabled()
+
     def prepare_fused(self, memory, bs):
         if getattr(self, "_fused_bs", 0) == bs:
             return
         dev, P = self.model.params.device, self.model.params.P
         self._ensure(bs)
         self.n_tiles = (bs + 31) // 32
-        self.fslabs = torch.zeros(self.n_tiles, P, device=dev)
-        self.fpartials = torch.zeros(self.n_tiles, 8, dtype=torch.float64, device=dev)
+        self.split = self.split_eligible(self.n_tiles)
+        # gradient slabs: one per tile; with the role-split kernel a fold region behind the parameters takes the critic
+        # role's first-layer gradient, and every (tile, role) workgroup has its own row of loss partials
+        self.slab_stride = P + (self.L0_FOLD if self.split else 0)
+        self.fold = (P, self.L0_FOLD) if self.split else None
+        self.n_part_rows = self.n_tiles * (2 if self.split else 1)
+        self.fslabs = torch.zeros(self.n_tiles, self.slab_stride, device=dev)
+        self.fpartials = torch.zeros(self.n_part_rows, 8, dtype=torch.float64, device=dev)
         self.params_t = torch.zeros(P, device=dev)
         self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
         self.stats = torch.zeros(4096, 2, device=dev)
@@ -221,6 +242,7 @@ class PPO_Learner(Learner):
         """One launch for gather + forward + loss + backward, then reduce + Adam, then refresh the derived layouts."""
         m, opt, f = self.model, self.optimizer, memory.soa.fields
         M = idx.numel()
+        fold = self.fold if (self.split and ops.fast_kernels_enabled()) else None     # (tests switch the specialised kernels off)
         rows = None
         base = getattr(self, "_rows_idx", None)
         if base is not None:                               # `idx` is a row of the index matrix the records were gathered for
@@ -232,17 +254,19 @@ class PPO_Learner(Learner):
                                 f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs, frag_image=self.frag,
                                 f_packed=self.packed if getattr(self, "_packed_valid", False) else None, f_rows=rows,
                                 partials=self.fpartials, diag=self.diag if self.keep_diag else None,
-                                slab_stride=m.params.P, M=M, n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim,
+                                slab_stride=self.slab_stride, l0_fold_off=fold[0] if fold else 0, M=M,
+                                n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim,
                                 clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
-        self._last_S, self._last_partials = self.n_tiles, self.fpartials
+        n_t = (M + 31) // 32
+        self._last_S, self._last_partials = n_t * (2 if fold else 1), self.fpartials
         dist = self.distributed_training and self.world_size > 1
         if finish and not dist and m.params.P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
             # slab reduction + clip + Adam + derived layouts in ONE launch (xrl_reduce_adam)
             clip = self.grad_clip_norm if self.use_grad_clip else 0.0
-            ops.reduce_adam(self.fslabs, self.n_tiles, m.params.P, m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state,
-                            self.sumsq, clip, self._mirrors, self.opt_sync)
+            ops.reduce_adam(self.fslabs, n_t, self.slab_stride, m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state,
+                            self.sumsq, clip, self._mirrors, self.opt_sync, fold=fold)
             return
-        ops.grad_reduce(self.fslabs, self.n_tiles, m.params.P, m.params.P, opt.grad, self.sumsq)
+        ops.grad_reduce(self.fslabs, n_t, self.slab_stride, m.params.P, opt.grad, self.sumsq, fold=fold)
         if finish:
             if dist:
                 self.allreduce_grad()

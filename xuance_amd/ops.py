@@ -149,7 +149,12 @@ def write_adam_state(t, st):
     t.copy_(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
 
 
-def grad_reduce(slabs, n_split, slab_stride, P, grad, sumsq_part):
+def grad_reduce(slabs, n_split, slab_stride, P, grad, sumsq_part, fold=None):
+    """fold = (fold_off, fold_len): slab columns [fold_off, fold_off + fold_len) are added onto columns [0, fold_len)."""
+    if fold:
+        call("xrl_grad_reduce_fold", ptr(slabs), int(n_split), int(slab_stride), int(P), ptr(grad), ptr(sumsq_part),
+             sumsq_part.numel(), int(fold[0]), int(fold[1]), stream_ptr())
+        return
     call("xrl_grad_reduce", ptr(slabs), int(n_split), int(slab_stride), int(P), ptr(grad), ptr(sumsq_part),
          sumsq_part.numel(), stream_ptr())
 
@@ -176,7 +181,7 @@ def adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, max_norm, mirror
 
 
 def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, max_norm, mirrors, sync, target=None,
-                target_every=0):
+                target_every=0, fold=None):
     """grad_reduce + clip + Adam + mirrors (+ the periodic hard target update) in one launch (blocks meet at a counter
     barrier); same numbers."""
     mir = Mirrors()
@@ -185,6 +190,8 @@ def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq
         mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
     if target is not None and target_every > 0:
         mir.target, mir.target_every = target.data_ptr(), int(target_every)
+    if fold:
+        mir.fold_off, mir.fold_len = int(fold[0]), int(fold[1])
     call("xrl_reduce_adam", ptr(slabs), int(n_split), int(slab_stride), ptr(params), ptr(grad), ptr(m), ptr(v), int(P),
          ptr(state), ptr(sumsq_part), sumsq_part.numel(), float(max_norm if max_norm else 0.0), C.byref(mir), ptr(sync),
          stream_ptr())
