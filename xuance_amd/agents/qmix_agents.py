@@ -120,7 +120,21 @@ class QMIX_Agents(AgentSurface):
         if totals is not None:
             self._totals_h.copy_(totals)
             seen = self._totals_h.clone()
+        graph_steps = self.use_graph_updates and two_buf and totals is not None and hasattr(env, "enqueue_step")
         while episodes < n_episodes:
+            if graph_steps:
+                # the whole vector step (acting forward incl. the recurrence, action selection, provider step, staging store,
+                # episode close, reset flags, RNG counters) as ONE graph launch -- one graph per observation-buffer set; the
+                # host only flips its buffer bookkeeping and makes the step's one read (the loop condition needs it)
+                self._step_graph(env._cur).launch()
+                env.flip()
+                self._host_step += 1
+                self._totals_h.copy_(totals)
+                episodes += int(self._totals_h[0] - seen[0])
+                self.current_step += int(self._totals_h[1] - seen[1])
+                seen.copy_(self._totals_h)
+                self._update_explore_factor()
+                continue
             if two_buf:
                 obs, state, avail = env.buf_obs, env.buf_state, env.buf_avail
             else:
@@ -149,6 +163,39 @@ class QMIX_Agents(AgentSurface):
                 episodes += int(self._counts_h[0])
                 self.current_step += int(self._counts_h[1])
             self._update_explore_factor()
+
+    def _step_graph(self, cur):
+        """Captured vector step of run_episodes acting on the provider's buffer set `cur` (same launches, same order and
+        same Philox step indices as the eager loop: the indices come from device counters that start at the host's values)."""
+        if not hasattr(self, "_step_graphs"):
+            self._step_graphs = {}
+            self._rng_dev = torch.zeros(2, dtype=torch.int32, device=self.device)      # [agent step, provider step]
+        g = self._step_graphs.get(cur)
+        if g is not None:
+            return g
+        env, n, N, A, mem = self.envs, self.n_envs, self.n_agents, self.n_actions, self.memory
+        R = n * N
+        if not self._step_graphs:                                                     # first capture: counters take over here
+            self._rng_dev.copy_(torch.tensor([self._host_step, env._host_step], dtype=torch.int32))
+        self.model.seq_workspace(2, R, 1)                                             # (no allocation inside the capture)
+        obs, state, avail = env._sets[cur]
+        torch.cuda.synchronize()
+        g = ops.Graph()
+        with g:
+            q = self.model.agent_forward_seq(obs.view(R, -1), R, 1, which=2, h0=self.rnn_h, reset=self.reset_rows,
+                                             h_last=self.rnn_h, c0=self.rnn_c, c_last=self.rnn_c)
+            ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
+                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,
+                                    step_dev=self._rng_dev[0:1])
+            env.enqueue_step(cur, counter=self._rng_dev[1:2])
+            mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
+                      avail_actions=avail, state=state, episode_steps=env.prev_steps)
+            mem.finish_paths(env.done, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail)
+            torch.mul(env.done[:, None].expand(n, N), 1.0, out=self.reset_rows.view(n, N))   # (a kernel, not a memcpy node)
+            ops.counter_add(self._rng_dev[0:1], 1)
+            ops.counter_add(self._rng_dev[1:2], 1)
+        self._step_graphs[cur] = g
+        return g
 
     def _train_rnn(self, train_steps):                         # off_policy_marl.py:335-349
         info, start = {}, self.current_step

@@ -180,10 +180,22 @@ class SyntheticSMACVecEnv(_Base):
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
     def step_device(self):
+        self.enqueue_step(self._cur)
+        self.flip()
+
+    # -- the two halves of step_device, for callers that capture a vector step into a hipGraph (one graph per buffer set):
+    #    enqueue_step(cur) launches the kernel that acts on buffer set `cur` and writes set `cur ^ 1`; with counter != None
+    #    the Philox step index comes from that device counter (the caller advances it inside the graph) instead of the
+    #    host's `_host_step`.  flip() is the host bookkeeping of one step (rebinding buf_*; no launch).
+    def enqueue_step(self, cur, counter=None):
         from .. import ops
-        acted_state = self.buf_state
+        new = self._sets[cur ^ 1]
+        kw = self._kw(new, prev_state=self._sets[cur][1])
+        if counter is not None:
+            kw.update(step=0, step_dev=counter)
+        ops.synth_marl_step(**kw)
+
+    def flip(self):
         self._cur ^= 1
-        new = self._sets[self._cur]
-        ops.synth_marl_step(**self._kw(new, prev_state=acted_state))
-        self.buf_obs, self.buf_state, self.buf_avail = new
+        self.buf_obs, self.buf_state, self.buf_avail = self._sets[self._cur]
         self._host_step += 1
