@@ -27,13 +27,15 @@ __global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* _
         // (8 independent 16-byte loads in flight), the 4 group sums are combined through LDS in group order.  The slab
         // order inside a group is fixed, so the result is deterministic (it differs from a purely sequential s = 0..S-1
         // sum only by fp32 re-association).
-        __shared__ float4 gsum[4][64];
+        __shared__ double gsum[4][64][4];
         const int64_t P4 = P / 4;
         const int64_t st4 = slab_stride / 4;
         const int pq = threadIdx.x & 63, sg = threadIdx.x >> 6;
         for (int64_t base = (int64_t)blockIdx.x * 64; base < P4; base += (int64_t)gridDim.x * 64) {
             const int64_t i = base + pq;
-            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            // float64 accumulators: the 256 per-workgroup partials of a parameter cancel heavily (policy-gradient terms sum to a
+            // small total), and Adam turns a relative gradient error straight into a relative step error
+            double gx = 0.0, gy = 0.0, gz = 0.0, gw = 0.0;
             if (i < P4) {
                 const float4* src = reinterpret_cast<const float4*>(slabs) + i;
                 int s = sg;
@@ -42,9 +44,9 @@ __global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* _
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(s + 4 * j) * st4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { g.x += v[j].x; g.y += v[j].y; g.z += v[j].z; g.w += v[j].w; }
+                    for (int j = 0; j < 8; ++j) { gx += v[j].x; gy += v[j].y; gz += v[j].z; gw += v[j].w; }
                 }
-                for (; s < n_split; s += 4) { const float4 v = src[(int64_t)s * st4]; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+                for (; s < n_split; s += 4) { const float4 v = src[(int64_t)s * st4]; gx += v.x; gy += v.y; gz += v.z; gw += v.w; }
                 if (i * 4 < fold_len) {
                     const float4* src2 = src + fold_off / 4;
                     for (s = sg; s + 28 < n_split; s += 32) {
@@ -52,32 +54,35 @@ __global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* _
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = src2[(int64_t)(s + 4 * j) * st4];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) { g.x += v[j].x; g.y += v[j].y; g.z += v[j].z; g.w += v[j].w; }
+                        for (int j = 0; j < 8; ++j) { gx += v[j].x; gy += v[j].y; gz += v[j].z; gw += v[j].w; }
                     }
-                    for (; s < n_split; s += 4) { const float4 v = src2[(int64_t)s * st4]; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+                    for (; s < n_split; s += 4) { const float4 v = src2[(int64_t)s * st4]; gx += v.x; gy += v.y; gz += v.z; gw += v.w; }
                 }
             }
-            gsum[sg][pq] = g;
+            gsum[sg][pq][0] = gx; gsum[sg][pq][1] = gy; gsum[sg][pq][2] = gz; gsum[sg][pq][3] = gw;
             __syncthreads();
             if (sg == 0 && i < P4) {
-                float4 t = gsum[0][pq];
+                double t0 = gsum[0][pq][0], t1 = gsum[0][pq][1], t2 = gsum[0][pq][2], t3 = gsum[0][pq][3];
 #pragma unroll
-                for (int k = 1; k < 4; ++k) { const float4 u = gsum[k][pq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+                for (int k = 1; k < 4; ++k) { t0 += gsum[k][pq][0]; t1 += gsum[k][pq][1]; t2 += gsum[k][pq][2]; t3 += gsum[k][pq][3]; }
+                const float4 t = make_float4((float)t0, (float)t1, (float)t2, (float)t3);       // rounded once
                 reinterpret_cast<float4*>(grad)[i] = t;
                 sq += (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
             }
             __syncthreads();
         }
         for (int64_t i = P4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-            float g = 0.f;
-            for (int s = 0; s < n_split; ++s) g += slabs[(size_t)s * slab_stride + i];
+            double gd = 0.0;
+            for (int s = 0; s < n_split; ++s) gd += slabs[(size_t)s * slab_stride + i];
+            const float g = (float)gd;
             grad[i] = g;
             sq += (double)g * (double)g;
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-            float g = 0.f;
-            for (int s = 0; s < n_split; ++s) g += slabs[(size_t)s * slab_stride + i];
+            double gd = 0.0;
+            for (int s = 0; s < n_split; ++s) gd += slabs[(size_t)s * slab_stride + i];
+            const float g = (float)gd;
             grad[i] = g;
             sq += (double)g * (double)g;
         }
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     // the number of barrier participants (device-scope atomics) small.
     __shared__ double scratch[16];
     __shared__ double gscratch[RA_GROUPS][4];
-    __shared__ float4 gsum[RA_GROUPS][4][64];
+    __shared__ double gsum[RA_GROUPS][4][64][4];
     __shared__ float gtot[RA_GROUPS][256];
     __shared__ int s_fail;
     const int grp = threadIdx.x >> 8, tg = threadIdx.x & 255;
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     // ---- phase 1: exactly grad_reduce_kernel's vector path for this group's 64 quads
     double sq = 0.0;
     {
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        double gx = 0.0, gy = 0.0, gz = 0.0, gw = 0.0;                   // (same statements as grad_reduce_kernel)
         if (qi < P4) {
             const float4* src = reinterpret_cast<const float4*>(slabs) + qi;
             int s = sg;
@@ -192,29 +197,30 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
 #pragma unroll
                 for (int j = 0; j < 8; ++j) w[j] = src[(int64_t)(s + 4 * j) * st4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { g.x += w[j].x; g.y += w[j].y; g.z += w[j].z; g.w += w[j].w; }
+                for (int j = 0; j < 8; ++j) { gx += w[j].x; gy += w[j].y; gz += w[j].z; gw += w[j].w; }
             }
-            for (; s < n_split; s += 4) { const float4 w = src[(int64_t)s * st4]; g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w; }
-            if (qi * 4 < mir.fold_len) {                            // (same statements as grad_reduce_kernel's fold)
+            for (; s < n_split; s += 4) { const float4 w = src[(int64_t)s * st4]; gx += w.x; gy += w.y; gz += w.z; gw += w.w; }
+            if (qi * 4 < mir.fold_len) {
                 const float4* src2 = src + mir.fold_off / 4;
                 for (s = sg; s + 28 < n_split; s += 32) {
                     float4 w[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) w[j] = src2[(int64_t)(s + 4 * j) * st4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { g.x += w[j].x; g.y += w[j].y; g.z += w[j].z; g.w += w[j].w; }
+                    for (int j = 0; j < 8; ++j) { gx += w[j].x; gy += w[j].y; gz += w[j].z; gw += w[j].w; }
                 }
-                for (; s < n_split; s += 4) { const float4 w = src2[(int64_t)s * st4]; g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w; }
+                for (; s < n_split; s += 4) { const float4 w = src2[(int64_t)s * st4]; gx += w.x; gy += w.y; gz += w.z; gw += w.w; }
             }
         }
-        gsum[grp][sg][pq] = g;
+        gsum[grp][sg][pq][0] = gx; gsum[grp][sg][pq][1] = gy; gsum[grp][sg][pq][2] = gz; gsum[grp][sg][pq][3] = gw;
         __syncthreads();
         if (sg == 0) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (qi < P4) {
-                t = gsum[grp][0][pq];
+                double t0 = gsum[grp][0][pq][0], t1 = gsum[grp][0][pq][1], t2 = gsum[grp][0][pq][2], t3 = gsum[grp][0][pq][3];
 #pragma unroll
-                for (int k = 1; k < 4; ++k) { const float4 u = gsum[grp][k][pq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+                for (int k = 1; k < 4; ++k) { t0 += gsum[grp][k][pq][0]; t1 += gsum[grp][k][pq][1]; t2 += gsum[grp][k][pq][2]; t3 += gsum[grp][k][pq][3]; }
+                t = make_float4((float)t0, (float)t1, (float)t2, (float)t3);
                 sq += (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
             }
             *reinterpret_cast<float4*>(&gtot[grp][pq * 4]) = t;
