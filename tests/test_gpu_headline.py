@@ -172,7 +172,12 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
             b = dict(obs=s["obs"], actions=s["actions"], returns=s["returns"], advantages=s["advantages"],
                      old_logp=s["aux_batch"]["old_logp"])
             oinfo, _ = oracle.ppo_update(sd, opt, b, cfg)
-            oracle.ppo_update(sd64, opt64, {k_: np.asarray(v_, np.float64) for k_, v_ in b.items()}, cfg)
+            # float64 chain: same float32 buffer contents, every operation from the advantage normalisation on in float64
+            b64 = {k_: np.asarray(v_, np.float64) for k_, v_ in b.items()}
+            env_i, t_i = np.divmod(idx[k], T)
+            a64 = buf.advantages[env_i, t_i].astype(np.float64)
+            b64["advantages"] = (a64 - a64.mean()) / (a64.std() + 1e-8)                     # memory_tools.py:281-282
+            oracle.ppo_update(sd64, opt64, b64, cfg)
         for key, ok in (("actor_loss", "a_loss"), ("critic_loss", "c_loss"), ("entropy", "e_loss"),
                         ("predict_value", "predict_value")):
             assert_close(info[key], oinfo[ok], 1e-5, f"{key} (pass {it})")
