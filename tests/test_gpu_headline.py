@@ -167,6 +167,14 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
         assert idx.shape == (64, n * T // 8)
         for e in range(8):                                             # every epoch is a permutation of the buffer
             assert np.array_equal(np.sort(idx[8 * e:8 * e + 8].reshape(-1)), np.arange(n * T))
+        # The update chain consumes the DEVICE's buffer (every field of it was just compared with the oracle's own chain;
+        # GAE bit for bit): differences of 1e-6 in returns / advantages between two float32 rollouts would otherwise be
+        # amplified by Adam into parameter differences that say nothing about the update arithmetic.
+        dbuf = oracle.OnPolicyBufferOracle((4,), (), n, T)
+        dbuf.size = T
+        dbuf.observations, dbuf.actions = f["observations"].transpose(1, 0, 2), f["actions"].T
+        dbuf.returns, dbuf.values, dbuf.advantages, dbuf.old_logp = f["returns"].T, f["values"].T, f["advantages"].T, f["aux_old_logp"].T
+        buf = dbuf
         for k in range(idx.shape[0]):
             s = buf.sample(idx[k])
             b = dict(obs=s["obs"], actions=s["actions"], returns=s["returns"], advantages=s["advantages"],
