@@ -138,6 +138,17 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
     knife_total, bounds = 0, {}
     for it in range(2):                                               # second pass: replayed graphs, carried statistics
         sd_dev = {k: npy(v) for k, v in agent.model.state_dict().items()}
+        if it > 0:
+            # every pass starts the oracle chains (float32 and float64) from the device's state -- parameters and Adam
+            # moments: the drift of 64 chained steps is judged per pass (below), it must not leak into the next pass's
+            # per-minibatch loss comparison
+            osd = agent.learner.optimizer.state_dict()
+            for i, k_ in enumerate(agent.model.ref_order):
+                for chain, o_, dt in ((sd, opt, np.float32), (sd64, opt64, np.float64)):
+                    chain[k_][...] = sd_dev[k_].astype(dt)
+                    o_.m[k_][...] = osd["state"][i]["exp_avg"].cpu().numpy().astype(dt)
+                    o_.v[k_][...] = osd["state"][i]["exp_avg_sq"].cpu().numpy().astype(dt)
+            opt.t = opt64.t = opt.sched_steps = opt64.sched_steps = int(agent.learner.optimizer.read().step)
         agent.rollout()
         torch.cuda.synchronize()
         # the path bench.py times: ONE persistent launch for the whole rollout, no time-out, exchange inside one L2
