@@ -671,6 +671,28 @@ typedef struct {
     int32_t flags;         /* xrl_episode_finish: bit0 = zero the staging row after the copy (the `filled` field) */
     int32_t pad;
 } xrl_episode_field_t;
+/* Device-side loop control of run_episodes (off_policy_marl.py:464-546) for callers that enqueue vector steps ahead of the
+ * host's knowledge of their outcome; launch once at the end of every (captured) vector step -- see csrc/episodes.hip. */
+typedef struct {
+    const int64_t* totals;     /* [2] the provider's running totals: episodes finished, env steps in them */
+    const int64_t* base;       /* [2] the totals when the call began */
+    const int64_t* call;       /* [2] the agent's current_step when the call began, n_episodes of the call */
+    int64_t* snap;             /* [2] out: (episodes, env steps) of this call as of the last step that counted */
+    int32_t* active;           /* [1] in: the step that just ran counted; out: the next one will (host sets 1 per call) */
+    double* e_state;           /* [1] in/out: the agent's e_greedy (double, as the host keeps it) */
+    float* eps_dev;            /* [1] out: e_greedy as the action-selection kernels read it */
+    float* active_f;           /* [1] out: 1.0f / 0.0f -- multiply `done` with it before xrl_episode_finish */
+    int32_t* active_i;         /* [2] out: 1 / 0 twice -- add to the two RNG step counters */
+    int32_t* host_flags;       /* [ring] or NULL: device pointer of pinned host memory (xrl_host_device_pointer); launch k of a
+                                * call writes its `active` output to host_flags[k % ring] with system scope */
+    int32_t* seq;              /* [1] in/out: launches of this call so far (the host sets 0 per call); NULL iff host_flags NULL */
+    double start_greedy, end_greedy, delta_greedy;
+    int32_t ring, pad;
+} xrl_marl_gate_t;
+/* Device address of page-locked host memory (hipHostMalloc / torch pin_memory), for kernels that publish a word to the host. */
+int xrl_host_device_pointer(void* pinned_host, void** device_out);
+int xrl_marl_loop_gate(const xrl_marl_gate_t* gate, xrl_stream_t stream);
+
 /* store (:904-921): a = staging [n_envs][slots][row], b = step data [n_envs][row]: staging[env][steps[env]] <- b[env]
  * (`filled` is a field whose step data is ones). */
 int xrl_episode_store_step(const xrl_episode_field_t* fields, int n_fields, const int32_t* steps, int n_envs,

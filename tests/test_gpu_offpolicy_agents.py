@@ -537,26 +537,32 @@ def test_runner_surface_of_the_dqn_and_qmix_agents(tmp_path):
     assert "Test-Results/Episode-Rewards" in m2.logged[-1][1]
 
 
-def test_captured_vector_step_equals_the_eager_episode_loop():
+@pytest.mark.parametrize("lag", [0, 1, 3])
+def test_captured_vector_step_equals_the_eager_episode_loop(lag):
     """run_episodes of the recurrent QMIX agents with the vector step captured as one hipGraph per observation-buffer set
     (use_hip_graph) vs the eager launch sequence: the same Philox step indices (device counters that start at the host's
-    values), hence the same actions, episodes, ring contents, GRU state, exploration schedule and step accounting."""
+    values), hence the same actions, episodes, ring contents, exploration schedule and step accounting -- also when the
+    host enqueues `lag` steps ahead of its knowledge of the loop condition (the dry steps after the call's last episode
+    change nothing a later call or an update can see; the GRU state and the episode staging they touch are re-zeroed by the
+    next call, so those two are compared at lag 0 only)."""
     from xuance_amd.agents import QMIX_Agents
     from xuance_amd.envs import SyntheticSMACVecEnv
     res = []
     for graph in (False, True):
         torch.manual_seed(0)
         agent = QMIX_Agents(_rnn_cfg(use_hip_graph=graph, start_training=10 ** 9, start_greedy=0.6, end_greedy=0.05,
-                                     decay_step_greedy=400),
+                                     decay_step_greedy=400, episode_loop_lag=lag),
                             SyntheticSMACVecEnv(8, seed=3, max_episode_steps=12, p_term=0.05))
         for _ in range(3):
             agent.run_episodes(8)
         torch.cuda.synchronize()
         assert (getattr(agent, "_step_graphs", None) is not None and len(agent._step_graphs) == 2) == graph
         mem = agent.memory
-        res.append(dict(ptr_size=mem.ptr_size.cpu().numpy(), h=agent.rnn_h.cpu().numpy(), step=np.array([agent.current_step, agent._host_step]),
-                        eps=np.array([agent.e_greedy]), **{k: v.cpu().numpy() for k, v in mem.data.items()},
-                        **{"ep_" + k: v.cpu().numpy() for k, v in mem.episode_data.items()}))
+        res.append(dict(ptr_size=mem.ptr_size.cpu().numpy(), step=np.array([agent.current_step, agent._host_step, agent.envs._host_step]),
+                        eps=np.array([agent.e_greedy]), eps_dev=agent.eps_dev.cpu().numpy(),
+                        **({"h": agent.rnn_h.cpu().numpy()} if lag == 0 else {}),
+                        **{k: v.cpu().numpy() for k, v in mem.data.items()},
+                        **({"ep_" + k: v.cpu().numpy() for k, v in mem.episode_data.items()} if lag == 0 else {})))
     a, b = res
     assert a["ptr_size"][1] >= 24 and a["step"][0] > 0
     for k in a:

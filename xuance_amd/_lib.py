@@ -186,6 +186,14 @@ class PpoFused(C.Structure):
                 ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p)]
 
 
+class MarlGate(C.Structure):
+    _fields_ = [("totals", c_void_p), ("base", c_void_p), ("call", c_void_p), ("snap", c_void_p), ("active", c_void_p),
+                ("e_state", c_void_p), ("eps_dev", c_void_p), ("active_f", c_void_p), ("active_i", c_void_p),
+                ("host_flags", c_void_p), ("seq", c_void_p),
+                ("start_greedy", C.c_double), ("end_greedy", C.c_double), ("delta_greedy", C.c_double),
+                ("ring", c_int32), ("pad", c_int32)]
+
+
 class Mirrors(C.Structure):
     _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("target_every", c_int32), ("target", c_void_p),
                 ("fold_off", c_int64), ("fold_len", c_int32), ("pad", c_int32)]
@@ -213,6 +221,8 @@ _SIGS = {
     "xrl_episode_store_step": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_episode_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_episode_gather": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
+    "xrl_marl_loop_gate": [C.POINTER(MarlGate), c_void_p],
+    "xrl_host_device_pointer": [c_void_p, C.POINTER(c_void_p)],
     "xrl_per_store": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_void_p],
     "xrl_per_sample": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                        c_void_p, c_void_p],

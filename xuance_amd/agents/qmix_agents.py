@@ -57,6 +57,7 @@ class QMIX_Agents(AgentSurface):
         dev, R = self.device, self.n_envs * self.n_agents
         self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
         self._host_step = 0
+        self.episode_loop_lag = max(0, int(getattr(config, "episode_loop_lag", 1)))   # steps enqueued ahead of the host
         self.act_f = torch.zeros(self.n_envs, self.n_agents, device=dev)
         if self.use_rnn:
             self.rnn_h = torch.zeros(R, self.model.RH, device=dev)           # init_rnn_states (value_factorization.py:151-159)
@@ -117,24 +118,12 @@ class QMIX_Agents(AgentSurface):
         # an env that alternates its observation buffers and keeps running episode totals saves the copies and the
         # reductions of a step (envs/synthetic.py); any other env goes through clones and two small sums
         two_buf, totals = getattr(env, "double_buffered", False), getattr(env, "episode_totals", None)
+        if self.use_graph_updates and two_buf and totals is not None and hasattr(env, "enqueue_step"):
+            return self._run_episodes_captured(n_episodes, totals)
         if totals is not None:
             self._totals_h.copy_(totals)
             seen = self._totals_h.clone()
-        graph_steps = self.use_graph_updates and two_buf and totals is not None and hasattr(env, "enqueue_step")
         while episodes < n_episodes:
-            if graph_steps:
-                # the whole vector step (acting forward incl. the recurrence, action selection, provider step, staging store,
-                # episode close, reset flags, RNG counters) as ONE graph launch -- one graph per observation-buffer set; the
-                # host only flips its buffer bookkeeping and makes the step's one read (the loop condition needs it)
-                self._step_graph(env._cur).launch()
-                env.flip()
-                self._host_step += 1
-                self._totals_h.copy_(totals)
-                episodes += int(self._totals_h[0] - seen[0])
-                self.current_step += int(self._totals_h[1] - seen[1])
-                seen.copy_(self._totals_h)
-                self._update_explore_factor()
-                continue
             if two_buf:
                 obs, state, avail = env.buf_obs, env.buf_state, env.buf_avail
             else:
@@ -164,12 +153,58 @@ class QMIX_Agents(AgentSurface):
                 self.current_step += int(self._counts_h[1])
             self._update_explore_factor()
 
+    def _run_episodes_captured(self, n_episodes, totals):
+        """run_episodes with the whole vector step -- acting forward incl. the recurrence, action selection, provider step,
+        staging store, episode close, reset flags, RNG counters and the loop's own bookkeeping (marl_loop_gate: episodes
+        finished, current_step, the e-greedy schedule, `episodes < n_episodes`) -- as ONE graph launch per step, one graph
+        per observation-buffer set.  The host enqueues step s + `episode_loop_lag` before it reads whether step s + 1 still
+        belongs to the call (one 4-byte pinned read per step, never waited on while the device has work), so a call ends with
+        `episode_loop_lag` dry steps that change nothing the eager loop would see (csrc/episodes.hip)."""
+        env, lag = self.envs, self.episode_loop_lag
+        for c in (0, 1):
+            self._step_graph(c)
+        g, ring = self._gate, self._flag_h.numel()
+        g["base"].copy_(totals)
+        self._call_h[0], self._call_h[1] = self.current_step, n_episodes
+        g["call"].copy_(self._call_h, non_blocking=True)
+        g["e_state"].fill_(self.e_greedy)
+        g["active"].fill_(1); g["active_i"].fill_(1); g["active_f"].fill_(1.0); g["seq"].zero_()
+        launched, counted = 0, None
+        while counted is None:
+            self._step_graph(env._cur).launch()
+            self._flag_ev[launched % ring].record()
+            env.flip()
+            launched += 1
+            k = launched - 1 - lag                                         # the newest step whose outcome is read now
+            if k >= 0:
+                self._flag_ev[k % ring].synchronize()
+                if int(self._flag_h[k % ring]) == 0:                       # "step k + 1 is not part of the call"
+                    counted = k + 1
+        torch.cuda.current_stream().synchronize()
+        self._snap_h.copy_(g["snap"])
+        self._host_step += counted
+        env._host_step -= launched - counted                               # (flip() counted the dry steps too)
+        self.current_step += int(self._snap_h[1])
+        self.e_greedy = self._eps_on_device = float(g["e_state"].item())
+
     def _step_graph(self, cur):
         """Captured vector step of run_episodes acting on the provider's buffer set `cur` (same launches, same order and
         same Philox step indices as the eager loop: the indices come from device counters that start at the host's values)."""
         if not hasattr(self, "_step_graphs"):
+            dev = self.device
             self._step_graphs = {}
-            self._rng_dev = torch.zeros(2, dtype=torch.int32, device=self.device)      # [agent step, provider step]
+            self._rng_dev = torch.zeros(2, dtype=torch.int32, device=dev)              # [agent step, provider step]
+            self._gate = dict(base=torch.zeros(2, dtype=torch.int64, device=dev), call=torch.zeros(2, dtype=torch.int64, device=dev),
+                              snap=torch.zeros(2, dtype=torch.int64, device=dev), active=torch.ones(1, dtype=torch.int32, device=dev),
+                              e_state=torch.zeros(1, dtype=torch.float64, device=dev), active_f=torch.ones(1, device=dev),
+                              active_i=torch.ones(2, dtype=torch.int32, device=dev), seq=torch.zeros(1, dtype=torch.int32, device=dev))
+            self._done_gated = torch.zeros(self.n_envs, device=dev)
+            k = self.episode_loop_lag + 2                                             # ring of per-step flags in pinned memory
+            self._flag_h = torch.ones(k, dtype=torch.int32).pin_memory()
+            self._flag_ev = [torch.cuda.Event() for _ in range(k)]
+            self._snap_h = torch.zeros(2, dtype=torch.int64).pin_memory()
+            self._call_h = torch.zeros(2, dtype=torch.int64).pin_memory()
+            self._gate_const = dict(host_flags=ops.host_device_pointer(self._flag_h), ring=k)
         g = self._step_graphs.get(cur)
         if g is not None:
             return g
@@ -179,6 +214,7 @@ class QMIX_Agents(AgentSurface):
             self._rng_dev.copy_(torch.tensor([self._host_step, env._host_step], dtype=torch.int32))
         self.model.seq_workspace(2, R, 1)                                             # (no allocation inside the capture)
         obs, state, avail = env._sets[cur]
+        gt = self._gate
         torch.cuda.synchronize()
         g = ops.Graph()
         with g:
@@ -190,10 +226,12 @@ class QMIX_Agents(AgentSurface):
             env.enqueue_step(cur, counter=self._rng_dev[1:2])
             mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
                       avail_actions=avail, state=state, episode_steps=env.prev_steps)
-            mem.finish_paths(env.done, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail)
+            torch.mul(env.done, gt["active_f"], out=self._done_gated)                  # a dry step closes no episode
+            mem.finish_paths(self._done_gated, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail)
             torch.mul(env.done[:, None].expand(n, N), 1.0, out=self.reset_rows.view(n, N))   # (a kernel, not a memcpy node)
-            ops.counter_add(self._rng_dev[0:1], 1)
-            ops.counter_add(self._rng_dev[1:2], 1)
+            torch.add(self._rng_dev, gt["active_i"], out=self._rng_dev)
+            ops.marl_loop_gate(totals=env.episode_totals, start_greedy=float(self.start_greedy), end_greedy=float(self.end_greedy),
+                               delta_greedy=float(self.delta_egreedy), eps_dev=self.eps_dev, **self._gate_const, **gt)
         self._step_graphs[cur] = g
         return g
 

@@ -79,6 +79,36 @@ __global__ void __launch_bounds__(256) episode_gather_kernel(EpPack f, const int
     }
 }
 
+// Loop control of OffPolicyMARLAgents.run_episodes (off_policy_marl.py:464-546) kept on the device, so that the host may
+// enqueue vector step s + 1 before it has read the outcome of step s.  Launched at the END of every captured vector step: it
+// settles the step exactly as the host loop does after env.step -- episodes finished so far, `current_step += episode_step`
+// of the episodes that ended (:532), `_update_explore_factor()` (:197-204, incl. its one-call undershoot below end_greedy)
+// -- and decides whether the NEXT step still belongs to the call (`episodes < n_episodes`, :464).  A step launched after the
+// call is over is dry: the captured step multiplies `done` by active_f (no episode is closed into the ring) and adds
+// active_i to its RNG step counters (they do not advance); its other writes land in per-call state the next call resets.
+__global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int act = *g.active;                                                  // did the step that just ran count?
+    if (act) {
+        const long long ep = g.totals[0] - g.base[0], st = g.totals[1] - g.base[1];
+        g.snap[0] = ep; g.snap[1] = st;
+        double e = *g.e_state;
+        const double cur = (double)(g.call[0] + st);
+        e = (e > g.end_greedy) ? g.start_greedy - g.delta_greedy * cur : g.end_greedy;
+        *g.e_state = e;
+        *g.eps_dev = (float)e;
+        if (ep >= g.call[1]) act = 0;
+        *g.active = act;
+    }
+    *g.active_f = act ? 1.f : 0.f;
+    g.active_i[0] = act; g.active_i[1] = act;
+    if (g.host_flags) {                                                   // the host's copy: slot (launch index mod ring)
+        const int k = *g.seq;
+        *g.seq = k + 1;
+        __hip_atomic_store(g.host_flags + (k % g.ring), act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 static int pack(const xrl_episode_field_t* fields, int n, EpPack& p) {
     if (!fields || n <= 0 || n > EP_MAX_FIELDS) return XRL_EINVAL;
     p.n = n;
@@ -115,6 +145,22 @@ extern "C" int xrl_episode_finish(const xrl_episode_field_t* fields, int n_field
                        ptr_size, n_envs, buffer_size);
     hipLaunchKernelGGL(episode_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), done, ptr_size, n_envs,
                        buffer_size);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_host_device_pointer(void* pinned_host, void** device_out) {
+    XRL_CHECK_ARG(pinned_host != nullptr && device_out != nullptr);
+    XRL_CHECK_HIP(hipHostGetDevicePointer(device_out, pinned_host, 0));
+    return XRL_OK;
+}
+
+extern "C" int xrl_marl_loop_gate(const xrl_marl_gate_t* gate, xrl_stream_t stream) {
+    XRL_CHECK_ARG(gate != nullptr);
+    const xrl_marl_gate_t& g = *gate;
+    XRL_CHECK_ARG(g.totals && g.base && g.snap && g.active && g.call && g.e_state && g.eps_dev && g.active_f && g.active_i);
+    XRL_CHECK_ARG(g.host_flags == nullptr || (g.seq != nullptr && g.ring > 0));
+    hipLaunchKernelGGL(marl_loop_gate_kernel, dim3(1), dim3(64), 0, as_stream(stream), g);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -396,6 +396,18 @@ def episode_store_step(items, steps, n_envs):
 def episode_finish(items, done, end_step, ptr_size, n_envs, buffer_size):
     call("xrl_episode_finish", _ep_fields(items), len(items), ptr(_chk(done)), ptr(_chk(end_step, torch.int32)),
          ptr(_chk(ptr_size, torch.int32)), int(n_envs), int(buffer_size), stream_ptr())
+
+
+def host_device_pointer(pinned):
+    """Device address (int) of a pinned host tensor, for kernels that publish a word straight to the host."""
+    assert pinned.is_pinned()
+    out = C.c_void_p()
+    call("xrl_host_device_pointer", C.c_void_p(pinned.data_ptr()), C.byref(out))
+    return out.value
+
+
+def marl_loop_gate(**kw):
+    call("xrl_marl_loop_gate", C.byref(_struct(MarlGate, kw)), stream_ptr())
 
 
 def episode_gather(items, idx, B):
