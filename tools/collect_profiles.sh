@@ -7,8 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o ppo -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o ppo -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o ppo -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o ppo -- $CMD > $OUT/pmc_write.log 2>&1
 python $ROOT/tools/summarize_pmc.py $OUT $TAG

@@ -28,7 +28,7 @@ for k in sorted(set(fetch) | set(write)):
     kernels[short] = {"launches": max(fetch[k][1], write[k][1]), "FETCH_SIZE_KB_per_launch_raw": round(fr, 1),
                       "WRITE_SIZE_KB_per_launch_raw": round(wr, 1), "hbm_bytes_per_launch": int((2 * fr + wr) * 1024)}
 doc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 3 "
-                  "--warmup 1 --no-cpu-baseline --no-roofline",
+                  "--warmup 1 --no-cpu-baseline --no-secondary --no-roofline",
        "unit_note": "raw counter values are KB; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a wide "
                     "coalesced stream); WRITE_SIZE uncalibrated; Infinity-Cache hits are counted",
        "kernels": kernels}
