@@ -23,6 +23,7 @@
 #ifndef XRL_HIP_H
 #define XRL_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -223,6 +224,38 @@ int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_
 int xrl_reduce_adam(const float* slabs, int n_split, int64_t slab_stride, float* params, float* grad, float* m, float* v,
                     int64_t P, xrl_adam_state_t* state, double* sumsq_part, int n_part, double max_norm,
                     const xrl_mirrors_t* mirrors, uint32_t* sync, xrl_stream_t stream);
+
+/* Data-parallel ranks (one process per GPU; replaces the DistributedDataParallel gradient all-reduce of
+ * xuance/torch/learners/learner.py:60-65 + torch's DDP hooks for this path): xrl_reduce_adam in which the ranks average
+ * their reduced gradients INSIDE the launch, through exchange buffers every rank allocates with xrl_ipc_alloc and maps
+ * from its peers with xrl_ipc_open (xGMI peer access; two ranks on one GPU work the same way).  Averaging is the fp32 sum
+ * in rank order times 1/world on every rank, so the replicas stay bit-identical; norm, clip and Adam then act on the
+ * averaged gradient as in xrl_reduce_adam.  A peer that does not show up within max_spins polls sets sync[2] = 2 and makes
+ * the norm NaN (the update of that call is invalid).
+ * Buffer layout: uint32 flags[2][XRL_XC_MAX_GROUPS] | float data[2][4 * stride4]  (index 0/1 = parity of the step). */
+#define XRL_XC_MAX_RANKS 8
+#define XRL_XC_MAX_GROUPS 1024
+#define XRL_XC_DATA_OFFSET (2 * XRL_XC_MAX_GROUPS)      /* in 4-byte words from the buffer base */
+#define XRL_IPC_HANDLE_BYTES 64
+typedef struct {
+    float* base[XRL_XC_MAX_RANKS];   /* base[rank] = this rank's buffer, base[r] = rank r's buffer as mapped here */
+    int64_t stride4;                 /* float4 slots per parity (>= P / 4) */
+    int32_t world, rank;
+    int32_t max_spins, pad;
+    float inv_world, pad2;
+} xrl_exchange_t;
+#define XRL_XC_BYTES(stride4) (4 * (size_t)XRL_XC_DATA_OFFSET + 2 * 16 * (size_t)(stride4))
+int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t slab_stride, float* params, float* grad, float* m,
+                             float* v, int64_t P, xrl_adam_state_t* state, double* sumsq_part, int n_part, double max_norm,
+                             const xrl_mirrors_t* mirrors, uint32_t* sync, const xrl_exchange_t* exchange,
+                             xrl_stream_t stream);
+/* Exchange-buffer memory: zero-filled fine-grained device memory + its 64-byte IPC handle; open / close a peer's handle;
+ * free one's own; clear (stream-ordered memset, outside graph capture only). */
+int xrl_ipc_alloc(size_t bytes, void** ptr_out, unsigned char* handle_out);
+int xrl_ipc_open(const unsigned char* handle, void** ptr_out);
+int xrl_ipc_close(void* peer_ptr);
+int xrl_ipc_free(void* ptr);
+int xrl_ipc_clear(void* ptr, size_t bytes, xrl_stream_t stream);
 
 
 /* ------------------------------------------------------------------ rollout-side ops (one small launch per step)

@@ -3,6 +3,7 @@ TWO processes sharing the one GPU of the test box over the gloo backend (RCCL ne
 call site is identical).  Checks: both ranks end with identical parameters, and those equal a single-process run
 on the concatenated data semantics (mean of the two ranks' gradients)."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -41,7 +42,7 @@ def _worker(rank, world, port, q):
     torch.cuda.synchronize()
     # local gradient of the LAST minibatch before averaging is gone; report params and a local re-computation
     q.put((rank, p0.cpu().numpy(), agent.model.params.flat.cpu().numpy(), float(agent.learner.optimizer.read().step),
-           {k: float(v) for k, v in infos[-1].items()}))
+           {k: float(v) for k, v in infos[-1].items()}, getattr(agent.learner, "_xc", None) is not None))
     xd.barrier()
     import torch.distributed as dist
     dist.destroy_process_group()
@@ -66,25 +67,46 @@ def _collect(q, procs, n=2, limit=200):
     return sorted(out, key=lambda t: t[0])
 
 
-def test_two_ranks_share_gradients_and_stay_in_sync():
+def _run_two_ranks(exchange):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
+    old = os.environ.get("XRL_DIST_EXCHANGE")
+    os.environ["XRL_DIST_EXCHANGE"] = "1" if exchange else "0"       # (spawned children inherit the environment)
+    try:
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+    finally:
+        if old is None:
+            os.environ.pop("XRL_DIST_EXCHANGE")
+        else:
+            os.environ["XRL_DIST_EXCHANGE"] = old
     res = _collect(q, procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    (r0, p0a, pa, stepa, ia), (r1, p0b, pb, stepb, ib) = res
-    assert np.array_equal(p0a, p0b)                       # broadcast of rank 0's initial parameters
-    assert stepa == stepb == 4                             # 2 rollouts x 2 minibatches
-    assert np.array_equal(pa, pb)                          # same averaged gradients -> bit-identical parameters
-    assert not np.array_equal(pa, p0a)
-    assert any(k.endswith("/rank_0") for k in ia) and any(k.endswith("/rank_1") for k in ib)   # ppo_learner.py:72-80
-    assert ia["actor_loss/rank_0"] != ib["actor_loss/rank_1"]                                  # different env shards
+    return res
+
+
+def test_two_ranks_share_gradients_and_stay_in_sync():
+    """Two ranks (processes) on the one GPU of the test box, each with its own env shard: (a) gradients averaged INSIDE
+    the optimiser launch through IPC-mapped exchange buffers (xrl_reduce_adam_exchange, one update graph per phase as on
+    one GPU), (b) gradients averaged by the process group between graphs cut at the collectives.  Replicas bit-identical
+    in both; and for two ranks (a + b) * 0.5 == (a + b) / 2, so the two ways agree bit for bit as well."""
+    out = {}
+    for exchange in (True, False):
+        (r0, p0a, pa, stepa, ia, xa), (r1, p0b, pb, stepb, ib, xb) = _run_two_ranks(exchange)
+        assert xa == xb == exchange                            # the path under test is the one that ran
+        assert np.array_equal(p0a, p0b)                       # broadcast of rank 0's initial parameters
+        assert stepa == stepb == 4                             # 2 rollouts x 2 minibatches
+        assert np.array_equal(pa, pb)                          # same averaged gradients -> bit-identical parameters
+        assert not np.array_equal(pa, p0a)
+        assert any(k.endswith("/rank_0") for k in ia) and any(k.endswith("/rank_1") for k in ib)   # ppo_learner.py:72-80
+        assert ia["actor_loss/rank_0"] != ib["actor_loss/rank_1"]                                  # different env shards
+        out[exchange] = pa
+    assert np.array_equal(out[True], out[False])
 
 
 # ---------------------------------------------------------------------------------------------- off-policy learners, 2 ranks
@@ -204,3 +226,17 @@ def test_bench_contract_with_two_ranks():
     assert d["config"]["parallelism"] == "dp2" and d["config"]["env_steps_per_step"] == 2 * 64 * 64
     assert abs(d["value"] - d["config"]["env_steps_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     assert any(k.endswith("/rank_0") for k in d["config"]["last_info"])
+
+
+def test_rccl_all_reduce_replays_from_a_captured_graph():
+    """dist.captured_allreduce_works on a ONE-rank RCCL group (the test box has one GPU): the process group's collective,
+    issued while ops.Graph captures a side stream, becomes part of the graph and replays with the right numbers -- the
+    mechanism the N > 1 update phase uses to stay one graph (agents/ppo_agent.py:_update_distributed)."""
+    code = ("import os, sys; sys.path.insert(0, %r); import torch, torch.distributed as dist; "
+            "from xuance_amd import dist as xd; xd.init_distributed_mode('nccl'); "
+            "ok = xd.captured_allreduce_works(torch.device('cuda', 0)); dist.destroy_process_group(); "
+            "print('CAPTURED_OK' if ok else 'CAPTURED_FAIL')") % ROOT
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=200)
+    assert "CAPTURED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -9,8 +9,12 @@ import bench
 from xuance_amd.agents import PPO_Agent
 from xuance_amd.envs import DeviceCartPoleVecEnv
 
-for dist_path in (False, True):
+from xuance_amd import dist as xdist
+
+for dist_path, whole in ((False, False), (True, False), (True, True)):
     torch.manual_seed(1)
+    # whole = the phase as ONE graph, as when the RCCL calls are captured (dist.collective_capturable); stubbed here too
+    xdist.collective_capturable = (lambda dev: True) if whole else (lambda dev: False)
     cfg = bench.make_config(256, 256, 2 if dist_path else 1, 0)
     agent = PPO_Agent(cfg, DeviceCartPoleVecEnv(256, seed=1))
     for _ in range(3):
@@ -19,4 +23,4 @@ for dist_path in (False, True):
     for _ in range(10):
         agent.rollout(); agent.update()
     torch.cuda.synchronize()
-    print("distributed path" if dist_path else "single-GPU path", round((time.perf_counter() - t0) / 10 * 1e3, 3), "ms per rollout+update")
+    print(("distributed path, %s" % ("one graph per phase" if whole else "cut at the collectives")) if dist_path else "single-GPU path", round((time.perf_counter() - t0) / 10 * 1e3, 3), "ms per rollout+update")

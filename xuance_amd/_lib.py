@@ -186,6 +186,11 @@ class PpoFused(C.Structure):
                 ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p)]
 
 
+class Exchange(C.Structure):
+    _fields_ = [("base", c_void_p * 8), ("stride4", c_int64), ("world", c_int32), ("rank", c_int32),
+                ("max_spins", c_int32), ("pad", c_int32), ("inv_world", c_float), ("pad2", c_float)]
+
+
 class MarlGate(C.Structure):
     _fields_ = [("totals", c_void_p), ("base", c_void_p), ("call", c_void_p), ("snap", c_void_p), ("active", c_void_p),
                 ("e_state", c_void_p), ("eps_dev", c_void_p), ("active_f", c_void_p), ("active_i", c_void_p),
@@ -272,6 +277,13 @@ _SIGS = {
                               C.POINTER(Mirrors), c_void_p],
     "xrl_reduce_adam": [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
                         c_double, C.POINTER(Mirrors), c_void_p, c_void_p],
+    "xrl_reduce_adam_exchange": [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                 c_int, c_double, C.POINTER(Mirrors), c_void_p, C.POINTER(Exchange), c_void_p],
+    "xrl_ipc_alloc": [C.c_size_t, C.POINTER(c_void_p), c_void_p],
+    "xrl_ipc_open": [c_void_p, C.POINTER(c_void_p)],
+    "xrl_ipc_close": [c_void_p],
+    "xrl_ipc_free": [c_void_p],
+    "xrl_ipc_clear": [c_void_p, C.c_size_t, c_void_p],
     "xrl_graph_begin": [c_void_p],
     "xrl_graph_end": [c_void_p, C.POINTER(c_void_p)],
     "xrl_graph_launch": [c_void_p, c_void_p],

@@ -354,39 +354,70 @@ class PPO_Agent(AgentSurface):
         self.current_step += self.n_envs * self.horizon_size
 
     def _update_distributed(self):
-        """N > 1 ranks: the per-minibatch launch sequence is captured in two graphs split at the gradient
-        all-reduce (RCCL runs on its own stream, outside the capture)."""
+        """N > 1 ranks.  The gradient all-reduce is the only thing between two minibatches that cannot simply be replayed
+        from a graph of this process alone, so the update phase is cut AT the collectives and nowhere else: graph 0 =
+        [indices, advantage statistics, minibatch 0 up to its reduced gradient], graph k = [optimiser step of minibatch
+        k - 1 on the averaged gradient, minibatch k up to its reduced gradient], graph nb = [the last optimiser step]:
+        nb + 1 graph launches and nb collectives per phase.  With `dist_graph_collective` (validated once per process by
+        dist.collective_capturable) the RCCL calls are captured as well and the whole phase is ONE graph, as on one GPU."""
         assert not self.rem, "multi-GPU updates need buffer_size divisible by n_minibatch"
+        from .. import dist as xdist
         mem, lr = self.memory, self.learner
         nb, bs = self.idx.shape
         fused = lr.fused_eligible(mem)
-        if fused:
-            lr.prepare_fused(mem, bs)
-            lr.prepare_rows(self.idx.numel())
-        else:
-            lr.prepare_buffer_update(mem, bs)
         step = lr.enqueue_minibatch_fused if fused else lr.enqueue_minibatch_from_buffer
+
+        def head(k):
+            if k == 0 and not getattr(self, "_fixed_idx", False):
+                self._new_indices()
+            if k == 0 and mem.use_advnorm:
+                ops.adv_stats(mem.soa.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs,
+                              self.horizon_size, lr.stats)
+            if k == 0 and fused:
+                lr.refresh_fused_params(mem, self.idx)
+            if k > 0:
+                lr.finish_after_allreduce()
+            if k < nb:
+                step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None, finish=False)
+
         if getattr(self, "_mb_graphs", None) is None:
+            if fused:
+                lr.prepare_fused(mem, bs)
+                lr.prepare_rows(self.idx.numel())
+            else:
+                lr.prepare_buffer_update(mem, bs)
+            whole = bool(getattr(self.config, "dist_graph_collective", "auto")) and xdist.collective_capturable(self.device)
             torch.cuda.synchronize()
             self._mb_graphs = []
-            for k in range(nb):
+            if whole:
                 g = ops.Graph()
                 with g:
-                    if k == 0 and not getattr(self, "_fixed_idx", False):
-                        self._new_indices()
-                    if k == 0 and mem.use_advnorm:
-                        ops.adv_stats(mem.soa.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs,
-                                      self.horizon_size, lr.stats)
-                    if k == 0 and fused:
-                        lr.refresh_fused_params(mem, self.idx)
-                    step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None, finish=False)
-                self._mb_graphs.append(g)
+                    for k in range(nb + 1):
+                        head(k)
+                        if k < nb:
+                            xdist.allreduce_mean_(lr.optimizer.grad)
+                self._mb_graphs, self._whole_phase_graph = [g], True
+            else:
+                for k in range(nb + 1):
+                    g = ops.Graph()
+                    with g:
+                        head(k)
+                    self._mb_graphs.append(g)
+                self._whole_phase_graph = False
+        if self._whole_phase_graph:
+            self._mb_graphs[0].launch()
+            return
         for k in range(nb):
-            self._mb_graphs[k].launch()                     # gather + forward + loss + backward + slab reduction
-            lr.allreduce_and_finish()                       # RCCL mean of the flat gradient, then norm/clip/Adam in one launch
+            self._mb_graphs[k].launch()                     # [Adam of k - 1,] gather + forward + loss + backward + slab reduction
+            xdist.allreduce_mean_(lr.optimizer.grad)        # RCCL mean of the flat gradient
+        self._mb_graphs[nb].launch()
 
     def update(self):
-        if self.learner.distributed_training and self.learner.world_size > 1:
+        lr = self.learner
+        multi = lr.distributed_training and lr.world_size > 1
+        if multi and not self.rem and lr.fused_eligible(self.memory) and lr.gradient_exchange() is not None:
+            multi = False           # the ranks meet inside xrl_reduce_adam_exchange: the single-GPU update graph is the N-GPU one
+        if multi:
             self._update_distributed()
         elif self.use_graph:
             if self._update_graph is None:

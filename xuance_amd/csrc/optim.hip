@@ -167,11 +167,19 @@ __device__ __forceinline__ double group_sum(double v, double* scratch4, int tg) 
     return wave_sum(t);
 }
 
+// XC: the ranks of a data-parallel job meet INSIDE this launch.  Each group publishes its 256 reduced gradient values in its
+// rank's exchange buffer (fine-grained device memory every peer has mapped through an IPC handle), flags them with the
+// optimiser step number, waits for the same flag of every peer, reads their 256 values over xGMI and averages in rank
+// order -- so every rank holds bit-identical averaged gradients and the launch count of an update equals the single-GPU
+// one (no collective call, nothing for a graph to be cut at).  Buffers alternate with the step's parity: a peer can only
+// publish step s + 1 after its step-s launch -- and with it every read of this rank's step-s values -- has finished.
+template <bool XC>
 __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __restrict__ slabs, int n_split, int64_t slab_stride,
                                                                  float* __restrict__ params, float* __restrict__ grad,
                                                                  float* __restrict__ m, float* __restrict__ v, int64_t P,
                                                                  xrl_adam_state_t* __restrict__ st, double* sumsq_part, int n_part,
-                                                                 double max_norm, xrl_mirrors_t mir, unsigned* sync) {
+                                                                 double max_norm, xrl_mirrors_t mir, unsigned* sync,
+                                                                 xrl_exchange_t xc) {
     // a block = RA_GROUPS groups of 256 threads; group `vb` (virtual block) does what block vb of grad_reduce_kernel /
     // adam_step_kernel does, so every partial sum and every parameter sees the same arithmetic; fewer, larger blocks keep
     // the number of barrier participants (device-scope atomics) small.
@@ -179,9 +187,10 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     __shared__ double gscratch[RA_GROUPS][4];
     __shared__ double gsum[RA_GROUPS][4][64][4];
     __shared__ float gtot[RA_GROUPS][256];
-    __shared__ int s_fail;
+    __shared__ int s_fail, s_xfail;
     const int grp = threadIdx.x >> 8, tg = threadIdx.x & 255;
     const int vb = blockIdx.x * RA_GROUPS + grp, n_vb = (int)((P / 4 + 63) / 64);
+    if (XC && threadIdx.x == 0) s_xfail = 0;
     const int64_t P4 = P / 4, st4 = slab_stride / 4;
     const int pq = tg & 63, sg = tg >> 6;
     const int64_t qi = (int64_t)vb * 64 + pq;
@@ -221,8 +230,41 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
 #pragma unroll
                 for (int k = 1; k < 4; ++k) { t0 += gsum[grp][k][pq][0]; t1 += gsum[grp][k][pq][1]; t2 += gsum[grp][k][pq][2]; t3 += gsum[grp][k][pq][3]; }
                 t = make_float4((float)t0, (float)t1, (float)t2, (float)t3);
-                sq += (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
             }
+            if (XC) {                                                    // (sg == 0: exactly one wave per group gets here)
+                const unsigned xstep = (unsigned)(st->step + 1);
+                const int64_t slot = (int64_t)(xstep & 1u) * xc.stride4 + qi;
+                const int64_t fslot = (int64_t)(xstep & 1u) * XRL_XC_MAX_GROUPS + vb;
+                if (qi < P4) reinterpret_cast<float4*>(xc.base[xc.rank] + XRL_XC_DATA_OFFSET)[slot] = t;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // the wave's stores are visible system-wide ...
+                if (pq == 0 && vb < n_vb)                                 // ... before its flag is
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(xc.base[xc.rank]) + fslot, xstep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (vb < n_vb) {
+                    int spins = 0;
+                    for (;;) {
+                        int ok = 1;
+                        if (pq < xc.world && pq != xc.rank)
+                            ok = __hip_atomic_load(reinterpret_cast<const unsigned*>(xc.base[pq]) + fslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == xstep;
+                        if (__all(ok)) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > xc.max_spins) {
+                            if (pq == 0) { s_xfail = 1; __hip_atomic_store(&sync[2], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                    if (qi < P4) {
+                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int r = 0; r < xc.world; ++r) {              // rank order on every rank
+                            float4 w = t;
+                            if (r != xc.rank) w = reinterpret_cast<const float4*>(xc.base[r] + XRL_XC_DATA_OFFSET)[slot];
+                            if (r == 0) a = w; else { a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w; }
+                        }
+                        t = make_float4(a.x * xc.inv_world, a.y * xc.inv_world, a.z * xc.inv_world, a.w * xc.inv_world);
+                    }
+                }
+            }
+            if (qi < P4) sq += (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
             *reinterpret_cast<float4*>(&gtot[grp][pq * 4]) = t;
         }
     }
@@ -265,7 +307,7 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     double ssum = 0.0;
     for (int j = tg; j < n_part; j += RED_THREADS)
         ssum += j < n_vb ? __hip_atomic_load(&sumsq_part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    const double total_norm = s_fail ? __builtin_nan("") : sqrt(group_sum(ssum, gscratch[grp], tg));
+    const double total_norm = (s_fail || (XC && s_xfail)) ? __builtin_nan("") : sqrt(group_sum(ssum, gscratch[grp], tg));
     float coef = 1.f;
     if (max_norm > 0.0) {
         const double c = max_norm / (total_norm + 1e-6);
@@ -305,9 +347,10 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
 
 using namespace xrl;
 
-extern "C" int xrl_reduce_adam(const float* slabs, int n_split, int64_t slab_stride, float* params, float* grad, float* m,
-                               float* v, int64_t P, xrl_adam_state_t* state, double* sumsq_part, int n_part, double max_norm,
-                               const xrl_mirrors_t* mirrors, uint32_t* sync, xrl_stream_t stream) {
+extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t slab_stride, float* params, float* grad,
+                                        float* m, float* v, int64_t P, xrl_adam_state_t* state, double* sumsq_part, int n_part,
+                                        double max_norm, const xrl_mirrors_t* mirrors, uint32_t* sync,
+                                        const xrl_exchange_t* exchange, xrl_stream_t stream) {
     XRL_CHECK_ARG(slabs && params && grad && m && v && state && sumsq_part && sync && n_split >= 1 && P > 0);
     XRL_CHECK_ARG((P & 3) == 0 && (slab_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0));
     const int n_vb = (int)((P / 4 + 63) / 64);
@@ -320,9 +363,66 @@ extern "C" int xrl_reduce_adam(const float* slabs, int n_split, int64_t slab_str
     for (int q = 0; q < mir.n; ++q) XRL_CHECK_ARG(mir.map[q] && mir.dst[q]);
     XRL_CHECK_ARG(mir.fold_len >= 0 && (mir.fold_len & 3) == 0 && (mir.fold_off & 3) == 0 &&
                   (mir.fold_len == 0 || (mir.fold_off >= P && mir.fold_off + mir.fold_len <= slab_stride && mir.fold_len <= P)));
-    hipLaunchKernelGGL(reduce_adam_kernel, dim3(nb), dim3(RA_THREADS), 0, as_stream(stream), slabs, n_split, slab_stride, params,
-                       grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync);
+    if (exchange && exchange->world > 1) {
+        const xrl_exchange_t& xc = *exchange;
+        XRL_CHECK_ARG(xc.world <= XRL_XC_MAX_RANKS && xc.rank >= 0 && xc.rank < xc.world && n_vb <= XRL_XC_MAX_GROUPS);
+        XRL_CHECK_ARG(xc.stride4 >= P / 4 && xc.max_spins > 0);
+        for (int r = 0; r < xc.world; ++r) XRL_CHECK_ARG(xc.base[r] != nullptr);
+        hipLaunchKernelGGL(reduce_adam_kernel<true>, dim3(nb), dim3(RA_THREADS), 0, as_stream(stream), slabs, n_split, slab_stride,
+                           params, grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync, xc);
+    } else {
+        hipLaunchKernelGGL(reduce_adam_kernel<false>, dim3(nb), dim3(RA_THREADS), 0, as_stream(stream), slabs, n_split, slab_stride,
+                           params, grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync, xrl_exchange_t{});
+    }
     XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_reduce_adam(const float* slabs, int n_split, int64_t slab_stride, float* params, float* grad, float* m,
+                               float* v, int64_t P, xrl_adam_state_t* state, double* sumsq_part, int n_part, double max_norm,
+                               const xrl_mirrors_t* mirrors, uint32_t* sync, xrl_stream_t stream) {
+    return xrl_reduce_adam_exchange(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, n_part, max_norm,
+                                    mirrors, sync, nullptr, stream);
+}
+
+// ---- exchange buffers: fine-grained device memory (coherent for system-scope accesses of peers) shared through IPC handles
+extern "C" int xrl_ipc_alloc(size_t bytes, void** ptr_out, unsigned char* handle_out) {
+    XRL_CHECK_ARG(bytes > 0 && ptr_out && handle_out);
+    void* p = nullptr;
+    XRL_CHECK_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+    XRL_CHECK_HIP(hipMemset(p, 0, bytes));
+    XRL_CHECK_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    XRL_CHECK_HIP(hipIpcGetMemHandle(&h, p));
+    static_assert(sizeof(h) == XRL_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    memcpy(handle_out, &h, sizeof(h));
+    *ptr_out = p;
+    return XRL_OK;
+}
+
+extern "C" int xrl_ipc_open(const unsigned char* handle, void** ptr_out) {
+    XRL_CHECK_ARG(handle && ptr_out);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    XRL_CHECK_HIP(hipIpcOpenMemHandle(ptr_out, h, hipIpcMemLazyEnablePeerAccess));
+    return XRL_OK;
+}
+
+extern "C" int xrl_ipc_close(void* peer_ptr) {
+    XRL_CHECK_ARG(peer_ptr != nullptr);
+    XRL_CHECK_HIP(hipIpcCloseMemHandle(peer_ptr));
+    return XRL_OK;
+}
+
+extern "C" int xrl_ipc_free(void* ptr) {
+    XRL_CHECK_ARG(ptr != nullptr);
+    XRL_CHECK_HIP(hipFree(ptr));
+    return XRL_OK;
+}
+
+extern "C" int xrl_ipc_clear(void* ptr, size_t bytes, xrl_stream_t stream) {
+    XRL_CHECK_ARG(ptr != nullptr && bytes > 0);
+    XRL_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, as_stream(stream)));     // (never inside a captured graph: see rollout_persist.hip)
     return XRL_OK;
 }
 

@@ -52,6 +52,156 @@ def allreduce_mean_(flat):
     return flat
 
 
+_capturable = None
+
+
+def captured_allreduce_works(device):
+    """Capture an all-reduce of a known tensor into a hipGraph (ops.Graph on a side stream: the process group's own stream
+    is forked from and joined to it by the events torch records, so the collective becomes part of the graph), replay it
+    twice and compare with the known answer.  True only if every rank saw the right numbers both times."""
+    from . import ops
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ok = True
+    try:
+        x = torch.full((1024,), float(rank + 1), device=device)
+        y = torch.zeros_like(x)
+        warm = x.clone()
+        dist.all_reduce(warm, op=dist.ReduceOp.SUM)        # communicator set-up happens outside the capture
+        torch.cuda.synchronize()
+        g = ops.Graph()
+        with g:
+            torch.mul(x, 1.0, out=y)
+            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+            torch.mul(y, 1.0 / world, out=y)
+        for _ in range(2):
+            y.zero_()
+            g.launch()
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(y, torch.full_like(y, (world + 1) / 2.0)))
+    except Exception:                                      # a build whose RCCL / process group refuses stream capture
+        ok = False
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() == 1.0)
+
+
+def collective_capturable(device):
+    """May the gradient all-reduce be captured into the update graph?  RCCL only (gloo reduces on the host), more than one
+    rank, not disabled by XRL_DIST_GRAPH_COLLECTIVE=0, and proven once per process by captured_allreduce_works."""
+    global _capturable, _avg_ok
+    if _capturable is None:
+        _capturable = False
+        if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl" and \
+                os.environ.get("XRL_DIST_GRAPH_COLLECTIVE", "1") != "0":
+            allreduce_mean_(torch.ones(4, device=device))  # settles whether ncclAvg exists before anything is captured
+            _capturable = captured_allreduce_works(device)
+    return _capturable
+
+
+class GradientExchange:
+    """Exchange buffers of xrl_reduce_adam_exchange for gradients of up to P values: this rank's buffer (fine-grained
+    device memory) and every peer's, mapped through IPC handles that travel over the process group once.  After this
+    set-up the data path of an update makes no collective call at all (include/xrl_hip.h, csrc/optim.hip)."""
+
+    def __init__(self, P, device, max_spins=4_000_000):
+        from . import ops
+        from ._lib import Exchange
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        assert 1 < self.world <= ops.XC_MAX_RANKS and (P + 255) // 256 <= ops.XC_MAX_GROUPS
+        self.stride4 = (P + 255) // 256 * 64
+        self.nbytes = ops.xc_bytes(self.stride4)
+        self.ptr, handle = ops.ipc_alloc(self.nbytes)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, handle)
+        self.peers = [self.ptr if r == self.rank else ops.ipc_open(h) for r, h in enumerate(handles)]
+        x = Exchange()
+        for r, p in enumerate(self.peers):
+            x.base[r] = p
+        x.stride4, x.world, x.rank, x.max_spins, x.inv_world = self.stride4, self.world, self.rank, int(max_spins), 1.0 / self.world
+        self.struct = x
+        dist.barrier()                                         # nobody polls a buffer that is not mapped everywhere yet
+
+    def clear(self):
+        """Forget the step numbers of an earlier life (a checkpoint was loaded: the optimiser step may repeat)."""
+        from . import ops
+        torch.cuda.synchronize()
+        dist.barrier()                                         # every rank's launches that poll these flags are over
+        ops.ipc_clear(self.ptr, self.nbytes)
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def close(self):
+        from . import ops
+        if getattr(self, "peers", None):
+            torch.cuda.synchronize()
+            for r, p in enumerate(self.peers):
+                if r != self.rank:
+                    ops.ipc_close(p)
+            ops.ipc_free(self.ptr)
+            self.peers = None
+
+
+_exchange_ok = None
+
+
+def exchange_selftest(device, P=3000, rounds=5):
+    """xrl_reduce_adam_exchange against the process group's own all-reduce on a scratch problem (rank-dependent slabs, an
+    optimiser of its own, both buffer parities and their reuse): every rank must reproduce (sum in rank order) / world bit
+    for bit in the gradient the launch reports, see no time-out, and end with the same parameters as every other rank."""
+    from . import ops
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ok, xc = True, None
+    try:
+        xc = GradientExchange(P, device, max_spins=400_000)
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        slabs_all = torch.randn(rounds, world, 3, P, generator=g)           # the same numbers on every rank
+        params = torch.zeros(P, device=device)
+        grad, m, v = torch.zeros_like(params), torch.zeros_like(params), torch.zeros_like(params)
+        state = ops.adam_state_tensor(1e-3, 1, 1.0, 1e-5, 0.0, device=device)
+        n_part = (P + 255) // 256
+        sumsq = torch.zeros(n_part, dtype=torch.float64, device=device)
+        sync = torch.zeros(4 + n_part + 8, dtype=torch.int32, device=device)
+        for k in range(rounds):
+            ops.reduce_adam(slabs_all[k, rank].to(device).contiguous(), 3, P, params, grad, m, v, P, state, sumsq, 0.0, [], sync,
+                            exchange=xc)
+            local = [slabs_all[k, r].to(device).sum(0) for r in range(world)]   # NOT the kernel's float64 slab sum: compare
+            torch.cuda.synchronize()                                              # through the collective below instead
+            mine = grad.clone()
+            ref = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(ref, mine)                                           # every rank reports the same averaged gradient
+            ok = ok and all(torch.equal(r, mine) for r in ref) and int(sync[2]) == 0
+            expect = sum(local[1:], local[0]) / world
+            ok = ok and bool(torch.allclose(mine, expect, rtol=1e-5, atol=1e-6))
+        ref = [torch.zeros_like(params) for _ in range(world)]
+        dist.all_gather(ref, params)
+        ok = ok and all(torch.equal(r, params) for r in ref)
+    except Exception:
+        if os.environ.get("XRL_DIST_DEBUG"):
+            import traceback
+            traceback.print_exc()
+        ok = False
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if xc is not None:
+        try:
+            xc.close()
+        except Exception:
+            pass
+    return bool(flag.item() == 1.0)
+
+
+def exchange_usable(device):
+    """May gradients be averaged inside the optimiser launch (GradientExchange)?  More than one rank, every rank's GPU
+    reachable from this one (IPC + peer access), not disabled by XRL_DIST_EXCHANGE=0, proven once by exchange_selftest."""
+    global _exchange_ok
+    if _exchange_ok is None:
+        _exchange_ok = False
+        if dist.is_initialized() and 1 < dist.get_world_size() <= 8 and torch.cuda.is_available() and \
+                os.environ.get("XRL_DIST_EXCHANGE", "1") != "0":
+            _exchange_ok = exchange_selftest(device)
+    return _exchange_ok
+
+
 def broadcast_(flat, src=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(flat, src=src)

@@ -142,6 +142,18 @@ class Learner:
         self.total_iters = self.estimate_total_iterations()
         self.iterations = 0
 
+    def gradient_exchange(self):
+        """The ranks' gradient exchange buffers (dist.GradientExchange) when averaging inside the optimiser launch is
+        usable in this job, else None (the learners then all-reduce through the process group).  Collective on first use:
+        every rank gets here at the same point of its first update."""
+        if not hasattr(self, "_xc"):
+            from .. import dist as xdist
+            self._xc = None
+            if self.distributed_training and self.world_size > 1 and getattr(self.config, "dist_gradient_exchange", True) \
+                    and xdist.exchange_usable(self.device):
+                self._xc = xdist.GradientExchange(self.model.params.P, self.device)
+        return self._xc
+
     def sync_replicas_from_rank0(self):
         """What the reference's DistributedDataParallel wrap does at construction (deep_q_network.py:55-59,
         value_factorization.py:44-48): every rank starts from rank 0's parameters (and target copies).  Ranks are seeded
@@ -205,6 +217,8 @@ class Learner:
             for i, st in enumerate(ckpt["cuda_rng_state"][:torch.cuda.device_count()]):
                 torch.cuda.set_rng_state(st.cpu().to(torch.uint8), device=i)
         self._safe_scheduler_step()
+        if getattr(self, "_xc", None) is not None:                              # so do the exchange buffers' flags (all ranks load)
+            self._xc.clear()
         if getattr(self, "opt_sync", None) is not None:                         # barrier flags of xrl_reduce_adam hold step
             self.opt_sync.zero_()                                               # values: a rewound step must not match them
         return os.path.dirname(path)

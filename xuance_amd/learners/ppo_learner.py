@@ -98,8 +98,12 @@ class PPO_Learner(Learner):
         layouts in ONE launch (xrl_reduce_adam over the averaged gradient as a single slab) when the fused kernels are
         in use; the generic two-launch sequence otherwise.  Same numbers either way."""
         from ..dist import allreduce_mean_
+        allreduce_mean_(self.optimizer.grad)
+        self.finish_after_allreduce()
+
+    def finish_after_allreduce(self):
+        """The launches that follow the gradient all-reduce (capturable: no collective in here)."""
         model, opt, P = self.model, self.optimizer, self.model.params.P
-        allreduce_mean_(opt.grad)
         if getattr(self, "_mirror", False) and P % 4 == 0 and getattr(self, "opt_sync", None) is not None and \
                 getattr(self.config, "use_fused_optimizer", True):
             clip = self.grad_clip_norm if self.use_grad_clip else 0.0
@@ -108,7 +112,6 @@ class PPO_Learner(Learner):
         else:
             ops.grad_reduce(opt.grad, 1, P, P, opt.grad, self.sumsq)
             self.finish_step()
-
     def finish_step(self):
         """clip_grad_norm_ + Adam.step + LinearLR.step (ppo_learner.py:63-67).  When the fused kernels are in use the
         same launch also refreshes their derived parameter layouts."""
@@ -260,11 +263,13 @@ class PPO_Learner(Learner):
         n_t = (M + 31) // 32
         self._last_S, self._last_partials = n_t * (2 if fold else 1), self.fpartials
         dist = self.distributed_training and self.world_size > 1
-        if finish and not dist and m.params.P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
-            # slab reduction + clip + Adam + derived layouts in ONE launch (xrl_reduce_adam)
+        xc = self.gradient_exchange() if dist and finish else None
+        if finish and (not dist or xc is not None) and m.params.P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
+            # slab reduction (+ with several ranks: the gradient average over the ranks, inside the launch) + clip + Adam +
+            # derived layouts in ONE launch (xrl_reduce_adam / xrl_reduce_adam_exchange)
             clip = self.grad_clip_norm if self.use_grad_clip else 0.0
             ops.reduce_adam(self.fslabs, n_t, self.slab_stride, m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state,
-                            self.sumsq, clip, self._mirrors, self.opt_sync, fold=fold)
+                            self.sumsq, clip, self._mirrors, self.opt_sync, fold=fold, exchange=xc)
             return
         ops.grad_reduce(self.fslabs, n_t, self.slab_stride, m.params.P, opt.grad, self.sumsq, fold=fold)
         if finish:

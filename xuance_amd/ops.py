@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -181,9 +181,9 @@ def adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, max_norm, mirror
 
 
 def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, max_norm, mirrors, sync, target=None,
-                target_every=0, fold=None):
+                target_every=0, fold=None, exchange=None):
     """grad_reduce + clip + Adam + mirrors (+ the periodic hard target update) in one launch (blocks meet at a counter
-    barrier); same numbers."""
+    barrier); same numbers.  exchange: a dist.GradientExchange -- the ranks average their gradients inside the launch."""
     mir = Mirrors()
     mir.n = len(mirrors)
     for q, (mp, dst) in enumerate(mirrors):
@@ -192,9 +192,48 @@ def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq
         mir.target, mir.target_every = target.data_ptr(), int(target_every)
     if fold:
         mir.fold_off, mir.fold_len = int(fold[0]), int(fold[1])
+    if exchange is not None:
+        assert exchange.stride4 * 4 >= P
+        call("xrl_reduce_adam_exchange", ptr(slabs), int(n_split), int(slab_stride), ptr(params), ptr(grad), ptr(m), ptr(v),
+             int(P), ptr(state), ptr(sumsq_part), sumsq_part.numel(), float(max_norm if max_norm else 0.0), C.byref(mir),
+             ptr(sync), C.byref(exchange.struct), stream_ptr())
+        return
     call("xrl_reduce_adam", ptr(slabs), int(n_split), int(slab_stride), ptr(params), ptr(grad), ptr(m), ptr(v), int(P),
          ptr(state), ptr(sumsq_part), sumsq_part.numel(), float(max_norm if max_norm else 0.0), C.byref(mir), ptr(sync),
          stream_ptr())
+
+
+XC_MAX_RANKS, XC_MAX_GROUPS, IPC_HANDLE_BYTES = 8, 1024, 64
+
+
+def xc_bytes(stride4):
+    return 4 * 2 * XC_MAX_GROUPS + 2 * 16 * int(stride4)
+
+
+def ipc_alloc(nbytes):
+    """-> (device pointer, 64-byte IPC handle) of zero-filled fine-grained device memory."""
+    init_device()
+    p, h = C.c_void_p(), (C.c_ubyte * IPC_HANDLE_BYTES)()
+    call("xrl_ipc_alloc", C.c_size_t(int(nbytes)), C.byref(p), C.cast(h, C.c_void_p))
+    return p.value, bytes(h)
+
+
+def ipc_open(handle):
+    h, p = (C.c_ubyte * IPC_HANDLE_BYTES).from_buffer_copy(handle), C.c_void_p()
+    call("xrl_ipc_open", C.cast(h, C.c_void_p), C.byref(p))
+    return p.value
+
+
+def ipc_close(p):
+    call("xrl_ipc_close", C.c_void_p(p))
+
+
+def ipc_free(p):
+    call("xrl_ipc_free", C.c_void_p(p))
+
+
+def ipc_clear(p, nbytes):
+    call("xrl_ipc_clear", C.c_void_p(p), C.c_size_t(int(nbytes)), stream_ptr())
 
 
 def pack_mid_frags(plan, params_flat, frag):
@@ -503,6 +542,14 @@ class Graph:
         try:
             if et is None:
                 call("xrl_graph_end", self.stream.cuda_stream, C.byref(self.handle))
+            else:                                          # leave no stream of this thread in capture mode behind
+                junk = C.c_void_p()
+                try:
+                    call("xrl_graph_end", self.stream.cuda_stream, C.byref(junk))
+                    if junk:
+                        _lib.load().xrl_graph_destroy(junk)
+                except Exception:
+                    pass
         finally:
             self._ctx.__exit__(et, ev, tb)
         return False
