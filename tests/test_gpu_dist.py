@@ -67,7 +67,7 @@ def _collect(q, procs, n=2, limit=200):
     return sorted(out, key=lambda t: t[0])
 
 
-def _run_two_ranks(exchange):
+def _run_two_ranks(exchange, target=None, extra=()):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -75,7 +75,7 @@ def _run_two_ranks(exchange):
     old = os.environ.get("XRL_DIST_EXCHANGE")
     os.environ["XRL_DIST_EXCHANGE"] = "1" if exchange else "0"       # (spawned children inherit the environment)
     try:
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+        procs = [ctx.Process(target=target or _worker, args=(r, 2, port, q) + tuple(extra)) for r in range(2)]
         for p in procs:
             p.start()
     finally:
@@ -166,31 +166,25 @@ def _offpolicy_worker(rank, world, port, q, kind):
     xd.broadcast_(net.params.flat, 0)            # (the fixtures start with target != eval on purpose: leave the target alone)
     infos = [call(sub(g, f"u{(rank + u) % 2}/batch")) for u in range(2)]       # ranks see different batches every update
     torch.cuda.synchronize()
-    q.put((rank, net.params.flat.cpu().numpy(), float(learner.optimizer.read().step), sorted(infos[-1].keys())))
+    q.put((rank, net.params.flat.cpu().numpy(), float(learner.optimizer.read().step), sorted(infos[-1].keys()),
+           getattr(learner, "_xc", None) is not None))
     xd.barrier()
     import torch.distributed as dist
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", [True, False])
 @pytest.mark.parametrize("kind", ["dqn_mlp", "qmix_ff_double", "qmix_rnn_double_fixed"])
-def test_offpolicy_learners_two_ranks(kind):
+def test_offpolicy_learners_two_ranks(kind, exchange):
     """DQN / QMIX with distributed_training: each rank updates on its own batch, the flat gradient is averaged between the
     slab reduction and the optimiser launch (the reference wraps these models in DDP: deep_q_network.py:55-59,
     value_factorization.py:44-48).  Ranks must stay bit-identical; for the feed-forward losses (a mean over the batch) the
-    result must equal ONE process updating on the concatenation of the two batches."""
-    import torch.multiprocessing as mp
+    result must equal ONE process updating on the concatenation of the two batches.  exchange: the average is taken inside
+    the optimiser launch (xrl_reduce_adam_exchange) instead of by the process group."""
     from conftest import sub
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = free_port()
-    procs = [ctx.Process(target=_offpolicy_worker, args=(r, 2, port, q, kind)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = _collect(q, procs)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    (_, pa, stepa, ka), (_, pb, stepb, kb) = res
+    res = _run_two_ranks(exchange, _offpolicy_worker, (kind,))
+    (_, pa, stepa, ka, xa), (_, pb, stepb, kb, xb) = res
+    assert xa == xb == exchange
     assert stepa == stepb == 2 and np.array_equal(pa, pb)
     net, learner, call, g = _build_offpolicy(kind, False)
     p0 = net.params.flat.cpu().numpy().copy()

@@ -110,16 +110,30 @@ class GradientExchange:
         assert 1 < self.world <= ops.XC_MAX_RANKS and (P + 255) // 256 <= ops.XC_MAX_GROUPS
         self.stride4 = (P + 255) // 256 * 64
         self.nbytes = ops.xc_bytes(self.stride4)
-        self.ptr, handle = ops.ipc_alloc(self.nbytes)
+        self.ptr, self.peers, handle, err = None, None, None, None
+        # every rank makes the same collective calls whatever fails locally (a rank that raised early would leave its
+        # peers waiting in a collective it never joins)
+        try:
+            self.ptr, handle = ops.ipc_alloc(self.nbytes)
+        except Exception as ex:
+            err = ex
         handles = [None] * self.world
         dist.all_gather_object(handles, handle)
-        self.peers = [self.ptr if r == self.rank else ops.ipc_open(h) for r, h in enumerate(handles)]
+        if err is None and all(h is not None for h in handles):
+            try:
+                self.peers = [self.ptr if r == self.rank else ops.ipc_open(h) for r, h in enumerate(handles)]
+            except Exception as ex:
+                err = ex
+        oks = [None] * self.world
+        dist.all_gather_object(oks, self.peers is not None)    # (also the barrier: nobody polls a buffer not mapped everywhere)
+        if not all(oks):
+            self.close()
+            raise RuntimeError(f"GradientExchange: set-up failed on rank(s) {[r for r, o in enumerate(oks) if not o]}: {err}")
         x = Exchange()
         for r, p in enumerate(self.peers):
             x.base[r] = p
         x.stride4, x.world, x.rank, x.max_spins, x.inv_world = self.stride4, self.world, self.rank, int(max_spins), 1.0 / self.world
         self.struct = x
-        dist.barrier()                                         # nobody polls a buffer that is not mapped everywhere yet
 
     def clear(self):
         """Forget the step numbers of an earlier life (a checkpoint was loaded: the optimiser step may repeat)."""
@@ -132,62 +146,65 @@ class GradientExchange:
 
     def close(self):
         from . import ops
-        if getattr(self, "peers", None):
-            torch.cuda.synchronize()
-            for r, p in enumerate(self.peers):
-                if r != self.rank:
-                    ops.ipc_close(p)
+        torch.cuda.synchronize()
+        for r, p in enumerate(self.peers or []):
+            if r != self.rank:
+                ops.ipc_close(p)
+        if self.ptr is not None:
             ops.ipc_free(self.ptr)
-            self.peers = None
+        self.peers, self.ptr = None, None
 
 
 _exchange_ok = None
 
 
 def exchange_selftest(device, P=3000, rounds=5):
-    """xrl_reduce_adam_exchange against the process group's own all-reduce on a scratch problem (rank-dependent slabs, an
-    optimiser of its own, both buffer parities and their reuse): every rank must reproduce (sum in rank order) / world bit
-    for bit in the gradient the launch reports, see no time-out, and end with the same parameters as every other rank."""
+    """xrl_reduce_adam_exchange on a scratch problem (slabs that depend on the rank but are known to every rank, an
+    optimiser of its own, both buffer parities and their reuse): in every round every rank must find, bit for bit, (the
+    fp32 sum in rank order of the ranks' slab sums) * (1 / world) in the gradient the launch reports, see no time-out, and
+    hold the same gradient and parameters as every other rank (compared through the process group)."""
     from . import ops
     rank, world = dist.get_rank(), dist.get_world_size()
-    ok, xc = True, None
     try:
-        xc = GradientExchange(P, device, max_spins=400_000)
-        g = torch.Generator(device="cpu").manual_seed(1234)
-        slabs_all = torch.randn(rounds, world, 3, P, generator=g)           # the same numbers on every rank
-        params = torch.zeros(P, device=device)
-        grad, m, v = torch.zeros_like(params), torch.zeros_like(params), torch.zeros_like(params)
-        state = ops.adam_state_tensor(1e-3, 1, 1.0, 1e-5, 0.0, device=device)
-        n_part = (P + 255) // 256
-        sumsq = torch.zeros(n_part, dtype=torch.float64, device=device)
-        sync = torch.zeros(4 + n_part + 8, dtype=torch.int32, device=device)
-        for k in range(rounds):
+        xc = GradientExchange(P, device, max_spins=400_000)      # (raises on every rank or on none)
+    except RuntimeError:
+        return False
+    ok = True
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    slabs_all = torch.randn(rounds, world, 3, P, generator=g)   # the same numbers on every rank
+    params = torch.zeros(P, device=device)
+    grad, m, v = torch.zeros_like(params), torch.zeros_like(params), torch.zeros_like(params)
+    n_part = (P + 255) // 256
+    sumsq = torch.zeros(n_part, dtype=torch.float64, device=device)
+    sync = torch.zeros(4 + n_part + 8, dtype=torch.int32, device=device)
+    state = ops.adam_state_tensor(1e-3, 1, 1.0, 1e-5, 0.0, device=device)
+    for k in range(rounds):
+        try:                                                     # local work may fail; the collectives below always run
             ops.reduce_adam(slabs_all[k, rank].to(device).contiguous(), 3, P, params, grad, m, v, P, state, sumsq, 0.0, [], sync,
                             exchange=xc)
-            local = [slabs_all[k, r].to(device).sum(0) for r in range(world)]   # NOT the kernel's float64 slab sum: compare
-            torch.cuda.synchronize()                                              # through the collective below instead
-            mine = grad.clone()
-            ref = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(ref, mine)                                           # every rank reports the same averaged gradient
-            ok = ok and all(torch.equal(r, mine) for r in ref) and int(sync[2]) == 0
-            expect = sum(local[1:], local[0]) / world
-            ok = ok and bool(torch.allclose(mine, expect, rtol=1e-5, atol=1e-6))
-        ref = [torch.zeros_like(params) for _ in range(world)]
-        dist.all_gather(ref, params)
-        ok = ok and all(torch.equal(r, params) for r in ref)
-    except Exception:
-        if os.environ.get("XRL_DIST_DEBUG"):
-            import traceback
-            traceback.print_exc()
-        ok = False
-    flag = torch.tensor([1.0 if ok else 0.0], device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if xc is not None:
-        try:
-            xc.close()
+            torch.cuda.synchronize()
+            ok = ok and int(sync[2]) == 0
         except Exception:
-            pass
-    return bool(flag.item() == 1.0)
+            if os.environ.get("XRL_DIST_DEBUG"):
+                import traceback
+                traceback.print_exc()
+            ok = False
+        mine = torch.cat([grad, params])
+        ref = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(ref, mine)                               # every rank reports the same averaged gradient and parameters
+        ok = ok and all(torch.equal(r, mine) for r in ref)
+        local = [slabs_all[k, r].to(device).double().sum(0).float() for r in range(world)]    # the launch's float64 slab sums
+        expect = local[0]
+        for r in range(1, world):
+            expect = expect + local[r]
+        ok = ok and bool(torch.equal(grad, expect * (1.0 / world)))
+    oks = [None] * world
+    dist.all_gather_object(oks, bool(ok))
+    try:
+        xc.close()
+    except Exception:
+        pass
+    return all(oks)
 
 
 def exchange_usable(device):

@@ -149,10 +149,16 @@ class Learner:
         if not hasattr(self, "_xc"):
             from .. import dist as xdist
             self._xc = None
+            from .. import ops
             if self.distributed_training and self.world_size > 1 and getattr(self.config, "dist_gradient_exchange", True) \
+                    and self.model.params.P % 4 == 0 and (self.model.params.P + 255) // 256 <= ops.XC_MAX_GROUPS \
                     and xdist.exchange_usable(self.device):
                 self._xc = xdist.GradientExchange(self.model.params.P, self.device)
         return self._xc
+
+    def needs_collective(self):
+        """Several ranks AND no in-launch exchange: the update must stop at a process-group all-reduce."""
+        return bool(self.distributed_training and self.world_size > 1 and self.gradient_exchange() is None)
 
     def sync_replicas_from_rank0(self):
         """What the reference's DistributedDataParallel wrap does at construction (deep_q_network.py:55-59,

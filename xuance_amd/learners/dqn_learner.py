@@ -53,11 +53,13 @@ class DQN_Learner(Learner):
                    ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)))
         model.backward(self.X, M, self.slabs, S)
         P, clip = model.params.P, (self.grad_clip_norm if self.use_grad_clip else 0.0)
-        if not (self.distributed_training and self.world_size > 1) and P % 4 == 0 and (P + 255) // 256 <= 512 and \
+        if not self.needs_collective() and P % 4 == 0 and (P + 255) // 256 <= 512 and \
                 getattr(self.config, "use_fused_optimizer", True):
-            # slab reduction + norm + clip + Adam + LinearLR + periodic hard target update (:50-57) in ONE launch
+            # slab reduction (+ the average over the ranks, inside the launch) + norm + clip + Adam + LinearLR + periodic
+            # hard target update (:50-57) in ONE launch
             ops.reduce_adam(self.slabs, S, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
-                            self.opt_sync, target=model.target_flat, target_every=self.sync_frequency)
+                            self.opt_sync, target=model.target_flat, target_every=self.sync_frequency,
+                            exchange=self.gradient_exchange())
             return S
         ops.grad_reduce(self.slabs, S, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
@@ -100,7 +102,7 @@ class DQN_Learner(Learner):
                 ops.sum_partials_batched(self._phase_partials, S, 8, self._epoch_sums, n_epochs, 32 * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
-            if not (self.distributed_training and self.world_size > 1):
+            if not self.needs_collective():
                 torch.cuda.synchronize()                    # ... and is then captured for the following calls
                 g = ops.Graph()
                 with g:

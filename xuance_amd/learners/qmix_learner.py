@@ -157,9 +157,10 @@ class QMIX_Learner(Learner):
         gradient is all-reduced between the reduction and the optimiser launch."""
         m, opt, P = self.model, self.optimizer, self.model.params.P
         clip = self.grad_clip_norm if self.use_grad_clip else 0.0
-        if not (self.distributed_training and self.world_size > 1) and P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
+        if not self.needs_collective() and P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
             ops.reduce_adam(self.slabs, S, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
-                            self.opt_sync, target=m.target_flat, target_every=self.sync_frequency)
+                            self.opt_sync, target=m.target_flat, target_every=self.sync_frequency,
+                            exchange=self.gradient_exchange())
             return
         ops.grad_reduce(self.slabs, S, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
@@ -281,7 +282,7 @@ class QMIX_Learner(Learner):
                 ops.sum_partials_batched(self._phase_partials, B, 8, self._epoch_sums, n_epochs, B * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
-            if not (self.distributed_training and self.world_size > 1):
+            if not self.needs_collective():
                 torch.cuda.synchronize()                    # ... and is then captured for the following calls (the gradient
                 g = ops.Graph()                             #     all-reduce of the multi-GPU path cannot be captured)
                 with g:
@@ -358,7 +359,7 @@ class QMIX_Learner(Learner):
                 ops.sum_partials_batched(self._phase_partials, T * B, 8, self._epoch_sums, n_epochs, T * B * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()
-            if not (self.distributed_training and self.world_size > 1) and getattr(self.config, "use_hip_graph", True):
+            if not self.needs_collective() and getattr(self.config, "use_hip_graph", True):
                 torch.cuda.synchronize()
                 g = ops.Graph()
                 with g:
