@@ -243,6 +243,12 @@ def main():
                       "env": "device-resident CartPole-v1 (xrl_cartpole_step)", "parallelism": "dp%d" % world,
                       "env_steps_per_step": world * args.n_envs * args.horizon,
                       "last_info": {k: round(float(v), 6) for k, v in info.items()}}}
+    if world > 1:      # which of the three ways (chosen by self-tests at start-up, xuance_amd/dist.py) averaged the gradients
+        out["config"]["gradient_average"] = (
+            "inside the optimiser launch through IPC-mapped exchange buffers (xrl_reduce_adam_exchange; no collective call on the data path)"
+            if getattr(agent.learner, "_xc", None) is not None else
+            "process-group all-reduce captured in the update graph" if getattr(agent, "_whole_phase_graph", False) else
+            "process-group all-reduce between update graphs cut at the collectives")
     # the update-phase rate separately (transitions consumed per second by GAE + sampling + the
     # minibatch updates), so that the simulator's share is separable.  Timed after the contract region, same graphs.
     phases = None

@@ -210,6 +210,8 @@ typedef struct {
                              * launch performs is a multiple of target_every, target[i] <- new parameter
                              * (copy_target(), dqn_learner.py:56-57, qmix_learner.py:105-106; same as xrl_sync_target) */
     float* target;          /* NULL or [P] */
+    float* target_image;    /* NULL, or a derived layout of the TARGET: whenever target[i] is refreshed, so is
+                             * target_image[map[0][i]] (map[0][i] < 0: skip) */
     int64_t fold_off;       /* xrl_reduce_adam only: slab columns [fold_off, fold_off + fold_len) are a second partial of */
     int32_t fold_len;       /* columns [0, fold_len) (ppo_split_kernel's critic-role first-layer gradient); 0 = none */
     int32_t pad;
@@ -630,6 +632,58 @@ typedef struct {
                                 * arrays one time slot further (caller passes offset pointers). */
 } xrl_qmix_t;
 int xrl_qmix_mix_td(const xrl_qmix_t* p, xrl_stream_t stream);
+
+/* The whole QMIX_Learner.update for feed-forward agents in ONE launch (qmix_learner.py:24-112 between the sampled batch and
+ * optimizer.step(); heads/q_mix_head.py:28-95; value_factorization.py:66-150): per-agent Q networks eval(obs) /
+ * eval(next_obs) / target(next_obs), masked (double-)Q target action, eval and target hyper-networks, monotonic mixing,
+ * TD target, MSE loss, and the backward pass down to every weight gradient.  The batch is cut into groups of items_per_wg
+ * transitions; workgroup g keeps its group's activations in LDS from the observations to the gradients and writes its
+ * partial of every parameter gradient to slabs[g] (sum the ceil(B / items_per_wg) slabs with xrl_reduce_adam /
+ * xrl_grad_reduce: fixed order, bit-deterministic).  Same numbers as the layered path (xrl_linear_fwd x3, xrl_qmix_mix_td,
+ * xrl_linear_bwd_*) up to fp32 summation order.  Weights are read from two weight IMAGES (eval, target) that already have
+ * the padded LDS layout, so staging them is a straight copy; the gradient of the parameter at flat offset o (w_off / b_off /
+ * mix_off, torch nn.Linear layout [out][in]) is written to slab offset o. */
+#define XRL_QF_MAX_LAYERS 4
+enum { XRL_QF_FIRST_W = 0, XRL_QF_FIRST_B, XRL_QF_B1_W, XRL_QF_B1_B, XRL_QF_W1_W, XRL_QF_W1_B, XRL_QF_W2_W, XRL_QF_W2_B,
+       XRL_QF_B2_W, XRL_QF_B2_B, XRL_QF_N_OFF };
+typedef struct {          /* float offsets inside a weight image (xrl_qmix_fused_layout): agent block, then mixer block */
+    int32_t w[XRL_QF_MAX_LAYERS], b[XRL_QF_MAX_LAYERS], ldw[XRL_QF_MAX_LAYERS];   /* agent layer l: W_l [N_l][ldw_l], b_l; block offsets */
+    int32_t mw[5], mb[5], mldw[5];                 /* mixer: FIRST, B1, W1, W2, B2 (offsets inside the mixer block) */
+    int32_t agent_floats, mixer_floats;            /* block sizes; the mixer block starts at agent_floats */
+} xrl_qf_image_t;
+typedef struct {
+    const float* img_eval;      /* weight image of the eval networks  [agent_floats + mixer_floats], 16-byte aligned: element */
+    const float* img_target;    /* (n, k) of a matrix at block offset w + n * ldw + k, padding zero; keep them current with
+                                 * xrl_mirrors_t (map = parameter index -> image index) and .target_image */
+    int32_t n_layers;           /* nn.Linear layers of the agent network (representation + Q head), <= XRL_QF_MAX_LAYERS */
+    int32_t act;                /* XRL_ACT_* after every layer but the last */
+    int32_t dims[XRL_QF_MAX_LAYERS + 1];   /* dims[0] = obs_dim ... dims[n_layers] = n_actions */
+    int32_t pad0;
+    int64_t w_off[XRL_QF_MAX_LAYERS], b_off[XRL_QF_MAX_LAYERS];
+    int64_t mix_off[XRL_QF_N_OFF];          /* FIRST = [hyper_w_1.0; hyper_w_2.0; hyper_b_2.0] stacked ([3 HH][S], biases [3 HH]);
+                                             * B1 = hyper_b_1 [H][S]; W1 = hyper_w_1.2 [N H][HH]; W2 = hyper_w_2.2 [H][HH];
+                                             * B2 = hyper_b_2.2 [1][HH] */
+    int32_t N, A, S, H, HH;     /* agents, actions, state dim, mixer embed dim (<= 64), hyper hidden dim */
+    int32_t B, items_per_wg, double_q;
+    const float* obs;           /* [B][N][obs_dim] */
+    const float* obs_next;
+    const float* state;         /* [B][S] */
+    const float* state_next;
+    const float* actions;       /* [B][N] f32 */
+    const float* rewards;       /* [B][N] */
+    const float* terminals;     /* [B][N] f32 0/1 */
+    const float* agent_mask;    /* [B][N] f32 0/1 */
+    const float* avail_next;    /* NULL or [B][N][A] f32 0/1 */
+    float* slabs;               /* [ceil(B / items_per_wg)][slab_stride] */
+    int64_t slab_stride;
+    double* partials;           /* [B][8]: (q_tot_eval - y)^2, q_tot_eval, 0... (as xrl_qmix_mix_td) */
+    float* diag;                /* NULL or [3][B]: q_tot_eval, q_tot_next, q_tot_target */
+    float gamma, pad1;
+    long long* dbg;             /* NULL, or [16] cycle-counter stamps of workgroup 0 at the phase boundaries (diagnostics) */
+} xrl_qmix_fused_t;
+int xrl_qmix_fused_update(const xrl_qmix_fused_t* p, xrl_stream_t stream);
+int xrl_qmix_fused_lds_bytes(const xrl_qmix_fused_t* p);   /* LDS the launch needs (must be <= 160 KB), -1 on bad dims */
+int xrl_qmix_fused_layout(const xrl_qmix_fused_t* p, xrl_qf_image_t* out);   /* needs n_layers, dims, N, S, H, HH only */
 
 /* One-layer GRU over whole sequences, time-major (Basic_RNN, rl_models/representations/rnn.py:52-77; nn.GRU built by
  * rl_models/modules/layers.py:79-98; the recurrent agents of qmix/sc2/3m.yaml).  gi = x W_ih^T + b_ih for all steps is

@@ -77,9 +77,12 @@ def test_dqn_learner_vs_reference_fixture(name):
                   ("evalQ", "predictQ", "targetQ"), "Qloss")
 
 
+@pytest.mark.parametrize("fused,items", [(True, 1), (True, 3), (True, 4), (False, 0)])
 @pytest.mark.parametrize("double_q,size", [(True, None), (False, None), (True, "c5")])
-def test_qmix_learner_vs_reference_fixture(double_q, size):
-    """size "c5": the batch of configs/qmix/sc2/3m.yaml:32 (32 transitions x 3 agents)."""
+def test_qmix_learner_vs_reference_fixture(double_q, size, fused, items):
+    """size "c5": the batch of configs/qmix/sc2/3m.yaml:32 (32 transitions x 3 agents).  fused: the whole update as ONE
+    launch (xrl_qmix_fused_update; `items` transitions per workgroup: 1 = the default, 3 = a ragged last group, 4 = eight
+    groups) vs the layered path (grouped GEMM launches + xrl_qmix_mix_td): both against the reference's numbers at 1e-5."""
     from xuance_amd.nets import MixingQNet
     from xuance_amd.learners import QMIX_Learner
     g = load_golden(f"qmix_ff_{'double' if double_q else 'single'}" + (f"_{size}" if size else ""))
@@ -92,8 +95,9 @@ def test_qmix_learner_vs_reference_fixture(double_q, size):
     cb = Capture()
     learner = QMIX_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
                                     use_grad_clip=True, grad_clip_norm=float(gclip), double_q=bool(dq),
-                                    use_actions_mask=True, use_parameter_sharing=True, n_epochs=8), keys, net, cb)
-    assert learner.total_iters == int(total)
+                                    use_actions_mask=True, use_parameter_sharing=True, n_epochs=8,
+                                    use_fused_qmix_update=fused, fused_qmix_items_per_wg=items), keys, net, cb)
+    assert learner.total_iters == int(total) and learner.fused_eligible() == fused
 
     def call(b):
         # hand the learner the reference buffer's nested format: field -> agent -> [B, ...]

@@ -99,11 +99,14 @@ def qmix_3m(rnn, n=64, steps=None, ref=None):
                        % (n, what, "%d episodes" % n if rnn else "vector step"),
            "value": round(env_steps / dt, 1), "unit": "env-steps/s", "update_us": round(upd_us, 2),
            "env_steps_timed": int(env_steps), "seconds": round(dt, 3),
-           "roofline": {"bound": "mfma", "kernel": "update graph (xrl::gemm_f32_kernel launches + " + ("xrl::gru_*_kernel + " if rnn else "")
-                                                    + "xrl::qmix_prefetch_kernel + xrl::reduce_adam_kernel)",
+           "roofline": {"bound": "mfma", "kernel": ("update graph (xrl::gemm_f32_kernel launches + xrl::gru_*_kernel + xrl::qmix_prefetch_kernel + "
+                                                    "xrl::reduce_adam_kernel)") if rnn else
+                                                   "update graph (draw+gather, xrl::qmix_fused_kernel, xrl::reduce_adam_kernel)",
                         "achieved": round(tf, 4), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 5),
                         "traffic": None, "avg_launch_us": round(upd_us, 2), "algorithmic_flops_per_launch": flops,
-                        "note": "one 'launch' = one whole update (a graph of ~9 kernels); launch-latency-bound at batch 32, see DESIGN.md section 3"}}
+                        "note": ("one 'launch' = one whole update (a graph of ~9 kernels); launch-latency-bound at batch 32, see DESIGN.md section 3")
+                                if rnn else "one 'launch' = one whole update = 3 kernels; the fused kernel is VALU fp32 on 32 workgroups (one "
+                                            "transition each), latency-bound: DESIGN.md section 3"}}
     if ref:
         out["cpu_baseline"] = ref
     return out

@@ -186,6 +186,22 @@ class PpoFused(C.Structure):
                 ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p)]
 
 
+class QfImage(C.Structure):
+    _fields_ = [("w", c_int32 * 4), ("b", c_int32 * 4), ("ldw", c_int32 * 4), ("mw", c_int32 * 5), ("mb", c_int32 * 5),
+                ("mldw", c_int32 * 5), ("agent_floats", c_int32), ("mixer_floats", c_int32)]
+
+
+class QmixFused(C.Structure):
+    _fields_ = [("img_eval", c_void_p), ("img_target", c_void_p), ("n_layers", c_int32), ("act", c_int32), ("dims", c_int32 * 5),
+                ("pad0", c_int32), ("w_off", c_int64 * 4), ("b_off", c_int64 * 4), ("mix_off", c_int64 * 10),
+                ("N", c_int32), ("A", c_int32), ("S", c_int32), ("H", c_int32), ("HH", c_int32),
+                ("B", c_int32), ("items_per_wg", c_int32), ("double_q", c_int32),
+                ("obs", c_void_p), ("obs_next", c_void_p), ("state", c_void_p), ("state_next", c_void_p), ("actions", c_void_p),
+                ("rewards", c_void_p), ("terminals", c_void_p), ("agent_mask", c_void_p), ("avail_next", c_void_p),
+                ("slabs", c_void_p), ("slab_stride", c_int64), ("partials", c_void_p), ("diag", c_void_p),
+                ("gamma", c_float), ("pad1", c_float), ("dbg", c_void_p)]
+
+
 class Exchange(C.Structure):
     _fields_ = [("base", c_void_p * 8), ("stride4", c_int64), ("world", c_int32), ("rank", c_int32),
                 ("max_spins", c_int32), ("pad", c_int32), ("inv_world", c_float), ("pad2", c_float)]
@@ -201,7 +217,7 @@ class MarlGate(C.Structure):
 
 class Mirrors(C.Structure):
     _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("target_every", c_int32), ("target", c_void_p),
-                ("fold_off", c_int64), ("fold_len", c_int32), ("pad", c_int32)]
+                ("target_image", c_void_p), ("fold_off", c_int64), ("fold_len", c_int32), ("pad", c_int32)]
 
 
 class MarlAct(C.Structure):
@@ -227,6 +243,9 @@ _SIGS = {
     "xrl_episode_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_episode_gather": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_marl_loop_gate": [C.POINTER(MarlGate), c_void_p],
+    "xrl_qmix_fused_update": [C.POINTER(QmixFused), c_void_p],
+    "xrl_qmix_fused_lds_bytes": [C.POINTER(QmixFused)],
+    "xrl_qmix_fused_layout": [C.POINTER(QmixFused), C.POINTER(QfImage)],
     "xrl_host_device_pointer": [c_void_p, C.POINTER(c_void_p)],
     "xrl_per_store": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_void_p],
     "xrl_per_sample": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

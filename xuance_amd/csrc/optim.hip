@@ -129,7 +129,10 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
 #pragma unroll
         for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
             if (q < mir.n) { const int j = mir.map[q][i]; if (j >= 0) mir.dst[q][j] = pn; }
-        if (mir.target && mir.target_every > 0 && step % mir.target_every == 0) mir.target[i] = pn;
+        if (mir.target && mir.target_every > 0 && step % mir.target_every == 0) {
+            mir.target[i] = pn;
+            if (mir.target_image) { const int j = mir.map[0][i]; if (j >= 0) mir.target_image[j] = pn; }
+        }
     }
     // The last block to finish advances the device-resident state (every block has consumed the old state by
     // the time it takes its ticket; the next launch observes the new state across the kernel boundary).
@@ -326,7 +329,10 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
 #pragma unroll
         for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
             if (q < mir.n) { const int j = mir.map[q][i]; if (j >= 0) mir.dst[q][j] = pn; }
-        if (mir.target && mir.target_every > 0 && step % mir.target_every == 0) mir.target[i] = pn;
+        if (mir.target && mir.target_every > 0 && step % mir.target_every == 0) {
+            mir.target[i] = pn;
+            if (mir.target_image) { const int j = mir.map[0][i]; if (j >= 0) mir.target_image[j] = pn; }
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -361,6 +367,7 @@ extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t
     if (mirrors) mir = *mirrors;
     XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);
     for (int q = 0; q < mir.n; ++q) XRL_CHECK_ARG(mir.map[q] && mir.dst[q]);
+    XRL_CHECK_ARG(mir.target_image == nullptr || (mir.n >= 1 && mir.target));
     XRL_CHECK_ARG(mir.fold_len >= 0 && (mir.fold_len & 3) == 0 && (mir.fold_off & 3) == 0 &&
                   (mir.fold_len == 0 || (mir.fold_off >= P && mir.fold_off + mir.fold_len <= slab_stride && mir.fold_len <= P)));
     if (exchange && exchange->world > 1) {

@@ -1,0 +1,543 @@
+// QMIX_Learner.update for feed-forward agents (multi_agent_rl/qmix_learner.py:24-112; heads/q_mix_head.py:28-95;
+// value_factorization.py:66-150) as ONE launch: per-agent Q networks (eval on obs, eval + target on next_obs), masked
+// double-Q target action, the eval / target hyper-networks, monotonic mixing, TD error, and the whole backward pass down
+// to every weight gradient.
+//
+// Shape of the problem: 32 transitions x 3 agents, networks 30-64-64-9 and 48-{32,..}-{96,32,1}: ~9 MFLOP and 69 KB of
+// parameters per update.  The layered path spends 68 us on it in 9 launches, every one of them latency-bound.  Nothing in
+// the update couples two transitions except the constant 1/B of the mean, so the batch is cut into groups of
+// `items_per_wg` transitions and a workgroup carries its group through everything with all activations in LDS ("per-agent
+// Q in LDS"): no grid barrier, no atomics; workgroup g writes its weight-gradient partial to slab g and xrl_reduce_adam
+// sums the slabs in fixed order.  At 12..24 rows per workgroup an MFMA tile would be mostly padding and the chain is
+// latency-bound either way, so the products are plain FMA loops over LDS rows.  What decides the time is the number of
+// DEPENDENT global round trips: a first version that read each layer's weights from L2 inside its product made ~30 of them
+// (75 us, slower than the layered path).  So the weights come to LDS too, in two bursts with every load in flight at once:
+// [eval agent | target agent | target mixer] at the start, and the eval mixer over the target mixer's space once the
+// target hyper-networks have run (106 KB of weights + ~30 KB of activations at 4 transitions per workgroup).
+#include "common.h"
+
+// (the library is built with -ffp-contract=off for the kernels that must round like NumPy; nothing here has to, and the
+// products are VALU-bound: fused multiply-adds halve their instruction count)
+#pragma clang fp contract(fast)
+
+namespace xrl {
+
+constexpr int QF_THREADS = 1024;                // 16 waves: independent products run side by side on their own thread ranges
+constexpr int QF_PAD = 4;                     // LDS rows are allocated in multiples of 4 (the 4-row products read whole groups)
+
+__device__ __forceinline__ float qf_elu(float x) { return x > 0.f ? x : expm1f(x); }
+
+// The launch runs ~40 small matrix products ONCE each on a handful of workgroups, and the instruction cache is cold at every
+// launch: with the product routines inlined at every call site the kernel was 70 KB of straight-line code and spent its
+// time fetching instructions (190 k cycles, every phase 10-20x its arithmetic).  The routines are therefore real functions
+// (one copy each, reused by every product); their LDS operands are offsets into the one dynamic LDS block so that the
+// accesses stay ds_read / ds_write.
+extern __shared__ __attribute__((aligned(16))) float qf_lds[];
+typedef const __attribute__((address_space(1))) float* QfGlobalIn;      // (a generic pointer argument would mean flat accesses)
+typedef __attribute__((address_space(1))) float* QfGlobalOut;
+typedef float qf_f4 __attribute__((ext_vector_type(4)));
+
+// n4 float4 from a weight image in global memory -> LDS offset dst: the images have the LDS layout already (rows padded to
+// pad4(K) + 4 floats, see xrl_qmix_fused_layout), so a stage is a straight copy with eight loads in flight per thread and no
+// index arithmetic (a first version re-laid the nn.Linear matrices on the way: one exposed memory latency per matrix and a
+// division per element made the start-up burst 34 k cycles)
+__device__ __noinline__ void qf_copy(QfGlobalIn src, int dst, int n4) {
+    float* lds = qf_lds;
+    const __attribute__((address_space(1))) qf_f4* g = reinterpret_cast<const __attribute__((address_space(1))) qf_f4*>(src);
+    for (int i = threadIdx.x; i < n4; i += 8 * QF_THREADS) {
+        qf_f4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int q = i + j * QF_THREADS; v[j] = 0.f; if (q < n4) v[j] = g[q]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int q = i + j * QF_THREADS; if (q < n4) *reinterpret_cast<qf_f4*>(lds + dst + 4 * q) = v[j]; }
+    }
+}
+
+template <int QF_RB>
+__device__ __forceinline__ void qf_lin_fwd_t(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
+                                             int tid0) {
+    float* lds = qf_lds;
+    const int n_rg = (rows + QF_RB - 1) / QF_RB, K4 = (K + 3) & ~3;
+    for (int item = (threadIdx.x - tid0) & (QF_THREADS - 1); item < Nout * n_rg; item += QF_THREADS) {
+        const int n = item % Nout, r0 = (item / Nout) * QF_RB;
+        const float* w = lds + W + n * ldw;
+        const float* x0 = lds + in + r0 * ldi;
+        float acc[QF_RB];
+#pragma unroll
+        for (int j = 0; j < QF_RB; ++j) acc[j] = 0.f;
+#pragma unroll(QF_RB == 1 ? 4 : 1)
+        for (int k = 0; k < K4; k += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + k);
+#pragma unroll
+            for (int j = 0; j < QF_RB; ++j) {
+                const float4 x = *reinterpret_cast<const float4*>(x0 + j * ldi + k);   // rows padded: readable
+                acc[j] += x.x * wv.x; acc[j] += x.y * wv.y; acc[j] += x.z * wv.z; acc[j] += x.w * wv.w;
+            }
+        }
+        const float bias = lds[b + n];
+#pragma unroll
+        for (int j = 0; j < QF_RB; ++j)
+            if (r0 + j < rows) lds[out + (r0 + j) * ldo + n] = act_apply(acc[j] + bias, act);
+    }
+}
+
+// (few rows: one row per work item spreads the product over more threads; many rows: four rows share every weight read.
+//  tid0, a multiple of 64: the thread that takes work item 0 -- products between two barriers get disjoint thread ranges)
+__device__ __noinline__ void qf_lin_fwd_fn(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
+                                           int tid0) {
+    if (Nout * rows > 512) qf_lin_fwd_t<4>(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+    else qf_lin_fwd_t<1>(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+}
+
+// does any lane of this wave get one of n_items work items when item 0 goes to thread tid0?  (a call costs every wave that
+// makes it a few hundred cycles even when it finds nothing to do -- with ~45 products per launch that was most of the time)
+__device__ __forceinline__ bool qf_wave_in(int n_items, int tid0) {
+    return (int)(((threadIdx.x & ~63u) - (unsigned)tid0) & (QF_THREADS - 1)) < n_items;
+}
+__device__ __forceinline__ void qf_lin_fwd(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
+                                           int tid0) {
+    if (qf_wave_in(Nout * rows, tid0)) qf_lin_fwd_fn(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+}
+
+// dx[r][k] = (sum_n dz[r][n] W[n][k]) * act'(y[r][k])      (y = the layer input's own activation output, < 0: none)
+template <int QF_RB>
+__device__ __forceinline__ void qf_lin_bwd_data_t(int W, int ldw, int K, int Nout, int dz, int ldz, int rows, int dx, int ldx, int y,
+                                                  int ldy, int act, int tid0) {
+    float* lds = qf_lds;
+    const int n_rg = (rows + QF_RB - 1) / QF_RB;
+    for (int item = (threadIdx.x - tid0) & (QF_THREADS - 1); item < K * n_rg; item += QF_THREADS) {
+        const int k = item % K, r0 = (item / K) * QF_RB;
+        float acc[QF_RB];
+#pragma unroll
+        for (int j = 0; j < QF_RB; ++j) acc[j] = 0.f;
+#pragma unroll(QF_RB == 1 ? 8 : 2)
+        for (int n = 0; n < Nout; ++n) {
+            const float wv = lds[W + n * ldw + k];
+#pragma unroll
+            for (int j = 0; j < QF_RB; ++j) acc[j] += lds[dz + (r0 + j) * ldz + n] * wv;
+        }
+#pragma unroll
+        for (int j = 0; j < QF_RB; ++j)
+            if (r0 + j < rows) lds[dx + (r0 + j) * ldx + k] = acc[j] * (y >= 0 ? act_grad_from_out(lds[y + (r0 + j) * ldy + k], act) : 1.f);
+    }
+}
+
+__device__ void qf_lin_bwd_data_fn(int W, int ldw, int K, int Nout, int dz, int ldz, int rows, int dx, int ldx, int y, int ldy, int act,
+                                   int tid0);
+__device__ __forceinline__ void qf_lin_bwd_data(int W, int ldw, int K, int Nout, int dz, int ldz, int rows, int dx, int ldx, int y,
+                                                int ldy, int act, int tid0) {
+    if (qf_wave_in(K * rows, tid0)) qf_lin_bwd_data_fn(W, ldw, K, Nout, dz, ldz, rows, dx, ldx, y, ldy, act, tid0);
+}
+__device__ __noinline__ void qf_lin_bwd_data_fn(int W, int ldw, int K, int Nout, int dz, int ldz, int rows, int dx, int ldx, int y,
+                                                int ldy, int act, int tid0) {
+    if (K * rows > 512) qf_lin_bwd_data_t<4>(W, ldw, K, Nout, dz, ldz, rows, dx, ldx, y, ldy, act, tid0);
+    else qf_lin_bwd_data_t<1>(W, ldw, K, Nout, dz, ldz, rows, dx, ldx, y, ldy, act, tid0);
+}
+
+// dW[n][k] = sum_r dz[r][n] in[r][k],  db[n] = sum_r dz[r][n]   -> this workgroup's slab (every element written once)
+__device__ void qf_lin_bwd_weight_fn(QfGlobalOut dW, QfGlobalOut db, int K, int Nout, int dz, int ldz, int in, int ldi, int rows, int tid0);
+__device__ __forceinline__ void qf_lin_bwd_weight(QfGlobalOut dW, QfGlobalOut db, int K, int Nout, int dz, int ldz, int in, int ldi,
+                                                  int rows, int tid0) {
+    if (qf_wave_in(Nout * ((K + 3) / 4), tid0) || qf_wave_in(Nout, tid0 + 512))
+        qf_lin_bwd_weight_fn(dW, db, K, Nout, dz, ldz, in, ldi, rows, tid0);
+}
+__device__ __noinline__ void qf_lin_bwd_weight_fn(QfGlobalOut dW, QfGlobalOut db, int K, int Nout, int dz, int ldz, int in, int ldi,
+                                                  int rows, int tid0) {
+    float* lds = qf_lds;
+    const int kq = (K + 3) / 4;
+    const bool vec = (K & 3) == 0 && (((uintptr_t)dW & 15) == 0);
+    for (int item = (threadIdx.x - tid0) & (QF_THREADS - 1); item < Nout * kq; item += QF_THREADS) {
+        const int q = item % kq, n = item / kq;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int r = 0; r < rows; ++r) {
+            const float g = lds[dz + r * ldz + n];
+            const float4 x = *reinterpret_cast<const float4*>(lds + in + r * ldi + 4 * q);
+            acc.x += g * x.x; acc.y += g * x.y; acc.z += g * x.z; acc.w += g * x.w;
+        }
+        QfGlobalOut o = dW + (size_t)n * K + 4 * q;
+        if (vec) { qf_f4 t; t.x = acc.x; t.y = acc.y; t.z = acc.z; t.w = acc.w; *reinterpret_cast<__attribute__((address_space(1))) qf_f4*>(o) = t; }
+        else {
+            if (4 * q + 0 < K) o[0] = acc.x;
+            if (4 * q + 1 < K) o[1] = acc.y;
+            if (4 * q + 2 < K) o[2] = acc.z;
+            if (4 * q + 3 < K) o[3] = acc.w;
+        }
+    }
+    for (int n = (threadIdx.x - tid0 - 512) & (QF_THREADS - 1); n < Nout; n += QF_THREADS) {     // (other threads than item 0's)
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += lds[dz + r * ldz + n];
+        db[n] = s;
+    }
+}
+
+struct QfLds {                      // offsets (floats) into the dynamic LDS block; host and device compute them alike
+    int x0, x1, h[XRL_QF_MAX_LAYERS], q, qne, qnt, t0, t1, u0, u1, s0, s1, hid_e, raw_e, hid_t, raw_t, d_raw, d_hid, total;
+    int ld[XRL_QF_MAX_LAYERS + 1], ldmax, lds, ldh, ldr, rows_pad;
+    int we[XRL_QF_MAX_LAYERS], be[XRL_QF_MAX_LAYERS], wt[XRL_QF_MAX_LAYERS], bt[XRL_QF_MAX_LAYERS], ldw[XRL_QF_MAX_LAYERS];
+    int mw[5], mb[5], mldw[5];      // the mixer staged at the moment (target first, then eval): FIRST, B1, W1, W2, B2
+    int act_i, rew, term, amask, avail, clear_end;
+    int ag_e, ag_t, mix;            // LDS offsets of the three weight blocks (each the copy of one image block)
+};
+
+__host__ __device__ inline int qf_pad4(int w) { return (w + 3) / 4 * 4; }
+
+// the weight images: agent block [W_0 .. W_{L-1} | b_0 .. b_{L-1}], mixer block [FIRST B1 W1 W2 B2 | their biases]; matrix
+// rows padded to pad4(K) + 4 floats (conflict-free 16-byte LDS reads with one row per lane), bias vectors to quads
+__host__ __device__ inline void qf_image_layout(const xrl_qmix_fused_t& p, xrl_qf_image_t& im) {
+    int off = 0;
+    for (int l = 0; l < XRL_QF_MAX_LAYERS; ++l) { im.w[l] = im.b[l] = im.ldw[l] = 0; }
+    for (int l = 0; l < p.n_layers; ++l) { im.ldw[l] = qf_pad4(p.dims[l]) + 4; im.w[l] = off; off += p.dims[l + 1] * im.ldw[l]; }
+    for (int l = 0; l < p.n_layers; ++l) { im.b[l] = off; off += qf_pad4(p.dims[l + 1]); }
+    im.agent_floats = off;
+    const int mK[5] = {p.S, p.S, p.HH, p.HH, p.HH}, mN[5] = {3 * p.HH, p.H, p.N * p.H, p.H, 1};
+    off = 0;
+    for (int i = 0; i < 5; ++i) { im.mldw[i] = qf_pad4(mK[i]) + 4; im.mw[i] = off; off += mN[i] * im.mldw[i]; }
+    for (int i = 0; i < 5; ++i) { im.mb[i] = off; off += qf_pad4(mN[i]); }
+    im.mixer_floats = off;
+}
+
+__host__ __device__ inline QfLds qf_layout(const xrl_qmix_fused_t& p) {
+    QfLds L;
+    const int rows = p.items_per_wg * p.N;
+    L.rows_pad = (rows + QF_PAD - 1) / QF_PAD * QF_PAD;         // the 4-row products read whole row groups
+    const int bw_pad = (p.items_per_wg + QF_PAD - 1) / QF_PAD * QF_PAD;
+    int off = 0, ldmax = 0;
+    for (int l = 0; l <= p.n_layers; ++l) { L.ld[l] = qf_pad4(p.dims[l]); if (l > 0 && L.ld[l] > ldmax) ldmax = L.ld[l]; }
+    L.ldmax = ldmax;
+    L.x0 = off; off += L.rows_pad * L.ld[0];
+    L.x1 = off; off += L.rows_pad * L.ld[0];
+    for (int l = 1; l < p.n_layers; ++l) { L.h[l] = off; off += L.rows_pad * L.ld[l]; }
+    const int ldq = L.ld[p.n_layers];
+    L.q = off; off += L.rows_pad * ldq;
+    L.qne = off; off += L.rows_pad * ldq;
+    L.qnt = off; off += L.rows_pad * ldq;
+    L.t0 = off; off += L.rows_pad * ldmax;
+    L.t1 = off; off += L.rows_pad * ldmax;
+    L.u0 = off; off += L.rows_pad * ldmax;
+    L.u1 = off; off += L.rows_pad * ldmax;
+    L.lds = qf_pad4(p.S); L.ldh = qf_pad4(3 * p.HH + p.H); L.ldr = qf_pad4(p.N * p.H + p.H + 1);
+    L.s0 = off; off += bw_pad * L.lds;
+    L.s1 = off; off += bw_pad * L.lds;
+    L.hid_e = off; off += bw_pad * L.ldh;
+    L.raw_e = off; off += bw_pad * L.ldr;
+    L.hid_t = off; off += bw_pad * L.ldh;
+    L.raw_t = off; off += bw_pad * L.ldr;
+    L.d_raw = off; off += bw_pad * L.ldr;
+    L.d_hid = off; off += bw_pad * L.ldh;
+    L.act_i = off; off += L.rows_pad;
+    L.rew = off; off += L.rows_pad;
+    L.term = off; off += L.rows_pad;
+    L.amask = off; off += L.rows_pad;
+    L.avail = off; off += L.rows_pad * qf_pad4(p.A);
+    L.clear_end = off;                                          // below: whole copies of image blocks (their padding is zero)
+    xrl_qf_image_t im;
+    qf_image_layout(p, im);
+    L.ag_e = off; off += im.agent_floats;
+    L.ag_t = off; off += im.agent_floats;
+    L.mix = off; off += im.mixer_floats;
+    for (int l = 0; l < p.n_layers; ++l) {
+        L.ldw[l] = im.ldw[l];
+        L.we[l] = L.ag_e + im.w[l]; L.be[l] = L.ag_e + im.b[l];
+        L.wt[l] = L.ag_t + im.w[l]; L.bt[l] = L.ag_t + im.b[l];
+    }
+    for (int i = 0; i < 5; ++i) { L.mw[i] = L.mix + im.mw[i]; L.mb[i] = L.mix + im.mb[i]; L.mldw[i] = im.mldw[i]; }
+    L.total = off;
+    return L;
+}
+
+struct QfArgs { xrl_qmix_fused_t p; QfLds L; int agent4, mixer4, pad[2]; };   // L = qf_layout(p), block sizes in float4: from the host
+typedef const __attribute__((address_space(4))) QfArgs QfArgsK;
+typedef const __attribute__((address_space(4))) xrl_qmix_fused_t* QfP;
+typedef const __attribute__((address_space(4))) QfLds* QfL;
+
+// hyper-networks of the mixer staged in LDS (q_mix_head.py:50-64), one layer per call (no barrier inside):
+// A: hid = [relu(W_f s + b_f) (3 HH) | W_b1 s + b_b1 (H)];  B: raw = [w1 | w2 | b2] from hid
+__device__ __forceinline__ void qf_hyper_layer(QfP p, QfL L, int layer, int s, int hid, int raw, int bw, int tid0) {
+    const int HH = p->HH, H = p->H, N = p->N;
+    if (layer == 0) {
+        qf_lin_fwd(L->mw[0], L->mldw[0], L->mb[0], p->S, 3 * HH, s, L->lds, bw, hid, L->ldh, XRL_ACT_RELU, tid0);
+        qf_lin_fwd(L->mw[1], L->mldw[1], L->mb[1], p->S, H, s, L->lds, bw, hid + 3 * HH, L->ldh, XRL_ACT_NONE, tid0 + 128);
+    } else {
+        qf_lin_fwd(L->mw[2], L->mldw[2], L->mb[2], HH, N * H, hid, L->ldh, bw, raw, L->ldr, XRL_ACT_NONE, tid0);
+        qf_lin_fwd(L->mw[3], L->mldw[3], L->mb[3], HH, H, hid + HH, L->ldh, bw, raw + N * H, L->ldr, XRL_ACT_NONE, tid0 + 128);
+        qf_lin_fwd(L->mw[4], L->mldw[4], L->mb[4], HH, 1, hid + 2 * HH, L->ldh, bw, raw + N * H + H, L->ldr, XRL_ACT_NONE, tid0 + 192);
+    }
+}
+
+__global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_unused) {
+    // the arguments are read where they lie, in the kernel argument segment (scalar loads, any index): touching the by-value
+    // parameter with a run-time index would make the compiler copy it to scratch memory first
+    const QfArgsK* args = (const QfArgsK*)__builtin_amdgcn_kernarg_segment_ptr();
+    QfP p = &args->p;
+    QfL L = &args->L;
+    float* lds = qf_lds;
+#define QF_STAMP(i) do { if (p->dbg && blockIdx.x == 0 && threadIdx.x == 0) p->dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+    QF_STAMP(0);
+    const int N = p->N, A = p->A, H = p->H, HH = p->HH, nl = p->n_layers;
+    const int b0 = blockIdx.x * p->items_per_wg;
+    const int bw = min(p->items_per_wg, p->B - b0), rows = bw * N, r_base = b0 * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ldq = L->ld[nl];
+    QfGlobalOut gslab = (QfGlobalOut)(p->slabs + (size_t)blockIdx.x * p->slab_stride);
+
+    // ---- 0. ONE burst of global loads: every thread first issues its share of the weight blocks [target mixer | target agent
+    //         | eval agent] (float4 chunks of the images) and of the input words (observations, states, per-row scalars,
+    //         availability), then the activations' zero padding is written while those loads are in flight (the products read
+    //         whole row groups and whole k quads), and only then the loaded values go to LDS: one memory latency in all
+    const int ldav = qf_pad4(A), D = p->dims[0], S = p->S;
+    const int n_obs = rows * D, n_st = bw * S, n_av = rows * A;
+    const int seg1 = n_obs, seg2 = 2 * n_obs, seg3 = seg2 + n_st, seg4 = seg3 + n_st, seg5 = seg4 + 4 * rows, n_in = seg5 + n_av;
+    auto in_word = [&](int w, int& dst) -> const float* {               // input word w: where it comes from, where it goes
+        if (w < seg2) { const int u = w < seg1 ? w : w - seg1, r = u / D, k = u - r * D;
+                        dst = (w < seg1 ? L->x0 : L->x1) + r * L->ld[0] + k; return (w < seg1 ? p->obs : p->obs_next) + (size_t)r_base * D + u; }
+        if (w < seg4) { const int u = w < seg3 ? w - seg2 : w - seg3, r = u / S, k = u - r * S;
+                        dst = (w < seg3 ? L->s0 : L->s1) + r * L->lds + k; return (w < seg3 ? p->state : p->state_next) + (size_t)b0 * S + u; }
+        if (w < seg5) { const int u = w - seg4, f = u / rows, i = u - f * rows;
+                        dst = (f == 0 ? L->act_i : f == 1 ? L->rew : f == 2 ? L->term : L->amask) + i;
+                        return (f == 0 ? p->actions : f == 1 ? p->rewards : f == 2 ? p->terminals : p->agent_mask) + r_base + i; }
+        const int u = w - seg5, r = u / A, k = u - r * A;
+        dst = L->avail + r * ldav + k;
+        return p->avail_next ? p->avail_next + (size_t)r_base * A + u : nullptr;
+    };
+    {
+        typedef const __attribute__((address_space(1))) qf_f4* G;
+        const int na = args->mixer4, nb = args->agent4, n_w = na + 2 * nb;
+        const G sa = (G)(p->img_target + 4 * args->agent4), sb = (G)p->img_target, sc = (G)p->img_eval;
+        qf_f4 wv[8];
+        float iv[2];
+        int idst[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = tid + j * QF_THREADS;
+            wv[j] = 0.f;
+            if (q < na) wv[j] = sa[q];
+            else if (q < na + nb) wv[j] = sb[q - na];
+            else if (q < n_w) wv[j] = sc[q - na - nb];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int w = tid + j * QF_THREADS;
+            idst[j] = -1; iv[j] = 1.f;
+            if (w < n_in) { const float* src = in_word(w, idst[j]); if (src) iv[j] = *src; }
+        }
+        for (int i = tid; i < L->clear_end; i += QF_THREADS) lds[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) if (idst[j] >= 0) lds[idst[j]] = iv[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = tid + j * QF_THREADS;
+            if (q < na) *reinterpret_cast<qf_f4*>(lds + L->mix + 4 * q) = wv[j];
+            else if (q < na + nb) *reinterpret_cast<qf_f4*>(lds + L->ag_t + 4 * (q - na)) = wv[j];
+            else if (q < n_w) *reinterpret_cast<qf_f4*>(lds + L->ag_e + 4 * (q - na - nb)) = wv[j];
+        }
+        for (int w = tid + 2 * QF_THREADS; w < n_in; w += QF_THREADS) {       // (larger groups: the rest, one more latency)
+            int dst; const float* src = in_word(w, dst);
+            lds[dst] = src ? *src : 1.f;
+        }
+        for (int q = tid + 8 * QF_THREADS; q < n_w; q += QF_THREADS) {        // (larger networks: likewise)
+            if (q < na) *reinterpret_cast<qf_f4*>(lds + L->mix + 4 * q) = sa[q];
+            else if (q < na + nb) *reinterpret_cast<qf_f4*>(lds + L->ag_t + 4 * (q - na)) = sb[q - na];
+            else *reinterpret_cast<qf_f4*>(lds + L->ag_e + 4 * (q - na - nb)) = sc[q - na - nb];
+        }
+    }
+    __syncthreads();
+
+    QF_STAMP(1);
+    // ---- 1..4. forward.  Between two barriers run, side by side on disjoint thread ranges: layer l of the three agent
+    //            passes (target(next), eval(next) for the double-Q argmax, eval(obs) kept for the backward pass) and one
+    //            step of the mixer sequence: target hyper layer A, target hyper layer B, eval mixer weights over the target
+    //            mixer's LDS space, eval hyper layer A, eval hyper layer B
+    int mix_step = 0;
+    for (int l = 0; l < nl || mix_step < 5; ++l) {
+        if (l < nl) {
+            const bool last = l == nl - 1;
+            const int act = last ? XRL_ACT_NONE : p->act, K = p->dims[l], Nn = p->dims[l + 1], ldi = L->ld[l], ldo = L->ld[l + 1];
+            const int in_t = l == 0 ? L->x1 : ((l & 1) ? L->t0 : L->t1), out_t = last ? L->qnt : (((l + 1) & 1) ? L->t0 : L->t1);
+            const int in_n = l == 0 ? L->x1 : ((l & 1) ? L->u0 : L->u1), out_n = last ? L->qne : (((l + 1) & 1) ? L->u0 : L->u1);
+            const int in_e = l == 0 ? L->x0 : L->h[l], out_e = last ? L->q : L->h[l + 1];
+            qf_lin_fwd(L->wt[l], L->ldw[l], L->bt[l], K, Nn, in_t, ldi, rows, out_t, ldo, act, 0);
+            if (p->double_q) qf_lin_fwd(L->we[l], L->ldw[l], L->be[l], K, Nn, in_n, ldi, rows, out_n, ldo, act, 256);
+            qf_lin_fwd(L->we[l], L->ldw[l], L->be[l], K, Nn, in_e, ldi, rows, out_e, ldo, act, 512);
+        }
+        switch (mix_step) {
+            case 0: qf_hyper_layer(p, L, 0, L->s1, L->hid_t, L->raw_t, bw, 768); break;
+            case 1: qf_hyper_layer(p, L, 1, L->s1, L->hid_t, L->raw_t, bw, 768); break;
+            case 2: qf_copy((QfGlobalIn)(p->img_eval + 4 * args->agent4), L->mix, args->mixer4); break;
+            case 3: qf_hyper_layer(p, L, 0, L->s0, L->hid_e, L->raw_e, bw, 768); break;
+            case 4: qf_hyper_layer(p, L, 1, L->s0, L->hid_e, L->raw_e, bw, 768); break;
+            default: break;
+        }
+        ++mix_step;
+        __syncthreads();
+    }
+    QF_STAMP(4);
+
+    // ---- 5. one wavefront per transition: taken / target Q, mixing, TD error, backward to d Q_eval and d(hyper outputs)
+    //         (the arithmetic of xrl_qmix_mix_td, statement by statement; lane n < N = agent n, lane h < H = hidden unit h)
+    float* dq = lds + L->t0;                                             // [rows][ldq]: d loss / d Q_eval(obs)
+    for (int i = tid; i < L->rows_pad * ldq; i += QF_THREADS) dq[i] = 0.f;
+    __syncthreads();
+    for (int bi = wave; bi < bw; bi += QF_THREADS / 64) {
+        const int b = b0 + bi;
+        float qe = 0.f, qn = 0.f, mask = 0.f;
+        int a_taken = 0;
+        if (lane < N) {
+            const int lr = bi * N + lane;
+            mask = lds[L->amask + lr];
+            a_taken = (int)lds[L->act_i + lr];
+            qe = lds[L->q + lr * ldq + a_taken] * mask;                                   // qmix_learner.py:48-50,60
+            const float* qt = lds + L->qnt + lr * ldq;
+            const float* av = lds + L->avail + lr * ldav;
+            if (p->double_q) {                                                            // :52-55
+                const float* qs = lds + L->qne + lr * ldq;
+                int best = 0; float bv = (av && av[0] == 0.f) ? -1e10f : qs[0];
+                for (int j = 1; j < A; ++j) {
+                    const float v = (av && av[j] == 0.f) ? -1e10f : qs[j];               // value_factorization.py:87-90
+                    if (v > bv) { bv = v; best = j; }
+                }
+                qn = (av && av[best] == 0.f) ? -1e10f : qt[best];
+            } else {                                                                     // :57-58
+                qn = (av && av[0] == 0.f) ? -1e10f : qt[0];
+                for (int j = 1; j < A; ++j) qn = fmaxf(qn, (av && av[j] == 0.f) ? -1e10f : qt[j]);
+            }
+            qn *= mask;                                                                  // :61
+        }
+        const float* e_raw = lds + L->raw_e + bi * L->ldr;
+        const float* t_raw = lds + L->raw_t + bi * L->ldr;
+        float pre_e = 0.f, pre_t = 0.f, w2e = 0.f, w2t = 0.f;
+        if (lane < H) { pre_e = lds[L->hid_e + bi * L->ldh + 3 * HH + lane]; pre_t = lds[L->hid_t + bi * L->ldh + 3 * HH + lane]; }
+        for (int n = 0; n < N; ++n) {
+            const float qen = __shfl(qe, n, 64), qnn = __shfl(qn, n, 64);
+            if (lane < H) {
+                pre_e += qen * fabsf(e_raw[n * H + lane]);                               // bmm(agent_qs, |w1|) + b1
+                pre_t += qnn * fabsf(t_raw[n * H + lane]);
+            }
+        }
+        float hid_e = 0.f, hid_t = 0.f;
+        if (lane < H) {
+            hid_e = qf_elu(pre_e); hid_t = qf_elu(pre_t);
+            w2e = fabsf(e_raw[N * H + lane]); w2t = fabsf(t_raw[N * H + lane]);
+        }
+        const float q_tot_e = wave_sum(hid_e * w2e) + e_raw[N * H + H];                  // bmm(hidden, |w2|) + b2
+        const float q_tot_n = wave_sum(hid_t * w2t) + t_raw[N * H + H];
+        float r = 0.f, dn = 1.f;
+        if (lane < N) { r = lds[L->rew + bi * N + lane]; dn = lds[L->term + bi * N + lane] != 0.f ? 1.f : 0.f; }
+        const float r_tot = wave_sum(r) / (float)N;                                      // :34
+        float all_d = dn;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) all_d = fminf(all_d, __shfl_xor(all_d, off, 64));   // :35
+        const float y = r_tot + (1.f - all_d) * p->gamma * q_tot_n;                       // :78
+        const float td = q_tot_e - y;
+        const float dq_tot = 2.f * td / (float)p->B;                                      // d mean(td^2) / d q_tot_eval (:86)
+        float* d_raw = lds + L->d_raw + bi * L->ldr;
+        float d_pre = 0.f;
+        if (lane < H) {
+            const float w2_raw = e_raw[N * H + lane];
+            const float sgn2 = (w2_raw > 0.f) - (w2_raw < 0.f);
+            d_raw[N * H + lane] = dq_tot * hid_e * sgn2;                                 // through abs()
+            d_pre = dq_tot * w2e * (pre_e > 0.f ? 1.f : expf(pre_e));                    // ELU'
+            lds[L->d_hid + bi * L->ldh + 3 * HH + lane] = d_pre;                           // = d hyper_b_1 output
+        }
+        if (lane == 0) d_raw[N * H + H] = dq_tot;
+        for (int n = 0; n < N; ++n) {
+            const float qen = __shfl(qe, n, 64);
+            float contrib = 0.f;
+            if (lane < H) {
+                const float w1_raw = e_raw[n * H + lane];
+                const float sgn1 = (w1_raw > 0.f) - (w1_raw < 0.f);
+                d_raw[n * H + lane] = qen * d_pre * sgn1;
+                contrib = d_pre * fabsf(w1_raw);
+            }
+            const float dqe = wave_sum(contrib);                                         // d loss / d (masked q_eval_n)
+            if (lane == n) dq[(bi * N + n) * ldq + a_taken] = dqe * mask;
+        }
+        if (lane == 0) {
+            double* o = p->partials + (size_t)b * 8;
+            o[0] = (double)td * td; o[1] = q_tot_e; o[2] = 0.0;
+            for (int j = 3; j < 8; ++j) o[j] = 0.0;
+            if (p->diag) { p->diag[b] = q_tot_e; p->diag[p->B + b] = q_tot_n; p->diag[2 * (size_t)p->B + b] = y; }
+        }
+    }
+    __syncthreads();
+
+    QF_STAMP(6);
+    // ---- 6..7. backward, again side by side between barriers: the agent network from d Q_eval(obs) (weight gradient of
+    //            layer l, data gradient into layer l - 1) and the eval hyper-networks (layer B's weight and data gradients,
+    //            then layer A's weight gradients); the target networks have no gradient
+    {
+        const int d_hid = L->d_hid, hid = L->hid_e, d_raw = L->d_raw;
+        int dz = L->t0, ldz = ldq, hyper_step = 0;                        // dz: d (pre-activation of layer l's output)
+        for (int l = nl - 1; l >= 0 || hyper_step < 2; --l) {
+            if (hyper_step == 0) {
+                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_W1_W], gslab + p->mix_off[XRL_QF_W1_B], HH, N * H, d_raw, L->ldr, hid, L->ldh, bw, 0);
+                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_W2_W], gslab + p->mix_off[XRL_QF_W2_B], HH, H, d_raw + N * H, L->ldr, hid + HH, L->ldh, bw, 768);
+                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_B2_W], gslab + p->mix_off[XRL_QF_B2_B], HH, 1, d_raw + N * H + H, L->ldr, hid + 2 * HH, L->ldh, bw, 960);
+                qf_lin_bwd_data(L->mw[2], L->mldw[2], HH, N * H, d_raw, L->ldr, bw, d_hid, L->ldh, hid, L->ldh, XRL_ACT_RELU, 256);
+                qf_lin_bwd_data(L->mw[3], L->mldw[3], HH, H, d_raw + N * H, L->ldr, bw, d_hid + HH, L->ldh, hid + HH, L->ldh, XRL_ACT_RELU, 384);
+                qf_lin_bwd_data(L->mw[4], L->mldw[4], HH, 1, d_raw + N * H + H, L->ldr, bw, d_hid + 2 * HH, L->ldh, hid + 2 * HH, L->ldh, XRL_ACT_RELU, 448);
+            } else if (hyper_step == 1) {
+                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_FIRST_W], gslab + p->mix_off[XRL_QF_FIRST_B], p->S, 3 * HH, d_hid, L->ldh, L->s0, L->lds, bw, 0);
+                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_B1_W], gslab + p->mix_off[XRL_QF_B1_B], p->S, H, d_hid + 3 * HH, L->ldh, L->s0, L->lds, bw, 384);
+            }
+            ++hyper_step;
+            if (l >= 0) {
+                const int in = l == 0 ? L->x0 : L->h[l], ldi = L->ld[l];
+                qf_lin_bwd_weight(gslab + p->w_off[l], gslab + p->b_off[l], p->dims[l], p->dims[l + 1], dz, ldz, in, ldi, rows, 512);
+                if (l > 0) {
+                    const int dx = (dz == L->t0) ? L->t1 : L->t0;
+                    // t0 / t1 rows are ldmax wide; the first dz (the Q head's) uses ldq, every later one ld[l]
+                    qf_lin_bwd_data(L->we[l], L->ldw[l], p->dims[l], p->dims[l + 1], dz, ldz, rows, dx, L->ld[l], in, ldi, p->act, 640);
+                    dz = dx; ldz = L->ld[l];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    QF_STAMP(8);
+}
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_qmix_fused_lds_bytes(const xrl_qmix_fused_t* p) {
+    if (!p || p->n_layers < 1 || p->n_layers > XRL_QF_MAX_LAYERS || p->items_per_wg < 1) return -1;
+    return qf_layout(*p).total * 4;
+}
+
+extern "C" int xrl_qmix_fused_layout(const xrl_qmix_fused_t* p, xrl_qf_image_t* out) {
+    XRL_CHECK_ARG(p && out && p->n_layers >= 1 && p->n_layers <= XRL_QF_MAX_LAYERS);
+    qf_image_layout(*p, *out);
+    XRL_CHECK_ARG((out->agent_floats & 3) == 0 && (out->mixer_floats & 3) == 0);
+    return XRL_OK;
+}
+
+extern "C" int xrl_qmix_fused_update(const xrl_qmix_fused_t* pp, xrl_stream_t stream) {
+    XRL_CHECK_ARG(pp != nullptr);
+    const xrl_qmix_fused_t& p = *pp;
+    XRL_CHECK_ARG(p.img_eval && p.img_target && ((reinterpret_cast<uintptr_t>(p.img_eval) | reinterpret_cast<uintptr_t>(p.img_target)) & 15) == 0);
+    XRL_CHECK_ARG(p.obs && p.obs_next && p.state && p.state_next && p.actions && p.rewards &&
+                  p.terminals && p.agent_mask && p.slabs && p.partials);
+    XRL_CHECK_ARG(p.n_layers >= 1 && p.n_layers <= XRL_QF_MAX_LAYERS && p.B > 0 && p.items_per_wg > 0);
+    XRL_CHECK_ARG(p.N >= 1 && p.N <= 64 && p.H >= 1 && p.H <= 64 && p.A >= 1 && p.dims[p.n_layers] == p.A && p.HH >= 1 && p.S >= 1);
+    XRL_CHECK_ARG((p.slab_stride & 3) == 0);
+    const QfLds L = qf_layout(p);
+    const size_t bytes = (size_t)L.total * 4;
+    XRL_CHECK_ARG(bytes <= 160 * 1024);
+    static size_t allowed = 0;
+    if (bytes > allowed) {
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qmix_fused_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        allowed = bytes;
+    }
+    const int n_wg = (p.B + p.items_per_wg - 1) / p.items_per_wg;
+    QfArgs args{};
+    xrl_qf_image_t im;
+    qf_image_layout(p, im);
+    args.p = p; args.L = L; args.agent4 = im.agent_floats / 4; args.mixer4 = im.mixer_floats / 4;
+    hipLaunchKernelGGL(qmix_fused_kernel, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

@@ -113,10 +113,36 @@ class QMIX_Learner(Learner):
             self.states[B:2 * B].copy_(torch.as_tensor(sample["state_next"], device=dev).reshape(B, -1))
         return B
 
+    _images_current = False      # True only inside a captured update phase (the phase's first launch sequence refreshes them)
+
+    def fused_eligible(self):
+        """The one-launch update (xrl_qmix_fused_update): QMIX mixer, feed-forward agents of at most 4 linear layers with one
+        hidden activation, mixer embed dim <= 64, activations of a group of transitions within the 160 KB of LDS."""
+        if not hasattr(self, "_fused"):
+            self._fused = None
+            m = self.model
+            ok = self.mixer_mode == 0 and not m.use_rnn and getattr(self.config, "use_fused_qmix_update", True) and \
+                1 <= len(m.agent_plan.stages) <= 4 and all(len(s) == 1 for s in m.agent_plan.stages) and \
+                len({s[0].act for s in m.agent_plan.stages[:-1]}) <= 1 and m.H <= 64 and m.n_agents <= 64
+            if ok:
+                fs = ops.QmixFusedState(m, self.double_q, self.gamma, int(getattr(self.config, "fused_qmix_items_per_wg", 1)))
+                if 0 < fs.lds_bytes() <= 160 * 1024:
+                    self._fused = fs
+        return self._fused is not None
+
     def _step(self, B):
         m, opt = self.model, self.optimizer
         N, A, H = m.n_agents, m.n_actions, m.H
         R = B * N
+        if self.fused_eligible() and self._fused.n_groups(B) <= self.slabs.shape[0]:
+            b = self.buf
+            if not self._images_current:                    # (a call outside a captured phase: somebody may have written the
+                self._fused.refresh()                       #  parameters -- load_model, copy_target, an adopter's module)
+            S = ops.qmix_fused_update(self._fused, B, self.X, self.X[R:], self.states, self.states[B:], b["actions"], b["rewards"],
+                                      b["terminals"], b["agent_mask"], b["avail_next"] if self.use_actions_mask else None,
+                                      self.slabs, m.params.P, self.partials, self.diag)
+            self._finish_step(S)
+            return
         S = pick_n_split(R)
         from ..nets import Plan
         # eval network on obs (+ next_obs for the double-Q argmax) and target network on next_obs (iql_learner.py:41-47,
@@ -157,11 +183,15 @@ class QMIX_Learner(Learner):
         gradient is all-reduced between the reduction and the optimiser launch."""
         m, opt, P = self.model, self.optimizer, self.model.params.P
         clip = self.grad_clip_norm if self.use_grad_clip else 0.0
+        fs = getattr(self, "_fused", None)
         if not self.needs_collective() and P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
-            ops.reduce_adam(self.slabs, S, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
-                            self.opt_sync, target=m.target_flat, target_every=self.sync_frequency,
-                            exchange=self.gradient_exchange())
+            # (the one-launch update reads weight images: the optimiser launch writes every new parameter there as well)
+            ops.reduce_adam(self.slabs, S, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip,
+                            [(fs.map, fs.img_eval)] if fs else [], self.opt_sync, target=m.target_flat,
+                            target_every=self.sync_frequency, exchange=self.gradient_exchange(),
+                            target_image=fs.img_target if fs else None)
             return
+        self._images_current = False
         ops.grad_reduce(self.slabs, S, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_
@@ -274,10 +304,14 @@ class QMIX_Learner(Learner):
 
             def enqueue():
                 # per update: draw, gather, step; the draw counter and the loss sums are settled once per phase
+                if self.fused_eligible():                   # weight images of the one-launch update: rebuilt once per phase
+                    self._fused.refresh()                   # (acting, checkpoints, target copies happen between phases),
+                    self._images_current = True             # kept current inside it by the optimiser launch's mirrors
                 for e in range(n_epochs):
                     memory.draw_into(self._idx, dst, seed, e, self._sample_counter)     # draw + gather: one launch
                     self.partials = self._phase_partials[e]
                     self._step(B)
+                self._images_current = False
                 ops.counter_add(self._sample_counter, n_epochs)
                 ops.sum_partials_batched(self._phase_partials, B, 8, self._epoch_sums, n_epochs, B * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key

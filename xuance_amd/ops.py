@@ -181,7 +181,7 @@ def adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, max_norm, mirror
 
 
 def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, max_norm, mirrors, sync, target=None,
-                target_every=0, fold=None, exchange=None):
+                target_every=0, fold=None, exchange=None, target_image=None):
     """grad_reduce + clip + Adam + mirrors (+ the periodic hard target update) in one launch (blocks meet at a counter
     barrier); same numbers.  exchange: a dist.GradientExchange -- the ranks average their gradients inside the launch."""
     mir = Mirrors()
@@ -190,6 +190,8 @@ def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq
         mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
     if target is not None and target_every > 0:
         mir.target, mir.target_every = target.data_ptr(), int(target_every)
+        if target_image is not None:                       # derived layout of the target, refreshed with it (through map[0])
+            mir.target_image = target_image.data_ptr()
     if fold:
         mir.fold_off, mir.fold_len = int(fold[0]), int(fold[1])
     if exchange is not None:
@@ -443,6 +445,89 @@ def host_device_pointer(pinned):
     out = C.c_void_p()
     call("xrl_host_device_pointer", C.c_void_p(pinned.data_ptr()), C.byref(out))
     return out.value
+
+
+class QmixFusedState:
+    """xrl_qmix_fused_t of a feed-forward MixingQNet with the QMIX mixer + the two weight images the launch reads (eval,
+    target: the parameters in the padded LDS layout of csrc/qmix_fused.hip) + the parameter -> image index map that
+    xrl_reduce_adam's mirror mechanism keeps them current with (batch pointers are filled in per call)."""
+
+    def __init__(self, model, double_q, gamma, items_per_wg):
+        from ._lib import QmixFused, QfImage
+        P = model.params
+        layers = [st[0] for st in model.agent_plan.stages]
+        assert all(len(st) == 1 for st in model.agent_plan.stages) and 1 <= len(layers) <= 4
+        q = QmixFused()
+        q.n_layers = len(layers)
+        acts = {L.act for L in layers[:-1]}
+        assert len(acts) <= 1 and layers[-1].act is None
+        q.act = ACT[acts.pop()] if acts else ACT[None]
+        q.dims[0] = layers[0].K
+        for i, L in enumerate(layers):
+            q.dims[i + 1] = L.N
+            q.w_off[i], q.b_off[i] = P.offsets[L.w_name], P.offsets[L.b_name]
+        m = "eval_Qtot"
+        names = [f"{m}.hyper_w_1.0", f"{m}.hyper_b_1", f"{m}.hyper_w_1.2", f"{m}.hyper_w_2.2", f"{m}.hyper_b_2.2"]
+        for i, n in enumerate(names):
+            q.mix_off[2 * i], q.mix_off[2 * i + 1] = P.offsets[n + ".weight"], P.offsets[n + ".bias"]
+        # the three first layers are one stacked matrix: [hyper_w_1.0; hyper_w_2.0; hyper_b_2.0] weights, then their biases
+        HH, S, H, N = model.HH, model.state_dim, model.H, model.n_agents
+        assert P.offsets[f"{m}.hyper_w_2.0.weight"] == P.offsets[f"{m}.hyper_w_1.0.weight"] + HH * S
+        assert P.offsets[f"{m}.hyper_b_2.0.weight"] == P.offsets[f"{m}.hyper_w_1.0.weight"] + 2 * HH * S
+        assert P.offsets[f"{m}.hyper_w_2.0.bias"] == P.offsets[f"{m}.hyper_w_1.0.bias"] + HH
+        assert P.offsets[f"{m}.hyper_b_2.0.bias"] == P.offsets[f"{m}.hyper_w_1.0.bias"] + 2 * HH
+        q.N, q.A, q.S, q.H, q.HH = N, model.n_actions, S, H, HH
+        q.items_per_wg, q.double_q, q.gamma = int(items_per_wg), int(bool(double_q)), float(gamma)
+        im = QfImage()
+        call("xrl_qmix_fused_layout", C.byref(q), C.byref(im))
+        # parameter index -> image index
+        import numpy as np
+        mp = np.full(P.P, -1, np.int32)
+
+        def place(off, rows, K, base, ldw):
+            r, k = np.divmod(np.arange(rows * K), K)
+            mp[off:off + rows * K] = base + r * ldw + k
+        for i, L in enumerate(layers):
+            place(q.w_off[i], L.N, L.K, im.w[i], im.ldw[i])
+            mp[q.b_off[i]:q.b_off[i] + L.N] = im.b[i] + np.arange(L.N)
+        mK, mN = [S, S, HH, HH, HH], [3 * HH, H, N * H, H, 1]
+        for i in range(5):
+            place(q.mix_off[2 * i], mN[i], mK[i], im.agent_floats + im.mw[i], im.mldw[i])
+            mp[q.mix_off[2 * i + 1]:q.mix_off[2 * i + 1] + mN[i]] = im.agent_floats + im.mb[i] + np.arange(mN[i])
+        used = mp[mp >= 0]                                  # (alignment gaps of the flat buffer map nowhere)
+        assert len(used) == sum(int(np.prod(sh)) for sh in P.shapes.values()) and len(np.unique(used)) == len(used)
+        dev = P.flat.device
+        n_img = im.agent_floats + im.mixer_floats
+        self.map = torch.as_tensor(mp, device=dev)          # what the optimiser launch's mirror reads (-1: skip)
+        self._map64 = torch.as_tensor(np.where(mp >= 0, mp, n_img), device=dev).to(torch.int64)   # gaps -> a spare slot
+        self.img_eval, self.img_target = torch.zeros(n_img + 4, device=dev), torch.zeros(n_img + 4, device=dev)
+        q.img_eval, q.img_target = self.img_eval.data_ptr(), self.img_target.data_ptr()
+        self.struct, self.model, self.items_per_wg = q, model, int(items_per_wg)
+        self.refresh()
+
+    def refresh(self):
+        """Rebuild both images from the flat buffers (after anything but xrl_reduce_adam changed the parameters)."""
+        self.img_eval.index_copy_(0, self._map64, self.model.params.flat)
+        self.img_target.index_copy_(0, self._map64, self.model.target_flat)
+
+    def lds_bytes(self):
+        return int(_lib.load().xrl_qmix_fused_lds_bytes(C.byref(self.struct)))
+
+    def n_groups(self, B):
+        return (int(B) + self.items_per_wg - 1) // self.items_per_wg
+
+
+def qmix_fused_update(fs, B, obs, obs_next, state, state_next, actions, rewards, terminals, agent_mask, avail_next, slabs,
+                      slab_stride, partials, diag):
+    q = fs.struct
+    q.B = int(B)
+    q.obs, q.obs_next, q.state, q.state_next = ptr(obs), ptr(obs_next), ptr(state), ptr(state_next)
+    q.actions, q.rewards, q.terminals, q.agent_mask = ptr(actions), ptr(rewards), ptr(terminals), ptr(agent_mask)
+    q.avail_next = ptr(avail_next) if avail_next is not None else None
+    q.slabs, q.slab_stride, q.partials = ptr(slabs), int(slab_stride), ptr(partials)
+    q.diag = ptr(diag) if diag is not None else None
+    call("xrl_qmix_fused_update", C.byref(q), stream_ptr())
+    return fs.n_groups(B)
 
 
 def marl_loop_gate(**kw):
