@@ -685,6 +685,31 @@ int xrl_qmix_fused_update(const xrl_qmix_fused_t* p, xrl_stream_t stream);
 int xrl_qmix_fused_lds_bytes(const xrl_qmix_fused_t* p);   /* LDS the launch needs (must be <= 160 KB), -1 on bad dims */
 int xrl_qmix_fused_layout(const xrl_qmix_fused_t* p, xrl_qf_image_t* out);   /* needs n_layers, dims, N, S, H, HH only */
 
+/* One acting step of the recurrent agents as ONE launch (value_factorization.py:66-92 with Basic_RNN, rnn.py:52-77: mlp
+ * blocks -> nn.GRU cell -> Q head; the reference calls it once per vector step, off_policy_marl.py:478-486): Q values of R
+ * rows from their observations and carried hidden states; the new hidden states replace the old ones.  rows_per_wg rows
+ * per workgroup, all weights staged in LDS from an IMAGE in the layout of xrl_marl_act_gru_layout (layers in the order
+ * pre[0..n_pre), W_ih, W_hh, post[0..n_post); matrix l at w[l] + n * ldw[l] + k, its bias at b[l]; padding zero).  Cell
+ * arithmetic as xrl_gru_forward.  Same numbers as xrl_linear_fwd + xrl_gru_forward + xrl_linear_fwd up to fp32 summation
+ * order. */
+#define XRL_QA_MAX_LAYERS 8
+typedef struct {
+    int32_t w[XRL_QA_MAX_LAYERS], b[XRL_QA_MAX_LAYERS], ldw[XRL_QA_MAX_LAYERS];
+    int32_t image_floats, lds_bytes;
+} xrl_qa_image_t;
+typedef struct {
+    const float* image;
+    const float* obs;           /* [R][O] */
+    float* h;                   /* [R][H] in: state before the step, out: state after it */
+    const float* reset;         /* NULL or [R] f32: != 0 -> this row starts from the zero state (rnn.py:86-92) */
+    float* q;                   /* [R][ldq] out */
+    int32_t R, rows_per_wg, O, H, ldq, act;     /* act: XRL_ACT_* after every pre layer and every post layer but the last */
+    int32_t n_pre, n_post;
+    int32_t pre[3], post[3];    /* widths: pre = the mlp blocks below the GRU, post = Q head (last = n_actions) */
+} xrl_marl_act_gru_t;
+int xrl_marl_act_gru(const xrl_marl_act_gru_t* p, xrl_stream_t stream);
+int xrl_marl_act_gru_layout(const xrl_marl_act_gru_t* p, xrl_qa_image_t* out);
+
 /* One-layer GRU over whole sequences, time-major (Basic_RNN, rl_models/representations/rnn.py:52-77; nn.GRU built by
  * rl_models/modules/layers.py:79-98; the recurrent agents of qmix/sc2/3m.yaml).  gi = x W_ih^T + b_ih for all steps is
  * the caller's GEMM (xrl_linear_fwd); this launch runs the serial part, one wavefront per sequence. H must be 64. */

@@ -567,3 +567,27 @@ def test_captured_vector_step_equals_the_eager_episode_loop(lag):
     assert a["ptr_size"][1] >= 24 and a["step"][0] > 0
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("R", [192, 7, 24])
+def test_one_launch_acting_step_of_the_recurrent_agents_vs_the_layered_path(R):
+    """xrl_marl_act_gru (mlp block -> GRU cell -> Q head from one LDS-staged weight image; rows split over workgroups, a
+    ragged last group) against xrl_linear_fwd + xrl_gru_forward + xrl_linear_fwd on the same observations: Q values and
+    carried hidden states over several steps with row resets, 1e-5; and after a parameter change + refresh()."""
+    from xuance_amd.nets import MixingQNet
+    torch.manual_seed(0)
+    net = MixingQNet(3, 30, 9, 48, (), (64,), 32, 32, "relu", use_rnn=True, fc_hidden=(64,), recurrent_hidden=64)
+    assert net.act_image() is not None
+    g = torch.Generator(device="cpu").manual_seed(1)
+    h_a, h_b = torch.zeros(R, 64, device="cuda"), torch.zeros(R, 64, device="cuda")
+    for step in range(5):
+        if step == 3:                                              # parameters move: the image must follow on refresh()
+            net.params.flat.add_(0.01 * torch.randn(net.params.flat.shape, generator=g).cuda())
+            net.act_image().refresh()
+        X = torch.randn(R, 30, generator=g).cuda()
+        reset = (torch.rand(R, generator=g) < (0.3 if step else 0.0)).float().cuda()
+        q_a = net.act_step(X, R, h_a, reset, fused=True).clone()
+        q_b = net.act_step(X, R, h_b, reset, fused=False).clone()
+        assert_close(q_a.cpu().numpy(), q_b.cpu().numpy(), 1e-5, f"q step {step}")
+        assert_close(h_a.cpu().numpy(), h_b.cpu().numpy(), 1e-5, f"h step {step}")
+    assert float(h_a.abs().max()) > 0

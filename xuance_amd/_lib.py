@@ -202,6 +202,16 @@ class QmixFused(C.Structure):
                 ("gamma", c_float), ("pad1", c_float), ("dbg", c_void_p)]
 
 
+class QaImage(C.Structure):
+    _fields_ = [("w", c_int32 * 8), ("b", c_int32 * 8), ("ldw", c_int32 * 8), ("image_floats", c_int32), ("lds_bytes", c_int32)]
+
+
+class MarlActGru(C.Structure):
+    _fields_ = [("image", c_void_p), ("obs", c_void_p), ("h", c_void_p), ("reset", c_void_p), ("q", c_void_p),
+                ("R", c_int32), ("rows_per_wg", c_int32), ("O", c_int32), ("H", c_int32), ("ldq", c_int32), ("act", c_int32),
+                ("n_pre", c_int32), ("n_post", c_int32), ("pre", c_int32 * 3), ("post", c_int32 * 3)]
+
+
 class Exchange(C.Structure):
     _fields_ = [("base", c_void_p * 8), ("stride4", c_int64), ("world", c_int32), ("rank", c_int32),
                 ("max_spins", c_int32), ("pad", c_int32), ("inv_world", c_float), ("pad2", c_float)]
@@ -246,6 +256,8 @@ _SIGS = {
     "xrl_qmix_fused_update": [C.POINTER(QmixFused), c_void_p],
     "xrl_qmix_fused_lds_bytes": [C.POINTER(QmixFused)],
     "xrl_qmix_fused_layout": [C.POINTER(QmixFused), C.POINTER(QfImage)],
+    "xrl_marl_act_gru": [C.POINTER(MarlActGru), c_void_p],
+    "xrl_marl_act_gru_layout": [C.POINTER(MarlActGru), C.POINTER(QaImage)],
     "xrl_host_device_pointer": [c_void_p, C.POINTER(c_void_p)],
     "xrl_per_store": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_void_p],
     "xrl_per_sample": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

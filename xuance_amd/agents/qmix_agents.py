@@ -114,6 +114,9 @@ class QMIX_Agents(AgentSurface):
         if self.rnn_c is not None:
             self.rnn_c.zero_()
         self.reset_rows.zero_()
+        fused_act = bool(getattr(self.config, "use_fused_acting", True))
+        if fused_act and self.model.act_image() is not None:
+            self.model.act_image().refresh()                    # (the parameters only change between run_episodes calls)
         episodes = 0
         # an env that alternates its observation buffers and keeps running episode totals saves the copies and the
         # reductions of a step (envs/synthetic.py); any other env goes through clones and two small sums
@@ -129,8 +132,7 @@ class QMIX_Agents(AgentSurface):
             else:
                 obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
                 steps = env.steps.clone()
-            q = self.model.agent_forward_seq(obs.view(R, -1), R, 1, which=2, h0=self.rnn_h, reset=self.reset_rows,
-                                             h_last=self.rnn_h, c0=self.rnn_c, c_last=self.rnn_c)
+            q = self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused_act)
             ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
                                     action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=self._host_step,
                                     step_dev=None)            # eager loop: the host knows the step index
@@ -213,13 +215,15 @@ class QMIX_Agents(AgentSurface):
         if not self._step_graphs:                                                     # first capture: counters take over here
             self._rng_dev.copy_(torch.tensor([self._host_step, env._host_step], dtype=torch.int32))
         self.model.seq_workspace(2, R, 1)                                             # (no allocation inside the capture)
+        if self.model.act_image() is not None:
+            self.model.act_q_buffer(R)
         obs, state, avail = env._sets[cur]
         gt = self._gate
         torch.cuda.synchronize()
         g = ops.Graph()
         with g:
-            q = self.model.agent_forward_seq(obs.view(R, -1), R, 1, which=2, h0=self.rnn_h, reset=self.reset_rows,
-                                             h_last=self.rnn_h, c0=self.rnn_c, c_last=self.rnn_c)
+            q = self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c,
+                                    fused=bool(getattr(self.config, "use_fused_acting", True)))
             ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
                                     action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,
                                     step_dev=self._rng_dev[0:1])
@@ -300,8 +304,9 @@ class QMIX_Agents(AgentSurface):
         if avail is not None and self.use_actions_mask:
             av = torch.as_tensor(np.asarray(avail) if not isinstance(avail, torch.Tensor) else avail, device=dev).to(torch.float32).reshape(R, A).contiguous()
         if self.use_rnn:
-            q = self.model.agent_forward_seq(X, R, 1, which=2, h0=rnn["h"], reset=rnn["reset"], h_last=rnn["h"], c0=rnn.get("c"),
-                                             c_last=rnn.get("c"))
+            if self.model.act_image() is not None:
+                self.model.act_image().refresh()
+            q = self.model.act_step(X, R, rnn["h"], rnn["reset"], rnn.get("c"))
         else:
             q = self.model.agent_plan.forward(X, self.obs_dim, R)
         act = torch.zeros(R, dtype=torch.int32, device=dev)

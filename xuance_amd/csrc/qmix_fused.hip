@@ -498,6 +498,150 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
     QF_STAMP(8);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// One ACTING step of the recurrent agents (value_factorization.py:66-92 -> Basic_RNN, rnn.py:52-77: mlp blocks -> nn.GRU
+// cell -> Q head) for R rows as ONE launch: the layered path is four GEMM launches of ~7 us on 192 rows plus the recurrence
+// launch.  Same scheme as the update above: rows_per_wg rows per workgroup, the whole weight image staged in LDS in one
+// burst, layer after layer from LDS, W_ih x and W_hh h side by side; the cell arithmetic is csrc/gru.hip's.
+struct QaLds {
+    int x, hin, a0, a1, gi, gh, hnew, q, reset, clear_end, img, total;
+    int ldx, ldh, lda, ldg, ldq, rows_pad;
+    int w[XRL_QA_MAX_LAYERS], b[XRL_QA_MAX_LAYERS], ldw[XRL_QA_MAX_LAYERS];    // image offsets (from the image base)
+    int image_floats;
+};
+
+__host__ __device__ inline void qa_layers(const xrl_marl_act_gru_t& p, int* K, int* Nn, int& n_layers) {
+    // layer list in image order: pre[0..n_pre), ih, hh, post[0..n_post)
+    int l = 0, feat = p.O;
+    for (int i = 0; i < p.n_pre; ++i) { K[l] = feat; Nn[l] = p.pre[i]; feat = p.pre[i]; ++l; }
+    K[l] = feat; Nn[l] = 3 * p.H; ++l;
+    K[l] = p.H; Nn[l] = 3 * p.H; ++l;
+    feat = p.H;
+    for (int i = 0; i < p.n_post; ++i) { K[l] = feat; Nn[l] = p.post[i]; feat = p.post[i]; ++l; }
+    n_layers = l;
+}
+
+__host__ __device__ inline QaLds qa_layout(const xrl_marl_act_gru_t& p) {
+    QaLds L;
+    int K[XRL_QA_MAX_LAYERS], Nn[XRL_QA_MAX_LAYERS], nl;
+    qa_layers(p, K, Nn, nl);
+    int off = 0, amax = p.H;
+    for (int i = 0; i < p.n_pre; ++i) if (p.pre[i] > amax) amax = p.pre[i];
+    for (int i = 0; i + 1 < p.n_post; ++i) if (p.post[i] > amax) amax = p.post[i];
+    L.rows_pad = (p.rows_per_wg + QF_PAD - 1) / QF_PAD * QF_PAD;
+    L.ldx = qf_pad4(p.O); L.ldh = qf_pad4(p.H); L.lda = qf_pad4(amax); L.ldg = qf_pad4(3 * p.H); L.ldq = qf_pad4(p.post[p.n_post - 1]);
+    L.x = off; off += L.rows_pad * L.ldx;
+    L.hin = off; off += L.rows_pad * L.ldh;
+    L.a0 = off; off += L.rows_pad * L.lda;
+    L.a1 = off; off += L.rows_pad * L.lda;
+    L.gi = off; off += L.rows_pad * L.ldg;
+    L.gh = off; off += L.rows_pad * L.ldg;
+    L.hnew = off; off += L.rows_pad * L.ldh;
+    L.q = off; off += L.rows_pad * L.ldq;
+    L.reset = off; off += L.rows_pad;
+    L.clear_end = off;
+    L.img = off;
+    int io = 0;
+    for (int l = 0; l < XRL_QA_MAX_LAYERS; ++l) { L.w[l] = L.b[l] = L.ldw[l] = 0; }
+    for (int l = 0; l < nl; ++l) { L.ldw[l] = qf_pad4(K[l]) + 4; L.w[l] = io; io += Nn[l] * L.ldw[l]; }
+    for (int l = 0; l < nl; ++l) { L.b[l] = io; io += qf_pad4(Nn[l]); }
+    L.image_floats = io;
+    L.total = off + io;
+    return L;
+}
+
+struct QaArgs { xrl_marl_act_gru_t p; QaLds L; };
+typedef const __attribute__((address_space(4))) QaArgs QaArgsK;
+
+__device__ __forceinline__ float qa_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float qa_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+
+__global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_value_unused) {
+    const QaArgsK* args = (const QaArgsK*)__builtin_amdgcn_kernarg_segment_ptr();
+    const __attribute__((address_space(4))) xrl_marl_act_gru_t* p = &args->p;
+    const __attribute__((address_space(4))) QaLds* L = &args->L;
+    float* lds = qf_lds;
+    const int tid = threadIdx.x, H = p->H, O = p->O;
+    const int r0 = blockIdx.x * p->rows_per_wg, rows = min(p->rows_per_wg, p->R - r0);
+    // ---- one burst: weight image, observations, previous hidden state, reset flags
+    {
+        typedef const __attribute__((address_space(1))) qf_f4* G;
+        const G src = (G)p->image;
+        const int n4 = L->image_floats >> 2, n_x = rows * O, n_h = rows * H, n_in = n_x + n_h + rows;
+        qf_f4 wv[10];
+        float iv[2];
+        int idst[2];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { const int q = tid + j * QF_THREADS; wv[j] = 0.f; if (q < n4) wv[j] = src[q]; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int w = tid + j * QF_THREADS;
+            idst[j] = -1; iv[j] = 0.f;
+            if (w < n_x) { const int r = w / O, k = w - r * O; idst[j] = L->x + r * L->ldx + k; iv[j] = p->obs[(size_t)r0 * O + w]; }
+            else if (w < n_x + n_h) { const int u = w - n_x, r = u / H, k = u - r * H; idst[j] = L->hin + r * L->ldh + k; iv[j] = p->h[(size_t)r0 * H + u]; }
+            else if (w < n_in) { const int r = w - n_x - n_h; idst[j] = L->reset + r; iv[j] = p->reset ? p->reset[r0 + r] : 0.f; }
+        }
+        for (int i = tid; i < L->clear_end; i += QF_THREADS) lds[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) if (idst[j] >= 0) lds[idst[j]] = iv[j];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { const int q = tid + j * QF_THREADS; if (q < n4) *reinterpret_cast<qf_f4*>(lds + L->img + 4 * q) = wv[j]; }
+        for (int q = tid + 10 * QF_THREADS; q < n4; q += QF_THREADS) *reinterpret_cast<qf_f4*>(lds + L->img + 4 * q) = src[q];
+        for (int w = tid + 2 * QF_THREADS; w < n_in; w += QF_THREADS) {
+            if (w < n_x) { const int r = w / O, k = w - r * O; lds[L->x + r * L->ldx + k] = p->obs[(size_t)r0 * O + w]; }
+            else if (w < n_x + n_h) { const int u = w - n_x, r = u / H, k = u - r * H; lds[L->hin + r * L->ldh + k] = p->h[(size_t)r0 * H + u]; }
+            else { const int r = w - n_x - n_h; lds[L->reset + r] = p->reset ? p->reset[r0 + r] : 0.f; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < rows * H; i += QF_THREADS) {                    // init_rnn_states_item (rnn.py:86-92): zero state
+        const int r = i / H, k = i - r * H;
+        if (lds[L->reset + r] != 0.f) lds[L->hin + r * L->ldh + k] = 0.f;
+    }
+    // ---- layers below the recurrence
+    int l = 0, in = L->x, ldi = L->ldx, feat = O;
+    for (int i = 0; i < p->n_pre; ++i, ++l) {
+        const int out = (i & 1) ? L->a1 : L->a0;
+        qf_lin_fwd(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, p->pre[i], in, ldi, rows, out, L->lda, p->act, 0);
+        __syncthreads();
+        in = out; ldi = L->lda; feat = p->pre[i];
+    }
+    // ---- gi = W_ih x + b_ih,  gh = W_hh h + b_hh  (side by side), then the cell (csrc/gru.hip's arithmetic)
+    qf_lin_fwd(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, 3 * H, in, ldi, rows, L->gi, L->ldg, XRL_ACT_NONE, 0);
+    qf_lin_fwd(L->img + L->w[l + 1], L->ldw[l + 1], L->img + L->b[l + 1], H, 3 * H, L->hin, L->ldh, rows, L->gh, L->ldg, XRL_ACT_NONE, 512);
+    l += 2;
+    __syncthreads();
+    for (int i = tid; i < rows * H; i += QF_THREADS) {
+        const int r = i / H, j = i - r * H;
+        const float* gi = lds + L->gi + r * L->ldg;
+        const float* gh = lds + L->gh + r * L->ldg;
+        const float h = lds[L->hin + r * L->ldh + j];
+        const float rg = qa_sigmoid(gi[j] + gh[j]);
+        const float z = qa_sigmoid(gi[H + j] + gh[H + j]);
+        const float n = qa_tanh(gi[2 * H + j] + rg * gh[2 * H + j]);
+        const float hn = (h - n) * z + n;
+        lds[L->hnew + r * L->ldh + j] = hn;
+        p->h[(size_t)(r0 + r) * H + j] = hn;                               // the state carried to the next step
+    }
+    __syncthreads();
+    // ---- Q head
+    in = L->hnew; ldi = L->ldh; feat = H;
+    for (int i = 0; i < p->n_post; ++i, ++l) {
+        const bool last = i == p->n_post - 1;
+        const int out = last ? L->q : ((i & 1) ? L->a1 : L->a0), ldo = last ? L->ldq : L->lda;
+        qf_lin_fwd(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, p->post[i], in, ldi, rows, out, ldo, last ? XRL_ACT_NONE : p->act, 0);
+        __syncthreads();
+        in = out; ldi = ldo; feat = p->post[i];
+    }
+    const int A = p->post[p->n_post - 1];
+    for (int i = tid; i < rows * A; i += QF_THREADS) {
+        const int r = i / A, k = i - r * A;
+        p->q[(size_t)(r0 + r) * p->ldq + k] = lds[L->q + r * L->ldq + k];
+    }
+}
+
 }  // namespace xrl
 
 using namespace xrl;
@@ -538,6 +682,38 @@ extern "C" int xrl_qmix_fused_update(const xrl_qmix_fused_t* pp, xrl_stream_t st
     qf_image_layout(p, im);
     args.p = p; args.L = L; args.agent4 = im.agent_floats / 4; args.mixer4 = im.mixer_floats / 4;
     hipLaunchKernelGGL(qmix_fused_kernel, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_marl_act_gru_layout(const xrl_marl_act_gru_t* p, xrl_qa_image_t* out) {
+    XRL_CHECK_ARG(p && out && p->n_pre >= 0 && p->n_post >= 1 && p->n_pre + p->n_post + 2 <= XRL_QA_MAX_LAYERS && p->rows_per_wg >= 1);
+    const QaLds L = qa_layout(*p);
+    for (int l = 0; l < XRL_QA_MAX_LAYERS; ++l) { out->w[l] = L.w[l]; out->b[l] = L.b[l]; out->ldw[l] = L.ldw[l]; }
+    out->image_floats = L.image_floats;
+    out->lds_bytes = L.total * 4;
+    return XRL_OK;
+}
+
+extern "C" int xrl_marl_act_gru(const xrl_marl_act_gru_t* pp, xrl_stream_t stream) {
+    XRL_CHECK_ARG(pp != nullptr);
+    const xrl_marl_act_gru_t& p = *pp;
+    XRL_CHECK_ARG(p.image && p.obs && p.h && p.q && p.R > 0 && p.rows_per_wg > 0 && p.H >= 1 && p.O >= 1);
+    XRL_CHECK_ARG(p.n_pre >= 0 && p.n_post >= 1 && p.n_pre + p.n_post + 2 <= XRL_QA_MAX_LAYERS);
+    XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p.image) & 15) == 0 && p.ldq >= p.post[p.n_post - 1]);
+    QaArgs args{};
+    args.p = p;
+    args.L = qa_layout(p);
+    const size_t bytes = (size_t)args.L.total * 4;
+    XRL_CHECK_ARG(bytes <= 160 * 1024 && (args.L.image_floats & 3) == 0);
+    static size_t allowed = 0;
+    if (bytes > allowed) {
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(marl_act_gru_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        allowed = bytes;
+    }
+    const int n_wg = (p.R + p.rows_per_wg - 1) / p.rows_per_wg;
+    hipLaunchKernelGGL(marl_act_gru_kernel, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

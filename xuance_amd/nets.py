@@ -683,6 +683,36 @@ class MixingQNet:
         self._recurrence(gi, ws, R, T1, flat, which == 0, h0=h0, c0=c0, reset=reset, h_last=h_last, c_last=c_last)
         return self.post_plans[which].forward(ws["hs"][R:], self.RH, T1 * R, flat=flat)
 
+    def act_step(self, X, R, h, reset=None, c=None, fused=True):
+        """Q values [R, n_actions] of ONE acting step from observations X [R, obs_dim] and the carried state h [R, H] (and c
+        for LSTM agents), which is replaced by the new state; rows with reset != 0 start from zeros.  GRU agents whose
+        weights fit LDS take the one-launch path (xrl_marl_act_gru); `act_image().refresh()` must have run since the
+        parameters last changed."""
+        st = self.act_image() if fused and not self.lstm else None
+        if st is None:
+            return self.agent_forward_seq(X, R, 1, which=2, h0=h, reset=reset, h_last=h, c0=c, c_last=c)
+        return st.launch(X, R, h, reset, self.act_q_buffer(R))
+
+    def act_q_buffer(self, R):
+        """(allocated outside any graph capture: callers that capture act_step touch it first)"""
+        q = self._act_q.get(R)
+        if q is None:
+            q = self._act_q[R] = torch.zeros(R, self.n_actions, device=self.params.device)
+        return q
+
+    def act_image(self):
+        """The acting launch's weight image (ops.MarlActGruState), or None when that launch cannot run this network."""
+        if not hasattr(self, "_act_state"):
+            self._act_state, self._act_q = None, {}
+            if self.use_rnn and not self.lstm:
+                try:
+                    st = ops.MarlActGruState(self)
+                    if st.lds_bytes <= 160 * 1024:
+                        self._act_state = st
+                except AssertionError:                          # a layer arrangement the launch does not cover
+                    self._act_state = None
+        return self._act_state
+
     def agent_forward_seq_pair(self, X, R, T1, ride_along=()):
         """Eval and target networks over the same sequences (iql_learner.py:41-57): the layers below and above the
         recurrence as grouped launches (eval + target in one), the two recurrences as one dual launch.

@@ -517,6 +517,62 @@ class QmixFusedState:
         return (int(B) + self.items_per_wg - 1) // self.items_per_wg
 
 
+class MarlActGruState:
+    """xrl_marl_act_gru_t of a recurrent MixingQNet (GRU agents) + the weight image its launch stages in LDS.  The image
+    only changes when the eval parameters do: `refresh()` rebuilds it (one launch) -- the agents call it when a
+    run_episodes call / an evaluation starts, updates happen between those."""
+
+    def __init__(self, model, rows_per_wg=6):
+        from ._lib import MarlActGru, QaImage
+        import numpy as np
+        P = model.params
+        pre = [st[0] for st in model.pre_plans[2].stages]          # mlp blocks ..., then the input side of the GRU
+        post = [st[0] for st in model.post_plans[2].stages]
+        assert not model.lstm and all(len(st) == 1 for st in model.pre_plans[2].stages + model.post_plans[2].stages)
+        fc, ih = pre[:-1], pre[-1]
+        assert len(fc) <= 3 and 1 <= len(post) <= 3 and ih.N == 3 * model.RH
+        acts = {L.act for L in fc} | {L.act for L in post[:-1]}
+        assert len(acts) <= 1 and post[-1].act is None and ih.act is None
+        q = MarlActGru()
+        q.O, q.H, q.n_pre, q.n_post = model.obs_dim, model.RH, len(fc), len(post)
+        q.act = ACT[acts.pop()] if acts else ACT[None]
+        for i, L in enumerate(fc):
+            q.pre[i] = L.N
+        for i, L in enumerate(post):
+            q.post[i] = L.N
+        q.rows_per_wg = int(rows_per_wg)
+        im = QaImage()
+        call("xrl_marl_act_gru_layout", C.byref(q), C.byref(im))
+        self.lds_bytes = int(im.lds_bytes)
+        mats = [(L.w_name, L.b_name, L.N, L.K) for L in fc] + [(ih.w_name, ih.b_name, ih.N, ih.K),
+                                                                (model.w_hh, model.b_hh, 3 * model.RH, model.RH)] + \
+               [(L.w_name, L.b_name, L.N, L.K) for L in post]
+        src, dst = [], []
+        for l, (wn, bn, N, K) in enumerate(mats):
+            r, k = np.divmod(np.arange(N * K), K)
+            src.append(P.offsets[wn] + np.arange(N * K)); dst.append(im.w[l] + r * im.ldw[l] + k)
+            src.append(P.offsets[bn] + np.arange(N)); dst.append(im.b[l] + np.arange(N))
+        dev = P.flat.device
+        self._src = torch.as_tensor(np.concatenate(src), device=dev).to(torch.int64)
+        self._dst = torch.as_tensor(np.concatenate(dst), device=dev).to(torch.int64)
+        self.image = torch.zeros(int(im.image_floats), device=dev)
+        q.image = self.image.data_ptr()
+        self.struct, self.model = q, model
+        self._stage = torch.zeros(self._src.numel(), device=dev)
+        self.refresh()
+
+    def refresh(self):
+        torch.index_select(self.model.params.flat, 0, self._src, out=self._stage)
+        self.image.index_copy_(0, self._dst, self._stage)
+
+    def launch(self, obs, R, h, reset, q_out):
+        s = self.struct
+        s.R, s.obs, s.h, s.q, s.ldq = int(R), ptr(obs), ptr(h), ptr(q_out), int(q_out.shape[1])
+        s.reset = ptr(reset) if reset is not None else None
+        call("xrl_marl_act_gru", C.byref(s), stream_ptr())
+        return q_out
+
+
 def qmix_fused_update(fs, B, obs, obs_next, state, state_next, actions, rewards, terminals, agent_mask, avail_next, slabs,
                       slab_stride, partials, diag):
     q = fs.struct
