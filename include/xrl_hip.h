@@ -706,6 +706,14 @@ typedef struct {
     int32_t R, rows_per_wg, O, H, ldq, act;     /* act: XRL_ACT_* after every pre layer and every post layer but the last */
     int32_t n_pre, n_post;
     int32_t pre[3], post[3];    /* widths: pre = the mlp blocks below the GRU, post = Q head (last = n_actions) */
+    /* optional: xrl_marl_select_actions for the same rows in the same launch (same arithmetic, same Philox keys) */
+    int32_t* action;            /* NULL (no selection) or [R] */
+    float* action_f;            /* NULL or [R] */
+    const float* avail;         /* NULL or [R][n_actions] f32 0/1 */
+    const float* eps_dev;       /* [1] with action */
+    const uint32_t* step_dev;   /* NULL or [1]: added to step */
+    uint64_t seed;
+    uint32_t step, pad;
 } xrl_marl_act_gru_t;
 int xrl_marl_act_gru(const xrl_marl_act_gru_t* p, xrl_stream_t stream);
 int xrl_marl_act_gru_layout(const xrl_marl_act_gru_t* p, xrl_qa_image_t* out);
@@ -794,12 +802,20 @@ typedef struct {
     double* e_state;           /* [1] in/out: the agent's e_greedy (double, as the host keeps it) */
     float* eps_dev;            /* [1] out: e_greedy as the action-selection kernels read it */
     float* active_f;           /* [1] out: 1.0f / 0.0f -- multiply `done` with it before xrl_episode_finish */
-    int32_t* active_i;         /* [2] out: 1 / 0 twice -- add to the two RNG step counters */
+    int32_t* active_i;         /* NULL or [2] out: 1 / 0 twice (for callers that advance their counters themselves) */
     int32_t* host_flags;       /* [ring] or NULL: device pointer of pinned host memory (xrl_host_device_pointer); launch k of a
                                 * call writes its `active` output to host_flags[k % ring] with system scope */
     int32_t* seq;              /* [1] in/out: launches of this call so far (the host sets 0 per call); NULL iff host_flags NULL */
     double start_greedy, end_greedy, delta_greedy;
     int32_t ring, pad;
+    /* optional bookkeeping of the same step, done by the same launch */
+    const float* done;         /* [n_envs] with reset_rows */
+    float* reset_rows;         /* NULL or [n_envs][n_agents]: <- done[env] (the rows that start their next step from zero state) */
+    uint32_t* counters;        /* NULL or [2]: both advanced by `active` as it was when the step ran (RNG step counters) */
+    int32_t n_envs, n_agents;
+    int32_t* ptr_size;         /* NULL, or the episode ring's {ptr, size}: advanced here by the number of done envs when the
+                                * step counted (then call xrl_episode_finish_gated with advance = 0) */
+    int32_t buffer_size, pad2;
 } xrl_marl_gate_t;
 /* Device address of page-locked host memory (hipHostMalloc / torch pin_memory), for kernels that publish a word to the host. */
 int xrl_host_device_pointer(void* pinned_host, void** device_out);
@@ -814,6 +830,11 @@ int xrl_episode_store_step(const xrl_episode_field_t* fields, int n_fields, cons
  * then ptr_size = {ptr, size} advance (device-resident: captured graphs and sampling kernels read them). */
 int xrl_episode_finish(const xrl_episode_field_t* fields, int n_fields, const float* done, const int32_t* end_step,
                        int32_t* ptr_size, int n_envs, int buffer_size, xrl_stream_t stream);
+/* Same, switched by a device scalar: gate NULL or *gate != 0 -> as above; *gate == 0 -> nothing is closed (a dry step of a
+ * loop that runs ahead of its stop condition, xrl_marl_loop_gate). */
+int xrl_episode_finish_gated(const xrl_episode_field_t* fields, int n_fields, const float* gate, const float* done,
+                             const int32_t* end_step, int32_t* ptr_size, int n_envs, int buffer_size, int advance,
+                             xrl_stream_t stream);   /* advance 0: ptr_size is only read (the caller advances it later) */
 /* sample (:970-996): a = time-major batch [slots][B][row], b = ring: a[t][i] <- b[idx[i]][t]. */
 int xrl_episode_gather(const xrl_episode_field_t* fields, int n_fields, const int64_t* idx, int B, xrl_stream_t stream);
 

@@ -537,32 +537,32 @@ def test_runner_surface_of_the_dqn_and_qmix_agents(tmp_path):
     assert "Test-Results/Episode-Rewards" in m2.logged[-1][1]
 
 
-@pytest.mark.parametrize("lag", [0, 1, 3])
-def test_captured_vector_step_equals_the_eager_episode_loop(lag):
+@pytest.mark.parametrize("lag,unroll", [(0, 2), (1, 4), (3, 2), (1, 8)])
+def test_captured_vector_step_equals_the_eager_episode_loop(lag, unroll):
     """run_episodes of the recurrent QMIX agents with the vector step captured as one hipGraph per observation-buffer set
-    (use_hip_graph) vs the eager launch sequence: the same Philox step indices (device counters that start at the host's
+    (use_hip_graph; `unroll` steps per graph launch) vs the eager launch sequence: the same Philox step indices (device counters that start at the host's
     values), hence the same actions, episodes, ring contents, exploration schedule and step accounting -- also when the
-    host enqueues `lag` steps ahead of its knowledge of the loop condition (the dry steps after the call's last episode
-    change nothing a later call or an update can see; the GRU state and the episode staging they touch are re-zeroed by the
-    next call, so those two are compared at lag 0 only)."""
+    host enqueues `lag` graph launches ahead of its knowledge of the loop condition (the dry steps after the call's last
+    episode change nothing a later call or an update can see; the GRU state and the episode staging they touch are
+    re-zeroed by the next call and not compared)."""
     from xuance_amd.agents import QMIX_Agents
     from xuance_amd.envs import SyntheticSMACVecEnv
     res = []
     for graph in (False, True):
         torch.manual_seed(0)
         agent = QMIX_Agents(_rnn_cfg(use_hip_graph=graph, start_training=10 ** 9, start_greedy=0.6, end_greedy=0.05,
-                                     decay_step_greedy=400, episode_loop_lag=lag),
+                                     decay_step_greedy=400, episode_loop_lag=lag, episode_loop_unroll=unroll),
                             SyntheticSMACVecEnv(8, seed=3, max_episode_steps=12, p_term=0.05))
         for _ in range(3):
             agent.run_episodes(8)
         torch.cuda.synchronize()
-        assert (getattr(agent, "_step_graphs", None) is not None and len(agent._step_graphs) == 2) == graph
+        assert (getattr(agent, "_steps_g", None) is not None) == graph
         mem = agent.memory
         res.append(dict(ptr_size=mem.ptr_size.cpu().numpy(), step=np.array([agent.current_step, agent._host_step, agent.envs._host_step]),
                         eps=np.array([agent.e_greedy]), eps_dev=agent.eps_dev.cpu().numpy(),
-                        **({"h": agent.rnn_h.cpu().numpy()} if lag == 0 else {}),
+
                         **{k: v.cpu().numpy() for k, v in mem.data.items()},
-                        **({"ep_" + k: v.cpu().numpy() for k, v in mem.episode_data.items()} if lag == 0 else {})))
+                        ))
     a, b = res
     assert a["ptr_size"][1] >= 24 and a["step"][0] > 0
     for k in a:
@@ -586,8 +586,15 @@ def test_one_launch_acting_step_of_the_recurrent_agents_vs_the_layered_path(R):
             net.act_image().refresh()
         X = torch.randn(R, 30, generator=g).cuda()
         reset = (torch.rand(R, generator=g) < (0.3 if step else 0.0)).float().cuda()
-        q_a = net.act_step(X, R, h_a, reset, fused=True).clone()
-        q_b = net.act_step(X, R, h_b, reset, fused=False).clone()
+        avail = (torch.rand(R, 9, generator=g) < 0.6).float()
+        avail[:, 0] = 1
+        acts = [torch.zeros(R, dtype=torch.int32, device="cuda") for _ in range(2)]
+        sel = lambda a: dict(avail=avail.cuda(), eps_dev=torch.tensor([0.4], device="cuda"), action=a, action_f=None, seed=5,
+                             step=step, step_dev=None)     # (the selection in the same launch vs xrl_marl_select_actions)
+        q_a = net.act_step(X, R, h_a, reset, fused=True, select=sel(acts[0])).clone()
+        q_b = net.act_step(X, R, h_b, reset, fused=False, select=sel(acts[1])).clone()
         assert_close(q_a.cpu().numpy(), q_b.cpu().numpy(), 1e-5, f"q step {step}")
+        assert np.array_equal(acts[0].cpu().numpy(), acts[1].cpu().numpy()), f"actions step {step}"
+        assert (avail.numpy()[np.arange(R), acts[0].cpu().numpy()] == 1).all()
         assert_close(h_a.cpu().numpy(), h_b.cpu().numpy(), 1e-5, f"h step {step}")
     assert float(h_a.abs().max()) > 0

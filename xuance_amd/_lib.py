@@ -209,7 +209,9 @@ class QaImage(C.Structure):
 class MarlActGru(C.Structure):
     _fields_ = [("image", c_void_p), ("obs", c_void_p), ("h", c_void_p), ("reset", c_void_p), ("q", c_void_p),
                 ("R", c_int32), ("rows_per_wg", c_int32), ("O", c_int32), ("H", c_int32), ("ldq", c_int32), ("act", c_int32),
-                ("n_pre", c_int32), ("n_post", c_int32), ("pre", c_int32 * 3), ("post", c_int32 * 3)]
+                ("n_pre", c_int32), ("n_post", c_int32), ("pre", c_int32 * 3), ("post", c_int32 * 3),
+                ("action", c_void_p), ("action_f", c_void_p), ("avail", c_void_p), ("eps_dev", c_void_p), ("step_dev", c_void_p),
+                ("seed", C.c_uint64), ("step", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class Exchange(C.Structure):
@@ -222,7 +224,8 @@ class MarlGate(C.Structure):
                 ("e_state", c_void_p), ("eps_dev", c_void_p), ("active_f", c_void_p), ("active_i", c_void_p),
                 ("host_flags", c_void_p), ("seq", c_void_p),
                 ("start_greedy", C.c_double), ("end_greedy", C.c_double), ("delta_greedy", C.c_double),
-                ("ring", c_int32), ("pad", c_int32)]
+                ("ring", c_int32), ("pad", c_int32), ("done", c_void_p), ("reset_rows", c_void_p), ("counters", c_void_p),
+                ("n_envs", c_int32), ("n_agents", c_int32), ("ptr_size", c_void_p), ("buffer_size", c_int32), ("pad2", c_int32)]
 
 
 class Mirrors(C.Structure):
@@ -251,6 +254,7 @@ _SIGS = {
     "xrl_qmix_mix_td": [C.POINTER(Qmix), c_void_p],
     "xrl_episode_store_step": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_episode_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "xrl_episode_finish_gated": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "xrl_episode_gather": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_marl_loop_gate": [C.POINTER(MarlGate), c_void_p],
     "xrl_qmix_fused_update": [C.POINTER(QmixFused), c_void_p],

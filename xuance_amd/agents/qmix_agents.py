@@ -57,7 +57,8 @@ class QMIX_Agents(AgentSurface):
         dev, R = self.device, self.n_envs * self.n_agents
         self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
         self._host_step = 0
-        self.episode_loop_lag = max(0, int(getattr(config, "episode_loop_lag", 1)))   # steps enqueued ahead of the host
+        self.episode_loop_lag = max(0, int(getattr(config, "episode_loop_lag", 1)))   # graph launches enqueued ahead of the host
+        self.episode_loop_unroll = max(2, int(getattr(config, "episode_loop_unroll", 4)) // 2 * 2)   # vector steps per graph launch
         self.act_f = torch.zeros(self.n_envs, self.n_agents, device=dev)
         if self.use_rnn:
             self.rnn_h = torch.zeros(R, self.model.RH, device=dev)           # init_rnn_states (value_factorization.py:151-159)
@@ -132,10 +133,10 @@ class QMIX_Agents(AgentSurface):
             else:
                 obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
                 steps = env.steps.clone()
-            q = self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused_act)
-            ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
-                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=self._host_step,
-                                    step_dev=None)            # eager loop: the host knows the step index
+            self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused_act,
+                                select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev, action=env.action,
+                                            action_f=self.act_f, seed=self.seed, step=self._host_step,
+                                            step_dev=None))    # eager loop: the host knows the step index
             env.step_device()
             self._host_step += 1
             mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
@@ -156,87 +157,85 @@ class QMIX_Agents(AgentSurface):
             self._update_explore_factor()
 
     def _run_episodes_captured(self, n_episodes, totals):
-        """run_episodes with the whole vector step -- acting forward incl. the recurrence, action selection, provider step,
-        staging store, episode close, reset flags, RNG counters and the loop's own bookkeeping (marl_loop_gate: episodes
-        finished, current_step, the e-greedy schedule, `episodes < n_episodes`) -- as ONE graph launch per step, one graph
-        per observation-buffer set.  The host enqueues step s + `episode_loop_lag` before it reads whether step s + 1 still
-        belongs to the call (one 4-byte pinned read per step, never waited on while the device has work), so a call ends with
-        `episode_loop_lag` dry steps that change nothing the eager loop would see (csrc/episodes.hip)."""
-        env, lag = self.envs, self.episode_loop_lag
-        for c in (0, 1):
-            self._step_graph(c)
+        """run_episodes with the vector step -- acting forward incl. the recurrence and the action selection, provider step,
+        staging store, episode close, and (marl_loop_gate) reset flags, RNG counters, ring pointers and the loop's own
+        bookkeeping: episodes finished, current_step, the e-greedy schedule, `episodes < n_episodes` -- captured, and
+        `episode_loop_unroll` (K, even: the observation-buffer sets alternate) consecutive steps per graph launch: at 5
+        launches and ~35 us of device time per step, one hipGraphLaunch per step leaves the loop host-bound.  The host
+        enqueues graph j + `episode_loop_lag` before it reads whether the step after graph j still belongs to the call (one
+        4-byte pinned read per graph, never waited on while the device has work), so a call ends with up to
+        K * (lag + 1) - 1 dry steps that change nothing the eager loop would see (csrc/episodes.hip)."""
+        env, lag, K = self.envs, self.episode_loop_lag, self.episode_loop_unroll
+        assert env._cur == 0, "the captured steps start on observation-buffer set 0"
+        graph = self._steps_graph()
         g, ring = self._gate, self._flag_h.numel()
         g["base"].copy_(totals)
         self._call_h[0], self._call_h[1] = self.current_step, n_episodes
         g["call"].copy_(self._call_h, non_blocking=True)
         g["e_state"].fill_(self.e_greedy)
-        g["active"].fill_(1); g["active_i"].fill_(1); g["active_f"].fill_(1.0); g["seq"].zero_()
-        launched, counted = 0, None
-        while counted is None:
-            self._step_graph(env._cur).launch()
-            self._flag_ev[launched % ring].record()
-            env.flip()
+        g["active"].fill_(1); g["active_f"].fill_(1.0); g["seq"].zero_()
+        launched, over = 0, False
+        while not over:
+            graph.launch()
+            self._flag_ev[launched % len(self._flag_ev)].record()
             launched += 1
-            k = launched - 1 - lag                                         # the newest step whose outcome is read now
-            if k >= 0:
-                self._flag_ev[k % ring].synchronize()
-                if int(self._flag_h[k % ring]) == 0:                       # "step k + 1 is not part of the call"
-                    counted = k + 1
+            j = launched - 1 - lag                                         # the newest graph whose outcome is read now
+            if j >= 0:
+                self._flag_ev[j % len(self._flag_ev)].synchronize()
+                over = int(self._flag_h[(j * K + K - 1) % ring]) == 0      # "the step after graph j is not part of the call"
         torch.cuda.current_stream().synchronize()
         self._snap_h.copy_(g["snap"])
-        self._host_step += counted
-        env._host_step -= launched - counted                               # (flip() counted the dry steps too)
+        self._rng_h.copy_(self._rng_dev)
+        self._host_step, env._host_step = int(self._rng_h[0]), int(self._rng_h[1])    # (advanced by the steps that counted)
         self.current_step += int(self._snap_h[1])
         self.e_greedy = self._eps_on_device = float(g["e_state"].item())
 
-    def _step_graph(self, cur):
-        """Captured vector step of run_episodes acting on the provider's buffer set `cur` (same launches, same order and
-        same Philox step indices as the eager loop: the indices come from device counters that start at the host's values)."""
-        if not hasattr(self, "_step_graphs"):
-            dev = self.device
-            self._step_graphs = {}
-            self._rng_dev = torch.zeros(2, dtype=torch.int32, device=dev)              # [agent step, provider step]
-            self._gate = dict(base=torch.zeros(2, dtype=torch.int64, device=dev), call=torch.zeros(2, dtype=torch.int64, device=dev),
-                              snap=torch.zeros(2, dtype=torch.int64, device=dev), active=torch.ones(1, dtype=torch.int32, device=dev),
-                              e_state=torch.zeros(1, dtype=torch.float64, device=dev), active_f=torch.ones(1, device=dev),
-                              active_i=torch.ones(2, dtype=torch.int32, device=dev), seq=torch.zeros(1, dtype=torch.int32, device=dev))
-            self._done_gated = torch.zeros(self.n_envs, device=dev)
-            k = self.episode_loop_lag + 2                                             # ring of per-step flags in pinned memory
-            self._flag_h = torch.ones(k, dtype=torch.int32).pin_memory()
-            self._flag_ev = [torch.cuda.Event() for _ in range(k)]
-            self._snap_h = torch.zeros(2, dtype=torch.int64).pin_memory()
-            self._call_h = torch.zeros(2, dtype=torch.int64).pin_memory()
-            self._gate_const = dict(host_flags=ops.host_device_pointer(self._flag_h), ring=k)
-        g = self._step_graphs.get(cur)
-        if g is not None:
-            return g
+    def _steps_graph(self):
+        """K captured vector steps of run_episodes, alternating between the provider's two buffer sets (same launches, same
+        order and same Philox step indices as the eager loop: the indices come from device counters that start at the host's
+        values)."""
+        if getattr(self, "_steps_g", None) is not None:
+            return self._steps_g
+        dev, K, lag = self.device, self.episode_loop_unroll, self.episode_loop_lag
         env, n, N, A, mem = self.envs, self.n_envs, self.n_agents, self.n_actions, self.memory
         R = n * N
-        if not self._step_graphs:                                                     # first capture: counters take over here
-            self._rng_dev.copy_(torch.tensor([self._host_step, env._host_step], dtype=torch.int32))
+        self._rng_dev = torch.tensor([self._host_step, env._host_step], dtype=torch.int32).to(dev)   # [agent step, provider step]
+        self._rng_h = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._gate = gt = dict(base=torch.zeros(2, dtype=torch.int64, device=dev), call=torch.zeros(2, dtype=torch.int64, device=dev),
+                               snap=torch.zeros(2, dtype=torch.int64, device=dev), active=torch.ones(1, dtype=torch.int32, device=dev),
+                               e_state=torch.zeros(1, dtype=torch.float64, device=dev), active_f=torch.ones(1, device=dev),
+                               seq=torch.zeros(1, dtype=torch.int32, device=dev))
+        ring = K * (lag + 2)                                                          # per-step flags in pinned memory
+        self._flag_h = torch.ones(ring, dtype=torch.int32).pin_memory()
+        self._flag_ev = [torch.cuda.Event() for _ in range(lag + 2)]
+        self._snap_h = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self._call_h = torch.zeros(2, dtype=torch.int64).pin_memory()
+        gate_const = dict(host_flags=ops.host_device_pointer(self._flag_h), ring=ring)
+        fused = bool(getattr(self.config, "use_fused_acting", True))
         self.model.seq_workspace(2, R, 1)                                             # (no allocation inside the capture)
         if self.model.act_image() is not None:
             self.model.act_q_buffer(R)
-        obs, state, avail = env._sets[cur]
-        gt = self._gate
         torch.cuda.synchronize()
         g = ops.Graph()
         with g:
-            q = self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c,
-                                    fused=bool(getattr(self.config, "use_fused_acting", True)))
-            ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
-                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=0,
-                                    step_dev=self._rng_dev[0:1])
-            env.enqueue_step(cur, counter=self._rng_dev[1:2])
-            mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
-                      avail_actions=avail, state=state, episode_steps=env.prev_steps)
-            torch.mul(env.done, gt["active_f"], out=self._done_gated)                  # a dry step closes no episode
-            mem.finish_paths(self._done_gated, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail)
-            torch.mul(env.done[:, None].expand(n, N), 1.0, out=self.reset_rows.view(n, N))   # (a kernel, not a memcpy node)
-            torch.add(self._rng_dev, gt["active_i"], out=self._rng_dev)
-            ops.marl_loop_gate(totals=env.episode_totals, start_greedy=float(self.start_greedy), end_greedy=float(self.end_greedy),
-                               delta_greedy=float(self.delta_egreedy), eps_dev=self.eps_dev, **self._gate_const, **gt)
-        self._step_graphs[cur] = g
+            for k in range(K):
+                cur = k & 1
+                obs, state, avail = env._sets[cur]
+                self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused,
+                                    select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
+                                                action=env.action, action_f=self.act_f, seed=self.seed, step=0,
+                                                step_dev=self._rng_dev[0:1]))
+                env.enqueue_step(cur, counter=self._rng_dev[1:2])
+                mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
+                          avail_actions=avail, state=state, episode_steps=env.prev_steps)
+                mem.finish_paths(env.done, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail,
+                                 gate=gt["active_f"], advance=False)                     # a dry step closes no episode
+                # reset flags of the finished envs' rows, RNG counters (+active), ring pointers and the loop's bookkeeping
+                ops.marl_loop_gate(totals=env.episode_totals, start_greedy=float(self.start_greedy),
+                                   end_greedy=float(self.end_greedy), delta_greedy=float(self.delta_egreedy),
+                                   eps_dev=self.eps_dev, done=env.done, reset_rows=self.reset_rows, counters=self._rng_dev,
+                                   n_envs=n, n_agents=N, ptr_size=mem.ptr_size, buffer_size=mem.buffer_size, **gate_const, **gt)
+        self._steps_g = g
         return g
 
     def _train_rnn(self, train_steps):                         # off_policy_marl.py:335-349

@@ -31,12 +31,12 @@ __global__ void __launch_bounds__(64) episode_store_kernel(EpPack f, const int32
 }
 
 // finish_path + store_episodes (:923-968) for every finished env, in env order.  grid (n_envs, n_fields), 256 threads
-__global__ void __launch_bounds__(256) episode_finish_kernel(EpPack f, const float* __restrict__ done,
+__global__ void __launch_bounds__(256) episode_finish_kernel(EpPack f, const float* __restrict__ gate, const float* __restrict__ done,
                                                              const int32_t* __restrict__ end_step,
                                                              const int32_t* __restrict__ ptr_size, int n_envs,
                                                              int buffer_size) {
     const int env = blockIdx.x, fi = blockIdx.y;
-    if (done[env] == 0.f) return;
+    if ((gate && *gate == 0.f) || done[env] == 0.f) return;
     int rank = 0;
     for (int j = 0; j < env; ++j) rank += done[j] != 0.f;                // this env's position among the finished ones
     const int dst_ep = (ptr_size[0] + rank) % buffer_size;               // self.ptr advances once per stored episode
@@ -57,8 +57,9 @@ __global__ void __launch_bounds__(256) episode_finish_kernel(EpPack f, const flo
     }
 }
 
-__global__ void episode_advance_kernel(const float* __restrict__ done, int32_t* __restrict__ ptr_size, int n_envs,
+__global__ void episode_advance_kernel(const float* __restrict__ gate, const float* __restrict__ done, int32_t* __restrict__ ptr_size, int n_envs,
                                        int buffer_size) {
+    if (gate && *gate == 0.f) return;
     int c = 0;
     for (int j = 0; j < n_envs; ++j) c += done[j] != 0.f;
     ptr_size[0] = (ptr_size[0] + c) % buffer_size;
@@ -87,8 +88,20 @@ __global__ void __launch_bounds__(256) episode_gather_kernel(EpPack f, const int
 // call is over is dry: the captured step multiplies `done` by active_f (no episode is closed into the ring) and adds
 // active_i to its RNG step counters (they do not advance); its other writes land in per-call state the next call resets.
 __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // the step's remaining per-row bookkeeping rides along: reset flags of the rows whose env finished (a dry step's are
+    // wiped by the next call), RNG step counters advanced by `active`
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g.reset_rows && t < g.n_envs * g.n_agents) g.reset_rows[t] = g.done[t / g.n_agents];
+    if (t != 0) return;
     int act = *g.active;                                                  // did the step that just ran count?
+    if (g.counters) { g.counters[0] += (unsigned)act; g.counters[1] += (unsigned)act; }
+    if (g.ptr_size && act) {                                              // episode_advance_kernel's statements
+        int c = 0;
+        for (int j = 0; j < g.n_envs; ++j) c += g.done[j] != 0.f;
+        g.ptr_size[0] = (g.ptr_size[0] + c) % g.buffer_size;
+        const int sz = g.ptr_size[1] + c;
+        g.ptr_size[1] = sz < g.buffer_size ? sz : g.buffer_size;
+    }
     if (act) {
         const long long ep = g.totals[0] - g.base[0], st = g.totals[1] - g.base[1];
         g.snap[0] = ep; g.snap[1] = st;
@@ -101,7 +114,7 @@ __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
         *g.active = act;
     }
     *g.active_f = act ? 1.f : 0.f;
-    g.active_i[0] = act; g.active_i[1] = act;
+    if (g.active_i) { g.active_i[0] = act; g.active_i[1] = act; }
     if (g.host_flags) {                                                   // the host's copy: slot (launch index mod ring)
         const int k = *g.seq;
         *g.seq = k + 1;
@@ -135,18 +148,25 @@ extern "C" int xrl_episode_store_step(const xrl_episode_field_t* fields, int n_f
     return XRL_OK;
 }
 
-extern "C" int xrl_episode_finish(const xrl_episode_field_t* fields, int n_fields, const float* done,
-                                  const int32_t* end_step, int32_t* ptr_size, int n_envs, int buffer_size,
-                                  xrl_stream_t stream) {
+extern "C" int xrl_episode_finish_gated(const xrl_episode_field_t* fields, int n_fields, const float* gate, const float* done,
+                                        const int32_t* end_step, int32_t* ptr_size, int n_envs, int buffer_size, int advance,
+                                        xrl_stream_t stream) {
     EpPack p;
     XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
     XRL_CHECK_ARG(done && end_step && ptr_size && n_envs > 0 && buffer_size > 0);
-    hipLaunchKernelGGL(episode_finish_kernel, dim3(n_envs, n_fields), dim3(256), 0, as_stream(stream), p, done, end_step,
+    hipLaunchKernelGGL(episode_finish_kernel, dim3(n_envs, n_fields), dim3(256), 0, as_stream(stream), p, gate, done, end_step,
                        ptr_size, n_envs, buffer_size);
-    hipLaunchKernelGGL(episode_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), done, ptr_size, n_envs,
-                       buffer_size);
+    if (advance)
+        hipLaunchKernelGGL(episode_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), gate, done, ptr_size, n_envs,
+                           buffer_size);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
+}
+
+extern "C" int xrl_episode_finish(const xrl_episode_field_t* fields, int n_fields, const float* done,
+                                  const int32_t* end_step, int32_t* ptr_size, int n_envs, int buffer_size,
+                                  xrl_stream_t stream) {
+    return xrl_episode_finish_gated(fields, n_fields, nullptr, done, end_step, ptr_size, n_envs, buffer_size, 1, stream);
 }
 
 extern "C" int xrl_host_device_pointer(void* pinned_host, void** device_out) {
@@ -158,9 +178,12 @@ extern "C" int xrl_host_device_pointer(void* pinned_host, void** device_out) {
 extern "C" int xrl_marl_loop_gate(const xrl_marl_gate_t* gate, xrl_stream_t stream) {
     XRL_CHECK_ARG(gate != nullptr);
     const xrl_marl_gate_t& g = *gate;
-    XRL_CHECK_ARG(g.totals && g.base && g.snap && g.active && g.call && g.e_state && g.eps_dev && g.active_f && g.active_i);
+    XRL_CHECK_ARG(g.totals && g.base && g.snap && g.active && g.call && g.e_state && g.eps_dev && g.active_f);
     XRL_CHECK_ARG(g.host_flags == nullptr || (g.seq != nullptr && g.ring > 0));
-    hipLaunchKernelGGL(marl_loop_gate_kernel, dim3(1), dim3(64), 0, as_stream(stream), g);
+    XRL_CHECK_ARG(g.reset_rows == nullptr || (g.done && g.n_envs > 0 && g.n_agents > 0));
+    XRL_CHECK_ARG(g.ptr_size == nullptr || (g.done && g.n_envs > 0 && g.buffer_size > 0));
+    const int n = g.reset_rows ? g.n_envs * g.n_agents : 1;
+    hipLaunchKernelGGL(marl_loop_gate_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), g);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -15,6 +15,7 @@
 // [eval agent | target agent | target mixer] at the start, and the eval mixer over the target mixer's space once the
 // target hyper-networks have run (106 KB of weights + ~30 KB of activations at 4 transitions per workgroup).
 #include "common.h"
+#include "rng.h"
 
 // (the library is built with -ffp-contract=off for the kernels that must round like NumPy; nothing here has to, and the
 // products are VALU-bound: fused multiply-adds halve their instruction count)
@@ -640,6 +641,15 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
         const int r = i / A, k = i - r * A;
         p->q[(size_t)(r0 + r) * p->ldq + k] = lds[L->q + r * L->ldq + k];
     }
+    // ---- optional: the step's action selection for these rows (xrl_marl_select_actions' arithmetic and Philox keys)
+    if (p->action && tid < rows) {
+        const int r = r0 + tid;
+        const uint32_t step = p->step + (p->step_dev ? *p->step_dev : 0u);
+        const int a = marl_select_row(lds + L->q + tid * L->ldq, p->avail ? p->avail + (size_t)r * A : nullptr, A, p->seed, step, r,
+                                      *p->eps_dev, nullptr, nullptr);
+        p->action[r] = a;
+        if (p->action_f) p->action_f[r] = (float)a;
+    }
 }
 
 }  // namespace xrl
@@ -701,6 +711,7 @@ extern "C" int xrl_marl_act_gru(const xrl_marl_act_gru_t* pp, xrl_stream_t strea
     XRL_CHECK_ARG(p.image && p.obs && p.h && p.q && p.R > 0 && p.rows_per_wg > 0 && p.H >= 1 && p.O >= 1);
     XRL_CHECK_ARG(p.n_pre >= 0 && p.n_post >= 1 && p.n_pre + p.n_post + 2 <= XRL_QA_MAX_LAYERS);
     XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p.image) & 15) == 0 && p.ldq >= p.post[p.n_post - 1]);
+    XRL_CHECK_ARG(p.action == nullptr || (p.eps_dev != nullptr && p.rows_per_wg <= QF_THREADS));
     QaArgs args{};
     args.p = p;
     args.L = qa_layout(p);

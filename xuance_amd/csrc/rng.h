@@ -31,4 +31,37 @@ __device__ __forceinline__ double u01d(uint32_t a, uint32_t b) {
 constexpr uint32_t STREAM_ACTION = 0x41435431u, STREAM_GAUSS = 0x47415500u, STREAM_RESET_A = 0x52455345u,
                    STREAM_RESET_B = 0x52455346u, STREAM_EGREEDY = 0x45475200u;
 
+
+// One row of xrl_marl_select_actions (off_policy_marl.py:212-255): masked greedy action of q_row unless the step's coin lands
+// under epsilon, then the k-th AVAILABLE action, k uniform.  Shared by marl_select_kernel and the one-launch acting step.
+__device__ __forceinline__ int marl_select_row(const float* q_row, const float* av, int A, uint64_t seed, uint32_t step, int r,
+                                               float eps, const float* coin_in, const float* uniforms) {
+    int best = 0, n_avail = 0;
+    float bv = (av && av[0] == 0.f) ? -1e10f : q_row[0];
+    for (int j = 0; j < A; ++j) {
+        const bool ok = !av || av[j] != 0.f;
+        n_avail += ok;
+        const float v = ok ? q_row[j] : -1e10f;
+        if (j > 0 && v > bv) { bv = v; best = j; }
+    }
+    uint32_t c[4];
+    philox4x32(seed, 0xFFFFFFFFu, step, STREAM_EGREEDY, c);               // the step coin: same counter for every row
+    const float coin = coin_in ? *coin_in : u01(c[0]);
+    int a = best;
+    if (coin < eps) {
+        uint32_t rr[4];
+        philox4x32(seed, (uint32_t)r, step, STREAM_EGREEDY + 1u, rr);
+        const float u = uniforms ? uniforms[r] : u01(rr[0]);
+        const int na = n_avail > 1 ? n_avail : 1;
+        int kth = (int)(u * (float)na), seen = 0;
+        if (kth > na - 1) kth = na - 1;
+        a = 0;
+        for (int j = 0; j < A; ++j) {
+            const bool ok = !av || av[j] != 0.f;
+            if (ok) { if (seen == kth) { a = j; break; } ++seen; }
+        }
+    }
+    return a;
+}
+
 }  // namespace xrl

@@ -433,32 +433,9 @@ __global__ void __launch_bounds__(256) egreedy_kernel(xrl_egreedy_t p) {
 __global__ void __launch_bounds__(256) marl_select_kernel(xrl_marl_act_t p) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.R) return;
-    const float* q = p.q + (size_t)r * p.ld;
-    const float* av = p.avail ? p.avail + (size_t)r * p.A : nullptr;
-    int best = 0, n_avail = 0;
-    float bv = (av && av[0] == 0.f) ? -1e10f : q[0];
-    for (int j = 0; j < p.A; ++j) {
-        const bool ok = !av || av[j] != 0.f;
-        n_avail += ok;
-        const float v = ok ? q[j] : -1e10f;
-        if (j > 0 && v > bv) { bv = v; best = j; }
-    }
     const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
-    uint32_t c[4];
-    philox4x32(p.seed, 0xFFFFFFFFu, step, STREAM_EGREEDY, c);             // the step coin: same counter for every row
-    const float coin = p.coin ? *p.coin : u01(c[0]);
-    int a = best;
-    if (coin < *p.eps_dev) {
-        uint32_t rr[4];
-        philox4x32(p.seed, (uint32_t)r, step, STREAM_EGREEDY + 1u, rr);
-        const float u = p.uniforms ? p.uniforms[r] : u01(rr[0]);
-        int kth = min((int)(u * (float)max(n_avail, 1)), max(n_avail, 1) - 1), seen = 0;
-        a = 0;
-        for (int j = 0; j < p.A; ++j) {
-            const bool ok = !av || av[j] != 0.f;
-            if (ok) { if (seen == kth) { a = j; break; } ++seen; }
-        }
-    }
+    const int a = marl_select_row(p.q + (size_t)r * p.ld, p.avail ? p.avail + (size_t)r * p.A : nullptr, p.A, p.seed, step, r,
+                                  *p.eps_dev, p.coin, p.uniforms);
     p.action[r] = a;
     if (p.action_f) p.action_f[r] = (float)a;
 }

@@ -206,7 +206,7 @@ class HipMARLOffPolicyBufferRNN:
         fields.append((self.episode_data["filled"], self._ones, None, 4, self.max_eps_len, 0))
         ops.episode_store_step(fields, steps, self.n_envs)
 
-    def finish_paths(self, done, end_step, obs=None, state=None, avail_actions=None):
+    def finish_paths(self, done, end_step, obs=None, state=None, avail_actions=None, gate=None, advance=True):
         """finish_path (:951-968) for every env with done != 0, in env order, in two launches.  done [n_envs] f32,
         end_step [n_envs] int32 (info['episode_step']), terminal obs / state / avail_actions as in `store`."""
         term = {"obs": obs, "state": state if self.store_global_state else None,
@@ -216,7 +216,7 @@ class HipMARLOffPolicyBufferRNN:
         fields = [(self.data[k], self.episode_data[k], term.get(k), 4 * w, sl, 1 if k == "filled" else 0)
                   for k, (w, sl) in self.layout.items()]
         ops.episode_finish(fields, done.to(torch.float32).contiguous(), self._dev_steps(end_step), self.ptr_size,
-                           self.n_envs, self.buffer_size)
+                           self.n_envs, self.buffer_size, gate=gate, advance=advance)   # gate: device scalar, 0 = close nothing
 
     def finish_path(self, i_env, **terminal_data):            # :951-968, one env (the reference's call)
         done = torch.zeros(self.n_envs, device=self.device)

@@ -683,15 +683,19 @@ class MixingQNet:
         self._recurrence(gi, ws, R, T1, flat, which == 0, h0=h0, c0=c0, reset=reset, h_last=h_last, c_last=c_last)
         return self.post_plans[which].forward(ws["hs"][R:], self.RH, T1 * R, flat=flat)
 
-    def act_step(self, X, R, h, reset=None, c=None, fused=True):
+    def act_step(self, X, R, h, reset=None, c=None, fused=True, select=None):
         """Q values [R, n_actions] of ONE acting step from observations X [R, obs_dim] and the carried state h [R, H] (and c
         for LSTM agents), which is replaced by the new state; rows with reset != 0 start from zeros.  GRU agents whose
         weights fit LDS take the one-launch path (xrl_marl_act_gru); `act_image().refresh()` must have run since the
-        parameters last changed."""
+        parameters last changed.  select: keyword arguments of ops.marl_select_actions (without q / R / A / ld): the
+        epsilon-greedy selection on these Q values, in the same launch on the one-launch path."""
         st = self.act_image() if fused and not self.lstm else None
         if st is None:
-            return self.agent_forward_seq(X, R, 1, which=2, h0=h, reset=reset, h_last=h, c0=c, c_last=c)
-        return st.launch(X, R, h, reset, self.act_q_buffer(R))
+            q = self.agent_forward_seq(X, R, 1, which=2, h0=h, reset=reset, h_last=h, c0=c, c_last=c)
+            if select is not None:
+                ops.marl_select_actions(q=q, R=R, A=self.n_actions, ld=self.n_actions, **select)
+            return q
+        return st.launch(X, R, h, reset, self.act_q_buffer(R), select=select)
 
     def act_q_buffer(self, R):
         """(allocated outside any graph capture: callers that capture act_step touch it first)"""

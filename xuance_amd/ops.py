@@ -434,9 +434,12 @@ def episode_store_step(items, steps, n_envs):
     call("xrl_episode_store_step", _ep_fields(items), len(items), ptr(_chk(steps, torch.int32)), int(n_envs), stream_ptr())
 
 
-def episode_finish(items, done, end_step, ptr_size, n_envs, buffer_size):
-    call("xrl_episode_finish", _ep_fields(items), len(items), ptr(_chk(done)), ptr(_chk(end_step, torch.int32)),
-         ptr(_chk(ptr_size, torch.int32)), int(n_envs), int(buffer_size), stream_ptr())
+def episode_finish(items, done, end_step, ptr_size, n_envs, buffer_size, gate=None, advance=True):
+    """gate: None, or a device float scalar -- 0 turns the call into a no-op (xrl_episode_finish_gated).  advance=False:
+    the ring's {ptr, size} are left for the caller to advance (xrl_marl_loop_gate does it in its own launch)."""
+    call("xrl_episode_finish_gated", _ep_fields(items), len(items), ptr(gate) if gate is not None else None, ptr(_chk(done)),
+         ptr(_chk(end_step, torch.int32)), ptr(_chk(ptr_size, torch.int32)), int(n_envs), int(buffer_size), int(bool(advance)),
+         stream_ptr())
 
 
 def host_device_pointer(pinned):
@@ -565,10 +568,20 @@ class MarlActGruState:
         torch.index_select(self.model.params.flat, 0, self._src, out=self._stage)
         self.image.index_copy_(0, self._dst, self._stage)
 
-    def launch(self, obs, R, h, reset, q_out):
+    def launch(self, obs, R, h, reset, q_out, select=None):
+        """select: None, or the keyword arguments of marl_select_actions (action, action_f, avail, eps_dev, seed, step,
+        step_dev) -- the selection then happens in the same launch."""
         s = self.struct
         s.R, s.obs, s.h, s.q, s.ldq = int(R), ptr(obs), ptr(h), ptr(q_out), int(q_out.shape[1])
         s.reset = ptr(reset) if reset is not None else None
+        if select is None:
+            s.action = None
+        else:
+            s.action, s.eps_dev = ptr(select["action"]), ptr(select["eps_dev"])
+            s.action_f = ptr(select["action_f"]) if select.get("action_f") is not None else None
+            s.avail = ptr(select["avail"]) if select.get("avail") is not None else None
+            s.step_dev = ptr(select["step_dev"]) if select.get("step_dev") is not None else None
+            s.seed, s.step = int(select["seed"]), int(select.get("step", 0))
         call("xrl_marl_act_gru", C.byref(s), stream_ptr())
         return q_out
 
