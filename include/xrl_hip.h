@@ -158,9 +158,20 @@ typedef struct {
     int32_t mode;          /* 0: PPO-clip surrogate; 1: A2C actor term -(adv * log_prob).mean() (a2c_learner.py:47), no ratio:
                             * old_logp is not read, partials[0] = sum adv*log_prob, n_clipped = 0;
                             * 2: PG actor term -(returns * log_prob).mean(), no critic (pg_learner.py:40-45): adv, value,
-                            * d_value, old_logp are not touched */
+                            * d_value, old_logp are not touched;
+                            * 3: PPO-KL (ppokl_learner.py:46-60): -(ratio * adv).mean() + kl_coef * KL(new || old).mean(), the old
+                            * log-prob and the KL from the OLD DISTRIBUTION's parameters below (old_logp is not read);
+                            * partials[5] = sum of KL (categorical: per row; gaussian: per row and dimension) */
+    int32_t pad_mode;
+    const float* old_a;    /* mode 3: [M][A] old logits (any normalisation) / old mu */
+    const float* old_b;    /* mode 3, gaussian: [M][A] old std */
+    const double* kl_coef; /* mode 3: [1] in device memory (advanced by xrl_ppokl_adapt) */
 } xrl_ppo_loss_t;
 
+/* kl_coef schedule of PPOKL_Learner.update (ppokl_learner.py:62-66): kl = sum_i partials[i][5] / count; > 1.5 target: x 2,
+ * < 0.5 target: / 2, clipped to [0.1, 20]; kl_out (NULL or [1]) receives kl.  Launch after the loss of the same update. */
+int xrl_ppokl_adapt(const double* partials, int n_split, double count, double* kl_coef, double target_kl, float* kl_out,
+                    xrl_stream_t stream);
 int xrl_ppo_loss_categorical(const xrl_ppo_loss_t* p, xrl_stream_t stream);
 int xrl_ppo_loss_gaussian(const xrl_ppo_loss_t* p, xrl_stream_t stream);
 /* out[j] = sum_s partials[s][j]  (float64 in, float64 out), j < width */

@@ -267,6 +267,85 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo", size=None):
     np.savez_compressed(os.path.join(OUT, f"{name}_{dist}{'_' + size if size else ''}.npz"), **out)
 
 
+def golden_ppokl(dist):
+    """PPOKL_Learner (ppokl_learner.py:14-101).  The reference's update reads `model_output.distribution` (:48) while
+    ActorCriticOutput names the field `distributions`, so it raises AttributeError as shipped.  The fixture runs the
+    UNMODIFIED learner on a model whose forward output also carries that attribute name (an alias set on the output object:
+    nothing of the learner is restated or patched); old_dists are reference distribution objects produced by
+    split_distributions, as PPOKL_Agent stores them (ppokl_agent.py:20-30)."""
+    from xuance.torch.learners import PPOKL_Learner
+    from xuance.torch.rl_models.modules.distributions import (CategoricalDistribution, DiagGaussianDistribution,
+                                                               split_distributions)
+    torch.manual_seed(3)
+    rng = np.random.default_rng(31)
+    init = torch.nn.init.orthogonal_
+    if dist == "categorical":
+        D, A, bs, act_fn = 4, 3, 96, nn.LeakyReLU
+        rep = Basic_MLP((D,), [128], None, init, act_fn, "cpu")
+        actor = CategoricalActorHead(128, [128], A, None, init, act_fn, "cpu")
+        critic = ValueHead(128, [128], None, init, act_fn, "cpu")
+    else:
+        D, A, bs, act_fn = 17, 6, 80, nn.LeakyReLU
+        rep = Basic_Identical((D,), "cpu")
+        actor = GaussianActorHead(D, [64, 64], A, None, init, act_fn, nn.Tanh, "cpu")
+        critic = ValueHead(D, [64, 64], None, init, act_fn, "cpu")
+    cfg = base_config(horizon_size=256, n_epochs=8, n_minibatch=8, vf_coef=0.25, ent_coef=0.01, target_kl=0.02, kl_coef=1.0,
+                      end_factor_lr_decay=0.5)
+    model = SharedActorCritic(rep, actor, critic)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.1))
+    inner = model.forward
+
+    def forward_with_alias(*a, **k):
+        out = inner(*a, **k)
+        out.distribution = out.distributions
+        return out
+    model.forward = forward_with_alias
+    cb = Capture()
+    learner = PPOKL_Learner(cfg, model, cb)
+    coefs, batches = [], []
+    for u in range(4):
+        obs = np.clip(rng.standard_normal((bs, D)), -5, 5).astype(np.float32)
+        noise = ([0.05, 0.6, 0.02, 0.3] if dist == "categorical" else [0.05, 0.3, 0.02, 0.2])[u]   # small / large KL: the coefficient halves, doubles, ...
+        with torch.no_grad():
+            d_new = inner(torch.from_numpy(obs)).distributions
+            if dist == "categorical":
+                old = CategoricalDistribution(A)
+                old.set_param(logits=d_new.logits + noise * torch.from_numpy(rng.standard_normal((bs, A)).astype(np.float32)))
+                actions = rng.integers(0, A, bs).astype(np.float32)
+                old_a, old_b = old.logits.numpy().copy(), np.zeros((bs, A), np.float32)
+            else:
+                old = DiagGaussianDistribution(A)
+                # (one std vector for the whole batch: GaussianActorHead's log_std is a parameter, actor_head.py:64-71)
+                # actions as a rollout would draw them (near mu, in units of std), the old policy a small step away
+                old.set_param(d_new.mu + noise * d_new.std * torch.from_numpy(rng.standard_normal((bs, A)).astype(np.float32)),
+                              d_new.std * torch.from_numpy(np.exp(0.3 * noise * rng.standard_normal(A)).astype(np.float32)))
+                actions = (d_new.mu + d_new.std * torch.from_numpy(rng.standard_normal((bs, A)).astype(np.float32))).numpy().copy()
+                old_a, old_b = old.mu.numpy().copy(), np.broadcast_to(old.std.numpy(), (bs, A)).copy()
+        adv = rng.standard_normal(bs).astype(np.float32)
+        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).astype(np.float32)
+        batches.append(dict(obs=obs, actions=actions, returns=rng.standard_normal(bs).astype(np.float32), advantages=adv,
+                            old_a=old_a, old_b=old_b, _old=split_distributions(old)))
+
+    def call(b):
+        info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], advantages=b["advantages"],
+                              aux_batch={"old_dist": b["_old"]}, batch_size=len(b["obs"]))
+        coefs.append(float(learner.kl_coef))
+        return info
+    clean = [{k: v for k, v in b.items() if not k.startswith("_")} for b in batches]
+    out = run_learner_updates(learner, model, cb, batches, call)
+    out = {k: v for k, v in out.items() if "/batch/_old" not in k}
+    for u, b in enumerate(clean):
+        out.update(flat(f"u{u}/batch", b))
+    out["kl_coef_after"] = np.array(coefs, np.float64)
+    out["cfg"] = np.array([cfg.learning_rate, cfg.vf_coef, cfg.ent_coef, cfg.target_kl, cfg.kl_coef, cfg.grad_clip_norm,
+                           cfg.end_factor_lr_decay, learner.total_iters])
+    out["n_updates"] = np.int64(4)
+    np.savez_compressed(os.path.join(OUT, f"ppokl_{dist}.npz"), **out)
+
+
 # ------------------------------------------------------------------------------ DQN
 def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None):
     """learner_cls: DQN_Learner (default), DDQN_Learner (ddqn_learner.py:39-47, the double-Q target) or DuelDQN_Learner
@@ -800,6 +879,8 @@ if __name__ == "__main__":
     golden_per_buffer()
     golden_pg("categorical")
     golden_pg("gaussian")
+    golden_ppokl("categorical")
+    golden_ppokl("gaussian")
     golden_baseline_sizes()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -383,8 +383,8 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
     v = critic.forward(h)[:, 0]
     B = obs.shape[0]
     adv, ret = batch["advantages"].astype(dt), batch["returns"].astype(dt)
-    a2c = loss_kind == "a2c"
-    old_logp = np.zeros(B, dt) if a2c else batch["old_logp"].astype(dt)
+    a2c, ppokl = loss_kind == "a2c", loss_kind == "ppokl"
+    old_logp = np.zeros(B, dt) if (a2c or ppokl) else batch["old_logp"].astype(dt)
     clip = dt(cfg.get("clip_range", 0.0))
 
     if dist == "categorical":
@@ -393,6 +393,11 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
         p = np.exp(lsm)
         logp = lsm[np.arange(B), a]                                     # Categorical.log_prob
         ent = -(p * lsm).sum(-1)                                        # Categorical.entropy
+        if ppokl:                                                       # ppokl_learner.py:51-54 (old_dists: stored logits)
+            q_old = log_softmax(batch["old_a"].astype(dt))              # Categorical(logits=...) normalises
+            old_logp = q_old[np.arange(B), a]
+            kl_row = (p * (lsm - q_old)).sum(-1)                        # torch kl_divergence(Categorical, Categorical)
+            kl = kl_row.mean()
     else:
         log_std = sd["actor.log_std"].astype(dt)
         std = np.exp(log_std)
@@ -402,6 +407,13 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
         lp = -((x - out_a) ** 2) / (2 * var) - log_std - dt(math.log(math.sqrt(2 * math.pi)))
         logp = lp.sum(-1)
         ent = np.broadcast_to((dt(0.5 + 0.5 * math.log(2 * math.pi)) + log_std).sum(-1), (B,)).astype(dt)
+        if ppokl:
+            mu_o, std_o = batch["old_a"].astype(dt), batch["old_b"].astype(dt)
+            old_logp = (-((x - mu_o) ** 2) / (2 * std_o * std_o) - np.log(std_o) - dt(math.log(math.sqrt(2 * math.pi)))).sum(-1)
+            var_ratio = (std / std_o) ** 2                             # torch kl_divergence(Normal, Normal): ELEMENTWISE,
+            t1 = ((out_a - mu_o) / std_o) ** 2                          # so .mean() below averages over B x A
+            kl_el = dt(0.5) * (var_ratio + t1 - 1 - np.log(var_ratio))
+            kl = kl_el.mean()
 
     ratio = np.exp(logp - old_logp)                                     # :52
     s1 = np.clip(ratio, 1 - clip, 1 + clip) * adv                       # :53
@@ -409,6 +421,9 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
     a_loss = -np.minimum(s1, s2).mean()                                 # :55
     if a2c:
         a_loss = -(adv * logp).mean()                                   # a2c_learner.py:47
+    if ppokl:
+        kl_coef = dt(cfg["kl_coef"])
+        a_loss = -(ratio * adv).mean() + kl_coef * kl                   # ppokl_learner.py:58
     c_loss = ((v - ret) ** 2).mean()                                    # :57
     e_loss = ent.mean()                                                 # :59
     loss = a_loss - dt(cfg["ent_coef"]) * e_loss + dt(cfg["vf_coef"]) * c_loss   # :60
@@ -425,6 +440,8 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
     dlogp = dratio * ratio
     if a2c:
         dlogp = -adv * invB
+    if ppokl:
+        dlogp = -adv * ratio * invB
     dv = dt(cfg["vf_coef"]) * 2 * (v - ret) * invB
     grads = {}
     if dist == "categorical":
@@ -434,11 +451,17 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
         # d entropy / d logits_j = -p_j (lsm_j + H)
         dent = -p * (lsm + ent[:, None])
         dlogits = dlogits + (-dt(cfg["ent_coef"]) * invB) * dent
+        if ppokl:                                                       # d kl_row / d logits_j = p_j (l_j - q_j - kl_row)
+            dlogits = dlogits + (kl_coef * invB) * p * (lsm - q_old - kl_row[:, None])
         dout_a = dlogits
     else:
         dmu = dlogp[:, None] * (x - out_a) / var
         dlog_std = (dlogp[:, None] * (((x - out_a) ** 2) / var - 1)).sum(0)
         dlog_std = dlog_std + (-dt(cfg["ent_coef"])) * np.ones_like(log_std)   # d mean(ent)/d log_std = 1
+        if ppokl:
+            w = kl_coef / dt(B * out_a.shape[1])
+            dmu = dmu + w * (out_a - mu_o) / (std_o * std_o)
+            dlog_std = dlog_std + w * (var_ratio - 1).sum(0)
         grads["actor.log_std"] = dlog_std.astype(dt)
         dout_a = dmu
     dh_a, g_actor = actor.backward(dout_a, need_dx=bool(rep_l))
@@ -456,7 +479,18 @@ def ppo_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", a
     info = dict(logits_or_mu=out_a, v_pred=v, log_prob=logp, ratio=ratio, surrogate1=s1, surrogate2=s2,
                 a_loss=a_loss, c_loss=c_loss, e_loss=e_loss, loss=loss, clip_ratio=cr,
                 predict_value=v.mean(), entropy=ent)
+    if ppokl:
+        info["kl"] = kl
     return info, grads
+
+
+def ppokl_adapt(kl_coef, kl, target_kl):
+    """The coefficient schedule of ppokl_learner.py:62-66 (a Python float; kl is a float32 tensor there)."""
+    if np.float32(kl) > np.float32(target_kl * 1.5):
+        kl_coef = kl_coef * 2.0
+    elif np.float32(kl) < np.float32(target_kl * 0.5):
+        kl_coef = kl_coef / 2.0
+    return float(np.clip(kl_coef, 0.1, 20))
 
 
 def pg_forward_backward(sd, batch, cfg, dist="categorical", act="leaky_relu", activation_action=None):

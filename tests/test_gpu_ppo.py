@@ -80,6 +80,65 @@ def test_a2c_learner_vs_reference_fixture(dist):
         assert_close(osd["state"][i]["exp_avg_sq"].cpu().numpy(), g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
 
 
+@pytest.mark.parametrize("as_objects", [False, True])
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+def test_ppokl_learner_vs_reference_fixture(dist, as_objects):
+    """PPOKL_Learner (xrl_ppo_loss_t.mode = 3 + xrl_ppokl_adapt) against the reference's ppokl_learner.py run
+    (tests/golden/ppokl_*.npz, see oracle/make_golden.py: golden_ppokl): losses, KL, gradients, parameters, Adam moments at
+    1e-5 and the coefficient schedule exactly.  old_dist as parameter arrays, or (as_objects) as per-sample objects with the
+    attributes of the reference's split distributions (logits / mu, std)."""
+    from xuance_amd.nets import ActorCriticNet
+    from xuance_amd.learners import REGISTRY_Learners
+    g = load_golden(f"ppokl_{dist}")
+    lr, vf, ent, target_kl, kl_coef, gclip, ef, total = g["cfg"]
+    if dist == "categorical":
+        net = ActorCriticNet(4, 3, "categorical", (128,), (128,), (128,), "leaky_relu")
+    else:
+        net = ActorCriticNet(17, 6, "gaussian", (), (64, 64), (64, 64), "leaky_relu", activation_action="tanh")
+    cfg = Namespace(horizon_size=256, n_epochs=8, n_minibatch=8, parallels=4, running_steps=120000, gamma=0.98,
+                    learning_rate=float(lr), vf_coef=float(vf), ent_coef=float(ent), target_kl=float(target_kl),
+                    kl_coef=float(kl_coef), use_grad_clip=True, grad_clip_norm=float(gclip), end_factor_lr_decay=float(ef),
+                    distributed_training=False, device="cuda", model_dir="/tmp/xrl_models")
+    cb = Capture()
+    learner = REGISTRY_Learners["PPOKL_Learner"](cfg, net, cb)
+    assert learner.total_iters == int(total) and list(net.ref_order) == [str(n) for n in g["param_names"]]
+    net.load_state_dict(sub(g, "init"))
+    for u in range(int(g["n_updates"])):
+        b = sub(g, f"u{u}/batch")
+        if dist == "categorical":
+            old = {"logits": b["old_a"]}
+            if as_objects:
+                old = np.array([Namespace(logits=torch.from_numpy(r[None])) for r in b["old_a"]], dtype=object)
+        else:
+            old = {"mu": b["old_a"], "std": b["old_b"][0]}
+            if as_objects:
+                old = np.array([Namespace(logits=None, mu=torch.from_numpy(m), std=torch.from_numpy(b["old_b"][0])) for m in b["old_a"]],
+                               dtype=object)
+        info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], advantages=b["advantages"],
+                              aux_batch={"old_dist": old}, batch_size=len(b["obs"]))
+        ref_info, ref_cb = sub(g, f"u{u}/info"), sub(g, f"u{u}/cb")
+        assert set(info) == set(ref_info)
+        for k in ("actor-loss", "critic-loss", "entropy", "kl", "predict_value"):
+            assert_close(info[k], ref_info[k], 1e-5, k)
+        assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "lr")
+        assert learner.kl_coef == float(g["kl_coef_after"][u])
+        rec = cb.records[-1]
+        lp_scale = max(1.0, float(np.abs(ref_cb["log_prob"]).max()))
+        assert_close(rec["v_pred"], ref_cb["v_pred"], 1e-5, "v_pred")
+        assert_close(rec["log_prob"], ref_cb["log_prob"], 1e-6, "log_prob", scale=lp_scale)
+        assert_close(rec["ratio"], ref_cb["ratio"], 1e-5, "ratio", scale=lp_scale)
+        assert_close(rec["loss"], ref_cb["loss"], 1e-5, "loss")
+        for k, rg in sub(g, f"u{u}/grad").items():
+            assert_close(net.params.view(k, learner.optimizer.grad).cpu().numpy(), rg, 1e-5, f"grad {k}")
+        sd = net.state_dict()
+        for k, rp in sub(g, f"u{u}/param").items():
+            assert_close(sd[k].cpu().numpy(), rp, 1e-5, f"param {k} after update {u}")
+    osd = learner.optimizer.state_dict()
+    for i, k in enumerate(net.ref_order):
+        assert_close(osd["state"][i]["exp_avg"].cpu().numpy(), g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
+        assert_close(osd["state"][i]["exp_avg_sq"].cpu().numpy(), g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
+
+
 @pytest.mark.parametrize("dist,size", [("categorical", None), ("gaussian", None), ("categorical", "c1"),
                                        ("categorical", "c2"), ("gaussian", "c4")])
 def test_ppo_learner_vs_reference_fixture(dist, size):

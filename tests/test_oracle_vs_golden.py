@@ -151,6 +151,35 @@ def test_a2c_update(oracle, dist):
     assert opt.lr < lr                                            # the short LinearLR horizon of the fixture is visible
 
 
+@pytest.mark.parametrize("dist", ["categorical", "gaussian"])
+def test_ppokl_update(oracle, dist):
+    """PPOKL_Learner.update (ppokl_learner.py:35-101; fixture: the unmodified learner on a model whose output also carries
+    the attribute name it reads, oracle/make_golden.py: golden_ppokl) replayed by the oracle: KL(new || old) from the stored
+    old distribution parameters (categorical: per row; Gaussian: torch's ELEMENTWISE Normal KL averaged over rows x dims),
+    the unclipped surrogate, the coefficient schedule (halved / doubled / clipped to [0.1, 20])."""
+    g = load_golden(f"ppokl_{dist}")
+    lr, vf, ent, target_kl, kl_coef, gclip, ef, total = g["cfg"]
+    cfg = dict(vf_coef=vf, ent_coef=ent, kl_coef=float(kl_coef))
+    aa = None if dist == "categorical" else "tanh"
+    opt_kwargs_clip["clip"] = gclip
+    fb = lambda sd, b: oracle.ppo_forward_backward(sd, b, cfg, dist=dist, act="leaky_relu", activation_action=aa, loss_kind="ppokl")
+    nu = int(g["n_updates"])
+    for u, info, grads, sd, opt in _replay(g, nu, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
+        cb, ref_info = sub(g, f"u{u}/cb"), sub(g, f"u{u}/info")
+        lp_scale = max(1.0, float(np.abs(cb["log_prob"]).max()))
+        for k in ("v_pred", "a_loss", "c_loss", "e_loss", "kl"):
+            assert_close(info[k], cb[k], 1e-5, k)
+        assert_close(info["log_prob"], cb["log_prob"], 1e-6, "log_prob", scale=lp_scale)
+        assert_close(info["ratio"], cb["ratio"], 1e-5, "ratio", scale=lp_scale)      # exp of a difference of two such sums
+        assert_close(info["kl"], ref_info["kl"], 1e-5, "kl")
+        cfg["kl_coef"] = oracle.ppokl_adapt(cfg["kl_coef"], info["kl"], target_kl)
+        assert cfg["kl_coef"] == float(g["kl_coef_after"][u])
+    assert len(set(g["kl_coef_after"].tolist())) > 1               # the schedule moved in the fixture
+    for k in [str(n) for n in g["param_names"]]:
+        assert_close(opt.m[k], g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
+        assert_close(opt.v[k], g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
+
+
 @pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp"])
 def test_dqn_mlp_update(oracle, name):
     """dqn_mlp: DQN_Learner (dqn_learner.py:28-75); ddqn_mlp: DDQN_Learner (ddqn_learner.py:28-75), same network;

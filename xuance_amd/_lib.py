@@ -30,7 +30,8 @@ class PpoLoss(C.Structure):
                 ("d_value", c_void_p), ("d_log_std", c_void_p), ("diag", c_void_p), ("partials", c_void_p),
                 ("M", c_int32), ("A", c_int32), ("ld_out", c_int32), ("ld_v", c_int32), ("out_act", c_int32),
                 ("n_split", c_int32), ("slab_stride", c_int64), ("clip_range", c_float), ("vf_coef", c_float),
-                ("ent_coef", c_float), ("mode", c_int32)]
+                ("ent_coef", c_float), ("mode", c_int32), ("pad_mode", c_int32), ("old_a", c_void_p), ("old_b", c_void_p),
+                ("kl_coef", c_void_p)]
 
 
 class AdamState(C.Structure):
@@ -257,6 +258,7 @@ _SIGS = {
     "xrl_episode_finish_gated": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "xrl_episode_gather": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_marl_loop_gate": [C.POINTER(MarlGate), c_void_p],
+    "xrl_ppokl_adapt": [c_void_p, c_int, c_double, c_void_p, c_double, c_void_p, c_void_p],
     "xrl_qmix_fused_update": [C.POINTER(QmixFused), c_void_p],
     "xrl_qmix_fused_lds_bytes": [C.POINTER(QmixFused)],
     "xrl_qmix_fused_layout": [C.POINTER(QmixFused), C.POINTER(QfImage)],

@@ -21,7 +21,9 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
     if (p.stats) { mean = p.stats[0]; denom = p.stats[1] + 1e-8f; }
     const int A = p.A;
 
-    double acc_s = 0.0, acc_c = 0.0, acc_e = 0.0, acc_v = 0.0, acc_n = 0.0;
+    double acc_s = 0.0, acc_c = 0.0, acc_e = 0.0, acc_v = 0.0, acc_n = 0.0, acc_k = 0.0;
+    const bool klm = p.mode == 3;                        // PPOKL_Learner (ppokl_learner.py:35-101)
+    const float klc = klm ? (float)*p.kl_coef : 0.f;     // (a Python float times a float32 tensor in the reference)
     // gaussian: per-thread partial of d log_std (A <= 32)
     float dls[32];
     if (GAUSSIAN) {
@@ -46,13 +48,28 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
             logp = o[a] - lse;
             ent = 0.f;
             for (int j = 0; j < A; ++j) { const float l = o[j] - lse; ent -= expf(l) * l; }
-            const Surrogate s = p.mode != 0 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM);
+            float kl_row = 0.f, lse_o = 0.f, old_lp = oldlp;
+            const float* qo = klm ? p.old_a + (size_t)m * A : nullptr;
+            if (klm) {                                   // old distribution = Categorical(logits = stored logits): normalise,
+                float mo = qo[0];                        // old log-prob of the action, KL(new || old) = sum p (l - q)
+                for (int j = 1; j < A; ++j) mo = fmaxf(mo, qo[j]);
+                float so = 0.f;
+                for (int j = 0; j < A; ++j) so += expf(qo[j] - mo);
+                lse_o = mo + logf(so);
+                old_lp = qo[a] - lse_o;
+                for (int j = 0; j < A; ++j) { const float l = o[j] - lse; kl_row += expf(l) * (l - (qo[j] - lse_o)); }
+                acc_k += kl_row;
+            }
+            const Surrogate s = klm ? surrogate_kl(logp, old_lp, adv, invM)
+                                    : (p.mode != 0 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM));
             float* dq = p.d_out + (size_t)m * p.ld_out;
-            const float ce = p.ent_coef * invM;
+            const float ce = p.ent_coef * invM, ck = klc * invM;
             for (int j = 0; j < A; ++j) {
                 const float l = o[j] - lse, pj = expf(l);
                 // d logp/d z_j = 1[j==a] - p_j ;  d H/d z_j = -p_j (l_j + H) ; loss has  -ent_coef * mean(H)
-                dq[j] = s.dlogp * ((j == a ? 1.f : 0.f) - pj) + ce * pj * (l + ent);
+                float g = s.dlogp * ((j == a ? 1.f : 0.f) - pj) + ce * pj * (l + ent);
+                if (klm) g += ck * pj * (l - (qo[j] - lse_o) - kl_row);          // d kl_row / d z_j
+                dq[j] = g;
             }
             acc_s += (double)fminf(s.s1, s.s2); acc_n += s.clipped;
             if (p.diag) { p.diag[m] = logp; p.diag[p.M + m] = s.ratio; p.diag[2 * (size_t)p.M + m] = s.s1; p.diag[3 * (size_t)p.M + m] = s.s2; }
@@ -64,14 +81,33 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
                 logp += -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;     // Normal.log_prob, summed (:179-180)
                 ent += 0.5f + LOG_SQRT_2PI + logf(sd);                           // Normal.entropy, summed (:182-183)
             }
-            const Surrogate s = p.mode != 0 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM);
+            float old_lp = oldlp;
+            const float* mo = klm ? p.old_a + (size_t)m * A : nullptr;
+            const float* so = klm ? p.old_b + (size_t)m * A : nullptr;
+            if (klm) {                                   // old distribution = Normal(old mu, old std): its log-prob of the action
+                old_lp = 0.f;
+                for (int j = 0; j < A; ++j) {
+                    const float d0 = x[j] - mo[j];
+                    old_lp += -(d0 * d0) / (2.f * so[j] * so[j]) - logf(so[j]) - LOG_SQRT_2PI;
+                }
+            }
+            const Surrogate s = klm ? surrogate_kl(logp, old_lp, adv, invM)
+                                    : (p.mode != 0 ? surrogate_a2c(logp, adv, invM) : surrogate(logp, oldlp, adv, lo, hi, invM));
             float* dq = p.d_out + (size_t)m * p.ld_out;
-#pragma unroll
+            const float ck = klm ? klc * invM / (float)A : 0.f;                  // kl.mean() runs over rows x dims (torch's
+#pragma unroll                                                                   // Normal-Normal KL is elementwise)
             for (int j = 0; j < 32; ++j) {
                 if (j < A) {
                     const float ls = p.log_std[j], sd = expf(ls), var = sd * sd, df = x[j] - o[j];
-                    dq[j] = s.dlogp * df / var * act_grad_from_out(o[j], p.out_act);   // through activation_action
-                    dls[j] += s.dlogp * (df * df / var - 1.f);
+                    float gmu = s.dlogp * df / var, gls = s.dlogp * (df * df / var - 1.f);
+                    if (klm) {
+                        const float vr = (sd / so[j]) * (sd / so[j]), dm = (o[j] - mo[j]) / so[j];
+                        acc_k += 0.5f * (vr + dm * dm - 1.f - logf(vr));
+                        gmu += ck * (o[j] - mo[j]) / (so[j] * so[j]);
+                        gls += ck * (vr - 1.f);
+                    }
+                    dq[j] = gmu * act_grad_from_out(o[j], p.out_act);           // through activation_action
+                    dls[j] += gls;
                 }
             }
             acc_s += (double)fminf(s.s1, s.s2); acc_n += s.clipped;
@@ -86,10 +122,10 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
     }
 
     const double t0 = block_sum(acc_s, scratch), t1 = block_sum(acc_c, scratch), t2 = block_sum(acc_e, scratch),
-                 t3 = block_sum(acc_v, scratch), t4 = block_sum(acc_n, scratch);
+                 t3 = block_sum(acc_v, scratch), t4 = block_sum(acc_n, scratch), t5 = block_sum(acc_k, scratch);
     if (threadIdx.x == 0) {
         double* q = p.partials + (size_t)blockIdx.x * 8;
-        q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = t4; q[5] = 0; q[6] = 0; q[7] = 0;
+        q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = t4; q[5] = t5; q[6] = 0; q[7] = 0;
     }
     if (GAUSSIAN && p.d_log_std) {
 #pragma unroll
@@ -102,6 +138,22 @@ __global__ void __launch_bounds__(LOSS_THREADS) ppo_loss_kernel(xrl_ppo_loss_t p
             }
         }
     }
+}
+
+// kl_coef schedule of PPOKL_Learner.update (ppokl_learner.py:62-66) on the device, so that chained updates need no host
+// round trip: kl = (sum of the loss launch's kl partials) / count (float32, as the reference's tensor), compared with
+// float32(target * 1.5) and float32(target * 0.5); the coefficient is a double like the reference's Python float.
+__global__ void ppokl_adapt_kernel(const double* __restrict__ partials, int n_split, double count, double* kl_coef, double target_kl,
+                                   float* kl_out) {
+    double s = 0.0;
+    for (int i = 0; i < n_split; ++i) s += partials[(size_t)i * 8 + 5];
+    const float kl = (float)(s / count);
+    double c = *kl_coef;
+    if (kl > (float)(target_kl * 1.5)) c = c * 2.0;
+    else if (kl < (float)(target_kl * 0.5)) c = c / 2.0;
+    c = c < 0.1 ? 0.1 : (c > 20.0 ? 20.0 : c);
+    *kl_coef = c;
+    if (kl_out) *kl_out = kl;
 }
 
 __global__ void __launch_bounds__(64) sum_partials_kernel(const double* __restrict__ partials, int n_rows, int width,
@@ -145,12 +197,13 @@ __global__ void __launch_bounds__(1024) sum_partials_wide_kernel(const double* _
 
 static int check(const xrl_ppo_loss_t* p, bool gaussian) {
     XRL_CHECK_ARG(p != nullptr);
-    XRL_CHECK_ARG(p->mode >= 0 && p->mode <= 2);
+    XRL_CHECK_ARG(p->mode >= 0 && p->mode <= 3);
     XRL_CHECK_ARG(p->out && p->actions && p->returns && p->d_out && p->partials && (p->old_logp || p->mode != 0));
     XRL_CHECK_ARG(p->mode == 2 || (p->value && p->adv && p->d_value));
     XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->A <= (gaussian ? 32 : 4096) && p->ld_out >= p->A && p->ld_v >= 1);
     XRL_CHECK_ARG(p->n_split >= 1);
     if (gaussian) XRL_CHECK_ARG(p->log_std != nullptr);
+    if (p->mode == 3) XRL_CHECK_ARG(p->old_a && p->kl_coef && (!gaussian || p->old_b));
     return XRL_OK;
 }
 
@@ -170,6 +223,14 @@ extern "C" int xrl_ppo_loss_gaussian(const xrl_ppo_loss_t* p, xrl_stream_t strea
     int rc = check(p, true);
     if (rc) return rc;
     hipLaunchKernelGGL(ppo_loss_kernel<true>, dim3(p->n_split), dim3(LOSS_THREADS), 0, as_stream(stream), *p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_ppokl_adapt(const double* partials, int n_split, double count, double* kl_coef, double target_kl, float* kl_out,
+                               xrl_stream_t stream) {
+    XRL_CHECK_ARG(partials && kl_coef && n_split >= 1 && count > 0);
+    hipLaunchKernelGGL(ppokl_adapt_kernel, dim3(1), dim3(1), 0, as_stream(stream), partials, n_split, count, kl_coef, target_kl, kl_out);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

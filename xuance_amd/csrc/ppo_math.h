@@ -38,4 +38,14 @@ __device__ __forceinline__ Surrogate surrogate_a2c(float logp, float adv, float 
     return r;
 }
 
+// PPO-KL actor term (ppokl_learner.py:57-58): -(ratio * adv).mean() (+ kl_coef * kl, added by the caller): no clipping.
+__device__ __forceinline__ Surrogate surrogate_kl(float logp, float old_logp, float adv, float invM) {
+    Surrogate r;
+    r.ratio = expf(logp - old_logp);
+    r.s1 = r.s2 = r.ratio * adv;
+    r.dlogp = -adv * r.ratio * invM;
+    r.clipped = 0;
+    return r;
+}
+
 }  // namespace xrl

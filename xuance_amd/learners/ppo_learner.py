@@ -77,7 +77,10 @@ class PPO_Learner(Learner):
             kw.update(log_std=model.params.ptr(ls),
                       d_log_std=self.slabs.data_ptr() + 4 * model.params.offsets[ls],
                       out_act=ops.ACT[model.activation_action])
+        kw.update(getattr(self, "_loss_extra", None) or {})             # (PPOKL_Learner: old distribution + kl_coef)
         ops.ppo_loss(model.dist, **kw)
+        if self.loss_mode == 3:                                         # the coefficient schedule, after the loss used it
+            ops.ppokl_adapt(self.partials, S, M * (A if model.dist == "gaussian" else 1), self.kl_coef_dev, self.target_kl, self.kl_dev)
         model.backward(obs, M, self.slabs, S, ldx)
         ops.grad_reduce(self.slabs, S, model.params.P, model.params.P, opt.grad, self.sumsq)
         if finish:
@@ -362,6 +365,83 @@ class A2C_Learner(PPO_Learner):
         A = self.model.action_dim
         cb = dict(model=self.policy, info=info, v_pred=heads[:M, A], log_prob=self.diag.view(-1)[0:M],
                   a_loss=info[self._key("actor-loss")], c_loss=info[self._key("critic-loss")], e_loss=info[self._key("entropy")])
+        cb["loss"] = cb["a_loss"] - self.ent_coef * cb["e_loss"] + self.vf_coef * cb["c_loss"]
+        info.update(self.callback.on_update_end(self.iterations, **cb) or {})
+        return info
+
+
+class PPOKL_Learner(PPO_Learner):
+    """PPO with a KL penalty (xuance/torch/learners/policy_gradient/ppokl_learner.py:14-101): actor term
+    -(ratio * adv).mean() + kl_coef * KL(new || old).mean() with the old log-prob AND the KL taken from the old distribution's
+    parameters (`aux_batch["old_dist"]`), no clipping; kl_coef doubles / halves around `target_kl` after every update and
+    stays in [0.1, 20] (:62-66) -- on the device (xrl_ppokl_adapt), so chained updates need no host round trip.  The
+    reference's own update raises AttributeError as shipped (:48 reads `model_output.distribution`); the fixtures run it
+    unmodified on a model whose output carries that attribute name (oracle/make_golden.py: golden_ppokl).  Torch's
+    Normal-Normal KL is elementwise, so for Gaussian policies `kl.mean()` averages over rows x action dims; kept.
+    `old_dist` may be the reference's array / list of per-sample distribution objects (split_distributions), or
+    {"logits": [M, A]} / {"mu": [M, A], "std": [M, A] or [A]} arrays.  Layered path (xrl_ppo_loss_t.mode = 3)."""
+
+    def __init__(self, config, model, callback=None):
+        if not hasattr(config, "clip_range"):
+            config.clip_range = 0.0
+        super().__init__(config, model, callback)
+        self.loss_mode = 3
+        dev = self.model.params.device
+        self.target_kl = float(config.target_kl)
+        self.kl_coef = float(config.kl_coef)                      # host mirror of the device value (read back with the losses)
+        self.kl_coef_dev = torch.tensor([self.kl_coef], dtype=torch.float64, device=dev)
+        self.kl_dev = torch.zeros(1, device=dev)
+
+    def fused_eligible(self, memory):
+        return False
+
+    def old_dist_arrays(self, od, M):
+        """-> (old_a [M, A], old_b [M, A] or None) device tensors from whatever `aux_batch['old_dist']` holds."""
+        A, dev = self.model.action_dim, self.model.params.device
+        if isinstance(od, dict):
+            if "logits" in od:
+                return self._as_dev(od["logits"]).reshape(M, A), None
+            std = self._as_dev(od["std"])
+            return self._as_dev(od["mu"]).reshape(M, A), (std.expand(M, A) if std.dim() == 1 else std.reshape(M, A)).contiguous()
+        items = list(np.asarray(od, dtype=object).reshape(-1))    # the reference's per-sample distribution objects
+        if hasattr(items[0], "logits") and items[0].logits is not None:
+            return torch.cat([torch.as_tensor(d.logits).reshape(1, A) for d in items]).to(dev).float().contiguous(), None
+        mu = torch.stack([torch.as_tensor(d.mu).reshape(A) for d in items]).to(dev).float().contiguous()
+        std = torch.stack([torch.as_tensor(d.std).reshape(A) for d in items]).to(dev).float().contiguous()
+        return mu, std
+
+    def _info(self, M, S, partials=None):
+        used = self.kl_coef                                       # the coefficient this update's loss was formed with
+        ops.sum_partials(self.partials if partials is None else partials, S, 8, self.sums)
+        rb = torch.cat([self.sums, self.kl_coef_dev]).cpu().numpy()   # the one host sync of an update
+        s = rb[:8]
+        self.kl_coef = float(rb[8])
+        count = M * (self.model.action_dim if self.model.dist == "gaussian" else 1)
+        kl = float(np.float32(s[5] / count))
+        k, st = self._key, self.optimizer.read()
+        return {k("actor-loss"): float(-s[0] / M + used * kl), k("critic-loss"): float(s[1] / M), k("entropy"): float(s[2] / M),
+                k("learning_rate"): st.last_lr, k("kl"): kl, k("predict_value"): float(s[3] / M)}
+
+    def update(self, **samples):                                  # ppokl_learner.py:35-101
+        self.iterations += 1
+        obs = self._as_dev(samples["obs"])
+        act, ret, adv = self._as_dev(samples["actions"]), self._as_dev(samples["returns"]), self._as_dev(samples["advantages"])
+        M = obs.shape[0]
+        obs = obs.reshape(M, -1)
+        self._ensure(M)
+        old_dists = samples["aux_batch"]["old_dist"]
+        info = self.callback.on_update_start(self.iterations, model=self.policy, obs=obs, act=act, returns=ret,
+                                             advantages=adv, old_dists=old_dists) or {}
+        old_a, old_b = self.old_dist_arrays(old_dists, M)
+        self._loss_extra = dict(old_a=old_a.data_ptr(), old_b=None if old_b is None else old_b.data_ptr(),
+                                kl_coef=self.kl_coef_dev.data_ptr())
+        S = self._step(obs, obs.shape[1], act, ret, adv, None, M)
+        info.update(self._info(M, S))
+        heads = self.model.plan.acts[len(self.model.plan.widths) - 1]
+        A, k = self.model.action_dim, self._key
+        d = self.diag.view(-1)
+        cb = dict(model=self.policy, info=info, a_dist=heads[:M, :A], v_pred=heads[:M, A], log_prob=d[0:M], ratio=d[M:2 * M],
+                  kl=info[k("kl")], a_loss=info[k("actor-loss")], c_loss=info[k("critic-loss")], e_loss=info[k("entropy")])
         cb["loss"] = cb["a_loss"] - self.ent_coef * cb["e_loss"] + self.vf_coef * cb["c_loss"]
         info.update(self.callback.on_update_end(self.iterations, **cb) or {})
         return info

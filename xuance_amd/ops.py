@@ -123,6 +123,12 @@ def ppo_loss(dist, **kw):
     call("xrl_ppo_loss_categorical" if dist == "categorical" else "xrl_ppo_loss_gaussian", C.byref(p), stream_ptr())
 
 
+def ppokl_adapt(partials, n_split, count, kl_coef, target_kl, kl_out=None):
+    """The kl_coef schedule of PPOKL_Learner.update on the device (xrl_ppokl_adapt)."""
+    call("xrl_ppokl_adapt", ptr(partials), int(n_split), float(count), ptr(kl_coef), float(target_kl),
+         ptr(kl_out) if kl_out is not None else None, stream_ptr())
+
+
 def sum_partials(partials, n_rows, width, out):
     call("xrl_sum_partials", ptr(partials), int(n_rows), int(width), ptr(out), stream_ptr())
 
