@@ -803,3 +803,32 @@ def test_runner_surface_of_the_ppo_agent(tmp_path):
     assert set(out.env_actions.tolist()) <= {0, 1}
     assert_close(out.log_probs, o.log_softmax(logits)[np.arange(5), out.env_actions], 1e-5, "log-probs of the draw")
     b.finish()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_ppokl_agent_stores_the_old_distribution_and_adapts_its_coefficient(graph):
+    """PPOKL_Agent (ppokl_agent.py:7-90) on the device CartPole: the vector step stores the old distribution's parameters
+    next to old_logp (they must reproduce it), the update phase feeds them to PPOKL_Learner (loss mode 3), the coefficient
+    moves within [0.1, 20] on the device across the chained minibatches, eager and as one graph alike."""
+    from xuance_amd.agents import REGISTRY_Agents
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    n, T = 16, 32
+    torch.manual_seed(0)
+    cfg = make_config(n, T, n_epochs=2, n_minibatch=2, target_kl=0.01, kl_coef=1.0, use_hip_graph=graph)
+    agent = REGISTRY_Agents["PPOKL"](cfg, DeviceCartPoleVecEnv(n, seed=2))
+    p0 = agent.model.params.flat.clone()
+    coefs = []
+    for _ in range(3):
+        agent.rollout()
+        f = agent.memory.soa.fields
+        logits, act, logp = npy(f["aux_old_a"]), npy(f["actions"]).astype(np.int64), npy(f["aux_old_logp"])
+        lsm = logits - np.log(np.exp(logits - logits.max(-1, keepdims=True)).sum(-1, keepdims=True)) - logits.max(-1, keepdims=True)
+        assert_close(np.take_along_axis(lsm, act[..., None], -1)[..., 0], logp, 1e-5, "old_logp from the stored logits")
+        info = agent.update()
+        assert set(info) == {"actor-loss", "critic-loss", "entropy", "learning_rate", "kl", "predict_value"}
+        assert all(np.isfinite(v) for v in info.values()) and info["kl"] >= 0.0
+        coefs.append(agent.learner.kl_coef)
+        assert 0.1 <= coefs[-1] <= 20.0
+    assert len(set(coefs)) > 1 or coefs[0] != 1.0                    # the schedule moved
+    assert not torch.equal(agent.model.params.flat, p0)
+    assert float(agent.learner.kl_coef_dev.item()) == agent.learner.kl_coef

@@ -547,6 +547,39 @@ class A2C_Agent(PPO_Agent):
         return A2C_Learner(*args)
 
 
+class PPOKL_Agent(PPO_Agent):
+    """PPO with a KL penalty (xuance/torch/agents/policy_gradient/ppokl_agent.py:7-90): PPO_Agent's loop with PPOKL_Learner;
+    what the reference stores per transition as `aux_info = {"old_dist": policy_output.distributions}` (:20-30, a Python
+    object per sample) is here the distribution's parameters in two more buffer fields -- old_a [A] (logits / mu) and, for
+    Gaussian policies, old_b [A] (std) -- written by the vector step and gathered with the minibatch."""
+
+    def __init__(self, config, envs, callback=None):
+        config.use_fused_rollout = False                        # the fused rollout kernels store old_logp only
+        super().__init__(config, envs, callback)
+
+    @property
+    def auxiliary_info_shape(self):
+        discrete = is_discrete(self.action_space)
+        A = self.action_space.n if discrete else int(self.action_space.shape[0])
+        shape = {"old_logp": (), "old_a": (A,)}
+        if not discrete:
+            shape["old_b"] = (A,)
+        return shape
+
+    def _build_learner(self, *args):
+        from ..learners.ppo_learner import PPOKL_Learner
+        return PPOKL_Learner(*args)
+
+    def _enqueue_step(self, t):
+        super()._enqueue_step(t)
+        n, A, f = self.n_envs, self.model.action_dim, self.memory.soa.fields
+        heads = self.model.plan.acts[len(self.model.plan.widths) - 1]      # rows [0, n): this step's policy output
+        torch.mul(heads[:n, :A], 1.0, out=f["aux_old_a"][t].view(n, A))      # (a kernel, not a memcpy node: graphs)
+        if self.model.dist == "gaussian":
+            torch.exp(self.model.params.view("actor.log_std", self.model.params.flat).view(1, A).expand(n, A),
+                      out=f["aux_old_b"][t].view(n, A))
+
+
 class PG_Agent(PPO_Agent):
     """Vanilla policy-gradient agent (xuance/torch/agents/policy_gradient/pg_agent.py:12-79 on core/on_policy.py:225-300):
     the on-policy loop with the actor-only VanillaPolicyGradient model (nets.ActorNet) and PG_Learner.  What differs from

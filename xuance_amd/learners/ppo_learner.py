@@ -395,6 +395,18 @@ class PPOKL_Learner(PPO_Learner):
     def fused_eligible(self, memory):
         return False
 
+    def prepare_buffer_update(self, memory, bs):               # the agent loop: the old distribution comes from the buffer's
+        fresh = getattr(self, "_stage_bs", 0) != bs               # aux fields old_a (logits / mu) and old_b (std)
+        super().prepare_buffer_update(memory, bs)
+        if fresh:
+            dev, A = self.model.params.device, self.model.action_dim
+            self._stage["aux_old_a"] = torch.zeros(bs, A, device=dev)
+            if self.model.dist == "gaussian":
+                self._stage["aux_old_b"] = torch.zeros(bs, A, device=dev)
+            self._loss_extra = dict(old_a=self._stage["aux_old_a"].data_ptr(),
+                                    old_b=self._stage["aux_old_b"].data_ptr() if "aux_old_b" in self._stage else None,
+                                    kl_coef=self.kl_coef_dev.data_ptr())
+
     def old_dist_arrays(self, od, M):
         """-> (old_a [M, A], old_b [M, A] or None) device tensors from whatever `aux_batch['old_dist']` holds."""
         A, dev = self.model.action_dim, self.model.params.device
