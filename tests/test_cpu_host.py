@@ -288,3 +288,55 @@ def test_oracle_philox_known_answer_vectors():
     s = o.cartpole_reset_state(3, np.arange(64), np.arange(64) % 5)
     assert s.shape == (64, 4) and s.dtype == np.float64 and np.abs(s).max() < 0.05
     assert not np.array_equal(s[0], o.cartpole_reset_state(3, np.arange(1), 1)[0])
+
+
+def test_shm_multi_agent_vec_env_matches_in_process_stepping():
+    """ShmSubprocVecMultiAgentEnv (the multi-agent twin of ShmSubprocVecEnv, reference surface
+    subproc_vec_maenv.py:8-170): 6 SMAC-3m-shaped host envs in 3 worker processes, step data through the shared block --
+    every return value of reset() / step() (obs dicts, reward / terminated dicts, truncated, infos incl. state, avail_actions,
+    agent_mask, episode_step / score and the reset_* entries of finished episodes) and the buf_* attributes equal those of
+    DummyVecMultiAgentEnv on identically seeded envs, over several auto-resets; actions as dict lists or as an array."""
+    from xuance_amd.envs import ShmSubprocVecMultiAgentEnv, DummyVecMultiAgentEnv, HostSMACLikeEnv
+    n = 6
+    venv = ShmSubprocVecMultiAgentEnv([HostSMACLikeEnv] * n, env_seed=5, in_series=2, device="cpu")
+    ref = DummyVecMultiAgentEnv([HostSMACLikeEnv] * n, env_seed=5)
+    assert venv.agents == ref.agents and venv.num_agents == 3 and venv.max_episode_steps == ref.max_episode_steps
+
+    def same(a, b, what):
+        if isinstance(a, dict):
+            assert set(a) == set(b), what
+            for k in a:
+                same(a[k], b[k], f"{what}/{k}")
+        elif isinstance(a, (list, tuple)):
+            assert len(a) == len(b), what
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, f"{what}[{i}]")
+        else:
+            assert np.array_equal(np.asarray(a, np.float64), np.asarray(b, np.float64)), what
+    o1, i1 = venv.reset()
+    o2, i2 = ref.reset()
+    same(o1, o2, "reset obs")
+    same([{k: i[k] for k in ("state", "avail_actions")} for i in i1], [{k: i[k] for k in ("state", "avail_actions")} for i in i2], "reset info")
+    rng = np.random.default_rng(0)
+    ended = 0
+    avail = list(ref.buf_avail_actions)                              # what the next action must respect: after an episode
+    for t in range(90):                                              # end the POST-RESET mask (info["reset_avail_actions"])
+        acts = [{a: int(np.flatnonzero(avail[e][a])[rng.integers(0, int(avail[e][a].sum()))]) for a in ref.agents}
+                for e in range(n)]
+        send = acts if t % 2 else np.array([[d[a] for a in ref.agents] for d in acts])
+        r1, r2 = venv.step(send), ref.step(acts)
+        for k, (x, y) in enumerate(zip(r1[:4], r2[:4])):
+            same(list(x), list(y), f"step {t} item {k}")
+        for e in range(n):
+            keys = ["state", "avail_actions", "agent_mask", "episode_step", "episode_score"]
+            if "reset_obs" in r2[4][e]:
+                keys += ["reset_obs", "reset_avail_actions", "reset_state"]
+                ended += 1
+            assert ("reset_obs" in r1[4][e]) == ("reset_obs" in r2[4][e])
+            same({k: r1[4][e][k] for k in keys}, {k: r2[4][e][k] for k in keys}, f"step {t} info {e}")
+        same(venv.buf_state, ref.buf_state, "buf_state")
+        same(venv.buf_avail_actions, ref.buf_avail_actions, "buf_avail_actions")
+        avail = [r2[4][e].get("reset_avail_actions", ref.buf_avail_actions[e]) for e in range(n)]
+    assert ended >= n                                               # every env went through an auto-reset at least once
+    venv.close(); ref.close()
+    assert venv.closed

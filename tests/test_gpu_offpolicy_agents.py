@@ -598,3 +598,37 @@ def test_one_launch_acting_step_of_the_recurrent_agents_vs_the_layered_path(R):
         assert (avail.numpy()[np.arange(R), acts[0].cpu().numpy()] == 1).all()
         assert_close(h_a.cpu().numpy(), h_b.cpu().numpy(), 1e-5, f"h step {step}")
     assert float(h_a.abs().max()) > 0
+
+
+def test_shm_multi_agent_vec_env_device_path_and_evaluation(tmp_path):
+    """ShmSubprocVecMultiAgentEnv on the GPU box: the shared block is page-locked, step_to_device lands a whole vector step
+    in HBM with one copy (device tensors equal the host views), a worker failure raises instead of hanging, and
+    QMIX_Agents.test() evaluates on it exactly as on DummyVecMultiAgentEnv (same seeds -> same scores)."""
+    from argparse import Namespace
+    from xuance_amd.envs import ShmSubprocVecMultiAgentEnv, DummyVecMultiAgentEnv, HostSMACLikeEnv, SyntheticSMACVecEnv
+    from xuance_amd.agents import QMIX_Agents
+    venv = ShmSubprocVecMultiAgentEnv([HostSMACLikeEnv] * 4, env_seed=9, in_series=2)       # (workers forked before any launch below)
+    venv2 = ShmSubprocVecMultiAgentEnv([HostSMACLikeEnv] * 4, env_seed=9, in_series=2)
+    assert venv._pinned
+    venv.reset()
+    acts = np.array([[int(np.flatnonzero(venv.buf_avail_actions[e][a])[0]) for a in venv.agents] for e in range(4)])
+    dev = venv.step_to_device(torch.as_tensor(acts, device="cuda"))
+    torch.cuda.synchronize()
+    for k, t in dev.items():
+        assert np.array_equal(t.cpu().numpy(), venv.v[k]), k
+    assert tuple(dev["obs"].shape) == (4, 3, 30) and tuple(dev["avail"].shape) == (4, 3, 9) and tuple(dev["state"].shape) == (4, 48)
+    with pytest.raises(RuntimeError, match="unavailable action"):    # strict env: an unavailable action is an error in the worker
+        for _ in range(50):
+            venv.step(np.full((4, 3), 8))
+    venv.closed = True                                               # (its workers are gone)
+    cfg = Namespace(use_rnn=True, rnn="GRU", fc_hidden_sizes=[64], recurrent_hidden_size=64, q_hidden_size=[64], activation="relu",
+                    hidden_dim_mixing_net=32, hidden_dim_hyper_net=32, parallels=8, buffer_size=64, batch_size=8, start_training=0,
+                    n_epochs=2, double_q=True, use_actions_mask=True, use_parameter_sharing=True, model_dir=str(tmp_path / "q"),
+                    agent="QMIX", seed=1, gamma=0.99, learning_rate=1e-3, start_greedy=0.5, end_greedy=0.05,
+                    decay_step_greedy=10000, sync_frequency=50, training_frequency=1, running_steps=100000, use_grad_clip=True,
+                    grad_clip_norm=10.0, distributed_training=False, device="cuda")
+    torch.manual_seed(0)
+    m = QMIX_Agents(cfg, SyntheticSMACVecEnv(8, seed=3, max_episode_steps=12, p_term=0.05))
+    s_shm = m.test(test_episodes=6, test_envs=venv2, close_envs=True)
+    s_ref = m.test(test_episodes=6, test_envs=DummyVecMultiAgentEnv([HostSMACLikeEnv] * 4, env_seed=9), close_envs=True)
+    assert venv2.closed and len(s_shm) >= 6 and s_shm == s_ref

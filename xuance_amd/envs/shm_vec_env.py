@@ -67,6 +67,9 @@ def _worker(remote, parent_remote, env_fns, env_seed, lo, block, lay, n, obs_sha
                 remote.send_bytes(b"k")
             elif cmd == b"c":
                 break
+    except Exception as ex:                  # tell the parent instead of dying silently: the forked siblings hold copies of
+        import traceback                     # this pipe's ends, so the parent would never see EOF and wait for ever
+        remote.send_bytes(b"x" + traceback.format_exc().encode()[-2000:])
     finally:
         for env in envs:
             env.close()
@@ -122,11 +125,17 @@ class ShmSubprocVecEnv:
         self.buf_obs = np.zeros((n,) + self.obs_shape, self.obs_dtype)
 
     # -- reference surface ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _ack(r):
+        msg = r.recv_bytes()
+        if msg != b"k":
+            raise RuntimeError("vector-env worker failed:\n" + msg[1:].decode(errors="replace"))
+
     def _all(self, cmd):
         for r in self.remotes:
             r.send_bytes(cmd)
         for r in self.remotes:
-            assert r.recv_bytes() == b"k"
+            self._ack(r)
 
     def reset(self):
         self._assert_not_closed()
@@ -145,9 +154,9 @@ class ShmSubprocVecEnv:
         self.waiting = True
 
     def _wait(self):
-        for r in self.remotes:
-            assert r.recv_bytes() == b"k"
         self.waiting = False
+        for r in self.remotes:
+            self._ack(r)
 
     def step_wait(self):
         self._assert_not_closed()
