@@ -691,6 +691,15 @@ typedef struct {
     float* diag;                /* NULL or [3][B]: q_tot_eval, q_tot_next, q_tot_target */
     float gamma, pad1;
     long long* dbg;             /* NULL, or [16] cycle-counter stamps of workgroup 0 at the phase boundaries (diagnostics) */
+    /* ring mode (ring_n_envs > 0): the nine batch pointers above are the FIELDS of the replay ring, [n_size][n_envs][row]
+     * (xrl_soa_store_step's layout), and transition b of the batch is the ring row xrl_sample_replay_indices' stream draws
+     * for (seed, counter + *counter_dev, b): the launch samples and gathers for itself (memory_tools_marl.py:742-765) */
+    int32_t ring_n_envs, ring_n_size;
+    const int32_t* size_dev;        /* [1] filled ring slots */
+    const uint32_t* counter_dev;    /* NULL or [1] */
+    int64_t* idx_out;               /* NULL or [B]: the rows drawn (flat index env * n_size + step) */
+    uint64_t draw_seed;
+    uint32_t draw_counter, pad3;
 } xrl_qmix_fused_t;
 int xrl_qmix_fused_update(const xrl_qmix_fused_t* p, xrl_stream_t stream);
 int xrl_qmix_fused_lds_bytes(const xrl_qmix_fused_t* p);   /* LDS the launch needs (must be <= 160 KB), -1 on bad dims */

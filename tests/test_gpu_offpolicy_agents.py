@@ -200,9 +200,12 @@ def test_dqn_agent_on_atari_shape():
     assert torch.equal(agent.memory.soa.fields["next_observations"][t], env.next_obs)
 
 
-def test_qmix_graph_update_phase_equals_eager_updates_on_the_same_indices():
+@pytest.mark.parametrize("mode", ["ring", "gathered", "layered"])
+def test_qmix_graph_update_phase_equals_eager_updates_on_the_same_indices(mode):
     """QMIX_Learner.update_from_buffer (device sampling + gather + update, n_epochs per hipGraph launch) vs
-    update(memory.sample(indexes)) with the indices the sampling kernel draws: identical parameters and losses."""
+    update(memory.sample(indexes)) with the indices the sampling kernel draws: identical parameters and losses.
+    mode: "ring" = the one-launch update draws and gathers its batch from the replay ring itself; "gathered" = a draw + gather
+    launch in front of it; "layered" = the grouped-GEMM path."""
     from xuance_amd import ops
     from xuance_amd.agents import QMIX_Agents
     from xuance_amd.envs import SyntheticSMACVecEnv
@@ -211,13 +214,15 @@ def test_qmix_graph_update_phase_equals_eager_updates_on_the_same_indices():
                learning_rate=7e-4, gamma=0.99, double_q=True, start_greedy=1.0, end_greedy=0.05, decay_step_greedy=50000,
                sync_frequency=5, training_frequency=1, start_training=10 ** 9, n_epochs=4, use_grad_clip=True,
                grad_clip_norm=10.0, use_actions_mask=True, use_parameter_sharing=True, use_rnn=False,
-               distributed_training=False, device="cuda", model_dir="/tmp/x")
+               distributed_training=False, device="cuda", model_dir="/tmp/x", use_fused_qmix_update=mode != "layered",
+               fused_qmix_gather_in_kernel=mode == "ring")
     res = []
     for graph in (False, True):
         torch.manual_seed(0)
         np.random.seed(0)
         agent = QMIX_Agents(Namespace(**cfg), SyntheticSMACVecEnv(16, seed=3))
         agent.train(25)                                       # fills 25 ring rows, no updates (start_training is far away)
+        assert agent.learner.fused_eligible() == (mode != "layered")
         lr, mem = agent.learner, agent.memory
         assert mem.size == 25 and int(mem.size_dev.item()) == 25
         infos = []

@@ -200,7 +200,9 @@ class QmixFused(C.Structure):
                 ("obs", c_void_p), ("obs_next", c_void_p), ("state", c_void_p), ("state_next", c_void_p), ("actions", c_void_p),
                 ("rewards", c_void_p), ("terminals", c_void_p), ("agent_mask", c_void_p), ("avail_next", c_void_p),
                 ("slabs", c_void_p), ("slab_stride", c_int64), ("partials", c_void_p), ("diag", c_void_p),
-                ("gamma", c_float), ("pad1", c_float), ("dbg", c_void_p)]
+                ("gamma", c_float), ("pad1", c_float), ("dbg", c_void_p),
+                ("ring_n_envs", c_int32), ("ring_n_size", c_int32), ("size_dev", c_void_p), ("counter_dev", c_void_p),
+                ("idx_out", c_void_p), ("draw_seed", C.c_uint64), ("draw_counter", C.c_uint32), ("pad3", C.c_uint32)]
 
 
 class QaImage(C.Structure):

@@ -38,21 +38,6 @@ __global__ void __launch_bounds__(256) store_step_kernel(FieldPack f, int n_envs
 }
 
 // ------------------------------------------------------------------------------------------ gather
-// Draw of xrl_sample_replay_indices for batch row b (same Philox stream: the fused draw + gather picks the same rows).
-struct ReplayDraw {
-    const int32_t* size_dev; uint64_t seed; uint32_t counter; const uint32_t* counter_dev; int64_t* idx_out;
-};
-__device__ __forceinline__ int64_t replay_draw(const ReplayDraw& s, int b, int n_envs, int n_size) {
-    const uint32_t ctr = s.counter + (s.counter_dev ? *s.counter_dev : 0u);
-    int size = *s.size_dev;
-    size = size < 1 ? 1 : (size > n_size ? n_size : size);
-    uint32_t r[4];
-    philox4x32(s.seed, (uint32_t)b, ctr, 0x53414D50u, r);
-    const int env = (int)(((uint64_t)r[0] * (uint64_t)n_envs) >> 32);
-    const int step = (int)(((uint64_t)r[1] * (uint64_t)size) >> 32);
-    return (int64_t)env * n_size + step;
-}
-
 // dst[b] = field[t_b][env_b], (env_b, t_b) = divmod(idx[b], T).  Unit V = 16 B or 4 B.
 // SAMPLED: the indices are not read but drawn here (bs <= 256: every workgroup draws all of them into LDS; workgroup
 // (0, 0) also writes them to draw.idx_out) -- one launch instead of xrl_sample_replay_indices + xrl_soa_gather.

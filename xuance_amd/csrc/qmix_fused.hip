@@ -289,17 +289,37 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
     const int ldav = qf_pad4(A), D = p->dims[0], S = p->S;
     const int n_obs = rows * D, n_st = bw * S, n_av = rows * A;
     const int seg1 = n_obs, seg2 = 2 * n_obs, seg3 = seg2 + n_st, seg4 = seg3 + n_st, seg5 = seg4 + 4 * rows, n_in = seg5 + n_av;
+    // ring mode: this group's transitions are rows of the replay ring, drawn here (the stream of xrl_sample_replay_indices)
+    const bool ring = p->ring_n_envs > 0;
+    auto ring_row = [&](int bi) -> size_t {                               // ring row (t * n_envs + env) of transition b0 + bi
+        ReplayDraw d;
+        d.size_dev = p->size_dev; d.seed = p->draw_seed; d.counter = p->draw_counter; d.counter_dev = p->counter_dev; d.idx_out = nullptr;
+        const int64_t fl = replay_draw(d, b0 + bi, p->ring_n_envs, p->ring_n_size);
+        const int env = (int)(fl / p->ring_n_size), t = (int)(fl - (int64_t)env * p->ring_n_size);
+        if (p->idx_out) p->idx_out[b0 + bi] = fl;                         // (every reader of the row writes the same value)
+        return (size_t)t * p->ring_n_envs + env;
+    };
     auto in_word = [&](int w, int& dst) -> const float* {               // input word w: where it comes from, where it goes
         if (w < seg2) { const int u = w < seg1 ? w : w - seg1, r = u / D, k = u - r * D;
-                        dst = (w < seg1 ? L->x0 : L->x1) + r * L->ld[0] + k; return (w < seg1 ? p->obs : p->obs_next) + (size_t)r_base * D + u; }
+                        dst = (w < seg1 ? L->x0 : L->x1) + r * L->ld[0] + k;
+                        const float* base = w < seg1 ? p->obs : p->obs_next;
+                        if (ring) { const int bi = r / N; return base + ring_row(bi) * (size_t)(N * D) + (u - bi * N * D); }
+                        return base + (size_t)r_base * D + u; }
         if (w < seg4) { const int u = w < seg3 ? w - seg2 : w - seg3, r = u / S, k = u - r * S;
-                        dst = (w < seg3 ? L->s0 : L->s1) + r * L->lds + k; return (w < seg3 ? p->state : p->state_next) + (size_t)b0 * S + u; }
+                        dst = (w < seg3 ? L->s0 : L->s1) + r * L->lds + k;
+                        const float* base = w < seg3 ? p->state : p->state_next;
+                        if (ring) return base + ring_row(r) * (size_t)S + k;
+                        return base + (size_t)b0 * S + u; }
         if (w < seg5) { const int u = w - seg4, f = u / rows, i = u - f * rows;
                         dst = (f == 0 ? L->act_i : f == 1 ? L->rew : f == 2 ? L->term : L->amask) + i;
-                        return (f == 0 ? p->actions : f == 1 ? p->rewards : f == 2 ? p->terminals : p->agent_mask) + r_base + i; }
+                        const float* base = f == 0 ? p->actions : f == 1 ? p->rewards : f == 2 ? p->terminals : p->agent_mask;
+                        if (ring) { const int bi = i / N; return base + ring_row(bi) * (size_t)N + (i - bi * N); }
+                        return base + r_base + i; }
         const int u = w - seg5, r = u / A, k = u - r * A;
         dst = L->avail + r * ldav + k;
-        return p->avail_next ? p->avail_next + (size_t)r_base * A + u : nullptr;
+        if (!p->avail_next) return nullptr;
+        if (ring) { const int bi = r / N; return p->avail_next + ring_row(bi) * (size_t)(N * A) + (u - bi * N * A); }
+        return p->avail_next + (size_t)r_base * A + u;
     };
     {
         typedef const __attribute__((address_space(1))) qf_f4* G;
@@ -677,6 +697,7 @@ extern "C" int xrl_qmix_fused_update(const xrl_qmix_fused_t* pp, xrl_stream_t st
     XRL_CHECK_ARG(p.n_layers >= 1 && p.n_layers <= XRL_QF_MAX_LAYERS && p.B > 0 && p.items_per_wg > 0);
     XRL_CHECK_ARG(p.N >= 1 && p.N <= 64 && p.H >= 1 && p.H <= 64 && p.A >= 1 && p.dims[p.n_layers] == p.A && p.HH >= 1 && p.S >= 1);
     XRL_CHECK_ARG((p.slab_stride & 3) == 0);
+    XRL_CHECK_ARG(p.ring_n_envs == 0 || (p.ring_n_envs > 0 && p.ring_n_size > 0 && p.size_dev != nullptr));
     const QfLds L = qf_layout(p);
     const size_t bytes = (size_t)L.total * 4;
     XRL_CHECK_ARG(bytes <= 160 * 1024);

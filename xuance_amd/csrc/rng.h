@@ -64,4 +64,20 @@ __device__ __forceinline__ int marl_select_row(const float* q_row, const float* 
     return a;
 }
 
+// Draw of xrl_sample_replay_indices for batch row b (same Philox stream: the fused draw + gather picks the same rows).
+struct ReplayDraw {
+    const int32_t* size_dev; uint64_t seed; uint32_t counter; const uint32_t* counter_dev; int64_t* idx_out;
+};
+__device__ __forceinline__ int64_t replay_draw(const ReplayDraw& s, int b, int n_envs, int n_size) {
+    const uint32_t ctr = s.counter + (s.counter_dev ? *s.counter_dev : 0u);
+    int size = *s.size_dev;
+    size = size < 1 ? 1 : (size > n_size ? n_size : size);
+    uint32_t r[4];
+    philox4x32(s.seed, (uint32_t)b, ctr, 0x53414D50u, r);
+    const int env = (int)(((uint64_t)r[0] * (uint64_t)n_envs) >> 32);
+    const int step = (int)(((uint64_t)r[1] * (uint64_t)size) >> 32);
+    return (int64_t)env * n_size + step;
+}
+
+
 }  // namespace xrl

@@ -130,7 +130,8 @@ class QMIX_Learner(Learner):
                     self._fused = fs
         return self._fused is not None
 
-    def _step(self, B):
+    def _step(self, B, ring=None):
+        """ring: None, or (memory, draw arguments): the one-launch update then reads its batch from the replay ring itself."""
         m, opt = self.model, self.optimizer
         N, A, H = m.n_agents, m.n_actions, m.H
         R = B * N
@@ -138,9 +139,17 @@ class QMIX_Learner(Learner):
             b = self.buf
             if not self._images_current:                    # (a call outside a captured phase: somebody may have written the
                 self._fused.refresh()                       #  parameters -- load_model, copy_target, an adopter's module)
-            S = ops.qmix_fused_update(self._fused, B, self.X, self.X[R:], self.states, self.states[B:], b["actions"], b["rewards"],
-                                      b["terminals"], b["agent_mask"], b["avail_next"] if self.use_actions_mask else None,
-                                      self.slabs, m.params.P, self.partials, self.diag)
+            if ring is not None:
+                f = ring["memory"].soa.fields
+                S = ops.qmix_fused_update(self._fused, B, f["obs"], f["obs_next"], f["state"], f["state_next"], f["actions"],
+                                          f["rewards"], f["terminals"], f["agent_mask"],
+                                          f["avail_actions_next"] if self.use_actions_mask else None, self.slabs, m.params.P,
+                                          self.partials, self.diag, ring=ring)
+            else:
+                S = ops.qmix_fused_update(self._fused, B, self.X, self.X[R:], self.states, self.states[B:], b["actions"],
+                                          b["rewards"], b["terminals"], b["agent_mask"],
+                                          b["avail_next"] if self.use_actions_mask else None, self.slabs, m.params.P,
+                                          self.partials, self.diag)
             self._finish_step(S)
             return
         S = pick_n_split(R)
@@ -307,10 +316,17 @@ class QMIX_Learner(Learner):
                 if self.fused_eligible():                   # weight images of the one-launch update: rebuilt once per phase
                     self._fused.refresh()                   # (acting, checkpoints, target copies happen between phases),
                     self._images_current = True             # kept current inside it by the optimiser launch's mirrors
+                in_kernel = self.fused_eligible() and self._fused.n_groups(B) <= self.slabs.shape[0] and \
+                    getattr(self.config, "fused_qmix_gather_in_kernel", True)
                 for e in range(n_epochs):
-                    memory.draw_into(self._idx, dst, seed, e, self._sample_counter)     # draw + gather: one launch
                     self.partials = self._phase_partials[e]
-                    self._step(B)
+                    if in_kernel:                           # the update launch draws and gathers its own batch from the ring
+                        self._step(B, ring=dict(memory=memory, n_envs=memory.n_envs, n_size=memory.n_size,
+                                                size_dev=memory.size_dev, seed=seed, counter=e,
+                                                counter_dev=self._sample_counter, idx_out=self._idx))
+                    else:
+                        memory.draw_into(self._idx, dst, seed, e, self._sample_counter)     # draw + gather: one launch
+                        self._step(B)
                 self._images_current = False
                 ops.counter_add(self._sample_counter, n_epochs)
                 ops.sum_partials_batched(self._phase_partials, B, 8, self._epoch_sums, n_epochs, B * 8, 8)

@@ -593,9 +593,18 @@ class MarlActGruState:
 
 
 def qmix_fused_update(fs, B, obs, obs_next, state, state_next, actions, rewards, terminals, agent_mask, avail_next, slabs,
-                      slab_stride, partials, diag):
+                      slab_stride, partials, diag, ring=None):
+    """ring: None (the nine tensors are the gathered batch) or dict(n_envs, n_size, size_dev, seed, counter, counter_dev,
+    idx_out): the nine tensors are then the replay ring's FIELDS and the launch draws and gathers its own batch."""
     q = fs.struct
     q.B = int(B)
+    if ring is None:
+        q.ring_n_envs = 0
+    else:
+        q.ring_n_envs, q.ring_n_size, q.size_dev = int(ring["n_envs"]), int(ring["n_size"]), ptr(ring["size_dev"])
+        q.draw_seed, q.draw_counter = int(ring["seed"]), int(ring.get("counter", 0))
+        q.counter_dev = ptr(ring["counter_dev"]) if ring.get("counter_dev") is not None else None
+        q.idx_out = ptr(ring["idx_out"]) if ring.get("idx_out") is not None else None
     q.obs, q.obs_next, q.state, q.state_next = ptr(obs), ptr(obs_next), ptr(state), ptr(state_next)
     q.actions, q.rewards, q.terminals, q.agent_mask = ptr(actions), ptr(rewards), ptr(terminals), ptr(agent_mask)
     q.avail_next = ptr(avail_next) if avail_next is not None else None
