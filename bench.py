@@ -112,9 +112,9 @@ def kernel_rooflines(agent):
           "algorithmic_flops_per_launch": fl_launch,
           "note": "latency-bound: %d rows x %.0f flop per launch (%s); see DESIGN.md section 3"
                   % (rows, fwd_flops_row, "%d vector steps of 2 x %d rows" % (T + 1, n) if persistent else "one vector step")}
-    # (2) fused minibatch kernel, timed INSIDE the real minibatch sequence: (graph of nb x [minibatch kernel, optimiser
-    #     launch]) minus (graph of nb x [optimiser launch]), per minibatch.  Timed alone, back to back, the kernel
-    #     re-reads parameters that are still in L2 and comes out ~10 % faster than what rocprofv3 sees in the loop.
+    # (2) fused minibatch kernel, timed INSIDE the real minibatch sequence (nb x [minibatch kernel, optimiser launch]) with
+    #     an event pair around every minibatch launch.  Timed alone, back to back, the kernel re-reads parameters that are
+    #     still in L2 and comes out ~10 % faster than what rocprofv3 sees in the loop.
     f = mem.soa.fields
     nb = agent.idx.shape[0]
 
@@ -133,16 +133,31 @@ def kernel_rooflines(agent):
         def ra():
             ops.reduce_adam(lr.fslabs, lr.n_tiles, lr.slab_stride, m.params.flat, opt.grad, opt.m, opt.v, m.params.P,
                             opt.state, lr.sumsq, clip, lr._mirrors, lr.opt_sync, fold=lr.fold)
-        g_both, g_opt = ops.Graph(), ops.Graph()           # the real minibatch sequence, and the optimiser launches alone
-        torch.cuda.synchronize()
-        with g_both:
-            for k in range(nb):
-                mb(k); ra()
-        with g_opt:
-            for k in range(nb):
-                ra()
-        g_both.launch(); g_opt.launch()
-        us_mb = (_event_time_us(g_both.launch, 3) - _event_time_us(g_opt.launch, 3)) / nb
+        # the real minibatch sequence [minibatch kernel, reduce + Adam] x nb, bracketed twice with HIP events: once around
+        # every PAIR, once around the optimiser launch of every pair only; the difference of the medians is the minibatch
+        # kernel in its real position (cold slabs, parameters just rewritten), the cost of the event packets cancels.  Two
+        # rollouts are enqueued first so that the host has queued the whole sequence before the device gets to it.
+        # (Earlier versions: graphs of pairs minus a graph of optimiser launches run alone -- alone they read warm slabs,
+        # the difference moved by +-4 us between runs; one bracket around the kernel minus an empty bracket -- an empty
+        # bracket costs 5.2 us, more than the two event packets add around a kernel.)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nb)]
+
+        def brackets(around_pair):
+            out = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                agent.rollout(); agent.rollout()
+                for k in range(nb):
+                    if around_pair:
+                        evs[k][0].record(); mb(k); ra(); evs[k][1].record()
+                    else:
+                        mb(k); evs[k][0].record(); ra(); evs[k][1].record()
+                torch.cuda.synchronize()
+                out += [x.elapsed_time(y) * 1e3 for x, y in evs]
+            out.sort()
+            return out[len(out) // 2]
+        us_pair, us_opt = brackets(True), brackets(False)
+        us_mb = us_pair - us_opt
         fl_mb = 3.0 * fwd_flops_row * bs
         n_mb = nb                                          # agent.idx holds n_epochs x n_minibatch index rows
         kname = "xrl::ppo_split_kernel" if lr.fold else "xrl::ppo_fast_kernel"
@@ -150,7 +165,10 @@ def kernel_rooflines(agent):
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
               "traffic": _pmc_traffic(kname), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_mb, 3),
               "algorithmic_flops_per_launch": fl_mb, "launches_per_step": n_mb, "us_per_step": round(us_mb * n_mb, 1),
-              "note": "%d rows x %.0f flop (forward + backward) per launch; see DESIGN.md section 3" % (bs, 3.0 * fwd_flops_row)}
+              "note": "%d rows x %.0f flop (forward + backward) per launch; avg_launch_us = median HIP-event bracket around "
+                      "[minibatch kernel, optimiser launch] inside the real sequence (%.1f us) minus the median bracket around "
+                      "the optimiser launch in the same position (%.1f us); see DESIGN.md section 3"
+                      % (bs, 3.0 * fwd_flops_row, us_pair, us_opt)}
     r1.update(launches_per_step=launches, us_per_step=round(us_launch * launches, 1))
     return r1, r2
 
