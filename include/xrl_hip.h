@@ -810,6 +810,7 @@ typedef struct {
     int32_t slots;
     int32_t flags;         /* xrl_episode_finish: bit0 = zero the staging row after the copy (the `filled` field) */
     int32_t pad;
+    const void* d;         /* xrl_episode_store_finish only: this step's data [n_envs][row] for the field, or NULL */
 } xrl_episode_field_t;
 /* Device-side loop control of run_episodes (off_policy_marl.py:464-546) for callers that enqueue vector steps ahead of the
  * host's knowledge of their outcome; launch once at the end of every (captured) vector step -- see csrc/episodes.hip. */
@@ -824,7 +825,8 @@ typedef struct {
     float* active_f;           /* [1] out: 1.0f / 0.0f -- multiply `done` with it before xrl_episode_finish */
     int32_t* active_i;         /* NULL or [2] out: 1 / 0 twice (for callers that advance their counters themselves) */
     int32_t* host_flags;       /* [ring] or NULL: device pointer of pinned host memory (xrl_host_device_pointer); launch k of a
-                                * call writes its `active` output to host_flags[k % ring] with system scope */
+                                * call writes 1 + its `active` output to host_flags[k % ring] with system scope (a host that
+                                * zeroes a slot before the launch can poll it: 0 = not yet) */
     int32_t* seq;              /* [1] in/out: launches of this call so far (the host sets 0 per call); NULL iff host_flags NULL */
     double start_greedy, end_greedy, delta_greedy;
     int32_t ring, pad;
@@ -850,6 +852,12 @@ int xrl_episode_store_step(const xrl_episode_field_t* fields, int n_fields, cons
  * then ptr_size = {ptr, size} advance (device-resident: captured graphs and sampling kernels read them). */
 int xrl_episode_finish(const xrl_episode_field_t* fields, int n_fields, const float* done, const int32_t* end_step,
                        int32_t* ptr_size, int n_envs, int buffer_size, xrl_stream_t stream);
+/* xrl_episode_store_step (a = unused / ring, b = staging, d = step data) followed by xrl_episode_finish_gated without the
+ * pointer advance, as ONE launch: per field, staging[env][steps[env]] <- d[env], then the episode close of the envs with
+ * done != 0.  ptr_size is only read. */
+int xrl_episode_store_finish(const xrl_episode_field_t* fields, int n_fields, const int32_t* steps, const float* gate,
+                             const float* done, const int32_t* end_step, const int32_t* ptr_size, int n_envs, int buffer_size,
+                             xrl_stream_t stream);
 /* Same, switched by a device scalar: gate NULL or *gate != 0 -> as above; *gate == 0 -> nothing is closed (a dry step of a
  * loop that runs ahead of its stop condition, xrl_marl_loop_gate). */
 int xrl_episode_finish_gated(const xrl_episode_field_t* fields, int n_fields, const float* gate, const float* done,

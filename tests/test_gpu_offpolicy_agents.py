@@ -561,7 +561,7 @@ def test_captured_vector_step_equals_the_eager_episode_loop(lag, unroll):
         for _ in range(3):
             agent.run_episodes(8)
         torch.cuda.synchronize()
-        assert (getattr(agent, "_steps_g", None) is not None) == graph
+        assert bool(getattr(agent, "_steps_g", None)) == graph
         mem = agent.memory
         res.append(dict(ptr_size=mem.ptr_size.cpu().numpy(), step=np.array([agent.current_step, agent._host_step, agent.envs._host_step]),
                         eps=np.array([agent.e_greedy]), eps_dev=agent.eps_dev.cpu().numpy(),

@@ -94,7 +94,7 @@ class Qmix(C.Structure):
 
 class EpisodeField(C.Structure):
     _fields_ = [("a", c_void_p), ("b", c_void_p), ("c", c_void_p), ("row_bytes", c_int32), ("slots", c_int32),
-                ("flags", c_int32), ("pad", c_int32)]
+                ("flags", c_int32), ("pad", c_int32), ("d", c_void_p)]
 
 
 class GruFwd(C.Structure):
@@ -257,6 +257,7 @@ _SIGS = {
     "xrl_qmix_mix_td": [C.POINTER(Qmix), c_void_p],
     "xrl_episode_store_step": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_episode_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "xrl_episode_store_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_episode_finish_gated": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "xrl_episode_gather": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_marl_loop_gate": [C.POINTER(MarlGate), c_void_p],

@@ -109,21 +109,17 @@ class QMIX_Agents(AgentSurface):
     def run_episodes(self, n_episodes):                        # off_policy_marl.py:426-546 (training mode)
         env, n, N, A, mem = self.envs, self.n_envs, self.n_agents, self.n_actions, self.memory
         R = n * N
-        env.reset()
-        mem.clear_episodes()
-        self.rnn_h.zero_()
-        if self.rnn_c is not None:
-            self.rnn_c.zero_()
-        self.reset_rows.zero_()
         fused_act = bool(getattr(self.config, "use_fused_acting", True))
-        if fused_act and self.model.act_image() is not None:
-            self.model.act_image().refresh()                    # (the parameters only change between run_episodes calls)
-        episodes = 0
+        if fused_act and self.model.act_image() is not None and getattr(self.model, "_act_stale", True):
+            self.model.act_image().refresh()                    # (kept current by the optimiser launch's mirrors otherwise)
+            self.model._act_stale = False
         # an env that alternates its observation buffers and keeps running episode totals saves the copies and the
         # reductions of a step (envs/synthetic.py); any other env goes through clones and two small sums
         two_buf, totals = getattr(env, "double_buffered", False), getattr(env, "episode_totals", None)
         if self.use_graph_updates and two_buf and totals is not None and hasattr(env, "enqueue_step"):
             return self._run_episodes_captured(n_episodes, totals)
+        self._call_prologue(env, mem)
+        episodes = 0
         if totals is not None:
             self._totals_h.copy_(totals)
             seen = self._totals_h.clone()
@@ -156,6 +152,15 @@ class QMIX_Agents(AgentSurface):
                 self.current_step += int(self._counts_h[1])
             self._update_explore_factor()
 
+    def _call_prologue(self, env, mem, counter=None):
+        """What a run_episodes call starts with (:436-462): env reset, empty staging rows, zero recurrent state and reset flags."""
+        env.reset() if counter is None else env.reset(counter=counter)
+        mem.clear_episodes()
+        self.rnn_h.zero_()
+        if self.rnn_c is not None:
+            self.rnn_c.zero_()
+        self.reset_rows.zero_()
+
     def _run_episodes_captured(self, n_episodes, totals):
         """run_episodes with the vector step -- acting forward incl. the recurrence and the action selection, provider step,
         staging store, episode close, and (marl_loop_gate) reset flags, RNG counters, ring pointers and the loop's own
@@ -167,28 +172,35 @@ class QMIX_Agents(AgentSurface):
         K * (lag + 1) - 1 dry steps that change nothing the eager loop would see (csrc/episodes.hip)."""
         env, lag, K = self.envs, self.episode_loop_lag, self.episode_loop_unroll
         assert env._cur == 0, "the captured steps start on observation-buffer set 0"
-        graph = self._steps_graph()
+        graphs = self._steps_graph()
         g, ring = self._gate, self._flag_h.numel()
-        g["base"].copy_(totals)
-        self._call_h[0], self._call_h[1] = self.current_step, n_episodes
-        g["call"].copy_(self._call_h, non_blocking=True)
-        g["e_state"].fill_(self.e_greedy)
-        g["active"].fill_(1); g["active_f"].fill_(1.0); g["seq"].zero_()
-        launched, over = 0, False
+        # per-call state of the gate: one host->device copy of a pinned template (call = [current_step, n_episodes], snap = 0,
+        # e_state, active = 1, seq = 0, active_f = 1) + the provider's totals as the call's base
+        t = self._gate_tpl
+        t["call"][0], t["call"][1] = self.current_step, n_episodes
+        t["e_state"][0] = self.e_greedy
+        self._gate_buf.copy_(self._gate_tpl_raw, non_blocking=True)
+        self._prologue_g.launch()                                          # the call's prologue + base <- totals: one launch
+        flags = self._flag_np
+        flags[:] = 0                                                       # 0 = "this step's gate has not run yet"
+        launched, over, spins = 0, False, 0
         while not over:
-            graph.launch()
-            self._flag_ev[launched % len(self._flag_ev)].record()
+            graphs[launched % len(graphs)].launch()                        # (alternating executables: see _steps_graph)
             launched += 1
             j = launched - 1 - lag                                         # the newest graph whose outcome is read now
             if j >= 0:
-                self._flag_ev[j % len(self._flag_ev)].synchronize()
-                over = int(self._flag_h[(j * K + K - 1) % ring]) == 0      # "the step after graph j is not part of the call"
-        torch.cuda.current_stream().synchronize()
-        self._snap_h.copy_(g["snap"])
-        self._rng_h.copy_(self._rng_dev)
-        self._host_step, env._host_step = int(self._rng_h[0]), int(self._rng_h[1])    # (advanced by the steps that counted)
-        self.current_step += int(self._snap_h[1])
-        self.e_greedy = self._eps_on_device = float(g["e_state"].item())
+                slot = (j * K + K - 1) % ring                              # its last step's flag: polled in pinned memory -- an
+                while flags[slot] == 0:                                    # event record + synchronize per graph cost 40 us of
+                    spins += 1                                             # device time each (108 -> 150 us per graph)
+                    if spins > 200_000_000:
+                        raise ops.XrlError("run_episodes: the captured vector steps did not report back")
+                over = int(flags[slot]) == 1                               # 1: "the step after graph j is not part of the call"
+                flags[slot] = 0
+        self._gate_out_h.copy_(self._gate_all)                             # ONE read of the call's outcome: gate block + RNG counters
+        out = self._gate_out
+        self._host_step, env._host_step = int(out["rng"][0]), int(out["rng"][1])   # (advanced by the steps that counted)
+        self.current_step += int(out["snap"][1])
+        self.e_greedy = self._eps_on_device = float(out["e_state"][0])
 
     def _steps_graph(self):
         """K captured vector steps of run_episodes, alternating between the provider's two buffer sets (same launches, same
@@ -199,47 +211,66 @@ class QMIX_Agents(AgentSurface):
         dev, K, lag = self.device, self.episode_loop_unroll, self.episode_loop_lag
         env, n, N, A, mem = self.envs, self.n_envs, self.n_agents, self.n_actions, self.memory
         R = n * N
-        self._rng_dev = torch.tensor([self._host_step, env._host_step], dtype=torch.int32).to(dev)   # [agent step, provider step]
-        self._rng_h = torch.zeros(2, dtype=torch.int32).pin_memory()
-        self._gate = gt = dict(base=torch.zeros(2, dtype=torch.int64, device=dev), call=torch.zeros(2, dtype=torch.int64, device=dev),
-                               snap=torch.zeros(2, dtype=torch.int64, device=dev), active=torch.ones(1, dtype=torch.int32, device=dev),
-                               e_state=torch.zeros(1, dtype=torch.float64, device=dev), active_f=torch.ones(1, device=dev),
-                               seq=torch.zeros(1, dtype=torch.int32, device=dev))
+        self._gate_all = torch.zeros(72, dtype=torch.uint8, device=dev)              # [0, 64): gate state, [64, 72): RNG counters
+        self._rng_dev = self._gate_all[64:72].view(torch.int32)                      # [agent step, provider step]
+        self._rng_dev.copy_(torch.tensor([self._host_step, env._host_step], dtype=torch.int32))
+        # gate state: one 64-byte device block with typed views (+ `base` apart: it is copied from the provider's totals),
+        # initialised per call from a pinned template of the same layout
+        def carve(raw):
+            return dict(call=raw[0:16].view(torch.int64), snap=raw[16:32].view(torch.int64), e_state=raw[32:40].view(torch.float64),
+                        active=raw[40:44].view(torch.int32), seq=raw[44:48].view(torch.int32), active_f=raw[48:52].view(torch.float32))
+        self._gate_buf = self._gate_all[:64]
+        self._gate_tpl_raw = torch.zeros(64, dtype=torch.uint8).pin_memory()
+        self._gate_tpl = carve(self._gate_tpl_raw)
+        self._gate_tpl["active"][0] = 1
+        self._gate_tpl["active_f"][0] = 1.0
+        self._gate = gt = dict(base=torch.zeros(2, dtype=torch.int64, device=dev), **carve(self._gate_buf))
+        self._gate_out_h = torch.zeros(72, dtype=torch.uint8).pin_memory()
+        self._gate_out = dict(rng=self._gate_out_h[64:72].view(torch.int32), **carve(self._gate_out_h))
         ring = K * (lag + 2)                                                          # per-step flags in pinned memory
-        self._flag_h = torch.ones(ring, dtype=torch.int32).pin_memory()
-        self._flag_ev = [torch.cuda.Event() for _ in range(lag + 2)]
-        self._snap_h = torch.zeros(2, dtype=torch.int64).pin_memory()
-        self._call_h = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self._flag_h = torch.zeros(ring, dtype=torch.int32).pin_memory()
+        self._flag_np = self._flag_h.numpy()
         gate_const = dict(host_flags=ops.host_device_pointer(self._flag_h), ring=ring)
         fused = bool(getattr(self.config, "use_fused_acting", True))
         self.model.seq_workspace(2, R, 1)                                             # (no allocation inside the capture)
         if self.model.act_image() is not None:
             self.model.act_q_buffer(R)
         torch.cuda.synchronize()
-        g = ops.Graph()
-        with g:
-            for k in range(K):
-                cur = k & 1
-                obs, state, avail = env._sets[cur]
-                self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused,
-                                    select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
-                                                action=env.action, action_f=self.act_f, seed=self.seed, step=0,
-                                                step_dev=self._rng_dev[0:1]))
-                env.enqueue_step(cur, counter=self._rng_dev[1:2])
-                mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
-                          avail_actions=avail, state=state, episode_steps=env.prev_steps)
-                mem.finish_paths(env.done, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail,
-                                 gate=gt["active_f"], advance=False)                     # a dry step closes no episode
-                # reset flags of the finished envs' rows, RNG counters (+active), ring pointers and the loop's bookkeeping
-                ops.marl_loop_gate(totals=env.episode_totals, start_greedy=float(self.start_greedy),
-                                   end_greedy=float(self.end_greedy), delta_greedy=float(self.delta_egreedy),
-                                   eps_dev=self.eps_dev, done=env.done, reset_rows=self.reset_rows, counters=self._rng_dev,
-                                   n_envs=n, n_agents=N, ptr_size=mem.ptr_size, buffer_size=mem.buffer_size, **gate_const, **gt)
-        self._steps_g = g
-        return g
+        # lag + 2 executables of the same capture, launched in turn: a launch of an executable whose previous launch is still
+        # running waits for it on the HOST (measured: one executable = a launch every 150 us for 108 us of device work, no
+        # overlap at all), so consecutive launches must be different executables for the host to run ahead
+        self._prologue_g = ops.Graph()                                             # (~270 us of host time per call as eager calls)
+        with self._prologue_g:
+            self._call_prologue(env, mem, counter=self._rng_dev[1:2])
+            torch.add(env.episode_totals, 0, out=gt["base"])                       # (a kernel, not a memcpy node)
+
+        def capture():
+            g = ops.Graph()
+            with g:
+                for k in range(K):
+                    cur = k & 1
+                    obs, state, avail = env._sets[cur]
+                    self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused,
+                                        select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
+                                                    action=env.action, action_f=self.act_f, seed=self.seed, step=0,
+                                                    step_dev=self._rng_dev[0:1]))
+                    env.enqueue_step(cur, counter=self._rng_dev[1:2])
+                    mem.store_and_finish(dict(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals,
+                                              agent_mask=env.agent_mask, avail_actions=avail, state=state),
+                                         env.prev_steps, env.done, env.end_step, obs=env.next_obs, state=env.next_state,
+                                         avail_actions=env.next_avail, gate=gt["active_f"])  # a dry step closes no episode
+                    # reset flags of the finished envs' rows, RNG counters (+active), ring pointers and the loop's bookkeeping
+                    ops.marl_loop_gate(totals=env.episode_totals, start_greedy=float(self.start_greedy),
+                                       end_greedy=float(self.end_greedy), delta_greedy=float(self.delta_egreedy),
+                                       eps_dev=self.eps_dev, done=env.done, reset_rows=self.reset_rows, counters=self._rng_dev,
+                                       n_envs=n, n_agents=N, ptr_size=mem.ptr_size, buffer_size=mem.buffer_size, **gate_const, **gt)
+            return g
+        self._steps_g = [capture() for _ in range(lag + 2)]
+        return self._steps_g
 
     def _train_rnn(self, train_steps):                         # off_policy_marl.py:335-349
         info, start = {}, self.current_step
+        self.model._act_stale = True                            # (whatever happened to the parameters since the last call)
         while self.current_step - start < train_steps * self.n_envs:
             self.run_episodes(self.n_envs)
             if self.current_step >= self.start_training:

@@ -13,6 +13,7 @@ struct EpPack {
     void* a[EP_MAX_FIELDS];
     const void* b[EP_MAX_FIELDS];
     const void* c[EP_MAX_FIELDS];
+    const void* d[EP_MAX_FIELDS];
     int row_bytes[EP_MAX_FIELDS];
     int slots[EP_MAX_FIELDS];
     int flags[EP_MAX_FIELDS];
@@ -31,11 +32,22 @@ __global__ void __launch_bounds__(64) episode_store_kernel(EpPack f, const int32
 }
 
 // finish_path + store_episodes (:923-968) for every finished env, in env order.  grid (n_envs, n_fields), 256 threads
+// steps != NULL: the step's store (episode_store_kernel's statements, field d -> staging) happens first, in the same block that
+// then closes the episode -- one launch per vector step for both (xrl_episode_store_finish).
 __global__ void __launch_bounds__(256) episode_finish_kernel(EpPack f, const float* __restrict__ gate, const float* __restrict__ done,
                                                              const int32_t* __restrict__ end_step,
                                                              const int32_t* __restrict__ ptr_size, int n_envs,
-                                                             int buffer_size) {
+                                                             int buffer_size, const int32_t* __restrict__ steps) {
     const int env = blockIdx.x, fi = blockIdx.y;
+    if (steps && f.d[fi]) {
+        const int rw0 = f.row_bytes[fi] >> 2, st = steps[env];
+        if (st >= 0 && st < f.slots[fi]) {
+            uint32_t* d = reinterpret_cast<uint32_t*>(const_cast<void*>(f.b[fi])) + ((size_t)env * f.slots[fi] + st) * rw0;
+            const uint32_t* s = reinterpret_cast<const uint32_t*>(f.d[fi]) + (size_t)env * rw0;
+            for (int i = threadIdx.x; i < rw0; i += 256) d[i] = s[i];
+        }
+        __syncthreads();                                                 // (this block is the staging row's only writer and reader)
+    }
     if ((gate && *gate == 0.f) || done[env] == 0.f) return;
     int rank = 0;
     for (int j = 0; j < env; ++j) rank += done[j] != 0.f;                // this env's position among the finished ones
@@ -118,7 +130,7 @@ __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
     if (g.host_flags) {                                                   // the host's copy: slot (launch index mod ring)
         const int k = *g.seq;
         *g.seq = k + 1;
-        __hip_atomic_store(g.host_flags + (k % g.ring), act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(g.host_flags + (k % g.ring), act + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // 1 / 2; the host keeps 0 = "not yet"
     }
 }
 
@@ -128,7 +140,7 @@ static int pack(const xrl_episode_field_t* fields, int n, EpPack& p) {
     for (int i = 0; i < n; ++i) {
         if (!fields[i].a || !fields[i].b || fields[i].row_bytes <= 0 || (fields[i].row_bytes & 3) || fields[i].slots <= 0)
             return XRL_EINVAL;
-        p.a[i] = fields[i].a; p.b[i] = fields[i].b; p.c[i] = fields[i].c;
+        p.a[i] = fields[i].a; p.b[i] = fields[i].b; p.c[i] = fields[i].c; p.d[i] = fields[i].d;
         p.row_bytes[i] = fields[i].row_bytes; p.slots[i] = fields[i].slots; p.flags[i] = fields[i].flags;
     }
     return XRL_OK;
@@ -155,10 +167,22 @@ extern "C" int xrl_episode_finish_gated(const xrl_episode_field_t* fields, int n
     XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
     XRL_CHECK_ARG(done && end_step && ptr_size && n_envs > 0 && buffer_size > 0);
     hipLaunchKernelGGL(episode_finish_kernel, dim3(n_envs, n_fields), dim3(256), 0, as_stream(stream), p, gate, done, end_step,
-                       ptr_size, n_envs, buffer_size);
+                       ptr_size, n_envs, buffer_size, (const int32_t*)nullptr);
     if (advance)
         hipLaunchKernelGGL(episode_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), gate, done, ptr_size, n_envs,
                            buffer_size);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_episode_store_finish(const xrl_episode_field_t* fields, int n_fields, const int32_t* steps, const float* gate,
+                                        const float* done, const int32_t* end_step, const int32_t* ptr_size, int n_envs,
+                                        int buffer_size, xrl_stream_t stream) {
+    EpPack p;
+    XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
+    XRL_CHECK_ARG(steps && done && end_step && ptr_size && n_envs > 0 && buffer_size > 0);
+    hipLaunchKernelGGL(episode_finish_kernel, dim3(n_envs, n_fields), dim3(256), 0, as_stream(stream), p, gate, done, end_step,
+                       ptr_size, n_envs, buffer_size, steps);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -174,9 +174,14 @@ class SyntheticSMACVecEnv(_Base):
                     step=self._host_step, step_dev=None, prev_state=prev_state, prev_steps=self.prev_steps,
                     totals=self.episode_totals)
 
-    def reset(self):
+    def reset(self, counter=None):
+        """counter: None (the Philox step index is the host's `_host_step`) or a device counter holding the same value, for
+        callers that capture the launch."""
         from .. import ops
-        ops.synth_marl_step(reset=True, **self._kw(self._sets[self._cur]))
+        kw = self._kw(self._sets[self._cur])
+        if counter is not None:
+            kw.update(step=0, step_dev=counter)
+        ops.synth_marl_step(reset=True, **kw)
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
     def step_device(self):

@@ -223,6 +223,9 @@ class Learner:
             for i, st in enumerate(ckpt["cuda_rng_state"][:torch.cuda.device_count()]):
                 torch.cuda.set_rng_state(st.cpu().to(torch.uint8), device=i)
         self._safe_scheduler_step()
+        if hasattr(self.model, "_act_state"):                                   # derived weight images follow on their next use
+            self.model._act_stale = True
+        self._images_current = False
         if getattr(self, "_xc", None) is not None:                              # so do the exchange buffers' flags (all ranks load)
             self._xc.clear()
         if getattr(self, "opt_sync", None) is not None:                         # barrier flags of xrl_reduce_adam hold step

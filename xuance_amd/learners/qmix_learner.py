@@ -195,12 +195,18 @@ class QMIX_Learner(Learner):
         fs = getattr(self, "_fused", None)
         if not self.needs_collective() and P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
             # (the one-launch update reads weight images: the optimiser launch writes every new parameter there as well)
+            mirrors = [(fs.map, fs.img_eval)] if fs else []
+            act = getattr(m, "_act_state", None)            # the acting launch's weight image follows every step too
+            if act is not None:
+                mirrors.append((act.map, act.image))
             ops.reduce_adam(self.slabs, S, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip,
-                            [(fs.map, fs.img_eval)] if fs else [], self.opt_sync, target=m.target_flat,
+                            mirrors, self.opt_sync, target=m.target_flat,
                             target_every=self.sync_frequency, exchange=self.gradient_exchange(),
                             target_image=fs.img_target if fs else None)
             return
         self._images_current = False
+        if getattr(m, "_act_state", None) is not None:
+            m._act_stale = True                             # (this path has no mirrors: the agents refresh before acting)
         ops.grad_reduce(self.slabs, S, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_

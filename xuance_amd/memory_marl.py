@@ -155,7 +155,14 @@ class HipMARLOffPolicyBufferRNN:
             self.layout["avail_actions"] = (N * self.n_actions, T + 1)
         self.data_keys = list(self.layout)
         mk = lambda rows: {k: torch.zeros(rows, sl, w, device=device) for k, (w, sl) in self.layout.items()}
-        self.data, self.episode_data = mk(buffer_size), mk(n_envs)
+        self.data = mk(buffer_size)
+        # the staging rows of all fields are views of ONE allocation: clear_episodes() is one launch
+        sizes = {k: n_envs * sl * w for k, (w, sl) in self.layout.items()}
+        self._staging = torch.zeros(sum((v + 3) // 4 * 4 for v in sizes.values()), device=device)
+        self.episode_data, off = {}, 0
+        for k, (w, sl) in self.layout.items():
+            self.episode_data[k] = self._staging[off:off + sizes[k]].view(n_envs, sl, w)
+            off += (sizes[k] + 3) // 4 * 4
         self.ptr_size = torch.zeros(2, dtype=torch.int32, device=device)       # ptr, size
         self.size_dev = self.ptr_size[1:2]
         self._ones = torch.ones(n_envs, 1, device=device)
@@ -181,8 +188,7 @@ class HipMARLOffPolicyBufferRNN:
         self.ptr_size.zero_()
 
     def clear_episodes(self):                                  # :859-902
-        for v in self.episode_data.values():
-            v.zero_()
+        self._staging.zero_()
 
     def _stack(self, v, width):
         if isinstance(v, dict):
@@ -217,6 +223,22 @@ class HipMARLOffPolicyBufferRNN:
                   for k, (w, sl) in self.layout.items()]
         ops.episode_finish(fields, done.to(torch.float32).contiguous(), self._dev_steps(end_step), self.ptr_size,
                            self.n_envs, self.buffer_size, gate=gate, advance=advance)   # gate: device scalar, 0 = close nothing
+
+    def store_and_finish(self, step_data, episode_steps, done, end_step, obs=None, state=None, avail_actions=None, gate=None):
+        """store(**step_data, episode_steps=...) followed by finish_paths(done, end_step, ..., gate=gate, advance=False) as ONE
+        launch (device tensors only: the captured vector step of the agents); the ring's {ptr, size} are left to the caller
+        (xrl_marl_loop_gate advances them)."""
+        steps = self._dev_steps(episode_steps)
+        items = {k: self._stack(v, self.layout[k][0]) for k, v in step_data.items() if k in self.layout and k != "filled"}
+        items["filled"] = self._ones
+        term = {"obs": obs, "state": state if self.store_global_state else None,
+                "avail_actions": avail_actions if self.use_actions_mask else None}
+        term = {k: self._stack(v, self.layout[k][0]).contiguous() for k, v in term.items() if v is not None}
+        self._term_keep = (term, items)                         # keep the temporaries alive until the launch ran
+        fields = [(self.data[k], self.episode_data[k], term.get(k), 4 * w, sl, 1 if k == "filled" else 0, items.get(k))
+                  for k, (w, sl) in self.layout.items()]
+        ops.episode_store_finish(fields, steps, done.to(torch.float32).contiguous(), self._dev_steps(end_step), self.ptr_size,
+                                 self.n_envs, self.buffer_size, gate=gate)
 
     def finish_path(self, i_env, **terminal_data):            # :951-968, one env (the reference's call)
         done = torch.zeros(self.n_envs, device=self.device)

@@ -430,14 +430,24 @@ def qmix_mix_td(**kw):
 def _ep_fields(items):
     """items: [(a, b, c or None, row_bytes, slots, flags)] of device tensors."""
     arr = (EpisodeField * len(items))()
-    for i, (a, b, c, rb, slots, flags) in enumerate(items):
+    for i, it in enumerate(items):
+        a, b, c, rb, slots, flags = it[:6]
         arr[i].a, arr[i].b, arr[i].c = a.data_ptr(), b.data_ptr(), (c.data_ptr() if c is not None else None)
         arr[i].row_bytes, arr[i].slots, arr[i].flags = int(rb), int(slots), int(flags)
+        arr[i].d = it[6].data_ptr() if len(it) > 6 and it[6] is not None else None      # (xrl_episode_store_finish: step data)
     return arr
 
 
 def episode_store_step(items, steps, n_envs):
     call("xrl_episode_store_step", _ep_fields(items), len(items), ptr(_chk(steps, torch.int32)), int(n_envs), stream_ptr())
+
+
+def episode_store_finish(items, steps, done, end_step, ptr_size, n_envs, buffer_size, gate=None):
+    """episode_store_step + episode_finish(advance=False) as one launch; items: (ring, staging, terminal or None, row_bytes,
+    slots, flags, step data or None) per field."""
+    call("xrl_episode_store_finish", _ep_fields(items), len(items), ptr(_chk(steps, torch.int32)),
+         ptr(gate) if gate is not None else None, ptr(_chk(done)), ptr(_chk(end_step, torch.int32)),
+         ptr(_chk(ptr_size, torch.int32)), int(n_envs), int(buffer_size), stream_ptr())
 
 
 def episode_finish(items, done, end_step, ptr_size, n_envs, buffer_size, gate=None, advance=True):
@@ -562,8 +572,12 @@ class MarlActGruState:
             src.append(P.offsets[wn] + np.arange(N * K)); dst.append(im.w[l] + r * im.ldw[l] + k)
             src.append(P.offsets[bn] + np.arange(N)); dst.append(im.b[l] + np.arange(N))
         dev = P.flat.device
-        self._src = torch.as_tensor(np.concatenate(src), device=dev).to(torch.int64)
-        self._dst = torch.as_tensor(np.concatenate(dst), device=dev).to(torch.int64)
+        src_all, dst_all = np.concatenate(src), np.concatenate(dst)
+        mp = np.full(P.P, -1, np.int32)                     # parameter index -> image index (xrl_reduce_adam's mirror map)
+        mp[src_all] = dst_all
+        self.map = torch.as_tensor(mp, device=dev)
+        self._src = torch.as_tensor(src_all, device=dev).to(torch.int64)
+        self._dst = torch.as_tensor(dst_all, device=dev).to(torch.int64)
         self.image = torch.zeros(int(im.image_floats), device=dev)
         q.image = self.image.data_ptr()
         self.struct, self.model = q, model
