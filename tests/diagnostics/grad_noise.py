@@ -1,7 +1,7 @@
-"""Scratch diagnostics: rounding noise of ONE minibatch gradient (8 192 rows, fixture ppo_categorical_c2) -- the HIP learner
+"""TEST DIAGNOSTICS (uses the oracle; run by hand on a GPU box: python tests/diagnostics/grad_noise.py) -- rounding noise of ONE minibatch gradient (8 192 rows, fixture ppo_categorical_c2) -- the HIP learner
 (layered path and the fused minibatch kernel) and the float32 oracle, each against the float64 oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from argparse import Namespace
