@@ -213,7 +213,7 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
         # boundary contributes its whole gradient or nothing: one such sample in a minibatch of 8 192 moves the actor's
         # gradient by ~1e-4 of its norm), and Adam divides by sqrt(v) + eps (a parameter whose gradient sits at noise level
         # still moves by ~lr per step).  Single updates are compared at 1e-5 against the reference's own fixtures at these
-        # batch sizes (tests/test_gpu_ppo.py) and their gradient noise against float64 in tools/grad_noise.py (1e-10).  So: within 1e-5 of the float32 oracle, or no further from the float64 chain than
+        # batch sizes (tests/test_gpu_ppo.py) and their gradient noise against float64 in tests/diagnostics/grad_noise.py (1e-10).  So: within 1e-5 of the float32 oracle, or no further from the float64 chain than
         # four times the drift the float32 oracle itself shows at this point (largest over the parameter tensors; the
         # drift of one tensor is a heavy-tailed maximum over thousands of weights).  Every number is recorded.
         got = agent.model.state_dict()
