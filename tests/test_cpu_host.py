@@ -340,3 +340,39 @@ def test_shm_multi_agent_vec_env_matches_in_process_stepping():
     assert ended >= n                                               # every env went through an auto-reset at least once
     venv.close(); ref.close()
     assert venv.closed
+
+
+def test_weight_images_of_the_one_launch_kernels_cover_every_parameter_once():
+    """Host side of xrl_qmix_fused_update / xrl_marl_act_gru (no GPU needed: the layout entry points are plain C): the
+    parameter -> image maps built from xrl_qmix_fused_layout / xrl_marl_act_gru_layout place every weight of the networks a
+    launch reads at its own image slot (matrix rows padded to pad4(K) + 4 floats), leave the padding zero, and follow the
+    parameters on refresh(); the LDS the launches ask for fits the 160 KB of a CU at the default group sizes."""
+    import torch
+    from xuance_amd import ops
+    from xuance_amd.nets import MixingQNet
+    torch.manual_seed(0)
+    net = MixingQNet(3, 30, 9, 48, (64,), (64,), 32, 32, "relu", device="cpu")
+    fs = ops.QmixFusedState(net, True, 0.99, 1)
+    mp = fs.map.numpy()
+    used = mp[mp >= 0]
+    n_par = sum(int(np.prod(s)) for s in net.params.shapes.values())
+    assert len(used) == n_par == 17258 and len(np.unique(used)) == n_par            # (SURVEY 8a17: 17 258 trainable, FF)
+    img = fs.img_eval.numpy()
+    assert np.array_equal(img[used], net.params.flat.numpy()[mp >= 0])
+    pad = np.ones(len(img), bool); pad[used] = False
+    assert not img[pad].any()
+    w = net.params.view("individual_q_networks.shared.critic_head.q_value.2.weight").numpy()   # [9, 64] -> rows 68 apart
+    o = int(mp[net.params.offsets["individual_q_networks.shared.critic_head.q_value.2.weight"]])
+    assert np.array_equal(img[o:o + 64], w[0]) and np.array_equal(img[o + 68:o + 68 + 64], w[1])
+    net.params.flat.mul_(2.0); net.copy_target(); fs.refresh()
+    assert np.array_equal(fs.img_eval.numpy()[used], net.params.flat.numpy()[mp >= 0])
+    assert np.array_equal(fs.img_target.numpy()[used], net.target_flat.numpy()[mp >= 0])
+    assert 0 < fs.lds_bytes() <= 160 * 1024
+    assert ops.QmixFusedState(net, True, 0.99, 16).lds_bytes() > 160 * 1024            # too many transitions per workgroup
+    rnn = MixingQNet(3, 30, 9, 48, (), (64,), 32, 32, "relu", use_rnn=True, fc_hidden=(64,), recurrent_hidden=64, device="cpu")
+    st = ops.MarlActGruState(rnn)
+    mpa = st.map.numpy()
+    ua = mpa[mpa >= 0]
+    agent_names = [n for n in rnn.params.shapes if n.startswith("individual_q_networks")]
+    assert len(ua) == sum(int(np.prod(rnn.params.shapes[n])) for n in agent_names) == 31689 and len(np.unique(ua)) == len(ua)
+    assert np.array_equal(st.image.numpy()[ua], rnn.params.flat.numpy()[mpa >= 0]) and st.lds_bytes <= 160 * 1024
