@@ -711,7 +711,7 @@ int xrl_qmix_fused_layout(const xrl_qmix_fused_t* p, xrl_qf_image_t* out);   /* 
  * per workgroup, all weights staged in LDS from an IMAGE in the layout of xrl_marl_act_gru_layout (layers in the order
  * pre[0..n_pre), W_ih, W_hh, post[0..n_post); matrix l at w[l] + n * ldw[l] + k, its bias at b[l]; padding zero).  Cell
  * arithmetic as xrl_gru_forward.  Same numbers as xrl_linear_fwd + xrl_gru_forward + xrl_linear_fwd up to fp32 summation
- * order. */
+ * order.  H == 0: feed-forward agents (no recurrent layer: pre = every hidden layer, post = the output layer; h unused). */
 #define XRL_QA_MAX_LAYERS 8
 typedef struct {
     int32_t w[XRL_QA_MAX_LAYERS], b[XRL_QA_MAX_LAYERS], ldw[XRL_QA_MAX_LAYERS];

@@ -226,14 +226,20 @@ def test_qmix_graph_update_phase_equals_eager_updates_on_the_same_indices(mode):
         lr, mem = agent.learner, agent.memory
         assert mem.size == 25 and int(mem.size_dev.item()) == 25
         infos = []
+
+        def perturb(it):                                      # between phases somebody else writes the parameters: the weight
+            if it == 1:                                       # images of the one-launch update must follow (model.version)
+                agent.model.load_state_dict({k: v * 1.01 for k, v in agent.model.state_dict().items()})
         if graph:
-            for _ in range(3):                                # first call eager + capture, then two graph launches
+            for it in range(3):                               # first call eager + capture, then two graph launches
+                perturb(it)
                 infos.append(lr.update_from_buffer(mem, 4, seed=7))
             assert lr._buf_graph is not None
         else:
             idx = torch.zeros(32, dtype=torch.int64, device="cuda")
             ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
-            for _ in range(3):
+            for it in range(3):
+                perturb(it)
                 for e in range(4):
                     ops.sample_replay_indices(idx, mem.n_envs, mem.n_size, mem.size_dev, 7, 0, ctr)
                     ops.counter_add(ctr, 1)
@@ -572,6 +578,28 @@ def test_captured_vector_step_equals_the_eager_episode_loop(lag, unroll):
     assert a["ptr_size"][1] >= 24 and a["step"][0] > 0
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_one_launch_acting_step_of_the_feed_forward_agents_vs_the_layered_path():
+    """xrl_marl_act_gru with H = 0 (no recurrent layer: Basic_MLP 64 + Q head 64-9 of the 3m shape) incl. the action selection
+    against three xrl_linear_fwd launches + xrl_marl_select_actions: Q values 1e-5, actions identical."""
+    from xuance_amd.nets import MixingQNet
+    torch.manual_seed(0)
+    net = MixingQNet(3, 30, 9, 48, (64,), (64,), 32, 32, "relu")
+    assert net.act_image() is not None and net.act_image().struct.H == 0
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for R in (192, 50):
+        X = torch.randn(R, 30, generator=g).cuda()
+        avail = (torch.rand(R, 9, generator=g) < 0.6).float()
+        avail[:, 0] = 1
+        acts = [torch.zeros(R, dtype=torch.int32, device="cuda") for _ in range(2)]
+        sel = lambda a: dict(avail=avail.cuda(), eps_dev=torch.tensor([0.3], device="cuda"), action=a, action_f=None, seed=9,
+                             step=R, step_dev=None)
+        q_a = net.act_step(X, R, None, fused=True, select=sel(acts[0])).clone()
+        q_b = net.act_step(X, R, None, fused=False, select=sel(acts[1])).clone()
+        assert_close(q_a.cpu().numpy()[:R, :9], q_b.cpu().numpy()[:R, :9], 1e-5, "q")     # (the plan's buffer may be larger)
+        assert np.array_equal(acts[0].cpu().numpy(), acts[1].cpu().numpy())
+        assert (avail.numpy()[np.arange(R), acts[0].cpu().numpy()] == 1).all()
 
 
 @pytest.mark.parametrize("R", [192, 7, 24])

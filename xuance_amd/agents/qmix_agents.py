@@ -110,9 +110,7 @@ class QMIX_Agents(AgentSurface):
         env, n, N, A, mem = self.envs, self.n_envs, self.n_agents, self.n_actions, self.memory
         R = n * N
         fused_act = bool(getattr(self.config, "use_fused_acting", True))
-        if fused_act and self.model.act_image() is not None and getattr(self.model, "_act_stale", True):
-            self.model.act_image().refresh()                    # (kept current by the optimiser launch's mirrors otherwise)
-            self.model._act_stale = False
+        self._refresh_act_image(fused_act)
         # an env that alternates its observation buffers and keeps running episode totals saves the copies and the
         # reductions of a step (envs/synthetic.py); any other env goes through clones and two small sums
         two_buf, totals = getattr(env, "double_buffered", False), getattr(env, "episode_totals", None)
@@ -151,6 +149,16 @@ class QMIX_Agents(AgentSurface):
                 episodes += int(self._counts_h[0])
                 self.current_step += int(self._counts_h[1])
             self._update_explore_factor()
+
+    def _refresh_act_image(self, fused_act=True):
+        """The acting launch's weight image follows the parameters through the optimiser launch's mirrors; rebuild it (two
+        launches) when anything else wrote them: the model's `version` moved (load_state_dict, copy_target), or a learner
+        path without mirrors / a checkpoint load raised `_act_stale`."""
+        m = self.model
+        if fused_act and m.act_image() is not None and \
+                (getattr(m, "_act_stale", True) or getattr(m, "version", 0) != getattr(m, "_act_version", -1)):
+            m.act_image().refresh()
+            m._act_stale, m._act_version = False, getattr(m, "version", 0)
 
     def _call_prologue(self, env, mem, counter=None):
         """What a run_episodes call starts with (:436-462): env reset, empty staging rows, zero recurrent state and reset flags."""
@@ -293,15 +301,20 @@ class QMIX_Agents(AgentSurface):
             self._started = True
         info = {}
         two_buf = getattr(env, "double_buffered", False)       # the acted-on tensors survive step_device(): no copies
+        fused_act = bool(getattr(self.config, "use_fused_acting", True))
+        self.model._act_stale = True                            # (whatever happened to the parameters since the last call)
         for _ in range(train_steps):
             if two_buf:
                 obs, state, avail = env.buf_obs, env.buf_state, env.buf_avail
             else:
                 obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
-            q = self.model.agent_plan.forward(obs.view(R, -1), self.obs_dim, R)      # shared network on [n*N, obs]
-            ops.marl_select_actions(q=q, avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
-                                    action=env.action, action_f=self.act_f, R=R, A=A, ld=A, seed=self.seed, step=self._host_step,
-                                    step_dev=None)            # eager loop: the host knows the step index
+            # shared network on [n*N, obs] + the epsilon-greedy selection: one launch (xrl_marl_act_gru with H = 0, its weight
+            # image kept current by the optimiser launch's mirrors), else three GEMM launches + xrl_marl_select_actions
+            self._refresh_act_image(fused_act)
+            self.model.act_step(obs.view(R, -1), R, None, fused=fused_act,
+                                select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev, action=env.action,
+                                            action_f=self.act_f, seed=self.seed, step=self._host_step,
+                                            step_dev=None))    # eager loop: the host knows the step index
             env.step_device()
             self._host_step += 1
             self.memory.store(obs=obs, actions=self.act_f, obs_next=env.next_obs, rewards=env.rewards,
@@ -334,8 +347,7 @@ class QMIX_Agents(AgentSurface):
         if avail is not None and self.use_actions_mask:
             av = torch.as_tensor(np.asarray(avail) if not isinstance(avail, torch.Tensor) else avail, device=dev).to(torch.float32).reshape(R, A).contiguous()
         if self.use_rnn:
-            if self.model.act_image() is not None:
-                self.model.act_image().refresh()
+            self._refresh_act_image()
             q = self.model.act_step(X, R, rnn["h"], rnn["reset"], rnn.get("c"))
         else:
             q = self.model.agent_plan.forward(X, self.obs_dim, R)

@@ -536,9 +536,11 @@ __host__ __device__ inline void qa_layers(const xrl_marl_act_gru_t& p, int* K, i
     // layer list in image order: pre[0..n_pre), ih, hh, post[0..n_post)
     int l = 0, feat = p.O;
     for (int i = 0; i < p.n_pre; ++i) { K[l] = feat; Nn[l] = p.pre[i]; feat = p.pre[i]; ++l; }
-    K[l] = feat; Nn[l] = 3 * p.H; ++l;
-    K[l] = p.H; Nn[l] = 3 * p.H; ++l;
-    feat = p.H;
+    if (p.H > 0) {                                       // H == 0: feed-forward agents, no recurrent layer
+        K[l] = feat; Nn[l] = 3 * p.H; ++l;
+        K[l] = p.H; Nn[l] = 3 * p.H; ++l;
+        feat = p.H;
+    }
     for (int i = 0; i < p.n_post; ++i) { K[l] = feat; Nn[l] = p.post[i]; feat = p.post[i]; ++l; }
     n_layers = l;
 }
@@ -589,7 +591,7 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
     {
         typedef const __attribute__((address_space(1))) qf_f4* G;
         const G src = (G)p->image;
-        const int n4 = L->image_floats >> 2, n_x = rows * O, n_h = rows * H, n_in = n_x + n_h + rows;
+        const int n4 = L->image_floats >> 2, n_x = rows * O, n_h = rows * H, n_in = n_x + n_h + (H > 0 ? rows : 0);
         qf_f4 wv[10];
         float iv[2];
         int idst[2];
@@ -629,26 +631,28 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
         __syncthreads();
         in = out; ldi = L->lda; feat = p->pre[i];
     }
-    // ---- gi = W_ih x + b_ih,  gh = W_hh h + b_hh  (side by side), then the cell (csrc/gru.hip's arithmetic)
-    qf_lin_fwd(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, 3 * H, in, ldi, rows, L->gi, L->ldg, XRL_ACT_NONE, 0);
-    qf_lin_fwd(L->img + L->w[l + 1], L->ldw[l + 1], L->img + L->b[l + 1], H, 3 * H, L->hin, L->ldh, rows, L->gh, L->ldg, XRL_ACT_NONE, 512);
-    l += 2;
-    __syncthreads();
-    for (int i = tid; i < rows * H; i += QF_THREADS) {
-        const int r = i / H, j = i - r * H;
-        const float* gi = lds + L->gi + r * L->ldg;
-        const float* gh = lds + L->gh + r * L->ldg;
-        const float h = lds[L->hin + r * L->ldh + j];
-        const float rg = qa_sigmoid(gi[j] + gh[j]);
-        const float z = qa_sigmoid(gi[H + j] + gh[H + j]);
-        const float n = qa_tanh(gi[2 * H + j] + rg * gh[2 * H + j]);
-        const float hn = (h - n) * z + n;
-        lds[L->hnew + r * L->ldh + j] = hn;
-        p->h[(size_t)(r0 + r) * H + j] = hn;                               // the state carried to the next step
+    if (H > 0) {
+        // ---- gi = W_ih x + b_ih,  gh = W_hh h + b_hh  (side by side), then the cell (csrc/gru.hip's arithmetic)
+        qf_lin_fwd(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, 3 * H, in, ldi, rows, L->gi, L->ldg, XRL_ACT_NONE, 0);
+        qf_lin_fwd(L->img + L->w[l + 1], L->ldw[l + 1], L->img + L->b[l + 1], H, 3 * H, L->hin, L->ldh, rows, L->gh, L->ldg, XRL_ACT_NONE, 512);
+        l += 2;
+        __syncthreads();
+        for (int i = tid; i < rows * H; i += QF_THREADS) {
+            const int r = i / H, j = i - r * H;
+            const float* gi = lds + L->gi + r * L->ldg;
+            const float* gh = lds + L->gh + r * L->ldg;
+            const float h = lds[L->hin + r * L->ldh + j];
+            const float rg = qa_sigmoid(gi[j] + gh[j]);
+            const float z = qa_sigmoid(gi[H + j] + gh[H + j]);
+            const float n = qa_tanh(gi[2 * H + j] + rg * gh[2 * H + j]);
+            const float hn = (h - n) * z + n;
+            lds[L->hnew + r * L->ldh + j] = hn;
+            p->h[(size_t)(r0 + r) * H + j] = hn;                               // the state carried to the next step
+        }
+        __syncthreads();
+        in = L->hnew; ldi = L->ldh; feat = H;
     }
-    __syncthreads();
     // ---- Q head
-    in = L->hnew; ldi = L->ldh; feat = H;
     for (int i = 0; i < p->n_post; ++i, ++l) {
         const bool last = i == p->n_post - 1;
         const int out = last ? L->q : ((i & 1) ? L->a1 : L->a0), ldo = last ? L->ldq : L->lda;
@@ -729,8 +733,8 @@ extern "C" int xrl_marl_act_gru_layout(const xrl_marl_act_gru_t* p, xrl_qa_image
 extern "C" int xrl_marl_act_gru(const xrl_marl_act_gru_t* pp, xrl_stream_t stream) {
     XRL_CHECK_ARG(pp != nullptr);
     const xrl_marl_act_gru_t& p = *pp;
-    XRL_CHECK_ARG(p.image && p.obs && p.h && p.q && p.R > 0 && p.rows_per_wg > 0 && p.H >= 1 && p.O >= 1);
-    XRL_CHECK_ARG(p.n_pre >= 0 && p.n_post >= 1 && p.n_pre + p.n_post + 2 <= XRL_QA_MAX_LAYERS);
+    XRL_CHECK_ARG(p.image && p.obs && p.q && p.R > 0 && p.rows_per_wg > 0 && p.H >= 0 && p.O >= 1 && (p.h || p.H == 0));
+    XRL_CHECK_ARG(p.n_pre >= 0 && p.n_post >= 1 && p.n_pre + p.n_post + 2 <= XRL_QA_MAX_LAYERS && (p.H > 0 || p.n_pre >= 1));
     XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p.image) & 15) == 0 && p.ldq >= p.post[p.n_post - 1]);
     XRL_CHECK_ARG(p.action == nullptr || (p.eps_dev != nullptr && p.rows_per_wg <= QF_THREADS));
     QaArgs args{};

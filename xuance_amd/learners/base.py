@@ -226,6 +226,7 @@ class Learner:
         if hasattr(self.model, "_act_state"):                                   # derived weight images follow on their next use
             self.model._act_stale = True
         self._images_current = False
+        self._images_stale = True
         if getattr(self, "_xc", None) is not None:                              # so do the exchange buffers' flags (all ranks load)
             self._xc.clear()
         if getattr(self, "opt_sync", None) is not None:                         # barrier flags of xrl_reduce_adam hold step

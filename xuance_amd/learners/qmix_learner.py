@@ -113,7 +113,9 @@ class QMIX_Learner(Learner):
             self.states[B:2 * B].copy_(torch.as_tensor(sample["state_next"], device=dev).reshape(B, -1))
         return B
 
-    _images_current = False      # True only inside a captured update phase (the phase's first launch sequence refreshes them)
+    _images_current = False      # True only inside an update phase (the images are known to be current there)
+    _images_stale = True         # something other than the optimiser launch's mirrors may have changed the parameters
+    _images_version = -1         # the model's `version` the images were last rebuilt at
 
     def fused_eligible(self):
         """The one-launch update (xrl_qmix_fused_update): QMIX mixer, feed-forward agents of at most 4 linear layers with one
@@ -205,6 +207,7 @@ class QMIX_Learner(Learner):
                             target_image=fs.img_target if fs else None)
             return
         self._images_current = False
+        self._images_stale = True
         if getattr(m, "_act_state", None) is not None:
             m._act_stale = True                             # (this path has no mirrors: the agents refresh before acting)
         ops.grad_reduce(self.slabs, S, P, P, opt.grad, self.sumsq)
@@ -303,6 +306,10 @@ class QMIX_Learner(Learner):
             return self._update_from_episodes(memory, n_epochs, seed, sync)
         B, m, dev = memory.batch_size, self.model, self.model.params.device
         key = (id(memory), n_epochs, B)
+        ver = getattr(m, "version", 0)
+        if self.fused_eligible() and (self._images_stale or ver != self._images_version):   # (eager, outside the captured
+            self._fused.refresh()                           # phase: load_state_dict / copy_target bump the model's version,
+            self._images_stale, self._images_version = False, ver   # load_model and the unfused optimiser path set the flag)
         if getattr(self, "_buf_graph_key", None) != key:
             self._ensure(B)
             R, N = B * m.n_agents, m.n_agents
@@ -319,9 +326,9 @@ class QMIX_Learner(Learner):
 
             def enqueue():
                 # per update: draw, gather, step; the draw counter and the loss sums are settled once per phase
-                if self.fused_eligible():                   # weight images of the one-launch update: rebuilt once per phase
-                    self._fused.refresh()                   # (acting, checkpoints, target copies happen between phases),
-                    self._images_current = True             # kept current inside it by the optimiser launch's mirrors
+                if self.fused_eligible():                   # weight images of the one-launch update: kept current by the
+                    self._images_current = True             # optimiser launch's mirrors (update_from_buffer refreshed them
+                                                            # before this phase if anything else touched the parameters)
                 in_kernel = self.fused_eligible() and self._fused.n_groups(B) <= self.slabs.shape[0] and \
                     getattr(self.config, "fused_qmix_gather_in_kernel", True)
                 for e in range(n_epochs):

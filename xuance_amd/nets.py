@@ -691,7 +691,8 @@ class MixingQNet:
         epsilon-greedy selection on these Q values, in the same launch on the one-launch path."""
         st = self.act_image() if fused and not self.lstm else None
         if st is None:
-            q = self.agent_forward_seq(X, R, 1, which=2, h0=h, reset=reset, h_last=h, c0=c, c_last=c)
+            q = self.agent_forward_seq(X, R, 1, which=2, h0=h, reset=reset, h_last=h, c0=c, c_last=c) if self.use_rnn else \
+                self.agent_plan.forward(X, self.obs_dim, R)
             if select is not None:
                 ops.marl_select_actions(q=q, R=R, A=self.n_actions, ld=self.n_actions, **select)
             return q
@@ -708,7 +709,7 @@ class MixingQNet:
         """The acting launch's weight image (ops.MarlActGruState), or None when that launch cannot run this network."""
         if not hasattr(self, "_act_state"):
             self._act_state, self._act_q = None, {}
-            if self.use_rnn and not self.lstm:
+            if not self.lstm:
                 try:
                     st = ops.MarlActGruState(self)
                     if st.lds_bytes <= 160 * 1024:
@@ -770,9 +771,16 @@ class MixingQNet:
             tk = self._target_key(k)
             dst = self.params.view(tk, self.target_flat) if tk else self.params.view(k)
             dst.copy_(torch.as_tensor(sd[k], dtype=torch.float32))
+        self.touched()
 
     def copy_target(self):                                        # value_factorization.py:169-174
         self.target_flat.copy_(self.params.flat)
+        self.touched()
+
+    def touched(self):
+        """Somebody other than the optimiser launch wrote the parameters: the derived weight images (the one-launch
+        update's, the acting launch's) are rebuilt on their next use (their owners compare `version`)."""
+        self.version = getattr(self, "version", 0) + 1
 
 
 class ConvStack:

@@ -537,23 +537,33 @@ class QmixFusedState:
 
 
 class MarlActGruState:
-    """xrl_marl_act_gru_t of a recurrent MixingQNet (GRU agents) + the weight image its launch stages in LDS.  The image
-    only changes when the eval parameters do: `refresh()` rebuilds it (one launch) -- the agents call it when a
-    run_episodes call / an evaluation starts, updates happen between those."""
+    """xrl_marl_act_gru_t of a MixingQNet's agent network (GRU agents: mlp blocks -> GRU cell -> Q head; feed-forward
+    agents: H = 0, every hidden layer a `pre` layer) + the weight image its launch stages in LDS.  The image follows the eval
+    parameters through xrl_reduce_adam's mirror maps (`map`: parameter index -> image index); `refresh()` rebuilds it (two
+    launches) after anything else changed them."""
 
     def __init__(self, model, rows_per_wg=6):
         from ._lib import MarlActGru, QaImage
         import numpy as np
         P = model.params
-        pre = [st[0] for st in model.pre_plans[2].stages]          # mlp blocks ..., then the input side of the GRU
-        post = [st[0] for st in model.post_plans[2].stages]
-        assert not model.lstm and all(len(st) == 1 for st in model.pre_plans[2].stages + model.post_plans[2].stages)
-        fc, ih = pre[:-1], pre[-1]
-        assert len(fc) <= 3 and 1 <= len(post) <= 3 and ih.N == 3 * model.RH
-        acts = {L.act for L in fc} | {L.act for L in post[:-1]}
-        assert len(acts) <= 1 and post[-1].act is None and ih.act is None
         q = MarlActGru()
-        q.O, q.H, q.n_pre, q.n_post = model.obs_dim, model.RH, len(fc), len(post)
+        if model.use_rnn:
+            pre = [st[0] for st in model.pre_plans[2].stages]      # mlp blocks ..., then the input side of the GRU
+            post = [st[0] for st in model.post_plans[2].stages]
+            assert not model.lstm and all(len(st) == 1 for st in model.pre_plans[2].stages + model.post_plans[2].stages)
+            fc, ih = pre[:-1], pre[-1]
+            assert len(fc) <= 3 and 1 <= len(post) <= 3 and ih.N == 3 * model.RH
+            q.H = model.RH
+            rec = [(ih.w_name, ih.b_name, ih.N, ih.K), (model.w_hh, model.b_hh, 3 * model.RH, model.RH)]
+            assert ih.act is None
+        else:
+            layers = [st[0] for st in model.agent_plan.stages]
+            assert all(len(st) == 1 for st in model.agent_plan.stages) and 2 <= len(layers) <= 4
+            fc, post, rec = layers[:-1], layers[-1:], []
+            q.H = 0
+        acts = {L.act for L in fc} | {L.act for L in post[:-1]}
+        assert len(acts) <= 1 and post[-1].act is None
+        q.O, q.n_pre, q.n_post = model.obs_dim, len(fc), len(post)
         q.act = ACT[acts.pop()] if acts else ACT[None]
         for i, L in enumerate(fc):
             q.pre[i] = L.N
@@ -563,9 +573,7 @@ class MarlActGruState:
         im = QaImage()
         call("xrl_marl_act_gru_layout", C.byref(q), C.byref(im))
         self.lds_bytes = int(im.lds_bytes)
-        mats = [(L.w_name, L.b_name, L.N, L.K) for L in fc] + [(ih.w_name, ih.b_name, ih.N, ih.K),
-                                                                (model.w_hh, model.b_hh, 3 * model.RH, model.RH)] + \
-               [(L.w_name, L.b_name, L.N, L.K) for L in post]
+        mats = [(L.w_name, L.b_name, L.N, L.K) for L in fc] + rec + [(L.w_name, L.b_name, L.N, L.K) for L in post]
         src, dst = [], []
         for l, (wn, bn, N, K) in enumerate(mats):
             r, k = np.divmod(np.arange(N * K), K)
@@ -592,7 +600,8 @@ class MarlActGruState:
         """select: None, or the keyword arguments of marl_select_actions (action, action_f, avail, eps_dev, seed, step,
         step_dev) -- the selection then happens in the same launch."""
         s = self.struct
-        s.R, s.obs, s.h, s.q, s.ldq = int(R), ptr(obs), ptr(h), ptr(q_out), int(q_out.shape[1])
+        s.R, s.obs, s.q, s.ldq = int(R), ptr(obs), ptr(q_out), int(q_out.shape[1])
+        s.h = ptr(h) if h is not None else None
         s.reset = ptr(reset) if reset is not None else None
         if select is None:
             s.action = None
