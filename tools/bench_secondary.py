@@ -11,6 +11,22 @@ import torch
 PEAK_FP32_MFMA_TFLOPS = 157.3
 
 
+def _pmc_bytes(which, kernel):
+    """HBM bytes per launch of `kernel` from the latest committed PMC summary of the QMIX loops (profiles/r*_qmix_<which>_pmc.json,
+    tools/collect_pmc_qmix.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md) -- copied from that builder-run pass, not measured
+    in this run; (None, None) if the file is not there."""
+    import glob, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r*_qmix_%s_pmc.json" % which)))
+    try:
+        for name, v in json.load(open(paths[-1]))["kernels"].items():
+            if name.startswith(kernel):
+                return int(v["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(paths[-1]) + " (committed rocprofv3 --pmc pass, not measured in this run)"
+    except Exception:
+        pass
+    return None, None
+
+
 def _events_us(fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -95,6 +111,7 @@ def qmix_3m(rnn, n=64, steps=None, ref=None):
         flops = B * N * _FF_AGENT_FWD * 5 + B * _MIXER_FWD * 4                    # eval f+b (3x), eval(next), target; mixer as above
         what = "feed-forward agents (Basic_MLP 64 + Q 64-9, batch 32 transitions)"
     tf = flops / upd_us / 1e6
+    traffic, traffic_source = _pmc_bytes("gru" if rnn else "ff", "xrl::gru_forward_kernel" if rnn else "xrl::qmix_fused_kernel")
     out = {"workload": "QMIX SMAC-3m shape, %d envs x 3 agents, obs 30 / state 48 / 9 masked actions, %s, 8 updates per %s"
                        % (n, what, "%d episodes" % n if rnn else "vector step"),
            "value": round(env_steps / dt, 1), "unit": "env-steps/s", "update_us": round(upd_us, 2),
@@ -103,7 +120,9 @@ def qmix_3m(rnn, n=64, steps=None, ref=None):
                                                     "xrl::reduce_adam_kernel)") if rnn else
                                                    "update graph (draw+gather, xrl::qmix_fused_kernel, xrl::reduce_adam_kernel)",
                         "achieved": round(tf, 4), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 5),
-                        "traffic": None, "avg_launch_us": round(upd_us, 2), "algorithmic_flops_per_launch": flops,
+                        "traffic": traffic, "traffic_source": traffic_source,
+                        "traffic_kernel": "xrl::gru_forward_kernel" if rnn else "xrl::qmix_fused_kernel",
+                        "avg_launch_us": round(upd_us, 2), "algorithmic_flops_per_launch": flops,
                         "note": ("one 'launch' = one whole update (a graph of ~9 kernels); launch-latency-bound at batch 32, see DESIGN.md section 3")
                                 if rnn else "one 'launch' = one whole update = 3 kernels; the fused kernel is VALU fp32 on 32 workgroups (one "
                                             "transition each), latency-bound: DESIGN.md section 3"}}
