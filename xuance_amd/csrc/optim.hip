@@ -362,7 +362,8 @@ extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t
     const int n_vb = (int)((P / 4 + 63) / 64);
     XRL_CHECK_ARG(n_vb <= n_part && n_part <= 1024);
     const int nb = (n_vb + RA_GROUPS - 1) / RA_GROUPS;
-    XRL_CHECK_ARG(nb <= 2 * device_cu_count());                 // every block resident (the barrier spins)
+    XRL_CHECK_ARG(nb <= 4 * device_cu_count());                 // every block resident (the barrier spins): 256 threads and
+                                                                // 13 KB of LDS per block, at least four fit a CU
     xrl_mirrors_t mir{};
     if (mirrors) mir = *mirrors;
     XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);

@@ -229,8 +229,9 @@ class Learner:
         self._images_stale = True
         if getattr(self, "_xc", None) is not None:                              # so do the exchange buffers' flags (all ranks load)
             self._xc.clear()
-        if getattr(self, "opt_sync", None) is not None:                         # barrier flags of xrl_reduce_adam hold step
-            self.opt_sync.zero_()                                               # values: a rewound step must not match them
+        for name in ("opt_sync", "_lsync"):                                     # barrier flags of xrl_reduce_adam hold step
+            if getattr(self, name, None) is not None:                           # values: a rewound step must not match them
+                getattr(self, name).zero_()
         return os.path.dirname(path)
 
     def _safe_scheduler_step(self):

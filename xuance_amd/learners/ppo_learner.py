@@ -41,6 +41,7 @@ class PPO_Learner(Learner):
         return update_times * self.config.n_epochs * self.config.n_minibatch
 
     def _ensure(self, M):
+        self._layered_fused_optimizer()
         if M <= self._cap:
             return
         dev, P = self.model.params.device, self.model.params.P
@@ -82,12 +83,32 @@ class PPO_Learner(Learner):
         if self.loss_mode == 3:                                         # the coefficient schedule, after the loss used it
             ops.ppokl_adapt(self.partials, S, M * (A if model.dist == "gaussian" else 1), self.kl_coef_dev, self.target_kl, self.kl_dev)
         model.backward(obs, M, self.slabs, S, ldx)
+        if finish and self._layered_fused_optimizer():
+            # slab reduction + norm + clip + Adam (+ the fused kernels' derived layouts when they exist) in ONE launch
+            ops.reduce_adam(self.slabs, S, model.params.P, model.params.flat, opt.grad, opt.m, opt.v, model.params.P, opt.state,
+                            self._lsumsq, self.grad_clip_norm if self.use_grad_clip else 0.0,
+                            self._mirrors if getattr(self, "_mirror", False) else [], self._lsync)
+            return S
         ops.grad_reduce(self.slabs, S, model.params.P, model.params.P, opt.grad, self.sumsq)
         if finish:
             if self.distributed_training and self.world_size > 1:
                 self.allreduce_grad()
             self.finish_step()
         return S
+
+    def _layered_fused_optimizer(self):
+        """May the layered path end in xrl_reduce_adam?  One rank, P % 4 == 0, at most 1 024 blocks of 256 parameters (all
+        resident: the launch's barrier spins), not switched off.  Allocates the launch's scratch on first use (outside any
+        graph capture: prepare_buffer_update / update() call it before they enqueue)."""
+        if not hasattr(self, "_lfo"):
+            P = self.model.params.P
+            self._lfo = not (self.distributed_training and self.world_size > 1) and P % 4 == 0 and (P + 255) // 256 <= 1024 \
+                and bool(getattr(self.config, "use_fused_optimizer", True))
+            if self._lfo:
+                dev = self.model.params.device
+                self._lsumsq = torch.zeros(1024, dtype=torch.float64, device=dev)
+                self._lsync = torch.zeros(4 + (P + 255) // 256 + 8, dtype=torch.int32, device=dev)
+        return self._lfo
 
     def allreduce_grad(self):
         """DDP-equivalent gradient averaging as ONE flat RCCL all-reduce, then the norm of the averaged gradient."""
@@ -128,8 +149,11 @@ class PPO_Learner(Learner):
 
     def _info(self, M, S, partials=None):
         ops.sum_partials(self.partials if partials is None else partials, S, 8, self.sums)
-        if getattr(self, "opt_sync", None) is not None:             # xrl_reduce_adam: sync[2] != 0 = barrier time-out
-            self._readback[10:12].view(torch.int32).copy_(self.opt_sync[:4])
+        sync = getattr(self, "opt_sync", None)
+        if sync is None and getattr(self, "_lfo", False):
+            sync = self._lsync
+        if sync is not None:                                        # xrl_reduce_adam: sync[2] != 0 = barrier time-out
+            self._readback[10:12].view(torch.int32).copy_(sync[:4])
         rb = self._readback.cpu().numpy()                           # the one host sync of an update
         s = rb[:8]
         self.last_status = rb[8:10].view(np.int32).tolist()
