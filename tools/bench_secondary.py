@@ -129,3 +129,82 @@ def qmix_3m(rnn, n=64, steps=None, ref=None):
     if ref:
         out["cpu_baseline"] = ref
     return out
+
+
+def ppo_c4(steps=3, warmup=2, ref=None):
+    """BASELINE configs[3] shapes on one GPU: PPO, Gaussian policy 17-256-256-6 + critic 17-256-256-1 (configs/ppo/mujoco.yaml),
+    128 envs x horizon 256, 16 epochs x 8 minibatches of 4 096, MuJoCo-shaped synthetic provider on the device; the layered
+    path (grouped fp32-MFMA GEMM launches; update phase one hipGraph).  Roofline of the update: algorithmic flops of one
+    minibatch (849 408 flop per sample) / its time."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import SyntheticMujocoVecEnv
+    n, T = 128, 256
+    cfg = Namespace(agent="PPO", representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
+                    critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", seed=1, parallels=n,
+                    running_steps=10 ** 9, horizon_size=T, n_epochs=16, n_minibatch=8, learning_rate=4e-4, vf_coef=0.25,
+                    ent_coef=0.0, clip_range=0.2, gamma=0.99, use_gae=True, gae_lambda=0.95, use_advnorm=True, use_grad_clip=True,
+                    grad_clip_norm=0.5, use_obsnorm=True, use_rewnorm=True, obsnorm_range=5, rewnorm_range=5,
+                    distributed_training=False, device="cuda", model_dir="/tmp/xrl_bench_models", use_hip_graph=True)
+    torch.manual_seed(0)
+    agent = PPO_Agent(cfg, SyntheticMujocoVecEnv(n, seed=4))
+    for _ in range(warmup):
+        agent.rollout(); agent.update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.rollout()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(steps):
+        agent.update()
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    us_mb = (t2 - t1) / steps / 128 * 1e6
+    flops = 849408.0 * 4096
+    tf = flops / us_mb / 1e6
+    out = {"workload": "PPO, HalfCheetah shapes (obs 17, Box(6), Gaussian 17-256-256-6 + critic 17-256-256-1), %d envs x horizon %d, "
+                       "16 epochs x 8 minibatches of 4096 (BASELINE configs[3], per GPU)" % (n, T),
+           "value": round(n * T * steps / (t2 - t0), 1), "unit": "env-steps/s", "ms_per_step": round((t2 - t0) / steps * 1e3, 3),
+           "rollout_ms": round((t1 - t0) / steps * 1e3, 3), "update_ms": round((t2 - t1) / steps * 1e3, 3),
+           "roofline": {"bound": "mfma", "kernel": "minibatch update (xrl::gemm_f32_kernel launches + xrl::ppo_loss_kernel + xrl::reduce_adam_kernel)",
+                        "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "traffic": None, "avg_launch_us": round(us_mb, 1), "algorithmic_flops_per_launch": flops,
+                        "note": "one 'launch' = one whole minibatch update (8 kernels, layered path); DESIGN.md section 8 item 1"}}
+    if ref:
+        out["cpu_baseline"] = ref
+    return out
+
+
+def dqn_c3(steps=60, ref=None):
+    """BASELINE configs[2] shapes: DQN, 64 envs x 84x84x4 uint8 frames (synthetic frame provider on the device), CNN
+    32/64/64 + 512, uint8 replay ring, batch 32, one update per vector step.  Roofline of the update graph: 2.7 GFLOP
+    (3x eval + 1x target forward-equivalents of the 21.2 MFLOP network at batch 32) / its time."""
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    n = 64
+    cfg = Namespace(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                    q_hidden_size=[512], activation="relu", seed=1, parallels=n, running_steps=10 ** 7,
+                    buffer_size=n * 512, batch_size=32, learning_rate=1e-4, gamma=0.99, start_greedy=0.5, end_greedy=0.05,
+                    decay_step_greedy=10 ** 6, sync_frequency=500, training_frequency=n, start_training=n * 8,
+                    use_grad_clip=False, grad_clip_norm=0.5, use_obsnorm=False, use_rewnorm=False,
+                    distributed_training=False, device="cuda", model_dir="/tmp/xrl_bench_models")
+    torch.manual_seed(0)
+    agent = DQN_Agent(cfg, SyntheticAtariVecEnv(n, seed=2))
+    agent.train(16)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    agent.train(steps)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    lr = agent.learner
+    lr.update_from_buffer(agent.memory, 1, seed=1)
+    graph_us = _events_us(lr._buf_graph.launch, 20)
+    flops = 4 * 21.2e6 * 32
+    tf = flops / graph_us / 1e6
+    out = {"workload": "DQN, Atari shapes (84x84x4 uint8 frames, CNN 32/64/64 + 512, 4 actions), %d envs, uint8 replay ring, batch 32, "
+                       "one update per vector step (BASELINE configs[2])" % n,
+           "value": round(n * steps / dt, 1), "unit": "env-steps/s", "vector_step_us": round(dt / steps * 1e6, 1),
+           "update_us": round(graph_us, 1),
+           "roofline": {"bound": "mfma", "kernel": "update graph (im2col + xrl::gemm_f32_kernel launches, eval + target networks, backward, xrl::reduce_adam_kernel)",
+                        "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "traffic": None, "avg_launch_us": round(graph_us, 1), "algorithmic_flops_per_launch": flops,
+                        "note": "one 'launch' = one whole update (a graph); launch- and im2col-bound at batch 32, DESIGN.md section 8 item 6"}}
+    if ref:
+        out["cpu_baseline"] = ref
+    return out
