@@ -67,7 +67,7 @@ def _collect(q, procs, n=2, limit=200):
     return sorted(out, key=lambda t: t[0])
 
 
-def _run_two_ranks(exchange, target=None, extra=()):
+def _run_two_ranks(exchange, target=None, extra=(), world=2):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -75,7 +75,7 @@ def _run_two_ranks(exchange, target=None, extra=()):
     old = os.environ.get("XRL_DIST_EXCHANGE")
     os.environ["XRL_DIST_EXCHANGE"] = "1" if exchange else "0"       # (spawned children inherit the environment)
     try:
-        procs = [ctx.Process(target=target or _worker, args=(r, 2, port, q) + tuple(extra)) for r in range(2)]
+        procs = [ctx.Process(target=target or _worker, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
         for p in procs:
             p.start()
     finally:
@@ -83,11 +83,22 @@ def _run_two_ranks(exchange, target=None, extra=()):
             os.environ.pop("XRL_DIST_EXCHANGE")
         else:
             os.environ["XRL_DIST_EXCHANGE"] = old
-    res = _collect(q, procs)
+    res = _collect(q, procs, n=world)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     return res
+
+
+def test_four_ranks_average_in_rank_order_and_stay_bit_identical():
+    """Four ranks on the one GPU, gradients averaged inside the optimiser launch: with more than two summands the fp32 sum
+    depends on its order, so every rank must add the four gradients in RANK order (xrl_reduce_adam_exchange) -- replicas
+    bit-identical after four chained optimiser steps, on four different env shards."""
+    res = sorted(_run_two_ranks(True, world=4), key=lambda r: r[0])
+    assert [r[0] for r in res] == [0, 1, 2, 3] and all(r[5] for r in res)          # the exchange is what ran
+    for r in res[1:]:
+        assert np.array_equal(r[2], res[0][2]) and r[3] == res[0][3] == 4
+    assert len({r[4]["actor_loss/rank_%d" % r[0]] for r in res}) == 4                # four different shards
 
 
 def test_two_ranks_share_gradients_and_stay_in_sync():
