@@ -233,7 +233,10 @@ int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_
 /* xrl_grad_reduce + xrl_adam_step_mirrors in ONE launch (same numbers): the blocks meet at a counter barrier between
  * the slab reduction and the Adam update (all of them are resident), the reduced gradient never leaves the chip in
  * between.  Needs P % 4 == 0, 16-byte aligned slabs, n_part >= ceil(P/256); sync: [4 + ceil(P/256)] uint32 scratch, zero-initialised
- * once (sync[2] != 0 afterwards reports a barrier time-out; the update of that call is then invalid). */
+ * once (sync[2] != 0 afterwards reports a barrier time-out; the update of that call is then invalid).
+ * max_norm <= 0 (use_grad_clip: False -- the QMIX and DQN configs): nothing depends on the total norm, so the blocks do
+ * NOT meet: each goes from its slab sums straight to its Adam quads, and the last block out adds up sumsq_part for
+ * state->last_grad_norm and advances *state. */
 int xrl_reduce_adam(const float* slabs, int n_split, int64_t slab_stride, float* params, float* grad, float* m, float* v,
                     int64_t P, xrl_adam_state_t* state, double* sumsq_part, int n_part, double max_norm,
                     const xrl_mirrors_t* mirrors, uint32_t* sync, xrl_stream_t stream);

@@ -74,6 +74,7 @@ def _run_two_ranks(exchange, target=None, extra=(), world=2):
     port = free_port()
     old = os.environ.get("XRL_DIST_EXCHANGE")
     os.environ["XRL_DIST_EXCHANGE"] = "1" if exchange else "0"       # (spawned children inherit the environment)
+    os.environ["XRL_DIST_SELFTEST_SPINS"] = "4000000"               # the ranks time-share ONE GPU here
     try:
         procs = [ctx.Process(target=target or _worker, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
         for p in procs:

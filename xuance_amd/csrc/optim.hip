@@ -286,15 +286,18 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     // ---- barrier without read-modify-write atomics: every block publishes its partial sum, then (after the store has been
     //      acknowledged) its flag = the optimiser step this launch performs -- a value no earlier launch has written -- and
     //      polls all flags with one coalesced device-scope load per round.  sync[4 + b] is block b's flag.
+    //      Without clipping (max_norm <= 0: configs/qmix/sc2/3m.yaml:45, configs/dqn/atari.yaml:39) nothing below depends on
+    //      the other blocks: no barrier at all; the last block out still reports the norm from the published partial sums.
+    const bool need_norm = max_norm > 0.0;
     if (tg == 0 && vb < n_vb) __hip_atomic_store(&sumsq_part[vb], tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         s_fail = 0;
-        __hip_atomic_store(&sync[4 + blockIdx.x], (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need_norm) __hip_atomic_store(&sync[4 + blockIdx.x], (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    {
+    if (need_norm) {
         int spins = 0;
         for (;;) {
             int ok = 1;
@@ -308,9 +311,10 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     __syncthreads();
     // ---- phase 2: exactly adam_step_kernel for parameter i (every group forms the norm like a 256-thread block would)
     double ssum = 0.0;
-    for (int j = tg; j < n_part; j += RED_THREADS)
-        ssum += j < n_vb ? __hip_atomic_load(&sumsq_part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    const double total_norm = (s_fail || (XC && s_xfail)) ? __builtin_nan("") : sqrt(group_sum(ssum, gscratch[grp], tg));
+    if (need_norm)
+        for (int j = tg; j < n_part; j += RED_THREADS)
+            ssum += j < n_vb ? __hip_atomic_load(&sumsq_part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    double total_norm = (s_fail || (XC && s_xfail)) ? __builtin_nan("") : (need_norm ? sqrt(group_sum(ssum, gscratch[grp], tg)) : 0.0);
     float coef = 1.f;
     if (max_norm > 0.0) {
         const double c = max_norm / (total_norm + 1e-6);
@@ -337,7 +341,17 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned left = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == gridDim.x - 1) {                            // last block out: reset the counter, advance the state
+        s_fail = (left == gridDim.x - 1) ? 2 : 0;                // (re-used as "this is the last block out")
+    }
+    __syncthreads();
+    if (s_fail == 2) {                                          // last block out: reset the counter, advance the state
+        if (!need_norm) {                                       // every block published its partial before its ticket
+            double t = 0.0;
+            for (int j = threadIdx.x; j < n_vb; j += blockDim.x)
+                t += __hip_atomic_load(&sumsq_part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total_norm = sqrt(block_sum(t, scratch));
+        }
+        if (threadIdx.x == 0) {
             __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             st->last_grad_norm = total_norm;
             st->step = step;
