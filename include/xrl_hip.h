@@ -586,6 +586,40 @@ int xrl_gather_rows(const float* packed, const int64_t* idx, float* out, int64_t
  * (the slot rotation spreads the simultaneous fetches of a workgroup's waves over all L2 channels)
  * Only params/layers of *p are read; frag_floats >= 2*N*K. */
 int xrl_pack_mid_frags(const xrl_ppo_fused_t* p, float* frag, int64_t frag_floats, xrl_stream_t stream);
+/* ------------------------------------------------------------------ fused PPO minibatch, two-branch Gaussian actor-critic
+ * D-256-256-{A | 1} (configs/ppo/mujoco.yaml:8-13: Basic_Identical representation, actor / critic hidden [256, 256];
+ * policies/gaussian.py ActorCriticPolicy, ppo_learner.py:46-62).  ONE launch per minibatch, two workgroups (actor branch,
+ * critic branch) per 32-row tile; rows are read from staged arrays (the caller gathered the minibatch, e.g. every minibatch of
+ * an update phase with one xrl_soa_gather).  Gradients go to slab row `tile` in the layout of params (both roles write
+ * disjoint ranges); reduce with xrl_reduce_adam(n_split = ceil(M/32)).  partials: [2*ceil(M/32)][8], row 2*tile + role. */
+typedef struct {
+    int32_t w0, b0, w1, b1, w2, b2;                    /* float offsets of the branch's three layers in params / a slab row */
+} xrl_wide_branch_t;
+typedef struct {
+    const float* params;
+    const float* frag;                                 /* xrl_ppo_wide_pack image: [2][256*256] middle layers in B-fragment order */
+    xrl_wide_branch_t br[2];                           /* 0: actor (D-256-256-A), 1: critic (D-256-256-1) */
+    int32_t log_std_off;
+    int32_t D, A, H;                                   /* D <= 24, A <= 8, H == 256 */
+    int32_t act, out_act;                              /* hidden activation (relu | leaky_relu | tanh), activation_action (none | tanh) */
+    int32_t M, dbg_role;
+    const float* obs;                                  /* [M][D], 16-byte aligned */
+    const float* actions;                              /* [M][A], 16-byte aligned */
+    const float* ret; const float* adv; const float* old_logp;   /* [M] */
+    const float* stats;                                /* NULL or (mean, std) of this minibatch's advantages */
+    float* slabs; int64_t slab_stride;
+    double* partials;
+    float* diag;                                       /* NULL or [4][M]: log_prob, ratio, surrogate1, surrogate2 */
+    float* heads;                                      /* NULL or [M][A + 1]: actor output (after activation_action) | value --
+                                                        * the callback tensors a_dist / v_pred of ppo_learner.py:82-88 */
+    float clip_range, vf_coef, ent_coef, pad0;
+    long long* dbg;                                    /* NULL, or [16] shader-clock stamps of the last tile's role dbg_role */
+} xrl_ppo_wide_t;
+int xrl_ppo_wide_minibatch(const xrl_ppo_wide_t* p, xrl_stream_t stream);
+/* frag[b][t][(q + t) mod 32][l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s] (b: branch, t: 32-row tile, q: 8-wide k-chunk,
+ * l: lane): every prefetch instruction of a wave reads one contiguous 1 KB run.  Only params / br of *p are read;
+ * frag holds 2*256*256 floats.  Kept current afterwards by the optimiser launch (xrl_mirrors_t map built from this layout). */
+int xrl_ppo_wide_pack(const xrl_ppo_wide_t* p, float* frag, xrl_stream_t stream);
 /* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */
 int xrl_transpose_mid(const xrl_ppo_fused_t* p, float* params_t, xrl_stream_t stream);
 

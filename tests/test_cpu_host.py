@@ -32,7 +32,8 @@ def test_ctypes_structs_match_c_layout():
     pairs = {"xrl_field_t": _lib.Field, "xrl_gemm_t": _lib.Gemm, "xrl_ppo_loss_t": _lib.PpoLoss,
              "xrl_adam_state_t": _lib.AdamState, "xrl_rms_t": _lib.Rms, "xrl_sample_t": _lib.Sample,
              "xrl_cartpole_t": _lib.CartPole, "xrl_poststep_t": _lib.PostStep, "xrl_egreedy_t": _lib.EGreedy,
-             "xrl_mirrors_t": _lib.Mirrors, "xrl_exchange_t": _lib.Exchange, "xrl_marl_gate_t": _lib.MarlGate}
+             "xrl_mirrors_t": _lib.Mirrors, "xrl_exchange_t": _lib.Exchange, "xrl_marl_gate_t": _lib.MarlGate,
+             "xrl_ppo_wide_t": _lib.PpoWide}
     for extra in ("xrl_dqn_td_t", "xrl_qmix_t"):
         cls = getattr(_lib, {"xrl_dqn_td_t": "DqnTd", "xrl_qmix_t": "Qmix"}[extra], None)
         if cls is not None:
@@ -41,6 +42,7 @@ def test_ctypes_structs_match_c_layout():
     for cname in pairs:
         src += f'printf("{cname} %zu\\n", sizeof({cname}));\n'
     src += 'printf("adam.base_lr %zu\\n", offsetof(xrl_adam_state_t, base_lr));\n'
+    src += 'printf("wide.obs %zu\\n", offsetof(xrl_ppo_wide_t, obs));\nprintf("wide.dbg %zu\\n", offsetof(xrl_ppo_wide_t, dbg));\n'
     src += 'printf("loss.M %zu\\n", offsetof(xrl_ppo_loss_t, M));\nreturn 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c, exe = os.path.join(d, "sz.c"), os.path.join(d, "sz")
@@ -51,6 +53,7 @@ def test_ctypes_structs_match_c_layout():
         assert int(out[cname]) == ctypes.sizeof(cls), cname
     assert int(out["adam.base_lr"]) == _lib.AdamState.base_lr.offset
     assert int(out["loss.M"]) == _lib.PpoLoss.M.offset
+    assert int(out["wide.obs"]) == _lib.PpoWide.obs.offset and int(out["wide.dbg"]) == _lib.PpoWide.dbg.offset
 
 
 @pytest.mark.parametrize("dist,args", [("categorical", (4, 2, "categorical", (128,), (128,), (128,), "leaky_relu")),

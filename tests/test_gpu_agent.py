@@ -452,19 +452,22 @@ def test_adam_mirrors_keep_every_derived_layout_current():
     assert torch.equal(lr.params_t[lo:hi], pt[lo:hi]) and torch.equal(lr.cache_image, img) and torch.equal(lr.frag[:lr.frag.numel() // 2], fr[:fr.numel() // 2])
 
 
-def test_ppo_gaussian_agent_on_mujoco_shape(oracle):
-    """C4 shapes (obs 17, Box(6), Gaussian actor 17-256-256-6 tanh, critic 17-256-256-1, Basic_Identical): the layered
-    rollout + update path end to end, checked against the oracle on the device's own rollout data."""
+@pytest.mark.parametrize("wide,use_graph", [(True, False), (True, True), (False, False)])
+def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph):
+    """C4 shapes (obs 17, Box(6), Gaussian actor 17-256-256-6 tanh, critic 17-256-256-1, Basic_Identical): rollout + update
+    end to end, checked against the oracle on the device's own rollout data.  wide: the update runs as ONE launch per
+    minibatch (xrl_ppo_wide_minibatch: csrc/ppo_wide.hip) from rows gathered once per phase; otherwise the layered path."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import SyntheticMujocoVecEnv
     torch.manual_seed(0)
     n, T = 32, 16
     cfg = make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
                       critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1,
-                      n_minibatch=2, ent_coef=0.0, gamma=0.99, use_hip_graph=False)
+                      n_minibatch=2, ent_coef=0.0, gamma=0.99, use_hip_graph=use_graph, use_fused_update=wide)
     env = SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=10)
     agent = PPO_Agent(cfg, env)
     assert agent.model.dist == "gaussian" and not agent.use_fused_rollout
+    assert agent.learner.wide_eligible() == wide and agent.learner.fused_eligible(agent.memory) == wide
     assert sum(int(np.prod(v.shape)) for v in agent.model.state_dict().values()) == 142605    # SURVEY 8a parameter count
     sd = {k: npy(v) for k, v in agent.model.state_dict().items()}
     agent.rollout()
@@ -497,6 +500,13 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle):
     for k_, val in sd.items():
         assert_close(npy(got[k_]), val, 1e-5, f"param {k_}")
     assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss")
+    assert_close(info["actor_loss"], oi["a_loss"], 1e-5, "actor_loss")
+    if wide:                            # the optimiser launch kept the fragment-ordered copy of the middle layers current
+        lr = agent.learner
+        fr = lr._wide.frag.clone()
+        lr._wide.pack()
+        torch.cuda.synchronize()
+        assert torch.equal(fr, lr._wide.frag)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

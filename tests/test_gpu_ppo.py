@@ -179,6 +179,52 @@ def test_ppo_learner_vs_reference_fixture(dist, size):
     assert learner.iterations == nu and learner.scheduler.last_epoch == nu
 
 
+@pytest.mark.parametrize("M,act,oact", [(96, "leaky_relu", "tanh"), (100, "relu", None), (1000, "tanh", "tanh"), (37, "leaky_relu", "tanh")])
+def test_wide_minibatch_kernel_matches_the_layered_path(M, act, oact):
+    """xrl_ppo_wide_minibatch (one launch: both branches of the 17-256-256-{6 | 1} Gaussian actor-critic forward, loss,
+    backward) against the layered path (grouped GEMM launches + xrl_ppo_loss_gaussian) on the same random minibatch, two
+    chained updates: ragged last tiles (M % 32 != 0), every activation pair the kernel is instantiated for.  1e-5 on
+    everything the reference's update reports (the c4 fixture of test_ppo_learner_vs_reference_fixture pins the same kernel
+    to the reference itself)."""
+    from xuance_amd.nets import ActorCriticNet
+    from xuance_amd.learners import REGISTRY_Learners
+    rng = np.random.default_rng(M)
+    out = {}
+    for wide in (True, False):
+        torch.manual_seed(5)
+        net = ActorCriticNet(17, 6, "gaussian", (), (256, 256), (256, 256), act, activation_action=oact)
+        cfg = Namespace(horizon_size=256, n_epochs=16, n_minibatch=8, parallels=4, running_steps=120000, gamma=0.99,
+                        learning_rate=4e-4, vf_coef=0.25, ent_coef=0.01, clip_range=0.2, use_grad_clip=True, grad_clip_norm=0.5,
+                        end_factor_lr_decay=0.5, distributed_training=False, device="cuda", model_dir="/tmp/xrl_models",
+                        use_fused_update=wide)
+        cb = Capture()
+        lr = REGISTRY_Learners["PPO_Learner"](cfg, net, cb)
+        assert lr.wide_eligible() == wide
+        r = np.random.default_rng(M)
+        res = []
+        for u in range(2):
+            obs = r.standard_normal((M, 17)).astype(np.float32)
+            acts = (0.3 * r.standard_normal((M, 6))).astype(np.float32)
+            b = dict(obs=obs, actions=acts, returns=r.standard_normal(M).astype(np.float32),
+                     values=r.standard_normal(M).astype(np.float32), advantages=r.standard_normal(M).astype(np.float32),
+                     aux_batch={"old_logp": (-2.0 + 0.2 * r.standard_normal(M)).astype(np.float32)}, batch_size=M)
+            info = lr.update(**b)
+            rec = cb.records[-1]
+            res.append(dict(info=info, grad=lr.optimizer.grad.cpu().numpy().copy(), params=net.params.flat.cpu().numpy().copy(),
+                            **{k: rec[k] for k in ("v_pred", "log_prob", "ratio", "surrogate1", "surrogate2", "a_dist")}))
+        out[wide] = res
+    for a, b in zip(out[True], out[False]):
+        for k in ("actor_loss", "critic_loss", "entropy", "predict_value", "clip_ratio", "learning_rate"):
+            assert_close(a["info"][k], b["info"][k], 1e-5, k)
+        sc = max(1.0, float(np.abs(b["log_prob"]).max()))
+        for k in ("v_pred", "a_dist"):
+            assert_close(a[k], b[k], 1e-5, k)
+        for k in ("log_prob", "ratio", "surrogate1", "surrogate2"):
+            assert_close(a[k], b[k], 1e-5, k, scale=sc * max(1.0, float(np.abs(b[k]).max())))
+        assert_close(a["grad"], b["grad"], 1e-5, "clipped gradient")
+        assert_close(a["params"], b["params"], 1e-5, "parameters")
+
+
 @pytest.mark.parametrize("tag", ["gae", "nogae"])
 def test_onpolicy_buffer_vs_reference_fixture(tag):
     from xuance_amd.memory import HipOnPolicyBuffer

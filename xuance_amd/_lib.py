@@ -187,6 +187,20 @@ class PpoFused(C.Structure):
                 ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p)]
 
 
+class WideBranch(C.Structure):
+    _fields_ = [("w0", c_int32), ("b0", c_int32), ("w1", c_int32), ("b1", c_int32), ("w2", c_int32), ("b2", c_int32)]
+
+
+class PpoWide(C.Structure):
+    _fields_ = [("params", c_void_p), ("frag", c_void_p), ("br", WideBranch * 2), ("log_std_off", c_int32),
+                ("D", c_int32), ("A", c_int32), ("H", c_int32), ("act", c_int32), ("out_act", c_int32),
+                ("M", c_int32), ("dbg_role", c_int32),
+                ("obs", c_void_p), ("actions", c_void_p), ("ret", c_void_p), ("adv", c_void_p), ("old_logp", c_void_p),
+                ("stats", c_void_p), ("slabs", c_void_p), ("slab_stride", c_int64), ("partials", c_void_p), ("diag", c_void_p),
+                ("heads", c_void_p), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float), ("pad0", c_float),
+                ("dbg", c_void_p)]
+
+
 class QfImage(C.Structure):
     _fields_ = [("w", c_int32 * 4), ("b", c_int32 * 4), ("ldw", c_int32 * 4), ("mw", c_int32 * 5), ("mb", c_int32 * 5),
                 ("mldw", c_int32 * 5), ("agent_floats", c_int32), ("mixer_floats", c_int32)]
@@ -247,6 +261,8 @@ _SIGS = {
     "xrl_ppo_fused_minibatch": [C.POINTER(PpoFused), c_void_p],
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
+    "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],
+    "xrl_ppo_wide_pack": [C.POINTER(PpoWide), c_void_p, c_void_p],
     "xrl_gather_rows": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "xrl_pack_transitions": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrl_init": [],

@@ -1,0 +1,508 @@
+// Fused PPO minibatch for the two-branch actor-critic D-256-256-{A | 1} with a Gaussian head (BASELINE configs[3], the
+// MuJoCo network of configs/ppo/mujoco.yaml:8-13: Basic_Identical representation, actor_hidden_size = critic_hidden_size
+// = [256, 256]).  ONE launch: rows -> both layers forward -> Gaussian PPO-clip loss -> backward incl. every weight
+// gradient.  Reference semantics: memory_tools.py:267-287 (sample) + ppo_learner.py:46-62 (forward / loss / backward),
+// policies/gaussian.py + distributions.py:160-190 (DiagGaussianDistribution).
+//
+// Mapping (see ppo_fast.hip for the measurements behind the rules):
+//   * workgroup = (32-row tile, branch): the two branches share nothing but the rows, so a 4 096-row minibatch is
+//     128 tiles x 2 = 256 workgroups, one per CU; both roles write disjoint parameter ranges of the tile's slab row.
+//   * the 256 KB middle-layer weights arrive as ONE stream of B fragments (fragment-ordered copy kept current by the
+//     optimiser launch, xrl_ppo_wide_pack) that is issued first and stays in registers: 32 float4 per lane.  A CU pulls
+//     ~10 B/clk from L2, i.e. this stream lasts as long as the forward layer's matrix work; a second stream for the
+//     backward pass (W^T) would double it, so backward-data re-uses the forward fragments through LDS, one wave's
+//     32 rows (32 KB) per stage, two stage buffers (the dead h2 region and a dedicated one).
+//   * 8 waves, wave w owns output columns [32 w, 32 w + 32) of every 256-wide product -- forward, backward-data and the
+//     rows [32 w, ..) of dW1 -- so no split-K partial tiles are needed anywhere.
+//   * first layer (K = D <= 24) on the matrix cores too, B fragments read straight from the parameters.
+#include "common.h"
+#include "mlp_tile.h"
+#include "ppo_math.h"
+
+#pragma clang fp contract(off)
+
+namespace xrl {
+
+constexpr int WH = 256;                       // hidden width
+constexpr int WLD = WH + 4;                   // row stride of the 256-wide levels
+constexpr int WQ = WH / 8;                    // k-chunks of the middle layer
+constexpr int WXLD = 28;                      // row stride of the observation tile (D <= 24, zero padded)
+constexpr int WAM = 8;                        // max action dims
+constexpr int W_H1 = 0, W_H2 = W_H1 + FT * WLD, W_G2 = W_H2 + FT * WLD, W_ST = W_G2 + FT * WLD, W_XS = W_ST + 32 * WH,
+              W_RSC = W_XS + FT * WXLD + 8, W_DZH = W_RSC + FT * 16, W_IMG = W_DZH + FT * 16,
+              W_STAT = W_IMG + WAM * WLD + 16, W_LDS_FLOATS = W_STAT + 5 * FT * 2;
+constexpr int W_LDS_BYTES = W_LDS_FLOATS * 4;
+static_assert(W_LDS_BYTES <= 160 * 1024, "tile does not fit the LDS of a CU");
+static_assert((W_STAT % 2) == 0, "row statistics are doubles");
+
+template <int CTRL>
+__device__ __forceinline__ float wdpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// all-reduce over a row of 16 lanes (xor butterfly 8, 4, 2, 1 as row-rotate DPP moves)
+__device__ __forceinline__ float wrow16_sum(float v) {
+    v += wdpp<0x128>(v); v += wdpp<0x124>(v); v += wdpp<0x122>(v); v += wdpp<0x121>(v);
+    return v;
+}
+
+#define WSTAMP(k) do { if (dbg_me) p.dbg[k] = clock64(); } while (0)
+
+template <int ACT, int OACT>
+__global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* h1 = lds + W_H1;                            // [32][260] first hidden level; later dLoss/d(its pre-activation)
+    float* h2 = lds + W_H2;                            // [32][260] second hidden level; later stage buffer 0
+    float* g2 = lds + W_G2;                            // [32][260] dLoss/d(pre-activation of h2)
+    float* stg = lds + W_ST;                           // [32][256] stage buffer 1
+    float* xs = lds + W_XS;                            // [32][28] observations (columns D.. zero)
+    float* rsc = lds + W_RSC;                          // [32][16] action[0..7] | ret | adv | old_logp
+    float* dzh = lds + W_DZH;                          // [32][16] dLoss/d(head pre-activations)[0..7] | d log_std terms[0..7]
+    float* pimg = lds + W_IMG;                         // head weights [nout][260] | head bias[8] | log_std[8]
+    double* rowstat = reinterpret_cast<double*>(lds + W_STAT);   // [5][32] per-row loss terms
+
+    kernarg_prefetch<sizeof(xrl_ppo_wide_t)>();
+    const int tid = threadIdx.x, M = p.M, D = p.D, A = p.A;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = blockIdx.x & 1, tile = blockIdx.x >> 1;        // role 0: actor, 1: critic
+    const int m0 = tile * FT;
+    const int r = tid >> 4, sub = tid & 15, m_row = m0 + r;
+    const bool row_ok = m_row < M;
+    xrl_wide_branch_t br;                               // (static indices: a run-time index would copy the struct to scratch)
+    br.w0 = role ? p.br[1].w0 : p.br[0].w0; br.b0 = role ? p.br[1].b0 : p.br[0].b0;
+    br.w1 = role ? p.br[1].w1 : p.br[0].w1; br.b1 = role ? p.br[1].b1 : p.br[0].b1;
+    br.w2 = role ? p.br[1].w2 : p.br[0].w2; br.b2 = role ? p.br[1].b2 : p.br[0].b2;
+    const int nout = role == 0 ? A : 1;
+    float* slab = p.slabs + (size_t)tile * p.slab_stride;
+    const bool dbg_me = p.dbg && tid == 0 && blockIdx.x == gridDim.x - 2 + (p.dbg_role & 1);
+    WSTAMP(0);
+
+    // ================= loads: everything small first (vmcnt retires in order), then the weight stream
+    const int rows_here = min(FT, M - m0);
+    float4 recv = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        // waves 0-2: observations as 8 D float4 of the contiguous [32][D] block; wave 3: actions; wave 4: the three scalars
+        const float* src = nullptr; int c = 0, n_el = 0;
+        if (tid < 192) { src = p.obs + (size_t)m0 * D; c = tid; n_el = rows_here * D; if (c >= 8 * D) src = nullptr; }
+        else if (tid < 256) { src = p.actions + (size_t)m0 * A; c = tid - 192; n_el = rows_here * A; if (c >= 8 * A) src = nullptr; }
+        if (src) {
+            if (4 * c + 3 < n_el) recv = *reinterpret_cast<const float4*>(src + 4 * c);
+            else {
+                if (4 * c + 0 < n_el) recv.x = src[4 * c + 0];
+                if (4 * c + 1 < n_el) recv.y = src[4 * c + 1];
+                if (4 * c + 2 < n_el) recv.z = src[4 * c + 2];
+            }
+        }
+        if (tid >= 256 && tid < 256 + FT && m0 + (tid - 256) < M) {
+            const int m = m0 + tid - 256;
+            recv.x = p.ret[m]; recv.y = p.adv[m]; recv.z = p.old_logp[m];
+        }
+    }
+    float st_mean = 0.f, st_std = 1.f;
+    if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
+    float4 w2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < nout * 64) w2v = *reinterpret_cast<const float4*>(p.params + br.w2 + (size_t)(tid >> 6) * WH + 4 * (tid & 63));
+    float smallv = 0.f;
+    if (tid >= 448 && tid < 448 + nout) smallv = p.params[br.b2 + tid - 448];
+    if (tid >= 456 && tid < 456 + A) smallv = p.params[p.log_std_off + tid - 456];
+    float4 w0f[3];                                      // B fragments of the first layer: W0[32 w + li][8 q + 4 lh + s], zero for k >= D
+    {
+        const float* w0 = p.params + br.w0 + (size_t)(wave * 32 + li) * D;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = 8 * q + 4 * lh;
+            w0f[q].x = k + 0 < D ? w0[k + 0] : 0.f;
+            w0f[q].y = k + 1 < D ? w0[k + 1] : 0.f;
+            w0f[q].z = k + 2 < D ? w0[k + 2] : 0.f;
+            w0f[q].w = k + 3 < D ? w0[k + 3] : 0.f;
+        }
+    }
+    const float b0v = p.params[br.b0 + wave * 32 + li], b1v = p.params[br.b1 + wave * 32 + li];
+    float4 pf[WQ];                                      // B fragments of W1: output tile `wave`, all 32 k-chunks
+    {
+        const float* base = p.frag + (size_t)role * WH * WH + ((size_t)wave * WQ * 64 + lane) * 4;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) pf[q] = *reinterpret_cast<const float4*>(base + frag_slot(q, wave, WQ, 1) * 256);
+    }
+    // hand the small things over through LDS
+    if (tid < 192) {
+        if (tid < 8 * D) {
+            const float v4[4] = {recv.x, recv.y, recv.z, recv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = 4 * tid + i, rr = e / D, kk = e - rr * D; xs[rr * WXLD + kk] = v4[i]; }
+        }
+    } else if (tid < 256) {
+        const int c = tid - 192;
+        if (c < 8 * A) {
+            const float v4[4] = {recv.x, recv.y, recv.z, recv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = 4 * c + i, rr = e / A, kk = e - rr * A; rsc[rr * 16 + kk] = v4[i]; }
+        }
+    } else if (tid < 256 + FT) {
+        const int rr = tid - 256;
+        rsc[rr * 16 + 8] = recv.x; rsc[rr * 16 + 9] = recv.y; rsc[rr * 16 + 10] = recv.z;
+    } else if (tid >= 320) {                            // zero padding of the observation tile: columns D .. 27
+        for (int e = tid - 320; e < FT * (WXLD - D); e += FUSED_THREADS - 320) {
+            const int rr = e / (WXLD - D), kk = D + e - rr * (WXLD - D);
+            xs[rr * WXLD + kk] = 0.f;
+        }
+    }
+    if (tid < nout * 64) *reinterpret_cast<float4*>(pimg + (tid >> 6) * WLD + 4 * (tid & 63)) = w2v;
+    if (tid >= 448 && tid < 448 + nout) pimg[WAM * WLD + tid - 448] = smallv;
+    if (tid >= 456 && tid < 456 + A) pimg[WAM * WLD + 8 + tid - 456] = smallv;
+    if (tid < 8) xs[FT * WXLD + tid] = 0.f;            // (tail the first-layer gradient's B operand may touch)
+    lds_barrier();                                                                                   // #0 rows, head image
+    WSTAMP(1);
+
+    // ================= forward: D -> 256 (three 8-wide k-chunks), 256 -> 256 (32 chunks from the register stream)
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* arow = xs + li * WXLD + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 af = *reinterpret_cast<const float4*>(arow + q * 8);
+            MFMA4(af, w0f[q], acc)
+        }
+        const int col = wave * 32 + li;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            h1[row * WLD + col] = act_apply_c<ACT>(acc[rr] + b0v);
+        }
+    }
+    lds_barrier();                                                                                   // #1 h1
+    WSTAMP(2);
+    {
+        const float* arow = h1 + li * WLD + 4 * lh;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int hq = 0; hq < WQ / 8; ++hq) {
+            float4 af[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) af[q] = *reinterpret_cast<const float4*>(arow + (hq * 8 + q) * 8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { MFMA4(af[q], pf[hq * 8 + q], acc) }
+        }
+        const int col = wave * 32 + li;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            h2[row * WLD + col] = act_apply_c<ACT>(acc[rr] + b1v);
+        }
+    }
+    lds_barrier();                                                                                   // #2 h2
+    WSTAMP(3);
+
+    // ================= head forward (VALU, 16 threads per row), loss, head backward
+    {
+        float4 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(h2 + r * WLD + 4 * (sub + 16 * i));
+        float z[WAM];
+#pragma unroll
+        for (int j = 0; j < WAM; ++j) {
+            z[j] = 0.f;
+            if (j < nout) {
+                float c = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 w = *reinterpret_cast<const float4*>(pimg + j * WLD + 4 * (sub + 16 * i));
+                    c += a[i].x * w.x + a[i].y * w.y + a[i].z * w.z + a[i].w * w.w;
+                }
+                z[j] = wrow16_sum(c) + pimg[WAM * WLD + j];
+            }
+        }
+        float dz[WAM];
+#pragma unroll
+        for (int j = 0; j < WAM; ++j) dz[j] = 0.f;
+        float gls[WAM];
+#pragma unroll
+        for (int j = 0; j < WAM; ++j) gls[j] = 0.f;
+        double t_s = 0.0, t_c = 0.0, t_e = 0.0, t_v = 0.0, t_n = 0.0;
+        const float invM = 1.f / (float)M;
+        if (role == 0) {
+            float mu[WAM];
+#pragma unroll
+            for (int j = 0; j < WAM; ++j) mu[j] = j < A ? act_apply_c<OACT>(z[j]) : 0.f;         // activation_action
+            if (row_ok) {
+                float adv = rsc[r * 16 + 9];
+                const float old_lp = rsc[r * 16 + 10];
+                asm volatile("" : "+v"(st_std));        // keeps hipcc from consuming the statistics (and waiting) at the top
+                if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, st_mean), st_std + 1e-8f);             // memory_tools.py:281-282
+                const float lo = (float)(1.0 - (double)p.clip_range), hi = (float)(1.0 + (double)p.clip_range);
+                float logp = 0.f, ent = 0.f;
+#pragma unroll
+                for (int j = 0; j < WAM; ++j) {
+                    if (j < A) {
+                        const float ls = pimg[WAM * WLD + 8 + j], sd = expf(ls), var = sd * sd, df = rsc[r * 16 + j] - mu[j];
+                        logp += -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;               // Normal.log_prob, summed
+                        ent += 0.5f + LOG_SQRT_2PI + logf(sd);                                     // Normal.entropy, summed
+                    }
+                }
+                const Surrogate s = surrogate(logp, old_lp, adv, lo, hi, invM);
+#pragma unroll
+                for (int j = 0; j < WAM; ++j) {
+                    if (j < A) {
+                        const float ls = pimg[WAM * WLD + 8 + j], sd = expf(ls), var = sd * sd, df = rsc[r * 16 + j] - mu[j];
+                        const float gmu = s.dlogp * df / var;
+                        gls[j] = s.dlogp * (df * df / var - 1.f);
+                        dz[j] = gmu * act_grad_c<OACT>(mu[j]);
+                    }
+                }
+                t_s = (double)fminf(s.s1, s.s2); t_n = s.clipped; t_e = ent;
+                if (p.diag && sub == 0) {
+                    const int m = m_row;
+                    p.diag[m] = logp; p.diag[M + m] = s.ratio; p.diag[2 * (size_t)M + m] = s.s1; p.diag[3 * (size_t)M + m] = s.s2;
+                }
+                if (p.heads && sub == 0) {
+#pragma unroll
+                    for (int j = 0; j < WAM; ++j)
+                        if (j < A) p.heads[(size_t)m_row * (A + 1) + j] = mu[j];
+                }
+            }
+        } else if (row_ok) {
+            const float v = z[0], dv = v - rsc[r * 16 + 8];
+            if (p.heads && sub == 0) p.heads[(size_t)m_row * (A + 1) + A] = v;
+            dz[0] = p.vf_coef * 2.f * dv * invM;                                                    // d(vf * mean((v-ret)^2))/dv
+            t_c = (double)dv * dv; t_v = v;
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int j = 0; j < WAM; ++j) { dzh[r * 16 + j] = dz[j]; dzh[r * 16 + 8 + j] = gls[j]; }
+            rowstat[0 * FT + r] = t_s; rowstat[1 * FT + r] = t_c; rowstat[2 * FT + r] = t_e; rowstat[3 * FT + r] = t_v; rowstat[4 * FT + r] = t_n;
+        }
+        // dH2 = dZ . W2, times act'(h2): this thread's four k-chunks
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < WAM; ++j) {
+                if (j < nout) {
+                    const float4 w = *reinterpret_cast<const float4*>(pimg + j * WLD + 4 * (sub + 16 * i));
+                    g.x += dz[j] * w.x; g.y += dz[j] * w.y; g.z += dz[j] * w.z; g.w += dz[j] * w.w;
+                }
+            }
+            g.x *= act_grad_c<ACT>(a[i].x); g.y *= act_grad_c<ACT>(a[i].y); g.z *= act_grad_c<ACT>(a[i].z); g.w *= act_grad_c<ACT>(a[i].w);
+            *reinterpret_cast<float4*>(g2 + r * WLD + 4 * (sub + 16 * i)) = g;
+        }
+    }
+    lds_barrier();                                                                                   // #3 g2, dzh, rowstat
+    WSTAMP(4);
+
+    // ================= backward
+    if (wave == 7) {                                    // loss terms of the tile (rows on lanes 0..31 of one wave)
+        double acc_s = 0.0, acc_c = 0.0, acc_e = 0.0, acc_v = 0.0, acc_n = 0.0;
+        if (lane < FT) { acc_s = rowstat[lane]; acc_c = rowstat[FT + lane]; acc_e = rowstat[2 * FT + lane]; acc_v = rowstat[3 * FT + lane]; acc_n = rowstat[4 * FT + lane]; }
+        acc_s = wave_sum(acc_s); acc_c = wave_sum(acc_c); acc_e = wave_sum(acc_e); acc_v = wave_sum(acc_v); acc_n = wave_sum(acc_n);
+        if (lane == 0) {
+            double* q = p.partials + (size_t)blockIdx.x * 8;
+            q[0] = acc_s; q[1] = acc_c; q[2] = acc_e; q[3] = acc_v; q[4] = acc_n; q[5] = 0; q[6] = 0; q[7] = 0;
+        }
+    }
+    // ---- head weight gradients, head bias / log_std gradients, second-layer bias gradient: reductions over the 32 rows
+    for (int o = tid; o < nout * WH; o += FUSED_THREADS) {
+        const int j = o >> 8, k = o & (WH - 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < FT; ++rr) acc += dzh[rr * 16 + j] * h2[rr * WLD + k];
+        slab[br.w2 + o] = acc;
+    }
+    if (tid >= 256) {
+        const int t = tid - 256;
+        float acc = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < FT; ++rr) acc += g2[rr * WLD + t];
+        slab[br.b1 + t] = acc;
+    } else if (tid < 16) {
+        const int j = tid & 7, ls = tid >> 3;          // 0..7: head bias, 8..15: log_std (actor only)
+        if (j < nout && (ls == 0 || role == 0)) {
+            float acc = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < FT; ++rr) acc += dzh[rr * 16 + tid];
+            // d(-ent_coef * mean_m sum_j(log_std_j + c))/d log_std_j = -ent_coef, added once (tile 0)
+            if (ls && tile == 0) acc -= p.ent_coef;
+            slab[(ls ? p.log_std_off : br.b2) + j] = acc;
+        }
+    }
+    WSTAMP(5);
+    // ---- dW1[n][k] = sum_rows g2[row][n] * h1[row][k]: wave w owns rows n in [32 w, 32 w + 32), 8 column tiles in two passes
+    {
+        const float* arow = g2 + lh * WLD + wave * 32 + li;             // A[i = n][k = row]
+        const float* brow = h1 + lh * WLD + li;                         // B[k = row][j]
+        float* dW = slab + br.w1 + (size_t)(wave * 32) * WH;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < FT / 2; ++s) {
+                const float av = arow[2 * s * WLD];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float bv = brow[2 * s * WLD + (half * 4 + t) * 32];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                    dW[(size_t)row * WH + (half * 4 + t) * 32 + li] = acc[t][rr];
+                }
+        }
+    }
+    WSTAMP(6);
+    // ---- dH1 = g2 . W1, wave w owns output columns k in [32 w, 32 w + 32).  The B operand (W1 with the reduction index n on
+    //      the MFMA's k axis) comes from the forward fragments through LDS: stage j = rows n in [32 j, 32 j + 32) = the
+    //      fragments of wave j, written as the float4s they are (4-float groups XOR-swizzled by the row so that rows do not
+    //      collide) and read back as the four scalars of an MFMA4 (lanes = consecutive k: conflict-free).
+    {
+        const float* arow = g2 + li * WLD + 4 * lh;
+        const int k_out = wave * 32 + li;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (int jp = 0; jp < 4; ++jp) {                                // stages 2 jp (buffer h2) and 2 jp + 1 (buffer stg)
+            lds_barrier();                                              // buffers free (first: h2 / h1's readers are done)
+            if ((wave >> 1) == jp) {
+                float* T = (wave & 1) ? stg : h2;
+#pragma unroll
+                for (int qq = 0; qq < WQ; ++qq)                         // W1[n][8 qq + 4 lh .. + 3] -> group 2 qq + lh of row li
+                    *reinterpret_cast<float4*>(T + li * WH + (((2 * qq + lh) ^ li) << 2)) = pf[qq];
+            }
+            lds_barrier();                                              // stages visible
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float* T = jj ? stg : h2;
+                const int j = 2 * jp + jj;
+                float4 af[4], bt[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const float4*>(arow + (4 * j + i) * 8);   // n-chunk 4 j + i
+                    float bs[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int nr = 8 * i + 4 * lh + s4;            // row of the stage
+                        bs[s4] = T[nr * WH + ((((k_out >> 2) ^ nr) << 2) | (k_out & 3))];
+                    }
+                    bt[i] = make_float4(bs[0], bs[1], bs[2], bs[3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { MFMA4(af[i], bt[i], acc) }
+            }
+        }
+        // g1 = dH1 * act'(h1), in place (h1's other readers finished before the first stage barrier)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            float* q = h1 + row * WLD + k_out;
+            *q = acc[rr] * act_grad_c<ACT>(*q);
+        }
+    }
+    lds_barrier();                                                                                   // #4 g1
+    WSTAMP(7);
+    // ---- first layer: dW0[c][k] = sum_rows g1[row][c] * x[row][k] on the matrix cores (wave w: rows c in [32 w, ..), one
+    //      32-column tile of which the first D are kept), db0[c]
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* arow = h1 + lh * WLD + wave * 32 + li;             // A[i = c][k = row]
+        const float* brow = xs + lh * WXLD + li;                        // B[k = row][j]: columns >= 28 alias the next row (discarded)
+#pragma unroll
+        for (int s = 0; s < FT / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s * WLD], brow[2 * s * WXLD], acc, 0, 0, 0);
+        if (li < D) {
+            float* dW = slab + br.w0 + (size_t)(wave * 32) * D + li;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                dW[(size_t)row * D] = acc[rr];
+            }
+        }
+        if (tid < WH) {
+            float accb = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < FT; ++rr) accb += h1[rr * WLD + tid];
+            slab[br.b0 + tid] = accb;
+        }
+    }
+    WSTAMP(8);
+}
+
+// frag[b][tile t][slot (q + t) mod 32][lane l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s]
+__global__ void __launch_bounds__(256) ppo_wide_pack_kernel(xrl_ppo_wide_t p, float* __restrict__ frag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;                // one float4 of the destination
+    if (i >= 2 * WH * WH / 4) return;
+    const int b = i / (WH * WH / 4), e = i - b * (WH * WH / 4);
+    const int l = e & 63, slot = (e >> 6) & (WQ - 1), t = e >> 11;
+    const int q = (slot - t + WQ) & (WQ - 1);
+    const int w1 = b ? p.br[1].w1 : p.br[0].w1;
+    const float* src = p.params + w1 + (size_t)(32 * t + (l & 31)) * WH + 8 * q + 4 * (l >> 5);
+    *reinterpret_cast<float4*>(frag + (size_t)i * 4) = *reinterpret_cast<const float4*>(src);
+}
+
+static int wide_check(const xrl_ppo_wide_t* p) {
+    XRL_CHECK_ARG(p != nullptr && p->params && p->H == WH && p->D >= 1 && p->D <= 24 && p->A >= 1 && p->A <= WAM);
+    for (int b = 0; b < 2; ++b) XRL_CHECK_ARG(p->br[b].w1 % 4 == 0 && p->br[b].w2 % 4 == 0);
+    return XRL_OK;
+}
+
+#define WIDE_FOR_EACH(X) X(XRL_ACT_RELU, XRL_ACT_NONE) X(XRL_ACT_RELU, XRL_ACT_TANH) X(XRL_ACT_LEAKY_RELU, XRL_ACT_NONE) \
+    X(XRL_ACT_LEAKY_RELU, XRL_ACT_TANH) X(XRL_ACT_TANH, XRL_ACT_NONE) X(XRL_ACT_TANH, XRL_ACT_TANH)
+
+int init_ppo_wide() {
+#define WIDE_ATTR(a, o) XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_wide_kernel<a, o>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES));
+    WIDE_FOR_EACH(WIDE_ATTR)
+#undef WIDE_ATTR
+    return XRL_OK;
+}
+
+static bool wide_act_ok(int act, int out_act) {
+    return (act == XRL_ACT_RELU || act == XRL_ACT_LEAKY_RELU || act == XRL_ACT_TANH) && (out_act == XRL_ACT_NONE || out_act == XRL_ACT_TANH);
+}
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_ppo_wide_pack(const xrl_ppo_wide_t* p, float* frag, xrl_stream_t stream) {
+    int rc = wide_check(p);
+    if (rc != XRL_OK) return rc;
+    XRL_CHECK_ARG(frag != nullptr && (reinterpret_cast<uintptr_t>(p->params) & 15) == 0);
+    hipLaunchKernelGGL(ppo_wide_pack_kernel, dim3(2 * WH * WH / 4 / 256), dim3(256), 0, as_stream(stream), *p, frag);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_ppo_wide_minibatch(const xrl_ppo_wide_t* p, xrl_stream_t stream) {
+    int rc = wide_check(p);
+    if (rc != XRL_OK) return rc;
+    XRL_CHECK_ARG(p->frag && p->obs && p->actions && p->ret && p->adv && p->old_logp && p->slabs && p->partials && p->M > 0);
+    XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->params) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->frag) & 15) == 0);
+    XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->obs) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->actions) & 15) == 0);
+    static bool inited = false;
+    if (!inited) {
+        rc = init_ppo_wide();
+        if (rc != XRL_OK) return rc;
+        inited = true;
+    }
+    const int n_tiles = (p->M + FT - 1) / FT;
+    XRL_CHECK_ARG(wide_act_ok(p->act, p->out_act));
+#define WIDE_LAUNCH(a, o)                                                                                                     \
+    if (p->act == a && p->out_act == o)                                                                                       \
+        hipLaunchKernelGGL((ppo_wide_kernel<a, o>), dim3(2 * n_tiles), dim3(FUSED_THREADS), W_LDS_BYTES, as_stream(stream), *p);
+    WIDE_FOR_EACH(WIDE_LAUNCH)
+#undef WIDE_LAUNCH
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

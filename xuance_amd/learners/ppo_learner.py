@@ -24,7 +24,7 @@ class PPO_Learner(Learner):
         self.scheduler = LinearLRHandle(self.optimizer)
         dev = P.device
         self._cap = 0
-        self.sumsq = torch.zeros(128, dtype=torch.float64, device=dev)
+        self.sumsq = torch.zeros(1024, dtype=torch.float64, device=dev)
         # everything the host reads back per update phase in ONE copy: 8 loss sums + 4 status words (the whole-rollout
         # launch's time-out / XCC flags, PPO_Agent.persist_status) + 4 words of the fused optimiser's barrier scratch
         self._readback = torch.zeros(12, dtype=torch.float64, device=dev)
@@ -165,6 +165,49 @@ class PPO_Learner(Learner):
                 self._key("entropy"): float(s[2] / M), self._key("learning_rate"): st.last_lr,
                 self._key("predict_value"): float(s[3] / M), self._key("clip_ratio"): float(s[4] / M)}
 
+    # ------------------------------------------------------------------ two-branch Gaussian class D-256-256-{A | 1}: ONE launch
+    def wide_eligible(self):
+        """xrl_ppo_wide_minibatch (csrc/ppo_wide.hip) covers this learner: PPO-clip loss on the MuJoCo network class
+        (configs/ppo/mujoco.yaml:8-13), specialised kernels not switched off (config.use_fused_update / xrl_set_fast_kernels)."""
+        return bool(getattr(self.config, "use_fused_update", True)) and self.loss_mode == 0 and type(self).update is PPO_Learner.update \
+            and ops.PpoWideState.eligible(self.model) and ops.fast_kernels_enabled()
+
+    def _wide_prepare(self, M):
+        """Allocations of the wide path for minibatches of up to M rows (outside any graph capture)."""
+        dev, P = self.model.params.device, self.model.params.P
+        if getattr(self, "_wide", None) is None:
+            self._wide = ops.PpoWideState(self.model)
+            self._mirrors = [(self._wide.map, self._wide.frag)]      # the optimiser launch keeps the fragment copy current
+            self._mirror = True
+            self.opt_sync = torch.zeros(4 + (P + 255) // 256 + 8, dtype=torch.int32, device=dev)
+        n_t = (M + 31) // 32
+        if n_t > getattr(self, "_wide_tiles", 0):
+            self.fslabs = torch.zeros(n_t, P, device=dev)            # one gradient row per 32-row tile (both branches)
+            self.fpartials = torch.zeros(2 * n_t, 8, dtype=torch.float64, device=dev)
+            self._wide_tiles, self.slab_stride, self.fold, self.split = n_t, P, None, False
+        self._ensure(M)
+
+    def _step_wide(self, obs, act, ret, adv, old_logp, M, stats=None, finish=True, heads=None):
+        """One minibatch from staged rows: forward + loss + backward in one launch, then slab reduction + clip + Adam (+ the
+        gradient average over the ranks) in a second one.  Pointers may be tensors or raw addresses."""
+        m, opt, P = self.model, self.optimizer, self.model.params.P
+        n_t = (M + 31) // 32
+        self._wide.launch(M, obs, act, ret, adv, old_logp, self.fslabs, P, self.fpartials, self.clip_range, self.vf_coef,
+                          self.ent_coef, stats=stats, diag=self.diag if self.keep_diag else None, heads=heads)
+        self._last_S, self._last_partials = 2 * n_t, self.fpartials
+        dist = self.distributed_training and self.world_size > 1
+        xc = self.gradient_exchange() if dist and finish else None
+        if finish and (not dist or xc is not None) and getattr(self.config, "use_fused_optimizer", True):
+            clip = self.grad_clip_norm if self.use_grad_clip else 0.0
+            ops.reduce_adam(self.fslabs, n_t, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip,
+                            self._mirrors, self.opt_sync, exchange=xc)
+            return
+        ops.grad_reduce(self.fslabs, n_t, P, P, opt.grad, self.sumsq)
+        if finish:
+            if dist:
+                self.allreduce_grad()
+            self.finish_step()
+
     # ------------------------------------------------------------------ fused path: minibatches straight from HBM
     def prepare_buffer_update(self, memory, bs):
         """Allocate the minibatch staging tensors once (nothing may be allocated while a hipGraph is captured)."""
@@ -186,6 +229,8 @@ class PPO_Learner(Learner):
         """One-launch gather+forward+loss+backward: categorical head, 4-d observations, middle layers in 32-multiples,
         activations + gradients of a 32-row tile must fit in LDS."""
         m, plan = self.model, self.model.plan
+        if self.wide_eligible():                                   # the two-branch Gaussian class has its own kernel
+            return tuple(memory.act_shape) == (m.action_dim,)
         if not getattr(self.config, "use_fused_update", True) or m.dist != "categorical" or m.obs_dim != 4:
             return False
         if len(plan.stages) < 2 or len(plan.stages[0]) != 1 or len(plan.widths) > 6:
@@ -217,6 +262,14 @@ class PPO_Learner(Learner):
         if getattr(self, "_fused_bs", 0) == bs:
             return
         dev, P = self.model.params.device, self.model.params.P
+        if self.wide_eligible():
+            assert bs % 4 == 0, "the wide minibatch kernel reads 16-byte aligned row blocks: batch size must be a multiple of 4"
+            self._wide_prepare(bs)
+            self.n_tiles = (bs + 31) // 32
+            self.n_part_rows = 2 * self.n_tiles
+            self.stats = torch.zeros(4096, 2, device=dev)
+            self._fused_bs = bs
+            return
         self._ensure(bs)
         self.n_tiles = (bs + 31) // 32
         self.split = self.split_eligible(self.n_tiles)
@@ -245,12 +298,30 @@ class PPO_Learner(Learner):
 
     def prepare_rows(self, count):
         """Allocate the gathered-record staging of an update phase (outside graph capture)."""
+        if getattr(self, "_wide", None) is not None:
+            if getattr(self, "_wstage_rows", 0) != count:
+                dev, D, A = self.model.params.device, self.model.obs_dim, self.model.action_dim
+                self._wstage = {"observations": torch.zeros(count, D, device=dev), "actions": torch.zeros(count, A, device=dev),
+                                "returns": torch.zeros(count, device=dev), "advantages": torch.zeros(count, device=dev),
+                                "aux_old_logp": torch.zeros(count, device=dev)}
+                self._wstage_rows = count
+            return
         if getattr(self, "rows", None) is None or self.rows.numel() != count * 8:
             self.rows = torch.zeros(count * 8, device=self.model.params.device)
 
     def refresh_fused_params(self, memory=None, idx_all=None):
         """Derived parameter layouts the fused kernel reads (transposed middle weights, packed small parameters); with
         `memory`, also the packed transition records of the finished rollout (once per update phase)."""
+        if getattr(self, "_wide", None) is not None:
+            self._wide.pack()
+            self._rows_idx = None
+            if memory is not None and idx_all is not None:
+                # every minibatch of the phase gathered with ONE launch into row-contiguous staging
+                self.prepare_rows(idx_all.numel())
+                st, f = self._wstage, memory.soa
+                ops.soa_gather([(st[n], f.fields[n], f.row_bytes[n]) for n in st], idx_all.view(-1), memory.n_envs, memory.n_size)
+                self._rows_idx = idx_all
+            return
         if memory is not None:
             f = memory.soa.fields
             ops.pack_transitions(f["observations"], f["actions"], f["returns"], f["advantages"], f["aux_old_logp"],
@@ -272,6 +343,18 @@ class PPO_Learner(Learner):
         """One launch for gather + forward + loss + backward, then reduce + Adam, then refresh the derived layouts."""
         m, opt, f = self.model, self.optimizer, memory.soa.fields
         M = idx.numel()
+        if getattr(self, "_wide", None) is not None:
+            base, st = getattr(self, "_rows_idx", None), None
+            if base is not None:                           # `idx` is a row of the index matrix the rows were gathered for
+                off = (idx.data_ptr() - base.data_ptr()) // 8
+                if 0 <= off and off + M <= base.numel() and idx.is_contiguous():
+                    st = {n: t[off:off + M] for n, t in self._wstage.items()}
+            if st is None:                                 # any other index set: gather it now
+                self.prepare_rows(M)
+                st, fs = self._wstage, memory.soa
+                ops.soa_gather([(st[n], fs.fields[n], fs.row_bytes[n]) for n in st], idx, memory.n_envs, memory.n_size)
+            return self._step_wide(st["observations"], st["actions"], st["returns"], st["advantages"], st["aux_old_logp"], M,
+                                   stats=stats, finish=finish)
         fold = self.fold if (self.split and ops.fast_kernels_enabled()) else None     # (tests switch the specialised kernels off)
         rows = None
         base = getattr(self, "_rows_idx", None)
@@ -335,10 +418,19 @@ class PPO_Learner(Learner):
         self._ensure(M)
         info = self.callback.on_update_start(self.iterations, policy=self.policy, obs=obs, act=act, returns=ret,
                                              advantages=adv, old_logp=old_logp) or {}
-        S = self._step(obs, obs.shape[1], act, ret, adv, old_logp, M)
-        info.update(self._info(M, S))
-        heads = self.model.plan.acts[len(self.model.plan.widths) - 1]
         A = self.model.action_dim
+        if self.wide_eligible():
+            self._wide_prepare(M)
+            self._wide.pack()                                       # (the parameters may have been loaded since the last call)
+            if getattr(self, "_wheads", None) is None or self._wheads.shape[0] < M:
+                self._wheads = torch.zeros(M, A + 1, device=obs.device)
+            heads = self._wheads
+            self._step_wide(obs, act.reshape(M, -1).contiguous(), ret, adv, old_logp, M, heads=heads)
+            info.update(self._info(M, self._last_S, self.fpartials))
+        else:
+            S = self._step(obs, obs.shape[1], act, ret, adv, old_logp, M)
+            info.update(self._info(M, S))
+            heads = self.model.plan.acts[len(self.model.plan.widths) - 1]
         d = self.diag.view(-1)                                      # the loss kernel packs [4][M] for the current M
         cb = dict(policy=self.policy, info=info, v_pred=heads[:M, A], log_prob=d[0:M], ratio=d[M:2 * M],
                   surrogate1=d[2 * M:3 * M], surrogate2=d[3 * M:4 * M],

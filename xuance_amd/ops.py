@@ -379,6 +379,67 @@ def ppo_fused_minibatch(plan, **kw):
     call("xrl_ppo_fused_minibatch", C.byref(p), stream_ptr())
 
 
+class PpoWideState:
+    """Host side of xrl_ppo_wide_minibatch for an ActorCriticNet of the class D-256-256-{A | 1} with a Gaussian head (the
+    MuJoCo network, configs/ppo/mujoco.yaml:8-13): layer offsets, the fragment-ordered copy of the two middle layers and the
+    optimiser mirror map that keeps it current (built by running the layout kernel on an index ramp, so that it cannot
+    disagree with it)."""
+
+    @staticmethod
+    def eligible(model):
+        pl = getattr(model, "plan", None)
+        if pl is None or getattr(model, "dist", None) != "gaussian" or not hasattr(model, "head_ld"):
+            return False
+        D, A = model.obs_dim, model.action_dim
+        if list(pl.widths) != [D, 512, 512, A + 1] or not (1 <= D <= 24 and 1 <= A <= 8) or model.head_ld != A + 1:
+            return False
+        if model.activation not in ("relu", "leaky_relu", "tanh") or model.activation_action not in (None, "tanh"):
+            return False
+        return "actor.mu.0.weight" in model.params.offsets and model.params.P % 4 == 0
+
+    def __init__(self, model):
+        assert self.eligible(model)
+        self.model = model
+        P, o = model.params, model.params.offsets
+        self.D, self.A = model.obs_dim, model.action_dim
+        d = _lib.PpoWide()
+        for b, key in enumerate(("actor.mu", "critic.values")):
+            br = d.br[b]
+            br.w0, br.b0 = o[f"{key}.0.weight"], o[f"{key}.0.bias"]
+            br.w1, br.b1 = o[f"{key}.2.weight"], o[f"{key}.2.bias"]
+            br.w2, br.b2 = o[f"{key}.4.weight"], o[f"{key}.4.bias"]
+        d.log_std_off = o[getattr(model, "log_std_name", "actor.log_std")]
+        d.D, d.A, d.H = self.D, self.A, 256
+        d.act, d.out_act = ACT[model.activation], ACT[model.activation_action]
+        self.desc = d
+        dev = P.device
+        self.frag = torch.zeros(2 * 256 * 256, device=dev)
+        ramp = torch.arange(P.P, dtype=torch.float32, device=dev) + 1.0           # exact in fp32 for P < 2^24
+        self.pack(ramp)
+        torch.cuda.synchronize()
+        self.map = torch.full((P.P,), -1, dtype=torch.int32, device=dev)
+        self.map[(self.frag - 1.0).to(torch.int64)] = torch.arange(self.frag.numel(), dtype=torch.int32, device=dev)
+        self.pack()
+
+    def pack(self, flat=None):
+        """frag <- the middle layers of `flat` (default: the model's parameters); one launch, capturable."""
+        d = self.desc
+        d.params = (self.model.params.flat if flat is None else flat).data_ptr()
+        call("xrl_ppo_wide_pack", C.byref(d), ptr(self.frag), stream_ptr())
+
+    def launch(self, M, obs, actions, ret, adv, old_logp, slabs, slab_stride, partials, clip_range, vf_coef, ent_coef,
+               stats=None, diag=None, heads=None, dbg=None, dbg_role=0):
+        d = self.desc
+        d.params, d.frag = self.model.params.flat.data_ptr(), self.frag.data_ptr()
+        d.M, d.dbg_role = int(M), int(dbg_role)
+        as_ptr = lambda t: None if t is None else (t.data_ptr() if isinstance(t, torch.Tensor) else int(t))
+        d.obs, d.actions, d.ret, d.adv, d.old_logp = as_ptr(obs), as_ptr(actions), as_ptr(ret), as_ptr(adv), as_ptr(old_logp)
+        d.stats, d.slabs, d.slab_stride, d.partials = as_ptr(stats), as_ptr(slabs), int(slab_stride), as_ptr(partials)
+        d.diag, d.heads, d.dbg = as_ptr(diag), as_ptr(heads), as_ptr(dbg)
+        d.clip_range, d.vf_coef, d.ent_coef = float(clip_range), float(vf_coef), float(ent_coef)
+        call("xrl_ppo_wide_minibatch", C.byref(d), stream_ptr())
+
+
 def transpose_mid(plan, params_flat, params_t):
     p = PpoFused()
     p.params = params_flat.data_ptr()
