@@ -620,6 +620,31 @@ int xrl_ppo_wide_minibatch(const xrl_ppo_wide_t* p, xrl_stream_t stream);
  * l: lane): every prefetch instruction of a wave reads one contiguous 1 KB run.  Only params / br of *p are read;
  * frag holds 2*256*256 floats.  Kept current afterwards by the optimiser launch (xrl_mirrors_t map built from this layout). */
 int xrl_ppo_wide_pack(const xrl_ppo_wide_t* p, float* frag, xrl_stream_t stream);
+/* Acting step of the same network class in ONE launch (replaces three grouped GEMM launches + xrl_policy_sample of the layered
+ * rollout step; on_policy agent: policy(obs) -> stochastic_sample / log_prob / values, ppo_agent.py:97-135): x holds 2n
+ * normalised observations, rows [0, n) the ones acted on, rows [n, 2n) the previous step's next observations whose values
+ * bootstrap truncated episodes.  flags bit 0: act -- action = mu + std * N(0,1) (the Philox draws of xrl_policy_sample: key
+ * seed, counter (row, step + *step_dev, STREAM_GAUSS + dim)), log-prob and value of rows [0, n); bit 1: values of rows
+ * [n, 2n) -> bootv_prev.  Same numbers as the layered sequence up to the summation order inside a dot product. */
+typedef struct {
+    const float* params;
+    const float* frag;                                 /* xrl_ppo_wide_pack image */
+    xrl_wide_branch_t br[2];
+    int32_t log_std_off;
+    int32_t D, A, H;
+    int32_t act, out_act;
+    int32_t n, flags;
+    const float* x;                                    /* [2n][D] */
+    float* act_out;                                    /* [n][A] */
+    float* env_action_f;                               /* NULL or [n][A]: the same actions for the vector env */
+    float* logp_out;                                   /* [n] */
+    float* val_out;                                    /* NULL or [n] */
+    float* bootv_prev;                                 /* [n] (flags bit 1) */
+    uint64_t seed;
+    uint32_t step, pad0;
+    const uint32_t* step_dev;
+} xrl_wide_act_t;
+int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream);
 /* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */
 int xrl_transpose_mid(const xrl_ppo_fused_t* p, float* params_t, xrl_stream_t stream);
 

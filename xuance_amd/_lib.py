@@ -201,6 +201,14 @@ class PpoWide(C.Structure):
                 ("dbg", c_void_p)]
 
 
+class WideAct(C.Structure):
+    _fields_ = [("params", c_void_p), ("frag", c_void_p), ("br", WideBranch * 2), ("log_std_off", c_int32),
+                ("D", c_int32), ("A", c_int32), ("H", c_int32), ("act", c_int32), ("out_act", c_int32),
+                ("n", c_int32), ("flags", c_int32), ("x", c_void_p), ("act_out", c_void_p), ("env_action_f", c_void_p),
+                ("logp_out", c_void_p), ("val_out", c_void_p), ("bootv_prev", c_void_p), ("seed", C.c_uint64),
+                ("step", C.c_uint32), ("pad0", C.c_uint32), ("step_dev", c_void_p)]
+
+
 class QfImage(C.Structure):
     _fields_ = [("w", c_int32 * 4), ("b", c_int32 * 4), ("ldw", c_int32 * 4), ("mw", c_int32 * 5), ("mb", c_int32 * 5),
                 ("mldw", c_int32 * 5), ("agent_floats", c_int32), ("mixer_floats", c_int32)]
@@ -263,6 +271,7 @@ _SIGS = {
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
     "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],
     "xrl_ppo_wide_pack": [C.POINTER(PpoWide), c_void_p, c_void_p],
+    "xrl_wide_act_step": [C.POINTER(WideAct), c_void_p],
     "xrl_gather_rows": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "xrl_pack_transitions": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "xrl_init": [],

@@ -123,13 +123,19 @@ class PPO_Agent(AgentSurface):
         ops.obs_normalize(x=env.buf_obs, mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=self.X,
                           out1=f["observations"][t], n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(self.use_obsnorm),
                           normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
-        heads = self.model.forward(self.X, 2 * n)
-        # actions / log-probs / values of rows [0,n) -> buffer slot t; value of rows [n,2n) -> bootv[t-1]
-        ops.policy_sample(heads=heads, log_std=self.model.params.ptr("actor.log_std") if gaussian else None,
-                          act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
-                          env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
-                          bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A, ld=A + 1, gaussian=int(gaussian),
-                          seed=self.seed, step=t, step_dev=self.step_counter)
+        wide = self._wide_acting()
+        if wide is not None:
+            # forward of both branches + sample + log-prob + values in ONE launch (csrc/ppo_wide.hip: wide_act_kernel)
+            wide.act(self.X, n, self.seed, t, self.step_counter, act_out=f["actions"][t], env_action_f=env.action,
+                     logp_out=f["aux_old_logp"][t], val_out=f["values"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None)
+        else:
+            heads = self.model.forward(self.X, 2 * n)
+            # actions / log-probs / values of rows [0,n) -> buffer slot t; value of rows [n,2n) -> bootv[t-1]
+            ops.policy_sample(heads=heads, log_std=self.model.params.ptr("actor.log_std") if gaussian else None,
+                              act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
+                              env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
+                              bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A, ld=A + 1, gaussian=int(gaussian),
+                              seed=self.seed, step=t, step_dev=self.step_counter)
         if hasattr(env, "advance"):
             env.step_device(offset=t)                           # static step index: the env's counter ticks once per rollout
         else:
@@ -227,10 +233,14 @@ class PPO_Agent(AgentSurface):
         if hasattr(self.envs, "advance"):
             self.envs.advance(T)
         # buffer full: vals = get_terminated_values(next_obs) for every env (ppo_agent.py:129-135)
-        heads = self.model.forward(self.X, 2 * n)
-        ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
-                          bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
-                          gaussian=0, seed=self.seed, step=0, step_dev=None)
+        wide = self._wide_acting()
+        if wide is not None:
+            wide.act(self.X, n, self.seed, 0, None, bootv_prev=self.memory.soa.fields["bootv"][T - 1])
+        else:
+            heads = self.model.forward(self.X, 2 * n)
+            ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
+                              bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
+                              gaussian=0, seed=self.seed, step=0, step_dev=None)
         ops.counter_add(self.step_counter, T)
         f = self.memory.soa.fields
         ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
@@ -304,6 +314,19 @@ class PPO_Agent(AgentSurface):
         kernel notices in every launch and exchanges through device-scope stores then (status[3] counts those launches)."""
         return st[0] == 0
 
+    def _wide_acting(self):
+        """The learner's PpoWideState when the acting step of the layered rollout can run as one launch (the two-branch
+        Gaussian class of csrc/ppo_wide.hip, PPO-clip learner; config.use_fused_acting: False switches it off), else None.
+        Its fragment-ordered copy of the middle layers is the one the update phase keeps current."""
+        if not hasattr(self, "_wact"):
+            lr = self.learner
+            ok = type(self)._enqueue_step is PPO_Agent._enqueue_step and bool(_get(self.config, "use_fused_acting", True)) and \
+                hasattr(lr, "wide_eligible") and lr.wide_eligible()
+            if ok:
+                lr._wide_prepare(self.batch_size)
+            self._wact = lr._wide if ok else None
+        return self._wact
+
     def _rollout_state_tensors(self):
         """Everything a rollout launch mutates besides the buffer slots it overwrites (simulator, statistics, counters)."""
         env, t = self.envs, [self.returns, self.step_counter]
@@ -311,6 +334,8 @@ class PPO_Agent(AgentSurface):
         return t + list(self.pp.values())
 
     def _launch_rollout(self):
+        if not self.use_fused_rollout:
+            self._wide_acting()                                   # (allocates on first use: never inside a capture)
         if self.use_graph and getattr(self.envs, "graph_safe", True):
             if self._rollout_graph is None:
                 torch.cuda.synchronize()
@@ -468,6 +493,8 @@ class PPO_Agent(AgentSurface):
     def _after_load(self):
         if self.use_fused_rollout and self.use_obsnorm:            # both ping-pong slots start from the same statistics
             self.pp["obs_stats"][1].copy_(self.pp["obs_stats"][0]); self.pp["obs_count"][1].copy_(self.pp["obs_count"][0])
+        if getattr(self, "_wact", None) is not None:
+            self._wact.pack()                                      # fragment-ordered copy of the loaded middle layers
         self._rollout_graph = None                                 # parameters' derived layouts are rebuilt on the next rollout/update
         self._update_graph = None
         self._mb_graphs = None

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "mlp_tile.h"
 #include "ppo_math.h"
+#include "rng.h"
 
 #pragma clang fp contract(off)
 
@@ -439,6 +440,177 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
     WSTAMP(8);
 }
 
+// ------------------------------------------------------------------------------------------------ acting step
+// One launch for what the layered rollout step spends four on (three grouped GEMM launches + xrl_policy_sample; reference:
+// OnPolicyAgent.action / ppo_agent.py:97-135 -- policy(obs) -> dist.stochastic_sample(), log_prob, values; values of the next
+// observations for the bootstrap).  Workgroup = (32-row tile, branch) as in the minibatch kernel: actor tiles over rows
+// [0, n), critic tiles over the rows whose value is wanted.  Nothing couples two workgroups: the actor role samples and
+// writes action / log-prob, the critic role writes the value -- same Philox draws and the same arithmetic as
+// policy_sample_kernel (rollout.hip), the log-prob summed over the action dims in the same order.
+template <int ACT, int OACT>
+__global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* h1 = lds;                                   // [32][260]
+    float* h2 = h1 + FT * WLD;                         // [32][260]
+    float* xs = h2 + FT * WLD;                         // [32][28]
+    float* pimg = xs + FT * WXLD + 8;                  // head weights [nout][260] | head bias[8] | log_std[8]
+    float* terms = pimg + WAM * WLD + 16;              // [32][8] per-dim log-prob terms
+
+    kernarg_prefetch<sizeof(xrl_wide_act_t)>();
+    const int tid = threadIdx.x, D = p.D, A = p.A, n = p.n;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool acting = (p.flags & 1) != 0, boot = (p.flags & 2) != 0;
+    const int tiles_a = acting ? (n + FT - 1) / FT : 0;
+    const int role = (int)blockIdx.x < tiles_a ? 0 : 1;
+    const int c_lo = acting ? 0 : n, c_hi = boot ? 2 * n : n;
+    const int row0 = role == 0 ? (int)blockIdx.x * FT : c_lo + ((int)blockIdx.x - tiles_a) * FT;
+    const int rows_here = min(FT, (role == 0 ? n : c_hi) - row0);
+    const int r = tid >> 4, sub = tid & 15;
+    xrl_wide_branch_t br;
+    br.w0 = role ? p.br[1].w0 : p.br[0].w0; br.b0 = role ? p.br[1].b0 : p.br[0].b0;
+    br.w1 = role ? p.br[1].w1 : p.br[0].w1; br.b1 = role ? p.br[1].b1 : p.br[0].b1;
+    br.w2 = role ? p.br[1].w2 : p.br[0].w2; br.b2 = role ? p.br[1].b2 : p.br[0].b2;
+    const int nout = role == 0 ? A : 1;
+
+    // ---- loads: small things first, then the weight stream
+    float xv[2] = {0.f, 0.f};
+    {
+        const float* src = p.x + (size_t)row0 * D;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int e = tid + i * FUSED_THREADS; if (e < rows_here * D) xv[i] = src[e]; }
+    }
+    uint32_t step = p.step;
+    if (p.step_dev) step += *p.step_dev;
+    float4 w2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < nout * 64) w2v = *reinterpret_cast<const float4*>(p.params + br.w2 + (size_t)(tid >> 6) * WH + 4 * (tid & 63));
+    float smallv = 0.f;
+    if (tid >= 448 && tid < 448 + nout) smallv = p.params[br.b2 + tid - 448];
+    if (tid >= 456 && tid < 456 + A) smallv = p.params[p.log_std_off + tid - 456];
+    float4 w0f[3];
+    {
+        const float* w0 = p.params + br.w0 + (size_t)(wave * 32 + li) * D;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = 8 * q + 4 * lh;
+            w0f[q].x = k + 0 < D ? w0[k + 0] : 0.f;
+            w0f[q].y = k + 1 < D ? w0[k + 1] : 0.f;
+            w0f[q].z = k + 2 < D ? w0[k + 2] : 0.f;
+            w0f[q].w = k + 3 < D ? w0[k + 3] : 0.f;
+        }
+    }
+    const float b0v = p.params[br.b0 + wave * 32 + li], b1v = p.params[br.b1 + wave * 32 + li];
+    float4 pf[WQ];
+    {
+        const float* base = p.frag + (size_t)role * WH * WH + ((size_t)wave * WQ * 64 + lane) * 4;
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) pf[q] = *reinterpret_cast<const float4*>(base + frag_slot(q, wave, WQ, 1) * 256);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * FUSED_THREADS;
+        if (e < FT * D) { const int rr = e / D, kk = e - rr * D; xs[rr * WXLD + kk] = xv[i]; }
+    }
+    for (int e = tid; e < FT * (WXLD - D); e += FUSED_THREADS) {       // zero padding: columns D .. 27
+        const int rr = e / (WXLD - D), kk = D + e - rr * (WXLD - D);
+        xs[rr * WXLD + kk] = 0.f;
+    }
+    if (tid < nout * 64) *reinterpret_cast<float4*>(pimg + (tid >> 6) * WLD + 4 * (tid & 63)) = w2v;
+    if (tid >= 448 && tid < 448 + nout) pimg[WAM * WLD + tid - 448] = smallv;
+    if (tid >= 456 && tid < 456 + A) pimg[WAM * WLD + 8 + tid - 456] = smallv;
+    lds_barrier();
+
+    // ---- forward: same products, operand order and epilogues as ppo_wide_kernel
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* arow = xs + li * WXLD + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 af = *reinterpret_cast<const float4*>(arow + q * 8);
+            MFMA4(af, w0f[q], acc)
+        }
+        const int col = wave * 32 + li;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            h1[row * WLD + col] = act_apply_c<ACT>(acc[rr] + b0v);
+        }
+    }
+    lds_barrier();
+    {
+        const float* arow = h1 + li * WLD + 4 * lh;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int hq = 0; hq < WQ / 8; ++hq) {
+            float4 af[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) af[q] = *reinterpret_cast<const float4*>(arow + (hq * 8 + q) * 8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { MFMA4(af[q], pf[hq * 8 + q], acc) }
+        }
+        const int col = wave * 32 + li;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            h2[row * WLD + col] = act_apply_c<ACT>(acc[rr] + b1v);
+        }
+    }
+    lds_barrier();
+    // ---- heads (VALU, 16 threads per row)
+    float zmine = 0.f;                                  // head pre-activation `sub` of row r (actor), value (critic: sub 0)
+    {
+        float4 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(h2 + r * WLD + 4 * (sub + 16 * i));
+#pragma unroll
+        for (int j = 0; j < WAM; ++j) {
+            if (j < nout) {
+                float c = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 w = *reinterpret_cast<const float4*>(pimg + j * WLD + 4 * (sub + 16 * i));
+                    c += a[i].x * w.x + a[i].y * w.y + a[i].z * w.z + a[i].w * w.w;
+                }
+                const float zj = wrow16_sum(c) + pimg[WAM * WLD + j];
+                if (sub == j) zmine = zj;
+            }
+        }
+    }
+    const int e = row0 + r;
+    const bool row_ok = r < rows_here;
+    if (role == 0) {
+        if (row_ok && sub < A) {
+            const int j = sub;
+            const float mu = act_apply_c<OACT>(zmine);
+            uint32_t rn[4];
+            philox4x32(p.seed, (uint32_t)e, step, STREAM_GAUSS + (uint32_t)j, rn);
+            const float u1 = fmaxf(u01(rn[0]), 5.96e-8f), u2 = u01(rn[1]);
+            const float zn = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+            const float ls = pimg[WAM * WLD + 8 + j], sd = expf(ls);
+            const float x = mu + sd * zn;                  // Normal(mu, std).sample()
+            const float df = x - mu;
+            terms[r * 8 + j] = -(df * df) / (2.f * sd * sd) - logf(sd) - LOG_SQRT_2PI;
+            p.act_out[(size_t)e * A + j] = x;
+            if (p.env_action_f) p.env_action_f[(size_t)e * A + j] = x;
+        }
+        lds_barrier();
+        if (row_ok && sub == 0) {
+            float logp = 0.f;
+            for (int j = 0; j < A; ++j) logp += terms[r * 8 + j];
+            p.logp_out[e] = logp;
+        }
+    } else if (row_ok && sub == 0) {
+        if (e < n) { if (p.val_out) p.val_out[e] = zmine; }
+        else if (p.bootv_prev) p.bootv_prev[e - n] = zmine;
+    }
+}
+
+constexpr int WA_LDS_BYTES = (2 * FT * WLD + FT * WXLD + 8 + WAM * WLD + 16 + FT * 8) * 4;
+
 // frag[b][tile t][slot (q + t) mod 32][lane l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s]
 __global__ void __launch_bounds__(256) ppo_wide_pack_kernel(xrl_ppo_wide_t p, float* __restrict__ frag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;                // one float4 of the destination
@@ -462,6 +634,9 @@ static int wide_check(const xrl_ppo_wide_t* p) {
 
 int init_ppo_wide() {
 #define WIDE_ATTR(a, o) XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_wide_kernel<a, o>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES));
+    WIDE_FOR_EACH(WIDE_ATTR)
+#undef WIDE_ATTR
+#define WIDE_ATTR(a, o) XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_act_kernel<a, o>), hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS_BYTES));
     WIDE_FOR_EACH(WIDE_ATTR)
 #undef WIDE_ATTR
     return XRL_OK;
@@ -501,6 +676,32 @@ extern "C" int xrl_ppo_wide_minibatch(const xrl_ppo_wide_t* p, xrl_stream_t stre
 #define WIDE_LAUNCH(a, o)                                                                                                     \
     if (p->act == a && p->out_act == o)                                                                                       \
         hipLaunchKernelGGL((ppo_wide_kernel<a, o>), dim3(2 * n_tiles), dim3(FUSED_THREADS), W_LDS_BYTES, as_stream(stream), *p);
+    WIDE_FOR_EACH(WIDE_LAUNCH)
+#undef WIDE_LAUNCH
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream) {
+    XRL_CHECK_ARG(p != nullptr && p->params && p->frag && p->x && p->H == WH && p->D >= 1 && p->D <= 24 && p->A >= 1 && p->A <= WAM);
+    XRL_CHECK_ARG(p->n > 0 && (p->flags & 3) != 0 && wide_act_ok(p->act, p->out_act));
+    XRL_CHECK_ARG(!(p->flags & 1) || (p->act_out && p->logp_out));
+    XRL_CHECK_ARG(!(p->flags & 2) || p->bootv_prev);
+    XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->params) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->frag) & 15) == 0);
+    for (int b = 0; b < 2; ++b) XRL_CHECK_ARG(p->br[b].w1 % 4 == 0 && p->br[b].w2 % 4 == 0);
+    static bool inited = false;
+    if (!inited) {
+        int rc = init_ppo_wide();
+        if (rc != XRL_OK) return rc;
+        inited = true;
+    }
+    const bool acting = p->flags & 1, boot = p->flags & 2;
+    const int tiles_a = acting ? (p->n + FT - 1) / FT : 0;
+    const int c_rows = (boot ? 2 * p->n : p->n) - (acting ? 0 : p->n);
+    const int grid = tiles_a + (c_rows + FT - 1) / FT;
+#define WIDE_LAUNCH(a, o)                                                                                                     \
+    if (p->act == a && p->out_act == o)                                                                                       \
+        hipLaunchKernelGGL((wide_act_kernel<a, o>), dim3(grid), dim3(FUSED_THREADS), WA_LDS_BYTES, as_stream(stream), *p);
     WIDE_FOR_EACH(WIDE_LAUNCH)
 #undef WIDE_LAUNCH
     XRL_CHECK_LAUNCH();

@@ -427,6 +427,24 @@ class PpoWideState:
         d.params = (self.model.params.flat if flat is None else flat).data_ptr()
         call("xrl_ppo_wide_pack", C.byref(d), ptr(self.frag), stream_ptr())
 
+    def act(self, x, n, seed, step, step_dev, act_out=None, env_action_f=None, logp_out=None, val_out=None, bootv_prev=None):
+        """xrl_wide_act_step: sample / log-prob / value of rows [0, n) of x (when act_out is given) and the values of rows
+        [n, 2n) (when bootv_prev is given), one launch."""
+        a, d = getattr(self, "_act_desc", None), self.desc
+        if a is None:
+            a = self._act_desc = _lib.WideAct()
+            for b in range(2):
+                for f, _ in _lib.WideBranch._fields_:
+                    setattr(a.br[b], f, getattr(d.br[b], f))
+            a.log_std_off, a.D, a.A, a.H, a.act, a.out_act = d.log_std_off, d.D, d.A, d.H, d.act, d.out_act
+        as_ptr = lambda t: None if t is None else (t.data_ptr() if isinstance(t, torch.Tensor) else int(t))
+        a.params, a.frag = self.model.params.flat.data_ptr(), self.frag.data_ptr()
+        a.n, a.flags = int(n), (1 if act_out is not None else 0) | (2 if bootv_prev is not None else 0)
+        a.x, a.act_out, a.env_action_f, a.logp_out = as_ptr(x), as_ptr(act_out), as_ptr(env_action_f), as_ptr(logp_out)
+        a.val_out, a.bootv_prev = as_ptr(val_out), as_ptr(bootv_prev)
+        a.seed, a.step, a.step_dev = int(seed), int(step), as_ptr(step_dev)
+        call("xrl_wide_act_step", C.byref(a), stream_ptr())
+
     def launch(self, M, obs, actions, ret, adv, old_logp, slabs, slab_stride, partials, clip_range, vf_coef, ent_coef,
                stats=None, diag=None, heads=None, dbg=None, dbg_role=0):
         d = self.desc
