@@ -597,7 +597,7 @@ typedef struct {
 } xrl_wide_branch_t;
 typedef struct {
     const float* params;
-    const float* frag;                                 /* xrl_ppo_wide_pack image: [2][256*256] middle layers in B-fragment order */
+    const float* frag;                                 /* xrl_ppo_wide_pack image: [2][2][256*256] middle layers in B-fragment order */
     xrl_wide_branch_t br[2];                           /* 0: actor (D-256-256-A), 1: critic (D-256-256-1) */
     int32_t log_std_off;
     int32_t D, A, H;                                   /* D <= 24, A <= 8, H == 256 */
@@ -616,9 +616,11 @@ typedef struct {
     long long* dbg;                                    /* NULL, or [16] shader-clock stamps of the last tile's role dbg_role */
 } xrl_ppo_wide_t;
 int xrl_ppo_wide_minibatch(const xrl_ppo_wide_t* p, xrl_stream_t stream);
-/* frag[b][t][(q + t) mod 32][l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s] (b: branch, t: 32-row tile, q: 8-wide k-chunk,
- * l: lane): every prefetch instruction of a wave reads one contiguous 1 KB run.  Only params / br of *p are read;
- * frag holds 2*256*256 floats.  Kept current afterwards by the optimiser launch (xrl_mirrors_t map built from this layout). */
+/* frag[b][0][t][(q + t) mod 32][l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s]   forward section
+ * frag[b][1][t][(q + t) mod 32][l][s] = W1_b[8 q + 4 (l >> 5) + s][32 t + (l & 31)]   backward section (reduction index on k)
+ * (b: branch, t: 32-wide output tile, q: 8-wide chunk of the reduction index, l: lane): every prefetch instruction of a wave
+ * reads one contiguous 1 KB run.  Only params / br of *p are read; frag holds 4*256*256 floats.  Kept current afterwards by
+ * the optimiser launch (two xrl_mirrors_t maps built from this layout: one per section). */
 int xrl_ppo_wide_pack(const xrl_ppo_wide_t* p, float* frag, xrl_stream_t stream);
 /* Acting step of the same network class in ONE launch (replaces three grouped GEMM launches + xrl_policy_sample of the layered
  * rollout step; on_policy agent: policy(obs) -> stochastic_sample / log_prob / values, ppo_agent.py:97-135): x holds 2n
@@ -643,6 +645,17 @@ typedef struct {
     uint64_t seed;
     uint32_t step, pad0;
     const uint32_t* step_dev;
+    /* Optional: rows [0, n) from RAW observations -- RunningMeanStd.update + _process_observation inside this launch
+     * (what xrl_obs_normalize does, the same arithmetic; statistic_tools.py:117-185, agent.py:262-283).  raw != NULL: rows
+     * [0, n) of x are ignored; the statistics are read from *_in and written to *_out (different buffers: the workgroups
+     * of a launch read the old ones while one of them stores the new ones -- the caller alternates two sets);
+     * n <= 4 * floor(1024 / D). */
+    const float* raw;                                  /* NULL or [n][D] */
+    const float* mean_in; const float* var_in; const double* count_in;
+    float* mean_out; float* var_out; double* count_out;
+    float* obs_slot;                                   /* NULL or [n][D]: the normalised rows (the rollout buffer's slot) */
+    int32_t update, normalize;                         /* as xrl_rms_t */
+    float range, pad1;
 } xrl_wide_act_t;
 int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream);
 /* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */

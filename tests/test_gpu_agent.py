@@ -501,6 +501,19 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph):
         assert_close(npy(got[k_]), val, 1e-5, f"param {k_}")
     assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss")
     assert_close(info["actor_loss"], oi["a_loss"], 1e-5, "actor_loss")
+    if wide:
+        # running statistics + normalisation inside the acting launch == xrl_obs_normalize as a launch of its own, bit for bit
+        torch.manual_seed(0)
+        cfg2 = make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
+                           critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1,
+                           n_minibatch=2, ent_coef=0.0, gamma=0.99, use_hip_graph=False, use_fused_obsnorm=False)
+        b = PPO_Agent(cfg2, SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=10))
+        assert agent._wstats is not None and b._wide_acting() is not None and b._wstats is None
+        b.rollout()
+        torch.cuda.synchronize()
+        f2 = {k: npy(v) for k, v in b.memory.soa.fields.items()}
+        for k in ("observations", "actions", "values", "aux_old_logp", "rewards", "advantages", "returns", "bootv"):
+            assert np.array_equal(f[k], f2[k]), k
     if wide:                            # the optimiser launch kept the fragment-ordered copy of the middle layers current
         lr = agent.learner
         fr = lr._wide.frag.clone()

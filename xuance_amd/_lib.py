@@ -206,7 +206,10 @@ class WideAct(C.Structure):
                 ("D", c_int32), ("A", c_int32), ("H", c_int32), ("act", c_int32), ("out_act", c_int32),
                 ("n", c_int32), ("flags", c_int32), ("x", c_void_p), ("act_out", c_void_p), ("env_action_f", c_void_p),
                 ("logp_out", c_void_p), ("val_out", c_void_p), ("bootv_prev", c_void_p), ("seed", C.c_uint64),
-                ("step", C.c_uint32), ("pad0", C.c_uint32), ("step_dev", c_void_p)]
+                ("step", C.c_uint32), ("pad0", C.c_uint32), ("step_dev", c_void_p),
+                ("raw", c_void_p), ("mean_in", c_void_p), ("var_in", c_void_p), ("count_in", c_void_p),
+                ("mean_out", c_void_p), ("var_out", c_void_p), ("count_out", c_void_p), ("obs_slot", c_void_p),
+                ("update", c_int32), ("normalize", c_int32), ("range", c_float), ("pad1", c_float)]
 
 
 class QfImage(C.Structure):

@@ -119,15 +119,25 @@ class PPO_Agent(AgentSurface):
         env, mem, n, D, A = self.envs, self.memory, self.n_envs, self.obs_dim, self.model.action_dim
         f = mem.soa.fields
         gaussian = self.model.dist == "gaussian"
-        # obs_rms.update(obs); obs = _process_observation(obs); memory.observations[t] = obs   (ppo_agent.py:114-115,128)
-        ops.obs_normalize(x=env.buf_obs, mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=self.X,
-                          out1=f["observations"][t], n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(self.use_obsnorm),
-                          normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
         wide = self._wide_acting()
+        fold = wide is not None and self._wstats is not None
+        stats = (self.obs_mean, self.obs_var, self.obs_count)
+        if not fold:
+            # obs_rms.update(obs); obs = _process_observation(obs); memory.observations[t] = obs   (ppo_agent.py:114-115,128)
+            ops.obs_normalize(x=env.buf_obs, mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=self.X,
+                              out1=f["observations"][t], n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(self.use_obsnorm),
+                              normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
         if wide is not None:
-            # forward of both branches + sample + log-prob + values in ONE launch (csrc/ppo_wide.hip: wide_act_kernel)
+            # forward of both branches + sample + log-prob + values in ONE launch (csrc/ppo_wide.hip: wide_act_kernel); with
+            # `fold` the running statistics + normalisation as well (two statistics sets alternate: the workgroups of a
+            # launch read one while the other is written; horizon_size is even, so set 0 is current between rollouts)
+            kw = {}
+            if fold:
+                stats = self._wstats[(t + 1) & 1]
+                kw = dict(raw=env.buf_obs, stats_in=self._wstats[t & 1], stats_out=stats, obs_slot=f["observations"][t],
+                          update=int(self.use_obsnorm), normalize=int(self.use_obsnorm), obs_range=float(self.obsnorm_range))
             wide.act(self.X, n, self.seed, t, self.step_counter, act_out=f["actions"][t], env_action_f=env.action,
-                     logp_out=f["aux_old_logp"][t], val_out=f["values"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None)
+                     logp_out=f["aux_old_logp"][t], val_out=f["values"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None, **kw)
         else:
             heads = self.model.forward(self.X, 2 * n)
             # actions / log-probs / values of rows [0,n) -> buffer slot t; value of rows [n,2n) -> bootv[t-1]
@@ -141,7 +151,7 @@ class PPO_Agent(AgentSurface):
         else:
             env.step_device()
         ops.rollout_poststep(reward=env.reward, terminated=env.terminated, truncated=env.truncated, next_obs=env.next_obs,
-                             obs_mean=self.obs_mean, obs_var=self.obs_var, next_obs_norm=self.X[n:], rew_out=f["rewards"][t],
+                             obs_mean=stats[0], obs_var=stats[1], next_obs_norm=self.X[n:], rew_out=f["rewards"][t],
                              term_out=f["terminals"][t], seg_out=f["seg"][t], ret_track=self.returns,
                              ret_mean=self.ret_mean, ret_var=self.ret_var, ret_count=self.ret_count, n=n, D=D, ld_next=D,
                              use_obsnorm=int(self.use_obsnorm), use_rewnorm=int(self.use_rewnorm),
@@ -325,6 +335,14 @@ class PPO_Agent(AgentSurface):
             if ok:
                 lr._wide_prepare(self.batch_size)
             self._wact = lr._wide if ok else None
+            # running statistics + normalisation inside the acting launch: needs a second statistics set, an even horizon
+            # (set 0 = obs_mean / obs_var / obs_count is then current whenever the host looks) and few enough rows
+            self._wstats = None
+            D = self.obs_dim
+            if ok and bool(_get(self.config, "use_fused_obsnorm", True)) and self.horizon_size % 2 == 0 and \
+                    self.n_envs <= 4 * (1024 // D) and tuple(self.envs.buf_obs.shape) == (self.n_envs, D):
+                self._wstats = [(self.obs_mean, self.obs_var, self.obs_count),
+                                (torch.zeros_like(self.obs_mean), torch.ones_like(self.obs_var), torch.zeros_like(self.obs_count))]
         return self._wact
 
     def _rollout_state_tensors(self):

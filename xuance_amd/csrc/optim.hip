@@ -340,8 +340,15 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned left = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_fail = (left == gridDim.x - 1) ? 2 : 0;                // (re-used as "this is the last block out")
+        if (need_norm) {
+            // every block read the optimiser state BEFORE it published its flag, so whoever is past the barrier may advance
+            // it: block 0 does, and nobody takes a ticket (one read-modify-write on ONE address per block serialises: with
+            // the 558 blocks of the MuJoCo network that chain was several microseconds long)
+            s_fail = blockIdx.x == 0 ? 2 : 0;
+        } else {
+            const unsigned left = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_fail = (left == gridDim.x - 1) ? 2 : 0;            // (re-used as "this is the last block out")
+        }
     }
     __syncthreads();
     if (s_fail == 2) {                                          // last block out: reset the counter, advance the state

@@ -7,11 +7,13 @@
 // Mapping (see ppo_fast.hip for the measurements behind the rules):
 //   * workgroup = (32-row tile, branch): the two branches share nothing but the rows, so a 4 096-row minibatch is
 //     128 tiles x 2 = 256 workgroups, one per CU; both roles write disjoint parameter ranges of the tile's slab row.
-//   * the 256 KB middle-layer weights arrive as ONE stream of B fragments (fragment-ordered copy kept current by the
-//     optimiser launch, xrl_ppo_wide_pack) that is issued first and stays in registers: 32 float4 per lane.  A CU pulls
-//     ~10 B/clk from L2, i.e. this stream lasts as long as the forward layer's matrix work; a second stream for the
-//     backward pass (W^T) would double it, so backward-data re-uses the forward fragments through LDS, one wave's
-//     32 rows (32 KB) per stage, two stage buffers (the dead h2 region and a dedicated one).
+//   * the 256 KB middle-layer weights arrive as a stream of B fragments (fragment-ordered copy kept current by the
+//     optimiser launch, xrl_ppo_wide_pack) that is issued first and lands in registers: 32 float4 per lane.  A CU pulls
+//     ~10 B/clk from L2, i.e. this stream lasts as long as the forward layer's matrix work.  Backward-data needs the
+//     transposed fragments: a SECOND stream (the copy's backward section) into the same registers, issued the moment the
+//     forward layer has consumed them -- it has the head / loss / weight-gradient phases (~30 k cycles, no global loads)
+//     to arrive.  (First version: forward fragments transposed through LDS in eight 32 KB stages: 28-37 k cycles for
+//     16 k cycles of matrix work, the stage writes and barriers could not be hidden.)
 //   * 8 waves, wave w owns output columns [32 w, 32 w + 32) of every 256-wide product -- forward, backward-data and the
 //     rows [32 w, ..) of dW1 -- so no split-K partial tiles are needed anywhere.
 //   * first layer (K = D <= 24) on the matrix cores too, B fragments read straight from the parameters.
@@ -27,9 +29,10 @@ namespace xrl {
 constexpr int WH = 256;                       // hidden width
 constexpr int WLD = WH + 4;                   // row stride of the 256-wide levels
 constexpr int WQ = WH / 8;                    // k-chunks of the middle layer
+constexpr int WQ_EARLY = 24;                  // backward chunks requested right after the forward layer
 constexpr int WXLD = 28;                      // row stride of the observation tile (D <= 24, zero padded)
 constexpr int WAM = 8;                        // max action dims
-constexpr int W_H1 = 0, W_H2 = W_H1 + FT * WLD, W_G2 = W_H2 + FT * WLD, W_ST = W_G2 + FT * WLD, W_XS = W_ST + 32 * WH,
+constexpr int W_H1 = 0, W_H2 = W_H1 + FT * WLD, W_G2 = W_H2 + FT * WLD, W_XS = W_G2 + FT * WLD,
               W_RSC = W_XS + FT * WXLD + 8, W_DZH = W_RSC + FT * 16, W_IMG = W_DZH + FT * 16,
               W_STAT = W_IMG + WAM * WLD + 16, W_LDS_FLOATS = W_STAT + 5 * FT * 2;
 constexpr int W_LDS_BYTES = W_LDS_FLOATS * 4;
@@ -46,15 +49,31 @@ __device__ __forceinline__ float wrow16_sum(float v) {
     return v;
 }
 
+// One B-fragment chunk through a buffer descriptor: the per-lane part of the address is ONE 32-bit register shared by all 32
+// chunks, the chunk's place (wave-uniform: section, tile, rotated slot) rides in the scalar offset.  With flat loads hipcc
+// keeps a 64-bit address pair per chunk alive (64 VGPRs next to the 128 the fragments occupy -> spills, and a spill of an
+// in-flight fragment is a full s_waitcnt vmcnt(0) in the middle of the stream).
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 wfrag_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const wu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wfrag_rsrc(const float* frag) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(frag), 0, 4 * WH * WH * 4, 0x00020000);
+}
+// byte offset of chunk q of output tile `wave` in section sec (0 forward, 1 backward) of branch `role`
+__device__ __forceinline__ int wfrag_soff(int role, int sec, int wave, int q) {
+    return ((role * 2 + sec) * WH * WH + (wave * WQ + frag_slot(q, wave, WQ, 1)) * 256) * 4;
+}
+
 #define WSTAMP(k) do { if (dbg_me) p.dbg[k] = clock64(); } while (0)
 
 template <int ACT, int OACT>
 __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* h1 = lds + W_H1;                            // [32][260] first hidden level; later dLoss/d(its pre-activation)
-    float* h2 = lds + W_H2;                            // [32][260] second hidden level; later stage buffer 0
+    float* h2 = lds + W_H2;                            // [32][260] second hidden level
     float* g2 = lds + W_G2;                            // [32][260] dLoss/d(pre-activation of h2)
-    float* stg = lds + W_ST;                           // [32][256] stage buffer 1
     float* xs = lds + W_XS;                            // [32][28] observations (columns D.. zero)
     float* rsc = lds + W_RSC;                          // [32][16] action[0..7] | ret | adv | old_logp
     float* dzh = lds + W_DZH;                          // [32][16] dLoss/d(head pre-activations)[0..7] | d log_std terms[0..7]
@@ -120,11 +139,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
     }
     const float b0v = p.params[br.b0 + wave * 32 + li], b1v = p.params[br.b1 + wave * 32 + li];
     float4 pf[WQ];                                      // B fragments of W1: output tile `wave`, all 32 k-chunks
-    {
-        const float* base = p.frag + (size_t)role * WH * WH + ((size_t)wave * WQ * 64 + lane) * 4;
+    const __amdgpu_buffer_rsrc_t frs = wfrag_rsrc(p.frag);
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) pf[q] = *reinterpret_cast<const float4*>(base + frag_slot(q, wave, WQ, 1) * 256);
-    }
+    for (int q = 0; q < WQ; ++q) pf[q] = wfrag_load(frs, lane * 16, wfrag_soff(role, 0, wave, q));
     // hand the small things over through LDS
     if (tid < 192) {
         if (tid < 8 * D) {
@@ -194,19 +211,31 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
             h2[row * WLD + col] = act_apply_c<ACT>(acc[rr] + b1v);
         }
+        // the forward fragments are consumed: the same registers take the backward section (W1 with the reduction index
+        // n on the fragment's k axis: lane (li, lh) of chunk q holds W1[8 q + 4 lh + s][32 wave + li]), needed at dH1
+        // (the scheduler must not lift these loads into the loop above: a fragment register would then have to hold its old
+        //  and its new value at once, and the one that does not fit is spilled behind an s_waitcnt vmcnt(0))
+        // Chunks 0 .. WQ_EARLY - 1 now; the rest when dH1 starts (their latency hides behind the first chunks' matrix work):
+        // all 32 in flight through the loss / weight-gradient phases left those phases too few registers.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < WQ_EARLY; ++q) pf[q] = wfrag_load(frs, lane * 16, wfrag_soff(role, 1, wave, q));
+        __builtin_amdgcn_sched_barrier(0);
     }
     lds_barrier();                                                                                   // #2 h2
     WSTAMP(3);
 
-    // ================= head forward (VALU, 16 threads per row), loss, head backward
+    // ================= head forward (VALU, 16 threads per row), loss, head backward.  The 16 threads of a row all hold the
+    // row's head pre-activations after the DPP all-reduce; the per-dimension work of the Gaussian loss (tanh, the log-prob
+    // term, the gradient of mu and log_std) is spread over them -- thread `sub` owns action dim `sub` -- instead of
+    // every thread evaluating all of it (measured: 15.2 k cycles for the actor role, 4 k for the critic's single output).
     {
         float4 a[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(h2 + r * WLD + 4 * (sub + 16 * i));
-        float z[WAM];
+        float zmine = 0.f, z0 = 0.f;
 #pragma unroll
         for (int j = 0; j < WAM; ++j) {
-            z[j] = 0.f;
             if (j < nout) {
                 float c = 0.f;
 #pragma unroll
@@ -214,68 +243,60 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
                     const float4 w = *reinterpret_cast<const float4*>(pimg + j * WLD + 4 * (sub + 16 * i));
                     c += a[i].x * w.x + a[i].y * w.y + a[i].z * w.z + a[i].w * w.w;
                 }
-                z[j] = wrow16_sum(c) + pimg[WAM * WLD + j];
+                const float zj = wrow16_sum(c) + pimg[WAM * WLD + j];
+                if (sub == j) zmine = zj;
+                if (j == 0) z0 = zj;
             }
         }
-        float dz[WAM];
-#pragma unroll
-        for (int j = 0; j < WAM; ++j) dz[j] = 0.f;
-        float gls[WAM];
-#pragma unroll
-        for (int j = 0; j < WAM; ++j) gls[j] = 0.f;
+        float my_dz = 0.f, my_gls = 0.f;                // dLoss/d(head pre-activation `sub`), d log_std term `sub` of this row
         double t_s = 0.0, t_c = 0.0, t_e = 0.0, t_v = 0.0, t_n = 0.0;
         const float invM = 1.f / (float)M;
         if (role == 0) {
-            float mu[WAM];
-#pragma unroll
-            for (int j = 0; j < WAM; ++j) mu[j] = j < A ? act_apply_c<OACT>(z[j]) : 0.f;         // activation_action
+            const bool mine = sub < A;
+            float mu = 0.f, df = 0.f, var = 1.f, term = 0.f, entj = 0.f;
+            if (mine) {
+                mu = act_apply_c<OACT>(zmine);                                                      // activation_action
+                const float ls = pimg[WAM * WLD + 8 + sub], sd = expf(ls);
+                var = sd * sd; df = rsc[r * 16 + sub] - mu;
+                term = -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;                          // Normal.log_prob of this dim
+                entj = 0.5f + LOG_SQRT_2PI + logf(sd);                                              // Normal.entropy of this dim
+            }
+            const float logp = wrow16_sum(term), ent = wrow16_sum(entj);                            // summed over the action dims
             if (row_ok) {
                 float adv = rsc[r * 16 + 9];
                 const float old_lp = rsc[r * 16 + 10];
                 asm volatile("" : "+v"(st_std));        // keeps hipcc from consuming the statistics (and waiting) at the top
                 if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, st_mean), st_std + 1e-8f);             // memory_tools.py:281-282
                 const float lo = (float)(1.0 - (double)p.clip_range), hi = (float)(1.0 + (double)p.clip_range);
-                float logp = 0.f, ent = 0.f;
-#pragma unroll
-                for (int j = 0; j < WAM; ++j) {
-                    if (j < A) {
-                        const float ls = pimg[WAM * WLD + 8 + j], sd = expf(ls), var = sd * sd, df = rsc[r * 16 + j] - mu[j];
-                        logp += -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;               // Normal.log_prob, summed
-                        ent += 0.5f + LOG_SQRT_2PI + logf(sd);                                     // Normal.entropy, summed
-                    }
-                }
                 const Surrogate s = surrogate(logp, old_lp, adv, lo, hi, invM);
-#pragma unroll
-                for (int j = 0; j < WAM; ++j) {
-                    if (j < A) {
-                        const float ls = pimg[WAM * WLD + 8 + j], sd = expf(ls), var = sd * sd, df = rsc[r * 16 + j] - mu[j];
-                        const float gmu = s.dlogp * df / var;
-                        gls[j] = s.dlogp * (df * df / var - 1.f);
-                        dz[j] = gmu * act_grad_c<OACT>(mu[j]);
-                    }
+                if (mine) {
+                    const float gmu = s.dlogp * df / var;
+                    my_gls = s.dlogp * (df * df / var - 1.f);
+                    my_dz = gmu * act_grad_c<OACT>(mu);
+                    if (p.heads) p.heads[(size_t)m_row * (A + 1) + sub] = mu;
                 }
                 t_s = (double)fminf(s.s1, s.s2); t_n = s.clipped; t_e = ent;
                 if (p.diag && sub == 0) {
                     const int m = m_row;
                     p.diag[m] = logp; p.diag[M + m] = s.ratio; p.diag[2 * (size_t)M + m] = s.s1; p.diag[3 * (size_t)M + m] = s.s2;
                 }
-                if (p.heads && sub == 0) {
-#pragma unroll
-                    for (int j = 0; j < WAM; ++j)
-                        if (j < A) p.heads[(size_t)m_row * (A + 1) + j] = mu[j];
-                }
             }
         } else if (row_ok) {
-            const float v = z[0], dv = v - rsc[r * 16 + 8];
-            if (p.heads && sub == 0) p.heads[(size_t)m_row * (A + 1) + A] = v;
-            dz[0] = p.vf_coef * 2.f * dv * invM;                                                    // d(vf * mean((v-ret)^2))/dv
+            const float v = z0, dv = v - rsc[r * 16 + 8];
+            if (sub == 0) {
+                my_dz = p.vf_coef * 2.f * dv * invM;                                                // d(vf * mean((v-ret)^2))/dv
+                if (p.heads) p.heads[(size_t)m_row * (A + 1) + A] = v;
+            }
             t_c = (double)dv * dv; t_v = v;
         }
+        if (sub < 8) { dzh[r * 16 + sub] = my_dz; dzh[r * 16 + 8 + sub] = my_gls; }
         if (sub == 0) {
-#pragma unroll
-            for (int j = 0; j < WAM; ++j) { dzh[r * 16 + j] = dz[j]; dzh[r * 16 + 8 + j] = gls[j]; }
             rowstat[0 * FT + r] = t_s; rowstat[1 * FT + r] = t_c; rowstat[2 * FT + r] = t_e; rowstat[3 * FT + r] = t_v; rowstat[4 * FT + r] = t_n;
         }
+        // the row's 16 threads sit in one wave and a wave's LDS operations execute in order: the values are there
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float4 d0 = *reinterpret_cast<const float4*>(dzh + r * 16), d1 = *reinterpret_cast<const float4*>(dzh + r * 16 + 4);
+        const float dz[WAM] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
         // dH2 = dZ . W2, times act'(h2): this thread's four k-chunks
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -330,78 +351,60 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
         }
     }
     WSTAMP(5);
-    // ---- dW1[n][k] = sum_rows g2[row][n] * h1[row][k]: wave w owns rows n in [32 w, 32 w + 32), 8 column tiles in two passes
+    // ---- dW1[n][k] = sum_rows g2[row][n] * h1[row][k]: wave w owns rows n in [32 w, 32 w + 32), 8 column tiles in four
+    //      passes of two (32 accumulator registers at a time: the backward fragments in flight hold 128)
     {
         const float* arow = g2 + lh * WLD + wave * 32 + li;             // A[i = n][k = row]
         const float* brow = h1 + lh * WLD + li;                         // B[k = row][j]
         float* dW = slab + br.w1 + (size_t)(wave * 32) * WH;
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            f32x16 acc[4];
+        for (int pass = 0; pass < 4; ++pass) {
+            f32x16 acc[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #pragma unroll
             for (int s = 0; s < FT / 2; ++s) {
                 const float av = arow[2 * s * WLD];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float bv = brow[2 * s * WLD + (half * 4 + t) * 32];
+                for (int t = 0; t < 2; ++t) {
+                    const float bv = brow[2 * s * WLD + (pass * 2 + t) * 32];
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) {
                     const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                    dW[(size_t)row * WH + (half * 4 + t) * 32 + li] = acc[t][rr];
+                    dW[(size_t)row * WH + (pass * 2 + t) * 32 + li] = acc[t][rr];
                 }
         }
     }
     WSTAMP(6);
-    // ---- dH1 = g2 . W1, wave w owns output columns k in [32 w, 32 w + 32).  The B operand (W1 with the reduction index n on
-    //      the MFMA's k axis) comes from the forward fragments through LDS: stage j = rows n in [32 j, 32 j + 32) = the
-    //      fragments of wave j, written as the float4s they are (4-float groups XOR-swizzled by the row so that rows do not
-    //      collide) and read back as the four scalars of an MFMA4 (lanes = consecutive k: conflict-free).
+    // ---- dH1 = g2 . W1, wave w owns output columns k in [32 w, 32 w + 32): the same loop as the forward layer with the
+    //      backward fragments (in flight since the forward layer finished)
     {
         const float* arow = g2 + li * WLD + 4 * lh;
         const int k_out = wave * 32 + li;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 1
-        for (int jp = 0; jp < 4; ++jp) {                                // stages 2 jp (buffer h2) and 2 jp + 1 (buffer stg)
-            lds_barrier();                                              // buffers free (first: h2 / h1's readers are done)
-            if ((wave >> 1) == jp) {
-                float* T = (wave & 1) ? stg : h2;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int qq = 0; qq < WQ; ++qq)                         // W1[n][8 qq + 4 lh .. + 3] -> group 2 qq + lh of row li
-                    *reinterpret_cast<float4*>(T + li * WH + (((2 * qq + lh) ^ li) << 2)) = pf[qq];
-            }
-            lds_barrier();                                              // stages visible
+        for (int q = WQ_EARLY; q < WQ; ++q) pf[q] = wfrag_load(frs, lane * 16, wfrag_soff(role, 1, wave, q));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const float* T = jj ? stg : h2;
-                const int j = 2 * jp + jj;
-                float4 af[4], bt[4];
+        for (int hq = 0; hq < WQ / 8; ++hq) {
+            float4 af[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    af[i] = *reinterpret_cast<const float4*>(arow + (4 * j + i) * 8);   // n-chunk 4 j + i
-                    float bs[4];
+            for (int q = 0; q < 8; ++q) af[q] = *reinterpret_cast<const float4*>(arow + (hq * 8 + q) * 8);
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const int nr = 8 * i + 4 * lh + s4;            // row of the stage
-                        bs[s4] = T[nr * WH + ((((k_out >> 2) ^ nr) << 2) | (k_out & 3))];
-                    }
-                    bt[i] = make_float4(bs[0], bs[1], bs[2], bs[3]);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { MFMA4(af[i], bt[i], acc) }
-            }
+            for (int q = 0; q < 8; ++q) { MFMA4(af[q], pf[hq * 8 + q], acc) }
         }
-        // g1 = dH1 * act'(h1), in place (h1's other readers finished before the first stage barrier)
+        lds_barrier();                                                  // every wave is done with h1 (dW1's B operand)
+        // g1 = dH1 * act'(h1), in place
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
@@ -450,8 +453,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
 template <int ACT, int OACT>
 __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* h1 = lds;                                   // [32][260]
-    float* h2 = h1 + FT * WLD;                         // [32][260]
+    float* h1 = lds;                                   // [32][260]  (before the first layer: the statistics' partial sums)
+    float* h2 = h1 + FT * WLD;                         // [32][260]  (before the first layer: batch / running moments)
     float* xs = h2 + FT * WLD;                         // [32][28]
     float* pimg = xs + FT * WXLD + 8;                  // head weights [nout][260] | head bias[8] | log_std[8]
     float* terms = pimg + WAM * WLD + 16;              // [32][8] per-dim log-prob terms
@@ -472,11 +475,35 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     br.w1 = role ? p.br[1].w1 : p.br[0].w1; br.b1 = role ? p.br[1].b1 : p.br[0].b1;
     br.w2 = role ? p.br[1].w2 : p.br[0].w2; br.b2 = role ? p.br[1].b2 : p.br[0].b2;
     const int nout = role == 0 ? A : 1;
+    // rows [0, n) may come as RAW observations: RunningMeanStd.update + _process_observation happen here then (every
+    // workgroup that owns such rows forms the same statistics from all n rows; the first actor workgroup stores them)
+    const bool from_raw = p.raw != nullptr && row0 < n;
+    const bool stats_writer = from_raw && blockIdx.x == 0;
 
     // ---- loads: small things first, then the weight stream
+    constexpr int RV = 4;                               // rows per virtual thread of the statistics (host checks n <= RV * (1024 / D))
+    const int R = 1024 / D;
+    float rawv[2][RV];
+    float old_mean = 0.f, old_var = 1.f;
+    double old_cnt = 0.0;
+    if (from_raw) {
+        if (p.update) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int vt = tid + v * FUSED_THREADS, d = vt % D, r0 = vt / D;
+#pragma unroll
+                for (int k = 0; k < RV; ++k) {
+                    const int rr = r0 + k * R;
+                    rawv[v][k] = (r0 < R && rr < n) ? p.raw[(size_t)rr * D + d] : 0.f;
+                }
+            }
+        }
+        if (tid < D) { old_mean = p.mean_in[tid]; old_var = p.var_in[tid]; }
+        old_cnt = *p.count_in;
+    }
     float xv[2] = {0.f, 0.f};
     {
-        const float* src = p.x + (size_t)row0 * D;
+        const float* src = (from_raw ? p.raw : p.x) + (size_t)row0 * D;
 #pragma unroll
         for (int i = 0; i < 2; ++i) { const int e = tid + i * FUSED_THREADS; if (e < rows_here * D) xv[i] = src[e]; }
     }
@@ -501,10 +528,87 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     }
     const float b0v = p.params[br.b0 + wave * 32 + li], b1v = p.params[br.b1 + wave * 32 + li];
     float4 pf[WQ];
-    {
-        const float* base = p.frag + (size_t)role * WH * WH + ((size_t)wave * WQ * 64 + lane) * 4;
+    const __amdgpu_buffer_rsrc_t frs = wfrag_rsrc(p.frag);
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) pf[q] = *reinterpret_cast<const float4*>(base + frag_slot(q, wave, WQ, 1) * 256);
+    for (int q = 0; q < WQ; ++q) pf[q] = wfrag_load(frs, lane * 16, wfrag_soff(role, 0, wave, q));
+
+    if (from_raw) {
+        // RunningMeanStd.update (statistic_tools.py:117-185) with the arithmetic of rms_normalize_kernel (rollout.hip): its
+        // 1 024 threads are this workgroup's threads twice over; every sum runs in the same order, in float64
+        double* part = reinterpret_cast<double*>(h1);                  // [1024]
+        double* bmean = reinterpret_cast<double*>(h2);                 // [32]
+        double* bvar = bmean + 32;                                     // [32]
+        float* s_mean = reinterpret_cast<float*>(bvar + 32);           // [32]
+        float* s_std = s_mean + 32;                                    // [32]
+        if (p.update) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int vt = tid + v * FUSED_THREADS, r0 = vt / D;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < RV; ++k) if (r0 < R && r0 + k * R < n) acc += (double)rawv[v][k];
+                part[vt] = r0 < R ? acc : 0.0;
+            }
+            lds_barrier();
+            if (tid < D) {
+                double t = 0.0;
+                for (int rr = 0; rr < R; ++rr) t += part[rr * D + tid];
+                bmean[tid] = (double)(float)(t / n);                   // np.mean returns float32
+            }
+            lds_barrier();
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int vt = tid + v * FUSED_THREADS, d = vt % D, r0 = vt / D;
+                double q = 0.0;
+                if (r0 < R) {
+                    const double m = bmean[d];
+#pragma unroll
+                    for (int k = 0; k < RV; ++k) if (r0 + k * R < n) { const double df = (double)rawv[v][k] - m; q += df * df; }
+                }
+                part[vt] = r0 < R ? q : 0.0;
+            }
+            lds_barrier();
+            if (tid < D) {
+                double t = 0.0;
+                for (int rr = 0; rr < R; ++rr) t += part[rr * D + tid];
+                const float bstd = (float)sqrt(t / n);                 // np.std -> float32
+                const float bv = bstd * bstd;                          // batch_var = np.square(batch_std)
+                // update_from_moments (statistic_tools.py:173-185), float32 arrays with a Python-float count
+                const double tot = old_cnt + (double)n;
+                const float bm = (float)bmean[tid];
+                const float delta = bm - old_mean;
+                const float new_mean = old_mean + delta * (float)n / (float)tot;
+                const float m_a = old_var * (float)old_cnt;
+                const float m_b = bv * (float)n;
+                const float M2 = m_a + m_b + (delta * delta) * (float)old_cnt * (float)n / (float)tot;
+                const float new_var = M2 / (float)tot;
+                if (stats_writer) { p.mean_out[tid] = new_mean; p.var_out[tid] = new_var; }
+                s_mean[tid] = new_mean; s_std[tid] = sqrtf(new_var);
+            }
+            if (stats_writer && tid == 0) *p.count_out = old_cnt + (double)n;
+        } else {
+            if (tid < D) {
+                s_mean[tid] = old_mean; s_std[tid] = sqrtf(old_var);
+                if (stats_writer) { p.mean_out[tid] = old_mean; p.var_out[tid] = old_var; }
+            }
+            if (stats_writer && tid == 0) *p.count_out = old_cnt;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * FUSED_THREADS;
+            if (e < rows_here * D) {
+                const int d = e % D;
+                float v = xv[i];
+                if (p.normalize) {
+                    v = (v - s_mean[d]) / (s_std[d] + 1e-8f);          // _process_observation (agent.py:262-283)
+                    v = fminf(fmaxf(v, -p.range), p.range);
+                }
+                xv[i] = v;
+                if (p.obs_slot) p.obs_slot[(size_t)row0 * D + e] = v;
+            }
+        }
+        lds_barrier();                                                  // the scratch regions become h1 / h2 again
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -611,16 +715,24 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
 
 constexpr int WA_LDS_BYTES = (2 * FT * WLD + FT * WXLD + 8 + WAM * WLD + 16 + FT * 8) * 4;
 
-// frag[b][tile t][slot (q + t) mod 32][lane l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s]
+// frag[b][0][tile t][slot (q + t) mod 32][lane l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s]      (forward section)
+// frag[b][1][tile t][slot (q + t) mod 32][lane l][s] = W1_b[8 q + 4 (l >> 5) + s][32 t + (l & 31)]      (backward section)
 __global__ void __launch_bounds__(256) ppo_wide_pack_kernel(xrl_ppo_wide_t p, float* __restrict__ frag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;                // one float4 of the destination
-    if (i >= 2 * WH * WH / 4) return;
-    const int b = i / (WH * WH / 4), e = i - b * (WH * WH / 4);
+    if (i >= 4 * WH * WH / 4) return;
+    const int sec = i / (WH * WH / 4), e = i - sec * (WH * WH / 4);
+    const int b = sec >> 1, bwd = sec & 1;
     const int l = e & 63, slot = (e >> 6) & (WQ - 1), t = e >> 11;
     const int q = (slot - t + WQ) & (WQ - 1);
     const int w1 = b ? p.br[1].w1 : p.br[0].w1;
-    const float* src = p.params + w1 + (size_t)(32 * t + (l & 31)) * WH + 8 * q + 4 * (l >> 5);
-    *reinterpret_cast<float4*>(frag + (size_t)i * 4) = *reinterpret_cast<const float4*>(src);
+    float4 v;
+    if (!bwd) {
+        v = *reinterpret_cast<const float4*>(p.params + w1 + (size_t)(32 * t + (l & 31)) * WH + 8 * q + 4 * (l >> 5));
+    } else {
+        const float* src = p.params + w1 + (size_t)(8 * q + 4 * (l >> 5)) * WH + 32 * t + (l & 31);
+        v = make_float4(src[0], src[WH], src[2 * WH], src[3 * WH]);
+    }
+    *reinterpret_cast<float4*>(frag + (size_t)i * 4) = v;
 }
 
 static int wide_check(const xrl_ppo_wide_t* p) {
@@ -654,7 +766,7 @@ extern "C" int xrl_ppo_wide_pack(const xrl_ppo_wide_t* p, float* frag, xrl_strea
     int rc = wide_check(p);
     if (rc != XRL_OK) return rc;
     XRL_CHECK_ARG(frag != nullptr && (reinterpret_cast<uintptr_t>(p->params) & 15) == 0);
-    hipLaunchKernelGGL(ppo_wide_pack_kernel, dim3(2 * WH * WH / 4 / 256), dim3(256), 0, as_stream(stream), *p, frag);
+    hipLaunchKernelGGL(ppo_wide_pack_kernel, dim3(4 * WH * WH / 4 / 256), dim3(256), 0, as_stream(stream), *p, frag);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
@@ -686,6 +798,8 @@ extern "C" int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream) {
     XRL_CHECK_ARG(p != nullptr && p->params && p->frag && p->x && p->H == WH && p->D >= 1 && p->D <= 24 && p->A >= 1 && p->A <= WAM);
     XRL_CHECK_ARG(p->n > 0 && (p->flags & 3) != 0 && wide_act_ok(p->act, p->out_act));
     XRL_CHECK_ARG(!(p->flags & 1) || (p->act_out && p->logp_out));
+    if (p->raw) XRL_CHECK_ARG((p->flags & 1) && p->mean_in && p->var_in && p->count_in && p->mean_out && p->var_out && p->count_out &&
+                              p->mean_in != p->mean_out && p->n <= 4 * (1024 / p->D));
     XRL_CHECK_ARG(!(p->flags & 2) || p->bootv_prev);
     XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->params) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->frag) & 15) == 0);
     for (int b = 0; b < 2; ++b) XRL_CHECK_ARG(p->br[b].w1 % 4 == 0 && p->br[b].w2 % 4 == 0);

@@ -177,7 +177,7 @@ class PPO_Learner(Learner):
         dev, P = self.model.params.device, self.model.params.P
         if getattr(self, "_wide", None) is None:
             self._wide = ops.PpoWideState(self.model)
-            self._mirrors = [(self._wide.map, self._wide.frag)]      # the optimiser launch keeps the fragment copy current
+            self._mirrors = list(self._wide.mirrors)                # the optimiser launch keeps the fragment copy current
             self._mirror = True
             self.opt_sync = torch.zeros(4 + (P + 255) // 256 + 8, dtype=torch.int32, device=dev)
         n_t = (M + 31) // 32

@@ -413,12 +413,18 @@ class PpoWideState:
         d.act, d.out_act = ACT[model.activation], ACT[model.activation_action]
         self.desc = d
         dev = P.device
-        self.frag = torch.zeros(2 * 256 * 256, device=dev)
+        self.frag = torch.zeros(4 * 256 * 256, device=dev)          # [branch][forward | backward section][256 * 256]
         ramp = torch.arange(P.P, dtype=torch.float32, device=dev) + 1.0           # exact in fp32 for P < 2^24
         self.pack(ramp)
         torch.cuda.synchronize()
-        self.map = torch.full((P.P,), -1, dtype=torch.int32, device=dev)
-        self.map[(self.frag - 1.0).to(torch.int64)] = torch.arange(self.frag.numel(), dtype=torch.int32, device=dev)
+        src = (self.frag - 1.0).to(torch.int64).view(2, 2, -1)                   # parameter index held by every slot
+        dst = torch.arange(self.frag.numel(), dtype=torch.int32, device=dev).view(2, 2, -1)
+        self.maps = []
+        for sec in range(2):                                                      # every weight has one slot per section
+            m = torch.full((P.P,), -1, dtype=torch.int32, device=dev)
+            m[src[:, sec].reshape(-1)] = dst[:, sec].reshape(-1)
+            self.maps.append(m)
+        self.mirrors = [(self.maps[0], self.frag), (self.maps[1], self.frag)]
         self.pack()
 
     def pack(self, flat=None):
@@ -427,9 +433,11 @@ class PpoWideState:
         d.params = (self.model.params.flat if flat is None else flat).data_ptr()
         call("xrl_ppo_wide_pack", C.byref(d), ptr(self.frag), stream_ptr())
 
-    def act(self, x, n, seed, step, step_dev, act_out=None, env_action_f=None, logp_out=None, val_out=None, bootv_prev=None):
+    def act(self, x, n, seed, step, step_dev, act_out=None, env_action_f=None, logp_out=None, val_out=None, bootv_prev=None,
+            raw=None, stats_in=None, stats_out=None, obs_slot=None, update=0, normalize=0, obs_range=0.0):
         """xrl_wide_act_step: sample / log-prob / value of rows [0, n) of x (when act_out is given) and the values of rows
-        [n, 2n) (when bootv_prev is given), one launch."""
+        [n, 2n) (when bootv_prev is given), one launch.  raw: rows [0, n) as raw observations, normalised inside the launch
+        with the running statistics stats_in = (mean, var, count) -> stats_out (RunningMeanStd.update when `update`)."""
         a, d = getattr(self, "_act_desc", None), self.desc
         if a is None:
             a = self._act_desc = _lib.WideAct()
@@ -443,6 +451,10 @@ class PpoWideState:
         a.x, a.act_out, a.env_action_f, a.logp_out = as_ptr(x), as_ptr(act_out), as_ptr(env_action_f), as_ptr(logp_out)
         a.val_out, a.bootv_prev = as_ptr(val_out), as_ptr(bootv_prev)
         a.seed, a.step, a.step_dev = int(seed), int(step), as_ptr(step_dev)
+        a.raw, a.obs_slot = as_ptr(raw), as_ptr(obs_slot)
+        a.mean_in, a.var_in, a.count_in = [as_ptr(t) for t in (stats_in or (None, None, None))]
+        a.mean_out, a.var_out, a.count_out = [as_ptr(t) for t in (stats_out or (None, None, None))]
+        a.update, a.normalize, a.range = int(update), int(normalize), float(obs_range)
         call("xrl_wide_act_step", C.byref(a), stream_ptr())
 
     def launch(self, M, obs, actions, ret, adv, old_logp, slabs, slab_stride, partials, clip_range, vf_coef, ent_coef,
