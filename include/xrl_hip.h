@@ -627,7 +627,9 @@ int xrl_ppo_wide_pack(const xrl_ppo_wide_t* p, float* frag, xrl_stream_t stream)
  * normalised observations, rows [0, n) the ones acted on, rows [n, 2n) the previous step's next observations whose values
  * bootstrap truncated episodes.  flags bit 0: act -- action = mu + std * N(0,1) (the Philox draws of xrl_policy_sample: key
  * seed, counter (row, step + *step_dev, STREAM_GAUSS + dim)), log-prob and value of rows [0, n); bit 1: values of rows
- * [n, 2n) -> bootv_prev.  Same numbers as the layered sequence up to the summation order inside a dot product. */
+ * [n, 2n) -> bootv_prev.  Same numbers as the layered sequence up to the summation order inside a dot product.  Grid: four
+ * workgroups per (32-row tile, branch), one per 64 output columns of the middle layer (a CU streams only ~25 GB/s of
+ * weights); the last of the four to finish adds the head's partial sums in part order and samples. */
 typedef struct {
     const float* params;
     const float* frag;                                 /* xrl_ppo_wide_pack image */
@@ -656,6 +658,9 @@ typedef struct {
     float* obs_slot;                                   /* NULL or [n][D]: the normalised rows (the rollout buffer's slot) */
     int32_t update, normalize;                         /* as xrl_rms_t */
     float range, pad1;
+    /* scratch the four workgroups of a (tile, branch) pair meet in: xchg [pairs][4][32][8] floats, xcnt [pairs] uint32
+     * zero-initialised once (self-resetting); pairs = ceil(n/32) actor + up to ceil(2n/32) critic tiles */
+    float* xchg; uint32_t* xcnt;
 } xrl_wide_act_t;
 int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream);
 /* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */

@@ -209,7 +209,8 @@ class WideAct(C.Structure):
                 ("step", C.c_uint32), ("pad0", C.c_uint32), ("step_dev", c_void_p),
                 ("raw", c_void_p), ("mean_in", c_void_p), ("var_in", c_void_p), ("count_in", c_void_p),
                 ("mean_out", c_void_p), ("var_out", c_void_p), ("count_out", c_void_p), ("obs_slot", c_void_p),
-                ("update", c_int32), ("normalize", c_int32), ("range", c_float), ("pad1", c_float)]
+                ("update", c_int32), ("normalize", c_int32), ("range", c_float), ("pad1", c_float),
+                ("xchg", c_void_p), ("xcnt", c_void_p)]
 
 
 class QfImage(C.Structure):

@@ -334,6 +334,7 @@ class PPO_Agent(AgentSurface):
                 hasattr(lr, "wide_eligible") and lr.wide_eligible()
             if ok:
                 lr._wide_prepare(self.batch_size)
+                lr._wide.prepare_act(self.n_envs)
             self._wact = lr._wide if ok else None
             # running statistics + normalisation inside the acting launch: needs a second statistics set, an even horizon
             # (set 0 = obs_mean / obs_var / obs_count is then current whenever the host looks) and few enough rows

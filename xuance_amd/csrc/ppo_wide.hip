@@ -444,30 +444,46 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
 }
 
 // ------------------------------------------------------------------------------------------------ acting step
-// One launch for what the layered rollout step spends four on (three grouped GEMM launches + xrl_policy_sample; reference:
-// OnPolicyAgent.action / ppo_agent.py:97-135 -- policy(obs) -> dist.stochastic_sample(), log_prob, values; values of the next
-// observations for the bootstrap).  Workgroup = (32-row tile, branch) as in the minibatch kernel: actor tiles over rows
-// [0, n), critic tiles over the rows whose value is wanted.  Nothing couples two workgroups: the actor role samples and
-// writes action / log-prob, the critic role writes the value -- same Philox draws and the same arithmetic as
-// policy_sample_kernel (rollout.hip), the log-prob summed over the action dims in the same order.
+// One launch for what the layered rollout step spends five on (xrl_obs_normalize, three grouped GEMM launches,
+// xrl_policy_sample; reference: OnPolicyAgent.action / ppo_agent.py:97-135 -- policy(obs) -> dist.stochastic_sample(),
+// log_prob, values; values of the next observations for the bootstrap).  A vector step has few rows (n = 128: 4 actor
+// + 8 critic tiles) and a CU pulls only ~25 GB/s out of L2, so a workgroup that streamed a branch's whole 256 KB middle
+// layer spent 10 us doing so (measured: 20 us per launch).  Each (tile, branch) is therefore given to WA_PARTS
+// workgroups, one per 64 output columns of the middle layer (64 KB of fragments each); everything up to the head is
+// column-local, the head's dot products are summed over the parts by whichever workgroup of the four finishes last
+// (sc1 stores -> ticket counter -> sc1 loads, summed in part order: no spinning, no dependence on the arrival order).
+// That workgroup samples and writes action / log-prob (actor) or the value (critic) -- the Philox draws and the
+// arithmetic of policy_sample_kernel (rollout.hip), the log-prob summed over the action dims in the same order.
+constexpr int WA_PARTS = 4;
+constexpr int WA_H2LD = 68;                   // row stride of the 64-column slice of the second hidden level
+constexpr int WA_RED = 8 * 32 * 33;           // K-quarter partial tiles of the slice: [4 quarters][2 column tiles][32][33]
+constexpr int WA_OFF_RED = FT * WLD, WA_OFF_H2 = WA_OFF_RED + WA_RED, WA_OFF_XS = WA_OFF_H2 + FT * WA_H2LD,
+              WA_OFF_IMG = WA_OFF_XS + FT * WXLD + 8, WA_OFF_TERMS = WA_OFF_IMG + WAM * WA_H2LD + 16,
+              WA_LDS_FLOATS = WA_OFF_TERMS + FT * 8 + 4;
+constexpr int WA_LDS_BYTES = WA_LDS_FLOATS * 4;
+static_assert(WA_RED >= 2048 + 64 + 64 + 64, "statistics scratch lives in the partial-tile region");
+
 template <int ACT, int OACT>
 __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* h1 = lds;                                   // [32][260]  (before the first layer: the statistics' partial sums)
-    float* h2 = h1 + FT * WLD;                         // [32][260]  (before the first layer: batch / running moments)
-    float* xs = h2 + FT * WLD;                         // [32][28]
-    float* pimg = xs + FT * WXLD + 8;                  // head weights [nout][260] | head bias[8] | log_std[8]
-    float* terms = pimg + WAM * WLD + 16;              // [32][8] per-dim log-prob terms
+    float* h1 = lds;                                   // [32][260]
+    float* red = lds + WA_OFF_RED;                     // partial tiles  (before the first layer: the statistics' scratch)
+    float* h2p = lds + WA_OFF_H2;                      // [32][68] this part's 64 columns of the second hidden level
+    float* xs = lds + WA_OFF_XS;                       // [32][28]
+    float* pimg = lds + WA_OFF_IMG;                    // head weights of the slice [nout][68] | head bias[8] | log_std[8]
+    float* terms = lds + WA_OFF_TERMS;                 // [32][8] per-dim log-prob terms
+    int* s_last = reinterpret_cast<int*>(terms + FT * 8);
 
     kernarg_prefetch<sizeof(xrl_wide_act_t)>();
     const int tid = threadIdx.x, D = p.D, A = p.A, n = p.n;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool acting = (p.flags & 1) != 0, boot = (p.flags & 2) != 0;
+    const int pair = (int)blockIdx.x / WA_PARTS, part = (int)blockIdx.x % WA_PARTS;
     const int tiles_a = acting ? (n + FT - 1) / FT : 0;
-    const int role = (int)blockIdx.x < tiles_a ? 0 : 1;
+    const int role = pair < tiles_a ? 0 : 1;
     const int c_lo = acting ? 0 : n, c_hi = boot ? 2 * n : n;
-    const int row0 = role == 0 ? (int)blockIdx.x * FT : c_lo + ((int)blockIdx.x - tiles_a) * FT;
+    const int row0 = role == 0 ? pair * FT : c_lo + (pair - tiles_a) * FT;
     const int rows_here = min(FT, (role == 0 ? n : c_hi) - row0);
     const int r = tid >> 4, sub = tid & 15;
     xrl_wide_branch_t br;
@@ -475,8 +491,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     br.w1 = role ? p.br[1].w1 : p.br[0].w1; br.b1 = role ? p.br[1].b1 : p.br[0].b1;
     br.w2 = role ? p.br[1].w2 : p.br[0].w2; br.b2 = role ? p.br[1].b2 : p.br[0].b2;
     const int nout = role == 0 ? A : 1;
+    const int tw = wave & 1, kq = wave >> 1;           // this wave's column tile of the slice and K-quarter in the middle layer
     // rows [0, n) may come as RAW observations: RunningMeanStd.update + _process_observation happen here then (every
-    // workgroup that owns such rows forms the same statistics from all n rows; the first actor workgroup stores them)
+    // workgroup that owns such rows forms the same statistics from all n rows; workgroup 0 stores them)
     const bool from_raw = p.raw != nullptr && row0 < n;
     const bool stats_writer = from_raw && blockIdx.x == 0;
 
@@ -510,7 +527,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     uint32_t step = p.step;
     if (p.step_dev) step += *p.step_dev;
     float4 w2v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < nout * 64) w2v = *reinterpret_cast<const float4*>(p.params + br.w2 + (size_t)(tid >> 6) * WH + 4 * (tid & 63));
+    if (tid < nout * 16) w2v = *reinterpret_cast<const float4*>(p.params + br.w2 + (size_t)(tid >> 4) * WH + 64 * part + 4 * (tid & 15));
     float smallv = 0.f;
     if (tid >= 448 && tid < 448 + nout) smallv = p.params[br.b2 + tid - 448];
     if (tid >= 456 && tid < 456 + A) smallv = p.params[p.log_std_off + tid - 456];
@@ -526,17 +543,18 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
             w0f[q].w = k + 3 < D ? w0[k + 3] : 0.f;
         }
     }
-    const float b0v = p.params[br.b0 + wave * 32 + li], b1v = p.params[br.b1 + wave * 32 + li];
-    float4 pf[WQ];
+    const float b0v = p.params[br.b0 + wave * 32 + li];
+    const float b1c = p.params[br.b1 + 64 * part + (tid & 63)];        // bias of the slice column this thread finishes below
+    float4 pf[8];                                       // B fragments: column tile 2 part + tw of the middle layer, chunks 8 kq ..
     const __amdgpu_buffer_rsrc_t frs = wfrag_rsrc(p.frag);
 #pragma unroll
-    for (int q = 0; q < WQ; ++q) pf[q] = wfrag_load(frs, lane * 16, wfrag_soff(role, 0, wave, q));
+    for (int q = 0; q < 8; ++q) pf[q] = wfrag_load(frs, lane * 16, wfrag_soff(role, 0, 2 * part + tw, 8 * kq + q));
 
     if (from_raw) {
         // RunningMeanStd.update (statistic_tools.py:117-185) with the arithmetic of rms_normalize_kernel (rollout.hip): its
         // 1 024 threads are this workgroup's threads twice over; every sum runs in the same order, in float64
-        double* part = reinterpret_cast<double*>(h1);                  // [1024]
-        double* bmean = reinterpret_cast<double*>(h2);                 // [32]
+        double* part_s = reinterpret_cast<double*>(red);               // [1024]
+        double* bmean = part_s + 1024;                                 // [32]
         double* bvar = bmean + 32;                                     // [32]
         float* s_mean = reinterpret_cast<float*>(bvar + 32);           // [32]
         float* s_std = s_mean + 32;                                    // [32]
@@ -547,12 +565,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < RV; ++k) if (r0 < R && r0 + k * R < n) acc += (double)rawv[v][k];
-                part[vt] = r0 < R ? acc : 0.0;
+                part_s[vt] = r0 < R ? acc : 0.0;
             }
             lds_barrier();
             if (tid < D) {
                 double t = 0.0;
-                for (int rr = 0; rr < R; ++rr) t += part[rr * D + tid];
+                for (int rr = 0; rr < R; ++rr) t += part_s[rr * D + tid];
                 bmean[tid] = (double)(float)(t / n);                   // np.mean returns float32
             }
             lds_barrier();
@@ -565,12 +583,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
 #pragma unroll
                     for (int k = 0; k < RV; ++k) if (r0 + k * R < n) { const double df = (double)rawv[v][k] - m; q += df * df; }
                 }
-                part[vt] = r0 < R ? q : 0.0;
+                part_s[vt] = r0 < R ? q : 0.0;
             }
             lds_barrier();
             if (tid < D) {
                 double t = 0.0;
-                for (int rr = 0; rr < R; ++rr) t += part[rr * D + tid];
+                for (int rr = 0; rr < R; ++rr) t += part_s[rr * D + tid];
                 const float bstd = (float)sqrt(t / n);                 // np.std -> float32
                 const float bv = bstd * bstd;                          // batch_var = np.square(batch_std)
                 // update_from_moments (statistic_tools.py:173-185), float32 arrays with a Python-float count
@@ -605,10 +623,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
                     v = fminf(fmaxf(v, -p.range), p.range);
                 }
                 xv[i] = v;
-                if (p.obs_slot) p.obs_slot[(size_t)row0 * D + e] = v;
+                if (p.obs_slot && part == 0 && role == 0) p.obs_slot[(size_t)row0 * D + e] = v;
             }
         }
-        lds_barrier();                                                  // the scratch regions become h1 / h2 again
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -619,12 +636,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         const int rr = e / (WXLD - D), kk = D + e - rr * (WXLD - D);
         xs[rr * WXLD + kk] = 0.f;
     }
-    if (tid < nout * 64) *reinterpret_cast<float4*>(pimg + (tid >> 6) * WLD + 4 * (tid & 63)) = w2v;
-    if (tid >= 448 && tid < 448 + nout) pimg[WAM * WLD + tid - 448] = smallv;
-    if (tid >= 456 && tid < 456 + A) pimg[WAM * WLD + 8 + tid - 456] = smallv;
+    if (tid < nout * 16) *reinterpret_cast<float4*>(pimg + (tid >> 4) * WA_H2LD + 4 * (tid & 15)) = w2v;
+    if (tid >= 448 && tid < 448 + nout) pimg[WAM * WA_H2LD + tid - 448] = smallv;
+    if (tid >= 456 && tid < 456 + A) pimg[WAM * WA_H2LD + 8 + tid - 456] = smallv;
     lds_barrier();
 
-    // ---- forward: same products, operand order and epilogues as ppo_wide_kernel
+    // ---- first layer: all 256 columns (every part needs them), same product and epilogue as ppo_wide_kernel
     {
         f32x16 acc;
 #pragma unroll
@@ -643,49 +660,69 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         }
     }
     lds_barrier();
+    // ---- middle layer, this part's 64 columns: wave = (column tile tw, K-quarter kq); the four quarters meet in LDS and are
+    //      added in quarter order
     {
-        const float* arow = h1 + li * WLD + 4 * lh;
+        const float* arow = h1 + li * WLD + 4 * lh + kq * 64;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float4 af[8];
 #pragma unroll
-        for (int hq = 0; hq < WQ / 8; ++hq) {
-            float4 af[8];
+        for (int q = 0; q < 8; ++q) af[q] = *reinterpret_cast<const float4*>(arow + q * 8);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) af[q] = *reinterpret_cast<const float4*>(arow + (hq * 8 + q) * 8);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { MFMA4(af[q], pf[hq * 8 + q], acc) }
-        }
-        const int col = wave * 32 + li;
+        for (int q = 0; q < 8; ++q) { MFMA4(af[q], pf[q], acc) }
+        float* dst = red + (kq * 2 + tw) * (32 * 33);
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-            h2[row * WLD + col] = act_apply_c<ACT>(acc[rr] + b1v);
+            dst[row * 33 + li] = acc[rr];
         }
     }
     lds_barrier();
-    // ---- heads (VALU, 16 threads per row)
-    float zmine = 0.f;                                  // head pre-activation `sub` of row r (actor), value (critic: sub 0)
-    {
-        float4 a[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float4*>(h2 + r * WLD + 4 * (sub + 16 * i));
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * FUSED_THREADS, row = e >> 6, c = e & 63, t2 = c >> 5, cc = c & 31;
+        float v = red[(0 * 2 + t2) * (32 * 33) + row * 33 + cc];
+        v += red[(1 * 2 + t2) * (32 * 33) + row * 33 + cc];
+        v += red[(2 * 2 + t2) * (32 * 33) + row * 33 + cc];
+        v += red[(3 * 2 + t2) * (32 * 33) + row * 33 + cc];
+        h2p[row * WA_H2LD + c] = act_apply_c<ACT>(v + b1c);           // (c == tid & 63 for every i)
+    }
+    lds_barrier();
+    // ---- head: partial dot products over this part's 64 columns (16 threads per row, 4 columns each), published for the
+    //      last workgroup of the pair
+    const int e = row0 + r;
+    const bool row_ok = r < rows_here;
+    {
+        const float4 a = *reinterpret_cast<const float4*>(h2p + r * WA_H2LD + 4 * sub);
+        float zp = 0.f;
 #pragma unroll
         for (int j = 0; j < WAM; ++j) {
             if (j < nout) {
-                float c = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 w = *reinterpret_cast<const float4*>(pimg + j * WLD + 4 * (sub + 16 * i));
-                    c += a[i].x * w.x + a[i].y * w.y + a[i].z * w.z + a[i].w * w.w;
-                }
-                const float zj = wrow16_sum(c) + pimg[WAM * WLD + j];
-                if (sub == j) zmine = zj;
+                const float4 w = *reinterpret_cast<const float4*>(pimg + j * WA_H2LD + 4 * sub);
+                const float zj = wrow16_sum(a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w);
+                if (sub == j) zp = zj;
             }
         }
+        if (sub < 8) __hip_atomic_store(p.xchg + (((size_t)pair * WA_PARTS + part) * FT + r) * 8 + sub, zp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int e = row0 + r;
-    const bool row_ok = r < rows_here;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the partial sums are out (acknowledged) before the ticket is taken
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.xcnt + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = t == WA_PARTS - 1;
+        if (t == WA_PARTS - 1) __hip_atomic_store(p.xcnt + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    float zmine = 0.f;                                  // head pre-activation `sub` of row r (actor), value (critic: sub 0)
+    if (sub < 8) {
+        const float* src = p.xchg + ((size_t)pair * WA_PARTS * FT + r) * 8 + sub;
+#pragma unroll
+        for (int c = 0; c < WA_PARTS; ++c) zmine += __hip_atomic_load(src + (size_t)c * FT * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        zmine += pimg[WAM * WA_H2LD + sub];
+    }
     if (role == 0) {
         if (row_ok && sub < A) {
             const int j = sub;
@@ -694,7 +731,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
             philox4x32(p.seed, (uint32_t)e, step, STREAM_GAUSS + (uint32_t)j, rn);
             const float u1 = fmaxf(u01(rn[0]), 5.96e-8f), u2 = u01(rn[1]);
             const float zn = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
-            const float ls = pimg[WAM * WLD + 8 + j], sd = expf(ls);
+            const float ls = pimg[WAM * WA_H2LD + 8 + j], sd = expf(ls);
             const float x = mu + sd * zn;                  // Normal(mu, std).sample()
             const float df = x - mu;
             terms[r * 8 + j] = -(df * df) / (2.f * sd * sd) - logf(sd) - LOG_SQRT_2PI;
@@ -712,8 +749,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         else if (p.bootv_prev) p.bootv_prev[e - n] = zmine;
     }
 }
-
-constexpr int WA_LDS_BYTES = (2 * FT * WLD + FT * WXLD + 8 + WAM * WLD + 16 + FT * 8) * 4;
 
 // frag[b][0][tile t][slot (q + t) mod 32][lane l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s]      (forward section)
 // frag[b][1][tile t][slot (q + t) mod 32][lane l][s] = W1_b[8 q + 4 (l >> 5) + s][32 t + (l & 31)]      (backward section)
@@ -812,7 +847,8 @@ extern "C" int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream) {
     const bool acting = p->flags & 1, boot = p->flags & 2;
     const int tiles_a = acting ? (p->n + FT - 1) / FT : 0;
     const int c_rows = (boot ? 2 * p->n : p->n) - (acting ? 0 : p->n);
-    const int grid = tiles_a + (c_rows + FT - 1) / FT;
+    const int grid = (tiles_a + (c_rows + FT - 1) / FT) * WA_PARTS;
+    XRL_CHECK_ARG(p->xchg && p->xcnt);
 #define WIDE_LAUNCH(a, o)                                                                                                     \
     if (p->act == a && p->out_act == o)                                                                                       \
         hipLaunchKernelGGL((wide_act_kernel<a, o>), dim3(grid), dim3(FUSED_THREADS), WA_LDS_BYTES, as_stream(stream), *p);

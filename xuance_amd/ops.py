@@ -455,7 +455,17 @@ class PpoWideState:
         a.mean_in, a.var_in, a.count_in = [as_ptr(t) for t in (stats_in or (None, None, None))]
         a.mean_out, a.var_out, a.count_out = [as_ptr(t) for t in (stats_out or (None, None, None))]
         a.update, a.normalize, a.range = int(update), int(normalize), float(obs_range)
+        self.prepare_act(n)
+        a.xchg, a.xcnt = self._xchg.data_ptr(), self._xcnt.data_ptr()
         call("xrl_wide_act_step", C.byref(a), stream_ptr())
+
+    def prepare_act(self, n):
+        """Scratch of xrl_wide_act_step for n envs (call once outside graph capture; act() allocates on demand otherwise)."""
+        pairs = 3 * ((int(n) + 31) // 32)
+        if getattr(self, "_xchg", None) is None or self._xcnt.numel() < pairs:
+            dev = self.frag.device
+            self._xchg = torch.zeros(pairs * 4 * 32 * 8, device=dev)
+            self._xcnt = torch.zeros(pairs, dtype=torch.int32, device=dev)
 
     def launch(self, M, obs, actions, ret, adv, old_logp, slabs, slab_stride, partials, clip_range, vf_coef, ent_coef,
                stats=None, diag=None, heads=None, dbg=None, dbg_role=0):
