@@ -661,6 +661,12 @@ typedef struct {
     /* scratch the four workgroups of a (tile, branch) pair meet in: xchg [pairs][4][32][8] floats, xcnt [pairs] uint32
      * zero-initialised once (self-resetting); pairs = ceil(n/32) actor + up to ceil(2n/32) critic tiles */
     float* xchg; uint32_t* xcnt;
+    /* Optional: rows [n, 2n) from the RAW next observations of the previous vector step (NULL: from x), normalised with
+     * (mean_in, var_in) when `normalize` -- and that step's bookkeeping (xrl_rollout_poststep with next_obs_norm = NULL) done
+     * by one extra workgroup of this launch.  n % 32 == 0. */
+    const float* next_raw;
+    xrl_poststep_t post;
+    int32_t has_post, pad2;
 } xrl_wide_act_t;
 int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream);
 /* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */

@@ -33,7 +33,7 @@ def test_ctypes_structs_match_c_layout():
              "xrl_adam_state_t": _lib.AdamState, "xrl_rms_t": _lib.Rms, "xrl_sample_t": _lib.Sample,
              "xrl_cartpole_t": _lib.CartPole, "xrl_poststep_t": _lib.PostStep, "xrl_egreedy_t": _lib.EGreedy,
              "xrl_mirrors_t": _lib.Mirrors, "xrl_exchange_t": _lib.Exchange, "xrl_marl_gate_t": _lib.MarlGate,
-             "xrl_ppo_wide_t": _lib.PpoWide}
+             "xrl_ppo_wide_t": _lib.PpoWide, "xrl_wide_act_t": _lib.WideAct}
     for extra in ("xrl_dqn_td_t", "xrl_qmix_t"):
         cls = getattr(_lib, {"xrl_dqn_td_t": "DqnTd", "xrl_qmix_t": "Qmix"}[extra], None)
         if cls is not None:
@@ -42,6 +42,7 @@ def test_ctypes_structs_match_c_layout():
     for cname in pairs:
         src += f'printf("{cname} %zu\\n", sizeof({cname}));\n'
     src += 'printf("adam.base_lr %zu\\n", offsetof(xrl_adam_state_t, base_lr));\n'
+    src += 'printf("act.post %zu\\n", offsetof(xrl_wide_act_t, post));\nprintf("act.xchg %zu\\n", offsetof(xrl_wide_act_t, xchg));\n'
     src += 'printf("wide.obs %zu\\n", offsetof(xrl_ppo_wide_t, obs));\nprintf("wide.dbg %zu\\n", offsetof(xrl_ppo_wide_t, dbg));\n'
     src += 'printf("loss.M %zu\\n", offsetof(xrl_ppo_loss_t, M));\nreturn 0;}\n'
     with tempfile.TemporaryDirectory() as d:
@@ -54,6 +55,7 @@ def test_ctypes_structs_match_c_layout():
     assert int(out["adam.base_lr"]) == _lib.AdamState.base_lr.offset
     assert int(out["loss.M"]) == _lib.PpoLoss.M.offset
     assert int(out["wide.obs"]) == _lib.PpoWide.obs.offset and int(out["wide.dbg"]) == _lib.PpoWide.dbg.offset
+    assert int(out["act.post"]) == _lib.WideAct.post.offset and int(out["act.xchg"]) == _lib.WideAct.xchg.offset
 
 
 @pytest.mark.parametrize("dist,args", [("categorical", (4, 2, "categorical", (128,), (128,), (128,), "leaky_relu")),

@@ -508,12 +508,14 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph):
                            critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1,
                            n_minibatch=2, ent_coef=0.0, gamma=0.99, use_hip_graph=False, use_fused_obsnorm=False)
         b = PPO_Agent(cfg2, SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=10))
-        assert agent._wstats is not None and b._wide_acting() is not None and b._wstats is None
+        assert agent._wstats is not None and agent._wpost and b._wide_acting() is not None and b._wstats is None and not b._wpost
         b.rollout()
         torch.cuda.synchronize()
         f2 = {k: npy(v) for k, v in b.memory.soa.fields.items()}
-        for k in ("observations", "actions", "values", "aux_old_logp", "rewards", "advantages", "returns", "bootv"):
-            assert np.array_equal(f[k], f2[k]), k
+        for k in ("observations", "actions", "values", "aux_old_logp", "rewards", "terminals", "seg", "advantages", "returns", "bootv"):
+            assert np.array_equal(f[k], f2[k]), k              # (incl. the bookkeeping that rode in the acting launches)
+        for x, y in ((agent.ret_mean, b.ret_mean), (agent.ret_var, b.ret_var), (agent.ret_count, b.ret_count), (agent.returns, b.returns)):
+            assert torch.equal(x, y)
     if wide:                            # the optimiser launch kept the fragment-ordered copy of the middle layers current
         lr = agent.learner
         fr = lr._wide.frag.clone()

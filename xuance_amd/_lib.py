@@ -210,7 +210,8 @@ class WideAct(C.Structure):
                 ("raw", c_void_p), ("mean_in", c_void_p), ("var_in", c_void_p), ("count_in", c_void_p),
                 ("mean_out", c_void_p), ("var_out", c_void_p), ("count_out", c_void_p), ("obs_slot", c_void_p),
                 ("update", c_int32), ("normalize", c_int32), ("range", c_float), ("pad1", c_float),
-                ("xchg", c_void_p), ("xcnt", c_void_p)]
+                ("xchg", c_void_p), ("xcnt", c_void_p), ("next_raw", c_void_p), ("post", PostStep), ("has_post", c_int32),
+                ("pad2", c_int32)]
 
 
 class QfImage(C.Structure):

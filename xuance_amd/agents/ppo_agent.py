@@ -136,6 +136,8 @@ class PPO_Agent(AgentSurface):
                 stats = self._wstats[(t + 1) & 1]
                 kw = dict(raw=env.buf_obs, stats_in=self._wstats[t & 1], stats_out=stats, obs_slot=f["observations"][t],
                           update=int(self.use_obsnorm), normalize=int(self.use_obsnorm), obs_range=float(self.obsnorm_range))
+                if self._wpost and t > 0:                   # the previous step's bookkeeping + its next observations, raw
+                    kw.update(next_raw=env.next_obs, post=self._post_args(t - 1, self._wstats[t & 1]))
             wide.act(self.X, n, self.seed, t, self.step_counter, act_out=f["actions"][t], env_action_f=env.action,
                      logp_out=f["aux_old_logp"][t], val_out=f["values"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None, **kw)
         else:
@@ -150,13 +152,21 @@ class PPO_Agent(AgentSurface):
             env.step_device(offset=t)                           # static step index: the env's counter ticks once per rollout
         else:
             env.step_device()
-        ops.rollout_poststep(reward=env.reward, terminated=env.terminated, truncated=env.truncated, next_obs=env.next_obs,
-                             obs_mean=stats[0], obs_var=stats[1], next_obs_norm=self.X[n:], rew_out=f["rewards"][t],
-                             term_out=f["terminals"][t], seg_out=f["seg"][t], ret_track=self.returns,
-                             ret_mean=self.ret_mean, ret_var=self.ret_var, ret_count=self.ret_count, n=n, D=D, ld_next=D,
-                             use_obsnorm=int(self.use_obsnorm), use_rewnorm=int(self.use_rewnorm),
-                             last_step=int(t == self.horizon_size - 1), obs_range=float(self.obsnorm_range),
-                             rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
+        if fold and self._wpost:
+            return                                          # (rides in the next acting launch / the bootstrap launch)
+        ops.rollout_poststep(**self._post_args(t, stats, self.X[n:]))
+
+    def _post_args(self, t, stats, next_obs_norm=None):
+        """Keyword arguments of xrl_rollout_poststep for vector step t (stats: the observation statistics after that step's
+        update; next_obs_norm None: the consumer normalises the next observations itself)."""
+        env, f, n, D = self.envs, self.memory.soa.fields, self.n_envs, self.obs_dim
+        return dict(reward=env.reward, terminated=env.terminated, truncated=env.truncated, next_obs=env.next_obs,
+                    obs_mean=stats[0], obs_var=stats[1], next_obs_norm=next_obs_norm, rew_out=f["rewards"][t],
+                    term_out=f["terminals"][t], seg_out=f["seg"][t], ret_track=self.returns,
+                    ret_mean=self.ret_mean, ret_var=self.ret_var, ret_count=self.ret_count, n=n, D=D, ld_next=D,
+                    use_obsnorm=int(self.use_obsnorm), use_rewnorm=int(self.use_rewnorm),
+                    last_step=int(t == self.horizon_size - 1), obs_range=float(self.obsnorm_range),
+                    rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
 
     def _enqueue_rollout_fused(self, kernel_only=False):
         """ONE persistent launch (or T launches of xrl_rollout_step_cartpole + one bootstrap-only launch) + GAE: same
@@ -245,7 +255,12 @@ class PPO_Agent(AgentSurface):
         # buffer full: vals = get_terminated_values(next_obs) for every env (ppo_agent.py:129-135)
         wide = self._wide_acting()
         if wide is not None:
-            wide.act(self.X, n, self.seed, 0, None, bootv_prev=self.memory.soa.fields["bootv"][T - 1])
+            kw = {}
+            if self._wstats is not None and self._wpost:    # step T - 1's bookkeeping and raw next observations (T is even:
+                st = self._wstats[0]                        #  set 0 holds the current statistics)
+                kw = dict(next_raw=self.envs.next_obs, post=self._post_args(T - 1, st), stats_in=st,
+                          normalize=int(self.use_obsnorm), obs_range=float(self.obsnorm_range))
+            wide.act(self.X, n, self.seed, 0, None, bootv_prev=self.memory.soa.fields["bootv"][T - 1], **kw)
         else:
             heads = self.model.forward(self.X, 2 * n)
             ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
@@ -344,6 +359,9 @@ class PPO_Agent(AgentSurface):
                     self.n_envs <= 4 * (1024 // D) and tuple(self.envs.buf_obs.shape) == (self.n_envs, D):
                 self._wstats = [(self.obs_mean, self.obs_var, self.obs_count),
                                 (torch.zeros_like(self.obs_mean), torch.ones_like(self.obs_var), torch.zeros_like(self.obs_count))]
+            # ... and the previous step's bookkeeping as one more workgroup of the acting launch (rows [n, 2n) then come as raw
+            # next observations; tiles must not straddle row n)
+            self._wpost = self._wstats is not None and self.n_envs % 32 == 0 and bool(_get(self.config, "use_fused_poststep", True))
         return self._wact
 
     def _rollout_state_tensors(self):

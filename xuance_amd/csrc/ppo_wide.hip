@@ -21,6 +21,7 @@
 #include "mlp_tile.h"
 #include "ppo_math.h"
 #include "rng.h"
+#include "poststep.h"
 
 #pragma clang fp contract(off)
 
@@ -475,6 +476,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     int* s_last = reinterpret_cast<int*>(terms + FT * 8);
 
     kernarg_prefetch<sizeof(xrl_wide_act_t)>();
+    if (p.has_post && blockIdx.x == gridDim.x - 1) {    // the PREVIOUS vector step's bookkeeping, beside the acting workgroups
+        poststep_body<FUSED_THREADS>(p.post, reinterpret_cast<unsigned long long*>(lds));
+        return;
+    }
     const int tid = threadIdx.x, D = p.D, A = p.A, n = p.n;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -496,6 +501,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     // workgroup that owns such rows forms the same statistics from all n rows; workgroup 0 stores them)
     const bool from_raw = p.raw != nullptr && row0 < n;
     const bool stats_writer = from_raw && blockIdx.x == 0;
+    // rows [n, 2n) may come as the RAW next observations of the previous step: normalised here with the statistics as they are
+    // (what xrl_rollout_poststep writes to x otherwise; get_terminated_values, on_policy.py:109)
+    const bool from_next = p.next_raw != nullptr && row0 >= n;
 
     // ---- loads: small things first, then the weight stream
     constexpr int RV = 4;                               // rows per virtual thread of the statistics (host checks n <= RV * (1024 / D))
@@ -517,10 +525,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         }
         if (tid < D) { old_mean = p.mean_in[tid]; old_var = p.var_in[tid]; }
         old_cnt = *p.count_in;
-    }
+    } else if (from_next && tid < D) { old_mean = p.mean_in[tid]; old_var = p.var_in[tid]; }
     float xv[2] = {0.f, 0.f};
     {
-        const float* src = (from_raw ? p.raw : p.x) + (size_t)row0 * D;
+        const float* src = from_raw ? p.raw + (size_t)row0 * D : (from_next ? p.next_raw + (size_t)(row0 - n) * D : p.x + (size_t)row0 * D);
 #pragma unroll
         for (int i = 0; i < 2; ++i) { const int e = tid + i * FUSED_THREADS; if (e < rows_here * D) xv[i] = src[e]; }
     }
@@ -611,6 +619,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
             }
             if (stats_writer && tid == 0) *p.count_out = old_cnt;
         }
+    } else if (from_next) {
+        float* s_mean = red + 2 * (1024 + 64);
+        if (tid < D) { s_mean[tid] = old_mean; s_mean[32 + tid] = sqrtf(old_var); }
+    }
+    if (from_raw || from_next) {
+        const float* s_mean = red + 2 * (1024 + 64);
+        const float* s_std = s_mean + 32;
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -623,7 +638,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
                     v = fminf(fmaxf(v, -p.range), p.range);
                 }
                 xv[i] = v;
-                if (p.obs_slot && part == 0 && role == 0) p.obs_slot[(size_t)row0 * D + e] = v;
+                if (from_raw && p.obs_slot && part == 0 && role == 0) p.obs_slot[(size_t)row0 * D + e] = v;
             }
         }
     }
@@ -847,7 +862,13 @@ extern "C" int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream) {
     const bool acting = p->flags & 1, boot = p->flags & 2;
     const int tiles_a = acting ? (p->n + FT - 1) / FT : 0;
     const int c_rows = (boot ? 2 * p->n : p->n) - (acting ? 0 : p->n);
-    const int grid = (tiles_a + (c_rows + FT - 1) / FT) * WA_PARTS;
+    const int grid = (tiles_a + (c_rows + FT - 1) / FT) * WA_PARTS + (p->has_post ? 1 : 0);
+    if (p->next_raw) XRL_CHECK_ARG(boot && p->mean_in && p->var_in && p->n % FT == 0);
+    if (p->has_post) {
+        const xrl_poststep_t& q = p->post;
+        XRL_CHECK_ARG(q.reward && q.terminated && q.truncated && q.rew_out && q.term_out && q.seg_out && q.ret_track && q.ret_mean &&
+                      q.ret_var && q.ret_count && q.n > 0 && q.D > 0 && (q.next_obs_norm == nullptr || (q.next_obs && (!q.use_obsnorm || (q.obs_mean && q.obs_var)))));
+    }
     XRL_CHECK_ARG(p->xchg && p->xcnt);
 #define WIDE_LAUNCH(a, o)                                                                                                     \
     if (p->act == a && p->out_act == o)                                                                                       \

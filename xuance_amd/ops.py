@@ -434,10 +434,12 @@ class PpoWideState:
         call("xrl_ppo_wide_pack", C.byref(d), ptr(self.frag), stream_ptr())
 
     def act(self, x, n, seed, step, step_dev, act_out=None, env_action_f=None, logp_out=None, val_out=None, bootv_prev=None,
-            raw=None, stats_in=None, stats_out=None, obs_slot=None, update=0, normalize=0, obs_range=0.0):
+            raw=None, stats_in=None, stats_out=None, obs_slot=None, update=0, normalize=0, obs_range=0.0, next_raw=None, post=None):
         """xrl_wide_act_step: sample / log-prob / value of rows [0, n) of x (when act_out is given) and the values of rows
         [n, 2n) (when bootv_prev is given), one launch.  raw: rows [0, n) as raw observations, normalised inside the launch
-        with the running statistics stats_in = (mean, var, count) -> stats_out (RunningMeanStd.update when `update`)."""
+        with the running statistics stats_in = (mean, var, count) -> stats_out (RunningMeanStd.update when `update`).
+        next_raw: rows [n, 2n) as the previous step's raw next observations (normalised with stats_in); post: the keyword
+        arguments of rollout_poststep for the previous step -- its bookkeeping then rides in this launch."""
         a, d = getattr(self, "_act_desc", None), self.desc
         if a is None:
             a = self._act_desc = _lib.WideAct()
@@ -455,6 +457,8 @@ class PpoWideState:
         a.mean_in, a.var_in, a.count_in = [as_ptr(t) for t in (stats_in or (None, None, None))]
         a.mean_out, a.var_out, a.count_out = [as_ptr(t) for t in (stats_out or (None, None, None))]
         a.update, a.normalize, a.range = int(update), int(normalize), float(obs_range)
+        a.next_raw, a.has_post = as_ptr(next_raw), int(post is not None)
+        a.post = _struct(PostStep, post) if post is not None else PostStep()
         self.prepare_act(n)
         a.xchg, a.xcnt = self._xchg.data_ptr(), self._xcnt.data_ptr()
         call("xrl_wide_act_step", C.byref(a), stream_ptr())
