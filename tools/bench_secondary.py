@@ -133,9 +133,10 @@ def qmix_3m(rnn, n=64, steps=None, ref=None):
 
 def ppo_c4(steps=3, warmup=2, ref=None):
     """BASELINE configs[3] shapes on one GPU: PPO, Gaussian policy 17-256-256-6 + critic 17-256-256-1 (configs/ppo/mujoco.yaml),
-    128 envs x horizon 256, 16 epochs x 8 minibatches of 4 096, MuJoCo-shaped synthetic provider on the device; the layered
-    path (grouped fp32-MFMA GEMM launches; update phase one hipGraph).  Roofline of the update: algorithmic flops of one
-    minibatch (849 408 flop per sample) / its time."""
+    128 envs x horizon 256, 16 epochs x 8 minibatches of 4 096, MuJoCo-shaped synthetic provider on the device.  Update: ONE
+    launch per minibatch for forward + loss + backward (xrl::ppo_wide_kernel, csrc/ppo_wide.hip) + the optimiser launch;
+    rollout: two launches per vector step (acting incl. statistics / bookkeeping, provider).  Roofline of the dominant
+    kernel: algorithmic flops of one minibatch (849 408 flop per sample) / its HIP-event-timed launch."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import SyntheticMujocoVecEnv
     n, T = 128, 256
@@ -159,15 +160,30 @@ def ppo_c4(steps=3, warmup=2, ref=None):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     us_mb = (t2 - t1) / steps / 128 * 1e6
     flops = 849408.0 * 4096
-    tf = flops / us_mb / 1e6
+    lr = agent.learner
+    wide = getattr(lr, "_wide", None)
+    if wide is not None:                                # the one-launch minibatch kernel, timed by itself on staged rows
+        bs, P = agent.batch_size, agent.model.params.P
+        st = {k: v[3 * bs:4 * bs] for k, v in lr._wstage.items()}
+        fn = lambda: wide.launch(bs, st["observations"], st["actions"], st["returns"], st["advantages"], st["aux_old_logp"],
+                                 lr.fslabs, P, lr.fpartials, lr.clip_range, lr.vf_coef, lr.ent_coef, stats=lr.stats[3])
+        for _ in range(10):
+            fn()
+        us_k = _events_us(fn, 200)
+        kname, note = "xrl::ppo_wide_kernel", ("forward + Gaussian PPO-clip loss + backward of one 4 096-row minibatch in one launch; with the "
+                                                 "optimiser launch (xrl::reduce_adam_kernel) a minibatch takes %.1f us = %.3f of peak" % (us_mb, flops / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS))
+    else:
+        us_k, kname, note = us_mb, "minibatch update (xrl::gemm_f32_kernel launches + xrl::ppo_loss_kernel + xrl::reduce_adam_kernel)", \
+            "one 'launch' = one whole minibatch update (layered path)"
+    tf = flops / us_k / 1e6
     out = {"workload": "PPO, HalfCheetah shapes (obs 17, Box(6), Gaussian 17-256-256-6 + critic 17-256-256-1), %d envs x horizon %d, "
                        "16 epochs x 8 minibatches of 4096 (BASELINE configs[3], per GPU)" % (n, T),
            "value": round(n * T * steps / (t2 - t0), 1), "unit": "env-steps/s", "ms_per_step": round((t2 - t0) / steps * 1e3, 3),
            "rollout_ms": round((t1 - t0) / steps * 1e3, 3), "update_ms": round((t2 - t1) / steps * 1e3, 3),
-           "roofline": {"bound": "mfma", "kernel": "minibatch update (xrl::gemm_f32_kernel launches + xrl::ppo_loss_kernel + xrl::reduce_adam_kernel)",
-                        "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "traffic": None, "avg_launch_us": round(us_mb, 1), "algorithmic_flops_per_launch": flops,
-                        "note": "one 'launch' = one whole minibatch update (8 kernels, layered path); DESIGN.md section 8 item 1"}}
+           "update_us_per_minibatch": round(us_mb, 1),
+           "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_us": round(us_k, 1),
+                        "algorithmic_flops_per_launch": flops, "note": note}}
     if ref:
         out["cpu_baseline"] = ref
     return out

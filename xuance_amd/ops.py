@@ -826,9 +826,18 @@ class Graph:
         self.handle = C.c_void_p()
         self.stream = None
 
+    _capture_streams = {}        # device index -> THE stream every capture of this process runs on
+
     def __enter__(self):
         init_device()
-        self.stream = torch.cuda.Stream()
+        # One capture stream per device for the whole process.  A new torch.cuda.Stream() per capture walks through torch's
+        # pool of 32 streams = 32 hardware queues of this process; with a few more processes on the same GPU (the
+        # several-ranks-on-one-GPU tests after a long pytest session) the queues outnumber the hardware's slots, the driver
+        # time-slices them, and kernels of different ranks that wait for each other inside a launch no longer overlap.
+        dev = torch.cuda.current_device()
+        if dev not in Graph._capture_streams:
+            Graph._capture_streams[dev] = torch.cuda.Stream()
+        self.stream = Graph._capture_streams[dev]
         self.stream.wait_stream(torch.cuda.current_stream())
         self._ctx = torch.cuda.stream(self.stream)
         self._ctx.__enter__()
