@@ -13,11 +13,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 
 def _pmc_bytes(which, kernel):
     """HBM bytes per launch of `kernel` from the latest committed PMC summary of the QMIX loops (profiles/r*_qmix_<which>_pmc.json,
-    tools/collect_pmc_qmix.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md) -- copied from that builder-run pass, not measured
-    in this run; (None, None) if the file is not there."""
+    tools/collect_pmc_qmix.sh) or of the C4 loop (which = "c4": profiles/r*_c4_pmc.json, tools/collect_pmc_c4.sh); FETCH_SIZE
+    doubled per MI355X_MICROARCH.md -- copied from that builder-run pass, not measured in this run; (None, None) if the file is
+    not there."""
     import glob, json, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    paths = sorted(glob.glob(os.path.join(root, "profiles", "r*_qmix_%s_pmc.json" % which)))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r*_%s_pmc.json" % (which if which == "c4" else "qmix_" + which))))
     try:
         for name, v in json.load(open(paths[-1]))["kernels"].items():
             if name.startswith(kernel):
@@ -176,14 +177,15 @@ def ppo_c4(steps=3, warmup=2, ref=None):
         us_k, kname, note = us_mb, "minibatch update (xrl::gemm_f32_kernel launches + xrl::ppo_loss_kernel + xrl::reduce_adam_kernel)", \
             "one 'launch' = one whole minibatch update (layered path)"
     tf = flops / us_k / 1e6
+    traffic, traffic_src = _pmc_bytes("c4", kname) if wide is not None else (None, None)
     out = {"workload": "PPO, HalfCheetah shapes (obs 17, Box(6), Gaussian 17-256-256-6 + critic 17-256-256-1), %d envs x horizon %d, "
                        "16 epochs x 8 minibatches of 4096 (BASELINE configs[3], per GPU)" % (n, T),
            "value": round(n * T * steps / (t2 - t0), 1), "unit": "env-steps/s", "ms_per_step": round((t2 - t0) / steps * 1e3, 3),
            "rollout_ms": round((t1 - t0) / steps * 1e3, 3), "update_ms": round((t2 - t1) / steps * 1e3, 3),
            "update_us_per_minibatch": round(us_mb, 1),
            "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_us": round(us_k, 1),
-                        "algorithmic_flops_per_launch": flops, "note": note}}
+                        "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "avg_launch_us": round(us_k, 1), "algorithmic_flops_per_launch": flops, "note": note}}
     if ref:
         out["cpu_baseline"] = ref
     return out
