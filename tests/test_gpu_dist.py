@@ -15,7 +15,7 @@ torch = pytest.importorskip("torch")
 from conftest import ROOT, free_port  # noqa: E402
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shape="cartpole"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -24,13 +24,20 @@ def _worker(rank, world, port, q):
     from test_gpu_agent import make_config
     from xuance_amd import dist as xd
     from xuance_amd.agents import PPO_Agent
-    from xuance_amd.envs import DeviceCartPoleVecEnv
+    from xuance_amd.envs import DeviceCartPoleVecEnv, SyntheticMujocoVecEnv
     torch.cuda.set_device(0)
     xd.init_distributed_mode("gloo")
     torch.manual_seed(0)
     n, T = 32, 32
-    cfg = make_config(n, T, n_epochs=1, n_minibatch=2, distributed_training=True, seed=1 + rank)
-    agent = PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=10 + rank))
+    if shape == "mujoco":             # the two-branch Gaussian class: one-launch minibatch + one-launch acting (csrc/ppo_wide.hip)
+        cfg = make_config(n, T, n_epochs=1, n_minibatch=2, distributed_training=True, seed=1 + rank, representation="Basic_Identical",
+                          representation_hidden_size=[], actor_hidden_size=[256, 256], critic_hidden_size=[256, 256],
+                          activation="leaky_relu", activation_action="tanh", ent_coef=0.0, gamma=0.99)
+        agent = PPO_Agent(cfg, SyntheticMujocoVecEnv(n, seed=10 + rank, max_episode_steps=20))
+        assert agent.learner.wide_eligible()
+    else:
+        cfg = make_config(n, T, n_epochs=1, n_minibatch=2, distributed_training=True, seed=1 + rank)
+        agent = PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=10 + rank))
     xd.broadcast_(agent.model.params.flat, 0)
     p0 = agent.model.params.flat.clone()
     idx = np.stack([np.random.default_rng(7).permutation(n * T)]).reshape(2, -1)
@@ -119,6 +126,18 @@ def test_two_ranks_share_gradients_and_stay_in_sync():
         assert ia["actor_loss/rank_0"] != ib["actor_loss/rank_1"]                                  # different env shards
         out[exchange] = pa
     assert np.array_equal(out[True], out[False])
+
+
+def test_two_ranks_on_the_mujoco_shape_stay_in_sync():
+    """The two-branch Gaussian class (xrl_ppo_wide_minibatch + xrl_wide_act_step) with two ranks, gradients averaged by the
+    process group between graphs cut at the collectives: replicas bit-identical after four chained steps on different env
+    shards.  (The in-launch exchange is not exercised at this shape HERE: its optimiser launch has 558 blocks that must all be
+    resident, and two ranks sharing ONE GPU would need 1 116 slots of its 1 024 -- one rank per GPU, as deployed, has them;
+    the exchange itself is shape-agnostic and covered by the tests above.)"""
+    (r0, p0a, pa, stepa, ia, xa), (r1, p0b, pb, stepb, ib, xb) = _run_two_ranks(False, extra=("mujoco",))
+    assert not xa and not xb and np.array_equal(p0a, p0b) and stepa == stepb == 4
+    assert np.array_equal(pa, pb) and not np.array_equal(pa, p0a)
+    assert ia["actor_loss/rank_0"] != ib["actor_loss/rank_1"]
 
 
 # ---------------------------------------------------------------------------------------------- off-policy learners, 2 ranks

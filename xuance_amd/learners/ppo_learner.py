@@ -157,9 +157,11 @@ class PPO_Learner(Learner):
         rb = self._readback.cpu().numpy()                           # the one host sync of an update
         s = rb[:8]
         self.last_status = rb[8:10].view(np.int32).tolist()
-        if rb[10:12].view(np.int32)[2] != 0:
-            raise ops.XrlError("xrl_reduce_adam: inter-block barrier timed out -- the optimiser step of this update phase "
-                               "is invalid (set use_fused_optimizer: False to use the two-launch sequence)")
+        code = int(rb[10:12].view(np.int32)[2])
+        if code != 0:
+            raise ops.XrlError("xrl_reduce_adam: %s timed out -- the optimiser step of this update phase is invalid (set "
+                               "use_fused_optimizer: False to use the two-launch sequence)"
+                               % ("the wait for the other ranks' gradient rows" if code == 2 else "the inter-block barrier"))
         st = self.optimizer.read()
         return {self._key("actor_loss"): float(-s[0] / M), self._key("critic_loss"): float(s[1] / M),
                 self._key("entropy"): float(s[2] / M), self._key("learning_rate"): st.last_lr,
