@@ -667,6 +667,7 @@ typedef struct {
     const float* next_raw;
     xrl_poststep_t post;
     int32_t has_post, pad2;
+    long long* dbg;                                    /* NULL, or [32] shader-clock stamps of the four workgroups of pair 0 (diagnostics) */
 } xrl_wide_act_t;
 int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream);
 /* params_t <- params with every middle layer's weight transposed (call after each optimiser step). */

@@ -58,3 +58,14 @@ ra = lambda: ops.reduce_adam(lr.fslabs, lr.n_tiles, P, m.params.flat, opt.grad, 
 print("wide kernel        : %.2f us" % timed(lambda: launch()))
 print("reduce + adam      : %.2f us" % timed(ra))
 print("both, back to back : %.2f us" % timed(lambda: (launch(), ra())))
+
+# ---- acting launch: stamps of the four workgroups of (actor tile 0) inside the captured rollout
+agent._wact.act_dbg = torch.zeros(32, dtype=torch.int64, device="cuda")
+agent._rollout_graph = None
+agent.rollout(); agent.rollout()
+torch.cuda.synchronize()
+d = agent._wact.act_dbg.cpu().numpy().reshape(4, 8)
+an = ["start", "rows + statistics -> LDS", "layer 0", "layer 1 slice", "head slice -> ticket", "combine + sample"]
+for part in range(4):
+    print("acting, part", part, ":", ", ".join(f"{an[i]} {int(d[part, i] - d[part, i - 1])}" for i in range(1, 6) if d[part, i] > 0),
+          "| total", int(max(d[part]) - d[part, 0]))

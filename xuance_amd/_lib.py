@@ -211,7 +211,7 @@ class WideAct(C.Structure):
                 ("mean_out", c_void_p), ("var_out", c_void_p), ("count_out", c_void_p), ("obs_slot", c_void_p),
                 ("update", c_int32), ("normalize", c_int32), ("range", c_float), ("pad1", c_float),
                 ("xchg", c_void_p), ("xcnt", c_void_p), ("next_raw", c_void_p), ("post", PostStep), ("has_post", c_int32),
-                ("pad2", c_int32)]
+                ("pad2", c_int32), ("dbg", c_void_p)]
 
 
 class QfImage(C.Structure):

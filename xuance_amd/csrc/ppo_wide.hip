@@ -33,9 +33,10 @@ constexpr int WQ = WH / 8;                    // k-chunks of the middle layer
 constexpr int WQ_EARLY = 24;                  // backward chunks requested right after the forward layer
 constexpr int WXLD = 28;                      // row stride of the observation tile (D <= 24, zero padded)
 constexpr int WAM = 8;                        // max action dims
+constexpr int W0S = 32 * 24;                  // first-layer rows of one wave's 32 output columns, staged in LDS (D <= 24)
 constexpr int W_H1 = 0, W_H2 = W_H1 + FT * WLD, W_G2 = W_H2 + FT * WLD, W_XS = W_G2 + FT * WLD,
               W_RSC = W_XS + FT * WXLD + 8, W_DZH = W_RSC + FT * 16, W_IMG = W_DZH + FT * 16,
-              W_STAT = W_IMG + WAM * WLD + 16, W_LDS_FLOATS = W_STAT + 5 * FT * 2;
+              W_STAT = W_IMG + WAM * WLD + 16, W_W0 = W_STAT + 5 * FT * 2, W_LDS_FLOATS = W_W0 + 8 * W0S;
 constexpr int W_LDS_BYTES = W_LDS_FLOATS * 4;
 static_assert(W_LDS_BYTES <= 160 * 1024, "tile does not fit the LDS of a CU");
 static_assert((W_STAT % 2) == 0, "row statistics are doubles");
@@ -126,17 +127,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
     float smallv = 0.f;
     if (tid >= 448 && tid < 448 + nout) smallv = p.params[br.b2 + tid - 448];
     if (tid >= 456 && tid < 456 + A) smallv = p.params[p.log_std_off + tid - 456];
-    float4 w0f[3];                                      // B fragments of the first layer: W0[32 w + li][8 q + 4 lh + s], zero for k >= D
+    // first-layer weights of this wave's 32 output columns: one contiguous block of 32 D floats, fetched as whole float4s and
+    // handed over through LDS (per-lane fragment loads would be 12 uncoalesced 4-byte loads in front of the weight stream)
+    float4 w0v[3];
     {
-        const float* w0 = p.params + br.w0 + (size_t)(wave * 32 + li) * D;
+        const float4* w0 = reinterpret_cast<const float4*>(p.params + br.w0 + (size_t)(wave * 32) * D);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int k = 8 * q + 4 * lh;
-            w0f[q].x = k + 0 < D ? w0[k + 0] : 0.f;
-            w0f[q].y = k + 1 < D ? w0[k + 1] : 0.f;
-            w0f[q].z = k + 2 < D ? w0[k + 2] : 0.f;
-            w0f[q].w = k + 3 < D ? w0[k + 3] : 0.f;
-        }
+        for (int i = 0; i < 3; ++i) { const int c = lane + 64 * i; w0v[i] = c < 8 * D ? w0[c] : make_float4(0.f, 0.f, 0.f, 0.f); }
     }
     const float b0v = p.params[br.b0 + wave * 32 + li], b1v = p.params[br.b1 + wave * 32 + li];
     float4 pf[WQ];                                      // B fragments of W1: output tile `wave`, all 32 k-chunks
@@ -170,8 +167,25 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
     if (tid >= 448 && tid < 448 + nout) pimg[WAM * WLD + tid - 448] = smallv;
     if (tid >= 456 && tid < 456 + A) pimg[WAM * WLD + 8 + tid - 456] = smallv;
     if (tid < 8) xs[FT * WXLD + tid] = 0.f;            // (tail the first-layer gradient's B operand may touch)
-    lds_barrier();                                                                                   // #0 rows, head image
+    {
+        float* w0s = lds + W_W0 + wave * W0S;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int c = lane + 64 * i; if (c < 8 * D) *reinterpret_cast<float4*>(w0s + 4 * c) = w0v[i]; }
+    }
+    lds_barrier();                                                                                   // #0 rows, head image, W0
     WSTAMP(1);
+    float4 w0f[3];                                      // B fragments of the first layer: W0[32 w + li][8 q + 4 lh + s], zero for k >= D
+    {
+        const float* w0r = lds + W_W0 + wave * W0S + li * D;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = 8 * q + 4 * lh;
+            w0f[q].x = k + 0 < D ? w0r[k + 0] : 0.f;
+            w0f[q].y = k + 1 < D ? w0r[k + 1] : 0.f;
+            w0f[q].z = k + 2 < D ? w0r[k + 2] : 0.f;
+            w0f[q].w = k + 3 < D ? w0r[k + 3] : 0.f;
+        }
+    }
 
     // ================= forward: D -> 256 (three 8-wide k-chunks), 256 -> 256 (32 chunks from the register stream)
     {
@@ -460,7 +474,7 @@ constexpr int WA_H2LD = 68;                   // row stride of the 64-column sli
 constexpr int WA_RED = 8 * 32 * 33;           // K-quarter partial tiles of the slice: [4 quarters][2 column tiles][32][33]
 constexpr int WA_OFF_RED = FT * WLD, WA_OFF_H2 = WA_OFF_RED + WA_RED, WA_OFF_XS = WA_OFF_H2 + FT * WA_H2LD,
               WA_OFF_IMG = WA_OFF_XS + FT * WXLD + 8, WA_OFF_TERMS = WA_OFF_IMG + WAM * WA_H2LD + 16,
-              WA_LDS_FLOATS = WA_OFF_TERMS + FT * 8 + 4;
+              WA_OFF_W0 = WA_OFF_TERMS + FT * 8 + 4, WA_LDS_FLOATS = WA_OFF_W0 + 8 * W0S;
 constexpr int WA_LDS_BYTES = WA_LDS_FLOATS * 4;
 static_assert(WA_RED >= 2048 + 64 + 64 + 64, "statistics scratch lives in the partial-tile region");
 
@@ -501,6 +515,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     // workgroup that owns such rows forms the same statistics from all n rows; workgroup 0 stores them)
     const bool from_raw = p.raw != nullptr && row0 < n;
     const bool stats_writer = from_raw && blockIdx.x == 0;
+    const bool dbg_me = p.dbg && tid == 0 && pair == 0;
+#define ASTAMP(k) do { if (dbg_me) p.dbg[part * 8 + (k)] = clock64(); } while (0)
+    ASTAMP(0);
     // rows [n, 2n) may come as the RAW next observations of the previous step: normalised here with the statistics as they are
     // (what xrl_rollout_poststep writes to x otherwise; get_terminated_values, on_policy.py:109)
     const bool from_next = p.next_raw != nullptr && row0 >= n;
@@ -539,17 +556,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     float smallv = 0.f;
     if (tid >= 448 && tid < 448 + nout) smallv = p.params[br.b2 + tid - 448];
     if (tid >= 456 && tid < 456 + A) smallv = p.params[p.log_std_off + tid - 456];
-    float4 w0f[3];
+    float4 w0v[3];
     {
-        const float* w0 = p.params + br.w0 + (size_t)(wave * 32 + li) * D;
+        const float4* w0 = reinterpret_cast<const float4*>(p.params + br.w0 + (size_t)(wave * 32) * D);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int k = 8 * q + 4 * lh;
-            w0f[q].x = k + 0 < D ? w0[k + 0] : 0.f;
-            w0f[q].y = k + 1 < D ? w0[k + 1] : 0.f;
-            w0f[q].z = k + 2 < D ? w0[k + 2] : 0.f;
-            w0f[q].w = k + 3 < D ? w0[k + 3] : 0.f;
-        }
+        for (int i = 0; i < 3; ++i) { const int c = lane + 64 * i; w0v[i] = c < 8 * D ? w0[c] : make_float4(0.f, 0.f, 0.f, 0.f); }
     }
     const float b0v = p.params[br.b0 + wave * 32 + li];
     const float b1c = p.params[br.b1 + 64 * part + (tid & 63)];        // bias of the slice column this thread finishes below
@@ -654,7 +665,25 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     if (tid < nout * 16) *reinterpret_cast<float4*>(pimg + (tid >> 4) * WA_H2LD + 4 * (tid & 15)) = w2v;
     if (tid >= 448 && tid < 448 + nout) pimg[WAM * WA_H2LD + tid - 448] = smallv;
     if (tid >= 456 && tid < 456 + A) pimg[WAM * WA_H2LD + 8 + tid - 456] = smallv;
+    {
+        float* w0s = lds + WA_OFF_W0 + wave * W0S;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int c = lane + 64 * i; if (c < 8 * D) *reinterpret_cast<float4*>(w0s + 4 * c) = w0v[i]; }
+    }
     lds_barrier();
+    ASTAMP(1);
+    float4 w0f[3];                                      // B fragments of the first layer: W0[32 w + li][8 q + 4 lh + s], zero for k >= D
+    {
+        const float* w0r = lds + WA_OFF_W0 + wave * W0S + li * D;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = 8 * q + 4 * lh;
+            w0f[q].x = k + 0 < D ? w0r[k + 0] : 0.f;
+            w0f[q].y = k + 1 < D ? w0r[k + 1] : 0.f;
+            w0f[q].z = k + 2 < D ? w0r[k + 2] : 0.f;
+            w0f[q].w = k + 3 < D ? w0r[k + 3] : 0.f;
+        }
+    }
 
     // ---- first layer: all 256 columns (every part needs them), same product and epilogue as ppo_wide_kernel
     {
@@ -675,6 +704,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         }
     }
     lds_barrier();
+    ASTAMP(2);
     // ---- middle layer, this part's 64 columns: wave = (column tile tw, K-quarter kq); the four quarters meet in LDS and are
     //      added in quarter order
     {
@@ -705,6 +735,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         h2p[row * WA_H2LD + c] = act_apply_c<ACT>(v + b1c);           // (c == tid & 63 for every i)
     }
     lds_barrier();
+    ASTAMP(3);
     // ---- head: partial dot products over this part's 64 columns (16 threads per row, 4 columns each), published for the
     //      last workgroup of the pair
     const int e = row0 + r;
@@ -730,6 +761,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         if (t == WA_PARTS - 1) __hip_atomic_store(p.xcnt + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
     }
     __syncthreads();
+    ASTAMP(4);
     if (!*s_last) return;
     float zmine = 0.f;                                  // head pre-activation `sub` of row r (actor), value (critic: sub 0)
     if (sub < 8) {
@@ -763,6 +795,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         if (e < n) { if (p.val_out) p.val_out[e] = zmine; }
         else if (p.bootv_prev) p.bootv_prev[e - n] = zmine;
     }
+    ASTAMP(5);
+#undef ASTAMP
 }
 
 // frag[b][0][tile t][slot (q + t) mod 32][lane l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s]      (forward section)
@@ -787,7 +821,7 @@ __global__ void __launch_bounds__(256) ppo_wide_pack_kernel(xrl_ppo_wide_t p, fl
 
 static int wide_check(const xrl_ppo_wide_t* p) {
     XRL_CHECK_ARG(p != nullptr && p->params && p->H == WH && p->D >= 1 && p->D <= 24 && p->A >= 1 && p->A <= WAM);
-    for (int b = 0; b < 2; ++b) XRL_CHECK_ARG(p->br[b].w1 % 4 == 0 && p->br[b].w2 % 4 == 0);
+    for (int b = 0; b < 2; ++b) XRL_CHECK_ARG(p->br[b].w0 % 4 == 0 && p->br[b].w1 % 4 == 0 && p->br[b].w2 % 4 == 0);
     return XRL_OK;
 }
 
@@ -852,7 +886,7 @@ extern "C" int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream) {
                               p->mean_in != p->mean_out && p->n <= 4 * (1024 / p->D));
     XRL_CHECK_ARG(!(p->flags & 2) || p->bootv_prev);
     XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->params) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->frag) & 15) == 0);
-    for (int b = 0; b < 2; ++b) XRL_CHECK_ARG(p->br[b].w1 % 4 == 0 && p->br[b].w2 % 4 == 0);
+    for (int b = 0; b < 2; ++b) XRL_CHECK_ARG(p->br[b].w0 % 4 == 0 && p->br[b].w1 % 4 == 0 && p->br[b].w2 % 4 == 0);
     static bool inited = false;
     if (!inited) {
         int rc = init_ppo_wide();

@@ -458,6 +458,7 @@ class PpoWideState:
         a.mean_out, a.var_out, a.count_out = [as_ptr(t) for t in (stats_out or (None, None, None))]
         a.update, a.normalize, a.range = int(update), int(normalize), float(obs_range)
         a.next_raw, a.has_post = as_ptr(next_raw), int(post is not None)
+        a.dbg = as_ptr(getattr(self, "act_dbg", None))          # (diagnostics: tools/probe_wide_phases.py)
         a.post = _struct(PostStep, post) if post is not None else PostStep()
         self.prepare_act(n)
         a.xchg, a.xcnt = self._xchg.data_ptr(), self._xcnt.data_ptr()
