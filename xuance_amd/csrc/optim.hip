@@ -282,7 +282,14 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
     const float w1 = (float)(1.0 - b1), fb2 = (float)b2, w2 = (float)(1.0 - b2), wd = (float)st->weight_decay;
     const int64_t i = (int64_t)vb * RED_THREADS + tg;
     float p0 = 0.f, m0 = 0.f, v0 = 0.f;
-    if (i < P) { p0 = params[i]; m0 = m[i]; v0 = v[i]; }
+    int mj[XRL_MAX_MIRRORS];                                          // (the mirror slots of parameter i: fetched here too, not
+#pragma unroll                                                        //  as a dependent load behind the barrier)
+    for (int q = 0; q < XRL_MAX_MIRRORS; ++q) mj[q] = -1;
+    if (i < P) {
+        p0 = params[i]; m0 = m[i]; v0 = v[i];
+#pragma unroll
+        for (int q = 0; q < XRL_MAX_MIRRORS; ++q) if (q < mir.n) mj[q] = mir.map[q][i];
+    }
     // ---- barrier without read-modify-write atomics: every block publishes its partial sum, then (after the store has been
     //      acknowledged) its flag = the optimiser step this launch performs -- a value no earlier launch has written -- and
     //      polls all flags with one coalesced device-scope load per round.  sync[4 + b] is block b's flag.
@@ -332,10 +339,10 @@ __global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __
         params[i] = pn;
 #pragma unroll
         for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
-            if (q < mir.n) { const int j = mir.map[q][i]; if (j >= 0) mir.dst[q][j] = pn; }
+            if (q < mir.n && mj[q] >= 0) mir.dst[q][mj[q]] = pn;
         if (mir.target && mir.target_every > 0 && step % mir.target_every == 0) {
             mir.target[i] = pn;
-            if (mir.target_image) { const int j = mir.map[0][i]; if (j >= 0) mir.target_image[j] = pn; }
+            if (mir.target_image && mj[0] >= 0) mir.target_image[mj[0]] = pn;
         }
     }
     __syncthreads();
