@@ -651,7 +651,7 @@ typedef struct {
      * (what xrl_obs_normalize does, the same arithmetic; statistic_tools.py:117-185, agent.py:262-283).  raw != NULL: rows
      * [0, n) of x are ignored; the statistics are read from *_in and written to *_out (different buffers: the workgroups
      * of a launch read the old ones while one of them stores the new ones -- the caller alternates two sets);
-     * n <= 4 * floor(1024 / D). */
+     * n <= 4 * floor(1024 / D); n % 32 == 0 when rows [n, 2n) are evaluated in the same launch. */
     const float* raw;                                  /* NULL or [n][D] */
     const float* mean_in; const float* var_in; const double* count_in;
     float* mean_out; float* var_out; double* count_out;

@@ -355,13 +355,13 @@ class PPO_Agent(AgentSurface):
             # (set 0 = obs_mean / obs_var / obs_count is then current whenever the host looks) and few enough rows
             self._wstats = None
             D = self.obs_dim
-            if ok and bool(_get(self.config, "use_fused_obsnorm", True)) and self.horizon_size % 2 == 0 and \
+            if ok and bool(_get(self.config, "use_fused_obsnorm", True)) and self.horizon_size % 2 == 0 and self.n_envs % 32 == 0 and \
                     self.n_envs <= 4 * (1024 // D) and tuple(self.envs.buf_obs.shape) == (self.n_envs, D):
                 self._wstats = [(self.obs_mean, self.obs_var, self.obs_count),
                                 (torch.zeros_like(self.obs_mean), torch.ones_like(self.obs_var), torch.zeros_like(self.obs_count))]
             # ... and the previous step's bookkeeping as one more workgroup of the acting launch (rows [n, 2n) then come as raw
             # next observations; tiles must not straddle row n)
-            self._wpost = self._wstats is not None and self.n_envs % 32 == 0 and bool(_get(self.config, "use_fused_poststep", True))
+            self._wpost = self._wstats is not None and bool(_get(self.config, "use_fused_poststep", True))
         return self._wact
 
     def _rollout_state_tensors(self):

@@ -883,7 +883,8 @@ extern "C" int xrl_wide_act_step(const xrl_wide_act_t* p, xrl_stream_t stream) {
     XRL_CHECK_ARG(p->n > 0 && (p->flags & 3) != 0 && wide_act_ok(p->act, p->out_act));
     XRL_CHECK_ARG(!(p->flags & 1) || (p->act_out && p->logp_out));
     if (p->raw) XRL_CHECK_ARG((p->flags & 1) && p->mean_in && p->var_in && p->count_in && p->mean_out && p->var_out && p->count_out &&
-                              p->mean_in != p->mean_out && p->n <= 4 * (1024 / p->D));
+                              p->mean_in != p->mean_out && p->n <= 4 * (1024 / p->D) &&
+                              (p->n % FT == 0 || !(p->flags & 2)));   // a critic tile must not hold raw and normalised rows
     XRL_CHECK_ARG(!(p->flags & 2) || p->bootv_prev);
     XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->params) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->frag) & 15) == 0);
     for (int b = 0; b < 2; ++b) XRL_CHECK_ARG(p->br[b].w0 % 4 == 0 && p->br[b].w1 % 4 == 0 && p->br[b].w2 % 4 == 0);
