@@ -516,6 +516,21 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph):
             assert np.array_equal(f[k], f2[k]), k              # (incl. the bookkeeping that rode in the acting launches)
         for x, y in ((agent.ret_mean, b.ret_mean), (agent.ret_var, b.ret_var), (agent.ret_count, b.ret_count), (agent.returns, b.returns)):
             assert torch.equal(x, y)
+    if wide and use_graph:
+        # run-to-run determinism of the whole path (the acting launch's four-workgroup hand-off sums in part order whoever
+        # arrives last; gradient rows are reduced in row order): a second agent from the same seeds lands on the same bits
+        torch.manual_seed(0)
+        c = PPO_Agent(make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
+                                  critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1,
+                                  n_minibatch=2, ent_coef=0.0, gamma=0.99, use_hip_graph=True, use_fused_update=True),
+                      SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=10))
+        c.rollout()
+        c.set_indices(idx)
+        c.update()
+        torch.cuda.synchronize()
+        for k, v in c.memory.soa.fields.items():
+            assert np.array_equal(npy(v), f[k]), k
+        assert torch.equal(c.model.params.flat, agent.model.params.flat)
     if wide:                            # the optimiser launch kept the fragment-ordered copy of the middle layers current
         lr = agent.learner
         fr = lr._wide.frag.clone()
