@@ -1211,6 +1211,17 @@ def action_uniforms(seed, n_envs, step):
     return u01(philox4x32(seed, np.arange(n_envs), step, STREAM_ACTION)[0])
 
 
+def action_gaussians(seed, n_envs, step, A):
+    """The standard normals the device draws for env e, action dim j at global vector step `step` (xrl_policy_sample,
+    xrl_wide_act_step: Box-Muller on the first two words of Philox(seed; e, step, STREAM_GAUSS + j), float32)."""
+    z = np.zeros((n_envs, A), np.float32)
+    for j in range(A):
+        r = philox4x32(seed, np.arange(n_envs), step, STREAM_GAUSS + j)
+        u1, u2 = np.maximum(u01(r[0]), np.float32(5.96e-8)), u01(r[1])
+        z[:, j] = np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)
+    return z
+
+
 # --------------------------------------------------------------------------------------
 # CartPole-v1 physics (public equations, Barto-Sutton-Anderson 1983 / Gymnasium classic_control;
 # NOT part of the reference tree -- SURVEY.md section 7).  float64 state, float32 observations.

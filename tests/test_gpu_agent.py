@@ -480,6 +480,11 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph):
     x = f["actions"].reshape(-1, 6)
     lp = (-((x - mu) ** 2) / (2 * np.exp(ls) ** 2) - ls - 0.5 * np.log(2 * np.pi)).sum(-1)
     assert_close(f["aux_old_logp"].reshape(-1), lp, 1e-5, "old_logp", scale=float(np.abs(lp).max()))
+    # the actions themselves: mu + std * N(0, 1) with the engine's Philox draws (first rollout: global step = t)
+    mu3 = mu.reshape(T, n, 6)
+    for t_ in (0, 1, T - 1):
+        z = oracle.action_gaussians(agent.seed, n, t_, 6)
+        assert_close(f["actions"][t_], mu3[t_] + np.exp(ls) * z, 1e-5, f"actions at step {t_}", scale=4.0)
     assert (f["seg"][9] & 1).all() and (f["seg"][T - 1] & 1).all()       # truncation at 10 steps and at buffer end
     # update: oracle on the same minibatches
     idx = np.stack([np.random.default_rng(3).permutation(n * T)]).reshape(2, -1)
