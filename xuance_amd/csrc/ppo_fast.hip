@@ -23,6 +23,8 @@ constexpr int PI_FLOATS = PI_BH + 4;          // 1680: first layer | biases | me
 constexpr int PF_LDS_FLOATS = FT * (2 * PLD1 + 2 * PLD2) + NW * 32 * 33 + 3 * FT * 4 + PI_FLOATS;
 constexpr int PF_LDS_BYTES = PF_LDS_FLOATS * 4 + FT * 5 * 8;
 
+typedef unsigned fu32x4 __attribute__((ext_vector_type(4)));
+
 template <int CTRL>
 __device__ __forceinline__ float pdpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
@@ -167,6 +169,25 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
         for (int rr = 0; rr < 16; ++rr) {
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
             h2[row * PLD2 + col] = act_apply_c<ACT>(acc[rr] + bm);
+        }
+        // The forward fragments are consumed: the same registers take this wave's share of the BACKWARD section of the
+        // fragment copy (W1 with the reduction index n on the fragment's k axis; output tile kt = wave / 2, n-chunks
+        // q = half, half + 2, ..: xrl_pack_mid_frags), needed at dH1.  It has the head / loss / weight-gradient phases
+        // (~14 k cycles, no global loads) to arrive -- 128 KB per workgroup at the ~10 B/clk a CU pulls from L2.  Through a
+        // buffer descriptor: one VGPR of per-lane offset for all 16 loads, the chunk's place in the scalar offset.
+        // (Until round 2 the forward fragments were transposed through LDS in four 32 KB stages instead: 17 k cycles for
+        // 8 k of matrix work; measured on the 256-wide sibling, csrc/ppo_wide.hip.)
+        {
+            const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.frag_image), 0, 2 * 2 * PH * PH * 4, 0x00020000);
+            const int kt = wave >> 1, half = wave & 1;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < PD; ++i) {
+                const int q = half + 2 * i;
+                const fu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (2 * PH * PH + (kt * 32 + frag_slot(q, kt, 32, 2)) * 256) * 4, 0);
+                pf[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     lds_barrier();                                                                                   // #2 h2
@@ -320,58 +341,29 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
             }
     }
     QSTAMP(5);
-    // ---- dH1 = g2 . W1: output tile kt = wave / 2 (columns 32 kt ..), n-half = wave & 1 (chunks q = half, half + 2, ..),
-    //      partial tiles meet in `red`.  The B operand (W1 with the reduction index n on the MFMA's k axis) comes from the
-    //      forward fragments through LDS in four stages of 64 rows of W1: stage j = T[n - 64 j][k], written as the float4s
-    //      the fragments already are (4-float groups XOR-swizzled by the row so that rows do not collide) and read back as
-    //      the four scalars of an MFMA4 (lanes = consecutive k: conflict-free).  Waves 2j, 2j+1 own the rows of stage j.
-    //      Two stage buffers: the (dead) h2 region and the not-yet-used partial-tile region.
+    // ---- dH1 = g2 . W1: output tile kt = wave / 2 (columns 32 kt ..), n-half = wave & 1 (chunks q = half, half + 2, ..,
+    //      ascending: the same summation order as ever), partial tiles meet in `red`.  The B operand comes from the
+    //      backward fragments requested after the forward layer.
     {
         const int kt = wave >> 1, half = wave & 1;
         const float* arow = g2 + li * PLD2 + 4 * lh;
-        const int k_out = kt * 32 + li;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {                                // stages 2 jp (buffer h2) and 2 jp + 1 (buffer red)
-            lds_barrier();                                              // buffers free (first: h2 no longer read)
-            if ((wave >> 2) == jp) {                                    // waves 4 jp .. 4 jp + 3 own rows 128 jp .. 128 jp + 127
-                float* T = ((wave >> 1) & 1) ? red : h2;
-                const int nl = 32 * (wave & 1) + li;                    // row of this lane inside its stage
+        for (int hq = 0; hq < 2; ++hq) {
+            float4 af[PD / 2];
 #pragma unroll
-                for (int qq = 0; qq < PD; ++qq)                         // W1[n][8 qq + 4 lh .. + 3] -> group 2 qq + lh of row nl
-                    *reinterpret_cast<float4*>(T + nl * 128 + ((((2 * qq + lh) ^ (nl & 31))) << 2)) = pf[qq];
-            }
-            lds_barrier();                                              // stages visible
+            for (int i = 0; i < PD / 2; ++i) af[i] = *reinterpret_cast<const float4*>(arow + (half + 2 * (hq * 8 + i)) * 8);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const float* T = jj ? red : h2;
-                const int j = 2 * jp + jj;
-                float4 af[4], bt[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int q = 8 * j + half + 2 * i;                 // n-chunk (of 8) consumed by this wave, ascending
-                    af[i] = *reinterpret_cast<const float4*>(arow + q * 8);
-                    const int n0 = 8 * (half + 2 * i) + 4 * lh;         // rows n0 .. n0 + 3 of the stage
-                    float bs[4];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const int nr = n0 + s4;
-                        bs[s4] = T[nr * 128 + ((((k_out >> 2) ^ (nr & 31)) << 2) | (k_out & 3))];
-                    }
-                    bt[i] = make_float4(bs[0], bs[1], bs[2], bs[3]);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { MFMA4(af[i], bt[i], acc) }
-            }
+            for (int i = 0; i < PD / 2; ++i) { MFMA4(af[i], pf[hq * 8 + i], acc) }
         }
-        lds_barrier();                                                  // stage buffer `red` consumed: partial tiles may land
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
             red[(wave * 32 + row) * 33 + li] = acc[rr];
         }
+        (void)kt;
     }
     lds_barrier();                                                                                   // #4 red
     QSTAMP(6);
@@ -416,7 +408,7 @@ bool g_fast_enabled_ppo = true;
 
 bool ppo_fast_eligible(const xrl_ppo_fused_t& p) {
     if (!g_fast_enabled_ppo) return false;
-    if (p.D != 4 || p.A != 2 || p.n_layers != 4 || p.n_head_layers != 2 || p.n_levels != 4) return false;
+    if (p.D != 4 || p.A != 2 || p.n_layers != 4 || p.n_head_layers != 2 || p.n_levels != 4 || !p.frag_image) return false;
     const xrl_fused_layer_t &L0 = p.layers[0], &L1 = p.layers[1], &Ha = p.layers[2], &Hc = p.layers[3];
     if (p.level_width[1] != PH || p.level_width[2] != 2 * PH || p.level_width[3] != 3) return false;
     if (L0.K != 4 || L0.N != PH || L0.in_level != 0 || L0.out_level != 1 || L0.out_off != 0) return false;

@@ -293,8 +293,8 @@ class PPO_Learner(Learner):
         nf = ops.mid_frag_floats(self.model.plan)
         self.frag = torch.zeros(nf, device=dev) if nf else None       # MFMA-fragment-ordered copy of the middle layer
         if nf:
-            mf, _ = ops.frag_layout_maps(self.model.plan, P, dev)   # (the backward section is no longer read: the
-            self._mirrors += [(mf, self.frag)]                      #  minibatch kernel transposes the forward fragments in LDS)
+            mf, mb = ops.frag_layout_maps(self.model.plan, P, dev)  # forward section: first stream of the minibatch kernel;
+            self._mirrors += [(mf, self.frag), (mb, self.frag)]     # backward section: its second one (backward-data)
         self.packed = torch.zeros(memory.n_size * memory.n_envs * 8, device=dev)   # transition records the kernel gathers
         self._mirror = True
 
