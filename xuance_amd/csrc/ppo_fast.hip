@@ -3,7 +3,8 @@
 // extent a compile-time constant.  What that buys (see rollout_fast.hip for the measurements behind each rule):
 //   * no LDS parameter cache -- first-layer / head weights and biases sit in the registers of the threads that use them;
 //   * both 128 KB weight streams (W1 for the forward, W1^T for backward-data) are B-fragment register prefetches that
-//     stay in flight across LDS-only barriers; the second one is issued as soon as the first has been consumed;
+//     stay in flight across LDS-only barriers; the second one is issued as soon as the first has been consumed and has
+//     the loss / weight-gradient phases to arrive;
 //   * every loop is unrolled, so each phase issues its LDS reads back to back instead of one latency per access;
 //   * the 16 threads of a row all hold the row's logits after the DPP reduction, so the loss and the head backward need
 //     no broadcast and no extra barrier; h2 chunks stay in registers between the head forward and backward.
@@ -105,9 +106,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fast_kernel(xrl_ppo_fused_t
     if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
     float4 imgv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < PI_FLOATS / 4) imgv = *reinterpret_cast<const float4*>(img + tid * 4);
-    // ONE weight stream per workgroup: backward-data needs W1 transposed, and the per-CU stream rate (~10 B/clk) makes a
-    // second 128 KB stream as expensive as all the matrix-core work of the tile; the forward fragments stay in registers
-    // and are transposed through LDS instead (128 B/clk) when the backward pass needs them.
+    // First weight stream: the forward fragments.  Backward-data needs W1 transposed: a second 128 KB stream (the fragment
+    // copy's backward section) is requested right after the forward layer, see there; the per-CU stream rate (~10 B/clk)
+    // makes it as long as all the matrix-core work of the tile, but nothing waits for it until dH1.
     {
         // one load instruction per chunk whatever the source layout (two code paths assigning pf[] make hipcc split every
         // 16-byte load into four 4-byte ones: 4x the instructions and 4x the L1 traffic)

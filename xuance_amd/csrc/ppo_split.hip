@@ -10,7 +10,7 @@
 // What it is for: SMALL minibatches.  At the headline size (8 192 rows = 256 tiles) ppo_fast_kernel already has one
 // workgroup per CU; this kernel then runs two per CU (77 KB of LDS each) and -- measured with phase stamps,
 // tools/probe_split_phases.py -- wins nothing: the time of such a kernel is the LATENCY of one workgroup's chain of phases
-// (stream -> first layer -> 64 chained MFMAs -> heads / loss -> small gradients -> dW -> four transposition stages + dH ->
+// (stream -> first layer -> 64 chained MFMAs -> heads / loss -> small gradients -> dW -> dH from the second fragment stream ->
 // first-layer gradients), not matrix-pipe throughput, and halving a workgroup's work halves only some of those chains
 // (in-loop 33.1 vs 32.4 us per minibatch, plus 2.6 us for the fold in the reduction).  With 16 envs (512-row minibatches,
 // 16 tiles) the same split puts the minibatch on 32 CUs instead of 16 and shortens the dW / head / small-gradient phases:
@@ -26,6 +26,7 @@
 
 namespace xrl {
 
+typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
 constexpr int SH = 128;                      // hidden width (trunk and each branch)
 constexpr int SLD = SH + 4;                  // row stride of every LDS level
 // packed image layout (pack_rollout_cache_kernel) for 4-128-256-{2|1} -- see ppo_fast.hip
@@ -48,9 +49,9 @@ template <int ACT>
 __global__ void __launch_bounds__(FUSED_THREADS) ppo_split_kernel(xrl_ppo_fused_t p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* h1 = lds;                                   // [32][132] first hidden level
-    float* h2 = h1 + FT * SLD;                         // [32][132] this role's branch level; later transposition stage A
+    float* h2 = h1 + FT * SLD;                         // [32][132] this role's branch level
     float* g2 = h2 + FT * SLD;                         // [32][132] dLoss/d(pre-activation of h2)
-    float* xb = g2 + FT * SLD;                         // [32][132] transposition stage B; later g1 (this role's part)
+    float* xb = g2 + FT * SLD;                         // [32][132] g1 (this role's part)
     float* xs = xb + FT * SLD;                         // [32][4] gathered observations
     float* dzh = xs + FT * 4;                          // [32][4] dLoss/d(logits | value)
     float* rsc = dzh + FT * 4;                         // [32][4] gathered act | ret | adv | old_logp
@@ -168,6 +169,21 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_split_kernel(xrl_ppo_fused_
         for (int rr = 0; rr < 16; ++rr) {
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
             h2[row * SLD + col] = act_apply_c<ACT>(acc[rr] + bm);
+        }
+        // forward fragments consumed: the same registers take the BACKWARD section of the fragment copy for dH1 below (output
+        // tile kt = wave, this role's 16 n-chunks q = 16 role + i; xrl_pack_mid_frags) -- a second stream that has the
+        // head / loss / weight-gradient phases to arrive, instead of transposing the forward fragments through LDS
+        // (csrc/ppo_fast.hip, csrc/ppo_wide.hip: measured there)
+        {
+            const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.frag_image), 0, 2 * 2 * SH * SH * 4, 0x00020000);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < PD; ++i) {
+                const int q = 16 * role + i;
+                const su32x4 v = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (2 * SH * SH + (wave * 32 + frag_slot(q, wave, 32, 2)) * 256) * 4, 0);
+                pf[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     lds_barrier();                                                                                   // #2 h2
@@ -324,57 +340,26 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_split_kernel(xrl_ppo_fused_
             }
     }
     SSTAMP(6);
-    // ---- this role's part of dH1 = g2 . W1 (sum over its 128 rows n): wave kt < 4 owns output columns [32 kt, 32 kt + 32).
-    //      The B operand (W1 with n on the MFMA's k axis) comes from the forward fragments through LDS in four stages of 32
-    //      rows of W1 (wave j holds exactly the rows of stage j): written as the float4s the fragments already are (4-float
-    //      groups XOR-swizzled by the row), read back as the four scalars of an MFMA4 (lanes = consecutive k: conflict-free).
-    //      Stage buffers: the (dead) h2 region and xb.
-    {
-        const int kt = wave, k_out = kt * 32 + li;
+    // ---- this role's part of dH1 = g2 . W1 (sum over its 128 rows n): wave kt < 4 owns output columns [32 kt, 32 kt + 32);
+    //      B operand = the backward fragments requested after the forward layer (n-chunks ascending: the order it always had)
+    if (wave < 4) {
+        const int k_out = wave * 32 + li;
         const float* arow = g2 + li * SLD + 4 * lh;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {                                // stages 2 jp (buffer h2) and 2 jp + 1 (buffer xb)
-            lds_barrier();                                              // buffers free (first: h2 / head gradients done)
-            if (wave < 4 && (wave >> 1) == jp) {
-                float* T = (wave & 1) ? xb : h2;
+        for (int hq = 0; hq < 2; ++hq) {
+            float4 af[PD / 2];
 #pragma unroll
-                for (int qq = 0; qq < PD; ++qq)                         // W1[n][8 qq + 4 lh .. + 3] -> group 2 qq + lh of row li
-                    *reinterpret_cast<float4*>(T + li * 128 + (((2 * qq + lh) ^ li) << 2)) = pf[qq];
-            }
-            lds_barrier();                                              // stages visible
-            if (wave < 4) {
+            for (int i = 0; i < PD / 2; ++i) af[i] = *reinterpret_cast<const float4*>(arow + (hq * 8 + i) * 8);
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const float* T = jj ? xb : h2;
-                    const int j = 2 * jp + jj;                          // stage = n rows [32 j, 32 j + 32) = n-chunks 4 j .. 4 j + 3
-                    float4 af[4], bt[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        af[i] = *reinterpret_cast<const float4*>(arow + (4 * j + i) * 8);
-                        const int n0 = 8 * i + 4 * lh;                  // rows n0 .. n0 + 3 of the stage
-                        float bs[4];
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            const int nr = n0 + s4;
-                            bs[s4] = T[nr * 128 + ((((k_out >> 2) ^ nr) << 2) | (k_out & 3))];
-                        }
-                        bt[i] = make_float4(bs[0], bs[1], bs[2], bs[3]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { MFMA4(af[i], bt[i], acc) }
-                }
-            }
+            for (int i = 0; i < PD / 2; ++i) { MFMA4(af[i], pf[hq * 8 + i], acc) }
         }
-        lds_barrier();                                                  // stage buffer xb consumed: g1 may land there
-        if (wave < 4) {
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                xb[row * SLD + k_out] = acc[rr] * act_grad_c<ACT>(h1[row * SLD + k_out]);
-            }
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            xb[row * SLD + k_out] = acc[rr] * act_grad_c<ACT>(h1[row * SLD + k_out]);
         }
     }
     lds_barrier();                                                                                   // #5 g1 (this role's part)
