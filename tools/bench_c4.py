@@ -1,7 +1,8 @@
 """PPO at the shapes of BASELINE config C4 (HalfCheetah: obs 17, Box(6), Gaussian actor 17-256-256-6, critic
-17-256-256-1, 128 envs per GPU, horizon 256, 16 epochs x 8 minibatches of 4096) on one MI355X: the general layered
-path (grouped GEMM launches, update phase as one hipGraph; the synthetic MuJoCo-shaped env is a torch program, so the
-rollout is eager).  One JSON line."""
+17-256-256-1, 128 envs per GPU, horizon 256, 16 epochs x 8 minibatches of 4096) on one MI355X: rollout = two launches per
+vector step (xrl_wide_act_step + the MuJoCo-shaped synthetic provider), update = xrl_ppo_wide_minibatch + the optimiser
+launch per minibatch, both phases replayed from hipGraphs (csrc/ppo_wide.hip; config keys use_fused_update / use_fused_acting
+= False select the general layered path instead).  One JSON line."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from argparse import Namespace
