@@ -381,3 +381,20 @@ def test_weight_images_of_the_one_launch_kernels_cover_every_parameter_once():
     agent_names = [n for n in rnn.params.shapes if n.startswith("individual_q_networks")]
     assert len(ua) == sum(int(np.prod(rnn.params.shapes[n])) for n in agent_names) == 31689 and len(np.unique(ua)) == len(ua)
     assert np.array_equal(st.image.numpy()[ua], rnn.params.flat.numpy()[mpa >= 0]) and st.lds_bytes <= 160 * 1024
+
+
+def test_wide_kernel_class_is_recognised_on_the_host():
+    """Which networks xrl_ppo_wide_minibatch / xrl_wide_act_step cover (ops.PpoWideState.eligible, pure host logic): the two-branch
+    Gaussian class D-256-256-{A | 1} of configs/ppo/mujoco.yaml with D <= 24, A <= 8 and the activations the kernels are
+    instantiated for -- nothing else (shared representation, other widths, categorical heads, sigmoid)."""
+    from xuance_amd import ops
+    from xuance_amd.nets import ActorCriticNet
+    mk = lambda *a, **k: ActorCriticNet(*a, device="cpu", init=False, **k)
+    assert ops.PpoWideState.eligible(mk(17, 6, "gaussian", (), (256, 256), (256, 256), "leaky_relu", activation_action="tanh"))
+    assert ops.PpoWideState.eligible(mk(24, 8, "gaussian", (), (256, 256), (256, 256), "relu", activation_action=None))
+    assert not ops.PpoWideState.eligible(mk(25, 6, "gaussian", (), (256, 256), (256, 256), "relu", activation_action="tanh"))
+    assert not ops.PpoWideState.eligible(mk(17, 9, "gaussian", (), (256, 256), (256, 256), "relu", activation_action="tanh"))
+    assert not ops.PpoWideState.eligible(mk(17, 6, "gaussian", (), (128, 128), (128, 128), "relu", activation_action="tanh"))
+    assert not ops.PpoWideState.eligible(mk(17, 6, "gaussian", (256,), (256,), (256,), "relu", activation_action="tanh"))
+    assert not ops.PpoWideState.eligible(mk(17, 6, "categorical", (), (256, 256), (256, 256), "relu"))
+    assert not ops.PpoWideState.eligible(mk(17, 6, "gaussian", (), (256, 256), (256, 256), "sigmoid", activation_action="tanh"))
