@@ -544,6 +544,51 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph):
         assert torch.equal(fr, lr._wide.frag)
 
 
+@pytest.mark.parametrize("n,T,D,A,act,oact,obsnorm", [(48, 16, 17, 6, "leaky_relu", "tanh", True),     # tiles straddle row n
+                                                      (32, 15, 17, 6, "leaky_relu", "tanh", True),     # odd horizon
+                                                      (64, 8, 24, 8, "relu", None, True),              # largest D, A
+                                                      (32, 8, 3, 1, "tanh", "tanh", False),            # smallest, no obs norm
+                                                      (96, 8, 17, 6, "relu", "tanh", True)])
+def test_wide_acting_launch_matches_the_layered_rollout(n, T, D, A, act, oact, obsnorm):
+    """xrl_wide_act_step in every configuration the agent can put it in (with / without the statistics and the bookkeeping
+    inside the launch -- env counts that are not tile multiples and odd horizons fall back to launches of their own) against
+    the layered rollout (use_fused_acting: False: xrl_obs_normalize + three GEMM launches + xrl_policy_sample +
+    xrl_rollout_poststep) from the same seeds: statistics and bookkeeping bit for bit, network outputs within 1e-5 (the
+    dot products are summed in another order), over a whole rollout with episode ends, followed by one update phase."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import SyntheticMujocoVecEnv
+    out = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        cfg = make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
+                          critic_hidden_size=[256, 256], activation=act, activation_action=oact, n_epochs=1, n_minibatch=2,
+                          ent_coef=0.0, gamma=0.99, use_hip_graph=fused, use_fused_acting=fused, use_obsnorm=obsnorm)
+        agent = PPO_Agent(cfg, SyntheticMujocoVecEnv(n, seed=4, obs_dim=D, act_dim=A, max_episode_steps=5))
+        agent.rollout()
+        torch.cuda.synchronize()
+        assert (agent._wide_acting() is not None) == fused
+        if fused:
+            assert (agent._wstats is not None) == (T % 2 == 0 and n % 32 == 0)
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        st = dict(obs_mean=npy(agent.obs_mean), obs_var=npy(agent.obs_var), obs_count=npy(agent.obs_count),
+                  ret_mean=npy(agent.ret_mean), ret_var=npy(agent.ret_var), ret_count=npy(agent.ret_count))
+        info = agent.update()
+        out[fused] = (f, st, info, npy(agent.model.params.flat))
+    (f1, s1, i1, p1), (f0, s0, i0, p0) = out[True], out[False]
+    # the first vector step sees identical inputs: statistics and normalised observations agree bit for bit there; later
+    # steps act on actions that differ in the last bits, so trajectories are compared with the tolerance of the whole path
+    assert np.array_equal(f1["observations"][0], f0["observations"][0])
+    assert_close(f1["values"][0], f0["values"][0], 1e-5, "values[0]")
+    assert_close(f1["actions"][0], f0["actions"][0], 1e-5, "actions[0]", scale=4.0)
+    assert_close(f1["aux_old_logp"][0], f0["aux_old_logp"][0], 1e-5, "logp[0]", scale=float(np.abs(f0["aux_old_logp"][0]).max()))
+    assert np.array_equal(f1["terminals"], f0["terminals"]) and np.array_equal(f1["seg"], f0["seg"])
+    for k in ("observations", "actions", "values", "rewards", "advantages", "returns"):
+        assert_close(f1[k], f0[k], 2e-4, k, scale=max(1.0, float(np.abs(f0[k]).max())))
+    for k in s0:
+        assert_close(s1[k], s0[k], 1e-5, k)
+    assert np.isfinite(p1).all() and np.isfinite(i1["actor_loss"])
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_a2c_agent_vs_oracle(oracle, use_graph):
     """A2C_Agent (a2c_agent.py:18-79 + a2c_learner.py:34-90) on the device CartPole: ActorCritic model with one trunk
