@@ -156,8 +156,10 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
 // device-scope store and meets the other blocks at a counter barrier (relaxed atomics; all blocks are resident: one
 // 256-thread block per 256 parameters).  Saves a kernel boundary, the argument fetch + first round trip of the second
 // launch and the re-read of the gradient.  sync[1] departures (self-resetting), sync[2] time-out flag, sync[4 + b] arrival flag of block b.
-constexpr int RA_GROUPS = 1;                      // 256-thread groups per block (measured: 4 groups = 4x fewer barrier participants but the 35 MB slab read then rides on 34 CUs: 22.8 vs 15.8 us)
-constexpr int RA_THREADS = RED_THREADS * RA_GROUPS;
+// 256-thread groups per block of reduce_adam_kernel: 1 while the blocks do not outnumber the CUs (measured at the headline's 134
+// blocks: 4 groups = 4x fewer barrier participants, but the 35 MB slab read then rides on 34 CUs: 22.8 vs 15.8 us); 2 once
+// that still leaves a block for every CU (the MuJoCo network's 558 blocks -> 279: half as many flags to publish and poll).
+constexpr int RA_GROUPS_WIDE = 2;
 
 // block_sum over ONE 256-thread group of a larger block (same tree as block_sum on a 256-thread block)
 __device__ __forceinline__ double group_sum(double v, double* scratch4, int tg) {
@@ -176,23 +178,23 @@ __device__ __forceinline__ double group_sum(double v, double* scratch4, int tg) 
 // order -- so every rank holds bit-identical averaged gradients and the launch count of an update equals the single-GPU
 // one (no collective call, nothing for a graph to be cut at).  Buffers alternate with the step's parity: a peer can only
 // publish step s + 1 after its step-s launch -- and with it every read of this rank's step-s values -- has finished.
-template <bool XC>
-__global__ void __launch_bounds__(RA_THREADS) reduce_adam_kernel(const float* __restrict__ slabs, int n_split, int64_t slab_stride,
+template <bool XC, int G>
+__global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const float* __restrict__ slabs, int n_split, int64_t slab_stride,
                                                                  float* __restrict__ params, float* __restrict__ grad,
                                                                  float* __restrict__ m, float* __restrict__ v, int64_t P,
                                                                  xrl_adam_state_t* __restrict__ st, double* sumsq_part, int n_part,
                                                                  double max_norm, xrl_mirrors_t mir, unsigned* sync,
                                                                  xrl_exchange_t xc) {
-    // a block = RA_GROUPS groups of 256 threads; group `vb` (virtual block) does what block vb of grad_reduce_kernel /
+    // a block = G groups of 256 threads; group `vb` (virtual block) does what block vb of grad_reduce_kernel /
     // adam_step_kernel does, so every partial sum and every parameter sees the same arithmetic; fewer, larger blocks keep
     // the number of barrier participants (device-scope atomics) small.
     __shared__ double scratch[16];
-    __shared__ double gscratch[RA_GROUPS][4];
-    __shared__ double gsum[RA_GROUPS][4][64][4];
-    __shared__ float gtot[RA_GROUPS][256];
+    __shared__ double gscratch[G][4];
+    __shared__ double gsum[G][4][64][4];
+    __shared__ float gtot[G][256];
     __shared__ int s_fail, s_xfail;
     const int grp = threadIdx.x >> 8, tg = threadIdx.x & 255;
-    const int vb = blockIdx.x * RA_GROUPS + grp, n_vb = (int)((P / 4 + 63) / 64);
+    const int vb = blockIdx.x * G + grp, n_vb = (int)((P / 4 + 63) / 64);
     if (XC && threadIdx.x == 0) s_xfail = 0;
     const int64_t P4 = P / 4, st4 = slab_stride / 4;
     const int pq = tg & 63, sg = tg >> 6;
@@ -389,7 +391,8 @@ extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t
     XRL_CHECK_ARG((P & 3) == 0 && (slab_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0));
     const int n_vb = (int)((P / 4 + 63) / 64);
     XRL_CHECK_ARG(n_vb <= n_part && n_part <= 1024);
-    const int nb = (n_vb + RA_GROUPS - 1) / RA_GROUPS;
+    const int G = n_vb >= RA_GROUPS_WIDE * device_cu_count() ? RA_GROUPS_WIDE : 1;   // (every CU keeps a block)
+    const int nb = (n_vb + G - 1) / G;
     XRL_CHECK_ARG(nb <= 4 * device_cu_count());                 // every block resident (the barrier spins): 256 threads and
                                                                 // 13 KB of LDS per block, at least four fit a CU
     xrl_mirrors_t mir{};
@@ -404,10 +407,17 @@ extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t
         XRL_CHECK_ARG(xc.world <= XRL_XC_MAX_RANKS && xc.rank >= 0 && xc.rank < xc.world && n_vb <= XRL_XC_MAX_GROUPS);
         XRL_CHECK_ARG(xc.stride4 >= P / 4 && xc.max_spins > 0);
         for (int r = 0; r < xc.world; ++r) XRL_CHECK_ARG(xc.base[r] != nullptr);
-        hipLaunchKernelGGL(reduce_adam_kernel<true>, dim3(nb), dim3(RA_THREADS), 0, as_stream(stream), slabs, n_split, slab_stride,
-                           params, grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync, xc);
+        if (G == 1)
+            hipLaunchKernelGGL((reduce_adam_kernel<true, 1>), dim3(nb), dim3(RED_THREADS), 0, as_stream(stream), slabs, n_split, slab_stride,
+                               params, grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync, xc);
+        else
+            hipLaunchKernelGGL((reduce_adam_kernel<true, RA_GROUPS_WIDE>), dim3(nb), dim3(RED_THREADS * RA_GROUPS_WIDE), 0, as_stream(stream), slabs, n_split, slab_stride,
+                               params, grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync, xc);
+    } else if (G == 1) {
+        hipLaunchKernelGGL((reduce_adam_kernel<false, 1>), dim3(nb), dim3(RED_THREADS), 0, as_stream(stream), slabs, n_split, slab_stride,
+                           params, grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync, xrl_exchange_t{});
     } else {
-        hipLaunchKernelGGL(reduce_adam_kernel<false>, dim3(nb), dim3(RA_THREADS), 0, as_stream(stream), slabs, n_split, slab_stride,
+        hipLaunchKernelGGL((reduce_adam_kernel<false, RA_GROUPS_WIDE>), dim3(nb), dim3(RED_THREADS * RA_GROUPS_WIDE), 0, as_stream(stream), slabs, n_split, slab_stride,
                            params, grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, sync, xrl_exchange_t{});
     }
     XRL_CHECK_LAUNCH();
