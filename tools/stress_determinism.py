@@ -8,7 +8,7 @@ from test_gpu_headline import c2_config, npy
 from xuance_amd.agents import PPO_Agent
 from xuance_amd.envs import DeviceCartPoleVecEnv
 
-n, T, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+n, T, reps = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (256, 256, 5)
 kw = dict(use_persistent_rollout=os.environ.get("PERSIST", "1") == "1", use_hip_graph=os.environ.get("GRAPH", "1") == "1",
           use_fused_optimizer=os.environ.get("FUSEDOPT", "1") == "1",
           persistent_coherent_exchange=os.environ.get("COHERENT", "0") == "1")
