@@ -24,7 +24,7 @@ lr, m, opt = agent.learner, agent.model, agent.learner.optimizer
 bs, P = agent.batch_size, m.params.P
 st = {k: v[3 * bs:4 * bs] for k, v in lr._wstage.items()}
 dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
-names = ["start", "loads->LDS", "layer0", "layer1", "heads+loss", "small grads", "dW1", "dH1 (8 stages)", "dW0"]
+names = ["start", "loads->LDS", "layer0", "layer1", "heads+loss", "small grads", "dW1", "dH1", "dW0"]
 
 
 def launch(role=None):
