@@ -16,7 +16,8 @@
 //     16 k cycles of matrix work, the stage writes and barriers could not be hidden.)
 //   * 8 waves, wave w owns output columns [32 w, 32 w + 32) of every 256-wide product -- forward, backward-data and the
 //     rows [32 w, ..) of dW1 -- so no split-K partial tiles are needed anywhere.
-//   * first layer (K = D <= 24) on the matrix cores too, B fragments read straight from the parameters.
+//   * first layer (K = D <= 24) on the matrix cores too; its weights are fetched as whole float4s of each wave's 32 rows and
+//     handed over through LDS (per-lane fragment loads would be uncoalesced 4-byte loads in front of the weight stream).
 #include "common.h"
 #include "mlp_tile.h"
 #include "ppo_math.h"
