@@ -8,6 +8,7 @@ Every fixture stores the exact inputs next to the reference's outputs so any eng
 Versions used to generate the committed fixtures: torch 2.10.0+rocm7.0 (CPU path), numpy 2.2.6,
 python 3.10.12, 8 threads.
 """
+import copy
 import os
 import sys
 from argparse import Namespace
@@ -236,6 +237,7 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo", size=None):
     if name == "a2c":
         cfg.running_steps = 40          # the LinearLR horizon of a2c_learner.py:21; short so the decay is visible
         cfg.end_factor_lr_decay = 0.5
+    model64 = as_double(model)                                   # the reference ITSELF in float64 (twin below)
     learner = learner_cls(cfg, model, cb)
     batches = []
     for u in range(n_updates):
@@ -254,17 +256,118 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo", size=None):
         batches.append(dict(obs=obs, actions=actions, returns=ret, advantages=adv, old_logp=old_logp,
                             values=quant(rng.standard_normal(bs).astype(np.float32))))
 
-    def call(b):
-        return learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
-                              advantages=b["advantages"], aux_batch={"old_logp": b["old_logp"]},
-                              batch_size=len(b["obs"]))
+    def call(b, L=learner):
+        return L.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
+                        advantages=b["advantages"], aux_batch={"old_logp": b["old_logp"]},
+                        batch_size=len(b["obs"]))
     out = run_learner_updates(learner, model, cb, batches, call)
+    out.update(float64_twin(learner_cls(cfg, model64, Capture()), model64, batches, lambda L, b: call(b, L)))
     out["cfg"] = np.array([cfg.learning_rate, cfg.vf_coef, cfg.ent_coef, cfg.clip_range, cfg.grad_clip_norm,
                            getattr(cfg, "end_factor_lr_decay", 1.0),
                            cfg.running_steps if name == "a2c" else learner.total_iters])
     if size is not None:
         out["n_updates"] = np.int64(n_updates)
     np.savez_compressed(os.path.join(OUT, f"{name}_{dist}{'_' + size if size else ''}.npz"), **out)
+
+
+def as_double(model):
+    """model.double() of a reference policy, usable: the representation classes cast their input to float32
+    (representations/mlp.py:22,56) -- for the float64 yardstick that one cast is float64; nothing else is touched."""
+    from xuance.torch.rl_models.modules.outputs import RepresentationOutput
+    m64 = copy.deepcopy(model).double()
+    for rep in [m for m in m64.modules() if isinstance(m, (Basic_MLP, Basic_Identical))]:
+        body = getattr(rep, "model", None)
+        rep.forward = (lambda observations, _b=body, **kw: RepresentationOutput(
+            embeddings=_b(torch.as_tensor(observations, dtype=torch.float64)) if _b is not None
+            else torch.as_tensor(observations, dtype=torch.float64)))
+    return m64
+
+
+def float64_twin(learner64, model64, batches, call):
+    """The same updates by the reference's OWN learner on `model.double()` with float64 inputs: the yardstick for quantities
+    where the reference's float32 evaluation is itself further than 1e-5 (of the tensor's scale) from the exact value --
+    weight gradients summed over 8 192 rows with heavy cancellation (critic.values.0.weight of the C2 fixture: the float32
+    reference sits 1.5e-4 from this twin).  Stored rounded to float32 (6e-8 relative: far below what is compared).
+    `call(learner, batch)` = the generator's own update call."""
+    out = {}
+    for u, b in enumerate(batches):
+        call(learner64, {k: (np.asarray(v, np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in b.items()})
+        out.update(flat(f"u{u}/grad64", {n: p.grad.detach().numpy().astype(np.float32)
+                                         for n, p in model64.named_parameters() if p.grad is not None}))
+        out.update(flat(f"u{u}/param64", {k: v.astype(np.float32) for k, v in sd_np(model64).items()}))
+    return out
+
+
+CHAIN_ROWS, CHAIN_MB, CHAIN_EPOCHS = 65536, 8, 8                 # the headline's update phase: 8 epochs x 8 minibatches of 8 192
+
+
+def chain_indices(epochs=CHAIN_EPOCHS, rows=CHAIN_ROWS, n_mb=CHAIN_MB):
+    """Minibatch index matrix [epochs * n_mb, rows / n_mb] of the chain fixture: epoch e visits row (a_e * i + b_e) mod rows
+    (a_e odd: a permutation), cut into n_mb contiguous slices like on_policy.py:196-204 cuts its shuffled arange.  Pure integer
+    arithmetic, so the test rebuilds it instead of storing 2 MB of indices (tests/test_gpu_headline.py has the same lines)."""
+    i = np.arange(rows, dtype=np.int64)
+    return np.stack([((2 * (1103515245 * (e + 1) % 32768) + 1) * i + 12345 * (e + 1)) % rows for e in range(epochs)]
+                    ).reshape(epochs * n_mb, rows // n_mb)
+
+
+def golden_ppo_chain():
+    """64 CHAINED updates by the reference's PPO_Learner on the CartPole net over one synthetic 256 x 256 rollout (the headline's
+    update phase: 8 epochs x 8 minibatches of 8 192 rows, advantages normalised per minibatch exactly as
+    DummyOnPolicyBuffer.sample does, memory_tools.py:281-282), in float32 AND by the same learner on model.double().  The
+    distance between the two after 16 and 64 updates is how far the reference's own float32 arithmetic drifts over a chain
+    (PPO's clipped surrogate is discontinuous in the parameters, Adam divides by sqrt(v) + eps) -- the measured yardstick for
+    the engine's chain in tests/test_gpu_headline.py.  old_logp is the initial policy's own log-probability of the stored
+    action (ratio = 1 at the first update, as after a real rollout)."""
+    torch.manual_seed(3)
+    rng = np.random.default_rng(905)
+    act_fn, init = nn.LeakyReLU, torch.nn.init.orthogonal_
+    D, A, N = 4, 2, CHAIN_ROWS
+    rep = Basic_MLP((D,), [128], None, init, act_fn, "cpu")
+    actor = CategoricalActorHead(128, [128], A, None, init, act_fn, "cpu")
+    critic = ValueHead(128, [128], None, init, act_fn, "cpu")
+    cfg = base_config(horizon_size=256, n_epochs=8, n_minibatch=8, vf_coef=0.25, ent_coef=0.01, clip_range=0.2,
+                      parallels=256, running_steps=256 * 256 * 40)
+    model = SharedActorCritic(rep, actor, critic)
+    model64 = as_double(model)
+    learner, learner64 = PPO_Learner(cfg, model, Capture()), PPO_Learner(cfg, model64, Capture())
+    obs = q16(np.clip(rng.standard_normal((N, D)), -5, 5).astype(np.float32))
+    with torch.no_grad():
+        dist0 = model(torch.from_numpy(obs)).distributions
+        actions = dist0.stochastic_sample().numpy().astype(np.float32)
+        old_logp = dist0.log_prob(torch.from_numpy(actions)).numpy().astype(np.float32)
+    adv = q16((rng.standard_normal(N) * 2.0 + 0.3 * obs[:, 2]).astype(np.float32))      # raw (un-normalised) advantages
+    ret = q16((5.0 + 3.0 * rng.standard_normal(N)).astype(np.float32))
+    idx = chain_indices()
+    out = dict(obs=obs.astype(np.float16), actions=actions.astype(np.int8), old_logp=old_logp, advantages=adv.astype(np.float16),
+               returns=ret.astype(np.float16))
+    out.update(flat("init", sd_np(model)))
+    infos = []
+    for k in range(idx.shape[0]):
+        a = adv[idx[k]]
+        a = (a - np.mean(a)) / (np.std(a) + 1e-8)                                        # memory_tools.py:281-282
+        b = dict(obs=obs[idx[k]], actions=actions[idx[k]], returns=ret[idx[k]], advantages=a, old_logp=old_logp[idx[k]])
+        info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], advantages=b["advantages"],
+                              aux_batch={"old_logp": b["old_logp"]}, batch_size=len(a))
+        infos.append([info[n] for n in ("actor_loss", "critic_loss", "entropy", "predict_value", "clip_ratio", "learning_rate")])
+        a64 = adv[idx[k]].astype(np.float64)
+        a64 = (a64 - np.mean(a64)) / (np.std(a64) + 1e-8)
+        b64 = {n: np.asarray(v, np.float64) for n, v in b.items()}
+        learner64.update(obs=b64["obs"], actions=b64["actions"], returns=b64["returns"], advantages=a64,
+                         aux_batch={"old_logp": b64["old_logp"]}, batch_size=len(a))
+        if k == 0:
+            out.update(flat("u0/grad", {n: p.grad.numpy().copy() for n, p in model.named_parameters()}))
+            out.update(flat("u0/grad64", {n: p.grad.numpy().astype(np.float32) for n, p in model64.named_parameters()}))
+        if k + 1 in (1, 16, 64):
+            out.update(flat(f"after{k + 1}/param", sd_np(model)))
+            out.update(flat(f"after{k + 1}/param64", {n: v.astype(np.float32) for n, v in sd_np(model64).items()}))
+    out["infos"] = np.asarray(infos, np.float64)
+    out["cfg"] = np.array([cfg.learning_rate, cfg.vf_coef, cfg.ent_coef, cfg.clip_range, cfg.grad_clip_norm, 1.0,
+                           learner.total_iters])
+    out["param_names"] = np.array([n for n, _ in model.named_parameters()])
+    for n in out["param_names"]:
+        x32, x64 = out[f"after64/param/{n}"], out[f"after64/param64/{n}"]
+        print(f"  chain drift after 64 updates {n:36s} max|f32 - f64| / max|f64| = {np.abs(x32 - x64).max() / np.abs(x64).max():.2e}")
+    np.savez_compressed(os.path.join(OUT, "ppo_chain_c2.npz"), **out)
 
 
 def golden_ppokl(dist):
@@ -816,6 +919,7 @@ def golden_pg(dist):
                 p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.1))
     cfg = base_config(horizon_size=256, n_epochs=1, n_minibatch=1, ent_coef=0.01, end_factor_lr_decay=0.5)
     cb = Capture()
+    model64 = as_double(model)
     learner = PG_Learner(cfg, model, cb)
     batches = []
     for u in range(3):
@@ -824,6 +928,8 @@ def golden_pg(dist):
         batches.append(dict(obs=obs, actions=actions, returns=rng.standard_normal(bs).astype(np.float32)))
     out = run_learner_updates(learner, model, cb, batches,
                               lambda b: learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], batch_size=bs))
+    out.update(float64_twin(PG_Learner(cfg, model64, Capture()), model64, batches,
+                            lambda L, b: L.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], batch_size=bs)))
     out["cfg"] = np.array([cfg.learning_rate, cfg.ent_coef, cfg.grad_clip_norm, cfg.end_factor_lr_decay, learner.total_iters])
     np.savez_compressed(os.path.join(OUT, f"pg_{dist}.npz"), **out)
 
@@ -839,6 +945,7 @@ def golden_baseline_sizes():
     golden_qmix(True, size="c5")
     golden_qmix_rnn(True, size="c5")
     golden_qmix_rnn(True, fixed=True, size="c5")
+    golden_ppo_chain()
 
 
 if __name__ == "__main__":

@@ -545,6 +545,7 @@ def ppo_update(sd, opt, batch, cfg, **kw):
     raw = {k: g.copy() for k, g in grads.items()}
     if cfg.get("use_grad_clip", True):
         info["grad_norm"] = AdamOracle.clip_grad_norm_(grads, cfg["grad_clip_norm"])
+    info["clipped_grads"] = {k: g.copy() for k, g in grads.items()}     # what Adam consumes (tests propagate tolerances through it)
     opt.step(grads)
     info["learning_rate"] = opt.lr
     return info, raw

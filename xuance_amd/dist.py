@@ -3,8 +3,10 @@
 The path shards over environments: every rank owns n_envs/world envs and its own rollout
 buffer, parameters are replicated, and the ONLY data-path collective is one all-reduce (mean) of the flat
 gradient buffer per optimiser step -- 136 KB..570 KB, latency-bound on the xGMI mesh, hence a single flat message
-instead of DDP's per-bucket calls -- plus, when observation normalisation is on, the moments all-reduce of
-xuance/torch/utils/tensor_statistics.py:48-58.
+instead of DDP's per-bucket calls.  Observation / return statistics stay PER RANK, as in the reference's default
+(RunningMeanStd(use_mpi=False), statistic_tools.py:65-110); only its `use_tensor_memory` variant all-reduces batch moments
+per step (tensor_statistics.py:48-58) -- `allreduce_moments_` below is that rule for callers that want it, the agents do
+not call it.
 """
 import os
 
@@ -38,7 +40,12 @@ def world_size():
 
 def allreduce_mean_(flat):
     """In-place mean over ranks of one flat tensor (what DDP does to gradients, as ONE message)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("XRL_DIST_STUB") != "1":
+            raise RuntimeError("allreduce_mean_: WORLD_SIZE > 1 but torch.distributed is not initialised -- the ranks would "
+                               "train independent replicas (call xuance_amd.dist.init_distributed_mode() first)")
+        return flat
+    if dist.get_world_size() == 1:
         return flat
     global _avg_ok
     if _avg_ok and dist.get_backend() == "nccl":           # RCCL averages inside the collective: no extra launch
@@ -50,6 +57,22 @@ def allreduce_mean_(flat):
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)            # gloo (CPU tests) has no AVG
     flat.div_(dist.get_world_size())
     return flat
+
+
+def allreduce_moments_(batch_mean, batch_var, batch_count):
+    """The reference's `_sync_distributed_moments` (xuance/torch/utils/tensor_statistics.py:48-58) as ONE message: the
+    per-rank batch means and variances are AVERAGED over the ranks (the between-rank variance is ignored -- its rule, kept),
+    the counts are summed.  Tensors of any (equal) shape for mean / var, a scalar tensor for the count; in place."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return batch_mean, batch_var, batch_count
+    n = batch_mean.numel()
+    packed = torch.cat([batch_mean.reshape(-1), batch_var.reshape(-1), batch_count.reshape(-1)[:1].to(batch_mean.dtype)])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    w = dist.get_world_size()
+    batch_mean.copy_((packed[:n] / w).view_as(batch_mean))
+    batch_var.copy_((packed[n:2 * n] / w).view_as(batch_var))
+    batch_count.copy_(packed[2 * n:2 * n + 1].view_as(batch_count).to(batch_count.dtype))
+    return batch_mean, batch_var, batch_count
 
 
 _capturable = None

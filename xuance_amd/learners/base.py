@@ -132,6 +132,11 @@ class Learner:
         if self.distributed_training:
             self.world_size = int(os.environ["WORLD_SIZE"])
             self.rank = int(os.environ["RANK"])
+            if self.world_size > 1:                             # what Agent.__init__ does in the reference (agent.py:76-80:
+                import torch.distributed as tdist               # init_distributed_mode) when nobody has done it yet
+                if not tdist.is_initialized():
+                    from ..dist import init_distributed_mode
+                    init_distributed_mode()
         else:
             self.world_size, self.rank = 1, 0
         self.use_grad_clip = getattr(config, "use_grad_clip", False)
@@ -156,6 +161,30 @@ class Learner:
                 self._xc = xdist.GradientExchange(self.model.params.P, self.device)
         return self._xc
 
+    OPT_TIMEOUT_MSG = ("xrl_reduce_adam: %s timed out -- the optimiser step of this update phase is invalid: parameters of the "
+                       "blocks that saw the time-out were NOT stepped (set use_fused_optimizer: False to use the two-launch "
+                       "sequence, dist_gradient_exchange: False to average through the process group)")
+
+    def raise_on_optimizer_timeout(self, code=None):
+        """xrl_reduce_adam's status word sync[2]: 1 = the inter-block barrier, 2 = the wait for the other ranks' gradient rows
+        expired.  Every learner calls this where it reads an update's results back (`code` given: the caller has the word
+        already, e.g. inside its own read-back; else one 4-byte copy per optimiser scratch tensor of this learner)."""
+        if code is None:
+            code = 0
+            for name in ("opt_sync", "_lsync"):
+                t = getattr(self, name, None)
+                if t is not None:
+                    code = code or int(t[2].item())
+        if code:
+            raise ops.XrlError(self.OPT_TIMEOUT_MSG % ("the wait for the other ranks' gradient rows" if code == 2
+                                                       else "the inter-block barrier"))
+
+    def read_optimizer(self):
+        """optimizer.read() + the time-out check (the host is synchronous here anyway)."""
+        st = self.optimizer.read()
+        self.raise_on_optimizer_timeout()
+        return st
+
     def needs_collective(self):
         """Several ranks AND no in-launch exchange: the update must stop at a process-group all-reduce."""
         return bool(self.distributed_training and self.world_size > 1 and self.gradient_exchange() is None)
@@ -170,7 +199,10 @@ class Learner:
             return
         import torch.distributed as dist
         if not dist.is_initialized():
-            return
+            if os.environ.get("XRL_DIST_STUB") == "1":          # tools/time_distributed_path.py: structure cost, no peers
+                return
+            raise RuntimeError("distributed_training with WORLD_SIZE > 1 but torch.distributed is not initialised: the ranks "
+                               "would train independent replicas (xuance_amd.dist.init_distributed_mode() -- the agents call it)")
         from ..dist import broadcast_
         broadcast_(self.model.params.flat, 0)
         if getattr(self.model, "target_flat", None) is not None:

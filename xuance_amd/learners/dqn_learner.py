@@ -126,7 +126,7 @@ class DQN_Learner(Learner):
         n_epochs, M = self._pending_phase
         self._pending_phase = None
         sums = self._epoch_sums.cpu().numpy()               # the one host sync of the phase
-        st = self.optimizer.read()
+        st = self.read_optimizer()
         info, A = {}, self.n_actions
         for e in range(n_epochs):
             self.iterations += int(count)
@@ -160,7 +160,7 @@ class DQN_Learner(Learner):
         S = self._step(M, act, rew, ter)
         ops.sum_partials(self.partials, S, 8, self.sums)
         s = self.sums.cpu().numpy()
-        st = self.optimizer.read()
+        st = self.read_optimizer()
         info.update({self._key("Qloss"): float(s[0] / M), self._key("predictQ"): float(s[1] / M),
                      self._key("learning_rate"): st.last_lr})
         A = self.n_actions

@@ -157,11 +157,7 @@ class PPO_Learner(Learner):
         rb = self._readback.cpu().numpy()                           # the one host sync of an update
         s = rb[:8]
         self.last_status = rb[8:10].view(np.int32).tolist()
-        code = int(rb[10:12].view(np.int32)[2])
-        if code != 0:
-            raise ops.XrlError("xrl_reduce_adam: %s timed out -- the optimiser step of this update phase is invalid (set "
-                               "use_fused_optimizer: False to use the two-launch sequence)"
-                               % ("the wait for the other ranks' gradient rows" if code == 2 else "the inter-block barrier"))
+        self.raise_on_optimizer_timeout(int(rb[10:12].view(np.int32)[2]))
         st = self.optimizer.read()
         return {self._key("actor_loss"): float(-s[0] / M), self._key("critic_loss"): float(s[1] / M),
                 self._key("entropy"): float(s[2] / M), self._key("learning_rate"): st.last_lr,
@@ -548,7 +544,7 @@ class PPOKL_Learner(PPO_Learner):
         self.kl_coef = float(rb[8])
         count = M * (self.model.action_dim if self.model.dist == "gaussian" else 1)
         kl = float(np.float32(s[5] / count))
-        k, st = self._key, self.optimizer.read()
+        k, st = self._key, self.read_optimizer()
         return {k("actor-loss"): float(-s[0] / M + used * kl), k("critic-loss"): float(s[1] / M), k("entropy"): float(s[2] / M),
                 k("learning_rate"): st.last_lr, k("kl"): kl, k("predict_value"): float(s[3] / M)}
 

@@ -287,7 +287,7 @@ class QMIX_Learner(Learner):
 
     def _info_rnn(self, B, T, sums):
         """loss = sum((td * filled)^2) / sum(filled) (qmix_learner.py:82-84); predictQ = mean over all B*T (:101)."""
-        return {"learning_rate": self.optimizer.read().last_lr, "loss_Q": float(sums[0] / sums[2]),
+        return {"learning_rate": self.read_optimizer().last_lr, "loss_Q": float(sums[0] / sums[2]),
                 "predictQ": float(sums[1] / (B * T))}
 
     def _cb_rnn(self, B, T):
@@ -372,7 +372,7 @@ class QMIX_Learner(Learner):
         kind, n_epochs, B, T = self._pending_phase
         self._pending_phase = None
         sums = self._epoch_sums.cpu().numpy()               # the one host sync of the phase
-        st = self.optimizer.read() if kind == "ff" else None
+        st = self.read_optimizer() if kind == "ff" else None
         info = {}
         for e in range(n_epochs):
             self.iterations += int(count)
@@ -448,7 +448,7 @@ class QMIX_Learner(Learner):
         info = self.callback.on_update_start(self.iterations, model=self.policy) or {}
         self._step(B)
         ops.sum_partials(self.partials, B, 8, self.sums)
-        info.update(self._info_ff(B, self.sums.cpu().numpy(), self.optimizer.read().last_lr))
+        info.update(self._info_ff(B, self.sums.cpu().numpy(), self.read_optimizer().last_lr))
         info.update(self.callback.on_update_end(self.iterations, model=self.policy, info=info, **self._cb_ff(B)) or {})
         return info
 
