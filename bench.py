@@ -2,15 +2,23 @@
 """Benchmark of the hot path: env-steps/sec of PPO-Clip rollout+update on CartPole-v1 (BASELINE.json configs[1]:
 256 parallel envs per GPU, horizon 256, 8 epochs x 8 minibatches of 8192, net 4->128->{128->2,128->1}).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload c2|c4|qmix3m|qmix3m_gru]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch = one rollout of horizon_size vector steps on n_envs envs
 (policy inference, device CartPole physics, SoA store, obs/reward normalisation, GAE) followed by the full update
 phase (n_epochs x n_minibatch minibatch updates: gather, fp32-MFMA forward/backward, PPO loss, clip, Adam).
-Nothing is skipped inside the timed region.  Weak scaling: every rank owns n_envs envs and its own buffer,
-gradients are averaged with one flat RCCL all-reduce per optimiser step.  Rank 0 prints ONE JSON line.
+Nothing is skipped inside the timed region.  Weak scaling: every rank owns n_envs envs and its own buffer, gradients are
+averaged once per optimiser step.  Rank 0 prints ONE JSON line.
+
+N > 1: before the timed region every usable way of averaging the gradients (inside the optimiser launch through IPC-mapped
+peer buffers / RCCL all-reduce captured in the update graph / graphs cut at the all-reduce; xuance_amd/dist.py) is TIMED on
+the real workload and the fastest is adopted -- `config.gradient_paths_ms` holds all timings, `config.gradient_average` the one
+the timed region used, `config.rccl_world` a one-element all-reduce, `config.rollout_mode` how the rollouts ran.  The N-rank
+run also carries `secondary` lines for the two other configurations BASELINE.json sizes for a node: configs[3] (`c4`,
+HalfCheetah shapes, 128 envs/GPU) and configs[4] (`qmix3m`, 64 envs/GPU), so that a scaling run yields their curves too
+(`--workload` makes either the main line instead).
 """
 import argparse
 import json
@@ -28,14 +36,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 PEAK_HBM_GBS = 8000.0
 
 
-def make_config(n_envs, horizon, world, rank):
-    return Namespace(agent="PPO", env_id="CartPole-v1", representation="Basic_MLP", representation_hidden_size=[128],
-                     actor_hidden_size=[128], critic_hidden_size=[128], activation="leaky_relu", seed=1 + rank,
-                     parallels=n_envs, running_steps=10 ** 9, horizon_size=horizon, n_epochs=8, n_minibatch=8,
-                     learning_rate=4e-4, vf_coef=0.25, ent_coef=0.01, clip_range=0.2, gamma=0.98, use_gae=True,
-                     gae_lambda=0.95, use_advnorm=True, use_grad_clip=True, grad_clip_norm=0.5, use_obsnorm=True,
-                     use_rewnorm=True, obsnorm_range=5, rewnorm_range=5, distributed_training=world > 1, device="cuda",
-                     model_dir="/tmp/xrl_bench_models", use_hip_graph=True)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_workloads as bw  # noqa: E402
+
+make_config = bw.c2_config          # (tools/bench_secondary.py builds its 16-env agent from the same configuration)
 
 
 _PMC_SOURCE = [None]
@@ -211,6 +215,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the PPO-16-envs / QMIX-3m / eager-PyTorch lines")
     ap.add_argument("--no-role-split", action="store_true", help="one workgroup per minibatch tile (ppo_fast_kernel) instead of two")
+    ap.add_argument("--workload", choices=bw.WORKLOADS, default="c2", help="which BASELINE configuration is the main line")
+    ap.add_argument("--grad-path", choices=("measure", "auto", "exchange", "captured", "cut"), default="measure",
+                    help="N > 1: how the ranks average gradients; measure (default) = time every usable way, adopt the fastest")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -225,64 +232,39 @@ def main():
         from xuance_amd.dist import init_distributed_mode
         init_distributed_mode(os.environ.get("XRL_DIST_BACKEND", "nccl"))     # "nccl" = RCCL over xGMI
     import torch.distributed as dist
-    from xuance_amd.agents import PPO_Agent
-    from xuance_amd.envs import DeviceCartPoleVecEnv
+    device = torch.device("cuda", local_rank)
+    c2 = args.workload == "c2"
+    n_envs = args.n_envs if c2 else None
 
-    torch.manual_seed(1)                               # same initial parameters on every rank (DDP broadcasts rank 0's)
-    cfg = make_config(args.n_envs, args.horizon, world, rank)
-    cfg.use_role_split_update = False if args.no_role_split else "auto"
-    env = DeviceCartPoleVecEnv(args.n_envs, seed=1 + rank)
-    agent = PPO_Agent(cfg, env)
+    path, paths_ms = "auto", None
     if world > 1:
-        from xuance_amd.dist import broadcast_
-        broadcast_(agent.model.params.flat, 0)
+        if args.grad_path == "measure":
+            path, paths_ms = bw.measure_paths(args.workload, world, rank, device, n_envs, args.horizon)
+        else:
+            path = args.grad_path
+    extra = {"use_role_split_update": False if args.no_role_split else "auto"} if c2 else None
+    runner = bw.Runner(args.workload, world, rank, path, n_envs, args.horizon, extra=extra)
+    agent = runner.agent
+    elapsed, env_steps = bw.timed(runner, args.steps, args.warmup, world)
+    info = runner.info or {}
 
-    def step():
-        agent.rollout()
-        return agent.update()
-
-    for _ in range(args.warmup):
-        step()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    info = {}
-    for _ in range(args.steps):
-        info = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    env_steps = world * args.n_envs * args.horizon * args.steps
-    out = {"metric": "env-steps/sec (rollout+update), PPO-Clip CartPole-v1", "value": round(env_steps / elapsed, 1),
+    out = {"metric": runner.metric, "value": round(env_steps / elapsed, 1),
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "PPO-Clip CartPole-v1, %d envs/GPU x horizon %d, 8 epochs x 8 minibatches of %d, "
-                                  "net 4-128-{128-2,128-1} (BASELINE.json configs[1])"
-                                  % (args.n_envs, args.horizon, args.n_envs * args.horizon // 8),
-                      "env": "device-resident CartPole-v1 (xrl_cartpole_step)", "parallelism": "dp%d" % world,
-                      "env_steps_per_step": world * args.n_envs * args.horizon,
-                      "last_info": {k: round(float(v), 6) for k, v in info.items()}}}
-    if world > 1:      # which of the three ways (chosen by self-tests at start-up, xuance_amd/dist.py) averaged the gradients
-        out["config"]["gradient_average"] = (
-            "inside the optimiser launch through IPC-mapped exchange buffers (xrl_reduce_adam_exchange; no collective call on the data path)"
-            if getattr(agent.learner, "_xc", None) is not None else
-            "process-group all-reduce captured in the update graph" if getattr(agent, "_whole_phase_graph", False) else
-            "process-group all-reduce between update graphs cut at the collectives")
+           "config": {"workload": runner.describe, "env": runner.env_name, "parallelism": "dp%d" % world,
+                      "env_steps_per_step": env_steps // args.steps, "rollout_mode": runner.rollout_mode(),
+                      "last_info": {k: round(float(v), 6) for k, v in info.items() if isinstance(v, (int, float))}}}
+    if world > 1:      # which way averaged the gradients in the timed region, what every usable way cost, and a sign of life of RCCL
+        out["config"]["gradient_average"] = runner.gradient_average()
+        out["config"]["gradient_path"] = path
+        out["config"]["gradient_paths_ms"] = paths_ms
+        out["config"]["rccl_world"] = bw.rccl_world(world)
+        out["config"]["backend"] = dist.get_backend()
     # the update-phase rate separately (transitions consumed per second by GAE + sampling + the
     # minibatch updates), so that the simulator's share is separable.  Timed after the contract region, same graphs.
     phases = None
-    if world == 1 and not args.no_roofline:
+    if world == 1 and c2 and not args.no_roofline:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
@@ -300,10 +282,28 @@ def main():
                   "update_sample_passes_per_s": round(n_tr * 8 * 5 / (t3 - t2), 1),
                   "note": "rollout = %d vector steps incl. GAE; update = 8 epochs x 8 minibatches over the same %d transitions"
                           % (args.horizon, n_tr)}
+    nrank_secondary = {}
+    if world > 1 and c2 and not args.no_secondary:
+        # the two other node-sized BASELINE configurations on the same ranks (every rank takes part: collectives inside)
+        runner.close()
+        for w, st, wu in (("c4", 3, 1), ("qmix3m", 12, 3)):
+            try:
+                pw, pms = bw.measure_paths(w, world, rank, device, None, 256, passes=1 if w == "c4" else 4)
+                r = bw.Runner(w, world, rank, pw)
+                el, ns = bw.timed(r, st, wu, world)
+                nrank_secondary[w] = {"workload": r.describe, "value": round(ns / el, 1), "unit": "env-steps/s", "n_gpus": world,
+                                      "steps": st, "warmup": wu, "ms_per_step": round(el / st * 1e3, 4), "scaling": "weak",
+                                      "env_steps_per_step": ns // st, "gradient_average": r.gradient_average(),
+                                      "gradient_path": pw, "gradient_paths_ms": pms, "rollout_mode": r.rollout_mode()}
+                r.close()
+            except Exception as ex:                          # noqa: BLE001
+                nrank_secondary[w] = {"error": repr(ex)[:300]}
     if rank == 0:
+        if nrank_secondary:
+            out["secondary"] = nrank_secondary
         if phases is not None:
             out["phases"] = phases
-        if not args.no_roofline:
+        if c2 and not args.no_roofline:
             # `roofline` = the kernel with the largest share of the step (what rocprofv3 --stats puts first: the fused
             # minibatch kernel at the headline workload), the other of the two rides along under its own key
             first, second = kernel_rooflines(agent)
@@ -313,13 +313,12 @@ def main():
                 out["roofline"] = first
                 if second is not None:
                     out["roofline_update_kernel"] = second
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and c2 and not args.no_cpu_baseline:
             # cpu_baseline: the reference's own CPU torch path (kind "reference", timed where the reference exists);
             # cpu_port: the oracle's NumPy port of the same loop, timed live on THIS host's cores
             out["cpu_baseline"] = reference_cpu_baseline("ppo_cartpole", str(args.n_envs))
             out["cpu_port"] = cpu_baseline(args.n_envs, args.horizon)
-        if world == 1 and not args.no_secondary:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
+        if world == 1 and c2 and not args.no_secondary:
             sec = {}
             try:
                 import eager_torch_ppo
@@ -334,7 +333,7 @@ def main():
                 sec["qmix_3m_gru"] = bs.qmix_3m(True, ref=reference_cpu_baseline("qmix_3m_gru"))
                 # the two remaining BASELINE configs at their per-GPU shapes (the reference's CPU time exists per update only:
                 # profiles/ref_cpu_baseline.json; no simulator for either is installed, the providers are synthetic)
-                sec["ppo_halfcheetah_shape_c4"] = bs.ppo_c4()
+                sec["ppo_halfcheetah_shape_c4"] = bs.ppo_c4(ref=reference_cpu_baseline("ppo_halfcheetah_shape_c4"))
                 sec["dqn_atari_shape_c3"] = bs.dqn_c3(ref=_ref_update_ms("dqn_cnn_update_b32_ms", "one DQN_Learner.update, CNN, batch 32"))
             except Exception as ex:                          # noqa: BLE001
                 sec["error"] = repr(ex)

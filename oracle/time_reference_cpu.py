@@ -156,6 +156,59 @@ def ppo_agent_loop(n_envs, calls=3):
             "what": "reference PPO_Agent.train(256): 256 vector steps + 8 x 8 minibatch updates of %d" % (n_envs * 32)}
 
 
+class _HostMujocoShapedEnv:
+    """Host stand-in with HalfCheetah's shapes (obs 17, Box(6)): linear dynamics driven by the action plus noise, episodes of
+    1 000 steps -- what tools' device provider (xuance_amd/envs/synthetic.py: SyntheticMujocoVecEnv) is on the GPU side; the
+    simulator itself is third-party and not in the image, so neither side times physics."""
+    max_episode_steps = 1000
+
+    def __init__(self, env_seed=None):
+        self.observation_space, self.action_space = sp.Box(-np.inf, np.inf, (17,), np.float32), sp.Box(-1.0, 1.0, (6,), np.float32)
+        self.rng = np.random.default_rng(env_seed)
+        self.W = (self.rng.standard_normal((6, 17)) * 0.1).astype(np.float32)
+        self.state, self.steps, self.score = None, 0, 0.0
+
+    def reset(self, seed=None):
+        self.state = (self.rng.standard_normal(17) * 0.1).astype(np.float32)
+        self.steps, self.score = 0, 0.0
+        return self.state.copy(), {}
+
+    def step(self, action):
+        a = np.clip(np.asarray(action, np.float32), -1, 1)
+        self.state = (0.95 * self.state + a @ self.W + 0.05 * self.rng.standard_normal(17).astype(np.float32)).astype(np.float32)
+        r = float(self.state[0] - 0.1 * float(a @ a))
+        self.steps += 1
+        self.score += r
+        return self.state.copy(), r, False, self.steps >= self.max_episode_steps, {"episode_step": self.steps, "episode_score": self.score}
+
+    def close(self):
+        pass
+
+
+def ppo_c4_agent_loop(n_envs=128, calls=3):
+    """The reference's PPO_Agent.train with configs/ppo/mujoco.yaml (Gaussian_AC, Basic_Identical, 256-256 heads, 16 epochs x 8
+    minibatches) at BASELINE configs[3]'s per-GPU size: 128 envs x horizon 256, minibatches of 4 096."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import xuance.torch.agents.base.agent as agent_mod
+    from xuance.torch.agents import REGISTRY_Agents
+    from xuance_amd.envs import DummyVecEnv
+    agent_mod.SummaryWriter = _NullWriter
+    import xuance.torch.agents.policy_gradient.ppo_agent as pa
+    pa.tqdm = lambda x, *a, **k: x
+    cfg = _agent_config("ppo/mujoco.yaml", parallels=n_envs)
+    envs = DummyVecEnv([_HostMujocoShapedEnv] * n_envs, env_seed=1)
+    envs.reset()
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs)
+        rate, all_rates = _median_rate(agent, cfg.horizon_size, calls, lambda: agent.current_step)
+    finally:
+        os.chdir(cwd)
+    return {"env_steps_per_s": round(rate, 1), "runs": all_rates, "n_envs": n_envs,
+            "what": "reference PPO_Agent.train(256) with configs/ppo/mujoco.yaml on a MuJoCo-shaped host provider: 256 vector steps of "
+                    "%d envs + 16 x 8 minibatch updates of %d" % (n_envs, n_envs * 32)}
+
+
 def qmix_agent_loop(n_envs, rnn, calls=3):
     """The reference's QMIX_Agents.train (off_policy_marl.py:310-424) with configs/qmix/sc2/3m.yaml.  Recurrent agents (the
     yaml default) with use_actions_mask as in the yaml crash in the reference's own update (iql_learner.py:78-81, see
@@ -205,10 +258,19 @@ def qmix_agent_loop(n_envs, rnn, calls=3):
 
 if __name__ == "__main__":
     import platform
+    if len(sys.argv) > 2 and sys.argv[2] == "c4":          # add the C4 line to an existing record (same host, same settings)
+        with open(sys.argv[1]) as f:
+            out = json.load(f)
+        out["ppo_halfcheetah_shape_c4"] = ppo_c4_agent_loop()
+        print(json.dumps(out["ppo_halfcheetah_shape_c4"]))
+        with open(sys.argv[1], "w") as f:
+            json.dump(out, f, indent=1)
+        sys.exit(0)
     out = {"threads": os.cpu_count(), "cores": os.cpu_count(), "host": "build container (no GPU), %s" % platform.processor(),
            "torch": torch.__version__, "numpy": np.__version__,
            "ppo_cartpole": {str(n): ppo_agent_loop(n) for n in (4, 16, 256)},
            "qmix_3m_ff": qmix_agent_loop(64, False), "qmix_3m_gru": qmix_agent_loop(64, True),
+           "ppo_halfcheetah_shape_c4": ppo_c4_agent_loop(),
            "ppo_update_bs8192_ms": round(ppo(8192), 3),
            "qmix_ff_update_b32_ms": round(qmix(False), 3),
            "qmix_rnn_update_b32x60_ms": round(qmix(True), 3),

@@ -320,7 +320,9 @@ def test_fused_minibatch_kernel_equals_layered_path(n, T, nmb):
     assert scale > 0
     assert_close(g_fused / scale, g_ref / scale, 1e-5, "gradient")
     for key in ("actor_loss", "critic_loss", "entropy", "predict_value", "clip_ratio"):
-        assert_close(info_fused[key], info_ref[key], 1e-5, key)
+        # (the actor loss is a mean of surrogate terms that cancel almost exactly right after a rollout: scale = their magnitude)
+        assert_close(info_fused[key], info_ref[key], 1e-5, key,
+                     scale=float(np.abs(diag_ref[3 * bs:4 * bs]).mean()) if key == "actor_loss" else None)
     assert_close(diag_fused, diag_ref, 1e-5, "log_prob/ratio/surrogates")
 
 

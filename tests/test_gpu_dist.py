@@ -241,7 +241,7 @@ def test_bench_contract_with_two_ranks():
     port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--n-envs", "64", "--horizon", "64"]
+           "--n-envs", "64", "--horizon", "64", "--no-secondary"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -251,6 +251,40 @@ def test_bench_contract_with_two_ranks():
     assert d["config"]["parallelism"] == "dp2" and d["config"]["env_steps_per_step"] == 2 * 64 * 64
     assert abs(d["value"] - d["config"]["env_steps_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     assert any(k.endswith("/rank_0") for k in d["config"]["last_info"])
+    # every usable way of averaging the gradients was timed on the workload, the fastest adopted; RCCL/gloo sign of life
+    c = d["config"]
+    timed = {k: v for k, v in c["gradient_paths_ms"].items() if not isinstance(v, str)}
+    assert "cut" in c["gradient_paths_ms"] and timed and c["gradient_path"] == min(timed, key=timed.get)
+    assert c["rccl_world"] == 2 and c["backend"] == "gloo" and isinstance(c["gradient_average"], str)
+    assert c["rollout_mode"].startswith(("whole-rollout launch", "one launch per vector step"))
+
+
+@pytest.mark.parametrize("workload,extra", [("c4", ["--horizon", "32", "--steps", "1", "--warmup", "1"]),
+                                            ("qmix3m", ["--steps", "2", "--warmup", "1"])])
+def test_bench_contract_nrank_workloads(workload, extra):
+    """`bench.py --workload c4 | qmix3m` under torch.distributed.run with two ranks on the test box's one GPU (gloo): the N-rank
+    lines of BASELINE configs[3] (HalfCheetah shapes, 128 envs per rank) and configs[4] (QMIX SMAC-3m shape, 64 envs per rank;
+    the reference averages these modules' gradients through DDP, value_factorization.py:44-48) that a scaling run of the driver
+    needs for their curves."""
+    import json
+    import subprocess
+    env = dict(os.environ, XRL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "env-steps/s" and c["parallelism"] == "dp2"
+    assert ("HalfCheetah" if workload == "c4" else "QMIX") in d["metric"] and d["value"] > 0
+    if workload == "c4":
+        assert c["env_steps_per_step"] == 2 * 128 * 32 and "exchange" not in c["gradient_paths_ms"]     # ranks share the GPU here
+    else:
+        assert c["env_steps_per_step"] == 2 * 64 * 16
+    assert c["rccl_world"] == 2 and c["gradient_path"] in c["gradient_paths_ms"]
+    assert abs(d["value"] - c["env_steps_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
 
 
 def test_rccl_all_reduce_replays_from_a_captured_graph():

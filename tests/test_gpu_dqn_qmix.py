@@ -41,8 +41,8 @@ def check_updates(g, net, learner, cb, call, cb_keys, loss_key, n_updates=None, 
         info = call(sub(g, f"u{u}/batch"))
         ref_info, ref_cb = sub(g, f"u{u}/info"), sub(g, f"u{u}/cb")
         assert_close(info[loss_key], ref_info[loss_key], 1e-5, loss_key)
-        assert_close(info["predictQ"], ref_info["predictQ"], 1e-5, "predictQ",
-                     scale=max(float(np.abs(ref_cb[k]).mean()) for k in cb_keys))      # a mean of values of either sign
+        assert_close(info["predictQ"], ref_info["predictQ"], 1e-5, "predictQ",     # a mean of values of either sign
+                     scale=max(float(np.abs(ref_cb[k]).mean()) for k in cb_keys) if cb_keys else None)
         assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "lr")
         for k in cb_keys:
             assert_close(cb.records[-1][k], ref_cb[k], 1e-5, k)
