@@ -133,6 +133,10 @@ int xrl_col2im_nhwc(const float* dcol, const float* xact, float* dx, int B, int 
 int xrl_maxpool_hw_fwd(const float* y, float* feat, int32_t* argmax, int B, int P, int F, int ld_feat, xrl_stream_t stream);
 int xrl_maxpool_hw_bwd(const float* dfeat, const int32_t* argmax, const float* y, float* dy, int B, int P, int F, int ld_dfeat,
                        xrl_stream_t stream);
+/* nn.Flatten() of an NCHW activation (AC_CNN_Atari, rl_models/representations/cnn.py:90, configs/ppo/atari.yaml): the NHWC conv
+ * output y[B][P][F] -> feat[b][f * P + q]; backward: dy[b][q][f] = dfeat[b][f * P + q] where y > 0 (the ReLU in front), else 0 */
+int xrl_flatten_chw_fwd(const float* y, float* feat, int B, int P, int F, int ld_feat, xrl_stream_t stream);
+int xrl_flatten_chw_bwd(const float* dfeat, const float* y, float* dy, int B, int P, int F, int ld_dfeat, xrl_stream_t stream);
 
 /* ------------------------------------------------------------------ PPO-clip loss (ppo_learner.py:46-60,70) */
 

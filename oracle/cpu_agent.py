@@ -105,4 +105,4 @@ def run_ppo_cartpole(n_envs=256, horizon=256, n_rollouts=1, n_epochs=8, n_miniba
             break
     sec = time.perf_counter() - t0
     return dict(env_steps=done_rollouts * buffer_size, seconds=sec, rollouts=done_rollouts,
-                info={k: float(v) for k, v in info.items() if np.isscalar(v) or np.ndim(v) == 0})
+                info={k: float(v) for k, v in info.items() if not isinstance(v, dict) and (np.isscalar(v) or np.ndim(v) == 0)})

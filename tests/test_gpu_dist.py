@@ -272,7 +272,8 @@ def test_bench_contract_nrank_workloads(workload, extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
+    tb = r.stderr[r.stderr.find("Traceback"):][:3000] if "Traceback" in r.stderr else r.stderr[-2000:]
+    assert r.returncode == 0, tb
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])

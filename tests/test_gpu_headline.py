@@ -246,7 +246,7 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
 
 
 # ------------------------------------------------------------------ the update phase against the REFERENCE's own chain
-CHAIN_K = 2.0        # measured (profiles/r03_parity_errors_gpu.jsonl, "chain after..." lines): the engine / reference ratio is <= 0.94
+CHAIN_K = 2.0        # measured (profiles/r03_parity_errors_gpu.json, "chain after..." lines): the engine / reference ratio is <= 0.94
 #                      for every tensor above the 1e-5 floor after 16 and after 64 updates; 2.0 leaves room for a re-ordered sum
 
 

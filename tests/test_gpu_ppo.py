@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 # over 8 192 rows that cancel to 0.7 % of sum|terms|; the per-row softmax terms come from expf / logf, whose sub-ulp errors are
 # one-sided and do not cancel with the signal (torch's vectorised exp is unbiased; the reference sits 1.6e-7 from its twin).
 # Every other tensor of that fixture is within 1e-5 of the float32 reference or -- the critic's, whose float32 sgemm sums are
-# 1.5e-4 off in the reference itself -- within 1.1e-7 of the float64 twin (profiles/r03_parity_errors_gpu.jsonl).
+# 1.5e-4 off in the reference itself -- within 1.1e-7 of the float64 twin (profiles/r03_parity_errors_gpu.json).
 C2_TOL = 2e-5
 
 

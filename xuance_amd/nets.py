@@ -14,6 +14,8 @@ from collections import OrderedDict
 from dataclasses import dataclass
 from typing import List, Optional
 
+import math
+
 import numpy as np
 import torch
 
@@ -28,16 +30,23 @@ class FlatParams:
     """Named fp32 tensors carved out of one flat buffer; every tensor starts on a 16-byte boundary."""
 
     def __init__(self, specs, device):
+        """specs: (name, shape) -- or (name, shape, "packed"): the tensor starts right behind the previous one, without the
+        16-byte alignment (two bias vectors that ONE stacked GEMM reads as a single bias: [b_actor; b_critic] with an odd
+        number of actions)."""
         self.names, self.shapes, self.offsets = [], {}, {}
-        off = 0
-        for name, shape in specs:
+        off = end = 0
+        for spec in specs:
+            name, shape = spec[0], spec[1]
+            if len(spec) > 2 and spec[2] == "packed":
+                off = end
             self.names.append(name)
             self.shapes[name] = tuple(shape)
             self.offsets[name] = off
             n = 1
             for s in shape:
                 n *= s
-            off = _align4(off + n)
+            end = off + n
+            off = _align4(end)
         self.P = off
         self.device = device
         self.flat = torch.zeros(self.P, dtype=torch.float32, device=device)
@@ -805,11 +814,13 @@ class ConvStack:
             self.ksplit = [stack.ksplit_for(rows * OH * OW, F, C * k * k) for (H, W, C, k, s, p, OH, OW, F) in stack.geo]
             self.skw = [torch.empty(2 * ks * rows * OH * OW * F, device=dev) if ks > 1 else None
                         for ks, (H, W, C, k, s, p, OH, OW, F) in zip(self.ksplit, stack.geo)]
-            self.feat = torch.empty(rows, stack.geo[-1][8], device=dev)
-            self.arg = torch.zeros(rows, stack.geo[-1][8], dtype=torch.int32, device=dev) if keep else None
+            self.feat = torch.empty(rows, stack.n_feat, device=dev)
+            self.arg = torch.zeros(rows, stack.geo[-1][8], dtype=torch.int32, device=dev) if (keep and not stack.flatten) else None
 
-    def __init__(self, params, conv_names, obs_shape, kernels, strides, filters):
-        self.params, self.names = params, list(conv_names)
+    def __init__(self, params, conv_names, obs_shape, kernels, strides, filters, flatten=False):
+        """flatten: the stack ends in nn.Flatten() of the NCHW activation (AC_CNN_Atari, cnn.py:83-96: filters * OH * OW features
+        in (c, h, w) order) instead of the global max-pool of Basic_CNN."""
+        self.params, self.names, self.flatten = params, list(conv_names), bool(flatten)
         H, W, C = obs_shape
         self.geo = []
         for k, s, F in zip(kernels, strides, filters):
@@ -817,7 +828,7 @@ class ConvStack:
             OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
             self.geo.append((H, W, C, k, s, p, OH, OW, F))
             H, W, C = OH, OW, F
-        self.n_feat = filters[-1]
+        self.n_feat = filters[-1] * (H * W if self.flatten else 1)
         self._ws = {}
 
     @staticmethod
@@ -849,7 +860,10 @@ class ConvStack:
                                           aux=ws.skw[i].data_ptr() if ks > 1 else None, ldaux=ks if ks > 1 else 0)])
             x = ws.y[i]
         H, W, C, k, s, p, OH, OW, F = self.geo[-1]
-        ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, rows, OH * OW, F, F)
+        if self.flatten:
+            ops.flatten_chw_fwd(ws.y[-1], ws.feat, rows, OH * OW, F, self.n_feat)
+        else:
+            ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, rows, OH * OW, F, F)
         return ws.feat
 
     def forward_dual(self, x, M, Re, ws, flat_t):
@@ -895,7 +909,10 @@ class ConvStack:
             self._csq = torch.zeros(256, dtype=torch.float64, device=P.device)
         cs, stride = self._cslabs, self._cslabs.shape[1]
         H, W, C, k, s, p, OH, OW, F = self.geo[-1]
-        ops.maxpool_hw_bwd(dfeat, ws.arg, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
+        if self.flatten:
+            ops.flatten_chw_bwd(dfeat, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
+        else:
+            ops.maxpool_hw_bwd(dfeat, ws.arg, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
         wg = []
         for i in reversed(range(len(self.geo))):
             H, W, C, k, s, p, OH, OW, F = self.geo[i]
@@ -911,6 +928,117 @@ class ConvStack:
         # data-gradient chain (the three launches took 13 + 13 + 33 us one after the other, each on a part of the chip)
         ops.linear_bwd_weight(wg, self.N_SPLIT, stride)
         ops.grad_reduce(cs, self.N_SPLIT, stride, p_conv, slabs[0], self._csq)
+
+
+class ActorCriticCNN:
+    """SharedActorCritic over the AC_CNN_Atari representation of configs/ppo/atari.yaml (rl_models/representations/cnn.py:53-102:
+    x / 255, NHWC -> NCHW, Conv2d(k, s, pad=(k-s)//2) + ReLU x3, Flatten, Linear + ReLU per fc_hidden_sizes) with a
+    CategoricalActorHead and a ValueHead (actor_hidden_size / critic_hidden_size, both [] in the yaml: the heads sit directly
+    on the 512-wide embedding) -- the network DummyOnPolicyBuffer_Atari's uint8 frames train (memory_tools.py:290-328).
+
+    Convolution stack = ConvStack (im2col + fp32-MFMA GEMMs, NHWC) ending in xrl_flatten_chw_fwd, so the dense layer reads its
+    6 400 inputs in the reference's (c, h, w) order and `representation.model.7.weight` keeps the reference's layout; dense part
+    = a Plan: fc layers, then actor / critic hidden layers of one depth side by side, then [logits | value]."""
+
+    dist = "categorical"
+    activation_action = None
+
+    def __init__(self, obs_shape=(84, 84, 4), action_dim=4, kernels=(8, 4, 3), strides=(4, 2, 1), filters=(32, 64, 64),
+                 fc_hidden=(512,), actor_hidden=(), critic_hidden=(), activation="relu", device="cuda", init=True):
+        assert activation == "relu", "the convolution kernels apply ReLU (configs/ppo/atari.yaml: activation relu)"
+        ah, ch = list(actor_hidden or []), list(critic_hidden or [])
+        assert len(ah) == len(ch), "actor / critic hidden stacks must have equal depth"
+        self.obs_shape, self.action_dim = tuple(obs_shape), int(action_dim)
+        self.obs_dim = int(obs_shape[0] * obs_shape[1] * obs_shape[2])
+        self.kernels, self.strides, self.filters = tuple(kernels), tuple(strides), tuple(filters)
+        self.activation = activation
+        specs, self.conv_names = [], []
+        C = obs_shape[2]
+        for i, (k, f) in enumerate(zip(kernels, filters)):
+            n = f"representation.model.{2 * i}"
+            specs += [(n + ".weight", (f, C, k, k)), (n + ".bias", (f,))]
+            self.conv_names.append(n)
+            C = f
+        probe = ConvStack(None, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters, flatten=True)
+        feat = probe.n_feat
+        self.n_flat = feat
+        rep_order = [n + sfx for n in self.conv_names for sfx in (".weight", ".bias")]
+        widths, stages, lvl = [feat], [], 0
+        base = 2 * len(self.conv_names) + 1                       # index of the first Linear behind nn.Flatten()
+        self.fc_names = []
+        for j, h in enumerate(fc_hidden):
+            n = f"representation.model.{base + 2 * j}"
+            specs += [(n + ".weight", (h, feat)), (n + ".bias", (h,))]
+            rep_order += [n + ".weight", n + ".bias"]
+            self.fc_names.append(n)
+            stages.append([Layer(n, feat, h, activation, lvl, 0, lvl + 1, 0, n + ".weight", n + ".bias")])
+            widths.append(h)
+            feat, lvl = h, lvl + 1
+        # Both branches read the whole embedding: their first layers (the heads themselves when the hidden stacks are empty, as
+        # in the yaml) are ONE stacked GEMM [W_actor; W_critic] (adjacent weights, adjacent biases) -- the data-gradient GEMM
+        # of a Plan writes d(input), so two layers must not read the same columns of a hidden level.
+        a_order, c_order = [], []
+        sizes_a, sizes_c = ah + [action_dim], ch + [1]
+        fa = fc = feat
+        for i, (ha, hc) in enumerate(zip(sizes_a, sizes_c)):
+            na, nc = f"actor.logits.{2 * i}", f"critic.values.{2 * i}"
+            last = i == len(sizes_a) - 1
+            act_i = None if last else activation
+            a_order += [na + ".weight", na + ".bias"]
+            c_order += [nc + ".weight", nc + ".bias"]
+            if i == 0:
+                assert (ha * fa) % 4 == 0, "stacked actor / critic layer needs a 16-byte aligned critic weight"
+                specs += [(na + ".weight", (ha, fa)), (nc + ".weight", (hc, fc)), (na + ".bias", (ha,)), (nc + ".bias", (hc,), "packed")]
+                stages.append([Layer(na + "+" + nc, fa, ha + hc, act_i, lvl, 0, lvl + 1, 0, na + ".weight", na + ".bias")])
+            else:
+                specs += [(na + ".weight", (ha, fa)), (na + ".bias", (ha,)), (nc + ".weight", (hc, fc)), (nc + ".bias", (hc,))]
+                stages.append([Layer(na, fa, ha, act_i, lvl, 0, lvl + 1, 0, na + ".weight", na + ".bias"),
+                               Layer(nc, fc, hc, act_i, lvl, fa, lvl + 1, ha, nc + ".weight", nc + ".bias")])
+            widths.append(ha + hc)
+            fa, fc, lvl = ha, hc, lvl + 1
+        self.ref_order = rep_order + a_order + c_order            # the reference's state_dict order: representation, actor, critic
+        self.params = FlatParams(specs, device)
+        self.plan = Plan(self.params, widths, stages)
+        self.head_ld = action_dim + 1
+        self.conv = ConvStack(self.params, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters, flatten=True)
+        if init:
+            self.reset_parameters()
+
+    def reset_parameters(self):
+        """cnn.py:78-81: orthogonal_(gain sqrt 2), bias 0 for every conv / fc layer of the representation; the heads take the
+        agent's initialiser (orthogonal, gain 1; layers.py:23-26)."""
+        for name in self.ref_order:
+            v = self.params.view(name)
+            if name.endswith(".weight"):
+                gain = math.sqrt(2.0) if name.startswith("representation.") else 1.0
+                v.copy_(_orthogonal(v.shape) * gain)
+            else:
+                v.zero_()
+
+    state_dict = ActorCriticNet.state_dict
+    load_state_dict = ActorCriticNet.load_state_dict
+    parameters = ActorCriticNet.parameters
+
+    def forward(self, x_u8, M, ldx=None, keep=True):
+        """x_u8 [rows >= M, H*W*C] uint8 (or float32 in 0..255) frames -> heads [cap, A + 1].  keep: this pass will be
+        differentiated (its im2col columns and activations stay in the "grad" workspace)."""
+        ws = self.conv.workspace("grad" if keep else "act", M, keep)
+        if keep:
+            self._ws, self._M = ws, M
+        feat = self.conv.forward(x_u8[:M].reshape(M, -1), M, ws)
+        if keep:
+            self._feat_in = feat
+        return self.plan.forward(feat, self.n_flat, M)
+
+    @property
+    def d_heads(self):
+        return self.plan.dacts[len(self.plan.widths) - 1]
+
+    def backward(self, x_u8, M, slabs, n_split, ldx=None):
+        if getattr(self, "_dfeat", None) is None or self._dfeat.shape[0] < M:
+            self._dfeat = torch.zeros(M, self.n_flat, device=self.params.device)
+        self.plan.backward_grouped(self._feat_in, self.n_flat, M, slabs, n_split, dx0=self._dfeat)
+        self.conv.backward(self._dfeat, M, self._ws, slabs, n_split)
 
 
 class DeepQCNN:

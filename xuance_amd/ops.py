@@ -115,6 +115,14 @@ def maxpool_hw_bwd(dfeat, argmax, y, dy, B, P, F, ld_dfeat):
     call("xrl_maxpool_hw_bwd", ptr(dfeat), ptr(argmax), ptr(y), ptr(dy), B, P, F, ld_dfeat, stream_ptr())
 
 
+def flatten_chw_fwd(y, feat, B, P, F, ld_feat):
+    call("xrl_flatten_chw_fwd", ptr(y), ptr(feat), B, P, F, ld_feat, stream_ptr())
+
+
+def flatten_chw_bwd(dfeat, y, dy, B, P, F, ld_dfeat):
+    call("xrl_flatten_chw_bwd", ptr(dfeat), ptr(y), ptr(dy), B, P, F, ld_dfeat, stream_ptr())
+
+
 # ------------------------------------------------------------------------------------------ PPO loss
 def ppo_loss(dist, **kw):
     p = PpoLoss()
