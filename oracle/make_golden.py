@@ -370,6 +370,81 @@ def golden_ppo_chain():
     np.savez_compressed(os.path.join(OUT, "ppo_chain_c2.npz"), **out)
 
 
+PPO_CNN_ROWS = [0, 1, 255, 511]                                  # rows of the 512 x 6400 dense weight the fixture stores
+
+
+def ppo_cnn_fc_init(shape):
+    """Initial values of AC_CNN_Atari's dense weight in the PPO-CNN fixture: a formula instead of 13 MB of stored numbers
+    (integer arithmetic, then one IEEE multiply: any machine reproduces the bits; tests/test_gpu_ppo.py has the same lines)."""
+    i, j = np.meshgrid(np.arange(shape[0], dtype=np.int64), np.arange(shape[1], dtype=np.int64), indexing="ij")
+    return (((i * 131 + j * 7919 + 17) % 2003 - 1001).astype(np.float64) * 3e-5).astype(np.float32)
+
+
+def golden_ppo_cnn():
+    """PPO_Learner on SharedActorCritic(AC_CNN_Atari, CategoricalActorHead([]), ValueHead([])) -- configs/ppo/atari.yaml:
+    84 x 84 x 4 uint8 frame stacks, conv 32/64/64 (k 8/4/3, s 4/2/1), Flatten, Linear(6400, 512), heads on the embedding -- two
+    updates on 32 frames each.  3.36 M parameters, 3.28 M of them the dense weight: that tensor is INITIALISED from a formula
+    (ppo_cnn_fc_init) and only rows PPO_CNN_ROWS of its gradient / values / Adam moments are stored (`rows/<name>`); every other
+    tensor is stored whole.  Float64 twin of the gradients as in the other PPO fixtures."""
+    from xuance.torch.rl_models.representations.cnn import AC_CNN_Atari
+    torch.manual_seed(11)
+    rng = np.random.default_rng(611)
+    init = torch.nn.init.orthogonal_
+    A, bs = 4, 32
+    rep = AC_CNN_Atari((84, 84, 4), [8, 4, 3], [4, 2, 1], [32, 64, 64], None, init, nn.ReLU, "cpu", fc_hidden_sizes=[512])
+    actor = CategoricalActorHead(512, [], A, None, init, nn.ReLU, "cpu")
+    critic = ValueHead(512, [], None, init, nn.ReLU, "cpu")
+    model = SharedActorCritic(rep, actor, critic)
+    fc = "representation.model.7.weight"
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.from_numpy(rng.standard_normal(p.shape).astype(np.float32) * 0.1))
+            if n == fc:
+                p.copy_(torch.from_numpy(ppo_cnn_fc_init(tuple(p.shape))))
+    cfg = base_config(horizon_size=128, n_epochs=4, n_minibatch=4, parallels=8, running_steps=128 * 8 * 100, learning_rate=2.5e-4,
+                      vf_coef=0.25, ent_coef=0.01, clip_range=0.2, gamma=0.99, end_factor_lr_decay=0.5)
+    model64 = copy.deepcopy(model).double()
+    for m_ in [m for m in model64.modules() if isinstance(m, AC_CNN_Atari)]:     # its forward casts to float32 (cnn.py:100)
+        body = m_.model
+        from xuance.torch.rl_models.modules.outputs import RepresentationOutput
+        m_.forward = lambda observations, _b=body, **kw: RepresentationOutput(
+            embeddings=_b((torch.as_tensor(observations, dtype=torch.float64) / 255.0).permute((0, 3, 1, 2))))
+    cb = Capture()
+    learner, learner64 = PPO_Learner(cfg, model, cb), PPO_Learner(cfg, model64, Capture())
+    batches = []
+    for u in range(2):
+        obs = (rng.integers(0, 16, (bs, 84, 84, 4)) * 17).astype(np.uint8)
+        with torch.no_grad():
+            actions = rng.integers(0, A, bs).astype(np.float32)
+            old_logp = model(obs).distributions.log_prob(torch.from_numpy(actions)).numpy()
+        old_logp = (old_logp + rng.standard_normal(bs) * 0.3).astype(np.float32)
+        adv = rng.standard_normal(bs).astype(np.float32)
+        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).astype(np.float32)
+        batches.append(dict(obs=obs, actions=actions, returns=rng.standard_normal(bs).astype(np.float32), advantages=adv,
+                            old_logp=old_logp, values=rng.standard_normal(bs).astype(np.float32)))
+
+    def call(b, L=learner):
+        return L.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"], advantages=b["advantages"],
+                        aux_batch={"old_logp": b["old_logp"]}, batch_size=bs)
+    out = run_learner_updates(learner, model, cb, batches, call)
+    out.update(float64_twin(learner64, model64, batches, lambda L, b: call(
+        {k: (v if k == "obs" else v) for k, v in b.items()}, L)))
+    rows = np.asarray(PPO_CNN_ROWS)
+    for k in list(out):
+        if k.endswith("/" + fc):
+            if k.startswith("init/"):
+                assert np.array_equal(out[k], ppo_cnn_fc_init(out[k].shape))
+                del out[k]                                       # rebuilt from the formula
+            else:
+                out[k] = out[k][rows]
+    out["rows/" + fc] = rows
+    out["cfg"] = np.array([cfg.learning_rate, cfg.vf_coef, cfg.ent_coef, cfg.clip_range, cfg.grad_clip_norm, cfg.end_factor_lr_decay,
+                           learner.total_iters])
+    out["n_updates"] = np.int64(2)
+    np.savez_compressed(os.path.join(OUT, "ppo_cnn_atari.npz"), **out)
+
+
 def golden_ppokl(dist):
     """PPOKL_Learner (ppokl_learner.py:14-101).  The reference's update reads `model_output.distribution` (:48) while
     ActorCriticOutput names the field `distributions`, so it raises AttributeError as shipped.  The fixture runs the
@@ -946,6 +1021,7 @@ def golden_baseline_sizes():
     golden_qmix_rnn(True, size="c5")
     golden_qmix_rnn(True, fixed=True, size="c5")
     golden_ppo_chain()
+    golden_ppo_cnn()
 
 
 if __name__ == "__main__":

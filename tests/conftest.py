@@ -178,17 +178,27 @@ class LearnerFixtureCheck:
     step's scale, through AdamReplay's conditioning, + one ulp of the stored float32 parameter), and at the end Adam's moments
     (exp_avg: linear in the gradients, same bound; exp_avg_sq: |d v_i| <= 2 d sqrt(1 - b2^t) sqrt(v_i))."""
 
-    def __init__(self, g, init, lr, eps=1e-5, end_factor=1.0, total_iters=1, weight_decay=0.0, tol=1e-5):
+    def __init__(self, g, init, lr, eps=1e-5, end_factor=1.0, total_iters=1, weight_decay=0.0, tol=1e-5, init_extra=None):
+        """`rows/<name>` entries of the fixture: only those rows of that (large) tensor are stored -- the engine's tensor is cut to
+        the same rows wherever it is compared; init_extra: the reference's initial values of tensors the fixture rebuilds from
+        a formula instead of storing them (oracle/make_golden.py: golden_ppo_cnn)."""
         self.g, self.tol = g, tol
+        self.rows = {k[len("rows/"):]: np.asarray(v) for k, v in g.items() if k.startswith("rows/")}
         self.adam = AdamReplay(lr, eps, end_factor, total_iters, weight_decay=weight_decay)
-        self.before = {k: np.asarray(v, np.float32).copy() for k, v in init.items()}        # the ENGINE's parameters
+        self.before = {k: self._sl(k, np.asarray(v, np.float32)).copy() for k, v in init.items()}   # the ENGINE's parameters
         self.ref_before = {k: np.asarray(v, np.float32) for k, v in sub(g, "init").items()}
+        self.ref_before.update({k: self._sl(k, np.asarray(v, np.float32)) for k, v in (init_extra or {}).items()})
         self.delta = {}                                                                      # name -> gradient error bound held
         self.replay_checked = 0
         self.hist, self.ref_hist = [dict(self.before)], [dict(self.ref_before)]              # parameter sets: init, after u0, ...
 
+    def _sl(self, name, arr):
+        return arr[self.rows[name]] if name in self.rows else arr
+
     def update(self, u, grads, params_after):
         g = self.g
+        grads = {k: self._sl(k, np.asarray(v)) for k, v in grads.items()}
+        params_after = {k: self._sl(k, np.asarray(v)) for k, v in params_after.items()}
         ref_g, ref_g64 = sub(g, f"u{u}/grad"), sub(g, f"u{u}/grad64")
         ref_after = sub(g, f"u{u}/param")
         for n, rg in ref_g.items():
@@ -240,6 +250,8 @@ class LearnerFixtureCheck:
     def moments(self, exp_avg, exp_avg_sq):
         """name -> engine tensors after the last update, against `adam/exp_avg[_sq]/<name>` of the fixture."""
         bc2 = 1.0 - self.adam.b2 ** self.adam.t
+        exp_avg = {k: self._sl(k, np.asarray(v)) for k, v in exp_avg.items()}
+        exp_avg_sq = {k: self._sl(k, np.asarray(v)) for k, v in exp_avg_sq.items()}
         for n, a in exp_avg.items():
             if f"adam/exp_avg/{n}" not in self.g:
                 continue
@@ -255,10 +267,12 @@ class EngineFixtureCheck(LearnerFixtureCheck):
     """LearnerFixtureCheck fed from a xuance_amd learner: gradients = views of the flat (clipped, reduced) gradient buffer the
     optimiser launch leaves behind, parameters = net.state_dict(), moments = learner.optimizer.state_dict()."""
 
-    def __init__(self, g, net, learner, lr, end_factor=1.0, total_iters=1, weight_decay=0.0, tol=1e-5, state_source=None):
+    def __init__(self, g, net, learner, lr, end_factor=1.0, total_iters=1, weight_decay=0.0, tol=1e-5, state_source=None,
+                 init_extra=None):
         self.net, self.learner = net, learner
         self.state_source = net if state_source is None else state_source       # (seam tests: the caller's own nn.Module)
-        super().__init__(g, self._params(), lr, end_factor=end_factor, total_iters=total_iters, weight_decay=weight_decay, tol=tol)
+        super().__init__(g, self._params(), lr, end_factor=end_factor, total_iters=total_iters, weight_decay=weight_decay, tol=tol,
+                         init_extra=init_extra)
 
     def _params(self):
         return {k: v.detach().cpu().numpy().copy() for k, v in self.state_source.state_dict().items()}

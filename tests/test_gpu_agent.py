@@ -930,3 +930,61 @@ def test_ppokl_agent_stores_the_old_distribution_and_adapts_its_coefficient(grap
     assert len(set(coefs)) > 1 or coefs[0] != 1.0                    # the schedule moved
     assert not torch.equal(agent.model.params.flat, p0)
     assert float(agent.learner.kl_coef_dev.item()) == agent.learner.kl_coef
+
+
+def test_ppo_agent_on_atari_shape():
+    """PPO on uint8 frame stacks (configs/ppo/atari.yaml: AC_CNN_Atari representation, HipOnPolicyBuffer_Atari = the
+    reference's DummyOnPolicyBuffer_Atari, memory_tools.py:290-328) end to end on the device: the rollout stores the provider's
+    frames as they are, values / log-probs in the buffer are the network's own outputs on those frames, truncated paths bootstrap
+    from the next frames' values, and the update phase straight from the buffer equals PPO_Learner.update(**samples) on the same
+    rows (gather of uint8 rows + the same launches)."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    from xuance_amd.nets import ActorCriticCNN
+    from xuance_amd.memory import HipOnPolicyBuffer_Atari
+    torch.manual_seed(0)
+    n, T = 8, 16
+    cfg = make_config(n, T, representation="AC_CNN_Atari", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                      fc_hidden_sizes=[512], actor_hidden_size=[], critic_hidden_size=[], activation="relu", n_epochs=1,
+                      n_minibatch=2, use_obsnorm=False, use_rewnorm=True, learning_rate=2.5e-4, gamma=0.99, use_hip_graph=False)
+    env = SyntheticAtariVecEnv(n, seed=5, max_episode_steps=9)
+    agent = PPO_Agent(cfg, env)
+    assert isinstance(agent.model, ActorCriticCNN) and isinstance(agent.memory, HipOnPolicyBuffer_Atari) and agent.frames
+    assert agent.memory.soa.fields["observations"].dtype == torch.uint8
+    p0 = agent.model.params.flat.clone()
+    agent.rollout()
+    torch.cuda.synchronize()
+    f = agent.memory.soa.fields
+    obs = f["observations"].view(T, n, -1)
+    assert int(obs.max()) > 0 and (f["seg"][8] & 1).all() and (f["seg"][T - 1] & 1).all()     # truncation at 9 steps, buffer end
+    # the stored values / log-probs are the network's outputs on the stored frames (initial parameters)
+    heads = agent.model.forward(obs.reshape(T * n, -1), T * n, keep=False)[:T * n].clone()
+    A = agent.model.action_dim
+    assert_close(npy(f["values"]).reshape(-1), npy(heads[:, A]), 1e-5, "values")
+    lp = torch.log_softmax(heads[:, :A], -1).gather(1, f["actions"].view(-1, 1).long())[:, 0]
+    assert_close(npy(f["aux_old_logp"]).reshape(-1), npy(lp), 1e-5, "old_logp", scale=float(lp.abs().max()))
+    acts = npy(f["actions"])
+    assert set(np.unique(acts)) <= set(range(A))
+    # update phase from the buffer == update(**samples) on the same minibatches
+    idx = np.stack([np.random.default_rng(3).permutation(n * T)]).reshape(2, -1)
+    agent.set_indices(idx)
+    info = agent.update()
+    pa = agent.model.params.flat.clone()
+    agent.model.params.flat.copy_(p0)
+    twin = PPO_Agent(cfg, SyntheticAtariVecEnv(n, seed=5, max_episode_steps=9))
+    twin.model.params.flat.copy_(p0)
+    fields = {k: npy(v) for k, v in f.items()}
+    for k in range(2):
+        env_i, t_i = np.divmod(idx[k], T)
+        adv = fields["advantages"][t_i, env_i]
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        info2 = twin.learner.update(obs=fields["observations"][t_i, env_i], actions=fields["actions"][t_i, env_i],
+                                    returns=fields["returns"][t_i, env_i], values=fields["values"][t_i, env_i], advantages=adv,
+                                    aux_batch={"old_logp": fields["aux_old_logp"][t_i, env_i]}, batch_size=len(env_i))
+    for key in ("critic_loss", "entropy", "predict_value"):
+        assert_close(info[key], info2[key], 1e-5, key)
+    # (the advantage statistics are float64 on the device, float32 NumPy here; Adam turns differences at the level of its eps into
+    #  steps of either sign for the few entries whose gradient sits there: compared in the 2-norm over all 3.36 M parameters)
+    d = (pa - twin.model.params.flat).double().norm().item()
+    moved = (pa - p0).double().norm().item()
+    assert moved > 1e-3 and d <= 1e-2 * moved, (d, moved)

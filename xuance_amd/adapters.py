@@ -78,10 +78,38 @@ def _cfg(config, name, default=None):
 def _actor_critic(sd, module, config, device):
     dist = "categorical" if any(k.startswith("actor.logits.") for k in sd) else "gaussian"
     akey = "actor.logits" if dist == "categorical" else "actor.mu"
-    rep = _chain(sd, "representation.model") if any(k.startswith("representation.model.") for k in sd) else []
+    rep_w = sorted((k for k in sd if k.startswith("representation.model.") and k.endswith(".weight")), key=lambda k: int(k.split(".")[2]))
+    if any(sd[k].dim() == 4 for k in rep_w):
+        # AC_CNN_Atari (cnn.py:53-102, configs/ppo/atari.yaml): Conv2d + ReLU blocks at model.0, .2, ..., nn.Flatten(), then
+        # Linear + ReLU blocks; a CategoricalActorHead and a ValueHead on the embedding
+        if dist != "categorical":
+            raise AdoptError("convolutional SharedActorCritic: only the categorical head (policy Categorical_AC) is built")
+        convs, fcs = [k for k in rep_w if sd[k].dim() == 4], [k for k in rep_w if sd[k].dim() == 2]
+        nc = len(convs)
+        if [int(k.split(".")[2]) for k in convs] != list(range(0, 2 * nc, 2)) or \
+                [int(k.split(".")[2]) for k in fcs] != list(range(2 * nc + 1, 2 * nc + 1 + 2 * len(fcs), 2)) or not fcs:
+            raise AdoptError("convolutional representation is not Conv2d+ReLU blocks, Flatten, Linear+ReLU blocks (AC_CNN_Atari); "
+                             "Basic_CNN's global max-pool in front of an actor-critic is not built")
+        rep_mod = _sub(module, "representation")
+        shape = getattr(rep_mod, "input_shape", None)                 # (C, H, W) (cnn.py:66); frames are H x W x C
+        shape = (shape[1], shape[2], shape[0]) if shape is not None else None
+        if shape is None and _cfg(config, "observation_space") is not None:
+            shape = tuple(config.observation_space.shape)
+        strides = getattr(rep_mod, "strides", None) or _cfg(config, "strides")
+        if shape is None or strides is None:
+            raise AdoptError("convolutional SharedActorCritic: the frame shape and the strides are not in the state_dict -- pass the "
+                             "module (AC_CNN_Atari carries input_shape / strides) or a config with observation_space / strides")
+        a, c = _chain(sd, akey), _chain(sd, "critic.values")
+        net = nets.ActorCriticCNN(tuple(int(x) for x in shape), a[-1][0], tuple(int(sd[k].shape[2]) for k in convs),
+                                  tuple(int(x) for x in strides), tuple(int(sd[k].shape[0]) for k in convs),
+                                  tuple(int(sd[k].shape[0]) for k in fcs), tuple(x[0] for x in a[:-1]), tuple(x[0] for x in c[:-1]),
+                                  _activation_of(rep_mod, _cfg(config, "activation", "relu")), device=device, init=False)
+        if net.n_flat != int(sd[fcs[0]].shape[1]):
+            raise AdoptError(f"convolutional SharedActorCritic: {net.n_flat} flattened features for the stated frame shape / strides, "
+                             f"the first dense layer takes {int(sd[fcs[0]].shape[1])}")
+        return net
+    rep = _chain(sd, "representation.model") if rep_w else []
     a, c = _chain(sd, akey), _chain(sd, "critic.values")
-    if any(len(s) != 2 for s in rep):
-        raise AdoptError("SharedActorCritic with a convolutional representation is not supported by the HIP PPO path")
     obs_dim = rep[0][1] if rep else a[0][1]
     act = _activation_of(_sub(module, "representation") if rep else _sub(module, "actor"), _cfg(config, "activation", "leaky_relu"))
     aa = None

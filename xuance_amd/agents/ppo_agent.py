@@ -46,6 +46,8 @@ class PPO_Agent(AgentSurface):
         self.use_graph = _get(config, "use_hip_graph", True)
         dev, n = self.device, self.n_envs
         self.obs_dim = int(np.prod(space2shape(self.observation_space)))
+        # image observations (configs/ppo/atari.yaml: 84 x 84 x 4 uint8 frame stacks): AC_CNN_Atari network, uint8 buffer
+        self.frames = len(space2shape(self.observation_space)) == 3
         self.model = self._build_model()
         self.memory = self._build_memory(self.auxiliary_info_shape)
         self.learner = self._build_learner(self.config, self.model, self.callback)
@@ -58,7 +60,10 @@ class PPO_Agent(AgentSurface):
         self.ret_var = torch.ones(1, device=dev)
         self.ret_count = torch.full((1,), 1e-4, dtype=torch.float64, device=dev)
         self.returns = torch.zeros(n, device=dev)               # discounted return tracker (ppo_agent.py:144)
-        self.X = torch.zeros(2 * n, D, device=dev)              # policy input: [obs_t ; next_obs_{t-1}] (normalised)
+        self.X = torch.zeros(2 * n, D, device=dev) if not self.frames else None   # policy input: [obs_t ; next_obs_{t-1}] (normalised)
+        self.Xu8 = torch.zeros(2 * n, D, dtype=torch.uint8, device=dev) if self.frames else None   # the same rows as raw frames
+        if self.frames:
+            assert not self.use_obsnorm, "uint8 frames are stored and fed as they are (configs/ppo/atari.yaml: use_obsnorm False)"
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)   # RNG counter base, advanced per rollout
         self.perm_counter = torch.zeros(1, dtype=torch.int32, device=dev)   # one tick per update phase (index generation)
         self.model.plan.ensure(2 * n)
@@ -99,6 +104,13 @@ class PPO_Agent(AgentSurface):
     def _build_model(self):
         c = self.config
         discrete = is_discrete(self.action_space)
+        if self.frames:                                            # representation: "AC_CNN_Atari" (cnn.py:53-102)
+            from ..nets import ActorCriticCNN
+            assert discrete, "the convolutional actor-critic has a categorical head (policy: Categorical_AC)"
+            return ActorCriticCNN(tuple(space2shape(self.observation_space)), self.action_space.n, tuple(_get(c, "kernels", (8, 4, 3))),
+                                  tuple(_get(c, "strides", (4, 2, 1))), tuple(_get(c, "filters", (32, 64, 64))),
+                                  tuple(_get(c, "fc_hidden_sizes", (512,))), tuple(_get(c, "actor_hidden_size", ()) or ()),
+                                  tuple(_get(c, "critic_hidden_size", ()) or ()), _get(c, "activation", "relu"), device=self.device)
         rep = list(_get(c, "representation_hidden_size", []) or []) if _get(c, "representation", "Basic_MLP") != "Basic_Identical" else []
         return ActorCriticNet(self.obs_dim, self.action_space.n if discrete else int(self.action_space.shape[0]),
                               "categorical" if discrete else "gaussian", rep, list(c.actor_hidden_size),
@@ -107,6 +119,11 @@ class PPO_Agent(AgentSurface):
 
     def _build_memory(self, auxiliary_info_shape=None):
         c = self.config
+        if self.frames:                                            # DummyOnPolicyBuffer_Atari (memory_tools.py:290-328): uint8 frames
+            from ..memory import HipOnPolicyBuffer_Atari
+            return HipOnPolicyBuffer_Atari(self.observation_space, self.action_space, auxiliary_info_shape, self.n_envs,
+                                           self.horizon_size, _get(c, "use_gae", True), _get(c, "use_advnorm", True), self.gamma,
+                                           self.gae_lam, device=self.device)
         return HipOnPolicyBuffer(self.observation_space, self.action_space, auxiliary_info_shape, self.n_envs,
                                  self.horizon_size, _get(c, "use_gae", True), _get(c, "use_advnorm", True), self.gamma,
                                  self.gae_lam, device=self.device)
@@ -115,7 +132,25 @@ class PPO_Agent(AgentSurface):
         return PPO_Learner(*args)
 
     # -- one vector step on the device ------------------------------------------------------------------------
+    def _enqueue_step_frames(self, t):
+        """One vector step on uint8 frame stacks: the frames go to the buffer slot and to the network as they are (x / 255 is
+        the first convolution's im2col), rows [n, 2n) of the policy batch are the previous step's next frames (their values
+        bootstrap truncated paths, ppo_agent.py:130,156)."""
+        env, n, A, f = self.envs, self.n_envs, self.model.action_dim, self.memory.soa.fields
+        cur = env.buf_obs.view(n, -1)
+        f["observations"][t].view(n, -1).copy_(cur)               # memory.observations[t] = obs (uint8, ppo_agent.py:128)
+        self.Xu8[:n].copy_(cur)
+        heads = self.model.forward(self.Xu8, 2 * n, keep=False)
+        ops.policy_sample(heads=heads, log_std=None, act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
+                          env_action=env.action, env_action_f=None, bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A,
+                          ld=A + 1, gaussian=0, seed=self.seed, step=t, step_dev=self.step_counter)
+        env.step_device()
+        self.Xu8[n:].copy_(env.next_obs.view(n, -1))
+        ops.rollout_poststep(**self._post_args(t, (self.obs_mean, self.obs_var, self.obs_count), None))
+
     def _enqueue_step(self, t):
+        if self.frames:
+            return self._enqueue_step_frames(t)
         env, mem, n, D, A = self.envs, self.memory, self.n_envs, self.obs_dim, self.model.action_dim
         f = mem.soa.fields
         gaussian = self.model.dist == "gaussian"
@@ -262,7 +297,7 @@ class PPO_Agent(AgentSurface):
                           normalize=int(self.use_obsnorm), obs_range=float(self.obsnorm_range))
             wide.act(self.X, n, self.seed, 0, None, bootv_prev=self.memory.soa.fields["bootv"][T - 1], **kw)
         else:
-            heads = self.model.forward(self.X, 2 * n)
+            heads = self.model.forward(self.Xu8, 2 * n, keep=False) if self.frames else self.model.forward(self.X, 2 * n)
             ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
                               bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
                               gaussian=0, seed=self.seed, step=0, step_dev=None)
@@ -545,10 +580,10 @@ class PPO_Agent(AgentSurface):
         (CategoricalDistribution.deterministic_sample = argmax of the probabilities, Gaussian: the mean,
         distributions.py:150-153, 185-188) from the head outputs.  distributions: the head outputs as a dict when asked."""
         X = torch.as_tensor(np.asarray(observations) if not isinstance(observations, torch.Tensor) else observations,
-                            device=self.model.params.device).to(torch.float32).reshape(-1, self.obs_dim).contiguous()
+                            device=self.model.params.device).to(torch.uint8 if self.frames else torch.float32).reshape(-1, self.obs_dim).contiguous()
         m, A, gaussian = X.shape[0], self.model.action_dim, self.model.dist == "gaussian"
         critic = self.model.head_ld > A
-        heads = self.model.forward(X, m)
+        heads = self.model.forward(X, m, keep=False) if self.frames else self.model.forward(X, m)
         ls = None
         if gaussian:
             ls = self.model.params.ptr(getattr(self.model, "log_std_name", "actor.log_std"))

@@ -214,7 +214,7 @@ class PPO_Learner(Learner):
         dev = self.model.params.device
         self._ensure(bs)
         f = memory.soa
-        self._stage = {"observations": torch.zeros((bs,) + tuple(memory.obs_shape), device=dev),
+        self._stage = {"observations": torch.zeros((bs,) + tuple(memory.obs_shape), dtype=f.fields["observations"].dtype, device=dev),
                        "actions": torch.zeros((bs,) + tuple(memory.act_shape), device=dev),
                        "returns": torch.zeros(bs, device=dev), "advantages": torch.zeros(bs, device=dev),
                        "aux_old_logp": torch.zeros(bs, device=dev)}
@@ -406,7 +406,8 @@ class PPO_Learner(Learner):
     # ------------------------------------------------------------------ reference API (ppo_learner.py:35-95)
     def update(self, **samples):
         self.iterations += 1
-        obs = self._as_dev(samples["obs"])
+        # (uint8 frame stacks stay uint8: x / 255 happens in the first convolution's im2col, cnn.py:99)
+        obs = self._as_dev(samples["obs"], torch.uint8 if getattr(self.model, "obs_shape", None) is not None else torch.float32)
         act = self._as_dev(samples["actions"])
         ret = self._as_dev(samples["returns"])
         adv = self._as_dev(samples["advantages"])
