@@ -988,3 +988,60 @@ def test_ppo_agent_on_atari_shape():
     d = (pa - twin.model.params.flat).double().norm().item()
     moved = (pa - p0).double().norm().item()
     assert moved > 1e-3 and d <= 1e-2 * moved, (d, moved)
+
+
+def test_loop_callbacks_of_the_device_loops():
+    """xuance/common/callback.py:31-58 in the device loops: on_train_epochs_end after every update phase and on_train_step_end once
+    per rollout (kwargs steps = horizon) by default; with config.per_step_callbacks the rollout runs as per-step launches and
+    on_train_step / on_train_step_end fire per vector step with the buffer's slot as device tensors (ppo_agent.py:123-126,179-180) --
+    same rollout data either way.  The DQN loop is a host loop already: its hooks fire per vector step (off_policy.py:221-269)."""
+    from xuance_amd.agents import PPO_Agent, DQN_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+
+    class Rec:
+        def __init__(self):
+            self.calls = []
+
+        def on_update_start(self, it, **kw):
+            return {}
+
+        def on_update_end(self, it, **kw):
+            return {}
+
+        def on_train_step(self, step, **kw):
+            self.calls.append(("step", step, tuple(kw["obs"].shape), kw["obs"].is_cuda))
+
+        def on_train_step_end(self, step, **kw):
+            self.calls.append(("step_end", step, kw.get("steps")))
+
+        def on_train_epochs_end(self, step, **kw):
+            self.calls.append(("epochs_end", step, sorted(kw["update_info"])[:1]))
+    n, T = 32, 8
+    fields = []
+    for per_step in (False, True):
+        torch.manual_seed(0)
+        cb = Rec()
+        agent = PPO_Agent(make_config(n, T, per_step_callbacks=per_step, use_hip_graph=True), DeviceCartPoleVecEnv(n, seed=2), cb)
+        agent.train(2 * T)
+        torch.cuda.synchronize()
+        fields.append({k: npy(v) for k, v in agent.memory.soa.fields.items()})
+        kinds = [c[0] for c in cb.calls]
+        assert kinds.count("epochs_end") == 2
+        if per_step:
+            assert kinds.count("step") == 2 * T and kinds.count("step_end") == 2 * T
+            steps = [c[1] for c in cb.calls if c[0] == "step"]
+            assert steps == [t * n for t in range(2 * T)] and cb.calls[0][2] == (n, 4) and cb.calls[0][3]
+            assert [c[1] for c in cb.calls if c[0] == "step_end"] == [(t + 1) * n for t in range(2 * T)]
+        else:
+            assert kinds.count("step") == 0 and [c for c in cb.calls if c[0] == "step_end"] == [("step_end", n * T, T), ("step_end", 2 * n * T, T)]
+    for k in fields[0]:
+        assert np.array_equal(fields[0][k], fields[1][k]), k        # per-step launches == the whole-rollout launch, bit for bit
+    cb = Rec()
+    cfg = Namespace(representation_hidden_size=[64], q_hidden_size=[64], activation="relu", seed=1, parallels=16, running_steps=10 ** 5,
+                    buffer_size=16 * 64, batch_size=32, learning_rate=1e-3, gamma=0.99, start_greedy=0.5, end_greedy=0.05,
+                    decay_step_greedy=10000, sync_frequency=50, training_frequency=16, start_training=64, use_grad_clip=False,
+                    grad_clip_norm=0.5, use_obsnorm=False, use_rewnorm=False, distributed_training=False, device="cuda", model_dir="/tmp/x")
+    dqn = DQN_Agent(cfg, DeviceCartPoleVecEnv(16, seed=3), cb)
+    dqn.train(12)
+    kinds = [c[0] for c in cb.calls]
+    assert kinds.count("step") == 12 and kinds.count("step_end") == 12 and kinds.count("epochs_end") >= 5

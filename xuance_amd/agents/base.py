@@ -47,6 +47,28 @@ class AgentSurface:
                               seed=_get(c, "seed", 1), xuance_version=_get(c, "xuance_version", _pkg))       # agent.py:195-197
         self.logged = []                                                # log_infos sink: (step, dict) pairs
 
+    # -- the loop hooks of xuance/common/callback.py:31-58 --------------------------------------------------------------------
+    def _cb(self, hook, *args, **kwargs):
+        """Call `hook` of the user's callback if it has one (None / the learners' null object: nothing happens).  The device
+        loops call: on_train_step / on_train_step_end once per VECTOR step where the loop is a host loop anyway (DQN, feed-forward
+        QMIX; PPO with `per_step_callbacks: True`, which runs the rollout as per-step launches), otherwise once per ROLLOUT / per
+        run_episodes call with `steps=<vector steps covered>` in the kwargs; on_train_epochs_end after every update phase.  Tensors
+        handed over are the device tensors of the buffers (no copies, no host sync unless the callback reads them)."""
+        fn = getattr(self.callback, hook, None) if getattr(self, "callback", None) is not None else None
+        if fn is not None:
+            return fn(*args, **kwargs)
+
+    def _has_cb(self, hook):
+        """Does the user's callback OVERRIDE `hook` (a BaseCallback subclass that leaves it alone does not count)?"""
+        cb = getattr(self, "callback", None)
+        fn = getattr(type(cb), hook, None) if cb is not None else None
+        if fn is None:
+            return False
+        for base in type(cb).__mro__[1:]:
+            if base.__name__ == "BaseCallback" and getattr(base, hook, None) is fn:
+                return False
+        return True
+
     # -- logging hooks the loops call (agent.py:235-262); the reference writes tensorboard / wandb, out of scope here
     def log_infos(self, info, x_index):
         self.logged.append((int(x_index), dict(info)))

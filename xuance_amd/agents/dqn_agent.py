@@ -121,11 +121,18 @@ class DQN_Agent(AgentSurface):
             else:
                 self._normalize(env.next_obs if self.atari else env.next_obs.float(), self.Xn, update=False)
                 Xn = self.Xn
+            # off_policy.py:221-224 (device tensors: nothing is copied or synchronised unless the callback reads them)
+            self._cb("on_train_step", self.current_step, envs=env, model=self.model, obs=X.view(shp), acts=self.act_f,
+                     next_obs=Xn.view(shp), rewards=env.reward, terminals=env.terminated, truncations=getattr(env, "truncated", None),
+                     infos=None, train_steps=train_steps)
             self.memory.store(X.view(shp), self.act_f, env.reward, env.terminated, Xn.view(shp))
             if self.current_step > self.start_training and self.current_step % self.training_frequency == 0:
                 info = self._train_epochs(train_steps) or info
+                self._cb("on_train_epochs_end", self.current_step, model=self.model, memory=self.memory, train_steps=train_steps,
+                         update_info=info)                          # :232-234
             self.current_step += n
             self._update_explore_factor()
+            self._cb("on_train_step_end", self.current_step, envs=env, model=self.model, train_steps=train_steps, train_info=info)   # :268-269
         if self.use_graph_updates and hasattr(self.learner, "flush_info"):
             info = dict(self.learner.flush_info() or info)      # the one host read of this call (phases ran unsynchronised)
         if hasattr(env, "episode_stats"):

@@ -256,6 +256,8 @@ class PPO_Agent(AgentSurface):
                     val_slot=f["values"][t], logp_slot=f["aux_old_logp"][t], rew_slot=f["rewards"][t],
                     term_slot=f["terminals"][t], seg_slot=f["seg"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None,
                     last_step=int(t == T - 1), boot_only=0, step=t, **common)
+                if not kernel_only:
+                    self._step_hooks(t)
             ops.rollout_step_cartpole(self.model.plan, xnext_in=pp["xnext"][T & 1], bootv_prev=f["bootv"][T - 1], boot_only=1,
                                       last_step=0, step=0, **common)
         if kernel_only:
@@ -264,9 +266,30 @@ class PPO_Agent(AgentSurface):
         ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
                      self.gamma, self.gae_lam, self.memory.use_gae)
 
+    def _per_step(self):
+        """config.per_step_callbacks with a callback that overrides on_train_step / on_train_step_end: the rollout runs as eager
+        per-step launches (no whole-rollout launch, no rollout graph) and the hooks fire after every vector step."""
+        if not hasattr(self, "_per_step_cb"):
+            self._per_step_cb = bool(_get(self.config, "per_step_callbacks", False)) and \
+                (self._has_cb("on_train_step") or self._has_cb("on_train_step_end"))
+        return self._per_step_cb
+
+    def _step_hooks(self, t):
+        """ppo_agent.py:123-126,179-180 for vector step t of the running rollout: the buffer's slot t as device tensors."""
+        if not self._per_step():
+            return
+        f, n = self.memory.soa.fields, self.n_envs
+        step = self.current_step + t * n
+        self._cb("on_train_step", step, envs=self.envs, policy=self.model, obs=f["observations"][t], acts=f["actions"][t],
+                 vals=f["values"][t], rewards=f["rewards"][t], terminals=f["terminals"][t], aux_info={"old_logp": f["aux_old_logp"][t]},
+                 next_obs=getattr(self.envs, "next_obs", None), truncations=getattr(self.envs, "truncated", None), infos=None,
+                 train_steps=getattr(self, "_train_steps", None))
+        self._cb("on_train_step_end", step + n, envs=self.envs, policy=self.model, train_steps=getattr(self, "_train_steps", None),
+                 train_info=getattr(self, "_last_info", {}))
+
     def _persistent_ok(self, split_ok):
         """Whole-rollout launch: the 4-128-{128-2,128-1} class, all workgroups resident on one XCD (n_envs <= 320)."""
-        if not bool(_get(self.config, "use_persistent_rollout", True)) or not split_ok:
+        if not bool(_get(self.config, "use_persistent_rollout", True)) or not split_ok or self._per_step():
             return False
         plan = self.model.plan
         if list(plan.widths) != [4, 128, 256, 3] or 3 * ((self.n_envs + 31) // 32) > 32 or not ops.fast_kernels_enabled():
@@ -285,6 +308,7 @@ class PPO_Agent(AgentSurface):
         T, n, A = self.horizon_size, self.n_envs, self.model.action_dim
         for t in range(T):
             self._enqueue_step(t)
+            self._step_hooks(t)
         if hasattr(self.envs, "advance"):
             self.envs.advance(T)
         # buffer full: vals = get_terminated_values(next_obs) for every env (ppo_agent.py:129-135)
@@ -408,7 +432,7 @@ class PPO_Agent(AgentSurface):
     def _launch_rollout(self):
         if not self.use_fused_rollout:
             self._wide_acting()                                   # (allocates on first use: never inside a capture)
-        if self.use_graph and getattr(self.envs, "graph_safe", True):
+        if self.use_graph and getattr(self.envs, "graph_safe", True) and not self._per_step():
             if self._rollout_graph is None:
                 torch.cuda.synchronize()
                 g = ops.Graph()
@@ -546,9 +570,18 @@ class PPO_Agent(AgentSurface):
         """Runs ``train_steps`` vector steps (rounded up to whole rollouts of horizon_size steps)."""
         info = {}
         n_rollouts = (train_steps + self.horizon_size - 1) // self.horizon_size
+        self._train_steps = train_steps
         for _ in range(n_rollouts):
             self.rollout()
             info = self.update()
+            self._last_info = info
+            # ppo_agent.py:139-141; the per-step hooks fired inside the rollout when config.per_step_callbacks asks for them,
+            # otherwise on_train_step_end fires once per rollout (kwargs: steps = the vector steps it covers)
+            self._cb("on_train_epochs_end", self.current_step, policy=self.model, memory=self.memory, train_steps=train_steps,
+                     update_info=info)
+            if not self._per_step():
+                self._cb("on_train_step_end", self.current_step, envs=self.envs, policy=self.model, train_steps=train_steps,
+                         train_info=info, steps=self.horizon_size)
         eps, score, length = self.envs.episode_stats() if hasattr(self.envs, "episode_stats") else (0, 0.0, 0.0)
         info.update({"episodes": eps, "mean_episode_score": score, "mean_episode_length": length})
         return info

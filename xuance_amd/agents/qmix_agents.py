@@ -317,6 +317,10 @@ class QMIX_Agents(AgentSurface):
                                             step_dev=None))    # eager loop: the host knows the step index
             env.step_device()
             self._host_step += 1
+            # off_policy_marl.py:363-371 (device tensors; the loop is a host loop already, so the hooks cost nothing unused)
+            self._cb("on_train_step", self.current_step, envs=env, policy=self.model, obs=obs, actions=self.act_f, next_obs=env.next_obs,
+                     rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask, state=state, next_state=env.next_state,
+                     avail_actions=avail, next_avail_actions=env.next_avail, train_steps=train_steps)
             self.memory.store(obs=obs, actions=self.act_f, obs_next=env.next_obs, rewards=env.rewards,
                               terminals=env.terminals, agent_mask=env.agent_mask, state=state, state_next=env.next_state,
                               avail_actions=avail, avail_actions_next=env.next_avail)
@@ -326,8 +330,11 @@ class QMIX_Agents(AgentSurface):
                 else:
                     for _e in range(self.n_epochs):
                         info = self.learner.update(self.memory.sample())
+                self._cb("on_train_epochs_end", self.current_step, policy=self.model, memory=self.memory, train_steps=train_steps,
+                         update_info=info)
             self.current_step += n
             self._update_explore_factor()
+            self._cb("on_train_step_end", self.current_step, envs=env, policy=self.model, train_steps=train_steps, train_info=info)
         info = dict(self.learner.flush_info() or info)          # update phases ran unsynchronised: read the last one's info
         info["epsilon"] = self.e_greedy
         return info

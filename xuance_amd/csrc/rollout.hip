@@ -453,7 +453,8 @@ extern "C" int xrl_synth_marl_step(const xrl_synth_marl_t* params, int reset, xr
 extern "C" int xrl_rollout_poststep(const xrl_poststep_t* params, xrl_stream_t stream) {
     XRL_CHECK_ARG(params != nullptr);
     const xrl_poststep_t& p = *params;
-    XRL_CHECK_ARG(p.reward && p.terminated && p.truncated && p.next_obs && p.next_obs_norm && p.rew_out && p.term_out &&
+    // next_obs_norm NULL: the consumer takes the next observations as they are (uint8 frame stacks, agents/ppo_agent.py)
+    XRL_CHECK_ARG(p.reward && p.terminated && p.truncated && (p.next_obs || !p.next_obs_norm) && p.rew_out && p.term_out &&
                   p.seg_out && p.ret_track && p.ret_mean && p.ret_var && p.ret_count && p.n > 0 && p.D > 0);
     XRL_CHECK_ARG(!p.use_obsnorm || (p.obs_mean && p.obs_var));
     hipLaunchKernelGGL(poststep_kernel, dim3(1), dim3(POST_THREADS), 0, as_stream(stream), p);
