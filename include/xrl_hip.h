@@ -244,6 +244,10 @@ int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_
 int xrl_reduce_adam(const float* slabs, int n_split, int64_t slab_stride, float* params, float* grad, float* m, float* v,
                     int64_t P, xrl_adam_state_t* state, double* sumsq_part, int n_part, double max_norm,
                     const xrl_mirrors_t* mirrors, uint32_t* sync, xrl_stream_t stream);
+/* 1 if xrl_reduce_adam (with_exchange: xrl_reduce_adam_exchange) can run for P parameters on the current device: P % 4 == 0, at
+ * most 1 024 groups of 256, and every block of the launch resident at once (hipOccupancyMaxActiveBlocksPerMultiprocessor x the
+ * compute units: the launch's inter-block barrier spins).  Callers fall back to xrl_grad_reduce + xrl_adam_step otherwise. */
+int xrl_reduce_adam_fits(int64_t P, int with_exchange);
 
 /* Data-parallel ranks (one process per GPU; replaces the DistributedDataParallel gradient all-reduce of
  * xuance/torch/learners/learner.py:60-65 + torch's DDP hooks for this path): xrl_reduce_adam in which the ranks average

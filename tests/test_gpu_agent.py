@@ -956,7 +956,9 @@ def test_ppo_agent_on_atari_shape():
     torch.cuda.synchronize()
     f = agent.memory.soa.fields
     obs = f["observations"].view(T, n, -1)
-    assert int(obs.max()) > 0 and (f["seg"][8] & 1).all() and (f["seg"][T - 1] & 1).all()     # truncation at 9 steps, buffer end
+    seg = npy(f["seg"])
+    assert int(obs.max()) > 0 and (seg[:9] & 1).any(0).all() and (seg[T - 1] & 1).all()   # every env: a path end within 9 steps (cut-off
+    #                                                                                      or the provider's random terminations); buffer end
     # the stored values / log-probs are the network's outputs on the stored frames (initial parameters)
     heads = agent.model.forward(obs.reshape(T * n, -1), T * n, keep=False)[:T * n].clone()
     A = agent.model.action_dim

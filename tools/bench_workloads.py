@@ -114,6 +114,10 @@ class Runner:
             self.env_name = "SMAC-3m-shaped synthetic provider on the device (xrl_synth_marl_step; no simulator in the image)"
         for k, v in dict(_path_cfg(path), **(extra or {})).items():
             setattr(cfg, k, v)
+        if world > torch.cuda.device_count() and workload == "c4":
+            # ranks time-sharing ONE GPU (test boxes): the 279 blocks of this network's one-launch optimiser step spin on a
+            # barrier and need every block resident, which a second process on the device can prevent -- two launches instead
+            cfg.use_fused_optimizer = False
         self.ppo = workload in ("c2", "c4")
         self.agent = (PPO_Agent if self.ppo else QMIX_Agents)(cfg, env)
         if world > 1:

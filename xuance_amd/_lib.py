@@ -321,6 +321,7 @@ _SIGS = {
     "xrl_col2im_nhwc": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_maxpool_hw_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_maxpool_hw_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "xrl_reduce_adam_fits": [c_int64, c_int],
     "xrl_flatten_chw_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_flatten_chw_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_rollout_cartpole_persistent": [C.POINTER(RolloutPersist), c_void_p],

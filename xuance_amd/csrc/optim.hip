@@ -390,6 +390,34 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
 
 using namespace xrl;
 
+// How many blocks of the launch xrl_reduce_adam would make for P parameters can be RESIDENT at once (its barrier spins, so all of
+// them must be): the runtime's occupancy figure for the kernel instance that would run, times the compute units.  An
+// otherwise idle device is assumed -- another process on the same GPU (test boxes) can still take CUs away, which the
+// barrier's time-out reports (sync[2]); config.use_fused_optimizer: False selects the two-launch sequence.
+static void reduce_adam_geometry(int64_t P, bool exchange, int* n_blocks, int* capacity) {
+    const int n_vb = (int)((P / 4 + 63) / 64);
+    const int cus = device_cu_count();
+    const int G = n_vb >= RA_GROUPS_WIDE * cus ? RA_GROUPS_WIDE : 1;
+    *n_blocks = (n_vb + G - 1) / G;
+    static int per_cu[2][2] = {{0, 0}, {0, 0}};
+    int& pc = per_cu[exchange ? 1 : 0][G > 1 ? 1 : 0];
+    if (pc == 0) {
+        int nb = 0;
+        const void* fn = exchange ? (G > 1 ? (const void*)reduce_adam_kernel<true, RA_GROUPS_WIDE> : (const void*)reduce_adam_kernel<true, 1>)
+                                  : (G > 1 ? (const void*)reduce_adam_kernel<false, RA_GROUPS_WIDE> : (const void*)reduce_adam_kernel<false, 1>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RED_THREADS * G, 0) != hipSuccess || nb < 1) nb = 1;
+        pc = nb;
+    }
+    *capacity = pc * cus;
+}
+
+extern "C" int xrl_reduce_adam_fits(int64_t P, int with_exchange) {
+    if (P <= 0 || (P & 3)) return 0;
+    int nb = 0, cap = 0;
+    reduce_adam_geometry(P, with_exchange != 0, &nb, &cap);
+    return (nb <= cap && (P / 4 + 63) / 64 <= 1024) ? 1 : 0;
+}
+
 extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t slab_stride, float* params, float* grad,
                                         float* m, float* v, int64_t P, xrl_adam_state_t* state, double* sumsq_part, int n_part,
                                         double max_norm, const xrl_mirrors_t* mirrors, uint32_t* sync,
@@ -400,8 +428,15 @@ extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t
     XRL_CHECK_ARG(n_vb <= n_part && n_part <= 1024);
     const int G = n_vb >= RA_GROUPS_WIDE * device_cu_count() ? RA_GROUPS_WIDE : 1;   // (every CU keeps a block)
     const int nb = (n_vb + G - 1) / G;
-    XRL_CHECK_ARG(nb <= 4 * device_cu_count());                 // every block resident (the barrier spins): 256 threads and
-                                                                // 13 KB of LDS per block, at least four fit a CU
+    {
+        int nb_q = 0, cap = 0;                                  // every block resident (the barrier spins): asked of the runtime
+        reduce_adam_geometry(P, exchange && exchange->world > 1, &nb_q, &cap);
+        if (nb > cap) {
+            set_error("xrl_reduce_adam: the launch's blocks cannot all be resident on this device (its barrier spins); use "
+                      "xrl_grad_reduce + xrl_adam_step (xrl_reduce_adam_fits tells in advance)");
+            return XRL_EINVAL;
+        }
+    }
     xrl_mirrors_t mir{};
     if (mirrors) mir = *mirrors;
     XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);

@@ -185,6 +185,16 @@ class Learner:
         self.raise_on_optimizer_timeout()
         return st
 
+    def _fused_optimizer_ok(self, with_exchange=False):
+        """May this learner's optimiser step be ONE launch (xrl_reduce_adam: slab reduction, norm, clip, Adam, derived layouts behind
+        a spinning inter-block barrier)?  Not switched off (config.use_fused_optimizer) and every block of that launch resident on
+        this device (xrl_reduce_adam_fits); else the two-launch sequence xrl_grad_reduce + xrl_adam_step runs -- same numbers."""
+        key = "_foo_x" if with_exchange else "_foo"
+        if not hasattr(self, key):
+            setattr(self, key, bool(getattr(self.config, "use_fused_optimizer", True)) and
+                    ops.reduce_adam_fits(self.model.params.P, with_exchange))
+        return getattr(self, key)
+
     def needs_collective(self):
         """Several ranks AND no in-launch exchange: the update must stop at a process-group all-reduce."""
         return bool(self.distributed_training and self.world_size > 1 and self.gradient_exchange() is None)

@@ -53,8 +53,7 @@ class DQN_Learner(Learner):
                    ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)))
         model.backward(self.X, M, self.slabs, S)
         P, clip = model.params.P, (self.grad_clip_norm if self.use_grad_clip else 0.0)
-        if not self.needs_collective() and P % 4 == 0 and (P + 255) // 256 <= 512 and \
-                getattr(self.config, "use_fused_optimizer", True):
+        if not self.needs_collective() and self._fused_optimizer_ok(self.gradient_exchange() is not None):
             # slab reduction (+ the average over the ranks, inside the launch) + norm + clip + Adam + LinearLR + periodic
             # hard target update (:50-57) in ONE launch
             ops.reduce_adam(self.slabs, S, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],

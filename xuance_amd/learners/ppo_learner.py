@@ -102,7 +102,7 @@ class PPO_Learner(Learner):
         graph capture: prepare_buffer_update / update() call it before they enqueue)."""
         if not hasattr(self, "_lfo"):
             P = self.model.params.P
-            self._lfo = not (self.distributed_training and self.world_size > 1) and P % 4 == 0 and (P + 255) // 256 <= 1024 \
+            self._lfo = not (self.distributed_training and self.world_size > 1) and ops.reduce_adam_fits(P) \
                 and bool(getattr(self.config, "use_fused_optimizer", True))
             if self._lfo:
                 dev = self.model.params.device
@@ -128,8 +128,7 @@ class PPO_Learner(Learner):
     def finish_after_allreduce(self):
         """The launches that follow the gradient all-reduce (capturable: no collective in here)."""
         model, opt, P = self.model, self.optimizer, self.model.params.P
-        if getattr(self, "_mirror", False) and P % 4 == 0 and getattr(self, "opt_sync", None) is not None and \
-                getattr(self.config, "use_fused_optimizer", True):
+        if getattr(self, "_mirror", False) and getattr(self, "opt_sync", None) is not None and self._fused_optimizer_ok(False):
             clip = self.grad_clip_norm if self.use_grad_clip else 0.0
             ops.reduce_adam(opt.grad, 1, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip,
                             self._mirrors, self.opt_sync)
@@ -195,7 +194,7 @@ class PPO_Learner(Learner):
         self._last_S, self._last_partials = 2 * n_t, self.fpartials
         dist = self.distributed_training and self.world_size > 1
         xc = self.gradient_exchange() if dist and finish else None
-        if finish and (not dist or xc is not None) and getattr(self.config, "use_fused_optimizer", True):
+        if finish and (not dist or xc is not None) and self._fused_optimizer_ok(xc is not None):
             clip = self.grad_clip_norm if self.use_grad_clip else 0.0
             ops.reduce_adam(self.fslabs, n_t, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip,
                             self._mirrors, self.opt_sync, exchange=xc)
@@ -372,7 +371,7 @@ class PPO_Learner(Learner):
         self._last_S, self._last_partials = n_t * (2 if fold else 1), self.fpartials
         dist = self.distributed_training and self.world_size > 1
         xc = self.gradient_exchange() if dist and finish else None
-        if finish and (not dist or xc is not None) and m.params.P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
+        if finish and (not dist or xc is not None) and self._fused_optimizer_ok(xc is not None):
             # slab reduction (+ with several ranks: the gradient average over the ranks, inside the launch) + clip + Adam +
             # derived layouts in ONE launch (xrl_reduce_adam / xrl_reduce_adam_exchange)
             clip = self.grad_clip_norm if self.use_grad_clip else 0.0

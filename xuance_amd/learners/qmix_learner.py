@@ -195,7 +195,7 @@ class QMIX_Learner(Learner):
         m, opt, P = self.model, self.optimizer, self.model.params.P
         clip = self.grad_clip_norm if self.use_grad_clip else 0.0
         fs = getattr(self, "_fused", None)
-        if not self.needs_collective() and P % 4 == 0 and getattr(self.config, "use_fused_optimizer", True):
+        if not self.needs_collective() and self._fused_optimizer_ok(self.gradient_exchange() is not None):
             # (the one-launch update reads weight images: the optimiser launch writes every new parameter there as well)
             mirrors = [(fs.map, fs.img_eval)] if fs else []
             act = getattr(m, "_act_state", None)            # the acting launch's weight image follows every step too

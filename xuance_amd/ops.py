@@ -219,6 +219,13 @@ def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq
          stream_ptr())
 
 
+def reduce_adam_fits(P, with_exchange=False):
+    """May xrl_reduce_adam run for P parameters here (every block of its spinning barrier resident)?  The learners take the
+    two-launch sequence (xrl_grad_reduce + xrl_adam_step) when not."""
+    from ._lib import load
+    return bool(load().xrl_reduce_adam_fits(int(P), int(bool(with_exchange))))
+
+
 XC_MAX_RANKS, XC_MAX_GROUPS, IPC_HANDLE_BYTES = 8, 1024, 64
 
 
