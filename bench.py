@@ -141,13 +141,14 @@ def kernel_rooflines(agent):
                                 partials=lr.fpartials, diag=None, slab_stride=lr.slab_stride,
                                 l0_fold_off=lr.fold[0] if lr.fold else 0, M=bs, n_envs=n, T=T, D=4,
                                 frag_image=lr.frag, f_packed=lr.packed, f_rows=lr.rows[k * bs * 8:(k + 1) * bs * 8],
+                                pad0=64 if getattr(lr, "pair", False) else 0,
                                 A=m.action_dim, clip_range=lr.clip_range, vf_coef=lr.vf_coef, ent_coef=lr.ent_coef)
     r2 = None
     if lr.fused_eligible(mem) and getattr(lr, "rows", None) is not None and getattr(lr, "opt_sync", None) is not None:
         clip = lr.grad_clip_norm if lr.use_grad_clip else 0.0
         opt = lr.optimizer
         def ra():
-            ops.reduce_adam(lr.fslabs, lr.n_tiles, lr.slab_stride, m.params.flat, opt.grad, opt.m, opt.v, m.params.P,
+            ops.reduce_adam(lr.fslabs, getattr(lr, "n_slabs", lr.n_tiles), lr.slab_stride, m.params.flat, opt.grad, opt.m, opt.v, m.params.P,
                             opt.state, lr.sumsq, clip, lr._mirrors, lr.opt_sync, fold=lr.fold)
         # the real minibatch sequence [minibatch kernel, reduce + Adam] x nb, bracketed twice with HIP events: once around
         # every PAIR, once around the optimiser launch of every pair only; the difference of the medians is the minibatch
@@ -176,7 +177,7 @@ def kernel_rooflines(agent):
         us_mb = us_pair - us_opt
         fl_mb = 3.0 * fwd_flops_row * bs
         n_mb = nb                                          # agent.idx holds n_epochs x n_minibatch index rows
-        kname = "xrl::ppo_split_kernel" if lr.fold else "xrl::ppo_fast_kernel"
+        kname = "xrl::ppo_pair_kernel" if getattr(lr, "pair", False) else ("xrl::ppo_split_kernel" if lr.fold else "xrl::ppo_fast_kernel")
         r2 = {"bound": "mfma", "kernel": kname, "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
               "traffic": _pmc_traffic(kname), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_mb, 3),

@@ -557,7 +557,10 @@ typedef struct {
     const float* params_t;      /* same layout, middle-layer weights stored transposed ([K][N]) -- xrl_transpose_mid */
     const float* cache_image;   /* xrl_pack_rollout_cache image (first layer, biases, merged heads) */
     xrl_fused_layer_t layers[XRL_FUSED_MAX_LAYERS];
-    int32_t n_layers, n_levels, n_head_layers, pad0;
+    int32_t n_layers, n_levels, n_head_layers;
+    int32_t pad0;               /* tile_rows: 0 / 32 = one gradient slab per 32-row tile; 64 (with l0_fold_off, the role-split layout) =
+                                 * the 64-row role-split kernel (ppo_pair.hip): slab and partials rows per 64 rows -- ceil(M/64) slabs,
+                                 * partials [2 ceil(M/64)][8] */
     int32_t level_width[XRL_FUSED_MAX_LEVELS];
     /* rollout buffer fields [T][n_envs][...] and the minibatch's env-major flat indices (memory_tools.py:270) */
     const float* f_obs; const float* f_act; const float* f_ret; const float* f_adv; const float* f_logp;

@@ -194,11 +194,12 @@ def _load_rows(memory, b, n, T):
 
 
 @pytest.mark.parametrize("size,n,T,kernel", [("c2", 32, 256, "fast"), ("c1", 4, 32, "split"), ("c1", 4, 32, "fast"),
-                                             ("c2", 32, 256, "any-shape")])
+                                             ("c2", 32, 256, "any-shape"), ("c2", 32, 256, "pair"), ("c1", 4, 32, "pair")])
 def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
     """The ONE-LAUNCH minibatch kernels pinned to the reference directly, at its own sizes: the rows of the C2 (8 192) / C1
     (128) fixtures are loaded into a HipOnPolicyBuffer and go through gather -> forward -> loss -> backward (xrl_ppo_fused_minibatch:
-    ppo_fast_kernel -- 256 tiles / 256 gradient slabs at C2 --, ppo_split_kernel for <= 32 tiles, the any-shape ppo_fused_kernel)
+    ppo_fast_kernel -- 256 tiles / 256 gradient slabs at C2 --, ppo_split_kernel for <= 32 tiles, ppo_pair_kernel -- (64-row tile,
+    role) workgroups, 128 slabs at C2 --, the any-shape ppo_fused_kernel)
     and xrl_reduce_adam, exactly as PPO_Agent's update phase enqueues them; compared with the reference's `u*/grad` (clipped),
     its float64 twin, its parameter steps and Adam moments (reference: ppo_learner.py:46-67).  The fixture's advantages are
     already normalised (what buffer.sample hands the learner), so the launch gets no statistics."""
@@ -213,7 +214,7 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
                     gamma=0.98, use_gae=True, gae_lambda=0.95, use_advnorm=True, use_grad_clip=True, grad_clip_norm=float(gclip),
                     end_factor_lr_decay=float(ef), use_obsnorm=False, use_rewnorm=False, obsnorm_range=5, rewnorm_range=5,
                     distributed_training=False, device="cuda", model_dir="/tmp/xrl_models", use_hip_graph=False,
-                    use_role_split_update=(kernel == "split"))
+                    use_role_split_update=(kernel == "split"), use_pair_update=(kernel == "pair"))
     prev = ops.fast_kernels_enabled()
     ops.set_fast_kernels(kernel != "any-shape")
     try:
@@ -225,7 +226,7 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
                                  tol=C2_TOL if size == "c2" else 1e-5)
         idx = torch.arange(n * T, dtype=torch.int64, device="cuda").view(1, -1)
         lr_.prepare_fused(mem, n * T)
-        assert lr_.split == (kernel == "split")
+        assert lr_.split == (kernel in ("split", "pair")) and lr_.pair == (kernel == "pair")
         lr_.prepare_rows(idx.numel())
         for u in range(int(g["n_updates"])):
             _load_rows(mem, sub(g, f"u{u}/batch"), n, T)

@@ -408,12 +408,16 @@ int init_ppo_fast();
 bool ppo_split_eligible(const xrl_ppo_fused_t& p);
 int launch_ppo_split(const xrl_ppo_fused_t& p, hipStream_t stream);
 int init_ppo_split();
+bool ppo_pair_eligible(const xrl_ppo_fused_t& p);
+int launch_ppo_pair(const xrl_ppo_fused_t& p, hipStream_t stream);
+int init_ppo_pair();
 }
 using namespace xrl;
 
 extern "C" int xrl_init_ppo_fused(void) {
     if (int rc = init_ppo_fast()) return rc;
     if (int rc = init_ppo_split()) return rc;
+    if (int rc = init_ppo_pair()) return rc;
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fused_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     return XRL_OK;
@@ -429,6 +433,7 @@ extern "C" int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* pp, xrl_stream_t s
     XRL_CHECK_ARG(p.n_head_layers >= 1 && p.n_head_layers < p.n_layers && p.layers[0].K == 4 && p.layers[0].in_level == 0);
     XRL_CHECK_ARG(p.level_width[0] == 4 && p.level_width[p.n_levels - 1] == p.A + 1);
     for (int l = 1; l < p.n_layers - p.n_head_layers; ++l) XRL_CHECK_ARG(p.layers[l].N % 32 == 0 && p.layers[l].K % 32 == 0);
+    if (ppo_pair_eligible(p)) return launch_ppo_pair(p, as_stream(stream));        // (64-row tile, role) workgroups: tile_rows == 64
     if (ppo_split_eligible(p)) return launch_ppo_split(p, as_stream(stream));      // two role workgroups per tile
     XRL_CHECK_ARG(p.l0_fold_off == 0);                                              // (a fold region means: role-split or nothing)
     if (ppo_fast_eligible(p)) return launch_ppo_fast(p, as_stream(stream));        // shape-specialised twin

@@ -255,6 +255,18 @@ class PPO_Learner(Learner):
             m.dist == "categorical" and m.params.offsets.get("representation.model.0.weight", -1) == 0 and \
             m.params.offsets.get("representation.model.0.bias", -1) == 512 and ops.fast_kernels_enabled()
 
+    def pair_eligible(self, n_tiles):
+        """64-row role-split minibatch kernel (csrc/ppo_pair.hip: one workgroup per (64-row tile, branch), half the weight stream and
+        half the gradient slabs of ppo_fast_kernel for the same number of workgroups): the split kernel's network class, minibatches
+        of at least 128 32-row tiles (so that the 64-row decomposition still fills the chip's CUs), an even number of them.
+        config.use_pair_update: "auto" (default) / True / False."""
+        want = getattr(self.config, "use_pair_update", "auto")
+        want = (n_tiles >= 128) if want == "auto" else bool(want)
+        m, plan = self.model, self.model.plan
+        return want and list(plan.widths) == [4, 128, 256, 3] and m.dist == "categorical" and \
+            m.params.offsets.get("representation.model.0.weight", -1) == 0 and \
+            m.params.offsets.get("representation.model.0.bias", -1) == 512 and ops.fast_kernels_enabled()
+
     def prepare_fused(self, memory, bs):
         if getattr(self, "_fused_bs", 0) == bs:
             return
@@ -269,12 +281,14 @@ class PPO_Learner(Learner):
             return
         self._ensure(bs)
         self.n_tiles = (bs + 31) // 32
-        self.split = self.split_eligible(self.n_tiles)
+        self.pair = self.pair_eligible(self.n_tiles)
+        self.split = self.pair or self.split_eligible(self.n_tiles)    # (the 64-row kernel uses the role-split slab layout)
         # gradient slabs: one per tile; with the role-split kernel a fold region behind the parameters takes the critic
         # role's first-layer gradient, and every (tile, role) workgroup has its own row of loss partials
         self.slab_stride = P + (self.L0_FOLD if self.split else 0)
         self.fold = (P, self.L0_FOLD) if self.split else None
         self.n_part_rows = self.n_tiles * (2 if self.split else 1)
+        self.n_slabs = (bs + 63) // 64 if self.pair else self.n_tiles  # gradient slabs one minibatch launch writes
         self.fslabs = torch.zeros(self.n_tiles, self.slab_stride, device=dev)
         self.fpartials = torch.zeros(self.n_part_rows, 8, dtype=torch.float64, device=dev)
         self.params_t = torch.zeros(P, device=dev)
@@ -359,15 +373,16 @@ class PPO_Learner(Learner):
             off = (idx.data_ptr() - base.data_ptr()) // 8
             if 0 <= off and off + M <= base.numel() and idx.is_contiguous():
                 rows = self.rows[off * 8:(off + M) * 8]
+        pair = bool(fold) and getattr(self, "pair", False)
         ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=self.params_t, cache_image=self.cache_image,
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs, frag_image=self.frag,
                                 f_packed=self.packed if getattr(self, "_packed_valid", False) else None, f_rows=rows,
                                 partials=self.fpartials, diag=self.diag if self.keep_diag else None,
                                 slab_stride=self.slab_stride, l0_fold_off=fold[0] if fold else 0, M=M,
-                                n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim,
+                                n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim, pad0=64 if pair else 0,
                                 clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
-        n_t = (M + 31) // 32
+        n_t = (M + 63) // 64 if pair else (M + 31) // 32             # gradient slabs (and, per role, partial rows) of this launch
         self._last_S, self._last_partials = n_t * (2 if fold else 1), self.fpartials
         dist = self.distributed_training and self.world_size > 1
         xc = self.gradient_exchange() if dist and finish else None
