@@ -177,7 +177,7 @@ def kernel_rooflines(agent):
         us_mb = us_pair - us_opt
         fl_mb = 3.0 * fwd_flops_row * bs
         n_mb = nb                                          # agent.idx holds n_epochs x n_minibatch index rows
-        kname = "xrl::ppo_pair_kernel" if getattr(lr, "pair", False) else ("xrl::ppo_split_kernel" if lr.fold else "xrl::ppo_fast_kernel")
+        kname = "xrl::ppo_trunk_kernel" if lr.fold else "xrl::ppo_fast_kernel"       # (role-split family: 64-row tiles at the headline size)
         r2 = {"bound": "mfma", "kernel": kname, "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
               "traffic": _pmc_traffic(kname), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_mb, 3),

@@ -559,8 +559,8 @@ typedef struct {
     xrl_fused_layer_t layers[XRL_FUSED_MAX_LAYERS];
     int32_t n_layers, n_levels, n_head_layers;
     int32_t pad0;               /* tile_rows: 0 / 32 = one gradient slab per 32-row tile; 64 (with l0_fold_off, the role-split layout) =
-                                 * the 64-row role-split kernel (ppo_pair.hip): slab and partials rows per 64 rows -- ceil(M/64) slabs,
-                                 * partials [2 ceil(M/64)][8] */
+                                 * 64-row tiles in the shared-trunk kernel (ppo_trunk.hip): slab and partials rows per 64 rows --
+                                 * ceil(M/64) slabs, partials [2 ceil(M/64)][8] */
     int32_t level_width[XRL_FUSED_MAX_LEVELS];
     /* rollout buffer fields [T][n_envs][...] and the minibatch's env-major flat indices (memory_tools.py:270) */
     const float* f_obs; const float* f_act; const float* f_ret; const float* f_adv; const float* f_logp;
@@ -571,9 +571,9 @@ typedef struct {
     float* diag;                /* NULL or [4][M] */
     int64_t slab_stride;
     int32_t M, n_envs, T, D, A;
-    int32_t l0_fold_off;        /* 0, or the slab column (>= P, multiple of 4) of a 640-float fold region: selects the role-split
-                                 * kernel (ppo_split.hip: TWO workgroups per tile, partials [2 n_tiles][8]; the critic role's
-                                 * first-layer gradient goes to the fold region -- reduce with xrl_mirrors_t.fold_off / _len) */
+    int32_t l0_fold_off;        /* 0, or the slab column (>= P, multiple of 4) of a (128 D + 128)-float fold region: selects the
+                                 * role-split shared-trunk kernel (ppo_trunk.hip: TWO workgroups per tile, partials [2 n_tiles][8]; the
+                                 * critic role's first-layer gradient goes to the fold region -- reduce with xrl_mirrors_t.fold_off / _len) */
     float clip_range, vf_coef, ent_coef, pad2;
     long long* dbg;             /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
     const float* frag_image;    /* NULL, or xrl_pack_mid_frags copy of the first middle layer in MFMA B-fragment order */
@@ -581,6 +581,11 @@ typedef struct {
                                  * first load then needs neither the index nor a dependent second hop */
     const float* f_packed;      /* NULL, or xrl_pack_transitions records [T*n_envs][8] = obs[4] | act | ret | adv | old_logp:
                                  * one 32-byte random access per sampled row instead of five (D == 4 only) */
+    /* the shared-trunk family D-128-{128-A | 128-1} (csrc/ppo_trunk.hip; selected with l0_fold_off > 0): */
+    int32_t dist;               /* 0 categorical (f_act: [T][n_envs] action indices as float), 1 Gaussian (f_act: [T][n_envs][A]) */
+    int32_t out_act;            /* Gaussian: activation_action on the mean, XRL_ACT_NONE | XRL_ACT_TANH (actor_head.py:62) */
+    int32_t log_std_off;        /* Gaussian: float offset of actor.log_std [A] in params / a slab row */
+    int32_t pad3;
 } xrl_ppo_fused_t;
 int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* p, xrl_stream_t stream);
 /* packed[i][0..7] = obs[i][0..3], act[i], ret[i], adv[i], logp[i] for i < count (the rollout buffer's [t][env] order):

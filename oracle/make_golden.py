@@ -207,12 +207,25 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo", size=None):
     configs C1 (128) and C2 (8 192); size="c4": the HalfCheetah-shape Gaussian net of configs/ppo/mujoco.yaml
     (Basic_Identical, 17-256-256-6 / 17-256-256-1, leaky_relu, tanh action activation) at its per-GPU minibatch 4 096."""
     torch.manual_seed(1)
-    rng = np.random.default_rng(5 if size is None else {"c1": 105, "c2": 205, "c4": 405}[size])
-    act_fn = nn.LeakyReLU if (dist == "categorical" or size == "c4") else nn.ReLU
+    # the other members of the shared-trunk family Basic_MLP [128] + actor [128] + critic [128] (configs/ppo/classic_control/*.yaml,
+    # box2d/{LunarLander,BipedalWalker}.yaml) at the minibatch their yaml gives: 10 envs x 256 / 8 = 320 rows
+    family = {"acrobot": (6, 3), "lunar": (8, 4), "pendulum": (3, 1), "walker": (24, 4)}
+    rng = np.random.default_rng(5 if size is None else {"c1": 105, "c2": 205, "c4": 405, "acrobot": 505, "lunar": 605,
+                                                       "pendulum": 705, "walker": 805}[size])
+    act_fn = nn.LeakyReLU if (dist == "categorical" or size in ("c4",) + tuple(family)) else nn.ReLU
     init = torch.nn.init.orthogonal_
     n_updates = 3 if size is None else 2
     quant = (lambda a: a) if size is None else q16
-    if dist == "categorical":
+    if size in family:
+        D, A = family[size]
+        bs = 320
+        rep = Basic_MLP((D,), [128], None, init, act_fn, "cpu")
+        actor = (CategoricalActorHead(128, [128], A, None, init, act_fn, "cpu") if dist == "categorical" else
+                 GaussianActorHead(128, [128], A, None, init, act_fn, nn.Tanh, "cpu"))
+        critic = ValueHead(128, [128], None, init, act_fn, "cpu")
+        cfg = base_config(horizon_size=256, n_epochs=8, n_minibatch=8, vf_coef=0.25, ent_coef=0.01, clip_range=0.2,
+                          parallels=10, end_factor_lr_decay=0.5)
+    elif dist == "categorical":
         D, A, bs = 4, 2, {None: 96, "c1": 128, "c2": 8192}[size]
         rep = Basic_MLP((D,), [128], None, init, act_fn, "cpu")
         actor = CategoricalActorHead(128, [128], A, None, init, act_fn, "cpu")
@@ -262,6 +275,9 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo", size=None):
                         batch_size=len(b["obs"]))
     out = run_learner_updates(learner, model, cb, batches, call)
     out.update(float64_twin(learner_cls(cfg, model64, Capture()), model64, batches, lambda L, b: call(b, L)))
+    if size in family:                                             # (the twin's parameters are not compared anywhere)
+        out = {k: v for k, v in out.items() if "/param64/" not in k}
+        out["shape"] = np.array([D, A])
     out["cfg"] = np.array([cfg.learning_rate, cfg.vf_coef, cfg.ent_coef, cfg.clip_range, cfg.grad_clip_norm,
                            getattr(cfg, "end_factor_lr_decay", 1.0),
                            cfg.running_steps if name == "a2c" else learner.total_iters])
@@ -1022,6 +1038,8 @@ def golden_baseline_sizes():
     golden_qmix_rnn(True, fixed=True, size="c5")
     golden_ppo_chain()
     golden_ppo_cnn()
+    for dist, size in (("categorical", "acrobot"), ("categorical", "lunar"), ("gaussian", "pendulum"), ("gaussian", "walker")):
+        golden_ppo(dist, size=size)
 
 
 if __name__ == "__main__":

@@ -370,7 +370,8 @@ def test_specialised_minibatch_kernel_is_bit_identical_to_any_shape_kernel(act, 
 
 @pytest.mark.parametrize("act,n,T,nmb", [("leaky_relu", 64, 64, 4), ("tanh", 50, 30, 3), ("relu", 256, 256, 8)])
 def test_role_split_minibatch_kernel_vs_single_workgroup_kernel(act, n, T, nmb):
-    """ppo_split_kernel (two workgroups per tile: actor branch / critic branch, two per CU) vs ppo_fast_kernel on the same
+    """The role-split kernel on 32-row tiles (ppo_trunk_kernel<.., 32, 4, 2>: two workgroups per tile -- actor branch / critic branch --,
+    two per CU; round 2's ppo_split_kernel) vs ppo_fast_kernel on the same
     minibatch: the per-sample diagnostics (log-prob, ratio, surrogates) and every branch / head gradient carry the SAME
     bits (same MFMA chains and reduction trees per element); the first-layer gradient -- whose two branch parts are now
     added by the slab reduction instead of in LDS -- and the loss sums agree to fp32 / fp64 re-association."""
@@ -380,7 +381,7 @@ def test_role_split_minibatch_kernel_vs_single_workgroup_kernel(act, n, T, nmb):
     res = []
     for split in (False, True):
         torch.manual_seed(0)
-        agent = PPO_Agent(make_config(n, T, n_epochs=1, n_minibatch=nmb, activation=act, use_role_split_update=split),
+        agent = PPO_Agent(make_config(n, T, n_epochs=1, n_minibatch=nmb, activation=act, use_role_split_update=split, use_pair_update=False),
                           DeviceCartPoleVecEnv(n, seed=2))
         agent.rollout()
         agent._new_indices()

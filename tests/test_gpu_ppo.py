@@ -243,6 +243,51 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
         ops.set_fast_kernels(prev)
 
 
+@pytest.mark.parametrize("dist,size,tiles", [("categorical", "acrobot", 32), ("categorical", "lunar", 32), ("gaussian", "pendulum", 32),
+                                             ("gaussian", "walker", 32), ("gaussian", "walker", 64), ("categorical", "acrobot", 64)])
+def test_shared_trunk_family_vs_reference_fixture(dist, size, tiles):
+    """The other members of the reference's shared-trunk PPO family (Basic_MLP [128] + actor [128] + critic [128]:
+    configs/ppo/classic_control/{Acrobot,Pendulum}.yaml, box2d/{LunarLander,BipedalWalker}.yaml -- (D, A) = (6, 3), (3, 1), (8, 4),
+    (24, 4), categorical and Gaussian with tanh on the mean) through the ONE-LAUNCH minibatch kernel (csrc/ppo_trunk.hip: (tile, role)
+    workgroups, 32- and 64-row tiles) + xrl_reduce_adam, from rows in a HipOnPolicyBuffer, at the 320-row minibatch their yaml
+    gives: the reference learner's loss terms, clipped gradients (float64-anchored), parameter steps, Adam moments."""
+    from xuance_amd.nets import ActorCriticNet
+    from xuance_amd.learners import PPO_Learner
+    from xuance_amd.memory import HipOnPolicyBuffer
+    from xuance_amd.spaces import Box, Discrete
+    g = load_golden(f"ppo_{dist}_{size}")
+    D, A = (int(x) for x in g["shape"])
+    lr, vf, ent, clip, gclip, ef, total = g["cfg"]
+    n, T = 10, 32                                                      # 320 rows = one minibatch
+    net = ActorCriticNet(D, A, dist, (128,), (128,), (128,), "leaky_relu", activation_action="tanh" if dist == "gaussian" else None)
+    assert list(net.ref_order) == [str(x) for x in g["param_names"]]
+    net.load_state_dict(sub(g, "init"))
+    cfg = Namespace(horizon_size=T, n_epochs=1, n_minibatch=1, parallels=n, running_steps=int(total) * n * T, gamma=0.98,
+                    learning_rate=float(lr), vf_coef=float(vf), ent_coef=float(ent), clip_range=float(clip), use_grad_clip=True,
+                    grad_clip_norm=float(gclip), end_factor_lr_decay=float(ef), distributed_training=False, device="cuda",
+                    model_dir="/tmp/xrl_models", use_pair_update=(tiles == 64))
+    learner = PPO_Learner(cfg, net, Capture())
+    assert learner.total_iters == int(total) and learner.trunk_eligible()
+    mem = HipOnPolicyBuffer(Box(-np.inf, np.inf, (D,), np.float32), Discrete(A) if dist == "categorical" else Box(-1, 1, (A,), np.float32),
+                            {"old_logp": ()}, n, T, device="cuda")
+    assert learner.fused_eligible(mem)
+    learner.prepare_fused(mem, n * T)
+    assert learner.split and learner.pair == (tiles == 64) and learner.params_t is None
+    chk = EngineFixtureCheck(g, net, learner, float(lr), end_factor=float(ef), total_iters=int(total))
+    idx = torch.arange(n * T, dtype=torch.int64, device="cuda").view(1, -1)
+    for u in range(int(g["n_updates"])):
+        _load_rows(mem, sub(g, f"u{u}/batch"), n, T)
+        learner.refresh_fused_params(mem, idx)
+        learner.enqueue_minibatch_fused(mem, idx[0], None)
+        info = learner.last_info(n * T)
+        ref_info, ref_cb = sub(g, f"u{u}/info"), sub(g, f"u{u}/cb")
+        assert_close(info["actor_loss"], ref_info["actor_loss"], 1e-5, "actor_loss", scale=float(np.abs(ref_cb["surrogate2"]).mean()))
+        for k in ("critic_loss", "entropy", "predict_value", "clip_ratio"):
+            assert_close(info[k], ref_info[k], 1e-5, k)
+        chk.after_update(u)
+    chk.finish()
+
+
 def ppo_cnn_fc_init(shape):
     """oracle/make_golden.py: ppo_cnn_fc_init (same lines): the dense weight's initial values in the PPO-CNN fixture."""
     i, j = np.meshgrid(np.arange(shape[0], dtype=np.int64), np.arange(shape[1], dtype=np.int64), indexing="ij")

@@ -116,13 +116,14 @@ opt_kwargs_clip = {}
 
 
 @pytest.mark.parametrize("dist,size", [("categorical", None), ("gaussian", None), ("categorical", "c1"),
-                                       ("categorical", "c2"), ("gaussian", "c4")])
+                                       ("categorical", "c2"), ("gaussian", "c4"), ("categorical", "acrobot"), ("categorical", "lunar"),
+                                       ("gaussian", "pendulum"), ("gaussian", "walker")])
 def test_ppo_update(oracle, dist, size):
     """size: the minibatch of BASELINE C1 (128) / C2 (8 192) on the CartPole net, C4 (4 096) on 17-256-256 (leaky_relu)."""
     g = load_golden(f"ppo_{dist}" + (f"_{size}" if size else ""))
     lr, vf, ent, clip, gclip, ef, total = g["cfg"]
     cfg = dict(vf_coef=vf, ent_coef=ent, clip_range=clip)
-    act = "leaky_relu" if (dist == "categorical" or size == "c4") else "relu"
+    act = "leaky_relu" if (dist == "categorical" or size is not None) else "relu"
     aa = None if dist == "categorical" else "tanh"
     opt_kwargs_clip["clip"] = gclip
     nu = int(g.get("n_updates", 3))

@@ -1,4 +1,4 @@
-"""Scratch: where a minibatch launch of ppo_pair_kernel (and of ppo_fast_kernel for comparison) spends its time -- shader-clock
+"""Scratch: where a minibatch launch of the 64-row role-split kernel (ppo_trunk_kernel<.., 64>; and of ppo_fast_kernel for comparison) spends its time -- shader-clock
 stamps of the last workgroup's phases, the 100 MHz real-time counter at the start / end of every workgroup (launch skew, slowest
 workgroup, tail) and the HIP-event time of the launch alone."""
 import os, sys

@@ -184,7 +184,8 @@ class PpoFused(C.Structure):
                 ("idx", c_void_p), ("stats", c_void_p), ("slabs", c_void_p), ("partials", c_void_p), ("diag", c_void_p),
                 ("slab_stride", c_int64), ("M", c_int32), ("n_envs", c_int32), ("T", c_int32), ("D", c_int32),
                 ("A", c_int32), ("l0_fold_off", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
-                ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p)]
+                ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p),
+                ("dist", c_int32), ("out_act", c_int32), ("log_std_off", c_int32), ("pad3", c_int32)]
 
 
 class WideBranch(C.Structure):

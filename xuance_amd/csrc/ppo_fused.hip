@@ -405,19 +405,15 @@ namespace xrl {
 bool ppo_fast_eligible(const xrl_ppo_fused_t& p);
 int launch_ppo_fast(const xrl_ppo_fused_t& p, hipStream_t stream);
 int init_ppo_fast();
-bool ppo_split_eligible(const xrl_ppo_fused_t& p);
-int launch_ppo_split(const xrl_ppo_fused_t& p, hipStream_t stream);
-int init_ppo_split();
-bool ppo_pair_eligible(const xrl_ppo_fused_t& p);
-int launch_ppo_pair(const xrl_ppo_fused_t& p, hipStream_t stream);
-int init_ppo_pair();
+bool ppo_trunk_eligible(const xrl_ppo_fused_t& p);
+int launch_ppo_trunk(const xrl_ppo_fused_t& p, hipStream_t stream);
+int init_ppo_trunk();
 }
 using namespace xrl;
 
 extern "C" int xrl_init_ppo_fused(void) {
     if (int rc = init_ppo_fast()) return rc;
-    if (int rc = init_ppo_split()) return rc;
-    if (int rc = init_ppo_pair()) return rc;
+    if (int rc = init_ppo_trunk()) return rc;
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fused_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     return XRL_OK;
@@ -426,16 +422,20 @@ extern "C" int xrl_init_ppo_fused(void) {
 extern "C" int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* pp, xrl_stream_t stream) {
     XRL_CHECK_ARG(pp != nullptr);
     const xrl_ppo_fused_t& p = *pp;
-    XRL_CHECK_ARG(p.params && p.params_t && p.cache_image && (reinterpret_cast<uintptr_t>(p.cache_image) & 15) == 0);
+    XRL_CHECK_ARG(p.params != nullptr);
     XRL_CHECK_ARG(p.f_obs && p.f_act && p.f_ret && p.f_adv && p.f_logp && p.idx && p.slabs && p.partials);
-    XRL_CHECK_ARG(p.M > 0 && p.D == 4 && p.A >= 2 && p.n_envs > 0 && p.T > 0);
+    XRL_CHECK_ARG(p.M > 0 && p.n_envs > 0 && p.T > 0);
+    // the shared-trunk family D-128-{128-A | 128-1} (D <= 24, A <= 8, categorical | Gaussian): (tile, role) workgroups, 32- or 64-row tiles
+    if (p.l0_fold_off > 0) {
+        if (!ppo_trunk_eligible(p)) { set_error("xrl_ppo_fused_minibatch: a fold region was given but the network is not of the shared-trunk family (csrc/ppo_trunk.hip)"); return XRL_EINVAL; }
+        return launch_ppo_trunk(p, as_stream(stream));
+    }
+    XRL_CHECK_ARG(p.params_t && p.cache_image && (reinterpret_cast<uintptr_t>(p.cache_image) & 15) == 0);
+    XRL_CHECK_ARG(p.D == 4 && p.A >= 2 && p.dist == 0);
     XRL_CHECK_ARG(p.n_layers >= 2 && p.n_layers <= XRL_FUSED_MAX_LAYERS && p.n_levels >= 3 && p.n_levels <= XRL_FUSED_MAX_LEVELS);
     XRL_CHECK_ARG(p.n_head_layers >= 1 && p.n_head_layers < p.n_layers && p.layers[0].K == 4 && p.layers[0].in_level == 0);
     XRL_CHECK_ARG(p.level_width[0] == 4 && p.level_width[p.n_levels - 1] == p.A + 1);
     for (int l = 1; l < p.n_layers - p.n_head_layers; ++l) XRL_CHECK_ARG(p.layers[l].N % 32 == 0 && p.layers[l].K % 32 == 0);
-    if (ppo_pair_eligible(p)) return launch_ppo_pair(p, as_stream(stream));        // (64-row tile, role) workgroups: tile_rows == 64
-    if (ppo_split_eligible(p)) return launch_ppo_split(p, as_stream(stream));      // two role workgroups per tile
-    XRL_CHECK_ARG(p.l0_fold_off == 0);                                              // (a fold region means: role-split or nothing)
     if (ppo_fast_eligible(p)) return launch_ppo_fast(p, as_stream(stream));        // shape-specialised twin
     const size_t lds_bytes = ppo_fused_lds_bytes(p);
     XRL_CHECK_ARG(lds_bytes <= 156 * 1024);

@@ -1,0 +1,586 @@
+// One-launch PPO minibatch for the reference's shared-trunk actor-critic family  D -> 128 -> {128 -> A | 128 -> 1}:
+// Basic_MLP [128] + actor_hidden_size [128] + critic_hidden_size [128] -- every configs/ppo/classic_control/*.yaml and the MLP
+// ones of configs/ppo/box2d/ (CartPole 4/2, Acrobot 6/3, MountainCar 2/3, LunarLander 8/4: Categorical_AC; Pendulum 3/1,
+// BipedalWalker 24/4: Gaussian_AC with tanh on the mean) -- for D <= 24, A <= 8, categorical or Gaussian head.
+//
+// template <ACT, HEAD, PT>: hidden activation; HEAD 0 = categorical, 1 = Gaussian (mean as is), 2 = Gaussian (tanh on the mean);
+// PT = rows per workgroup.  Workgroup = (PT-row tile, role): role 0 owns the actor branch (rows 0..127 of the stacked branch
+// layer, the A head rows, log_std), role 1 the critic branch -- they need nothing from each other (csrc/ppo_split.hip, round 2):
+// the shared first layer is recomputed by both, every other parameter belongs to one role (disjoint slab regions), and the
+// first-layer gradient, linear in dLoss/dh1 = actor part + critic part, is formed per role: the actor's in the slab's
+// first-layer region, the critic's in a fold region behind the parameters that the reduction adds onto it.
+//   PT = 32 (16 threads per row in the VALU phases, two workgroups per CU): small minibatches -- the yaml defaults give 320 rows;
+//   PT = 64 (8 threads per row, two 32-row MFMA blocks per workgroup, one workgroup per CU): half the weight stream per CU and
+//            half the gradient slabs per row -- minibatches of >= 128 32-row tiles (round 3; the CartPole headline).
+// This file replaces round 2's ppo_split.hip and round 3's ppo_pair.hip (its (4, 2, categorical) instances ARE those kernels:
+// same MFMA chains, same reduction trees per element).  The small parameters (first layer, biases, heads, log_std: <= 20 KB)
+// come straight from the flat parameter buffer into LDS, so the class needs no packed image and no mirror map of its own; only
+// the 128 -> 256 branch layer is read in MFMA B-fragment order (xrl_pack_mid_frags copy, kept current by the optimiser launch).
+// Rows: gathered per launch through idx from the rollout buffer's fields, or -- D = 4, categorical -- from the 32-byte records
+// of xrl_pack_transitions / xrl_gather_rows.
+// Reference semantics: memory_tools.py:267-287 (sample) + ppo_learner.py:46-62 (forward / loss / backward),
+// distributions.py:128-192 (Categorical / DiagGaussian log_prob, entropy), actor_head.py:14-72.
+#include "common.h"
+#include "mlp_tile.h"
+#include "ppo_math.h"
+
+namespace xrl {
+
+typedef unsigned tu32x4 __attribute__((ext_vector_type(4)));
+constexpr int TH = 128;                      // hidden width (trunk and each branch)
+constexpr int TLD = TH + 4;                  // row stride of every LDS level
+constexpr int TDMAX = 24, TXLD = 28;         // observation width limit / row stride of the gathered observations
+constexpr int TAMAX = 8;                     // head width limit
+
+template <int PT>
+struct TrunkLds {
+    // h1, h2 (xb -- dLoss/dh1 -- takes h2's place once the head gradients have been formed), g2; gathered rows; parameters
+    static constexpr int H1 = 0, H2 = H1 + PT * TLD, G2 = H2 + PT * TLD, XS = G2 + PT * TLD, RSC = XS + PT * TXLD,
+                         DZH = RSC + PT * 12, W0T = DZH + PT * 16, B0 = W0T + TDMAX * TLD, BM = B0 + TH, WH = BM + TH,
+                         BH = WH + TAMAX * TLD, LS = BH + TAMAX, SRC = LS + TAMAX, FLOATS = SRC + PT;
+    static constexpr int BYTES = FLOATS * 4 + PT * 5 * 8;
+};
+
+template <int TPR>
+__device__ __forceinline__ float trow_sum(float v) {                   // sum over the TPR (8 | 16) consecutive lanes of a row
+    if (TPR == 16) v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+// rows [r0, r0 + PT / 2) of column c of g1 times NQ2 float2 chunks of the observations: the first-layer weight gradient of one thread
+template <int NQ2, int PT>
+__device__ __forceinline__ void dw0_rows(const float* gcol, const float* xin, float (&acc)[TDMAX / 2], float& ab) {
+#pragma unroll 4
+    for (int rr = 0; rr < PT / 2; ++rr) {
+        const float g = gcol[rr * TLD];
+        ab += g;
+#pragma unroll
+        for (int q = 0; q < NQ2; ++q) {
+            const float2 x = *reinterpret_cast<const float2*>(xin + rr * TXLD + 2 * q);
+            acc[2 * q] += g * x.x; acc[2 * q + 1] += g * x.y;
+        }
+    }
+}
+
+// DS / AS: compile-time observation / head width of an instance (0 = taken from the arguments): the CartPole class (4, 2) -- the
+// headline -- gets its loops resolved at compile time
+template <int ACT, int HEAD, int PT, int DS, int AS>
+__global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_t p) {
+    using L = TrunkLds<PT>;
+    constexpr int TPR = FUSED_THREADS / PT;            // threads per row in the VALU phases: 16 | 8
+    constexpr int CPT = TH / TPR;                      // first-layer columns per thread: 8 | 16
+    constexpr int NCH = (TH / 4) / TPR;                // float4 chunks of the branch level per thread: 2 | 4
+    constexpr int RB = PT / 32;                        // 32-row MFMA blocks per workgroup: 1 | 2
+    constexpr bool GAUSS = HEAD != 0;
+    constexpr int OACT = HEAD == 2 ? XRL_ACT_TANH : XRL_ACT_NONE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* h1 = lds + L::H1;
+    float* h2 = lds + L::H2;
+    float* g2 = lds + L::G2;
+    float* xb = h2;                                    // (see TrunkLds)
+    float* xs = lds + L::XS;                           // [PT][28] gathered observations, zero beyond D
+    float* rsc = lds + L::RSC;                         // [PT][12] act[<= 8] | ret | adv | old_logp
+    float* dzh = lds + L::DZH;                         // [PT][16] dLoss/d(head pre-activations)[8] | d log_std terms[8]
+    float* w0t = lds + L::W0T;                         // [D][132] first-layer weights, k-major
+    float* b0s = lds + L::B0;
+    float* bms = lds + L::BM;                          // this role's branch bias
+    float* whs = lds + L::WH;                          // [nout][132] this role's head rows
+    float* bhs = lds + L::BH;
+    float* lss = lds + L::LS;                          // log_std
+    int* srcs = reinterpret_cast<int*>(lds + L::SRC);  // [PT] buffer row of each minibatch row
+    double* rowstat = reinterpret_cast<double*>(lds + L::FLOATS);       // [5][PT] per-row loss terms
+
+    kernarg_prefetch<sizeof(xrl_ppo_fused_t)>();
+    const int tid = threadIdx.x, M = p.M, D = DS ? DS : p.D, A = AS ? AS : p.A;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cblk = wave & 3, rblk = RB == 2 ? (wave >> 2) : 0;       // MFMA phases: 32-column block / 32-row block of this wave
+    const int tile = blockIdx.x >> 1, role = blockIdx.x & 1;
+    const bool actor = role == 0;
+    const int nout = actor ? A : 1;
+    const int cb = role * TH;                          // this role's first column of the stacked branch level
+    const int m0 = tile * PT;
+    const int r = tid / TPR, sub = tid % TPR, m_row = m0 + r;
+    const bool row_ok = m_row < M;
+    float* slab = p.slabs + (size_t)tile * p.slab_stride;
+    const xrl_fused_layer_t &L0 = p.layers[0], &L1 = p.layers[1], &La = p.layers[2], &Lc = p.layers[3];
+    const xrl_fused_layer_t& Lh = actor ? La : Lc;
+
+    long long* dbg = p.dbg;                            // diagnostics (tools/probe_pair_phases.py), see the end of the kernel
+    const bool dbg_me = dbg && tid == 0 && blockIdx.x == gridDim.x - 1;
+#define TSTAMP(k) do { if (dbg_me) dbg[k] = clock64(); } while (0)
+    if (dbg && tid == 0) dbg[16 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+    TSTAMP(0);
+
+    // ================= loads: this role's 64 KB of W1 B-fragments (waves w and w + 4 of a 64-row tile fetch the same lines), the
+    //                   small parameters, the rows
+    float4 pf[PD];
+    const bool records = !GAUSS && D == 4 && (p.f_rows || p.f_packed);
+    if (records) {                                     // 32-byte records obs[4] | act | ret | adv | old_logp: one wave
+        if (wave == 7 && lane < PT) {
+            const int m = m0 + lane;
+            float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) {
+                size_t at = (size_t)m;
+                if (!p.f_rows) {
+                    const int64_t fl = p.idx[m];
+                    const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);
+                    at = (size_t)t * p.n_envs + env;
+                }
+                const float4* rec = reinterpret_cast<const float4*>(p.f_rows ? p.f_rows : p.f_packed) + at * 2;
+                xr = rec[0]; sc = rec[1];
+            }
+            *reinterpret_cast<float4*>(xs + lane * TXLD) = xr;
+            *reinterpret_cast<float4*>(xs + lane * TXLD + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            rsc[lane * 12 + 0] = sc.x; rsc[lane * 12 + 8] = sc.y; rsc[lane * 12 + 9] = sc.z; rsc[lane * 12 + 10] = sc.w;
+        }
+    } else if (tid < PT) {                             // buffer row of each minibatch row (env-major flat index, memory_tools.py:270)
+        const int m = m0 + tid;
+        int src = -1;
+        if (m < M) {
+            const int64_t fl = p.idx[m];
+            const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);
+            src = t * p.n_envs + env;
+        }
+        srcs[tid] = src;
+    }
+    float st_mean = 0.f, st_std = 1.f;
+    if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
+    // small parameters straight from the flat buffer: W0 [128][D] -> k-major, biases, this role's head rows, log_std
+    for (int e = tid; e < TH * D; e += FUSED_THREADS) {
+        const int c = e / D, k = e - c * D;
+        w0t[k * TLD + c] = p.params[L0.w_off + e];
+    }
+    if (tid < TH) b0s[tid] = p.params[L0.b_off + tid];
+    else if (tid < 2 * TH) bms[tid - TH] = p.params[L1.b_off + cb + tid - TH];
+    else if (tid < 2 * TH + TAMAX) {
+        const int j = tid - 2 * TH;
+        bhs[j] = j < nout ? p.params[Lh.b_off + j] : 0.f;
+        lss[j] = (GAUSS && j < A) ? p.params[p.log_std_off + j] : 0.f;
+    }
+    for (int e = tid; e < nout * TH; e += FUSED_THREADS) {
+        const int j = e >> 7, k = e & (TH - 1);
+        whs[j * TLD + k] = p.params[Lh.w_off + e];
+    }
+    // (the fragment stream is requested AFTER the small loads: a wave's loads retire in order, and the first layer must not wait
+    //  for 64 KB of weights it does not read)
+    {
+        const int t = 4 * role + cblk;                                   // tile of the stacked 256-row W1
+        const float* base = p.frag_image + ((size_t)t * (TH / 8) * 64 + lane) * 4;
+#pragma unroll
+        for (int q = 0; q < PD; ++q) pf[q] = *reinterpret_cast<const float4*>(base + frag_slot(q, t, TH / 8, 1) * 256);
+    }
+    if (!records) {
+        lds_barrier();                                                                               // (srcs)
+        // observations (zero padded to 28 columns), actions, ret | adv | old_logp
+        for (int e = tid; e < PT * TXLD; e += FUSED_THREADS) {
+            const int rr = e / TXLD, k = e - rr * TXLD, src = srcs[rr];
+            xs[e] = (k < D && src >= 0) ? p.f_obs[(size_t)src * D + k] : 0.f;
+        }
+        const int na = GAUSS ? A : 1;
+        for (int e = tid; e < PT * 12; e += FUSED_THREADS) {
+            const int rr = e / 12, k = e - rr * 12, src = srcs[rr];
+            float v = 0.f;
+            if (src >= 0) {
+                if (k < na) v = p.f_act[(size_t)src * na + k];
+                else if (k == 8) v = p.f_ret[src];
+                else if (k == 9) v = p.f_adv[src];
+                else if (k == 10) v = p.f_logp[src];
+            }
+            rsc[e] = v;
+        }
+    }
+    lds_barrier();                                                                                   // #0 rows, parameters
+    TSTAMP(1);
+
+    // ================= forward: first layer on the VALU (k-ordered fma chain == the MFMA result): CPT columns per thread, walked in
+    //                   an order rotated by `sub` (one instruction's reads of the TPR threads of a row fall on different banks)
+    {
+        float acc[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+        const float* xr = xs + r * TXLD;
+        const float* wcol = w0t + sub * CPT;
+        for (int k = 0; k < D; ++k) {
+            const float x = xr[k];
+            const float* wk = wcol + k * TLD;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) acc[j] = __fmaf_rn(x, wk[(j + sub) % CPT], acc[j]);
+        }
+        float* dst = h1 + r * TLD + sub * CPT;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int cc = (j + sub) % CPT;
+            dst[cc] = act_apply_c<ACT>(acc[j] + b0s[sub * CPT + cc]);
+        }
+    }
+    lds_barrier();                                                                                   // #1 h1
+    TSTAMP(2);
+    // ---- this role's branch layer 128 -> 128 on the matrix cores: wave (cblk, rblk) owns columns [32 cblk, +32) of rows [32 rblk, +32)
+    //      (PT = 32: waves 0..3 only, as in ppo_split_kernel)
+    if (RB == 2 || wave < 4) {
+        const float* arow = h1 + (rblk * 32 + li) * TLD + 4 * lh;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+            float4 af[PD / 2];
+#pragma unroll
+            for (int q = 0; q < PD / 2; ++q) af[q] = *reinterpret_cast<const float4*>(arow + (hq * 8 + q) * 8);
+#pragma unroll
+            for (int q = 0; q < PD / 2; ++q) { MFMA4(af[q], pf[hq * 8 + q], acc) }
+        }
+        const int col = cblk * 32 + li;
+        const float bm = bms[col];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            h2[row * TLD + col] = act_apply_c<ACT>(acc[rr] + bm);
+        }
+        // forward fragments consumed: the same registers take the BACKWARD section of the fragment copy for dH1 below (output tile
+        // kt = cblk, this role's 16 n-chunks q = 16 role + i; xrl_pack_mid_frags) -- a second stream that has the head / loss /
+        // weight-gradient phases to arrive, instead of transposing the forward fragments through LDS (measured: csrc/ppo_wide.hip)
+        {
+            const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.frag_image), 0, 2 * 2 * TH * TH * 4, 0x00020000);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < PD; ++i) {
+                const int q = 16 * role + i;
+                const tu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (2 * TH * TH + (cblk * 32 + frag_slot(q, cblk, 32, 2)) * 256) * 4, 0);
+                pf[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    lds_barrier();                                                                                   // #2 h2
+    TSTAMP(3);
+
+    // ================= head forward (VALU, TPR threads per row), this role's loss terms, head backward -- in registers.
+    // k-chunks q = sub + TPR i (the 32 float4 chunks of this role's 128 columns).  After the all-reduce every thread of a row holds
+    // the row's head pre-activations; thread `sub` owns action dimension `sub` of the Gaussian loss (as in ppo_wide_kernel).
+    float4 a[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) a[i] = *reinterpret_cast<const float4*>(h2 + r * TLD + 4 * (sub + TPR * i));
+    float z[TAMAX];
+#pragma unroll
+    for (int j = 0; j < TAMAX; ++j) {
+        z[j] = 0.f;
+        if (j < nout) {
+            float c = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(whs + j * TLD + 4 * (sub + TPR * i));
+                c += a[i].x * w.x + a[i].y * w.y + a[i].z * w.z + a[i].w * w.w;
+            }
+            z[j] = trow_sum<TPR>(c) + bhs[j];
+        }
+    }
+    {
+        float dz[TAMAX], my_gls = 0.f;
+#pragma unroll
+        for (int j = 0; j < TAMAX; ++j) dz[j] = 0.f;
+        double t_s = 0.0, t_c = 0.0, t_e = 0.0, t_v = 0.0, t_n = 0.0;
+        const float invM = 1.f / (float)M;
+        if (actor) {
+            float adv = rsc[r * 12 + 9];
+            const float old_lp = rsc[r * 12 + 10];
+            asm volatile("" : "+v"(st_std));
+            if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, st_mean), st_std + 1e-8f);                   // memory_tools.py:281-282
+            const float lo = (float)(1.0 - (double)p.clip_range), hi = (float)(1.0 + (double)p.clip_range);
+            if (!GAUSS) {
+                if (row_ok) {
+                    const int act = (int)rsc[r * 12];
+                    float mx = z[0];
+#pragma unroll
+                    for (int j = 1; j < TAMAX; ++j) if (j < A) mx = fmaxf(mx, z[j]);
+                    float se = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TAMAX; ++j) if (j < A) se += expf(z[j] - mx);
+                    const float lse = mx + logf(se);
+                    float zact = z[0];
+#pragma unroll
+                    for (int j = 1; j < TAMAX; ++j) if (j == act) zact = z[j];
+                    const float logp = zact - lse;
+                    float ent = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TAMAX; ++j) if (j < A) { const float l = z[j] - lse; ent -= expf(l) * l; }
+                    const Surrogate s = surrogate(logp, old_lp, adv, lo, hi, invM);
+                    const float ce = p.ent_coef * invM;
+#pragma unroll
+                    for (int j = 0; j < TAMAX; ++j)
+                        if (j < A) { const float l = z[j] - lse, pj = expf(l); dz[j] = s.dlogp * ((j == act ? 1.f : 0.f) - pj) + ce * pj * (l + ent); }
+                    t_s = (double)fminf(s.s1, s.s2); t_n = s.clipped; t_e = ent;
+                    if (p.diag && sub == 0) {
+                        const int m = m_row;
+                        p.diag[m] = logp; p.diag[M + m] = s.ratio; p.diag[2 * (size_t)M + m] = s.s1; p.diag[3 * (size_t)M + m] = s.s2;
+                    }
+                }
+            } else {
+                // DiagGaussianDistribution (distributions.py:155-192): log_prob / entropy summed over the action dims; dim `sub`
+                const bool mine = sub < A;
+                float zmine = 0.f;
+#pragma unroll
+                for (int j = 0; j < TAMAX; ++j) if (j == sub) zmine = z[j];
+                float mu = 0.f, df = 0.f, var = 1.f, term = 0.f, entj = 0.f;
+                if (mine) {
+                    mu = act_apply_c<OACT>(zmine);                                                   // activation_action (actor_head.py:62)
+                    const float ls = lss[sub], sd = expf(ls);
+                    var = sd * sd; df = rsc[r * 12 + sub] - mu;
+                    term = -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;
+                    entj = 0.5f + LOG_SQRT_2PI + logf(sd);
+                }
+                const float logp = trow_sum<TPR>(term), ent = trow_sum<TPR>(entj);
+                float my_dz = 0.f;
+                if (row_ok) {
+                    const Surrogate s = surrogate(logp, old_lp, adv, lo, hi, invM);
+                    if (mine) {
+                        my_dz = (s.dlogp * df / var) * act_grad_c<OACT>(mu);
+                        my_gls = s.dlogp * (df * df / var - 1.f);
+                    }
+                    t_s = (double)fminf(s.s1, s.s2); t_n = s.clipped; t_e = ent;
+                    if (p.diag && sub == 0) {
+                        const int m = m_row;
+                        p.diag[m] = logp; p.diag[M + m] = s.ratio; p.diag[2 * (size_t)M + m] = s.s1; p.diag[3 * (size_t)M + m] = s.s2;
+                    }
+                }
+                if (sub < TAMAX) { dzh[r * 16 + sub] = my_dz; dzh[r * 16 + 8 + sub] = my_gls; }
+                // the row's threads sit in one wave and a wave's LDS operations execute in order: the values are there
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const float4 d0 = *reinterpret_cast<const float4*>(dzh + r * 16), d1 = *reinterpret_cast<const float4*>(dzh + r * 16 + 4);
+                dz[0] = d0.x; dz[1] = d0.y; dz[2] = d0.z; dz[3] = d0.w; dz[4] = d1.x; dz[5] = d1.y; dz[6] = d1.z; dz[7] = d1.w;
+            }
+        } else if (row_ok) {
+            const float v = z[0], dv = v - rsc[r * 12 + 8];
+            dz[0] = p.vf_coef * 2.f * dv * invM;
+            t_c = (double)dv * dv; t_v = v;
+        }
+        if (sub == 0) {
+            if (!(actor && GAUSS)) {
+#pragma unroll
+                for (int j = 0; j < TAMAX; ++j) { dzh[r * 16 + j] = dz[j]; dzh[r * 16 + 8 + j] = 0.f; }
+            }
+            rowstat[0 * PT + r] = t_s; rowstat[1 * PT + r] = t_c; rowstat[2 * PT + r] = t_e; rowstat[3 * PT + r] = t_v; rowstat[4 * PT + r] = t_n;
+        }
+        // dH2 = dZh . W_h, times act'(h2): this thread's k-chunks
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < TAMAX; ++j) {
+                if (j < nout) {
+                    const float4 w = *reinterpret_cast<const float4*>(whs + j * TLD + 4 * (sub + TPR * i));
+                    g.x += dz[j] * w.x; g.y += dz[j] * w.y; g.z += dz[j] * w.z; g.w += dz[j] * w.w;
+                }
+            }
+            g.x *= act_grad_c<ACT>(a[i].x); g.y *= act_grad_c<ACT>(a[i].y); g.z *= act_grad_c<ACT>(a[i].z); g.w *= act_grad_c<ACT>(a[i].w);
+            *reinterpret_cast<float4*>(g2 + r * TLD + 4 * (sub + TPR * i)) = g;
+        }
+    }
+    lds_barrier();                                                                                   // #3 g2, dzh, rowstat
+    TSTAMP(4);
+
+    // ================= backward
+    // ---- loss terms of this (tile, role): one lane per row; the actor fills surrogate / entropy / clip count, the critic the value
+    //      terms -- the partials reduction adds the rows of all workgroups
+    if (wave == 7) {
+        double acc_s = 0.0, acc_c = 0.0, acc_e = 0.0, acc_v = 0.0, acc_n = 0.0;
+        if (lane < PT) { acc_s = rowstat[lane]; acc_c = rowstat[PT + lane]; acc_e = rowstat[2 * PT + lane]; acc_v = rowstat[3 * PT + lane]; acc_n = rowstat[4 * PT + lane]; }
+        acc_s = wave_sum(acc_s); acc_c = wave_sum(acc_c); acc_e = wave_sum(acc_e); acc_v = wave_sum(acc_v); acc_n = wave_sum(acc_n);
+        if (lane == 0) {
+            double* q = p.partials + (size_t)blockIdx.x * 8;
+            q[0] = acc_s; q[1] = acc_c; q[2] = acc_e; q[3] = acc_v; q[4] = acc_n; q[5] = 0; q[6] = 0; q[7] = 0;
+        }
+    }
+    // ---- head weight / bias gradients, log_std gradient, this role's branch-layer bias gradient: VALU sums over the PT rows
+    for (int e = tid; e < nout * TH; e += FUSED_THREADS) {
+        const int j = e >> 7, k = e & (TH - 1);
+        const float* hp = h2 + k;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < PT; ++rr) acc += dzh[rr * 16 + j] * hp[rr * TLD];
+        slab[Lh.w_off + e] = acc;
+    }
+    if (tid >= 4 * 64 && tid < 4 * 64 + TH) {
+        const int t = tid - 4 * 64;
+        float acc0 = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < PT; ++rr) acc0 += g2[rr * TLD + t];
+        slab[L1.b_off + cb + t] = acc0;
+    } else if (tid >= 6 * 64 && tid < 6 * 64 + 2 * TAMAX) {
+        const int t = tid - 6 * 64;                                      // 0..7 head bias, 8..15 log_std
+        if (t < nout || (t >= 8 && GAUSS && actor && t - 8 < A)) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < PT; ++rr) acc += dzh[rr * 16 + t];
+            // d(-ent_coef * mean_m sum_j(log_std_j + c)) / d log_std_j = -ent_coef, added once (tile 0), as in ppo_loss.hip / ppo_wide.hip
+            if (t >= 8 && tile == 0) acc -= p.ent_coef;
+            if (t < 8) slab[Lh.b_off + t] = acc;
+            else slab[p.log_std_off + t - 8] = acc;
+        }
+    }
+    TSTAMP(5);
+    // ---- dW1[n][k] = sum over the PT rows of g2[row][n] * h1[row][k] for this role's 128 rows n: 4 x 4 tiles of 32 x 32, wave w owns
+    //      n-tile (w & 3) and the k-tiles 2 (w >> 2), 2 (w >> 2) + 1; PT / 2 chained MFMAs per tile, rows in order
+    {
+        const int nt = wave & 3, kt0 = 2 * (wave >> 2);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        const float* arow = g2 + lh * TLD + nt * 32 + li;               // A[i = n][k = row]
+        const float* brow = h1 + lh * TLD + kt0 * 32 + li;              // B[k = row][j]
+#pragma unroll 8
+        for (int s = 0; s < PT / 2; ++s) {
+            const float av = arow[2 * s * TLD];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float bv = brow[2 * s * TLD + t * 32];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+        float* dW = slab + L1.w_off + (size_t)(cb + nt * 32) * TH;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                dW[(size_t)row * TH + (kt0 + t) * 32 + li] = acc[t][rr];
+            }
+    }
+    TSTAMP(6);
+    // ---- this role's part of dH1 = g2 . W1 (sum over its 128 rows n): wave (cblk, rblk) owns output columns [32 cblk, +32) of rows
+    //      [32 rblk, +32); B operand = the backward fragments requested after the forward layer.  The result (times act'(h1)) goes
+    //      where h2 was: every wave is past its last read of h2 (head gradients above) once it is through the barrier below.
+    f32x16 dacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
+    if (RB == 2 || wave < 4) {
+        const float* arow = g2 + (rblk * 32 + li) * TLD + 4 * lh;
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+            float4 af[PD / 2];
+#pragma unroll
+            for (int i = 0; i < PD / 2; ++i) af[i] = *reinterpret_cast<const float4*>(arow + (hq * 8 + i) * 8);
+#pragma unroll
+            for (int i = 0; i < PD / 2; ++i) { MFMA4(af[i], pf[hq * 8 + i], dacc) }
+        }
+    }
+    lds_barrier();                                                                                   // #4 h2 is free
+    if (RB == 2 || wave < 4) {
+        const int k_out = cblk * 32 + li;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            xb[row * TLD + k_out] = dacc[rr] * act_grad_c<ACT>(h1[row * TLD + k_out]);
+        }
+    }
+    lds_barrier();                                                                                   // #5 g1 (this role's part)
+    TSTAMP(7);
+    // ---- first layer: dW0[c][k] = sum_rows g1[row][c] * x[row][k], db0[c] -- the actor's part into the slab's first-layer region,
+    //      the critic's into the fold region behind the parameters (the reduction adds it onto the same columns).
+    //      thread = (column c, row half lh, component range by wave >> 2): halves met by a lane shuffle; the components in float2 chunks
+    //      (the gathered observation rows are zero beyond D)
+    {
+        float* dst = actor ? slab : slab + p.l0_fold_off;
+        const int w_at = actor ? L0.w_off : 0, b_at = actor ? L0.b_off : TH * D;
+        const int kh = ((D + 3) / 4) * 2;                              // components per range, even
+        const int c = cblk * 32 + li, k0 = (wave >> 2) * kh, nk = min(kh, D - k0), nq2 = (max(nk, 0) + 1) / 2;
+        const float* gcol = xb + (lh * (PT / 2)) * TLD + c;
+        const float* xin = xs + (lh * (PT / 2)) * TXLD + k0;
+        float acc[TDMAX / 2], ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < TDMAX / 2; ++k) acc[k] = 0.f;
+        switch (nq2) {
+            case 1: dw0_rows<1, PT>(gcol, xin, acc, ab); break;
+            case 2: dw0_rows<2, PT>(gcol, xin, acc, ab); break;
+            case 3: dw0_rows<3, PT>(gcol, xin, acc, ab); break;
+            case 4: dw0_rows<4, PT>(gcol, xin, acc, ab); break;
+            case 5: dw0_rows<5, PT>(gcol, xin, acc, ab); break;
+            case 6: dw0_rows<6, PT>(gcol, xin, acc, ab); break;
+            default: dw0_rows<0, PT>(gcol, xin, acc, ab); break;      // (no components in this range: the bias sum only)
+        }
+        ab += __shfl_xor(ab, 32, 64);
+#pragma unroll
+        for (int k = 0; k < TDMAX / 2; ++k) {
+            if (k < nk) {                                                // (nk is uniform over the wave)
+                const float v = acc[k] + __shfl_xor(acc[k], 32, 64);
+                if (lh == 0) dst[w_at + c * D + k0 + k] = v;
+            }
+        }
+        if (lh == 0 && (wave >> 2) == 0) dst[b_at + c] = ab;
+    }
+    TSTAMP(8);
+    if (dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this thread's stores are out
+        dbg[17 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+#undef TSTAMP
+}
+
+// the family: widths [D, 128, 256, A + 1] with D <= 24, A <= 8, the first layer at the front of the flat layout (the fold region maps
+// onto columns [0, 128 D + 128)), the fragment copy of the branch layer present, hidden activation relu / leaky_relu / tanh
+bool ppo_trunk_eligible(const xrl_ppo_fused_t& p) {
+    if (p.n_layers != 4 || p.n_head_layers != 2 || p.n_levels != 4 || !p.frag_image || p.l0_fold_off <= 0) return false;
+    const xrl_fused_layer_t &L0 = p.layers[0], &L1 = p.layers[1], &La = p.layers[2], &Lc = p.layers[3];
+    const int D = p.D, A = p.A;
+    if (D < 1 || D > TDMAX || A < 1 || A > TAMAX) return false;
+    if (L0.K != D || L0.N != TH || L1.K != TH || L1.N != 2 * TH || La.K != TH || La.N != A || Lc.K != TH || Lc.N != 1) return false;
+    if (La.in_off != 0 || Lc.in_off != TH || L0.w_off != 0 || L0.b_off != TH * D) return false;
+    if (L0.act != L1.act || (L0.act != XRL_ACT_RELU && L0.act != XRL_ACT_LEAKY_RELU && L0.act != XRL_ACT_TANH)) return false;
+    if (p.dist != 0 && p.dist != 1) return false;
+    if (p.dist == 1 && (p.log_std_off <= 0 || (p.out_act != XRL_ACT_NONE && p.out_act != XRL_ACT_TANH))) return false;
+    if ((p.l0_fold_off & 3) || p.l0_fold_off + TH * D + TH > p.slab_stride) return false;
+    return p.pad0 == 0 || p.pad0 == 32 || p.pad0 == 64;
+}
+
+template <int ACT, int HEAD, int DS, int AS>
+static int launch_trunk_pt(const xrl_ppo_fused_t& p, hipStream_t stream) {
+    if (p.pad0 == 64) {
+        const int n_tiles = (p.M + 63) / 64;
+        hipLaunchKernelGGL((ppo_trunk_kernel<ACT, HEAD, 64, DS, AS>), dim3(2 * n_tiles), dim3(FUSED_THREADS), TrunkLds<64>::BYTES, stream, p);
+    } else {
+        const int n_tiles = (p.M + 31) / 32;
+        hipLaunchKernelGGL((ppo_trunk_kernel<ACT, HEAD, 32, DS, AS>), dim3(2 * n_tiles), dim3(FUSED_THREADS), TrunkLds<32>::BYTES, stream, p);
+    }
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+template <int ACT>
+static int launch_trunk_head(const xrl_ppo_fused_t& p, hipStream_t stream) {
+    if (p.dist == 0) return (p.D == 4 && p.A == 2) ? launch_trunk_pt<ACT, 0, 4, 2>(p, stream) : launch_trunk_pt<ACT, 0, 0, 0>(p, stream);
+    return p.out_act == XRL_ACT_TANH ? launch_trunk_pt<ACT, 2, 0, 0>(p, stream) : launch_trunk_pt<ACT, 1, 0, 0>(p, stream);
+}
+
+int launch_ppo_trunk(const xrl_ppo_fused_t& p, hipStream_t stream) {
+    switch (p.layers[0].act) {
+        case XRL_ACT_RELU: return launch_trunk_head<XRL_ACT_RELU>(p, stream);
+        case XRL_ACT_LEAKY_RELU: return launch_trunk_head<XRL_ACT_LEAKY_RELU>(p, stream);
+        default: return launch_trunk_head<XRL_ACT_TANH>(p, stream);
+    }
+}
+
+template <int ACT, int HEAD, int DS, int AS>
+static int init_trunk_one() {
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_kernel<ACT, HEAD, 32, DS, AS>), hipFuncAttributeMaxDynamicSharedMemorySize, TrunkLds<32>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_kernel<ACT, HEAD, 64, DS, AS>), hipFuncAttributeMaxDynamicSharedMemorySize, TrunkLds<64>::BYTES));
+    return XRL_OK;
+}
+
+int init_ppo_trunk() {
+#define TRUNK_INIT(a) \
+    if (int rc = init_trunk_one<a, 0, 0, 0>()) return rc; \
+    if (int rc = init_trunk_one<a, 0, 4, 2>()) return rc; \
+    if (int rc = init_trunk_one<a, 1, 0, 0>()) return rc; \
+    if (int rc = init_trunk_one<a, 2, 0, 0>()) return rc;
+    TRUNK_INIT(XRL_ACT_RELU)
+    TRUNK_INIT(XRL_ACT_LEAKY_RELU)
+    TRUNK_INIT(XRL_ACT_TANH)
+#undef TRUNK_INIT
+    return XRL_OK;
+}
+
+}  // namespace xrl

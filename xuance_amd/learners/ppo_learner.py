@@ -222,12 +222,37 @@ class PPO_Learner(Learner):
         self._last_S = pick_n_split(bs)
 
     # ------------------------------------------------------------------ fused minibatch kernel (xrl_ppo_fused_minibatch)
+    def trunk_eligible(self):
+        """The shared-trunk family of csrc/ppo_trunk.hip: D -> 128 -> {128 -> A | 128 -> 1} with D <= 24, A <= 8, a categorical or
+        Gaussian head (activation_action none / tanh), hidden activation relu / leaky_relu / tanh, the first layer at the front of
+        the flat layout -- Basic_MLP [128] + actor [128] + critic [128]: every configs/ppo/classic_control/*.yaml and the MLP ones
+        of configs/ppo/box2d/.  PPO-clip loss only (the subclasses with other losses override fused_eligible)."""
+        m, plan = self.model, self.model.plan
+        D, A = m.obs_dim, m.action_dim
+        if not getattr(self.config, "use_fused_update", True) or not ops.fast_kernels_enabled() or self.loss_mode != 0:
+            return False
+        if list(plan.widths) != [D, 128, 256, A + 1] or not (1 <= D <= 24 and 1 <= A <= 8):
+            return False
+        if m.activation not in ("relu", "leaky_relu", "tanh") or (m.dist == "gaussian" and m.activation_action not in (None, "tanh")):
+            return False
+        off = m.params.offsets
+        return off.get("representation.model.0.weight", -1) == 0 and off.get("representation.model.0.bias", -1) == 128 * D \
+            and m.params.P % 4 == 0
+
+    def cartpole_class(self):
+        """(D, A, head) = (4, 2.., categorical): the class that also has ppo_fast_kernel and the 32-byte transition records."""
+        m = self.model
+        return m.obs_dim == 4 and m.dist == "categorical"
+
     def fused_eligible(self, memory):
-        """One-launch gather+forward+loss+backward: categorical head, 4-d observations, middle layers in 32-multiples,
-        activations + gradients of a 32-row tile must fit in LDS."""
+        """One-launch gather + forward + loss + backward per minibatch: the two-branch Gaussian class (ppo_wide.hip), the
+        shared-trunk family (ppo_trunk.hip), or -- categorical head, 4-d observations, middle layers in 32-multiples, a 32-row
+        tile's activations + gradients in LDS -- the any-shape kernel (ppo_fused.hip)."""
         m, plan = self.model, self.model.plan
         if self.wide_eligible():                                   # the two-branch Gaussian class has its own kernel
             return tuple(memory.act_shape) == (m.action_dim,)
+        if self.trunk_eligible():
+            return tuple(memory.act_shape) == (() if m.dist == "categorical" else (m.action_dim,))
         if not getattr(self.config, "use_fused_update", True) or m.dist != "categorical" or m.obs_dim != 4:
             return False
         if len(plan.stages) < 2 or len(plan.stages[0]) != 1 or len(plan.widths) > 6:
@@ -240,32 +265,26 @@ class PPO_Learner(Learner):
         floats = sum(2 * 32 * ld(w) for w in plan.widths[1:]) + 8 * 32 * 33 + ops.rollout_cache_floats(plan) + 64
         return floats * 4 <= 150 * 1024 and tuple(memory.act_shape) == ()
 
-    L0_FOLD = 640        # first-layer weights (128 x 4) + bias of the 4-128-{128-2,128-1} network
-
     def split_eligible(self, n_tiles):
-        """Role-split minibatch kernel (csrc/ppo_split.hip: two workgroups per 32-row tile, one per branch): the
-        4-128-{128-2,128-1} class with the first layer at the front of the flat layout.  config.use_role_split_update:
-        "auto" (default) = for minibatches of at most 32 tiles, where the split puts a small minibatch on twice as many CUs
-        (measured: 16 tiles 29.8 vs 34.1 us per minibatch; 256 tiles 51.1 vs 47.0 us -- see the kernel's header);
-        True / False force it on / off."""
-        m, plan = self.model, self.model.plan
+        """Role-split workgroups -- (tile, branch), csrc/ppo_trunk.hip -- for this minibatch size?  The shared-trunk family; for the
+        CartPole class, which also has the single-workgroup ppo_fast_kernel: config.use_role_split_update "auto" (default) = for
+        minibatches of at most 32 tiles, where the split puts a small minibatch on twice as many CUs (measured: 16 tiles 29.8 vs
+        34.1 us per minibatch; 256 tiles of 32 rows 51.1 vs 47.0 us), or of at least 128 tiles, where 64-row tiles pay
+        (pair_eligible); True / False force it on / off.  Every other member of the family always runs role-split."""
+        if not self.trunk_eligible():
+            return False
+        if not self.cartpole_class():
+            return True
         want = getattr(self.config, "use_role_split_update", "auto")
-        want = (n_tiles <= 32) if want == "auto" else bool(want)
-        return want and list(plan.widths) == [4, 128, 256, 3] and \
-            m.dist == "categorical" and m.params.offsets.get("representation.model.0.weight", -1) == 0 and \
-            m.params.offsets.get("representation.model.0.bias", -1) == 512 and ops.fast_kernels_enabled()
+        return (n_tiles <= 32) if want == "auto" else bool(want)
 
     def pair_eligible(self, n_tiles):
-        """64-row role-split minibatch kernel (csrc/ppo_pair.hip: one workgroup per (64-row tile, branch), half the weight stream and
-        half the gradient slabs of ppo_fast_kernel for the same number of workgroups): the split kernel's network class, minibatches
-        of at least 128 32-row tiles (so that the 64-row decomposition still fills the chip's CUs), an even number of them.
-        config.use_pair_update: "auto" (default) / True / False."""
+        """64-row tiles in the role-split kernel (one workgroup per (64-row tile, branch): half the weight stream per CU and half the
+        gradient slabs for the same number of workgroups): minibatches of at least 128 32-row tiles, so that the 64-row
+        decomposition still fills the chip's CUs.  config.use_pair_update: "auto" (default) / True / False."""
         want = getattr(self.config, "use_pair_update", "auto")
         want = (n_tiles >= 128) if want == "auto" else bool(want)
-        m, plan = self.model, self.model.plan
-        return want and list(plan.widths) == [4, 128, 256, 3] and m.dist == "categorical" and \
-            m.params.offsets.get("representation.model.0.weight", -1) == 0 and \
-            m.params.offsets.get("representation.model.0.bias", -1) == 512 and ops.fast_kernels_enabled()
+        return want and self.trunk_eligible()
 
     def prepare_fused(self, memory, bs):
         if getattr(self, "_fused_bs", 0) == bs:
@@ -280,31 +299,39 @@ class PPO_Learner(Learner):
             self._fused_bs = bs
             return
         self._ensure(bs)
+        m, D = self.model, self.model.obs_dim
         self.n_tiles = (bs + 31) // 32
         self.pair = self.pair_eligible(self.n_tiles)
-        self.split = self.pair or self.split_eligible(self.n_tiles)    # (the 64-row kernel uses the role-split slab layout)
+        self.split = self.pair or self.split_eligible(self.n_tiles)    # role-split workgroups (csrc/ppo_trunk.hip)
+        self.records = self.cartpole_class()                           # 32-byte transition records (obs[4] | act | ret | adv | logp)
         # gradient slabs: one per tile; with the role-split kernel a fold region behind the parameters takes the critic
         # role's first-layer gradient, and every (tile, role) workgroup has its own row of loss partials
-        self.slab_stride = P + (self.L0_FOLD if self.split else 0)
-        self.fold = (P, self.L0_FOLD) if self.split else None
+        l0_fold = 128 * D + 128
+        self.slab_stride = P + (l0_fold if self.split else 0)
+        self.fold = (P, l0_fold) if self.split else None
         self.n_part_rows = self.n_tiles * (2 if self.split else 1)
         self.n_slabs = (bs + 63) // 64 if self.pair else self.n_tiles  # gradient slabs one minibatch launch writes
         self.fslabs = torch.zeros(self.n_tiles, self.slab_stride, device=dev)
         self.fpartials = torch.zeros(self.n_part_rows, 8, dtype=torch.float64, device=dev)
-        self.params_t = torch.zeros(P, device=dev)
-        self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
         self.stats = torch.zeros(4096, 2, device=dev)
         self.sumsq = torch.zeros(256, dtype=torch.float64, device=dev)
         self.opt_sync = torch.zeros(4 + (P + 255) // 256 + 8, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
         self._fused_bs = bs
-        self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
-        self._mirrors = [(self.map_t, self.params_t), (self.map_img, self.cache_image)]
+        self._mirrors = []
+        self.params_t = self.cache_image = None
+        if not self.split or self.cartpole_class():
+            # derived layouts of the single-workgroup kernels (ppo_fast / ppo_fused: transposed middle weights, packed small
+            # parameters); the CartPole class keeps them current too -- its agent's rollout kernels read the same image
+            self.params_t = torch.zeros(P, device=dev)
+            self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
+            self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
+            self._mirrors = [(self.map_t, self.params_t), (self.map_img, self.cache_image)]
         nf = ops.mid_frag_floats(self.model.plan)
         self.frag = torch.zeros(nf, device=dev) if nf else None       # MFMA-fragment-ordered copy of the middle layer
         if nf:
             mf, mb = ops.frag_layout_maps(self.model.plan, P, dev)  # forward section: first stream of the minibatch kernel;
             self._mirrors += [(mf, self.frag), (mb, self.frag)]     # backward section: its second one (backward-data)
-        self.packed = torch.zeros(memory.n_size * memory.n_envs * 8, device=dev)   # transition records the kernel gathers
+        self.packed = torch.zeros(memory.n_size * memory.n_envs * 8, device=dev) if self.records else None   # transition records
         self._mirror = True
 
     def prepare_rows(self, count):
@@ -317,7 +344,7 @@ class PPO_Learner(Learner):
                                 "aux_old_logp": torch.zeros(count, device=dev)}
                 self._wstage_rows = count
             return
-        if getattr(self, "rows", None) is None or self.rows.numel() != count * 8:
+        if getattr(self, "records", True) and (getattr(self, "rows", None) is None or self.rows.numel() != count * 8):
             self.rows = torch.zeros(count * 8, device=self.model.params.device)
 
     def refresh_fused_params(self, memory=None, idx_all=None):
@@ -333,7 +360,7 @@ class PPO_Learner(Learner):
                 ops.soa_gather([(st[n], f.fields[n], f.row_bytes[n]) for n in st], idx_all.view(-1), memory.n_envs, memory.n_size)
                 self._rows_idx = idx_all
             return
-        if memory is not None:
+        if memory is not None and getattr(self, "records", True):
             f = memory.soa.fields
             ops.pack_transitions(f["observations"], f["actions"], f["returns"], f["advantages"], f["aux_old_logp"],
                                  self.packed, memory.n_size * memory.n_envs)
@@ -345,8 +372,9 @@ class PPO_Learner(Learner):
                 self.prepare_rows(idx_all.numel())
                 ops.gather_rows(self.packed, idx_all, self.rows, idx_all.numel(), memory.n_envs, memory.n_size)
                 self._rows_idx = idx_all
-        ops.transpose_mid(self.model.plan, self.model.params.flat, self.params_t)
-        ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)
+        if self.params_t is not None:
+            ops.transpose_mid(self.model.plan, self.model.params.flat, self.params_t)
+            ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)
         if self.frag is not None:
             ops.pack_mid_frags(self.model.plan, self.model.params.flat, self.frag)
 
@@ -374,13 +402,16 @@ class PPO_Learner(Learner):
             if 0 <= off and off + M <= base.numel() and idx.is_contiguous():
                 rows = self.rows[off * 8:(off + M) * 8]
         pair = bool(fold) and getattr(self, "pair", False)
+        gauss = m.dist == "gaussian"
         ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=self.params_t, cache_image=self.cache_image,
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs, frag_image=self.frag,
                                 f_packed=self.packed if getattr(self, "_packed_valid", False) else None, f_rows=rows,
                                 partials=self.fpartials, diag=self.diag if self.keep_diag else None,
                                 slab_stride=self.slab_stride, l0_fold_off=fold[0] if fold else 0, M=M,
-                                n_envs=memory.n_envs, T=memory.n_size, D=4, A=m.action_dim, pad0=64 if pair else 0,
+                                n_envs=memory.n_envs, T=memory.n_size, D=m.obs_dim, A=m.action_dim, pad0=64 if pair else 0,
+                                dist=int(gauss), out_act=ops.ACT[m.activation_action] if gauss else 0,
+                                log_std_off=m.params.offsets[getattr(m, "log_std_name", "actor.log_std")] if gauss else 0,
                                 clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
         n_t = (M + 63) // 64 if pair else (M + 31) // 32             # gradient slabs (and, per role, partial rows) of this launch
         self._last_S, self._last_partials = n_t * (2 if fold else 1), self.fpartials
