@@ -106,7 +106,7 @@ def kernel_rooflines(agent):
     """Rooflines of the two kernels that make up the timed region (profiles/*.csv), timed live with HIP events on the
     launch stream: (1) xrl::rollout_persistent_kernel -- ONE launch per rollout: T vector steps + the bootstrap pass (or,
     when the persistent form is not eligible, xrl::rollout_step_fast_kernel, T + 1 launches) -- and
-    (2) xrl::ppo_fast_kernel -- one launch per minibatch -- measured over back-to-back launches on the last minibatch.
+    (2) xrl::ppo_trunk_kernel -- one launch per minibatch, (64-row tile, role) workgroups -- measured inside the real minibatch sequence.
     `achieved` = ALGORITHMIC fp32 flops of the policy network (67 328 flop forward per row, 201 984
     flop forward+backward per sample) divided by the launch time; both kernels are latency-bound at this workload."""
     from xuance_amd import ops
@@ -177,7 +177,7 @@ def kernel_rooflines(agent):
         us_mb = us_pair - us_opt
         fl_mb = 3.0 * fwd_flops_row * bs
         n_mb = nb                                          # agent.idx holds n_epochs x n_minibatch index rows
-        kname = "xrl::ppo_trunk_kernel" if lr.fold else "xrl::ppo_fast_kernel"       # (role-split family: 64-row tiles at the headline size)
+        kname = "xrl::ppo_trunk_kernel" if lr.fold else "xrl::ppo_fused_kernel"      # (role-split family: 64-row tiles at the headline size)
         r2 = {"bound": "mfma", "kernel": kname, "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
               "traffic": _pmc_traffic(kname), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_mb, 3),
@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the PPO-16-envs / QMIX-3m / eager-PyTorch lines")
-    ap.add_argument("--no-role-split", action="store_true", help="one workgroup per minibatch tile (ppo_fast_kernel) instead of two")
+    ap.add_argument("--no-role-split", action="store_true", help="the any-shape minibatch kernel (one workgroup per tile, ppo_fused_kernel) instead of the role-split family")
     ap.add_argument("--workload", choices=bw.WORKLOADS, default="c2", help="which BASELINE configuration is the main line")
     ap.add_argument("--grad-path", choices=("measure", "auto", "exchange", "captured", "cut"), default="measure",
                     help="N > 1: how the ranks average gradients; measure (default) = time every usable way, adopt the fastest")
@@ -243,7 +243,7 @@ def main():
             path, paths_ms = bw.measure_paths(args.workload, world, rank, device, n_envs, args.horizon)
         else:
             path = args.grad_path
-    extra = {"use_role_split_update": False if args.no_role_split else "auto"} if c2 else None
+    extra = {"use_role_split_update": not args.no_role_split} if c2 else None
     runner = bw.Runner(args.workload, world, rank, path, n_envs, args.horizon, extra=extra)
     agent = runner.agent
     elapsed, env_steps = bw.timed(runner, args.steps, args.warmup, world)

@@ -326,52 +326,10 @@ def test_fused_minibatch_kernel_equals_layered_path(n, T, nmb):
     assert_close(diag_fused, diag_ref, 1e-5, "log_prob/ratio/surrogates")
 
 
-@pytest.mark.parametrize("act,n,T,nmb", [("leaky_relu", 64, 64, 4), ("tanh", 50, 30, 3), ("relu", 24, 40, 2)])
-def test_specialised_minibatch_kernel_is_bit_identical_to_any_shape_kernel(act, n, T, nmb):
-    """ppo_fast_kernel (compile-time 4-128-{128-2,128-1}, one workgroup per tile) vs ppo_fused_kernel: same gradient slabs,
-    loss terms, diagnostics.  (use_role_split_update=False: the role-split kernel has its own test below.)"""
-    from xuance_amd import ops
-    from xuance_amd.agents import PPO_Agent
-    from xuance_amd.envs import DeviceCartPoleVecEnv
-    torch.manual_seed(0)
-    env = DeviceCartPoleVecEnv(n, seed=2)
-    agent = PPO_Agent(make_config(n, T, n_epochs=1, n_minibatch=nmb, activation=act, use_role_split_update=False), env)
-    agent.rollout()
-    agent._new_indices()
-    mem, lr = agent.memory, agent.learner
-    assert lr.fused_eligible(mem)
-    bs = agent.batch_size
-    lr.prepare_buffer_update(mem, bs)
-    lr.prepare_fused(mem, bs)
-    lr.refresh_fused_params()
-    ops.adv_stats(mem.soa.fields["advantages"], agent.idx.view(-1), bs, agent.idx.shape[0], n, T, lr.stats)
-    k = agent.idx.shape[0] - 1
-    res = []
-    try:
-        for fast in (False, True, True):
-            if len(res) == 2:                             # third pass: records pre-gathered for the whole phase
-                lr.refresh_fused_params(mem, agent.idx)
-            ops.set_fast_kernels(fast)
-            lr.fslabs.zero_(); lr.optimizer.grad.zero_()
-            lr.enqueue_minibatch_fused(mem, agent.idx[k], lr.stats[k], finish=False)
-            torch.cuda.synchronize()
-            n_tiles = (bs + 31) // 32
-            res.append(dict(slabs=npy(lr.fslabs.view(-1)[:n_tiles * lr.model.params.P]), grad=npy(lr.optimizer.grad),
-                            partials=npy(lr.fpartials.view(-1)[:n_tiles * 8]), diag=npy(lr.diag.view(-1)[:4 * bs])))
-    finally:
-        ops.set_fast_kernels(True)
-    a, b, c = res
-    assert lr._rows_idx is not None
-    assert np.isfinite(a["grad"]).all() and np.abs(a["grad"]).max() > 0 and (a["slabs"] != 0).mean() > 0.5
-    for key in a:
-        assert np.array_equal(a[key], b[key]), key
-        assert np.array_equal(a[key], c[key]), key + " (pre-gathered rows)"
-
-
 @pytest.mark.parametrize("act,n,T,nmb", [("leaky_relu", 64, 64, 4), ("tanh", 50, 30, 3), ("relu", 256, 256, 8)])
 def test_role_split_minibatch_kernel_vs_single_workgroup_kernel(act, n, T, nmb):
     """The role-split kernel on 32-row tiles (ppo_trunk_kernel<.., 32, 4, 2>: two workgroups per tile -- actor branch / critic branch --,
-    two per CU; round 2's ppo_split_kernel) vs ppo_fast_kernel on the same
+    two per CU) vs the any-shape single-workgroup kernel (ppo_fused_kernel, config.use_role_split_update: False) on the same
     minibatch: the per-sample diagnostics (log-prob, ratio, surrogates) and every branch / head gradient carry the SAME
     bits (same MFMA chains and reduction trees per element); the first-layer gradient -- whose two branch parts are now
     added by the slab reduction instead of in LDS -- and the loss sums agree to fp32 / fp64 re-association."""

@@ -294,7 +294,7 @@ def _chain_distance(tag, got, g, names):
 
 
 def test_update_phase_chain_vs_reference_chain():
-    """The headline's update phase -- 8 epochs x 8 minibatches of 8 192 rows through ppo_fast_kernel + xrl_reduce_adam, as ONE
+    """The headline's update phase -- 8 epochs x 8 minibatches of 8 192 rows through ppo_trunk_kernel (64-row tiles) + xrl_reduce_adam, as ONE
     captured graph -- on the data set of tests/golden/ppo_chain_c2.npz, against the 64 chained updates the REFERENCE's
     PPO_Learner made on the same minibatches (oracle/make_golden.py: golden_ppo_chain), in float32 and on model.double().
     (1) first update alone, eagerly: clipped gradient / parameter step / loss terms at the tensors' own scale (float64 twin

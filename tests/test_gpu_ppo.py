@@ -12,7 +12,7 @@ torch = pytest.importorskip("torch")
 
 
 # The one gradient tensor of the C2 fixture (8 192 rows) the engine does not hold at 1e-5 of its own scale: actor.logits.0.bias,
-# 1.26e-5 from the reference AND from its float64 twin on every path (layered, ppo_fast, any-shape).  Its 128 entries are sums
+# 1.26e-5 from the reference AND from its float64 twin on every path (layered, role-split, any-shape).  Its 128 entries are sums
 # over 8 192 rows that cancel to 0.7 % of sum|terms|; the per-row softmax terms come from expf / logf, whose sub-ulp errors are
 # one-sided and do not cancel with the signal (torch's vectorised exp is unbiased; the reference sits 1.6e-7 from its twin).
 # Every other tensor of that fixture is within 1e-5 of the float32 reference or -- the critic's, whose float32 sgemm sums are
@@ -193,13 +193,14 @@ def _load_rows(memory, b, n, T):
     f["aux_old_logp"].copy_(tm(b["old_logp"]))
 
 
-@pytest.mark.parametrize("size,n,T,kernel", [("c2", 32, 256, "fast"), ("c1", 4, 32, "split"), ("c1", 4, 32, "fast"),
+@pytest.mark.parametrize("size,n,T,kernel", [("c2", 32, 256, "split"), ("c1", 4, 32, "split"), ("c1", 4, 32, "unsplit"),
                                              ("c2", 32, 256, "any-shape"), ("c2", 32, 256, "pair"), ("c1", 4, 32, "pair")])
 def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
     """The ONE-LAUNCH minibatch kernels pinned to the reference directly, at its own sizes: the rows of the C2 (8 192) / C1
     (128) fixtures are loaded into a HipOnPolicyBuffer and go through gather -> forward -> loss -> backward (xrl_ppo_fused_minibatch:
-    ppo_fast_kernel -- 256 tiles / 256 gradient slabs at C2 --, ppo_split_kernel for <= 32 tiles, ppo_pair_kernel -- (64-row tile,
-    role) workgroups, 128 slabs at C2 --, the any-shape ppo_fused_kernel)
+    ppo_trunk_kernel with (32-row tile, role) workgroups -- "split": 512 workgroups / 256 gradient slabs at C2 -- and with (64-row
+    tile, role) workgroups -- "pair": 128 slabs at C2, the headline's kernel --, the any-shape ppo_fused_kernel with the specialised
+    kernels switched off or the role split declined -- "unsplit")
     and xrl_reduce_adam, exactly as PPO_Agent's update phase enqueues them; compared with the reference's `u*/grad` (clipped),
     its float64 twin, its parameter steps and Adam moments (reference: ppo_learner.py:46-67).  The fixture's advantages are
     already normalised (what buffer.sample hands the learner), so the launch gets no statistics."""
@@ -214,7 +215,7 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
                     gamma=0.98, use_gae=True, gae_lambda=0.95, use_advnorm=True, use_grad_clip=True, grad_clip_norm=float(gclip),
                     end_factor_lr_decay=float(ef), use_obsnorm=False, use_rewnorm=False, obsnorm_range=5, rewnorm_range=5,
                     distributed_training=False, device="cuda", model_dir="/tmp/xrl_models", use_hip_graph=False,
-                    use_role_split_update=(kernel == "split"), use_pair_update=(kernel == "pair"))
+                    use_role_split_update=(kernel in ("split", "pair")), use_pair_update=(kernel == "pair"))
     prev = ops.fast_kernels_enabled()
     ops.set_fast_kernels(kernel != "any-shape")
     try:

@@ -1,4 +1,4 @@
-"""Scratch: where a minibatch launch of the 64-row role-split kernel (ppo_trunk_kernel<.., 64>; and of ppo_fast_kernel for comparison) spends its time -- shader-clock
+"""Scratch: where a minibatch launch of the 64-row role-split kernel (ppo_trunk_kernel<.., 64>; and of the 32-row form for comparison) spends its time -- shader-clock
 stamps of the last workgroup's phases, the 100 MHz real-time counter at the start / end of every workgroup (launch skew, slowest
 workgroup, tail) and the HIP-event time of the launch alone."""
 import os, sys
@@ -41,4 +41,4 @@ for pair in (True, False):
         print("  workgroup start skew us: min %.2f max %.2f; durations us: min %.2f median %.2f max %.2f; last end %.2f"
               % (0.0, (t[:, 0] - t0).max(), (t[:, 1] - t[:, 0]).min(), np.median(t[:, 1] - t[:, 0]), (t[:, 1] - t[:, 0]).max(), (t[:, 1] - t0).max()))
     else:
-        print("fast: alone %.1f us" % us)
+        print("32-row tiles: alone %.1f us" % us)

@@ -402,9 +402,7 @@ static size_t ppo_fused_lds_bytes(const xrl_ppo_fused_t& p) {
 }  // namespace xrl
 
 namespace xrl {
-bool ppo_fast_eligible(const xrl_ppo_fused_t& p);
-int launch_ppo_fast(const xrl_ppo_fused_t& p, hipStream_t stream);
-int init_ppo_fast();
+bool g_fast_enabled_ppo = true;                      // xrl_set_fast_kernels (tests): the specialised kernel families on / off
 bool ppo_trunk_eligible(const xrl_ppo_fused_t& p);
 int launch_ppo_trunk(const xrl_ppo_fused_t& p, hipStream_t stream);
 int init_ppo_trunk();
@@ -412,7 +410,6 @@ int init_ppo_trunk();
 using namespace xrl;
 
 extern "C" int xrl_init_ppo_fused(void) {
-    if (int rc = init_ppo_fast()) return rc;
     if (int rc = init_ppo_trunk()) return rc;
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fused_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -427,7 +424,7 @@ extern "C" int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* pp, xrl_stream_t s
     XRL_CHECK_ARG(p.M > 0 && p.n_envs > 0 && p.T > 0);
     // the shared-trunk family D-128-{128-A | 128-1} (D <= 24, A <= 8, categorical | Gaussian): (tile, role) workgroups, 32- or 64-row tiles
     if (p.l0_fold_off > 0) {
-        if (!ppo_trunk_eligible(p)) { set_error("xrl_ppo_fused_minibatch: a fold region was given but the network is not of the shared-trunk family (csrc/ppo_trunk.hip)"); return XRL_EINVAL; }
+        if (!g_fast_enabled_ppo || !ppo_trunk_eligible(p)) { set_error("xrl_ppo_fused_minibatch: a fold region was given but the network is not of the shared-trunk family (csrc/ppo_trunk.hip)"); return XRL_EINVAL; }
         return launch_ppo_trunk(p, as_stream(stream));
     }
     XRL_CHECK_ARG(p.params_t && p.cache_image && (reinterpret_cast<uintptr_t>(p.cache_image) & 15) == 0);
@@ -436,7 +433,6 @@ extern "C" int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* pp, xrl_stream_t s
     XRL_CHECK_ARG(p.n_head_layers >= 1 && p.n_head_layers < p.n_layers && p.layers[0].K == 4 && p.layers[0].in_level == 0);
     XRL_CHECK_ARG(p.level_width[0] == 4 && p.level_width[p.n_levels - 1] == p.A + 1);
     for (int l = 1; l < p.n_layers - p.n_head_layers; ++l) XRL_CHECK_ARG(p.layers[l].N % 32 == 0 && p.layers[l].K % 32 == 0);
-    if (ppo_fast_eligible(p)) return launch_ppo_fast(p, as_stream(stream));        // shape-specialised twin
     const size_t lds_bytes = ppo_fused_lds_bytes(p);
     XRL_CHECK_ARG(lds_bytes <= 156 * 1024);
     const int n_tiles = (p.M + FT - 1) / FT;

@@ -266,25 +266,19 @@ class PPO_Learner(Learner):
         return floats * 4 <= 150 * 1024 and tuple(memory.act_shape) == ()
 
     def split_eligible(self, n_tiles):
-        """Role-split workgroups -- (tile, branch), csrc/ppo_trunk.hip -- for this minibatch size?  The shared-trunk family; for the
-        CartPole class, which also has the single-workgroup ppo_fast_kernel: config.use_role_split_update "auto" (default) = for
-        minibatches of at most 32 tiles, where the split puts a small minibatch on twice as many CUs (measured: 16 tiles 29.8 vs
-        34.1 us per minibatch; 256 tiles of 32 rows 51.1 vs 47.0 us), or of at least 128 tiles, where 64-row tiles pay
-        (pair_eligible); True / False force it on / off.  Every other member of the family always runs role-split."""
-        if not self.trunk_eligible():
-            return False
-        if not self.cartpole_class():
-            return True
-        want = getattr(self.config, "use_role_split_update", "auto")
-        return (n_tiles <= 32) if want == "auto" else bool(want)
+        """Role-split workgroups -- (tile, branch), csrc/ppo_trunk.hip -- for this minibatch?  Every member of the shared-trunk family,
+        at every size: round 3 measured the CartPole class against round 2's single-workgroup-per-tile kernel (ppo_fast_kernel,
+        retired): update phase 1.64 vs 2.06 ms at 16 tiles, 1.92 vs 2.23 at 64, 2.27 vs 2.53 at 128, and with 64-row tiles 2.73 vs
+        2.87 at 256 (tools/microbench_tiles.py).  config.use_role_split_update: False selects the any-shape kernel (ppo_fused.hip)."""
+        return self.trunk_eligible() and bool(getattr(self.config, "use_role_split_update", True))
 
     def pair_eligible(self, n_tiles):
         """64-row tiles in the role-split kernel (one workgroup per (64-row tile, branch): half the weight stream per CU and half the
-        gradient slabs for the same number of workgroups): minibatches of at least 128 32-row tiles, so that the 64-row
-        decomposition still fills the chip's CUs.  config.use_pair_update: "auto" (default) / True / False."""
+        gradient slabs): minibatches of at least 192 32-row tiles (measured: 128 tiles 2.40 ms with 64-row tiles vs 2.27 with 32-row
+        tiles, 256 tiles 2.73 vs 3.08).  config.use_pair_update: "auto" (default) / True / False."""
         want = getattr(self.config, "use_pair_update", "auto")
-        want = (n_tiles >= 128) if want == "auto" else bool(want)
-        return want and self.trunk_eligible()
+        want = (n_tiles >= 192) if want == "auto" else bool(want)
+        return want and self.split_eligible(n_tiles)
 
     def prepare_fused(self, memory, bs):
         if getattr(self, "_fused_bs", 0) == bs:
@@ -301,8 +295,8 @@ class PPO_Learner(Learner):
         self._ensure(bs)
         m, D = self.model, self.model.obs_dim
         self.n_tiles = (bs + 31) // 32
-        self.pair = self.pair_eligible(self.n_tiles)
-        self.split = self.pair or self.split_eligible(self.n_tiles)    # role-split workgroups (csrc/ppo_trunk.hip)
+        self.split = self.split_eligible(self.n_tiles)                 # role-split workgroups (csrc/ppo_trunk.hip)
+        self.pair = self.pair_eligible(self.n_tiles)                   # ... on 64-row tiles
         self.records = self.cartpole_class()                           # 32-byte transition records (obs[4] | act | ret | adv | logp)
         # gradient slabs: one per tile; with the role-split kernel a fold region behind the parameters takes the critic
         # role's first-layer gradient, and every (tile, role) workgroup has its own row of loss partials
