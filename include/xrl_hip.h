@@ -169,11 +169,13 @@ typedef struct {
     int32_t pad_mode;
     const float* old_a;    /* mode 3: [M][A] old logits (any normalisation) / old mu */
     const float* old_b;    /* mode 3, gaussian: [M][A] old std */
-    const double* kl_coef; /* mode 3: [1] in device memory (advanced by xrl_ppokl_adapt) */
+    const double* kl_coef; /* mode 3: [2] in device memory: [0] the coefficient (advanced by xrl_ppokl_adapt), [1] scratch of that call */
 } xrl_ppo_loss_t;
 
 /* kl_coef schedule of PPOKL_Learner.update (ppokl_learner.py:62-66): kl = sum_i partials[i][5] / count; > 1.5 target: x 2,
- * < 0.5 target: / 2, clipped to [0.1, 20]; kl_out (NULL or [1]) receives kl.  Launch after the loss of the same update. */
+ * < 0.5 target: / 2, clipped to [0.1, 20]; kl_out (NULL or [1]) receives kl.  Launch after the loss of the same update.
+ * kl_coef: [2] doubles -- [0] is advanced, [1] receives the value [0] had on entry (what this update's loss was formed with:
+ * the host logs actor-loss = -surrogate + kl_coef_used * kl from it, also at the end of a chain of captured updates). */
 int xrl_ppokl_adapt(const double* partials, int n_split, double count, double* kl_coef, double target_kl, float* kl_out,
                     xrl_stream_t stream);
 int xrl_ppo_loss_categorical(const xrl_ppo_loss_t* p, xrl_stream_t stream);

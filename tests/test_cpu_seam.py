@@ -71,6 +71,18 @@ def check_shared_storage(module, learner):
         for p in module.parameters():
             p.mul_(0.5)                                                   # an in-place edit through the module ...
     assert torch.allclose(net.state_dict()[next(iter(sd))], (ours[next(iter(sd))] + 1.0) * 0.5)   # ... lands in the flat buffer
+    # the two writers the reference itself has bump the net's version (derived weight images are rebuilt on their next use)
+    v0 = getattr(net, "version", 0)
+    module.load_state_dict(module.state_dict())
+    assert getattr(net, "version", 0) > v0
+    if hasattr(module, "copy_target"):
+        v1 = net.version
+        module.copy_target()
+        assert net.version > v1
+        tk = next(k for k in sd if k.startswith("target_"))
+        src = tk[len("target_"):] if tk[len("target_"):] in sd else None
+        if src is not None:
+            assert torch.equal(module.state_dict()[tk], module.state_dict()[src])
 
 
 def test_ppo_learner_takes_the_references_shared_actor_critic(ref):

@@ -254,4 +254,26 @@ def adopt(model, config=None, device=None, **hints):
             for name, p in module.named_parameters():
                 p.data = views[name]                      # same shape / dtype; the storage is now the flat device buffer
         net.module = module                               # what callbacks receive as `policy`
+        _hook_writes(module, net)
     return net
+
+
+def _hook_writes(module, net):
+    """The module and the engine share storage, so whatever writes parameters THROUGH the module (policy.load_state_dict -- an
+    in-place copy into the views --, policy.copy_target(), a caller's own optimiser) also changes what the engine's derived
+    weight images (the one-launch QMIX update's, the acting launches') were built from.  load_state_dict and copy_target -- the
+    two writers the reference itself has (drl_learner.py:119-121, value_factorization.py:169-174, deep_q_network.py:95-99) -- bump
+    the net's `version` (their owners rebuild on the next use); anything else must call net.touched() itself."""
+    touched = getattr(net, "touched", None)
+    if touched is None:
+        def touched():
+            net.version = getattr(net, "version", 0) + 1
+    if hasattr(module, "register_load_state_dict_post_hook"):
+        module.register_load_state_dict_post_hook(lambda m, incompatible: touched())
+    ct = getattr(module, "copy_target", None)
+    if callable(ct):
+        def copy_target(*a, **k):
+            out = ct(*a, **k)
+            touched()
+            return out
+        module.copy_target = copy_target

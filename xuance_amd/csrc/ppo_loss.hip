@@ -149,6 +149,7 @@ __global__ void ppokl_adapt_kernel(const double* __restrict__ partials, int n_sp
     for (int i = 0; i < n_split; ++i) s += partials[(size_t)i * 8 + 5];
     const float kl = (float)(s / count);
     double c = *kl_coef;
+    kl_coef[1] = c;                                   // the coefficient the loss of THIS update was formed with (host log: actor-loss)
     if (kl > (float)(target_kl * 1.5)) c = c * 2.0;
     else if (kl < (float)(target_kl * 0.5)) c = c / 2.0;
     c = c < 0.1 ? 0.1 : (c > 20.0 ? 20.0 : c);

@@ -543,7 +543,7 @@ class PPOKL_Learner(PPO_Learner):
         dev = self.model.params.device
         self.target_kl = float(config.target_kl)
         self.kl_coef = float(config.kl_coef)                      # host mirror of the device value (read back with the losses)
-        self.kl_coef_dev = torch.tensor([self.kl_coef], dtype=torch.float64, device=dev)
+        self.kl_coef_dev = torch.tensor([self.kl_coef, self.kl_coef], dtype=torch.float64, device=dev)   # [current, used by the last loss]
         self.kl_dev = torch.zeros(1, device=dev)
 
     def fused_eligible(self, memory):
@@ -577,11 +577,12 @@ class PPOKL_Learner(PPO_Learner):
         return mu, std
 
     def _info(self, M, S, partials=None):
-        used = self.kl_coef                                       # the coefficient this update's loss was formed with
         ops.sum_partials(self.partials if partials is None else partials, S, 8, self.sums)
         rb = torch.cat([self.sums, self.kl_coef_dev]).cpu().numpy()   # the one host sync of an update
         s = rb[:8]
-        self.kl_coef = float(rb[8])
+        # the coefficient the LAST update's loss was formed with comes from the device (xrl_ppokl_adapt stores it): the host
+        # mirror is stale after a chain of captured updates
+        self.kl_coef, used = float(rb[8]), float(rb[9])
         count = M * (self.model.action_dim if self.model.dist == "gaussian" else 1)
         kl = float(np.float32(s[5] / count))
         k, st = self._key, self.read_optimizer()
