@@ -888,7 +888,7 @@ def test_ppokl_agent_stores_the_old_distribution_and_adapts_its_coefficient(grap
         assert 0.1 <= coefs[-1] <= 20.0
     assert len(set(coefs)) > 1 or coefs[0] != 1.0                    # the schedule moved
     assert not torch.equal(agent.model.params.flat, p0)
-    assert float(agent.learner.kl_coef_dev.item()) == agent.learner.kl_coef
+    assert float(agent.learner.kl_coef_dev[0].item()) == agent.learner.kl_coef        # [current, used by the last loss]
 
 
 def test_ppo_agent_on_atari_shape():

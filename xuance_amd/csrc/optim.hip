@@ -12,7 +12,7 @@ constexpr int RED_THREADS = 256;
 // grad[p] = sum_s slabs[s][p]   (fixed order s = 0..S-1 -> deterministic);  block partial of sum grad^2 (fp64).
 // Each thread owns 4 consecutive parameters (one 16-byte load per slab) and keeps up to 8 slab loads in flight.
 // fold: slab columns [fold_off, fold_off + fold_len) hold a second partial of columns [0, fold_len) (the critic role's
-// first-layer gradient of ppo_split_kernel); they are added after the main columns, slab group by slab group, in the same
+// first-layer gradient of ppo_trunk_kernel); they are added after the main columns, slab group by slab group, in the same
 // fixed order.  fold_len == 0: no fold.
 __global__ void __launch_bounds__(RED_THREADS) grad_reduce_kernel(const float* __restrict__ slabs, int n_split,
                                                                   int64_t slab_stride, int64_t P,

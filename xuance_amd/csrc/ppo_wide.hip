@@ -4,7 +4,7 @@
 // gradient.  Reference semantics: memory_tools.py:267-287 (sample) + ppo_learner.py:46-62 (forward / loss / backward),
 // policies/gaussian.py + distributions.py:160-190 (DiagGaussianDistribution).
 //
-// Mapping (see ppo_fast.hip for the measurements behind the rules):
+// Mapping (DESIGN.md section 3 has the measurements behind the rules):
 //   * workgroup = (32-row tile, branch): the two branches share nothing but the rows, so a 4 096-row minibatch is
 //     128 tiles x 2 = 256 workgroups, one per CU; both roles write disjoint parameter ranges of the tile's slab row.
 //   * the 256 KB middle-layer weights arrive as a stream of B fragments (fragment-ordered copy kept current by the

@@ -240,7 +240,7 @@ class PPO_Learner(Learner):
             and m.params.P % 4 == 0
 
     def cartpole_class(self):
-        """(D, A, head) = (4, 2.., categorical): the class that also has ppo_fast_kernel and the 32-byte transition records."""
+        """(D, A, head) = (4, 2.., categorical): the class with the compile-time kernel instance and the 32-byte transition records."""
         m = self.model
         return m.obs_dim == 4 and m.dist == "categorical"
 
@@ -314,7 +314,7 @@ class PPO_Learner(Learner):
         self._mirrors = []
         self.params_t = self.cache_image = None
         if not self.split or self.cartpole_class():
-            # derived layouts of the single-workgroup kernels (ppo_fast / ppo_fused: transposed middle weights, packed small
+            # derived layouts of the single-workgroup kernel (ppo_fused: transposed middle weights, packed small
             # parameters); the CartPole class keeps them current too -- its agent's rollout kernels read the same image
             self.params_t = torch.zeros(P, device=dev)
             self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
