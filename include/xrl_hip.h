@@ -138,6 +138,51 @@ int xrl_maxpool_hw_bwd(const float* dfeat, const int32_t* argmax, const float* y
 int xrl_flatten_chw_fwd(const float* y, float* feat, int B, int P, int F, int ld_feat, xrl_stream_t stream);
 int xrl_flatten_chw_bwd(const float* dfeat, const float* y, float* dy, int B, int P, int F, int ld_dfeat, xrl_stream_t stream);
 
+/* ------------------------------------------------------------------ the same convolutions as IMPLICIT GEMMs on the fp32
+ * matrix cores (csrc/conv_mfma.hip): no column matrix in memory.  One group = one convolution-shaped product
+ *   out[b][hh*so + ph][ww*so + pw][n] = epi( sum_{th, tw, c} img[b][hh*sh + off_h + th][ww*sh + off_w + tw][c] * w[n][(th, tw, c)] )
+ * over (hh, ww) in [0, nh) x [0, nw), taps Th x Tw, out-of-image taps read as 0; epi = activation(. + bias[n]) and, when `mask`
+ * is given, times [mask[same index as out] > 0].  Three uses:
+ *   forward of Conv2d(k, s, pad p) + ReLU (cnn.py:11-50, layers.py:36-65): img = layer input (uint8: values / 255.0 as cnn.py:45,
+ *     or float32), Th = Tw = k, sh = s, off = -p, nh x nw = OH x OW, so = 1, ph = pw = 0;
+ *   gradient w.r.t. the layer input: one group per residue class (rh, rw) of (h + p, w + p) mod s -- img = dY [B][OH][OW][F],
+ *     taps = the kernel rows / columns of that class in reverse order, sh = 1, so = s, mask = the layer's input activation;
+ *   weight gradient: xrl_conv_bwd_weight below.
+ * `w` is NOT the reference tensor but an image of it in the order the matrix cores consume (a wave's 16-byte loads are
+ * contiguous): w4[((q * N/32 + nb) * 64 + lane) * 4 + s] = W'[nb*32 + lane%32][8q + 4*(lane/32) + s] with W'[n][(th, tw, c)]
+ * the reordered weight; xrl_gather_images builds the images from the flat parameters through index maps the host made once
+ * (nets.ConvStack).  Limits: C a power of two >= 4 (uint8: C == 4), N in {32, 64}, Th*Tw*C a multiple of 32, nw >= 2. */
+typedef struct {
+    const void* img;
+    const float* w;        /* fragment-ordered weight image (forward / input-gradient uses) */
+    const float* bias;     /* [N] or NULL */
+    const float* mask;     /* NULL, or [same shape as out] */
+    float* out;            /* forward / input gradient: [B][OHt][OWt][N].  weight gradient: slab 0 of dW in the REFERENCE layout
+                            * [N][C][Th][Tw] (slab s at out + s * slab_stride) */
+    const float* dy;       /* weight gradient only: dY [B][nh][nw][N] */
+    float* dbias;          /* weight gradient only: slab 0 of the bias gradient [N], or NULL */
+    int32_t B, IH, IW, C;
+    int32_t Th, Tw, nh, nw;
+    int32_t sh, off_h, off_w, so;
+    int32_t ph, pw, OHt, OWt;
+    int32_t N, act, img_u8, pad;
+} xrl_conv_t;
+/* k_split in {1, 2, 4}: waves of a workgroup that share one 32-row strip and split its reduction (4 / k_split strips per
+ * workgroup); groups of one launch share N, img_u8 and k_split (<= 8 groups). */
+int xrl_conv_fwd(const xrl_conv_t* groups, int n_groups, int k_split, xrl_stream_t stream);
+/* dW[n][c][th][tw] = sum_rows dY[row][n] * patch(row)[(th, tw, c)], dbias[n] = sum_rows dY[row][n]; rows split into n_split
+ * chunks, chunk s written to slab s (fixed order inside a chunk: four waves, then row pairs). */
+int xrl_conv_bwd_weight(const xrl_conv_t* groups, int n_groups, int n_split, int64_t slab_stride, xrl_stream_t stream);
+/* dst[j] = map[j] >= 0 ? src[map[j]] : 0 for up to 8 (src, map, dst, n) jobs in one launch: derived weight layouts from the
+ * flat parameter buffer (map: image index -> parameter index, int32 [n]). */
+typedef struct {
+    const float* src;
+    const int32_t* map;
+    float* dst;
+    int64_t n;
+} xrl_image_job_t;
+int xrl_gather_images(const xrl_image_job_t* jobs, int n_jobs, xrl_stream_t stream);
+
 /* ------------------------------------------------------------------ PPO-clip loss (ppo_learner.py:46-60,70) */
 
 typedef struct {

@@ -12,6 +12,10 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
 class Capture:
     def __init__(self):
         self.records = []
@@ -104,16 +108,19 @@ def test_qmix_learner_vs_reference_fixture(double_q, size, fused, items):
     check_updates(g, net, learner, cb, call, ("q_tot_eval", "q_tot_next", "q_tot_target"), "loss_Q")
 
 
+@pytest.mark.parametrize("implicit", [True, False])
 @pytest.mark.parametrize("name", ["dqn_cnn", "dqn_cnn_c3"])
-def test_dqn_cnn_learner_vs_reference_fixture(name):
+def test_dqn_cnn_learner_vs_reference_fixture(name, implicit):
     """BASELINE config C3 shapes: 84x84x4 uint8 frames, CNN 32/64/64 (k 8/4/3, s 4/2/1) + global max-pool + 64-512-4 head.
-    dqn_cnn: batch 4; dqn_cnn_c3: the batch of configs/dqn/atari.yaml:27 (32), where the split-K forward GEMMs and the
-    64-chunk weight-gradient slabs of the convolution layers engage."""
+    dqn_cnn: batch 4; dqn_cnn_c3: the batch of configs/dqn/atari.yaml:27 (32).  implicit: the convolutions as implicit GEMMs on
+    the matrix cores (csrc/conv_mfma.hip: forward, input gradient per residue class, weight gradient, all reading the NHWC
+    activations in place) -- the default -- or the im2col + GEMM path (csrc/conv.hip), both against the reference's updates."""
     from xuance_amd.nets import DeepQCNN
     from xuance_amd.learners import DQN_Learner
     g = load_golden(name)
     lr, gamma, sync, gclip, use_clip, total = g["cfg"]
-    net = DeepQCNN((84, 84, 4), 4)
+    net = DeepQCNN((84, 84, 4), 4, implicit_conv=implicit)
+    assert net.conv.implicit == implicit
     assert list(net.ref_order) == list(sub(g, "init").keys())
     assert sum(int(np.prod(net.params.shapes[k])) for k in net.trainable_order) == 113316      # SURVEY 8a
     net.load_state_dict(sub(g, "init"))
@@ -122,6 +129,44 @@ def test_dqn_cnn_learner_vs_reference_fixture(name):
                                    use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip)), net, cb)
     check_updates(g, net, learner, cb, lambda b: learner.update(batch_size=len(b["obs"]), **b),
                   ("evalQ", "predictQ", "targetQ"), "Qloss")
+
+
+@pytest.mark.parametrize("double_q", [False, True])
+@pytest.mark.parametrize("M,shape", [(32, (84, 84, 4)), (5, (44, 36, 4))])
+def test_implicit_gemm_convolutions_vs_im2col_path(M, shape, double_q):
+    """The three passes of an update (eval on obs, target on next_obs, eval on next_obs under double-Q) and the whole
+    backward of the convolution stack, implicit GEMMs against im2col + GEMM on the same parameters and frames: both are fp32
+    sums of the same products in different orders (1e-5 of each tensor's scale).  Odd frame sizes: every residue class of
+    the stride-2 layer's input gradient has its own extent."""
+    from xuance_amd.nets import DeepQCNN
+    torch.manual_seed(3)
+    a = DeepQCNN(shape, 6, implicit_conv=True)
+    b = DeepQCNN(shape, 6, implicit_conv=False)
+    assert a.conv.implicit and not b.conv.implicit
+    a.params.flat.copy_(torch.randn_like(a.params.flat) * 0.05)
+    a.target_flat.copy_(torch.randn_like(a.target_flat) * 0.05)
+    b.params.flat.copy_(a.params.flat); b.target_flat.copy_(a.target_flat)
+    X = torch.randint(0, 256, (3 * M, shape[0] * shape[1] * shape[2]), dtype=torch.uint8, device="cuda")
+    d = torch.randn(M, 6, device="cuda")
+    got = []
+    for net in (a, b):
+        q_e, q_t = net.forward_pair(X, M, double_q)
+        Re = 2 * M if double_q else M
+        out = {"q_eval": npy(q_e[:Re]), "q_target": npy(q_t[:M])}
+        for i, y in enumerate(net._ws.y):
+            out[f"y{i}"] = npy(y[:(Re + M) * net.conv.geo[i][6] * net.conv.geo[i][7]])
+        net.d_out[:M, :6].copy_(d)
+        slabs = torch.zeros(4, net.params.P, device="cuda")
+        net.backward(X, M, slabs, 4)
+        g = npy(slabs.sum(0))
+        for k in net.trainable_order:
+            o = net.params.offsets[k]
+            out["grad/" + k] = g[o:o + int(np.prod(net.params.shapes[k]))]
+        for i, dy in enumerate(net._ws.dy):
+            out[f"dy{i}"] = npy(dy[:M * net.conv.geo[i][6] * net.conv.geo[i][7]])
+        got.append(out)
+    for k in got[0]:
+        assert_close(got[0][k], got[1][k], 1e-5, k)
 
 
 @pytest.mark.parametrize("R,T1", [(96, 61), (5, 3), (192, 1)])

@@ -295,14 +295,15 @@ def ppo_cnn_fc_init(shape):
     return (((i * 131 + j * 7919 + 17) % 2003 - 1001).astype(np.float64) * 3e-5).astype(np.float32)
 
 
-@pytest.mark.parametrize("seam", [False, True])
-def test_ppo_cnn_learner_vs_reference_fixture(seam):
+@pytest.mark.parametrize("seam,implicit", [(False, True), (False, False), (True, True)])
+def test_ppo_cnn_learner_vs_reference_fixture(seam, implicit):
     """PPO with the convolutional actor-critic of configs/ppo/atari.yaml -- SharedActorCritic(AC_CNN_Atari, CategoricalActorHead,
     ValueHead), the network DummyOnPolicyBuffer_Atari's uint8 frame stacks train (memory_tools.py:290-328) -- through
     PPO_Learner.update on nets.ActorCriticCNN (ConvStack + xrl_flatten_chw_* + the dense plan), against the reference learner's own
     two updates on 32 frames (tests/golden/ppo_cnn_atari.npz, oracle/make_golden.py: golden_ppo_cnn): loss terms, clipped gradients
     of every tensor (the 3.3 M-entry dense weight: the stored rows), parameter steps, Adam moments.  seam: the learner is handed a
-    reference-shaped nn.Module (adapters.adopt reads the architecture off its state_dict) instead of the native container."""
+    reference-shaped nn.Module (adapters.adopt reads the architecture off its state_dict) instead of the native container.
+    implicit: convolutions as implicit GEMMs (csrc/conv_mfma.hip, the default) or im2col + GEMM (csrc/conv.hip)."""
     from xuance_amd.nets import ActorCriticCNN
     from xuance_amd.learners import REGISTRY_Learners
     g = load_golden("ppo_cnn_atari")
@@ -324,9 +325,10 @@ def test_ppo_cnn_learner_vs_reference_fixture(seam):
         net = learner.model
         assert isinstance(net, ActorCriticCNN) and learner.policy is module
     else:
-        net = ActorCriticCNN((84, 84, 4), 4)
+        net = ActorCriticCNN((84, 84, 4), 4, implicit_conv=implicit)
         net.load_state_dict(init)
         learner = REGISTRY_Learners["PPO_Learner"](cfg, net, cb)
+    assert net.conv.implicit == implicit
     assert list(net.ref_order) == names and learner.total_iters == int(total)
     assert sum(int(np.prod(net.params.shapes[k])) for k in names) == 3357861          # conv 77 984 + dense 3 277 312 + heads 2 565
     chk = EngineFixtureCheck(g, net, learner, float(lr), end_factor=float(ef), total_iters=int(total), init_extra={fc: init[fc]},

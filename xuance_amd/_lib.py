@@ -24,6 +24,18 @@ class Gemm(C.Structure):
                 ("ldc", c_int32), ("ldaux", c_int32), ("act", c_int32), ("pad", c_int32)]
 
 
+class Conv(C.Structure):
+    _fields_ = [("img", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("mask", c_void_p), ("out", c_void_p), ("dy", c_void_p),
+                ("dbias", c_void_p), ("B", c_int32), ("IH", c_int32), ("IW", c_int32), ("C", c_int32), ("Th", c_int32),
+                ("Tw", c_int32), ("nh", c_int32), ("nw", c_int32), ("sh", c_int32), ("off_h", c_int32), ("off_w", c_int32),
+                ("so", c_int32), ("ph", c_int32), ("pw", c_int32), ("OHt", c_int32), ("OWt", c_int32), ("N", c_int32),
+                ("act", c_int32), ("img_u8", c_int32), ("pad", c_int32)]
+
+
+class ImageJob(C.Structure):
+    _fields_ = [("src", c_void_p), ("map", c_void_p), ("dst", c_void_p), ("n", C.c_int64)]
+
+
 class PpoLoss(C.Structure):
     _fields_ = [("out", c_void_p), ("value", c_void_p), ("actions", c_void_p), ("adv", c_void_p), ("stats", c_void_p),
                 ("returns", c_void_p), ("old_logp", c_void_p), ("log_std", c_void_p), ("d_out", c_void_p),
@@ -323,6 +335,9 @@ _SIGS = {
     "xrl_maxpool_hw_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_maxpool_hw_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_reduce_adam_fits": [c_int64, c_int],
+    "xrl_conv_fwd": [c_void_p, c_int, c_int, c_void_p],
+    "xrl_conv_bwd_weight": [c_void_p, c_int, c_int, C.c_int64, c_void_p],
+    "xrl_gather_images": [c_void_p, c_int, c_void_p],
     "xrl_flatten_chw_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_flatten_chw_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_rollout_cartpole_persistent": [C.POINTER(RolloutPersist), c_void_p],

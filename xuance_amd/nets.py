@@ -803,21 +803,26 @@ class ConvStack:
             dev = stack.params.device
             self.rows, self.keep = rows, keep
             self.col, self.y, self.dy, self.dcol = [], [], [], []
+            self.x_in = None                                   # the frames the first layer read (its weight gradient reads them again)
             for (H, W, C, k, s, p, OH, OW, F) in stack.geo:
                 M, K = rows * OH * OW, C * k * k
-                self.col.append(torch.empty(M, K, device=dev))
                 self.y.append(torch.empty(M, F, device=dev))
                 if keep:
                     self.dy.append(torch.empty(M, F, device=dev))
+                if stack.implicit:                             # (implicit GEMMs: no column matrices)
+                    continue
+                self.col.append(torch.empty(M, K, device=dev))
+                if keep:
                     self.dcol.append(torch.empty(M, K, device=dev))
             # split-K workspaces of the forward GEMMs (layers whose row-tile count alone cannot fill the chip)
-            self.ksplit = [stack.ksplit_for(rows * OH * OW, F, C * k * k) for (H, W, C, k, s, p, OH, OW, F) in stack.geo]
+            self.ksplit = [1 if stack.implicit else stack.ksplit_for(rows * OH * OW, F, C * k * k)
+                           for (H, W, C, k, s, p, OH, OW, F) in stack.geo]
             self.skw = [torch.empty(2 * ks * rows * OH * OW * F, device=dev) if ks > 1 else None
                         for ks, (H, W, C, k, s, p, OH, OW, F) in zip(self.ksplit, stack.geo)]
             self.feat = torch.empty(rows, stack.n_feat, device=dev)
             self.arg = torch.zeros(rows, stack.geo[-1][8], dtype=torch.int32, device=dev) if (keep and not stack.flatten) else None
 
-    def __init__(self, params, conv_names, obs_shape, kernels, strides, filters, flatten=False):
+    def __init__(self, params, conv_names, obs_shape, kernels, strides, filters, flatten=False, implicit=True):
         """flatten: the stack ends in nn.Flatten() of the NCHW activation (AC_CNN_Atari, cnn.py:83-96: filters * OH * OW features
         in (c, h, w) order) instead of the global max-pool of Basic_CNN."""
         self.params, self.names, self.flatten = params, list(conv_names), bool(flatten)
@@ -830,6 +835,117 @@ class ConvStack:
             H, W, C = OH, OW, F
         self.n_feat = filters[-1] * (H * W if self.flatten else 1)
         self._ws = {}
+        self.implicit = implicit and self._implicit_eligible()
+        if self.implicit:
+            self._build_image_maps()
+
+    # ---- implicit GEMMs on the matrix cores (csrc/conv_mfma.hip) ------------------------------------------------------------
+    def _implicit_eligible(self):
+        pow2 = lambda v: v >= 4 and (v & (v - 1)) == 0
+        for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            if not (pow2(C) and F in (32, 64) and (k * k * C) % 32 == 0 and OW >= 2 and k <= 16 and s <= k):
+                return False
+            if i > 0:                                         # input-gradient products: N = C, reduction over (taps of a class, F)
+                if C not in (32, 64) or not pow2(F) or W < 2 * s:
+                    return False
+                for rh in range(s):
+                    for rw in range(s):
+                        if (-(-(k - rh) // s) * -(-(k - rw) // s) * F) % 32:
+                            return False
+        return True
+
+    @staticmethod
+    def _frag_index(N, Kp):
+        """(n, k') of every element of a fragment-ordered weight image [Kp/8][N/32][64 lanes][4] (csrc/conv_mfma.hip)."""
+        j = np.arange(N * Kp, dtype=np.int64)
+        s4, lane, rest = j % 4, (j // 4) % 64, j // 256
+        nb, q = rest % (N // 32), rest // (N // 32)
+        return nb * 32 + lane % 32, 8 * q + 4 * (lane // 32) + s4
+
+    def _build_image_maps(self):
+        """Index maps image -> flat parameter for (a) the forward weights of every layer in (th, tw, c) order and (b) the
+        input-gradient weights of layers 1.., one block per residue class (rh, rw) of (h + p, w + p) mod s with that class's
+        kernel rows / columns reversed; both in the matrix cores' fragment order.  xrl_gather_images fills the images."""
+        P = self.params
+        maps, self._fwd_off, self._dx = [], [], []
+        pos = 0
+        for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            w_off = P.offsets[self.names[i] + ".weight"]
+            n, kp = self._frag_index(F, k * k * C)
+            tap, c = kp // C, kp % C
+            maps.append(w_off + n * (C * k * k) + c * (k * k) + tap)
+            self._fwd_off.append(pos)
+            pos += F * k * k * C
+        self._n_fwd = pos
+        for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            classes = []
+            if i > 0:
+                w_off = P.offsets[self.names[i] + ".weight"]
+                for rh in range(s):
+                    for rw in range(s):
+                        Th, Tw = -(-(k - rh) // s), -(-(k - rw) // s)
+                        n, kp = self._frag_index(C, Th * Tw * F)
+                        tap, f = kp // F, kp % F
+                        kh, kw = rh + s * (Th - 1 - tap // Tw), rw + s * (Tw - 1 - tap % Tw)
+                        maps.append(w_off + f * (C * k * k) + n * (k * k) + kh * k + kw)
+                        ph, pw = (rh - p) % s, (rw - p) % s
+                        classes.append(dict(off=pos, Th=Th, Tw=Tw, ph=ph, pw=pw, nh=-(-(H - ph) // s), nw=-(-(W - pw) // s),
+                                            off_h=(ph + p - rh) // s - (Th - 1), off_w=(pw + p - rw) // s - (Tw - 1)))
+                        pos += C * Th * Tw * F
+            self._dx.append(classes)
+        self._map = torch.from_numpy(np.concatenate(maps).astype(np.int32)).to(P.device)
+        self._n_img = pos
+        self._images = {}
+
+    def images(self, flat=None, with_dx=True):
+        """(image tensor, pack job) of the parameter set `flat` (None: the stack's own)."""
+        flat = self.params.flat if flat is None else flat
+        img = self._images.get(flat.data_ptr())
+        if img is None:
+            img = self._images[flat.data_ptr()] = torch.zeros(self._n_img, device=self.params.device)
+        return img, (flat, self._map, img, self._n_img if with_dx else self._n_fwd)
+
+    @staticmethod
+    def _k_split(rows):
+        strips = (rows + 31) // 32
+        return 1 if strips >= 2048 else (2 if strips >= 768 else 4)
+
+    def _fwd_group(self, i, x, frames, img, flat, out):
+        H, W, C, k, s, p, OH, OW, F = self.geo[i]
+        return ops.conv_desc(img=x, w=img.data_ptr() + 4 * self._fwd_off[i], bias=self.params.ptr(self.names[i] + ".bias", flat),
+                             out=out, B=frames, IH=H, IW=W, C=C, Th=k, Tw=k, nh=OH, nw=OW, sh=s, off_h=-p, off_w=-p, so=1,
+                             ph=0, pw=0, OHt=OH, OWt=OW, N=F, act=ops.ACT["relu"],
+                             img_u8=int(isinstance(x, torch.Tensor) and x.dtype == torch.uint8))
+
+    def _forward_implicit(self, x, rows, ws, flat):
+        img, job = self.images(flat, with_dx=ws.keep)
+        ops.gather_images([job])
+        ws.x_in = x
+        for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            ops.conv_fwd([self._fwd_group(i, x, rows, img, flat, ws.y[i])], self._k_split(rows * OH * OW))
+            x = ws.y[i]
+
+    def _backward_implicit(self, rows, ws, cs, stride, flat):
+        """dy[-1] is set: input gradients down the stack (one launch per layer, a group per residue class), then every
+        layer's weight / bias gradient in one grouped launch into the private slab set `cs`."""
+        P = self.params
+        img, _ = self.images(flat)
+        wg = []
+        for i in reversed(range(len(self.geo))):
+            H, W, C, k, s, p, OH, OW, F = self.geo[i]
+            n = self.names[i]
+            x = ws.y[i - 1] if i > 0 else ws.x_in
+            wg.append(ops.conv_desc(img=x, dy=ws.dy[i], out=cs.data_ptr() + 4 * P.offsets[n + ".weight"],
+                                    dbias=cs.data_ptr() + 4 * P.offsets[n + ".bias"], B=rows, IH=H, IW=W, C=C, Th=k, Tw=k,
+                                    nh=OH, nw=OW, sh=s, off_h=-p, off_w=-p, so=1, OHt=OH, OWt=OW, N=F,
+                                    img_u8=int(x.dtype == torch.uint8)))
+            if i > 0:
+                groups = [ops.conv_desc(img=ws.dy[i], w=img.data_ptr() + 4 * c["off"], mask=ws.y[i - 1], out=ws.dy[i - 1], B=rows,
+                                        IH=OH, IW=OW, C=F, Th=c["Th"], Tw=c["Tw"], nh=c["nh"], nw=c["nw"], sh=1, off_h=c["off_h"],
+                                        off_w=c["off_w"], so=s, ph=c["ph"], pw=c["pw"], OHt=H, OWt=W, N=C, act=0, img_u8=0)
+                          for c in self._dx[i]]
+                ops.conv_fwd(groups, self._k_split(rows * max(c["nh"] * c["nw"] for c in self._dx[i])))
+        ops.conv_bwd_weight(wg, self.N_SPLIT_IMPLICIT, stride)
 
     @staticmethod
     def ksplit_for(M, N, K):
@@ -850,6 +966,9 @@ class ConvStack:
         """x: [rows, H*W*C] uint8 (or float32) NHWC frames -> ws.feat[:rows] (n_feat features per frame)."""
         P = self.params
         for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            if self.implicit:
+                self._forward_implicit(x, rows, ws, flat)
+                break
             M, K = rows * OH * OW, C * k * k
             ops.im2col_nhwc(x, ws.col[i], rows, H, W, C, k, s, p)
             n = self.names[i]
@@ -873,7 +992,19 @@ class ConvStack:
         ws rows: frames [0, Re) eval, [Re, Re+M) target; returns ws.feat.  Re = M (DQN) or 2M (double-Q)."""
         P = self.params
         tot = Re + M
+        if self.implicit:
+            img_e, job_e = self.images(None)
+            img_t, job_t = self.images(flat_t, with_dx=False)
+            ops.gather_images([job_e, job_t])
+            ws.x_in = x
+            xe, xt = x, x[M:]
+            for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+                ops.conv_fwd([self._fwd_group(i, xe, Re, img_e, None, ws.y[i]),
+                              self._fwd_group(i, xt, M, img_t, flat_t, ws.y[i][Re * OH * OW:])], self._k_split(Re * OH * OW))
+                xe, xt = ws.y[i], ws.y[i][Re * OH * OW:]
         for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            if self.implicit:
+                break
             K, ohw = C * k * k, OH * OW
             n = self.names[i]
             if i == 0:
@@ -896,6 +1027,7 @@ class ConvStack:
         return ws.feat
 
     N_SPLIT = 64                                              # row chunks of a conv layer's weight gradient (parallelism)
+    N_SPLIT_IMPLICIT = 16                                     # (implicit path: a workgroup's four waves split its chunk again)
 
     def backward(self, dfeat, rows, ws, slabs, n_split, flat=None):
         """dfeat [rows, n_feat] -> weight / bias gradients of every conv layer, summed into slabs[0] (the conv parameters
@@ -913,6 +1045,10 @@ class ConvStack:
             ops.flatten_chw_bwd(dfeat, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
         else:
             ops.maxpool_hw_bwd(dfeat, ws.arg, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
+        if self.implicit:
+            self._backward_implicit(rows, ws, cs, stride, flat)
+            ops.grad_reduce(cs, self.N_SPLIT_IMPLICIT, stride, p_conv, slabs[0], self._csq)
+            return
         wg = []
         for i in reversed(range(len(self.geo))):
             H, W, C, k, s, p, OH, OW, F = self.geo[i]
@@ -944,7 +1080,8 @@ class ActorCriticCNN:
     activation_action = None
 
     def __init__(self, obs_shape=(84, 84, 4), action_dim=4, kernels=(8, 4, 3), strides=(4, 2, 1), filters=(32, 64, 64),
-                 fc_hidden=(512,), actor_hidden=(), critic_hidden=(), activation="relu", device="cuda", init=True):
+                 fc_hidden=(512,), actor_hidden=(), critic_hidden=(), activation="relu", device="cuda", init=True,
+                 implicit_conv=True):
         assert activation == "relu", "the convolution kernels apply ReLU (configs/ppo/atari.yaml: activation relu)"
         ah, ch = list(actor_hidden or []), list(critic_hidden or [])
         assert len(ah) == len(ch), "actor / critic hidden stacks must have equal depth"
@@ -959,7 +1096,7 @@ class ActorCriticCNN:
             specs += [(n + ".weight", (f, C, k, k)), (n + ".bias", (f,))]
             self.conv_names.append(n)
             C = f
-        probe = ConvStack(None, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters, flatten=True)
+        probe = ConvStack(None, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters, flatten=True, implicit=False)
         feat = probe.n_feat
         self.n_flat = feat
         rep_order = [n + sfx for n in self.conv_names for sfx in (".weight", ".bias")]
@@ -1000,7 +1137,8 @@ class ActorCriticCNN:
         self.params = FlatParams(specs, device)
         self.plan = Plan(self.params, widths, stages)
         self.head_ld = action_dim + 1
-        self.conv = ConvStack(self.params, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters, flatten=True)
+        self.conv = ConvStack(self.params, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters, flatten=True,
+                              implicit=implicit_conv)
         if init:
             self.reset_parameters()
 
@@ -1049,7 +1187,7 @@ class DeepQCNN:
     parameter buffer, csrc/conv.hip), the Q head, TD target, gradient slabs, clip, Adam and target sync as everywhere."""
 
     def __init__(self, obs_shape=(84, 84, 4), n_actions=4, kernels=(8, 4, 3), strides=(4, 2, 1), filters=(32, 64, 64),
-                 q_hidden=(512,), activation="relu", device="cuda", init=True):
+                 q_hidden=(512,), activation="relu", device="cuda", init=True, implicit_conv=True):
         assert activation == "relu"
         self.obs_shape, self.n_actions, self.obs_dim = tuple(obs_shape), n_actions, int(obs_shape[0] * obs_shape[1] * obs_shape[2])
         self.kernels, self.strides, self.filters = tuple(kernels), tuple(strides), tuple(filters)
@@ -1072,7 +1210,7 @@ class DeepQCNN:
         head = [k for k in order if k.startswith("eval_Q_head.")]
         self.ref_order = rep + ["target_" + k for k in rep] + head + ["target_Q_head." + k[len("eval_Q_head."):] for k in head]
         self.trainable_order = rep + head
-        self.conv = ConvStack(self.params, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters)
+        self.conv = ConvStack(self.params, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters, implicit=implicit_conv)
         if init:
             for name in order:
                 v = self.params.view(name)

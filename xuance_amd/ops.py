@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Conv, ImageJob, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -113,6 +113,39 @@ def maxpool_hw_fwd(y, feat, argmax, B, P, F, ld_feat):
 
 def maxpool_hw_bwd(dfeat, argmax, y, dy, B, P, F, ld_dfeat):
     call("xrl_maxpool_hw_bwd", ptr(dfeat), ptr(argmax), ptr(y), ptr(dy), B, P, F, ld_dfeat, stream_ptr())
+
+
+def conv_desc(**kw):
+    """One group of xrl_conv_fwd / xrl_conv_bwd_weight (xrl_conv_t); tensors or raw addresses for the pointer fields."""
+    g = Conv()
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(g, k, v)
+    return g
+
+
+def _carr(groups):
+    arr = (Conv * len(groups))()
+    for i, g in enumerate(groups):
+        arr[i] = g
+    return arr
+
+
+def conv_fwd(groups, k_split):
+    call("xrl_conv_fwd", _carr(groups), len(groups), int(k_split), stream_ptr())
+
+
+def conv_bwd_weight(groups, n_split, slab_stride):
+    call("xrl_conv_bwd_weight", _carr(groups), len(groups), int(n_split), int(slab_stride), stream_ptr())
+
+
+def gather_images(jobs):
+    """jobs: [(src, map_int32, dst, n)]: dst[j] = src[map[j]] (map < 0: 0), all jobs in one launch."""
+    arr = (ImageJob * len(jobs))()
+    for i, (src, mp, dst, n) in enumerate(jobs):
+        arr[i].src, arr[i].map, arr[i].dst, arr[i].n = ptr(src), ptr(mp), ptr(dst), int(n)
+    call("xrl_gather_images", arr, len(jobs), stream_ptr())
 
 
 def flatten_chw_fwd(y, feat, B, P, F, ld_feat):
