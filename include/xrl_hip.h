@@ -149,9 +149,10 @@ int xrl_flatten_chw_bwd(const float* dfeat, const float* y, float* dy, int B, in
  *     taps = the kernel rows / columns of that class in reverse order, sh = 1, so = s, mask = the layer's input activation;
  *   weight gradient: xrl_conv_bwd_weight below.
  * `w` is NOT the reference tensor but an image of it in the order the matrix cores consume (a wave's 16-byte loads are
- * contiguous): w4[((q * N/32 + nb) * 64 + lane) * 4 + s] = W'[nb*32 + lane%32][8q + 4*(lane/32) + s] with W'[n][(th, tw, c)]
- * the reordered weight; xrl_gather_images builds the images from the flat parameters through index maps the host made once
- * (nets.ConvStack).  Limits: C a power of two >= 4 (uint8: C == 4), N in {32, 64}, Th*Tw*C a multiple of 32, nw >= 2. */
+ * contiguous): with W'[n][(th, tw, c)] the reordered weight and the reduction index cut into groups of 32 and sub-steps of 4,
+ *   w4[(((gq * 4 + s) * N/32 + nb) * 64 + lane) * 4 + j] = W'[nb*32 + lane%32][32 gq + 16 (lane/32) + 4 s + j];
+ * xrl_gather_images builds the images from the flat parameters through index maps the host made once (nets.ConvStack).
+ * Limits: N in {32, 64}, Th*Tw*C a multiple of 32, nw >= 2; C a power of two >= 16, or uint8 with C == 4 and Tw % 4 == 0. */
 typedef struct {
     const void* img;
     const float* w;        /* fragment-ordered weight image (forward / input-gradient uses) */
@@ -165,14 +166,20 @@ typedef struct {
     int32_t Th, Tw, nh, nw;
     int32_t sh, off_h, off_w, so;
     int32_t ph, pw, OHt, OWt;
-    int32_t N, act, img_u8, pad;
+    int32_t N, act, img_u8;
+    int32_t pad;           /* weight gradient only: this group's own number of row chunks (<= n_split; 0: n_split) -- slabs beyond
+                            * it are not written */
 } xrl_conv_t;
 /* k_split in {1, 2, 4}: waves of a workgroup that share one 32-row strip and split its reduction (4 / k_split strips per
  * workgroup); groups of one launch share N, img_u8 and k_split (<= 8 groups). */
 int xrl_conv_fwd(const xrl_conv_t* groups, int n_groups, int k_split, xrl_stream_t stream);
+/* diagnostics: the same launch writing 8 int64 time stamps per workgroup (tools/probe_conv_phases.py) */
+int xrl_conv_fwd_probe(const xrl_conv_t* groups, int n_groups, int k_split, long long* dbg, xrl_stream_t stream);
 /* dW[n][c][th][tw] = sum_rows dY[row][n] * patch(row)[(th, tw, c)], dbias[n] = sum_rows dY[row][n]; rows split into n_split
  * chunks, chunk s written to slab s (fixed order inside a chunk: four waves, then row pairs). */
 int xrl_conv_bwd_weight(const xrl_conv_t* groups, int n_groups, int n_split, int64_t slab_stride, xrl_stream_t stream);
+int xrl_conv_bwd_weight_probe(const xrl_conv_t* groups, int n_groups, int n_split, int64_t slab_stride, long long* dbg,
+                              xrl_stream_t stream);   /* diagnostics, as xrl_conv_fwd_probe (launch the groups of ONE kernel variant) */
 /* dst[j] = map[j] >= 0 ? src[map[j]] : 0 for up to 8 (src, map, dst, n) jobs in one launch: derived weight layouts from the
  * flat parameter buffer (map: image index -> parameter index, int32 [n]). */
 typedef struct {

@@ -336,7 +336,9 @@ _SIGS = {
     "xrl_maxpool_hw_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_reduce_adam_fits": [c_int64, c_int],
     "xrl_conv_fwd": [c_void_p, c_int, c_int, c_void_p],
+    "xrl_conv_fwd_probe": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrl_conv_bwd_weight": [c_void_p, c_int, c_int, C.c_int64, c_void_p],
+    "xrl_conv_bwd_weight_probe": [c_void_p, c_int, c_int, C.c_int64, c_void_p, c_void_p],
     "xrl_gather_images": [c_void_p, c_int, c_void_p],
     "xrl_flatten_chw_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_flatten_chw_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

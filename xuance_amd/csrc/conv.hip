@@ -105,7 +105,16 @@ __global__ void __launch_bounds__(256) maxpool_hw_fwd_kernel(const float* __rest
         int bi = 0x7fffffff;
         if (f < F && part < parts) {
             const float* src = y + (int64_t)b * P * F + f;
-            for (int q = part; q < P; q += parts) { const float v = src[(int64_t)q * F]; if (v > best) { best = v; bi = q; } }
+            constexpr int U = 8;                                        // 8 loads in flight per thread (the scan is latency-bound)
+            int q = part;
+            for (; q + (U - 1) * parts < P; q += U * parts) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = src[(int64_t)(q + u * parts) * F];
+#pragma unroll
+                for (int u = 0; u < U; ++u) if (v[u] > best) { best = v[u]; bi = q + u * parts; }
+            }
+            for (; q < P; q += parts) { const float v = src[(int64_t)q * F]; if (v > best) { best = v; bi = q; } }
         }
         s_v[threadIdx.x] = best; s_i[threadIdx.x] = bi;
         __syncthreads();

@@ -51,16 +51,16 @@ class DQN_Learner(Learner):
         ops.dqn_td(q_eval=q_all, q_next=q_next, q_next_eval=q_all[M:] if self.double_q else None, actions=act,
                    rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A,
                    ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)))
-        model.backward(self.X, M, self.slabs, S)
+        S_opt = model.backward(self.X, M, self.slabs, S) or S     # (convolutional nets write 32 row chunks of their own)
         P, clip = model.params.P, (self.grad_clip_norm if self.use_grad_clip else 0.0)
         if not self.needs_collective() and self._fused_optimizer_ok(self.gradient_exchange() is not None):
             # slab reduction (+ the average over the ranks, inside the launch) + norm + clip + Adam + LinearLR + periodic
             # hard target update (:50-57) in ONE launch
-            ops.reduce_adam(self.slabs, S, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
+            ops.reduce_adam(self.slabs, S_opt, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
                             self.opt_sync, target=model.target_flat, target_every=self.sync_frequency,
                             exchange=self.gradient_exchange())
             return S
-        ops.grad_reduce(self.slabs, S, P, P, opt.grad, self.sumsq)
+        ops.grad_reduce(self.slabs, S_opt, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_
             allreduce_mean_(opt.grad)

@@ -845,8 +845,10 @@ class ConvStack:
         for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
             if not (pow2(C) and F in (32, 64) and (k * k * C) % 32 == 0 and OW >= 2 and k <= 16 and s <= k):
                 return False
+            if C < 16 and not (i == 0 and C == 4 and k % 4 == 0):   # (narrow inputs: the 4 stacked uint8 frames of a pixel only)
+                return False
             if i > 0:                                         # input-gradient products: N = C, reduction over (taps of a class, F)
-                if C not in (32, 64) or not pow2(F) or W < 2 * s:
+                if C not in (32, 64) or not pow2(F) or F < 16 or W < 2 * s:
                     return False
                 for rh in range(s):
                     for rw in range(s):
@@ -856,11 +858,12 @@ class ConvStack:
 
     @staticmethod
     def _frag_index(N, Kp):
-        """(n, k') of every element of a fragment-ordered weight image [Kp/8][N/32][64 lanes][4] (csrc/conv_mfma.hip)."""
+        """(n, k') of every element of a fragment-ordered weight image [Kp/32][4][N/32][64 lanes][4] (include/xrl_hip.h:
+        xrl_conv_t.w): sub-step s of group gq feeds lane-half h the indices 32 gq + 16 h + 4 s + (0..3)."""
         j = np.arange(N * Kp, dtype=np.int64)
-        s4, lane, rest = j % 4, (j // 4) % 64, j // 256
+        j4, lane, rest = j % 4, (j // 4) % 64, j // 256
         nb, q = rest % (N // 32), rest // (N // 32)
-        return nb * 32 + lane % 32, 8 * q + 4 * (lane // 32) + s4
+        return nb * 32 + lane % 32, 32 * (q // 4) + 16 * (lane // 32) + 4 * (q % 4) + j4
 
     def _build_image_maps(self):
         """Index maps image -> flat parameter for (a) the forward weights of every layer in (th, tw, c) order and (b) the
@@ -908,7 +911,7 @@ class ConvStack:
     @staticmethod
     def _k_split(rows):
         strips = (rows + 31) // 32
-        return 1 if strips >= 2048 else (2 if strips >= 768 else 4)
+        return 1 if strips >= 2048 else (2 if strips >= 768 else (4 if strips >= 384 else 8))
 
     def _fwd_group(self, i, x, frames, img, flat, out):
         H, W, C, k, s, p, OH, OW, F = self.geo[i]
@@ -918,6 +921,9 @@ class ConvStack:
                              img_u8=int(isinstance(x, torch.Tensor) and x.dtype == torch.uint8))
 
     def _forward_implicit(self, x, rows, ws, flat):
+        if self.geo[0][2] < 16 and x.dtype != torch.uint8:
+            raise ValueError("implicit-GEMM convolutions read 4-channel frames as uint8 (the replay ring's format); build the network "
+                             "with implicit_conv=False for float32 frames")
         img, job = self.images(flat, with_dx=ws.keep)
         ops.gather_images([job])
         ws.x_in = x
@@ -925,12 +931,26 @@ class ConvStack:
             ops.conv_fwd([self._fwd_group(i, x, rows, img, flat, ws.y[i])], self._k_split(rows * OH * OW))
             x = ws.y[i]
 
+    def _dw_splits(self, rows, n_max, n_cu=256):
+        """Row chunks per layer of the weight-gradient launches.  The uint8 first layer and the float32 layers go out as two
+        launches (kernel variants), one workgroup per (32 reduction columns, chunk), 8 waves each -- one workgroup per compute
+        unit at these register counts: each launch gets as many chunks as keep its workgroups within ONE round (a 272-workgroup
+        launch ran 16 of them after the other 256 and took twice as long), and no more than leave a wave ~30 rows."""
+        tiles = [C * k * k // 32 for (H, W, C, k, s, p, OH, OW, F) in self.geo]
+        u8 = [i == 0 and self.geo[0][2] == 4 for i in range(len(self.geo))]
+        out = []
+        for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
+            same = sum(t for t, v in zip(tiles, u8) if v == u8[i])
+            n = max(1, min(n_max, n_cu // same, (rows * OH * OW) // (8 * 24)))
+            out.append(n)
+        return out
+
     def _backward_implicit(self, rows, ws, cs, stride, flat):
         """dy[-1] is set: input gradients down the stack (one launch per layer, a group per residue class), then every
         layer's weight / bias gradient in one grouped launch into the private slab set `cs`."""
         P = self.params
         img, _ = self.images(flat)
-        wg = []
+        wg, splits = [], self._dw_splits(rows, self.N_SPLIT_IMPLICIT)
         for i in reversed(range(len(self.geo))):
             H, W, C, k, s, p, OH, OW, F = self.geo[i]
             n = self.names[i]
@@ -938,14 +958,15 @@ class ConvStack:
             wg.append(ops.conv_desc(img=x, dy=ws.dy[i], out=cs.data_ptr() + 4 * P.offsets[n + ".weight"],
                                     dbias=cs.data_ptr() + 4 * P.offsets[n + ".bias"], B=rows, IH=H, IW=W, C=C, Th=k, Tw=k,
                                     nh=OH, nw=OW, sh=s, off_h=-p, off_w=-p, so=1, OHt=OH, OWt=OW, N=F,
-                                    img_u8=int(x.dtype == torch.uint8)))
+                                    img_u8=int(x.dtype == torch.uint8), pad=splits[i]))
             if i > 0:
                 groups = [ops.conv_desc(img=ws.dy[i], w=img.data_ptr() + 4 * c["off"], mask=ws.y[i - 1], out=ws.dy[i - 1], B=rows,
                                         IH=OH, IW=OW, C=F, Th=c["Th"], Tw=c["Tw"], nh=c["nh"], nw=c["nw"], sh=1, off_h=c["off_h"],
                                         off_w=c["off_w"], so=s, ph=c["ph"], pw=c["pw"], OHt=H, OWt=W, N=C, act=0, img_u8=0)
                           for c in self._dx[i]]
-                ops.conv_fwd(groups, self._k_split(rows * max(c["nh"] * c["nw"] for c in self._dx[i])))
+                ops.conv_fwd(groups, self._k_split(rows * sum(c["nh"] * c["nw"] for c in self._dx[i])))
         ops.conv_bwd_weight(wg, self.N_SPLIT_IMPLICIT, stride)
+
 
     @staticmethod
     def ksplit_for(M, N, K):
@@ -1000,7 +1021,7 @@ class ConvStack:
             xe, xt = x, x[M:]
             for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
                 ops.conv_fwd([self._fwd_group(i, xe, Re, img_e, None, ws.y[i]),
-                              self._fwd_group(i, xt, M, img_t, flat_t, ws.y[i][Re * OH * OW:])], self._k_split(Re * OH * OW))
+                              self._fwd_group(i, xt, M, img_t, flat_t, ws.y[i][Re * OH * OW:])], self._k_split((Re + M) * OH * OW))
                 xe, xt = ws.y[i], ws.y[i][Re * OH * OW:]
         for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
             if self.implicit:
@@ -1027,9 +1048,9 @@ class ConvStack:
         return ws.feat
 
     N_SPLIT = 64                                              # row chunks of a conv layer's weight gradient (parallelism)
-    N_SPLIT_IMPLICIT = 16                                     # (implicit path: a workgroup's four waves split its chunk again)
+    N_SPLIT_IMPLICIT = 32                                     # (implicit path: a workgroup's four waves split its chunk again)
 
-    def backward(self, dfeat, rows, ws, slabs, n_split, flat=None):
+    def backward(self, dfeat, rows, ws, slabs, n_split, flat=None, direct=False):
         """dfeat [rows, n_feat] -> weight / bias gradients of every conv layer, summed into slabs[0] (the conv parameters
         are the first `p_conv` floats of the layout; their regions in slabs[1:] stay zero).  The GEMM rows of a conv
         layer are B*OH*OW (14 112 for the first Atari layer at batch 32), so the weight-gradient GEMM is split over
@@ -1046,9 +1067,14 @@ class ConvStack:
         else:
             ops.maxpool_hw_bwd(dfeat, ws.arg, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
         if self.implicit:
+            if direct and slabs.shape[0] >= self.N_SPLIT_IMPLICIT:
+                # the caller's optimiser launch sums N_SPLIT_IMPLICIT slabs: the chunks go straight into the caller's slab set
+                # (no private set, no extra reduction launch)
+                self._backward_implicit(rows, ws, slabs, slabs.stride(0), flat)
+                return self.N_SPLIT_IMPLICIT
             self._backward_implicit(rows, ws, cs, stride, flat)
             ops.grad_reduce(cs, self.N_SPLIT_IMPLICIT, stride, p_conv, slabs[0], self._csq)
-            return
+            return n_split
         wg = []
         for i in reversed(range(len(self.geo))):
             H, W, C, k, s, p, OH, OW, F = self.geo[i]
@@ -1064,6 +1090,7 @@ class ConvStack:
         # data-gradient chain (the three launches took 13 + 13 + 33 us one after the other, each on a part of the chip)
         ops.linear_bwd_weight(wg, self.N_SPLIT, stride)
         ops.grad_reduce(cs, self.N_SPLIT, stride, p_conv, slabs[0], self._csq)
+        return n_split
 
 
 class ActorCriticCNN:
@@ -1263,4 +1290,7 @@ class DeepQCNN:
         if getattr(self, "_dfeat", None) is None or self._dfeat.shape[0] < M:
             self._dfeat = torch.zeros(M, self.filters[-1], device=self.params.device)
         self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat)
-        self.conv.backward(self._dfeat, M, self._ws, slabs, n_split)
+        if getattr(self, "_head_split", n_split) != n_split:      # (head rows of slabs beyond n_split must read as zero)
+            slabs.zero_()
+        self._head_split = n_split
+        return self.conv.backward(self._dfeat, M, self._ws, slabs, n_split, direct=True)   # number of slabs to sum

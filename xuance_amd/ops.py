@@ -132,12 +132,18 @@ def _carr(groups):
     return arr
 
 
-def conv_fwd(groups, k_split):
-    call("xrl_conv_fwd", _carr(groups), len(groups), int(k_split), stream_ptr())
+def conv_fwd(groups, k_split, dbg=None):
+    if dbg is not None:
+        call("xrl_conv_fwd_probe", _carr(groups), len(groups), int(k_split), ptr(dbg), stream_ptr())
+    else:
+        call("xrl_conv_fwd", _carr(groups), len(groups), int(k_split), stream_ptr())
 
 
-def conv_bwd_weight(groups, n_split, slab_stride):
-    call("xrl_conv_bwd_weight", _carr(groups), len(groups), int(n_split), int(slab_stride), stream_ptr())
+def conv_bwd_weight(groups, n_split, slab_stride, dbg=None):
+    if dbg is not None:
+        call("xrl_conv_bwd_weight_probe", _carr(groups), len(groups), int(n_split), int(slab_stride), ptr(dbg), stream_ptr())
+    else:
+        call("xrl_conv_bwd_weight", _carr(groups), len(groups), int(n_split), int(slab_stride), stream_ptr())
 
 
 def gather_images(jobs):
