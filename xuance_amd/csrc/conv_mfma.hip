@@ -46,6 +46,8 @@ struct ConvStage {            // operands of ONE group of 32 reduction indices (
     float4 b[4][NB];
 };
 
+// (the wave index goes through readfirstlane everywhere in this file: what is derived from it -- the wave's reduction range, hence
+// the scalar offset of its weight loads -- is then uniform for the compiler too; without it every such load sat in a waterfall loop)
 // KS waves share one 32-row strip and split its reduction; a workgroup has 4 (KS <= 4) or 8 waves = 4 / KS or 1 strips.
 template <int NB, bool U8, int KS, int D>
 __global__ void __launch_bounds__(KS == 8 ? 512 : 256) conv_mfma_kernel(ConvBatch p) {
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(KS == 8 ? 512 : 256) conv_mfma_kernel(ConvBatc
     const xrl_conv_t& g = p.g[blockIdx.y];
     const int M = g.B * g.nh * g.nw, strips = (M + 31) >> 5;
     if ((int)blockIdx.x * RS >= strips) return;                          // (uniform: the grid is sized for the largest group)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const int strip = blockIdx.x * RS + wave / KS, kpart = wave % KS;
     long long* dbg = p.dbg ? p.dbg + 8 * (blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
     const bool dbg_me = dbg && threadIdx.x == 0;
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(512) conv_dw_mfma_kernel(ConvBatch p) {
     const int C = g.C, lc = 31 - __clz(C), Tw = g.Tw, kk = g.Th * Tw, Kp = kk * C;
     const int ktile = blockIdx.x, split = blockIdx.y;
     if (ktile * 32 >= Kp) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     if (U8 && threadIdx.x < 256) s_tab[threadIdx.x] = (float)threadIdx.x / 255.0f;
     long long* dbg = p.dbg ? p.dbg + 8 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) : nullptr;
     const bool dbg_me = dbg && threadIdx.x == 0;
