@@ -31,60 +31,71 @@ struct GemmBatch {
 enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
 
 // ---- global -> register staging -------------------------------------------------------------------
+// Operands are read with BUFFER loads whose offset is out of range for a row / column outside the matrix: the hardware
+// returns 0 and fetches nothing, and -- the point -- every load is unconditional.  (The first version guarded its loads with
+// branches (row < R, vector or scalar path, `if (next slab exists)`); the compiler cannot count the loads in flight across such
+// branches and put s_waitcnt vmcnt(0) in front of every slab: the three-slot register ring below never had more than one slab
+// in flight.  Found with the convolution kernels of csrc/conv_mfma.hip, same cause.)
+typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned GEMM_OOB = 0x7fffff00u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const float* base, int rows, int ld, int cols) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (unsigned)(((rows - 1) * ld + cols) * 4), 0x00020000);
+}
+__device__ __forceinline__ float4 as_f4(gu32x4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // k-contiguous operand: tile rows r0..r0+63 (bounded by R), k range k0..k0+31 (bounded by K); row-major, ld.
-// thread t loads 2 float4: rows (t>>3) and (t>>3)+32, k offset (t&7)*4.
-__device__ __forceinline__ void load_kcontig(const float* __restrict__ P, int ld, int R, int K, int r0, int k0,
-                                             float4 (&reg)[2]) {
+// thread t loads 2 float4: rows (t>>3) and (t>>3)+32, k offset (t&7)*4.  VEC: ld, K multiples of 4 and a 16-byte aligned base
+// (one 16-byte load per quad; K % 4 == 0 makes every quad all-in or all-out); otherwise four 4-byte loads.
+template <bool VEC>
+__device__ __forceinline__ void load_kcontig(__amdgpu_buffer_rsrc_t rs, int ld, int R, int K, int r0, int k0, float4 (&reg)[2]) {
     const int t = threadIdx.x;
     const int kk = k0 + (t & 7) * 4;
-    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = r0 + (t >> 3) + 32 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R) {
-            const float* p = P + (size_t)r * ld + kk;
-            if (vec && kk + 3 < K) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                if (kk + 0 < K) v.x = p[0];
-                if (kk + 1 < K) v.y = p[1];
-                if (kk + 2 < K) v.z = p[2];
-                if (kk + 3 < K) v.w = p[3];
-            }
+        const unsigned base = (__umul24(r, ld) + kk) << 2;
+        if (VEC) {
+            reg[i] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, (r < R && kk < K) ? base : GEMM_OOB, 0, 0));
+        } else {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                e[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (r < R && kk + j < K) ? base + 4 * j : GEMM_OOB, 0, 0));
+            reg[i] = make_float4(e[0], e[1], e[2], e[3]);
         }
-        reg[i] = v;
     }
 }
 
 // k-major operand: tile k rows k0..k0+31 (bounded by Kr), columns c0..c0+63 (bounded by C); row-major, ld.
 // `ones_col`: column index that reads as 1.0 for valid rows (bias-gradient trick of the TN mode), or -1.
 // thread t loads 2 float4: k rows (t>>4) and (t>>4)+16, column offset (t&15)*4.
-__device__ __forceinline__ void load_kmajor(const float* __restrict__ P, int ld, int Kr, int C, int k0, int c0,
-                                            int ones_col, float4 (&reg)[2]) {
+template <bool VEC>
+__device__ __forceinline__ void load_kmajor(__amdgpu_buffer_rsrc_t rs, int ld, int Kr, int C, int k0, int c0, int ones_col,
+                                            float4 (&reg)[2]) {
     const int t = threadIdx.x;
     const int cc = c0 + (t & 15) * 4;
-    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int k = k0 + (t >> 4) + 16 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < Kr) {
-            const float* p = P + (size_t)k * ld + cc;
-            if (vec && cc + 3 < C) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                if (cc + 0 < C) v.x = p[0];
-                if (cc + 1 < C) v.y = p[1];
-                if (cc + 2 < C) v.z = p[2];
-                if (cc + 3 < C) v.w = p[3];
-            }
-            if (ones_col >= 0) {
-                if (cc + 0 == ones_col) v.x = 1.f;
-                if (cc + 1 == ones_col) v.y = 1.f;
-                if (cc + 2 == ones_col) v.z = 1.f;
-                if (cc + 3 == ones_col) v.w = 1.f;
-            }
+        const unsigned base = (__umul24(k, ld) + cc) << 2;
+        float4 v;
+        if (VEC) {
+            v = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, (k < Kr && cc < C) ? base : GEMM_OOB, 0, 0));
+        } else {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                e[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (k < Kr && cc + j < C) ? base + 4 * j : GEMM_OOB, 0, 0));
+            v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        if (ones_col >= 0) {
+            const bool kv = k < Kr;
+            if (kv && cc + 0 == ones_col) v.x = 1.f;
+            if (kv && cc + 1 == ones_col) v.y = 1.f;
+            if (kv && cc + 2 == ones_col) v.z = 1.f;
+            if (kv && cc + 3 == ones_col) v.w = 1.f;
         }
         reg[i] = v;
     }
@@ -103,7 +114,7 @@ __device__ __forceinline__ void stage_kmajor(float* S, const float4 (&reg)[2]) {
         *reinterpret_cast<float4*>(&S[((t >> 4) + 16 * i) * LDR + (t & 15) * 4]) = reg[i];
 }
 
-template <int MODE>
+template <int MODE, bool VA, bool VB>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     __shared__ __attribute__((aligned(16))) float sA[64 * LDK > 32 * LDR ? 64 * LDK : 32 * LDR];
     __shared__ __attribute__((aligned(16))) float sB[64 * LDK > 32 * LDR ? 64 * LDK : 32 * LDR];
@@ -154,28 +165,33 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     // With a single slab in flight every iteration waited out most of a global round trip (measured ~2 us per 32-wide
     // slab on the [3200..5856] x [64..256] x [256..576] layers of the CNN / recurrent / MuJoCo-shaped networks).
     float4 ra[3][2], rb[3][2];
+    __amdgpu_buffer_rsrc_t rsa, rsb;
+    if (MODE == MODE_NT) { rsa = gemm_rsrc(g.A, g.M, g.lda, g.K); rsb = gemm_rsrc(g.B, g.N, g.ldb, g.K); }
+    else if (MODE == MODE_NN) { rsa = gemm_rsrc(g.A, g.M, g.lda, g.K); rsb = gemm_rsrc(g.B, g.K, g.ldb, g.N); }
+    else { rsa = gemm_rsrc(g.A, g.M, g.lda, g.N); rsb = gemm_rsrc(g.B, g.M, g.ldb, g.K); }
+    // (reduction indices >= kend are out of range for the loaders: a slab past the end costs its load instructions, no traffic)
     auto load_tiles = [&](int k0, float4 (&qa)[2], float4 (&qb)[2]) {
         if (MODE == MODE_NT) {
-            load_kcontig(g.A, g.lda, g.M, g.K, m0, k0, qa);
-            load_kcontig(g.B, g.ldb, g.N, g.K, n0, k0, qb);
+            load_kcontig<VA>(rsa, g.lda, g.M, kend, m0, k0, qa);
+            load_kcontig<VB>(rsb, g.ldb, g.N, kend, n0, k0, qb);
         } else if (MODE == MODE_NN) {
-            load_kcontig(g.A, g.lda, g.M, g.K, m0, k0, qa);
-            load_kmajor(g.B, g.ldb, g.K, g.N, k0, n0, -1, qb);
+            load_kcontig<VA>(rsa, g.lda, g.M, kend, m0, k0, qa);
+            load_kmajor<VB>(rsb, g.ldb, kend, g.N, k0, n0, -1, qb);
         } else {
-            load_kmajor(g.A, g.lda, kend, g.N, k0, m0, -1, qa);                       // dY[m, n']
-            load_kmajor(g.B, g.ldb, kend, g.K, k0, n0, g.dbias ? g.K : -1, qb);      // X[m, k'] (+ ones column)
+            load_kmajor<VA>(rsa, g.lda, kend, g.N, k0, m0, -1, qa);                       // dY[m, n']
+            load_kmajor<VB>(rsb, g.ldb, kend, g.K, k0, n0, g.dbias ? g.K : -1, qb);      // X[m, k'] (+ ones column)
         }
     };
 
-    if (kbeg < kend) load_tiles(kbeg, ra[0], rb[0]);
-    if (kbeg + BK < kend) load_tiles(kbeg + BK, ra[1], rb[1]);
+    load_tiles(kbeg, ra[0], rb[0]);
+    load_tiles(kbeg + BK, ra[1], rb[1]);
     int k0 = kbeg;
 #define GEMM_SLAB_STEP(CUR, NXT)                                                                                         \
     {                                                                                                                    \
         if (MODE == MODE_TN) stage_kmajor(sA, ra[CUR]); else stage_kcontig(sA, ra[CUR]);                                 \
         if (MODE == MODE_NT) stage_kcontig(sB, rb[CUR]); else stage_kmajor(sB, rb[CUR]);                                 \
         lds_barrier();                             /* LDS-only: __syncthreads() would also drain the prefetches */       \
-        if (k0 + 2 * BK < kend) load_tiles(k0 + 2 * BK, ra[NXT], rb[NXT]);                                               \
+        load_tiles(k0 + 2 * BK, ra[NXT], rb[NXT]);                                                                       \
         if (wave_live) {                                                                                                 \
             _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                                         \
                 float a4[4], b4[4];                                                                                      \
@@ -450,17 +466,37 @@ static int launch(int mode, const xrl_gemm_t* groups, int n_groups, int n_split,
                 max_el = el > max_el ? el : max_el;
             }
     dim3 grid(max_tiles, mode == MODE_TN ? n_split : ksplit, n_groups);
+    // 16-byte operand loads need quads that are entirely inside or outside the matrix: leading dimension and the extent along
+    // the contiguous direction multiples of 4, base 16-byte aligned -- for every group of the launch (else 4-byte loads)
+    bool va = true, vb = true;
+    for (int i = 0; i < n_groups; ++i) {
+        const xrl_gemm_t& g = groups[i];
+        const int ea = mode == MODE_TN ? g.N : g.K, eb = mode == MODE_NT ? g.K : (mode == MODE_NN ? g.N : g.K);
+        const int rows_a = g.M, rows_b = mode == MODE_NT ? g.N : (mode == MODE_NN ? g.K : g.M);
+        va = va && (g.lda % 4 == 0) && (ea % 4 == 0) && (reinterpret_cast<uintptr_t>(g.A) % 16 == 0);
+        vb = vb && (g.ldb % 4 == 0) && (eb % 4 == 0) && (reinterpret_cast<uintptr_t>(g.B) % 16 == 0);
+        XRL_CHECK_ARG((int64_t)rows_a * g.lda * 4 < ((int64_t)1 << 31) && (int64_t)rows_b * g.ldb * 4 < ((int64_t)1 << 31));
+        XRL_CHECK_ARG(g.lda < (1 << 24) && g.ldb < (1 << 24) && rows_a < (1 << 24) && rows_b < (1 << 24));
+    }
+#define GEMM_LAUNCH(M_)                                                                                                  \
+    {                                                                                                                    \
+        if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<M_, true, true>), grid, 256, 0, as_stream(stream), b);          \
+        else if (va) hipLaunchKernelGGL((gemm_f32_kernel<M_, true, false>), grid, 256, 0, as_stream(stream), b);          \
+        else if (vb) hipLaunchKernelGGL((gemm_f32_kernel<M_, false, true>), grid, 256, 0, as_stream(stream), b);          \
+        else hipLaunchKernelGGL((gemm_f32_kernel<M_, false, false>), grid, 256, 0, as_stream(stream), b);                 \
+    }
     if (mode == MODE_NT && ksplit > 1) {
-        hipLaunchKernelGGL(gemm_f32_kernel<MODE_NT>, grid, 256, 0, as_stream(stream), b);
+        GEMM_LAUNCH(MODE_NT)
         unsigned nb = (unsigned)((max_el + 255) / 256);
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(nb, n_groups), dim3(256), 0, as_stream(stream), b);
         XRL_CHECK_LAUNCH();
         return XRL_OK;
     }
-    if (mode == MODE_NT) hipLaunchKernelGGL(gemm_f32_kernel<MODE_NT>, grid, 256, 0, as_stream(stream), b);
-    else if (mode == MODE_NN) hipLaunchKernelGGL(gemm_f32_kernel<MODE_NN>, grid, 256, 0, as_stream(stream), b);
-    else hipLaunchKernelGGL(gemm_f32_kernel<MODE_TN>, grid, 256, 0, as_stream(stream), b);
+    if (mode == MODE_NT) GEMM_LAUNCH(MODE_NT)
+    else if (mode == MODE_NN) GEMM_LAUNCH(MODE_NN)
+    else GEMM_LAUNCH(MODE_TN)
+#undef GEMM_LAUNCH
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
