@@ -97,12 +97,15 @@ def qmix_3m(rnn, n=64, steps=None, ref=None):
     agent.train(60 if rnn else 20)
     torch.cuda.synchronize()
     s0, t0 = agent.current_step, time.perf_counter()
-    agent.train(steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    while True:                                     # at least half a second of loop (a 13 ms window does not carry three digits)
+        agent.train(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dt >= 0.5:
+            break
     env_steps = agent.current_step - s0
     lr = agent.learner
-    graph_us = _events_us(lr._buf_graph.launch, 20)
+    graph_us = _events_us(lr._buf_graph.launch, 200)
     upd_us = graph_us / 8
     B, N, T = 32, 3, 60
     if rnn:

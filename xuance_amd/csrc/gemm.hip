@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
         if (MODE == MODE_NT) stage_kcontig(sB, rb[CUR]); else stage_kmajor(sB, rb[CUR]);                                 \
         lds_barrier();                             /* LDS-only: __syncthreads() would also drain the prefetches */       \
         load_tiles(k0 + 2 * BK, ra[NXT], rb[NXT]);                                                                       \
-        if (wave_live) {                                                                                                 \
+        if (wave_live && k0 < kend) {              /* (a step past the end: staged zeros, no products) */                \
             _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                                         \
                 float a4[4], b4[4];                                                                                      \
                 if (MODE == MODE_TN) {                                                                                   \
@@ -213,14 +213,14 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
         }                                                                                                                \
         lds_barrier();                             /* slab consumed; the next two are still on their way */              \
         k0 += BK;                                                                                                        \
-        if (k0 >= kend) break;                                                                                           \
     }
-    if (kbeg < kend)
-        for (;;) {
-            GEMM_SLAB_STEP(0, 2)
-            GEMM_SLAB_STEP(1, 0)
-            GEMM_SLAB_STEP(2, 1)
-        }
+    /* three steps per trip and ONE exit test: with an exit after every step the loop head is reached from three places, each
+     * with different loads in flight, and the compiler falls back to waiting for all of them there */
+    while (k0 < kend) {
+        GEMM_SLAB_STEP(0, 2)
+        GEMM_SLAB_STEP(1, 0)
+        GEMM_SLAB_STEP(2, 1)
+    }
 #undef GEMM_SLAB_STEP
 
     if (!wave_live) return;
