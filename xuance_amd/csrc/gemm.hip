@@ -184,15 +184,13 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
     };
 
     load_tiles(kbeg, ra[0], rb[0]);
-    load_tiles(kbeg + BK, ra[1], rb[1]);
     int k0 = kbeg;
-#define GEMM_SLAB_STEP(CUR, NXT)                                                                                         \
+#define GEMM_SLAB_STEP(CUR, KC)                                                                                          \
     {                                                                                                                    \
         if (MODE == MODE_TN) stage_kmajor(sA, ra[CUR]); else stage_kcontig(sA, ra[CUR]);                                 \
         if (MODE == MODE_NT) stage_kcontig(sB, rb[CUR]); else stage_kmajor(sB, rb[CUR]);                                 \
         lds_barrier();                             /* LDS-only: __syncthreads() would also drain the prefetches */       \
-        load_tiles(k0 + 2 * BK, ra[NXT], rb[NXT]);                                                                       \
-        if (wave_live && k0 < kend) {              /* (a step past the end: staged zeros, no products) */                \
+        if (wave_live && (KC) < kend) {            /* (a step past the end: staged zeros, no products) */                \
             _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                                         \
                 float a4[4], b4[4];                                                                                      \
                 if (MODE == MODE_TN) {                                                                                   \
@@ -211,15 +209,20 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmBatch p) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], acc, 0, 0, 0);                              \
             }                                                                                                            \
         }                                                                                                                \
-        lds_barrier();                             /* slab consumed; the next two are still on their way */              \
-        k0 += BK;                                                                                                        \
+        lds_barrier();                             /* slab consumed */                                                   \
     }
-    /* three steps per trip and ONE exit test: with an exit after every step the loop head is reached from three places, each
-     * with different loads in flight, and the compiler falls back to waiting for all of them there */
+    /* Three slabs per trip.  The only loads in flight across the loop's back edge are those of slot 0 -- the first thing a trip
+     * needs -- so the wait the compiler puts at the loop head costs nothing extra; slots 1 and 2 are requested at the top of the
+     * trip, before slot 0 is waited for, and slot 0 of the NEXT trip right after its registers are staged.  (With loads of two
+     * slots pending at the back edge the compiler waited for all of them at the head.) */
     while (k0 < kend) {
-        GEMM_SLAB_STEP(0, 2)
-        GEMM_SLAB_STEP(1, 0)
-        GEMM_SLAB_STEP(2, 1)
+        load_tiles(k0 + BK, ra[1], rb[1]);
+        load_tiles(k0 + 2 * BK, ra[2], rb[2]);
+        GEMM_SLAB_STEP(0, k0)
+        load_tiles(k0 + 3 * BK, ra[0], rb[0]);
+        GEMM_SLAB_STEP(1, k0 + BK)
+        GEMM_SLAB_STEP(2, k0 + 2 * BK)
+        k0 += 3 * BK;
     }
 #undef GEMM_SLAB_STEP
 
