@@ -222,10 +222,10 @@ def dqn_c3(steps=60, ref=None):
                        "one update per vector step (BASELINE configs[2])" % n,
            "value": round(n * steps / dt, 1), "unit": "env-steps/s", "vector_step_us": round(dt / steps * 1e6, 1),
            "update_us": round(graph_us, 1),
-           "roofline": {"bound": "mfma", "kernel": "update graph (im2col + xrl::gemm_f32_kernel launches, eval + target networks, backward, xrl::reduce_adam_kernel)",
+           "roofline": {"bound": "mfma", "kernel": "update graph (xrl::conv_mfma_kernel / conv_dw_mfma_kernel implicit GEMMs + Q-head launches, eval + target networks, backward, xrl::reduce_adam_kernel)",
                         "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                         "traffic": None, "avg_launch_us": round(graph_us, 1), "algorithmic_flops_per_launch": flops,
-                        "note": "one 'launch' = one whole update (a graph); launch- and im2col-bound at batch 32, DESIGN.md section 8 item 6"}}
+                        "note": "one 'launch' = one whole update (a graph); 26 launches at batch 32: launch- and latency-bound, DESIGN.md section 3 'Round 3: implicit-GEMM convolutions'"}}
     if ref:
         out["cpu_baseline"] = ref
     return out
