@@ -541,7 +541,7 @@ def golden_ppokl(dist):
 
 
 # ------------------------------------------------------------------------------ DQN
-def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None):
+def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None, levels=None):
     """learner_cls: DQN_Learner (default), DDQN_Learner (ddqn_learner.py:39-47, the double-Q target) or DuelDQN_Learner
     with model_cls=DuelingDeepQNetwork (dueldqn_learner.py:28-75, q_head.py:42-80).
     size="c3" (kind "cnn"): the batch of configs/dqn/atari.yaml:27 (32 frames of 84x84x4), two updates, lr 1e-4, no clip;
@@ -578,6 +578,9 @@ def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None):
         if kind == "mlp":
             obs = rng.standard_normal((bs, D)).astype(np.float32)
             nxt = rng.standard_normal((bs, D)).astype(np.float32)
+        elif levels is not None:                       # (a few grey levels: the file compresses)
+            obs = (rng.integers(0, levels, (bs, 84, 84, 4)) * (255 // (levels - 1))).astype(np.uint8)
+            nxt = (rng.integers(0, levels, (bs, 84, 84, 4)) * (255 // (levels - 1))).astype(np.uint8)
         elif size is not None:
             obs = (rng.integers(0, 16, (bs, 84, 84, 4)) * 17).astype(np.uint8)
             nxt = (rng.integers(0, 16, (bs, 84, 84, 4)) * 17).astype(np.uint8)
@@ -1025,6 +1028,14 @@ def golden_pg(dist):
     np.savez_compressed(os.path.join(OUT, f"pg_{dist}.npz"), **out)
 
 
+def golden_dueldqn_cnn():
+    """DuelDQN_Learner on DuelingDeepQNetwork over Basic_CNN (dueldqn_learner.py:28-75, q_head.py:42-80, cnn.py:11-50): batch 4 of
+    84x84x4 frames with 6 grey levels, three updates -> dueldqn_cnn.npz."""
+    from xuance.torch.learners import DuelDQN_Learner
+    from xuance.torch.rl_models.architectures.single_agent.deep_q_network import DuelingDeepQNetwork
+    golden_dqn("cnn", DuelDQN_Learner, "dueldqn", DuelingDeepQNetwork, levels=6)
+
+
 def golden_baseline_sizes():
     """Fixtures at the batch sizes of the BASELINE configs (C1 128, C2 8 192, C3 32 frames, C4 4 096 on 17-256-256,
     C5 32 transitions / 32 episodes x 60 steps): the split-K epilogues, multi-slab reductions and multi-tile paths of
@@ -1064,6 +1075,7 @@ if __name__ == "__main__":
     from xuance.torch.learners import DuelDQN_Learner
     from xuance.torch.rl_models.architectures.single_agent.deep_q_network import DuelingDeepQNetwork
     golden_dqn("mlp", DuelDQN_Learner, "dueldqn", DuelingDeepQNetwork)
+    golden_dueldqn_cnn()
     golden_qmix(True)
     golden_qmix(False)
     golden_qmix(True, "vdn")

@@ -131,6 +131,24 @@ def test_dqn_cnn_learner_vs_reference_fixture(name, implicit):
                   ("evalQ", "predictQ", "targetQ"), "Qloss")
 
 
+def test_dueldqn_cnn_learner_vs_reference_fixture():
+    """DuelDQN_Learner on DuelingDeepQNetwork over Basic_CNN (dueldqn_learner.py:28-75, q_head.py:42-80 on cnn.py:11-50) -- the
+    dueling streams behind the convolution stack -- against the reference learner's own three updates (tests/golden/dueldqn_cnn.npz,
+    oracle/make_golden.py: golden_dueldqn_cnn)."""
+    from xuance_amd.nets import DeepQCNN
+    from xuance_amd.learners import DuelDQN_Learner
+    g = load_golden("dueldqn_cnn")
+    lr, gamma, sync, gclip, use_clip, total = g["cfg"]
+    net = DeepQCNN((84, 84, 4), 4, dueling=True)
+    assert list(net.ref_order) == list(sub(g, "init").keys()) and net.conv.implicit
+    net.load_state_dict(sub(g, "init"))
+    cb = Capture()
+    learner = DuelDQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
+                                       use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip)), net, cb)
+    check_updates(g, net, learner, cb, lambda b: learner.update(batch_size=len(b["obs"]), **b),
+                  ("evalQ", "predictQ", "targetQ"), "Qloss")
+
+
 @pytest.mark.parametrize("double_q", [False, True])
 @pytest.mark.parametrize("M,shape", [(32, (84, 84, 4)), (5, (44, 36, 4))])
 def test_implicit_gemm_convolutions_vs_im2col_path(M, shape, double_q):

@@ -136,8 +136,6 @@ def _deep_q(sd, module, config, device):
     conv = any(sd[k].dim() == 4 for k in rep_keys)
     act = _activation_of(_sub(module, "eval_Q_head"), _cfg(config, "activation", "relu"))
     if conv:
-        if dueling:
-            raise AdoptError("dueling head on a convolutional representation is not built")
         ws = [sd[k] for k in sorted(rep_keys, key=lambda k: int(k.split(".")[2]))]
         rep_mod = _sub(module, "representation")
         shape = getattr(rep_mod, "input_shape", None)                 # Basic_CNN keeps (C, H, W) (cnn.py:24); frames are H x W x C
@@ -148,9 +146,14 @@ def _deep_q(sd, module, config, device):
         if shape is None or strides is None:
             raise AdoptError("convolutional DeepQNetwork: the frame shape and the strides are not in the state_dict -- pass "
                              "the module (Basic_CNN carries input_shape / strides) or a config with observation_space / strides")
-        q = _chain(sd, "eval_Q_head.q_value")
-        return nets.DeepQCNN(tuple(shape), q[-1][0], tuple(int(w.shape[2]) for w in ws), tuple(int(s) for s in strides),
-                             tuple(int(w.shape[0]) for w in ws), tuple(s[0] for s in q[:-1]), act, device=device, init=False)
+        if dueling:                                                   # DuelingQValueHead: streams of half the hidden width (q_head.py:55-62)
+            v, a = _chain(sd, "eval_Q_head.v_model"), _chain(sd, "eval_Q_head.a_model")
+            n_actions, hidden = a[-1][0], tuple(2 * s[0] for s in v[:-1])
+        else:
+            q = _chain(sd, "eval_Q_head.q_value")
+            n_actions, hidden = q[-1][0], tuple(s[0] for s in q[:-1])
+        return nets.DeepQCNN(tuple(shape), n_actions, tuple(int(w.shape[2]) for w in ws), tuple(int(s) for s in strides),
+                             tuple(int(w.shape[0]) for w in ws), hidden, act, device=device, init=False, dueling=dueling)
     rep = _chain(sd, "representation.model") if rep_keys else []
     if dueling:
         v, a = _chain(sd, "eval_Q_head.v_model"), _chain(sd, "eval_Q_head.a_model")

@@ -455,6 +455,45 @@ def _seq_layers(prefix, in_dim, sizes, activation, last_act, lvl0, specs, order,
     return feat, lvl
 
 
+def _q_head_layers(feat, q_hidden, n_actions, activation, dueling, lvl, specs, order, stages, widths):
+    """BasicQhead (q_head.py:8-39) or DuelingQValueHead (q_head.py:42-80) behind `feat` features at activation level `lvl`: appends to
+    specs / order / stages / widths (shared by DeepQNet and DeepQCNN)."""
+    if not dueling:
+        _seq_layers("eval_Q_head.q_value", feat, list(q_hidden) + [n_actions], activation, None, lvl, specs, order,
+                    stages, widths)
+    else:
+        # DuelingQValueHead (q_head.py:42-80): v_model feat -> h/2 ... -> 1 and a_model feat -> h/2 ... -> A side by
+        # side (two groups per launch); the output level is [advantages (A) | value], combined inside xrl_dqn_td
+        v_specs, a_specs, v_order, a_order = [], [], [], []
+        assert len(list(q_hidden)) >= 1, "dueling head: at least one hidden layer (the two streams' first layers are stacked)"
+        vin, ain, k_in = 0, 0, feat
+        for i, h in enumerate(list(q_hidden)):
+            hh = h // 2
+            nv, na = f"eval_Q_head.v_model.{2 * i}", f"eval_Q_head.a_model.{2 * i}"
+            v_order += [nv + ".weight", nv + ".bias"]; a_order += [na + ".weight", na + ".bias"]
+            if i == 0:
+                # both streams read the same features: ONE stacked layer [v; a] (one data-gradient GEMM into the shared
+                # input); the flat layout keeps the two weights, then the two biases, adjacent
+                assert (hh * k_in) % 4 == 0 and hh % 4 == 0
+                specs += [(nv + ".weight", (hh, k_in)), (na + ".weight", (hh, k_in)), (nv + ".bias", (hh,)), (na + ".bias", (hh,))]
+                stages.append([Layer(nv + "+" + na, k_in, 2 * hh, activation, lvl, 0, lvl + 1, 0, nv + ".weight", nv + ".bias")])
+            else:
+                specs += [(nv + ".weight", (hh, k_in)), (nv + ".bias", (hh,)), (na + ".weight", (hh, k_in)), (na + ".bias", (hh,))]
+                stages.append([Layer(nv, k_in, hh, activation, lvl, vin, lvl + 1, 0, nv + ".weight", nv + ".bias"),
+                               Layer(na, k_in, hh, activation, lvl, ain, lvl + 1, hh, na + ".weight", na + ".bias")])
+            widths.append(2 * hh)
+            lvl, k_in, vin, ain = lvl + 1, hh, 0, hh
+        i = len(list(q_hidden))
+        nv, na = f"eval_Q_head.v_model.{2 * i}", f"eval_Q_head.a_model.{2 * i}"
+        specs += [(nv + ".weight", (1, k_in)), (nv + ".bias", (1,)), (na + ".weight", (n_actions, k_in)), (na + ".bias", (n_actions,))]
+        v_order += [nv + ".weight", nv + ".bias"]; a_order += [na + ".weight", na + ".bias"]
+        stages.append([Layer(na, k_in, n_actions, None, lvl, ain, lvl + 1, 0, na + ".weight", na + ".bias"),
+                       Layer(nv, k_in, 1, None, lvl, vin, lvl + 1, n_actions, nv + ".weight", nv + ".bias")])
+        widths.append(n_actions + 1)
+        order += v_order + a_order                          # state_dict order of the reference head: v_model, a_model
+
+
+
 class DeepQNet:
     """DeepQNetwork with an MLP / identity representation (rl_models/architectures/single_agent/deep_q_network.py:19-99):
     eval and target networks share one parameter layout; the target lives in a second flat buffer."""
@@ -465,39 +504,7 @@ class DeepQNet:
         specs, order, stages, widths = [], [], [], [obs_dim]
         feat, lvl = _seq_layers("representation.model", obs_dim, list(representation_hidden or []), activation, "same",
                                 0, specs, order, stages, widths)
-        if not dueling:
-            _seq_layers("eval_Q_head.q_value", feat, list(q_hidden) + [n_actions], activation, None, lvl, specs, order,
-                        stages, widths)
-        else:
-            # DuelingQValueHead (q_head.py:42-80): v_model feat -> h/2 ... -> 1 and a_model feat -> h/2 ... -> A side by
-            # side (two groups per launch); the output level is [advantages (A) | value], combined inside xrl_dqn_td
-            v_specs, a_specs, v_order, a_order = [], [], [], []
-            assert len(list(q_hidden)) >= 1, "dueling head: at least one hidden layer (the two streams' first layers are stacked)"
-            vin, ain, k_in = 0, 0, feat
-            for i, h in enumerate(list(q_hidden)):
-                hh = h // 2
-                nv, na = f"eval_Q_head.v_model.{2 * i}", f"eval_Q_head.a_model.{2 * i}"
-                v_order += [nv + ".weight", nv + ".bias"]; a_order += [na + ".weight", na + ".bias"]
-                if i == 0:
-                    # both streams read the same features: ONE stacked layer [v; a] (one data-gradient GEMM into the shared
-                    # input); the flat layout keeps the two weights, then the two biases, adjacent
-                    assert (hh * k_in) % 4 == 0 and hh % 4 == 0
-                    specs += [(nv + ".weight", (hh, k_in)), (na + ".weight", (hh, k_in)), (nv + ".bias", (hh,)), (na + ".bias", (hh,))]
-                    stages.append([Layer(nv + "+" + na, k_in, 2 * hh, activation, lvl, 0, lvl + 1, 0, nv + ".weight", nv + ".bias")])
-                else:
-                    specs += [(nv + ".weight", (hh, k_in)), (nv + ".bias", (hh,)), (na + ".weight", (hh, k_in)), (na + ".bias", (hh,))]
-                    stages.append([Layer(nv, k_in, hh, activation, lvl, vin, lvl + 1, 0, nv + ".weight", nv + ".bias"),
-                                   Layer(na, k_in, hh, activation, lvl, ain, lvl + 1, hh, na + ".weight", na + ".bias")])
-                widths.append(2 * hh)
-                lvl, k_in, vin, ain = lvl + 1, hh, 0, hh
-            i = len(list(q_hidden))
-            nv, na = f"eval_Q_head.v_model.{2 * i}", f"eval_Q_head.a_model.{2 * i}"
-            specs += [(nv + ".weight", (1, k_in)), (nv + ".bias", (1,)), (na + ".weight", (n_actions, k_in)), (na + ".bias", (n_actions,))]
-            v_order += [nv + ".weight", nv + ".bias"]; a_order += [na + ".weight", na + ".bias"]
-            stages.append([Layer(na, k_in, n_actions, None, lvl, ain, lvl + 1, 0, na + ".weight", na + ".bias"),
-                           Layer(nv, k_in, 1, None, lvl, vin, lvl + 1, n_actions, nv + ".weight", nv + ".bias")])
-            widths.append(n_actions + 1)
-            order += v_order + a_order                          # state_dict order of the reference head: v_model, a_model
+        _q_head_layers(feat, q_hidden, n_actions, activation, dueling, lvl, specs, order, stages, widths)
         self.eval_order = order
         self.params = FlatParams(specs, device)
         self.target_flat = self.params.like()
@@ -1214,8 +1221,9 @@ class DeepQCNN:
     parameter buffer, csrc/conv.hip), the Q head, TD target, gradient slabs, clip, Adam and target sync as everywhere."""
 
     def __init__(self, obs_shape=(84, 84, 4), n_actions=4, kernels=(8, 4, 3), strides=(4, 2, 1), filters=(32, 64, 64),
-                 q_hidden=(512,), activation="relu", device="cuda", init=True, implicit_conv=True):
+                 q_hidden=(512,), activation="relu", device="cuda", init=True, implicit_conv=True, dueling=False):
         assert activation == "relu"
+        self.dueling = bool(dueling)
         self.obs_shape, self.n_actions, self.obs_dim = tuple(obs_shape), n_actions, int(obs_shape[0] * obs_shape[1] * obs_shape[2])
         self.kernels, self.strides, self.filters = tuple(kernels), tuple(strides), tuple(filters)
         specs, order, stages, widths = [], [], [], [filters[-1]]
@@ -1227,8 +1235,7 @@ class DeepQCNN:
             order += [n + ".weight", n + ".bias"]
             self.conv_names.append(n)
             C = f
-        _seq_layers("eval_Q_head.q_value", filters[-1], list(q_hidden) + [n_actions], activation, None, 0, specs, order,
-                    stages, widths)
+        _q_head_layers(filters[-1], q_hidden, n_actions, activation, self.dueling, 0, specs, order, stages, widths)
         self.params = FlatParams(specs, device)
         self.target_flat = self.params.like()
         self.plan = Plan(self.params, widths, stages)
