@@ -764,6 +764,30 @@ typedef struct {
                                 * (DuelingQValueHead, rl_models/heads/q_head.py:42-80; dueldqn_learner.py:28-75); ld >= A + 1 */
 } xrl_dqn_td_t;
 int xrl_dqn_td(const xrl_dqn_td_t* p, xrl_stream_t stream);
+/* The last layer of a BasicQhead (q_head.py:8-39: Linear(H, n_actions)), xrl_dqn_td's rule and the layer's data gradient in ONE
+ * launch: q = h . W^T + b for the eval network on obs (rows [0, M) of h_eval; rows [M, 2M) = next_obs under double-Q) and the target
+ * network on next_obs, TD target / loss / dQ as xrl_dqn_td, d_h[m] = dQ[m][a_m] * W_eval[a_m] * act'(h_eval[m]).  partials: [M][8],
+ * one row per transition ({td^2, predictQ, 0...}). */
+typedef struct {
+    const float* h_eval;       /* [M or 2M][ld_h] hidden activations in front of the Q layer (outputs of `act`) */
+    const float* h_target;     /* [M][ld_h] */
+    const float* w_eval;       /* [A][H] */
+    const float* b_eval;       /* [A] */
+    const float* w_target;
+    const float* b_target;
+    const float* actions;      /* [M] f32 */
+    const float* rewards;
+    const float* terminals;
+    float* q_eval;             /* [M or 2M][ld_q] written */
+    float* q_target;           /* [M][ld_q] written */
+    float* d_q;                /* [M][ld_q] */
+    float* d_h;                /* [M][ld_h] */
+    float* diag;               /* NULL or [2M]: predictQ | targetQ */
+    double* partials;          /* [M][8] */
+    int32_t M, A, H, ld_h, ld_q, double_q, act, pad;
+    float gamma, pad2;
+} xrl_dqn_head_td_t;
+int xrl_dqn_head_td(const xrl_dqn_head_td_t* p, xrl_stream_t stream);
 
 /* QMIX_Learner.update between the per-agent Q-networks and the hyper-networks
  * (multi_agent_rl/qmix_learner.py:34-86, iql_learner.py:63-81, heads/q_mix_head.py:66-95): gather taken Q, masked

@@ -55,9 +55,11 @@ def check_updates(g, net, learner, cb, call, cb_keys, loss_key, n_updates=None, 
 
 
 @pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp"])
-def test_dqn_learner_vs_reference_fixture(name):
+@pytest.mark.parametrize("fused_head", [True, False])
+def test_dqn_learner_vs_reference_fixture(name, fused_head):
     """DQN_Learner / DDQN_Learner / DuelDQN_Learner, each against the reference's own learner run (dueling: DuelingQValueHead
-    as two GEMM groups per layer + the V + A - mean(A) combination inside xrl_dqn_td)."""
+    as two GEMM groups per layer + the V + A - mean(A) combination inside xrl_dqn_td).  fused_head: the Q layer, the TD rule and the
+    layer's data gradient as ONE launch (xrl_dqn_head_td, the default for a BasicQhead) or the layered launches."""
     from xuance_amd.nets import DeepQNet
     from xuance_amd.learners import DQN_Learner, DDQN_Learner, DuelDQN_Learner
     DQN_Learner = {"dqn": DQN_Learner, "ddq": DDQN_Learner, "due": DuelDQN_Learner}[name[:3]]
@@ -68,8 +70,8 @@ def test_dqn_learner_vs_reference_fixture(name):
     net.load_state_dict(sub(g, "init"))
     cb = Capture()
     learner = DQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
-                                   use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip)), net, cb)
-    assert learner.total_iters == int(total)
+                                   use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip), use_fused_q_head=fused_head), net, cb)
+    assert learner.total_iters == int(total) and (net.fused_head() is None) == name.startswith("duel")
     check_updates(g, net, learner, cb, lambda b: learner.update(batch_size=len(b["obs"]), **b),
                   ("evalQ", "predictQ", "targetQ"), "Qloss")
 

@@ -32,6 +32,14 @@ class Conv(C.Structure):
                 ("act", c_int32), ("img_u8", c_int32), ("pad", c_int32)]
 
 
+class DqnHeadTd(C.Structure):
+    _fields_ = [("h_eval", c_void_p), ("h_target", c_void_p), ("w_eval", c_void_p), ("b_eval", c_void_p), ("w_target", c_void_p),
+                ("b_target", c_void_p), ("actions", c_void_p), ("rewards", c_void_p), ("terminals", c_void_p), ("q_eval", c_void_p),
+                ("q_target", c_void_p), ("d_q", c_void_p), ("d_h", c_void_p), ("diag", c_void_p), ("partials", c_void_p),
+                ("M", c_int32), ("A", c_int32), ("H", c_int32), ("ld_h", c_int32), ("ld_q", c_int32), ("double_q", c_int32),
+                ("act", c_int32), ("pad", c_int32), ("gamma", c_float), ("pad2", c_float)]
+
+
 class ImageJob(C.Structure):
     _fields_ = [("src", c_void_p), ("map", c_void_p), ("dst", c_void_p), ("n", C.c_int64)]
 
@@ -335,6 +343,7 @@ _SIGS = {
     "xrl_maxpool_hw_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_maxpool_hw_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_reduce_adam_fits": [c_int64, c_int],
+    "xrl_dqn_head_td": [c_void_p, c_void_p],
     "xrl_conv_fwd": [c_void_p, c_int, c_int, c_void_p],
     "xrl_conv_fwd_probe": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrl_conv_bwd_weight": [c_void_p, c_int, c_int, C.c_int64, c_void_p],

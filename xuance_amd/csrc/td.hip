@@ -55,6 +55,79 @@ __global__ void __launch_bounds__(256) dqn_td_kernel(xrl_dqn_td_t p) {
     }
 }
 
+// Q layer + TD target + the Q layer's data gradient as ONE launch (dqn_learner.py:39-46, ddqn_learner.py:39-47 behind a
+// BasicQhead, q_head.py:8-39): at batch 32 the 512 -> n_actions layer, the TD rule and the gradient back into the hidden layer were
+// three launches of 4.5-7 us for a few thousand multiply-adds each.  One workgroup per transition m: the (row, action) dot
+// products of its up to three rows -- hidden activations of the eval network on obs[m] (and on next_obs[m] under double-Q) and of
+// the target network on next_obs[m] -- are spread over the four waves, the TD rule is dqn_td_kernel's, and
+// d_h[m][j] = dQ[m][a_m] * W[a_m][j] * act'(h[m][j]) leaves through all 256 threads.  The Q values go where the layered path puts
+// them (callbacks read them there), d_q feeds the layer's weight-gradient GEMM as before.
+__global__ void __launch_bounds__(256) dqn_head_td_kernel(xrl_dqn_head_td_t p) {
+    __shared__ float s_q[3 * 64];
+    const int A = p.A, H = p.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_rows = p.double_q ? 3 : 2;
+    for (int m = blockIdx.x; m < p.M; m += gridDim.x) {
+        const float* h0 = p.h_eval + (size_t)m * p.ld_h;
+        const float* h1 = p.h_target + (size_t)m * p.ld_h;
+        const float* h2 = p.h_eval + (size_t)(p.M + m) * p.ld_h;
+        // everything the tail needs that does not depend on the Q values is requested NOW (the taken action, its weight row and the
+        // hidden activations for d_h): the launch is a chain of memory round trips otherwise (three of them: 9 us)
+        const int a_taken = (int)p.actions[m];
+        const float rew = p.rewards[m], ter = p.terminals[m];
+        const float* wa = p.w_eval + (size_t)a_taken * H;
+        float pw[2], ph[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = threadIdx.x + 256 * u;
+            pw[u] = j < H ? wa[j] : 0.f;
+            ph[u] = j < H ? h0[j] : 0.f;
+        }
+        for (int pr = wave; pr < n_rows * A; pr += 4) {
+            const int r = pr / A, a = pr - r * A;
+            const float* h = r == 0 ? h0 : (r == 1 ? h1 : h2);
+            const float* w = (r == 1 ? p.w_target : p.w_eval) + (size_t)a * H;
+            float acc = 0.f;
+            for (int k = lane; k < H; k += 64) acc = fmaf(h[k], w[k], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) s_q[r * 64 + a] = acc + (r == 1 ? p.b_target : p.b_eval)[a];
+        }
+        __syncthreads();
+        if (threadIdx.x < A) {                                           // the layered path's output level
+            p.q_eval[(size_t)m * p.ld_q + threadIdx.x] = s_q[threadIdx.x];
+            p.q_target[(size_t)m * p.ld_q + threadIdx.x] = s_q[64 + threadIdx.x];
+            if (p.double_q) p.q_eval[(size_t)(p.M + m) * p.ld_q + threadIdx.x] = s_q[128 + threadIdx.x];
+        }
+        // (every thread evaluates the TD rule on the LDS values: no second barrier, no broadcast)
+        const float pred = s_q[a_taken];                                 // :42
+        float tq;
+        if (p.double_q) {                                                // argmax of the eval net on next_obs
+            int best = 0; float bv = s_q[128];
+            for (int j = 1; j < A; ++j) if (s_q[128 + j] > bv) { bv = s_q[128 + j]; best = j; }
+            tq = s_q[64 + best];
+        } else {
+            tq = s_q[64];
+            for (int j = 1; j < A; ++j) tq = fmaxf(tq, s_q[64 + j]);     // :43
+        }
+        const float y = rew + p.gamma * (1.f - ter) * tq;                // :44
+        const float td = pred - y, g = 2.f * td / (float)p.M;            // MSELoss backward through gather
+        if (threadIdx.x < A) p.d_q[(size_t)m * p.ld_q + threadIdx.x] = ((int)threadIdx.x == a_taken) ? g : 0.f;
+        if (threadIdx.x == 0) {
+            if (p.diag) { p.diag[m] = pred; p.diag[p.M + m] = y; }
+            double* q = p.partials + (size_t)m * 8;
+            q[0] = (double)td * td; q[1] = pred;
+            for (int j = 2; j < 8; ++j) q[j] = 0.0;
+        }
+        float* dh = p.d_h + (size_t)m * p.ld_h;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = threadIdx.x + 256 * u;
+            if (j < H) dh[j] = g * pw[u] * act_grad_from_out(ph[u], p.act);
+        }
+        for (int j = threadIdx.x + 512; j < H; j += 256) dh[j] = g * wa[j] * act_grad_from_out(h0[j], p.act);
+        __syncthreads();                                                 // (s_q is rewritten by the next transition)
+    }
+}
+
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
 
 // One wavefront per batch row b.  Lane n < N owns agent n, lane h < H owns mixer hidden unit h.
@@ -376,6 +449,15 @@ extern "C" int xrl_dqn_td(const xrl_dqn_td_t* p, xrl_stream_t stream) {
     XRL_CHECK_ARG(p && p->q_eval && p->q_next && p->actions && p->rewards && p->terminals && p->d_q && p->partials);
     XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->ld >= p->A + (p->dueling ? 1 : 0) && p->n_split >= 1);
     hipLaunchKernelGGL(dqn_td_kernel, dim3(p->n_split), dim3(256), 0, as_stream(stream), *p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_dqn_head_td(const xrl_dqn_head_td_t* p, xrl_stream_t stream) {
+    XRL_CHECK_ARG(p && p->h_eval && p->h_target && p->w_eval && p->b_eval && p->w_target && p->b_target && p->actions && p->rewards &&
+                  p->terminals && p->q_eval && p->q_target && p->d_q && p->d_h && p->partials);
+    XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->A <= 64 && p->H > 0 && p->ld_h >= p->H && p->ld_q >= p->A);
+    hipLaunchKernelGGL(dqn_head_td_kernel, dim3(p->M < 1024 ? p->M : 1024), dim3(256), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

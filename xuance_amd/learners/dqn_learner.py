@@ -46,12 +46,21 @@ class DQN_Learner(Learner):
         """self.X rows [0,M) = obs, rows [M,2M) = obs_next (already on the device)."""
         model, opt, A = self.model, self.optimizer, self.n_actions
         S = pick_n_split(M)
-        q_all, q_next = model.forward_pair(self.X, M, self.double_q)   # evalQ (:39) [+ Q_eval(s')], targetQ (:40): grouped
-        d_q = model.d_out
-        ops.dqn_td(q_eval=q_all, q_next=q_next, q_next_eval=q_all[M:] if self.double_q else None, actions=act,
-                   rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A,
-                   ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)))
-        S_opt = model.backward(self.X, M, self.slabs, S) or S     # (convolutional nets write 32 row chunks of their own)
+        fused = bool(getattr(self.config, "use_fused_q_head", True)) and M <= self.partials.shape[0] and \
+            getattr(model, "fused_head", lambda: None)() is not None
+        q_all, q_next = model.forward_pair(self.X, M, self.double_q, skip_last=fused)   # evalQ (:39) [+ Q_eval(s')], targetQ (:40)
+        if fused:
+            # the Q layer itself, the TD rule and the layer's data gradient: one launch (xrl_dqn_head_td), one partials row per row
+            model.head_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma)
+            S_opt = model.backward(self.X, M, self.slabs, S, skip_last_dg=True) or S
+            S_loss = M
+        else:
+            d_q = model.d_out
+            ops.dqn_td(q_eval=q_all, q_next=q_next, q_next_eval=q_all[M:] if self.double_q else None, actions=act,
+                       rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A,
+                       ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)))
+            S_opt = model.backward(self.X, M, self.slabs, S) or S     # (convolutional nets write 32 row chunks of their own)
+            S_loss = S
         P, clip = model.params.P, (self.grad_clip_norm if self.use_grad_clip else 0.0)
         if not self.needs_collective() and self._fused_optimizer_ok(self.gradient_exchange() is not None):
             # slab reduction (+ the average over the ranks, inside the launch) + norm + clip + Adam + LinearLR + periodic
@@ -59,7 +68,7 @@ class DQN_Learner(Learner):
             ops.reduce_adam(self.slabs, S_opt, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
                             self.opt_sync, target=model.target_flat, target_every=self.sync_frequency,
                             exchange=self.gradient_exchange())
-            return S
+            return S_loss
         ops.grad_reduce(self.slabs, S_opt, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_
@@ -67,7 +76,7 @@ class DQN_Learner(Learner):
             ops.grad_reduce(opt.grad, 1, P, P, opt.grad, self.sumsq)
         ops.adam_step(model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip)
         ops.sync_target(model.params.flat, model.target_flat, P, opt.state, self.sync_frequency)   # :56-57
-        return S
+        return S_loss
 
     # ------------------------------------------------------------------ whole update phases straight from the HBM replay buffer
     def update_from_buffer(self, memory, n_epochs=1, seed=1, sync=True):

@@ -129,10 +129,11 @@ class Plan:
         return self.acts[len(self.widths) - 1]
 
     @staticmethod
-    def forward_many(items):
+    def forward_many(items, skip_last=False):
         """Several independent plans as ONE grouped launch per stage (an eval network and its target twin; the agent
         networks and the mixer's hyper-networks): items = [(plan, x, ldx, M, flat)]; stage i of every plan that has one
-        goes into launch i.  Returns each plan's output level."""
+        goes into launch i.  Returns each plan's output level.  skip_last: every plan stops in front of its last stage (the
+        caller's own launch computes it: xrl_dqn_head_td)."""
         depth = max(len(it[0].stages) for it in items)
         for plan, x, ldx, M, flat in items:
             plan.ensure(M)
@@ -140,15 +141,18 @@ class Plan:
             groups = []
             for plan, x, ldx, M, flat in items:
                 P = plan.params
+                if skip_last and si == len(plan.stages) - 1:
+                    continue
                 for L in (plan.stages[si] if si < len(plan.stages) else ()):
                     a, lda = plan._buf(plan.acts, L.in_level, L.in_off, x, ldx)
                     c, ldc = plan._buf(plan.acts, L.out_level, L.out_off, x, ldx)
                     groups.append(ops.gemm_desc(a, P.ptr(L.w_name, flat), c, M, L.N, L.K, lda, L.K, ldc,
                                                 bias=P.ptr(L.b_name, flat), act=L.act))
-            ops.linear_fwd(groups)
+            if groups:
+                ops.linear_fwd(groups)
         return [it[0].acts[len(it[0].widths) - 1] for it in items]
 
-    def backward(self, x, ldx, M, slabs, n_split, flat=None, dx0=None, defer_wgrad=None):
+    def backward(self, x, ldx, M, slabs, n_split, flat=None, dx0=None, defer_wgrad=None, skip_last_dg=False):
         """dacts[last] must hold d loss / d (pre-activation) of the last level. Writes weight/bias gradient
         partials into slabs[s][layout of params].  dx0: optional [M, widths[0]] tensor receiving d loss / d input.
         defer_wgrad: a list -> only the data-gradient chain is launched here and the weight-gradient GEMM descriptors are
@@ -177,8 +181,8 @@ class Plan:
                 defer_wgrad.extend(wg)
             else:
                 ops.linear_bwd_weight(wg, n_split, stride)
-            if dg:
-                ops.linear_bwd_data(dg)
+            if dg and not (skip_last_dg and si == len(self.stages) - 1):     # (skip_last_dg: the caller's launch already wrote
+                ops.linear_bwd_data(dg)                                       #  the gradient in front of the last stage)
 
     @staticmethod
     def backward_many(items, slabs, n_split):
@@ -208,11 +212,11 @@ class Plan:
         for i in range(0, len(wg), 8):
             ops.linear_bwd_weight(wg[i:i + 8], n_split, slabs.shape[1])
 
-    def backward_grouped(self, x, ldx, M, slabs, n_split, flat=None, dx0=None):
+    def backward_grouped(self, x, ldx, M, slabs, n_split, flat=None, dx0=None, skip_last_dg=False):
         """backward() with the data-gradient chain first and ALL weight gradients of the plan as one grouped launch
         (chunks of 8 groups): same kernels per layer, fewer launches."""
         wg = []
-        self.backward(x, ldx, M, slabs, n_split, flat=flat, dx0=dx0, defer_wgrad=wg)
+        self.backward(x, ldx, M, slabs, n_split, flat=flat, dx0=dx0, defer_wgrad=wg, skip_last_dg=skip_last_dg)
         for i in range(0, len(wg), 8):
             ops.linear_bwd_weight(wg[i:i + 8], n_split, slabs.shape[1])
 
@@ -551,17 +555,40 @@ class DeepQNet:
     def target(self, x, M, ldx=None):
         return self.target_plan.forward(x, self.obs_dim if ldx is None else ldx, M, flat=self.target_flat)
 
-    def forward_pair(self, X, M, double_q):
+    def forward_pair(self, X, M, double_q, skip_last=False):
         """Eval network on X[:M] (+ X[M:2M] under double-Q) and target network on X[M:2M] as grouped launches."""
         return Plan.forward_many([(self.plan, X, self.obs_dim, 2 * M if double_q else M, None),
-                                  (self.target_plan, X[M:], self.obs_dim, M, self.target_flat)])
+                                  (self.target_plan, X[M:], self.obs_dim, M, self.target_flat)], skip_last=skip_last)
+
+    def fused_head(self):
+        """The last layer as xrl_dqn_head_td wants it, or None: a single Linear(H, n_actions) without activation behind a hidden
+        level of its own (BasicQhead with at least one hidden layer; not the dueling streams)."""
+        last = self.plan.stages[-1]
+        if self.dueling or len(last) != 1 or len(self.plan.stages) < 2:
+            return None
+        L = last[0]
+        if L.act not in (None, "none") or L.in_level < 1 or L.in_off != 0 or L.K != self.plan.widths[L.in_level] or L.N > 64:
+            return None
+        return L
+
+    def head_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma):
+        """Q layer + TD + the Q layer's data gradient (after forward_pair(..., skip_last=True)); backward(..., skip_last_dg=True)
+        continues from there."""
+        L, pl, tp = self.fused_head(), self.plan, self.target_plan
+        lvl = L.in_level
+        ops.dqn_head_td(h_eval=pl.acts[lvl], h_target=tp.acts[lvl], w_eval=self.params.ptr(L.w_name), b_eval=self.params.ptr(L.b_name),
+                        w_target=self.params.ptr(L.w_name, self.target_flat), b_target=self.params.ptr(L.b_name, self.target_flat),
+                        actions=actions, rewards=rewards, terminals=terminals, q_eval=pl.acts[L.out_level], q_target=tp.acts[L.out_level],
+                        d_q=pl.dacts[L.out_level], d_h=pl.dacts[lvl], diag=diag, partials=partials, M=M, A=L.N, H=L.K,
+                        ld_h=pl.widths[lvl], ld_q=pl.widths[L.out_level], double_q=int(double_q),
+                        act=ops.ACT[pl._act_of(lvl, 0)], gamma=float(gamma))
 
     @property
     def d_out(self):
         return self.plan.dacts[len(self.plan.widths) - 1]
 
-    def backward(self, x, M, slabs, n_split):
-        self.plan.backward_grouped(x, self.obs_dim, M, slabs, n_split)
+    def backward(self, x, M, slabs, n_split, skip_last_dg=False):
+        self.plan.backward_grouped(x, self.obs_dim, M, slabs, n_split, skip_last_dg=skip_last_dg)
 
 
 class MixingQNet:
@@ -1277,7 +1304,10 @@ class DeepQCNN:
         self._tfeat = self.conv.forward(x_u8.reshape(M, -1), M, ws, flat=self.target_flat)
         return self.target_plan.forward(self._tfeat, self.filters[-1], M, flat=self.target_flat)
 
-    def forward_pair(self, X, M, double_q):
+    fused_head = DeepQNet.fused_head
+    head_td = DeepQNet.head_td
+
+    def forward_pair(self, X, M, double_q, skip_last=False):
         """One update's three network passes (dqn_learner.py:39-40, ddqn_learner.py:40): eval Q of obs = X[:M] (kept for
         backward), target Q of next_obs = X[M:2M] and, under double-Q, eval Q of next_obs -- as one im2col + one grouped
         GEMM launch per layer.  Returns (Q_eval [Re, A], Q_target [M, A])."""
@@ -1286,17 +1316,18 @@ class DeepQCNN:
         self._ws = ws
         feat = self.conv.forward_dual(X[:2 * M].reshape(2 * M, -1), M, Re, ws, self.target_flat)
         self._feat_in = feat
-        q_e, q_t = Plan.forward_many([(self.plan, feat, F, Re, None), (self.target_plan, feat[Re:], F, M, self.target_flat)])
+        q_e, q_t = Plan.forward_many([(self.plan, feat, F, Re, None), (self.target_plan, feat[Re:], F, M, self.target_flat)],
+                                     skip_last=skip_last)
         return q_e, q_t
 
     @property
     def d_out(self):
         return self.plan.dacts[len(self.plan.widths) - 1]
 
-    def backward(self, x_u8, M, slabs, n_split):
+    def backward(self, x_u8, M, slabs, n_split, skip_last_dg=False):
         if getattr(self, "_dfeat", None) is None or self._dfeat.shape[0] < M:
             self._dfeat = torch.zeros(M, self.filters[-1], device=self.params.device)
-        self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat)
+        self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat, skip_last_dg=skip_last_dg)
         if getattr(self, "_head_split", n_split) != n_split:      # (head rows of slabs beyond n_split must read as zero)
             slabs.zero_()
         self._head_split = n_split

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Conv, ImageJob, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Conv, ImageJob, DqnHeadTd, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -113,6 +113,11 @@ def maxpool_hw_fwd(y, feat, argmax, B, P, F, ld_feat):
 
 def maxpool_hw_bwd(dfeat, argmax, y, dy, B, P, F, ld_dfeat):
     call("xrl_maxpool_hw_bwd", ptr(dfeat), ptr(argmax), ptr(y), ptr(dy), B, P, F, ld_dfeat, stream_ptr())
+
+
+def dqn_head_td(**kw):
+    """Q layer + TD rule + the layer's data gradient in one launch (xrl_dqn_head_td)."""
+    call("xrl_dqn_head_td", C.byref(_struct(DqnHeadTd, kw)), stream_ptr())
 
 
 def conv_desc(**kw):
