@@ -1046,6 +1046,10 @@ int xrl_episode_finish_gated(const xrl_episode_field_t* fields, int n_fields, co
                              xrl_stream_t stream);   /* advance 0: ptr_size is only read (the caller advances it later) */
 /* sample (:970-996): a = time-major batch [slots][B][row], b = ring: a[t][i] <- b[idx[i]][t]. */
 int xrl_episode_gather(const xrl_episode_field_t* fields, int n_fields, const int64_t* idx, int B, xrl_stream_t stream);
+/* xrl_sample_replay_indices(idx_out, B, 1, n_size, ...) + xrl_episode_gather in ONE launch (same Philox stream, same episodes). */
+int xrl_episode_gather_sampled(const xrl_episode_field_t* fields, int n_fields, int64_t* idx_out, int B, int n_size,
+                               const int32_t* size_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_dev,
+                               xrl_stream_t stream);
 
 /* ------------------------------------------------------------------ prioritized replay (PerOffPolicyBuffer)
  * memory_tools.py:471-598 with segtree_tool.py:24-230.  Per-env sum and min segment trees, [n_envs][2*capacity] float64

@@ -5,6 +5,7 @@
 // agents are homogeneous), so a step write is one contiguous row per field and an episode is one contiguous block; the
 // gather writes the learner's TIME-MAJOR batch ([slot][episode][row]) directly.  All HBM-bound, 4- or 16-byte units.
 #include "common.h"
+#include "rng.h"
 
 namespace xrl {
 
@@ -84,6 +85,30 @@ __global__ void __launch_bounds__(256) episode_gather_kernel(EpPack f, const int
     const int b = blockIdx.x, fi = blockIdx.y;
     const int rw = f.row_bytes[fi] >> 2, slots = f.slots[fi];
     const uint32_t* s = reinterpret_cast<const uint32_t*>(f.b[fi]) + (size_t)idx[b] * slots * rw;
+    uint32_t* d = reinterpret_cast<uint32_t*>(f.a[fi]);
+    const int n = slots * rw;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / rw, w = i - t * rw;
+        d[((size_t)t * B + b) * rw + w] = s[i];
+    }
+}
+
+// The same with the uniform draw inside (xrl_sample_replay_indices' stream with n_envs = 1: episode = floor(u * size), u from
+// Philox(seed, b, counter + *counter_dev)): every workgroup of episode b forms the same index itself, field 0's writes it to idx_out.
+// One launch less per update of the recurrent learners (a launch costs ~5 us at these sizes whatever it does).
+__global__ void __launch_bounds__(256) episode_gather_sampled_kernel(EpPack f, int64_t* __restrict__ idx_out, int B, int n_size,
+                                                                    const int32_t* __restrict__ size_dev, uint64_t seed, uint32_t counter,
+                                                                    const uint32_t* __restrict__ counter_dev) {
+    const int b = blockIdx.x, fi = blockIdx.y;
+    const uint32_t ctr = counter + (counter_dev ? *counter_dev : 0u);
+    int size = *size_dev;
+    size = size < 1 ? 1 : (size > n_size ? n_size : size);
+    uint32_t r[4];
+    philox4x32(seed, (uint32_t)b, ctr, 0x53414D50u, r);
+    const int64_t ep = (int64_t)(((uint64_t)r[1] * (uint64_t)size) >> 32);   // (n_envs = 1: env = 0, flat index = step)
+    if (fi == 0 && threadIdx.x == 0) idx_out[b] = ep;
+    const int rw = f.row_bytes[fi] >> 2, slots = f.slots[fi];
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(f.b[fi]) + (size_t)ep * slots * rw;
     uint32_t* d = reinterpret_cast<uint32_t*>(f.a[fi]);
     const int n = slots * rw;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -218,6 +243,18 @@ extern "C" int xrl_episode_gather(const xrl_episode_field_t* fields, int n_field
     XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
     XRL_CHECK_ARG(idx && B > 0);
     hipLaunchKernelGGL(episode_gather_kernel, dim3(B, n_fields), dim3(256), 0, as_stream(stream), p, idx, B);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_episode_gather_sampled(const xrl_episode_field_t* fields, int n_fields, int64_t* idx_out, int B, int n_size,
+                                          const int32_t* size_dev, uint64_t seed, uint32_t counter, const uint32_t* counter_dev,
+                                          xrl_stream_t stream) {
+    EpPack p;
+    XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
+    XRL_CHECK_ARG(idx_out && size_dev && B > 0 && n_size > 0);
+    hipLaunchKernelGGL(episode_gather_sampled_kernel, dim3(B, n_fields), dim3(256), 0, as_stream(stream), p, idx_out, B, n_size, size_dev,
+                       seed, counter, counter_dev);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -414,8 +414,7 @@ class QMIX_Learner(Learner):
 
             def enqueue():
                 for e in range(n_epochs):
-                    ops.sample_replay_indices(self._idx, 1, memory.buffer_size, memory.size_dev, seed, e, self._sample_counter)
-                    memory.gather_into(self._idx, dst)
+                    memory.draw_into(self._idx, dst, seed, e, self._sample_counter)      # draw + gather: one launch
                     self.partials = self._phase_partials[e]
                     self._step_rnn(B, T)
                 ops.counter_add(self._sample_counter, n_epochs)

@@ -262,6 +262,12 @@ class HipMARLOffPolicyBufferRNN:
         ops.episode_gather([(dst[k], self.data[k], None, 4 * self.layout[k][0], self.layout[k][1], 0) for k in dst],
                            idx, idx.numel())
 
+    def draw_into(self, idx_out, dst, seed, counter, counter_dev):
+        """Uniform draw of idx_out.numel() episodes (xrl_sample_replay_indices' stream, following the filling ring through size_dev)
+        + gather_into, as ONE launch."""
+        ops.episode_gather_sampled([(dst[k], self.data[k], None, 4 * self.layout[k][0], self.layout[k][1], 0) for k in dst],
+                                   idx_out, idx_out.numel(), self.buffer_size, self.size_dev, seed, counter, counter_dev)
+
     def sample(self, batch_size=None, indexes=None):           # :970-996
         size = self.size
         assert size > 0, "You need to first store experience data into the buffer!"

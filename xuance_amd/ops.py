@@ -810,6 +810,12 @@ def episode_gather(items, idx, B):
     call("xrl_episode_gather", _ep_fields(items), len(items), ptr(_chk(idx, torch.int64)), int(B), stream_ptr())
 
 
+def episode_gather_sampled(items, idx_out, B, n_size, size_dev, seed, counter=0, counter_dev=None):
+    """sample_replay_indices(idx_out, 1, n_size, ...) + episode_gather in one launch (xrl_episode_gather_sampled)."""
+    call("xrl_episode_gather_sampled", _ep_fields(items), len(items), ptr(_chk(idx_out, torch.int64)), int(B), int(n_size),
+         ptr(size_dev), int(seed), int(counter), ptr(counter_dev), stream_ptr())
+
+
 def per_store(sum_tree, min_tree, max_priority, ptr_, alpha, n_envs, capacity):
     call("xrl_per_store", ptr(sum_tree), ptr(min_tree), ptr(max_priority), int(ptr_), float(alpha), int(n_envs), int(capacity),
          stream_ptr())
