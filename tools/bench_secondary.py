@@ -194,6 +194,47 @@ def ppo_c4(steps=3, warmup=2, ref=None):
     return out
 
 
+def ppo_atari(steps=3, warmup=2):
+    """configs/ppo/atari.yaml shapes: PPO on 84x84x4 uint8 frame stacks, AC_CNN_Atari (32/64/64 conv + 512 dense) with a categorical
+    head, 8 envs x horizon 128 in a HipOnPolicyBuffer_Atari (uint8), 4 epochs x 4 minibatches of 256 frames; synthetic frame
+    provider on the device.  The network is 3.36 M parameters (the 6400 -> 512 layer); roofline of a minibatch: its algorithmic
+    flops (conv 21.2 MFLOP + dense 6.6 MFLOP per frame and forward pass, x3 for forward + two backward products) / its time."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    n, T = 8, 128
+    cfg = Namespace(agent="PPO", representation="AC_CNN_Atari", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                    fc_hidden_sizes=[512], actor_hidden_size=[], critic_hidden_size=[], activation="relu", seed=1, parallels=n,
+                    running_steps=10 ** 7, horizon_size=T, n_epochs=4, n_minibatch=4, learning_rate=2.5e-4, vf_coef=0.25, ent_coef=0.01,
+                    clip_range=0.2, gamma=0.99, use_gae=True, gae_lambda=0.95, use_advnorm=True, use_grad_clip=True, grad_clip_norm=0.5,
+                    use_obsnorm=False, use_rewnorm=False, obsnorm_range=5, rewnorm_range=5, distributed_training=False, device="cuda",
+                    model_dir="/tmp/xrl_bench_models", use_hip_graph=True)
+    torch.manual_seed(0)
+    agent = PPO_Agent(cfg, SyntheticAtariVecEnv(n, seed=5))
+    for _ in range(warmup):
+        agent.rollout(); agent.update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.rollout()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(steps):
+        agent.update()
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    us_mb = (t2 - t1) / steps / 16 * 1e6
+    flops = 3 * (21.2e6 + 2 * 6400 * 512 + 2 * 512 * 5) * 256
+    tf = flops / us_mb / 1e6
+    return {"workload": "PPO, Atari shapes (84x84x4 uint8 frames, AC_CNN_Atari 32/64/64 + 512, 4 actions; configs/ppo/atari.yaml), %d envs x "
+                        "horizon %d, 4 epochs x 4 minibatches of 256 frames, uint8 rollout buffer" % (n, T),
+            "value": round(n * T * steps / (t2 - t0), 1), "unit": "env-steps/s", "ms_per_step": round((t2 - t0) / steps * 1e3, 3),
+            "rollout_ms": round((t1 - t0) / steps * 1e3, 3), "update_ms": round((t2 - t1) / steps * 1e3, 3),
+            "update_us_per_minibatch": round(us_mb, 1),
+            "roofline": {"bound": "mfma", "kernel": "minibatch update (implicit-GEMM convolutions xrl::conv_mfma_kernel / conv_dw_*, dense xrl::gemm_f32_kernel "
+                                                    "launches, xrl::ppo_loss_kernel, xrl::reduce_adam_kernel over 3.36 M parameters)",
+                         "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": None, "avg_launch_us": round(us_mb, 1), "algorithmic_flops_per_launch": flops,
+                         "note": "one 'launch' = one whole minibatch update (layered path over the convolution stack); the rollout is 128 eager vector steps of 8 envs (the frame provider alternates its observation buffers and takes the step index from the host, so it is not captured into a graph): ~15 launches per step, host-bound; no reference CPU time taken for this shape"}}
+
+
 def dqn_c3(steps=60, ref=None):
     """BASELINE configs[2] shapes: DQN, 64 envs x 84x84x4 uint8 frames (synthetic frame provider on the device), CNN
     32/64/64 + 512, uint8 replay ring, batch 32, one update per vector step.  Roofline of the update graph: 2.7 GFLOP
