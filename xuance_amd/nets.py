@@ -114,6 +114,24 @@ class Plan:
             return x.data_ptr() + 4 * off, ldx
         return store[lvl].data_ptr() + 4 * off, self.widths[lvl]
 
+    def _split_k(self, L, M):
+        """(workspace, K ranges) for a layer with a LONG reduction and few output tiles -- the 6 400 -> 512 layer of AC_CNN_Atari on a
+        256-frame minibatch is 32 tiles walking 200 slabs each (135 us) -- or (None, 0): xrl_linear_fwd's split-K."""
+        if L.K < 2048:
+            return None, 0
+        tiles, ks = ((M + 63) // 64) * ((L.N + 63) // 64), 1
+        while tiles * ks < 384 and L.K // (ks * 2) >= 128 and ks < 16:
+            ks *= 2
+        if ks == 1:
+            return None, 0
+        ws = getattr(self, "_skw", None)
+        if ws is None:
+            ws = self._skw = {}
+        key = (L.w_name, ks)
+        if key not in ws or ws[key].numel() < ks * M * L.N:
+            ws[key] = torch.empty(ks * max(M, self.cap) * L.N, device=self.params.device)
+        return ws[key], ks
+
     def forward(self, x, ldx, M, flat=None):
         """x: device tensor holding the input rows with row stride ldx (floats)."""
         self.ensure(M)
@@ -123,8 +141,9 @@ class Plan:
             for L in stage:
                 a, lda = self._buf(self.acts, L.in_level, L.in_off, x, ldx)
                 c, ldc = self._buf(self.acts, L.out_level, L.out_off, x, ldx)
+                aux, ks = self._split_k(L, M)
                 groups.append(ops.gemm_desc(a, P.ptr(L.w_name, flat), c, M, L.N, L.K, lda, L.K, ldc,
-                                            bias=P.ptr(L.b_name, flat), act=L.act))
+                                            bias=P.ptr(L.b_name, flat), act=L.act, aux=aux.data_ptr() if ks else None, ldaux=ks))
             ops.linear_fwd(groups)
         return self.acts[len(self.widths) - 1]
 
