@@ -951,6 +951,33 @@ def test_ppo_agent_on_atari_shape():
     assert moved > 1e-3 and d <= 1e-2 * moved, (d, moved)
 
 
+def test_ppo_atari_rollout_as_one_graph_equals_the_eager_rollout():
+    """The frame provider alternates between two observation buffers (period 2) and numbers its steps from a device counter inside a
+    captured rollout (step_device(offset=t) + advance(T)): a captured rollout of an even horizon replays on the same addresses and
+    draws the same random streams as the eager loop -- two consecutive rollouts, every buffer field and the provider's state bit-equal."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    n, T = 4, 6
+    out = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        cfg = make_config(n, T, representation="AC_CNN_Atari", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                          fc_hidden_sizes=[512], actor_hidden_size=[], critic_hidden_size=[], activation="relu", n_epochs=1,
+                          n_minibatch=2, use_obsnorm=False, use_rewnorm=True, learning_rate=2.5e-4, gamma=0.99, use_hip_graph=graph)
+        agent = PPO_Agent(cfg, SyntheticAtariVecEnv(n, seed=5, max_episode_steps=5))
+        snaps = []
+        for _ in range(2):
+            agent.rollout()
+            torch.cuda.synchronize()
+            f = agent.memory.soa.fields
+            snaps.append({k: npy(v) for k, v in f.items()} | {"env_obs": npy(agent.envs.buf_obs), "env_steps": npy(agent.envs.steps)})
+        assert (agent._rollout_graph is not None) == graph
+        out.append(snaps)
+    for a, b in zip(*out):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+
+
 def test_loop_callbacks_of_the_device_loops():
     """xuance/common/callback.py:31-58 in the device loops: on_train_epochs_end after every update phase and on_train_step_end once
     per rollout (kwargs steps = horizon) by default; with config.per_step_callbacks the rollout runs as per-step launches and

@@ -232,7 +232,7 @@ def ppo_atari(steps=3, warmup=2):
                                                     "launches, xrl::ppo_loss_kernel, xrl::reduce_adam_kernel over 3.36 M parameters)",
                          "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": None, "avg_launch_us": round(us_mb, 1), "algorithmic_flops_per_launch": flops,
-                         "note": "one 'launch' = one whole minibatch update (layered path over the convolution stack); the rollout is 128 eager vector steps of 8 envs (the frame provider alternates its observation buffers and takes the step index from the host, so it is not captured into a graph): ~15 launches per step, host-bound; no reference CPU time taken for this shape"}}
+                         "note": "one 'launch' = one whole minibatch update (layered path over the convolution stack); the rollout is one captured graph of 128 vector steps of 8 envs (~15 launches per step: launch-bound at 8 envs); no reference CPU time taken for this shape"}}
 
 
 def dqn_c3(steps=60, ref=None):

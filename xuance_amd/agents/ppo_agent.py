@@ -144,7 +144,10 @@ class PPO_Agent(AgentSurface):
         ops.policy_sample(heads=heads, log_std=None, act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
                           env_action=env.action, env_action_f=None, bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A,
                           ld=A + 1, gaussian=0, seed=self.seed, step=t, step_dev=self.step_counter)
-        env.step_device()
+        if hasattr(env, "advance"):
+            env.step_device(offset=t)                               # static step index: the env's counter ticks once per rollout
+        else:
+            env.step_device()
         self.Xu8[n:].copy_(env.next_obs.view(n, -1))
         ops.rollout_poststep(**self._post_args(t, (self.obs_mean, self.obs_var, self.obs_count), None))
 
@@ -432,8 +435,11 @@ class PPO_Agent(AgentSurface):
     def _launch_rollout(self):
         if not self.use_fused_rollout:
             self._wide_acting()                                   # (allocates on first use: never inside a capture)
-        if self.use_graph and getattr(self.envs, "graph_safe", True) and not self._per_step():
+        safe = getattr(self.envs, "graph_safe", True) or (getattr(self.envs, "graph_safe_even", False) and self.horizon_size % 2 == 0)
+        if self.use_graph and safe and not self._per_step():
             if self._rollout_graph is None:
+                if self.frames:                                       # (workspaces of the convolution stack: allocated outside the capture)
+                    self.model.forward(self.Xu8, 2 * self.n_envs, keep=False)
                 torch.cuda.synchronize()
                 g = ops.Graph()
                 with g:

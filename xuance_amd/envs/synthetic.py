@@ -40,8 +40,9 @@ class SyntheticAtariVecEnv(_Base):
     vector step (xrl_synth_frames_step).  `double_buffered`: step_device() leaves the tensor that was `buf_obs` before the
     call untouched and rebinds `buf_obs` to the other of two buffers, so an agent can hand (obs, next_obs) to the replay
     ring without copying the 28 KB frames."""
-    graph_safe = False          # buf_obs alternates between two tensors: addresses change from step to step
-    double_buffered = True
+    graph_safe = False          # buf_obs alternates between two tensors: addresses change from step to step ...
+    graph_safe_even = True      # ... with period 2: a captured sequence of an EVEN number of steps (step_device(offset=t) + advance)
+    double_buffered = True      #     replays on the same addresses
 
     def __init__(self, num_envs, seed=1, device="cuda", n_actions=4, max_episode_steps=1000, p_term=0.002):
         super().__init__(num_envs, seed, device, max_episode_steps)
@@ -56,24 +57,33 @@ class SyntheticAtariVecEnv(_Base):
         self.done = torch.zeros(self.num_envs, device=device)
         self.end_step = torch.zeros(self.num_envs, dtype=torch.int32, device=device)
         self._host_step = 0
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)    # (captured rollouts: advance())
 
-    def _kw(self, cur):
+    def _kw(self, cur, offset=None):
         return dict(cur_obs=cur, next_obs=self.next_obs, action=self.action, reward=self.reward, terminated=self.terminated,
                     truncated=self.truncated, done=self.done, steps=self.steps, end_step=self.end_step, n=self.num_envs,
                     row_bytes=84 * 84 * 4, A=self.action_space.n, max_steps=self.max_episode_steps, p_term=self.p_term,
-                    seed=self.seed, step=self._host_step, step_dev=None)     # eager loops: the host knows the step index
+                    seed=self.seed, step=self._host_step if offset is None else int(offset),      # eager loops: the host knows
+                    step_dev=None if offset is None else self.step_counter)                         # the step index
 
     def reset(self):
         from .. import ops
         ops.synth_frames_step(reset=True, **self._kw(self.buf_obs))
         return self.buf_obs, [{} for _ in range(self.num_envs)]
 
-    def step_device(self):
+    def step_device(self, offset=None):
+        """offset=t: a step of a captured rollout -- step index = device counter + t, the counter ticks once per rollout through
+        advance(T) (as SyntheticMujocoVecEnv); an on-policy agent uses either this or the host-indexed form, never both."""
         from .. import ops
         self._cur ^= 1
-        ops.synth_frames_step(**self._kw(self._bufs[self._cur]))
+        ops.synth_frames_step(**self._kw(self._bufs[self._cur], offset))
         self.buf_obs = self._bufs[self._cur]
-        self._host_step += 1
+        if offset is None:
+            self._host_step += 1
+
+    def advance(self, k):
+        from .. import ops
+        ops.counter_add(self.step_counter, int(k))
 
 
 class SyntheticMujocoVecEnv(_Base):
