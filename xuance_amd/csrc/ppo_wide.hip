@@ -526,42 +526,74 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
     // ---- loads: small things first, then the weight stream
     constexpr int RV = 4;                               // rows per virtual thread of the statistics (host checks n <= RV * (1024 / D))
     const int R = 1024 / D;
+    // Every load below is UNCONDITIONAL -- an index that is not wanted reads element 0 of a valid array and the value is dropped --
+    // so that all of them are in flight together: written as `if (cond) v = p[i]` the compiler waits for each one before it
+    // requests the next ("Loads the compiler can count"): eight dependent round trips at the top of a 13 us
+    // launch that runs 256 times per rollout.
     float rawv[2][RV];
     float old_mean = 0.f, old_var = 1.f;
     double old_cnt = 0.0;
-    if (from_raw) {
-        if (p.update) {
+    {
+        const bool want_raw = from_raw && p.update;
+        const float* rawp = want_raw ? p.raw : p.params;
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int vt = tid + v * FUSED_THREADS, d = vt % D, r0 = vt / D;
+        for (int v = 0; v < 2; ++v) {
+            const int vt = tid + v * FUSED_THREADS, d = vt % D, r0 = vt / D;
 #pragma unroll
-                for (int k = 0; k < RV; ++k) {
-                    const int rr = r0 + k * R;
-                    rawv[v][k] = (r0 < R && rr < n) ? p.raw[(size_t)rr * D + d] : 0.f;
-                }
+            for (int k = 0; k < RV; ++k) {
+                const int rr = r0 + k * R;
+                const bool ok = want_raw && r0 < R && rr < n;
+                const float val = rawp[ok ? (size_t)rr * D + d : 0];
+                rawv[v][k] = ok ? val : 0.f;
             }
         }
-        if (tid < D) { old_mean = p.mean_in[tid]; old_var = p.var_in[tid]; }
-        old_cnt = *p.count_in;
-    } else if (from_next && tid < D) { old_mean = p.mean_in[tid]; old_var = p.var_in[tid]; }
+        const bool want_ms = (from_raw || from_next) && tid < D;
+        const float* mp = want_ms ? p.mean_in : p.params;
+        const float* vp = want_ms ? p.var_in : p.params;
+        const float mv = mp[want_ms ? tid : 0], vv = vp[want_ms ? tid : 0];
+        old_mean = want_ms ? mv : 0.f; old_var = want_ms ? vv : 1.f;
+        const double* cp = from_raw ? p.count_in : reinterpret_cast<const double*>(p.params);
+        const double cv = *cp;
+        old_cnt = from_raw ? cv : 0.0;
+    }
     float xv[2] = {0.f, 0.f};
     {
         const float* src = from_raw ? p.raw + (size_t)row0 * D : (from_next ? p.next_raw + (size_t)(row0 - n) * D : p.x + (size_t)row0 * D);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { const int e = tid + i * FUSED_THREADS; if (e < rows_here * D) xv[i] = src[e]; }
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * FUSED_THREADS;
+            const bool ok = e < rows_here * D;
+            const float val = src[ok ? e : 0];
+            xv[i] = ok ? val : 0.f;
+        }
     }
     uint32_t step = p.step;
-    if (p.step_dev) step += *p.step_dev;
-    float4 w2v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < nout * 16) w2v = *reinterpret_cast<const float4*>(p.params + br.w2 + (size_t)(tid >> 4) * WH + 64 * part + 4 * (tid & 15));
-    float smallv = 0.f;
-    if (tid >= 448 && tid < 448 + nout) smallv = p.params[br.b2 + tid - 448];
-    if (tid >= 456 && tid < 456 + A) smallv = p.params[p.log_std_off + tid - 456];
+    {
+        const uint32_t* sd = p.step_dev ? p.step_dev : reinterpret_cast<const uint32_t*>(p.params);
+        const uint32_t sv = *sd;
+        step += p.step_dev ? sv : 0u;
+    }
+    float4 w2v;
+    {
+        const bool ok = tid < nout * 16;
+        const float4 val = *reinterpret_cast<const float4*>(p.params + br.w2 + (size_t)(ok ? (tid >> 4) : 0) * WH + 64 * part + 4 * (tid & 15));
+        w2v = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float smallv;
+    {
+        const bool is_b2 = tid >= 448 && tid < 448 + nout, is_ls = tid >= 456 && tid < 456 + A;
+        const float val = p.params[is_ls ? p.log_std_off + tid - 456 : (is_b2 ? br.b2 + tid - 448 : 0)];
+        smallv = (is_b2 || is_ls) ? val : 0.f;
+    }
     float4 w0v[3];
     {
         const float4* w0 = reinterpret_cast<const float4*>(p.params + br.w0 + (size_t)(wave * 32) * D);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { const int c = lane + 64 * i; w0v[i] = c < 8 * D ? w0[c] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int i = 0; i < 3; ++i) {
+            const int c = lane + 64 * i;
+            const float4 val = w0[c < 8 * D ? c : 0];
+            w0v[i] = c < 8 * D ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     const float b0v = p.params[br.b0 + wave * 32 + li];
     const float b1c = p.params[br.b1 + 64 * part + (tid & 63)];        // bias of the slice column this thread finishes below
