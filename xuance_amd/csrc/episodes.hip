@@ -129,31 +129,41 @@ __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
     // wiped by the next call), RNG step counters advanced by `active`
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (g.reset_rows && t < g.n_envs * g.n_agents) g.reset_rows[t] = g.done[t / g.n_agents];
+    if (t >= 64) return;
+    // The first wave counts the finished envs together (one load per lane instead of one thread walking n_envs dependent loads),
+    // and everything lane 0 reads below is requested here, unconditionally, in one go: this launch sits on the critical path of
+    // every vector step and used to be a chain of ~8 memory round trips on a single thread.
+    int c = 0;
+    if (g.ptr_size) {
+        for (int j = t; j < g.n_envs; j += 64) c += g.done[j] != 0.f;
+        c = wave_sum(c);
+    }
     if (t != 0) return;
     int act = *g.active;                                                  // did the step that just ran count?
+    const long long tot0 = g.totals[0], tot1 = g.totals[1], bas0 = g.base[0], bas1 = g.base[1], call0 = g.call[0], call1 = g.call[1];
+    double e = *g.e_state;
+    const int ps0 = g.ptr_size ? g.ptr_size[0] : 0, ps1 = g.ptr_size ? g.ptr_size[1] : 0;
+    const int seq = g.host_flags ? *g.seq : 0;
     if (g.counters) { g.counters[0] += (unsigned)act; g.counters[1] += (unsigned)act; }
     if (g.ptr_size && act) {                                              // episode_advance_kernel's statements
-        int c = 0;
-        for (int j = 0; j < g.n_envs; ++j) c += g.done[j] != 0.f;
-        g.ptr_size[0] = (g.ptr_size[0] + c) % g.buffer_size;
-        const int sz = g.ptr_size[1] + c;
+        g.ptr_size[0] = (ps0 + c) % g.buffer_size;
+        const int sz = ps1 + c;
         g.ptr_size[1] = sz < g.buffer_size ? sz : g.buffer_size;
     }
     if (act) {
-        const long long ep = g.totals[0] - g.base[0], st = g.totals[1] - g.base[1];
+        const long long ep = tot0 - bas0, st = tot1 - bas1;
         g.snap[0] = ep; g.snap[1] = st;
-        double e = *g.e_state;
-        const double cur = (double)(g.call[0] + st);
+        const double cur = (double)(call0 + st);
         e = (e > g.end_greedy) ? g.start_greedy - g.delta_greedy * cur : g.end_greedy;
         *g.e_state = e;
         *g.eps_dev = (float)e;
-        if (ep >= g.call[1]) act = 0;
+        if (ep >= call1) act = 0;
         *g.active = act;
     }
     *g.active_f = act ? 1.f : 0.f;
     if (g.active_i) { g.active_i[0] = act; g.active_i[1] = act; }
     if (g.host_flags) {                                                   // the host's copy: slot (launch index mod ring)
-        const int k = *g.seq;
+        const int k = seq;
         *g.seq = k + 1;
         __hip_atomic_store(g.host_flags + (k % g.ring), act + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // 1 / 2; the host keeps 0 = "not yet"
     }
