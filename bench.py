@@ -79,18 +79,6 @@ def reference_cpu_baseline(key, sub=None):
         return {"value": None, "kind": "reference", "error": repr(ex)}
 
 
-def _ref_update_ms(key, what):
-    """Per-update time of the unmodified reference learner on host cores (profiles/ref_cpu_baseline.json)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "ref_cpu_baseline.json")) as f:
-            r = json.load(f)
-        return {"value": r[key], "unit": "ms per update", "cores": r["cores"], "kind": "reference",
-                "sample": what + "; unmodified reference on device 'cpu', %d threads; measured on: %s "
-                          "(profiles/ref_cpu_baseline.json, oracle/time_reference_cpu.py)" % (r["threads"], r["host"])}
-    except Exception as ex:                                  # noqa: BLE001
-        return {"value": None, "kind": "reference", "error": repr(ex)}
-
-
 def _event_time_us(fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -335,7 +323,7 @@ def main():
                 # the two remaining BASELINE configs at their per-GPU shapes (the reference's CPU time exists per update only:
                 # profiles/ref_cpu_baseline.json; no simulator for either is installed, the providers are synthetic)
                 sec["ppo_halfcheetah_shape_c4"] = bs.ppo_c4(ref=reference_cpu_baseline("ppo_halfcheetah_shape_c4"))
-                sec["dqn_atari_shape_c3"] = bs.dqn_c3(ref=_ref_update_ms("dqn_cnn_update_b32_ms", "one DQN_Learner.update, CNN, batch 32"))
+                sec["dqn_atari_shape_c3"] = bs.dqn_c3(ref=reference_cpu_baseline("dqn_atari_shape_c3"))
                 sec["ppo_atari_shape"] = bs.ppo_atari()          # (configs/ppo/atari.yaml: the uint8 rollout buffer's user)
             except Exception as ex:                          # noqa: BLE001
                 sec["error"] = repr(ex)

@@ -209,6 +209,60 @@ def ppo_c4_agent_loop(n_envs=128, calls=3):
                     "%d envs + 16 x 8 minibatch updates of %d" % (n_envs, n_envs * 32)}
 
 
+class _HostAtariShapedEnv:
+    """Host stand-in with Atari's shapes (84x84x4 uint8 frame stacks, Discrete(4)): random frames, random terminations, 1 000-step
+    cut-off -- what xuance_amd/envs/synthetic.py: SyntheticAtariVecEnv is on the GPU side (no emulator in the image: neither side times it)."""
+    max_episode_steps = 1000
+
+    def __init__(self, env_seed=None):
+        self.observation_space, self.action_space = sp.Box(0, 255, (84, 84, 4), np.uint8), sp.Discrete(4)
+        self.rng = np.random.default_rng(env_seed)
+        self.steps, self.score = 0, 0.0
+
+    def _frame(self):
+        return self.rng.integers(0, 256, (84, 84, 4), dtype=np.uint8)
+
+    def reset(self, seed=None):
+        self.steps, self.score = 0, 0.0
+        return self._frame(), {}
+
+    def step(self, action):
+        self.steps += 1
+        r = float(self.rng.random() < 0.05)
+        self.score += r
+        term = bool(self.rng.random() < 0.002)
+        return self._frame(), r, term, self.steps >= self.max_episode_steps, {"episode_step": self.steps, "episode_score": self.score}
+
+    def close(self):
+        pass
+
+
+def dqn_c3_agent_loop(n_envs=64, steps=48, calls=3):
+    """The reference's DQN_Agent.train (off_policy.py:183-262) with configs/dqn/atari.yaml at the size of BASELINE configs[2] as the
+    GPU line runs it (tools/bench_secondary.py: dqn_c3): 64 envs, batch 32, ONE update per vector step (training_frequency = n_envs),
+    a replay ring of 64 x 128 transitions (the yaml's 500 000 frames of host memory are not needed to time the loop)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import xuance.torch.agents.base.agent as agent_mod
+    from xuance.torch.agents import REGISTRY_Agents
+    from xuance_amd.envs import DummyVecEnv
+    agent_mod.SummaryWriter = _NullWriter
+    import xuance.torch.agents.core.off_policy as op
+    op.tqdm = lambda x, *a, **k: x
+    cfg = _agent_config("dqn/atari.yaml", parallels=n_envs, buffer_size=n_envs * 128, start_training=n_envs * 8,
+                        training_frequency=n_envs)
+    envs = DummyVecEnv([_HostAtariShapedEnv] * n_envs, env_seed=1)
+    envs.reset()
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs)
+        rate, all_rates = _median_rate(agent, steps, calls, lambda: agent.current_step)
+    finally:
+        os.chdir(cwd)
+    return {"env_steps_per_s": round(rate, 1), "runs": all_rates, "n_envs": n_envs,
+            "what": "reference DQN_Agent.train(%d) with configs/dqn/atari.yaml on an Atari-shaped host provider: %d vector steps of %d envs, "
+                    "one DQN_Learner.update (CNN, batch 32) per vector step" % (steps, steps, n_envs)}
+
+
 def qmix_agent_loop(n_envs, rnn, calls=3):
     """The reference's QMIX_Agents.train (off_policy_marl.py:310-424) with configs/qmix/sc2/3m.yaml.  Recurrent agents (the
     yaml default) with use_actions_mask as in the yaml crash in the reference's own update (iql_learner.py:78-81, see
@@ -258,6 +312,14 @@ def qmix_agent_loop(n_envs, rnn, calls=3):
 
 if __name__ == "__main__":
     import platform
+    if len(sys.argv) > 2 and sys.argv[2] == "c3":          # add the C3 loop line to an existing record (same host, same settings)
+        with open(sys.argv[1]) as f:
+            out = json.load(f)
+        out["dqn_atari_shape_c3"] = dqn_c3_agent_loop()
+        print(json.dumps(out["dqn_atari_shape_c3"]))
+        with open(sys.argv[1], "w") as f:
+            json.dump(out, f, indent=1)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "c4":          # add the C4 line to an existing record (same host, same settings)
         with open(sys.argv[1]) as f:
             out = json.load(f)
@@ -270,7 +332,7 @@ if __name__ == "__main__":
            "torch": torch.__version__, "numpy": np.__version__,
            "ppo_cartpole": {str(n): ppo_agent_loop(n) for n in (4, 16, 256)},
            "qmix_3m_ff": qmix_agent_loop(64, False), "qmix_3m_gru": qmix_agent_loop(64, True),
-           "ppo_halfcheetah_shape_c4": ppo_c4_agent_loop(),
+           "ppo_halfcheetah_shape_c4": ppo_c4_agent_loop(), "dqn_atari_shape_c3": dqn_c3_agent_loop(),
            "ppo_update_bs8192_ms": round(ppo(8192), 3),
            "qmix_ff_update_b32_ms": round(qmix(False), 3),
            "qmix_rnn_update_b32x60_ms": round(qmix(True), 3),
