@@ -390,6 +390,25 @@ typedef struct {
 } xrl_cartpole_t;
 int xrl_cartpole_step(const xrl_cartpole_t* p, int reset, xrl_stream_t stream);
 
+/* Device-resident Pendulum-v1 (kind 1), MountainCar-v0 (2), Acrobot-v1 (3): the other environments of the reference's
+ * configs/ppo/classic_control/*.yaml, same contract as xrl_cartpole_step.  Dynamics as published with Gymnasium's classic_control
+ * package (third-party; csrc/classic.h restates them, oracle/xrl_oracle.py is the NumPy twin).  obs: [n][3 | 2 | 6]. */
+typedef struct {
+    double* state;            /* [n][4] (Pendulum: theta, theta_dot; MountainCar: position, velocity; Acrobot: all four) */
+    int32_t* steps;           /* [n] */
+    int32_t* episodes;        /* [n] finished-episode counter (also the reset RNG counter) */
+    const int32_t* action;    /* [n] discrete action (MountainCar, Acrobot: 0 / 1 / 2) or NULL */
+    const float* action_f;    /* [n] continuous action (Pendulum: torque, clipped to +-2 here) or NULL */
+    float* obs;               /* [n][D] observation the agent sees next (after auto-reset) */
+    float* next_obs;          /* [n][D] observation returned by the step before any reset */
+    float* reward; float* terminated; float* truncated;   /* [n] */
+    float* ep_score;          /* [n] */
+    double* stats;            /* [4] finished episodes, sum of scores, sum of lengths, - */
+    int32_t n, kind, max_steps, pad;
+    uint64_t seed;
+} xrl_classic_t;
+int xrl_classic_step(const xrl_classic_t* p, int reset, xrl_stream_t stream);
+
 /* Synthetic MuJoCo-shaped vector env on the device (an input provider for the continuous-control shapes of BASELINE
  * config C4 -- no simulator is installed; NOT a reference component): state' = tanh(state.A + clip(a).B) + 0.01 N(0,1),
  * reward = state'[0] - 0.1 |a|^2, truncation after max_steps, same auto-reset contract as xrl_cartpole_step. */

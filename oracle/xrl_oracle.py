@@ -1207,6 +1207,21 @@ def cartpole_reset_state(seed, envs, episodes):
     return np.stack([-0.05 + 0.1 * u01d(r[j], q[j]) for j in range(4)], -1)
 
 
+def classic_reset_state(kind, seed, envs, episodes):
+    """classic.h classic_reset: float64 initial state [n, 4] of env `e` at the start of its `episode`-th episode.  kind 1 Pendulum-v1
+    (uniform(-[pi, 1], [pi, 1])), 2 MountainCar-v0 (position uniform(-0.6, -0.4), velocity 0), 3 Acrobot-v1 (uniform(-0.1, 0.1) x 4):
+    the ranges of Gymnasium's reset(); the random words are the engine's Philox streams."""
+    r = philox4x32(seed, envs, episodes, STREAM_RESET_A)
+    q = philox4x32(seed, envs, episodes, STREAM_RESET_B)
+    u = [u01d(r[j], q[j]) for j in range(4)]
+    z = np.zeros_like(u[0])
+    if kind == 1:
+        return np.stack([-math.pi + 2.0 * math.pi * u[0], -1.0 + 2.0 * u[1], z, z], -1)
+    if kind == 2:
+        return np.stack([-0.6 + 0.2 * u[0], z, z, z], -1)
+    return np.stack([-0.1 + 0.2 * u[j] for j in range(4)], -1)
+
+
 def action_uniforms(seed, n_envs, step):
     """The uniform the device draws for env e at global vector step `step` (xrl_policy_sample / the fused rollout kernels)."""
     return u01(philox4x32(seed, np.arange(n_envs), step, STREAM_ACTION)[0])
@@ -1221,6 +1236,115 @@ def action_gaussians(seed, n_envs, step, A):
         u1, u2 = np.maximum(u01(r[0]), np.float32(5.96e-8)), u01(r[1])
         z[:, j] = np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)
     return z
+
+
+# --------------------------------------------------------------------------------------
+# Pendulum-v1, MountainCar-v0, Acrobot-v1 (Gymnasium classic_control: pendulum.py, mountain_car.py, acrobot.py; the reference
+# pins gymnasium >= 0.28, < 1.3 in setup.py:73; third-party, not in the reference tree and not in this image).  PARITY UNPINNED: no
+# Gymnasium here to check these restatements of the published equations against -- they pin the DEVICE envs (csrc/classic.h) to
+# one NumPy statement of the same equations.  float64 state, float32 observations, vectorised over envs.
+# --------------------------------------------------------------------------------------
+class PendulumOracle:
+    max_speed, max_torque, dt, g, m, l, max_steps = 8.0, 2.0, 0.05, 10.0, 1.0, 1.0, 200
+
+    def __init__(self, state):
+        self.state = np.array(state, np.float64)[:, :2].copy()      # theta, theta_dot
+        self.steps = np.zeros(len(self.state), np.int64)
+
+    @staticmethod
+    def observe(state):
+        return np.stack([np.cos(state[:, 0]), np.sin(state[:, 0]), state[:, 1]], 1).astype(np.float32)
+
+    def step(self, action):
+        th, thdot = self.state.T
+        u = np.clip(np.asarray(action, np.float32).reshape(-1), np.float32(-self.max_torque), np.float32(self.max_torque)).astype(np.float64)
+        an = ((th + math.pi) % (2 * math.pi)) - math.pi                  # angle_normalize
+        costs = an ** 2 + 0.1 * thdot ** 2 + 0.001 * (u ** 2)
+        nthdot = thdot + (3 * self.g / (2 * self.l) * np.sin(th) + 3.0 / (self.m * self.l ** 2) * u) * self.dt
+        nthdot = np.clip(nthdot, -self.max_speed, self.max_speed)
+        nth = th + nthdot * self.dt
+        self.state = np.stack([nth, nthdot], 1)
+        self.steps += 1
+        return self.observe(self.state), (-costs).astype(np.float32), np.zeros(len(th), bool), self.steps >= self.max_steps
+
+
+class MountainCarOracle:
+    min_position, max_position, max_speed, goal_position, force, gravity, max_steps = -1.2, 0.6, 0.07, 0.5, 0.001, 0.0025, 200
+
+    def __init__(self, state):
+        self.state = np.array(state, np.float64)[:, :2].copy()      # position, velocity
+        self.steps = np.zeros(len(self.state), np.int64)
+
+    @staticmethod
+    def observe(state):
+        return state.astype(np.float32)
+
+    def step(self, action):
+        position, velocity = self.state.T.copy()
+        velocity = velocity + (np.asarray(action, np.float64) - 1) * self.force + np.cos(3 * position) * (-self.gravity)
+        velocity = np.clip(velocity, -self.max_speed, self.max_speed)
+        position = position + velocity
+        position = np.clip(position, self.min_position, self.max_position)
+        velocity = np.where((position == self.min_position) & (velocity < 0), 0.0, velocity)
+        self.state = np.stack([position, velocity], 1)
+        self.steps += 1
+        term = (position >= self.goal_position) & (velocity >= 0.0)
+        return self.observe(self.state), np.full(len(position), -1.0, np.float32), term, self.steps >= self.max_steps
+
+
+class AcrobotOracle:
+    dt, max_steps = 0.2, 500
+
+    def __init__(self, state):
+        self.state = np.array(state, np.float64).copy()             # theta1, theta2, dtheta1, dtheta2
+        self.steps = np.zeros(len(self.state), np.int64)
+
+    @staticmethod
+    def observe(s):
+        return np.stack([np.cos(s[:, 0]), np.sin(s[:, 0]), np.cos(s[:, 1]), np.sin(s[:, 1]), s[:, 2], s[:, 3]], 1).astype(np.float32)
+
+    @staticmethod
+    def _dsdt(s, a):                                                # acrobot.py: _dsdt, "book" variant
+        m1 = m2 = l1 = 1.0
+        lc1 = lc2 = 0.5
+        I1 = I2 = 1.0
+        g = 9.8
+        t1, t2, dt1, dt2 = s.T
+        d1 = m1 * lc1 ** 2 + m2 * (l1 ** 2 + lc2 ** 2 + 2 * l1 * lc2 * np.cos(t2)) + I1 + I2
+        d2 = m2 * (lc2 ** 2 + l1 * lc2 * np.cos(t2)) + I2
+        phi2 = m2 * lc2 * g * np.cos(t1 + t2 - math.pi / 2.0)
+        phi1 = (-m2 * l1 * lc2 * dt2 ** 2 * np.sin(t2) - 2 * m2 * l1 * lc2 * dt2 * dt1 * np.sin(t2)
+                + (m1 * lc1 + m2 * l1) * g * np.cos(t1 - math.pi / 2) + phi2)
+        ddt2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * dt1 ** 2 * np.sin(t2) - phi2) / (m2 * lc2 ** 2 + I2 - d2 ** 2 / d1)
+        ddt1 = -(d2 * ddt2 + phi1) / d1
+        return np.stack([dt1, dt2, ddt1, ddt2], 1)
+
+    @staticmethod
+    def _wrap(x, m, M):
+        x = x.copy()
+        diff = M - m
+        while (x > M).any():
+            x = np.where(x > M, x - diff, x)
+        while (x < m).any():
+            x = np.where(x < m, x + diff, x)
+        return x
+
+    def step(self, action):
+        s, dt = self.state, self.dt
+        a = np.asarray(action, np.float64) - 1.0                     # AVAIL_TORQUE = [-1, 0, +1]
+        k1 = self._dsdt(s, a)
+        k2 = self._dsdt(s + dt / 2.0 * k1, a)
+        k3 = self._dsdt(s + dt / 2.0 * k2, a)
+        k4 = self._dsdt(s + dt * k3, a)
+        ns = s + dt / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        ns[:, 0] = self._wrap(ns[:, 0], -math.pi, math.pi)
+        ns[:, 1] = self._wrap(ns[:, 1], -math.pi, math.pi)
+        ns[:, 2] = np.clip(ns[:, 2], -4 * math.pi, 4 * math.pi)
+        ns[:, 3] = np.clip(ns[:, 3], -9 * math.pi, 9 * math.pi)
+        self.state = ns
+        self.steps += 1
+        term = -np.cos(ns[:, 0]) - np.cos(ns[:, 1] + ns[:, 0]) > 1.0
+        return self.observe(ns), np.where(term, 0.0, -1.0).astype(np.float32), term, self.steps >= self.max_steps
 
 
 # --------------------------------------------------------------------------------------

@@ -978,6 +978,38 @@ def test_ppo_atari_rollout_as_one_graph_equals_the_eager_rollout():
             assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("name,dist", [("DevicePendulumVecEnv", "gaussian"), ("DeviceMountainCarVecEnv", "categorical"),
+                                       ("DeviceAcrobotVecEnv", "categorical")])
+def test_ppo_agent_on_the_other_classic_control_envs(name, dist):
+    """configs/ppo/classic_control/{Pendulum-v1, MountainCar-v0, Acrobot-v1}.yaml end to end on the device: the env is a device env
+    (xrl_classic_step), the rollout a captured graph of the layered step, the minibatch update the one-launch shared-trunk kernel
+    (fused_eligible) -- two iterations run, parameters move, everything stays finite, and the graph path equals the eager path
+    bit for bit (same launches, same Philox streams)."""
+    import xuance_amd.envs as envs
+    from xuance_amd.agents import PPO_Agent
+    n, T = 16, 32
+    out = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        kw = dict(activation_action="tanh") if dist == "gaussian" else {}
+        agent = PPO_Agent(make_config(n, T, use_hip_graph=graph, **kw), getattr(envs, name)(n, seed=3, max_episode_steps=20))
+        assert agent.model.dist == dist and agent.learner.fused_eligible(agent.memory)
+        p0 = agent.model.params.flat.clone()
+        infos = [agent.train(T)]
+        # acting on MORE rows than the loops use grows the dense workspaces (Plan.ensure reallocates): the captured rollout and
+        # update graphs hold the old pointers and must be captured again, not replayed (they were replayed into freed memory --
+        # the optimiser's barrier words, as it happened -- until round 3 sized the workspaces up front and added this check)
+        agent.get_actions(np.zeros((600, agent.obs_dim), np.float32))
+        infos += [agent.train(T) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert all(np.isfinite(v) for i in infos for v in i.values() if isinstance(v, float))
+        assert not torch.equal(agent.model.params.flat, p0)
+        ep, score, length = agent.envs.episode_stats()
+        assert ep >= n and 0 < length <= 20
+        out.append(npy(agent.model.params.flat))
+    assert np.array_equal(out[0], out[1])
+
+
 def test_loop_callbacks_of_the_device_loops():
     """xuance/common/callback.py:31-58 in the device loops: on_train_epochs_end after every update phase and on_train_step_end once
     per rollout (kwargs steps = horizon) by default; with config.per_step_callbacks the rollout runs as per-step launches and

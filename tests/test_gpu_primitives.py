@@ -453,3 +453,55 @@ def test_device_philox_streams_equal_the_oracle_restatement(ops, oracle):
     tie = np.abs(p0 - u) < 1e-6
     assert np.array_equal(act.cpu().numpy().astype(int)[~tie], ref[~tie]) and tie.sum() <= 1
     assert np.array_equal(env.state.cpu().numpy(), oracle.cartpole_reset_state(9, np.arange(n), 0))
+
+
+@pytest.mark.parametrize("kind,name", [(1, "DevicePendulumVecEnv"), (2, "DeviceMountainCarVecEnv"), (3, "DeviceAcrobotVecEnv")])
+def test_classic_control_device_envs_vs_oracle(oracle, kind, name):
+    """xrl_classic_step (csrc/classic_control.hip, csrc/classic.h) against the NumPy statement of the same published equations
+    (oracle/xrl_oracle.py: PendulumOracle / MountainCarOracle / AcrobotOracle): 64 envs, random actions, enough steps for cut-offs,
+    terminations and auto-resets; observations, rewards, flags per step; the float64 state within a few ulp (the device's sin / cos
+    are not NumPy's); initial and reset states bit-equal (same Philox words, same affine map)."""
+    import xuance_amd.envs as envs
+    n, seed = 64, 11
+    steps = {1: 230, 2: 230, 3: 560}[kind]
+    env = getattr(envs, name)(n, seed=seed)
+    env.reset()
+    torch.cuda.synchronize()
+    s0 = oracle.classic_reset_state(kind, seed, np.arange(n), np.zeros(n, np.int64))
+    assert np.array_equal(env.state.cpu().numpy(), s0)
+    O = {1: oracle.PendulumOracle, 2: oracle.MountainCarOracle, 3: oracle.AcrobotOracle}[kind]
+    ref = O(s0)
+    assert_close(env.buf_obs.cpu().numpy(), O.observe(ref.state), 1e-6, "initial observation")
+    rng = np.random.default_rng(5)
+    episodes = np.zeros(n, np.int64)
+    n_term = n_trunc = 0
+    for t in range(steps):
+        if kind == 1:
+            a = (rng.standard_normal((n, 1)) * 2).astype(np.float32)         # beyond +-2 as well: the env clips
+        else:
+            a = rng.integers(0, 3, n)
+            if kind == 2:
+                a = np.where(rng.random(n) < 0.7, 2 * (ref.state[:, 1] >= 0), a)   # mostly pump the car: some envs reach the flag
+        obs, rew, term, trunc, infos = env.step(a)
+        o_ref, r_ref, term_ref, trunc_ref = ref.step(a)
+        assert np.array_equal(term, term_ref) and np.array_equal(trunc, trunc_ref), t
+        assert_close(obs, o_ref, 1e-6, f"obs step {t}")
+        assert_close(rew, r_ref, 1e-6, f"reward step {t}", scale=max(1.0, float(np.abs(r_ref).max())))
+        done = term | trunc
+        n_term += int(term.sum()); n_trunc += int((trunc & ~term).sum())
+        if done.any():
+            idx = np.nonzero(done)[0]
+            episodes[idx] += 1
+            fresh = oracle.classic_reset_state(kind, seed, idx, episodes[idx])
+            ref.state[idx] = fresh[:, :ref.state.shape[1]]
+            ref.steps[idx] = 0
+            assert np.array_equal(env.state.cpu().numpy()[idx], fresh)           # the reset state: bit-equal
+            for i in idx:
+                assert_close(infos[i]["reset_obs"], O.observe(ref.state[i:i + 1])[0], 1e-6, "reset_obs")
+        live = ~done
+        dev_state = env.state.cpu().numpy()[:, :ref.state.shape[1]]
+        assert not live.any() or np.abs(dev_state[live] - ref.state[live]).max() <= 1e-9 * max(1.0, np.abs(ref.state).max()), t
+        ref.state[live] = dev_state[live]                                         # (follow the device: ulp differences must not pile up)
+    assert n_trunc > 0 and (kind == 1 or n_term > 0), (n_term, n_trunc)
+    ep, score, length = env.episode_stats()
+    assert ep == n_term + n_trunc and length > 0

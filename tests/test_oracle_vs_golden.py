@@ -1,5 +1,7 @@
 """CPU: pins oracle/xrl_oracle.py against fixtures generated from the unmodified reference
 (oracle/make_golden.py -> tests/golden/*.npz).  The oracle is the checker used by the -m gpu tests."""
+import math
+
 import numpy as np
 import pytest
 
@@ -382,3 +384,38 @@ def test_pg_update(oracle, dist):
         assert_close(info["a_loss"], cb["a_loss"], 1e-5, "a_loss", scale=float(np.abs(cb["log_prob"]).mean()))
         assert_close(info["e_loss"], cb["e_loss"], 1e-5, "e_loss")
     assert_close(opt.lr, sub(g, "u2/info")["learning_rate"], 1e-9, "lr")
+
+
+def test_classic_control_oracles_known_answers():
+    """PendulumOracle / MountainCarOracle / AcrobotOracle (oracle/xrl_oracle.py) on states whose next state follows from the
+    published equations by hand -- no Gymnasium in the image to run against (the oracle's header says so)."""
+    from oracle import xrl_oracle as o
+    m = o.MountainCarOracle(np.array([[-0.5, 0.0, 0, 0]]))
+    obs, r, term, trunc = m.step(np.array([2]))
+    v = 0.001 - 0.0025 * math.cos(-1.5)                                   # velocity += (a - 1) force - gravity cos(3 x)
+    assert np.allclose(m.state, [[-0.5 + v, v]], rtol=0, atol=1e-15) and r[0] == -1 and not term[0]
+    m = o.MountainCarOracle(np.array([[-1.2, -0.01, 0, 0]]))             # inelastic left wall
+    m.step(np.array([0]))
+    assert m.state[0, 0] == -1.2 and m.state[0, 1] == 0.0
+    m = o.MountainCarOracle(np.array([[0.49, 0.05, 0, 0]]))              # the flag
+    assert m.step(np.array([2]))[2][0]
+    p = o.PendulumOracle(np.array([[0.0, 0.0, 0, 0]]))
+    obs, r, term, trunc = p.step(np.array([[5.0]]))                       # torque clipped to 2: theta_dot' = 3 * 2 * 0.05
+    assert np.allclose(p.state, [[0.015, 0.3]], rtol=0, atol=1e-15) and abs(r[0] + 0.004) < 1e-9 and not term[0]
+    p = o.PendulumOracle(np.array([[math.pi, 0.0, 0, 0]]))               # hanging: cost pi^2 (angle_normalize(pi) = -pi)
+    assert abs(p.step(np.array([[0.0]]))[1][0] + math.pi ** 2) < 1e-5
+    p = o.PendulumOracle(np.array([[1.0, 7.9, 0, 0]]))                   # speed clipped at 8
+    p.step(np.array([[2.0]]))
+    assert p.state[0, 1] == 8.0
+    a = o.AcrobotOracle(np.zeros((1, 4)))                                 # at rest hanging down: stays (cos(-pi/2) ~ 6e-17)
+    obs, r, term, trunc = a.step(np.array([1]))
+    assert np.abs(a.state).max() < 1e-15 and r[0] == -1 and not term[0]
+    assert np.allclose(obs, [[1, 0, 1, 0, 0, 0]], atol=1e-7)
+    a = o.AcrobotOracle(np.array([[math.pi - 0.01, 0.0, 0.0, 0.0]]))      # nearly upright: -cos(t1) - cos(t1 + t2) > 1
+    assert a.step(np.array([1]))[2][0]
+    s = o.classic_reset_state(1, 3, np.arange(64), np.zeros(64, np.int64))
+    assert (np.abs(s[:, 0]) <= math.pi).all() and (np.abs(s[:, 1]) <= 1).all() and s[:, 0].std() > 1.0
+    s = o.classic_reset_state(2, 3, np.arange(64), np.zeros(64, np.int64))
+    assert ((s[:, 0] >= -0.6) & (s[:, 0] <= -0.4)).all() and (s[:, 1:] == 0).all()
+    s = o.classic_reset_state(3, 3, np.arange(64), np.zeros(64, np.int64))
+    assert (np.abs(s) <= 0.1).all() and s.std() > 0.03

@@ -80,6 +80,13 @@ class CartPole(C.Structure):
                 ("max_steps", c_int), ("seed", C.c_uint64)]
 
 
+class Classic(C.Structure):
+    _fields_ = [("state", c_void_p), ("steps", c_void_p), ("episodes", c_void_p), ("action", c_void_p), ("action_f", c_void_p),
+                ("obs", c_void_p), ("next_obs", c_void_p), ("reward", c_void_p), ("terminated", c_void_p), ("truncated", c_void_p),
+                ("ep_score", c_void_p), ("stats", c_void_p), ("n", c_int32), ("kind", c_int32), ("max_steps", c_int32),
+                ("pad", c_int32), ("seed", C.c_uint64)]
+
+
 class PostStep(C.Structure):
     _fields_ = [("reward", c_void_p), ("terminated", c_void_p), ("truncated", c_void_p), ("next_obs", c_void_p),
                 ("obs_mean", c_void_p), ("obs_var", c_void_p), ("next_obs_norm", c_void_p), ("rew_out", c_void_p),
@@ -335,6 +342,7 @@ _SIGS = {
     "xrl_obs_normalize": [C.POINTER(Rms), c_void_p],
     "xrl_policy_sample": [C.POINTER(Sample), c_void_p],
     "xrl_cartpole_step": [C.POINTER(CartPole), c_int, c_void_p],
+    "xrl_classic_step": [C.POINTER(Classic), c_int, c_void_p],
     "xrl_rollout_poststep": [C.POINTER(PostStep), c_void_p],
     "xrl_egreedy": [C.POINTER(EGreedy), c_void_p],
     "xrl_counter_add": [c_void_p, C.c_uint32, c_void_p],

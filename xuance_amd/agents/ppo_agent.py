@@ -66,9 +66,12 @@ class PPO_Agent(AgentSurface):
             assert not self.use_obsnorm, "uint8 frames are stored and fed as they are (configs/ppo/atari.yaml: use_obsnorm False)"
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)   # RNG counter base, advanced per rollout
         self.perm_counter = torch.zeros(1, dtype=torch.int32, device=dev)   # one tick per update phase (index generation)
-        self.model.plan.ensure(2 * n)
         self.buffer_size = n * self.horizon_size
         self.batch_size = self.buffer_size // self.n_minibatch
+        # the dense workspaces at their FINAL size before anything is captured: Plan.ensure reallocates when it grows, and a
+        # rollout graph captured at 2 n rows would keep writing to the old (freed, soon reused) activations once the learner's
+        # first update had asked for minibatch rows
+        self.model.plan.ensure(max(2 * n, self.batch_size, self.buffer_size - self.n_minibatch * self.batch_size))
         self.idx = torch.zeros(self.n_epochs * self.n_minibatch, self.batch_size, dtype=torch.int64, device=dev)
         # buffer_size not divisible by n_minibatch: the reference's loop `range(0, buffer_size, batch_size)` ends every epoch
         # with one SHORT minibatch of the remaining transitions (on_policy.py:198-203)
@@ -432,12 +435,19 @@ class PPO_Agent(AgentSurface):
         t += [getattr(env, k) for k in ("state", "steps", "episodes", "ep_score", "stats", "buf_obs")]
         return t + list(self.pp.values())
 
+    def _ws_sig(self):
+        """Changes whenever a workspace a captured graph may point into was reallocated (Plan.ensure grew, a convolution
+        workspace was replaced by a larger one -- e.g. get_actions on more rows than the loops use)."""
+        return (self.model.plan.cap, getattr(getattr(self.model, "conv", None), "ws_gen", 0))
+
     def _launch_rollout(self):
         if not self.use_fused_rollout:
             self._wide_acting()                                   # (allocates on first use: never inside a capture)
         safe = getattr(self.envs, "graph_safe", True) or (getattr(self.envs, "graph_safe_even", False) and self.horizon_size % 2 == 0)
         if self.use_graph and safe and not self._per_step():
-            if self._rollout_graph is None:
+            if self._rollout_graph is not None and self._ws_sig() != self._rollout_cap:
+                self._rollout_graph = None        # the dense workspaces grew since the capture (a larger get_actions batch):
+            if self._rollout_graph is None:       # the old graph holds freed pointers -- capture again
                 if self.frames:                                       # (workspaces of the convolution stack: allocated outside the capture)
                     self.model.forward(self.Xu8, 2 * self.n_envs, keep=False)
                 torch.cuda.synchronize()
@@ -445,6 +455,7 @@ class PPO_Agent(AgentSurface):
                 with g:
                     self._enqueue_rollout()
                 self._rollout_graph = g
+                self._rollout_cap = self._ws_sig()
             self._rollout_graph.launch()
         else:
             self._enqueue_rollout()
@@ -547,6 +558,8 @@ class PPO_Agent(AgentSurface):
         if multi:
             self._update_distributed()
         elif self.use_graph:
+            if self._update_graph is not None and self._ws_sig() != self._update_cap:
+                self._update_graph = None         # (see _launch_rollout)
             if self._update_graph is None:
                 if self.rem:
                     self.learner.prepare_buffer_update(self.memory, self.batch_size)
@@ -560,6 +573,7 @@ class PPO_Agent(AgentSurface):
                 with g:
                     self._enqueue_update()
                 self._update_graph = g
+                self._update_cap = self._ws_sig()
             self._update_graph.launch()
         else:
             self._enqueue_update()

@@ -888,6 +888,7 @@ class ConvStack:
             H, W, C = OH, OW, F
         self.n_feat = filters[-1] * (H * W if self.flatten else 1)
         self._ws = {}
+        self.ws_gen = 0
         self.implicit = implicit and self._implicit_eligible()
         if self.implicit:
             self._build_image_maps()
@@ -1033,6 +1034,8 @@ class ConvStack:
     def workspace(self, tag, rows, keep):
         ws = self._ws.get(tag)
         if ws is None or ws.rows < rows:
+            if ws is not None:
+                self.ws_gen += 1                       # a workspace was REPLACED: captured graphs that used it hold freed pointers
             ws = self._ws[tag] = ConvStack.Workspace(self, rows, keep)
         return ws
 

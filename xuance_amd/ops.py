@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Conv, ImageJob, DqnHeadTd, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Conv, ImageJob, DqnHeadTd, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -383,6 +383,11 @@ def policy_sample(**kw):
 
 def cartpole_step(reset=False, **kw):
     call("xrl_cartpole_step", C.byref(_struct(CartPole, kw)), int(bool(reset)), stream_ptr())
+
+
+def classic_step(reset=False, **kw):
+    """Pendulum-v1 / MountainCar-v0 / Acrobot-v1 on the device (xrl_classic_step; kind 1 / 2 / 3)."""
+    call("xrl_classic_step", C.byref(_struct(Classic, kw)), int(bool(reset)), stream_ptr())
 
 
 def synth_control_step(reset=False, **kw):
