@@ -284,6 +284,12 @@ typedef struct {
     int64_t fold_off;       /* xrl_reduce_adam only: slab columns [fold_off, fold_off + fold_len) are a second partial of */
     int32_t fold_len;       /* columns [0, fold_len) (ppo_split_kernel's critic-role first-layer gradient); 0 = none */
     int32_t pad;
+    /* xrl_reduce_adam[_exchange] only -- two bookkeeping launches of an update phase riding in the optimiser launch (one of
+     * its blocks does them next to its slab loads; at the DQN-C3 update they were 8 of 150 us as launches of their own): */
+    uint32_t* tick;         /* NULL, or a device counter advanced by tick_inc (xrl_counter_add: the replay draw counter) */
+    const double* part;     /* NULL, or [part_rows][8] float64 loss partials ... */
+    double* part_out;       /* ... summed row by row into part_out[8] (xrl_sum_partials, same order) */
+    int32_t tick_inc, part_rows;
 } xrl_mirrors_t;
 int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
                           const double* sumsq_part, int n_part, double max_norm, const xrl_mirrors_t* mirrors,

@@ -288,7 +288,8 @@ class MarlGate(C.Structure):
 
 class Mirrors(C.Structure):
     _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("target_every", c_int32), ("target", c_void_p),
-                ("target_image", c_void_p), ("fold_off", c_int64), ("fold_len", c_int32), ("pad", c_int32)]
+                ("target_image", c_void_p), ("fold_off", c_int64), ("fold_len", c_int32), ("pad", c_int32), ("tick", c_void_p),
+                ("part", c_void_p), ("part_out", c_void_p), ("tick_inc", c_int32), ("part_rows", c_int32)]
 
 
 class MarlAct(C.Structure):

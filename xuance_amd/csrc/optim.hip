@@ -196,6 +196,25 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
     const int grp = threadIdx.x >> 8, tg = threadIdx.x & 255;
     const int vb = blockIdx.x * G + grp, n_vb = (int)((P / 4 + 63) / 64);
     if (XC && threadIdx.x == 0) s_xfail = 0;
+    // bookkeeping of the update phase that used to be launches of their own (xrl_mirrors_t.tick / .part): the last block
+    // (the one with the fewest parameters) does it while its slab loads are in flight
+    if (blockIdx.x == gridDim.x - 1) {
+        if (mir.part_out && threadIdx.x < 8) {
+            const double* pp = mir.part + threadIdx.x;
+            double s = 0.0;
+            int r = 0;
+            for (; r + 8 <= mir.part_rows; r += 8) {                     // xrl_sum_partials' order: row by row
+                double w8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w8[q] = pp[(size_t)(r + q) * 8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += w8[q];
+            }
+            for (; r < mir.part_rows; ++r) s += pp[(size_t)r * 8];
+            mir.part_out[threadIdx.x] = s;
+        }
+        if (mir.tick && threadIdx.x == 64) *mir.tick += (unsigned)mir.tick_inc;
+    }
     const int64_t P4 = P / 4, st4 = slab_stride / 4;
     const int pq = tg & 63, sg = tg >> 6;
     const int64_t qi = (int64_t)vb * 64 + pq;
@@ -444,6 +463,7 @@ extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t
     XRL_CHECK_ARG(mir.target_image == nullptr || (mir.n >= 1 && mir.target));
     XRL_CHECK_ARG(mir.fold_len >= 0 && (mir.fold_len & 3) == 0 && (mir.fold_off & 3) == 0 &&
                   (mir.fold_len == 0 || (mir.fold_off >= P && mir.fold_off + mir.fold_len <= slab_stride && mir.fold_len <= P)));
+    XRL_CHECK_ARG((mir.part == nullptr) == (mir.part_out == nullptr) && (mir.part == nullptr || mir.part_rows >= 1));
     if (exchange && exchange->world > 1) {
         const xrl_exchange_t& xc = *exchange;
         XRL_CHECK_ARG(xc.world <= XRL_XC_MAX_RANKS && xc.rank >= 0 && xc.rank < xc.world && n_vb <= XRL_XC_MAX_GROUPS);

@@ -65,10 +65,25 @@ class DQN_Learner(Learner):
         if not self.needs_collective() and self._fused_optimizer_ok(self.gradient_exchange() is not None):
             # slab reduction (+ the average over the ranks, inside the launch) + norm + clip + Adam + LinearLR + periodic
             # hard target update (:50-57) in ONE launch
-            ops.reduce_adam(self.slabs, S_opt, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, [],
+            # (a one-update phase's draw-counter tick and loss sums ride in the same launch: update_from_buffer)
+            tail = self._tail(S_loss) if getattr(self, "_tail", None) else {}
+            conv = getattr(model, "conv", None)
+            mirrors, timg = [], None
+            if conv is not None and conv.implicit and getattr(self.config, "use_live_weight_images", True):
+                # the convolution stack's fragment-ordered weight images follow the step inside this launch (and the target's
+                # image the periodic hard update): the passes stop rebuilding them (xrl_gather_images, ~5 us per update / act)
+                inv_f, inv_d = conv.inverse_maps()
+                img_e, img_t = conv.images(None)[0], conv.images(model.target_flat)[0]
+                mirrors, timg = [(inv_f, img_e), (inv_d, img_e)], img_t
+            ops.reduce_adam(self.slabs, S_opt, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, mirrors,
                             self.opt_sync, target=model.target_flat, target_every=self.sync_frequency,
-                            exchange=self.gradient_exchange())
+                            exchange=self.gradient_exchange(), target_image=timg, **tail)
+            if mirrors:
+                conv.mark_live(model.params.flat, model.target_flat)
+            self._tail_done = bool(tail)
             return S_loss
+        if getattr(model, "conv", None) is not None:
+            model.conv.invalidate()
         ops.grad_reduce(self.slabs, S_opt, P, P, opt.grad, self.sumsq)
         if self.distributed_training and self.world_size > 1:
             from ..dist import allreduce_mean_
@@ -88,6 +103,12 @@ class DQN_Learner(Learner):
         step while the update runs; `flush_info()` later returns the info of the last phase launched."""
         M, dev = memory.batch_size, self.model.params.device
         key = (id(memory), n_epochs, M)
+        conv = getattr(self.model, "conv", None)
+        if conv is not None and conv.implicit and getattr(self, "_buf_graph", None) is not None:
+            flats = (self.model.params.flat, self.model.target_flat)
+            if not all(conv.is_live(f) for f in flats):     # load_state_dict / copy_target / an adopted module wrote parameters:
+                conv.pack_images([(None, True), (flats[1], False)])   # the captured phase has no xrl_gather_images in it (the
+                conv.mark_live(*flats)                                # optimiser launch keeps the weight images current)
         if getattr(self, "_buf_graph_key", None) != key:
             self._ensure(M)
             self._idx = torch.zeros(M, dtype=torch.int64, device=dev)
@@ -102,12 +123,19 @@ class DQN_Learner(Learner):
 
             def enqueue():
                 # per update: draw, gather, step; the draw counter and the loss sums are settled once per phase
+                self._tail_done = False
                 for e in range(n_epochs):
                     memory.draw_into(self._idx, dst, seed, e, self._sample_counter)     # draw + gather: one launch
                     self.partials = self._phase_partials[e]
-                    S = self._step(M, self._act, self._rew, self._ter)
-                ops.counter_add(self._sample_counter, n_epochs)
-                ops.sum_partials_batched(self._phase_partials, S, 8, self._epoch_sums, n_epochs, 32 * 8, 8)
+                    if n_epochs == 1:                       # (one update per phase -- the DQN loops: both ride in the optimiser launch)
+                        self._tail = lambda S: dict(tick=(self._sample_counter, 1), partials=(self._phase_partials[0], S, self._epoch_sums[0]))
+                    try:
+                        S = self._step(M, self._act, self._rew, self._ter)
+                    finally:
+                        self._tail = None
+                if not self._tail_done:
+                    ops.counter_add(self._sample_counter, n_epochs)
+                    ops.sum_partials_batched(self._phase_partials, S, 8, self._epoch_sums, n_epochs, 32 * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
             if not self.needs_collective():

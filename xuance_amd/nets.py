@@ -889,6 +889,7 @@ class ConvStack:
         self.n_feat = filters[-1] * (H * W if self.flatten else 1)
         self._ws = {}
         self.ws_gen = 0
+        self._live, self.owner = {}, None
         self.implicit = implicit and self._implicit_eligible()
         if self.implicit:
             self._build_image_maps()
@@ -962,6 +963,51 @@ class ConvStack:
             img = self._images[flat.data_ptr()] = torch.zeros(self._n_img, device=self.params.device)
         return img, (flat, self._map, img, self._n_img if with_dx else self._n_fwd)
 
+    # -- images kept current by the optimiser launch (xrl_reduce_adam's mirrors) instead of being rebuilt by every pass ---------
+    def inverse_maps(self):
+        """(parameter -> forward-image position, parameter -> input-gradient-image position), int32 [flat.numel()], -1 = none:
+        what xrl_mirrors_t.map wants.  A weight sits once in each of the two image sections."""
+        if getattr(self, "_inv", None) is None:
+            m = self._map.cpu().numpy().astype(np.int64)
+            inv = []
+            for lo, hi in ((0, self._n_fwd), (self._n_fwd, self._n_img)):
+                a = np.full(self.params.flat.numel(), -1, np.int32)
+                sec = m[lo:hi]
+                ok = sec >= 0
+                assert len(np.unique(sec[ok])) == int(ok.sum()), "a weight sits twice in one image section"
+                a[sec[ok]] = (np.arange(lo, hi)[ok]).astype(np.int32)
+                inv.append(torch.from_numpy(a).to(self.params.device))
+            self._inv = tuple(inv)
+        return self._inv
+
+    def _version(self):
+        return getattr(getattr(self, "owner", None), "version", 0)
+
+    def is_live(self, flat=None):
+        """The image of `flat` is current: the last writer of these parameters was an optimiser launch that mirrored its step
+        into the image (mark_live), and nobody has bumped the owning network's `version` since."""
+        flat = self.params.flat if flat is None else flat
+        return self._live.get(flat.data_ptr(), None) == self._version()
+
+    def mark_live(self, *flats):
+        for f in flats:
+            self._live[f.data_ptr()] = self._version()
+
+    def invalidate(self):
+        self._live.clear()
+
+    def pack_images(self, jobs):
+        """xrl_gather_images for the jobs whose image is not live (jobs: [(flat or None, with_dx)]) -> the image tensors."""
+        out, todo = [], []
+        for flat, with_dx in jobs:
+            img, job = self.images(flat, with_dx)
+            out.append(img)
+            if not self.is_live(flat):
+                todo.append(job)
+        if todo:
+            ops.gather_images(todo)
+        return out
+
     @staticmethod
     def _k_split(rows):
         strips = (rows + 31) // 32
@@ -978,8 +1024,7 @@ class ConvStack:
         if self.geo[0][2] < 16 and x.dtype != torch.uint8:
             raise ValueError("implicit-GEMM convolutions read 4-channel frames as uint8 (the replay ring's format); build the network "
                              "with implicit_conv=False for float32 frames")
-        img, job = self.images(flat, with_dx=ws.keep)
-        ops.gather_images([job])
+        img, = self.pack_images([(flat, ws.keep)])
         ws.x_in = x
         for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
             ops.conv_fwd([self._fwd_group(i, x, rows, img, flat, ws.y[i])], self._k_split(rows * OH * OW))
@@ -1070,9 +1115,7 @@ class ConvStack:
         P = self.params
         tot = Re + M
         if self.implicit:
-            img_e, job_e = self.images(None)
-            img_t, job_t = self.images(flat_t, with_dx=False)
-            ops.gather_images([job_e, job_t])
+            img_e, img_t = self.pack_images([(None, True), (flat_t, False)])
             ws.x_in = x
             xe, xt = x, x[M:]
             for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
@@ -1294,6 +1337,7 @@ class DeepQCNN:
         self.ref_order = rep + ["target_" + k for k in rep] + head + ["target_Q_head." + k[len("eval_Q_head."):] for k in head]
         self.trainable_order = rep + head
         self.conv = ConvStack(self.params, self.conv_names, self.obs_shape, self.kernels, self.strides, self.filters, implicit=implicit_conv)
+        self.conv.owner = self
         if init:
             for name in order:
                 v = self.params.view(name)
@@ -1302,8 +1346,19 @@ class DeepQCNN:
 
     _target_key = DeepQNet._target_key
     state_dict = DeepQNet.state_dict
-    load_state_dict = DeepQNet.load_state_dict
-    copy_target = DeepQNet.copy_target
+
+    def load_state_dict(self, sd):
+        DeepQNet.load_state_dict(self, sd)
+        self.touched()
+
+    def copy_target(self):
+        DeepQNet.copy_target(self)
+        self.touched()
+
+    def touched(self):
+        """Somebody other than a mirroring optimiser launch wrote the parameters: the convolution stack's weight images are
+        rebuilt by the next pass (ConvStack.is_live compares `version`)."""
+        self.version = getattr(self, "version", 0) + 1
 
     def forward(self, x_u8, M, ldx=None):
         """Rows [0, M) are differentiated through (eval Q of obs); returns Q [rows, n_actions]."""

@@ -239,11 +239,17 @@ def adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, max_norm, mirror
 
 
 def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, max_norm, mirrors, sync, target=None,
-                target_every=0, fold=None, exchange=None, target_image=None):
+                target_every=0, fold=None, exchange=None, target_image=None, tick=None, partials=None):
     """grad_reduce + clip + Adam + mirrors (+ the periodic hard target update) in one launch (blocks meet at a counter
-    barrier); same numbers.  exchange: a dist.GradientExchange -- the ranks average their gradients inside the launch."""
+    barrier); same numbers.  exchange: a dist.GradientExchange -- the ranks average their gradients inside the launch.
+    tick = (counter tensor, increment), partials = (float64 [rows, 8] tensor, rows, float64 [8] out): xrl_counter_add and
+    xrl_sum_partials of an update phase done by one block of this launch instead of by launches of their own."""
     mir = Mirrors()
     mir.n = len(mirrors)
+    if tick is not None:
+        mir.tick, mir.tick_inc = tick[0].data_ptr(), int(tick[1])
+    if partials is not None:
+        mir.part, mir.part_rows, mir.part_out = partials[0].data_ptr(), int(partials[1]), partials[2].data_ptr()
     for q, (mp, dst) in enumerate(mirrors):
         mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
     if target is not None and target_every > 0:
