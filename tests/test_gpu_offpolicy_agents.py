@@ -382,6 +382,47 @@ def test_dqn_graph_update_phase_equals_eager_updates_on_the_same_indices(atari):
     assert np.abs(pa).max() > 0 and np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(ia, ib)
 
 
+def test_dqn_cnn_weight_images_kept_by_the_optimiser_launch_equal_rebuilt_ones():
+    """The convolution stack's fragment-ordered weight images: kept current by xrl_reduce_adam's mirrors (and the target's image by
+    the in-launch hard update) against rebuilt by xrl_gather_images in every pass (config.use_live_weight_images: False) -- one
+    update per captured phase (the draw-counter tick and the loss sums ride in the optimiser launch as well), acting in between,
+    and writers the optimiser does not see: load_state_dict and copy_target bump the network's version, the next phase re-packs
+    before its graph runs.  Bit-equal parameters, targets, losses and stored actions."""
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    n = 8
+    cfg = dict(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+               q_hidden_size=[512], activation="relu", seed=1, parallels=n, running_steps=10 ** 6, buffer_size=n * 64, batch_size=16,
+               learning_rate=1e-3, gamma=0.99, start_greedy=0.3, end_greedy=0.05, decay_step_greedy=10 ** 5, sync_frequency=3,
+               training_frequency=1, start_training=10 ** 9, n_epochs=1, use_grad_clip=False, use_obsnorm=False, use_rewnorm=False,
+               distributed_training=False, device="cuda", model_dir="/tmp/x")
+    res = []
+    for live in (True, False):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        agent = DQN_Agent(Namespace(use_live_weight_images=live, **cfg), SyntheticAtariVecEnv(n, seed=2))
+        agent.train(20)
+        lr, mem, net = agent.learner, agent.memory, agent.model
+        infos = [lr.update_from_buffer(mem, 1, seed=5) for _ in range(4)]
+        assert lr._buf_graph is not None and net.conv.is_live() == live and net.conv.is_live(net.target_flat) == live
+        agent.train(6)                                       # acting on the current weights (no updates: start_training)
+        sd = {k: v * 0.5 for k, v in net.state_dict().items()}
+        net.load_state_dict(sd)
+        assert not net.conv.is_live()
+        infos += [lr.update_from_buffer(mem, 1, seed=5) for _ in range(2)]
+        net.copy_target()
+        infos += [lr.update_from_buffer(mem, 1, seed=5) for _ in range(2)]
+        agent.train(3)
+        torch.cuda.synchronize()
+        assert lr.iterations == 8
+        res.append((net.params.flat.cpu().numpy().copy(), net.target_flat.cpu().numpy().copy(),
+                    np.array([[i["Qloss"], i["predictQ"]] for i in infos]), mem.soa.fields["actions"].cpu().numpy().copy()
+                    if hasattr(mem, "soa") else None))
+    (pa, ta, ia, aa), (pb, tb, ib, ab) = res
+    assert np.abs(pa).max() > 0 and np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(ia, ib)
+    assert aa is None or np.array_equal(aa, ab)
+
+
 def _rnn_cfg(**kw):
     c = dict(q_hidden_size=[64], fc_hidden_sizes=[64], recurrent_hidden_size=64, hidden_dim_mixing_net=32,
              hidden_dim_hyper_net=32, activation="relu", seed=1, parallels=8, running_steps=10 ** 6, buffer_size=64,

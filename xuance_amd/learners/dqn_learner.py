@@ -104,7 +104,8 @@ class DQN_Learner(Learner):
         M, dev = memory.batch_size, self.model.params.device
         key = (id(memory), n_epochs, M)
         conv = getattr(self.model, "conv", None)
-        if conv is not None and conv.implicit and getattr(self, "_buf_graph", None) is not None:
+        if conv is not None and conv.implicit and getattr(self.config, "use_live_weight_images", True) \
+                and getattr(self, "_buf_graph", None) is not None:
             flats = (self.model.params.flat, self.model.target_flat)
             if not all(conv.is_live(f) for f in flats):     # load_state_dict / copy_target / an adopted module wrote parameters:
                 conv.pack_images([(None, True), (flats[1], False)])   # the captured phase has no xrl_gather_images in it (the
