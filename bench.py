@@ -193,6 +193,34 @@ def cpu_baseline(n_envs, horizon, budget_s=20.0):
                       "(NumPy, %d BLAS threads, %.1f s)" % (r["rollouts"], n_envs, horizon, threads, r["seconds"])}
 
 
+def box_yardstick():
+    """Two fixed measurements of the BOX this run landed on -- not of this library: a 256 MB device copy (HBM rate) and a
+    chain of 400 one-thread launches on one stream (what a small dependent launch costs here).  Fresh boxes of the pool
+    differ (the same library gave a 147-149 us DQN-C3 update graph on some and 178-179 us on
+    others); every launch-bound line of this JSON scales with the second number, so it is recorded next to them."""
+    from xuance_amd import ops
+    x = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    y = torch.empty_like(x)
+    c = torch.zeros(1, dtype=torch.int32, device="cuda")
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for _ in range(3):
+        y.copy_(x)
+    for _ in range(50):
+        ops.counter_add(c, 1)
+    torch.cuda.synchronize()
+    e[0].record()
+    for _ in range(10):
+        y.copy_(x)
+    e[1].record()
+    e[2].record()
+    for _ in range(400):
+        ops.counter_add(c, 1)
+    e[3].record()
+    torch.cuda.synchronize()
+    return {"copy_GBps": round(10 * 2 * x.numel() * 4 / (e[0].elapsed_time(e[1]) * 1e-3) / 1e9, 1),
+            "small_launch_us": round(e[2].elapsed_time(e[3]) * 1e3 / 400, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +278,11 @@ def main():
         out["config"]["gradient_paths_ms"] = paths_ms
         out["config"]["rccl_world"] = bw.rccl_world(world)
         out["config"]["backend"] = dist.get_backend()
+    if rank == 0:
+        try:
+            out["config"]["box"] = box_yardstick()
+        except Exception as ex:                                    # (a yardstick must never cost the line)
+            out["config"]["box"] = {"error": repr(ex)[:200]}
     # the update-phase rate separately (transitions consumed per second by GAE + sampling + the
     # minibatch updates), so that the simulator's share is separable.  Timed after the contract region, same graphs.
     phases = None

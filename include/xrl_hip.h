@@ -812,6 +812,33 @@ typedef struct {
     int32_t M, A, H, ld_h, ld_q, double_q, act, pad;
     float gamma, pad2;
 } xrl_dqn_head_td_t;
+
+/* xrl_dqn_head_td extended backwards to the last convolution's output and forwards to the convolution stack's incoming gradient
+ * (Basic_CNN, cnn.py:11-50: AdaptiveMaxPool2d((1,1)) over P = OH*OW positions of F = 64 filters; BasicQhead F -> H -> n_actions,
+ * q_head.py:8-39): pool of the frames of transition m, hidden layer of the eval and the target network, xrl_dqn_head_td's part,
+ * d_feat = d_h . W1, and the pool's backward into dY of the last convolution -- one launch, one workgroup per transition. */
+typedef struct {
+    const float* y_eval;       /* [M or 2M frames][P][F] last convolution's (relu) output, eval network: obs | next_obs (double-Q) */
+    const float* y_target;     /* [M][P][F] target network on next_obs */
+    float* feat_eval;          /* [M or 2M][ld_f] pooled features, written (the hidden layer's weight gradient reads rows [0, M)) */
+    float* feat_target;        /* NULL or [M][ld_f] */
+    int32_t* arg;              /* NULL or [M][F] first-maximum positions of the eval(obs) frames */
+    const float* w1_eval; const float* b1_eval; const float* w1_target; const float* b1_target;   /* [H][F], [H] */
+    const float* w2_eval; const float* b2_eval; const float* w2_target; const float* b2_target;   /* [A][H], [A] */
+    const float* actions; const float* rewards; const float* terminals;                           /* [M] f32 */
+    float* q_eval;             /* [M or 2M][ld_q] written */
+    float* q_target;           /* [M][ld_q] written */
+    float* d_q;                /* [M][ld_q] */
+    float* h_eval;             /* [M or 2M][ld_h] hidden activations, written */
+    float* d_h;                /* [M][ld_h] */
+    float* d_feat;             /* NULL or [M][ld_f] */
+    float* dy;                 /* [M][P][F] gradient w.r.t. the last convolution's pre-activation output */
+    float* diag;               /* NULL or [2M] */
+    double* partials;          /* [M][8] */
+    int32_t M, A, H, F, P, ld_h, ld_q, ld_f, double_q, act;
+    float gamma, pad;
+} xrl_dqn_tail_td_t;
+int xrl_dqn_tail_td(const xrl_dqn_tail_td_t* p, xrl_stream_t stream);
 int xrl_dqn_head_td(const xrl_dqn_head_td_t* p, xrl_stream_t stream);
 
 /* QMIX_Learner.update between the per-agent Q-networks and the hyper-networks

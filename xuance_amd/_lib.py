@@ -40,6 +40,14 @@ class DqnHeadTd(C.Structure):
                 ("act", c_int32), ("pad", c_int32), ("gamma", c_float), ("pad2", c_float)]
 
 
+class DqnTailTd(C.Structure):
+    _fields_ = [(k, c_void_p) for k in ("y_eval", "y_target", "feat_eval", "feat_target", "arg", "w1_eval", "b1_eval", "w1_target",
+                                        "b1_target", "w2_eval", "b2_eval", "w2_target", "b2_target", "actions", "rewards", "terminals",
+                                        "q_eval", "q_target", "d_q", "h_eval", "d_h", "d_feat", "dy", "diag", "partials")] + \
+               [(k, c_int32) for k in ("M", "A", "H", "F", "P", "ld_h", "ld_q", "ld_f", "double_q", "act")] + \
+               [("gamma", c_float), ("pad", c_float)]
+
+
 class ImageJob(C.Structure):
     _fields_ = [("src", c_void_p), ("map", c_void_p), ("dst", c_void_p), ("n", C.c_int64)]
 
@@ -355,6 +363,7 @@ _SIGS = {
     "xrl_maxpool_hw_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_reduce_adam_fits": [c_int64, c_int],
     "xrl_dqn_head_td": [c_void_p, c_void_p],
+    "xrl_dqn_tail_td": [c_void_p, c_void_p],
     "xrl_conv_fwd": [c_void_p, c_int, c_int, c_void_p],
     "xrl_conv_fwd_probe": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrl_conv_bwd_weight": [c_void_p, c_int, c_int, C.c_int64, c_void_p],

@@ -128,6 +128,208 @@ __global__ void __launch_bounds__(256) dqn_head_td_kernel(xrl_dqn_head_td_t p) {
     }
 }
 
+// Everything between the last convolution and the convolution stack's backward pass of a DQN update on Basic_CNN features
+// (cnn.py:11-50 -> q_head.py:8-39 -> dqn_learner.py:39-46), ONE launch, one workgroup per transition m:
+//   global max-pool of the three frames the transition needs (eval(obs), target(next_obs), eval(next_obs) under double-Q)
+//   -> hidden layer F -> H of both networks -> Q layer -> TD rule, loss terms, dQ -> d_h -> d_feat = d_h . W1
+//   -> the pool's backward: dY of the last convolution (the gradient lands on the first maximum, times relu').
+// At batch 32 these were six launches (pool 4.8, grouped dense GEMM 9.0, xrl_dqn_head_td 9.7, backward-data 8.9, pool backward 4.8 us
+// + their boundaries) for 0.2 MFLOP per transition.  Lane mapping of the two F x H products: 16 lanes share a weight row (one
+// 256-byte line, a float4 each), a wave covers 4 rows per load instruction (1 KB contiguous), the workgroup's waves 4 rows each per round.  The eval matrix is loaded ONCE, all rounds up front (H / 16 float4 per lane), and stays in registers for the
+// backward product; the forward partial sums meet through a quad reduction (DPP) + LDS, the backward ones (one float4 of
+// d_feat per lane, summed over the lane's rows) through LDS in a fixed order.  512 threads: 8 waves share the rounds (16 float4 per
+// matrix and lane, both matrices requested at the start), the pool's positions and the Q layer's (row, action) pairs.
+constexpr int TAIL_F = 64, TAIL_HMAX = 512, TAIL_T = 512, TAIL_W = TAIL_T / 64, TAIL_RR = 4 * TAIL_W;   // weight rows per round
+constexpr int TAIL_RMAX = TAIL_HMAX / TAIL_RR, TAIL_PQ = 16;                     // up to TAIL_W * TAIL_PQ = 128 pooled positions
+constexpr int TAIL_QP = 2;                                                        // (row, action) pairs of the Q layer per wave
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+
+__global__ void __launch_bounds__(TAIL_T) dqn_tail_td_kernel(xrl_dqn_tail_td_t p) {
+    __shared__ __attribute__((aligned(16))) float s_f[3][TAIL_F];
+    __shared__ __attribute__((aligned(16))) float s_part[3][TAIL_HMAX][4];
+    __shared__ float s_h[3][TAIL_HMAX];
+    __shared__ float s_dh[TAIL_HMAX];
+    __shared__ float s_q[3 * 64];
+    __shared__ float s_mv[3][TAIL_W][TAIL_F];
+    __shared__ int s_mi[3][TAIL_W][TAIL_F];
+    __shared__ int s_arg[TAIL_F];
+    __shared__ __attribute__((aligned(16))) float s_red[TAIL_RR][TAIL_F];
+    __shared__ float s_df[TAIL_F];
+    constexpr int F = TAIL_F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = p.A, H = p.H, P = p.P, M = p.M, m = blockIdx.x;
+    const int n_rows = p.double_q ? 3 : 2, rounds = (H + TAIL_RR - 1) / TAIL_RR;
+    const int k4 = lane & 15, rsub = lane >> 4, jrow = 4 * wave + rsub;            // this lane's weight row within a round
+    // ---- every load that does not depend on computed values, now: both hidden matrices (all rounds; the eval one stays in
+    // registers for the backward product), the three frames' activations, the Q-layer rows this wave will need, the scalars
+    float4 we[TAIL_RMAX], wt[TAIL_RMAX];
+#pragma unroll
+    for (int i = 0; i < TAIL_RMAX; ++i) {
+        const int j = min(TAIL_RR * i + jrow, H - 1);                              // (rows beyond H: a valid address, unused)
+        we[i] = *reinterpret_cast<const float4*>(p.w1_eval + (size_t)j * F + 4 * k4);
+        wt[i] = *reinterpret_cast<const float4*>(p.w1_target + (size_t)j * F + 4 * k4);
+    }
+    const float* frame[3] = {p.y_eval + (size_t)m * P * F, p.y_target + (size_t)m * P * F, p.y_eval + (size_t)(p.double_q ? M + m : m) * P * F};
+    const int f = lane, pg = wave;                                                 // pool: thread (position group, filter)
+    float pv[3][TAIL_PQ];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < TAIL_PQ; ++q) pv[r][q] = frame[r][(size_t)min(pg + TAIL_W * q, P - 1) * F + f];
+    const int a_taken = (int)p.actions[m];
+    const float rew = p.rewards[m], ter = p.terminals[m];
+    float w2[TAIL_QP][TAIL_HMAX / 64];                                             // Q-layer rows of this wave's (row, action) pairs
+#pragma unroll
+    for (int u = 0; u < TAIL_QP; ++u) {
+        const int pr = min(wave + TAIL_W * u, n_rows * A - 1), r = pr / A, a = pr - r * A;
+        const float* w = (r == 1 ? p.w2_target : p.w2_eval) + (size_t)a * H;
+#pragma unroll
+        for (int t = 0; t < TAIL_HMAX / 64; ++t) w2[u][t] = w[min(lane + 64 * t, H - 1)];
+    }
+    const float wa_j = p.w2_eval[(size_t)a_taken * H + min(tid, H - 1)];           // (the taken action's Q row, for d_h)
+    const float b1e = p.b1_eval[min(tid, H - 1)], b1t = p.b1_target[min(tid, H - 1)];
+    // ---- global max-pool, first maximum wins (xrl_maxpool_hw_fwd's rule: larger value, then smaller position)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < TAIL_PQ; ++q) {
+            const int pos = pg + TAIL_W * q;
+            if (pos < P && pv[r][q] > best) { best = pv[r][q]; bi = pos; }
+        }
+        s_mv[r][pg][f] = best; s_mi[r][pg][f] = bi;
+    }
+    __syncthreads();
+    if (tid < 3 * F) {
+        const int r = tid >> 6;
+        float best = s_mv[r][0][f];
+        int bi = s_mi[r][0][f];
+#pragma unroll
+        for (int g = 1; g < TAIL_W; ++g) {
+            const float v = s_mv[r][g][f];
+            const int vi = s_mi[r][g][f];
+            if (v > best || (v == best && vi < bi)) { best = v; bi = vi; }
+        }
+        s_f[r][f] = best;
+        if (r == 0) { s_arg[f] = bi; p.feat_eval[(size_t)m * p.ld_f + f] = best; if (p.arg) p.arg[(size_t)m * F + f] = bi; }
+        if (r == 1 && p.feat_target) p.feat_target[(size_t)m * p.ld_f + f] = best;
+        if (r == 2 && p.double_q) p.feat_eval[(size_t)(M + m) * p.ld_f + f] = best;
+    }
+    __syncthreads();
+    // ---- hidden layer: partial dot products per (row, quad of k), eval network on rows 0 (and 2), target network on row 1
+    const float4 f0 = *reinterpret_cast<const float4*>(&s_f[0][4 * k4]), f1 = *reinterpret_cast<const float4*>(&s_f[1][4 * k4]),
+                 f2 = *reinterpret_cast<const float4*>(&s_f[2][4 * k4]);
+#pragma unroll
+    for (int i = 0; i < TAIL_RMAX; ++i) {
+        const int j = TAIL_RR * i + jrow;
+        if (j < H) {                                                               // (uniform per 16 lanes: the quad reduction is safe)
+            const float s0 = quad_sum(dot4(f0, we[i])), s1 = quad_sum(dot4(f1, wt[i]));
+            if ((k4 & 3) == 0) { s_part[0][j][k4 >> 2] = s0; s_part[1][j][k4 >> 2] = s1; }
+            if (p.double_q) {
+                const float s2 = quad_sum(dot4(f2, we[i]));
+                if ((k4 & 3) == 0) s_part[2][j][k4 >> 2] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < H) {
+        for (int r = 0; r < n_rows; ++r) {
+            const float4 q4 = *reinterpret_cast<const float4*>(&s_part[r][tid][0]);
+            const float hv = act_apply(((q4.x + q4.y) + (q4.z + q4.w)) + (r == 1 ? b1t : b1e), p.act);
+            s_h[r][tid] = hv;
+            if (r == 0) p.h_eval[(size_t)m * p.ld_h + tid] = hv;
+            if (r == 2) p.h_eval[(size_t)(M + m) * p.ld_h + tid] = hv;
+        }
+    }
+    __syncthreads();
+    // ---- Q layer ((row, action) pairs over the waves), TD rule: xrl_dqn_head_td's statements on the LDS rows
+#pragma unroll
+    for (int u = 0; u < TAIL_QP; ++u) {
+        const int pr = wave + TAIL_W * u;
+        if (pr < n_rows * A) {
+            const int r = pr / A, a = pr - r * A;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < TAIL_HMAX / 64; ++t) if (lane + 64 * t < H) acc = fmaf(s_h[r][lane + 64 * t], w2[u][t], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) s_q[r * 64 + a] = acc + (r == 1 ? p.b2_target : p.b2_eval)[a];
+        }
+    }
+    for (int pr = wave + TAIL_W * TAIL_QP; pr < n_rows * A; pr += TAIL_W) {         // (more pairs than prefetched: n_actions > 5)
+        const int r = pr / A, a = pr - r * A;
+        const float* w = (r == 1 ? p.w2_target : p.w2_eval) + (size_t)a * H;
+        float acc = 0.f;
+        for (int k = lane; k < H; k += 64) acc = fmaf(s_h[r][k], w[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) s_q[r * 64 + a] = acc + (r == 1 ? p.b2_target : p.b2_eval)[a];
+    }
+    __syncthreads();
+    if (tid < A) {
+        p.q_eval[(size_t)m * p.ld_q + tid] = s_q[tid];
+        p.q_target[(size_t)m * p.ld_q + tid] = s_q[64 + tid];
+        if (p.double_q) p.q_eval[(size_t)(M + m) * p.ld_q + tid] = s_q[128 + tid];
+    }
+    const float pred = s_q[a_taken];                                       // dqn_learner.py:42
+    float tq;
+    if (p.double_q) {                                                      // ddqn_learner.py:40-44: argmax of the eval net on next_obs
+        int best = 0; float bv = s_q[128];
+        for (int j = 1; j < A; ++j) if (s_q[128 + j] > bv) { bv = s_q[128 + j]; best = j; }
+        tq = s_q[64 + best];
+    } else {
+        tq = s_q[64];
+        for (int j = 1; j < A; ++j) tq = fmaxf(tq, s_q[64 + j]);           // :43
+    }
+    const float y = rew + p.gamma * (1.f - ter) * tq;                      // :44
+    const float td = pred - y, g = 2.f * td / (float)M;                    // MSELoss backward through gather
+    if (tid < A) p.d_q[(size_t)m * p.ld_q + tid] = (tid == a_taken) ? g : 0.f;
+    if (tid == 0) {
+        if (p.diag) { p.diag[m] = pred; p.diag[M + m] = y; }
+        double* q = p.partials + (size_t)m * 8;
+        q[0] = (double)td * td; q[1] = pred;
+        for (int j = 2; j < 8; ++j) q[j] = 0.0;
+    }
+    if (tid < H) {
+        const float d = g * wa_j * act_grad_from_out(s_h[0][tid], p.act);
+        s_dh[tid] = d;
+        p.d_h[(size_t)m * p.ld_h + tid] = d;
+    }
+    __syncthreads();
+    // ---- d_feat = d_h . W1 from the registers, then the pool's backward
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TAIL_RMAX; ++i) {
+        const int j = TAIL_RR * i + jrow;
+        if (j < H) {
+            const float d = s_dh[j];
+            acc.x = fmaf(d, we[i].x, acc.x); acc.y = fmaf(d, we[i].y, acc.y); acc.z = fmaf(d, we[i].z, acc.z); acc.w = fmaf(d, we[i].w, acc.w);
+        }
+    }
+    *reinterpret_cast<float4*>(&s_red[jrow][4 * k4]) = acc;
+    __syncthreads();
+    if (tid < F) {
+        float sum = s_red[0][tid];
+#pragma unroll
+        for (int g2 = 1; g2 < TAIL_RR; ++g2) sum += s_red[g2][tid];
+        s_df[tid] = sum;
+        if (p.d_feat) p.d_feat[(size_t)m * p.ld_f + tid] = sum;
+    }
+    __syncthreads();
+    float* dy = p.dy + (size_t)m * P * F;
+    for (int i = tid; i < P * F; i += TAIL_T) {
+        const int q = i >> 6, ff = i & 63;
+        dy[i] = (q == s_arg[ff] && s_f[0][ff] > 0.f) ? s_df[ff] : 0.f;    // xrl_maxpool_hw_bwd: first maximum, times relu'
+    }
+}
+
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
 
 // One wavefront per batch row b.  Lane n < N owns agent n, lane h < H owns mixer hidden unit h.
@@ -458,6 +660,18 @@ extern "C" int xrl_dqn_head_td(const xrl_dqn_head_td_t* p, xrl_stream_t stream) 
                   p->terminals && p->q_eval && p->q_target && p->d_q && p->d_h && p->partials);
     XRL_CHECK_ARG(p->M > 0 && p->A > 0 && p->A <= 64 && p->H > 0 && p->ld_h >= p->H && p->ld_q >= p->A);
     hipLaunchKernelGGL(dqn_head_td_kernel, dim3(p->M < 1024 ? p->M : 1024), dim3(256), 0, as_stream(stream), *p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_dqn_tail_td(const xrl_dqn_tail_td_t* p, xrl_stream_t stream) {
+    XRL_CHECK_ARG(p && p->y_eval && p->y_target && p->feat_eval && p->w1_eval && p->b1_eval && p->w1_target && p->b1_target &&
+                  p->w2_eval && p->b2_eval && p->w2_target && p->b2_target && p->actions && p->rewards && p->terminals &&
+                  p->q_eval && p->q_target && p->d_q && p->h_eval && p->d_h && p->dy && p->partials);
+    XRL_CHECK_ARG(p->M > 0 && p->M <= 65535 && p->A > 0 && p->A <= 64 && p->F == TAIL_F && p->H >= 1 && p->H <= TAIL_HMAX);
+    XRL_CHECK_ARG(p->P > 0 && p->P <= TAIL_W * TAIL_PQ && p->ld_h >= p->H && p->ld_q >= p->A && p->ld_f >= p->F);
+    XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->w1_eval) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->w1_target) & 15) == 0);
+    hipLaunchKernelGGL(dqn_tail_td_kernel, dim3(p->M), dim3(TAIL_T), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -48,8 +48,15 @@ class DQN_Learner(Learner):
         S = pick_n_split(M)
         fused = bool(getattr(self.config, "use_fused_q_head", True)) and M <= self.partials.shape[0] and \
             getattr(model, "fused_head", lambda: None)() is not None
-        q_all, q_next = model.forward_pair(self.X, M, self.double_q, skip_last=fused)   # evalQ (:39) [+ Q_eval(s')], targetQ (:40)
-        if fused:
+        tail = fused and bool(getattr(self.config, "use_fused_q_tail", True)) and getattr(model, "fused_tail", lambda: None)() is not None
+        q_all, q_next = model.forward_pair(self.X, M, self.double_q, skip_last="tail" if tail else fused)   # evalQ (:39) [+ Q_eval(s')], targetQ (:40)
+        if tail:
+            # Basic_CNN + BasicQhead at batch <= 32: everything between the last convolution and the convolution stack's backward
+            # pass in one launch (xrl_dqn_tail_td)
+            model.tail_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma)
+            S_opt = model.backward(self.X, M, self.slabs, S, tail=True) or S
+            S_loss = M
+        elif fused:
             # the Q layer itself, the TD rule and the layer's data gradient: one launch (xrl_dqn_head_td), one partials row per row
             model.head_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma)
             S_opt = model.backward(self.X, M, self.slabs, S, skip_last_dg=True) or S

@@ -171,7 +171,7 @@ class Plan:
                 ops.linear_fwd(groups)
         return [it[0].acts[len(it[0].widths) - 1] for it in items]
 
-    def backward(self, x, ldx, M, slabs, n_split, flat=None, dx0=None, defer_wgrad=None, skip_last_dg=False):
+    def backward(self, x, ldx, M, slabs, n_split, flat=None, dx0=None, defer_wgrad=None, skip_last_dg=False, weights_only=False):
         """dacts[last] must hold d loss / d (pre-activation) of the last level. Writes weight/bias gradient
         partials into slabs[s][layout of params].  dx0: optional [M, widths[0]] tensor receiving d loss / d input.
         defer_wgrad: a list -> only the data-gradient chain is launched here and the weight-gradient GEMM descriptors are
@@ -200,6 +200,8 @@ class Plan:
                 defer_wgrad.extend(wg)
             else:
                 ops.linear_bwd_weight(wg, n_split, stride)
+            if weights_only:                                                  # (every data gradient came from the caller's launch)
+                continue
             if dg and not (skip_last_dg and si == len(self.stages) - 1):     # (skip_last_dg: the caller's launch already wrote
                 ops.linear_bwd_data(dg)                                       #  the gradient in front of the last stage)
 
@@ -231,11 +233,12 @@ class Plan:
         for i in range(0, len(wg), 8):
             ops.linear_bwd_weight(wg[i:i + 8], n_split, slabs.shape[1])
 
-    def backward_grouped(self, x, ldx, M, slabs, n_split, flat=None, dx0=None, skip_last_dg=False):
+    def backward_grouped(self, x, ldx, M, slabs, n_split, flat=None, dx0=None, skip_last_dg=False, weights_only=False):
         """backward() with the data-gradient chain first and ALL weight gradients of the plan as one grouped launch
         (chunks of 8 groups): same kernels per layer, fewer launches."""
         wg = []
-        self.backward(x, ldx, M, slabs, n_split, flat=flat, dx0=dx0, defer_wgrad=wg, skip_last_dg=skip_last_dg)
+        self.backward(x, ldx, M, slabs, n_split, flat=flat, dx0=dx0, defer_wgrad=wg, skip_last_dg=skip_last_dg,
+                      weights_only=weights_only)
         for i in range(0, len(wg), 8):
             ops.linear_bwd_weight(wg[i:i + 8], n_split, slabs.shape[1])
 
@@ -1107,7 +1110,7 @@ class ConvStack:
             ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, rows, OH * OW, F, F)
         return ws.feat
 
-    def forward_dual(self, x, M, Re, ws, flat_t):
+    def forward_dual(self, x, M, Re, ws, flat_t, pool=True):
         """Eval network on frames [0, Re) and target network (parameters `flat_t`) on frames [M, 2M) of x [2M, H*W*C] in
         ONE pass: one im2col per layer over all frames (the first layer's columns of the next_obs frames are shared by the
         target and, under double-Q, the eval network) and one grouped GEMM launch per layer (eval rows | target rows).
@@ -1143,13 +1146,14 @@ class ConvStack:
                             ops.gemm_desc(a_t, P.ptr(n + ".weight", flat_t), y_t, M * ohw, F, K, K, K, F,
                                           bias=P.ptr(n + ".bias", flat_t), act="relu", aux=w_t, ldaux=ks if ks > 1 else 0)])
         H, W, C, k, s, p, OH, OW, F = self.geo[-1]
-        ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, tot, OH * OW, F, F)
+        if pool:                                              # (pool=False: the caller's launch pools -- xrl_dqn_tail_td)
+            ops.maxpool_hw_fwd(ws.y[-1], ws.feat, ws.arg, tot, OH * OW, F, F)
         return ws.feat
 
     N_SPLIT = 64                                              # row chunks of a conv layer's weight gradient (parallelism)
     N_SPLIT_IMPLICIT = 32                                     # (implicit path: a workgroup's four waves split its chunk again)
 
-    def backward(self, dfeat, rows, ws, slabs, n_split, flat=None, direct=False):
+    def backward(self, dfeat, rows, ws, slabs, n_split, flat=None, direct=False, pool=True):
         """dfeat [rows, n_feat] -> weight / bias gradients of every conv layer, summed into slabs[0] (the conv parameters
         are the first `p_conv` floats of the layout; their regions in slabs[1:] stay zero).  The GEMM rows of a conv
         layer are B*OH*OW (14 112 for the first Atari layer at batch 32), so the weight-gradient GEMM is split over
@@ -1161,7 +1165,9 @@ class ConvStack:
             self._csq = torch.zeros(256, dtype=torch.float64, device=P.device)
         cs, stride = self._cslabs, self._cslabs.shape[1]
         H, W, C, k, s, p, OH, OW, F = self.geo[-1]
-        if self.flatten:
+        if not pool:
+            pass                                              # (ws.dy[-1] already holds the last layer's gradient: xrl_dqn_tail_td)
+        elif self.flatten:
             ops.flatten_chw_bwd(dfeat, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
         else:
             ops.maxpool_hw_bwd(dfeat, ws.arg, ws.y[-1], ws.dy[-1], rows, OH * OW, F, dfeat.shape[1])
@@ -1384,6 +1390,37 @@ class DeepQCNN:
     fused_head = DeepQNet.fused_head
     head_td = DeepQNet.head_td
 
+    def fused_tail(self):
+        """(hidden layer, Q layer) as xrl_dqn_tail_td wants them, or None: Basic_CNN's global max-pool over at most 128 positions of
+        64 filters (implicit-GEMM stack: the last layer's gradient is written in place), then exactly Linear(64, H) + activation
+        and Linear(H, n_actions), H <= 512 -- configs/dqn/atari.yaml."""
+        L2 = self.fused_head()
+        st = self.plan.stages
+        Hc, Wc, C, k, s, p, OH, OW, F = self.conv.geo[-1]
+        if L2 is None or len(st) != 2 or len(st[0]) != 1 or not self.conv.implicit or self.conv.flatten or F != 64 or OH * OW > 128:
+            return None
+        L1 = st[0][0]
+        if L1.in_level != 0 or L1.in_off != 0 or L1.K != 64 or L1.N > 512 or L1.N != self.plan.widths[1] or L2.K != L1.N:
+            return None
+        return L1, L2
+
+    def tail_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma):
+        """After forward_pair(..., skip_last="tail"): pool + hidden + Q layers + TD + the gradients back to the last convolution's
+        output in one launch; backward(..., tail=True) continues with the weight gradients and the convolution stack."""
+        (L1, L2), pl, tp, ws = self.fused_tail(), self.plan, self.target_plan, self._ws
+        Hc, Wc, C, k, s, p, OH, OW, F = self.conv.geo[-1]
+        Re, Pp = (2 * M if double_q else M), OH * OW
+        prm, tf = self.params, self.target_flat
+        pl.ensure(Re); tp.ensure(M)
+        ops.dqn_tail_td(y_eval=ws.y[-1], y_target=ws.y[-1][Re * Pp:], feat_eval=ws.feat, feat_target=ws.feat[Re:], arg=ws.arg,
+                        w1_eval=prm.ptr(L1.w_name), b1_eval=prm.ptr(L1.b_name), w1_target=prm.ptr(L1.w_name, tf),
+                        b1_target=prm.ptr(L1.b_name, tf), w2_eval=prm.ptr(L2.w_name), b2_eval=prm.ptr(L2.b_name),
+                        w2_target=prm.ptr(L2.w_name, tf), b2_target=prm.ptr(L2.b_name, tf), actions=actions, rewards=rewards,
+                        terminals=terminals, q_eval=pl.acts[2], q_target=tp.acts[2], d_q=pl.dacts[2], h_eval=pl.acts[1],
+                        d_h=pl.dacts[1], d_feat=None, dy=ws.dy[-1], diag=diag, partials=partials, M=M, A=L2.N, H=L1.N, F=F, P=Pp,
+                        ld_h=pl.widths[1], ld_q=pl.widths[2], ld_f=ws.feat.shape[1], double_q=int(double_q), act=ops.ACT[L1.act],
+                        gamma=float(gamma))
+
     def forward_pair(self, X, M, double_q, skip_last=False):
         """One update's three network passes (dqn_learner.py:39-40, ddqn_learner.py:40): eval Q of obs = X[:M] (kept for
         backward), target Q of next_obs = X[M:2M] and, under double-Q, eval Q of next_obs -- as one im2col + one grouped
@@ -1391,8 +1428,10 @@ class DeepQCNN:
         Re, F = (2 * M if double_q else M), self.filters[-1]
         ws = self.conv.workspace("dual", 3 * M, True)
         self._ws = ws
-        feat = self.conv.forward_dual(X[:2 * M].reshape(2 * M, -1), M, Re, ws, self.target_flat)
+        feat = self.conv.forward_dual(X[:2 * M].reshape(2 * M, -1), M, Re, ws, self.target_flat, pool=skip_last != "tail")
         self._feat_in = feat
+        if skip_last == "tail":                            # (xrl_dqn_tail_td does the rest of the forward pass)
+            return None, None
         q_e, q_t = Plan.forward_many([(self.plan, feat, F, Re, None), (self.target_plan, feat[Re:], F, M, self.target_flat)],
                                      skip_last=skip_last)
         return q_e, q_t
@@ -1401,11 +1440,12 @@ class DeepQCNN:
     def d_out(self):
         return self.plan.dacts[len(self.plan.widths) - 1]
 
-    def backward(self, x_u8, M, slabs, n_split, skip_last_dg=False):
+    def backward(self, x_u8, M, slabs, n_split, skip_last_dg=False, tail=False):
         if getattr(self, "_dfeat", None) is None or self._dfeat.shape[0] < M:
             self._dfeat = torch.zeros(M, self.filters[-1], device=self.params.device)
-        self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat, skip_last_dg=skip_last_dg)
+        self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat, skip_last_dg=skip_last_dg,
+                                   weights_only=tail)
         if getattr(self, "_head_split", n_split) != n_split:      # (head rows of slabs beyond n_split must read as zero)
             slabs.zero_()
         self._head_split = n_split
-        return self.conv.backward(self._dfeat, M, self._ws, slabs, n_split, direct=True)   # number of slabs to sum
+        return self.conv.backward(self._dfeat, M, self._ws, slabs, n_split, direct=True, pool=not tail)   # number of slabs to sum

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Conv, ImageJob, DqnHeadTd, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -118,6 +118,12 @@ def maxpool_hw_bwd(dfeat, argmax, y, dy, B, P, F, ld_dfeat):
 def dqn_head_td(**kw):
     """Q layer + TD rule + the layer's data gradient in one launch (xrl_dqn_head_td)."""
     call("xrl_dqn_head_td", C.byref(_struct(DqnHeadTd, kw)), stream_ptr())
+
+
+def dqn_tail_td(**kw):
+    """Max-pool of the last convolution's output, hidden + Q layer of both networks, TD rule, d_h, d_feat and the pool's
+    backward in one launch (xrl_dqn_tail_td)."""
+    call("xrl_dqn_tail_td", C.byref(_struct(DqnTailTd, kw)), stream_ptr())
 
 
 def conv_desc(**kw):
