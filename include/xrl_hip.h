@@ -837,6 +837,11 @@ typedef struct {
     double* partials;          /* [M][8] */
     int32_t M, A, H, F, P, ld_h, ld_q, ld_f, double_q, act;
     float gamma, pad;
+    /* NULL, or the gradient slabs of the optimiser launch, [>= M][slab_stride]: transition m writes ITS term of the two dense layers'
+     * weight / bias gradients (d_h[m] x feat[m], d_h[m], d_q[m] x h[m], d_q[m]) into slab m at the parameters' offsets -- the
+     * slab reduction of xrl_reduce_adam is then the sum over the batch (in order of m), and no weight-gradient GEMM is launched. */
+    float* slabs;
+    int64_t slab_stride, off_w1, off_b1, off_w2, off_b2;
 } xrl_dqn_tail_td_t;
 int xrl_dqn_tail_td(const xrl_dqn_tail_td_t* p, xrl_stream_t stream);
 int xrl_dqn_head_td(const xrl_dqn_head_td_t* p, xrl_stream_t stream);

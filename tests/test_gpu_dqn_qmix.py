@@ -110,7 +110,7 @@ def test_qmix_learner_vs_reference_fixture(double_q, size, fused, items):
     check_updates(g, net, learner, cb, call, ("q_tot_eval", "q_tot_next", "q_tot_target"), "loss_Q")
 
 
-@pytest.mark.parametrize("implicit,tail", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("implicit,tail", [(True, True), (True, "gemm"), (True, False), (False, False)])
 @pytest.mark.parametrize("name", ["dqn_cnn", "dqn_cnn_c3"])
 def test_dqn_cnn_learner_vs_reference_fixture(name, implicit, tail):
     """BASELINE config C3 shapes: 84x84x4 uint8 frames, CNN 32/64/64 (k 8/4/3, s 4/2/1) + global max-pool + 64-512-4 head.
@@ -118,7 +118,9 @@ def test_dqn_cnn_learner_vs_reference_fixture(name, implicit, tail):
     the matrix cores (csrc/conv_mfma.hip: forward, input gradient per residue class, weight gradient, all reading the NHWC
     activations in place) -- the default -- or the im2col + GEMM path (csrc/conv.hip), both against the reference's updates.
     tail: everything between the last convolution and the stack's backward pass (pool, hidden + Q layers of both networks, TD rule,
-    d_h, d_feat, the pool's backward) as ONE launch (xrl_dqn_tail_td) -- the default at batch <= 32 -- or as the layered launches."""
+    d_h, d_feat, the pool's backward) as ONE launch (xrl_dqn_tail_td) -- the default at batch <= 32 -- or as the layered launches;
+    True: each transition's term of the dense layers' weight gradients goes straight into its own gradient slab (the optimiser
+    launch's slab sum is the batch sum), "gemm": the weight-gradient GEMM launch computes them."""
     from xuance_amd.nets import DeepQCNN
     from xuance_amd.learners import DQN_Learner
     g = load_golden(name)
@@ -130,7 +132,8 @@ def test_dqn_cnn_learner_vs_reference_fixture(name, implicit, tail):
     net.load_state_dict(sub(g, "init"))
     cb = Capture()
     learner = DQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
-                                   use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip), use_fused_q_tail=tail), net, cb)
+                                   use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip), use_fused_q_tail=bool(tail),
+                                   use_tail_slab_gradients=tail is True), net, cb)
     assert (net.fused_tail() is not None) == implicit
     check_updates(g, net, learner, cb, lambda b: learner.update(batch_size=len(b["obs"]), **b),
                   ("evalQ", "predictQ", "targetQ"), "Qloss")

@@ -45,7 +45,8 @@ class DqnTailTd(C.Structure):
                                         "b1_target", "w2_eval", "b2_eval", "w2_target", "b2_target", "actions", "rewards", "terminals",
                                         "q_eval", "q_target", "d_q", "h_eval", "d_h", "d_feat", "dy", "diag", "partials")] + \
                [(k, c_int32) for k in ("M", "A", "H", "F", "P", "ld_h", "ld_q", "ld_f", "double_q", "act")] + \
-               [("gamma", c_float), ("pad", c_float)]
+               [("gamma", c_float), ("pad", c_float), ("slabs", c_void_p)] + \
+               [(k, C.c_int64) for k in ("slab_stride", "off_w1", "off_b1", "off_w2", "off_b2")]
 
 
 class ImageJob(C.Structure):

@@ -303,7 +303,9 @@ __global__ void __launch_bounds__(TAIL_T) dqn_tail_td_kernel(xrl_dqn_tail_td_t p
         p.d_h[(size_t)m * p.ld_h + tid] = d;
     }
     __syncthreads();
-    // ---- d_feat = d_h . W1 from the registers, then the pool's backward
+    // ---- d_feat = d_h . W1 from the registers (and this transition's term of the dense layers' gradients into ITS slab:
+    // rank-1 products, written where the weight-gradient GEMM would have put their sum), then the pool's backward
+    float* slab = p.slabs ? p.slabs + (size_t)m * p.slab_stride : nullptr;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < TAIL_RMAX; ++i) {
@@ -311,7 +313,16 @@ __global__ void __launch_bounds__(TAIL_T) dqn_tail_td_kernel(xrl_dqn_tail_td_t p
         if (j < H) {
             const float d = s_dh[j];
             acc.x = fmaf(d, we[i].x, acc.x); acc.y = fmaf(d, we[i].y, acc.y); acc.z = fmaf(d, we[i].z, acc.z); acc.w = fmaf(d, we[i].w, acc.w);
+            if (slab) *reinterpret_cast<float4*>(slab + p.off_w1 + (size_t)j * F + 4 * k4) = make_float4(d * f0.x, d * f0.y, d * f0.z, d * f0.w);
         }
+    }
+    if (slab) {
+        if (tid < H) {
+            slab[p.off_b1 + tid] = s_dh[tid];
+            const float gh = g * s_h[0][tid];
+            for (int a = 0; a < A; ++a) slab[p.off_w2 + (size_t)a * H + tid] = (a == a_taken) ? gh : 0.f;
+        }
+        if (tid < A) slab[p.off_b2 + tid] = (tid == a_taken) ? g : 0.f;
     }
     *reinterpret_cast<float4*>(&s_red[jrow][4 * k4]) = acc;
     __syncthreads();
@@ -671,6 +682,8 @@ extern "C" int xrl_dqn_tail_td(const xrl_dqn_tail_td_t* p, xrl_stream_t stream) 
     XRL_CHECK_ARG(p->M > 0 && p->M <= 65535 && p->A > 0 && p->A <= 64 && p->F == TAIL_F && p->H >= 1 && p->H <= TAIL_HMAX);
     XRL_CHECK_ARG(p->P > 0 && p->P <= TAIL_W * TAIL_PQ && p->ld_h >= p->H && p->ld_q >= p->A && p->ld_f >= p->F);
     XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->w1_eval) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->w1_target) & 15) == 0);
+    XRL_CHECK_ARG(p->slabs == nullptr || ((reinterpret_cast<uintptr_t>(p->slabs) & 15) == 0 && p->slab_stride % 4 == 0 && p->off_w1 % 4 == 0 &&
+                                          p->off_w1 >= 0 && p->off_b1 >= 0 && p->off_w2 >= 0 && p->off_b2 >= 0));
     hipLaunchKernelGGL(dqn_tail_td_kernel, dim3(p->M), dim3(TAIL_T), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;

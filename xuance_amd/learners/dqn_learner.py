@@ -53,7 +53,9 @@ class DQN_Learner(Learner):
         if tail:
             # Basic_CNN + BasicQhead at batch <= 32: everything between the last convolution and the convolution stack's backward
             # pass in one launch (xrl_dqn_tail_td)
-            model.tail_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma)
+            in_slabs = bool(getattr(self.config, "use_tail_slab_gradients", True)) and M <= self.slabs.shape[0] and \
+                model.conv.N_SPLIT_IMPLICIT == self.slabs.shape[0]
+            model.tail_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma, slabs=self.slabs if in_slabs else None)
             S_opt = model.backward(self.X, M, self.slabs, S, tail=True) or S
             S_loss = M
         elif fused:

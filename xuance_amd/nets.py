@@ -1404,7 +1404,7 @@ class DeepQCNN:
             return None
         return L1, L2
 
-    def tail_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma):
+    def tail_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma, slabs=None):
         """After forward_pair(..., skip_last="tail"): pool + hidden + Q layers + TD + the gradients back to the last convolution's
         output in one launch; backward(..., tail=True) continues with the weight gradients and the convolution stack."""
         (L1, L2), pl, tp, ws = self.fused_tail(), self.plan, self.target_plan, self._ws
@@ -1412,7 +1412,13 @@ class DeepQCNN:
         Re, Pp = (2 * M if double_q else M), OH * OW
         prm, tf = self.params, self.target_flat
         pl.ensure(Re); tp.ensure(M)
-        ops.dqn_tail_td(y_eval=ws.y[-1], y_target=ws.y[-1][Re * Pp:], feat_eval=ws.feat, feat_target=ws.feat[Re:], arg=ws.arg,
+        kw = {}
+        if slabs is not None:          # each transition's term of the dense layers' gradients straight into its slab
+            off = prm.offsets
+            kw = dict(slabs=slabs, slab_stride=slabs.stride(0), off_w1=off[L1.w_name], off_b1=off[L1.b_name], off_w2=off[L2.w_name],
+                      off_b2=off[L2.b_name])
+        self._tail_slabs = slabs is not None
+        ops.dqn_tail_td(**kw, y_eval=ws.y[-1], y_target=ws.y[-1][Re * Pp:], feat_eval=ws.feat, feat_target=ws.feat[Re:], arg=ws.arg,
                         w1_eval=prm.ptr(L1.w_name), b1_eval=prm.ptr(L1.b_name), w1_target=prm.ptr(L1.w_name, tf),
                         b1_target=prm.ptr(L1.b_name, tf), w2_eval=prm.ptr(L2.w_name), b2_eval=prm.ptr(L2.b_name),
                         w2_target=prm.ptr(L2.w_name, tf), b2_target=prm.ptr(L2.b_name, tf), actions=actions, rewards=rewards,
@@ -1443,9 +1449,12 @@ class DeepQCNN:
     def backward(self, x_u8, M, slabs, n_split, skip_last_dg=False, tail=False):
         if getattr(self, "_dfeat", None) is None or self._dfeat.shape[0] < M:
             self._dfeat = torch.zeros(M, self.filters[-1], device=self.params.device)
-        self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat, skip_last_dg=skip_last_dg,
-                                   weights_only=tail)
-        if getattr(self, "_head_split", n_split) != n_split:      # (head rows of slabs beyond n_split must read as zero)
+        in_slabs = tail and getattr(self, "_tail_slabs", False)   # (xrl_dqn_tail_td wrote the dense layers' terms, one slab per row)
+        if not in_slabs:
+            self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat, skip_last_dg=skip_last_dg,
+                                       weights_only=tail)
+        split = -M if in_slabs else n_split
+        if getattr(self, "_head_split", split) != split:          # (head rows of slabs beyond the ones written must read as zero)
             slabs.zero_()
-        self._head_split = n_split
+        self._head_split = split
         return self.conv.backward(self._dfeat, M, self._ws, slabs, n_split, direct=True, pool=not tail)   # number of slabs to sum
