@@ -844,6 +844,23 @@ typedef struct {
     int64_t slab_stride, off_w1, off_b1, off_w2, off_b2;
 } xrl_dqn_tail_td_t;
 int xrl_dqn_tail_td(const xrl_dqn_tail_td_t* p, xrl_stream_t stream);
+
+/* The acting side of the same network (OffPolicyAgent.exploration on DeepQNetwork.forward, off_policy.py:129-148,
+ * deep_q_network.py:61-80): pool of env e's frame, hidden layer, Q layer, greedy action + epsilon coin as xrl_egreedy -- one launch. */
+typedef struct {
+    const float* y;            /* [n][P][F] last convolution's output */
+    const float* w1; const float* b1; const float* w2; const float* b2;   /* [H][F], [H], [A][H], [A] */
+    const float* eps_dev;
+    int32_t* action;           /* [n] */
+    float* action_f;           /* NULL or [n] */
+    float* q;                  /* NULL or [n][ld_q] */
+    float* feat;               /* NULL or [n][ld_f] */
+    const uint32_t* step_dev;
+    uint64_t seed;
+    uint32_t step;
+    int32_t n, A, H, F, P, ld_q, ld_f, act, pad;
+} xrl_dqn_act_tail_t;
+int xrl_dqn_act_tail(const xrl_dqn_act_tail_t* p, xrl_stream_t stream);
 int xrl_dqn_head_td(const xrl_dqn_head_td_t* p, xrl_stream_t stream);
 
 /* QMIX_Learner.update between the per-agent Q-networks and the hyper-networks

@@ -382,6 +382,35 @@ def test_dqn_graph_update_phase_equals_eager_updates_on_the_same_indices(atari):
     assert np.abs(pa).max() > 0 and np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(ia, ib)
 
 
+def test_dqn_cnn_acting_in_one_launch_equals_the_layered_acting():
+    """DQN_Agent's acting step on a convolutional Q network: convolutions, then pool + hidden + Q layers + the epsilon-greedy choice
+    as ONE launch (xrl_dqn_act_tail) against the layered launches (max-pool, GEMM, Q layer, xrl_egreedy): same Philox coin and random
+    action per env, Q values within 1e-5 of their scale (the hidden layer's sum runs in another order), so the same actions unless
+    two Q values of an env tie within that -- every stored action is compared; and the same loop with updates runs on."""
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    n = 16
+    cfg = dict(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+               q_hidden_size=[512], activation="relu", seed=1, parallels=n, running_steps=10 ** 6, buffer_size=n * 64, batch_size=16,
+               learning_rate=1e-3, gamma=0.99, start_greedy=0.3, end_greedy=0.05, decay_step_greedy=10 ** 5, sync_frequency=3,
+               training_frequency=1, start_training=10 ** 9, n_epochs=1, use_grad_clip=False, use_obsnorm=False, use_rewnorm=False,
+               distributed_training=False, device="cuda", model_dir="/tmp/x")
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        agent = DQN_Agent(Namespace(use_fused_q_tail=fused, **cfg), SyntheticAtariVecEnv(n, seed=2))
+        assert agent._act_fused == fused
+        agent.train(24)
+        torch.cuda.synchronize()
+        q = agent.model.plan.acts[2][:n, :4].cpu().numpy().copy()
+        res.append((agent.memory.soa.fields["actions"].cpu().numpy().copy() if hasattr(agent.memory, "soa") else
+                    agent.memory.data["actions"].cpu().numpy().copy(), q, agent.envs.action.cpu().numpy().copy()))
+    (aa, qa, ea), (ab, qb, eb) = res
+    assert_close(qa, qb, 1e-5, "Q values of the last acting step")
+    assert np.array_equal(aa, ab) and np.array_equal(ea, eb) and len(np.unique(aa)) > 1
+
+
 def test_dqn_cnn_weight_images_kept_by_the_optimiser_launch_equal_rebuilt_ones():
     """The convolution stack's fragment-ordered weight images: kept current by xrl_reduce_adam's mirrors (and the target's image by
     the in-launch hard update) against rebuilt by xrl_gather_images in every pass (config.use_live_weight_images: False) -- one

@@ -196,15 +196,24 @@ def timed(runner, steps, warmup, world):
     ranks of the elapsed time, the SUM over ranks of the env steps."""
     import time
     import torch.distributed as dist
+    import gc
     for _ in range(warmup):
         runner.step()
-    fence(world)
-    runner.mark()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        runner.step()
-    fence(world)
-    elapsed = time.perf_counter() - t0
+    # Objects of earlier measurements (the runners of measure_paths, their captured graphs) are destroyed NOW, and the collector
+    # stays off inside the timed region: destroying a graph's executable stalls the host for tens of milliseconds.  Nothing of the
+    # K steps is skipped by this -- the steps allocate no cyclic garbage worth collecting.
+    gc.collect()
+    gc.disable()
+    try:
+        fence(world)
+        runner.mark()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.step()
+        fence(world)
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     n = runner.env_steps_since_mark(steps)
     if world > 1:
         t = torch.tensor([elapsed, -float(n)], dtype=torch.float64, device="cuda")

@@ -49,6 +49,12 @@ class DqnTailTd(C.Structure):
                [(k, C.c_int64) for k in ("slab_stride", "off_w1", "off_b1", "off_w2", "off_b2")]
 
 
+class DqnActTail(C.Structure):
+    _fields_ = [(k, c_void_p) for k in ("y", "w1", "b1", "w2", "b2", "eps_dev", "action", "action_f", "q", "feat", "step_dev")] + \
+               [("seed", C.c_uint64), ("step", C.c_uint32)] + \
+               [(k, c_int32) for k in ("n", "A", "H", "F", "P", "ld_q", "ld_f", "act", "pad")]
+
+
 class ImageJob(C.Structure):
     _fields_ = [("src", c_void_p), ("map", c_void_p), ("dst", c_void_p), ("n", C.c_int64)]
 
@@ -365,6 +371,7 @@ _SIGS = {
     "xrl_reduce_adam_fits": [c_int64, c_int],
     "xrl_dqn_head_td": [c_void_p, c_void_p],
     "xrl_dqn_tail_td": [c_void_p, c_void_p],
+    "xrl_dqn_act_tail": [c_void_p, c_void_p],
     "xrl_conv_fwd": [c_void_p, c_int, c_int, c_void_p],
     "xrl_conv_fwd_probe": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "xrl_conv_bwd_weight": [c_void_p, c_int, c_int, C.c_int64, c_void_p],

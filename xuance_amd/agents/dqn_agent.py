@@ -55,6 +55,8 @@ class DQN_Agent(AgentSurface):
         self.eps_dev = torch.full((1,), float(self.e_greedy), device=dev)
         self._eps_on_device = self.e_greedy
         self._host_step = 0
+        self._act_fused = bool(getattr(config, "use_fused_q_tail", True)) and hasattr(self.model, "act_egreedy") and \
+            getattr(self.model, "fused_tail", lambda: None)() is not None
         self.act_f = torch.zeros(n, device=dev)
         self.model.plan.ensure(max(n, 2 * config.batch_size))
         assert not (self.atari and self.use_obsnorm), "Atari frames are stored as uint8 (configs/dqn/atari.yaml:42-43)"
@@ -111,9 +113,12 @@ class DQN_Agent(AgentSurface):
             else:
                 self._normalize(env.buf_obs if self.atari else env.buf_obs.float(), self.X, update=True)   # obs_rms.update; process
                 X = self.X
-            q = self.model.forward(X[:n], n)
-            ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=q.stride(0), seed=self.seed,
-                        step=self._host_step, step_dev=None)       # eager loop: the host knows the step index
+            if self._act_fused:                                    # (convolutional Q network: pool .. epsilon-greedy in one launch)
+                self.model.act_egreedy(X[:n], n, self.eps_dev, env.action, self.act_f, self.seed, self._host_step)
+            else:
+                q = self.model.forward(X[:n], n)
+                ops.egreedy(q=q, eps_dev=self.eps_dev, action=env.action, action_f=self.act_f, n=n, A=A, ld=q.stride(0), seed=self.seed,
+                            step=self._host_step, step_dev=None)   # eager loop: the host knows the step index
             env.step_device()
             self._host_step += 1
             if zero_copy:

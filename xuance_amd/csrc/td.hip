@@ -4,6 +4,7 @@
 //   sync_target     : dqn_learner.py:56-57 / qmix_learner.py:105-106 (hard target copy), graph-capturable
 // All HBM/latency bound: per row a few hundred bytes; the dense work (Q-networks, hyper-networks) runs in gemm.hip.
 #include "common.h"
+#include "rng.h"
 
 namespace xrl {
 
@@ -338,6 +339,95 @@ __global__ void __launch_bounds__(TAIL_T) dqn_tail_td_kernel(xrl_dqn_tail_td_t p
     for (int i = tid; i < P * F; i += TAIL_T) {
         const int q = i >> 6, ff = i & 63;
         dy[i] = (q == s_arg[ff] && s_f[0][ff] > 0.f) ? s_df[ff] : 0.f;    // xrl_maxpool_hw_bwd: first maximum, times relu'
+    }
+}
+
+// The acting twin of dqn_tail_td_kernel (off_policy.py:129-148 on deep_q_network.py:61-80): pool of env e's frame, hidden layer,
+// Q layer, greedy action + the per-env epsilon coin (xrl_egreedy's rule and Philox stream) -- one launch instead of four.
+__global__ void __launch_bounds__(TAIL_T) dqn_act_tail_kernel(xrl_dqn_act_tail_t p) {
+    __shared__ __attribute__((aligned(16))) float s_f[TAIL_F];
+    __shared__ __attribute__((aligned(16))) float s_part[TAIL_HMAX][4];
+    __shared__ float s_h[TAIL_HMAX];
+    __shared__ float s_q[64];
+    __shared__ float s_mv[TAIL_W][TAIL_F];
+    constexpr int F = TAIL_F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int A = p.A, H = p.H, P = p.P, e = blockIdx.x;
+    const int k4 = lane & 15, rsub = lane >> 4, jrow = 4 * wave + rsub;
+    float4 we[TAIL_RMAX];
+#pragma unroll
+    for (int i = 0; i < TAIL_RMAX; ++i)
+        we[i] = *reinterpret_cast<const float4*>(p.w1 + (size_t)min(TAIL_RR * i + jrow, H - 1) * F + 4 * k4);
+    const float* frame = p.y + (size_t)e * P * F;
+    float pv[TAIL_PQ];
+#pragma unroll
+    for (int q = 0; q < TAIL_PQ; ++q) pv[q] = frame[(size_t)min(wave + TAIL_W * q, P - 1) * F + lane];
+    float w2[TAIL_QP][TAIL_HMAX / 64];
+#pragma unroll
+    for (int u = 0; u < TAIL_QP; ++u) {
+        const float* w = p.w2 + (size_t)min(wave + TAIL_W * u, A - 1) * H;
+#pragma unroll
+        for (int t = 0; t < TAIL_HMAX / 64; ++t) w2[u][t] = w[min(lane + 64 * t, H - 1)];
+    }
+    const float b1 = p.b1[min(tid, H - 1)], eps = *p.eps_dev;
+    const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
+    float best = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < TAIL_PQ; ++q) if (wave + TAIL_W * q < P) best = fmaxf(best, pv[q]);
+    s_mv[wave][lane] = best;
+    __syncthreads();
+    if (tid < F) {
+        float v = s_mv[0][tid];
+#pragma unroll
+        for (int g = 1; g < TAIL_W; ++g) v = fmaxf(v, s_mv[g][tid]);
+        s_f[tid] = v;
+        if (p.feat) p.feat[(size_t)e * p.ld_f + tid] = v;
+    }
+    __syncthreads();
+    const float4 f0 = *reinterpret_cast<const float4*>(&s_f[4 * k4]);
+#pragma unroll
+    for (int i = 0; i < TAIL_RMAX; ++i) {
+        const int j = TAIL_RR * i + jrow;
+        if (j < H) {
+            const float s0 = quad_sum(dot4(f0, we[i]));
+            if ((k4 & 3) == 0) s_part[j][k4 >> 2] = s0;
+        }
+    }
+    __syncthreads();
+    if (tid < H) {
+        const float4 q4 = *reinterpret_cast<const float4*>(&s_part[tid][0]);
+        s_h[tid] = act_apply(((q4.x + q4.y) + (q4.z + q4.w)) + b1, p.act);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < TAIL_QP; ++u) {
+        const int a = wave + TAIL_W * u;
+        if (a < A) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < TAIL_HMAX / 64; ++t) if (lane + 64 * t < H) acc = fmaf(s_h[lane + 64 * t], w2[u][t], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) s_q[a] = acc + p.b2[a];
+        }
+    }
+    for (int a = wave + TAIL_W * TAIL_QP; a < A; a += TAIL_W) {
+        const float* w = p.w2 + (size_t)a * H;
+        float acc = 0.f;
+        for (int k = lane; k < H; k += 64) acc = fmaf(s_h[k], w[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) s_q[a] = acc + p.b2[a];
+    }
+    __syncthreads();
+    if (tid < A && p.q) p.q[(size_t)e * p.ld_q + tid] = s_q[tid];
+    if (tid == 0) {
+        int bi = 0;
+        float bv = s_q[0];
+        for (int j = 1; j < A; ++j) if (s_q[j] > bv) { bv = s_q[j]; bi = j; }   // argmax: first maximal index (xrl_egreedy)
+        uint32_t r[4];
+        philox4x32(p.seed, (uint32_t)e, step, STREAM_EGREEDY, r);
+        const int a = (u01(r[0]) < eps) ? (int)(r[1] % (uint32_t)A) : bi;
+        p.action[e] = a;
+        if (p.action_f) p.action_f[e] = (float)a;
     }
 }
 
@@ -685,6 +775,16 @@ extern "C" int xrl_dqn_tail_td(const xrl_dqn_tail_td_t* p, xrl_stream_t stream) 
     XRL_CHECK_ARG(p->slabs == nullptr || ((reinterpret_cast<uintptr_t>(p->slabs) & 15) == 0 && p->slab_stride % 4 == 0 && p->off_w1 % 4 == 0 &&
                                           p->off_w1 >= 0 && p->off_b1 >= 0 && p->off_w2 >= 0 && p->off_b2 >= 0));
     hipLaunchKernelGGL(dqn_tail_td_kernel, dim3(p->M), dim3(TAIL_T), 0, as_stream(stream), *p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_dqn_act_tail(const xrl_dqn_act_tail_t* p, xrl_stream_t stream) {
+    XRL_CHECK_ARG(p && p->y && p->w1 && p->b1 && p->w2 && p->b2 && p->eps_dev && p->action);
+    XRL_CHECK_ARG(p->n > 0 && p->n <= 65535 && p->A > 0 && p->A <= 64 && p->F == TAIL_F && p->H >= 1 && p->H <= TAIL_HMAX);
+    XRL_CHECK_ARG(p->P > 0 && p->P <= TAIL_W * TAIL_PQ && (!p->q || p->ld_q >= p->A) && (!p->feat || p->ld_f >= p->F));
+    XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->w1) & 15) == 0);
+    hipLaunchKernelGGL(dqn_act_tail_kernel, dim3(p->n), dim3(TAIL_T), 0, as_stream(stream), *p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -1087,8 +1087,9 @@ class ConvStack:
             ws = self._ws[tag] = ConvStack.Workspace(self, rows, keep)
         return ws
 
-    def forward(self, x, rows, ws, flat=None):
-        """x: [rows, H*W*C] uint8 (or float32) NHWC frames -> ws.feat[:rows] (n_feat features per frame)."""
+    def forward(self, x, rows, ws, flat=None, pool=True):
+        """x: [rows, H*W*C] uint8 (or float32) NHWC frames -> ws.feat[:rows] (n_feat features per frame); pool=False: the caller's
+        launch pools ws.y[-1] itself."""
         P = self.params
         for i, (H, W, C, k, s, p, OH, OW, F) in enumerate(self.geo):
             if self.implicit:
@@ -1104,6 +1105,8 @@ class ConvStack:
                                           aux=ws.skw[i].data_ptr() if ks > 1 else None, ldaux=ks if ks > 1 else 0)])
             x = ws.y[i]
         H, W, C, k, s, p, OH, OW, F = self.geo[-1]
+        if not pool:
+            return
         if self.flatten:
             ops.flatten_chw_fwd(ws.y[-1], ws.feat, rows, OH * OW, F, self.n_feat)
         else:
@@ -1403,6 +1406,28 @@ class DeepQCNN:
         if L1.in_level != 0 or L1.in_off != 0 or L1.K != 64 or L1.N > 512 or L1.N != self.plan.widths[1] or L2.K != L1.N:
             return None
         return L1, L2
+
+    def act_egreedy(self, x_u8, n, eps_dev, action, action_f, seed, step, step_dev=None):
+        """Q(obs) of the eval network + OffPolicyAgent.exploration's choice for n frames: the convolutions, then pool + hidden + Q
+        layers + the epsilon-greedy action in ONE launch (xrl_dqn_act_tail) when fused_tail() covers the network.  Returns the Q
+        tensor [n, n_actions] (rows of plan.acts[last])."""
+        tail = self.fused_tail()
+        if tail is None:
+            q = self.forward(x_u8, n)
+            ops.egreedy(q=q, eps_dev=eps_dev, action=action, action_f=action_f, n=n, A=self.n_actions, ld=q.stride(0), seed=seed,
+                        step=step, step_dev=step_dev)
+            return q
+        L1, L2 = tail
+        ws = self.conv.workspace("nograd", n, False)
+        self.conv.forward(x_u8[:n].reshape(n, -1), n, ws, pool=False)
+        Hc, Wc, C, k, s, p, OH, OW, F = self.conv.geo[-1]
+        self.plan.ensure(n)
+        q, prm = self.plan.acts[2], self.params
+        ops.dqn_act_tail(y=ws.y[-1], w1=prm.ptr(L1.w_name), b1=prm.ptr(L1.b_name), w2=prm.ptr(L2.w_name), b2=prm.ptr(L2.b_name),
+                         eps_dev=eps_dev, action=action, action_f=action_f, q=q, feat=ws.feat, step_dev=step_dev, seed=int(seed),
+                         step=int(step), n=n, A=L2.N, H=L1.N, F=F, P=OH * OW, ld_q=self.plan.widths[2], ld_f=ws.feat.shape[1],
+                         act=ops.ACT[L1.act])
+        return q
 
     def tail_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma, slabs=None):
         """After forward_pair(..., skip_last="tail"): pool + hidden + Q layers + TD + the gradients back to the last convolution's

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -124,6 +124,11 @@ def dqn_tail_td(**kw):
     """Max-pool of the last convolution's output, hidden + Q layer of both networks, TD rule, d_h, d_feat and the pool's
     backward in one launch (xrl_dqn_tail_td)."""
     call("xrl_dqn_tail_td", C.byref(_struct(DqnTailTd, kw)), stream_ptr())
+
+
+def dqn_act_tail(**kw):
+    """Pool + hidden + Q layer + epsilon-greedy action of a DeepQCNN in one launch (xrl_dqn_act_tail)."""
+    call("xrl_dqn_act_tail", C.byref(_struct(DqnActTail, kw)), stream_ptr())
 
 
 def conv_desc(**kw):
