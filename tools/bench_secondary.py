@@ -212,6 +212,8 @@ def ppo_atari(steps=3, warmup=2):
     agent = PPO_Agent(cfg, SyntheticAtariVecEnv(n, seed=5))
     for _ in range(warmup):
         agent.rollout(); agent.update()
+    import gc
+    gc.collect()                                    # (see dqn_c3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
