@@ -139,6 +139,43 @@ def test_dqn_cnn_learner_vs_reference_fixture(name, implicit, tail):
                   ("evalQ", "predictQ", "targetQ"), "Qloss")
 
 
+@pytest.mark.parametrize("M,shape", [(32, (84, 84, 4)), (7, (44, 36, 4))])
+@pytest.mark.parametrize("double_q", [False, True])
+def test_dqn_cnn_tail_launch_vs_the_layered_launches(double_q, M, shape):
+    """xrl_dqn_tail_td (pool .. pool backward in one launch, each transition's dense gradient terms into its own slab) against the
+    launches it replaces -- which the reference fixtures pin -- on the same parameters and batch, under DQN and double-Q (three
+    frames per transition; no reference fixture of DDQN behind the convolution stack exists): Q values, TD terms, the gradient of
+    EVERY parameter (the reduced slabs) and the incoming gradient of the last convolution at 1e-5 of each tensor's scale.  The
+    second shape has 11 x 9 pooled positions and a batch that leaves slab rows untouched."""
+    from xuance_amd.nets import DeepQCNN
+    from xuance_amd.learners import DQN_Learner, DDQN_Learner
+    rng = np.random.default_rng(3)
+    batch = dict(obs=rng.integers(0, 256, (M,) + shape, dtype=np.uint8), obs_next=rng.integers(0, 256, (M,) + shape, dtype=np.uint8),
+                 actions=rng.integers(0, 4, M).astype(np.float32), rewards=rng.standard_normal(M).astype(np.float32),
+                 terminals=(rng.random(M) < 0.2).astype(np.float32))
+    out = []
+    for tail in (True, False):
+        torch.manual_seed(0)
+        net = DeepQCNN(shape, 4)
+        cls = DDQN_Learner if double_q else DQN_Learner
+        lr = cls(base_cfg(learning_rate=1e-4, gamma=0.99, sync_frequency=100, use_grad_clip=False, use_fused_q_tail=tail), net, Capture())
+        assert net.fused_tail() is not None
+        info = lr.update(batch_size=M, **batch)
+        torch.cuda.synchronize()
+        Re = 2 * M if double_q else M
+        out.append(dict(q=npy(net.plan.acts[2][:Re, :4]), qt=npy(net.target_plan.acts[2][:M, :4]), dq=npy(net.plan.dacts[2][:M, :4]),
+                        dh=npy(net.plan.dacts[1][:M]), h=npy(net.plan.acts[1][:Re]), grad=npy(lr.optimizer.grad),
+                        dy=npy(net._ws.dy[-1][:M * net.conv.geo[-1][6] * net.conv.geo[-1][7]]), loss=info["Qloss"], pq=info["predictQ"]))
+    a, b = out
+    for k in ("q", "qt", "dq", "dh", "h", "dy", "loss", "pq"):
+        assert_close(a[k], b[k], 1e-5, k)
+    P = net.params
+    for name in net.trainable_order:                                   # every parameter's gradient at ITS scale
+        o, n = P.offsets[name], int(np.prod(P.shapes[name]))
+        assert np.abs(b["grad"][o:o + n]).max() > 0, name
+        assert_close(a["grad"][o:o + n], b["grad"][o:o + n], 1e-5, "gradient of " + name)
+
+
 def test_dueldqn_cnn_learner_vs_reference_fixture():
     """DuelDQN_Learner on DuelingDeepQNetwork over Basic_CNN (dueldqn_learner.py:28-75, q_head.py:42-80 on cnn.py:11-50) -- the
     dueling streams behind the convolution stack -- against the reference learner's own three updates (tests/golden/dueldqn_cnn.npz,
