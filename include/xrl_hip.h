@@ -55,6 +55,9 @@ typedef struct {
 /* store_element x6 (memory_tools.py:44-61,232-240; off-policy :365-372): field[t] <- src for every field.
  * Time-major layout makes each field one contiguous copy of n_envs*row_bytes bytes. fields: HOST array. */
 int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n_envs, int t, xrl_stream_t stream);
+/* ... and *size_dev <- new_size in the same launch (the filled-slot count of a replay ring that device-side sampling follows) */
+int xrl_soa_store_step_sized(const xrl_field_t* fields, int n_fields, int n_envs, int t, int32_t* size_dev, int32_t new_size,
+                             xrl_stream_t stream);
 
 /* DummyOnPolicyBuffer.finish_path for every env and every closed path segment at once
  * (memory_tools.py:242-265, call sites ppo_agent.py:129-135,146-157).
@@ -500,10 +503,11 @@ typedef struct {
     const float* q;          // [n][ld] Q-values
     const float* uniforms;   // optional [n] supplied uniforms
     const int32_t* randoms;  // optional [n] supplied random actions
-    const float* eps_dev;    // epsilon in device memory
+    const float* eps_dev;    // epsilon in device memory, or NULL: `eps` below (eager loops: the host knows the value, no fill launch)
     int32_t* action;         // [n]
     float* action_f;         // [n] float copy for the replay buffer (actions are stored as float32)
     int n, A, ld;
+    float eps;               // used when eps_dev is NULL
     uint64_t seed;
     uint32_t step;
     const uint32_t* step_dev;
@@ -515,12 +519,13 @@ int xrl_egreedy(const xrl_egreedy_t* p, xrl_stream_t stream);
 typedef struct {
     const float* q;          /* [R][ld] per-agent Q-values, R = n_envs * n_agents */
     const float* avail;      /* NULL or [R][A] f32 0/1 */
-    const float* eps_dev;    /* [1] epsilon in device memory */
+    const float* eps_dev;    /* [1] epsilon in device memory, or NULL: `eps` below */
     const float* coin;       /* NULL or [1] supplied uniform for the step coin (parity tests) */
     const float* uniforms;   /* NULL or [R] supplied uniforms for the random actions */
     int32_t* action;         /* [R] */
     float* action_f;         /* NULL or [R] float32 copy (the replay buffer stores actions as float32) */
-    int32_t R, A, ld, pad;
+    int32_t R, A, ld;
+    float eps;               /* used when eps_dev is NULL */
     uint64_t seed;
     uint32_t step; const uint32_t* step_dev;
 } xrl_marl_act_t;
@@ -850,7 +855,7 @@ int xrl_dqn_tail_td(const xrl_dqn_tail_td_t* p, xrl_stream_t stream);
 typedef struct {
     const float* y;            /* [n][P][F] last convolution's output */
     const float* w1; const float* b1; const float* w2; const float* b2;   /* [H][F], [H], [A][H], [A] */
-    const float* eps_dev;
+    const float* eps_dev;      /* [1], or NULL: `eps` below */
     int32_t* action;           /* [n] */
     float* action_f;           /* NULL or [n] */
     float* q;                  /* NULL or [n][ld_q] */
@@ -858,7 +863,8 @@ typedef struct {
     const uint32_t* step_dev;
     uint64_t seed;
     uint32_t step;
-    int32_t n, A, H, F, P, ld_q, ld_f, act, pad;
+    int32_t n, A, H, F, P, ld_q, ld_f, act;
+    float eps;                 /* used when eps_dev is NULL */
 } xrl_dqn_act_tail_t;
 int xrl_dqn_act_tail(const xrl_dqn_act_tail_t* p, xrl_stream_t stream);
 int xrl_dqn_head_td(const xrl_dqn_head_td_t* p, xrl_stream_t stream);
@@ -985,10 +991,11 @@ typedef struct {
     int32_t* action;            /* NULL (no selection) or [R] */
     float* action_f;            /* NULL or [R] */
     const float* avail;         /* NULL or [R][n_actions] f32 0/1 */
-    const float* eps_dev;       /* [1] with action */
+    const float* eps_dev;       /* [1] with action, or NULL: `eps` below */
     const uint32_t* step_dev;   /* NULL or [1]: added to step */
     uint64_t seed;
-    uint32_t step, pad;
+    uint32_t step;
+    float eps;                  /* used when eps_dev is NULL */
 } xrl_marl_act_gru_t;
 int xrl_marl_act_gru(const xrl_marl_act_gru_t* p, xrl_stream_t stream);
 int xrl_marl_act_gru_layout(const xrl_marl_act_gru_t* p, xrl_qa_image_t* out);

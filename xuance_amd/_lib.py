@@ -52,7 +52,7 @@ class DqnTailTd(C.Structure):
 class DqnActTail(C.Structure):
     _fields_ = [(k, c_void_p) for k in ("y", "w1", "b1", "w2", "b2", "eps_dev", "action", "action_f", "q", "feat", "step_dev")] + \
                [("seed", C.c_uint64), ("step", C.c_uint32)] + \
-               [(k, c_int32) for k in ("n", "A", "H", "F", "P", "ld_q", "ld_f", "act", "pad")]
+               [(k, c_int32) for k in ("n", "A", "H", "F", "P", "ld_q", "ld_f", "act")] + [("eps", c_float)]
 
 
 class ImageJob(C.Structure):
@@ -113,7 +113,7 @@ class PostStep(C.Structure):
 
 class EGreedy(C.Structure):
     _fields_ = [("q", c_void_p), ("uniforms", c_void_p), ("randoms", c_void_p), ("eps_dev", c_void_p),
-                ("action", c_void_p), ("action_f", c_void_p), ("n", c_int), ("A", c_int), ("ld", c_int),
+                ("action", c_void_p), ("action_f", c_void_p), ("n", c_int), ("A", c_int), ("ld", c_int), ("eps", c_float),
                 ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
 
 
@@ -284,7 +284,7 @@ class MarlActGru(C.Structure):
                 ("R", c_int32), ("rows_per_wg", c_int32), ("O", c_int32), ("H", c_int32), ("ldq", c_int32), ("act", c_int32),
                 ("n_pre", c_int32), ("n_post", c_int32), ("pre", c_int32 * 3), ("post", c_int32 * 3),
                 ("action", c_void_p), ("action_f", c_void_p), ("avail", c_void_p), ("eps_dev", c_void_p), ("step_dev", c_void_p),
-                ("seed", C.c_uint64), ("step", C.c_uint32), ("pad", C.c_uint32)]
+                ("seed", C.c_uint64), ("step", C.c_uint32), ("eps", c_float)]
 
 
 class Exchange(C.Structure):
@@ -310,7 +310,7 @@ class Mirrors(C.Structure):
 class MarlAct(C.Structure):
     _fields_ = [("q", c_void_p), ("avail", c_void_p), ("eps_dev", c_void_p), ("coin", c_void_p), ("uniforms", c_void_p),
                 ("action", c_void_p), ("action_f", c_void_p), ("R", c_int32), ("A", c_int32), ("ld", c_int32),
-                ("pad", c_int32), ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
+                ("eps", c_float), ("seed", C.c_uint64), ("step", C.c_uint32), ("step_dev", c_void_p)]
 
 
 _SIGS = {
@@ -384,6 +384,7 @@ _SIGS = {
     "xrl_random_permutation": [c_void_p, c_int, c_int64, c_int64, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
     "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],
     "xrl_soa_store_step": [C.POINTER(Field), c_int, c_int, c_int, c_void_p],
+    "xrl_soa_store_step_sized": [C.POINTER(Field), c_int, c_int, c_int, c_void_p, c_int32, c_void_p],
     "xrl_gae_scan": [c_void_p] * 7 + [c_int, c_int, c_double, c_double, c_int, c_void_p],
     "xrl_adv_stats": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "xrl_soa_gather": [C.POINTER(Field), c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

@@ -97,11 +97,17 @@ class QMIX_Agents(AgentSurface):
     def _build_learner(self, *args):
         return self.learner_cls(*args)
 
-    def _update_explore_factor(self):                          # off_policy_marl.py:197-204
+    def _update_explore_factor(self, push=True):               # off_policy_marl.py:197-204
         if self.e_greedy > self.end_greedy:
             self.e_greedy = self.start_greedy - self.delta_egreedy * self.current_step
         else:
             self.e_greedy = self.end_greedy
+        if push:
+            self._push_eps()
+
+    def _push_eps(self):
+        """epsilon into device memory for the launches that read it there (the feed-forward loop hands the value to its acting
+        launch as an argument instead: no fill launch per vector step)."""
         if self.e_greedy != getattr(self, "_eps_on_device", None):
             self.eps_dev.fill_(float(self.e_greedy))
             self._eps_on_device = self.e_greedy
@@ -312,7 +318,7 @@ class QMIX_Agents(AgentSurface):
             # image kept current by the optimiser launch's mirrors), else three GEMM launches + xrl_marl_select_actions
             self._refresh_act_image(fused_act)
             self.model.act_step(obs.view(R, -1), R, None, fused=fused_act,
-                                select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev, action=env.action,
+                                select=dict(avail=avail if self.use_actions_mask else None, eps_dev=None, eps=float(self.e_greedy), action=env.action,
                                             action_f=self.act_f, seed=self.seed, step=self._host_step,
                                             step_dev=None))    # eager loop: the host knows the step index
             env.step_device()
@@ -333,8 +339,9 @@ class QMIX_Agents(AgentSurface):
                 self._cb("on_train_epochs_end", self.current_step, policy=self.model, memory=self.memory, train_steps=train_steps,
                          update_info=info)
             self.current_step += n
-            self._update_explore_factor()
+            self._update_explore_factor(push=False)
             self._cb("on_train_step_end", self.current_step, envs=env, policy=self.model, train_steps=train_steps, train_info=info)
+        self._push_eps()
         info = dict(self.learner.flush_info() or info)          # update phases ran unsynchronised: read the last one's info
         info["epsilon"] = self.e_greedy
         return info

@@ -27,8 +27,9 @@ struct FieldPack {
 // ------------------------------------------------------------------------------------------ store
 // field[t] <- src : one contiguous copy of n_envs*row_bytes per field (blockIdx.y = field).
 template <typename V>
-__global__ void __launch_bounds__(256) store_step_kernel(FieldPack f, int n_envs, int t) {
+__global__ void __launch_bounds__(256) store_step_kernel(FieldPack f, int n_envs, int t, int32_t* size_dev, int32_t new_size) {
     const int fi = blockIdx.y;
+    if (size_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *size_dev = new_size;   // filled slots of a replay ring
     const size_t step_bytes = (size_t)n_envs * f.row_bytes[fi];
     const size_t n = step_bytes / sizeof(V);
     const V* __restrict__ s = reinterpret_cast<const V*>(f.src[fi]);
@@ -347,7 +348,8 @@ extern "C" int xrl_device_info(int* cu_count, int* wave_size, char* arch, int ar
     return XRL_OK;
 }
 
-extern "C" int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n_envs, int t, xrl_stream_t stream) {
+extern "C" int xrl_soa_store_step_sized(const xrl_field_t* fields, int n_fields, int n_envs, int t, int32_t* size_dev, int32_t new_size,
+                                        xrl_stream_t stream) {
     FieldPack fp; bool vec16;
     XRL_CHECK_ARG(pack_fields(fields, n_fields, fp, vec16) == XRL_OK);
     XRL_CHECK_ARG(n_envs > 0 && t >= 0);
@@ -362,10 +364,14 @@ extern "C" int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     dim3 grid((unsigned)nb, n_fields);
-    if (vec16) hipLaunchKernelGGL(store_step_kernel<uint4>, grid, 256, 0, as_stream(stream), fp, n_envs, t);
-    else hipLaunchKernelGGL(store_step_kernel<uint32_t>, grid, 256, 0, as_stream(stream), fp, n_envs, t);
+    if (vec16) hipLaunchKernelGGL(store_step_kernel<uint4>, grid, 256, 0, as_stream(stream), fp, n_envs, t, size_dev, new_size);
+    else hipLaunchKernelGGL(store_step_kernel<uint32_t>, grid, 256, 0, as_stream(stream), fp, n_envs, t, size_dev, new_size);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
+}
+
+extern "C" int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n_envs, int t, xrl_stream_t stream) {
+    return xrl_soa_store_step_sized(fields, n_fields, n_envs, t, nullptr, 0, stream);
 }
 
 extern "C" int xrl_soa_gather(const xrl_field_t* fields, int n_fields, const int64_t* idx, int bs, int n_envs, int T,

@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
         const int r = r0 + tid;
         const uint32_t step = p->step + (p->step_dev ? *p->step_dev : 0u);
         const int a = marl_select_row(lds + L->q + tid * L->ldq, p->avail ? p->avail + (size_t)r * A : nullptr, A, p->seed, step, r,
-                                      *p->eps_dev, nullptr, nullptr);
+                                      p->eps_dev ? *p->eps_dev : p->eps, nullptr, nullptr);
         p->action[r] = a;
         if (p->action_f) p->action_f[r] = (float)a;
     }
@@ -736,7 +736,7 @@ extern "C" int xrl_marl_act_gru(const xrl_marl_act_gru_t* pp, xrl_stream_t strea
     XRL_CHECK_ARG(p.image && p.obs && p.q && p.R > 0 && p.rows_per_wg > 0 && p.H >= 0 && p.O >= 1 && (p.h || p.H == 0));
     XRL_CHECK_ARG(p.n_pre >= 0 && p.n_post >= 1 && p.n_pre + p.n_post + 2 <= XRL_QA_MAX_LAYERS && (p.H > 0 || p.n_pre >= 1));
     XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p.image) & 15) == 0 && p.ldq >= p.post[p.n_post - 1]);
-    XRL_CHECK_ARG(p.action == nullptr || (p.eps_dev != nullptr && p.rows_per_wg <= QF_THREADS));
+    XRL_CHECK_ARG(p.action == nullptr || p.rows_per_wg <= QF_THREADS);
     QaArgs args{};
     args.p = p;
     args.L = qa_layout(p);

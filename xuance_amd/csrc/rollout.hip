@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(256) egreedy_kernel(xrl_egreedy_t p) {
     philox4x32(p.seed, (uint32_t)e, step, STREAM_EGREEDY, r);
     const float u = p.uniforms ? p.uniforms[e] : u01(r[0]);
     const int ra = p.randoms ? p.randoms[e] : (int)(r[1] % (uint32_t)p.A);
-    const int a = (u < *p.eps_dev) ? ra : best;
+    const int a = (u < (p.eps_dev ? *p.eps_dev : p.eps)) ? ra : best;
     p.action[e] = a;
     if (p.action_f) p.action_f[e] = (float)a;
 }
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) marl_select_kernel(xrl_marl_act_t p) {
     if (r >= p.R) return;
     const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
     const int a = marl_select_row(p.q + (size_t)r * p.ld, p.avail ? p.avail + (size_t)r * p.A : nullptr, p.A, p.seed, step, r,
-                                  *p.eps_dev, p.coin, p.uniforms);
+                                  p.eps_dev ? *p.eps_dev : p.eps, p.coin, p.uniforms);
     p.action[r] = a;
     if (p.action_f) p.action_f[r] = (float)a;
 }
@@ -465,7 +465,7 @@ extern "C" int xrl_rollout_poststep(const xrl_poststep_t* params, xrl_stream_t s
 extern "C" int xrl_egreedy(const xrl_egreedy_t* params, xrl_stream_t stream) {
     XRL_CHECK_ARG(params != nullptr);
     const xrl_egreedy_t& p = *params;
-    XRL_CHECK_ARG(p.q && p.eps_dev && p.action && p.n > 0 && p.A > 0 && p.ld >= p.A);
+    XRL_CHECK_ARG(p.q && p.action && p.n > 0 && p.A > 0 && p.ld >= p.A);
     hipLaunchKernelGGL(egreedy_kernel, dim3((p.n + 255) / 256), dim3(256), 0, as_stream(stream), p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
@@ -474,7 +474,7 @@ extern "C" int xrl_egreedy(const xrl_egreedy_t* params, xrl_stream_t stream) {
 extern "C" int xrl_marl_select_actions(const xrl_marl_act_t* params, xrl_stream_t stream) {
     XRL_CHECK_ARG(params != nullptr);
     const xrl_marl_act_t& p = *params;
-    XRL_CHECK_ARG(p.q && p.eps_dev && p.action && p.R > 0 && p.A > 0 && p.ld >= p.A);
+    XRL_CHECK_ARG(p.q && p.action && p.R > 0 && p.A > 0 && p.ld >= p.A);
     hipLaunchKernelGGL(marl_select_kernel, dim3((p.R + 255) / 256), dim3(256), 0, as_stream(stream), p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;

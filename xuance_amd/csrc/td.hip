@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(TAIL_T) dqn_act_tail_kernel(xrl_dqn_act_tail_t
 #pragma unroll
         for (int t = 0; t < TAIL_HMAX / 64; ++t) w2[u][t] = w[min(lane + 64 * t, H - 1)];
     }
-    const float b1 = p.b1[min(tid, H - 1)], eps = *p.eps_dev;
+    const float b1 = p.b1[min(tid, H - 1)], eps = p.eps_dev ? *p.eps_dev : p.eps;
     const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
     float best = -INFINITY;
 #pragma unroll
@@ -780,7 +780,7 @@ extern "C" int xrl_dqn_tail_td(const xrl_dqn_tail_td_t* p, xrl_stream_t stream) 
 }
 
 extern "C" int xrl_dqn_act_tail(const xrl_dqn_act_tail_t* p, xrl_stream_t stream) {
-    XRL_CHECK_ARG(p && p->y && p->w1 && p->b1 && p->w2 && p->b2 && p->eps_dev && p->action);
+    XRL_CHECK_ARG(p && p->y && p->w1 && p->b1 && p->w2 && p->b2 && p->action);
     XRL_CHECK_ARG(p->n > 0 && p->n <= 65535 && p->A > 0 && p->A <= 64 && p->F == TAIL_F && p->H >= 1 && p->H <= TAIL_HMAX);
     XRL_CHECK_ARG(p->P > 0 && p->P <= TAIL_W * TAIL_PQ && (!p->q || p->ld_q >= p->A) && (!p->feat || p->ld_f >= p->F));
     XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->w1) & 15) == 0);

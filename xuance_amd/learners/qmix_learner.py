@@ -201,10 +201,13 @@ class QMIX_Learner(Learner):
             act = getattr(m, "_act_state", None)            # the acting launch's weight image follows every step too
             if act is not None:
                 mirrors.append((act.map, act.image))
+            tail = getattr(self, "_tail", None) or {}           # (update_from_buffer: this epoch's loss sums, the phase's draw-counter tick)
             ops.reduce_adam(self.slabs, S, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip,
                             mirrors, self.opt_sync, target=m.target_flat,
                             target_every=self.sync_frequency, exchange=self.gradient_exchange(),
-                            target_image=fs.img_target if fs else None)
+                            target_image=fs.img_target if fs else None, **tail)
+            if tail:
+                self._tail_done += 1
             return
         self._images_current = False
         self._images_stale = True
@@ -331,18 +334,29 @@ class QMIX_Learner(Learner):
                                                             # before this phase if anything else touched the parameters)
                 in_kernel = self.fused_eligible() and self._fused.n_groups(B) <= self.slabs.shape[0] and \
                     getattr(self.config, "fused_qmix_gather_in_kernel", True)
+                self._tail_done = 0
                 for e in range(n_epochs):
                     self.partials = self._phase_partials[e]
-                    if in_kernel:                           # the update launch draws and gathers its own batch from the ring
-                        self._step(B, ring=dict(memory=memory, n_envs=memory.n_envs, n_size=memory.n_size,
-                                                size_dev=memory.size_dev, seed=seed, counter=e,
-                                                counter_dev=self._sample_counter, idx_out=self._idx))
-                    else:
-                        memory.draw_into(self._idx, dst, seed, e, self._sample_counter)     # draw + gather: one launch
-                        self._step(B)
+                    # this epoch's loss sums -- and, with the last epoch, the phase's draw-counter tick -- ride in the optimiser
+                    # launch (xrl_mirrors_t.part / .tick) instead of two launches behind the phase
+                    self._tail = dict(partials=(self._phase_partials[e], B, self._epoch_sums[e]))
+                    if e == n_epochs - 1:
+                        self._tail["tick"] = (self._sample_counter, n_epochs)
+                    try:
+                        if in_kernel:                       # the update launch draws and gathers its own batch from the ring
+                            self._step(B, ring=dict(memory=memory, n_envs=memory.n_envs, n_size=memory.n_size,
+                                                    size_dev=memory.size_dev, seed=seed, counter=e,
+                                                    counter_dev=self._sample_counter, idx_out=self._idx))
+                        else:
+                            memory.draw_into(self._idx, dst, seed, e, self._sample_counter)     # draw + gather: one launch
+                            self._step(B)
+                    finally:
+                        self._tail = None
                 self._images_current = False
-                ops.counter_add(self._sample_counter, n_epochs)
-                ops.sum_partials_batched(self._phase_partials, B, 8, self._epoch_sums, n_epochs, B * 8, 8)
+                if self._tail_done != n_epochs:             # (the two-launch optimiser path: nothing rode along)
+                    assert self._tail_done == 0
+                    ops.counter_add(self._sample_counter, n_epochs)
+                    ops.sum_partials_batched(self._phase_partials, B, 8, self._epoch_sums, n_epochs, B * 8, 8)
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
             if not self.needs_collective():

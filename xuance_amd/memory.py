@@ -255,11 +255,12 @@ class HipOffPolicyBuffer:
         step = self.stager.put({"observations": obs, "actions": acts, "rewards": rews, "terminals": terminals,
                                 "next_observations": next_obs})
         f = self.soa
-        ops.soa_store_step([(f.fields[k], step[k], f.row_bytes[k]) for k in step], self.n_envs, self.ptr)
+        grow = self.size < self.n_size                         # (the filled-slot count for device-side sampling rides in the launch)
+        ops.soa_store_step([(f.fields[k], step[k], f.row_bytes[k]) for k in step], self.n_envs, self.ptr,
+                           size_dev=self.size_dev if grow else None, new_size=self.size + 1)
         self.ptr = (self.ptr + 1) % self.n_size
-        if self.size < self.n_size:
-            self.size += 1
-            self.size_dev.fill_(self.size)                   # `size` for sampling kernels inside captured graphs
+        if grow:
+            self.size += 1                   # `size` for sampling kernels inside captured graphs
 
     def gather_into(self, idx, dst):
         """dst: field name -> device tensor [bs, row] (a learner's staging views); one launch, no host work."""

@@ -70,11 +70,12 @@ class HipMARLOffPolicyBuffer:
         items = {k: self._stack(v) for k, v in step_data.items() if k in self.specs}
         step = self.stager.put(items)
         f = self.soa
-        ops.soa_store_step([(f.fields[k], step[k], f.row_bytes[k]) for k in step], self.n_envs, self.ptr)
+        grow = self.size < self.n_size                         # (the filled-slot count for device-side sampling rides in the launch)
+        ops.soa_store_step([(f.fields[k], step[k], f.row_bytes[k]) for k in step], self.n_envs, self.ptr,
+                           size_dev=self.size_dev if grow else None, new_size=self.size + 1)
         self.ptr = (self.ptr + 1) % self.n_size
-        if self.size < self.n_size:
+        if grow:
             self.size += 1
-            self.size_dev.fill_(self.size)
 
     def gather_into(self, idx, dst):
         """dst: field name -> device tensor [bs, row] (e.g. a learner's staging views); one launch, no host work."""

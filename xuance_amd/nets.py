@@ -1407,15 +1407,16 @@ class DeepQCNN:
             return None
         return L1, L2
 
-    def act_egreedy(self, x_u8, n, eps_dev, action, action_f, seed, step, step_dev=None):
-        """Q(obs) of the eval network + OffPolicyAgent.exploration's choice for n frames: the convolutions, then pool + hidden + Q
+    def act_egreedy(self, x_u8, n, eps_dev, action, action_f, seed, step, step_dev=None, eps=0.0):
+        """Q(obs) of the eval network + OffPolicyAgent.exploration's choice for n frames (epsilon from eps_dev, or by value when
+        eps_dev is None): the convolutions, then pool + hidden + Q
         layers + the epsilon-greedy action in ONE launch (xrl_dqn_act_tail) when fused_tail() covers the network.  Returns the Q
         tensor [n, n_actions] (rows of plan.acts[last])."""
         tail = self.fused_tail()
         if tail is None:
             q = self.forward(x_u8, n)
-            ops.egreedy(q=q, eps_dev=eps_dev, action=action, action_f=action_f, n=n, A=self.n_actions, ld=q.stride(0), seed=seed,
-                        step=step, step_dev=step_dev)
+            ops.egreedy(q=q, eps_dev=eps_dev, eps=float(eps), action=action, action_f=action_f, n=n, A=self.n_actions, ld=q.stride(0),
+                        seed=seed, step=step, step_dev=step_dev)
             return q
         L1, L2 = tail
         ws = self.conv.workspace("nograd", n, False)
@@ -1424,7 +1425,7 @@ class DeepQCNN:
         self.plan.ensure(n)
         q, prm = self.plan.acts[2], self.params
         ops.dqn_act_tail(y=ws.y[-1], w1=prm.ptr(L1.w_name), b1=prm.ptr(L1.b_name), w2=prm.ptr(L2.w_name), b2=prm.ptr(L2.b_name),
-                         eps_dev=eps_dev, action=action, action_f=action_f, q=q, feat=ws.feat, step_dev=step_dev, seed=int(seed),
+                         eps_dev=eps_dev, eps=float(eps), action=action, action_f=action_f, q=q, feat=ws.feat, step_dev=step_dev, seed=int(seed),
                          step=int(step), n=n, A=L2.N, H=L1.N, F=F, P=OH * OW, ld_q=self.plan.widths[2], ld_f=ws.feat.shape[1],
                          act=ops.ACT[L1.act])
         return q

@@ -34,10 +34,14 @@ def _fields(pairs, flags=None):
     return arr
 
 
-def soa_store_step(pairs, n_envs, t):
-    """pairs: [(field_tensor [T,n_envs,...], step_tensor [n_envs,...], row_bytes)]"""
+def soa_store_step(pairs, n_envs, t, size_dev=None, new_size=0):
+    """pairs: [(field_tensor [T,n_envs,...], step_tensor [n_envs,...], row_bytes)]; size_dev: int32 [1] tensor that receives
+    new_size in the same launch (a replay ring's filled-slot count)."""
     arr = _fields(pairs)
-    call("xrl_soa_store_step", arr, len(pairs), int(n_envs), int(t), stream_ptr())
+    if size_dev is not None:
+        call("xrl_soa_store_step_sized", arr, len(pairs), int(n_envs), int(t), ptr(size_dev), int(new_size), stream_ptr())
+    else:
+        call("xrl_soa_store_step", arr, len(pairs), int(n_envs), int(t), stream_ptr())
 
 
 def soa_gather(pairs, idx, n_envs, T, stats=None, flags=None):
@@ -793,7 +797,9 @@ class MarlActGruState:
         if select is None:
             s.action = None
         else:
-            s.action, s.eps_dev = ptr(select["action"]), ptr(select["eps_dev"])
+            s.action = ptr(select["action"])
+            s.eps_dev = ptr(select["eps_dev"]) if select.get("eps_dev") is not None else None   # (None: epsilon by value)
+            s.eps = float(select.get("eps", 0.0))
             s.action_f = ptr(select["action_f"]) if select.get("action_f") is not None else None
             s.avail = ptr(select["avail"]) if select.get("avail") is not None else None
             s.step_dev = ptr(select["step_dev"]) if select.get("step_dev") is not None else None
