@@ -78,3 +78,26 @@ def test_image_maps_and_class_geometry_vs_torch_conv():
 def test_shapes_outside_the_kernel_limits_take_the_im2col_path():
     P = _Params([("c0.weight", (16, 3, 3, 3)), ("c0.bias", (16,))])
     assert not ConvStack(P, ["c0"], (32, 32, 3), (3,), (1,), (16,)).implicit
+
+
+def test_inverse_image_maps_invert_the_pack_maps():
+    """ConvStack.inverse_maps (what xrl_reduce_adam's mirrors take: parameter -> image position) against the pack map
+    (xrl_gather_images: image position -> parameter): every weight of every layer sits exactly once in the forward section, every
+    weight of layers 1.. exactly once in the input-gradient section, biases and dense parameters nowhere."""
+    from xuance_amd.nets import DeepQCNN
+    net = DeepQCNN((84, 84, 4), 4, device="cpu")
+    cs = net.conv
+    inv_f, inv_d = (t.numpy() for t in cs.inverse_maps())
+    m = cs._map.numpy()
+    for inv, lo, hi in ((inv_f, 0, cs._n_fwd), (inv_d, cs._n_fwd, cs._n_img)):
+        pos = np.nonzero(inv >= 0)[0]
+        assert np.array_equal(m[inv[pos]], pos) and ((inv[pos] >= lo) & (inv[pos] < hi)).all()
+        assert np.array_equal(np.sort(inv[pos]), np.arange(lo, hi)[m[lo:hi] >= 0])
+    P = net.params
+    for i, name in enumerate(cs.names):
+        o, n = P.offsets[name + ".weight"], int(np.prod(P.shapes[name + ".weight"]))
+        assert (inv_f[o:o + n] >= 0).all() and (inv_d[o:o + n] >= 0).all() == (i > 0)
+        ob = P.offsets[name + ".bias"]
+        assert (inv_f[ob:ob + P.shapes[name + ".bias"][0]] < 0).all()
+    dense = P.offsets["eval_Q_head.q_value.0.weight"]
+    assert (inv_f[dense:] < 0).all() and (inv_d[dense:] < 0).all()

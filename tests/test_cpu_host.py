@@ -33,7 +33,9 @@ def test_ctypes_structs_match_c_layout():
              "xrl_adam_state_t": _lib.AdamState, "xrl_rms_t": _lib.Rms, "xrl_sample_t": _lib.Sample,
              "xrl_cartpole_t": _lib.CartPole, "xrl_poststep_t": _lib.PostStep, "xrl_egreedy_t": _lib.EGreedy,
              "xrl_mirrors_t": _lib.Mirrors, "xrl_exchange_t": _lib.Exchange, "xrl_marl_gate_t": _lib.MarlGate,
-             "xrl_ppo_wide_t": _lib.PpoWide, "xrl_wide_act_t": _lib.WideAct}
+             "xrl_ppo_wide_t": _lib.PpoWide, "xrl_wide_act_t": _lib.WideAct, "xrl_conv_t": _lib.Conv, "xrl_classic_t": _lib.Classic,
+             "xrl_dqn_head_td_t": _lib.DqnHeadTd, "xrl_dqn_tail_td_t": _lib.DqnTailTd, "xrl_dqn_act_tail_t": _lib.DqnActTail,
+             "xrl_marl_act_t": _lib.MarlAct, "xrl_marl_act_gru_t": _lib.MarlActGru}
     for extra in ("xrl_dqn_td_t", "xrl_qmix_t"):
         cls = getattr(_lib, {"xrl_dqn_td_t": "DqnTd", "xrl_qmix_t": "Qmix"}[extra], None)
         if cls is not None:
@@ -44,7 +46,16 @@ def test_ctypes_structs_match_c_layout():
     src += 'printf("adam.base_lr %zu\\n", offsetof(xrl_adam_state_t, base_lr));\n'
     src += 'printf("act.post %zu\\n", offsetof(xrl_wide_act_t, post));\nprintf("act.xchg %zu\\n", offsetof(xrl_wide_act_t, xchg));\n'
     src += 'printf("wide.obs %zu\\n", offsetof(xrl_ppo_wide_t, obs));\nprintf("wide.dbg %zu\\n", offsetof(xrl_ppo_wide_t, dbg));\n'
-    src += 'printf("loss.M %zu\\n", offsetof(xrl_ppo_loss_t, M));\nreturn 0;}\n'
+    src += 'printf("loss.M %zu\\n", offsetof(xrl_ppo_loss_t, M));\n'
+    offs = {"xrl_mirrors_t": (_lib.Mirrors, ("tick", "part_out", "tick_inc", "part_rows")),        # fields added in round 3
+            "xrl_egreedy_t": (_lib.EGreedy, ("eps", "seed", "step_dev")), "xrl_marl_act_t": (_lib.MarlAct, ("eps", "seed")),
+            "xrl_marl_act_gru_t": (_lib.MarlActGru, ("eps_dev", "step", "eps")),
+            "xrl_dqn_tail_td_t": (_lib.DqnTailTd, ("partials", "M", "act", "gamma", "slabs", "slab_stride", "off_b2")),
+            "xrl_dqn_act_tail_t": (_lib.DqnActTail, ("step_dev", "seed", "step", "n", "act", "eps"))}
+    for cname, (cls, fields) in offs.items():
+        for f in fields:
+            src += f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));\n'
+    src += 'return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c, exe = os.path.join(d, "sz.c"), os.path.join(d, "sz")
         open(c, "w").write(src)
@@ -52,6 +63,9 @@ def test_ctypes_structs_match_c_layout():
         out = dict(line.split() for line in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())
     for cname, cls in pairs.items():
         assert int(out[cname]) == ctypes.sizeof(cls), cname
+    for cname, (cls, fields) in offs.items():
+        for f in fields:
+            assert int(out[f"{cname}.{f}"]) == getattr(cls, f).offset, (cname, f)
     assert int(out["adam.base_lr"]) == _lib.AdamState.base_lr.offset
     assert int(out["loss.M"]) == _lib.PpoLoss.M.offset
     assert int(out["wide.obs"]) == _lib.PpoWide.obs.offset and int(out["wide.dbg"]) == _lib.PpoWide.dbg.offset
