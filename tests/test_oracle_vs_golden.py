@@ -419,3 +419,60 @@ def test_classic_control_oracles_known_answers():
     assert ((s[:, 0] >= -0.6) & (s[:, 0] <= -0.4)).all() and (s[:, 1:] == 0).all()
     s = o.classic_reset_state(3, 3, np.arange(64), np.zeros(64, np.int64))
     assert (np.abs(s) <= 0.1).all() and s.std() > 0.03
+
+
+def test_classic_control_oracles_conserve_what_the_physics_conserves():
+    """No Gymnasium here to pin the restated dynamics against (header of oracle/xrl_oracle.py), so pin them against physics the
+    restatement does not contain: with zero torque the acrobot's total energy -- written from the Lagrangian's terms, not from
+    _dsdt -- stays put to the integrator's accuracy over whole swings (a sign or coefficient slip in phi1 / phi2 / d1 / d2 breaks
+    it at once); the mountain car with the engine off moves on the level set of v^2 / 2 + (g / 3) sin(3 x); the pendulum without
+    torque keeps l^2 m / 6 * thdot^2 + m g l / 2 * cos(th) (checked at a fine step: semi-implicit Euler wobbles by O(dt))."""
+    from oracle import xrl_oracle as o
+    rng = np.random.default_rng(1)
+    # acrobot ("book" parameters: m = l = I = 1, lc = 0.5, g = 9.8)
+    def energy(s):
+        t1, t2, w1, w2 = s.T
+        d1 = 0.25 + (1 + 0.25 + np.cos(t2)) + 2.0
+        d2 = 0.25 + 0.5 * np.cos(t2) + 1.0
+        kin = 0.5 * (d1 * w1 ** 2 + 2 * d2 * w1 * w2 + 1.25 * w2 ** 2)
+        pot = -(0.5 + 1.0) * 9.8 * np.cos(t1) - 0.5 * 9.8 * np.cos(t1 + t2)
+        return kin + pot
+    s0 = np.stack([rng.uniform(-2.5, 2.5, 64), rng.uniform(-2.5, 2.5, 64), rng.uniform(-1, 1, 64), rng.uniform(-1, 1, 64)], 1)
+    # (a) the vector field itself: dE/dt = grad E . dsdt(s, torque 0) = 0 at random states (central differences of E)
+    f = o.AcrobotOracle._dsdt(s0, np.zeros(64))
+    dE = np.zeros(64)
+    for j in range(4):
+        h = np.zeros(4); h[j] = 1e-6
+        dE += (energy(s0 + h) - energy(s0 - h)) / 2e-6 * f[:, j]
+    assert np.abs(dE).max() < 1e-6 * np.abs(energy(s0)).max(), np.abs(dE).max()
+    f1 = o.AcrobotOracle._dsdt(s0, np.ones(64))                   # ... and a torque on the second joint feeds power tau * dtheta2
+    dE1 = sum((energy(s0 + np.eye(4)[j] * 1e-6) - energy(s0 - np.eye(4)[j] * 1e-6)) / 2e-6 * f1[:, j] for j in range(4))
+    assert np.abs(dE1 - s0[:, 3]).max() < 1e-5
+    # (b) the integrator: the oracle's RK4 step at a fine dt keeps the energy over 2 simulated seconds (at the env's own dt = 0.2 a
+    # fast swing moves by more than a radian per step and RK4's error is visible; that is Gymnasium's discretisation, kept as it is)
+    a = o.AcrobotOracle(s0)
+    a.dt = 0.002
+    e0 = energy(a.state)
+    for _ in range(1000):
+        a.step(np.ones(64, np.int64))
+    clipped = (np.abs(a.state[:, 2]) >= 4 * math.pi - 1e-9) | (np.abs(a.state[:, 3]) >= 9 * math.pi - 1e-9)
+    drift = np.abs(energy(a.state) - e0)[~clipped]
+    assert len(drift) > 32 and drift.max() < 1e-6 * (np.abs(e0).max() + 1), drift.max()
+    # mountain car, engine off: v' = v - g cos(3 x), x' = x + v'  (symplectic Euler: the invariant holds to O(step))
+    m = o.MountainCarOracle(np.stack([rng.uniform(-0.9, 0.0, 64), np.zeros(64), np.zeros(64), np.zeros(64)], 1))
+    h0 = 0.5 * m.state[:, 1] ** 2 + 0.0025 / 3 * np.sin(3 * m.state[:, 0])
+    for _ in range(150):
+        m.step(np.ones(64, np.int64))
+    inside = (m.state[:, 0] > -1.19) & (np.abs(m.state[:, 1]) < 0.069)
+    h1 = 0.5 * m.state[:, 1] ** 2 + 0.0025 / 3 * np.sin(3 * m.state[:, 0])
+    assert inside.sum() > 32 and np.abs(h1 - h0)[inside].max() < 0.05 * 0.0025 / 3 * 2
+    # pendulum without torque (angle from upright; rod: I = m l^2 / 3)
+    p = o.PendulumOracle(np.stack([rng.uniform(-3, 3, 64), rng.uniform(-1, 1, 64), np.zeros(64), np.zeros(64)], 1))
+    def pend_e(st):
+        return st[:, 1] ** 2 / 6 + 10.0 / 2 * np.cos(st[:, 0])
+    p.dt = 0.0005                                                  # (the env's dt = 0.05 wobbles by O(dt); the equations are what is checked)
+    e0 = pend_e(p.state)
+    for _ in range(4000):
+        p.step(np.zeros((64, 1), np.float32))
+    free = np.abs(p.state[:, 1]) < 7.99
+    assert free.sum() > 32 and np.abs(pend_e(p.state) - e0)[free].max() < 0.02   # of a 10-unit energy range
