@@ -92,8 +92,9 @@ def _event_time_us(fn, reps):
 
 def kernel_rooflines(agent):
     """Rooflines of the two kernels that make up the timed region (profiles/*.csv), timed live with HIP events on the
-    launch stream: (1) xrl::rollout_persistent_kernel -- ONE launch per rollout: T vector steps + the bootstrap pass (or,
-    when the persistent form is not eligible, xrl::rollout_step_fast_kernel, T + 1 launches) -- and
+    launch stream: (1) xrl::actor_rollout_kernel + xrl::critic_values_kernel -- the T vector steps of a rollout as ONE launch
+    with only the actor on the step chain, then values / bootstrap values of the rollout as one batched launch (or, when the
+    network is not of that class, xrl::rollout_step_cartpole_kernel, T + 1 launches) -- and
     (2) xrl::ppo_trunk_kernel -- one launch per minibatch, (64-row tile, role) workgroups -- measured inside the real minibatch sequence.
     `achieved` = ALGORITHMIC fp32 flops of the policy network (67 328 flop forward per row, 201 984
     flop forward+backward per sample) divided by the launch time; both kernels are latency-bound at this workload."""
@@ -101,21 +102,24 @@ def kernel_rooflines(agent):
     lr, mem, m = agent.learner, agent.memory, agent.model
     T, n, bs = agent.horizon_size, agent.n_envs, agent.batch_size
     fwd_flops_row = sum(2.0 * L.N * L.K for st in m.plan.stages for L in st)
-    # (1) rollout kernel(s), without the GAE scan / counter bump / parameter re-pack of the rollout graph
-    persistent = getattr(agent, "persist_status", None) is not None
+    # (1) rollout kernel(s), without the GAE scan / counter bump of the rollout graph
+    actor = agent._actor_rollout() is not None
+    persistent = actor and getattr(agent, "persist_status", None) is not None
     kernel_only = lambda: agent._enqueue_rollout_fused(kernel_only=True)
     kernel_only()
-    launches = 1 if persistent else T + 1
+    launches = 1 if persistent else (T if actor else T + 1)
     us_launch = _event_time_us(kernel_only, 5) / launches
-    rows = 2 * n * (T + 1 if persistent else 1)           # act tiles + bootstrap tiles, per launch
+    rows = n * T if persistent else (n if actor else 2 * n)   # rows through the whole network per launch (+ the sparse bootstrap rows)
     fl_launch = fwd_flops_row * rows
-    name = "xrl::rollout_persistent_kernel" if persistent else "xrl::rollout_step_fast_kernel"
+    name = ("xrl::actor_rollout_kernel + xrl::critic_values_kernel" if persistent else "xrl::actor_rollout_kernel") if actor \
+        else "xrl::rollout_step_cartpole_kernel"
     r1 = {"bound": "mfma", "kernel": name, "achieved": round(fl_launch / us_launch / 1e6, 4),
           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_launch / us_launch / 1e6 / PEAK_FP32_MFMA_TFLOPS, 5),
-          "traffic": _pmc_traffic(name), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_launch, 3),
+          "traffic": _pmc_traffic("xrl::actor_rollout_kernel" if actor else name), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_launch, 3),
           "algorithmic_flops_per_launch": fl_launch,
           "note": "latency-bound: %d rows x %.0f flop per launch (%s); see DESIGN.md section 3"
-                  % (rows, fwd_flops_row, "%d vector steps of 2 x %d rows" % (T + 1, n) if persistent else "one vector step")}
+                  % (rows, fwd_flops_row, "%d vector steps of %d envs on the actor chain + their values as one batched pass" % (T, n)
+                     if persistent else "one vector step")}
     # (2) fused minibatch kernel, timed INSIDE the real minibatch sequence (nb x [minibatch kernel, optimiser launch]) with
     #     an event pair around every minibatch launch.  Timed alone, back to back, the kernel re-reads parameters that are
     #     still in L2 and comes out ~10 % faster than what rocprofv3 sees in the loop.

@@ -599,27 +599,52 @@ typedef struct {
     long long* dbg;                                    /* NULL, or [16] shader-clock stamps of the last workgroup (diagnostics) */
 } xrl_rollout_step_t;
 int xrl_rollout_step_cartpole(const xrl_rollout_step_t* p, xrl_stream_t stream);
-/* Persistent form: all T vector steps of a rollout plus the final bootstrap pass in ONE launch (the workgroups stay
- * resident, parameters / simulator state / running statistics stay on chip, steps are separated by a counter barrier in
- * the L2 of one XCD).  Same results as T calls of xrl_rollout_step_cartpole(step t: slots of row t, the _in / _out buffers swapped
- * every step, bootv_prev = bootv[t-1]) followed by one boot_only call.  Requirements: the 4-128-{128-2,128-1} network
- * class with role_split and frag_image, 3*ceil(n/32) <= CUs of one XCD (n <= 320 on MI355X).
- * step0 describes step 0: *_slot = row 0 of the [T][n] fields, *_in = ping-pong buffer 0, *_out = buffer 1
- * (step0.bootv_prev, last_step, boot_only are ignored; step0.step is the RNG step of row 0).  After the call the
- * statistics / flags of the last step are in buffer T & 1, exactly as after the per-step calls. */
+/* ------------------------------------------------------------------ rollout of the 4-128-{128-2,128-1} class (csrc/rollout_actor.hip)
+ * The step loop of PPO_Agent.train (ppo_agent.py:111-177) for a device-resident CartPole with ONLY the actor on the step
+ * chain: xrl_rollout_cartpole_run executes vector steps [t0, t0 + n_steps) of a rollout of horizon T -- obs_rms.update,
+ * normalisation, actor forward (fp32 MFMA, 16-row tiles), Categorical sample / log-prob, physics with auto-reset, path-end
+ * flags, return tracker, normalised rewards and ret_rms.update in env order -- in ONE launch (n_steps = T: the whole
+ * rollout; n_steps = 1: one launch per vector step, same arithmetic, bit-identical).  It leaves values / bootstrap values
+ * to xrl_rollout_cartpole_values, which evaluates V(obs[t][e]) for the same steps and V(next_obs[t][e]) where seg == 1
+ * (a path cut without termination: truncation / buffer full) as one batched pass over the whole device.
+ * State is updated in place.  Requirements: n <= 256 (16 envs per workgroup, <= 16 actor workgroups + 1 on one XCD).
+ * Layout of the layers in `params` (float offsets): w0 [128][4], b0 [128]; w1 [256][128] / b1 [256] = the stacked branch
+ * layer (rows 0..127 actor, 128..255 critic); wa [2][128], ba [2]; wc [1][128], bc [1].
+ * Replaces, for this class, T calls of xrl_rollout_step_cartpole + the bootstrap pass (same numbers up to fp32 summation
+ * order: 16x16x4 tiles, per-workgroup partial sums of the observation statistics). */
 typedef struct {
-    xrl_rollout_step_t step0;
-    float* bootv;               /* [T][n] bootstrap values */
-    uint32_t* barrier;          /* [128] scratch flags (zeroed by the call, on the stream) */
-    int32_t* status;            /* [4] zero-initialised by the caller: [0] != 0 -> a barrier timed out, results invalid;
-                                 * [1] XCC id of workgroup 0, [2] bit mask of every XCC id the workgroups ever ran on,
-                                 * [3] launches whose workgroups did not share one L2 (exchange through device-scope stores) */
-    int32_t T;
-    int32_t flags;              /* bit 0: always exchange through device-scope stores (diagnostics / tests) */
-} xrl_rollout_persist_t;
-int xrl_rollout_cartpole_persistent(const xrl_rollout_persist_t* p, xrl_stream_t stream);
-/* The fused kernels have shape-specialised twins (compile-time extents, bit-identical results) that are selected
- * automatically when the network is the 4-128-{128-2,128-1} class; 0 forces the any-shape kernels (parity tests). */
+    const float* params;
+    int32_t w0, b0, w1, b1, wa, ba, wc, bc;
+    int32_t act;                                       /* hidden activation (XRL_ACT_*) */
+    int32_t n, T, t0, n_steps;
+    int32_t max_steps, use_obsnorm, use_rewnorm;
+    int32_t flags;                                     /* bit 0: exchange through device-scope stores whatever the placement (tests) */
+    float obs_range, rew_range, gamma, pad0;
+    uint64_t seed, env_seed;
+    uint32_t step; uint32_t pad1;                      /* Philox step of vector step t: step + *step_dev + t */
+    const uint32_t* step_dev;
+    /* state, updated in place */
+    float* obs_raw;                                    /* [n][4] raw observations the agent acts on next */
+    float* obs_stats; double* obs_count;               /* [8] mean | var, [1] */
+    float* ret_stats; double* ret_count;               /* [2] mean, var, [1] */
+    float* ret_track;                                  /* [n] discounted return tracker */
+    double* cp_state; int32_t* cp_steps; int32_t* cp_episodes; float* cp_score; double* cp_stats;
+    /* rollout-buffer fields [T][n] ([T][n][4] observations) */
+    float* f_obs; float* f_act; float* f_logp; float* f_rew; float* f_term; uint8_t* f_seg; float* f_val; float* bootv;
+    /* scratch */
+    float* xnext;                                      /* [T][n][4] normalised next observations (before an auto-reset) */
+    uint8_t* ended;                                    /* [T][n4] episode ended at this step (n4 = n rounded up to 4; zero-initialised) */
+    float* ret_final;                                  /* [T][n4] discounted return of an episode that ended at this step */
+    uint32_t* xchg;                                    /* [2048] exchange words (zeroed by the call, on the stream) */
+    int32_t* status;                                   /* [4] zero-initialised by the caller: [0] != 0 -> a wait timed out, results invalid;
+                                                        * [1] XCC id of workgroup 0, [2] mask of every XCC id ever seen, [3] launches that
+                                                        * exchanged through device-scope stores */
+    long long* dbg;                                    /* NULL, or [16]: shader-clock stamps of workgroup 0's chain wave at step n_steps / 2 */
+} xrl_rollout_run_t;
+int xrl_rollout_cartpole_run(const xrl_rollout_run_t* p, xrl_stream_t stream);
+int xrl_rollout_cartpole_values(const xrl_rollout_run_t* p, xrl_stream_t stream);
+/* The shape-specialised kernel families (the rollout above, the shared-trunk minibatch kernels) are selected automatically
+ * when the network is of their class; 0 forces the any-shape kernels (parity tests). */
 int xrl_set_fast_kernels(int enable);
 /* Re-pack the small parameters (first layer, biases, merged heads) into the image the step kernel copies to LDS with
  * one round trip; call once per rollout after the parameters changed.  Only params/layers/levels of *p are read. */

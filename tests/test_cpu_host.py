@@ -35,7 +35,7 @@ def test_ctypes_structs_match_c_layout():
              "xrl_mirrors_t": _lib.Mirrors, "xrl_exchange_t": _lib.Exchange, "xrl_marl_gate_t": _lib.MarlGate,
              "xrl_ppo_wide_t": _lib.PpoWide, "xrl_wide_act_t": _lib.WideAct, "xrl_conv_t": _lib.Conv, "xrl_classic_t": _lib.Classic,
              "xrl_dqn_head_td_t": _lib.DqnHeadTd, "xrl_dqn_tail_td_t": _lib.DqnTailTd, "xrl_dqn_act_tail_t": _lib.DqnActTail,
-             "xrl_marl_act_t": _lib.MarlAct, "xrl_marl_act_gru_t": _lib.MarlActGru}
+             "xrl_marl_act_t": _lib.MarlAct, "xrl_marl_act_gru_t": _lib.MarlActGru, "xrl_rollout_run_t": _lib.RolloutRun}
     for extra in ("xrl_dqn_td_t", "xrl_qmix_t"):
         cls = getattr(_lib, {"xrl_dqn_td_t": "DqnTd", "xrl_qmix_t": "Qmix"}[extra], None)
         if cls is not None:
@@ -51,7 +51,8 @@ def test_ctypes_structs_match_c_layout():
             "xrl_egreedy_t": (_lib.EGreedy, ("eps", "seed", "step_dev")), "xrl_marl_act_t": (_lib.MarlAct, ("eps", "seed")),
             "xrl_marl_act_gru_t": (_lib.MarlActGru, ("eps_dev", "step", "eps")),
             "xrl_dqn_tail_td_t": (_lib.DqnTailTd, ("partials", "M", "act", "gamma", "slabs", "slab_stride", "off_b2")),
-            "xrl_dqn_act_tail_t": (_lib.DqnActTail, ("step_dev", "seed", "step", "n", "act", "eps"))}
+            "xrl_dqn_act_tail_t": (_lib.DqnActTail, ("step_dev", "seed", "step", "n", "act", "eps")),
+            "xrl_rollout_run_t": (_lib.RolloutRun, ("act", "flags", "gamma", "seed", "step", "step_dev", "obs_raw", "cp_stats", "f_val", "xchg", "dbg"))}
     for cname, (cls, fields) in offs.items():
         for f in fields:
             src += f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));\n'

@@ -186,24 +186,26 @@ def test_cartpole_learns():
     assert s0 < 60 and s1 > 100, (s0, s1)
 
 
-def test_fused_rollout_step_equals_unfused_sequence():
-    """xrl_rollout_step_cartpole (one launch per step) must reproduce the seven-launch sequence it replaces."""
+@pytest.mark.parametrize("kernel", ["any-shape", "actor"])
+def test_fused_rollout_step_equals_unfused_sequence(kernel):
+    """xrl_rollout_step_cartpole (one launch per step, any shape) and xrl_rollout_cartpole_run + _values (the whole rollout of
+    the 4-128-{128-2,128-1} class) must reproduce the seven-launch sequence per step they replace."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv
     res = []
     for fused in (False, True):
         torch.manual_seed(0)
-        env = DeviceCartPoleVecEnv(100, seed=3)          # not a multiple of the 32-row tile
+        env = DeviceCartPoleVecEnv(100, seed=3)          # not a multiple of the 32-row / 16-row tiles
         env.max_episode_steps = 30
-        agent = PPO_Agent(make_config(100, 48, use_fused_rollout=fused), env)
+        agent = PPO_Agent(make_config(100, 48, use_fused_rollout=fused, use_actor_rollout=(kernel == "actor")), env)
         assert agent.use_fused_rollout == fused
+        assert not fused or (agent._actor_rollout() is not None) == (kernel == "actor")
         agent.rollout()
         agent.rollout()                                   # second rollout: state carried across the boundary
         torch.cuda.synchronize()
         f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
         if fused:
-            i = agent.horizon_size & 1
-            stats = dict(obs_mean=npy(agent.pp["obs_stats"][i][:4]), obs_var=npy(agent.pp["obs_stats"][i][4:]),
+            stats = dict(obs_mean=npy(agent.pp["obs_stats"][0][:4]), obs_var=npy(agent.pp["obs_stats"][0][4:]),
                          ret_track=npy(agent.returns), eps=env.episode_stats())
         else:
             stats = dict(obs_mean=npy(agent.obs_mean), obs_var=npy(agent.obs_var), ret_track=npy(agent.returns),
@@ -212,51 +214,70 @@ def test_fused_rollout_step_equals_unfused_sequence():
     (fa, sa), (fb, sb) = res
     assert np.array_equal(fa["actions"], fb["actions"]) and np.array_equal(fa["seg"], fb["seg"])
     assert np.array_equal(fa["terminals"], fb["terminals"])
-    for k in ("observations", "values", "aux_old_logp", "rewards", "bootv", "advantages", "returns"):
+    for k in ("observations", "values", "aux_old_logp", "rewards", "advantages", "returns"):
         assert_close(fb[k], fa[k], 2e-6, k, scale=max(1.0, float(np.abs(fa[k]).max())))
+    need = fa["seg"] == 1                                 # bootstrap values are consumed where a path was cut without termination
+    assert need.any()
+    assert_close(fb["bootv"][need], fa["bootv"][need], 2e-6, "bootv", scale=max(1.0, float(np.abs(fa["bootv"][need]).max())))
     for k in ("obs_mean", "obs_var", "ret_track"):
         assert_close(sb[k], sa[k], 1e-6, k)
     assert sa["eps"][0] == sb["eps"][0] and sa["eps"][0] > 100
 
 
-@pytest.mark.parametrize("act,n,norm", [("leaky_relu", 100, True), ("tanh", 64, True), ("relu", 37, True), ("sigmoid", 32, False)])
-def test_specialised_rollout_kernel_is_bit_identical_to_any_shape_kernel(act, n, norm):
-    """rollout_step_fast_kernel (compile-time 4-128-{128-2,128-1}) vs rollout_step_cartpole_kernel: same bits everywhere."""
+def _rollout_snapshot(agent, env):
+    f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+    f.update(obs_stats=npy(agent.pp["obs_stats"][0]), ret_stats=npy(agent.pp["ret_stats"][0]),
+             obs_count=npy(agent.pp["obs_count"][0]), ret_count=npy(agent.pp["ret_count"][0]),
+             obs_raw=npy(agent.pp["obs_raw"][0]), ret_track=npy(agent.returns), cp_state=npy(env.state),
+             cp_steps=npy(env.steps), cp_episodes=npy(env.episodes), eps=np.asarray(env.episode_stats()))
+    return f
+
+
+@pytest.mark.parametrize("act,n,norm", [("leaky_relu", 100, True), ("tanh", 64, True), ("relu", 37, True), ("sigmoid", 32, False),
+                                        ("leaky_relu", 16, True), ("relu", 256, True)])
+def test_actor_rollout_kernel_equals_any_shape_step_kernel(act, n, norm):
+    """xrl_rollout_cartpole_run + xrl_rollout_cartpole_values (csrc/rollout_actor.hip: actor-only step chain on 16-row tiles,
+    per-workgroup partial sums of the observation statistics, values as a batched pass afterwards) vs T launches of the
+    any-shape step kernel (rollout_step_cartpole_kernel, 32-row tiles, values inside the step): the same trajectory --
+    actions, episode ends and simulator state equal, everything real-valued to fp32 summation-order accuracy.  (An action
+    could legitimately differ where the uniform lands within an ulp of the CDF; none does on these seeds.)"""
     from xuance_amd import ops
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv
     res = []
-    try:
-        for fast in (False, True):
-            ops.set_fast_kernels(fast)
-            torch.manual_seed(0)
-            env = DeviceCartPoleVecEnv(n, seed=3)
-            env.max_episode_steps = 30
-            agent = PPO_Agent(make_config(n, 48, activation=act, use_obsnorm=norm, use_rewnorm=norm,
-                                          use_persistent_rollout=False), env)
-            assert agent.use_fused_rollout
-            agent.rollout()
-            agent.rollout()
-            torch.cuda.synchronize()
-            i = agent.horizon_size & 1
-            f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
-            f.update(obs_stats=npy(agent.pp["obs_stats"][i]), ret_stats=npy(agent.pp["ret_stats"][i]),
-                     ret_track=npy(agent.returns), cp_state=npy(env.state), eps=np.asarray(env.episode_stats()))
-            res.append(f)
-    finally:
-        ops.set_fast_kernels(True)
+    for v2 in (False, True):
+        torch.manual_seed(0)
+        env = DeviceCartPoleVecEnv(n, seed=3)
+        env.max_episode_steps = 30
+        agent = PPO_Agent(make_config(n, 48, activation=act, use_obsnorm=norm, use_rewnorm=norm, use_actor_rollout=v2), env)
+        assert agent.use_fused_rollout and (agent._actor_rollout() is not None) == v2
+        agent.rollout()
+        agent.rollout()
+        torch.cuda.synchronize()
+        if v2:
+            assert agent.persist_status.tolist()[0] == 0
+        res.append(_rollout_snapshot(agent, env))
     a, b = res
     assert a["eps"][0] > 50
-    for k in a:
+    need = (a["seg"] == 1)                                          # bootstrap values exist where a path was cut without termination
+    # (ret_stats / ret_count: the any-shape kernel merges a step's episode ends at the NEXT step, so its statistics lag by the
+    # last step's ends between rollouts; their effect -- every step's normalised reward -- is compared)
+    for k in ("actions", "terminals", "seg", "cp_steps", "cp_episodes", "obs_count"):
         assert np.array_equal(a[k], b[k]), k
+    for k in ("observations", "values", "aux_old_logp", "rewards", "advantages", "returns", "obs_stats", "obs_raw",
+              "ret_track", "cp_state", "eps"):
+        assert_close(b[k], a[k], 2e-6, k, scale=max(1.0, float(np.abs(a[k]).max())))
+    assert need.any()
+    assert_close(b["bootv"][need], a["bootv"][need], 2e-6, "bootv", scale=max(1.0, float(np.abs(a["bootv"][need]).max())))
 
 
-@pytest.mark.parametrize("act,n,norm", [("leaky_relu", 100, True), ("tanh", 256, True), ("relu", 37, True), ("relu", 64, False)])
+@pytest.mark.parametrize("act,n,norm", [("leaky_relu", 100, True), ("tanh", 256, True), ("relu", 37, True), ("relu", 64, False), ("tanh", 16, True)])
 def test_persistent_rollout_is_bit_identical_to_per_step_launches(act, n, norm):
-    """rollout_persistent_kernel (ONE launch per rollout, counter barrier between steps) vs T + 1 launches of
-    rollout_step_fast_kernel: every buffer field, statistic and simulator state must carry the same bits -- with the
-    exchange through plain stores in one L2 (what the launch geometry aims for; status[3] counts launches that did not get
-    that placement) and with the exchange forced through device-scope stores (the mode for any other placement)."""
+    """actor_rollout_kernel as ONE launch per rollout (resident workgroups, one tagged message per workgroup and step) vs T
+    launches of the same kernel with n_steps = 1 (state handed over in memory): every buffer field, statistic and simulator
+    state must carry the same bits -- with the messages as plain stores in one L2 (what the launch geometry aims for;
+    status[3] counts launches that did not get that placement) and forced through device-scope stores (the mode for any
+    other placement)."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv
     res = []
@@ -266,23 +287,21 @@ def test_persistent_rollout_is_bit_identical_to_per_step_launches(act, n, norm):
         env.max_episode_steps = 30
         agent = PPO_Agent(make_config(n, 48, activation=act, use_persistent_rollout=bool(persistent), use_obsnorm=norm,
                                       use_rewnorm=norm, persistent_coherent_exchange=(persistent == "coherent")), env)
-        assert agent.use_fused_rollout
+        assert agent.use_fused_rollout and agent._actor_rollout() is not None
         agent.rollout()
         agent.rollout()
         torch.cuda.synchronize()
         if persistent:
             st = agent.persist_status.tolist()
             assert st[0] == 0, st                                      # no time-out
-            assert st[3] == (2 if persistent == "coherent" else st[3]) and (st[3] == 0) == (bin(st[2]).count("1") == 1 and persistent is True), st
+            exchanges = norm and n > 16                               # (one workgroup / no statistics: no messages at all)
+            if persistent == "coherent":
+                assert st[3] == (2 if exchanges else 0), st
+            else:
+                assert (st[3] == 0) == (bin(st[2]).count("1") <= 1), st
         else:
             assert getattr(agent, "persist_status", None) is None
-        i = agent.horizon_size & 1
-        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
-        f.update(obs_stats=npy(agent.pp["obs_stats"][i]), ret_stats=npy(agent.pp["ret_stats"][i]),
-                 obs_count=npy(agent.pp["obs_count"][i]), ret_count=npy(agent.pp["ret_count"][i]),
-                 obs_raw=npy(agent.pp["obs_raw"][i]), ret_track=npy(agent.returns), cp_state=npy(env.state),
-                 cp_steps=npy(env.steps), cp_episodes=npy(env.episodes), eps=np.asarray(env.episode_stats()))
-        res.append(f)
+        res.append(_rollout_snapshot(agent, env))
     a, b, c = res
     assert a["eps"][0] > 50
     for k in a:
@@ -777,8 +796,8 @@ def test_unusable_whole_rollout_launch_falls_back_and_redoes_the_rollout():
         if inject:
             orig = agent._persistent_ok
 
-            def faulty(split_ok):
-                ok = orig(split_ok)
+            def faulty():
+                ok = orig()
                 if ok:
                     agent.persist_status[0:1].fill_(1)                # "a barrier timed out"
                 return ok
@@ -813,7 +832,7 @@ def test_whole_rollout_time_out_after_the_first_rollout_raises_at_the_update_rea
     agent.update()
     agent.rollout()
     agent.persist_status[0:1].fill_(1)                                # what a barrier time-out leaves behind
-    with pytest.raises(ops.XrlError, match="xrl_rollout_cartpole_persistent"):
+    with pytest.raises(ops.XrlError, match="xrl_rollout_cartpole_run"):
         agent.update()
 
 

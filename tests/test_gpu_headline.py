@@ -68,13 +68,13 @@ def replay_rollout(oracle, sd, f, n, T, env_seed, agent_seed, step0, carry, max_
         done = term | trunc
         ends = done | (t == T - 1)
         assert np.array_equal((f["seg"][t] & 1) > 0, ends), f"path ends t={t}"
-        assert_close(f["bootv"][t][ends], boot[ends], 1e-5, f"bootstrap values t={t}")
+        need = ends & ~term                                            # finish_path(vals[i], i): the value is consumed there only
+        assert np.array_equal(f["seg"][t] == 1, need), f"paths cut without termination t={t}"
+        assert_close(f["bootv"][t][need], boot[need], 1e-5, f"bootstrap values t={t}")
         if buf.full:                                                   # ppo_agent.py:129-135
             for i in range(n):
                 buf.finish_path(0.0 if term[i] else boot[i], i)
         returns = (gamma * returns + rew).astype(np.float32)
-        if t == T - 1:
-            carry["ret_var_before_last_merge"] = float(ret_rms.var)   # the device merges a step's episode ends one step later
         for i in np.flatnonzero(done):
             ret_rms.update(returns[i:i + 1])
             returns[i] = 0.0
@@ -151,8 +151,9 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
             opt.t = opt64.t = opt.sched_steps = opt64.sched_steps = int(agent.learner.optimizer.read().step)
         agent.rollout()
         torch.cuda.synchronize()
-        # the path bench.py times: ONE persistent launch for the whole rollout, no time-out, exchange inside one L2
-        assert agent._rollout_graph is not None and agent.persist_status is not None
+        # the path bench.py times: ONE launch of the actor kernel for the whole rollout (+ the batched values launch), no
+        # time-out, messages inside one L2
+        assert agent._rollout_graph is not None and agent.persist_status is not None and agent._actor_rollout() is not None
         stt = agent.persist_status.tolist()
         assert stt[0] == 0 and stt[3] == 0, stt
         f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
@@ -163,12 +164,10 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
         knife_total += knife
         assert_close(npy(env.state), carry["st"].state, 1e-6, "simulator state after the rollout")
         assert np.array_equal(npy(env.episodes), carry["episodes"]), "episode counters"
-        i = T & 1
-        assert_close(npy(agent.pp["obs_stats"][i][:4]), carry["obs_rms"].mean, 1e-5, "obs_rms.mean")
-        assert_close(npy(agent.pp["obs_stats"][i][4:]), carry["obs_rms"].var, 1e-5, "obs_rms.var")
-        # ret_rms: the device defers the merges of a step's episode ends to the next step (their effect, the normalised
-        # rewards of every step, is compared above); at the end of a rollout the last step's ends are still pending
-        assert_close(npy(agent.pp["ret_stats"][i])[1], carry["ret_var_before_last_merge"], 1e-5, "ret_rms.var")
+        assert_close(npy(agent.pp["obs_stats"][0][:4]), carry["obs_rms"].mean, 1e-5, "obs_rms.mean")
+        assert_close(npy(agent.pp["obs_stats"][0][4:]), carry["obs_rms"].var, 1e-5, "obs_rms.var")
+        assert_close(npy(agent.pp["ret_stats"][0])[1], float(carry["ret_rms"].var), 1e-5, "ret_rms.var")
+        assert_close(npy(agent.pp["ret_stats"][0])[0], float(carry["ret_rms"].mean), 1e-5, "ret_rms.mean")
         assert_close(npy(agent.returns), carry["returns"], 1e-5, "return tracker")
         gae_bit_exact(oracle, f, n, T)
         scale = float(np.abs(buf.advantages).max())

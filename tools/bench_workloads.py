@@ -156,15 +156,16 @@ class Runner:
         return "process-group all-reduce between eager launches of the update"
 
     def rollout_mode(self):
-        """How the timed rollouts ran (c2: csrc/rollout_persist.hip reports its placement per launch)."""
+        """How the timed rollouts ran (c2: csrc/rollout_actor.hip reports its placement per launch)."""
         a = self.agent
         if self.workload == "c2":
             if getattr(a, "persist_status", None) is None:
-                return "one launch per vector step (xrl_rollout_step_cartpole)"
+                return "one launch per vector step (%s)" % ("xrl_rollout_cartpole_run, n_steps = 1" if a._actor_rollout() is not None
+                                                             else "xrl_rollout_step_cartpole")
             st = [int(x) for x in getattr(a.learner, "last_status", None) or a.persist_status.tolist()]
             st += [0] * (4 - len(st))
-            return ("whole-rollout launch (xrl_rollout_cartpole_persistent), status %s: %s" %
-                    (st, "surviving workgroups on ONE XCD, plain-store exchange through its L2" if st[3] == 0 else
+            return ("whole-rollout launch (xrl_rollout_cartpole_run: actor-only step chain) + batched values launch, status %s: %s" %
+                    (st, "workgroups on ONE XCD, plain-store messages through its L2" if st[3] == 0 else
                      "%d launch(es) found their workgroups on several XCDs and exchanged through device-scope stores" % st[3]))
         if self.workload == "c4":
             return "two launches per vector step (xrl_wide_act_step incl. statistics + bookkeeping; provider)" if a._wide_acting() is not None \

@@ -213,9 +213,15 @@ class SynthMarl(C.Structure):
                 ("step", C.c_uint32), ("step_dev", c_void_p), ("prev_state", c_void_p), ("prev_steps", c_void_p), ("totals", c_void_p)]
 
 
-class RolloutPersist(C.Structure):
-    _fields_ = [("step0", RolloutStep), ("bootv", c_void_p), ("barrier", c_void_p), ("status", c_void_p),
-                ("T", c_int32), ("flags", c_int32)]
+class RolloutRun(C.Structure):
+    """xrl_rollout_run_t (csrc/rollout_actor.hip): steps [t0, t0 + n_steps) of a CartPole rollout of the 4-128-{128-2,128-1} class."""
+    _fields_ = [("params", c_void_p)] + [(k, c_int32) for k in ("w0", "b0", "w1", "b1", "wa", "ba", "wc", "bc", "act", "n", "T", "t0",
+                                                                  "n_steps", "max_steps", "use_obsnorm", "use_rewnorm", "flags")] + \
+               [("obs_range", c_float), ("rew_range", c_float), ("gamma", c_float), ("pad0", c_float),
+                ("seed", C.c_uint64), ("env_seed", C.c_uint64), ("step", C.c_uint32), ("pad1", C.c_uint32), ("step_dev", c_void_p)] + \
+               [(k, c_void_p) for k in ("obs_raw", "obs_stats", "obs_count", "ret_stats", "ret_count", "ret_track", "cp_state", "cp_steps",
+                                        "cp_episodes", "cp_score", "cp_stats", "f_obs", "f_act", "f_logp", "f_rew", "f_term", "f_seg",
+                                        "f_val", "bootv", "xnext", "ended", "ret_final", "xchg", "status", "dbg")]
 
 
 class PpoFused(C.Structure):
@@ -379,7 +385,8 @@ _SIGS = {
     "xrl_gather_images": [c_void_p, c_int, c_void_p],
     "xrl_flatten_chw_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_flatten_chw_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
-    "xrl_rollout_cartpole_persistent": [C.POINTER(RolloutPersist), c_void_p],
+    "xrl_rollout_cartpole_run": [C.POINTER(RolloutRun), c_void_p],
+    "xrl_rollout_cartpole_values": [C.POINTER(RolloutRun), c_void_p],
     "xrl_sample_replay_indices": [c_void_p, c_int, c_int, c_int, c_void_p, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
     "xrl_random_permutation": [c_void_p, c_int, c_int64, c_int64, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
     "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],

@@ -210,10 +210,36 @@ class PPO_Agent(AgentSurface):
                     rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
 
     def _enqueue_rollout_fused(self, kernel_only=False):
-        """ONE persistent launch (or T launches of xrl_rollout_step_cartpole + one bootstrap-only launch) + GAE: same
-        numbers as _enqueue_rollout.  kernel_only: just the rollout kernel(s) (bench.py times them in isolation)."""
+        """The whole rollout on the device + GAE: same numbers as _enqueue_rollout (the layered path).  kernel_only: just the
+        rollout kernel(s) (bench.py times them in isolation)."""
         T, n, D, A = self.horizon_size, self.n_envs, self.obs_dim, self.model.action_dim
         env, f, pp = self.envs, self.memory.soa.fields, self.pp
+        cpr = self._actor_rollout()
+        if cpr is not None:
+            # the 4-128-{128-2,128-1} class (csrc/rollout_actor.hip): only the actor is on the step chain; ONE launch for all
+            # T steps (resident workgroups, the step boundary is one tagged message per workgroup), or -- per-step callbacks,
+            # or after a launch reported a time-out -- one launch per vector step of the same kernel (bit-identical); values
+            # and bootstrap values of the whole rollout follow as one batched launch
+            if self._persistent_ok():
+                cpr.run(0, T, flags=int(bool(_get(self.config, "persistent_coherent_exchange", False))),
+                        dbg=getattr(self, "rollout_dbg", None))
+                cpr.values(0, T)
+            else:
+                hooks = self._per_step() and not kernel_only
+                for t in range(T):
+                    cpr.run(t, 1)
+                    if hooks:
+                        cpr.values(t, 1)
+                        self._step_hooks(t)
+                if not hooks:
+                    cpr.values(0, T)
+            if kernel_only:
+                return
+            ops.counter_add(self.step_counter, T)
+            ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
+                         self.gamma, self.gae_lam, self.memory.use_gae)
+            return
+        # any other shape / more envs: T launches of the any-shape step kernel + one bootstrap-only launch
         if not kernel_only:
             ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image, self.frag_image)   # params changed
         plan = self.model.plan
@@ -228,44 +254,22 @@ class PPO_Agent(AgentSurface):
                       use_rewnorm=int(self.use_rewnorm), obs_range=float(self.obsnorm_range),
                       rew_range=float(self.rewnorm_range), gamma=float(self.gamma), seed=self.seed, env_seed=env.seed,
                       step_dev=self.step_counter)
-        step0 = dict(obs_raw_in=pp["obs_raw"][0], obs_raw_out=pp["obs_raw"][1], xnext_in=pp["xnext"][0],
-                     xnext_out=pp["xnext"][1], obs_stats_in=pp["obs_stats"][0], obs_stats_out=pp["obs_stats"][1],
-                     obs_count_in=pp["obs_count"][0], obs_count_out=pp["obs_count"][1], ret_stats_in=pp["ret_stats"][0],
-                     ret_stats_out=pp["ret_stats"][1], ret_count_in=pp["ret_count"][0], ret_count_out=pp["ret_count"][1],
-                     ended_in=pp["ended"][0], ended_out=pp["ended"][1], ret_final_in=pp["ret_final"][0],
-                     ret_final_out=pp["ret_final"][1], obs_slot=f["observations"][0], act_slot=f["actions"][0],
-                     val_slot=f["values"][0], logp_slot=f["aux_old_logp"][0], rew_slot=f["rewards"][0],
-                     term_slot=f["terminals"][0], seg_slot=f["seg"][0], last_step=0, boot_only=0, step=0)
-        persistent = self._persistent_ok(split_ok)
-        if persistent:
-            # ONE launch for the whole rollout: resident workgroups, flag barrier between steps (rollout_persist.hip).  The
-            # library refuses (before launching anything) when the workgroups cannot all be resident on one XCD, e.g. on a
-            # partitioned device: fall back to one launch per step.
-            try:
-                ops.rollout_cartpole_persistent(plan, T, f["bootv"], self.persist_barrier, self.persist_status,
-                                                flags=int(bool(_get(self.config, "persistent_coherent_exchange", False))),
-                                                **step0, **common)
-            except ops.XrlError:
-                persistent = False
-                self.persist_status = None
-                self.config.use_persistent_rollout = False
-        if not persistent:
-            for t in range(T):
-                i, o = t & 1, (t + 1) & 1
-                ops.rollout_step_cartpole(
-                    self.model.plan, obs_raw_in=pp["obs_raw"][i], obs_raw_out=pp["obs_raw"][o], xnext_in=pp["xnext"][i],
-                    xnext_out=pp["xnext"][o], obs_stats_in=pp["obs_stats"][i], obs_stats_out=pp["obs_stats"][o],
-                    obs_count_in=pp["obs_count"][i], obs_count_out=pp["obs_count"][o], ret_stats_in=pp["ret_stats"][i],
-                    ret_stats_out=pp["ret_stats"][o], ret_count_in=pp["ret_count"][i], ret_count_out=pp["ret_count"][o],
-                    ended_in=pp["ended"][i], ended_out=pp["ended"][o], ret_final_in=pp["ret_final"][i],
-                    ret_final_out=pp["ret_final"][o], obs_slot=f["observations"][t], act_slot=f["actions"][t],
-                    val_slot=f["values"][t], logp_slot=f["aux_old_logp"][t], rew_slot=f["rewards"][t],
-                    term_slot=f["terminals"][t], seg_slot=f["seg"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None,
-                    last_step=int(t == T - 1), boot_only=0, step=t, **common)
-                if not kernel_only:
-                    self._step_hooks(t)
-            ops.rollout_step_cartpole(self.model.plan, xnext_in=pp["xnext"][T & 1], bootv_prev=f["bootv"][T - 1], boot_only=1,
-                                      last_step=0, step=0, **common)
+        for t in range(T):
+            i, o = t & 1, (t + 1) & 1
+            ops.rollout_step_cartpole(
+                self.model.plan, obs_raw_in=pp["obs_raw"][i], obs_raw_out=pp["obs_raw"][o], xnext_in=pp["xnext"][i],
+                xnext_out=pp["xnext"][o], obs_stats_in=pp["obs_stats"][i], obs_stats_out=pp["obs_stats"][o],
+                obs_count_in=pp["obs_count"][i], obs_count_out=pp["obs_count"][o], ret_stats_in=pp["ret_stats"][i],
+                ret_stats_out=pp["ret_stats"][o], ret_count_in=pp["ret_count"][i], ret_count_out=pp["ret_count"][o],
+                ended_in=pp["ended"][i], ended_out=pp["ended"][o], ret_final_in=pp["ret_final"][i],
+                ret_final_out=pp["ret_final"][o], obs_slot=f["observations"][t], act_slot=f["actions"][t],
+                val_slot=f["values"][t], logp_slot=f["aux_old_logp"][t], rew_slot=f["rewards"][t],
+                term_slot=f["terminals"][t], seg_slot=f["seg"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None,
+                last_step=int(t == T - 1), boot_only=0, step=t, **common)
+            if not kernel_only:
+                self._step_hooks(t)
+        ops.rollout_step_cartpole(self.model.plan, xnext_in=pp["xnext"][T & 1], bootv_prev=f["bootv"][T - 1], boot_only=1,
+                                  last_step=0, step=0, **common)
         if kernel_only:
             return
         ops.counter_add(self.step_counter, T)
@@ -293,20 +297,40 @@ class PPO_Agent(AgentSurface):
         self._cb("on_train_step_end", step + n, envs=self.envs, policy=self.model, train_steps=getattr(self, "_train_steps", None),
                  train_info=getattr(self, "_last_info", {}))
 
-    def _persistent_ok(self, split_ok):
-        """Whole-rollout launch: the 4-128-{128-2,128-1} class, all workgroups resident on one XCD (n_envs <= 320)."""
-        if not bool(_get(self.config, "use_persistent_rollout", True)) or not split_ok or self._per_step():
-            return False
-        plan = self.model.plan
-        if list(plan.widths) != [4, 128, 256, 3] or 3 * ((self.n_envs + 31) // 32) > 32 or not ops.fast_kernels_enabled():
-            return False
-        if getattr(self, "persist_status", None) is None:
-            self.persist_barrier = torch.zeros(128, dtype=torch.int32, device=self.device)
-            # the status words ride in the learner's read-back block: the host sees them at the one sync of every update
-            self.persist_status = self.learner.status_words
-            self.persist_status.zero_()
-            self._persist_validated = False
-        return True
+    def _actor_rollout(self):
+        """ops.CartPoleRollout of this agent when the network is the 4-128-{128-2,128-1} class and n_envs <= 256
+        (config.use_actor_rollout: False keeps the any-shape per-step kernel), else None.  State lives in slot 0 of the
+        ping-pong tensors (where the any-shape path leaves it after an even number of steps)."""
+        if not hasattr(self, "_cpr"):
+            self._cpr = None
+            if bool(_get(self.config, "use_actor_rollout", True)) and ops.CartPoleRollout.eligible(self.model.plan, self.n_envs):
+                env, f, pp, n, T, dev = self.envs, self.memory.soa.fields, self.pp, self.n_envs, self.horizon_size, self.device
+                n4 = (n + 3) // 4 * 4
+                self.persist_xchg = torch.zeros(2048, dtype=torch.int32, device=dev)
+                # the status words ride in the learner's read-back block: the host sees them at the one sync of every update
+                status = self.learner.status_words
+                status.zero_()
+                self.persist_status = status if bool(_get(self.config, "use_persistent_rollout", True)) and not self._per_step() else None
+                self._cpr = ops.CartPoleRollout(
+                    self.model.plan, T, params=self.model.params.flat, n=n, max_steps=int(env.max_episode_steps),
+                    use_obsnorm=int(self.use_obsnorm), use_rewnorm=int(self.use_rewnorm), obs_range=float(self.obsnorm_range),
+                    rew_range=float(self.rewnorm_range), gamma=float(self.gamma), seed=self.seed, env_seed=env.seed, step=0,
+                    step_dev=self.step_counter, obs_raw=pp["obs_raw"][0], obs_stats=pp["obs_stats"][0], obs_count=pp["obs_count"][0],
+                    ret_stats=pp["ret_stats"][0], ret_count=pp["ret_count"][0], ret_track=self.returns, cp_state=env.state,
+                    cp_steps=env.steps, cp_episodes=env.episodes, cp_score=env.ep_score, cp_stats=env.stats,
+                    f_obs=f["observations"], f_act=f["actions"], f_logp=f["aux_old_logp"], f_rew=f["rewards"], f_term=f["terminals"],
+                    f_seg=f["seg"], f_val=f["values"], bootv=f["bootv"], xnext=torch.zeros(T, n, 4, device=dev),
+                    ended=torch.zeros(T, n4, dtype=torch.uint8, device=dev), ret_final=torch.zeros(T, n4, device=dev),
+                    xchg=self.persist_xchg, status=status)
+        elif self._cpr is not None and not ops.fast_kernels_enabled():
+            return None
+        return self._cpr
+
+    def _persistent_ok(self):
+        """Whole-rollout launch of the actor kernel: unless switched off (config.use_persistent_rollout, or after a launch
+        reported a time-out) or per-step callbacks want the host between the steps."""
+        return bool(_get(self.config, "use_persistent_rollout", True)) and not self._per_step() and \
+            getattr(self, "persist_status", None) is not None
 
     def _enqueue_rollout(self):
         if self.use_fused_rollout:
@@ -397,7 +421,7 @@ class PPO_Agent(AgentSurface):
             self._mb_graphs = None
         self._fixed_idx = True
 
-    # -- whole-rollout launch: its failure flags (csrc/rollout_persist.hip) are part of the contract -----------------------
+    # -- whole-rollout launch: its failure flags (csrc/rollout_actor.hip) are part of the contract -----------------------
     @staticmethod
     def _persist_status_ok(st):
         """status[0] != 0: a barrier timed out (results invalid).  Workgroups on more than one XCD are NOT a failure: the
@@ -581,9 +605,8 @@ class PPO_Agent(AgentSurface):
         info = self.learner.last_info(self.rem if self.rem else self.batch_size)
         if getattr(self, "persist_status", None) is not None and not self._persist_status_ok(self.learner.last_status):
             # read at the one host sync of the update phase: the rollout this update consumed was cut short
-            raise ops.XrlError(f"xrl_rollout_cartpole_persistent: status {self.learner.last_status} (barrier time-out or "
-                               "workgroups on more than one XCD): the last rollout is incomplete; restart with "
-                               "use_persistent_rollout: False")
+            raise ops.XrlError(f"xrl_rollout_cartpole_run: status {self.learner.last_status} (a wait between the resident "
+                               "workgroups timed out): the last rollout is incomplete; restart with use_persistent_rollout: False")
         return info
 
     def train(self, train_steps):
@@ -784,7 +807,7 @@ class PG_Agent(PPO_Agent):
                              rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
         # get_terminated_values = the processed reward (pg_agent.py:66-79); terminated envs close with 0 (seg bit 2)
         torch.mul(f["rewards"][t], 1.0, out=f["bootv"][t])      # (an elementwise KERNEL: a D2D copy would become a memcpy node
-        #                                                            when this step is captured, see csrc/rollout_persist.hip)
+        #                                                            when this step is captured, see csrc/rollout_actor.hip)
 
     def _enqueue_rollout(self):
         T = self.horizon_size

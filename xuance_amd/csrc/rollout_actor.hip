@@ -1,0 +1,745 @@
+// On-policy rollout of the 4-128-{128-2,128-1} class on a device-resident CartPole, second design (round 4).
+//
+// What a vector step of PPO_Agent.train (ppo_agent.py:111-177, on_policy.py:128-169) REALLY chains: obs statistics over
+// all envs -> normalise -> ACTOR forward -> sample -> envs.step -> next observations.  The critic (values of the stored
+// observations, bootstrap values of truncated paths) and the return statistics (reward normalisation) consume a step's
+// results but nothing of the next step depends on them.  So
+//   * actor_rollout_kernel keeps ONLY the actor on the step chain: workgroup w owns 16 envs (one 16-row MFMA tile,
+//     v_mfma_f32_16x16x4_f32: 64 instructions of 8 passes per matrix wave instead of the 64 x 16 passes of a 32-row tile),
+//     weights in registers for all the steps of the launch, simulator state in LDS / registers;
+//   * the only thing the workgroups exchange per step are their 16-row partial sums of the new raw observations (8 doubles).
+//     They travel as sixteen 8-byte units {tag, half a double}: a unit is one atomic 64-bit store / load, the tag is the
+//     step, so DATA AND FLAG ARE ONE MESSAGE -- a step boundary is one store latency + one load latency (the first design:
+//     stores -> vmcnt(0) -> workgroup barrier -> flag store -> flag poll -> workgroup barrier -> data loads);
+//   * one extra workgroup ("bookkeeper", one wave) trails the actors through per-workgroup progress words and does what
+//     couples the envs without feeding back: ret_rms.update() of finished episodes in env order, the normalised reward;
+//   * critic_values_kernel evaluates V(obs[t][e]) for the whole segment and V(next_obs) where a path was cut without
+//     termination, AFTER the steps, as a batched pass over all 256 CUs (32-row tiles, first layer of tile i + 1 on the
+//     vector waves while the matrix waves run tile i).
+// The same actor kernel serves one launch per rollout (n_steps = T) and one launch per vector step (n_steps = 1, the mode
+// for per-step callbacks and the fallback when the resident form is not available): state is handed over in memory, the
+// arithmetic is the same instruction stream, results are bit-identical (tested).
+// n <= 16: one workgroup, no exchange at all.  n <= 256: up to 16 workgroups on ONE XCD (grid 8x oversubscribed, only
+// blockIdx % 8 == 0 stays, as in the first design: plain stores + device-scope loads are coherent inside one L2; the XCC
+// ids are checked in every launch and the exchange falls back to device-scope stores when they differ).
+#include "common.h"
+#include "rng.h"
+#include "cartpole.h"
+
+namespace xrl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AR = 16;                    // envs (rows) per actor workgroup
+constexpr int AH = 128;                   // hidden width
+constexpr int ALD = AH + 4;               // LDS row stride of an activation tile
+constexpr int ATH = 512;                  // threads per workgroup
+constexpr int AMAXWG = 16;                // actor workgroups (16 x 16 = 256 envs)
+// exchange scratch (32-bit words): [0, 1024) = two slots of 256 units of 8 bytes, the message of step k in slot k & 1, unit u of
+// workgroup w at 64-bit index slot * 256 + u * 16 + w (a workgroup can only overwrite a slot two steps later, and it gets there
+// only after every workgroup has published the step in between, i.e. has consumed the slot's old content);
+// [1024, 1040) progress words; [1056] XCC mask of the launch
+constexpr int XW_DONE = 1024, XW_MASK = 1056, XW_WORDS = 2048;
+
+template <int CTRL>
+__device__ __forceinline__ float adpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double adpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row (rotations: every lane ends with the same bits)
+template <typename T>
+__device__ __forceinline__ T row16_sum(T v) {
+    v += adpp<0x128>(v); v += adpp<0x124>(v); v += adpp<0x122>(v); v += adpp<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ float a_ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned a_ld_dev(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long a_ld_dev(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void a_st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void a_st_dev(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void a_st_dev(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void a_st_dev(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a store another workgroup of the launch reads: plain inside one L2, device scope otherwise
+template <typename T>
+__device__ __forceinline__ void a_st(T* p, T v, bool multi) { if (multi) a_st_dev(p, v); else *p = v; }
+
+#define MFMA16(a, b, acc) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), acc, 0, 0, 0)
+
+// RunningMeanStd.update_from_moments (statistic_tools.py:150-185) for one dimension, batch sums S1, S2 over n rows
+__device__ __forceinline__ void rms_merge(double S1, double S2, int n, float& st_mean, float& st_var, double& st_cnt, float& new_sd) {
+#pragma clang fp contract(off)
+    // n a power of two: scaling by 1/n is the exact same number as the division (and ~400 cycles shorter)
+    const bool pow2 = (n & (n - 1)) == 0;
+    const double inv_n = 1.0 / (double)n;
+    const double m = pow2 ? S1 * inv_n : S1 / n;
+    const float bmean = (float)m;
+    const float bstd = (float)sqrt(fmax((pow2 ? S2 * inv_n : S2 / n) - m * m, 0.0));
+    const float bv = bstd * bstd;
+    const double cnt = st_cnt, tot = cnt + (double)n;
+    const float delta = bmean - st_mean;
+    const float new_mean = st_mean + delta * (float)n / (float)tot;
+    const float m_a = st_var * (float)cnt, m_b = bv * (float)n;
+    const float M2 = m_a + m_b + (delta * delta) * (float)cnt * (float)n / (float)tot;
+    const float new_var = M2 / (float)tot;
+    new_sd = sqrtf(new_var);
+    st_mean = new_mean; st_var = new_var; st_cnt = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the trailing workgroup: rewards of step t (normalised with the return statistics BEFORE that step's episode ends,
+// ppo_agent.py:128), then ret_rms.update(returns[i:i+1]) for every env that finished at step t, in env order (:146-149)
+__device__ __forceinline__ void rollout_bookkeeper(const xrl_rollout_run_t& q, int n_act) {
+#pragma clang fp contract(off)
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, n = q.n, n4 = (n + 3) & ~3;
+    unsigned* xw = q.xchg;
+    float mean = q.ret_stats[0], var = q.ret_stats[1];
+    double count = *q.ret_count;
+    bool dead = false;
+    for (int k = 0; k < q.n_steps && !dead; ++k) {
+        const int t = q.t0 + k;
+        float rstd = sqrtf(var);
+        rstd = fminf(fmaxf(rstd, 0.1f), 100.f);
+        float rn = 1.0f;
+        if (q.use_rewnorm) rn = fminf(fmaxf(1.0f / rstd, -q.rew_range), q.rew_range);
+        for (int e = lane; e < n; e += 64) q.f_rew[(size_t)t * n + e] = rn;
+        // every actor workgroup has completed step k (its stores of that step are in L2)
+        int spins = 0;
+        for (;;) {
+            const unsigned f = lane < n_act ? a_ld_dev(xw + XW_DONE + lane) : 0xffffffffu;
+            if (__ballot(f < (unsigned)(k + 1)) == 0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 255) == 0 && (spins > 2000000 || __hip_atomic_load(q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (lane == 0) __hip_atomic_store(q.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                break;
+            }
+        }
+        if (dead) break;
+        unsigned w = 0u;
+        float rf[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int base = 0; base < n4; base += 256) {                 // (n <= 256: one round)
+            const int e4 = base + 4 * lane;
+            w = 0u;
+            if (e4 < n4) {
+                w = a_ld_dev(reinterpret_cast<const unsigned*>(q.ended + (size_t)t * n4 + e4));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) rf[b] = a_ld_dev(q.ret_final + (size_t)t * n4 + e4 + b);
+            }
+            unsigned long long mm = __ballot(w != 0u);
+            while (mm) {
+                const int src = __ffsll((long long)mm) - 1; mm &= mm - 1;
+                const unsigned ws = (unsigned)__builtin_amdgcn_readlane((int)w, src);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float bmv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rf[b]), src));
+                    if ((ws >> (8 * b)) & 0xffu) {
+                        const double tot = count + 1.0; const float delta = bmv - mean;
+                        const float new_mean = mean + delta * 1.0f / (float)tot;
+                        const float M2 = var * (float)count + 0.f + (delta * delta) * (float)count * 1.0f / (float)tot;
+                        mean = new_mean; var = M2 / (float)tot; count = tot;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0 && !dead) { q.ret_stats[0] = mean; q.ret_stats[1] = var; *q.ret_count = count; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Every wave role runs its OWN step loop (same three LDS barriers per step in each): what a role keeps in scalar registers
+// is then live only on that role's path -- one loop body with all roles inside kept every kernel argument live through the
+// chain wave's tail and restored ~110 of them per step from spill lanes.
+template <int ACT>
+__global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q) {
+#pragma clang fp contract(off)
+    if (blockIdx.x & 7) return;                                  // keep one XCD's share of the grid (see header)
+    const int n = q.n, n_act = (n + AR - 1) / AR;
+    const int wg = blockIdx.x >> 3;
+    if (wg >= n_act) { rollout_bookkeeper(q, n_act); return; }
+
+    __shared__ __attribute__((aligned(16))) float h1[AR * ALD];
+    __shared__ __attribute__((aligned(16))) float s_raw[AR][4];          // raw observations this workgroup's envs act on
+    __shared__ __attribute__((aligned(16))) float s_norm[8];             // mean[4] | std[4] after the step's statistics update
+    __shared__ __attribute__((aligned(16))) float plog[AR][8];           // partial logits [row][matrix wave][action]
+    __shared__ __attribute__((aligned(16))) double ph_state[2][AR][4];   // physics step for both actions
+    __shared__ int ph_term[2][AR];
+    __shared__ __attribute__((aligned(16))) double rs_state[AR][4];      // state after an auto-reset
+    __shared__ __attribute__((aligned(16))) double cp_lds[AR][4];        // simulator state
+    __shared__ int ep_lds[AR];
+    __shared__ float s_u[AR];
+    __shared__ int s_abort, s_multi;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e0 = wg * AR, n_steps = q.n_steps;
+    const bool use_norm = q.use_obsnorm != 0;
+    const float obs_range = q.obs_range;
+    const float* P = q.params;
+    const int cl = lane & 15, g = lane >> 4;                     // lane = (DPP row g, position cl)
+
+    // ---- first layer: thread (fr = row, fk = four consecutive hidden units), weights in registers
+    const int fr = tid >> 5, fk = (tid & 31) * 4;
+    float4 w0r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w0r[j] = *reinterpret_cast<const float4*>(P + q.w0 + (size_t)(fk + j) * 4);
+    const float4 b0r = *reinterpret_cast<const float4*>(P + q.b0 + fk);
+    // normalise the row + first layer on the VALU -> h1 (all waves, between barriers #1 and #2)
+    auto first_layer = [&]() {
+        float4 x = *reinterpret_cast<const float4*>(&s_raw[fr][0]);
+        if (use_norm) {
+            const float4 nm = *reinterpret_cast<const float4*>(&s_norm[0]), ns = *reinterpret_cast<const float4*>(&s_norm[4]);
+            x.x = fminf(fmaxf((x.x - nm.x) / (ns.x + 1e-8f), -obs_range), obs_range);
+            x.y = fminf(fmaxf((x.y - nm.y) / (ns.y + 1e-8f), -obs_range), obs_range);
+            x.z = fminf(fmaxf((x.z - nm.z) / (ns.z + 1e-8f), -obs_range), obs_range);
+            x.w = fminf(fmaxf((x.w - nm.w) / (ns.w + 1e-8f), -obs_range), obs_range);
+        }
+        const float bq[4] = {b0r.x, b0r.y, b0r.z, b0r.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = __fmaf_rn(x.x, w0r[j].x, 0.f);
+            acc = __fmaf_rn(x.y, w0r[j].y, acc);
+            acc = __fmaf_rn(x.z, w0r[j].z, acc);
+            acc = __fmaf_rn(x.w, w0r[j].w, acc);
+            o[j] = act_apply_c<ACT>(acc + bq[j]);
+        }
+        *reinterpret_cast<float4*>(h1 + fr * ALD + fk) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+
+    if (wave < 4) {
+        // ================================================================ matrix waves
+        // B fragments of the actor half of the stacked branch layer, straight from the row-major weights: wave w owns columns
+        // [32 w, 32 w + 32) as two 16-column tiles; lane (g, cl) holds, for k-chunk c, W1[col][16 c + 4 g .. + 3] -- the MFMA with
+        // component s multiplies k = 16 c + 4 g + s on both operands
+        float4 bfr[2][8];
+        float bm[2], whr[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 32 * wave + 16 * j + cl;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bfr[j][c] = *reinterpret_cast<const float4*>(P + q.w1 + (size_t)col * AH + 16 * c + 4 * g);
+            bm[j] = P[q.b1 + col];
+            whr[j][0] = P[q.wa + col]; whr[j][1] = P[q.wa + AH + col];
+        }
+        for (int k = 0; k < n_steps; ++k) {
+            lds_barrier();                                                                         // #1
+            if (s_abort) break;
+            first_layer();
+            lds_barrier();                                                                         // #2 h1 ready
+            const float* arow = h1 + cl * ALD + 4 * g;
+            float4 af[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) af[c] = *reinterpret_cast<const float4*>(arow + 16 * c);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                MFMA16(af[c].x, bfr[0][c].x, acc0); MFMA16(af[c].x, bfr[1][c].x, acc1);
+                MFMA16(af[c].y, bfr[0][c].y, acc0); MFMA16(af[c].y, bfr[1][c].y, acc1);
+                MFMA16(af[c].z, bfr[0][c].z, acc0); MFMA16(af[c].z, bfr[1][c].z, acc1);
+                MFMA16(af[c].w, bfr[0][c].w, acc0); MFMA16(af[c].w, bfr[1][c].w, acc1);
+            }
+            // epilogue: activation, this wave's 32 columns of both logits, summed over the 16 lanes of a row of the tile
+            float pl[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ha = act_apply_c<ACT>(acc0[i] + bm[0]), hb = act_apply_c<ACT>(acc1[i] + bm[1]);
+                pl[i][0] = row16_sum(ha * whr[0][0] + hb * whr[1][0]);
+                pl[i][1] = row16_sum(ha * whr[0][1] + hb * whr[1][1]);
+            }
+            if (cl == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<float2*>(&plog[4 * g + i][2 * wave]) = make_float2(pl[i][0], pl[i][1]);
+            }
+            lds_barrier();                                                                         // #3
+        }
+    } else if (wave == 5) {
+        // ================================================================ envs.step for both actions; memory.observations[t]
+        const int row = cl, e = e0 + row;
+        float* po = q.f_obs + ((size_t)q.t0 * n + e) * 4;
+        for (int k = 0; k < n_steps; ++k) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores of the previous step are in L2
+            lds_barrier();                                                                         // #1
+            if (s_abort) break;
+            first_layer();
+            lds_barrier();                                                                         // #2
+            if (lane < 32) {                                     // DPP row 0: action 0, row 1: action 1
+                const double cps[4] = {cp_lds[row][0], cp_lds[row][1], cp_lds[row][2], cp_lds[row][3]};
+                double x, xd, th, thd;
+                bool term;
+                cartpole_advance(cps, g, x, xd, th, thd, term);
+                ph_state[g][row][0] = x; ph_state[g][row][1] = xd; ph_state[g][row][2] = th; ph_state[g][row][3] = thd;
+                ph_term[g][row] = term ? 1 : 0;
+            } else if (lane < 48) {                              // the normalised observation of the row -> buffer slot t
+                float4 x = *reinterpret_cast<const float4*>(&s_raw[row][0]);
+                if (use_norm) {
+                    const float4 nm = *reinterpret_cast<const float4*>(&s_norm[0]), ns = *reinterpret_cast<const float4*>(&s_norm[4]);
+                    x.x = fminf(fmaxf((x.x - nm.x) / (ns.x + 1e-8f), -obs_range), obs_range);
+                    x.y = fminf(fmaxf((x.y - nm.y) / (ns.y + 1e-8f), -obs_range), obs_range);
+                    x.z = fminf(fmaxf((x.z - nm.z) / (ns.z + 1e-8f), -obs_range), obs_range);
+                    x.w = fminf(fmaxf((x.w - nm.w) / (ns.w + 1e-8f), -obs_range), obs_range);
+                }
+                if (e < n) *reinterpret_cast<float4*>(po) = x;
+            }
+            po += (size_t)n * 4;
+            lds_barrier();                                                                         // #3
+        }
+    } else if (wave == 6) {
+        // ================================================================ state after an auto-reset into the next episode
+        const int row = cl, e = e0 + row;
+        const uint64_t env_seed = q.env_seed;
+        for (int k = 0; k < n_steps; ++k) {
+            lds_barrier();                                                                         // #1
+            if (s_abort) break;
+            first_layer();
+            lds_barrier();                                                                         // #2
+            if (lane < 32) {
+                uint32_t o[4], qq[4];
+                philox4x32(env_seed, (uint32_t)e, (uint32_t)(ep_lds[row] + 1), g ? STREAM_RESET_B : STREAM_RESET_A, o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qq[j] = __shfl_xor(o[j], 16, 64);
+                if (g == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rs_state[row][j] = -0.05 + 0.1 * u01d(o[j], qq[j]);
+                }
+            }
+            lds_barrier();                                                                         // #3
+        }
+    } else if (wave == 7) {
+        // ================================================================ sampling uniform of (env, step); progress word
+        const int row = cl, e = e0 + row;
+        const uint64_t seed = q.seed;
+        const uint32_t step0 = q.step + (q.step_dev ? *q.step_dev : 0u) + (uint32_t)q.t0;
+        unsigned* done = q.xchg + XW_DONE + wg;
+        for (int k = 0; k < n_steps; ++k) {
+            lds_barrier();                                                                         // #1
+            if (s_abort) break;
+            if (lane == 0 && k > 0) a_st_dev(done, (unsigned)k);     // steps < k complete, their stores in L2 (trailing readers)
+            first_layer();
+            lds_barrier();                                                                         // #2
+            if (lane < 16) {
+                uint32_t rr4[4];
+                philox4x32(seed, (uint32_t)e, step0 + (uint32_t)k, STREAM_ACTION, rr4);
+                s_u[row] = u01(rr4[0]);
+            }
+            lds_barrier();                                                                         // #3
+        }
+    } else {
+        // ================================================================ wave 4, the chain wave: lane (d = DPP row, row) --
+        // every lane of a row carries the row's state, DPP row d reduces dimension d of the observations
+        const int row = cl, d = g, e = e0 + row;
+        const bool row_ok = e < n;
+        const bool single = n_act == 1;                          // one workgroup: the partial sums ARE the batch sums
+        unsigned long long* xu = reinterpret_cast<unsigned long long*>(q.xchg);
+        long long* dbg = q.dbg;
+        const bool dbg_on = dbg != nullptr && wg == 0;
+        const int dbg_k = n_steps / 2;
+        const int max_steps = q.max_steps, T = q.T, t0 = q.t0;
+        const float gamma = q.gamma;
+        const float bh0 = P[q.ba], bh1 = P[q.ba + 1];
+        int cp_steps = 0, cp_ep = 0;
+        float cp_score = 0.f, rtrack = 0.f;
+        float st_mean = 0.f, st_var = 1.f;
+        double st_cnt = 0.0;
+        if (row_ok) { cp_steps = q.cp_steps[e]; cp_score = q.cp_score[e]; rtrack = q.ret_track[e]; cp_ep = q.cp_episodes[e]; }
+        if (use_norm) { st_mean = q.obs_stats[d]; st_var = q.obs_stats[4 + d]; st_cnt = *q.obs_count; }
+        if (lane == 0) { s_abort = 0; s_multi = (q.flags & 1) ? 1 : 0; }
+        if (d == 0) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+            if (row_ok) {
+                o = *reinterpret_cast<const float4*>(q.obs_raw + (size_t)e * 4);
+                c0 = q.cp_state[(size_t)e * 4 + 0]; c1 = q.cp_state[(size_t)e * 4 + 1];
+                c2 = q.cp_state[(size_t)e * 4 + 2]; c3 = q.cp_state[(size_t)e * 4 + 3];
+            }
+            *reinterpret_cast<float4*>(&s_raw[row][0]) = o;
+            cp_lds[row][0] = c0; cp_lds[row][1] = c1; cp_lds[row][2] = c2; cp_lds[row][3] = c3;
+            ep_lds[row] = cp_ep;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // per-lane record pointers (advance by one buffer row per step): nothing of the argument block stays in scalar registers
+        const int n4 = (n + 3) & ~3;
+        const size_t o0 = (size_t)t0 * n + e;
+        float* p_act = q.f_act + o0; float* p_logp = q.f_logp + o0; float* p_term = q.f_term + o0;
+        uint8_t* p_seg = q.f_seg + o0; float* p_xn = q.xnext + o0 * 4;
+        float* p_rfin = q.ret_final + (size_t)t0 * n4 + e; uint8_t* p_end = q.ended + (size_t)t0 * n4 + e;
+        double* cp_stats = q.cp_stats;
+        // partial sums of the raw observations of this workgroup's rows, dimension d: (sum, sum of squares) in every lane of row d
+        double ps1 = 0.0, ps2 = 0.0;
+        if (use_norm) {
+            const double v = row_ok ? (double)s_raw[row][d] : 0.0;
+            ps1 = row16_sum(v); ps2 = row16_sum(v * v);
+            if (!single) {
+                // placement: every workgroup ORs its XCC id into the launch's mask BEFORE its first message; whoever has seen all
+                // first messages sees the complete mask
+                if (lane == 0) {
+                    unsigned xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    if (wg == 0) __hip_atomic_store(q.status + 1, (int)(xcc & 0xf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicOr(q.status + 2, 1 << (xcc & 0xf));
+                    const unsigned seen = atomicOr(q.xchg + XW_MASK, 1u << (xcc & 0xf));
+                    asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+                }
+                // unit u = 8 * half + j (j = d: sum, 4 + d: sum of squares): positions 0..3 of DPP row d publish (lo s1, lo s2, hi s1, hi s2)
+                if (row < 4) {
+                    const double sv = (row & 1) ? ps2 : ps1;
+                    const unsigned word = (row & 2) ? (unsigned)__double2hiint(sv) : (unsigned)__double2loint(sv);
+                    const int u = 8 * (row >> 1) + 4 * (row & 1) + d;
+                    a_st_dev(xu + 256 + u * 16 + wg, ((unsigned long long)word << 32) | 1ull);      // first message (tag 1, slot 1): always device scope
+                }
+            }
+        }
+        bool multi = (q.flags & 1) != 0;
+        int k = 0;
+        for (; k < n_steps; ++k) {
+            const bool stamp = dbg_on && k == dbg_k;
+            long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0, ts7 = 0;
+            if (stamp) ts0 = clock64();
+            // ---------------- (1) statistics of the step: the partial sums of all workgroups
+            if (use_norm) {
+                double S1 = ps1, S2 = ps2;
+                if (!single) {
+                    const unsigned tag = (unsigned)(k + 1);
+                    unsigned long long u0, u1, u2, u3;
+                    int spins = 0;
+                    const bool live = cl < n_act;
+                    const unsigned long long* xs = xu + (tag & 1u) * 256 + lane;
+                    for (;;) {
+                        u0 = a_ld_dev(xs); u1 = a_ld_dev(xs + 64); u2 = a_ld_dev(xs + 128); u3 = a_ld_dev(xs + 192);
+                        const bool ok = !live || ((unsigned)u0 == tag && (unsigned)u1 == tag && (unsigned)u2 == tag && (unsigned)u3 == tag);
+                        if (__ballot(!ok) == 0ull) break;
+                        if ((++spins & 255) == 0 && (spins > 2000000 || __hip_atomic_load(q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            if (lane == 0) { __hip_atomic_store(q.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
+                            break;
+                        }
+                    }
+                    // lane (DPP row d, workgroup cl): loads 0 / 2 = lo / hi of that workgroup's sum of dimension d, loads 1 / 3 of its squares
+                    const double v1 = live ? __hiloint2double((int)(u2 >> 32), (int)(u0 >> 32)) : 0.0;
+                    const double v2 = live ? __hiloint2double((int)(u3 >> 32), (int)(u1 >> 32)) : 0.0;
+                    S1 = row16_sum(v1); S2 = row16_sum(v2);
+                    if (k == 0 && lane == 0) {
+                        const unsigned mask = a_ld_dev(q.xchg + XW_MASK);
+                        if (__popc(mask) != 1) s_multi = 1;
+                        if ((__popc(mask) != 1 || (q.flags & 1)) && wg == 0) atomicAdd(q.status + 3, 1);
+                    }
+                }
+                if (stamp) ts1 = clock64();
+                float new_sd;
+                rms_merge(S1, S2, n, st_mean, st_var, st_cnt, new_sd);
+                if (row == 0) { s_norm[d] = st_mean; s_norm[4 + d] = new_sd; }
+            }
+            if (stamp) ts2 = clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores of the previous step are in L2
+            lds_barrier();                                                                         // #1 statistics / raw rows ready
+            if (s_abort) break;
+            multi = s_multi != 0;
+            first_layer();
+            lds_barrier();                                                                         // #2
+            if (stamp) ts3 = clock64();
+            lds_barrier();                                                                         // #3 logits, physics, draws ready
+            // ---------------- (4) sample, pick the transition, publish the new partial sums
+            if (stamp) ts4 = clock64();
+            const float u = s_u[row];
+            const float4 pA = *reinterpret_cast<const float4*>(&plog[row][0]), pB = *reinterpret_cast<const float4*>(&plog[row][4]);
+            const double2 sa0 = *reinterpret_cast<const double2*>(&ph_state[0][row][0]), sa1 = *reinterpret_cast<const double2*>(&ph_state[0][row][2]);
+            const double2 sb0 = *reinterpret_cast<const double2*>(&ph_state[1][row][0]), sb1 = *reinterpret_cast<const double2*>(&ph_state[1][row][2]);
+            const double2 rs0 = *reinterpret_cast<const double2*>(&rs_state[row][0]), rs1 = *reinterpret_cast<const double2*>(&rs_state[row][2]);
+            const int term_a = ph_term[0][row], term_b = ph_term[1][row];
+            float nmv[4] = {0.f, 0.f, 0.f, 0.f}, nsv[4] = {1.f, 1.f, 1.f, 1.f};
+            if (use_norm) {
+                const float4 nm = *reinterpret_cast<const float4*>(&s_norm[0]), ns = *reinterpret_cast<const float4*>(&s_norm[4]);
+                nmv[0] = nm.x; nmv[1] = nm.y; nmv[2] = nm.z; nmv[3] = nm.w; nsv[0] = ns.x; nsv[1] = ns.y; nsv[2] = ns.z; nsv[3] = ns.w;
+            }
+            const float l0 = ((pA.x + pA.z) + (pB.x + pB.z)) + bh0, l1 = ((pA.y + pA.w) + (pB.y + pB.w)) + bh1;
+            // ---- get_actions: Categorical(logits).sample() by inverse CDF on the step's uniform, log-prob
+            int a;
+            float logp;
+            {
+                const float mx = fmaxf(l0, l1);
+                float se = 0.f;
+                se += expf(l0 - mx); se += expf(l1 - mx);
+                const float lse = mx + logf(se);
+                float c = 0.f;
+                c += expf(l0 - lse);
+                a = c > u ? 0 : 1;
+                logp = (a ? l1 : l0) - lse;
+            }
+            if (stamp) ts5 = clock64();
+            // ---- envs.step(acts): the pre-computed transition of the drawn action + auto-reset
+            const double x = a ? sb0.x : sa0.x, xd = a ? sb0.y : sa0.y, th = a ? sb1.x : sa1.x, thd = a ? sb1.y : sa1.y;
+            const bool term = (a ? term_b : term_a) != 0;
+            const int steps = cp_steps + 1;
+            const bool trunc = steps >= max_steps;
+            const bool fin = term || trunc;
+            const float nobs[4] = {(float)x, (float)xd, (float)th, (float)thd};
+            const float score = cp_score + 1.0f;
+            const float robs[4] = {fin ? (float)rs0.x : nobs[0], fin ? (float)rs0.y : nobs[1], fin ? (float)rs1.x : nobs[2], fin ? (float)rs1.y : nobs[3]};
+            const float tr = gamma * rtrack + 1.0f;               // self.returns = gamma * self.returns + rewards (reward 1)
+            if (fin) cp_ep += 1;
+            cp_steps = fin ? 0 : steps; cp_score = fin ? 0.f : score; rtrack = fin ? 0.f : tr;
+            // ---- partial sums of the new raw observations (dimension d of this lane's DPP row) and the message of step k + 1
+            if (use_norm && k + 1 < n_steps) {
+                const float rv = d == 0 ? robs[0] : d == 1 ? robs[1] : d == 2 ? robs[2] : robs[3];
+                const double v = row_ok ? (double)rv : 0.0;
+                ps1 = row16_sum(v); ps2 = row16_sum(v * v);
+                if (!single && row < 4) {
+                    const double sv = (row & 1) ? ps2 : ps1;
+                    const unsigned word = (row & 2) ? (unsigned)__double2hiint(sv) : (unsigned)__double2loint(sv);
+                    const int uu = 8 * (row >> 1) + 4 * (row & 1) + d;
+                    a_st(xu + (k & 1) * 256 + uu * 16 + wg, ((unsigned long long)word << 32) | (unsigned long long)(unsigned)(k + 2), multi);
+                }
+            }
+            if (stamp) ts6 = clock64();
+            // ---- state for the next step (LDS) and the step's record (memory)
+            if (d == 0) {
+                *reinterpret_cast<float4*>(&s_raw[row][0]) = make_float4(robs[0], robs[1], robs[2], robs[3]);
+                *reinterpret_cast<double2*>(&cp_lds[row][0]) = fin ? rs0 : make_double2(x, xd);
+                *reinterpret_cast<double2*>(&cp_lds[row][2]) = fin ? rs1 : make_double2(th, thd);
+                ep_lds[row] = cp_ep;
+                if (row_ok) {
+                    *p_act = (float)a;
+                    *p_logp = logp;
+                    *p_term = term ? 1.f : 0.f;
+                    *p_seg = (term || trunc || t0 + k == T - 1) ? (uint8_t)(1 | (term ? 6 : 0)) : (uint8_t)0;
+                    float nv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = nobs[j];
+                        if (use_norm) { v = (v - nmv[j]) / (nsv[j] + 1e-8f); v = fminf(fmaxf(v, -obs_range), obs_range); }
+                        nv[j] = v;
+                    }
+                    *reinterpret_cast<float4*>(p_xn) = make_float4(nv[0], nv[1], nv[2], nv[3]);   // (read after the launch)
+                    // what the bookkeeper reads inside the launch: always device scope (its placement is not part of the check;
+                    // nothing waits for these stores before the next step's barrier #1)
+                    if (fin) a_st_dev(p_rfin, tr);
+                    a_st_dev(p_end, (uint8_t)(fin ? 1 : 0));
+                    if (fin) { atomicAdd(&cp_stats[0], 1.0); atomicAdd(&cp_stats[1], (double)score); atomicAdd(&cp_stats[2], (double)steps); }
+                }
+            }
+            p_act += n; p_logp += n; p_term += n; p_seg += n; p_xn += (size_t)n * 4; p_rfin += n4; p_end += n4;
+            if (stamp) {
+                ts7 = clock64();
+                if (lane == 0) { dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = ts3; dbg[4] = ts4; dbg[5] = ts5; dbg[6] = ts6; dbg[7] = ts7; dbg[15] = 8; }
+            }
+        }
+        // ---- hand the state back
+        if (k == n_steps) {
+            if (d == 0 && row_ok) {
+                q.cp_steps[e] = cp_steps; q.cp_score[e] = cp_score; q.ret_track[e] = rtrack; q.cp_episodes[e] = cp_ep;
+                q.cp_state[(size_t)e * 4 + 0] = cp_lds[row][0]; q.cp_state[(size_t)e * 4 + 1] = cp_lds[row][1];
+                q.cp_state[(size_t)e * 4 + 2] = cp_lds[row][2]; q.cp_state[(size_t)e * 4 + 3] = cp_lds[row][3];
+                *reinterpret_cast<float4*>(q.obs_raw + (size_t)e * 4) = *reinterpret_cast<const float4*>(&s_raw[row][0]);
+            }
+            if (wg == 0 && use_norm && row == 0) {
+                q.obs_stats[d] = st_mean; q.obs_stats[4 + d] = st_var;
+                if (d == 0) *q.obs_count = st_cnt;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && !s_abort) a_st_dev(q.xchg + XW_DONE + wg, (unsigned)n_steps);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// V(obs) for rows [t0 n, (t0 + n_steps) n) of the buffer and V(next_obs) for the rows of that range where a path was cut
+// without termination (seg == 1: truncation or buffer full; finish_path(vals[i], i), ppo_agent.py:130-135,153-157).
+// Jobs are 32-row tiles; workgroup w takes jobs w, w + G, ...: the value tiles first, then those of its bootstrap tiles that
+// hold at least one such row.  Waves 0-3: branch layer of the critic half on the matrix cores (two 16-row tiles per wave
+// pass, weights in registers) + the value head's partial dot products; waves 4-7: rows + first layer of the NEXT job and
+// the finished values of the previous one.
+template <int ACT>
+__global__ void __launch_bounds__(ATH) critic_values_kernel(xrl_rollout_run_t q) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float h1[2][32 * ALD];
+    __shared__ __attribute__((aligned(16))) float pv[2][32][4];          // partial values [row][matrix wave]
+    __shared__ unsigned long long s_need;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = q.n, G = gridDim.x, w = blockIdx.x;
+    const float* P = q.params;
+    const size_t r0 = (size_t)q.t0 * n, R = (size_t)q.n_steps * n;
+    const int n_tiles = (int)((R + 31) / 32);
+    const int mine = w < n_tiles ? (n_tiles - 1 - w) / G + 1 : 0;        // tiles w, w + G, ... of either kind
+    const int cl = lane & 15, g = lane >> 4;
+    // ---- which of this workgroup's bootstrap tiles are needed (one round trip, all candidates at once; <= 64 per workgroup)
+    if (wave == 4) {
+        bool need = false;
+        if (lane < mine && lane < 64) {
+            const size_t base = r0 + (size_t)(w + lane * G) * 32;
+            for (int i = 0; i < 32; ++i) { const size_t r = base + i; if (r < r0 + R && q.f_seg[r] == 1) need = true; }
+        }
+        const unsigned long long m = __ballot(need);
+        if (lane == 0) s_need = m;
+    }
+    // ---- weights
+    const int vt = tid - 256, vr = vt >> 3, vs = vt & 7;                  // vector threads: row vr, hidden units [16 vs, 16 vs + 16)
+    float4 big[16], b0r[4];
+    float4 bfr[2][8];
+    float bm[2] = {0.f, 0.f}, whr[2] = {0.f, 0.f};
+    if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 32 * wave + 16 * j + cl;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bfr[j][c] = *reinterpret_cast<const float4*>(P + q.w1 + (size_t)(AH + col) * AH + 16 * c + 4 * g);
+            bm[j] = P[q.b1 + AH + col];
+            whr[j] = P[q.wc + col];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) big[j] = *reinterpret_cast<const float4*>(P + q.w0 + (size_t)(vs * 16 + j) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0r[j] = *reinterpret_cast<const float4*>(P + q.b0 + vs * 16 + 4 * j);
+    }
+    const float bc = P[q.bc];
+    __syncthreads();
+    const unsigned long long need = s_need;
+    const int n_jobs = mine + __popcll(need);
+    // job i < mine: value tile w + i G; else the (i - mine)-th set bit of `need`: bootstrap tile
+    auto job_tile = [&](int i, bool& boot) -> int {
+        boot = i >= mine;
+        if (!boot) return w + i * G;
+        unsigned long long m = need;
+        for (int s = 0; s < i - mine; ++s) m &= m - 1;
+        return w + (__ffsll((long long)m) - 1) * G;
+    };
+    auto first_layer = [&](int i) {                                       // vector waves: rows of job i -> h1[i & 1]
+        bool boot;
+        const int tile = job_tile(i, boot);
+        const size_t r = r0 + (size_t)tile * 32 + vr;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < r0 + R) x = *reinterpret_cast<const float4*>((boot ? q.xnext : q.f_obs) + r * 4);
+        float* dst = h1[i & 1] + vr * ALD + vs * 16;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float bq[4] = {b0r[gq].x, b0r[gq].y, b0r[gq].z, b0r[gq].w};
+            float o[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 ww = big[gq * 4 + jj];
+                float acc = __fmaf_rn(x.x, ww.x, 0.f);
+                acc = __fmaf_rn(x.y, ww.y, acc);
+                acc = __fmaf_rn(x.z, ww.z, acc);
+                acc = __fmaf_rn(x.w, ww.w, acc);
+                o[jj] = act_apply_c<ACT>(acc + bq[jj]);
+            }
+            *reinterpret_cast<float4*>(dst + 4 * gq) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    auto finish = [&](int i) {                                            // wave 4: values of job i from pv[i & 1]
+        if (wave != 4 || lane >= 32) return;
+        bool boot;
+        const int tile = job_tile(i, boot);
+        const size_t r = r0 + (size_t)tile * 32 + lane;
+        const float4 pp = *reinterpret_cast<const float4*>(&pv[i & 1][lane][0]);
+        const float v = ((pp.x + pp.y) + (pp.z + pp.w)) + bc;
+        if (r < r0 + R) (boot ? q.bootv : q.f_val)[r] = v;
+    };
+    if (n_jobs == 0) return;
+    if (wave >= 4) first_layer(0);
+    lds_barrier();
+    for (int i = 0; i < n_jobs; ++i) {
+        if (wave < 4) {
+            const float* arow = h1[i & 1] + cl * ALD + 4 * g;
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[rt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * c), a1 = *reinterpret_cast<const float4*>(arow + 16 * ALD + 16 * c);
+                MFMA16(a0.x, bfr[0][c].x, acc[0][0]); MFMA16(a0.x, bfr[1][c].x, acc[0][1]); MFMA16(a1.x, bfr[0][c].x, acc[1][0]); MFMA16(a1.x, bfr[1][c].x, acc[1][1]);
+                MFMA16(a0.y, bfr[0][c].y, acc[0][0]); MFMA16(a0.y, bfr[1][c].y, acc[0][1]); MFMA16(a1.y, bfr[0][c].y, acc[1][0]); MFMA16(a1.y, bfr[1][c].y, acc[1][1]);
+                MFMA16(a0.z, bfr[0][c].z, acc[0][0]); MFMA16(a0.z, bfr[1][c].z, acc[0][1]); MFMA16(a1.z, bfr[0][c].z, acc[1][0]); MFMA16(a1.z, bfr[1][c].z, acc[1][1]);
+                MFMA16(a0.w, bfr[0][c].w, acc[0][0]); MFMA16(a0.w, bfr[1][c].w, acc[0][1]); MFMA16(a1.w, bfr[0][c].w, acc[1][0]); MFMA16(a1.w, bfr[1][c].w, acc[1][1]);
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const float ha = act_apply_c<ACT>(acc[rt][0][ii] + bm[0]), hb = act_apply_c<ACT>(acc[rt][1][ii] + bm[1]);
+                    const float s = row16_sum(ha * whr[0] + hb * whr[1]);
+                    if (cl == 0) pv[i & 1][16 * rt + 4 * g + ii][wave] = s;
+                }
+        } else {
+            if (i + 1 < n_jobs) first_layer(i + 1);
+            if (i > 0) finish(i - 1);
+        }
+        lds_barrier();
+    }
+    finish(n_jobs - 1);
+}
+
+__global__ void zero_xchg_kernel(uint32_t* p) {
+#pragma unroll
+    for (int i = 0; i < XW_WORDS / 512; ++i) p[threadIdx.x + 512 * i] = 0u;
+}
+
+static bool g_fast_enabled = true;
+bool rollout_fast_enabled() { return g_fast_enabled; }
+
+}  // namespace xrl
+
+using namespace xrl;
+
+namespace xrl { extern bool g_fast_enabled_ppo; }
+extern "C" int xrl_set_fast_kernels(int enable) {
+    xrl::g_fast_enabled = enable != 0;
+    xrl::g_fast_enabled_ppo = enable != 0;
+    return XRL_OK;
+}
+
+static int check_run(const xrl_rollout_run_t& q, const char* who) {
+    if (!(q.params && q.n > 0 && q.T >= 1 && q.t0 >= 0 && q.n_steps >= 1 && q.t0 + q.n_steps <= q.T)) {
+        set_error("%s: invalid sizes (n %d, T %d, t0 %d, n_steps %d)", who, q.n, q.T, q.t0, q.n_steps);
+        return XRL_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(q.params) & 15) || (q.w0 & 3) || (q.b0 & 3) || (q.w1 & 3)) {
+        set_error("%s: parameter blocks must be 16-byte aligned", who);
+        return XRL_EINVAL;
+    }
+    return XRL_OK;
+}
+
+extern "C" int xrl_rollout_cartpole_run(const xrl_rollout_run_t* qq, xrl_stream_t stream) {
+    XRL_CHECK_ARG(qq != nullptr);
+    const xrl_rollout_run_t& q = *qq;
+    if (int rc = check_run(q, "xrl_rollout_cartpole_run")) return rc;
+    XRL_CHECK_ARG(q.n <= AR * AMAXWG);
+    XRL_CHECK_ARG(q.obs_raw && q.obs_stats && q.obs_count && q.ret_stats && q.ret_count && q.ret_track);
+    XRL_CHECK_ARG(q.cp_state && q.cp_steps && q.cp_episodes && q.cp_score && q.cp_stats);
+    XRL_CHECK_ARG(q.f_obs && q.f_act && q.f_logp && q.f_rew && q.f_term && q.f_seg && q.xnext && q.ended && q.ret_final);
+    XRL_CHECK_ARG(q.xchg && q.status);
+    XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(q.ended) & 3) == 0 && (reinterpret_cast<uintptr_t>(q.xchg) & 7) == 0);
+    const int n_wg = (q.n + AR - 1) / AR + 1;                           // actors + the bookkeeper
+    XRL_CHECK_ARG(n_wg <= device_cu_count() / 8);                       // all resident on ONE XCD, one per CU
+    // zeroed by a kernel, not by hipMemsetAsync: a memset node of a captured graph does not order the kernel nodes around it
+    // (ROCm 7.2, tools/stress_determinism.py)
+    hipLaunchKernelGGL(zero_xchg_kernel, dim3(1), dim3(512), 0, as_stream(stream), q.xchg);
+    XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);)
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_rollout_cartpole_values(const xrl_rollout_run_t* qq, xrl_stream_t stream) {
+    XRL_CHECK_ARG(qq != nullptr);
+    const xrl_rollout_run_t& q = *qq;
+    if (int rc = check_run(q, "xrl_rollout_cartpole_values")) return rc;
+    XRL_CHECK_ARG(q.f_obs && q.xnext && q.f_seg && q.f_val && q.bootv);
+    const long long R = (long long)q.n_steps * q.n;
+    const int n_tiles = (int)((R + 31) / 32);
+    int grid = device_cu_count();
+    if (grid <= 0) grid = 256;
+    if (grid > n_tiles) grid = n_tiles;
+    XRL_CHECK_ARG((n_tiles + grid - 1) / grid <= 64);                   // candidates of one workgroup: one ballot
+    XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((critic_values_kernel<ACT>), dim3(grid), dim3(ATH), 0, as_stream(stream), q);)
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

@@ -446,10 +446,6 @@ static size_t fused_lds_bytes(const xrl_rollout_step_t& p) {
 
 using namespace xrl;
 
-namespace xrl {
-bool rollout_fast_eligible(const xrl_rollout_step_t& p);
-int launch_rollout_fast(const xrl_rollout_step_t& p, int grid, hipStream_t stream);
-}
 extern "C" int xrl_init_ppo_fused(void);
 extern "C" int xrl_pack_rollout_cache2(const xrl_rollout_step_t* pp, float* image, int64_t image_floats, float* frag,
                                        xrl_stream_t stream);
@@ -486,7 +482,6 @@ extern "C" int xrl_rollout_step_cartpole(const xrl_rollout_step_t* pp, xrl_strea
     if (p.role_split) XRL_CHECK_ARG(p.split_col > 0 && p.split_col % 32 == 0 && p.n_layers - p.n_head_layers == 2);
     const int act_groups = p.role_split ? 2 : 1;
     const int grid = p.boot_only ? n_tiles : (p.bootv_prev ? (act_groups + 1) * n_tiles : act_groups * n_tiles);
-    if (rollout_fast_eligible(p)) return launch_rollout_fast(p, grid, as_stream(stream));   // shape-specialised twin
     hipLaunchKernelGGL(rollout_step_cartpole_kernel, dim3(grid), dim3(FUSED_THREADS), lds_bytes, as_stream(stream), p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutPersist, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -596,18 +596,41 @@ def rollout_step_cartpole(plan, **kw):
     call("xrl_rollout_step_cartpole", C.byref(p), stream_ptr())
 
 
-def rollout_cartpole_persistent(plan, T, bootv, barrier, status, flags=0, **kw):
-    """All T steps + the bootstrap pass in one launch; kw as for rollout_step_cartpole (describing step 0)."""
-    q = RolloutPersist()
-    q.flags = int(flags)
-    assert barrier.numel() >= 128
-    for k, v in kw.items():
-        if isinstance(v, torch.Tensor):
-            v = v.data_ptr()
-        setattr(q.step0, k, v)
-    fused_layers_from_plan(plan, q.step0)
-    q.bootv, q.barrier, q.status, q.T = bootv.data_ptr(), barrier.data_ptr(), status.data_ptr(), int(T)
-    call("xrl_rollout_cartpole_persistent", C.byref(q), stream_ptr())
+class CartPoleRollout:
+    """Host side of xrl_rollout_cartpole_run / xrl_rollout_cartpole_values (csrc/rollout_actor.hip): the descriptor of one
+    agent's rollout -- layer offsets of the 4-128-{128-2,128-1} network, state and buffer pointers, scratch -- built once;
+    run(t0, n_steps) / values(t0, n_steps) enqueue steps [t0, t0 + n_steps) on the current stream."""
+
+    MAX_ENVS = 256
+
+    @staticmethod
+    def eligible(plan, n):
+        st = plan.stages
+        return list(plan.widths) == [4, 128, 256, 3] and n <= CartPoleRollout.MAX_ENVS and len(st) == 3 and len(st[0]) == 1 and \
+            len(st[1]) == 1 and len(st[2]) == 2 and st[1][0].act == st[0][0].act and fast_kernels_enabled()
+
+    def __init__(self, plan, T, **kw):
+        q = self.q = RolloutRun()
+        off = plan.params.offsets
+        L0, L1, (Ha, Hc) = plan.stages[0][0], plan.stages[1][0], plan.stages[2]
+        q.w0, q.b0, q.w1, q.b1 = off[L0.w_name], off[L0.b_name], off[L1.w_name], off[L1.b_name]
+        q.wa, q.ba, q.wc, q.bc = off[Ha.w_name], off[Ha.b_name], off[Hc.w_name], off[Hc.b_name]
+        q.act, q.T = ACT[L0.act], int(T)
+        self._keep = []
+        for k, v in kw.items():
+            if isinstance(v, torch.Tensor):
+                self._keep.append(v)
+                v = v.data_ptr()
+            setattr(q, k, v)
+
+    def run(self, t0, n_steps, flags=0, dbg=None):
+        self.q.t0, self.q.n_steps, self.q.flags = int(t0), int(n_steps), int(flags)
+        self.q.dbg = None if dbg is None else dbg.data_ptr()
+        call("xrl_rollout_cartpole_run", C.byref(self.q), stream_ptr())
+
+    def values(self, t0, n_steps):
+        self.q.t0, self.q.n_steps = int(t0), int(n_steps)
+        call("xrl_rollout_cartpole_values", C.byref(self.q), stream_ptr())
 
 
 def dqn_td(**kw):
