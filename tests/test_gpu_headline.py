@@ -199,12 +199,17 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
             env_i, t_i = np.divmod(idx[k], T)
             a64 = buf.advantages[env_i, t_i].astype(np.float64)
             b64["advantages"] = (a64 - a64.mean()) / (a64.std() + 1e-8)                     # memory_tools.py:281-282
-            oracle.ppo_update(sd64, opt64, b64, cfg)
+            oinfo64, _ = oracle.ppo_update(sd64, opt64, b64, cfg)
         for key, ok in (("actor_loss", "a_loss"), ("critic_loss", "c_loss"), ("entropy", "e_loss"),
                         ("predict_value", "predict_value")):
-            # (the actor loss is a mean of surrogate terms that cancel to ~1e-3 of their magnitude: scale = that magnitude)
-            assert_close(info[key], oinfo[ok], 1e-5, f"{key} (pass {it})",
-                         scale=float(np.abs(oinfo["surrogate2"]).mean()) if key == "actor_loss" else None)
+            # The losses of the LAST minibatch, which all 63 earlier chained steps feed.  (The actor loss is a mean of surrogate terms
+            # that cancel to ~1e-3 of their magnitude: scale = that magnitude.)  Tolerance: 1e-5, or -- where the float32 oracle's OWN
+            # chain has drifted further than that from the float64 chain on the same data -- 4x that drift (measured round 4:
+            # actor_loss 1.0e-5 of scale for the engine where the oracle sits at the same distance from float64; both recorded).
+            scale = float(np.abs(oinfo["surrogate2"]).mean()) if key == "actor_loss" else max(abs(float(oinfo64[ok])), 1e-30)
+            drift = abs(float(oinfo[ok]) - float(oinfo64[ok])) / scale
+            _record(f"{key} (pass {it}): float32 oracle vs float64 chain (the yardstick of the next line)", drift, drift, 0.0, 1)
+            assert_close(info[key], oinfo64[ok], max(1e-5, 4.0 * drift), f"{key} (pass {it}) vs the float64 chain", scale=scale)
         # clip_ratio is a COUNT of samples with ratio outside [1 - eps, 1 + eps], divided by the minibatch size: a ratio
         # within float32 rounding of the boundary may fall on either side (<= 2 such samples of 8 192)
         assert abs(info["clip_ratio"] - float(oinfo["clip_ratio"])) * idx.shape[1] <= 2.0 + 1e-6, "clip_ratio"

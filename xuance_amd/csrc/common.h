@@ -104,7 +104,7 @@ __device__ __forceinline__ void code_prefetch_done(unsigned v) { asm volatile(""
 template <int ACT>
 __device__ __forceinline__ float act_apply_c(float z) {
     if (ACT == XRL_ACT_RELU) return z > 0.f ? z : 0.f;
-    if (ACT == XRL_ACT_LEAKY_RELU) return z > 0.f ? z : z * 0.01f;
+    if (ACT == XRL_ACT_LEAKY_RELU) return fmaxf(z, z * 0.01f);          // the same number as z > 0 ? z : 0.01 z, without the compare -> VCC -> select chain
     if (ACT == XRL_ACT_TANH) return tanhf(z);
     if (ACT == XRL_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
     return z;

@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int AR = 16;                    // envs (rows) per actor workgroup
 constexpr int AH = 128;                   // hidden width
-constexpr int ALD = AH + 4;               // LDS row stride of an activation tile
+constexpr int ALD = AH + 4;               // LDS row stride of an activation tile (values kernel)
 constexpr int ATH = 512;                  // threads per workgroup
 constexpr int AMAXWG = 16;                // actor workgroups (16 x 16 = 256 envs)
 // exchange scratch (32-bit words): [0, 1024) = two slots of 256 units of 8 bytes, the message of step k in slot k & 1, unit u of
@@ -69,26 +69,6 @@ template <typename T>
 __device__ __forceinline__ void a_st(T* p, T v, bool multi) { if (multi) a_st_dev(p, v); else *p = v; }
 
 #define MFMA16(a, b, acc) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), acc, 0, 0, 0)
-
-// RunningMeanStd.update_from_moments (statistic_tools.py:150-185) for one dimension, batch sums S1, S2 over n rows
-__device__ __forceinline__ void rms_merge(double S1, double S2, int n, float& st_mean, float& st_var, double& st_cnt, float& new_sd) {
-#pragma clang fp contract(off)
-    // n a power of two: scaling by 1/n is the exact same number as the division (and ~400 cycles shorter)
-    const bool pow2 = (n & (n - 1)) == 0;
-    const double inv_n = 1.0 / (double)n;
-    const double m = pow2 ? S1 * inv_n : S1 / n;
-    const float bmean = (float)m;
-    const float bstd = (float)sqrt(fmax((pow2 ? S2 * inv_n : S2 / n) - m * m, 0.0));
-    const float bv = bstd * bstd;
-    const double cnt = st_cnt, tot = cnt + (double)n;
-    const float delta = bmean - st_mean;
-    const float new_mean = st_mean + delta * (float)n / (float)tot;
-    const float m_a = st_var * (float)cnt, m_b = bv * (float)n;
-    const float M2 = m_a + m_b + (delta * delta) * (float)cnt * (float)n / (float)tot;
-    const float new_var = M2 / (float)tot;
-    new_sd = sqrtf(new_var);
-    st_mean = new_mean; st_var = new_var; st_cnt = tot;
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // the trailing workgroup: rewards of step t (normalised with the return statistics BEFORE that step's episode ends,
@@ -163,14 +143,16 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
     const int wg = blockIdx.x >> 3;
     if (wg >= n_act) { rollout_bookkeeper(q, n_act); return; }
 
-    __shared__ __attribute__((aligned(16))) float h1[AR * ALD];
     __shared__ __attribute__((aligned(16))) float s_raw[AR][4];          // raw observations this workgroup's envs act on
-    __shared__ __attribute__((aligned(16))) float s_norm[8];             // mean[4] | std[4] after the step's statistics update
-    __shared__ __attribute__((aligned(16))) float plog[AR][8];           // partial logits [row][matrix wave][action]
-    __shared__ __attribute__((aligned(16))) double ph_state[2][AR][4];   // physics step for both actions
-    __shared__ int ph_term[2][AR];
-    __shared__ __attribute__((aligned(16))) double rs_state[AR][4];      // state after an auto-reset
-    __shared__ __attribute__((aligned(16))) double cp_lds[AR][4];        // simulator state
+    __shared__ __attribute__((aligned(16))) float s_norm[8];             // mean[4] | 1 / (std[4] + 1e-8) after the step's statistics update
+    __shared__ __attribute__((aligned(16))) float plog[4][AR][2];        // partial logits [matrix wave][row][action]
+    __shared__ __attribute__((aligned(16))) double ph_state[2][AR][4];   // physics step for both actions (private to wave 5)
+    __shared__ __attribute__((aligned(16))) float ph_f[2][2][AR][4];     // ... as the float32 observations they produce, by step parity
+    __shared__ int ph_term[2][2][AR];
+    __shared__ __attribute__((aligned(16))) double rs_state[2][AR][4];   // state after an auto-reset, by step parity
+    __shared__ __attribute__((aligned(16))) float rs_f[2][AR][4];        // ... as float32 observations
+    __shared__ __attribute__((aligned(16))) float s_rec[AR][4];          // the step's record of a row: action, log-prob, flags (bit 0 terminated, bit 1 episode over), return tracker
+    __shared__ int s_sel[AR];                                            // what the step did to the env: 0 / 1 action taken, 2 reset
     __shared__ int ep_lds[AR];
     __shared__ float s_u[AR];
     __shared__ int s_abort, s_multi;
@@ -182,197 +164,326 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
     const float obs_range = q.obs_range;
     const float* P = q.params;
     const int cl = lane & 15, g = lane >> 4;                     // lane = (DPP row g, position cl)
+    long long* dbg = q.dbg;
+    const bool dbg_on = dbg != nullptr && wg == 0 && lane == 0;
+    const int dbg_k = n_steps / 2;
 
-    // ---- first layer: thread (fr = row, fk = four consecutive hidden units), weights in registers
-    const int fr = tid >> 5, fk = (tid & 31) * 4;
-    float4 w0r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w0r[j] = *reinterpret_cast<const float4*>(P + q.w0 + (size_t)(fk + j) * 4);
-    const float4 b0r = *reinterpret_cast<const float4*>(P + q.b0 + fk);
-    // normalise the row + first layer on the VALU -> h1 (all waves, between barriers #1 and #2)
-    auto first_layer = [&]() {
-        float4 x = *reinterpret_cast<const float4*>(&s_raw[fr][0]);
+    // _process_observation (agent.py:262-280) of a raw row with the step's statistics (the quotient as a product with the
+    // reciprocal the statistics wave took once: within 2 ulp of the division)
+    auto normalise = [&](float4 x) -> float4 {
         if (use_norm) {
-            const float4 nm = *reinterpret_cast<const float4*>(&s_norm[0]), ns = *reinterpret_cast<const float4*>(&s_norm[4]);
-            x.x = fminf(fmaxf((x.x - nm.x) / (ns.x + 1e-8f), -obs_range), obs_range);
-            x.y = fminf(fmaxf((x.y - nm.y) / (ns.y + 1e-8f), -obs_range), obs_range);
-            x.z = fminf(fmaxf((x.z - nm.z) / (ns.z + 1e-8f), -obs_range), obs_range);
-            x.w = fminf(fmaxf((x.w - nm.w) / (ns.w + 1e-8f), -obs_range), obs_range);
+            const float4 nm = *reinterpret_cast<const float4*>(&s_norm[0]), ni = *reinterpret_cast<const float4*>(&s_norm[4]);
+            x.x = fminf(fmaxf((x.x - nm.x) * ni.x, -obs_range), obs_range);
+            x.y = fminf(fmaxf((x.y - nm.y) * ni.y, -obs_range), obs_range);
+            x.z = fminf(fmaxf((x.z - nm.z) * ni.z, -obs_range), obs_range);
+            x.w = fminf(fmaxf((x.w - nm.w) * ni.w, -obs_range), obs_range);
         }
-        const float bq[4] = {b0r.x, b0r.y, b0r.z, b0r.w};
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float acc = __fmaf_rn(x.x, w0r[j].x, 0.f);
-            acc = __fmaf_rn(x.y, w0r[j].y, acc);
-            acc = __fmaf_rn(x.z, w0r[j].z, acc);
-            acc = __fmaf_rn(x.w, w0r[j].w, acc);
-            o[j] = act_apply_c<ACT>(acc + bq[j]);
-        }
-        *reinterpret_cast<float4*>(h1 + fr * ALD + fk) = make_float4(o[0], o[1], o[2], o[3]);
+        return x;
     };
+    // A step of a workgroup, seen from its LDS barriers (all eight waves pass the same three per step):
+    //   #1  statistics of the step (chain wave) and raw rows (records wave) in LDS  -> matrix waves: the whole actor network
+    //   #3  partial logits in LDS                                                    -> chain wave: sample, the env's fate
+    //   #0  fate + record scalars of the step in LDS  -> wave 5: physics of the NEXT step for both actions; wave 6: its reset draw;
+    //       wave 7: this step's records to memory, next raw rows, next sampling uniform -- while the chain wave reduces, publishes
+    //       and collects the messages of the next step.
+    // (Helper work used to sit beside the matrix waves: a wave sharing a SIMD with back-to-back MFMAs gets ~1 VALU issue per MFMA,
+    //  and with the 4 k-cycle chain of the 32-row tiles halved the helpers had become the longest waves of the step.)
 
     if (wave < 4) {
-        // ================================================================ matrix waves
-        // B fragments of the actor half of the stacked branch layer, straight from the row-major weights: wave w owns columns
-        // [32 w, 32 w + 32) as two 16-column tiles; lane (g, cl) holds, for k-chunk c, W1[col][16 c + 4 g .. + 3] -- the MFMA with
-        // component s multiplies k = 16 c + 4 g + s on both operands
-        float4 bfr[2][8];
-        float bm[2], whr[2][2];
+        // ================================================================ matrix waves: the actor network, registers to registers
+        // Everything is computed TRANSPOSED, D[unit][row], because the 16x16x4 result layout -- lane (g, cl) holds D[4 g + i][cl] --
+        // IS the B-operand layout of the next product over those 16 units as its k: lane (g, cl) supplies B[k = 4 g + s][n = cl] to
+        // the MFMA with component s.  So
+        //   first layer : 8 MFMAs (one per 16 hidden units = one k-chunk of the branch layer), A = W0 rows, B = the normalised
+        //                 observation element x[row cl][dim g], C = bias; activation in place -> hf[c] (every matrix wave computes
+        //                 all of it: no h1 in LDS, no barrier between the layers, the activations issue under the MFMAs in flight)
+        //   branch layer: wave w owns hidden units [32 w, 32 w + 32) as two tiles; A = W1 straight from the row-major weights (lane
+        //                 (g, cl): W1[col0 + cl][16 c + 4 g .. + 3]), B = hf[c]; four independent accumulator chains (even / odd
+        //                 k-chunks per tile), the bias rides in as C
+        //   logits      : 8 MFMAs with A = head weights (rows 0, 1 of a 16-row operand, the rest zero), B = the activated tile
+        float4 wfr[2][8];
+        float w0f[8];
+        f32x4 b0f[8], bmf[2];
+        float whf[2][4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            w0f[c] = P[q.w0 + (size_t)(16 * c + cl) * 4 + g];                              // A[m = cl (hidden unit)][k = g (obs dim)]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b0f[c][i] = P[q.b0 + 16 * c + 4 * g + i];
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = 32 * wave + 16 * j + cl;
+            const int col0 = 32 * wave + 16 * j;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) bfr[j][c] = *reinterpret_cast<const float4*>(P + q.w1 + (size_t)col * AH + 16 * c + 4 * g);
-            bm[j] = P[q.b1 + col];
-            whr[j][0] = P[q.wa + col]; whr[j][1] = P[q.wa + AH + col];
-        }
-        for (int k = 0; k < n_steps; ++k) {
-            lds_barrier();                                                                         // #1
-            if (s_abort) break;
-            first_layer();
-            lds_barrier();                                                                         // #2 h1 ready
-            const float* arow = h1 + cl * ALD + 4 * g;
-            float4 af[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) af[c] = *reinterpret_cast<const float4*>(arow + 16 * c);
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                MFMA16(af[c].x, bfr[0][c].x, acc0); MFMA16(af[c].x, bfr[1][c].x, acc1);
-                MFMA16(af[c].y, bfr[0][c].y, acc0); MFMA16(af[c].y, bfr[1][c].y, acc1);
-                MFMA16(af[c].z, bfr[0][c].z, acc0); MFMA16(af[c].z, bfr[1][c].z, acc1);
-                MFMA16(af[c].w, bfr[0][c].w, acc0); MFMA16(af[c].w, bfr[1][c].w, acc1);
-            }
-            // epilogue: activation, this wave's 32 columns of both logits, summed over the 16 lanes of a row of the tile
-            float pl[4][2];
+            for (int c = 0; c < 8; ++c) wfr[j][c] = *reinterpret_cast<const float4*>(P + q.w1 + (size_t)(col0 + cl) * AH + 16 * c + 4 * g);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float ha = act_apply_c<ACT>(acc0[i] + bm[0]), hb = act_apply_c<ACT>(acc1[i] + bm[1]);
-                pl[i][0] = row16_sum(ha * whr[0][0] + hb * whr[1][0]);
-                pl[i][1] = row16_sum(ha * whr[0][1] + hb * whr[1][1]);
+                bmf[j][i] = P[q.b1 + col0 + 4 * g + i];
+                whf[j][i] = cl < 2 ? P[q.wa + cl * AH + col0 + 4 * g + i] : 0.f;           // A[m = cl (action)][k = 4 g + i (unit of the tile)]
             }
-            if (cl == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<float2*>(&plog[4 * g + i][2 * wave]) = make_float2(pl[i][0], pl[i][1]);
-            }
-            lds_barrier();                                                                         // #3
         }
-    } else if (wave == 5) {
-        // ================================================================ envs.step for both actions; memory.observations[t]
-        const int row = cl, e = e0 + row;
-        float* po = q.f_obs + ((size_t)q.t0 * n + e) * 4;
-        for (int k = 0; k < n_steps; ++k) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores of the previous step are in L2
+        int k = 0;
+        for (; k < n_steps; ++k) {
             lds_barrier();                                                                         // #1
             if (s_abort) break;
-            first_layer();
-            lds_barrier();                                                                         // #2
-            if (lane < 32) {                                     // DPP row 0: action 0, row 1: action 1
-                const double cps[4] = {cp_lds[row][0], cp_lds[row][1], cp_lds[row][2], cp_lds[row][3]};
+            const bool stamp = dbg_on && wave == 0 && k == dbg_k;
+            if (stamp) dbg[8] = clock64();
+            float xn = s_raw[cl][g];
+            if (use_norm) xn = fminf(fmaxf((xn - s_norm[g]) * s_norm[4 + g], -obs_range), obs_range);
+            // Program order = issue order of a wave: a VALU instruction overlaps a running MFMA only when it sits BETWEEN two MFMAs.
+            // So: the activations of k-chunks c + 2, c + 3 ride between the branch-layer MFMAs of chunks c, c + 1; tile 0 finishes
+            // first and its epilogue (activation + head MFMAs) rides between tile 1's MFMAs; only tile 1's epilogue is exposed.
+            // (sched_group_barrier pins the pattern: 1 MFMA, then up to 3 VALU.)
+#define XRL_INTERLEAVE(n_mfma)                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < (n_mfma); ++s_) {                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                             \
+    }
+            f32x4 hf[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) hf[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[c], xn, b0f[c], 0, 0, 0);   // (bias as the C operand)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hf[c][i] = act_apply_c<ACT>(hf[c][i]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // all eight first-layer MFMAs in flight before the first activation waits
+            __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[2][2], lg[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; lg[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            // ---- tile 0 (+ the first layer's remaining activations)
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                if (c == 0) acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[0][0].x, hf[0][0], bmf[0], 0, 0, 0);     // (bias as the C operand)
+                else MFMA16(wfr[0][c].x, hf[c][0], acc[0][0]);
+                MFMA16(wfr[0][c + 1].x, hf[c + 1][0], acc[0][1]);
+                MFMA16(wfr[0][c].y, hf[c][1], acc[0][0]); MFMA16(wfr[0][c + 1].y, hf[c + 1][1], acc[0][1]);
+                MFMA16(wfr[0][c].z, hf[c][2], acc[0][0]); MFMA16(wfr[0][c + 1].z, hf[c + 1][2], acc[0][1]);
+                MFMA16(wfr[0][c].w, hf[c][3], acc[0][0]); MFMA16(wfr[0][c + 1].w, hf[c + 1][3], acc[0][1]);
+                if (c + 2 < 8) {
+#pragma unroll
+                    for (int cc = c + 2; cc < c + 4; ++cc)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hf[cc][i] = act_apply_c<ACT>(hf[cc][i]);
+                }
+                XRL_INTERLEAVE(8)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- tile 1 (+ tile 0's epilogue: activation in place, then its 16 units' share of both logits on the matrix cores)
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                if (c == 0) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[1][0].x, hf[0][0], bmf[1], 0, 0, 0);
+                else MFMA16(wfr[1][c].x, hf[c][0], acc[1][0]);
+                MFMA16(wfr[1][c + 1].x, hf[c + 1][0], acc[1][1]);
+                MFMA16(wfr[1][c].y, hf[c][1], acc[1][0]); MFMA16(wfr[1][c + 1].y, hf[c + 1][1], acc[1][1]);
+                if (c < 4) {
+#pragma unroll
+                    for (int i = 2 * (c / 2); i < 2 * (c / 2) + 2; ++i) {                           // c = 0: units i = 0, 1; c = 2: i = 2, 3
+                        const float h = act_apply_c<ACT>(acc[0][0][i] + acc[0][1][i]);
+                        MFMA16(whf[0][i], h, lg[0]);
+                    }
+                }
+                MFMA16(wfr[1][c].z, hf[c][2], acc[1][0]); MFMA16(wfr[1][c + 1].z, hf[c + 1][2], acc[1][1]);
+                MFMA16(wfr[1][c].w, hf[c][3], acc[1][0]); MFMA16(wfr[1][c + 1].w, hf[c + 1][3], acc[1][1]);
+                XRL_INTERLEAVE(10)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (stamp) dbg[9] = clock64();
+            // ---- tile 1's epilogue
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float h = act_apply_c<ACT>(acc[1][0][i] + acc[1][1][i]);
+                MFMA16(whf[1][i], h, lg[1]);
+            }
+#undef XRL_INTERLEAVE
+            // lg[.][i] of lane (g, cl) = logit of action 4 g + i, row cl: actions 0, 1 live in DPP row 0
+            if (g == 0) *reinterpret_cast<float2*>(&plog[wave][cl][0]) = make_float2(lg[0][0] + lg[1][0], lg[0][1] + lg[1][1]);
+            if (stamp) dbg[10] = clock64();
+            lds_barrier();                                                                         // #3
+            lds_barrier();                                                                         // #0
+        }
+    } else if (wave == 5) {
+        // ================================================================ envs.step for both actions (lanes 0..31: DPP row 0 action
+        // 0, row 1 action 1; the simulator state lives in these lanes' registers); memory.observations[t] (lanes 32..47)
+        const int row = cl, e = e0 + row;
+        float* po = q.f_obs + ((size_t)q.t0 * n + e) * 4;
+        double cps[4] = {0.0, 0.0, 0.0, 0.0};
+        if (lane < 32 && e < n) {
+            cps[0] = q.cp_state[(size_t)e * 4 + 0]; cps[1] = q.cp_state[(size_t)e * 4 + 1];
+            cps[2] = q.cp_state[(size_t)e * 4 + 2]; cps[3] = q.cp_state[(size_t)e * 4 + 3];
+        }
+        // the state the drawn action of step k (or its auto-reset) left behind: s_sel by the chain wave
+        auto adopt = [&](int k) {
+            const int sel = s_sel[row];
+            const double* src = sel == 2 ? &rs_state[k & 1][row][0] : &ph_state[sel & 1][row][0];
+            const double2 s01 = *reinterpret_cast<const double2*>(src), s23 = *reinterpret_cast<const double2*>(src + 2);
+            cps[0] = s01.x; cps[1] = s01.y; cps[2] = s23.x; cps[3] = s23.y;
+        };
+        auto physics = [&](int k) {                              // outcomes of step k
+            if (lane < 32) {
                 double x, xd, th, thd;
                 bool term;
                 cartpole_advance(cps, g, x, xd, th, thd, term);
-                ph_state[g][row][0] = x; ph_state[g][row][1] = xd; ph_state[g][row][2] = th; ph_state[g][row][3] = thd;
-                ph_term[g][row] = term ? 1 : 0;
-            } else if (lane < 48) {                              // the normalised observation of the row -> buffer slot t
-                float4 x = *reinterpret_cast<const float4*>(&s_raw[row][0]);
-                if (use_norm) {
-                    const float4 nm = *reinterpret_cast<const float4*>(&s_norm[0]), ns = *reinterpret_cast<const float4*>(&s_norm[4]);
-                    x.x = fminf(fmaxf((x.x - nm.x) / (ns.x + 1e-8f), -obs_range), obs_range);
-                    x.y = fminf(fmaxf((x.y - nm.y) / (ns.y + 1e-8f), -obs_range), obs_range);
-                    x.z = fminf(fmaxf((x.z - nm.z) / (ns.z + 1e-8f), -obs_range), obs_range);
-                    x.w = fminf(fmaxf((x.w - nm.w) / (ns.w + 1e-8f), -obs_range), obs_range);
-                }
+                *reinterpret_cast<double2*>(&ph_state[g][row][0]) = make_double2(x, xd);
+                *reinterpret_cast<double2*>(&ph_state[g][row][2]) = make_double2(th, thd);
+                *reinterpret_cast<float4*>(&ph_f[k & 1][g][row][0]) = make_float4((float)x, (float)xd, (float)th, (float)thd);
+                ph_term[k & 1][g][row] = term ? 1 : 0;
+            }
+        };
+        physics(0);
+        int k = 0;
+        for (; k < n_steps; ++k) {
+            lds_barrier();                                                                         // #1
+            if (s_abort) break;
+            if (lane >= 32 && lane < 48) {                       // the normalised observation of the row -> buffer slot t
+                const float4 x = normalise(*reinterpret_cast<const float4*>(&s_raw[row][0]));
                 if (e < n) *reinterpret_cast<float4*>(po) = x;
             }
             po += (size_t)n * 4;
             lds_barrier();                                                                         // #3
+            lds_barrier();                                                                         // #0
+            const bool stamp = dbg_on && k == dbg_k;
+            if (stamp) dbg[11] = clock64();
+            if (lane < 32) adopt(k);
+            if (k + 1 < n_steps) physics(k + 1);
+            if (stamp) dbg[12] = clock64();
+        }
+        if (k == n_steps && lane < 16 && e < n) {                // hand the simulator state back
+            q.cp_state[(size_t)e * 4 + 0] = cps[0]; q.cp_state[(size_t)e * 4 + 1] = cps[1];
+            q.cp_state[(size_t)e * 4 + 2] = cps[2]; q.cp_state[(size_t)e * 4 + 3] = cps[3];
         }
     } else if (wave == 6) {
         // ================================================================ state after an auto-reset into the next episode
         const int row = cl, e = e0 + row;
         const uint64_t env_seed = q.env_seed;
-        for (int k = 0; k < n_steps; ++k) {
-            lds_barrier();                                                                         // #1
-            if (s_abort) break;
-            first_layer();
-            lds_barrier();                                                                         // #2
+        auto draw = [&](int k, int ep) {                         // for step k: ep = episode counter after step k - 1
             if (lane < 32) {
                 uint32_t o[4], qq[4];
-                philox4x32(env_seed, (uint32_t)e, (uint32_t)(ep_lds[row] + 1), g ? STREAM_RESET_B : STREAM_RESET_A, o);
+                philox4x32(env_seed, (uint32_t)e, (uint32_t)(ep + 1), g ? STREAM_RESET_B : STREAM_RESET_A, o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) qq[j] = __shfl_xor(o[j], 16, 64);
                 if (g == 0) {
+                    double r[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) rs_state[row][j] = -0.05 + 0.1 * u01d(o[j], qq[j]);
+                    for (int j = 0; j < 4; ++j) r[j] = -0.05 + 0.1 * u01d(o[j], qq[j]);
+                    *reinterpret_cast<double2*>(&rs_state[k & 1][row][0]) = make_double2(r[0], r[1]);
+                    *reinterpret_cast<double2*>(&rs_state[k & 1][row][2]) = make_double2(r[2], r[3]);
+                    *reinterpret_cast<float4*>(&rs_f[k & 1][row][0]) = make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
                 }
             }
-            lds_barrier();                                                                         // #3
-        }
-    } else if (wave == 7) {
-        // ================================================================ sampling uniform of (env, step); progress word
-        const int row = cl, e = e0 + row;
-        const uint64_t seed = q.seed;
-        const uint32_t step0 = q.step + (q.step_dev ? *q.step_dev : 0u) + (uint32_t)q.t0;
-        unsigned* done = q.xchg + XW_DONE + wg;
-        for (int k = 0; k < n_steps; ++k) {
+        };
+        draw(0, e < n ? q.cp_episodes[e] : 0);
+        int k = 0;
+        for (; k < n_steps; ++k) {
             lds_barrier();                                                                         // #1
             if (s_abort) break;
-            if (lane == 0 && k > 0) a_st_dev(done, (unsigned)k);     // steps < k complete, their stores in L2 (trailing readers)
-            first_layer();
-            lds_barrier();                                                                         // #2
+            lds_barrier();                                                                         // #3
+            lds_barrier();                                                                         // #0
+            if (k + 1 < n_steps) draw(k + 1, ep_lds[row]);
+        }
+    } else if (wave == 7) {
+        // ================================================================ records wave: the step's transition to the buffer, the
+        // next raw rows, the sampling uniforms
+        const int row = cl, e = e0 + row;
+        const bool row_ok = e < n && lane < 16;
+        const uint64_t seed = q.seed;
+        const uint32_t step0 = q.step + (q.step_dev ? *q.step_dev : 0u) + (uint32_t)q.t0;
+        const int T = q.T, t0 = q.t0;
+        unsigned* done = q.xchg + XW_DONE + wg;
+        const int n4 = (n + 3) & ~3;
+        const size_t o0 = (size_t)t0 * n + e;
+        float* p_act = q.f_act + o0; float* p_logp = q.f_logp + o0; float* p_term = q.f_term + o0;
+        uint8_t* p_seg = q.f_seg + o0; float* p_xn = q.xnext + o0 * 4;
+        float* p_rfin = q.ret_final + (size_t)t0 * n4 + e; uint8_t* p_end = q.ended + (size_t)t0 * n4 + e;
+        auto draw = [&](int k) {
             if (lane < 16) {
                 uint32_t rr4[4];
                 philox4x32(seed, (uint32_t)e, step0 + (uint32_t)k, STREAM_ACTION, rr4);
                 s_u[row] = u01(rr4[0]);
             }
-            lds_barrier();                                                                         // #3
+        };
+        if (lane < 16) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok) o = *reinterpret_cast<const float4*>(q.obs_raw + (size_t)e * 4);
+            *reinterpret_cast<float4*>(&s_raw[row][0]) = o;
         }
+        draw(0);
+        int k = 0;
+        for (; k < n_steps; ++k) {
+            lds_barrier();                                                                         // #1
+            if (s_abort) break;
+            // idle until the env's fate is known: the stores of the previous step have reached L2 by now -- progress word for the
+            // trailing readers (steps < k complete)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && k > 0) a_st_dev(done, (unsigned)k);
+            // this step's statistics, into registers (the chain wave writes the next step's behind barrier #0)
+            const float4 nm = *reinterpret_cast<const float4*>(&s_norm[0]), ni = *reinterpret_cast<const float4*>(&s_norm[4]);
+            lds_barrier();                                                                         // #3
+            lds_barrier();                                                                         // #0
+            if (lane < 16) {
+                const float4 rec = *reinterpret_cast<const float4*>(&s_rec[row][0]);
+                const int a = (int)rec.x, flags = __float_as_int(rec.z);
+                const bool term = (flags & 1) != 0, fin = (flags & 2) != 0;
+                const float4 nobs = *reinterpret_cast<const float4*>(&ph_f[k & 1][a][row][0]);
+                const float4 robs = fin ? *reinterpret_cast<const float4*>(&rs_f[k & 1][row][0]) : nobs;
+                // get_terminated_values' input: next_obs (before the reset), normalised with this step's statistics (read after the launch)
+                float4 nv = nobs;
+                if (use_norm) {
+                    nv.x = fminf(fmaxf((nobs.x - nm.x) * ni.x, -obs_range), obs_range);
+                    nv.y = fminf(fmaxf((nobs.y - nm.y) * ni.y, -obs_range), obs_range);
+                    nv.z = fminf(fmaxf((nobs.z - nm.z) * ni.z, -obs_range), obs_range);
+                    nv.w = fminf(fmaxf((nobs.w - nm.w) * ni.w, -obs_range), obs_range);
+                }
+                *reinterpret_cast<float4*>(&s_raw[row][0]) = robs;
+                if (row_ok) {
+                    *p_act = rec.x;
+                    *p_logp = rec.y;
+                    *p_term = term ? 1.f : 0.f;
+                    *p_seg = (fin || t0 + k == T - 1) ? (uint8_t)(1 | (term ? 6 : 0)) : (uint8_t)0;
+                    *reinterpret_cast<float4*>(p_xn) = nv;
+                    // what the bookkeeper reads inside the launch: always device scope (its placement is not part of the check)
+                    if (fin) a_st_dev(p_rfin, rec.w);
+                    a_st_dev(p_end, (uint8_t)(fin ? 1 : 0));
+                }
+            }
+            p_act += n; p_logp += n; p_term += n; p_seg += n; p_xn += (size_t)n * 4; p_rfin += n4; p_end += n4;
+            if (k + 1 < n_steps) draw(k + 1);
+        }
+        if (k == n_steps && row_ok) *reinterpret_cast<float4*>(q.obs_raw + (size_t)e * 4) = *reinterpret_cast<const float4*>(&s_raw[row][0]);
     } else {
         // ================================================================ wave 4, the chain wave: lane (d = DPP row, row) --
-        // every lane of a row carries the row's state, DPP row d reduces dimension d of the observations
+        // every lane of a row carries the row's counters, DPP row d reduces dimension d of the observations
         const int row = cl, d = g, e = e0 + row;
         const bool row_ok = e < n;
         const bool single = n_act == 1;                          // one workgroup: the partial sums ARE the batch sums
         unsigned long long* xu = reinterpret_cast<unsigned long long*>(q.xchg);
-        long long* dbg = q.dbg;
-        const bool dbg_on = dbg != nullptr && wg == 0;
-        const int dbg_k = n_steps / 2;
-        const int max_steps = q.max_steps, T = q.T, t0 = q.t0;
+        const int max_steps = q.max_steps;
         const float gamma = q.gamma;
         const float bh0 = P[q.ba], bh1 = P[q.ba + 1];
         int cp_steps = 0, cp_ep = 0;
         float cp_score = 0.f, rtrack = 0.f;
         float st_mean = 0.f, st_var = 1.f;
         double st_cnt = 0.0;
+        // episode statistics of this launch (added to the env's counters once, at the end; integer-valued: exact in any order)
+        int ep_cnt = 0, ep_steps = 0;
+        double ep_score = 0.0;
         if (row_ok) { cp_steps = q.cp_steps[e]; cp_score = q.cp_score[e]; rtrack = q.ret_track[e]; cp_ep = q.cp_episodes[e]; }
         if (use_norm) { st_mean = q.obs_stats[d]; st_var = q.obs_stats[4 + d]; st_cnt = *q.obs_count; }
         if (lane == 0) { s_abort = 0; s_multi = (q.flags & 1) ? 1 : 0; }
-        if (d == 0) {
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-            if (row_ok) {
-                o = *reinterpret_cast<const float4*>(q.obs_raw + (size_t)e * 4);
-                c0 = q.cp_state[(size_t)e * 4 + 0]; c1 = q.cp_state[(size_t)e * 4 + 1];
-                c2 = q.cp_state[(size_t)e * 4 + 2]; c3 = q.cp_state[(size_t)e * 4 + 3];
-            }
-            *reinterpret_cast<float4*>(&s_raw[row][0]) = o;
-            cp_lds[row][0] = c0; cp_lds[row][1] = c1; cp_lds[row][2] = c2; cp_lds[row][3] = c3;
-            ep_lds[row] = cp_ep;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // per-lane record pointers (advance by one buffer row per step): nothing of the argument block stays in scalar registers
-        const int n4 = (n + 3) & ~3;
-        const size_t o0 = (size_t)t0 * n + e;
-        float* p_act = q.f_act + o0; float* p_logp = q.f_logp + o0; float* p_term = q.f_term + o0;
-        uint8_t* p_seg = q.f_seg + o0; float* p_xn = q.xnext + o0 * 4;
-        float* p_rfin = q.ret_final + (size_t)t0 * n4 + e; uint8_t* p_end = q.ended + (size_t)t0 * n4 + e;
-        double* cp_stats = q.cp_stats;
+        if (d == 0) ep_lds[row] = cp_ep;
+        // message of a step: unit u = 8 * half + j (j = d: sum, 4 + d: sum of squares) of this workgroup -- positions 0..3 of DPP
+        // row d hold (lo s1, lo s2, hi s1, hi s2)
+        const int unit = (8 * (row >> 1) + 4 * (row & 1) + d) * 16 + wg;
+        auto message = [&](double s1, double s2, unsigned tag) -> unsigned long long {
+            const double sv = (row & 1) ? s2 : s1;
+            const unsigned word = (row & 2) ? (unsigned)__double2hiint(sv) : (unsigned)__double2loint(sv);
+            return ((unsigned long long)word << 32) | (unsigned long long)tag;
+        };
         // partial sums of the raw observations of this workgroup's rows, dimension d: (sum, sum of squares) in every lane of row d
         double ps1 = 0.0, ps2 = 0.0;
         if (use_norm) {
-            const double v = row_ok ? (double)s_raw[row][d] : 0.0;
+            const double v = row_ok ? (double)q.obs_raw[(size_t)e * 4 + d] : 0.0;
             ps1 = row16_sum(v); ps2 = row16_sum(v * v);
             if (!single) {
                 // placement: every workgroup ORs its XCC id into the launch's mask BEFORE its first message; whoever has seen all
@@ -385,31 +496,30 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
                     const unsigned seen = atomicOr(q.xchg + XW_MASK, 1u << (xcc & 0xf));
                     asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
                 }
-                // unit u = 8 * half + j (j = d: sum, 4 + d: sum of squares): positions 0..3 of DPP row d publish (lo s1, lo s2, hi s1, hi s2)
-                if (row < 4) {
-                    const double sv = (row & 1) ? ps2 : ps1;
-                    const unsigned word = (row & 2) ? (unsigned)__double2hiint(sv) : (unsigned)__double2loint(sv);
-                    const int u = 8 * (row >> 1) + 4 * (row & 1) + d;
-                    a_st_dev(xu + 256 + u * 16 + wg, ((unsigned long long)word << 32) | 1ull);      // first message (tag 1, slot 1): always device scope
-                }
+                if (row < 4) a_st_dev(xu + 256 + unit, message(ps1, ps2, 1u));   // first message (tag 1, slot 1): always device scope
             }
         }
-        bool multi = (q.flags & 1) != 0;
+        bool multi = true;                                       // until the placement is known (first poll): device-scope stores
         int k = 0;
         for (; k < n_steps; ++k) {
             const bool stamp = dbg_on && k == dbg_k;
-            long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0, ts7 = 0;
+            long long ts0 = 0, ts1 = 0, ts2 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
             if (stamp) ts0 = clock64();
             // ---------------- (1) statistics of the step: the partial sums of all workgroups
             if (use_norm) {
                 double S1 = ps1, S2 = ps2;
+                // what of the merge does not depend on the batch sums, ahead of the wait for them
+                const double cnt = st_cnt, tot = cnt + (double)n;
+                const float nf = (float)n, cntf = (float)cnt, rt = 1.0f / (float)tot;
                 if (!single) {
                     const unsigned tag = (unsigned)(k + 1);
-                    unsigned long long u0, u1, u2, u3;
                     int spins = 0;
                     const bool live = cl < n_act;
                     const unsigned long long* xs = xu + (tag & 1u) * 256 + lane;
+                    unsigned long long u0, u1, u2, u3;
                     for (;;) {
+                        // device-scope loads: never served by this CU's L1 (workgroup-scope loads, sc0, are: tried, the poll then spins
+                        // on a stale line for ever)
                         u0 = a_ld_dev(xs); u1 = a_ld_dev(xs + 64); u2 = a_ld_dev(xs + 128); u3 = a_ld_dev(xs + 192);
                         const bool ok = !live || ((unsigned)u0 == tag && (unsigned)u1 == tag && (unsigned)u2 == tag && (unsigned)u3 == tag);
                         if (__ballot(!ok) == 0ull) break;
@@ -422,118 +532,87 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
                     const double v1 = live ? __hiloint2double((int)(u2 >> 32), (int)(u0 >> 32)) : 0.0;
                     const double v2 = live ? __hiloint2double((int)(u3 >> 32), (int)(u1 >> 32)) : 0.0;
                     S1 = row16_sum(v1); S2 = row16_sum(v2);
-                    if (k == 0 && lane == 0) {
+                    if (k == 0) {
                         const unsigned mask = a_ld_dev(q.xchg + XW_MASK);
-                        if (__popc(mask) != 1) s_multi = 1;
-                        if ((__popc(mask) != 1 || (q.flags & 1)) && wg == 0) atomicAdd(q.status + 3, 1);
+                        multi = __popc(mask) != 1 || (q.flags & 1);
+                        if (lane == 0 && multi && wg == 0) atomicAdd(q.status + 3, 1);
                     }
                 }
                 if (stamp) ts1 = clock64();
-                float new_sd;
-                rms_merge(S1, S2, n, st_mean, st_var, st_cnt, new_sd);
-                if (row == 0) { s_norm[d] = st_mean; s_norm[4 + d] = new_sd; }
+                // RunningMeanStd.update (statistic_tools.py:117-185: batch mean, np.std ** 2, update_from_moments) for dimension d.
+                // On the step chain, so: one division (1 / tot, above) shared by the three quotients of update_from_moments, the batch
+                // variance straight from the float64 sums (no detour over its root), and 1 / (std + 1e-8) from the hardware's root and
+                // reciprocal (1 ulp each): everything within ~2 ulp of the reference's own float32 evaluation.
+                {
+                    const bool pow2 = (n & (n - 1)) == 0;        // scaling by 1/n is then the exact same number as the division
+                    const double inv_n = 1.0 / (double)n;
+                    const double m = pow2 ? S1 * inv_n : S1 / n;
+                    const float bmean = (float)m;
+                    const float bv = (float)fmax((pow2 ? S2 * inv_n : S2 / n) - m * m, 0.0);
+                    const float delta = bmean - st_mean;
+                    const float new_mean = st_mean + delta * nf * rt;
+                    const float M2 = st_var * cntf + bv * nf + (delta * delta) * cntf * nf * rt;
+                    const float new_var = M2 * rt;
+                    st_mean = new_mean; st_var = new_var; st_cnt = tot;
+                    if (row == 0) { s_norm[d] = new_mean; s_norm[4 + d] = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(new_var) + 1e-8f); }
+                }
             }
             if (stamp) ts2 = clock64();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores of the previous step are in L2
             lds_barrier();                                                                         // #1 statistics / raw rows ready
             if (s_abort) break;
-            multi = s_multi != 0;
-            first_layer();
-            lds_barrier();                                                                         // #2
-            if (stamp) ts3 = clock64();
-            lds_barrier();                                                                         // #3 logits, physics, draws ready
+            // everything of the tail that does not need the logits
+            const float u = s_u[row];
+            const float oa = ph_f[k & 1][0][row][d], ob = ph_f[k & 1][1][row][d], orst = rs_f[k & 1][row][d];   // dimension d of the three possible next observations
+            const int term_a = ph_term[k & 1][0][row], term_b = ph_term[k & 1][1][row];
+            lds_barrier();                                                                         // #3 logits ready
             // ---------------- (4) sample, pick the transition, publish the new partial sums
             if (stamp) ts4 = clock64();
-            const float u = s_u[row];
-            const float4 pA = *reinterpret_cast<const float4*>(&plog[row][0]), pB = *reinterpret_cast<const float4*>(&plog[row][4]);
-            const double2 sa0 = *reinterpret_cast<const double2*>(&ph_state[0][row][0]), sa1 = *reinterpret_cast<const double2*>(&ph_state[0][row][2]);
-            const double2 sb0 = *reinterpret_cast<const double2*>(&ph_state[1][row][0]), sb1 = *reinterpret_cast<const double2*>(&ph_state[1][row][2]);
-            const double2 rs0 = *reinterpret_cast<const double2*>(&rs_state[row][0]), rs1 = *reinterpret_cast<const double2*>(&rs_state[row][2]);
-            const int term_a = ph_term[0][row], term_b = ph_term[1][row];
-            float nmv[4] = {0.f, 0.f, 0.f, 0.f}, nsv[4] = {1.f, 1.f, 1.f, 1.f};
-            if (use_norm) {
-                const float4 nm = *reinterpret_cast<const float4*>(&s_norm[0]), ns = *reinterpret_cast<const float4*>(&s_norm[4]);
-                nmv[0] = nm.x; nmv[1] = nm.y; nmv[2] = nm.z; nmv[3] = nm.w; nsv[0] = ns.x; nsv[1] = ns.y; nsv[2] = ns.z; nsv[3] = ns.w;
-            }
-            const float l0 = ((pA.x + pA.z) + (pB.x + pB.z)) + bh0, l1 = ((pA.y + pA.w) + (pB.y + pB.w)) + bh1;
-            // ---- get_actions: Categorical(logits).sample() by inverse CDF on the step's uniform, log-prob
+            const float2 p0 = *reinterpret_cast<const float2*>(&plog[0][row][0]), p1 = *reinterpret_cast<const float2*>(&plog[1][row][0]);
+            const float2 p2 = *reinterpret_cast<const float2*>(&plog[2][row][0]), p3 = *reinterpret_cast<const float2*>(&plog[3][row][0]);
+            const float l0 = ((p0.x + p1.x) + (p2.x + p3.x)) + bh0, l1 = ((p0.y + p1.y) + (p2.y + p3.y)) + bh1;
+            // ---- get_actions: Categorical(logits).sample() by inverse CDF on the step's uniform, log-prob.  Two actions: the larger
+            // logit's exp(l - max) is exactly 1; hardware exp2 / log2 (1 ulp) for the other terms
             int a;
             float logp;
             {
-                const float mx = fmaxf(l0, l1);
-                float se = 0.f;
-                se += expf(l0 - mx); se += expf(l1 - mx);
-                const float lse = mx + logf(se);
-                float c = 0.f;
-                c += expf(l0 - lse);
+                const float mx = fmaxf(l0, l1), mn = fminf(l0, l1);
+                const float se = 1.0f + __expf(mn - mx);
+                const float lse = mx + __logf(se);
+                const float c = __expf(l0 - lse);
                 a = c > u ? 0 : 1;
                 logp = (a ? l1 : l0) - lse;
             }
-            if (stamp) ts5 = clock64();
             // ---- envs.step(acts): the pre-computed transition of the drawn action + auto-reset
-            const double x = a ? sb0.x : sa0.x, xd = a ? sb0.y : sa0.y, th = a ? sb1.x : sa1.x, thd = a ? sb1.y : sa1.y;
             const bool term = (a ? term_b : term_a) != 0;
             const int steps = cp_steps + 1;
             const bool trunc = steps >= max_steps;
             const bool fin = term || trunc;
-            const float nobs[4] = {(float)x, (float)xd, (float)th, (float)thd};
             const float score = cp_score + 1.0f;
-            const float robs[4] = {fin ? (float)rs0.x : nobs[0], fin ? (float)rs0.y : nobs[1], fin ? (float)rs1.x : nobs[2], fin ? (float)rs1.y : nobs[3]};
             const float tr = gamma * rtrack + 1.0f;               // self.returns = gamma * self.returns + rewards (reward 1)
             if (fin) cp_ep += 1;
-            cp_steps = fin ? 0 : steps; cp_score = fin ? 0.f : score; rtrack = fin ? 0.f : tr;
+            if (d == 0) {
+                s_sel[row] = fin ? 2 : a; ep_lds[row] = cp_ep;
+                *reinterpret_cast<float4*>(&s_rec[row][0]) = make_float4((float)a, logp, __int_as_float((term ? 1 : 0) | (fin ? 2 : 0)), tr);
+            }
+            if (stamp) ts5 = clock64();
+            lds_barrier();                                                                         // #0 the env's fate: records, next step's physics / draws start
             // ---- partial sums of the new raw observations (dimension d of this lane's DPP row) and the message of step k + 1
             if (use_norm && k + 1 < n_steps) {
-                const float rv = d == 0 ? robs[0] : d == 1 ? robs[1] : d == 2 ? robs[2] : robs[3];
+                const float rv = fin ? orst : (a ? ob : oa);
                 const double v = row_ok ? (double)rv : 0.0;
                 ps1 = row16_sum(v); ps2 = row16_sum(v * v);
-                if (!single && row < 4) {
-                    const double sv = (row & 1) ? ps2 : ps1;
-                    const unsigned word = (row & 2) ? (unsigned)__double2hiint(sv) : (unsigned)__double2loint(sv);
-                    const int uu = 8 * (row >> 1) + 4 * (row & 1) + d;
-                    a_st(xu + (k & 1) * 256 + uu * 16 + wg, ((unsigned long long)word << 32) | (unsigned long long)(unsigned)(k + 2), multi);
-                }
+                if (!single && row < 4) a_st(xu + (k & 1) * 256 + unit, message(ps1, ps2, (unsigned)(k + 2)), multi);
             }
             if (stamp) ts6 = clock64();
-            // ---- state for the next step (LDS) and the step's record (memory)
-            if (d == 0) {
-                *reinterpret_cast<float4*>(&s_raw[row][0]) = make_float4(robs[0], robs[1], robs[2], robs[3]);
-                *reinterpret_cast<double2*>(&cp_lds[row][0]) = fin ? rs0 : make_double2(x, xd);
-                *reinterpret_cast<double2*>(&cp_lds[row][2]) = fin ? rs1 : make_double2(th, thd);
-                ep_lds[row] = cp_ep;
-                if (row_ok) {
-                    *p_act = (float)a;
-                    *p_logp = logp;
-                    *p_term = term ? 1.f : 0.f;
-                    *p_seg = (term || trunc || t0 + k == T - 1) ? (uint8_t)(1 | (term ? 6 : 0)) : (uint8_t)0;
-                    float nv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = nobs[j];
-                        if (use_norm) { v = (v - nmv[j]) / (nsv[j] + 1e-8f); v = fminf(fmaxf(v, -obs_range), obs_range); }
-                        nv[j] = v;
-                    }
-                    *reinterpret_cast<float4*>(p_xn) = make_float4(nv[0], nv[1], nv[2], nv[3]);   // (read after the launch)
-                    // what the bookkeeper reads inside the launch: always device scope (its placement is not part of the check;
-                    // nothing waits for these stores before the next step's barrier #1)
-                    if (fin) a_st_dev(p_rfin, tr);
-                    a_st_dev(p_end, (uint8_t)(fin ? 1 : 0));
-                    if (fin) { atomicAdd(&cp_stats[0], 1.0); atomicAdd(&cp_stats[1], (double)score); atomicAdd(&cp_stats[2], (double)steps); }
-                }
-            }
-            p_act += n; p_logp += n; p_term += n; p_seg += n; p_xn += (size_t)n * 4; p_rfin += n4; p_end += n4;
-            if (stamp) {
-                ts7 = clock64();
-                if (lane == 0) { dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = ts3; dbg[4] = ts4; dbg[5] = ts5; dbg[6] = ts6; dbg[7] = ts7; dbg[15] = 8; }
-            }
+            if (fin && row_ok) { ep_cnt += 1; ep_steps += steps; ep_score += (double)score; }
+            cp_steps = fin ? 0 : steps; cp_score = fin ? 0.f : score; rtrack = fin ? 0.f : tr;
+            if (stamp) { dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[4] = ts4; dbg[5] = ts5; dbg[6] = ts6; dbg[15] = 8; }
         }
         // ---- hand the state back
         if (k == n_steps) {
             if (d == 0 && row_ok) {
                 q.cp_steps[e] = cp_steps; q.cp_score[e] = cp_score; q.ret_track[e] = rtrack; q.cp_episodes[e] = cp_ep;
-                q.cp_state[(size_t)e * 4 + 0] = cp_lds[row][0]; q.cp_state[(size_t)e * 4 + 1] = cp_lds[row][1];
-                q.cp_state[(size_t)e * 4 + 2] = cp_lds[row][2]; q.cp_state[(size_t)e * 4 + 3] = cp_lds[row][3];
-                *reinterpret_cast<float4*>(q.obs_raw + (size_t)e * 4) = *reinterpret_cast<const float4*>(&s_raw[row][0]);
+                if (ep_cnt) { atomicAdd(&q.cp_stats[0], (double)ep_cnt); atomicAdd(&q.cp_stats[1], ep_score); atomicAdd(&q.cp_stats[2], (double)ep_steps); }
             }
             if (wg == 0 && use_norm && row == 0) {
                 q.obs_stats[d] = st_mean; q.obs_stats[4 + d] = st_var;
