@@ -209,9 +209,9 @@ def golden_ppo(dist, learner_cls=PPO_Learner, name="ppo", size=None):
     torch.manual_seed(1)
     # the other members of the shared-trunk family Basic_MLP [128] + actor [128] + critic [128] (configs/ppo/classic_control/*.yaml,
     # box2d/{LunarLander,BipedalWalker}.yaml) at the minibatch their yaml gives: 10 envs x 256 / 8 = 320 rows
-    family = {"acrobot": (6, 3), "lunar": (8, 4), "pendulum": (3, 1), "walker": (24, 4)}
+    family = {"acrobot": (6, 3), "lunar": (8, 4), "pendulum": (3, 1), "walker": (24, 4), "mountaincar": (2, 3)}
     rng = np.random.default_rng(5 if size is None else {"c1": 105, "c2": 205, "c4": 405, "acrobot": 505, "lunar": 605,
-                                                       "pendulum": 705, "walker": 805}[size])
+                                                       "pendulum": 705, "walker": 805, "mountaincar": 905}[size])
     act_fn = nn.LeakyReLU if (dist == "categorical" or size in ("c4",) + tuple(family)) else nn.ReLU
     init = torch.nn.init.orthogonal_
     n_updates = 3 if size is None else 2
@@ -1049,7 +1049,8 @@ def golden_baseline_sizes():
     golden_qmix_rnn(True, fixed=True, size="c5")
     golden_ppo_chain()
     golden_ppo_cnn()
-    for dist, size in (("categorical", "acrobot"), ("categorical", "lunar"), ("gaussian", "pendulum"), ("gaussian", "walker")):
+    for dist, size in (("categorical", "acrobot"), ("categorical", "lunar"), ("gaussian", "pendulum"), ("gaussian", "walker"),
+                       ("categorical", "mountaincar")):
         golden_ppo(dist, size=size)
 
 

@@ -234,24 +234,27 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
             _record(f"device-data chain {k_} pass {it}: engine vs f64 oracle chain [f32 oracle vs f64: {rec[k_]['f32_oracle_vs_f64']:.3e}]",
                     rec[k_]["hip_vs_f64"], rec[k_]["hip_vs_f32_oracle"], 0.0, g_.size)
         _write_bounds(n, T, bounds)
-        # The chained PARAMETERS are held to a measured bound where a reference chain exists: test_update_phase_chain_vs_reference_chain
-        # (fixture with the reference's own float32 and float64 chains: the engine ends no further from the float64 chain than the
-        # reference's torch ops do).  Here, on the device's own rollout data, only this engine, the NumPy oracle and its float64 twin
-        # exist, and three float32 evaluations of a 64-step chain drift apart chaotically (round 3, 256 envs: actor.logits.0.bias
-        # 6.6e-3 of its scale for the engine, 5.6e-4 for the NumPy oracle, where on the fixture's data engine and torch both sit at
-        # 1.9e-3): the numbers are recorded (profiles/), the integrated check above -- every loss term of the LAST minibatch, which
-        # all 63 earlier steps feed, at 1e-5 -- is the assertion, and the parameters get a sanity bound that a wrong step would miss
-        # by orders of magnitude.
+        # The chained PARAMETERS.  Where a reference chain exists they are held against it: test_update_phase_chain_vs_reference_chain
+        # (fixture with the reference's own float32 and float64 chains).  Here, on the device's own rollout data, only this engine, the
+        # NumPy oracle and its float64 twin exist, and three float32 evaluations of a 64-step chain drift apart chaotically (PPO's
+        # clipped surrogate has a discontinuous gradient, Adam divides by sqrt(v) + eps).  The yardstick is therefore the float32
+        # ORACLE's own distance from the float64 chain on the same tensor: the engine may be DEV_K times as far (measured worst case,
+        # round 3, 256 envs: actor.logits.0.bias 6.6e-3 of its scale for the engine vs 5.6e-4 for the oracle = 12x -- the 2-element
+        # tensor whose gradient is a sum cancelling to < 1 % of its terms; every other tensor < 4x; all numbers are recorded in
+        # profiles/).  The integrated check above -- every loss term of the LAST minibatch, which all 63 earlier steps feed, against the
+        # float64 chain -- is the sharp assertion; a wrong step would miss this one by orders of magnitude.
+        DEV_K = 32.0
         for k_, r_ in rec.items():
-            assert r_["hip_vs_f32_oracle"] <= 1e-5 or r_["hip_vs_f64"] <= 2e-2, f"param {k_} after {64 * (it + 1)} updates: {r_}"
+            assert r_["hip_vs_f64"] <= max(1e-5, DEV_K * r_["f32_oracle_vs_f64"]), f"param {k_} after {64 * (it + 1)} updates: {r_}"
         st_ = agent.learner.optimizer.read()
         assert st_.step == 64 * (it + 1)
     assert knife_total <= 2, knife_total                               # ties of a float32 cdf with a 24-bit uniform are rare
 
 
 # ------------------------------------------------------------------ the update phase against the REFERENCE's own chain
-CHAIN_K = 2.0        # measured (profiles/r03_parity_errors_gpu.json, "chain after..." lines): the engine / reference ratio is <= 0.94
-#                      for every tensor above the 1e-5 floor after 16 and after 64 updates; 2.0 leaves room for a re-ordered sum
+CHAIN_K = 2.0        # measured (profiles/r03_parity_errors_gpu.json, "chain after..." lines): engine / reference distance from the float64
+#                      chain <= 1.35 (after 16 updates, actor.logits.0.bias: 4.96e-4 vs 3.69e-4), <= 0.94 after 64 updates, for every
+#                      tensor above the 1e-5 floor; 2.0 leaves room for a re-ordered sum
 
 
 def chain_indices(epochs=8, rows=65536, n_mb=8):

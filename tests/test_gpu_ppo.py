@@ -17,7 +17,8 @@ torch = pytest.importorskip("torch")
 # one-sided and do not cancel with the signal (torch's vectorised exp is unbiased; the reference sits 1.6e-7 from its twin).
 # Every other tensor of that fixture is within 1e-5 of the float32 reference or -- the critic's, whose float32 sgemm sums are
 # 1.5e-4 off in the reference itself -- within 1.1e-7 of the float64 twin (profiles/r03_parity_errors_gpu.json).
-C2_TOL = 2e-5
+# A NAMED exception: every other tensor of the C2 fixture is held at 1e-5.
+C2_EXCEPT = {"actor.logits.0.bias": 2e-5}
 
 
 class Capture:
@@ -155,7 +156,7 @@ def test_ppo_learner_vs_reference_fixture(dist, size):
     net.load_state_dict(sub(g, "init"))
     nu = int(g.get("n_updates", 3))
     lr, vf, ent, clip, gclip, ef, total = g["cfg"]
-    chk = EngineFixtureCheck(g, net, learner, float(lr), end_factor=float(ef), total_iters=int(total), tol=C2_TOL if size == "c2" else 1e-5)
+    chk = EngineFixtureCheck(g, net, learner, float(lr), end_factor=float(ef), total_iters=int(total), tol=1e-5, tol_except=C2_EXCEPT if size == "c2" else None)
     for u in range(nu):
         b = sub(g, f"u{u}/batch")
         info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], values=b["values"],
@@ -224,7 +225,7 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
         assert lr_.total_iters == int(total) and lr_.fused_eligible(mem) and agent.batch_size == n * T
         agent.model.load_state_dict(sub(g, "init"))
         chk = EngineFixtureCheck(g, agent.model, lr_, float(lr), end_factor=float(ef), total_iters=int(total),
-                                 tol=C2_TOL if size == "c2" else 1e-5)
+                                 tol=1e-5, tol_except=C2_EXCEPT if size == "c2" else None)
         idx = torch.arange(n * T, dtype=torch.int64, device="cuda").view(1, -1)
         lr_.prepare_fused(mem, n * T)
         assert lr_.split == (kernel in ("split", "pair")) and lr_.pair == (kernel == "pair")
@@ -245,11 +246,12 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
 
 
 @pytest.mark.parametrize("dist,size,tiles", [("categorical", "acrobot", 32), ("categorical", "lunar", 32), ("gaussian", "pendulum", 32),
-                                             ("gaussian", "walker", 32), ("gaussian", "walker", 64), ("categorical", "acrobot", 64)])
+                                             ("gaussian", "walker", 32), ("gaussian", "walker", 64), ("categorical", "acrobot", 64),
+                                             ("categorical", "mountaincar", 32), ("categorical", "mountaincar", 64)])
 def test_shared_trunk_family_vs_reference_fixture(dist, size, tiles):
     """The other members of the reference's shared-trunk PPO family (Basic_MLP [128] + actor [128] + critic [128]:
-    configs/ppo/classic_control/{Acrobot,Pendulum}.yaml, box2d/{LunarLander,BipedalWalker}.yaml -- (D, A) = (6, 3), (3, 1), (8, 4),
-    (24, 4), categorical and Gaussian with tanh on the mean) through the ONE-LAUNCH minibatch kernel (csrc/ppo_trunk.hip: (tile, role)
+    configs/ppo/classic_control/{Acrobot,Pendulum,MountainCar}.yaml, box2d/{LunarLander,BipedalWalker}.yaml -- (D, A) = (6, 3), (3, 1),
+    (2, 3), (8, 4), (24, 4), categorical and Gaussian with tanh on the mean) through the ONE-LAUNCH minibatch kernel (csrc/ppo_trunk.hip: (tile, role)
     workgroups, 32- and 64-row tiles) + xrl_reduce_adam, from rows in a HipOnPolicyBuffer, at the 320-row minibatch their yaml
     gives: the reference learner's loss terms, clipped gradients (float64-anchored), parameter steps, Adam moments."""
     from xuance_amd.nets import ActorCriticNet
@@ -361,7 +363,7 @@ def test_minibatch_gradient_noise_vs_float64(size):
     products are exact fused-multiply-add chains, its slab sums fixed-order, its norm float64 -- beyond 1.5x + 1e-7 of the
     tensor's scale (the twin itself casts the probability ratio to float32, ppo_learner.py:52), or 2e-6 of the tensor's scale
     where the reference is quieter than that (measured: the actor's tensors at C2, 2.4e-7 ... 1.1e-6 against the reference's
-    4e-8 ... 1.4e-7 -- one-sided expf / logf rounding, see C2_TOL; the critic's tensors 5e-9 against the reference's 3.5e-6).  Layered path (C1 / C2) and the
+    4e-8 ... 1.4e-7 -- one-sided expf / logf rounding, see C2_EXCEPT; the critic's tensors 5e-9 against the reference's 3.5e-6).  Layered path (C1 / C2) and the
     one-launch wide kernel (C4); the CartPole one-launch kernels meet the same twin in
     test_one_launch_minibatch_kernels_vs_reference_fixture."""
     dist = "gaussian" if size == "c4" else "categorical"
@@ -565,9 +567,10 @@ def test_pg_learner_vs_reference_fixture(dist):
     learner = PG_Learner(cfg, net, cb)
     assert learner.total_iters == int(total)
     # categorical: the head's 2-element bias gradient is +-(one sum over 96 rows cancelling to ~3 % of its terms): per-term
-    # float32 rounding shows at 2e-5 of that tensor's scale (measured: 1.9e-5 here, 2.0e-5 in the NumPy oracle) -- held at 3e-5
-    chk = EngineFixtureCheck(g, net, learner, float(lr), end_factor=float(ef), total_iters=int(total),
-                             tol=3e-5 if dist == "categorical" else 1e-5)
+    # float32 rounding shows at 2e-5 of that tensor's scale (measured: 1.9e-5 here, 2.0e-5 in the NumPy oracle) -- THAT tensor is
+    # held at 3e-5 (a named exception), every other one at 1e-5
+    chk = EngineFixtureCheck(g, net, learner, float(lr), end_factor=float(ef), total_iters=int(total), tol=1e-5,
+                             tol_except={"actor.actor_head.logits.2.bias": 3e-5} if dist == "categorical" else None)
     for u in range(3):
         b = sub(g, f"u{u}/batch")
         info = learner.update(obs=b["obs"], actions=b["actions"], returns=b["returns"], batch_size=len(b["obs"]))

@@ -119,7 +119,7 @@ opt_kwargs_clip = {}
 
 @pytest.mark.parametrize("dist,size", [("categorical", None), ("gaussian", None), ("categorical", "c1"),
                                        ("categorical", "c2"), ("gaussian", "c4"), ("categorical", "acrobot"), ("categorical", "lunar"),
-                                       ("gaussian", "pendulum"), ("gaussian", "walker")])
+                                       ("gaussian", "pendulum"), ("gaussian", "walker"), ("categorical", "mountaincar")])
 def test_ppo_update(oracle, dist, size):
     """size: the minibatch of BASELINE C1 (128) / C2 (8 192) on the CartPole net, C4 (4 096) on 17-256-256 (leaky_relu)."""
     g = load_golden(f"ppo_{dist}" + (f"_{size}" if size else ""))

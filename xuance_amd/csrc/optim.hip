@@ -225,6 +225,15 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
         if (qi < P4) {
             const float4* src = reinterpret_cast<const float4*>(slabs) + qi;
             int s = sg;
+            // (same summation order whatever the batching: 32 loads in flight per thread turn the four dependent round trips of a
+            //  128-slab reduction into one)
+            for (; s + 124 < n_split; s += 128) {
+                float4 w[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) w[j] = src[(int64_t)(s + 4 * j) * st4];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) { gx += w[j].x; gy += w[j].y; gz += w[j].z; gw += w[j].w; }
+            }
             for (; s + 28 < n_split; s += 32) {
                 float4 w[8];
 #pragma unroll
@@ -235,7 +244,15 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
             for (; s < n_split; s += 4) { const float4 w = src[(int64_t)s * st4]; gx += w.x; gy += w.y; gz += w.z; gw += w.w; }
             if (qi * 4 < mir.fold_len) {
                 const float4* src2 = src + mir.fold_off / 4;
-                for (s = sg; s + 28 < n_split; s += 32) {
+                s = sg;
+                for (; s + 124 < n_split; s += 128) {
+                    float4 w[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) w[j] = src2[(int64_t)(s + 4 * j) * st4];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) { gx += w[j].x; gy += w[j].y; gz += w[j].z; gw += w[j].w; }
+                }
+                for (; s + 28 < n_split; s += 32) {
                     float4 w[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) w[j] = src2[(int64_t)(s + 4 * j) * st4];

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) dqn_head_td_kernel(xrl_dqn_head_td_t p) {
         const float* h2 = p.h_eval + (size_t)(p.M + m) * p.ld_h;
         // everything the tail needs that does not depend on the Q values is requested NOW (the taken action, its weight row and the
         // hidden activations for d_h): the launch is a chain of memory round trips otherwise (three of them: 9 us)
-        const int a_taken = (int)p.actions[m];
+        const int a_taken = min(max((int)p.actions[m], 0), p.A - 1);   // (a corrupt stored action must not index outside the row)
         const float rew = p.rewards[m], ter = p.terminals[m];
         const float* wa = p.w_eval + (size_t)a_taken * H;
         float pw[2], ph[2];
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(TAIL_T) dqn_tail_td_kernel(xrl_dqn_tail_td_t p
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int q = 0; q < TAIL_PQ; ++q) pv[r][q] = frame[r][(size_t)min(pg + TAIL_W * q, P - 1) * F + f];
-    const int a_taken = (int)p.actions[m];
+    const int a_taken = min(max((int)p.actions[m], 0), p.A - 1);
     const float rew = p.rewards[m], ter = p.terminals[m];
     float w2[TAIL_QP][TAIL_HMAX / 64];                                             // Q-layer rows of this wave's (row, action) pairs
 #pragma unroll
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(64) qmix_kernel(xrl_qmix_t p) {
     if (lane < N) {
         const size_t row = (size_t)b * N + lane;
         mask = p.agent_mask[row] * fl;                                                // outputs.py:138-143
-        a_taken = (int)p.actions[row];
+        a_taken = min(max((int)p.actions[row], 0), A - 1);
         qe = p.q_eval[row * p.ldq + a_taken] * mask;                                  // qmix_learner.py:48-50,60
         const float* qt = p.q_next + row * p.ldq;
         const float* av = p.avail_next ? p.avail_next + row * A : nullptr;

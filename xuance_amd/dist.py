@@ -66,11 +66,13 @@ def allreduce_moments_(batch_mean, batch_var, batch_count):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return batch_mean, batch_var, batch_count
     n = batch_mean.numel()
-    packed = torch.cat([batch_mean.reshape(-1), batch_var.reshape(-1), batch_count.reshape(-1)[:1].to(batch_mean.dtype)])
+    # one float64 message: float32 means / variances travel exactly, and so does the count (summed counts above 2^24 would lose
+    # their integer part in float32; the reference reduces the count in its own dtype)
+    packed = torch.cat([batch_mean.reshape(-1).double(), batch_var.reshape(-1).double(), batch_count.reshape(-1)[:1].double()])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     w = dist.get_world_size()
-    batch_mean.copy_((packed[:n] / w).view_as(batch_mean))
-    batch_var.copy_((packed[n:2 * n] / w).view_as(batch_var))
+    batch_mean.copy_((packed[:n] / w).view_as(batch_mean).to(batch_mean.dtype))
+    batch_var.copy_((packed[n:2 * n] / w).view_as(batch_var).to(batch_var.dtype))
     batch_count.copy_(packed[2 * n:2 * n + 1].view_as(batch_count).to(batch_count.dtype))
     return batch_mean, batch_var, batch_count
 

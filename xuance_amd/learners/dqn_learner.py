@@ -48,9 +48,10 @@ class DQN_Learner(Learner):
         S = pick_n_split(M)
         fused = bool(getattr(self.config, "use_fused_q_head", True)) and M <= self.partials.shape[0] and \
             getattr(model, "fused_head", lambda: None)() is not None
-        tail = fused and bool(getattr(self.config, "use_fused_q_tail", True)) and getattr(model, "fused_tail", lambda: None)() is not None
-        q_all, q_next = model.forward_pair(self.X, M, self.double_q, skip_last="tail" if tail else fused)   # evalQ (:39) [+ Q_eval(s')], targetQ (:40)
-        if tail:
+        use_tail = fused and bool(getattr(self.config, "use_fused_q_tail", True)) and getattr(model, "fused_tail", lambda: None)() is not None
+        q_all, q_next = model.forward_pair(self.X, M, self.double_q, skip_last="tail" if use_tail else fused)   # evalQ (:39) [+ Q_eval(s')], targetQ (:40)
+        self._tail_done = False                                       # (set below when the optimiser launch carried the phase's ride-along)
+        if use_tail:
             # Basic_CNN + BasicQhead at batch <= 32: everything between the last convolution and the convolution stack's backward
             # pass in one launch (xrl_dqn_tail_td)
             in_slabs = bool(getattr(self.config, "use_tail_slab_gradients", True)) and M <= self.slabs.shape[0] and \
@@ -75,7 +76,7 @@ class DQN_Learner(Learner):
             # slab reduction (+ the average over the ranks, inside the launch) + norm + clip + Adam + LinearLR + periodic
             # hard target update (:50-57) in ONE launch
             # (a one-update phase's draw-counter tick and loss sums ride in the same launch: update_from_buffer)
-            tail = self._tail(S_loss) if getattr(self, "_tail", None) else {}
+            ride_kw = self._tail(S_loss) if getattr(self, "_tail", None) else {}      # ride-along of a one-update phase (update_from_buffer)
             conv = getattr(model, "conv", None)
             mirrors, timg = [], None
             if conv is not None and conv.implicit and getattr(self.config, "use_live_weight_images", True):
@@ -86,10 +87,10 @@ class DQN_Learner(Learner):
                 mirrors, timg = [(inv_f, img_e), (inv_d, img_e)], img_t
             ops.reduce_adam(self.slabs, S_opt, P, model.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip, mirrors,
                             self.opt_sync, target=model.target_flat, target_every=self.sync_frequency,
-                            exchange=self.gradient_exchange(), target_image=timg, **tail)
+                            exchange=self.gradient_exchange(), target_image=timg, **ride_kw)
             if mirrors:
                 conv.mark_live(model.params.flat, model.target_flat)
-            self._tail_done = bool(tail)
+            self._tail_done = bool(ride_kw)
             return S_loss
         if getattr(model, "conv", None) is not None:
             model.conv.invalidate()

@@ -1479,8 +1479,19 @@ class DeepQCNN:
         if not in_slabs:
             self.plan.backward_grouped(self._feat_in, self.filters[-1], M, slabs, n_split, dx0=self._dfeat, skip_last_dg=skip_last_dg,
                                        weights_only=tail)
+        # The dense layers' terms sit in `written` slab rows (one per transition from xrl_dqn_tail_td, n_split from the layered
+        # backward); the reduction sums more rows than that over every column, so the dense columns of the rows beyond must read as
+        # zero.  They do once zeroed -- until the way of writing changes (another batch size, tail <-> layered): then the stale
+        # terms of the old layout are cleared, AFTER this update's writers (zeroing the whole slab block here, as round 3 did,
+        # wiped what xrl_dqn_tail_td / backward_grouped had just written: that update stepped the dense layers with zero gradients).
         split = -M if in_slabs else n_split
-        if getattr(self, "_head_split", split) != split:          # (head rows of slabs beyond the ones written must read as zero)
-            slabs.zero_()
+        if getattr(self, "_head_split", split) != split:
+            written = M if in_slabs else n_split
+            off = self.params.offsets
+            names = [nm for st in self.plan.stages for L in st for nm in (L.w_name, L.b_name)]
+            lo = min(off[nm] for nm in names)
+            hi = max(off[nm] + (L.N * L.K if nm == L.w_name else L.N) for st in self.plan.stages for L in st for nm in (L.w_name, L.b_name))
+            if written < slabs.shape[0]:
+                slabs[written:, lo:hi].zero_()
         self._head_split = split
         return self.conv.backward(self._dfeat, M, self._ws, slabs, n_split, direct=True, pool=not tail)   # number of slabs to sum
