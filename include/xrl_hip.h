@@ -955,7 +955,8 @@ typedef struct {
     int32_t n_layers;           /* nn.Linear layers of the agent network (representation + Q head), <= XRL_QF_MAX_LAYERS */
     int32_t act;                /* XRL_ACT_* after every layer but the last */
     int32_t dims[XRL_QF_MAX_LAYERS + 1];   /* dims[0] = obs_dim ... dims[n_layers] = n_actions */
-    int32_t pad0;
+    int32_t products;           /* the matrix products: 0 = on the matrix cores (16x16x4 fp32 MFMA tiles) when a workgroup carries
+                                 * items_per_wg * N >= 8 rows, else VALU loops; 1 = MFMA, 2 = VALU (parity tests) */
     int64_t w_off[XRL_QF_MAX_LAYERS], b_off[XRL_QF_MAX_LAYERS];
     int64_t mix_off[XRL_QF_N_OFF];          /* FIRST = [hyper_w_1.0; hyper_w_2.0; hyper_b_2.0] stacked ([3 HH][S], biases [3 HH]);
                                              * B1 = hyper_b_1 [H][S]; W1 = hyper_w_1.2 [N H][HH]; W2 = hyper_w_2.2 [H][HH];

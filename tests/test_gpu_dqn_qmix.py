@@ -76,12 +76,15 @@ def test_dqn_learner_vs_reference_fixture(name, fused_head):
                   ("evalQ", "predictQ", "targetQ"), "Qloss")
 
 
-@pytest.mark.parametrize("fused,items", [(True, 1), (True, 3), (True, 4), (False, 0)])
+@pytest.mark.parametrize("fused,items,products", [(True, 1, 2), (True, 3, 0), (True, 4, 2), (False, 0, 0), (True, 5, 0), (True, 4, 1), (True, 1, 1),
+                                                  (True, None, 0)])
 @pytest.mark.parametrize("double_q,size", [(True, None), (False, None), (True, "c5")])
-def test_qmix_learner_vs_reference_fixture(double_q, size, fused, items):
+def test_qmix_learner_vs_reference_fixture(double_q, size, fused, items, products):
     """size "c5": the batch of configs/qmix/sc2/3m.yaml:32 (32 transitions x 3 agents).  fused: the whole update as ONE
-    launch (xrl_qmix_fused_update; `items` transitions per workgroup: 1 = the default, 3 = a ragged last group, 4 = eight
-    groups) vs the layered path (grouped GEMM launches + xrl_qmix_mix_td): both against the reference's numbers at 1e-5."""
+    launch (xrl_qmix_fused_update; `items` transitions per workgroup: 1 = one transition, 3 = a ragged last group, 4 = eight
+    groups, 5 = 15 rows per 16-row matrix-core tile, None = the learner's own choice; products: 0 = MFMA tiles from 8 rows per
+    workgroup on, 1 = MFMA tiles whatever the rows, 2 = the VALU loops) vs the layered path (grouped GEMM launches + xrl_qmix_mix_td):
+    all against the reference's numbers at 1e-5."""
     from xuance_amd.nets import MixingQNet
     from xuance_amd.learners import QMIX_Learner
     g = load_golden(f"qmix_ff_{'double' if double_q else 'single'}" + (f"_{size}" if size else ""))
@@ -95,7 +98,7 @@ def test_qmix_learner_vs_reference_fixture(double_q, size, fused, items):
     learner = QMIX_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
                                     use_grad_clip=True, grad_clip_norm=float(gclip), double_q=bool(dq),
                                     use_actions_mask=True, use_parameter_sharing=True, n_epochs=8,
-                                    use_fused_qmix_update=fused, fused_qmix_items_per_wg=items), keys, net, cb)
+                                    use_fused_qmix_update=fused, fused_qmix_items_per_wg=items, fused_qmix_products=products), keys, net, cb)
     assert learner.total_iters == int(total) and learner.fused_eligible() == fused
 
     def call(b):

@@ -270,7 +270,7 @@ class QfImage(C.Structure):
 
 class QmixFused(C.Structure):
     _fields_ = [("img_eval", c_void_p), ("img_target", c_void_p), ("n_layers", c_int32), ("act", c_int32), ("dims", c_int32 * 5),
-                ("pad0", c_int32), ("w_off", c_int64 * 4), ("b_off", c_int64 * 4), ("mix_off", c_int64 * 10),
+                ("products", c_int32), ("w_off", c_int64 * 4), ("b_off", c_int64 * 4), ("mix_off", c_int64 * 10),
                 ("N", c_int32), ("A", c_int32), ("S", c_int32), ("H", c_int32), ("HH", c_int32),
                 ("B", c_int32), ("items_per_wg", c_int32), ("double_q", c_int32),
                 ("obs", c_void_p), ("obs_next", c_void_p), ("state", c_void_p), ("state_next", c_void_p), ("actions", c_void_p),

@@ -54,6 +54,15 @@ __device__ __noinline__ void qf_copy(QfGlobalIn src, int dst, int n4) {
     }
 }
 
+// act_apply's switch is if-converted by hipcc (tanhf AND expf evaluated for every value, ~775 cycles each: common.h): the activations
+// these networks actually use get a branch of their own (act is uniform), the rest goes through a real call
+__device__ __noinline__ float qf_act_slow(float v, int act) { return act_apply(v, act); }
+__device__ __forceinline__ float qf_act(float v, int act) {
+    if (act == XRL_ACT_NONE) return v;
+    if (act == XRL_ACT_RELU) return v > 0.f ? v : 0.f;
+    return qf_act_slow(v, act);
+}
+
 template <int QF_RB>
 __device__ __forceinline__ void qf_lin_fwd_t(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
                                              int tid0) {
@@ -78,7 +87,7 @@ __device__ __forceinline__ void qf_lin_fwd_t(int W, int ldw, int b, int K, int N
         const float bias = lds[b + n];
 #pragma unroll
         for (int j = 0; j < QF_RB; ++j)
-            if (r0 + j < rows) lds[out + (r0 + j) * ldo + n] = act_apply(acc[j] + bias, act);
+            if (r0 + j < rows) lds[out + (r0 + j) * ldo + n] = qf_act(acc[j] + bias, act);
     }
 }
 
@@ -172,6 +181,164 @@ __device__ __noinline__ void qf_lin_bwd_weight_fn(QfGlobalOut dW, QfGlobalOut db
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same three products on the matrix cores (v_mfma_f32_16x16x4_f32), for workgroups that carry enough transitions to fill a
+// 16-row tile (items_per_wg * N >= 8: `products`).  Everything is computed TRANSPOSED -- D[feature][row] = sum A[feature][.] B[.][row]
+// -- because then both operands and the result are 16-byte LDS accesses in the row-major [row][feature] layout the VALU products
+// use: lane (g = lane / 16, cl = lane % 16) supplies A[m = cl][k = 4 g + s] and B[k = 4 g + s][n = cl] to the MFMA with component s
+// of a float4, and holds D[m = 4 g + i][n = cl] in element i of the result.  A work item is one (16-row, 16-feature) tile; item j of
+// a product goes to wave (tid0 / 64 + j) mod 16 -- the call sites hand consecutive products consecutive tile ranges, so a phase's
+// tiles are dealt round-robin to the 16 waves.  Out-of-range rows / features: the WEIGHT-side operand is zeroed (its image holds
+// other matrices there), the activation-side operand is read at a clamped address (finite values times zero).
+// A VALU product phase at 3 rows per workgroup and an MFMA phase at 15 rows cost about the same (~1 k cycles: one LDS latency +
+// K / 4 dependent MFMAs); what the larger groups buy is 5x fewer workgroups, slabs and weight bursts per update.
+typedef float qf_acc4 __attribute__((ext_vector_type(4)));
+#define QF_MFMA(a, b, acc) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), acc, 0, 0, 0)
+
+__device__ __forceinline__ bool qf_mm_wave_in(int n_tiles, int tid0) {
+    return (int)((((threadIdx.x & ~63u) - (unsigned)tid0) & (QF_THREADS - 1)) >> 6) < n_tiles;
+}
+__host__ __device__ inline int qf_tiles(int a, int b) { return ((a + 15) >> 4) * ((b + 15) >> 4); }
+
+// (Arguments of a real function arrive in vector registers and the compiler must assume they differ per lane: every loop and
+//  branch on them becomes exec-mask juggling, every division a 40-instruction expansion -- measured 3 k cycles for a tile of 8
+//  MFMAs.  They ARE uniform: readfirstlane hands them to the scalar unit.)
+#define QF_UNI(x) x = __builtin_amdgcn_readfirstlane(x)
+
+// element-wise activation of a tile's four values; act is uniform, so this is one scalar branch
+__device__ __forceinline__ void qf_act4(float (&v)[4], int act) {
+    if (act == XRL_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    } else if (act != XRL_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = qf_act_slow(v[i], act);
+    }
+}
+
+// out[r][n] = act(sum_k in[r][k] W[n][k] + b[n])
+__device__ __noinline__ void qf_mm_fwd_fn(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
+                                          int tid0) {
+    QF_UNI(W); QF_UNI(ldw); QF_UNI(b); QF_UNI(K); QF_UNI(Nout); QF_UNI(in); QF_UNI(ldi); QF_UNI(rows); QF_UNI(out); QF_UNI(ldo);
+    QF_UNI(act); QF_UNI(tid0);
+    float* lds = qf_lds;
+    const int lane = threadIdx.x & 63, cl = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(((threadIdx.x - (unsigned)tid0) & (QF_THREADS - 1)) >> 6));
+    const int n_nt = (Nout + 15) >> 4, n_items = ((rows + 15) >> 4) * n_nt, K4 = (K + 3) & ~3, kc = (K + 15) >> 4;
+    for (int item = wv; item < n_items; item += QF_THREADS / 64) {
+        const int nt = item % n_nt, rt = item / n_nt;
+        const int n = nt * 16 + cl, r = min(rt * 16 + cl, rows - 1);
+        const bool n_ok = n < Nout;
+        const float* wrow = lds + W + min(n, Nout - 1) * ldw;
+        const float* xrow = lds + in + r * ldi;
+        qf_acc4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < kc; c0 += 4) {               // up to four k-chunks: all their LDS reads in flight, then 16 MFMAs on four chains
+            float4 a[4], x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = 16 * (c0 + j) + 4 * g, kr = min(kk, K4 - 4);
+                a[j] = *reinterpret_cast<const float4*>(wrow + kr);
+                x[j] = *reinterpret_cast<const float4*>(xrow + kr);
+                if (!n_ok || kk >= K4) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (c0 + j < kc) { QF_MFMA(a[j].x, x[j].x, acc0); QF_MFMA(a[j].y, x[j].y, acc1); QF_MFMA(a[j].z, x[j].z, acc2); QF_MFMA(a[j].w, x[j].w, acc3); }
+            }
+        }
+        const int n0 = nt * 16 + 4 * g, row = rt * 16 + cl;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ((acc0[i] + acc1[i]) + (acc2[i] + acc3[i])) + lds[b + min(n0 + i, Nout - 1)];
+        qf_act4(v, act);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (n0 + i >= Nout) v[i] = 0.f;
+        if (row < rows && n0 < ((Nout + 3) & ~3)) *reinterpret_cast<float4*>(lds + out + row * ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// dx[r][k] = (sum_n dz[r][n] W[n][k]) * act'(y[r][k])
+__device__ __noinline__ void qf_mm_bwd_data_fn(int W, int ldw, int K, int Nout, int dz, int ldz, int rows, int dx, int ldx, int y, int ldy,
+                                               int act, int tid0) {
+    QF_UNI(W); QF_UNI(ldw); QF_UNI(K); QF_UNI(Nout); QF_UNI(dz); QF_UNI(ldz); QF_UNI(rows); QF_UNI(dx); QF_UNI(ldx); QF_UNI(y); QF_UNI(ldy);
+    QF_UNI(act); QF_UNI(tid0);
+    float* lds = qf_lds;
+    const int lane = threadIdx.x & 63, cl = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(((threadIdx.x - (unsigned)tid0) & (QF_THREADS - 1)) >> 6));
+    const int n_kt = (K + 15) >> 4, n_items = ((rows + 15) >> 4) * n_kt, N4 = (Nout + 3) & ~3, nc = (Nout + 15) >> 4;
+    for (int item = wv; item < n_items; item += QF_THREADS / 64) {
+        const int kt = item % n_kt, rt = item / n_kt;
+        const int k = kt * 16 + cl, r = min(rt * 16 + cl, rows - 1);
+        const bool k_ok = k < K;
+        const float* wcol = lds + W + min(k, K - 1);                      // A[m = k][contraction n] = W[n][k]
+        const float* zrow = lds + dz + r * ldz;
+        qf_acc4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < nc; c0 += 2) {
+            float4 z[2];
+            float a[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nn = 16 * (c0 + j) + 4 * g;
+                z[j] = *reinterpret_cast<const float4*>(zrow + min(nn, N4 - 4));
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const float w = wcol[min(nn + s_, Nout - 1) * ldw];
+                    a[j][s_] = (k_ok && nn + s_ < Nout) ? w : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (c0 + j < nc) { QF_MFMA(a[j][0], z[j].x, acc0); QF_MFMA(a[j][1], z[j].y, acc1); QF_MFMA(a[j][2], z[j].z, acc2); QF_MFMA(a[j][3], z[j].w, acc3); }
+            }
+        }
+        const int k0 = kt * 16 + 4 * g, row = rt * 16 + cl;
+        if (row < rows && k0 < ((K + 3) & ~3)) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = y >= 0 ? act_grad_from_out(lds[y + row * ldy + min(k0 + i, K - 1)], act) : 1.f;
+                v[i] = k0 + i < K ? ((acc0[i] + acc1[i]) + (acc2[i] + acc3[i])) * d : 0.f;
+            }
+            *reinterpret_cast<float4*>(lds + dx + row * ldx + k0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// dW[n][k] = sum_r dz[r][n] in[r][k],  db[n] = sum_r dz[r][n]   -> this workgroup's slab
+__device__ __noinline__ void qf_mm_bwd_weight_fn(QfGlobalOut dW, QfGlobalOut db, int K, int Nout, int dz, int ldz, int in, int ldi, int rows,
+                                                 int tid0) {
+    QF_UNI(K); QF_UNI(Nout); QF_UNI(dz); QF_UNI(ldz); QF_UNI(in); QF_UNI(ldi); QF_UNI(rows); QF_UNI(tid0);
+    float* lds = qf_lds;
+    const int lane = threadIdx.x & 63, cl = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(((threadIdx.x - (unsigned)tid0) & (QF_THREADS - 1)) >> 6));
+    const int n_kt = (K + 15) >> 4, n_items = ((Nout + 15) >> 4) * n_kt, rc = (rows + 15) >> 4;
+    for (int item = wv; item < n_items; item += QF_THREADS / 64) {
+        const int kt = item % n_kt, nt = item / n_kt;
+        const int n = nt * 16 + cl, k = kt * 16 + cl;
+        const float* zcol = lds + dz + min(n, Nout - 1);                  // A[m = n][contraction r] = dz[r][n]
+        const float* xcol = lds + in + min(k, K - 1);                     // B[contraction r][n' = k] = in[r][k]
+        qf_acc4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < rc; ++c) {
+            float a[4], x[4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int r = 16 * c + 4 * g + s_, rr = min(r, rows - 1);
+                const float zv = zcol[rr * ldz];
+                a[s_] = (n < Nout && r < rows) ? zv : 0.f;
+                x[s_] = xcol[rr * ldi];
+            }
+            QF_MFMA(a[0], x[0], acc0); QF_MFMA(a[1], x[1], acc1); QF_MFMA(a[2], x[2], acc0); QF_MFMA(a[3], x[3], acc1);
+            if (kt == 0) { QF_MFMA(a[0], 1.f, accb); QF_MFMA(a[1], 1.f, accb); QF_MFMA(a[2], 1.f, accb); QF_MFMA(a[3], 1.f, accb); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nn = nt * 16 + 4 * g + i;
+            if (nn < Nout && k < K) dW[(size_t)nn * K + k] = acc0[i] + acc1[i];
+            if (kt == 0 && cl == 0 && nn < Nout) db[nn] = accb[i];
+        }
+    }
+}
+
 struct QfLds {                      // offsets (floats) into the dynamic LDS block; host and device compute them alike
     int x0, x1, h[XRL_QF_MAX_LAYERS], q, qne, qnt, t0, t1, u0, u1, s0, s1, hid_e, raw_e, hid_t, raw_t, d_raw, d_hid, total;
     int ld[XRL_QF_MAX_LAYERS + 1], ldmax, lds, ldh, ldr, rows_pad;
@@ -182,6 +349,9 @@ struct QfLds {                      // offsets (floats) into the dynamic LDS blo
 };
 
 __host__ __device__ inline int qf_pad4(int w) { return (w + 3) / 4 * 4; }
+__host__ __device__ inline bool qf_mfma_products(const xrl_qmix_fused_t& p) {
+    return p.products == 1 || (p.products == 0 && p.items_per_wg * p.N >= 8);
+}
 
 // the weight images: agent block [W_0 .. W_{L-1} | b_0 .. b_{L-1}], mixer block [FIRST B1 W1 W2 B2 | their biases]; matrix
 // rows padded to pad4(K) + 4 floats (conflict-free 16-byte LDS reads with one row per lane), bias vectors to quads
@@ -201,10 +371,17 @@ __host__ __device__ inline void qf_image_layout(const xrl_qmix_fused_t& p, xrl_q
 __host__ __device__ inline QfLds qf_layout(const xrl_qmix_fused_t& p) {
     QfLds L;
     const int rows = p.items_per_wg * p.N;
-    L.rows_pad = (rows + QF_PAD - 1) / QF_PAD * QF_PAD;         // the 4-row products read whole row groups
-    const int bw_pad = (p.items_per_wg + QF_PAD - 1) / QF_PAD * QF_PAD;
+    // the 4-row VALU products read whole row groups; the matrix-core tiles clamp their row addresses instead (no padding rows:
+    // 5 transitions x 3 agents = 15 rows per workgroup fit beside the weights, 16 padded ones would not)
+    const int pad = qf_mfma_products(p) ? 1 : QF_PAD;
+    L.rows_pad = (rows + pad - 1) / pad * pad;
+    const int bw_pad = (p.items_per_wg + pad - 1) / pad * pad;
     int off = 0, ldmax = 0;
-    for (int l = 0; l <= p.n_layers; ++l) { L.ld[l] = qf_pad4(p.dims[l]); if (l > 0 && L.ld[l] > ldmax) ldmax = L.ld[l]; }
+    // matrix-core tiles read one activation ROW per lane (16 rows at once): a row stride that is a multiple of 32 floats puts all
+    // 16 on the same four LDS banks (measured: product phases of 6.4 k cycles instead of ~2 k) -> four floats of padding per row,
+    // as the weight images have
+    const int rpad = qf_mfma_products(p) ? 4 : 0;
+    for (int l = 0; l <= p.n_layers; ++l) { L.ld[l] = qf_pad4(p.dims[l]) + rpad; if (l > 0 && L.ld[l] > ldmax) ldmax = L.ld[l]; }
     L.ldmax = ldmax;
     L.x0 = off; off += L.rows_pad * L.ld[0];
     L.x1 = off; off += L.rows_pad * L.ld[0];
@@ -217,7 +394,7 @@ __host__ __device__ inline QfLds qf_layout(const xrl_qmix_fused_t& p) {
     L.t1 = off; off += L.rows_pad * ldmax;
     L.u0 = off; off += L.rows_pad * ldmax;
     L.u1 = off; off += L.rows_pad * ldmax;
-    L.lds = qf_pad4(p.S); L.ldh = qf_pad4(3 * p.HH + p.H); L.ldr = qf_pad4(p.N * p.H + p.H + 1);
+    L.lds = qf_pad4(p.S) + rpad; L.ldh = qf_pad4(3 * p.HH + p.H) + rpad; L.ldr = qf_pad4(p.N * p.H + p.H + 1) + rpad;
     L.s0 = off; off += bw_pad * L.lds;
     L.s1 = off; off += bw_pad * L.lds;
     L.hid_e = off; off += bw_pad * L.ldh;
@@ -251,20 +428,6 @@ struct QfArgs { xrl_qmix_fused_t p; QfLds L; int agent4, mixer4, pad[2]; };   //
 typedef const __attribute__((address_space(4))) QfArgs QfArgsK;
 typedef const __attribute__((address_space(4))) xrl_qmix_fused_t* QfP;
 typedef const __attribute__((address_space(4))) QfLds* QfL;
-
-// hyper-networks of the mixer staged in LDS (q_mix_head.py:50-64), one layer per call (no barrier inside):
-// A: hid = [relu(W_f s + b_f) (3 HH) | W_b1 s + b_b1 (H)];  B: raw = [w1 | w2 | b2] from hid
-__device__ __forceinline__ void qf_hyper_layer(QfP p, QfL L, int layer, int s, int hid, int raw, int bw, int tid0) {
-    const int HH = p->HH, H = p->H, N = p->N;
-    if (layer == 0) {
-        qf_lin_fwd(L->mw[0], L->mldw[0], L->mb[0], p->S, 3 * HH, s, L->lds, bw, hid, L->ldh, XRL_ACT_RELU, tid0);
-        qf_lin_fwd(L->mw[1], L->mldw[1], L->mb[1], p->S, H, s, L->lds, bw, hid + 3 * HH, L->ldh, XRL_ACT_NONE, tid0 + 128);
-    } else {
-        qf_lin_fwd(L->mw[2], L->mldw[2], L->mb[2], HH, N * H, hid, L->ldh, bw, raw, L->ldr, XRL_ACT_NONE, tid0);
-        qf_lin_fwd(L->mw[3], L->mldw[3], L->mb[3], HH, H, hid + HH, L->ldh, bw, raw + N * H, L->ldr, XRL_ACT_NONE, tid0 + 128);
-        qf_lin_fwd(L->mw[4], L->mldw[4], L->mb[4], HH, 1, hid + 2 * HH, L->ldh, bw, raw + N * H + H, L->ldr, XRL_ACT_NONE, tid0 + 192);
-    }
-}
 
 __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_unused) {
     // the arguments are read where they lie, in the kernel argument segment (scalar loads, any index): touching the by-value
@@ -370,28 +533,68 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
     //            passes (target(next), eval(next) for the double-Q argmax, eval(obs) kept for the backward pass) and one
     //            step of the mixer sequence: target hyper layer A, target hyper layer B, eval mixer weights over the target
     //            mixer's LDS space, eval hyper layer A, eval hyper layer B
+    // products: VALU loops, or -- enough rows to fill a tile -- matrix-core tiles dealt round-robin over the waves (tb: tiles handed out
+    // in the current phase)
+    const bool mm = p->products == 1 || (p->products == 0 && p->items_per_wg * N >= 8);      // (= qf_mfma_products)
+    int tb = 0;
+    auto FWD = [&](int W_, int ldw_, int b_, int K_, int Nn_, int in_, int ldi_, int rows_, int out_, int ldo_, int act_, int tid0_) {
+        if (mm) {
+            const int t = qf_tiles(rows_, Nn_), t0 = 64 * (tb & 15);
+            tb += t;
+            if (qf_mm_wave_in(t, t0)) qf_mm_fwd_fn(W_, ldw_, b_, K_, Nn_, in_, ldi_, rows_, out_, ldo_, act_, t0);
+        } else qf_lin_fwd(W_, ldw_, b_, K_, Nn_, in_, ldi_, rows_, out_, ldo_, act_, tid0_);
+    };
+    auto BWDD = [&](int W_, int ldw_, int K_, int Nn_, int dz_, int ldz_, int rows_, int dx_, int ldx_, int y_, int ldy_, int act_, int tid0_) {
+        if (mm) {
+            const int t = qf_tiles(rows_, K_), t0 = 64 * (tb & 15);
+            tb += t;
+            if (qf_mm_wave_in(t, t0)) qf_mm_bwd_data_fn(W_, ldw_, K_, Nn_, dz_, ldz_, rows_, dx_, ldx_, y_, ldy_, act_, t0);
+        } else qf_lin_bwd_data(W_, ldw_, K_, Nn_, dz_, ldz_, rows_, dx_, ldx_, y_, ldy_, act_, tid0_);
+    };
+    auto BWDW = [&](QfGlobalOut dW_, QfGlobalOut db_, int K_, int Nn_, int dz_, int ldz_, int in_, int ldi_, int rows_, int tid0_) {
+        if (mm) {
+            const int t = qf_tiles(Nn_, K_), t0 = 64 * (tb & 15);
+            tb += t;
+            if (qf_mm_wave_in(t, t0)) qf_mm_bwd_weight_fn(dW_, db_, K_, Nn_, dz_, ldz_, in_, ldi_, rows_, t0);
+        } else qf_lin_bwd_weight(dW_, db_, K_, Nn_, dz_, ldz_, in_, ldi_, rows_, tid0_);
+    };
+    // hyper-networks of the mixer staged in LDS (q_mix_head.py:50-64), one layer per call (no barrier inside):
+    // A: hid = [relu(W_f s + b_f) (3 HH) | W_b1 s + b_b1 (H)];  B: raw = [w1 | w2 | b2] from hid
+    auto HYPER = [&](int layer, int s_, int hid_, int raw_, int tid0_) {
+        if (layer == 0) {
+            FWD(L->mw[0], L->mldw[0], L->mb[0], p->S, 3 * HH, s_, L->lds, bw, hid_, L->ldh, XRL_ACT_RELU, tid0_);
+            FWD(L->mw[1], L->mldw[1], L->mb[1], p->S, H, s_, L->lds, bw, hid_ + 3 * HH, L->ldh, XRL_ACT_NONE, tid0_ + 128);
+        } else {
+            FWD(L->mw[2], L->mldw[2], L->mb[2], HH, N * H, hid_, L->ldh, bw, raw_, L->ldr, XRL_ACT_NONE, tid0_);
+            FWD(L->mw[3], L->mldw[3], L->mb[3], HH, H, hid_ + HH, L->ldh, bw, raw_ + N * H, L->ldr, XRL_ACT_NONE, tid0_ + 128);
+            FWD(L->mw[4], L->mldw[4], L->mb[4], HH, 1, hid_ + 2 * HH, L->ldh, bw, raw_ + N * H + H, L->ldr, XRL_ACT_NONE, tid0_ + 192);
+        }
+    };
     int mix_step = 0;
     for (int l = 0; l < nl || mix_step < 5; ++l) {
+        tb = 0;
         if (l < nl) {
             const bool last = l == nl - 1;
             const int act = last ? XRL_ACT_NONE : p->act, K = p->dims[l], Nn = p->dims[l + 1], ldi = L->ld[l], ldo = L->ld[l + 1];
             const int in_t = l == 0 ? L->x1 : ((l & 1) ? L->t0 : L->t1), out_t = last ? L->qnt : (((l + 1) & 1) ? L->t0 : L->t1);
             const int in_n = l == 0 ? L->x1 : ((l & 1) ? L->u0 : L->u1), out_n = last ? L->qne : (((l + 1) & 1) ? L->u0 : L->u1);
             const int in_e = l == 0 ? L->x0 : L->h[l], out_e = last ? L->q : L->h[l + 1];
-            qf_lin_fwd(L->wt[l], L->ldw[l], L->bt[l], K, Nn, in_t, ldi, rows, out_t, ldo, act, 0);
-            if (p->double_q) qf_lin_fwd(L->we[l], L->ldw[l], L->be[l], K, Nn, in_n, ldi, rows, out_n, ldo, act, 256);
-            qf_lin_fwd(L->we[l], L->ldw[l], L->be[l], K, Nn, in_e, ldi, rows, out_e, ldo, act, 512);
+            FWD(L->wt[l], L->ldw[l], L->bt[l], K, Nn, in_t, ldi, rows, out_t, ldo, act, 0);
+            if (p->double_q) FWD(L->we[l], L->ldw[l], L->be[l], K, Nn, in_n, ldi, rows, out_n, ldo, act, 256);
+            FWD(L->we[l], L->ldw[l], L->be[l], K, Nn, in_e, ldi, rows, out_e, ldo, act, 512);
         }
         switch (mix_step) {
-            case 0: qf_hyper_layer(p, L, 0, L->s1, L->hid_t, L->raw_t, bw, 768); break;
-            case 1: qf_hyper_layer(p, L, 1, L->s1, L->hid_t, L->raw_t, bw, 768); break;
+            case 0: HYPER(0, L->s1, L->hid_t, L->raw_t, 768); break;
+            case 1: HYPER(1, L->s1, L->hid_t, L->raw_t, 768); break;
             case 2: qf_copy((QfGlobalIn)(p->img_eval + 4 * args->agent4), L->mix, args->mixer4); break;
-            case 3: qf_hyper_layer(p, L, 0, L->s0, L->hid_e, L->raw_e, bw, 768); break;
-            case 4: qf_hyper_layer(p, L, 1, L->s0, L->hid_e, L->raw_e, bw, 768); break;
+            case 3: HYPER(0, L->s0, L->hid_e, L->raw_e, 768); break;
+            case 4: HYPER(1, L->s0, L->hid_e, L->raw_e, 768); break;
             default: break;
         }
         ++mix_step;
+        if (p->dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && l < 6) p->dbg[32 + 16 * l + (threadIdx.x >> 6)] = (long long)__builtin_readcyclecounter();   // (diagnostics: [128])
         __syncthreads();
+        if (l < 6) QF_STAMP(16 + l);
     }
     QF_STAMP(4);
 
@@ -491,25 +694,26 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
         const int d_hid = L->d_hid, hid = L->hid_e, d_raw = L->d_raw;
         int dz = L->t0, ldz = ldq, hyper_step = 0;                        // dz: d (pre-activation of layer l's output)
         for (int l = nl - 1; l >= 0 || hyper_step < 2; --l) {
+            tb = 0;
             if (hyper_step == 0) {
-                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_W1_W], gslab + p->mix_off[XRL_QF_W1_B], HH, N * H, d_raw, L->ldr, hid, L->ldh, bw, 0);
-                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_W2_W], gslab + p->mix_off[XRL_QF_W2_B], HH, H, d_raw + N * H, L->ldr, hid + HH, L->ldh, bw, 768);
-                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_B2_W], gslab + p->mix_off[XRL_QF_B2_B], HH, 1, d_raw + N * H + H, L->ldr, hid + 2 * HH, L->ldh, bw, 960);
-                qf_lin_bwd_data(L->mw[2], L->mldw[2], HH, N * H, d_raw, L->ldr, bw, d_hid, L->ldh, hid, L->ldh, XRL_ACT_RELU, 256);
-                qf_lin_bwd_data(L->mw[3], L->mldw[3], HH, H, d_raw + N * H, L->ldr, bw, d_hid + HH, L->ldh, hid + HH, L->ldh, XRL_ACT_RELU, 384);
-                qf_lin_bwd_data(L->mw[4], L->mldw[4], HH, 1, d_raw + N * H + H, L->ldr, bw, d_hid + 2 * HH, L->ldh, hid + 2 * HH, L->ldh, XRL_ACT_RELU, 448);
+                BWDW(gslab + p->mix_off[XRL_QF_W1_W], gslab + p->mix_off[XRL_QF_W1_B], HH, N * H, d_raw, L->ldr, hid, L->ldh, bw, 0);
+                BWDW(gslab + p->mix_off[XRL_QF_W2_W], gslab + p->mix_off[XRL_QF_W2_B], HH, H, d_raw + N * H, L->ldr, hid + HH, L->ldh, bw, 768);
+                BWDW(gslab + p->mix_off[XRL_QF_B2_W], gslab + p->mix_off[XRL_QF_B2_B], HH, 1, d_raw + N * H + H, L->ldr, hid + 2 * HH, L->ldh, bw, 960);
+                BWDD(L->mw[2], L->mldw[2], HH, N * H, d_raw, L->ldr, bw, d_hid, L->ldh, hid, L->ldh, XRL_ACT_RELU, 256);
+                BWDD(L->mw[3], L->mldw[3], HH, H, d_raw + N * H, L->ldr, bw, d_hid + HH, L->ldh, hid + HH, L->ldh, XRL_ACT_RELU, 384);
+                BWDD(L->mw[4], L->mldw[4], HH, 1, d_raw + N * H + H, L->ldr, bw, d_hid + 2 * HH, L->ldh, hid + 2 * HH, L->ldh, XRL_ACT_RELU, 448);
             } else if (hyper_step == 1) {
-                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_FIRST_W], gslab + p->mix_off[XRL_QF_FIRST_B], p->S, 3 * HH, d_hid, L->ldh, L->s0, L->lds, bw, 0);
-                qf_lin_bwd_weight(gslab + p->mix_off[XRL_QF_B1_W], gslab + p->mix_off[XRL_QF_B1_B], p->S, H, d_hid + 3 * HH, L->ldh, L->s0, L->lds, bw, 384);
+                BWDW(gslab + p->mix_off[XRL_QF_FIRST_W], gslab + p->mix_off[XRL_QF_FIRST_B], p->S, 3 * HH, d_hid, L->ldh, L->s0, L->lds, bw, 0);
+                BWDW(gslab + p->mix_off[XRL_QF_B1_W], gslab + p->mix_off[XRL_QF_B1_B], p->S, H, d_hid + 3 * HH, L->ldh, L->s0, L->lds, bw, 384);
             }
             ++hyper_step;
             if (l >= 0) {
                 const int in = l == 0 ? L->x0 : L->h[l], ldi = L->ld[l];
-                qf_lin_bwd_weight(gslab + p->w_off[l], gslab + p->b_off[l], p->dims[l], p->dims[l + 1], dz, ldz, in, ldi, rows, 512);
+                BWDW(gslab + p->w_off[l], gslab + p->b_off[l], p->dims[l], p->dims[l + 1], dz, ldz, in, ldi, rows, 512);
                 if (l > 0) {
                     const int dx = (dz == L->t0) ? L->t1 : L->t0;
                     // t0 / t1 rows are ldmax wide; the first dz (the Q head's) uses ldq, every later one ld[l]
-                    qf_lin_bwd_data(L->we[l], L->ldw[l], p->dims[l], p->dims[l + 1], dz, ldz, rows, dx, L->ld[l], in, ldi, p->act, 640);
+                    BWDD(L->we[l], L->ldw[l], p->dims[l], p->dims[l + 1], dz, ldz, rows, dx, L->ld[l], in, ldi, p->act, 640);
                     dz = dx; ldz = L->ld[l];
                 }
             }

@@ -127,9 +127,16 @@ class QMIX_Learner(Learner):
                 1 <= len(m.agent_plan.stages) <= 4 and all(len(s) == 1 for s in m.agent_plan.stages) and \
                 len({s[0].act for s in m.agent_plan.stages[:-1]}) <= 1 and m.H <= 64 and m.n_agents <= 64
             if ok:
-                fs = ops.QmixFusedState(m, self.double_q, self.gamma, int(getattr(self.config, "fused_qmix_items_per_wg", 1)))
-                if 0 < fs.lds_bytes() <= 160 * 1024:
-                    self._fused = fs
+                # transitions per workgroup: config.fused_qmix_items_per_wg, default ONE (32 workgroups, VALU products).  Larger groups
+                # run their products as matrix-core tiles (5 x 3 agents = 15 rows of a 16-row tile: 7 workgroups / slabs per update) --
+                # measured round 4 (profiles/r04_b_qmix_ff_mfma.txt): parity identical, the launch 25 -> 34 us: the update's 9 MFLOP on
+                # 7 CUs are bound by the per-CU fp32 MFMA rate (~2.5 k cycles per product phase) where 32 CUs share them at 3 rows each.
+                want = getattr(self.config, "fused_qmix_items_per_wg", None)
+                for items in ([int(want)] if want else [1]):
+                    fs = ops.QmixFusedState(m, self.double_q, self.gamma, items, int(getattr(self.config, "fused_qmix_products", 0)))
+                    if 0 < fs.lds_bytes() <= 160 * 1024:
+                        self._fused = fs
+                        break
         return self._fused is not None
 
     def _step(self, B, ring=None):

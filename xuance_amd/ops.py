@@ -685,7 +685,9 @@ class QmixFusedState:
     target: the parameters in the padded LDS layout of csrc/qmix_fused.hip) + the parameter -> image index map that
     xrl_reduce_adam's mirror mechanism keeps them current with (batch pointers are filled in per call)."""
 
-    def __init__(self, model, double_q, gamma, items_per_wg):
+    def __init__(self, model, double_q, gamma, items_per_wg, products=0):
+        """items_per_wg: transitions per workgroup; products: 0 = matrix-core tiles when a workgroup's items_per_wg * n_agents
+        rows fill half a 16-row tile, VALU loops otherwise; 1 / 2 force either (parity tests)."""
         from ._lib import QmixFused, QfImage
         P = model.params
         layers = [st[0] for st in model.agent_plan.stages]
@@ -710,7 +712,7 @@ class QmixFusedState:
         assert P.offsets[f"{m}.hyper_w_2.0.bias"] == P.offsets[f"{m}.hyper_w_1.0.bias"] + HH
         assert P.offsets[f"{m}.hyper_b_2.0.bias"] == P.offsets[f"{m}.hyper_w_1.0.bias"] + 2 * HH
         q.N, q.A, q.S, q.H, q.HH = N, model.n_actions, S, H, HH
-        q.items_per_wg, q.double_q, q.gamma = int(items_per_wg), int(bool(double_q)), float(gamma)
+        q.items_per_wg, q.double_q, q.gamma, q.products = int(items_per_wg), int(bool(double_q)), float(gamma), int(products)
         im = QfImage()
         call("xrl_qmix_fused_layout", C.byref(q), C.byref(im))
         # parameter index -> image index
