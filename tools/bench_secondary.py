@@ -28,6 +28,22 @@ def _pmc_bytes(which, kernel):
     return None, None
 
 
+def _pmc_step_bytes(pattern, per_kernel):
+    """HBM bytes of ALL kernels of a profiled loop per launch of `per_kernel` (one per update / vector step), from the latest committed
+    PMC summary matching `pattern`; (None, None) if missing.  Copied from that builder-run pass, not measured in this run."""
+    import glob, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", pattern)))
+    try:
+        ks = json.load(open(paths[-1]))["kernels"]
+        n = [v["launches"] for k, v in ks.items() if k.startswith(per_kernel)][0]
+        tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values())
+        return int(tot / n), ("profiles/" + os.path.basename(paths[-1]) + " (committed rocprofv3 --pmc passes of tools/profile_dqn_c3.py: every kernel "
+                              "of the loop -- acting, store, update -- per launch of " + per_kernel + "; not measured in this run)")
+    except Exception:
+        return None, None
+
+
 def _events_us(fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -270,13 +286,14 @@ def dqn_c3(steps=200, ref=None):
     graph_us = _events_us(lr._buf_graph.launch, 20)
     flops = 4 * 21.2e6 * 32
     tf = flops / graph_us / 1e6
+    traffic, traffic_src = _pmc_step_bytes("r*_dqn_c3_pmc.json", "xrl::dqn_tail_td_kernel")
     out = {"workload": "DQN, Atari shapes (84x84x4 uint8 frames, CNN 32/64/64 + 512, 4 actions), %d envs, uint8 replay ring, batch 32, "
                        "one update per vector step (BASELINE configs[2])" % n,
            "value": round(n * steps / dt, 1), "unit": "env-steps/s", "vector_step_us": round(dt / steps * 1e6, 1),
            "update_us": round(graph_us, 1),
            "roofline": {"bound": "mfma", "kernel": "update graph (xrl::conv_mfma_kernel / conv_dw_mfma_kernel implicit GEMMs + Q-head launches, eval + target networks, backward, xrl::reduce_adam_kernel)",
                         "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "traffic": None, "avg_launch_us": round(graph_us, 1), "algorithmic_flops_per_launch": flops,
+                        "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(graph_us, 1), "algorithmic_flops_per_launch": flops,
                         "note": "one 'launch' = one whole update (a graph); 10 launches at batch 32 (replay gather, 3 convolutions, xrl_dqn_tail_td, 2 input-gradient + 2 weight-gradient convolutions, xrl_reduce_adam): launch- and latency-bound, DESIGN.md section 3 'Round 3: implicit-GEMM convolutions'"}}
     if ref:
         out["cpu_baseline"] = ref
