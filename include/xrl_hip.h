@@ -643,6 +643,44 @@ typedef struct {
 } xrl_rollout_run_t;
 int xrl_rollout_cartpole_run(const xrl_rollout_run_t* p, xrl_stream_t stream);
 int xrl_rollout_cartpole_values(const xrl_rollout_run_t* p, xrl_stream_t stream);
+/* ------------------------------------------------------------------ rollout of the two-branch Gaussian class (csrc/rollout_wide.hip)
+ * Vector steps [t0, t0 + n_steps) of a rollout of horizon T of PPO's step loop (ppo_agent.py:111-177) for the network class
+ * D-256-256-{A | 1} (configs/ppo/mujoco.yaml) on the device-resident continuous-control provider (the dynamics of
+ * xrl_synth_control_step), ONE launch, only the actor on the step chain: obs_rms.update + normalisation, actor forward (fp32 MFMA,
+ * 16-row tiles, the 256 x 256 layer in registers), Normal(mu, std).sample() + log-prob (Philox streams of xrl_policy_sample),
+ * dynamics with auto-reset, path-end flags, return tracker, normalised rewards + ret_rms.update in env order (a trailing
+ * workgroup).  Values / bootstrap values are the caller's batched pass over f_obs / xnext afterwards.  State in place; n <= 256. */
+typedef struct {
+    const float* params;
+    int32_t w0, b0, w1, b1, w2, b2, log_std_off;       /* actor branch: [256][D], [256], [256][256], [256], [A][256], [A]; log_std [A] */
+    int32_t act, out_act;                              /* hidden activation; activation_action on the mean (none | tanh) */
+    int32_t D, A, H;                                   /* D <= 20, A <= 8, H == 256 */
+    int32_t n, T, t0, n_steps;
+    int32_t max_steps, use_obsnorm, use_rewnorm, flags;
+    float obs_range, rew_range, gamma, pad0;
+    uint64_t seed, env_seed;
+    uint32_t step, env_step;                           /* Philox step of vector step t: step + *step_dev + t (policy), env_step + *env_step_dev + t */
+    const uint32_t* step_dev; const uint32_t* env_step_dev;
+    /* state, updated in place */
+    float* obs_raw;                                    /* [n][D] raw observations the agent acts on next */
+    float* obs_mean; float* obs_var; double* obs_count;   /* [D], [D], [1] */
+    float* ret_mean; float* ret_var; double* ret_count;   /* [1] each */
+    float* ret_track;                                  /* [n] */
+    float* env_state; int32_t* env_steps; float* env_score; double* env_stats;   /* [n][D], [n], [n], [4] */
+    const float* Amat; const float* Bmat;              /* [D][D], [A][D] */
+    /* rollout-buffer fields [T][n] (observations [T][n][D], actions [T][n][A]) */
+    float* f_obs; float* f_act; float* f_logp; float* f_rew; float* f_term; uint8_t* f_seg;
+    /* scratch */
+    float* xnext;                                      /* [T][n][D] normalised next observations (before an auto-reset) */
+    uint8_t* ended; float* ret_final; float* raw_rew;  /* [T][n4] each (n4 = n rounded up to 4; `ended` zero-initialised) */
+    uint32_t* xchg;                                    /* [xrl_rollout_wide_words()] exchange words (zeroed by the call) */
+    int32_t* status;                                   /* [4] as xrl_rollout_run_t.status */
+    long long* dbg;                                    /* NULL, or [16] shader-clock stamps of workgroup 0 at step n_steps / 2 */
+} xrl_rollout_wide_t;
+int xrl_rollout_wide_run(const xrl_rollout_wide_t* p, xrl_stream_t stream);
+int xrl_rollout_wide_words(void);
+/* dst[i] = src[i * ld] for i < n (a column of a row-major matrix: the value column of the batched head outputs -> buffer field). */
+int xrl_copy_column(const float* src, int ld, float* dst, int64_t n, xrl_stream_t stream);
 /* The shape-specialised kernel families (the rollout above, the shared-trunk minibatch kernels) are selected automatically
  * when the network is of their class; 0 forces the any-shape kernels (parity tests). */
 int xrl_set_fast_kernels(int enable);

@@ -35,7 +35,8 @@ def test_ctypes_structs_match_c_layout():
              "xrl_mirrors_t": _lib.Mirrors, "xrl_exchange_t": _lib.Exchange, "xrl_marl_gate_t": _lib.MarlGate,
              "xrl_ppo_wide_t": _lib.PpoWide, "xrl_wide_act_t": _lib.WideAct, "xrl_conv_t": _lib.Conv, "xrl_classic_t": _lib.Classic,
              "xrl_dqn_head_td_t": _lib.DqnHeadTd, "xrl_dqn_tail_td_t": _lib.DqnTailTd, "xrl_dqn_act_tail_t": _lib.DqnActTail,
-             "xrl_marl_act_t": _lib.MarlAct, "xrl_marl_act_gru_t": _lib.MarlActGru, "xrl_rollout_run_t": _lib.RolloutRun}
+             "xrl_marl_act_t": _lib.MarlAct, "xrl_marl_act_gru_t": _lib.MarlActGru, "xrl_rollout_run_t": _lib.RolloutRun,
+             "xrl_rollout_wide_t": _lib.RolloutWide}
     for extra in ("xrl_dqn_td_t", "xrl_qmix_t"):
         cls = getattr(_lib, {"xrl_dqn_td_t": "DqnTd", "xrl_qmix_t": "Qmix"}[extra], None)
         if cls is not None:
@@ -52,7 +53,9 @@ def test_ctypes_structs_match_c_layout():
             "xrl_marl_act_gru_t": (_lib.MarlActGru, ("eps_dev", "step", "eps")),
             "xrl_dqn_tail_td_t": (_lib.DqnTailTd, ("partials", "M", "act", "gamma", "slabs", "slab_stride", "off_b2")),
             "xrl_dqn_act_tail_t": (_lib.DqnActTail, ("step_dev", "seed", "step", "n", "act", "eps")),
-            "xrl_rollout_run_t": (_lib.RolloutRun, ("act", "flags", "gamma", "seed", "step", "step_dev", "obs_raw", "cp_stats", "f_val", "xchg", "dbg"))}
+            "xrl_rollout_run_t": (_lib.RolloutRun, ("act", "flags", "gamma", "seed", "step", "step_dev", "obs_raw", "cp_stats", "f_val", "xchg", "dbg")),
+            "xrl_rollout_wide_t": (_lib.RolloutWide, ("log_std_off", "H", "flags", "gamma", "seed", "env_step", "env_step_dev", "obs_raw", "ret_var",
+                                                      "env_stats", "Bmat", "f_seg", "raw_rew", "xchg", "dbg"))}
     for cname, (cls, fields) in offs.items():
         for f in fields:
             src += f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));\n'

@@ -432,25 +432,30 @@ def test_adam_mirrors_keep_every_derived_layout_current():
     assert torch.equal(lr.params_t[lo:hi], pt[lo:hi]) and torch.equal(lr.cache_image, img) and torch.equal(lr.frag, fr)
 
 
-@pytest.mark.parametrize("wide,use_graph,n,T,nmb", [(True, False, 32, 16, 2), (True, True, 32, 16, 2), (False, False, 32, 16, 2),
-                                                    (True, True, 128, 256, 8)])
-def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph, n, T, nmb):
+@pytest.mark.parametrize("wide,use_graph,n,T,nmb,whole", [(True, False, 32, 16, 2, False), (True, True, 32, 16, 2, False),
+                                                          (False, False, 32, 16, 2, False), (True, True, 128, 256, 8, False),
+                                                          (True, False, 32, 16, 2, True), (True, True, 128, 256, 8, True),
+                                                          (True, True, 100, 32, 2, True)])
+def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph, n, T, nmb, whole):
     """C4 shapes (obs 17, Box(6), Gaussian actor 17-256-256-6 tanh, critic 17-256-256-1, Basic_Identical): rollout + update
     end to end, checked against the oracle on the device's own rollout data.  wide: the update runs as ONE launch per
     minibatch (xrl_ppo_wide_minibatch: csrc/ppo_wide.hip) from rows gathered once per phase; otherwise the layered path.
     (128, 256, 8): the BASELINE configs[3] size per GPU -- 128 envs x horizon 256, minibatches of 4 096, graphs on, acting launch
-    with the running statistics and the bookkeeping inside (what tools/bench_c4.py times); ONE epoch of 8 chained minibatches
-    instead of the config's 16 x 8, so that the oracle's replay of the update chain stays a few seconds."""
+    with the running statistics and the bookkeeping inside; ONE epoch of 8 chained minibatches instead of the config's 16 x 8, so
+    that the oracle's replay of the update chain stays a few seconds.  whole: the rollout as ONE launch with only the actor on the
+    step chain + batched values (xrl_rollout_wide_run, csrc/rollout_wide.hip: what tools/bench_c4.py times since round 4) instead
+    of the launches per vector step; every check against the oracle is the same, and the two forms are compared with each other
+    in test_wide_rollout_launch_matches_the_launches_per_step."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import SyntheticMujocoVecEnv
     torch.manual_seed(0)
     ms = 10 if T == 16 else 100                                        # episode cut-off of the provider (truncations inside the rollout)
     cfg = make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
                       critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1,
-                      n_minibatch=nmb, ent_coef=0.0, gamma=0.99, use_hip_graph=use_graph, use_fused_update=wide)
+                      n_minibatch=nmb, ent_coef=0.0, gamma=0.99, use_hip_graph=use_graph, use_fused_update=wide, use_wide_rollout=whole)
     env = SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=ms)
     agent = PPO_Agent(cfg, env)
-    assert agent.model.dist == "gaussian" and not agent.use_fused_rollout
+    assert agent.model.dist == "gaussian" and not agent.use_fused_rollout and (agent._wide_rollout() is not None) == whole
     assert agent.learner.wide_eligible() == wide and agent.learner.fused_eligible(agent.memory) == wide
     assert sum(int(np.prod(v.shape)) for v in agent.model.state_dict().values()) == 142605    # SURVEY 8a parameter count
     sd = {k: npy(v) for k, v in agent.model.state_dict().items()}
@@ -469,7 +474,11 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph, n, T, nmb):
     for t_ in (0, 1, T - 1):
         z = oracle.action_gaussians(agent.seed, n, t_, 6)
         assert_close(f["actions"][t_], mu3[t_] + np.exp(ls) * z, 1e-5, f"actions at step {t_}", scale=4.0)
-    assert (f["seg"][ms - 1] & 1).all() and (f["seg"][T - 1] & 1).all()  # truncation at the cut-off and at buffer end
+    if ms - 1 < T:
+        assert (f["seg"][ms - 1] & 1).all()                                # truncation at the cut-off ...
+    assert (f["seg"][T - 1] & 1).all()                                     # ... and at buffer end
+    if whole:
+        assert agent._wr_status.tolist()[0] == 0
     # update: oracle on the same minibatches
     idx = np.stack([np.random.default_rng(3).permutation(n * T)]).reshape(nmb, -1)
     agent.set_indices(idx)
@@ -492,12 +501,12 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph, n, T, nmb):
     chain.check({k_: npy(v_) for k_, v_ in agent.model.state_dict().items()}, sd, sd0)
     assert_close(info["critic_loss"], oi["c_loss"], 1e-5, "critic_loss")
     assert_close(info["actor_loss"], oi["a_loss"], 1e-5, "actor_loss", scale=float(np.abs(oi["surrogate2"]).mean()))
-    if wide:
+    if wide and not whole:
         # running statistics + normalisation inside the acting launch == xrl_obs_normalize as a launch of its own, bit for bit
         torch.manual_seed(0)
         cfg2 = make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
                            critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1,
-                           n_minibatch=nmb, ent_coef=0.0, gamma=0.99, use_hip_graph=False, use_fused_obsnorm=False)
+                           n_minibatch=nmb, ent_coef=0.0, gamma=0.99, use_hip_graph=False, use_fused_obsnorm=False, use_wide_rollout=False)
         b = PPO_Agent(cfg2, SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=ms))
         assert agent._wstats is not None and agent._wpost and b._wide_acting() is not None and b._wstats is None and not b._wpost
         b.rollout()
@@ -513,7 +522,7 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph, n, T, nmb):
         torch.manual_seed(0)
         c = PPO_Agent(make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
                                   critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1,
-                                  n_minibatch=nmb, ent_coef=0.0, gamma=0.99, use_hip_graph=True, use_fused_update=True),
+                                  n_minibatch=nmb, ent_coef=0.0, gamma=0.99, use_hip_graph=True, use_fused_update=True, use_wide_rollout=whole),
                       SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=ms))
         c.rollout()
         c.set_indices(idx)
@@ -528,6 +537,49 @@ def test_ppo_gaussian_agent_on_mujoco_shape(oracle, wide, use_graph, n, T, nmb):
         lr._wide.pack()
         torch.cuda.synchronize()
         assert torch.equal(fr, lr._wide.frag)
+
+
+@pytest.mark.parametrize("n,T,norm,ms", [(128, 48, True, 20), (100, 32, True, 10), (16, 32, True, 12), (64, 32, False, 10)])
+def test_wide_rollout_launch_matches_the_launches_per_step(n, T, norm, ms):
+    """xrl_rollout_wide_run (ONE launch per rollout: actor-only step chain on 16-row tiles, per-workgroup partial sums of the
+    observation statistics, dynamics and records inside, batched values afterwards) vs the launches per vector step
+    (xrl_wide_act_step + xrl_synth_control_step + bookkeeping): same Philox draws, same dynamics arithmetic -- two rollouts agree to
+    fp32 summation-order accuracy on every field (continuous actions: nothing can flip), episode ends equal; and the whole-rollout
+    launch equals the same kernel launched once per vector step bit for bit."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import SyntheticMujocoVecEnv
+    res = []
+    for mode in ("steps", "whole", "whole-per-step"):
+        torch.manual_seed(0)
+        cb = None
+        cfg = make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
+                          critic_hidden_size=[256, 256], activation="leaky_relu", activation_action="tanh", n_epochs=1, n_minibatch=2,
+                          ent_coef=0.0, gamma=0.99, use_hip_graph=mode != "whole-per-step", use_obsnorm=norm, use_rewnorm=norm,
+                          use_wide_rollout=mode != "steps")
+        env = SyntheticMujocoVecEnv(n, seed=4, max_episode_steps=ms)
+        agent = PPO_Agent(cfg, env)
+        assert (agent._wide_rollout() is not None) == (mode != "steps")
+        if mode == "whole-per-step":
+            agent._per_step = lambda: True                             # (what a per-step callback makes of the rollout)
+        agent.rollout()
+        agent.rollout()
+        torch.cuda.synchronize()
+        f = {k: npy(v) for k, v in agent.memory.soa.fields.items()}
+        f.update(obs_mean=npy(agent.obs_mean), obs_var=npy(agent.obs_var), obs_count=npy(agent.obs_count), ret_mean=npy(agent.ret_mean),
+                 ret_var=npy(agent.ret_var), ret_count=npy(agent.ret_count), ret_track=npy(agent.returns), state=npy(env.state),
+                 steps=npy(env.steps), stats=npy(env.stats), buf_obs=npy(env.buf_obs))
+        res.append(f)
+    a, b, c = res
+    assert a["stats"][0] > 0                                           # episodes ended inside the rollouts
+    for k in ("seg", "terminals", "steps", "obs_count", "ret_count"):
+        assert np.array_equal(a[k], b[k]), k
+    need = a["seg"] == 1
+    for k in ("observations", "actions", "values", "aux_old_logp", "rewards", "advantages", "returns", "obs_mean", "obs_var", "ret_mean",
+              "ret_var", "ret_track", "state", "buf_obs", "stats"):
+        assert_close(b[k], a[k], 2e-5, k, scale=max(1.0, float(np.abs(a[k]).max())))
+    assert_close(b["bootv"][need], a["bootv"][need], 2e-5, "bootv", scale=max(1.0, float(np.abs(a["bootv"][need]).max())))
+    for k in b:
+        assert np.array_equal(b[k], c[k]), k + " (one launch per rollout vs the same kernel once per vector step)"
 
 
 @pytest.mark.parametrize("n,T,D,A,act,oact,obsnorm", [(48, 16, 17, 6, "leaky_relu", "tanh", True),     # tiles straddle row n
@@ -548,7 +600,8 @@ def test_wide_acting_launch_matches_the_layered_rollout(n, T, D, A, act, oact, o
         torch.manual_seed(0)
         cfg = make_config(n, T, representation="Basic_Identical", representation_hidden_size=[], actor_hidden_size=[256, 256],
                           critic_hidden_size=[256, 256], activation=act, activation_action=oact, n_epochs=1, n_minibatch=2,
-                          ent_coef=0.0, gamma=0.99, use_hip_graph=fused, use_fused_acting=fused, use_obsnorm=obsnorm)
+                          ent_coef=0.0, gamma=0.99, use_hip_graph=fused, use_fused_acting=fused, use_obsnorm=obsnorm,
+                          use_wide_rollout=False)                                 # (the launches per vector step are what is tested here)
         agent = PPO_Agent(cfg, SyntheticMujocoVecEnv(n, seed=4, obs_dim=D, act_dim=A, max_episode_steps=5))
         agent.rollout()
         torch.cuda.synchronize()

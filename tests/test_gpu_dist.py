@@ -33,6 +33,7 @@ def _worker(rank, world, port, q, shape="cartpole"):
         cfg = make_config(n, T, n_epochs=1, n_minibatch=2, distributed_training=True, seed=1 + rank, representation="Basic_Identical",
                           representation_hidden_size=[], actor_hidden_size=[256, 256], critic_hidden_size=[256, 256],
                           activation="leaky_relu", activation_action="tanh", ent_coef=0.0, gamma=0.99,
+                          use_wide_rollout=False,      # (likewise: the whole-rollout launch's workgroups wait for each other)
                           use_fused_optimizer=False)   # (the one-launch optimiser's 558 blocks meet at a barrier inside the launch and
         #                                                 must all be resident: two ranks time-sharing ONE GPU can overlap two such
         #                                                 launches -- 1 116 blocks for 1 024 slots -- and time out; tools/bench_workloads.py

@@ -118,6 +118,7 @@ class Runner:
             # ranks time-sharing ONE GPU (test boxes): the 279 blocks of this network's one-launch optimiser step spin on a
             # barrier and need every block resident, which a second process on the device can prevent -- two launches instead
             cfg.use_fused_optimizer = False
+            cfg.use_wide_rollout = False                    # (likewise the whole-rollout launch: its workgroups wait for each other)
         self.ppo = workload in ("c2", "c4")
         self.agent = (PPO_Agent if self.ppo else QMIX_Agents)(cfg, env)
         if world > 1:
@@ -168,6 +169,8 @@ class Runner:
                     (st, "workgroups on ONE XCD, plain-store messages through its L2" if st[3] == 0 else
                      "%d launch(es) found their workgroups on several XCDs and exchanged through device-scope stores" % st[3]))
         if self.workload == "c4":
+            if getattr(a, "_wr", None) is not None:
+                return "whole-rollout launch (xrl_rollout_wide_run: actor-only step chain, dynamics inside) + batched values passes"
             return "two launches per vector step (xrl_wide_act_step incl. statistics + bookkeeping; provider)" if a._wide_acting() is not None \
                 else "layered launches per vector step"
         return "one acting launch + provider + store per vector step; updates as one graph per phase" if getattr(a.learner, "_buf_graph", None) is not None \

@@ -224,6 +224,18 @@ class RolloutRun(C.Structure):
                                         "f_val", "bootv", "xnext", "ended", "ret_final", "xchg", "status", "dbg")]
 
 
+class RolloutWide(C.Structure):
+    """xrl_rollout_wide_t (csrc/rollout_wide.hip): steps [t0, t0 + n_steps) of a rollout of the D-256-256-{A | 1} Gaussian class."""
+    _fields_ = [("params", c_void_p)] + [(k, c_int32) for k in ("w0", "b0", "w1", "b1", "w2", "b2", "log_std_off", "act", "out_act", "D", "A", "H",
+                                                                  "n", "T", "t0", "n_steps", "max_steps", "use_obsnorm", "use_rewnorm", "flags")] + \
+               [("obs_range", c_float), ("rew_range", c_float), ("gamma", c_float), ("pad0", c_float),
+                ("seed", C.c_uint64), ("env_seed", C.c_uint64), ("step", C.c_uint32), ("env_step", C.c_uint32),
+                ("step_dev", c_void_p), ("env_step_dev", c_void_p)] + \
+               [(k, c_void_p) for k in ("obs_raw", "obs_mean", "obs_var", "obs_count", "ret_mean", "ret_var", "ret_count", "ret_track", "env_state", "env_steps",
+                                        "env_score", "env_stats", "Amat", "Bmat", "f_obs", "f_act", "f_logp", "f_rew", "f_term", "f_seg",
+                                        "xnext", "ended", "ret_final", "raw_rew", "xchg", "status", "dbg")]
+
+
 class PpoFused(C.Structure):
     _fields_ = [("params", c_void_p), ("params_t", c_void_p), ("cache_image", c_void_p), ("layers", FusedLayer * 8),
                 ("n_layers", c_int32), ("n_levels", c_int32), ("n_head_layers", c_int32), ("pad0", c_int32),
@@ -386,6 +398,8 @@ _SIGS = {
     "xrl_flatten_chw_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_flatten_chw_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "xrl_rollout_cartpole_run": [C.POINTER(RolloutRun), c_void_p],
+    "xrl_rollout_wide_run": [C.POINTER(RolloutWide), c_void_p],
+    "xrl_copy_column": [c_void_p, C.c_int, c_void_p, c_int64, c_void_p],
     "xrl_rollout_cartpole_values": [C.POINTER(RolloutRun), c_void_p],
     "xrl_sample_replay_indices": [c_void_p, c_int, c_int, c_int, c_void_p, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
     "xrl_random_permutation": [c_void_p, c_int, c_int64, c_int64, C.c_uint64, C.c_uint32, c_void_p, c_void_p],
@@ -431,7 +445,7 @@ _lib = None
 
 def exported_symbols():
     """Names every entry point include/xrl_hip.h declares (checked by the CPU test-suite)."""
-    return ["xrl_version", "xrl_last_error", "xrl_rollout_cache_floats"] + list(_SIGS)
+    return ["xrl_version", "xrl_last_error", "xrl_rollout_cache_floats", "xrl_rollout_wide_words"] + list(_SIGS)
 
 
 def load():
@@ -450,6 +464,8 @@ def load():
     lib.xrl_last_error.restype = C.c_char_p
     lib.xrl_rollout_cache_floats.restype = c_int64
     lib.xrl_rollout_cache_floats.argtypes = [C.POINTER(RolloutStep)]
+    lib.xrl_rollout_wide_words.restype = c_int
+    lib.xrl_rollout_wide_words.argtypes = []
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args

@@ -332,9 +332,65 @@ class PPO_Agent(AgentSurface):
         return bool(_get(self.config, "use_persistent_rollout", True)) and not self._per_step() and \
             getattr(self, "persist_status", None) is not None
 
+    def _wide_rollout(self):
+        """ops.WideRollout of this agent -- the whole rollout as one launch with only the actor on the step chain
+        (csrc/rollout_wide.hip) -- when the network is the two-branch Gaussian class, the env the device-resident continuous-control
+        provider and n_envs <= 256 (config.use_wide_rollout: False keeps the launches per vector step), else None."""
+        if not hasattr(self, "_wr"):
+            self._wr = None
+            from ..envs.synthetic import SyntheticMujocoVecEnv
+            env, n, T, dev = self.envs, self.n_envs, self.horizon_size, self.device
+            ok = bool(_get(self.config, "use_wide_rollout", True)) and type(self)._enqueue_step is PPO_Agent._enqueue_step and \
+                type(env) is SyntheticMujocoVecEnv and self.model.dist == "gaussian" and ops.WideRollout.eligible(self.model, n) and \
+                tuple(env.buf_obs.shape) == (n, self.obs_dim)
+            if ok:
+                f, D = self.memory.soa.fields, self.obs_dim
+                n4 = (n + 3) // 4 * 4
+                self._wr_xnext = torch.zeros(T * n, D, device=dev)
+                self._wr_xchg = torch.zeros(ops.WideRollout.xchg_words(), dtype=torch.int32, device=dev)
+                # the status words ride in the learner's read-back block: the host sees them at the one sync of every update
+                self._wr_status = self.learner.status_words
+                self._wr_status.zero_()
+                self.model.plan.ensure(T * n)                     # (the batched values pass; before any capture)
+                self._wr = ops.WideRollout(
+                    self.model, T, params=self.model.params.flat, n=n, max_steps=int(env.max_episode_steps),
+                    use_obsnorm=int(self.use_obsnorm), use_rewnorm=int(self.use_rewnorm), obs_range=float(self.obsnorm_range),
+                    rew_range=float(self.rewnorm_range), gamma=float(self.gamma), seed=self.seed, env_seed=env.seed, step=0, env_step=0,
+                    step_dev=self.step_counter, env_step_dev=env.step_counter, obs_raw=env.buf_obs, obs_mean=self.obs_mean,
+                    obs_var=self.obs_var, obs_count=self.obs_count, ret_mean=self.ret_mean, ret_var=self.ret_var, ret_count=self.ret_count,
+                    ret_track=self.returns, env_state=env.state, env_steps=env.steps, env_score=env.ep_score, env_stats=env.stats,
+                    Amat=env.A, Bmat=env.B, f_obs=f["observations"], f_act=f["actions"], f_logp=f["aux_old_logp"], f_rew=f["rewards"],
+                    f_term=f["terminals"], f_seg=f["seg"], xnext=self._wr_xnext, ended=torch.zeros(T, n4, dtype=torch.uint8, device=dev),
+                    ret_final=torch.zeros(T, n4, device=dev), raw_rew=torch.zeros(T, n4, device=dev), xchg=self._wr_xchg,
+                    status=self._wr_status)
+        return self._wr
+
+    def _enqueue_rollout_wide(self, wr):
+        """The whole rollout of the two-branch Gaussian class: one launch for the T vector steps (actor chain, dynamics, statistics,
+        records), then values and bootstrap values of every stored row as two batched forward passes (the layered GEMM plan at
+        T x n rows) -- same numbers as the launches per vector step up to fp32 summation order."""
+        T, n, A, f = self.horizon_size, self.n_envs, self.model.action_dim, self.memory.soa.fields
+        M = T * n
+        if self._per_step():
+            for t in range(T):
+                wr.run(t, 1)
+        else:
+            wr.run(0, T)
+        heads = self.model.forward(f["observations"].view(M, -1), M)
+        ops.copy_column(heads, A + 1, A, f["values"], M)
+        heads = self.model.forward(self._wr_xnext, M)
+        ops.copy_column(heads, A + 1, A, f["bootv"], M)
+        self.envs.advance(T)
+        ops.counter_add(self.step_counter, T)
+        ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
+                     self.gamma, self.gae_lam, self.memory.use_gae)
+
     def _enqueue_rollout(self):
         if self.use_fused_rollout:
             return self._enqueue_rollout_fused()
+        wr = self._wide_rollout()
+        if wr is not None:
+            return self._enqueue_rollout_wide(wr)
         T, n, A = self.horizon_size, self.n_envs, self.model.action_dim
         for t in range(T):
             self._enqueue_step(t)
@@ -467,6 +523,7 @@ class PPO_Agent(AgentSurface):
     def _launch_rollout(self):
         if not self.use_fused_rollout:
             self._wide_acting()                                   # (allocates on first use: never inside a capture)
+            self._wide_rollout()
         safe = getattr(self.envs, "graph_safe", True) or (getattr(self.envs, "graph_safe_even", False) and self.horizon_size % 2 == 0)
         if self.use_graph and safe and not self._per_step():
             if self._rollout_graph is not None and self._ws_sig() != self._rollout_cap:
@@ -492,6 +549,28 @@ class PPO_Agent(AgentSurface):
             self._started = True
         first = self.use_fused_rollout and not getattr(self, "_persist_checked", False)
         saved = [x.clone() for x in self._rollout_state_tensors()] if first else None
+        wide_first = not self.use_fused_rollout and not getattr(self, "_wide_checked", False) and self._wide_rollout() is not None
+        if wide_first:
+            # first whole-rollout launch of the Gaussian class: read its status synchronously (a wait between the resident workgroups
+            # that timed out leaves the rollout incomplete): restore, fall back to the launches per vector step for good, redo
+            self._wide_checked = True
+            env = self.envs
+            wstate = [self.returns, self.step_counter, env.step_counter, env.state, env.steps, env.ep_score, env.stats, env.buf_obs,
+                      self.obs_mean, self.obs_var, self.obs_count, self.ret_mean, self.ret_var, self.ret_count]
+            wsaved = [x.clone() for x in wstate]
+            self._launch_rollout()
+            torch.cuda.synchronize()
+            if self._wr_status.tolist()[0] != 0:
+                import warnings
+                warnings.warn(f"xuance_amd: whole-rollout launch of the Gaussian class unusable on this device (status "
+                              f"{self._wr_status.tolist()}); falling back to the launches per vector step")
+                for x, s0 in zip(wstate, wsaved):
+                    x.copy_(s0)
+                self._wr, self._rollout_graph = None, None
+                self.config.use_wide_rollout = False
+                self._launch_rollout()
+            self.current_step += self.n_envs * self.horizon_size
+            return
         self._launch_rollout()
         if first:
             # First rollout of this agent: if it went through the whole-rollout launch, read its status synchronously.
@@ -603,6 +682,9 @@ class PPO_Agent(AgentSurface):
             self._enqueue_update()
         self.learner.iterations += self.idx.shape[0] + (self.n_epochs if self.rem else 0)
         info = self.learner.last_info(self.rem if self.rem else self.batch_size)
+        if getattr(self, "_wr", None) is not None and self.learner.last_status[0] != 0:
+            raise ops.XrlError(f"xrl_rollout_wide_run: status {self.learner.last_status} (a wait between the resident workgroups timed "
+                               "out): the last rollout is incomplete; restart with use_wide_rollout: False")
         if getattr(self, "persist_status", None) is not None and not self._persist_status_ok(self.learner.last_status):
             # read at the one host sync of the update phase: the rollout this update consumed was cut short
             raise ops.XrlError(f"xrl_rollout_cartpole_run: status {self.learner.last_status} (a wait between the resident "

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, RolloutWide, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -631,6 +631,49 @@ class CartPoleRollout:
     def values(self, t0, n_steps):
         self.q.t0, self.q.n_steps = int(t0), int(n_steps)
         call("xrl_rollout_cartpole_values", C.byref(self.q), stream_ptr())
+
+
+class WideRollout:
+    """Host side of xrl_rollout_wide_run (csrc/rollout_wide.hip): the whole rollout of the D-256-256-{A | 1} Gaussian class on the
+    device-resident continuous-control provider as ONE launch with only the actor on the step chain (n_envs <= 256); values and
+    bootstrap values are the caller's batched pass afterwards."""
+
+    MAX_ENVS = 256
+
+    @staticmethod
+    def eligible(model, n):
+        return PpoWideState.eligible(model) and n <= WideRollout.MAX_ENVS and model.obs_dim <= 20 and fast_kernels_enabled()
+
+    @staticmethod
+    def xchg_words():
+        return int(_lib.load().xrl_rollout_wide_words())
+
+    def __init__(self, model, T, **kw):
+        q = self.q = RolloutWide()
+        o = model.params.offsets
+        key = "actor.mu"
+        q.w0, q.b0 = o[f"{key}.0.weight"], o[f"{key}.0.bias"]
+        q.w1, q.b1 = o[f"{key}.2.weight"], o[f"{key}.2.bias"]
+        q.w2, q.b2 = o[f"{key}.4.weight"], o[f"{key}.4.bias"]
+        q.log_std_off = o[getattr(model, "log_std_name", "actor.log_std")]
+        q.D, q.A, q.H, q.T = model.obs_dim, model.action_dim, 256, int(T)
+        q.act, q.out_act = ACT[model.activation], ACT[model.activation_action]
+        self._keep = []
+        for k, v in kw.items():
+            if isinstance(v, torch.Tensor):
+                self._keep.append(v)
+                v = v.data_ptr()
+            setattr(q, k, v)
+
+    def run(self, t0, n_steps, flags=0, dbg=None):
+        self.q.t0, self.q.n_steps, self.q.flags = int(t0), int(n_steps), int(flags)
+        self.q.dbg = None if dbg is None else dbg.data_ptr()
+        call("xrl_rollout_wide_run", C.byref(self.q), stream_ptr())
+
+
+def copy_column(src, ld, col, dst, n, row0=0):
+    """dst[i] = src[row0 + i][col] for i < n (src row-major with `ld` columns)."""
+    call("xrl_copy_column", src.data_ptr() + 4 * (int(row0) * int(ld) + int(col)), int(ld), ptr(dst), int(n), stream_ptr())
 
 
 def dqn_td(**kw):
