@@ -28,6 +28,18 @@ __device__ __forceinline__ double u01d(uint32_t a, uint32_t b) {
     return (double)((((uint64_t)a << 21) ^ (uint64_t)b) & ((1ull << 53) - 1)) * (1.0 / 9007199254740992.0);
 }
 
+// Standard normal for the SYNTHETIC providers' noise (not a reference quantity): Box-Muller on one Philox call with the hardware's
+// log2 / sqrt / cos (v_cos_f32 takes revolutions: cos(2 pi u) is one instruction) -- the library's logf / cosf cost ~1.5 k cycles
+// per draw on the step chain of the whole-rollout launch (csrc/rollout_wide.hip), these ~100.
+__device__ __forceinline__ float provider_normal(uint64_t seed, uint32_t e, uint32_t step, uint32_t stream) {
+    uint32_t r[4];
+    philox4x32(seed, e, step, stream, r);
+    const float u1 = fmaxf(u01(r[0]), 1e-7f), u2 = u01(r[1]);
+    return __builtin_amdgcn_sqrtf(-2.f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+}
+// tanh of the providers' dynamics: 1 - 2 / (exp(2 x) + 1) on the hardware's exp2 / rcp (|error| ~ 1e-7)
+__device__ __forceinline__ float provider_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
+
 constexpr uint32_t STREAM_ACTION = 0x41435431u, STREAM_GAUSS = 0x47415500u, STREAM_RESET_A = 0x52455345u,
                    STREAM_RESET_B = 0x52455346u, STREAM_EGREEDY = 0x45475200u;
 

@@ -188,10 +188,7 @@ __global__ void __launch_bounds__(256) cartpole_reset_kernel(xrl_cartpole_t p) {
 // + 0.01 N(0,1), reward = state'[0] - 0.1 |a|^2, truncation after max_steps, reset to 0.1 N(0,1); same auto-reset
 // contract as the CartPole kernel.  One thread per env; the noise is Philox keyed by (seed, env, step).
 __device__ __forceinline__ float synth_normal(uint64_t seed, uint32_t e, uint32_t step, uint32_t j) {
-    uint32_t r[4];
-    philox4x32(seed, e, step, 0x53594E00u + j, r);
-    const float u1 = fmaxf(u01(r[0]), 1e-7f), u2 = u01(r[1]);
-    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    return provider_normal(seed, e, step, 0x53594E00u + j);
 }
 
 // One wavefront per env: lane j < D owns state component j (the first version ran one THREAD per env: a serial 17 x 23
@@ -217,7 +214,7 @@ __global__ void __launch_bounds__(256) synth_control_kernel(xrl_synth_ctl_t p, i
             pen += ai * ai;
             acc += ai * p.Bmat[i * D + jj];
         }
-        yj = tanhf(acc) + 0.01f * synth_normal(p.seed, (uint32_t)e, step, (uint32_t)jj);
+        yj = provider_tanh(acc) + 0.01f * synth_normal(p.seed, (uint32_t)e, step, (uint32_t)jj);
     }
     const float y0 = __shfl(yj, 0, 64);
     const float rew = y0 - 0.1f * pen;

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     __shared__ __attribute__((aligned(16))) float s_norm[2][WDM];        // mean | 1 / (std + 1e-8) of the step
     __shared__ __attribute__((aligned(16))) float pmu[8][WR][WAM];       // partial pre-activations of the mean [wave][row][action]
     __shared__ __attribute__((aligned(16))) float s_act[WR][WAM];        // sampled actions of the step
-    __shared__ __attribute__((aligned(16))) float s_zn[WR][WAM];         // standard normals of the step's action draw
+    __shared__ __attribute__((aligned(16))) float s_zn[2][WR][WAM];      // standard normals of the action draw, by step parity
     __shared__ float s_amat[WDM * WDM], s_bmat[WAM * WDM];
     // the small parameters (first layer, both hidden biases, head rows): read from here every step -- only the 256 x 256 layer's
     // 128 fragment registers per lane stay resident (with the small ones in registers as well the kernel spilled 42 VGPRs)
@@ -164,8 +164,9 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     const int dbg_k = n_steps / 2;
 
     // ---- item threads: thread i < 16 D owns (row ir, dimension id) of the physics / records; per-row counters live with id == 0
-    const bool item = tid < WR * D;
-    const int ir = item ? tid / D : 0, id = item ? tid - ir * D : 0, ie = e0 + ir;
+    const int it_ = tid - 64;                                    // (items start at wave 1: wave 0 samples while they prepare / integrate)
+    const bool item = it_ >= 0 && it_ < WR * D;
+    const int ir = item ? it_ / D : 0, id = item ? it_ - ir * D : 0, ie = e0 + ir;
     const bool item_ok = item && ie < n;
     int ep_steps = 0;
     float ep_score = 0.f, rtrack = 0.f;
@@ -227,11 +228,25 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     };
     // action noise of step k (Philox stream of xrl_policy_sample) -> s_zn, by waves 1..7's spare lanes: thread i < 16 A
     auto draw_actions = [&](int k) {
-        const int i = tid - 64;
+        const int i = tid - (WTH - WR * WAM);                  // (the last two waves: free of item threads for D <= 20)
         if (i >= 0 && i < WR * A) {
             const int r = i / A, j = i - r * A;
-            s_zn[r][j] = w_normal(q.seed, (uint32_t)(e0 + r), pstep0 + (uint32_t)k, STREAM_GAUSS + (uint32_t)j, 5.96e-8f);
+            s_zn[k & 1][r][j] = w_normal(q.seed, (uint32_t)(e0 + r), pstep0 + (uint32_t)k, STREAM_GAUSS + (uint32_t)j, 5.96e-8f);
         }
+    };
+    // What step k's dynamics need that does not depend on its action -- the simulator's noise, the state's part of the
+    // pre-activation -- and the step's action normals: computed while the statistics messages of the step are in flight (behind
+    // publish(), in front of the poll), i.e. off the step chain
+    float noise = 0.f, pre_s = 0.f;
+    auto prepare = [&](int k) {
+        if (item) {
+            noise = 0.01f * provider_normal(q.env_seed, (uint32_t)ie, estep0 + (uint32_t)k, 0x53594E00u + (uint32_t)id);
+            float acc = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < WDM; ++kk) if (kk < D) acc += s_st[ir][kk] * s_amat[kk * D + id];
+            pre_s = acc;
+        }
+        draw_actions(k);
     };
     bool multi = true;                                           // until the placement is known: device-scope message stores
     if (use_norm) {
@@ -248,7 +263,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             publish(1u, true);
         }
     }
-    draw_actions(0);
+    prepare(0);
 
     int k = 0;
     for (; k < n_steps; ++k) {
@@ -301,10 +316,8 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             }
         }
         if (stamp) dbg[1] = clock64();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores of the previous step are in L2
         lds_barrier();                                                                             // #1 statistics ready
         if (s_abort) break;
-        if (tid == 64 && k > 0) w_st_dev(q.xchg + WX_DONE + wg, (unsigned)k);       // steps < k complete (trailing readers)
         // ================= P2: first layer (wave: its 32 units), transposed: D[unit][row] = sum_d W0[unit][d] xn[row][d]
         {
             float xn[5];
@@ -371,10 +384,11 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             // lg[i] of lane (g, cl) = partial pre-activation of action 4 g + i, row cl
             if (g < 2) *reinterpret_cast<float4*>(&pmu[wave][cl][4 * g]) = make_float4(lg[0] + lg2[0], lg[1] + lg2[1], lg[2] + lg2[2], lg[3] + lg2[3]);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores of the previous step are in L2 (long since)
         lds_barrier();                                                                             // #3 partial means ready
+        if (tid == 64 && k > 0) w_st_dev(q.xchg + WX_DONE + wg, (unsigned)k);       // steps < k complete (trailing readers)
         if (stamp) dbg[3] = clock64();
-        // ================= P4: wave 0: Normal(mu, std).sample(), log-prob; the others: the simulator's noise of this step
-        float noise = 0.f;
+        // ================= P4: wave 0: Normal(mu, std).sample(), log-prob
         if (wave == 0) {
             // lane (g, row): actions j = g and g + 4
             float lp = 0.f;
@@ -387,7 +401,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
                     for (int w = 0; w < 8; ++w) pre += pmu[w][cl][j];
                     const float mu = act_apply_c<OACT>(pre + s_head[0][j]);
                     const float sd = s_head[1][j];
-                    const float x = mu + sd * s_zn[cl][j];                                       // Normal(mu, std).sample()
+                    const float x = mu + sd * s_zn[k & 1][cl][j];                                // Normal(mu, std).sample()
                     const float df = x - mu;
                     lp += -(df * df) / (2.f * sd * sd) - s_head[2][j] - 0.91893853320467274178f;
                     s_act[cl][j] = x;
@@ -397,20 +411,20 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             lp += __shfl_xor(lp, 16, 64); lp += __shfl_xor(lp, 32, 64);
             if (g == 0 && e0 + cl < n) q.f_logp[(size_t)t * n + e0 + cl] = lp;
         }
-        if (item) noise = 0.01f * w_normal(q.env_seed, (uint32_t)ie, estep0 + (uint32_t)k, 0x53594E00u + (uint32_t)id, 1e-7f);
         lds_barrier();                                                                             // #4 actions ready
         if (stamp) dbg[4] = clock64();
         // ================= P5: dynamics (item threads), records, next raw observations; action noise of the next step
         if (item) {
-            float acc = 0.f;
-            for (int kk = 0; kk < D; ++kk) acc += s_st[ir][kk] * s_amat[kk * D + id];
-            float pen = 0.f;
-            for (int j = 0; j < A; ++j) {
-                const float ai = fminf(fmaxf(s_act[ir][j], -1.f), 1.f);
-                pen += ai * ai;
-                acc += ai * s_bmat[j * D + id];
+            float acc = pre_s, pen = 0.f;
+#pragma unroll
+            for (int j = 0; j < WAM; ++j) {
+                if (j < A) {
+                    const float ai = fminf(fmaxf(s_act[ir][j], -1.f), 1.f);
+                    pen += ai * ai;
+                    acc += ai * s_bmat[j * D + id];
+                }
             }
-            const float y = tanhf(acc) + noise;
+            const float y = provider_tanh(acc) + noise;
             if (id == 0) { s_y0[ir] = y; s_pen[ir] = pen; s_trunc[ir] = (ep_steps + 1 >= q.max_steps) ? 1 : 0; }
             // (the row's truncation flag: every item thread of the row needs it -- through LDS, read behind the wave-local wait below)
             // next observation before the reset, normalised with this step's statistics (get_terminated_values' input)
@@ -423,13 +437,12 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             //  barrier #5a below)
             noise = y;                                           // (carried across the barrier)
         }
-        draw_actions(k + 1);
         lds_barrier();                                                                             // #5a y0 / pen / truncation of every row
         if (item) {
             const float y = noise;
             const bool trunc = s_trunc[ir] != 0;
             float v = y;
-            if (trunc) v = 0.1f * w_normal(q.env_seed, (uint32_t)ie, estep0 + (uint32_t)k, 0x53594E00u + 64u + (uint32_t)id, 1e-7f);
+            if (trunc) v = 0.1f * provider_normal(q.env_seed, (uint32_t)ie, estep0 + (uint32_t)k, 0x53594E00u + 64u + (uint32_t)id);
             s_st[ir][id] = v; s_raw[ir][id] = v;
             if (id == 0) {
                 const float rew = s_y0[ir] - 0.1f * s_pen[ir];
@@ -452,6 +465,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
         lds_barrier();                                                                             // #5 next raw rows ready
         if (stamp) dbg[5] = clock64();
         if (use_norm && !single && k + 1 < n_steps) publish((unsigned)(k + 2), multi);
+        if (k + 1 < n_steps) prepare(k + 1);
         if (stamp) { dbg[6] = clock64(); dbg[15] = 7; }
     }
 
