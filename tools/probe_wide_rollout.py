@@ -39,9 +39,17 @@ for whole in (True, False):
         r["actor_launch_us"] = round(bench._event_time_us(lambda: wr.run(0, T), 5), 1)
         M, A, f = n * T, 6, agent.memory.soa.fields
         r["values_pass_us"] = round(bench._event_time_us(lambda: (agent.model.forward(f["observations"].view(M, -1), M)), 5), 1)
-        dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
-        wr.run(0, T, dbg=dbg); torch.cuda.synchronize()
+        r["variants_us (spread, backoff, 16-byte loads)"] = {}
+        for spread in (0, 1, 2, 3):
+            for bits in (0, 0x100, 0x200, 0x300):
+                fl = (spread << 4) | bits
+                r["variants_us (spread, backoff, 16-byte loads)"]["%d %d %d" % (spread, bits >> 8 & 1, bits >> 9 & 1)] = round(bench._event_time_us(lambda: wr.run(0, T, flags=fl), 3), 1)
+        fl = int(os.environ.get("WIDE_FLAGS", "0"), 0)
+        dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
+        wr.run(0, T, flags=fl, dbg=dbg); torch.cuda.synchronize()
         d = dbg.tolist()
+        r["waves: prepare done | messages in | merge done (cycles from the step's start), poll rounds"] = [
+            [d[16 + w] - d[0], d[24 + w] - d[0], d[40 + w] - d[0], d[32 + w]] for w in range(8)]
         names = ["statistics (poll + merge)", "barrier 1 + first layer + barrier 2", "middle layer + mean partials + barrier 3",
                  "sample + simulator noise + barrier 4", "dynamics + records + barriers 5a / 5", "partial sums + message"]
         r["phase_cycles_of_step_128"] = {names[i]: d[i + 1] - d[i] for i in range(6)}

@@ -807,10 +807,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_act_kernel(xrl_wide_act_t 
         if (row_ok && sub < A) {
             const int j = sub;
             const float mu = act_apply_c<OACT>(zmine);
-            uint32_t rn[4];
-            philox4x32(p.seed, (uint32_t)e, step, STREAM_GAUSS + (uint32_t)j, rn);
-            const float u1 = fmaxf(u01(rn[0]), 5.96e-8f), u2 = u01(rn[1]);
-            const float zn = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+            const float zn = policy_normal(p.seed, (uint32_t)e, step, (uint32_t)j);
             const float ls = pimg[WAM * WA_H2LD + 8 + j], sd = expf(ls);
             const float x = mu + sd * zn;                  // Normal(mu, std).sample()
             const float df = x - mu;

@@ -37,6 +37,16 @@ __device__ __forceinline__ float provider_normal(uint64_t seed, uint32_t e, uint
     const float u1 = fmaxf(u01(r[0]), 1e-7f), u2 = u01(r[1]);
     return __builtin_amdgcn_sqrtf(-2.f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
+// Standard normal of the policy's Normal(mu, std).sample() (xrl_policy_sample, xrl_wide_act_step, xrl_rollout_wide_run: one
+// definition, the same draw for (seed, env, step, action) on every path): Box-Muller on a Philox call, hardware log2 / sqrt / cos
+// (|error| ~ 1e-6 against the float64 evaluation the oracle restates it with; the reference's own draws are torch's generator,
+// which no engine can reproduce)
+__device__ __forceinline__ float policy_normal(uint64_t seed, uint32_t e, uint32_t step, uint32_t j) {
+    uint32_t r[4];
+    philox4x32(seed, e, step, 0x47415500u + j, r);            // STREAM_GAUSS + j
+    const float u1 = fmaxf(u01(r[0]), 5.96e-8f), u2 = u01(r[1]);
+    return __builtin_amdgcn_sqrtf(-2.f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+}
 // tanh of the providers' dynamics: 1 - 2 / (exp(2 x) + 1) on the hardware's exp2 / rcp (|error| ~ 1e-7)
 __device__ __forceinline__ float provider_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 

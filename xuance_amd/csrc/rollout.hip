@@ -122,10 +122,7 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(xrl_sample_t p) {
             float z;
             if (p.noise) z = p.noise[(size_t)e * A + j];
             else {
-                uint32_t r[4];
-                philox4x32(p.seed, (uint32_t)e, step, STREAM_GAUSS + (uint32_t)j, r);
-                const float u1 = fmaxf(u01(r[0]), 5.96e-8f), u2 = u01(r[1]);
-                z = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+                z = policy_normal(p.seed, (uint32_t)e, step, (uint32_t)j);
             }
             const float ls = p.log_std[j], sd = expf(ls);
             const float x = h[j] + sd * z;                // Normal(mu, std).sample()

@@ -21,6 +21,7 @@
 namespace xrl {
 
 typedef float wf32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WR = 16;                    // envs per workgroup
 constexpr int WH = 256;                   // hidden width
@@ -31,8 +32,11 @@ constexpr int WTH = 512;                  // threads per workgroup (8 waves, all
 constexpr int WMAXWG = 16;
 // exchange scratch (32-bit words): two slots of WSLOT 8-byte units -- unit ((d * 16 + wg) * 4 + k), k = lo s1, lo s2, hi s1, hi s2 of
 // dimension d; progress words; XCC mask
-constexpr int WSLOT = WDM * 16 * 4;
-constexpr int WX_DONE = 4 * WSLOT, WX_MASK = WX_DONE + 32, WX_WORDS = WX_DONE + 64;
+// (a dimension's 16 x 4 units are 512 bytes; flags bits 4..6 spread the dimensions further apart -- 512 B << s -- so that the
+//  128 polling waves of a step do not all queue on two or three L2 channels)
+constexpr int WUNITS = 16 * 4, WSPREAD_MAX = 3;
+constexpr int WSLOT_MAX = WDM * (WUNITS << WSPREAD_MAX);
+constexpr int WX_DONE = 4 * WSLOT_MAX, WX_MASK = WX_DONE + 32, WX_WORDS = WX_DONE + 64;
 
 template <int CTRL>
 __device__ __forceinline__ double wdpp(double v) {
@@ -53,13 +57,6 @@ template <typename T>
 __device__ __forceinline__ void w_st(T* p, T v, bool multi) { if (multi) w_st_dev(p, v); else *p = v; }
 
 #define WMFMA(a, b, acc) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), acc, 0, 0, 0)
-
-__device__ __forceinline__ float w_normal(uint64_t seed, uint32_t e, uint32_t step, uint32_t stream, float umin) {   // Box-Muller on Philox
-    uint32_t r[4];
-    philox4x32(seed, e, step, stream, r);
-    const float u1 = fmaxf(u01(r[0]), umin), u2 = u01(r[1]);
-    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
-}
 
 // the trailing workgroup: normalised rewards of step t (return statistics BEFORE that step's episode ends, ppo_agent.py:128), then
 // ret_rms.update(returns[i:i+1]) for every env whose episode ended at step t, in env order (:146-149)
@@ -200,6 +197,8 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     double st_cnt = 0.0;
     if (use_norm && sd_ok) { st_mean = q.obs_mean[sd_]; st_var = q.obs_var[sd_]; st_cnt = *q.obs_count; }
     unsigned long long* xu = reinterpret_cast<unsigned long long*>(q.xchg);
+    const int spread = min((q.flags >> 4) & 7, WSPREAD_MAX), ustride = WUNITS << spread, WSLOT = WDM * ustride;
+    const bool backoff = (q.flags & 0x100) != 0, wide_ld = (q.flags & 0x200) != 0;
     const uint32_t pstep0 = q.step + (q.step_dev ? *q.step_dev : 0u) + (uint32_t)t0;        // Philox step of the policy's draws
     const uint32_t estep0 = q.env_step + (q.env_step_dev ? *q.env_step_dev : 0u) + (uint32_t)t0;   // ... of the simulator's noise
     if (tid < WAM) {
@@ -222,7 +221,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             const double sv = (cl & 1) ? ps2 : ps1;
             const unsigned word = (cl & 2) ? (unsigned)__double2hiint(sv) : (unsigned)__double2loint(sv);
             const unsigned long long m = ((unsigned long long)word << 32) | (unsigned long long)tag;
-            unsigned long long* dst = xu + (tag & 1u) * WSLOT + (sd_ * 16 + wg) * 4 + cl;
+            unsigned long long* dst = xu + (tag & 1u) * WSLOT + sd_ * ustride + wg * 4 + cl;
             if (dev) w_st_dev(dst, m); else *dst = m;
         }
     };
@@ -231,7 +230,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
         const int i = tid - (WTH - WR * WAM);                  // (the last two waves: free of item threads for D <= 20)
         if (i >= 0 && i < WR * A) {
             const int r = i / A, j = i - r * A;
-            s_zn[k & 1][r][j] = w_normal(q.seed, (uint32_t)(e0 + r), pstep0 + (uint32_t)k, STREAM_GAUSS + (uint32_t)j, 5.96e-8f);
+            s_zn[k & 1][r][j] = policy_normal(q.seed, (uint32_t)(e0 + r), pstep0 + (uint32_t)k, (uint32_t)j);
         }
     };
     // What step k's dynamics need that does not depend on its action -- the simulator's noise, the state's part of the
@@ -270,6 +269,8 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
         const int t = t0 + k;
         const bool stamp = dbg_on && k == dbg_k;
         if (stamp) dbg[0] = clock64();
+        const bool wstamp = dbg != nullptr && wg == 0 && lane == 0 && k == dbg_k;
+        if (wstamp) dbg[16 + wave] = clock64();                  // (this wave's prepare() is done)
         // ================= P1: statistics of the step (every wave: its dimensions)
         if (use_norm) {
             double S1 = 0.0, S2 = 0.0;
@@ -279,18 +280,28 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             if (!single) {
                 const unsigned tag = (unsigned)(k + 1);
                 const bool live = sd_ok && cl < n_act;
-                const unsigned long long* xs = xu + (tag & 1u) * WSLOT + ((sd_ok ? sd_ : 0) * 16 + cl) * 4;
+                const unsigned long long* xs = xu + (tag & 1u) * WSLOT + (sd_ok ? sd_ : 0) * ustride + cl * 4;
                 unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0;
                 int spins = 0;
                 for (;;) {
-                    if (live) { u0 = w_ld_dev(xs); u1 = w_ld_dev(xs + 1); u2 = w_ld_dev(xs + 2); u3 = w_ld_dev(xs + 3); }
+                    if (live) {
+                        if (wide_ld) {                           // two 16-byte device-scope loads (each 8-byte unit is still one message)
+                            wu32x4 a, b;
+                            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                                         : "=&v"(a), "=&v"(b) : "v"(xs) : "memory");
+                            u0 = ((unsigned long long)a[1] << 32) | a[0]; u1 = ((unsigned long long)a[3] << 32) | a[2];
+                            u2 = ((unsigned long long)b[1] << 32) | b[0]; u3 = ((unsigned long long)b[3] << 32) | b[2];
+                        } else { u0 = w_ld_dev(xs); u1 = w_ld_dev(xs + 1); u2 = w_ld_dev(xs + 2); u3 = w_ld_dev(xs + 3); }
+                    }
                     const bool ok = !live || ((unsigned)u0 == tag && (unsigned)u1 == tag && (unsigned)u2 == tag && (unsigned)u3 == tag);
                     if (__ballot(!ok) == 0ull) break;
+                    if (backoff) __builtin_amdgcn_s_sleep(4);
                     if ((++spins & 255) == 0 && (spins > 2000000 || __hip_atomic_load(q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                         if (lane == 0) { __hip_atomic_store(q.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
                         break;
                     }
                 }
+                if (wstamp) { dbg[24 + wave] = clock64(); dbg[32 + wave] = spins; }      // (its messages are in)
                 const double v1 = live ? __hiloint2double((int)(u2 >> 32), (int)(u0 >> 32)) : 0.0;
                 const double v2 = live ? __hiloint2double((int)(u3 >> 32), (int)(u1 >> 32)) : 0.0;
                 S1 = w_row16_sum(v1); S2 = w_row16_sum(v2);
@@ -316,6 +327,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             }
         }
         if (stamp) dbg[1] = clock64();
+        if (wstamp) dbg[40 + wave] = clock64();
         lds_barrier();                                                                             // #1 statistics ready
         if (s_abort) break;
         // ================= P2: first layer (wave: its 32 units), transposed: D[unit][row] = sum_d W0[unit][d] xn[row][d]
@@ -499,7 +511,7 @@ __global__ void copy_column_kernel(const float* __restrict__ src, int ld, float*
 }
 
 __global__ void zero_wide_xchg_kernel(uint32_t* p) {
-    for (int i = threadIdx.x; i < WX_WORDS; i += 512) p[i] = 0u;
+    for (int i = blockIdx.x * 512 + threadIdx.x; i < WX_WORDS; i += 512 * gridDim.x) p[i] = 0u;
 }
 
 }  // namespace xrl
@@ -529,7 +541,7 @@ extern "C" int xrl_rollout_wide_run(const xrl_rollout_wide_t* qq, xrl_stream_t s
     XRL_CHECK_ARG(q.out_act == XRL_ACT_NONE || q.out_act == XRL_ACT_TANH);
     const int n_wg = (q.n + WR - 1) / WR + 1;                           // actors + the bookkeeper
     XRL_CHECK_ARG(n_wg <= device_cu_count() / 8);
-    hipLaunchKernelGGL(zero_wide_xchg_kernel, dim3(1), dim3(512), 0, as_stream(stream), q.xchg);
+    hipLaunchKernelGGL(zero_wide_xchg_kernel, dim3(16), dim3(512), 0, as_stream(stream), q.xchg);
     XRL_ACT_DISPATCH(q.act,
         if (q.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((wide_rollout_kernel<ACT, XRL_ACT_TANH>), dim3(8 * n_wg), dim3(WTH), 0, as_stream(stream), q);
         else hipLaunchKernelGGL((wide_rollout_kernel<ACT, XRL_ACT_NONE>), dim3(8 * n_wg), dim3(WTH), 0, as_stream(stream), q);)
