@@ -39,11 +39,6 @@ for whole in (True, False):
         r["actor_launch_us"] = round(bench._event_time_us(lambda: wr.run(0, T), 5), 1)
         M, A, f = n * T, 6, agent.memory.soa.fields
         r["values_pass_us"] = round(bench._event_time_us(lambda: (agent.model.forward(f["observations"].view(M, -1), M)), 5), 1)
-        r["variants_us (spread, backoff, 16-byte loads)"] = {}
-        for spread in (0, 1, 2, 3):
-            for bits in (0, 0x100, 0x200, 0x300):
-                fl = (spread << 4) | bits
-                r["variants_us (spread, backoff, 16-byte loads)"]["%d %d %d" % (spread, bits >> 8 & 1, bits >> 9 & 1)] = round(bench._event_time_us(lambda: wr.run(0, T, flags=fl), 3), 1)
         fl = int(os.environ.get("WIDE_FLAGS", "0"), 0)
         dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
         wr.run(0, T, flags=fl, dbg=dbg); torch.cuda.synchronize()

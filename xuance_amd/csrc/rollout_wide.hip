@@ -21,7 +21,6 @@
 namespace xrl {
 
 typedef float wf32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WR = 16;                    // envs per workgroup
 constexpr int WH = 256;                   // hidden width
@@ -32,11 +31,11 @@ constexpr int WTH = 512;                  // threads per workgroup (8 waves, all
 constexpr int WMAXWG = 16;
 // exchange scratch (32-bit words): two slots of WSLOT 8-byte units -- unit ((d * 16 + wg) * 4 + k), k = lo s1, lo s2, hi s1, hi s2 of
 // dimension d; progress words; XCC mask
-// (a dimension's 16 x 4 units are 512 bytes; flags bits 4..6 spread the dimensions further apart -- 512 B << s -- so that the
-//  128 polling waves of a step do not all queue on two or three L2 channels)
-constexpr int WUNITS = 16 * 4, WSPREAD_MAX = 3;
-constexpr int WSLOT_MAX = WDM * (WUNITS << WSPREAD_MAX);
-constexpr int WX_DONE = 4 * WSLOT_MAX, WX_MASK = WX_DONE + 32, WX_WORDS = WX_DONE + 64;
+// (measured, r04: spreading the dimensions over more L2 channels, 16-byte polling loads and a back-off between polling rounds
+//  all leave the launch time unchanged -- the wait is the message's flight, not a queue)
+constexpr int WUNITS = 16 * 4;
+constexpr int WSLOT = WDM * WUNITS;
+constexpr int WX_DONE = 4 * WSLOT, WX_MASK = WX_DONE + 32, WX_WORDS = WX_DONE + 64;
 
 template <int CTRL>
 __device__ __forceinline__ double wdpp(double v) {
@@ -136,14 +135,14 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     __shared__ __attribute__((aligned(16))) float pmu[8][WR][WAM];       // partial pre-activations of the mean [wave][row][action]
     __shared__ __attribute__((aligned(16))) float s_act[WR][WAM];        // sampled actions of the step
     __shared__ __attribute__((aligned(16))) float s_zn[2][WR][WAM];      // standard normals of the action draw, by step parity
-    __shared__ float s_amat[WDM * WDM], s_bmat[WAM * WDM];
+    __shared__ __attribute__((aligned(16))) float s_amatT[WDM][WDM], s_bmatT[WDM][WAM];   // provider matrices, transposed: [output][input]
     // the small parameters (first layer, both hidden biases, head rows): read from here every step -- only the 256 x 256 layer's
     // 128 fragment registers per lane stay resident (with the small ones in registers as well the kernel spilled 42 VGPRs)
     __shared__ float s_w0[WH * WDM], s_b0[WH], s_b1[WH], s_w2[WAM * WH];
     __shared__ float s_head[3][WAM];                                     // head bias | std | log std per action
     __shared__ int s_fin[WR][2];                                         // episodes finished in this launch: count, steps
     __shared__ double s_fin_score[WR];
-    __shared__ float s_y0[WR], s_pen[WR];
+    __shared__ float s_y0[WR];
     __shared__ int s_trunc[WR];
     __shared__ int s_abort, s_multi;
 
@@ -166,10 +165,10 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     const int ir = item ? it_ / D : 0, id = item ? it_ - ir * D : 0, ie = e0 + ir;
     const bool item_ok = item && ie < n;
     int ep_steps = 0;
-    float ep_score = 0.f, rtrack = 0.f;
+    float ep_score = 0.f, rtrack = 0.f, row_pen = 0.f;
     // ---- one-time loads
-    for (int i = tid; i < D * D; i += WTH) s_amat[i] = q.Amat[i];
-    for (int i = tid; i < A * D; i += WTH) s_bmat[i] = q.Bmat[i];
+    for (int i = tid; i < WDM * WDM; i += WTH) { const int o = i / WDM, kk = i - o * WDM; s_amatT[o][kk] = (o < D && kk < D) ? q.Amat[kk * D + o] : 0.f; }
+    for (int i = tid; i < WDM * WAM; i += WTH) { const int o = i / WAM, j = i - o * WAM; s_bmatT[o][j] = (o < D && j < A) ? q.Bmat[j * D + o] : 0.f; }
     for (int i = tid; i < WR * WDM; i += WTH) {
         const int r = i / WDM, d = i - r * WDM;
         const bool ok = d < D && e0 + r < n;
@@ -177,7 +176,9 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
         s_st[r][d] = ok ? q.env_state[(size_t)(e0 + r) * D + d] : 0.f;
     }
     if (tid < 2 * WDM) s_norm[tid / WDM][tid % WDM] = tid < WDM ? 0.f : 1.f;
-    if (item_ok && id == 0) { ep_steps = q.env_steps[ie]; ep_score = q.env_score[ie]; rtrack = q.ret_track[ie]; }
+    // per-row episode counters: wave 0's lanes 0..15 (row = lane) -- the wave that samples also keeps the books of the rows
+    const bool rowl = tid < WR, row_ok = rowl && e0 + tid < n;
+    if (row_ok) { ep_steps = q.env_steps[e0 + tid]; ep_score = q.env_score[e0 + tid]; rtrack = q.ret_track[e0 + tid]; }
     if (tid == 0) { s_abort = 0; s_multi = (q.flags & 1) ? 1 : 0; }
     // weights: the middle layer's rows of this wave's hidden units [32 wave, +32) (two 16-unit tiles) in registers; the rest in LDS
     float4 w1f[2][16];
@@ -197,8 +198,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     double st_cnt = 0.0;
     if (use_norm && sd_ok) { st_mean = q.obs_mean[sd_]; st_var = q.obs_var[sd_]; st_cnt = *q.obs_count; }
     unsigned long long* xu = reinterpret_cast<unsigned long long*>(q.xchg);
-    const int spread = min((q.flags >> 4) & 7, WSPREAD_MAX), ustride = WUNITS << spread, WSLOT = WDM * ustride;
-    const bool backoff = (q.flags & 0x100) != 0, wide_ld = (q.flags & 0x200) != 0;
+    constexpr int ustride = WUNITS;
     const uint32_t pstep0 = q.step + (q.step_dev ? *q.step_dev : 0u) + (uint32_t)t0;        // Philox step of the policy's draws
     const uint32_t estep0 = q.env_step + (q.env_step_dev ? *q.env_step_dev : 0u) + (uint32_t)t0;   // ... of the simulator's noise
     if (tid < WAM) {
@@ -225,27 +225,41 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             if (dev) w_st_dev(dst, m); else *dst = m;
         }
     };
-    // action noise of step k (Philox stream of xrl_policy_sample) -> s_zn, by waves 1..7's spare lanes: thread i < 16 A
-    auto draw_actions = [&](int k) {
-        const int i = tid - (WTH - WR * WAM);                  // (the last two waves: free of item threads for D <= 20)
-        if (i >= 0 && i < WR * A) {
-            const int r = i / A, j = i - r * A;
-            s_zn[k & 1][r][j] = policy_normal(q.seed, (uint32_t)(e0 + r), pstep0 + (uint32_t)k, (uint32_t)j);
-        }
+    // The normals of a step -- the simulator's noise (item threads) and the action draws (Philox stream of xrl_policy_sample; the
+    // last two waves' threads i < 16 A, free of item threads for D <= 20) -- depend on nothing the step computes: one Philox call
+    // per thread, written WITHOUT a branch so that the step loop can issue it between the middle layer's MFMAs (the matrix pipe
+    // bounds that phase; the vector slots beside it are idle) one step ahead.
+    const int di = tid - (WTH - WR * WAM);
+    const bool drawer = di >= 0 && di < WR * A;
+    const int dr = drawer ? di / A : 0, dj = drawer ? di - dr * A : 0;
+    const uint64_t nz_seed = drawer ? q.seed : q.env_seed;
+    const uint32_t nz_env = drawer ? (uint32_t)(e0 + dr) : (uint32_t)ie;
+    const uint32_t nz_stream = drawer ? 0x47415500u + (uint32_t)dj : 0x53594E00u + (uint32_t)id;
+    const uint32_t nz_step0 = drawer ? pstep0 : estep0;
+    const float nz_floor = drawer ? 5.96e-8f : 1e-7f, nz_scale = drawer ? 1.f : 0.01f;     // (policy_normal | 0.01 provider_normal)
+    auto step_normal = [&](int k) {
+        uint32_t r[4];
+        philox4x32(nz_seed, nz_env, nz_step0 + (uint32_t)k, nz_stream, r);
+        const float u1 = fmaxf(u01(r[0]), nz_floor), u2 = u01(r[1]);
+        return nz_scale * (__builtin_amdgcn_sqrtf(-2.f * __logf(u1)) * __builtin_amdgcn_cosf(u2));
     };
-    // What step k's dynamics need that does not depend on its action -- the simulator's noise, the state's part of the
-    // pre-activation -- and the step's action normals: computed while the statistics messages of the step are in flight (behind
-    // publish(), in front of the poll), i.e. off the step chain
+    // the state's part of the dynamics' pre-activation (sum over kk in order, as xrl_synth_control_step): behind publish(), in front
+    // of the poll -- off the step chain
     float noise = 0.f, pre_s = 0.f;
-    auto prepare = [&](int k) {
+    auto prepare = [&]() {
         if (item) {
-            noise = 0.01f * provider_normal(q.env_seed, (uint32_t)ie, estep0 + (uint32_t)k, 0x53594E00u + (uint32_t)id);
             float acc = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < WDM; ++kk) if (kk < D) acc += s_st[ir][kk] * s_amat[kk * D + id];
+            for (int c = 0; c < WDM / 4; ++c) {
+                const float4 sv = *reinterpret_cast<const float4*>(&s_st[ir][4 * c]);
+                const float4 av = *reinterpret_cast<const float4*>(&s_amatT[id][4 * c]);
+                if (4 * c + 0 < D) acc += sv.x * av.x;
+                if (4 * c + 1 < D) acc += sv.y * av.y;
+                if (4 * c + 2 < D) acc += sv.z * av.z;
+                if (4 * c + 3 < D) acc += sv.w * av.w;
+            }
             pre_s = acc;
         }
-        draw_actions(k);
     };
     bool multi = true;                                           // until the placement is known: device-scope message stores
     if (use_norm) {
@@ -262,7 +276,12 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             publish(1u, true);
         }
     }
-    prepare(0);
+    {
+        const float z0 = step_normal(0);
+        if (drawer) s_zn[0][dr][dj] = z0;
+        noise = z0;
+    }
+    prepare();
 
     int k = 0;
     for (; k < n_steps; ++k) {
@@ -284,18 +303,9 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
                 unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0;
                 int spins = 0;
                 for (;;) {
-                    if (live) {
-                        if (wide_ld) {                           // two 16-byte device-scope loads (each 8-byte unit is still one message)
-                            wu32x4 a, b;
-                            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                                         : "=&v"(a), "=&v"(b) : "v"(xs) : "memory");
-                            u0 = ((unsigned long long)a[1] << 32) | a[0]; u1 = ((unsigned long long)a[3] << 32) | a[2];
-                            u2 = ((unsigned long long)b[1] << 32) | b[0]; u3 = ((unsigned long long)b[3] << 32) | b[2];
-                        } else { u0 = w_ld_dev(xs); u1 = w_ld_dev(xs + 1); u2 = w_ld_dev(xs + 2); u3 = w_ld_dev(xs + 3); }
-                    }
+                    if (live) { u0 = w_ld_dev(xs); u1 = w_ld_dev(xs + 1); u2 = w_ld_dev(xs + 2); u3 = w_ld_dev(xs + 3); }
                     const bool ok = !live || ((unsigned)u0 == tag && (unsigned)u1 == tag && (unsigned)u2 == tag && (unsigned)u3 == tag);
                     if (__ballot(!ok) == 0ull) break;
-                    if (backoff) __builtin_amdgcn_s_sleep(4);
                     if ((++spins & 255) == 0 && (spins > 2000000 || __hip_atomic_load(q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                         if (lane == 0) { __hip_atomic_store(q.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
                         break;
@@ -360,6 +370,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
         lds_barrier();                                                                             // #2 h1 ready
         if (stamp) dbg[2] = clock64();
         // ================= P3: middle layer (this wave's 32 units over all 256 inputs) + its share of the mean's pre-activation
+        float nz_next;
         {
             wf32x4 acc[2][2];
 #pragma unroll
@@ -368,6 +379,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
                 acc[j][0] = (wf32x4){bb.x, bb.y, bb.z, bb.w}; acc[j][1] = (wf32x4){0.f, 0.f, 0.f, 0.f};
             }
             const float* hrow = h1 + cl * WLD + 4 * g;
+            nz_next = step_normal(k + 1);                        // (vector work for the slots between the MFMAs below)
 #pragma unroll
             for (int c4 = 0; c4 < 16; c4 += 4) {
                 float4 hf[4];
@@ -382,6 +394,10 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
                     WMFMA(w1f[0][cc].w, hf[c].w, acc[0][par]); WMFMA(w1f[1][cc].w, hf[c].w, acc[1][par]);
                 }
             }
+            // (pin the pattern: one MFMA, then up to three of the normal's vector instructions, while those last)
+#pragma unroll
+            for (int i = 0; i < 44; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+            __builtin_amdgcn_sched_barrier(0);
             wf32x4 lg = {0.f, 0.f, 0.f, 0.f}, lg2 = {0.f, 0.f, 0.f, 0.f};
             // head: A[m = action cl][k = unit 4 g + i] from the LDS copy (rows >= A are zero)
             const float4 wa = *reinterpret_cast<const float4*>(&s_w2[min(cl, WAM - 1) * WH + 32 * wave + 4 * g]);
@@ -394,8 +410,10 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
                 WMFMA(whb[i], act_apply_c<ACT>(acc[1][0][i] + acc[1][1][i]), lg2);
             }
             // lg[i] of lane (g, cl) = partial pre-activation of action 4 g + i, row cl
+            asm volatile("" : "+v"(nz_next));                    // (keeps the normal's instructions in THIS block: the compiler sinks them to the use)
             if (g < 2) *reinterpret_cast<float4*>(&pmu[wave][cl][4 * g]) = make_float4(lg[0] + lg2[0], lg[1] + lg2[1], lg[2] + lg2[2], lg[3] + lg2[3]);
         }
+        if (drawer) s_zn[(k + 1) & 1][dr][dj] = nz_next;           // (read in P4 of step k + 1; P4 of this step reads the other parity)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores of the previous step are in L2 (long since)
         lds_barrier();                                                                             // #3 partial means ready
         if (tid == 64 && k > 0) w_st_dev(q.xchg + WX_DONE + wg, (unsigned)k);       // steps < k complete (trailing readers)
@@ -422,62 +440,60 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             }
             lp += __shfl_xor(lp, 16, 64); lp += __shfl_xor(lp, 32, 64);
             if (g == 0 && e0 + cl < n) q.f_logp[(size_t)t * n + e0 + cl] = lp;
+            if (rowl) {                                          // the row's truncation flag and action penalty (sum over j in order)
+                s_trunc[tid] = (ep_steps + 1 >= q.max_steps) ? 1 : 0;
+                float pen = 0.f;
+#pragma unroll
+                for (int j = 0; j < WAM; ++j) if (j < A) { const float ai = fminf(fmaxf(s_act[tid][j], -1.f), 1.f); pen += ai * ai; }
+                row_pen = pen;
+            }
         }
         lds_barrier();                                                                             // #4 actions ready
         if (stamp) dbg[4] = clock64();
-        // ================= P5: dynamics (item threads), records, next raw observations; action noise of the next step
+        // ================= P5: dynamics (item threads), next raw observations / state
         if (item) {
-            float acc = pre_s, pen = 0.f;
+            float acc = pre_s;
+            const float4 a0 = *reinterpret_cast<const float4*>(&s_act[ir][0]), a1 = *reinterpret_cast<const float4*>(&s_act[ir][4]);
+            const float4 b0 = *reinterpret_cast<const float4*>(&s_bmatT[id][0]), b1 = *reinterpret_cast<const float4*>(&s_bmatT[id][4]);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int j = 0; j < WAM; ++j) {
-                if (j < A) {
-                    const float ai = fminf(fmaxf(s_act[ir][j], -1.f), 1.f);
-                    pen += ai * ai;
-                    acc += ai * s_bmat[j * D + id];
-                }
-            }
+            for (int j = 0; j < WAM; ++j) if (j < A) acc += fminf(fmaxf(av[j], -1.f), 1.f) * bv[j];
             const float y = provider_tanh(acc) + noise;
-            if (id == 0) { s_y0[ir] = y; s_pen[ir] = pen; s_trunc[ir] = (ep_steps + 1 >= q.max_steps) ? 1 : 0; }
-            // (the row's truncation flag: every item thread of the row needs it -- through LDS, read behind the wave-local wait below)
+            if (id == 0) s_y0[ir] = y;
             // next observation before the reset, normalised with this step's statistics (get_terminated_values' input)
             if (item_ok) {
                 float xv = y;
                 if (use_norm) xv = fminf(fmaxf((xv - s_norm[0][id]) * s_norm[1][id], -obs_range), obs_range);
                 q.xnext[((size_t)t * n + ie) * D + id] = xv;
             }
-            // (the row's truncation flag lives with its id == 0 thread, possibly in another wave: through LDS, the state update waits for
-            //  barrier #5a below)
-            noise = y;                                           // (carried across the barrier)
-        }
-        lds_barrier();                                                                             // #5a y0 / pen / truncation of every row
-        if (item) {
-            const float y = noise;
-            const bool trunc = s_trunc[ir] != 0;
             float v = y;
-            if (trunc) v = 0.1f * provider_normal(q.env_seed, (uint32_t)ie, estep0 + (uint32_t)k, 0x53594E00u + 64u + (uint32_t)id);
+            if (s_trunc[ir] != 0) v = 0.1f * provider_normal(q.env_seed, (uint32_t)ie, estep0 + (uint32_t)k, 0x53594E00u + 64u + (uint32_t)id);
             s_st[ir][id] = v; s_raw[ir][id] = v;
-            if (id == 0) {
-                const float rew = s_y0[ir] - 0.1f * s_pen[ir];
-                const int steps = ep_steps + 1;
-                const float score = ep_score + rew;
-                const float tr = q.gamma * rtrack + rew;          // self.returns = gamma * self.returns + rewards
-                if (item_ok) {
-                    const int n4 = (n + 3) & ~3;
-                    const size_t o = (size_t)t * n + ie, o4 = (size_t)t * n4 + ie;
-                    q.f_term[o] = 0.f;
-                    q.f_seg[o] = (trunc || t == T - 1) ? (uint8_t)1 : (uint8_t)0;
-                    w_st_dev(q.raw_rew + o4, rew);
-                    if (trunc) w_st_dev(q.ret_final + o4, tr);
-                    w_st_dev(q.ended + o4, (uint8_t)(trunc ? 1 : 0));
-                    if (trunc) { s_fin[ir][0] += 1; s_fin[ir][1] += steps; s_fin_score[ir] += (double)score; }
-                }
-                ep_steps = trunc ? 0 : steps; ep_score = trunc ? 0.f : score; rtrack = trunc ? 0.f : tr;
-            }
         }
+        noise = nz_next;
         lds_barrier();                                                                             // #5 next raw rows ready
         if (stamp) dbg[5] = clock64();
         if (use_norm && !single && k + 1 < n_steps) publish((unsigned)(k + 2), multi);
-        if (k + 1 < n_steps) prepare(k + 1);
+        if (k + 1 < n_steps) prepare();
+        // the rows' records and episode counters (wave 0's lanes 0..15; its stores trail the message)
+        if (rowl) {
+            const bool trunc = s_trunc[tid] != 0;
+            const float rew = s_y0[tid] - 0.1f * row_pen;
+            const int steps = ep_steps + 1;
+            const float score = ep_score + rew;
+            const float tr = q.gamma * rtrack + rew;              // self.returns = gamma * self.returns + rewards
+            if (row_ok) {
+                const int n4 = (n + 3) & ~3;
+                const size_t o = (size_t)t * n + e0 + tid, o4 = (size_t)t * n4 + e0 + tid;
+                q.f_term[o] = 0.f;
+                q.f_seg[o] = (trunc || t == T - 1) ? (uint8_t)1 : (uint8_t)0;
+                w_st_dev(q.raw_rew + o4, rew);
+                if (trunc) w_st_dev(q.ret_final + o4, tr);
+                w_st_dev(q.ended + o4, (uint8_t)(trunc ? 1 : 0));
+                if (trunc) { s_fin[tid][0] += 1; s_fin[tid][1] += steps; s_fin_score[tid] += (double)score; }
+            }
+            ep_steps = trunc ? 0 : steps; ep_score = trunc ? 0.f : score; rtrack = trunc ? 0.f : tr;
+        }
         if (stamp) { dbg[6] = clock64(); dbg[15] = 7; }
     }
 
@@ -492,10 +508,11 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
         if (item_ok) {
             qa->obs_raw[(size_t)ie * D + id] = s_raw[ir][id];
             qa->env_state[(size_t)ie * D + id] = s_st[ir][id];
-            if (id == 0) {
-                qa->env_steps[ie] = ep_steps; qa->env_score[ie] = ep_score; qa->ret_track[ie] = rtrack;
-                if (s_fin[ir][0]) { atomicAdd(&qa->env_stats[0], (double)s_fin[ir][0]); atomicAdd(&qa->env_stats[1], s_fin_score[ir]); atomicAdd(&qa->env_stats[2], (double)s_fin[ir][1]); }
-            }
+        }
+        if (row_ok) {
+            const int e = e0 + tid;
+            qa->env_steps[e] = ep_steps; qa->env_score[e] = ep_score; qa->ret_track[e] = rtrack;
+            if (s_fin[tid][0]) { atomicAdd(&qa->env_stats[0], (double)s_fin[tid][0]); atomicAdd(&qa->env_stats[1], s_fin_score[tid]); atomicAdd(&qa->env_stats[2], (double)s_fin[tid][1]); }
         }
         if (wg == 0 && use_norm && sd_ok && cl == 0) {
             qa->obs_mean[sd_] = st_mean; qa->obs_var[sd_] = st_var;
