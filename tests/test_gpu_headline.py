@@ -227,6 +227,7 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
             g_, x64 = npy(got[k_]).astype(np.float64), sd64[k_]
             S = float(np.abs(x64).max())                                # the tensor's own scale
             rec[k_] = dict(hip_vs_f64=float(np.abs(g_ - x64).max() / S), f32_oracle_vs_f64=float(np.abs(v - x64).max() / S),
+                           moved=float(np.abs(x64 - sd_dev[k_].astype(np.float64)).max() / S),
                            hip_vs_f32_oracle=float(np.abs(g_ - v).max() / S),
                            hip_vs_f64_rms=float(np.sqrt(np.mean(((g_ - x64) / S) ** 2))),
                            f32_oracle_vs_f64_rms=float(np.sqrt(np.mean(((v - x64) / S) ** 2))))
@@ -243,9 +244,15 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
         # tensor whose gradient is a sum cancelling to < 1 % of its terms; every other tensor < 4x; all numbers are recorded in
         # profiles/).  The integrated check above -- every loss term of the LAST minibatch, which all 63 earlier steps feed, against the
         # float64 chain -- is the sharp assertion; a wrong step would miss this one by orders of magnitude.
-        DEV_K = 32.0
+        # Round 4 (first layer of the minibatch kernel on the matrix cores: each h1 element rounds differently in its last bit) showed
+        # the third yardstick this needs: a tensor on which the float32 ORACLE happens to sit unusually close to the float64 chain
+        # (actor.logits.2.weight: 6e-7 of its scale) says nothing about how far another float32 evaluation may land -- the engine
+        # came out at 3.0e-5 there, 0.05 % of the distance the tensor moved in these 64 updates (`moved`, recorded).  The engine may
+        # therefore also be MOVED_K of that distance from the float64 chain.
+        DEV_K, MOVED_K = 32.0, 2e-3
         for k_, r_ in rec.items():
-            assert r_["hip_vs_f64"] <= max(1e-5, DEV_K * r_["f32_oracle_vs_f64"]), f"param {k_} after {64 * (it + 1)} updates: {r_}"
+            assert r_["hip_vs_f64"] <= max(1e-5, DEV_K * r_["f32_oracle_vs_f64"], MOVED_K * r_["moved"]), \
+                f"param {k_} after {64 * (it + 1)} updates: {r_}"
         st_ = agent.learner.optimizer.read()
         assert st_.step == 64 * (it + 1)
     assert knife_total <= 2, knife_total                               # ties of a float32 cdf with a 24-bit uniform are rare

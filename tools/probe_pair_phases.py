@@ -18,7 +18,7 @@ for pair in (True, False):
     agent.rollout(); agent.update(); torch.cuda.synchronize()
     lr, mem, m = agent.learner, agent.memory, agent.model
     f, bs = mem.soa.fields, agent.batch_size
-    dbg = torch.zeros(16 + 2 * 512, dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(2048, dtype=torch.int64, device="cuda")
 
     def launch(d):
         ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=lr.params_t, cache_image=lr.cache_image,
@@ -38,6 +38,10 @@ for pair in (True, False):
         t = d[16:16 + 2 * 256].reshape(256, 2).astype(np.float64) * 10e-3      # us
         t0 = t[:, 0].min()
         print("pair: alone %.1f us; phases (cycles):" % us, dict(zip(names, ph.tolist())))
+        w = d[1100:1100 + 128].reshape(8, 16)[:, :8] - d[0]
+        print("  waves of the last workgroup (cycles from its start): small grads done | dW1 MFMAs done | dW1 stored | dH1 MFMAs done | past barrier 4 | g1 stored | past barrier 5 | end")
+        for i in range(8):
+            print("   wave", i, w[i].tolist())
         print("  workgroup start skew us: min %.2f max %.2f; durations us: min %.2f median %.2f max %.2f; last end %.2f"
               % (0.0, (t[:, 0] - t0).max(), (t[:, 1] - t[:, 0]).min(), np.median(t[:, 1] - t[:, 0]), (t[:, 1] - t[:, 0]).max(), (t[:, 1] - t0).max()))
     else:

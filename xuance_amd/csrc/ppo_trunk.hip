@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
     long long* dbg = p.dbg;                            // diagnostics (tools/probe_pair_phases.py), see the end of the kernel
     const bool dbg_me = dbg && tid == 0 && blockIdx.x == gridDim.x - 1;
 #define TSTAMP(k) do { if (dbg_me) dbg[k] = clock64(); } while (0)
+    // per-wave stamps of the last workgroup (dbg[1100 + 16 wave + k]): where each wave is inside the backward phases
+    const bool dbg_w = dbg && (tid & 63) == 0 && blockIdx.x == gridDim.x - 1;
+#define WSTAMP(k) do { if (dbg_w) dbg[1100 + 16 * (tid >> 6) + (k)] = clock64(); } while (0)
     if (dbg && tid == 0) dbg[16 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
     TSTAMP(0);
 
@@ -152,6 +155,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
         const int c = e / D, k = e - c * D;
         w0t[k * TLD + c] = p.params[L0.w_off + e];
     }
+    if ((D & 1) && tid < TH) w0t[D * TLD + tid] = 0.f;    // (the first layer's MFMAs walk k in pairs)
     if (tid < TH) b0s[tid] = p.params[L0.b_off + tid];
     else if (tid < 2 * TH) bms[tid - TH] = p.params[L1.b_off + cb + tid - TH];
     else if (tid < 2 * TH + TAMAX) {
@@ -194,25 +198,27 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
     lds_barrier();                                                                                   // #0 rows, parameters
     TSTAMP(1);
 
-    // ================= forward: first layer on the VALU (k-ordered fma chain == the MFMA result): CPT columns per thread, walked in
-    //                   an order rotated by `sub` (one instruction's reads of the TPR threads of a row fall on different banks)
-    {
-        float acc[CPT];
+    // ================= forward: first layer on the matrix cores (round 4; the VALU form -- a k-ordered fma chain per element,
+    //                   the same numbers -- took 3.7 k cycles of LDS reads at 64 rows): wave (cblk, rblk), ceil(D / 2) MFMAs
+    if (RB == 2 || wave < 4) {
+        f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
-        const float* xr = xs + r * TXLD;
-        const float* wcol = w0t + sub * CPT;
-        for (int k = 0; k < D; ++k) {
-            const float x = xr[k];
-            const float* wk = wcol + k * TLD;
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) acc[j] = __fmaf_rn(x, wk[(j + sub) % CPT], acc[j]);
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* xr = xs + (rblk * 32 + li) * TXLD + lh;            // A[i = row][k = lh + 2 s] (zero beyond D)
+        const float* wk = w0t + lh * TLD + cblk * 32 + li;              // B[k = lh + 2 s][j = column]
+        const int ns = (D + 1) >> 1;
+        if (DS == 4) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0], wk[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[2], wk[2 * TLD], acc, 0, 0, 0);
+        } else {
+            for (int s2 = 0; s2 < ns; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[2 * s2], wk[2 * s2 * TLD], acc, 0, 0, 0);
         }
-        float* dst = h1 + r * TLD + sub * CPT;
+        const int col = cblk * 32 + li;
+        const float b0v = b0s[col];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int cc = (j + sub) % CPT;
-            dst[cc] = act_apply_c<ACT>(acc[j] + b0s[sub * CPT + cc]);
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            h1[row * TLD + col] = act_apply_c<ACT>(acc[rr] + b0v);
         }
     }
     lds_barrier();                                                                                   // #1 h1
@@ -384,35 +390,38 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
     // ================= backward
     // ---- loss terms of this (tile, role): one lane per row; the actor fills surrogate / entropy / clip count, the critic the value
     //      terms -- the partials reduction adds the rows of all workgroups
-    if (wave == 7) {
-        double acc_s = 0.0, acc_c = 0.0, acc_e = 0.0, acc_v = 0.0, acc_n = 0.0;
-        if (lane < PT) { acc_s = rowstat[lane]; acc_c = rowstat[PT + lane]; acc_e = rowstat[2 * PT + lane]; acc_v = rowstat[3 * PT + lane]; acc_n = rowstat[4 * PT + lane]; }
-        acc_s = wave_sum(acc_s); acc_c = wave_sum(acc_c); acc_e = wave_sum(acc_e); acc_v = wave_sum(acc_v); acc_n = wave_sum(acc_n);
-        if (lane == 0) {
-            double* q = p.partials + (size_t)blockIdx.x * 8;
-            q[0] = acc_s; q[1] = acc_c; q[2] = acc_e; q[3] = acc_v; q[4] = acc_n; q[5] = 0; q[6] = 0; q[7] = 0;
-        }
-    }
-    // ---- head weight / bias gradients, log_std gradient, this role's branch-layer bias gradient: VALU sums over the PT rows
+    // (one statistic per wave: next to another wave's MFMAs a wave gets a vector issue slot per MFMA -- five reductions in one wave
+    //  took ~10 k cycles there and held the workgroup's last barrier)
+    if (wave < 5) {
+        double a = lane < PT ? rowstat[wave * PT + lane] : 0.0;
+        a = wave_sum(a);
+        if (lane == 0) p.partials[(size_t)blockIdx.x * 8 + wave] = a;
+    } else if (wave == 5 && lane < 3) p.partials[(size_t)blockIdx.x * 8 + 5 + lane] = 0.0;
+    // ---- head weight / bias gradients, log_std gradient, this role's branch-layer bias gradient: VALU sums over the PT rows, rows in
+    //      order.  Measured in round 4 (tools/probe_pair_phases.py, per-wave stamps): next to another wave's MFMAs a wave gets
+    //      about one vector issue slot per MFMA: a wave WITHOUT small gradients used to start the weight-gradient MFMAs below at once
+    //      and the loops of the wave it shares a SIMD with crawled (10 k cycles instead of 2-3 k, holding the workgroup's last
+    //      barrier) -- hence the barrier behind this phase.  Dealing the elements evenly to all eight waves (5.0 k cycles, every
+    //      wave) and carrying them inside the MFMA loop (13 k instead of 7.5 k for the loop) were both slower than this form.
     for (int e = tid; e < nout * TH; e += FUSED_THREADS) {
         const int j = e >> 7, k = e & (TH - 1);
         const float* hp = h2 + k;
         float acc = 0.f;
-#pragma unroll 8
+#pragma unroll 16
         for (int rr = 0; rr < PT; ++rr) acc += dzh[rr * 16 + j] * hp[rr * TLD];
         slab[Lh.w_off + e] = acc;
     }
     if (tid >= 4 * 64 && tid < 4 * 64 + TH) {
         const int t = tid - 4 * 64;
         float acc0 = 0.f;
-#pragma unroll 8
+#pragma unroll 16
         for (int rr = 0; rr < PT; ++rr) acc0 += g2[rr * TLD + t];
         slab[L1.b_off + cb + t] = acc0;
     } else if (tid >= 6 * 64 && tid < 6 * 64 + 2 * TAMAX) {
         const int t = tid - 6 * 64;                                      // 0..7 head bias, 8..15 log_std
         if (t < nout || (t >= 8 && GAUSS && actor && t - 8 < A)) {
             float acc = 0.f;
-#pragma unroll 8
+#pragma unroll 16
             for (int rr = 0; rr < PT; ++rr) acc += dzh[rr * 16 + t];
             // d(-ent_coef * mean_m sum_j(log_std_j + c)) / d log_std_j = -ent_coef, added once (tile 0), as in ppo_loss.hip / ppo_wide.hip
             if (t >= 8 && tile == 0) acc -= p.ent_coef;
@@ -420,9 +429,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
             else slab[p.log_std_off + t - 8] = acc;
         }
     }
+    WSTAMP(0);
+    lds_barrier();                                                                                   // #3b no MFMA beside a vector loop
     TSTAMP(5);
     // ---- dW1[n][k] = sum over the PT rows of g2[row][n] * h1[row][k] for this role's 128 rows n: 4 x 4 tiles of 32 x 32, wave w owns
     //      n-tile (w & 3) and the k-tiles 2 (w >> 2), 2 (w >> 2) + 1; PT / 2 chained MFMAs per tile, rows in order
+    f32x16 dacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
     {
         const int nt = wave & 3, kt0 = 2 * (wave >> 2);
         f32x16 acc[2];
@@ -441,7 +455,27 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
             }
         }
+        if (dbg_w) { float t_ = acc[1][15]; asm volatile("" ::"v"(t_)); }
+        TSTAMP(6);
+        WSTAMP(1);
+        // ---- this role's part of dH1 = g2 . W1 (sum over its 128 rows n): wave (cblk, rblk) owns output columns [32 cblk, +32) of
+        //      rows [32 rblk, +32); B operand = the backward fragments requested after the forward layer.  The result (times act'(h1))
+        //      goes where h2 was: every wave is past its last read of h2 once it is through the barrier below.
+        //      The 32 stores of this wave's dW1 tiles are issued BETWEEN these MFMAs, one per two (round 4: issued in one burst behind
+        //      the weight-gradient loop, the eight waves' 64 KB queued on the CU's ~10 B/clk store path and the waves stood 1-6 k
+        //      cycles in front of their next MFMA).
         float* dW = slab + L1.w_off + (size_t)(cb + nt * 32) * TH;
+        if (RB == 2 || wave < 4) {
+            const float* arow2 = g2 + (rblk * 32 + li) * TLD + 4 * lh;
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                float4 af[PD / 2];
+#pragma unroll
+                for (int i = 0; i < PD / 2; ++i) af[i] = *reinterpret_cast<const float4*>(arow2 + (hq * 8 + i) * 8);
+#pragma unroll
+                for (int i = 0; i < PD / 2; ++i) { MFMA4(af[i], pf[hq * 8 + i], dacc) }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -449,26 +483,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
                 const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
                 dW[(size_t)row * TH + (kt0 + t) * 32 + li] = acc[t][rr];
             }
-    }
-    TSTAMP(6);
-    // ---- this role's part of dH1 = g2 . W1 (sum over its 128 rows n): wave (cblk, rblk) owns output columns [32 cblk, +32) of rows
-    //      [32 rblk, +32); B operand = the backward fragments requested after the forward layer.  The result (times act'(h1)) goes
-    //      where h2 was: every wave is past its last read of h2 (head gradients above) once it is through the barrier below.
-    f32x16 dacc;
+        if (RB == 2) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
-    if (RB == 2 || wave < 4) {
-        const float* arow = g2 + (rblk * 32 + li) * TLD + 4 * lh;
-#pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-            float4 af[PD / 2];
-#pragma unroll
-            for (int i = 0; i < PD / 2; ++i) af[i] = *reinterpret_cast<const float4*>(arow + (hq * 8 + i) * 8);
-#pragma unroll
-            for (int i = 0; i < PD / 2; ++i) { MFMA4(af[i], pf[hq * 8 + i], dacc) }
+            for (int i = 0; i < 32; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); }
         }
     }
+    if (dbg_w) { float t_ = dacc[15]; asm volatile("" ::"v"(t_)); }
+    WSTAMP(3);
     lds_barrier();                                                                                   // #4 h2 is free
+    WSTAMP(4);
     if (RB == 2 || wave < 4) {
         const int k_out = cblk * 32 + li;
 #pragma unroll
@@ -477,8 +500,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
             xb[row * TLD + k_out] = dacc[rr] * act_grad_c<ACT>(h1[row * TLD + k_out]);
         }
     }
+    WSTAMP(5);
     lds_barrier();                                                                                   // #5 g1 (this role's part)
     TSTAMP(7);
+    WSTAMP(6);
     // ---- first layer: dW0[c][k] = sum_rows g1[row][c] * x[row][k], db0[c] -- the actor's part into the slab's first-layer region,
     //      the critic's into the fold region behind the parameters (the reduction adds it onto the same columns).
     //      thread = (column c, row half lh, component range by wave >> 2): halves met by a lane shuffle; the components in float2 chunks
@@ -513,11 +538,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
         if (lh == 0 && (wave >> 2) == 0) dst[b_at + c] = ab;
     }
     TSTAMP(8);
+    WSTAMP(7);
     if (dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this thread's stores are out
         dbg[17 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 #undef TSTAMP
+#undef WSTAMP
 }
 
 // the family: widths [D, 128, 256, A + 1] with D <= 24, A <= 8, the first layer at the front of the flat layout (the fold region maps
