@@ -58,6 +58,11 @@ int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n_envs, int 
 /* ... and *size_dev <- new_size in the same launch (the filled-slot count of a replay ring that device-side sampling follows) */
 int xrl_soa_store_step_sized(const xrl_field_t* fields, int n_fields, int n_envs, int t, int32_t* size_dev, int32_t new_size,
                              xrl_stream_t stream);
+/* The same store with the ring slot taken from a device counter (a captured vector step: the arguments do not change from step to
+ * step): c = *counter_dev + offset; slot = (slot_bias + c) mod n_size; *size_dev = min(size_bias + c + 1, n_size).  The counter
+ * is only read (the caller advances it with a launch of its own). */
+int xrl_soa_store_step_ring(const xrl_field_t* fields, int n_fields, int n_envs, int n_size, int64_t slot_bias, int64_t size_bias,
+                            const int32_t* counter_dev, int32_t offset, int32_t* size_dev, xrl_stream_t stream);
 
 /* DummyOnPolicyBuffer.finish_path for every env and every closed path segment at once
  * (memory_tools.py:242-265, call sites ppo_agent.py:129-135,146-157).
@@ -927,7 +932,14 @@ typedef struct {
     uint64_t seed;
     uint32_t step;
     int32_t n, A, H, F, P, ld_q, ld_f, act;
-    float eps;                 /* used when eps_dev is NULL */
+    float eps;                 /* used when eps_dev is NULL and eps_sched is 0 */
+    /* eps_sched != 0: epsilon of vector step k = step + *step_dev computed HERE, the host's own arithmetic (off_policy.py:119-127:
+     * e_greedy = start_greedy - current_step * delta_egreedy in float64 while the previous value is above end_greedy; current_step
+     * = k * eps_n): e = (float)(eps_start - (double)(min(k, eps_kstar) * eps_n) * eps_delta), eps_kstar = the first k whose value
+     * is <= end_greedy (a host constant).  What a captured vector step needs: no argument changes from step to step. */
+    int32_t eps_sched, eps_n;
+    uint32_t eps_kstar, pad1;
+    double eps_start, eps_delta;
 } xrl_dqn_act_tail_t;
 int xrl_dqn_act_tail(const xrl_dqn_act_tail_t* p, xrl_stream_t stream);
 int xrl_dqn_head_td(const xrl_dqn_head_td_t* p, xrl_stream_t stream);

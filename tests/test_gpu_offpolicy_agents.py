@@ -281,6 +281,45 @@ def test_dqn_agent_on_atari_shape():
     assert torch.equal(agent.memory.soa.fields["next_observations"][t], env.next_obs)
 
 
+def test_dqn_vector_step_pair_graph_equals_the_launch_by_launch_loop():
+    """DQN_Agent.train with two vector steps per graph launch (acting with epsilon from the step counter, provider, ring store with
+    the slot from the counter, update phase -- DQN_Agent._run_pair) against the launch-by-launch loop: identical parameters, target,
+    ring contents, counters and epsilon after the same number of steps -- across the ring's wrap-around, the end of the epsilon decay
+    and an odd number of steps (the launch-by-launch loop takes over between pairs)."""
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    n = 16
+    out = []
+    for pair in (True, False):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = Namespace(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                        q_hidden_size=[512], activation="relu", seed=1, parallels=n, running_steps=10 ** 6,
+                        buffer_size=n * 24, batch_size=32, learning_rate=1e-4, gamma=0.99, start_greedy=0.5, end_greedy=0.05,
+                        decay_step_greedy=n * n * 30, sync_frequency=7, training_frequency=1, start_training=n * 4,
+                        use_grad_clip=True, grad_clip_norm=0.5, use_obsnorm=False, use_rewnorm=False,
+                        distributed_training=False, device="cuda", model_dir="/tmp/x", use_step_graph=pair)
+        env = SyntheticAtariVecEnv(n, seed=2, max_episode_steps=11)
+        agent = DQN_Agent(cfg, env)
+        infos = [agent.train(9), agent.train(21), agent.train(12)]         # 42 steps: ring of 24 slots wraps, epsilon bottoms out at ~30
+        torch.cuda.synchronize()
+        assert (getattr(agent, "_pair_graph", None) is not None) == pair
+        mem = agent.memory
+        out.append(dict(params=agent.model.params.flat.cpu().numpy().copy(), target=agent.model.target_flat.cpu().numpy().copy(),
+                        fields={k: v.cpu().numpy().copy() for k, v in mem.soa.fields.items()}, ptr=mem.ptr, size=mem.size,
+                        size_dev=int(mem.size_dev.item()), eps=agent.e_greedy, cs=agent.current_step, hs=agent._host_step,
+                        it=agent.learner.iterations, obs=env.buf_obs.cpu().numpy().copy(), steps=env.steps.cpu().numpy().copy(),
+                        q=[(i["Qloss"], i["predictQ"]) for i in infos], opt=int(agent.learner.optimizer.read().step)))
+    a, b = out
+    for k in ("ptr", "size", "size_dev", "eps", "cs", "hs", "it", "q", "opt"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    assert a["eps"] <= 0.05 and a["size"] == 24
+    for k in ("params", "target", "obs", "steps"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in a["fields"]:
+        assert np.array_equal(a["fields"][k], b["fields"][k]), k
+
+
 @pytest.mark.parametrize("mode", ["ring", "gathered", "layered"])
 def test_qmix_graph_update_phase_equals_eager_updates_on_the_same_indices(mode):
     """QMIX_Learner.update_from_buffer (device sampling + gather + update, n_epochs per hipGraph launch) vs

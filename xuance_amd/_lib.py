@@ -52,7 +52,9 @@ class DqnTailTd(C.Structure):
 class DqnActTail(C.Structure):
     _fields_ = [(k, c_void_p) for k in ("y", "w1", "b1", "w2", "b2", "eps_dev", "action", "action_f", "q", "feat", "step_dev")] + \
                [("seed", C.c_uint64), ("step", C.c_uint32)] + \
-               [(k, c_int32) for k in ("n", "A", "H", "F", "P", "ld_q", "ld_f", "act")] + [("eps", c_float)]
+               [(k, c_int32) for k in ("n", "A", "H", "F", "P", "ld_q", "ld_f", "act")] + [("eps", c_float)] + \
+               [("eps_sched", c_int32), ("eps_n", c_int32), ("eps_kstar", C.c_uint32), ("pad1", C.c_uint32),
+                ("eps_start", C.c_double), ("eps_delta", C.c_double)]
 
 
 class ImageJob(C.Structure):
@@ -406,6 +408,7 @@ _SIGS = {
     "xrl_device_info": [C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_int],
     "xrl_soa_store_step": [C.POINTER(Field), c_int, c_int, c_int, c_void_p],
     "xrl_soa_store_step_sized": [C.POINTER(Field), c_int, c_int, c_int, c_void_p, c_int32, c_void_p],
+    "xrl_soa_store_step_ring": [C.POINTER(Field), c_int, c_int, c_int, C.c_int64, C.c_int64, c_void_p, c_int32, c_void_p, c_void_p],
     "xrl_gae_scan": [c_void_p] * 7 + [c_int, c_int, c_double, c_double, c_int, c_void_p],
     "xrl_adv_stats": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "xrl_soa_gather": [C.POINTER(Field), c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

@@ -105,44 +105,19 @@ class DQN_Agent(AgentSurface):
                           normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
 
     def train(self, train_steps):
-        env, n, A = self.envs, self.n_envs, self.action_space.n
+        env = self.envs
         if not self._started:
             env.reset()
             self._started = True
         info = {}
-        zero_copy = self.atari and getattr(env, "double_buffered", False)     # uint8 frames go to the ring as they are
-        shp = (n,) + tuple(self.obs_shape)
-        for _ in range(train_steps):
-            if zero_copy:
-                X = env.buf_obs.view(n, -1)                   # stays intact over step_device(): the env alternates buffers
-            else:
-                self._normalize(env.buf_obs if self.atari else env.buf_obs.float(), self.X, update=True)   # obs_rms.update; process
-                X = self.X
-            if self._act_fused:                                    # (convolutional Q network: pool .. epsilon-greedy in one launch)
-                self.model.act_egreedy(X[:n], n, None, env.action, self.act_f, self.seed, self._host_step, eps=float(self.e_greedy))
-            else:
-                q = self.model.forward(X[:n], n)
-                ops.egreedy(q=q, eps_dev=None, eps=float(self.e_greedy), action=env.action, action_f=self.act_f, n=n, A=A, ld=q.stride(0), seed=self.seed,
-                            step=self._host_step, step_dev=None)   # eager loop: the host knows the step index
-            env.step_device()
-            self._host_step += 1
-            if zero_copy:
-                Xn = env.next_obs.view(n, -1)
-            else:
-                self._normalize(env.next_obs if self.atari else env.next_obs.float(), self.Xn, update=False)
-                Xn = self.Xn
-            # off_policy.py:221-224 (device tensors: nothing is copied or synchronised unless the callback reads them)
-            self._cb("on_train_step", self.current_step, envs=env, model=self.model, obs=X.view(shp), acts=self.act_f,
-                     next_obs=Xn.view(shp), rewards=env.reward, terminals=env.terminated, truncations=getattr(env, "truncated", None),
-                     infos=None, train_steps=train_steps)
-            self.memory.store(X.view(shp), self.act_f, env.reward, env.terminated, Xn.view(shp))
-            if self.current_step > self.start_training and self.current_step % self.training_frequency == 0:
-                info = self._train_epochs(train_steps) or info
-                self._cb("on_train_epochs_end", self.current_step, model=self.model, memory=self.memory, train_steps=train_steps,
-                         update_info=info)                          # :232-234
-            self.current_step += n
-            self._update_explore_factor()
-            self._cb("on_train_step_end", self.current_step, envs=env, model=self.model, train_steps=train_steps, train_info=info)   # :268-269
+        left = train_steps
+        while left > 0:
+            if left >= 2 and self._pair_ready():
+                self._run_pair()
+                left -= 2
+                continue
+            info = self._eager_step(train_steps, info)
+            left -= 1
         if self.use_graph_updates and hasattr(self.learner, "flush_info"):
             info = dict(self.learner.flush_info() or info)      # the one host read of this call (phases ran unsynchronised)
         if hasattr(env, "episode_stats"):
@@ -150,6 +125,114 @@ class DQN_Agent(AgentSurface):
             info.update({"episodes": eps, "mean_episode_score": score, "mean_episode_length": length})
         info["epsilon"] = self.e_greedy
         return info
+
+    def _eager_step(self, train_steps, info):
+        """One vector step, launch by launch (off_policy.py:207-269)."""
+        env, n, A = self.envs, self.n_envs, self.action_space.n
+        zero_copy = self.atari and getattr(env, "double_buffered", False)     # uint8 frames go to the ring as they are
+        shp = (n,) + tuple(self.obs_shape)
+        if zero_copy:
+            X = env.buf_obs.view(n, -1)                   # stays intact over step_device(): the env alternates buffers
+        else:
+            self._normalize(env.buf_obs if self.atari else env.buf_obs.float(), self.X, update=True)   # obs_rms.update; process
+            X = self.X
+        if self._act_fused:                                    # (convolutional Q network: pool .. epsilon-greedy in one launch)
+            self.model.act_egreedy(X[:n], n, None, env.action, self.act_f, self.seed, self._host_step, eps=float(self.e_greedy))
+        else:
+            q = self.model.forward(X[:n], n)
+            ops.egreedy(q=q, eps_dev=None, eps=float(self.e_greedy), action=env.action, action_f=self.act_f, n=n, A=A, ld=q.stride(0), seed=self.seed,
+                        step=self._host_step, step_dev=None)   # eager loop: the host knows the step index
+        env.step_device()
+        self._host_step += 1
+        if zero_copy:
+            Xn = env.next_obs.view(n, -1)
+        else:
+            self._normalize(env.next_obs if self.atari else env.next_obs.float(), self.Xn, update=False)
+            Xn = self.Xn
+        # off_policy.py:221-224 (device tensors: nothing is copied or synchronised unless the callback reads them)
+        self._cb("on_train_step", self.current_step, envs=env, model=self.model, obs=X.view(shp), acts=self.act_f,
+                 next_obs=Xn.view(shp), rewards=env.reward, terminals=env.terminated, truncations=getattr(env, "truncated", None),
+                 infos=None, train_steps=train_steps)
+        self.memory.store(X.view(shp), self.act_f, env.reward, env.terminated, Xn.view(shp))
+        if self.current_step > self.start_training and self.current_step % self.training_frequency == 0:
+            info = self._train_epochs(train_steps) or info
+            self._cb("on_train_epochs_end", self.current_step, model=self.model, memory=self.memory, train_steps=train_steps,
+                     update_info=info)                          # :232-234
+        self.current_step += n
+        self._update_explore_factor()
+        self._cb("on_train_step_end", self.current_step, envs=env, model=self.model, train_steps=train_steps, train_info=info)   # :268-269
+        return info
+
+    # -- two vector steps as ONE graph launch (acting, provider, store, update phase -- twice: the provider's two observation
+    #    buffers alternate, so the addresses repeat with period 2).  Nothing in it takes an argument that changes from step to step:
+    #    the step index is a device counter (the provider's), epsilon is computed from it by the acting launch (the host's float64
+    #    arithmetic), the ring slot and the filled-slot count by the store launch, the draw counter and the loss sums ride in the
+    #    optimiser launch (DQN_Learner.update_from_buffer).  The host mirrors (current_step, e_greedy, memory.ptr / size, the step
+    #    counters) advance without reading anything back, so the launch-by-launch loop can take over at any pair boundary.
+    def _eps_kstar(self):
+        """First vector step whose epsilon is <= end_greedy (where _update_explore_factor stops updating)."""
+        if getattr(self, "_kstar", None) is None:
+            k, e = 0, self.start_greedy
+            while e > self.end_greedy:
+                k += 1
+                e = self.start_greedy - (k * self.n_envs) * self.delta_egreedy
+            self._kstar = k
+        return self._kstar
+
+    def _pair_ready(self):
+        env, lr, n = self.envs, self.learner, self.n_envs
+        if not (bool(_get(self.config, "use_step_graph", True)) and self.use_graph_updates and self._act_fused and self.atari
+                and getattr(env, "double_buffered", False) and getattr(env, "graph_safe_even", False)
+                and hasattr(lr, "phase_ready") and type(self.memory) in (HipOffPolicyBuffer, HipOffPolicyBuffer_Atari)):
+            return False
+        if any(self._has_cb(h) for h in ("on_train_step", "on_train_epochs_end", "on_train_step_end")) or lr.needs_collective():
+            return False
+        from ..learners.base import _NullCallback
+        if not isinstance(lr.callback, _NullCallback) or not lr.phase_ready(self.memory, self.n_epochs):
+            return False
+        if self.e_greedy is None or self.current_step != self._host_step * n:
+            return False
+        for cs in (self.current_step, self.current_step + n):
+            if not (cs > self.start_training and cs % self.training_frequency == 0):
+                return False
+        par = getattr(self, "_pair_parity", None)
+        return par is None or par == env._cur                      # (the other parity: one launch-by-launch step first)
+
+    def _enqueue_pair(self, d_act, bias):
+        env, n, mem = self.envs, self.n_envs, self.memory
+        shp = (n,) + tuple(self.obs_shape)
+        sched = (n, self._eps_kstar(), self.start_greedy, self.delta_egreedy)
+        for t in (0, 1):
+            X = env.buf_obs.view(n, -1)
+            self.model.act_egreedy(X, n, None, env.action, self.act_f, self.seed, d_act + t, step_dev=env.step_counter, eps_sched=sched)
+            env.step_device(offset=t)
+            mem.store_ring(X.view(shp), self.act_f, env.reward, env.terminated, env.next_obs, env.step_counter, t, bias, mirror=False)
+            self.learner.enqueue_phase()
+        env.advance(2)
+
+    def _run_pair(self):
+        env, mem, lr, n = self.envs, self.memory, self.learner, self.n_envs
+        if getattr(self, "_vc_mirror", None) != env._host_step:     # the device counter follows the provider's own step index
+            env.step_counter.fill_(int(env._host_step))
+            self._vc_mirror = env._host_step
+        d_act = (self._host_step - env._host_step) & 0xffffffff
+        key = (d_act, mem.ring_bias(env._host_step), env._cur, id(mem))
+        if getattr(self, "_pair_key", None) != key:
+            torch.cuda.synchronize()
+            g = ops.Graph()
+            with g:
+                self._enqueue_pair(d_act, key[1])
+            self._pair_graph, self._pair_key, self._pair_parity = g, key, env._cur
+        lr.ensure_live_images()
+        self._pair_graph.launch()
+        for _ in range(2):
+            mem.advance_mirrors(1)
+            self._host_step += 1
+            env._host_step += 1
+            self.current_step += n
+            self._update_explore_factor()
+        self._vc_mirror += 2
+        lr.note_phases(mem, self.n_epochs, 2)
 
     def _train_epochs(self, train_steps):
         if self.use_graph_updates:

@@ -26,9 +26,19 @@ struct FieldPack {
 
 // ------------------------------------------------------------------------------------------ store
 // field[t] <- src : one contiguous copy of n_envs*row_bytes per field (blockIdx.y = field).
+// RING: slot and filled-slot count from a device counter (xrl_soa_store_step_ring); every block reads the counter, nobody writes it
+struct RingCursor { const int32_t* counter; int32_t offset, n_size; long long slot_bias, size_bias; };
 template <typename V>
-__global__ void __launch_bounds__(256) store_step_kernel(FieldPack f, int n_envs, int t, int32_t* size_dev, int32_t new_size) {
+__global__ void __launch_bounds__(256) store_step_kernel(FieldPack f, int n_envs, int t, int32_t* size_dev, int32_t new_size, RingCursor rc) {
     const int fi = blockIdx.y;
+    if (rc.counter) {
+        const long long c = (long long)*rc.counter + rc.offset;
+        long long sl = (rc.slot_bias + c) % rc.n_size;
+        if (sl < 0) sl += rc.n_size;
+        t = (int)sl;
+        const long long ns = rc.size_bias + c + 1;
+        new_size = (int32_t)(ns < rc.n_size ? ns : rc.n_size);
+    }
     if (size_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *size_dev = new_size;   // filled slots of a replay ring
     const size_t step_bytes = (size_t)n_envs * f.row_bytes[fi];
     const size_t n = step_bytes / sizeof(V);
@@ -348,8 +358,8 @@ extern "C" int xrl_device_info(int* cu_count, int* wave_size, char* arch, int ar
     return XRL_OK;
 }
 
-extern "C" int xrl_soa_store_step_sized(const xrl_field_t* fields, int n_fields, int n_envs, int t, int32_t* size_dev, int32_t new_size,
-                                        xrl_stream_t stream) {
+static int store_step_launch(const xrl_field_t* fields, int n_fields, int n_envs, int t, int32_t* size_dev, int32_t new_size,
+                             const RingCursor& rc, xrl_stream_t stream) {
     FieldPack fp; bool vec16;
     XRL_CHECK_ARG(pack_fields(fields, n_fields, fp, vec16) == XRL_OK);
     XRL_CHECK_ARG(n_envs > 0 && t >= 0);
@@ -357,17 +367,28 @@ extern "C" int xrl_soa_store_step_sized(const xrl_field_t* fields, int n_fields,
     for (int i = 0; i < n_fields; ++i) {
         const size_t sb = (size_t)n_envs * fp.row_bytes[i];
         max_bytes = sb > max_bytes ? sb : max_bytes;
-        if ((sb & 15) || (((size_t)t * sb) & 15)) vec16 = false;
+        if ((sb & 15) || (!rc.counter && (((size_t)t * sb) & 15))) vec16 = false;   // (a ring cursor: every slot, sb a multiple of 16)
     }
     const size_t unit = vec16 ? 16 : 4;
     size_t nb = (max_bytes / unit + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     dim3 grid((unsigned)nb, n_fields);
-    if (vec16) hipLaunchKernelGGL(store_step_kernel<uint4>, grid, 256, 0, as_stream(stream), fp, n_envs, t, size_dev, new_size);
-    else hipLaunchKernelGGL(store_step_kernel<uint32_t>, grid, 256, 0, as_stream(stream), fp, n_envs, t, size_dev, new_size);
+    if (vec16) hipLaunchKernelGGL(store_step_kernel<uint4>, grid, 256, 0, as_stream(stream), fp, n_envs, t, size_dev, new_size, rc);
+    else hipLaunchKernelGGL(store_step_kernel<uint32_t>, grid, 256, 0, as_stream(stream), fp, n_envs, t, size_dev, new_size, rc);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
+}
+
+extern "C" int xrl_soa_store_step_sized(const xrl_field_t* fields, int n_fields, int n_envs, int t, int32_t* size_dev, int32_t new_size,
+                                        xrl_stream_t stream) {
+    return store_step_launch(fields, n_fields, n_envs, t, size_dev, new_size, RingCursor{nullptr, 0, 1, 0, 0}, stream);
+}
+
+extern "C" int xrl_soa_store_step_ring(const xrl_field_t* fields, int n_fields, int n_envs, int n_size, int64_t slot_bias, int64_t size_bias,
+                                       const int32_t* counter_dev, int32_t offset, int32_t* size_dev, xrl_stream_t stream) {
+    XRL_CHECK_ARG(counter_dev != nullptr && n_size >= 1);
+    return store_step_launch(fields, n_fields, n_envs, 0, size_dev, 0, RingCursor{counter_dev, offset, n_size, (long long)slot_bias, (long long)size_bias}, stream);
 }
 
 extern "C" int xrl_soa_store_step(const xrl_field_t* fields, int n_fields, int n_envs, int t, xrl_stream_t stream) {

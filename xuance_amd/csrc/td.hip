@@ -369,8 +369,13 @@ __global__ void __launch_bounds__(TAIL_T) dqn_act_tail_kernel(xrl_dqn_act_tail_t
 #pragma unroll
         for (int t = 0; t < TAIL_HMAX / 64; ++t) w2[u][t] = w[min(lane + 64 * t, H - 1)];
     }
-    const float b1 = p.b1[min(tid, H - 1)], eps = p.eps_dev ? *p.eps_dev : p.eps;
+    const float b1 = p.b1[min(tid, H - 1)];
     const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
+    float eps = p.eps_dev ? *p.eps_dev : p.eps;
+    if (p.eps_sched) {                                  // the host's schedule (off_policy.py:119-127), evaluated from the step counter
+        const long long cs = (long long)min(step, p.eps_kstar) * (long long)p.eps_n;          // current_step
+        eps = (float)__dsub_rn(p.eps_start, __dmul_rn((double)cs, p.eps_delta));
+    }
     float best = -INFINITY;
 #pragma unroll
     for (int q = 0; q < TAIL_PQ; ++q) if (wave + TAIL_W * q < P) best = fmaxf(best, pv[q]);

@@ -113,13 +113,7 @@ class DQN_Learner(Learner):
         step while the update runs; `flush_info()` later returns the info of the last phase launched."""
         M, dev = memory.batch_size, self.model.params.device
         key = (id(memory), n_epochs, M)
-        conv = getattr(self.model, "conv", None)
-        if conv is not None and conv.implicit and getattr(self.config, "use_live_weight_images", True) \
-                and getattr(self, "_buf_graph", None) is not None:
-            flats = (self.model.params.flat, self.model.target_flat)
-            if not all(conv.is_live(f) for f in flats):     # load_state_dict / copy_target / an adopted module wrote parameters:
-                conv.pack_images([(None, True), (flats[1], False)])   # the captured phase has no xrl_gather_images in it (the
-                conv.mark_live(*flats)                                # optimiser launch keeps the weight images current)
+        self.ensure_live_images()
         if getattr(self, "_buf_graph_key", None) != key:
             self._ensure(M)
             self._idx = torch.zeros(M, dtype=torch.int64, device=dev)
@@ -164,6 +158,31 @@ class DQN_Learner(Learner):
             self.iterations += n_epochs
             return None
         return self._phase_info(count=True)
+
+    def ensure_live_images(self):
+        """Before a captured update phase is replayed: the convolution stack's weight images must be the parameters' (the
+        captured phase has no xrl_gather_images in it -- the optimiser launch keeps the images current)."""
+        conv = getattr(self.model, "conv", None)
+        if conv is not None and conv.implicit and getattr(self.config, "use_live_weight_images", True) \
+                and getattr(self, "_buf_graph", None) is not None:
+            flats = (self.model.params.flat, self.model.target_flat)
+            if not all(conv.is_live(f) for f in flats):     # load_state_dict / copy_target / an adopted module wrote parameters
+                conv.pack_images([(None, True), (flats[1], False)])
+                conv.mark_live(*flats)
+
+    def phase_ready(self, memory, n_epochs):
+        """Has update_from_buffer(memory, n_epochs) captured its phase (the launches an enclosing capture may enqueue through
+        enqueue_phase)?"""
+        return getattr(self, "_buf_graph", None) is not None and getattr(self, "_buf_graph_key", None) == (id(memory), n_epochs, memory.batch_size)
+
+    def enqueue_phase(self):
+        """The launches of one update phase, for a caller that captures them into a larger graph (DQN_Agent's vector-step pair)."""
+        self._buf_enqueue()
+
+    def note_phases(self, memory, n_epochs, k):
+        """Host bookkeeping of k phases that ran inside a caller's graph (what update_from_buffer(sync=False) does per call)."""
+        self._pending_phase = (n_epochs, memory.batch_size)
+        self.iterations += n_epochs * k
 
     def flush_info(self):
         """Info of the last update phase launched with sync=False ({} if there was none)."""

@@ -262,6 +262,28 @@ class HipOffPolicyBuffer:
         if grow:
             self.size += 1                   # `size` for sampling kernels inside captured graphs
 
+    def ring_bias(self, counter_value):
+        """(slot_bias, size_bias) of store_ring for a device counter that currently holds `counter_value`: the next store lands in
+        slot `ptr` and makes `size + 1` slots filled."""
+        return (self.ptr - int(counter_value)) % self.n_size, self.size - int(counter_value)
+
+    def store_ring(self, obs, acts, rews, terminals, next_obs, counter_dev, offset, bias, mirror=True):
+        """store() of device tensors inside a captured vector step: slot and filled-slot count come from `counter_dev` + offset
+        (xrl_soa_store_step_ring; `bias` = ring_bias(counter's value at capture)).  The host mirrors advance as in store()."""
+        step = {"observations": obs, "actions": acts, "rewards": rews, "terminals": terminals, "next_observations": next_obs}
+        f = self.soa
+        for k, x in step.items():
+            assert x.is_cuda and x.is_contiguous() and x.dtype == f.fields[k].dtype, k
+        ops.soa_store_step_ring([(f.fields[k], step[k], f.row_bytes[k]) for k in step], self.n_envs, self.n_size, bias[0], bias[1],
+                                counter_dev, offset, self.size_dev)
+        if mirror:
+            self.advance_mirrors(1)
+
+    def advance_mirrors(self, k):
+        """Host-side ptr / size after k stores that ran on the device (a replayed graph)."""
+        self.ptr = (self.ptr + k) % self.n_size
+        self.size = min(self.size + k, self.n_size)
+
     def gather_into(self, idx, dst):
         """dst: field name -> device tensor [bs, row] (a learner's staging views); one launch, no host work."""
         f = self.soa

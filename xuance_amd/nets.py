@@ -1407,7 +1407,7 @@ class DeepQCNN:
             return None
         return L1, L2
 
-    def act_egreedy(self, x_u8, n, eps_dev, action, action_f, seed, step, step_dev=None, eps=0.0):
+    def act_egreedy(self, x_u8, n, eps_dev, action, action_f, seed, step, step_dev=None, eps=0.0, eps_sched=None):
         """Q(obs) of the eval network + OffPolicyAgent.exploration's choice for n frames (epsilon from eps_dev, or by value when
         eps_dev is None): the convolutions, then pool + hidden + Q
         layers + the epsilon-greedy action in ONE launch (xrl_dqn_act_tail) when fused_tail() covers the network.  Returns the Q
@@ -1426,8 +1426,9 @@ class DeepQCNN:
         q, prm = self.plan.acts[2], self.params
         ops.dqn_act_tail(y=ws.y[-1], w1=prm.ptr(L1.w_name), b1=prm.ptr(L1.b_name), w2=prm.ptr(L2.w_name), b2=prm.ptr(L2.b_name),
                          eps_dev=eps_dev, eps=float(eps), action=action, action_f=action_f, q=q, feat=ws.feat, step_dev=step_dev, seed=int(seed),
-                         step=int(step), n=n, A=L2.N, H=L1.N, F=F, P=OH * OW, ld_q=self.plan.widths[2], ld_f=ws.feat.shape[1],
-                         act=ops.ACT[L1.act])
+                         step=int(step) & 0xffffffff, n=n, A=L2.N, H=L1.N, F=F, P=OH * OW, ld_q=self.plan.widths[2], ld_f=ws.feat.shape[1],
+                         act=ops.ACT[L1.act], **(dict(eps_sched=1, eps_n=int(eps_sched[0]), eps_kstar=int(eps_sched[1]),
+                                                      eps_start=float(eps_sched[2]), eps_delta=float(eps_sched[3])) if eps_sched else {}))
         return q
 
     def tail_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma, slabs=None):

@@ -44,6 +44,15 @@ def soa_store_step(pairs, n_envs, t, size_dev=None, new_size=0):
         call("xrl_soa_store_step", arr, len(pairs), int(n_envs), int(t), stream_ptr())
 
 
+def soa_store_step_ring(pairs, n_envs, n_size, slot_bias, size_bias, counter_dev, offset, size_dev):
+    """soa_store_step with the ring slot / filled-slot count derived from a device counter (xrl_soa_store_step_ring): slot =
+    (slot_bias + *counter_dev + offset) mod n_size, *size_dev = min(size_bias + *counter_dev + offset + 1, n_size)."""
+    _chk(counter_dev, torch.int32)
+    arr = _fields(pairs)
+    call("xrl_soa_store_step_ring", arr, len(pairs), int(n_envs), int(n_size), int(slot_bias), int(size_bias), ptr(counter_dev),
+         int(offset), ptr(size_dev), stream_ptr())
+
+
 def soa_gather(pairs, idx, n_envs, T, stats=None, flags=None):
     """pairs: [(dst [bs,...], field [T,n_envs,...], row_bytes)]; idx int64 env-major flat indices."""
     _chk(idx, torch.int64)
