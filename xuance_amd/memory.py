@@ -265,7 +265,9 @@ class HipOffPolicyBuffer:
     def ring_bias(self, counter_value):
         """(slot_bias, size_bias) of store_ring for a device counter that currently holds `counter_value`: the next store lands in
         slot `ptr` and makes `size + 1` slots filled."""
-        return (self.ptr - int(counter_value)) % self.n_size, self.size - int(counter_value)
+        # (a full ring: any bias that keeps min(size_bias + c + 1, n_size) at n_size -- one constant, so that a caller's captured
+        #  arguments stop changing once the ring has wrapped)
+        return (self.ptr - int(counter_value)) % self.n_size, (self.size - int(counter_value)) if self.size < self.n_size else 1 << 40
 
     def store_ring(self, obs, acts, rews, terminals, next_obs, counter_dev, offset, bias, mirror=True):
         """store() of device tensors inside a captured vector step: slot and filled-slot count come from `counter_dev` + offset
