@@ -409,7 +409,7 @@ def main():
                 # profiles/ref_cpu_baseline.json; no simulator for either is installed, the providers are synthetic)
                 sec["ppo_halfcheetah_shape_c4"] = bs.ppo_c4(ref=reference_cpu_baseline("ppo_halfcheetah_shape_c4"))
                 sec["dqn_atari_shape_c3"] = bs.dqn_c3(ref=reference_cpu_baseline("dqn_atari_shape_c3"))
-                sec["ppo_atari_shape"] = bs.ppo_atari()          # (configs/ppo/atari.yaml: the uint8 rollout buffer's user)
+                sec["ppo_atari_shape"] = bs.ppo_atari(ref=reference_cpu_baseline("ppo_atari_shape"))          # (configs/ppo/atari.yaml: the uint8 rollout buffer's user)
             except Exception as ex:                          # noqa: BLE001
                 sec["error"] = repr(ex)
             out["secondary"] = sec

@@ -263,6 +263,30 @@ def dqn_c3_agent_loop(n_envs=64, steps=48, calls=3):
                     "one DQN_Learner.update (CNN, batch 32) per vector step" % (steps, steps, n_envs)}
 
 
+def ppo_atari_agent_loop(n_envs=8, calls=3):
+    """The reference's PPO_Agent.train with configs/ppo/atari.yaml (AC_CNN_Atari 32/64/64 + 512, Categorical_AC, uint8 rollout buffer)
+    at the size tools/bench_secondary.py: ppo_atari runs: 8 envs x horizon 128, 4 epochs x 4 minibatches of 256 frames."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import xuance.torch.agents.base.agent as agent_mod
+    from xuance.torch.agents import REGISTRY_Agents
+    from xuance_amd.envs import DummyVecEnv
+    agent_mod.SummaryWriter = _NullWriter
+    import xuance.torch.agents.policy_gradient.ppo_agent as pa
+    pa.tqdm = lambda x, *a, **k: x
+    cfg = _agent_config("ppo/atari.yaml", parallels=n_envs, horizon_size=128, n_epochs=4, n_minibatch=4)
+    envs = DummyVecEnv([_HostAtariShapedEnv] * n_envs, env_seed=1)
+    envs.reset()
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs)
+        rate, all_rates = _median_rate(agent, cfg.horizon_size, calls, lambda: agent.current_step)
+    finally:
+        os.chdir(cwd)
+    return {"env_steps_per_s": round(rate, 1), "runs": all_rates, "n_envs": n_envs,
+            "what": "reference PPO_Agent.train(128) with configs/ppo/atari.yaml on an Atari-shaped host provider: 128 vector steps of "
+                    "%d envs + 4 x 4 minibatch updates of %d frames" % (n_envs, n_envs * 32)}
+
+
 def qmix_agent_loop(n_envs, rnn, calls=3):
     """The reference's QMIX_Agents.train (off_policy_marl.py:310-424) with configs/qmix/sc2/3m.yaml.  Recurrent agents (the
     yaml default) with use_actions_mask as in the yaml crash in the reference's own update (iql_learner.py:78-81, see
@@ -320,6 +344,14 @@ if __name__ == "__main__":
         with open(sys.argv[1], "w") as f:
             json.dump(out, f, indent=1)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "ppo_atari":   # add the PPO-Atari line to an existing record (same host, same settings)
+        with open(sys.argv[1]) as f:
+            out = json.load(f)
+        out["ppo_atari_shape"] = ppo_atari_agent_loop()
+        print(json.dumps(out["ppo_atari_shape"]))
+        with open(sys.argv[1], "w") as f:
+            json.dump(out, f, indent=1)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "c4":          # add the C4 line to an existing record (same host, same settings)
         with open(sys.argv[1]) as f:
             out = json.load(f)
@@ -333,6 +365,7 @@ if __name__ == "__main__":
            "ppo_cartpole": {str(n): ppo_agent_loop(n) for n in (4, 16, 256)},
            "qmix_3m_ff": qmix_agent_loop(64, False), "qmix_3m_gru": qmix_agent_loop(64, True),
            "ppo_halfcheetah_shape_c4": ppo_c4_agent_loop(), "dqn_atari_shape_c3": dqn_c3_agent_loop(),
+           "ppo_atari_shape": ppo_atari_agent_loop(),
            "ppo_update_bs8192_ms": round(ppo(8192), 3),
            "qmix_ff_update_b32_ms": round(qmix(False), 3),
            "qmix_rnn_update_b32x60_ms": round(qmix(True), 3),

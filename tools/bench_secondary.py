@@ -210,7 +210,7 @@ def ppo_c4(steps=3, warmup=2, ref=None):
     return out
 
 
-def ppo_atari(steps=3, warmup=2):
+def ppo_atari(steps=3, warmup=2, ref=None):
     """configs/ppo/atari.yaml shapes: PPO on 84x84x4 uint8 frame stacks, AC_CNN_Atari (32/64/64 conv + 512 dense) with a categorical
     head, 8 envs x horizon 128 in a HipOnPolicyBuffer_Atari (uint8), 4 epochs x 4 minibatches of 256 frames; synthetic frame
     provider on the device.  The network is 3.36 M parameters (the 6400 -> 512 layer); roofline of a minibatch: its algorithmic
@@ -241,7 +241,7 @@ def ppo_atari(steps=3, warmup=2):
     us_mb = (t2 - t1) / steps / 16 * 1e6
     flops = 3 * (21.2e6 + 2 * 6400 * 512 + 2 * 512 * 5) * 256
     tf = flops / us_mb / 1e6
-    return {"workload": "PPO, Atari shapes (84x84x4 uint8 frames, AC_CNN_Atari 32/64/64 + 512, 4 actions; configs/ppo/atari.yaml), %d envs x "
+    out = {"workload": "PPO, Atari shapes (84x84x4 uint8 frames, AC_CNN_Atari 32/64/64 + 512, 4 actions; configs/ppo/atari.yaml), %d envs x "
                         "horizon %d, 4 epochs x 4 minibatches of 256 frames, uint8 rollout buffer" % (n, T),
             "value": round(n * T * steps / (t2 - t0), 1), "unit": "env-steps/s", "ms_per_step": round((t2 - t0) / steps * 1e3, 3),
             "rollout_ms": round((t1 - t0) / steps * 1e3, 3), "update_ms": round((t2 - t1) / steps * 1e3, 3),
@@ -250,7 +250,10 @@ def ppo_atari(steps=3, warmup=2):
                                                     "launches, xrl::ppo_loss_kernel, xrl::reduce_adam_kernel over 3.36 M parameters)",
                          "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": None, "avg_launch_us": round(us_mb, 1), "algorithmic_flops_per_launch": flops,
-                         "note": "one 'launch' = one whole minibatch update (layered path over the convolution stack); the rollout is one captured graph of 128 vector steps of 8 envs (~15 launches per step: launch-bound at 8 envs); no reference CPU time taken for this shape"}}
+                         "note": "one 'launch' = one whole minibatch update (layered path over the convolution stack); the rollout is one captured graph of 128 vector steps of 8 envs (~15 launches per step: launch-bound at 8 envs)"}}
+    if ref:
+        out["cpu_baseline"] = ref
+    return out
 
 
 def dqn_c3(steps=200, ref=None):
