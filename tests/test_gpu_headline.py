@@ -247,7 +247,7 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
         # Round 4 (first layer of the minibatch kernel on the matrix cores: each h1 element rounds differently in its last bit) showed
         # the third yardstick this needs: a tensor on which the float32 ORACLE happens to sit unusually close to the float64 chain
         # (actor.logits.2.weight: 6e-7 of its scale) says nothing about how far another float32 evaluation may land -- the engine
-        # came out at 3.0e-5 there, 0.05 % of the distance the tensor moved in these 64 updates (`moved`, recorded).  The engine may
+        # came out at 3.0e-5 there, 0.04 % of the distance the tensor moved in these 64 updates (`moved`, recorded).  The engine may
         # therefore also be MOVED_K of that distance from the float64 chain.
         DEV_K, MOVED_K = 32.0, 2e-3
         for k_, r_ in rec.items():
