@@ -298,6 +298,10 @@ typedef struct {
     const double* part;     /* NULL, or [part_rows][8] float64 loss partials ... */
     double* part_out;       /* ... summed row by row into part_out[8] (xrl_sum_partials, same order) */
     int32_t tick_inc, part_rows;
+    /* xrl_reduce_adam[_exchange] only: parameter ranges [alt_lo[i], alt_hi[i]) (multiples of 4) whose gradient is the sum of the
+     * first alt_split slab rows instead of n_split (xrl_wide_dw1's parts); alt_split = 0: none */
+    int64_t alt_lo[2], alt_hi[2];
+    int32_t alt_split, pad2;
 } xrl_mirrors_t;
 int xrl_adam_step_mirrors(float* params, float* grad, float* m, float* v, int64_t P, xrl_adam_state_t* state,
                           const double* sumsq_part, int n_part, double max_norm, const xrl_mirrors_t* mirrors,
@@ -782,8 +786,19 @@ typedef struct {
                                                         * the callback tensors a_dist / v_pred of ppo_learner.py:82-88 */
     float clip_range, vf_coef, ent_coef, pad0;
     long long* dbg;                                    /* NULL, or [16] shader-clock stamps of the last tile's role dbg_role */
+    /* NULL, or [2][rows_ld][256] each: the launch then leaves the middle layer's weight gradient to xrl_wide_dw1 -- every workgroup
+     * stores its tile's 32 rows of dLoss/d(pre-activation of h2) and of h1 here (64 KB) instead of forming and storing a 256 x 256
+     * partial of dW1 (256 KB per workgroup, 92 % of the 73 MB of gradient rows a 4 096-row minibatch wrote), and writes nothing
+     * to the w1 ranges of its slab row. */
+    float* rows_g2; float* rows_h1;
+    int64_t rows_ld;                                   /* rows per branch in rows_g2 / rows_h1, >= 32 * ceil(M / 32) */
 } xrl_ppo_wide_t;
 int xrl_ppo_wide_minibatch(const xrl_ppo_wide_t* p, xrl_stream_t stream);
+/* dW1 of both branches from the rows xrl_ppo_wide_minibatch left (rows_g2, rows_h1): split over the rows in ceil(32 ceil(M / 32) /
+ * 128) parts of 128 rows; part s goes to the w1 ranges of slab row s (dW1[n][k] = sum over the part's rows of g2[row][n] *
+ * h1[row][k], rows in order).  xrl_reduce_adam then sums that many rows for those ranges (xrl_mirrors_t.alt_*).  Returns the
+ * number of parts through *n_parts. */
+int xrl_wide_dw1(const xrl_ppo_wide_t* p, int32_t* n_parts, xrl_stream_t stream);
 /* frag[b][0][t][(q + t) mod 32][l][s] = W1_b[32 t + (l & 31)][8 q + 4 (l >> 5) + s]   forward section
  * frag[b][1][t][(q + t) mod 32][l][s] = W1_b[8 q + 4 (l >> 5) + s][32 t + (l & 31)]   backward section (reduction index on k)
  * (b: branch, t: 32-wide output tile, q: 8-wide chunk of the reduction index, l: lane): every prefetch instruction of a wave

@@ -387,13 +387,15 @@ def test_minibatch_gradient_noise_vs_float64(size):
     assert not worse, f"noisier than the reference's float32 gradient and than 2e-6 of the tensor's scale: {worse}"
 
 
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("M,act,oact", [(96, "leaky_relu", "tanh"), (100, "relu", None), (1000, "tanh", "tanh"), (37, "leaky_relu", "tanh")])
-def test_wide_minibatch_kernel_matches_the_layered_path(M, act, oact):
+def test_wide_minibatch_kernel_matches_the_layered_path(M, act, oact, split):
     """xrl_ppo_wide_minibatch (one launch: both branches of the 17-256-256-{6 | 1} Gaussian actor-critic forward, loss,
     backward) against the layered path (grouped GEMM launches + xrl_ppo_loss_gaussian) on the same random minibatch, two
     chained updates: ragged last tiles (M % 32 != 0), every activation pair the kernel is instantiated for.  1e-5 on
     everything the reference's update reports (the c4 fixture of test_ppo_learner_vs_reference_fixture pins the same kernel
-    to the reference itself)."""
+    to the reference itself).  split: the middle layers' weight gradient as xrl_wide_dw1's launch over all rows (the default) or
+    inside the minibatch launch, tile by tile."""
     from xuance_amd.nets import ActorCriticNet
     from xuance_amd.learners import REGISTRY_Learners
     rng = np.random.default_rng(M)
@@ -404,7 +406,7 @@ def test_wide_minibatch_kernel_matches_the_layered_path(M, act, oact):
         cfg = Namespace(horizon_size=256, n_epochs=16, n_minibatch=8, parallels=4, running_steps=120000, gamma=0.99,
                         learning_rate=4e-4, vf_coef=0.25, ent_coef=0.01, clip_range=0.2, use_grad_clip=True, grad_clip_norm=0.5,
                         end_factor_lr_decay=0.5, distributed_training=False, device="cuda", model_dir="/tmp/xrl_models",
-                        use_fused_update=wide)
+                        use_fused_update=wide, use_wide_split_dw1=split)
         cb = Capture()
         lr = REGISTRY_Learners["PPO_Learner"](cfg, net, cb)
         assert lr.wide_eligible() == wide

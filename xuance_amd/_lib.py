@@ -261,7 +261,7 @@ class PpoWide(C.Structure):
                 ("obs", c_void_p), ("actions", c_void_p), ("ret", c_void_p), ("adv", c_void_p), ("old_logp", c_void_p),
                 ("stats", c_void_p), ("slabs", c_void_p), ("slab_stride", c_int64), ("partials", c_void_p), ("diag", c_void_p),
                 ("heads", c_void_p), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float), ("pad0", c_float),
-                ("dbg", c_void_p)]
+                ("dbg", c_void_p), ("rows_g2", c_void_p), ("rows_h1", c_void_p), ("rows_ld", c_int64)]
 
 
 class WideAct(C.Structure):
@@ -324,7 +324,8 @@ class MarlGate(C.Structure):
 class Mirrors(C.Structure):
     _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("target_every", c_int32), ("target", c_void_p),
                 ("target_image", c_void_p), ("fold_off", c_int64), ("fold_len", c_int32), ("pad", c_int32), ("tick", c_void_p),
-                ("part", c_void_p), ("part_out", c_void_p), ("tick_inc", c_int32), ("part_rows", c_int32)]
+                ("part", c_void_p), ("part_out", c_void_p), ("tick_inc", c_int32), ("part_rows", c_int32),
+                ("alt_lo", c_int64 * 2), ("alt_hi", c_int64 * 2), ("alt_split", c_int32), ("pad2", c_int32)]
 
 
 class MarlAct(C.Structure):
@@ -340,6 +341,7 @@ _SIGS = {
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
     "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],
     "xrl_ppo_wide_pack": [C.POINTER(PpoWide), c_void_p, c_void_p],
+    "xrl_wide_dw1": [C.POINTER(PpoWide), C.POINTER(c_int32), c_void_p],
     "xrl_wide_act_step": [C.POINTER(WideAct), c_void_p],
     "xrl_gather_rows": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "xrl_pack_transitions": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],

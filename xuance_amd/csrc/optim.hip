@@ -225,6 +225,10 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
         if (qi < P4) {
             const float4* src = reinterpret_cast<const float4*>(slabs) + qi;
             int s = sg;
+            if (mir.alt_split > 0) {                                     // ranges whose gradient is split over fewer rows (xrl_wide_dw1)
+                const int64_t e0 = qi * 4;
+                if ((e0 >= mir.alt_lo[0] && e0 < mir.alt_hi[0]) || (e0 >= mir.alt_lo[1] && e0 < mir.alt_hi[1])) n_split = mir.alt_split;
+            }
             // (same summation order whatever the batching: 32 loads in flight per thread turn the four dependent round trips of a
             //  128-slab reduction into one)
             for (; s + 124 < n_split; s += 128) {
@@ -481,6 +485,9 @@ extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t
     XRL_CHECK_ARG(mir.fold_len >= 0 && (mir.fold_len & 3) == 0 && (mir.fold_off & 3) == 0 &&
                   (mir.fold_len == 0 || (mir.fold_off >= P && mir.fold_off + mir.fold_len <= slab_stride && mir.fold_len <= P)));
     XRL_CHECK_ARG((mir.part == nullptr) == (mir.part_out == nullptr) && (mir.part == nullptr || mir.part_rows >= 1));
+    XRL_CHECK_ARG(mir.alt_split >= 0 && mir.alt_split <= n_split);
+    if (mir.alt_split > 0)
+        for (int i = 0; i < 2; ++i) XRL_CHECK_ARG(mir.alt_lo[i] >= 0 && mir.alt_lo[i] <= mir.alt_hi[i] && mir.alt_hi[i] <= P && !(mir.alt_lo[i] & 3) && !(mir.alt_hi[i] & 3));
     if (exchange && exchange->world > 1) {
         const xrl_exchange_t& xc = *exchange;
         XRL_CHECK_ARG(xc.world <= XRL_XC_MAX_RANKS && xc.rank >= 0 && xc.rank < xc.world && n_vb <= XRL_XC_MAX_GROUPS);

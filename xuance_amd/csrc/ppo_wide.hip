@@ -367,6 +367,20 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_wide_kernel(xrl_ppo_wide_t 
         }
     }
     WSTAMP(5);
+    if (p.rows_g2) {
+        // ---- the weight gradient of the middle layer is xrl_wide_dw1's: this tile's rows of g2 and h1 go to global memory (64 KB
+        //      instead of a 256 KB partial of dW1; round 4 -- a CU moved ~800 KB per tile at its ~10 B/clk, 285 KB of them these
+        //      stores, and the optimiser launch re-read all of it)
+        const size_t base = ((size_t)role * (size_t)p.rows_ld + (size_t)m0) * WH;
+        float4* G = reinterpret_cast<float4*>(p.rows_g2 + base);
+        float4* Hr = reinterpret_cast<float4*>(p.rows_h1 + base);
+#pragma unroll
+        for (int i = 0; i < FT * (WH / 4) / FUSED_THREADS; ++i) {
+            const int e = tid + i * FUSED_THREADS, rr = e >> 6, c4 = e & 63;
+            G[e] = *reinterpret_cast<const float4*>(g2 + rr * WLD + 4 * c4);
+            Hr[e] = *reinterpret_cast<const float4*>(h1 + rr * WLD + 4 * c4);
+        }
+    } else
     // ---- dW1[n][k] = sum_rows g2[row][n] * h1[row][k]: wave w owns rows n in [32 w, 32 w + 32), 8 column tiles in four
     //      passes of two (32 accumulator registers at a time: the backward fragments in flight hold 128)
     {
@@ -872,6 +886,62 @@ static bool wide_act_ok(int act, int out_act) {
     return (act == XRL_ACT_RELU || act == XRL_ACT_LEAKY_RELU || act == XRL_ACT_TANH) && (out_act == XRL_ACT_NONE || out_act == XRL_ACT_TANH);
 }
 
+// dW1 of both branches from the rows ppo_wide_kernel left in global memory (xrl_wide_dw1): workgroup = (part of DW_ROWS rows, branch,
+// 128 x 128 quarter of the 256 x 256 matrix); the part's rows of g2 (its 128 columns n) and h1 (its 128 columns k) staged in LDS,
+// then the weight-gradient loop of the minibatch kernels: wave w owns the 32-row block (w & 3) of n and two 32-column blocks of k,
+// DW_ROWS / 2 chained MFMAs per block, rows in order.  8 * parts workgroups (4 096 rows: 256), 128 KB read + 16.4 k cycles of
+// matrix work + 64 KB written each: 15.6 us at 4 096 rows.  (Measured, round 4: requesting the rows as two halves and starting the
+// first half's MFMAs while the second is on its way does not shorten it: 16.5 us.)
+constexpr int DW_ROWS = 128, DW_LD = 128 + 4;
+constexpr int DW_LDS_BYTES = 2 * DW_ROWS * DW_LD * 4;
+__global__ void __launch_bounds__(FUSED_THREADS) wide_dw1_kernel(xrl_ppo_wide_t p, int rows, int parts) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sG = lds;
+    float* sH = lds + DW_ROWS * DW_LD;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = blockIdx.x % parts, q = blockIdx.x / parts, kt = q & 1, nt = (q >> 1) & 1, role = q >> 2;
+    const int r0 = part * DW_ROWS;
+    const size_t base = ((size_t)role * (size_t)p.rows_ld + (size_t)r0) * WH;
+    const float* G = p.rows_g2 + base + nt * 128;
+    const float* Hh = p.rows_h1 + base + kt * 128;
+#pragma unroll
+    for (int i = 0; i < DW_ROWS * 32 / FUSED_THREADS; ++i) {
+        const int e = tid + i * FUSED_THREADS, rr = e >> 5, c4 = e & 31;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), h = g;
+        if (r0 + rr < rows) {
+            g = *reinterpret_cast<const float4*>(G + (size_t)rr * WH + 4 * c4);
+            h = *reinterpret_cast<const float4*>(Hh + (size_t)rr * WH + 4 * c4);
+        }
+        *reinterpret_cast<float4*>(sG + rr * DW_LD + 4 * c4) = g;
+        *reinterpret_cast<float4*>(sH + rr * DW_LD + 4 * c4) = h;
+    }
+    __syncthreads();
+    const int a = wave & 3, b0 = 2 * (wave >> 2);
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const float* arow = sG + lh * DW_LD + a * 32 + li;                  // A[i = n][k = row]
+    const float* brow = sH + lh * DW_LD + b0 * 32 + li;                 // B[k = row][j = k column]
+#pragma unroll 8
+    for (int s = 0; s < DW_ROWS / 2; ++s) {
+        const float av = arow[2 * s * DW_LD];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[2 * s * DW_LD + t * 32], acc[t], 0, 0, 0);
+    }
+    const int w1 = role ? p.br[1].w1 : p.br[0].w1;
+    float* dW = p.slabs + (size_t)part * p.slab_stride + w1 + (size_t)(nt * 128 + a * 32) * WH + kt * 128;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            dW[(size_t)row * WH + (b0 + t) * 32 + li] = acc[t][rr];
+        }
+}
+
 }  // namespace xrl
 
 using namespace xrl;
@@ -905,6 +975,22 @@ extern "C" int xrl_ppo_wide_minibatch(const xrl_ppo_wide_t* p, xrl_stream_t stre
     WIDE_FOR_EACH(WIDE_LAUNCH)
 #undef WIDE_LAUNCH
     XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_wide_dw1(const xrl_ppo_wide_t* p, int32_t* n_parts, xrl_stream_t stream) {
+    XRL_CHECK_ARG(p && p->rows_g2 && p->rows_h1 && p->slabs && p->M > 0 && p->H == WH);
+    XRL_CHECK_ARG((reinterpret_cast<uintptr_t>(p->rows_g2) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->rows_h1) & 15) == 0);
+    const int rows = ((p->M + FT - 1) / FT) * FT, parts = (rows + DW_ROWS - 1) / DW_ROWS;
+    XRL_CHECK_ARG(p->rows_ld >= rows);
+    static bool inited = false;
+    if (!inited) {
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_dw1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES));
+        inited = true;
+    }
+    hipLaunchKernelGGL(wide_dw1_kernel, dim3(8 * parts), dim3(FUSED_THREADS), DW_LDS_BYTES, as_stream(stream), *p, rows, parts);
+    XRL_CHECK_LAUNCH();
+    if (n_parts) *n_parts = parts;
     return XRL_OK;
 }
 

@@ -178,6 +178,7 @@ class PPO_Learner(Learner):
             self._mirror = True
             self.opt_sync = torch.zeros(4 + (P + 255) // 256 + 8, dtype=torch.int32, device=dev)
         n_t = (M + 31) // 32
+        self._wide.prepare_rows(M)
         if n_t > getattr(self, "_wide_tiles", 0):
             self.fslabs = torch.zeros(n_t, P, device=dev)            # one gradient row per 32-row tile (both branches)
             self.fpartials = torch.zeros(2 * n_t, 8, dtype=torch.float64, device=dev)
@@ -189,15 +190,19 @@ class PPO_Learner(Learner):
         gradient average over the ranks) in a second one.  Pointers may be tensors or raw addresses."""
         m, opt, P = self.model, self.optimizer, self.model.params.P
         n_t = (M + 31) // 32
-        self._wide.launch(M, obs, act, ret, adv, old_logp, self.fslabs, P, self.fpartials, self.clip_range, self.vf_coef,
-                          self.ent_coef, stats=stats, diag=self.diag if self.keep_diag else None, heads=heads)
-        self._last_S, self._last_partials = 2 * n_t, self.fpartials
         dist = self.distributed_training and self.world_size > 1
         xc = self.gradient_exchange() if dist and finish else None
-        if finish and (not dist or xc is not None) and self._fused_optimizer_ok(xc is not None):
+        one_launch_opt = finish and (not dist or xc is not None) and self._fused_optimizer_ok(xc is not None)
+        # the middle layers' weight gradient (92 % of the parameters) as a launch of its own over all rows, its parts summed by the
+        # optimiser launch (config.use_wide_split_dw1; the two-launch optimiser path keeps the per-tile form)
+        split = one_launch_opt and bool(getattr(self.config, "use_wide_split_dw1", True))
+        parts = self._wide.launch(M, obs, act, ret, adv, old_logp, self.fslabs, P, self.fpartials, self.clip_range, self.vf_coef,
+                                  self.ent_coef, stats=stats, diag=self.diag if self.keep_diag else None, heads=heads, split_dw1=split)
+        self._last_S, self._last_partials = 2 * n_t, self.fpartials
+        if one_launch_opt:
             clip = self.grad_clip_norm if self.use_grad_clip else 0.0
             ops.reduce_adam(self.fslabs, n_t, P, m.params.flat, opt.grad, opt.m, opt.v, P, opt.state, self.sumsq, clip,
-                            self._mirrors, self.opt_sync, exchange=xc)
+                            self._mirrors, self.opt_sync, exchange=xc, alt=(parts, self._wide.w1_ranges()) if split else None)
             return
         ops.grad_reduce(self.fslabs, n_t, P, P, opt.grad, self.sumsq)
         if finish:

@@ -263,7 +263,7 @@ def adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, max_norm, mirror
 
 
 def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, max_norm, mirrors, sync, target=None,
-                target_every=0, fold=None, exchange=None, target_image=None, tick=None, partials=None):
+                target_every=0, fold=None, exchange=None, target_image=None, tick=None, partials=None, alt=None):
     """grad_reduce + clip + Adam + mirrors (+ the periodic hard target update) in one launch (blocks meet at a counter
     barrier); same numbers.  exchange: a dist.GradientExchange -- the ranks average their gradients inside the launch.
     tick = (counter tensor, increment), partials = (float64 [rows, 8] tensor, rows, float64 [8] out): xrl_counter_add and
@@ -282,6 +282,10 @@ def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq
             mir.target_image = target_image.data_ptr()
     if fold:
         mir.fold_off, mir.fold_len = int(fold[0]), int(fold[1])
+    if alt:                                                # (parts, [(lo, hi), (lo, hi)]): ranges summed over `parts` rows only
+        mir.alt_split = int(alt[0])
+        for i, (lo, hi) in enumerate(alt[1]):
+            mir.alt_lo[i], mir.alt_hi[i] = int(lo), int(hi)
     if exchange is not None:
         assert exchange.stride4 * 4 >= P
         call("xrl_reduce_adam_exchange", ptr(slabs), int(n_split), int(slab_stride), ptr(params), ptr(grad), ptr(m), ptr(v),
@@ -566,8 +570,23 @@ class PpoWideState:
             self._xchg = torch.zeros(pairs * 4 * 32 * 8, device=dev)
             self._xcnt = torch.zeros(pairs, dtype=torch.int32, device=dev)
 
+    def prepare_rows(self, M):
+        """Row buffers of the split weight gradient (xrl_wide_dw1) for minibatches of up to M rows (outside graph capture)."""
+        rows = ((int(M) + 31) // 32) * 32
+        if getattr(self, "_rows_ld", 0) < rows:
+            dev = self.frag.device
+            self._rows_g2 = torch.zeros(2, rows, 256, device=dev)
+            self._rows_h1 = torch.zeros(2, rows, 256, device=dev)
+            self._rows_ld = rows
+
+    def w1_ranges(self):
+        d = self.desc
+        return [(d.br[b].w1, d.br[b].w1 + 256 * 256) for b in range(2)]
+
     def launch(self, M, obs, actions, ret, adv, old_logp, slabs, slab_stride, partials, clip_range, vf_coef, ent_coef,
-               stats=None, diag=None, heads=None, dbg=None, dbg_role=0):
+               stats=None, diag=None, heads=None, dbg=None, dbg_role=0, split_dw1=False):
+        """split_dw1: the middle layer's weight gradient as a second launch over all rows (xrl_wide_dw1) -- returns the number of
+        slab rows its ranges (w1_ranges()) are split over (reduce_adam's alt=...), else None."""
         d = self.desc
         d.params, d.frag = self.model.params.flat.data_ptr(), self.frag.data_ptr()
         d.M, d.dbg_role = int(M), int(dbg_role)
@@ -576,7 +595,17 @@ class PpoWideState:
         d.stats, d.slabs, d.slab_stride, d.partials = as_ptr(stats), as_ptr(slabs), int(slab_stride), as_ptr(partials)
         d.diag, d.heads, d.dbg = as_ptr(diag), as_ptr(heads), as_ptr(dbg)
         d.clip_range, d.vf_coef, d.ent_coef = float(clip_range), float(vf_coef), float(ent_coef)
+        if split_dw1:
+            self.prepare_rows(M)
+            d.rows_g2, d.rows_h1, d.rows_ld = self._rows_g2.data_ptr(), self._rows_h1.data_ptr(), self._rows_ld
+        else:
+            d.rows_g2, d.rows_h1, d.rows_ld = None, None, 0
         call("xrl_ppo_wide_minibatch", C.byref(d), stream_ptr())
+        if split_dw1:
+            parts = C.c_int32(0)
+            call("xrl_wide_dw1", C.byref(d), C.byref(parts), stream_ptr())
+            return int(parts.value)
+        return None
 
 
 def transpose_mid(plan, params_flat, params_t):
