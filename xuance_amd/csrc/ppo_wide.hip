@@ -890,8 +890,9 @@ static bool wide_act_ok(int act, int out_act) {
 // 128 x 128 quarter of the 256 x 256 matrix); the part's rows of g2 (its 128 columns n) and h1 (its 128 columns k) staged in LDS,
 // then the weight-gradient loop of the minibatch kernels: wave w owns the 32-row block (w & 3) of n and two 32-column blocks of k,
 // DW_ROWS / 2 chained MFMAs per block, rows in order.  8 * parts workgroups (4 096 rows: 256), 128 KB read + 16.4 k cycles of
-// matrix work + 64 KB written each: 15.6 us at 4 096 rows.  (Measured, round 4: requesting the rows as two halves and starting the
-// first half's MFMAs while the second is on its way does not shorten it: 16.5 us.)
+// matrix work + 64 KB written each.  (Measured, round 4: requesting the rows as two halves and starting the first half's MFMAs while
+// the second is on its way does not shorten it -- 16.5 vs 15.6 us at 4 096 rows; the MFMA operands straight from global memory,
+// without the staging: 25.4 us.)
 constexpr int DW_ROWS = 128, DW_LD = 128 + 4;
 constexpr int DW_LDS_BYTES = 2 * DW_ROWS * DW_LD * 4;
 __global__ void __launch_bounds__(FUSED_THREADS) wide_dw1_kernel(xrl_ppo_wide_t p, int rows, int parts) {
@@ -908,11 +909,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) wide_dw1_kernel(xrl_ppo_wide_t 
 #pragma unroll
     for (int i = 0; i < DW_ROWS * 32 / FUSED_THREADS; ++i) {
         const int e = tid + i * FUSED_THREADS, rr = e >> 5, c4 = e & 31;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), h = g;
-        if (r0 + rr < rows) {
-            g = *reinterpret_cast<const float4*>(G + (size_t)rr * WH + 4 * c4);
-            h = *reinterpret_cast<const float4*>(Hh + (size_t)rr * WH + 4 * c4);
-        }
+        // (unconditional loads from a clamped row, zeroed by a select: a branch around each load makes hipcc wait for every one
+        //  of them in turn -- eight dependent round trips)
+        const bool ok = r0 + rr < rows;
+        const size_t o = (size_t)(ok ? rr : 0) * WH + 4 * c4;
+        float4 g = *reinterpret_cast<const float4*>(G + o), h = *reinterpret_cast<const float4*>(Hh + o);
+        if (!ok) { g = make_float4(0.f, 0.f, 0.f, 0.f); h = g; }
         *reinterpret_cast<float4*>(sG + rr * DW_LD + 4 * c4) = g;
         *reinterpret_cast<float4*>(sH + rr * DW_LD + 4 * c4) = h;
     }
