@@ -133,7 +133,7 @@ def kernel_rooflines(agent):
                                 partials=lr.fpartials, diag=None, slab_stride=lr.slab_stride,
                                 l0_fold_off=lr.fold[0] if lr.fold else 0, M=bs, n_envs=n, T=T, D=4,
                                 frag_image=lr.frag, f_packed=lr.packed, f_rows=lr.rows[k * bs * 8:(k + 1) * bs * 8],
-                                pad0=64 if getattr(lr, "pair", False) else 0,
+                                pad0=(66 if getattr(lr, "chain", False) else 64) if getattr(lr, "pair", False) else 0,
                                 A=m.action_dim, clip_range=lr.clip_range, vf_coef=lr.vf_coef, ent_coef=lr.ent_coef)
     r2 = None
     if lr.fused_eligible(mem) and getattr(lr, "rows", None) is not None and getattr(lr, "opt_sync", None) is not None:

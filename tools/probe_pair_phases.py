@@ -11,8 +11,9 @@ from xuance_amd import ops
 from xuance_amd.agents import PPO_Agent
 from xuance_amd.envs import DeviceCartPoleVecEnv
 n = 256
-for pair in (True, False):
-    cfg = bench.make_config(n, 256, 1, 0); cfg.use_pair_update = pair
+for mode in ("chain", "pair", "tile32"):
+    pair = mode != "tile32"
+    cfg = bench.make_config(n, 256, 1, 0); cfg.use_pair_update = pair; cfg.use_chain_update = mode == "chain"
     torch.manual_seed(1)
     agent = PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=1))
     agent.rollout(); agent.update(); torch.cuda.synchronize()
@@ -26,13 +27,16 @@ for pair in (True, False):
                                 f_logp=f["aux_old_logp"], idx=agent.idx[3], stats=lr.stats[3], slabs=lr.fslabs, partials=lr.fpartials,
                                 diag=None, slab_stride=lr.slab_stride, l0_fold_off=lr.fold[0] if lr.fold else 0, M=bs, n_envs=n, T=256,
                                 D=4, A=2, clip_range=0.2, vf_coef=0.25, ent_coef=0.01, dbg=d, frag_image=lr.frag, f_packed=lr.packed,
-                                f_rows=lr.rows[3 * bs * 8:4 * bs * 8], pad0=64 if lr.pair else 0)
+                                f_rows=lr.rows[3 * bs * 8:4 * bs * 8], pad0=(66 if lr.chain else 64) if lr.pair else 0)
     for _ in range(3):
         launch(dbg)
         torch.cuda.synchronize()
     us = bench._event_time_us(lambda: launch(None), 50)
     d = dbg.cpu().numpy()
-    if pair:
+    if mode == "chain":
+        names = ["start", "rows + small parameters", "weight block + h1 in LDS", "branch layer, head, loss, g2 (chain waves)", "dW1 || dH1", "g1 stored", "end"]
+        print("chain: alone %.1f us; phases (cycles):" % us, dict(zip(names, (d[:7] - d[0]).tolist())))
+    elif pair:
         names = ["start", "rows gathered", "h1", "h2 (fwd MFMA)", "heads+loss+g2", "small grads", "dW1", "dH1+g1", "end"]
         ph = d[:9] - d[0]
         t = d[16:16 + 2 * 256].reshape(256, 2).astype(np.float64) * 10e-3      # us
