@@ -12,6 +12,13 @@
 //     row order unchanged) WHILE the chain waves form dH1 -- both on the matrix pipe, no barrier between them;
 //   * vector sums over rows (head weights / biases, branch bias) are 16-lane DPP reductions of the chain waves' registers, four
 //     partials per element met in LDS.
+// MEASURED (round 4, 8 192-row minibatch, tools/probe_pair_phases.py): 31.1 us per launch alone against 25.3 us for ppo_trunk_kernel
+// -- NOT the default (config.use_chain_update).  Cycles of a workgroup: rows + small parameters 6.8 k, weight block + first layer
+// 5.0 k (the first layer's operand loads retire behind the 64 KB weight block: loads return in order), branch layer + head + loss +
+// g2 + the DPP row sums 17.3 k (8.2 k of MFMA; ~1 800 vector instructions, 390 of them DPP moves the compiler does not fold into
+// the adds), dW1 || dH1 24.1 k (16.4 k of MFMA; the helper waves' 64 KB of dW1 stores in one burst at the end), tail 3.3 k = 56.5 k
+// against 44.6 k.  What the form buys -- one weight stream, no hand-over of h1 / h2 through LDS in the forward -- is spent on the
+// row reductions that the [row][unit] layout of ppo_trunk_kernel gets from plain LDS column loops.
 // Gradient slabs, loss partials, fold region: the layout of ppo_trunk_kernel (xrl_reduce_adam does not know which kernel wrote them).
 // Reference semantics: memory_tools.py:267-287 (sample) + ppo_learner.py:46-62 (forward / loss / backward),
 // distributions.py:128-153 (CategoricalDistribution), actor_head.py:14-43.
@@ -137,27 +144,30 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_chain_kernel(xrl_ppo_fused_
         }
         srcs[tid] = src;
     }
+    // (every load below is UNCONDITIONAL -- clamped address, value selected afterwards: a load under a branch makes hipcc wait for all
+    //  loads in flight at its first use, and the 64 KB weight block is in flight behind these)
     float st_mean = 0.f, st_std = 1.f;
-    if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
-    if (tid < CH) b0s[tid] = p.params[L0.b_off + tid];
-    else if (tid < 2 * CH) bms[tid - CH] = p.params[L1.b_off + cb + tid - CH];
-    else if (tid < 2 * CH + 4) bhs[tid - 2 * CH] = tid - 2 * CH < nout ? p.params[Lh.b_off + tid - 2 * CH] : 0.f;
     {
-        const int j = tid >> 7, k = tid & (CH - 1);                       // 512 threads = 4 head rows x 128
-        whs[tid] = j < nout ? p.params[Lh.w_off + j * CH + k] : 0.f;
+        const float* sp = p.stats ? p.stats : p.params;
+        const float a = sp[0], b = sp[1];
+        if (p.stats) { st_mean = a; st_std = b; }
     }
-    // first-layer weights of the chain waves as MFMA A operands: A[m = unit 16 t + cl][k = component 4 c + g]
+    // small parameters: thread -> (b0 | this role's branch bias | head bias) and one head-row element
+    const int sm_at = tid < CH ? L0.b_off + tid : tid < 2 * CH ? L1.b_off + cb + tid - CH : Lh.b_off + min(tid - 2 * CH, nout - 1);
+    const float smv = p.params[sm_at];
+    const int hj = tid >> 7, hk = tid & (CH - 1);                         // 512 threads = 4 head rows x 128
+    const float whv = p.params[Lh.w_off + min(hj, nout - 1) * CH + hk];
+    // first-layer weights as MFMA A operands: A[m = unit 16 t + cl][k = component 4 c + g] (every wave loads them; the chain waves use them)
     constexpr int KC = DS ? (DS + 3) / 4 : CKC;
     float w0r[8][KC];
-    if (chain) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                const int d = 4 * c + g;
-                w0r[t][c] = d < D ? p.params[L0.w_off + (size_t)(16 * t + cl) * D + d] : 0.f;
-            }
-    }
+        for (int c = 0; c < KC; ++c) {
+            const int d = 4 * c + g;
+            const float v = p.params[L0.w_off + (size_t)(16 * t + cl) * D + min(d, D - 1)];
+            w0r[t][c] = d < D ? v : 0.f;
+        }
     // this role's 128 rows of the branch layer W1[256][128]: 8 float4 per thread (float4 f = tid + 512 j: unit f / 32, chunk f % 32)
     float4 w1v[8];
     {
@@ -165,6 +175,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_chain_kernel(xrl_ppo_fused_
 #pragma unroll
         for (int j = 0; j < 8; ++j) w1v[j] = w1g[tid + FUSED_THREADS * j];
     }
+    if (tid < CH) b0s[tid] = smv;
+    else if (tid < 2 * CH) bms[tid - CH] = smv;
+    else if (tid < 2 * CH + 4) bhs[tid - 2 * CH] = tid - 2 * CH < nout ? smv : 0.f;
+    whs[tid] = hj < nout ? whv : 0.f;
     if (!records) {
         lds_barrier();                                                                               // (srcs)
         for (int e = tid; e < CPT * CXLD; e += FUSED_THREADS) {
@@ -211,23 +225,29 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_chain_kernel(xrl_ppo_fused_
 
     // ================= chain waves: branch layer, head, loss, head backward, g2 -- in registers
     float dz[CAMAX] = {0.f, 0.f, 0.f, 0.f};
-    cf32x4 g2T[8];
+    cf32x4 g2T[8], dh[8];
     if (chain) {
         cf32x4 h2T[8];
+        // A[m = unit 16 t + cl][k = 16 s + 4 g + {0..3}]: chunk (4 s + g) of the unit's row sits at slot (4 s + g) ^ cl
+        // = 4 (s ^ (cl >> 2)) + (g ^ (cl & 3)): one address register per s, the tile t in the instruction's offset.  Two tiles at a
+        // time: their chains are independent (a chain's next MFMA waits for the previous one's result)
+        const float* wlane = w1s + cl * CH + 4 * (g ^ (cl & 3));
+        const int c2 = cl >> 2;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float4 bb = *reinterpret_cast<const float4*>(&bms[16 * t + 4 * g]);
-            cf32x4 acc = {bb.x, bb.y, bb.z, bb.w};
-            const float* wrow = w1s + (16 * t + cl) * CH;                                           // A[m = unit 16 t + cl][k]
+        for (int t = 0; t < 8; t += 2) {
+            const float4 b0v = *reinterpret_cast<const float4*>(&bms[16 * t + 4 * g]), b1v = *reinterpret_cast<const float4*>(&bms[16 * t + 16 + 4 * g]);
+            cf32x4 acc0 = {b0v.x, b0v.y, b0v.z, b0v.w}, acc1 = {b1v.x, b1v.y, b1v.z, b1v.w};
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const float4 a = *reinterpret_cast<const float4*>(wrow + 4 * ((4 * s + g) ^ cl));    // k = 16 s + 4 g + {0..3}
-                CMFMA(a.x, h1T[s][0], acc); CMFMA(a.y, h1T[s][1], acc); CMFMA(a.z, h1T[s][2], acc); CMFMA(a.w, h1T[s][3], acc);
+                const float* ws = wlane + 16 * (s ^ c2);
+                const float4 a0 = *reinterpret_cast<const float4*>(ws + 16 * t * CH), a1 = *reinterpret_cast<const float4*>(ws + (16 * t + 16) * CH);
+                CMFMA(a0.x, h1T[s][0], acc0); CMFMA(a1.x, h1T[s][0], acc1);
+                CMFMA(a0.y, h1T[s][1], acc0); CMFMA(a1.y, h1T[s][1], acc1);
+                CMFMA(a0.z, h1T[s][2], acc0); CMFMA(a1.z, h1T[s][2], acc1);
+                CMFMA(a0.w, h1T[s][3], acc0); CMFMA(a1.w, h1T[s][3], acc1);
             }
-            cf32x4 o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = act_apply_c<ACT>(acc[i]);
-            h2T[t] = o;
+            for (int i = 0; i < 4; ++i) { h2T[t][i] = act_apply_c<ACT>(acc0[i]); h2T[t + 1][i] = act_apply_c<ACT>(acc1[i]); }
         }
         // head: z[j][row] = sum_units wh[j][unit] h2[row][unit]: A[m = j = cl][k = unit] (rows >= nout are zero), two accumulators
         cf32x4 za = {0.f, 0.f, 0.f, 0.f}, zb = za;
@@ -367,28 +387,41 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_chain_kernel(xrl_ppo_fused_
                 dW[(size_t)r * CH + t * 32 + li] = acc[t][rr];
             }
     } else {
-        // ---- dH1^T[k][row] = sum_units W1[unit][k] g2^T[unit][row] (this role's 128 units), times act'(h1): in place of h1T
+        // ---- dH1^T[k][row] = sum_units W1[unit][k] g2^T[unit][row] (this role's 128 units): A[m = k = 16 s + cl][unit 16 t + 4 g + i]
+        //      sits at unit * 128 + 4 ((4 s + (cl >> 2)) ^ (4 g + i)) + (cl & 3) = unit * 128 + 16 (s ^ g) + 4 ((cl >> 2) ^ i) + (cl & 3):
+        //      four address registers (one per i), s and t in the instruction's offset / one XOR per s.  NOTHING but MFMAs and LDS reads in
+        //      this loop: the waves beside these are issuing MFMAs too, and a vector instruction gets about one slot per MFMA there --
+        //      the activation's derivative waits for the barrier.  Two k-tiles at a time (independent chains).
+        const int c2 = cl >> 2, kr = cl & 3;
+        const float* wi0 = w1s + (4 * g + 0) * CH + 4 * (c2 ^ 0) + kr;
+        const float* wi1 = w1s + (4 * g + 1) * CH + 4 * (c2 ^ 1) + kr;
+        const float* wi2 = w1s + (4 * g + 2) * CH + 4 * (c2 ^ 2) + kr;
+        const float* wi3 = w1s + (4 * g + 3) * CH + 4 * (c2 ^ 3) + kr;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < 8; s += 2) {
             cf32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-            const int kq = 4 * s + (cl >> 2), kr = cl & 3;               // k = 16 s + cl: chunk, place in the chunk
+            const int o0 = 16 * (s ^ g), o1 = 16 * ((s + 1) ^ g);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const float* wu = w1s + (16 * t + 4 * g) * CH + kr;     // units 16 t + 4 g + i: (unit & 15) = 4 g + i
-                const float w0 = wu[0 * CH + 4 * (kq ^ (4 * g + 0))], w1 = wu[1 * CH + 4 * (kq ^ (4 * g + 1))];
-                const float w2 = wu[2 * CH + 4 * (kq ^ (4 * g + 2))], w3 = wu[3 * CH + 4 * (kq ^ (4 * g + 3))];
-                CMFMA(w0, g2T[t][0], a0); CMFMA(w1, g2T[t][1], a1); CMFMA(w2, g2T[t][2], a0); CMFMA(w3, g2T[t][3], a1);
+                const int ut = 16 * t * CH;
+                CMFMA(wi0[ut + o0], g2T[t][0], a0); CMFMA(wi0[ut + o1], g2T[t][0], a1);
+                CMFMA(wi1[ut + o0], g2T[t][1], a0); CMFMA(wi1[ut + o1], g2T[t][1], a1);
+                CMFMA(wi2[ut + o0], g2T[t][2], a0); CMFMA(wi2[ut + o1], g2T[t][2], a1);
+                CMFMA(wi3[ut + o0], g2T[t][3], a0); CMFMA(wi3[ut + o1], g2T[t][3], a1);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) h1T[s][i] = (a0[i] + a1[i]) * act_grad_c<ACT>(h1T[s][i]);
+            dh[s] = a0; dh[s + 1] = a1;
         }
     }
     lds_barrier();                                                                                   // #3 nobody reads h1 / g2 any more
     CSTAMP(4);
     if (chain) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-            *reinterpret_cast<float4*>(xb + row * CLD + 16 * s + 4 * g) = make_float4(h1T[s][0], h1T[s][1], h1T[s][2], h1T[s][3]);
+        for (int s = 0; s < 8; ++s) {
+            float4 o;
+            o.x = dh[s][0] * act_grad_c<ACT>(h1T[s][0]); o.y = dh[s][1] * act_grad_c<ACT>(h1T[s][1]);
+            o.z = dh[s][2] * act_grad_c<ACT>(h1T[s][2]); o.w = dh[s][3] * act_grad_c<ACT>(h1T[s][3]);
+            *reinterpret_cast<float4*>(xb + row * CLD + 16 * s + 4 * g) = o;
+        }
     }
     lds_barrier();                                                                                   // #4 g1 (this role's part)
     CSTAMP(5);

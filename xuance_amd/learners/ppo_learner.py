@@ -302,8 +302,9 @@ class PPO_Learner(Learner):
         self.n_tiles = (bs + 31) // 32
         self.split = self.split_eligible(self.n_tiles)                 # role-split workgroups (csrc/ppo_trunk.hip)
         self.pair = self.pair_eligible(self.n_tiles)                   # ... on 64-row tiles
-        # ... with the forward / backward-data products as register chains (csrc/ppo_chain.hip: categorical head, A <= 4)
-        self.chain = self.pair and m.dist != "gaussian" and m.action_dim <= 4 and bool(getattr(self.config, "use_chain_update", True))
+        # ... with the forward / backward-data products as register chains (csrc/ppo_chain.hip: categorical head, A <= 4).  Off by
+        # default: measured in round 4 at 31.1 us per launch against 25.3 us for ppo_trunk_kernel
+        self.chain = self.pair and m.dist != "gaussian" and m.action_dim <= 4 and bool(getattr(self.config, "use_chain_update", False))
         self.records = self.cartpole_class()                           # 32-byte transition records (obs[4] | act | ret | adv | logp)
         # gradient slabs: one per tile; with the role-split kernel a fold region behind the parameters takes the critic
         # role's first-layer gradient, and every (tile, role) workgroup has its own row of loss partials
