@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
     __shared__ int s_fail, s_xfail;
     const int grp = threadIdx.x >> 8, tg = threadIdx.x & 255;
     const int vb = blockIdx.x * G + grp, n_vb = (int)((P / 4 + 63) / 64);
+    const unsigned failed_before = __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an earlier launch timed out
     if (XC && threadIdx.x == 0) s_xfail = 0;
     // bookkeeping of the update phase that used to be launches of their own (xrl_mirrors_t.tick / .part): the last block
     // (the one with the fewest parameters) does it while its slab loads are in flight
@@ -374,7 +375,9 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
     // above is never multiplied in, and Adam on a partial / stale peer average would leave the replicas diverged silently.
     // The block that failed skips its parameters; sync[2] stays set and the last block out reports a NaN norm (the learners
     // read both after the phase and raise).
-    const bool poisoned = s_fail == 1 || (XC && s_xfail) || total_norm != total_norm;
+    // (with clipping off there is no barrier in front of this point, so a failed wait in ANOTHER block, or in an earlier
+    //  launch of the same captured phase, is seen through the status word itself: one relaxed load per thread, issued at kernel start)
+    const bool poisoned = s_fail == 1 || (XC && s_xfail) || total_norm != total_norm || failed_before != 0u;
     if (i < P && !poisoned) {
         float g = gtot[grp][tg] * coef;
         grad[i] = g;

@@ -451,6 +451,16 @@ __global__ void __launch_bounds__(64) qmix_kernel(xrl_qmix_t p) {
         // round trips cost most of this kernel's 19 us at 1 920 rows)
         float s = 0.f;
         int i = lane;
+        if (p.B <= 64 * 32) {
+            // the step mask's sum as ONE round trip (32 clamped loads per lane in flight; a count of 0 / 1 flags: exact in any order) --
+            // the loop below is four dependent round trips at the recurrent update's 1 920 rows, in every one of its 1 920 workgroups
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = p.filled[min(lane + 64 * u, p.B - 1)];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += lane + 64 * u < p.B ? v[u] : 0.f;
+            i = p.B;
+        }
         for (; i + 64 * 7 < p.B; i += 64 * 8) {
             float v[8];
 #pragma unroll
@@ -643,6 +653,16 @@ __global__ void __launch_bounds__(64) qmix_prefetch_kernel(xrl_qmix_t p) {
     if (p.filled) {
         float s = 0.f;
         int i = lane;
+        if (p.B <= 64 * 32) {
+            // the step mask's sum as ONE round trip (32 clamped loads per lane in flight; a count of 0 / 1 flags: exact in any order) --
+            // the loop below is four dependent round trips at the recurrent update's 1 920 rows, in every one of its 1 920 workgroups
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = p.filled[min(lane + 64 * u, p.B - 1)];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += lane + 64 * u < p.B ? v[u] : 0.f;
+            i = p.B;
+        }
         for (; i + 64 * 7 < p.B; i += 64 * 8) {
             float v[8];
 #pragma unroll

@@ -162,8 +162,9 @@ class Learner:
         return self._xc
 
     OPT_TIMEOUT_MSG = ("xrl_reduce_adam: %s timed out -- the optimiser step of this update phase is invalid: parameters of the "
-                       "blocks that saw the time-out were NOT stepped (set use_fused_optimizer: False to use the two-launch "
-                       "sequence, dist_gradient_exchange: False to average through the process group)")
+                       "blocks that saw the time-out were NOT stepped, later launches of the phase stepped nothing -- the replica is "
+                       "partially updated and cannot be repaired in place: reload a checkpoint (set use_fused_optimizer: False to use "
+                       "the two-launch sequence, dist_gradient_exchange: False to average through the process group)")
 
     def raise_on_optimizer_timeout(self, code=None):
         """xrl_reduce_adam's status word sync[2]: 1 = the inter-block barrier, 2 = the wait for the other ranks' gradient rows
