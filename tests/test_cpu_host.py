@@ -48,11 +48,12 @@ def test_ctypes_structs_match_c_layout():
     src += 'printf("act.post %zu\\n", offsetof(xrl_wide_act_t, post));\nprintf("act.xchg %zu\\n", offsetof(xrl_wide_act_t, xchg));\n'
     src += 'printf("wide.obs %zu\\n", offsetof(xrl_ppo_wide_t, obs));\nprintf("wide.dbg %zu\\n", offsetof(xrl_ppo_wide_t, dbg));\n'
     src += 'printf("loss.M %zu\\n", offsetof(xrl_ppo_loss_t, M));\n'
-    offs = {"xrl_mirrors_t": (_lib.Mirrors, ("tick", "part_out", "tick_inc", "part_rows")),        # fields added in round 3
+    offs = {"xrl_mirrors_t": (_lib.Mirrors, ("tick", "part_out", "tick_inc", "part_rows", "alt_lo", "alt_hi", "alt_split")),   # fields added in rounds 3, 4
             "xrl_egreedy_t": (_lib.EGreedy, ("eps", "seed", "step_dev")), "xrl_marl_act_t": (_lib.MarlAct, ("eps", "seed")),
             "xrl_marl_act_gru_t": (_lib.MarlActGru, ("eps_dev", "step", "eps")),
             "xrl_dqn_tail_td_t": (_lib.DqnTailTd, ("partials", "M", "act", "gamma", "slabs", "slab_stride", "off_b2")),
-            "xrl_dqn_act_tail_t": (_lib.DqnActTail, ("step_dev", "seed", "step", "n", "act", "eps")),
+            "xrl_dqn_act_tail_t": (_lib.DqnActTail, ("step_dev", "seed", "step", "n", "act", "eps", "eps_sched", "eps_kstar", "eps_start", "eps_delta")),
+            "xrl_ppo_wide_t": (_lib.PpoWide, ("rows_g2", "rows_h1", "rows_ld")),
             "xrl_rollout_run_t": (_lib.RolloutRun, ("act", "flags", "gamma", "seed", "step", "step_dev", "obs_raw", "cp_stats", "f_val", "xchg", "dbg")),
             "xrl_rollout_wide_t": (_lib.RolloutWide, ("log_std_off", "H", "flags", "gamma", "seed", "env_step", "env_step_dev", "obs_raw", "ret_var",
                                                       "env_stats", "Bmat", "f_seg", "raw_rew", "xchg", "dbg"))}
