@@ -62,6 +62,12 @@ class PPO_Agent(AgentSurface):
         self.returns = torch.zeros(n, device=dev)               # discounted return tracker (ppo_agent.py:144)
         self.X = torch.zeros(2 * n, D, device=dev) if not self.frames else None   # policy input: [obs_t ; next_obs_{t-1}] (normalised)
         self.Xu8 = torch.zeros(2 * n, D, dtype=torch.uint8, device=dev) if self.frames else None   # the same rows as raw frames
+        # a provider that can write into the policy's input batches (envs/synthetic.py: bind_policy_batch) saves the two frame copies of a
+        # vector step: two batches alternate with the provider's observation buffers
+        self._xin = None
+        if self.frames and hasattr(self.envs, "bind_policy_batch") and bool(_get(config, "use_bound_frames", True)):
+            self._xin = [torch.zeros(2 * n, D, dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.envs.bind_policy_batch(self._xin)
         if self.frames:
             assert not self.use_obsnorm, "uint8 frames are stored and fed as they are (configs/ppo/atari.yaml: use_obsnorm False)"
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)   # RNG counter base, advanced per rollout
@@ -142,8 +148,11 @@ class PPO_Agent(AgentSurface):
         env, n, A, f = self.envs, self.n_envs, self.model.action_dim, self.memory.soa.fields
         cur = env.buf_obs.view(n, -1)
         f["observations"][t].view(n, -1).copy_(cur)               # memory.observations[t] = obs (uint8, ppo_agent.py:128)
-        self.Xu8[:n].copy_(cur)
-        heads = self.model.forward(self.Xu8, 2 * n, keep=False)
+        if self._xin is not None:
+            heads = self.model.forward(self._xin[env._cur], 2 * n, keep=False)   # [obs_t ; next_obs_{t-1}], written there by the provider
+        else:
+            self.Xu8[:n].copy_(cur)
+            heads = self.model.forward(self.Xu8, 2 * n, keep=False)
         ops.policy_sample(heads=heads, log_std=None, act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
                           env_action=env.action, env_action_f=None, bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A,
                           ld=A + 1, gaussian=0, seed=self.seed, step=t, step_dev=self.step_counter)
@@ -151,8 +160,13 @@ class PPO_Agent(AgentSurface):
             env.step_device(offset=t)                               # static step index: the env's counter ticks once per rollout
         else:
             env.step_device()
-        self.Xu8[n:].copy_(env.next_obs.view(n, -1))
+        if self._xin is None:
+            self.Xu8[n:].copy_(env.next_obs.view(n, -1))
         ops.rollout_poststep(**self._post_args(t, (self.obs_mean, self.obs_var, self.obs_count), None))
+
+    def _policy_frames(self):
+        """The policy's uint8 input batch [obs ; previous next_obs] as it stands now."""
+        return self._xin[self.envs._cur] if self._xin is not None else self.Xu8
 
     def _enqueue_step(self, t):
         if self.frames:
@@ -407,7 +421,7 @@ class PPO_Agent(AgentSurface):
                           normalize=int(self.use_obsnorm), obs_range=float(self.obsnorm_range))
             wide.act(self.X, n, self.seed, 0, None, bootv_prev=self.memory.soa.fields["bootv"][T - 1], **kw)
         else:
-            heads = self.model.forward(self.Xu8, 2 * n, keep=False) if self.frames else self.model.forward(self.X, 2 * n)
+            heads = self.model.forward(self._policy_frames(), 2 * n, keep=False) if self.frames else self.model.forward(self.X, 2 * n)
             ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
                               bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
                               gaussian=0, seed=self.seed, step=0, step_dev=None)
@@ -530,7 +544,7 @@ class PPO_Agent(AgentSurface):
                 self._rollout_graph = None        # the dense workspaces grew since the capture (a larger get_actions batch):
             if self._rollout_graph is None:       # the old graph holds freed pointers -- capture again
                 if self.frames:                                       # (workspaces of the convolution stack: allocated outside the capture)
-                    self.model.forward(self.Xu8, 2 * self.n_envs, keep=False)
+                    self.model.forward(self._policy_frames(), 2 * self.n_envs, keep=False)
                 torch.cuda.synchronize()
                 g = ops.Graph()
                 with g:

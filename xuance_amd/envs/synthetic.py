@@ -66,6 +66,19 @@ class SyntheticAtariVecEnv(_Base):
                     seed=self.seed, step=self._host_step if offset is None else int(offset),      # eager loops: the host knows
                     step_dev=None if offset is None else self.step_counter)                         # the step index
 
+    def bind_policy_batch(self, batches):
+        """batches: two uint8 tensors [2 n, 84 * 84 * 4].  From now on the provider writes its observations straight into the policy's
+        input batches -- rows [0, n) of batches[i] are observation buffer i, rows [n, 2 n) receive the next observations of the step
+        that makes buffer i current -- so that an on-policy agent's [obs_t ; next_obs_{t-1}] batch of step t IS batches[self._cur]
+        (no copies; PPO on frame stacks, agents/ppo_agent.py)."""
+        n = self.num_envs
+        new = [b[:n].view(n, 84, 84, 4) for b in batches]
+        new[self._cur].copy_(self._bufs[self._cur])
+        self._bufs, self._nexts = new, [b[n:].view(n, 84, 84, 4) for b in batches]
+        self.buf_obs = self._bufs[self._cur]
+        self._nexts[self._cur].copy_(self.next_obs)
+        self.next_obs = self._nexts[self._cur]
+
     def reset(self):
         from .. import ops
         ops.synth_frames_step(reset=True, **self._kw(self.buf_obs))
@@ -76,6 +89,8 @@ class SyntheticAtariVecEnv(_Base):
         advance(T) (as SyntheticMujocoVecEnv); an on-policy agent uses either this or the host-indexed form, never both."""
         from .. import ops
         self._cur ^= 1
+        if getattr(self, "_nexts", None) is not None:
+            self.next_obs = self._nexts[self._cur]
         ops.synth_frames_step(**self._kw(self._bufs[self._cur], offset))
         self.buf_obs = self._bufs[self._cur]
         if offset is None:
