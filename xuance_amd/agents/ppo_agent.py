@@ -64,6 +64,7 @@ class PPO_Agent(AgentSurface):
         self.Xu8 = torch.zeros(2 * n, D, dtype=torch.uint8, device=dev) if self.frames else None   # the same rows as raw frames
         # a provider that can write into the policy's input batches (envs/synthetic.py: bind_policy_batch) saves the two frame copies of a
         # vector step: two batches alternate with the provider's observation buffers
+        self._acting_fast = False                                   # (set while a rollout is enqueued: _enqueue_rollout)
         self._xin = None
         if self.frames and hasattr(self.envs, "bind_policy_batch") and bool(_get(config, "use_bound_frames", True)):
             self._xin = [torch.zeros(2 * n, D, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -149,10 +150,10 @@ class PPO_Agent(AgentSurface):
         cur = env.buf_obs.view(n, -1)
         f["observations"][t].view(n, -1).copy_(cur)               # memory.observations[t] = obs (uint8, ppo_agent.py:128)
         if self._xin is not None:
-            heads = self.model.forward(self._xin[env._cur], 2 * n, keep=False)   # [obs_t ; next_obs_{t-1}], written there by the provider
+            heads = self.model.forward(self._xin[env._cur], 2 * n, keep=False, acting=self._acting_fast)   # [obs_t ; next_obs_{t-1}], written there by the provider
         else:
             self.Xu8[:n].copy_(cur)
-            heads = self.model.forward(self.Xu8, 2 * n, keep=False)
+            heads = self.model.forward(self.Xu8, 2 * n, keep=False, acting=self._acting_fast)
         ops.policy_sample(heads=heads, log_std=None, act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
                           env_action=env.action, env_action_f=None, bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A,
                           ld=A + 1, gaussian=0, seed=self.seed, step=t, step_dev=self.step_counter)
@@ -406,11 +407,31 @@ class PPO_Agent(AgentSurface):
         if wr is not None:
             return self._enqueue_rollout_wide(wr)
         T, n, A = self.horizon_size, self.n_envs, self.model.action_dim
-        for t in range(T):
-            self._enqueue_step(t)
-            self._step_hooks(t)
-        if hasattr(self.envs, "advance"):
-            self.envs.advance(T)
+        # frame stacks: the parameters do not change inside a rollout, so the convolution weight images are built ONCE (not by every
+        # vector step's pass: 5 us each) and the dense layer reads the last convolution's output in place through a column-permuted
+        # copy of its weights (no flatten launch: 10.8 us per step); config.use_fast_frame_acting
+        conv = getattr(self.model, "conv", None)
+        fast = self.frames and conv is not None and conv.implicit and hasattr(self.model, "refresh_acting_params") and \
+            bool(_get(self.config, "use_fast_frame_acting", True))
+        if fast:
+            self.model.refresh_acting_params()
+            conv.invalidate()
+            conv.pack_images([(None, False)])
+            conv.mark_live(self.model.params.flat)
+            self._acting_fast = True
+        try:
+            for t in range(T):
+                self._enqueue_step(t)
+                self._step_hooks(t)
+            if hasattr(self.envs, "advance"):
+                self.envs.advance(T)
+            self._enqueue_rollout_tail(T, n, A)
+        finally:
+            if fast:
+                self._acting_fast = False
+                conv.invalidate()
+
+    def _enqueue_rollout_tail(self, T, n, A):
         # buffer full: vals = get_terminated_values(next_obs) for every env (ppo_agent.py:129-135)
         wide = self._wide_acting()
         if wide is not None:
@@ -421,7 +442,7 @@ class PPO_Agent(AgentSurface):
                           normalize=int(self.use_obsnorm), obs_range=float(self.obsnorm_range))
             wide.act(self.X, n, self.seed, 0, None, bootv_prev=self.memory.soa.fields["bootv"][T - 1], **kw)
         else:
-            heads = self.model.forward(self._policy_frames(), 2 * n, keep=False) if self.frames else self.model.forward(self.X, 2 * n)
+            heads = self.model.forward(self._policy_frames(), 2 * n, keep=False, acting=self._acting_fast) if self.frames else self.model.forward(self.X, 2 * n)
             ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
                               bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
                               gaussian=0, seed=self.seed, step=0, step_dev=None)
@@ -545,6 +566,9 @@ class PPO_Agent(AgentSurface):
             if self._rollout_graph is None:       # the old graph holds freed pointers -- capture again
                 if self.frames:                                       # (workspaces of the convolution stack: allocated outside the capture)
                     self.model.forward(self._policy_frames(), 2 * self.n_envs, keep=False)
+                    if hasattr(self.model, "refresh_acting_params"):  # (... and the acting copy of the dense parameters)
+                        self.model.refresh_acting_params()
+                        self.model.forward(self._policy_frames(), 2 * self.n_envs, keep=False, acting=True)
                 torch.cuda.synchronize()
                 g = ops.Graph()
                 with g:

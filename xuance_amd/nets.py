@@ -1292,12 +1292,42 @@ class ActorCriticCNN:
     load_state_dict = ActorCriticNet.load_state_dict
     parameters = ActorCriticNet.parameters
 
-    def forward(self, x_u8, M, ldx=None, keep=True):
+    # -- acting passes without the (c, h, w) flatten launch: a copy of the dense parameters whose first fc layer has its columns in the
+    #    convolution output's own (h, w, c) order, so that the layer reads the last convolution's NHWC output as it lies (round 4: the
+    #    flatten launch was 10.8 of the ~80 us of a PPO-Atari vector step).  Refreshed once per rollout (refresh_acting_params: two
+    #    small copies + one column gather, capturable); products are summed in a different column order than on the training path.
+    def acting_params(self):
+        if getattr(self, "_act_flat", None) is None:
+            Hc, Wc, C, k, s, p, OH, OW, F = self.conv.geo[-1]
+            Pp = OH * OW
+            assert Pp * F == self.n_flat
+            new = torch.arange(Pp * F, dtype=torch.int64)
+            self._act_perm = ((new % F) * Pp + new // F).to(self.params.device)      # new column p * F + f <- reference column f * P + p
+            self._act_flat = self.params.flat.clone()
+            n = self.fc_names[0] + ".weight"
+            self._act_w = (self.params.offsets[n], self.params.view(n).numel())
+        return self._act_flat
+
+    def refresh_acting_params(self):
+        af, (off, cnt) = self.acting_params(), self._act_w
+        flat, n = self.params.flat, self.fc_names[0] + ".weight"
+        if off > 0:
+            af[:off].copy_(flat[:off])
+        af[off + cnt:].copy_(flat[off + cnt:])
+        W = self.params.view(n)
+        torch.index_select(W, 1, self._act_perm, out=af[off:off + cnt].view(W.shape))
+
+    def forward(self, x_u8, M, ldx=None, keep=True, acting=False):
         """x_u8 [rows >= M, H*W*C] uint8 (or float32 in 0..255) frames -> heads [cap, A + 1].  keep: this pass will be
-        differentiated (its im2col columns and activations stay in the "grad" workspace)."""
+        differentiated (its im2col columns and activations stay in the "grad" workspace).  acting (with keep=False): the dense part
+        reads the last convolution's output in place through acting_params() -- the caller has refreshed them since the last
+        parameter update (refresh_acting_params)."""
         ws = self.conv.workspace("grad" if keep else "act", M, keep)
         if keep:
             self._ws, self._M = ws, M
+        if acting and not keep and self.conv.implicit and getattr(self, "_act_flat", None) is not None:
+            self.conv.forward(x_u8[:M].reshape(M, -1), M, ws, pool=False)
+            return self.plan.forward(ws.y[-1].view(-1)[:M * self.n_flat].view(M, self.n_flat), self.n_flat, M, flat=self._act_flat)
         feat = self.conv.forward(x_u8[:M].reshape(M, -1), M, ws)
         if keep:
             self._feat_in = feat
