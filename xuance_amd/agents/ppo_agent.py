@@ -391,9 +391,9 @@ class PPO_Agent(AgentSurface):
                 wr.run(t, 1)
         else:
             wr.run(0, T)
-        heads = self.model.forward(f["observations"].view(M, -1), M)
+        heads = self.model.forward_values(f["observations"].view(M, -1), M)
         ops.copy_column(heads, A + 1, A, f["values"], M)
-        heads = self.model.forward(self._wr_xnext, M)
+        heads = self.model.forward_values(self._wr_xnext, M)
         ops.copy_column(heads, A + 1, A, f["bootv"], M)
         self.envs.advance(T)
         ops.counter_add(self.step_counter, T)

@@ -132,11 +132,12 @@ class Plan:
             ws[key] = torch.empty(ks * max(M, self.cap) * L.N, device=self.params.device)
         return ws[key], ks
 
-    def forward(self, x, ldx, M, flat=None):
-        """x: device tensor holding the input rows with row stride ldx (floats)."""
+    def forward(self, x, ldx, M, flat=None, stages=None):
+        """x: device tensor holding the input rows with row stride ldx (floats).  stages: a subset of the plan's layers to run
+        instead of all of them (ActorCriticNet.critic_stages: the value branch alone)."""
         self.ensure(M)
         P = self.params
-        for stage in self.stages:
+        for stage in (self.stages if stages is None else stages):
             groups = []
             for L in stage:
                 a, lda = self._buf(self.acts, L.in_level, L.in_off, x, ldx)
@@ -331,6 +332,14 @@ class ActorCriticNet:
         self.params = FlatParams(specs, device)
         self.plan = Plan(self.params, widths, stages)
         self.head_ld = action_dim + 1
+        # the value branch alone (forward_values): with no shared representation the critic's layers form a chain of their own -- its
+        # half of the stacked first level, then its layer of every later stage
+        self.critic_stages = None
+        if not rep_layers:
+            (na0, ka0, oa0), (nc0, kc0, oc0) = a_layers[0], c_layers[0]
+            cs = [[Layer(nc0, kc0, oc0, activation, 0, 0, 1, oa0, nc0 + ".weight", nc0 + ".bias")]]
+            cs += [[st[1]] for st in stages[1:]]
+            self.critic_stages = cs
         if init:
             self.reset_parameters()
 
@@ -365,6 +374,13 @@ class ActorCriticNet:
     def forward(self, x, M, ldx=None):
         """Returns the head buffer [cap, action_dim+1]: columns [0,A) actor output, column A the value."""
         return self.plan.forward(x, self.obs_dim if ldx is None else ldx, M)
+
+    def forward_values(self, x, M, ldx=None):
+        """The head buffer with only column A (the value) computed: the critic branch alone where the network has no shared
+        representation (half the launches' work; the bootstrap / value passes of a whole rollout), else forward()."""
+        if self.critic_stages is None:
+            return self.forward(x, M, ldx)
+        return self.plan.forward(x, self.obs_dim if ldx is None else ldx, M, stages=self.critic_stages)
 
     @property
     def d_heads(self):
