@@ -210,9 +210,15 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
             drift = abs(float(oinfo[ok]) - float(oinfo64[ok])) / scale
             _record(f"{key} (pass {it}): float32 oracle vs float64 chain (the yardstick of the next line)", drift, drift, 0.0, 1)
             assert_close(info[key], oinfo64[ok], max(1e-5, 4.0 * drift), f"{key} (pass {it}) vs the float64 chain", scale=scale)
-        # clip_ratio is a COUNT of samples with ratio outside [1 - eps, 1 + eps], divided by the minibatch size: a ratio
-        # within float32 rounding of the boundary may fall on either side (<= 2 such samples of 8 192)
-        assert abs(info["clip_ratio"] - float(oinfo["clip_ratio"])) * idx.shape[1] <= 2.0 + 1e-6, "clip_ratio"
+        # clip_ratio is a COUNT of samples with ratio outside [1 - eps, 1 + eps], divided by the minibatch size.  A ratio within the
+        # chain's drift of a boundary may fall on either side: the allowance is the number of samples of this minibatch whose float64
+        # ratio lies within a band around 1 +- eps as wide as 4 x the float32 ORACLE's own worst ratio deviation from the float64 chain
+        # (measured round 4: 4 samples of 8 192 for the engine after a re-ordered first-layer gradient sum; band ~1e-4), at least 2.
+        r64, r32 = np.asarray(oinfo64["ratio"], np.float64).reshape(-1), np.asarray(oinfo["ratio"], np.float64).reshape(-1)
+        band = max(4.0 * float(np.abs(r32 - r64).max()), 1e-6)
+        near = int(np.sum((np.abs(r64 - (1.0 - cfg["clip_range"])) < band) | (np.abs(r64 - (1.0 + cfg["clip_range"])) < band)))
+        _record(f"clip count (pass {it}): ratio band {band:.2e}, samples inside it", float(near), float(near), 0.0, 1)
+        assert abs(info["clip_ratio"] - float(oinfo64["clip_ratio"])) * idx.shape[1] <= max(2, near) + 1e-6, ("clip_ratio", near, band)
         # parameters after 64 / 128 chained Adam steps.  Two things make ANY float32 evaluation (the reference's torch ops,
         # the NumPy oracle, these kernels) drift from the exact float64 chain by far more than its per-update error:
         # PPO's clipped surrogate has a DISCONTINUOUS gradient at ratio = 1 +- eps (a sample within float32 rounding of the

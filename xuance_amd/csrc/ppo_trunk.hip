@@ -34,7 +34,7 @@ constexpr int TAMAX = 8;                     // head width limit
 
 template <int PT>
 struct TrunkLds {
-    // h1, h2 (xb -- dLoss/dh1 -- takes h2's place once the head gradients have been formed), g2; gathered rows; parameters
+    // h1, h2 (the first-layer gradient's partial sums take h2's place once the head gradients have been formed), g2; gathered rows; parameters
     static constexpr int H1 = 0, H2 = H1 + PT * TLD, G2 = H2 + PT * TLD, XS = G2 + PT * TLD, RSC = XS + PT * TXLD,
                          DZH = RSC + PT * 12, W0T = DZH + PT * 16, B0 = W0T + TDMAX * TLD, BM = B0 + TH, WH = BM + TH,
                          BH = WH + TAMAX * TLD, LS = BH + TAMAX, SRC = LS + TAMAX, FLOATS = SRC + PT;
@@ -46,21 +46,6 @@ __device__ __forceinline__ float trow_sum(float v) {                   // sum ov
     if (TPR == 16) v += __shfl_xor(v, 8, 64);
     v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     return v;
-}
-
-// rows [r0, r0 + PT / 2) of column c of g1 times NQ2 float2 chunks of the observations: the first-layer weight gradient of one thread
-template <int NQ2, int PT>
-__device__ __forceinline__ void dw0_rows(const float* gcol, const float* xin, float (&acc)[TDMAX / 2], float& ab) {
-#pragma unroll 4
-    for (int rr = 0; rr < PT / 2; ++rr) {
-        const float g = gcol[rr * TLD];
-        ab += g;
-#pragma unroll
-        for (int q = 0; q < NQ2; ++q) {
-            const float2 x = *reinterpret_cast<const float2*>(xin + rr * TXLD + 2 * q);
-            acc[2 * q] += g * x.x; acc[2 * q + 1] += g * x.y;
-        }
-    }
 }
 
 // DS / AS: compile-time observation / head width of an instance (0 = taken from the arguments): the CartPole class (4, 2) -- the
@@ -78,7 +63,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
     float* h1 = lds + L::H1;
     float* h2 = lds + L::H2;
     float* g2 = lds + L::G2;
-    float* xb = h2;                                    // (see TrunkLds)
     float* xs = lds + L::XS;                           // [PT][28] gathered observations, zero beyond D
     float* rsc = lds + L::RSC;                         // [PT][12] act[<= 8] | ret | adv | old_logp
     float* dzh = lds + L::DZH;                         // [PT][16] dLoss/d(head pre-activations)[8] | d log_std terms[8]
@@ -490,52 +474,64 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
     }
     if (dbg_w) { float t_ = dacc[15]; asm volatile("" ::"v"(t_)); }
     WSTAMP(3);
-    lds_barrier();                                                                                   // #4 h2 is free
     WSTAMP(4);
-    if (RB == 2 || wave < 4) {
-        const int k_out = cblk * 32 + li;
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-            xb[row * TLD + k_out] = dacc[rr] * act_grad_c<ACT>(h1[row * TLD + k_out]);
-        }
-    }
-    WSTAMP(5);
-    lds_barrier();                                                                                   // #5 g1 (this role's part)
-    TSTAMP(7);
-    WSTAMP(6);
-    // ---- first layer: dW0[c][k] = sum_rows g1[row][c] * x[row][k], db0[c] -- the actor's part into the slab's first-layer region,
-    //      the critic's into the fold region behind the parameters (the reduction adds it onto the same columns).
-    //      thread = (column c, row half lh, component range by wave >> 2): halves met by a lane shuffle; the components in float2 chunks
-    //      (the gathered observation rows are zero beyond D)
+    // ---- first layer: dW0[c][k] = sum_rows g1[row][c] * x[row][k], db0[c], g1 = dH1 * act'(h1) -- straight from the dH1 accumulators
+    //      (round 4: g1 used to go to LDS ([row][column] where h2 was), two barriers around it, and come back through column loops: 4.4 k
+    //      cycles): lane (li, lh) of wave (cblk, rblk) holds 16 rows of column 32 cblk + li; it sums them against the rows' observations
+    //      (every lane of a half-wave reads the same row of xs: broadcasts), the halves meet by a lane shuffle, the two row blocks of a
+    //      64-row tile through LDS (where h2 was: nobody reads it after barrier #3b).  The actor's part goes into the slab's first-layer
+    //      region, the critic's into the fold region behind the parameters (the reduction adds it onto the same columns).
     {
         float* dst = actor ? slab : slab + p.l0_fold_off;
         const int w_at = actor ? L0.w_off : 0, b_at = actor ? L0.b_off : TH * D;
-        const int kh = ((D + 3) / 4) * 2;                              // components per range, even
-        const int c = cblk * 32 + li, k0 = (wave >> 2) * kh, nk = min(kh, D - k0), nq2 = (max(nk, 0) + 1) / 2;
-        const float* gcol = xb + (lh * (PT / 2)) * TLD + c;
-        const float* xin = xs + (lh * (PT / 2)) * TXLD + k0;
-        float acc[TDMAX / 2], ab = 0.f;
+        constexpr int NQ = DS ? (DS + 3) / 4 : TDMAX / 4;               // float4 chunks of an observation row
+        float* part = h2;                                                // [RB][128][TDMAX + 1] partial sums of the row blocks
+        constexpr int PLD = TDMAX + 1;
+        if (RB == 2 || wave < 4) {
+            const int c = cblk * 32 + li;
+            float acc[4 * NQ], ab = 0.f;
 #pragma unroll
-        for (int k = 0; k < TDMAX / 2; ++k) acc[k] = 0.f;
-        switch (nq2) {
-            case 1: dw0_rows<1, PT>(gcol, xin, acc, ab); break;
-            case 2: dw0_rows<2, PT>(gcol, xin, acc, ab); break;
-            case 3: dw0_rows<3, PT>(gcol, xin, acc, ab); break;
-            case 4: dw0_rows<4, PT>(gcol, xin, acc, ab); break;
-            case 5: dw0_rows<5, PT>(gcol, xin, acc, ab); break;
-            case 6: dw0_rows<6, PT>(gcol, xin, acc, ab); break;
-            default: dw0_rows<0, PT>(gcol, xin, acc, ab); break;      // (no components in this range: the bias sum only)
-        }
-        ab += __shfl_xor(ab, 32, 64);
+            for (int k = 0; k < 4 * NQ; ++k) acc[k] = 0.f;
 #pragma unroll
-        for (int k = 0; k < TDMAX / 2; ++k) {
-            if (k < nk) {                                                // (nk is uniform over the wave)
-                const float v = acc[k] + __shfl_xor(acc[k], 32, 64);
-                if (lh == 0) dst[w_at + c * D + k0 + k] = v;
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                const float g = dacc[rr] * act_grad_c<ACT>(h1[row * TLD + c]);
+                ab += g;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (4 * q < D) {
+                        const float4 x = *reinterpret_cast<const float4*>(xs + row * TXLD + 4 * q);    // (zero beyond D)
+                        acc[4 * q] += g * x.x; acc[4 * q + 1] += g * x.y; acc[4 * q + 2] += g * x.z; acc[4 * q + 3] += g * x.w;
+                    }
+                }
+            }
+            ab += __shfl_xor(ab, 32, 64);
+#pragma unroll
+            for (int k = 0; k < 4 * NQ; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+            if (RB == 1) {
+                if (lh == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4 * NQ; ++k) if (k < D) dst[w_at + c * D + k] = acc[k];
+                    dst[b_at + c] = ab;
+                }
+            } else if (lh == 0) {
+                float* pp = part + (rblk * TH + c) * PLD;
+#pragma unroll
+                for (int k = 0; k < 4 * NQ; ++k) if (k < D) pp[k] = acc[k];
+                pp[TDMAX] = ab;
             }
         }
-        if (lh == 0 && (wave >> 2) == 0) dst[b_at + c] = ab;
+        if (RB == 2) {
+            WSTAMP(5);
+            lds_barrier();                                                                           // #4 the two row blocks' partial sums
+            TSTAMP(7);
+            WSTAMP(6);
+            for (int e = tid; e < TH * (D + 1); e += FUSED_THREADS) {
+                const int c = e / (D + 1), k = e - c * (D + 1), kk = k < D ? k : TDMAX;
+                const float v = part[c * PLD + kk] + part[(TH + c) * PLD + kk];
+                dst[k < D ? w_at + c * D + k : b_at + c] = v;
+            }
+        }
     }
     TSTAMP(8);
     WSTAMP(7);
