@@ -460,6 +460,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
                 for (int i = 0; i < PD / 2; ++i) { MFMA4(af[i], pf[hq * 8 + i], dacc) }
             }
         }
+        if (!(p.pad3 & 1)) {                                             // (pad3 bit 0: diagnostics -- tools/probe_pair_sequence.py times the pair without these stores)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -467,6 +468,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
                 const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
                 dW[(size_t)row * TH + (kt0 + t) * 32 + li] = acc[t][rr];
             }
+        }
         if (RB == 2) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); }
