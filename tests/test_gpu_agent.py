@@ -404,7 +404,7 @@ def test_fused_reduce_adam_is_bit_identical_to_the_two_launches():
         if fused_opt:
             assert lr.opt_sync.tolist()[:3] == [0, 0, 0]          # barrier reset itself, no time-out
         res.append(dict(p=npy(agent.model.params.flat), m=npy(opt.m), v=npy(opt.v), g=npy(opt.grad), frag=npy(lr.frag),
-                        img=npy(lr.cache_image), sched=np.array([st.step, st.sched_steps, st.last_lr, st.last_grad_norm]),
+                        img=npy(lr.cache_image) if lr.cache_image is not None else np.zeros(1), sched=np.array([st.step, st.sched_steps, st.last_lr, st.last_grad_norm]),
                         info=np.array([info[k] for k in sorted(info)])))
     a, b = res
     assert a["sched"][0] == 8
@@ -412,24 +412,32 @@ def test_fused_reduce_adam_is_bit_identical_to_the_two_launches():
         assert np.array_equal(a[k], b[k]), k
 
 
-def test_adam_mirrors_keep_every_derived_layout_current():
-    """After full update phases the transposed / packed / fragment-ordered copies equal a fresh re-pack of the parameters."""
+@pytest.mark.parametrize("split", [True, False])
+def test_adam_mirrors_keep_every_derived_layout_current(split):
+    """After full update phases the derived parameter copies equal a fresh re-pack of the parameters: the fragment-ordered copy of the
+    branch layer (both sections) always; the transposed / packed copies of the any-shape minibatch kernel when that kernel is the
+    one in use (role split declined) -- the role-split kernel reads neither, so its learner does not maintain them."""
     from xuance_amd import ops
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import DeviceCartPoleVecEnv
     torch.manual_seed(0)
-    agent = PPO_Agent(make_config(64, 32, n_epochs=2, n_minibatch=2), DeviceCartPoleVecEnv(64, seed=5))
+    agent = PPO_Agent(make_config(64, 32, n_epochs=2, n_minibatch=2, use_role_split_update=split), DeviceCartPoleVecEnv(64, seed=5))
     for _ in range(2):
         agent.rollout()
         agent.update()
     lr, plan, flat = agent.learner, agent.model.plan, agent.model.params.flat
-    assert lr.frag is not None and len(lr._mirrors) == 4
-    pt, img, fr = torch.zeros_like(lr.params_t), torch.zeros_like(lr.cache_image), torch.zeros_like(lr.frag)
-    ops.transpose_mid(plan, flat, pt); ops.pack_rollout_cache(plan, flat, img); ops.pack_mid_frags(plan, flat, fr)
+    assert lr.split == split and lr.frag is not None and len(lr._mirrors) == (2 if split else 4)
+    fr = torch.zeros_like(lr.frag)
+    ops.pack_mid_frags(plan, flat, fr)
     torch.cuda.synchronize()
-    mid = [L for st in plan.stages[1:-1] for L in st]
-    lo = agent.model.params.offsets[mid[0].w_name]; hi = lo + mid[0].N * mid[0].K
-    assert torch.equal(lr.params_t[lo:hi], pt[lo:hi]) and torch.equal(lr.cache_image, img) and torch.equal(lr.frag, fr)
+    assert torch.equal(lr.frag, fr)
+    if not split:
+        pt, img = torch.zeros_like(lr.params_t), torch.zeros_like(lr.cache_image)
+        ops.transpose_mid(plan, flat, pt); ops.pack_rollout_cache(plan, flat, img)
+        torch.cuda.synchronize()
+        mid = [L for st in plan.stages[1:-1] for L in st]
+        lo = agent.model.params.offsets[mid[0].w_name]; hi = lo + mid[0].N * mid[0].K
+        assert torch.equal(lr.params_t[lo:hi], pt[lo:hi]) and torch.equal(lr.cache_image, img)
 
 
 @pytest.mark.parametrize("wide,use_graph,n,T,nmb,whole", [(True, False, 32, 16, 2, False), (True, True, 32, 16, 2, False),

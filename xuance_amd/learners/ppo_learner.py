@@ -321,9 +321,10 @@ class PPO_Learner(Learner):
         self._fused_bs = bs
         self._mirrors = []
         self.params_t = self.cache_image = None
-        if not self.split or self.cartpole_class():
-            # derived layouts of the single-workgroup kernel (ppo_fused: transposed middle weights, packed small
-            # parameters); the CartPole class keeps them current too -- its agent's rollout kernels read the same image
+        if not self.split:
+            # derived layouts of the single-workgroup kernel (ppo_fused: transposed middle weights, packed small parameters).  (Until
+            # round 4 the role-split CartPole class kept them current as well, for rollout kernels that have since been replaced: two
+            # of the optimiser launch's four mirror maps, ~70 k scattered stores per step, for nobody.)
             self.params_t = torch.zeros(P, device=dev)
             self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
             self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
