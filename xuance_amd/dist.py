@@ -128,7 +128,7 @@ class GradientExchange:
     device memory) and every peer's, mapped through IPC handles that travel over the process group once.  After this
     set-up the data path of an update makes no collective call at all (include/xrl_hip.h, csrc/optim.hip)."""
 
-    def __init__(self, P, device, max_spins=4_000_000):
+    def __init__(self, P, device, max_spins=None):
         from . import ops
         from ._lib import Exchange
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -157,6 +157,11 @@ class GradientExchange:
         x = Exchange()
         for r, p in enumerate(self.peers):
             x.base[r] = p
+        # polling rounds a group waits for its peers' rows before the launch gives up (sleep 2 between rounds: ~0.3 s at the default).
+        # XRL_DIST_EXCHANGE_SPINS raises it where ranks may be far apart for reasons other than a dead peer -- several ranks time-sharing
+        # ONE GPU (test boxes): a rank can sit in this wait for as long as its peers take to capture their first update graph
+        if max_spins is None:
+            max_spins = int(os.environ.get("XRL_DIST_EXCHANGE_SPINS", 4_000_000))
         x.stride4, x.world, x.rank, x.max_spins, x.inv_world = self.stride4, self.world, self.rank, int(max_spins), 1.0 / self.world
         self.struct = x
 
