@@ -421,3 +421,53 @@ def test_wide_kernel_class_is_recognised_on_the_host():
     assert not ops.PpoWideState.eligible(mk(17, 6, "gaussian", (256,), (256,), (256,), "relu", activation_action="tanh"))
     assert not ops.PpoWideState.eligible(mk(17, 6, "categorical", (), (256, 256), (256, 256), "relu"))
     assert not ops.PpoWideState.eligible(mk(17, 6, "gaussian", (), (256, 256), (256, 256), "sigmoid", activation_action="tanh"))
+
+
+def test_epsilon_schedule_from_a_step_counter_equals_the_reference_loop():
+    """xrl_dqn_act_tail_t.eps_sched (csrc/td.hip): epsilon of vector step k = (float32)(start - (double)(min(k, k*) * n) * delta) must be
+    the value OffPolicyAgent._update_explore_factor (off_policy.py:119-127) has reached after k vector steps -- `e = start -
+    current_step * delta` re-evaluated while the PREVIOUS value is above end_greedy, current_step growing by n per step -- for
+    every k, including the steps after the schedule has stopped (it stops one step LATE, on the first value <= end, not at end)."""
+    import struct
+    f32 = lambda x: struct.unpack("f", struct.pack("f", x))[0]
+    for n, start, end, decay in ((64, 0.5, 0.05, 10 ** 6), (16, 0.5, 0.05, 16 * 16 * 30), (8, 1.0, 0.01, 1000), (3, 1.0, 0.1, 50),
+                                 (5, 0.3, 0.3, 100)):
+        delta = (start - end) / (decay / n)
+        # the reference's loop
+        ref, e, cs = [], start, 0
+        for k in range(400):
+            ref.append(e)
+            cs += n
+            if e > end:
+                e = start - cs * delta
+        # the host constant k* and the launch's arithmetic
+        from xuance_amd.agents.dqn_agent import eps_kstar
+        kstar = eps_kstar(start, end, delta, n)
+        for k in range(400):
+            got = f32(start - float(min(k, kstar) * n) * delta)
+            assert got == f32(ref[k]), (n, k, got, ref[k])
+
+
+def test_ring_cursor_of_a_captured_store_equals_the_host_store_sequence():
+    """xrl_soa_store_step_ring: slot = (slot_bias + c) mod n_size, filled = min(size_bias + c + 1, n_size) with (slot_bias, size_bias)
+    = HipOffPolicyBuffer.ring_bias(counter value) taken once -- against store()'s own ptr / size sequence, across the ring's
+    wrap-around and for a capture taken at any point of the filling (the full ring's bias is one constant)."""
+    class Ring:                                                # the host mirrors of HipOffPolicyBuffer (memory.py), nothing else
+        def __init__(self, n_size):
+            self.n_size, self.ptr, self.size = n_size, 0, 0
+    from xuance_amd.memory import HipOffPolicyBuffer
+    for n_size in (1, 5, 24):
+        for start in (0, 3, n_size - 1, n_size, 2 * n_size + 1):
+            r = Ring(n_size)
+            for _ in range(start):                              # stores before the capture
+                r.ptr, r.size = (r.ptr + 1) % n_size, min(r.size + 1, n_size)
+            c0 = 1000 + start                                   # the device counter's value at capture (any offset from the step count)
+            sb, zb = HipOffPolicyBuffer.ring_bias(r, c0)
+            for j in range(3 * n_size + 2):                     # replays: counter c0 + j
+                c = c0 + j
+                slot, filled = (sb + c) % n_size, min(zb + c + 1, n_size)
+                assert slot == r.ptr and filled == min(r.size + 1, n_size), (n_size, start, j)
+                r.ptr, r.size = (r.ptr + 1) % n_size, min(r.size + 1, n_size)
+                if r.size == n_size:                            # (what DQN_Agent._run_pair does: a new key once the ring is full)
+                    sb2, zb2 = HipOffPolicyBuffer.ring_bias(r, c + 1)
+                    assert (sb2 - sb) % n_size == 0 and min(zb2 + c + 2, n_size) == n_size

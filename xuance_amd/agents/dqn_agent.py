@@ -19,6 +19,16 @@ def _get(cfg, name, default=None):
     return getattr(cfg, name, default)
 
 
+def eps_kstar(start_greedy, end_greedy, delta_egreedy, n_envs):
+    """First vector step k whose epsilon start - (k n) delta is <= end_greedy: where OffPolicyAgent._update_explore_factor
+    (off_policy.py:119-127) stops updating -- the host constant of xrl_dqn_act_tail_t.eps_sched."""
+    k, e = 0, start_greedy
+    while e > end_greedy:
+        k += 1
+        e = start_greedy - (k * n_envs) * delta_egreedy
+    return k
+
+
 class DQN_Agent(AgentSurface):
     def __init__(self, config: Namespace, envs, callback=None):
         self.config, self.envs, self.callback = config, envs, callback
@@ -170,13 +180,8 @@ class DQN_Agent(AgentSurface):
     #    optimiser launch (DQN_Learner.update_from_buffer).  The host mirrors (current_step, e_greedy, memory.ptr / size, the step
     #    counters) advance without reading anything back, so the launch-by-launch loop can take over at any pair boundary.
     def _eps_kstar(self):
-        """First vector step whose epsilon is <= end_greedy (where _update_explore_factor stops updating)."""
         if getattr(self, "_kstar", None) is None:
-            k, e = 0, self.start_greedy
-            while e > self.end_greedy:
-                k += 1
-                e = self.start_greedy - (k * self.n_envs) * self.delta_egreedy
-            self._kstar = k
+            self._kstar = eps_kstar(self.start_greedy, self.end_greedy, self.delta_egreedy, self.n_envs)
         return self._kstar
 
     def _pair_ready(self):
