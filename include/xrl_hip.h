@@ -409,7 +409,7 @@ typedef struct {
 int xrl_cartpole_step(const xrl_cartpole_t* p, int reset, xrl_stream_t stream);
 
 /* Device-resident Pendulum-v1 (kind 1), MountainCar-v0 (2), Acrobot-v1 (3): the other environments of the reference's
- * configs/ppo/classic_control/*.yaml, same contract as xrl_cartpole_step.  Dynamics as published with Gymnasium's classic_control
+ * the yaml files of configs/ppo/classic_control, same contract as xrl_cartpole_step.  Dynamics as published with Gymnasium's classic_control
  * package (third-party; csrc/classic.h restates them, oracle/xrl_oracle.py is the NumPy twin).  obs: [n][3 | 2 | 6]. */
 typedef struct {
     double* state;            /* [n][4] (Pendulum: theta, theta_dot; MountainCar: position, velocity; Acrobot: all four) */
