@@ -14,7 +14,7 @@ for r in recs:
     tagged = any(k in r for k in ("err64", "ref64", "bound")) or any(w in r["what"] for w in ("chain after", "noise", "float64"))
     if ratio > 0.25 or tagged:
         keep.append({k: v for k, v in r.items() if k != "err_legacy"})
-out = {"what": "Strict -m gpu run of round 3 (%d tests): every numeric comparison goes through tests/conftest.py (assert_close: error "
+out = {"what": "Strict -m gpu run (%d tests; profiles/r03_* = round 3, r04_* = round 4): every numeric comparison goes through tests/conftest.py (assert_close: error "
                "relative to the tensor's OWN scale; assert_grad_close: float64-anchored; LearnerFixtureCheck: parameter steps through "
                "Adam's conditioning; 'chain after..': the engine against the reference's own 64-update float32 / float64 chains).  "
                "per_test: number of comparisons and the worst err / tol; records: every comparison above a quarter of its tolerance "
