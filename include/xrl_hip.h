@@ -875,6 +875,11 @@ typedef struct {
     float gamma;
     int32_t dueling;           /* != 0: head rows are [advantages (A) | value] and Q = V + (A_j - mean A)
                                 * (DuelingQValueHead, rl_models/heads/q_head.py:42-80; dueldqn_learner.py:28-75); ld >= A + 1 */
+    float huber_delta;         /* <= 0: loss = mean((predictQ - y)^2), the reference's DQN default (dqn_learner.py:25,46);
+                                * > 0: loss = nn.HuberLoss(delta = huber_delta, reduction "mean")(predictQ, y), the form of the
+                                * reference's `use_huber_loss` / `huber_delta` switch (learners/base/marl_learner.py:193-197);
+                                * partials[.][0] then sums the Huber terms.  Same field in xrl_dqn_head_td_t / xrl_dqn_tail_td_t. */
+    int32_t pad;
 } xrl_dqn_td_t;
 int xrl_dqn_td(const xrl_dqn_td_t* p, xrl_stream_t stream);
 /* The last layer of a BasicQhead (q_head.py:8-39: Linear(H, n_actions)), xrl_dqn_td's rule and the layer's data gradient in ONE
@@ -898,7 +903,7 @@ typedef struct {
     float* diag;               /* NULL or [2M]: predictQ | targetQ */
     double* partials;          /* [M][8] */
     int32_t M, A, H, ld_h, ld_q, double_q, act, pad;
-    float gamma, pad2;
+    float gamma, huber_delta;  /* huber_delta: see xrl_dqn_td_t */
 } xrl_dqn_head_td_t;
 
 /* xrl_dqn_head_td extended backwards to the last convolution's output and forwards to the convolution stack's incoming gradient
@@ -924,7 +929,7 @@ typedef struct {
     float* diag;               /* NULL or [2M] */
     double* partials;          /* [M][8] */
     int32_t M, A, H, F, P, ld_h, ld_q, ld_f, double_q, act;
-    float gamma, pad;
+    float gamma, huber_delta;  /* huber_delta: see xrl_dqn_td_t */
     /* NULL, or the gradient slabs of the optimiser launch, [>= M][slab_stride]: transition m writes ITS term of the two dense layers'
      * weight / bias gradients (d_h[m] x feat[m], d_h[m], d_q[m] x h[m], d_q[m]) into slab m at the parameters' offsets -- the
      * slab reduction of xrl_reduce_adam is then the sum over the batch (in order of m), and no weight-gradient GEMM is launched. */

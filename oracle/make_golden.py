@@ -541,9 +541,14 @@ def golden_ppokl(dist):
 
 
 # ------------------------------------------------------------------------------ DQN
-def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None, levels=None):
+def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None, levels=None, huber=None):
     """learner_cls: DQN_Learner (default), DDQN_Learner (ddqn_learner.py:39-47, the double-Q target) or DuelDQN_Learner
     with model_cls=DuelingDeepQNetwork (dueldqn_learner.py:28-75, q_head.py:42-80).
+    huber: the UNMODIFIED learner's update with its loss module (the attribute `mse_loss`, dqn_learner.py:25,46) set to
+    nn.HuberLoss(delta=huber) -- the loss the reference's learners build behind `use_huber_loss` / `huber_delta`
+    (learners/base/marl_learner.py:193-197; there with reduction "none" + a masked mean, here the module's own "mean", which
+    is what DQN_Learner's call site `self.mse_loss(predictQ, targetQ)` expects).  Rewards are scaled by 2 so that TD errors
+    fall on both sides of delta.
     size="c3" (kind "cnn"): the batch of configs/dqn/atari.yaml:27 (32 frames of 84x84x4), two updates, lr 1e-4, no clip;
     frames take 16 grey levels so the file compresses."""
     learner_cls = learner_cls or DQN_Learner
@@ -573,6 +578,8 @@ def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None, lev
                       training_frequency=1, use_grad_clip=(kind == "mlp"), grad_clip_norm=0.5)
     cb = Capture()
     learner = learner_cls(cfg, model, cb)
+    if huber is not None:
+        learner.mse_loss = nn.HuberLoss(reduction="mean", delta=float(huber))
     batches = []
     for u in range(n_updates):
         if kind == "mlp":
@@ -588,7 +595,7 @@ def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None, lev
             obs = rng.integers(0, 256, (bs, 84, 84, 4)).astype(np.uint8)
             nxt = rng.integers(0, 256, (bs, 84, 84, 4)).astype(np.uint8)
         batches.append(dict(obs=obs, obs_next=nxt, actions=rng.integers(0, A, bs).astype(np.float32),
-                            rewards=rng.standard_normal(bs).astype(np.float32),
+                            rewards=(rng.standard_normal(bs) * (2.0 if huber is not None else 1.0)).astype(np.float32),
                             terminals=(rng.random(bs) < 0.2).astype(np.float32)))
 
     def call(b):
@@ -596,6 +603,10 @@ def golden_dqn(kind, learner_cls=None, name=None, model_cls=None, size=None, lev
     out = run_learner_updates(learner, model, cb, batches, call)
     out["cfg"] = np.array([cfg.learning_rate, cfg.gamma, cfg.sync_frequency, cfg.grad_clip_norm,
                            float(cfg.use_grad_clip), learner.total_iters])
+    if huber is not None:
+        out["huber_delta"] = np.float64(huber)
+        td = np.concatenate([out[f"u{u}/cb/predictQ"] - out[f"u{u}/cb/targetQ"] for u in range(n_updates)])
+        assert (np.abs(td) > huber).any() and (np.abs(td) < huber).any(), "both branches of the Huber loss must be taken"
     if size is not None:
         out["n_updates"] = np.int64(n_updates)
     np.savez_compressed(os.path.join(OUT, f"{name or 'dqn'}_{kind}{'_' + size if size else ''}.npz"), **out)
@@ -1073,6 +1084,8 @@ if __name__ == "__main__":
     golden_dqn("mlp")
     golden_dqn("cnn")
     golden_dqn("mlp", DDQN_Learner, "ddqn")
+    golden_dqn("mlp", name="dqn_huber", huber=1.0)
+    golden_dqn("cnn", name="dqn_huber", huber=1.0, levels=4)
     from xuance.torch.learners import DuelDQN_Learner
     from xuance.torch.rl_models.architectures.single_agent.deep_q_network import DuelingDeepQNetwork
     golden_dqn("mlp", DuelDQN_Learner, "dueldqn", DuelingDeepQNetwork)

@@ -563,6 +563,21 @@ def collect_seq(sd, prefix, act, last_act=None):
     return layers
 
 
+def td_loss_mean(pred, target, huber_delta=0.0):
+    """nn.MSELoss()(pred, target) (dqn_learner.py:25,46) and its gradient w.r.t. pred; with huber_delta > 0 nn.HuberLoss(delta,
+    reduction "mean") instead -- the loss the reference's learners build behind `use_huber_loss` (marl_learner.py:193-197):
+    0.5 z^2 where |z| < delta, delta (|z| - 0.5 delta) beyond (torch's definition)."""
+    z = pred - target
+    B = z.dtype.type(z.size)
+    if not huber_delta or huber_delta <= 0:
+        return (z ** 2).mean(), 2 * z / B
+    d = z.dtype.type(huber_delta)
+    az = np.abs(z)
+    quad = az < d
+    loss = np.where(quad, z.dtype.type(0.5) * z * z, d * (az - z.dtype.type(0.5) * d)).mean()
+    return loss, np.where(quad, z, d * np.sign(z)) / B
+
+
 def dqn_forward_backward(sd, batch, cfg, act="relu"):
     """DQN_Learner.update forward/loss/backward for an MLP-representation DeepQNetwork.
 
@@ -591,8 +606,7 @@ def dqn_forward_backward(sd, batch, cfg, act="relu"):
         tmax = targetQ_all.max(-1)                                      # :43
     g = dt(cfg["gamma"])
     targetQ = batch["rewards"].astype(dt) + g * (1 - batch["terminals"].astype(dt)) * tmax   # :44
-    loss = ((predictQ - targetQ) ** 2).mean()                           # :46
-    dpred = 2 * (predictQ - targetQ) / dt(B)
+    loss, dpred = td_loss_mean(predictQ, targetQ, cfg.get("huber_delta", 0.0))   # :46
     dQ = np.zeros_like(evalQ)
     dQ[np.arange(B), a] = dpred
     dh, g_q = q.backward(dQ, need_dx=bool(rep_l))

@@ -51,7 +51,9 @@ def test_ctypes_structs_match_c_layout():
     offs = {"xrl_mirrors_t": (_lib.Mirrors, ("tick", "part_out", "tick_inc", "part_rows", "alt_lo", "alt_hi", "alt_split")),   # fields added in rounds 3, 4
             "xrl_egreedy_t": (_lib.EGreedy, ("eps", "seed", "step_dev")), "xrl_marl_act_t": (_lib.MarlAct, ("eps", "seed")),
             "xrl_marl_act_gru_t": (_lib.MarlActGru, ("eps_dev", "step", "eps")),
-            "xrl_dqn_tail_td_t": (_lib.DqnTailTd, ("partials", "M", "act", "gamma", "slabs", "slab_stride", "off_b2")),
+            "xrl_dqn_tail_td_t": (_lib.DqnTailTd, ("partials", "M", "act", "gamma", "huber_delta", "slabs", "slab_stride", "off_b2")),
+            "xrl_dqn_head_td_t": (_lib.DqnHeadTd, ("partials", "act", "gamma", "huber_delta")),                 # round 5: Huber switch
+            "xrl_dqn_td_t": (_lib.DqnTd, ("partials", "gamma", "dueling", "huber_delta")),
             "xrl_dqn_act_tail_t": (_lib.DqnActTail, ("step_dev", "seed", "step", "n", "act", "eps", "eps_sched", "eps_kstar", "eps_start", "eps_delta")),
             "xrl_ppo_wide_t": (_lib.PpoWide, ("rows_g2", "rows_h1", "rows_ld")),
             "xrl_rollout_run_t": (_lib.RolloutRun, ("act", "flags", "gamma", "seed", "step", "step_dev", "obs_raw", "cp_stats", "f_val", "xchg", "dbg")),

@@ -54,12 +54,14 @@ def check_updates(g, net, learner, cb, call, cb_keys, loss_key, n_updates=None, 
     chk.finish(net.trainable_order)
 
 
-@pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp"])
+@pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp", "dqn_huber_mlp"])
 @pytest.mark.parametrize("fused_head", [True, False])
 def test_dqn_learner_vs_reference_fixture(name, fused_head):
     """DQN_Learner / DDQN_Learner / DuelDQN_Learner, each against the reference's own learner run (dueling: DuelingQValueHead
     as two GEMM groups per layer + the V + A - mean(A) combination inside xrl_dqn_td).  fused_head: the Q layer, the TD rule and the
-    layer's data gradient as ONE launch (xrl_dqn_head_td, the default for a BasicQhead) or the layered launches."""
+    layer's data gradient as ONE launch (xrl_dqn_head_td, the default for a BasicQhead) or the layered launches.
+    dqn_huber_mlp: `use_huber_loss` / `huber_delta` (the reference's switch names, marl_learner.py:193-197) against the reference's
+    DQN_Learner.update run with nn.HuberLoss(delta 1) as its loss module; TD errors of the fixture fall on both sides of delta."""
     from xuance_amd.nets import DeepQNet
     from xuance_amd.learners import DQN_Learner, DDQN_Learner, DuelDQN_Learner
     DQN_Learner = {"dqn": DQN_Learner, "ddq": DDQN_Learner, "due": DuelDQN_Learner}[name[:3]]
@@ -69,9 +71,11 @@ def test_dqn_learner_vs_reference_fixture(name, fused_head):
     assert list(net.ref_order) == list(sub(g, "init").keys())          # same state_dict order as the reference
     net.load_state_dict(sub(g, "init"))
     cb = Capture()
-    learner = DQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
+    hub = dict(use_huber_loss=True, huber_delta=float(g["huber_delta"])) if "huber_delta" in g else {}
+    learner = DQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync), **hub,
                                    use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip), use_fused_q_head=fused_head), net, cb)
     assert learner.total_iters == int(total) and (net.fused_head() is None) == name.startswith("duel")
+    assert (learner.huber_delta > 0) == ("huber" in name)
     check_updates(g, net, learner, cb, lambda b: learner.update(batch_size=len(b["obs"]), **b),
                   ("evalQ", "predictQ", "targetQ"), "Qloss")
 
@@ -114,7 +118,7 @@ def test_qmix_learner_vs_reference_fixture(double_q, size, fused, items, product
 
 
 @pytest.mark.parametrize("implicit,tail", [(True, True), (True, "gemm"), (True, False), (False, False)])
-@pytest.mark.parametrize("name", ["dqn_cnn", "dqn_cnn_c3"])
+@pytest.mark.parametrize("name", ["dqn_cnn", "dqn_cnn_c3", "dqn_huber_cnn"])
 def test_dqn_cnn_learner_vs_reference_fixture(name, implicit, tail):
     """BASELINE config C3 shapes: 84x84x4 uint8 frames, CNN 32/64/64 (k 8/4/3, s 4/2/1) + global max-pool + 64-512-4 head.
     dqn_cnn: batch 4; dqn_cnn_c3: the batch of configs/dqn/atari.yaml:27 (32).  implicit: the convolutions as implicit GEMMs on
@@ -134,7 +138,8 @@ def test_dqn_cnn_learner_vs_reference_fixture(name, implicit, tail):
     assert sum(int(np.prod(net.params.shapes[k])) for k in net.trainable_order) == 113316
     net.load_state_dict(sub(g, "init"))
     cb = Capture()
-    learner = DQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync),
+    hub = dict(use_huber_loss=True, huber_delta=float(g["huber_delta"])) if "huber_delta" in g else {}   # (dqn_huber_cnn: see above)
+    learner = DQN_Learner(base_cfg(learning_rate=float(lr), gamma=float(gamma), sync_frequency=int(sync), **hub,
                                    use_grad_clip=bool(use_clip), grad_clip_norm=float(gclip), use_fused_q_tail=bool(tail),
                                    use_tail_slab_gradients=tail is True), net, cb)
     assert (net.fused_tail() is not None) == implicit

@@ -200,17 +200,19 @@ def test_ppokl_update(oracle, dist):
     assert len(set(g["kl_coef_after"].tolist())) > 1               # the schedule moved in the fixture
 
 
-@pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp"])
+@pytest.mark.parametrize("name", ["dqn_mlp", "ddqn_mlp", "dueldqn_mlp", "dqn_huber_mlp"])
 def test_dqn_mlp_update(oracle, name):
     """dqn_mlp: DQN_Learner (dqn_learner.py:28-75); ddqn_mlp: DDQN_Learner (ddqn_learner.py:28-75), same network;
-    dueldqn_mlp: DuelDQN_Learner on DuelingDeepQNetwork (dueldqn_learner.py:28-75, q_head.py:42-80)."""
+    dueldqn_mlp: DuelDQN_Learner on DuelingDeepQNetwork (dueldqn_learner.py:28-75, q_head.py:42-80); dqn_huber_mlp: DQN_Learner
+    with nn.HuberLoss(delta 1) as its loss module (the reference's `use_huber_loss` form, marl_learner.py:193-197)."""
     g = load_golden(name)
     lr, gamma, sync, gclip, use_clip, total = g["cfg"]
     opt_kwargs_clip["clip"] = gclip if use_clip else None
     if name.startswith("duel"):
         fb = lambda sd, b: oracle.dueldqn_forward_backward(sd, b, dict(gamma=gamma))
     else:
-        fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma, double_q=name.startswith("ddqn")))
+        fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma, double_q=name.startswith("ddqn"),
+                                                                   huber_delta=float(g["huber_delta"]) if "huber_delta" in g else 0.0))
 
     def on_update(u, sd):
         if (u + 1) % int(sync) == 0:

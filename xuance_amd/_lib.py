@@ -37,7 +37,7 @@ class DqnHeadTd(C.Structure):
                 ("b_target", c_void_p), ("actions", c_void_p), ("rewards", c_void_p), ("terminals", c_void_p), ("q_eval", c_void_p),
                 ("q_target", c_void_p), ("d_q", c_void_p), ("d_h", c_void_p), ("diag", c_void_p), ("partials", c_void_p),
                 ("M", c_int32), ("A", c_int32), ("H", c_int32), ("ld_h", c_int32), ("ld_q", c_int32), ("double_q", c_int32),
-                ("act", c_int32), ("pad", c_int32), ("gamma", c_float), ("pad2", c_float)]
+                ("act", c_int32), ("pad", c_int32), ("gamma", c_float), ("huber_delta", c_float)]
 
 
 class DqnTailTd(C.Structure):
@@ -45,7 +45,7 @@ class DqnTailTd(C.Structure):
                                         "b1_target", "w2_eval", "b2_eval", "w2_target", "b2_target", "actions", "rewards", "terminals",
                                         "q_eval", "q_target", "d_q", "h_eval", "d_h", "d_feat", "dy", "diag", "partials")] + \
                [(k, c_int32) for k in ("M", "A", "H", "F", "P", "ld_h", "ld_q", "ld_f", "double_q", "act")] + \
-               [("gamma", c_float), ("pad", c_float), ("slabs", c_void_p)] + \
+               [("gamma", c_float), ("huber_delta", c_float), ("slabs", c_void_p)] + \
                [(k, C.c_int64) for k in ("slab_stride", "off_w1", "off_b1", "off_w2", "off_b2")]
 
 
@@ -123,7 +123,7 @@ class DqnTd(C.Structure):
     _fields_ = [("q_eval", c_void_p), ("q_next", c_void_p), ("q_next_eval", c_void_p), ("actions", c_void_p),
                 ("rewards", c_void_p), ("terminals", c_void_p), ("d_q", c_void_p), ("diag", c_void_p),
                 ("partials", c_void_p), ("M", c_int32), ("A", c_int32), ("ld", c_int32), ("n_split", c_int32),
-                ("gamma", c_float), ("dueling", c_int32)]
+                ("gamma", c_float), ("dueling", c_int32), ("huber_delta", c_float), ("pad", c_int32)]
 
 
 class Qmix(C.Structure):

@@ -8,6 +8,18 @@
 
 namespace xrl {
 
+// Loss of one TD error and its derivative: nn.MSELoss (delta <= 0: dqn_learner.py:25,46) or nn.HuberLoss(delta) (the form the
+// reference's learners use where they switch it on: learners/base/marl_learner.py:193-197 `use_huber_loss` / `huber_delta`;
+// torch: 0.5 z^2 for |z| < delta, delta (|z| - 0.5 delta) beyond; backward z, or +-delta).  Both with reduction "mean": the
+// caller divides by the row count.
+__device__ __forceinline__ double td_loss(float td, float delta, float& dl) {
+    if (!(delta > 0.f)) { dl = 2.f * td; return (double)td * td; }
+    const float a = fabsf(td);
+    if (a < delta) { dl = td; return (double)(0.5f * td * td); }
+    dl = copysignf(delta, td);
+    return (double)(delta * (a - 0.5f * delta));
+}
+
 __global__ void __launch_bounds__(256) dqn_td_kernel(xrl_dqn_td_t p) {
     __shared__ double scratch[16];
     const int chunk = (p.M + p.n_split - 1) / p.n_split;
@@ -38,7 +50,9 @@ __global__ void __launch_bounds__(256) dqn_td_kernel(xrl_dqn_td_t p) {
         const float y = p.rewards[m] + p.gamma * (1.f - p.terminals[m]) * tq;    // :44
         const float td = pred - y;
         float* dq = p.d_q + (size_t)m * p.ld;
-        const float g = 2.f * td * invM;                                 // MSELoss backward through gather
+        float dl;
+        const double lo = td_loss(td, p.huber_delta, dl);
+        const float g = dl * invM;                                       // MSELoss / HuberLoss backward through gather
         if (duel) {      // dA_j = g [j == a] + (-g) / A (backward of `- mean`), dV = g
             for (int j = 0; j < A; ++j) dq[j] = ((j == a) ? g : 0.f) + (-g) / (float)A;
             dq[A] = g;
@@ -46,7 +60,7 @@ __global__ void __launch_bounds__(256) dqn_td_kernel(xrl_dqn_td_t p) {
             for (int j = 0; j < A; ++j) dq[j] = (j == a) ? g : 0.f;
         }
         if (p.diag) { p.diag[m] = pred; p.diag[p.M + m] = y; }
-        acc_l += (double)td * td; acc_q += pred;
+        acc_l += lo; acc_q += pred;
     }
     const double t0 = block_sum(acc_l, scratch), t1 = block_sum(acc_q, scratch);
     if (threadIdx.x == 0) {
@@ -110,12 +124,15 @@ __global__ void __launch_bounds__(256) dqn_head_td_kernel(xrl_dqn_head_td_t p) {
             for (int j = 1; j < A; ++j) tq = fmaxf(tq, s_q[64 + j]);     // :43
         }
         const float y = rew + p.gamma * (1.f - ter) * tq;                // :44
-        const float td = pred - y, g = 2.f * td / (float)p.M;            // MSELoss backward through gather
+        const float td = pred - y;
+        float dl;
+        const double lo = td_loss(td, p.huber_delta, dl);
+        const float g = dl / (float)p.M;                                 // MSELoss / HuberLoss backward through gather
         if (threadIdx.x < A) p.d_q[(size_t)m * p.ld_q + threadIdx.x] = ((int)threadIdx.x == a_taken) ? g : 0.f;
         if (threadIdx.x == 0) {
             if (p.diag) { p.diag[m] = pred; p.diag[p.M + m] = y; }
             double* q = p.partials + (size_t)m * 8;
-            q[0] = (double)td * td; q[1] = pred;
+            q[0] = lo; q[1] = pred;
             for (int j = 2; j < 8; ++j) q[j] = 0.0;
         }
         float* dh = p.d_h + (size_t)m * p.ld_h;
@@ -290,12 +307,15 @@ __global__ void __launch_bounds__(TAIL_T) dqn_tail_td_kernel(xrl_dqn_tail_td_t p
         for (int j = 1; j < A; ++j) tq = fmaxf(tq, s_q[64 + j]);           // :43
     }
     const float y = rew + p.gamma * (1.f - ter) * tq;                      // :44
-    const float td = pred - y, g = 2.f * td / (float)M;                    // MSELoss backward through gather
+    const float td = pred - y;
+    float dl;
+    const double lo = td_loss(td, p.huber_delta, dl);
+    const float g = dl / (float)M;                                         // MSELoss / HuberLoss backward through gather
     if (tid < A) p.d_q[(size_t)m * p.ld_q + tid] = (tid == a_taken) ? g : 0.f;
     if (tid == 0) {
         if (p.diag) { p.diag[m] = pred; p.diag[M + m] = y; }
         double* q = p.partials + (size_t)m * 8;
-        q[0] = (double)td * td; q[1] = pred;
+        q[0] = lo; q[1] = pred;
         for (int j = 2; j < 8; ++j) q[j] = 0.0;
     }
     if (tid < H) {

@@ -1,5 +1,6 @@
 """DQN learner on the HIP engine: same constructor / ``update(**samples)`` contract / info keys / callback hooks as
-xuance/torch/learners/qlearning_family/dqn_learner.py:12-75 (MSE TD loss, max-target, hard target sync).  With
+xuance/torch/learners/qlearning_family/dqn_learner.py:12-75 (MSE TD loss -- or, with ``use_huber_loss``, nn.HuberLoss(
+``huber_delta``) in its place --, max-target, hard target sync).  With
 ``double_q=True`` the target action comes from the eval network (the DDQN rule, ddqn_learner.py:39-47)."""
 import torch
 
@@ -14,6 +15,11 @@ class DQN_Learner(Learner):
         model = self.model                                          # (a reference nn.Module was adopted by the base class)
         self.sync_frequency = config.sync_frequency
         self.double_q = bool(getattr(config, "double_q", False))
+        # TD loss: nn.MSELoss as in the reference's DQN family (dqn_learner.py:25,46) unless config.use_huber_loss asks for
+        # nn.HuberLoss(delta = config.huber_delta) -- the switch and its names as the reference's learners carry them
+        # (learners/base/marl_learner.py:193-197); 0 = MSE for the kernels
+        self.huber_delta = float(getattr(config, "huber_delta", 1.0) or 0.0) if bool(getattr(config, "use_huber_loss", False)) else 0.0
+        assert self.huber_delta >= 0.0, "huber_delta must be positive"
         self.n_actions = model.n_actions
         P = model.params
         self.optimizer = AdamHandle(P, model.trainable_order, self.learning_rate, eps=1e-5,
@@ -56,19 +62,21 @@ class DQN_Learner(Learner):
             # pass in one launch (xrl_dqn_tail_td)
             in_slabs = bool(getattr(self.config, "use_tail_slab_gradients", True)) and M <= self.slabs.shape[0] and \
                 model.conv.N_SPLIT_IMPLICIT == self.slabs.shape[0]
-            model.tail_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma, slabs=self.slabs if in_slabs else None)
+            model.tail_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma, slabs=self.slabs if in_slabs else None,
+                          huber_delta=self.huber_delta)
             S_opt = model.backward(self.X, M, self.slabs, S, tail=True) or S
             S_loss = M
         elif fused:
             # the Q layer itself, the TD rule and the layer's data gradient: one launch (xrl_dqn_head_td), one partials row per row
-            model.head_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma)
+            model.head_td(M, self.double_q, act, rew, ter, self.diag, self.partials, self.gamma, huber_delta=self.huber_delta)
             S_opt = model.backward(self.X, M, self.slabs, S, skip_last_dg=True) or S
             S_loss = M
         else:
             d_q = model.d_out
             ops.dqn_td(q_eval=q_all, q_next=q_next, q_next_eval=q_all[M:] if self.double_q else None, actions=act,
                        rewards=rew, terminals=ter, d_q=d_q, diag=self.diag, partials=self.partials, M=M, A=A,
-                       ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)))
+                       ld=q_all.shape[1], n_split=S, gamma=float(self.gamma), dueling=int(getattr(model, "dueling", False)),
+                       huber_delta=self.huber_delta)
             S_opt = model.backward(self.X, M, self.slabs, S) or S     # (convolutional nets write 32 row chunks of their own)
             S_loss = S
         P, clip = model.params.P, (self.grad_clip_norm if self.use_grad_clip else 0.0)

@@ -609,7 +609,7 @@ class DeepQNet:
             return None
         return L
 
-    def head_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma):
+    def head_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma, huber_delta=0.0):
         """Q layer + TD + the Q layer's data gradient (after forward_pair(..., skip_last=True)); backward(..., skip_last_dg=True)
         continues from there."""
         L, pl, tp = self.fused_head(), self.plan, self.target_plan
@@ -619,7 +619,7 @@ class DeepQNet:
                         actions=actions, rewards=rewards, terminals=terminals, q_eval=pl.acts[L.out_level], q_target=tp.acts[L.out_level],
                         d_q=pl.dacts[L.out_level], d_h=pl.dacts[lvl], diag=diag, partials=partials, M=M, A=L.N, H=L.K,
                         ld_h=pl.widths[lvl], ld_q=pl.widths[L.out_level], double_q=int(double_q),
-                        act=ops.ACT[pl._act_of(lvl, 0)], gamma=float(gamma))
+                        act=ops.ACT[pl._act_of(lvl, 0)], gamma=float(gamma), huber_delta=float(huber_delta))
 
     @property
     def d_out(self):
@@ -1477,7 +1477,7 @@ class DeepQCNN:
                                                       eps_start=float(eps_sched[2]), eps_delta=float(eps_sched[3])) if eps_sched else {}))
         return q
 
-    def tail_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma, slabs=None):
+    def tail_td(self, M, double_q, actions, rewards, terminals, diag, partials, gamma, slabs=None, huber_delta=0.0):
         """After forward_pair(..., skip_last="tail"): pool + hidden + Q layers + TD + the gradients back to the last convolution's
         output in one launch; backward(..., tail=True) continues with the weight gradients and the convolution stack."""
         (L1, L2), pl, tp, ws = self.fused_tail(), self.plan, self.target_plan, self._ws
@@ -1498,7 +1498,7 @@ class DeepQCNN:
                         terminals=terminals, q_eval=pl.acts[2], q_target=tp.acts[2], d_q=pl.dacts[2], h_eval=pl.acts[1],
                         d_h=pl.dacts[1], d_feat=None, dy=ws.dy[-1], diag=diag, partials=partials, M=M, A=L2.N, H=L1.N, F=F, P=Pp,
                         ld_h=pl.widths[1], ld_q=pl.widths[2], ld_f=ws.feat.shape[1], double_q=int(double_q), act=ops.ACT[L1.act],
-                        gamma=float(gamma))
+                        gamma=float(gamma), huber_delta=float(huber_delta))
 
     def forward_pair(self, X, M, double_q, skip_last=False):
         """One update's three network passes (dqn_learner.py:39-40, ddqn_learner.py:40): eval Q of obs = X[:M] (kept for
