@@ -1,0 +1,185 @@
+"""TEST INFRASTRUCTURE ONLY -- reference-run fixtures of the AGENT LOOPS: the
+UNMODIFIED reference agents (through oracle/ref_shim.py), constructed from the reference's own yaml configs by
+REGISTRY_Agents[...] exactly as oracle/time_reference_cpu.py constructs them for timing, run through their own ``train()`` on
+deterministic host simulators behind the reference's own vector-env classes:
+
+  golden_agent_ppo       PPO_Agent.train           (agents/policy_gradient/ppo_agent.py:111-181, core/on_policy.py:128-205)
+  golden_agent_dqn       DQN_Agent.train           (agents/core/off_policy.py:119-148, 174-270)
+  golden_agent_qmix_ff   QMIX_Agents.train         (agents/core/off_policy_marl.py:112-166, 212-255, 358-424)
+  golden_agent_qmix_rnn  QMIX_Agents.train -> run_episodes  (off_policy_marl.py:334-356, 426-571)
+
+Nothing of the reference is edited.  What is recorded comes through the reference's own callback hooks (`on_train_step`,
+`on_train_epochs_end`, `on_train_step_end`, callback.py:13-60) plus three instance-level wrappers that only LISTEN: the
+buffer's ``sample`` (to note the indices NumPy drew -- the RNG state is saved, the call made, the state restored, the same
+draws repeated and the state after the call re-installed), the agent's ``exploration`` (same trick on the torch / NumPy
+streams: the coin, the uniforms, the random actions) and the learner's ``update``.  Per vector step: what the loop acted on,
+the actions it took, what the simulators returned, what it stored; per update phase: the whole buffer as the learner saw it,
+the indices of every minibatch, the parameters after the phase, the running statistics and epsilon.
+
+The fixtures are replayed by tests/test_gpu_agent_replay.py through xuance_amd.agents.* on a recorded-trajectory provider
+(xuance_amd/envs/recorded.py) with the recorded actions / draws / indices supplied, and by tests/test_oracle_vs_golden.py
+through the oracle's restatement of the loops.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_agents.py [ppo|dqn|qmix_ff|qmix_rnn ...]
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import importlib.util
+
+spec = importlib.util.spec_from_file_location("mg", os.path.join(HERE, "make_golden.py"))
+mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+import numpy as np
+import torch
+
+sp, OUT = mg.sp, mg.OUT
+
+
+class _NullWriter:
+    def __init__(self, *a, **k): pass
+    def add_scalar(self, *a, **k): pass
+    def add_scalars(self, *a, **k): pass
+
+
+class _Quiet:                                                      # tqdm stand-in: iterable and context manager, silent
+    last_print_n = n = 0
+    def __init__(self, it=None, *a, **k): self.it = it
+    def __iter__(self): return iter(self.it)
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+    def update(self, *a, **k): pass
+
+
+def agent_config(yaml_rel, **over):
+    """basic.yaml + the algorithm's yaml of the reference tree + overrides (what xuance.get_arguments assembles)."""
+    import yaml
+    from argparse import Namespace
+    root = "/root/reference/xuance/configs"
+    c = yaml.safe_load(open(os.path.join(root, "basic.yaml")))
+    c.update(yaml.safe_load(open(os.path.join(root, yaml_rel))))
+    c.update(device="cpu", log_dir="/tmp/xrl_ref_logs", model_dir="/tmp/xrl_ref_models", logger="tensorboard", render=False,
+             render_mode="rgb_array", fps=50, test_mode=False, dl_toolbox="torch", running_steps=10 ** 6)
+    c.update(over)
+    return Namespace(**c)
+
+
+def seed_all(seed):
+    import random
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+
+
+def sd_np(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def rms_np(prefix, rms):
+    """RunningMeanStd (statistic_tools.py:65-110) as arrays."""
+    return {f"{prefix}/mean": np.array(rms.mean, np.float64).copy(), f"{prefix}/var": np.array(rms.var, np.float64).copy(),
+            f"{prefix}/count": np.float64(rms.count)}
+
+
+# ------------------------------------------------------------------------------------------------------------------ PPO
+def golden_agent_ppo():
+    """PPO_Agent with configs/ppo/classic_control/CartPole-v1.yaml (network 4-128-{128-2, 128-1}, obs / reward normalisation on,
+    GAE, advantage normalisation, clip 0.5) at 8 envs x horizon 32, 2 epochs x 2 minibatches, on CartPole simulators cut at 23 steps
+    (terminations AND truncations inside every rollout) behind the reference's DummyVecEnv + XuanCeEnvWrapper: three rollouts
+    (96 vector steps) = three buffer fills, three update phases of 4 minibatches."""
+    from xuance.common.callback import BaseCallback
+    import xuance.torch.agents.base.agent as agent_mod
+    import xuance.torch.agents.policy_gradient.ppo_agent as pa
+    from xuance.torch.agents import REGISTRY_Agents
+    from xuance.environment.vector_envs.dummy.dummy_vec_env import DummyVecEnv
+    from xuance.environment.utils.wrapper import XuanCeEnvWrapper
+    from xuance_amd.envs import NumpyCartPoleEnv
+
+    class ShortCartPole(NumpyCartPoleEnv):
+        max_episode_steps = 23
+
+    agent_mod.SummaryWriter = _NullWriter
+    pa.tqdm = lambda x, *a, **k: x
+    n, T, rollouts = 8, 32, 3
+    cfg = agent_config("ppo/classic_control/CartPole-v1.yaml", parallels=n, horizon_size=T, n_epochs=2, n_minibatch=2, seed=7)
+    seed_all(cfg.seed)
+    envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 11)
+    envs.observation_space, envs.action_space = sp.Box(-np.inf, np.inf, (4,), np.float32), sp.Discrete(2)   # (the shim's gymnasium types)
+    envs.reset()
+    out, steps, phases = {}, [], []
+
+    class Rec(BaseCallback):
+        def on_train_step(self, current_step, **kw):
+            ag = self.agent
+            with torch.no_grad():
+                po = ag.model(torch.as_tensor(kw["obs"]))                     # (listening only: the logits behind the sampled actions)
+                probs = po.distributions.probs.numpy().copy()
+            steps.append(dict(obs=np.array(kw["obs"], np.float32), acts=np.array(kw["acts"]), vals=np.array(kw["vals"], np.float32),
+                              logp=np.array(kw["aux_info"]["old_logp"], np.float32), next_obs=np.array(kw["next_obs"], np.float32),
+                              rewards=np.array(kw["rewards"], np.float32), terminals=np.array(kw["terminals"]),
+                              truncations=np.array(kw["truncations"]), probs=probs,
+                              reset_obs=np.stack([np.asarray(i.get("reset_obs", np.zeros(4)), np.float32) for i in kw["infos"]]),
+                              episode_step=np.array([i["episode_step"] for i in kw["infos"]]),
+                              episode_score=np.array([i["episode_score"] for i in kw["infos"]], np.float64)))
+
+        def on_train_epochs_end(self, current_step, **kw):
+            m = kw["memory"]
+            ph = dict(buffer={k: np.array(getattr(m, k)).copy() for k in ("observations", "actions", "rewards", "returns", "values",
+                                                                          "terminals", "advantages")},
+                      old_logp=np.array(m.auxiliary_infos["old_logp"]).copy(), param=sd_np(kw["policy"]),
+                      info={k: np.float64(v) for k, v in kw["update_info"].items() if np.isscalar(v)},
+                      indices=np.stack(self.indices), iterations=np.int64(self.agent.learner.iterations), grads=self.grads)
+            self.indices, self.grads = [], []
+            phases.append(ph)
+
+        def on_train_step_end(self, current_step, **kw):
+            ag = self.agent
+            steps[-1].update(returns_track=np.array(ag.returns, np.float64).copy(), current_step=np.int64(current_step),
+                             **rms_np("obs_rms", ag.obs_rms), **rms_np("ret_rms", ag.ret_rms))
+
+    cb = Rec()
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs, callback=cb)
+    finally:
+        os.chdir(cwd)
+    cb.agent, cb.indices, cb.grads = agent, [], []
+    sample0, update0 = agent.memory.sample, agent.learner.update
+    agent.memory.sample = lambda indexes: (cb.indices.append(np.array(indexes).copy()), sample0(indexes))[1]
+
+    def update(**samples):                                             # (listening: the clipped gradients each update stepped with)
+        info = update0(**samples)
+        cb.grads.append({k: p.grad.detach().numpy().copy() for k, p in agent.model.named_parameters() if p.grad is not None})
+        return info
+    agent.learner.update = update
+    out.update(mg.flat("init", sd_np(agent.model)))
+    out["raw_obs0"] = np.array(envs.buf_obs, np.float32).copy()
+    agent.train(T * rollouts)
+    assert len(steps) == T * rollouts and len(phases) == rollouts
+    for k in steps[0]:
+        out[f"step/{k}"] = np.stack([s[k] for s in steps])
+    for p, ph in enumerate(phases):
+        out.update(mg.flat(f"phase{p}/buffer", ph["buffer"]))
+        out[f"phase{p}/buffer/old_logp"] = ph["old_logp"]
+        out.update(mg.flat(f"phase{p}/param", ph["param"]))
+        out.update(mg.flat(f"phase{p}/info", ph["info"]))
+        out[f"phase{p}/indices"], out[f"phase{p}/iterations"] = ph["indices"], ph["iterations"]
+        for u, g in enumerate(ph["grads"]):
+            out.update(mg.flat(f"phase{p}/grad{u}", g))
+    term, trunc = out["step/terminals"], out["step/truncations"]
+    assert term.sum() > 8 and (trunc & ~term).sum() > 8, (term.sum(), trunc.sum())
+    out["cfg"] = np.array([n, T, cfg.n_epochs, cfg.n_minibatch, cfg.gamma, cfg.gae_lambda, cfg.learning_rate, cfg.vf_coef, cfg.ent_coef,
+                           cfg.clip_range, cfg.grad_clip_norm, cfg.obsnorm_range, cfg.rewnorm_range, agent.learner.total_iters,
+                           ShortCartPole.max_episode_steps], np.float64)
+    out["cfg_names"] = np.array("n_envs horizon_size n_epochs n_minibatch gamma gae_lambda learning_rate vf_coef ent_coef clip_range "
+                                "grad_clip_norm obsnorm_range rewnorm_range total_iters max_episode_steps".split())
+    np.savez_compressed(os.path.join(OUT, "agent_ppo.npz"), **out)
+    print("agent_ppo:", len(out), "arrays;", int(term.sum()), "terminations,", int((trunc & ~term).sum()), "truncations")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    todo = sys.argv[1:] or ["ppo", "dqn", "qmix_ff", "qmix_rnn"]
+    for name in todo:
+        globals()[f"golden_agent_{name}"]()

@@ -1,0 +1,106 @@
+"""GPU: the agent LOOPS of xuance_amd.agents.* against runs of the REFERENCE's own agents (tests/golden/agent_*.npz, recorded by
+oracle/make_golden_agents.py from the unmodified PPO_Agent.train / DQN_Agent.train / QMIX_Agents.train through their callback
+hooks).  The simulators' outputs come back from a tape (xuance_amd.envs.RecordedVecEnv), the reference's random decisions -- its
+sampled actions, exploration coins, random actions, minibatch / replay indices -- are supplied through the agents' replay hooks;
+EVERYTHING ELSE is the device loop's own work and is compared with what the reference did at the same moment: the order of
+`obs_rms.update` / normalise / store (ppo_agent.py:114-128, off_policy.py:207-227), values and log-probs of the acting pass, reward
+processing against `ret_rms` and the discounted-return tracker (agent.py:285-294, ppo_agent.py:144-149), path closing on
+termination / truncation / buffer end (ppo_agent.py:129-160), GAE, the epsilon schedule (off_policy.py:119-127), greedy / masked
+greedy actions, the update trigger (`current_step > start_training`, off_policy.py:228), ring positions, target syncs -- and the
+parameters after every update phase.  Stored integers / flags / raw frames must be EQUAL, floating-point fields agree at 1e-5 of
+their own scale, parameters within what gradients agreeing at 1e-5 allow (conftest.ChainCheck on the reference's own recorded
+gradients)."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, sub, assert_close, ChainCheck
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def categorical_uniforms(probs, acts):
+    """Uniforms whose inverse-CDF image under `probs` is `acts`: the midpoint of each taken action's CDF interval (float64)."""
+    p = np.asarray(probs, np.float64)
+    cdf = np.cumsum(p, -1)
+    a = np.asarray(acts, np.int64)[..., None]
+    hi = np.take_along_axis(cdf, a, -1)[..., 0]
+    lo = hi - np.take_along_axis(p, a, -1)[..., 0]
+    return (0.5 * (lo + hi)).astype(np.float32)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_ppo_agent_replays_the_reference_run(use_graph):
+    """agent_ppo.npz: the reference's PPO_Agent (configs/ppo/classic_control/CartPole-v1.yaml) over three rollouts of 8 envs x 32
+    steps with 31 terminations and 12 truncations, 2 x 2 minibatch updates per rollout.  use_graph: the rollout and the update phase
+    as one captured hipGraph each (replayed on the following stretch of the tape / the next indices) or launch by launch."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import RecordedVecEnv
+    from xuance_amd.spaces import Discrete
+    g = load_golden("agent_ppo")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
+    S = g["step/acts"].shape[0]
+    rollouts = S // T
+    env = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
+                         g["step/reset_obs"], action_space=Discrete(2), max_episode_steps=int(c["max_episode_steps"]))
+    env.prepare(T)
+    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128], critic_hidden_size=[128],
+                    activation="leaky_relu", seed=1, parallels=n, running_steps=10 ** 6, horizon_size=T, n_epochs=E, n_minibatch=MB,
+                    learning_rate=c["learning_rate"], vf_coef=c["vf_coef"], ent_coef=c["ent_coef"], clip_range=c["clip_range"],
+                    gamma=c["gamma"], use_gae=True, gae_lambda=c["gae_lambda"], use_advnorm=True, use_grad_clip=True,
+                    grad_clip_norm=c["grad_clip_norm"], use_obsnorm=True, use_rewnorm=True, obsnorm_range=c["obsnorm_range"],
+                    rewnorm_range=c["rewnorm_range"], distributed_training=False, device="cuda", model_dir="/tmp/xrl_models",
+                    use_hip_graph=use_graph)
+    agent = PPO_Agent(cfg, env)
+    assert not agent.use_fused_rollout and agent.learner.total_iters == int(c["total_iters"])
+    init = sub(g, "init")
+    assert list(agent.model.ref_order) == list(init)
+    agent.model.load_state_dict(init)
+    noise = categorical_uniforms(g["step/probs"], g["step/acts"]).reshape(rollouts, T, n)
+    assert g["step/probs"].min() > 1e-3                                # (no taken action sits in a CDF interval narrower than the tolerance)
+    chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))
+    f = agent.memory.soa.fields
+    tm = lambda a: np.swapaxes(np.asarray(a), 0, 1)                    # the reference's env-major [n][T] -> time-major
+    for p in range(rollouts):
+        agent.set_action_noise(noise[p])
+        agent.set_indices(g[f"phase{p}/indices"])
+        agent.rollout()
+        torch.cuda.synchronize()
+        buf, last = sub(g, f"phase{p}/buffer"), (p + 1) * T - 1
+        assert np.array_equal(npy(f["actions"]), tm(buf["actions"])), f"rollout {p}: stored actions"
+        assert np.array_equal(npy(f["actions"]), g["step/acts"][p * T:(p + 1) * T].astype(np.float32))
+        assert np.array_equal(npy(f["terminals"]) > 0, tm(buf["terminals"]) > 0), f"rollout {p}: stored terminals"
+        assert_close(npy(f["observations"]), tm(buf["observations"]), 1e-5, f"rollout {p}: stored (normalised) observations")
+        assert_close(npy(f["rewards"]), tm(buf["rewards"]), 1e-5, f"rollout {p}: stored (processed) rewards")
+        assert_close(npy(f["values"]), tm(buf["values"]), 1e-5, f"rollout {p}: stored values")
+        assert_close(npy(f["aux_old_logp"]), tm(buf["old_logp"]), 1e-5, f"rollout {p}: stored old_logp")
+        assert_close(npy(f["returns"]), tm(buf["returns"]), 1e-5, f"rollout {p}: returns (finish_path on termination / truncation / buffer end)")
+        assert_close(npy(f["advantages"]), tm(buf["advantages"]), 1e-5, f"rollout {p}: GAE advantages", scale=float(np.abs(buf["returns"]).max()))
+        # running statistics and the return tracker as the reference left them after the rollout's last vector step
+        assert_close(npy(agent.obs_mean), g["step/obs_rms/mean"][last], 1e-5, "obs_rms.mean", scale=float(np.sqrt(g["step/obs_rms/var"][last]).max()))
+        assert_close(npy(agent.obs_var), g["step/obs_rms/var"][last], 1e-5, "obs_rms.var")
+        assert_close(npy(agent.obs_count)[0], g["step/obs_rms/count"][last], 1e-9, "obs_rms.count")
+        assert_close(npy(agent.ret_mean)[0], g["step/ret_rms/mean"][last], 1e-5, "ret_rms.mean")
+        assert_close(npy(agent.ret_var)[0], g["step/ret_rms/var"][last], 1e-5, "ret_rms.var")
+        assert_close(npy(agent.ret_count)[0], g["step/ret_rms/count"][last], 1e-9, "ret_rms.count")
+        assert_close(npy(agent.returns), g["step/returns_track"][last], 1e-5, "discounted-return tracker", scale=max(1.0, float(np.abs(g["step/returns_track"][last]).max())))
+        assert agent.current_step == int(g["step/current_step"][last])
+        info = agent.update()
+        ref_info = sub(g, f"phase{p}/info")
+        for k in ("actor_loss", "critic_loss", "entropy", "predict_value"):
+            assert_close(info[k], ref_info[k], 1e-5, f"phase {p} {k}",
+                         scale=max(abs(float(ref_info[k])), 1.0 if k in ("actor_loss", "predict_value") else 0.0))   # (means of O(1) terms of either sign)
+        assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "learning_rate")
+        assert agent.learner.iterations == int(g[f"phase{p}/iterations"])
+        for u in range(E * MB):
+            chain.step(sub(g, f"phase{p}/grad{u}"))
+        got = {k: npy(v) for k, v in agent.model.state_dict().items()}
+        chain.check(got, sub(g, f"phase{p}/param"), init, what=f"phase {p} param")
+    assert (agent._rollout_graph is not None) == use_graph and (agent._update_graph is not None) == use_graph

@@ -88,6 +88,10 @@ class PPO_Agent(AgentSurface):
         self._update_graph = None
         self._started = False
         self._act_calls = 1 << 20                                   # Philox step offset of get_actions() draws (outside the rollout's range)
+        # Supplied randomness for the rollout's action draws (xrl_sample_t.noise), [horizon_size, n] uniforms (categorical) or
+        # [horizon_size, n, A] standard normals (Gaussian), refilled by the caller before every rollout: replays of recorded runs
+        # (set_action_noise; layered rollout only -- the one-launch rollout kernels draw from their Philox streams)
+        self.action_noise = None
         # fused rollout (one launch per vector step) for the device CartPole with a categorical policy
         from ..envs.cartpole import DeviceCartPoleVecEnv
         self.use_fused_rollout = bool(_get(config, "use_fused_rollout", True)) and isinstance(envs, DeviceCartPoleVecEnv) \
@@ -154,7 +158,8 @@ class PPO_Agent(AgentSurface):
         else:
             self.Xu8[:n].copy_(cur)
             heads = self.model.forward(self.Xu8, 2 * n, keep=False, acting=self._acting_fast)
-        ops.policy_sample(heads=heads, log_std=None, act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
+        ops.policy_sample(heads=heads, log_std=None, noise=None if self.action_noise is None else self.action_noise[t],
+                          act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
                           env_action=env.action, env_action_f=None, bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A,
                           ld=A + 1, gaussian=0, seed=self.seed, step=t, step_dev=self.step_counter)
         if hasattr(env, "advance"):
@@ -183,6 +188,7 @@ class PPO_Agent(AgentSurface):
             ops.obs_normalize(x=env.buf_obs, mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=self.X,
                               out1=f["observations"][t], n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(self.use_obsnorm),
                               normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
+        assert wide is None or self.action_noise is None, "supplied action noise needs the layered acting step (use_fused_acting: False)"
         if wide is not None:
             # forward of both branches + sample + log-prob + values in ONE launch (csrc/ppo_wide.hip: wide_act_kernel); with
             # `fold` the running statistics + normalisation as well (two statistics sets alternate: the workgroups of a
@@ -200,6 +206,7 @@ class PPO_Agent(AgentSurface):
             heads = self.model.forward(self.X, 2 * n)
             # actions / log-probs / values of rows [0,n) -> buffer slot t; value of rows [n,2n) -> bootv[t-1]
             ops.policy_sample(heads=heads, log_std=self.model.params.ptr("actor.log_std") if gaussian else None,
+                              noise=None if self.action_noise is None else self.action_noise[t],
                               act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
                               env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
                               bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A, ld=A + 1, gaussian=int(gaussian),
@@ -500,6 +507,19 @@ class PPO_Agent(AgentSurface):
         ops.counter_add(self.perm_counter, 1)
 
     # -- public API -----------------------------------------------------------------------------------------------
+    def set_action_noise(self, noise):
+        """Parity / replay hook: the next rollout's action draws come from `noise` ([horizon_size, n] uniforms for a categorical
+        policy -- the action is the inverse CDF of the softmax at that uniform --, [horizon_size, n, A] standard normals for a
+        Gaussian one) instead of the Philox stream.  The values are copied into one staging tensor, so a captured rollout graph
+        replays on whatever the caller staged last."""
+        assert not self.use_fused_rollout and self._wide_rollout() is None, \
+            "supplied action noise needs the layered rollout (use_fused_rollout / use_wide_rollout: False)"
+        x = torch.as_tensor(np.asarray(noise, np.float32), device=self.device)
+        if self.action_noise is None:
+            self.action_noise = torch.zeros_like(x).contiguous()
+            self._rollout_graph = None                      # (a graph captured before drew from the Philox stream)
+        self.action_noise.copy_(x.reshape(self.action_noise.shape))
+
     def set_indices(self, idx):
         """Parity hook: use the caller's minibatch indices (e.g. the ones NumPy produced for the reference); with a
         remainder ([n_epochs, buffer_size]: every epoch's whole permutation)."""

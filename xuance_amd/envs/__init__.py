@@ -5,9 +5,10 @@ from .shm_vec_env import ShmSubprocVecEnv
 from .shm_vec_maenv import ShmSubprocVecMultiAgentEnv
 from .dummy_vec_env import DummyVecEnv, DummyVecMultiAgentEnv, HostSMACLikeEnv
 from .synthetic import SyntheticAtariVecEnv, SyntheticMujocoVecEnv, SyntheticSMACVecEnv
+from .recorded import RecordedVecEnv
 
 REGISTRY_VEC_ENV = {"DeviceCartPoleVecEnv": DeviceCartPoleVecEnv, "DevicePendulumVecEnv": DevicePendulumVecEnv,
                     "DeviceMountainCarVecEnv": DeviceMountainCarVecEnv, "DeviceAcrobotVecEnv": DeviceAcrobotVecEnv, "SyntheticAtariVecEnv": SyntheticAtariVecEnv,
                     "SyntheticMujocoVecEnv": SyntheticMujocoVecEnv, "SyntheticSMACVecEnv": SyntheticSMACVecEnv, "ShmSubprocVecEnv": ShmSubprocVecEnv,
                     "ShmSubprocVecMultiAgentEnv": ShmSubprocVecMultiAgentEnv,
-                    "DummyVecEnv": DummyVecEnv, "DummyVecMultiAgentEnv": DummyVecMultiAgentEnv}
+                    "DummyVecEnv": DummyVecEnv, "DummyVecMultiAgentEnv": DummyVecMultiAgentEnv, "RecordedVecEnv": RecordedVecEnv}
