@@ -177,6 +177,119 @@ def golden_agent_ppo():
     np.savez_compressed(os.path.join(OUT, "agent_ppo.npz"), **out)
     print("agent_ppo:", len(out), "arrays;", int(term.sum()), "terminations,", int((trunc & ~term).sum()), "truncations")
 
+# ------------------------------------------------------------------------------------------------------------------ DQN
+def golden_agent_dqn():
+    """DQN_Agent with configs/dqn/classic_control/CartPole-v1.yaml (network 4-128-128-2, MSE TD loss, no normalisation, no
+    clipping) at 8 envs, a replay ring of 16 rows per env (it wraps three times), batch 16, start_training 48, an update every
+    second vector step (training_frequency 16 with current_step growing by 8), hard target sync every 5 updates, epsilon from 0.5
+    to 0.01 with decay_step_greedy = 1 920 (the schedule's floor is reached at vector step 30 and frozen, off_policy.py:119-127),
+    64 vector steps on CartPole simulators cut at 13 steps."""
+    from xuance.common.callback import BaseCallback
+    import xuance.torch.agents.base.agent as agent_mod
+    import xuance.torch.agents.core.off_policy as op
+    from xuance.torch.agents import REGISTRY_Agents
+    from xuance.environment.vector_envs.dummy.dummy_vec_env import DummyVecEnv
+    from xuance.environment.utils.wrapper import XuanCeEnvWrapper
+    from xuance_amd.envs import NumpyCartPoleEnv
+
+    class ShortCartPole(NumpyCartPoleEnv):
+        max_episode_steps = 13
+
+    agent_mod.SummaryWriter = _NullWriter
+    op.tqdm = lambda x, *a, **k: x
+    n, S, A = 8, 64, 2
+    cfg = agent_config("dqn/classic_control/CartPole-v1.yaml", parallels=n, buffer_size=n * 16, batch_size=16, start_training=n * 6,
+                       training_frequency=16, sync_frequency=5, decay_step_greedy=n * n * 30, seed=5)
+    seed_all(cfg.seed)
+    envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 3)
+    envs.observation_space, envs.action_space = sp.Box(-np.inf, np.inf, (4,), np.float32), sp.Discrete(A)
+    envs.reset()
+    out, steps, phases = {}, [], []
+
+    class Rec(BaseCallback):
+        def on_train_step(self, current_step, **kw):
+            steps.append(dict(obs=np.array(kw["obs"], np.float32), acts=np.array(kw["policy_out"].env_actions), next_obs=np.array(kw["next_obs"], np.float32),
+                              rewards=np.array(kw["rewards"], np.float32), terminals=np.array(kw["terminals"]),
+                              truncations=np.array(kw["truncations"]), eps_acted=np.float64(self.agent.e_greedy),
+                              reset_obs=np.stack([np.asarray(i.get("reset_obs", np.zeros(4)), np.float32) for i in kw["infos"]]),
+                              step_index=np.int64(current_step), **self.draw))
+
+        def on_train_epochs_end(self, current_step, **kw):
+            phases.append(dict(param=sd_np(kw["model"]), indices=np.stack(self.indices), grads=self.grads, at_step=np.int64(len(steps) - 1),
+                               info={k: np.float64(v) for k, v in kw["update_info"].items() if np.isscalar(v) and v is not None},
+                               iterations=np.int64(self.agent.learner.iterations)))
+            self.indices, self.grads = [], []
+
+        def on_train_step_end(self, current_step, **kw):
+            ag = self.agent
+            steps[-1].update(eps_after=np.float64(ag.e_greedy), current_step=np.int64(current_step), ptr=np.int64(ag.memory.ptr),
+                             size=np.int64(ag.memory.size))
+
+    cb = Rec()
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs, callback=cb)
+    finally:
+        os.chdir(cwd)
+    cb.agent, cb.indices, cb.grads, cb.draw = agent, [], [], None
+    sample0, update0, explore0 = agent.memory.sample, agent.learner.update, agent.exploration
+
+    def sample(batch_size=None):                                      # (listening: the choices NumPy made, memory_tools.py:374-377)
+        st = np.random.get_state()
+        smp = sample0(batch_size)
+        after = np.random.get_state()
+        np.random.set_state(st)
+        env_c, step_c = np.random.choice(agent.memory.n_envs, agent.memory.batch_size), np.random.choice(agent.memory.size, agent.memory.batch_size)
+        assert np.array_equal(smp["obs"], agent.memory.observations[env_c, step_c])
+        np.random.set_state(after)
+        cb.indices.append(np.stack([env_c, step_c]))
+        return smp
+
+    def update(**samples):
+        info = update0(**samples)
+        cb.grads.append({k: p.grad.detach().numpy().copy() for k, p in agent.model.named_parameters() if p.grad is not None})
+        return info
+
+    def exploration(pi_actions):                                      # (listening: the coin and the random actions, off_policy.py:138-141)
+        st = torch.get_rng_state()
+        acts = explore0(pi_actions)
+        after = torch.get_rng_state()
+        torch.set_rng_state(st)
+        u, r = torch.rand(n), torch.randint(0, A, size=(n,))
+        assert torch.equal(torch.where(u < agent.e_greedy, r, pi_actions), acts)
+        torch.set_rng_state(after)
+        cb.draw = dict(coin=u.numpy().copy(), random_actions=r.numpy().copy(), greedy=pi_actions.numpy().copy())
+        return acts
+    agent.memory.sample, agent.learner.update, agent.exploration = sample, update, exploration
+    out.update(mg.flat("init", sd_np(agent.model)))
+    out["raw_obs0"] = np.array(envs.buf_obs, np.float32).copy()
+    agent.train(S)
+    assert len(steps) == S
+    for k in steps[0]:
+        out[f"step/{k}"] = np.stack([s[k] for s in steps])
+    for p, ph in enumerate(phases):
+        if p < 2 or p % 5 == 4 or p == len(phases) - 1:              # (parameter snapshots of some phases: every target sync is among them)
+            out.update(mg.flat(f"phase{p}/param", ph["param"]))
+        out.update(mg.flat(f"phase{p}/info", ph["info"]))
+        out[f"phase{p}/indices"], out[f"phase{p}/iterations"], out[f"phase{p}/at_step"] = ph["indices"], ph["iterations"], ph["at_step"]
+        for u, g in enumerate(ph["grads"]):
+            out.update(mg.flat(f"phase{p}/grad{u}", g))
+    out["n_phases"] = np.int64(len(phases))
+    m = agent.memory
+    out.update(mg.flat("final_buffer", {k: np.array(getattr(m, k)).copy() for k in ("observations", "next_observations", "actions", "rewards", "terminals")}))
+    term, trunc = out["step/terminals"], out["step/truncations"]
+    explored = out["step/coin"] < out["step/eps_acted"][:, None]
+    assert term.sum() > 8 and (trunc & ~term).sum() > 4 and explored.sum() > 20 and (~explored).sum() > 200
+    assert out["step/eps_after"][-1] <= cfg.end_greedy and len(np.unique(out["step/eps_after"])) > 20
+    out["cfg"] = np.array([n, S, cfg.buffer_size, cfg.batch_size, cfg.gamma, cfg.learning_rate, cfg.start_training, cfg.training_frequency,
+                           cfg.sync_frequency, cfg.start_greedy, cfg.end_greedy, cfg.decay_step_greedy, agent.learner.total_iters,
+                           ShortCartPole.max_episode_steps], np.float64)
+    out["cfg_names"] = np.array("n_envs n_steps buffer_size batch_size gamma learning_rate start_training training_frequency sync_frequency "
+                                "start_greedy end_greedy decay_step_greedy total_iters max_episode_steps".split())
+    np.savez_compressed(os.path.join(OUT, "agent_dqn.npz"), **out)
+    print("agent_dqn:", len(out), "arrays;", len(phases), "update phases,", int(term.sum()), "terminations,", int((trunc & ~term).sum()),
+          "truncations,", int(explored.sum()), "explored actions; final epsilon", out["step/eps_after"][-1])
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

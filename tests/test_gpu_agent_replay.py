@@ -104,3 +104,78 @@ def test_ppo_agent_replays_the_reference_run(use_graph):
         got = {k: npy(v) for k, v in agent.model.state_dict().items()}
         chain.check(got, sub(g, f"phase{p}/param"), init, what=f"phase {p} param")
     assert (agent._rollout_graph is not None) == use_graph and (agent._update_graph is not None) == use_graph
+
+
+def test_dqn_agent_replays_the_reference_run():
+    """agent_dqn.npz: the reference's DQN_Agent (configs/dqn/classic_control/CartPole-v1.yaml) over 64 vector steps of 8 envs: a
+    16-row ring that wraps three times, 28 update phases from vector step 8 on (every second step), target syncs every 5 updates,
+    epsilon from 0.5 to its floor at step 30 (frozen at the undershoot value -0.0063, off_policy.py:119-127), 41 terminations and
+    7 truncations.  Per vector step: the action of every env (greedy argmax of the device's Q values, or the supplied random
+    action where the supplied coin is below the device's epsilon), epsilon, current_step, the ring's write position and fill;
+    per update phase: loss and parameters; at the end the whole ring, bit for bit."""
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import RecordedVecEnv
+    from xuance_amd.spaces import Discrete
+    g = load_golden("agent_dqn")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, S, B = int(c["n_envs"]), int(c["n_steps"]), int(c["batch_size"])
+    env = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
+                         g["step/reset_obs"], action_space=Discrete(2), max_episode_steps=int(c["max_episode_steps"]))
+    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[128], q_hidden_size=[128], activation="relu", seed=1,
+                    parallels=n, running_steps=10 ** 6, buffer_size=int(c["buffer_size"]), batch_size=B, learning_rate=c["learning_rate"],
+                    gamma=c["gamma"], start_greedy=c["start_greedy"], end_greedy=c["end_greedy"], decay_step_greedy=c["decay_step_greedy"],
+                    sync_frequency=int(c["sync_frequency"]), training_frequency=int(c["training_frequency"]),
+                    start_training=int(c["start_training"]), n_epochs=1, use_grad_clip=False, grad_clip_norm=0.5, use_obsnorm=False,
+                    use_rewnorm=False, distributed_training=False, device="cuda", model_dir="/tmp/xrl_models")
+    agent = DQN_Agent(cfg, env)
+    init = sub(g, "init")
+    assert list(agent.model.ref_order) == list(init) and agent.learner.total_iters == int(c["total_iters"])
+    agent.model.load_state_dict(init)
+    P = int(g["n_phases"])
+    agent.set_replay(coins=g["step/coin"], random_actions=g["step/random_actions"], indices=[g[f"phase{p}/indices"][0] for p in range(P)])
+    mem, f = agent.memory, agent.memory.soa.fields
+    trainable = [k for k in init if not k.startswith("target_")]
+    chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))
+    phase, flips = 0, 0
+    for s in range(S):
+        assert agent.e_greedy == g["step/eps_acted"][s] and agent.current_step == int(g["step/step_index"][s])
+        slot = mem.ptr
+        info = agent.train(1)
+        acts = npy(env.action)
+        explore = g["step/coin"][s] < np.float32(g["step/eps_acted"][s])
+        assert np.array_equal(acts[explore], g["step/random_actions"][s][explore]), f"step {s}: explored actions"
+        for e in np.flatnonzero(acts != g["step/acts"][s]):                        # (a greedy action may differ from the reference's only on a tie)
+            q = npy(agent.model.forward(f["observations"][slot], n))[e]
+            assert abs(q[0] - q[1]) < 1e-5 * max(1.0, np.abs(q).max()), (s, e, q)
+            flips += 1
+        if s == 0:
+            # The reference's first stored "obs" of a train() call is its vector env's buffer AFTER the step (an alias of
+            # DummyVecEnv.buf_obs, see tests/test_oracle_agent_loops.py: test_dqn_agent_loop): the device loop stored what the
+            # policy acted on; the reference's row is input data of this replay (update phases sample it until the ring wraps).
+            assert np.array_equal(npy(f["observations"][0]), g["raw_obs0"]) and np.array_equal(g["step/obs"][0], g["step/next_obs"][0])
+            f["observations"][0].copy_(torch.as_tensor(g["step/obs"][0]))
+        assert agent.e_greedy == g["step/eps_after"][s] and agent.current_step == int(g["step/current_step"][s])
+        assert mem.ptr == int(g["step/ptr"][s]) and mem.size == int(g["step/size"][s])
+        if phase < P and int(g[f"phase{phase}/at_step"]) == s:
+            assert agent.learner.iterations == int(g[f"phase{phase}/iterations"]), f"update trigger at step {s}"
+            assert_close(info["Qloss"], g[f"phase{phase}/info/Qloss"], 1e-5, f"phase {phase} Qloss")
+            assert_close(info["predictQ"], g[f"phase{phase}/info/predictQ"], 1e-5, f"phase {phase} predictQ", scale=1.0)
+            chain.step({k: v for k, v in sub(g, f"phase{phase}/grad0").items()})
+            ref_p = sub(g, f"phase{phase}/param")
+            if ref_p:
+                got = {k: npy(v) for k, v in agent.model.state_dict().items()}
+                chain.check({k: got[k] for k in trainable}, {k: ref_p[k] for k in trainable}, init, what=f"phase {phase} param")
+                if agent.learner.iterations % int(c["sync_frequency"]) == 0:             # hard target sync: exact copies of the eval tensors
+                    for k in init:
+                        if k.startswith("target_"):
+                            src = k[len("target_"):] if k.startswith("target_representation") else "eval_Q_head." + k[len("target_Q_head."):]
+                            assert np.array_equal(got[k], got[src]), f"phase {phase}: {k} is not the copy of {src}"
+            phase += 1
+        else:
+            assert agent.learner.iterations == (int(g[f"phase{phase - 1}/iterations"]) if phase else 0)
+    assert phase == P and flips <= 2
+    fb = sub(g, "final_buffer")
+    tm = lambda a: np.swapaxes(np.asarray(a), 0, 1)
+    for k in ("observations", "next_observations", "actions", "rewards"):
+        assert np.array_equal(npy(f[k]), tm(fb[k])), f"ring field {k}"
+    assert np.array_equal(npy(f["terminals"]) > 0, tm(fb["terminals"]) > 0)

@@ -21,11 +21,21 @@ def _get(cfg, name, default=None):
 
 def eps_kstar(start_greedy, end_greedy, delta_egreedy, n_envs):
     """First vector step k whose epsilon start - (k n) delta is <= end_greedy: where OffPolicyAgent._update_explore_factor
-    (off_policy.py:119-127) stops updating -- the host constant of xrl_dqn_act_tail_t.eps_sched."""
-    k, e = 0, start_greedy
-    while e > end_greedy:
+    (off_policy.py:119-127) stops updating -- the host constant of xrl_dqn_act_tail_t.eps_sched.  A schedule that never gets
+    there (delta <= 0 or NaN, or too small to move the float) returns 0xffffffff."""
+    val = lambda k: start_greedy - (k * n_envs) * delta_egreedy      # the reference's own float64 expression
+    if not start_greedy > end_greedy:
+        return 0
+    if not delta_egreedy > 0 or not np.isfinite(delta_egreedy):
+        return 0xffffffff
+    g = (start_greedy - end_greedy) / (n_envs * delta_egreedy)
+    if not np.isfinite(g) or g >= 0xffffffff:
+        return 0xffffffff
+    k = max(int(np.ceil(g)), 1)
+    while k > 1 and val(k - 1) <= end_greedy:                          # (the closed form is within one step of the float64 answer)
+        k -= 1
+    while val(k) > end_greedy and k < 0xffffffff:
         k += 1
-        e = start_greedy - (k * n_envs) * delta_egreedy
     return k
 
 
@@ -72,6 +82,26 @@ class DQN_Agent(AgentSurface):
         assert not (self.atari and self.use_obsnorm), "Atari frames are stored as uint8 (configs/dqn/atari.yaml:42-43)"
         self._started = False
         self._act_calls = 0
+        assert not self.use_rewnorm, "reward normalisation is not built for the off-policy loops (every configs/dqn/*.yaml has use_rewnorm: False)"
+        # Supplied randomness (replays of recorded runs, set_replay): per vector step the exploration coins [S, n] and the random
+        # actions [S, n] (off_policy.py:138-139: torch.rand(n_envs), torch.randint(n_actions)); per update the replay choices
+        # [2, batch] = (env_choices, step_choices) of memory_tools.py:376-377.  Both are consumed in order.
+        self.explore_tape = None
+        self.index_tape = None
+
+    def set_replay(self, coins=None, random_actions=None, indices=None):
+        """Replay hook: the loop's random decisions come from the caller (a recorded run) instead of the Philox streams.  With
+        coins / random_actions the acting step is the layered one (xrl_egreedy takes supplied draws); with indices every update is
+        `learner.update(**memory.sample(indexes))`, launch by launch (the captured update phase draws inside its gather launch:
+        tests/test_gpu_offpolicy_agents.py shows the two bit-identical on the same indices)."""
+        dev = self.device
+        if coins is not None:
+            self.explore_tape = (torch.as_tensor(np.asarray(coins, np.float32), device=dev).contiguous(),
+                                 torch.as_tensor(np.asarray(random_actions, np.int32), device=dev).contiguous())
+            self._act_fused = False
+        if indices is not None:
+            self.index_tape = [np.asarray(i, np.int64) for i in indices]
+            self._index_pos = 0
 
     def _build_model(self):
         c = self.config
@@ -150,8 +180,11 @@ class DQN_Agent(AgentSurface):
             self.model.act_egreedy(X[:n], n, None, env.action, self.act_f, self.seed, self._host_step, eps=float(self.e_greedy))
         else:
             q = self.model.forward(X[:n], n)
+            tape = {}
+            if self.explore_tape is not None:
+                tape = dict(uniforms=self.explore_tape[0][self._host_step], randoms=self.explore_tape[1][self._host_step])
             ops.egreedy(q=q, eps_dev=None, eps=float(self.e_greedy), action=env.action, action_f=self.act_f, n=n, A=A, ld=q.stride(0), seed=self.seed,
-                        step=self._host_step, step_dev=None)   # eager loop: the host knows the step index
+                        step=self._host_step, step_dev=None, **tape)   # eager loop: the host knows the step index
         env.step_device()
         self._host_step += 1
         if zero_copy:
@@ -186,6 +219,8 @@ class DQN_Agent(AgentSurface):
 
     def _pair_ready(self):
         env, lr, n = self.envs, self.learner, self.n_envs
+        if self.explore_tape is not None or self.index_tape is not None:
+            return False
         if not (bool(_get(self.config, "use_step_graph", True)) and self.use_graph_updates and self._act_fused and self.atari
                 and getattr(env, "double_buffered", False) and getattr(env, "graph_safe_even", False)
                 and hasattr(lr, "phase_ready") and type(self.memory) in (HipOffPolicyBuffer, HipOffPolicyBuffer_Atari)):
@@ -240,6 +275,13 @@ class DQN_Agent(AgentSurface):
         lr.note_phases(mem, self.n_epochs, 2)
 
     def _train_epochs(self, train_steps):
+        if self.index_tape is not None:
+            info = {}
+            for _e in range(self.n_epochs):
+                env_c, step_c = self.index_tape[self._index_pos]
+                self._index_pos += 1
+                info = self.learner.update(**self.memory.sample(indexes=env_c * self.memory.n_size + step_c))
+            return info
         if self.use_graph_updates:
             return self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed, sync=False)
         info = {}
