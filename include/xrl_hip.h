@@ -1200,6 +1200,13 @@ typedef struct {
 /* Device address of page-locked host memory (hipHostMalloc / torch pin_memory), for kernels that publish a word to the host. */
 int xrl_host_device_pointer(void* pinned_host, void** device_out);
 int xrl_marl_loop_gate(const xrl_marl_gate_t* gate, xrl_stream_t stream);
+/* out [n_envs][state_dim] = the global state OffPolicyMARLAgents.train / run_episodes STORE for the coming vector step
+ * (core/off_policy_marl.py:384-399, 496-511 with store_experience :151-153 and memory_tools_marl.py:731-740): a copy of `state`
+ * unless some env finished its episode in the previous step (done_prev [n_envs] != 0; NULL = none) -- then EVERY row is the
+ * (reset) state row of the last such env, because the loops assign `state = info[i]["reset_state"]` (the list itself, not
+ * element i) and the buffer broadcasts the single vector over its env axis.  A reference defect, reproduced so that buffers and
+ * updates equal the reference's (QMIX_Agents: config.reference_state_broadcast, default on). */
+int xrl_marl_stored_state(const float* state, const float* done_prev, float* out, int n_envs, int state_dim, xrl_stream_t stream);
 
 /* store (:904-921): a = staging [n_envs][slots][row], b = step data [n_envs][row]: staging[env][steps[env]] <- b[env]
  * (`filled` is a field whose step data is ones). */

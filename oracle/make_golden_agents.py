@@ -291,6 +291,291 @@ def golden_agent_dqn():
           "truncations,", int(explored.sum()), "explored actions; final epsilon", out["step/eps_after"][-1])
 
 
+# ------------------------------------------------------------------------------------------------------------------ QMIX
+def _smac_like_env(max_steps):
+    from xuance_amd.envs import HostSMACLikeEnv
+
+    class Env(HostSMACLikeEnv):
+        max_episode_steps = max_steps
+        groups_info = None
+
+        def __init__(self, env_seed=None):
+            super().__init__(env_seed)
+            self.num_agents = self.n_agents
+            self.env_info = {"max_episode_steps": self.max_episode_steps}
+    return Env
+
+
+def _stack(list_of_dicts, keys, dtype=None):
+    """[n_envs] dicts keyed by agent -> [n_envs, n_agents, ...]."""
+    return np.stack([[np.asarray(d[k]) for k in keys] for d in list_of_dicts]).astype(dtype) if dtype else \
+        np.stack([[np.asarray(d[k]) for k in keys] for d in list_of_dicts])
+
+
+def _marl_envs(Env, n, seed):
+    from xuance.environment.vector_envs.dummy.dummy_vec_maenv import DummyVecMultiAgentEnv
+    envs = DummyVecMultiAgentEnv([Env] * n, seed)
+    envs.observation_space = {k: sp.Box(-np.inf, np.inf, (30,), np.float32) for k in envs.agents}
+
+    class _Disc(sp.Discrete):                                          # gymnasium's Discrete.sample (masks-off exploration, :242)
+        def sample(self):
+            return int(np.random.randint(self.n))
+    envs.action_space = {k: _Disc(9) for k in envs.agents}
+    envs.state_space = sp.Box(-np.inf, np.inf, (48,), np.float32)
+    return envs
+
+
+def golden_agent_qmix_ff():
+    """QMIX_Agents with configs/qmix/sc2/3m.yaml and representation Basic_MLP (feed-forward agents; parameter sharing, action masks,
+    double-Q, global state) at 4 envs, a ring of 20 rows per env (it wraps), batch 8, start_training 16 (first update phase at
+    vector step 4, `current_step >= start_training`, off_policy_marl.py:376), 2 updates every second vector step (training_frequency
+    8 with current_step growing by 4), hard target sync every 4 updates, epsilon from 1.0 to 0.05 over 30 vector steps (ONE coin
+    per vector step, :236), 36 vector steps on the SMAC-3m-shaped host env cut at 11 steps behind the reference's
+    DummyVecMultiAgentEnv."""
+    from xuance.common.callback import MultiAgentBaseCallback
+    import xuance.torch.agents.base.agents_marl as am
+    import xuance.torch.agents.core.off_policy_marl as opm
+    from xuance.torch.agents import REGISTRY_Agents
+    am.SummaryWriter = _NullWriter
+    opm.tqdm = _Quiet
+    n, S, N, A = 4, 36, 3, 9
+    cfg = agent_config("qmix/sc2/3m.yaml", parallels=n, use_rnn=False, representation="Basic_MLP", buffer_size=n * 20, batch_size=8,
+                       start_training=n * 4, training_frequency=2 * n, n_epochs=2, sync_frequency=4, decay_step_greedy=n * n * 30, seed=3)
+    seed_all(cfg.seed)
+    envs = _marl_envs(_smac_like_env(11), n, 21)
+    envs.reset()
+    keys = list(envs.agents)
+    out, steps, phases = {}, [], []
+
+    class Rec(MultiAgentBaseCallback):
+        def on_train_step(self, current_step, **kw):
+            info = kw["infos"]
+            done = np.array([all(t.values()) or bool(tr) for t, tr in zip(kw["terminals"], kw["truncations"])])
+            z_obs, z_av = {k: np.zeros(30, np.float32) for k in keys}, {k: np.zeros(A, np.float32) for k in keys}
+            steps.append(dict(
+                stored_obs=_stack(kw["obs"], keys, np.float32), stored_avail=_stack(kw["avail_actions"], keys, np.float32),
+                stored_state=np.broadcast_to(np.asarray(kw["state"], np.float32), (n, 48)).copy(),
+                acts=_stack(kw["acts"], keys).astype(np.int64), next_obs=_stack(kw["next_obs"], keys, np.float32),
+                next_state=np.asarray(kw["next_state"], np.float32), next_avail=_stack(kw["next_avail_actions"], keys, np.float32),
+                rewards=_stack(kw["rewards"], keys, np.float32), terminals=_stack(kw["terminals"], keys).astype(bool),
+                truncations=np.asarray(kw["truncations"], bool), agent_mask=_stack([i["agent_mask"] for i in info], keys).astype(bool),
+                reset_obs=_stack([i.get("reset_obs", z_obs) for i in info], keys, np.float32),
+                reset_state=np.stack([np.asarray(i.get("reset_state", np.zeros(48)), np.float32) for i in info]),
+                reset_avail=_stack([i.get("reset_avail_actions", z_av) for i in info], keys, np.float32),
+                episode_step=np.array([i["episode_step"] for i in info], np.int64),
+                done=done, eps_acted=np.float64(self.agent.e_greedy), step_index=np.int64(current_step), **self.draw))
+
+        def on_train_epochs_end(self, current_step, **kw):
+            phases.append(dict(param=sd_np(kw["model"]), indices=np.stack(self.indices), grads=self.grads, at_step=np.int64(len(steps) - 1),
+                               infos=self.infos, iterations=np.int64(self.agent.learner.iterations)))
+            self.indices, self.grads, self.infos = [], [], []
+
+        def on_train_step_end(self, current_step, **kw):
+            ag = self.agent
+            steps[-1].update(eps_after=np.float64(ag.e_greedy), current_step=np.int64(current_step), ptr=np.int64(ag.memory.ptr),
+                             size=np.int64(ag.memory.size))
+
+    cb = Rec()
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs, callback=cb)
+    finally:
+        os.chdir(cwd)
+    cb.agent, cb.indices, cb.grads, cb.infos, cb.draw = agent, [], [], [], None
+    out["acted_obs0"] = _stack(envs.buf_obs, keys, np.float32)        # what the FIRST acting pass sees (before the alias below matters)
+    out["acted_avail0"] = _stack(envs.buf_avail_actions, keys, np.float32)
+    out["acted_state0"] = np.asarray(envs.buf_state, np.float32).copy()
+    sample0, update0, explore0 = agent.memory.sample, agent.learner.update, agent.exploration
+
+    def sample(batch_size=None):                                      # (listening: memory_tools_marl.py:742-747)
+        st = np.random.get_state()
+        smp = sample0(batch_size)
+        after = np.random.get_state()
+        np.random.set_state(st)
+        m = agent.memory
+        env_c, step_c = np.random.choice(m.n_envs, m.batch_size), np.random.choice(m.size, m.batch_size)
+        assert np.array_equal(smp["state"], m.data["state"][env_c, step_c])
+        np.random.set_state(after)
+        cb.indices.append(np.stack([env_c, step_c]))
+        return smp
+
+    def update(sample):
+        info = update0(sample)
+        cb.grads.append({k: p.grad.detach().numpy().copy() for k, p in agent.model.named_parameters() if p.grad is not None})
+        cb.infos.append({k: np.float64(v) for k, v in info.items() if np.isscalar(v)})
+        return info
+
+    def exploration(batch_size, pi_actions_dict, avail_actions_list=None):   # (listening: ONE coin per vector step, :236; random available actions)
+        st_np = np.random.get_state()
+        acts = explore0(batch_size, pi_actions_dict, avail_actions_list)
+        after = np.random.get_state()
+        np.random.set_state(st_np)
+        coin = np.random.rand()
+        np.random.set_state(after)
+        cb.draw = dict(coin=np.float64(coin), greedy=_stack(pi_actions_dict, keys).astype(np.int64),
+                       acted_avail=_stack(avail_actions_list, keys, np.float32))
+        return acts
+    agent.memory.sample, agent.learner.update, agent.exploration = sample, update, exploration
+    out.update(mg.flat("init", sd_np(agent.model)))
+    agent.train(S)
+    assert len(steps) == S
+    for k in steps[0]:
+        out[f"step/{k}"] = np.stack([s[k] for s in steps])
+    for p, ph in enumerate(phases):
+        if p < 2 or p % 4 == 3 or p == len(phases) - 1:
+            out.update(mg.flat(f"phase{p}/param", ph["param"]))
+        out[f"phase{p}/indices"], out[f"phase{p}/iterations"], out[f"phase{p}/at_step"] = ph["indices"], ph["iterations"], ph["at_step"]
+        for u, (g, inf) in enumerate(zip(ph["grads"], ph["infos"])):
+            out.update(mg.flat(f"phase{p}/grad{u}", g))
+            out.update(mg.flat(f"phase{p}/info{u}", inf))
+    out["n_phases"] = np.int64(len(phases))
+    m = agent.memory
+    for k, v in m.data.items():
+        if isinstance(v, dict):
+            out[f"final_buffer/{k}"] = np.stack([v[a] for a in keys], 2)          # [n_envs, n_size, n_agents, ...]
+        else:
+            out[f"final_buffer/{k}"] = np.array(v).copy()
+    explored = out["step/coin"] < out["step/eps_acted"]
+    done = out["step/done"]
+    print("explored steps", int(explored.sum()), "of", S, "; episode ends", int(done.sum()), "terminated", int(out["step/terminals"].all(-1).sum()))
+    assert 8 < explored.sum() < S - 8 and done.sum() > 8 and out["step/terminals"].all(-1).sum() >= 2
+    out["cfg"] = np.array([n, S, N, A, cfg.buffer_size, cfg.batch_size, cfg.gamma, cfg.learning_rate, cfg.start_training, cfg.training_frequency,
+                           cfg.n_epochs, cfg.sync_frequency, cfg.start_greedy, cfg.end_greedy, cfg.decay_step_greedy, agent.learner.total_iters,
+                           11], np.float64)
+    out["cfg_names"] = np.array("n_envs n_steps n_agents n_actions buffer_size batch_size gamma learning_rate start_training training_frequency "
+                                "n_epochs sync_frequency start_greedy end_greedy decay_step_greedy total_iters max_episode_steps".split())
+    np.savez_compressed(os.path.join(OUT, "agent_qmix_ff.npz"), **out)
+    print("agent_qmix_ff:", len(out), "arrays;", len(phases), "update phases; final epsilon", out["step/eps_after"][-1])
+
+
+def golden_agent_qmix_rnn():
+    """QMIX_Agents with configs/qmix/sc2/3m.yaml as shipped (Basic_RNN: fc 64 -> GRU 64, Q head 64-9; double-Q, parameter sharing,
+    global state) except `use_actions_mask: False` -- with the masks on, the reference's own recurrent update raises
+    (iql_learner.py:78-81 indexes a [B, T, A] mask with a [B, T+1, ...] tensor; see oracle/make_golden.py: golden_qmix_rnn) -- at 4 envs,
+    episodes cut at 11 steps, a ring of 16 episodes (it wraps), batch 4 episodes, 2 updates after every run_episodes(4) call once
+    current_step >= 60, target sync every 3 updates, epsilon 1.0 -> 0.05 over 200 env steps (updated per finished episode,
+    off_policy_marl.py:532-534): train(60) = six run_episodes calls."""
+    from xuance.common.callback import MultiAgentBaseCallback
+    import xuance.torch.agents.base.agents_marl as am
+    import xuance.torch.agents.core.off_policy_marl as opm
+    from xuance.torch.agents import REGISTRY_Agents
+    am.SummaryWriter = _NullWriter
+    opm.tqdm = _Quiet
+    n, N, A, L = 4, 3, 9, 11
+    cfg = agent_config("qmix/sc2/3m.yaml", parallels=n, use_actions_mask=False, buffer_size=16, batch_size=4, start_training=60,
+                       n_epochs=2, sync_frequency=3, decay_step_greedy=n * 200, seed=11)
+    seed_all(cfg.seed)
+    Env = _smac_like_env(L)
+    Env.strict_actions = False                                        # (with the masks off the reference picks unavailable actions)
+    envs = _marl_envs(Env, n, 31)
+    keys = list(envs.agents)
+    out, steps, phases, resets = {}, [], [], []
+
+    class Rec(MultiAgentBaseCallback):
+        def on_test_step(self, **kw):                                 # (run_episodes reports every step here, training mode included: :476-483)
+            info = kw["infos"]
+            done = np.array([all(t.values()) or bool(tr) for t, tr in zip(kw["terminals"], kw["truncations"])])
+            z_obs, z_av = {k: np.zeros(30, np.float32) for k in keys}, {k: np.zeros(A, np.float32) for k in keys}
+            steps.append(dict(
+                acted_obs=_stack(kw["obs"], keys, np.float32), stored_state=np.broadcast_to(np.asarray(kw["state"], np.float32), (n, 48)).copy(),
+                acts=_stack(kw["acts"], keys).astype(np.int64), next_obs=_stack(kw["next_obs"], keys, np.float32),
+                next_state=np.asarray(kw["next_state"], np.float32), next_avail=_stack([i["avail_actions"] for i in info], keys, np.float32),
+                rewards=_stack(kw["rewards"], keys, np.float32), terminals=_stack(kw["terminals"], keys).astype(bool),
+                truncations=np.asarray(kw["truncations"], bool), agent_mask=_stack([i["agent_mask"] for i in info], keys).astype(bool),
+                reset_obs=_stack([i.get("reset_obs", z_obs) for i in info], keys, np.float32),
+                reset_state=np.stack([np.asarray(i.get("reset_state", np.zeros(48)), np.float32) for i in info]),
+                reset_avail=_stack([i.get("reset_avail_actions", z_av) for i in info], keys, np.float32),
+                episode_step=np.array([i["episode_step"] for i in info], np.int64), done=done, call=np.int64(len(resets) - 1),
+                eps_acted=np.float64(self.eps_acted), current_step_before=np.int64(kw["current_train_step"]), **self.draw))
+
+        def on_train_epochs_end(self, current_step, **kw):
+            phases.append(dict(param=sd_np(kw["model"]), indices=np.stack(self.indices), grads=self.grads, infos=self.infos,
+                               after_call=np.int64(len(resets) - 1), iterations=np.int64(self.agent.learner.iterations)))
+            self.indices, self.grads, self.infos = [], [], []
+
+    cb = Rec()
+    cwd = os.getcwd(); os.chdir("/tmp")
+    try:
+        agent = REGISTRY_Agents[cfg.agent](cfg, envs, callback=cb)
+    finally:
+        os.chdir(cwd)
+    cb.agent, cb.indices, cb.grads, cb.infos, cb.draw, cb.eps_acted = agent, [], [], [], None, None
+    sample0, update0, explore0, reset0, run0 = agent.memory.sample, agent.learner.update, agent.exploration, envs.reset, agent.run_episodes
+    calls = []
+
+    def reset():                                                      # (listening: what every run_episodes call starts from, :436-441)
+        r = reset0()
+        resets.append(dict(obs=_stack(envs.buf_obs, keys, np.float32), state=np.asarray(envs.buf_state, np.float32).copy(),
+                           avail=_stack(envs.buf_avail_actions, keys, np.float32), at=len(steps)))
+        return r
+
+    def run_episodes(*a, **k):
+        r = run0(*a, **k)
+        calls.append(dict(current_step=np.int64(agent.current_step), eps=np.float64(agent.e_greedy), ptr=np.int64(agent.memory.ptr),
+                          size=np.int64(agent.memory.size), n_steps=np.int64(len(steps))))
+        return r
+
+    def sample(batch_size=None):                                      # (listening: memory_tools_marl.py:982)
+        st = np.random.get_state()
+        smp = sample0(batch_size)
+        after = np.random.get_state()
+        np.random.set_state(st)
+        m = agent.memory
+        ep = np.random.choice(m.size, m.batch_size)
+        assert np.array_equal(smp["state"], m.data["state"][ep])
+        np.random.set_state(after)
+        cb.indices.append(ep)
+        return smp
+
+    def update(sample):
+        info = update0(sample)
+        cb.grads.append({k: p.grad.detach().numpy().copy() for k, p in agent.model.named_parameters() if p.grad is not None})
+        cb.infos.append({k: np.float64(v) for k, v in info.items() if np.isscalar(v)})
+        return info
+
+    def exploration(batch_size, pi_actions_dict, avail_actions_list=None):   # (listening: the step's coin)
+        st_np = np.random.get_state()
+        cb.eps_acted = agent.e_greedy
+        acts = explore0(batch_size, pi_actions_dict, avail_actions_list)
+        after = np.random.get_state()
+        np.random.set_state(st_np)
+        coin = np.random.rand()
+        np.random.set_state(after)
+        cb.draw = dict(coin=np.float64(coin), greedy=_stack(pi_actions_dict, keys).astype(np.int64))
+        return acts
+    agent.memory.sample, agent.learner.update, agent.exploration, envs.reset, agent.run_episodes = sample, update, exploration, reset, run_episodes
+    out.update(mg.flat("init", sd_np(agent.model)))
+    agent.train(60)
+    for k in steps[0]:
+        out[f"step/{k}"] = np.stack([s[k] for s in steps])
+    for k in calls[0]:
+        out[f"call/{k}"] = np.stack([c_[k] for c_ in calls])
+    for i, r in enumerate(resets):
+        for k in ("obs", "state", "avail"):
+            out[f"reset{i}/{k}"] = r[k]
+        out[f"reset{i}/at"] = np.int64(r["at"])
+    out["n_resets"], out["n_phases"] = np.int64(len(resets)), np.int64(len(phases))
+    for p, ph in enumerate(phases):
+        out.update(mg.flat(f"phase{p}/param", ph["param"]))
+        out[f"phase{p}/indices"], out[f"phase{p}/iterations"], out[f"phase{p}/after_call"] = ph["indices"], ph["iterations"], ph["after_call"]
+        for u, (g, inf) in enumerate(zip(ph["grads"], ph["infos"])):
+            out.update(mg.flat(f"phase{p}/grad{u}", g))
+            out.update(mg.flat(f"phase{p}/info{u}", inf))
+    m = agent.memory
+    for k, v in m.data.items():
+        out[f"final_buffer/{k}"] = np.stack([v[a] for a in keys], 2) if isinstance(v, dict) else np.array(v).copy()   # [episodes, slots, N, ...]
+    explored = out["step/coin"] < out["step/eps_acted"]
+    print("calls", len(calls), "steps", len(steps), "explored", int(explored.sum()), "episodes", int(out["step/done"].sum()),
+          "ring", int(m.ptr), int(m.size), "phases", len(phases), "final eps", agent.e_greedy, "current_step", agent.current_step)
+    assert len(phases) >= 3 and 5 < explored.sum() < len(steps) - 5 and out["step/done"].sum() > 16
+    out["cfg"] = np.array([n, N, A, L, cfg.buffer_size, cfg.batch_size, cfg.gamma, cfg.learning_rate, cfg.start_training, cfg.n_epochs,
+                           cfg.sync_frequency, cfg.start_greedy, cfg.end_greedy, cfg.decay_step_greedy, agent.learner.total_iters, 60], np.float64)
+    out["cfg_names"] = np.array("n_envs n_agents n_actions max_episode_steps buffer_size batch_size gamma learning_rate start_training n_epochs "
+                                "sync_frequency start_greedy end_greedy decay_step_greedy total_iters train_steps".split())
+    np.savez_compressed(os.path.join(OUT, "agent_qmix_rnn.npz"), **out)
+    print("agent_qmix_rnn:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     todo = sys.argv[1:] or ["ppo", "dqn", "qmix_ff", "qmix_rnn"]

@@ -8,7 +8,7 @@ loops are compared with the same fixtures in tests/test_gpu_agent_replay.py."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, sub, assert_close
+from conftest import load_golden, sub, assert_close, ChainCheck
 
 
 def test_ppo_agent_loop(oracle):
@@ -165,3 +165,94 @@ def test_dqn_agent_loop(oracle):
         assert np.array_equal(getattr(buf, k), fb[k]), k
     assert np.array_equal(buf.terminals > 0, fb["terminals"] > 0)
     assert any(k.startswith("target_") and not np.array_equal(sd[k], g[f"init/{k}"]) for k in sd)    # target syncs happened
+
+
+def stored_state_rule(cur_state, done_prev):
+    """off_policy_marl.py:395 (`state = info[i]["reset_state"]` replaces the whole list) + store_experience :151-153 + the buffer's
+    per-env write (memory_tools_marl.py:731-740): after a vector step in which envs finished, what is stored as `state` of the NEXT
+    step is the reset state of the last finished env, in every env's row."""
+    if done_prev is None or not done_prev.any():
+        return cur_state
+    last = int(np.flatnonzero(done_prev)[-1])
+    return np.broadcast_to(cur_state[last], cur_state.shape).copy()
+
+
+def test_qmix_ff_agent_loop(oracle):
+    """core/off_policy_marl.py:358-424 with qmix_agents.py:40: per vector step the masked greedy actions of the shared Q network,
+    ONE exploration coin for the whole step (:236: every agent of every env then takes a random AVAILABLE action), env step, store;
+    an update phase of n_epochs updates when `current_step >= start_training and current_step % training_frequency == 0` (:376);
+    epsilon = start - delta * current_step with delta = (start - end) / (decay_step_greedy / n_envs), clamped to end_greedy one
+    step after it first falls below (:197-204).  Reference quirks that are INPUT DATA here: the first stored obs / avail_actions
+    of a train() call are the vector env's lists after the step (aliases of DummyVecMultiAgentEnv.buf_obs / buf_avail_actions,
+    off_policy_marl.py:358-359 with dummy_vec_maenv.py:74-75); the stored state after an episode end (stored_state_rule)."""
+    o = oracle
+    g = load_golden("agent_qmix_ff")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, S, N, A, B, E = (int(c[k]) for k in ("n_envs", "n_steps", "n_agents", "n_actions", "batch_size", "n_epochs"))
+    sd = {k: v.copy() for k, v in sub(g, "init").items()}
+    trainable = [k for k in sd if not k.startswith("target_")]
+    opt = o.AdamOracle({k: sd[k] for k in trainable}, lr=c["learning_rate"], eps=1e-5, total_iters=int(c["total_iters"]))
+    buf = o.MarlBufferOracle(n, int(c["buffer_size"]) // n, N, 30, A, 48)
+    chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))      # (parameters: within what gradients agreeing at 1e-5 allow)
+    init = sub(g, "init")
+    ocfg = dict(gamma=c["gamma"], double_q=True, use_actions_mask=True)
+    delta = (c["start_greedy"] - c["end_greedy"]) / (c["decay_step_greedy"] / n)
+    pe = "individual_q_networks.shared"
+    obs, avail, state = g["acted_obs0"], g["acted_avail0"], g["acted_state0"]
+    eps, cur, phase, updates, done_prev, ties = c["start_greedy"], 0, 0, 0, None, 0
+    for s in range(S):
+        assert eps == g["step/eps_acted"][s] and cur == int(g["step/step_index"][s])
+        assert np.array_equal(avail, g["step/acted_avail"][s])
+        h = o.MLP(o.collect_seq(sd, f"{pe}.representation.obs_representation.model", "relu", last_act="relu")).forward(obs.reshape(n * N, -1))
+        q = o.MLP(o.collect_seq(sd, f"{pe}.critic_head.q_value", "relu")).forward(h)
+        greedy = np.where(avail.reshape(n * N, A) > 0, q, -1e10).argmax(-1)                 # value_factorization.py:87-90
+        ref_greedy = g["step/greedy"][s].reshape(-1)
+        for r in np.flatnonzero(greedy != ref_greedy):
+            assert abs(q[r, greedy[r]] - q[r, ref_greedy[r]]) < 1e-5 * max(1.0, np.abs(q[r]).max()), (s, r)
+            ties += 1
+        acts = g["step/acts"][s]
+        if g["step/coin"][s] < eps:
+            assert (avail.reshape(-1, A)[np.arange(n * N), acts.reshape(-1)] > 0).all()     # random AVAILABLE actions
+        else:
+            assert np.array_equal(acts, g["step/greedy"][s])
+        st_obs, st_avail = (obs, avail) if s > 0 else (g["step/next_obs"][0], g["step/next_avail"][0])   # (the alias, see docstring)
+        assert np.array_equal(g["step/stored_obs"][s], st_obs) and np.array_equal(g["step/stored_avail"][s], st_avail)
+        st_state = stored_state_rule(state, done_prev)
+        assert np.array_equal(g["step/stored_state"][s], st_state), f"step {s}: stored state"
+        buf.store(obs=st_obs, actions=acts, obs_next=g["step/next_obs"][s], rewards=g["step/rewards"][s], terminals=g["step/terminals"][s],
+                  agent_mask=g["step/agent_mask"][s], state=st_state, state_next=g["step/next_state"][s], avail_actions=st_avail > 0,
+                  avail_actions_next=g["step/next_avail"][s] > 0)
+        if cur >= c["start_training"] and cur % int(c["training_frequency"]) == 0:
+            assert int(g[f"phase{phase}/at_step"]) == s
+            for e in range(E):
+                env_c, step_c = g[f"phase{phase}/indices"][e]
+                assert step_c.max() < buf.size
+                b = buf.sample(env_c, step_c)
+                info, grads = o.qmix_forward_backward(sd, b, ocfg, group="shared")
+                for name, rg in sub(g, f"phase{phase}/grad{e}").items():
+                    assert_close(grads[name], rg, 1e-5, f"phase {phase} update {e}: gradient {name}")
+                ri = sub(g, f"phase{phase}/info{e}")
+                assert_close(info["loss"], ri["loss_Q"], 1e-5, "loss_Q")
+                opt.step(grads)
+                chain.step(sub(g, f"phase{phase}/grad{e}"))
+                updates += 1
+                if updates % int(c["sync_frequency"]) == 0:
+                    o.qmix_copy_target(sd)
+            assert updates == int(g[f"phase{phase}/iterations"])
+            ref_p = sub(g, f"phase{phase}/param")
+            if ref_p:
+                chain.check({k: sd[k] for k in trainable}, {k: ref_p[k] for k in trainable}, init, what=f"phase {phase} param")
+            phase += 1
+        done_prev = g["step/done"][s]
+        d3, d2 = done_prev[:, None, None], done_prev[:, None]
+        obs = np.where(d3, g["step/reset_obs"][s], g["step/next_obs"][s])
+        avail = np.where(d3, g["step/reset_avail"][s], g["step/next_avail"][s])
+        state = np.where(d2, g["step/reset_state"][s], g["step/next_state"][s])
+        cur += n
+        eps = c["start_greedy"] - delta * cur if eps > c["end_greedy"] else c["end_greedy"]
+        assert eps == g["step/eps_after"][s] and cur == int(g["step/current_step"][s])
+        assert buf.ptr == int(g["step/ptr"][s]) and buf.size == int(g["step/size"][s])
+    assert phase == int(g["n_phases"]) and ties <= 3
+    for k, v in sub(g, "final_buffer").items():
+        mine = buf.data[k]
+        assert np.array_equal(np.asarray(mine, np.float32), np.asarray(v, np.float32).reshape(mine.shape)), f"final buffer field {k}"

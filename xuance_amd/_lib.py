@@ -359,6 +359,7 @@ _SIGS = {
     "xrl_episode_gather_sampled": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_int, c_void_p, C.c_uint64, C.c_uint32, c_void_p,
                                    c_void_p],
     "xrl_marl_loop_gate": [C.POINTER(MarlGate), c_void_p],
+    "xrl_marl_stored_state": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_ppokl_adapt": [c_void_p, c_int, c_double, c_void_p, c_double, c_void_p, c_void_p],
     "xrl_qmix_fused_update": [C.POINTER(QmixFused), c_void_p],
     "xrl_qmix_fused_lds_bytes": [C.POINTER(QmixFused)],

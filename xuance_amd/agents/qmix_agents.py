@@ -29,6 +29,8 @@ def _get(cfg, name, default=None):
 
 class QMIX_Agents(AgentSurface):
     mixer_name, learner_cls = "QMIX", QMIX_Learner
+    eps_decay_per_env = True        # qmix_agents.py:40, vdn_agents.py:38: delta = (start - end) / (decay_step_greedy / n_envs);
+    #                                 iql_agents.py:37: / decay_step_greedy
 
     def __init__(self, config: Namespace, envs, callback=None):
         self.config, self.envs, self.callback = config, envs, callback
@@ -45,7 +47,8 @@ class QMIX_Agents(AgentSurface):
         self.seed = int(_get(config, "seed", 1))
         self.start_greedy, self.end_greedy = config.start_greedy, config.end_greedy
         self.e_greedy = config.start_greedy
-        self.delta_egreedy = (self.start_greedy - self.end_greedy) / config.decay_step_greedy
+        self.delta_egreedy = (self.start_greedy - self.end_greedy) / \
+            ((config.decay_step_greedy / self.n_envs) if self.eps_decay_per_env else config.decay_step_greedy)
         self.current_step = 0
         k0 = self.agent_keys[0]
         self.obs_dim = envs.observation_space[k0].shape[0]
@@ -60,6 +63,17 @@ class QMIX_Agents(AgentSurface):
         self.episode_loop_lag = max(0, int(getattr(config, "episode_loop_lag", 1)))   # graph launches enqueued ahead of the host
         self.episode_loop_unroll = max(2, int(getattr(config, "episode_loop_unroll", 4)) // 2 * 2)   # vector steps per graph launch
         self.act_f = torch.zeros(self.n_envs, self.n_agents, device=dev)
+        # The reference's loops store, for the vector step after ANY episode end, the reset state of the last finished env in every
+        # env's row (off_policy_marl.py:395, :507 assign `state = info[i]["reset_state"]`, the buffer broadcasts the single vector:
+        # xrl_marl_stored_state).  On by default -- buffers and updates then equal the reference's on the same simulator outputs
+        # (tests/test_gpu_agent_replay.py); `reference_state_broadcast: False` stores every env's own state.
+        self.state_broadcast = bool(_get(config, "reference_state_broadcast", True))
+        self._stored_state = torch.zeros(self.n_envs, self.state_dim, device=dev) if self.state_broadcast else None
+        self._no_done = torch.zeros(self.n_envs, device=dev)
+        # Supplied randomness (replays of recorded runs, set_replay): per vector step the exploration coin [S] and the uniforms
+        # [S, n_envs * n_agents] behind the random available actions; per update the replay choices.  Consumed in order.
+        self.explore_tape = None
+        self.index_tape = None
         if self.use_rnn:
             self.rnn_h = torch.zeros(R, self.model.RH, device=dev)           # init_rnn_states (value_factorization.py:151-159)
             self.rnn_c = torch.zeros(R, self.model.RH, device=dev) if self.model.lstm else None   # LSTM cell states (rnn.py:79-84)
@@ -282,17 +296,54 @@ class QMIX_Agents(AgentSurface):
         self._steps_g = [capture() for _ in range(lag + 2)]
         return self._steps_g
 
+    def set_replay(self, coins=None, uniforms=None, indices=None):
+        """Replay hook: the loop's random decisions come from the caller (a recorded run) instead of the Philox streams -- coins [S]
+        (ONE per vector step, off_policy_marl.py:236) and uniforms [S, n_envs * n_agents] (row r takes its floor(u n_avail)-th
+        available action when the coin lands) make the acting step the layered one (xrl_marl_select_actions takes supplied draws);
+        with indices ([2, batch] = (env_choices, step_choices) of memory_tools_marl.py:755-756 per update, or [batch] episode rows for
+        the recurrent buffer) every update is `learner.update(memory.sample(indexes))`, launch by launch."""
+        dev = self.device
+        if coins is not None:
+            self.explore_tape = (torch.as_tensor(np.asarray(coins, np.float32), device=dev).contiguous(),
+                                 torch.as_tensor(np.asarray(uniforms, np.float32), device=dev).contiguous())
+            self._tape_pos = 0
+        if indices is not None:
+            self.index_tape = [np.asarray(i, np.int64) for i in indices]
+            self._index_pos = 0
+
+    def _tape_kw(self):
+        if self.explore_tape is None:
+            return {}
+        k = self._tape_pos
+        self._tape_pos += 1
+        return dict(coin=self.explore_tape[0][k:k + 1], uniforms=self.explore_tape[1][k])
+
+    def _train_epochs(self):
+        """train_epochs (off_policy_marl.py:573-594): n_epochs x (sample, update)."""
+        info = None
+        if self.index_tape is not None:
+            for _e in range(self.n_epochs):
+                idx = self.index_tape[self._index_pos]
+                self._index_pos += 1
+                if idx.ndim == 2:
+                    idx = idx[0] * self.memory.n_size + idx[1]
+                info = self.learner.update(self.memory.sample(indexes=idx))
+            return info
+        if self.use_graph_updates:
+            return self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed, sync=False)
+        for _e in range(self.n_epochs):
+            info = self.learner.update(self.memory.sample())
+        return info
+
     def _train_rnn(self, train_steps):                         # off_policy_marl.py:335-349
         info, start = {}, self.current_step
         self.model._act_stale = True                            # (whatever happened to the parameters since the last call)
         while self.current_step - start < train_steps * self.n_envs:
             self.run_episodes(self.n_envs)
             if self.current_step >= self.start_training:
-                if self.use_graph_updates:
-                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed, sync=False) or info
-                else:
-                    for _e in range(self.n_epochs):
-                        info = self.learner.update(self.memory.sample())
+                info = self._train_epochs() or info
+                self._cb("on_train_epochs_end", self.current_step, policy=self.model, memory=self.memory, train_steps=train_steps,
+                         update_info=info)
         info = dict(self.learner.flush_info() or info)          # update phases ran unsynchronised: read the last one's info
         info["epsilon"] = self.e_greedy
         return info
@@ -309,7 +360,7 @@ class QMIX_Agents(AgentSurface):
         two_buf = getattr(env, "double_buffered", False)       # the acted-on tensors survive step_device(): no copies
         fused_act = bool(getattr(self.config, "use_fused_acting", True))
         self.model._act_stale = True                            # (whatever happened to the parameters since the last call)
-        for _ in range(train_steps):
+        for k in range(train_steps):
             if two_buf:
                 obs, state, avail = env.buf_obs, env.buf_state, env.buf_avail
             else:
@@ -317,10 +368,14 @@ class QMIX_Agents(AgentSurface):
             # shared network on [n*N, obs] + the epsilon-greedy selection: one launch (xrl_marl_act_gru with H = 0, its weight
             # image kept current by the optimiser launch's mirrors), else three GEMM launches + xrl_marl_select_actions
             self._refresh_act_image(fused_act)
-            self.model.act_step(obs.view(R, -1), R, None, fused=fused_act,
+            if self.state_broadcast:                            # what the reference stores as this step's state (see __init__)
+                # (k == 0: a train() call starts from the vector env's own buf_state, off_policy_marl.py:360)
+                ops.marl_stored_state(state, env.done if k > 0 else None, self._stored_state)
+                state = self._stored_state
+            self.model.act_step(obs.view(R, -1), R, None, fused=fused_act and self.explore_tape is None,
                                 select=dict(avail=avail if self.use_actions_mask else None, eps_dev=None, eps=float(self.e_greedy), action=env.action,
                                             action_f=self.act_f, seed=self.seed, step=self._host_step,
-                                            step_dev=None))    # eager loop: the host knows the step index
+                                            step_dev=None, **self._tape_kw()))    # eager loop: the host knows the step index
             env.step_device()
             self._host_step += 1
             # off_policy_marl.py:363-371 (device tensors; the loop is a host loop already, so the hooks cost nothing unused)
@@ -331,11 +386,7 @@ class QMIX_Agents(AgentSurface):
                               terminals=env.terminals, agent_mask=env.agent_mask, state=state, state_next=env.next_state,
                               avail_actions=avail, avail_actions_next=env.next_avail)
             if self.current_step >= self.start_training and self.current_step % self.training_frequency == 0:
-                if self.use_graph_updates:
-                    info = self.learner.update_from_buffer(self.memory, self.n_epochs, seed=self.seed, sync=False) or info
-                else:
-                    for _e in range(self.n_epochs):
-                        info = self.learner.update(self.memory.sample())
+                info = self._train_epochs() or info
                 self._cb("on_train_epochs_end", self.current_step, policy=self.model, memory=self.memory, train_steps=train_steps,
                          update_info=info)
             self.current_step += n
@@ -420,3 +471,4 @@ class VDN_Agents(QMIX_Agents):
 class IQL_Agents(QMIX_Agents):
     """xuance/torch/agents/multi_agent_rl/iql_agents.py: independent Q-learners (IndependentMixer, IQL_Learner)."""
     mixer_name, learner_cls = "Independent", IQL_Learner
+    eps_decay_per_env = False

@@ -234,6 +234,35 @@ extern "C" int xrl_host_device_pointer(void* pinned_host, void** device_out) {
     return XRL_OK;
 }
 
+namespace xrl {
+// The global state the reference's multi-agent loops STORE for a vector step that follows an episode end: every env's row is
+// the reset state of the LAST env that finished in the previous step (off_policy_marl.py:395 and :507 assign
+// `state = info[i]["reset_state"]` -- the whole list, not `state[i]` -- and store_experience hands that single vector to the
+// buffer, whose per-env write broadcasts it, memory_tools_marl.py:731-740); without an episode end, or with zero_done, a copy.
+// state rows of finished envs already hold their reset state (the providers' auto-reset contract).  One workgroup per env row.
+__global__ void __launch_bounds__(64) marl_stored_state_kernel(const float* state, const float* done, float* out, int n, int S) {
+    __shared__ int last;
+    if (threadIdx.x == 0) last = -1;
+    __syncthreads();
+    if (done) {
+        int l = -1;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) if (done[e] != 0.f) l = e;
+        if (l >= 0) atomicMax(&last, l);
+    }
+    __syncthreads();
+    const int src = last >= 0 ? last : (int)blockIdx.x;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) out[(size_t)blockIdx.x * S + j] = state[(size_t)src * S + j];
+}
+}  // namespace xrl
+
+extern "C" int xrl_marl_stored_state(const float* state, const float* done_prev, float* out, int n_envs, int state_dim,
+                                     xrl_stream_t stream) {
+    XRL_CHECK_ARG(state && out && state != out && n_envs > 0 && state_dim > 0);
+    hipLaunchKernelGGL(xrl::marl_stored_state_kernel, dim3(n_envs), dim3(64), 0, as_stream(stream), state, done_prev, out, n_envs, state_dim);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
 extern "C" int xrl_marl_loop_gate(const xrl_marl_gate_t* gate, xrl_stream_t stream) {
     XRL_CHECK_ARG(gate != nullptr);
     const xrl_marl_gate_t& g = *gate;

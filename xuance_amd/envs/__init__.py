@@ -5,10 +5,11 @@ from .shm_vec_env import ShmSubprocVecEnv
 from .shm_vec_maenv import ShmSubprocVecMultiAgentEnv
 from .dummy_vec_env import DummyVecEnv, DummyVecMultiAgentEnv, HostSMACLikeEnv
 from .synthetic import SyntheticAtariVecEnv, SyntheticMujocoVecEnv, SyntheticSMACVecEnv
-from .recorded import RecordedVecEnv
+from .recorded import RecordedVecEnv, RecordedMultiAgentVecEnv
 
 REGISTRY_VEC_ENV = {"DeviceCartPoleVecEnv": DeviceCartPoleVecEnv, "DevicePendulumVecEnv": DevicePendulumVecEnv,
                     "DeviceMountainCarVecEnv": DeviceMountainCarVecEnv, "DeviceAcrobotVecEnv": DeviceAcrobotVecEnv, "SyntheticAtariVecEnv": SyntheticAtariVecEnv,
                     "SyntheticMujocoVecEnv": SyntheticMujocoVecEnv, "SyntheticSMACVecEnv": SyntheticSMACVecEnv, "ShmSubprocVecEnv": ShmSubprocVecEnv,
                     "ShmSubprocVecMultiAgentEnv": ShmSubprocVecMultiAgentEnv,
-                    "DummyVecEnv": DummyVecEnv, "DummyVecMultiAgentEnv": DummyVecMultiAgentEnv, "RecordedVecEnv": RecordedVecEnv}
+                    "DummyVecEnv": DummyVecEnv, "DummyVecMultiAgentEnv": DummyVecMultiAgentEnv, "RecordedVecEnv": RecordedVecEnv,
+                    "RecordedMultiAgentVecEnv": RecordedMultiAgentVecEnv}

@@ -103,3 +103,67 @@ class RecordedVecEnv:
 
     def close(self):
         pass
+
+
+class RecordedMultiAgentVecEnv:
+    """The multi-agent twin: a recorded run of a vector env with the reference's multi-agent contract (dummy_vec_maenv.py:33-83 --
+    per-agent observations, global state, availability masks, per-agent rewards / terminated flags, one truncated flag per env,
+    `reset_obs` / `reset_state` / `reset_avail_actions` of finished envs, `episode_step`) played back with the surface of
+    envs/synthetic.py: SyntheticSMACVecEnv (buf_obs [n, N, O], buf_state [n, S], buf_avail [n, N, A], next_*, rewards / terminals
+    [n, N], agent_mask, done, end_step, steps).  ``reset()`` loads the next recorded reset (the episode loop of recurrent agents
+    resets its envs at the start of every run_episodes call, off_policy_marl.py:436); eager loops only."""
+    graph_safe = False
+
+    def __init__(self, resets, next_obs, next_state, next_avail, rewards, terminals, truncations, agent_mask, reset_obs, reset_state,
+                 reset_avail, episode_step=None, agent_keys=None, max_episode_steps=None, device="cuda"):
+        """resets: [dict(obs [n, N, O], state [n, S], avail [n, N, A], at=tape position)] in call order; everything else [S, n, ...]
+        per recorded vector step (reset_* rows matter for finished envs only; episode_step = infos[i]["episode_step"])."""
+        next_obs = np.asarray(next_obs, np.float32)
+        S, n, N, O = next_obs.shape
+        A, Sd = np.asarray(next_avail).shape[-1], np.asarray(next_state).shape[-1]
+        self.num_envs, self.n_agents, self.obs_dim, self.state_dim, self.n_actions = n, N, O, Sd, A
+        self.n_steps, self.device, self.max_episode_steps = S, device, max_episode_steps
+        self.agent_keys = self.agents = list(agent_keys or [f"agent_{i}" for i in range(N)])
+        self.observation_space = {k: Box(-np.inf, np.inf, (O,), np.float32) for k in self.agent_keys}
+        self.action_space = {k: Discrete(A) for k in self.agent_keys}
+        self.state_space = Box(-np.inf, np.inf, (Sd,), np.float32)
+        term = np.asarray(terminals) > 0
+        done = term.all(-1) | (np.asarray(truncations) > 0)
+        d3, d2 = done[:, :, None, None], done[:, :, None]
+        f32 = lambda x: _dev(x, torch.float32, device)
+        self._next = (f32(next_obs), f32(next_state), f32(next_avail))
+        self._cur = (f32(np.where(d3, reset_obs, next_obs)), f32(np.where(d2, reset_state, next_state)), f32(np.where(d3, reset_avail, next_avail)))
+        self._rew, self._term, self._mask, self._done = f32(rewards), f32(term), f32(agent_mask), f32(done)
+        es = np.asarray(episode_step, np.int64) if episode_step is not None else np.zeros((S, n), np.int64)
+        self._end = _dev(es, torch.int32, device)
+        self._steps_next = _dev(np.where(done, 0, es), torch.int32, device)
+        self._resets = [dict(obs=f32(r["obs"]), state=f32(r["state"]), avail=f32(r["avail"]), at=int(r["at"])) for r in resets]
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=device)
+        self.buf_obs, self.buf_state, self.buf_avail = z(n, N, O), z(n, Sd), z(n, N, A)
+        self.next_obs, self.next_state, self.next_avail = z(n, N, O), z(n, Sd), z(n, N, A)
+        self.rewards, self.terminals, self.agent_mask = z(n, N), z(n, N), torch.ones(n, N, device=device)
+        self.done, self.end_step, self.steps = z(n), z(n, dt=torch.int32), z(n, dt=torch.int32)
+        self.action = z(n, N, dt=torch.int32)
+        self._pos, self._n_resets = 0, 0
+
+    def reset(self):
+        r = self._resets[self._n_resets]
+        assert r["at"] == self._pos, f"reset #{self._n_resets} was recorded at tape position {r['at']}, the loop is at {self._pos}"
+        self._n_resets += 1
+        self.buf_obs.copy_(r["obs"]); self.buf_state.copy_(r["state"]); self.buf_avail.copy_(r["avail"])
+        self.steps.zero_(); self.done.zero_()
+        return self.buf_obs, [{} for _ in range(self.num_envs)]
+
+    def step_device(self):
+        k = self._pos
+        assert k < self.n_steps, "the tape is exhausted"
+        self._pos += 1
+        for dst, src in zip((self.next_obs, self.next_state, self.next_avail), self._next):
+            dst.copy_(src[k])
+        for dst, src in zip((self.buf_obs, self.buf_state, self.buf_avail), self._cur):
+            dst.copy_(src[k])
+        self.rewards.copy_(self._rew[k]); self.terminals.copy_(self._term[k]); self.agent_mask.copy_(self._mask[k])
+        self.done.copy_(self._done[k]); self.end_step.copy_(self._end[k]); self.steps.copy_(self._steps_next[k])
+
+    def close(self):
+        pass

@@ -936,6 +936,13 @@ def qmix_fused_update(fs, B, obs, obs_next, state, state_next, actions, rewards,
     return fs.n_groups(B)
 
 
+def marl_stored_state(state, done_prev, out):
+    """out <- the state rows the reference's multi-agent loops store for the coming step (xrl_marl_stored_state)."""
+    n, S = state.shape
+    call("xrl_marl_stored_state", ptr(_chk(state, torch.float32)), ptr(done_prev) if done_prev is not None else None,
+         ptr(_chk(out, torch.float32)), int(n), int(S), stream_ptr())
+
+
 def marl_loop_gate(**kw):
     call("xrl_marl_loop_gate", C.byref(_struct(MarlGate, kw)), stream_ptr())
 
