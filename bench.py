@@ -288,9 +288,28 @@ def main():
                     help="N > 1: how the ranks average gradients; measure (default) = time every usable way, adopt the fastest")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher of its N ranks (one process per GPU, rendezvous on
+        # 127.0.0.1 -- the reference's launch contract, xuance/torch/utils/operations.py:11-28: RANK / LOCAL_RANK / WORLD_SIZE from
+        # the environment) and returns their exit code; the driver's own `python -m torch.distributed.run ... bench.py --gpus N`
+        # arrives here with WORLD_SIZE set and runs as a rank.
+        import socket
+        import subprocess
+        if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus and not os.environ.get("XRL_BENCH_SHARE_GPUS"):
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (XRL_BENCH_SHARE_GPUS=1 lets ranks share devices: a "
+                             "functional check, not a measurement)" % (args.gpus, torch.cuda.device_count()))
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks -- refusing to report a line whose n_gpus "
+                         "is not what was asked for" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     local_rank %= torch.cuda.device_count()            # (ranks share a device only in the 2-rank gloo test on a 1-GPU box)
@@ -329,6 +348,8 @@ def main():
         out["config"]["gradient_paths_ms"] = paths_ms
         out["config"]["rccl_world"] = bw.rccl_world(world)
         out["config"]["backend"] = dist.get_backend()
+        if out["config"]["rccl_world"] != world:
+            raise SystemExit("bench.py: the RCCL all-reduce over the %d ranks counted %s participants" % (world, out["config"]["rccl_world"]))
     if rank == 0:
         try:
             out["config"]["box"] = box_yardstick()

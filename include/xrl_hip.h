@@ -651,6 +651,12 @@ typedef struct {
     long long* dbg;                                    /* NULL, or [16]: shader-clock stamps of workgroup 0's chain wave at step n_steps / 2 */
 } xrl_rollout_run_t;
 int xrl_rollout_cartpole_run(const xrl_rollout_run_t* p, xrl_stream_t stream);
+/* Largest n_envs the whole-rollout launches accept on THIS device: their workgroups (16 envs each + one bookkeeper) must all be
+ * resident on one XCD, one per CU (cu_count / 8 - 1 actor workgroups; 256 envs on an MI355X, fewer on a partitioned or smaller
+ * device).  Callers ask before choosing the one-launch rollout (ops.CartPoleRollout.eligible / WideRollout.eligible) and fall back
+ * to the launches per vector step above it; xrl_rollout_*_run itself answers XRL_EINVAL. */
+int xrl_rollout_cartpole_max_envs(void);
+int xrl_rollout_wide_max_envs(void);
 int xrl_rollout_cartpole_values(const xrl_rollout_run_t* p, xrl_stream_t stream);
 /* ------------------------------------------------------------------ rollout of the two-branch Gaussian class (csrc/rollout_wide.hip)
  * Vector steps [t0, t0 + n_steps) of a rollout of horizon T of PPO's step loop (ppo_agent.py:111-177) for the network class
@@ -1187,15 +1193,22 @@ typedef struct {
                                 * zeroes a slot before the launch can poll it: 0 = not yet) */
     int32_t* seq;              /* [1] in/out: launches of this call so far (the host sets 0 per call); NULL iff host_flags NULL */
     double start_greedy, end_greedy, delta_greedy;
-    int32_t ring, pad;
+    int32_t ring;
+    int32_t reset_rule;        /* which rows of reset_rows a finished env i flags: 0 = its own rows [i][0..n_agents); 1 = the reference's
+                                * rule, flattened row i only (init_rnn_states_item passes batch_index = [i_env] to a state tensor whose
+                                * batch axis is n_envs * n_agents: value_factorization.py:161-167, representations/rnn.py:86-92) */
     /* optional bookkeeping of the same step, done by the same launch */
     const float* done;         /* [n_envs] with reset_rows */
-    float* reset_rows;         /* NULL or [n_envs][n_agents]: <- done[env] (the rows that start their next step from zero state) */
+    float* reset_rows;         /* NULL or [n_envs][n_agents]: the rows that start their next step from zero state (reset_rule) */
     uint32_t* counters;        /* NULL or [2]: both advanced by `active` as it was when the step ran (RNG step counters) */
     int32_t n_envs, n_agents;
     int32_t* ptr_size;         /* NULL, or the episode ring's {ptr, size}: advanced here by the number of done envs when the
                                 * step counted (then call xrl_episode_finish_gated with advance = 0) */
     int32_t buffer_size, pad2;
+    const int32_t* end_step;   /* NULL, or [n_envs] info["episode_step"] of the envs that finished: the epsilon update is then applied
+                                * once PER FINISHED ENV in env order, on the running current_step, as the reference's loop does
+                                * (off_policy_marl.py:532-534) -- it differs from one application on the step's total only in the step
+                                * where epsilon crosses end_greedy with more than one env finishing */
 } xrl_marl_gate_t;
 /* Device address of page-locked host memory (hipHostMalloc / torch pin_memory), for kernels that publish a word to the host. */
 int xrl_host_device_pointer(void* pinned_host, void** device_out);

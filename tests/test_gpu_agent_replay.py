@@ -292,3 +292,78 @@ def test_qmix_ff_agents_replay_the_reference_run():
         mine = npy(f[k])                                                           # [n_size][n_envs][row]
         ref = np.swapaxes(np.asarray(v, np.float32), 0, 1).reshape(mine.shape)     # the reference: [n_envs][n_size][n_agents][...]
         assert np.array_equal(mine, ref), f"ring field {k}"
+
+
+def test_qmix_rnn_agents_replay_the_reference_run():
+    """agent_qmix_rnn.npz: the reference's QMIX_Agents as configs/qmix/sc2/3m.yaml ships them (Basic_RNN: fc 64 -> GRU 64 -> Q head;
+    masks off, see oracle/make_golden_agents.py) through train(60) = seven run_episodes(4) calls (77 vector steps, 28 episodes, a
+    16-episode ring that wraps) with six update phases of 2 updates.  Compared: every greedy action (they depend on WHICH recurrent
+    rows a finished env zeroes -- the reference's own rule, QMIX_Agents.reference_rnn_reset), epsilon and current_step after every
+    call (the per-finished-env update of off_policy_marl.py:532-534), ring position, losses, parameters after every phase (only
+    the mixer trains: iql_learner.py:58), and the whole episode ring bit for bit, stored states included."""
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import RecordedMultiAgentVecEnv
+    g = load_golden("agent_qmix_rnn")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, N, A, T, B, E = (int(c[k]) for k in ("n_envs", "n_agents", "n_actions", "max_episode_steps", "batch_size", "n_epochs"))
+    S, P = g["step/acts"].shape[0], int(g["n_phases"])
+    resets = [dict(obs=g[f"reset{i}/obs"], state=g[f"reset{i}/state"], avail=g[f"reset{i}/avail"], at=int(g[f"reset{i}/at"]))
+              for i in range(int(g["n_resets"]))]
+    env = RecordedMultiAgentVecEnv(resets, g["step/next_obs"], g["step/next_state"], g["step/next_avail"], g["step/rewards"],
+                                   g["step/terminals"], g["step/truncations"], g["step/agent_mask"], g["step/reset_obs"],
+                                   g["step/reset_state"], g["step/reset_avail"], g["step/episode_step"], max_episode_steps=T)
+    cfg = Namespace(representation_hidden_size=[64], q_hidden_size=[64], fc_hidden_sizes=[64], recurrent_hidden_size=64, rnn="GRU",
+                    hidden_dim_mixing_net=32, hidden_dim_hyper_net=32, activation="relu", seed=1, parallels=n, running_steps=10 ** 6,
+                    buffer_size=int(c["buffer_size"]), batch_size=B, learning_rate=c["learning_rate"], gamma=c["gamma"], double_q=True,
+                    start_greedy=c["start_greedy"], end_greedy=c["end_greedy"], decay_step_greedy=c["decay_step_greedy"],
+                    sync_frequency=int(c["sync_frequency"]), training_frequency=1, start_training=int(c["start_training"]), n_epochs=E,
+                    use_grad_clip=False, grad_clip_norm=0.5, use_actions_mask=False, use_parameter_sharing=True, use_rnn=True,
+                    episode_length=T, distributed_training=False, device="cuda", model_dir="/tmp/xrl_models")
+    init = sub(g, "init")
+    trainable = [k for k in init if not k.startswith("target_")]
+    chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))
+    st = dict(phase=0)
+
+    def epochs_end(step, **kw):
+        p = st["phase"]
+        call = int(g[f"phase{p}/after_call"])
+        assert step == int(g["call/current_step"][call]) and agent.e_greedy == g["call/eps"][call], f"phase {p}: loop state"
+        assert agent.memory.ptr == int(g["call/ptr"][call]) and agent.memory.size == int(g["call/size"][call])
+        assert agent.learner.iterations == int(g[f"phase{p}/iterations"])
+        assert_close(kw["update_info"]["loss_Q"], g[f"phase{p}/info{E - 1}/loss_Q"], 1e-5, f"phase {p} loss_Q")
+        for e in range(E):
+            chain.step(sub(g, f"phase{p}/grad{e}"))
+        got = {k: npy(v) for k, v in agent.model.state_dict().items()}
+        ref_p = sub(g, f"phase{p}/param")
+        chain.check({k: got[k] for k in trainable if k in chain.allow}, {k: ref_p[k] for k in trainable if k in chain.allow}, init,
+                    what=f"phase {p} param")
+        for k in trainable:
+            if k not in chain.allow:                                               # the agent networks: no gradient in the reference
+                assert np.array_equal(got[k], init[k]) and np.array_equal(ref_p[k], init[k]), k
+        st["phase"] += 1
+
+    agent = QMIX_Agents(cfg, env, _LoopTap(None, epochs_end))
+    assert list(agent.model.ref_order) == list(init) and agent.learner.total_iters == int(c["total_iters"])
+    agent.model.load_state_dict(init)
+    explored = g["step/coin"] < g["step/eps_acted"].astype(np.float32)
+    uni = np.where(explored[:, None], (g["step/acts"].reshape(S, n * N) + 0.5) / A, 0.5).astype(np.float32)   # masks off: action = floor(u A)
+    agent.set_replay(coins=g["step/coin"], uniforms=uni, indices=[g[f"phase{p}/indices"][e] for p in range(P) for e in range(E)])
+    # every step's actions, collected by the recorded env's own hook (the loop hands them to the simulator)
+    taken = []
+    step0 = env.step_device
+    env.step_device = lambda: (taken.append(env.action.clone()), step0())[1]
+    agent.train(int(c["train_steps"]))
+    torch.cuda.synchronize()
+    assert st["phase"] == P and len(taken) == S and env._n_resets == len(resets)
+    acts = np.stack([npy(a) for a in taken]).astype(np.int64)
+    ties = 0
+    for s, e, a in zip(*np.nonzero(acts != g["step/acts"])):
+        assert not explored[s], f"step {s}: a random action differs"
+        ties += 1                                                                   # (a greedy action may differ only on a tie: rare)
+    assert ties <= 3, ties
+    assert agent.current_step == int(g["call/current_step"][-1]) and agent.e_greedy == g["call/eps"][-1]
+    mem = agent.memory
+    assert mem.ptr == int(g["call/ptr"][-1]) and mem.size == int(g["call/size"][-1])
+    for k, v in sub(g, "final_buffer").items():
+        mine = npy(mem.data[k])
+        assert np.array_equal(mine.reshape(-1), np.asarray(v, np.float32).reshape(-1)), f"episode ring field {k}"

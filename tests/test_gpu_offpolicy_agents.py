@@ -514,7 +514,10 @@ def test_qmix_rnn_agents_episode_loop_vs_oracle(oracle):
     torch.manual_seed(0)
     n, N, T = 8, 3, 12
     env = SyntheticSMACVecEnv(n, seed=3, max_episode_steps=T)
-    agent = QMIX_Agents(_rnn_cfg(), env)
+    # reference_rnn_reset False: a finished env restarts ITS OWN recurrent rows from zero, which is what check (1) restates; the
+    # reference's rule (flattened row i, the default: tests/test_gpu_agent_replay.py replays it against the reference's own run)
+    # leaves a finished env's rows running
+    agent = QMIX_Agents(_rnn_cfg(reference_rnn_reset=False), env)
     mem, lr, net = agent.memory, agent.learner, agent.model
     sd = {k: v.cpu().numpy().copy() for k, v in net.state_dict().items()}
     agent.run_episodes(n)
@@ -540,6 +543,7 @@ def test_qmix_rnn_agents_episode_loop_vs_oracle(oracle):
         assert np.take_along_axis(av, acts[..., None], -1).all()
     # (3) update phases (eager+capture, then graph replays) vs the oracle on the same episodes
     opt = oracle.AdamOracle({k: sd[k] for k in net.ref_order}, lr=7e-4, eps=1e-5, total_iters=lr.total_iters)
+    chain, sd0 = ChainCheck(7e-4, total_iters=lr.total_iters), {k: v.copy() for k, v in sd.items()}
     cfg = dict(gamma=0.99, double_q=True, use_actions_mask=True, agent_grad=True)
     seen = []
     lr.callback.on_update_end = lambda it, **kw: seen.append(it) or {}
@@ -559,12 +563,17 @@ def test_qmix_rnn_agents_episode_loop_vs_oracle(oracle):
             oi, grads = oracle.qmix_rnn_forward_backward(sd, b, cfg)
             oracle.AdamOracle.clip_grad_norm_(grads, 10.0)
             opt.step(grads)
+            chain.step(grads)
             if (2 * phase + e + 1) % 3 == 0:
                 oracle.qmix_copy_target(sd)
         assert_close(info["loss_Q"], oi["loss"], 1e-5, "loss_Q")
-        got = net.state_dict()
-        for k, v in sd.items():
-            assert_close(got[k].cpu().numpy(), v, 1e-5, f"{k} after phase {phase}")
+        # parameters: within what gradients agreeing at 1e-5 of their scale allow (conftest.ChainCheck: an Adam step on an entry
+        # whose gradient sits at eps is ill-conditioned -- a 2-update-old GRU bias moved 2.6e-5 of its 1.4e-3 apart on one box)
+        got = {k: v.cpu().numpy() for k, v in net.state_dict().items()}
+        chain.check({k: got[k] for k in chain.allow}, {k: sd[k] for k in chain.allow}, sd0, what=f"phase {phase} param")
+        ev = lambda k: k[len("target_"):] if k.startswith("target_individual") else "eval_Qtot." + k[len("target_Qtot."):]
+        tk = [k for k in sd if k.startswith("target_") and ev(k) in chain.allow]
+        chain.check({ev(k): got[k] for k in tk}, {ev(k): sd[k] for k in tk}, sd0, what=f"phase {phase} target copy of")
     assert lr._buf_graph is not None and lr.iterations == 6 and seen == [1, 2, 3, 4, 5, 6]
 
 
@@ -625,7 +634,7 @@ def test_qmix_lstm_agents_episode_loop(oracle):
     n, N, T = 8, 3, 12
     for seed in range(3, 20):          # a provider seed for which some episode ends early, so that envs are mid-episode at the end
         env = SyntheticSMACVecEnv(n, seed=seed, max_episode_steps=T)
-        agent = QMIX_Agents(_rnn_cfg(rnn="LSTM"), env)
+        agent = QMIX_Agents(_rnn_cfg(rnn="LSTM", reference_rnn_reset=False), env)      # (the env's own rows restart: see the GRU twin above)
         assert agent.model.lstm and agent.model.G == 256
         sd = {k: v.cpu().numpy().copy() for k, v in agent.model.state_dict().items()}
         agent.run_episodes(n)

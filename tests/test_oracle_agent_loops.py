@@ -256,3 +256,96 @@ def test_qmix_ff_agent_loop(oracle):
     for k, v in sub(g, "final_buffer").items():
         mine = buf.data[k]
         assert np.array_equal(np.asarray(mine, np.float32), np.asarray(v, np.float32).reshape(mine.shape)), f"final buffer field {k}"
+
+
+def test_qmix_rnn_agent_loop(oracle):
+    """core/off_policy_marl.py:334-356 + run_episodes :426-546 with recurrent agents (configs/qmix/sc2/3m.yaml, masks off): train()
+    alternates run_episodes(n_envs) -- envs reset, staging rows cleared, GRU state zero; per vector step the greedy actions of the
+    recurrent Q network on the carried state, ONE exploration coin, env step, store at each env's own episode step; a finished env
+    closes its episode into the ring (terminal obs / state at slot episode_step), gets its GRU rows zeroed, and `current_step +=
+    episode_step` followed by the epsilon update PER FINISHED ENV (:532-534) -- with n_epochs updates on `np.random.choice(size,
+    batch)` episodes once current_step >= start_training.  The stored state follows stored_state_rule inside a call.  Which GRU
+    rows a finished env zeroes is the reference's own rule (below): with any other rule the greedy actions of later steps differ."""
+    o = oracle
+    g = load_golden("agent_qmix_rnn")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, N, A, T, B, E = (int(c[k]) for k in ("n_envs", "n_agents", "n_actions", "max_episode_steps", "batch_size", "n_epochs"))
+    sd = {k: v.copy() for k, v in sub(g, "init").items()}
+    init = sub(g, "init")
+    trainable = [k for k in sd if not k.startswith("target_")]
+    opt = o.AdamOracle({k: sd[k] for k in trainable}, lr=c["learning_rate"], eps=1e-5, total_iters=int(c["total_iters"]))
+    chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))
+    buf = o.EpisodeBufferOracle(n, int(c["buffer_size"]), T, N, 30, A, 48)
+    ocfg = dict(gamma=c["gamma"], double_q=True, use_actions_mask=False, agent_grad=False)   # (the unmodified reference: only the mixer trains, iql_learner.py:58)
+    delta = (c["start_greedy"] - c["end_greedy"]) / (c["decay_step_greedy"] / n)
+    eps, cur, s, phase, updates, ties = c["start_greedy"], 0, 0, 0, 0, 0
+    n_calls = int(g["n_resets"])
+    for call in range(n_calls):
+        assert int(g[f"reset{call}/at"]) == s
+        obs, state = g[f"reset{call}/obs"], g[f"reset{call}/state"]
+        buf.clear_episodes()
+        pe = "individual_q_networks.shared"
+        rp = f"{pe}.representation.obs_representation"
+        fc, qh = o.MLP(o.collect_seq(sd, f"{rp}.mlp", "relu", last_act="relu")), o.MLP(o.collect_seq(sd, f"{pe}.critic_head.q_value", "relu"))
+        gw = [sd[f"{rp}.rnn.{k}_l0"] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        h = np.zeros((n * N, gw[1].shape[1]), np.float32)                            # init_rnn_states (value_factorization.py:151-159)
+        done_prev, episodes = None, 0
+        while episodes < n:
+            assert int(g["step/call"][s]) == call and eps == g["step/eps_acted"][s] and cur == int(g["step/current_step_before"][s])
+            assert np.array_equal(obs, g["step/acted_obs"][s])
+            hs, _ = o.gru_forward(fc.forward(obs.reshape(n * N, -1))[:, None], h, *gw)   # one step on the carried state (rnn.py:52-77)
+            h = hs[:, -1]
+            q = qh.forward(h)
+            greedy = q.argmax(-1).reshape(n, N)
+            for e, a in zip(*np.nonzero(greedy != g["step/greedy"][s])):
+                qq = q[e * N + a]
+                assert abs(qq[greedy[e, a]] - qq[g["step/greedy"][s][e, a]]) < 1e-5 * max(1.0, np.abs(qq).max()), (s, e, a)
+                ties += 1
+            acts = g["step/acts"][s]
+            if not g["step/coin"][s] < eps:
+                assert np.array_equal(acts, g["step/greedy"][s])
+            st_state = stored_state_rule(state, done_prev)
+            assert np.array_equal(g["step/stored_state"][s], st_state), f"step {s}: stored state"
+            es = g["step/episode_step"][s]
+            buf.store(es - 1, obs=obs, actions=acts, rewards=g["step/rewards"][s], terminals=g["step/terminals"][s],
+                      agent_mask=g["step/agent_mask"][s], state=st_state)
+            done_prev = g["step/done"][s]
+            for i in np.flatnonzero(done_prev):
+                episodes += 1
+                buf.finish_path(i, int(es[i]), g["step/next_obs"][s][i], g["step/next_state"][s][i], 0.0)
+                # init_rnn_states_item(i_env=i) (:504-505) zeroes FLATTENED row i of the [n_envs * n_agents, H] state (batch_index =
+                # [i_env], value_factorization.py:161-167, rnn.py:86-92) -- agent i % N of env i // N, not env i's agents
+                h[i] = 0.0
+                cur += int(es[i])
+                eps = c["start_greedy"] - delta * cur if eps > c["end_greedy"] else c["end_greedy"]    # :197-204, per finished env
+            d3, d2 = done_prev[:, None, None], done_prev[:, None]
+            obs = np.where(d3, g["step/reset_obs"][s], g["step/next_obs"][s])
+            state = np.where(d2, g["step/reset_state"][s], g["step/next_state"][s])
+            s += 1
+        assert s == int(g["call/n_steps"][call]) and cur == int(g["call/current_step"][call]) and eps == g["call/eps"][call]
+        assert buf.ptr == int(g["call/ptr"][call]) and buf.size == int(g["call/size"][call])
+        if cur >= c["start_training"]:
+            assert int(g[f"phase{phase}/after_call"]) == call
+            for e in range(E):
+                ii = g[f"phase{phase}/indices"][e]
+                assert ii.max() < buf.size
+                d = buf.sample(ii)
+                b = dict(obs=d["obs"].transpose(0, 2, 1, 3), actions=d["actions"].transpose(0, 2, 1), rewards=d["rewards"].transpose(0, 2, 1),
+                         terminals=d["terminals"].transpose(0, 2, 1), agent_mask=d["agent_mask"].transpose(0, 2, 1),
+                         avail_actions=np.ones((B, N, T + 1, A), np.float32), state=d["state"], filled=d["filled"])
+                info, grads = o.qmix_rnn_forward_backward(sd, b, ocfg)
+                for name, rg in sub(g, f"phase{phase}/grad{e}").items():
+                    assert_close(grads[name], rg, 1e-5, f"phase {phase} update {e}: gradient {name}")
+                assert_close(info["loss"], g[f"phase{phase}/info{e}/loss_Q"], 1e-5, "loss_Q")
+                opt.step(grads)
+                chain.step(sub(g, f"phase{phase}/grad{e}"))
+                updates += 1
+                if updates % int(c["sync_frequency"]) == 0:
+                    o.qmix_copy_target(sd)
+            assert updates == int(g[f"phase{phase}/iterations"])
+            ref_p = sub(g, f"phase{phase}/param")
+            chain.check({k: sd[k] for k in trainable}, {k: ref_p[k] for k in trainable}, init, what=f"phase {phase} param")
+            phase += 1
+    assert phase == int(g["n_phases"]) and s == g["step/acts"].shape[0] and ties <= 3
+    for k, v in sub(g, "final_buffer").items():
+        assert np.array_equal(np.asarray(buf.data[k], np.float32), np.asarray(v, np.float32).reshape(buf.data[k].shape)), f"ring field {k}"

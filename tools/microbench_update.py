@@ -11,6 +11,7 @@ n = 256
 agent = PPO_Agent(make_config(n, 256, 1, 0), DeviceCartPoleVecEnv(n, seed=1))
 agent.rollout(); agent.update(); torch.cuda.synchronize()
 lr, mem = agent.learner, agent.memory
+lr._derived_layouts()            # params_t / cache_image: the role-split learner does not keep them, the direct calls below need them
 m, f = lr.model, mem.soa.fields
 dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
 idx = agent.idx[3]

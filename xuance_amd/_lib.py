@@ -317,8 +317,9 @@ class MarlGate(C.Structure):
                 ("e_state", c_void_p), ("eps_dev", c_void_p), ("active_f", c_void_p), ("active_i", c_void_p),
                 ("host_flags", c_void_p), ("seq", c_void_p),
                 ("start_greedy", C.c_double), ("end_greedy", C.c_double), ("delta_greedy", C.c_double),
-                ("ring", c_int32), ("pad", c_int32), ("done", c_void_p), ("reset_rows", c_void_p), ("counters", c_void_p),
-                ("n_envs", c_int32), ("n_agents", c_int32), ("ptr_size", c_void_p), ("buffer_size", c_int32), ("pad2", c_int32)]
+                ("ring", c_int32), ("reset_rule", c_int32), ("done", c_void_p), ("reset_rows", c_void_p), ("counters", c_void_p),
+                ("n_envs", c_int32), ("n_agents", c_int32), ("ptr_size", c_void_p), ("buffer_size", c_int32), ("pad2", c_int32),
+                ("end_step", c_void_p)]
 
 
 class Mirrors(C.Structure):
@@ -359,6 +360,8 @@ _SIGS = {
     "xrl_episode_gather_sampled": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_int, c_void_p, C.c_uint64, C.c_uint32, c_void_p,
                                    c_void_p],
     "xrl_marl_loop_gate": [C.POINTER(MarlGate), c_void_p],
+    "xrl_rollout_cartpole_max_envs": [],
+    "xrl_rollout_wide_max_envs": [],
     "xrl_marl_stored_state": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_ppokl_adapt": [c_void_p, c_int, c_double, c_void_p, c_double, c_void_p, c_void_p],
     "xrl_qmix_fused_update": [C.POINTER(QmixFused), c_void_p],

@@ -256,7 +256,10 @@ class DQN_Agent(AgentSurface):
             env.step_counter.fill_(int(env._host_step))
             self._vc_mirror = env._host_step
         d_act = (self._host_step - env._host_step) & 0xffffffff
-        key = (d_act, mem.ring_bias(env._host_step), env._cur, id(mem))
+        # (+ the workspaces' signature: a get_actions / test call on more rows reallocates the plan's activations and the convolution
+        #  workspace the captured launches point into)
+        key = (d_act, mem.ring_bias(env._host_step), env._cur, id(mem), self.model.plan.cap,
+               getattr(getattr(self.model, "conv", None), "ws_gen", 0))
         if getattr(self, "_pair_key", None) != key:
             torch.cuda.synchronize()
             g = ops.Graph()

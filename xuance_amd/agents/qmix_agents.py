@@ -69,7 +69,10 @@ class QMIX_Agents(AgentSurface):
         # (tests/test_gpu_agent_replay.py); `reference_state_broadcast: False` stores every env's own state.
         self.state_broadcast = bool(_get(config, "reference_state_broadcast", True))
         self._stored_state = torch.zeros(self.n_envs, self.state_dim, device=dev) if self.state_broadcast else None
-        self._no_done = torch.zeros(self.n_envs, device=dev)
+        # ... and zero the recurrent state of flattened row i -- not of env i's rows -- when env i finishes (init_rnn_states_item is
+        # handed batch_index = [i_env] for a state whose batch axis is n_envs * n_agents: value_factorization.py:161-167 with
+        # representations/rnn.py:86-92).  `reference_rnn_reset: False` resets the finished env's own rows.
+        self.reference_rnn_reset = bool(_get(config, "reference_rnn_reset", True))
         # Supplied randomness (replays of recorded runs, set_replay): per vector step the exploration coin [S] and the uniforms
         # [S, n_envs * n_agents] behind the random available actions; per update the replay choices.  Consumed in order.
         self.explore_tape = None
@@ -78,8 +81,8 @@ class QMIX_Agents(AgentSurface):
             self.rnn_h = torch.zeros(R, self.model.RH, device=dev)           # init_rnn_states (value_factorization.py:151-159)
             self.rnn_c = torch.zeros(R, self.model.RH, device=dev) if self.model.lstm else None   # LSTM cell states (rnn.py:79-84)
             self.reset_rows = torch.zeros(R, device=dev)
-            self._counts = torch.zeros(2, device=dev)
-            self._counts_h = torch.zeros(2).pin_memory() if torch.cuda.is_available() else torch.zeros(2)
+            self._ends = torch.zeros(self.n_envs, device=dev)
+            self._ends_h = torch.zeros(self.n_envs).pin_memory() if torch.cuda.is_available() else torch.zeros(self.n_envs)
             self._totals_h = torch.zeros(2, dtype=torch.int64)
             if torch.cuda.is_available():
                 self._totals_h = self._totals_h.pin_memory()
@@ -138,37 +141,44 @@ class QMIX_Agents(AgentSurface):
             return self._run_episodes_captured(n_episodes, totals)
         self._call_prologue(env, mem)
         episodes = 0
-        if totals is not None:
-            self._totals_h.copy_(totals)
-            seen = self._totals_h.clone()
+        first = True
         while episodes < n_episodes:
             if two_buf:
                 obs, state, avail = env.buf_obs, env.buf_state, env.buf_avail
             else:
                 obs, state, avail = env.buf_obs.clone(), env.buf_state.clone(), env.buf_avail.clone()
                 steps = env.steps.clone()
-            self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused_act,
+            if self.state_broadcast:                            # what the reference stores as this step's state (see __init__;
+                ops.marl_stored_state(state, None if first else env.done, self._stored_state)   # a call starts from the reset state)
+                state, first = self._stored_state, False
+            self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused_act and self.explore_tape is None,
                                 select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev, action=env.action,
                                             action_f=self.act_f, seed=self.seed, step=self._host_step,
-                                            step_dev=None))    # eager loop: the host knows the step index
+                                            step_dev=None, **self._tape_kw()))    # eager loop: the host knows the step index
             env.step_device()
             self._host_step += 1
             mem.store(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals, agent_mask=env.agent_mask,
                       avail_actions=avail, state=state, episode_steps=env.prev_steps if two_buf else steps)
             mem.finish_paths(env.done, env.end_step, obs=env.next_obs, state=env.next_state, avail_actions=env.next_avail)
-            self.reset_rows.view(n, N).copy_(env.done[:, None].expand(n, N))
-            if totals is not None:
-                self._totals_h.copy_(totals)                   # the step's only host read
-                episodes += int(self._totals_h[0] - seen[0])
-                self.current_step += int(self._totals_h[1] - seen[1])      # current_step += info[i]["episode_step"] (:532)
-                seen.copy_(self._totals_h)
-            else:
-                self._counts[0] = env.done.sum()
-                self._counts[1] = (env.done * env.end_step).sum()
-                self._counts_h.copy_(self._counts)             # the step's only host read
-                episodes += int(self._counts_h[0])
-                self.current_step += int(self._counts_h[1])
-            self._update_explore_factor()
+            self._set_reset_rows(self.reset_rows, env.done, n, N)
+            # the step's only host read: episode lengths of the envs that finished, in env order -- `current_step +=
+            # info[i]["episode_step"]` and the epsilon update once per finished env (:532-534)
+            torch.mul(env.done, env.end_step, out=self._ends)
+            self._ends_h.copy_(self._ends)
+            for v in self._ends_h.tolist():
+                if v > 0:
+                    episodes += 1
+                    self.current_step += int(v)
+                    self._update_explore_factor(push=False)
+            self._push_eps()
+
+    def _set_reset_rows(self, rows, done, m, N):
+        """rows [m * N] <- 1 where the recurrent state restarts from zero after this step (see reference_rnn_reset)."""
+        if self.reference_rnn_reset:
+            rows.zero_()
+            rows[:m].copy_(done)
+        else:
+            rows.view(m, N).copy_(done[:, None].expand(m, N))
 
     def _refresh_act_image(self, fused_act=True):
         """The acting launch's weight image follows the parameters through the optimiser launch's mirrors; rebuild it (two
@@ -188,6 +198,8 @@ class QMIX_Agents(AgentSurface):
         if self.rnn_c is not None:
             self.rnn_c.zero_()
         self.reset_rows.zero_()
+        if self.state_broadcast and hasattr(env, "done"):
+            env.done.zero_()                                    # (no episode end precedes a call's first step: xrl_marl_stored_state)
 
     def _run_episodes_captured(self, n_episodes, totals):
         """run_episodes with the vector step -- acting forward incl. the recurrence and the action selection, provider step,
@@ -278,6 +290,9 @@ class QMIX_Agents(AgentSurface):
                 for k in range(K):
                     cur = k & 1
                     obs, state, avail = env._sets[cur]
+                    if self.state_broadcast:                     # what the reference stores as this step's state (see __init__)
+                        ops.marl_stored_state(state, env.done, self._stored_state)
+                        state = self._stored_state
                     self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused,
                                         select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
                                                     action=env.action, action_f=self.act_f, seed=self.seed, step=0,
@@ -291,7 +306,8 @@ class QMIX_Agents(AgentSurface):
                     ops.marl_loop_gate(totals=env.episode_totals, start_greedy=float(self.start_greedy),
                                        end_greedy=float(self.end_greedy), delta_greedy=float(self.delta_egreedy),
                                        eps_dev=self.eps_dev, done=env.done, reset_rows=self.reset_rows, counters=self._rng_dev,
-                                       n_envs=n, n_agents=N, ptr_size=mem.ptr_size, buffer_size=mem.buffer_size, **gate_const, **gt)
+                                       n_envs=n, n_agents=N, ptr_size=mem.ptr_size, buffer_size=mem.buffer_size,
+                                       reset_rule=int(self.reference_rnn_reset), end_step=env.end_step, **gate_const, **gt)
             return g
         self._steps_g = [capture() for _ in range(lag + 2)]
         return self._steps_g
@@ -455,7 +471,7 @@ class QMIX_Agents(AgentSurface):
                     ended[i] = 1.0                                         # init_rnn_states_item (:504-505)
                     scores.append(float(np.mean([info[i]["episode_score"][k] for k in keys])))
             if rnn is not None:
-                rnn["reset"].view(m, self.n_agents).copy_(torch.from_numpy(ended).to(self.device)[:, None].expand(m, self.n_agents))
+                self._set_reset_rows(rnn["reset"], torch.from_numpy(ended).to(self.device), m, self.n_agents)
         self.log_infos({"Test-Results/Episode-Rewards": float(np.mean(scores)),
                         "Test-Results/Episode-Rewards-Std": float(np.std(scores))}, self.current_step)
         if close_envs:

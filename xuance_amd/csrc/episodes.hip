@@ -124,21 +124,29 @@ __global__ void __launch_bounds__(256) episode_gather_sampled_kernel(EpPack f, i
 // -- and decides whether the NEXT step still belongs to the call (`episodes < n_episodes`, :464).  A step launched after the
 // call is over is dry: the captured step multiplies `done` by active_f (no episode is closed into the ring) and adds
 // active_i to its RNG step counters (they do not advance); its other writes land in per-call state the next call resets.
+constexpr int GATE_MAX_ENVS = 1024;
 __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
     // the step's remaining per-row bookkeeping rides along: reset flags of the rows whose env finished (a dry step's are
     // wiped by the next call), RNG step counters advanced by `active`
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g.reset_rows && t < g.n_envs * g.n_agents) g.reset_rows[t] = g.done[t / g.n_agents];
+    if (g.reset_rows && t < g.n_envs * g.n_agents)
+        g.reset_rows[t] = g.reset_rule ? (t < g.n_envs ? g.done[t] : 0.f) : g.done[t / g.n_agents];
     if (t >= 64) return;
     // The first wave counts the finished envs together (one load per lane instead of one thread walking n_envs dependent loads),
     // and everything lane 0 reads below is requested here, unconditionally, in one go: this launch sits on the critical path of
     // every vector step and used to be a chain of ~8 memory round trips on a single thread.
+    // (end_step: the finished envs' episode lengths go through LDS in env order for lane 0's per-env epsilon updates)
+    __shared__ int s_len[GATE_MAX_ENVS];
     int c = 0;
-    if (g.ptr_size) {
-        for (int j = t; j < g.n_envs; j += 64) c += g.done[j] != 0.f;
+    if (g.ptr_size || g.end_step) {
+        for (int j = t; j < g.n_envs; j += 64) {
+            const bool d = g.done[j] != 0.f;
+            c += d;
+            if (g.end_step && j < GATE_MAX_ENVS) s_len[j] = d ? g.end_step[j] : 0;
+        }
         c = wave_sum(c);
     }
-    if (t != 0) return;
+    if (t != 0) return;                                                   // (s_len: written and read by this one wave)
     int act = *g.active;                                                  // did the step that just ran count?
     const long long tot0 = g.totals[0], tot1 = g.totals[1], bas0 = g.base[0], bas1 = g.base[1], call0 = g.call[0], call1 = g.call[1];
     double e = *g.e_state;
@@ -151,10 +159,19 @@ __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
         g.ptr_size[1] = sz < g.buffer_size ? sz : g.buffer_size;
     }
     if (act) {
-        const long long ep = tot0 - bas0, st = tot1 - bas1;
+        const long long ep = tot0 - bas0, st = tot1 - bas1, st_prev = g.snap[1];
         g.snap[0] = ep; g.snap[1] = st;
-        const double cur = (double)(call0 + st);
-        e = (e > g.end_greedy) ? g.start_greedy - g.delta_greedy * cur : g.end_greedy;
+        if (g.end_step && c >= 2 && g.n_envs <= GATE_MAX_ENVS) {          // per finished env, in env order (:532-534)
+            long long cur_i = call0 + st_prev;
+            for (int j = 0; j < g.n_envs; ++j)
+                if (s_len[j] > 0) {
+                    cur_i += s_len[j];
+                    e = (e > g.end_greedy) ? g.start_greedy - g.delta_greedy * (double)cur_i : g.end_greedy;
+                }
+        } else if (!g.end_step || c >= 1) {
+            const double cur = (double)(call0 + st);
+            e = (e > g.end_greedy) ? g.start_greedy - g.delta_greedy * cur : g.end_greedy;
+        }
         *g.e_state = e;
         *g.eps_dev = (float)e;
         if (ep >= call1) act = 0;

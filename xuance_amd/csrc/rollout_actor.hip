@@ -787,6 +787,12 @@ static int check_run(const xrl_rollout_run_t& q, const char* who) {
     return XRL_OK;
 }
 
+extern "C" int xrl_rollout_cartpole_max_envs(void) {
+    // the whole-rollout launch keeps its workgroups (AR envs each + the bookkeeper) resident on ONE XCD, one per CU
+    const int wg = device_cu_count() / 8 - 1;
+    return AR * (wg < AMAXWG ? (wg > 0 ? wg : 0) : AMAXWG);
+}
+
 extern "C" int xrl_rollout_cartpole_run(const xrl_rollout_run_t* qq, xrl_stream_t stream) {
     XRL_CHECK_ARG(qq != nullptr);
     const xrl_rollout_run_t& q = *qq;

@@ -545,6 +545,11 @@ extern "C" int xrl_copy_column(const float* src, int ld, float* dst, int64_t n, 
     return XRL_OK;
 }
 
+extern "C" int xrl_rollout_wide_max_envs(void) {
+    const int wg = device_cu_count() / 8 - 1;                           // (as xrl_rollout_cartpole_max_envs: WR envs per workgroup)
+    return WR * (wg > 0 ? wg : 0);
+}
+
 extern "C" int xrl_rollout_wide_run(const xrl_rollout_wide_t* qq, xrl_stream_t stream) {
     XRL_CHECK_ARG(qq != nullptr);
     const xrl_rollout_wide_t& q = *qq;

@@ -120,7 +120,7 @@ class DQN_Learner(Learner):
         callback to serve) the call returns None right after the launch, so the host goes on enqueueing the next vector
         step while the update runs; `flush_info()` later returns the info of the last phase launched."""
         M, dev = memory.batch_size, self.model.params.device
-        key = (id(memory), n_epochs, M)
+        key = self._phase_key(memory, n_epochs)
         self.ensure_live_images()
         if getattr(self, "_buf_graph_key", None) != key:
             self._ensure(M)
@@ -157,6 +157,7 @@ class DQN_Learner(Learner):
                 with g:
                     enqueue()
                 self._buf_graph = g
+            self._buf_graph_key = self._phase_key(memory, n_epochs)     # (the workspaces as they are after the eager phase)
         elif self._buf_graph is not None:
             self._buf_graph.launch()
         else:
@@ -166,6 +167,13 @@ class DQN_Learner(Learner):
             self.iterations += n_epochs
             return None
         return self._phase_info(count=True)
+
+    def _phase_key(self, memory, n_epochs):
+        """What a captured update phase is valid for: the buffer, the shape -- and the workspaces it points into (Plan.ensure /
+        a larger convolution workspace after an acting call on more rows reallocate them: capture again)."""
+        m = self.model
+        return (id(memory), n_epochs, memory.batch_size, m.plan.cap, getattr(m, "target_plan", m.plan).cap,
+                getattr(getattr(m, "conv", None), "ws_gen", 0))
 
     def ensure_live_images(self):
         """Before a captured update phase is replayed: the convolution stack's weight images must be the parameters' (the
@@ -181,7 +189,7 @@ class DQN_Learner(Learner):
     def phase_ready(self, memory, n_epochs):
         """Has update_from_buffer(memory, n_epochs) captured its phase (the launches an enclosing capture may enqueue through
         enqueue_phase)?"""
-        return getattr(self, "_buf_graph", None) is not None and getattr(self, "_buf_graph_key", None) == (id(memory), n_epochs, memory.batch_size)
+        return getattr(self, "_buf_graph", None) is not None and getattr(self, "_buf_graph_key", None) == self._phase_key(memory, n_epochs)
 
     def enqueue_phase(self):
         """The launches of one update phase, for a caller that captures them into a larger graph (DQN_Agent's vector-step pair)."""

@@ -321,14 +321,12 @@ class PPO_Learner(Learner):
         self._fused_bs = bs
         self._mirrors = []
         self.params_t = self.cache_image = None
-        if not self.split:
+        if not self.split or not ops.fast_kernels_enabled():
             # derived layouts of the single-workgroup kernel (ppo_fused: transposed middle weights, packed small parameters).  (Until
             # round 4 the role-split CartPole class kept them current as well, for rollout kernels that have since been replaced: two
-            # of the optimiser launch's four mirror maps, ~70 k scattered stores per step, for nobody.)
-            self.params_t = torch.zeros(P, device=dev)
-            self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
-            self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
-            self._mirrors = [(self.map_t, self.params_t), (self.map_img, self.cache_image)]
+            # of the optimiser launch's four mirror maps, ~70 k scattered stores per step, for nobody.  A role-split learner gets
+            # them when the specialised kernels are switched off -- here, or on the first such minibatch: _derived_layouts.)
+            self._derived_layouts(fill=False)
         nf = ops.mid_frag_floats(self.model.plan)
         self.frag = torch.zeros(nf, device=dev) if nf else None       # MFMA-fragment-ordered copy of the middle layer
         if nf:
@@ -381,6 +379,21 @@ class PPO_Learner(Learner):
         if self.frag is not None:
             ops.pack_mid_frags(self.model.plan, self.model.params.flat, self.frag)
 
+    def _derived_layouts(self, fill=True):
+        """params_t / cache_image of the any-shape minibatch kernel (xrl_ppo_fused_minibatch without a fold region needs both) and
+        their mirror maps in the optimiser launch; `fill`: from the current parameters (a role-split learner that loses its
+        specialised kernels mid-way: ops.set_fast_kernels(False))."""
+        if self.params_t is not None:
+            return
+        P, dev = self.model.params.P, self.model.params.device
+        self.params_t = torch.zeros(P, device=dev)
+        self.cache_image = torch.zeros(ops.rollout_cache_floats(self.model.plan) + 16, device=dev)
+        self.map_t, self.map_img = ops.derived_layout_maps(self.model.plan, P, dev)
+        self._mirrors = [(self.map_t, self.params_t), (self.map_img, self.cache_image)] + list(self._mirrors)
+        if fill:
+            ops.transpose_mid(self.model.plan, self.model.params.flat, self.params_t)
+            ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)
+
     def enqueue_minibatch_fused(self, memory, idx, stats=None, finish=True):
         """One launch for gather + forward + loss + backward, then reduce + Adam, then refresh the derived layouts."""
         m, opt, f = self.model, self.optimizer, memory.soa.fields
@@ -398,6 +411,8 @@ class PPO_Learner(Learner):
             return self._step_wide(st["observations"], st["actions"], st["returns"], st["advantages"], st["aux_old_logp"], M,
                                    stats=stats, finish=finish)
         fold = self.fold if (self.split and ops.fast_kernels_enabled()) else None     # (tests switch the specialised kernels off)
+        if fold is None and self.params_t is None:
+            self._derived_layouts()                        # (not inside a capture: switch the kernels off before the first update)
         rows = None
         base = getattr(self, "_rows_idx", None)
         if base is not None:                               # `idx` is a row of the index matrix the records were gathered for

@@ -133,7 +133,9 @@ class QMIX_Learner(Learner):
                 # 7 CUs are bound by the per-CU fp32 MFMA rate (~2.5 k cycles per product phase) where 32 CUs share them at 3 rows each.
                 want = getattr(self.config, "fused_qmix_items_per_wg", None)
                 for items in ([int(want)] if want else [1]):
-                    fs = ops.QmixFusedState(m, self.double_q, self.gamma, items, int(getattr(self.config, "fused_qmix_products", 0)))
+                    # products: 2 = VALU (the default, whatever n_agents is: the matrix-core form measured slower, and its automatic
+                    # choice -- 0 -- would engage for any team of >= 8 agents at one transition per workgroup); 1 / 0 opt in
+                    fs = ops.QmixFusedState(m, self.double_q, self.gamma, items, int(getattr(self.config, "fused_qmix_products", 2)))
                     if 0 < fs.lds_bytes() <= 160 * 1024:
                         self._fused = fs
                         break

@@ -644,8 +644,16 @@ class CartPoleRollout:
     @staticmethod
     def eligible(plan, n):
         st = plan.stages
-        return list(plan.widths) == [4, 128, 256, 3] and n <= CartPoleRollout.MAX_ENVS and len(st) == 3 and len(st[0]) == 1 and \
+        return list(plan.widths) == [4, 128, 256, 3] and n <= CartPoleRollout.max_envs() and len(st) == 3 and len(st[0]) == 1 and \
             len(st[1]) == 1 and len(st[2]) == 2 and st[1][0].act == st[0][0].act and fast_kernels_enabled()
+
+    @staticmethod
+    def max_envs():
+        """min(MAX_ENVS, what THIS device keeps resident on one XCD): xrl_rollout_cartpole_max_envs (a partitioned or smaller GPU
+        takes fewer envs in the one-launch rollout; above it the agent uses the launches per vector step)."""
+        if torch.cuda.is_available():
+            return min(CartPoleRollout.MAX_ENVS, int(_lib.load().xrl_rollout_cartpole_max_envs()))
+        return CartPoleRollout.MAX_ENVS
 
     def __init__(self, plan, T, **kw):
         q = self.q = RolloutRun()
@@ -680,7 +688,8 @@ class WideRollout:
 
     @staticmethod
     def eligible(model, n):
-        return PpoWideState.eligible(model) and n <= WideRollout.MAX_ENVS and model.obs_dim <= 20 and fast_kernels_enabled()
+        cap = min(WideRollout.MAX_ENVS, int(_lib.load().xrl_rollout_wide_max_envs())) if torch.cuda.is_available() else WideRollout.MAX_ENVS
+        return PpoWideState.eligible(model) and n <= cap and model.obs_dim <= 20 and fast_kernels_enabled()
 
     @staticmethod
     def xchg_words():
