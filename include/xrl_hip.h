@@ -1209,6 +1209,12 @@ typedef struct {
                                 * once PER FINISHED ENV in env order, on the running current_step, as the reference's loop does
                                 * (off_policy_marl.py:532-534) -- it differs from one application on the step's total only in the step
                                 * where epsilon crosses end_greedy with more than one env finishing */
+    /* NULL, or: stored_state [n_envs][state_dim] <- xrl_marl_stored_state(next_state, done) for the NEXT vector step (what the
+     * reference's loop will store as its state: every row = the row of the last env that finished in THIS step, else a copy) --
+     * the same launch instead of one of its own per captured step */
+    const float* next_state;
+    float* stored_state;
+    int32_t state_dim, pad3;
 } xrl_marl_gate_t;
 /* Device address of page-locked host memory (hipHostMalloc / torch pin_memory), for kernels that publish a word to the host. */
 int xrl_host_device_pointer(void* pinned_host, void** device_out);

@@ -43,9 +43,9 @@ def oracle():
 _PARITY_LOG = []          # (test id, what, err / tensor scale, err / max(1,|ref|), tol) of every comparison of the session
 
 
-def _record(what, err_tensor, err_legacy, tol, n):
+def _record(what, err_tensor, err_legacy, tol, n, **extra):
     _PARITY_LOG.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": what,
-                        "err": float(err_tensor), "err_legacy": float(err_legacy), "tol": float(tol), "n": int(n)})
+                        "err": float(err_tensor), "err_legacy": float(err_legacy), "tol": float(tol), "n": int(n), **extra})
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -125,8 +125,13 @@ def assert_grad_close(a, ref32, ref64=None, tol=1e-5, what=""):
     ref64 = np.asarray(ref64, np.float64)
     d64 = float(np.abs(a - ref64).max(initial=0.0)) / S
     r64 = float(np.abs(ref32 - ref64).max(initial=0.0)) / S            # the reference's own float32 error
-    _record(what + " [vs f32 ref]", d32, d32, tol, a.size)
-    _record(what + " [vs f64 twin; the f32 reference itself: %.3e]" % r64, d64, d64, max(tol, r64), a.size)
+    # ONE record per comparison, saying which clause decided: "f32" = within tol of the reference's float32 gradient (then the float64
+    # numbers are information only: the two float64 distances of an update later than the first also contain the distance between the
+    # float32 and float64 TRAJECTORIES); "f64" = an exception to the 1e-5 float32 rule, listed by tools/compact_parity_report.py
+    decided = "f32" if d32 <= tol else "f64"
+    _record(what + (" [vs f32 ref]" if decided == "f32" else " [EXCEPTION: vs f64 twin; vs f32 ref %.3e; the f32 reference itself: %.3e]" % (d32, r64)),
+            d32 if decided == "f32" else d64, d32, tol if decided == "f32" else max(tol, r64), a.size,
+            decided_by=decided, d32=d32, d64=d64, ref32_vs_ref64=r64)
     if os.environ.get("XRL_PARITY_LEGACY") != "1":
         assert d32 <= tol or d64 <= max(tol, r64), \
             f"{what}: {d32:.3e} from the float32 reference, {d64:.3e} from its float64 twin (the reference itself: {r64:.3e}), tol {tol}"

@@ -255,7 +255,9 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
         # (actor.logits.2.weight: 6e-7 of its scale) says nothing about how far another float32 evaluation may land -- the engine
         # came out at 3.0e-5 there, 0.04 % of the distance the tensor moved in these 64 updates (`moved`, recorded).  The engine may
         # therefore also be MOVED_K of that distance from the float64 chain.
-        DEV_K, MOVED_K = 32.0, 2e-3
+        # (round 5: 32 / 2e-3 -> 8 / 1e-3; measured worst of the round's boxes: 6.2x (critic.values.0.bias), and 3.9e-4 of the distance moved for the two
+        #  tensors the float32 oracle sits within 6e-7 of the float64 chain on -- profiles/r05_parity_bounds_headline_256x256.json)
+        DEV_K, MOVED_K = 8.0, 1e-3
         for k_, r_ in rec.items():
             assert r_["hip_vs_f64"] <= max(1e-5, DEV_K * r_["f32_oracle_vs_f64"], MOVED_K * r_["moved"]), \
                 f"param {k_} after {64 * (it + 1)} updates: {r_}"
@@ -265,9 +267,9 @@ def test_headline_rollout_and_update_vs_oracle(oracle, n, T):
 
 
 # ------------------------------------------------------------------ the update phase against the REFERENCE's own chain
-CHAIN_K = 2.0        # measured (profiles/r03_parity_errors_gpu.json, "chain after..." lines): engine / reference distance from the float64
+CHAIN_K = 1.5        # (round 5: 2.0 -> 1.5)  measured (profiles/r03_parity_errors_gpu.json, "chain after..." lines): engine / reference distance from the float64
 #                      chain <= 1.35 (after 16 updates, actor.logits.0.bias: 4.96e-4 vs 3.69e-4), <= 0.94 after 64 updates, for every
-#                      tensor above the 1e-5 floor; 2.0 leaves room for a re-ordered sum
+#                      tensor above the 1e-5 floor
 
 
 def chain_indices(epochs=8, rows=65536, n_mb=8):

@@ -256,22 +256,28 @@ def ppo_atari(steps=3, warmup=2, ref=None):
     return out
 
 
-def dqn_c3(steps=200, ref=None):
-    """BASELINE configs[2] shapes: DQN, 64 envs x 84x84x4 uint8 frames (synthetic frame provider on the device), CNN
-    32/64/64 + 512, uint8 replay ring, batch 32, one update per vector step.  Roofline of the update graph: 2.7 GFLOP
-    (3x eval + 1x target forward-equivalents of the 21.2 MFLOP network at batch 32) / its time."""
+def dqn_c3(steps=200, ref=None, buffer_size=499968, start_training=10000):
+    """BASELINE configs[2] AT ITS CONFIGURATION (configs/dqn/atari.yaml with 64 envs): DQN, 64 envs x 84x84x4 uint8 frames (synthetic
+    frame provider on the device), CNN 32/64/64 + 512, uint8 replay ring of 499 968 transitions = 7 812 slots x 64 envs x 2 x 28 224 B
+    = 28.2 GB in HBM (memory_tools.py:105,354: buffer_size // n_envs slots per env), batch 32, start_training 10 000, one update per
+    vector step (training_frequency = n_envs).  The ring is FILLED before the timed window (HipOffPolicyBuffer.fill_synthetic: the
+    loop would need 7 812 vector steps to do it) and the loop is past start_training, so every sampled row comes from anywhere
+    in the 28 GB.  Roofline of the update graph: 2.7 GFLOP (3x eval + 1x target forward-equivalents of the 21.2 MFLOP
+    network at batch 32) / its time; `replay_gather`: the draw + gather launch alone (56 448 B per sampled transition)."""
     from xuance_amd.agents import DQN_Agent
     from xuance_amd.envs import SyntheticAtariVecEnv
     n = 64
     cfg = Namespace(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
                     q_hidden_size=[512], activation="relu", seed=1, parallels=n, running_steps=10 ** 7,
-                    buffer_size=n * 512, batch_size=32, learning_rate=1e-4, gamma=0.99, start_greedy=0.5, end_greedy=0.05,
-                    decay_step_greedy=10 ** 6, sync_frequency=500, training_frequency=n, start_training=n * 8,
+                    buffer_size=int(buffer_size), batch_size=32, learning_rate=1e-4, gamma=0.99, start_greedy=0.5, end_greedy=0.05,
+                    decay_step_greedy=10 ** 6, sync_frequency=500, training_frequency=n, start_training=int(start_training),
                     use_grad_clip=False, grad_clip_norm=0.5, use_obsnorm=False, use_rewnorm=False,
                     distributed_training=False, device="cuda", model_dir="/tmp/xrl_bench_models")
     torch.manual_seed(0)
     agent = DQN_Agent(cfg, SyntheticAtariVecEnv(n, seed=2))
-    agent.train(16)
+    agent.memory.fill_synthetic(seed=4)
+    agent.train(start_training // n + 16)            # past start_training (`current_step > start_training`, off_policy.py:228) + warm-up updates
+    assert agent.learner.iterations > 0 and agent.memory.size == agent.memory.n_size == buffer_size // n
     import gc
     gc.collect()                                    # (graphs of agents an earlier line built are destroyed HERE, not inside the window:
     torch.cuda.synchronize()                        #  a 60-step window caught such a 40 ms stall now and then -- 72 k instead of 335 k)
@@ -287,13 +293,24 @@ def dqn_c3(steps=200, ref=None):
     lr = agent.learner
     lr.update_from_buffer(agent.memory, 1, seed=1)
     graph_us = _events_us(lr._buf_graph.launch, 20)
+    # the draw + gather launch alone, rows from anywhere in the full ring
+    mem, M = agent.memory, 32
+    dst = {"observations": lr.X[:M], "next_observations": lr.X[M:2 * M], "actions": lr._act, "rewards": lr._rew, "terminals": lr._ter}
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gather_us = _events_us(lambda: mem.draw_into(lr._idx, dst, 7, 0, ctr), 200)
+    gather_bytes = M * (2 * 84 * 84 * 4 + 12)
     flops = 4 * 21.2e6 * 32
     tf = flops / graph_us / 1e6
     traffic, traffic_src = _pmc_step_bytes("r*_dqn_c3_pmc.json", "xrl::dqn_tail_td_kernel")
     out = {"workload": "DQN, Atari shapes (84x84x4 uint8 frames, CNN 32/64/64 + 512, 4 actions), %d envs, uint8 replay ring, batch 32, "
-                       "one update per vector step (BASELINE configs[2])" % n,
+                       "one update per vector step (BASELINE configs[2] at its configuration: 499 968-transition ring = 28.2 GB, start_training 10 000)" % n,
            "value": round(n * steps / dt, 1), "unit": "env-steps/s", "vector_step_us": round(dt / steps * 1e6, 1),
            "update_us": round(graph_us, 1),
+           "replay": {"slots_per_env": mem.n_size, "transitions": mem.n_size * n, "ring_GB": round(mem.n_size * n * 2 * 84 * 84 * 4 / 1e9, 2),
+                      "start_training": int(start_training), "filled": "HipOffPolicyBuffer.fill_synthetic before the timed window"},
+           "replay_gather": {"us": round(gather_us, 2), "algorithmic_bytes": gather_bytes, "GBps": round(gather_bytes / gather_us / 1e3, 1),
+                             "note": "xrl_soa_gather_sampled at batch 32: 1.8 MB per launch out of a 28 GB ring -- latency-bound (one 28 KB row per "
+                                     "4 workgroups); profiles/r05_scale_gather.json has the kernel at batches where HBM bounds it"},
            "roofline": {"bound": "mfma", "kernel": "update graph (xrl::conv_mfma_kernel / conv_dw_mfma_kernel implicit GEMMs + Q-head launches, eval + target networks, backward, xrl::reduce_adam_kernel)",
                         "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(graph_us, 1), "algorithmic_flops_per_launch": flops,

@@ -319,7 +319,7 @@ class MarlGate(C.Structure):
                 ("start_greedy", C.c_double), ("end_greedy", C.c_double), ("delta_greedy", C.c_double),
                 ("ring", c_int32), ("reset_rule", c_int32), ("done", c_void_p), ("reset_rows", c_void_p), ("counters", c_void_p),
                 ("n_envs", c_int32), ("n_agents", c_int32), ("ptr_size", c_void_p), ("buffer_size", c_int32), ("pad2", c_int32),
-                ("end_step", c_void_p)]
+                ("end_step", c_void_p), ("next_state", c_void_p), ("stored_state", c_void_p), ("state_dim", c_int32), ("pad3", c_int32)]
 
 
 class Mirrors(C.Structure):

@@ -280,8 +280,11 @@ class QMIX_Agents(AgentSurface):
         # running waits for it on the HOST (measured: one executable = a launch every 150 us for 108 us of device work, no
         # overlap at all), so consecutive launches must be different executables for the host to run ahead
         self._prologue_g = ops.Graph()                                             # (~270 us of host time per call as eager calls)
+        self._state_in_gate = bool(getattr(self.config, "state_broadcast_in_gate", True))
         with self._prologue_g:
             self._call_prologue(env, mem, counter=self._rng_dev[1:2])
+            if self.state_broadcast and self._state_in_gate:
+                ops.marl_stored_state(env._sets[0][1], None, self._stored_state)   # the first step of a call stores the reset state
             torch.add(env.episode_totals, 0, out=gt["base"])                       # (a kernel, not a memcpy node)
 
         def capture():
@@ -290,8 +293,12 @@ class QMIX_Agents(AgentSurface):
                 for k in range(K):
                     cur = k & 1
                     obs, state, avail = env._sets[cur]
-                    if self.state_broadcast:                     # what the reference stores as this step's state (see __init__)
-                        ops.marl_stored_state(state, env.done, self._stored_state)
+                    fold = {}
+                    if self.state_broadcast:                     # what the reference stores as this step's state (see __init__):
+                        if self._state_in_gate:                  # produced by the PREVIOUS step's gate launch (the call's first: prologue)
+                            fold = dict(next_state=env._sets[cur ^ 1][1], stored_state=self._stored_state, state_dim=self.state_dim)
+                        else:
+                            ops.marl_stored_state(state, env.done, self._stored_state)
                         state = self._stored_state
                     self.model.act_step(obs.view(R, -1), R, self.rnn_h, self.reset_rows, self.rnn_c, fused=fused,
                                         select=dict(avail=avail if self.use_actions_mask else None, eps_dev=self.eps_dev,
@@ -307,7 +314,7 @@ class QMIX_Agents(AgentSurface):
                                        end_greedy=float(self.end_greedy), delta_greedy=float(self.delta_egreedy),
                                        eps_dev=self.eps_dev, done=env.done, reset_rows=self.reset_rows, counters=self._rng_dev,
                                        n_envs=n, n_agents=N, ptr_size=mem.ptr_size, buffer_size=mem.buffer_size,
-                                       reset_rule=int(self.reference_rnn_reset), end_step=env.end_step, **gate_const, **gt)
+                                       reset_rule=int(self.reference_rnn_reset), end_step=env.end_step, **fold, **gate_const, **gt)
             return g
         self._steps_g = [capture() for _ in range(lag + 2)]
         return self._steps_g

@@ -131,6 +131,33 @@ __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (g.reset_rows && t < g.n_envs * g.n_agents)
         g.reset_rows[t] = g.reset_rule ? (t < g.n_envs ? g.done[t] : 0.f) : g.done[t / g.n_agents];
+    if (g.stored_state && threadIdx.x >= 64) {                            // xrl_marl_stored_state for the next step, riding along
+        // Waves 1..3 of every block do this; wave 0 -- block 0's carries the loop bookkeeping, this launch's chain -- goes straight on.
+        // Every thread requests ITS elements of the next state before anybody knows whether an env finished: in the common step (no
+        // episode end) the copy costs no dependent round trip; only a step that did end an episode reads the finished env's row
+        // behind the scan.  No workgroup barrier: each wave finds the last finished env for itself.
+        constexpr int PRE = 16;
+        const int tot = g.n_envs * g.state_dim, nthr = gridDim.x * 192, tt = blockIdx.x * 192 + ((int)threadIdx.x - 64);
+        const bool pre = tot <= nthr * PRE;
+        float own[PRE];
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < PRE; ++k) { const int i = tt + k * nthr; own[k] = i < tot ? g.next_state[i] : 0.f; }
+        }
+        int last = -1;
+        for (int e = threadIdx.x & 63; e < g.n_envs; e += 64) if (g.done[e] != 0.f) last = e;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+        if (last < 0 && pre) {
+#pragma unroll
+            for (int k = 0; k < PRE; ++k) { const int i = tt + k * nthr; if (i < tot) g.stored_state[i] = own[k]; }
+        } else {
+            for (int i = tt; i < tot; i += nthr) {
+                const int e = i / g.state_dim;
+                g.stored_state[i] = g.next_state[(size_t)(last >= 0 ? last : e) * g.state_dim + (i - e * g.state_dim)];
+            }
+        }
+    }
     if (t >= 64) return;
     // The first wave counts the finished envs together (one load per lane instead of one thread walking n_envs dependent loads),
     // and everything lane 0 reads below is requested here, unconditionally, in one go: this launch sits on the critical path of
@@ -287,6 +314,7 @@ extern "C" int xrl_marl_loop_gate(const xrl_marl_gate_t* gate, xrl_stream_t stre
     XRL_CHECK_ARG(g.host_flags == nullptr || (g.seq != nullptr && g.ring > 0));
     XRL_CHECK_ARG(g.reset_rows == nullptr || (g.done && g.n_envs > 0 && g.n_agents > 0));
     XRL_CHECK_ARG(g.ptr_size == nullptr || (g.done && g.n_envs > 0 && g.buffer_size > 0));
+    XRL_CHECK_ARG(g.stored_state == nullptr || (g.next_state && g.done && g.n_envs > 0 && g.state_dim > 0 && g.next_state != g.stored_state));
     const int n = g.reset_rows ? g.n_envs * g.n_agents : 1;
     hipLaunchKernelGGL(marl_loop_gate_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), g);
     XRL_CHECK_LAUNCH();

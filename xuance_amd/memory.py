@@ -262,6 +262,31 @@ class HipOffPolicyBuffer:
         if grow:
             self.size += 1                   # `size` for sampling kernels inside captured graphs
 
+    def fill_synthetic(self, seed=0, chunk=256):
+        """Fill the WHOLE ring with synthetic transitions on the device (frames / observations uniform over their dtype's range in
+        slabs of `chunk` slots, actions over the action set, N(0,1) rewards, 2 % terminals) and mark it full: measurements at a
+        configuration's real replay size (configs/dqn/atari.yaml: 500 000 frames = 28 GB of uint8 stacks) without the
+        hours of environment steps that fill it."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed(int(seed))
+        f = self.soa.fields
+        for k in ("observations", "next_observations"):
+            x = f[k]
+            for t0 in range(0, self.n_size, chunk):
+                if x.dtype == torch.uint8:
+                    x[t0:t0 + chunk].random_(0, 256, generator=g)
+                else:
+                    x[t0:t0 + chunk].normal_(generator=g)
+        n_act = getattr(self.action_space, "n", None)
+        if n_act is not None:
+            f["actions"].random_(0, int(n_act), generator=g)
+        else:
+            f["actions"].uniform_(-1.0, 1.0, generator=g)
+        f["rewards"].normal_(generator=g)
+        f["terminals"].copy_((torch.rand(f["terminals"].shape, device=self.device, generator=g) < 0.02).float())
+        self.size = self.n_size
+        self.size_dev.fill_(self.n_size)
+
     def ring_bias(self, counter_value):
         """(slot_bias, size_bias) of store_ring for a device counter that currently holds `counter_value`: the next store lands in
         slot `ptr` and makes `size + 1` slots filled."""
