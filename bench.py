@@ -43,13 +43,61 @@ make_config = bw.c2_config          # (tools/bench_secondary.py builds its 16-en
 
 
 _PMC_SOURCE = [None]
+_LIVE_PMC = {}          # kernel name (up to its argument list) -> HBM bytes per launch, measured by live_pmc() in THIS run
+
+
+def live_pmc(timeout_s=150):
+    """HBM traffic of the bench's kernels measured in this run: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE:
+    separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes) over a 3-step child of this command, FETCH_SIZE doubled
+    (gfx950 tallies a wide coalesced stream at 64 B per 128-B request), WRITE_SIZE raw; fills _LIVE_PMC.  Returns a note (why it did
+    not run: no rocprofv3, a pass failed or timed out -- the committed pass of profiles/ is reported then, and says so)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-roofline"]
+    acc = {"FETCH_SIZE": defaultdict(lambda: [0.0, 0]), "WRITE_SIZE": defaultdict(lambda: [0.0, 0])}
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(d, ctr)
+            pr = subprocess.Popen([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "x", "--"] + child, cwd="/tmp",
+                                  env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                return "rocprofv3 --pmc %s pass timed out after %d s" % (ctr, timeout_s)
+            if rc != 0:
+                return "rocprofv3 --pmc %s pass exited with %d" % (ctr, rc)
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") == ctr:
+                            a = acc[ctr][row["Kernel_Name"]]
+                            a[0] += float(row["Counter_Value"]); a[1] += 1
+    for k in set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"]):
+        fr = acc["FETCH_SIZE"][k][0] / max(acc["FETCH_SIZE"][k][1], 1)
+        wr = acc["WRITE_SIZE"][k][0] / max(acc["WRITE_SIZE"][k][1], 1)
+        _LIVE_PMC[k.split("(")[0].replace("void ", "")] = int((2 * fr + wr) * 1024)
+    return None if _LIVE_PMC else "the passes produced no counter rows"
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/, FETCH_SIZE doubled
-    per MI355X_MICROARCH.md); None if the summary is not there.  PMC counters cannot be read from inside the process:
-    this number is COPIED from the builder-run pass named in `traffic_source`, not measured in this run."""
+    """HBM bytes per launch of `kernel`: measured in this run when live_pmc() ran (the default at N = 1), else from the committed
+    rocprofv3 PMC passes of this same command (profiles/, FETCH_SIZE doubled per MI355X_MICROARCH.md) -- `traffic_source` says
+    which; None if neither exists."""
     import glob
+    for name, v in _LIVE_PMC.items():
+        if name.startswith(kernel):
+            _PMC_SOURCE[0] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over a 3-step "
+                              "child of this command; 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes")
+            return v
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ppo_c2_pmc_hbm.json")))      # latest committed pass
     try:
         with open(paths[-1]) as f:
@@ -281,6 +329,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC pass instead of two rocprofv3 passes of a 3-step child run")
     ap.add_argument("--no-secondary", action="store_true", help="skip the PPO-16-envs / QMIX-3m / eager-PyTorch lines")
     ap.add_argument("--no-role-split", action="store_true", help="the any-shape minibatch kernel (one workgroup per tile, ppo_fused_kernel) instead of the role-split family")
     ap.add_argument("--workload", choices=bw.WORKLOADS, default="c2", help="which BASELINE configuration is the main line")
@@ -397,6 +446,12 @@ def main():
             out["secondary"] = nrank_secondary
         if phases is not None:
             out["phases"] = phases
+        pmc_note = None
+        if world == 1 and c2 and not args.no_roofline and not args.no_live_pmc:
+            try:
+                pmc_note = live_pmc()
+            except Exception as ex:                          # noqa: BLE001  (a profiler problem must never cost the line)
+                pmc_note = repr(ex)[:200]
         if c2 and not args.no_roofline:
             # `roofline` = the kernel with the largest share of the step (what rocprofv3 --stats puts first: the fused
             # minibatch kernel at the headline workload), the other of the two rides along under its own key
@@ -408,6 +463,8 @@ def main():
                 if second is not None:
                     out["roofline_update_kernel"] = second
             out["hbm_kernels"] = hbm_kernels(agent)
+            if pmc_note:
+                out["roofline"]["live_pmc_note"] = pmc_note
         if world == 1 and c2 and not args.no_cpu_baseline:
             # cpu_baseline: the reference's own CPU torch path (kind "reference", timed where the reference exists);
             # cpu_port: the oracle's NumPy port of the same loop, timed live on THIS host's cores

@@ -3,7 +3,8 @@ UNMODIFIED reference agents (through oracle/ref_shim.py), constructed from the r
 REGISTRY_Agents[...] exactly as oracle/time_reference_cpu.py constructs them for timing, run through their own ``train()`` on
 deterministic host simulators behind the reference's own vector-env classes:
 
-  golden_agent_ppo       PPO_Agent.train           (agents/policy_gradient/ppo_agent.py:111-181, core/on_policy.py:128-205)
+  golden_agent_ppo       PPO_Agent.train           (agents/policy_gradient/ppo_agent.py:111-181, core/on_policy.py:128-205); categorical
+                         (CartPole yaml) and Gaussian (mujoco yaml: BASELINE configs[3]'s network)
   golden_agent_dqn       DQN_Agent.train           (agents/core/off_policy.py:119-148, 174-270)
   golden_agent_qmix_ff   QMIX_Agents.train         (agents/core/off_policy_marl.py:112-166, 212-255, 358-424)
   golden_agent_qmix_rnn  QMIX_Agents.train -> run_episodes  (off_policy_marl.py:334-356, 426-571)
@@ -83,11 +84,42 @@ def rms_np(prefix, rms):
 
 
 # ------------------------------------------------------------------------------------------------------------------ PPO
-def golden_agent_ppo():
-    """PPO_Agent with configs/ppo/classic_control/CartPole-v1.yaml (network 4-128-{128-2, 128-1}, obs / reward normalisation on,
-    GAE, advantage normalisation, clip 0.5) at 8 envs x horizon 32, 2 epochs x 2 minibatches, on CartPole simulators cut at 23 steps
-    (terminations AND truncations inside every rollout) behind the reference's DummyVecEnv + XuanCeEnvWrapper: three rollouts
-    (96 vector steps) = three buffer fills, three update phases of 4 minibatches."""
+class HostControlShapedEnv:
+    """Host stand-in with HalfCheetah's shapes (obs 17, Box(6)): linear-tanh dynamics driven by the action plus noise, a small
+    termination probability and a cut at max_episode_steps -- the simulator itself is third-party and not in the image."""
+    max_episode_steps = 19
+
+    def __init__(self, env_seed=None):
+        self.observation_space, self.action_space = sp.Box(-np.inf, np.inf, (17,), np.float32), sp.Box(-1.0, 1.0, (6,), np.float32)
+        self.rng = np.random.default_rng(env_seed)
+        self.W = (self.rng.standard_normal((6, 17)) * 0.3).astype(np.float32)
+        self.state, self.steps = None, 0
+
+    def reset(self, seed=None):
+        self.state = (self.rng.standard_normal(17) * 0.5).astype(np.float32)
+        self.steps = 0
+        return self.state.copy(), {}
+
+    def step(self, action):
+        a = np.clip(np.asarray(action, np.float32), -1, 1)
+        self.state = np.tanh(0.9 * self.state + a @ self.W + 0.1 * self.rng.standard_normal(17).astype(np.float32)).astype(np.float32)
+        r = float(self.state[0] - 0.1 * float(a @ a))
+        self.steps += 1
+        term = bool(self.rng.random() < 0.04)
+        return self.state.copy(), r, term, self.steps >= self.max_episode_steps, {}
+
+    def close(self):
+        pass
+
+
+def golden_agent_ppo(kind="categorical"):
+    """PPO_Agent over three rollouts of 8 envs x 32 steps (three buffer fills, three update phases of 2 x 2 minibatches), terminations
+    AND truncations inside every rollout, behind the reference's DummyVecEnv + XuanCeEnvWrapper.
+    categorical: configs/ppo/classic_control/CartPole-v1.yaml (network 4-128-{128-2, 128-1}, obs / reward normalisation on, GAE,
+    advantage normalisation, clip 0.5) on CartPole simulators cut at 23 steps -> agent_ppo.npz.
+    gaussian: configs/ppo/mujoco.yaml (Gaussian_AC on Basic_Identical: actor 17-256-256-6 with tanh on the mean, state-independent
+    log_std, critic 17-256-256-1; BASELINE configs[3]'s network) on the HalfCheetah-shaped host env above -> agent_ppo_gaussian.npz
+    (recorded next to every action: the distribution's mean and std, so that a replay can hand the sampler the very normals)."""
     from xuance.common.callback import BaseCallback
     import xuance.torch.agents.base.agent as agent_mod
     import xuance.torch.agents.policy_gradient.ppo_agent as pa
@@ -99,13 +131,20 @@ def golden_agent_ppo():
     class ShortCartPole(NumpyCartPoleEnv):
         max_episode_steps = 23
 
+    gauss = kind == "gaussian"
     agent_mod.SummaryWriter = _NullWriter
     pa.tqdm = lambda x, *a, **k: x
     n, T, rollouts = 8, 32, 3
-    cfg = agent_config("ppo/classic_control/CartPole-v1.yaml", parallels=n, horizon_size=T, n_epochs=2, n_minibatch=2, seed=7)
+    if gauss:
+        cfg = agent_config("ppo/mujoco.yaml", parallels=n, horizon_size=T, n_epochs=1, n_minibatch=2, seed=13)   # (142 k parameters: one epoch keeps the file at 5 MB)
+        Env, D = HostControlShapedEnv, 17
+    else:
+        cfg = agent_config("ppo/classic_control/CartPole-v1.yaml", parallels=n, horizon_size=T, n_epochs=2, n_minibatch=2, seed=7)
+        Env, D = ShortCartPole, 4
     seed_all(cfg.seed)
-    envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 11)
-    envs.observation_space, envs.action_space = sp.Box(-np.inf, np.inf, (4,), np.float32), sp.Discrete(2)   # (the shim's gymnasium types)
+    envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(Env(env_seed=env_seed))] * n, 11)
+    envs.observation_space = sp.Box(-np.inf, np.inf, (D,), np.float32)                    # (the shim's gymnasium types)
+    envs.action_space = sp.Box(-1.0, 1.0, (6,), np.float32) if gauss else sp.Discrete(2)
     envs.reset()
     out, steps, phases = {}, [], []
 
@@ -113,13 +152,14 @@ def golden_agent_ppo():
         def on_train_step(self, current_step, **kw):
             ag = self.agent
             with torch.no_grad():
-                po = ag.model(torch.as_tensor(kw["obs"]))                     # (listening only: the logits behind the sampled actions)
-                probs = po.distributions.probs.numpy().copy()
+                po = ag.model(torch.as_tensor(kw["obs"]))                     # (listening only: the distribution behind the sampled actions)
+                dist = dict(mu=po.distributions.mu.numpy().copy(), std=po.distributions.std.numpy().copy()) if gauss else \
+                    dict(probs=po.distributions.probs.numpy().copy())
             steps.append(dict(obs=np.array(kw["obs"], np.float32), acts=np.array(kw["acts"]), vals=np.array(kw["vals"], np.float32),
                               logp=np.array(kw["aux_info"]["old_logp"], np.float32), next_obs=np.array(kw["next_obs"], np.float32),
                               rewards=np.array(kw["rewards"], np.float32), terminals=np.array(kw["terminals"]),
-                              truncations=np.array(kw["truncations"]), probs=probs,
-                              reset_obs=np.stack([np.asarray(i.get("reset_obs", np.zeros(4)), np.float32) for i in kw["infos"]]),
+                              truncations=np.array(kw["truncations"]), **dist,
+                              reset_obs=np.stack([np.asarray(i.get("reset_obs", np.zeros(D)), np.float32) for i in kw["infos"]]),
                               episode_step=np.array([i["episode_step"] for i in kw["infos"]]),
                               episode_score=np.array([i["episode_score"] for i in kw["infos"]], np.float64)))
 
@@ -171,11 +211,17 @@ def golden_agent_ppo():
     assert term.sum() > 8 and (trunc & ~term).sum() > 8, (term.sum(), trunc.sum())
     out["cfg"] = np.array([n, T, cfg.n_epochs, cfg.n_minibatch, cfg.gamma, cfg.gae_lambda, cfg.learning_rate, cfg.vf_coef, cfg.ent_coef,
                            cfg.clip_range, cfg.grad_clip_norm, cfg.obsnorm_range, cfg.rewnorm_range, agent.learner.total_iters,
-                           ShortCartPole.max_episode_steps], np.float64)
+                           Env.max_episode_steps], np.float64)
     out["cfg_names"] = np.array("n_envs horizon_size n_epochs n_minibatch gamma gae_lambda learning_rate vf_coef ent_coef clip_range "
                                 "grad_clip_norm obsnorm_range rewnorm_range total_iters max_episode_steps".split())
-    np.savez_compressed(os.path.join(OUT, "agent_ppo.npz"), **out)
-    print("agent_ppo:", len(out), "arrays;", int(term.sum()), "terminations,", int((trunc & ~term).sum()), "truncations")
+    name = "agent_ppo_gaussian" if gauss else "agent_ppo"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ":", len(out), "arrays;", int(term.sum()), "terminations,", int((trunc & ~term).sum()), "truncations")
+
+
+def golden_agent_ppo_gaussian():
+    golden_agent_ppo("gaussian")
+
 
 # ------------------------------------------------------------------------------------------------------------------ DQN
 def golden_agent_dqn():
@@ -578,6 +624,6 @@ def golden_agent_qmix_rnn():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    todo = sys.argv[1:] or ["ppo", "dqn", "qmix_ff", "qmix_rnn"]
+    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "dqn", "qmix_ff", "qmix_rnn"]
     for name in todo:
         globals()[f"golden_agent_{name}"]()

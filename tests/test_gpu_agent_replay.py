@@ -36,35 +36,47 @@ def categorical_uniforms(probs, acts):
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
-def test_ppo_agent_replays_the_reference_run(use_graph):
+@pytest.mark.parametrize("kind", ["categorical", "gaussian"])
+def test_ppo_agent_replays_the_reference_run(kind, use_graph):
     """agent_ppo.npz: the reference's PPO_Agent (configs/ppo/classic_control/CartPole-v1.yaml) over three rollouts of 8 envs x 32
-    steps with 31 terminations and 12 truncations, 2 x 2 minibatch updates per rollout.  use_graph: the rollout and the update phase
-    as one captured hipGraph each (replayed on the following stretch of the tape / the next indices) or launch by launch."""
+    steps with 31 terminations and 12 truncations, 2 x 2 minibatch updates per rollout.  agent_ppo_gaussian.npz: the same loop with
+    configs/ppo/mujoco.yaml (Gaussian_AC on Basic_Identical: 17-256-256-{6, 1}, tanh on the mean, log_std parameter -- BASELINE
+    configs[3]'s network), 25 terminations and 23 truncations, 1 x 2 updates per rollout; the sampler gets the reference's own
+    normals (action - mean) / std.  use_graph: the rollout and the update phase as one captured hipGraph each (replayed on the
+    following stretch of the tape / the next indices) or launch by launch."""
     from xuance_amd.agents import PPO_Agent
     from xuance_amd.envs import RecordedVecEnv
-    from xuance_amd.spaces import Discrete
-    g = load_golden("agent_ppo")
+    from xuance_amd.spaces import Box, Discrete
+    gauss = kind == "gaussian"
+    g = load_golden("agent_ppo_gaussian" if gauss else "agent_ppo")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
     S = g["step/acts"].shape[0]
     rollouts = S // T
+    A = g["step/acts"].shape[2] if gauss else 2
     env = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
-                         g["step/reset_obs"], action_space=Discrete(2), max_episode_steps=int(c["max_episode_steps"]))
+                         g["step/reset_obs"], action_space=Box(-1.0, 1.0, (A,), np.float32) if gauss else Discrete(2),
+                         max_episode_steps=int(c["max_episode_steps"]))
     env.prepare(T)
-    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128], critic_hidden_size=[128],
-                    activation="leaky_relu", seed=1, parallels=n, running_steps=10 ** 6, horizon_size=T, n_epochs=E, n_minibatch=MB,
+    net = dict(representation="Basic_Identical", representation_hidden_size=None, actor_hidden_size=[256, 256], critic_hidden_size=[256, 256],
+               activation="leaky_relu", activation_action="tanh", use_fused_acting=False, use_wide_rollout=False) if gauss else \
+        dict(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128], critic_hidden_size=[128], activation="leaky_relu")
+    cfg = Namespace(seed=1, parallels=n, running_steps=10 ** 6, horizon_size=T, n_epochs=E, n_minibatch=MB,
                     learning_rate=c["learning_rate"], vf_coef=c["vf_coef"], ent_coef=c["ent_coef"], clip_range=c["clip_range"],
                     gamma=c["gamma"], use_gae=True, gae_lambda=c["gae_lambda"], use_advnorm=True, use_grad_clip=True,
                     grad_clip_norm=c["grad_clip_norm"], use_obsnorm=True, use_rewnorm=True, obsnorm_range=c["obsnorm_range"],
                     rewnorm_range=c["rewnorm_range"], distributed_training=False, device="cuda", model_dir="/tmp/xrl_models",
-                    use_hip_graph=use_graph)
+                    use_hip_graph=use_graph, **net)
     agent = PPO_Agent(cfg, env)
     assert not agent.use_fused_rollout and agent.learner.total_iters == int(c["total_iters"])
     init = sub(g, "init")
     assert list(agent.model.ref_order) == list(init)
     agent.model.load_state_dict(init)
-    noise = categorical_uniforms(g["step/probs"], g["step/acts"]).reshape(rollouts, T, n)
-    assert g["step/probs"].min() > 1e-3                                # (no taken action sits in a CDF interval narrower than the tolerance)
+    if gauss:
+        noise = ((g["step/acts"] - g["step/mu"]) / g["step/std"].reshape(S, 1, A)).astype(np.float32).reshape(rollouts, T, n, A)
+    else:
+        noise = categorical_uniforms(g["step/probs"], g["step/acts"]).reshape(rollouts, T, n)
+        assert g["step/probs"].min() > 1e-3                            # (no taken action sits in a CDF interval narrower than the tolerance)
     chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))
     f = agent.memory.soa.fields
     tm = lambda a: np.swapaxes(np.asarray(a), 0, 1)                    # the reference's env-major [n][T] -> time-major
@@ -74,10 +86,13 @@ def test_ppo_agent_replays_the_reference_run(use_graph):
         agent.rollout()
         torch.cuda.synchronize()
         buf, last = sub(g, f"phase{p}/buffer"), (p + 1) * T - 1
-        assert np.array_equal(npy(f["actions"]), tm(buf["actions"])), f"rollout {p}: stored actions"
-        assert np.array_equal(npy(f["actions"]), g["step/acts"][p * T:(p + 1) * T].astype(np.float32))
+        if gauss:     # x = mu + std z with the device's own mean (1e-5 from the reference's): not bit-equal, 1e-5 of the action scale
+            assert_close(npy(f["actions"]).reshape(T, n, A), tm(buf["actions"]), 1e-5, f"rollout {p}: stored actions", scale=max(1.0, float(np.abs(buf["actions"]).max())))
+        else:
+            assert np.array_equal(npy(f["actions"]), tm(buf["actions"])), f"rollout {p}: stored actions"
+            assert np.array_equal(npy(f["actions"]), g["step/acts"][p * T:(p + 1) * T].astype(np.float32))
         assert np.array_equal(npy(f["terminals"]) > 0, tm(buf["terminals"]) > 0), f"rollout {p}: stored terminals"
-        assert_close(npy(f["observations"]), tm(buf["observations"]), 1e-5, f"rollout {p}: stored (normalised) observations")
+        assert_close(npy(f["observations"]).reshape(T, n, -1), tm(buf["observations"]), 1e-5, f"rollout {p}: stored (normalised) observations")
         assert_close(npy(f["rewards"]), tm(buf["rewards"]), 1e-5, f"rollout {p}: stored (processed) rewards")
         assert_close(npy(f["values"]), tm(buf["values"]), 1e-5, f"rollout {p}: stored values")
         assert_close(npy(f["aux_old_logp"]), tm(buf["old_logp"]), 1e-5, f"rollout {p}: stored old_logp")
@@ -87,7 +102,7 @@ def test_ppo_agent_replays_the_reference_run(use_graph):
         assert_close(npy(agent.obs_mean), g["step/obs_rms/mean"][last], 1e-5, "obs_rms.mean", scale=float(np.sqrt(g["step/obs_rms/var"][last]).max()))
         assert_close(npy(agent.obs_var), g["step/obs_rms/var"][last], 1e-5, "obs_rms.var")
         assert_close(npy(agent.obs_count)[0], g["step/obs_rms/count"][last], 1e-9, "obs_rms.count")
-        assert_close(npy(agent.ret_mean)[0], g["step/ret_rms/mean"][last], 1e-5, "ret_rms.mean")
+        assert_close(npy(agent.ret_mean)[0], g["step/ret_rms/mean"][last], 1e-5, "ret_rms.mean", scale=max(1e-3, float(np.sqrt(g["step/ret_rms/var"][last]))))
         assert_close(npy(agent.ret_var)[0], g["step/ret_rms/var"][last], 1e-5, "ret_rms.var")
         assert_close(npy(agent.ret_count)[0], g["step/ret_rms/count"][last], 1e-9, "ret_rms.count")
         assert_close(npy(agent.returns), g["step/returns_track"][last], 1e-5, "discounted-return tracker", scale=max(1.0, float(np.abs(g["step/returns_track"][last]).max())))

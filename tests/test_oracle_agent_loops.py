@@ -11,43 +11,59 @@ import pytest
 from conftest import load_golden, sub, assert_close, ChainCheck
 
 
-def test_ppo_agent_loop(oracle):
+@pytest.mark.parametrize("kind", ["categorical", "gaussian"])
+def test_ppo_agent_loop(oracle, kind):
     """ppo_agent.py:111-181 + core/on_policy.py:182-205: per vector step obs_rms.update(raw obs) -> normalise -> act -> env ->
     store (normalised obs, action, processed reward, value, TERMINATED flag, old_logp); buffer full: V(next_obs) under the CURRENT
     statistics closes every path (0 for terminated envs), the update phase runs, the buffer is cleared; after that the return
-    tracker / ret_rms / per-env path closing of finished episodes (no-ops on the emptied buffer when both coincide)."""
+    tracker / ret_rms / per-env path closing of finished episodes (no-ops on the emptied buffer when both coincide).
+    categorical: agent_ppo.npz (CartPole yaml); gaussian: agent_ppo_gaussian.npz (mujoco yaml: 17-256-256-{6, 1}, tanh on the mean,
+    state-independent log_std -- actions are NOT rescaled or clipped on the way to the env, wrapper.py:19,90-91)."""
     o = oracle
-    g = load_golden("agent_ppo")
+    gauss = kind == "gaussian"
+    g = load_golden("agent_ppo_gaussian" if gauss else "agent_ppo")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
-    S = g["step/acts"].shape[0]
+    S, D = g["step/acts"].shape[0], g["raw_obs0"].shape[1]
+    A = g["step/acts"].shape[2] if gauss else 2
+    fw = dict(dist="gaussian", act="leaky_relu", activation_action="tanh") if gauss else {}
     sd = {k: v.copy() for k, v in sub(g, "init").items()}
     opt = o.AdamOracle(sd, lr=c["learning_rate"], eps=1e-5, total_iters=int(c["total_iters"]))
     ucfg = dict(vf_coef=c["vf_coef"], ent_coef=c["ent_coef"], clip_range=c["clip_range"], use_grad_clip=True, grad_clip_norm=c["grad_clip_norm"])
-    obs_rms, ret_rms = o.RunningMeanStdOracle((4,)), o.RunningMeanStdOracle(())
+    obs_rms, ret_rms = o.RunningMeanStdOracle((D,)), o.RunningMeanStdOracle(())
     returns = np.zeros(n, np.float32)
-    buf = o.OnPolicyBufferOracle((4,), (), n, T, gamma=c["gamma"], gae_lam=c["gae_lambda"])
+    buf = o.OnPolicyBufferOracle((D,), (A,) if gauss else (), n, T, gamma=c["gamma"], gae_lam=c["gae_lambda"])
     raw = g["raw_obs0"].copy()
     phase = 0
     for s in range(S):
         obs_rms.update(raw)
         obs_n = o.process_observation(raw, obs_rms, c["obsnorm_range"]).astype(np.float32)
         assert_close(obs_n, g["step/obs"][s], 1e-6, f"step {s}: normalised obs")
-        logits, value = o.actor_critic_forward(sd, obs_n)
-        probs = np.exp(o.log_softmax(logits))
-        assert_close(probs, g["step/probs"][s], 1e-5, f"step {s}: action probabilities")
+        head, value = o.actor_critic_forward(sd, obs_n, **fw)
         acts = g["step/acts"][s]                                                    # fixed input: what the reference sampled
-        # (the uniforms the GPU replay supplies reproduce these actions through the inverse CDF)
-        cdf = np.cumsum(g["step/probs"][s].astype(np.float64), -1)
-        u = (cdf[np.arange(n), acts] - 0.5 * g["step/probs"][s][np.arange(n), acts]).astype(np.float32)
-        assert np.array_equal(o.categorical_sample_icdf(logits, u), acts)
-        logp = o.log_softmax(logits)[np.arange(n), acts]
-        assert_close(value, g["step/vals"][s], 1e-5, f"step {s}: values")
-        assert_close(logp, g["step/logp"][s], 1e-5, f"step {s}: log-probs")
+        if gauss:
+            assert_close(head, g["step/mu"][s], 1e-5, f"step {s}: mean of the action distribution", scale=1.0)
+            assert_close(np.exp(sd["actor.log_std"]), g["step/std"][s].reshape(-1, A)[0], 1e-6, "std")
+            # (the normals the GPU replay supplies reproduce these actions: x = mu + std z)
+            z = ((acts - g["step/mu"][s]) / g["step/std"][s]).astype(np.float32)
+            x, logp = o.gaussian_sample_reparam(head, sd["actor.log_std"], z)
+            assert_close(x, acts, 1e-5, f"step {s}: actions from the supplied normals", scale=max(1.0, float(np.abs(acts).max())))
+            logp = o.gaussian_sample_reparam(head, sd["actor.log_std"], ((acts - head) / np.exp(sd["actor.log_std"])).astype(np.float32))[1]
+            assert_close(logp, g["step/logp"][s], 1e-5, f"step {s}: log-probs", scale=max(1.0, float(np.abs(g["step/logp"][s]).max())))
+        else:
+            probs = np.exp(o.log_softmax(head))
+            assert_close(probs, g["step/probs"][s], 1e-5, f"step {s}: action probabilities")
+            # (the uniforms the GPU replay supplies reproduce these actions through the inverse CDF)
+            cdf = np.cumsum(g["step/probs"][s].astype(np.float64), -1)
+            u = (cdf[np.arange(n), acts] - 0.5 * g["step/probs"][s][np.arange(n), acts]).astype(np.float32)
+            assert np.array_equal(o.categorical_sample_icdf(head, u), acts)
+            logp = o.log_softmax(head)[np.arange(n), acts]
+            assert_close(logp, g["step/logp"][s], 1e-5, f"step {s}: log-probs")
+        assert_close(value, g["step/vals"][s], 1e-5, f"step {s}: values", scale=max(1e-2, float(np.abs(g["step/vals"][s]).max())))
         next_obs, rew, term, trunc = g["step/next_obs"][s], g["step/rewards"][s], g["step/terminals"][s], g["step/truncations"][s]
-        buf.store(obs_n, acts, o.process_reward(rew, ret_rms, c["rewnorm_range"]), value, term, {"old_logp": logp})
+        buf.store(obs_n, acts, o.process_reward(rew, ret_rms, c["rewnorm_range"]), value, term, {"old_logp": g["step/logp"][s] if gauss else logp})
         if buf.full:
-            vals = o.actor_critic_forward(sd, o.process_observation(next_obs, obs_rms, c["obsnorm_range"]).astype(np.float32))[1]
+            vals = o.actor_critic_forward(sd, o.process_observation(next_obs, obs_rms, c["obsnorm_range"]).astype(np.float32), **fw)[1]
             for i in range(n):
                 buf.finish_path(0.0 if term[i] else vals[i], i)
             ref = sub(g, f"phase{phase}/buffer")
@@ -63,7 +79,7 @@ def test_ppo_agent_loop(oracle):
             for k in range(E * MB):
                 b = buf.sample(idx[k])
                 info, grads = o.ppo_update(sd, opt, dict(obs=b["obs"], actions=b["actions"], returns=b["returns"], advantages=b["advantages"],
-                                                         old_logp=b["aux_batch"]["old_logp"]), ucfg)
+                                                         old_logp=b["aux_batch"]["old_logp"]), ucfg, **fw)
                 ref_g = sub(g, f"phase{phase}/grad{k}")
                 for name, rg in ref_g.items():
                     assert_close(info["clipped_grads"][name], rg, 1e-5, f"phase {phase} update {k}: clipped gradient {name}")
@@ -85,7 +101,7 @@ def test_ppo_agent_loop(oracle):
                 if term[i]:
                     buf.finish_path(0.0, i)
                 else:
-                    vals = o.actor_critic_forward(sd, o.process_observation(next_obs, obs_rms, c["obsnorm_range"]).astype(np.float32))[1]
+                    vals = o.actor_critic_forward(sd, o.process_observation(next_obs, obs_rms, c["obsnorm_range"]).astype(np.float32), **fw)[1]
                     buf.finish_path(vals[i], i)
                 raw[i] = g["step/reset_obs"][s][i]
         assert_close(returns, g["step/returns_track"][s], 1e-5, f"step {s}: return tracker", scale=max(1.0, float(np.abs(g["step/returns_track"][s]).max())))
