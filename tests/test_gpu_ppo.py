@@ -195,15 +195,13 @@ def _load_rows(memory, b, n, T):
 
 
 @pytest.mark.parametrize("size,n,T,kernel", [("c2", 32, 256, "split"), ("c1", 4, 32, "split"), ("c1", 4, 32, "unsplit"),
-                                             ("c2", 32, 256, "any-shape"), ("c2", 32, 256, "pair"), ("c1", 4, 32, "pair"),
-                                             ("c2", 32, 256, "chain"), ("c1", 4, 32, "chain")])
+                                             ("c2", 32, 256, "any-shape"), ("c2", 32, 256, "pair"), ("c1", 4, 32, "pair")])
 def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
     """The ONE-LAUNCH minibatch kernels pinned to the reference directly, at its own sizes: the rows of the C2 (8 192) / C1
     (128) fixtures are loaded into a HipOnPolicyBuffer and go through gather -> forward -> loss -> backward (xrl_ppo_fused_minibatch:
     ppo_trunk_kernel with (32-row tile, role) workgroups -- "split": 512 workgroups / 256 gradient slabs at C2 -- and with (64-row
     tile, role) workgroups -- "pair": 128 slabs at C2, the headline's kernel --, the any-shape ppo_fused_kernel with the specialised
-    kernels switched off or the role split declined -- "unsplit"; "chain": the 64-row form with register-chained forward /
-    backward-data products, csrc/ppo_chain.hip, off by default)
+    kernels switched off or the role split declined -- "unsplit")
     and xrl_reduce_adam, exactly as PPO_Agent's update phase enqueues them; compared with the reference's `u*/grad` (clipped),
     its float64 twin, its parameter steps and Adam moments (reference: ppo_learner.py:46-67).  The fixture's advantages are
     already normalised (what buffer.sample hands the learner), so the launch gets no statistics."""
@@ -218,8 +216,7 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
                     gamma=0.98, use_gae=True, gae_lambda=0.95, use_advnorm=True, use_grad_clip=True, grad_clip_norm=float(gclip),
                     end_factor_lr_decay=float(ef), use_obsnorm=False, use_rewnorm=False, obsnorm_range=5, rewnorm_range=5,
                     distributed_training=False, device="cuda", model_dir="/tmp/xrl_models", use_hip_graph=False,
-                    use_role_split_update=(kernel in ("split", "pair", "chain")), use_pair_update=(kernel in ("pair", "chain")),
-                    use_chain_update=(kernel == "chain"))
+                    use_role_split_update=(kernel in ("split", "pair")), use_pair_update=(kernel == "pair"))
     prev = ops.fast_kernels_enabled()
     ops.set_fast_kernels(kernel != "any-shape")
     try:

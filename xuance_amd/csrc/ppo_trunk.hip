@@ -547,10 +547,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
 
 // the family: widths [D, 128, 256, A + 1] with D <= 24, A <= 8, the first layer at the front of the flat layout (the fold region maps
 // onto columns [0, 128 D + 128)), the fragment copy of the branch layer present, hidden activation relu / leaky_relu / tanh
-bool ppo_chain_eligible(const xrl_ppo_fused_t& p);
-int launch_ppo_chain(const xrl_ppo_fused_t& p, hipStream_t stream);
-int init_ppo_chain();
-
 bool ppo_trunk_eligible(const xrl_ppo_fused_t& p) {
     if (p.n_layers != 4 || p.n_head_layers != 2 || p.n_levels != 4 || !p.frag_image || p.l0_fold_off <= 0) return false;
     const xrl_fused_layer_t &L0 = p.layers[0], &L1 = p.layers[1], &La = p.layers[2], &Lc = p.layers[3];
@@ -562,7 +558,7 @@ bool ppo_trunk_eligible(const xrl_ppo_fused_t& p) {
     if (p.dist != 0 && p.dist != 1) return false;
     if (p.dist == 1 && (p.log_std_off <= 0 || (p.out_act != XRL_ACT_NONE && p.out_act != XRL_ACT_TANH))) return false;
     if ((p.l0_fold_off & 3) || p.l0_fold_off + TH * D + TH > p.slab_stride) return false;
-    return p.pad0 == 0 || p.pad0 == 32 || p.pad0 == 64 || (p.pad0 == 66 && ppo_chain_eligible(p));   // 66: csrc/ppo_chain.hip
+    return p.pad0 == 0 || p.pad0 == 32 || p.pad0 == 64;   // (66 was round 4's register-chained variant: measured slower, tools/csrc/ppo_chain.hip)
 }
 
 template <int ACT, int HEAD, int DS, int AS>
@@ -585,7 +581,6 @@ static int launch_trunk_head(const xrl_ppo_fused_t& p, hipStream_t stream) {
 }
 
 int launch_ppo_trunk(const xrl_ppo_fused_t& p, hipStream_t stream) {
-    if (p.pad0 == 66) return launch_ppo_chain(p, stream);
     switch (p.layers[0].act) {
         case XRL_ACT_RELU: return launch_trunk_head<XRL_ACT_RELU>(p, stream);
         case XRL_ACT_LEAKY_RELU: return launch_trunk_head<XRL_ACT_LEAKY_RELU>(p, stream);
@@ -601,7 +596,6 @@ static int init_trunk_one() {
 }
 
 int init_ppo_trunk() {
-    if (int rc = init_ppo_chain()) return rc;
 #define TRUNK_INIT(a) \
     if (int rc = init_trunk_one<a, 0, 0, 0>()) return rc; \
     if (int rc = init_trunk_one<a, 0, 4, 2>()) return rc; \

@@ -302,9 +302,8 @@ class PPO_Learner(Learner):
         self.n_tiles = (bs + 31) // 32
         self.split = self.split_eligible(self.n_tiles)                 # role-split workgroups (csrc/ppo_trunk.hip)
         self.pair = self.pair_eligible(self.n_tiles)                   # ... on 64-row tiles
-        # ... with the forward / backward-data products as register chains (csrc/ppo_chain.hip: categorical head, A <= 4).  Off by
-        # default: measured in round 4 at 31.1 us per launch against 25.3 us for ppo_trunk_kernel
-        self.chain = self.pair and m.dist != "gaussian" and m.action_dim <= 4 and bool(getattr(self.config, "use_chain_update", False))
+        # (round 4's variant with register-chained forward / backward-data products -- 31.1 us per launch against 25.3 us for
+        #  ppo_trunk_kernel, DESIGN.md section 3 -- left the library in round 5: tools/csrc/ppo_chain.hip keeps the source)
         self.records = self.cartpole_class()                           # 32-byte transition records (obs[4] | act | ret | adv | logp)
         # gradient slabs: one per tile; with the role-split kernel a fold region behind the parameters takes the critic
         # role's first-layer gradient, and every (tile, role) workgroup has its own row of loss partials
@@ -427,7 +426,7 @@ class PPO_Learner(Learner):
                                 f_packed=self.packed if getattr(self, "_packed_valid", False) else None, f_rows=rows,
                                 partials=self.fpartials, diag=self.diag if self.keep_diag else None,
                                 slab_stride=self.slab_stride, l0_fold_off=fold[0] if fold else 0, M=M,
-                                n_envs=memory.n_envs, T=memory.n_size, D=m.obs_dim, A=m.action_dim, pad0=(66 if getattr(self, "chain", False) else 64) if pair else 0,
+                                n_envs=memory.n_envs, T=memory.n_size, D=m.obs_dim, A=m.action_dim, pad0=64 if pair else 0,
                                 dist=int(gauss), out_act=ops.ACT[m.activation_action] if gauss else 0,
                                 log_std_off=m.params.offsets[getattr(m, "log_std_name", "actor.log_std")] if gauss else 0,
                                 clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
