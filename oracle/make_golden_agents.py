@@ -371,8 +371,20 @@ def _marl_envs(Env, n, seed):
     return envs
 
 
-def golden_agent_qmix_ff():
-    """QMIX_Agents with configs/qmix/sc2/3m.yaml and representation Basic_MLP (feed-forward agents; parameter sharing, action masks,
+def golden_agent_vdn_ff():
+    golden_agent_qmix_ff("vdn")
+
+
+def golden_agent_iql_ff():
+    golden_agent_qmix_ff("iql")
+
+
+def golden_agent_qmix_ff(algo="qmix"):
+    """algo "vdn" / "iql": the same loop through VDN_Agents / IQL_Agents with configs/vdn/sc2/3m.yaml / configs/iql/sc2/3m.yaml (sum mixer /
+    independent learners; no global state is stored, off_policy_marl.py:97,151; IQL's epsilon decays by (start - end) /
+    decay_step_greedy per env step, iql_agents.py:37, VDN's and QMIX's by / (decay_step_greedy / n_envs), vdn_agents.py:38) ->
+    agent_{vdn,iql}_ff.npz (IQL: decay_step_greedy / n_envs times shorter so that both schedules reach their floor inside the run).
+    QMIX_Agents with configs/qmix/sc2/3m.yaml and representation Basic_MLP (feed-forward agents; parameter sharing, action masks,
     double-Q, global state) at 4 envs, a ring of 20 rows per env (it wraps), batch 8, start_training 16 (first update phase at
     vector step 4, `current_step >= start_training`, off_policy_marl.py:376), 2 updates every second vector step (training_frequency
     8 with current_step growing by 4), hard target sync every 4 updates, epsilon from 1.0 to 0.05 over 30 vector steps (ONE coin
@@ -385,8 +397,9 @@ def golden_agent_qmix_ff():
     am.SummaryWriter = _NullWriter
     opm.tqdm = _Quiet
     n, S, N, A = 4, 36, 3, 9
-    cfg = agent_config("qmix/sc2/3m.yaml", parallels=n, use_rnn=False, representation="Basic_MLP", buffer_size=n * 20, batch_size=8,
-                       start_training=n * 4, training_frequency=2 * n, n_epochs=2, sync_frequency=4, decay_step_greedy=n * n * 30, seed=3)
+    cfg = agent_config(f"{algo}/sc2/3m.yaml", parallels=n, use_rnn=False, representation="Basic_MLP", buffer_size=n * 20, batch_size=8,
+                       start_training=n * 4, training_frequency=2 * n, n_epochs=2, sync_frequency=4,
+                       decay_step_greedy=n * n * 30 if algo != "iql" else n * 30, seed=3)
     seed_all(cfg.seed)
     envs = _marl_envs(_smac_like_env(11), n, 21)
     envs.reset()
@@ -400,9 +413,10 @@ def golden_agent_qmix_ff():
             z_obs, z_av = {k: np.zeros(30, np.float32) for k in keys}, {k: np.zeros(A, np.float32) for k in keys}
             steps.append(dict(
                 stored_obs=_stack(kw["obs"], keys, np.float32), stored_avail=_stack(kw["avail_actions"], keys, np.float32),
-                stored_state=np.broadcast_to(np.asarray(kw["state"], np.float32), (n, 48)).copy(),
+                stored_state=np.broadcast_to(np.asarray(kw["state"], np.float32), (n, 48)).copy() if kw["state"] is not None else np.zeros((n, 48), np.float32),
                 acts=_stack(kw["acts"], keys).astype(np.int64), next_obs=_stack(kw["next_obs"], keys, np.float32),
-                next_state=np.asarray(kw["next_state"], np.float32), next_avail=_stack(kw["next_avail_actions"], keys, np.float32),
+                next_state=np.asarray(kw["next_state"] if kw["next_state"] is not None else [i["state"] for i in info], np.float32),
+                next_avail=_stack(kw["next_avail_actions"], keys, np.float32),
                 rewards=_stack(kw["rewards"], keys, np.float32), terminals=_stack(kw["terminals"], keys).astype(bool),
                 truncations=np.asarray(kw["truncations"], bool), agent_mask=_stack([i["agent_mask"] for i in info], keys).astype(bool),
                 reset_obs=_stack([i.get("reset_obs", z_obs) for i in info], keys, np.float32),
@@ -440,7 +454,7 @@ def golden_agent_qmix_ff():
         np.random.set_state(st)
         m = agent.memory
         env_c, step_c = np.random.choice(m.n_envs, m.batch_size), np.random.choice(m.size, m.batch_size)
-        assert np.array_equal(smp["state"], m.data["state"][env_c, step_c])
+        assert np.array_equal(smp["rewards"][keys[0]], m.data["rewards"][keys[0]][env_c, step_c])
         np.random.set_state(after)
         cb.indices.append(np.stack([env_c, step_c]))
         return smp
@@ -490,8 +504,9 @@ def golden_agent_qmix_ff():
                            11], np.float64)
     out["cfg_names"] = np.array("n_envs n_steps n_agents n_actions buffer_size batch_size gamma learning_rate start_training training_frequency "
                                 "n_epochs sync_frequency start_greedy end_greedy decay_step_greedy total_iters max_episode_steps".split())
-    np.savez_compressed(os.path.join(OUT, "agent_qmix_ff.npz"), **out)
-    print("agent_qmix_ff:", len(out), "arrays;", len(phases), "update phases; final epsilon", out["step/eps_after"][-1])
+    out["uses_global_state"] = np.int64(bool(agent.use_global_state))
+    np.savez_compressed(os.path.join(OUT, f"agent_{algo}_ff.npz"), **out)
+    print(f"agent_{algo}_ff:", len(out), "arrays;", len(phases), "update phases; final epsilon", out["step/eps_after"][-1])
 
 
 def golden_agent_qmix_rnn():
@@ -624,6 +639,6 @@ def golden_agent_qmix_rnn():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "dqn", "qmix_ff", "qmix_rnn"]
+    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "dqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
     for name in todo:
         globals()[f"golden_agent_{name}"]()

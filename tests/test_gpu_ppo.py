@@ -228,7 +228,7 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
                                  tol=1e-5, tol_except=C2_EXCEPT if size == "c2" else None)
         idx = torch.arange(n * T, dtype=torch.int64, device="cuda").view(1, -1)
         lr_.prepare_fused(mem, n * T)
-        assert lr_.split == (kernel in ("split", "pair", "chain")) and lr_.pair == (kernel in ("pair", "chain")) and lr_.chain == (kernel == "chain")
+        assert lr_.split == (kernel in ("split", "pair")) and lr_.pair == (kernel == "pair")
         lr_.prepare_rows(idx.numel())
         for u in range(int(g["n_updates"])):
             _load_rows(mem, sub(g, f"u{u}/batch"), n, T)

@@ -193,8 +193,11 @@ def stored_state_rule(cur_state, done_prev):
     return np.broadcast_to(cur_state[last], cur_state.shape).copy()
 
 
-def test_qmix_ff_agent_loop(oracle):
-    """core/off_policy_marl.py:358-424 with qmix_agents.py:40: per vector step the masked greedy actions of the shared Q network,
+@pytest.mark.parametrize("algo", ["qmix", "vdn", "iql"])
+def test_qmix_ff_agent_loop(oracle, algo):
+    """algo vdn / iql: VDN_Agents / IQL_Agents through the same loop (agent_{vdn,iql}_ff.npz): no global state is stored, the sum mixer /
+    independent TD, and IQL's epsilon decays by (start - end) / decay_step_greedy per env step (iql_agents.py:37).
+    core/off_policy_marl.py:358-424 with qmix_agents.py:40: per vector step the masked greedy actions of the shared Q network,
     ONE exploration coin for the whole step (:236: every agent of every env then takes a random AVAILABLE action), env step, store;
     an update phase of n_epochs updates when `current_step >= start_training and current_step % training_frequency == 0` (:376);
     epsilon = start - delta * current_step with delta = (start - end) / (decay_step_greedy / n_envs), clamped to end_greedy one
@@ -202,17 +205,20 @@ def test_qmix_ff_agent_loop(oracle):
     of a train() call are the vector env's lists after the step (aliases of DummyVecMultiAgentEnv.buf_obs / buf_avail_actions,
     off_policy_marl.py:358-359 with dummy_vec_maenv.py:74-75); the stored state after an episode end (stored_state_rule)."""
     o = oracle
-    g = load_golden("agent_qmix_ff")
+    g = load_golden(f"agent_{algo}_ff")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, S, N, A, B, E = (int(c[k]) for k in ("n_envs", "n_steps", "n_agents", "n_actions", "batch_size", "n_epochs"))
+    global_state = bool(g["uses_global_state"])
+    assert global_state == (algo == "qmix")
     sd = {k: v.copy() for k, v in sub(g, "init").items()}
     trainable = [k for k in sd if not k.startswith("target_")]
     opt = o.AdamOracle({k: sd[k] for k in trainable}, lr=c["learning_rate"], eps=1e-5, total_iters=int(c["total_iters"]))
     buf = o.MarlBufferOracle(n, int(c["buffer_size"]) // n, N, 30, A, 48)
     chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))      # (parameters: within what gradients agreeing at 1e-5 allow)
     init = sub(g, "init")
-    ocfg = dict(gamma=c["gamma"], double_q=True, use_actions_mask=True)
-    delta = (c["start_greedy"] - c["end_greedy"]) / (c["decay_step_greedy"] / n)
+    ocfg = dict(gamma=c["gamma"], double_q=True, use_actions_mask=True, mixer=algo)
+    ipre = "shared/" if algo == "iql" else ""                                        # (IQL's info keys carry the group, iql_learner.py:128-131)
+    delta = (c["start_greedy"] - c["end_greedy"]) / ((c["decay_step_greedy"] / n) if algo != "iql" else c["decay_step_greedy"])
     pe = "individual_q_networks.shared"
     obs, avail, state = g["acted_obs0"], g["acted_avail0"], g["acted_state0"]
     eps, cur, phase, updates, done_prev, ties = c["start_greedy"], 0, 0, 0, None, 0
@@ -233,7 +239,7 @@ def test_qmix_ff_agent_loop(oracle):
             assert np.array_equal(acts, g["step/greedy"][s])
         st_obs, st_avail = (obs, avail) if s > 0 else (g["step/next_obs"][0], g["step/next_avail"][0])   # (the alias, see docstring)
         assert np.array_equal(g["step/stored_obs"][s], st_obs) and np.array_equal(g["step/stored_avail"][s], st_avail)
-        st_state = stored_state_rule(state, done_prev)
+        st_state = stored_state_rule(state, done_prev) if global_state else np.zeros_like(state)
         assert np.array_equal(g["step/stored_state"][s], st_state), f"step {s}: stored state"
         buf.store(obs=st_obs, actions=acts, obs_next=g["step/next_obs"][s], rewards=g["step/rewards"][s], terminals=g["step/terminals"][s],
                   agent_mask=g["step/agent_mask"][s], state=st_state, state_next=g["step/next_state"][s], avail_actions=st_avail > 0,
@@ -248,7 +254,7 @@ def test_qmix_ff_agent_loop(oracle):
                 for name, rg in sub(g, f"phase{phase}/grad{e}").items():
                     assert_close(grads[name], rg, 1e-5, f"phase {phase} update {e}: gradient {name}")
                 ri = sub(g, f"phase{phase}/info{e}")
-                assert_close(info["loss"], ri["loss_Q"], 1e-5, "loss_Q")
+                assert_close(info["loss"], ri[ipre + "loss_Q"], 1e-5, "loss_Q")
                 opt.step(grads)
                 chain.step(sub(g, f"phase{phase}/grad{e}"))
                 updates += 1
@@ -269,7 +275,9 @@ def test_qmix_ff_agent_loop(oracle):
         assert eps == g["step/eps_after"][s] and cur == int(g["step/current_step"][s])
         assert buf.ptr == int(g["step/ptr"][s]) and buf.size == int(g["step/size"][s])
     assert phase == int(g["n_phases"]) and ties <= 3
-    for k, v in sub(g, "final_buffer").items():
+    fb = sub(g, "final_buffer")
+    assert ("state" in fb) == global_state
+    for k, v in fb.items():
         mine = buf.data[k]
         assert np.array_equal(np.asarray(mine, np.float32), np.asarray(v, np.float32).reshape(mine.shape)), f"final buffer field {k}"
 

@@ -24,7 +24,7 @@ def trunk(pad3=0):
                             f_logp=f["aux_old_logp"], idx=agent.idx[3], stats=lr.stats[3], slabs=lr.fslabs, partials=lr.fpartials,
                             diag=None, slab_stride=lr.slab_stride, l0_fold_off=lr.fold[0] if lr.fold else 0, M=bs, n_envs=n, T=256,
                             D=4, A=2, clip_range=0.2, vf_coef=0.25, ent_coef=0.01, frag_image=lr.frag, f_packed=lr.packed,
-                            f_rows=lr.rows[3 * bs * 8:4 * bs * 8], pad0=(66 if lr.chain else 64) if lr.pair else 0, pad3=pad3)
+                            f_rows=lr.rows[3 * bs * 8:4 * bs * 8], pad0=64 if lr.pair else 0, pad3=pad3)
 
 def adam():
     ops.reduce_adam(lr.fslabs, lr.n_slabs, lr.slab_stride, m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state, lr.sumsq, 0.5,
