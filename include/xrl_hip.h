@@ -504,6 +504,11 @@ typedef struct {
     int n, D, ld_next;
     int use_obsnorm, use_rewnorm, last_step;   // last_step: buffer becomes full -> every env closes its path
     float obs_range, rew_range, gamma;
+    /* NULL, or [n]: what PG_Agent's get_terminated_values returns for env e at the moment its path closes (pg_agent.py:66-79:
+     * _process_reward(rewards), i.e. the raw reward over the CURRENT return statistics): for an env whose episode ended in this step
+     * that is after ret_rms.update of every finished env up to and including itself (on_policy.py:272-283); at last_step and for
+     * every other env the value stored in rew_out */
+    float* pg_bootv;
 } xrl_poststep_t;
 int xrl_rollout_poststep(const xrl_poststep_t* p, xrl_stream_t stream);
 

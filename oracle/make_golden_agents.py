@@ -131,11 +131,16 @@ def golden_agent_ppo(kind="categorical"):
     class ShortCartPole(NumpyCartPoleEnv):
         max_episode_steps = 23
 
-    gauss = kind == "gaussian"
+    gauss, pg = kind == "gaussian", kind == "pg"
     agent_mod.SummaryWriter = _NullWriter
     pa.tqdm = lambda x, *a, **k: x
+    import xuance.torch.agents.core.on_policy as onp
+    onp.tqdm = lambda x, *a, **k: x
     n, T, rollouts = 8, 32, 3
-    if gauss:
+    if pg:
+        cfg = agent_config("pg/classic_control/CartPole-v1.yaml", parallels=n, horizon_size=T, seed=17)
+        Env, D = ShortCartPole, 4
+    elif gauss:
         cfg = agent_config("ppo/mujoco.yaml", parallels=n, horizon_size=T, n_epochs=1, n_minibatch=2, seed=13)   # (142 k parameters: one epoch keeps the file at 5 MB)
         Env, D = HostControlShapedEnv, 17
     else:
@@ -155,8 +160,10 @@ def golden_agent_ppo(kind="categorical"):
                 po = ag.model(torch.as_tensor(kw["obs"]))                     # (listening only: the distribution behind the sampled actions)
                 dist = dict(mu=po.distributions.mu.numpy().copy(), std=po.distributions.std.numpy().copy()) if gauss else \
                     dict(probs=po.distributions.probs.numpy().copy())
-            steps.append(dict(obs=np.array(kw["obs"], np.float32), acts=np.array(kw["acts"]), vals=np.array(kw["vals"], np.float32),
-                              logp=np.array(kw["aux_info"]["old_logp"], np.float32), next_obs=np.array(kw["next_obs"], np.float32),
+            logp = kw["aux_info"]["old_logp"] if kw["aux_info"] and "old_logp" in kw["aux_info"] else np.zeros(n)   # (PG: get_aux_info() is empty)
+            steps.append(dict(obs=np.array(kw["obs"], np.float32), acts=np.array(kw["acts"]),
+                              vals=np.broadcast_to(np.asarray(kw["vals"], np.float32), (n,)).copy(),       # (PG: the scalar 0, on_policy.py:160)
+                              logp=np.array(logp, np.float32), next_obs=np.array(kw["next_obs"], np.float32),
                               rewards=np.array(kw["rewards"], np.float32), terminals=np.array(kw["terminals"]),
                               truncations=np.array(kw["truncations"]), **dist,
                               reset_obs=np.stack([np.asarray(i.get("reset_obs", np.zeros(D)), np.float32) for i in kw["infos"]]),
@@ -167,7 +174,8 @@ def golden_agent_ppo(kind="categorical"):
             m = kw["memory"]
             ph = dict(buffer={k: np.array(getattr(m, k)).copy() for k in ("observations", "actions", "rewards", "returns", "values",
                                                                           "terminals", "advantages")},
-                      old_logp=np.array(m.auxiliary_infos["old_logp"]).copy(), param=sd_np(kw["policy"]),
+                      old_logp=np.array(m.auxiliary_infos["old_logp"]).copy() if m.auxiliary_infos and "old_logp" in m.auxiliary_infos else np.zeros((n, T), np.float32),
+                      param=sd_np(kw["policy"] if "policy" in kw else kw["model"]),
                       info={k: np.float64(v) for k, v in kw["update_info"].items() if np.isscalar(v)},
                       indices=np.stack(self.indices), iterations=np.int64(self.agent.learner.iterations), grads=self.grads)
             self.indices, self.grads = [], []
@@ -209,18 +217,26 @@ def golden_agent_ppo(kind="categorical"):
             out.update(mg.flat(f"phase{p}/grad{u}", g))
     term, trunc = out["step/terminals"], out["step/truncations"]
     assert term.sum() > 8 and (trunc & ~term).sum() > 8, (term.sum(), trunc.sum())
-    out["cfg"] = np.array([n, T, cfg.n_epochs, cfg.n_minibatch, cfg.gamma, cfg.gae_lambda, cfg.learning_rate, cfg.vf_coef, cfg.ent_coef,
-                           cfg.clip_range, cfg.grad_clip_norm, cfg.obsnorm_range, cfg.rewnorm_range, agent.learner.total_iters,
+    out["cfg"] = np.array([n, T, cfg.n_epochs, cfg.n_minibatch, cfg.gamma, cfg.gae_lambda, cfg.learning_rate, getattr(cfg, "vf_coef", 0.0), cfg.ent_coef,
+                           getattr(cfg, "clip_range", 0.0), cfg.grad_clip_norm, cfg.obsnorm_range, cfg.rewnorm_range, agent.learner.total_iters,
                            Env.max_episode_steps], np.float64)
     out["cfg_names"] = np.array("n_envs horizon_size n_epochs n_minibatch gamma gae_lambda learning_rate vf_coef ent_coef clip_range "
                                 "grad_clip_norm obsnorm_range rewnorm_range total_iters max_episode_steps".split())
-    name = "agent_ppo_gaussian" if gauss else "agent_ppo"
+    name = "agent_pg" if pg else "agent_ppo_gaussian" if gauss else "agent_ppo"
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name + ":", len(out), "arrays;", int(term.sum()), "terminations,", int((trunc & ~term).sum()), "truncations")
 
 
 def golden_agent_ppo_gaussian():
     golden_agent_ppo("gaussian")
+
+
+def golden_agent_pg():
+    """PG_Agent (agents/policy_gradient/pg_agent.py:12-79 on the generic loop core/on_policy.py:232-300) with
+    configs/pg/classic_control/CartPole-v1.yaml: actor-only VanillaPolicyGradient, stored values 0, discounted-sum returns
+    (use_gae False, advantage normalisation off), a cut path closes with the PROCESSED REWARD of its last step
+    (get_terminated_values, pg_agent.py:66-79), one update per rollout -> agent_pg.npz."""
+    golden_agent_ppo("pg")
 
 
 # ------------------------------------------------------------------------------------------------------------------ DQN
@@ -639,6 +655,6 @@ def golden_agent_qmix_rnn():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "dqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
+    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "pg", "dqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
     for name in todo:
         globals()[f"golden_agent_{name}"]()

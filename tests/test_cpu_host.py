@@ -49,6 +49,7 @@ def test_ctypes_structs_match_c_layout():
     src += 'printf("wide.obs %zu\\n", offsetof(xrl_ppo_wide_t, obs));\nprintf("wide.dbg %zu\\n", offsetof(xrl_ppo_wide_t, dbg));\n'
     src += 'printf("loss.M %zu\\n", offsetof(xrl_ppo_loss_t, M));\n'
     offs = {"xrl_mirrors_t": (_lib.Mirrors, ("tick", "part_out", "tick_inc", "part_rows", "alt_lo", "alt_hi", "alt_split")),   # fields added in rounds 3, 4
+            "xrl_poststep_t": (_lib.PostStep, ("ret_count", "n", "gamma", "pg_bootv")),
             "xrl_marl_gate_t": (_lib.MarlGate, ("ring", "reset_rule", "done", "ptr_size", "buffer_size", "end_step")),   # round 5
             "xrl_egreedy_t": (_lib.EGreedy, ("eps", "seed", "step_dev")), "xrl_marl_act_t": (_lib.MarlAct, ("eps", "seed")),
             "xrl_marl_act_gru_t": (_lib.MarlActGru, ("eps_dev", "step", "eps")),

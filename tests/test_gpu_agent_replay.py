@@ -389,3 +389,58 @@ def test_qmix_rnn_agents_replay_the_reference_run():
     for k, v in sub(g, "final_buffer").items():
         mine = npy(mem.data[k])
         assert np.array_equal(mine.reshape(-1), np.asarray(v, np.float32).reshape(-1)), f"episode ring field {k}"
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_pg_agent_replays_the_reference_run(use_graph):
+    """agent_pg.npz: the reference's PG_Agent (configs/pg/classic_control/CartPole-v1.yaml: actor-only policy, stored values 0,
+    discounted-sum returns, no advantage normalisation) over three rollouts of 8 envs x 32 steps (30 terminations, 13 truncations),
+    one whole-buffer update per rollout.  What this pins beyond the PPO replay: the value that closes a CUT path -- the processed
+    reward of its last step over the return statistics as they are AFTER ret_rms.update of the finished envs up to and including the
+    env itself (pg_agent.py:66-79 called from on_policy.py:272-283; xrl_poststep_t.pg_bootv) -- visible in `returns`."""
+    from xuance_amd.agents import PG_Agent
+    from xuance_amd.envs import RecordedVecEnv
+    from xuance_amd.spaces import Discrete
+    g = load_golden("agent_pg")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, T = int(c["n_envs"]), int(c["horizon_size"])
+    S = g["step/acts"].shape[0]
+    rollouts = S // T
+    env = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
+                         g["step/reset_obs"], action_space=Discrete(2), max_episode_steps=int(c["max_episode_steps"]))
+    env.prepare(T)
+    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128], activation="relu", seed=1,
+                    parallels=n, running_steps=10 ** 6, horizon_size=T, n_epochs=1, n_minibatch=1, learning_rate=c["learning_rate"],
+                    ent_coef=c["ent_coef"], gamma=c["gamma"], use_gae=False, gae_lambda=c["gae_lambda"], use_advnorm=False,
+                    use_grad_clip=True, grad_clip_norm=c["grad_clip_norm"], use_obsnorm=True, use_rewnorm=True,
+                    obsnorm_range=c["obsnorm_range"], rewnorm_range=c["rewnorm_range"], distributed_training=False, device="cuda",
+                    model_dir="/tmp/xrl_models", use_hip_graph=use_graph)
+    agent = PG_Agent(cfg, env)
+    init = sub(g, "init")
+    assert list(agent.model.ref_order) == list(init) and agent.learner.total_iters == int(c["total_iters"])
+    agent.model.load_state_dict(init)
+    noise = categorical_uniforms(g["step/probs"], g["step/acts"]).reshape(rollouts, T, n)
+    chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))
+    f = agent.memory.soa.fields
+    tm = lambda a: np.swapaxes(np.asarray(a), 0, 1)
+    for p in range(rollouts):
+        agent.set_action_noise(noise[p])
+        agent.set_indices(g[f"phase{p}/indices"])
+        agent.rollout()
+        torch.cuda.synchronize()
+        buf, last = sub(g, f"phase{p}/buffer"), (p + 1) * T - 1
+        assert np.array_equal(npy(f["actions"]), tm(buf["actions"])) and np.array_equal(npy(f["terminals"]) > 0, tm(buf["terminals"]) > 0)
+        assert not npy(f["values"]).any() and not buf["values"].any()
+        assert_close(npy(f["observations"]), tm(buf["observations"]), 1e-5, f"rollout {p}: stored observations")
+        assert_close(npy(f["rewards"]), tm(buf["rewards"]), 1e-5, f"rollout {p}: stored rewards")
+        assert_close(npy(f["returns"]), tm(buf["returns"]), 1e-5, f"rollout {p}: returns (cut paths closed with the processed reward)")
+        assert_close(npy(f["advantages"]), tm(buf["advantages"]), 1e-5, f"rollout {p}: advantages", scale=float(np.abs(buf["returns"]).max()))
+        assert_close(npy(agent.ret_var)[0], g["step/ret_rms/var"][last], 1e-5, "ret_rms.var")
+        assert_close(npy(agent.returns), g["step/returns_track"][last], 1e-5, "return tracker", scale=max(1.0, float(np.abs(g["step/returns_track"][last]).max())))
+        info = agent.update()
+        ri = sub(g, f"phase{p}/info")
+        assert_close(info["actor-loss"], ri["actor-loss"], 1e-5, f"phase {p} actor-loss", scale=max(1.0, abs(float(ri["actor-loss"]))))
+        assert_close(info["entropy"], ri["entropy"], 1e-5, f"phase {p} entropy")
+        chain.step(sub(g, f"phase{p}/grad0"))
+        got = {k: npy(v) for k, v in agent.model.state_dict().items()}
+        chain.check(got, sub(g, f"phase{p}/param"), init, what=f"phase {p} param")

@@ -113,6 +113,72 @@ def test_ppo_agent_loop(oracle, kind):
     assert phase == S // T == 3
 
 
+def test_pg_agent_loop(oracle):
+    """pg_agent.py:12-79 on the generic on-policy loop (core/on_policy.py:232-300), agent_pg.npz: actor-only policy (relu), the stored
+    value of every step is 0 (on_policy.py:160), a path that is cut -- truncation or buffer end -- closes with the PROCESSED REWARD of
+    its last step (get_terminated_values(next_obs, rewards) = _process_reward(rewards), pg_agent.py:66-79), a terminated one with 0;
+    configs/pg/classic_control/CartPole-v1.yaml: use_gae False (returns = discounted reward sums, advantages = rewards + gamma v' - v
+    with v = 0), no advantage normalisation, ONE update on the whole buffer per rollout (PG_Learner: -mean(returns log_prob) - ent_coef H)."""
+    o = oracle
+    g = load_golden("agent_pg")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, T = int(c["n_envs"]), int(c["horizon_size"])
+    S = g["step/acts"].shape[0]
+    sd = {k: v.copy() for k, v in sub(g, "init").items()}
+    opt = o.AdamOracle(sd, lr=c["learning_rate"], eps=1e-5, total_iters=int(c["total_iters"]))
+    obs_rms, ret_rms = o.RunningMeanStdOracle((4,)), o.RunningMeanStdOracle(())
+    returns = np.zeros(n, np.float32)
+    buf = o.OnPolicyBufferOracle((4,), (), n, T, gamma=c["gamma"], gae_lam=c["gae_lambda"], use_gae=False, use_advnorm=False)
+    rep = lambda x: o.MLP(o.collect_seq(sd, "actor.actor_head.logits", "relu")).forward(
+        o.MLP(o.collect_seq(sd, "actor.representation.model", "relu", last_act="relu")).forward(x))
+    raw, phase = g["raw_obs0"].copy(), 0
+    for s in range(S):
+        obs_rms.update(raw)
+        obs_n = o.process_observation(raw, obs_rms, c["obsnorm_range"]).astype(np.float32)
+        assert_close(obs_n, g["step/obs"][s], 1e-6, f"step {s}: normalised obs")
+        probs = np.exp(o.log_softmax(rep(obs_n)))
+        assert_close(probs, g["step/probs"][s], 1e-5, f"step {s}: action probabilities")
+        acts = g["step/acts"][s]
+        assert not g["step/vals"][s].any()
+        next_obs, rew, term, trunc = g["step/next_obs"][s], g["step/rewards"][s], g["step/terminals"][s], g["step/truncations"][s]
+        rew_n = o.process_reward(rew, ret_rms, c["rewnorm_range"])
+        buf.store(obs_n, acts, rew_n, np.zeros(n, np.float32), term, None)
+        if buf.full:
+            for i in range(n):
+                buf.finish_path(0.0 if term[i] else rew_n[i], i)
+            ref = sub(g, f"phase{phase}/buffer")
+            assert np.array_equal(buf.actions, ref["actions"]) and np.array_equal(buf.terminals > 0, ref["terminals"] > 0)
+            for k in ("observations", "rewards", "returns", "advantages"):
+                assert_close(getattr(buf, k), ref[k], 1e-5, f"phase {phase}: buffer {k}", scale=float(np.abs(ref["returns"]).max()) if k == "advantages" else None)
+            idx = g[f"phase{phase}/indices"]
+            assert idx.shape == (1, n * T) and np.array_equal(np.sort(idx[0]), np.arange(n * T))
+            b = buf.sample(idx[0])
+            info, grads = o.pg_forward_backward(sd, dict(obs=b["obs"], actions=b["actions"], returns=b["returns"]), dict(ent_coef=c["ent_coef"]), act="relu")
+            o.AdamOracle.clip_grad_norm_(grads, c["grad_clip_norm"])
+            for name, rg in sub(g, f"phase{phase}/grad0").items():
+                assert_close(grads[name], rg, 3e-5 if name.endswith("logits.2.bias") else 1e-5, f"phase {phase}: clipped gradient {name}")   # (the 2-element head bias: tests/test_oracle_vs_golden.py: test_pg_update)
+            opt.step(grads)
+            ri = sub(g, f"phase{phase}/info")
+            assert_close(info["a_loss"], ri["actor-loss"], 1e-5, "actor-loss", scale=float(np.abs(info["log_prob"]).mean()))
+            assert_close(info["e_loss"], ri["entropy"], 1e-5, "entropy")
+            for name, rp in sub(g, f"phase{phase}/param").items():
+                moved = float(np.abs(rp - g[f"init/{name}"]).max())
+                assert_close(sd[name], rp, 2e-4, f"phase {phase}: parameter {name} (relative to the distance it moved)", scale=moved)
+            buf.clear()
+            phase += 1
+        returns = (c["gamma"] * returns + rew).astype(np.float32)
+        raw = next_obs.copy()
+        for i in range(n):
+            if term[i] or trunc[i]:
+                ret_rms.update(returns[i:i + 1])
+                returns[i] = 0.0
+                buf.finish_path(0 if term[i] else o.process_reward(rew, ret_rms, c["rewnorm_range"])[i], i)   # (:279-283: AFTER ret_rms.update of this env)
+                raw[i] = g["step/reset_obs"][s][i]
+        assert_close(returns, g["step/returns_track"][s], 1e-5, f"step {s}: return tracker", scale=max(1.0, float(np.abs(g["step/returns_track"][s]).max())))
+        assert_close(ret_rms.var, g["step/ret_rms/var"][s], 1e-5, "ret_rms.var")
+    assert phase == 3
+
+
 def test_dqn_agent_loop(oracle):
     """core/off_policy.py:183-270 with dqn_agent.py:28-30: per vector step (obs_rms / normalisation are off in configs/dqn/*.yaml)
     greedy action of the eval network, the per-env coin `torch.rand(n) < e_greedy` against random actions (:138-141), env step, store

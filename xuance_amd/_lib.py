@@ -110,7 +110,7 @@ class PostStep(C.Structure):
                 ("term_out", c_void_p), ("seg_out", c_void_p), ("ret_track", c_void_p), ("ret_mean", c_void_p),
                 ("ret_var", c_void_p), ("ret_count", c_void_p), ("n", c_int), ("D", c_int), ("ld_next", c_int),
                 ("use_obsnorm", c_int), ("use_rewnorm", c_int), ("last_step", c_int), ("obs_range", c_float),
-                ("rew_range", c_float), ("gamma", c_float)]
+                ("rew_range", c_float), ("gamma", c_float), ("pg_bootv", c_void_p)]
 
 
 class EGreedy(C.Structure):

@@ -930,6 +930,7 @@ class PG_Agent(PPO_Agent):
                           normalize=int(self.use_obsnorm), range=float(self.obsnorm_range))
         heads = self.model.forward(self.X, n)
         ops.policy_sample(heads=heads, log_std=self.model.params.ptr(self.model.log_std_name) if gaussian else None,
+                          noise=None if self.action_noise is None else self.action_noise[t],
                           act_out=f["actions"][t], val_out=None, logp_out=f["aux_old_logp"][t],
                           env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
                           bootv_prev=None, n=n, A=A, ld=self.model.head_ld, gaussian=int(gaussian),
@@ -938,16 +939,15 @@ class PG_Agent(PPO_Agent):
             env.step_device(offset=t)
         else:
             env.step_device()
+        # get_terminated_values = the processed reward (pg_agent.py:66-79) over the return statistics of the moment the path closes:
+        # written by the same launch (xrl_poststep_t.pg_bootv); terminated envs close with 0 (seg bit 2)
         ops.rollout_poststep(reward=env.reward, terminated=env.terminated, truncated=env.truncated, next_obs=env.next_obs,
                              obs_mean=self.obs_mean, obs_var=self.obs_var, next_obs_norm=self.X[n:], rew_out=f["rewards"][t],
                              term_out=f["terminals"][t], seg_out=f["seg"][t], ret_track=self.returns,
                              ret_mean=self.ret_mean, ret_var=self.ret_var, ret_count=self.ret_count, n=n, D=D, ld_next=D,
                              use_obsnorm=int(self.use_obsnorm), use_rewnorm=int(self.use_rewnorm),
                              last_step=int(t == self.horizon_size - 1), obs_range=float(self.obsnorm_range),
-                             rew_range=float(self.rewnorm_range), gamma=float(self.gamma))
-        # get_terminated_values = the processed reward (pg_agent.py:66-79); terminated envs close with 0 (seg bit 2)
-        torch.mul(f["rewards"][t], 1.0, out=f["bootv"][t])      # (an elementwise KERNEL: a D2D copy would become a memcpy node
-        #                                                            when this step is captured, see csrc/rollout_actor.hip)
+                             rew_range=float(self.rewnorm_range), gamma=float(self.gamma), pg_bootv=f["bootv"][t])
 
     def _enqueue_rollout(self):
         T = self.horizon_size

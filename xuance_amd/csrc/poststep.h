@@ -18,6 +18,7 @@ __device__ __forceinline__ void poststep_body(const xrl_poststep_t& p, unsigned 
         float rn = r;
         if (p.use_rewnorm) rn = fminf(fmaxf(r / rstd, -p.rew_range), p.rew_range);
         p.rew_out[e] = rn;
+        if (p.pg_bootv) p.pg_bootv[e] = rn;
         const bool term = p.terminated[e] != 0.f, trunc = p.truncated[e] != 0.f;
         p.term_out[e] = term ? 1.f : 0.f;
         uint8_t sg = 0;
@@ -66,6 +67,14 @@ __device__ __forceinline__ void poststep_body(const xrl_poststep_t& p, unsigned 
                     const float M2 = m_a + m_b + (delta * delta) * (float)count * 1.0f / (float)tot;
                     mean = new_mean; var = M2 / (float)tot; count = tot;
                     p.ret_track[e] = 0.f;
+                    if (p.pg_bootv && !p.last_step) {                // the closing value of THIS env's path: its reward over the statistics
+                        float v = p.reward[e];                      // as they are now (get_terminated_values is called after the update)
+                        if (p.use_rewnorm) {
+                            const float sd = fminf(fmaxf(sqrtf(var), 0.1f), 100.f);
+                            v = fminf(fmaxf(v / sd, -p.rew_range), p.rew_range);
+                        }
+                        p.pg_bootv[e] = v;
+                    }
                 }
             }
             *p.ret_mean = mean; *p.ret_var = var; *p.ret_count = count;
