@@ -240,7 +240,43 @@ def golden_agent_pg():
 
 
 # ------------------------------------------------------------------------------------------------------------------ DQN
-def golden_agent_dqn():
+class HostAtariShapedEnv:
+    """Host stand-in with Atari's shapes (84x84x4 uint8 frame stacks, Discrete(4)): blocky frames of four grey levels (the fixture
+    compresses), a small termination probability, a cut at max_episode_steps; no emulator is in the image."""
+    max_episode_steps = 9
+
+    def __init__(self, env_seed=None):
+        self.observation_space, self.action_space = sp.Box(0, 255, (84, 84, 4), np.uint8), sp.Discrete(4)
+        self.rng = np.random.default_rng(env_seed)
+        self.steps = 0
+
+    def _frame(self):
+        return np.kron(self.rng.integers(0, 4, (7, 7, 4)) * 85, np.ones((12, 12, 1), np.int64)).astype(np.uint8)
+
+    def reset(self, seed=None):
+        self.steps = 0
+        return self._frame(), {}
+
+    def step(self, action):
+        self.steps += 1
+        r = float(self.rng.integers(0, 3))
+        term = bool(self.rng.random() < 0.08)
+        return self._frame(), r, term, self.steps >= self.max_episode_steps, {}
+
+    def close(self):
+        pass
+
+
+def golden_agent_dqn_atari():
+    """DQN_Agent with configs/dqn/atari.yaml (BASELINE configs[2]'s network: Basic_CNN 32/64/64 + global max-pool + 64-512-4, uint8
+    replay buffer DummyOffPolicyBuffer_Atari, no normalisation) at 4 envs, a ring of 12 rows per env (it wraps), batch 8, 22 vector
+    steps on the Atari-shaped host env behind DummyVecEnv_Atari.  Atari mode of the loop (off_policy.py:240-242): an env that
+    TERMINATED without truncation keeps acting on its next observation -- no reset_obs, no ret_rms update, no episode count -- only a
+    truncation restarts it -> agent_dqn_atari.npz."""
+    golden_agent_dqn(atari=True)
+
+
+def golden_agent_dqn(atari=False):
     """DQN_Agent with configs/dqn/classic_control/CartPole-v1.yaml (network 4-128-128-2, MSE TD loss, no normalisation, no
     clipping) at 8 envs, a replay ring of 16 rows per env (it wraps three times), batch 16, start_training 48, an update every
     second vector step (training_frequency 16 with current_step growing by 8), hard target sync every 5 updates, epsilon from 0.5
@@ -259,21 +295,32 @@ def golden_agent_dqn():
 
     agent_mod.SummaryWriter = _NullWriter
     op.tqdm = lambda x, *a, **k: x
-    n, S, A = 8, 64, 2
-    cfg = agent_config("dqn/classic_control/CartPole-v1.yaml", parallels=n, buffer_size=n * 16, batch_size=16, start_training=n * 6,
-                       training_frequency=16, sync_frequency=5, decay_step_greedy=n * n * 30, seed=5)
-    seed_all(cfg.seed)
-    envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 3)
-    envs.observation_space, envs.action_space = sp.Box(-np.inf, np.inf, (4,), np.float32), sp.Discrete(A)
+    if atari:
+        from xuance.environment.vector_envs.dummy.dummy_vec_env import DummyVecEnv_Atari
+        n, S, A = 4, 22, 4
+        cfg = agent_config("dqn/atari.yaml", parallels=n, buffer_size=n * 12, batch_size=8, start_training=n * 3, training_frequency=2 * n,
+                           sync_frequency=3, decay_step_greedy=n * n * 20, seed=9)
+        seed_all(cfg.seed)
+        envs = DummyVecEnv_Atari([lambda env_seed: XuanCeEnvWrapper(HostAtariShapedEnv(env_seed=env_seed))] * n, 3)
+        envs.observation_space, envs.action_space = sp.Box(0, 255, (84, 84, 4), np.uint8), sp.Discrete(A)
+        odt, oshape, Env = np.uint8, (84, 84, 4), HostAtariShapedEnv
+    else:
+        n, S, A = 8, 64, 2
+        cfg = agent_config("dqn/classic_control/CartPole-v1.yaml", parallels=n, buffer_size=n * 16, batch_size=16, start_training=n * 6,
+                           training_frequency=16, sync_frequency=5, decay_step_greedy=n * n * 30, seed=5)
+        seed_all(cfg.seed)
+        envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 3)
+        envs.observation_space, envs.action_space = sp.Box(-np.inf, np.inf, (4,), np.float32), sp.Discrete(A)
+        odt, oshape, Env = np.float32, (4,), ShortCartPole
     envs.reset()
     out, steps, phases = {}, [], []
 
     class Rec(BaseCallback):
         def on_train_step(self, current_step, **kw):
-            steps.append(dict(obs=np.array(kw["obs"], np.float32), acts=np.array(kw["policy_out"].env_actions), next_obs=np.array(kw["next_obs"], np.float32),
+            steps.append(dict(obs=np.array(kw["obs"], odt), acts=np.array(kw["policy_out"].env_actions), next_obs=np.array(kw["next_obs"], odt),
                               rewards=np.array(kw["rewards"], np.float32), terminals=np.array(kw["terminals"]),
                               truncations=np.array(kw["truncations"]), eps_acted=np.float64(self.agent.e_greedy),
-                              reset_obs=np.stack([np.asarray(i.get("reset_obs", np.zeros(4)), np.float32) for i in kw["infos"]]),
+                              reset_obs=np.stack([np.asarray(i.get("reset_obs", np.zeros(oshape)), odt) for i in kw["infos"]]),
                               step_index=np.int64(current_step), **self.draw))
 
         def on_train_epochs_end(self, current_step, **kw):
@@ -324,13 +371,13 @@ def golden_agent_dqn():
         return acts
     agent.memory.sample, agent.learner.update, agent.exploration = sample, update, exploration
     out.update(mg.flat("init", sd_np(agent.model)))
-    out["raw_obs0"] = np.array(envs.buf_obs, np.float32).copy()
+    out["raw_obs0"] = np.array(envs.buf_obs, odt).copy()
     agent.train(S)
     assert len(steps) == S
     for k in steps[0]:
         out[f"step/{k}"] = np.stack([s[k] for s in steps])
     for p, ph in enumerate(phases):
-        if p < 2 or p % 5 == 4 or p == len(phases) - 1:              # (parameter snapshots of some phases: every target sync is among them)
+        if (p % 3 == 2 or p == len(phases) - 1) if atari else (p < 2 or p % 5 == 4 or p == len(phases) - 1):   # (snapshots of some phases: every target sync is among them)
             out.update(mg.flat(f"phase{p}/param", ph["param"]))
         out.update(mg.flat(f"phase{p}/info", ph["info"]))
         out[f"phase{p}/indices"], out[f"phase{p}/iterations"], out[f"phase{p}/at_step"] = ph["indices"], ph["iterations"], ph["at_step"]
@@ -341,15 +388,16 @@ def golden_agent_dqn():
     out.update(mg.flat("final_buffer", {k: np.array(getattr(m, k)).copy() for k in ("observations", "next_observations", "actions", "rewards", "terminals")}))
     term, trunc = out["step/terminals"], out["step/truncations"]
     explored = out["step/coin"] < out["step/eps_acted"][:, None]
-    assert term.sum() > 8 and (trunc & ~term).sum() > 4 and explored.sum() > 20 and (~explored).sum() > 200
-    assert out["step/eps_after"][-1] <= cfg.end_greedy and len(np.unique(out["step/eps_after"])) > 20
+    assert term.sum() > (4 if atari else 8) and (trunc & ~term).sum() > 4 and explored.sum() > (5 if atari else 20) and (~explored).sum() > (50 if atari else 200)
+    assert out["step/eps_after"][-1] <= cfg.end_greedy and len(np.unique(out["step/eps_after"])) > (10 if atari else 20)
     out["cfg"] = np.array([n, S, cfg.buffer_size, cfg.batch_size, cfg.gamma, cfg.learning_rate, cfg.start_training, cfg.training_frequency,
                            cfg.sync_frequency, cfg.start_greedy, cfg.end_greedy, cfg.decay_step_greedy, agent.learner.total_iters,
-                           ShortCartPole.max_episode_steps], np.float64)
+                           Env.max_episode_steps], np.float64)
     out["cfg_names"] = np.array("n_envs n_steps buffer_size batch_size gamma learning_rate start_training training_frequency sync_frequency "
                                 "start_greedy end_greedy decay_step_greedy total_iters max_episode_steps".split())
-    np.savez_compressed(os.path.join(OUT, "agent_dqn.npz"), **out)
-    print("agent_dqn:", len(out), "arrays;", len(phases), "update phases,", int(term.sum()), "terminations,", int((trunc & ~term).sum()),
+    name = "agent_dqn_atari" if atari else "agent_dqn"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ":", len(out), "arrays;", len(phases), "update phases,", int(term.sum()), "terminations,", int((trunc & ~term).sum()),
           "truncations,", int(explored.sum()), "explored actions; final epsilon", out["step/eps_after"][-1])
 
 
@@ -655,6 +703,6 @@ def golden_agent_qmix_rnn():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "pg", "dqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
+    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "pg", "dqn", "dqn_atari", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
     for name in todo:
         globals()[f"golden_agent_{name}"]()

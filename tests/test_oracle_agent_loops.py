@@ -179,32 +179,37 @@ def test_pg_agent_loop(oracle):
     assert phase == 3
 
 
-def test_dqn_agent_loop(oracle):
-    """core/off_policy.py:183-270 with dqn_agent.py:28-30: per vector step (obs_rms / normalisation are off in configs/dqn/*.yaml)
+@pytest.mark.parametrize("atari", [False, True])
+def test_dqn_agent_loop(oracle, atari):
+    """atari: agent_dqn_atari.npz (configs/dqn/atari.yaml: uint8 frame stacks, Basic_CNN) -- the oracle has no convolutions, so the
+    Q values are not recomputed there (the device replay does that); everything else of the loop is, plus the Atari rule: an env that
+    terminated WITHOUT truncation keeps acting on its next observation (off_policy.py:240-242).
+    core/off_policy.py:183-270 with dqn_agent.py:28-30: per vector step (obs_rms / normalisation are off in configs/dqn/*.yaml)
     greedy action of the eval network, the per-env coin `torch.rand(n) < e_greedy` against random actions (:138-141), env step, store
     (obs, action, reward, TERMINATED flag, next_obs) at the ring's write position; an update phase when `current_step >
     start_training and current_step % training_frequency == 0` (:228) on `np.random.choice` (env, step < size) pairs; then
     current_step += n_envs and the epsilon schedule (:119-127: recomputed while the PREVIOUS value is above end_greedy, so it
     undershoots the floor once -- the fixture ends at -0.0063)."""
     o = oracle
-    g = load_golden("agent_dqn")
+    g = load_golden("agent_dqn_atari" if atari else "agent_dqn")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, S, B = int(c["n_envs"]), int(c["n_steps"]), int(c["batch_size"])
     sd = {k: v.copy() for k, v in sub(g, "init").items()}
     trainable = [k for k in sd if not k.startswith("target_")]
     opt = o.AdamOracle({k: sd[k] for k in trainable}, lr=c["learning_rate"], eps=1e-5, total_iters=int(c["total_iters"]))
-    buf = o.OffPolicyBufferOracle((4,), (), n, int(c["buffer_size"]), B)
+    buf = o.OffPolicyBufferOracle(g["raw_obs0"].shape[1:], (), n, int(c["buffer_size"]), B, obs_dtype=g["raw_obs0"].dtype)
     eps_seq = o.egreedy_schedule(c["start_greedy"], c["end_greedy"], c["decay_step_greedy"], n, S + 1)
     raw = g["raw_obs0"].copy()
     cur, phase, updates, flips = 0, 0, 0, 0
     for s in range(S):
         assert eps_seq[s] == g["step/eps_acted"][s] and int(g["step/step_index"][s]) == cur
-        q = o.MLP(o.collect_seq(sd, "eval_Q_head.q_value", "relu")).forward(
-            o.MLP(o.collect_seq(sd, "representation.model", "relu", last_act="relu")).forward(raw))
-        greedy = q.argmax(-1)
-        for e in np.flatnonzero(greedy != g["step/greedy"][s]):                     # an argmax may flip only on a tie at 1e-5
-            assert abs(q[e, 0] - q[e, 1]) < 1e-5 * max(1.0, np.abs(q[e]).max()), (s, e, q[e])
-            flips += 1
+        if not atari:
+            q = o.MLP(o.collect_seq(sd, "eval_Q_head.q_value", "relu")).forward(
+                o.MLP(o.collect_seq(sd, "representation.model", "relu", last_act="relu")).forward(raw))
+            greedy = q.argmax(-1)
+            for e in np.flatnonzero(greedy != g["step/greedy"][s]):                 # an argmax may flip only on a tie at 1e-5
+                assert abs(q[e, 0] - q[e, 1]) < 1e-5 * max(1.0, np.abs(q[e]).max()), (s, e, q[e])
+                flips += 1
         acts = o.egreedy_select(g["step/greedy"][s], g["step/random_actions"][s], g["step/coin"][s], np.float32(eps_seq[s]))
         assert np.array_equal(acts, g["step/acts"][s]), f"step {s}: actions"
         next_obs, rew, term, trunc = g["step/next_obs"][s], g["step/rewards"][s], g["step/terminals"][s], g["step/truncations"][s]
@@ -224,20 +229,22 @@ def test_dqn_agent_loop(oracle):
             assert int(g[f"phase{phase}/at_step"]) == s
             env_c, step_c = g[f"phase{phase}/indices"][0]
             assert step_c.max() < buf.size
-            info, grads = o.dqn_forward_backward(sd, buf.sample_at(env_c, step_c), dict(gamma=c["gamma"]))
-            for name, rg in sub(g, f"phase{phase}/grad0").items():
-                assert_close(grads[name], rg, 1e-5, f"phase {phase}: gradient {name}")
-            assert_close(info["loss"], g[f"phase{phase}/info/Qloss"], 1e-5, "Qloss")
-            opt.step(grads)
             updates += 1
-            if updates % int(c["sync_frequency"]) == 0:
-                o.dqn_copy_target(sd)
+            if not atari:
+                info, grads = o.dqn_forward_backward(sd, buf.sample_at(env_c, step_c), dict(gamma=c["gamma"]))
+                for name, rg in sub(g, f"phase{phase}/grad0").items():
+                    assert_close(grads[name], rg, 1e-5, f"phase {phase}: gradient {name}")
+                assert_close(info["loss"], g[f"phase{phase}/info/Qloss"], 1e-5, "Qloss")
+                opt.step(grads)
+                if updates % int(c["sync_frequency"]) == 0:
+                    o.dqn_copy_target(sd)
+                for name, rp in sub(g, f"phase{phase}/param").items():
+                    moved = float(np.abs(rp - g[f"init/{name}"]).max()) or 1.0
+                    assert_close(sd[name], rp, 2e-4, f"phase {phase}: parameter {name} (relative to the distance it moved)", scale=moved)
             assert updates == int(g[f"phase{phase}/iterations"])
-            for name, rp in sub(g, f"phase{phase}/param").items():
-                moved = float(np.abs(rp - g[f"init/{name}"]).max()) or 1.0
-                assert_close(sd[name], rp, 2e-4, f"phase {phase}: parameter {name} (relative to the distance it moved)", scale=moved)
             phase += 1
-        raw = np.where((term | trunc)[:, None], g["step/reset_obs"][s], next_obs)
+        restart = trunc if atari else (term | trunc)                                  # (Atari mode: off_policy.py:240-242)
+        raw = np.where(restart.reshape((n,) + (1,) * (next_obs.ndim - 1)), g["step/reset_obs"][s], next_obs)
         cur += n
         assert int(g["step/current_step"][s]) == cur and eps_seq[s + 1] == g["step/eps_after"][s]
         assert buf.ptr == int(g["step/ptr"][s]) and buf.size == int(g["step/size"][s])
@@ -246,7 +253,7 @@ def test_dqn_agent_loop(oracle):
     for k in ("observations", "next_observations", "actions", "rewards"):
         assert np.array_equal(getattr(buf, k), fb[k]), k
     assert np.array_equal(buf.terminals > 0, fb["terminals"] > 0)
-    assert any(k.startswith("target_") and not np.array_equal(sd[k], g[f"init/{k}"]) for k in sd)    # target syncs happened
+    assert atari or any(k.startswith("target_") and not np.array_equal(sd[k], g[f"init/{k}"]) for k in sd)    # target syncs happened
 
 
 def stored_state_rule(cur_state, done_prev):

@@ -26,9 +26,11 @@ class RecordedVecEnv:
     graph_safe = True
 
     def __init__(self, obs0, next_obs, rewards, terminated, truncated, reset_obs, observation_space=None, action_space=None,
-                 max_episode_steps=None, device="cuda"):
+                 max_episode_steps=None, device="cuda", restart=None):
         """obs0 [n, *obs]: what the loop acts on first; next_obs [S, n, *obs], rewards / terminated / truncated [S, n]: what step k
-        returned; reset_obs [S, n, *obs]: ``infos[i]["reset_obs"]`` of the envs that finished in step k (other rows ignored)."""
+        returned; reset_obs [S, n, *obs]: ``infos[i]["reset_obs"]`` of the envs that finished in step k (other rows ignored).
+        restart [S, n] (default terminated | truncated): the envs whose next acted-on observation is reset_obs -- the Atari mode of the
+        reference's loops restarts on truncation only (off_policy.py:240-242, ppo_agent.py:150-151)."""
         next_obs = np.asarray(next_obs)
         S, n = next_obs.shape[:2]
         self.num_envs, self.n_steps, self.device = int(n), int(S), device
@@ -37,7 +39,7 @@ class RecordedVecEnv:
         self.observation_space = observation_space or Box(-np.inf, np.inf, self.obs_shape, np.uint8 if odt == torch.uint8 else np.float32)
         self.action_space = action_space or Discrete(2)
         self.max_episode_steps = max_episode_steps
-        done = (np.asarray(terminated) > 0) | (np.asarray(truncated) > 0)
+        done = ((np.asarray(terminated) > 0) | (np.asarray(truncated) > 0)) if restart is None else (np.asarray(restart) > 0)
         cur = np.where(done.reshape((S, n) + (1,) * len(self.obs_shape)), np.asarray(reset_obs), next_obs)   # dummy_vec_env.py:71-74 + the
         self._cur = _dev(np.concatenate([np.asarray(obs0)[None], cur]), odt, device)                           # agent's obs[i] = reset_obs
         self._next = _dev(next_obs, odt, device)
