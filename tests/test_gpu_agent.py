@@ -668,7 +668,10 @@ def test_a2c_agent_vs_oracle(oracle, use_graph):
     cfg = make_config(n, T, n_epochs=1, n_minibatch=1, running_steps=4000, end_factor_lr_decay=0.5, use_hip_graph=use_graph)
     agent = A2C_Agent(cfg, DeviceCartPoleVecEnv(n, seed=5))
     assert list(agent.model.plan.widths) == [4, 256, 256, 3] and agent.learner.loss_mode == 1
-    sd = {k: npy(v) for k, v in agent.model.state_dict().items()}
+    # (state_dict() speaks the reference ActorCritic's key names -- actor.representation.model.*, actor.actor_head.logits.*, ... --;
+    #  the oracle's layer chains are named like the engine's internal ones)
+    assert list(agent.model.state_dict())[:3] == ["actor.representation.model.0.weight", "actor.representation.model.0.bias", "actor.actor_head.logits.0.weight"]
+    sd = {n_: npy(agent.model.params.view(n_)) for n_ in agent.model.ref_order}
     opt = oracle.AdamOracle(sd, lr=4e-4, eps=1e-5, end_factor=0.5, total_iters=4000)
     c = dict(vf_coef=0.25, ent_coef=0.01, use_grad_clip=True, grad_clip_norm=0.5)
     for it in range(3 if use_graph else 2):                       # the third pass replays the captured graphs
@@ -687,9 +690,8 @@ def test_a2c_agent_vs_oracle(oracle, use_graph):
         s = buf.sample(idx[0])
         oi, _ = oracle.ppo_update(sd, opt, dict(obs=s["obs"], actions=s["actions"], returns=s["returns"],
                                                 advantages=s["advantages"]), c, loss_kind="a2c")
-        got = agent.model.state_dict()
         for k_, val in sd.items():
-            assert_close(npy(got[k_]), val, 1e-5, f"param {k_} after update {it}")
+            assert_close(npy(agent.model.params.view(k_)), val, 1e-5, f"param {k_} after update {it}")
         assert_close(info["actor-loss"], oi["a_loss"], 1e-5, "actor-loss")
         assert_close(info["critic-loss"], oi["c_loss"], 1e-5, "critic-loss")
         assert_close(info["learning_rate"], oi["learning_rate"], 1e-9, "lr")

@@ -36,7 +36,7 @@ def categorical_uniforms(probs, acts):
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
-@pytest.mark.parametrize("kind", ["categorical", "gaussian"])
+@pytest.mark.parametrize("kind", ["categorical", "gaussian", "a2c"])
 def test_ppo_agent_replays_the_reference_run(kind, use_graph):
     """agent_ppo.npz: the reference's PPO_Agent (configs/ppo/classic_control/CartPole-v1.yaml) over three rollouts of 8 envs x 32
     steps with 31 terminations and 12 truncations, 2 x 2 minibatch updates per rollout.  agent_ppo_gaussian.npz: the same loop with
@@ -44,11 +44,13 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
     configs[3]'s network), 25 terminations and 23 truncations, 1 x 2 updates per rollout; the sampler gets the reference's own
     normals (action - mean) / std.  use_graph: the rollout and the update phase as one captured hipGraph each (replayed on the
     following stretch of the tape / the next indices) or launch by launch."""
-    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.agents import PPO_Agent, A2C_Agent
     from xuance_amd.envs import RecordedVecEnv
     from xuance_amd.spaces import Box, Discrete
-    gauss = kind == "gaussian"
-    g = load_golden("agent_ppo_gaussian" if gauss else "agent_ppo")
+    gauss, a2c = kind == "gaussian", kind == "a2c"
+    # a2c: agent_a2c.npz -- the reference's A2C_Agent (configs/a2c/classic_control/CartPole-v1.yaml: ActorCritic with one representation
+    # per head -- nets.ActorCriticNet(head_rep_layers=1) speaks its key names --, A2C_Learner, 1 x 2 updates per rollout, no old_logp)
+    g = load_golden("agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
     S = g["step/acts"].shape[0]
@@ -67,17 +69,18 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
                     grad_clip_norm=c["grad_clip_norm"], use_obsnorm=True, use_rewnorm=True, obsnorm_range=c["obsnorm_range"],
                     rewnorm_range=c["rewnorm_range"], distributed_training=False, device="cuda", model_dir="/tmp/xrl_models",
                     use_hip_graph=use_graph, **net)
-    agent = PPO_Agent(cfg, env)
-    assert not agent.use_fused_rollout and agent.learner.total_iters == int(c["total_iters"])
+    agent = (A2C_Agent if a2c else PPO_Agent)(cfg, env)
+    # (A2C_Learner's LinearLR runs over config.running_steps, a2c_learner.py:19-21, not over its estimate_total_iterations())
+    assert not agent.use_fused_rollout and agent.learner.total_iters == (cfg.running_steps if a2c else int(c["total_iters"]))
     init = sub(g, "init")
-    assert list(agent.model.ref_order) == list(init)
+    assert list(getattr(agent.model, "state_keys", agent.model.ref_order)) == list(init)
     agent.model.load_state_dict(init)
     if gauss:
         noise = ((g["step/acts"] - g["step/mu"]) / g["step/std"].reshape(S, 1, A)).astype(np.float32).reshape(rollouts, T, n, A)
     else:
         noise = categorical_uniforms(g["step/probs"], g["step/acts"]).reshape(rollouts, T, n)
         assert g["step/probs"].min() > 1e-3                            # (no taken action sits in a CDF interval narrower than the tolerance)
-    chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))
+    chain = ChainCheck(c["learning_rate"], total_iters=agent.learner.total_iters)
     f = agent.memory.soa.fields
     tm = lambda a: np.swapaxes(np.asarray(a), 0, 1)                    # the reference's env-major [n][T] -> time-major
     for p in range(rollouts):
@@ -95,7 +98,8 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
         assert_close(npy(f["observations"]).reshape(T, n, -1), tm(buf["observations"]), 1e-5, f"rollout {p}: stored (normalised) observations")
         assert_close(npy(f["rewards"]), tm(buf["rewards"]), 1e-5, f"rollout {p}: stored (processed) rewards")
         assert_close(npy(f["values"]), tm(buf["values"]), 1e-5, f"rollout {p}: stored values")
-        assert_close(npy(f["aux_old_logp"]), tm(buf["old_logp"]), 1e-5, f"rollout {p}: stored old_logp")
+        if not a2c:
+            assert_close(npy(f["aux_old_logp"]), tm(buf["old_logp"]), 1e-5, f"rollout {p}: stored old_logp")
         assert_close(npy(f["returns"]), tm(buf["returns"]), 1e-5, f"rollout {p}: returns (finish_path on termination / truncation / buffer end)")
         assert_close(npy(f["advantages"]), tm(buf["advantages"]), 1e-5, f"rollout {p}: GAE advantages", scale=float(np.abs(buf["returns"]).max()))
         # running statistics and the return tracker as the reference left them after the rollout's last vector step
@@ -109,9 +113,9 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
         assert agent.current_step == int(g["step/current_step"][last])
         info = agent.update()
         ref_info = sub(g, f"phase{p}/info")
-        for k in ("actor_loss", "critic_loss", "entropy", "predict_value"):
+        for k in (("actor-loss", "critic-loss", "entropy", "predict_value") if a2c else ("actor_loss", "critic_loss", "entropy", "predict_value")):
             assert_close(info[k], ref_info[k], 1e-5, f"phase {p} {k}",
-                         scale=max(abs(float(ref_info[k])), 1.0 if k in ("actor_loss", "predict_value") else 0.0))   # (means of O(1) terms of either sign)
+                         scale=max(abs(float(ref_info[k])), 1.0 if k in ("actor_loss", "actor-loss", "predict_value") else 0.0))   # (means of O(1) terms of either sign)
         assert_close(info["learning_rate"], ref_info["learning_rate"], 1e-9, "learning_rate")
         assert agent.learner.iterations == int(g[f"phase{p}/iterations"])
         for u in range(E * MB):

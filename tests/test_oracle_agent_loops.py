@@ -11,7 +11,23 @@ import pytest
 from conftest import load_golden, sub, assert_close, ChainCheck
 
 
-@pytest.mark.parametrize("kind", ["categorical", "gaussian"])
+def a2c_names(keys):
+    """The reference's ActorCritic keys (one representation per head: actor.representation.model.*, actor.actor_head.logits.*, critic.*)
+    -> the oracle's layer-chain names (actor.logits.<2i>, critic.values.<2i>: the representation's layers first)."""
+    out = {}
+    for head, hk, ok in (("actor", "actor_head.logits", "actor.logits"), ("critic", "critic_head.values", "critic.values")):
+        nrep = len({k.split(".")[3] for k in keys if k.startswith(f"{head}.representation.model.")})
+        for k in keys:
+            if k.startswith(f"{head}.representation.model."):
+                i, suf = k.split(".")[3], k.split(".")[4]
+                out[k] = f"{ok}.{int(i)}.{suf}"
+            elif k.startswith(f"{head}.{hk}."):
+                i, suf = k.split(".")[3], k.split(".")[4]
+                out[k] = f"{ok}.{int(i) + 2 * nrep}.{suf}"
+    return out
+
+
+@pytest.mark.parametrize("kind", ["categorical", "gaussian", "a2c"])
 def test_ppo_agent_loop(oracle, kind):
     """ppo_agent.py:111-181 + core/on_policy.py:182-205: per vector step obs_rms.update(raw obs) -> normalise -> act -> env ->
     store (normalised obs, action, processed reward, value, TERMINATED flag, old_logp); buffer full: V(next_obs) under the CURRENT
@@ -20,16 +36,22 @@ def test_ppo_agent_loop(oracle, kind):
     categorical: agent_ppo.npz (CartPole yaml); gaussian: agent_ppo_gaussian.npz (mujoco yaml: 17-256-256-{6, 1}, tanh on the mean,
     state-independent log_std -- actions are NOT rescaled or clipped on the way to the env, wrapper.py:19,90-91)."""
     o = oracle
-    gauss = kind == "gaussian"
-    g = load_golden("agent_ppo_gaussian" if gauss else "agent_ppo")
+    gauss, a2c = kind == "gaussian", kind == "a2c"
+    # a2c: agent_a2c.npz -- A2C_Agent on the generic loop (core/on_policy.py:232-300) with configs/a2c/classic_control/CartPole-v1.yaml:
+    # the same path-closing rules with V(next_obs) from the critic's own representation, no old_logp in the buffer, A2C_Learner's loss
+    g = load_golden("agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
     S, D = g["step/acts"].shape[0], g["raw_obs0"].shape[1]
     A = g["step/acts"].shape[2] if gauss else 2
     fw = dict(dist="gaussian", act="leaky_relu", activation_action="tanh") if gauss else {}
-    sd = {k: v.copy() for k, v in sub(g, "init").items()}
+    names = a2c_names(list(sub(g, "init"))) if a2c else {k: k for k in sub(g, "init")}
+    back = {v: k for k, v in names.items()}
+    sd = {names[k]: v.copy() for k, v in sub(g, "init").items()}
     opt = o.AdamOracle(sd, lr=c["learning_rate"], eps=1e-5, total_iters=int(c["total_iters"]))
     ucfg = dict(vf_coef=c["vf_coef"], ent_coef=c["ent_coef"], clip_range=c["clip_range"], use_grad_clip=True, grad_clip_norm=c["grad_clip_norm"])
+    if a2c:
+        fw = dict(loss_kind="a2c")
     obs_rms, ret_rms = o.RunningMeanStdOracle((D,)), o.RunningMeanStdOracle(())
     returns = np.zeros(n, np.float32)
     buf = o.OnPolicyBufferOracle((D,), (A,) if gauss else (), n, T, gamma=c["gamma"], gae_lam=c["gae_lambda"])
@@ -39,7 +61,8 @@ def test_ppo_agent_loop(oracle, kind):
         obs_rms.update(raw)
         obs_n = o.process_observation(raw, obs_rms, c["obsnorm_range"]).astype(np.float32)
         assert_close(obs_n, g["step/obs"][s], 1e-6, f"step {s}: normalised obs")
-        head, value = o.actor_critic_forward(sd, obs_n, **fw)
+        afw = {k: v for k, v in fw.items() if k != "loss_kind"}
+        head, value = o.actor_critic_forward(sd, obs_n, **afw)
         acts = g["step/acts"][s]                                                    # fixed input: what the reference sampled
         if gauss:
             assert_close(head, g["step/mu"][s], 1e-5, f"step {s}: mean of the action distribution", scale=1.0)
@@ -58,19 +81,21 @@ def test_ppo_agent_loop(oracle, kind):
             u = (cdf[np.arange(n), acts] - 0.5 * g["step/probs"][s][np.arange(n), acts]).astype(np.float32)
             assert np.array_equal(o.categorical_sample_icdf(head, u), acts)
             logp = o.log_softmax(head)[np.arange(n), acts]
-            assert_close(logp, g["step/logp"][s], 1e-5, f"step {s}: log-probs")
+            if not a2c:                                                              # (A2C's loop asks for no log-probs, on_policy.py:236)
+                assert_close(logp, g["step/logp"][s], 1e-5, f"step {s}: log-probs")
         assert_close(value, g["step/vals"][s], 1e-5, f"step {s}: values", scale=max(1e-2, float(np.abs(g["step/vals"][s]).max())))
         next_obs, rew, term, trunc = g["step/next_obs"][s], g["step/rewards"][s], g["step/terminals"][s], g["step/truncations"][s]
         buf.store(obs_n, acts, o.process_reward(rew, ret_rms, c["rewnorm_range"]), value, term, {"old_logp": g["step/logp"][s] if gauss else logp})
         if buf.full:
-            vals = o.actor_critic_forward(sd, o.process_observation(next_obs, obs_rms, c["obsnorm_range"]).astype(np.float32), **fw)[1]
+            vals = o.actor_critic_forward(sd, o.process_observation(next_obs, obs_rms, c["obsnorm_range"]).astype(np.float32), **afw)[1]
             for i in range(n):
                 buf.finish_path(0.0 if term[i] else vals[i], i)
             ref = sub(g, f"phase{phase}/buffer")
             assert np.array_equal(buf.actions, ref["actions"]) and np.array_equal(buf.terminals > 0, ref["terminals"] > 0)
             for k in ("observations", "rewards", "values", "returns"):
                 assert_close(getattr(buf, k), ref[k], 1e-5, f"phase {phase}: buffer {k}")
-            assert_close(buf.old_logp, ref["old_logp"], 1e-5, f"phase {phase}: buffer old_logp")
+            if not a2c:
+                assert_close(buf.old_logp, ref["old_logp"], 1e-5, f"phase {phase}: buffer old_logp")
             assert_close(buf.advantages, ref["advantages"], 1e-5, f"phase {phase}: buffer advantages", scale=float(np.abs(ref["returns"]).max()))
             idx = g[f"phase{phase}/indices"]
             assert idx.shape == (E * MB, n * T // MB)
@@ -82,14 +107,14 @@ def test_ppo_agent_loop(oracle, kind):
                                                          old_logp=b["aux_batch"]["old_logp"]), ucfg, **fw)
                 ref_g = sub(g, f"phase{phase}/grad{k}")
                 for name, rg in ref_g.items():
-                    assert_close(info["clipped_grads"][name], rg, 1e-5, f"phase {phase} update {k}: clipped gradient {name}")
+                    assert_close(info["clipped_grads"][names[name]], rg, 1e-5, f"phase {phase} update {k}: clipped gradient {name}")
             ri = sub(g, f"phase{phase}/info")
-            assert_close(info["a_loss"], ri["actor_loss"], 1e-5, "actor_loss", scale=1.0)
-            assert_close(info["c_loss"], ri["critic_loss"], 1e-5, "critic_loss")
+            assert_close(info["a_loss"], ri["actor-loss" if a2c else "actor_loss"], 1e-5, "actor_loss", scale=1.0)
+            assert_close(info["c_loss"], ri["critic-loss" if a2c else "critic_loss"], 1e-5, "critic_loss")
             assert_close(info["e_loss"], ri["entropy"], 1e-5, "entropy")
             for name, rp in sub(g, f"phase{phase}/param").items():
                 moved = float(np.abs(rp - g[f"init/{name}"]).max())
-                assert_close(sd[name], rp, 2e-4, f"phase {phase}: parameter {name} (relative to the distance it moved)", scale=moved)
+                assert_close(sd[names[name]], rp, 2e-4, f"phase {phase}: parameter {name} (relative to the distance it moved)", scale=moved)
             buf.clear()
             phase += 1
         returns = (c["gamma"] * returns + rew).astype(np.float32)
@@ -101,7 +126,7 @@ def test_ppo_agent_loop(oracle, kind):
                 if term[i]:
                     buf.finish_path(0.0, i)
                 else:
-                    vals = o.actor_critic_forward(sd, o.process_observation(next_obs, obs_rms, c["obsnorm_range"]).astype(np.float32), **fw)[1]
+                    vals = o.actor_critic_forward(sd, o.process_observation(next_obs, obs_rms, c["obsnorm_range"]).astype(np.float32), **afw)[1]
                     buf.finish_path(vals[i], i)
                 raw[i] = g["step/reset_obs"][s][i]
         assert_close(returns, g["step/returns_track"][s], 1e-5, f"step {s}: return tracker", scale=max(1.0, float(np.abs(g["step/returns_track"][s]).max())))

@@ -855,7 +855,7 @@ class A2C_Agent(PPO_Agent):
         return ActorCriticNet(self.obs_dim, self.action_space.n if discrete else int(self.action_space.shape[0]),
                               "categorical" if discrete else "gaussian", [], rep + list(c.actor_hidden_size),
                               rep + list(c.critic_hidden_size), _get(c, "activation", "leaky_relu"),
-                              None if discrete else _get(c, "activation_action", "tanh"), device=self.device)
+                              None if discrete else _get(c, "activation_action", "tanh"), device=self.device, head_rep_layers=len(rep))
 
     def _build_learner(self, *args):
         from ..learners.ppo_learner import A2C_Learner

@@ -261,7 +261,11 @@ class ActorCriticNet:
     """SharedActorCritic re-laid-out for the device: first actor/critic hidden layers are stacked into one GEMM."""
 
     def __init__(self, obs_dim, action_dim, dist="categorical", representation_hidden=(128,), actor_hidden=(128,),
-                 critic_hidden=(128,), activation="leaky_relu", activation_action=None, device="cuda", init=True):
+                 critic_hidden=(128,), activation="leaky_relu", activation_action=None, device="cuda", init=True, head_rep_layers=0):
+        """head_rep_layers = k > 0 (with no shared representation): the first k layers of each head stack are that head's OWN copy of the
+        representation -- the reference's ActorCritic model of A2C_Agent (architectures/single_agent/actor_critic.py:75-125) -- and
+        state_dict() / load_state_dict() speak that module's key names (actor.representation.model.*, actor.actor_head.logits.*,
+        critic.representation.model.*, critic.critic_head.values.*), so its checkpoints load here and ours there."""
         assert dist in ("categorical", "gaussian")
         self.obs_dim, self.action_dim, self.dist = obs_dim, action_dim, dist
         self.activation, self.activation_action = activation, activation_action
@@ -295,6 +299,20 @@ class ActorCriticNet:
             self.ref_order.insert(idx, "actor.log_std")
         for n, k, o in c_layers + [c_out]:
             self.ref_order += [n + ".weight", n + ".bias"]
+        self.ext_names = {}                                           # internal name -> the reference module's key (head_rep_layers)
+        if head_rep_layers:
+            assert not rep and 0 < head_rep_layers <= len(ah)
+            for i in range(len(ah) + 1):
+                for suf in (".weight", ".bias"):
+                    if i < head_rep_layers:
+                        self.ext_names[f"{akey}.{2 * i}{suf}"] = f"actor.representation.model.{2 * i}{suf}"
+                        self.ext_names[f"critic.values.{2 * i}{suf}"] = f"critic.representation.model.{2 * i}{suf}"
+                    else:
+                        j = 2 * (i - head_rep_layers)
+                        self.ext_names[f"{akey}.{2 * i}{suf}"] = f"actor.actor_head.{akey.split('.')[1]}.{j}{suf}"
+                        self.ext_names[f"critic.values.{2 * i}{suf}"] = f"critic.critic_head.values.{j}{suf}"
+            if dist == "gaussian":
+                self.ext_names["actor.log_std"] = "actor.actor_head.log_std"
 
         # physical layout: per level, [W_actor; W_critic] adjacent and [b_actor; b_critic] adjacent
         for n, k, o in rep_layers:
@@ -360,12 +378,21 @@ class ActorCriticNet:
             sd["actor.log_std"] = -torch.ones(self.action_dim)
         self.load_state_dict(sd)
 
+    @property
+    def state_keys(self):
+        """Keys of state_dict(), in the reference module's order."""
+        ext = getattr(self, "ext_names", {})
+        return [ext.get(n, n) for n in self.ref_order]
+
     def state_dict(self):
-        return OrderedDict((n, self.params.view(n).detach().clone()) for n in self.ref_order)
+        ext = getattr(self, "ext_names", {})
+        return OrderedDict((ext.get(n, n), self.params.view(n).detach().clone()) for n in self.ref_order)
 
     def load_state_dict(self, sd):
+        ext = getattr(self, "ext_names", {})
         for n in self.ref_order:
-            self.params.view(n).copy_(torch.as_tensor(sd[n], dtype=torch.float32))
+            e = ext.get(n, n)
+            self.params.view(n).copy_(torch.as_tensor(sd[e if e in sd else n], dtype=torch.float32))
 
     def parameters(self):
         return [self.params.view(n) for n in self.ref_order]
