@@ -286,7 +286,16 @@ def golden_agent_dqn_atari():
     golden_agent_dqn(atari=True)
 
 
-def golden_agent_dqn(atari=False):
+def golden_agent_perdqn():
+    """PerDQN_Agent (agents/qlearning_family/perdqn_agent.py:12-107) with configs/perdqn/classic_control/CartPole-v1.yaml (PER_alpha 0.5,
+    PER_beta0 0.4): prioritized replay per env (memory_tools.py:471-598: batch_size / n_envs proportional draws per env from
+    `random.random()`, importance weights, priorities <- |TD error| after every update), beta += (1 - beta0) / train_steps after every
+    update PHASE (:72), and the agent's OWN epsilon rule -- `e_greedy -= delta` per vector step while above end_greedy (:104-105), not
+    DQN_Agent's `start - current_step * delta` -- at 8 envs, a 16-row ring, batch 16 (2 per env), 64 vector steps -> agent_perdqn.npz."""
+    golden_agent_dqn(per=True)
+
+
+def golden_agent_dqn(atari=False, per=False):
     """DQN_Agent with configs/dqn/classic_control/CartPole-v1.yaml (network 4-128-128-2, MSE TD loss, no normalisation, no
     clipping) at 8 envs, a replay ring of 16 rows per env (it wraps three times), batch 16, start_training 48, an update every
     second vector step (training_frequency 16 with current_step growing by 8), hard target sync every 5 updates, epsilon from 0.5
@@ -316,8 +325,9 @@ def golden_agent_dqn(atari=False):
         odt, oshape, Env = np.uint8, (84, 84, 4), HostAtariShapedEnv
     else:
         n, S, A = 8, 64, 2
-        cfg = agent_config("dqn/classic_control/CartPole-v1.yaml", parallels=n, buffer_size=n * 16, batch_size=16, start_training=n * 6,
-                           training_frequency=16, sync_frequency=5, decay_step_greedy=n * n * 30, seed=5)
+        cfg = agent_config(("perdqn" if per else "dqn") + "/classic_control/CartPole-v1.yaml", parallels=n, buffer_size=n * 16, batch_size=16,
+                           start_training=n * 6, training_frequency=16, sync_frequency=5,
+                           decay_step_greedy=n * 30 if per else n * n * 30, seed=21 if per else 5)
         seed_all(cfg.seed)
         envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 3)
         envs.observation_space, envs.action_space = sp.Box(-np.inf, np.inf, (4,), np.float32), sp.Discrete(A)
@@ -335,9 +345,9 @@ def golden_agent_dqn(atari=False):
 
         def on_train_epochs_end(self, current_step, **kw):
             phases.append(dict(param=sd_np(kw["model"]), indices=np.stack(self.indices), grads=self.grads, at_step=np.int64(len(steps) - 1),
-                               info={k: np.float64(v) for k, v in kw["update_info"].items() if np.isscalar(v) and v is not None},
-                               iterations=np.int64(self.agent.learner.iterations)))
-            self.indices, self.grads = [], []
+                               info={k: np.float64(v) for k, v in (self.last_info if per else kw["update_info"]).items() if np.isscalar(v) and v is not None},
+                               iterations=np.int64(self.agent.learner.iterations), **({"per": self.per, "per_beta": np.float64(kw["per_beta"])} if per else {})))
+            self.indices, self.grads, self.per = [], [], []
 
         def on_train_step_end(self, current_step, **kw):
             ag = self.agent
@@ -350,8 +360,28 @@ def golden_agent_dqn(atari=False):
         agent = REGISTRY_Agents[cfg.agent](cfg, envs, callback=cb)
     finally:
         os.chdir(cwd)
-    cb.agent, cb.indices, cb.grads, cb.draw = agent, [], [], None
+    cb.agent, cb.indices, cb.grads, cb.draw, cb.per, cb.last_info = agent, [], [], None, [], {}
     sample0, update0, explore0 = agent.memory.sample, agent.learner.update, agent.exploration
+
+    def per_sample(beta):                                             # (listening: the uniforms behind the proportional draws, :560)
+        import random
+        st = random.getstate()
+        smp = sample0(beta)
+        after = random.getstate()
+        random.setstate(st)
+        k = agent.memory.batch_size // n
+        uni = np.array([[random.random() for _ in range(k)] for _ in range(n)])
+        random.setstate(after)
+        cb.indices.append(np.stack([np.arange(n).repeat(k), smp["step_choices"].flatten()]))
+        cb.per.append(dict(beta=np.float64(beta), uniforms=uni, step_choices=smp["step_choices"].copy(), weights=smp["weights"].copy()))
+        return smp
+
+    def per_update(**samples):
+        td, info = update0(**samples)
+        cb.grads.append({k: p.grad.detach().numpy().copy() for k, p in agent.model.named_parameters() if p.grad is not None})
+        cb.per[-1]["td_error"] = np.asarray(td, np.float32).copy()
+        cb.last_info = info
+        return td, info
 
     def sample(batch_size=None):                                      # (listening: the choices NumPy made, memory_tools.py:374-377)
         st = np.random.get_state()
@@ -379,7 +409,7 @@ def golden_agent_dqn(atari=False):
         torch.set_rng_state(after)
         cb.draw = dict(coin=u.numpy().copy(), random_actions=r.numpy().copy(), greedy=pi_actions.numpy().copy())
         return acts
-    agent.memory.sample, agent.learner.update, agent.exploration = sample, update, exploration
+    agent.memory.sample, agent.learner.update, agent.exploration = (per_sample if per else sample), (per_update if per else update), exploration
     out.update(mg.flat("init", sd_np(agent.model)))
     out["raw_obs0"] = np.array(envs.buf_obs, odt).copy()
     agent.train(S)
@@ -393,19 +423,26 @@ def golden_agent_dqn(atari=False):
         out[f"phase{p}/indices"], out[f"phase{p}/iterations"], out[f"phase{p}/at_step"] = ph["indices"], ph["iterations"], ph["at_step"]
         for u, g in enumerate(ph["grads"]):
             out.update(mg.flat(f"phase{p}/grad{u}", g))
+        if per:
+            out.update(mg.flat(f"phase{p}/per", ph["per"][0]))
+            out[f"phase{p}/per_beta_after"] = ph["per_beta"]
     out["n_phases"] = np.int64(len(phases))
     m = agent.memory
     out.update(mg.flat("final_buffer", {k: np.array(getattr(m, k)).copy() for k in ("observations", "next_observations", "actions", "rewards", "terminals")}))
+    if per:                                                               # the priority trees' leaves and the running maxima
+        out["final_priorities"] = np.array([[m._it_sum[i][j] for j in range(m.n_size)] for i in range(n)], np.float64)
+        out["final_max_priority"] = np.array(m._max_priority, np.float64)
+        out["per_cfg"] = np.array([cfg.PER_alpha, cfg.PER_beta0], np.float64)
     term, trunc = out["step/terminals"], out["step/truncations"]
     explored = out["step/coin"] < out["step/eps_acted"][:, None]
     assert term.sum() > (4 if atari else 8) and (trunc & ~term).sum() > 4 and explored.sum() > (5 if atari else 20) and (~explored).sum() > (50 if atari else 200)
-    assert out["step/eps_after"][-1] <= cfg.end_greedy and len(np.unique(out["step/eps_after"])) > (10 if atari else 20)
+    assert out["step/eps_after"][-1] <= cfg.end_greedy + 1e-12 and len(np.unique(out["step/eps_after"])) > (10 if atari else 20)
     out["cfg"] = np.array([n, S, cfg.buffer_size, cfg.batch_size, cfg.gamma, cfg.learning_rate, cfg.start_training, cfg.training_frequency,
                            cfg.sync_frequency, cfg.start_greedy, cfg.end_greedy, cfg.decay_step_greedy, agent.learner.total_iters,
                            Env.max_episode_steps], np.float64)
     out["cfg_names"] = np.array("n_envs n_steps buffer_size batch_size gamma learning_rate start_training training_frequency sync_frequency "
                                 "start_greedy end_greedy decay_step_greedy total_iters max_episode_steps".split())
-    name = "agent_dqn_atari" if atari else "agent_dqn"
+    name = "agent_dqn_atari" if atari else "agent_perdqn" if per else "agent_dqn"
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name + ":", len(out), "arrays;", len(phases), "update phases,", int(term.sum()), "terminations,", int((trunc & ~term).sum()),
           "truncations,", int(explored.sum()), "explored actions; final epsilon", out["step/eps_after"][-1])
@@ -713,6 +750,6 @@ def golden_agent_qmix_rnn():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "a2c", "pg", "dqn", "dqn_atari", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
+    todo = sys.argv[1:] or ["ppo", "ppo_gaussian", "a2c", "pg", "dqn", "dqn_atari", "perdqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
     for name in todo:
         globals()[f"golden_agent_{name}"]()

@@ -456,3 +456,69 @@ def test_pg_agent_replays_the_reference_run(use_graph):
         chain.step(sub(g, f"phase{p}/grad0"))
         got = {k: npy(v) for k, v in agent.model.state_dict().items()}
         chain.check(got, sub(g, f"phase{p}/param"), init, what=f"phase {p} param")
+
+
+def test_perdqn_agent_replays_the_reference_run():
+    """agent_perdqn.npz: the reference's PerDQN_Agent (configs/perdqn/classic_control/CartPole-v1.yaml) over 64 vector steps of 8 envs,
+    28 update phases on prioritized samples (2 transitions per env from each env's sum tree; the reference's `random.random()` uniforms
+    are supplied), priorities <- |TD error| after every update, PER_beta after every phase, epsilon by this agent's own rule (minus delta
+    per vector step, perdqn_agent.py:104-105).  Per phase: the transitions the device trees pick EQUAL the reference's, importance
+    weights, loss, parameters; at the end the priority leaves and the ring."""
+    from xuance_amd.agents import PerDQN_Agent
+    from xuance_amd.envs import RecordedVecEnv
+    from xuance_amd.spaces import Discrete
+    g = load_golden("agent_perdqn")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, S, B = int(c["n_envs"]), int(c["n_steps"]), int(c["batch_size"])
+    alpha, beta0 = g["per_cfg"].tolist()
+    env = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
+                         g["step/reset_obs"], action_space=Discrete(2), max_episode_steps=int(c["max_episode_steps"]))
+    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[128], q_hidden_size=[128], activation="relu", seed=1,
+                    parallels=n, running_steps=10 ** 6, buffer_size=int(c["buffer_size"]), batch_size=B, learning_rate=c["learning_rate"],
+                    gamma=c["gamma"], start_greedy=c["start_greedy"], end_greedy=c["end_greedy"], decay_step_greedy=c["decay_step_greedy"],
+                    sync_frequency=int(c["sync_frequency"]), training_frequency=int(c["training_frequency"]),
+                    start_training=int(c["start_training"]), n_epochs=1, use_grad_clip=False, grad_clip_norm=0.5, use_obsnorm=False,
+                    use_rewnorm=False, PER_alpha=alpha, PER_beta0=beta0, distributed_training=False, device="cuda", model_dir="/tmp/xrl_models")
+    P = int(g["n_phases"])
+    init = sub(g, "init")
+    trainable = [k for k in init if not k.startswith("target_")]
+    chain = ChainCheck(c["learning_rate"], total_iters=int(c["total_iters"]))
+    st = dict(s=0, phase=0)
+
+    def step_end(step, **kw):
+        s = st["s"]
+        assert np.array_equal(npy(env.action), g["step/acts"][s]), f"step {s}: actions"      # (no tie in this run)
+        if s == 0:                                                                            # (the buf_obs alias of the reference's first step)
+            agent.memory.soa.fields["observations"][0].copy_(torch.as_tensor(g["step/obs"][0]))
+        assert agent.e_greedy == g["step/eps_after"][s] and step == int(g["step/current_step"][s])
+        st["s"] += 1
+
+    def epochs_end(step, **kw):
+        p = st["phase"]
+        mem = agent.memory
+        assert int(g[f"phase{p}/at_step"]) == st["s"] and agent.learner.iterations == int(g[f"phase{p}/iterations"])
+        assert np.array_equal(npy(mem.step_choices), g[f"phase{p}/per/step_choices"]), f"phase {p}: the transitions the trees pick"
+        assert_close(npy(mem.weights), g[f"phase{p}/per/weights"], 1e-6, f"phase {p}: importance weights")   # (float32 ** in the reference under NumPy 2)
+        assert agent.PER_beta == float(g[f"phase{p}/per_beta_after"])
+        assert_close(kw["update_info"]["Qloss"], g[f"phase{p}/info/Qloss"], 1e-5, f"phase {p} Qloss")
+        chain.step(sub(g, f"phase{p}/grad0"))
+        ref_p = sub(g, f"phase{p}/param")
+        if ref_p:
+            got = {k: npy(v) for k, v in agent.model.state_dict().items()}
+            chain.check({k: got[k] for k in trainable}, {k: ref_p[k] for k in trainable}, init, what=f"phase {p} param")
+        st["phase"] += 1
+
+    agent = PerDQN_Agent(cfg, env, _LoopTap(step_end, epochs_end))
+    assert list(agent.model.ref_order) == list(init)
+    agent.model.load_state_dict(init)
+    agent.set_replay(coins=g["step/coin"], random_actions=g["step/random_actions"], indices=[g[f"phase{p}/per/uniforms"] for p in range(P)])
+    agent.train(S)                                                # ONE call: PER_beta's increment is (1 - beta0) / train_steps
+    torch.cuda.synchronize()
+    assert st["s"] == S and st["phase"] == P
+    mem = agent.memory
+    leaves = npy(mem.it_sum)[:, mem.capacity:mem.capacity + mem.n_size]
+    assert_close(leaves, g["final_priorities"], 1e-6, "priorities in the sum trees' leaves")
+    assert_close(npy(mem.max_priority), g["final_max_priority"], 1e-6, "running maxima of the priorities")
+    fb = sub(g, "final_buffer")
+    for k in ("observations", "next_observations", "actions", "rewards"):
+        assert np.array_equal(npy(mem.soa.fields[k]), np.swapaxes(fb[k], 0, 1)), f"ring field {k}"

@@ -471,3 +471,61 @@ def test_qmix_rnn_agent_loop(oracle):
     assert phase == int(g["n_phases"]) and s == g["step/acts"].shape[0] and ties <= 3
     for k, v in sub(g, "final_buffer").items():
         assert np.array_equal(np.asarray(buf.data[k], np.float32), np.asarray(v, np.float32).reshape(buf.data[k].shape)), f"ring field {k}"
+
+
+def test_perdqn_agent_loop(oracle):
+    """perdqn_agent.py:43-107 (agent_perdqn.npz): DQN's acting / store, then per update phase `memory.sample(PER_beta)` -- batch / n_envs
+    stratified proportional draws per env from the sum tree (memory_tools.py:542-565; the recorded `random.random()` uniforms are the
+    input), importance weights (recorded, not used by the reference's loss, perdqn_learner.py:49) -- `learner.update` (DQN's arithmetic),
+    `update_priorities(step_choices, |TD error|)` (:586-597), `PER_beta += (1 - PER_beta0) / train_steps`; epsilon by the agent's OWN rule:
+    minus delta per vector step while above end_greedy (:104-105)."""
+    o = oracle
+    g = load_golden("agent_perdqn")
+    c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
+    n, S, B = int(c["n_envs"]), int(c["n_steps"]), int(c["batch_size"])
+    alpha, beta0 = g["per_cfg"].tolist()
+    sd = {k: v.copy() for k, v in sub(g, "init").items()}
+    trainable = [k for k in sd if not k.startswith("target_")]
+    opt = o.AdamOracle({k: sd[k] for k in trainable}, lr=c["learning_rate"], eps=1e-5, total_iters=int(c["total_iters"]))
+    buf = o.OffPolicyBufferOracle((4,), (), n, int(c["buffer_size"]), B)
+    per = o.PerBufferOracle(n, int(c["buffer_size"]) // n, B, alpha)
+    delta = (c["start_greedy"] - c["end_greedy"]) / (c["decay_step_greedy"] / n)
+    raw = g["raw_obs0"].copy()
+    eps, beta, cur, phase, updates = c["start_greedy"], beta0, 0, 0, 0
+    for s in range(S):
+        assert eps == g["step/eps_acted"][s] and cur == int(g["step/step_index"][s])
+        acts = o.egreedy_select(g["step/greedy"][s], g["step/random_actions"][s], g["step/coin"][s], np.float32(eps))
+        assert np.array_equal(acts, g["step/acts"][s])
+        next_obs, rew, term, trunc = g["step/next_obs"][s], g["step/rewards"][s], g["step/terminals"][s], g["step/truncations"][s]
+        buf.store(next_obs if s == 0 else raw, acts, rew, term, next_obs)        # (s == 0: the buf_obs alias, see test_dqn_agent_loop)
+        per.store()
+        if cur > c["start_training"] and cur % int(c["training_frequency"]) == 0:
+            assert int(g[f"phase{phase}/at_step"]) == s and beta == float(g[f"phase{phase}/per/beta"])
+            steps, weights = per.sample(beta, g[f"phase{phase}/per/uniforms"])
+            assert np.array_equal(steps, g[f"phase{phase}/per/step_choices"]), f"phase {phase}: the transitions the trees pick"
+            # (1e-6, not 1e-12: under the NumPy >= 2 of this image the reference's `priority ** alpha` of a float32 |TD error| stays
+            #  float32 -- under the NumPy < 2 it pins, and here, it is float64; oracle/xrl_oracle.py: PerBufferOracle)
+            assert_close(weights, g[f"phase{phase}/per/weights"], 1e-6, f"phase {phase}: importance weights")
+            env_c = np.arange(n).repeat(B // n)
+            info, grads = o.dqn_forward_backward(sd, buf.sample_at(env_c, steps.flatten()), dict(gamma=c["gamma"]))
+            for name, rg in sub(g, f"phase{phase}/grad0").items():
+                assert_close(grads[name], rg, 1e-5, f"phase {phase}: gradient {name}")
+            td = np.abs(info["targetQ"] - info["predictQ"])                        # perdqn_learner.py:48
+            assert_close(td, g[f"phase{phase}/per/td_error"], 1e-5, f"phase {phase}: |TD error|", scale=max(1.0, float(td.max())))
+            per.update_priorities(steps, g[f"phase{phase}/per/td_error"].astype(np.float32))
+            opt.step(grads)
+            updates += 1
+            if updates % int(c["sync_frequency"]) == 0:
+                o.dqn_copy_target(sd)
+            beta += (1 - beta0) / S
+            assert beta == float(g[f"phase{phase}/per_beta_after"])
+            phase += 1
+        raw = np.where((term | trunc)[:, None], g["step/reset_obs"][s], next_obs)
+        cur += n
+        if eps > c["end_greedy"]:
+            eps -= delta
+        assert eps == g["step/eps_after"][s]
+    assert phase == int(g["n_phases"])
+    leaves = per.sum[:, per.cap:per.cap + per.n_size]
+    assert_close(leaves, g["final_priorities"], 1e-6, "priorities in the sum trees' leaves")
+    assert_close(per.max_priority, g["final_max_priority"], 1e-6, "running maxima of the priorities")

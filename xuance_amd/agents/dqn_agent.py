@@ -100,7 +100,7 @@ class DQN_Agent(AgentSurface):
                                  torch.as_tensor(np.asarray(random_actions, np.int32), device=dev).contiguous())
             self._act_fused = False
         if indices is not None:
-            self.index_tape = [np.asarray(i, np.int64) for i in indices]
+            self.index_tape = [np.asarray(i) for i in indices]          # ([2, batch] int choices; PerDQN_Agent: float64 uniforms)
             self._index_pos = 0
 
     def _build_model(self):
@@ -281,7 +281,7 @@ class DQN_Agent(AgentSurface):
         if self.index_tape is not None:
             info = {}
             for _e in range(self.n_epochs):
-                env_c, step_c = self.index_tape[self._index_pos]
+                env_c, step_c = self.index_tape[self._index_pos].astype(np.int64)
                 self._index_pos += 1
                 info = self.learner.update(**self.memory.sample(indexes=env_c * self.memory.n_size + step_c))
             return info
@@ -366,10 +366,23 @@ class PerDQN_Agent(DQN_Agent):
         from ..learners.dqn_learner import PerDQN_Learner
         return PerDQN_Learner(*args)
 
+    def _update_explore_factor(self):
+        # perdqn_agent.py:104-105: this agent's OWN rule -- a fixed decrement per vector step while above end_greedy (DQN_Agent
+        # recomputes start - current_step * delta, off_policy.py:119-127); pinned by tests/golden/agent_perdqn.npz
+        if self.e_greedy > self.end_greedy:
+            self.e_greedy -= self.delta_egreedy
+
+    def _pair_ready(self):
+        return False                                        # (the captured vector-step pair evaluates DQN_Agent's schedule)
+
     def _train_epochs(self, train_steps):
         info = {}
         for _e in range(self.n_epochs):
-            samples = self.memory.sample(self.PER_beta)
+            uni = None
+            if self.index_tape is not None:                 # replay: the proportional draws' uniforms [n_envs, batch / n_envs] (set_replay)
+                uni = self.index_tape[self._index_pos]
+                self._index_pos += 1
+            samples = self.memory.sample(self.PER_beta, uniforms=uni)
             td, info = self.learner.update(**samples)
             self.memory.update_priorities(samples["step_choices"], td)
         self.PER_beta += (1 - self.PER_beta0) / train_steps
