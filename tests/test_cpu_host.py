@@ -475,3 +475,77 @@ def test_ring_cursor_of_a_captured_store_equals_the_host_store_sequence():
                 if r.size == n_size:                            # (what DQN_Agent._run_pair does: a new key once the ring is full)
                     sb2, zb2 = HipOffPolicyBuffer.ring_bias(r, c + 1)
                     assert (sb2 - sb) % n_size == 0 and min(zb2 + c + 2, n_size) == n_size
+
+
+def test_recorded_vec_envs_play_a_tape_back():
+    """envs/recorded.py on CPU tensors: step k of the tape comes back through the providers' surface -- eager (host step index) and with
+    the device counter + static offsets a captured rollout uses --, the next acted-on observation is reset_obs where the env restarted
+    (terminated | truncated, or the caller's `restart` mask: the loops' Atari mode), the multi-agent twin loads its recorded resets in order."""
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from xuance_amd.envs import RecordedVecEnv, RecordedMultiAgentVecEnv
+    g = load_golden("agent_dqn")
+    S, n = g["step/acts"].shape
+    done = g["step/terminals"] | g["step/truncations"]
+    cur = np.where(done[:, :, None], g["step/reset_obs"], g["step/next_obs"])
+    env = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"], g["step/reset_obs"], device="cpu")
+    env.reset()
+    assert np.array_equal(env.buf_obs.numpy(), g["raw_obs0"])
+    for k in range(5):
+        env.step_device()
+        assert np.array_equal(env.next_obs.numpy(), g["step/next_obs"][k]) and np.array_equal(env.buf_obs.numpy(), cur[k])
+        assert np.array_equal(env.reward.numpy(), g["step/rewards"][k]) and np.array_equal(env.terminated.numpy() > 0, g["step/terminals"][k])
+    env.reset()
+    env.prepare(4)
+    for base in (0, 4):                                    # two "rollouts" of 4 steps on the counter + offset form
+        for t in range(4):
+            env.step_device(offset=t)
+            assert np.array_equal(env.next_obs.numpy(), g["step/next_obs"][base + t]) and np.array_equal(env.buf_obs.numpy(), cur[base + t])
+        env.advance(4)
+    only_trunc = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
+                                g["step/reset_obs"], device="cpu", restart=g["step/truncations"])
+    only_trunc.reset()
+    k = int(np.flatnonzero((g["step/terminals"] & ~g["step/truncations"]).any(1))[0])      # a step where an env terminated without truncation
+    for _ in range(k + 1):
+        only_trunc.step_device()
+    e = int(np.flatnonzero(g["step/terminals"][k] & ~g["step/truncations"][k])[0])
+    assert np.array_equal(only_trunc.buf_obs.numpy()[e], g["step/next_obs"][k][e])          # it keeps acting on its next observation
+    q = load_golden("agent_qmix_rnn")
+    resets = [dict(obs=q[f"reset{i}/obs"], state=q[f"reset{i}/state"], avail=q[f"reset{i}/avail"], at=int(q[f"reset{i}/at"])) for i in range(int(q["n_resets"]))]
+    ma = RecordedMultiAgentVecEnv(resets, q["step/next_obs"], q["step/next_state"], q["step/next_avail"], q["step/rewards"], q["step/terminals"],
+                                  q["step/truncations"], q["step/agent_mask"], q["step/reset_obs"], q["step/reset_state"], q["step/reset_avail"],
+                                  q["step/episode_step"], device="cpu")
+    pos = 0
+    for i, r in enumerate(resets[:3]):
+        ma.reset()
+        assert np.array_equal(ma.buf_obs.numpy(), r["obs"]) and not ma.steps.any()
+        end = resets[i + 1]["at"]
+        while pos < end:
+            assert np.array_equal(ma.buf_obs.numpy(), q["step/acted_obs"][pos])              # what the reference's loop acted on at this step
+            assert np.array_equal(ma.steps.numpy(), q["step/episode_step"][pos] - 1)
+            ma.step_device()
+            assert np.array_equal(ma.done.numpy() > 0, q["step/done"][pos]) and np.array_equal(ma.end_step.numpy()[q["step/done"][pos]], q["step/episode_step"][pos][q["step/done"][pos]])
+            pos += 1
+    with pytest.raises(AssertionError):
+        ma.step_device(); ma.reset(); ma.reset()                                             # a reset the tape does not hold at this position
+
+
+def test_epsilon_schedule_constants():
+    """agents/dqn_agent.py: eps_kstar (closed form) = the first vector step at which OffPolicyAgent._update_explore_factor stops
+    (off_policy.py:119-127), against the loop it replaces; degenerate schedules end instead of spinning."""
+    import random
+    from xuance_amd.agents.dqn_agent import eps_kstar
+
+    def by_loop(s, e, d, n):
+        k, x = 0, s
+        while x > e:
+            k += 1
+            x = s - (k * n) * d
+        return k
+    rnd = random.Random(0)
+    for _ in range(500):
+        s = rnd.uniform(0.1, 1.0); e = rnd.uniform(0.0, s); n = rnd.choice([1, 4, 8, 64, 256]); dec = rnd.choice([1000, 5000, 77777, 10 ** 5])
+        d = (s - e) / (dec / n)
+        assert eps_kstar(s, e, d, n) == by_loop(s, e, d, n), (s, e, d, n)
+    assert eps_kstar(0.5, 0.1, 0.0, 8) == 0xffffffff and eps_kstar(0.5, 0.1, float("nan"), 8) == 0xffffffff and eps_kstar(0.5, 0.5, 0.1, 8) == 0

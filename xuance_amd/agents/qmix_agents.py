@@ -68,6 +68,9 @@ class QMIX_Agents(AgentSurface):
         # xrl_marl_stored_state).  On by default -- buffers and updates then equal the reference's on the same simulator outputs
         # (tests/test_gpu_agent_replay.py); `reference_state_broadcast: False` stores every env's own state.
         self.state_broadcast = bool(_get(config, "reference_state_broadcast", True))
+        if self.state_broadcast and not hasattr(envs, "done"):
+            raise AttributeError("reference_state_broadcast needs the provider's per-env `done` flags of the last vector step (envs.done, "
+                                 "as envs/synthetic.py: SyntheticSMACVecEnv has them); set reference_state_broadcast: False for a provider without")
         self._stored_state = torch.zeros(self.n_envs, self.state_dim, device=dev) if self.state_broadcast else None
         # ... and zero the recurrent state of flattened row i -- not of env i's rows -- when env i finishes (init_rnn_states_item is
         # handed batch_index = [i_env] for a state whose batch axis is n_envs * n_agents: value_factorization.py:161-167 with
