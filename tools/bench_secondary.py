@@ -61,6 +61,15 @@ def _c4_rocprof_pair_us():
         return None, None
 
 
+def _settle():
+    """Before a timed window: destroy the graphs / buffers of agents an EARLIER line built now (Python's cycle collector would otherwise
+    do it somewhere inside the window -- hipGraphDestroy / hipFree of a whole agent stalls the device for ~40 ms: 72 k instead of 335 k on
+    the C3 line in round 4, 23 instead of 9 ms per C4 update in profiles/r05_e_bench.json), then wait for the device."""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+
+
 def _events_us(fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -80,7 +89,7 @@ def ppo_small(make_config, kernel_rooflines, n_envs=16, horizon=256, steps=20, w
     agent = PPO_Agent(make_config(n_envs, horizon, 1, 0), DeviceCartPoleVecEnv(n_envs, seed=1))
     for _ in range(warmup):
         agent.rollout(); agent.update()
-    torch.cuda.synchronize()
+    _settle()
     t0 = time.perf_counter()
     for _ in range(steps):
         agent.rollout()
@@ -128,7 +137,7 @@ def qmix_3m(rnn, n=64, steps=None, ref=None):
     agent = QMIX_Agents(_qmix_cfg(n, rnn), SyntheticSMACVecEnv(n, seed=3))
     steps = steps or (180 if rnn else 200)
     agent.train(60 if rnn else 20)
-    torch.cuda.synchronize()
+    _settle()
     s0, t0 = agent.current_step, time.perf_counter()
     while True:                                     # at least half a second of loop (a 13 ms window does not carry three digits)
         agent.train(steps)
@@ -168,7 +177,7 @@ def qmix_3m(rnn, n=64, steps=None, ref=None):
     return out
 
 
-def ppo_c4(steps=3, warmup=2, ref=None):
+def ppo_c4(steps=5, warmup=2, ref=None):
     """BASELINE configs[3] shapes on one GPU: PPO, Gaussian policy 17-256-256-6 + critic 17-256-256-1 (configs/ppo/mujoco.yaml),
     128 envs x horizon 256, 16 epochs x 8 minibatches of 4 096, MuJoCo-shaped synthetic provider on the device.  Update: ONE
     launch per minibatch for forward + loss + backward (xrl::ppo_wide_kernel, csrc/ppo_wide.hip) + the optimiser launch;
@@ -187,7 +196,7 @@ def ppo_c4(steps=3, warmup=2, ref=None):
     agent = PPO_Agent(cfg, SyntheticMujocoVecEnv(n, seed=4))
     for _ in range(warmup):
         agent.rollout(); agent.update()
-    torch.cuda.synchronize()
+    _settle()
     t0 = time.perf_counter()
     for _ in range(steps):
         agent.rollout()
@@ -258,7 +267,7 @@ def ppo_atari(steps=3, warmup=2, ref=None):
         agent.rollout(); agent.update()
     import gc
     gc.collect()                                    # (see dqn_c3)
-    torch.cuda.synchronize()
+    _settle()
     t0 = time.perf_counter()
     for _ in range(steps):
         agent.rollout()
@@ -306,9 +315,7 @@ def dqn_c3(steps=200, ref=None, buffer_size=499968, start_training=10000):
     agent.memory.fill_synthetic(seed=4)
     agent.train(start_training // n + 16)            # past start_training (`current_step > start_training`, off_policy.py:228) + warm-up updates
     assert agent.learner.iterations > 0 and agent.memory.size == agent.memory.n_size == buffer_size // n
-    import gc
-    gc.collect()                                    # (graphs of agents an earlier line built are destroyed HERE, not inside the window:
-    torch.cuda.synchronize()                        #  a 60-step window caught such a 40 ms stall now and then -- 72 k instead of 335 k)
+    _settle()
     n_done, t0 = 0, time.perf_counter()
     while True:                                     # at least half a second of loop
         agent.train(steps)
