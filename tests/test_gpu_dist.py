@@ -253,6 +253,102 @@ def test_offpolicy_learners_two_ranks(kind, exchange):
     np.testing.assert_allclose(pa[trainable], single[trainable], rtol=0, atol=3e-6)
 
 
+def _build_ppo_from_fixture(distributed):
+    """The CartPole-class learner on the fixture `ppo_categorical` (96-row minibatches), updates through the ONE-LAUNCH minibatch kernel
+    from rows in a HipOnPolicyBuffer + xrl_reduce_adam[_exchange] -- the launches PPO_Agent's update phase enqueues, i.e. the path an
+    N-rank job runs (tests/test_gpu_ppo.py: test_shared_trunk_family_vs_reference_fixture is the one-rank form)."""
+    from argparse import Namespace
+    import torch
+    from conftest import load_golden
+    from test_gpu_ppo import _load_rows
+    from xuance_amd.learners import PPO_Learner
+    from xuance_amd.memory import HipOnPolicyBuffer
+    from xuance_amd.nets import ActorCriticNet
+    from xuance_amd.spaces import Box, Discrete
+    g = load_golden("ppo_categorical")
+    lr, vf, ent, clip, gclip, ef, total = g["cfg"]
+    n, T = 3, 32                                                       # 96 rows = one minibatch
+    net = ActorCriticNet(4, 2, "categorical", (128,), (128,), (128,), "leaky_relu")
+    cfg = Namespace(horizon_size=T, n_epochs=1, n_minibatch=1, parallels=n, running_steps=int(total) * n * T, gamma=0.98,
+                    learning_rate=float(lr), vf_coef=float(vf), ent_coef=float(ent), clip_range=float(clip), use_grad_clip=True,
+                    grad_clip_norm=float(gclip), end_factor_lr_decay=float(ef), distributed_training=distributed, device="cuda",
+                    model_dir="/tmp/xrl_models")
+    learner = PPO_Learner(cfg, net, None)
+    assert learner.total_iters == int(total) and learner.trunk_eligible()
+    mem = HipOnPolicyBuffer(Box(-np.inf, np.inf, (4,), np.float32), Discrete(2), {"old_logp": ()}, n, T, device="cuda")
+    assert learner.fused_eligible(mem)
+    learner.prepare_fused(mem, n * T)
+    idx = torch.arange(n * T, dtype=torch.int64, device="cuda").view(1, -1)
+
+    def call(b):
+        _load_rows(mem, b, n, T)
+        learner.refresh_fused_params(mem, idx)
+        learner.enqueue_minibatch_fused(mem, idx[0], None)
+        return learner.last_info(n * T)
+    return net, learner, call, g
+
+
+def _ddp_fixture_worker(rank, world, port, q, kind):
+    """One rank of the replay of oracle/make_golden_ddp.py's run: same initial parameters, batch (rank + u) % 2 at update u, the
+    engine's averaged (clipped) gradient and its parameters after every update against the fixture's (conftest.EngineFixtureCheck:
+    gradients at each tensor's scale, steps through Adam's conditioning)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import traceback
+    import torch
+    from conftest import sub, load_golden, EngineFixtureCheck, assert_close
+    from xuance_amd import dist as xd
+    torch.cuda.set_device(0)
+    xd.init_distributed_mode("gloo")
+    err = None
+    try:
+        if kind == "ppo_categorical":
+            net, learner, call, g = _build_ppo_from_fixture(True)
+            net.load_state_dict(sub(g, "init"))
+        else:
+            net, learner, call, g = _build_offpolicy(kind, True)
+        assert learner.world_size == 2
+        d = load_golden("ddp2_" + kind)
+        merged = dict(d)
+        merged.update({k: v for k, v in g.items() if k.startswith("init/")})
+        if kind == "ppo_categorical":
+            okw = dict(end_factor=float(g["cfg"][5]), total_iters=int(g["cfg"][6]))
+            loss = "actor_loss"
+        else:
+            okw = dict(total_iters=int(g["cfg"][-1]))
+            loss = "Qloss" if kind == "dqn_mlp" else "loss_Q"
+        chk = EngineFixtureCheck(merged, net, learner, float(g["cfg"][0]), **okw)
+        for u in range(int(d["n_updates"])):
+            info = call(sub(g, f"u{(rank + u) % 2}/batch"))
+            ref = sub(d, f"u{u}/info_rank{rank}")
+            mine = {k.split("/rank_")[0]: v for k, v in info.items()}
+            assert_close(mine[loss], ref[loss], 1e-5, f"{loss} of rank {rank}", scale=max(abs(float(ref[loss])), 1e-2))
+            chk.after_update(u)
+        torch.cuda.synchronize()
+    except Exception:                                         # noqa: BLE001  (reported through the queue: the parent shows it)
+        err = traceback.format_exc()
+    q.put((rank, err, None if err else net.params.flat.cpu().numpy(), getattr(learner, "_xc", None) is not None if not err else None))
+    xd.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", [True, False])
+@pytest.mark.parametrize("kind", ["dqn_mlp", "qmix_ff_double", "ppo_categorical"])
+def test_two_ranks_match_the_reference_under_ddp(kind, exchange):
+    """SURVEY 8(e)'s multi-GPU oracle: two REFERENCE processes under torch's DistributedDataParallel over gloo, each rank on its own
+    batch (oracle/make_golden_ddp.py -> tests/golden/ddp2_*.npz: DQN as deep_q_network.py:55-59 wraps it, QMIX's critic + mixer,
+    PPO's three parts), replayed by two ranks of this engine on the one GPU: every update's averaged, clipped gradient at 1e-5 of
+    its tensor's scale, the parameter steps through Adam's conditioning, every rank's own loss; replicas bit-identical.  Both ways of
+    averaging: inside the optimiser launch (xrl_reduce_adam_exchange) and by the process group."""
+    res = _run_two_ranks(exchange, _ddp_fixture_worker, (kind,))
+    for rank, err, _, _ in res:
+        assert err is None, f"rank {rank}:\n{err}"
+    (_, _, pa, xa), (_, _, pb, xb) = res
+    assert xa == xb == exchange and np.array_equal(pa, pb)
+
+
 def test_bench_contract_with_two_ranks():
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank,
     127.0.0.1 rendezvous), here with two ranks sharing the test box's one GPU over gloo: rank 0 prints ONE JSON line with

@@ -478,3 +478,52 @@ def test_classic_control_oracles_conserve_what_the_physics_conserves():
         p.step(np.zeros((64, 1), np.float32))
     free = np.abs(p.state[:, 1]) < 7.99
     assert free.sum() > 32 and np.abs(pend_e(p.state) - e0)[free].max() < 0.02   # of a 10-unit energy range
+
+
+# ---------------------------------------------------------------------------------------------- two ranks
+@pytest.mark.parametrize("kind", ["dqn_mlp", "qmix_ff_double", "ppo_categorical"])
+def test_two_rank_update_vs_reference_under_ddp(oracle, kind):
+    """The N-rank update rule -- every rank's gradient of its OWN batch, the MEAN over the ranks, then clip_grad_norm_, Adam, scheduler --
+    pinned to two reference processes under torch's DistributedDataParallel over gloo (oracle/make_golden_ddp.py ->
+    tests/golden/ddp2_*.npz; what is the reference's there and what the script's: its header).  Rank r updates on batch (r + u) % 2 of
+    the single-process fixture at update u; the fixture holds the averaged (clipped) gradients and the parameters after each update,
+    bit-equal on both ranks, and each rank's own info dict."""
+    g, d = load_golden(kind), load_golden("ddp2_" + kind)
+    assert int(d["world"]) == 2
+    if kind == "dqn_mlp":
+        lr, gamma, sync, gclip, use_clip, total = g["cfg"]
+        clip, okw = (gclip if use_clip else None), dict(lr=lr, total_iters=int(total))
+        fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma, double_q=False, huber_delta=0.0))
+        copy_target, loss_key = oracle.dqn_copy_target, "Qloss"
+    elif kind == "qmix_ff_double":
+        lr, gamma, sync, gclip, dq, total = g["cfg"]
+        clip, okw = gclip, dict(lr=lr, total_iters=int(total))
+        fb = lambda sd, b: oracle.qmix_forward_backward(sd, b, dict(gamma=gamma, double_q=bool(dq), use_actions_mask=True), group=str(g["group"]))
+        copy_target, loss_key = oracle.qmix_copy_target, "loss_Q"
+    else:
+        lr, vf, ent, cr, gclip, ef, total = g["cfg"]
+        clip, okw, sync = gclip, dict(lr=lr, end_factor=ef, total_iters=int(total)), 0
+        fb = lambda sd, b: oracle.ppo_forward_backward(sd, b, dict(vf_coef=vf, ent_coef=ent, clip_range=cr), dist="categorical", act="leaky_relu")
+        copy_target, loss_key = None, "actor_loss"
+    sd = {k: v.copy() for k, v in sub(g, "init").items()}
+    names = [str(n) for n in g["param_names"]]
+    opt = oracle.AdamOracle({k: sd[k] for k in names}, **okw)
+    merged = dict(d)
+    merged.update({k: v for k, v in g.items() if k.startswith("init/")})
+    chk = LearnerFixtureCheck(merged, sd, okw["lr"], end_factor=okw.get("end_factor", 1.0), total_iters=okw["total_iters"])
+    for u in range(int(d["n_updates"])):
+        per_rank = [fb(sd, sub(g, f"u{(r + u) % 2}/batch")) for r in range(2)]
+        for r, (info, _) in enumerate(per_rank):                       # every rank reports ITS batch's loss
+            ref = sub(d, f"u{u}/info_rank{r}")
+            key = next(k for k in ref if k.split("/")[0] == loss_key)    # (PPO under distributed_training would add /rank_r; here plain)
+            mine = info["a_loss"] if kind == "ppo_categorical" else info["loss"]
+            assert_close(mine, ref[key], 1e-5, f"{loss_key} rank {r}", scale=max(abs(float(ref[key])), 1e-2 if kind == "ppo_categorical" else 0.0) or 1.0)
+        grads = {k: ((per_rank[0][1][k] + per_rank[1][1][k]) * np.float32(0.5)).astype(np.float32) for k in per_rank[0][1]}
+        if clip is not None:
+            oracle.AdamOracle.clip_grad_norm_(grads, clip)               # after the average: DDP averages inside backward
+        opt.step(grads)
+        if copy_target is not None and (u + 1) % int(sync) == 0:
+            copy_target(sd)
+        chk.update(u, grads, sd)
+    assert chk.replay_checked > 0
+    assert sub(d, "u0/info_rank0")[key] != sub(d, "u0/info_rank1")[key]
