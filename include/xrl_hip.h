@@ -327,7 +327,8 @@ int xrl_reduce_adam_fits(int64_t P, int with_exchange);
  * from its peers with xrl_ipc_open (xGMI peer access; two ranks on one GPU work the same way).  Averaging is the fp32 sum
  * in rank order times 1/world on every rank, so the replicas stay bit-identical; norm, clip and Adam then act on the
  * averaged gradient as in xrl_reduce_adam.  A peer that does not show up within max_spins polls sets sync[2] = 2 and makes
- * the norm NaN (the update of that call is invalid).
+ * the norm NaN (the update of that call is invalid).  With clipping on, the launch's own inter-block barrier (the norm) is reached by a
+ * block only after its peer wait, so its bound is 2 000 000 + 4 * max_spins polls here (2 000 000 in xrl_reduce_adam).
  * Buffer layout: uint32 flags[2][XRL_XC_MAX_GROUPS] | float data[2][4 * stride4]  (index 0/1 = parity of the step). */
 #define XRL_XC_MAX_RANKS 8
 #define XRL_XC_MAX_GROUPS 1024

@@ -349,6 +349,11 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
     }
     __syncthreads();
     if (need_norm) {
+        // (with the ranks meeting in this launch a block reaches this barrier only after ITS wait for the peers' rows: the blocks that
+        //  were served first must outwait the ones still waiting for a late rank, so the bound grows with the exchange's own -- a spin
+        //  here is several times shorter than one there; seen with four rank processes time-sharing one GPU: the barrier expired while
+        //  other blocks of the same launch were still inside their (much longer) peer wait)
+        const int barrier_spins = !XC ? 2000000 : (xc.max_spins > 500000000 ? 2147000000 : 2000000 + 4 * xc.max_spins);
         int spins = 0;
         for (;;) {
             int ok = 1;
@@ -356,7 +361,7 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
                 ok &= __hip_atomic_load(&sync[4 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)step;
             if (__syncthreads_and(ok)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > 2000000) { if (threadIdx.x == 0) { s_fail = 1; __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } break; }
+            if (++spins > barrier_spins) { if (threadIdx.x == 0) { s_fail = 1; __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } break; }
         }
     }
     __syncthreads();
