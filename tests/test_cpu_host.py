@@ -201,6 +201,86 @@ def test_multi_rank_plumbing_gloo_world2():
     assert res[0][4] == (0, 256) and res[1][4] == (256, 512)
 
 
+def _gloo_ddp_worker(rank, world, port, q, kind):
+    """One rank of the two-process replay of tests/golden/ddp2_<kind>.npz on CPU: the oracle's gradient of THIS rank's batch, the ranks'
+    mean through the product's own collective helper (dist.allreduce_mean_ on ONE flat float32 message: what every learner calls
+    between its slab reduction and its optimiser step), then clip + Adam as the oracle restates them."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import traceback
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from conftest import load_golden, sub, LearnerFixtureCheck
+    from oracle import xrl_oracle as oracle
+    from xuance_amd import dist as xd
+    torch.set_num_threads(2)
+    xd.init_distributed_mode("gloo")
+    err = None
+    try:
+        g, d = load_golden(kind), load_golden("ddp2_" + kind)
+        if kind == "dqn_mlp":
+            lr, gamma, sync, gclip, use_clip, total = g["cfg"]
+            clip = gclip if use_clip else None
+            fb = lambda sd, b: oracle.dqn_forward_backward(sd, b, dict(gamma=gamma, double_q=False, huber_delta=0.0))
+            copy_target = oracle.dqn_copy_target
+        else:
+            lr, gamma, sync, gclip, dq, total = g["cfg"]
+            clip = gclip
+            fb = lambda sd, b: oracle.qmix_forward_backward(sd, b, dict(gamma=gamma, double_q=bool(dq), use_actions_mask=True), group=str(g["group"]))
+            copy_target = oracle.qmix_copy_target
+        sd = {k: v.copy() for k, v in sub(g, "init").items()}
+        names = [str(n) for n in g["param_names"]]
+        opt = oracle.AdamOracle({k: sd[k] for k in names}, lr=lr, total_iters=int(total))
+        merged = dict(d)
+        merged.update({k: v for k, v in g.items() if k.startswith("init/")})
+        chk = LearnerFixtureCheck(merged, sd, lr, total_iters=int(total))
+        for u in range(int(d["n_updates"])):
+            _, grads = fb(sd, sub(g, f"u{(rank + u) % 2}/batch"))
+            order = [n for n in names if n in grads]
+            flat = torch.from_numpy(np.concatenate([np.asarray(grads[n], np.float32).ravel() for n in order]))
+            xd.allreduce_mean_(flat)                                 # the collective under test
+            off, avg = 0, {}
+            for n in order:
+                k = grads[n].size
+                avg[n] = flat[off:off + k].numpy().reshape(grads[n].shape).copy()
+                off += k
+            if clip is not None:
+                oracle.AdamOracle.clip_grad_norm_(avg, clip)
+            opt.step(avg)
+            if (u + 1) % int(sync) == 0:
+                copy_target(sd)
+            chk.update(u, avg, sd)
+        assert chk.replay_checked > 0
+    except Exception:                                             # noqa: BLE001
+        err = traceback.format_exc()
+    q.put((rank, err, None if err else np.concatenate([sd[n].ravel() for n in names])))
+    xd.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["dqn_mlp", "qmix_ff_double"])
+def test_two_rank_gradient_mean_gloo_vs_reference_ddp(kind):
+    """World-size-2 gloo run on CPU of the N-rank update rule against the REFERENCE's two-process DistributedDataParallel run
+    (tests/golden/ddp2_*.npz, oracle/make_golden_ddp.py): each rank's own batch, the mean through xuance_amd.dist.allreduce_mean_, the
+    averaged clipped gradients and the parameter steps of both updates within the fixture tolerances; replicas bit-identical."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_gloo_ddp_worker, args=(r, 2, port, q, kind)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, _ in res:
+        assert err is None, f"rank {rank}:\n{err}"
+    assert np.array_equal(res[0][2], res[1][2])
+
+
 def test_checkpoint_layout_is_the_references(tmp_path):
     """(1) a `.pth` written by the REFERENCE's Learner.save_model (tests/golden/ppo_ckpt_ref.pth, produced by
     oracle/make_golden.py golden_checkpoint) loads into this engine's learner -- parameters, Adam moments, step, lr;
