@@ -429,6 +429,10 @@ typedef const __attribute__((address_space(4))) QfArgs QfArgsK;
 typedef const __attribute__((address_space(4))) xrl_qmix_fused_t* QfP;
 typedef const __attribute__((address_space(4))) QfLds* QfL;
 
+// MM: the products on the matrix cores (qf_mm_*) instead of the VALU loops.  A template argument, not a run-time branch: with both forms
+// behind `if (mm)` at every call site the default (VALU) launch carried the other form's call sites through its cold instruction cache
+// and ran 2.8 us slower (round 4 -> 5: 34.8 -> 37.6 us per update on every box, profiles/r0[2-5]_*_bench.json)
+template <bool MM>
 __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_unused) {
     // the arguments are read where they lie, in the kernel argument segment (scalar loads, any index): touching the by-value
     // parameter with a run-time index would make the compiler copy it to scratch memory first
@@ -535,24 +539,24 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
     //            mixer's LDS space, eval hyper layer A, eval hyper layer B
     // products: VALU loops, or -- enough rows to fill a tile -- matrix-core tiles dealt round-robin over the waves (tb: tiles handed out
     // in the current phase)
-    const bool mm = p->products == 1 || (p->products == 0 && p->items_per_wg * N >= 8);      // (= qf_mfma_products)
+    constexpr bool mm = MM;                                                                  // (the launcher: qf_mfma_products)
     int tb = 0;
     auto FWD = [&](int W_, int ldw_, int b_, int K_, int Nn_, int in_, int ldi_, int rows_, int out_, int ldo_, int act_, int tid0_) {
-        if (mm) {
+        if constexpr (mm) {
             const int t = qf_tiles(rows_, Nn_), t0 = 64 * (tb & 15);
             tb += t;
             if (qf_mm_wave_in(t, t0)) qf_mm_fwd_fn(W_, ldw_, b_, K_, Nn_, in_, ldi_, rows_, out_, ldo_, act_, t0);
         } else qf_lin_fwd(W_, ldw_, b_, K_, Nn_, in_, ldi_, rows_, out_, ldo_, act_, tid0_);
     };
     auto BWDD = [&](int W_, int ldw_, int K_, int Nn_, int dz_, int ldz_, int rows_, int dx_, int ldx_, int y_, int ldy_, int act_, int tid0_) {
-        if (mm) {
+        if constexpr (mm) {
             const int t = qf_tiles(rows_, K_), t0 = 64 * (tb & 15);
             tb += t;
             if (qf_mm_wave_in(t, t0)) qf_mm_bwd_data_fn(W_, ldw_, K_, Nn_, dz_, ldz_, rows_, dx_, ldx_, y_, ldy_, act_, t0);
         } else qf_lin_bwd_data(W_, ldw_, K_, Nn_, dz_, ldz_, rows_, dx_, ldx_, y_, ldy_, act_, tid0_);
     };
     auto BWDW = [&](QfGlobalOut dW_, QfGlobalOut db_, int K_, int Nn_, int dz_, int ldz_, int in_, int ldi_, int rows_, int tid0_) {
-        if (mm) {
+        if constexpr (mm) {
             const int t = qf_tiles(Nn_, K_), t0 = 64 * (tb & 15);
             tb += t;
             if (qf_mm_wave_in(t, t0)) qf_mm_bwd_weight_fn(dW_, db_, K_, Nn_, dz_, ldz_, in_, ldi_, rows_, t0);
@@ -909,18 +913,20 @@ extern "C" int xrl_qmix_fused_update(const xrl_qmix_fused_t* pp, xrl_stream_t st
     const QfLds L = qf_layout(p);
     const size_t bytes = (size_t)L.total * 4;
     XRL_CHECK_ARG(bytes <= 160 * 1024);
-    static size_t allowed = 0;
-    if (bytes > allowed) {
-        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qmix_fused_kernel),
+    const bool mm = qf_mfma_products(p);
+    static size_t allowed[2] = {0, 0};
+    if (bytes > allowed[mm]) {
+        XRL_CHECK_HIP(hipFuncSetAttribute(mm ? reinterpret_cast<const void*>(qmix_fused_kernel<true>) : reinterpret_cast<const void*>(qmix_fused_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        allowed = bytes;
+        allowed[mm] = bytes;
     }
     const int n_wg = (p.B + p.items_per_wg - 1) / p.items_per_wg;
     QfArgs args{};
     xrl_qf_image_t im;
     qf_image_layout(p, im);
     args.p = p; args.L = L; args.agent4 = im.agent_floats / 4; args.mixer4 = im.mixer_floats / 4;
-    hipLaunchKernelGGL(qmix_fused_kernel, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    if (mm) hipLaunchKernelGGL(qmix_fused_kernel<true>, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    else hipLaunchKernelGGL(qmix_fused_kernel<false>, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
