@@ -426,7 +426,10 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
                 const int a = (int)rec.x, flags = __float_as_int(rec.z);
                 const bool term = (flags & 1) != 0, fin = (flags & 2) != 0;
                 const float4 nobs = *reinterpret_cast<const float4*>(&ph_f[k & 1][a][row][0]);
-                const float4 robs = fin ? *reinterpret_cast<const float4*>(&rs_f[k & 1][row][0]) : nobs;
+                // (both rows are read and the VALUES selected: `fin ? *lds_ptr : nobs` became a select between an LDS address and the address of
+                //  a stack copy of nobs -- a scratch store and a FLAT load through a generic pointer on every step of the chain)
+                const float4 rsv = *reinterpret_cast<const float4*>(&rs_f[k & 1][row][0]);
+                const float4 robs = make_float4(fin ? rsv.x : nobs.x, fin ? rsv.y : nobs.y, fin ? rsv.z : nobs.z, fin ? rsv.w : nobs.w);
                 // get_terminated_values' input: next_obs (before the reset), normalised with this step's statistics (read after the launch)
                 float4 nv = nobs;
                 if (use_norm) {
