@@ -63,7 +63,10 @@ __device__ __forceinline__ float qf_act(float v, int act) {
     return qf_act_slow(v, act);
 }
 
-template <int QF_RB>
+// FAST: the activation is none / relu (what these networks use), applied inline -- the product routine is then a leaf function.  With
+// the call to qf_act_slow inside, qf_lin_fwd_fn kept a value in a callee-saved VGPR across it and so saved / restored that register
+// through SCRATCH memory in its own prologue / epilogue: a scratch reload in front of every return, ~10 times per launch per wave.
+template <int QF_RB, bool FAST>
 __device__ __forceinline__ void qf_lin_fwd_t(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
                                              int tid0) {
     float* lds = qf_lds;
@@ -87,7 +90,10 @@ __device__ __forceinline__ void qf_lin_fwd_t(int W, int ldw, int b, int K, int N
         const float bias = lds[b + n];
 #pragma unroll
         for (int j = 0; j < QF_RB; ++j)
-            if (r0 + j < rows) lds[out + (r0 + j) * ldo + n] = qf_act(acc[j] + bias, act);
+            if (r0 + j < rows) {
+                const float v = acc[j] + bias;
+                lds[out + (r0 + j) * ldo + n] = FAST ? ((act == XRL_ACT_RELU && !(v > 0.f)) ? 0.f : v) : qf_act(v, act);
+            }
     }
 }
 
@@ -95,8 +101,13 @@ __device__ __forceinline__ void qf_lin_fwd_t(int W, int ldw, int b, int K, int N
 //  tid0, a multiple of 64: the thread that takes work item 0 -- products between two barriers get disjoint thread ranges)
 __device__ __noinline__ void qf_lin_fwd_fn(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
                                            int tid0) {
-    if (Nout * rows > 512) qf_lin_fwd_t<4>(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
-    else qf_lin_fwd_t<1>(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+    if (Nout * rows > 512) qf_lin_fwd_t<4, true>(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+    else qf_lin_fwd_t<1, true>(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+}
+__device__ __noinline__ void qf_lin_fwd_any_fn(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
+                                               int tid0) {      // (any other activation: through qf_act_slow)
+    if (Nout * rows > 512) qf_lin_fwd_t<4, false>(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+    else qf_lin_fwd_t<1, false>(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
 }
 
 // does any lane of this wave get one of n_items work items when item 0 goes to thread tid0?  (a call costs every wave that
@@ -106,7 +117,10 @@ __device__ __forceinline__ bool qf_wave_in(int n_items, int tid0) {
 }
 __device__ __forceinline__ void qf_lin_fwd(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
                                            int tid0) {
-    if (qf_wave_in(Nout * rows, tid0)) qf_lin_fwd_fn(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+    if (qf_wave_in(Nout * rows, tid0)) {
+        if (act == XRL_ACT_NONE || act == XRL_ACT_RELU) qf_lin_fwd_fn(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+        else qf_lin_fwd_any_fn(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+    }
 }
 
 // dx[r][k] = (sum_n dz[r][n] W[n][k]) * act'(y[r][k])      (y = the layer input's own activation output, < 0: none)
