@@ -756,6 +756,38 @@ typedef struct {
     int32_t pad3;
 } xrl_ppo_fused_t;
 int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* p, xrl_stream_t stream);
+/* The minibatch launch of the shared-trunk family (l0_fold_off > 0) CHAINED to the optimiser step of the minibatch before it:
+ * the launch's workgroups first do what xrl_reduce_adam would have done for the PREVIOUS minibatch's slabs -- slab sums in
+ * xrl_reduce_adam's order, global-norm clip, Adam, mirror maps: the same statements on the same elements, bit-identical
+ * parameters / moments / state -- meet at two in-launch barriers (the norm; the new parameters, agent-scope release / acquire)
+ * and then run the minibatch on the updated parameters.  Per minibatch this replaces the pair {xrl_ppo_fused_minibatch,
+ * xrl_reduce_adam} (train_epochs' loss.backward(); clip_grad_norm_; optimizer.step(); scheduler.step() -- ppo_learner.py:46-67)
+ * by ONE launch: one kernel boundary, one argument fetch and one cold start fewer, and the optimiser's blocks no longer wait for
+ * a launch of their own.  An update phase is: xrl_ppo_fused_minibatch (first minibatch), xrl_ppo_trunk_chained x (n - 1),
+ * xrl_reduce_adam (the last minibatch's step).
+ * opt->slabs must hold the previous launch's n_split slab rows (normally the same buffer as p->slabs: every workgroup is past
+ * the first barrier -- and with it past its slab reads -- before any workgroup writes a new slab).  Needs every workgroup of
+ * the launch resident at once (xrl_ppo_trunk_chain_fits), 2 * ceil(M / tile_rows) >= ceil(P / 256) workgroups, P % 4 == 0.
+ * Of opt->mirrors only map / dst / n and fold_off / fold_len are honoured (anything else set: XRL_EINVAL).
+ * opt->sync: [XRL_CHAIN_SYNC_WORDS] uint32, zero-initialised once; sync[2] != 0 afterwards = a barrier timed out (the phase's
+ * updates are invalid from that launch on; the state's norm reads NaN). */
+#define XRL_CHAIN_MAX_WGS 512
+#define XRL_CHAIN_SYNC_WORDS (4 + 2 * XRL_CHAIN_MAX_WGS)
+typedef struct {
+    const float* slabs;          /* the previous minibatch's gradient slabs [n_split][slab_stride] */
+    int64_t slab_stride;
+    float* params; float* grad; float* m; float* v;
+    int64_t P;
+    xrl_adam_state_t* state;
+    double* sumsq_part;          /* [n_part] */
+    double max_norm;             /* <= 0: no clipping (the barriers stay: every workgroup needs the new parameters) */
+    uint32_t* sync;
+    int32_t n_split, n_part;
+    xrl_mirrors_t mirrors;
+} xrl_opt_chain_t;
+int xrl_ppo_trunk_chained(const xrl_ppo_fused_t* p, const xrl_opt_chain_t* opt, xrl_stream_t stream);
+/* 1 if xrl_ppo_trunk_chained can run a minibatch of M rows in tiles of tile_rows (32 | 64) for P parameters on this device */
+int xrl_ppo_trunk_chain_fits(int32_t M, int32_t tile_rows, int64_t P);
 /* packed[i][0..7] = obs[i][0..3], act[i], ret[i], adv[i], logp[i] for i < count (the rollout buffer's [t][env] order):
  * the record form the fused minibatch kernel gathers from; run once per update phase after the advantages exist. */
 int xrl_pack_transitions(const float* f_obs, const float* f_act, const float* f_ret, const float* f_adv,

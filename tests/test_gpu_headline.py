@@ -361,3 +361,35 @@ def test_update_phase_chain_vs_reference_chain():
     _chain_distance("after64", {k: npy(v) for k, v in agent.model.state_dict().items()}, g, names)
     assert_close(info["critic_loss"], infos[63, 1], 2e-4, "critic_loss after 63 chained updates")
     assert_close(info["entropy"], infos[63, 2], 2e-4, "entropy after 63 chained updates")
+
+
+def _chained_twin(g, chained, graph):
+    agent = _chain_agent(g, graph=graph)
+    agent.config.use_chained_update = chained
+    agent.learner.config.use_chained_update = chained
+    return agent
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_chained_update_phase_is_bit_identical_to_the_launch_pair(graph):
+    """xrl_ppo_trunk_chained (round 6): the optimiser step of minibatch k done by the workgroups of minibatch k + 1's launch -- the
+    headline's update phase is then minibatch, 63 x chained minibatch, xrl_reduce_adam instead of 64 x {minibatch, xrl_reduce_adam}.
+    Same statements on the same elements: parameters, moments, clipped gradient, optimiser state and loss terms must be EQUAL to
+    the launch pair's after one and after three update phases (192 optimiser steps; a stale read of a parameter another
+    workgroup has just written -- the hand-over crosses all eight XCDs -- would show as a difference here)."""
+    g = load_golden("ppo_chain_c2")
+    a, b = _chained_twin(g, True, graph), _chained_twin(g, False, graph)
+    for phase in range(3):
+        ia, ib = a.update(), b.update()
+        torch.cuda.synchronize()
+        assert any(a.learner._chain_ok.values()) and not any(b.learner._chain_ok.values())
+        sa, sb = a.learner.optimizer.read(), b.learner.optimizer.read()
+        assert sa.step == sb.step == 64 * (phase + 1) and sa.sched_steps == sb.sched_steps
+        assert sa.last_grad_norm == sb.last_grad_norm and sa.last_lr == sb.last_lr
+        assert int(a.learner.opt_sync[2].item()) == 0, "a barrier of the chained launch timed out"
+        for k, v in a.model.state_dict().items():
+            assert torch.equal(v, b.model.state_dict()[k]), f"phase {phase}: {k} differs"
+        for name in ("m", "v", "grad"):
+            assert torch.equal(getattr(a.learner.optimizer, name), getattr(b.learner.optimizer, name)), f"phase {phase}: optimiser {name}"
+        assert torch.equal(a.learner.frag, b.learner.frag), "fragment-ordered copy of the branch layer"
+        assert ia == ib, (ia, ib)

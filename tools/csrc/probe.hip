@@ -170,3 +170,150 @@ extern "C" int xrl_probe_xcd_barrier(int iters, int n_wg, unsigned* counter, flo
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
+
+// ---- co-issue probe (round 6): what a wave can do NEXT TO a wave of the same SIMD that issues back-to-back fp32 MFMAs.
+// One 512-thread workgroup per CU: waves w and w + 4 share a SIMD.  Waves 0..3 run role_a, waves 4..7 role_b:
+//   0 idle | 1 chained v_mfma_f32_32x32x2_f32 (one accumulator) | 2 four independent accumulators | 3 VALU: 8 independent fma chains
+//   4 LDS reads (ds_read_b128 + one add) | 5 bf16 v_mfma_f32_32x32x16_bf16 chained | 6 VALU transcendental (v_exp_f32 chains)
+// prio_b: s_setprio of the role_b waves.  out[wave] = shader cycles of the wave's own loop (iters iterations).
+namespace xrl {
+typedef float cf32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cbf16x8;
+
+template <int ROLE>
+__device__ __forceinline__ float coissue_role(int iters, float seed, const float* lds) {
+    float r = 0.f;
+    if (ROLE == 1) {
+        cf32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = seed;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 1.0f, acc, 0, 0, 0);
+        }
+        r = acc[0] + acc[15];
+    } else if (ROLE == 2) {
+        cf32x16 acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][i] = seed;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 1.0f, acc[a], 0, 0, 0);
+        }
+        r = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    } else if (ROLE == 3) {
+        float c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = seed + i;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c[i] = __builtin_fmaf(c[i], 0.999f, seed);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r += c[i];
+    } else if (ROLE == 4) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* p = reinterpret_cast<const float4*>(lds) + (threadIdx.x & 63);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const float4 v = p[64 * ((k + it) & 15)]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        }
+        r = s.x + s.y + s.z + s.w;
+    } else if (ROLE == 5) {
+        cf32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = seed;
+        cbf16x8 a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = (__bf16)seed; b[i] = (__bf16)1.0f; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        r = acc[0] + acc[15];
+    } else if (ROLE == 6) {
+        float c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = seed + 0.01f * i;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_exp2f(c[i] * 0.25f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r += c[i];
+    } else if (ROLE >= 7 && ROLE <= 10) {
+        // the SAME wave: one f32 MFMA (four accumulators in turn), then NV independent fmas -- 16 MFMAs + 16 NV fmas per iteration
+        constexpr int NV = ROLE == 7 ? 4 : ROLE == 8 ? 8 : ROLE == 9 ? 12 : 16;
+        cf32x16 acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][i] = seed;
+        float c[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = seed + i;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 1.0f, acc[k & 3], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) c[i] = __builtin_fmaf(c[i], 0.999f, seed);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r += c[i];
+        r += acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    }
+    return r;
+}
+
+__device__ __forceinline__ float coissue_dispatch(int role, int iters, float seed, const float* lds) {
+    switch (role) {
+        case 1: return coissue_role<1>(iters, seed, lds);
+        case 2: return coissue_role<2>(iters, seed, lds);
+        case 3: return coissue_role<3>(iters, seed, lds);
+        case 4: return coissue_role<4>(iters, seed, lds);
+        case 5: return coissue_role<5>(iters, seed, lds);
+        case 6: return coissue_role<6>(iters, seed, lds);
+        case 7: return coissue_role<7>(iters, seed, lds);
+        case 8: return coissue_role<8>(iters, seed, lds);
+        case 9: return coissue_role<9>(iters, seed, lds);
+        case 10: return coissue_role<10>(iters, seed, lds);
+        default: return 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(512) coissue_probe_kernel(int role_a, int role_b, int iters_a, int iters_b, int prio_b, long long* out, float* sink, float seed) {
+    __shared__ __attribute__((aligned(16))) float lds[64 * 16 * 4];
+    for (int i = threadIdx.x; i < 64 * 16 * 4; i += 512) lds[i] = seed * i;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool b_side = wave >= 4;
+    if (b_side && prio_b) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_barrier();
+    const long long c0 = clock64();
+    const float r = b_side ? coissue_dispatch(role_b, iters_b, seed, lds) : coissue_dispatch(role_a, iters_a, seed, lds);
+    asm volatile("" ::"v"(r));
+    const long long c1 = clock64();
+    if (b_side && prio_b) __builtin_amdgcn_s_setprio(0);
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) out[wave] = c1 - c0;
+    if (r == 12345.678f) sink[threadIdx.x] = r;
+}
+}  // namespace xrl
+
+extern "C" int xrl_probe_coissue(int role_a, int role_b, int iters_a, int iters_b, int prio_b, int blocks, long long* out, float* sink, xrl_stream_t stream) {
+    XRL_CHECK_ARG(out && sink && blocks >= 1);
+    hipLaunchKernelGGL(xrl::coissue_probe_kernel, dim3(blocks), dim3(512), 0, xrl::as_stream(stream), role_a, role_b, iters_a, iters_b, prio_b, out, sink, 1.0f);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}

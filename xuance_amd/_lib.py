@@ -329,6 +329,17 @@ class Mirrors(C.Structure):
                 ("alt_lo", c_int64 * 2), ("alt_hi", c_int64 * 2), ("alt_split", c_int32), ("pad2", c_int32)]
 
 
+class OptChain(C.Structure):
+    """xrl_opt_chain_t: the optimiser step of the previous minibatch, done by the next minibatch launch (xrl_ppo_trunk_chained)."""
+    _fields_ = [("slabs", c_void_p), ("slab_stride", c_int64), ("params", c_void_p), ("grad", c_void_p), ("m", c_void_p),
+                ("v", c_void_p), ("P", c_int64), ("state", c_void_p), ("sumsq_part", c_void_p), ("max_norm", C.c_double),
+                ("sync", c_void_p), ("n_split", c_int32), ("n_part", c_int32), ("mirrors", Mirrors)]
+
+
+CHAIN_MAX_WGS = 512
+CHAIN_SYNC_WORDS = 4 + 2 * CHAIN_MAX_WGS
+
+
 class MarlAct(C.Structure):
     _fields_ = [("q", c_void_p), ("avail", c_void_p), ("eps_dev", c_void_p), ("coin", c_void_p), ("uniforms", c_void_p),
                 ("action", c_void_p), ("action_f", c_void_p), ("R", c_int32), ("A", c_int32), ("ld", c_int32),
@@ -338,6 +349,8 @@ class MarlAct(C.Structure):
 _SIGS = {
     "xrl_marl_select_actions": [C.POINTER(MarlAct), c_void_p],
     "xrl_ppo_fused_minibatch": [C.POINTER(PpoFused), c_void_p],
+    "xrl_ppo_trunk_chained": [C.POINTER(PpoFused), C.POINTER(OptChain), c_void_p],
+    "xrl_ppo_trunk_chain_fits": [c_int32, c_int32, c_int64],
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
     "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],

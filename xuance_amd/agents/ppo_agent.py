@@ -476,9 +476,14 @@ class PPO_Agent(AgentSurface):
             lr.refresh_fused_params(mem, self.idx)
         if mem.use_advnorm:
             ops.adv_stats(f.fields["advantages"], self.idx.view(-1), bs, nb, self.n_envs, self.horizon_size, lr.stats)
-        step = lr.enqueue_minibatch_fused if fused else lr.enqueue_minibatch_from_buffer
+        if fused:
+            # (the optimiser step of minibatch k rides in the launch of minibatch k + 1 where the learner can chain them)
+            for k in range(nb):
+                lr.enqueue_minibatch_fused(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None, defer=True)
+            lr.finish_pending()
+            return
         for k in range(nb):
-            step(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None)
+            lr.enqueue_minibatch_from_buffer(mem, self.idx[k], lr.stats[k] if mem.use_advnorm else None)
 
     def _enqueue_update_ragged(self):
         """buffer_size % n_minibatch != 0: per epoch n_minibatch full minibatches and one short one (layered path)."""

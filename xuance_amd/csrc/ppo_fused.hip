@@ -404,12 +404,13 @@ static size_t ppo_fused_lds_bytes(const xrl_ppo_fused_t& p) {
 namespace xrl {
 bool g_fast_enabled_ppo = true;                      // xrl_set_fast_kernels (tests): the specialised kernel families on / off
 bool ppo_trunk_eligible(const xrl_ppo_fused_t& p);
-int launch_ppo_trunk(const xrl_ppo_fused_t& p, hipStream_t stream);
+int launch_ppo_trunk(const xrl_ppo_fused_t& p, const xrl_opt_chain_t* o, hipStream_t stream);
 int init_ppo_trunk();
+int init_ppo_fused();
 }
 using namespace xrl;
 
-extern "C" int xrl_init_ppo_fused(void) {
+int xrl::init_ppo_fused() {
     if (int rc = init_ppo_trunk()) return rc;
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fused_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -425,7 +426,7 @@ extern "C" int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* pp, xrl_stream_t s
     // the shared-trunk family D-128-{128-A | 128-1} (D <= 24, A <= 8, categorical | Gaussian): (tile, role) workgroups, 32- or 64-row tiles
     if (p.l0_fold_off > 0) {
         if (!g_fast_enabled_ppo || !ppo_trunk_eligible(p)) { set_error("xrl_ppo_fused_minibatch: a fold region was given but the network is not of the shared-trunk family (csrc/ppo_trunk.hip)"); return XRL_EINVAL; }
-        return launch_ppo_trunk(p, as_stream(stream));
+        return launch_ppo_trunk(p, nullptr, as_stream(stream));
     }
     XRL_CHECK_ARG(p.params_t && p.cache_image && (reinterpret_cast<uintptr_t>(p.cache_image) & 15) == 0);
     XRL_CHECK_ARG(p.D == 4 && p.A >= 2 && p.dist == 0);

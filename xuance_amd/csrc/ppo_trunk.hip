@@ -23,8 +23,14 @@
 #include "common.h"
 #include "mlp_tile.h"
 #include "ppo_math.h"
+#include "opt_chain.h"
 
 namespace xrl {
+
+// second kernel argument: the optimiser step of the previous minibatch (CHAIN instances, xrl_ppo_trunk_chained) or nothing
+template <bool CHAIN> struct trunk_chain_arg { typedef xrl_opt_chain_t type; };
+struct trunk_no_chain { int unused; };
+template <> struct trunk_chain_arg<false> { typedef trunk_no_chain type; };
 
 typedef unsigned tu32x4 __attribute__((ext_vector_type(4)));
 constexpr int TH = 128;                      // hidden width (trunk and each branch)
@@ -49,9 +55,10 @@ __device__ __forceinline__ float trow_sum(float v) {                   // sum ov
 }
 
 // DS / AS: compile-time observation / head width of an instance (0 = taken from the arguments): the CartPole class (4, 2) -- the
-// headline -- gets its loops resolved at compile time
-template <int ACT, int HEAD, int PT, int DS, int AS>
-__global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_t p) {
+// headline -- gets its loops resolved at compile time.  CHAIN: the launch's workgroups first finish the optimiser step of the
+// minibatch before this one (csrc/opt_chain.h) and run on the parameters it leaves.
+template <int ACT, int HEAD, int PT, int DS, int AS, bool CHAIN>
+__global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_t p, typename trunk_chain_arg<CHAIN>::type o) {
     using L = TrunkLds<PT>;
     constexpr int TPR = FUSED_THREADS / PT;            // threads per row in the VALU phases: 16 | 8
     constexpr int CPT = TH / TPR;                      // first-layer columns per thread: 8 | 16
@@ -75,7 +82,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
     int* srcs = reinterpret_cast<int*>(lds + L::SRC);  // [PT] buffer row of each minibatch row
     double* rowstat = reinterpret_cast<double*>(lds + L::FLOATS);       // [5][PT] per-row loss terms
 
-    kernarg_prefetch<sizeof(xrl_ppo_fused_t)>();
+    kernarg_prefetch<sizeof(xrl_ppo_fused_t) + (CHAIN ? sizeof(xrl_opt_chain_t) : 0)>();
     const int tid = threadIdx.x, M = p.M, D = DS ? DS : p.D, A = AS ? AS : p.A;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,6 +139,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
         }
         srcs[tid] = src;
     }
+    // (the rows above depend on no parameter: requested before the optimiser step of the previous minibatch, which every load
+    //  below has to wait for)
+    if constexpr (CHAIN) chain_prologue(o, h1, dbg ? dbg + 2048 : nullptr);      // (diagnostics: dbg holds >= 2048 + 8 x workgroups words then)
     float st_mean = 0.f, st_std = 1.f;
     if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
     // small parameters straight from the flat buffer: W0 [128][D] -> k-major, biases, this role's head rows, log_std
@@ -547,6 +557,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
 
 // the family: widths [D, 128, 256, A + 1] with D <= 24, A <= 8, the first layer at the front of the flat layout (the fold region maps
 // onto columns [0, 128 D + 128)), the fragment copy of the branch layer present, hidden activation relu / leaky_relu / tanh
+extern bool g_fast_enabled_ppo;
 bool ppo_trunk_eligible(const xrl_ppo_fused_t& p) {
     if (p.n_layers != 4 || p.n_head_layers != 2 || p.n_levels != 4 || !p.frag_image || p.l0_fold_off <= 0) return false;
     const xrl_fused_layer_t &L0 = p.layers[0], &L1 = p.layers[1], &La = p.layers[2], &Lc = p.layers[3];
@@ -561,37 +572,51 @@ bool ppo_trunk_eligible(const xrl_ppo_fused_t& p) {
     return p.pad0 == 0 || p.pad0 == 32 || p.pad0 == 64;   // (66 was round 4's register-chained variant: measured slower, tools/csrc/ppo_chain.hip)
 }
 
+// (CHAIN instances exist for the CartPole class -- categorical head, (D, A) = (4, 2), the headline's -- only: the chained launch
+//  measured slower than the launch pair (DESIGN.md section 3 "Round 6"), so it stays an option of that class, not of the family)
 template <int ACT, int HEAD, int DS, int AS>
-static int launch_trunk_pt(const xrl_ppo_fused_t& p, hipStream_t stream) {
+static int launch_trunk_pt(const xrl_ppo_fused_t& p, const xrl_opt_chain_t* o, hipStream_t stream) {
+    constexpr bool HAS_CHAIN = HEAD == 0 && DS == 4 && AS == 2;
+    if (o && !HAS_CHAIN) { set_error("xrl_ppo_trunk_chained: only the categorical (4, 2) class has chained instances"); return XRL_EINVAL; }
     if (p.pad0 == 64) {
         const int n_tiles = (p.M + 63) / 64;
-        hipLaunchKernelGGL((ppo_trunk_kernel<ACT, HEAD, 64, DS, AS>), dim3(2 * n_tiles), dim3(FUSED_THREADS), TrunkLds<64>::BYTES, stream, p);
+        if constexpr (HAS_CHAIN) {
+            if (o) { hipLaunchKernelGGL((ppo_trunk_kernel<ACT, HEAD, 64, DS, AS, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), TrunkLds<64>::BYTES, stream, p, *o); XRL_CHECK_LAUNCH(); return XRL_OK; }
+        }
+        hipLaunchKernelGGL((ppo_trunk_kernel<ACT, HEAD, 64, DS, AS, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), TrunkLds<64>::BYTES, stream, p, trunk_no_chain{0});
     } else {
         const int n_tiles = (p.M + 31) / 32;
-        hipLaunchKernelGGL((ppo_trunk_kernel<ACT, HEAD, 32, DS, AS>), dim3(2 * n_tiles), dim3(FUSED_THREADS), TrunkLds<32>::BYTES, stream, p);
+        if constexpr (HAS_CHAIN) {
+            if (o) { hipLaunchKernelGGL((ppo_trunk_kernel<ACT, HEAD, 32, DS, AS, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), TrunkLds<32>::BYTES, stream, p, *o); XRL_CHECK_LAUNCH(); return XRL_OK; }
+        }
+        hipLaunchKernelGGL((ppo_trunk_kernel<ACT, HEAD, 32, DS, AS, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), TrunkLds<32>::BYTES, stream, p, trunk_no_chain{0});
     }
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
 
 template <int ACT>
-static int launch_trunk_head(const xrl_ppo_fused_t& p, hipStream_t stream) {
-    if (p.dist == 0) return (p.D == 4 && p.A == 2) ? launch_trunk_pt<ACT, 0, 4, 2>(p, stream) : launch_trunk_pt<ACT, 0, 0, 0>(p, stream);
-    return p.out_act == XRL_ACT_TANH ? launch_trunk_pt<ACT, 2, 0, 0>(p, stream) : launch_trunk_pt<ACT, 1, 0, 0>(p, stream);
+static int launch_trunk_head(const xrl_ppo_fused_t& p, const xrl_opt_chain_t* o, hipStream_t stream) {
+    if (p.dist == 0) return (p.D == 4 && p.A == 2) ? launch_trunk_pt<ACT, 0, 4, 2>(p, o, stream) : launch_trunk_pt<ACT, 0, 0, 0>(p, o, stream);
+    return p.out_act == XRL_ACT_TANH ? launch_trunk_pt<ACT, 2, 0, 0>(p, o, stream) : launch_trunk_pt<ACT, 1, 0, 0>(p, o, stream);
 }
 
-int launch_ppo_trunk(const xrl_ppo_fused_t& p, hipStream_t stream) {
+int launch_ppo_trunk(const xrl_ppo_fused_t& p, const xrl_opt_chain_t* o, hipStream_t stream) {
     switch (p.layers[0].act) {
-        case XRL_ACT_RELU: return launch_trunk_head<XRL_ACT_RELU>(p, stream);
-        case XRL_ACT_LEAKY_RELU: return launch_trunk_head<XRL_ACT_LEAKY_RELU>(p, stream);
-        default: return launch_trunk_head<XRL_ACT_TANH>(p, stream);
+        case XRL_ACT_RELU: return launch_trunk_head<XRL_ACT_RELU>(p, o, stream);
+        case XRL_ACT_LEAKY_RELU: return launch_trunk_head<XRL_ACT_LEAKY_RELU>(p, o, stream);
+        default: return launch_trunk_head<XRL_ACT_TANH>(p, o, stream);
     }
 }
 
 template <int ACT, int HEAD, int DS, int AS>
 static int init_trunk_one() {
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_kernel<ACT, HEAD, 32, DS, AS>), hipFuncAttributeMaxDynamicSharedMemorySize, TrunkLds<32>::BYTES));
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_kernel<ACT, HEAD, 64, DS, AS>), hipFuncAttributeMaxDynamicSharedMemorySize, TrunkLds<64>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_kernel<ACT, HEAD, 32, DS, AS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TrunkLds<32>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_kernel<ACT, HEAD, 64, DS, AS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TrunkLds<64>::BYTES));
+    if constexpr (HEAD == 0 && DS == 4 && AS == 2) {
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_kernel<ACT, HEAD, 32, DS, AS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TrunkLds<32>::BYTES));
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_kernel<ACT, HEAD, 64, DS, AS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TrunkLds<64>::BYTES));
+    }
     return XRL_OK;
 }
 
@@ -608,4 +633,60 @@ int init_ppo_trunk() {
     return XRL_OK;
 }
 
+// Workgroups of a chained launch that can be resident at once (its barriers spin): the runtime's occupancy figure for the
+// headline instance (every instance of the family has the same LDS footprint per tile size; registers differ by a few) times the
+// compute units, with the guide's caveat that the API may answer one block per CU high near an SGPR edge: at 134 KB (64-row tiles)
+// or 77 KB (32-row tiles) of LDS per workgroup LDS is the limit, not registers.
+int trunk_chain_capacity(int tile_rows) {
+    static int cap[2] = {0, 0};
+    int& c = cap[tile_rows == 64 ? 1 : 0];
+    if (c == 0) {
+        int nb = 0;
+        const void* fn = tile_rows == 64 ? (const void*)ppo_trunk_kernel<XRL_ACT_LEAKY_RELU, 0, 64, 4, 2, true>
+                                         : (const void*)ppo_trunk_kernel<XRL_ACT_LEAKY_RELU, 0, 32, 4, 2, true>;
+        const size_t lds = tile_rows == 64 ? TrunkLds<64>::BYTES : TrunkLds<32>::BYTES;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, FUSED_THREADS, lds) != hipSuccess || nb < 1) nb = 1;
+        if (nb > 1) nb = 1;                                 // (one workgroup per CU is all the launch counts on)
+        c = nb * device_cu_count();
+    }
+    return c;
+}
+
 }  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_ppo_trunk_chain_fits(int32_t M, int32_t tile_rows, int64_t P) {
+    if (M <= 0 || (tile_rows != 32 && tile_rows != 64) || P <= 0 || (P & 3)) return 0;
+    const int grid = 2 * ((M + tile_rows - 1) / tile_rows);
+    const int n_vb = (int)((P / 4 + 63) / 64);
+    return (grid >= n_vb && grid <= XRL_CHAIN_MAX_WGS && grid <= trunk_chain_capacity(tile_rows)) ? 1 : 0;
+}
+
+extern "C" int xrl_ppo_trunk_chained(const xrl_ppo_fused_t* pp, const xrl_opt_chain_t* oo, xrl_stream_t stream) {
+    XRL_CHECK_ARG(pp != nullptr && oo != nullptr);
+    const xrl_ppo_fused_t& p = *pp;
+    const xrl_opt_chain_t& o = *oo;
+    XRL_CHECK_ARG(p.params != nullptr && p.l0_fold_off > 0 && p.dist == 0 && p.D == 4 && p.A == 2);
+    XRL_CHECK_ARG(p.f_obs && p.f_act && p.f_ret && p.f_adv && p.f_logp && p.idx && p.slabs && p.partials);
+    XRL_CHECK_ARG(p.M > 0 && p.n_envs > 0 && p.T > 0);
+    if (!g_fast_enabled_ppo || !ppo_trunk_eligible(p)) { set_error("xrl_ppo_trunk_chained: the network is not of the shared-trunk family (csrc/ppo_trunk.hip)"); return XRL_EINVAL; }
+    XRL_CHECK_ARG(o.slabs && o.params && o.grad && o.m && o.v && o.state && o.sumsq_part && o.sync && o.n_split >= 1 && o.P > 0);
+    XRL_CHECK_ARG(o.params == p.params);                      // the minibatch runs on the parameters the prologue leaves
+    XRL_CHECK_ARG((o.P & 3) == 0 && (o.slab_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(o.slabs) & 15) == 0));
+    const int n_vb = (int)((o.P / 4 + 63) / 64);
+    XRL_CHECK_ARG(n_vb <= o.n_part && o.n_part <= 1024);
+    const xrl_mirrors_t& mir = o.mirrors;
+    XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);
+    for (int q = 0; q < mir.n; ++q) XRL_CHECK_ARG(mir.map[q] && mir.dst[q]);
+    XRL_CHECK_ARG(mir.target == nullptr && mir.target_image == nullptr && mir.tick == nullptr && mir.part == nullptr && mir.part_out == nullptr && mir.alt_split == 0);
+    XRL_CHECK_ARG(mir.fold_len >= 0 && (mir.fold_len & 3) == 0 && (mir.fold_off & 3) == 0 &&
+                  (mir.fold_len == 0 || (mir.fold_off >= o.P && mir.fold_off + mir.fold_len <= o.slab_stride && mir.fold_len <= o.P)));
+    const int tile_rows = p.pad0 == 64 ? 64 : 32;
+    if (!xrl_ppo_trunk_chain_fits(p.M, tile_rows, o.P)) {
+        set_error("xrl_ppo_trunk_chained: %d rows in %d-row tiles for %lld parameters do not fit the chained launch on this device "
+                  "(needs ceil(P / 256) <= workgroups <= resident capacity; xrl_ppo_trunk_chain_fits tells in advance)", p.M, tile_rows, (long long)o.P);
+        return XRL_EINVAL;
+    }
+    return launch_ppo_trunk(p, &o, as_stream(stream));
+}

@@ -446,12 +446,12 @@ static size_t fused_lds_bytes(const xrl_rollout_step_t& p) {
 
 using namespace xrl;
 
-extern "C" int xrl_init_ppo_fused(void);
+namespace xrl { int init_ppo_fused(); }      // (csrc/ppo_fused.hip; internal: not part of the C ABI)
 extern "C" int xrl_pack_rollout_cache2(const xrl_rollout_step_t* pp, float* image, int64_t image_floats, float* frag,
                                        xrl_stream_t stream);
 
 extern "C" int xrl_init(void) {
-    if (int rc = xrl_init_ppo_fused()) return rc;
+    if (int rc = init_ppo_fused()) return rc;
     // kernels that carve more than 64 KB of dynamic LDS need the attribute; set it outside any graph capture
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_step_cartpole_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));

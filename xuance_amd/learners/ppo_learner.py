@@ -316,8 +316,11 @@ class PPO_Learner(Learner):
         self.fpartials = torch.zeros(self.n_part_rows, 8, dtype=torch.float64, device=dev)
         self.stats = torch.zeros(4096, 2, device=dev)
         self.sumsq = torch.zeros(256, dtype=torch.float64, device=dev)
-        self.opt_sync = torch.zeros(4 + (P + 255) // 256 + 8, dtype=torch.int32, device=dev)   # barrier scratch of xrl_reduce_adam
+        # barrier scratch of xrl_reduce_adam and of the chained minibatch launch (xrl_ppo_trunk_chained)
+        self.opt_sync = torch.zeros(max(4 + (P + 255) // 256 + 8, ops.CHAIN_SYNC_WORDS), dtype=torch.int32, device=dev)
         self._fused_bs = bs
+        self._pending_opt = None                                       # optimiser step the next minibatch launch will do (chained)
+        self._chain_ok = {}
         self._mirrors = []
         self.params_t = self.cache_image = None
         if not self.split or not ops.fast_kernels_enabled():
@@ -393,8 +396,34 @@ class PPO_Learner(Learner):
             ops.transpose_mid(self.model.plan, self.model.params.flat, self.params_t)
             ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)
 
-    def enqueue_minibatch_fused(self, memory, idx, stats=None, finish=True):
-        """One launch for gather + forward + loss + backward, then reduce + Adam, then refresh the derived layouts."""
+    def chain_eligible(self, M, pair):
+        """May the optimiser step of a minibatch ride in the NEXT minibatch launch (xrl_ppo_trunk_chained)?  The CartPole class of the
+        shared-trunk family on one rank (with several ranks the gradient average sits in the optimiser launch), the one-launch
+        optimiser usable, every workgroup of the launch resident and at least ceil(P / 256) of them.  OFF unless
+        config.use_chained_update: True -- measured on the headline (round 6, profiles/r06_a_probe_chain.json): 44.4 us per minibatch
+        against 42.7 us for the launch pair; the two in-launch barriers cost what the kernel boundary they replace costs
+        (DESIGN.md section 3 "Round 6")."""
+        key = (M, bool(pair))
+        if key not in self._chain_ok:
+            ok = bool(getattr(self.config, "use_chained_update", False)) and self.split and ops.fast_kernels_enabled() \
+                and self.cartpole_class() and self.model.action_dim == 2 \
+                and not (self.distributed_training and self.world_size > 1) and self._fused_optimizer_ok(False) \
+                and ops.ppo_trunk_chain_fits(M, 64 if pair else 32, self.model.params.P)
+            self._chain_ok[key] = ok
+        return self._chain_ok[key] and ops.fast_kernels_enabled()
+
+    def finish_pending(self):
+        """The optimiser step a chained minibatch launch was going to do, as a launch of its own (end of an update phase)."""
+        o = getattr(self, "_pending_opt", None)
+        if o is not None:
+            self._pending_opt = None
+            ops.reduce_adam(o["slabs"], o["n_split"], o["slab_stride"], o["params"], o["grad"], o["m"], o["v"], o["P"], o["state"],
+                            o["sumsq_part"], o["max_norm"], o["mirrors"], o["sync"], fold=o["fold"])
+
+    def enqueue_minibatch_fused(self, memory, idx, stats=None, finish=True, defer=False):
+        """One launch for gather + forward + loss + backward, then reduce + Adam, then refresh the derived layouts.
+        defer (the agent's update phase): the optimiser step may wait for the next minibatch launch, which then does it in its
+        prologue (xrl_ppo_trunk_chained); finish_pending() after the last minibatch."""
         m, opt, f = self.model, self.optimizer, memory.soa.fields
         M = idx.numel()
         if getattr(self, "_wide", None) is not None:
@@ -420,7 +449,13 @@ class PPO_Learner(Learner):
                 rows = self.rows[off * 8:(off + M) * 8]
         pair = bool(fold) and getattr(self, "pair", False)
         gauss = m.dist == "gaussian"
-        ops.ppo_fused_minibatch(m.plan, params=m.params.flat, params_t=self.params_t, cache_image=self.cache_image,
+        pending = getattr(self, "_pending_opt", None)
+        if pending is not None and not (fold and self.chain_eligible(M, pair)):
+            self.finish_pending()
+            pending = None
+        self._pending_opt = None
+        launch = ops.ppo_fused_minibatch if pending is None else (lambda plan, **kw: ops.ppo_trunk_chained(plan, pending, **kw))
+        launch(m.plan, params=m.params.flat, params_t=self.params_t, cache_image=self.cache_image,
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs, frag_image=self.frag,
                                 f_packed=self.packed if getattr(self, "_packed_valid", False) else None, f_rows=rows,
@@ -429,7 +464,8 @@ class PPO_Learner(Learner):
                                 n_envs=memory.n_envs, T=memory.n_size, D=m.obs_dim, A=m.action_dim, pad0=64 if pair else 0,
                                 dist=int(gauss), out_act=ops.ACT[m.activation_action] if gauss else 0,
                                 log_std_off=m.params.offsets[getattr(m, "log_std_name", "actor.log_std")] if gauss else 0,
-                                clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef)
+                                clip_range=self.clip_range, vf_coef=self.vf_coef, ent_coef=self.ent_coef,
+                                dbg=getattr(self, "_dbg", None))
         n_t = (M + 63) // 64 if pair else (M + 31) // 32             # gradient slabs (and, per role, partial rows) of this launch
         self._last_S, self._last_partials = n_t * (2 if fold else 1), self.fpartials
         dist = self.distributed_training and self.world_size > 1
@@ -438,6 +474,12 @@ class PPO_Learner(Learner):
             # slab reduction (+ with several ranks: the gradient average over the ranks, inside the launch) + clip + Adam +
             # derived layouts in ONE launch (xrl_reduce_adam / xrl_reduce_adam_exchange)
             clip = self.grad_clip_norm if self.use_grad_clip else 0.0
+            if defer and fold and self.chain_eligible(M, pair):
+                # ... of the NEXT minibatch's launch: its workgroups do this step first (bit-identical; csrc/opt_chain.h)
+                self._pending_opt = dict(slabs=self.fslabs, n_split=n_t, slab_stride=self.slab_stride, params=m.params.flat,
+                                         grad=opt.grad, m=opt.m, v=opt.v, P=m.params.P, state=opt.state, sumsq_part=self.sumsq,
+                                         max_norm=clip, mirrors=self._mirrors, sync=self.opt_sync, fold=fold)
+                return
             ops.reduce_adam(self.fslabs, n_t, self.slab_stride, m.params.flat, opt.grad, opt.m, opt.v, m.params.P, opt.state,
                             self.sumsq, clip, self._mirrors, self.opt_sync, fold=fold, exchange=xc)
             return

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, RolloutWide, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, MarlAct, call, ptr,
+from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, RolloutWide, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, OptChain, CHAIN_SYNC_WORDS, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -475,6 +475,33 @@ def ppo_fused_minibatch(plan, **kw):
     p = _struct(PpoFused, kw)
     fused_layers_from_plan(plan, p)
     call("xrl_ppo_fused_minibatch", C.byref(p), stream_ptr())
+
+
+def ppo_trunk_chain_fits(M, tile_rows, P):
+    """May xrl_ppo_trunk_chained run a minibatch of M rows in tiles of tile_rows for P parameters on this device?"""
+    from ._lib import load
+    return bool(load().xrl_ppo_trunk_chain_fits(int(M), int(tile_rows), int(P)))
+
+
+def ppo_trunk_chained(plan, opt, **kw):
+    """The shared-trunk minibatch launch whose workgroups first finish the optimiser step of the minibatch before it
+    (xrl_ppo_trunk_chained).  opt: dict(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq_part, max_norm, mirrors,
+    sync, fold) -- what ops.reduce_adam would have been called with for the previous minibatch."""
+    p = _struct(PpoFused, kw)
+    fused_layers_from_plan(plan, p)
+    o = OptChain()
+    o.slabs, o.slab_stride, o.n_split = opt["slabs"].data_ptr(), int(opt["slab_stride"]), int(opt["n_split"])
+    o.params, o.grad, o.m, o.v = (opt[k].data_ptr() for k in ("params", "grad", "m", "v"))
+    o.P, o.state, o.sumsq_part, o.n_part = int(opt["P"]), opt["state"].data_ptr(), opt["sumsq_part"].data_ptr(), opt["sumsq_part"].numel()
+    o.max_norm, o.sync = float(opt["max_norm"] or 0.0), opt["sync"].data_ptr()
+    assert opt["sync"].numel() >= CHAIN_SYNC_WORDS
+    mir = o.mirrors
+    mir.n = len(opt["mirrors"])
+    for q, (mp, dst) in enumerate(opt["mirrors"]):
+        mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
+    if opt.get("fold"):
+        mir.fold_off, mir.fold_len = int(opt["fold"][0]), int(opt["fold"][1])
+    call("xrl_ppo_trunk_chained", C.byref(p), C.byref(o), stream_ptr())
 
 
 class PpoWideState:
