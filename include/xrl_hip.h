@@ -655,6 +655,19 @@ typedef struct {
                                                         * [1] XCC id of workgroup 0, [2] mask of every XCC id ever seen, [3] launches that
                                                         * exchanged through device-scope stores */
     long long* dbg;                                    /* NULL, or [16]: shader-clock stamps of workgroup 0's chain wave at step n_steps / 2 */
+    /* Tape provider (round 6; parity replays of recorded runs, envs/recorded.py: TapeCartPoleVecEnv).  tape_next_obs != NULL: what
+     * envs.step() returned comes from these arrays instead of the in-kernel CartPole physics / reset draws -- row *tape_pos + t of
+     * the tape for vector step t of the rollout: next observation (before an auto-reset), terminated / truncated flags, the first
+     * observation of the next episode where either is set (infos[i]["reset_obs"], dummy_vec_env.py:65-76).  The reward stays the
+     * class's constant 1 (CartPole-v1).  tape_u != NULL: the sampling uniform of (step t, env e) is tape_u[t * n + e] instead of
+     * the Philox draw (Categorical.sample by inverse CDF).  Everything else -- statistics, normalisation, the actor, log-probs,
+     * path ends, return tracker, reward normalisation, records -- is the same instruction stream as without a tape. */
+    const float* tape_next_obs;                        /* [tape_rows][n][4] */
+    const float* tape_reset_obs;                       /* [tape_rows][n][4] */
+    const float* tape_term; const float* tape_trunc;   /* [tape_rows][n], 0 / 1 */
+    const uint32_t* tape_pos;                          /* [1] tape row of the rollout's vector step 0 */
+    const float* tape_u;                               /* NULL or [T][n] */
+    int32_t tape_rows, pad2;
 } xrl_rollout_run_t;
 int xrl_rollout_cartpole_run(const xrl_rollout_run_t* p, xrl_stream_t stream);
 /* Largest n_envs the whole-rollout launches accept on THIS device: their workgroups (16 envs each + one bookkeeper) must all be

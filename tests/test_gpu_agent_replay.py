@@ -36,7 +36,7 @@ def categorical_uniforms(probs, acts):
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
-@pytest.mark.parametrize("kind", ["categorical", "gaussian", "a2c"])
+@pytest.mark.parametrize("kind", ["categorical", "categorical-one-launch", "categorical-one-launch-40", "gaussian", "a2c"])
 def test_ppo_agent_replays_the_reference_run(kind, use_graph):
     """agent_ppo.npz: the reference's PPO_Agent (configs/ppo/classic_control/CartPole-v1.yaml) over three rollouts of 8 envs x 32
     steps with 31 terminations and 12 truncations, 2 x 2 minibatch updates per rollout.  agent_ppo_gaussian.npz: the same loop with
@@ -45,21 +45,34 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
     normals (action - mean) / std.  use_graph: the rollout and the update phase as one captured hipGraph each (replayed on the
     following stretch of the tape / the next indices) or launch by launch."""
     from xuance_amd.agents import PPO_Agent, A2C_Agent
-    from xuance_amd.envs import RecordedVecEnv
+    from xuance_amd.envs import RecordedVecEnv, TapeCartPoleVecEnv
     from xuance_amd.spaces import Box, Discrete
+    # "categorical-one-launch" (round 6): the same reference run replayed through the TIMED rollout path -- xrl_rollout_cartpole_run, the
+    # whole rollout as one launch of resident workgroups (csrc/rollout_actor.hip), + xrl_rollout_cartpole_values -- with the tape as the
+    # kernel's provider (xrl_rollout_run_t.tape_*) and the recorded action draws as its uniforms: every assertion below is the one the
+    # launches per vector step pass.  "-40": agent_ppo_40.npz, 40 envs = three actor workgroups + the bookkeeper, so the per-step
+    # exchange of the observation statistics between workgroups (the tagged messages) is on the replayed path too.
+    one_launch = kind.startswith("categorical-one-launch")
+    big = kind.endswith("-40")
+    if one_launch:
+        kind = "categorical"
     gauss, a2c = kind == "gaussian", kind == "a2c"
     # a2c: agent_a2c.npz -- the reference's A2C_Agent (configs/a2c/classic_control/CartPole-v1.yaml: ActorCritic with one representation
     # per head -- nets.ActorCriticNet(head_rep_layers=1) speaks its key names --, A2C_Learner, 1 x 2 updates per rollout, no old_logp)
-    g = load_golden("agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo")
+    g = load_golden("agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo_40" if big else "agent_ppo")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
     S = g["step/acts"].shape[0]
     rollouts = S // T
     A = g["step/acts"].shape[2] if gauss else 2
-    env = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
-                         g["step/reset_obs"], action_space=Box(-1.0, 1.0, (A,), np.float32) if gauss else Discrete(2),
-                         max_episode_steps=int(c["max_episode_steps"]))
-    env.prepare(T)
+    if one_launch:
+        env = TapeCartPoleVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
+                                 g["step/reset_obs"], max_episode_steps=int(c["max_episode_steps"]))
+    else:
+        env = RecordedVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
+                             g["step/reset_obs"], action_space=Box(-1.0, 1.0, (A,), np.float32) if gauss else Discrete(2),
+                             max_episode_steps=int(c["max_episode_steps"]))
+        env.prepare(T)
     net = dict(representation="Basic_Identical", representation_hidden_size=None, actor_hidden_size=[256, 256], critic_hidden_size=[256, 256],
                activation="leaky_relu", activation_action="tanh", use_fused_acting=False, use_wide_rollout=False) if gauss else \
         dict(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128], critic_hidden_size=[128], activation="leaky_relu")
@@ -71,7 +84,8 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
                     use_hip_graph=use_graph, **net)
     agent = (A2C_Agent if a2c else PPO_Agent)(cfg, env)
     # (A2C_Learner's LinearLR runs over config.running_steps, a2c_learner.py:19-21, not over its estimate_total_iterations())
-    assert not agent.use_fused_rollout and agent.learner.total_iters == (cfg.running_steps if a2c else int(c["total_iters"]))
+    assert agent.use_fused_rollout == one_launch and (not one_launch or (agent._actor_rollout() is not None and agent._persistent_ok()))
+    assert agent.learner.total_iters == (cfg.running_steps if a2c else int(c["total_iters"]))
     init = sub(g, "init")
     assert list(getattr(agent.model, "state_keys", agent.model.ref_order)) == list(init)
     agent.model.load_state_dict(init)
@@ -103,12 +117,15 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
         assert_close(npy(f["returns"]), tm(buf["returns"]), 1e-5, f"rollout {p}: returns (finish_path on termination / truncation / buffer end)")
         assert_close(npy(f["advantages"]), tm(buf["advantages"]), 1e-5, f"rollout {p}: GAE advantages", scale=float(np.abs(buf["returns"]).max()))
         # running statistics and the return tracker as the reference left them after the rollout's last vector step
-        assert_close(npy(agent.obs_mean), g["step/obs_rms/mean"][last], 1e-5, "obs_rms.mean", scale=float(np.sqrt(g["step/obs_rms/var"][last]).max()))
-        assert_close(npy(agent.obs_var), g["step/obs_rms/var"][last], 1e-5, "obs_rms.var")
-        assert_close(npy(agent.obs_count)[0], g["step/obs_rms/count"][last], 1e-9, "obs_rms.count")
-        assert_close(npy(agent.ret_mean)[0], g["step/ret_rms/mean"][last], 1e-5, "ret_rms.mean", scale=max(1e-3, float(np.sqrt(g["step/ret_rms/var"][last]))))
-        assert_close(npy(agent.ret_var)[0], g["step/ret_rms/var"][last], 1e-5, "ret_rms.var")
-        assert_close(npy(agent.ret_count)[0], g["step/ret_rms/count"][last], 1e-9, "ret_rms.count")
+        om, ov, oc = agent._obs_stats_tensors()            # (the one-launch rollout keeps its statistics in the kernel's state block)
+        rm, rv, rc = (agent.pp["ret_stats"][0][0:1], agent.pp["ret_stats"][0][1:2], agent.pp["ret_count"][0]) if one_launch else \
+            (agent.ret_mean, agent.ret_var, agent.ret_count)
+        assert_close(npy(om), g["step/obs_rms/mean"][last], 1e-5, "obs_rms.mean", scale=float(np.sqrt(g["step/obs_rms/var"][last]).max()))
+        assert_close(npy(ov), g["step/obs_rms/var"][last], 1e-5, "obs_rms.var")
+        assert_close(npy(oc)[0], g["step/obs_rms/count"][last], 1e-9, "obs_rms.count")
+        assert_close(npy(rm)[0], g["step/ret_rms/mean"][last], 1e-5, "ret_rms.mean", scale=max(1e-3, float(np.sqrt(g["step/ret_rms/var"][last]))))
+        assert_close(npy(rv)[0], g["step/ret_rms/var"][last], 1e-5, "ret_rms.var")
+        assert_close(npy(rc)[0], g["step/ret_rms/count"][last], 1e-9, "ret_rms.count")
         assert_close(npy(agent.returns), g["step/returns_track"][last], 1e-5, "discounted-return tracker", scale=max(1.0, float(np.abs(g["step/returns_track"][last]).max())))
         assert agent.current_step == int(g["step/current_step"][last])
         info = agent.update()

@@ -27,7 +27,7 @@ def a2c_names(keys):
     return out
 
 
-@pytest.mark.parametrize("kind", ["categorical", "gaussian", "a2c"])
+@pytest.mark.parametrize("kind", ["categorical", "categorical40", "gaussian", "a2c"])
 def test_ppo_agent_loop(oracle, kind):
     """ppo_agent.py:111-181 + core/on_policy.py:182-205: per vector step obs_rms.update(raw obs) -> normalise -> act -> env ->
     store (normalised obs, action, processed reward, value, TERMINATED flag, old_logp); buffer full: V(next_obs) under the CURRENT
@@ -39,7 +39,7 @@ def test_ppo_agent_loop(oracle, kind):
     gauss, a2c = kind == "gaussian", kind == "a2c"
     # a2c: agent_a2c.npz -- A2C_Agent on the generic loop (core/on_policy.py:232-300) with configs/a2c/classic_control/CartPole-v1.yaml:
     # the same path-closing rules with V(next_obs) from the critic's own representation, no old_logp in the buffer, A2C_Learner's loss
-    g = load_golden("agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo")
+    g = load_golden("agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo_40" if kind == "categorical40" else "agent_ppo")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
     S, D = g["step/acts"].shape[0], g["raw_obs0"].shape[1]
@@ -135,7 +135,7 @@ def test_ppo_agent_loop(oracle, kind):
         assert_close(ret_rms.var, g["step/ret_rms/var"][s], 1e-5, "ret_rms.var")
         assert_close(obs_rms.count, g["step/obs_rms/count"][s], 1e-12, "obs_rms.count")
         assert_close(ret_rms.count, g["step/ret_rms/count"][s], 1e-12, "ret_rms.count")
-    assert phase == S // T == 3
+    assert phase == S // T == (2 if kind == "categorical40" else 3)
 
 
 def test_pg_agent_loop(oracle):

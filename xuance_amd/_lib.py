@@ -223,7 +223,9 @@ class RolloutRun(C.Structure):
                 ("seed", C.c_uint64), ("env_seed", C.c_uint64), ("step", C.c_uint32), ("pad1", C.c_uint32), ("step_dev", c_void_p)] + \
                [(k, c_void_p) for k in ("obs_raw", "obs_stats", "obs_count", "ret_stats", "ret_count", "ret_track", "cp_state", "cp_steps",
                                         "cp_episodes", "cp_score", "cp_stats", "f_obs", "f_act", "f_logp", "f_rew", "f_term", "f_seg",
-                                        "f_val", "bootv", "xnext", "ended", "ret_final", "xchg", "status", "dbg")]
+                                        "f_val", "bootv", "xnext", "ended", "ret_final", "xchg", "status", "dbg",
+                                        "tape_next_obs", "tape_reset_obs", "tape_term", "tape_trunc", "tape_pos", "tape_u")] + \
+               [("tape_rows", c_int32), ("pad2", c_int32)]
 
 
 class RolloutWide(C.Structure):

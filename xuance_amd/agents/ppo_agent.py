@@ -94,8 +94,8 @@ class PPO_Agent(AgentSurface):
         self.action_noise = None
         # fused rollout (one launch per vector step) for the device CartPole with a categorical policy
         from ..envs.cartpole import DeviceCartPoleVecEnv
-        self.use_fused_rollout = bool(_get(config, "use_fused_rollout", True)) and isinstance(envs, DeviceCartPoleVecEnv) \
-            and self.model.dist == "categorical" and self.horizon_size % 2 == 0
+        self.use_fused_rollout = bool(_get(config, "use_fused_rollout", True)) and self.model.dist == "categorical" and \
+            (isinstance(envs, DeviceCartPoleVecEnv) or getattr(envs, "is_cartpole_tape", False)) and self.horizon_size % 2 == 0
         if self.use_fused_rollout:
             # ping-pong copies of everything one workgroup reads from another workgroup's previous step
             self.pp = {"obs_raw": torch.zeros(2, n, D, device=dev), "xnext": torch.zeros(2, n, D, device=dev),
@@ -258,9 +258,12 @@ class PPO_Agent(AgentSurface):
             if kernel_only:
                 return
             ops.counter_add(self.step_counter, T)
+            if getattr(env, "tape", None) is not None:
+                ops.counter_add(env.tape_pos, T)                # the next rollout reads the following stretch of the tape
             ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],
                          self.gamma, self.gae_lam, self.memory.use_gae)
             return
+        assert getattr(env, "tape", None) is None, "a tape provider needs the actor rollout kernel (4-128-{128-2,128-1}, n_envs <= 256)"
         # any other shape / more envs: T launches of the any-shape step kernel + one bootstrap-only launch
         if not kernel_only:
             ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image, self.frag_image)   # params changed
@@ -344,6 +347,15 @@ class PPO_Agent(AgentSurface):
                     f_seg=f["seg"], f_val=f["values"], bootv=f["bootv"], xnext=torch.zeros(T, n, 4, device=dev),
                     ended=torch.zeros(T, n4, dtype=torch.uint8, device=dev), ret_final=torch.zeros(T, n4, device=dev),
                     xchg=self.persist_xchg, status=status)
+                tape = getattr(env, "tape", None)
+                if tape is not None:
+                    # a recorded run as the provider (envs/recorded.py: TapeCartPoleVecEnv): the kernel reads the simulators' outputs from
+                    # the tape and its sampling uniforms from the staging tensor set_action_noise fills (xrl_rollout_run_t.tape_*)
+                    self.action_noise = torch.zeros(T, n, device=dev)
+                    q = self._cpr.q
+                    q.tape_next_obs, q.tape_reset_obs = tape["next_obs"].data_ptr(), tape["reset_obs"].data_ptr()
+                    q.tape_term, q.tape_trunc = tape["term"].data_ptr(), tape["trunc"].data_ptr()
+                    q.tape_pos, q.tape_rows, q.tape_u = env.tape_pos.data_ptr(), int(env.n_steps), self.action_noise.data_ptr()
         elif self._cpr is not None and not ops.fast_kernels_enabled():
             return None
         return self._cpr
@@ -517,9 +529,14 @@ class PPO_Agent(AgentSurface):
         policy -- the action is the inverse CDF of the softmax at that uniform --, [horizon_size, n, A] standard normals for a
         Gaussian one) instead of the Philox stream.  The values are copied into one staging tensor, so a captured rollout graph
         replays on whatever the caller staged last."""
+        x = torch.as_tensor(np.asarray(noise, np.float32), device=self.device)
+        if self.use_fused_rollout and getattr(self.envs, "tape", None) is not None:
+            # the one-launch rollout over a tape reads its uniforms from the staging tensor (xrl_rollout_run_t.tape_u)
+            assert self._actor_rollout() is not None, "a tape provider needs the actor rollout kernel"
+            self.action_noise.copy_(x.reshape(self.action_noise.shape))
+            return
         assert not self.use_fused_rollout and self._wide_rollout() is None, \
             "supplied action noise needs the layered rollout (use_fused_rollout / use_wide_rollout: False)"
-        x = torch.as_tensor(np.asarray(noise, np.float32), device=self.device)
         if self.action_noise is None:
             self.action_noise = torch.zeros_like(x).contiguous()
             self._rollout_graph = None                      # (a graph captured before drew from the Philox stream)
@@ -573,6 +590,8 @@ class PPO_Agent(AgentSurface):
         """Everything a rollout launch mutates besides the buffer slots it overwrites (simulator, statistics, counters)."""
         env, t = self.envs, [self.returns, self.step_counter]
         t += [getattr(env, k) for k in ("state", "steps", "episodes", "ep_score", "stats", "buf_obs")]
+        if getattr(env, "tape", None) is not None:
+            t.append(env.tape_pos)
         return t + list(self.pp.values())
 
     def _ws_sig(self):

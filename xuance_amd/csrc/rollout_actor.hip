@@ -135,7 +135,9 @@ __device__ __forceinline__ void rollout_bookkeeper(const xrl_rollout_run_t& q, i
 // Every wave role runs its OWN step loop (same three LDS barriers per step in each): what a role keeps in scalar registers
 // is then live only on that role's path -- one loop body with all roles inside kept every kernel argument live through the
 // chain wave's tail and restored ~110 of them per step from spill lanes.
-template <int ACT>
+// TAPE: the simulators' outputs (and, optionally, the sampling uniforms) come from a recorded tape (xrl_rollout_run_t.tape_*):
+// the physics wave, the reset wave and the uniform draw READ what they otherwise compute; every other instruction is shared.
+template <int ACT, bool TAPE>
 __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q) {
 #pragma clang fp contract(off)
     if (blockIdx.x & 7) return;                                  // keep one XCD's share of the grid (see header)
@@ -320,15 +322,30 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
             const double2 s01 = *reinterpret_cast<const double2*>(src), s23 = *reinterpret_cast<const double2*>(src + 2);
             cps[0] = s01.x; cps[1] = s01.y; cps[2] = s23.x; cps[3] = s23.y;
         };
+        const size_t tape_row0 = TAPE ? (size_t)(*q.tape_pos) + (size_t)q.t0 : 0;
         auto physics = [&](int k) {                              // outcomes of step k
             if (lane < 32) {
-                double x, xd, th, thd;
-                bool term;
-                cartpole_advance(cps, g, x, xd, th, thd, term);
-                *reinterpret_cast<double2*>(&ph_state[g][row][0]) = make_double2(x, xd);
-                *reinterpret_cast<double2*>(&ph_state[g][row][2]) = make_double2(th, thd);
-                *reinterpret_cast<float4*>(&ph_f[k & 1][g][row][0]) = make_float4((float)x, (float)xd, (float)th, (float)thd);
-                ph_term[k & 1][g][row] = term ? 1 : 0;
+                if constexpr (TAPE) {                            // what the recorded simulator returned (the same for both actions)
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    int fl = 0;
+                    const size_t r = tape_row0 + (size_t)k;
+                    if (e < n && r < (size_t)q.tape_rows) {
+                        o = *reinterpret_cast<const float4*>(q.tape_next_obs + (r * n + e) * 4);
+                        fl = (q.tape_term[r * n + e] > 0.f ? 1 : 0) | (q.tape_trunc[r * n + e] > 0.f ? 2 : 0);
+                    }
+                    *reinterpret_cast<double2*>(&ph_state[g][row][0]) = make_double2((double)o.x, (double)o.y);
+                    *reinterpret_cast<double2*>(&ph_state[g][row][2]) = make_double2((double)o.z, (double)o.w);
+                    *reinterpret_cast<float4*>(&ph_f[k & 1][g][row][0]) = o;
+                    ph_term[k & 1][g][row] = fl;                 // bit 0 terminated, bit 1 truncated (the chain wave reads both from here)
+                } else {
+                    double x, xd, th, thd;
+                    bool term;
+                    cartpole_advance(cps, g, x, xd, th, thd, term);
+                    *reinterpret_cast<double2*>(&ph_state[g][row][0]) = make_double2(x, xd);
+                    *reinterpret_cast<double2*>(&ph_state[g][row][2]) = make_double2(th, thd);
+                    *reinterpret_cast<float4*>(&ph_f[k & 1][g][row][0]) = make_float4((float)x, (float)xd, (float)th, (float)thd);
+                    ph_term[k & 1][g][row] = term ? 1 : 0;
+                }
             }
         };
         physics(0);
@@ -357,7 +374,19 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
         // ================================================================ state after an auto-reset into the next episode
         const int row = cl, e = e0 + row;
         const uint64_t env_seed = q.env_seed;
+        const size_t tape_row0 = TAPE ? (size_t)(*q.tape_pos) + (size_t)q.t0 : 0;
         auto draw = [&](int k, int ep) {                         // for step k: ep = episode counter after step k - 1
+            if constexpr (TAPE) {                                // infos[i]["reset_obs"] of the recorded step
+                if (lane < 16) {
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const size_t r = tape_row0 + (size_t)k;
+                    if (e < n && r < (size_t)q.tape_rows) o = *reinterpret_cast<const float4*>(q.tape_reset_obs + (r * n + e) * 4);
+                    *reinterpret_cast<double2*>(&rs_state[k & 1][row][0]) = make_double2((double)o.x, (double)o.y);
+                    *reinterpret_cast<double2*>(&rs_state[k & 1][row][2]) = make_double2((double)o.z, (double)o.w);
+                    *reinterpret_cast<float4*>(&rs_f[k & 1][row][0]) = o;
+                }
+                return;
+            }
             if (lane < 32) {
                 uint32_t o[4], qq[4];
                 philox4x32(env_seed, (uint32_t)e, (uint32_t)(ep + 1), g ? STREAM_RESET_B : STREAM_RESET_A, o);
@@ -398,6 +427,7 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
         float* p_rfin = q.ret_final + (size_t)t0 * n4 + e; uint8_t* p_end = q.ended + (size_t)t0 * n4 + e;
         auto draw = [&](int k) {
             if (lane < 16) {
+                if (TAPE && q.tape_u) { s_u[row] = e < n ? q.tape_u[(size_t)(t0 + k) * n + e] : 0.f; return; }   // supplied uniforms
                 uint32_t rr4[4];
                 philox4x32(seed, (uint32_t)e, step0 + (uint32_t)k, STREAM_ACTION, rr4);
                 s_u[row] = u01(rr4[0]);
@@ -586,9 +616,10 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
                 logp = (a ? l1 : l0) - lse;
             }
             // ---- envs.step(acts): the pre-computed transition of the drawn action + auto-reset
-            const bool term = (a ? term_b : term_a) != 0;
+            const int tfl = a ? term_b : term_a;
+            const bool term = TAPE ? (tfl & 1) != 0 : tfl != 0;
             const int steps = cp_steps + 1;
-            const bool trunc = steps >= max_steps;
+            const bool trunc = TAPE ? (tfl & 2) != 0 : steps >= max_steps;        // (tape: the recorded simulator's own time limit)
             const bool fin = term || trunc;
             const float score = cp_score + 1.0f;
             const float tr = gamma * rtrack + 1.0f;               // self.returns = gamma * self.returns + rewards (reward 1)
@@ -811,7 +842,14 @@ extern "C" int xrl_rollout_cartpole_run(const xrl_rollout_run_t* qq, xrl_stream_
     // zeroed by a kernel, not by hipMemsetAsync: a memset node of a captured graph does not order the kernel nodes around it
     // (ROCm 7.2, tools/stress_determinism.py)
     hipLaunchKernelGGL(zero_xchg_kernel, dim3(1), dim3(512), 0, as_stream(stream), q.xchg);
-    XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);)
+    if (q.tape_next_obs) {
+        XRL_CHECK_ARG(q.tape_reset_obs && q.tape_term && q.tape_trunc && q.tape_pos && q.tape_rows >= 1);
+        XRL_CHECK_ARG(((reinterpret_cast<uintptr_t>(q.tape_next_obs) | reinterpret_cast<uintptr_t>(q.tape_reset_obs)) & 15) == 0);
+        XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT, true>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);)
+    } else {
+        XRL_CHECK_ARG(q.tape_u == nullptr);                              // (supplied uniforms ride with a tape only)
+        XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT, false>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);)
+    }
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -107,6 +107,50 @@ class RecordedVecEnv:
         pass
 
 
+class TapeCartPoleVecEnv:
+    """A recorded run of a CartPole-class vector env (4-d observations, two actions, reward 1 per step) as the provider of the
+    ONE-LAUNCH rollout kernel (csrc/rollout_actor.hip, xrl_rollout_run_t.tape_*): the resident workgroups read what `envs.step()`
+    returned -- next observation, terminated / truncated, `infos[i]["reset_obs"]` -- from this tape instead of integrating the
+    in-kernel physics; the agent supplies the recorded action draws through `PPO_Agent.set_action_noise`.  Everything else of the
+    timed rollout path runs unchanged, which pins it to a run of the reference's own PPO_Agent.train (tests/test_gpu_agent_replay.py;
+    reference: ppo_agent.py:111-181, on_policy.py:128-169, dummy_vec_env.py:65-76).  Duck-types envs/cartpole.py's provider (the
+    simulator-state tensors exist, unused by the tape instances of the kernel); `tape_pos` is the device counter of the tape row of the
+    next rollout's first vector step (PPO_Agent advances it by horizon_size per rollout, inside the captured rollout graph)."""
+    graph_safe = True
+    is_cartpole_tape = True
+
+    def __init__(self, obs0, next_obs, rewards, terminated, truncated, reset_obs, max_episode_steps=500, device="cuda"):
+        next_obs = np.asarray(next_obs, np.float32)
+        S, n, D = next_obs.shape
+        assert D == 4, "the CartPole class: 4-d observations"
+        assert np.all(np.asarray(rewards) == 1.0), "the one-launch CartPole rollout has the class's reward (1 per step) built in"
+        self.num_envs, self.n_steps, self.device, self.seed = int(n), int(S), device, 0
+        self.max_episode_steps = int(max_episode_steps)
+        self.observation_space = Box(-np.inf, np.inf, (4,), np.float32)
+        self.action_space = Discrete(2)
+        f32 = lambda x: _dev(x, torch.float32, device)
+        self._obs0 = f32(obs0)
+        self.tape = dict(next_obs=f32(next_obs), reset_obs=f32(np.asarray(reset_obs, np.float32)),
+                         term=f32(np.asarray(terminated) > 0), trunc=f32(np.asarray(truncated) > 0))
+        self.tape_pos = torch.zeros(1, dtype=torch.int32, device=device)
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=device)
+        self.state, self.steps, self.episodes = z(n, 4, dt=torch.float64), z(n, dt=torch.int32), z(n, dt=torch.int32)
+        self.action, self.buf_obs, self.next_obs = z(n, dt=torch.int32), z(n, 4), z(n, 4)
+        self.reward, self.terminated, self.truncated, self.ep_score = z(n), z(n), z(n), z(n)
+        self.stats = z(4, dt=torch.float64)
+
+    def reset(self):
+        self.buf_obs.copy_(self._obs0)
+        self.tape_pos.zero_()
+        return self.buf_obs, [{} for _ in range(self.num_envs)]
+
+    def step_device(self, offset=None):
+        raise NotImplementedError("TapeCartPoleVecEnv feeds the one-launch rollout kernel only (use RecordedVecEnv for the launches per vector step)")
+
+    def close(self):
+        pass
+
+
 class RecordedMultiAgentVecEnv:
     """The multi-agent twin: a recorded run of a vector env with the reference's multi-agent contract (dummy_vec_maenv.py:33-83 --
     per-agent observations, global state, availability masks, per-agent rewards / terminated flags, one truncated flag per env,
