@@ -710,6 +710,17 @@ typedef struct {
     uint32_t* xchg;                                    /* [xrl_rollout_wide_words()] exchange words (zeroed by the call) */
     int32_t* status;                                   /* [4] as xrl_rollout_run_t.status */
     long long* dbg;                                    /* NULL, or [16] shader-clock stamps of workgroup 0 at step n_steps / 2 */
+    /* Tape provider (round 6; envs/recorded.py: TapeControlVecEnv), as xrl_rollout_run_t.tape_*: tape_next_obs != NULL -> row
+     * *tape_pos + t of the tape is what envs.step() returned at vector step t (next observation before an auto-reset, reward,
+     * terminated / truncated, infos[i]["reset_obs"]) instead of the in-kernel provider dynamics; a terminated path then closes with
+     * value 0 (seg bit pattern of xrl_rollout_cartpole_run).  tape_z != NULL: the standard normal of (step t, env e, action j) is
+     * tape_z[(t * n + e) * A + j] instead of the Philox draw (action = mean + std * z, distributions.py:165-178). */
+    const float* tape_next_obs;                        /* [tape_rows][n][D] */
+    const float* tape_reset_obs;                       /* [tape_rows][n][D] */
+    const float* tape_rew; const float* tape_term; const float* tape_trunc;   /* [tape_rows][n] */
+    const uint32_t* tape_pos;                          /* [1] tape row of the rollout's vector step 0 */
+    const float* tape_z;                               /* NULL or [T][n][A] */
+    int32_t tape_rows, pad2;
 } xrl_rollout_wide_t;
 int xrl_rollout_wide_run(const xrl_rollout_wide_t* p, xrl_stream_t stream);
 int xrl_rollout_wide_words(void);

@@ -131,13 +131,18 @@ def golden_agent_ppo(kind="categorical"):
     class ShortCartPole(NumpyCartPoleEnv):
         max_episode_steps = 23
 
-    gauss, pg, a2c, big = kind == "gaussian", kind == "pg", kind == "a2c", kind == "categorical40"
+    gauss, pg, a2c, big = kind in ("gaussian", "gaussian40"), kind == "pg", kind == "a2c", kind in ("categorical40", "gaussian40")
     agent_mod.SummaryWriter = _NullWriter
     pa.tqdm = lambda x, *a, **k: x
     import xuance.torch.agents.core.on_policy as onp
     onp.tqdm = lambda x, *a, **k: x
-    n, T, rollouts = (40, 16, 2) if big else (8, 32, 3)
-    if big:
+    n, T, rollouts = (40, 8, 3) if kind == "gaussian40" else (40, 16, 2) if big else (8, 32, 3)
+    if kind == "gaussian40":
+        # agent_ppo_gaussian_40.npz (round 6): 40 envs = three workgroups of xrl_rollout_wide_run; three rollouts of 8 steps (the host
+        # env truncates at 19), one update per rollout (142 k parameters: ~4 MB)
+        cfg = agent_config("ppo/mujoco.yaml", parallels=n, horizon_size=T, n_epochs=1, n_minibatch=1, seed=29)
+        Env, D = HostControlShapedEnv, 17
+    elif big:
         # agent_ppo_40.npz (round 6): 40 envs = three 16-env workgroups of the one-launch rollout kernel (csrc/rollout_actor.hip), so a
         # replay through that kernel also crosses its per-step exchange of observation statistics; two rollouts of 16 steps, 1 x 2 updates
         cfg = agent_config("ppo/classic_control/CartPole-v1.yaml", parallels=n, horizon_size=T, n_epochs=1, n_minibatch=2, seed=23)
@@ -230,7 +235,7 @@ def golden_agent_ppo(kind="categorical"):
                            Env.max_episode_steps], np.float64)
     out["cfg_names"] = np.array("n_envs horizon_size n_epochs n_minibatch gamma gae_lambda learning_rate vf_coef ent_coef clip_range "
                                 "grad_clip_norm obsnorm_range rewnorm_range total_iters max_episode_steps".split())
-    name = "agent_pg" if pg else "agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo_40" if big else "agent_ppo"
+    name = "agent_pg" if pg else "agent_a2c" if a2c else ("agent_ppo_gaussian_40" if big else "agent_ppo_gaussian") if gauss else "agent_ppo_40" if big else "agent_ppo"
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name + ":", len(out), "arrays;", int(term.sum()), "terminations,", int((trunc & ~term).sum()), "truncations")
 
@@ -241,6 +246,10 @@ def golden_agent_ppo_gaussian():
 
 def golden_agent_ppo_40():
     golden_agent_ppo("categorical40")
+
+
+def golden_agent_ppo_gaussian_40():
+    golden_agent_ppo("gaussian40")
 
 
 def golden_agent_a2c():
@@ -759,6 +768,6 @@ def golden_agent_qmix_rnn():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    todo = sys.argv[1:] or ["ppo", "ppo_40", "ppo_gaussian", "a2c", "pg", "dqn", "dqn_atari", "perdqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
+    todo = sys.argv[1:] or ["ppo", "ppo_40", "ppo_gaussian", "ppo_gaussian_40", "a2c", "pg", "dqn", "dqn_atari", "perdqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
     for name in todo:
         globals()[f"golden_agent_{name}"]()

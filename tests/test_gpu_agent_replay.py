@@ -36,7 +36,8 @@ def categorical_uniforms(probs, acts):
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
-@pytest.mark.parametrize("kind", ["categorical", "categorical-one-launch", "categorical-one-launch-40", "gaussian", "a2c"])
+@pytest.mark.parametrize("kind", ["categorical", "categorical-one-launch", "categorical-one-launch-40", "gaussian", "gaussian-one-launch",
+                                  "gaussian-one-launch-40", "a2c"])
 def test_ppo_agent_replays_the_reference_run(kind, use_graph):
     """agent_ppo.npz: the reference's PPO_Agent (configs/ppo/classic_control/CartPole-v1.yaml) over three rollouts of 8 envs x 32
     steps with 31 terminations and 12 truncations, 2 x 2 minibatch updates per rollout.  agent_ppo_gaussian.npz: the same loop with
@@ -45,27 +46,31 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
     normals (action - mean) / std.  use_graph: the rollout and the update phase as one captured hipGraph each (replayed on the
     following stretch of the tape / the next indices) or launch by launch."""
     from xuance_amd.agents import PPO_Agent, A2C_Agent
-    from xuance_amd.envs import RecordedVecEnv, TapeCartPoleVecEnv
+    from xuance_amd.envs import RecordedVecEnv, TapeCartPoleVecEnv, TapeControlVecEnv
     from xuance_amd.spaces import Box, Discrete
     # "categorical-one-launch" (round 6): the same reference run replayed through the TIMED rollout path -- xrl_rollout_cartpole_run, the
     # whole rollout as one launch of resident workgroups (csrc/rollout_actor.hip), + xrl_rollout_cartpole_values -- with the tape as the
     # kernel's provider (xrl_rollout_run_t.tape_*) and the recorded action draws as its uniforms: every assertion below is the one the
     # launches per vector step pass.  "-40": agent_ppo_40.npz, 40 envs = three actor workgroups + the bookkeeper, so the per-step
     # exchange of the observation statistics between workgroups (the tagged messages) is on the replayed path too.
-    one_launch = kind.startswith("categorical-one-launch")
+    # "gaussian-one-launch[-40]": agent_ppo_gaussian[_40].npz through xrl_rollout_wide_run (csrc/rollout_wide.hip, BASELINE configs[3]'s
+    # rollout kernel) with the recorded normals; its values / bootstrap values are the agent's two batched passes afterwards.
+    one_launch = "-one-launch" in kind
     big = kind.endswith("-40")
-    if one_launch:
-        kind = "categorical"
+    kind = kind.split("-")[0]
     gauss, a2c = kind == "gaussian", kind == "a2c"
     # a2c: agent_a2c.npz -- the reference's A2C_Agent (configs/a2c/classic_control/CartPole-v1.yaml: ActorCritic with one representation
     # per head -- nets.ActorCriticNet(head_rep_layers=1) speaks its key names --, A2C_Learner, 1 x 2 updates per rollout, no old_logp)
-    g = load_golden("agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo_40" if big else "agent_ppo")
+    g = load_golden("agent_a2c" if a2c else ("agent_ppo_gaussian_40" if big else "agent_ppo_gaussian") if gauss else "agent_ppo_40" if big else "agent_ppo")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
     S = g["step/acts"].shape[0]
     rollouts = S // T
     A = g["step/acts"].shape[2] if gauss else 2
-    if one_launch:
+    if one_launch and gauss:
+        env = TapeControlVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
+                                g["step/reset_obs"], act_dim=A, max_episode_steps=int(c["max_episode_steps"]))
+    elif one_launch:
         env = TapeCartPoleVecEnv(g["raw_obs0"], g["step/next_obs"], g["step/rewards"], g["step/terminals"], g["step/truncations"],
                                  g["step/reset_obs"], max_episode_steps=int(c["max_episode_steps"]))
     else:
@@ -74,7 +79,7 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
                              max_episode_steps=int(c["max_episode_steps"]))
         env.prepare(T)
     net = dict(representation="Basic_Identical", representation_hidden_size=None, actor_hidden_size=[256, 256], critic_hidden_size=[256, 256],
-               activation="leaky_relu", activation_action="tanh", use_fused_acting=False, use_wide_rollout=False) if gauss else \
+               activation="leaky_relu", activation_action="tanh", use_fused_acting=False, use_wide_rollout=one_launch) if gauss else \
         dict(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128], critic_hidden_size=[128], activation="leaky_relu")
     cfg = Namespace(seed=1, parallels=n, running_steps=10 ** 6, horizon_size=T, n_epochs=E, n_minibatch=MB,
                     learning_rate=c["learning_rate"], vf_coef=c["vf_coef"], ent_coef=c["ent_coef"], clip_range=c["clip_range"],
@@ -84,7 +89,10 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
                     use_hip_graph=use_graph, **net)
     agent = (A2C_Agent if a2c else PPO_Agent)(cfg, env)
     # (A2C_Learner's LinearLR runs over config.running_steps, a2c_learner.py:19-21, not over its estimate_total_iterations())
-    assert agent.use_fused_rollout == one_launch and (not one_launch or (agent._actor_rollout() is not None and agent._persistent_ok()))
+    if gauss:
+        assert not agent.use_fused_rollout and (agent._wide_rollout() is not None) == one_launch
+    else:
+        assert agent.use_fused_rollout == one_launch and (not one_launch or (agent._actor_rollout() is not None and agent._persistent_ok()))
     assert agent.learner.total_iters == (cfg.running_steps if a2c else int(c["total_iters"]))
     init = sub(g, "init")
     assert list(getattr(agent.model, "state_keys", agent.model.ref_order)) == list(init)
@@ -117,8 +125,8 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
         assert_close(npy(f["returns"]), tm(buf["returns"]), 1e-5, f"rollout {p}: returns (finish_path on termination / truncation / buffer end)")
         assert_close(npy(f["advantages"]), tm(buf["advantages"]), 1e-5, f"rollout {p}: GAE advantages", scale=float(np.abs(buf["returns"]).max()))
         # running statistics and the return tracker as the reference left them after the rollout's last vector step
-        om, ov, oc = agent._obs_stats_tensors()            # (the one-launch rollout keeps its statistics in the kernel's state block)
-        rm, rv, rc = (agent.pp["ret_stats"][0][0:1], agent.pp["ret_stats"][0][1:2], agent.pp["ret_count"][0]) if one_launch else \
+        om, ov, oc = agent._obs_stats_tensors()            # (the one-launch CartPole rollout keeps its statistics in the kernel's state block)
+        rm, rv, rc = (agent.pp["ret_stats"][0][0:1], agent.pp["ret_stats"][0][1:2], agent.pp["ret_count"][0]) if (one_launch and not gauss) else \
             (agent.ret_mean, agent.ret_var, agent.ret_count)
         assert_close(npy(om), g["step/obs_rms/mean"][last], 1e-5, "obs_rms.mean", scale=float(np.sqrt(g["step/obs_rms/var"][last]).max()))
         assert_close(npy(ov), g["step/obs_rms/var"][last], 1e-5, "obs_rms.var")

@@ -27,7 +27,7 @@ def a2c_names(keys):
     return out
 
 
-@pytest.mark.parametrize("kind", ["categorical", "categorical40", "gaussian", "a2c"])
+@pytest.mark.parametrize("kind", ["categorical", "categorical40", "gaussian", "gaussian40", "a2c"])
 def test_ppo_agent_loop(oracle, kind):
     """ppo_agent.py:111-181 + core/on_policy.py:182-205: per vector step obs_rms.update(raw obs) -> normalise -> act -> env ->
     store (normalised obs, action, processed reward, value, TERMINATED flag, old_logp); buffer full: V(next_obs) under the CURRENT
@@ -36,10 +36,11 @@ def test_ppo_agent_loop(oracle, kind):
     categorical: agent_ppo.npz (CartPole yaml); gaussian: agent_ppo_gaussian.npz (mujoco yaml: 17-256-256-{6, 1}, tanh on the mean,
     state-independent log_std -- actions are NOT rescaled or clipped on the way to the env, wrapper.py:19,90-91)."""
     o = oracle
-    gauss, a2c = kind == "gaussian", kind == "a2c"
+    gauss, a2c = kind in ("gaussian", "gaussian40"), kind == "a2c"
     # a2c: agent_a2c.npz -- A2C_Agent on the generic loop (core/on_policy.py:232-300) with configs/a2c/classic_control/CartPole-v1.yaml:
     # the same path-closing rules with V(next_obs) from the critic's own representation, no old_logp in the buffer, A2C_Learner's loss
-    g = load_golden("agent_a2c" if a2c else "agent_ppo_gaussian" if gauss else "agent_ppo_40" if kind == "categorical40" else "agent_ppo")
+    g = load_golden({"a2c": "agent_a2c", "gaussian": "agent_ppo_gaussian", "gaussian40": "agent_ppo_gaussian_40", "categorical40": "agent_ppo_40",
+                     "categorical": "agent_ppo"}[kind])
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, T, E, MB = (int(c[k]) for k in ("n_envs", "horizon_size", "n_epochs", "n_minibatch"))
     S, D = g["step/acts"].shape[0], g["raw_obs0"].shape[1]

@@ -237,7 +237,9 @@ class RolloutWide(C.Structure):
                 ("step_dev", c_void_p), ("env_step_dev", c_void_p)] + \
                [(k, c_void_p) for k in ("obs_raw", "obs_mean", "obs_var", "obs_count", "ret_mean", "ret_var", "ret_count", "ret_track", "env_state", "env_steps",
                                         "env_score", "env_stats", "Amat", "Bmat", "f_obs", "f_act", "f_logp", "f_rew", "f_term", "f_seg",
-                                        "xnext", "ended", "ret_final", "raw_rew", "xchg", "status", "dbg")]
+                                        "xnext", "ended", "ret_final", "raw_rew", "xchg", "status", "dbg",
+                                        "tape_next_obs", "tape_reset_obs", "tape_rew", "tape_term", "tape_trunc", "tape_pos", "tape_z")] + \
+               [("tape_rows", c_int32), ("pad2", c_int32)]
 
 
 class PpoFused(C.Structure):

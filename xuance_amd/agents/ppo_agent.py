@@ -375,7 +375,8 @@ class PPO_Agent(AgentSurface):
             from ..envs.synthetic import SyntheticMujocoVecEnv
             env, n, T, dev = self.envs, self.n_envs, self.horizon_size, self.device
             ok = bool(_get(self.config, "use_wide_rollout", True)) and type(self)._enqueue_step is PPO_Agent._enqueue_step and \
-                type(env) is SyntheticMujocoVecEnv and self.model.dist == "gaussian" and ops.WideRollout.eligible(self.model, n) and \
+                (type(env) is SyntheticMujocoVecEnv or getattr(env, "is_control_tape", False)) and self.model.dist == "gaussian" and \
+                ops.WideRollout.eligible(self.model, n) and \
                 tuple(env.buf_obs.shape) == (n, self.obs_dim)
             if ok:
                 f, D = self.memory.soa.fields, self.obs_dim
@@ -397,6 +398,15 @@ class PPO_Agent(AgentSurface):
                     f_term=f["terminals"], f_seg=f["seg"], xnext=self._wr_xnext, ended=torch.zeros(T, n4, dtype=torch.uint8, device=dev),
                     ret_final=torch.zeros(T, n4, device=dev), raw_rew=torch.zeros(T, n4, device=dev), xchg=self._wr_xchg,
                     status=self._wr_status)
+                tape = getattr(env, "tape", None)
+                if tape is not None:
+                    # a recorded run as the provider (envs/recorded.py: TapeControlVecEnv): the simulators' outputs from the tape, the action
+                    # draws' normals from the staging tensor set_action_noise fills (xrl_rollout_wide_t.tape_*)
+                    self.action_noise = torch.zeros(T, n, self.model.action_dim, device=dev)
+                    q = self._wr.q
+                    q.tape_next_obs, q.tape_reset_obs, q.tape_rew = (tape[k].data_ptr() for k in ("next_obs", "reset_obs", "rew"))
+                    q.tape_term, q.tape_trunc = tape["term"].data_ptr(), tape["trunc"].data_ptr()
+                    q.tape_pos, q.tape_rows, q.tape_z = env.tape_pos.data_ptr(), int(env.n_steps), self.action_noise.data_ptr()
         return self._wr
 
     def _enqueue_rollout_wide(self, wr):
@@ -530,9 +540,10 @@ class PPO_Agent(AgentSurface):
         Gaussian one) instead of the Philox stream.  The values are copied into one staging tensor, so a captured rollout graph
         replays on whatever the caller staged last."""
         x = torch.as_tensor(np.asarray(noise, np.float32), device=self.device)
-        if self.use_fused_rollout and getattr(self.envs, "tape", None) is not None:
-            # the one-launch rollout over a tape reads its uniforms from the staging tensor (xrl_rollout_run_t.tape_u)
-            assert self._actor_rollout() is not None, "a tape provider needs the actor rollout kernel"
+        if getattr(self.envs, "tape", None) is not None and (self.use_fused_rollout or getattr(self.envs, "is_control_tape", False)):
+            # the one-launch rollouts over a tape read their draws from the staging tensor (xrl_rollout_run_t.tape_u / xrl_rollout_wide_t.tape_z)
+            assert (self._actor_rollout() if self.use_fused_rollout else self._wide_rollout()) is not None, \
+                "a tape provider needs the one-launch rollout kernel of the network's class"
             self.action_noise.copy_(x.reshape(self.action_noise.shape))
             return
         assert not self.use_fused_rollout and self._wide_rollout() is None, \
@@ -639,6 +650,8 @@ class PPO_Agent(AgentSurface):
             env = self.envs
             wstate = [self.returns, self.step_counter, env.step_counter, env.state, env.steps, env.ep_score, env.stats, env.buf_obs,
                       self.obs_mean, self.obs_var, self.obs_count, self.ret_mean, self.ret_var, self.ret_count]
+            if getattr(env, "tape", None) is not None:
+                wstate.append(env.tape_pos)
             wsaved = [x.clone() for x in wstate]
             self._launch_rollout()
             torch.cuda.synchronize()

@@ -120,7 +120,9 @@ __device__ __forceinline__ void wide_bookkeeper(const xrl_rollout_wide_t& q, int
     if (lane == 0) { *q.ret_mean = mean; *q.ret_var = var; *q.ret_count = count; }
 }
 
-template <int ACT, int OACT>
+// TAPE: the provider's outputs and the action draws' normals come from a recorded tape (xrl_rollout_wide_t.tape_*); every other
+// instruction is shared with the timed instances.
+template <int ACT, int OACT, bool TAPE>
 __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q) {
 #pragma clang fp contract(off)
     if (blockIdx.x & 7) return;                                  // one XCD's share of the grid (rollout_actor.hip)
@@ -237,7 +239,11 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     const uint32_t nz_stream = drawer ? 0x47415500u + (uint32_t)dj : 0x53594E00u + (uint32_t)id;
     const uint32_t nz_step0 = drawer ? pstep0 : estep0;
     const float nz_floor = drawer ? 5.96e-8f : 1e-7f, nz_scale = drawer ? 1.f : 0.01f;     // (policy_normal | 0.01 provider_normal)
-    auto step_normal = [&](int k) {
+    const size_t tape_row0 = TAPE ? (size_t)(*q.tape_pos) + (size_t)t0 : 0;
+    auto step_normal = [&](int k) -> float {
+        if constexpr (TAPE) {                                    // supplied normals of the action draw; the provider's noise is on the tape
+            if (q.tape_z) return (drawer && t0 + k < T && e0 + dr < n) ? q.tape_z[((size_t)(t0 + k) * n + e0 + dr) * A + dj] : 0.f;
+        }
         uint32_t r[4];
         philox4x32(nz_seed, nz_env, nz_step0 + (uint32_t)k, nz_stream, r);
         const float u1 = fmaxf(u01(r[0]), nz_floor), u2 = u01(r[1]);
@@ -440,7 +446,13 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             }
             lp += __shfl_xor(lp, 16, 64); lp += __shfl_xor(lp, 32, 64);
             if (g == 0 && e0 + cl < n) q.f_logp[(size_t)t * n + e0 + cl] = lp;
-            if (rowl) {                                          // the row's truncation flag and action penalty (sum over j in order)
+            if (rowl) {                                          // the row's episode-end flags (bit 0 over, bit 1 terminated) and action penalty (sum over j in order)
+                if constexpr (TAPE) {
+                    const size_t r = tape_row0 + (size_t)k;
+                    const bool okr = e0 + tid < n && r < (size_t)q.tape_rows;
+                    const bool tm = okr && q.tape_term[r * n + e0 + tid] > 0.f, tc = okr && q.tape_trunc[r * n + e0 + tid] > 0.f;
+                    s_trunc[tid] = ((tm || tc) ? 1 : 0) | (tm ? 2 : 0);
+                } else
                 s_trunc[tid] = (ep_steps + 1 >= q.max_steps) ? 1 : 0;
                 float pen = 0.f;
 #pragma unroll
@@ -458,7 +470,11 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
             const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int j = 0; j < WAM; ++j) if (j < A) acc += fminf(fmaxf(av[j], -1.f), 1.f) * bv[j];
-            const float y = provider_tanh(acc) + noise;
+            float y = provider_tanh(acc) + noise;
+            if constexpr (TAPE) {                                // what the recorded simulator returned
+                const size_t r = tape_row0 + (size_t)k;
+                y = (item_ok && r < (size_t)q.tape_rows) ? q.tape_next_obs[(r * n + ie) * D + id] : 0.f;
+            }
             if (id == 0) s_y0[ir] = y;
             // next observation before the reset, normalised with this step's statistics (get_terminated_values' input)
             if (item_ok) {
@@ -467,6 +483,10 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
                 q.xnext[((size_t)t * n + ie) * D + id] = xv;
             }
             float v = y;
+            if constexpr (TAPE) {                                // infos[i]["reset_obs"] of the recorded step
+                const size_t r = tape_row0 + (size_t)k;
+                if (s_trunc[ir] != 0) v = (item_ok && r < (size_t)q.tape_rows) ? q.tape_reset_obs[(r * n + ie) * D + id] : 0.f;
+            } else
             if (s_trunc[ir] != 0) v = 0.1f * provider_normal(q.env_seed, (uint32_t)ie, estep0 + (uint32_t)k, 0x53594E00u + 64u + (uint32_t)id);
             s_st[ir][id] = v; s_raw[ir][id] = v;
         }
@@ -477,16 +497,21 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
         if (k + 1 < n_steps) prepare();
         // the rows' records and episode counters (wave 0's lanes 0..15; its stores trail the message)
         if (rowl) {
-            const bool trunc = s_trunc[tid] != 0;
-            const float rew = s_y0[tid] - 0.1f * row_pen;
+            const bool trunc = s_trunc[tid] != 0;                 // (the episode is over: truncated, or -- tape -- terminated)
+            const bool term = TAPE && (s_trunc[tid] & 2) != 0;
+            float rew = s_y0[tid] - 0.1f * row_pen;
+            if constexpr (TAPE) {
+                const size_t r = tape_row0 + (size_t)k;
+                rew = (row_ok && r < (size_t)q.tape_rows) ? q.tape_rew[r * n + e0 + tid] : 0.f;
+            }
             const int steps = ep_steps + 1;
             const float score = ep_score + rew;
             const float tr = q.gamma * rtrack + rew;              // self.returns = gamma * self.returns + rewards
             if (row_ok) {
                 const int n4 = (n + 3) & ~3;
                 const size_t o = (size_t)t * n + e0 + tid, o4 = (size_t)t * n4 + e0 + tid;
-                q.f_term[o] = 0.f;
-                q.f_seg[o] = (trunc || t == T - 1) ? (uint8_t)1 : (uint8_t)0;
+                q.f_term[o] = term ? 1.f : 0.f;
+                q.f_seg[o] = (trunc || t == T - 1) ? (uint8_t)(1 | (term ? 6 : 0)) : (uint8_t)0;
                 w_st_dev(q.raw_rew + o4, rew);
                 if (trunc) w_st_dev(q.ret_final + o4, tr);
                 w_st_dev(q.ended + o4, (uint8_t)(trunc ? 1 : 0));
@@ -564,9 +589,18 @@ extern "C" int xrl_rollout_wide_run(const xrl_rollout_wide_t* qq, xrl_stream_t s
     const int n_wg = (q.n + WR - 1) / WR + 1;                           // actors + the bookkeeper
     XRL_CHECK_ARG(n_wg <= device_cu_count() / 8);
     hipLaunchKernelGGL(zero_wide_xchg_kernel, dim3(16), dim3(512), 0, as_stream(stream), q.xchg);
+    if (q.tape_next_obs) {
+        XRL_CHECK_ARG(q.tape_reset_obs && q.tape_rew && q.tape_term && q.tape_trunc && q.tape_pos && q.tape_rows >= 1);
+        XRL_ACT_DISPATCH(q.act,
+            if (q.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((wide_rollout_kernel<ACT, XRL_ACT_TANH, true>), dim3(8 * n_wg), dim3(WTH), 0, as_stream(stream), q);
+            else hipLaunchKernelGGL((wide_rollout_kernel<ACT, XRL_ACT_NONE, true>), dim3(8 * n_wg), dim3(WTH), 0, as_stream(stream), q);)
+        XRL_CHECK_LAUNCH();
+        return XRL_OK;
+    }
+    XRL_CHECK_ARG(q.tape_z == nullptr);                                  // (supplied normals ride with a tape only)
     XRL_ACT_DISPATCH(q.act,
-        if (q.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((wide_rollout_kernel<ACT, XRL_ACT_TANH>), dim3(8 * n_wg), dim3(WTH), 0, as_stream(stream), q);
-        else hipLaunchKernelGGL((wide_rollout_kernel<ACT, XRL_ACT_NONE>), dim3(8 * n_wg), dim3(WTH), 0, as_stream(stream), q);)
+        if (q.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((wide_rollout_kernel<ACT, XRL_ACT_TANH, false>), dim3(8 * n_wg), dim3(WTH), 0, as_stream(stream), q);
+        else hipLaunchKernelGGL((wide_rollout_kernel<ACT, XRL_ACT_NONE, false>), dim3(8 * n_wg), dim3(WTH), 0, as_stream(stream), q);)
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

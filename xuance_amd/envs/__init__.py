@@ -5,7 +5,7 @@ from .shm_vec_env import ShmSubprocVecEnv
 from .shm_vec_maenv import ShmSubprocVecMultiAgentEnv
 from .dummy_vec_env import DummyVecEnv, DummyVecMultiAgentEnv, HostSMACLikeEnv
 from .synthetic import SyntheticAtariVecEnv, SyntheticMujocoVecEnv, SyntheticSMACVecEnv
-from .recorded import RecordedVecEnv, RecordedMultiAgentVecEnv, TapeCartPoleVecEnv
+from .recorded import RecordedVecEnv, RecordedMultiAgentVecEnv, TapeCartPoleVecEnv, TapeControlVecEnv
 
 REGISTRY_VEC_ENV = {"DeviceCartPoleVecEnv": DeviceCartPoleVecEnv, "DevicePendulumVecEnv": DevicePendulumVecEnv,
                     "DeviceMountainCarVecEnv": DeviceMountainCarVecEnv, "DeviceAcrobotVecEnv": DeviceAcrobotVecEnv, "SyntheticAtariVecEnv": SyntheticAtariVecEnv,

@@ -151,6 +151,52 @@ class TapeCartPoleVecEnv:
         pass
 
 
+class TapeControlVecEnv:
+    """TapeCartPoleVecEnv's twin for the two-branch Gaussian class D-256-256-{A | 1} (configs/ppo/mujoco.yaml; csrc/rollout_wide.hip,
+    xrl_rollout_wide_t.tape_*): a recorded run of a continuous-control vector env (observations [D <= 20], Box(A <= 8) actions, any
+    rewards, terminations and truncations) as the provider of the one-launch rollout kernel xrl_rollout_wide_run; the recorded action
+    draws go in through `PPO_Agent.set_action_noise` as standard normals.  Duck-types envs/synthetic.py: SyntheticMujocoVecEnv."""
+    graph_safe = True
+    is_control_tape = True
+
+    def __init__(self, obs0, next_obs, rewards, terminated, truncated, reset_obs, act_dim, max_episode_steps=1000, device="cuda"):
+        from .. import ops
+        self._ops = ops
+        next_obs = np.asarray(next_obs, np.float32)
+        S, n, D = next_obs.shape
+        self.num_envs, self.n_steps, self.device, self.seed = int(n), int(S), device, 0
+        self.max_episode_steps = int(max_episode_steps)
+        self.observation_space = Box(-np.inf, np.inf, (D,), np.float32)
+        self.action_space = Box(-1.0, 1.0, (int(act_dim),), np.float32)
+        f32 = lambda x: _dev(x, torch.float32, device)
+        self._obs0 = f32(obs0)
+        self.tape = dict(next_obs=f32(next_obs), reset_obs=f32(np.asarray(reset_obs, np.float32)), rew=f32(rewards),
+                         term=f32(np.asarray(terminated) > 0), trunc=f32(np.asarray(truncated) > 0))
+        self.tape_pos = torch.zeros(1, dtype=torch.int32, device=device)
+        z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=device)
+        self.A, self.B, self.state = z(D, D), z(int(act_dim), D), z(n, D)
+        self.steps, self.ep_score, self.stats = z(n, dt=torch.int32), z(n), z(4, dt=torch.float64)
+        self.step_counter = z(1, dt=torch.int32)
+        self.buf_obs, self.next_obs = z(n, D), z(n, D)
+        self.action = z(n, int(act_dim))
+        self.reward, self.terminated, self.truncated = z(n), z(n), z(n)
+
+    def reset(self):
+        self.buf_obs.copy_(self._obs0)
+        self.tape_pos.zero_()
+        return self.buf_obs, [{} for _ in range(self.num_envs)]
+
+    def advance(self, k):
+        self._ops.counter_add(self.step_counter, int(k))
+        self._ops.counter_add(self.tape_pos, int(k))            # the next rollout reads the following stretch of the tape
+
+    def step_device(self, offset=None):
+        raise NotImplementedError("TapeControlVecEnv feeds the one-launch rollout kernel only (use RecordedVecEnv for the launches per vector step)")
+
+    def close(self):
+        pass
+
+
 class RecordedMultiAgentVecEnv:
     """The multi-agent twin: a recorded run of a vector env with the reference's multi-agent contract (dummy_vec_maenv.py:33-83 --
     per-agent observations, global state, availability masks, per-agent rewards / terminated flags, one truncated flag per env,
