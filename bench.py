@@ -400,6 +400,8 @@ def main():
         out["config"]["gradient_paths_ms"] = paths_ms
         out["config"]["rccl_world"] = bw.rccl_world(world)
         out["config"]["backend"] = dist.get_backend()
+        # (round 6: also at the top level of the line, so that one SCALE run of the driver records every path's cost per N)
+        out["gradient_paths_ms"], out["rccl_world"], out["gradient_path"] = paths_ms, out["config"]["rccl_world"], path
         if out["config"]["rccl_world"] != world:
             raise SystemExit("bench.py: the RCCL all-reduce over the %d ranks counted %s participants" % (world, out["config"]["rccl_world"]))
     if rank == 0:
@@ -473,6 +475,9 @@ def main():
             # cpu_port: the oracle's NumPy port of the same loop, timed live on THIS host's cores
             out["cpu_baseline"] = reference_cpu_baseline("ppo_cartpole", str(args.n_envs))
             out["cpu_port"] = cpu_baseline(args.n_envs, args.horizon)
+            # (round 6: the one SAME-HOST CPU figure also rides inside cpu_baseline, next to the reference's number from the build host)
+            if isinstance(out["cpu_baseline"], dict):
+                out["cpu_baseline"]["same_host_port"] = out["cpu_port"]
         if world == 1 and c2 and not args.no_secondary:
             sec = {}
             try:
@@ -484,6 +489,7 @@ def main():
                 import bench_secondary as bs
                 sec["ppo_cartpole_16_envs"] = bs.ppo_small(make_config, kernel_rooflines, 16, args.horizon,
                                                            ref=reference_cpu_baseline("ppo_cartpole", "16"))
+                sec["ppo_acrobot_256_envs"] = bs.ppo_acrobot(make_config)
                 sec["qmix_3m_ff"] = bs.qmix_3m(False, ref=reference_cpu_baseline("qmix_3m_ff"))
                 sec["qmix_3m_gru"] = bs.qmix_3m(True, ref=reference_cpu_baseline("qmix_3m_gru"))
                 # the two remaining BASELINE configs at their per-GPU shapes (the reference's CPU time exists per update only:

@@ -1126,6 +1126,39 @@ typedef struct {
     uint64_t draw_seed;
     uint32_t draw_counter, pad3;
 } xrl_qmix_fused_t;
+/* A whole update phase of the feed-forward QMIX learner -- train_epochs' n_epochs x {sample, update} (off_policy_marl.py:573-594 with
+ * qmix_learner.py:24-112) -- as ONE launch (round 6): the workgroups of xrl_qmix_fused_update stay resident for the n_updates updates of
+ * the phase; after every update they meet (flags through the L2 they share: the launch keeps blockIdx % 8 == 0 of an 8x
+ * oversubscribed grid, i.e. one XCD's share, as the one-launch rollout kernels do; any other placement is noticed and goes through
+ * agent-scope release / acquire fences), workgroup g sums its 1/n-th of the parameters over the slabs in xrl_reduce_adam's order,
+ * applies Adam (+ LinearLR, + the periodic hard target update) and writes the new parameters to params, both weight images and the
+ * acting launch's image; a second meeting, and every workgroup re-stages the weights for the next update.  Same statements per element
+ * as n_updates x {xrl_qmix_fused_update(ring mode, counter + u), xrl_reduce_adam}: parameters, moments, target and images bit-identical.
+ * Needs: ring mode (p->ring_n_envs > 0: update u draws with counter draw_counter + u), no gradient clipping (configs/qmix/sc2/3m.yaml:45:
+ * nothing then depends on the global norm inside an update), ceil(B / items_per_wg) <= compute units / 8 workgroups, P % 4 == 0.
+ * p->partials is ignored: update u writes its loss partials to phase_partials[u] and their sums to epoch_sums[u]. */
+#define XRL_QF_PHASE_SYNC_WORDS 256
+typedef struct {
+    int32_t n_updates;
+    int32_t sync_every;         /* > 0: target <- parameters whenever the optimiser step is a multiple of it (copy_target, qmix_learner.py:105-106) */
+    float* params; float* grad; float* m; float* v;
+    int64_t P;
+    xrl_adam_state_t* state;
+    const int32_t* map;         /* [P] parameter index -> index in the weight images (< 0: none); p->img_eval / p->img_target are written */
+    float* target;              /* [P] target parameters */
+    float* act_image;           /* NULL, or the acting launch's weight image ... */
+    const int32_t* act_map;     /* ... and its map [P] */
+    double* phase_partials;     /* [n_updates][B][8] */
+    double* epoch_sums;         /* [n_updates][8] */
+    double* sumsq_part;         /* [>= workgroups] partial sums of squares of the reduced gradient (last_grad_norm) */
+    float* scalars;             /* [2 n_updates] scratch: Adam's step size / sqrt(bias correction 2) per update (filled by the call) */
+    uint32_t* tick;             /* NULL, or a counter advanced by tick_inc at the end of the phase (the replay draw counter) */
+    int32_t tick_inc, pad;
+    uint32_t* sync;             /* [XRL_QF_PHASE_SYNC_WORDS] zero-initialised once; sync[2] != 0 afterwards: a wait timed out (phase invalid) */
+} xrl_qmix_phase_t;
+int xrl_qmix_fused_phase(const xrl_qmix_fused_t* p, const xrl_qmix_phase_t* phase, xrl_stream_t stream);
+/* 1 if xrl_qmix_fused_phase can run B transitions in groups of items_per_wg for P parameters on this device */
+int xrl_qmix_fused_phase_fits(int32_t B, int32_t items_per_wg, int64_t P);
 int xrl_qmix_fused_update(const xrl_qmix_fused_t* p, xrl_stream_t stream);
 int xrl_qmix_fused_lds_bytes(const xrl_qmix_fused_t* p);   /* LDS the launch needs (must be <= 160 KB), -1 on bad dims */
 int xrl_qmix_fused_layout(const xrl_qmix_fused_t* p, xrl_qf_image_t* out);   /* needs n_layers, dims, N, S, H, HH only */

@@ -372,7 +372,10 @@ def test_bench_contract_with_two_ranks():
     the whole-job value, max-over-ranks timing, n_gpus = 2, weak scaling."""
     import json
     import subprocess
-    env = dict(os.environ, XRL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (round 6) where two devices are visible the contract runs as it does on the node: one GPU per rank over RCCL; ranks that have
+    # to share the test box's one GPU go over gloo (RCCL refuses duplicate devices)
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = dict(os.environ, XRL_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
@@ -390,7 +393,8 @@ def test_bench_contract_with_two_ranks():
     c = d["config"]
     timed = {k: v for k, v in c["gradient_paths_ms"].items() if not isinstance(v, str)}
     assert "cut" in c["gradient_paths_ms"] and timed and c["gradient_path"] == min(timed, key=timed.get)
-    assert c["rccl_world"] == 2 and c["backend"] == "gloo" and isinstance(c["gradient_average"], str)
+    assert c["rccl_world"] == 2 and c["backend"] == backend and isinstance(c["gradient_average"], str)
+    assert d["rccl_world"] == 2 and d["gradient_paths_ms"] == c["gradient_paths_ms"]     # (also at the top of the line: a SCALE run's record)
     assert c["rollout_mode"].startswith(("whole-rollout launch", "one launch per vector step"))
 
 

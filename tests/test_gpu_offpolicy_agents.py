@@ -864,3 +864,45 @@ def test_shm_multi_agent_vec_env_device_path_and_evaluation(tmp_path):
     s_shm = m.test(test_episodes=6, test_envs=venv2, close_envs=True)
     s_ref = m.test(test_episodes=6, test_envs=DummyVecMultiAgentEnv([HostSMACLikeEnv] * 4, env_seed=9), close_envs=True)
     assert venv2.closed and len(s_shm) >= 6 and s_shm == s_ref
+
+
+def test_qmix_phase_launch_is_bit_identical_to_the_launch_pairs():
+    """xrl_qmix_fused_phase (round 6): the 8 updates of a feed-forward QMIX vector step as ONE launch -- resident workgroups, slab sums /
+    Adam / target sync / weight images between two updates inside the launch -- against the captured sequence of 8 x {xrl_qmix_fused_update,
+    xrl_reduce_adam} it replaces: two agents that differ in this switch only, same seeds, same device provider, 40 vector steps (a few
+    hundred updates, several hard target syncs): parameters, target, moments, both weight images, the acting image, the replay ring and
+    the optimiser's counters must be EQUAL (a stale weight or slab read between two workgroups of the launch would part the runs)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_secondary as bs
+    from xuance_amd.agents import QMIX_Agents
+    from xuance_amd.envs import SyntheticSMACVecEnv
+    agents = []
+    for phase in (True, False):
+        cfg = bs._qmix_cfg(64, False)
+        cfg.use_qmix_phase_launch = phase
+        cfg.sync_frequency = 50
+        torch.manual_seed(0)
+        agents.append(QMIX_Agents(cfg, SyntheticSMACVecEnv(64, seed=3)))
+    a, b = agents
+    for rnd in range(4):
+        a.train(12); b.train(12)
+        torch.cuda.synchronize()
+        la, lb = a.learner, b.learner
+        assert la._phase_launch and not lb._phase_launch, "the switch did not select the two paths"
+        assert int(la._phase_sync[2].item()) == 0, "a meeting of the phase launch timed out"
+        sa, sb = la.read_optimizer(), lb.read_optimizer()
+        assert sa.step == sb.step > 0 and sa.sched_steps == sb.sched_steps and sa.last_lr == sb.last_lr
+        assert abs(sa.last_grad_norm - sb.last_grad_norm) <= 1e-12 * max(1.0, abs(sb.last_grad_norm))      # (reported only: float64 sum order)
+        for name in ("flat",):
+            assert torch.equal(a.model.params.flat, b.model.params.flat), f"round {rnd}: parameters"
+        assert torch.equal(a.model.target_flat, b.model.target_flat), f"round {rnd}: target parameters"
+        assert torch.equal(la.optimizer.m, lb.optimizer.m) and torch.equal(la.optimizer.v, lb.optimizer.v) and torch.equal(la.optimizer.grad, lb.optimizer.grad)
+        assert torch.equal(la._fused.img_eval, lb._fused.img_eval) and torch.equal(la._fused.img_target, lb._fused.img_target)
+        if getattr(a.model, "_act_state", None) is not None:
+            assert torch.equal(a.model._act_state.image, b.model._act_state.image), "acting launch's weight image"
+        assert torch.equal(la._epoch_sums, lb._epoch_sums), "loss sums of the last phase"
+        assert torch.equal(la._sample_counter, lb._sample_counter)
+        for k, v in a.memory.soa.fields.items():
+            assert torch.equal(v, b.memory.soa.fields[k]), f"round {rnd}: replay ring field {k}"
+    assert sa.step >= 150 and sa.step // 50 >= 3, "the run did not cross several hard target syncs"

@@ -107,6 +107,42 @@ def ppo_small(make_config, kernel_rooflines, n_envs=16, horizon=256, steps=20, w
     return out
 
 
+def ppo_acrobot(make_config, n_envs=256, horizon=256, steps=10, warmup=3):
+    """PPO-Clip on the device Acrobot-v1 (configs/ppo/classic_control/Acrobot-v1.yaml's network 6-128-{128-3, 128-1} and
+    hyper-parameters) at the headline's sizes: a NON-CartPole member of the shared-trunk family -- the any-(D, A) instances of
+    ppo_trunk_kernel on 64-row tiles and the general captured rollout (one launch group per vector step; only the (4, 2) class has the
+    one-launch rollout kernel) -- so the gap to the specialised class is on record (review item 6 of round 5)."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceAcrobotVecEnv
+    torch.manual_seed(1)
+    agent = PPO_Agent(make_config(n_envs, horizon, 1, 0), DeviceAcrobotVecEnv(n_envs, seed=1))
+    for _ in range(warmup):
+        agent.rollout(); agent.update()
+    _settle()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.rollout()
+        agent.update()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(3):
+        agent.rollout()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(3):
+        agent.update()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    lr = agent.learner
+    return {"workload": "PPO-Clip Acrobot-v1 (device env), %d envs x horizon %d, 8 epochs x 8 minibatches of %d, network 6-128-{128-3, 128-1}"
+                        % (n_envs, horizon, n_envs * horizon // 8),
+            "value": round(n_envs * horizon * steps / dt, 1), "unit": "env-steps/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "steps": steps, "warmup": warmup, "rollout_ms": round((t2 - t1) / 3 * 1e3, 4), "update_ms": round((t3 - t2) / 3 * 1e3, 4),
+            "update_kernel": "ppo_trunk_kernel<leaky_relu, categorical, %d rows, any (D, A)>" % (64 if getattr(lr, "pair", False) else 32),
+            "rollout_path": "captured launches per vector step (general path)"}
+
+
 def _qmix_cfg(n, rnn):
     c = dict(q_hidden_size=[64], hidden_dim_mixing_net=32, hidden_dim_hyper_net=32, activation="relu", seed=1, parallels=n,
              running_steps=10 ** 7, batch_size=32, learning_rate=7e-4, gamma=0.99, double_q=True, start_greedy=1.0,

@@ -299,6 +299,17 @@ class QmixFused(C.Structure):
                 ("idx_out", c_void_p), ("draw_seed", C.c_uint64), ("draw_counter", C.c_uint32), ("pad3", C.c_uint32)]
 
 
+class QmixPhase(C.Structure):
+    """xrl_qmix_phase_t: the optimiser's side of a whole update phase done by one launch (xrl_qmix_fused_phase)."""
+    _fields_ = [("n_updates", c_int32), ("sync_every", c_int32), ("params", c_void_p), ("grad", c_void_p), ("m", c_void_p), ("v", c_void_p),
+                ("P", c_int64), ("state", c_void_p), ("map", c_void_p), ("target", c_void_p), ("act_image", c_void_p), ("act_map", c_void_p),
+                ("phase_partials", c_void_p), ("epoch_sums", c_void_p), ("sumsq_part", c_void_p), ("scalars", c_void_p), ("tick", c_void_p),
+                ("tick_inc", c_int32), ("pad", c_int32), ("sync", c_void_p)]
+
+
+QF_PHASE_SYNC_WORDS = 256
+
+
 class QaImage(C.Structure):
     _fields_ = [("w", c_int32 * 8), ("b", c_int32 * 8), ("ldw", c_int32 * 8), ("image_floats", c_int32), ("lds_bytes", c_int32)]
 
@@ -382,6 +393,8 @@ _SIGS = {
     "xrl_marl_stored_state": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_ppokl_adapt": [c_void_p, c_int, c_double, c_void_p, c_double, c_void_p, c_void_p],
     "xrl_qmix_fused_update": [C.POINTER(QmixFused), c_void_p],
+    "xrl_qmix_fused_phase": [C.POINTER(QmixFused), C.POINTER(QmixPhase), c_void_p],
+    "xrl_qmix_fused_phase_fits": [c_int32, c_int32, c_int64],
     "xrl_qmix_fused_lds_bytes": [C.POINTER(QmixFused)],
     "xrl_qmix_fused_layout": [C.POINTER(QmixFused), C.POINTER(QfImage)],
     "xrl_marl_act_gru": [C.POINTER(MarlActGru), c_void_p],

@@ -69,8 +69,12 @@ class QMIX_Agents(AgentSurface):
         # (tests/test_gpu_agent_replay.py); `reference_state_broadcast: False` stores every env's own state.
         self.state_broadcast = bool(_get(config, "reference_state_broadcast", True))
         if self.state_broadcast and not hasattr(envs, "done"):
-            raise AttributeError("reference_state_broadcast needs the provider's per-env `done` flags of the last vector step (envs.done, "
-                                 "as envs/synthetic.py: SyntheticSMACVecEnv has them); set reference_state_broadcast: False for a provider without")
+            #  a provider without per-env `done` flags of the last vector step (envs.done, as envs/synthetic.py has them)
+            # cannot feed the reproduction of that defect: store every env's own state and say so
+            import warnings
+            warnings.warn("xuance_amd: reference_state_broadcast needs the provider's per-env `done` flags (envs.done); this provider "
+                          "has none -- storing every env's own global state (reference_state_broadcast: False)")
+            self.state_broadcast = False
         self._stored_state = torch.zeros(self.n_envs, self.state_dim, device=dev) if self.state_broadcast else None
         # ... and zero the recurrent state of flattened row i -- not of env i's rows -- when env i finishes (init_rnn_states_item is
         # handed batch_index = [i_env] for a state whose batch axis is n_envs * n_agents: value_factorization.py:161-167 with
@@ -140,7 +144,8 @@ class QMIX_Agents(AgentSurface):
         # an env that alternates its observation buffers and keeps running episode totals saves the copies and the
         # reductions of a step (envs/synthetic.py); any other env goes through clones and two small sums
         two_buf, totals = getattr(env, "double_buffered", False), getattr(env, "episode_totals", None)
-        if self.use_graph_updates and two_buf and totals is not None and hasattr(env, "enqueue_step"):
+        # (the captured loop draws from the Philox streams -- a supplied exploration tape needs the eager loop)
+        if self.use_graph_updates and two_buf and totals is not None and hasattr(env, "enqueue_step") and self.explore_tape is None:
             return self._run_episodes_captured(n_episodes, totals)
         self._call_prologue(env, mem)
         episodes = 0

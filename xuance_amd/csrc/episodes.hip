@@ -188,13 +188,16 @@ __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
     if (act) {
         const long long ep = tot0 - bas0, st = tot1 - bas1, st_prev = g.snap[1];
         g.snap[0] = ep; g.snap[1] = st;
-        if (g.end_step && c >= 2 && g.n_envs <= GATE_MAX_ENVS) {          // per finished env, in env order (:532-534)
+        if (g.end_step && c >= 2) {                                       // per finished env, in env order (:532-534)
             long long cur_i = call0 + st_prev;
-            for (int j = 0; j < g.n_envs; ++j)
-                if (s_len[j] > 0) {
-                    cur_i += s_len[j];
+            for (int j = 0; j < g.n_envs; ++j) {
+                // (envs beyond the LDS copy are read from memory -- the rule is the same for any n_envs, as in the eager loop)
+                const int len = j < GATE_MAX_ENVS ? s_len[j] : (g.done[j] != 0.f ? g.end_step[j] : 0);
+                if (len > 0) {
+                    cur_i += len;
                     e = (e > g.end_greedy) ? g.start_greedy - g.delta_greedy * (double)cur_i : g.end_greedy;
                 }
+            }
         } else if (!g.end_step || c >= 1) {
             const double cur = (double)(call0 + st);
             e = (e > g.end_greedy) ? g.start_greedy - g.delta_greedy * cur : g.end_greedy;

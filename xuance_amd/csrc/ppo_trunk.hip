@@ -501,36 +501,47 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
         constexpr int PLD = TDMAX + 1;
         if (RB == 2 || wave < 4) {
             const int c = cblk * 32 + li;
-            float acc[4 * NQ], ab = 0.f;
+            // (round 6: any-D instances walk the observation row in passes of two float4 chunks -- 8 accumulators live instead of 24:
+            //  the 64-row any-(D, A) instances spilled 12-13 VGPRs here; same sums, element by element, rows in the same order)
+            constexpr int NQP = DS ? NQ : 2, NPASS = NQ / NQP;
+            float ab = 0.f;
+            float* pp = part + (rblk * TH + c) * PLD;
+#pragma unroll 1
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int q0 = pass * NQP;
+                if (pass > 0 && 4 * q0 >= D) break;
+                float acc[4 * NQP];
 #pragma unroll
-            for (int k = 0; k < 4 * NQ; ++k) acc[k] = 0.f;
+                for (int k = 0; k < 4 * NQP; ++k) acc[k] = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                const float g = dacc[rr] * act_grad_c<ACT>(h1[row * TLD + c]);
-                ab += g;
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                    const float g = dacc[rr] * act_grad_c<ACT>(h1[row * TLD + c]);
+                    if (pass == 0) ab += g;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (4 * q < D) {
-                        const float4 x = *reinterpret_cast<const float4*>(xs + row * TXLD + 4 * q);    // (zero beyond D)
-                        acc[4 * q] += g * x.x; acc[4 * q + 1] += g * x.y; acc[4 * q + 2] += g * x.z; acc[4 * q + 3] += g * x.w;
+                    for (int q = 0; q < NQP; ++q) {
+                        if (4 * (q0 + q) < D) {
+                            const float4 x = *reinterpret_cast<const float4*>(xs + row * TXLD + 4 * (q0 + q));    // (zero beyond D)
+                            acc[4 * q] += g * x.x; acc[4 * q + 1] += g * x.y; acc[4 * q + 2] += g * x.z; acc[4 * q + 3] += g * x.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4 * NQP; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+                if (lh == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4 * NQP; ++k) {
+                        if (4 * q0 + k < D) {
+                            if (RB == 1) dst[w_at + c * D + 4 * q0 + k] = acc[k];
+                            else pp[4 * q0 + k] = acc[k];
+                        }
                     }
                 }
             }
             ab += __shfl_xor(ab, 32, 64);
-#pragma unroll
-            for (int k = 0; k < 4 * NQ; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
-            if (RB == 1) {
-                if (lh == 0) {
-#pragma unroll
-                    for (int k = 0; k < 4 * NQ; ++k) if (k < D) dst[w_at + c * D + k] = acc[k];
-                    dst[b_at + c] = ab;
-                }
-            } else if (lh == 0) {
-                float* pp = part + (rblk * TH + c) * PLD;
-#pragma unroll
-                for (int k = 0; k < 4 * NQ; ++k) if (k < D) pp[k] = acc[k];
-                pp[TDMAX] = ab;
+            if (lh == 0) {
+                if (RB == 1) dst[b_at + c] = ab;
+                else pp[TDMAX] = ab;
             }
         }
         if (RB == 2) {

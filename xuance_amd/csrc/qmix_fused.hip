@@ -54,6 +54,29 @@ __device__ __noinline__ void qf_copy(QfGlobalIn src, int dst, int n4) {
     }
 }
 
+// 16-byte load that is served by the L2, never by this CU's L1 (agent-scope `sc1`): what another workgroup of the SAME launch has
+// written since this CU last read the line (xrl_qmix_fused_phase: weight images, gradient slabs)
+__device__ __forceinline__ qf_f4 qf_ld4_dev(__amdgpu_buffer_rsrc_t rs, int q4) {
+    typedef unsigned qf_u4 __attribute__((ext_vector_type(4)));
+    const qf_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, q4 * 16, 0, 16);           // aux 16 = sc1
+    qf_f4 r; r.x = __uint_as_float(v.x); r.y = __uint_as_float(v.y); r.z = __uint_as_float(v.z); r.w = __uint_as_float(v.w);
+    return r;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t qf_rsrc(const float* p, long long floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(floats * 4), 0x00020000);
+}
+__device__ __noinline__ void qf_copy_dev(const float* src, int src_floats, int dst, int n4) {     // qf_copy through qf_ld4_dev
+    float* lds = qf_lds;
+    const __amdgpu_buffer_rsrc_t rs = qf_rsrc(src, src_floats);
+    for (int i = threadIdx.x; i < n4; i += 8 * QF_THREADS) {
+        qf_f4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int q = i + j * QF_THREADS; v[j] = 0.f; if (q < n4) v[j] = qf_ld4_dev(rs, q); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int q = i + j * QF_THREADS; if (q < n4) *reinterpret_cast<qf_f4*>(lds + dst + 4 * q) = v[j]; }
+    }
+}
+
 // act_apply's switch is if-converted by hipcc (tanhf AND expf evaluated for every value, ~775 cycles each: common.h): the activations
 // these networks actually use get a branch of their own (act is uniform), the rest goes through a real call
 __device__ __noinline__ float qf_act_slow(float v, int act) { return act_apply(v, act); }
@@ -115,10 +138,14 @@ __device__ __noinline__ void qf_lin_fwd_any_fn(int W, int ldw, int b, int K, int
 __device__ __forceinline__ bool qf_wave_in(int n_items, int tid0) {
     return (int)(((threadIdx.x & ~63u) - (unsigned)tid0) & (QF_THREADS - 1)) < n_items;
 }
+// ANYACT: the kernel instance may meet an activation other than none / relu.  A template argument of the kernels (round 6): an instance
+// that never does (the networks of configs/qmix/sc2/3m.yaml, every fixture) then has no call site of the twin whose callee-saved register
+// goes through scratch -- and with it no scratch allocation at all (16 bytes per lane were reserved for a routine the launch never entered)
+template <bool ANYACT>
 __device__ __forceinline__ void qf_lin_fwd(int W, int ldw, int b, int K, int Nout, int in, int ldi, int rows, int out, int ldo, int act,
                                            int tid0) {
     if (qf_wave_in(Nout * rows, tid0)) {
-        if (act == XRL_ACT_NONE || act == XRL_ACT_RELU) qf_lin_fwd_fn(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
+        if (!ANYACT || act == XRL_ACT_NONE || act == XRL_ACT_RELU) qf_lin_fwd_fn(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
         else qf_lin_fwd_any_fn(W, ldw, b, K, Nout, in, ldi, rows, out, ldo, act, tid0);
     }
 }
@@ -439,6 +466,12 @@ __host__ __device__ inline QfLds qf_layout(const xrl_qmix_fused_t& p) {
 }
 
 struct QfArgs { xrl_qmix_fused_t p; QfLds L; int agent4, mixer4, pad[2]; };   // L = qf_layout(p), block sizes in float4: from the host
+struct QfArgsPh { QfArgs a; xrl_qmix_phase_t ph; };                            // the phase launch (xrl_qmix_fused_phase): + the optimiser's side
+template <bool PHASE> struct qf_kernel_arg { typedef QfArgs type; };
+template <> struct qf_kernel_arg<true> { typedef QfArgsPh type; };
+typedef const __attribute__((address_space(4))) xrl_qmix_phase_t* QfPh;
+// words of xrl_qmix_phase_t.sync: [2] time-out, [3] XCC mask of the launch, [8 + g] / [72 + g] the two meeting flags of workgroup g
+constexpr int QFS_FAIL = 2, QFS_MASK = 3, QFS_A = 8, QFS_B = 72, QF_PHASE_MAX_WG = 64;
 typedef const __attribute__((address_space(4))) QfArgs QfArgsK;
 typedef const __attribute__((address_space(4))) xrl_qmix_fused_t* QfP;
 typedef const __attribute__((address_space(4))) QfLds* QfL;
@@ -446,22 +479,192 @@ typedef const __attribute__((address_space(4))) QfLds* QfL;
 // MM: the products on the matrix cores (qf_mm_*) instead of the VALU loops.  A template argument, not a run-time branch: with both forms
 // behind `if (mm)` at every call site the default (VALU) launch carried the other form's call sites through its cold instruction cache
 // and ran 2.8 us slower (round 4 -> 5: 34.8 -> 37.6 us per update on every box, profiles/r0[2-5]_*_bench.json)
-template <bool MM>
-__global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_unused) {
-    // the arguments are read where they lie, in the kernel argument segment (scalar loads, any index): touching the by-value
-    // parameter with a run-time index would make the compiler copy it to scratch memory first
-    const QfArgsK* args = (const QfArgsK*)__builtin_amdgcn_kernarg_segment_ptr();
+// ------------------------------------------------------------------------------------------------------------------
+// xrl_qmix_fused_phase: the optimiser step of update u, done between two updates by the resident workgroups of the launch -- what
+// xrl_reduce_adam does in a launch of its own: the same statements on the same elements in the same order (no clipping: nothing
+// here needs the global norm, so the workgroups meet only to hand over slabs and parameters).  Returns whether the launch's
+// workgroups sit on more than one XCD (then the meetings use agent-scope fences; inside one L2 drained plain stores + L1-bypassing
+// loads are coherent).
+typedef const __attribute__((address_space(4))) xrl_qmix_fused_t* QfPq;
+typedef const __attribute__((address_space(4))) QfLds* QfLq;
+__device__ __noinline__ void qf_phase_meet(unsigned* sync, int base, int wg, int n_wg, unsigned epoch, bool multi) {
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < 64) {
+        if (tid == 0) {
+            if (multi) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __hip_atomic_store(sync + base + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int spins = 0;
+        for (;;) {
+            const unsigned f = tid < n_wg ? __hip_atomic_load(sync + base + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+            if (__all(f == epoch)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255) == 0 && (spins > 4000000 || __hip_atomic_load(sync + QFS_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (tid == 0) __hip_atomic_store(sync + QFS_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (multi) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+__device__ __noinline__ bool qf_phase_step(QfPh ph, QfPq p, QfLq L, int wg, int n_wg, int u, int n_upd, unsigned step0, unsigned sched0, bool multi) {
+#pragma clang fp contract(off)      // (this file contracts its products; the optimiser's statements must round like csrc/optim.hip's: every multiply and add on its own)
+    float* lds = qf_lds;
+    const int tid = threadIdx.x;
+    unsigned* sync = ph->sync;
+    const unsigned step = step0 + (unsigned)u + 1u;                       // the optimiser step this update performs
+    long long* dbg = (wg == 0 && tid == 0 && u == n_upd / 2) ? p->dbg : nullptr;     // diagnostics (tools/probe_qmix_phase.py): [64 + k]
+#define QPS(k) do { if (dbg) dbg[64 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+    QPS(0);
+    // ---- meeting A: every slab of update u is in the L2
+    qf_phase_meet(sync, QFS_A, wg, n_wg, 2u * step, multi);
+    QPS(1);
+    if (u == 0) {                                                         // every workgroup's XCC bit is in (set before its first arrival)
+        const unsigned mask = __hip_atomic_load(sync + QFS_MASK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        multi = __popc(mask) != 1;
+    }
+    const bool dead = __hip_atomic_load(sync + QFS_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    // ---- this workgroup's quads: [q_lo, q_lo + n_q) of the P / 4, an even split; thread (pq, sg) sums slabs sg, sg + 4, ... of quad q_lo + pq
+    const long long P4 = ph->P / 4;
+    const int per = (int)((P4 + n_wg - 1) / n_wg), q_lo = wg * per, n_q = max(0, min(per, (int)P4 - q_lo));
+    double (*gsum)[4] = reinterpret_cast<double (*)[4]>(lds + L->ag_e);   // [4][n_q][4] where the eval agent's weights were
+    double* red = reinterpret_cast<double*>(lds + L->ag_e) + 16 * per;    // [16] partial squared norms
+    const int n_split = n_wg;
+    const __amdgpu_buffer_rsrc_t rs_s = qf_rsrc((const float*)p->slabs, (long long)n_split * p->slab_stride);
+    const int st4 = (int)(p->slab_stride / 4);
+    for (int it = tid; it < 4 * n_q; it += QF_THREADS) {
+        const int sg = it / n_q, pq = it - sg * n_q, qi = q_lo + pq;
+        double gx = 0.0, gy = 0.0, gz = 0.0, gw = 0.0;
+        int sl = sg;
+        for (; sl + 28 < n_split; sl += 32) {
+            qf_f4 w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = qf_ld4_dev(rs_s, (sl + 4 * j) * st4 + qi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gx += w[j].x; gy += w[j].y; gz += w[j].z; gw += w[j].w; }
+        }
+        for (; sl < n_split; sl += 4) { const qf_f4 w = qf_ld4_dev(rs_s, sl * st4 + qi); gx += w.x; gy += w.y; gz += w.z; gw += w.w; }
+        double* o = gsum[sg * n_q + pq];
+        o[0] = gx; o[1] = gy; o[2] = gz; o[3] = gw;
+    }
+    QPS(2);
+    // the loss sums of update u (xrl_sum_partials' order, row by row) ride with the last workgroup: its rows are all in the L2 now
+    // (eight L1-bypassing loads in flight per thread: as 32 dependent atomic loads this made the last workgroup the launch's straggler --
+    //  every other workgroup stood 14 k cycles in meeting B)
+    if (wg == n_wg - 1 && tid >= QF_THREADS - 8) {
+        typedef unsigned qf_u2 __attribute__((ext_vector_type(2)));
+        const int c = tid - (QF_THREADS - 8), B = p->B;
+        const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(ph->phase_partials + (size_t)u * B * 8), 0, B * 64, 0x00020000);
+        double sacc = 0.0;
+        int r = 0;
+        for (; r + 8 <= B; r += 8) {
+            qf_u2 w8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w8[q] = __builtin_amdgcn_raw_buffer_load_b64(rs_p, ((r + q) * 8 + c) * 8, 0, 16);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sacc += __hiloint2double((int)w8[q].y, (int)w8[q].x);
+        }
+        for (; r < B; ++r) { const qf_u2 w = __builtin_amdgcn_raw_buffer_load_b64(rs_p, (r * 8 + c) * 8, 0, 16); sacc += __hiloint2double((int)w.y, (int)w.x); }
+        ph->epoch_sums[(size_t)u * 8 + c] = sacc;
+    }
+    const xrl_adam_state_t* st = ph->state;
+    __syncthreads();
+    QPS(3);
+    // ---- Adam for the 4 n_q parameters (adam_step_kernel's statements; the step's float64 scalars -- lr / (1 - beta1^t), sqrt(1 - beta2^t):
+    //      torch._single_tensor_adam -- come from qf_adam_scalars_kernel, launched in front of the phase: float64 pow() does not fit the
+    //      128 registers a 1 024-thread workgroup leaves a thread)
+    {
+        const float step_size = ph->scalars[2 * u], bc2_sqrt = ph->scalars[2 * u + 1];
+        const float eps = (float)st->eps, w1 = (float)(1.0 - st->beta1), fb2 = (float)st->beta2, w2 = (float)(1.0 - st->beta2), wd = (float)st->weight_decay;
+        const bool hard = ph->sync_every > 0 && (int)step % ph->sync_every == 0;
+        float* img_e = const_cast<float*>((const float*)p->img_eval);
+        float* img_t = const_cast<float*>((const float*)p->img_target);
+        double sq = 0.0;
+        for (int e = tid; e < 4 * n_q && !dead; e += QF_THREADS) {
+            const int pq = e >> 2, c = e & 3;
+            const long long i = 4ll * (q_lo + pq) + c;
+            const double t0 = ((gsum[0 * n_q + pq][c] + gsum[1 * n_q + pq][c]) + gsum[2 * n_q + pq][c]) + gsum[3 * n_q + pq][c];
+            float g = (float)t0;                                          // rounded once (grad_reduce_kernel)
+            sq += (double)g * (double)g;
+            ph->grad[i] = g;                                              // (coef = 1: no clipping)
+            const float p0 = ph->params[i], m0 = ph->m[i], v0 = ph->v[i];
+            if (wd != 0.f) g += wd * p0;
+            const float mi = m0 + (g - m0) * w1;
+            const float vi = v0 * fb2 + w2 * g * g;
+            ph->m[i] = mi; ph->v[i] = vi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            const float pn = p0 - step_size * (mi / denom);
+            ph->params[i] = pn;
+            const int j = ph->map[i];
+            if (j >= 0) img_e[j] = pn;
+            if (ph->act_image) { const int ja = ph->act_map[i]; if (ja >= 0) ph->act_image[ja] = pn; }
+            if (hard) { ph->target[i] = pn; if (j >= 0) img_t[j] = pn; }
+        }
+        // this workgroup's share of the squared norm (reported, not used: no clipping)
+        sq = wave_sum(sq);
+        if ((tid & 63) == 0) red[tid >> 6] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < QF_THREADS / 64; ++w) t += red[w];
+            __hip_atomic_store(ph->sumsq_part + wg, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    QPS(4);
+    // ---- meeting B: the new parameters / images are in the L2
+    qf_phase_meet(sync, QFS_B, wg, n_wg, 2u * step + 1u, multi);
+    QPS(5);
+    if (wg == 0 && tid == 0) {                                            // (every workgroup took the state's counters before its first arrival)
+        xrl_adam_state_t* sw = ph->state;
+        double t = 0.0;
+        for (int w = 0; w < n_wg; ++w) t += __hip_atomic_load(ph->sumsq_part + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool bad = __hip_atomic_load(sync + QFS_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        sw->last_grad_norm = bad ? __builtin_nan("") : sqrt(t);
+        sw->step = (int)step;
+        const int ns = (int)sched0 + u + 1;
+        sw->sched_steps = ns;
+        const int k2 = ns < sw->total_iters ? ns : sw->total_iters;
+        sw->last_lr = sw->base_lr * (1.0 + (sw->end_factor - 1.0) * (double)k2 / (double)sw->total_iters);
+        if (u == n_upd - 1 && ph->tick) *ph->tick += (unsigned)ph->tick_inc;
+    }
+#undef QPS
+    return multi;
+}
+
+// step_size and sqrt(bias correction 2) of the n_updates optimiser steps a phase is about to make (adam_step_kernel's own expressions)
+__global__ void qf_adam_scalars_kernel(const xrl_adam_state_t* st, int n_updates, float* out) {
+#pragma clang fp contract(off)
+    const int u = threadIdx.x;
+    if (u >= n_updates) return;
+    const int step = st->step + 1 + u, sched = st->sched_steps + u;
+    const int k = sched < st->total_iters ? sched : st->total_iters;
+    const double lr = st->base_lr * (1.0 + (st->end_factor - 1.0) * (double)k / (double)st->total_iters);
+    const double b1 = st->beta1, b2 = st->beta2;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    out[2 * u] = (float)(lr / bc1);
+    out[2 * u + 1] = (float)sqrt(bc2);
+}
+
+// One update of workgroup `wg`: the whole launch of xrl_qmix_fused_update, or update u of a phase (PHASE: xrl_qmix_fused_phase).
+// The arguments are read where they lie, in the kernel argument segment (scalar loads, any index): touching a by-value
+// parameter with a run-time index would make the compiler copy it to scratch memory first.
+template <bool MM, bool ANYACT, bool PHASE>
+__device__ __forceinline__ void qf_update_body(const QfArgsK* args, QfPh ph, const int wg, const int u) {
     QfP p = &args->p;
     QfL L = &args->L;
     float* lds = qf_lds;
-#define QF_STAMP(i) do { if (p->dbg && blockIdx.x == 0 && threadIdx.x == 0) p->dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define QF_STAMP(i) do { if (p->dbg && blockIdx.x == 0 && threadIdx.x == 0 && (!PHASE || u == ph->n_updates / 2)) p->dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
     QF_STAMP(0);
     const int N = p->N, A = p->A, H = p->H, HH = p->HH, nl = p->n_layers;
-    const int b0 = blockIdx.x * p->items_per_wg;
+    const int b0 = wg * p->items_per_wg;
     const int bw = min(p->items_per_wg, p->B - b0), rows = bw * N, r_base = b0 * N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ldq = L->ld[nl];
-    QfGlobalOut gslab = (QfGlobalOut)(p->slabs + (size_t)blockIdx.x * p->slab_stride);
+    QfGlobalOut gslab = (QfGlobalOut)(p->slabs + (size_t)wg * p->slab_stride);
 
     // ---- 0. ONE burst of global loads: every thread first issues its share of the weight blocks [target mixer | target agent
     //         | eval agent] (float4 chunks of the images) and of the input words (observations, states, per-row scalars,
@@ -474,7 +677,7 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
     const bool ring = p->ring_n_envs > 0;
     auto ring_row = [&](int bi) -> size_t {                               // ring row (t * n_envs + env) of transition b0 + bi
         ReplayDraw d;
-        d.size_dev = p->size_dev; d.seed = p->draw_seed; d.counter = p->draw_counter; d.counter_dev = p->counter_dev; d.idx_out = nullptr;
+        d.size_dev = p->size_dev; d.seed = p->draw_seed; d.counter = p->draw_counter + (uint32_t)u; d.counter_dev = p->counter_dev; d.idx_out = nullptr;
         const int64_t fl = replay_draw(d, b0 + bi, p->ring_n_envs, p->ring_n_size);
         const int env = (int)(fl / p->ring_n_size), t = (int)(fl - (int64_t)env * p->ring_n_size);
         if (p->idx_out) p->idx_out[b0 + bi] = fl;                         // (every reader of the row writes the same value)
@@ -502,6 +705,9 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
         if (ring) { const int bi = r / N; return p->avail_next + ring_row(bi) * (size_t)(N * A) + (u - bi * N * A); }
         return p->avail_next + (size_t)r_base * A + u;
     };
+    // (PHASE: the images are rewritten by the other workgroups between two updates -- read past this CU's L1)
+    const int img_floats = 4 * (args->agent4 + args->mixer4);
+    const __amdgpu_buffer_rsrc_t rs_t = qf_rsrc(p->img_target, PHASE ? img_floats : 0), rs_e = qf_rsrc(p->img_eval, PHASE ? img_floats : 0);
     {
         typedef const __attribute__((address_space(1))) qf_f4* G;
         const int na = args->mixer4, nb = args->agent4, n_w = na + 2 * nb;
@@ -513,9 +719,15 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
         for (int j = 0; j < 8; ++j) {
             const int q = tid + j * QF_THREADS;
             wv[j] = 0.f;
+            if constexpr (PHASE) {
+                if (q < na) wv[j] = qf_ld4_dev(rs_t, args->agent4 + q);
+                else if (q < na + nb) wv[j] = qf_ld4_dev(rs_t, q - na);
+                else if (q < n_w) wv[j] = qf_ld4_dev(rs_e, q - na - nb);
+            } else {
             if (q < na) wv[j] = sa[q];
             else if (q < na + nb) wv[j] = sb[q - na];
             else if (q < n_w) wv[j] = sc[q - na - nb];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -539,9 +751,9 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
             lds[dst] = src ? *src : 1.f;
         }
         for (int q = tid + 8 * QF_THREADS; q < n_w; q += QF_THREADS) {        // (larger networks: likewise)
-            if (q < na) *reinterpret_cast<qf_f4*>(lds + L->mix + 4 * q) = sa[q];
-            else if (q < na + nb) *reinterpret_cast<qf_f4*>(lds + L->ag_t + 4 * (q - na)) = sb[q - na];
-            else *reinterpret_cast<qf_f4*>(lds + L->ag_e + 4 * (q - na - nb)) = sc[q - na - nb];
+            if (q < na) *reinterpret_cast<qf_f4*>(lds + L->mix + 4 * q) = PHASE ? qf_ld4_dev(rs_t, args->agent4 + q) : sa[q];
+            else if (q < na + nb) *reinterpret_cast<qf_f4*>(lds + L->ag_t + 4 * (q - na)) = PHASE ? qf_ld4_dev(rs_t, q - na) : sb[q - na];
+            else *reinterpret_cast<qf_f4*>(lds + L->ag_e + 4 * (q - na - nb)) = PHASE ? qf_ld4_dev(rs_e, q - na - nb) : sc[q - na - nb];
         }
     }
     __syncthreads();
@@ -560,7 +772,7 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
             const int t = qf_tiles(rows_, Nn_), t0 = 64 * (tb & 15);
             tb += t;
             if (qf_mm_wave_in(t, t0)) qf_mm_fwd_fn(W_, ldw_, b_, K_, Nn_, in_, ldi_, rows_, out_, ldo_, act_, t0);
-        } else qf_lin_fwd(W_, ldw_, b_, K_, Nn_, in_, ldi_, rows_, out_, ldo_, act_, tid0_);
+        } else qf_lin_fwd<ANYACT>(W_, ldw_, b_, K_, Nn_, in_, ldi_, rows_, out_, ldo_, act_, tid0_);
     };
     auto BWDD = [&](int W_, int ldw_, int K_, int Nn_, int dz_, int ldz_, int rows_, int dx_, int ldx_, int y_, int ldy_, int act_, int tid0_) {
         if constexpr (mm) {
@@ -604,13 +816,15 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
         switch (mix_step) {
             case 0: HYPER(0, L->s1, L->hid_t, L->raw_t, 768); break;
             case 1: HYPER(1, L->s1, L->hid_t, L->raw_t, 768); break;
-            case 2: qf_copy((QfGlobalIn)(p->img_eval + 4 * args->agent4), L->mix, args->mixer4); break;
+            case 2: if constexpr (PHASE) qf_copy_dev(p->img_eval + 4 * args->agent4, 4 * args->mixer4, L->mix, args->mixer4);
+                    else qf_copy((QfGlobalIn)(p->img_eval + 4 * args->agent4), L->mix, args->mixer4);
+                    break;
             case 3: HYPER(0, L->s0, L->hid_e, L->raw_e, 768); break;
             case 4: HYPER(1, L->s0, L->hid_e, L->raw_e, 768); break;
             default: break;
         }
         ++mix_step;
-        if (p->dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && l < 6) p->dbg[32 + 16 * l + (threadIdx.x >> 6)] = (long long)__builtin_readcyclecounter();   // (diagnostics: [128])
+        if (p->dbg && blockIdx.x == 0 && u == 0 && (threadIdx.x & 63) == 0 && l < 6) p->dbg[32 + 16 * l + (threadIdx.x >> 6)] = (long long)__builtin_readcyclecounter();   // (diagnostics: [128])
         __syncthreads();
         if (l < 6) QF_STAMP(16 + l);
     }
@@ -696,7 +910,7 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
             if (lane == n) dq[(bi * N + n) * ldq + a_taken] = dqe * mask;
         }
         if (lane == 0) {
-            double* o = p->partials + (size_t)b * 8;
+            double* o = (PHASE ? ph->phase_partials + (size_t)u * p->B * 8 : p->partials) + (size_t)b * 8;
             o[0] = (double)td * td; o[1] = q_tot_e; o[2] = 0.0;
             for (int j = 3; j < 8; ++j) o[j] = 0.0;
             if (p->diag) { p->diag[b] = q_tot_e; p->diag[p->B + b] = q_tot_n; p->diag[2 * (size_t)p->B + b] = y; }
@@ -741,6 +955,43 @@ __global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(QfArgs by_value_
     QF_STAMP(8);
 }
 
+
+
+
+
+// PHASE (xrl_qmix_fused_phase): the workgroups stay for all updates of a phase and do the optimiser steps between them
+template <bool MM, bool ANYACT, bool PHASE>
+__global__ void __launch_bounds__(QF_THREADS) qmix_fused_kernel(typename qf_kernel_arg<PHASE>::type by_value_unused) {
+    const QfArgsK* args = (const QfArgsK*)__builtin_amdgcn_kernarg_segment_ptr();      // (QfArgs is the first member of QfArgsPh)
+    if constexpr (!PHASE) {
+        qf_update_body<MM, ANYACT, false>(args, nullptr, (int)blockIdx.x, 0);
+    } else {
+        if (blockIdx.x & 7) return;                                      // one XCD's share of the grid (rollout_actor.hip)
+        const int wg = (int)(blockIdx.x >> 3), n_wg = (int)(gridDim.x >> 3);
+        QfPh ph = (QfPh)((const __attribute__((address_space(4))) char*)args + offsetof(QfArgsPh, ph));
+        // (read before this workgroup's first arrival: workgroup 0 advances the state behind every second meeting)
+        const unsigned step0 = (unsigned)__hip_atomic_load(&ph->state->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned sched0 = (unsigned)__hip_atomic_load(&ph->state->sched_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned seen = atomicOr(ph->sync + QFS_MASK, 1u << (xcc & 0xf));
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+        }
+        bool multi = true;                                               // placement unknown until the first meeting: fences
+        const int n_upd = ph->n_updates;
+        for (int u = 0; u < n_upd; ++u) {
+            // (the argument pointer is laundered per update: with the body inlined into this loop everything it reads from the argument
+            //  segment was hoisted out of the loop and kept live across it -- 220 spilled SGPRs, 127 spilled VGPRs; as a real call the body
+            //  saved ~50 callee-saved registers through scratch per update)
+            const QfArgsK* a = args;
+            asm volatile("" : "+s"(a));
+            QfPh ph_u = (QfPh)((const __attribute__((address_space(4))) char*)a + offsetof(QfArgsPh, ph));
+            qf_update_body<false, ANYACT, true>(a, ph_u, wg, u);
+            multi = qf_phase_step(ph_u, &a->p, &a->L, wg, n_wg, u, n_upd, step0, sched0, multi);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // One ACTING step of the recurrent agents (value_factorization.py:66-92 -> Basic_RNN, rnn.py:52-77: mlp blocks -> nn.GRU
@@ -802,6 +1053,7 @@ typedef const __attribute__((address_space(4))) QaArgs QaArgsK;
 __device__ __forceinline__ float qa_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float qa_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 
+template <bool ANYACT>
 __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_value_unused) {
     const QaArgsK* args = (const QaArgsK*)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) xrl_marl_act_gru_t* p = &args->p;
@@ -849,14 +1101,14 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
     int l = 0, in = L->x, ldi = L->ldx, feat = O;
     for (int i = 0; i < p->n_pre; ++i, ++l) {
         const int out = (i & 1) ? L->a1 : L->a0;
-        qf_lin_fwd(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, p->pre[i], in, ldi, rows, out, L->lda, p->act, 0);
+        qf_lin_fwd<ANYACT>(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, p->pre[i], in, ldi, rows, out, L->lda, p->act, 0);
         __syncthreads();
         in = out; ldi = L->lda; feat = p->pre[i];
     }
     if (H > 0) {
         // ---- gi = W_ih x + b_ih,  gh = W_hh h + b_hh  (side by side), then the cell (csrc/gru.hip's arithmetic)
-        qf_lin_fwd(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, 3 * H, in, ldi, rows, L->gi, L->ldg, XRL_ACT_NONE, 0);
-        qf_lin_fwd(L->img + L->w[l + 1], L->ldw[l + 1], L->img + L->b[l + 1], H, 3 * H, L->hin, L->ldh, rows, L->gh, L->ldg, XRL_ACT_NONE, 512);
+        qf_lin_fwd<ANYACT>(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, 3 * H, in, ldi, rows, L->gi, L->ldg, XRL_ACT_NONE, 0);
+        qf_lin_fwd<ANYACT>(L->img + L->w[l + 1], L->ldw[l + 1], L->img + L->b[l + 1], H, 3 * H, L->hin, L->ldh, rows, L->gh, L->ldg, XRL_ACT_NONE, 512);
         l += 2;
         __syncthreads();
         for (int i = tid; i < rows * H; i += QF_THREADS) {
@@ -878,7 +1130,7 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
     for (int i = 0; i < p->n_post; ++i, ++l) {
         const bool last = i == p->n_post - 1;
         const int out = last ? L->q : ((i & 1) ? L->a1 : L->a0), ldo = last ? L->ldq : L->lda;
-        qf_lin_fwd(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, p->post[i], in, ldi, rows, out, ldo, last ? XRL_ACT_NONE : p->act, 0);
+        qf_lin_fwd<ANYACT>(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, p->post[i], in, ldi, rows, out, ldo, last ? XRL_ACT_NONE : p->act, 0);
         __syncthreads();
         in = out; ldi = ldo; feat = p->post[i];
     }
@@ -930,8 +1182,11 @@ extern "C" int xrl_qmix_fused_update(const xrl_qmix_fused_t* pp, xrl_stream_t st
     const bool mm = qf_mfma_products(p);
     static size_t allowed[2] = {0, 0};
     if (bytes > allowed[mm]) {
-        XRL_CHECK_HIP(hipFuncSetAttribute(mm ? reinterpret_cast<const void*>(qmix_fused_kernel<true>) : reinterpret_cast<const void*>(qmix_fused_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        if (mm) XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qmix_fused_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        else {
+            XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qmix_fused_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qmix_fused_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        }
         allowed[mm] = bytes;
     }
     const int n_wg = (p.B + p.items_per_wg - 1) / p.items_per_wg;
@@ -939,8 +1194,63 @@ extern "C" int xrl_qmix_fused_update(const xrl_qmix_fused_t* pp, xrl_stream_t st
     xrl_qf_image_t im;
     qf_image_layout(p, im);
     args.p = p; args.L = L; args.agent4 = im.agent_floats / 4; args.mixer4 = im.mixer_floats / 4;
-    if (mm) hipLaunchKernelGGL(qmix_fused_kernel<true>, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
-    else hipLaunchKernelGGL(qmix_fused_kernel<false>, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    const bool any_act = p.act != XRL_ACT_NONE && p.act != XRL_ACT_RELU;
+    if (mm) hipLaunchKernelGGL((qmix_fused_kernel<true, true, false>), dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    else if (any_act) hipLaunchKernelGGL((qmix_fused_kernel<false, true, false>), dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    else hipLaunchKernelGGL((qmix_fused_kernel<false, false, false>), dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+// workgroups of the phase launch that one XCD keeps resident (one 1 024-thread workgroup per CU)
+static int qf_phase_capacity() { const int c = device_cu_count() / 8; return c < QF_PHASE_MAX_WG ? c : QF_PHASE_MAX_WG; }
+
+extern "C" int xrl_qmix_fused_phase_fits(int32_t B, int32_t items_per_wg, int64_t P) {
+    if (B <= 0 || items_per_wg <= 0 || P <= 0 || (P & 3)) return 0;
+    const int n_wg = (B + items_per_wg - 1) / items_per_wg;
+    return n_wg <= qf_phase_capacity() ? 1 : 0;
+}
+
+extern "C" int xrl_qmix_fused_phase(const xrl_qmix_fused_t* pp, const xrl_qmix_phase_t* php, xrl_stream_t stream) {
+    XRL_CHECK_ARG(pp != nullptr && php != nullptr);
+    const xrl_qmix_fused_t& p = *pp;
+    const xrl_qmix_phase_t& ph = *php;
+    XRL_CHECK_ARG(p.img_eval && p.img_target && ((reinterpret_cast<uintptr_t>(p.img_eval) | reinterpret_cast<uintptr_t>(p.img_target)) & 15) == 0);
+    XRL_CHECK_ARG(p.obs && p.obs_next && p.state && p.state_next && p.actions && p.rewards && p.terminals && p.agent_mask && p.slabs);
+    XRL_CHECK_ARG(p.n_layers >= 1 && p.n_layers <= XRL_QF_MAX_LAYERS && p.B > 0 && p.items_per_wg > 0);
+    XRL_CHECK_ARG(p.N >= 1 && p.N <= 64 && p.H >= 1 && p.H <= 64 && p.A >= 1 && p.dims[p.n_layers] == p.A && p.HH >= 1 && p.S >= 1);
+    XRL_CHECK_ARG((p.slab_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(p.slabs) & 15) == 0);
+    XRL_CHECK_ARG(p.ring_n_envs > 0 && p.ring_n_size > 0 && p.size_dev != nullptr);          // every update draws its own batch
+    XRL_CHECK_ARG(ph.n_updates >= 1 && ph.params && ph.grad && ph.m && ph.v && ph.state && ph.map && ph.target && ph.phase_partials &&
+                  ph.epoch_sums && ph.sumsq_part && ph.sync && ph.P > 0 && (ph.P & 3) == 0 && ph.P <= p.slab_stride);
+    XRL_CHECK_ARG((ph.act_image == nullptr) == (ph.act_map == nullptr));
+    XRL_CHECK_ARG(!qf_mfma_products(p));                                                      // (the VALU product instances)
+    const int n_wg = (p.B + p.items_per_wg - 1) / p.items_per_wg;
+    if (!xrl_qmix_fused_phase_fits(p.B, p.items_per_wg, ph.P)) {
+        set_error("xrl_qmix_fused_phase: %d workgroups do not stay resident on one XCD of this device (%d)", n_wg, qf_phase_capacity());
+        return XRL_EINVAL;
+    }
+    const QfLds L = qf_layout(p);
+    const size_t bytes = (size_t)L.total * 4;
+    XRL_CHECK_ARG(bytes <= 160 * 1024);
+    xrl_qf_image_t im;
+    qf_image_layout(p, im);
+    const int per = (int)((ph.P / 4 + n_wg - 1) / n_wg);
+    XRL_CHECK_ARG(32 * per + 2 * 20 <= im.agent_floats);                                          // the slab sums' LDS scratch (where the eval agent's weights were)
+    static size_t allowed = 0;
+    if (bytes > allowed) {
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qmix_fused_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qmix_fused_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        allowed = bytes;
+    }
+    XRL_CHECK_ARG(ph.scalars != nullptr && ph.n_updates <= 64);
+    hipLaunchKernelGGL(qf_adam_scalars_kernel, dim3(1), dim3(64), 0, as_stream(stream), ph.state, ph.n_updates, ph.scalars);
+    QfArgsPh args{};
+    args.a.p = p; args.a.L = L; args.a.agent4 = im.agent_floats / 4; args.a.mixer4 = im.mixer_floats / 4;
+    args.ph = ph;
+    const bool any_act = p.act != XRL_ACT_NONE && p.act != XRL_ACT_RELU;
+    if (any_act) hipLaunchKernelGGL((qmix_fused_kernel<false, true, true>), dim3(8 * n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    else hipLaunchKernelGGL((qmix_fused_kernel<false, false, true>), dim3(8 * n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
@@ -968,12 +1278,13 @@ extern "C" int xrl_marl_act_gru(const xrl_marl_act_gru_t* pp, xrl_stream_t strea
     XRL_CHECK_ARG(bytes <= 160 * 1024 && (args.L.image_floats & 3) == 0);
     static size_t allowed = 0;
     if (bytes > allowed) {
-        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(marl_act_gru_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(marl_act_gru_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(marl_act_gru_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         allowed = bytes;
     }
     const int n_wg = (p.R + p.rows_per_wg - 1) / p.rows_per_wg;
-    hipLaunchKernelGGL(marl_act_gru_kernel, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    if (p.act != XRL_ACT_NONE && p.act != XRL_ACT_RELU) hipLaunchKernelGGL(marl_act_gru_kernel<true>, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
+    else hipLaunchKernelGGL(marl_act_gru_kernel<false>, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -29,6 +29,7 @@ constexpr int WDM = 20;                   // observation width limit (row stride
 constexpr int WAM = 8;                    // action width limit
 constexpr int WTH = 512;                  // threads per workgroup (8 waves, all matrix waves)
 constexpr int WMAXWG = 16;
+constexpr int WLC = 2;                    // k-chunks (of 16) of the middle layer's weights kept in LDS instead of registers
 // exchange scratch (32-bit words): two slots of WSLOT 8-byte units -- unit ((d * 16 + wg) * 4 + k), k = lo s1, lo s2, hi s1, hi s2 of
 // dimension d; progress words; XCC mask
 // (measured, r04: spreading the dimensions over more L2 channels, 16-byte polling loads and a back-off between polling rounds
@@ -141,6 +142,7 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     // the small parameters (first layer, both hidden biases, head rows): read from here every step -- only the 256 x 256 layer's
     // 128 fragment registers per lane stay resident (with the small ones in registers as well the kernel spilled 42 VGPRs)
     __shared__ float s_w0[WH * WDM], s_b0[WH], s_b1[WH], s_w2[WAM * WH];
+    __shared__ __attribute__((aligned(16))) float s_w1l[8 * 2 * WLC * 64][4];      // [wave][tile][chunk][lane]: the middle layer's LDS-resident k-chunks
     __shared__ float s_head[3][WAM];                                     // head bias | std | log std per action
     __shared__ int s_fin[WR][2];                                         // episodes finished in this launch: count, steps
     __shared__ double s_fin_score[WR];
@@ -183,12 +185,19 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
     if (row_ok) { ep_steps = q.env_steps[e0 + tid]; ep_score = q.env_score[e0 + tid]; rtrack = q.ret_track[e0 + tid]; }
     if (tid == 0) { s_abort = 0; s_multi = (q.flags & 1) ? 1 : 0; }
     // weights: the middle layer's rows of this wave's hidden units [32 wave, +32) (two 16-unit tiles) in registers; the rest in LDS
-    float4 w1f[2][16];
+    // (round 6: the last WLC of the 16 k-chunks live in LDS, not in registers -- 8 VGPRs per chunk: with all 128 fragment registers
+    //  resident the kernel sat at the 256-register limit and spilled 7-10 VGPRs inside the step loop; two ds_read_b128 per chunk and
+    //  step instead, in the shadow of the MFMAs)
+    float4 w1f[2][16 - WLC];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int u0 = 32 * wave + 16 * j;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) w1f[j][c] = *reinterpret_cast<const float4*>(P + q.w1 + (size_t)(u0 + cl) * WH + 16 * c + 4 * g);
+        for (int c = 0; c < 16 - WLC; ++c) w1f[j][c] = *reinterpret_cast<const float4*>(P + q.w1 + (size_t)(u0 + cl) * WH + 16 * c + 4 * g);
+#pragma unroll
+        for (int c = 16 - WLC; c < 16; ++c)
+            *reinterpret_cast<float4*>(&s_w1l[((wave * 2 + j) * WLC + (c - (16 - WLC))) * 64 + lane][0]) =
+                *reinterpret_cast<const float4*>(P + q.w1 + (size_t)(u0 + cl) * WH + 16 * c + 4 * g);
     }
     for (int i = tid; i < WH * WDM; i += WTH) { const int u = i / WDM, d = i - u * WDM; s_w0[i] = d < D ? P[q.w0 + (size_t)u * D + d] : 0.f; }
     for (int i = tid; i < WH; i += WTH) { s_b0[i] = P[q.b0 + i]; s_b1[i] = P[q.b1 + i]; }
@@ -394,10 +403,16 @@ __global__ void __launch_bounds__(WTH) wide_rollout_kernel(xrl_rollout_wide_t q)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int cc = c4 + c, par = c & 1;
-                    WMFMA(w1f[0][cc].x, hf[c].x, acc[0][par]); WMFMA(w1f[1][cc].x, hf[c].x, acc[1][par]);
-                    WMFMA(w1f[0][cc].y, hf[c].y, acc[0][par]); WMFMA(w1f[1][cc].y, hf[c].y, acc[1][par]);
-                    WMFMA(w1f[0][cc].z, hf[c].z, acc[0][par]); WMFMA(w1f[1][cc].z, hf[c].z, acc[1][par]);
-                    WMFMA(w1f[0][cc].w, hf[c].w, acc[0][par]); WMFMA(w1f[1][cc].w, hf[c].w, acc[1][par]);
+                    float4 wa_, wb_;
+                    if (cc < 16 - WLC) { wa_ = w1f[0][cc < 16 - WLC ? cc : 0]; wb_ = w1f[1][cc < 16 - WLC ? cc : 0]; }
+                    else {
+                        wa_ = *reinterpret_cast<const float4*>(&s_w1l[((wave * 2 + 0) * WLC + (cc - (16 - WLC))) * 64 + lane][0]);
+                        wb_ = *reinterpret_cast<const float4*>(&s_w1l[((wave * 2 + 1) * WLC + (cc - (16 - WLC))) * 64 + lane][0]);
+                    }
+                    WMFMA(wa_.x, hf[c].x, acc[0][par]); WMFMA(wb_.x, hf[c].x, acc[1][par]);
+                    WMFMA(wa_.y, hf[c].y, acc[0][par]); WMFMA(wb_.y, hf[c].y, acc[1][par]);
+                    WMFMA(wa_.z, hf[c].z, acc[0][par]); WMFMA(wb_.z, hf[c].z, acc[1][par]);
+                    WMFMA(wa_.w, hf[c].w, acc[0][par]); WMFMA(wb_.w, hf[c].w, acc[1][par]);
                 }
             }
             // (pin the pattern: one MFMA, then up to three of the normal's vector instructions, while those last)

@@ -125,7 +125,10 @@ class DQN_Learner(Learner):
         if getattr(self, "_buf_graph_key", None) != key:
             self._ensure(M)
             self._idx = torch.zeros(M, dtype=torch.int64, device=dev)
-            self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            # (a re-capture -- a workspace grew behind a get_actions / test() on more rows -- must not restart the replay
+            #  draws: the Philox stream is keyed by (seed, epoch, counter), so the counter lives as long as the learner)
+            if getattr(self, "_sample_counter", None) is None:
+                self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
             self._epoch_sums = torch.zeros(n_epochs, 8, dtype=torch.float64, device=dev)
             self._act, self._rew, self._ter = (torch.zeros(M, device=dev) for _ in range(3))
             dst = {"observations": self.X[:M], "next_observations": self.X[M:2 * M], "actions": self._act,

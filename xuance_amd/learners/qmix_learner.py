@@ -326,7 +326,8 @@ class QMIX_Learner(Learner):
             self._ensure(B)
             R, N = B * m.n_agents, m.n_agents
             self._idx = torch.zeros(B, dtype=torch.int64, device=dev)
-            self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            if getattr(self, "_sample_counter", None) is None:      # (kept across re-captures: the replay draws' Philox counter)
+                self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
             self._epoch_sums = torch.zeros(n_epochs, 8, dtype=torch.float64, device=dev)
             dst = {"obs": self.X[:R].view(B, -1), "obs_next": self.X[R:2 * R].view(B, -1), "actions": self.buf["actions"][:B],
                    "rewards": self.buf["rewards"][:B], "terminals": self.buf["terminals"][:B],
@@ -335,9 +336,43 @@ class QMIX_Learner(Learner):
                 dst["avail_actions_next"] = self.buf["avail_next"][:B].view(B, -1)
 
             self._phase_partials = torch.zeros(n_epochs, B, 8, dtype=torch.float64, device=dev)
+            self._phase_sumsq = torch.zeros(64, dtype=torch.float64, device=dev)
+            self._phase_scalars = torch.zeros(2 * max(n_epochs, 1), device=dev)
+            if getattr(self, "_phase_sync", None) is None:
+                self._phase_sync = torch.zeros(ops._lib.QF_PHASE_SYNC_WORDS, dtype=torch.int32, device=dev)
+
+            def phase_launch_ok():
+                """The whole phase as ONE launch (xrl_qmix_fused_phase, round 6): the one-launch update reading its batches from the ring,
+                no gradient clipping, one rank, the one-launch optimiser usable, the workgroups resident on one XCD.  OFF unless
+                config.use_qmix_phase_launch: True -- bit-identical to the launch pairs (tests/test_gpu_offpolicy_agents.py) and measured
+                slower: 42.9 us per update against 34.8 us (profiles/r06_d_qmix_phase.json; DESIGN.md section 3 "Round 6": 32 workgroups
+                on ONE XCD pull slabs / parameters at ~10 B/clk per CU, the separate optimiser launch spreads them over 68 CUs and 8 L2s)."""
+                fs = self._fused if self.fused_eligible() else None
+                return fs is not None and bool(getattr(self.config, "use_qmix_phase_launch", False)) and not self.use_grad_clip and \
+                    getattr(self.config, "fused_qmix_gather_in_kernel", True) and fs.n_groups(B) <= self.slabs.shape[0] and \
+                    int(fs.struct.products) == 2 and not self.needs_collective() and self.gradient_exchange() is None and \
+                    self._fused_optimizer_ok(False) and ops.qmix_fused_phase_fits(B, fs.items_per_wg, m.params.P)
+
+            def enqueue_phase():
+                fs, opt, P = self._fused, self.optimizer, m.params
+                self._images_current = True
+                act = getattr(m, "_act_state", None)            # the acting launch's weight image follows every step too
+                f = memory.soa.fields
+                ops.qmix_fused_phase(fs, B, f, f["avail_actions_next"] if self.use_actions_mask else None, self.slabs, P.P, self.diag,
+                                     dict(n_envs=memory.n_envs, n_size=memory.n_size, size_dev=memory.size_dev, seed=seed, counter=0,
+                                          counter_dev=self._sample_counter, idx_out=self._idx),
+                                     dict(n_updates=n_epochs, sync_every=self.sync_frequency, params=P.flat, grad=opt.grad, m=opt.m, v=opt.v, P=P.P,
+                                          state=opt.state, map=fs.map, target=m.target_flat, act_image=act.image if act is not None else None,
+                                          act_map=act.map if act is not None else None, phase_partials=self._phase_partials,
+                                          epoch_sums=self._epoch_sums, sumsq_part=self._phase_sumsq, scalars=self._phase_scalars,
+                                          tick=self._sample_counter, tick_inc=n_epochs, sync=self._phase_sync))
+                self.partials = self._phase_partials[n_epochs - 1]
+                self._images_current = False
 
             def enqueue():
                 # per update: draw, gather, step; the draw counter and the loss sums are settled once per phase
+                if self._phase_launch:
+                    return enqueue_phase()
                 if self.fused_eligible():                   # weight images of the one-launch update: kept current by the
                     self._images_current = True             # optimiser launch's mirrors (update_from_buffer refreshed them
                                                             # before this phase if anything else touched the parameters)
@@ -366,6 +401,7 @@ class QMIX_Learner(Learner):
                     assert self._tail_done == 0
                     ops.counter_add(self._sample_counter, n_epochs)
                     ops.sum_partials_batched(self._phase_partials, B, 8, self._epoch_sums, n_epochs, B * 8, 8)
+            self._phase_launch = phase_launch_ok() and n_epochs <= 64
             self._buf_enqueue, self._buf_graph, self._buf_graph_key = enqueue, None, key
             enqueue()                                       # this call's phase runs eagerly (lazy allocations happen here) ...
             if not self.needs_collective():
@@ -425,7 +461,8 @@ class QMIX_Learner(Learner):
             self._ensure_rnn(B, T)
             T1, N = T + 1, m.n_agents
             self._idx = torch.zeros(B, dtype=torch.int64, device=dev)
-            self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            if getattr(self, "_sample_counter", None) is None:      # (kept across re-captures: the replay draws' Philox counter)
+                self._sample_counter = torch.zeros(1, dtype=torch.int32, device=dev)
             self._epoch_sums = torch.zeros(n_epochs, 8, dtype=torch.float64, device=dev)
             dst = {"obs": self.Xs.view(T1, B, -1), "actions": self.seq["actions"], "rewards": self.seq["rewards"],
                    "terminals": self.seq["terminals"], "agent_mask": self.seq["agent_mask"],

@@ -295,7 +295,9 @@ class ActorCriticNet:
             self.ref_order += [n + ".weight", n + ".bias"]
         if dist == "gaussian":
             # nn.Module registers parameters before sub-modules' parameters: actor.log_std precedes actor.mu.*
-            idx = self.ref_order.index(f"{akey}.0.weight")
+            # (with one representation per head -- head_rep_layers, the reference's ActorCritic -- log_std is a parameter of
+            #  actor.actor_head, behind actor.representation.*: in front of the first HEAD layer, not of the branch's first layer)
+            idx = self.ref_order.index(f"{akey}.{2 * int(head_rep_layers or 0)}.weight")
             self.ref_order.insert(idx, "actor.log_std")
         for n, k, o in c_layers + [c_out]:
             self.ref_order += [n + ".weight", n + ".bias"]

@@ -972,6 +972,36 @@ def qmix_fused_update(fs, B, obs, obs_next, state, state_next, actions, rewards,
     return fs.n_groups(B)
 
 
+def qmix_fused_phase_fits(B, items_per_wg, P):
+    return bool(_lib.load().xrl_qmix_fused_phase_fits(int(B), int(items_per_wg), int(P)))
+
+
+def qmix_fused_phase(fs, B, fields, avail_next, slabs, slab_stride, diag, ring, ph):
+    """A whole update phase of the feed-forward QMIX learner as ONE launch (xrl_qmix_fused_phase): `fields` = the replay ring's field
+    tensors, `ring` as in qmix_fused_update (update u draws with counter + u), `ph`: dict(n_updates, sync_every, params, grad, m, v, P,
+    state, map, target, act_image, act_map, phase_partials, epoch_sums, sumsq_part, scalars, tick, tick_inc, sync)."""
+    from ._lib import QmixPhase
+    q = fs.struct
+    q.B = int(B)
+    q.ring_n_envs, q.ring_n_size, q.size_dev = int(ring["n_envs"]), int(ring["n_size"]), ptr(ring["size_dev"])
+    q.draw_seed, q.draw_counter = int(ring["seed"]), int(ring.get("counter", 0))
+    q.counter_dev = ptr(ring["counter_dev"]) if ring.get("counter_dev") is not None else None
+    q.idx_out = ptr(ring["idx_out"]) if ring.get("idx_out") is not None else None
+    f = fields
+    q.obs, q.obs_next, q.state, q.state_next = ptr(f["obs"]), ptr(f["obs_next"]), ptr(f["state"]), ptr(f["state_next"])
+    q.actions, q.rewards, q.terminals, q.agent_mask = ptr(f["actions"]), ptr(f["rewards"]), ptr(f["terminals"]), ptr(f["agent_mask"])
+    q.avail_next = ptr(avail_next) if avail_next is not None else None
+    q.slabs, q.slab_stride, q.partials = ptr(slabs), int(slab_stride), ptr(ph["phase_partials"])
+    q.diag = ptr(diag) if diag is not None else None
+    h = QmixPhase()
+    h.n_updates, h.sync_every, h.P, h.tick_inc = int(ph["n_updates"]), int(ph["sync_every"]), int(ph["P"]), int(ph.get("tick_inc", 0))
+    for k in ("params", "grad", "m", "v", "state", "map", "target", "act_image", "act_map", "phase_partials", "epoch_sums", "sumsq_part",
+              "scalars", "tick", "sync"):
+        setattr(h, k, ptr(ph.get(k)))
+    call("xrl_qmix_fused_phase", C.byref(q), C.byref(h), stream_ptr())
+    return fs.n_groups(B)
+
+
 def marl_stored_state(state, done_prev, out):
     """out <- the state rows the reference's multi-agent loops store for the coming step (xrl_marl_stored_state)."""
     n, S = state.shape
