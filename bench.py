@@ -316,8 +316,24 @@ def box_yardstick():
         ops.counter_add(c, 1)
     e[3].record()
     torch.cuda.synchronize()
-    return {"copy_GBps": round(10 * 2 * x.numel() * 4 / (e[0].elapsed_time(e[1]) * 1e-3) / 1e9, 1),
-            "small_launch_us": round(e[2].elapsed_time(e[3]) * 1e3 / 400, 3)}
+    out = {"copy_GBps": round(10 * 2 * x.numel() * 4 / (e[0].elapsed_time(e[1]) * 1e-3) / 1e9, 1),
+           "small_launch_us": round(e[2].elapsed_time(e[3]) * 1e3 / 400, 3)}
+    # (round 6, review item 8) the shader clock this box sustains under matrix-core load: shader cycles / 100 MHz wall ticks of a chain of
+    # dependent fp32 MFMAs on every CU (tools/csrc/probe.hip: mfma_chain_kernel) -- every compute-bound line scales with it
+    try:
+        import ctypes as C
+        from tools import probe_lib
+        o = torch.zeros(2, dtype=torch.int64, device="cuda"); sink = torch.zeros(64 * 1024, device="cuda")
+        for _ in range(2):
+            probe_lib.call("xrl_probe_mfma_chain", 20000, 1024, C.c_void_p(o.data_ptr()), C.c_void_p(sink.data_ptr()),
+                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+        cyc, ticks = o.tolist()
+        out["shader_clock_GHz_mfma_load"] = round(cyc / (ticks / 100e6) / 1e9, 3)
+    except Exception as ex:                                        # noqa: BLE001  (diagnostics library not built: no yardstick)
+        out["shader_clock_GHz_mfma_load"] = None
+        out["shader_clock_note"] = repr(ex)[:120]
+    return out
 
 
 def main():

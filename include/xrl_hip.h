@@ -186,6 +186,9 @@ int xrl_conv_fwd_probe(const xrl_conv_t* groups, int n_groups, int k_split, long
 /* dW[n][c][th][tw] = sum_rows dY[row][n] * patch(row)[(th, tw, c)], dbias[n] = sum_rows dY[row][n]; rows split into n_split
  * chunks, chunk s written to slab s (fixed order inside a chunk: four waves, then row pairs). */
 int xrl_conv_bwd_weight(const xrl_conv_t* groups, int n_groups, int n_split, int64_t slab_stride, xrl_stream_t stream);
+/* Weight-gradient groups of different kinds (32 | 64 filters, uint8 | float32 input) in ONE launch (1) or one launch per kind (0, the
+ * default: the one-launch form measured slower, profiles/r06_g_conv_overlap.json) -- same numbers either way (tested). */
+int xrl_set_conv_dw_mixed(int enable);
 int xrl_conv_bwd_weight_probe(const xrl_conv_t* groups, int n_groups, int n_split, int64_t slab_stride, long long* dbg,
                               xrl_stream_t stream);   /* diagnostics, as xrl_conv_fwd_probe (launch the groups of ONE kernel variant) */
 /* dst[j] = map[j] >= 0 ? src[map[j]] : 0 for up to 8 (src, map, dst, n) jobs in one launch: derived weight layouts from the

@@ -906,3 +906,34 @@ def test_qmix_phase_launch_is_bit_identical_to_the_launch_pairs():
         for k, v in a.memory.soa.fields.items():
             assert torch.equal(v, b.memory.soa.fields[k]), f"round {rnd}: replay ring field {k}"
     assert sa.step >= 150 and sa.step // 50 >= 3, "the run did not cross several hard target syncs"
+
+
+def test_conv_weight_gradients_of_all_layers_in_one_launch_equal_the_launch_per_kind():
+    """conv_dw_mixed_kernel (round 6): the weight gradients of the uint8 first layer (32 filters) and of the float32 upper layers (64
+    filters) as ONE launch against one launch per kind (xrl_set_conv_dw_mixed(0)): the same body per workgroup, so six DQN updates on the
+    Atari-shaped network (captured phases, hard target syncs in between) must leave bit-equal parameters, targets and losses."""
+    from xuance_amd.agents import DQN_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    from xuance_amd._lib import call
+    n = 8
+    cfg = dict(env_name="Atari", representation="Basic_CNN", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+               q_hidden_size=[512], activation="relu", seed=1, parallels=n, running_steps=10 ** 6, buffer_size=n * 64, batch_size=16,
+               learning_rate=1e-3, gamma=0.99, start_greedy=0.3, end_greedy=0.05, decay_step_greedy=10 ** 5, sync_frequency=3,
+               training_frequency=1, start_training=10 ** 9, n_epochs=1, use_grad_clip=False, use_obsnorm=False, use_rewnorm=False,
+               distributed_training=False, device="cuda", model_dir="/tmp/x")
+    res = []
+    try:
+        for mixed in (1, 0):
+            call("xrl_set_conv_dw_mixed", mixed)
+            torch.manual_seed(0)
+            np.random.seed(0)
+            agent = DQN_Agent(Namespace(**cfg), SyntheticAtariVecEnv(n, seed=2))
+            agent.train(20)
+            lr, mem, net = agent.learner, agent.memory, agent.model
+            infos = [lr.update_from_buffer(mem, 1, seed=5) for _ in range(6)]
+            torch.cuda.synchronize()
+            res.append((net.params.flat.cpu().numpy().copy(), net.target_flat.cpu().numpy().copy(), np.array([[i["Qloss"], i["predictQ"]] for i in infos])))
+    finally:
+        call("xrl_set_conv_dw_mixed", 0)
+    (pa, ta, ia), (pb, tb, ib) = res
+    assert np.abs(pa).max() > 0 and np.array_equal(pa, pb) and np.array_equal(ta, tb) and np.array_equal(ia, ib)

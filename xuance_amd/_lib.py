@@ -392,6 +392,7 @@ _SIGS = {
     "xrl_rollout_wide_max_envs": [],
     "xrl_marl_stored_state": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_ppokl_adapt": [c_void_p, c_int, c_double, c_void_p, c_double, c_void_p, c_void_p],
+    "xrl_set_conv_dw_mixed": [c_int],
     "xrl_qmix_fused_update": [C.POINTER(QmixFused), c_void_p],
     "xrl_qmix_fused_phase": [C.POINTER(QmixFused), C.POINTER(QmixPhase), c_void_p],
     "xrl_qmix_fused_phase_fits": [c_int32, c_int32, c_int64],

@@ -230,12 +230,10 @@ __global__ void __launch_bounds__(KS == 8 ? 512 : 256) conv_mfma_kernel(ConvBatc
 // eighth of the chunk's rows each -- 25..55 rows, ALL of whose operands are requested before the first product: the loop is a
 // chain of memory round trips otherwise (measured: 7 batches x ~4 k cycles per wave) -- and meet in LDS.  MFMA A operand = dY^T (lane (f, h): dY[row_h][f], 128 contiguous bytes
 // per row across the lanes), B operand = the patch value (row_h, k') read from the image in place.
+// the kernel's body: a routine so that one launch can carry groups of different (N / 32, uint8) kinds (conv_dw_mixed_kernel below)
 template <int NB, bool U8>
-__global__ void __launch_bounds__(512) conv_dw_mfma_kernel(ConvBatch p) {
+__device__ __forceinline__ void conv_dw_body(const ConvBatch& p, float* s_tab, float* s_red, float* s_db) {
     constexpr int DW_WAVES = 8;
-    __shared__ float s_tab[256];
-    extern __shared__ __attribute__((aligned(16))) float s_red[];        // [DW_WAVES][NB][16][64]
-    __shared__ float s_db[DW_WAVES * NB * 64];
     const xrl_conv_t& g = p.g[blockIdx.z];
     const int C = g.C, lc = 31 - __clz(C), Tw = g.Tw, kk = g.Th * Tw, Kp = kk * C;
     const int ktile = blockIdx.x, split = blockIdx.y;
@@ -356,6 +354,28 @@ __global__ void __launch_bounds__(512) conv_dw_mfma_kernel(ConvBatch p) {
     if (dbg_me) { dbg[5] = clock64(); dbg[1] = (long long)__builtin_amdgcn_s_memrealtime(); }
 }
 
+template <int NB, bool U8>
+__global__ void __launch_bounds__(512) conv_dw_mfma_kernel(ConvBatch p) {
+    __shared__ float s_tab[256];
+    extern __shared__ __attribute__((aligned(16))) float s_red[];        // [DW_WAVES][NB][16][64]
+    __shared__ float s_db[8 * NB * 64];
+    conv_dw_body<NB, U8>(p, s_tab, s_red, s_db);
+}
+
+// Groups of different kinds in ONE launch (round 6): the weight gradients of a convolution stack are independent of each other, but the
+// first layer (uint8 frames, 32 filters) and the upper ones (float32 activations, 64 filters) are different instances of the body and
+// went out as two launches one after the other (DQN-C3: 10.5 + 16.8 us, each on a part of the chip).  The kind is uniform per workgroup
+// (blockIdx.z = group).
+__global__ void __launch_bounds__(512) conv_dw_mixed_kernel(ConvBatch p) {
+    __shared__ float s_tab[256];
+    extern __shared__ __attribute__((aligned(16))) float s_red[];        // sized for NB = 2
+    __shared__ float s_db[8 * 2 * 64];
+    const xrl_conv_t& g = p.g[blockIdx.z];
+    const bool two = g.N == 64, u8 = g.img_u8 != 0;
+    if (two) { if (u8) conv_dw_body<2, true>(p, s_tab, s_red, s_db); else conv_dw_body<2, false>(p, s_tab, s_red, s_db); }
+    else { if (u8) conv_dw_body<1, true>(p, s_tab, s_red, s_db); else conv_dw_body<1, false>(p, s_tab, s_red, s_db); }
+}
+
 struct ImageJobs {
     xrl_image_job_t j[8];
     int n;
@@ -438,9 +458,40 @@ extern "C" int xrl_conv_fwd_probe(const xrl_conv_t* groups, int n_groups, int k_
     return conv_fwd_launch(groups, n_groups, k_split, dbg, stream);
 }
 
+// OFF by default: measured slower (profiles/r06_g_conv_overlap.json: DQN-C3 update 120.7 -> 125.8 us, PPO-Atari update 7.61 -> 8.11 ms) -- the
+// merged grid is sized for the largest group and the 212-register body halves the residency of the 32-filter groups
+static bool g_conv_dw_mixed = false;         // xrl_set_conv_dw_mixed (tests, A/B measurements)
+extern "C" int xrl_set_conv_dw_mixed(int enable) { g_conv_dw_mixed = enable != 0; return XRL_OK; }
+
 static int conv_dw_launch(const xrl_conv_t* groups, int n_groups, int n_split, int64_t slab_stride, long long* dbg, xrl_stream_t stream) {
     XRL_CHECK_ARG(groups && n_groups >= 1 && n_groups <= CONV_MAX_GROUPS && n_split >= 1 && n_split <= 65535);
-    // the kernel is instantiated per (N / 32, uint8): groups that differ go out as separate launches (same stream, any order)
+    // the body is instantiated per (N / 32, uint8).  Groups of more than one kind: ONE launch of the mixed kernel (g_conv_dw_mixed, round 6);
+    // else (or with the switch off) one launch per kind (same stream, any order)
+    {
+        int kinds = 0, max_tiles = 0;
+        ConvBatch b;
+        b.n_groups = 0; b.ks = 1; b.n_split = n_split; b.pad = 0; b.slab_stride = slab_stride; b.dbg = dbg;
+        for (int i = 0; i < n_groups; ++i) {
+            const int rc = check_group(groups[i], true);
+            if (rc != XRL_OK) return rc;
+            XRL_CHECK_ARG(groups[i].N == 32 || groups[i].N == 64);
+            XRL_CHECK_ARG(groups[i].pad >= 0 && groups[i].pad <= n_split);
+            kinds |= 1 << ((groups[i].N == 64 ? 2 : 0) + (groups[i].img_u8 ? 1 : 0));
+            b.g[b.n_groups++] = groups[i];
+            const int tiles = groups[i].Th * groups[i].Tw * groups[i].C / 32;
+            max_tiles = tiles > max_tiles ? tiles : max_tiles;
+        }
+        if (g_conv_dw_mixed && (kinds & (kinds - 1)) != 0 && dbg == nullptr) {
+            static bool attr_mixed = false;
+            if (!attr_mixed) {
+                XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dw_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 16 * 64 * 4));
+                attr_mixed = true;
+            }
+            hipLaunchKernelGGL(conv_dw_mixed_kernel, dim3(max_tiles, n_split, b.n_groups), dim3(512), (size_t)8 * 2 * 16 * 64 * sizeof(float), as_stream(stream), b);
+            XRL_CHECK_LAUNCH();
+            return XRL_OK;
+        }
+    }
     for (int nbv = 1; nbv <= 2; ++nbv)
         for (int u8 = 0; u8 <= 1; ++u8) {
             ConvBatch b;

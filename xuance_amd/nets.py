@@ -1098,6 +1098,12 @@ class ConvStack:
         P = self.params
         img, _ = self.images(flat)
         wg, splits = [], self._dw_splits(rows, self.N_SPLIT_IMPLICIT)
+        # (round 6) the weight gradients of layers >= 1 need nothing the last data-gradient launch produces: they go out on a side
+        # branch as soon as their dy exists and run beside that launch and the first layer's weight gradient (DQN-C3: 16.8 us of the
+        # update's chain of ten launches; config.overlap_conv_wgrad / ConvStack.overlap_wgrad: False keeps one grouped launch at the end)
+        # MEASURED SLOWER (profiles/r06_g_conv_overlap.json: DQN-C3 update 120.3 -> 131.5 us, PPO-Atari update 7.65 -> 7.98 ms): a fork / join
+        # between two hardware queues costs more than the 16.8 us it takes off the chain -- off unless ConvStack.overlap_wgrad = True
+        side = ops.Branch() if (getattr(self, "overlap_wgrad", False) and len(self.geo) >= 2 and torch.cuda.is_available()) else None
         for i in reversed(range(len(self.geo))):
             H, W, C, k, s, p, OH, OW, F = self.geo[i]
             n = self.names[i]
@@ -1106,6 +1112,11 @@ class ConvStack:
                                     dbias=cs.data_ptr() + 4 * P.offsets[n + ".bias"], B=rows, IH=H, IW=W, C=C, Th=k, Tw=k,
                                     nh=OH, nw=OW, sh=s, off_h=-p, off_w=-p, so=1, OHt=OH, OWt=OW, N=F,
                                     img_u8=int(x.dtype == torch.uint8), pad=splits[i]))
+            if side is not None and i == 1:
+                side.begin()
+                ops.conv_bwd_weight(wg, self.N_SPLIT_IMPLICIT, stride)
+                side.end()
+                wg = []
             if i > 0:
                 groups = [ops.conv_desc(img=ws.dy[i], w=img.data_ptr() + 4 * c["off"], mask=ws.y[i - 1], out=ws.dy[i - 1], B=rows,
                                         IH=OH, IW=OW, C=F, Th=c["Th"], Tw=c["Tw"], nh=c["nh"], nw=c["nw"], sh=1, off_h=c["off_h"],
@@ -1113,6 +1124,8 @@ class ConvStack:
                           for c in self._dx[i]]
                 ops.conv_fwd(groups, self._k_split(rows * sum(c["nh"] * c["nw"] for c in self._dx[i])))
         ops.conv_bwd_weight(wg, self.N_SPLIT_IMPLICIT, stride)
+        if side is not None:
+            side.join()
 
 
     @staticmethod

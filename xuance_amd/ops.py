@@ -1092,6 +1092,38 @@ def fast_kernels_enabled():
 
 
 # ------------------------------------------------------------------------------------------ graphs
+class Branch:
+    """Launches that may run BESIDE what the caller enqueues next on the current stream (round 6: independent launches of an update --
+    a convolution stack's weight gradients of the upper layers next to the rest of its data-gradient chain): begin() forks ONE per-device
+    side stream off the current stream (an event), end() leaves it, join() makes the current stream wait for it.  Inside an ops.Graph
+    capture the fork / join become two parallel branches of the graph (the side stream joins the capture through the event)."""
+    _streams = {}        # device index -> THE side stream of this process (one more hardware queue, not one per caller: see Graph.__enter__)
+
+    def __init__(self):
+        dev = torch.cuda.current_device()
+        if dev not in Branch._streams:
+            Branch._streams[dev] = torch.cuda.Stream()
+        self.side = Branch._streams[dev]
+        self._ctx = None
+
+    def begin(self):
+        self.main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+
+    def end(self):
+        self._done = torch.cuda.Event()
+        self._done.record(self.side)
+        self._ctx.__exit__(None, None, None)
+        self._ctx = None
+
+    def join(self):
+        torch.cuda.current_stream().wait_event(self._done)
+
+
 class Graph:
     """hipGraph capture / replay of a sequence of xrl ops issued on the current torch stream."""
 
