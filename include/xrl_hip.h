@@ -118,6 +118,9 @@ typedef struct {
  *   in order and applies bias + activation: for layers with few output tiles and a long reduction (the 3 200 x 64 x 512
  *   convolution GEMMs of the Atari Q-network would otherwise occupy 50 of 256 CUs). */
 int xrl_linear_fwd(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream);
+/* xrl_linear_fwd without its split-K epilogue: groups that carry a workspace (aux, ldaux = K ranges > 1) leave their raw partial
+ * sums ws[s][m][n] there and write nothing to C -- the caller's next launch sums them (xrl_ppo_act_tail). */
+int xrl_linear_fwd_partials(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream);
 /* backward w.r.t. the layer input (autograd of the same block):
  *   C[M,N] = (A[M,K] . B[K,N]) * act'(aux[M,N])        A = dY, B = weight [out=K,in=N] */
 int xrl_linear_bwd_data(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream);
@@ -515,6 +518,33 @@ typedef struct {
     float* pg_bootv;
 } xrl_poststep_t;
 int xrl_rollout_poststep(const xrl_poststep_t* p, xrl_stream_t stream);
+
+/* The tail of an on-policy ACTING pass of an actor-critic network whose heads sit directly on one wide hidden layer (AC_CNN_Atari of
+ * configs/ppo/atari.yaml: Linear(6 400, 512) + ReLU, CategoricalActorHead / ValueHead on the 512 features; cnn.py:53-102,
+ * on_policy.py:128-169) as ONE launch (round 6): the split-K partial sums xrl_linear_fwd_partials left for that layer are summed
+ * (xrl_linear_fwd's own epilogue: partials in order, + bias, activation), the actor's logits and the critic's value follow as one
+ * wavefront per (row, head) with xrl_linear_fwd's skinny-layer arithmetic, rows [0, n) are sampled exactly as xrl_policy_sample does
+ * (same Philox draws / supplied uniforms; action, log-prob, value -> the buffer slot, the env's action), rows [n, M) give bootv_prev --
+ * the same numbers as the three launches it replaces, bit for bit.  Beside that workgroup: one workgroup does the PREVIOUS vector
+ * step's bookkeeping (post_n > 0: xrl_rollout_poststep's arguments in `post`) and a few copy the observations the policy acted on
+ * into their buffer slot (memory.observations[t] = obs, ppo_agent.py:128: copy_bytes > 0). */
+typedef struct {
+    const float* ws;            /* [ks][M][H] partial sums of the hidden layer's product (xrl_linear_fwd_partials) */
+    const float* bias;          /* [H] */
+    int32_t ks, M, H, act;      /* M = rows of the policy batch (<= 64), H % 64 == 0, H <= 1 024; act: XRL_ACT_* of the hidden layer */
+    const float* w_actor; const float* b_actor;     /* [A][H], [A] */
+    const float* w_critic; const float* b_critic;   /* [1][H], [1] */
+    /* xrl_sample_t's fields (categorical) */
+    const float* noise;
+    float* act_out; float* val_out; float* logp_out; int32_t* env_action; float* bootv_prev;
+    int32_t n, A;
+    uint64_t seed; uint32_t step; uint32_t pad0; const uint32_t* step_dev;
+    float* heads_out;           /* NULL, or [M][A + 1]: the head outputs (tests) */
+    xrl_poststep_t post;        /* the previous step's bookkeeping ... */
+    int32_t post_n, pad1;       /* ... when post_n > 0 */
+    const void* copy_src; void* copy_dst; int64_t copy_bytes;     /* 16-byte aligned, copy_bytes % 16 == 0 */
+} xrl_ppo_act_tail_t;
+int xrl_ppo_act_tail(const xrl_ppo_act_tail_t* p, xrl_stream_t stream);
 
 /* OffPolicyAgent.exploration (core/off_policy.py:129-148): greedy argmax + per-env epsilon coin. */
 typedef struct {

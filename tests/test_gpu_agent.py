@@ -1086,6 +1086,40 @@ def test_ppo_atari_rollout_as_one_graph_equals_the_eager_rollout():
             assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_ppo_atari_acting_tail_in_one_launch_equals_the_launches(graph):
+    """xrl_ppo_act_tail (round 6): behind the hidden layer's split-K product of a vector step on frame stacks -- epilogue, logits + value,
+    sample / log-prob / value / bootstrap value, the previous step's bookkeeping, the copy of the frames into their buffer slot -- as ONE
+    launch against the five launches it replaces (config.use_frame_act_tail: False): two consecutive rollouts with episode ends of both
+    kinds inside, every buffer field (actions, log-probs, values, bootstrap values, processed rewards, flags, the stored frames,
+    advantages, returns), the return statistics and the provider's state bit-equal; also with the reward normalisation on."""
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import SyntheticAtariVecEnv
+    n, T = 8, 12
+    out = []
+    for tail in (True, False):
+        torch.manual_seed(0)
+        cfg = make_config(n, T, representation="AC_CNN_Atari", kernels=[8, 4, 3], strides=[4, 2, 1], filters=[32, 64, 64],
+                          fc_hidden_sizes=[512], actor_hidden_size=[], critic_hidden_size=[], activation="relu", n_epochs=1,
+                          n_minibatch=2, use_obsnorm=False, use_rewnorm=True, learning_rate=2.5e-4, gamma=0.99, use_hip_graph=graph,
+                          use_frame_act_tail=tail)
+        agent = PPO_Agent(cfg, SyntheticAtariVecEnv(n, seed=5, max_episode_steps=5, p_term=0.05))
+        snaps = []
+        for _ in range(2):
+            agent.rollout()
+            torch.cuda.synchronize()
+            assert bool(getattr(agent, "_ftail_ok", False)) == tail
+            f = agent.memory.soa.fields
+            snaps.append({k: npy(v) for k, v in f.items()} | {"env_obs": npy(agent.envs.buf_obs), "env_steps": npy(agent.envs.steps),
+                                                               "ret_mean": npy(agent.ret_mean), "ret_var": npy(agent.ret_var),
+                                                               "ret_count": npy(agent.ret_count), "returns_track": npy(agent.returns)})
+        out.append(snaps)
+    for a, b in zip(*out):
+        assert (a["seg"] & 1).any() and a["terminals"].any() and int(a["observations"].max()) > 0
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("name,dist", [("DevicePendulumVecEnv", "gaussian"), ("DeviceMountainCarVecEnv", "categorical"),
                                        ("DeviceAcrobotVecEnv", "categorical")])
 def test_ppo_agent_on_the_other_classic_control_envs(name, dist):

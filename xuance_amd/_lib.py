@@ -113,6 +113,16 @@ class PostStep(C.Structure):
                 ("rew_range", c_float), ("gamma", c_float), ("pg_bootv", c_void_p)]
 
 
+class PpoActTail(C.Structure):
+    """xrl_ppo_act_tail_t: split-K epilogue + heads + sampling (+ the previous step's bookkeeping, + the observation copy) in one launch."""
+    _fields_ = [("ws", c_void_p), ("bias", c_void_p), ("ks", c_int32), ("M", c_int32), ("H", c_int32), ("act", c_int32),
+                ("w_actor", c_void_p), ("b_actor", c_void_p), ("w_critic", c_void_p), ("b_critic", c_void_p),
+                ("noise", c_void_p), ("act_out", c_void_p), ("val_out", c_void_p), ("logp_out", c_void_p), ("env_action", c_void_p),
+                ("bootv_prev", c_void_p), ("n", c_int32), ("A", c_int32), ("seed", C.c_uint64), ("step", C.c_uint32), ("pad0", C.c_uint32),
+                ("step_dev", c_void_p), ("heads_out", c_void_p), ("post", PostStep), ("post_n", c_int32), ("pad1", c_int32),
+                ("copy_src", c_void_p), ("copy_dst", c_void_p), ("copy_bytes", c_int64)]
+
+
 class EGreedy(C.Structure):
     _fields_ = [("q", c_void_p), ("uniforms", c_void_p), ("randoms", c_void_p), ("eps_dev", c_void_p),
                 ("action", c_void_p), ("action_f", c_void_p), ("n", c_int), ("A", c_int), ("ld", c_int), ("eps", c_float),
@@ -452,6 +462,8 @@ _SIGS = {
     "xrl_soa_gather_sampled": [C.POINTER(Field), c_int, c_void_p, c_int, c_int, c_int, c_void_p, C.c_uint64, C.c_uint32, c_void_p,
                                c_void_p],
     "xrl_linear_fwd": [C.POINTER(Gemm), c_int, c_void_p],
+    "xrl_linear_fwd_partials": [C.POINTER(Gemm), c_int, c_void_p],
+    "xrl_ppo_act_tail": [C.POINTER(PpoActTail), c_void_p],
     "xrl_linear_bwd_data": [C.POINTER(Gemm), c_int, c_void_p],
     "xrl_linear_bwd_weight": [C.POINTER(Gemm), c_int, c_int, c_int64, c_void_p],
     "xrl_ppo_loss_categorical": [C.POINTER(PpoLoss), c_void_p],

@@ -152,6 +152,18 @@ class PPO_Agent(AgentSurface):
         bootstrap truncated paths, ppo_agent.py:130,156)."""
         env, n, A, f = self.envs, self.n_envs, self.model.action_dim, self.memory.soa.fields
         cur = env.buf_obs.view(n, -1)
+        if self._frame_tail():
+            # (round 6) everything behind the hidden layer's product as ONE launch (xrl_ppo_act_tail): its split-K epilogue, logits + value,
+            # sample / log-prob / value / bootstrap value, the PREVIOUS step's bookkeeping and the copy of `cur` into the buffer slot --
+            # five small launches of a vector step (the last step's bookkeeping follows the loop: _enqueue_rollout_tail)
+            x = self._xin[env._cur]
+            self.model.act_tail(x, 2 * n, n, post=self._post_args(t - 1, (self.obs_mean, self.obs_var, self.obs_count), None) if t > 0 else None,
+                                copy=(cur, f["observations"][t], cur.numel() * cur.element_size()),
+                                noise=None if self.action_noise is None else self.action_noise[t], act_out=f["actions"][t],
+                                val_out=f["values"][t], logp_out=f["aux_old_logp"][t], env_action=env.action,
+                                bootv_prev=f["bootv"][t - 1] if t > 0 else None, seed=self.seed, step=t, step_dev=self.step_counter)
+            env.step_device(offset=t)
+            return
         f["observations"][t].view(n, -1).copy_(cur)               # memory.observations[t] = obs (uint8, ppo_agent.py:128)
         if self._xin is not None:
             heads = self.model.forward(self._xin[env._cur], 2 * n, keep=False, acting=self._acting_fast)   # [obs_t ; next_obs_{t-1}], written there by the provider
@@ -169,6 +181,18 @@ class PPO_Agent(AgentSurface):
         if self._xin is None:
             self.Xu8[n:].copy_(env.next_obs.view(n, -1))
         ops.rollout_poststep(**self._post_args(t, (self.obs_mean, self.obs_var, self.obs_count), None))
+
+    def _frame_tail(self):
+        """May a vector step on frame stacks end in xrl_ppo_act_tail?  The fast acting pass is on (a rollout is being enqueued), the
+        provider writes the policy's batches and takes static step offsets, the network is the class the launch serves, nobody wants a
+        callback between the steps; config.use_frame_act_tail: False keeps the launches."""
+        if not (self._acting_fast and self._xin is not None and hasattr(self.envs, "advance")) or self._per_step():
+            return False
+        if not hasattr(self, "_ftail_ok"):
+            self._ftail_ok = bool(_get(self.config, "use_frame_act_tail", True)) and type(self)._enqueue_step is PPO_Agent._enqueue_step and \
+                hasattr(self.model, "act_tail_eligible") and self.model.act_tail_eligible(2 * self.n_envs) and \
+                (self.n_envs * int(np.prod(self.envs.buf_obs.shape[1:]))) % 16 == 0
+        return self._ftail_ok
 
     def _policy_frames(self):
         """The policy's uint8 input batch [obs ; previous next_obs] as it stands now."""
@@ -470,6 +494,11 @@ class PPO_Agent(AgentSurface):
                 kw = dict(next_raw=self.envs.next_obs, post=self._post_args(T - 1, st), stats_in=st,
                           normalize=int(self.use_obsnorm), obs_range=float(self.obsnorm_range))
             wide.act(self.X, n, self.seed, 0, None, bootv_prev=self.memory.soa.fields["bootv"][T - 1], **kw)
+        elif self.frames and self._frame_tail():
+            # the last step's bookkeeping rides in the bootstrap pass's tail launch (xrl_ppo_act_tail with act_out = None: values only)
+            self.model.act_tail(self._policy_frames(), 2 * n, n, post=self._post_args(T - 1, (self.obs_mean, self.obs_var, self.obs_count), None),
+                                act_out=None, val_out=None, logp_out=None, env_action=None,
+                                bootv_prev=self.memory.soa.fields["bootv"][T - 1], seed=self.seed, step=0, step_dev=None)
         else:
             heads = self.model.forward(self._policy_frames(), 2 * n, keep=False, acting=self._acting_fast) if self.frames else self.model.forward(self.X, 2 * n)
             ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,

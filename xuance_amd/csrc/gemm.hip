@@ -409,7 +409,7 @@ static bool all_skinny(int mode, const xrl_gemm_t* groups, int n_groups) {
 }
 
 static int launch(int mode, const xrl_gemm_t* groups, int n_groups, int n_split, int64_t slab_stride,
-                  xrl_stream_t stream) {
+                  xrl_stream_t stream, bool skip_epilogue = false) {
     XRL_CHECK_ARG(groups != nullptr && n_groups >= 1 && n_groups <= MAX_GROUPS);
     XRL_CHECK_ARG(n_split >= 1 && n_split <= 65535);
     if (all_rowwise_nn(mode, groups, n_groups)) {
@@ -490,6 +490,7 @@ static int launch(int mode, const xrl_gemm_t* groups, int n_groups, int n_split,
     }
     if (mode == MODE_NT && ksplit > 1) {
         GEMM_LAUNCH(MODE_NT)
+        if (skip_epilogue) { XRL_CHECK_LAUNCH(); return XRL_OK; }       // (xrl_linear_fwd_partials: the caller's launch sums ws[s][m][n])
         unsigned nb = (unsigned)((max_el + 255) / 256);
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(nb, n_groups), dim3(256), 0, as_stream(stream), b);
@@ -508,6 +509,11 @@ static int launch(int mode, const xrl_gemm_t* groups, int n_groups, int n_split,
 
 extern "C" int xrl_linear_fwd(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream) {
     return xrl::launch(xrl::MODE_NT, groups, n_groups, 1, 0, stream);
+}
+extern "C" int xrl_linear_fwd_partials(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream) {
+    XRL_CHECK_ARG(groups && n_groups >= 1);
+    for (int i = 0; i < n_groups; ++i) XRL_CHECK_ARG(groups[i].aux && groups[i].ldaux > 1);       // every group leaves partials
+    return xrl::launch(xrl::MODE_NT, groups, n_groups, 1, 0, stream, true);
 }
 extern "C" int xrl_linear_bwd_data(const xrl_gemm_t* groups, int n_groups, xrl_stream_t stream) {
     return xrl::launch(xrl::MODE_NN, groups, n_groups, 1, 0, stream);

@@ -120,6 +120,8 @@ class Plan:
         if L.K < 2048:
             return None, 0
         tiles, ks = ((M + 63) // 64) * ((L.N + 63) // 64), 1
+        # (round 6, measured: K ranges below 128 reduction steps -- 32 ranges for a 16-row acting pass -- are slower: PPO-Atari rollout
+        #  7.08 -> 8.27 ms)
         while tiles * ks < 384 and L.K // (ks * 2) >= 128 and ks < 16:
             ks *= 2
         if ks == 1:
@@ -1390,6 +1392,39 @@ class ActorCriticCNN:
         if keep:
             self._feat_in = feat
         return self.plan.forward(feat, self.n_flat, M)
+
+    def act_tail_eligible(self, M):
+        """May an acting pass end in xrl_ppo_act_tail?  The heads sit directly on ONE hidden layer (configs/ppo/atari.yaml: fc_hidden_sizes
+        [512], actor / critic hidden []), that layer is a split-K product at M rows, the fast acting copy of the dense parameters exists."""
+        st = self.plan.stages
+        if len(st) != 2 or len(st[0]) != 1 or len(st[1]) != 1 or not self.conv.implicit or getattr(self, "_act_flat", None) is None:
+            return False
+        L, Lh = st[0][0], st[1][0]                       # (the heads: ONE stacked layer [W_actor; W_critic], adjacent biases)
+        return M <= 64 and L.N % 64 == 0 and L.N <= 1024 and self.action_dim <= 16 and self.plan._split_k(L, M)[1] > 1 and \
+            Lh.N == self.action_dim + 1 and Lh.K == L.N and Lh.act is None and Lh.in_off == 0
+
+    def act_tail(self, x_u8, M, n, post=None, copy=None, **sample):
+        """An acting pass on M rows of frames ending in ONE tail launch (xrl_ppo_act_tail): convolutions, the hidden layer's split-K
+        product WITHOUT its epilogue, then epilogue + heads + sampling (+ the previous step's bookkeeping `post`, + the observation copy
+        `copy` = (src, dst, bytes)).  Same numbers as forward(acting=True) + ops.policy_sample (+ ops.rollout_poststep)."""
+        ws = self.conv.workspace("act", M, False)
+        self.conv.forward(x_u8[:M].reshape(M, -1), M, ws, pool=False)
+        plan, P, flat = self.plan, self.params, self._act_flat
+        plan.ensure(M)
+        L, Lh = plan.stages[0][0], plan.stages[1][0]
+        A = self.action_dim
+        x = ws.y[-1].view(-1)[:M * self.n_flat].view(M, self.n_flat)
+        aux, ks = plan._split_k(L, M)
+        c, ldc = plan._buf(plan.acts, L.out_level, L.out_off, x, self.n_flat)
+        ops.linear_fwd_partials([ops.gemm_desc(x.data_ptr(), P.ptr(L.w_name, flat), c, M, L.N, L.K, self.n_flat, L.K, ldc,
+                                               bias=P.ptr(L.b_name, flat), act=L.act, aux=aux.data_ptr(), ldaux=ks)])
+        wa, ba = P.ptr(Lh.w_name, flat), P.ptr(Lh.b_name, flat)        # rows [0, A): the logits, row A: the value
+        kw = dict(ws=aux, bias=P.ptr(L.b_name, flat), ks=ks, M=M, H=L.N, act=ops.ACT[L.act], w_actor=wa, b_actor=ba,
+                  w_critic=wa + 4 * A * L.N, b_critic=ba + 4 * A, n=n, A=A)
+        if copy is not None:
+            kw.update(copy_src=copy[0], copy_dst=copy[1], copy_bytes=int(copy[2]))
+        kw.update(sample)
+        ops.ppo_act_tail(post=post, **kw)
 
     @property
     def d_heads(self):

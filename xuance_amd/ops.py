@@ -103,6 +103,26 @@ def linear_fwd(groups):
     call("xrl_linear_fwd", _garr(groups), len(groups), stream_ptr())
 
 
+def linear_fwd_partials(groups):
+    """xrl_linear_fwd without the split-K epilogue: every group leaves its raw partial sums in its workspace (aux)."""
+    call("xrl_linear_fwd_partials", _garr(groups), len(groups), stream_ptr())
+
+
+def ppo_act_tail(post=None, **kw):
+    """xrl_ppo_act_tail: the hidden layer's split-K epilogue, logits + value, sampling / log-prob / value / bootstrap value, and --
+    post: xrl_rollout_poststep's keyword arguments of the PREVIOUS vector step -- that step's bookkeeping, and the copy of the observations
+    into their buffer slot (copy_src / copy_dst / copy_bytes), in one launch."""
+    from ._lib import PpoActTail
+    p = _struct(PpoActTail, kw)
+    if post is not None:
+        for k, v in post.items():
+            if isinstance(v, torch.Tensor):
+                v = v.data_ptr()
+            setattr(p.post, k, v)
+        p.post_n = int(post["n"])
+    call("xrl_ppo_act_tail", C.byref(p), stream_ptr())
+
+
 def linear_bwd_data(groups):
     call("xrl_linear_bwd_data", _garr(groups), len(groups), stream_ptr())
 
