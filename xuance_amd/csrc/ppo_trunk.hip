@@ -405,22 +405,26 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
         for (int rr = 0; rr < PT; ++rr) acc += dzh[rr * 16 + j] * hp[rr * TLD];
         slab[Lh.w_off + e] = acc;
     }
+    // (bias gradients: plain column sums of per-row terms, summed in DOUBLE and rounded once per tile.  With advantages normalised to
+    //  mean 0 the head bias' 8 192 terms cancel to 6e-5 of sum|terms| (tests/test_oracle_head_bias_floor.py): 64 float adds per tile
+    //  left the sum 5.7e-5 of its own size from the float64 value -- as far as torch's float32 sum -- where float32 TERMS summed
+    //  exactly land at < 2e-5; the slabs are summed in double by xrl_reduce_adam already)
     if (tid >= 4 * 64 && tid < 4 * 64 + TH) {
         const int t = tid - 4 * 64;
-        float acc0 = 0.f;
+        double acc0 = 0.0;
 #pragma unroll 16
-        for (int rr = 0; rr < PT; ++rr) acc0 += g2[rr * TLD + t];
-        slab[L1.b_off + cb + t] = acc0;
+        for (int rr = 0; rr < PT; ++rr) acc0 += (double)g2[rr * TLD + t];
+        slab[L1.b_off + cb + t] = (float)acc0;
     } else if (tid >= 6 * 64 && tid < 6 * 64 + 2 * TAMAX) {
         const int t = tid - 6 * 64;                                      // 0..7 head bias, 8..15 log_std
         if (t < nout || (t >= 8 && GAUSS && actor && t - 8 < A)) {
-            float acc = 0.f;
+            double acc = 0.0;
 #pragma unroll 16
-            for (int rr = 0; rr < PT; ++rr) acc += dzh[rr * 16 + t];
+            for (int rr = 0; rr < PT; ++rr) acc += (double)dzh[rr * 16 + t];
             // d(-ent_coef * mean_m sum_j(log_std_j + c)) / d log_std_j = -ent_coef, added once (tile 0), as in ppo_loss.hip / ppo_wide.hip
-            if (t >= 8 && tile == 0) acc -= p.ent_coef;
-            if (t < 8) slab[Lh.b_off + t] = acc;
-            else slab[p.log_std_off + t - 8] = acc;
+            if (t >= 8 && tile == 0) acc -= (double)p.ent_coef;
+            if (t < 8) slab[Lh.b_off + t] = (float)acc;
+            else slab[p.log_std_off + t - 8] = (float)acc;
         }
     }
     WSTAMP(0);
