@@ -1199,14 +1199,19 @@ int xrl_qmix_fused_layout(const xrl_qmix_fused_t* p, xrl_qf_image_t* out);   /* 
 /* One acting step of the recurrent agents as ONE launch (value_factorization.py:66-92 with Basic_RNN, rnn.py:52-77: mlp
  * blocks -> nn.GRU cell -> Q head; the reference calls it once per vector step, off_policy_marl.py:478-486): Q values of R
  * rows from their observations and carried hidden states; the new hidden states replace the old ones.  rows_per_wg rows
- * per workgroup, all weights staged in LDS from an IMAGE in the layout of xrl_marl_act_gru_layout (layers in the order
- * pre[0..n_pre), W_ih, W_hh, post[0..n_post); matrix l at w[l] + n * ldw[l] + k, its bias at b[l]; padding zero).  Cell
+ * per workgroup, weights from an IMAGE in the layout of xrl_marl_act_gru_layout (layers in the order
+ * pre[0..n_pre), W_ih, W_hh, post[0..n_post); matrix l at w[l], row-major or interleaved: xrl_qa_image_t; its bias at b[l]; padding
+ * zero) -- staged in LDS by the general kernel, held in registers (one thread per output) by the kernel for one row per workgroup.  Cell
  * arithmetic as xrl_gru_forward.  Same numbers as xrl_linear_fwd + xrl_gru_forward + xrl_linear_fwd up to fp32 summation
  * order.  H == 0: feed-forward agents (no recurrent layer: pre = every hidden layer, post = the output layer; h unused). */
 #define XRL_QA_MAX_LAYERS 8
 typedef struct {
     int32_t w[XRL_QA_MAX_LAYERS], b[XRL_QA_MAX_LAYERS], ldw[XRL_QA_MAX_LAYERS];
     int32_t image_floats, lds_bytes;
+    int32_t interleaved;        /* 0: matrix l row-major, element (n, k) at w[l] + n * ldw[l] + k.  1 (the one-thread-per-output kernel:
+                                 * rows_per_wg == 1, every layer <= 64 wide, H 0 or 64, O <= 64, lds_staged == 0): k-quads interleaved
+                                 * over the outputs, element (n, k) at w[l] + ((k / 4) * ldw[l] + n) * 4 + k % 4, ldw = outputs padded to 64 */
+    int32_t pad;
 } xrl_qa_image_t;
 typedef struct {
     const float* image;
@@ -1226,9 +1231,15 @@ typedef struct {
     uint64_t seed;
     uint32_t step;
     float eps;                  /* used when eps_dev is NULL */
+    int32_t lds_staged;         /* != 0: the kernel that stages a row-major image in LDS even where the other one could serve (bit-identical) */
+    int32_t pad;
 } xrl_marl_act_gru_t;
 int xrl_marl_act_gru(const xrl_marl_act_gru_t* p, xrl_stream_t stream);
 int xrl_marl_act_gru_layout(const xrl_marl_act_gru_t* p, xrl_qa_image_t* out);
+/* Measurement aid (tools/probe_act_gru.py): stamps != NULL -> every workgroup of the following xrl_marl_act_gru launches writes 16
+ * int64 clock stamps (slot 0 / 15: s_memrealtime at start / end, 1..7: s_memtime at the phase boundaries) to stamps[16 * workgroup];
+ * NULL switches it off again.  Not for production use. */
+int xrl_debug_act_gru_stamps(long long* stamps);
 
 /* One-layer GRU over whole sequences, time-major (Basic_RNN, rl_models/representations/rnn.py:52-77; nn.GRU built by
  * rl_models/modules/layers.py:79-98; the recurrent agents of qmix/sc2/3m.yaml).  gi = x W_ih^T + b_ih for all steps is

@@ -488,6 +488,25 @@ def test_weight_images_of_the_one_launch_kernels_cover_every_parameter_once():
     agent_names = [n for n in rnn.params.shapes if n.startswith("individual_q_networks")]
     assert len(ua) == sum(int(np.prod(rnn.params.shapes[n])) for n in agent_names) == 31689 and len(np.unique(ua)) == len(ua)
     assert np.array_equal(st.image.numpy()[ua], rnn.params.flat.numpy()[mpa >= 0]) and st.lds_bytes <= 160 * 1024
+    # (round 6) one row per workgroup and every layer <= 64 wide: the INTERLEAVED image of the one-thread-per-output kernel -- element
+    # (n, k) of matrix l at w[l] + ((k // 4) * ldw[l] + n) * 4 + k % 4, ldw = outputs padded to 64; more rows per workgroup or
+    # lds_staged: row-major rows (element (n, k) at w[l] + n * ldw[l] + k) for the kernel that stages the image in LDS
+    from xuance_amd import _lib
+    import ctypes as C
+    for kw, inter in ((dict(), 1), (dict(rows_per_wg=6), 0), (dict(lds_staged=True), 0)):
+        st = ops.MarlActGruState(rnn, **kw)
+        im = _lib.QaImage()
+        _lib.call("xrl_marl_act_gru_layout", C.byref(st.struct), C.byref(im))
+        assert im.interleaved == inter and im.lds_bytes == st.lds_bytes <= 160 * 1024
+        m2 = st.map.numpy()
+        assert np.array_equal(st.image.numpy()[m2[m2 >= 0]], rnn.params.flat.numpy()[m2 >= 0]) and len(np.unique(m2[m2 >= 0])) == len(ua)
+        w_ih = [n for n in agent_names if n.endswith("weight_ih_l0")]
+        assert len(w_ih) == 1
+        o, W = rnn.params.offsets[w_ih[0]], rnn.params.view(w_ih[0]).numpy()            # [192, 64], layer 1 of the image
+        nn, kk = 77, 13
+        at = im.w[1] + ((kk // 4) * im.ldw[1] + nn) * 4 + kk % 4 if inter else im.w[1] + nn * im.ldw[1] + kk
+        assert int(m2[o + nn * 64 + kk]) == at and st.image.numpy()[at] == W[nn, kk]
+        assert im.ldw[1] == (192 if inter else 68)
 
 
 def test_wide_kernel_class_is_recognised_on_the_host():

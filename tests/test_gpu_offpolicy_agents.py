@@ -832,6 +832,50 @@ def test_one_launch_acting_step_of_the_recurrent_agents_vs_the_layered_path(R):
     assert float(h_a.abs().max()) > 0
 
 
+@pytest.mark.parametrize("rnn", [True, False])
+@pytest.mark.parametrize("R,rpw", [(192, 6), (192, 1), (7, 4), (50, 3)])
+def test_acting_launch_with_weights_in_registers_is_bit_identical_to_the_lds_staged_form(rnn, R, rpw):
+    """xrl_marl_act_gru's two kernels (round 6): one thread per output with its weight row in registers (marl_act_rows_kernel, the
+    default where the shape allows it) vs the weight image staged in LDS (marl_act_gru_kernel): every output is the same fma chain in
+    the same order, so Q values, carried hidden states and selected actions must be EQUAL -- over several steps with row resets, a
+    ragged last workgroup, recurrent and feed-forward agents."""
+    import ctypes as C
+    from xuance_amd import ops, _lib
+    from xuance_amd.nets import MixingQNet
+    torch.manual_seed(0)
+    if rnn:
+        net = MixingQNet(3, 30, 9, 48, (), (64,), 32, 32, "relu", use_rnn=True, fc_hidden=(64,), recurrent_hidden=64)
+    else:
+        net = MixingQNet(3, 30, 9, 48, (64,), (64,), 32, 32, "relu")
+    sts = [ops.MarlActGruState(net, rows_per_wg=1, lds_staged=False), ops.MarlActGruState(net, rows_per_wg=rpw, lds_staged=True)]
+    im = _lib.QaImage()
+    for st, inter in zip(sts, (1, 0)):
+        _lib.call("xrl_marl_act_gru_layout", C.byref(st.struct), C.byref(im))
+        assert im.interleaved == inter
+    g = torch.Generator(device="cpu").manual_seed(4)
+    hs = [torch.zeros(R, 64, device="cuda") for _ in range(2)] if rnn else [None, None]
+    if True:
+        for step in range(4):
+            X = torch.randn(R, 30, generator=g).cuda()
+            reset = (torch.rand(R, generator=g) < (0.3 if step else 0.0)).float().cuda() if rnn else None
+            avail = (torch.rand(R, 9, generator=g) < 0.6).float()
+            avail[:, 0] = 1
+            avail = avail.cuda()
+            eps = torch.tensor([0.4], device="cuda")
+            outs = []
+            for form in (0, 1):
+                q = torch.full((R, 9), -7.0, device="cuda")
+                a, af = torch.zeros(R, dtype=torch.int32, device="cuda"), torch.zeros(R, device="cuda")
+                sts[form].launch(X, R, hs[form], reset, q, select=dict(avail=avail, eps_dev=eps, action=a, action_f=af, seed=5, step=step, step_dev=None))
+                torch.cuda.synchronize()
+                outs.append((q, a, af))
+            assert torch.equal(outs[0][0], outs[1][0]), f"q step {step}"
+            assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), f"actions step {step}"
+            if rnn:
+                assert torch.equal(hs[0], hs[1]), f"h step {step}"
+            assert float(outs[0][0].abs().max()) > 0 and (avail.cpu().numpy()[np.arange(R), outs[0][1].cpu().numpy()] == 1).all()
+
+
 def test_shm_multi_agent_vec_env_device_path_and_evaluation(tmp_path):
     """ShmSubprocVecMultiAgentEnv on the GPU box: the shared block is page-locked, step_to_device lands a whole vector step
     in HBM with one copy (device tensors equal the host views), a worker failure raises instead of hanging, and

@@ -321,7 +321,8 @@ QF_PHASE_SYNC_WORDS = 256
 
 
 class QaImage(C.Structure):
-    _fields_ = [("w", c_int32 * 8), ("b", c_int32 * 8), ("ldw", c_int32 * 8), ("image_floats", c_int32), ("lds_bytes", c_int32)]
+    _fields_ = [("w", c_int32 * 8), ("b", c_int32 * 8), ("ldw", c_int32 * 8), ("image_floats", c_int32), ("lds_bytes", c_int32),
+                ("interleaved", c_int32), ("pad", c_int32)]
 
 
 class MarlActGru(C.Structure):
@@ -329,7 +330,7 @@ class MarlActGru(C.Structure):
                 ("R", c_int32), ("rows_per_wg", c_int32), ("O", c_int32), ("H", c_int32), ("ldq", c_int32), ("act", c_int32),
                 ("n_pre", c_int32), ("n_post", c_int32), ("pre", c_int32 * 3), ("post", c_int32 * 3),
                 ("action", c_void_p), ("action_f", c_void_p), ("avail", c_void_p), ("eps_dev", c_void_p), ("step_dev", c_void_p),
-                ("seed", C.c_uint64), ("step", C.c_uint32), ("eps", c_float)]
+                ("seed", C.c_uint64), ("step", C.c_uint32), ("eps", c_float), ("lds_staged", c_int32), ("pad", c_int32)]
 
 
 class Exchange(C.Structure):
@@ -410,6 +411,7 @@ _SIGS = {
     "xrl_qmix_fused_layout": [C.POINTER(QmixFused), C.POINTER(QfImage)],
     "xrl_marl_act_gru": [C.POINTER(MarlActGru), c_void_p],
     "xrl_marl_act_gru_layout": [C.POINTER(MarlActGru), C.POINTER(QaImage)],
+    "xrl_debug_act_gru_stamps": [C.c_void_p],
     "xrl_host_device_pointer": [c_void_p, C.POINTER(c_void_p)],
     "xrl_per_store": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_void_p],
     "xrl_per_sample": [c_void_p, c_void_p, c_void_p, c_int, C.c_double, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -259,10 +259,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
                         slab[L.w_off + j * L.K + k] = acc;
                     }
                 }
-                if (tid < L.N) {
-                    float acc = 0.f;
-                    for (int rr = 0; rr < FT; ++rr) acc += dheads[rr * ldh + L.out_off + tid];
-                    slab[L.b_off + tid] = acc;
+                if (tid < L.N) {                                   // (bias gradients: the tile's rows added in double, rounded once -- as
+                    double acc = 0.0;                              //  ppo_trunk_kernel does since round 6: the two kernels carry the same bits)
+                    for (int rr = 0; rr < FT; ++rr) acc += (double)dheads[rr * ldh + L.out_off + tid];
+                    slab[L.b_off + tid] = (float)acc;
                 }
             }
         }
@@ -296,10 +296,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_fused_kernel(xrl_ppo_fused_
             tile_weight_grad(dz, ldz, hin, ldi, L.N, L.K, slab + L.w_off);
             PSTAMP();
             for (int j = tid; j < L.N; j += FUSED_THREADS) {
-                float acc = 0.f;
+                double acc = 0.0;
 #pragma unroll 8
-                for (int rr = 0; rr < FT; ++rr) acc += dz[rr * ldz + j];
-                slab[L.b_off + j] = acc;
+                for (int rr = 0; rr < FT; ++rr) acc += (double)dz[rr * ldz + j];
+                slab[L.b_off + j] = (float)acc;
             }
             // dH_in = dZ . W  ==  "forward" with the transposed weights W^T[K][N]; epilogue multiplies by act'(H_in)
             int pact = L0.act;

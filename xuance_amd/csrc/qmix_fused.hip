@@ -107,7 +107,8 @@ __device__ __forceinline__ void qf_lin_fwd_t(int W, int ldw, int b, int K, int N
 #pragma unroll
             for (int j = 0; j < QF_RB; ++j) {
                 const float4 x = *reinterpret_cast<const float4*>(x0 + j * ldi + k);   // rows padded: readable
-                acc[j] += x.x * wv.x; acc[j] += x.y * wv.y; acc[j] += x.z * wv.z; acc[j] += x.w * wv.w;
+                acc[j] = __builtin_fmaf(x.x, wv.x, acc[j]); acc[j] = __builtin_fmaf(x.y, wv.y, acc[j]);
+                acc[j] = __builtin_fmaf(x.z, wv.z, acc[j]); acc[j] = __builtin_fmaf(x.w, wv.w, acc[j]);
             }
         }
         const float bias = lds[b + n];
@@ -1005,6 +1006,15 @@ struct QaLds {
     int image_floats;
 };
 
+// the shapes marl_act_rows_kernel takes: one row per workgroup, every layer <= 64 wide, H = 64 (or 0), O <= 64; lds_staged forces
+// the other kernel (tests: the two must agree bit for bit)
+__host__ __device__ inline bool qa_rows_form(const xrl_marl_act_gru_t& p) {
+    if (p.lds_staged || p.rows_per_wg != 1 || p.O > 64 || !(p.H == 0 || p.H == 64) || p.n_pre > 3 || p.n_post > 3) return false;
+    for (int i = 0; i < p.n_pre; ++i) if (p.pre[i] > 64) return false;
+    for (int i = 0; i < p.n_post; ++i) if (p.post[i] > 64) return false;
+    return true;
+}
+
 __host__ __device__ inline void qa_layers(const xrl_marl_act_gru_t& p, int* K, int* Nn, int& n_layers) {
     // layer list in image order: pre[0..n_pre), ih, hh, post[0..n_post)
     int l = 0, feat = p.O;
@@ -1040,7 +1050,11 @@ __host__ __device__ inline QaLds qa_layout(const xrl_marl_act_gru_t& p) {
     L.img = off;
     int io = 0;
     for (int l = 0; l < XRL_QA_MAX_LAYERS; ++l) { L.w[l] = L.b[l] = L.ldw[l] = 0; }
-    for (int l = 0; l < nl; ++l) { L.ldw[l] = qf_pad4(K[l]) + 4; L.w[l] = io; io += Nn[l] * L.ldw[l]; }
+    if (qa_rows_form(p)) {        // marl_act_rows_kernel: k-quads interleaved over the outputs (ldw = outputs padded to a wave)
+        for (int l = 0; l < nl; ++l) { L.ldw[l] = (Nn[l] + 63) / 64 * 64; L.w[l] = io; io += ((K[l] + 3) / 4) * L.ldw[l] * 4; }
+    } else {
+        for (int l = 0; l < nl; ++l) { L.ldw[l] = qf_pad4(K[l]) + 4; L.w[l] = io; io += Nn[l] * L.ldw[l]; }
+    }
     for (int l = 0; l < nl; ++l) { L.b[l] = io; io += qf_pad4(Nn[l]); }
     L.image_floats = io;
     L.total = off + io;
@@ -1051,7 +1065,19 @@ struct QaArgs { xrl_marl_act_gru_t p; QaLds L; };
 typedef const __attribute__((address_space(4))) QaArgs QaArgsK;
 
 __device__ __forceinline__ float qa_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
-__device__ __forceinline__ float qa_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+__device__ __forceinline__ float qa_tanh(float x) { return __builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)), 1.f); }
+// the GRU cell of both acting kernels, every fused multiply-add spelled out (under `contract(fast)` the compiler is free to fuse or not,
+// and did it differently at different sites: the two kernels must round alike)
+__device__ __forceinline__ float qa_cell(float gi_r, float gi_z, float gi_n, float gh_r, float gh_z, float gh_n, float h) {
+    const float rg = qa_sigmoid(gi_r + gh_r);
+    const float z = qa_sigmoid(gi_z + gh_z);
+    const float n = qa_tanh(__builtin_fmaf(rg, gh_n, gi_n));
+    return __builtin_fmaf(h - n, z, n);
+}
+
+// tools/probe_act_gru.py: per-workgroup clock stamps of the acting launch's phases (xrl_debug_act_gru_stamps; NULL = off)
+__device__ long long* g_qa_dbg = nullptr;
+#define QSTAMP(k) do { if (qdbg && threadIdx.x == 0) qdbg[16 * blockIdx.x + (k)] = (k) == 0 || (k) == 15 ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 template <bool ANYACT>
 __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_value_unused) {
@@ -1060,6 +1086,8 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
     const __attribute__((address_space(4))) QaLds* L = &args->L;
     float* lds = qf_lds;
     const int tid = threadIdx.x, H = p->H, O = p->O;
+    long long* const qdbg = g_qa_dbg;
+    QSTAMP(0); QSTAMP(1);
     const int r0 = blockIdx.x * p->rows_per_wg, rows = min(p->rows_per_wg, p->R - r0);
     // ---- one burst: weight image, observations, previous hidden state, reset flags
     {
@@ -1093,6 +1121,7 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
         }
     }
     __syncthreads();
+    QSTAMP(2);
     for (int i = tid; i < rows * H; i += QF_THREADS) {                    // init_rnn_states_item (rnn.py:86-92): zero state
         const int r = i / H, k = i - r * H;
         if (lds[L->reset + r] != 0.f) lds[L->hin + r * L->ldh + k] = 0.f;
@@ -1105,25 +1134,25 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
         __syncthreads();
         in = out; ldi = L->lda; feat = p->pre[i];
     }
+    QSTAMP(3);
     if (H > 0) {
         // ---- gi = W_ih x + b_ih,  gh = W_hh h + b_hh  (side by side), then the cell (csrc/gru.hip's arithmetic)
         qf_lin_fwd<ANYACT>(L->img + L->w[l], L->ldw[l], L->img + L->b[l], feat, 3 * H, in, ldi, rows, L->gi, L->ldg, XRL_ACT_NONE, 0);
         qf_lin_fwd<ANYACT>(L->img + L->w[l + 1], L->ldw[l + 1], L->img + L->b[l + 1], H, 3 * H, L->hin, L->ldh, rows, L->gh, L->ldg, XRL_ACT_NONE, 512);
         l += 2;
         __syncthreads();
+        QSTAMP(4);
         for (int i = tid; i < rows * H; i += QF_THREADS) {
             const int r = i / H, j = i - r * H;
             const float* gi = lds + L->gi + r * L->ldg;
             const float* gh = lds + L->gh + r * L->ldg;
             const float h = lds[L->hin + r * L->ldh + j];
-            const float rg = qa_sigmoid(gi[j] + gh[j]);
-            const float z = qa_sigmoid(gi[H + j] + gh[H + j]);
-            const float n = qa_tanh(gi[2 * H + j] + rg * gh[2 * H + j]);
-            const float hn = (h - n) * z + n;
+            const float hn = qa_cell(gi[j], gi[H + j], gi[2 * H + j], gh[j], gh[H + j], gh[2 * H + j], h);
             lds[L->hnew + r * L->ldh + j] = hn;
             p->h[(size_t)(r0 + r) * H + j] = hn;                               // the state carried to the next step
         }
         __syncthreads();
+        QSTAMP(5);
         in = L->hnew; ldi = L->ldh; feat = H;
     }
     // ---- Q head
@@ -1134,6 +1163,7 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
         __syncthreads();
         in = out; ldi = ldo; feat = p->post[i];
     }
+    QSTAMP(6);
     const int A = p->post[p->n_post - 1];
     for (int i = tid; i < rows * A; i += QF_THREADS) {
         const int r = i / A, k = i - r * A;
@@ -1148,7 +1178,185 @@ __global__ void __launch_bounds__(QF_THREADS) marl_act_gru_kernel(QaArgs by_valu
         p->action[r] = a;
         if (p->action_f) p->action_f[r] = (float)a;
     }
+    QSTAMP(7); QSTAMP(15);
 }
+// ---- the same step with ONE THREAD PER OUTPUT and the weights in registers (round 6; tools/probe_act_gru.py, profiles/r06_k_act_gru.json).
+// marl_act_gru_kernel above stages the whole weight image (108 KB for 3m.yaml's agents) in LDS before anything starts and its products
+// read weights AND inputs from LDS: stamps of a 6-row workgroup -- image burst 6.3 k cycles, fc 3.0 k, gate products 10.9 k (LDS return
+// bandwidth: five 16-byte reads per 16 fma), cell 0.9 k, Q head 4.6 k (54 work items walking K = 64 one after the other behind a call
+// each), stores + selection 4.1 k (dependent loads of mask / epsilon / step).  Here a workgroup takes ONE row and 12 waves:
+//   waves 0..5   thread n < 3 H: row n of W_ih, thread 3 H + n: row n of W_hh        (H == 64; idle for feed-forward agents)
+//   waves 6..8   pre layer 0..2, lane = output
+//   waves 9..11  post layer 0..2, lane = output
+// every thread pulls its weight row (<= 64 floats) and bias from the image in global memory straight into registers while observations /
+// hidden state / mask go to LDS; the image is INTERLEAVED for that (xrl_qa_image_t.interleaved: the four weights k = 4 i .. 4 i + 3 of
+// output n at w[l] + (i * ldw[l] + n) * 4, ldw = outputs padded to 64: a wave's load is one contiguous KB -- with row-major rows every
+// 16-byte load of a wave touched 64 cache lines and the burst alone took 8-9 k cycles); the inputs of a product are broadcast LDS reads;
+// W_hh h does not wait for the layers below.  Every output is the same fma chain over k = 0, 1, ... as qf_lin_fwd_t's: results are
+// bit-identical to the kernel above (tests/test_gpu_offpolicy_agents.py).  One row per workgroup: with two the compiler keeps both rows'
+// 16 input quads live next to the 64 weight registers and spills (85 registers at two rows, 581 at four; 18.7 / 48 us per launch).
+constexpr int QR_THREADS = 768, QR_ROWS = 1, QR_LD = 68, QR_LDG = 196;
+constexpr int QR_X = 0, QR_H = QR_X + QR_ROWS * QR_LD, QR_A0 = QR_H + QR_ROWS * QR_LD, QR_A1 = QR_A0 + QR_ROWS * QR_LD,
+              QR_HN = QR_A1 + QR_ROWS * QR_LD, QR_Q = QR_HN + QR_ROWS * QR_LD, QR_GI = QR_Q + QR_ROWS * QR_LD,
+              QR_GH = QR_GI + QR_ROWS * QR_LDG, QR_AV = QR_GH + QR_ROWS * QR_LDG, QR_RNG = QR_AV + QR_ROWS * 64, QR_TOTAL = QR_RNG + 4;
+
+// one output for every row of the workgroup: acc_r = sum_k x_r[k] w[k] in qf_lin_fwd_t's order, + bias (x: LDS offset, rows of QR_LD).
+// All 16 k-quads of all RPW rows, no predicates: weights beyond K are zero, inputs beyond K / rows beyond the batch are zero-filled LDS
+// (adding x * 0 leaves the sum as it is), so the 16 reads of a row are in flight together -- with `if (i < K4)` / `if (j < rows)` around
+// them every read was a branch target of its own and its latency stood in the chain: 3.7 k cycles for the 30-wide fc product of one row
+template <int RPW>
+__device__ __forceinline__ void qr_product(const float* lds, int in, const qf_f4 (&w)[16], float bias, float (&v)[RPW]) {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        float4 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = *reinterpret_cast<const float4*>(lds + in + j * QR_LD + 4 * i);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                         // (spelled out: left to `contract(fast)` one of the five call sites became pk_mul + add)
+            acc = __builtin_fmaf(x[i].x, w[i].x, acc); acc = __builtin_fmaf(x[i].y, w[i].y, acc);
+            acc = __builtin_fmaf(x[i].z, w[i].z, acc); acc = __builtin_fmaf(x[i].w, w[i].w, acc);
+        }
+        v[j] = acc + bias;
+    }
+}
+
+template <bool ANYACT>
+__global__ void __launch_bounds__(QR_THREADS) marl_act_rows_kernel(QaArgs by_value_unused) {
+    const QaArgsK* args = (const QaArgsK*)__builtin_amdgcn_kernarg_segment_ptr();
+    const __attribute__((address_space(4))) xrl_marl_act_gru_t* p = &args->p;
+    const __attribute__((address_space(4))) QaLds* L = &args->L;
+    __shared__ __attribute__((aligned(16))) float lds[QR_TOTAL];
+    typedef const __attribute__((address_space(1))) qf_f4* G4;
+    typedef const __attribute__((address_space(1))) float* G1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, H = p->H, O = p->O;
+    constexpr int RPW = QR_ROWS;
+    const int r0 = blockIdx.x, rows = 1;
+    const int n_pre = p->n_pre, n_post = p->n_post, A = p->post[n_post - 1], act = p->act;
+    long long* const qdbg = g_qa_dbg;
+    QSTAMP(0); QSTAMP(1);
+    // ---- this thread's role: layer l of the image, output n, K inputs
+    int l = -1, n = 0, K = 0;
+    {
+        const int feat_pre = n_pre > 0 ? p->pre[n_pre - 1] : O;
+        if (wave < 6) {
+            if (H > 0 && tid < 6 * H) { l = n_pre + (tid >= 3 * H ? 1 : 0); n = tid >= 3 * H ? tid - 3 * H : tid; K = tid >= 3 * H ? H : feat_pre; }
+        } else if (wave < 9) {
+            const int i = wave - 6;
+            if (i < n_pre && lane < p->pre[i]) { l = i; n = lane; K = i == 0 ? O : p->pre[i - 1]; }
+        } else {
+            const int i = wave - 9;
+            if (i < n_post && lane < p->post[i]) { l = n_pre + (H > 0 ? 2 : 0) + i; n = lane; K = i == 0 ? (H > 0 ? H : feat_pre) : p->post[i - 1]; }
+        }
+    }
+    const int K4 = (K + 3) >> 2;
+    // ---- weights and bias -> registers (loads in flight while the inputs are staged)
+    qf_f4 w[16];
+    float bias = 0.f;
+    {
+        const int lw = l >= 0 ? l : 0;
+        const G4 wp = (G4)(p->image + L->w[lw]) + n;
+        const int np = L->ldw[lw];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { w[i] = 0.f; if (l >= 0 && i < K4) w[i] = wp[i * np]; }
+        if (l >= 0) bias = ((G1)p->image)[L->b[lw] + n];
+    }
+    // ---- inputs: observations (pad zero), hidden state (zero where the row starts an episode, rnn.py:86-92), action mask
+    {
+        float xv = 0.f, hv = 0.f, rv = 0.f;
+        const int r = tid / QR_LD, k = tid - r * QR_LD;                     // QR_ROWS * QR_LD = 272 <= QR_THREADS
+        const bool in_x = r < rows && k < O, in_h = H > 0 && r < rows && k < H;
+        if (in_x) xv = ((G1)p->obs)[(size_t)(r0 + r) * O + k];
+        if (in_h) { hv = ((G1)p->h)[(size_t)(r0 + r) * H + k]; if (p->reset) rv = ((G1)p->reset)[r0 + r]; }
+        float av = 1.f;                                                      // (no mask: every action available)
+        const int t2 = tid - 512;                                            // waves 8..11: the mask, QR_ROWS * 64 entries
+        const bool in_av = p->action && p->avail && t2 >= 0 && (t2 >> 6) < rows && (t2 & 63) < A;
+        if (in_av) av = ((G1)p->avail)[(size_t)(r0 + (t2 >> 6)) * A + (t2 & 63)];
+        if (tid < QR_ROWS * QR_LD) {
+            lds[QR_X + tid] = xv;
+            lds[QR_H + tid] = rv != 0.f ? 0.f : hv;
+            lds[QR_A0 + tid] = 0.f; lds[QR_A1 + tid] = 0.f; lds[QR_HN + tid] = 0.f;
+        }
+        if (t2 >= 0 && t2 < QR_ROWS * 64) lds[QR_AV + t2] = av;
+    }
+    float eps = 0.f;
+    if (p->action && tid < rows) eps = p->eps_dev ? *p->eps_dev : p->eps;
+    // the step's coin and the row's uniform (marl_select_row's Philox draws) in two idle lanes, under the weight loads' latency
+    if (p->action && tid >= QR_THREADS - 2) {
+        const uint32_t step = p->step + (p->step_dev ? *p->step_dev : 0u);
+        lds[QR_RNG + (tid & 1)] = (tid & 1) ? marl_step_coin(p->seed, step) : marl_row_uniform(p->seed, step, r0);
+    }
+    __syncthreads();
+    QSTAMP(2);
+    float v[RPW];
+    // ---- W_hh h (needs nothing of the layers below)
+    if (H > 0 && wave < 6 && l == n_pre + 1) {
+        qr_product<RPW>(lds, QR_H, w, bias, v);
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) if (j < rows) lds[QR_GH + j * QR_LDG + n] = v[j];
+    }
+    // ---- layers below the recurrence
+    int in = QR_X;
+    for (int i = 0; i < n_pre; ++i) {
+        const int out = (i & 1) ? QR_A1 : QR_A0;
+        if (wave == 6 + i && l == i) {
+            qr_product<RPW>(lds, in, w, bias, v);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+                if (j < rows) lds[out + j * QR_LD + n] = ANYACT ? qf_act(v[j], act) : ((act == XRL_ACT_RELU && !(v[j] > 0.f)) ? 0.f : v[j]);
+        }
+        __syncthreads();
+        in = out;
+    }
+    QSTAMP(3);
+    if (H > 0) {
+        if (wave < 6 && l == n_pre) {
+            qr_product<RPW>(lds, in, w, bias, v);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) if (j < rows) lds[QR_GI + j * QR_LDG + n] = v[j];
+        }
+        __syncthreads();
+        QSTAMP(4);
+        if (tid < rows * H) {                                               // the cell (marl_act_gru_kernel's statements); rows * H <= 256
+            const int r = tid / H, j = tid - r * H;
+            const float* gi = lds + QR_GI + r * QR_LDG;
+            const float* gh = lds + QR_GH + r * QR_LDG;
+            const float h = lds[QR_H + r * QR_LD + j];
+            const float hn = qa_cell(gi[j], gi[H + j], gi[2 * H + j], gh[j], gh[H + j], gh[2 * H + j], h);
+            lds[QR_HN + r * QR_LD + j] = hn;
+            p->h[(size_t)(r0 + r) * H + j] = hn;
+        }
+        __syncthreads();
+        QSTAMP(5);
+        in = QR_HN;
+    }
+    // ---- Q head
+    for (int i = 0; i < n_post; ++i) {
+        const bool last = i == n_post - 1;
+        const int out = last ? QR_Q : (((n_pre + i) & 1) ? QR_A1 : QR_A0);
+        if (wave == 9 + i && l >= 0) {
+            qr_product<RPW>(lds, in, w, bias, v);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+                if (j < rows) {
+                    const float y = last ? v[j] : (ANYACT ? qf_act(v[j], act) : ((act == XRL_ACT_RELU && !(v[j] > 0.f)) ? 0.f : v[j]));
+                    lds[out + j * QR_LD + n] = y;
+                    if (last) p->q[(size_t)(r0 + j) * p->ldq + n] = y;
+                }
+        }
+        __syncthreads();
+        in = out;
+    }
+    QSTAMP(6);
+    if (p->action && tid < rows) {
+        const int r = r0 + tid;
+        const int a = marl_pick_row(lds + QR_Q + tid * QR_LD, lds + QR_AV + tid * 64, A, lds[QR_RNG + 1], lds[QR_RNG], eps);
+        p->action[r] = a;
+        if (p->action_f) p->action_f[r] = (float)a;
+    }
+    QSTAMP(7); QSTAMP(15);
+}
+#undef QSTAMP
 
 }  // namespace xrl
 
@@ -1255,12 +1463,18 @@ extern "C" int xrl_qmix_fused_phase(const xrl_qmix_fused_t* pp, const xrl_qmix_p
     return XRL_OK;
 }
 
+extern "C" int xrl_debug_act_gru_stamps(long long* stamps) {
+    XRL_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_qa_dbg), &stamps, sizeof(stamps)));
+    return XRL_OK;
+}
+
 extern "C" int xrl_marl_act_gru_layout(const xrl_marl_act_gru_t* p, xrl_qa_image_t* out) {
     XRL_CHECK_ARG(p && out && p->n_pre >= 0 && p->n_post >= 1 && p->n_pre + p->n_post + 2 <= XRL_QA_MAX_LAYERS && p->rows_per_wg >= 1);
     const QaLds L = qa_layout(*p);
     for (int l = 0; l < XRL_QA_MAX_LAYERS; ++l) { out->w[l] = L.w[l]; out->b[l] = L.b[l]; out->ldw[l] = L.ldw[l]; }
     out->image_floats = L.image_floats;
-    out->lds_bytes = L.total * 4;
+    out->interleaved = qa_rows_form(*p) ? 1 : 0;
+    out->lds_bytes = out->interleaved ? QR_TOTAL * 4 : L.total * 4;
     return XRL_OK;
 }
 
@@ -1274,15 +1488,22 @@ extern "C" int xrl_marl_act_gru(const xrl_marl_act_gru_t* pp, xrl_stream_t strea
     QaArgs args{};
     args.p = p;
     args.L = qa_layout(p);
+    XRL_CHECK_ARG((args.L.image_floats & 3) == 0);
+    const int n_wg = (p.R + p.rows_per_wg - 1) / p.rows_per_wg;
+    if (qa_rows_form(p)) {                                                 // one thread per output, weights in registers
+        if (p.act != XRL_ACT_NONE && p.act != XRL_ACT_RELU) hipLaunchKernelGGL(marl_act_rows_kernel<true>, dim3(p.R), dim3(QR_THREADS), 0, as_stream(stream), args);
+        else hipLaunchKernelGGL(marl_act_rows_kernel<false>, dim3(p.R), dim3(QR_THREADS), 0, as_stream(stream), args);
+        XRL_CHECK_LAUNCH();
+        return XRL_OK;
+    }
     const size_t bytes = (size_t)args.L.total * 4;
-    XRL_CHECK_ARG(bytes <= 160 * 1024 && (args.L.image_floats & 3) == 0);
+    XRL_CHECK_ARG(bytes <= 160 * 1024);
     static size_t allowed = 0;
     if (bytes > allowed) {
         XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(marl_act_gru_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(marl_act_gru_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         allowed = bytes;
     }
-    const int n_wg = (p.R + p.rows_per_wg - 1) / p.rows_per_wg;
     if (p.act != XRL_ACT_NONE && p.act != XRL_ACT_RELU) hipLaunchKernelGGL(marl_act_gru_kernel<true>, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
     else hipLaunchKernelGGL(marl_act_gru_kernel<false>, dim3(n_wg), dim3(QF_THREADS), bytes, as_stream(stream), args);
     XRL_CHECK_LAUNCH();

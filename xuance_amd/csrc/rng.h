@@ -56,8 +56,9 @@ constexpr uint32_t STREAM_ACTION = 0x41435431u, STREAM_GAUSS = 0x47415500u, STRE
 
 // One row of xrl_marl_select_actions (off_policy_marl.py:212-255): masked greedy action of q_row unless the step's coin lands
 // under epsilon, then the k-th AVAILABLE action, k uniform.  Shared by marl_select_kernel and the one-launch acting step.
-__device__ __forceinline__ int marl_select_row(const float* q_row, const float* av, int A, uint64_t seed, uint32_t step, int r,
-                                               float eps, const float* coin_in, const float* uniforms) {
+// (the choice itself, given the step's coin and the row's uniform: the one-thread-per-output acting kernel draws them in idle lanes
+//  while its weights are in flight)
+__device__ __forceinline__ int marl_pick_row(const float* q_row, const float* av, int A, float coin, float u, float eps) {
     int best = 0, n_avail = 0;
     float bv = (av && av[0] == 0.f) ? -1e10f : q_row[0];
     for (int j = 0; j < A; ++j) {
@@ -66,14 +67,8 @@ __device__ __forceinline__ int marl_select_row(const float* q_row, const float* 
         const float v = ok ? q_row[j] : -1e10f;
         if (j > 0 && v > bv) { bv = v; best = j; }
     }
-    uint32_t c[4];
-    philox4x32(seed, 0xFFFFFFFFu, step, STREAM_EGREEDY, c);               // the step coin: same counter for every row
-    const float coin = coin_in ? *coin_in : u01(c[0]);
     int a = best;
     if (coin < eps) {
-        uint32_t rr[4];
-        philox4x32(seed, (uint32_t)r, step, STREAM_EGREEDY + 1u, rr);
-        const float u = uniforms ? uniforms[r] : u01(rr[0]);
         const int na = n_avail > 1 ? n_avail : 1;
         int kth = (int)(u * (float)na), seen = 0;
         if (kth > na - 1) kth = na - 1;
@@ -84,6 +79,23 @@ __device__ __forceinline__ int marl_select_row(const float* q_row, const float* 
         }
     }
     return a;
+}
+__device__ __forceinline__ float marl_step_coin(uint64_t seed, uint32_t step) {      // the step coin: same counter for every row
+    uint32_t c[4];
+    philox4x32(seed, 0xFFFFFFFFu, step, STREAM_EGREEDY, c);
+    return u01(c[0]);
+}
+__device__ __forceinline__ float marl_row_uniform(uint64_t seed, uint32_t step, int r) {
+    uint32_t rr[4];
+    philox4x32(seed, (uint32_t)r, step, STREAM_EGREEDY + 1u, rr);
+    return u01(rr[0]);
+}
+__device__ __forceinline__ int marl_select_row(const float* q_row, const float* av, int A, uint64_t seed, uint32_t step, int r,
+                                               float eps, const float* coin_in, const float* uniforms) {
+    const float coin = coin_in ? *coin_in : marl_step_coin(seed, step);
+    float u = 0.f;
+    if (coin < eps) u = uniforms ? uniforms[r] : marl_row_uniform(seed, step, r);
+    return marl_pick_row(q_row, av, A, coin, u, eps);
 }
 
 // Draw of xrl_sample_replay_indices for batch row b (same Philox stream: the fused draw + gather picks the same rows).

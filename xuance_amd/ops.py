@@ -895,7 +895,7 @@ class MarlActGruState:
     parameters through xrl_reduce_adam's mirror maps (`map`: parameter index -> image index); `refresh()` rebuilds it (two
     launches) after anything else changed them."""
 
-    def __init__(self, model, rows_per_wg=6):
+    def __init__(self, model, rows_per_wg=1, lds_staged=False):
         from ._lib import MarlActGru, QaImage
         import numpy as np
         P = model.params
@@ -923,6 +923,7 @@ class MarlActGruState:
         for i, L in enumerate(post):
             q.post[i] = L.N
         q.rows_per_wg = int(rows_per_wg)
+        q.lds_staged = 1 if lds_staged else 0
         im = QaImage()
         call("xrl_marl_act_gru_layout", C.byref(q), C.byref(im))
         self.lds_bytes = int(im.lds_bytes)
@@ -930,7 +931,8 @@ class MarlActGruState:
         src, dst = [], []
         for l, (wn, bn, N, K) in enumerate(mats):
             r, k = np.divmod(np.arange(N * K), K)
-            src.append(P.offsets[wn] + np.arange(N * K)); dst.append(im.w[l] + r * im.ldw[l] + k)
+            src.append(P.offsets[wn] + np.arange(N * K))
+            dst.append(im.w[l] + ((k // 4) * im.ldw[l] + r) * 4 + k % 4 if im.interleaved else im.w[l] + r * im.ldw[l] + k)
             src.append(P.offsets[bn] + np.arange(N)); dst.append(im.b[l] + np.arange(N))
         dev = P.flat.device
         src_all, dst_all = np.concatenate(src), np.concatenate(dst)
