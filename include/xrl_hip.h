@@ -1358,6 +1358,14 @@ typedef struct {
 /* Device address of page-locked host memory (hipHostMalloc / torch pin_memory), for kernels that publish a word to the host. */
 int xrl_host_device_pointer(void* pinned_host, void** device_out);
 int xrl_marl_loop_gate(const xrl_marl_gate_t* gate, xrl_stream_t stream);
+/* xrl_episode_store_finish followed by xrl_marl_loop_gate as ONE launch (the captured vector step of run_episodes: store_experience +
+ * finish_path of memory_tools_marl.py:904-968, then the loop control of off_policy_marl.py:464-546): every block of the finish takes a
+ * ticket when it is done, the block that draws the last one runs the gate's statements -- after every read of `gate` (= loop_gate's
+ * active_f) and of the ring's ptr that the gate rewrites.  ticket: [1] u32 of the caller, zero before the first launch (re-armed by
+ * the launch).  Same results as the two launches. */
+int xrl_episode_store_finish_gate(const xrl_episode_field_t* fields, int n_fields, const int32_t* steps, const float* gate,
+                                  const float* done, const int32_t* end_step, const int32_t* ptr_size, int n_envs,
+                                  int buffer_size, const xrl_marl_gate_t* loop_gate, uint32_t* ticket, xrl_stream_t stream);
 /* out [n_envs][state_dim] = the global state OffPolicyMARLAgents.train / run_episodes STORE for the coming vector step
  * (core/off_policy_marl.py:384-399, 496-511 with store_experience :151-153 and memory_tools_marl.py:731-740): a copy of `state`
  * unless some env finished its episode in the previous step (done_prev [n_envs] != 0; NULL = none) -- then EVERY row is the

@@ -747,21 +747,22 @@ def test_runner_surface_of_the_dqn_and_qmix_agents(tmp_path):
     assert "Test-Results/Episode-Rewards" in m2.logged[-1][1]
 
 
-@pytest.mark.parametrize("lag,unroll", [(0, 2), (1, 4), (3, 2), (1, 8)])
-def test_captured_vector_step_equals_the_eager_episode_loop(lag, unroll):
+@pytest.mark.parametrize("lag,unroll,merged", [(0, 2, False), (1, 4, False), (3, 2, False), (1, 8, False), (1, 4, True)])
+def test_captured_vector_step_equals_the_eager_episode_loop(lag, unroll, merged):
     """run_episodes of the recurrent QMIX agents with the vector step captured as one hipGraph per observation-buffer set
     (use_hip_graph; `unroll` steps per graph launch) vs the eager launch sequence: the same Philox step indices (device counters that start at the host's
     values), hence the same actions, episodes, ring contents, exploration schedule and step accounting -- also when the
     host enqueues `lag` graph launches ahead of its knowledge of the loop condition (the dry steps after the call's last
     episode change nothing a later call or an update can see; the GRU state and the episode staging they touch are
-    re-zeroed by the next call and not compared)."""
+    re-zeroed by the next call and not compared).  merged (round 6, config.gate_in_finish; measured slower, off by default): the loop's gate rides in the store + finish launch
+    (xrl_episode_store_finish_gate: the last block of the finish carries it) instead of a launch of its own."""
     from xuance_amd.agents import QMIX_Agents
     from xuance_amd.envs import SyntheticSMACVecEnv
     res = []
     for graph in (False, True):
         torch.manual_seed(0)
         agent = QMIX_Agents(_rnn_cfg(use_hip_graph=graph, start_training=10 ** 9, start_greedy=0.6, end_greedy=0.05,
-                                     decay_step_greedy=400, episode_loop_lag=lag, episode_loop_unroll=unroll),
+                                     decay_step_greedy=400, episode_loop_lag=lag, episode_loop_unroll=unroll, gate_in_finish=merged),
                             SyntheticSMACVecEnv(8, seed=3, max_episode_steps=12, p_term=0.05))
         for _ in range(3):
             agent.run_episodes(8)

@@ -394,6 +394,8 @@ _SIGS = {
     "xrl_episode_store_step": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_episode_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "xrl_episode_store_finish": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "xrl_episode_store_finish_gate": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      C.POINTER(MarlGate), c_void_p, c_void_p],
     "xrl_episode_finish_gated": [C.POINTER(EpisodeField), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "xrl_episode_gather": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_void_p],
     "xrl_episode_gather_sampled": [C.POINTER(EpisodeField), c_int, c_void_p, c_int, c_int, c_void_p, C.c_uint64, C.c_uint32, c_void_p,

@@ -313,16 +313,23 @@ class QMIX_Agents(AgentSurface):
                                                     action=env.action, action_f=self.act_f, seed=self.seed, step=0,
                                                     step_dev=self._rng_dev[0:1]))
                     env.enqueue_step(cur, counter=self._rng_dev[1:2])
+                    # reset flags of the finished envs' rows, RNG counters (+active), ring pointers and the loop's bookkeeping
+                    gate_kw = dict(totals=env.episode_totals, start_greedy=float(self.start_greedy),
+                                   end_greedy=float(self.end_greedy), delta_greedy=float(self.delta_egreedy),
+                                   eps_dev=self.eps_dev, done=env.done, reset_rows=self.reset_rows, counters=self._rng_dev,
+                                   n_envs=n, n_agents=N, ptr_size=mem.ptr_size, buffer_size=mem.buffer_size,
+                                   reset_rule=int(self.reference_rnn_reset), end_step=env.end_step, **fold, **gate_const, **gt)
+                    # (round 6, config.gate_in_finish: True -- the gate rides in the store + finish launch, whose last block carries it
+                    #  (xrl_episode_store_finish_gate).  Same results, measured SLOWER: 576 blocks drawing a ticket from one word cost
+                    #  more than the launch they save, loop 1.10 M vs 1.22 M env-steps/s; off by default)
+                    merged = bool(getattr(self.config, "gate_in_finish", False))
                     mem.store_and_finish(dict(obs=obs, actions=self.act_f, rewards=env.rewards, terminals=env.terminals,
                                               agent_mask=env.agent_mask, avail_actions=avail, state=state),
                                          env.prev_steps, env.done, env.end_step, obs=env.next_obs, state=env.next_state,
-                                         avail_actions=env.next_avail, gate=gt["active_f"])  # a dry step closes no episode
-                    # reset flags of the finished envs' rows, RNG counters (+active), ring pointers and the loop's bookkeeping
-                    ops.marl_loop_gate(totals=env.episode_totals, start_greedy=float(self.start_greedy),
-                                       end_greedy=float(self.end_greedy), delta_greedy=float(self.delta_egreedy),
-                                       eps_dev=self.eps_dev, done=env.done, reset_rows=self.reset_rows, counters=self._rng_dev,
-                                       n_envs=n, n_agents=N, ptr_size=mem.ptr_size, buffer_size=mem.buffer_size,
-                                       reset_rule=int(self.reference_rnn_reset), end_step=env.end_step, **fold, **gate_const, **gt)
+                                         avail_actions=env.next_avail, gate=gt["active_f"],   # a dry step closes no episode
+                                         loop_gate=gate_kw if merged else None)
+                    if not merged:
+                        ops.marl_loop_gate(**gate_kw)
             return g
         self._steps_g = [capture() for _ in range(lag + 2)]
         return self._steps_g

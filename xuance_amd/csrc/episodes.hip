@@ -35,10 +35,9 @@ __global__ void __launch_bounds__(64) episode_store_kernel(EpPack f, const int32
 // finish_path + store_episodes (:923-968) for every finished env, in env order.  grid (n_envs, n_fields), 256 threads
 // steps != NULL: the step's store (episode_store_kernel's statements, field d -> staging) happens first, in the same block that
 // then closes the episode -- one launch per vector step for both (xrl_episode_store_finish).
-__global__ void __launch_bounds__(256) episode_finish_kernel(EpPack f, const float* __restrict__ gate, const float* __restrict__ done,
-                                                             const int32_t* __restrict__ end_step,
-                                                             const int32_t* __restrict__ ptr_size, int n_envs,
-                                                             int buffer_size, const int32_t* __restrict__ steps) {
+__device__ __forceinline__ void episode_finish_body(const EpPack& f, const float* __restrict__ gate, const float* __restrict__ done,
+                                                    const int32_t* __restrict__ end_step, const int32_t* __restrict__ ptr_size,
+                                                    int buffer_size, const int32_t* __restrict__ steps) {
     const int env = blockIdx.x, fi = blockIdx.y;
     if (steps && f.d[fi]) {
         const int rw0 = f.row_bytes[fi] >> 2, st = steps[env];
@@ -68,6 +67,13 @@ __global__ void __launch_bounds__(256) episode_finish_kernel(EpPack f, const flo
         ring[i] = v;
         if (f.flags[fi] & 1) stage[i] = 0u;                              // `filled` of this env is cleared (:921)
     }
+}
+
+__global__ void __launch_bounds__(256) episode_finish_kernel(EpPack f, const float* __restrict__ gate, const float* __restrict__ done,
+                                                             const int32_t* __restrict__ end_step,
+                                                             const int32_t* __restrict__ ptr_size, int n_envs,
+                                                             int buffer_size, const int32_t* __restrict__ steps) {
+    episode_finish_body(f, gate, done, end_step, ptr_size, buffer_size, steps);
 }
 
 __global__ void episode_advance_kernel(const float* __restrict__ gate, const float* __restrict__ done, int32_t* __restrict__ ptr_size, int n_envs,
@@ -125,19 +131,22 @@ __global__ void __launch_bounds__(256) episode_gather_sampled_kernel(EpPack f, i
 // call is over is dry: the captured step multiplies `done` by active_f (no episode is closed into the ring) and adds
 // active_i to its RNG step counters (they do not advance); its other writes land in per-call state the next call resets.
 constexpr int GATE_MAX_ENVS = 1024;
-__global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
+// (block / n_blocks: the 256-thread blocks that share the work -- the launch's own grid, or 0 / 1 when the LAST block of
+//  episode_finish_gate_kernel carries the gate)
+__device__ __forceinline__ void marl_loop_gate_body(const xrl_marl_gate_t& g, int block, int n_blocks) {
     // the step's remaining per-row bookkeeping rides along: reset flags of the rows whose env finished (a dry step's are
     // wiped by the next call), RNG step counters advanced by `active`
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g.reset_rows && t < g.n_envs * g.n_agents)
-        g.reset_rows[t] = g.reset_rule ? (t < g.n_envs ? g.done[t] : 0.f) : g.done[t / g.n_agents];
+    const int t = block * 256 + (int)threadIdx.x;
+    if (g.reset_rows)
+        for (int q = t; q < g.n_envs * g.n_agents; q += n_blocks * 256)
+            g.reset_rows[q] = g.reset_rule ? (q < g.n_envs ? g.done[q] : 0.f) : g.done[q / g.n_agents];
     if (g.stored_state && threadIdx.x >= 64) {                            // xrl_marl_stored_state for the next step, riding along
         // Waves 1..3 of every block do this; wave 0 -- block 0's carries the loop bookkeeping, this launch's chain -- goes straight on.
         // Every thread requests ITS elements of the next state before anybody knows whether an env finished: in the common step (no
         // episode end) the copy costs no dependent round trip; only a step that did end an episode reads the finished env's row
         // behind the scan.  No workgroup barrier: each wave finds the last finished env for itself.
         constexpr int PRE = 16;
-        const int tot = g.n_envs * g.state_dim, nthr = gridDim.x * 192, tt = blockIdx.x * 192 + ((int)threadIdx.x - 64);
+        const int tot = g.n_envs * g.state_dim, nthr = n_blocks * 192, tt = block * 192 + ((int)threadIdx.x - 64);
         const bool pre = tot <= nthr * PRE;
         float own[PRE];
         if (pre) {
@@ -216,6 +225,34 @@ __global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) {
     }
 }
 
+__global__ void marl_loop_gate_kernel(xrl_marl_gate_t g) { marl_loop_gate_body(g, blockIdx.x, gridDim.x); }
+
+// xrl_episode_store_finish and xrl_marl_loop_gate as ONE launch (round 6): the captured vector step of the recurrent agents was
+// act / provider / store + finish / gate, four launches of 5-6 us for ~23 us of work; the gate only has to run after every block of the
+// finish has read what it rewrites (active_f, the ring's ptr).  Each block takes a ticket when it is done; the block that draws the last
+// one carries the gate's statements (one 256-thread block does what the gate's own launch did with one block at these sizes) and
+// re-arms the ticket.  No block waits for another.
+__global__ void __launch_bounds__(256) episode_finish_gate_kernel(EpPack f, const float* __restrict__ gate, const float* __restrict__ done,
+                                                                  const int32_t* __restrict__ end_step, const int32_t* __restrict__ ptr_size,
+                                                                  int buffer_size, const int32_t* __restrict__ steps, xrl_marl_gate_t g,
+                                                                  unsigned int* __restrict__ ticket) {
+    episode_finish_body(f, gate, done, end_step, ptr_size, buffer_size, steps);
+    __shared__ int s_last;
+    __syncthreads();
+    // (no fences: the gate reads nothing a finish block writes; what it WRITES -- active_f, the ring's ptr -- the other blocks have READ,
+    //  and a load whose value has come back (the __syncthreads above waits for this block's) cannot see a later store.  An agent-scope
+    //  release per block -- 576 L2 write-backs per launch -- made the launch 30 us)
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned k = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = k == total - 1u;
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    marl_loop_gate_body(g, 0, 1);
+}
+
 static int pack(const xrl_episode_field_t* fields, int n, EpPack& p) {
     if (!fields || n <= 0 || n > EP_MAX_FIELDS) return XRL_EINVAL;
     p.n = n;
@@ -265,6 +302,24 @@ extern "C" int xrl_episode_store_finish(const xrl_episode_field_t* fields, int n
     XRL_CHECK_ARG(steps && done && end_step && ptr_size && n_envs > 0 && buffer_size > 0);
     hipLaunchKernelGGL(episode_finish_kernel, dim3(n_envs, n_fields), dim3(256), 0, as_stream(stream), p, gate, done, end_step,
                        ptr_size, n_envs, buffer_size, steps);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_episode_store_finish_gate(const xrl_episode_field_t* fields, int n_fields, const int32_t* steps, const float* gate,
+                                             const float* done, const int32_t* end_step, const int32_t* ptr_size, int n_envs,
+                                             int buffer_size, const xrl_marl_gate_t* loop_gate, uint32_t* ticket, xrl_stream_t stream) {
+    EpPack p;
+    XRL_CHECK_ARG(pack(fields, n_fields, p) == XRL_OK);
+    XRL_CHECK_ARG(steps && done && end_step && ptr_size && n_envs > 0 && buffer_size > 0 && loop_gate && ticket);
+    const xrl_marl_gate_t& g = *loop_gate;
+    XRL_CHECK_ARG(g.totals && g.base && g.snap && g.active && g.call && g.e_state && g.eps_dev && g.active_f);
+    XRL_CHECK_ARG(g.host_flags == nullptr || (g.seq != nullptr && g.ring > 0));
+    XRL_CHECK_ARG(g.reset_rows == nullptr || (g.done && g.n_envs > 0 && g.n_agents > 0));
+    XRL_CHECK_ARG(g.ptr_size == nullptr || (g.done && g.n_envs > 0 && g.buffer_size > 0));
+    XRL_CHECK_ARG(g.stored_state == nullptr || (g.next_state && g.done && g.n_envs > 0 && g.state_dim > 0 && g.next_state != g.stored_state));
+    hipLaunchKernelGGL(episode_finish_gate_kernel, dim3(n_envs, n_fields), dim3(256), 0, as_stream(stream), p, gate, done, end_step,
+                       ptr_size, buffer_size, steps, g, ticket);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -225,10 +225,12 @@ class HipMARLOffPolicyBufferRNN:
         ops.episode_finish(fields, done.to(torch.float32).contiguous(), self._dev_steps(end_step), self.ptr_size,
                            self.n_envs, self.buffer_size, gate=gate, advance=advance)   # gate: device scalar, 0 = close nothing
 
-    def store_and_finish(self, step_data, episode_steps, done, end_step, obs=None, state=None, avail_actions=None, gate=None):
+    def store_and_finish(self, step_data, episode_steps, done, end_step, obs=None, state=None, avail_actions=None, gate=None,
+                         loop_gate=None):
         """store(**step_data, episode_steps=...) followed by finish_paths(done, end_step, ..., gate=gate, advance=False) as ONE
         launch (device tensors only: the captured vector step of the agents); the ring's {ptr, size} are left to the caller
-        (xrl_marl_loop_gate advances them)."""
+        (xrl_marl_loop_gate advances them).  loop_gate: the keyword arguments of ops.marl_loop_gate -- the gate then rides in the
+        same launch (xrl_episode_store_finish_gate: the last block to finish carries it)."""
         steps = self._dev_steps(episode_steps)
         items = {k: self._stack(v, self.layout[k][0]) for k, v in step_data.items() if k in self.layout and k != "filled"}
         items["filled"] = self._ones
@@ -238,6 +240,12 @@ class HipMARLOffPolicyBufferRNN:
         self._term_keep = (term, items)                         # keep the temporaries alive until the launch ran
         fields = [(self.data[k], self.episode_data[k], term.get(k), 4 * w, sl, 1 if k == "filled" else 0, items.get(k))
                   for k, (w, sl) in self.layout.items()]
+        if loop_gate is not None:
+            if getattr(self, "_ticket", None) is None:
+                self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
+            ops.episode_store_finish_gate(fields, steps, done.to(torch.float32).contiguous(), self._dev_steps(end_step), self.ptr_size,
+                                          self.n_envs, self.buffer_size, gate, loop_gate, self._ticket)
+            return
         ops.episode_store_finish(fields, steps, done.to(torch.float32).contiguous(), self._dev_steps(end_step), self.ptr_size,
                                  self.n_envs, self.buffer_size, gate=gate)
 

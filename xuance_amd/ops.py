@@ -801,6 +801,14 @@ def episode_store_finish(items, steps, done, end_step, ptr_size, n_envs, buffer_
          ptr(_chk(ptr_size, torch.int32)), int(n_envs), int(buffer_size), stream_ptr())
 
 
+def episode_store_finish_gate(items, steps, done, end_step, ptr_size, n_envs, buffer_size, gate, loop_gate, ticket):
+    """episode_store_finish + marl_loop_gate(**loop_gate) as one launch (xrl_episode_store_finish_gate); ticket: [1] int32 zeros."""
+    call("xrl_episode_store_finish_gate", _ep_fields(items), len(items), ptr(_chk(steps, torch.int32)),
+         ptr(gate) if gate is not None else None, ptr(_chk(done)), ptr(_chk(end_step, torch.int32)),
+         ptr(_chk(ptr_size, torch.int32)), int(n_envs), int(buffer_size), C.byref(_struct(MarlGate, loop_gate)), ptr(_chk(ticket, torch.int32)),
+         stream_ptr())
+
+
 def episode_finish(items, done, end_step, ptr_size, n_envs, buffer_size, gate=None, advance=True):
     """gate: None, or a device float scalar -- 0 turns the call into a no-op (xrl_episode_finish_gated).  advance=False:
     the ring's {ptr, size} are left for the caller to advance (xrl_marl_loop_gate does it in its own launch)."""
