@@ -434,6 +434,35 @@ typedef struct {
 } xrl_classic_t;
 int xrl_classic_step(const xrl_classic_t* p, int reset, xrl_stream_t stream);
 
+/* The tail of an on-policy acting step on a device env as ONE launch (round 6; csrc/act_tail.hip): the heads' product
+ * (actor_head.py / critic_head.py: A outputs on the actor branch's features, one value on the critic's), OnPolicyAgent.get_actions'
+ * sampling (on_policy.py:128-169 = xrl_policy_sample) and the env's step (xrl_classic_step / xrl_cartpole_step) -- what a vector step
+ * of PPO_Agent's general path does in three launches after the hidden layers.  Rows [0, n) of hb are this step's observations, rows
+ * [n, 2n) the previous step's next observations (their value -> sample.bootv_prev).  Bit-identical to xrl_linear_fwd (heads) +
+ * xrl_policy_sample + the env step.  K <= 128 and a multiple of 32, A <= 8, both feature blocks inside the first 256 columns. */
+typedef struct {
+    const float* hb;            /* [2n | n][ldh] the level the heads read */
+    const float* w_actor;       /* [A][ldw_a], k contiguous */
+    const float* b_actor;       /* [A] or NULL */
+    const float* w_critic;      /* [1][ldw_c] */
+    const float* b_critic;      /* [1] or NULL */
+    float* heads;               /* NULL or [2n][A + 1] out: what the heads' xrl_linear_fwd writes (rows [n, 2n): the value column only,
+                                 * unless boot_actor) */
+    int32_t ldh, K, a_off, c_off;      /* actor features: columns [a_off, a_off + K) of a row of hb; critic: [c_off, c_off + K) */
+    int32_t ldw_a, ldw_c;
+    int32_t boot_rows;          /* 1: rows [n, 2n) exist (sample.bootv_prev may be set) */
+    int32_t boot_actor;         /* 1: also the actor outputs of rows [n, 2n) (nobody reads them) */
+    int32_t env_kind;           /* 0: no env step; 1..3: xrl_classic_t.kind (classic); 4: CartPole (cartpole) */
+    int32_t act_actor;          /* XRL_ACT_* applied to the actor's outputs (activation_action of a Gaussian head), XRL_ACT_NONE else */
+    xrl_sample_t sample;        /* .heads is ignored; n, A, ld = A + 1; act_out NULL: bootstrap values only (no env step) */
+    xrl_classic_t classic;
+    xrl_cartpole_t cartpole;
+} xrl_act_tail_t;
+int xrl_act_tail(const xrl_act_tail_t* p, xrl_stream_t stream);
+/* Measurement aid (tools/probe_act_tail.py): stamps != NULL -> workgroup 0 of the following xrl_act_tail launches writes its s_memtime at
+ * start / features staged / heads done / sampled / end to stamps[0..4]; NULL switches it off.  Not for production use. */
+int xrl_debug_act_tail_stamps(long long* stamps);
+
 /* Synthetic MuJoCo-shaped vector env on the device (an input provider for the continuous-control shapes of BASELINE
  * config C4 -- no simulator is installed; NOT a reference component): state' = tanh(state.A + clip(a).B) + 0.01 N(0,1),
  * reward = state'[0] - 0.1 |a|^2, truncation after max_steps, same auto-reset contract as xrl_cartpole_step. */
@@ -518,6 +547,9 @@ typedef struct {
     float* pg_bootv;
 } xrl_poststep_t;
 int xrl_rollout_poststep(const xrl_poststep_t* p, xrl_stream_t stream);
+/* xrl_rollout_poststep(post) followed by xrl_obs_normalize(rms) as ONE launch (round 6): the previous vector step's bookkeeping and
+ * this step's RunningMeanStd.update + normalisation, both single workgroups; same results as the two launches. */
+int xrl_post_norm(const xrl_poststep_t* post, const xrl_rms_t* rms, xrl_stream_t stream);
 
 /* The tail of an on-policy ACTING pass of an actor-critic network whose heads sit directly on one wide hidden layer (AC_CNN_Atari of
  * configs/ppo/atari.yaml: Linear(6 400, 512) + ReLU, CategoricalActorHead / ValueHead on the 512 features; cnn.py:53-102,

@@ -39,7 +39,9 @@ def test_rollout_and_update_vs_oracle(oracle, use_gae):
     torch.manual_seed(0)
     env = DeviceCartPoleVecEnv(n, seed=3)
     env.max_episode_steps = 25                     # force truncations inside the rollout
-    agent = PPO_Agent(make_config(n, T, use_gae=use_gae), env)
+    # (use_post_norm False: this test looks at the buffer after EVERY vector step; with the default a step's bookkeeping rides in the
+    #  next step's first launch -- test_device_act_tail_in_one_launch_equals_the_launches shows that form equal to this one)
+    agent = PPO_Agent(make_config(n, T, use_gae=use_gae, use_post_norm=False), env)
     sd0 = {k: npy(v) for k, v in agent.model.state_dict().items()}
     env.reset()
     agent._started = True
@@ -1118,6 +1120,48 @@ def test_ppo_atari_acting_tail_in_one_launch_equals_the_launches(graph):
         assert (a["seg"] & 1).any() and a["terminals"].any() and int(a["observations"].max()) > 0
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("name,n,T", [("DeviceAcrobotVecEnv", 70, 12), ("DeviceMountainCarVecEnv", 16, 10), ("DevicePendulumVecEnv", 130, 8),
+                                      ("DeviceCartPoleVecEnv", 64, 10)])
+def test_device_act_tail_in_one_launch_equals_the_launches(name, n, T, graph):
+    """xrl_act_tail + xrl_post_norm (round 6): the general path's vector step on a device env -- normalise + store, three grouped products,
+    xrl_policy_sample, the env's step, xrl_rollout_poststep: seven launches -- as four: [the previous step's bookkeeping + statistics /
+    normalisation / store], the two hidden stages, [heads + sampling + env step] (config.use_device_act_tail; off by default: no faster) --
+    and as six (config.use_post_norm, the default: only the first merge) -- against the seven (both switches off).
+    Three training iterations (rollout + update, so the parameters move between the rollouts) with episode ends of both kinds inside:
+    every buffer field (observations, actions, log-probs, values, bootstrap values, processed rewards, flags, advantages, returns), the
+    observation / return statistics, the env's state and counters and the parameters bit-equal; categorical and Gaussian heads, several
+    workgroups with a ragged last one (70 / 130 envs at 16 per workgroup)."""
+    import xuance_amd.envs as envs
+    from xuance_amd.agents import PPO_Agent
+    out = []
+    for tail, post_norm in ((True, True), (False, True), (False, False)):     # (the last: the seven launches)
+        torch.manual_seed(0)
+        kw = dict(activation_action="tanh") if name == "DevicePendulumVecEnv" else {}
+        env = getattr(envs, name)(n, seed=3)
+        env.max_episode_steps = 7
+        agent = PPO_Agent(make_config(n, T, use_hip_graph=graph, use_fused_rollout=False, use_device_act_tail=tail, use_post_norm=post_norm,
+                                      **kw), env)
+        snaps = []
+        for it in range(3):
+            agent.train(T)
+            torch.cuda.synchronize()
+            assert (agent._device_tail() is not None) == tail and agent._post_norm_ok() == post_norm
+            f = agent.memory.soa.fields
+            snaps.append({k: npy(v) for k, v in f.items()} | {
+                "env_obs": npy(env.buf_obs), "env_state": npy(env.state), "env_steps": npy(env.steps), "env_episodes": npy(env.episodes),
+                "env_stats": npy(env.stats), "obs_mean": npy(agent.obs_mean), "obs_var": npy(agent.obs_var), "obs_count": npy(agent.obs_count),
+                "ret_mean": npy(agent.ret_mean), "ret_var": npy(agent.ret_var), "ret_count": npy(agent.ret_count),
+                "returns_track": npy(agent.returns), "params": npy(agent.model.params.flat),
+                "heads_act_rows": npy(agent.model.plan.acts[len(agent.model.plan.widths) - 1][:n])})
+        out.append(snaps)
+    for other in out[:2]:
+        for a, b in zip(other, out[2]):
+            assert (a["seg"] & 1).any() and float(np.abs(a["observations"]).max()) > 0
+            for k in a:
+                assert np.array_equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("name,dist", [("DevicePendulumVecEnv", "gaussian"), ("DeviceMountainCarVecEnv", "categorical"),

@@ -104,6 +104,13 @@ class Classic(C.Structure):
                 ("pad", c_int32), ("seed", C.c_uint64)]
 
 
+class ActTail(C.Structure):
+    _fields_ = [("hb", c_void_p), ("w_actor", c_void_p), ("b_actor", c_void_p), ("w_critic", c_void_p), ("b_critic", c_void_p),
+                ("heads", c_void_p), ("ldh", c_int32), ("K", c_int32), ("a_off", c_int32), ("c_off", c_int32), ("ldw_a", c_int32),
+                ("ldw_c", c_int32), ("boot_rows", c_int32), ("boot_actor", c_int32), ("env_kind", c_int32), ("act_actor", c_int32),
+                ("sample", Sample), ("classic", Classic), ("cartpole", CartPole)]
+
+
 class PostStep(C.Structure):
     _fields_ = [("reward", c_void_p), ("terminated", c_void_p), ("truncated", c_void_p), ("next_obs", c_void_p),
                 ("obs_mean", c_void_p), ("obs_var", c_void_p), ("next_obs_norm", c_void_p), ("rew_out", c_void_p),
@@ -412,6 +419,9 @@ _SIGS = {
     "xrl_qmix_fused_lds_bytes": [C.POINTER(QmixFused)],
     "xrl_qmix_fused_layout": [C.POINTER(QmixFused), C.POINTER(QfImage)],
     "xrl_marl_act_gru": [C.POINTER(MarlActGru), c_void_p],
+    "xrl_act_tail": [C.POINTER(ActTail), c_void_p],
+    "xrl_debug_act_tail_stamps": [c_void_p],
+    "xrl_post_norm": [C.POINTER(PostStep), C.POINTER(Rms), c_void_p],
     "xrl_marl_act_gru_layout": [C.POINTER(MarlActGru), C.POINTER(QaImage)],
     "xrl_debug_act_gru_stamps": [C.c_void_p],
     "xrl_host_device_pointer": [c_void_p, C.POINTER(c_void_p)],

@@ -198,6 +198,93 @@ class PPO_Agent(AgentSurface):
         """The policy's uint8 input batch [obs ; previous next_obs] as it stands now."""
         return self._xin[self.envs._cur] if self._xin is not None else self.Xu8
 
+    def _device_tail(self):
+        """May a vector step of the general path end in xrl_act_tail (heads + sampling + the device env's step as one launch, the previous
+        step's bookkeeping riding in the normalisation launch: xrl_post_norm -- four launches per vector step instead of seven)?  A
+        device CartPole / Pendulum / MountainCar / Acrobot provider, an actor-critic whose heads are single layers on two disjoint
+        blocks of one hidden level (K <= 128, a multiple of 32; A <= 8), no callback between the steps.  config.use_device_act_tail,
+        default False: bit-identical to the launches it replaces and measured no faster (tools/probe_act_tail.py: 10.4 us without the
+        env's step against 7.1 + 3.1 for the heads' product and xrl_policy_sample -- two waves per workgroup walk staging, products,
+        sampling and the simulator one latency after the other; profiles/r06_l_act_tail.json).  Returns None or (env_kind, actor head
+        layer, critic head layer)."""
+        if self._per_step():
+            return None
+        if not bool(_get(self.config, "use_device_act_tail", False)):
+            return None
+        if not hasattr(self, "_dtail"):
+            self._dtail = None
+            env, m = self.envs, self.model
+            kind = getattr(env, "kind", 0) if hasattr(env, "_kw") and type(env).__name__ != "DeviceCartPoleVecEnv" else 0
+            if type(env).__name__ == "DeviceCartPoleVecEnv":
+                kind = 4
+            plan = getattr(m, "plan", None)
+            ok = type(self)._enqueue_step in (PPO_Agent._enqueue_step,) and \
+                kind in (1, 2, 3, 4) and plan is not None and len(plan.stages) >= 2 and len(plan.stages[-1]) == 2
+            if ok:
+                La, Lc = plan.stages[-1]
+                if Lc.N != 1:
+                    La, Lc = Lc, La
+                A = m.action_dim
+                lvl = len(plan.widths) - 1
+                ok = La.N == A and Lc.N == 1 and A <= 8 and La.K == Lc.K and La.K % 32 == 0 and 32 <= La.K <= 128 and \
+                    La.in_level == Lc.in_level == lvl - 1 and La.out_level == Lc.out_level == lvl and La.out_off == 0 and Lc.out_off == A and \
+                    Lc.act is None and plan.widths[lvl] == A + 1 and \
+                    (La.in_off + La.K <= Lc.in_off or Lc.in_off + Lc.K <= La.in_off) and max(La.in_off, Lc.in_off) + La.K <= 256
+                if ok:
+                    self._dtail = (kind, La, Lc)
+        return self._dtail
+
+    def _post_norm_ok(self):
+        """May step t's bookkeeping ride in step t + 1's statistics / normalisation launch (xrl_post_norm: both are single workgroups
+        of reductions over the env axis, 10.2 us together against 7.0 + 4.6 us as two launches)?  The general path (no frames, no wide
+        acting launch), no callback between the steps; config.use_post_norm: False keeps the two launches."""
+        return not self.frames and not self._per_step() and bool(_get(self.config, "use_post_norm", True)) and \
+            type(self)._enqueue_step is PPO_Agent._enqueue_step
+
+    def _enqueue_step_device_tail(self, t, tail):
+        """_enqueue_step with step t - 1's bookkeeping in this step's first launch (xrl_post_norm; the last step's: in
+        _enqueue_rollout_tail) and, with `tail`, heads + sample + env step as one launch (xrl_act_tail).  Same numbers as the seven
+        launches (tests/test_gpu_agent.py)."""
+        env, mem, n, D, A = self.envs, self.memory, self.n_envs, self.obs_dim, self.model.action_dim
+        f, m = mem.soa.fields, self.model
+        plan, P = getattr(m, "plan", None), m.params
+        gaussian = m.dist == "gaussian"
+        stats = (self.obs_mean, self.obs_var, self.obs_count)
+        rms = dict(x=env.buf_obs, mean=self.obs_mean, var=self.obs_var, count=self.obs_count, out0=self.X, out1=f["observations"][t],
+                   n=n, D=D, ld_x=D, ld0=D, ld1=D, update=int(self.use_obsnorm), normalize=int(self.use_obsnorm),
+                   range=float(self.obsnorm_range))
+        if t > 0:
+            ops.post_norm(self._post_args(t - 1, stats, self.X[n:]), rms)
+        else:
+            ops.obs_normalize(**rms)
+        if tail is None:
+            heads = m.forward(self.X, 2 * n)
+            ops.policy_sample(heads=heads, log_std=P.ptr("actor.log_std") if gaussian else None,
+                              noise=None if self.action_noise is None else self.action_noise[t],
+                              act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
+                              env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
+                              bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A, ld=A + 1, gaussian=int(gaussian),
+                              seed=self.seed, step=t, step_dev=self.step_counter)
+            if hasattr(env, "advance"):
+                env.step_device(offset=t)
+            else:
+                env.step_device()
+            return
+        kind, La, Lc = tail
+        plan.forward(self.X, D, 2 * n, stages=plan.stages[:-1])
+        lvl = La.in_level
+        ekw = env._kw()
+        ops.act_tail(sample=dict(heads=None, log_std=P.ptr("actor.log_std") if gaussian else None,
+                                 noise=None if self.action_noise is None else self.action_noise[t],
+                                 act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
+                                 env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
+                                 bootv_prev=f["bootv"][t - 1] if t > 0 else None, n=n, A=A, ld=A + 1, gaussian=int(gaussian),
+                                 seed=self.seed, step=t, step_dev=self.step_counter),
+                     env_kind=kind, classic=ekw if kind != 4 else None, cartpole=ekw if kind == 4 else None,
+                     hb=plan.acts[lvl], ldh=plan.widths[lvl], K=La.K, a_off=La.in_off, c_off=Lc.in_off,
+                     w_actor=P.ptr(La.w_name), b_actor=P.ptr(La.b_name), w_critic=P.ptr(Lc.w_name), b_critic=P.ptr(Lc.b_name),
+                     ldw_a=La.K, ldw_c=Lc.K, heads=plan.acts[La.out_level], boot_rows=1, boot_actor=0, act_actor=ops.ACT[La.act])
+
     def _enqueue_step(self, t):
         if self.frames:
             return self._enqueue_step_frames(t)
@@ -205,6 +292,8 @@ class PPO_Agent(AgentSurface):
         f = mem.soa.fields
         gaussian = self.model.dist == "gaussian"
         wide = self._wide_acting()
+        if wide is None and self._post_norm_ok():
+            return self._enqueue_step_device_tail(t, self._device_tail())
         fold = wide is not None and self._wstats is not None
         stats = (self.obs_mean, self.obs_var, self.obs_count)
         if not fold:
@@ -500,6 +589,8 @@ class PPO_Agent(AgentSurface):
                                 act_out=None, val_out=None, logp_out=None, env_action=None,
                                 bootv_prev=self.memory.soa.fields["bootv"][T - 1], seed=self.seed, step=0, step_dev=None)
         else:
+            if self._wide_acting() is None and self._post_norm_ok():   # the last step's bookkeeping (rode in the next step's launch so far)
+                ops.rollout_poststep(**self._post_args(T - 1, (self.obs_mean, self.obs_var, self.obs_count), self.X[n:]))
             heads = self.model.forward(self._policy_frames(), 2 * n, keep=False, acting=self._acting_fast) if self.frames else self.model.forward(self.X, 2 * n)
             ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
                               bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,

@@ -58,4 +58,35 @@ __device__ __forceinline__ void cartpole_advance(const double* s, int a, double&
     term = (x < -x_thr) || (x > x_thr) || (th < -theta_thr) || (th > theta_thr);
 }
 
+// One env of xrl_cartpole_step (cartpole_step_kernel's statements; also csrc/act_tail.hip)
+__device__ __forceinline__ void cartpole_step_one(const xrl_cartpole_t& p, int e) {
+    double* s = p.state + (size_t)e * 4;
+    double x, xd, th, thd;
+    bool term;
+    cartpole_advance(s, p.action[e], x, xd, th, thd, term);
+    const int steps = p.steps[e] + 1;
+    const bool trunc = steps >= p.max_steps;
+    float* no = p.next_obs + (size_t)e * 4;
+    no[0] = (float)x; no[1] = (float)xd; no[2] = (float)th; no[3] = (float)thd;
+    p.reward[e] = 1.0f;
+    p.terminated[e] = term ? 1.f : 0.f;
+    p.truncated[e] = trunc ? 1.f : 0.f;
+    const float score = p.ep_score[e] + 1.0f;
+    float* o = p.obs + (size_t)e * 4;
+    if (term || trunc) {
+        const int ep = p.episodes[e] + 1;
+        p.episodes[e] = ep;
+        cartpole_reset(s, p.seed, e, (uint32_t)ep);
+        p.steps[e] = 0;
+        p.ep_score[e] = 0.f;
+        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];   // info["reset_obs"]
+        atomicAdd(&p.stats[0], 1.0); atomicAdd(&p.stats[1], (double)score); atomicAdd(&p.stats[2], (double)steps);
+    } else {
+        s[0] = x; s[1] = xd; s[2] = th; s[3] = thd;
+        p.steps[e] = steps;
+        p.ep_score[e] = score;
+        o[0] = no[0]; o[1] = no[1]; o[2] = no[2]; o[3] = no[3];
+    }
+}
+
 }  // namespace xrl

@@ -108,4 +108,37 @@ __device__ __forceinline__ void classic_advance(int kind, const double* s, int a
     }
 }
 
+// One env of xrl_classic_step (classic_step_kernel's statements; also the tail launch of the on-policy acting step, csrc/act_tail.hip)
+__device__ __forceinline__ void classic_step_one(const xrl_classic_t& p, int e) {
+    const int kind = p.kind, D = classic_obs_dim(kind);
+    double* s = p.state + (size_t)e * 4;
+    float* o = p.obs + (size_t)e * D;
+    double ns[4];
+    float reward;
+    bool term;
+    classic_advance(kind, s, p.action ? p.action[e] : 0, p.action_f ? p.action_f[e] : 0.f, ns, reward, term);
+    const int steps = p.steps[e] + 1;
+    const bool trunc = steps >= p.max_steps;
+    float* no = p.next_obs + (size_t)e * D;
+    classic_observe(kind, ns, no);
+    p.reward[e] = reward;
+    p.terminated[e] = term ? 1.f : 0.f;
+    p.truncated[e] = trunc ? 1.f : 0.f;
+    const float score = p.ep_score[e] + reward;
+    if (term || trunc) {
+        const int ep = p.episodes[e] + 1;
+        p.episodes[e] = ep;
+        classic_reset(kind, s, p.seed, e, (uint32_t)ep);
+        p.steps[e] = 0;
+        p.ep_score[e] = 0.f;
+        classic_observe(kind, s, o);                                     // info["reset_obs"]
+        atomicAdd(&p.stats[0], 1.0); atomicAdd(&p.stats[1], (double)score); atomicAdd(&p.stats[2], (double)steps);
+    } else {
+        s[0] = ns[0]; s[1] = ns[1]; s[2] = ns[2]; s[3] = ns[3];
+        p.steps[e] = steps;
+        p.ep_score[e] = score;
+        for (int j = 0; j < D; ++j) o[j] = no[j];
+    }
+}
+
 }  // namespace xrl

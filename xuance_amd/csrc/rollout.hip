@@ -10,6 +10,7 @@
 #include "rng.h"
 #include "cartpole.h"
 #include "poststep.h"
+#include "sample.h"
 
 namespace xrl {
 
@@ -18,7 +19,7 @@ namespace xrl {
 constexpr int RMS_THREADS = 1024;
 constexpr int RMS_MAXD = 64;
 
-__global__ void __launch_bounds__(RMS_THREADS) rms_normalize_kernel(xrl_rms_t p) {
+__device__ __forceinline__ void rms_normalize_body(const xrl_rms_t& p) {
 #pragma clang fp contract(off)
     __shared__ double part[RMS_THREADS];
     __shared__ double bmean[RMS_MAXD], bvar[RMS_MAXD];
@@ -86,54 +87,14 @@ __global__ void __launch_bounds__(RMS_THREADS) rms_normalize_kernel(xrl_rms_t p)
     }
 }
 
+__global__ void __launch_bounds__(RMS_THREADS) rms_normalize_kernel(xrl_rms_t p) { rms_normalize_body(p); }
+
 // ------------------------------------------------------------------------------------------------ policy sampling
 
 __global__ void __launch_bounds__(256) policy_sample_kernel(xrl_sample_t p) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.n) return;
-    const float* h = p.heads + (size_t)e * p.ld;
-    const int A = p.A;
-    if (p.bootv_prev) p.bootv_prev[e] = p.heads[(size_t)(p.n + e) * p.ld + A];
-    if (!p.act_out) return;                                // bootstrap-only launch (end of a rollout)
-    const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
-    float logp;
-    if (!p.gaussian) {
-        float u;
-        if (p.noise) u = p.noise[e];
-        else { uint32_t r[4]; philox4x32(p.seed, (uint32_t)e, step, STREAM_ACTION, r); u = u01(r[0]); }
-        float mx = h[0];
-        for (int j = 1; j < A; ++j) mx = fmaxf(mx, h[j]);
-        float se = 0.f;
-        for (int j = 0; j < A; ++j) se += expf(h[j] - mx);
-        const float lse = mx + logf(se);
-        // inverse CDF over softmax probabilities accumulated left to right in float32
-        int a = A - 1;
-        float c = 0.f;
-        for (int j = 0; j < A; ++j) {
-            c += expf(h[j] - lse);
-            if (c > u) { a = j; break; }
-        }
-        logp = h[a] - lse;                               // Categorical.log_prob (distributions.py:147-148)
-        p.act_out[e] = (float)a;
-        if (p.env_action) p.env_action[e] = a;
-    } else {
-        logp = 0.f;
-        for (int j = 0; j < A; ++j) {
-            float z;
-            if (p.noise) z = p.noise[(size_t)e * A + j];
-            else {
-                z = policy_normal(p.seed, (uint32_t)e, step, (uint32_t)j);
-            }
-            const float ls = p.log_std[j], sd = expf(ls);
-            const float x = h[j] + sd * z;                // Normal(mu, std).sample()
-            const float df = x - h[j];
-            logp += -(df * df) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
-            p.act_out[(size_t)e * A + j] = x;
-            if (p.env_action_f) p.env_action_f[(size_t)e * A + j] = x;
-        }
-    }
-    if (p.val_out) p.val_out[e] = h[A];                  // actor-only policies (VanillaPolicyGradient) have no value column
-    p.logp_out[e] = logp;
+    policy_sample_one(p, e, p.heads + (size_t)e * p.ld, p.bootv_prev ? p.heads[(size_t)(p.n + e) * p.ld + p.A] : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------ CartPole-v1
@@ -141,33 +102,7 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(xrl_sample_t p) {
 __global__ void __launch_bounds__(256) cartpole_step_kernel(xrl_cartpole_t p) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.n) return;
-    double* s = p.state + (size_t)e * 4;
-    double x, xd, th, thd;
-    bool term;
-    cartpole_advance(s, p.action[e], x, xd, th, thd, term);
-    const int steps = p.steps[e] + 1;
-    const bool trunc = steps >= p.max_steps;
-    float* no = p.next_obs + (size_t)e * 4;
-    no[0] = (float)x; no[1] = (float)xd; no[2] = (float)th; no[3] = (float)thd;
-    p.reward[e] = 1.0f;
-    p.terminated[e] = term ? 1.f : 0.f;
-    p.truncated[e] = trunc ? 1.f : 0.f;
-    const float score = p.ep_score[e] + 1.0f;
-    float* o = p.obs + (size_t)e * 4;
-    if (term || trunc) {
-        const int ep = p.episodes[e] + 1;
-        p.episodes[e] = ep;
-        cartpole_reset(s, p.seed, e, (uint32_t)ep);
-        p.steps[e] = 0;
-        p.ep_score[e] = 0.f;
-        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];   // info["reset_obs"]
-        atomicAdd(&p.stats[0], 1.0); atomicAdd(&p.stats[1], (double)score); atomicAdd(&p.stats[2], (double)steps);
-    } else {
-        s[0] = x; s[1] = xd; s[2] = th; s[3] = thd;
-        p.steps[e] = steps;
-        p.ep_score[e] = score;
-        o[0] = no[0]; o[1] = no[1]; o[2] = no[2]; o[3] = no[3];
-    }
+    cartpole_step_one(p, e);
 }
 
 __global__ void __launch_bounds__(256) cartpole_reset_kernel(xrl_cartpole_t p) {
@@ -343,6 +278,17 @@ __global__ void __launch_bounds__(POST_THREADS) poststep_kernel(xrl_poststep_t p
     poststep_body<POST_THREADS>(p, ended_mask);
 }
 
+// xrl_rollout_poststep of vector step t - 1 followed by xrl_obs_normalize of step t as ONE launch (xrl_post_norm): both are single
+// workgroups of 1 024 threads whose work is a few reductions over the env axis, back to back in every vector step of the on-policy loop
+// (ppo_agent.py:114-115 after :144-177 of the previous step); neither reads what the other writes.
+static_assert(POST_THREADS == RMS_THREADS, "one workgroup runs both bodies");
+__global__ void __launch_bounds__(POST_THREADS) post_norm_kernel(xrl_poststep_t post, xrl_rms_t rms) {
+    __shared__ unsigned long long ended_mask[64];
+    poststep_body<POST_THREADS>(post, ended_mask);
+    __syncthreads();
+    rms_normalize_body(rms);
+}
+
 // epsilon-greedy selection (off_policy.py:138-141): where(rand < eps, randint, greedy)
 
 __global__ void __launch_bounds__(256) egreedy_kernel(xrl_egreedy_t p) {
@@ -452,6 +398,19 @@ extern "C" int xrl_rollout_poststep(const xrl_poststep_t* params, xrl_stream_t s
                   p.seg_out && p.ret_track && p.ret_mean && p.ret_var && p.ret_count && p.n > 0 && p.D > 0);
     XRL_CHECK_ARG(!p.use_obsnorm || (p.obs_mean && p.obs_var));
     hipLaunchKernelGGL(poststep_kernel, dim3(1), dim3(POST_THREADS), 0, as_stream(stream), p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_post_norm(const xrl_poststep_t* post, const xrl_rms_t* rms, xrl_stream_t stream) {
+    XRL_CHECK_ARG(post != nullptr && rms != nullptr);
+    const xrl_poststep_t& p = *post;
+    XRL_CHECK_ARG(p.reward && p.terminated && p.truncated && (p.next_obs || !p.next_obs_norm) && p.rew_out && p.term_out &&
+                  p.seg_out && p.ret_track && p.ret_mean && p.ret_var && p.ret_count && p.n > 0 && p.D > 0);
+    XRL_CHECK_ARG(!p.use_obsnorm || (p.obs_mean && p.obs_var));
+    const xrl_rms_t& r = *rms;
+    XRL_CHECK_ARG(r.x && r.mean && r.var && r.count && r.n > 0 && r.D > 0 && r.D <= RMS_MAXD);
+    hipLaunchKernelGGL(post_norm_kernel, dim3(1), dim3(POST_THREADS), 0, as_stream(stream), p, r);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, RolloutWide, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, OptChain, CHAIN_SYNC_WORDS, MarlAct, call, ptr,
+from ._lib import (ActTail, Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, RolloutWide, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, OptChain, CHAIN_SYNC_WORDS, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -429,6 +429,24 @@ def _struct(cls, kw):
 
 def obs_normalize(**kw):
     call("xrl_obs_normalize", C.byref(_struct(Rms, kw)), stream_ptr())
+
+
+def post_norm(post, rms):
+    """rollout_poststep(**post) + obs_normalize(**rms) as one launch (xrl_post_norm)."""
+    call("xrl_post_norm", C.byref(_struct(PostStep, post)), C.byref(_struct(Rms, rms)), stream_ptr())
+
+
+def act_tail(sample, env_kind=0, classic=None, cartpole=None, **kw):
+    """Heads + policy_sample(**sample) + the device env's step as one launch (xrl_act_tail); classic / cartpole: the keyword
+    arguments of ops.classic_step / ops.cartpole_step."""
+    q = _struct(ActTail, kw)
+    q.env_kind = int(env_kind)
+    q.sample = _struct(Sample, sample)
+    if classic is not None:
+        q.classic = _struct(Classic, classic)
+    if cartpole is not None:
+        q.cartpole = _struct(CartPole, cartpole)
+    call("xrl_act_tail", C.byref(q), stream_ptr())
 
 
 def policy_sample(**kw):
