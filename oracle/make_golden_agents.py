@@ -304,6 +304,11 @@ def golden_agent_dqn_atari():
     golden_agent_dqn(atari=True)
 
 
+def golden_agent_dqn_subproc():
+    """agent_dqn.npz's run behind the reference's SubprocVecEnv instead of DummyVecEnv (40 vector steps)."""
+    golden_agent_dqn(subproc=True)
+
+
 def golden_agent_perdqn():
     """PerDQN_Agent (agents/qlearning_family/perdqn_agent.py:12-107) with configs/perdqn/classic_control/CartPole-v1.yaml (PER_alpha 0.5,
     PER_beta0 0.4): prioritized replay per env (memory_tools.py:471-598: batch_size / n_envs proportional draws per env from
@@ -313,7 +318,7 @@ def golden_agent_perdqn():
     golden_agent_dqn(per=True)
 
 
-def golden_agent_dqn(atari=False, per=False):
+def golden_agent_dqn(atari=False, per=False, subproc=False):
     """DQN_Agent with configs/dqn/classic_control/CartPole-v1.yaml (network 4-128-128-2, MSE TD loss, no normalisation, no
     clipping) at 8 envs, a replay ring of 16 rows per env (it wraps three times), batch 16, start_training 48, an update every
     second vector step (training_frequency 16 with current_step growing by 8), hard target sync every 5 updates, epsilon from 0.5
@@ -342,12 +347,19 @@ def golden_agent_dqn(atari=False, per=False):
         envs.observation_space, envs.action_space = sp.Box(0, 255, (84, 84, 4), np.uint8), sp.Discrete(A)
         odt, oshape, Env = np.uint8, (84, 84, 4), HostAtariShapedEnv
     else:
-        n, S, A = 8, 64, 2
+        n, S, A = 8, 40 if subproc else 64, 2
         cfg = agent_config(("perdqn" if per else "dqn") + "/classic_control/CartPole-v1.yaml", parallels=n, buffer_size=n * 16, batch_size=16,
                            start_training=n * 6, training_frequency=16, sync_frequency=5,
-                           decay_step_greedy=n * 30 if per else n * n * 30, seed=21 if per else 5)
+                           decay_step_greedy=n * 30 if per else (n * n * 12 if subproc else n * n * 30), seed=21 if per else (13 if subproc else 5))
         seed_all(cfg.seed)
-        envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 3)
+        if subproc:
+            # the reference's OTHER vector env (environment/vector_envs/subprocess/subproc_vec_env.py: one worker process per env, pipes):
+            # it rebinds buf_obs in step_wait (:117), so the `obs` the loop stores at the first step of a train() call is what the
+            # policy acted on -- no alias as with DummyVecEnv (tests/test_oracle_agent_loops.py: test_dqn_agent_loop)
+            from xuance.environment.vector_envs.subprocess.subproc_vec_env import SubprocVecEnv
+            envs = SubprocVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 3)
+        else:
+            envs = DummyVecEnv([lambda env_seed: XuanCeEnvWrapper(ShortCartPole(env_seed=env_seed))] * n, 3)
         envs.observation_space, envs.action_space = sp.Box(-np.inf, np.inf, (4,), np.float32), sp.Discrete(A)
         odt, oshape, Env = np.float32, (4,), ShortCartPole
     envs.reset()
@@ -453,14 +465,19 @@ def golden_agent_dqn(atari=False, per=False):
         out["per_cfg"] = np.array([cfg.PER_alpha, cfg.PER_beta0], np.float64)
     term, trunc = out["step/terminals"], out["step/truncations"]
     explored = out["step/coin"] < out["step/eps_acted"][:, None]
-    assert term.sum() > (4 if atari else 8) and (trunc & ~term).sum() > 4 and explored.sum() > (5 if atari else 20) and (~explored).sum() > (50 if atari else 200)
-    assert out["step/eps_after"][-1] <= cfg.end_greedy + 1e-12 and len(np.unique(out["step/eps_after"])) > (10 if atari else 20)
+    assert term.sum() > (4 if atari else 8) and (trunc & ~term).sum() > (1 if subproc else 4) and explored.sum() > (5 if atari else 20) and \
+        (~explored).sum() > (50 if atari else 120 if subproc else 200)
+    assert out["step/eps_after"][-1] <= cfg.end_greedy + 1e-12 and len(np.unique(out["step/eps_after"])) > (10 if atari or subproc else 20)
+    if subproc:
+        assert np.array_equal(out["step/obs"][0], out["raw_obs0"]) and not np.array_equal(out["step/obs"][0], out["step/next_obs"][0])
+        out["vector_env"] = np.array("SubprocVecEnv")
+        envs.close()
     out["cfg"] = np.array([n, S, cfg.buffer_size, cfg.batch_size, cfg.gamma, cfg.learning_rate, cfg.start_training, cfg.training_frequency,
                            cfg.sync_frequency, cfg.start_greedy, cfg.end_greedy, cfg.decay_step_greedy, agent.learner.total_iters,
                            Env.max_episode_steps], np.float64)
     out["cfg_names"] = np.array("n_envs n_steps buffer_size batch_size gamma learning_rate start_training training_frequency sync_frequency "
                                 "start_greedy end_greedy decay_step_greedy total_iters max_episode_steps".split())
-    name = "agent_dqn_atari" if atari else "agent_perdqn" if per else "agent_dqn"
+    name = "agent_dqn_atari" if atari else "agent_perdqn" if per else "agent_dqn_subproc" if subproc else "agent_dqn"
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name + ":", len(out), "arrays;", len(phases), "update phases,", int(term.sum()), "terminations,", int((trunc & ~term).sum()),
           "truncations,", int(explored.sum()), "explored actions; final epsilon", out["step/eps_after"][-1])
@@ -768,6 +785,6 @@ def golden_agent_qmix_rnn():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    todo = sys.argv[1:] or ["ppo", "ppo_40", "ppo_gaussian", "ppo_gaussian_40", "a2c", "pg", "dqn", "dqn_atari", "perdqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
+    todo = sys.argv[1:] or ["ppo", "ppo_40", "ppo_gaussian", "ppo_gaussian_40", "a2c", "pg", "dqn", "dqn_subproc", "dqn_atari", "perdqn", "qmix_ff", "vdn_ff", "iql_ff", "qmix_rnn"]
     for name in todo:
         globals()[f"golden_agent_{name}"]()

@@ -150,9 +150,12 @@ def test_ppo_agent_replays_the_reference_run(kind, use_graph):
     assert (agent._rollout_graph is not None) == use_graph and (agent._update_graph is not None) == use_graph
 
 
-@pytest.mark.parametrize("atari", [False, True])
-def test_dqn_agent_replays_the_reference_run(atari):
-    """atari: agent_dqn_atari.npz -- configs/dqn/atari.yaml (BASELINE configs[2]'s network: Basic_CNN 32/64/64 + global max-pool +
+@pytest.mark.parametrize("kind", ["dummy", "atari", "subproc"])
+def test_dqn_agent_replays_the_reference_run(kind):
+    """subproc (round 6): agent_dqn_subproc.npz -- the CartPole configuration below behind the reference's SubprocVecEnv (40 vector
+    steps): that vector env rebinds buf_obs, so the first stored observation of the reference's train() call is what the policy acted
+    on and the replay runs WITHOUT the one patched ring row the DummyVecEnv fixtures need (see `s == 0` below).
+    atari: agent_dqn_atari.npz -- configs/dqn/atari.yaml (BASELINE configs[2]'s network: Basic_CNN 32/64/64 + global max-pool +
     64-512-4 on 84x84x4 uint8 frame stacks; uint8 ring), 4 envs, 22 vector steps, 9 update phases, a 12-row ring that wraps, the
     loop's Atari mode (an env that terminated without truncation keeps acting on its next observation, off_policy.py:240-242).
     agent_dqn.npz: the reference's DQN_Agent (configs/dqn/classic_control/CartPole-v1.yaml) over 64 vector steps of 8 envs: a
@@ -164,7 +167,8 @@ def test_dqn_agent_replays_the_reference_run(atari):
     from xuance_amd.agents import DQN_Agent
     from xuance_amd.envs import RecordedVecEnv
     from xuance_amd.spaces import Discrete
-    g = load_golden("agent_dqn_atari" if atari else "agent_dqn")
+    atari, subproc = kind == "atari", kind == "subproc"
+    g = load_golden("agent_dqn_atari" if atari else "agent_dqn_subproc" if subproc else "agent_dqn")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, S, B = int(c["n_envs"]), int(c["n_steps"]), int(c["batch_size"])
     A = 4 if atari else 2
@@ -200,7 +204,9 @@ def test_dqn_agent_replays_the_reference_run(atari):
             q = npy(agent.model.forward(f["observations"][slot].view(n, -1), n))[e][:A]
             assert abs(q[acts[e]] - q[g["step/acts"][s][e]]) < 1e-5 * max(1.0, np.abs(q).max()), (s, e, q)
             flips += 1
-        if s == 0:
+        if s == 0 and subproc:       # no alias behind SubprocVecEnv: the reference stored what its policy acted on, and so did the device loop
+            assert np.array_equal(g["step/obs"][0], g["raw_obs0"]) and np.array_equal(npy(f["observations"][0]).reshape(g["raw_obs0"].shape), g["raw_obs0"])
+        elif s == 0:
             # The reference's first stored "obs" of a train() call is its vector env's buffer AFTER the step (an alias of
             # DummyVecEnv.buf_obs, see tests/test_oracle_agent_loops.py: test_dqn_agent_loop): the device loop stored what the
             # policy acted on; the reference's row is input data of this replay (update phases sample it until the ring wraps).

@@ -205,9 +205,11 @@ def test_pg_agent_loop(oracle):
     assert phase == 3
 
 
-@pytest.mark.parametrize("atari", [False, True])
-def test_dqn_agent_loop(oracle, atari):
-    """atari: agent_dqn_atari.npz (configs/dqn/atari.yaml: uint8 frame stacks, Basic_CNN) -- the oracle has no convolutions, so the
+@pytest.mark.parametrize("kind", ["dummy", "atari", "subproc"])
+def test_dqn_agent_loop(oracle, kind):
+    """subproc (round 6): agent_dqn_subproc.npz -- the CartPole run behind the reference's SubprocVecEnv (40 vector steps): buf_obs is
+    rebound there, the first stored observation is the one acted on (no alias, see `s == 0` below).
+    atari: agent_dqn_atari.npz (configs/dqn/atari.yaml: uint8 frame stacks, Basic_CNN) -- the oracle has no convolutions, so the
     Q values are not recomputed there (the device replay does that); everything else of the loop is, plus the Atari rule: an env that
     terminated WITHOUT truncation keeps acting on its next observation (off_policy.py:240-242).
     core/off_policy.py:183-270 with dqn_agent.py:28-30: per vector step (obs_rms / normalisation are off in configs/dqn/*.yaml)
@@ -217,7 +219,8 @@ def test_dqn_agent_loop(oracle, atari):
     current_step += n_envs and the epsilon schedule (:119-127: recomputed while the PREVIOUS value is above end_greedy, so it
     undershoots the floor once -- the fixture ends at -0.0063)."""
     o = oracle
-    g = load_golden("agent_dqn_atari" if atari else "agent_dqn")
+    atari, subproc = kind == "atari", kind == "subproc"
+    g = load_golden("agent_dqn_atari" if atari else "agent_dqn_subproc" if subproc else "agent_dqn")
     c = dict(zip(g["cfg_names"].tolist(), g["cfg"].tolist()))
     n, S, B = int(c["n_envs"]), int(c["n_steps"]), int(c["batch_size"])
     sd = {k: v.copy() for k, v in sub(g, "init").items()}
@@ -240,7 +243,9 @@ def test_dqn_agent_loop(oracle, atari):
         assert np.array_equal(acts, g["step/acts"][s]), f"step {s}: actions"
         next_obs, rew, term, trunc = g["step/next_obs"][s], g["step/rewards"][s], g["step/terminals"][s], g["step/truncations"][s]
         stored = raw
-        if s == 0:
+        if s == 0 and subproc:
+            assert np.array_equal(g["step/obs"][0], raw) and not np.array_equal(raw, next_obs)       # (SubprocVecEnv: no alias)
+        elif s == 0:
             # A quirk of the reference's FIRST vector step of a train() call, input data here: with normalisation off `obs` is still
             # the vector env's own buf_obs array (off_policy.py:184,187; agent.py:262-283 returns its argument), which
             # DummyVecEnv.step_wait overwrites in place (dummy_vec_env.py:74,88-93) -- what the loop stores as "obs" of that step
