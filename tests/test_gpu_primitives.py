@@ -312,6 +312,45 @@ def test_adam_clip(ops, oracle, P):
         assert_close(d_v.cpu().numpy(), opt.v["w"], 1e-6, "v")
 
 
+@pytest.mark.parametrize("P", [4096, 1703936 // 16])
+def test_adam_step_with_16_byte_accesses_equals_the_element_loop(ops, P):
+    """xrl_adam_step_mirrors (round 6): four consecutive elements per thread through 16-byte accesses where every array allows it
+    (P % 4 == 0, 16-byte aligned bases) vs the element-by-element loop (taken here by handing the same numbers over at a base that is
+    4 bytes off alignment): parameters, moments, clipped gradient, both mirrors and the optimiser state bit-equal over three steps."""
+    g = torch.Generator(device="cpu").manual_seed(P)
+    mk = lambda: torch.randn(P, generator=g)
+    p0, v0 = mk(), mk().abs() * 1e-3
+    m0 = mk() * 0.1
+    grads = [mk() * (10.0 if k == 1 else 0.01) for k in range(3)]
+    perm_a, perm_b = torch.randperm(P, generator=g).to(torch.int32), torch.randperm(P, generator=g).to(torch.int32)
+    perm_b[::7] = -1
+    res = []
+    for off in (0, 1):                                      # off = 1: every array starts 4 bytes past a 16-byte boundary
+        def put(x, dtype=torch.float32):
+            buf = torch.zeros(P + 4, dtype=dtype, device="cuda")
+            buf[off:off + P].copy_(x)
+            return buf[off:off + P]
+        p, m, v = put(p0), put(m0), put(v0)
+        ma, mb = put(perm_a, torch.int32), put(perm_b, torch.int32)
+        da, db = torch.zeros(P, device="cuda"), torch.full((P,), -3.0, device="cuda")
+        st = ops.adam_state_tensor(3e-4, 10, end_factor=0.5)
+        part = torch.zeros(4, dtype=torch.float64, device="cuda")
+        gs = []
+        for k in range(3):
+            gk = put(grads[k])
+            part.zero_(); part[0] = float((grads[k].double() ** 2).sum())
+            ops.adam_step_mirrors(p, gk, m, v, P, st, part, 0.5, [(ma, da), (mb, db)])
+            torch.cuda.synchronize()
+            gs.append(gk.clone())
+        s = ops.read_adam_state(st)
+        res.append((p.clone(), m.clone(), v.clone(), da, db, gs, (s.step, s.sched_steps, s.last_grad_norm, s.last_lr)))
+    a, b = res
+    for x, y, name in zip(a[:5], b[:5], ("params", "m", "v", "mirror a", "mirror b")):
+        assert torch.equal(x, y), name
+    assert all(torch.equal(x, y) for x, y in zip(a[5], b[5])) and a[6] == b[6] and a[6][0] == 3
+    assert torch.equal(a[3][perm_a.long().cuda()], a[0]) and float((a[4] == -3.0).sum()) == float((perm_b < 0).sum())
+
+
 def test_graph_replay(ops):
     P = 1000
     a = torch.ones(P, device="cuda"); g = torch.full((P,), 0.1, device="cuda")
