@@ -149,28 +149,52 @@ __global__ void __launch_bounds__(256) maxpool_hw_bwd_kernel(const float* __rest
 // nn.Flatten() of an NCHW activation (AC_CNN_Atari, cnn.py:90): the engine keeps conv outputs NHWC -- y[(b, q), f] with q = h * W
 // + w -- while the dense layer behind the flatten indexes its input (f, q) = f * P + q.  One workgroup per frame, the frame's
 // P x F block goes through LDS so that both the read and the write are contiguous.
-__global__ void __launch_bounds__(256) flatten_chw_fwd_kernel(const float* __restrict__ y, float* __restrict__ feat, int P, int F,
-                                                              int ld_feat) {
+// (round 6: 1 024 threads per frame and the loads of a pass requested four at a time before the first LDS store -- as plain loops
+//  of 256 threads every element was a global round trip of its own, twelve in a row per thread: 12 / 18 us per launch at 256 frames)
+constexpr int FLAT_THREADS = 1024;
+__global__ void __launch_bounds__(FLAT_THREADS) flatten_chw_fwd_kernel(const float* __restrict__ y, float* __restrict__ feat, int P, int F,
+                                                                       int ld_feat) {
     extern __shared__ float s_blk[];                                    // [P][F + 1]
     const int b = blockIdx.x, n = P * F;
     const float* src = y + (int64_t)b * n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s_blk[(i / F) * (F + 1) + i % F] = src[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * FLAT_THREADS) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * FLAT_THREADS; v[u] = i < n ? src[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * FLAT_THREADS; if (i < n) s_blk[(i / F) * (F + 1) + i % F] = v[u]; }
+    }
     __syncthreads();
     float* dst = feat + (int64_t)b * ld_feat;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = s_blk[(i % P) * (F + 1) + i / P];    // i = f * P + q
+    for (int i = threadIdx.x; i < n; i += FLAT_THREADS) dst[i] = s_blk[(i % P) * (F + 1) + i / P];    // i = f * P + q
 }
 
 // dY[(b, q), f] = dfeat[b][f * P + q] where y > 0 (the ReLU in front of the flatten), else 0
-__global__ void __launch_bounds__(256) flatten_chw_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ y,
-                                                              float* __restrict__ dy, int P, int F, int ld_dfeat) {
+__global__ void __launch_bounds__(FLAT_THREADS) flatten_chw_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ y,
+                                                                       float* __restrict__ dy, int P, int F, int ld_dfeat) {
     extern __shared__ float s_blk[];                                    // [F][P + 1]
     const int b = blockIdx.x, n = P * F;
     const float* src = dfeat + (int64_t)b * ld_dfeat;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s_blk[(i / P) * (P + 1) + i % P] = src[i];    // i = f * P + q
-    __syncthreads();
     const float* yy = y + (int64_t)b * n;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * FLAT_THREADS) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * FLAT_THREADS; v[u] = i < n ? src[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * FLAT_THREADS; if (i < n) s_blk[(i / P) * (P + 1) + i % P] = v[u]; }    // i = f * P + q
+    }
+    __syncthreads();
     float* dst = dy + (int64_t)b * n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = yy[i] > 0.f ? s_blk[(i % F) * (P + 1) + i / F] : 0.f;   // i = q * F + f
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * FLAT_THREADS) {
+        float yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * FLAT_THREADS; yv[u] = i < n ? yy[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * FLAT_THREADS;
+            if (i < n) dst[i] = yv[u] > 0.f ? s_blk[(i % F) * (P + 1) + i / F] : 0.f;   // i = q * F + f
+        }
+    }
 }
 
 static int grid_for(int64_t total) {
@@ -229,14 +253,14 @@ extern "C" int xrl_maxpool_hw_bwd(const float* dfeat, const int32_t* argmax, con
 
 extern "C" int xrl_flatten_chw_fwd(const float* y, float* feat, int B, int P, int F, int ld_feat, xrl_stream_t stream) {
     XRL_CHECK_ARG(y && feat && B > 0 && P > 0 && F > 0 && ld_feat >= P * F && (size_t)P * (F + 1) * 4 <= 64 * 1024);
-    hipLaunchKernelGGL(flatten_chw_fwd_kernel, dim3(B), dim3(256), (size_t)P * (F + 1) * 4, as_stream(stream), y, feat, P, F, ld_feat);
+    hipLaunchKernelGGL(flatten_chw_fwd_kernel, dim3(B), dim3(FLAT_THREADS), (size_t)P * (F + 1) * 4, as_stream(stream), y, feat, P, F, ld_feat);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
 
 extern "C" int xrl_flatten_chw_bwd(const float* dfeat, const float* y, float* dy, int B, int P, int F, int ld_dfeat, xrl_stream_t stream) {
     XRL_CHECK_ARG(dfeat && y && dy && B > 0 && P > 0 && F > 0 && ld_dfeat >= P * F && (size_t)F * (P + 1) * 4 <= 64 * 1024);
-    hipLaunchKernelGGL(flatten_chw_bwd_kernel, dim3(B), dim3(256), (size_t)F * (P + 1) * 4, as_stream(stream), dfeat, y, dy, P, F, ld_dfeat);
+    hipLaunchKernelGGL(flatten_chw_bwd_kernel, dim3(B), dim3(FLAT_THREADS), (size_t)F * (P + 1) * 4, as_stream(stream), dfeat, y, dy, P, F, ld_dfeat);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
