@@ -58,14 +58,24 @@ __device__ __forceinline__ void episode_finish_body(const EpPack& f, const float
     const int es = end_step[env];
     const uint32_t* term = f.c[fi] ? reinterpret_cast<const uint32_t*>(f.c[fi]) + (size_t)env * rw : nullptr;
     const int n = slots * rw;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        uint32_t v = stage[i];
-        if (term && i / rw == es) {                                      // terminal obs / state / avail_actions (:931-937)
-            v = term[i - es * rw];
-            stage[i] = v;                                                // the reference writes it into episode_data first
+    // (eight words requested before the first store, as in the gather below: a finished episode is up to 5 490 words per block)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            v[u] = 0u;
+            if (i < n) v[u] = (term && i / rw == es) ? term[i - es * rw] : stage[i];   // terminal obs / state / avail_actions (:931-937)
         }
-        ring[i] = v;
-        if (f.flags[fi] & 1) stage[i] = 0u;                              // `filled` of this env is cleared (:921)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            if (i < n) {
+                if (term && i / rw == es) stage[i] = v[u];               // the reference writes it into episode_data first
+                ring[i] = v[u];
+                if (f.flags[fi] & 1) stage[i] = 0u;                      // `filled` of this env is cleared (:921)
+            }
+        }
     }
 }
 
@@ -117,9 +127,17 @@ __global__ void __launch_bounds__(256) episode_gather_sampled_kernel(EpPack f, i
     const uint32_t* s = reinterpret_cast<const uint32_t*>(f.b[fi]) + (size_t)ep * slots * rw;
     uint32_t* d = reinterpret_cast<uint32_t*>(f.a[fi]);
     const int n = slots * rw;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int t = i / rw, w = i - t * rw;
-        d[((size_t)t * B + b) * rw + w] = s[i];
+    // (eight loads requested before the first store: an episode of the obs field is 5 490 words = 21 trips of this loop per thread, and
+    //  as a plain loop every trip was a global round trip of its own)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; v[u] = i < n ? s[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            if (i < n) { const int t = i / rw, w = i - t * rw; d[((size_t)t * B + b) * rw + w] = v[u]; }
+        }
     }
 }
 
