@@ -351,6 +351,27 @@ def test_adam_step_with_16_byte_accesses_equals_the_element_loop(ops, P):
     assert torch.equal(a[3][perm_a.long().cuda()], a[0]) and float((a[4] == -3.0).sum()) == float((perm_b < 0).sum())
 
 
+@pytest.mark.parametrize("P", [4096, 840004, 77])
+def test_grad_reduce_of_one_slab_equals_the_general_path(ops, P):
+    """xrl_grad_reduce with ONE slab (round 6: its four waves take four trips of the block's walk at once instead of one wave walking
+    alone) against the general path on the same numbers (two slabs, the second all zero: x + 0 = x): the gradient and every block's
+    partial sum of squares -- hence the clip coefficient -- bit-equal."""
+    g = torch.Generator(device="cpu").manual_seed(P)
+    x = torch.randn(P, generator=g).cuda()
+    two = torch.zeros(2, P, device="cuda")
+    two[0].copy_(x)
+    out = []
+    for slabs, S in ((x.view(1, P).clone(), 1), (two, 2)):
+        grad = torch.full((P,), 7.0, device="cuda")
+        part = torch.zeros(256, dtype=torch.float64, device="cuda")
+        ops.grad_reduce(slabs, S, P, P, grad, part)
+        torch.cuda.synchronize()
+        out.append((grad, part))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][0], x)
+    assert torch.equal(out[0][1], out[1][1]) and float(out[0][1].sum()) > 0
+    assert abs(float(out[0][1].sum()) - float((x.double() ** 2).sum())) < 1e-9 * float((x.double() ** 2).sum())
+
+
 def test_graph_replay(ops):
     P = 1000
     a = torch.ones(P, device="cuda"); g = torch.full((P,), 0.1, device="cuda")

@@ -281,7 +281,15 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(GemmBatch p) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / g.N), n = (int)(i - (int64_t)m * g.N);
         float s = g.aux[i];
-        for (int q = 1; q < g.ldaux; ++q) s += g.aux[(size_t)q * total + i];
+        int q = 1;
+        for (; q + 8 <= g.ldaux; q += 8) {              // (eight partials requested at a time, added in order: one load per trip was a
+            float w8[8];                                //  chain of ldaux global round trips)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = g.aux[(size_t)(q + j) * total + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += w8[j];
+        }
+        for (; q < g.ldaux; ++q) s += g.aux[(size_t)q * total + i];
         const float z = s + (g.bias ? g.bias[n] : 0.f);
         float y = z;
         XRL_ACT_DISPATCH(g.act, y = act_apply_c<ACT>(z);)
