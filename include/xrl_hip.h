@@ -646,6 +646,34 @@ typedef struct {
     int32_t pad;
 } xrl_fused_layer_t;
 
+/* Whole feed-forward plans as ONE launch (round 6; csrc/mlp_chain.hip): every job is a DAG of Linear(+activation) layers on LEVELS of a
+ * row tile (level 0 = the input, a layer reads columns [in_off, in_off + K) of an earlier level and writes [out_off, out_off + N) of a
+ * later one: xrl_fused_layer_t, listed in execution order); up to XRL_CHAIN_MAX_JOBS independent jobs share the launch (an eval network
+ * and its target twin, the mixers' hyper-networks).  Bit-identical to one xrl_linear_fwd per stage.  out[l] != NULL: level l of every
+ * row is written to out[l][row * ld_out[l] + col].  tile0: prefix sums of ceil(M / 32) over the jobs (tile0[0] = 0). */
+#define XRL_CHAIN_MAX_JOBS 4
+typedef struct {
+    const float* x;             /* [M][ldx] input rows; level_width[0] columns are read */
+    const float* params;        /* flat parameter buffer the layers' offsets refer to */
+    xrl_fused_layer_t layers[XRL_FUSED_MAX_LAYERS];
+    int32_t n_layers, n_levels;
+    int32_t level_width[XRL_FUSED_MAX_LEVELS];
+    float* out[XRL_FUSED_MAX_LEVELS];
+    int32_t ld_out[XRL_FUSED_MAX_LEVELS];
+    int32_t ldx, M;
+} xrl_mlp_chain_job_t;
+typedef struct {
+    xrl_mlp_chain_job_t job[XRL_CHAIN_MAX_JOBS];
+    int32_t n_jobs;
+    int32_t tile0[XRL_CHAIN_MAX_JOBS + 1];
+    int32_t pad[2];
+} xrl_mlp_chain_t;
+int xrl_mlp_chain_fwd(const xrl_mlp_chain_t* p, xrl_stream_t stream);
+int xrl_mlp_chain_lds_bytes(const xrl_mlp_chain_t* p);     /* LDS the launch needs (must be <= 160 KB), -1 on a malformed description */
+/* Measurement aid (tools/probe_mlp_chain.py): stamps != NULL -> workgroup 0 of the following launches writes its s_memtime at start,
+ * inputs staged, after every stage, after the write-back to stamps[0..], their count to stamps[15]; NULL: off. */
+int xrl_debug_mlp_chain_stamps(long long* stamps);
+
 typedef struct {
     const float* params;                               /* flat parameter buffer */
     const float* cache_image;                          /* packed LDS parameter-cache image (xrl_pack_rollout_cache) */

@@ -372,6 +372,49 @@ def test_grad_reduce_of_one_slab_equals_the_general_path(ops, P):
     assert abs(float(out[0][1].sum()) - float((x.double() ** 2).sum())) < 1e-9 * float((x.double() ** 2).sum())
 
 
+@pytest.mark.parametrize("M", [512, 37, 5856])
+def test_plans_as_one_launch_equal_the_launch_per_stage(ops, M):
+    """xrl_mlp_chain_fwd (round 6): whole feed-forward plans -- the actor-critic of the classic-control yaml files (6-128-{128-3, 128-1},
+    leaky_relu; tanh), the fc -> W_ih chain below the recurrent QMIX agents' GRU and their Q head above it, eval and target twins and
+    the two mixers' hyper-network plans riding in the same launch -- as ONE launch (a workgroup keeps a 32-row tile of every level in
+    LDS) against one grouped xrl_linear_fwd per stage: EVERY level of every plan bit-equal (same MFMA chains), ragged last tiles."""
+    from xuance_amd.nets import ActorCriticNet, MixingQNet, Plan
+    torch.manual_seed(M)
+    g = torch.Generator(device="cpu").manual_seed(M)
+
+    def run(items, chain):
+        for plan, *_ in items:
+            plan.ensure(M)
+            for lvl in plan.acts:
+                plan.acts[lvl].fill_(-9.0)
+        out = Plan.forward_chain(items) if chain else Plan.forward_many(items)
+        assert out is not None
+        torch.cuda.synchronize()
+        return [{lvl: a[:M].clone() for lvl, a in plan.acts.items()} for plan, *_ in items]
+
+    for act in ("leaky_relu", "tanh"):
+        net = ActorCriticNet(6, 3, "categorical", (128,), (128,), (128,), act)
+        X = torch.randn(M, 6, generator=g).cuda()
+        items = [(net.plan, X, 6, M, None)]
+        a, b = run(items, False), run(items, True)
+        for pa, pb in zip(a, b):
+            for lvl in pa:
+                assert torch.equal(pa[lvl], pb[lvl]), (act, lvl)
+        assert float(a[0][len(net.plan.widths) - 1].abs().max()) > 0
+    q = MixingQNet(3, 30, 9, 48, (), (64,), 32, 32, "relu", use_rnn=True, fc_hidden=(64,), recurrent_hidden=64)
+    q.target_flat.add_(0.01 * torch.randn(q.target_flat.shape, generator=g).cuda())
+    Xo, Hs, St = torch.randn(M, 30, generator=g).cuda(), torch.randn(M, 64, generator=g).cuda(), torch.randn(M, 48, generator=g).cuda()
+    pre = [(q.pre_plans[0], Xo, 30, M, None), (q.pre_plans[1], Xo, 30, M, q.target_flat)]
+    post = [(q.post_plans[0], Hs, 64, M, None), (q.post_plans[1], Hs, 64, M, q.target_flat),
+            (q.mixer_plan, St, 48, M, None), (q.mixer_target_plan, St, 48, M, q.target_flat)]
+    for items in (pre, post):
+        a, b = run(items, False), run(items, True)
+        for i, (pa, pb) in enumerate(zip(a, b)):
+            for lvl in pa:
+                assert torch.equal(pa[lvl], pb[lvl]), (i, lvl)
+            assert float(pa[max(pa)].abs().max()) > 0
+
+
 def test_graph_replay(ops):
     P = 1000
     a = torch.ones(P, device="cuda"); g = torch.full((P,), 0.1, device="cuda")

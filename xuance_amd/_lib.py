@@ -188,6 +188,15 @@ class FusedLayer(C.Structure):
                 ("in_level", c_int32), ("in_off", c_int32), ("out_level", c_int32), ("out_off", c_int32), ("pad", c_int32)]
 
 
+class MlpChainJob(C.Structure):
+    _fields_ = [("x", c_void_p), ("params", c_void_p), ("layers", FusedLayer * 8), ("n_layers", c_int32), ("n_levels", c_int32),
+                ("level_width", c_int32 * 6), ("out", c_void_p * 6), ("ld_out", c_int32 * 6), ("ldx", c_int32), ("M", c_int32)]
+
+
+class MlpChain(C.Structure):
+    _fields_ = [("job", MlpChainJob * 4), ("n_jobs", c_int32), ("tile0", c_int32 * 5), ("pad", c_int32 * 2)]
+
+
 class RolloutStep(C.Structure):
     _fields_ = [("params", c_void_p), ("cache_image", c_void_p), ("frag_image", c_void_p), ("layers", FusedLayer * 8), ("n_layers", c_int32), ("n_levels", c_int32),
                 ("n_head_layers", c_int32), ("pad0", c_int32), ("level_width", c_int32 * 6),
@@ -419,6 +428,9 @@ _SIGS = {
     "xrl_qmix_fused_lds_bytes": [C.POINTER(QmixFused)],
     "xrl_qmix_fused_layout": [C.POINTER(QmixFused), C.POINTER(QfImage)],
     "xrl_marl_act_gru": [C.POINTER(MarlActGru), c_void_p],
+    "xrl_mlp_chain_fwd": [C.POINTER(MlpChain), c_void_p],
+    "xrl_mlp_chain_lds_bytes": [C.POINTER(MlpChain)],
+    "xrl_debug_mlp_chain_stamps": [c_void_p],
     "xrl_act_tail": [C.POINTER(ActTail), c_void_p],
     "xrl_debug_act_tail_stamps": [c_void_p],
     "xrl_post_norm": [C.POINTER(PostStep), C.POINTER(Rms), c_void_p],

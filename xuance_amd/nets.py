@@ -150,6 +150,38 @@ class Plan:
             ops.linear_fwd(groups)
         return self.acts[len(self.widths) - 1]
 
+    # -- the whole plan as ONE launch (xrl_mlp_chain_fwd, csrc/mlp_chain.hip; round 6) ----------------------------------------------
+    def chain_job(self, x, ldx, M, flat=None, levels=None):
+        """The plan as a job of ops.mlp_chain_desc: layers in stage order, every level written back to self.acts (`levels`: only
+        those -- e.g. the output level of a pass that no backward follows).  None if the launch cannot take the plan: more than 8
+        layers / 6 levels, a split-K layer, a layer input that does not start on a 16-byte column."""
+        self.ensure(M)
+        layers = [L for stage in self.stages for L in stage]
+        if len(layers) > 8 or len(self.widths) > 6 or any(self._split_k(L, M)[1] for L in layers) or any(L.in_off & 3 for L in layers):
+            return None
+        P = self.params
+        base = (P.flat if flat is None else flat).data_ptr()
+        out = {lvl: (self.acts[lvl].data_ptr(), self.widths[lvl]) for lvl in range(1, len(self.widths)) if levels is None or lvl in levels}
+        return dict(x=x.data_ptr() if isinstance(x, torch.Tensor) else int(x), ldx=ldx, M=M, params=base, level_width=list(self.widths), out=out,
+                    layers=[dict(w_off=P.offsets[L.w_name], b_off=P.offsets[L.b_name], K=L.K, N=L.N, act=ops.ACT[L.act], in_level=L.in_level,
+                                 in_off=L.in_off, out_level=L.out_level, out_off=L.out_off) for L in layers])
+
+    @staticmethod
+    def forward_chain(items, levels=None):
+        """forward_many as ONE launch: items = [(plan, x, ldx, M, flat)], at most 4.  Returns each plan's output level, or None when
+        one of the plans does not fit the launch (the caller then takes forward_many).  Same numbers, bit for bit."""
+        if not (1 <= len(items) <= 4) or not ops.fast_kernels_enabled():
+            return None
+        jobs = [plan.chain_job(x, ldx, M, flat, levels) for plan, x, ldx, M, flat in items]
+        if any(j is None for j in jobs):
+            return None
+        desc = ops.mlp_chain_desc(jobs)
+        nb = ops.mlp_chain_lds_bytes(desc)
+        if nb < 0 or nb > 160 * 1024:
+            return None
+        ops.mlp_chain_fwd(desc)
+        return [it[0].acts[len(it[0].widths) - 1] for it in items]
+
     @staticmethod
     def forward_many(items, skip_last=False):
         """Several independent plans as ONE grouped launch per stage (an eval network and its target twin; the agent
@@ -402,9 +434,20 @@ class ActorCriticNet:
         return [self.params.view(n) for n in self.ref_order]
 
     # -- compute -------------------------------------------------------------------------------------
+    CHAIN_MAX_ROWS = 1024
+
     def forward(self, x, M, ldx=None):
-        """Returns the head buffer [cap, action_dim+1]: columns [0,A) actor output, column A the value."""
-        return self.plan.forward(x, self.obs_dim if ldx is None else ldx, M)
+        """Returns the head buffer [cap, action_dim+1]: columns [0,A) actor output, column A the value.  use_chain_forward = True
+        (default False) and at most CHAIN_MAX_ROWS rows: the whole plan as ONE launch (Plan.forward_chain, xrl_mlp_chain_fwd) --
+        bit-identical and measured no faster: 21.6 us against 19.6 us for the three launches of an acting pass
+        (tools/probe_mlp_chain.py, profiles/r06_p_mlp_chain.json: every phase of the single workgroup per tile is a handful of
+        dependent LDS / global round trips, where the per-stage launches overlap theirs across 16-64 workgroups)."""
+        ld = self.obs_dim if ldx is None else ldx
+        if M <= self.CHAIN_MAX_ROWS and getattr(self, "use_chain_forward", False):
+            out = Plan.forward_chain([(self.plan, x, ld, M, None)])
+            if out is not None:
+                return out[0]
+        return self.plan.forward(x, ld, M)
 
     def forward_values(self, x, M, ldx=None):
         """The head buffer with only column A (the value) computed: the critic branch alone where the network has no shared
@@ -837,10 +880,16 @@ class MixingQNet:
         layers above the recurrence.  Returns [Q_eval, Q_target, outputs of the ride-along plans...]."""
         H, M, tf = self.RH, T1 * R, self.target_flat
         ws0, ws1 = self.seq_workspace(0, R, T1), self.seq_workspace(1, R, T1)
-        gi0, gi1 = Plan.forward_many([(self.pre_plans[0], X, self.obs_dim, M, None), (self.pre_plans[1], X, self.obs_dim, M, tf)])
+        # (round 6, use_chain_forward = True; off by default: measured slower) the layers below the recurrence as ONE launch, the layers
+        # above it (+ the ride-along plans) as one: Plan.forward_chain (xrl_mlp_chain_fwd; bit-identical to the launch per stage)
+        chain = getattr(self, "use_chain_forward", False) and M <= 1024    # (default False; 5 856 rows: 106 -> 123 us per update)
+        pre = [(self.pre_plans[0], X, self.obs_dim, M, None), (self.pre_plans[1], X, self.obs_dim, M, tf)]
+        out = Plan.forward_chain(pre) if chain else None
+        gi0, gi1 = out if out is not None else Plan.forward_many(pre)
         self._recurrence(gi0, ws0, R, T1, None, True, second=(gi1, ws1, tf))
-        return Plan.forward_many([(self.post_plans[0], ws0["hs"][R:], H, M, None), (self.post_plans[1], ws1["hs"][R:], H, M, tf)]
-                                 + list(ride_along))
+        post = [(self.post_plans[0], ws0["hs"][R:], H, M, None), (self.post_plans[1], ws1["hs"][R:], H, M, tf)] + list(ride_along)
+        out = Plan.forward_chain(post) if chain else None
+        return out if out is not None else Plan.forward_many(post)
 
     def agent_backward_seq(self, X, R, T1, slabs, n_split, defer_wgrad=None):
         """post_plans[0].dacts[last] holds dLoss/dQ [T1*R, A]: data-gradient chain Q head -> BPTT -> layers below the

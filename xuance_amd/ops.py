@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import XrlError  # noqa: F401  (re-exported)
-from ._lib import (ActTail, Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, RolloutWide, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, OptChain, CHAIN_SYNC_WORDS, MarlAct, call, ptr,
+from ._lib import (ActTail, MlpChain, Conv, ImageJob, DqnHeadTd, DqnTailTd, DqnActTail, Classic, Exchange, MarlGate, SynthMarl, SynthFrames, LstmFwd, LstmBwd, EpisodeField, GruFwd, GruBwd, Mirrors, RolloutRun, RolloutWide, SynthCtl, ACT, Field, Gemm, PpoLoss, AdamState, Rms, Sample, CartPole, PostStep, EGreedy, DqnTd, Qmix, RolloutStep, FusedLayer, PpoFused, OptChain, CHAIN_SYNC_WORDS, MarlAct, call, ptr,
                    stream_ptr)
 
 
@@ -429,6 +429,37 @@ def _struct(cls, kw):
 
 def obs_normalize(**kw):
     call("xrl_obs_normalize", C.byref(_struct(Rms, kw)), stream_ptr())
+
+
+def mlp_chain_desc(jobs):
+    """xrl_mlp_chain_t of up to 4 jobs: dict(x, ldx, M, params (pointer), layers [dict(w_off, b_off, K, N, act, in_level, in_off,
+    out_level, out_off)], level_width [..], out {level: (pointer, ld)})."""
+    q = MlpChain()
+    q.n_jobs = len(jobs)
+    t = 0
+    for j, jb in enumerate(jobs):
+        J = q.job[j]
+        J.x, J.ldx, J.M, J.params = int(jb["x"]), int(jb["ldx"]), int(jb["M"]), int(jb["params"])
+        J.n_layers, J.n_levels = len(jb["layers"]), len(jb["level_width"])
+        for l, w in enumerate(jb["level_width"]):
+            J.level_width[l] = int(w)
+        for l, L in enumerate(jb["layers"]):
+            for k, v in L.items():
+                setattr(J.layers[l], k, int(v))
+        for l, (pt, ld) in jb.get("out", {}).items():
+            J.out[l], J.ld_out[l] = int(pt), int(ld)
+        q.tile0[j] = t
+        t += (int(jb["M"]) + 31) // 32
+    q.tile0[len(jobs)] = t
+    return q
+
+
+def mlp_chain_lds_bytes(desc):
+    return int(_lib.load().xrl_mlp_chain_lds_bytes(C.byref(desc)))
+
+
+def mlp_chain_fwd(desc):
+    call("xrl_mlp_chain_fwd", C.byref(desc), stream_ptr())
 
 
 def post_norm(post, rms):
