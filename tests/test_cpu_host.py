@@ -36,7 +36,11 @@ def test_ctypes_structs_match_c_layout():
              "xrl_ppo_wide_t": _lib.PpoWide, "xrl_wide_act_t": _lib.WideAct, "xrl_conv_t": _lib.Conv, "xrl_classic_t": _lib.Classic,
              "xrl_dqn_head_td_t": _lib.DqnHeadTd, "xrl_dqn_tail_td_t": _lib.DqnTailTd, "xrl_dqn_act_tail_t": _lib.DqnActTail,
              "xrl_marl_act_t": _lib.MarlAct, "xrl_marl_act_gru_t": _lib.MarlActGru, "xrl_rollout_run_t": _lib.RolloutRun,
-             "xrl_rollout_wide_t": _lib.RolloutWide}
+             "xrl_rollout_wide_t": _lib.RolloutWide,
+             # round 6
+             "xrl_act_tail_t": _lib.ActTail, "xrl_mlp_chain_job_t": _lib.MlpChainJob, "xrl_mlp_chain_t": _lib.MlpChain,
+             "xrl_ppo_act_tail_t": _lib.PpoActTail, "xrl_opt_chain_t": _lib.OptChain, "xrl_qmix_phase_t": _lib.QmixPhase,
+             "xrl_qa_image_t": _lib.QaImage}
     for extra in ("xrl_dqn_td_t", "xrl_qmix_t"):
         cls = getattr(_lib, {"xrl_dqn_td_t": "DqnTd", "xrl_qmix_t": "Qmix"}[extra], None)
         if cls is not None:
@@ -52,7 +56,11 @@ def test_ctypes_structs_match_c_layout():
             "xrl_poststep_t": (_lib.PostStep, ("ret_count", "n", "gamma", "pg_bootv")),
             "xrl_marl_gate_t": (_lib.MarlGate, ("ring", "reset_rule", "done", "ptr_size", "buffer_size", "end_step")),   # round 5
             "xrl_egreedy_t": (_lib.EGreedy, ("eps", "seed", "step_dev")), "xrl_marl_act_t": (_lib.MarlAct, ("eps", "seed")),
-            "xrl_marl_act_gru_t": (_lib.MarlActGru, ("eps_dev", "step", "eps")),
+            "xrl_marl_act_gru_t": (_lib.MarlActGru, ("eps_dev", "step", "eps", "lds_staged")),
+            "xrl_act_tail_t": (_lib.ActTail, ("heads", "ldh", "boot_rows", "env_kind", "act_actor", "sample", "classic", "cartpole")),
+            "xrl_mlp_chain_job_t": (_lib.MlpChainJob, ("layers", "n_layers", "level_width", "out", "ld_out", "ldx", "M")),
+            "xrl_mlp_chain_t": (_lib.MlpChain, ("n_jobs", "tile0")),
+            "xrl_qa_image_t": (_lib.QaImage, ("image_floats", "lds_bytes", "interleaved")),
             "xrl_dqn_tail_td_t": (_lib.DqnTailTd, ("partials", "M", "act", "gamma", "huber_delta", "slabs", "slab_stride", "off_b2")),
             "xrl_dqn_head_td_t": (_lib.DqnHeadTd, ("partials", "act", "gamma", "huber_delta")),                 # round 5: Huber switch
             "xrl_dqn_td_t": (_lib.DqnTd, ("partials", "gamma", "dueling", "huber_delta")),
