@@ -297,7 +297,9 @@ typedef struct {
                              * target_image[map[0][i]] (map[0][i] < 0: skip) */
     int64_t fold_off;       /* xrl_reduce_adam only: slab columns [fold_off, fold_off + fold_len) are a second partial of */
     int32_t fold_len;       /* columns [0, fold_len) (ppo_split_kernel's critic-role first-layer gradient); 0 = none */
-    int32_t pad;
+    int32_t split_plane;    /* SPLIT mirror stores: a map value j <= -2 names 16-bit element e = -(j + 2) of dst (read as uint16_t*): the
+                             * new parameter w goes there as three bf16 parts, dst16[e] = bf16(w), dst16[e + split_plane] = bf16(w - h),
+                             * dst16[e + 2 split_plane] = bf16(w - h - m) (xrl_pack_mid_frags16's planes).  0 with no such map. */
     /* xrl_reduce_adam[_exchange] only -- two bookkeeping launches of an update phase riding in the optimiser launch (one of
      * its blocks does them next to its slab loads; at the DQN-C3 update they were 8 of 150 us as launches of their own): */
     uint32_t* tick;         /* NULL, or a device counter advanced by tick_inc (xrl_counter_add: the replay draw counter) */
@@ -871,6 +873,9 @@ typedef struct {
     int32_t out_act;            /* Gaussian: activation_action on the mean, XRL_ACT_NONE | XRL_ACT_TANH (actor_head.py:62) */
     int32_t log_std_off;        /* Gaussian: float offset of actor.log_std [A] in params / a slab row */
     int32_t pad3;
+    const uint16_t* frag16;     /* NULL, or the xrl_pack_mid_frags16 image of the branch layer (three bf16 planes): with 64-row tiles and the
+                                 * CartPole class ((D, A) = (4, 2), categorical) the minibatch launch then forms its three 128-wide products
+                                 * as exact 3-way bf16 splits on the matrix cores (csrc/ppo_trunk_bx.hip) */
 } xrl_ppo_fused_t;
 int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* p, xrl_stream_t stream);
 /* The minibatch launch of the shared-trunk family (l0_fold_off > 0) CHAINED to the optimiser step of the minibatch before it:
@@ -919,6 +924,18 @@ int xrl_gather_rows(const float* packed, const int64_t* idx, float* out, int64_t
  * (the slot rotation spreads the simultaneous fetches of a workgroup's waves over all L2 channels)
  * Only params/layers of *p are read; frag_floats >= 2*N*K. */
 int xrl_pack_mid_frags(const xrl_ppo_fused_t* p, float* frag, int64_t frag_floats, xrl_stream_t stream);
+/* image <- the stacked branch layer W[256][128] of the shared-trunk family as THREE bf16 planes h | m | l (XRL_FRAG16_PLANE elements
+ * each) with  W[n][k] == h + m + l  exactly:  h = bf16(w), m = bf16(w - h), l = bf16(w - h - m), round-to-nearest-even.  Inside a
+ * plane, in the order the lanes of v_mfma_f32_32x32x16_bf16 consume it (a lane's 8 elements contiguous, a wave's load 1 KB):
+ *   forward section  [8 tiles t][8 k-steps][64 lanes][8]: W[32 t + (l & 31)][16 qq + 8 (l >> 5) + e] in slot (qq + t) mod 8 of tile t
+ *   backward section [4 tiles kt][16 n-steps][64 lanes][8]: W[16 q + 8 (l >> 5) + e][32 kt + (l & 31)] in slot (q + kt) mod 16 (offset 256*128)
+ * The optimiser launches keep it current through SPLIT mirror maps (xrl_mirrors_t.split_plane).  image_elems >= 3 * XRL_FRAG16_PLANE.
+ * Replaces nothing in the reference: it is a derived layout of policy.actor / critic first Linear (policies/categorical.py ActorCriticPolicy). */
+#define XRL_FRAG16_PLANE (2 * 256 * 128)
+int xrl_pack_mid_frags16(const xrl_ppo_fused_t* p, uint16_t* image, int64_t image_elems, xrl_stream_t stream);
+/* diagnostics: the split-product kernel's weight-gradient operands through ds_read_b64_tr_b16 (1, default) or 2-byte LDS reads (0);
+ * same numbers either way. */
+int xrl_set_split_product_tr(int on);
 /* ------------------------------------------------------------------ fused PPO minibatch, two-branch Gaussian actor-critic
  * D-256-256-{A | 1} (configs/ppo/mujoco.yaml:8-13: Basic_Identical representation, actor / critic hidden [256, 256];
  * policies/gaussian.py ActorCriticPolicy, ppo_learner.py:46-62).  ONE launch per minibatch, two workgroups (actor branch,

@@ -195,12 +195,15 @@ def _load_rows(memory, b, n, T):
 
 
 @pytest.mark.parametrize("size,n,T,kernel", [("c2", 32, 256, "split"), ("c1", 4, 32, "split"), ("c1", 4, 32, "unsplit"),
-                                             ("c2", 32, 256, "any-shape"), ("c2", 32, 256, "pair"), ("c1", 4, 32, "pair")])
+                                             ("c2", 32, 256, "any-shape"), ("c2", 32, 256, "pair"), ("c1", 4, 32, "pair"),
+                                             ("c2", 32, 256, "pair-f32"), ("c1", 4, 32, "pair-f32")])
 def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
     """The ONE-LAUNCH minibatch kernels pinned to the reference directly, at its own sizes: the rows of the C2 (8 192) / C1
     (128) fixtures are loaded into a HipOnPolicyBuffer and go through gather -> forward -> loss -> backward (xrl_ppo_fused_minibatch:
     ppo_trunk_kernel with (32-row tile, role) workgroups -- "split": 512 workgroups / 256 gradient slabs at C2 -- and with (64-row
-    tile, role) workgroups -- "pair": 128 slabs at C2, the headline's kernel --, the any-shape ppo_fused_kernel with the specialised
+    tile, role) workgroups -- "pair": 128 slabs at C2, the headline's kernel: ppo_trunk_bx_kernel, the 128-wide products as exact
+    3-way bf16 splits on the matrix cores; "pair-f32": the same tiles on the float32 matrix instruction (use_split_products: False)
+    --, the any-shape ppo_fused_kernel with the specialised
     kernels switched off or the role split declined -- "unsplit")
     and xrl_reduce_adam, exactly as PPO_Agent's update phase enqueues them; compared with the reference's `u*/grad` (clipped),
     its float64 twin, its parameter steps and Adam moments (reference: ppo_learner.py:46-67).  The fixture's advantages are
@@ -216,7 +219,8 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
                     gamma=0.98, use_gae=True, gae_lambda=0.95, use_advnorm=True, use_grad_clip=True, grad_clip_norm=float(gclip),
                     end_factor_lr_decay=float(ef), use_obsnorm=False, use_rewnorm=False, obsnorm_range=5, rewnorm_range=5,
                     distributed_training=False, device="cuda", model_dir="/tmp/xrl_models", use_hip_graph=False,
-                    use_role_split_update=(kernel in ("split", "pair")), use_pair_update=(kernel == "pair"))
+                    use_role_split_update=(kernel in ("split", "pair", "pair-f32")), use_pair_update=kernel.startswith("pair"),
+                    use_split_products=(kernel == "pair"))
     prev = ops.fast_kernels_enabled()
     ops.set_fast_kernels(kernel != "any-shape")
     try:
@@ -228,7 +232,8 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
                                  tol=1e-5, tol_except=C2_EXCEPT if size == "c2" else None)
         idx = torch.arange(n * T, dtype=torch.int64, device="cuda").view(1, -1)
         lr_.prepare_fused(mem, n * T)
-        assert lr_.split == (kernel in ("split", "pair")) and lr_.pair == (kernel == "pair")
+        assert lr_.split == (kernel in ("split", "pair", "pair-f32")) and lr_.pair == kernel.startswith("pair")
+        assert (lr_.frag16 is not None) == (kernel == "pair")
         lr_.prepare_rows(idx.numel())
         for u in range(int(g["n_updates"])):
             _load_rows(mem, sub(g, f"u{u}/batch"), n, T)
@@ -586,3 +591,118 @@ def test_pg_learner_vs_reference_fixture(dist):
         assert_close(rec["log_prob"], ref_cb["log_prob"], 1e-6, "log_prob", scale=max(1.0, float(np.abs(ref_cb["log_prob"]).max())))
         chk.after_update(u)
     chk.finish()
+
+
+def _pair_agent(n, T, split_products, seed=3, **kw):
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceCartPoleVecEnv
+    cfg = Namespace(representation="Basic_MLP", representation_hidden_size=[128], actor_hidden_size=[128], critic_hidden_size=[128],
+                    activation=kw.get("activation", "leaky_relu"), seed=seed, parallels=n, running_steps=1000 * n * T, horizon_size=T,
+                    n_epochs=1, n_minibatch=1, learning_rate=7e-4, vf_coef=0.25, ent_coef=0.01, clip_range=0.2, gamma=0.98, use_gae=True,
+                    gae_lambda=0.95, use_advnorm=True, use_grad_clip=True, grad_clip_norm=0.5, end_factor_lr_decay=0.5,
+                    use_obsnorm=False, use_rewnorm=False, obsnorm_range=5, rewnorm_range=5, distributed_training=False, device="cuda",
+                    model_dir="/tmp/xrl_models", use_hip_graph=False, use_role_split_update=True, use_pair_update=True,
+                    use_split_products=split_products)
+    return PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=seed))
+
+
+def _bf16_planes_to_float(img, plane):
+    """float32 value of every element of a three-plane bf16 image: (h + m) + l, each part widened exactly."""
+    u = img.view(torch.int16).to(torch.int32) & 0xFFFF
+    f = (u << 16).view(torch.float32)
+    return (f[:plane] + f[plane:2 * plane]) + f[2 * plane:3 * plane], f
+
+
+def test_split_fragment_image_is_exact_and_follows_its_maps():
+    """xrl_pack_mid_frags16: every weight of the branch layer appears in both sections of the image as three bf16 parts whose sum IS
+    the float32 weight (bit for bit), |m| <= 2^-8 |h|, |l| <= 2^-16 |h|; the positions are the ones the split mirror maps name
+    (ops.frag16_layout_maps = csrc/split3.h's index formulas); and after optimiser steps through those maps (xrl_reduce_adam's split
+    mirror stores) the image equals a fresh pack of the new parameters."""
+    from xuance_amd import ops
+    agent = _pair_agent(32, 64, True)
+    lr_, net = agent.learner, agent.model
+    lr_.prepare_fused(agent.memory, 32 * 64)
+    assert lr_.frag16 is not None and lr_.pair
+    P = net.params.P
+    torch.manual_seed(5)
+    net.params.flat.copy_(torch.randn(P, device="cuda") * torch.logspace(-6, 2, P, device="cuda")[torch.randperm(P, device="cuda")])
+    lr_.refresh_fused_params()
+    torch.cuda.synchronize()
+    plane = ops.FRAG16_PLANE
+    val, parts = _bf16_planes_to_float(lr_.frag16, plane)
+    mf, mb = ops.frag16_layout_maps(net.plan, P, "cuda")
+    for mp in (mf, mb):
+        i = torch.nonzero(mp <= -2).flatten()
+        assert i.numel() == 256 * 128
+        e = (-(mp[i].to(torch.int64) + 2))
+        w = net.params.flat[i]
+        assert torch.equal(val[e].view(torch.int32), w.view(torch.int32))
+        h, m, l = parts[e], parts[plane + e], parts[2 * plane + e]
+        assert bool((m.abs() <= h.abs() * 2.0 ** -8).all()) and bool((l.abs() <= h.abs() * 2.0 ** -16).all())
+    assert torch.unique(torch.cat([-(mf[mf <= -2].long() + 2), -(mb[mb <= -2].long() + 2)])).numel() == plane
+    # optimiser steps keep it current
+    agent.train(2 * 64)
+    torch.cuda.synchronize()
+    kept = lr_.frag16.clone()
+    lr_.frag16.zero_()
+    ops.pack_mid_frags16(net.plan, net.params.flat, lr_.frag16)
+    torch.cuda.synchronize()
+    assert torch.equal(kept, lr_.frag16)
+
+
+@pytest.mark.parametrize("activation", ["leaky_relu", "relu", "tanh"])
+def test_split_product_minibatch_against_the_float32_instruction(activation):
+    """ppo_trunk_bx_kernel beside ppo_trunk_kernel<.., 64, 4, 2> on the same rollout and the same parameters: every gradient slab
+    element, loss partial and diagnostic within 2e-6 of the tensor's scale (the six-product form drops <= 2^-23 per scalar product;
+    everything outside the three products is the same statement), the first-layer products bit-identical -- and the weight-gradient
+    operands through the LDS transpose read or through 2-byte reads give the SAME bits (they are two ways of loading the same planes)."""
+    from xuance_amd import ops
+    n, T = 64, 64
+    out = {}
+    for tag, split in (("bx", True), ("f32", False)):
+        agent = _pair_agent(n, T, split, activation=activation)
+        lr_, mem = agent.learner, agent.memory
+        agent.train(T)                                                # one rollout + one update phase: a real buffer, moved parameters
+        torch.cuda.synchronize()
+        if tag == "bx":
+            ref_agent = agent
+        else:                                                         # same parameters and rollout for the comparison launch
+            agent.model.params.flat.copy_(ref_agent.model.params.flat)
+            for k, v in ref_agent.memory.soa.fields.items():
+                mem.soa.fields[k].copy_(v)
+        lr_.prepare_fused(mem, n * T)
+        idx = torch.randperm(n * T, device="cuda").view(1, -1)
+        if tag != "bx":
+            idx = out["idx"]
+        out["idx"] = idx
+        lr_.prepare_rows(idx.numel())
+        lr_.refresh_fused_params(mem, idx)
+        assert (lr_.frag16 is not None) == split and lr_.pair
+        lr_.enqueue_minibatch_fused(mem, idx[0], None, finish=False)
+        torch.cuda.synchronize()
+        out[tag] = (lr_.fslabs[:n * T // 64].clone(), lr_.fpartials.clone())
+        if tag == "bx":
+            ops.set_split_product_tr(False)
+            try:
+                lr_.fslabs.zero_()
+                lr_.enqueue_minibatch_fused(mem, idx[0], None, finish=False)
+                torch.cuda.synchronize()
+                assert torch.equal(lr_.fslabs[:n * T // 64], out["bx"][0]), "transpose-read and 2-byte-read operands differ"
+            finally:
+                ops.set_split_product_tr(True)
+    (sb, pb), (sf, pf) = out["bx"], out["f32"]
+    P = ref_agent.model.params.P
+    gb, gf = sb.double().sum(0), sf.double().sum(0)
+    offs = ref_agent.model.params.offsets
+    names = sorted(offs, key=lambda k: offs[k])
+    from conftest import _record
+    for k in names:
+        lo, hi = offs[k], offs[k] + int(np.prod(ref_agent.model.params.shapes[k]))
+        a, b = gb[lo:hi], gf[lo:hi]
+        S = float(b.abs().max()) + 1e-30
+        err = float((a - b).abs().max()) / S
+        _record(f"split-product minibatch vs float32 instruction, {activation} {k}", err, err, 2e-6, a.numel())
+        assert err <= 2e-6, (k, err)
+    # fold region (the critic role's first-layer gradient) rides behind the parameters
+    assert float((gb[P:] - gf[P:]).abs().max()) <= 2e-6 * (float(gf[P:].abs().max()) + 1e-30)
+    assert torch.allclose(pb, pf, rtol=1e-6, atol=1e-9)

@@ -277,7 +277,7 @@ class PpoFused(C.Structure):
                 ("slab_stride", c_int64), ("M", c_int32), ("n_envs", c_int32), ("T", c_int32), ("D", c_int32),
                 ("A", c_int32), ("l0_fold_off", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
                 ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p),
-                ("dist", c_int32), ("out_act", c_int32), ("log_std_off", c_int32), ("pad3", c_int32)]
+                ("dist", c_int32), ("out_act", c_int32), ("log_std_off", c_int32), ("pad3", c_int32), ("frag16", c_void_p)]
 
 
 class WideBranch(C.Structure):
@@ -366,7 +366,7 @@ class MarlGate(C.Structure):
 
 class Mirrors(C.Structure):
     _fields_ = [("map", c_void_p * 4), ("dst", c_void_p * 4), ("n", c_int32), ("target_every", c_int32), ("target", c_void_p),
-                ("target_image", c_void_p), ("fold_off", c_int64), ("fold_len", c_int32), ("pad", c_int32), ("tick", c_void_p),
+                ("target_image", c_void_p), ("fold_off", c_int64), ("fold_len", c_int32), ("split_plane", c_int32), ("tick", c_void_p),
                 ("part", c_void_p), ("part_out", c_void_p), ("tick_inc", c_int32), ("part_rows", c_int32),
                 ("alt_lo", c_int64 * 2), ("alt_hi", c_int64 * 2), ("alt_split", c_int32), ("pad2", c_int32)]
 
@@ -395,6 +395,8 @@ _SIGS = {
     "xrl_ppo_trunk_chain_fits": [c_int32, c_int32, c_int64],
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
+    "xrl_pack_mid_frags16": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
+    "xrl_set_split_product_tr": [c_int32],
     "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],
     "xrl_ppo_wide_pack": [C.POINTER(PpoWide), c_void_p, c_void_p],
     "xrl_wide_dw1": [C.POINTER(PpoWide), C.POINTER(c_int32), c_void_p],

@@ -4,6 +4,7 @@
 //  base/marl_learner.py:64-75 with multi_agent_rl/qmix_learner.py:88-96).
 // The optimiser state (step counters, learning rate) lives in device memory so a captured hipGraph advances it.
 #include "common.h"
+#include "split3.h"
 
 namespace xrl {
 
@@ -168,10 +169,10 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
 #pragma unroll
             for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
                 if (q < mir.n) {
-                    if (mp[q].x >= 0) mir.dst[q][mp[q].x] = pn.x;
-                    if (mp[q].y >= 0) mir.dst[q][mp[q].y] = pn.y;
-                    if (mp[q].z >= 0) mir.dst[q][mp[q].z] = pn.z;
-                    if (mp[q].w >= 0) mir.dst[q][mp[q].w] = pn.w;
+                    mirror_store(mir.dst[q], mp[q].x, pn.x, mir.split_plane);
+                    mirror_store(mir.dst[q], mp[q].y, pn.y, mir.split_plane);
+                    mirror_store(mir.dst[q], mp[q].z, pn.z, mir.split_plane);
+                    mirror_store(mir.dst[q], mp[q].w, pn.w, mir.split_plane);
                 }
             if (sync_target) {
                 reinterpret_cast<float4*>(mir.target)[q4] = pn;
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(RED_THREADS) adam_step_kernel(float* __restric
             // derived layouts kept in sync in the same launch (transposed middle weights, packed LDS-cache image)
 #pragma unroll
             for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
-                if (q < mir.n) { const int j = mir.map[q][i]; if (j >= 0) mir.dst[q][j] = pn; }
+                if (q < mir.n) mirror_store(mir.dst[q], mir.map[q][i], pn, mir.split_plane);
             if (sync_target) {
                 mir.target[i] = pn;
                 if (mir.target_image) { const int j = mir.map[0][i]; if (j >= 0) mir.target_image[j] = pn; }
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(RED_THREADS * G) reduce_adam_kernel(const floa
         params[i] = pn;
 #pragma unroll
         for (int q = 0; q < XRL_MAX_MIRRORS; ++q)
-            if (q < mir.n && mj[q] >= 0) mir.dst[q][mj[q]] = pn;
+            if (q < mir.n) mirror_store(mir.dst[q], mj[q], pn, mir.split_plane);
         if (mir.target && mir.target_every > 0 && step % mir.target_every == 0) {
             mir.target[i] = pn;
             if (mir.target_image && mj[0] >= 0) mir.target_image[mj[0]] = pn;
@@ -553,7 +554,7 @@ extern "C" int xrl_reduce_adam_exchange(const float* slabs, int n_split, int64_t
     }
     xrl_mirrors_t mir{};
     if (mirrors) mir = *mirrors;
-    XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);
+    XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS && mir.split_plane >= 0);
     for (int q = 0; q < mir.n; ++q) XRL_CHECK_ARG(mir.map[q] && mir.dst[q]);
     XRL_CHECK_ARG(mir.target_image == nullptr || (mir.n >= 1 && mir.target));
     XRL_CHECK_ARG(mir.fold_len >= 0 && (mir.fold_len & 3) == 0 && (mir.fold_off & 3) == 0 &&
@@ -693,7 +694,7 @@ extern "C" int xrl_adam_step_mirrors(float* params, float* grad, float* m, float
     XRL_CHECK_ARG(params && grad && m && v && state && sumsq_part && P > 0 && n_part >= 1 && n_part <= 1024);
     xrl_mirrors_t mir{};
     if (mirrors) mir = *mirrors;
-    XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);
+    XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS && mir.split_plane >= 0);
     for (int q = 0; q < mir.n; ++q) XRL_CHECK_ARG(mir.map[q] && mir.dst[q]);
     launch_adam_step(params, grad, m, v, P, state, sumsq_part, n_part, max_norm, mir, as_stream(stream));
     XRL_CHECK_LAUNCH();

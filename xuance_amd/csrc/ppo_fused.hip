@@ -407,11 +407,15 @@ bool ppo_trunk_eligible(const xrl_ppo_fused_t& p);
 int launch_ppo_trunk(const xrl_ppo_fused_t& p, const xrl_opt_chain_t* o, hipStream_t stream);
 int init_ppo_trunk();
 int init_ppo_fused();
+bool ppo_trunk_bx_eligible(const xrl_ppo_fused_t& p);           // csrc/ppo_trunk_bx.hip: the CartPole class on exact 3-way bf16 splits
+int launch_ppo_trunk_bx(const xrl_ppo_fused_t& p, hipStream_t stream);
+int init_ppo_trunk_bx();
 }
 using namespace xrl;
 
 int xrl::init_ppo_fused() {
     if (int rc = init_ppo_trunk()) return rc;
+    if (int rc = init_ppo_trunk_bx()) return rc;
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_fused_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     return XRL_OK;
@@ -426,6 +430,7 @@ extern "C" int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* pp, xrl_stream_t s
     // the shared-trunk family D-128-{128-A | 128-1} (D <= 24, A <= 8, categorical | Gaussian): (tile, role) workgroups, 32- or 64-row tiles
     if (p.l0_fold_off > 0) {
         if (!g_fast_enabled_ppo || !ppo_trunk_eligible(p)) { set_error("xrl_ppo_fused_minibatch: a fold region was given but the network is not of the shared-trunk family (csrc/ppo_trunk.hip)"); return XRL_EINVAL; }
+        if (ppo_trunk_bx_eligible(p)) return launch_ppo_trunk_bx(p, as_stream(stream));
         return launch_ppo_trunk(p, nullptr, as_stream(stream));
     }
     XRL_CHECK_ARG(p.params_t && p.cache_image && (reinterpret_cast<uintptr_t>(p.cache_image) & 15) == 0);

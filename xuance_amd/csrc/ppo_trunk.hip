@@ -695,6 +695,7 @@ extern "C" int xrl_ppo_trunk_chained(const xrl_ppo_fused_t* pp, const xrl_opt_ch
     XRL_CHECK_ARG(mir.n >= 0 && mir.n <= XRL_MAX_MIRRORS);
     for (int q = 0; q < mir.n; ++q) XRL_CHECK_ARG(mir.map[q] && mir.dst[q]);
     XRL_CHECK_ARG(mir.target == nullptr && mir.target_image == nullptr && mir.tick == nullptr && mir.part == nullptr && mir.part_out == nullptr && mir.alt_split == 0);
+    XRL_CHECK_ARG(mir.split_plane == 0 && p.frag16 == nullptr);   // (the chained launch has no split-product instances and no split mirror stores)
     XRL_CHECK_ARG(mir.fold_len >= 0 && (mir.fold_len & 3) == 0 && (mir.fold_off & 3) == 0 &&
                   (mir.fold_len == 0 || (mir.fold_off >= o.P && mir.fold_off + mir.fold_len <= o.slab_stride && mir.fold_len <= o.P)));
     const int tile_rows = p.pad0 == 64 ? 64 : 32;

@@ -1,0 +1,566 @@
+// The headline's minibatch launch with its three 128-wide products as EXACT 3-WAY bf16 SPLITS on the matrix cores.
+//
+// csrc/ppo_trunk.hip spends 51 % of a wave's life behind v_mfma_f32_32x32x2_f32 (64 pipe cycles for 4 096 flop: the fp32 matrix
+// instruction runs at the fp32 VECTOR rate and shares its issue with it -- DESIGN.md section 3 "Round 6" (b)).  The bf16 instruction
+// v_mfma_f32_32x32x16_bf16 does 8x the k-depth in HALF the pipe cycles.  A float32 x is the exact sum of three bf16 numbers
+//      h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)        (round-to-nearest-even; 3 x 8 significand bits = 24; both
+//                                                                  subtractions and the last conversion are exact)
+// so a product of two float32 numbers is the exact sum of nine bf16 x bf16 products, each of which the matrix core forms exactly
+// and accumulates in float32.  This kernel issues the six largest -- (h,h) (h,m) (m,h) (m,m) (h,l) (l,h): what is dropped,
+// (m,l) + (l,m) + (l,l), is <= 2^-23 |x y| per scalar product, signed at random: the size of ONE float32 rounding of that product,
+// i.e. of the error the fp32 instruction's own accumulation makes per term.  Six bf16 instructions (192 pipe cycles) replace eight fp32
+// ones (512) for the same 32 x 32 x 16 block: the matrix pipe is busy 9.3 k instead of 24.8 k cycles per SIMD.
+// What it is NOT: a bf16 computation.  No operand is rounded to 8 (or 16) bits; the parity fixtures hold at the same 1e-5 as the
+// fp32 kernel (tests/test_gpu_ppo.py: test_split_product_minibatch_*), and against the float64 twin the gradients are as close as
+// the fp32 kernel's (profiles/r06_q_*).
+//
+// Where the splits are made (a split costs ~4.5 vector instructions per element, and the vector ALU shares the matrix pipe's issue:
+// splitting at every CONSUMER would cost what the bf16 instructions save):
+//   * W1 (both orientations): by the OPTIMISER launch -- the fragment image this kernel streams holds three bf16 planes
+//     (xrl_pack_mid_frags16; kept current through split mirror maps, xrl_mirrors_t.split_plane);
+//   * h1 and g2 = dLoss/dz2: once, by the thread that PRODUCES the element, into three row-major 16-bit planes in LDS (6 bytes per
+//     element instead of 4); all three products read them: forward and backward-data as 16-byte row reads, the weight gradient
+//     (k = the row axis: a column slice per lane) through ds_read_b64_tr_b16, the LDS transpose read of gfx950;
+//   * h2 stays float32 (only the vector phases read it).
+// The first layer (k = 4: two fp32 instructions) stays on v_mfma_f32_32x32x2_f32: same numbers as ppo_trunk_kernel.  It and the
+// branch layer are issued TRANSPOSED (A = weights, B = rows): a lane then holds 4 CONSECUTIVE columns of one row, and h1's planes /
+// h2 are written as 8- / 16-byte stores instead of 2- / 4-byte ones.
+//
+// Class: the CartPole class of the shared-trunk family ((D, A) = (4, 2), categorical head, 64-row tiles) -- the headline; LDS
+// 151 KB of the CU's 160: wider observation / action rows do not fit beside the six planes (they keep csrc/ppo_trunk.hip).
+// Everything outside the three products -- gather, head, loss, the small gradients, slab layout, loss partials -- is
+// ppo_trunk_kernel<ACT, 0, 64, 4, 2>'s code, statement for statement.
+// Reference semantics: memory_tools.py:267-287 (sample) + ppo_learner.py:46-62 (forward / loss / backward).
+#include "common.h"
+#include "mlp_tile.h"
+#include "ppo_math.h"
+#include "split3.h"
+
+namespace xrl {
+
+typedef unsigned bu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bu32x2 __attribute__((ext_vector_type(2)));
+typedef short bs16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BH = 128;                      // hidden width (trunk and each branch)
+constexpr int BLD = BH + 4;                  // float32 row stride (h2)
+constexpr int BPL = BH + 8;                  // row stride of a 16-bit plane (elements; 272 bytes: 16-byte row reads conflict-free)
+constexpr int BPT = 64;                      // rows per workgroup
+constexpr int BPLANE = BPT * BPL;            // elements per plane
+constexpr int BD = 4, BA = 2;                // observation / head width of the class
+constexpr int BXLD = 8;                      // row stride of the gathered observations
+
+struct BxLds {                               // byte offsets
+    static constexpr int H1P = 0, G2P = H1P + 3 * BPLANE * 2, H2 = G2P + 3 * BPLANE * 2, XS = H2 + BPT * BLD * 4,
+                         RSC = XS + BPT * BXLD * 4, DZH = RSC + BPT * 12 * 4, W0T = DZH + BPT * 16 * 4, B0 = W0T + BD * BLD * 4,
+                         BM = B0 + BH * 4, WH = BM + BH * 4, BHS = WH + BA * BLD * 4, SRC = BHS + 8 * 4, RST = SRC + BPT * 4,
+                         BYTES = RST + BPT * 5 * 8;
+};
+static_assert(BxLds::BYTES <= 160 * 1024, "LDS");
+static_assert((BxLds::RST & 7) == 0 && (BxLds::H2 & 15) == 0 && (BxLds::G2P & 15) == 0, "alignment");
+
+__device__ __forceinline__ float plane_value(const unsigned short* pl, int o) {          // the float32 an element was split from (exact)
+    return (bf16_bits_to_float(pl[o]) + bf16_bits_to_float(pl[BPLANE + o])) + bf16_bits_to_float(pl[2 * BPLANE + o]);
+}
+
+#define BX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0)
+// acc += the six largest of the nine (part of x) x (part of y) products, smallest first; x = A-operand planes, y = B-operand planes
+#define BX_MFMA6(xh, xm, xl, yh, ym, yl, acc)                                                  \
+    acc = BX_MFMA(xl, yh, acc); acc = BX_MFMA(xh, yl, acc); acc = BX_MFMA(xm, ym, acc);        \
+    acc = BX_MFMA(xm, yh, acc); acc = BX_MFMA(xh, ym, acc); acc = BX_MFMA(xh, yh, acc);
+
+// column slice of a row-major plane as a 32x32x16 operand: rows r0 + 8 lh + 0..7 of column c0 + li.  TR: two ds_read_b64_tr_b16 (lane q
+// of a 16-lane group passes the address of (row + q / 4, 4 (q % 4)) and receives column q of four rows); else eight 2-byte reads.
+template <bool TR>
+__device__ __forceinline__ bu32x4 plane_column8(const unsigned short* pl, int r0, int c0, int li, int lh) {
+    bu32x4 v;
+    if (TR) {
+        const int i = li & 15;
+        const unsigned short* at = pl + (r0 + 8 * lh + (i >> 2)) * BPL + c0 + 16 * (li >> 4) + 4 * (i & 3);
+        typedef __attribute__((address_space(3))) bs16x4* lptr;
+        const bs16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)at);
+        const bs16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(at + 4 * BPL));
+        const bu32x2 a = __builtin_bit_cast(bu32x2, t0), b = __builtin_bit_cast(bu32x2, t1);
+        v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
+    } else {
+        const unsigned short* at = pl + (r0 + 8 * lh) * BPL + c0 + li;
+        v.x = (unsigned)at[0] | ((unsigned)at[BPL] << 16);
+        v.y = (unsigned)at[2 * BPL] | ((unsigned)at[3 * BPL] << 16);
+        v.z = (unsigned)at[4 * BPL] | ((unsigned)at[5 * BPL] << 16);
+        v.w = (unsigned)at[6 * BPL] | ((unsigned)at[7 * BPL] << 16);
+    }
+    return v;
+}
+
+// four consecutive columns of a row -> the three planes (8-byte stores)
+__device__ __forceinline__ void plane_store4(unsigned short* pl, int o, float v0, float v1, float v2, float v3) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pair(v0, v1, h0, m0, l0);
+    split3_pair(v2, v3, h1, m1, l1);
+    *reinterpret_cast<uint2*>(pl + o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(pl + BPLANE + o) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(pl + 2 * BPLANE + o) = make_uint2(l0, l1);
+}
+
+template <int ACT, bool TR>
+__global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fused_t p) {
+    using L = BxLds;
+    constexpr int TPR = FUSED_THREADS / BPT;           // threads per row in the VALU phases: 8
+    constexpr int NCH = (BH / 4) / TPR;                // float4 chunks of the branch level per thread: 4
+    constexpr int D = BD, A = BA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned short* h1p = reinterpret_cast<unsigned short*>(lds_raw + L::H1P);   // [3][64][136] h1 as bf16 planes
+    unsigned short* g2p = reinterpret_cast<unsigned short*>(lds_raw + L::G2P);   // [3][64][136] dLoss/dz2 as bf16 planes
+    float* h2 = reinterpret_cast<float*>(lds_raw + L::H2);                        // [64][132] (later: the row blocks' first-layer partial sums)
+    float* xs = reinterpret_cast<float*>(lds_raw + L::XS);                        // [64][8] gathered observations, zero beyond D
+    float* rsc = reinterpret_cast<float*>(lds_raw + L::RSC);                      // [64][12] act | . | ret | adv | old_logp
+    float* dzh = reinterpret_cast<float*>(lds_raw + L::DZH);                      // [64][16] dLoss/d(head pre-activations)
+    float* w0t = reinterpret_cast<float*>(lds_raw + L::W0T);                      // [4][132] first-layer weights, k-major
+    float* b0s = reinterpret_cast<float*>(lds_raw + L::B0);
+    float* bms = reinterpret_cast<float*>(lds_raw + L::BM);                       // this role's branch bias
+    float* whs = reinterpret_cast<float*>(lds_raw + L::WH);                       // [nout][132] this role's head rows
+    float* bhs = reinterpret_cast<float*>(lds_raw + L::BHS);
+    int* srcs = reinterpret_cast<int*>(lds_raw + L::SRC);
+    double* rowstat = reinterpret_cast<double*>(lds_raw + L::RST);                // [5][64] per-row loss terms
+
+    kernarg_prefetch<sizeof(xrl_ppo_fused_t)>();
+    const int tid = threadIdx.x, M = p.M;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cblk = wave & 3, rblk = wave >> 2;       // matrix phases: 32-column block / 32-row block of this wave
+    const int tile = blockIdx.x >> 1, role = blockIdx.x & 1;
+    const bool actor = role == 0;
+    const int nout = actor ? A : 1;
+    const int cb = role * BH;                          // this role's first column of the stacked branch level
+    const int m0 = tile * BPT;
+    const int r = tid / TPR, sub = tid % TPR, m_row = m0 + r;
+    const bool row_ok = m_row < M;
+    float* slab = p.slabs + (size_t)tile * p.slab_stride;
+    const xrl_fused_layer_t &L0 = p.layers[0], &L1 = p.layers[1], &La = p.layers[2], &Lc = p.layers[3];
+    const xrl_fused_layer_t& Lh = actor ? La : Lc;
+
+    long long* dbg = p.dbg;                            // diagnostics (tools/probe_pair_phases.py)
+    const bool dbg_me = dbg && tid == 0 && blockIdx.x == gridDim.x - 1;
+#define TSTAMP(k) do { if (dbg_me) dbg[k] = clock64(); } while (0)
+    if (dbg && tid == 0) dbg[16 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+    TSTAMP(0);
+
+    // ================= loads: rows, small parameters, then this role's forward fragment planes (8 k-steps x 3 planes x 16 bytes per lane)
+    const bool records = p.f_rows || p.f_packed;
+    if (records) {                                     // 32-byte records obs[4] | act | ret | adv | old_logp: one wave
+        if (wave == 7) {
+            const int m = m0 + lane;
+            float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) {
+                size_t at = (size_t)m;
+                if (!p.f_rows) {
+                    const int64_t fl = p.idx[m];
+                    const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);
+                    at = (size_t)t * p.n_envs + env;
+                }
+                const float4* rec = reinterpret_cast<const float4*>(p.f_rows ? p.f_rows : p.f_packed) + at * 2;
+                xr = rec[0]; sc = rec[1];
+            }
+            *reinterpret_cast<float4*>(xs + lane * BXLD) = xr;
+            *reinterpret_cast<float4*>(xs + lane * BXLD + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            rsc[lane * 12 + 0] = sc.x; rsc[lane * 12 + 8] = sc.y; rsc[lane * 12 + 9] = sc.z; rsc[lane * 12 + 10] = sc.w;
+        }
+    } else if (tid < BPT) {                            // buffer row of each minibatch row (env-major flat index, memory_tools.py:270)
+        const int m = m0 + tid;
+        int src = -1;
+        if (m < M) {
+            const int64_t fl = p.idx[m];
+            const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);
+            src = t * p.n_envs + env;
+        }
+        srcs[tid] = src;
+    }
+    float st_mean = 0.f, st_std = 1.f;
+    if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
+    for (int e = tid; e < BH * D; e += FUSED_THREADS) {
+        const int c = e / D, k = e - c * D;
+        w0t[k * BLD + c] = p.params[L0.w_off + e];
+    }
+    if (tid < BH) b0s[tid] = p.params[L0.b_off + tid];
+    else if (tid < 2 * BH) bms[tid - BH] = p.params[L1.b_off + cb + tid - BH];
+    else if (tid < 2 * BH + 8) {
+        const int j = tid - 2 * BH;
+        bhs[j] = j < nout ? p.params[Lh.b_off + j] : 0.f;
+    }
+    for (int e = tid; e < nout * BH; e += FUSED_THREADS) {
+        const int j = e >> 7, k = e & (BH - 1);
+        whs[j * BLD + k] = p.params[Lh.w_off + e];
+    }
+    // (fragment stream requested AFTER the small loads: a wave's loads retire in order)
+    bu32x4 pf[8][3];
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.frag16), 0, 3 * XRL_FRAG16_PLANE * 2, 0x00020000);
+    {
+        const int t = 4 * role + cblk;                                   // 32-row tile of the stacked 256-row W1
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                pf[qq][pl] = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (pl * XRL_FRAG16_PLANE + (t * 8 + ((qq + t) & 7)) * 512) * 2, 0);
+    }
+    if (!records) {
+        lds_barrier();                                                                               // (srcs)
+        for (int e = tid; e < BPT * BXLD; e += FUSED_THREADS) {
+            const int rr = e / BXLD, k = e - rr * BXLD, src = srcs[rr];
+            xs[e] = (k < D && src >= 0) ? p.f_obs[(size_t)src * D + k] : 0.f;
+        }
+        for (int e = tid; e < BPT * 12; e += FUSED_THREADS) {
+            const int rr = e / 12, k = e - rr * 12, src = srcs[rr];
+            float v = 0.f;
+            if (src >= 0) {
+                if (k < 1) v = p.f_act[src];
+                else if (k == 8) v = p.f_ret[src];
+                else if (k == 9) v = p.f_adv[src];
+                else if (k == 10) v = p.f_logp[src];
+            }
+            rsc[e] = v;
+        }
+    }
+    lds_barrier();                                                                                   // #0 rows, parameters
+    TSTAMP(1);
+
+    // ================= forward.  First layer, transposed: C[i = column n][j = row] = sum_k W0[n][k] x[row][k] -- ppo_trunk_kernel's two
+    // fp32 instructions with the operands exchanged (the same products in the same order); lane (li = row, lh) then holds columns
+    // 32 cblk + 8 g + 4 lh + 0..3 (g = 0..3): four consecutive k of the next product -> split once, three 8-byte stores per group
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* wk = w0t + lh * BLD + cblk * 32 + li;              // A[i = column][k = lh + 2 s]
+        const float* xr = xs + (rblk * 32 + li) * BXLD + lh;            // B[k = lh + 2 s][j = row]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[0], xr[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[2 * BLD], xr[2], acc, 0, 0, 0);
+        const int row = rblk * 32 + li;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = cblk * 32 + 8 * g + 4 * lh;
+            const float4 b = *reinterpret_cast<const float4*>(b0s + n0);
+            plane_store4(h1p, row * BPL + n0, act_apply_c<ACT>(acc[4 * g] + b.x), act_apply_c<ACT>(acc[4 * g + 1] + b.y),
+                         act_apply_c<ACT>(acc[4 * g + 2] + b.z), act_apply_c<ACT>(acc[4 * g + 3] + b.w));
+        }
+    }
+    lds_barrier();                                                                                   // #1 h1
+    TSTAMP(2);
+    // ---- this role's branch layer 128 -> 128, transposed as well: wave (cblk, rblk): C[i = column 32 cblk + ..][j = row 32 rblk + li];
+    //      A = the weight planes in registers, B = h1's planes (16-byte row reads: k = 16 qq + 8 lh + 0..7)
+    {
+        const unsigned short* hrow = h1p + (rblk * 32 + li) * BPL + 8 * lh;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const bu32x4 xh = *reinterpret_cast<const bu32x4*>(hrow + 16 * qq), xm = *reinterpret_cast<const bu32x4*>(hrow + BPLANE + 16 * qq),
+                         xl = *reinterpret_cast<const bu32x4*>(hrow + 2 * BPLANE + 16 * qq);
+            // (term names: activation part, weight part -- the operands of the instruction are (weights, rows))
+            acc = BX_MFMA(pf[qq][0], xl, acc); acc = BX_MFMA(pf[qq][2], xh, acc); acc = BX_MFMA(pf[qq][1], xm, acc);
+            acc = BX_MFMA(pf[qq][0], xm, acc); acc = BX_MFMA(pf[qq][1], xh, acc); acc = BX_MFMA(pf[qq][0], xh, acc);
+        }
+        const int row = rblk * 32 + li;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = cblk * 32 + 8 * g + 4 * lh;
+            const float4 b = *reinterpret_cast<const float4*>(bms + n0);
+            *reinterpret_cast<float4*>(h2 + row * BLD + n0) = make_float4(act_apply_c<ACT>(acc[4 * g] + b.x), act_apply_c<ACT>(acc[4 * g + 1] + b.y),
+                                                                         act_apply_c<ACT>(acc[4 * g + 2] + b.z), act_apply_c<ACT>(acc[4 * g + 3] + b.w));
+        }
+        // forward planes consumed: the same registers take the BACKWARD section (output tile kt = cblk of dH1, this role's 8 n-steps
+        // q = 8 role + qq), which has the head / loss / weight-gradient phases to arrive
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const int q = 8 * role + qq;
+                pf[qq][pl] = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (pl * XRL_FRAG16_PLANE + XRL_FRAG16_PLANE / 2 + (cblk * 16 + ((q + cblk) & 15)) * 512) * 2, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();                                                                                   // #2 h2
+    TSTAMP(3);
+
+    // ================= head forward (VALU, 8 threads per row), this role's loss terms, head backward -- in registers
+    float4 a[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) a[i] = *reinterpret_cast<const float4*>(h2 + r * BLD + 4 * (sub + TPR * i));
+    float z[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        z[j] = 0.f;
+        if (j < nout) {
+            float c = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(whs + j * BLD + 4 * (sub + TPR * i));
+                c += a[i].x * w.x + a[i].y * w.y + a[i].z * w.z + a[i].w * w.w;
+            }
+            c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 1, 64);
+            z[j] = c + bhs[j];
+        }
+    }
+    {
+        float dz[A];
+#pragma unroll
+        for (int j = 0; j < A; ++j) dz[j] = 0.f;
+        double t_s = 0.0, t_c = 0.0, t_e = 0.0, t_v = 0.0, t_n = 0.0;
+        const float invM = 1.f / (float)M;
+        if (actor) {
+            float adv = rsc[r * 12 + 9];
+            const float old_lp = rsc[r * 12 + 10];
+            asm volatile("" : "+v"(st_std));
+            if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, st_mean), st_std + 1e-8f);                   // memory_tools.py:281-282
+            const float lo = (float)(1.0 - (double)p.clip_range), hi = (float)(1.0 + (double)p.clip_range);
+            if (row_ok) {
+                const int act = (int)rsc[r * 12];
+                float mx = z[0];
+#pragma unroll
+                for (int j = 1; j < A; ++j) mx = fmaxf(mx, z[j]);
+                float se = 0.f;
+#pragma unroll
+                for (int j = 0; j < A; ++j) se += expf(z[j] - mx);
+                const float lse = mx + logf(se);
+                float zact = z[0];
+#pragma unroll
+                for (int j = 1; j < A; ++j) if (j == act) zact = z[j];
+                const float logp = zact - lse;
+                float ent = 0.f;
+#pragma unroll
+                for (int j = 0; j < A; ++j) { const float l = z[j] - lse; ent -= expf(l) * l; }
+                const Surrogate s = surrogate(logp, old_lp, adv, lo, hi, invM);
+                const float ce = p.ent_coef * invM;
+#pragma unroll
+                for (int j = 0; j < A; ++j) { const float l = z[j] - lse, pj = expf(l); dz[j] = s.dlogp * ((j == act ? 1.f : 0.f) - pj) + ce * pj * (l + ent); }
+                t_s = (double)fminf(s.s1, s.s2); t_n = s.clipped; t_e = ent;
+                if (p.diag && sub == 0) {
+                    const int m = m_row;
+                    p.diag[m] = logp; p.diag[M + m] = s.ratio; p.diag[2 * (size_t)M + m] = s.s1; p.diag[3 * (size_t)M + m] = s.s2;
+                }
+            }
+        } else if (row_ok) {
+            const float v = z[0], dv = v - rsc[r * 12 + 8];
+            dz[0] = p.vf_coef * 2.f * dv * invM;
+            t_c = (double)dv * dv; t_v = v;
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dzh[r * 16 + j] = j < A ? dz[j < A ? j : 0] : 0.f; dzh[r * 16 + 8 + j] = 0.f; }
+            rowstat[0 * BPT + r] = t_s; rowstat[1 * BPT + r] = t_c; rowstat[2 * BPT + r] = t_e; rowstat[3 * BPT + r] = t_v; rowstat[4 * BPT + r] = t_n;
+        }
+        // g2 = (dZh . W_h) * act'(h2): this thread's k-chunks, split where they are made
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                if (j < nout) {
+                    const float4 w = *reinterpret_cast<const float4*>(whs + j * BLD + 4 * (sub + TPR * i));
+                    g.x += dz[j] * w.x; g.y += dz[j] * w.y; g.z += dz[j] * w.z; g.w += dz[j] * w.w;
+                }
+            }
+            g.x *= act_grad_c<ACT>(a[i].x); g.y *= act_grad_c<ACT>(a[i].y); g.z *= act_grad_c<ACT>(a[i].z); g.w *= act_grad_c<ACT>(a[i].w);
+            plane_store4(g2p, r * BPL + 4 * (sub + TPR * i), g.x, g.y, g.z, g.w);
+        }
+    }
+    lds_barrier();                                                                                   // #3 g2, dzh, rowstat
+    TSTAMP(4);
+
+    // ================= backward
+    // ---- loss terms of this (tile, role): one statistic per wave (see ppo_trunk_kernel)
+    if (wave < 5) {
+        double s = rowstat[wave * BPT + lane];
+        s = wave_sum(s);
+        if (lane == 0) p.partials[(size_t)blockIdx.x * 8 + wave] = s;
+    } else if (wave == 5 && lane < 3) p.partials[(size_t)blockIdx.x * 8 + 5 + lane] = 0.0;
+    // ---- head weight / bias gradients, this role's branch-layer bias gradient: VALU sums over the 64 rows, rows in order
+    for (int e = tid; e < nout * BH; e += FUSED_THREADS) {
+        const int j = e >> 7, k = e & (BH - 1);
+        const float* hp = h2 + k;
+        float acc = 0.f;
+#pragma unroll 16
+        for (int rr = 0; rr < BPT; ++rr) acc += dzh[rr * 16 + j] * hp[rr * BLD];
+        slab[Lh.w_off + e] = acc;
+    }
+    if (tid >= 4 * 64 && tid < 4 * 64 + BH) {                           // (column sums in double, rounded once: ppo_trunk_kernel's note)
+        const int t = tid - 4 * 64;
+        double acc0 = 0.0;
+#pragma unroll 16
+        for (int rr = 0; rr < BPT; ++rr) acc0 += (double)plane_value(g2p, rr * BPL + t);
+        slab[L1.b_off + cb + t] = (float)acc0;
+    } else if (tid >= 6 * 64 && tid < 6 * 64 + 8) {
+        const int t = tid - 6 * 64;
+        if (t < nout) {
+            double acc = 0.0;
+#pragma unroll 16
+            for (int rr = 0; rr < BPT; ++rr) acc += (double)dzh[rr * 16 + t];
+            slab[Lh.b_off + t] = (float)acc;
+        }
+    }
+    lds_barrier();                                                                                   // #3b no matrix instruction beside a vector loop
+    TSTAMP(5);
+    // ---- dW1[n][k] = sum over the 64 rows of g2[row][n] * h1[row][k] for this role's 128 rows n: 4 x 4 tiles of 32 x 32, wave w owns
+    //      n-tile (w & 3) and the k-tiles 2 (w >> 2), 2 (w >> 2) + 1; four 16-row steps; both operands are column slices of planes
+    f32x16 dacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
+    {
+        const int nt = wave & 3, kt0 = 2 * (wave >> 2);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+        for (int rs = 0; rs < 4; ++rs) {
+            const bu32x4 gh = plane_column8<TR>(g2p, 16 * rs, nt * 32, li, lh), gm = plane_column8<TR>(g2p + BPLANE, 16 * rs, nt * 32, li, lh),
+                         gl = plane_column8<TR>(g2p + 2 * BPLANE, 16 * rs, nt * 32, li, lh);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int c0 = (kt0 + t) * 32;
+                const bu32x4 xh = plane_column8<TR>(h1p, 16 * rs, c0, li, lh), xm = plane_column8<TR>(h1p + BPLANE, 16 * rs, c0, li, lh),
+                             xl = plane_column8<TR>(h1p + 2 * BPLANE, 16 * rs, c0, li, lh);
+                BX_MFMA6(gh, gm, gl, xh, xm, xl, acc[t])
+            }
+        }
+        TSTAMP(6);
+        // ---- this role's part of dH1 = g2 . W1 (sum over its 128 rows n): wave (cblk, rblk) owns output columns [32 cblk, +32) of
+        //      rows [32 rblk, +32); A = g2's planes (row reads), B = the backward planes requested after the forward layer.
+        //      The 32 stores of this wave's dW1 tiles are issued between these instructions (ppo_trunk_kernel's note).
+        float* dW = slab + L1.w_off + (size_t)(cb + nt * 32) * BH;
+        {
+            const unsigned short* grow = g2p + (rblk * 32 + li) * BPL + 8 * lh;
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const bu32x4 gh = *reinterpret_cast<const bu32x4*>(grow + 16 * qq), gm = *reinterpret_cast<const bu32x4*>(grow + BPLANE + 16 * qq),
+                             gl = *reinterpret_cast<const bu32x4*>(grow + 2 * BPLANE + 16 * qq);
+                BX_MFMA6(gh, gm, gl, pf[qq][0], pf[qq][1], pf[qq][2], dacc)
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                dW[(size_t)row * BH + (kt0 + t) * 32 + li] = acc[t][rr];
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
+    }
+    // ---- first layer: dW0[c][k] = sum_rows g1[row][c] * x[row][k], db0[c], g1 = dH1 * act'(h1) -- straight from the dH1 accumulators
+    //      (ppo_trunk_kernel's form; h1 comes back from its planes, exactly)
+    {
+        float* dst = actor ? slab : slab + p.l0_fold_off;
+        const int w_at = actor ? L0.w_off : 0, b_at = actor ? L0.b_off : BH * D;
+        float* part = h2;                                                // [2][128][D + 1] partial sums of the row blocks
+        constexpr int PLD = D + 1;
+        {
+            const int c = cblk * 32 + li;
+            float ab = 0.f;
+            float acc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                const float g = dacc[rr] * act_grad_c<ACT>(plane_value(h1p, row * BPL + c));
+                ab += g;
+                const float4 x = *reinterpret_cast<const float4*>(xs + row * BXLD);
+                acc[0] += g * x.x; acc[1] += g * x.y; acc[2] += g * x.z; acc[3] += g * x.w;
+            }
+            // (h2's last readers -- the head weight gradient -- are behind barrier #3b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+            ab += __shfl_xor(ab, 32, 64);
+            if (lh == 0) {
+                float* pp = part + (rblk * BH + c) * PLD;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pp[k] = acc[k];
+                pp[D] = ab;
+            }
+        }
+        lds_barrier();                                                                               // #4 the two row blocks' partial sums
+        TSTAMP(7);
+        for (int e = tid; e < BH * (D + 1); e += FUSED_THREADS) {
+            const int c = e / (D + 1), k = e - c * (D + 1);
+            const float v = part[c * PLD + k] + part[(BH + c) * PLD + k];
+            dst[k < D ? w_at + c * D + k : b_at + c] = v;
+        }
+    }
+    TSTAMP(8);
+    if (dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg[17 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+#undef TSTAMP
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+static int g_bx_tr = 1;                                   // weight-gradient operands through ds_read_b64_tr_b16 (0: 2-byte reads; diagnostics)
+
+bool ppo_trunk_bx_eligible(const xrl_ppo_fused_t& p) {
+    return p.frag16 != nullptr && p.pad0 == 64 && p.dist == 0 && p.D == BD && p.A == BA && p.layers[1].N == 2 * BH && p.layers[1].K == BH;
+}
+
+template <int ACT>
+static int launch_bx(const xrl_ppo_fused_t& p, hipStream_t stream) {
+    const int n_tiles = (p.M + BPT - 1) / BPT;
+    if (g_bx_tr) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
+    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+int launch_ppo_trunk_bx(const xrl_ppo_fused_t& p, hipStream_t stream) {
+    switch (p.layers[0].act) {
+        case XRL_ACT_RELU: return launch_bx<XRL_ACT_RELU>(p, stream);
+        case XRL_ACT_LEAKY_RELU: return launch_bx<XRL_ACT_LEAKY_RELU>(p, stream);
+        default: return launch_bx<XRL_ACT_TANH>(p, stream);
+    }
+}
+
+template <int ACT>
+static int init_bx_one() {
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
+    return XRL_OK;
+}
+
+int init_ppo_trunk_bx() {
+    if (int rc = init_bx_one<XRL_ACT_RELU>()) return rc;
+    if (int rc = init_bx_one<XRL_ACT_LEAKY_RELU>()) return rc;
+    if (int rc = init_bx_one<XRL_ACT_TANH>()) return rc;
+    return XRL_OK;
+}
+
+// image <- W[256][128] of the stacked branch layer as three bf16 planes in the order the kernel's lanes consume it (include/xrl_hip.h)
+__global__ void __launch_bounds__(256) pack_mid_frags16_kernel(const float* __restrict__ W, unsigned short* __restrict__ img) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * BH * BH; i += gridDim.x * blockDim.x) {
+        const int n = i >> 7, k = i & (BH - 1);
+        unsigned short h, m, l;
+        split3(W[i], h, m, l);
+        const int f = xrl_frag16_fwd_index(n, k), b = xrl_frag16_bwd_index(n, k);
+        img[f] = h; img[XRL_FRAG16_PLANE + f] = m; img[2 * XRL_FRAG16_PLANE + f] = l;
+        img[b] = h; img[XRL_FRAG16_PLANE + b] = m; img[2 * XRL_FRAG16_PLANE + b] = l;
+    }
+}
+
+}  // namespace xrl
+
+using namespace xrl;
+
+extern "C" int xrl_pack_mid_frags16(const xrl_ppo_fused_t* pp, uint16_t* image, int64_t image_elems, xrl_stream_t stream) {
+    XRL_CHECK_ARG(pp != nullptr && image != nullptr && pp->params != nullptr && pp->n_layers >= 2);
+    const xrl_fused_layer_t& L = pp->layers[1];
+    XRL_CHECK_ARG(L.N == 2 * BH && L.K == BH && image_elems >= 3 * (int64_t)XRL_FRAG16_PLANE);
+    hipLaunchKernelGGL(pack_mid_frags16_kernel, dim3(64), dim3(256), 0, as_stream(stream), pp->params + L.w_off, image);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+extern "C" int xrl_set_split_product_tr(int on) {
+    g_bx_tr = on ? 1 : 0;
+    return XRL_OK;
+}

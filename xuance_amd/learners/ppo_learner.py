@@ -334,6 +334,16 @@ class PPO_Learner(Learner):
         if nf:
             mf, mb = ops.frag_layout_maps(self.model.plan, P, dev)  # forward section: first stream of the minibatch kernel;
             self._mirrors += [(mf, self.frag), (mb, self.frag)]     # backward section: its second one (backward-data)
+        # 64-row tiles of the CartPole class: the three 128-wide products as exact 3-way bf16 splits on the matrix cores
+        # (csrc/ppo_trunk_bx.hip) -- the branch layer as three bf16 planes, kept current by SPLIT mirror maps of the optimiser launch.
+        # config.use_split_products: False keeps the float32 matrix instruction (csrc/ppo_trunk.hip).
+        self.frag16 = None
+        if nf and self.split and self.pair and getattr(self.config, "use_split_products", True) \
+                and ops.split_products_class(self.model.plan, D, self.model.action_dim, self.model.dist) \
+                and len(self._mirrors) + 2 <= 4 and not getattr(self.config, "use_chained_update", False):
+            self.frag16 = torch.zeros(3 * ops.FRAG16_PLANE, dtype=torch.int16, device=dev)
+            mf16, mb16 = ops.frag16_layout_maps(self.model.plan, P, dev)
+            self._mirrors += [(mf16, self.frag16, ops.FRAG16_PLANE), (mb16, self.frag16, ops.FRAG16_PLANE)]
         self.packed = torch.zeros(memory.n_size * memory.n_envs * 8, device=dev) if self.records else None   # transition records
         self._mirror = True
 
@@ -380,6 +390,8 @@ class PPO_Learner(Learner):
             ops.pack_rollout_cache(self.model.plan, self.model.params.flat, self.cache_image)
         if self.frag is not None:
             ops.pack_mid_frags(self.model.plan, self.model.params.flat, self.frag)
+        if getattr(self, "frag16", None) is not None:
+            ops.pack_mid_frags16(self.model.plan, self.model.params.flat, self.frag16)
 
     def _derived_layouts(self, fill=True):
         """params_t / cache_image of the any-shape minibatch kernel (xrl_ppo_fused_minibatch without a fold region needs both) and
@@ -408,6 +420,7 @@ class PPO_Learner(Learner):
             ok = bool(getattr(self.config, "use_chained_update", False)) and self.split and ops.fast_kernels_enabled() \
                 and self.cartpole_class() and self.model.action_dim == 2 \
                 and not (self.distributed_training and self.world_size > 1) and self._fused_optimizer_ok(False) \
+                and getattr(self, "frag16", None) is None \
                 and ops.ppo_trunk_chain_fits(M, 64 if pair else 32, self.model.params.P)
             self._chain_ok[key] = ok
         return self._chain_ok[key] and ops.fast_kernels_enabled()
@@ -458,6 +471,7 @@ class PPO_Learner(Learner):
         launch(m.plan, params=m.params.flat, params_t=self.params_t, cache_image=self.cache_image,
                                 f_obs=f["observations"], f_act=f["actions"], f_ret=f["returns"], f_adv=f["advantages"],
                                 f_logp=f["aux_old_logp"], idx=idx, stats=stats, slabs=self.fslabs, frag_image=self.frag,
+                                frag16=self.frag16 if (pair and getattr(self, "frag16", None) is not None) else None,
                                 f_packed=self.packed if getattr(self, "_packed_valid", False) else None, f_rows=rows,
                                 partials=self.fpartials, diag=self.diag if self.keep_diag else None,
                                 slab_stride=self.slab_stride, l0_fold_off=fold[0] if fold else 0, M=M,

@@ -272,12 +272,21 @@ def adam_step_mirrored(params, grad, m, v, P, state, sumsq_part, max_norm, map_a
          stream_ptr())
 
 
+def fill_mirrors(mir, mirrors):
+    """(map, dst) pairs into an xrl_mirrors_t; a triple (map, dst, plane) is a SPLIT mirror (map values <= -2 name 16-bit elements
+    of a three-plane bf16 image, planes `plane` elements apart: xrl_mirrors_t.split_plane)."""
+    mir.n = len(mirrors)
+    for q, mm in enumerate(mirrors):
+        mir.map[q] = mm[0].data_ptr(); mir.dst[q] = mm[1].data_ptr()
+        if len(mm) > 2:
+            assert mir.split_plane in (0, int(mm[2]))
+            mir.split_plane = int(mm[2])
+
+
 def adam_step_mirrors(params, grad, m, v, P, state, sumsq_part, max_norm, mirrors):
     """`mirrors`: up to 4 (int32 map [P], destination tensor) pairs refreshed in the Adam launch."""
     mir = Mirrors()
-    mir.n = len(mirrors)
-    for q, (mp, dst) in enumerate(mirrors):
-        mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
+    fill_mirrors(mir, mirrors)
     call("xrl_adam_step_mirrors", ptr(params), ptr(grad), ptr(m), ptr(v), int(P), ptr(state), ptr(sumsq_part),
          sumsq_part.numel(), float(max_norm if max_norm else 0.0), C.byref(mir), stream_ptr())
 
@@ -289,13 +298,11 @@ def reduce_adam(slabs, n_split, slab_stride, params, grad, m, v, P, state, sumsq
     tick = (counter tensor, increment), partials = (float64 [rows, 8] tensor, rows, float64 [8] out): xrl_counter_add and
     xrl_sum_partials of an update phase done by one block of this launch instead of by launches of their own."""
     mir = Mirrors()
-    mir.n = len(mirrors)
     if tick is not None:
         mir.tick, mir.tick_inc = tick[0].data_ptr(), int(tick[1])
     if partials is not None:
         mir.part, mir.part_rows, mir.part_out = partials[0].data_ptr(), int(partials[1]), partials[2].data_ptr()
-    for q, (mp, dst) in enumerate(mirrors):
-        mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
+    fill_mirrors(mir, mirrors)
     if target is not None and target_every > 0:
         mir.target, mir.target_every = target.data_ptr(), int(target_every)
         if target_image is not None:                       # derived layout of the target, refreshed with it (through map[0])
@@ -362,6 +369,47 @@ def pack_mid_frags(plan, params_flat, frag):
     p.params = params_flat.data_ptr()
     fused_layers_from_plan(plan, p)
     call("xrl_pack_mid_frags", C.byref(p), ptr(frag), frag.numel(), stream_ptr())
+
+
+FRAG16_PLANE = 2 * 256 * 128            # XRL_FRAG16_PLANE: 16-bit elements per plane of the split fragment image
+
+
+def split_products_class(plan, obs_dim, action_dim, dist):
+    """The class csrc/ppo_trunk_bx.hip is built for: 4-128-{128-2 | 128-1}, categorical (the CartPole headline)."""
+    return dist != "gaussian" and obs_dim == 4 and action_dim == 2 and list(plan.widths) == [4, 128, 256, 3]
+
+
+def pack_mid_frags16(plan, params_flat, image):
+    """image (int16 [3 * FRAG16_PLANE]) <- the branch layer as three bf16 planes in matrix-core lane order (xrl_pack_mid_frags16)."""
+    p = PpoFused()
+    p.params = params_flat.data_ptr()
+    fused_layers_from_plan(plan, p)
+    call("xrl_pack_mid_frags16", C.byref(p), ptr(image), image.numel(), stream_ptr())
+
+
+def frag16_layout_maps(plan, P, device):
+    """int32 SPLIT mirror maps [P] (value -(e + 2): 16-bit element e of a plane; -1: not mirrored) of the forward / backward section of
+    the split fragment image -- the index formulas of csrc/split3.h (xrl_frag16_fwd_index / _bwd_index), checked against the pack
+    kernel by tests/test_gpu_ppo.py."""
+    mids = [L for st in plan.stages[1:-1] for L in st]
+    w_off = plan.params.offsets[mids[0].w_name]
+    i = torch.arange(256 * 128, dtype=torch.int64, device=device)
+    n, k = i >> 7, i & 127
+    t, qq = n >> 5, k >> 4
+    fwd = ((t * 8 + ((qq + t) & 7)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)
+    kt, q = k >> 5, n >> 4
+    bwd = 256 * 128 + ((kt * 16 + ((q + kt) & 15)) * 64 + (k & 31) + 32 * ((n >> 3) & 1)) * 8 + (n & 7)
+    maps = []
+    for e in (fwd, bwd):
+        m = torch.full((P,), -1, dtype=torch.int32, device=device)
+        m[w_off:w_off + 256 * 128] = (-(e + 2)).to(torch.int32)
+        maps.append(m)
+    return maps
+
+
+def set_split_product_tr(on):
+    """Diagnostics: the split-product kernel's weight-gradient operands through the LDS transpose read (default) or 2-byte reads."""
+    call("xrl_set_split_product_tr", int(bool(on)))
 
 
 def pack_transitions(f_obs, f_act, f_ret, f_adv, f_logp, packed, count):
@@ -565,9 +613,7 @@ def ppo_trunk_chained(plan, opt, **kw):
     o.max_norm, o.sync = float(opt["max_norm"] or 0.0), opt["sync"].data_ptr()
     assert opt["sync"].numel() >= CHAIN_SYNC_WORDS
     mir = o.mirrors
-    mir.n = len(opt["mirrors"])
-    for q, (mp, dst) in enumerate(opt["mirrors"]):
-        mir.map[q] = mp.data_ptr(); mir.dst[q] = dst.data_ptr()
+    fill_mirrors(mir, opt["mirrors"])
     if opt.get("fold"):
         mir.fold_off, mir.fold_len = int(opt["fold"][0]), int(opt["fold"][1])
     call("xrl_ppo_trunk_chained", C.byref(p), C.byref(o), stream_ptr())
