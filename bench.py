@@ -181,6 +181,7 @@ def kernel_rooflines(agent):
                                 partials=lr.fpartials, diag=None, slab_stride=lr.slab_stride,
                                 l0_fold_off=lr.fold[0] if lr.fold else 0, M=bs, n_envs=n, T=T, D=4,
                                 frag_image=lr.frag, f_packed=lr.packed, f_rows=lr.rows[k * bs * 8:(k + 1) * bs * 8],
+                                frag16=lr.frag16 if (getattr(lr, "pair", False) and getattr(lr, "frag16", None) is not None) else None,
                                 pad0=(66 if getattr(lr, "chain", False) else 64) if getattr(lr, "pair", False) else 0,
                                 A=m.action_dim, clip_range=lr.clip_range, vf_coef=lr.vf_coef, ent_coef=lr.ent_coef)
     r2 = None
@@ -217,7 +218,9 @@ def kernel_rooflines(agent):
         us_mb = us_pair - us_opt
         fl_mb = 3.0 * fwd_flops_row * bs
         n_mb = nb                                          # agent.idx holds n_epochs x n_minibatch index rows
-        kname = "xrl::ppo_trunk_kernel" if lr.fold else "xrl::ppo_fused_kernel"      # (role-split family: 64-row tiles at the headline size)
+        bx = bool(lr.fold) and getattr(lr, "pair", False) and getattr(lr, "frag16", None) is not None
+        # (role-split family, 64-row tiles at the headline size: the 128-wide products as exact 3-way bf16 splits, csrc/ppo_trunk_bx.hip)
+        kname = ("xrl::ppo_trunk_bx_kernel" if bx else "xrl::ppo_trunk_kernel") if lr.fold else "xrl::ppo_fused_kernel"
         r2 = {"bound": "mfma", "kernel": kname, "achieved": round(fl_mb / us_mb / 1e6, 3),
               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_mb / us_mb / 1e6 / PEAK_FP32_MFMA_TFLOPS, 4),
               "traffic": _pmc_traffic(kname), "traffic_source": _PMC_SOURCE[0], "avg_launch_us": round(us_mb, 3),
@@ -226,6 +229,17 @@ def kernel_rooflines(agent):
                       "[minibatch kernel, optimiser launch] inside the real sequence (%.1f us) minus the median bracket around "
                       "the optimiser launch in the same position (%.1f us); see DESIGN.md section 3"
                       % (bs, 3.0 * fwd_flops_row, us_pair, us_opt)}
+        if bx:
+            # what the matrix pipe executes: six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block of each of the three 128-wide
+            # products (the exact 3-way split of both operands, the six largest of the nine part products), float32 accumulation
+            big = 3.0 * 2.0 * 128 * 256 * bs
+            r2["matrix_pipe"] = {"instruction": "v_mfma_f32_32x32x16_bf16 x 6 per fp32 32x32x16 block (exact 3-way bf16 split of both operands; "
+                                                "dropped part products <= 2^-23 per scalar product), float32 accumulate",
+                                 "executed_bf16_flops_per_launch": 6.0 * big, "executed_TFLOPs": round(6.0 * big / us_mb / 1e6, 2),
+                                 "bf16_dense_peak_TFLOPs": 2500.0, "frac_of_bf16_peak": round(6.0 * big / us_mb / 1e6 / 2500.0, 4),
+                                 "pipe_cycles_vs_fp32_instruction": "6 x 32 = 192 instead of 8 x 64 = 512 per block"}
+            r2["note"] += ("; `peak` stays the float32 matrix peak the ALGORITHMIC float32 flops are priced against -- the products run as "
+                           "bf16 split triples (matrix_pipe), results within float32 rounding of the fp32 instruction's")
     r1.update(launches_per_step=launches, us_per_step=round(us_launch * launches, 1))
     return r1, r2
 

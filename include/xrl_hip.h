@@ -936,6 +936,11 @@ int xrl_pack_mid_frags16(const xrl_ppo_fused_t* p, uint16_t* image, int64_t imag
 /* diagnostics: the split-product kernel's weight-gradient operands through ds_read_b64_tr_b16 (1, default) or 2-byte LDS reads (0);
  * same numbers either way. */
 int xrl_set_split_product_tr(int on);
+/* diagnostics: which weight-streamed products of the split-product kernel have the two waves of a 32-column block split the k-range
+ * (each streams half of the fragment planes, the halves meet through LDS) instead of the rows: 0 none, 1 the backward-data product
+ * (default), 2 both.  Another summation order: results differ by float32 rounding (and, with 2, by what that does to act'(h2) of
+ * pre-activations within rounding noise of zero: csrc/ppo_trunk_bx.hip). */
+int xrl_set_split_product_ksplit(int mode);
 /* ------------------------------------------------------------------ fused PPO minibatch, two-branch Gaussian actor-critic
  * D-256-256-{A | 1} (configs/ppo/mujoco.yaml:8-13: Basic_Identical representation, actor / critic hidden [256, 256];
  * policies/gaussian.py ActorCriticPolicy, ppo_learner.py:46-62).  ONE launch per minibatch, two workgroups (actor branch,

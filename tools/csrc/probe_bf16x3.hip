@@ -39,6 +39,25 @@ __global__ void tr_probe(unsigned short* out, int r0, int c0) {         // out[l
     }
 }
 
+// (3) how v_mfma_f32_32x32x16_bf16 rounds acc + sum of products: one product p = a * b (exact in bf16 x bf16) onto C = c
+__global__ void round_probe(float c, float a, float b, int nprod, float* out) {
+    const int lane = threadIdx.x;
+    bf16x8 av, bv;
+    for (int e = 0; e < 8; ++e) { av[e] = (__bf16)0.f; bv[e] = (__bf16)0.f; }
+    if (lane < 32) for (int e = 0; e < nprod && e < 8; ++e) { av[e] = (__bf16)a; bv[e] = (__bf16)b; }   // k = 0..nprod-1 (lh = 0)
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = c;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+    if (lane == 0) out[0] = acc[0];
+}
+__global__ void round_probe_f32(float c, float a, float b, float* out) {
+    const int lane = threadIdx.x;
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = c;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lane < 32 ? a : 0.f, lane < 32 ? b : 0.f, acc, 0, 0, 0);
+    if (lane == 0) out[0] = acc[0];
+}
+
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)(u >> 16); }
 static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
@@ -72,6 +91,26 @@ int main() {
         }
         printf("ds_read_b64_tr_b16 (r0 %d, c0 %d): %s (%d mismatches)\n", cs[0], cs[1], b2 ? "WRONG" : "ok", b2);
         rc |= b2 != 0;
+    }
+    {
+        float* dR; hipMalloc(&dR, 4);
+        struct { float c, a, b; int n; const char* what; } rc[] = {
+            {1.f, 0x1p-13f, 0x1p-13f, 1, "+1 + 2^-26        (RNE +1 | to-zero +1 | to -inf +1)"},
+            {1.f, -0x1p-13f, 0x1p-13f, 1, "+1 - 2^-26        (RNE +1 | to-zero 1-2^-24 | to -inf 1-2^-24)"},
+            {-1.f, 0x1p-13f, 0x1p-13f, 1, "-1 + 2^-26        (RNE -1 | to-zero -(1-2^-24) | to -inf -1)"},
+            {1.f, 1.5f, 0x1p-24f, 1, "+1 + 0.75 ulp     (RNE 1+2^-23 | to-zero +1 | to -inf +1)"},
+            {-1.f, -1.5f, 0x1p-24f, 1, "-1 - 0.75 ulp     (RNE -(1+2^-23) | to-zero -1 | to -inf -(1+2^-23))"},
+            {1.f, 0x1p-13f, 0x1p-14f, 8, "+1 + 8 x 2^-27 = +1 + 2^-24 = half an ulp, in 8 products (exact sum first: tie -> +1; product by product to-zero: +1)"},
+            {1.f, 1.5f, 0x1p-27f, 8, "+1 + 8 x 1.5 x 2^-27 = +1 + 0.75 ulp in 8 products (sum first: RNE 1+2^-23)"},
+        };
+        for (auto& t : rc) {
+            float r = 0, r32 = 0;
+            hipLaunchKernelGGL(round_probe, dim3(1), dim3(64), 0, 0, t.c, t.a, t.b, t.n, dR);
+            hipMemcpy(&r, dR, 4, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL(round_probe_f32, dim3(1), dim3(64), 0, 0, t.c, t.a, t.b * (float)t.n, dR);
+            hipMemcpy(&r32, dR, 4, hipMemcpyDeviceToHost);
+            printf("round %s: bf16 mfma %.9g (%a)   f32 mfma %.9g (%a)\n", t.what, r, r, r32, r32);
+        }
     }
     if (hipDeviceSynchronize() != hipSuccess) { printf("device error\n"); return 2; }
     return rc;

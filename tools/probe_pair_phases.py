@@ -11,9 +11,9 @@ from xuance_amd import ops
 from xuance_amd.agents import PPO_Agent
 from xuance_amd.envs import DeviceCartPoleVecEnv
 n = 256
-for mode in ("pair", "tile32"):      # ("chain": round 4's variant, tools/csrc/ppo_chain.hip, no longer in the library)
+for mode in ("pair-bx", "pair", "tile32"):      # ("chain": round 4's variant, tools/csrc/ppo_chain.hip, no longer in the library)
     pair = mode != "tile32"
-    cfg = bench.make_config(n, 256, 1, 0); cfg.use_pair_update = pair; 
+    cfg = bench.make_config(n, 256, 1, 0); cfg.use_pair_update = pair; cfg.use_split_products = mode == "pair-bx"
     torch.manual_seed(1)
     agent = PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=1))
     agent.rollout(); agent.update(); torch.cuda.synchronize()
@@ -27,7 +27,8 @@ for mode in ("pair", "tile32"):      # ("chain": round 4's variant, tools/csrc/p
                                 f_logp=f["aux_old_logp"], idx=agent.idx[3], stats=lr.stats[3], slabs=lr.fslabs, partials=lr.fpartials,
                                 diag=None, slab_stride=lr.slab_stride, l0_fold_off=lr.fold[0] if lr.fold else 0, M=bs, n_envs=n, T=256,
                                 D=4, A=2, clip_range=0.2, vf_coef=0.25, ent_coef=0.01, dbg=d, frag_image=lr.frag, f_packed=lr.packed,
-                                f_rows=lr.rows[3 * bs * 8:4 * bs * 8], pad0=64 if lr.pair else 0)
+                                f_rows=lr.rows[3 * bs * 8:4 * bs * 8], pad0=64 if lr.pair else 0,
+                                frag16=lr.frag16 if mode == "pair-bx" else None)
     for _ in range(3):
         launch(dbg)
         torch.cuda.synchronize()

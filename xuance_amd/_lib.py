@@ -397,6 +397,7 @@ _SIGS = {
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
     "xrl_pack_mid_frags16": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
     "xrl_set_split_product_tr": [c_int32],
+    "xrl_set_split_product_ksplit": [c_int32],
     "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],
     "xrl_ppo_wide_pack": [C.POINTER(PpoWide), c_void_p, c_void_p],
     "xrl_wide_dw1": [C.POINTER(PpoWide), C.POINTER(c_int32), c_void_p],

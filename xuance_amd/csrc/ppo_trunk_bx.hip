@@ -54,7 +54,7 @@ struct BxLds {                               // byte offsets
     static constexpr int H1P = 0, G2P = H1P + 3 * BPLANE * 2, H2 = G2P + 3 * BPLANE * 2, XS = H2 + BPT * BLD * 4,
                          RSC = XS + BPT * BXLD * 4, DZH = RSC + BPT * 12 * 4, W0T = DZH + BPT * 16 * 4, B0 = W0T + BD * BLD * 4,
                          BM = B0 + BH * 4, WH = BM + BH * 4, BHS = WH + BA * BLD * 4, SRC = BHS + 8 * 4, RST = SRC + BPT * 4,
-                         BYTES = RST + BPT * 5 * 8;
+                         BGP = RST + BPT * 5 * 8, BYTES = BGP + 2 * BH * 8;
 };
 static_assert(BxLds::BYTES <= 160 * 1024, "LDS");
 static_assert((BxLds::RST & 7) == 0 && (BxLds::H2 & 15) == 0 && (BxLds::G2P & 15) == 0, "alignment");
@@ -102,9 +102,24 @@ __device__ __forceinline__ void plane_store4(unsigned short* pl, int o, float v0
     *reinterpret_cast<uint2*>(pl + 2 * BPLANE + o) = make_uint2(l0, l1);
 }
 
-template <int ACT, bool TR>
+// K-split: the two waves that own the same 32 columns (one per 32-row block) split the k-range of the two weight-streamed products instead of the
+// rows: each streams HALF of the tile's fragment planes and forms partial sums for BOTH row blocks, the halves meet through LDS (one
+// extra barrier per product).  Without it both waves request the same 48 KB and the workgroup pulls 96 KB per direction through a CU
+// that takes ~10 bytes per clock from L2: the forward product then ends when the stream does (11.9 k cycles into the launch).
+// KSF / KSB: the forward / the backward-data product.  DEFAULT: backward only.  Forward, the other summation order is harmless as
+// arithmetic (one more float32 addition per element) but h2 feeds a DISCONTINUOUS function, act'(h2): of the ~2 M pre-activations of a
+// minibatch about 0.2 lie within float32 summation noise of zero, and an evaluation whose noise lands such an element on the other
+// side than exact arithmetic moves one term of the 8 192-row gradient sums by 99 % -- 1e-4 of a cancelling tensor's scale.  The
+// reference's own float32 gradient sits 6e-5 ... 1.5e-4 from its float64 twin on the C2 fixture for exactly that reason; the
+// row-split forward happens to agree with the twin on every element of the fixtures (3e-7), the k-split one flips one
+// (tools/probe_split_noise.py: critic.values.0.weight 2.5e-4) -- a coin any float32 evaluation tosses, but the fixtures are held
+// where they are.  dH1 feeds only sums (g1 = dH1 * act'(h1), h1 untouched): the k-split there stays at 1e-7.
+// LB: the barrier behind the small gradients moved behind the two matrix phases that follow them (a wave that is through with its share
+// of the vector sums starts on the weight gradient at once).
+template <int ACT, bool TR, bool KSF, bool KSB, bool LB = false>
 __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fused_t p) {
     using L = BxLds;
+    constexpr int NQF = KSF ? 4 : 8, NQB = KSB ? 4 : 8, NQ = NQF > NQB ? NQF : NQB;     // k-steps of the weight-streamed products per wave
     constexpr int TPR = FUSED_THREADS / BPT;           // threads per row in the VALU phases: 8
     constexpr int NCH = (BH / 4) / TPR;                // float4 chunks of the branch level per thread: 4
     constexpr int D = BD, A = BA;
@@ -122,6 +137,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     float* bhs = reinterpret_cast<float*>(lds_raw + L::BHS);
     int* srcs = reinterpret_cast<int*>(lds_raw + L::SRC);
     double* rowstat = reinterpret_cast<double*>(lds_raw + L::RST);                // [5][64] per-row loss terms
+    double* bgp = reinterpret_cast<double*>(lds_raw + L::BGP);                    // [2][128] branch-bias gradient of the two row halves
 
     kernarg_prefetch<sizeof(xrl_ppo_fused_t)>();
     const int tid = threadIdx.x, M = p.M;
@@ -145,12 +161,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     if (dbg && tid == 0) dbg[16 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
     TSTAMP(0);
 
-    // ================= loads: rows, small parameters, then this role's forward fragment planes (8 k-steps x 3 planes x 16 bytes per lane)
+    // ================= loads: EVERY request first (record rows, the three small-parameter words of this thread, this role's forward
+    // fragment planes: 8 k-steps x 3 planes x 16 bytes per lane), then the LDS writes -- written as loops over the parameter arrays the
+    // compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per array: five L2 round trips in a row in front of the fragment stream
     const bool records = p.f_rows || p.f_packed;
+    float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (records) {                                     // 32-byte records obs[4] | act | ret | adv | old_logp: one wave
         if (wave == 7) {
             const int m = m0 + lane;
-            float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < M) {
                 size_t at = (size_t)m;
                 if (!p.f_rows) {
@@ -161,9 +179,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
                 const float4* rec = reinterpret_cast<const float4*>(p.f_rows ? p.f_rows : p.f_packed) + at * 2;
                 xr = rec[0]; sc = rec[1];
             }
-            *reinterpret_cast<float4*>(xs + lane * BXLD) = xr;
-            *reinterpret_cast<float4*>(xs + lane * BXLD + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            rsc[lane * 12 + 0] = sc.x; rsc[lane * 12 + 8] = sc.y; rsc[lane * 12 + 9] = sc.z; rsc[lane * 12 + 10] = sc.w;
         }
     } else if (tid < BPT) {                            // buffer row of each minibatch row (env-major flat index, memory_tools.py:270)
         const int m = m0 + tid;
@@ -177,31 +192,38 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     }
     float st_mean = 0.f, st_std = 1.f;
     if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
-    for (int e = tid; e < BH * D; e += FUSED_THREADS) {
-        const int c = e / D, k = e - c * D;
-        w0t[k * BLD + c] = p.params[L0.w_off + e];
-    }
-    if (tid < BH) b0s[tid] = p.params[L0.b_off + tid];
-    else if (tid < 2 * BH) bms[tid - BH] = p.params[L1.b_off + cb + tid - BH];
-    else if (tid < 2 * BH + 8) {
-        const int j = tid - 2 * BH;
-        bhs[j] = j < nout ? p.params[Lh.b_off + j] : 0.f;
-    }
-    for (int e = tid; e < nout * BH; e += FUSED_THREADS) {
-        const int j = e >> 7, k = e & (BH - 1);
-        whs[j * BLD + k] = p.params[Lh.w_off + e];
-    }
-    // (fragment stream requested AFTER the small loads: a wave's loads retire in order)
-    bu32x4 pf[8][3];
+    // W0 [128][4]: one element per thread; b0 | this role's branch bias | head bias: one word of threads 0..263; head rows: threads 0..nout*128
+    static_assert(BH * BD == FUSED_THREADS, "one first-layer weight per thread");
+    const float w0v = p.params[L0.w_off + tid];
+    float smv = 0.f;
+    if (tid < BH) smv = p.params[L0.b_off + tid];
+    else if (tid < 2 * BH) smv = p.params[L1.b_off + cb + tid - BH];
+    else if (tid < 2 * BH + nout) smv = p.params[Lh.b_off + tid - 2 * BH];
+    float whv = 0.f;
+    if (tid < nout * BH) whv = p.params[Lh.w_off + tid];
+    bu32x4 pf[NQ][3];
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.frag16), 0, 3 * XRL_FRAG16_PLANE * 2, 0x00020000);
     {
         const int t = 4 * role + cblk;                                   // 32-row tile of the stacked 256-row W1
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq)
+        for (int j = 0; j < NQF; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                pf[qq][pl] = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (pl * XRL_FRAG16_PLANE + (t * 8 + ((qq + t) & 7)) * 512) * 2, 0);
+            for (int pl = 0; pl < 3; ++pl) {
+                const int qq = KSF ? 4 * rblk + j : j;
+                pf[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (pl * XRL_FRAG16_PLANE + (t * 8 + ((qq + t) & 7)) * 512) * 2, 0);
+            }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (records && wave == 7) {
+        *reinterpret_cast<float4*>(xs + lane * BXLD) = xr;
+        *reinterpret_cast<float4*>(xs + lane * BXLD + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        rsc[lane * 12 + 0] = sc.x; rsc[lane * 12 + 8] = sc.y; rsc[lane * 12 + 9] = sc.z; rsc[lane * 12 + 10] = sc.w;
+    }
+    w0t[(tid & (BD - 1)) * BLD + (tid >> 2)] = w0v;                      // element e = column (e >> 2), k (e & 3) -> k-major
+    if (tid < BH) b0s[tid] = smv;
+    else if (tid < 2 * BH) bms[tid - BH] = smv;
+    else if (tid < 2 * BH + 8) bhs[tid - 2 * BH] = smv;
+    if (tid < nout * BH) whs[(tid >> 7) * BLD + (tid & (BH - 1))] = whv;
     if (!records) {
         lds_barrier();                                                                               // (srcs)
         for (int e = tid; e < BPT * BXLD; e += FUSED_THREADS) {
@@ -248,35 +270,71 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     // ---- this role's branch layer 128 -> 128, transposed as well: wave (cblk, rblk): C[i = column 32 cblk + ..][j = row 32 rblk + li];
     //      A = the weight planes in registers, B = h1's planes (16-byte row reads: k = 16 qq + 8 lh + 0..7)
     {
-        const unsigned short* hrow = h1p + (rblk * 32 + li) * BPL + 8 * lh;
-        f32x16 acc;
+        const int row = rblk * 32 + li;                                 // the row this lane finishes
+        if constexpr (!KSF) {
+            const unsigned short* hrow = h1p + row * BPL + 8 * lh;
+            f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) {
-            const bu32x4 xh = *reinterpret_cast<const bu32x4*>(hrow + 16 * qq), xm = *reinterpret_cast<const bu32x4*>(hrow + BPLANE + 16 * qq),
-                         xl = *reinterpret_cast<const bu32x4*>(hrow + 2 * BPLANE + 16 * qq);
-            // (term names: activation part, weight part -- the operands of the instruction are (weights, rows))
-            acc = BX_MFMA(pf[qq][0], xl, acc); acc = BX_MFMA(pf[qq][2], xh, acc); acc = BX_MFMA(pf[qq][1], xm, acc);
-            acc = BX_MFMA(pf[qq][0], xm, acc); acc = BX_MFMA(pf[qq][1], xh, acc); acc = BX_MFMA(pf[qq][0], xh, acc);
-        }
-        const int row = rblk * 32 + li;
+            for (int qq = 0; qq < 8; ++qq) {
+                const bu32x4 xh = *reinterpret_cast<const bu32x4*>(hrow + 16 * qq), xm = *reinterpret_cast<const bu32x4*>(hrow + BPLANE + 16 * qq),
+                             xl = *reinterpret_cast<const bu32x4*>(hrow + 2 * BPLANE + 16 * qq);
+                // (term names: activation part, weight part -- the operands of the instruction are (weights, rows))
+                acc = BX_MFMA(pf[qq][0], xl, acc); acc = BX_MFMA(pf[qq][2], xh, acc); acc = BX_MFMA(pf[qq][1], xm, acc);
+                acc = BX_MFMA(pf[qq][0], xm, acc); acc = BX_MFMA(pf[qq][1], xh, acc); acc = BX_MFMA(pf[qq][0], xh, acc);
+            }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n0 = cblk * 32 + 8 * g + 4 * lh;
-            const float4 b = *reinterpret_cast<const float4*>(bms + n0);
-            *reinterpret_cast<float4*>(h2 + row * BLD + n0) = make_float4(act_apply_c<ACT>(acc[4 * g] + b.x), act_apply_c<ACT>(acc[4 * g + 1] + b.y),
-                                                                         act_apply_c<ACT>(acc[4 * g + 2] + b.z), act_apply_c<ACT>(acc[4 * g + 3] + b.w));
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = cblk * 32 + 8 * g + 4 * lh;
+                const float4 b = *reinterpret_cast<const float4*>(bms + n0);
+                *reinterpret_cast<float4*>(h2 + row * BLD + n0) = make_float4(act_apply_c<ACT>(acc[4 * g] + b.x), act_apply_c<ACT>(acc[4 * g + 1] + b.y),
+                                                                             act_apply_c<ACT>(acc[4 * g + 2] + b.z), act_apply_c<ACT>(acc[4 * g + 3] + b.w));
+            }
+        } else {
+            // k-steps 4 rblk .. 4 rblk + 3 for both row blocks: `mine` = this wave's block (rows 32 rblk + li), `other` = the partner's
+            const int orow = (1 - rblk) * 32 + li;
+            const unsigned short* hmine = h1p + row * BPL + 8 * lh + 64 * rblk;
+            const unsigned short* hother = h1p + orow * BPL + 8 * lh + 64 * rblk;
+            f32x16 mine, other;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { mine[i] = 0.f; other[i] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bu32x4 xh = *reinterpret_cast<const bu32x4*>(hmine + 16 * j), xm = *reinterpret_cast<const bu32x4*>(hmine + BPLANE + 16 * j),
+                             xl = *reinterpret_cast<const bu32x4*>(hmine + 2 * BPLANE + 16 * j);
+                const bu32x4 yh = *reinterpret_cast<const bu32x4*>(hother + 16 * j), ym = *reinterpret_cast<const bu32x4*>(hother + BPLANE + 16 * j),
+                             yl = *reinterpret_cast<const bu32x4*>(hother + 2 * BPLANE + 16 * j);
+                mine = BX_MFMA(pf[j][0], xl, mine); other = BX_MFMA(pf[j][0], yl, other);
+                mine = BX_MFMA(pf[j][2], xh, mine); other = BX_MFMA(pf[j][2], yh, other);
+                mine = BX_MFMA(pf[j][1], xm, mine); other = BX_MFMA(pf[j][1], ym, other);
+                mine = BX_MFMA(pf[j][0], xm, mine); other = BX_MFMA(pf[j][0], ym, other);
+                mine = BX_MFMA(pf[j][1], xh, mine); other = BX_MFMA(pf[j][1], yh, other);
+                mine = BX_MFMA(pf[j][0], xh, mine); other = BX_MFMA(pf[j][0], yh, other);
+            }
+            // the partner's half of `other` rows goes where their h2 will be; it leaves its half of this wave's rows there
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(h2 + orow * BLD + cblk * 32 + 8 * g + 4 * lh) = make_float4(other[4 * g], other[4 * g + 1], other[4 * g + 2], other[4 * g + 3]);
+            lds_barrier();                                                                           // #1b the k-halves
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = cblk * 32 + 8 * g + 4 * lh;
+                const float4 b = *reinterpret_cast<const float4*>(bms + n0), o = *reinterpret_cast<const float4*>(h2 + row * BLD + n0);
+                // (k-half 0 + k-half 1, whichever wave adds them)
+                *reinterpret_cast<float4*>(h2 + row * BLD + n0) = make_float4(act_apply_c<ACT>((mine[4 * g] + o.x) + b.x), act_apply_c<ACT>((mine[4 * g + 1] + o.y) + b.y),
+                                                                             act_apply_c<ACT>((mine[4 * g + 2] + o.z) + b.z), act_apply_c<ACT>((mine[4 * g + 3] + o.w) + b.w));
+            }
         }
         // forward planes consumed: the same registers take the BACKWARD section (output tile kt = cblk of dH1, this role's 8 n-steps
         // q = 8 role + qq), which has the head / loss / weight-gradient phases to arrive
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq)
+        for (int j = 0; j < NQB; ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                const int q = 8 * role + qq;
-                pf[qq][pl] = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (pl * XRL_FRAG16_PLANE + XRL_FRAG16_PLANE / 2 + (cblk * 16 + ((q + cblk) & 15)) * 512) * 2, 0);
+                const int q = 8 * role + (KSB ? 4 * rblk + j : j);
+                pf[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (pl * XRL_FRAG16_PLANE + XRL_FRAG16_PLANE / 2 + (cblk * 16 + ((q + cblk) & 15)) * 512) * 2, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -384,14 +442,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         for (int rr = 0; rr < BPT; ++rr) acc += dzh[rr * 16 + j] * hp[rr * BLD];
         slab[Lh.w_off + e] = acc;
     }
-    if (tid >= 4 * 64 && tid < 4 * 64 + BH) {                           // (column sums in double, rounded once: ppo_trunk_kernel's note)
-        const int t = tid - 4 * 64;
+    // (column sums in double, rounded once: ppo_trunk_kernel's note.  The branch bias: waves 4..7, column t, rows [32 rh, +32) -- each
+    //  element comes back from its three planes exactly; the two halves meet behind the barrier.  The head rows' loops above run on
+    //  waves 0..3 / 0..1 meanwhile.)
+    if (tid >= 4 * 64) {
+        const int t = (tid - 4 * 64) & (BH - 1), rh = (tid - 4 * 64) >> 7;
         double acc0 = 0.0;
 #pragma unroll 16
-        for (int rr = 0; rr < BPT; ++rr) acc0 += (double)plane_value(g2p, rr * BPL + t);
-        slab[L1.b_off + cb + t] = (float)acc0;
-    } else if (tid >= 6 * 64 && tid < 6 * 64 + 8) {
-        const int t = tid - 6 * 64;
+        for (int rr = 0; rr < BPT / 2; ++rr) acc0 += (double)plane_value(g2p, (rh * (BPT / 2) + rr) * BPL + t);
+        bgp[rh * BH + t] = acc0;
+    } else if (tid >= 3 * 64 && tid < 3 * 64 + 8) {
+        const int t = tid - 3 * 64;
         if (t < nout) {
             double acc = 0.0;
 #pragma unroll 16
@@ -399,7 +460,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
             slab[Lh.b_off + t] = (float)acc;
         }
     }
-    lds_barrier();                                                                                   // #3b no matrix instruction beside a vector loop
+    if constexpr (!LB) {
+        lds_barrier();                                                                               // #3b no matrix instruction beside a vector loop
+        if (tid < BH) slab[L1.b_off + cb + tid] = (float)(bgp[tid] + bgp[BH + tid]);
+    }
     TSTAMP(5);
     // ---- dW1[n][k] = sum over the 64 rows of g2[row][n] * h1[row][k] for this role's 128 rows n: 4 x 4 tiles of 32 x 32, wave w owns
     //      n-tile (w & 3) and the k-tiles 2 (w >> 2), 2 (w >> 2) + 1; four 16-row steps; both operands are column slices of planes
@@ -430,13 +494,33 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         //      rows [32 rblk, +32); A = g2's planes (row reads), B = the backward planes requested after the forward layer.
         //      The 32 stores of this wave's dW1 tiles are issued between these instructions (ppo_trunk_kernel's note).
         float* dW = slab + L1.w_off + (size_t)(cb + nt * 32) * BH;
-        {
+        f32x16 dother;
+        if constexpr (!KSB) {
             const unsigned short* grow = g2p + (rblk * 32 + li) * BPL + 8 * lh;
 #pragma unroll
             for (int qq = 0; qq < 8; ++qq) {
                 const bu32x4 gh = *reinterpret_cast<const bu32x4*>(grow + 16 * qq), gm = *reinterpret_cast<const bu32x4*>(grow + BPLANE + 16 * qq),
                              gl = *reinterpret_cast<const bu32x4*>(grow + 2 * BPLANE + 16 * qq);
                 BX_MFMA6(gh, gm, gl, pf[qq][0], pf[qq][1], pf[qq][2], dacc)
+            }
+        } else {
+            // n-steps 4 rblk .. 4 rblk + 3 of this role's 8, both row blocks (dacc: this wave's rows, dother: the partner's)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dother[i] = 0.f;
+            const unsigned short* gmine = g2p + (rblk * 32 + li) * BPL + 8 * lh + 64 * rblk;
+            const unsigned short* goth = g2p + ((1 - rblk) * 32 + li) * BPL + 8 * lh + 64 * rblk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bu32x4 gh = *reinterpret_cast<const bu32x4*>(gmine + 16 * j), gm = *reinterpret_cast<const bu32x4*>(gmine + BPLANE + 16 * j),
+                             gl = *reinterpret_cast<const bu32x4*>(gmine + 2 * BPLANE + 16 * j);
+                const bu32x4 oh = *reinterpret_cast<const bu32x4*>(goth + 16 * j), om = *reinterpret_cast<const bu32x4*>(goth + BPLANE + 16 * j),
+                             ol = *reinterpret_cast<const bu32x4*>(goth + 2 * BPLANE + 16 * j);
+                dacc = BX_MFMA(gl, pf[j][0], dacc); dother = BX_MFMA(ol, pf[j][0], dother);
+                dacc = BX_MFMA(gh, pf[j][2], dacc); dother = BX_MFMA(oh, pf[j][2], dother);
+                dacc = BX_MFMA(gm, pf[j][1], dacc); dother = BX_MFMA(om, pf[j][1], dother);
+                dacc = BX_MFMA(gm, pf[j][0], dacc); dother = BX_MFMA(om, pf[j][0], dother);
+                dacc = BX_MFMA(gh, pf[j][1], dacc); dother = BX_MFMA(oh, pf[j][1], dother);
+                dacc = BX_MFMA(gh, pf[j][0], dacc); dother = BX_MFMA(oh, pf[j][0], dother);
             }
         }
 #pragma unroll
@@ -448,13 +532,32 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
             }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
+        if constexpr (LB) {
+            lds_barrier();                                                                           // #3b, late: h2 / dzh / rsc have no reader left
+            if (tid < BH) slab[L1.b_off + cb + tid] = (float)(bgp[tid] + bgp[BH + tid]);
+        }
+        if constexpr (KSB) {
+            // the n-halves meet where h2 was (its last readers are behind barrier #3b): [wave][4][64 lanes] float4
+            float4* xch = reinterpret_cast<float4*>(h2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xch[(wave * 4 + g) * 64 + lane] = make_float4(dother[4 * g], dother[4 * g + 1], dother[4 * g + 2], dother[4 * g + 3]);
+            lds_barrier();                                                                           // #3c the n-halves
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = xch[((wave ^ 4) * 4 + g) * 64 + lane];
+                dacc[4 * g] += o.x; dacc[4 * g + 1] += o.y; dacc[4 * g + 2] += o.z; dacc[4 * g + 3] += o.w;
+            }
+        }
     }
     // ---- first layer: dW0[c][k] = sum_rows g1[row][c] * x[row][k], db0[c], g1 = dH1 * act'(h1) -- straight from the dH1 accumulators
     //      (ppo_trunk_kernel's form; h1 comes back from its planes, exactly)
     {
         float* dst = actor ? slab : slab + p.l0_fold_off;
         const int w_at = actor ? L0.w_off : 0, b_at = actor ? L0.b_off : BH * D;
-        float* part = h2;                                                // [2][128][D + 1] partial sums of the row blocks
+        // [2][128][D + 1] partial sums of the row blocks: where h2 was, or (KSB: h2's place holds the n-halves other waves may still be
+        // reading) where the row scalars and head gradients were -- dead since barrier #3b
+        float* part = KSB ? rsc : h2;
+        static_assert(2 * BH * (BD + 1) * 4 <= BPT * 12 * 4 + BPT * 16 * 4 && BxLds::DZH == BxLds::RSC + BPT * 12 * 4, "first-layer partial sums");
         constexpr int PLD = D + 1;
         {
             const int c = cblk * 32 + li;
@@ -499,6 +602,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 static int g_bx_tr = 1;                                   // weight-gradient operands through ds_read_b64_tr_b16 (0: 2-byte reads; diagnostics)
+static int g_bx_ks = 5;                                   // the wave pair of a column block splits k, not rows: 0 nowhere, 1 backward-data product, 2 both
 
 bool ppo_trunk_bx_eligible(const xrl_ppo_fused_t& p) {
     return p.frag16 != nullptr && p.pad0 == 64 && p.dist == 0 && p.D == BD && p.A == BA && p.layers[1].N == 2 * BH && p.layers[1].K == BH;
@@ -507,8 +611,11 @@ bool ppo_trunk_bx_eligible(const xrl_ppo_fused_t& p) {
 template <int ACT>
 static int launch_bx(const xrl_ppo_fused_t& p, hipStream_t stream) {
     const int n_tiles = (p.M + BPT - 1) / BPT;
-    if (g_bx_tr) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
-    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
+    if (!g_bx_tr) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, false, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
+    else if (g_bx_ks == 1) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
+    else if (g_bx_ks == 5) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
+    else if (g_bx_ks == 2) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
+    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
@@ -523,8 +630,11 @@ int launch_ppo_trunk_bx(const xrl_ppo_fused_t& p, hipStream_t stream) {
 
 template <int ACT>
 static int init_bx_one() {
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
     return XRL_OK;
 }
 
@@ -562,5 +672,11 @@ extern "C" int xrl_pack_mid_frags16(const xrl_ppo_fused_t* pp, uint16_t* image, 
 
 extern "C" int xrl_set_split_product_tr(int on) {
     g_bx_tr = on ? 1 : 0;
+    return XRL_OK;
+}
+
+extern "C" int xrl_set_split_product_ksplit(int mode) {
+    XRL_CHECK_ARG((mode >= 0 && mode <= 2) || mode == 5);            // (5: mode 1 with the barrier behind the small gradients moved behind the matrix phases)
+    g_bx_ks = mode;
     return XRL_OK;
 }

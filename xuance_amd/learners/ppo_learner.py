@@ -340,9 +340,12 @@ class PPO_Learner(Learner):
         self.frag16 = None
         if nf and self.split and self.pair and getattr(self.config, "use_split_products", True) \
                 and ops.split_products_class(self.model.plan, D, self.model.action_dim, self.model.dist) \
-                and len(self._mirrors) + 2 <= 4 and not getattr(self.config, "use_chained_update", False):
+                and not getattr(self.config, "use_chained_update", False):
             self.frag16 = torch.zeros(3 * ops.FRAG16_PLANE, dtype=torch.int16, device=dev)
             mf16, mb16 = ops.frag16_layout_maps(self.model.plan, P, dev)
+            # (every minibatch launch of this learner then reads the split image: the float32 fragment copy is refreshed once per
+            #  update phase -- refresh_fused_params -- and is nobody's operand in between: its two mirror maps leave the optimiser launch)
+            self._mirrors = [mm for mm in self._mirrors if mm[1] is not self.frag]
             self._mirrors += [(mf16, self.frag16, ops.FRAG16_PLANE), (mb16, self.frag16, ops.FRAG16_PLANE)]
         self.packed = torch.zeros(memory.n_size * memory.n_envs * 8, device=dev) if self.records else None   # transition records
         self._mirror = True

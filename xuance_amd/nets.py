@@ -470,6 +470,8 @@ class ActorNet:
     ActorCriticNet (forward -> head buffer [cap, action_dim], d_heads, backward), reference parameter names
     ``actor.representation.model.<i>``, ``actor.actor_head.{logits|mu}.<i>``, ``actor.actor_head.log_std``."""
 
+    CHAIN_MAX_ROWS = ActorCriticNet.CHAIN_MAX_ROWS                     # (forward is ActorCriticNet's)
+
     def __init__(self, obs_dim, action_dim, dist="categorical", representation_hidden=(128,), actor_hidden=(128,),
                  activation="leaky_relu", activation_action=None, device="cuda", init=True):
         assert dist in ("categorical", "gaussian")

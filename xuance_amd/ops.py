@@ -412,6 +412,12 @@ def set_split_product_tr(on):
     call("xrl_set_split_product_tr", int(bool(on)))
 
 
+def set_split_product_ksplit(mode):
+    """Diagnostics: the split-product kernel's wave pairs split k instead of rows in 0 no / 1 the backward-data (default) / 2 both
+    weight-streamed products."""
+    call("xrl_set_split_product_ksplit", int(mode))
+
+
 def pack_transitions(f_obs, f_act, f_ret, f_adv, f_logp, packed, count):
     call("xrl_pack_transitions", ptr(f_obs), ptr(f_act), ptr(f_ret), ptr(f_adv), ptr(f_logp), ptr(packed), int(count),
          stream_ptr())
@@ -570,6 +576,9 @@ def init_device():
     if not _inited:
         call("xrl_init")
         _inited = True
+        import os
+        if os.environ.get("XRL_SPLIT_PRODUCT_KSPLIT"):             # diagnostics (tools/, profiles/r06_q_*): see set_split_product_ksplit
+            set_split_product_ksplit(int(os.environ["XRL_SPLIT_PRODUCT_KSPLIT"]))
 
 
 def fused_layers_from_plan(plan, p):
