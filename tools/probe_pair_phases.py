@@ -43,6 +43,9 @@ for mode in ("pair-bx", "pair", "tile32"):      # ("chain": round 4's variant, t
         t = d[16:16 + 2 * 256].reshape(256, 2).astype(np.float64) * 10e-3      # us
         t0 = t[:, 0].min()
         print("pair: alone %.1f us; phases (cycles):" % us, dict(zip(names, ph.tolist())))
+        if mode == "pair-bx":
+            print("  split-product kernel, inside 'dH1+g1' (cycles from start): dH1 issued + dW stores queued %d | late barrier %d | n-halves met %d | first-layer sums formed %d | barrier #4 %d"
+                  % tuple(int(d[k] - d[0]) for k in (9, 10, 11, 12, 7)))
         w = d[1100:1100 + 128].reshape(8, 16)[:, :8] - d[0]
         print("  waves of the last workgroup (cycles from its start): small grads done | dW1 MFMAs done | dW1 stored | dH1 MFMAs done | past barrier 4 | g1 stored | past barrier 5 | end")
         for i in range(8):

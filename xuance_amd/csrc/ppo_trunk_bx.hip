@@ -467,6 +467,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     TSTAMP(5);
     // ---- dW1[n][k] = sum over the 64 rows of g2[row][n] * h1[row][k] for this role's 128 rows n: 4 x 4 tiles of 32 x 32, wave w owns
     //      n-tile (w & 3) and the k-tiles 2 (w >> 2), 2 (w >> 2) + 1; four 16-row steps; both operands are column slices of planes
+    //      (the instruction's A operand is h1's slice, B is g2's: the tile comes out as [k][n])
     f32x16 dacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
@@ -486,7 +487,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
                 const int c0 = (kt0 + t) * 32;
                 const bu32x4 xh = plane_column8<TR>(h1p, 16 * rs, c0, li, lh), xm = plane_column8<TR>(h1p + BPLANE, 16 * rs, c0, li, lh),
                              xl = plane_column8<TR>(h1p + 2 * BPLANE, 16 * rs, c0, li, lh);
-                BX_MFMA6(gh, gm, gl, xh, xm, xl, acc[t])
+                BX_MFMA6(xh, xm, xl, gh, gm, gl, acc[t])                // (transposed: C[i = k][j = n] -- see the stores below)
             }
         }
         TSTAMP(6);
@@ -523,17 +524,22 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
                 dacc = BX_MFMA(gh, pf[j][0], dacc); dother = BX_MFMA(oh, pf[j][0], dother);
             }
         }
+        // (the weight-gradient tiles were formed TRANSPOSED -- A = h1's column slices, B = g2's -- so that lane (li, lh) holds
+        //  dW1[n = 32 nt + li][k = 32 kt + 8 g + 4 lh + 0..3]: four consecutive floats of a slab row, 8 stores of 16 bytes per lane
+        //  instead of 32 of 4.  The slab write-out is bound by store ISSUE on this chip (MI355X_MICROARCH.md: a row-per-lane epilogue
+        //  of narrow stores drains at ~7 bytes per clock and CU), and 64 KB per workgroup at that rate was the longest part of this phase.)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                dW[(size_t)row * BH + (kt0 + t) * 32 + li] = acc[t][rr];
-            }
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(dW + (size_t)li * BH + (kt0 + t) * 32 + 8 * g + 4 * lh) =
+                    make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
+        for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 6, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); }
+        TSTAMP(9);
         if constexpr (LB) {
             lds_barrier();                                                                           // #3b, late: h2 / dzh / rsc have no reader left
+            TSTAMP(10);
             if (tid < BH) slab[L1.b_off + cb + tid] = (float)(bgp[tid] + bgp[BH + tid]);
         }
         if constexpr (KSB) {
@@ -542,6 +548,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
 #pragma unroll
             for (int g = 0; g < 4; ++g) xch[(wave * 4 + g) * 64 + lane] = make_float4(dother[4 * g], dother[4 * g + 1], dother[4 * g + 2], dother[4 * g + 3]);
             lds_barrier();                                                                           // #3c the n-halves
+            TSTAMP(11);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 o = xch[((wave ^ 4) * 4 + g) * 64 + lane];
@@ -584,6 +591,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
                 pp[D] = ab;
             }
         }
+        TSTAMP(12);
         lds_barrier();                                                                               // #4 the two row blocks' partial sums
         TSTAMP(7);
         for (int e = tid; e < BH * (D + 1); e += FUSED_THREADS) {
