@@ -11,9 +11,9 @@ from xuance_amd import ops
 from xuance_amd.agents import PPO_Agent
 from xuance_amd.envs import DeviceCartPoleVecEnv
 n = 256
-for mode in ("pair-bx", "pair", "tile32"):      # ("chain": round 4's variant, tools/csrc/ppo_chain.hip, no longer in the library)
+for mode in ("pair-bx", "pair-bx-actor", "pair", "tile32"):      # ("chain": round 4's variant, tools/csrc/ppo_chain.hip, no longer in the library)
     pair = mode != "tile32"
-    cfg = bench.make_config(n, 256, 1, 0); cfg.use_pair_update = pair; cfg.use_split_products = mode == "pair-bx"
+    cfg = bench.make_config(n, 256, 1, 0); cfg.use_pair_update = pair; cfg.use_split_products = mode.startswith("pair-bx")
     torch.manual_seed(1)
     agent = PPO_Agent(cfg, DeviceCartPoleVecEnv(n, seed=1))
     agent.rollout(); agent.update(); torch.cuda.synchronize()
@@ -28,7 +28,7 @@ for mode in ("pair-bx", "pair", "tile32"):      # ("chain": round 4's variant, t
                                 diag=None, slab_stride=lr.slab_stride, l0_fold_off=lr.fold[0] if lr.fold else 0, M=bs, n_envs=n, T=256,
                                 D=4, A=2, clip_range=0.2, vf_coef=0.25, ent_coef=0.01, dbg=d, frag_image=lr.frag, f_packed=lr.packed,
                                 f_rows=lr.rows[3 * bs * 8:4 * bs * 8], pad0=64 if lr.pair else 0,
-                                frag16=lr.frag16 if mode == "pair-bx" else None)
+                                frag16=lr.frag16 if mode.startswith("pair-bx") else None, pad3=2 if mode == "pair-bx-actor" else 0)
     for _ in range(3):
         launch(dbg)
         torch.cuda.synchronize()
@@ -42,8 +42,8 @@ for mode in ("pair-bx", "pair", "tile32"):      # ("chain": round 4's variant, t
         ph = d[:9] - d[0]
         t = d[16:16 + 2 * 256].reshape(256, 2).astype(np.float64) * 10e-3      # us
         t0 = t[:, 0].min()
-        print("pair: alone %.1f us; phases (cycles):" % us, dict(zip(names, ph.tolist())))
-        if mode == "pair-bx":
+        print("%s: alone %.1f us; phases (cycles):" % (mode, us), dict(zip(names, ph.tolist())))
+        if mode.startswith("pair-bx"):
             print("  split-product kernel, inside 'dH1+g1' (cycles from start): dH1 issued + dW stores queued %d | late barrier %d | n-halves met %d | first-layer sums formed %d | barrier #4 %d"
                   % tuple(int(d[k] - d[0]) for k in (9, 10, 11, 12, 7)))
         w = d[1100:1100 + 128].reshape(8, 16)[:, :8] - d[0]

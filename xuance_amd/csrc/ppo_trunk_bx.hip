@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     const xrl_fused_layer_t& Lh = actor ? La : Lc;
 
     long long* dbg = p.dbg;                            // diagnostics (tools/probe_pair_phases.py)
-    const bool dbg_me = dbg && tid == 0 && blockIdx.x == gridDim.x - 1;
+    const bool dbg_me = dbg && tid == 0 && blockIdx.x == gridDim.x - (p.pad3 & 2 ? 2 : 1);   // (pad3 bit 1: stamp an ACTOR workgroup)
 #define TSTAMP(k) do { if (dbg_me) dbg[k] = clock64(); } while (0)
     if (dbg && tid == 0) dbg[16 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
     TSTAMP(0);
@@ -205,8 +205,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.frag16), 0, 3 * XRL_FRAG16_PLANE * 2, 0x00020000);
     {
         const int t = 4 * role + cblk;                                   // 32-row tile of the stacked 256-row W1
+        // (the first half of the stream only: a wave cannot reach its LDS writes -- and the workgroup its first barrier -- before all of
+        //  its requests are ISSUED, and 24 x 1 KB per wave through one CU's address path is ~1.4 k cycles; the second half goes out
+        //  behind the barrier, in front of the first layer, and is first needed after four k-steps of the branch layer)
 #pragma unroll
-        for (int j = 0; j < NQF; ++j)
+        for (int j = 0; j < NQF / 2; ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 const int qq = KSF ? 4 * rblk + j : j;
@@ -244,6 +247,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     }
     lds_barrier();                                                                                   // #0 rows, parameters
     TSTAMP(1);
+    {
+        const int t = 4 * role + cblk;
+#pragma unroll
+        for (int j = NQF / 2; j < NQF; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const int qq = KSF ? 4 * rblk + j : j;
+                pf[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 16, (pl * XRL_FRAG16_PLANE + (t * 8 + ((qq + t) & 7)) * 512) * 2, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ================= forward.  First layer, transposed: C[i = column n][j = row] = sum_k W0[n][k] x[row][k] -- ppo_trunk_kernel's two
     // fp32 instructions with the operands exchanged (the same products in the same order); lane (li = row, lh) then holds columns
@@ -575,7 +589,11 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                const float g = dacc[rr] * act_grad_c<ACT>(plane_value(h1p, row * BPL + c));
+                // (relu / leaky_relu: act' depends on the SIGN of h1 only, and h = bf16(h1) has h1's sign and is zero only where h1 is:
+                //  one 2-byte read instead of three and two additions; tanh needs the value: all three planes, exactly)
+                const float h1v = (ACT == XRL_ACT_RELU || ACT == XRL_ACT_LEAKY_RELU) ? bf16_bits_to_float(h1p[row * BPL + c])
+                                                                                      : plane_value(h1p, row * BPL + c);
+                const float g = dacc[rr] * act_grad_c<ACT>(h1v);
                 ab += g;
                 const float4 x = *reinterpret_cast<const float4*>(xs + row * BXLD);
                 acc[0] += g * x.x; acc[1] += g * x.y; acc[2] += g * x.z; acc[3] += g * x.w;
