@@ -721,3 +721,49 @@ def test_split_product_minibatch_against_the_float32_instruction(activation):
     # fold region (the critic role's first-layer gradient) rides behind the parameters
     assert float((gb[P:] - gf[P:]).abs().max()) <= tol * (float(gf[P:].abs().max()) + 1e-30)
     assert torch.allclose(pb, pf, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("records", [True, False])
+def test_split_product_minibatch_on_ragged_minibatches_and_field_rows(records):
+    """The split-product kernel where its index arithmetic differs from the full-tile record path: a minibatch that ends inside a
+    64-row tile (M = 64 k - 17: rows past M must contribute nothing to any sum) and rows gathered through `idx` from the buffer's
+    FIELDS instead of the packed 32-byte records.  Against the float32-instruction kernel on the same launch arguments: 2e-6 of each
+    tensor's scale, loss partials 1e-6; and the slab rows of tiles behind the last one stay untouched."""
+    from xuance_amd import ops
+    n, T = 64, 64
+    M = n * T - 64 * 5 - 17
+    out = {}
+    for tag, split in (("bx", True), ("f32", False)):
+        agent = _pair_agent(n, T, split, seed=11)
+        lr_, mem = agent.learner, agent.memory
+        agent.train(T)
+        torch.cuda.synchronize()
+        if tag == "bx":
+            ref_agent = agent
+            idx = torch.randperm(n * T, device="cuda")[:M].contiguous()
+        else:
+            agent.model.params.flat.copy_(ref_agent.model.params.flat)
+            for k, v in ref_agent.memory.soa.fields.items():
+                mem.soa.fields[k].copy_(v)
+        lr_.prepare_fused(mem, n * T)
+        lr_.refresh_fused_params(mem, None)                           # packed records of the rollout, no gathered rows
+        if not records:
+            lr_._packed_valid = False                                 # rows through idx from the fields
+        lr_._rows_idx = None
+        assert (lr_.frag16 is not None) == split and lr_.pair
+        lr_.fslabs.fill_(7.0)
+        lr_.enqueue_minibatch_fused(mem, idx, None, finish=False)
+        torch.cuda.synchronize()
+        nt = (M + 63) // 64
+        assert bool((lr_.fslabs[nt:] == 7.0).all()), "a workgroup wrote behind the last tile's slab"
+        out[tag] = (lr_.fslabs[:nt].clone(), lr_.fpartials[:2 * nt].clone())
+    (sb, pb), (sf, pf) = out["bx"], out["f32"]
+    gb, gf = sb.double().sum(0), sf.double().sum(0)
+    offs, shapes, P = ref_agent.model.params.offsets, ref_agent.model.params.shapes, ref_agent.model.params.P
+    for k in offs:
+        lo, hi = offs[k], offs[k] + int(np.prod(shapes[k]))
+        S = float(gf[lo:hi].abs().max()) + 1e-30
+        err = float((gb[lo:hi] - gf[lo:hi]).abs().max()) / S
+        assert err <= 2e-6, (k, err)
+    assert float((gb[P:] - gf[P:]).abs().max()) <= 2e-6 * (float(gf[P:].abs().max()) + 1e-30)
+    assert torch.allclose(pb, pf, rtol=1e-6, atol=1e-9)
