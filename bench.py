@@ -424,6 +424,14 @@ def main():
            "config": {"workload": runner.describe, "env": runner.env_name, "parallelism": "dp%d" % world,
                       "env_steps_per_step": env_steps // args.steps, "rollout_mode": runner.rollout_mode(),
                       "last_info": {k: round(float(v), 6) for k, v in info.items() if isinstance(v, (int, float))}}}
+    lr_ = getattr(agent, "learner", None)
+    if c2 and getattr(lr_, "frag16", None) is not None:
+        # operands, accumulators and results of the timed region are float32; what the key does NOT say: how the minibatch launch forms
+        # its three 128-wide float32 products on the matrix cores (no value is rounded to bf16 anywhere)
+        out["dtype_note"] = ("f32 end to end.  The update launch (xrl::ppo_trunk_bx_kernel) forms its 128-wide float32 products as exact 3-way bf16 "
+                             "splits of both operands (x == h + m + l bit for bit), six v_mfma_f32_32x32x16_bf16 per 32x32x16 block with float32 "
+                             "accumulation; the three dropped part products are <= 2^-23 of a scalar product.  Same reference fixtures at the same "
+                             "1e-5 as the float32-instruction kernel (config use_split_products: False selects that one); DESIGN.md section 3 'Round 6' (j)")
     if world > 1:      # which way averaged the gradients in the timed region, what every usable way cost, and a sign of life of RCCL
         out["config"]["gradient_average"] = runner.gradient_average()
         out["config"]["gradient_path"] = path
