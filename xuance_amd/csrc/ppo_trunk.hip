@@ -144,22 +144,29 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
     if constexpr (CHAIN) chain_prologue(o, h1, dbg ? dbg + 2048 : nullptr);      // (diagnostics: dbg holds >= 2048 + 8 x workgroups words then)
     float st_mean = 0.f, st_std = 1.f;
     if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
-    // small parameters straight from the flat buffer: W0 [128][D] -> k-major, biases, this role's head rows, log_std
-    for (int e = tid; e < TH * D; e += FUSED_THREADS) {
-        const int c = e / D, k = e - c * D;
-        w0t[k * TLD + c] = p.params[L0.w_off + e];
+    // small parameters straight from the flat buffer: W0 [128][D] -> k-major, biases, this role's head rows, log_std.  EVERY request
+    // first (a fixed number per thread), the LDS writes behind the fragment stream's requests: written as loops over the arrays the
+    // compiler emitted load -> s_waitcnt vmcnt(0) -> ds_write per array -- five L2 round trips in a row in front of the stream
+    // (round 6, found in csrc/ppo_trunk_bx.hip's listing; same values, same LDS image)
+    constexpr int W0Q = DS ? (TH * DS + FUSED_THREADS - 1) / FUSED_THREADS : (TH * TDMAX + FUSED_THREADS - 1) / FUSED_THREADS;
+    constexpr int WHQ = AS ? (TH * AS + FUSED_THREADS - 1) / FUSED_THREADS : (TH * TAMAX + FUSED_THREADS - 1) / FUSED_THREADS;
+    float w0v[W0Q], whv[WHQ], smv = 0.f, lsv = 0.f;
+#pragma unroll
+    for (int q = 0; q < W0Q; ++q) {
+        const int e = tid + q * FUSED_THREADS;
+        w0v[q] = e < TH * D ? p.params[L0.w_off + e] : 0.f;
     }
-    if ((D & 1) && tid < TH) w0t[D * TLD + tid] = 0.f;    // (the first layer's MFMAs walk k in pairs)
-    if (tid < TH) b0s[tid] = p.params[L0.b_off + tid];
-    else if (tid < 2 * TH) bms[tid - TH] = p.params[L1.b_off + cb + tid - TH];
+    if (tid < TH) smv = p.params[L0.b_off + tid];
+    else if (tid < 2 * TH) smv = p.params[L1.b_off + cb + tid - TH];
     else if (tid < 2 * TH + TAMAX) {
         const int j = tid - 2 * TH;
-        bhs[j] = j < nout ? p.params[Lh.b_off + j] : 0.f;
-        lss[j] = (GAUSS && j < A) ? p.params[p.log_std_off + j] : 0.f;
+        if (j < nout) smv = p.params[Lh.b_off + j];
+        if (GAUSS && j < A) lsv = p.params[p.log_std_off + j];
     }
-    for (int e = tid; e < nout * TH; e += FUSED_THREADS) {
-        const int j = e >> 7, k = e & (TH - 1);
-        whs[j * TLD + k] = p.params[Lh.w_off + e];
+#pragma unroll
+    for (int q = 0; q < WHQ; ++q) {
+        const int e = tid + q * FUSED_THREADS;
+        whv[q] = e < nout * TH ? p.params[Lh.w_off + e] : 0.f;
     }
     // (the fragment stream is requested AFTER the small loads: a wave's loads retire in order, and the first layer must not wait
     //  for 64 KB of weights it does not read)
@@ -168,6 +175,21 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
         const float* base = p.frag_image + ((size_t)t * (TH / 8) * 64 + lane) * 4;
 #pragma unroll
         for (int q = 0; q < PD; ++q) pf[q] = *reinterpret_cast<const float4*>(base + frag_slot(q, t, TH / 8, 1) * 256);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < W0Q; ++q) {
+        const int e = tid + q * FUSED_THREADS;
+        if (e < TH * D) { const int c = e / D, k = e - c * D; w0t[k * TLD + c] = w0v[q]; }
+    }
+    if ((D & 1) && tid < TH) w0t[D * TLD + tid] = 0.f;    // (the first layer's MFMAs walk k in pairs)
+    if (tid < TH) b0s[tid] = smv;
+    else if (tid < 2 * TH) bms[tid - TH] = smv;
+    else if (tid < 2 * TH + TAMAX) { bhs[tid - 2 * TH] = smv; lss[tid - 2 * TH] = lsv; }
+#pragma unroll
+    for (int q = 0; q < WHQ; ++q) {
+        const int e = tid + q * FUSED_THREADS;
+        if (e < nout * TH) whs[(e >> 7) * TLD + (e & (TH - 1))] = whv[q];
     }
     if (!records) {
         lds_barrier();                                                                               // (srcs)
