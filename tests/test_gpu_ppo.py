@@ -252,13 +252,19 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
 
 @pytest.mark.parametrize("dist,size,tiles", [("categorical", "acrobot", 32), ("categorical", "lunar", 32), ("gaussian", "pendulum", 32),
                                              ("gaussian", "walker", 32), ("gaussian", "walker", 64), ("categorical", "acrobot", 64),
-                                             ("categorical", "mountaincar", 32), ("categorical", "mountaincar", 64)])
+                                             ("categorical", "mountaincar", 32), ("categorical", "mountaincar", 64),
+                                             ("categorical", "lunar", 64), ("categorical", "acrobot", "64-f32"),
+                                             ("categorical", "mountaincar", "64-f32"), ("categorical", "lunar", "64-f32")])
 def test_shared_trunk_family_vs_reference_fixture(dist, size, tiles):
     """The other members of the reference's shared-trunk PPO family (Basic_MLP [128] + actor [128] + critic [128]:
     configs/ppo/classic_control/{Acrobot,Pendulum,MountainCar}.yaml, box2d/{LunarLander,BipedalWalker}.yaml -- (D, A) = (6, 3), (3, 1),
     (2, 3), (8, 4), (24, 4), categorical and Gaussian with tanh on the mean) through the ONE-LAUNCH minibatch kernel (csrc/ppo_trunk.hip: (tile, role)
     workgroups, 32- and 64-row tiles) + xrl_reduce_adam, from rows in a HipOnPolicyBuffer, at the 320-row minibatch their yaml
-    gives: the reference learner's loss terms, clipped gradients (float64-anchored), parameter steps, Adam moments."""
+    gives: the reference learner's loss terms, clipped gradients (float64-anchored), parameter steps, Adam moments.  64-row tiles of
+    the categorical members with D <= 8, A <= 4 run the split-product kernel (csrc/ppo_trunk_bx.hip, any-(D, A) instance); "64-f32":
+    the float32 matrix instruction on the same tiles (use_split_products: False)."""
+    f32 = tiles == "64-f32"
+    tiles = 64 if f32 else tiles
     from xuance_amd.nets import ActorCriticNet
     from xuance_amd.learners import PPO_Learner
     from xuance_amd.memory import HipOnPolicyBuffer
@@ -273,7 +279,7 @@ def test_shared_trunk_family_vs_reference_fixture(dist, size, tiles):
     cfg = Namespace(horizon_size=T, n_epochs=1, n_minibatch=1, parallels=n, running_steps=int(total) * n * T, gamma=0.98,
                     learning_rate=float(lr), vf_coef=float(vf), ent_coef=float(ent), clip_range=float(clip), use_grad_clip=True,
                     grad_clip_norm=float(gclip), end_factor_lr_decay=float(ef), distributed_training=False, device="cuda",
-                    model_dir="/tmp/xrl_models", use_pair_update=(tiles == 64))
+                    model_dir="/tmp/xrl_models", use_pair_update=(tiles == 64), use_split_products=not f32)
     learner = PPO_Learner(cfg, net, Capture())
     assert learner.total_iters == int(total) and learner.trunk_eligible()
     mem = HipOnPolicyBuffer(Box(-np.inf, np.inf, (D,), np.float32), Discrete(A) if dist == "categorical" else Box(-1, 1, (A,), np.float32),
@@ -281,6 +287,7 @@ def test_shared_trunk_family_vs_reference_fixture(dist, size, tiles):
     assert learner.fused_eligible(mem)
     learner.prepare_fused(mem, n * T)
     assert learner.split and learner.pair == (tiles == 64) and learner.params_t is None
+    assert (learner.frag16 is not None) == (tiles == 64 and not f32 and dist == "categorical" and D <= 8 and A <= 4)
     chk = EngineFixtureCheck(g, net, learner, float(lr), end_factor=float(ef), total_iters=int(total))
     idx = torch.arange(n * T, dtype=torch.int64, device="cuda").view(1, -1)
     for u in range(int(g["n_updates"])):

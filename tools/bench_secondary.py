@@ -139,7 +139,9 @@ def ppo_acrobot(make_config, n_envs=256, horizon=256, steps=10, warmup=3):
                         % (n_envs, horizon, n_envs * horizon // 8),
             "value": round(n_envs * horizon * steps / dt, 1), "unit": "env-steps/s", "ms_per_step": round(dt / steps * 1e3, 4),
             "steps": steps, "warmup": warmup, "rollout_ms": round((t2 - t1) / 3 * 1e3, 4), "update_ms": round((t3 - t2) / 3 * 1e3, 4),
-            "update_kernel": "ppo_trunk_kernel<leaky_relu, categorical, %d rows, any (D, A)>" % (64 if getattr(lr, "pair", False) else 32),
+            "update_kernel": ("ppo_trunk_bx_kernel<leaky_relu, any (D <= 8, A <= 4)>: 64-row tiles, the 128-wide products as exact 3-way bf16 splits"
+                              if getattr(lr, "frag16", None) is not None else
+                              "ppo_trunk_kernel<leaky_relu, categorical, %d rows, any (D, A)>" % (64 if getattr(lr, "pair", False) else 32)),
             "rollout_path": "captured launches per vector step (general path)"}
 
 

@@ -26,10 +26,11 @@
 // branch layer are issued TRANSPOSED (A = weights, B = rows): a lane then holds 4 CONSECUTIVE columns of one row, and h1's planes /
 // h2 are written as 8- / 16-byte stores instead of 2- / 4-byte ones.
 //
-// Class: the CartPole class of the shared-trunk family ((D, A) = (4, 2), categorical head, 64-row tiles) -- the headline; LDS
-// 151 KB of the CU's 160: wider observation / action rows do not fit beside the six planes (they keep csrc/ppo_trunk.hip).
-// Everything outside the three products -- gather, head, loss, the small gradients, slab layout, loss partials -- is
-// ppo_trunk_kernel<ACT, 0, 64, 4, 2>'s code, statement for statement.
+// Class: the categorical members of the shared-trunk family with D <= 8, A <= 4 on 64-row tiles -- the CartPole class (4, 2), the
+// headline, as a compile-time instance (LDS 153 KB of the CU's 160); Acrobot (6, 3), LunarLander (8, 4), MountainCar (2, 3) through an
+// any-(D, A) instance (156 KB).  Wider rows (BipedalWalker's 24) do not fit beside the six planes, the Gaussian heads are not
+// instantiated: both keep csrc/ppo_trunk.hip.  Everything outside the three products -- gather, head, loss, the small gradients, slab
+// layout, loss partials -- is ppo_trunk_kernel<ACT, 0, 64, DS, AS>'s code, statement for statement.
 // Reference semantics: memory_tools.py:267-287 (sample) + ppo_learner.py:46-62 (forward / loss / backward).
 #include "common.h"
 #include "mlp_tile.h"
@@ -47,17 +48,20 @@ constexpr int BLD = BH + 4;                  // float32 row stride (h2)
 constexpr int BPL = BH + 8;                  // row stride of a 16-bit plane (elements; 272 bytes: 16-byte row reads conflict-free)
 constexpr int BPT = 64;                      // rows per workgroup
 constexpr int BPLANE = BPT * BPL;            // elements per plane
-constexpr int BD = 4, BA = 2;                // observation / head width of the class
+constexpr int BDMAX = 8, BAMAX = 4;          // observation / head width limits of the any-(D, A) instances (six planes + these rows: 160 KB)
 constexpr int BXLD = 8;                      // row stride of the gathered observations
 
+template <int DM, int AM>                    // rows for DM observation dims / AM head rows
 struct BxLds {                               // byte offsets
     static constexpr int H1P = 0, G2P = H1P + 3 * BPLANE * 2, H2 = G2P + 3 * BPLANE * 2, XS = H2 + BPT * BLD * 4,
-                         RSC = XS + BPT * BXLD * 4, DZH = RSC + BPT * 12 * 4, W0T = DZH + BPT * 16 * 4, B0 = W0T + BD * BLD * 4,
-                         BM = B0 + BH * 4, WH = BM + BH * 4, BHS = WH + BA * BLD * 4, SRC = BHS + 8 * 4, RST = SRC + BPT * 4,
+                         RSC = XS + BPT * BXLD * 4, DZH = RSC + BPT * 12 * 4, W0T = DZH + BPT * 16 * 4, B0 = W0T + DM * BLD * 4,
+                         BM = B0 + BH * 4, WH = BM + BH * 4, BHS = WH + AM * BLD * 4, SRC = BHS + 8 * 4, RST = SRC + BPT * 4,
                          BGP = RST + BPT * 5 * 8, BYTES = BGP + 2 * BH * 8;
+    static_assert(BYTES <= 160 * 1024, "LDS");
+    static_assert((RST & 7) == 0 && (H2 & 15) == 0 && (G2P & 15) == 0 && (B0 & 15) == 0 && (WH & 15) == 0, "alignment");
+    // the row blocks' first-layer partial sums [2][128][DM + 1] go where the row scalars, head gradients and first-layer weights were
+    static_assert(DZH == RSC + BPT * 12 * 4 && W0T == DZH + BPT * 16 * 4 && 2 * BH * (DM + 1) * 4 <= B0 - RSC, "first-layer partial sums");
 };
-static_assert(BxLds::BYTES <= 160 * 1024, "LDS");
-static_assert((BxLds::RST & 7) == 0 && (BxLds::H2 & 15) == 0 && (BxLds::G2P & 15) == 0, "alignment");
 
 __device__ __forceinline__ float plane_value(const unsigned short* pl, int o) {          // the float32 an element was split from (exact)
     return (bf16_bits_to_float(pl[o]) + bf16_bits_to_float(pl[BPLANE + o])) + bf16_bits_to_float(pl[2 * BPLANE + o]);
@@ -116,13 +120,15 @@ __device__ __forceinline__ void plane_store4(unsigned short* pl, int o, float v0
 // where they are.  dH1 feeds only sums (g1 = dH1 * act'(h1), h1 untouched): the k-split there stays at 1e-7.
 // LB: the barrier behind the small gradients moved behind the two matrix phases that follow them (a wave that is through with its share
 // of the vector sums starts on the weight gradient at once).
-template <int ACT, bool TR, bool KSF, bool KSB, bool LB = false>
+// DS / AS: compile-time observation / head width (the CartPole class (4, 2): the headline) or 0 = from the arguments, D <= 8, A <= 4
+// (Acrobot 6 / 3, LunarLander 8 / 4, MountainCar 2 / 3: every categorical classic-control / Box2D yaml of the reference).
+template <int ACT, bool TR, bool KSF, bool KSB, bool LB = false, int DS = 4, int AS = 2>
 __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fused_t p) {
-    using L = BxLds;
+    constexpr int DM = DS ? DS : BDMAX, AM = AS ? AS : BAMAX;
+    using L = BxLds<DM, AM>;
     constexpr int NQF = KSF ? 4 : 8, NQB = KSB ? 4 : 8, NQ = NQF > NQB ? NQF : NQB;     // k-steps of the weight-streamed products per wave
     constexpr int TPR = FUSED_THREADS / BPT;           // threads per row in the VALU phases: 8
     constexpr int NCH = (BH / 4) / TPR;                // float4 chunks of the branch level per thread: 4
-    constexpr int D = BD, A = BA;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned short* h1p = reinterpret_cast<unsigned short*>(lds_raw + L::H1P);   // [3][64][136] h1 as bf16 planes
     unsigned short* g2p = reinterpret_cast<unsigned short*>(lds_raw + L::G2P);   // [3][64][136] dLoss/dz2 as bf16 planes
@@ -140,7 +146,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     double* bgp = reinterpret_cast<double*>(lds_raw + L::BGP);                    // [2][128] branch-bias gradient of the two row halves
 
     kernarg_prefetch<sizeof(xrl_ppo_fused_t)>();
-    const int tid = threadIdx.x, M = p.M;
+    const int tid = threadIdx.x, M = p.M, D = DS ? DS : p.D, A = AS ? AS : p.A;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cblk = wave & 3, rblk = wave >> 2;       // matrix phases: 32-column block / 32-row block of this wave
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     // ================= loads: EVERY request first (record rows, the three small-parameter words of this thread, this role's forward
     // fragment planes: 8 k-steps x 3 planes x 16 bytes per lane), then the LDS writes -- written as loops over the parameter arrays the
     // compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per array: five L2 round trips in a row in front of the fragment stream
-    const bool records = p.f_rows || p.f_packed;
+    const bool records = D == 4 && (p.f_rows || p.f_packed);
     float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (records) {                                     // 32-byte records obs[4] | act | ret | adv | old_logp: one wave
         if (wave == 7) {
@@ -195,9 +201,15 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     }
     float st_mean = 0.f, st_std = 1.f;
     if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
-    // W0 [128][4]: one element per thread; b0 | this role's branch bias | head bias: one word of threads 0..263; head rows: threads 0..nout*128
-    static_assert(BH * BD == FUSED_THREADS, "one first-layer weight per thread");
-    const float w0v = p.params[L0.w_off + tid];
+    // W0 [128][D]: one (D = 4) or two elements per thread; b0 | this role's branch bias | head bias: one word of threads 0..263; head rows:
+    // threads 0..nout*128
+    constexpr int W0Q = (BH * DM + FUSED_THREADS - 1) / FUSED_THREADS;
+    float w0v[W0Q];
+#pragma unroll
+    for (int q = 0; q < W0Q; ++q) {
+        const int e = tid + q * FUSED_THREADS;
+        w0v[q] = e < BH * D ? p.params[L0.w_off + e] : 0.f;
+    }
     float smv = 0.f;
     if (tid < BH) smv = p.params[L0.b_off + tid];
     else if (tid < 2 * BH) smv = p.params[L1.b_off + cb + tid - BH];
@@ -225,7 +237,12 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         *reinterpret_cast<float4*>(xs + lane * BXLD + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         rsc[lane * 12 + 0] = sc.x; rsc[lane * 12 + 8] = sc.y; rsc[lane * 12 + 9] = sc.z; rsc[lane * 12 + 10] = sc.w;
     }
-    w0t[(tid & (BD - 1)) * BLD + (tid >> 2)] = w0v;                      // element e = column (e >> 2), k (e & 3) -> k-major
+#pragma unroll
+    for (int q = 0; q < W0Q; ++q) {                                      // element e = column e / D, k = e % D -> k-major
+        const int e = tid + q * FUSED_THREADS;
+        if (e < BH * D) { const int c = e / D, k = e - c * D; w0t[k * BLD + c] = w0v[q]; }
+    }
+    if (!DS && (D & 1) && tid < BH) w0t[D * BLD + tid] = 0.f;           // (the first layer's MFMAs walk k in pairs)
     if (tid < BH) b0s[tid] = smv;
     else if (tid < 2 * BH) bms[tid - BH] = smv;
     else if (tid < 2 * BH + 8) bhs[tid - 2 * BH] = smv;
@@ -271,8 +288,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         const float* wk = w0t + lh * BLD + cblk * 32 + li;              // A[i = column][k = lh + 2 s]
         const float* xr = xs + (rblk * 32 + li) * BXLD + lh;            // B[k = lh + 2 s][j = row]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[0], xr[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[2 * BLD], xr[2], acc, 0, 0, 0);
+        if (DS == 4) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[0], xr[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[2 * BLD], xr[2], acc, 0, 0, 0);
+        } else {
+            const int ns = (D + 1) >> 1;
+            for (int s2 = 0; s2 < ns; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[2 * s2 * BLD], xr[2 * s2], acc, 0, 0, 0);
+        }
         const int row = rblk * 32 + li;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -362,9 +384,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     float4 a[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) a[i] = *reinterpret_cast<const float4*>(h2 + r * BLD + 4 * (sub + TPR * i));
-    float z[A];
+    float z[AM];
 #pragma unroll
-    for (int j = 0; j < A; ++j) {
+    for (int j = 0; j < AM; ++j) {
         z[j] = 0.f;
         if (j < nout) {
             float c = 0.f;
@@ -378,9 +400,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         }
     }
     {
-        float dz[A];
+        float dz[AM];
 #pragma unroll
-        for (int j = 0; j < A; ++j) dz[j] = 0.f;
+        for (int j = 0; j < AM; ++j) dz[j] = 0.f;
         double t_s = 0.0, t_c = 0.0, t_e = 0.0, t_v = 0.0, t_n = 0.0;
         const float invM = 1.f / (float)M;
         if (actor) {
@@ -393,22 +415,23 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
                 const int act = (int)rsc[r * 12];
                 float mx = z[0];
 #pragma unroll
-                for (int j = 1; j < A; ++j) mx = fmaxf(mx, z[j]);
+                for (int j = 1; j < AM; ++j) if (j < A) mx = fmaxf(mx, z[j]);
                 float se = 0.f;
 #pragma unroll
-                for (int j = 0; j < A; ++j) se += expf(z[j] - mx);
+                for (int j = 0; j < AM; ++j) if (j < A) se += expf(z[j] - mx);
                 const float lse = mx + logf(se);
                 float zact = z[0];
 #pragma unroll
-                for (int j = 1; j < A; ++j) if (j == act) zact = z[j];
+                for (int j = 1; j < AM; ++j) if (j == act) zact = z[j];
                 const float logp = zact - lse;
                 float ent = 0.f;
 #pragma unroll
-                for (int j = 0; j < A; ++j) { const float l = z[j] - lse; ent -= expf(l) * l; }
+                for (int j = 0; j < AM; ++j) if (j < A) { const float l = z[j] - lse; ent -= expf(l) * l; }
                 const Surrogate s = surrogate(logp, old_lp, adv, lo, hi, invM);
                 const float ce = p.ent_coef * invM;
 #pragma unroll
-                for (int j = 0; j < A; ++j) { const float l = z[j] - lse, pj = expf(l); dz[j] = s.dlogp * ((j == act ? 1.f : 0.f) - pj) + ce * pj * (l + ent); }
+                for (int j = 0; j < AM; ++j)
+                    if (j < A) { const float l = z[j] - lse, pj = expf(l); dz[j] = s.dlogp * ((j == act ? 1.f : 0.f) - pj) + ce * pj * (l + ent); }
                 t_s = (double)fminf(s.s1, s.s2); t_n = s.clipped; t_e = ent;
                 if (p.diag && sub == 0) {
                     const int m = m_row;
@@ -422,7 +445,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         }
         if (sub == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { dzh[r * 16 + j] = j < A ? dz[j < A ? j : 0] : 0.f; dzh[r * 16 + 8 + j] = 0.f; }
+            for (int j = 0; j < 8; ++j) { dzh[r * 16 + j] = j < AM ? dz[j < AM ? j : 0] : 0.f; dzh[r * 16 + 8 + j] = 0.f; }
             rowstat[0 * BPT + r] = t_s; rowstat[1 * BPT + r] = t_c; rowstat[2 * BPT + r] = t_e; rowstat[3 * BPT + r] = t_v; rowstat[4 * BPT + r] = t_n;
         }
         // g2 = (dZh . W_h) * act'(h2): this thread's k-chunks, split where they are made
@@ -430,7 +453,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         for (int i = 0; i < NCH; ++i) {
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < A; ++j) {
+            for (int j = 0; j < AM; ++j) {
                 if (j < nout) {
                     const float4 w = *reinterpret_cast<const float4*>(whs + j * BLD + 4 * (sub + TPR * i));
                     g.x += dz[j] * w.x; g.y += dz[j] * w.y; g.z += dz[j] * w.z; g.w += dz[j] * w.w;
@@ -581,14 +604,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         // [2][128][D + 1] partial sums of the row blocks: where h2 was, or (KSB: h2's place holds the n-halves other waves may still be
         // reading) where the row scalars and head gradients were -- dead since barrier #3b
         float* part = KSB ? rsc : h2;
-        static_assert(2 * BH * (BD + 1) * 4 <= BPT * 12 * 4 + BPT * 16 * 4 && BxLds::DZH == BxLds::RSC + BPT * 12 * 4, "first-layer partial sums");
-        constexpr int PLD = D + 1;
+        // (BxLds: RSC, DZH, W0T are contiguous and hold [2][128][DM + 1] floats; the first-layer weights' last readers are behind barrier #1)
+        constexpr int PLD = DM + 1;
         {
             const int c = cblk * 32 + li;
             float ab = 0.f;
-            float acc[4];
+            float acc[DM];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = 0.f;
+            for (int k = 0; k < DM; ++k) acc[k] = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int row = rblk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
@@ -598,26 +621,31 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
                                                                                       : plane_value(h1p, row * BPL + c);
                 const float g = dacc[rr] * act_grad_c<ACT>(h1v);
                 ab += g;
-                const float4 x = *reinterpret_cast<const float4*>(xs + row * BXLD);
-                acc[0] += g * x.x; acc[1] += g * x.y; acc[2] += g * x.z; acc[3] += g * x.w;
+#pragma unroll
+                for (int q = 0; q < DM / 4; ++q) {
+                    if (4 * q < D) {
+                        const float4 x = *reinterpret_cast<const float4*>(xs + row * BXLD + 4 * q);      // (zero beyond D)
+                        acc[4 * q] += g * x.x; acc[4 * q + 1] += g * x.y; acc[4 * q + 2] += g * x.z; acc[4 * q + 3] += g * x.w;
+                    }
+                }
             }
             // (h2's last readers -- the head weight gradient -- are behind barrier #3b)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
+            for (int k = 0; k < DM; ++k) acc[k] += __shfl_xor(acc[k], 32, 64);
             ab += __shfl_xor(ab, 32, 64);
             if (lh == 0) {
                 float* pp = part + (rblk * BH + c) * PLD;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pp[k] = acc[k];
-                pp[D] = ab;
+                for (int k = 0; k < DM; ++k) pp[k] = acc[k];
+                pp[DM] = ab;
             }
         }
         TSTAMP(12);
         lds_barrier();                                                                               // #4 the two row blocks' partial sums
         TSTAMP(7);
         for (int e = tid; e < BH * (D + 1); e += FUSED_THREADS) {
-            const int c = e / (D + 1), k = e - c * (D + 1);
-            const float v = part[c * PLD + k] + part[(BH + c) * PLD + k];
+            const int c = e / (D + 1), k = e - c * (D + 1), kk = k < D ? k : DM;
+            const float v = part[c * PLD + kk] + part[(BH + c) * PLD + kk];
             dst[k < D ? w_at + c * D + k : b_at + c] = v;
         }
     }
@@ -634,17 +662,24 @@ static int g_bx_tr = 1;                                   // weight-gradient ope
 static int g_bx_ks = 5;                                   // the wave pair of a column block splits k, not rows: 0 nowhere, 1 backward-data product, 2 both
 
 bool ppo_trunk_bx_eligible(const xrl_ppo_fused_t& p) {
-    return p.frag16 != nullptr && p.pad0 == 64 && p.dist == 0 && p.D == BD && p.A == BA && p.layers[1].N == 2 * BH && p.layers[1].K == BH;
+    return p.frag16 != nullptr && p.pad0 == 64 && p.dist == 0 && p.D >= 1 && p.D <= BDMAX && p.A >= 1 && p.A <= BAMAX &&
+           p.layers[1].N == 2 * BH && p.layers[1].K == BH;
 }
 
 template <int ACT>
 static int launch_bx(const xrl_ppo_fused_t& p, hipStream_t stream) {
     const int n_tiles = (p.M + BPT - 1) / BPT;
-    if (!g_bx_tr) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, false, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
-    else if (g_bx_ks == 1) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
-    else if (g_bx_ks == 5) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
-    else if (g_bx_ks == 2) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
-    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), BxLds::BYTES, stream, p);
+    constexpr int LDSB = BxLds<4, 2>::BYTES, LDSG = BxLds<BDMAX, BAMAX>::BYTES;
+    if (!(p.D == 4 && p.A == 2)) {                        // any (D <= 8, A <= 4): the default form only
+        hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+        XRL_CHECK_LAUNCH();
+        return XRL_OK;
+    }
+    if (!g_bx_tr) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, false, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
+    else if (g_bx_ks == 1) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
+    else if (g_bx_ks == 5) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
+    else if (g_bx_ks == 2) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
+    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
@@ -659,11 +694,12 @@ int launch_ppo_trunk_bx(const xrl_ppo_fused_t& p, hipStream_t stream) {
 
 template <int ACT>
 static int init_bx_one() {
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
-    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<4, 2>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<4, 2>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<4, 2>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<4, 2>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<4, 2>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<BDMAX, BAMAX>::BYTES));
     return XRL_OK;
 }
 
