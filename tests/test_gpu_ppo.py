@@ -646,6 +646,11 @@ def test_split_fragment_image_is_exact_and_follows_its_maps():
         assert torch.equal(val[e].view(torch.int32), w.view(torch.int32))
         h, m, l = parts[e], parts[plane + e], parts[2 * plane + e]
         assert bool((m.abs() <= h.abs() * 2.0 ** -8).all()) and bool((l.abs() <= h.abs() * 2.0 ** -16).all())
+        # ... and each part is the oracle's (oracle/split3.py: round-to-nearest-even at every step), bit for bit
+        from oracle import split3 as S
+        oh, om, ol = S.split3(w.cpu().numpy())
+        for dev, ref in ((h, oh), (m, om), (l, ol)):
+            assert np.array_equal(dev.cpu().numpy().view(np.uint32), ref.view(np.uint32))
     assert torch.unique(torch.cat([-(mf[mf <= -2].long() + 2), -(mb[mb <= -2].long() + 2)])).numel() == plane
     # optimiser steps keep it current
     agent.train(2 * 64)
