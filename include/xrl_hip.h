@@ -873,8 +873,8 @@ typedef struct {
     int32_t out_act;            /* Gaussian: activation_action on the mean, XRL_ACT_NONE | XRL_ACT_TANH (actor_head.py:62) */
     int32_t log_std_off;        /* Gaussian: float offset of actor.log_std [A] in params / a slab row */
     int32_t pad3;
-    const uint16_t* frag16;     /* NULL, or the xrl_pack_mid_frags16 image of the branch layer (three bf16 planes): with 64-row tiles and a
-                                 * categorical head, D <= 8, A <= 4 (CartPole (4, 2) -- the headline --, Acrobot, LunarLander, MountainCar) the
+    const uint16_t* frag16;     /* NULL, or the xrl_pack_mid_frags16 image of the branch layer (three bf16 planes): with 64-row tiles and
+                                 * D <= 8, A <= 4 (CartPole (4, 2) -- the headline --, Acrobot, LunarLander, MountainCar; Gaussian: Pendulum) the
                                  * minibatch launch then forms its three 128-wide products as exact 3-way bf16 splits on the matrix cores
                                  * (csrc/ppo_trunk_bx.hip) */
 } xrl_ppo_fused_t;

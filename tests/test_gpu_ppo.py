@@ -254,14 +254,15 @@ def test_one_launch_minibatch_kernels_vs_reference_fixture(size, n, T, kernel):
                                              ("gaussian", "walker", 32), ("gaussian", "walker", 64), ("categorical", "acrobot", 64),
                                              ("categorical", "mountaincar", 32), ("categorical", "mountaincar", 64),
                                              ("categorical", "lunar", 64), ("categorical", "acrobot", "64-f32"),
-                                             ("categorical", "mountaincar", "64-f32"), ("categorical", "lunar", "64-f32")])
+                                             ("categorical", "mountaincar", "64-f32"), ("categorical", "lunar", "64-f32"),
+                                             ("gaussian", "pendulum", 64), ("gaussian", "pendulum", "64-f32")])
 def test_shared_trunk_family_vs_reference_fixture(dist, size, tiles):
     """The other members of the reference's shared-trunk PPO family (Basic_MLP [128] + actor [128] + critic [128]:
     configs/ppo/classic_control/{Acrobot,Pendulum,MountainCar}.yaml, box2d/{LunarLander,BipedalWalker}.yaml -- (D, A) = (6, 3), (3, 1),
     (2, 3), (8, 4), (24, 4), categorical and Gaussian with tanh on the mean) through the ONE-LAUNCH minibatch kernel (csrc/ppo_trunk.hip: (tile, role)
     workgroups, 32- and 64-row tiles) + xrl_reduce_adam, from rows in a HipOnPolicyBuffer, at the 320-row minibatch their yaml
     gives: the reference learner's loss terms, clipped gradients (float64-anchored), parameter steps, Adam moments.  64-row tiles of
-    the categorical members with D <= 8, A <= 4 run the split-product kernel (csrc/ppo_trunk_bx.hip, any-(D, A) instance); "64-f32":
+    the members with D <= 8, A <= 4 (categorical, and Pendulum's Gaussian head) run the split-product kernel (csrc/ppo_trunk_bx.hip, any-(D, A) instances); "64-f32":
     the float32 matrix instruction on the same tiles (use_split_products: False)."""
     f32 = tiles == "64-f32"
     tiles = 64 if f32 else tiles
@@ -287,7 +288,7 @@ def test_shared_trunk_family_vs_reference_fixture(dist, size, tiles):
     assert learner.fused_eligible(mem)
     learner.prepare_fused(mem, n * T)
     assert learner.split and learner.pair == (tiles == 64) and learner.params_t is None
-    assert (learner.frag16 is not None) == (tiles == 64 and not f32 and dist == "categorical" and D <= 8 and A <= 4)
+    assert (learner.frag16 is not None) == (tiles == 64 and not f32 and D <= 8 and A <= 4)
     chk = EngineFixtureCheck(g, net, learner, float(lr), end_factor=float(ef), total_iters=int(total))
     idx = torch.arange(n * T, dtype=torch.int64, device="cuda").view(1, -1)
     for u in range(int(g["n_updates"])):

@@ -26,10 +26,10 @@
 // branch layer are issued TRANSPOSED (A = weights, B = rows): a lane then holds 4 CONSECUTIVE columns of one row, and h1's planes /
 // h2 are written as 8- / 16-byte stores instead of 2- / 4-byte ones.
 //
-// Class: the categorical members of the shared-trunk family with D <= 8, A <= 4 on 64-row tiles -- the CartPole class (4, 2), the
-// headline, as a compile-time instance (LDS 153 KB of the CU's 160); Acrobot (6, 3), LunarLander (8, 4), MountainCar (2, 3) through an
-// any-(D, A) instance (156 KB).  Wider rows (BipedalWalker's 24) do not fit beside the six planes, the Gaussian heads are not
-// instantiated: both keep csrc/ppo_trunk.hip.  Everything outside the three products -- gather, head, loss, the small gradients, slab
+// Class: the members of the shared-trunk family with D <= 8, A <= 4 on 64-row tiles -- the CartPole class (4, 2), the headline, as a
+// compile-time instance (LDS 153 KB of the CU's 160); Acrobot (6, 3), LunarLander (8, 4), MountainCar (2, 3) and the Gaussian Pendulum
+// (3, 1; tanh on the mean) through any-(D, A) instances (156 KB): every classic-control PPO yaml of the reference.  Wider rows
+// (BipedalWalker's 24) do not fit beside the six planes and keep csrc/ppo_trunk.hip.  Everything outside the three products -- gather, head, loss, the small gradients, slab
 // layout, loss partials -- is ppo_trunk_kernel<ACT, 0, 64, DS, AS>'s code, statement for statement.
 // Reference semantics: memory_tools.py:267-287 (sample) + ppo_learner.py:46-62 (forward / loss / backward).
 #include "common.h"
@@ -55,7 +55,7 @@ template <int DM, int AM>                    // rows for DM observation dims / A
 struct BxLds {                               // byte offsets
     static constexpr int H1P = 0, G2P = H1P + 3 * BPLANE * 2, H2 = G2P + 3 * BPLANE * 2, XS = H2 + BPT * BLD * 4,
                          RSC = XS + BPT * BXLD * 4, DZH = RSC + BPT * 12 * 4, W0T = DZH + BPT * 16 * 4, B0 = W0T + DM * BLD * 4,
-                         BM = B0 + BH * 4, WH = BM + BH * 4, BHS = WH + AM * BLD * 4, SRC = BHS + 8 * 4, RST = SRC + BPT * 4,
+                         BM = B0 + BH * 4, WH = BM + BH * 4, BHS = WH + AM * BLD * 4, LS = BHS + 8 * 4, SRC = LS + 8 * 4, RST = SRC + BPT * 4,
                          BGP = RST + BPT * 5 * 8, BYTES = BGP + 2 * BH * 8;
     static_assert(BYTES <= 160 * 1024, "LDS");
     static_assert((RST & 7) == 0 && (H2 & 15) == 0 && (G2P & 15) == 0 && (B0 & 15) == 0 && (WH & 15) == 0, "alignment");
@@ -122,9 +122,12 @@ __device__ __forceinline__ void plane_store4(unsigned short* pl, int o, float v0
 // of the vector sums starts on the weight gradient at once).
 // DS / AS: compile-time observation / head width (the CartPole class (4, 2): the headline) or 0 = from the arguments, D <= 8, A <= 4
 // (Acrobot 6 / 3, LunarLander 8 / 4, MountainCar 2 / 3: every categorical classic-control / Box2D yaml of the reference).
-template <int ACT, bool TR, bool KSF, bool KSB, bool LB = false, int DS = 4, int AS = 2>
+// HEAD: 0 categorical, 1 Gaussian (mean as is), 2 Gaussian (tanh on the mean) -- ppo_trunk_kernel's heads (distributions.py:128-192).
+template <int ACT, bool TR, bool KSF, bool KSB, bool LB = false, int DS = 4, int AS = 2, int HEAD = 0>
 __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fused_t p) {
     constexpr int DM = DS ? DS : BDMAX, AM = AS ? AS : BAMAX;
+    constexpr bool GAUSS = HEAD != 0;
+    constexpr int OACT = HEAD == 2 ? XRL_ACT_TANH : XRL_ACT_NONE;
     using L = BxLds<DM, AM>;
     constexpr int NQF = KSF ? 4 : 8, NQB = KSB ? 4 : 8, NQ = NQF > NQB ? NQF : NQB;     // k-steps of the weight-streamed products per wave
     constexpr int TPR = FUSED_THREADS / BPT;           // threads per row in the VALU phases: 8
@@ -141,6 +144,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     float* bms = reinterpret_cast<float*>(lds_raw + L::BM);                       // this role's branch bias
     float* whs = reinterpret_cast<float*>(lds_raw + L::WH);                       // [nout][132] this role's head rows
     float* bhs = reinterpret_cast<float*>(lds_raw + L::BHS);
+    float* lss = reinterpret_cast<float*>(lds_raw + L::LS);                       // log_std
     int* srcs = reinterpret_cast<int*>(lds_raw + L::SRC);
     double* rowstat = reinterpret_cast<double*>(lds_raw + L::RST);                // [5][64] per-row loss terms
     double* bgp = reinterpret_cast<double*>(lds_raw + L::BGP);                    // [2][128] branch-bias gradient of the two row halves
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     // ================= loads: EVERY request first (record rows, the three small-parameter words of this thread, this role's forward
     // fragment planes: 8 k-steps x 3 planes x 16 bytes per lane), then the LDS writes -- written as loops over the parameter arrays the
     // compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per array: five L2 round trips in a row in front of the fragment stream
-    const bool records = D == 4 && (p.f_rows || p.f_packed);
+    const bool records = !GAUSS && D == 4 && (p.f_rows || p.f_packed);
     float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (records) {                                     // 32-byte records obs[4] | act | ret | adv | old_logp: one wave
         if (wave == 7) {
@@ -214,6 +218,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     if (tid < BH) smv = p.params[L0.b_off + tid];
     else if (tid < 2 * BH) smv = p.params[L1.b_off + cb + tid - BH];
     else if (tid < 2 * BH + nout) smv = p.params[Lh.b_off + tid - 2 * BH];
+    float lsv = 0.f;
+    if (GAUSS && tid >= 2 * BH && tid < 2 * BH + A) lsv = p.params[p.log_std_off + tid - 2 * BH];
     float whv = 0.f;
     if (tid < nout * BH) whv = p.params[Lh.w_off + tid];
     bu32x4 pf[NQ][3];
@@ -245,7 +251,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     if (!DS && (D & 1) && tid < BH) w0t[D * BLD + tid] = 0.f;           // (the first layer's MFMAs walk k in pairs)
     if (tid < BH) b0s[tid] = smv;
     else if (tid < 2 * BH) bms[tid - BH] = smv;
-    else if (tid < 2 * BH + 8) bhs[tid - 2 * BH] = smv;
+    else if (tid < 2 * BH + 8) { bhs[tid - 2 * BH] = smv; lss[tid - 2 * BH] = lsv; }
     if (tid < nout * BH) whs[(tid >> 7) * BLD + (tid & (BH - 1))] = whv;
     if (!records) {
         lds_barrier();                                                                               // (srcs)
@@ -256,8 +262,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         for (int e = tid; e < BPT * 12; e += FUSED_THREADS) {
             const int rr = e / 12, k = e - rr * 12, src = srcs[rr];
             float v = 0.f;
+            const int na = GAUSS ? A : 1;
             if (src >= 0) {
-                if (k < 1) v = p.f_act[src];
+                if (k < na) v = p.f_act[(size_t)src * na + k];
                 else if (k == 8) v = p.f_ret[src];
                 else if (k == 9) v = p.f_adv[src];
                 else if (k == 10) v = p.f_logp[src];
@@ -411,6 +418,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
             asm volatile("" : "+v"(st_std));
             if (p.stats) adv = __fdiv_rn(__fsub_rn(adv, st_mean), st_std + 1e-8f);                   // memory_tools.py:281-282
             const float lo = (float)(1.0 - (double)p.clip_range), hi = (float)(1.0 + (double)p.clip_range);
+            if constexpr (!GAUSS) {
             if (row_ok) {
                 const int act = (int)rsc[r * 12];
                 float mx = z[0];
@@ -438,14 +446,56 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
                     p.diag[m] = logp; p.diag[M + m] = s.ratio; p.diag[2 * (size_t)M + m] = s.s1; p.diag[3 * (size_t)M + m] = s.s2;
                 }
             }
+            } else {
+                // DiagGaussianDistribution (distributions.py:155-192): log_prob / entropy summed over the action dims; thread `sub` of a row
+                // owns dimension `sub` (ppo_trunk_kernel's statements)
+                const bool mine = sub < A;
+                float zmine = 0.f;
+#pragma unroll
+                for (int j = 0; j < AM; ++j) if (j == sub) zmine = z[j];
+                float df = 0.f, var = 1.f, term = 0.f, entj = 0.f, mu = 0.f;
+                if (mine) {
+                    mu = act_apply_c<OACT>(zmine);                                                   // activation_action (actor_head.py:62)
+                    const float ls = lss[sub], sd = expf(ls);
+                    var = sd * sd; df = rsc[r * 12 + sub] - mu;
+                    term = -(df * df) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;
+                    entj = 0.5f + LOG_SQRT_2PI + logf(sd);
+                }
+                float logp = term, ent = entj;
+                logp += __shfl_xor(logp, 4, 64); logp += __shfl_xor(logp, 2, 64); logp += __shfl_xor(logp, 1, 64);
+                ent += __shfl_xor(ent, 4, 64); ent += __shfl_xor(ent, 2, 64); ent += __shfl_xor(ent, 1, 64);
+                float my_dz = 0.f, my_gls = 0.f;
+                if (row_ok) {
+                    const Surrogate s = surrogate(logp, old_lp, adv, lo, hi, invM);
+                    if (mine) {
+                        my_dz = (s.dlogp * df / var) * act_grad_c<OACT>(mu);
+                        my_gls = s.dlogp * (df * df / var - 1.f);
+                    }
+                    t_s = (double)fminf(s.s1, s.s2); t_n = s.clipped; t_e = ent;
+                    if (p.diag && sub == 0) {
+                        const int m = m_row;
+                        p.diag[m] = logp; p.diag[M + m] = s.ratio; p.diag[2 * (size_t)M + m] = s.s1; p.diag[3 * (size_t)M + m] = s.s2;
+                    }
+                }
+                dzh[r * 16 + sub] = my_dz; dzh[r * 16 + 8 + sub] = my_gls;          // (8 threads per row = the 8 + 8 slots)
+                // the row's threads sit in one wave and a wave's LDS operations execute in order: the values are there
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const float4 d0 = *reinterpret_cast<const float4*>(dzh + r * 16);
+                dz[0] = d0.x;
+                if (AM > 1) dz[1 < AM ? 1 : 0] = d0.y;
+                if (AM > 2) dz[2 < AM ? 2 : 0] = d0.z;
+                if (AM > 3) dz[3 < AM ? 3 : 0] = d0.w;
+            }
         } else if (row_ok) {
             const float v = z[0], dv = v - rsc[r * 12 + 8];
             dz[0] = p.vf_coef * 2.f * dv * invM;
             t_c = (double)dv * dv; t_v = v;
         }
         if (sub == 0) {
+            if (!(actor && GAUSS)) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { dzh[r * 16 + j] = j < AM ? dz[j < AM ? j : 0] : 0.f; dzh[r * 16 + 8 + j] = 0.f; }
+                for (int j = 0; j < 8; ++j) { dzh[r * 16 + j] = j < AM ? dz[j < AM ? j : 0] : 0.f; dzh[r * 16 + 8 + j] = 0.f; }
+            }
             rowstat[0 * BPT + r] = t_s; rowstat[1 * BPT + r] = t_c; rowstat[2 * BPT + r] = t_e; rowstat[3 * BPT + r] = t_v; rowstat[4 * BPT + r] = t_n;
         }
         // g2 = (dZh . W_h) * act'(h2): this thread's k-chunks, split where they are made
@@ -491,13 +541,16 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
 #pragma unroll 16
         for (int rr = 0; rr < BPT / 2; ++rr) acc0 += (double)plane_value(g2p, (rh * (BPT / 2) + rr) * BPL + t);
         bgp[rh * BH + t] = acc0;
-    } else if (tid >= 3 * 64 && tid < 3 * 64 + 8) {
-        const int t = tid - 3 * 64;
-        if (t < nout) {
+    } else if (tid >= 3 * 64 && tid < 3 * 64 + 16) {
+        const int t = tid - 3 * 64;                                      // 0..7 head bias, 8..15 log_std
+        if (t < nout || (t >= 8 && GAUSS && actor && t - 8 < A)) {
             double acc = 0.0;
 #pragma unroll 16
             for (int rr = 0; rr < BPT; ++rr) acc += (double)dzh[rr * 16 + t];
-            slab[Lh.b_off + t] = (float)acc;
+            // d(-ent_coef * mean_m sum_j(log_std_j + c)) / d log_std_j = -ent_coef, added once (tile 0), as in ppo_trunk_kernel
+            if (t >= 8 && tile == 0) acc -= (double)p.ent_coef;
+            if (t < 8) slab[Lh.b_off + t] = (float)acc;
+            else slab[p.log_std_off + t - 8] = (float)acc;
         }
     }
     if constexpr (!LB) {
@@ -662,7 +715,7 @@ static int g_bx_tr = 1;                                   // weight-gradient ope
 static int g_bx_ks = 5;                                   // the wave pair of a column block splits k, not rows: 0 nowhere, 1 backward-data product, 2 both
 
 bool ppo_trunk_bx_eligible(const xrl_ppo_fused_t& p) {
-    return p.frag16 != nullptr && p.pad0 == 64 && p.dist == 0 && p.D >= 1 && p.D <= BDMAX && p.A >= 1 && p.A <= BAMAX &&
+    return p.frag16 != nullptr && p.pad0 == 64 && (p.dist == 0 || p.dist == 1) && p.D >= 1 && p.D <= BDMAX && p.A >= 1 && p.A <= BAMAX &&
            p.layers[1].N == 2 * BH && p.layers[1].K == BH;
 }
 
@@ -670,6 +723,12 @@ template <int ACT>
 static int launch_bx(const xrl_ppo_fused_t& p, hipStream_t stream) {
     const int n_tiles = (p.M + BPT - 1) / BPT;
     constexpr int LDSB = BxLds<4, 2>::BYTES, LDSG = BxLds<BDMAX, BAMAX>::BYTES;
+    if (p.dist == 1) {                                    // Gaussian heads (Pendulum (3, 1)): any (D <= 8, A <= 4), the default form only
+        if (p.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0, 2>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+        else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0, 1>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+        XRL_CHECK_LAUNCH();
+        return XRL_OK;
+    }
     if (!(p.D == 4 && p.A == 2)) {                        // any (D <= 8, A <= 4): the default form only
         hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
         XRL_CHECK_LAUNCH();
@@ -700,6 +759,8 @@ static int init_bx_one() {
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<4, 2>::BYTES));
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<4, 2>::BYTES));
     XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<BDMAX, BAMAX>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<BDMAX, BAMAX>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<BDMAX, BAMAX>::BYTES));
     return XRL_OK;
 }
 

@@ -375,9 +375,10 @@ FRAG16_PLANE = 2 * 256 * 128            # XRL_FRAG16_PLANE: 16-bit elements per 
 
 
 def split_products_class(plan, obs_dim, action_dim, dist):
-    """The class csrc/ppo_trunk_bx.hip is built for: D-128-{128-A | 128-1} with D <= 8, A <= 4, categorical -- the CartPole headline
-    (4, 2) as a compile-time instance, Acrobot (6, 3) / LunarLander (8, 4) / MountainCar (2, 3) through the any-(D, A) one."""
-    return dist != "gaussian" and 1 <= obs_dim <= 8 and 1 <= action_dim <= 4 and list(plan.widths) == [obs_dim, 128, 256, action_dim + 1]
+    """The class csrc/ppo_trunk_bx.hip is built for: D-128-{128-A | 128-1} with D <= 8, A <= 4 -- the CartPole headline (4, 2) as a
+    compile-time instance, Acrobot (6, 3) / LunarLander (8, 4) / MountainCar (2, 3) and the Gaussian Pendulum (3, 1) through the
+    any-(D, A) ones: every classic-control PPO yaml of the reference."""
+    return 1 <= obs_dim <= 8 and 1 <= action_dim <= 4 and list(plan.widths) == [obs_dim, 128, 256, action_dim + 1]
 
 
 def pack_mid_frags16(plan, params_flat, image):
