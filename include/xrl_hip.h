@@ -877,6 +877,8 @@ typedef struct {
                                  * D <= 8, A <= 4 (CartPole (4, 2) -- the headline --, Acrobot, LunarLander, MountainCar; Gaussian: Pendulum) the
                                  * minibatch launch then forms its three 128-wide products as exact 3-way bf16 splits on the matrix cores
                                  * (csrc/ppo_trunk_bx.hip) */
+    float* fwd_out;             /* xrl_trunk_forward16 only: [M][fwd_ld] head buffer -- columns [0, A) the actor's output, column A the value */
+    int32_t fwd_ld, pad4;
 } xrl_ppo_fused_t;
 int xrl_ppo_fused_minibatch(const xrl_ppo_fused_t* p, xrl_stream_t stream);
 /* The minibatch launch of the shared-trunk family (l0_fold_off > 0) CHAINED to the optimiser step of the minibatch before it:
@@ -936,6 +938,12 @@ int xrl_pack_mid_frags(const xrl_ppo_fused_t* p, float* frag, int64_t frag_float
 int xrl_pack_mid_frags16(const xrl_ppo_fused_t* p, uint16_t* image, int64_t image_elems, xrl_stream_t stream);
 /* diagnostics: the split-product kernel's weight-gradient operands through ds_read_b64_tr_b16 (1, default) or 2-byte LDS reads (0);
  * same numbers either way. */
+/* The ACTING pass of the shared-trunk networks with D <= 8, A <= 4 as ONE launch (replaces the three launches of the layered forward:
+ * ActorCriticPolicy.forward of policies/categorical.py / gaussian.py -- representation, actor head, critic head; on_policy.py:128-169
+ * calls it once per vector step): row m of p->f_obs [M][D] (contiguous) -> p->fwd_out[m][0..A) = logits | activation_action(mean),
+ * p->fwd_out[m][A] = value.  Reads params, layers, frag16 (must be current: xrl_pack_mid_frags16 or the optimiser's split mirror stores),
+ * M, D, A, dist, out_act, fwd_out, fwd_ld of *p; the 128-wide product runs as the exact 3-way bf16 split of the minibatch kernel. */
+int xrl_trunk_forward16(const xrl_ppo_fused_t* p, xrl_stream_t stream);
 int xrl_set_split_product_tr(int on);
 /* diagnostics: which weight-streamed products of the split-product kernel have the two waves of a 32-column block split the k-range
  * (each streams half of the fragment planes, the halves meet through LDS) instead of the rows: 0 none, 1 the backward-data product

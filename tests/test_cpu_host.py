@@ -40,7 +40,7 @@ def test_ctypes_structs_match_c_layout():
              # round 6
              "xrl_act_tail_t": _lib.ActTail, "xrl_mlp_chain_job_t": _lib.MlpChainJob, "xrl_mlp_chain_t": _lib.MlpChain,
              "xrl_ppo_act_tail_t": _lib.PpoActTail, "xrl_opt_chain_t": _lib.OptChain, "xrl_qmix_phase_t": _lib.QmixPhase,
-             "xrl_qa_image_t": _lib.QaImage}
+             "xrl_qa_image_t": _lib.QaImage, "xrl_ppo_fused_t": _lib.PpoFused}
     for extra in ("xrl_dqn_td_t", "xrl_qmix_t"):
         cls = getattr(_lib, {"xrl_dqn_td_t": "DqnTd", "xrl_qmix_t": "Qmix"}[extra], None)
         if cls is not None:

@@ -780,3 +780,60 @@ def test_split_product_minibatch_on_ragged_minibatches_and_field_rows(records):
         assert err <= 2e-6, (k, err)
     assert float((gb[P:] - gf[P:]).abs().max()) <= 2e-6 * (float(gf[P:].abs().max()) + 1e-30)
     assert torch.allclose(pb, pf, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("dist,D,A,act", [("categorical", 6, 3, "leaky_relu"), ("categorical", 8, 4, "relu"), ("categorical", 2, 3, "tanh"),
+                                          ("gaussian", 3, 1, "leaky_relu"), ("categorical", 4, 2, "leaky_relu")])
+def test_acting_pass_in_one_launch_matches_the_layered_forward(dist, D, A, act):
+    """xrl_trunk_forward16 (the forward-only instances of csrc/ppo_trunk_bx.hip: representation, branch layer as exact 3-way bf16 splits,
+    both heads, activation_action -- one launch) against the three launches of the layered forward (nets.Plan.forward: float32 matrix
+    instruction) on the same parameters and rows, incl. a last tile that ends inside 64 rows: every logit / mean / value within 2e-6 of
+    the head buffer's scale; rows beyond M untouched."""
+    from xuance_amd import ops
+    from xuance_amd.nets import ActorCriticNet
+    torch.manual_seed(3)
+    net = ActorCriticNet(D, A, dist, (128,), (128,), (128,), act, activation_action="tanh" if dist == "gaussian" else None)
+    net.params.flat.copy_(torch.randn(net.params.P, device="cuda") * 0.2)
+    M = 64 * 5 - 23
+    X = torch.randn(M + 64, D, device="cuda")
+    ref = net.forward(X, M)[:M].clone()
+    img = torch.zeros(3 * ops.FRAG16_PLANE, dtype=torch.int16, device="cuda")
+    ops.pack_mid_frags16(net.plan, net.params.flat, img)
+    out = torch.full((M + 64, A + 1), 7.0, device="cuda")
+    gauss = dist == "gaussian"
+    ops.trunk_forward16(net.plan, net.params.flat, img, X, M, out, A + 1, D, A, gauss, ops.ACT[net.activation_action] if gauss else 0)
+    torch.cuda.synchronize()
+    assert bool((out[M:] == 7.0).all())
+    S = float(ref.abs().max())
+    err = float((out[:M] - ref).abs().max()) / S
+    from conftest import _record
+    _record(f"one-launch acting pass vs layered forward, {dist} ({D}, {A}) {act}", err, err, 2e-6, ref.numel())
+    assert err <= 2e-6, err
+
+
+def test_general_path_rollout_uses_the_one_launch_acting_pass():
+    """PPO on the device Acrobot at the headline's sizes (256 envs, minibatches of 8 192: the update phase runs the split-product kernel,
+    so its weight planes exist): the rollout's acting pass goes through xrl_trunk_forward16; with use_trunk_forward: False through the
+    layered forward.  Same seeds: the first vector step's values / log-probs agree to 1e-5, its actions are equal, both agents train."""
+    import bench
+    from xuance_amd.agents import PPO_Agent
+    from xuance_amd.envs import DeviceAcrobotVecEnv
+    outs = {}
+    for tf in (True, False):
+        cfg = bench.make_config(256, 256, 1, 0)
+        cfg.use_trunk_forward = tf
+        torch.manual_seed(1)
+        agent = PPO_Agent(cfg, DeviceAcrobotVecEnv(256, seed=1))
+        info = agent.train(256)
+        torch.cuda.synchronize()
+        assert (agent._trunk_forward() is not None) == tf
+        f = agent.memory.soa.fields
+        assert all(np.isfinite(float(v)) for v in info.values() if isinstance(v, (int, float)))
+        agent2 = PPO_Agent(cfg, DeviceAcrobotVecEnv(256, seed=1))     # first step of a fresh agent: same parameters in both modes
+        agent2.rollout()
+        torch.cuda.synchronize()
+        f2 = agent2.memory.soa.fields
+        outs[tf] = (f2["values"][0].clone(), f2["aux_old_logp"][0].clone(), f2["actions"][0].clone())
+    (v1, l1, a1), (v0, l0, a0) = outs[True], outs[False]
+    assert torch.equal(a1, a0)
+    assert float((v1 - v0).abs().max()) <= 1e-5 * (float(v0.abs().max()) + 1e-30) and float((l1 - l0).abs().max()) <= 1e-5

@@ -277,7 +277,8 @@ class PpoFused(C.Structure):
                 ("slab_stride", c_int64), ("M", c_int32), ("n_envs", c_int32), ("T", c_int32), ("D", c_int32),
                 ("A", c_int32), ("l0_fold_off", c_int32), ("clip_range", c_float), ("vf_coef", c_float), ("ent_coef", c_float),
                 ("pad2", c_float), ("dbg", c_void_p), ("frag_image", c_void_p), ("f_rows", c_void_p), ("f_packed", c_void_p),
-                ("dist", c_int32), ("out_act", c_int32), ("log_std_off", c_int32), ("pad3", c_int32), ("frag16", c_void_p)]
+                ("dist", c_int32), ("out_act", c_int32), ("log_std_off", c_int32), ("pad3", c_int32), ("frag16", c_void_p),
+                ("fwd_out", c_void_p), ("fwd_ld", c_int32), ("pad4", c_int32)]
 
 
 class WideBranch(C.Structure):
@@ -396,6 +397,7 @@ _SIGS = {
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
     "xrl_pack_mid_frags16": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
+    "xrl_trunk_forward16": [C.POINTER(PpoFused), c_void_p],
     "xrl_set_split_product_tr": [c_int32],
     "xrl_set_split_product_ksplit": [c_int32],
     "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],

@@ -198,6 +198,39 @@ class PPO_Agent(AgentSurface):
         """The policy's uint8 input batch [obs ; previous next_obs] as it stands now."""
         return self._xin[self.envs._cur] if self._xin is not None else self.Xu8
 
+    def _trunk_forward(self):
+        """The acting pass of the general path as ONE launch (xrl_trunk_forward16: csrc/ppo_trunk_bx.hip's forward-only instances) instead
+        of the three of the layered forward?  A shared-trunk network with D <= 8, A <= 4 (every classic-control / LunarLander PPO yaml)
+        whose update phase runs the split-product minibatch kernel -- then the learner owns the three-plane bf16 image of the branch
+        layer, its optimiser launch keeps it current, and a rollout re-packs it once at its start (one 3 us launch: parameters loaded
+        from outside are never stale).  config.use_trunk_forward: False keeps the layered forward.  Returns the image or None."""
+        if not hasattr(self, "_tf16"):
+            self._tf16 = None
+            lr, m = self.learner, self.model
+            plan = getattr(m, "plan", None)
+            ok = bool(_get(self.config, "use_trunk_forward", True)) and not self.frames and plan is not None \
+                and type(self)._enqueue_step is PPO_Agent._enqueue_step and hasattr(lr, "trunk_eligible") and lr.trunk_eligible() \
+                and ops.split_products_class(plan, m.obs_dim, m.action_dim, m.dist) and not self.use_fused_rollout \
+                and self._wide_acting() is None and lr.fused_eligible(self.memory)
+            if ok:
+                lr.prepare_fused(self.memory, self.batch_size)        # (outside any capture: _launch_rollout asks before it captures)
+                if getattr(lr, "frag16", None) is not None:
+                    plan.ensure(2 * self.n_envs)
+                    self._tf16 = lr.frag16
+        return self._tf16
+
+    def _acting_forward(self, rows):
+        """Head buffer [rows][A + 1] of the acting pass over self.X: one launch for the shared-trunk class, the layered forward else."""
+        img = self._trunk_forward()
+        m = self.model
+        if img is None or rows > m.plan.cap:
+            return m.forward(self.X, rows)
+        heads = m.plan.acts[len(m.plan.widths) - 1]
+        gauss = m.dist == "gaussian"
+        ops.trunk_forward16(m.plan, m.params.flat, img, self.X, rows, heads, m.plan.widths[-1], m.obs_dim, m.action_dim, gauss,
+                            ops.ACT[m.activation_action] if gauss else 0)
+        return heads
+
     def _device_tail(self):
         """May a vector step of the general path end in xrl_act_tail (heads + sampling + the device env's step as one launch, the previous
         step's bookkeeping riding in the normalisation launch: xrl_post_norm -- four launches per vector step instead of seven)?  A
@@ -258,7 +291,7 @@ class PPO_Agent(AgentSurface):
         else:
             ops.obs_normalize(**rms)
         if tail is None:
-            heads = m.forward(self.X, 2 * n)
+            heads = self._acting_forward(2 * n)
             ops.policy_sample(heads=heads, log_std=P.ptr("actor.log_std") if gaussian else None,
                               noise=None if self.action_noise is None else self.action_noise[t],
                               act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
@@ -316,7 +349,7 @@ class PPO_Agent(AgentSurface):
             wide.act(self.X, n, self.seed, t, self.step_counter, act_out=f["actions"][t], env_action_f=env.action,
                      logp_out=f["aux_old_logp"][t], val_out=f["values"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None, **kw)
         else:
-            heads = self.model.forward(self.X, 2 * n)
+            heads = self._acting_forward(2 * n)
             # actions / log-probs / values of rows [0,n) -> buffer slot t; value of rows [n,2n) -> bootv[t-1]
             ops.policy_sample(heads=heads, log_std=self.model.params.ptr("actor.log_std") if gaussian else None,
                               noise=None if self.action_noise is None else self.action_noise[t],
@@ -562,6 +595,8 @@ class PPO_Agent(AgentSurface):
             conv.mark_live(self.model.params.flat)
             self._acting_fast = True
         try:
+            if not self.frames and self._trunk_forward() is not None:    # the acting pass's weight planes from the parameters of the moment
+                ops.pack_mid_frags16(self.model.plan, self.model.params.flat, self._trunk_forward())
             for t in range(T):
                 self._enqueue_step(t)
                 self._step_hooks(t)
@@ -591,7 +626,7 @@ class PPO_Agent(AgentSurface):
         else:
             if self._wide_acting() is None and self._post_norm_ok():   # the last step's bookkeeping (rode in the next step's launch so far)
                 ops.rollout_poststep(**self._post_args(T - 1, (self.obs_mean, self.obs_var, self.obs_count), self.X[n:]))
-            heads = self.model.forward(self._policy_frames(), 2 * n, keep=False, acting=self._acting_fast) if self.frames else self.model.forward(self.X, 2 * n)
+            heads = self.model.forward(self._policy_frames(), 2 * n, keep=False, acting=self._acting_fast) if self.frames else self._acting_forward(2 * n)
             ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
                               bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
                               gaussian=0, seed=self.seed, step=0, step_dev=None)
@@ -734,6 +769,8 @@ class PPO_Agent(AgentSurface):
         if not self.use_fused_rollout:
             self._wide_acting()                                   # (allocates on first use: never inside a capture)
             self._wide_rollout()
+            if not self.frames:
+                self._trunk_forward()                             # (may prepare the learner's fused state: never inside a capture)
         safe = getattr(self.envs, "graph_safe", True) or (getattr(self.envs, "graph_safe_even", False) and self.horizon_size % 2 == 0)
         if self.use_graph and safe and not self._per_step():
             if self._rollout_graph is not None and self._ws_sig() != self._rollout_cap:

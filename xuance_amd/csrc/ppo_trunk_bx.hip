@@ -123,7 +123,11 @@ __device__ __forceinline__ void plane_store4(unsigned short* pl, int o, float v0
 // DS / AS: compile-time observation / head width (the CartPole class (4, 2): the headline) or 0 = from the arguments, D <= 8, A <= 4
 // (Acrobot 6 / 3, LunarLander 8 / 4, MountainCar 2 / 3: every categorical classic-control / Box2D yaml of the reference).
 // HEAD: 0 categorical, 1 Gaussian (mean as is), 2 Gaussian (tanh on the mean) -- ppo_trunk_kernel's heads (distributions.py:128-192).
-template <int ACT, bool TR, bool KSF, bool KSB, bool LB = false, int DS = 4, int AS = 2, int HEAD = 0>
+// FWD: the forward pass only -- the ACTING pass of the on-policy loop for these networks (policies/categorical.py, gaussian.py
+// ActorCriticPolicy.forward: representation -> actor head | critic head) as ONE launch instead of the three of the layered path: row m
+// of f_obs [M][D] in, fwd_out[m][0..A) = the actor's output (activation_action applied), fwd_out[m][A] = the value.  Same products,
+// same planes; nothing of the loss / backward phases is instantiated.
+template <int ACT, bool TR, bool KSF, bool KSB, bool LB = false, int DS = 4, int AS = 2, int HEAD = 0, bool FWD = false>
 __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fused_t p) {
     constexpr int DM = DS ? DS : BDMAX, AM = AS ? AS : BAMAX;
     constexpr bool GAUSS = HEAD != 0;
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     // ================= loads: EVERY request first (record rows, the three small-parameter words of this thread, this role's forward
     // fragment planes: 8 k-steps x 3 planes x 16 bytes per lane), then the LDS writes -- written as loops over the parameter arrays the
     // compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per array: five L2 round trips in a row in front of the fragment stream
-    const bool records = !GAUSS && D == 4 && (p.f_rows || p.f_packed);
+    const bool records = !FWD && !GAUSS && D == 4 && (p.f_rows || p.f_packed);
     float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (records) {                                     // 32-byte records obs[4] | act | ret | adv | old_logp: one wave
         if (wave == 7) {
@@ -197,14 +201,17 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         const int m = m0 + tid;
         int src = -1;
         if (m < M) {
-            const int64_t fl = p.idx[m];
-            const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);
-            src = t * p.n_envs + env;
+            if (FWD) src = m;
+            else {
+                const int64_t fl = p.idx[m];
+                const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);
+                src = t * p.n_envs + env;
+            }
         }
         srcs[tid] = src;
     }
     float st_mean = 0.f, st_std = 1.f;
-    if (p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
+    if (!FWD && p.stats) { st_mean = p.stats[0]; st_std = p.stats[1]; }
     // W0 [128][D]: one (D = 4) or two elements per thread; b0 | this role's branch bias | head bias: one word of threads 0..263; head rows:
     // threads 0..nout*128
     constexpr int W0Q = (BH * DM + FUSED_THREADS - 1) / FUSED_THREADS;
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
             const int rr = e / BXLD, k = e - rr * BXLD, src = srcs[rr];
             xs[e] = (k < D && src >= 0) ? p.f_obs[(size_t)src * D + k] : 0.f;
         }
-        for (int e = tid; e < BPT * 12; e += FUSED_THREADS) {
+        for (int e = tid; e < BPT * 12 && !FWD; e += FUSED_THREADS) {
             const int rr = e / 12, k = e - rr * 12, src = srcs[rr];
             float v = 0.f;
             const int na = GAUSS ? A : 1;
@@ -376,7 +383,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
         // q = 8 role + qq), which has the head / loss / weight-gradient phases to arrive
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NQB; ++j)
+        for (int j = 0; j < (FWD ? 0 : NQB); ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 const int q = 8 * role + (KSB ? 4 * rblk + j : j);
@@ -405,6 +412,16 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
             c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 1, 64);
             z[j] = c + bhs[j];
         }
+    }
+    if constexpr (FWD) {
+        if (sub == 0 && row_ok) {
+            float* out = p.fwd_out + (size_t)m_row * p.fwd_ld;
+            if (actor) {
+#pragma unroll
+                for (int j = 0; j < AM; ++j) if (j < A) out[j] = act_apply_c<OACT>(z[j]);
+            } else out[A] = z[0];
+        }
+        return;
     }
     {
         float dz[AM];
@@ -764,7 +781,9 @@ static int init_bx_one() {
     return XRL_OK;
 }
 
+int init_ppo_trunk_bx_fwd();
 int init_ppo_trunk_bx() {
+    if (int rc = init_ppo_trunk_bx_fwd()) return rc;
     if (int rc = init_bx_one<XRL_ACT_RELU>()) return rc;
     if (int rc = init_bx_one<XRL_ACT_LEAKY_RELU>()) return rc;
     if (int rc = init_bx_one<XRL_ACT_TANH>()) return rc;
@@ -794,6 +813,51 @@ extern "C" int xrl_pack_mid_frags16(const xrl_ppo_fused_t* pp, uint16_t* image, 
     hipLaunchKernelGGL(pack_mid_frags16_kernel, dim3(64), dim3(256), 0, as_stream(stream), pp->params + L.w_off, image);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
+}
+
+template <int ACT>
+static int launch_bx_fwd(const xrl_ppo_fused_t& p, hipStream_t stream) {
+    const int n_tiles = (p.M + BPT - 1) / BPT;
+    constexpr int LDSG = BxLds<BDMAX, BAMAX>::BYTES;
+    if (p.dist == 0) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 0, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+    else if (p.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 2, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 1, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+    XRL_CHECK_LAUNCH();
+    return XRL_OK;
+}
+
+namespace xrl {
+template <int ACT>
+static int init_bx_fwd() {
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<BDMAX, BAMAX>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<BDMAX, BAMAX>::BYTES));
+    XRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BxLds<BDMAX, BAMAX>::BYTES));
+    return XRL_OK;
+}
+int init_ppo_trunk_bx_fwd() {
+    if (int rc = init_bx_fwd<XRL_ACT_RELU>()) return rc;
+    if (int rc = init_bx_fwd<XRL_ACT_LEAKY_RELU>()) return rc;
+    if (int rc = init_bx_fwd<XRL_ACT_TANH>()) return rc;
+    return XRL_OK;
+}
+}  // namespace xrl
+
+extern "C" int xrl_trunk_forward16(const xrl_ppo_fused_t* pp, xrl_stream_t stream) {
+    XRL_CHECK_ARG(pp != nullptr);
+    const xrl_ppo_fused_t& p = *pp;
+    XRL_CHECK_ARG(p.params && p.frag16 && p.f_obs && p.fwd_out && p.M > 0 && p.fwd_ld >= p.A + 1);
+    XRL_CHECK_ARG(p.D >= 1 && p.D <= BDMAX && p.A >= 1 && p.A <= BAMAX && (p.dist == 0 || p.dist == 1));
+    XRL_CHECK_ARG(p.dist == 0 || p.out_act == XRL_ACT_NONE || p.out_act == XRL_ACT_TANH);
+    XRL_CHECK_ARG(p.n_layers == 4 && p.n_head_layers == 2);
+    const xrl_fused_layer_t &L0 = p.layers[0], &L1 = p.layers[1], &La = p.layers[2], &Lc = p.layers[3];
+    XRL_CHECK_ARG(L0.K == p.D && L0.N == BH && L1.K == BH && L1.N == 2 * BH && La.K == BH && La.N == p.A && Lc.K == BH && Lc.N == 1);
+    XRL_CHECK_ARG(La.in_off == 0 && Lc.in_off == BH && L0.act == L1.act);
+    XRL_CHECK_ARG(L0.act == XRL_ACT_RELU || L0.act == XRL_ACT_LEAKY_RELU || L0.act == XRL_ACT_TANH);
+    switch (L0.act) {
+        case XRL_ACT_RELU: return launch_bx_fwd<XRL_ACT_RELU>(p, as_stream(stream));
+        case XRL_ACT_LEAKY_RELU: return launch_bx_fwd<XRL_ACT_LEAKY_RELU>(p, as_stream(stream));
+        default: return launch_bx_fwd<XRL_ACT_TANH>(p, as_stream(stream));
+    }
 }
 
 extern "C" int xrl_set_split_product_tr(int on) {

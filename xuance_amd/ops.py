@@ -389,6 +389,16 @@ def pack_mid_frags16(plan, params_flat, image):
     call("xrl_pack_mid_frags16", C.byref(p), ptr(image), image.numel(), stream_ptr())
 
 
+def trunk_forward16(plan, params_flat, frag16, X, M, out, ld, D, A, gaussian, out_act):
+    """The acting pass of a shared-trunk network (D <= 8, A <= 4) as one launch (xrl_trunk_forward16): rows of X [M][D] -> out[m][0..A]
+    (actor output | value); frag16 must hold the current branch layer (pack_mid_frags16 / the optimiser's split mirrors)."""
+    p = PpoFused()
+    p.params, p.frag16, p.f_obs, p.fwd_out = params_flat.data_ptr(), frag16.data_ptr(), X.data_ptr(), out.data_ptr()
+    p.M, p.D, p.A, p.fwd_ld, p.dist, p.out_act = int(M), int(D), int(A), int(ld), int(bool(gaussian)), int(out_act)
+    fused_layers_from_plan(plan, p)
+    call("xrl_trunk_forward16", C.byref(p), stream_ptr())
+
+
 def frag16_layout_maps(plan, P, device):
     """int32 SPLIT mirror maps [P] (value -(e + 2): 16-bit element e of a plane; -1: not mirrored) of the forward / backward section of
     the split fragment image -- the index formulas of csrc/split3.h (xrl_frag16_fwd_index / _bwd_index), checked against the pack
