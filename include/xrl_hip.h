@@ -942,8 +942,12 @@ int xrl_pack_mid_frags16(const xrl_ppo_fused_t* p, uint16_t* image, int64_t imag
  * ActorCriticPolicy.forward of policies/categorical.py / gaussian.py -- representation, actor head, critic head; on_policy.py:128-169
  * calls it once per vector step): row m of p->f_obs [M][D] (contiguous) -> p->fwd_out[m][0..A) = logits | activation_action(mean),
  * p->fwd_out[m][A] = value.  Reads params, layers, frag16 (must be current: xrl_pack_mid_frags16 or the optimiser's split mirror stores),
- * M, D, A, dist, out_act, fwd_out, fwd_ld of *p; the 128-wide product runs as the exact 3-way bf16 split of the minibatch kernel. */
-int xrl_trunk_forward16(const xrl_ppo_fused_t* p, xrl_stream_t stream);
+ * M, D, A, dist, out_act, fwd_out, fwd_ld of *p; the 128-wide product runs as the exact 3-way bf16 split of the minibatch kernel.
+ * sample != NULL (sample->n rows of observations, M == n or 2 n; .heads / .ld ignored): the launch also does xrl_policy_sample's work
+ * (get_actions, on_policy.py:128-169; the same statements, csrc/sample.h) and writes NO head buffer -- the actor role samples
+ * act_out / env_action / logp_out of rows [0, n), the critic role writes val_out of rows [0, n) and bootv_prev from rows [n, 2 n);
+ * act_out == NULL: bootstrap values only. */
+int xrl_trunk_forward16(const xrl_ppo_fused_t* p, const xrl_sample_t* sample, xrl_stream_t stream);
 int xrl_set_split_product_tr(int on);
 /* diagnostics: which weight-streamed products of the split-product kernel have the two waves of a 32-column block split the k-range
  * (each streams half of the fragment planes, the halves meet through LDS) instead of the rows: 0 none, 1 the backward-data product

@@ -837,3 +837,52 @@ def test_general_path_rollout_uses_the_one_launch_acting_pass():
     (v1, l1, a1), (v0, l0, a0) = outs[True], outs[False]
     assert torch.equal(a1, a0)
     assert float((v1 - v0).abs().max()) <= 1e-5 * (float(v0.abs().max()) + 1e-30) and float((l1 - l0).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("dist,D,A", [("categorical", 6, 3), ("gaussian", 3, 1), ("categorical", 8, 4)])
+def test_acting_pass_with_sampling_in_one_launch_matches_forward_plus_policy_sample(dist, D, A):
+    """xrl_trunk_forward16 with a sample argument (heads, action sampling, log-prob, values, bootstrap values: one launch, the two heads in
+    different workgroups) against layered forward + xrl_policy_sample on the same rows and the same supplied randomness: actions EQUAL,
+    log-probs / values / bootstrap values at 1e-5; then the bootstrap-only form (act_out = None) and a Philox-drawn run (same counter:
+    same draws, equal actions)."""
+    from xuance_amd import ops
+    from xuance_amd.nets import ActorCriticNet
+    torch.manual_seed(5)
+    gauss = dist == "gaussian"
+    net = ActorCriticNet(D, A, dist, (128,), (128,), (128,), "leaky_relu", activation_action="tanh" if gauss else None)
+    net.params.flat.copy_(torch.randn(net.params.P, device="cuda") * 0.2)
+    n = 200
+    X = torch.randn(2 * n, D, device="cuda")
+    img = torch.zeros(3 * ops.FRAG16_PLANE, dtype=torch.int16, device="cuda")
+    ops.pack_mid_frags16(net.plan, net.params.flat, img)
+    log_std = net.params.ptr("actor.log_std") if gauss else None
+    oact = ops.ACT[net.activation_action] if gauss else 0
+    for noise in (torch.rand(n, device="cuda") if not gauss else torch.randn(n, A, device="cuda"), None):
+        res = {}
+        for tag in ("fused", "layered"):
+            act = torch.zeros(n, A if gauss else 1, device="cuda").squeeze(-1) if not gauss else torch.zeros(n, A, device="cuda")
+            val, logp, boot = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+            env_a = torch.zeros(n, dtype=torch.int32, device="cuda") if not gauss else torch.zeros(n, A, device="cuda")
+            kw = dict(log_std=log_std, noise=noise, act_out=act, val_out=val, logp_out=logp, env_action=None if gauss else env_a,
+                      env_action_f=env_a if gauss else None, bootv_prev=boot, n=n, A=A, ld=A + 1, gaussian=int(gauss), seed=77, step=3,
+                      step_dev=None)
+            if tag == "fused":
+                ops.trunk_forward16(net.plan, net.params.flat, img, X, 2 * n, None, 0, D, A, gauss, oact, sample=kw)
+            else:
+                ops.policy_sample(heads=net.forward(X, 2 * n), **kw)
+            torch.cuda.synchronize()
+            res[tag] = (act.clone(), val.clone(), logp.clone(), boot.clone(), env_a.clone())
+        (a1, v1, l1, b1, e1), (a0, v0, l0, b0, e0) = res["fused"], res["layered"]
+        if gauss:
+            assert float((a1 - a0).abs().max()) <= 1e-5 * (float(a0.abs().max()) + 1e-30)
+        else:
+            assert torch.equal(a1, a0) and torch.equal(e1, e0)
+        for x, y in ((v1, v0), (l1, l0), (b1, b0)):
+            assert float((x - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1.0)
+    # bootstrap values only
+    boot2 = torch.zeros(n, device="cuda")
+    ops.trunk_forward16(net.plan, net.params.flat, img, X, 2 * n, None, 0, D, A, gauss, oact,
+                        sample=dict(act_out=None, val_out=None, logp_out=None, bootv_prev=boot2, n=n, A=A, ld=A + 1, gaussian=0,
+                                    seed=77, step=0, step_dev=None))
+    torch.cuda.synchronize()
+    assert float((boot2 - res["layered"][3]).abs().max()) <= 1e-5 * max(float(boot2.abs().max()), 1.0)

@@ -397,7 +397,7 @@ _SIGS = {
     "xrl_transpose_mid": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_pack_mid_frags": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
     "xrl_pack_mid_frags16": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
-    "xrl_trunk_forward16": [C.POINTER(PpoFused), c_void_p],
+    "xrl_trunk_forward16": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_set_split_product_tr": [c_int32],
     "xrl_set_split_product_ksplit": [c_int32],
     "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],

@@ -231,6 +231,18 @@ class PPO_Agent(AgentSurface):
                             ops.ACT[m.activation_action] if gauss else 0)
         return heads
 
+    def _act_sample(self, rows, **kw):
+        """Acting pass over self.X[:rows] + xrl_policy_sample's work (kw: its arguments without `heads`): ONE launch for the shared-trunk
+        class (xrl_trunk_forward16 with a sample argument: the actor role's workgroups sample, the critic role's write the values; no
+        head buffer in between; config.use_trunk_sample: False keeps the two launches), else forward + xrl_policy_sample."""
+        img, m = self._trunk_forward(), self.model
+        if img is not None and rows <= m.plan.cap and bool(_get(self.config, "use_trunk_sample", True)):
+            gauss = m.dist == "gaussian"
+            ops.trunk_forward16(m.plan, m.params.flat, img, self.X, rows, None, 0, m.obs_dim, m.action_dim, gauss,
+                                ops.ACT[m.activation_action] if gauss else 0, sample=kw)
+        else:
+            ops.policy_sample(heads=self._acting_forward(rows), **kw)
+
     def _device_tail(self):
         """May a vector step of the general path end in xrl_act_tail (heads + sampling + the device env's step as one launch, the previous
         step's bookkeeping riding in the normalisation launch: xrl_post_norm -- four launches per vector step instead of seven)?  A
@@ -291,8 +303,7 @@ class PPO_Agent(AgentSurface):
         else:
             ops.obs_normalize(**rms)
         if tail is None:
-            heads = self._acting_forward(2 * n)
-            ops.policy_sample(heads=heads, log_std=P.ptr("actor.log_std") if gaussian else None,
+            self._act_sample(2 * n, log_std=P.ptr("actor.log_std") if gaussian else None,
                               noise=None if self.action_noise is None else self.action_noise[t],
                               act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
                               env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
@@ -349,9 +360,8 @@ class PPO_Agent(AgentSurface):
             wide.act(self.X, n, self.seed, t, self.step_counter, act_out=f["actions"][t], env_action_f=env.action,
                      logp_out=f["aux_old_logp"][t], val_out=f["values"][t], bootv_prev=f["bootv"][t - 1] if t > 0 else None, **kw)
         else:
-            heads = self._acting_forward(2 * n)
             # actions / log-probs / values of rows [0,n) -> buffer slot t; value of rows [n,2n) -> bootv[t-1]
-            ops.policy_sample(heads=heads, log_std=self.model.params.ptr("actor.log_std") if gaussian else None,
+            self._act_sample(2 * n, log_std=self.model.params.ptr("actor.log_std") if gaussian else None,
                               noise=None if self.action_noise is None else self.action_noise[t],
                               act_out=f["actions"][t], val_out=f["values"][t], logp_out=f["aux_old_logp"][t],
                               env_action=None if gaussian else env.action, env_action_f=env.action if gaussian else None,
@@ -626,10 +636,14 @@ class PPO_Agent(AgentSurface):
         else:
             if self._wide_acting() is None and self._post_norm_ok():   # the last step's bookkeeping (rode in the next step's launch so far)
                 ops.rollout_poststep(**self._post_args(T - 1, (self.obs_mean, self.obs_var, self.obs_count), self.X[n:]))
-            heads = self.model.forward(self._policy_frames(), 2 * n, keep=False, acting=self._acting_fast) if self.frames else self._acting_forward(2 * n)
-            ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
-                              bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
-                              gaussian=0, seed=self.seed, step=0, step_dev=None)
+            if self.frames:
+                heads = self.model.forward(self._policy_frames(), 2 * n, keep=False, acting=self._acting_fast)
+                ops.policy_sample(heads=heads, act_out=None, val_out=None, logp_out=None,
+                                  bootv_prev=self.memory.soa.fields["bootv"][T - 1], n=n, A=A, ld=A + 1,
+                                  gaussian=0, seed=self.seed, step=0, step_dev=None)
+            else:
+                self._act_sample(2 * n, act_out=None, val_out=None, logp_out=None, bootv_prev=self.memory.soa.fields["bootv"][T - 1],
+                                 n=n, A=A, ld=A + 1, gaussian=0, seed=self.seed, step=0, step_dev=None)
         ops.counter_add(self.step_counter, T)
         f = self.memory.soa.fields
         ops.gae_scan(f["rewards"], f["values"], f["terminals"], f["bootv"], f["seg"], f["advantages"], f["returns"],

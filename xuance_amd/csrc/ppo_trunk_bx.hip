@@ -36,6 +36,7 @@
 #include "mlp_tile.h"
 #include "ppo_math.h"
 #include "split3.h"
+#include "sample.h"
 
 namespace xrl {
 
@@ -127,8 +128,16 @@ __device__ __forceinline__ void plane_store4(unsigned short* pl, int o, float v0
 // ActorCriticPolicy.forward: representation -> actor head | critic head) as ONE launch instead of the three of the layered path: row m
 // of f_obs [M][D] in, fwd_out[m][0..A) = the actor's output (activation_action applied), fwd_out[m][A] = the value.  Same products,
 // same planes; nothing of the loss / backward phases is instantiated.
+// With smp.n > 0 the forward-only launch also does what xrl_policy_sample does behind the layered forward (OnPolicyAgent.get_actions,
+// core/on_policy.py:128-169; the same statements: csrc/sample.h): rows [0, n) are the observations -- the actor role samples the action
+// and its log-prob, the critic role writes the value --, rows [n, 2 n) the previous step's next observations, whose value is bootv[t - 1]
+// (their actor workgroups have nothing to do and leave).
+template <bool FWD> struct bx_fwd_arg { typedef xrl_sample_t type; };
+struct bx_no_sample { int unused; };
+template <> struct bx_fwd_arg<false> { typedef bx_no_sample type; };
+
 template <int ACT, bool TR, bool KSF, bool KSB, bool LB = false, int DS = 4, int AS = 2, int HEAD = 0, bool FWD = false>
-__global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fused_t p) {
+__global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fused_t p, typename bx_fwd_arg<FWD>::type smp) {
     constexpr int DM = DS ? DS : BDMAX, AM = AS ? AS : BAMAX;
     constexpr bool GAUSS = HEAD != 0;
     constexpr int OACT = HEAD == 2 ? XRL_ACT_TANH : XRL_ACT_NONE;
@@ -153,7 +162,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     double* rowstat = reinterpret_cast<double*>(lds_raw + L::RST);                // [5][64] per-row loss terms
     double* bgp = reinterpret_cast<double*>(lds_raw + L::BGP);                    // [2][128] branch-bias gradient of the two row halves
 
-    kernarg_prefetch<sizeof(xrl_ppo_fused_t)>();
+    kernarg_prefetch<sizeof(xrl_ppo_fused_t) + (FWD ? sizeof(xrl_sample_t) : 0)>();
     const int tid = threadIdx.x, M = p.M, D = DS ? DS : p.D, A = AS ? AS : p.A;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,6 +175,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     const int nout = actor ? A : 1;
     const int cb = role * BH;                          // this role's first column of the stacked branch level
     const int m0 = tile * BPT;
+    if constexpr (FWD) {
+        if (smp.n > 0 && actor && (m0 >= smp.n || !smp.act_out)) return;   // (uniform: no action is sampled for these rows)
+    }
     const int r = tid / TPR, sub = tid % TPR, m_row = m0 + r;
     const bool row_ok = m_row < M;
     float* slab = p.slabs + (size_t)tile * p.slab_stride;
@@ -415,11 +427,24 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_bx_kernel(xrl_ppo_fus
     }
     if constexpr (FWD) {
         if (sub == 0 && row_ok) {
-            float* out = p.fwd_out + (size_t)m_row * p.fwd_ld;
-            if (actor) {
+            if (smp.n > 0) {                                             // heads + xrl_policy_sample's work, no head buffer
+                if (actor) {
+                    if (m_row < smp.n && smp.act_out) {
+                        float h[AM];
 #pragma unroll
-                for (int j = 0; j < AM; ++j) if (j < A) out[j] = act_apply_c<OACT>(z[j]);
-            } else out[A] = z[0];
+                        for (int j = 0; j < AM; ++j) h[j] = act_apply_c<OACT>(z[j]);
+                        policy_sample_actor(smp, m_row, h);
+                    }
+                } else if (m_row < smp.n) {
+                    if (smp.act_out && smp.val_out) smp.val_out[m_row] = z[0];
+                } else if (smp.bootv_prev) smp.bootv_prev[m_row - smp.n] = z[0];
+            } else {
+                float* out = p.fwd_out + (size_t)m_row * p.fwd_ld;
+                if (actor) {
+#pragma unroll
+                    for (int j = 0; j < AM; ++j) if (j < A) out[j] = act_apply_c<OACT>(z[j]);
+                } else out[A] = z[0];
+            }
         }
         return;
     }
@@ -741,21 +766,21 @@ static int launch_bx(const xrl_ppo_fused_t& p, hipStream_t stream) {
     const int n_tiles = (p.M + BPT - 1) / BPT;
     constexpr int LDSB = BxLds<4, 2>::BYTES, LDSG = BxLds<BDMAX, BAMAX>::BYTES;
     if (p.dist == 1) {                                    // Gaussian heads (Pendulum (3, 1)): any (D <= 8, A <= 4), the default form only
-        if (p.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0, 2>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
-        else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0, 1>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+        if (p.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0, 2>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p, bx_no_sample{0});
+        else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0, 1>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p, bx_no_sample{0});
         XRL_CHECK_LAUNCH();
         return XRL_OK;
     }
     if (!(p.D == 4 && p.A == 2)) {                        // any (D <= 8, A <= 4): the default form only
-        hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+        hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true, 0, 0>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p, bx_no_sample{0});
         XRL_CHECK_LAUNCH();
         return XRL_OK;
     }
-    if (!g_bx_tr) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, false, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
-    else if (g_bx_ks == 1) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
-    else if (g_bx_ks == 5) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
-    else if (g_bx_ks == 2) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
-    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p);
+    if (!g_bx_tr) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, false, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p, bx_no_sample{0});
+    else if (g_bx_ks == 1) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p, bx_no_sample{0});
+    else if (g_bx_ks == 5) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p, bx_no_sample{0});
+    else if (g_bx_ks == 2) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, true, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p, bx_no_sample{0});
+    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSB, stream, p, bx_no_sample{0});
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
@@ -816,12 +841,12 @@ extern "C" int xrl_pack_mid_frags16(const xrl_ppo_fused_t* pp, uint16_t* image, 
 }
 
 template <int ACT>
-static int launch_bx_fwd(const xrl_ppo_fused_t& p, hipStream_t stream) {
+static int launch_bx_fwd(const xrl_ppo_fused_t& p, const xrl_sample_t& smp, hipStream_t stream) {
     const int n_tiles = (p.M + BPT - 1) / BPT;
     constexpr int LDSG = BxLds<BDMAX, BAMAX>::BYTES;
-    if (p.dist == 0) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 0, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
-    else if (p.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 2, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
-    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 1, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p);
+    if (p.dist == 0) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 0, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p, smp);
+    else if (p.out_act == XRL_ACT_TANH) hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 2, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p, smp);
+    else hipLaunchKernelGGL((ppo_trunk_bx_kernel<ACT, true, false, false, false, 0, 0, 1, true>), dim3(2 * n_tiles), dim3(FUSED_THREADS), LDSG, stream, p, smp);
     XRL_CHECK_LAUNCH();
     return XRL_OK;
 }
@@ -842,10 +867,19 @@ int init_ppo_trunk_bx_fwd() {
 }
 }  // namespace xrl
 
-extern "C" int xrl_trunk_forward16(const xrl_ppo_fused_t* pp, xrl_stream_t stream) {
+extern "C" int xrl_trunk_forward16(const xrl_ppo_fused_t* pp, const xrl_sample_t* sample, xrl_stream_t stream) {
     XRL_CHECK_ARG(pp != nullptr);
     const xrl_ppo_fused_t& p = *pp;
-    XRL_CHECK_ARG(p.params && p.frag16 && p.f_obs && p.fwd_out && p.M > 0 && p.fwd_ld >= p.A + 1);
+    xrl_sample_t smp{};
+    if (sample) {
+        smp = *sample;
+        XRL_CHECK_ARG(smp.n > 0 && smp.n <= p.M && smp.A == p.A && (p.M == smp.n || p.M == 2 * smp.n));
+        XRL_CHECK_ARG(smp.act_out == nullptr || smp.gaussian == p.dist);      // (bootstrap-only calls carry no distribution)
+        XRL_CHECK_ARG(smp.act_out == nullptr || smp.logp_out != nullptr);
+        XRL_CHECK_ARG(smp.act_out == nullptr || !smp.gaussian || smp.log_std != nullptr);
+        XRL_CHECK_ARG(smp.bootv_prev == nullptr || p.M == 2 * smp.n);
+    }
+    XRL_CHECK_ARG(p.params && p.frag16 && p.f_obs && p.M > 0 && (sample || (p.fwd_out && p.fwd_ld >= p.A + 1)));
     XRL_CHECK_ARG(p.D >= 1 && p.D <= BDMAX && p.A >= 1 && p.A <= BAMAX && (p.dist == 0 || p.dist == 1));
     XRL_CHECK_ARG(p.dist == 0 || p.out_act == XRL_ACT_NONE || p.out_act == XRL_ACT_TANH);
     XRL_CHECK_ARG(p.n_layers == 4 && p.n_head_layers == 2);
@@ -854,9 +888,9 @@ extern "C" int xrl_trunk_forward16(const xrl_ppo_fused_t* pp, xrl_stream_t strea
     XRL_CHECK_ARG(La.in_off == 0 && Lc.in_off == BH && L0.act == L1.act);
     XRL_CHECK_ARG(L0.act == XRL_ACT_RELU || L0.act == XRL_ACT_LEAKY_RELU || L0.act == XRL_ACT_TANH);
     switch (L0.act) {
-        case XRL_ACT_RELU: return launch_bx_fwd<XRL_ACT_RELU>(p, as_stream(stream));
-        case XRL_ACT_LEAKY_RELU: return launch_bx_fwd<XRL_ACT_LEAKY_RELU>(p, as_stream(stream));
-        default: return launch_bx_fwd<XRL_ACT_TANH>(p, as_stream(stream));
+        case XRL_ACT_RELU: return launch_bx_fwd<XRL_ACT_RELU>(p, smp, as_stream(stream));
+        case XRL_ACT_LEAKY_RELU: return launch_bx_fwd<XRL_ACT_LEAKY_RELU>(p, smp, as_stream(stream));
+        default: return launch_bx_fwd<XRL_ACT_TANH>(p, smp, as_stream(stream));
     }
 }
 

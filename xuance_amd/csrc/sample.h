@@ -6,11 +6,10 @@
 
 namespace xrl {
 
-// h: the row's head outputs (cols [0, A) actor output, col A value); boot_value: the value of row n + e (read only with p.bootv_prev)
-__device__ __forceinline__ void policy_sample_one(const xrl_sample_t& p, int e, const float* h, float boot_value) {
+// the ACTOR half of a row: action from the head outputs h[0..A), its log-prob; what needs no value (csrc/ppo_trunk_bx.hip's forward-only
+// instances run the two heads in different workgroups: the critic's writes val_out / bootv_prev itself)
+__device__ __forceinline__ void policy_sample_actor(const xrl_sample_t& p, int e, const float* h) {
     const int A = p.A;
-    if (p.bootv_prev) p.bootv_prev[e] = boot_value;
-    if (!p.act_out) return;                                // bootstrap-only launch (end of a rollout)
     const uint32_t step = p.step + (p.step_dev ? *p.step_dev : 0u);
     float logp;
     if (!p.gaussian) {
@@ -48,8 +47,15 @@ __device__ __forceinline__ void policy_sample_one(const xrl_sample_t& p, int e, 
             if (p.env_action_f) p.env_action_f[(size_t)e * A + j] = x;
         }
     }
-    if (p.val_out) p.val_out[e] = h[A];                  // actor-only policies (VanillaPolicyGradient) have no value column
     p.logp_out[e] = logp;
+}
+
+// h: the row's head outputs (cols [0, A) actor output, col A value); boot_value: the value of row n + e (read only with p.bootv_prev)
+__device__ __forceinline__ void policy_sample_one(const xrl_sample_t& p, int e, const float* h, float boot_value) {
+    if (p.bootv_prev) p.bootv_prev[e] = boot_value;
+    if (!p.act_out) return;                                // bootstrap-only launch (end of a rollout)
+    policy_sample_actor(p, e, h);
+    if (p.val_out) p.val_out[e] = h[p.A];                  // actor-only policies (VanillaPolicyGradient) have no value column
 }
 
 }  // namespace xrl

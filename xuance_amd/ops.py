@@ -389,14 +389,17 @@ def pack_mid_frags16(plan, params_flat, image):
     call("xrl_pack_mid_frags16", C.byref(p), ptr(image), image.numel(), stream_ptr())
 
 
-def trunk_forward16(plan, params_flat, frag16, X, M, out, ld, D, A, gaussian, out_act):
+def trunk_forward16(plan, params_flat, frag16, X, M, out, ld, D, A, gaussian, out_act, sample=None):
     """The acting pass of a shared-trunk network (D <= 8, A <= 4) as one launch (xrl_trunk_forward16): rows of X [M][D] -> out[m][0..A]
-    (actor output | value); frag16 must hold the current branch layer (pack_mid_frags16 / the optimiser's split mirrors)."""
+    (actor output | value); frag16 must hold the current branch layer (pack_mid_frags16 / the optimiser's split mirrors).  sample =
+    policy_sample's keyword arguments: the launch samples actions / log-probs / values / bootstrap values itself, no head buffer."""
     p = PpoFused()
-    p.params, p.frag16, p.f_obs, p.fwd_out = params_flat.data_ptr(), frag16.data_ptr(), X.data_ptr(), out.data_ptr()
+    p.params, p.frag16, p.f_obs = params_flat.data_ptr(), frag16.data_ptr(), X.data_ptr()
+    p.fwd_out = out.data_ptr() if out is not None else None
     p.M, p.D, p.A, p.fwd_ld, p.dist, p.out_act = int(M), int(D), int(A), int(ld), int(bool(gaussian)), int(out_act)
     fused_layers_from_plan(plan, p)
-    call("xrl_trunk_forward16", C.byref(p), stream_ptr())
+    smp = C.byref(_struct(Sample, sample)) if sample is not None else None
+    call("xrl_trunk_forward16", C.byref(p), smp, stream_ptr())
 
 
 def frag16_layout_maps(plan, P, device):
