@@ -279,10 +279,19 @@ class PPO_Learner(Learner):
 
     def pair_eligible(self, n_tiles):
         """64-row tiles in the role-split kernel (one workgroup per (64-row tile, branch): half the weight stream per CU and half the
-        gradient slabs): minibatches of at least 192 32-row tiles (measured: 128 tiles 2.40 ms with 64-row tiles vs 2.27 with 32-row
-        tiles, 256 tiles 2.73 vs 3.08).  config.use_pair_update: "auto" (default) / True / False."""
+        gradient slabs): minibatches of at least 192 32-row tiles on the float32 instruction (measured: 128 tiles 2.40 ms with 64-row
+        tiles vs 2.27 with 32-row tiles, 256 tiles 2.73 vs 3.08), of at least 112 where they run the split-product kernel.
+        config.use_pair_update: "auto" (default) / True / False."""
         want = getattr(self.config, "use_pair_update", "auto")
-        want = (n_tiles >= 192) if want == "auto" else bool(want)
+        if want == "auto":
+            # (round 6: where the 64-row tiles run the split-product kernel they pay from 128 tiles on -- tools/sweep_pair_threshold.py,
+            #  update phase of 64 minibatches: 128 tiles 2.27 -> 1.97 ms, 160 tiles 3.06 -> 2.19 ms, 96 tiles a tie at 2.02 ms)
+            m = self.model
+            bx = bool(getattr(self.config, "use_split_products", True)) and not getattr(self.config, "use_chained_update", False) \
+                and ops.split_products_class(m.plan, m.obs_dim, m.action_dim, m.dist)
+            want = n_tiles >= (112 if bx else 192)
+        else:
+            want = bool(want)
         return want and self.split_eligible(n_tiles)
 
     def prepare_fused(self, memory, bs):
