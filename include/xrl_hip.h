@@ -948,6 +948,9 @@ int xrl_pack_mid_frags16(const xrl_ppo_fused_t* p, uint16_t* image, int64_t imag
  * act_out / env_action / logp_out of rows [0, n), the critic role writes val_out of rows [0, n) and bootv_prev from rows [n, 2 n);
  * act_out == NULL: bootstrap values only. */
 int xrl_trunk_forward16(const xrl_ppo_fused_t* p, const xrl_sample_t* sample, xrl_stream_t stream);
+/* The whole-rollout / per-step actor kernel of the CartPole class (xrl_rollout_cartpole_run): its 128-deep branch-layer products as exact
+ * 3-way bf16 splits on v_mfma_f32_16x16x32_bf16 (1) or on the float32 instruction (0); see csrc/rollout_actor.hip. */
+int xrl_set_rollout_split_products(int on);
 int xrl_set_split_product_tr(int on);
 /* diagnostics: which weight-streamed products of the split-product kernel have the two waves of a 32-column block split the k-range
  * (each streams half of the fragment planes, the halves meet through LDS) instead of the rows: 0 none, 1 the backward-data product

@@ -399,6 +399,7 @@ _SIGS = {
     "xrl_pack_mid_frags16": [C.POINTER(PpoFused), c_void_p, c_int64, c_void_p],
     "xrl_trunk_forward16": [C.POINTER(PpoFused), c_void_p, c_void_p],
     "xrl_set_split_product_tr": [c_int32],
+    "xrl_set_rollout_split_products": [c_int32],
     "xrl_set_split_product_ksplit": [c_int32],
     "xrl_ppo_wide_minibatch": [C.POINTER(PpoWide), c_void_p],
     "xrl_ppo_wide_pack": [C.POINTER(PpoWide), c_void_p, c_void_p],

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "rng.h"
 #include "cartpole.h"
+#include "split3.h"
 
 namespace xrl {
 
@@ -137,7 +138,16 @@ __device__ __forceinline__ void rollout_bookkeeper(const xrl_rollout_run_t& q, i
 // chain wave's tail and restored ~110 of them per step from spill lanes.
 // TAPE: the simulators' outputs (and, optionally, the sampling uniforms) come from a recorded tape (xrl_rollout_run_t.tape_*):
 // the physics wave, the reset wave and the uniform draw READ what they otherwise compute; every other instruction is shared.
-template <int ACT, bool TAPE>
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+#define AMFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0)
+
+// BX: the branch layer's 128-deep products as exact 3-way bf16 splits (csrc/ppo_trunk_bx.hip, csrc/split3.h) on v_mfma_f32_16x16x32_bf16:
+// a k-step of 32 = the chunk pair (2 t, 2 t + 1); lane (g, cl) supplies, for A and for B alike, the eight k-values 32 t + 4 g + s and
+// 32 t + 16 + 4 g + s (s = 0..3) -- a sum over k allows any assignment both operands share, so the float32 registers of the 16x16x4
+// form (the weights' float4s, the first layer's result fragments) become the bf16 operands as they are.  The weights are split once per
+// launch (they stay in registers for all its steps), the 32 activations of a lane once per step: 48 instructions of 16 pipe cycles per
+// wave and step instead of 128 of 32.
+template <int ACT, bool TAPE, bool BX = false>
 __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q) {
 #pragma clang fp contract(off)
     if (blockIdx.x & 7) return;                                  // keep one XCD's share of the grid (see header)
@@ -224,6 +234,19 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
                 whf[j][i] = cl < 2 ? P[q.wa + cl * AH + col0 + 4 * g + i] : 0.f;           // A[m = cl (action)][k = 4 g + i (unit of the tile)]
             }
         }
+        au32x4 wbx[BX ? 2 : 1][BX ? 4 : 1][3];                       // BX: [tile][k-step][h | m | l], eight bf16 per lane
+        if constexpr (BX) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 a = wfr[j][2 * t], b = wfr[j][2 * t + 1];
+                    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+                    split3_pair(a.x, a.y, h0, m0, l0); split3_pair(a.z, a.w, h1, m1, l1);
+                    split3_pair(b.x, b.y, h2, m2, l2); split3_pair(b.z, b.w, h3, m3, l3);
+                    wbx[j][t][0] = (au32x4){h0, h1, h2, h3}; wbx[j][t][1] = (au32x4){m0, m1, m2, m3}; wbx[j][t][2] = (au32x4){l0, l1, l2, l3};
+                }
+        }
         int k = 0;
         for (; k < n_steps; ++k) {
             lds_barrier();                                                                         // #1
@@ -254,6 +277,36 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
             f32x4 acc[2][2], lg[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) { acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; lg[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            if constexpr (BX) {
+                // every activation first (the first layer's remaining chunks), then per k-step: split the lane's eight activations, six
+                // part products per tile (smallest first), the two tiles' chains alternating
+#pragma unroll
+                for (int c = 2; c < 8; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hf[c][i] = act_apply_c<ACT>(hf[c][i]);
+                acc[0][0] = bmf[0]; acc[1][0] = bmf[1];                                             // (bias as the C operand)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+                    split3_pair(hf[2 * t][0], hf[2 * t][1], h0, m0, l0); split3_pair(hf[2 * t][2], hf[2 * t][3], h1, m1, l1);
+                    split3_pair(hf[2 * t + 1][0], hf[2 * t + 1][1], h2, m2, l2); split3_pair(hf[2 * t + 1][2], hf[2 * t + 1][3], h3, m3, l3);
+                    const au32x4 xh = {h0, h1, h2, h3}, xm = {m0, m1, m2, m3}, xl = {l0, l1, l2, l3};
+                    acc[0][0] = AMFMA16B(wbx[0][t][0], xl, acc[0][0]); acc[1][0] = AMFMA16B(wbx[1][t][0], xl, acc[1][0]);
+                    acc[0][0] = AMFMA16B(wbx[0][t][2], xh, acc[0][0]); acc[1][0] = AMFMA16B(wbx[1][t][2], xh, acc[1][0]);
+                    acc[0][0] = AMFMA16B(wbx[0][t][1], xm, acc[0][0]); acc[1][0] = AMFMA16B(wbx[1][t][1], xm, acc[1][0]);
+                    acc[0][0] = AMFMA16B(wbx[0][t][0], xm, acc[0][0]); acc[1][0] = AMFMA16B(wbx[1][t][0], xm, acc[1][0]);
+                    acc[0][0] = AMFMA16B(wbx[0][t][1], xh, acc[0][0]); acc[1][0] = AMFMA16B(wbx[1][t][1], xh, acc[1][0]);
+                    acc[0][0] = AMFMA16B(wbx[0][t][0], xh, acc[0][0]); acc[1][0] = AMFMA16B(wbx[1][t][0], xh, acc[1][0]);
+                }
+                if (stamp) dbg[9] = clock64();
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float h = act_apply_c<ACT>(acc[j][0][i]);
+                        MFMA16(whf[j][i], h, lg[j]);
+                    }
+            } else {
             // ---- tile 0 (+ the first layer's remaining activations)
 #pragma unroll
             for (int c = 0; c < 8; c += 2) {
@@ -297,6 +350,7 @@ __global__ void __launch_bounds__(ATH) actor_rollout_kernel(xrl_rollout_run_t q)
             for (int i = 0; i < 4; ++i) {
                 const float h = act_apply_c<ACT>(acc[1][0][i] + acc[1][1][i]);
                 MFMA16(whf[1][i], h, lg[1]);
+            }
             }
 #undef XRL_INTERLEAVE
             // lg[.][i] of lane (g, cl) = logit of action 4 g + i, row cl: actions 0, 1 live in DPP row 0
@@ -803,6 +857,11 @@ bool rollout_fast_enabled() { return g_fast_enabled; }
 using namespace xrl;
 
 namespace xrl { extern bool g_fast_enabled_ppo; }
+static int g_rollout_bx = 1;                       // xrl_set_rollout_split_products: the actor rollout's branch layer as exact 3-way bf16 splits
+extern "C" int xrl_set_rollout_split_products(int on) {
+    g_rollout_bx = on ? 1 : 0;
+    return XRL_OK;
+}
 extern "C" int xrl_set_fast_kernels(int enable) {
     xrl::g_fast_enabled = enable != 0;
     xrl::g_fast_enabled_ppo = enable != 0;
@@ -845,10 +904,12 @@ extern "C" int xrl_rollout_cartpole_run(const xrl_rollout_run_t* qq, xrl_stream_
     if (q.tape_next_obs) {
         XRL_CHECK_ARG(q.tape_reset_obs && q.tape_term && q.tape_trunc && q.tape_pos && q.tape_rows >= 1);
         XRL_CHECK_ARG(((reinterpret_cast<uintptr_t>(q.tape_next_obs) | reinterpret_cast<uintptr_t>(q.tape_reset_obs)) & 15) == 0);
-        XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT, true>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);)
+        if (g_rollout_bx) { XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT, true, true>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);) }
+        else { XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT, true, false>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);) }
     } else {
         XRL_CHECK_ARG(q.tape_u == nullptr);                              // (supplied uniforms ride with a tape only)
-        XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT, false>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);)
+        if (g_rollout_bx) { XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT, false, true>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);) }
+        else { XRL_ACT_DISPATCH(q.act, hipLaunchKernelGGL((actor_rollout_kernel<ACT, false, false>), dim3(8 * n_wg), dim3(ATH), 0, as_stream(stream), q);) }
     }
     XRL_CHECK_LAUNCH();
     return XRL_OK;

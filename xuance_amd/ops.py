@@ -427,6 +427,11 @@ def set_split_product_tr(on):
     call("xrl_set_split_product_tr", int(bool(on)))
 
 
+def set_rollout_split_products(on):
+    """The CartPole class' actor rollout kernel: branch-layer products as exact 3-way bf16 splits (True) or on the float32 instruction."""
+    call("xrl_set_rollout_split_products", int(bool(on)))
+
+
 def set_split_product_ksplit(mode):
     """Diagnostics: the split-product kernel's wave pairs split k instead of rows in 0 no / 1 the backward-data (default) / 2 both
     weight-streamed products."""
@@ -592,6 +597,8 @@ def init_device():
         call("xrl_init")
         _inited = True
         import os
+        if os.environ.get("XRL_ROLLOUT_SPLIT_PRODUCTS"):           # diagnostics: the actor rollout kernel's branch layer on the bf16 instruction
+            call("xrl_set_rollout_split_products", int(os.environ["XRL_ROLLOUT_SPLIT_PRODUCTS"]))
         if os.environ.get("XRL_SPLIT_PRODUCT_KSPLIT"):             # diagnostics (tools/, profiles/r06_q_*): see set_split_product_ksplit
             set_split_product_ksplit(int(os.environ["XRL_SPLIT_PRODUCT_KSPLIT"]))
 
