@@ -19,9 +19,22 @@ namespace xrl {
 constexpr int RMS_THREADS = 1024;
 constexpr int RMS_MAXD = 64;
 
+constexpr int RMS_STAGE = 16;
+// part2[j][d] = sum of part[r][d] over r = j, j + 16, ... < R (threads [0, 16 D)); ends in a barrier
+__device__ __forceinline__ void rms_stage_sum(const double* part, double* part2, int D, int R, int tid) {
+    if (tid < RMS_STAGE * D) {
+        const int d = tid % D, j = tid / D;
+        double t = 0.0;
+        for (int r = j; r < R; r += RMS_STAGE) t += part[r * D + d];
+        part2[j * D + d] = t;
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void rms_normalize_body(const xrl_rms_t& p) {
 #pragma clang fp contract(off)
     __shared__ double part[RMS_THREADS];
+    __shared__ double part2[RMS_STAGE * RMS_MAXD];
     __shared__ double bmean[RMS_MAXD], bvar[RMS_MAXD];
     __shared__ float s_mean[RMS_MAXD], s_std[RMS_MAXD];
     const int D = p.D, n = p.n, tid = threadIdx.x;
@@ -34,9 +47,14 @@ __device__ __forceinline__ void rms_normalize_body(const xrl_rms_t& p) {
         if (live) for (int r = r0; r < n; r += R) s += (double)p.x[(size_t)r * p.ld_x + d];
         part[tid] = live ? s : 0.0;
         __syncthreads();
+        // (the R partial sums of a dimension meet in two stages -- 16 threads per dimension take every 16th, then one thread the 16 --
+        //  instead of one thread walking all R of them: that loop was a chain of ~170 dependent LDS reads, twice per launch, a third of
+        //  the launch's 10 us; float64 sums of float32 values: the order does not reach the float32 results)
+        rms_stage_sum(part, part2, D, R, tid);
         if (tid < D) {
             double t = 0.0;
-            for (int r = 0; r < R; ++r) t += part[r * D + tid];
+#pragma unroll
+            for (int j = 0; j < RMS_STAGE; ++j) t += part2[j * D + tid];
             bmean[tid] = (double)(float)(t / n);       // np.mean returns float32
         }
         __syncthreads();
@@ -47,9 +65,11 @@ __device__ __forceinline__ void rms_normalize_body(const xrl_rms_t& p) {
         }
         part[tid] = live ? q : 0.0;
         __syncthreads();
+        rms_stage_sum(part, part2, D, R, tid);
         if (tid < D) {
             double t = 0.0;
-            for (int r = 0; r < R; ++r) t += part[r * D + tid];
+#pragma unroll
+            for (int j = 0; j < RMS_STAGE; ++j) t += part2[j * D + tid];
             const float bstd = (float)sqrt(t / n);     // np.std -> float32
             bvar[tid] = (double)(bstd * bstd);         // batch_var = np.square(batch_std)
         }
