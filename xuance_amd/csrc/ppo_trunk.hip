@@ -79,7 +79,6 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
     float* whs = lds + L::WH;                          // [nout][132] this role's head rows
     float* bhs = lds + L::BH;
     float* lss = lds + L::LS;                          // log_std
-    int* srcs = reinterpret_cast<int*>(lds + L::SRC);  // [PT] buffer row of each minibatch row
     double* rowstat = reinterpret_cast<double*>(lds + L::FLOATS);       // [5][PT] per-row loss terms
 
     kernarg_prefetch<sizeof(xrl_ppo_fused_t) + (CHAIN ? sizeof(xrl_opt_chain_t) : 0)>();
@@ -129,15 +128,40 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
             *reinterpret_cast<float4*>(xs + lane * TXLD + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             rsc[lane * 12 + 0] = sc.x; rsc[lane * 12 + 8] = sc.y; rsc[lane * 12 + 9] = sc.z; rsc[lane * 12 + 10] = sc.w;
         }
-    } else if (tid < PT) {                             // buffer row of each minibatch row (env-major flat index, memory_tools.py:270)
-        const int m = m0 + tid;
+    }
+    // rows through idx from the buffer's FIELDS: thread (row r, sub) takes the observation elements sub, sub + TPR, ... of its row and the
+    // scalar slots sub, sub + TPR, ... (slots 0..7 action components, 8 return, 9 advantage, 10 old log-prob) -- every thread resolves its
+    // row's buffer index itself (env-major flat index -> time-major row, memory_tools.py:270) and ALL gathers of the tile are in flight
+    // together (round 6: as loops over the tile behind a shared index array they were three dependent round trips to scattered rows)
+    constexpr int GXQ = (TXLD + TPR - 1) / TPR, GSQ = (12 + TPR - 1) / TPR;
+    float g_x[GXQ], g_s[GSQ];
+#pragma unroll
+    for (int qx = 0; qx < GXQ; ++qx) g_x[qx] = 0.f;
+#pragma unroll
+    for (int qs = 0; qs < GSQ; ++qs) g_s[qs] = 0.f;
+    if (!records) {
         int src = -1;
-        if (m < M) {
-            const int64_t fl = p.idx[m];
+        if (row_ok) {
+            const int64_t fl = p.idx[m_row];
             const int env = (int)(fl / p.T), t = (int)(fl - (int64_t)env * p.T);
             src = t * p.n_envs + env;
         }
-        srcs[tid] = src;
+        if (src >= 0) {
+            const int na = GAUSS ? A : 1;
+#pragma unroll
+            for (int qx = 0; qx < GXQ; ++qx) {
+                const int k = sub + qx * TPR;
+                if (k < D) g_x[qx] = p.f_obs[(size_t)src * D + k];
+            }
+#pragma unroll
+            for (int qs = 0; qs < GSQ; ++qs) {
+                const int k = sub + qs * TPR;
+                if (k < na) g_s[qs] = p.f_act[(size_t)src * na + k];
+                else if (k == 8) g_s[qs] = p.f_ret[src];
+                else if (k == 9) g_s[qs] = p.f_adv[src];
+                else if (k == 10) g_s[qs] = p.f_logp[src];
+            }
+        }
     }
     // (the rows above depend on no parameter: requested before the optimiser step of the previous minibatch, which every load
     //  below has to wait for)
@@ -192,23 +216,16 @@ __global__ void __launch_bounds__(FUSED_THREADS) ppo_trunk_kernel(xrl_ppo_fused_
         if (e < nout * TH) whs[(e >> 7) * TLD + (e & (TH - 1))] = whv[q];
     }
     if (!records) {
-        lds_barrier();                                                                               // (srcs)
         // observations (zero padded to 28 columns), actions, ret | adv | old_logp
-        for (int e = tid; e < PT * TXLD; e += FUSED_THREADS) {
-            const int rr = e / TXLD, k = e - rr * TXLD, src = srcs[rr];
-            xs[e] = (k < D && src >= 0) ? p.f_obs[(size_t)src * D + k] : 0.f;
+#pragma unroll
+        for (int qx = 0; qx < GXQ; ++qx) {
+            const int k = sub + qx * TPR;
+            if (k < TXLD) xs[r * TXLD + k] = g_x[qx];
         }
-        const int na = GAUSS ? A : 1;
-        for (int e = tid; e < PT * 12; e += FUSED_THREADS) {
-            const int rr = e / 12, k = e - rr * 12, src = srcs[rr];
-            float v = 0.f;
-            if (src >= 0) {
-                if (k < na) v = p.f_act[(size_t)src * na + k];
-                else if (k == 8) v = p.f_ret[src];
-                else if (k == 9) v = p.f_adv[src];
-                else if (k == 10) v = p.f_logp[src];
-            }
-            rsc[e] = v;
+#pragma unroll
+        for (int qs = 0; qs < GSQ; ++qs) {
+            const int k = sub + qs * TPR;
+            if (k < 12) rsc[r * 12 + k] = g_s[qs];
         }
     }
     lds_barrier();                                                                                   // #0 rows, parameters
