@@ -1142,8 +1142,11 @@ def test_device_act_tail_in_one_launch_equals_the_launches(name, n, T, graph):
         kw = dict(activation_action="tanh") if name == "DevicePendulumVecEnv" else {}
         env = getattr(envs, name)(n, seed=3)
         env.max_episode_steps = 7
+        # (use_trunk_forward: False -- the three forms differ in how the launches AROUND the hidden stages are grouped; all of them on the
+        #  layered float32 forward, which xrl_act_tail's form consumes stage by stage.  The one-launch acting pass has its own tests:
+        #  tests/test_gpu_ppo.py::test_acting_pass_*, test_general_path_rollout_uses_the_one_launch_acting_pass)
         agent = PPO_Agent(make_config(n, T, use_hip_graph=graph, use_fused_rollout=False, use_device_act_tail=tail, use_post_norm=post_norm,
-                                      **kw), env)
+                                      use_trunk_forward=False, **kw), env)
         snaps = []
         for it in range(3):
             agent.train(T)

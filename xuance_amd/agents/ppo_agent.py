@@ -201,9 +201,9 @@ class PPO_Agent(AgentSurface):
     def _trunk_forward(self):
         """The acting pass of the general path as ONE launch (xrl_trunk_forward16: csrc/ppo_trunk_bx.hip's forward-only instances) instead
         of the three of the layered forward?  A shared-trunk network with D <= 8, A <= 4 (every classic-control / LunarLander PPO yaml)
-        whose update phase runs the split-product minibatch kernel -- then the learner owns the three-plane bf16 image of the branch
-        layer, its optimiser launch keeps it current, and a rollout re-packs it once at its start (one 3 us launch: parameters loaded
-        from outside are never stale).  config.use_trunk_forward: False keeps the layered forward.  Returns the image or None."""
+        (the reference's default sizes included): the three-plane bf16 image of the branch layer -- the learner's where its update phase
+        runs the split-product minibatch kernel, else the agent's own -- is re-packed once at the start of every rollout (one 3 us
+        launch: parameters loaded from outside are never stale).  config.use_trunk_forward: False keeps the layered forward.  Returns the image or None."""
         if not hasattr(self, "_tf16"):
             self._tf16 = None
             lr, m = self.learner, self.model
@@ -214,9 +214,11 @@ class PPO_Agent(AgentSurface):
                 and self._wide_acting() is None and lr.fused_eligible(self.memory)
             if ok:
                 lr.prepare_fused(self.memory, self.batch_size)        # (outside any capture: _launch_rollout asks before it captures)
-                if getattr(lr, "frag16", None) is not None:
-                    plan.ensure(2 * self.n_envs)
-                    self._tf16 = lr.frag16
+                plan.ensure(2 * self.n_envs)
+                # the learner's image where its update phase runs the split-product kernel (minibatches of >= 112 tiles), else one of the
+                # agent's own: either way re-packed at the start of every rollout (_enqueue_rollout)
+                self._tf16 = lr.frag16 if getattr(lr, "frag16", None) is not None else \
+                    torch.zeros(3 * ops.FRAG16_PLANE, dtype=torch.int16, device=self.device)
         return self._tf16
 
     def _acting_forward(self, rows):
