@@ -209,11 +209,15 @@ class PPO_Agent(AgentSurface):
             lr, m = self.learner, self.model
             plan = getattr(m, "plan", None)
             ok = bool(_get(self.config, "use_trunk_forward", True)) and not self.frames and plan is not None \
-                and type(self)._enqueue_step is PPO_Agent._enqueue_step and hasattr(lr, "trunk_eligible") and lr.trunk_eligible() \
-                and ops.split_products_class(plan, m.obs_dim, m.action_dim, m.dist) and not self.use_fused_rollout \
-                and self._wide_acting() is None and lr.fused_eligible(self.memory)
+                and type(self)._enqueue_step is PPO_Agent._enqueue_step and ops.fast_kernels_enabled() \
+                and hasattr(m, "dist") and ops.split_products_class(plan, m.obs_dim, m.action_dim, m.dist) \
+                and getattr(m, "activation", None) in ("relu", "leaky_relu", "tanh") \
+                and (m.dist != "gaussian" or getattr(m, "activation_action", None) in (None, "tanh")) \
+                and not self.use_fused_rollout and self._wide_acting() is None
             if ok:
-                lr.prepare_fused(self.memory, self.batch_size)        # (outside any capture: _launch_rollout asks before it captures)
+                # (any learner of the PPO family -- PPO-clip, PPO-KL, A2C: the acting pass does not depend on the loss)
+                if hasattr(lr, "trunk_eligible") and lr.trunk_eligible() and lr.fused_eligible(self.memory):
+                    lr.prepare_fused(self.memory, self.batch_size)    # (outside any capture: _launch_rollout asks before it captures)
                 plan.ensure(2 * self.n_envs)
                 # the learner's image where its update phase runs the split-product kernel (minibatches of >= 112 tiles), else one of the
                 # agent's own: either way re-packed at the start of every rollout (_enqueue_rollout)
