@@ -528,6 +528,8 @@ def main():
                 sec["ppo_cartpole_16_envs"] = bs.ppo_small(make_config, kernel_rooflines, 16, args.horizon,
                                                            ref=reference_cpu_baseline("ppo_cartpole", "16"))
                 sec["ppo_acrobot_256_envs"] = bs.ppo_acrobot(make_config)
+                # (the reference's default size for this yaml: configs/ppo/classic_control/Acrobot-v1.yaml, parallels 10)
+                sec["ppo_acrobot_10_envs"] = bs.ppo_acrobot(make_config, n_envs=10, steps=10, warmup=3)
                 sec["qmix_3m_ff"] = bs.qmix_3m(False, ref=reference_cpu_baseline("qmix_3m_ff"))
                 sec["qmix_3m_gru"] = bs.qmix_3m(True, ref=reference_cpu_baseline("qmix_3m_gru"))
                 # the two remaining BASELINE configs at their per-GPU shapes (the reference's CPU time exists per update only:

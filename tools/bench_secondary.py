@@ -142,7 +142,9 @@ def ppo_acrobot(make_config, n_envs=256, horizon=256, steps=10, warmup=3):
             "update_kernel": ("ppo_trunk_bx_kernel<leaky_relu, any (D <= 8, A <= 4)>: 64-row tiles, the 128-wide products as exact 3-way bf16 splits"
                               if getattr(lr, "frag16", None) is not None else
                               "ppo_trunk_kernel<leaky_relu, categorical, %d rows, any (D, A)>" % (64 if getattr(lr, "pair", False) else 32)),
-            "rollout_path": "captured launches per vector step (general path)"}
+            "rollout_path": ("captured launches per vector step (general path): statistics / bookkeeping, acting pass + sampling as one launch "
+                             "(xrl_trunk_forward16), the env's step" if agent._trunk_forward() is not None else
+                             "captured launches per vector step (general path)")}
 
 
 def _qmix_cfg(n, rnn):
